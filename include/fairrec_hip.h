@@ -1,0 +1,153 @@
+/*
+ * fairrec_hip.h -- C ABI of libfairrec_hip.so: the MI355X (gfx950) kernels behind the
+ * RecBole-FairRec training hot path (embedding gather -> score -> fairness-regularised loss ->
+ * backward -> Adam).
+ *
+ * The reference has no native boundary at all: its "operators" on this
+ * path are stock PyTorch calls made from Python.  Every entry point below therefore cites the
+ * reference Python call sites (file:line under the reference checkout) whose work it replaces.
+ *
+ * Conventions
+ *   - plain C: raw DEVICE pointers, sizes, scalars and a hipStream_t (passed as void*); no torch types.
+ *   - every call is asynchronous on `stream`, never synchronises, never allocates or frees: the caller
+ *     owns all buffers and passes a workspace (size from the matching *_workspace_bytes query).
+ *   - return value: 0 = ok, <0 = FR_E* (invalid argument / HIP error); message via fr_last_error()
+ *     (thread-local).  Data-dependent faults that can only be seen on the device (row id out of range,
+ *     more than two sensitive groups in a batch) set bits in the caller-supplied `err_flag` word.
+ *   - ids are int64 at the boundary (torch.LongTensor, dataset.py:1790-1791), values fp32, tables
+ *     fp32 [n_rows, dim] row-major.
+ */
+#ifndef FAIRREC_HIP_H
+#define FAIRREC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(__GNUC__) || defined(__clang__)
+#define FR_API __attribute__((visibility("default")))
+#else
+#define FR_API
+#endif
+
+#define FR_OK 0
+#define FR_EINVAL (-1)      /* bad argument (null pointer, unsupported dim, workspace too small ...) */
+#define FR_EHIP (-2)        /* a HIP runtime call failed; see fr_last_error() */
+#define FR_EUNSUPPORTED (-3)
+
+/* bits of the device-side error word */
+#define FR_DEV_ERR_INDEX_RANGE 1u   /* a row id was <0 or >= n_rows (reference: IndexError in F.embedding) */
+#define FR_DEV_ERR_SST_GROUPS 2u    /* >2 distinct sensitive values in one batch (reference: IndexError at focf.py:86) */
+
+/* FOCF fairness objectives -- FOCF.get_loss_fun, focf.py:50-68 */
+enum fr_focf_objective {
+    FR_FOCF_NONE = 0, FR_FOCF_VALUE = 1, FR_FOCF_ABSOLUTE = 2, FR_FOCF_UNDER = 3, FR_FOCF_OVER = 4,
+    FR_FOCF_NONPARITY = 5
+};
+
+/*
+ * An embedding table with lazily-applied dense Adam (coupled L2).
+ *
+ * Replaces: nn.Embedding weight + the per-parameter state of torch.optim.Adam built at
+ * trainer.py:139 (exp_avg, exp_avg_sq, step).  The reference sweeps the whole table every step
+ * (dense gradient, dense Adam).  Here a row's state is (p,m,v) "as of step last[row]"; the steps a
+ * row missed have gradient wd*p only and are replayed in registers, in the reference's op order,
+ * when the row is next read (or by the bounded-staleness sweeper / fr_table_flush).  Results are
+ * those of the dense update up to fp32 rounding.
+ */
+typedef struct fr_table {
+    float* p;          /* [n_rows, dim] parameters (the nn.Embedding weight storage) */
+    float* m;          /* [n_rows, dim] exp_avg */
+    float* v;          /* [n_rows, dim] exp_avg_sq */
+    int32_t* last;     /* [n_rows] optimizer step the row's (p,m,v) are current for */
+    int32_t* stamp;    /* [n_rows] last step at which the row was gathered for training */
+    int64_t n_rows;
+    int32_t dim;       /* embedding_size; 1..256 */
+    int32_t step;      /* optimizer step count of this tensor so far (torch: state['step']) */
+} fr_table;
+
+/*
+ * Adam hyper-parameters (torch.optim.Adam defaults + lr/weight_decay from trainer.py:131-139) and the
+ * per-step scalars torch computes in double on the host (torch/optim/adam.py, _single_tensor_adam):
+ *   scalars[2*j]   = (float)(lr / (1 - beta1^j))
+ *   scalars[2*j+1] = (float)(1 / sqrt(1 - beta2^j))       for j = 1..cap ; entry 0 unused.
+ * Steps beyond `cap` use entry `cap` (the host guarantees both scalars have saturated there).
+ */
+typedef struct fr_adam {
+    const float* scalars;  /* device, float[2*(cap+1)] */
+    int32_t cap;
+    float weight_decay, beta1, beta2, eps;
+} fr_adam;
+
+FR_API int fr_version(void);
+FR_API const char* fr_last_error(void);
+
+/*
+ * Sort the M row ids of a batch and cut them into segments of equal id.
+ * Replaces the dedup the reference gets implicitly from dense embedding_dense_backward (autograd of
+ * nn.Embedding, focf.py:138-139) and from torch.unique(return_inverse) at focf.py:77-78 / nfcf.py:79-80.
+ *   perm[j]      : batch position of the j-th smallest (id, position) pair        [M]
+ *   seg_start[k] : first j of segment k; seg_start[n_seg] = M                      [M+1]
+ *   seg_row[k]   : the row id of segment k                                         [M]
+ *   seg_of[b]    : segment index of batch position b  (= torch.unique inverse)     [M]
+ *   n_seg        : number of distinct ids                                          [1]
+ * M <= FR_SORT_MAX.
+ */
+#define FR_SORT_MAX 16384
+FR_API int fr_sort_segments(const int64_t* idx, int64_t M, int64_t n_rows, int32_t* perm, int32_t* seg_start,
+                     int32_t* seg_row, int32_t* seg_of, int32_t* n_seg, uint32_t* err_flag, void* stream);
+
+/* ---- FOCF (focf.py) ---------------------------------------------------------------------------- */
+
+FR_API size_t fr_focf_workspace_bytes(int64_t B, int32_t dim);
+
+/*
+ * Forward of one training batch: FOCF.calculate_loss, focf.py:152-169 (= forward :136-143, MSELoss
+ * :158, get_item_ratings :75-91 and the unfairness terms :93-134).  Reads the tables (never writes
+ * p/m/v/last), leaves the caught-up rows and dLoss/dpred in the workspace for fr_focf_backward_adam.
+ *   loss_out[0] = loss, loss_out[1] = mse part, loss_out[2] = fairness part (unweighted)   (device)
+ *   pred_out    = pred_scores [B] (device, may be NULL)
+ */
+FR_API int fr_focf_forward(const fr_table* U, const fr_table* I, const fr_adam* adam, const int64_t* user,
+                    const int64_t* item, const float* rating, const float* sst, int64_t B, int32_t objective,
+                    float fair_weight, void* ws, size_t ws_bytes, float* loss_out, float* pred_out,
+                    uint32_t* err_flag, void* stream);
+
+/*
+ * loss.backward() + optimizer.step() for the batch of the preceding fr_focf_forward on the same
+ * workspace: autograd of focf.py:152-169 (dense embedding gradient) followed by Adam.step()
+ * (trainer.py:193-196).  Duplicate rows are summed in batch order before the update, rows not in the
+ * batch are left to the lazy replay; `sweep_period` S>0 additionally brings rows
+ * [s*ceil(n/S), (s+1)*ceil(n/S)), s = step mod S, up to date each call (bounds the replay length).
+ * Increments U->step / I->step semantics are the CALLER's: pass tables whose .step is the step being
+ * applied (old step + 1) in both calls of a batch.
+ */
+FR_API int fr_focf_backward_adam(const fr_table* U, const fr_table* I, const fr_adam* adam, int64_t B,
+                          int32_t sweep_period, void* ws, size_t ws_bytes, void* stream);
+
+/* FOCF.predict, focf.py:145-150: clamp(pred, 0, max_rating) / max_rating on up-to-date rows (read only). */
+FR_API int fr_focf_predict(const fr_table* U, const fr_table* I, const fr_adam* adam, const int64_t* user,
+                    const int64_t* item, int64_t B, float max_rating, float* out, uint32_t* err_flag, void* stream);
+
+/* ---- lazy Adam table maintenance ---------------------------------------------------------------- */
+
+/* Bring every row of the table up to step `t->step` (needed before anything reads the whole table:
+ * state_dict / checkpoint trainer.py:221-240, full_sort_predict focf.py:171-178, evaluation). */
+FR_API int fr_table_flush(const fr_table* t, const fr_adam* adam, void* stream);
+
+/* Gather rows as of step t->step (read only; replay in registers): out[j,:] = p[idx[j],:]. */
+FR_API int fr_table_gather(const fr_table* t, const fr_adam* adam, const int64_t* idx, int64_t M, float* out,
+                    uint32_t* err_flag, void* stream);
+
+/* Dense fused Adam step for small dense parameters (MLP weights, biases): one step of
+ * torch.optim.Adam on a flat fp32 tensor, `step` = the step being applied. */
+FR_API int fr_adam_dense(float* p, const float* g, float* m, float* v, int64_t n, const fr_adam* adam, int32_t step,
+                  void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FAIRREC_HIP_H */

@@ -1,0 +1,123 @@
+// Shared host/device helpers for libfairrec_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "fairrec_hip.h"
+
+namespace fr {
+
+constexpr int WAVE = 64;
+
+// ---- host-side error plumbing -------------------------------------------------------------------
+void set_error(const char* fmt, ...);
+
+#define FR_CHECK_ARG(cond, ...)          \
+    do {                                 \
+        if (!(cond)) {                   \
+            ::fr::set_error(__VA_ARGS__); \
+            return FR_EINVAL;            \
+        }                                \
+    } while (0)
+
+#define FR_CHECK_HIP(expr)                                                                          \
+    do {                                                                                            \
+        hipError_t e__ = (expr);                                                                    \
+        if (e__ != hipSuccess) {                                                                    \
+            ::fr::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+            return FR_EHIP;                                                                         \
+        }                                                                                           \
+    } while (0)
+
+#define FR_CHECK_LAUNCH()  FR_CHECK_HIP(hipGetLastError())
+
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// ---- device helpers -----------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float x) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+    return x;  // every lane holds the total; fixed butterfly order => deterministic
+}
+
+template <int W>
+__device__ __forceinline__ float group_sum(float x) {  // sum over aligned groups of W lanes
+#pragma unroll
+    for (int o = W / 2; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+    return x;
+}
+
+__device__ __forceinline__ int uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
+
+// Adam constants in the form the kernels consume.
+struct AdamC {
+    const float2* sc;  // per-step (step_size, 1/sqrt(bias_correction2)); entry 0 unused
+    int cap;
+    float wd, b1, omb1, b2, omb2, eps;
+};
+
+inline AdamC make_adamc(const fr_adam* a) {
+    AdamC c;
+    c.sc = reinterpret_cast<const float2*>(a->scalars);
+    c.cap = a->cap;
+    c.wd = a->weight_decay;
+    c.b1 = a->beta1;
+    c.omb1 = (float)(1.0 - (double)a->beta1);
+    c.b2 = a->beta2;
+    c.omb2 = (float)(1.0 - (double)a->beta2);
+    c.eps = a->eps;
+    return c;
+}
+
+// One Adam step on one element, in the op order of torch/optim/adam.py::_single_tensor_adam
+// (grad.add(param, alpha=wd); exp_avg.lerp_; exp_avg_sq.mul_().addcmul_(); sqrt/bc2_sqrt + eps; addcdiv_).
+// `gd` is the data gradient (0 for a replayed step).  ss = lr/bc1, ib = 1/sqrt(bc2).
+// v_sqrt_f32 / v_rcp_f32 are 1-ulp; the division by bc2_sqrt is a multiplication by its fp32 reciprocal.
+__device__ __forceinline__ void adam_elem(float& p, float& m, float& v, float gd, float ss, float ib, const AdamC& c) {
+    float g = fmaf(c.wd, p, gd);
+    m = fmaf(c.omb1, g - m, m);
+    v = fmaf(c.omb2 * g, g, v * c.b2);
+    float den = fmaf(__builtin_amdgcn_sqrtf(v), ib, c.eps);
+    p = fmaf(-ss * m, __builtin_amdgcn_rcpf(den), p);
+}
+
+__device__ __forceinline__ float2 step_scalars(const AdamC& c, int j) {
+    return c.sc[j < c.cap ? j : c.cap];
+}
+
+// A row (or the part of it one lane owns): element e of lane l is column l + 64*e.
+template <int E>
+struct RowFrag {
+    float x[E];
+};
+
+template <int E>
+__device__ __forceinline__ void load_row(RowFrag<E>& f, const float* base, int D, int lane) {
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        int d = lane + 64 * e;
+        f.x[e] = d < D ? base[d] : 0.f;
+    }
+}
+
+template <int E>
+__device__ __forceinline__ void store_row(const RowFrag<E>& f, float* base, int D, int lane) {
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        int d = lane + 64 * e;
+        if (d < D) base[d] = f.x[e];
+    }
+}
+
+// Replay the zero-data-gradient steps (from, to] on a row fragment; `from`/`to` are wave-uniform.
+template <int E>
+__device__ __forceinline__ void replay(RowFrag<E>& p, RowFrag<E>& m, RowFrag<E>& v, int from, int to, const AdamC& c) {
+    for (int j = from + 1; j <= to; ++j) {
+        float2 s = step_scalars(c, j);
+#pragma unroll
+        for (int e = 0; e < E; ++e) adam_elem(p.x[e], m.x[e], v.x[e], 0.f, s.x, s.y, c);
+    }
+}
+
+}  // namespace fr

@@ -1,0 +1,566 @@
+// FOCF training step on MI355X: fused lazy-Adam gather + dot, fairness statistics, backward + Adam.
+//
+// Reference being replaced (all stock PyTorch ops called from Python):
+//   FOCF.forward            focf.py:136-143   two nn.Embedding gathers + mul + sum
+//   FOCF.calculate_loss     focf.py:152-169   MSELoss + fair_weight * unfairness term
+//   FOCF.get_item_ratings   focf.py:75-91     2x torch.unique + 3x index_put_(accumulate)
+//   *_unfairness            focf.py:93-134    smooth_l1 on per-item group means
+//   loss.backward()         trainer.py:193    dense embedding_dense_backward (N x D per table)
+//   optimizer.step()        trainer.py:196    dense torch.optim.Adam over both tables
+//
+// Kernel chain per batch (one wave = one interaction / one distinct row; lane = embedding column):
+//   sort      : (row,pos) sort + segmentation of user ids and item ids, min/max of the sst column
+//   gather    : rows read from HBM once, missed Adam steps replayed in registers, dot product,
+//               caught-up (p,m,v) parked in the workspace (L2/Infinity-Cache resident), MSE partials
+//   fair      : per distinct item: group sums in batch order -> unfairness term and dLoss/dpred
+//   finalize  : fixed-order reduction of the partials -> loss scalar
+//   bwd_adam  : per distinct row: sum_b dLoss/dpred[b] * other_row[b] (batch order), Adam step,
+//               row written back once; plus the bounded-staleness sweeper slice
+#include "common.hpp"
+#include "kernels.hpp"
+
+namespace fr {
+
+struct FocfWs {
+    // sort outputs
+    int32_t *perm_u, *seg_start_u, *seg_row_u, *seg_of_u, *nseg_u;
+    int32_t *perm_i, *seg_start_i, *seg_row_i, *seg_of_i, *nseg_i;
+    float* sst_minmax;   // [2]
+    float* pred;         // [B]
+    float* coef;         // [B] dLoss/dpred
+    float* mse_part;     // [gather blocks]
+    float* fair_part;    // [fair blocks]
+    float* side[6];      // ue, mu, vu, ie, mi, vi : [B, D] each
+    int n_gather_blocks, n_fair_blocks;
+    size_t bytes;
+};
+
+static constexpr int GATHER_THREADS = 256;  // 4 waves = 4 interactions per block
+static constexpr int FAIR_THREADS = 256;    // 16 lanes per item segment -> 16 segments per block
+static constexpr int FAIR_GROUP = 16;
+
+static FocfWs focf_layout(void* base, int64_t B, int D) {
+    FocfWs w;
+    size_t off = 0;
+    auto take = [&](size_t nbytes) {
+        void* p = base ? (void*)((char*)base + off) : nullptr;
+        off = align_up(off + nbytes, 256);
+        return p;
+    };
+    const size_t Bp = (size_t)B + 1;
+    w.perm_u = (int32_t*)take(Bp * 4);
+    w.seg_start_u = (int32_t*)take(Bp * 4);
+    w.seg_row_u = (int32_t*)take(Bp * 4);
+    w.seg_of_u = (int32_t*)take(Bp * 4);
+    w.nseg_u = (int32_t*)take(4);
+    w.perm_i = (int32_t*)take(Bp * 4);
+    w.seg_start_i = (int32_t*)take(Bp * 4);
+    w.seg_row_i = (int32_t*)take(Bp * 4);
+    w.seg_of_i = (int32_t*)take(Bp * 4);
+    w.nseg_i = (int32_t*)take(4);
+    w.sst_minmax = (float*)take(8);
+    w.pred = (float*)take(Bp * 4);
+    w.coef = (float*)take(Bp * 4);
+    w.n_gather_blocks = (int)((B * WAVE + GATHER_THREADS - 1) / GATHER_THREADS);
+    w.n_fair_blocks = (int)((B * FAIR_GROUP + FAIR_THREADS - 1) / FAIR_THREADS);
+    if (w.n_gather_blocks < 1) w.n_gather_blocks = 1;
+    if (w.n_fair_blocks < 1) w.n_fair_blocks = 1;
+    w.mse_part = (float*)take((size_t)w.n_gather_blocks * 4);
+    w.fair_part = (float*)take((size_t)w.n_fair_blocks * 4);
+    for (int k = 0; k < 6; ++k) w.side[k] = (float*)take((size_t)B * D * 4);
+    w.bytes = off;
+    return w;
+}
+
+// ------------------------------------------------------------------------------------------------
+// gather: one wave per interaction
+// ------------------------------------------------------------------------------------------------
+template <int E, bool TRAIN>
+__global__ __launch_bounds__(GATHER_THREADS) void focf_gather_kernel(
+    TableV U, TableV I, AdamC c, const int64_t* __restrict__ user, const int64_t* __restrict__ item,
+    const float* __restrict__ rating, int B, int upto_u, int upto_i, FocfWs w, float max_rating,
+    float* __restrict__ predict_out, uint32_t* err) {
+    const int lane = threadIdx.x & 63;
+    const int wib = threadIdx.x >> 6;
+    const int b = blockIdx.x * (GATHER_THREADS / WAVE) + wib;
+    __shared__ float red[GATHER_THREADS / WAVE];
+    float e2 = 0.f;
+    if (b < B) {
+        long long ul = user[b], il = item[b];
+        if (ul < 0 || ul >= U.n_rows || il < 0 || il >= I.n_rows) {
+            if (lane == 0 && err) atomicOr(err, FR_DEV_ERR_INDEX_RANGE);
+            ul = ul < 0 || ul >= U.n_rows ? 0 : ul;
+            il = il < 0 || il >= I.n_rows ? 0 : il;
+        }
+        const int ur = uniform((int)ul), ir = uniform((int)il);
+        const int D = U.D;
+        const int t0u = uniform(U.last[ur]), t0i = uniform(I.last[ir]);
+        const float* up = U.p + (size_t)ur * D;
+        const float* ip = I.p + (size_t)ir * D;
+        RowFrag<E> pu, mu, vu, pi, mi, vi;
+        load_row<E>(pu, up, D, lane);
+        load_row<E>(pi, ip, D, lane);
+        load_row<E>(mu, U.m + (size_t)ur * D, D, lane);
+        load_row<E>(vu, U.v + (size_t)ur * D, D, lane);
+        load_row<E>(mi, I.m + (size_t)ir * D, D, lane);
+        load_row<E>(vi, I.v + (size_t)ir * D, D, lane);
+
+        // replay the optimizer steps each row missed (zero data gradient, weight decay only)
+        if (upto_u == upto_i) {
+            const int lo = t0u < t0i ? t0u : t0i;
+            for (int j = lo + 1; j <= upto_u; ++j) {
+                const float2 s = step_scalars(c, j);
+                if (j > t0u) {
+#pragma unroll
+                    for (int e = 0; e < E; ++e) adam_elem(pu.x[e], mu.x[e], vu.x[e], 0.f, s.x, s.y, c);
+                }
+                if (j > t0i) {
+#pragma unroll
+                    for (int e = 0; e < E; ++e) adam_elem(pi.x[e], mi.x[e], vi.x[e], 0.f, s.x, s.y, c);
+                }
+            }
+        } else {
+            replay<E>(pu, mu, vu, t0u, upto_u, c);
+            replay<E>(pi, mi, vi, t0i, upto_i, c);
+        }
+
+        float dot = 0.f;
+#pragma unroll
+        for (int e = 0; e < E; ++e) dot = fmaf(pu.x[e], pi.x[e], dot);
+        dot = wave_sum(dot);
+
+        if (TRAIN) {
+            const size_t so = (size_t)b * D;
+            store_row<E>(pu, w.side[0] + so, D, lane);
+            store_row<E>(mu, w.side[1] + so, D, lane);
+            store_row<E>(vu, w.side[2] + so, D, lane);
+            store_row<E>(pi, w.side[3] + so, D, lane);
+            store_row<E>(mi, w.side[4] + so, D, lane);
+            store_row<E>(vi, w.side[5] + so, D, lane);
+            const float er = dot - rating[b];
+            e2 = er * er;
+            if (lane == 0) {
+                U.stamp[ur] = upto_u + 1;
+                I.stamp[ir] = upto_i + 1;
+                w.pred[b] = dot;
+                w.coef[b] = 2.f * er / (float)B;  // d mean((pred-r)^2) / d pred
+            }
+        } else if (lane == 0) {
+            predict_out[b] = fminf(fmaxf(dot, 0.f), max_rating) / max_rating;
+        }
+    }
+    if (TRAIN) {
+        if (lane == 0) red[wib] = e2;
+        __syncthreads();
+        if (threadIdx.x == 0) w.mse_part[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// fairness term on the distinct items of the batch: 16 lanes per item
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float smooth_l1(float x) {  // F.smooth_l1_loss(|x|, 0), beta = 1
+    float a = fabsf(x);
+    return a < 1.f ? 0.5f * a * a : a - 0.5f;
+}
+
+__global__ __launch_bounds__(FAIR_THREADS) void focf_fair_kernel(FocfWs w, const float* __restrict__ rating,
+                                                                 const float* __restrict__ sst, int B, int objective,
+                                                                 float fair_weight, uint32_t* err) {
+    const int sub = threadIdx.x & (FAIR_GROUP - 1);
+    const int gib = threadIdx.x / FAIR_GROUP;
+    const int k = blockIdx.x * (FAIR_THREADS / FAIR_GROUP) + gib;
+    const int K = w.nseg_i[0];
+    const float smin = w.sst_minmax[0], smax = w.sst_minmax[1];
+    __shared__ float red[FAIR_THREADS / FAIR_GROUP];
+    float term = 0.f;
+    if (k < K) {
+        const int j0 = w.seg_start_i[k], j1 = w.seg_start_i[k + 1];
+        float sp0 = 0.f, sp1 = 0.f, st0 = 0.f, st1 = 0.f, n0 = 0.f, n1 = 0.f;
+        bool bad = false;
+        for (int j = j0 + sub; j < j1; j += FAIR_GROUP) {
+            const int b = w.perm_i[j];
+            const float s = sst[b], pr = w.pred[b], r = rating[b];
+            bad |= (s != smin && s != smax);
+            if (s == smin) {
+                sp0 += pr; st0 += r; n0 += 1.f;
+            } else {
+                sp1 += pr; st1 += r; n1 += 1.f;
+            }
+        }
+        if (bad && err) atomicOr(err, FR_DEV_ERR_SST_GROUPS);
+        sp0 = group_sum<FAIR_GROUP>(sp0); sp1 = group_sum<FAIR_GROUP>(sp1);
+        st0 = group_sum<FAIR_GROUP>(st0); st1 = group_sum<FAIR_GROUP>(st1);
+        n0 = group_sum<FAIR_GROUP>(n0);   n1 = group_sum<FAIR_GROUP>(n1);
+        const float c0 = n0 + 1e-5f, c1 = n1 + 1e-5f;          // sst_num += 1e-5, focf.py:89
+        const float P0 = sp0 / c0, P1 = sp1 / c1, T0 = st0 / c0, T1 = st1 / c1;
+        float d0, d1, q0, q1;  // d_g and d d_g / d P_g
+        if (objective == FR_FOCF_VALUE) {
+            d0 = P0 - T0; d1 = P1 - T1; q0 = 1.f; q1 = 1.f;
+        } else if (objective == FR_FOCF_ABSOLUTE) {
+            d0 = fabsf(P0 - T0); d1 = fabsf(P1 - T1);
+            q0 = (P0 > T0) ? 1.f : (P0 < T0 ? -1.f : 0.f);
+            q1 = (P1 > T1) ? 1.f : (P1 < T1 ? -1.f : 0.f);
+        } else if (objective == FR_FOCF_UNDER) {
+            d0 = (T0 - P0 > 0.f) ? T0 - P0 : 0.f; d1 = (T1 - P1 > 0.f) ? T1 - P1 : 0.f;
+            q0 = (T0 - P0 > 0.f) ? -1.f : 0.f;    q1 = (T1 - P1 > 0.f) ? -1.f : 0.f;
+        } else {  // over
+            d0 = (P0 - T0 > 0.f) ? P0 - T0 : 0.f; d1 = (P1 - T1 > 0.f) ? P1 - T1 : 0.f;
+            q0 = (P0 - T0 > 0.f) ? 1.f : 0.f;     q1 = (P1 - T1 > 0.f) ? 1.f : 0.f;
+        }
+        const float delta = d0 - d1;
+        const float x = fabsf(delta);
+        term = smooth_l1(x);
+        const float sgn = delta > 0.f ? 1.f : (delta < 0.f ? -1.f : 0.f);
+        const float dx = (x < 1.f ? x : 1.f) * sgn * fair_weight / (float)K;  // d(fw * mean_k sl1)/d delta
+        const float g0 = dx * q0 / c0, g1 = -dx * q1 / c1;
+        for (int j = j0 + sub; j < j1; j += FAIR_GROUP) {
+            const int b = w.perm_i[j];
+            w.coef[b] += (sst[b] == smin) ? g0 : g1;
+        }
+    }
+    if (sub == 0) red[gib] = term;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float s = 0.f;
+#pragma unroll
+        for (int q = 0; q < FAIR_THREADS / FAIR_GROUP; ++q) s += red[q];
+        w.fair_part[blockIdx.x] = s;
+    }
+}
+
+// nonparity (focf.py:127-134): smooth_l1(mean(pred | g0), mean(pred | g1)); one workgroup, fixed order
+__global__ __launch_bounds__(1024) void focf_nonparity_kernel(FocfWs w, const float* __restrict__ sst, int B,
+                                                             float fair_weight, uint32_t* err) {
+    __shared__ float red[4][16];
+    const float smin = w.sst_minmax[0], smax = w.sst_minmax[1];
+    float s0 = 0.f, s1 = 0.f, n0 = 0.f, n1 = 0.f;
+    for (int b = threadIdx.x; b < B; b += 1024) {
+        const float s = sst[b], pr = w.pred[b];
+        if (s == smin) { s0 += pr; n0 += 1.f; }
+        else if (s == smax) { s1 += pr; n1 += 1.f; }   // rows of a third group are ignored, as in the reference
+    }
+    s0 = wave_sum(s0); s1 = wave_sum(s1); n0 = wave_sum(n0); n1 = wave_sum(n1);
+    const int wid = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[0][wid] = s0; red[1][wid] = s1; red[2][wid] = n0; red[3][wid] = n1; }
+    __syncthreads();
+    s0 = s1 = n0 = n1 = 0.f;
+    for (int q = 0; q < 16; ++q) { s0 += red[0][q]; s1 += red[1][q]; n0 += red[2][q]; n1 += red[3][q]; }
+    if (smin == smax || n1 == 0.f) {  // reference: IndexError (sst_unique_value[1]) -- flag it
+        if (threadIdx.x == 0) {
+            if (err) atomicOr(err, FR_DEV_ERR_SST_GROUPS);
+            w.fair_part[0] = 0.f;
+        }
+        return;
+    }
+    const float a = s0 / n0, bb = s1 / n1;
+    const float delta = a - bb;
+    const float dl = fminf(fmaxf(delta, -1.f), 1.f) * fair_weight;
+    for (int b = threadIdx.x; b < B; b += 1024) {
+        const float s = sst[b];
+        if (s == smin) w.coef[b] += dl / n0;
+        else if (s == smax) w.coef[b] -= dl / n1;
+    }
+    if (threadIdx.x == 0) w.fair_part[0] = smooth_l1(delta);
+}
+
+__global__ __launch_bounds__(256) void focf_finalize_kernel(FocfWs w, int B, int objective, float fair_weight,
+                                                            float* __restrict__ loss_out) {
+    __shared__ float red[2][4];
+    float a = 0.f, f = 0.f;
+    for (int q = threadIdx.x; q < w.n_gather_blocks; q += 256) a += w.mse_part[q];
+    int nf = objective == FR_FOCF_NONE ? 0 : (objective == FR_FOCF_NONPARITY ? 1 : w.n_fair_blocks);
+    for (int q = threadIdx.x; q < nf; q += 256) f += w.fair_part[q];
+    a = wave_sum(a);
+    f = wave_sum(f);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = a; red[1][threadIdx.x >> 6] = f; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        a = ((red[0][0] + red[0][1]) + red[0][2]) + red[0][3];
+        f = ((red[1][0] + red[1][1]) + red[1][2]) + red[1][3];
+        const float mse = a / (float)B;
+        float fair = 0.f;
+        if (objective == FR_FOCF_NONPARITY) fair = f;
+        else if (objective != FR_FOCF_NONE) fair = f / (float)w.nseg_i[0];
+        loss_out[0] = objective == FR_FOCF_NONE ? mse : mse + fair_weight * fair;
+        loss_out[1] = mse;
+        loss_out[2] = fair;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward + Adam: one wave per distinct row, plus sweeper waves
+// ------------------------------------------------------------------------------------------------
+template <int E>
+__device__ __forceinline__ void segment_update(const TableV& T, const AdamC& c, int k, const int32_t* seg_start,
+                                               const int32_t* seg_row, const int32_t* perm, const float* coef,
+                                               const float* sp, const float* sm, const float* sv, const float* other,
+                                               int lane) {
+    const int D = T.D;
+    const int j0 = uniform(seg_start[k]), j1 = uniform(seg_start[k + 1]);
+    const int row = uniform(seg_row[k]);
+    const int b0 = uniform(perm[j0]);
+    RowFrag<E> p, m, v, g;
+    load_row<E>(p, sp + (size_t)b0 * D, D, lane);
+    load_row<E>(m, sm + (size_t)b0 * D, D, lane);
+    load_row<E>(v, sv + (size_t)b0 * D, D, lane);
+#pragma unroll
+    for (int e = 0; e < E; ++e) g.x[e] = 0.f;
+    for (int j = j0; j < j1; ++j) {
+        const int b = uniform(perm[j]);
+        const float cb = coef[b];
+        RowFrag<E> o;
+        load_row<E>(o, other + (size_t)b * D, D, lane);
+        {
+#pragma clang fp contract(off)  // product rounded, then added: grad_row += coef * other_row (autograd order)
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                float prod = cb * o.x[e];
+                g.x[e] = g.x[e] + prod;
+            }
+        }
+    }
+    const float2 s = step_scalars(c, T.step);
+#pragma unroll
+    for (int e = 0; e < E; ++e) adam_elem(p.x[e], m.x[e], v.x[e], g.x[e], s.x, s.y, c);
+    store_row<E>(p, T.p + (size_t)row * D, D, lane);
+    store_row<E>(m, T.m + (size_t)row * D, D, lane);
+    store_row<E>(v, T.v + (size_t)row * D, D, lane);
+    if (lane == 0) T.last[row] = T.step;
+}
+
+// Bring one untouched row up to `upto` (all missed steps have zero data gradient).
+template <int E>
+__device__ __forceinline__ void sweep_row(const TableV& T, const AdamC& c, long long row, int upto, bool check_stamp,
+                                          int lane) {
+    const int D = T.D;
+    if (check_stamp && uniform(T.stamp[row]) == upto) return;  // touched this step: a segment wave owns it
+    const int t0 = uniform(T.last[row]);
+    if (t0 >= upto) return;
+    RowFrag<E> p, m, v;
+    load_row<E>(p, T.p + (size_t)row * D, D, lane);
+    load_row<E>(m, T.m + (size_t)row * D, D, lane);
+    load_row<E>(v, T.v + (size_t)row * D, D, lane);
+    replay<E>(p, m, v, t0, upto, c);
+    store_row<E>(p, T.p + (size_t)row * D, D, lane);
+    store_row<E>(m, T.m + (size_t)row * D, D, lane);
+    store_row<E>(v, T.v + (size_t)row * D, D, lane);
+    if (lane == 0) T.last[row] = upto;
+}
+
+template <int E>
+__global__ __launch_bounds__(256) void focf_backward_adam_kernel(TableV U, TableV I, AdamC c, int B, FocfWs w,
+                                                                 long long sw_lo_u, int sw_n_u, long long sw_lo_i,
+                                                                 int sw_n_i) {
+    const int lane = threadIdx.x & 63;
+    long long wv = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wv < B) {
+        if (wv < w.nseg_u[0])
+            segment_update<E>(U, c, (int)wv, w.seg_start_u, w.seg_row_u, w.perm_u, w.coef, w.side[0], w.side[1],
+                              w.side[2], w.side[3], lane);
+        return;
+    }
+    wv -= B;
+    if (wv < B) {
+        if (wv < w.nseg_i[0])
+            segment_update<E>(I, c, (int)wv, w.seg_start_i, w.seg_row_i, w.perm_i, w.coef, w.side[3], w.side[4],
+                              w.side[5], w.side[0], lane);
+        return;
+    }
+    wv -= B;
+    if (wv < sw_n_u) {
+        sweep_row<E>(U, c, sw_lo_u + wv, U.step, true, lane);
+        return;
+    }
+    wv -= sw_n_u;
+    if (wv < sw_n_i) sweep_row<E>(I, c, sw_lo_i + wv, I.step, true, lane);
+}
+
+// ------------------------------------------------------------------------------------------------
+// table maintenance
+// ------------------------------------------------------------------------------------------------
+template <int E>
+__global__ __launch_bounds__(256) void table_flush_kernel(TableV T, AdamC c) {
+    const int lane = threadIdx.x & 63;
+    const long long nw = (long long)gridDim.x * 4;
+    for (long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); row < T.n_rows; row += nw)
+        sweep_row<E>(T, c, row, T.step, false, lane);
+}
+
+template <int E>
+__global__ __launch_bounds__(256) void table_gather_kernel(TableV T, AdamC c, const int64_t* __restrict__ idx,
+                                                           long long M, float* __restrict__ out, uint32_t* err) {
+    const int lane = threadIdx.x & 63;
+    const long long j = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= M) return;
+    long long r = idx[j];
+    if (r < 0 || r >= T.n_rows) {
+        if (lane == 0 && err) atomicOr(err, FR_DEV_ERR_INDEX_RANGE);
+        r = 0;
+    }
+    const int row = uniform((int)r);
+    const int D = T.D;
+    const int t0 = uniform(T.last[row]);
+    RowFrag<E> p, m, v;
+    load_row<E>(p, T.p + (size_t)row * D, D, lane);
+    if (t0 < T.step) {
+        load_row<E>(m, T.m + (size_t)row * D, D, lane);
+        load_row<E>(v, T.v + (size_t)row * D, D, lane);
+        replay<E>(p, m, v, t0, T.step, c);
+    }
+    store_row<E>(p, out + (size_t)j * D, D, lane);
+}
+
+__global__ __launch_bounds__(256) void adam_dense_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                         float* __restrict__ m, float* __restrict__ v, long long n,
+                                                         AdamC c, int step) {
+    const float2 s = step_scalars(c, step);
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        float pp = p[i], mm = m[i], vv = v[i];
+        adam_elem(pp, mm, vv, g[i], s.x, s.y, c);
+        p[i] = pp; m[i] = mm; v[i] = vv;
+    }
+}
+
+#define FR_DISPATCH_E(D, ...)                          \
+    switch (((D) + 63) / 64) {                         \
+        case 1: { constexpr int E = 1; __VA_ARGS__; } break;  \
+        case 2: { constexpr int E = 2; __VA_ARGS__; } break;  \
+        case 3: { constexpr int E = 3; __VA_ARGS__; } break;  \
+        default: { constexpr int E = 4; __VA_ARGS__; } break; \
+    }
+
+}  // namespace fr
+
+using namespace fr;
+
+extern "C" size_t fr_focf_workspace_bytes(int64_t B, int32_t dim) {
+    if (B < 0 || dim < 1) return 0;
+    return focf_layout(nullptr, B, dim).bytes;
+}
+
+extern "C" int fr_focf_forward(const fr_table* U, const fr_table* I, const fr_adam* adam, const int64_t* user,
+                               const int64_t* item, const float* rating, const float* sst, int64_t B,
+                               int32_t objective, float fair_weight, void* ws, size_t ws_bytes, float* loss_out,
+                               float* pred_out, uint32_t* err_flag, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    int rc;
+    if ((rc = check_table(U, "fr_focf_forward(U)")) || (rc = check_table(I, "fr_focf_forward(I)")) ||
+        (rc = check_adam(adam, "fr_focf_forward")))
+        return rc;
+    FR_CHECK_ARG(U->dim == I->dim, "fr_focf_forward: user dim %d != item dim %d", U->dim, I->dim);
+    FR_CHECK_ARG(user && item && rating && loss_out && ws, "fr_focf_forward: null pointer");
+    FR_CHECK_ARG(objective >= FR_FOCF_NONE && objective <= FR_FOCF_NONPARITY, "fr_focf_forward: objective %d",
+                 objective);
+    FR_CHECK_ARG(objective == FR_FOCF_NONE || sst, "fr_focf_forward: sst column required for a fairness objective");
+    FR_CHECK_ARG(B >= 1 && B <= FR_SORT_MAX, "fr_focf_forward: batch size %lld not in 1..%d", (long long)B,
+                 FR_SORT_MAX);
+    FR_CHECK_ARG(U->step >= 1 && I->step >= 1, "fr_focf_forward: table.step must be the step being applied (>=1)");
+    FocfWs w = focf_layout(ws, B, U->dim);
+    FR_CHECK_ARG(ws_bytes >= w.bytes, "fr_focf_forward: workspace %zu < %zu bytes", ws_bytes, w.bytes);
+
+    SortJob ju{user, U->n_rows, w.perm_u, w.seg_start_u, w.seg_row_u, w.seg_of_u, w.nseg_u, nullptr, nullptr};
+    SortJob ji{item, I->n_rows, w.perm_i, w.seg_start_i, w.seg_row_i, w.seg_of_i, w.nseg_i,
+               objective == FR_FOCF_NONE ? nullptr : sst, w.sst_minmax};
+    if ((rc = launch_sort(ju, &ji, B, err_flag, stream))) return rc;
+
+    const AdamC c = make_adamc(adam);
+    const TableV Uv = view(U), Iv = view(I);
+    FR_DISPATCH_E(U->dim, focf_gather_kernel<E, true><<<dim3(w.n_gather_blocks), dim3(GATHER_THREADS), 0, stream>>>(Uv, Iv, c, user, item, rating, (int)B, U->step - 1, I->step - 1, w, 0.f, (float*)nullptr, err_flag));
+    FR_CHECK_LAUNCH();
+    if (objective == FR_FOCF_NONPARITY) {
+        hipLaunchKernelGGL(focf_nonparity_kernel, dim3(1), dim3(1024), 0, stream, w, sst, (int)B, fair_weight,
+                           err_flag);
+        FR_CHECK_LAUNCH();
+    } else if (objective != FR_FOCF_NONE) {
+        hipLaunchKernelGGL(focf_fair_kernel, dim3(w.n_fair_blocks), dim3(FAIR_THREADS), 0, stream, w, rating, sst,
+                           (int)B, objective, fair_weight, err_flag);
+        FR_CHECK_LAUNCH();
+    }
+    hipLaunchKernelGGL(focf_finalize_kernel, dim3(1), dim3(256), 0, stream, w, (int)B, objective, fair_weight,
+                       loss_out);
+    FR_CHECK_LAUNCH();
+    if (pred_out) FR_CHECK_HIP(hipMemcpyAsync(pred_out, w.pred, (size_t)B * 4, hipMemcpyDeviceToDevice, stream));
+    return FR_OK;
+}
+
+extern "C" int fr_focf_backward_adam(const fr_table* U, const fr_table* I, const fr_adam* adam, int64_t B,
+                                     int32_t sweep_period, void* ws, size_t ws_bytes, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    int rc;
+    if ((rc = check_table(U, "fr_focf_backward_adam(U)")) || (rc = check_table(I, "fr_focf_backward_adam(I)")) ||
+        (rc = check_adam(adam, "fr_focf_backward_adam")))
+        return rc;
+    FR_CHECK_ARG(U->dim == I->dim && ws && B >= 1 && B <= FR_SORT_MAX, "fr_focf_backward_adam: bad argument");
+    FocfWs w = focf_layout(ws, B, U->dim);
+    FR_CHECK_ARG(ws_bytes >= w.bytes, "fr_focf_backward_adam: workspace %zu < %zu bytes", ws_bytes, w.bytes);
+    long long lo_u, hi_u, lo_i, hi_i;
+    sweep_range(U->n_rows, U->step, sweep_period, lo_u, hi_u);
+    sweep_range(I->n_rows, I->step, sweep_period, lo_i, hi_i);
+    const long long waves = 2 * B + (hi_u - lo_u) + (hi_i - lo_i);
+    const AdamC c = make_adamc(adam);
+    const TableV Uv = view(U), Iv = view(I);
+    FR_DISPATCH_E(U->dim, focf_backward_adam_kernel<E><<<dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, stream>>>(Uv, Iv, c, (int)B, w, lo_u, (int)(hi_u - lo_u), lo_i, (int)(hi_i - lo_i)));
+    FR_CHECK_LAUNCH();
+    return FR_OK;
+}
+
+extern "C" int fr_focf_predict(const fr_table* U, const fr_table* I, const fr_adam* adam, const int64_t* user,
+                               const int64_t* item, int64_t B, float max_rating, float* out, uint32_t* err_flag,
+                               void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    int rc;
+    if ((rc = check_table(U, "fr_focf_predict(U)")) || (rc = check_table(I, "fr_focf_predict(I)")) ||
+        (rc = check_adam(adam, "fr_focf_predict")))
+        return rc;
+    FR_CHECK_ARG(U->dim == I->dim && user && item && out && B >= 0, "fr_focf_predict: bad argument");
+    if (B == 0) return FR_OK;
+    const AdamC c = make_adamc(adam);
+    const TableV Uv = view(U), Iv = view(I);
+    FocfWs w{};
+    const unsigned blocks = (unsigned)((B * WAVE + GATHER_THREADS - 1) / GATHER_THREADS);
+    FR_DISPATCH_E(U->dim, focf_gather_kernel<E, false><<<dim3(blocks), dim3(GATHER_THREADS), 0, stream>>>(Uv, Iv, c, user, item, (const float*)nullptr, (int)B, U->step,
+                                              I->step, w, max_rating, out, err_flag));
+    FR_CHECK_LAUNCH();
+    return FR_OK;
+}
+
+extern "C" int fr_table_flush(const fr_table* t, const fr_adam* adam, void* stream_) {
+    int rc;
+    if ((rc = check_table(t, "fr_table_flush")) || (rc = check_adam(adam, "fr_table_flush"))) return rc;
+    if (t->step < 1) return FR_OK;
+    const AdamC c = make_adamc(adam);
+    const TableV Tv = view(t);
+    long long blocks = (t->n_rows + 3) / 4;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    FR_DISPATCH_E(t->dim, table_flush_kernel<E><<<dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream_>>>(Tv, c));
+    FR_CHECK_LAUNCH();
+    return FR_OK;
+}
+
+extern "C" int fr_table_gather(const fr_table* t, const fr_adam* adam, const int64_t* idx, int64_t M, float* out,
+                               uint32_t* err_flag, void* stream_) {
+    int rc;
+    if ((rc = check_table(t, "fr_table_gather")) || (rc = check_adam(adam, "fr_table_gather"))) return rc;
+    FR_CHECK_ARG(idx && out && M >= 0, "fr_table_gather: bad argument");
+    if (M == 0) return FR_OK;
+    const AdamC c = make_adamc(adam);
+    const TableV Tv = view(t);
+    FR_DISPATCH_E(t->dim, table_gather_kernel<E><<<dim3((unsigned)((M + 3) / 4)), dim3(256), 0, (hipStream_t)stream_>>>(Tv, c, idx, (long long)M, out, err_flag));
+    FR_CHECK_LAUNCH();
+    return FR_OK;
+}
+
+extern "C" int fr_adam_dense(float* p, const float* g, float* m, float* v, int64_t n, const fr_adam* adam,
+                             int32_t step, void* stream_) {
+    int rc;
+    if ((rc = check_adam(adam, "fr_adam_dense"))) return rc;
+    FR_CHECK_ARG(p && g && m && v && n >= 0 && step >= 1, "fr_adam_dense: bad argument");
+    if (n == 0) return FR_OK;
+    long long blocks = (n + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(adam_dense_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream_, p, g, m, v,
+                       (long long)n, make_adamc(adam), step);
+    FR_CHECK_LAUNCH();
+    return FR_OK;
+}

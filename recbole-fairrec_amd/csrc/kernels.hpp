@@ -1,0 +1,75 @@
+// Internal (non-ABI) declarations shared between the .hip translation units.
+#pragma once
+#include "common.hpp"
+
+namespace fr {
+
+struct SortJob {
+    const int64_t* idx;
+    int64_t n_rows;
+    int32_t* perm;
+    int32_t* seg_start;
+    int32_t* seg_row;
+    int32_t* seg_of;
+    int32_t* n_seg;
+    const float* aux;   // optional float column to min/max-reduce alongside (may be null)
+    float* aux_minmax;  // [2]
+};
+
+// Sort one (b == nullptr) or two index lists of the same length M in one launch (one workgroup each).
+int launch_sort(const SortJob& a, const SortJob* b, int64_t M, uint32_t* err, hipStream_t stream);
+
+// Device view of a lazy-Adam table.
+struct TableV {
+    float* p;
+    float* m;
+    float* v;
+    int32_t* last;
+    int32_t* stamp;
+    long long n_rows;
+    int D;
+    int step;
+};
+
+inline TableV view(const fr_table* t) {
+    return TableV{t->p, t->m, t->v, t->last, t->stamp, (long long)t->n_rows, t->dim, t->step};
+}
+
+inline int check_table(const fr_table* t, const char* who) {
+    if (!t || !t->p || !t->m || !t->v || !t->last || !t->stamp) {
+        set_error("%s: table has null pointers", who);
+        return FR_EINVAL;
+    }
+    if (t->dim < 1 || t->dim > 256) {
+        set_error("%s: embedding dim %d not in 1..256", who, t->dim);
+        return FR_EUNSUPPORTED;
+    }
+    if (t->n_rows < 1 || t->n_rows > 0x7fffffffLL) {
+        set_error("%s: n_rows %lld not in 1..2^31-1", who, (long long)t->n_rows);
+        return FR_EUNSUPPORTED;
+    }
+    return FR_OK;
+}
+
+inline int check_adam(const fr_adam* a, const char* who) {
+    if (!a || !a->scalars || a->cap < 1) {
+        set_error("%s: bad fr_adam", who);
+        return FR_EINVAL;
+    }
+    return FR_OK;
+}
+
+// Sweep slice of a table for optimizer step `step` with period S: rows [lo, hi).
+inline void sweep_range(long long n_rows, int step, int S, long long& lo, long long& hi) {
+    if (S <= 0) {
+        lo = hi = 0;
+        return;
+    }
+    long long chunk = (n_rows + S - 1) / S;
+    lo = (long long)(step % S) * chunk;
+    hi = lo + chunk;
+    if (lo > n_rows) lo = n_rows;
+    if (hi > n_rows) hi = n_rows;
+}
+
+}  // namespace fr

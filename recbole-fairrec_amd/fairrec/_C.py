@@ -1,0 +1,93 @@
+"""ctypes binding of libfairrec_hip.so (the C ABI declared in include/fairrec_hip.h).
+
+There is NO fallback: if the library is missing the import of anything that needs a kernel raises.
+Build it with `python __graft_entry__.py` (or `make -C recbole-fairrec_amd/csrc`).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_uint32, c_void_p
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libfairrec_hip.so")
+
+FR_SORT_MAX = 16384
+DEV_ERR_INDEX_RANGE = 1
+DEV_ERR_SST_GROUPS = 2
+
+FOCF_OBJECTIVES = {"none": 0, "value": 1, "absolute": 2, "under": 3, "over": 4, "nonparity": 5}
+
+
+class FrTable(Structure):
+    _fields_ = [("p", c_void_p), ("m", c_void_p), ("v", c_void_p), ("last", c_void_p), ("stamp", c_void_p),
+                ("n_rows", c_int64), ("dim", c_int32), ("step", c_int32)]
+
+
+class FrAdam(Structure):
+    _fields_ = [("scalars", c_void_p), ("cap", c_int32), ("weight_decay", c_float), ("beta1", c_float),
+                ("beta2", c_float), ("eps", c_float)]
+
+
+class FairrecError(RuntimeError):
+    pass
+
+
+# name -> (restype, argtypes); mirrors include/fairrec_hip.h one to one
+_PROTOS = {
+    "fr_version": (c_int, []),
+    "fr_last_error": (c_char_p, []),
+    "fr_sort_segments": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                 c_void_p, c_void_p]),
+    "fr_focf_workspace_bytes": (c_size_t, [c_int64, c_int32]),
+    "fr_focf_forward": (c_int, [POINTER(FrTable), POINTER(FrTable), POINTER(FrAdam), c_void_p, c_void_p, c_void_p,
+                                c_void_p, c_int64, c_int32, c_float, c_void_p, c_size_t, c_void_p, c_void_p,
+                                c_void_p, c_void_p]),
+    "fr_focf_backward_adam": (c_int, [POINTER(FrTable), POINTER(FrTable), POINTER(FrAdam), c_int64, c_int32,
+                                      c_void_p, c_size_t, c_void_p]),
+    "fr_focf_predict": (c_int, [POINTER(FrTable), POINTER(FrTable), POINTER(FrAdam), c_void_p, c_void_p, c_int64,
+                                c_float, c_void_p, c_void_p, c_void_p]),
+    "fr_table_flush": (c_int, [POINTER(FrTable), POINTER(FrAdam), c_void_p]),
+    "fr_table_gather": (c_int, [POINTER(FrTable), POINTER(FrAdam), c_void_p, c_int64, c_void_p, c_void_p,
+                                c_void_p]),
+    "fr_adam_dense": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, POINTER(FrAdam), c_int32,
+                              c_void_p]),
+}
+
+_lib = None
+
+
+def exported_names():
+    return sorted(_PROTOS)
+
+
+def lib():
+    """The loaded library; raises FairrecError (never falls back) when it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise FairrecError(
+                f"{LIB_PATH} not found: the HIP extension is not built. Run `python __graft_entry__.py` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback for the training hot path.")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _PROTOS.items():
+            fn = getattr(handle, name)  # AttributeError here = ABI mismatch between header and library
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = lib().fr_last_error()
+        raise FairrecError(f"{what} failed (rc={rc}): {msg.decode() if msg else ''}")
+
+
+def ptr(t) -> int:
+    """Device pointer of a torch tensor (0 for None)."""
+    return 0 if t is None else t.data_ptr()
+
+
+def current_stream() -> int:
+    import torch
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,63 @@
+"""Plugin base classes -- same names, attributes and method contracts as
+recbole/model/abstract_recommender.py:23-103 (AbstractRecommender / FairRecommender), so model code
+and trainers written against the reference keep working.  Clean-room: only the contract is shared.
+"""
+from logging import getLogger
+
+import numpy as np
+import torch.nn as nn
+
+from ..utils.enum_type import ModelType
+
+
+class AbstractRecommender(nn.Module):
+    """Contract (reference abstract_recommender.py:23-83): calculate_loss / predict / full_sort_predict,
+    other_parameter()/load_other_parameter() for non-tensor state, and a __str__ that reports the
+    number of trainable parameters."""
+
+    def __init__(self):
+        self.logger = getLogger()
+        super().__init__()
+
+    def calculate_loss(self, interaction):
+        raise NotImplementedError
+
+    def predict(self, interaction):
+        raise NotImplementedError
+
+    def full_sort_predict(self, interaction):
+        raise NotImplementedError
+
+    def other_parameter(self):
+        names = getattr(self, 'other_parameter_name', None)
+        return {k: getattr(self, k) for k in names} if names else dict()
+
+    def load_other_parameter(self, para):
+        if para is None:
+            return
+        for k, v in para.items():
+            setattr(self, k, v)
+
+    # hook used by fairrec.trainer.Trainer to build the fused optimizer; models that own HIP engines override
+    def hip_engine(self):
+        return None
+
+    def __str__(self):
+        n = sum(int(np.prod(p.size())) for p in self.parameters() if p.requires_grad)
+        return super().__str__() + f'\nTrainable parameters: {n}'
+
+
+class FairRecommender(AbstractRecommender):
+    """Reference abstract_recommender.py:86-103: reads USER_ID/ITEM_ID/NEG_PREFIX field names, the table
+    sizes from the dataset and the device from the config."""
+    type = ModelType.GENERAL
+
+    def __init__(self, config, dataset):
+        super().__init__()
+        self.USER_ID = config['USER_ID_FIELD']
+        self.ITEM_ID = config['ITEM_ID_FIELD']
+        self.POS_ITEM_ID = self.ITEM_ID
+        self.NEG_ITEM_ID = config['NEG_PREFIX'] + self.ITEM_ID
+        self.n_users = dataset.num(self.USER_ID)
+        self.n_items = dataset.num(self.ITEM_ID)
+        self.device = config['device']

@@ -1,0 +1,153 @@
+"""Host side of the lazily-applied dense Adam that backs every trainable embedding table.
+
+Replaces `torch.optim.Adam(params, lr=..., weight_decay=...)` as built by the reference at
+recbole/trainer/trainer.py:114-153 (learner 'adam').  The arithmetic is torch's `_single_tensor_adam`
+(coupled L2, bias corrections computed in double on the host); what changes is WHEN a row is updated:
+the HIP kernels replay the steps a row missed when it is next read, so the per-step HBM traffic is
+proportional to the batch, not to the table.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+from typing import Dict, Iterable, List, Optional
+
+import numpy as np
+import torch
+
+from . import _C
+
+
+def adam_step_scalars(lr: float, beta1: float, beta2: float, cap: int) -> np.ndarray:
+    """float32[2*(cap+1)]: entry j = (lr / (1 - beta1**j), 1 / sqrt(1 - beta2**j)), computed in Python double
+    exactly like torch/optim/adam.py (`bias_correction1 = 1 - beta1 ** step`, `step_size = lr / bias_correction1`,
+    `bias_correction2_sqrt = sqrt(bias_correction2)`) and rounded to fp32 once."""
+    out = np.zeros(2 * (cap + 1), dtype=np.float32)
+    for j in range(1, cap + 1):
+        bc1 = 1.0 - beta1 ** j
+        bc2 = 1.0 - beta2 ** j
+        out[2 * j] = lr / bc1
+        out[2 * j + 1] = 1.0 / math.sqrt(bc2)
+    return out
+
+
+class AdamHyper:
+    """lr / weight_decay / betas / eps + the device table of per-step scalars (fr_adam in the C ABI)."""
+
+    def __init__(self, lr=1e-3, weight_decay=0.0, betas=(0.9, 0.999), eps=1e-8, device="cuda", cap=32768):
+        self.lr, self.weight_decay, self.betas, self.eps = float(lr), float(weight_decay), tuple(betas), float(eps)
+        self.device = torch.device(device)
+        while True:
+            tab = adam_step_scalars(self.lr, self.betas[0], self.betas[1], cap)
+            # steps beyond `cap` reuse entry `cap`: only valid once both scalars stopped changing in fp32
+            if (tab[2 * cap] == np.float32(self.lr) and tab[2 * cap + 1] == np.float32(1.0)) or cap >= (1 << 22):
+                break
+            cap *= 2
+        self.cap = cap
+        self.saturated = bool(tab[2 * cap] == np.float32(self.lr) and tab[2 * cap + 1] == np.float32(1.0))
+        self.host_scalars = tab
+        self.scalars = torch.from_numpy(tab).to(self.device) if self.device.type == "cuda" else None
+        self._c = _C.FrAdam(_C.ptr(self.scalars), cap, self.weight_decay, self.betas[0], self.betas[1], self.eps)
+
+    def c(self) -> "_C.FrAdam":
+        return self._c
+
+    def check_step(self, step: int):
+        if step > self.cap and not self.saturated:
+            raise _C.FairrecError(f"Adam step {step} exceeds the scalar table ({self.cap}) and the bias "
+                                  "corrections have not saturated; raise `cap`")
+
+
+class LazyTable:
+    """An nn.Embedding weight with lazily-applied Adam state (fr_table in the C ABI).
+
+    `weight` stays the model's nn.Parameter (same storage), so `state_dict()` keys and shapes are the
+    reference's; `flush()` must run before anything reads the whole table.
+    """
+
+    def __init__(self, weight: torch.Tensor, trainable: bool = True):
+        assert weight.dim() == 2 and weight.dtype == torch.float32 and weight.is_contiguous()
+        self.weight = weight
+        self.n_rows, self.dim = weight.shape
+        self.trainable = trainable
+        self.step = 0            # optimizer steps applied so far (torch: state['step'])
+        self.m = self.v = self.last = self.stamp = None
+        self._dummy = None
+
+    def ensure_state(self):
+        dev = self.weight.device
+        if self.last is None:
+            self.last = torch.zeros(self.n_rows, dtype=torch.int32, device=dev)
+            self.stamp = torch.zeros(self.n_rows, dtype=torch.int32, device=dev)
+        if self.m is None:
+            if self.trainable:
+                self.m = torch.zeros_like(self.weight)
+                self.v = torch.zeros_like(self.weight)
+            else:  # frozen table: never replayed (last == step == 0), m/v never touched
+                self.m = self.v = self.weight
+
+    def c(self, step: Optional[int] = None) -> "_C.FrTable":
+        self.ensure_state()
+        w = self.weight.data if isinstance(self.weight, torch.nn.Parameter) else self.weight
+        return _C.FrTable(w.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), self.last.data_ptr(),
+                          self.stamp.data_ptr(), self.n_rows, self.dim, self.step if step is None else step)
+
+    def flush(self, hyper: AdamHyper):
+        """Bring every row up to `self.step` (fr_table_flush)."""
+        if self.step == 0 or not self.trainable:
+            return
+        t = self.c()
+        _C.check(_C.lib().fr_table_flush(ctypes.byref(t), ctypes.byref(hyper.c()), _C.current_stream()),
+                 "fr_table_flush")
+
+    def gather(self, hyper: AdamHyper, idx: torch.Tensor, err_flag: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Rows as of `self.step` without modifying the table (fr_table_gather)."""
+        idx = idx.contiguous()
+        out = torch.empty((idx.numel(), self.dim), dtype=torch.float32, device=self.weight.device)
+        t = self.c()
+        _C.check(_C.lib().fr_table_gather(ctypes.byref(t), ctypes.byref(hyper.c()), idx.data_ptr(), idx.numel(),
+                                          out.data_ptr(), _C.ptr(err_flag), _C.current_stream()), "fr_table_gather")
+        return out
+
+    # --- interchange with torch.optim.Adam.state_dict() (trainer.py:221-240 checkpoints) ---------------
+    def adam_state(self, hyper: AdamHyper) -> Dict[str, torch.Tensor]:
+        self.flush(hyper)
+        return {"step": torch.tensor(float(self.step)), "exp_avg": self.m, "exp_avg_sq": self.v}
+
+    def load_adam_state(self, state: Dict[str, torch.Tensor]):
+        self.ensure_state()
+        self.step = int(state["step"])
+        self.m.copy_(state["exp_avg"])
+        self.v.copy_(state["exp_avg_sq"])
+        self.last.fill_(self.step)
+
+
+class FusedLazyAdam:
+    """Drop-in for the `optimizer` object the reference Trainer drives (zero_grad / step / state_dict).
+
+    The embedding gradient is never materialised: `engine.backward_adam()` (one HIP launch) does
+    loss.backward() + optimizer.step() for the batch of the preceding `calculate_loss`.
+    Dense parameters (MLPs, biases) registered with the engine go through fr_adam_dense.
+    """
+
+    def __init__(self, engine, lr=1e-3, weight_decay=0.0, betas=(0.9, 0.999), eps=1e-8, sweep_period=None):
+        self.engine = engine
+        self.hyper = AdamHyper(lr, weight_decay, betas, eps, device=engine.device)
+        self.defaults = dict(lr=lr, weight_decay=weight_decay, betas=betas, eps=eps)
+        engine.bind_optimizer(self, sweep_period)
+
+    def zero_grad(self, set_to_none: bool = True):
+        pass  # gradients are never materialised: there is nothing to clear
+
+    def step(self, closure=None):
+        if closure is not None:
+            raise NotImplementedError("closure-based step is not supported by the fused path")
+        self.engine.backward_adam()
+
+    def state_dict(self):
+        return {"state": {name: t.adam_state(self.hyper) for name, t in self.engine.tables().items()},
+                "param_groups": [dict(self.defaults, params=list(self.engine.tables().keys()))]}
+
+    def load_state_dict(self, sd):
+        for name, st in sd["state"].items():
+            self.engine.tables()[name].load_adam_state(st)

@@ -1,0 +1,106 @@
+"""GPU: the building-block kernels against numpy / stock torch."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _sort(idx, n_rows):
+    from fairrec import _C
+    M = idx.numel()
+    dev = idx.device
+    perm = torch.full((M + 1,), -1, dtype=torch.int32, device=dev)
+    seg_start = torch.full((M + 1,), -1, dtype=torch.int32, device=dev)
+    seg_row = torch.full((M + 1,), -1, dtype=torch.int32, device=dev)
+    seg_of = torch.full((M + 1,), -1, dtype=torch.int32, device=dev)
+    nseg = torch.zeros(1, dtype=torch.int32, device=dev)
+    err = torch.zeros(1, dtype=torch.int32, device=dev)
+    _C.check(_C.lib().fr_sort_segments(idx.data_ptr(), M, n_rows, perm.data_ptr(), seg_start.data_ptr(),
+                                       seg_row.data_ptr(), seg_of.data_ptr(), nseg.data_ptr(), err.data_ptr(),
+                                       _C.current_stream()), "sort")
+    torch.cuda.synchronize()
+    return perm.cpu().numpy(), seg_start.cpu().numpy(), seg_row.cpu().numpy(), seg_of.cpu().numpy(), int(nseg), int(err)
+
+
+@pytest.mark.parametrize("M,n_rows", [(1, 5), (2, 2), (63, 10), (64, 1000), (1000, 50), (2048, 10 ** 6),
+                                      (2049, 300), (8192, 10 ** 5), (8192, 7), (16384, 10 ** 8)])
+def test_sort_segments_bit_exact(M, n_rows):
+    g = torch.Generator().manual_seed(M * 31 + n_rows % 97)
+    idx = torch.randint(0, n_rows, (M,), generator=g, dtype=torch.int64)
+    perm, seg_start, seg_row, seg_of, nseg, err = _sort(idx.cuda(), n_rows)
+    x = idx.numpy()
+    order = np.lexsort((np.arange(M), x))           # by row id, ties in batch order
+    uniq, inverse = np.unique(x, return_inverse=True)
+    assert err == 0 and nseg == len(uniq)
+    np.testing.assert_array_equal(perm[:M], order)
+    np.testing.assert_array_equal(seg_row[:nseg], uniq)
+    np.testing.assert_array_equal(seg_of[:M], inverse)   # == torch.unique(return_inverse=True)[1]
+    starts = np.searchsorted(x[order], uniq, side="left")
+    np.testing.assert_array_equal(seg_start[:nseg], starts)
+    assert seg_start[nseg] == M
+
+
+def test_sort_flags_out_of_range():
+    idx = torch.tensor([3, 9, -1, 2], dtype=torch.int64).cuda()
+    *_, err = _sort(idx, 9)
+    assert err & 1
+
+
+@pytest.mark.parametrize("n", [1, 1000, 1 << 20])
+def test_adam_dense_matches_torch(n):
+    from fairrec import _C
+    from fairrec.optim import AdamHyper
+    torch.manual_seed(n)
+    p0 = torch.randn(n)
+    hyper = AdamHyper(lr=1e-3, weight_decay=1e-3, device="cuda")
+    p = p0.clone().cuda()
+    m = torch.zeros_like(p)
+    v = torch.zeros_like(p)
+    ref = p0.clone().requires_grad_()
+    opt = torch.optim.Adam([ref], lr=1e-3, weight_decay=1e-3)
+    for step in range(1, 6):
+        g = torch.randn(n)
+        ref.grad = g.clone()
+        opt.step()
+        gg = g.cuda()
+        _C.check(_C.lib().fr_adam_dense(p.data_ptr(), gg.data_ptr(), m.data_ptr(), v.data_ptr(), n,
+                                        ctypes.byref(hyper.c()), step, _C.current_stream()), "adam_dense")
+    np.testing.assert_allclose(p.cpu().numpy(), ref.detach().numpy(), rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(m.cpu().numpy(), opt.state[ref]["exp_avg"].numpy(), rtol=1e-5, atol=1e-9)
+    np.testing.assert_allclose(v.cpu().numpy(), opt.state[ref]["exp_avg_sq"].numpy(), rtol=1e-5, atol=1e-12)
+
+
+def test_flush_matches_dense_torch_adam_with_zero_grads():
+    """A table nobody touches still moves under coupled L2: k lazy steps == k dense torch steps."""
+    from fairrec.optim import AdamHyper, LazyTable
+    torch.manual_seed(0)
+    w0 = torch.randn(300, 64) * 0.05
+    ref = w0.clone().requires_grad_()
+    opt = torch.optim.Adam([ref], lr=1e-3, weight_decay=1e-3)
+    # give the state a non-trivial start with one real gradient step
+    g = torch.randn_like(w0) * 0.01
+    ref.grad = g.clone()
+    opt.step()
+    for _ in range(150):
+        ref.grad = torch.zeros_like(w0)
+        opt.step()
+    hyper = AdamHyper(lr=1e-3, weight_decay=1e-3, device="cuda")
+    tab = LazyTable(w0.clone().cuda())
+    tab.ensure_state()
+    from fairrec import _C
+    gg = g.cuda()
+    _C.check(_C.lib().fr_adam_dense(tab.weight.data_ptr(), gg.data_ptr(), tab.m.data_ptr(), tab.v.data_ptr(),
+                                    w0.numel(), ctypes.byref(hyper.c()), 1, _C.current_stream()), "adam_dense")
+    tab.last.fill_(1)
+    tab.step = 151
+    rows = torch.tensor([0, 5, 299, 5], device="cuda")
+    got = tab.gather(hyper, rows).cpu().numpy()         # read-only catch-up
+    np.testing.assert_allclose(got, ref.detach().numpy()[[0, 5, 299, 5]], rtol=1e-4, atol=1e-6)
+    assert int(tab.last.max()) == 1                      # gather must not modify the table
+    tab.flush(hyper)
+    np.testing.assert_allclose(tab.weight.cpu().numpy(), ref.detach().numpy(), rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(tab.m.cpu().numpy(), opt.state[ref]["exp_avg"].numpy(), rtol=1e-4, atol=1e-9)
+    assert int(tab.last.min()) == 151
