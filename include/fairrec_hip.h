@@ -79,7 +79,8 @@ typedef struct fr_table {
 typedef struct fr_adam {
     const float* scalars;  /* device, float[2*(cap+1)] */
     int32_t cap;
-    float weight_decay, beta1, beta2, eps;
+    int32_t reserved_;
+    double weight_decay, beta1, beta2, eps; /* doubles: torch derives (1 - beta) in double before the fp32 cast */
 } fr_adam;
 
 FR_API int fr_version(void);

@@ -6,6 +6,10 @@
 
 #include "fairrec_hip.h"
 
+#ifndef FR_ADAM_PRECISE
+#define FR_ADAM_PRECISE 1
+#endif
+
 namespace fr {
 
 constexpr int WAVE = 64;
@@ -61,12 +65,12 @@ inline AdamC make_adamc(const fr_adam* a) {
     AdamC c;
     c.sc = reinterpret_cast<const float2*>(a->scalars);
     c.cap = a->cap;
-    c.wd = a->weight_decay;
-    c.b1 = a->beta1;
-    c.omb1 = (float)(1.0 - (double)a->beta1);
-    c.b2 = a->beta2;
-    c.omb2 = (float)(1.0 - (double)a->beta2);
-    c.eps = a->eps;
+    c.wd = (float)a->weight_decay;
+    c.b1 = (float)a->beta1;
+    c.omb1 = (float)(1.0 - a->beta1);  // torch: lerp weight / addcmul value are Python doubles cast to fp32 once
+    c.b2 = (float)a->beta2;
+    c.omb2 = (float)(1.0 - a->beta2);
+    c.eps = (float)a->eps;
     return c;
 }
 
@@ -78,8 +82,13 @@ __device__ __forceinline__ void adam_elem(float& p, float& m, float& v, float gd
     float g = fmaf(c.wd, p, gd);
     m = fmaf(c.omb1, g - m, m);
     v = fmaf(c.omb2 * g, g, v * c.b2);
+#if FR_ADAM_PRECISE
+    float den = fmaf(__fsqrt_rn(v), ib, c.eps);
+    p = p + __fdiv_rn(-ss * m, den);
+#else
     float den = fmaf(__builtin_amdgcn_sqrtf(v), ib, c.eps);
     p = fmaf(-ss * m, __builtin_amdgcn_rcpf(den), p);
+#endif
 }
 
 __device__ __forceinline__ float2 step_scalars(const AdamC& c, int j) {

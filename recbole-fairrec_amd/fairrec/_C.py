@@ -7,7 +7,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_uint32, c_void_p
+from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_size_t, c_uint32, c_void_p
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libfairrec_hip.so")
 
@@ -24,8 +24,8 @@ class FrTable(Structure):
 
 
 class FrAdam(Structure):
-    _fields_ = [("scalars", c_void_p), ("cap", c_int32), ("weight_decay", c_float), ("beta1", c_float),
-                ("beta2", c_float), ("eps", c_float)]
+    _fields_ = [("scalars", c_void_p), ("cap", c_int32), ("reserved_", c_int32), ("weight_decay", c_double),
+                ("beta1", c_double), ("beta2", c_double), ("eps", c_double)]
 
 
 class FairrecError(RuntimeError):

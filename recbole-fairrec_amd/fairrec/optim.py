@@ -47,7 +47,7 @@ class AdamHyper:
         self.saturated = bool(tab[2 * cap] == np.float32(self.lr) and tab[2 * cap + 1] == np.float32(1.0))
         self.host_scalars = tab
         self.scalars = torch.from_numpy(tab).to(self.device) if self.device.type == "cuda" else None
-        self._c = _C.FrAdam(_C.ptr(self.scalars), cap, self.weight_decay, self.betas[0], self.betas[1], self.eps)
+        self._c = _C.FrAdam(_C.ptr(self.scalars), cap, 0, self.weight_decay, self.betas[0], self.betas[1], self.eps)
 
     def c(self) -> "_C.FrAdam":
         return self._c

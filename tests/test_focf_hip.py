@@ -53,8 +53,10 @@ def test_training_matches_reference_golden(path, sweep):
             eng.flush()
             for tag, tab in (("U", eng.U), ("I", eng.I)):
                 _close(tab.weight.cpu().numpy(), z[f"{tag}_after{t + 1}"], f"{tag} after {t + 1}")
-                _close(tab.m.cpu().numpy(), z[f"m{tag}_after{t + 1}"], f"m{tag} after {t + 1}", atol=1e-9)
-                _close(tab.v.cpu().numpy(), z[f"v{tag}_after{t + 1}"], f"v{tag} after {t + 1}", atol=1e-12)
+                # moments: absolute floor scaled to the tensor (entries are differences of cancelling terms)
+                mref, vref = z[f"m{tag}_after{t + 1}"], z[f"v{tag}_after{t + 1}"]
+                _close(tab.m.cpu().numpy(), mref, f"m{tag} after {t + 1}", atol=1e-6 * np.abs(mref).max())
+                _close(tab.v.cpu().numpy(), vref, f"v{tag} after {t + 1}", atol=1e-6 * np.abs(vref).max())
     got = torch.stack(losses).cpu().numpy()[:, 0]
     _close(got, z["loss"], "loss curve", atol=1e-6)
     eng.check_device_errors()
