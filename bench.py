@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""bench.py -- training interactions/s of the FOCF hot path on MI355X (BASELINE.json configs[1]).
+
+One "step" = one pass of the hot path (sort -> lazy-Adam gather + dot -> fairness term -> loss ->
+backward + Adam) over one batch of B synthetic (user, item, rating, sensitive-attr) tuples that are
+already resident in HBM.  Workload: FOCF, fair_objective=value, 1 000 001 users x 100 001 items,
+embedding_size 64, B = 8192 per GPU, Adam lr 1e-3 with the reference's coupled weight_decay 1e-3
+(SURVEY.md §8-d cfg 2; uniform-random pairs = the figure of record).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "recbole-fairrec_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+N_USERS, N_ITEMS, DIM, BATCH = 1_000_001, 100_001, 64, 8192
+LR, WD, FAIR_WEIGHT, OBJECTIVE = 1e-3, 1e-3, 1.0, "value"
+# idx 8*2 + scalars 4*2 + gather 4*D*2 + Adam read m,v 8*D*2 + write p,m,v 12*D*2
+ALGO_BYTES_PER_INTERACTION = 16 + 8 + 4 * DIM * 2 + 8 * DIM * 2 + 12 * DIM * 2   # = 3096 at D = 64
+SEED = 2020
+
+
+def synth_batches(n_batches, batch, n_users, n_items, seed, item_dist="uniform"):
+    """Deterministic synthetic interactions: row 0 is [PAD] and never sampled."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    gender = (torch.rand(n_users, generator=g) < 0.5).to(torch.float32)
+    u = torch.randint(1, n_users, (n_batches, batch), generator=g, dtype=torch.int64)
+    if item_dist == "zipf":
+        x = torch.rand((n_batches, batch), generator=g)
+        i = ((n_items - 1) * x * x).floor().to(torch.int64) + 1
+    else:
+        i = torch.randint(1, n_items, (n_batches, batch), generator=g, dtype=torch.int64)
+    r = torch.randint(1, 6, (n_batches, batch), generator=g).to(torch.float32)
+    s = gender[u]
+    return u, i, r, s
+
+
+def xavier_tables(n_users, n_items, dim, seed, device):
+    g = torch.Generator(device="cpu").manual_seed(seed + 1)
+    U = torch.randn(n_users, dim, generator=g) * math.sqrt(2.0 / (n_users + dim))
+    I = torch.randn(n_items, dim, generator=g) * math.sqrt(2.0 / (n_items + dim))
+    return U.to(device), I.to(device)
+
+
+def cpu_baseline(budget_s=20.0):
+    """The reference's CPU step (oracle restatement + stock dense torch.optim.Adam) on the SAME workload,
+    timed on this host's cores on a bounded sample of steps."""
+    from oracle.focf import CpuTrainerBaseline   # checker / baseline only
+    threads = torch.get_num_threads()
+    base = CpuTrainerBaseline(N_USERS, N_ITEMS, DIM, LR, WD, FAIR_WEIGHT, OBJECTIVE, seed=SEED, threads=threads)
+    u, i, r, s = synth_batches(64, BATCH, N_USERS, N_ITEMS, SEED)
+    for k in range(2):
+        base.step(u[k], i[k], r[k], s[k])
+    t0 = time.perf_counter()
+    n = 0
+    while n < 60 and (time.perf_counter() - t0) < budget_s:
+        base.step(u[2 + n], i[2 + n], r[2 + n], s[2 + n])
+        n += 1
+    dt = time.perf_counter() - t0
+    return {"value": round(n * BATCH / dt, 1), "unit": "interactions/s", "cores": threads, "kind": "port",
+            "sample": f"{n} steps of B={BATCH} on the full {N_USERS}x{N_ITEMS}x{DIM} tables, "
+                      f"oracle FOCF step + dense torch.optim.Adam, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly instead of one hipGraph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--item-dist", default="uniform", choices=["uniform", "zipf"])
+    ap.add_argument("--sweep", type=int, default=None, help="lazy-Adam sweep period (default: auto)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    from fairrec import _C
+    from fairrec.model.fair_recommender.focf import FocfEngine
+    from fairrec.optim import FusedLazyAdam
+
+    K, W = args.steps, args.warmup
+    # every rank trains its own B-interaction stream (weak scaling); see DESIGN.md §6 for the sharded variant
+    u, i, r, s = (t.to(dev) for t in synth_batches(K + W, BATCH, N_USERS, N_ITEMS, SEED + rank, args.item_dist))
+    U, I = xavier_tables(N_USERS, N_ITEMS, DIM, SEED, dev)
+    eng = FocfEngine(U, I, OBJECTIVE, FAIR_WEIGHT, 5.0)
+    FusedLazyAdam(eng, lr=LR, weight_decay=WD, sweep_period=args.sweep)
+
+    def step(k):
+        eng.forward(u[k], i[k], r[k], s[k])
+        eng.backward_adam()
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for k in range(W):
+        step(k)
+    barrier()
+
+    graph = None
+    if not args.no_graph:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(graph, stream=side):
+                for k in range(W, W + K):
+                    step(k)
+        torch.cuda.current_stream().wait_stream(side)
+
+    barrier()
+    t0 = time.perf_counter()
+    if graph is not None:
+        graph.replay()
+    else:
+        for k in range(W, W + K):
+            step(k)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    eng.check_device_errors()
+    loss_last = float(eng.loss_ring[eng.loss_slot][0].item())
+
+    # ---- per-kernel device time: K more steps, eager, with the library's HIP-event profiler -----------
+    roofline = None
+    if rank == 0:
+        u2, i2, r2, s2 = (t.to(dev) for t in synth_batches(K, BATCH, N_USERS, N_ITEMS, SEED + 7919, args.item_dist))
+        _C.prof_reset()
+        _C.prof_enable(True)
+        for k in range(K):
+            eng.forward(u2[k], i2[k], r2[k], s2[k])
+            eng.backward_adam()
+        torch.cuda.synchronize()
+        _C.prof_enable(False)
+        prof = _C.prof_read()
+        per_kernel = {name: ms / n * 1e3 for name, (ms, n) in prof.items()}   # us per launch
+        dom = max(per_kernel, key=per_kernel.get)
+        algo_bytes = ALGO_BYTES_PER_INTERACTION * BATCH
+        achieved = algo_bytes / (per_kernel[dom] * 1e-6) / 1e9
+        traffic = None
+        pmc_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc_file):
+            traffic = json.load(open(pmc_file)).get(dom)
+        roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "algorithmic_bytes_per_launch": algo_bytes,
+                    "kernel_us": {k: round(v, 2) for k, v in sorted(per_kernel.items())},
+                    "measured": f"HIP events around every launch, {K} eager steps after the timed region"}
+
+    if rank == 0:
+        total = K * BATCH * world
+        out = {
+            "metric": "training interactions/sec + achieved HBM GB/s, FOCF emb=64 at 1/2/4/8 MI355X",
+            "value": round(total / dt, 1), "unit": "interactions/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": round(dt / K * 1e3, 5), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "FOCF fair_objective=value, 1000001 users x 100001 items, embedding_size=64, "
+                                   "B=8192 per GPU, Adam lr=1e-3 weight_decay=1e-3 (BASELINE.json configs[1])",
+                       "item_distribution": args.item_dist, "launch": "eager" if graph is None else "hipGraph",
+                       "lazy_adam_sweep_period": eng._sweep(BATCH), "final_loss": round(loss_last, 6)},
+            "roofline": roofline,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -148,6 +148,16 @@ FR_API int fr_table_gather(const fr_table* t, const fr_adam* adam, const int64_t
 FR_API int fr_adam_dense(float* p, const float* g, float* m, float* v, int64_t n, const fr_adam* adam, int32_t step,
                   void* stream);
 
+/* ---- built-in profiler -------------------------------------------------------------------------------
+ * When enabled every kernel launch of this library is bracketed by a hipEvent pair recorded on the
+ * launch stream; fr_prof_read synchronises the outstanding events and returns the accumulated device
+ * time and launch count of one kernel kind (bench.py's `roofline.achieved` comes from here). */
+FR_API int fr_prof_enable(int on);
+FR_API int fr_prof_reset(void);
+FR_API int fr_prof_kernel_count(void);
+FR_API const char* fr_prof_kernel_name(int kind);
+FR_API int fr_prof_read(int kind, double* total_ms, int64_t* count);
+
 #ifdef __cplusplus
 }
 #endif

@@ -7,7 +7,7 @@
 #include "fairrec_hip.h"
 
 #ifndef FR_ADAM_PRECISE
-#define FR_ADAM_PRECISE 1
+#define FR_ADAM_PRECISE 0
 #endif
 
 namespace fr {
@@ -119,13 +119,42 @@ __device__ __forceinline__ void store_row(const RowFrag<E>& f, float* base, int 
     }
 }
 
+__device__ __forceinline__ float lane_bcast(float x, int src_lane /*wave-uniform*/) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), src_lane));
+}
+
 // Replay the zero-data-gradient steps (from, to] on a row fragment; `from`/`to` are wave-uniform.
+// The per-step scalars are fetched 64 steps at a time (one coalesced load, lane q holds step base+q) and
+// broadcast with v_readlane, so the dependent chain of a replayed step holds no memory access.
 template <int E>
-__device__ __forceinline__ void replay(RowFrag<E>& p, RowFrag<E>& m, RowFrag<E>& v, int from, int to, const AdamC& c) {
-    for (int j = from + 1; j <= to; ++j) {
-        float2 s = step_scalars(c, j);
+__device__ __forceinline__ void replay(RowFrag<E>& p, RowFrag<E>& m, RowFrag<E>& v, int from, int to, const AdamC& c,
+                                       int lane) {
+    for (int base = from + 1; base <= to; base += 64) {
+        const float2 s = step_scalars(c, base + lane);
+        const int n = (to - base + 1) < 64 ? (to - base + 1) : 64;
+        for (int q = 0; q < n; ++q) {
+            const float ss = lane_bcast(s.x, q), ib = lane_bcast(s.y, q);
 #pragma unroll
-        for (int e = 0; e < E; ++e) adam_elem(p.x[e], m.x[e], v.x[e], 0.f, s.x, s.y, c);
+            for (int e = 0; e < E; ++e) adam_elem(p.x[e], m.x[e], v.x[e], 0.f, ss, ib, c);
+        }
+    }
+}
+
+// Same for two rows at once (independent chains interleave in the VALU).
+template <int E>
+__device__ __forceinline__ void replay2(RowFrag<E>& p0, RowFrag<E>& m0, RowFrag<E>& v0, RowFrag<E>& p1,
+                                        RowFrag<E>& m1, RowFrag<E>& v1, int from, int to, const AdamC& c, int lane) {
+    for (int base = from + 1; base <= to; base += 64) {
+        const float2 s = step_scalars(c, base + lane);
+        const int n = (to - base + 1) < 64 ? (to - base + 1) : 64;
+        for (int q = 0; q < n; ++q) {
+            const float ss = lane_bcast(s.x, q), ib = lane_bcast(s.y, q);
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                adam_elem(p0.x[e], m0.x[e], v0.x[e], 0.f, ss, ib, c);
+                adam_elem(p1.x[e], m1.x[e], v1.x[e], 0.f, ss, ib, c);
+            }
+        }
     }
 }
 

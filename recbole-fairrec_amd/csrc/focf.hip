@@ -105,23 +105,15 @@ __global__ __launch_bounds__(GATHER_THREADS) void focf_gather_kernel(
         load_row<E>(mi, I.m + (size_t)ir * D, D, lane);
         load_row<E>(vi, I.v + (size_t)ir * D, D, lane);
 
-        // replay the optimizer steps each row missed (zero data gradient, weight decay only)
+        // replay the optimizer steps each row missed (zero data gradient, weight decay only): first the
+        // steps only the staler row missed, then the common tail on both rows interleaved
         if (upto_u == upto_i) {
-            const int lo = t0u < t0i ? t0u : t0i;
-            for (int j = lo + 1; j <= upto_u; ++j) {
-                const float2 s = step_scalars(c, j);
-                if (j > t0u) {
-#pragma unroll
-                    for (int e = 0; e < E; ++e) adam_elem(pu.x[e], mu.x[e], vu.x[e], 0.f, s.x, s.y, c);
-                }
-                if (j > t0i) {
-#pragma unroll
-                    for (int e = 0; e < E; ++e) adam_elem(pi.x[e], mi.x[e], vi.x[e], 0.f, s.x, s.y, c);
-                }
-            }
+            if (t0u < t0i) replay<E>(pu, mu, vu, t0u, t0i, c, lane);
+            else if (t0i < t0u) replay<E>(pi, mi, vi, t0i, t0u, c, lane);
+            replay2<E>(pu, mu, vu, pi, mi, vi, t0u > t0i ? t0u : t0i, upto_u, c, lane);
         } else {
-            replay<E>(pu, mu, vu, t0u, upto_u, c);
-            replay<E>(pi, mi, vi, t0i, upto_i, c);
+            replay<E>(pu, mu, vu, t0u, upto_u, c, lane);
+            replay<E>(pi, mi, vi, t0i, upto_i, c, lane);
         }
 
         float dot = 0.f;
@@ -341,7 +333,7 @@ __device__ __forceinline__ void sweep_row(const TableV& T, const AdamC& c, long 
     load_row<E>(p, T.p + (size_t)row * D, D, lane);
     load_row<E>(m, T.m + (size_t)row * D, D, lane);
     load_row<E>(v, T.v + (size_t)row * D, D, lane);
-    replay<E>(p, m, v, t0, upto, c);
+    replay<E>(p, m, v, t0, upto, c, lane);
     store_row<E>(p, T.p + (size_t)row * D, D, lane);
     store_row<E>(m, T.m + (size_t)row * D, D, lane);
     store_row<E>(v, T.v + (size_t)row * D, D, lane);
@@ -406,7 +398,7 @@ __global__ __launch_bounds__(256) void table_gather_kernel(TableV T, AdamC c, co
     if (t0 < T.step) {
         load_row<E>(m, T.m + (size_t)row * D, D, lane);
         load_row<E>(v, T.v + (size_t)row * D, D, lane);
-        replay<E>(p, m, v, t0, T.step, c);
+        replay<E>(p, m, v, t0, T.step, c, lane);
     }
     store_row<E>(p, out + (size_t)j * D, D, lane);
 }
@@ -462,23 +454,47 @@ extern "C" int fr_focf_forward(const fr_table* U, const fr_table* I, const fr_ad
     SortJob ju{user, U->n_rows, w.perm_u, w.seg_start_u, w.seg_row_u, w.seg_of_u, w.nseg_u, nullptr, nullptr};
     SortJob ji{item, I->n_rows, w.perm_i, w.seg_start_i, w.seg_row_i, w.seg_of_i, w.nseg_i,
                objective == FR_FOCF_NONE ? nullptr : sst, w.sst_minmax};
-    if ((rc = launch_sort(ju, &ji, B, err_flag, stream))) return rc;
+    // The sort only reads the id columns, the gather only reads the tables: run them side by side
+    // (fork/join through events; under stream capture this becomes two parallel graph branches).
+    SideStream* ss = side_stream();
+    const bool overlap = ss != nullptr && !prof_on();
+    if (overlap) {
+        FR_CHECK_HIP(hipEventRecord(ss->fork, stream));
+        FR_CHECK_HIP(hipStreamWaitEvent(ss->stream, ss->fork, 0));
+        if ((rc = launch_sort(ju, &ji, B, err_flag, ss->stream))) return rc;
+        FR_CHECK_HIP(hipEventRecord(ss->join, ss->stream));
+    } else if ((rc = launch_sort(ju, &ji, B, err_flag, stream))) {
+        return rc;
+    }
 
     const AdamC c = make_adamc(adam);
     const TableV Uv = view(U), Iv = view(I);
-    FR_DISPATCH_E(U->dim, focf_gather_kernel<E, true><<<dim3(w.n_gather_blocks), dim3(GATHER_THREADS), 0, stream>>>(Uv, Iv, c, user, item, rating, (int)B, U->step - 1, I->step - 1, w, 0.f, (float*)nullptr, err_flag));
+    {
+        ProfScope prof(K_FOCF_GATHER, stream);
+        FR_DISPATCH_E(U->dim, focf_gather_kernel<E, true><<<dim3(w.n_gather_blocks), dim3(GATHER_THREADS), 0, stream>>>(Uv, Iv, c, user, item, rating, (int)B, U->step - 1, I->step - 1, w, 0.f, (float*)nullptr, err_flag));
+    }
     FR_CHECK_LAUNCH();
+    if (overlap) FR_CHECK_HIP(hipStreamWaitEvent(stream, ss->join, 0));
     if (objective == FR_FOCF_NONPARITY) {
-        hipLaunchKernelGGL(focf_nonparity_kernel, dim3(1), dim3(1024), 0, stream, w, sst, (int)B, fair_weight,
-                           err_flag);
+        {
+            ProfScope prof(K_FOCF_NONPARITY, stream);
+            hipLaunchKernelGGL(focf_nonparity_kernel, dim3(1), dim3(1024), 0, stream, w, sst, (int)B, fair_weight,
+                               err_flag);
+        }
         FR_CHECK_LAUNCH();
     } else if (objective != FR_FOCF_NONE) {
-        hipLaunchKernelGGL(focf_fair_kernel, dim3(w.n_fair_blocks), dim3(FAIR_THREADS), 0, stream, w, rating, sst,
-                           (int)B, objective, fair_weight, err_flag);
+        {
+            ProfScope prof(K_FOCF_FAIR, stream);
+            hipLaunchKernelGGL(focf_fair_kernel, dim3(w.n_fair_blocks), dim3(FAIR_THREADS), 0, stream, w, rating, sst,
+                               (int)B, objective, fair_weight, err_flag);
+        }
         FR_CHECK_LAUNCH();
     }
-    hipLaunchKernelGGL(focf_finalize_kernel, dim3(1), dim3(256), 0, stream, w, (int)B, objective, fair_weight,
-                       loss_out);
+    {
+        ProfScope prof(K_FOCF_FINALIZE, stream);
+        hipLaunchKernelGGL(focf_finalize_kernel, dim3(1), dim3(256), 0, stream, w, (int)B, objective, fair_weight,
+                           loss_out);
+    }
     FR_CHECK_LAUNCH();
     if (pred_out) FR_CHECK_HIP(hipMemcpyAsync(pred_out, w.pred, (size_t)B * 4, hipMemcpyDeviceToDevice, stream));
     return FR_OK;
@@ -500,7 +516,10 @@ extern "C" int fr_focf_backward_adam(const fr_table* U, const fr_table* I, const
     const long long waves = 2 * B + (hi_u - lo_u) + (hi_i - lo_i);
     const AdamC c = make_adamc(adam);
     const TableV Uv = view(U), Iv = view(I);
-    FR_DISPATCH_E(U->dim, focf_backward_adam_kernel<E><<<dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, stream>>>(Uv, Iv, c, (int)B, w, lo_u, (int)(hi_u - lo_u), lo_i, (int)(hi_i - lo_i)));
+    {
+        ProfScope prof(K_FOCF_BWD_ADAM, stream);
+        FR_DISPATCH_E(U->dim, focf_backward_adam_kernel<E><<<dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, stream>>>(Uv, Iv, c, (int)B, w, lo_u, (int)(hi_u - lo_u), lo_i, (int)(hi_i - lo_i)));
+    }
     FR_CHECK_LAUNCH();
     return FR_OK;
 }
@@ -519,8 +538,11 @@ extern "C" int fr_focf_predict(const fr_table* U, const fr_table* I, const fr_ad
     const TableV Uv = view(U), Iv = view(I);
     FocfWs w{};
     const unsigned blocks = (unsigned)((B * WAVE + GATHER_THREADS - 1) / GATHER_THREADS);
-    FR_DISPATCH_E(U->dim, focf_gather_kernel<E, false><<<dim3(blocks), dim3(GATHER_THREADS), 0, stream>>>(Uv, Iv, c, user, item, (const float*)nullptr, (int)B, U->step,
-                                              I->step, w, max_rating, out, err_flag));
+    {
+        ProfScope prof(K_FOCF_GATHER, stream);
+        FR_DISPATCH_E(U->dim, focf_gather_kernel<E, false><<<dim3(blocks), dim3(GATHER_THREADS), 0, stream>>>(Uv, Iv, c, user, item, (const float*)nullptr, (int)B, U->step,
+                                                  I->step, w, max_rating, out, err_flag));
+    }
     FR_CHECK_LAUNCH();
     return FR_OK;
 }
@@ -533,7 +555,10 @@ extern "C" int fr_table_flush(const fr_table* t, const fr_adam* adam, void* stre
     const TableV Tv = view(t);
     long long blocks = (t->n_rows + 3) / 4;
     if (blocks > 256 * 32) blocks = 256 * 32;
-    FR_DISPATCH_E(t->dim, table_flush_kernel<E><<<dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream_>>>(Tv, c));
+    {
+        ProfScope prof(K_TABLE_FLUSH, (hipStream_t)stream_);
+        FR_DISPATCH_E(t->dim, table_flush_kernel<E><<<dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream_>>>(Tv, c));
+    }
     FR_CHECK_LAUNCH();
     return FR_OK;
 }
@@ -546,7 +571,10 @@ extern "C" int fr_table_gather(const fr_table* t, const fr_adam* adam, const int
     if (M == 0) return FR_OK;
     const AdamC c = make_adamc(adam);
     const TableV Tv = view(t);
-    FR_DISPATCH_E(t->dim, table_gather_kernel<E><<<dim3((unsigned)((M + 3) / 4)), dim3(256), 0, (hipStream_t)stream_>>>(Tv, c, idx, (long long)M, out, err_flag));
+    {
+        ProfScope prof(K_TABLE_GATHER, (hipStream_t)stream_);
+        FR_DISPATCH_E(t->dim, table_gather_kernel<E><<<dim3((unsigned)((M + 3) / 4)), dim3(256), 0, (hipStream_t)stream_>>>(Tv, c, idx, (long long)M, out, err_flag));
+    }
     FR_CHECK_LAUNCH();
     return FR_OK;
 }
@@ -559,8 +587,11 @@ extern "C" int fr_adam_dense(float* p, const float* g, float* m, float* v, int64
     if (n == 0) return FR_OK;
     long long blocks = (n + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;
-    hipLaunchKernelGGL(adam_dense_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream_, p, g, m, v,
-                       (long long)n, make_adamc(adam), step);
+    {
+        ProfScope prof(K_ADAM_DENSE, (hipStream_t)stream_);
+        hipLaunchKernelGGL(adam_dense_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream_, p, g, m, v,
+                           (long long)n, make_adamc(adam), step);
+    }
     FR_CHECK_LAUNCH();
     return FR_OK;
 }

@@ -4,6 +4,31 @@
 
 namespace fr {
 
+// kernel kinds known to the built-in HIP-event profiler (fr_prof_*)
+enum KernelKind {
+    K_SORT = 0, K_FOCF_GATHER, K_FOCF_FAIR, K_FOCF_NONPARITY, K_FOCF_FINALIZE, K_FOCF_BWD_ADAM, K_TABLE_FLUSH,
+    K_TABLE_GATHER, K_ADAM_DENSE, K_COUNT
+};
+bool prof_on();
+void* prof_begin(int kind, hipStream_t s);
+void prof_end(void* h, hipStream_t s);
+
+// Brackets one kernel launch with profiler events (no-ops unless fr_prof_enable(1)).
+struct ProfScope {
+    void* h;
+    hipStream_t s;
+    ProfScope(int kind, hipStream_t st) : h(prof_on() ? prof_begin(kind, st) : nullptr), s(st) {}
+    ~ProfScope() { prof_end(h, s); }
+};
+
+// A helper stream + fork/join events owned by the library (created on first use, one per process = one per GPU).
+// nullptr when disabled with FAIRREC_NO_OVERLAP=1.
+struct SideStream {
+    hipStream_t stream;
+    hipEvent_t fork, join;
+};
+SideStream* side_stream();
+
 struct SortJob {
     const int64_t* idx;
     int64_t n_rows;

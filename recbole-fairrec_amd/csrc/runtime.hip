@@ -1,0 +1,132 @@
+// Error string plumbing, version, and the optional per-kernel HIP-event profiler of libfairrec_hip.so.
+#include <stdarg.h>
+#include <stdlib.h>
+
+#include <mutex>
+#include <vector>
+
+#include "common.hpp"
+#include "kernels.hpp"
+
+namespace fr {
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+// ---- profiler: hipEvent pairs recorded on the launch stream around each kernel --------------------
+static const char* const kKernelNames[K_COUNT] = {
+    "sort_segments_kernel", "focf_gather_kernel",     "focf_fair_kernel",    "focf_nonparity_kernel",
+    "focf_finalize_kernel", "focf_backward_adam_kernel", "table_flush_kernel", "table_gather_kernel",
+    "adam_dense_kernel"};
+
+struct ProfState {
+    bool on = false;
+    std::mutex mu;
+    std::vector<hipEvent_t> pool;
+    struct Pair {
+        hipEvent_t a, b;
+        int kind;
+    };
+    std::vector<Pair> open;
+    double total_ms[K_COUNT] = {0};
+    long long count[K_COUNT] = {0};
+};
+static ProfState g_prof;
+
+bool prof_on() { return g_prof.on; }
+
+static hipEvent_t take_event() {
+    if (!g_prof.pool.empty()) {
+        hipEvent_t e = g_prof.pool.back();
+        g_prof.pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+void* prof_begin(int kind, hipStream_t s) {
+    if (!g_prof.on) return nullptr;
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    ProfState::Pair p{take_event(), take_event(), kind};
+    (void)hipEventRecord(p.a, s);
+    g_prof.open.push_back(p);
+    return (void*)(uintptr_t)g_prof.open.size();  // 1-based handle
+}
+
+void prof_end(void* h, hipStream_t s) {
+    if (!h) return;
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    size_t i = (size_t)(uintptr_t)h - 1;
+    if (i < g_prof.open.size()) (void)hipEventRecord(g_prof.open[i].b, s);
+}
+
+static void prof_drain() {
+    for (auto& p : g_prof.open) {
+        float ms = 0.f;
+        if (hipEventSynchronize(p.b) == hipSuccess && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+            g_prof.total_ms[p.kind] += ms;
+            g_prof.count[p.kind] += 1;
+        }
+        g_prof.pool.push_back(p.a);
+        g_prof.pool.push_back(p.b);
+    }
+    g_prof.open.clear();
+}
+
+SideStream* side_stream() {
+    static SideStream ss;
+    static int state = 0;  // 0 = not tried, 1 = ready, -1 = disabled / failed
+    if (state == 0) {
+        const char* off = getenv("FAIRREC_NO_OVERLAP");
+        state = -1;
+        if (!(off && off[0] == '1') &&
+            hipStreamCreateWithFlags(&ss.stream, hipStreamNonBlocking) == hipSuccess &&
+            hipEventCreateWithFlags(&ss.fork, hipEventDisableTiming) == hipSuccess &&
+            hipEventCreateWithFlags(&ss.join, hipEventDisableTiming) == hipSuccess)
+            state = 1;
+    }
+    return state == 1 ? &ss : nullptr;
+}
+}  // namespace fr
+
+using namespace fr;
+
+extern "C" int fr_version(void) { return 1; }
+extern "C" const char* fr_last_error(void) { return g_err; }
+
+extern "C" int fr_prof_enable(int on) {
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    if (!on) prof_drain();
+    g_prof.on = on != 0;
+    return FR_OK;
+}
+
+extern "C" int fr_prof_reset(void) {
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    prof_drain();
+    for (int k = 0; k < K_COUNT; ++k) {
+        g_prof.total_ms[k] = 0;
+        g_prof.count[k] = 0;
+    }
+    return FR_OK;
+}
+
+extern "C" int fr_prof_kernel_count(void) { return K_COUNT; }
+
+extern "C" const char* fr_prof_kernel_name(int kind) { return kind >= 0 && kind < K_COUNT ? kKernelNames[kind] : ""; }
+
+extern "C" int fr_prof_read(int kind, double* total_ms, int64_t* count) {
+    FR_CHECK_ARG(kind >= 0 && kind < K_COUNT && total_ms && count, "fr_prof_read: bad argument");
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    prof_drain();
+    *total_ms = g_prof.total_ms[kind];
+    *count = g_prof.count[kind];
+    return FR_OK;
+}

@@ -5,13 +5,20 @@
 // segments so that duplicate rows are reduced in ascending batch order (the order the reference's
 // CPU index_put_/embedding backward accumulates in) -- deterministic, no atomics.
 //
-// Keys are (row id << 32 | batch position), so the bitonic network needs no stability.
+// Keys are (row id << 32 | batch position); the sort is a stable LSD radix sort on the row-id bits.
 #include "common.hpp"
 #include "kernels.hpp"
 
 namespace fr {
 
 static constexpr int SORT_THREADS = 1024;
+
+#ifdef FR_SORT_STAMPS   // diagnostic build only: phase time stamps of block 0 / thread 0
+__device__ unsigned long long g_sort_stamps[16];
+#define SORT_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_sort_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define SORT_STAMP(i) do {} while (0)
+#endif
 
 __device__ __forceinline__ int block_exclusive_scan_1024(int x, int* scratch /*>=17 ints*/, int& total) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -39,15 +46,23 @@ __device__ __forceinline__ int block_exclusive_scan_1024(int x, int* scratch /*>
     return scratch[wid] + inc - x;
 }
 
-__global__ __launch_bounds__(SORT_THREADS) void sort_segments_kernel(SortJob job0, SortJob job1, int M, int P,
+// Stable LSD radix sort of the row ids (8 bits per pass) with wave-level multisplit ranking:
+// wave w owns the contiguous chunk [w*P/16, (w+1)*P/16) and walks it 64 keys at a time, so
+// (wave, round, lane) order == batch order and ties keep ascending batch position.
+template <int KPT>
+__global__ __launch_bounds__(SORT_THREADS) void sort_segments_kernel(SortJob job0, SortJob job1, int M, int npass,
                                                                      uint32_t* err) {
+    constexpr int P = KPT * SORT_THREADS;
     extern __shared__ __align__(16) unsigned char smem[];
-    unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);
-    int* scratch = reinterpret_cast<int*>(smem + (size_t)P * 8);
-    float* fscratch = reinterpret_cast<float*>(scratch + 32);
+    unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);   // [P]
+    int* hist = reinterpret_cast<int*>(smem + (size_t)P * 8);                 // [256][16] digit-major
+    int* scratch = hist + 256 * 16;                                           // [32]
+    float* fscratch = reinterpret_cast<float*>(scratch + 32);                 // [32]
 
+    SORT_STAMP(0);
     const SortJob job = blockIdx.x == 0 ? job0 : job1;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
 
     bool bad = false;
     for (int j = tid; j < P; j += SORT_THREADS) {
@@ -78,9 +93,9 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_segments_kernel(SortJob job
             lo = fminf(lo, __shfl_xor(lo, o, 64));
             hi = fmaxf(hi, __shfl_xor(hi, o, 64));
         }
-        if ((tid & 63) == 0) {
-            fscratch[tid >> 6] = lo;
-            fscratch[16 + (tid >> 6)] = hi;
+        if (lane == 0) {
+            fscratch[wid] = lo;
+            fscratch[16 + wid] = hi;
         }
     }
     __syncthreads();
@@ -94,27 +109,63 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_segments_kernel(SortJob job
         job.aux_minmax[1] = hi;
     }
 
-    // bitonic sort, ascending
-    for (int k = 2; k <= P; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = tid; i < (P >> 1); i += SORT_THREADS) {
-                int a = ((i & ~(j - 1)) << 1) | (i & (j - 1));
-                int b = a + j;
-                unsigned long long ka = keys[a], kb = keys[b];
-                bool up = (a & k) == 0;
-                if ((ka > kb) == up) {
-                    keys[a] = kb;
-                    keys[b] = ka;
-                }
+    SORT_STAMP(1);
+    const int chunk = wid * (P / 16);
+    for (int pass = 0; pass < npass; ++pass) {
+        const int shift = 32 + 8 * pass;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) hist[tid * 4 + q] = 0;
+        __syncthreads();
+        unsigned long long key[KPT];
+        int lrank[KPT], slot[KPT];
+#pragma unroll
+        for (int r = 0; r < KPT; ++r) {
+            const unsigned long long k = keys[chunk + r * 64 + lane];
+            const int d = (int)(k >> shift) & 255;
+            unsigned long long peers = ~0ull;
+#pragma unroll
+            for (int bit = 0; bit < 8; ++bit) {
+                const bool on = (d >> bit) & 1;
+                const unsigned long long bal = __ballot(on);
+                peers &= on ? bal : ~bal;
             }
-            __syncthreads();
+            const int rank = __popcll(peers & lt_mask);
+            const int cnt = __popcll(peers);
+            const int leader = __ffsll((long long)peers) - 1;
+            int old = 0;
+            if (lane == leader) {
+                old = hist[d * 16 + wid];
+                hist[d * 16 + wid] = old + cnt;
+            }
+            old = __shfl(old, leader, 64);
+            key[r] = k;
+            lrank[r] = old + rank;
+            slot[r] = d * 16 + wid;
         }
+        SORT_STAMP(2 + 3 * pass);
+        __syncthreads();
+        {   // exclusive scan of the 4096 (digit, wave) counters in memory order
+            const int h0 = hist[tid * 4], h1 = hist[tid * 4 + 1], h2 = hist[tid * 4 + 2], h3 = hist[tid * 4 + 3];
+            int total;
+            const int ex = block_exclusive_scan_1024(h0 + h1 + h2 + h3, scratch, total);
+            hist[tid * 4] = ex;
+            hist[tid * 4 + 1] = ex + h0;
+            hist[tid * 4 + 2] = ex + h0 + h1;
+            hist[tid * 4 + 3] = ex + h0 + h1 + h2;
+        }
+        SORT_STAMP(3 + 3 * pass);
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < KPT; ++r) keys[hist[slot[r]] + lrank[r]] = key[r];
+        __syncthreads();
+        SORT_STAMP(4 + 3 * pass);
     }
 
     // segment heads + exclusive scan
-    const int C = P / SORT_THREADS;
+    constexpr int C = KPT;
     const int base = tid * C;
     int heads = 0;
+#pragma unroll
     for (int q = 0; q < C; ++q) {
         int j = base + q;
         if (j < M) {
@@ -122,8 +173,11 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_segments_kernel(SortJob job
             heads += (j == 0 || (unsigned)(keys[j - 1] >> 32) != r) ? 1 : 0;
         }
     }
+    SORT_STAMP(12);
     int total;
-    int seg = block_exclusive_scan_1024(heads, scratch, total) - 1;  // index of the segment open at `base`
+    int seg = block_exclusive_scan_1024(heads, scratch, total) - 1;
+    SORT_STAMP(13);  // index of the segment open at `base`
+#pragma unroll
     for (int q = 0; q < C; ++q) {
         int j = base + q;
         if (j < M) {
@@ -144,28 +198,37 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_segments_kernel(SortJob job
         job.seg_start[total] = M;
         job.n_seg[0] = total;
     }
+    SORT_STAMP(14);
 }
 
-int sort_pow2(int64_t M) {
-    int P = 2 * SORT_THREADS;
-    while (P < M) P <<= 1;
-    return P;
+template <int KPT>
+static int launch_sort_kpt(const SortJob& a, const SortJob* b, int M, int npass, uint32_t* err, hipStream_t stream) {
+    const size_t lds = (size_t)KPT * SORT_THREADS * 8 + (256 * 16 + 64) * sizeof(int);
+    static bool attr_set = false;
+    if (!attr_set) {
+        FR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sort_segments_kernel<KPT>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    ProfScope prof(K_SORT, stream);
+    hipLaunchKernelGGL(sort_segments_kernel<KPT>, dim3(b ? 2 : 1), dim3(SORT_THREADS), lds, stream, a, b ? *b : a, M,
+                       npass, err);
+    FR_CHECK_LAUNCH();
+    return FR_OK;
 }
 
 int launch_sort(const SortJob& a, const SortJob* b, int64_t M, uint32_t* err, hipStream_t stream) {
     FR_CHECK_ARG(M >= 0 && M <= FR_SORT_MAX, "sort: M=%lld exceeds FR_SORT_MAX=%d", (long long)M, FR_SORT_MAX);
-    const int P = sort_pow2(M);
-    const size_t lds = (size_t)P * 8 + 64 * sizeof(int);
-    static bool attr_set = false;
-    if (!attr_set) {
-        FR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sort_segments_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(sort_segments_kernel, dim3(b ? 2 : 1), dim3(SORT_THREADS), lds, stream, a, b ? *b : a, (int)M,
-                       P, err);
-    FR_CHECK_LAUNCH();
-    return FR_OK;
+    long long nmax = a.n_rows;
+    if (b && b->n_rows > nmax) nmax = b->n_rows;
+    int bits = 1;
+    while (bits < 32 && (1ll << bits) < nmax) ++bits;
+    const int npass = (bits + 7) / 8;   // 8 bits of the row id per LSD pass
+    if (M <= 1 * SORT_THREADS) return launch_sort_kpt<1>(a, b, (int)M, npass, err, stream);
+    if (M <= 2 * SORT_THREADS) return launch_sort_kpt<2>(a, b, (int)M, npass, err, stream);
+    if (M <= 4 * SORT_THREADS) return launch_sort_kpt<4>(a, b, (int)M, npass, err, stream);
+    if (M <= 8 * SORT_THREADS) return launch_sort_kpt<8>(a, b, (int)M, npass, err, stream);
+    return launch_sort_kpt<16>(a, b, (int)M, npass, err, stream);
 }
 
 }  // namespace fr

@@ -49,6 +49,11 @@ _PROTOS = {
     "fr_table_flush": (c_int, [POINTER(FrTable), POINTER(FrAdam), c_void_p]),
     "fr_table_gather": (c_int, [POINTER(FrTable), POINTER(FrAdam), c_void_p, c_int64, c_void_p, c_void_p,
                                 c_void_p]),
+    "fr_prof_enable": (c_int, [c_int]),
+    "fr_prof_reset": (c_int, []),
+    "fr_prof_kernel_count": (c_int, []),
+    "fr_prof_kernel_name": (c_char_p, [c_int]),
+    "fr_prof_read": (c_int, [c_int, POINTER(c_double), POINTER(c_int64)]),
     "fr_adam_dense": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, POINTER(FrAdam), c_int32,
                               c_void_p]),
 }
@@ -91,3 +96,22 @@ def ptr(t) -> int:
 def current_stream() -> int:
     import torch
     return torch.cuda.current_stream().cuda_stream
+
+
+def prof_enable(on: bool):
+    check(lib().fr_prof_enable(1 if on else 0), "fr_prof_enable")
+
+
+def prof_reset():
+    check(lib().fr_prof_reset(), "fr_prof_reset")
+
+
+def prof_read():
+    """{kernel name: (total device ms, launches)} from the library's HIP-event profiler."""
+    out = {}
+    for k in range(lib().fr_prof_kernel_count()):
+        ms, n = c_double(0), c_int64(0)
+        check(lib().fr_prof_read(k, ctypes.byref(ms), ctypes.byref(n)), "fr_prof_read")
+        if n.value:
+            out[lib().fr_prof_kernel_name(k).decode()] = (ms.value, n.value)
+    return out
