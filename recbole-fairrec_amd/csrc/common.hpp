@@ -59,6 +59,7 @@ struct AdamC {
     const float2* sc;  // per-step (step_size, 1/sqrt(bias_correction2)); entry 0 unused
     int cap;
     float wd, b1, omb1, b2, omb2, eps;
+    float k1, k2;  // (1-beta1)*wd and (1-beta2)*wd^2: a replayed step's gradient is wd*p
 };
 
 inline AdamC make_adamc(const fr_adam* a) {
@@ -71,6 +72,8 @@ inline AdamC make_adamc(const fr_adam* a) {
     c.b2 = (float)a->beta2;
     c.omb2 = (float)(1.0 - a->beta2);
     c.eps = (float)a->eps;
+    c.k1 = (float)((1.0 - a->beta1) * a->weight_decay);
+    c.k2 = (float)((1.0 - a->beta2) * a->weight_decay * a->weight_decay);
     return c;
 }
 
@@ -91,8 +94,29 @@ __device__ __forceinline__ void adam_elem(float& p, float& m, float& v, float gd
 #endif
 }
 
+// A replayed step: the data gradient is zero, so g = wd*p and
+//   m <- beta1*m + (1-beta1)*wd*p ;  v <- beta2*v + (1-beta2)*wd^2*p^2   (8 VALU + sqrt + rcp per element).
+__device__ __forceinline__ void adam_zero(float& p, float& m, float& v, float ss, float ib, const AdamC& c) {
+    m = fmaf(c.k1, p, c.b1 * m);
+    v = fmaf(c.k2 * p, p, c.b2 * v);
+#if FR_ADAM_PRECISE
+    float den = fmaf(__fsqrt_rn(v), ib, c.eps);
+    p = p + __fdiv_rn(-ss * m, den);
+#else
+    float den = fmaf(__builtin_amdgcn_sqrtf(v), ib, c.eps);
+    p = fmaf(-ss * m, __builtin_amdgcn_rcpf(den), p);
+#endif
+}
+
+// The per-step scalar table is written by the host before any launch and never changes while kernels
+// run: read it through the constant address space so that a wave-uniform index becomes an s_load
+// (scalar cache, no VALU/VMEM work in the replay loop).
+typedef const float __attribute__((address_space(4))) * ConstFPtr;
+
 __device__ __forceinline__ float2 step_scalars(const AdamC& c, int j) {
-    return c.sc[j < c.cap ? j : c.cap];
+    ConstFPtr sc = (ConstFPtr)c.sc;
+    const int k = 2 * (j < c.cap ? j : c.cap);
+    return make_float2(sc[k], sc[k + 1]);
 }
 
 // A row (or the part of it one lane owns): element e of lane l is column l + 64*e.
@@ -119,43 +143,61 @@ __device__ __forceinline__ void store_row(const RowFrag<E>& f, float* base, int 
     }
 }
 
-__device__ __forceinline__ float lane_bcast(float x, int src_lane /*wave-uniform*/) {
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), src_lane));
-}
-
-// Replay the zero-data-gradient steps (from, to] on a row fragment; `from`/`to` are wave-uniform.
-// The per-step scalars are fetched 64 steps at a time (one coalesced load, lane q holds step base+q) and
-// broadcast with v_readlane, so the dependent chain of a replayed step holds no memory access.
-template <int E>
-__device__ __forceinline__ void replay(RowFrag<E>& p, RowFrag<E>& m, RowFrag<E>& v, int from, int to, const AdamC& c,
-                                       int lane) {
-    for (int base = from + 1; base <= to; base += 64) {
-        const float2 s = step_scalars(c, base + lane);
-        const int n = (to - base + 1) < 64 ? (to - base + 1) : 64;
-        for (int q = 0; q < n; ++q) {
-            const float ss = lane_bcast(s.x, q), ib = lane_bcast(s.y, q);
+// Replay the zero-data-gradient steps (from, to] on NR row fragments at once (independent chains
+// interleave in the VALU).  `from`/`to` are wave-uniform; scalars of the next 4 steps are fetched
+// (s_load) while the current 4 are applied.
+template <int E, int NR>
+__device__ __forceinline__ void replay_n(RowFrag<E>* (&p)[NR], RowFrag<E>* (&m)[NR], RowFrag<E>* (&v)[NR], int from,
+                                         int to, const AdamC& c) {
+    int j = from + 1;
+    if (j > to) return;
+    float2 cur[4];
 #pragma unroll
-            for (int e = 0; e < E; ++e) adam_elem(p.x[e], m.x[e], v.x[e], 0.f, ss, ib, c);
+    for (int q = 0; q < 4; ++q) cur[q] = step_scalars(c, j + q);
+    for (; j + 3 <= to; j += 4) {
+        float2 nxt[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) nxt[q] = step_scalars(c, j + 4 + q);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+#pragma unroll
+                for (int e = 0; e < E; ++e) adam_zero(p[r]->x[e], m[r]->x[e], v[r]->x[e], cur[q].x, cur[q].y, c);
+            }
         }
-    }
-}
-
-// Same for two rows at once (independent chains interleave in the VALU).
-template <int E>
-__device__ __forceinline__ void replay2(RowFrag<E>& p0, RowFrag<E>& m0, RowFrag<E>& v0, RowFrag<E>& p1,
-                                        RowFrag<E>& m1, RowFrag<E>& v1, int from, int to, const AdamC& c, int lane) {
-    for (int base = from + 1; base <= to; base += 64) {
-        const float2 s = step_scalars(c, base + lane);
-        const int n = (to - base + 1) < 64 ? (to - base + 1) : 64;
-        for (int q = 0; q < n; ++q) {
-            const float ss = lane_bcast(s.x, q), ib = lane_bcast(s.y, q);
 #pragma unroll
-            for (int e = 0; e < E; ++e) {
-                adam_elem(p0.x[e], m0.x[e], v0.x[e], 0.f, ss, ib, c);
-                adam_elem(p1.x[e], m1.x[e], v1.x[e], 0.f, ss, ib, c);
+        for (int q = 0; q < 4; ++q) cur[q] = nxt[q];
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        if (j + q <= to) {
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+#pragma unroll
+                for (int e = 0; e < E; ++e) adam_zero(p[r]->x[e], m[r]->x[e], v[r]->x[e], cur[q].x, cur[q].y, c);
             }
         }
     }
+}
+
+template <int E>
+__device__ __forceinline__ void replay(RowFrag<E>& p, RowFrag<E>& m, RowFrag<E>& v, int from, int to, const AdamC& c,
+                                       int /*lane*/) {
+    RowFrag<E>* pp[1] = {&p};
+    RowFrag<E>* mm[1] = {&m};
+    RowFrag<E>* vv[1] = {&v};
+    replay_n<E, 1>(pp, mm, vv, from, to, c);
+}
+
+template <int E>
+__device__ __forceinline__ void replay2(RowFrag<E>& p0, RowFrag<E>& m0, RowFrag<E>& v0, RowFrag<E>& p1,
+                                        RowFrag<E>& m1, RowFrag<E>& v1, int from, int to, const AdamC& c,
+                                        int /*lane*/) {
+    RowFrag<E>* pp[2] = {&p0, &p1};
+    RowFrag<E>* mm[2] = {&m0, &m1};
+    RowFrag<E>* vv[2] = {&v0, &v1};
+    replay_n<E, 2>(pp, mm, vv, from, to, c);
 }
 
 }  // namespace fr

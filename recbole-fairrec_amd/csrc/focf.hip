@@ -451,8 +451,8 @@ extern "C" int fr_focf_forward(const fr_table* U, const fr_table* I, const fr_ad
     FocfWs w = focf_layout(ws, B, U->dim);
     FR_CHECK_ARG(ws_bytes >= w.bytes, "fr_focf_forward: workspace %zu < %zu bytes", ws_bytes, w.bytes);
 
-    SortJob ju{user, U->n_rows, w.perm_u, w.seg_start_u, w.seg_row_u, w.seg_of_u, w.nseg_u, nullptr, nullptr};
-    SortJob ji{item, I->n_rows, w.perm_i, w.seg_start_i, w.seg_row_i, w.seg_of_i, w.nseg_i,
+    SortJob ju{user, U->n_rows, w.perm_u, w.seg_start_u, w.seg_row_u, nullptr, w.nseg_u, nullptr, nullptr};
+    SortJob ji{item, I->n_rows, w.perm_i, w.seg_start_i, w.seg_row_i, nullptr, w.nseg_i,
                objective == FR_FOCF_NONE ? nullptr : sst, w.sst_minmax};
     // The sort only reads the id columns, the gather only reads the tables: run them side by side
     // (fork/join through events; under stream capture this becomes two parallel graph branches).

@@ -13,6 +13,9 @@ namespace fr {
 
 static constexpr int SORT_THREADS = 1024;
 
+// 8-bit digits; 7 bits when 16K 64-bit keys leave less LDS for the per-wave tables
+__host__ __device__ constexpr int sort_digit_bits(int kpt) { return kpt >= 16 ? 7 : 8; }
+
 #ifdef FR_SORT_STAMPS   // diagnostic build only: phase time stamps of block 0 / thread 0
 __device__ unsigned long long g_sort_stamps[16];
 #define SORT_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_sort_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -46,18 +49,24 @@ __device__ __forceinline__ int block_exclusive_scan_1024(int x, int* scratch /*>
     return scratch[wid] + inc - x;
 }
 
-// Stable LSD radix sort of the row ids (8 bits per pass) with wave-level multisplit ranking:
+// Stable LSD radix sort of the row ids (DB bits per pass) with wave-level multisplit ranking:
 // wave w owns the contiguous chunk [w*P/16, (w+1)*P/16) and walks it 64 keys at a time, so
 // (wave, round, lane) order == batch order and ties keep ascending batch position.
+// The lanes of a round that share a digit find each other through a 64-bit lane mask OR-ed into LDS
+// (order-independent, hence deterministic): rank = popcount(mask & lower lanes).
 template <int KPT>
 __global__ __launch_bounds__(SORT_THREADS) void sort_segments_kernel(SortJob job0, SortJob job1, int M, int npass,
                                                                      uint32_t* err) {
     constexpr int P = KPT * SORT_THREADS;
+    constexpr int DB = sort_digit_bits(KPT);
+    constexpr int NB = 1 << DB;                    // bins per pass
+    constexpr int HPT = 16 * NB / SORT_THREADS;    // (wave, digit) counters per thread in the scan
     extern __shared__ __align__(16) unsigned char smem[];
-    unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);   // [P]
-    int* hist = reinterpret_cast<int*>(smem + (size_t)P * 8);                 // [256][16] digit-major
-    int* scratch = hist + 256 * 16;                                           // [32]
-    float* fscratch = reinterpret_cast<float*>(scratch + 32);                 // [32]
+    unsigned long long* keys = reinterpret_cast<unsigned long long*>(smem);          // [P]
+    unsigned long long* masks = keys + P;                                           // [16 waves][NB]
+    int* hist = reinterpret_cast<int*>(masks + 16 * NB);                            // [16 waves][NB]
+    int* scratch = hist + 16 * NB;                                                  // [32]
+    float* fscratch = reinterpret_cast<float*>(scratch + 32);                       // [32]
 
     SORT_STAMP(0);
     const SortJob job = blockIdx.x == 0 ? job0 : job1;
@@ -78,6 +87,7 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_segments_kernel(SortJob job
         keys[j] = k;
     }
     if (bad && err) atomicOr(err, FR_DEV_ERR_INDEX_RANGE);
+    for (int j = tid; j < 16 * NB; j += SORT_THREADS) masks[j] = 0ull;
 
     // optional min/max of a float column (the sensitive attribute): the group of a row is its rank
     // among the values present in the batch (focf.py:77)
@@ -111,52 +121,59 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_segments_kernel(SortJob job
 
     SORT_STAMP(1);
     const int chunk = wid * (P / 16);
+    unsigned long long* mymask = masks + wid * NB;
+    int* myhist = hist + wid * NB;
     for (int pass = 0; pass < npass; ++pass) {
-        const int shift = 32 + 8 * pass;
+        const int shift = 32 + DB * pass;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) hist[tid * 4 + q] = 0;
+        for (int q = 0; q < HPT; ++q) hist[tid * HPT + q] = 0;
         __syncthreads();
         unsigned long long key[KPT];
-        int lrank[KPT], slot[KPT];
+        int lrank[KPT], dig[KPT];
 #pragma unroll
         for (int r = 0; r < KPT; ++r) {
             const unsigned long long k = keys[chunk + r * 64 + lane];
-            const int d = (int)(k >> shift) & 255;
-            unsigned long long peers = ~0ull;
-#pragma unroll
-            for (int bit = 0; bit < 8; ++bit) {
-                const bool on = (d >> bit) & 1;
-                const unsigned long long bal = __ballot(on);
-                peers &= on ? bal : ~bal;
-            }
+            const int d = (int)(k >> shift) & (NB - 1);
+            __hip_atomic_fetch_or(&mymask[d], 1ull << lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const unsigned long long peers = *(volatile unsigned long long*)&mymask[d];
             const int rank = __popcll(peers & lt_mask);
-            const int cnt = __popcll(peers);
             const int leader = __ffsll((long long)peers) - 1;
             int old = 0;
             if (lane == leader) {
-                old = hist[d * 16 + wid];
-                hist[d * 16 + wid] = old + cnt;
+                old = myhist[d];
+                myhist[d] = old + __popcll(peers);
+                *(volatile unsigned long long*)&mymask[d] = 0ull;   // every peer has read it (same wave, in order)
             }
             old = __shfl(old, leader, 64);
             key[r] = k;
             lrank[r] = old + rank;
-            slot[r] = d * 16 + wid;
+            dig[r] = d;
         }
         SORT_STAMP(2 + 3 * pass);
         __syncthreads();
-        {   // exclusive scan of the 4096 (digit, wave) counters in memory order
-            const int h0 = hist[tid * 4], h1 = hist[tid * 4 + 1], h2 = hist[tid * 4 + 2], h3 = hist[tid * 4 + 3];
+        {   // exclusive scan of the 16*NB counters in (digit, wave) order
+            // thread t owns digit t / (16 / HPT), waves HPT*(t % (16 / HPT)) .. +HPT-1
+            constexpr int TPD = 16 / HPT;   // threads per digit
+            const int d = tid / TPD, w0 = (tid % TPD) * HPT;
+            int* hp = hist + w0 * NB + d;
+            int h[HPT], sum = 0;
+#pragma unroll
+            for (int q = 0; q < HPT; ++q) {
+                h[q] = hp[q * NB];
+                sum += h[q];
+            }
             int total;
-            const int ex = block_exclusive_scan_1024(h0 + h1 + h2 + h3, scratch, total);
-            hist[tid * 4] = ex;
-            hist[tid * 4 + 1] = ex + h0;
-            hist[tid * 4 + 2] = ex + h0 + h1;
-            hist[tid * 4 + 3] = ex + h0 + h1 + h2;
+            int ex = block_exclusive_scan_1024(sum, scratch, total);
+#pragma unroll
+            for (int q = 0; q < HPT; ++q) {
+                hp[q * NB] = ex;
+                ex += h[q];
+            }
         }
         SORT_STAMP(3 + 3 * pass);
         __syncthreads();
 #pragma unroll
-        for (int r = 0; r < KPT; ++r) keys[hist[slot[r]] + lrank[r]] = key[r];
+        for (int r = 0; r < KPT; ++r) keys[myhist[dig[r]] + lrank[r]] = key[r];
         __syncthreads();
         SORT_STAMP(4 + 3 * pass);
     }
@@ -202,8 +219,10 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_segments_kernel(SortJob job
 }
 
 template <int KPT>
-static int launch_sort_kpt(const SortJob& a, const SortJob* b, int M, int npass, uint32_t* err, hipStream_t stream) {
-    const size_t lds = (size_t)KPT * SORT_THREADS * 8 + (256 * 16 + 64) * sizeof(int);
+static int launch_sort_kpt(const SortJob& a, const SortJob* b, int M, int bits, uint32_t* err, hipStream_t stream) {
+    const int npass = (bits + sort_digit_bits(KPT) - 1) / sort_digit_bits(KPT);
+    constexpr int NB = 1 << sort_digit_bits(KPT);
+    const size_t lds = (size_t)KPT * SORT_THREADS * 8 + (size_t)16 * NB * (8 + 4) + 64 * sizeof(int);
     static bool attr_set = false;
     if (!attr_set) {
         FR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sort_segments_kernel<KPT>),
@@ -223,12 +242,11 @@ int launch_sort(const SortJob& a, const SortJob* b, int64_t M, uint32_t* err, hi
     if (b && b->n_rows > nmax) nmax = b->n_rows;
     int bits = 1;
     while (bits < 32 && (1ll << bits) < nmax) ++bits;
-    const int npass = (bits + 7) / 8;   // 8 bits of the row id per LSD pass
-    if (M <= 1 * SORT_THREADS) return launch_sort_kpt<1>(a, b, (int)M, npass, err, stream);
-    if (M <= 2 * SORT_THREADS) return launch_sort_kpt<2>(a, b, (int)M, npass, err, stream);
-    if (M <= 4 * SORT_THREADS) return launch_sort_kpt<4>(a, b, (int)M, npass, err, stream);
-    if (M <= 8 * SORT_THREADS) return launch_sort_kpt<8>(a, b, (int)M, npass, err, stream);
-    return launch_sort_kpt<16>(a, b, (int)M, npass, err, stream);
+    if (M <= 1 * SORT_THREADS) return launch_sort_kpt<1>(a, b, (int)M, bits, err, stream);
+    if (M <= 2 * SORT_THREADS) return launch_sort_kpt<2>(a, b, (int)M, bits, err, stream);
+    if (M <= 4 * SORT_THREADS) return launch_sort_kpt<4>(a, b, (int)M, bits, err, stream);
+    if (M <= 8 * SORT_THREADS) return launch_sort_kpt<8>(a, b, (int)M, bits, err, stream);
+    return launch_sort_kpt<16>(a, b, (int)M, bits, err, stream);
 }
 
 }  // namespace fr

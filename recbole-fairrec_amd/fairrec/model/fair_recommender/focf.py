@@ -77,8 +77,8 @@ class FocfEngine:
     def _sweep(self, B: int) -> int:
         if self.sweep_period is not None:
             return int(self.sweep_period)
-        # default: sweep about B/2 rows of the larger table per step => a row is never more than S steps stale
-        return max(8, math.ceil(2 * max(self.U.n_rows, self.I.n_rows) / max(B, 1)))
+        # default: sweep about B rows of the larger table per step => a row is never more than S ~ N/B steps stale
+        return max(8, math.ceil(max(self.U.n_rows, self.I.n_rows) / max(B, 1)))
 
     def _workspace(self, B: int):
         need = _C.lib().fr_focf_workspace_bytes(B, self.U.dim)
