@@ -346,6 +346,17 @@ __global__ __launch_bounds__(256) void focf_backward_adam_kernel(TableV U, Table
                                                                  int sw_n_i) {
     const int lane = threadIdx.x & 63;
     long long wv = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    // longest jobs first: the sweeper rows carry up to S replayed steps, the segment waves exactly one
+    if (wv < sw_n_u) {
+        sweep_row<E>(U, c, sw_lo_u + wv, U.step, true, lane);
+        return;
+    }
+    wv -= sw_n_u;
+    if (wv < sw_n_i) {
+        sweep_row<E>(I, c, sw_lo_i + wv, I.step, true, lane);
+        return;
+    }
+    wv -= sw_n_i;
     if (wv < B) {
         if (wv < w.nseg_u[0])
             segment_update<E>(U, c, (int)wv, w.seg_start_u, w.seg_row_u, w.perm_u, w.coef, w.side[0], w.side[1],
@@ -353,19 +364,9 @@ __global__ __launch_bounds__(256) void focf_backward_adam_kernel(TableV U, Table
         return;
     }
     wv -= B;
-    if (wv < B) {
-        if (wv < w.nseg_i[0])
-            segment_update<E>(I, c, (int)wv, w.seg_start_i, w.seg_row_i, w.perm_i, w.coef, w.side[3], w.side[4],
-                              w.side[5], w.side[0], lane);
-        return;
-    }
-    wv -= B;
-    if (wv < sw_n_u) {
-        sweep_row<E>(U, c, sw_lo_u + wv, U.step, true, lane);
-        return;
-    }
-    wv -= sw_n_u;
-    if (wv < sw_n_i) sweep_row<E>(I, c, sw_lo_i + wv, I.step, true, lane);
+    if (wv < B && wv < w.nseg_i[0])
+        segment_update<E>(I, c, (int)wv, w.seg_start_i, w.seg_row_i, w.perm_i, w.coef, w.side[3], w.side[4],
+                          w.side[5], w.side[0], lane);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -123,30 +123,28 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_segments_kernel(SortJob job
     const int chunk = wid * (P / 16);
     unsigned long long* mymask = masks + wid * NB;
     int* myhist = hist + wid * NB;
+    unsigned long long key[KPT];
     for (int pass = 0; pass < npass; ++pass) {
         const int shift = 32 + DB * pass;
 #pragma unroll
         for (int q = 0; q < HPT; ++q) hist[tid * HPT + q] = 0;
-        __syncthreads();
-        unsigned long long key[KPT];
         int lrank[KPT], dig[KPT];
 #pragma unroll
+        for (int r = 0; r < KPT; ++r) key[r] = keys[chunk + r * 64 + lane];
+        __syncthreads();
+#pragma unroll
         for (int r = 0; r < KPT; ++r) {
-            const unsigned long long k = keys[chunk + r * 64 + lane];
-            const int d = (int)(k >> shift) & (NB - 1);
+            const int d = (int)(key[r] >> shift) & (NB - 1);
+            // one LDS round trip per round: OR my lane bit in, then read the mask and the running count back
             __hip_atomic_fetch_or(&mymask[d], 1ull << lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             const unsigned long long peers = *(volatile unsigned long long*)&mymask[d];
-            const int rank = __popcll(peers & lt_mask);
+            const int before = *(volatile int*)&myhist[d];   // same-digit keys of this wave's earlier rounds
             const int leader = __ffsll((long long)peers) - 1;
-            int old = 0;
-            if (lane == leader) {
-                old = myhist[d];
-                myhist[d] = old + __popcll(peers);
-                *(volatile unsigned long long*)&mymask[d] = 0ull;   // every peer has read it (same wave, in order)
+            if (lane == leader) {   // after every peer's reads (same wave, LDS is in order)
+                *(volatile int*)&myhist[d] = before + __popcll(peers);
+                *(volatile unsigned long long*)&mymask[d] = 0ull;
             }
-            old = __shfl(old, leader, 64);
-            key[r] = k;
-            lrank[r] = old + rank;
+            lrank[r] = before + __popcll(peers & lt_mask);
             dig[r] = d;
         }
         SORT_STAMP(2 + 3 * pass);
@@ -178,36 +176,62 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_segments_kernel(SortJob job
         SORT_STAMP(4 + 3 * pass);
     }
 
-    // segment heads + exclusive scan
-    constexpr int C = KPT;
-    const int base = tid * C;
-    int heads = 0;
+    // segment heads: element j = q*1024 + tid (conflict-free LDS reads, coalesced global writes);
+    // a 64-bit ballot per (q, wave) word, then one small scan over the 16*KPT word counts
+    int* wcnt = hist;   // reuse: [KPT][16]
+    unsigned long long bal[KPT];
 #pragma unroll
-    for (int q = 0; q < C; ++q) {
-        int j = base + q;
-        if (j < M) {
-            unsigned r = (unsigned)(keys[j] >> 32);
-            heads += (j == 0 || (unsigned)(keys[j - 1] >> 32) != r) ? 1 : 0;
-        }
+    for (int q = 0; q < KPT; ++q) {
+        const int j = q * SORT_THREADS + tid;
+        const unsigned long long k = keys[j];
+        const unsigned long long kp = j > 0 ? keys[j - 1] : ~k;
+        key[q] = k;
+        const bool head = j < M && (j == 0 || (unsigned)(k >> 32) != (unsigned)(kp >> 32));
+        bal[q] = __ballot(head);
+        if (lane == 0) wcnt[q * 16 + wid] = __popcll(bal[q]);
     }
     SORT_STAMP(12);
-    int total;
-    int seg = block_exclusive_scan_1024(heads, scratch, total) - 1;
-    SORT_STAMP(13);  // index of the segment open at `base`
+    __syncthreads();
+    if (wid == 0) {   // exclusive scan of 16*KPT <= 256 counts by one wave, 4 per lane
+        constexpr int NW = 16 * KPT;
+        constexpr int PL = (NW + 63) / 64;
+        int c[PL], sum = 0;
 #pragma unroll
-    for (int q = 0; q < C; ++q) {
-        int j = base + q;
+        for (int q = 0; q < PL; ++q) {
+            const int idx = lane * PL + q;
+            c[q] = idx < NW ? wcnt[idx] : 0;
+            sum += c[q];
+        }
+        int inc = sum;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int y = __shfl_up(inc, o, 64);
+            if (lane >= o) inc += y;
+        }
+        int ex = inc - sum;
+#pragma unroll
+        for (int q = 0; q < PL; ++q) {
+            const int idx = lane * PL + q;
+            if (idx < NW) wcnt[idx] = ex;
+            ex += c[q];
+        }
+        if (lane == 63) scratch[16] = inc;
+    }
+    __syncthreads();
+    SORT_STAMP(13);
+    const int total = scratch[16];
+#pragma unroll
+    for (int q = 0; q < KPT; ++q) {
+        const int j = q * SORT_THREADS + tid;
         if (j < M) {
-            unsigned long long k = keys[j];
-            unsigned r = (unsigned)(k >> 32);
-            bool head = (j == 0 || (unsigned)(keys[j - 1] >> 32) != r);
-            if (head) {
-                ++seg;
-                job.seg_start[seg] = j;
-                job.seg_row[seg] = (int)r;
-            }
-            int b = (int)(unsigned)k;
+            const unsigned long long k = key[q];
+            const int seg = wcnt[q * 16 + wid] + __popcll(bal[q] & (lt_mask | (1ull << lane))) - 1;
+            const int b = (int)(unsigned)k;
             job.perm[j] = b;
+            if ((bal[q] >> lane) & 1ull) {
+                job.seg_start[seg] = j;
+                job.seg_row[seg] = (int)(unsigned)(k >> 32);
+            }
             if (job.seg_of) job.seg_of[b] = seg;
         }
     }
