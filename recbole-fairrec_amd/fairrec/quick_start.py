@@ -1,0 +1,46 @@
+"""`run_recbole`-shaped entry (reference quick_start.py:20-71) for in-memory / synthetic datasets:
+Config -> init_seed -> dataset -> dataloaders -> model -> trainer.fit -> trainer.evaluate."""
+from __future__ import annotations
+
+from logging import getLogger
+
+from .config import Config
+from .data.dataloader import FOCFDataLoader, TrainDataLoader
+from .data.dataset import InteractionDataset, synthetic_dataset
+from .data.interaction import Interaction
+from .utils import get_model, get_trainer, init_seed
+
+
+def split_dataset(dataset: InteractionDataset, ratios=(0.8, 0.1, 0.1)):
+    """Random split by ratio after a torch.randperm shuffle (the RS split of the reference's eval_args)."""
+    dataset.shuffle()
+    n = len(dataset)
+    a, b = int(n * ratios[0]), int(n * (ratios[0] + ratios[1]))
+    mk = lambda sl: InteractionDataset(dataset.config, dataset.inter_feat[sl], dataset.user_feat, dataset.user_num,
+                                       dataset.item_num)
+    return mk(slice(0, a)), mk(slice(a, b)), mk(slice(b, n))
+
+
+def run_recbole(model=None, dataset=None, config_file_list=None, config_dict=None, saved=True):
+    """`dataset` is an InteractionDataset, or None for a synthetic one sized by config keys
+    `synthetic_users / synthetic_items / synthetic_interactions`."""
+    config = Config(model=model, dataset=getattr(dataset, 'name', 'synthetic'), config_file_list=config_file_list,
+                    config_dict=config_dict)
+    init_seed(config['seed'], config['reproducibility'])
+    logger = getLogger()
+    if dataset is None:
+        dataset = synthetic_dataset(config, config['synthetic_users'] or 1000, config['synthetic_items'] or 500,
+                                    config['synthetic_interactions'] or 50000, seed=config['seed'])
+    train_set, valid_set, test_set = split_dataset(dataset)
+    loader_cls = FOCFDataLoader if config['model'] == 'FOCF' and config['item_grouped_batches'] else TrainDataLoader
+    train_data = loader_cls(config, train_set, shuffle=True)
+    valid_data = TrainDataLoader(config, valid_set)
+    test_data = TrainDataLoader(config, test_set)
+    init_seed(config['seed'], config['reproducibility'])
+    model_obj = get_model(config['model'])(config, train_data.dataset).to(config['device'])
+    logger.info(model_obj)
+    trainer = get_trainer(None, config['model'])(config, model_obj)
+    best_valid_score, best_valid_result = trainer.fit(train_data, valid_data, saved=saved)
+    test_result = trainer.evaluate(test_data, load_best_model=saved)
+    return {'best_valid_score': best_valid_score, 'valid_score_bigger': config['valid_metric_bigger'],
+            'best_valid_result': best_valid_result, 'test_result': test_result}

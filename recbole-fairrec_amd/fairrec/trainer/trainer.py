@@ -1,0 +1,211 @@
+"""Trainer with the surface of recbole/trainer/trainer.py:62-531 (`Trainer(config, model)`, `fit`, `evaluate`,
+`resume_checkpoint`, overridable `_build_optimizer / _train_epoch / _valid_epoch / _save_checkpoint`).
+
+The step loop keeps the reference's shape (trainer.py:181-196)
+
+    zero_grad -> calculate_loss -> backward -> step
+
+but `optimizer` is fairrec.optim.FusedLazyAdam, so `step()` is ONE HIP launch doing the backward and the Adam
+update, and the two per-step host syncs of the reference (`loss.item()`, `isnan`) are taken once per epoch
+(losses are accumulated on the device; NaN still raises `ValueError('Training loss is nan')`).
+"""
+from __future__ import annotations
+
+import os
+from collections import OrderedDict
+from logging import getLogger
+from time import time
+
+import numpy as np
+import torch
+
+from ..optim import FusedLazyAdam
+from ..utils import calculate_valid_score, dict2str, early_stopping, ensure_dir, get_local_time
+
+
+class AbstractTrainer:
+    def __init__(self, config, model):
+        self.config = config
+        self.model = model
+
+    def fit(self, train_data):
+        raise NotImplementedError('Method [next] should be implemented.')
+
+    def evaluate(self, eval_data):
+        raise NotImplementedError('Method [next] should be implemented.')
+
+
+class Trainer(AbstractTrainer):
+    def __init__(self, config, model):
+        super().__init__(config, model)
+        self.logger = getLogger()
+        self.learner = config['learner'] or 'adam'
+        self.learning_rate = config['learning_rate']
+        self.epochs = config['epochs']
+        self.eval_step = min(config['eval_step'] or 1, self.epochs)
+        self.stopping_step = config['stopping_step']
+        self.clip_grad_norm = config['clip_grad_norm']
+        self.valid_metric = (config['valid_metric'] or 'rmse').lower()
+        self.valid_metric_bigger = bool(config['valid_metric_bigger'])
+        self.test_batch_size = config['eval_batch_size'] or 4096
+        self.device = config['device']
+        self.checkpoint_dir = config['checkpoint_dir'] or 'saved'
+        ensure_dir(self.checkpoint_dir)
+        self.saved_model_file = os.path.join(self.checkpoint_dir, '{}-{}.pth'.format(config['model'], get_local_time()))
+        self.weight_decay = config['weight_decay'] or 0.0
+
+        self.start_epoch = 0
+        self.cur_step = 0
+        self.best_valid_score = -np.inf if self.valid_metric_bigger else np.inf
+        self.best_valid_result = None
+        self.train_loss_dict = dict()
+        self.optimizer = self._build_optimizer()
+
+    # --- optimizer ----------------------------------------------------------------------------------------
+    def _build_optimizer(self, **kwargs):
+        """reference trainer.py:114-153.  Only learner 'adam' runs on the fused HIP path (the only learner the
+        reference's fair-model configs use)."""
+        learner = kwargs.pop('learner', self.learner)
+        learning_rate = kwargs.pop('learning_rate', self.learning_rate)
+        weight_decay = kwargs.pop('weight_decay', self.weight_decay)
+        engine = kwargs.pop('engine', None) or self.model.hip_engine()
+        if engine is None:
+            raise NotImplementedError(f'{type(self.model).__name__} exposes no HIP engine')
+        if learner.lower() != 'adam':
+            raise NotImplementedError(f"learner '{learner}' is not on the MI355X hot path yet (adam only)")
+        if self.clip_grad_norm:
+            raise NotImplementedError('clip_grad_norm needs a global gradient norm before the fused update; not supported yet')
+        return FusedLazyAdam(engine, lr=learning_rate, weight_decay=weight_decay,
+                             sweep_period=self.config['lazy_adam_sweep_period'])
+
+    # --- training -----------------------------------------------------------------------------------------
+    def _train_epoch(self, train_data, epoch_idx, loss_func=None, show_progress=False):
+        self.model.train()
+        loss_func = loss_func or self.model.calculate_loss
+        total = None
+        n_tuple = 0
+        for batch_idx, interaction in enumerate(train_data):
+            interaction = interaction.to(self.device)
+            self.optimizer.zero_grad()
+            losses = loss_func(interaction)
+            if isinstance(losses, tuple):
+                n_tuple = len(losses)
+                loss = sum(losses)
+                part = torch.stack([l.detach() for l in losses])
+            else:
+                loss = losses
+                part = losses.detach().view(1)
+            total = part.clone() if total is None else total + part
+            loss.backward()
+            self.optimizer.step()
+        if total is None:
+            return 0.0
+        vals = total.cpu().tolist()                 # the epoch's only host sync
+        self._check_nan(torch.tensor(vals))
+        eng = self.model.hip_engine()
+        if eng is not None:
+            eng.check_device_errors()
+        return tuple(vals) if n_tuple else vals[0]
+
+    def _check_nan(self, loss):
+        if torch.isnan(loss).any():
+            raise ValueError('Training loss is nan')
+
+    def _valid_epoch(self, valid_data, show_progress=False):
+        valid_result = self.evaluate(valid_data, load_best_model=False, show_progress=show_progress)
+        return calculate_valid_score(valid_result, self.valid_metric), valid_result
+
+    def _save_checkpoint(self, epoch, verbose=True, **kwargs):
+        """Same keys as trainer.py:221-240; model.state_dict() flushes the lazy tables first."""
+        saved_model_file = kwargs.pop('saved_model_file', self.saved_model_file)
+        state = {
+            'config': dict(self.config.final_config_dict) if hasattr(self.config, 'final_config_dict') else None,
+            'epoch': epoch,
+            'cur_step': self.cur_step,
+            'best_valid_score': self.best_valid_score,
+            'state_dict': self.model.state_dict(),
+            'other_parameter': self.model.other_parameter(),
+            'optimizer': self.optimizer.state_dict(),
+        }
+        torch.save(state, saved_model_file)
+        if verbose:
+            self.logger.info('Saving current: %s', saved_model_file)
+
+    def resume_checkpoint(self, resume_file):
+        resume_file = str(resume_file)
+        self.saved_model_file = resume_file
+        checkpoint = torch.load(resume_file, weights_only=False)
+        self.start_epoch = checkpoint['epoch'] + 1
+        self.cur_step = checkpoint['cur_step']
+        self.best_valid_score = checkpoint['best_valid_score']
+        self.model.load_state_dict(checkpoint['state_dict'])
+        self.model.load_other_parameter(checkpoint.get('other_parameter'))
+        self.optimizer.load_state_dict(checkpoint['optimizer'])
+        self.logger.info('Checkpoint loaded. Resume training from epoch %d', self.start_epoch)
+
+    def _generate_train_loss_output(self, epoch_idx, s_time, e_time, losses):
+        des = self.config['loss_decimal_place'] or 4
+        out = 'epoch %d training [time: %.2fs, ' % (epoch_idx, e_time - s_time)
+        if isinstance(losses, tuple):
+            out += ', '.join(('train_loss%d: %.' + str(des) + 'f') % (i + 1, l) for i, l in enumerate(losses))
+        else:
+            out += ('train loss: %.' + str(des) + 'f') % losses
+        return out + ']'
+
+    def fit(self, train_data, valid_data=None, verbose=True, saved=True, show_progress=False, callback_fn=None):
+        """reference trainer.py:332-418: returns (best_valid_score, best_valid_result)."""
+        if saved and self.start_epoch >= self.epochs:
+            self._save_checkpoint(-1, verbose=verbose)
+        for epoch_idx in range(self.start_epoch, self.epochs):
+            t0 = time()
+            train_loss = self._train_epoch(train_data, epoch_idx, show_progress=show_progress)
+            self.train_loss_dict[epoch_idx] = sum(train_loss) if isinstance(train_loss, tuple) else train_loss
+            if verbose:
+                self.logger.info(self._generate_train_loss_output(epoch_idx, t0, time(), train_loss))
+            if self.eval_step <= 0 or not valid_data:
+                if saved:
+                    self._save_checkpoint(epoch_idx, verbose=verbose)
+                continue
+            if (epoch_idx + 1) % self.eval_step == 0:
+                valid_score, valid_result = self._valid_epoch(valid_data, show_progress=show_progress)
+                self.best_valid_score, self.cur_step, stop_flag, update_flag = early_stopping(
+                    valid_score, self.best_valid_score, self.cur_step, max_step=self.stopping_step,
+                    bigger=self.valid_metric_bigger)
+                if verbose:
+                    self.logger.info('epoch %d evaluating [valid_score: %f] %s', epoch_idx, valid_score,
+                                     dict2str(valid_result))
+                if update_flag:
+                    if saved:
+                        self._save_checkpoint(epoch_idx, verbose=verbose)
+                    self.best_valid_result = valid_result
+                if callback_fn:
+                    callback_fn(epoch_idx, valid_score)
+                if stop_flag:
+                    break
+        return self.best_valid_score, self.best_valid_result
+
+    @torch.no_grad()
+    def evaluate(self, eval_data, load_best_model=False, model_file=None, show_progress=False):
+        """Value-type evaluation of `model.predict` on (user, item, rating) batches: RMSE / MAE of the
+        de-normalised score.  The reference's ranking evaluation (uni100 negatives, top-k and fairness metrics,
+        trainer.py:458-515 + recbole/evaluator) is the next row f-2 of SURVEY.md §8 and not built yet."""
+        if not eval_data:
+            return None
+        if load_best_model:
+            checkpoint = torch.load(model_file or self.saved_model_file, weights_only=False)
+            self.model.load_state_dict(checkpoint['state_dict'])
+            self.model.load_other_parameter(checkpoint.get('other_parameter'))
+        self.model.eval()
+        se = torch.zeros((), device=self.device)
+        ae = torch.zeros((), device=self.device)
+        n = 0
+        rating_field = self.config['RATING_FIELD']
+        max_rating = float(getattr(self.model, 'max_rating', 1.0))
+        for interaction in eval_data:
+            interaction = interaction.to(self.device)
+            score = self.model.predict(interaction).view(-1) * max_rating
+            err = score - interaction[rating_field].to(torch.float32)
+            se += (err * err).sum()
+            ae += err.abs().sum()
+            n += err.numel()
+        return OrderedDict(rmse=float((se / max(n, 1)).sqrt().item()), mae=float((ae / max(n, 1)).item()))

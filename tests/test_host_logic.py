@@ -1,0 +1,98 @@
+"""CPU: host-side plumbing (Interaction, Config, dataloaders, Adam scalar table, utils)."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from fairrec.config import Config
+from fairrec.data.dataloader import FOCFDataLoader, TrainDataLoader
+from fairrec.data.dataset import InteractionDataset, synthetic_dataset
+from fairrec.data.interaction import Interaction, cat_interactions
+from fairrec.optim import adam_step_scalars
+from fairrec.utils import early_stopping, get_model, get_trainer
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_interaction_contract():
+    it = Interaction({"a": torch.arange(6), "b": torch.arange(6).float() * 2})
+    assert len(it) == 6 and it.columns == ["a", "b"] and "a" in it
+    assert torch.equal(it[2:4]["a"], torch.tensor([2, 3]))
+    assert torch.equal(it[[0, 5]]["b"], torch.tensor([0.0, 10.0]))
+    assert torch.equal(it.repeat(2)["a"], torch.arange(6).repeat(2))
+    assert torch.equal(it.repeat_interleave(2)["a"], torch.arange(6).repeat_interleave(2))
+    it2 = Interaction({"a": torch.tensor([3, 1, 2]), "b": torch.tensor([0.0, 1.0, 2.0])})
+    it2.sort("a")
+    assert it2["b"].tolist() == [1.0, 2.0, 0.0]
+    assert len(cat_interactions([it, it])) == 12
+    it.update(Interaction({"c": torch.zeros(6)}))
+    it.drop("c")
+    with pytest.raises(ValueError):
+        it.drop("c")
+    assert it.to("cpu")["a"].device.type == "cpu"
+
+
+def test_config_priority_and_missing_keys(tmp_path):
+    f = tmp_path / "c.yaml"
+    f.write_text("embedding_size: 32\nweight_decay: 1e-6\nfair_objective: value\n")
+    c = Config(model="FOCF", config_file_list=[str(f)], config_dict={"embedding_size": 16})
+    assert c["embedding_size"] == 16            # dict > file > model yaml
+    assert c["weight_decay"] == 1e-6 and isinstance(c["weight_decay"], float)   # 1e-6 parses as float
+    assert c["fair_objective"] == "value" and c["fair_weight"] == 1.0
+    assert c["not_a_key"] is None               # configurator.py:405-409
+    assert c["learner"] == "adam" and c["learning_rate"] == 0.001
+
+
+def test_adam_scalars_match_torch_formula():
+    tab = adam_step_scalars(1e-3, 0.9, 0.999, 40000)
+    for j in (1, 2, 10, 1000, 20000, 40000):
+        assert tab[2 * j] == np.float32(1e-3 / (1 - 0.9 ** j))
+        assert tab[2 * j + 1] == np.float32(1 / math.sqrt(1 - 0.999 ** j))
+    assert tab[2 * 40000] == np.float32(1e-3) and tab[2 * 40000 + 1] == np.float32(1.0)   # saturated
+
+
+def test_train_dataloader_covers_dataset_once():
+    c = Config(model="FOCF", config_dict={"train_batch_size": 128})
+    ds = synthetic_dataset(c, 50, 40, 1000)
+    dl = TrainDataLoader(c, ds, shuffle=True)
+    torch.manual_seed(0)
+    seen = torch.cat([b["user_id"] * 1000 + b["item_id"] for b in dl])
+    assert len(dl) == 8 and seen.numel() == 1000
+    b = next(iter(dl))
+    assert set(b.columns) == {"user_id", "item_id", "rating", "gender"}
+    assert torch.equal(b["gender"], ds.user_feat["gender"][b["user_id"]])
+
+
+def test_focf_dataloader_matches_reference_golden():
+    z = np.load(os.path.join(GOLDEN, "dataloader_focf.npz"))
+    c = Config(model="FOCF", config_dict={"train_batch_size": int(z["step"])})
+    inter = Interaction({"user_id": torch.from_numpy(z["user_id"]), "item_id": torch.from_numpy(z["item_id"]),
+                         "rating": torch.from_numpy(z["rating"])})
+    ds = InteractionDataset(c, inter, None, n_users=100, n_items=int(z["item_num"]))
+    dl = FOCFDataLoader(c, ds)
+    np.random.seed(int(z["np_seed"]))
+    it = iter(dl)
+    for b in range(4):
+        batch = next(it)
+        for col in ("user", "item", "rating"):
+            np.testing.assert_array_equal(batch[f"{col}_id" if col != "rating" else "rating"].numpy(),
+                                          z[f"batch{b}_{col}"])
+
+
+def test_dispatch_and_early_stopping():
+    assert get_model("FOCF").__name__ == "FOCF"
+    assert get_trainer(None, "FOCF").__name__ == "Trainer"     # no FOCFTrainer -> plain Trainer (utils.py:76-94)
+    with pytest.raises(ValueError):
+        get_model("NoSuchModel")
+    assert early_stopping(0.5, 0.4, 3, 10, bigger=True) == (0.5, 0, False, True)
+    assert early_stopping(0.3, 0.4, 10, 10, bigger=True) == (0.4, 11, True, False)
+    assert early_stopping(0.3, 0.4, 0, 10, bigger=False) == (0.3, 0, False, True)
+
+
+def test_no_cpu_fallback():
+    from fairrec import _C
+    from fairrec.model.fair_recommender.focf import FocfEngine
+    with pytest.raises(_C.FairrecError):
+        FocfEngine(torch.zeros(4, 8), torch.zeros(4, 8), "none", 0.0, 5.0)
