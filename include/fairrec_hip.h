@@ -143,6 +143,23 @@ FR_API int fr_table_flush(const fr_table* t, const fr_adam* adam, void* stream);
 FR_API int fr_table_gather(const fr_table* t, const fr_adam* adam, const int64_t* idx, int64_t M, float* out,
                     uint32_t* err_flag, void* stream);
 
+/*
+ * Generic training pair for models whose score is not a plain dot product (NFCF nfcf.py:69-74, PFCN
+ * pfcn_biasedmf.py:144-166) and for the owner side of the row-sharded multi-GPU path:
+ *   fr_table_gather_train : sort idx into segments + gather the rows as of step t->step-1 (lazy replay) into
+ *                           rows_out[M,dim]; caught-up moments stay in the workspace.  Replaces nn.Embedding.forward.
+ *   ... the caller runs its forward/backward on rows_out and produces grad_rows[M,dim] = dLoss/d rows_out ...
+ *   fr_table_apply_grad   : per distinct row, sum grad_rows over duplicates in ascending position (what
+ *                           embedding_dense_backward does), apply Adam step t->step, write the row back; plus the
+ *                           sweeper slice.  Replaces loss.backward() on the embedding + optimizer.step().
+ * `t->step` is the step being applied in both calls; M <= FR_SORT_MAX.
+ */
+FR_API size_t fr_table_train_workspace_bytes(int64_t M, int32_t dim);
+FR_API int fr_table_gather_train(const fr_table* t, const fr_adam* adam, const int64_t* idx, int64_t M,
+                                 float* rows_out, void* ws, size_t ws_bytes, uint32_t* err_flag, void* stream);
+FR_API int fr_table_apply_grad(const fr_table* t, const fr_adam* adam, int64_t M, const float* rows,
+                               const float* grad_rows, int32_t sweep_period, void* ws, size_t ws_bytes, void* stream);
+
 /* Dense fused Adam step for small dense parameters (MLP weights, biases): one step of
  * torch.optim.Adam on a flat fp32 tensor, `step` = the step being applied. */
 FR_API int fr_adam_dense(float* p, const float* g, float* m, float* v, int64_t n, const fr_adam* adam, int32_t step,

@@ -40,9 +40,9 @@ def item_group_means(pred, rating, sst, item):
     _, g = torch.unique(sst, return_inverse=True)
     _, k = torch.unique(item, return_inverse=True)
     K = int(k.max().item()) + 1 if k.numel() else 0
-    sp = torch.zeros((K, 2), dtype=pred.dtype)
-    st = torch.zeros((K, 2), dtype=pred.dtype)
-    cn = torch.zeros((K, 2), dtype=pred.dtype)
+    sp = torch.zeros((K, 2), dtype=pred.dtype, device=pred.device)
+    st = torch.zeros((K, 2), dtype=pred.dtype, device=pred.device)
+    cn = torch.zeros((K, 2), dtype=pred.dtype, device=pred.device)
     sp.index_put_((k, g), pred, accumulate=True)
     st.index_put_((k, g), rating, accumulate=True)
     cn.index_put_((k, g), torch.ones_like(pred), accumulate=True)

@@ -18,6 +18,7 @@
 //               row written back once; plus the bounded-staleness sweeper slice
 #include "common.hpp"
 #include "kernels.hpp"
+#include "table.hpp"
 
 namespace fr {
 
@@ -284,63 +285,6 @@ __global__ __launch_bounds__(256) void focf_finalize_kernel(FocfWs w, int B, int
 // backward + Adam: one wave per distinct row, plus sweeper waves
 // ------------------------------------------------------------------------------------------------
 template <int E>
-__device__ __forceinline__ void segment_update(const TableV& T, const AdamC& c, int k, const int32_t* seg_start,
-                                               const int32_t* seg_row, const int32_t* perm, const float* coef,
-                                               const float* sp, const float* sm, const float* sv, const float* other,
-                                               int lane) {
-    const int D = T.D;
-    const int j0 = uniform(seg_start[k]), j1 = uniform(seg_start[k + 1]);
-    const int row = uniform(seg_row[k]);
-    const int b0 = uniform(perm[j0]);
-    RowFrag<E> p, m, v, g;
-    load_row<E>(p, sp + (size_t)b0 * D, D, lane);
-    load_row<E>(m, sm + (size_t)b0 * D, D, lane);
-    load_row<E>(v, sv + (size_t)b0 * D, D, lane);
-#pragma unroll
-    for (int e = 0; e < E; ++e) g.x[e] = 0.f;
-    for (int j = j0; j < j1; ++j) {
-        const int b = uniform(perm[j]);
-        const float cb = coef[b];
-        RowFrag<E> o;
-        load_row<E>(o, other + (size_t)b * D, D, lane);
-        {
-#pragma clang fp contract(off)  // product rounded, then added: grad_row += coef * other_row (autograd order)
-#pragma unroll
-            for (int e = 0; e < E; ++e) {
-                float prod = cb * o.x[e];
-                g.x[e] = g.x[e] + prod;
-            }
-        }
-    }
-    const float2 s = step_scalars(c, T.step);
-#pragma unroll
-    for (int e = 0; e < E; ++e) adam_elem(p.x[e], m.x[e], v.x[e], g.x[e], s.x, s.y, c);
-    store_row<E>(p, T.p + (size_t)row * D, D, lane);
-    store_row<E>(m, T.m + (size_t)row * D, D, lane);
-    store_row<E>(v, T.v + (size_t)row * D, D, lane);
-    if (lane == 0) T.last[row] = T.step;
-}
-
-// Bring one untouched row up to `upto` (all missed steps have zero data gradient).
-template <int E>
-__device__ __forceinline__ void sweep_row(const TableV& T, const AdamC& c, long long row, int upto, bool check_stamp,
-                                          int lane) {
-    const int D = T.D;
-    if (check_stamp && uniform(T.stamp[row]) == upto) return;  // touched this step: a segment wave owns it
-    const int t0 = uniform(T.last[row]);
-    if (t0 >= upto) return;
-    RowFrag<E> p, m, v;
-    load_row<E>(p, T.p + (size_t)row * D, D, lane);
-    load_row<E>(m, T.m + (size_t)row * D, D, lane);
-    load_row<E>(v, T.v + (size_t)row * D, D, lane);
-    replay<E>(p, m, v, t0, upto, c, lane);
-    store_row<E>(p, T.p + (size_t)row * D, D, lane);
-    store_row<E>(m, T.m + (size_t)row * D, D, lane);
-    store_row<E>(v, T.v + (size_t)row * D, D, lane);
-    if (lane == 0) T.last[row] = upto;
-}
-
-template <int E>
 __global__ __launch_bounds__(256) void focf_backward_adam_kernel(TableV U, TableV I, AdamC c, int B, FocfWs w,
                                                                  long long sw_lo_u, int sw_n_u, long long sw_lo_i,
                                                                  int sw_n_i) {
@@ -368,60 +312,6 @@ __global__ __launch_bounds__(256) void focf_backward_adam_kernel(TableV U, Table
         segment_update<E>(I, c, (int)wv, w.seg_start_i, w.seg_row_i, w.perm_i, w.coef, w.side[3], w.side[4],
                           w.side[5], w.side[0], lane);
 }
-
-// ------------------------------------------------------------------------------------------------
-// table maintenance
-// ------------------------------------------------------------------------------------------------
-template <int E>
-__global__ __launch_bounds__(256) void table_flush_kernel(TableV T, AdamC c) {
-    const int lane = threadIdx.x & 63;
-    const long long nw = (long long)gridDim.x * 4;
-    for (long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); row < T.n_rows; row += nw)
-        sweep_row<E>(T, c, row, T.step, false, lane);
-}
-
-template <int E>
-__global__ __launch_bounds__(256) void table_gather_kernel(TableV T, AdamC c, const int64_t* __restrict__ idx,
-                                                           long long M, float* __restrict__ out, uint32_t* err) {
-    const int lane = threadIdx.x & 63;
-    const long long j = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (j >= M) return;
-    long long r = idx[j];
-    if (r < 0 || r >= T.n_rows) {
-        if (lane == 0 && err) atomicOr(err, FR_DEV_ERR_INDEX_RANGE);
-        r = 0;
-    }
-    const int row = uniform((int)r);
-    const int D = T.D;
-    const int t0 = uniform(T.last[row]);
-    RowFrag<E> p, m, v;
-    load_row<E>(p, T.p + (size_t)row * D, D, lane);
-    if (t0 < T.step) {
-        load_row<E>(m, T.m + (size_t)row * D, D, lane);
-        load_row<E>(v, T.v + (size_t)row * D, D, lane);
-        replay<E>(p, m, v, t0, T.step, c, lane);
-    }
-    store_row<E>(p, out + (size_t)j * D, D, lane);
-}
-
-__global__ __launch_bounds__(256) void adam_dense_kernel(float* __restrict__ p, const float* __restrict__ g,
-                                                         float* __restrict__ m, float* __restrict__ v, long long n,
-                                                         AdamC c, int step) {
-    const float2 s = step_scalars(c, step);
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
-        float pp = p[i], mm = m[i], vv = v[i];
-        adam_elem(pp, mm, vv, g[i], s.x, s.y, c);
-        p[i] = pp; m[i] = mm; v[i] = vv;
-    }
-}
-
-#define FR_DISPATCH_E(D, ...)                          \
-    switch (((D) + 63) / 64) {                         \
-        case 1: { constexpr int E = 1; __VA_ARGS__; } break;  \
-        case 2: { constexpr int E = 2; __VA_ARGS__; } break;  \
-        case 3: { constexpr int E = 3; __VA_ARGS__; } break;  \
-        default: { constexpr int E = 4; __VA_ARGS__; } break; \
-    }
 
 }  // namespace fr
 
@@ -548,51 +438,3 @@ extern "C" int fr_focf_predict(const fr_table* U, const fr_table* I, const fr_ad
     return FR_OK;
 }
 
-extern "C" int fr_table_flush(const fr_table* t, const fr_adam* adam, void* stream_) {
-    int rc;
-    if ((rc = check_table(t, "fr_table_flush")) || (rc = check_adam(adam, "fr_table_flush"))) return rc;
-    if (t->step < 1) return FR_OK;
-    const AdamC c = make_adamc(adam);
-    const TableV Tv = view(t);
-    long long blocks = (t->n_rows + 3) / 4;
-    if (blocks > 256 * 32) blocks = 256 * 32;
-    {
-        ProfScope prof(K_TABLE_FLUSH, (hipStream_t)stream_);
-        FR_DISPATCH_E(t->dim, table_flush_kernel<E><<<dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream_>>>(Tv, c));
-    }
-    FR_CHECK_LAUNCH();
-    return FR_OK;
-}
-
-extern "C" int fr_table_gather(const fr_table* t, const fr_adam* adam, const int64_t* idx, int64_t M, float* out,
-                               uint32_t* err_flag, void* stream_) {
-    int rc;
-    if ((rc = check_table(t, "fr_table_gather")) || (rc = check_adam(adam, "fr_table_gather"))) return rc;
-    FR_CHECK_ARG(idx && out && M >= 0, "fr_table_gather: bad argument");
-    if (M == 0) return FR_OK;
-    const AdamC c = make_adamc(adam);
-    const TableV Tv = view(t);
-    {
-        ProfScope prof(K_TABLE_GATHER, (hipStream_t)stream_);
-        FR_DISPATCH_E(t->dim, table_gather_kernel<E><<<dim3((unsigned)((M + 3) / 4)), dim3(256), 0, (hipStream_t)stream_>>>(Tv, c, idx, (long long)M, out, err_flag));
-    }
-    FR_CHECK_LAUNCH();
-    return FR_OK;
-}
-
-extern "C" int fr_adam_dense(float* p, const float* g, float* m, float* v, int64_t n, const fr_adam* adam,
-                             int32_t step, void* stream_) {
-    int rc;
-    if ((rc = check_adam(adam, "fr_adam_dense"))) return rc;
-    FR_CHECK_ARG(p && g && m && v && n >= 0 && step >= 1, "fr_adam_dense: bad argument");
-    if (n == 0) return FR_OK;
-    long long blocks = (n + 255) / 256;
-    if (blocks > 256 * 16) blocks = 256 * 16;
-    {
-        ProfScope prof(K_ADAM_DENSE, (hipStream_t)stream_);
-        hipLaunchKernelGGL(adam_dense_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream_, p, g, m, v,
-                           (long long)n, make_adamc(adam), step);
-    }
-    FR_CHECK_LAUNCH();
-    return FR_OK;
-}

@@ -1,0 +1,78 @@
+// Device-side building blocks of the lazy-Adam embedding tables (shared by focf.hip and table.hip).
+#pragma once
+#include "common.hpp"
+#include "kernels.hpp"
+
+namespace fr {
+
+// One distinct row of a batch: sum the contributions of its members in ascending batch position, apply the
+// Adam step `T.step` to the caught-up state parked in the workspace, write the row back once.
+//   coef != nullptr : contribution of member b = coef[b] * other[b,:]   (rank-1 form: MF models)
+//   coef == nullptr : contribution of member b = other[b,:]             (gradient rows from an MLP backward)
+template <int E>
+__device__ __forceinline__ void segment_update(const TableV& T, const AdamC& c, int k, const int32_t* seg_start,
+                                               const int32_t* seg_row, const int32_t* perm, const float* coef,
+                                               const float* sp, const float* sm, const float* sv, const float* other,
+                                               int lane) {
+    const int D = T.D;
+    const int j0 = uniform(seg_start[k]), j1 = uniform(seg_start[k + 1]);
+    const int row = uniform(seg_row[k]);
+    const int b0 = uniform(perm[j0]);
+    RowFrag<E> p, m, v, g;
+    load_row<E>(p, sp + (size_t)b0 * D, D, lane);
+    load_row<E>(m, sm + (size_t)b0 * D, D, lane);
+    load_row<E>(v, sv + (size_t)b0 * D, D, lane);
+#pragma unroll
+    for (int e = 0; e < E; ++e) g.x[e] = 0.f;
+    for (int j = j0; j < j1; ++j) {
+        const int b = uniform(perm[j]);
+        const float cb = coef ? coef[b] : 1.f;
+        RowFrag<E> o;
+        load_row<E>(o, other + (size_t)b * D, D, lane);
+        {
+#pragma clang fp contract(off)  // product rounded, then added: grad_row += coef * other_row (autograd order)
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                float prod = cb * o.x[e];
+                g.x[e] = g.x[e] + prod;
+            }
+        }
+    }
+    const float2 s = step_scalars(c, T.step);
+#pragma unroll
+    for (int e = 0; e < E; ++e) adam_elem(p.x[e], m.x[e], v.x[e], g.x[e], s.x, s.y, c);
+    store_row<E>(p, T.p + (size_t)row * D, D, lane);
+    store_row<E>(m, T.m + (size_t)row * D, D, lane);
+    store_row<E>(v, T.v + (size_t)row * D, D, lane);
+    if (lane == 0) T.last[row] = T.step;
+}
+
+// Bring one untouched row up to `upto` (all missed steps have zero data gradient).
+template <int E>
+__device__ __forceinline__ void sweep_row(const TableV& T, const AdamC& c, long long row, int upto, bool check_stamp,
+                                          int lane) {
+    const int D = T.D;
+    if (check_stamp && uniform(T.stamp[row]) == upto) return;  // touched this step: a segment wave owns it
+    const int t0 = uniform(T.last[row]);
+    if (t0 >= upto) return;
+    RowFrag<E> p, m, v;
+    load_row<E>(p, T.p + (size_t)row * D, D, lane);
+    load_row<E>(m, T.m + (size_t)row * D, D, lane);
+    load_row<E>(v, T.v + (size_t)row * D, D, lane);
+    replay<E>(p, m, v, t0, upto, c, lane);
+    store_row<E>(p, T.p + (size_t)row * D, D, lane);
+    store_row<E>(m, T.m + (size_t)row * D, D, lane);
+    store_row<E>(v, T.v + (size_t)row * D, D, lane);
+    if (lane == 0) T.last[row] = upto;
+}
+
+#define FR_DISPATCH_E(D, ...)                          \
+    switch (((D) + 63) / 64) {                         \
+        case 1: { constexpr int E = 1; __VA_ARGS__; } break;  \
+        case 2: { constexpr int E = 2; __VA_ARGS__; } break;  \
+        case 3: { constexpr int E = 3; __VA_ARGS__; } break;  \
+        default: { constexpr int E = 4; __VA_ARGS__; } break; \
+    }
+
+
+}  // namespace fr

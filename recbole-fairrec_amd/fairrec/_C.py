@@ -49,6 +49,11 @@ _PROTOS = {
     "fr_table_flush": (c_int, [POINTER(FrTable), POINTER(FrAdam), c_void_p]),
     "fr_table_gather": (c_int, [POINTER(FrTable), POINTER(FrAdam), c_void_p, c_int64, c_void_p, c_void_p,
                                 c_void_p]),
+    "fr_table_train_workspace_bytes": (c_size_t, [c_int64, c_int32]),
+    "fr_table_gather_train": (c_int, [POINTER(FrTable), POINTER(FrAdam), c_void_p, c_int64, c_void_p, c_void_p,
+                                      c_size_t, c_void_p, c_void_p]),
+    "fr_table_apply_grad": (c_int, [POINTER(FrTable), POINTER(FrAdam), c_int64, c_void_p, c_void_p, c_int32,
+                                    c_void_p, c_size_t, c_void_p]),
     "fr_prof_enable": (c_int, [c_int]),
     "fr_prof_reset": (c_int, []),
     "fr_prof_kernel_count": (c_int, []),

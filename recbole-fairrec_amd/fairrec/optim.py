@@ -72,7 +72,9 @@ class LazyTable:
         self.trainable = trainable
         self.step = 0            # optimizer steps applied so far (torch: state['step'])
         self.m = self.v = self.last = self.stamp = None
-        self._dummy = None
+        self._ws = None
+        self._pending = None
+        self._grad_rows = None
 
     def ensure_state(self):
         dev = self.weight.device
@@ -109,6 +111,46 @@ class LazyTable:
                                           out.data_ptr(), _C.ptr(err_flag), _C.current_stream()), "fr_table_gather")
         return out
 
+    # --- generic training pair (models with an MLP between the embeddings and the loss) -----------------
+    def gather_train(self, hyper: AdamHyper, idx: torch.Tensor, err_flag: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """fr_table_gather_train for step `self.step + 1`: caught-up rows [M, dim]; remembers the batch so that
+        `apply_grad` can finish the step."""
+        idx = idx.contiguous()
+        M = idx.numel()
+        need = _C.lib().fr_table_train_workspace_bytes(M, self.dim)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.weight.device)
+        rows = torch.empty((M, self.dim), dtype=torch.float32, device=self.weight.device)
+        t = self.c(self.step + 1)
+        hyper.check_step(self.step + 1)
+        _C.check(_C.lib().fr_table_gather_train(ctypes.byref(t), ctypes.byref(hyper.c()), idx.data_ptr(), M,
+                                                rows.data_ptr(), self._ws.data_ptr(), self._ws.numel(),
+                                                _C.ptr(err_flag), _C.current_stream()), "fr_table_gather_train")
+        self._pending = (M, rows)
+        self._grad_rows = None
+        return rows
+
+    def apply_grad(self, hyper: AdamHyper, grad_rows: Optional[torch.Tensor] = None, sweep_period: int = 0):
+        """fr_table_apply_grad: duplicate-summed gradient + Adam step `self.step + 1` + sweeper slice."""
+        if self._pending is None:
+            raise _C.FairrecError("apply_grad without a preceding gather_train")
+        M, rows = self._pending
+        g = grad_rows if grad_rows is not None else self._grad_rows
+        if g is None:
+            raise _C.FairrecError("no gradient reached the gathered rows (loss.backward() not called?)")
+        g = g.contiguous()
+        assert g.shape == rows.shape and g.dtype == torch.float32
+        t = self.c(self.step + 1)
+        _C.check(_C.lib().fr_table_apply_grad(ctypes.byref(t), ctypes.byref(hyper.c()), M, rows.data_ptr(),
+                                              g.data_ptr(), int(sweep_period), self._ws.data_ptr(),
+                                              self._ws.numel(), _C.current_stream()), "fr_table_apply_grad")
+        self.step += 1
+        self._pending = None
+        self._grad_rows = None
+
+    def default_sweep(self, M: int) -> int:
+        return max(8, math.ceil(self.n_rows / max(M, 1)))
+
     # --- interchange with torch.optim.Adam.state_dict() (trainer.py:221-240 checkpoints) ---------------
     def adam_state(self, hyper: AdamHyper) -> Dict[str, torch.Tensor]:
         self.flush(hyper)
@@ -120,6 +162,23 @@ class LazyTable:
         self.m.copy_(state["exp_avg"])
         self.v.copy_(state["exp_avg_sq"])
         self.last.fill_(self.step)
+
+
+class LazyLookup(torch.autograd.Function):
+    """rows = table[idx] as a differentiable torch tensor: forward = fr_table_gather_train, backward parks
+    dLoss/drows in the table; the optimizer's step() then runs fr_table_apply_grad.  The dense [N, D] gradient
+    of nn.Embedding is never built."""
+
+    @staticmethod
+    def forward(ctx, weight, table, hyper, idx, err_flag):
+        ctx.table = table
+        return table.gather_train(hyper, idx, err_flag)
+
+    @staticmethod
+    def backward(ctx, grad_rows):
+        t = ctx.table
+        t._grad_rows = grad_rows if t._grad_rows is None else t._grad_rows + grad_rows
+        return None, None, None, None, None
 
 
 class FusedLazyAdam:

@@ -104,3 +104,41 @@ def test_flush_matches_dense_torch_adam_with_zero_grads():
     np.testing.assert_allclose(tab.weight.cpu().numpy(), ref.detach().numpy(), rtol=1e-4, atol=1e-6)
     np.testing.assert_allclose(tab.m.cpu().numpy(), opt.state[ref]["exp_avg"].numpy(), rtol=1e-4, atol=1e-9)
     assert int(tab.last.min()) == 151
+
+
+@pytest.mark.parametrize("case", ["focf_none", "focf_value", "focf_value_grouped", "focf_value_d128", "focf_value_long"])
+def test_generic_table_ops_match_reference_golden(case):
+    """gather_train -> torch autograd of the oracle's loss ON THE GPU -> apply_grad reproduces the reference's
+    training trajectory: pins the generic lazy-table pair independently of the fused FOCF kernels."""
+    import os
+    from fairrec.optim import AdamHyper, LazyLookup, LazyTable
+    from oracle import focf as O
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", case + ".npz"))
+    lr, wd, fw = (float(x) for x in z["hyper"][:3])
+    hyper = AdamHyper(lr=lr, weight_decay=wd, device="cuda")
+    Uw = torch.nn.Parameter(torch.tensor(z["U0"], device="cuda"))
+    Iw = torch.nn.Parameter(torch.tensor(z["I0"], device="cuda"))
+    U, I = LazyTable(Uw.data), LazyTable(Iw.data)
+    err = torch.zeros(1, dtype=torch.int32, device="cuda")
+    snaps = set(int(s) for s in z["snaps"])
+    losses = []
+    for t in range(z["user_id"].shape[0]):
+        u, i, r, s = (torch.tensor(z[k][t], device="cuda") for k in ("user_id", "item_id", "rating", "sst"))
+        ue = LazyLookup.apply(Uw, U, hyper, u, err)
+        ie = LazyLookup.apply(Iw, I, hyper, i, err)
+        pred = (ue * ie).sum(-1)
+        loss = torch.nn.functional.mse_loss(pred, r)
+        if str(z["objective"]) != "none":
+            loss = loss + fw * O.fairness_term(str(z["objective"]), pred, r, s, i)
+        losses.append(float(loss.detach()))
+        loss.backward()
+        U.apply_grad(hyper, sweep_period=3)
+        I.apply_grad(hyper, sweep_period=0)
+        if (t + 1) in snaps:
+            U.flush(hyper)
+            I.flush(hyper)
+            for tag, tab in (("U", U), ("I", I)):
+                a, b = tab.weight.cpu().numpy(), z[f"{tag}_after{t + 1}"]
+                assert (np.abs(a - b) <= 1e-4 * np.abs(b) + 1e-6).all(), (tag, t + 1, np.abs(a - b).max())
+    np.testing.assert_allclose(losses, z["loss"], rtol=1e-4)
+    assert int(err.item()) == 0
