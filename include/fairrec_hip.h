@@ -42,6 +42,8 @@ extern "C" {
 #define FR_DEV_ERR_INDEX_RANGE 1u   /* a row id was <0 or >= n_rows (reference: IndexError in F.embedding) */
 #define FR_DEV_ERR_SST_GROUPS 2u    /* >2 distinct sensitive values in one batch (reference: IndexError at focf.py:86) */
 
+#define FR_DEV_ERR_BUCKET_OVERFLOW 4u /* a per-owner exchange bucket exceeded its fixed capacity (raise shard_capacity) */
+
 /* FOCF fairness objectives -- FOCF.get_loss_fun, focf.py:50-68 */
 enum fr_focf_objective {
     FR_FOCF_NONE = 0, FR_FOCF_VALUE = 1, FR_FOCF_ABSOLUTE = 2, FR_FOCF_UNDER = 3, FR_FOCF_OVER = 4,
@@ -159,6 +161,39 @@ FR_API int fr_table_gather_train(const fr_table* t, const fr_adam* adam, const i
                                  float* rows_out, void* ws, size_t ws_bytes, uint32_t* err_flag, void* stream);
 FR_API int fr_table_apply_grad(const fr_table* t, const fr_adam* adam, int64_t M, const float* rows,
                                const float* grad_rows, int32_t sweep_period, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- row-sharded tables (multi-GPU) -----------------------------------------------------
+ * owner(row) = row mod G, local row = row div G.  All exchange buffers have the fixed shape [G, cap] slots so
+ * that a step needs no host sync; -1 ids are padding (ignored by fr_sort_segments / fr_table_gather_train). */
+FR_API int fr_bucket_by_owner(const int64_t* idx, int64_t M, int32_t G, int32_t cap, int64_t* send_ids,
+                              int32_t* slot_of, int32_t* counts, uint32_t* err_flag, void* stream);
+/* out[j,:] = src[slot_of[j],:]  (reply buffer in slot order -> batch order) */
+FR_API int fr_unbucket_rows(const float* src, const int32_t* slot_of, int64_t M, int32_t dim, float* out, void* stream);
+/* dst[slot_of[j],:] = scale[j] * src[j,:]  (batch order -> slot order; scale may be NULL; dst pre-zeroed) */
+FR_API int fr_bucket_rows(const float* src, const float* scale, const int32_t* slot_of, int64_t M, int32_t dim,
+                          float* dst, void* stream);
+
+/*
+ * Row-sharded FOCF step (one rank's share of focf.py:152-169 on the GLOBAL batch = concatenation of all ranks'
+ * batches).  Requester side works on the rows returned by the owners ([G*cap, dim] slot order):
+ *   fr_focf_shard_score : pred, MSE part of dLoss/dpred (2(pred-r)/n_global), sum of squared errors, and the
+ *                         (pred, rating, sst) records in item-slot order for the item owners   (rec = [3][n_slots])
+ *   fr_focf_shard_fair  : on the item OWNER, over the segments fr_table_gather_train left in the item table's
+ *                         workspace: per-item group statistics of the received records -> fairness part of
+ *                         dLoss/dpred per slot, NOT yet divided by K (sums[0] = sum of smooth-L1 terms; K = sum of
+ *                         the owners' segment counts, known after an all-reduce)
+ *   fr_focf_shard_grads : gradient rows c*ie / c*ue written in user-slot / item-slot order for the owners
+ */
+FR_API int fr_focf_shard_score(const float* rows_u, const float* rows_i, const int32_t* slot_u, const int32_t* slot_i,
+                               const float* rating, const float* sst, int64_t B, int32_t dim, int64_t n_global,
+                               float* pred, float* coef, float* rec, int64_t n_slots, float* sq_err_sum,
+                               float* scratch, void* stream);
+FR_API int fr_focf_shard_fair(void* item_ws, size_t ws_bytes, int64_t n_slots, int32_t dim, const float* rec,
+                              const float* minmax, int32_t objective, float fair_weight, float* coef_slots,
+                              float* sums, float* scratch, uint32_t* err_flag, void* stream);
+FR_API int fr_focf_shard_grads(const float* rows_u, const float* rows_i, const int32_t* slot_u, const int32_t* slot_i,
+                               const float* coef, const float* coef_slots, const float* inv_k, int64_t B, int32_t dim,
+                               float* grad_u_slots, float* grad_i_slots, void* stream);
 
 /* Dense fused Adam step for small dense parameters (MLP weights, biases): one step of
  * torch.optim.Adam on a flat fp32 tensor, `step` = the step being applied. */

@@ -157,23 +157,33 @@ __device__ __forceinline__ float smooth_l1(float x) {  // F.smooth_l1_loss(|x|, 
     return a < 1.f ? 0.5f * a * a : a - 0.5f;
 }
 
-__global__ __launch_bounds__(FAIR_THREADS) void focf_fair_kernel(FocfWs w, const float* __restrict__ rating,
-                                                                 const float* __restrict__ sst, int B, int objective,
-                                                                 float fair_weight, uint32_t* err) {
+// Segment arrays + member columns of the fairness term.  Single GPU: members are batch positions; sharded:
+// members are exchange-buffer slots on the item's owner rank and `pred/rating/sst` are the received records.
+struct FairArgs {
+    const int32_t *perm, *seg_start, *nseg;
+    const float* minmax;       // [2] min / max of the sst column over the (global) batch
+    const float *pred, *rating, *sst;
+    float* coef;               // dLoss/dpred of every member
+    float* fair_part;          // [gridDim.x] partial sums of the smooth-L1 terms
+    int accumulate;            // 1: coef[b] += g, 0: coef[b] = g
+};
+
+__global__ __launch_bounds__(FAIR_THREADS) void focf_fair_kernel(FairArgs w, int objective, float fair_weight,
+                                                                 int defer_k, uint32_t* err) {
     const int sub = threadIdx.x & (FAIR_GROUP - 1);
     const int gib = threadIdx.x / FAIR_GROUP;
     const int k = blockIdx.x * (FAIR_THREADS / FAIR_GROUP) + gib;
-    const int K = w.nseg_i[0];
-    const float smin = w.sst_minmax[0], smax = w.sst_minmax[1];
+    const int K = w.nseg[0];
+    const float smin = w.minmax[0], smax = w.minmax[1];
     __shared__ float red[FAIR_THREADS / FAIR_GROUP];
     float term = 0.f;
     if (k < K) {
-        const int j0 = w.seg_start_i[k], j1 = w.seg_start_i[k + 1];
+        const int j0 = w.seg_start[k], j1 = w.seg_start[k + 1];
         float sp0 = 0.f, sp1 = 0.f, st0 = 0.f, st1 = 0.f, n0 = 0.f, n1 = 0.f;
         bool bad = false;
         for (int j = j0 + sub; j < j1; j += FAIR_GROUP) {
-            const int b = w.perm_i[j];
-            const float s = sst[b], pr = w.pred[b], r = rating[b];
+            const int b = w.perm[j];
+            const float s = w.sst[b], pr = w.pred[b], r = w.rating[b];
             bad |= (s != smin && s != smax);
             if (s == smin) {
                 sp0 += pr; st0 += r; n0 += 1.f;
@@ -205,11 +215,13 @@ __global__ __launch_bounds__(FAIR_THREADS) void focf_fair_kernel(FocfWs w, const
         const float x = fabsf(delta);
         term = smooth_l1(x);
         const float sgn = delta > 0.f ? 1.f : (delta < 0.f ? -1.f : 0.f);
-        const float dx = (x < 1.f ? x : 1.f) * sgn * fair_weight / (float)K;  // d(fw * mean_k sl1)/d delta
+        // d(fw * mean_k sl1)/d delta; sharded: K is only known after an all-reduce, the requester divides later
+        const float dx = (x < 1.f ? x : 1.f) * sgn * fair_weight / (defer_k ? 1.f : (float)K);
         const float g0 = dx * q0 / c0, g1 = -dx * q1 / c1;
         for (int j = j0 + sub; j < j1; j += FAIR_GROUP) {
-            const int b = w.perm_i[j];
-            w.coef[b] += (sst[b] == smin) ? g0 : g1;
+            const int b = w.perm[j];
+            const float g = (w.sst[b] == smin) ? g0 : g1;
+            w.coef[b] = w.accumulate ? w.coef[b] + g : g;
         }
     }
     if (sub == 0) red[gib] = term;
@@ -313,6 +325,85 @@ __global__ __launch_bounds__(256) void focf_backward_adam_kernel(TableV U, Table
                           w.side[5], w.side[0], lane);
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// row-sharded FOCF (multi-GPU): requester-side scoring / gradient rows, owner-side fairness statistics
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void focf_shard_score_kernel(const float* __restrict__ rows_u,
+                                                               const float* __restrict__ rows_i,
+                                                               const int32_t* __restrict__ slot_u,
+                                                               const int32_t* __restrict__ slot_i,
+                                                               const float* __restrict__ rating,
+                                                               const float* __restrict__ sst, int B, int D,
+                                                               float inv_n, float* __restrict__ pred,
+                                                               float* __restrict__ coef, float* __restrict__ rec,
+                                                               long long n_slots, float* __restrict__ part) {
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    const int b = blockIdx.x * 4 + wib;
+    __shared__ float red[4];
+    float e2 = 0.f;
+    if (b < B) {
+        const int su = uniform(slot_u[b]), si = uniform(slot_i[b]);
+        float dot = 0.f;
+        if (su >= 0 && si >= 0)
+            for (int d = lane; d < D; d += 64) dot = fmaf(rows_u[(size_t)su * D + d], rows_i[(size_t)si * D + d], dot);
+        dot = wave_sum(dot);
+        const float r = rating[b];
+        const float er = dot - r;
+        e2 = er * er;
+        if (lane == 0) {
+            pred[b] = dot;
+            coef[b] = 2.f * er * inv_n;
+            if (rec && si >= 0) {
+                rec[si] = dot;
+                rec[n_slots + si] = r;
+                rec[2 * n_slots + si] = sst ? sst[b] : 0.f;
+            }
+        }
+    }
+    if (lane == 0) red[wib] = e2;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
+}
+
+// out[0] = sum(part[0..n)) in index order (one block); out[1] = *count when given
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __restrict__ part, int n,
+                                                              float* __restrict__ out,
+                                                              const int32_t* __restrict__ count) {
+    __shared__ float red[4];
+    float a = 0.f;
+    for (int q = threadIdx.x; q < n; q += 256) a += part[q];
+    a = wave_sum(a);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        out[0] = ((red[0] + red[1]) + red[2]) + red[3];
+        if (count) out[1] = (float)count[0];
+    }
+}
+
+__global__ __launch_bounds__(256) void focf_shard_grads_kernel(const float* __restrict__ rows_u,
+                                                               const float* __restrict__ rows_i,
+                                                               const int32_t* __restrict__ slot_u,
+                                                               const int32_t* __restrict__ slot_i,
+                                                               const float* __restrict__ coef,
+                                                               const float* __restrict__ coef_slots,
+                                                               const float* __restrict__ inv_k, int B, int D,
+                                                               float* __restrict__ grad_u, float* __restrict__ grad_i) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const int su = uniform(slot_u[b]), si = uniform(slot_i[b]);
+    if (su < 0 || si < 0) return;
+    float c = coef[b];
+    if (coef_slots) c += coef_slots[si] * (inv_k ? inv_k[0] : 1.f);
+    for (int d = lane; d < D; d += 64) {
+        const float ue = rows_u[(size_t)su * D + d], ie = rows_i[(size_t)si * D + d];
+        grad_u[(size_t)su * D + d] = c * ie;   // product rounded once: the owner adds the rows of duplicates
+        grad_i[(size_t)si * D + d] = c * ue;
+    }
+}
+
 }  // namespace fr
 
 using namespace fr;
@@ -376,8 +467,9 @@ extern "C" int fr_focf_forward(const fr_table* U, const fr_table* I, const fr_ad
     } else if (objective != FR_FOCF_NONE) {
         {
             ProfScope prof(K_FOCF_FAIR, stream);
-            hipLaunchKernelGGL(focf_fair_kernel, dim3(w.n_fair_blocks), dim3(FAIR_THREADS), 0, stream, w, rating, sst,
-                               (int)B, objective, fair_weight, err_flag);
+            FairArgs fa{w.perm_i, w.seg_start_i, w.nseg_i, w.sst_minmax, w.pred, rating, sst, w.coef, w.fair_part, 1};
+            hipLaunchKernelGGL(focf_fair_kernel, dim3(w.n_fair_blocks), dim3(FAIR_THREADS), 0, stream, fa, objective,
+                               fair_weight, 0, err_flag);
         }
         FR_CHECK_LAUNCH();
     }
@@ -438,3 +530,63 @@ extern "C" int fr_focf_predict(const fr_table* U, const fr_table* I, const fr_ad
     return FR_OK;
 }
 
+
+extern "C" int fr_focf_shard_score(const float* rows_u, const float* rows_i, const int32_t* slot_u,
+                                   const int32_t* slot_i, const float* rating, const float* sst, int64_t B,
+                                   int32_t dim, int64_t n_global, float* pred, float* coef, float* rec,
+                                   int64_t n_slots, float* sq_err_sum, float* scratch, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    FR_CHECK_ARG(rows_u && rows_i && slot_u && slot_i && rating && pred && coef && sq_err_sum && scratch && B >= 1 &&
+                     dim >= 1 && n_global >= B,
+                 "fr_focf_shard_score: bad argument");
+    const int blocks = (int)((B + 3) / 4);
+    {
+        ProfScope prof(K_FOCF_SHARD_SCORE, stream);
+        hipLaunchKernelGGL(focf_shard_score_kernel, dim3(blocks), dim3(256), 0, stream, rows_u, rows_i, slot_u, slot_i,
+                           rating, sst, (int)B, (int)dim, 1.f / (float)n_global, pred, coef, rec, (long long)n_slots,
+                           scratch);
+    }
+    FR_CHECK_LAUNCH();
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, stream, scratch, blocks, sq_err_sum,
+                       (const int32_t*)nullptr);
+    FR_CHECK_LAUNCH();
+    return FR_OK;
+}
+
+extern "C" int fr_focf_shard_fair(void* item_ws, size_t ws_bytes, int64_t n_slots, int32_t dim, const float* rec,
+                                  const float* minmax, int32_t objective, float fair_weight, float* coef_slots,
+                                  float* sums, float* scratch, uint32_t* err_flag, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    FR_CHECK_ARG(item_ws && rec && minmax && coef_slots && sums && scratch && n_slots >= 1, "fr_focf_shard_fair: bad argument");
+    FR_CHECK_ARG(objective >= FR_FOCF_VALUE && objective <= FR_FOCF_OVER,
+                 "fr_focf_shard_fair: objective %d has no per-item statistics", objective);
+    TableWs tw = table_layout(item_ws, n_slots, dim);
+    FR_CHECK_ARG(ws_bytes >= tw.bytes, "fr_focf_shard_fair: workspace too small");
+    const int blocks = (int)((n_slots * FAIR_GROUP + FAIR_THREADS - 1) / FAIR_THREADS);
+    FR_CHECK_HIP(hipMemsetAsync(coef_slots, 0, (size_t)n_slots * 4, stream));
+    {
+        ProfScope prof(K_FOCF_FAIR, stream);
+        FairArgs fa{tw.perm, tw.seg_start, tw.nseg, minmax, rec, rec + n_slots, rec + 2 * n_slots, coef_slots, scratch, 0};
+        hipLaunchKernelGGL(focf_fair_kernel, dim3(blocks), dim3(FAIR_THREADS), 0, stream, fa, objective, fair_weight, 1,
+                           err_flag);
+    }
+    FR_CHECK_LAUNCH();
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, stream, scratch, blocks, sums,
+                       (const int32_t*)tw.nseg);
+    FR_CHECK_LAUNCH();
+    return FR_OK;
+}
+
+extern "C" int fr_focf_shard_grads(const float* rows_u, const float* rows_i, const int32_t* slot_u,
+                                   const int32_t* slot_i, const float* coef, const float* coef_slots,
+                                   const float* inv_k, int64_t B, int32_t dim, float* grad_u_slots,
+                                   float* grad_i_slots, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    FR_CHECK_ARG(rows_u && rows_i && slot_u && slot_i && coef && grad_u_slots && grad_i_slots && B >= 1 && dim >= 1,
+                 "fr_focf_shard_grads: bad argument");
+    ProfScope prof(K_FOCF_SHARD_GRADS, stream);
+    hipLaunchKernelGGL(focf_shard_grads_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, stream, rows_u, rows_i,
+                       slot_u, slot_i, coef, coef_slots, inv_k, (int)B, (int)dim, grad_u_slots, grad_i_slots);
+    FR_CHECK_LAUNCH();
+    return FR_OK;
+}

@@ -22,7 +22,9 @@ void set_error(const char* fmt, ...) {
 static const char* const kKernelNames[K_COUNT] = {
     "sort_segments_kernel", "focf_gather_kernel",     "focf_fair_kernel",    "focf_nonparity_kernel",
     "focf_finalize_kernel", "focf_backward_adam_kernel", "table_flush_kernel", "table_gather_kernel",
-    "adam_dense_kernel",    "table_gather_train_kernel", "table_apply_grad_kernel"};
+    "adam_dense_kernel",    "table_gather_train_kernel", "table_apply_grad_kernel",
+    "bucket_by_owner_kernel", "unbucket_rows_kernel",     "bucket_rows_kernel",
+    "focf_shard_score_kernel", "focf_shard_grads_kernel"};
 
 struct ProfState {
     bool on = false;

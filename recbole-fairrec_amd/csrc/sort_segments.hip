@@ -78,7 +78,9 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_segments_kernel(SortJob job
         unsigned long long k = ~0ull;
         if (j < M) {
             long long r = job.idx[j];
-            if (r < 0 || r >= job.n_rows) {
+            if (r == -1) {
+                r = 0xFFFFFFFFll;   // padding slot ("hole"): sorts behind every real row, belongs to no segment
+            } else if (r < 0 || r >= job.n_rows) {
                 bad = true;
                 r = 0;
             }
@@ -186,7 +188,11 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_segments_kernel(SortJob job
         const unsigned long long k = keys[j];
         const unsigned long long kp = j > 0 ? keys[j - 1] : ~k;
         key[q] = k;
-        const bool head = j < M && (j == 0 || (unsigned)(k >> 32) != (unsigned)(kp >> 32));
+        const bool valid = (unsigned)(k >> 32) != 0xFFFFFFFFu;
+        const bool head = j < M && valid && (j == 0 || (unsigned)(k >> 32) != (unsigned)(kp >> 32));
+        // exactly one thread sees the end of the real keys (first hole / sentinel, or the end of the array)
+        if (!valid && (j == 0 || (unsigned)(kp >> 32) != 0xFFFFFFFFu)) scratch[17] = j;
+        if (valid && j == P - 1) scratch[17] = P;
         bal[q] = __ballot(head);
         if (lane == 0) wcnt[q * 16 + wid] = __popcll(bal[q]);
     }
@@ -223,8 +229,8 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_segments_kernel(SortJob job
 #pragma unroll
     for (int q = 0; q < KPT; ++q) {
         const int j = q * SORT_THREADS + tid;
-        if (j < M) {
-            const unsigned long long k = key[q];
+        const unsigned long long k = key[q];
+        if (j < M && (unsigned)(k >> 32) != 0xFFFFFFFFu) {
             const int seg = wcnt[q * 16 + wid] + __popcll(bal[q] & (lt_mask | (1ull << lane))) - 1;
             const int b = (int)(unsigned)k;
             job.perm[j] = b;
@@ -236,7 +242,7 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_segments_kernel(SortJob job
         }
     }
     if (tid == 0) {
-        job.seg_start[total] = M;
+        job.seg_start[total] = scratch[17];   // number of real (non-padding) ids
         job.n_seg[0] = total;
     }
     SORT_STAMP(14);

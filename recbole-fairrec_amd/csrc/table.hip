@@ -61,31 +61,6 @@ __global__ __launch_bounds__(256) void adam_dense_kernel(float* __restrict__ p, 
 // ------------------------------------------------------------------------------------------------
 // generic training pair
 // ------------------------------------------------------------------------------------------------
-struct TableWs {
-    int32_t *perm, *seg_start, *seg_row, *nseg;
-    float *m_side, *v_side;   // [M, D] caught-up moments of the gathered rows
-    size_t bytes;
-};
-
-static TableWs table_layout(void* base, int64_t M, int D) {
-    TableWs w;
-    size_t off = 0;
-    auto take = [&](size_t nbytes) {
-        void* p = base ? (void*)((char*)base + off) : nullptr;
-        off = align_up(off + nbytes, 256);
-        return p;
-    };
-    const size_t Mp = (size_t)M + 1;
-    w.perm = (int32_t*)take(Mp * 4);
-    w.seg_start = (int32_t*)take(Mp * 4);
-    w.seg_row = (int32_t*)take(Mp * 4);
-    w.nseg = (int32_t*)take(4);
-    w.m_side = (float*)take((size_t)M * D * 4);
-    w.v_side = (float*)take((size_t)M * D * 4);
-    w.bytes = off;
-    return w;
-}
-
 template <int E>
 __global__ __launch_bounds__(256) void table_gather_train_kernel(TableV T, AdamC c, const int64_t* __restrict__ idx,
                                                                  long long M, float* __restrict__ rows_out, TableWs w,
@@ -94,12 +69,19 @@ __global__ __launch_bounds__(256) void table_gather_train_kernel(TableV T, AdamC
     const long long j = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (j >= M) return;
     long long r = idx[j];
+    const int D = T.D;
+    if (r == -1) {   // padding slot of a fixed-capacity exchange buffer: no row, zero output
+        RowFrag<E> z;
+#pragma unroll
+        for (int e = 0; e < E; ++e) z.x[e] = 0.f;
+        store_row<E>(z, rows_out + (size_t)j * D, D, lane);
+        return;
+    }
     if (r < 0 || r >= T.n_rows) {
         if (lane == 0 && err) atomicOr(err, FR_DEV_ERR_INDEX_RANGE);
         r = 0;
     }
     const int row = uniform((int)r);
-    const int D = T.D;
     const int t0 = uniform(T.last[row]);
     RowFrag<E> p, m, v;
     load_row<E>(p, T.p + (size_t)row * D, D, lane);

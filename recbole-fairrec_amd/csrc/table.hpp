@@ -66,6 +66,32 @@ __device__ __forceinline__ void sweep_row(const TableV& T, const AdamC& c, long 
     if (lane == 0) T.last[row] = upto;
 }
 
+// Workspace of the generic training pair (fr_table_gather_train / fr_table_apply_grad).
+struct TableWs {
+    int32_t *perm, *seg_start, *seg_row, *nseg;
+    float *m_side, *v_side;   // [M, D] caught-up moments of the gathered rows
+    size_t bytes;
+};
+
+inline TableWs table_layout(void* base, int64_t M, int D) {
+    TableWs w;
+    size_t off = 0;
+    auto take = [&](size_t nbytes) {
+        void* p = base ? (void*)((char*)base + off) : nullptr;
+        off = align_up(off + nbytes, 256);
+        return p;
+    };
+    const size_t Mp = (size_t)M + 1;
+    w.perm = (int32_t*)take(Mp * 4);
+    w.seg_start = (int32_t*)take(Mp * 4);
+    w.seg_row = (int32_t*)take(Mp * 4);
+    w.nseg = (int32_t*)take(4);
+    w.m_side = (float*)take((size_t)M * D * 4);
+    w.v_side = (float*)take((size_t)M * D * 4);
+    w.bytes = off;
+    return w;
+}
+
 #define FR_DISPATCH_E(D, ...)                          \
     switch (((D) + 63) / 64) {                         \
         case 1: { constexpr int E = 1; __VA_ARGS__; } break;  \

@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libf
 FR_SORT_MAX = 16384
 DEV_ERR_INDEX_RANGE = 1
 DEV_ERR_SST_GROUPS = 2
+DEV_ERR_BUCKET_OVERFLOW = 4
 
 FOCF_OBJECTIVES = {"none": 0, "value": 1, "absolute": 2, "under": 3, "over": 4, "nonparity": 5}
 
@@ -54,6 +55,16 @@ _PROTOS = {
                                       c_size_t, c_void_p, c_void_p]),
     "fr_table_apply_grad": (c_int, [POINTER(FrTable), POINTER(FrAdam), c_int64, c_void_p, c_void_p, c_int32,
                                     c_void_p, c_size_t, c_void_p]),
+    "fr_bucket_by_owner": (c_int, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p,
+                                   c_void_p]),
+    "fr_unbucket_rows": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p]),
+    "fr_bucket_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p]),
+    "fr_focf_shard_score": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32,
+                                    c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
+    "fr_focf_shard_fair": (c_int, [c_void_p, c_size_t, c_int64, c_int32, c_void_p, c_void_p, c_int32, c_float,
+                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "fr_focf_shard_grads": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
+                                    c_int32, c_void_p, c_void_p, c_void_p]),
     "fr_prof_enable": (c_int, [c_int]),
     "fr_prof_reset": (c_int, []),
     "fr_prof_kernel_count": (c_int, []),
