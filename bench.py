@@ -86,6 +86,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--item-dist", default="uniform", choices=["uniform", "zipf"])
     ap.add_argument("--sweep", type=int, default=None, help="lazy-Adam sweep period (default: auto)")
+    ap.add_argument("--force-sharded", action="store_true", help="use the row-sharded engine even on one GPU")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -104,11 +105,24 @@ def main():
     from fairrec.optim import FusedLazyAdam
 
     K, W = args.steps, args.warmup
-    # every rank trains its own B-interaction stream (weak scaling); see DESIGN.md §6 for the sharded variant
+    sharded = world > 1 or args.force_sharded
+    # every rank feeds its own B interactions per step; N > 1: ONE optimizer step on the global batch of
+    # world*B interactions, tables row-sharded over the ranks (fairrec/sharded.py)
     u, i, r, s = (t.to(dev) for t in synth_batches(K + W, BATCH, N_USERS, N_ITEMS, SEED + rank, args.item_dist))
-    U, I = xavier_tables(N_USERS, N_ITEMS, DIM, SEED, dev)
-    eng = FocfEngine(U, I, OBJECTIVE, FAIR_WEIGHT, 5.0)
-    FusedLazyAdam(eng, lr=LR, weight_decay=WD, sweep_period=args.sweep)
+    if not sharded:
+        U, I = xavier_tables(N_USERS, N_ITEMS, DIM, SEED, dev)
+        eng = FocfEngine(U, I, OBJECTIVE, FAIR_WEIGHT, 5.0)
+        FusedLazyAdam(eng, lr=LR, weight_decay=WD, sweep_period=args.sweep)
+    else:
+        from fairrec.sharded import ShardedFocfEngine, shard_rows
+        if not torch.distributed.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29655")
+            torch.distributed.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        g = torch.Generator(device="cpu").manual_seed(SEED + 1 + 1000 * rank)
+        Us = (torch.randn(shard_rows(N_USERS, rank, world), DIM, generator=g) * math.sqrt(2.0 / (N_USERS + DIM))).to(dev)
+        Is = (torch.randn(shard_rows(N_ITEMS, rank, world), DIM, generator=g) * math.sqrt(2.0 / (N_ITEMS + DIM))).to(dev)
+        eng = ShardedFocfEngine(Us, Is, OBJECTIVE, FAIR_WEIGHT, LR, WD, sweep_period=args.sweep)
 
     def step(k):
         eng.forward(u[k], i[k], r[k], s[k])
@@ -124,14 +138,22 @@ def main():
     barrier()
 
     graph = None
-    if not args.no_graph:
+    if not args.no_graph:   # K steps (kernels and, when sharded, the RCCL collectives) captured in one hipGraph
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.stream(side):
-            with torch.cuda.graph(graph, stream=side):
-                for k in range(W, W + K):
-                    step(k)
+        try:
+            with torch.cuda.stream(side):
+                with torch.cuda.graph(graph, stream=side):
+                    for k in range(W, W + K):
+                        step(k)
+        except Exception as e:   # e.g. a collective that refuses capture: fall back to eager launches
+            if not sharded:
+                raise
+            print(f"[bench] graph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
+            graph = None
+            torch.cuda.synchronize()
+            eng2_steps = eng.U.step   # the capture attempt advanced the host-side step counters; keep them
         torch.cuda.current_stream().wait_stream(side)
 
     barrier()
@@ -148,11 +170,11 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     eng.check_device_errors()
-    loss_last = float(eng.loss_ring[eng.loss_slot][0].item())
+    loss_last = float(eng.loss_ring[eng.loss_slot][0].item()) if not sharded else float("nan")
 
     # ---- per-kernel device time: K more steps, eager, with the library's HIP-event profiler -----------
     roofline = None
-    if rank == 0:
+    if rank == 0 and not sharded:
         u2, i2, r2, s2 = (t.to(dev) for t in synth_batches(K, BATCH, N_USERS, N_ITEMS, SEED + 7919, args.item_dist))
         _C.prof_reset()
         _C.prof_enable(True)
@@ -186,7 +208,9 @@ def main():
             "config": {"workload": "FOCF fair_objective=value, 1000001 users x 100001 items, embedding_size=64, "
                                    "B=8192 per GPU, Adam lr=1e-3 weight_decay=1e-3 (BASELINE.json configs[1])",
                        "item_distribution": args.item_dist, "launch": "eager" if graph is None else "hipGraph",
-                       "lazy_adam_sweep_period": eng._sweep(BATCH), "final_loss": round(loss_last, 6)},
+                       "lazy_adam_sweep_period": eng._sweep(BATCH) if not sharded else args.sweep,
+                       "tables": "row-sharded over %d ranks, RCCL all-to-all" % world if sharded else "single GPU",
+                       "global_batch": BATCH * world, "final_loss": round(loss_last, 6) if not sharded else None},
             "roofline": roofline,
         }
         if not args.no_cpu_baseline and world == 1:
