@@ -153,7 +153,6 @@ def main():
             print(f"[bench] graph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
             graph = None
             torch.cuda.synchronize()
-            eng2_steps = eng.U.step   # the capture attempt advanced the host-side step counters; keep them
         torch.cuda.current_stream().wait_stream(side)
 
     barrier()

@@ -74,12 +74,15 @@ typedef struct fr_table {
 /*
  * Adam hyper-parameters (torch.optim.Adam defaults + lr/weight_decay from trainer.py:131-139) and the
  * per-step scalars torch computes in double on the host (torch/optim/adam.py, _single_tensor_adam):
- *   scalars[2*j]   = (float)(lr / (1 - beta1^j))
- *   scalars[2*j+1] = (float)(1 / sqrt(1 - beta2^j))       for j = 1..cap ; entry 0 unused.
- * Steps beyond `cap` use entry `cap` (the host guarantees both scalars have saturated there).
+ *   scalars[4*j]   = (float)(lr / (1 - beta1^j))                      step_size_j
+ *   scalars[4*j+1] = (float)(1 / sqrt(1 - beta2^j))                   1/sqrt(bias_correction2_j)
+ *   scalars[4*j+2] = (float)(sqrt(k2) * scalars[4j+1] / (step_size_j * k1))   with k1 = (1-beta1)*wd,
+ *   scalars[4*j+3] = (float)(eps / (step_size_j * k1))                         k2 = (1-beta2)*wd^2 (0 when wd = 0)
+ * for j = 1..cap ; entry 0 unused.  Entries 2,3 let a replayed step (gradient = wd*p only) run on scaled moments.
+ * Steps beyond `cap` use entry `cap` (the host guarantees the scalars have saturated there).
  */
 typedef struct fr_adam {
-    const float* scalars;  /* device, float[2*(cap+1)] */
+    const float* scalars;  /* device, float[4*(cap+1)] */
     int32_t cap;
     int32_t reserved_;
     double weight_decay, beta1, beta2, eps; /* doubles: torch derives (1 - beta) in double before the fp32 cast */

@@ -60,6 +60,7 @@ struct AdamC {
     int cap;
     float wd, b1, omb1, b2, omb2, eps;
     float k1, k2;  // (1-beta1)*wd and (1-beta2)*wd^2: a replayed step's gradient is wd*p
+    float inv_k1, inv_k2;
 };
 
 inline AdamC make_adamc(const fr_adam* a) {
@@ -74,6 +75,8 @@ inline AdamC make_adamc(const fr_adam* a) {
     c.eps = (float)a->eps;
     c.k1 = (float)((1.0 - a->beta1) * a->weight_decay);
     c.k2 = (float)((1.0 - a->beta2) * a->weight_decay * a->weight_decay);
+    c.inv_k1 = a->weight_decay != 0.0 ? (float)(1.0 / ((1.0 - a->beta1) * a->weight_decay)) : 0.f;
+    c.inv_k2 = a->weight_decay != 0.0 ? (float)(1.0 / ((1.0 - a->beta2) * a->weight_decay * a->weight_decay)) : 0.f;
     return c;
 }
 
@@ -113,10 +116,27 @@ __device__ __forceinline__ void adam_zero(float& p, float& m, float& v, float ss
 // (scalar cache, no VALU/VMEM work in the replay loop).
 typedef const float __attribute__((address_space(4))) * ConstFPtr;
 
-__device__ __forceinline__ float2 step_scalars(const AdamC& c, int j) {
+// Entry j of the table: (step_size, 1/sqrt(bc2), A, B); A and B drive the scaled replay below.
+__device__ __forceinline__ float4 step_scalars4(const AdamC& c, int j) {
     ConstFPtr sc = (ConstFPtr)c.sc;
-    const int k = 2 * (j < c.cap ? j : c.cap);
-    return make_float2(sc[k], sc[k + 1]);
+    const int k = 4 * (j < c.cap ? j : c.cap);
+    return make_float4(sc[k], sc[k + 1], sc[k + 2], sc[k + 3]);
+}
+
+__device__ __forceinline__ float2 step_scalars(const AdamC& c, int j) {
+    const float4 s = step_scalars4(c, j);
+    return make_float2(s.x, s.y);
+}
+
+// The same replayed step on scaled moments m' = m/k1, v' = v/k2 (k1 = (1-beta1)*wd, k2 = (1-beta2)*wd^2):
+//   m' <- beta1*m' + p ;  v' <- beta2*v' + p^2 ;  p <- p - m' / (sqrt(v')*A_j + B_j)
+// with A_j = sqrt(k2)/(sqrt(bc2_j)*step_size_j*k1), B_j = eps/(step_size_j*k1) from the host table:
+// 5 VALU + sqrt + rcp per element instead of 8 + 2.  Same mathematics, rounding differs by a few ulp.
+__device__ __forceinline__ void adam_zero_scaled(float& p, float& ms, float& vs, float A, float Bc, const AdamC& c) {
+    ms = fmaf(c.b1, ms, p);
+    vs = fmaf(c.b2, vs, p * p);
+    const float den = fmaf(__builtin_amdgcn_sqrtf(vs), A, Bc);
+    p = fmaf(-ms, __builtin_amdgcn_rcpf(den), p);
 }
 
 // A row (or the part of it one lane owns): element e of lane l is column l + 64*e.
@@ -146,38 +166,73 @@ __device__ __forceinline__ void store_row(const RowFrag<E>& f, float* base, int 
 // Replay the zero-data-gradient steps (from, to] on NR row fragments at once (independent chains
 // interleave in the VALU).  `from`/`to` are wave-uniform; scalars of the next 4 steps are fetched
 // (s_load) while the current 4 are applied.
+typedef float float16_t_ __attribute__((ext_vector_type(16)));
+typedef const float16_t_ __attribute__((address_space(4))) * ConstF16Ptr;
+
+template <int E, int NR, bool SCALED>
+__device__ __forceinline__ void replay_loop(RowFrag<E>* (&p)[NR], RowFrag<E>* (&m)[NR], RowFrag<E>* (&v)[NR], int j,
+                                            int to, const AdamC& c) {
+    auto one = [&](float s0, float s1, float s2, float s3) {
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                if (SCALED) adam_zero_scaled(p[r]->x[e], m[r]->x[e], v[r]->x[e], s2, s3, c);
+                else adam_zero(p[r]->x[e], m[r]->x[e], v[r]->x[e], s0, s1, c);
+            }
+        }
+    };
+    // main part: 4 steps per iteration, their 16 scalars fetched by ONE s_load_dwordx16 issued one iteration ahead
+    const int lim = to < c.cap ? to : c.cap;
+    if (j + 3 <= lim) {
+        ConstF16Ptr tab = (ConstF16Ptr)(c.sc + 2 * j);   // c.sc is float2*: entry j starts at float 4*j
+        float16_t_ cur = tab[0];
+        for (; j + 7 <= lim; j += 4) {
+            ++tab;
+            const float16_t_ nxt = tab[0];
+            one(cur[0], cur[1], cur[2], cur[3]);
+            one(cur[4], cur[5], cur[6], cur[7]);
+            one(cur[8], cur[9], cur[10], cur[11]);
+            one(cur[12], cur[13], cur[14], cur[15]);
+            cur = nxt;
+        }
+        one(cur[0], cur[1], cur[2], cur[3]);
+        one(cur[4], cur[5], cur[6], cur[7]);
+        one(cur[8], cur[9], cur[10], cur[11]);
+        one(cur[12], cur[13], cur[14], cur[15]);
+        j += 4;
+    }
+    // remainder (< 4 steps inside the table, and every step beyond `cap`, where the scalars are constant)
+    for (; j <= to; ++j) {
+        const float4 s = step_scalars4(c, j);
+        one(s.x, s.y, s.z, s.w);
+    }
+}
+
 template <int E, int NR>
 __device__ __forceinline__ void replay_n(RowFrag<E>* (&p)[NR], RowFrag<E>* (&m)[NR], RowFrag<E>* (&v)[NR], int from,
                                          int to, const AdamC& c) {
-    int j = from + 1;
-    if (j > to) return;
-    float2 cur[4];
+    if (from >= to) return;
+    if (!FR_ADAM_PRECISE && c.k1 != 0.f) {   // wave-uniform: weight decay on -> scaled moments
 #pragma unroll
-    for (int q = 0; q < 4; ++q) cur[q] = step_scalars(c, j + q);
-    for (; j + 3 <= to; j += 4) {
-        float2 nxt[4];
+        for (int r = 0; r < NR; ++r) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) nxt[q] = step_scalars(c, j + 4 + q);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-#pragma unroll
-            for (int r = 0; r < NR; ++r) {
-#pragma unroll
-                for (int e = 0; e < E; ++e) adam_zero(p[r]->x[e], m[r]->x[e], v[r]->x[e], cur[q].x, cur[q].y, c);
+            for (int e = 0; e < E; ++e) {
+                m[r]->x[e] *= c.inv_k1;
+                v[r]->x[e] *= c.inv_k2;
             }
         }
+        replay_loop<E, NR, true>(p, m, v, from + 1, to, c);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) cur[q] = nxt[q];
-    }
+        for (int r = 0; r < NR; ++r) {
 #pragma unroll
-    for (int q = 0; q < 3; ++q) {
-        if (j + q <= to) {
-#pragma unroll
-            for (int r = 0; r < NR; ++r) {
-#pragma unroll
-                for (int e = 0; e < E; ++e) adam_zero(p[r]->x[e], m[r]->x[e], v[r]->x[e], cur[q].x, cur[q].y, c);
+            for (int e = 0; e < E; ++e) {
+                m[r]->x[e] *= c.k1;
+                v[r]->x[e] *= c.k2;
             }
         }
+    } else {
+        replay_loop<E, NR, false>(p, m, v, from + 1, to, c);
     }
 }
 

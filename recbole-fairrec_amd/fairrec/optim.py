@@ -18,16 +18,25 @@ import torch
 from . import _C
 
 
-def adam_step_scalars(lr: float, beta1: float, beta2: float, cap: int) -> np.ndarray:
-    """float32[2*(cap+1)]: entry j = (lr / (1 - beta1**j), 1 / sqrt(1 - beta2**j)), computed in Python double
-    exactly like torch/optim/adam.py (`bias_correction1 = 1 - beta1 ** step`, `step_size = lr / bias_correction1`,
-    `bias_correction2_sqrt = sqrt(bias_correction2)`) and rounded to fp32 once."""
-    out = np.zeros(2 * (cap + 1), dtype=np.float32)
+def adam_step_scalars(lr: float, beta1: float, beta2: float, cap: int, weight_decay: float = 0.0,
+                      eps: float = 1e-8) -> np.ndarray:
+    """float32[4*(cap+1)]: entry j = (lr / (1 - beta1**j), 1 / sqrt(1 - beta2**j), A_j, B_j), computed in Python
+    double exactly like torch/optim/adam.py (`bias_correction1 = 1 - beta1 ** step`, `step_size = lr /
+    bias_correction1`, `bias_correction2_sqrt = sqrt(bias_correction2)`) and rounded to fp32 once.
+    A_j, B_j (include/fairrec_hip.h) serve the scaled replay of zero-data-gradient steps; 0 when weight_decay = 0."""
+    out = np.zeros(4 * (cap + 1), dtype=np.float32)
+    k1 = (1.0 - beta1) * weight_decay
+    k2 = (1.0 - beta2) * weight_decay * weight_decay
     for j in range(1, cap + 1):
         bc1 = 1.0 - beta1 ** j
         bc2 = 1.0 - beta2 ** j
-        out[2 * j] = lr / bc1
-        out[2 * j + 1] = 1.0 / math.sqrt(bc2)
+        ss = lr / bc1
+        ib = 1.0 / math.sqrt(bc2)
+        out[4 * j] = ss
+        out[4 * j + 1] = ib
+        if weight_decay != 0.0:
+            out[4 * j + 2] = math.sqrt(k2) * ib / (ss * k1)
+            out[4 * j + 3] = eps / (ss * k1)
     return out
 
 
@@ -38,13 +47,13 @@ class AdamHyper:
         self.lr, self.weight_decay, self.betas, self.eps = float(lr), float(weight_decay), tuple(betas), float(eps)
         self.device = torch.device(device)
         while True:
-            tab = adam_step_scalars(self.lr, self.betas[0], self.betas[1], cap)
+            tab = adam_step_scalars(self.lr, self.betas[0], self.betas[1], cap, self.weight_decay, self.eps)
             # steps beyond `cap` reuse entry `cap`: only valid once both scalars stopped changing in fp32
-            if (tab[2 * cap] == np.float32(self.lr) and tab[2 * cap + 1] == np.float32(1.0)) or cap >= (1 << 22):
+            if (tab[4 * cap] == np.float32(self.lr) and tab[4 * cap + 1] == np.float32(1.0)) or cap >= (1 << 22):
                 break
             cap *= 2
         self.cap = cap
-        self.saturated = bool(tab[2 * cap] == np.float32(self.lr) and tab[2 * cap + 1] == np.float32(1.0))
+        self.saturated = bool(tab[4 * cap] == np.float32(self.lr) and tab[4 * cap + 1] == np.float32(1.0))
         self.host_scalars = tab
         self.scalars = torch.from_numpy(tab).to(self.device) if self.device.type == "cuda" else None
         self._c = _C.FrAdam(_C.ptr(self.scalars), cap, 0, self.weight_decay, self.betas[0], self.betas[1], self.eps)

@@ -48,9 +48,9 @@ def test_config_priority_and_missing_keys(tmp_path):
 def test_adam_scalars_match_torch_formula():
     tab = adam_step_scalars(1e-3, 0.9, 0.999, 40000)
     for j in (1, 2, 10, 1000, 20000, 40000):
-        assert tab[2 * j] == np.float32(1e-3 / (1 - 0.9 ** j))
-        assert tab[2 * j + 1] == np.float32(1 / math.sqrt(1 - 0.999 ** j))
-    assert tab[2 * 40000] == np.float32(1e-3) and tab[2 * 40000 + 1] == np.float32(1.0)   # saturated
+        assert tab[4 * j] == np.float32(1e-3 / (1 - 0.9 ** j))
+        assert tab[4 * j + 1] == np.float32(1 / math.sqrt(1 - 0.999 ** j))
+    assert tab[4 * 40000] == np.float32(1e-3) and tab[4 * 40000 + 1] == np.float32(1.0)   # saturated
 
 
 def test_train_dataloader_covers_dataset_once():
