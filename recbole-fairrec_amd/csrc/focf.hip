@@ -31,13 +31,14 @@ struct FocfWs {
     float* coef;         // [B] dLoss/dpred
     float* mse_part;     // [gather blocks]
     float* fair_part;    // [fair blocks]
+    unsigned int* ticket;  // in-launch finalisation counter of the fair kernel (kept zero between launches)
     float* side[6];      // ue, mu, vu, ie, mi, vi : [B, D] each
     int n_gather_blocks, n_fair_blocks;
     size_t bytes;
 };
 
 static constexpr int GATHER_THREADS = 256;  // 4 waves = 4 interactions per block
-static constexpr int FAIR_THREADS = 256;    // 16 lanes per item segment -> 16 segments per block
+static constexpr int FAIR_THREADS = 1024;   // 16 lanes per item segment -> 64 segments per block (few blocks: cheap ticket)
 static constexpr int FAIR_GROUP = 16;
 
 static FocfWs focf_layout(void* base, int64_t B, int D) {
@@ -68,6 +69,7 @@ static FocfWs focf_layout(void* base, int64_t B, int D) {
     if (w.n_fair_blocks < 1) w.n_fair_blocks = 1;
     w.mse_part = (float*)take((size_t)w.n_gather_blocks * 4);
     w.fair_part = (float*)take((size_t)w.n_fair_blocks * 4);
+    w.ticket = (unsigned int*)take(4);
     for (int k = 0; k < 6; ++k) w.side[k] = (float*)take((size_t)B * D * 4);
     w.bytes = off;
     return w;
@@ -145,7 +147,10 @@ __global__ __launch_bounds__(GATHER_THREADS) void focf_gather_kernel(
     if (TRAIN) {
         if (lane == 0) red[wib] = e2;
         __syncthreads();
-        if (threadIdx.x == 0) w.mse_part[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
+        if (threadIdx.x == 0) {
+            w.mse_part[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
+            if (blockIdx.x == 0) *w.ticket = 0u;   // arm the fair kernel's in-launch finalisation (next launch)
+        }
     }
 }
 
@@ -166,6 +171,11 @@ struct FairArgs {
     float* coef;               // dLoss/dpred of every member
     float* fair_part;          // [gridDim.x] partial sums of the smooth-L1 terms
     int accumulate;            // 1: coef[b] += g, 0: coef[b] = g
+    // optional in-launch finalisation by the last block to arrive (single-GPU path): loss = mse + fw * fair
+    unsigned int* ticket;      // zero on entry, reset to zero by the last block; nullptr = no finalisation
+    const float* mse_part;     // [n_mse_part] partial sums of squared errors (written by an EARLIER launch)
+    int n_mse_part, batch;
+    float* loss_out;           // [3] loss, mse, fair
 };
 
 __global__ __launch_bounds__(FAIR_THREADS) void focf_fair_kernel(FairArgs w, int objective, float fair_weight,
@@ -226,11 +236,53 @@ __global__ __launch_bounds__(FAIR_THREADS) void focf_fair_kernel(FairArgs w, int
     }
     if (sub == 0) red[gib] = term;
     __syncthreads();
+    __shared__ int is_last;
     if (threadIdx.x == 0) {
         float s = 0.f;
 #pragma unroll
         for (int q = 0; q < FAIR_THREADS / FAIR_GROUP; ++q) s += red[q];
-        w.fair_part[blockIdx.x] = s;
+        is_last = 0;
+        if (w.ticket) {
+            // publish this block's partial with a write-through (sc1) store -- no L2 write-back fence, the L2s are
+            // full of the gather kernel's dirty lines -- drain it, then draw a ticket; the block that draws the last
+            // one reads every partial with sc1 loads and reduces them in index order, so the loss is
+            // bit-reproducible whatever the arrival order (cdna_hip_programming.md, Guideline 16, sc1 form)
+            __hip_atomic_store(&w.fair_part[blockIdx.x], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned t = __hip_atomic_fetch_add(w.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            is_last = (t == gridDim.x - 1) ? 1 : 0;
+        } else {
+            w.fair_part[blockIdx.x] = s;
+        }
+    }
+    __syncthreads();
+    if (!is_last) return;
+    float a = 0.f, fsum = 0.f;
+    for (int q = threadIdx.x; q < w.n_mse_part; q += FAIR_THREADS) a += w.mse_part[q];
+    for (int q = threadIdx.x; q < (int)gridDim.x; q += FAIR_THREADS)
+        fsum += __hip_atomic_load(&w.fair_part[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    a = wave_sum(a);
+    fsum = wave_sum(fsum);
+    __shared__ float red2[2][FAIR_THREADS / 64];
+    if ((threadIdx.x & 63) == 0) {
+        red2[0][threadIdx.x >> 6] = a;
+        red2[1][threadIdx.x >> 6] = fsum;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        a = 0.f;
+        fsum = 0.f;
+#pragma unroll
+        for (int q = 0; q < FAIR_THREADS / 64; ++q) {
+            a += red2[0][q];
+            fsum += red2[1][q];
+        }
+        const float mse = a / (float)w.batch;
+        const float fair = fsum / (float)K;
+        w.loss_out[0] = mse + fair_weight * fair;
+        w.loss_out[1] = mse;
+        w.loss_out[2] = fair;
+        *w.ticket = 0u;
     }
 }
 
@@ -467,18 +519,19 @@ extern "C" int fr_focf_forward(const fr_table* U, const fr_table* I, const fr_ad
     } else if (objective != FR_FOCF_NONE) {
         {
             ProfScope prof(K_FOCF_FAIR, stream);
-            FairArgs fa{w.perm_i, w.seg_start_i, w.nseg_i, w.sst_minmax, w.pred, rating, sst, w.coef, w.fair_part, 1};
+            FairArgs fa{w.perm_i, w.seg_start_i, w.nseg_i, w.sst_minmax, w.pred, rating, sst, w.coef, w.fair_part, 1,
+                        w.ticket, w.mse_part, w.n_gather_blocks, (int)B, loss_out};
             hipLaunchKernelGGL(focf_fair_kernel, dim3(w.n_fair_blocks), dim3(FAIR_THREADS), 0, stream, fa, objective,
                                fair_weight, 0, err_flag);
         }
         FR_CHECK_LAUNCH();
     }
-    {
+    if (objective == FR_FOCF_NONE || objective == FR_FOCF_NONPARITY) {
         ProfScope prof(K_FOCF_FINALIZE, stream);
         hipLaunchKernelGGL(focf_finalize_kernel, dim3(1), dim3(256), 0, stream, w, (int)B, objective, fair_weight,
                            loss_out);
+        FR_CHECK_LAUNCH();
     }
-    FR_CHECK_LAUNCH();
     if (pred_out) FR_CHECK_HIP(hipMemcpyAsync(pred_out, w.pred, (size_t)B * 4, hipMemcpyDeviceToDevice, stream));
     return FR_OK;
 }
@@ -566,7 +619,8 @@ extern "C" int fr_focf_shard_fair(void* item_ws, size_t ws_bytes, int64_t n_slot
     FR_CHECK_HIP(hipMemsetAsync(coef_slots, 0, (size_t)n_slots * 4, stream));
     {
         ProfScope prof(K_FOCF_FAIR, stream);
-        FairArgs fa{tw.perm, tw.seg_start, tw.nseg, minmax, rec, rec + n_slots, rec + 2 * n_slots, coef_slots, scratch, 0};
+        FairArgs fa{tw.perm, tw.seg_start, tw.nseg, minmax, rec, rec + n_slots, rec + 2 * n_slots, coef_slots, scratch, 0,
+                    nullptr, nullptr, 0, 0, nullptr};
         hipLaunchKernelGGL(focf_fair_kernel, dim3(blocks), dim3(FAIR_THREADS), 0, stream, fa, objective, fair_weight, 1,
                            err_flag);
     }
