@@ -505,14 +505,14 @@ extern "C" int fr_focf_forward(const fr_table* U, const fr_table* I, const fr_ad
     const TableV Uv = view(U), Iv = view(I);
     {
         ProfScope prof(K_FOCF_GATHER, stream);
-        FR_DISPATCH_E(U->dim, focf_gather_kernel<E, true><<<dim3(w.n_gather_blocks), dim3(GATHER_THREADS), 0, stream>>>(Uv, Iv, c, user, item, rating, (int)B, U->step - 1, I->step - 1, w, 0.f, (float*)nullptr, err_flag));
+        FR_DISPATCH_E(U->dim, FR_LAUNCH(prof, (focf_gather_kernel<E, true>), dim3(w.n_gather_blocks), dim3(GATHER_THREADS), 0, stream, Uv, Iv, c, user, item, rating, (int)B, U->step - 1, I->step - 1, w, 0.f, (float*)nullptr, err_flag));
     }
     FR_CHECK_LAUNCH();
     if (overlap) FR_CHECK_HIP(hipStreamWaitEvent(stream, ss->join, 0));
     if (objective == FR_FOCF_NONPARITY) {
         {
             ProfScope prof(K_FOCF_NONPARITY, stream);
-            hipLaunchKernelGGL(focf_nonparity_kernel, dim3(1), dim3(1024), 0, stream, w, sst, (int)B, fair_weight,
+            FR_LAUNCH(prof, focf_nonparity_kernel, dim3(1), dim3(1024), 0, stream, w, sst, (int)B, fair_weight,
                                err_flag);
         }
         FR_CHECK_LAUNCH();
@@ -521,14 +521,14 @@ extern "C" int fr_focf_forward(const fr_table* U, const fr_table* I, const fr_ad
             ProfScope prof(K_FOCF_FAIR, stream);
             FairArgs fa{w.perm_i, w.seg_start_i, w.nseg_i, w.sst_minmax, w.pred, rating, sst, w.coef, w.fair_part, 1,
                         w.ticket, w.mse_part, w.n_gather_blocks, (int)B, loss_out};
-            hipLaunchKernelGGL(focf_fair_kernel, dim3(w.n_fair_blocks), dim3(FAIR_THREADS), 0, stream, fa, objective,
+            FR_LAUNCH(prof, focf_fair_kernel, dim3(w.n_fair_blocks), dim3(FAIR_THREADS), 0, stream, fa, objective,
                                fair_weight, 0, err_flag);
         }
         FR_CHECK_LAUNCH();
     }
     if (objective == FR_FOCF_NONE || objective == FR_FOCF_NONPARITY) {
         ProfScope prof(K_FOCF_FINALIZE, stream);
-        hipLaunchKernelGGL(focf_finalize_kernel, dim3(1), dim3(256), 0, stream, w, (int)B, objective, fair_weight,
+        FR_LAUNCH(prof, focf_finalize_kernel, dim3(1), dim3(256), 0, stream, w, (int)B, objective, fair_weight,
                            loss_out);
         FR_CHECK_LAUNCH();
     }
@@ -554,7 +554,7 @@ extern "C" int fr_focf_backward_adam(const fr_table* U, const fr_table* I, const
     const TableV Uv = view(U), Iv = view(I);
     {
         ProfScope prof(K_FOCF_BWD_ADAM, stream);
-        FR_DISPATCH_E(U->dim, focf_backward_adam_kernel<E><<<dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, stream>>>(Uv, Iv, c, (int)B, w, lo_u, (int)(hi_u - lo_u), lo_i, (int)(hi_i - lo_i)));
+        FR_DISPATCH_E(U->dim, FR_LAUNCH(prof, (focf_backward_adam_kernel<E>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, stream, Uv, Iv, c, (int)B, w, lo_u, (int)(hi_u - lo_u), lo_i, (int)(hi_i - lo_i)));
     }
     FR_CHECK_LAUNCH();
     return FR_OK;
@@ -576,7 +576,7 @@ extern "C" int fr_focf_predict(const fr_table* U, const fr_table* I, const fr_ad
     const unsigned blocks = (unsigned)((B * WAVE + GATHER_THREADS - 1) / GATHER_THREADS);
     {
         ProfScope prof(K_FOCF_GATHER, stream);
-        FR_DISPATCH_E(U->dim, focf_gather_kernel<E, false><<<dim3(blocks), dim3(GATHER_THREADS), 0, stream>>>(Uv, Iv, c, user, item, (const float*)nullptr, (int)B, U->step,
+        FR_DISPATCH_E(U->dim, FR_LAUNCH(prof, (focf_gather_kernel<E, false>), dim3(blocks), dim3(GATHER_THREADS), 0, stream, Uv, Iv, c, user, item, (const float*)nullptr, (int)B, U->step,
                                                   I->step, w, max_rating, out, err_flag));
     }
     FR_CHECK_LAUNCH();
@@ -595,7 +595,7 @@ extern "C" int fr_focf_shard_score(const float* rows_u, const float* rows_i, con
     const int blocks = (int)((B + 3) / 4);
     {
         ProfScope prof(K_FOCF_SHARD_SCORE, stream);
-        hipLaunchKernelGGL(focf_shard_score_kernel, dim3(blocks), dim3(256), 0, stream, rows_u, rows_i, slot_u, slot_i,
+        FR_LAUNCH(prof, focf_shard_score_kernel, dim3(blocks), dim3(256), 0, stream, rows_u, rows_i, slot_u, slot_i,
                            rating, sst, (int)B, (int)dim, 1.f / (float)n_global, pred, coef, rec, (long long)n_slots,
                            scratch);
     }
@@ -621,7 +621,7 @@ extern "C" int fr_focf_shard_fair(void* item_ws, size_t ws_bytes, int64_t n_slot
         ProfScope prof(K_FOCF_FAIR, stream);
         FairArgs fa{tw.perm, tw.seg_start, tw.nseg, minmax, rec, rec + n_slots, rec + 2 * n_slots, coef_slots, scratch, 0,
                     nullptr, nullptr, 0, 0, nullptr};
-        hipLaunchKernelGGL(focf_fair_kernel, dim3(blocks), dim3(FAIR_THREADS), 0, stream, fa, objective, fair_weight, 1,
+        FR_LAUNCH(prof, focf_fair_kernel, dim3(blocks), dim3(FAIR_THREADS), 0, stream, fa, objective, fair_weight, 1,
                            err_flag);
     }
     FR_CHECK_LAUNCH();
@@ -639,7 +639,7 @@ extern "C" int fr_focf_shard_grads(const float* rows_u, const float* rows_i, con
     FR_CHECK_ARG(rows_u && rows_i && slot_u && slot_i && coef && grad_u_slots && grad_i_slots && B >= 1 && dim >= 1,
                  "fr_focf_shard_grads: bad argument");
     ProfScope prof(K_FOCF_SHARD_GRADS, stream);
-    hipLaunchKernelGGL(focf_shard_grads_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, stream, rows_u, rows_i,
+    FR_LAUNCH(prof, focf_shard_grads_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, stream, rows_u, rows_i,
                        slot_u, slot_i, coef, coef_slots, inv_k, (int)B, (int)dim, grad_u_slots, grad_i_slots);
     FR_CHECK_LAUNCH();
     return FR_OK;

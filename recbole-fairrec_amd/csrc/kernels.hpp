@@ -1,6 +1,7 @@
 // Internal (non-ABI) declarations shared between the .hip translation units.
 #pragma once
 #include "common.hpp"
+#include <hip/hip_ext.h>
 
 namespace fr {
 
@@ -11,16 +12,28 @@ enum KernelKind {
     K_BUCKET_ROWS, K_FOCF_SHARD_SCORE, K_FOCF_SHARD_GRADS, K_COUNT
 };
 bool prof_on();
-void* prof_begin(int kind, hipStream_t s);
-void prof_end(void* h, hipStream_t s);
+// Takes an event pair from the profiler's pool and registers it for kernel `kind` (not recorded here: the pair
+// is handed to hipExtLaunchKernelGGL, which stamps it at the kernel's own start and end on the GPU).
+bool prof_take(int kind, hipEvent_t* start, hipEvent_t* stop);
 
-// Brackets one kernel launch with profiler events (no-ops unless fr_prof_enable(1)).
 struct ProfScope {
-    void* h;
+    int kind;
     hipStream_t s;
-    ProfScope(int kind, hipStream_t st) : h(prof_on() ? prof_begin(kind, st) : nullptr), s(st) {}
-    ~ProfScope() { prof_end(h, s); }
+    ProfScope(int k, hipStream_t st) : kind(k), s(st) {}
 };
+
+// Launch `kernel`; when the profiler is on, with start/stop events that time exactly this kernel.
+template <typename K, typename... Args>
+inline void launch_kernel(const ProfScope& prof, K kernel, dim3 grid, dim3 block, size_t lds, hipStream_t stream,
+                          Args... args) {
+    hipEvent_t a, b;
+    if (prof_on() && prof_take(prof.kind, &a, &b))
+        hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, a, b, 0, args...);
+    else
+        hipLaunchKernelGGL(kernel, grid, block, lds, stream, args...);
+}
+#define FR_LAUNCH(prof, kernel, grid, block, lds, stream, ...) \
+    ::fr::launch_kernel(prof, kernel, grid, block, lds, stream, __VA_ARGS__)
 
 // A helper stream + fork/join events owned by the library (created on first use, one per process = one per GPU).
 // nullptr when disabled with FAIRREC_NO_OVERLAP=1.

@@ -53,20 +53,15 @@ static hipEvent_t take_event() {
     return e;
 }
 
-void* prof_begin(int kind, hipStream_t s) {
-    if (!g_prof.on) return nullptr;
+bool prof_take(int kind, hipEvent_t* start, hipEvent_t* stop) {
     std::lock_guard<std::mutex> lk(g_prof.mu);
+    if (!g_prof.on) return false;
     ProfState::Pair p{take_event(), take_event(), kind};
-    (void)hipEventRecord(p.a, s);
+    if (!p.a || !p.b) return false;
     g_prof.open.push_back(p);
-    return (void*)(uintptr_t)g_prof.open.size();  // 1-based handle
-}
-
-void prof_end(void* h, hipStream_t s) {
-    if (!h) return;
-    std::lock_guard<std::mutex> lk(g_prof.mu);
-    size_t i = (size_t)(uintptr_t)h - 1;
-    if (i < g_prof.open.size()) (void)hipEventRecord(g_prof.open[i].b, s);
+    *start = p.a;
+    *stop = p.b;
+    return true;
 }
 
 static void prof_drain() {

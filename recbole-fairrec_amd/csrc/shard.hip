@@ -128,7 +128,7 @@ extern "C" int fr_bucket_by_owner(const int64_t* idx, int64_t M, int32_t G, int3
     }
     hipStream_t stream = (hipStream_t)stream_;
     ProfScope prof(K_BUCKET, stream);
-    hipLaunchKernelGGL(bucket_by_owner_kernel, dim3(1), dim3(BUCKET_THREADS), lds, stream, idx, (int)M, (int)G,
+    FR_LAUNCH(prof, bucket_by_owner_kernel, dim3(1), dim3(BUCKET_THREADS), lds, stream, idx, (int)M, (int)G,
                        (int)cap, send_ids, slot_of, counts, err_flag);
     FR_CHECK_LAUNCH();
     return FR_OK;
@@ -140,7 +140,7 @@ extern "C" int fr_unbucket_rows(const float* src, const int32_t* slot_of, int64_
     if (M == 0) return FR_OK;
     hipStream_t stream = (hipStream_t)stream_;
     ProfScope prof(K_UNBUCKET, stream);
-    hipLaunchKernelGGL(unbucket_rows_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, stream, src, slot_of, (int)M,
+    FR_LAUNCH(prof, unbucket_rows_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, stream, src, slot_of, (int)M,
                        (int)dim, out);
     FR_CHECK_LAUNCH();
     return FR_OK;
@@ -152,7 +152,7 @@ extern "C" int fr_bucket_rows(const float* src, const float* scale, const int32_
     if (M == 0) return FR_OK;
     hipStream_t stream = (hipStream_t)stream_;
     ProfScope prof(K_BUCKET_ROWS, stream);
-    hipLaunchKernelGGL(bucket_rows_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, stream, src, scale, slot_of,
+    FR_LAUNCH(prof, bucket_rows_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, stream, src, scale, slot_of,
                        (int)M, (int)dim, dst);
     FR_CHECK_LAUNCH();
     return FR_OK;

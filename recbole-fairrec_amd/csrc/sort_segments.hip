@@ -260,7 +260,7 @@ static int launch_sort_kpt(const SortJob& a, const SortJob* b, int M, int bits, 
         attr_set = true;
     }
     ProfScope prof(K_SORT, stream);
-    hipLaunchKernelGGL(sort_segments_kernel<KPT>, dim3(b ? 2 : 1), dim3(SORT_THREADS), lds, stream, a, b ? *b : a, M,
+    FR_LAUNCH(prof, sort_segments_kernel<KPT>, dim3(b ? 2 : 1), dim3(SORT_THREADS), lds, stream, a, b ? *b : a, M,
                        npass, err);
     FR_CHECK_LAUNCH();
     return FR_OK;

@@ -125,7 +125,7 @@ extern "C" int fr_table_flush(const fr_table* t, const fr_adam* adam, void* stre
     if (blocks > 256 * 32) blocks = 256 * 32;
     {
         ProfScope prof(K_TABLE_FLUSH, (hipStream_t)stream_);
-        FR_DISPATCH_E(t->dim, table_flush_kernel<E><<<dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream_>>>(Tv, c));
+        FR_DISPATCH_E(t->dim, FR_LAUNCH(prof, (table_flush_kernel<E>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream_, Tv, c));
     }
     FR_CHECK_LAUNCH();
     return FR_OK;
@@ -141,7 +141,7 @@ extern "C" int fr_table_gather(const fr_table* t, const fr_adam* adam, const int
     const TableV Tv = view(t);
     {
         ProfScope prof(K_TABLE_GATHER, (hipStream_t)stream_);
-        FR_DISPATCH_E(t->dim, table_gather_kernel<E><<<dim3((unsigned)((M + 3) / 4)), dim3(256), 0, (hipStream_t)stream_>>>(Tv, c, idx, (long long)M, out, err_flag));
+        FR_DISPATCH_E(t->dim, FR_LAUNCH(prof, (table_gather_kernel<E>), dim3((unsigned)((M + 3) / 4)), dim3(256), 0, (hipStream_t)stream_, Tv, c, idx, (long long)M, out, err_flag));
     }
     FR_CHECK_LAUNCH();
     return FR_OK;
@@ -157,7 +157,7 @@ extern "C" int fr_adam_dense(float* p, const float* g, float* m, float* v, int64
     if (blocks > 256 * 16) blocks = 256 * 16;
     {
         ProfScope prof(K_ADAM_DENSE, (hipStream_t)stream_);
-        hipLaunchKernelGGL(adam_dense_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream_, p, g, m, v,
+        FR_LAUNCH(prof, adam_dense_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream_, p, g, m, v,
                            (long long)n, make_adamc(adam), step);
     }
     FR_CHECK_LAUNCH();
@@ -193,8 +193,7 @@ extern "C" int fr_table_gather_train(const fr_table* t, const fr_adam* adam, con
     const TableV Tv = view(t);
     {
         ProfScope prof(K_TABLE_GATHER_TRAIN, stream);
-        FR_DISPATCH_E(t->dim, table_gather_train_kernel<E><<<dim3((unsigned)((M + 3) / 4)), dim3(256), 0, stream>>>(
-                                  Tv, c, idx, (long long)M, rows_out, w, err_flag));
+        FR_DISPATCH_E(t->dim, FR_LAUNCH(prof, (table_gather_train_kernel<E>), dim3((unsigned)((M + 3) / 4)), dim3(256), 0, stream, Tv, c, idx, (long long)M, rows_out, w, err_flag));
     }
     FR_CHECK_LAUNCH();
     if (overlap) FR_CHECK_HIP(hipStreamWaitEvent(stream, ss->join, 0));
@@ -218,8 +217,7 @@ extern "C" int fr_table_apply_grad(const fr_table* t, const fr_adam* adam, int64
     const TableV Tv = view(t);
     {
         ProfScope prof(K_TABLE_APPLY_GRAD, stream);
-        FR_DISPATCH_E(t->dim, table_apply_grad_kernel<E><<<dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, stream>>>(
-                                  Tv, c, (long long)M, w, rows, grad_rows, lo, (int)(hi - lo)));
+        FR_DISPATCH_E(t->dim, FR_LAUNCH(prof, (table_apply_grad_kernel<E>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, stream, Tv, c, (long long)M, w, rows, grad_rows, lo, (int)(hi - lo)));
     }
     FR_CHECK_LAUNCH();
     return FR_OK;
