@@ -124,8 +124,14 @@ def main():
         Is = (torch.randn(shard_rows(N_ITEMS, rank, world), DIM, generator=g) * math.sqrt(2.0 / (N_ITEMS + DIM))).to(dev)
         eng = ShardedFocfEngine(Us, Is, OBJECTIVE, FAIR_WEIGHT, LR, WD, sweep_period=args.sweep)
 
+    n_batches = u.shape[0]
+
     def step(k):
-        eng.forward(u[k], i[k], r[k], s[k])
+        if sharded:
+            eng.forward(u[k], i[k], r[k], s[k])
+        else:   # the next batch's index sort is launched one step ahead (dataloader-style prefetch of the ids)
+            nxt = (u[k + 1], i[k + 1], s[k + 1]) if k + 1 < n_batches else None
+            eng.forward(u[k], i[k], r[k], s[k], next_batch=nxt)
         eng.backward_adam()
 
     def barrier():
@@ -178,7 +184,8 @@ def main():
         _C.prof_reset()
         _C.prof_enable(True)
         for k in range(K):
-            eng.forward(u2[k], i2[k], r2[k], s2[k])
+            nxt = (u2[k + 1], i2[k + 1], s2[k + 1]) if k + 1 < K else None
+            eng.forward(u2[k], i2[k], r2[k], s2[k], next_batch=nxt)
             eng.backward_adam()
         torch.cuda.synchronize()
         _C.prof_enable(False)
@@ -195,7 +202,8 @@ def main():
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "algorithmic_bytes_per_launch": algo_bytes,
                     "kernel_us": {k: round(v, 2) for k, v in sorted(per_kernel.items())},
-                    "measured": f"HIP events around every launch, {K} eager steps after the timed region"}
+                    "measured": f"hipExtLaunchKernelGGL start/stop events on every launch, {K} eager steps after the "
+                                "timed region (same look-ahead sort overlap as the timed steps)"}
 
     if rank == 0:
         total = K * BATCH * world

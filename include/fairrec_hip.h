@@ -117,10 +117,20 @@ FR_API size_t fr_focf_workspace_bytes(int64_t B, int32_t dim);
  *   loss_out[0] = loss, loss_out[1] = mse part, loss_out[2] = fairness part (unweighted)   (device)
  *   pred_out    = pred_scores [B] (device, may be NULL)
  */
+#define FR_FOCF_PREPARED 1   /* flags: fr_focf_prepare already ran for this batch on this workspace */
 FR_API int fr_focf_forward(const fr_table* U, const fr_table* I, const fr_adam* adam, const int64_t* user,
                     const int64_t* item, const float* rating, const float* sst, int64_t B, int32_t objective,
-                    float fair_weight, void* ws, size_t ws_bytes, float* loss_out, float* pred_out,
+                    float fair_weight, int32_t flags, void* ws, size_t ws_bytes, float* loss_out, float* pred_out,
                     uint32_t* err_flag, void* stream);
+
+/*
+ * The index-only part of fr_focf_forward (sort + segmentation of the id columns, min/max of sst), callable one
+ * batch AHEAD on another stream while the previous batch's kernels run: it depends on nothing but the ids, the
+ * way a dataloader prefetches the next batch (trainer.py:181 iterates `train_data`).  Pass `sst` = NULL for
+ * fair_objective none.  The caller orders it against the consumers of `ws` with events.
+ */
+FR_API int fr_focf_prepare(const int64_t* user, const int64_t* item, const float* sst, int64_t B, int64_t n_users,
+                    int64_t n_items, int32_t dim, void* ws, size_t ws_bytes, uint32_t* err_flag, void* stream);
 
 /*
  * loss.backward() + optimizer.step() for the batch of the preceding fr_focf_forward on the same

@@ -465,10 +465,27 @@ extern "C" size_t fr_focf_workspace_bytes(int64_t B, int32_t dim) {
     return focf_layout(nullptr, B, dim).bytes;
 }
 
+static int focf_launch_sort(const FocfWs& w, const int64_t* user, const int64_t* item, const float* sst, int64_t B,
+                            int64_t n_users, int64_t n_items, bool want_minmax, uint32_t* err_flag, hipStream_t stream) {
+    SortJob ju{user, n_users, w.perm_u, w.seg_start_u, w.seg_row_u, nullptr, w.nseg_u, nullptr, nullptr};
+    SortJob ji{item, n_items, w.perm_i, w.seg_start_i, w.seg_row_i, nullptr, w.nseg_i, want_minmax ? sst : nullptr,
+               w.sst_minmax};
+    return launch_sort(ju, &ji, B, err_flag, stream);
+}
+
+extern "C" int fr_focf_prepare(const int64_t* user, const int64_t* item, const float* sst, int64_t B, int64_t n_users,
+                               int64_t n_items, int32_t dim, void* ws, size_t ws_bytes, uint32_t* err_flag,
+                               void* stream_) {
+    FR_CHECK_ARG(user && item && ws && B >= 1 && B <= FR_SORT_MAX && dim >= 1, "fr_focf_prepare: bad argument");
+    FocfWs w = focf_layout(ws, B, dim);
+    FR_CHECK_ARG(ws_bytes >= w.bytes, "fr_focf_prepare: workspace %zu < %zu bytes", ws_bytes, w.bytes);
+    return focf_launch_sort(w, user, item, sst, B, n_users, n_items, sst != nullptr, err_flag, (hipStream_t)stream_);
+}
+
 extern "C" int fr_focf_forward(const fr_table* U, const fr_table* I, const fr_adam* adam, const int64_t* user,
                                const int64_t* item, const float* rating, const float* sst, int64_t B,
-                               int32_t objective, float fair_weight, void* ws, size_t ws_bytes, float* loss_out,
-                               float* pred_out, uint32_t* err_flag, void* stream_) {
+                               int32_t objective, float fair_weight, int32_t flags, void* ws, size_t ws_bytes,
+                               float* loss_out, float* pred_out, uint32_t* err_flag, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     int rc;
     if ((rc = check_table(U, "fr_focf_forward(U)")) || (rc = check_table(I, "fr_focf_forward(I)")) ||
@@ -485,20 +502,24 @@ extern "C" int fr_focf_forward(const fr_table* U, const fr_table* I, const fr_ad
     FocfWs w = focf_layout(ws, B, U->dim);
     FR_CHECK_ARG(ws_bytes >= w.bytes, "fr_focf_forward: workspace %zu < %zu bytes", ws_bytes, w.bytes);
 
-    SortJob ju{user, U->n_rows, w.perm_u, w.seg_start_u, w.seg_row_u, nullptr, w.nseg_u, nullptr, nullptr};
-    SortJob ji{item, I->n_rows, w.perm_i, w.seg_start_i, w.seg_row_i, nullptr, w.nseg_i,
-               objective == FR_FOCF_NONE ? nullptr : sst, w.sst_minmax};
-    // The sort only reads the id columns, the gather only reads the tables: run them side by side
-    // (fork/join through events; under stream capture this becomes two parallel graph branches).
+    // The sort only reads the id columns, the gather only reads the tables: unless the caller already ran
+    // fr_focf_prepare for this batch (software-pipelined one step ahead), run them side by side (fork/join through
+    // events; under stream capture this becomes two parallel graph branches).
+    const bool prepared = (flags & FR_FOCF_PREPARED) != 0;
     SideStream* ss = side_stream();
-    const bool overlap = ss != nullptr && !prof_on();
-    if (overlap) {
-        FR_CHECK_HIP(hipEventRecord(ss->fork, stream));
-        FR_CHECK_HIP(hipStreamWaitEvent(ss->stream, ss->fork, 0));
-        if ((rc = launch_sort(ju, &ji, B, err_flag, ss->stream))) return rc;
-        FR_CHECK_HIP(hipEventRecord(ss->join, ss->stream));
-    } else if ((rc = launch_sort(ju, &ji, B, err_flag, stream))) {
-        return rc;
+    const bool overlap = !prepared && ss != nullptr && !prof_on();
+    if (!prepared) {
+        if (overlap) {
+            FR_CHECK_HIP(hipEventRecord(ss->fork, stream));
+            FR_CHECK_HIP(hipStreamWaitEvent(ss->stream, ss->fork, 0));
+            if ((rc = focf_launch_sort(w, user, item, sst, B, U->n_rows, I->n_rows, objective != FR_FOCF_NONE, err_flag,
+                                       ss->stream)))
+                return rc;
+            FR_CHECK_HIP(hipEventRecord(ss->join, ss->stream));
+        } else if ((rc = focf_launch_sort(w, user, item, sst, B, U->n_rows, I->n_rows, objective != FR_FOCF_NONE,
+                                          err_flag, stream))) {
+            return rc;
+        }
     }
 
     const AdamC c = make_adamc(adam);

@@ -56,7 +56,10 @@ class FocfEngine:
         self.hyper = AdamHyper(device=self.device, cap=1)  # placeholder until an optimizer binds (step 0: no replay)
         self.optimizer: Optional[FusedLazyAdam] = None
         self.sweep_period: Optional[int] = None
-        self.ws = None
+        self.ws = [None, None]          # double-buffered per-batch workspaces (the next batch's sort runs one step ahead)
+        self.ws_cur = 0
+        self._side = None               # stream of the look-ahead sort
+        self._prep = None               # (key, ws index, done-event) of the batch prepared ahead
         self.loss_ring = torch.zeros((self.LOSS_SLOTS, 4), dtype=torch.float32, device=self.device)
         self.loss_slot = 0
         self.err_flag = torch.zeros(1, dtype=torch.int32, device=self.device)
@@ -80,17 +83,50 @@ class FocfEngine:
         # default: sweep about B rows of the larger table per step => a row is never more than S ~ N/B steps stale
         return max(8, math.ceil(max(self.U.n_rows, self.I.n_rows) / max(B, 1)))
 
-    def _workspace(self, B: int):
+    def _workspace(self, B: int, k: int):
         need = _C.lib().fr_focf_workspace_bytes(B, self.U.dim)
-        if self.ws is None or self.ws.numel() < need:
-            self.ws = torch.empty(need, dtype=torch.uint8, device=self.device)
-        return self.ws
+        if self.ws[k] is None or self.ws[k].numel() < need:
+            self.ws[k] = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self.ws[k]
+
+    @staticmethod
+    def _key(user, item):
+        return (user.data_ptr(), item.data_ptr(), user.numel())
+
+    def prepare(self, user, item, sst, ws_index: int):
+        """Index-only part of the NEXT batch (fr_focf_prepare: sort + segmentation + sst min/max) on a side stream,
+        overlapping the kernels of the current batch.  Pure function of the id columns."""
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        main = torch.cuda.current_stream()
+        B = user.numel()
+        ws = self._workspace(B, ws_index)
+        start = torch.cuda.Event()
+        start.record(main)                  # everything that last used ws[ws_index] was enqueued before this point
+        self._side.wait_event(start)
+        sst_arg = sst if self.objective != 0 else None
+        rc = _C.lib().fr_focf_prepare(user.data_ptr(), item.data_ptr(), _C.ptr(sst_arg), B, self.U.n_rows,
+                                      self.I.n_rows, self.U.dim, ws.data_ptr(), ws.numel(), self.err_flag.data_ptr(),
+                                      self._side.cuda_stream)
+        _C.check(rc, "fr_focf_prepare")
+        done = torch.cuda.Event()
+        done.record(self._side)
+        self._prep = (self._key(user, item), ws_index, done)
 
     # --- launches -------------------------------------------------------------------------------------
-    def forward(self, user, item, rating, sst, want_pred: bool = False):
-        """fr_focf_forward for the step `step+1`; returns (loss[4] device view, pred or None)."""
+    def forward(self, user, item, rating, sst, want_pred: bool = False, next_batch=None):
+        """fr_focf_forward for the step `step+1`; returns (loss[4] device view, pred or None).
+        `next_batch` = (user, item, sst) of the following step, if known: its sort is launched now, one step ahead."""
         B = user.numel()
-        ws = self._workspace(B)
+        flags = 0
+        if self._prep is not None and self._prep[0] == self._key(user, item):
+            _, self.ws_cur, done = self._prep
+            torch.cuda.current_stream().wait_event(done)
+            flags = 1                                            # FR_FOCF_PREPARED
+        self._prep = None
+        ws = self._workspace(B, self.ws_cur)
+        if next_batch is not None:
+            self.prepare(next_batch[0], next_batch[1], next_batch[2], 1 - self.ws_cur)
         self.loss_slot = (self.loss_slot + 1) % self.LOSS_SLOTS
         loss = self.loss_ring[self.loss_slot]
         pred = torch.empty(B, dtype=torch.float32, device=self.device) if want_pred else None
@@ -98,8 +134,8 @@ class FocfEngine:
         self.hyper.check_step(self.U.step + 1)
         rc = _C.lib().fr_focf_forward(ctypes.byref(tu), ctypes.byref(ti), ctypes.byref(self.hyper.c()),
                                       user.data_ptr(), item.data_ptr(), rating.data_ptr(), _C.ptr(sst), B,
-                                      self.objective, self.fair_weight, ws.data_ptr(), ws.numel(), loss.data_ptr(),
-                                      _C.ptr(pred), self.err_flag.data_ptr(), _C.current_stream())
+                                      self.objective, self.fair_weight, flags, ws.data_ptr(), ws.numel(),
+                                      loss.data_ptr(), _C.ptr(pred), self.err_flag.data_ptr(), _C.current_stream())
         _C.check(rc, "fr_focf_forward")
         self.pending_B = B
         return loss, pred
@@ -113,8 +149,8 @@ class FocfEngine:
         B = self.pending_B
         tu, ti = self.U.c(self.U.step + 1), self.I.c(self.I.step + 1)
         rc = _C.lib().fr_focf_backward_adam(ctypes.byref(tu), ctypes.byref(ti), ctypes.byref(self.hyper.c()), B,
-                                            self._sweep(B), self.ws.data_ptr(), self.ws.numel(),
-                                            _C.current_stream())
+                                            self._sweep(B), self.ws[self.ws_cur].data_ptr(),
+                                            self.ws[self.ws_cur].numel(), _C.current_stream())
         _C.check(rc, "fr_focf_backward_adam")
         self.U.step += 1
         self.I.step += 1
@@ -203,10 +239,16 @@ class FOCF(FairRecommender):
         ie = eng.I.gather(eng.hyper, item, eng.err_flag)
         return (ue * ie).sum(-1), ue, ie
 
+    def hint_next_batch(self, interaction):
+        """Optional trainer hook: the batch that will follow the next `calculate_loss` (None at the epoch end)."""
+        self._next_cols = self._cols(interaction) if interaction is not None else None
+
     def calculate_loss(self, interaction):
         eng = self.hip_engine()
         u, i, r, s = self._cols(interaction)
-        loss, _ = eng.forward(u, i, r, s)
+        nxt = getattr(self, '_next_cols', None)
+        self._next_cols = None
+        loss, _ = eng.forward(u, i, r, s, next_batch=(nxt[0], nxt[1], nxt[3]) if nxt is not None else None)
         if torch.is_grad_enabled():
             return _LossHandle.apply(loss[0], eng, self.user_embedding_layer.weight, self.item_embedding_layer.weight)
         return loss[0]

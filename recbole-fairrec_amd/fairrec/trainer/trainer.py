@@ -84,8 +84,16 @@ class Trainer(AbstractTrainer):
         loss_func = loss_func or self.model.calculate_loss
         total = None
         n_tuple = 0
-        for batch_idx, interaction in enumerate(train_data):
-            interaction = interaction.to(self.device)
+        hint = getattr(self.model, 'hint_next_batch', None)
+        it = iter(train_data)
+        nxt = next(it, None)
+        nxt = nxt.to(self.device) if nxt is not None else None
+        while nxt is not None:
+            interaction = nxt
+            nxt = next(it, None)                       # dataloader look-ahead by one batch
+            nxt = nxt.to(self.device) if nxt is not None else None
+            if hint is not None:
+                hint(nxt)                              # lets the model start the next batch's index sort early
             self.optimizer.zero_grad()
             losses = loss_func(interaction)
             if isinstance(losses, tuple):

@@ -30,21 +30,21 @@ def _engine(z, sweep):
     return eng
 
 
-@pytest.mark.parametrize("sweep", [0, 3, None], ids=["nosweep", "sweep3", "sweepdefault"])
+@pytest.mark.parametrize("sweep", [0, 3, None, "lookahead"], ids=["nosweep", "sweep3", "sweepdefault", "lookahead"])
 @pytest.mark.parametrize("path", CASES, ids=[os.path.basename(p)[:-4] for p in CASES])
 def test_training_matches_reference_golden(path, sweep):
     z = np.load(path)
-    eng = _engine(z, sweep)
+    lookahead = sweep == "lookahead"       # next batch's index sort launched one step ahead on a side stream
+    eng = _engine(z, 3 if lookahead else sweep)
     snaps = set(int(s) for s in z["snaps"])
     T = z["user_id"].shape[0]
     dev = "cuda"
     losses = []
+    cols = {k: torch.tensor(z[k], device=dev) for k in ("user_id", "item_id", "rating", "sst")}
     for t in range(T):
-        u = torch.tensor(z["user_id"][t], device=dev)
-        i = torch.tensor(z["item_id"][t], device=dev)
-        r = torch.tensor(z["rating"][t], device=dev)
-        s = torch.tensor(z["sst"][t], device=dev)
-        loss, pred = eng.forward(u, i, r, s, want_pred=(t == 0))
+        u, i, r, s = (cols[k][t] for k in ("user_id", "item_id", "rating", "sst"))
+        nxt = (cols["user_id"][t + 1], cols["item_id"][t + 1], cols["sst"][t + 1]) if lookahead and t + 1 < T else None
+        loss, pred = eng.forward(u, i, r, s, want_pred=(t == 0), next_batch=nxt)
         losses.append(loss.clone())
         if t == 0:
             _close(pred.cpu().numpy(), z["pred_step1"], "pred step 1", atol=1e-6)
