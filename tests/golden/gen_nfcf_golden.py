@@ -1,0 +1,161 @@
+#!/usr/bin/env python3
+"""Golden vectors for the NFCF hot path by RUNNING THE REFERENCE (build container only).
+
+Per case: initial state_dict, T batches (user, item, label, sst), the dropout masks actually applied (the
+reference draws them from torch's global RNG inside nn.Dropout; here each nn.Dropout of the reference's
+MLPLayers is swapped for a module that applies a RECORDED Bernoulli mask with the same 1/(1-p) scaling, so that
+inputs and outputs are both known), loss per step, and parameters + Adam moments after selected steps of
+`zero_grad -> calculate_loss -> backward -> optim.Adam(model.parameters(), lr, weight_decay).step()`
+(trainer.py:139,183-196).  Finetune cases go through NFCF.reset_params (nfcf.py:49-67) with a pretrain
+checkpoint written by the pretrain model.
+"""
+import os
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import _refshim  # noqa: E402
+
+_refshim.install()
+import torch  # noqa: E402
+import torch.nn as nn  # noqa: E402
+from recbole.data.interaction import Interaction  # noqa: E402
+from recbole.model.fair_recommender.nfcf import NFCF  # noqa: E402
+
+
+class _Cfg(dict):
+    def __getitem__(self, k):
+        return self.get(k, None)
+
+
+class _FakeDataset:
+    def __init__(self, n_users, n_items, gender):
+        self._n = {"user_id": n_users, "item_id": n_items}
+        self._uf = Interaction({"user_id": torch.arange(n_users), "gender": torch.from_numpy(gender)})
+
+    def num(self, field):
+        return self._n[field]
+
+    def get_user_feature(self):
+        return self._uf
+
+
+class RecordedDropout(nn.Module):
+    """Applies mask/(1-p) from a queue filled by the generator (same arithmetic as F.dropout in training)."""
+
+    def __init__(self, p, queue):
+        super().__init__()
+        self.p, self.queue = p, queue
+
+    def forward(self, x):
+        if self.p == 0.0:
+            return x
+        m = self.queue.pop(0)
+        assert m.shape == x.shape
+        return x * (m / (1.0 - self.p))
+
+
+def patch_dropout(model, p, queue):
+    seq = model.mlp_layers.mlp_layers
+    for k, mod in enumerate(seq):
+        if isinstance(mod, (nn.Dropout, RecordedDropout)):
+            seq[k] = RecordedDropout(p, queue)
+
+
+def run_case(name, stage, n_users, n_items, D, hidden, B, T, snaps, lr, wd, p_drop, fair_weight, seed):
+    torch.manual_seed(seed)
+    rng = np.random.default_rng(seed)
+    gender = rng.integers(0, 2, size=n_users).astype(np.float32)
+    base = dict(USER_ID_FIELD="user_id", ITEM_ID_FIELD="item_id", NEG_PREFIX="neg_", device=torch.device("cpu"),
+                LABEL_FIELD="label", embedding_size=D, mlp_hidden_size=list(hidden), dropout=p_drop,
+                sst_attr_list=["gender"], fair_weight=fair_weight)
+    ds = _FakeDataset(n_users, n_items, gender)
+    out = {"hidden": np.array(hidden), "hyper": np.array([lr, wd, fair_weight, p_drop], dtype=np.float64),
+           "stage": np.array(stage), "gender": gender}
+    model = NFCF(_Cfg(base, load_pretrain_path=None), ds)
+    if stage == "finetune":
+        # a short pretrain so that the checkpoint is not just noise, then the reference's own reset_params
+        opt0 = torch.optim.Adam(model.parameters(), lr=1e-2)
+        q0 = []
+        patch_dropout(model, 0.0, q0)
+        for _ in range(5):
+            u = torch.from_numpy(rng.integers(1, n_users, size=B))
+            i = torch.from_numpy(rng.integers(1, n_items, size=B))
+            lab = torch.from_numpy((rng.random(B) < 0.5).astype(np.float32))
+            opt0.zero_grad()
+            model.calculate_loss(Interaction({"user_id": u, "item_id": i, "label": lab})).backward()
+            opt0.step()
+        out["pretrain_user_embedding"] = model.user_embedding.weight.detach().numpy().copy()
+        tmp = tempfile.NamedTemporaryFile(suffix=".pth", delete=False)
+        tmp.close()
+        torch.save({"state_dict": model.state_dict()}, tmp.name)
+        model = NFCF(_Cfg(base, load_pretrain_path=tmp.name), ds)   # -> reset_params (nfcf.py:49-67)
+        os.unlink(tmp.name)
+    queue = []
+    patch_dropout(model, p_drop, queue)
+    for k, v in model.state_dict().items():
+        out["init." + k] = v.detach().numpy().copy()
+    opt = torch.optim.Adam(model.parameters(), lr=lr, weight_decay=wd)   # trainer.py:139
+    us, its, labs, ss, masks, losses = [], [], [], [], [], []
+    sizes = [2 * D] + list(hidden)
+    for t in range(T):
+        u = rng.integers(1, n_users, size=B)
+        pool = rng.integers(1, n_items, size=max(2, B // 4))          # duplicates among items (DF statistics)
+        i = pool[rng.integers(0, len(pool), size=B)]
+        lab = (rng.random(B) < 0.6).astype(np.float32)
+        s = gender[u]
+        step_masks = []
+        if p_drop > 0:
+            for w in sizes:
+                m = (torch.rand(B, w) >= p_drop).float()
+                queue.append(m)
+                step_masks.append(m.numpy())
+        inter = Interaction({"user_id": torch.from_numpy(u), "item_id": torch.from_numpy(i),
+                             "label": torch.from_numpy(lab), "gender": torch.from_numpy(s)})
+        opt.zero_grad()
+        loss = model.calculate_loss(inter)
+        losses.append(float(loss.item()))
+        loss.backward()
+        if t == 0:
+            with torch.no_grad():
+                out["grad_step1.mlp0"] = model.mlp_layers.mlp_layers[1].weight.grad.numpy().copy()
+                out["grad_step1.item"] = model.item_embedding.weight.grad.numpy().copy()
+        opt.step()
+        us.append(u); its.append(i); labs.append(lab); ss.append(s); masks.append(step_masks)
+        if (t + 1) in snaps:
+            for k, v in model.state_dict().items():
+                out[f"after{t + 1}." + k] = v.detach().numpy().copy()
+            for pname, prm in model.named_parameters():
+                if prm in opt.state and "exp_avg" in opt.state[prm]:
+                    out[f"after{t + 1}.m." + pname] = opt.state[prm]["exp_avg"].numpy().copy()
+    out.update(user_id=np.stack(us).astype(np.int64), item_id=np.stack(its).astype(np.int64), label=np.stack(labs),
+               sst=np.stack(ss), loss=np.array(losses), snaps=np.array(sorted(snaps)))
+    if p_drop > 0:
+        for li in range(len(sizes)):
+            out[f"mask{li}"] = np.stack([masks[t][li] for t in range(T)]).astype(np.uint8)
+    # predict() on the last batch in eval mode (dropout off), nfcf.py:112-115
+    model.eval()
+    patch_dropout(model, 0.0, [])
+    with torch.no_grad():
+        out["predict_last"] = model.predict(inter).numpy().copy()
+    path = os.path.join(HERE, f"nfcf_{name}.npz")
+    np.savez_compressed(path, **out)
+    print(f"{path}: loss[0]={losses[0]:.6f} loss[-1]={losses[-1]:.6f} {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+def main():
+    c = dict(n_users=50, n_items=40, B=64, lr=1e-3)
+    run_case("pretrain", "pretrain", D=8, hidden=(16, 8), T=10, snaps=(1, 10), wd=1e-6, p_drop=0.0, fair_weight=0.1, seed=1, **c)
+    run_case("pretrain_dropout", "pretrain", D=8, hidden=(16, 8), T=6, snaps=(6,), wd=1e-6, p_drop=0.2, fair_weight=0.1, seed=2, **c)
+    run_case("pretrain_wd", "pretrain", D=8, hidden=(16, 8), T=30, snaps=(30,), wd=1e-3, p_drop=0.0, fair_weight=0.1, seed=3, **c)
+    run_case("pretrain_d64", "pretrain", D=64, hidden=(128, 64), T=4, snaps=(4,), wd=1e-6, p_drop=0.2, fair_weight=0.1, seed=4, **c)
+    run_case("finetune", "finetune", D=8, hidden=(16, 8), T=10, snaps=(1, 10), wd=1e-6, p_drop=0.0, fair_weight=0.1, seed=5, **c)
+    run_case("finetune_dropout", "finetune", D=8, hidden=(16, 8), T=6, snaps=(6,), wd=1e-6, p_drop=0.2, fair_weight=0.5, seed=6, **c)
+    run_case("finetune_d64", "finetune", D=64, hidden=(128, 64), T=4, snaps=(4,), wd=1e-6, p_drop=0.0, fair_weight=0.1, seed=7, **c)
+
+
+if __name__ == "__main__":
+    main()
