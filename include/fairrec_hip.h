@@ -208,6 +208,24 @@ FR_API int fr_focf_shard_grads(const float* rows_u, const float* rows_i, const i
                                const float* coef, const float* coef_slots, const float* inv_k, int64_t B, int32_t dim,
                                float* grad_u_slots, float* grad_i_slots, void* stream);
 
+/* ---- dense layers (fp32 MFMA) ---------------------------------------------------------------------------
+ * One layer of recbole/model/layers.py MLPLayers (:62-72): Dropout -> Linear -> activation, forward and backward.
+ *   X = [x0 | x1] : [M, k0 + k1] (x1 may be NULL; the split serves cat(U[u], I[i]) of nfcf.py:72 without a copy)
+ *   mask          : [M, k0 + k1] bytes, 0 = dropped (the Bernoulli draw stays with the host RNG),
+ *                   NULL = no dropout; kept elements are multiplied by `scale` = 1/(1-p)
+ *   W [N, K], bias [N] : nn.Linear layout;  act: 0 none, 1 relu, 2 leakyrelu(0.01), 3 sigmoid, 4 tanh
+ *   Y [M, N]      : POST-activation output; the backward kernels rebuild act'(.) from it
+ * fr_linear_bwd_weight reduces over the batch in a fixed order (per-split slabs summed in split order). */
+FR_API int fr_linear_fwd(const float* x0, int32_t k0, const float* x1, int32_t k1, const uint8_t* mask, float scale,
+                         const float* W, const float* bias, int64_t M, int32_t N, int32_t act, float* Y, void* stream);
+FR_API int fr_linear_bwd_input(const float* dY, const float* Y, int32_t act, const float* W, const uint8_t* mask,
+                               float scale, int64_t M, int32_t N, float* dx0, int32_t k0, float* dx1, int32_t k1,
+                               void* stream);
+FR_API size_t fr_linear_bwd_weight_workspace_bytes(int64_t M, int32_t N, int32_t K);
+FR_API int fr_linear_bwd_weight(const float* dY, const float* Y, int32_t act, const float* x0, int32_t k0,
+                                const float* x1, int32_t k1, const uint8_t* mask, float scale, int64_t M, int32_t N,
+                                float* dW, float* db, void* ws, size_t ws_bytes, void* stream);
+
 /* Dense fused Adam step for small dense parameters (MLP weights, biases): one step of
  * torch.optim.Adam on a flat fp32 tensor, `step` = the step being applied. */
 FR_API int fr_adam_dense(float* p, const float* g, float* m, float* v, int64_t n, const fr_adam* adam, int32_t step,

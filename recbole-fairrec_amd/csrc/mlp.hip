@@ -1,0 +1,306 @@
+// Dense layers of the fair models on the fp32 matrix cores (v_mfma_f32_32x32x2_f32: exact f32, 1e-4 parity
+// rules out bf16 inputs -- SURVEY.md §7 hard part 7).
+//
+// Replaces recbole/model/layers.py:56-85 (MLPLayers = per layer Dropout -> Linear -> [BatchNorm1d] -> activation,
+// INCLUDING the last layer) and its autograd: nfcf.py:40 (scorer [2D,128,64,1]), pfcn_biasedmf.py:113-142
+// (filters / discriminators).  One kernel per layer direction:
+//   linear_fwd        Y  = act((X o mask*scale) W^T + b)
+//   linear_bwd_input  dX = ((dY o act'(Y)) W) o mask*scale
+//   linear_bwd_weight dW = (dY o act'(Y))^T (X o mask*scale)   (split over the batch, fixed-order reduction), db
+// Tiles: 256 threads = 4 waves, 64x64 output tile, each wave one 32x32 MFMA tile, 32-deep K chunks through LDS.
+#include "common.hpp"
+#include "kernels.hpp"
+
+namespace fr {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_LEAKY = 2, ACT_SIGMOID = 3, ACT_TANH = 4 };
+
+__device__ __forceinline__ float act_fwd(float x, int act) {
+    switch (act) {
+        case ACT_RELU: return x > 0.f ? x : 0.f;
+        case ACT_LEAKY: return x > 0.f ? x : 0.01f * x;
+        case ACT_SIGMOID: return 1.f / (1.f + __expf(-x));
+        case ACT_TANH: return tanhf(x);
+        default: return x;
+    }
+}
+
+// derivative expressed through the OUTPUT y = act(x)
+__device__ __forceinline__ float act_bwd(float y, int act) {
+    switch (act) {
+        case ACT_RELU: return y > 0.f ? 1.f : 0.f;
+        case ACT_LEAKY: return y > 0.f ? 1.f : 0.01f;
+        case ACT_SIGMOID: return y * (1.f - y);
+        case ACT_TANH: return 1.f - y * y;
+        default: return 1.f;
+    }
+}
+
+// An [M, K] fp32 matrix that may be the column-wise concatenation of two row-major blocks (cat(U[u], I[i])).
+struct CatMat {
+    const float* a;
+    const float* b;   // may be null
+    int ka, kb;       // widths; K = ka + kb
+    __device__ __forceinline__ float at(long long m, int k) const {
+        return k < ka ? a[m * ka + k] : b[m * kb + (k - ka)];
+    }
+};
+
+struct CatOut {
+    float* a;
+    float* b;
+    int ka, kb;
+    __device__ __forceinline__ void put(long long m, int k, float v) const {
+        if (k < ka) a[m * ka + k] = v;
+        else b[m * kb + (k - ka)] = v;
+    }
+};
+
+static constexpr int TM = 64, TN = 64, TK = 32, LDT = TK + 1;
+
+__device__ __forceinline__ void store_tile(const f32x16& acc, int wm, int wn, int lane, int m0, int n0, int M, int N,
+                                           const float* __restrict__ bias, int act, float* __restrict__ Y) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int col = n0 + wn * 32 + (lane & 31);
+        if (row < M && col < N) Y[(size_t)row * N + col] = act_fwd(acc[r] + (bias ? bias[col] : 0.f), act);
+    }
+}
+
+// Y[M,N] = act((X o mask*scale) W^T + b);  W is [N, K] row-major (nn.Linear.weight)
+__global__ __launch_bounds__(256) void linear_fwd_kernel(CatMat X, const unsigned char* __restrict__ mask, float scale,
+                                                         const float* __restrict__ W, const float* __restrict__ bias,
+                                                         int M, int N, int K, int act, float* __restrict__ Y) {
+    __shared__ float Xs[TM * LDT];
+    __shared__ float Ws[TN * LDT];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.x * TM, n0 = blockIdx.y * TN;
+    f32x16 acc = {0};
+    for (int k0 = 0; k0 < K; k0 += TK) {
+#pragma unroll
+        for (int q = 0; q < (TM * TK) / 256; ++q) {
+            const int e = q * 256 + tid, r = e / TK, c = e % TK;
+            const int m = m0 + r, k = k0 + c;
+            float x = 0.f;
+            if (m < M && k < K) {
+                x = X.at(m, k);
+                if (mask) x = mask[(size_t)m * K + k] ? x * scale : 0.f;
+            }
+            Xs[r * LDT + c] = x;
+            const int n = n0 + r;
+            Ws[r * LDT + c] = (n < N && k < K) ? W[(size_t)n * K + k] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < TK; kk += 2) {
+            const float a = Xs[(wm * 32 + (lane & 31)) * LDT + kk + (lane >> 5)];
+            const float b = Ws[(wn * 32 + (lane & 31)) * LDT + kk + (lane >> 5)];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    store_tile(acc, wm, wn, lane, m0, n0, M, N, bias, act, Y);
+}
+
+// dX[M,K] = ((dY o act'(Y)) W) o mask*scale
+__global__ __launch_bounds__(256) void linear_bwd_input_kernel(const float* __restrict__ dY, const float* __restrict__ Y,
+                                                               int act, const float* __restrict__ W,
+                                                               const unsigned char* __restrict__ mask, float scale,
+                                                               int M, int N, int K, CatOut dX) {
+    __shared__ float Gs[TM * LDT];          // [m][n chunk]
+    __shared__ float Ws[TK * (TN + 1)];     // [n chunk][k tile]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.x * TM, c0 = blockIdx.y * TN;   // output tile: rows m, columns k
+    f32x16 acc = {0};
+    for (int n0 = 0; n0 < N; n0 += TK) {
+#pragma unroll
+        for (int q = 0; q < (TM * TK) / 256; ++q) {
+            const int e = q * 256 + tid;
+            {
+                const int r = e / TK, c = e % TK;
+                const int m = m0 + r, n = n0 + c;
+                float g = 0.f;
+                if (m < M && n < N) g = dY[(size_t)m * N + n] * act_bwd(Y[(size_t)m * N + n], act);
+                Gs[r * LDT + c] = g;
+            }
+            {
+                const int r = e / TN, c = e % TN;          // r: n within chunk, c: k within tile
+                const int n = n0 + r, k = c0 + c;
+                Ws[r * (TN + 1) + c] = (n < N && k < K) ? W[(size_t)n * K + k] : 0.f;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < TK; kk += 2) {
+            const float a = Gs[(wm * 32 + (lane & 31)) * LDT + kk + (lane >> 5)];
+            const float b = Ws[(kk + (lane >> 5)) * (TN + 1) + wn * 32 + (lane & 31)];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int col = c0 + wn * 32 + (lane & 31);
+        if (row < M && col < K) {
+            float v = acc[r];
+            if (mask) v = mask[(size_t)row * K + col] ? v * scale : 0.f;
+            dX.put(row, col, v);
+        }
+    }
+}
+
+// slab[s][N][K] = sum over the rows of split s of (dY o act'(Y))[m,n] * (X o mask*scale)[m,k]
+__global__ __launch_bounds__(256) void linear_bwd_weight_kernel(const float* __restrict__ dY, const float* __restrict__ Y,
+                                                                int act, CatMat X, const unsigned char* __restrict__ mask,
+                                                                float scale, int M, int N, int K, int rows_per_split,
+                                                                float* __restrict__ slab) {
+    __shared__ float Gs[TK * (TM + 1)];   // [m chunk][n tile]
+    __shared__ float Xs[TK * (TN + 1)];   // [m chunk][k tile]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int n0 = blockIdx.x * TM, c0 = blockIdx.y * TN, s = blockIdx.z;
+    const int mlo = s * rows_per_split, mhi = min(M, mlo + rows_per_split);
+    f32x16 acc = {0};
+    for (int mb = mlo; mb < mhi; mb += TK) {
+#pragma unroll
+        for (int q = 0; q < (TM * TK) / 256; ++q) {
+            const int e = q * 256 + tid;
+            const int r = e / TM, c = e % TM;     // r: m within chunk, c: column within tile
+            const int m = mb + r;
+            {
+                const int n = n0 + c;
+                float g = 0.f;
+                if (m < mhi && n < N) g = dY[(size_t)m * N + n] * act_bwd(Y[(size_t)m * N + n], act);
+                Gs[r * (TM + 1) + c] = g;
+            }
+            {
+                const int k = c0 + c;
+                float x = 0.f;
+                if (m < mhi && k < K) {
+                    x = X.at(m, k);
+                    if (mask) x = mask[(size_t)m * K + k] ? x * scale : 0.f;
+                }
+                Xs[r * (TN + 1) + c] = x;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < TK; kk += 2) {
+            const float a = Gs[(kk + (lane >> 5)) * (TM + 1) + wm * 32 + (lane & 31)];
+            const float b = Xs[(kk + (lane >> 5)) * (TN + 1) + wn * 32 + (lane & 31)];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    float* out = slab + (size_t)s * N * K;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = n0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int col = c0 + wn * 32 + (lane & 31);
+        if (row < N && col < K) out[(size_t)row * K + col] = acc[r];
+    }
+}
+
+// dW[i] = sum_s slab[s][i] in split order (fixed order => reproducible)
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slab, int splits, long long n,
+                                                          float* __restrict__ out) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        float a = 0.f;
+        for (int s = 0; s < splits; ++s) a += slab[(size_t)s * n + i];
+        out[i] = a;
+    }
+}
+
+// db[n] = sum_m (dY o act'(Y))[m,n]: one wave per column block of 64, rows in fixed strides, LDS tree over 4 waves
+__global__ __launch_bounds__(256) void linear_bwd_bias_kernel(const float* __restrict__ dY, const float* __restrict__ Y,
+                                                              int act, int M, int N, float* __restrict__ db) {
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + lane;
+    float a = 0.f;
+    if (n < N)
+        for (int m = wave; m < M; m += 4) a += dY[(size_t)m * N + n] * act_bwd(Y[(size_t)m * N + n], act);
+    red[wave][lane] = a;
+    __syncthreads();
+    if (wave == 0 && n < N) db[n] = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
+}
+
+}  // namespace fr
+
+using namespace fr;
+
+static inline int act_ok(int act) { return act >= ACT_NONE && act <= ACT_TANH; }
+
+extern "C" int fr_linear_fwd(const float* x0, int32_t k0, const float* x1, int32_t k1, const uint8_t* mask, float scale,
+                             const float* W, const float* bias, int64_t M, int32_t N, int32_t act, float* Y,
+                             void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    FR_CHECK_ARG(x0 && W && Y && M >= 1 && N >= 1 && k0 >= 1 && k1 >= 0 && (k1 == 0 || x1) && act_ok(act),
+                 "fr_linear_fwd: bad argument");
+    const int K = k0 + k1;
+    CatMat X{x0, x1, k0, k1};
+    ProfScope prof(K_LINEAR_FWD, stream);
+    FR_LAUNCH(prof, linear_fwd_kernel, dim3((unsigned)((M + TM - 1) / TM), (unsigned)((N + TN - 1) / TN)), dim3(256), 0,
+              stream, X, mask, scale, W, bias, (int)M, (int)N, K, (int)act, Y);
+    FR_CHECK_LAUNCH();
+    return FR_OK;
+}
+
+extern "C" int fr_linear_bwd_input(const float* dY, const float* Y, int32_t act, const float* W, const uint8_t* mask,
+                                   float scale, int64_t M, int32_t N, float* dx0, int32_t k0, float* dx1, int32_t k1,
+                                   void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    FR_CHECK_ARG(dY && Y && W && dx0 && M >= 1 && N >= 1 && k0 >= 1 && k1 >= 0 && (k1 == 0 || dx1) && act_ok(act),
+                 "fr_linear_bwd_input: bad argument");
+    const int K = k0 + k1;
+    CatOut dX{dx0, dx1, k0, k1};
+    ProfScope prof(K_LINEAR_BWD_INPUT, stream);
+    FR_LAUNCH(prof, linear_bwd_input_kernel, dim3((unsigned)((M + TM - 1) / TM), (unsigned)((K + TN - 1) / TN)), dim3(256),
+              0, stream, dY, Y, (int)act, W, mask, scale, (int)M, (int)N, K, dX);
+    FR_CHECK_LAUNCH();
+    return FR_OK;
+}
+
+extern "C" size_t fr_linear_bwd_weight_workspace_bytes(int64_t M, int32_t N, int32_t K) {
+    if (M < 1 || N < 1 || K < 1) return 0;
+    long long splits = (M + 511) / 512;
+    if (splits > 64) splits = 64;
+    return (size_t)splits * N * K * sizeof(float);
+}
+
+extern "C" int fr_linear_bwd_weight(const float* dY, const float* Y, int32_t act, const float* x0, int32_t k0,
+                                    const float* x1, int32_t k1, const uint8_t* mask, float scale, int64_t M, int32_t N,
+                                    float* dW, float* db, void* ws, size_t ws_bytes, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    FR_CHECK_ARG(dY && Y && x0 && dW && ws && M >= 1 && N >= 1 && k0 >= 1 && k1 >= 0 && (k1 == 0 || x1) && act_ok(act),
+                 "fr_linear_bwd_weight: bad argument");
+    const int K = k0 + k1;
+    long long splits = (M + 511) / 512;
+    if (splits > 64) splits = 64;
+    const int rows_per_split = (int)(((M + splits - 1) / splits + TK - 1) / TK * TK);
+    FR_CHECK_ARG(ws_bytes >= (size_t)splits * N * K * sizeof(float), "fr_linear_bwd_weight: workspace too small");
+    CatMat X{x0, x1, k0, k1};
+    {
+        ProfScope prof(K_LINEAR_BWD_WEIGHT, stream);
+        FR_LAUNCH(prof, linear_bwd_weight_kernel,
+                  dim3((unsigned)((N + TM - 1) / TM), (unsigned)((K + TN - 1) / TN), (unsigned)splits), dim3(256), 0, stream,
+                  dY, Y, (int)act, X, mask, scale, (int)M, (int)N, K, rows_per_split, (float*)ws);
+    }
+    FR_CHECK_LAUNCH();
+    const long long n = (long long)N * K;
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256)), dim3(256), 0,
+                       stream, (const float*)ws, (int)splits, n, dW);
+    FR_CHECK_LAUNCH();
+    if (db) {
+        hipLaunchKernelGGL(linear_bwd_bias_kernel, dim3((unsigned)((N + 63) / 64)), dim3(256), 0, stream, dY, Y, (int)act,
+                           (int)M, (int)N, db);
+        FR_CHECK_LAUNCH();
+    }
+    return FR_OK;
+}

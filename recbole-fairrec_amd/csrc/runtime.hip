@@ -24,7 +24,8 @@ static const char* const kKernelNames[K_COUNT] = {
     "focf_finalize_kernel", "focf_backward_adam_kernel", "table_flush_kernel", "table_gather_kernel",
     "adam_dense_kernel",    "table_gather_train_kernel", "table_apply_grad_kernel",
     "bucket_by_owner_kernel", "unbucket_rows_kernel",     "bucket_rows_kernel",
-    "focf_shard_score_kernel", "focf_shard_grads_kernel"};
+    "focf_shard_score_kernel", "focf_shard_grads_kernel", "linear_fwd_kernel",
+    "linear_bwd_input_kernel", "linear_bwd_weight_kernel"};
 
 struct ProfState {
     bool on = false;

@@ -67,6 +67,13 @@ _PROTOS = {
                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "fr_focf_shard_grads": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                                     c_int32, c_void_p, c_void_p, c_void_p]),
+    "fr_linear_fwd": (c_int, [c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_float, c_void_p, c_void_p, c_int64,
+                              c_int32, c_int32, c_void_p, c_void_p]),
+    "fr_linear_bwd_input": (c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_float, c_int64, c_int32,
+                                    c_void_p, c_int32, c_void_p, c_int32, c_void_p]),
+    "fr_linear_bwd_weight_workspace_bytes": (c_size_t, [c_int64, c_int32, c_int32]),
+    "fr_linear_bwd_weight": (c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_void_p,
+                                     c_float, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "fr_prof_enable": (c_int, [c_int]),
     "fr_prof_reset": (c_int, []),
     "fr_prof_kernel_count": (c_int, []),
