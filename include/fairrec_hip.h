@@ -226,6 +226,17 @@ FR_API int fr_linear_bwd_weight(const float* dY, const float* Y, int32_t act, co
                                 const float* x1, int32_t k1, const uint8_t* mask, float scale, int64_t M, int32_t N,
                                 float* dW, float* db, void* ws, size_t ws_bytes, void* stream);
 
+/* ---- NFCF (nfcf.py) ---------------------------------------------------------------------------------------
+ * Loss head of NFCF.calculate_loss, nfcf.py:99-110: y [B] is the scorer MLP's output AFTER its last ReLU
+ * (layers.py:63-70); out = sigmoid(y) (:73); loss = BCELoss(out, label) (:105) [+ fair_weight * differential
+ * fairness over the label==1 rows (:76-97) when `item_ws` != NULL, i.e. when fine-tuning].  `item_ws` is the
+ * item table's workspace after fr_table_gather_train on the batch's item ids (its segments = torch.unique(item)).
+ * Writes out [B], dy [B] = dLoss/dy (the scorer's backward starts from it), loss[3] = (loss, bce, df). */
+FR_API size_t fr_nfcf_loss_workspace_bytes(int64_t B);
+FR_API int fr_nfcf_loss(const float* y, const float* label, const float* sst, int64_t B, float fair_weight, void* item_ws,
+                        size_t item_ws_bytes, int32_t dim, float* out, float* dy, float* loss, void* ws, size_t ws_bytes,
+                        uint32_t* err_flag, void* stream);
+
 /* Dense fused Adam step for small dense parameters (MLP weights, biases): one step of
  * torch.optim.Adam on a flat fp32 tensor, `step` = the step being applied. */
 FR_API int fr_adam_dense(float* p, const float* g, float* m, float* v, int64_t n, const fr_adam* adam, int32_t step,

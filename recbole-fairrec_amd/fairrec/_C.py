@@ -74,6 +74,9 @@ _PROTOS = {
     "fr_linear_bwd_weight_workspace_bytes": (c_size_t, [c_int64, c_int32, c_int32]),
     "fr_linear_bwd_weight": (c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_void_p,
                                      c_float, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "fr_nfcf_loss_workspace_bytes": (c_size_t, [c_int64]),
+    "fr_nfcf_loss": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_float, c_void_p, c_size_t, c_int32, c_void_p,
+                             c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
     "fr_prof_enable": (c_int, [c_int]),
     "fr_prof_reset": (c_int, []),
     "fr_prof_kernel_count": (c_int, []),

@@ -1,0 +1,156 @@
+"""`MLPLayers` with the constructor, module structure and parameter names of recbole/model/layers.py:30-85
+(per layer: Dropout -> Linear -> [BatchNorm1d] -> activation, the last layer included), so state_dict keys
+(`mlp_layers.<3l+1>.weight` ...) interchange with the reference.  The arithmetic runs on the fp32-MFMA kernels of
+csrc/mlp.hip through one autograd Function; there is no torch fallback for CUDA tensors and no CPU path.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence
+
+import torch
+import torch.nn as nn
+from torch.nn.init import normal_
+
+from .. import _C
+
+ACT_CODES = {None: 0, "none": 0, "relu": 1, "leakyrelu": 2, "sigmoid": 3, "tanh": 4}
+
+
+def activation_layer(activation_name='relu', emb_dim=None):
+    """Same name -> module mapping as the reference's activation_layer (layers.py:88-118)."""
+    if activation_name is None:
+        return None
+    name = activation_name.lower()
+    if name == 'sigmoid':
+        return nn.Sigmoid()
+    if name == 'tanh':
+        return nn.Tanh()
+    if name == 'relu':
+        return nn.ReLU()
+    if name == 'leakyrelu':
+        return nn.LeakyReLU()
+    if name == 'none':
+        return None
+    raise NotImplementedError("activation function {} is not implemented".format(activation_name))
+
+
+class _HipMLP(torch.autograd.Function):
+    """y = MLP([x0 | x1]) on the HIP linear kernels; saves the post-activation outputs and the dropout masks."""
+
+    @staticmethod
+    def forward(ctx, x0, x1, act, p_drop, masks, *params):
+        lib = _C.lib()
+        st = _C.current_stream()
+        n_layers = len(params) // 2
+        M = x0.shape[0]
+        x0 = x0.contiguous()
+        x1 = x1.contiguous() if x1 is not None else None
+        scale = 1.0 / (1.0 - p_drop) if p_drop > 0 else 1.0
+        ins = [(x0, x1)]
+        outs = []
+        for l in range(n_layers):
+            W, b = params[2 * l].contiguous(), params[2 * l + 1].contiguous()
+            a, c = ins[-1]
+            k0, k1 = a.shape[1], (c.shape[1] if c is not None else 0)
+            N = W.shape[0]
+            Y = torch.empty((M, N), dtype=torch.float32, device=x0.device)
+            mk = masks[l] if masks is not None else None
+            _C.check(lib.fr_linear_fwd(a.data_ptr(), k0, _C.ptr(c), k1, _C.ptr(mk), scale, W.data_ptr(), b.data_ptr(), M, N,
+                                       act, Y.data_ptr(), st), "fr_linear_fwd")
+            outs.append(Y)
+            ins.append((Y, None))
+        ctx.act, ctx.scale, ctx.masks, ctx.n_layers = act, scale, masks, n_layers
+        ctx.has_x1 = x1 is not None
+        ctx.save_for_backward(x0, *([x1] if x1 is not None else []), *params, *outs)
+        return outs[-1]
+
+    @staticmethod
+    def backward(ctx, dY):
+        lib = _C.lib()
+        st = _C.current_stream()
+        saved = list(ctx.saved_tensors)
+        x0 = saved.pop(0)
+        x1 = saved.pop(0) if ctx.has_x1 else None
+        L = ctx.n_layers
+        params, outs = saved[:2 * L], saved[2 * L:]
+        M = x0.shape[0]
+        grads: List[Optional[torch.Tensor]] = [None] * (2 * L)
+        dY = dY.contiguous()
+        dx0 = dx1 = None
+        for l in range(L - 1, -1, -1):
+            W = params[2 * l].contiguous()
+            Y = outs[l]
+            a, c = (outs[l - 1], None) if l > 0 else (x0, x1)
+            k0, k1 = a.shape[1], (c.shape[1] if c is not None else 0)
+            N, K = W.shape
+            mk = ctx.masks[l] if ctx.masks is not None else None
+            need = lib.fr_linear_bwd_weight_workspace_bytes(M, N, K)
+            ws = torch.empty(need, dtype=torch.uint8, device=x0.device)
+            dW = torch.empty_like(W)
+            db = torch.empty(N, dtype=torch.float32, device=x0.device)
+            _C.check(lib.fr_linear_bwd_weight(dY.data_ptr(), Y.data_ptr(), ctx.act, a.data_ptr(), k0, _C.ptr(c), k1,
+                                              _C.ptr(mk), ctx.scale, M, N, dW.data_ptr(), db.data_ptr(), ws.data_ptr(),
+                                              ws.numel(), st), "fr_linear_bwd_weight")
+            grads[2 * l], grads[2 * l + 1] = dW, db
+            need_dx = l > 0 or ctx.needs_input_grad[0] or (ctx.has_x1 and ctx.needs_input_grad[1])
+            if need_dx:
+                da = torch.empty((M, k0), dtype=torch.float32, device=x0.device)
+                dc = torch.empty((M, k1), dtype=torch.float32, device=x0.device) if k1 else None
+                _C.check(lib.fr_linear_bwd_input(dY.data_ptr(), Y.data_ptr(), ctx.act, W.data_ptr(), _C.ptr(mk), ctx.scale,
+                                                 M, N, da.data_ptr(), k0, _C.ptr(dc), k1, st), "fr_linear_bwd_input")
+                if l > 0:
+                    dY = da
+                else:
+                    dx0, dx1 = da, dc
+        return (dx0, dx1, None, None, None, *grads)
+
+
+class MLPLayers(nn.Module):
+    def __init__(self, layers, dropout=0., activation='relu', bn=False, init_method=None):
+        super().__init__()
+        self.layers = layers
+        self.dropout = dropout
+        self.activation = activation
+        self.use_bn = bn
+        self.init_method = init_method
+        if bn:
+            raise NotImplementedError("BatchNorm1d layers (PFCN filters / discriminators) are not on the HIP path yet")
+        if (activation.lower() if isinstance(activation, str) else activation) not in ACT_CODES:
+            raise NotImplementedError(f"activation {activation} is not on the HIP path")
+        mods = []
+        for input_size, output_size in zip(self.layers[:-1], self.layers[1:]):
+            mods.append(nn.Dropout(p=self.dropout))
+            mods.append(nn.Linear(input_size, output_size))
+            act = activation_layer(self.activation, output_size)
+            if act is not None:
+                mods.append(act)
+        self.mlp_layers = nn.Sequential(*mods)
+        self.forced_masks: Optional[Sequence[torch.Tensor]] = None   # tests inject recorded dropout masks here
+        if self.init_method is not None:
+            self.apply(self.init_weights)
+
+    def init_weights(self, module):
+        if isinstance(module, nn.Linear):
+            if self.init_method == 'norm':
+                normal_(module.weight.data, 0, 0.01)
+            if module.bias is not None:
+                module.bias.data.fill_(0.0)
+
+    def linears(self) -> List[nn.Linear]:
+        return [m for m in self.mlp_layers if isinstance(m, nn.Linear)]
+
+    def forward(self, input_feature, second_block=None):
+        """MLP(cat(input_feature, second_block)); `second_block` avoids materialising the concatenation."""
+        if input_feature.device.type != "cuda":
+            raise _C.FairrecError("MLPLayers runs only on a ROCm device; there is no CPU fallback")
+        lins = self.linears()
+        params = [t for lin in lins for t in (lin.weight, lin.bias)]
+        p = float(self.dropout) if self.training else 0.0
+        masks = None
+        if self.forced_masks is not None:
+            masks = [m.to(input_feature.device, torch.uint8).contiguous() for m in self.forced_masks]
+        elif p > 0.0:
+            M = input_feature.shape[0]
+            masks = [(torch.rand((M, lin.in_features), device=input_feature.device) >= p).to(torch.uint8) for lin in lins]
+        name = self.activation.lower() if isinstance(self.activation, str) else self.activation
+        return _HipMLP.apply(input_feature, second_block, ACT_CODES[name], p if masks is not None else 0.0, masks, *params)

@@ -213,9 +213,18 @@ class FusedLazyAdam:
         self.engine.backward_adam()
 
     def state_dict(self):
-        return {"state": {name: t.adam_state(self.hyper) for name, t in self.engine.tables().items()},
-                "param_groups": [dict(self.defaults, params=list(self.engine.tables().keys()))]}
+        state = {name: t.adam_state(self.hyper) for name, t in self.engine.tables().items()}
+        if hasattr(self.engine, "dense_state"):
+            state.update(self.engine.dense_state())
+        return {"state": state, "param_groups": [dict(self.defaults, params=list(state.keys()))]}
 
     def load_state_dict(self, sd):
+        tables = self.engine.tables()
+        dense = {}
         for name, st in sd["state"].items():
-            self.engine.tables()[name].load_adam_state(st)
+            if name in tables:
+                tables[name].load_adam_state(st)
+            else:
+                dense[name] = st
+        if dense:
+            self.engine.load_dense_state(dense)

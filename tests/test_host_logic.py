@@ -96,3 +96,27 @@ def test_no_cpu_fallback():
     from fairrec.model.fair_recommender.focf import FocfEngine
     with pytest.raises(_C.FairrecError):
         FocfEngine(torch.zeros(4, 8), torch.zeros(4, 8), "none", 0.0, 5.0)
+
+
+def test_nfcf_reset_params_matches_reference_golden(tmp_path):
+    """NFCF.reset_params (nfcf.py:49-67): de-biasing projection of the pre-trained user table, freeze, item re-init."""
+    from fairrec.model.fair_recommender.nfcf import NFCF
+    z = np.load(os.path.join(GOLDEN, "nfcf_finetune.npz"))
+    n_users, D = z["pretrain_user_embedding"].shape
+    n_items = z["init.item_embedding.weight"].shape[0]
+
+    class DS:
+        def num(self, f):
+            return {"user_id": n_users, "item_id": n_items}[f]
+
+        def get_user_feature(self):
+            return Interaction({"user_id": torch.arange(n_users), "gender": torch.from_numpy(z["gender"])})
+
+    ck = tmp_path / "pre.pth"
+    torch.save({"state_dict": {"user_embedding.weight": torch.tensor(z["pretrain_user_embedding"])}}, ck)
+    cfg = Config(model="NFCF", config_dict={"embedding_size": D, "mlp_hidden_size": [16, 8], "device": "cpu",
+                                            "load_pretrain_path": str(ck)})
+    m = NFCF(cfg, DS())
+    np.testing.assert_allclose(m.user_embedding.weight.detach().numpy(), z["init.user_embedding.weight"], rtol=1e-6, atol=1e-7)
+    assert not m.user_embedding.weight.requires_grad and m.item_embedding.weight.requires_grad
+    assert get_model("NFCF") is NFCF and get_trainer(None, "NFCF").__name__ == "Trainer"

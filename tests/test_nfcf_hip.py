@@ -1,0 +1,74 @@
+"""GPU parity: NFCF (lazy tables + fp32-MFMA scorer + BCE / differential-fairness head) vs the reference's golden
+vectors, through the plugin surface (model.calculate_loss -> loss.backward() -> optimizer.step())."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+CASES = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "nfcf_*.npz")))
+
+
+class _DS:
+    def __init__(self, n_users, n_items, gender):
+        from fairrec.data.interaction import Interaction
+        self._n = {"user_id": n_users, "item_id": n_items}
+        self._uf = Interaction({"user_id": torch.arange(n_users), "gender": torch.from_numpy(gender)})
+
+    def num(self, f):
+        return self._n[f]
+
+    def get_user_feature(self):
+        return self._uf
+
+
+@pytest.mark.parametrize("path", CASES, ids=[os.path.basename(p)[:-4] for p in CASES])
+def test_nfcf_training_matches_reference_golden(path, tmp_path):
+    from fairrec.config import Config
+    from fairrec.data.interaction import Interaction
+    from fairrec.model.fair_recommender.nfcf import NFCF
+    from fairrec.optim import FusedLazyAdam
+    z = np.load(path)
+    stage = str(z["stage"])
+    lr, wd, fw, p = (float(x) for x in z["hyper"])
+    n_users, D = z["init.user_embedding.weight"].shape
+    n_items = z["init.item_embedding.weight"].shape[0]
+    cfg = Config(model="NFCF", config_dict={"embedding_size": D, "mlp_hidden_size": [int(h) for h in z["hidden"]],
+                                            "dropout": p, "fair_weight": fw, "device": "cuda", "load_pretrain_path": None})
+    model = NFCF(cfg, _DS(n_users, n_items, z["gender"]))
+    init = {k[5:]: torch.tensor(z[k]) for k in z.files if k.startswith("init.")}
+    if stage == "finetune":     # the state reset_params produced in the reference (its projection is pinned in the oracle test)
+        model.load_pretrain_path = "reference-checkpoint"
+        model.user_embedding.weight.requires_grad = False
+    model.load_state_dict(init)
+    model = model.to("cuda")
+    model.train()
+    opt = FusedLazyAdam(model.hip_engine(), lr=lr, weight_decay=wd, sweep_period=3)
+    n_layers = len(z["hidden"]) + 1
+    snaps = set(int(s) for s in z["snaps"])
+    losses = []
+    for t in range(len(z["user_id"])):
+        inter = Interaction({"user_id": torch.tensor(z["user_id"][t]), "item_id": torch.tensor(z["item_id"][t]),
+                             "label": torch.tensor(z["label"][t]), "gender": torch.tensor(z["sst"][t])}).to("cuda")
+        if p > 0:
+            model.mlp_layers.forced_masks = [torch.tensor(z[f"mask{l}"][t]) for l in range(n_layers)]
+        opt.zero_grad()
+        loss = model.calculate_loss(inter)
+        losses.append(loss.detach().reshape(1).clone())
+        loss.backward()
+        opt.step()
+        if (t + 1) in snaps:
+            sd = model.state_dict()
+            for k, v in sd.items():
+                ref = z[f"after{t + 1}." + k]
+                a = v.cpu().numpy()
+                assert (np.abs(a - ref) <= 1e-4 * np.abs(ref) + 2e-6).all(), (k, t + 1, np.abs(a - ref).max())
+    np.testing.assert_allclose(torch.cat(losses).cpu().numpy(), z["loss"], rtol=1e-4)
+    model.hip_engine().check_device_errors()
+    model.eval()
+    model.mlp_layers.forced_masks = None
+    with torch.no_grad():
+        pr = model.predict(inter).cpu().numpy()
+    np.testing.assert_allclose(pr, z["predict_last"], rtol=1e-4, atol=1e-6)
