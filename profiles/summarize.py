@@ -21,7 +21,7 @@ dst = os.path.join(ROOT, "profiles")
 def one(pattern):
     files = glob.glob(os.path.join(src, pattern), recursive=True)
     assert files, pattern
-    return files[0]
+    return max(files, key=os.path.getmtime)   # gpurun merges runs into the same directory: take the newest
 
 
 shutil.copy(one("stats/**/*_kernel_stats.csv"), os.path.join(dst, f"{rnd}_kernel_stats.csv"))
