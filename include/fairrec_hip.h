@@ -226,6 +226,32 @@ FR_API int fr_linear_bwd_weight(const float* dY, const float* Y, int32_t act, co
                                 const float* x1, int32_t k1, const uint8_t* mask, float scale, int64_t M, int32_t N,
                                 float* dW, float* db, void* ws, size_t ws_bytes, void* stream);
 
+/* BatchNorm1d on batch statistics between Linear and activation (MLPLayers(bn=True), layers.py:66-67; the PFCN filters
+ * and discriminators, which the reference never puts in eval mode).  Z [M,N] -> Y = act(gamma * xhat + beta);
+ * xhat [M,N] and invstd [N] are kept for fr_bn_bwd; running_mean/var (may be NULL) follow torch (momentum, unbiased). */
+FR_API int fr_bn_fwd(const float* Z, const float* gamma, const float* beta, float eps, float momentum,
+                     float* running_mean, float* running_var, int64_t M, int32_t N, int32_t act, float* Y, float* xhat,
+                     float* invstd, void* stream);
+FR_API int fr_bn_bwd(const float* dY, const float* Y, int32_t act, const float* xhat, const float* invstd,
+                     const float* gamma, int64_t M, int32_t N, float* dZ, float* dgamma, float* dbeta, void* stream);
+
+/* ---- PFCN scoring / losses (pfcn_pmf.py, pfcn_biasedmf.py, loss.py) -------------------------------------------------
+ * fr_rowdot_*   : torch.mul(a, b).sum(-1) on gathered rows and its backward (da = g*b, db = g*a; either may be NULL)
+ * fr_bpr        : BPRLoss, loss.py:45-47
+ * fr_bpr_outer  : the same loss under PFCN_BiasedMF's [B] + [B,1] -> [B,B] broadcast (pfcn_biasedmf.py:192-195,
+ *                 SURVEY.md App. B-1): mean over all (i,j) of -log(1e-10 + sigmoid(a_j + c_i)); nothing of size B^2 is stored
+ * fr_softmax_ce : nn.CrossEntropyLoss (multi-class discriminators, pfcn_biasedmf.py:216) */
+FR_API int fr_rowdot_fwd(const float* a, const float* b, int64_t B, int32_t dim, float* out, void* stream);
+FR_API int fr_rowdot_bwd(const float* g, const float* a, const float* b, int64_t B, int32_t dim, float* da, float* db,
+                         void* stream);
+FR_API size_t fr_bpr_workspace_bytes(int64_t B, int32_t outer);
+FR_API int fr_bpr(const float* pos, const float* neg, int64_t B, float* loss, float* dpos, float* dneg, void* ws,
+                  size_t ws_bytes, void* stream);
+FR_API int fr_bpr_outer(const float* a, const float* c, int64_t B, float* loss, float* da, float* dc, void* ws,
+                        size_t ws_bytes, void* stream);
+FR_API int fr_softmax_ce(const float* logits, const int64_t* label, int64_t M, int32_t C, float* loss, float* dlogits,
+                         void* ws, size_t ws_bytes, uint32_t* err_flag, void* stream);
+
 /* ---- NFCF (nfcf.py) ---------------------------------------------------------------------------------------
  * Loss head of NFCF.calculate_loss, nfcf.py:99-110: y [B] is the scorer MLP's output AFTER its last ReLU
  * (layers.py:63-70); out = sigmoid(y) (:73); loss = BCELoss(out, label) (:105) [+ fair_weight * differential

@@ -304,3 +304,121 @@ extern "C" int fr_linear_bwd_weight(const float* dY, const float* Y, int32_t act
     }
     return FR_OK;
 }
+
+// ---- BatchNorm1d on batch statistics (training mode) --------------------------------------------------------------
+// Replaces nn.BatchNorm1d inside MLPLayers(bn=True) (layers.py:66-67; PFCN filters / discriminators, which the
+// reference never switches to eval mode -- SURVEY.md App. B-3).  One 1024-thread block per 64 columns: lane = column,
+// 16 waves stride over the rows, partial sums combined through LDS in wave order (fixed order => reproducible).
+namespace fr {
+
+__device__ __forceinline__ float col_reduce_16(float a, float (*red)[64], int wave, int lane) {
+    __syncthreads();
+    red[wave][lane] = a;
+    __syncthreads();
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) s += red[w][lane];
+    return s;
+}
+
+// Y = act(gamma * (Z - mean) / sqrt(var + eps) + beta); xhat and invstd are kept for the backward;
+// running_mean / running_var follow torch (momentum, unbiased variance).
+__global__ __launch_bounds__(1024) void bn_fwd_kernel(const float* __restrict__ Z, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, float eps, float momentum,
+                                                      float* __restrict__ rmean, float* __restrict__ rvar, int M, int N,
+                                                      int act, float* __restrict__ Y, float* __restrict__ xhat,
+                                                      float* __restrict__ invstd_out) {
+    __shared__ float red[16][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + lane;
+    const bool ok = n < N;
+    float s = 0.f;
+    if (ok)
+        for (int m = wave; m < M; m += 16) s += Z[(size_t)m * N + n];
+    const float mean = col_reduce_16(s, red, wave, lane) / (float)M;
+    float q = 0.f;
+    if (ok)
+        for (int m = wave; m < M; m += 16) {
+            const float d = Z[(size_t)m * N + n] - mean;
+            q += d * d;
+        }
+    const float ssq = col_reduce_16(q, red, wave, lane);
+    const float var = ssq / (float)M;
+    const float invstd = 1.f / sqrtf(var + eps);
+    if (ok) {
+        const float g = gamma[n], b = beta[n];
+        for (int m = wave; m < M; m += 16) {
+            const float xh = (Z[(size_t)m * N + n] - mean) * invstd;
+            xhat[(size_t)m * N + n] = xh;
+            Y[(size_t)m * N + n] = act_fwd(fmaf(g, xh, b), act);
+        }
+        if (wave == 0) {
+            invstd_out[n] = invstd;
+            if (rmean) {
+                rmean[n] = (1.f - momentum) * rmean[n] + momentum * mean;
+                rvar[n] = (1.f - momentum) * rvar[n] + momentum * (M > 1 ? ssq / (float)(M - 1) : var);
+            }
+        }
+    }
+}
+
+// dZ = invstd * gamma * (dA - mean(dA) - xhat * mean(dA * xhat)),  dA = dY o act'(Y);  dgamma = sum dA*xhat, dbeta = sum dA
+__global__ __launch_bounds__(1024) void bn_bwd_kernel(const float* __restrict__ dY, const float* __restrict__ Y, int act,
+                                                      const float* __restrict__ xhat, const float* __restrict__ invstd,
+                                                      const float* __restrict__ gamma, int M, int N,
+                                                      float* __restrict__ dZ, float* __restrict__ dgamma,
+                                                      float* __restrict__ dbeta) {
+    __shared__ float red[16][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + lane;
+    const bool ok = n < N;
+    float s1 = 0.f, s2 = 0.f;
+    if (ok)
+        for (int m = wave; m < M; m += 16) {
+            const size_t i = (size_t)m * N + n;
+            const float da = dY[i] * act_bwd(Y[i], act);
+            s1 += da;
+            s2 += da * xhat[i];
+        }
+    const float sum_da = col_reduce_16(s1, red, wave, lane);
+    const float sum_dax = col_reduce_16(s2, red, wave, lane);
+    if (ok) {
+        const float g = gamma[n], is = invstd[n];
+        const float m1 = sum_da / (float)M, m2 = sum_dax / (float)M;
+        for (int m = wave; m < M; m += 16) {
+            const size_t i = (size_t)m * N + n;
+            const float da = dY[i] * act_bwd(Y[i], act);
+            dZ[i] = is * g * (da - m1 - xhat[i] * m2);
+        }
+        if (wave == 0) {
+            dgamma[n] = sum_dax;
+            dbeta[n] = sum_da;
+        }
+    }
+}
+
+}  // namespace fr
+
+extern "C" int fr_bn_fwd(const float* Z, const float* gamma, const float* beta, float eps, float momentum,
+                         float* running_mean, float* running_var, int64_t M, int32_t N, int32_t act, float* Y,
+                         float* xhat, float* invstd, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    FR_CHECK_ARG(Z && gamma && beta && Y && xhat && invstd && M >= 1 && N >= 1 && act_ok(act), "fr_bn_fwd: bad argument");
+    ProfScope prof(K_BN_FWD, stream);
+    FR_LAUNCH(prof, bn_fwd_kernel, dim3((unsigned)((N + 63) / 64)), dim3(1024), 0, stream, Z, gamma, beta, eps, momentum,
+              running_mean, running_var, (int)M, (int)N, (int)act, Y, xhat, invstd);
+    FR_CHECK_LAUNCH();
+    return FR_OK;
+}
+
+extern "C" int fr_bn_bwd(const float* dY, const float* Y, int32_t act, const float* xhat, const float* invstd,
+                         const float* gamma, int64_t M, int32_t N, float* dZ, float* dgamma, float* dbeta, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    FR_CHECK_ARG(dY && Y && xhat && invstd && gamma && dZ && dgamma && dbeta && M >= 1 && N >= 1 && act_ok(act),
+                 "fr_bn_bwd: bad argument");
+    ProfScope prof(K_BN_BWD, stream);
+    FR_LAUNCH(prof, bn_bwd_kernel, dim3((unsigned)((N + 63) / 64)), dim3(1024), 0, stream, dY, Y, (int)act, xhat, invstd,
+              gamma, (int)M, (int)N, dZ, dgamma, dbeta);
+    FR_CHECK_LAUNCH();
+    return FR_OK;
+}

@@ -1,0 +1,241 @@
+// PFCN scoring / loss kernels: row-wise dot products of gathered rows, BPR loss (plain and the reference's
+// [B] + [B,1] -> [B,B] broadcast form), softmax cross-entropy for multi-class discriminators.
+//
+// Replaces pfcn_pmf.py:182-186 / pfcn_biasedmf.py:192-195 (torch.mul(...).sum(-1), BPRLoss loss.py:45-47) and
+// pfcn_biasedmf.py:211-216 (nn.CrossEntropyLoss) with their autograd.
+#include "common.hpp"
+#include "kernels.hpp"
+
+namespace fr {
+
+// out[b] = sum_d a[b,d] * b[b,d]                         (one wave per row)
+__global__ __launch_bounds__(256) void rowdot_fwd_kernel(const float* __restrict__ a, const float* __restrict__ b, int B,
+                                                         int D, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= B) return;
+    float s = 0.f;
+    for (int d = lane; d < D; d += 64) s = fmaf(a[(size_t)r * D + d], b[(size_t)r * D + d], s);
+    s = wave_sum(s);
+    if (lane == 0) out[r] = s;
+}
+
+// da[b,:] = g[b] * b[b,:],  db[b,:] = g[b] * a[b,:]
+__global__ __launch_bounds__(256) void rowdot_bwd_kernel(const float* __restrict__ g, const float* __restrict__ a,
+                                                         const float* __restrict__ b, int B, int D,
+                                                         float* __restrict__ da, float* __restrict__ db) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= B) return;
+    const float gr = g[r];
+    for (int d = lane; d < D; d += 64) {
+        const size_t i = (size_t)r * D + d;
+        if (da) da[i] = gr * b[i];
+        if (db) db[i] = gr * a[i];
+    }
+}
+
+__device__ __forceinline__ float bpr_term(float x, float& dterm) {
+    // -log(1e-10 + sigmoid(x)) and its derivative  -sigmoid'(x) / (1e-10 + sigmoid(x))
+    const float s = 1.f / (1.f + __expf(-x));
+    dterm = -s * (1.f - s) / (1e-10f + s);
+    return -__logf(1e-10f + s);
+}
+
+// plain BPR (PMF): loss = mean_b term(pos_b - neg_b); dpos = dterm / B, dneg = -dterm / B
+__global__ __launch_bounds__(256) void bpr_kernel(const float* __restrict__ pos, const float* __restrict__ neg, int B,
+                                                  float* __restrict__ dpos, float* __restrict__ dneg,
+                                                  float* __restrict__ part) {
+    __shared__ float red[4];
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    float l = 0.f;
+    if (b < B) {
+        float dt;
+        l = bpr_term(pos[b] - neg[b], dt);
+        dpos[b] = dt / (float)B;
+        dneg[b] = -dt / (float)B;
+    }
+    l = wave_sum(l);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = l;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
+}
+
+// BiasedMF's broadcast form: x_ij = a_j + c_i, loss = mean_ij term(x_ij).
+// One block per 64 values of i (rows), every thread walks all j: gc_i = sum_j dterm / B^2, and per-block partial
+// column sums ga_part[block][j]; a second kernel adds the partials in block order.  B^2 transcendental pairs, nothing
+// of size B^2 is ever stored (the reference materialises the [B,B] matrix).
+__global__ __launch_bounds__(256) void bpr_outer_kernel(const float* __restrict__ a, const float* __restrict__ c, int B,
+                                                        float* __restrict__ dc, float* __restrict__ ga_part,
+                                                        float* __restrict__ loss_part) {
+    __shared__ float cs[64];
+    __shared__ float red[4];
+    const int i0 = blockIdx.x * 64;
+    if (threadIdx.x < 64) cs[threadIdx.x] = (i0 + threadIdx.x < B) ? c[i0 + threadIdx.x] : 0.f;
+    __syncthreads();
+    const int ni = min(64, B - i0);
+    const float inv = 1.f / ((float)B * (float)B);
+    float lsum = 0.f;
+    // thread t owns columns j = t, t+256, ...: column sums over this block's rows
+    for (int j = threadIdx.x; j < B; j += 256) {
+        const float aj = a[j];
+        float gcol = 0.f;
+        for (int i = 0; i < ni; ++i) {
+            float dt;
+            lsum += bpr_term(aj + cs[i], dt);
+            gcol += dt;
+        }
+        ga_part[(size_t)blockIdx.x * B + j] = gcol * inv;
+    }
+    lsum = wave_sum(lsum);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = lsum;
+    __syncthreads();
+    if (threadIdx.x == 0) loss_part[blockIdx.x] = (((red[0] + red[1]) + red[2]) + red[3]) * inv;
+    // row sums gc_i: wave w of the block takes rows w, w+4, ...; lanes stride over j
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = wave; i < ni; i += 4) {
+        const float ci = cs[i];
+        float g = 0.f;
+        for (int j = lane; j < B; j += 64) {
+            float dt;
+            (void)bpr_term(a[j] + ci, dt);
+            g += dt;
+        }
+        g = wave_sum(g);
+        if (lane == 0) dc[i0 + i] = g * inv;
+    }
+}
+
+__global__ __launch_bounds__(256) void bpr_outer_reduce_kernel(const float* __restrict__ ga_part, int nblk, int B,
+                                                               float* __restrict__ da) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= B) return;
+    float s = 0.f;
+    for (int k = 0; k < nblk; ++k) s += ga_part[(size_t)k * B + j];
+    da[j] = s;
+}
+
+__global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restrict__ part, int n, float scale,
+                                                           float* __restrict__ out) {
+    __shared__ float red[4];
+    float a = 0.f;
+    for (int q = threadIdx.x; q < n; q += 256) a += part[q];
+    a = wave_sum(a);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = (((red[0] + red[1]) + red[2]) + red[3]) * scale;
+}
+
+// softmax cross-entropy, mean over rows: one thread per row, C <= 64 classes
+__global__ __launch_bounds__(256) void softmax_ce_kernel(const float* __restrict__ logits, const long long* __restrict__ label,
+                                                         int M, int C, float* __restrict__ dlogits,
+                                                         float* __restrict__ part, uint32_t* err) {
+    __shared__ float red[4];
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    float l = 0.f;
+    if (m < M) {
+        const float* z = logits + (size_t)m * C;
+        float mx = z[0];
+        for (int c = 1; c < C; ++c) mx = fmaxf(mx, z[c]);
+        float se = 0.f;
+        for (int c = 0; c < C; ++c) se += __expf(z[c] - mx);
+        long long y = label[m];
+        if (y < 0 || y >= C) {
+            if (err) atomicOr(err, FR_DEV_ERR_INDEX_RANGE);
+            y = 0;
+        }
+        const float lse = mx + __logf(se);
+        l = lse - z[y];
+        for (int c = 0; c < C; ++c)
+            dlogits[(size_t)m * C + c] = (__expf(z[c] - lse) - (c == (int)y ? 1.f : 0.f)) / (float)M;
+    }
+    l = wave_sum(l);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = l;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
+}
+
+}  // namespace fr
+
+using namespace fr;
+
+extern "C" int fr_rowdot_fwd(const float* a, const float* b, int64_t B, int32_t dim, float* out, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    FR_CHECK_ARG(a && b && out && B >= 1 && dim >= 1, "fr_rowdot_fwd: bad argument");
+    ProfScope prof(K_ROWDOT, stream);
+    FR_LAUNCH(prof, rowdot_fwd_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, stream, a, b, (int)B, (int)dim, out);
+    FR_CHECK_LAUNCH();
+    return FR_OK;
+}
+
+extern "C" int fr_rowdot_bwd(const float* g, const float* a, const float* b, int64_t B, int32_t dim, float* da, float* db,
+                             void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    FR_CHECK_ARG(g && a && b && (da || db) && B >= 1 && dim >= 1, "fr_rowdot_bwd: bad argument");
+    ProfScope prof(K_ROWDOT, stream);
+    FR_LAUNCH(prof, rowdot_bwd_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, stream, g, a, b, (int)B, (int)dim, da,
+              db);
+    FR_CHECK_LAUNCH();
+    return FR_OK;
+}
+
+extern "C" size_t fr_bpr_workspace_bytes(int64_t B, int32_t outer) {
+    if (B < 1) return 0;
+    const size_t nb = outer ? (size_t)(B + 63) / 64 : (size_t)(B + 255) / 256;
+    return align_up(nb * 4, 256) + (outer ? nb * (size_t)B * 4 : 0);
+}
+
+// BPRLoss (loss.py:45-47): loss[0] = mean -log(1e-10 + sigmoid(pos - neg)); dpos, dneg = dLoss/d(pos, neg)
+extern "C" int fr_bpr(const float* pos, const float* neg, int64_t B, float* loss, float* dpos, float* dneg, void* ws,
+                      size_t ws_bytes, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    FR_CHECK_ARG(pos && neg && loss && dpos && dneg && ws && B >= 1 && ws_bytes >= fr_bpr_workspace_bytes(B, 0),
+                 "fr_bpr: bad argument");
+    const int nb = (int)((B + 255) / 256);
+    {
+        ProfScope prof(K_BPR, stream);
+        FR_LAUNCH(prof, bpr_kernel, dim3(nb), dim3(256), 0, stream, pos, neg, (int)B, dpos, dneg, (float*)ws);
+    }
+    FR_CHECK_LAUNCH();
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, stream, (const float*)ws, nb, 1.f / (float)B, loss);
+    FR_CHECK_LAUNCH();
+    return FR_OK;
+}
+
+// The [B] + [B,1] broadcast of PFCN_BiasedMF: loss[0] = mean_{i,j} -log(1e-10 + sigmoid(a_j + c_i)),
+// a = (u.p - u.n) per row, c = (pos item bias - neg item bias) per row; da, dc = dLoss/d(a, c).
+extern "C" int fr_bpr_outer(const float* a, const float* c, int64_t B, float* loss, float* da, float* dc, void* ws,
+                            size_t ws_bytes, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    FR_CHECK_ARG(a && c && loss && da && dc && ws && B >= 1 && ws_bytes >= fr_bpr_workspace_bytes(B, 1),
+                 "fr_bpr_outer: bad argument");
+    const int nb = (int)((B + 63) / 64);
+    float* loss_part = (float*)ws;
+    float* ga_part = (float*)((char*)ws + align_up((size_t)nb * 4, 256));
+    {
+        ProfScope prof(K_BPR, stream);
+        FR_LAUNCH(prof, bpr_outer_kernel, dim3(nb), dim3(256), 0, stream, a, c, (int)B, dc, ga_part, loss_part);
+    }
+    FR_CHECK_LAUNCH();
+    hipLaunchKernelGGL(bpr_outer_reduce_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, stream,
+                       (const float*)ga_part, nb, (int)B, da);
+    FR_CHECK_LAUNCH();
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, stream, (const float*)loss_part, nb, 1.f, loss);
+    FR_CHECK_LAUNCH();
+    return FR_OK;
+}
+
+// nn.CrossEntropyLoss (mean): loss[0], dlogits [M, C]
+extern "C" int fr_softmax_ce(const float* logits, const int64_t* label, int64_t M, int32_t C, float* loss, float* dlogits,
+                             void* ws, size_t ws_bytes, uint32_t* err_flag, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    const int nb = (int)((M + 255) / 256);
+    FR_CHECK_ARG(logits && label && loss && dlogits && ws && M >= 1 && C >= 1 && C <= 64 && ws_bytes >= (size_t)nb * 4,
+                 "fr_softmax_ce: bad argument");
+    hipLaunchKernelGGL(softmax_ce_kernel, dim3(nb), dim3(256), 0, stream, logits, (const long long*)label, (int)M, (int)C,
+                       dlogits, (float*)ws, err_flag);
+    FR_CHECK_LAUNCH();
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, stream, (const float*)ws, nb, 1.f / (float)M, loss);
+    FR_CHECK_LAUNCH();
+    return FR_OK;
+}

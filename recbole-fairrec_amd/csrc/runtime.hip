@@ -25,7 +25,8 @@ static const char* const kKernelNames[K_COUNT] = {
     "adam_dense_kernel",    "table_gather_train_kernel", "table_apply_grad_kernel",
     "bucket_by_owner_kernel", "unbucket_rows_kernel",     "bucket_rows_kernel",
     "focf_shard_score_kernel", "focf_shard_grads_kernel", "linear_fwd_kernel",
-    "linear_bwd_input_kernel", "linear_bwd_weight_kernel", "nfcf_bce_kernel"};
+    "linear_bwd_input_kernel", "linear_bwd_weight_kernel", "nfcf_bce_kernel",
+    "bn_fwd_kernel", "bn_bwd_kernel", "rowdot_kernel", "bpr_kernel"};
 
 struct ProfState {
     bool on = false;

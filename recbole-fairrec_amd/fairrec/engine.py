@@ -34,28 +34,43 @@ class GenericEngine:
         self._tables: Dict[str, LazyTable] = {}
         self._weights: Dict[str, torch.nn.Parameter] = {}
         self._dense: Dict[str, DenseState] = {}
+        self._group: Dict[str, Optional[str]] = {}      # entry -> optimizer group ('filter' / 'dis' / None)
+        self._hyper_of: Dict[str, AdamHyper] = {}       # entry -> hyper-parameters of the optimizer that owns it
         self.hyper = AdamHyper(device=self.device, cap=1)
         self.optimizer = None
         self.sweep_period: Optional[int] = None
         self.err_flag = torch.zeros(1, dtype=torch.int32, device=self.device)
 
     # --- registration ---------------------------------------------------------------------------------
-    def add_table(self, name: str, weight: torch.nn.Parameter, trainable: bool = True) -> LazyTable:
+    def add_table(self, name: str, weight: torch.nn.Parameter, trainable: bool = True, group=None) -> LazyTable:
         t = LazyTable(weight.data, trainable=trainable)
         self._tables[name] = t
         self._weights[name] = weight
+        self._group[name] = group
         return t
 
-    def add_dense(self, name: str, p: torch.nn.Parameter):
+    def add_dense(self, name: str, p: torch.nn.Parameter, group=None):
         self._dense[name] = DenseState(p)
+        self._group[name] = group
 
-    def tables(self) -> Dict[str, LazyTable]:
-        return {k: t for k, t in self._tables.items() if t.trainable}
+    def _owned(self, name, group):
+        return group is None or self._group.get(name) == group
 
-    def bind_optimizer(self, opt, sweep_period):
+    def tables(self, group=None) -> Dict[str, LazyTable]:
+        return {k: t for k, t in self._tables.items() if t.trainable and self._owned(k, group)}
+
+    def bind_optimizer(self, opt, sweep_period, group=None):
+        """`group` = the subset of entries this optimizer owns (PFCN: optimizer_filter / optimizer_dis,
+        trainer.py:1201-1212); None = everything (the single default optimizer)."""
         self.optimizer, self.hyper, self.sweep_period = opt, opt.hyper, sweep_period
+        for name in list(self._tables) + list(self._dense):
+            if self._owned(name, group):
+                self._hyper_of[name] = opt.hyper
         for t in self._tables.values():
             t.ensure_state()
+
+    def _hyper(self, name) -> AdamHyper:
+        return self._hyper_of.get(name, self.hyper)
 
     # --- forward helpers --------------------------------------------------------------------------------
     def lookup(self, name: str, idx: torch.Tensor) -> torch.Tensor:
@@ -63,34 +78,46 @@ class GenericEngine:
         t = self._tables[name]
         idx = idx.to(self.device, torch.int64).contiguous()
         if t.trainable and torch.is_grad_enabled():
-            return LazyLookup.apply(self._weights[name], t, self.hyper, idx, self.err_flag)
-        return t.gather(self.hyper, idx, self.err_flag)
+            return LazyLookup.apply(self._weights[name], t, self._hyper(name), idx, self.err_flag)
+        return t.gather(self._hyper(name), idx, self.err_flag)
 
     # --- optimizer.step() -------------------------------------------------------------------------------
-    def backward_adam(self):
-        for t in self._tables.values():
-            if t.trainable and t._pending is not None:
-                if t._grad_rows is None:      # looked up but no gradient reached it: torch would skip the tensor
-                    t._pending = None
-                    continue
-                M = t._pending[0]
-                s = self.sweep_period if self.sweep_period is not None else t.default_sweep(M)
-                t.apply_grad(self.hyper, None, s)
+    def zero_grad(self, group=None):
+        for name, d in self._dense.items():
+            if self._owned(name, group):
+                d.p.grad = None
+        for name, t in self._tables.items():
+            if self._owned(name, group):
+                t._grad_rows = None
+
+    def backward_adam(self, group=None):
+        for name, t in self._tables.items():
+            if not (t.trainable and t._pending is not None):
+                continue
+            if not self._owned(name, group) or t._grad_rows is None:
+                # not this optimizer's tensor, or no gradient reached it: torch would skip it (no step, no decay)
+                t._pending = None
+                t._grad_rows = None
+                continue
+            M = t._pending[0]
+            s = self.sweep_period if self.sweep_period is not None else t.default_sweep(M)
+            t.apply_grad(self._hyper(name), None, s)
         st = _C.current_stream()
-        for d in self._dense.values():
+        for name, d in self._dense.items():
             g = d.p.grad
-            if g is None:
+            if g is None or not self._owned(name, group):
                 continue
             d.step += 1
-            self.hyper.check_step(d.step)
+            h = self._hyper(name)
+            h.check_step(d.step)
             g = g.contiguous()
             _C.check(_C.lib().fr_adam_dense(d.p.data.data_ptr(), g.data_ptr(), d.m.data_ptr(), d.v.data_ptr(),
-                                            d.p.numel(), ctypes.byref(self.hyper.c()), d.step, st), "fr_adam_dense")
+                                            d.p.numel(), ctypes.byref(h.c()), d.step, st), "fr_adam_dense")
             d.p.grad = None
 
     def flush(self):
-        for t in self._tables.values():
-            t.flush(self.hyper)
+        for name, t in self._tables.items():
+            t.flush(self._hyper(name))
 
     def check_device_errors(self):
         e = int(self.err_flag.item())
@@ -99,8 +126,9 @@ class GenericEngine:
             raise IndexError(f"device error word {e} (1: row id out of range, 2: unexpected sensitive groups)")
 
     # --- torch.optim.Adam-shaped state for checkpoints ----------------------------------------------------
-    def dense_state(self):
-        return {k: {"step": torch.tensor(float(d.step)), "exp_avg": d.m, "exp_avg_sq": d.v} for k, d in self._dense.items()}
+    def dense_state(self, group=None):
+        return {k: {"step": torch.tensor(float(d.step)), "exp_avg": d.m, "exp_avg_sq": d.v}
+                for k, d in self._dense.items() if self._owned(k, group)}
 
     def load_dense_state(self, sd):
         for k, st in sd.items():

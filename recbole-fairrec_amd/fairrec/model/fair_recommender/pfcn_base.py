@@ -1,0 +1,203 @@
+"""Shared machinery of the PFCN family on the MI355X hot path (PFCN_PMF, PFCN_BiasedMF).
+
+PFCN = adversarially filtered user embeddings (Li et al., "Towards personalized fairness based on causal notion").
+Plugin surface of recbole/model/fair_recommender/pfcn_biasedmf.py:24-242 / pfcn_pmf.py: attributes
+`user_embedding_layer`, `item_embedding_layer`, [`user_bias`, `item_bias`, `global_bias`], `filter_layer` (dict),
+`dis_layer_dict` (dict), `sst_dict`, `sst_size`; methods `forward / calculate_loss / calculate_dis_loss / predict /
+get_sst_embed`; config keys `embedding_size, sst_attr_list, filter_mode, dis_dropout, dis_weight,
+dis_hidden_size_list, activation`.  As in the reference the filter / discriminator MLPs live in plain dicts: they are
+not in `parameters()` / `state_dict()`, and `model.eval()` never reaches them (BatchNorm keeps using batch statistics,
+SURVEY.md App. B-3).  Embedding rows come from lazy-Adam tables, MLPs run on the fp32-MFMA kernels, dot products /
+BPR / BCE / CE on csrc/pfcn.hip.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from ... import _C
+from ...engine import GenericEngine
+from ...functional import Bpr, BprBroadcast, RowDot, SigmoidBce, SoftmaxCe
+from ...utils.enum_type import InputType
+from ..abstract_recommender import FairRecommender
+from ..layers import MLPLayers
+
+
+class PFCNBase(FairRecommender):
+    input_type = InputType.PAIRWISE
+    biased = False
+
+    def __init__(self, config, dataset):
+        super().__init__(config, dataset)
+        self.embedding_size = config['embedding_size']
+        self.sst_attrs = config['sst_attr_list']
+        self.filter_mode = config['filter_mode'].lower()
+        try:
+            assert self.filter_mode in ('cm', 'sm', 'none')
+        except AssertionError:
+            raise AssertionError('filter_mode must be cm, sm or none')
+        self.filter_num, self.sst_dict = self._get_filter_info()
+        self.sst_size = self._get_sst_size(dataset.get_user_feature())
+        if self.filter_mode != 'none':
+            self.dis_drop_out = config['dis_dropout']
+            self.dis_weight = config['dis_weight']
+            self.dis_hidden_size_list = config['dis_hidden_size_list']
+        self.activation = config['activation']
+
+        self.user_embedding_layer = nn.Embedding(self.n_users, self.embedding_size)
+        if self.biased:
+            self.user_bias = nn.Embedding(self.n_users, 1)
+        self.item_embedding_layer = nn.Embedding(self.n_items, self.embedding_size)
+        if self.biased:
+            self.item_bias = nn.Embedding(self.n_items, 1)
+            self.global_bias = nn.Parameter(torch.tensor(0.1))
+        if self.filter_mode != 'none':
+            self.filter_layer = self.init_filter()
+            self.dis_layer_dict = self.init_dis_layer()
+        self._engine = None
+
+    # --- construction (pfcn_biasedmf.py:67-142) ---------------------------------------------------------------
+    def _get_filter_info(self):
+        if self.filter_mode == 'cm':
+            return len(self.sst_attrs), {sst: i + 1 for i, sst in enumerate(self.sst_attrs)}
+        if self.filter_mode == 'sm':
+            return 2 ** len(self.sst_attrs) - 1, {sst: 2 ** i for i, sst in enumerate(self.sst_attrs)}
+        return 0, {}
+
+    def _get_sst_size(self, user_feature):
+        sst_size = {}
+        for sst in self.sst_attrs:
+            if sst not in user_feature.columns:
+                raise ValueError(f'{sst} sensitive attribute not in user feature')
+            sst_size[sst] = len(user_feature[sst][1:].unique())
+        return sst_size
+
+    def init_filter(self):
+        D = self.embedding_size
+        return {i + 1: MLPLayers([D, D * 2, D], activation=self.activation, bn=True, init_method='norm').to(self.device)
+                for i in range(self.filter_num)}
+
+    def init_dis_layer(self):
+        D = self.embedding_size
+        out = {}
+        for sst in self.sst_attrs:
+            output_dim = self.sst_size[sst]
+            if output_dim == 2:
+                output_dim = 1
+            out[sst] = MLPLayers([D] + list(self.dis_hidden_size_list) + [output_dim], dropout=self.dis_drop_out,
+                                 activation=self.activation, bn=True, init_method='norm').to(self.device)
+        return out
+
+    # --- engine: which optimizer owns what (trainer.py:1201-1235) ---------------------------------------------------
+    def hip_engine(self) -> GenericEngine:
+        uw = self.user_embedding_layer.weight
+        if self._engine is None or self._engine._tables["user_embedding_layer.weight"].weight.data_ptr() != uw.data_ptr():
+            eng = GenericEngine(uw.device)
+            g = 'filter' if self.filter_mode != 'none' else None
+            eng.add_table("user_embedding_layer.weight", uw, group=g)
+            eng.add_table("item_embedding_layer.weight", self.item_embedding_layer.weight, group=g)
+            if self.biased:
+                eng.add_table("user_bias.weight", self.user_bias.weight, group=g)
+                eng.add_table("item_bias.weight", self.item_bias.weight, group=g)
+                eng.add_dense("global_bias", self.global_bias, group=g)
+            if self.filter_mode != 'none':
+                for i, mlp in self.filter_layer.items():
+                    for n, p in mlp.named_parameters():
+                        eng.add_dense(f"filter.{i}.{n}", p, group='filter')
+                for sst, mlp in self.dis_layer_dict.items():
+                    for n, p in mlp.named_parameters():
+                        eng.add_dense(f"dis.{sst}.{n}", p, group='dis')
+            self._engine = eng
+        return self._engine
+
+    # --- forward pieces -------------------------------------------------------------------------------------------
+    def _filter(self, user_embed, sst_list):
+        """pfcn_biasedmf.py:149-164: sm = ONE filter picked by the bit-mask sum of the selected attributes;
+        cm = sum of the selected attributes' filters divided by the number of ALL filters."""
+        if self.filter_mode == 'none':
+            return user_embed
+        if self.filter_mode == 'sm':
+            return self.filter_layer[sum(self.sst_dict[s] for s in sst_list)](user_embed)
+        tmp = None
+        for s in sst_list:
+            e = self.filter_layer[self.sst_dict[s]](user_embed)
+            tmp = e if tmp is None else tmp + e
+        return tmp / len(self.filter_layer)
+
+    def forward(self, user, item=None, sst_list=None):
+        eng = self.hip_engine()
+        user_embed = self._filter(eng.lookup("user_embedding_layer.weight", user), sst_list)
+        item_embed = eng.lookup("item_embedding_layer.weight", item) if item is not None else None
+        return user_embed, item_embed
+
+    def _dis_terms(self, user_embed, interaction, sst_list):
+        eng = self.hip_engine()
+        total = 0.0
+        for sst in sst_list:
+            y = self.dis_layer_dict[sst](user_embed)
+            label = interaction[sst].to(eng.device)
+            if self.sst_size[sst] == 2:
+                total = total + SigmoidBce.apply(y, label.float())
+            else:
+                total = total + SoftmaxCe.apply(y, label.long(), eng.err_flag)
+        return total
+
+    def calculate_dis_loss(self, interaction, sst_list):
+        """pfcn_biasedmf.py:202-218, called on its own in the discriminator phase: only the discriminators are
+        trained there, so the user rows are read without building a gradient path (the reference lets autograd fill
+        U.grad and then never uses it); the filters still run forward -- their BatchNorm statistics advance."""
+        eng = self.hip_engine()
+        user = interaction[self.USER_ID]
+        with torch.no_grad():
+            user_embed = self._filter(eng.lookup("user_embedding_layer.weight", user), sst_list)
+        return self._dis_terms(user_embed, interaction, sst_list)
+
+    def calculate_loss(self, interaction, sst_list=None):
+        eng = self.hip_engine()
+        user = interaction[self.USER_ID]
+        pos_item, neg_item = interaction[self.POS_ITEM_ID], interaction[self.NEG_ITEM_ID]
+        B = user.numel()
+        ue_raw = eng.lookup("user_embedding_layer.weight", user)
+        user_embed = self._filter(ue_raw, sst_list)
+        items = torch.cat([pos_item.to(eng.device), neg_item.to(eng.device)])     # one gather for both id lists
+        ie = eng.lookup("item_embedding_layer.weight", items)
+        pos_e, neg_e = ie[:B], ie[B:]
+        dp, dn = RowDot.apply(user_embed, pos_e), RowDot.apply(user_embed, neg_e)
+        if self.biased:
+            ub = eng.lookup("user_bias.weight", user)
+            ib = eng.lookup("item_bias.weight", items)
+            bpr_loss = BprBroadcast.apply(dp, dn, ub, ib[:B], ib[B:], self.global_bias)
+        else:
+            bpr_loss = Bpr.apply(dp, dn)
+        if self.filter_mode != 'none':
+            # the reference calls forward() a second time inside calculate_dis_loss (pfcn_biasedmf.py:209): same rows,
+            # filters applied again (BatchNorm statistics advance twice), gradient flows through both passes
+            dis_loss = self._dis_terms(self._filter(ue_raw, sst_list), interaction, sst_list)
+            return bpr_loss - self.dis_weight * dis_loss
+        return bpr_loss
+
+    def predict(self, interaction, sst_list=None):
+        eng = self.hip_engine()
+        user, item = interaction[self.USER_ID], interaction[self.ITEM_ID]
+        with torch.no_grad():
+            ue, ie = self.forward(user, item, sst_list)
+            score = RowDot.apply(ue, ie).unsqueeze(-1)
+            if self.biased:
+                score = score + eng.lookup("user_bias.weight", user) + eng.lookup("item_bias.weight", item) + self.global_bias
+            return torch.sigmoid(score)
+
+    def get_sst_embed(self, user_data, sst_list=None):
+        ret = {}
+        idx = torch.arange(1, self.n_users)
+        sst_list = self.sst_attrs if self.filter_mode == 'none' else sst_list
+        for sst in sst_list:
+            ret[sst] = user_data[sst][idx - 1]
+        with torch.no_grad():
+            ret['embedding'], _ = self.forward(idx.to(self.device), None, sst_list)
+        return ret
+
+    def state_dict(self, *args, **kwargs):
+        if self._engine is not None:
+            self._engine.flush()
+        return super().state_dict(*args, **kwargs)

@@ -35,33 +35,49 @@ def activation_layer(activation_name='relu', emb_dim=None):
 
 
 class _HipMLP(torch.autograd.Function):
-    """y = MLP([x0 | x1]) on the HIP linear kernels; saves the post-activation outputs and the dropout masks."""
+    """y = MLP([x0 | x1]) on the HIP kernels: per layer fr_linear_fwd [-> fr_bn_fwd] with the activation fused into
+    the last of the two; saves the post-activation outputs, the dropout masks and the BatchNorm statistics."""
 
     @staticmethod
-    def forward(ctx, x0, x1, act, p_drop, masks, *params):
+    def forward(ctx, x0, x1, act, p_drop, masks, bn_buffers, *params):
         lib = _C.lib()
         st = _C.current_stream()
-        n_layers = len(params) // 2
+        use_bn = bn_buffers is not None
+        per = 4 if use_bn else 2
+        n_layers = len(params) // per
         M = x0.shape[0]
+        dev = x0.device
         x0 = x0.contiguous()
         x1 = x1.contiguous() if x1 is not None else None
         scale = 1.0 / (1.0 - p_drop) if p_drop > 0 else 1.0
-        ins = [(x0, x1)]
-        outs = []
+        cur = (x0, x1)
+        outs, xhats, invstds = [], [], []
         for l in range(n_layers):
-            W, b = params[2 * l].contiguous(), params[2 * l + 1].contiguous()
-            a, c = ins[-1]
+            W, b = params[per * l].contiguous(), params[per * l + 1].contiguous()
+            a, c = cur
             k0, k1 = a.shape[1], (c.shape[1] if c is not None else 0)
             N = W.shape[0]
-            Y = torch.empty((M, N), dtype=torch.float32, device=x0.device)
+            Y = torch.empty((M, N), dtype=torch.float32, device=dev)
             mk = masks[l] if masks is not None else None
             _C.check(lib.fr_linear_fwd(a.data_ptr(), k0, _C.ptr(c), k1, _C.ptr(mk), scale, W.data_ptr(), b.data_ptr(), M, N,
-                                       act, Y.data_ptr(), st), "fr_linear_fwd")
+                                       0 if use_bn else act, Y.data_ptr(), st), "fr_linear_fwd")
+            if use_bn:
+                g, be = params[per * l + 2].contiguous(), params[per * l + 3].contiguous()
+                rm, rv, eps, mom = bn_buffers[l]
+                Z = Y
+                Y = torch.empty_like(Z)
+                xh = torch.empty_like(Z)
+                inv = torch.empty(N, dtype=torch.float32, device=dev)
+                _C.check(lib.fr_bn_fwd(Z.data_ptr(), g.data_ptr(), be.data_ptr(), eps, mom, _C.ptr(rm), _C.ptr(rv), M, N, act,
+                                       Y.data_ptr(), xh.data_ptr(), inv.data_ptr(), st), "fr_bn_fwd")
+                xhats.append(xh)
+                invstds.append(inv)
             outs.append(Y)
-            ins.append((Y, None))
-        ctx.act, ctx.scale, ctx.masks, ctx.n_layers = act, scale, masks, n_layers
+            cur = (Y, None)
+        ctx.act, ctx.scale, ctx.masks, ctx.n_layers, ctx.use_bn = act, scale, masks, n_layers, use_bn
         ctx.has_x1 = x1 is not None
-        ctx.save_for_backward(x0, *([x1] if x1 is not None else []), *params, *outs)
+        ctx.n_params = len(params)
+        ctx.save_for_backward(x0, *([x1] if x1 is not None else []), *params, *outs, *xhats, *invstds)
         return outs[-1]
 
     @staticmethod
@@ -71,38 +87,51 @@ class _HipMLP(torch.autograd.Function):
         saved = list(ctx.saved_tensors)
         x0 = saved.pop(0)
         x1 = saved.pop(0) if ctx.has_x1 else None
-        L = ctx.n_layers
-        params, outs = saved[:2 * L], saved[2 * L:]
+        L, per = ctx.n_layers, (4 if ctx.use_bn else 2)
+        params = saved[:ctx.n_params]
+        rest = saved[ctx.n_params:]
+        outs, xhats, invstds = rest[:L], rest[L:2 * L], rest[2 * L:3 * L]
         M = x0.shape[0]
-        grads: List[Optional[torch.Tensor]] = [None] * (2 * L)
+        dev = x0.device
+        grads: List[Optional[torch.Tensor]] = [None] * ctx.n_params
         dY = dY.contiguous()
         dx0 = dx1 = None
         for l in range(L - 1, -1, -1):
-            W = params[2 * l].contiguous()
+            W = params[per * l].contiguous()
             Y = outs[l]
             a, c = (outs[l - 1], None) if l > 0 else (x0, x1)
             k0, k1 = a.shape[1], (c.shape[1] if c is not None else 0)
             N, K = W.shape
             mk = ctx.masks[l] if ctx.masks is not None else None
+            act = ctx.act
+            if ctx.use_bn:   # through activation + BatchNorm first; the linear layer then sees a plain gradient
+                g = params[per * l + 2].contiguous()
+                dZ = torch.empty_like(Y)
+                dg = torch.empty(N, dtype=torch.float32, device=dev)
+                dbt = torch.empty(N, dtype=torch.float32, device=dev)
+                _C.check(lib.fr_bn_bwd(dY.data_ptr(), Y.data_ptr(), act, xhats[l].data_ptr(), invstds[l].data_ptr(),
+                                       g.data_ptr(), M, N, dZ.data_ptr(), dg.data_ptr(), dbt.data_ptr(), st), "fr_bn_bwd")
+                grads[per * l + 2], grads[per * l + 3] = dg, dbt
+                dY, Y, act = dZ, dZ, 0
             need = lib.fr_linear_bwd_weight_workspace_bytes(M, N, K)
-            ws = torch.empty(need, dtype=torch.uint8, device=x0.device)
+            ws = torch.empty(need, dtype=torch.uint8, device=dev)
             dW = torch.empty_like(W)
-            db = torch.empty(N, dtype=torch.float32, device=x0.device)
-            _C.check(lib.fr_linear_bwd_weight(dY.data_ptr(), Y.data_ptr(), ctx.act, a.data_ptr(), k0, _C.ptr(c), k1,
+            db = torch.empty(N, dtype=torch.float32, device=dev)
+            _C.check(lib.fr_linear_bwd_weight(dY.data_ptr(), Y.data_ptr(), act, a.data_ptr(), k0, _C.ptr(c), k1,
                                               _C.ptr(mk), ctx.scale, M, N, dW.data_ptr(), db.data_ptr(), ws.data_ptr(),
                                               ws.numel(), st), "fr_linear_bwd_weight")
-            grads[2 * l], grads[2 * l + 1] = dW, db
+            grads[per * l], grads[per * l + 1] = dW, db
             need_dx = l > 0 or ctx.needs_input_grad[0] or (ctx.has_x1 and ctx.needs_input_grad[1])
             if need_dx:
-                da = torch.empty((M, k0), dtype=torch.float32, device=x0.device)
-                dc = torch.empty((M, k1), dtype=torch.float32, device=x0.device) if k1 else None
-                _C.check(lib.fr_linear_bwd_input(dY.data_ptr(), Y.data_ptr(), ctx.act, W.data_ptr(), _C.ptr(mk), ctx.scale,
+                da = torch.empty((M, k0), dtype=torch.float32, device=dev)
+                dc = torch.empty((M, k1), dtype=torch.float32, device=dev) if k1 else None
+                _C.check(lib.fr_linear_bwd_input(dY.data_ptr(), Y.data_ptr(), act, W.data_ptr(), _C.ptr(mk), ctx.scale,
                                                  M, N, da.data_ptr(), k0, _C.ptr(dc), k1, st), "fr_linear_bwd_input")
                 if l > 0:
                     dY = da
                 else:
                     dx0, dx1 = da, dc
-        return (dx0, dx1, None, None, None, *grads)
+        return (dx0, dx1, None, None, None, None, *grads)
 
 
 class MLPLayers(nn.Module):
@@ -113,14 +142,14 @@ class MLPLayers(nn.Module):
         self.activation = activation
         self.use_bn = bn
         self.init_method = init_method
-        if bn:
-            raise NotImplementedError("BatchNorm1d layers (PFCN filters / discriminators) are not on the HIP path yet")
         if (activation.lower() if isinstance(activation, str) else activation) not in ACT_CODES:
             raise NotImplementedError(f"activation {activation} is not on the HIP path")
         mods = []
         for input_size, output_size in zip(self.layers[:-1], self.layers[1:]):
             mods.append(nn.Dropout(p=self.dropout))
             mods.append(nn.Linear(input_size, output_size))
+            if self.use_bn:
+                mods.append(nn.BatchNorm1d(num_features=output_size))
             act = activation_layer(self.activation, output_size)
             if act is not None:
                 mods.append(act)
@@ -139,12 +168,26 @@ class MLPLayers(nn.Module):
     def linears(self) -> List[nn.Linear]:
         return [m for m in self.mlp_layers if isinstance(m, nn.Linear)]
 
+    def batchnorms(self) -> List[nn.BatchNorm1d]:
+        return [m for m in self.mlp_layers if isinstance(m, nn.BatchNorm1d)]
+
     def forward(self, input_feature, second_block=None):
-        """MLP(cat(input_feature, second_block)); `second_block` avoids materialising the concatenation."""
+        """MLP(cat(input_feature, second_block)); `second_block` avoids materialising the concatenation.
+        BatchNorm layers always use batch statistics while `self.training` (and the reference's dict-held PFCN MLPs are
+        never switched to eval mode); eval-mode BatchNorm (running statistics) is not on this path."""
         if input_feature.device.type != "cuda":
             raise _C.FairrecError("MLPLayers runs only on a ROCm device; there is no CPU fallback")
-        lins = self.linears()
-        params = [t for lin in lins for t in (lin.weight, lin.bias)]
+        lins, bns = self.linears(), self.batchnorms()
+        if self.use_bn and not self.training:
+            raise NotImplementedError("eval-mode BatchNorm (running statistics) is not on the HIP path")
+        if self.use_bn:
+            params = [t for lin, bn in zip(lins, bns) for t in (lin.weight, lin.bias, bn.weight, bn.bias)]
+            bn_buffers = [(bn.running_mean, bn.running_var, float(bn.eps), float(bn.momentum)) for bn in bns]
+            for bn in bns:
+                bn.num_batches_tracked += 1
+        else:
+            params = [t for lin in lins for t in (lin.weight, lin.bias)]
+            bn_buffers = None
         p = float(self.dropout) if self.training else 0.0
         masks = None
         if self.forced_masks is not None:
@@ -153,4 +196,5 @@ class MLPLayers(nn.Module):
             M = input_feature.shape[0]
             masks = [(torch.rand((M, lin.in_features), device=input_feature.device) >= p).to(torch.uint8) for lin in lins]
         name = self.activation.lower() if isinstance(self.activation, str) else self.activation
-        return _HipMLP.apply(input_feature, second_block, ACT_CODES[name], p if masks is not None else 0.0, masks, *params)
+        return _HipMLP.apply(input_feature, second_block, ACT_CODES[name], p if masks is not None else 0.0, masks,
+                             bn_buffers, *params)

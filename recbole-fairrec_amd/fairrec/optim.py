@@ -193,33 +193,45 @@ class LazyLookup(torch.autograd.Function):
 class FusedLazyAdam:
     """Drop-in for the `optimizer` object the reference Trainer drives (zero_grad / step / state_dict).
 
-    The embedding gradient is never materialised: `engine.backward_adam()` (one HIP launch) does
-    loss.backward() + optimizer.step() for the batch of the preceding `calculate_loss`.
-    Dense parameters (MLPs, biases) registered with the engine go through fr_adam_dense.
+    The embedding gradient is never materialised: `engine.backward_adam()` does loss.backward()'s embedding part
+    + optimizer.step() for the batch of the preceding `calculate_loss`.  Dense parameters (MLPs, biases)
+    registered with the engine go through fr_adam_dense.  `group` restricts the optimizer to a subset of the
+    engine's tensors (PFCN's optimizer_filter / optimizer_dis, trainer.py:1201-1212).
     """
 
-    def __init__(self, engine, lr=1e-3, weight_decay=0.0, betas=(0.9, 0.999), eps=1e-8, sweep_period=None):
+    def __init__(self, engine, lr=1e-3, weight_decay=0.0, betas=(0.9, 0.999), eps=1e-8, sweep_period=None, group=None):
         self.engine = engine
+        self.group = group
         self.hyper = AdamHyper(lr, weight_decay, betas, eps, device=engine.device)
         self.defaults = dict(lr=lr, weight_decay=weight_decay, betas=betas, eps=eps)
-        engine.bind_optimizer(self, sweep_period)
+        if group is None:
+            engine.bind_optimizer(self, sweep_period)
+        else:
+            engine.bind_optimizer(self, sweep_period, group)
 
     def zero_grad(self, set_to_none: bool = True):
-        pass  # gradients are never materialised: there is nothing to clear
+        if hasattr(self.engine, "zero_grad"):
+            self.engine.zero_grad(self.group) if self.group is not None else self.engine.zero_grad()
 
     def step(self, closure=None):
         if closure is not None:
             raise NotImplementedError("closure-based step is not supported by the fused path")
-        self.engine.backward_adam()
+        if self.group is not None:
+            self.engine.backward_adam(self.group)
+        else:
+            self.engine.backward_adam()
+
+    def _tables(self):
+        return self.engine.tables(self.group) if self.group is not None else self.engine.tables()
 
     def state_dict(self):
-        state = {name: t.adam_state(self.hyper) for name, t in self.engine.tables().items()}
+        state = {name: t.adam_state(self.hyper) for name, t in self._tables().items()}
         if hasattr(self.engine, "dense_state"):
-            state.update(self.engine.dense_state())
+            state.update(self.engine.dense_state(self.group) if self.group is not None else self.engine.dense_state())
         return {"state": state, "param_groups": [dict(self.defaults, params=list(state.keys()))]}
 
     def load_state_dict(self, sd):
-        tables = self.engine.tables()
+        tables = self._tables()
         dense = {}
         for name, st in sd["state"].items():
             if name in tables:

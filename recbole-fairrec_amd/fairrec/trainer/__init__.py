@@ -1,1 +1,2 @@
-from .trainer import AbstractTrainer, Trainer  # noqa: F401
+from .trainer import (AbstractTrainer, PFCN_BiasedMFTrainer, PFCN_PMFTrainer, PFCNTrainer,  # noqa: F401
+                      Trainer)

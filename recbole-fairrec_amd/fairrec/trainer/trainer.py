@@ -217,3 +217,91 @@ class Trainer(AbstractTrainer):
             ae += err.abs().sum()
             n += err.numel()
         return OrderedDict(rmse=float((se / max(n, 1)).sqrt().item()), mae=float((ae / max(n, 1)).item()))
+
+
+class PFCNTrainer(Trainer):
+    """Alternating filter / discriminator schedule of recbole/trainer/trainer.py:865-930: per epoch draw a random
+    non-empty subset of the sensitive attributes (`np.random.choice([0,1], sst_num)`, same RNG consumption), every
+    `train_epoch_interval` epochs one pass with `optimizer_filter` on `calculate_loss`, then always one pass with
+    `optimizer_dis` on `calculate_dis_loss`."""
+
+    def __init__(self, config, model):
+        self.filter_mode = config['filter_mode'].lower()
+        super().__init__(config, model)
+        self.train_epoch_interval = config['train_epoch_interval']
+        if self.filter_mode != 'none':
+            self.sst_num = len(self.config['sst_attr_list'])
+            self.mask_label = {i: sst for i, sst in enumerate(self.config['sst_attr_list'])}
+            # which tensors each optimizer owns is declared by the model's engine groups (trainer.py:1201-1235)
+            self.optimizer_filter = self._build_optimizer(group='filter')
+            self.optimizer_dis = self._build_optimizer(group='dis')
+
+    def _build_optimizer(self, **kwargs):
+        group = kwargs.pop('group', None)
+        if group is None and self.filter_mode != 'none':
+            return None           # the reference's default optimizer is never stepped when filters are on
+        from ..optim import FusedLazyAdam
+        if (kwargs.get('learner', self.learner) or 'adam').lower() != 'adam' or self.clip_grad_norm:
+            raise NotImplementedError('only learner adam without clip_grad_norm is on the MI355X hot path')
+        return FusedLazyAdam(self.model.hip_engine(), lr=kwargs.get('learning_rate', self.learning_rate),
+                             weight_decay=kwargs.get('weight_decay', self.weight_decay),
+                             sweep_period=self.config['lazy_adam_sweep_period'], group=group)
+
+    def _train_epoch(self, train_data, epoch_idx, loss_func=None, show_progress=False):
+        dis_loss, filter_loss = 0., 0.
+        if self.filter_mode != 'none':
+            mask = np.zeros(self.sst_num)
+            while mask.sum() == 0:
+                mask = np.random.choice([0, 1], self.sst_num)
+            sst_list = [sst for i, sst in self.mask_label.items() if mask[i] != 0]
+            if epoch_idx % self.config['train_epoch_interval'] == 0:
+                self.optimizer = self.optimizer_filter
+                filter_loss = self._train_epoch_with_mask(train_data, epoch_idx, self.model.calculate_loss, sst_list)
+            self.optimizer = self.optimizer_dis
+            dis_loss = self._train_epoch_with_mask(train_data, epoch_idx, self.model.calculate_dis_loss, sst_list)
+            return filter_loss, dis_loss
+        return self._train_epoch_with_mask(train_data, epoch_idx, self.model.calculate_loss, None)
+
+    def _train_epoch_with_mask(self, train_data, epoch_idx, loss_func=None, sst_list=None, show_progress=False):
+        self.model.train()
+        total = None
+        for interaction in train_data:
+            interaction = interaction.to(self.device)
+            self.optimizer.zero_grad()
+            loss = loss_func(interaction, sst_list)
+            total = loss.detach().clone() if total is None else total + loss.detach()
+            loss.backward()
+            self.optimizer.step()
+        if total is None:
+            return 0.0
+        val = float(total.item())
+        self._check_nan(torch.tensor(val))
+        self.model.hip_engine().check_device_errors()
+        return val
+
+    def _save_checkpoint(self, epoch, verbose=True, **kwargs):
+        """trainer.py:1133-1154: same keys, with optimizer_filter / optimizer_dis when filters are on."""
+        saved_model_file = kwargs.pop('saved_model_file', self.saved_model_file)
+        state = {
+            'config': dict(self.config.final_config_dict), 'epoch': epoch, 'cur_step': self.cur_step,
+            'best_valid_score': self.best_valid_score, 'state_dict': self.model.state_dict(),
+            'other_parameter': self.model.other_parameter(),
+        }
+        if self.filter_mode != 'none':
+            state['optimizer_filter'] = self.optimizer_filter.state_dict()
+            state['optimizer_dis'] = self.optimizer_dis.state_dict()
+        else:
+            state['optimizer'] = self.optimizer.state_dict()
+        torch.save(state, saved_model_file)
+
+    def evaluate(self, eval_data, load_best_model=False, model_file=None, show_progress=False):
+        raise NotImplementedError("PFCN evaluation (ranking metrics per sensitive-attribute subset, trainer.py:1036-1106) "
+                                  "belongs to the evaluator row f-2 and is not built yet")
+
+
+class PFCN_PMFTrainer(PFCNTrainer):
+    pass
+
+
+class PFCN_BiasedMFTrainer(PFCNTrainer):
+    pass

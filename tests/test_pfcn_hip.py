@@ -1,0 +1,148 @@
+"""GPU parity: PFCN_PMF / PFCN_BiasedMF (filters + discriminators with BatchNorm on the MFMA kernels, BPR incl. the
+[B,B] broadcast form, two optimizers) vs the reference's golden vectors, through the plugin surface."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+CASES = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "pfcn_*.npz")))
+
+
+class _DS:
+    def __init__(self, n_users, n_items, z):
+        from fairrec.data.interaction import Interaction
+        self._n = {"user_id": n_users, "item_id": n_items}
+        self._uf = Interaction({"user_id": torch.arange(n_users), "gender": torch.from_numpy(z["gender"]),
+                                "age": torch.from_numpy(z["age"])})
+
+    def num(self, f):
+        return self._n[f]
+
+    def get_user_feature(self):
+        return self._uf
+
+
+def _load_mlp(mlp, z, prefix):
+    sd = {k[len(prefix) + 1:]: torch.tensor(z[k]) for k in z.files if k.startswith(prefix + ".")}
+    mlp.load_state_dict(sd)
+
+
+@pytest.mark.parametrize("path", CASES, ids=[os.path.basename(p)[:-4] for p in CASES])
+def test_pfcn_training_matches_reference_golden(path):
+    from fairrec.config import Config
+    from fairrec.data.interaction import Interaction
+    from fairrec.optim import FusedLazyAdam
+    from fairrec.utils import get_model
+    z = np.load(path)
+    name, mode = str(z["model"]), str(z["mode"])
+    attrs = [str(a) for a in z["attrs"]]
+    lr, wd, dis_weight, p = (float(x) for x in z["hyper"])
+    n_users, D = z["init.model.user_embedding_layer.weight"].shape
+    n_items = z["init.model.item_embedding_layer.weight"].shape[0]
+    cfg = Config(model=name, config_dict={"embedding_size": D, "sst_attr_list": attrs, "filter_mode": mode,
+                                          "dis_hidden_size_list": [int(h) for h in z["dis_hidden"]], "dis_dropout": p,
+                                          "dis_weight": dis_weight, "device": "cuda"})
+    model = get_model(name)(cfg, _DS(n_users, n_items, z))
+    model.load_state_dict({k[11:]: torch.tensor(z[k]) for k in z.files if k.startswith("init.model.")})
+    model = model.to("cuda")
+    if mode != "none":
+        for i, mlp in model.filter_layer.items():
+            _load_mlp(mlp, z, f"init.filter.{i}")
+        for s, mlp in model.dis_layer_dict.items():
+            _load_mlp(mlp, z, f"init.dis.{s}")
+    eng = model.hip_engine()
+    if mode == "none":
+        opt_f, opt_d = FusedLazyAdam(eng, lr=lr, weight_decay=wd, sweep_period=2), None
+    else:
+        opt_f = FusedLazyAdam(eng, lr=lr, weight_decay=wd, sweep_period=2, group="filter")
+        opt_d = FusedLazyAdam(eng, lr=lr, weight_decay=wd, sweep_period=2, group="dis")
+    n_dis = len(z["dis_hidden"]) + 1
+    losses = []
+    for t, ph in enumerate(str(x) for x in z["phases"]):
+        u = z["user_id"][t]
+        inter = Interaction({"user_id": torch.tensor(u), "item_id": torch.tensor(z["item_id"][t]),
+                             "neg_item_id": torch.tensor(z["neg_item_id"][t]), "gender": torch.tensor(z["gender"][u]),
+                             "age": torch.tensor(z["age"][u])}).to("cuda")
+        sl = [s for s in str(z["sst_lists"][t]).split(",") if s] if mode != "none" else None
+        if mode != "none":
+            for s in sl:
+                model.dis_layer_dict[s].forced_masks = [torch.tensor(z[f"mask.{s}.{t}.{l}"]) for l in range(n_dis)]
+        opt = opt_f if ph == "F" else opt_d
+        opt.zero_grad()
+        loss = model.calculate_loss(inter, sl) if ph == "F" else model.calculate_dis_loss(inter, sl)
+        losses.append(loss.detach().reshape(1).clone())
+        loss.backward()
+        opt.step()
+    np.testing.assert_allclose(torch.cat(losses).cpu().numpy(), z["loss"], rtol=2e-4, atol=2e-5)
+    sd = model.state_dict()
+
+    def close(a, ref, what):
+        a = a.detach().cpu().numpy()
+        bad = np.abs(a - ref) > 1e-4 * np.abs(ref) + 1e-5 * max(1.0, float(np.abs(ref).max()))
+        assert not bad.any(), (what, float(np.abs(a - ref).max()))
+
+    for k, v in sd.items():
+        close(v, z["final.model." + k], k)
+
+    def skip(k):
+        # A Linear bias that feeds BatchNorm has an exactly-zero true gradient (the batch mean is subtracted again);
+        # what reaches Adam is rounding noise of order 1e-9 whose SIGN Adam turns into +-lr steps, so its trajectory
+        # is implementation noise in the reference too -- and it cannot influence any output.  Not comparable.
+        parts = k.split(".")
+        # BatchNorm's running_mean is the average of (x W^T + that bias), so it inherits the same noise; running_var does not.
+        return (k.endswith("num_batches_tracked") or k.endswith("running_mean")
+                or (parts[-1] == "bias" and int(parts[-2]) % 4 == 1))
+
+    if mode != "none":
+        for i, mlp in model.filter_layer.items():
+            for k, v in mlp.state_dict().items():
+                if not skip(k):
+                    close(v, z[f"final.filter.{i}.{k}"], f"filter.{i}.{k}")
+        for s, mlp in model.dis_layer_dict.items():
+            for k, v in mlp.state_dict().items():
+                if not skip(k):
+                    close(v, z[f"final.dis.{s}.{k}"], f"dis.{s}.{k}")
+    eng.check_device_errors()
+    pr = model.predict(inter, attrs if mode != "none" else None).cpu().numpy()
+    np.testing.assert_allclose(pr, z["predict_last"], rtol=2e-4, atol=2e-6)
+
+
+def test_pfcn_trainer_alternating_schedule(tmp_path):
+    """PFCNTrainer: mask draw per epoch, filter pass every `train_epoch_interval` epochs, discriminator pass always."""
+    from fairrec.config import Config
+    from fairrec.data.dataloader import TrainDataLoader
+    from fairrec.data.dataset import InteractionDataset
+    from fairrec.data.interaction import Interaction
+    from fairrec.utils import get_model, get_trainer, init_seed
+    init_seed(7)
+    n_users, n_items, n = 60, 50, 600
+    g = torch.Generator().manual_seed(1)
+    inter = Interaction({"user_id": torch.randint(1, n_users, (n,), generator=g),
+                         "item_id": torch.randint(1, n_items, (n,), generator=g),
+                         "neg_item_id": torch.randint(1, n_items, (n,), generator=g)})
+    users = Interaction({"user_id": torch.arange(n_users), "gender": (torch.rand(n_users, generator=g) < 0.5).float(),
+                         "age": torch.randint(0, 3, (n_users,), generator=g)})
+    users["age"][1:4] = torch.tensor([0, 1, 2])
+    cfg = Config(model="PFCN_BiasedMF", config_dict={
+        "embedding_size": 16, "sst_attr_list": ["gender", "age"], "filter_mode": "cm", "dis_hidden_size_list": [16, 8],
+        "train_batch_size": 128, "epochs": 3, "train_epoch_interval": 2, "device": "cuda", "checkpoint_dir": str(tmp_path)})
+    ds = InteractionDataset(cfg, inter, users, n_users, n_items)
+    model = get_model("PFCN_BiasedMF")(cfg, ds).to("cuda")
+    trainer_cls = get_trainer(None, "PFCN_BiasedMF")
+    assert trainer_cls.__name__ == "PFCN_BiasedMFTrainer"
+    trainer = trainer_cls(cfg, model)
+    trainer.fit(TrainDataLoader(cfg, ds, shuffle=True), valid_data=None, verbose=False, saved=True)
+    l = trainer.train_loss_dict
+    assert set(l) == {0, 1, 2} and all(np.isfinite(v) for v in l.values())
+    eng = model.hip_engine()
+    steps_per_epoch = 5                      # ceil(600 / 128)
+    assert eng._tables["user_embedding_layer.weight"].step == 2 * steps_per_epoch          # filter epochs 0 and 2
+    dis_steps = {d.step for k, d in eng._dense.items() if k.startswith("dis.")}
+    # a discriminator steps in the epochs whose random mask selected its attribute (at least one attribute per epoch)
+    assert all(s % steps_per_epoch == 0 and s <= 3 * steps_per_epoch for s in dis_steps) and max(dis_steps) >= steps_per_epoch
+    assert eng._dense["global_bias"].step == 2 * steps_per_epoch    # zero gradient, but present: it still steps (App. B-1)
+    ck = torch.load(trainer.saved_model_file, weights_only=False)
+    assert {"optimizer_filter", "optimizer_dis", "state_dict"} <= set(ck)
