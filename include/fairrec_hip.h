@@ -252,6 +252,22 @@ FR_API int fr_bpr_outer(const float* a, const float* c, int64_t B, float* loss, 
 FR_API int fr_softmax_ce(const float* logits, const int64_t* label, int64_t M, int32_t C, float* loss, float* dlogits,
                          void* ws, size_t ws_bytes, uint32_t* err_flag, void* stream);
 
+/* ---- FairGo graph ops (fairgo_pmf.py / fairgo_gcn.py) -----------------------------------------------------------
+ * fr_spmm_csr        : Y = L X for a CSR matrix (torch.sparse.mm at fairgo_pmf.py:198 with L = D^-1 A, :102-129); the
+ *                      backward is the same call on the CSR of L^T
+ * fr_row_gather      : out[j,:] = X[idx[j],:]           (`all_embeddings[user]`, fairgo_pmf.py:178-179, :194)
+ * fr_row_scatter_sum : its backward as a dense [n_rows, dim] gradient, duplicates summed in ascending position
+ * fr_mse             : nn.MSELoss (fairgo_pmf.py:182): loss[0], dpred = 2 (pred - target) / B */
+FR_API int fr_spmm_csr(const int64_t* indptr, const int32_t* col, const float* val, const float* X, int64_t n_rows,
+                       int32_t dim, float* Y, void* stream);
+FR_API int fr_row_gather(const float* X, const int64_t* idx, int64_t M, int64_t n_rows, int32_t dim, float* out,
+                         uint32_t* err_flag, void* stream);
+FR_API size_t fr_row_scatter_workspace_bytes(int64_t M);
+FR_API int fr_row_scatter_sum(const float* g, const int64_t* idx, int64_t M, int64_t n_rows, int32_t dim, float* dX,
+                              void* ws, size_t ws_bytes, uint32_t* err_flag, void* stream);
+FR_API int fr_mse(const float* pred, const float* target, int64_t B, float* loss, float* dpred, void* ws, size_t ws_bytes,
+                  void* stream);
+
 /* ---- NFCF (nfcf.py) ---------------------------------------------------------------------------------------
  * Loss head of NFCF.calculate_loss, nfcf.py:99-110: y [B] is the scorer MLP's output AFTER its last ReLU
  * (layers.py:63-70); out = sigmoid(y) (:73); loss = BCELoss(out, label) (:105) [+ fair_weight * differential

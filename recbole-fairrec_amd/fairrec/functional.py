@@ -131,3 +131,94 @@ class SoftmaxCe(torch.autograd.Function):
     def backward(ctx, g):
         (dl,) = ctx.saved_tensors
         return dl * g, None, None
+
+
+class Mse(torch.autograd.Function):
+    """nn.MSELoss()(pred, target) (fairgo_pmf.py:182)."""
+
+    @staticmethod
+    def forward(ctx, pred, target):
+        pred, target = pred.contiguous(), target.contiguous().to(torch.float32)
+        B, dev = pred.numel(), pred.device
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        dp = torch.empty_like(pred)
+        ws = _ws(((B + 255) // 256) * 4, dev)
+        _C.check(_C.lib().fr_mse(pred.data_ptr(), target.data_ptr(), B, loss.data_ptr(), dp.data_ptr(), ws.data_ptr(),
+                                 ws.numel(), _C.current_stream()), "fr_mse")
+        ctx.save_for_backward(dp)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (dp,) = ctx.saved_tensors
+        return dp * g, None
+
+
+class CsrMatrix:
+    """A sparse matrix and its transpose as device CSR arrays (indptr int64, col int32, val fp32)."""
+
+    def __init__(self, scipy_csr, device):
+        import numpy as np
+        self.shape = scipy_csr.shape
+        self.fwd = self._pack(scipy_csr, device)
+        self.bwd = self._pack(scipy_csr.transpose().tocsr(), device)
+
+    @staticmethod
+    def _pack(m, device):
+        import numpy as np
+        m.sort_indices()
+        return (torch.from_numpy(m.indptr.astype(np.int64)).to(device), torch.from_numpy(m.indices.astype(np.int32)).to(device),
+                torch.from_numpy(m.data.astype(np.float32)).to(device))
+
+
+class SpMM(torch.autograd.Function):
+    """Y = L X (torch.sparse.mm, fairgo_pmf.py:198); backward dX = L^T dY with the pre-built transpose."""
+
+    @staticmethod
+    def forward(ctx, X, L: CsrMatrix):
+        X = X.contiguous()
+        Y = torch.empty((L.shape[0], X.shape[1]), dtype=torch.float32, device=X.device)
+        ip, col, val = L.fwd
+        _C.check(_C.lib().fr_spmm_csr(ip.data_ptr(), col.data_ptr(), val.data_ptr(), X.data_ptr(), L.shape[0], X.shape[1],
+                                      Y.data_ptr(), _C.current_stream()), "fr_spmm_csr")
+        ctx.L = L
+        return Y
+
+    @staticmethod
+    def backward(ctx, dY):
+        L = ctx.L
+        dY = dY.contiguous()
+        dX = torch.empty((L.shape[1], dY.shape[1]), dtype=torch.float32, device=dY.device)
+        ip, col, val = L.bwd
+        _C.check(_C.lib().fr_spmm_csr(ip.data_ptr(), col.data_ptr(), val.data_ptr(), dY.data_ptr(), L.shape[1], dY.shape[1],
+                                      dX.data_ptr(), _C.current_stream()), "fr_spmm_csr")
+        return dX, None
+
+
+class RowGather(torch.autograd.Function):
+    """X[idx] on a whole-table activation (fairgo_pmf.py:178-179); backward = dense gradient with duplicates summed in
+    ascending batch position (fixed order, no atomics)."""
+
+    @staticmethod
+    def forward(ctx, X, idx, err_flag):
+        X = X.contiguous()
+        idx = idx.contiguous().to(torch.int64)
+        M, (N, D) = idx.numel(), X.shape
+        out = torch.empty((M, D), dtype=torch.float32, device=X.device)
+        _C.check(_C.lib().fr_row_gather(X.data_ptr(), idx.data_ptr(), M, N, D, out.data_ptr(), _C.ptr(err_flag),
+                                        _C.current_stream()), "fr_row_gather")
+        ctx.save_for_backward(idx)
+        ctx.shape, ctx.err = (N, D), err_flag
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        N, D = ctx.shape
+        g = g.contiguous()
+        M = idx.numel()
+        dX = torch.empty((N, D), dtype=torch.float32, device=g.device)
+        ws = _ws(_C.lib().fr_row_scatter_workspace_bytes(M), g.device)
+        _C.check(_C.lib().fr_row_scatter_sum(g.data_ptr(), idx.data_ptr(), M, N, D, dX.data_ptr(), ws.data_ptr(), ws.numel(),
+                                             _C.ptr(ctx.err), _C.current_stream()), "fr_row_scatter_sum")
+        return dX, None, None

@@ -1,0 +1,249 @@
+"""FairGo_PMF (Wu et al., "Learning fair representations for recommendation: a graph-based perspective") on the MI355X
+hot path.
+
+Plugin surface of recbole/model/fair_recommender/fairgo_pmf.py:21-268: attributes `user_embedding_layer`,
+`item_embedding_layer`, `dis_layer_dict`, `filter_layer_dict` (plain dicts), `aggr_layer`, mutable `train_stage`;
+methods `forward / calculate_loss / calculate_dis_loss / predict / full_sort_predict / get_sst_embed`; config keys
+`n_layers, activation, embedding_size, dis_hidden_size_list, filter_hidden_size_list, sst_attr_list, fair_weight,
+load_pretrain_weight, aggr_method, vs_weights`.
+
+pretrain  : plain MF regression on lazy-Adam tables (gather -> row dot -> MSE -> duplicate-summed update).
+finetune  : embeddings frozen; per step, as in the reference, the filter MLPs run over the WHOLE [n_users+n_items, D]
+            table on the fp32-MFMA kernels, `n_layers` CSR SpMMs with L = D^-1 A produce the local (graph) embeddings,
+            WAP / LBA / LVA aggregate them, discriminators score node and local embeddings.
+"""
+from __future__ import annotations
+
+import numpy as np
+import scipy.sparse as sp
+import torch
+import torch.nn as nn
+
+from ... import _C
+from ...engine import GenericEngine
+from ...functional import CsrMatrix, Mse, RowDot, RowGather, SigmoidBce, SoftmaxCe, SpMM
+from ...utils.enum_type import InputType
+from ..abstract_recommender import FairRecommender
+from ..layers import ACT_CODES, MLPLayers, _HipMLP, activation_layer
+
+
+class FairGo_PMF(FairRecommender):
+    input_type = InputType.POINTWISE
+
+    def __init__(self, config, dataset):
+        super().__init__(config, dataset)
+        self.RATING = config['RATING_FIELD']
+        self.n_layers = config['n_layers']
+        self.act = config['activation']
+        self.embedding_size = config['embedding_size']
+        self.dis_hidden_size_list = config['dis_hidden_size_list']
+        self.filter_hidden_size_list = config['filter_hidden_size_list']
+        self.sst_attrs = config['sst_attr_list']
+        self.fair_weight = config['fair_weight']
+        self.load_pretrain_weight = config['load_pretrain_weight']
+        self.train_stage = None
+        self.aggr_method = config['aggr_method'].upper()
+        self.vs_weights = None
+        if config['vs_weights'] is not None:
+            vs = torch.tensor(config['vs_weights'], dtype=torch.float32)
+            self.vs_weights = vs / vs.sum()
+            if self.aggr_method == 'LVA':
+                assert self.n_layers == len(self.vs_weights), 'n_layers should be equal to length of vs_weights'
+        self.max_rating = dataset.inter_feat[self.RATING].max()
+        self.rating_matrix = dataset.inter_matrix(form='coo', value_field=self.RATING).astype(np.float32)
+        self.sst_size = self._get_sst_size(dataset.get_user_feature())
+
+        self.user_embedding_layer = nn.Embedding(self.n_users, self.embedding_size, padding_idx=0)
+        self.item_embedding_layer = nn.Embedding(self.n_items, self.embedding_size, padding_idx=0)
+        if self.load_pretrain_weight:
+            self.user_embedding_layer.weight.data.copy_(torch.from_numpy(dataset.get_preload_weight('uid')))
+            self.item_embedding_layer.weight.data.copy_(torch.from_numpy(dataset.get_preload_weight('iid')))
+        self.dis_layer_dict = self.init_dis_layers()
+        self.filter_layer_dict = self.init_filter_layers()
+        D = self.embedding_size
+        self.aggr_layer = nn.Sequential(nn.Linear(self.n_layers * D, D), activation_layer(self.act), nn.Linear(D, D),
+                                        activation_layer(self.act), nn.Linear(D, D))
+        self._norm_csr_host = self.get_norm_rating_matrix()      # scipy CSR of L = D^-1 A (one-off host preprocessing)
+        self._L = None
+        self._engine = None
+
+    # --- construction ---------------------------------------------------------------------------------------------
+    def _get_sst_size(self, user_feature):
+        sst_size = {}
+        for sst in self.sst_attrs:
+            if sst not in user_feature.columns:
+                raise ValueError(f'{sst} sensitive attribute not in user feature')
+            sst_size[sst] = len(user_feature[sst][1:].unique())
+        return sst_size
+
+    def get_norm_rating_matrix(self):
+        """fairgo_pmf.py:102-129: A = weighted bipartite adjacency of the training ratings, L = diag(1/(rowsum+1e-7)) A."""
+        N = self.n_users + self.n_items
+        R = self.rating_matrix.tocoo()
+        A = sp.coo_matrix((np.concatenate([R.data, R.data]),
+                           (np.concatenate([R.row, R.col + self.n_users]), np.concatenate([R.col + self.n_users, R.row]))),
+                          shape=(N, N), dtype=np.float32).tocsr()
+        diag = 1.0 / (np.asarray(A.sum(axis=1)).flatten() + 1e-7)
+        return (sp.diags(diag.astype(np.float32)) * A).tocsr().astype(np.float32)
+
+    def init_dis_layers(self):
+        out = {}
+        for sst in self.sst_attrs:
+            od = self.sst_size[sst]
+            od = 1 if od == 2 else od
+            out[sst] = MLPLayers([self.embedding_size] + list(self.dis_hidden_size_list) + [od], activation=self.act).to(self.device)
+        return out
+
+    def init_filter_layers(self):
+        return {sst: MLPLayers([self.embedding_size] + list(self.filter_hidden_size_list) + [self.embedding_size],
+                               activation=self.act).to(self.device) for sst in self.sst_attrs}
+
+    # --- engine: optimizer_pretrain / optimizer_filter / optimizer_dis (trainer.py:837-847) ---------------------------
+    def hip_engine(self) -> GenericEngine:
+        uw = self.user_embedding_layer.weight
+        if self._engine is None or self._engine._tables["user_embedding_layer.weight"].weight.data_ptr() != uw.data_ptr():
+            eng = GenericEngine(uw.device)
+            eng.add_table("user_embedding_layer.weight", uw, group='pretrain')
+            eng.add_table("item_embedding_layer.weight", self.item_embedding_layer.weight, group='pretrain')
+            for s, mlp in self.filter_layer_dict.items():
+                for n, p in mlp.named_parameters():
+                    eng.add_dense(f"filter.{s}.{n}", p, group='filter')
+            for s, mlp in self.dis_layer_dict.items():
+                for n, p in mlp.named_parameters():
+                    eng.add_dense(f"dis.{s}.{n}", p, group='dis')
+            if self.aggr_method == 'LBA':
+                for n, p in self.aggr_layer.named_parameters():
+                    eng.add_dense(f"aggr_layer.{n}", p, group='dis')
+            self._engine = eng
+            self._L = CsrMatrix(self._norm_csr_host, uw.device)
+        return self._engine
+
+    # --- forward pieces -----------------------------------------------------------------------------------------------
+    def get_ego_embeddings(self):
+        self.hip_engine().flush()      # no-op unless the pretrain stage left rows behind the optimizer step
+        return torch.cat([self.user_embedding_layer.weight.data, self.item_embedding_layer.weight.data], dim=0)
+
+    def _filtered_table(self, sst_list):
+        E = self.get_ego_embeddings()
+        if self.train_stage == 'finetune':
+            if sst_list is None:
+                sst_list = self.sst_attrs
+            tmp = None
+            for sst in sst_list:
+                e = self.filter_layer_dict[sst](E)
+                tmp = e if tmp is None else tmp + e
+            E = tmp / len(self.filter_layer_dict)
+        return E
+
+    def forward(self, sst_list=None):
+        E = self._filtered_table(sst_list)
+        return torch.split(E, [self.n_users, self.n_items])
+
+    def _aggr(self, x):
+        code = ACT_CODES[self.act.lower()]
+        lins = [m for m in self.aggr_layer if isinstance(m, nn.Linear)]
+        x = _HipMLP.apply(x, None, code, 0.0, None, None, lins[0].weight, lins[0].bias)
+        x = _HipMLP.apply(x, None, code, 0.0, None, None, lins[1].weight, lins[1].bias)
+        return _HipMLP.apply(x, None, 0, 0.0, None, None, lins[2].weight, lins[2].bias)
+
+    def _dis_terms(self, E, interaction, sst_list):
+        """calculate_dis_loss, fairgo_pmf.py:190-238, on an already filtered whole table E."""
+        eng = self.hip_engine()
+        user = interaction[self.USER_ID].to(eng.device)
+        node = RowGather.apply(E, user, eng.err_flag)
+        H, hs = E, []
+        for _ in range(self.n_layers):
+            H = SpMM.apply(H, self._L)
+            hs.append(H)
+        lva = self.aggr_method == 'LVA' and self.n_layers > 1
+        if self.n_layers == 1:
+            G = hs[0]
+        elif self.aggr_method == 'WAP':
+            G = torch.stack(hs, dim=1).mean(dim=1)
+        elif self.aggr_method == 'LBA':
+            G = self._aggr(torch.cat(hs, dim=1))
+        if lva:
+            locals_ = [RowGather.apply(h, user, eng.err_flag) for h in hs]
+            vs = self.vs_weights.to(eng.device)
+        else:
+            local = RowGather.apply(G, user, eng.err_flag)
+        node_l, local_l = 0.0, 0.0
+        for sst in sst_list:
+            d = self.dis_layer_dict[sst]
+            label = interaction[sst].to(eng.device)
+            if self.sst_size[sst] == 2:
+                node_l = node_l + SigmoidBce.apply(d(node), label.float())
+                if lva:
+                    for i in range(self.n_layers):
+                        local_l = local_l + vs[i] * SigmoidBce.apply(d(locals_[i]), label.float())
+                else:
+                    local_l = local_l + SigmoidBce.apply(d(local), label.float())
+            else:
+                # the reference feeds sigmoid(logits) to CrossEntropy for the LOCAL term only (fairgo_pmf.py:233-235)
+                node_l = node_l + SoftmaxCe.apply(d(node), label.long(), eng.err_flag)
+                if lva:
+                    for i in range(self.n_layers):
+                        local_l = local_l + vs[i] * SoftmaxCe.apply(torch.sigmoid(d(locals_[i])), label.long(), eng.err_flag)
+                else:
+                    local_l = local_l + SoftmaxCe.apply(torch.sigmoid(d(local)), label.long(), eng.err_flag)
+        return node_l + local_l
+
+    def calculate_dis_loss(self, interaction, sst_list):
+        """Discriminator phase: only the discriminators (+ aggr_layer) train, so the filters run without a gradient path."""
+        with torch.no_grad():
+            E = self._filtered_table(sst_list)
+        return self._dis_terms(E, interaction, sst_list)
+
+    def calculate_loss(self, interaction, sst_list=None):
+        eng = self.hip_engine()
+        user = interaction[self.USER_ID].to(eng.device)
+        item = interaction[self.ITEM_ID].to(eng.device)
+        rating = interaction[self.RATING].to(eng.device, torch.float32)
+        B = user.numel()
+        if self.train_stage != 'finetune':
+            ue = eng.lookup("user_embedding_layer.weight", user)
+            ie = eng.lookup("item_embedding_layer.weight", item)
+            # padding_idx = 0: row 0 is zero and never receives a gradient (fairgo_pmf.py:60-61)
+            ue = ue * (user != 0).unsqueeze(1)
+            ie = ie * (item != 0).unsqueeze(1)
+            return Mse.apply(RowDot.apply(ue, ie), rating)
+        E = self._filtered_table(sst_list)
+        rows = RowGather.apply(E, torch.cat([user, item + self.n_users]), eng.err_flag)
+        mse = Mse.apply(RowDot.apply(rows[:B], rows[B:]), rating)
+        # the reference's calculate_dis_loss runs forward() again: same values, second pass through the filters
+        fair = self._dis_terms(self._filtered_table(sst_list), interaction, sst_list)
+        return mse - self.fair_weight * fair
+
+    def predict(self, interaction):
+        eng = self.hip_engine()
+        user = interaction[self.USER_ID].to(eng.device)
+        item = interaction[self.ITEM_ID].to(eng.device)
+        with torch.no_grad():
+            E = self._filtered_table(None)
+            rows = RowGather.apply(E, torch.cat([user, item + self.n_users]), eng.err_flag)
+            B = user.numel()
+            scores = RowDot.apply(rows[:B], rows[B:])
+            return torch.clamp(scores, min=0., max=float(self.max_rating)) / float(self.max_rating)
+
+    def full_sort_predict(self, interaction):
+        user = interaction[self.USER_ID].to(self.hip_engine().device)
+        with torch.no_grad():
+            ua, ia = self.forward()
+            pred = torch.matmul(ua[user], ia.transpose(0, 1))
+            return torch.clamp(pred.view(-1), min=0., max=float(self.max_rating)) / float(self.max_rating)
+
+    def get_sst_embed(self, user_data, sst_list=None):
+        ret = {}
+        idx = torch.arange(1, self.n_users)
+        sst_list = self.sst_attrs if sst_list is None else sst_list
+        for sst in sst_list:
+            ret[sst] = user_data[sst][idx - 1]
+        with torch.no_grad():
+            ua, _ = self.forward()
+        ret['embedding'] = ua[idx.to(ua.device)]
+        return ret
+
+    def state_dict(self, *args, **kwargs):
+        if self._engine is not None:
+            self._engine.flush()
+        return super().state_dict(*args, **kwargs)

@@ -154,6 +154,7 @@ class FocfEngine:
         _C.check(rc, "fr_focf_backward_adam")
         self.U.step += 1
         self.I.step += 1
+        self.U._dirty = self.I._dirty = True
         self.pending_B = 0
         self.backward_seen = False
 

@@ -84,6 +84,7 @@ class LazyTable:
         self._ws = None
         self._pending = None
         self._grad_rows = None
+        self._dirty = False      # some row may be behind `step` (set by an update, cleared by flush)
 
     def ensure_state(self):
         dev = self.weight.device
@@ -105,8 +106,9 @@ class LazyTable:
 
     def flush(self, hyper: AdamHyper):
         """Bring every row up to `self.step` (fr_table_flush)."""
-        if self.step == 0 or not self.trainable:
+        if self.step == 0 or not self.trainable or not self._dirty:
             return
+        self._dirty = False
         t = self.c()
         _C.check(_C.lib().fr_table_flush(ctypes.byref(t), ctypes.byref(hyper.c()), _C.current_stream()),
                  "fr_table_flush")
@@ -154,6 +156,7 @@ class LazyTable:
                                               g.data_ptr(), int(sweep_period), self._ws.data_ptr(),
                                               self._ws.numel(), _C.current_stream()), "fr_table_apply_grad")
         self.step += 1
+        self._dirty = True
         self._pending = None
         self._grad_rows = None
 
@@ -171,6 +174,7 @@ class LazyTable:
         self.m.copy_(state["exp_avg"])
         self.v.copy_(state["exp_avg_sq"])
         self.last.fill_(self.step)
+        self._dirty = False
 
 
 class LazyLookup(torch.autograd.Function):

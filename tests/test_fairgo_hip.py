@@ -1,0 +1,99 @@
+"""GPU parity: FairGo_PMF (pretrain on lazy tables; finetune = whole-table filter MLPs on MFMA, CSR SpMM, WAP/LBA/LVA,
+node + local discriminators, three optimizers) vs the reference's golden vectors, through the plugin surface."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+
+pytestmark = pytest.mark.gpu
+CASES = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "fairgo_*.npz")))
+
+
+class _DS:
+    def __init__(self, n_users, n_items, z):
+        from fairrec.data.interaction import Interaction
+        self._n = {"user_id": n_users, "item_id": n_items}
+        self._uf = Interaction({"user_id": torch.arange(n_users), "gender": torch.from_numpy(z["gender"]),
+                                "age": torch.from_numpy(z["age"])})
+        self.inter_feat = {"rating": torch.from_numpy(z["train_rating"])}
+        self._coo = sp.coo_matrix((z["train_rating"], (z["train_user"], z["train_item"])), shape=(n_users, n_items))
+
+    def num(self, f):
+        return self._n[f]
+
+    def get_user_feature(self):
+        return self._uf
+
+    def inter_matrix(self, form="coo", value_field=None):
+        return self._coo
+
+
+@pytest.mark.parametrize("path", CASES, ids=[os.path.basename(p)[:-4] for p in CASES])
+def test_fairgo_training_matches_reference_golden(path):
+    from fairrec.config import Config
+    from fairrec.data.interaction import Interaction
+    from fairrec.optim import FusedLazyAdam
+    from fairrec.utils import get_model
+    z = np.load(path)
+    attrs = [str(a) for a in z["attrs"]]
+    lr, wd, fw = (float(x) for x in z["hyper"])
+    n_users, D = z["init.model.user_embedding_layer.weight"].shape
+    n_items = z["init.model.item_embedding_layer.weight"].shape[0]
+    cfg = Config(model="FairGo_PMF", config_dict={
+        "embedding_size": D, "sst_attr_list": attrs, "aggr_method": str(z["aggr"]), "n_layers": int(z["n_layers"]),
+        "filter_hidden_size_list": [int(h) for h in z["filter_hidden"]], "dis_hidden_size_list": [int(h) for h in z["dis_hidden"]],
+        "vs_weights": [float(v) for v in z["vs_weights"]], "fair_weight": fw, "device": "cuda"})
+    model = get_model("FairGo_PMF")(cfg, _DS(n_users, n_items, z))
+    # the reference's L = D^-1 A, entry for entry
+    L = model._norm_csr_host.tocoo()
+    order = np.lexsort((L.col, L.row))
+    np.testing.assert_array_equal(L.row[order], z["L_row"])
+    np.testing.assert_array_equal(L.col[order], z["L_col"])
+    np.testing.assert_allclose(L.data[order], z["L_val"], rtol=1e-6)
+    model.load_state_dict({k[11:]: torch.tensor(z[k]) for k in z.files if k.startswith("init.model.")})
+    model = model.to("cuda")
+    for s in attrs:
+        model.filter_layer_dict[s].load_state_dict({k[len(f"init.filter.{s}."):]: torch.tensor(z[k]) for k in z.files
+                                                    if k.startswith(f"init.filter.{s}.")})
+        model.dis_layer_dict[s].load_state_dict({k[len(f"init.dis.{s}."):]: torch.tensor(z[k]) for k in z.files
+                                                 if k.startswith(f"init.dis.{s}.")})
+    eng = model.hip_engine()
+    opts = {ph: FusedLazyAdam(eng, lr=lr, weight_decay=wd, sweep_period=2, group=g)
+            for ph, g in (("P", "pretrain"), ("F", "filter"), ("D", "dis"))}
+    losses = []
+    for t, ph in enumerate(str(x) for x in z["phases"]):
+        u = z["user_id"][t]
+        inter = Interaction({"user_id": torch.tensor(u), "item_id": torch.tensor(z["item_id"][t]),
+                             "rating": torch.tensor(z["rating"][t]), "gender": torch.tensor(z["gender"][u]),
+                             "age": torch.tensor(z["age"][u])}).to("cuda")
+        sl = [s for s in str(z["sst_lists"][t]).split(",") if s]
+        model.train_stage = "pretrain" if ph == "P" else "finetune"
+        opts[ph].zero_grad()
+        if ph == "P":
+            loss = model.calculate_loss(inter, None)
+        elif ph == "F":
+            loss = model.calculate_loss(inter, sl)
+        else:
+            loss = model.calculate_dis_loss(inter, sl)
+        losses.append(loss.detach().reshape(1).clone())
+        loss.backward()
+        opts[ph].step()
+    np.testing.assert_allclose(torch.cat(losses).cpu().numpy(), z["loss"], rtol=2e-4, atol=2e-5)
+
+    def close(a, ref, what):
+        a = a.detach().cpu().numpy()
+        bad = np.abs(a - ref) > 1e-4 * np.abs(ref) + 1e-5 * max(1e-2, float(np.abs(ref).max()))
+        assert not bad.any(), (what, float(np.abs(a - ref).max()))
+
+    for k, v in model.state_dict().items():
+        close(v, z["final.model." + k], k)
+    for s in attrs:
+        for k, v in model.filter_layer_dict[s].state_dict().items():
+            close(v, z[f"final.filter.{s}.{k}"], f"filter.{s}.{k}")
+        for k, v in model.dis_layer_dict[s].state_dict().items():
+            close(v, z[f"final.dis.{s}.{k}"], f"dis.{s}.{k}")
+    eng.check_device_errors()
+    np.testing.assert_allclose(model.predict(inter).cpu().numpy(), z["predict_last"], rtol=2e-4, atol=2e-6)
