@@ -14,7 +14,7 @@ hyper = AdamHyper(lr=1e-3, weight_decay=1e-3, device="cuda")
 tab = LazyTable(torch.randn(N, D, device="cuda") * 0.01)
 tab.ensure_state(); tab.m.normal_(std=1e-3); tab.v.uniform_(1e-7, 1e-5)
 for rep in range(3):
-    tab.last.fill_(1); tab.step = 2
+    tab.last.fill_(1); tab.step = 2; tab._dirty = True
     tab.flush(hyper)
 torch.cuda.synchronize()
 print("flush known bytes per launch: read", N * (3 * D * 4 + 4), "write", N * (3 * D * 4 + 4))

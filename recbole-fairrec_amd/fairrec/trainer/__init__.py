@@ -1,2 +1,2 @@
-from .trainer import (AbstractTrainer, PFCN_BiasedMFTrainer, PFCN_PMFTrainer, PFCNTrainer,  # noqa: F401
-                      Trainer)
+from .trainer import (AbstractTrainer, FairGo_GCNTrainer, FairGo_PMFTrainer, FairGoTrainer,  # noqa: F401
+                      PFCN_BiasedMFTrainer, PFCN_PMFTrainer, PFCNTrainer, Trainer)

@@ -239,7 +239,7 @@ class PFCNTrainer(Trainer):
     def _build_optimizer(self, **kwargs):
         group = kwargs.pop('group', None)
         if group is None and self.filter_mode != 'none':
-            return None           # the reference's default optimizer is never stepped when filters are on
+            return None           # the reference's default optimizer is never stepped when filters are on (PFCN, FairGo)
         from ..optim import FusedLazyAdam
         if (kwargs.get('learner', self.learner) or 'adam').lower() != 'adam' or self.clip_grad_norm:
             raise NotImplementedError('only learner adam without clip_grad_norm is on the MI355X hot path')
@@ -304,4 +304,76 @@ class PFCN_PMFTrainer(PFCNTrainer):
 
 
 class PFCN_BiasedMFTrainer(PFCNTrainer):
+    pass
+
+
+class FairGoTrainer(PFCNTrainer):
+    """recbole/trainer/trainer.py:534-736: `pretrain_epochs` of plain MF regression with optimizer_pretrain, a pretrain
+    checkpoint, then the same alternating filter / discriminator schedule as PFCN with optimizer_filter /
+    optimizer_dis; `model.train_stage` is switched by the trainer."""
+
+    def __init__(self, config, model):
+        self.filter_mode = 'fairgo'            # always filtered: reuse PFCNTrainer's alternating epoch
+        Trainer.__init__(self, config, model)
+        self.train_epoch_interval = config['train_epoch_interval']
+        self.sst_num = len(self.config['sst_attr_list'])
+        self.mask_label = {i: sst for i, sst in enumerate(self.config['sst_attr_list'])}
+        self.load_pretrain_weight = config['load_pretrain_weight']
+        self.optimizer_filter = self._build_optimizer(group='filter')
+        self.optimizer_dis = self._build_optimizer(group='dis')
+        self.optimizer_pretrain = None
+        if config['pretrain_model_file_path'] is not None:
+            ck = torch.load(config['pretrain_model_file_path'], weights_only=False)
+            self.model.load_state_dict(ck['state_dict'])
+            self.model.load_other_parameter(ck.get('other_parameter'))
+            self.model.train_stage = 'finetune'
+        elif self.load_pretrain_weight:
+            self.model.train_stage = 'finetune'
+        else:
+            self.model.train_stage = 'pretrain'
+            self.pretrain_epochs = config['pretrain_epochs']
+            self.optimizer_pretrain = self._build_optimizer(group='pretrain')
+
+    def save_pretrained_model(self, saved_model_file):
+        torch.save({'config': dict(self.config.final_config_dict), 'state_dict': self.model.state_dict(),
+                    'optimizer': self.optimizer.state_dict(), 'other_parameter': self.model.other_parameter()},
+                   saved_model_file)
+
+    def pretrain(self, train_data, valid_data=None, verbose=True, saved=True, show_progress=False):
+        self.saved_pretrain_model_file = os.path.join(
+            self.checkpoint_dir, '{}-{}-pretrain.pth'.format(self.config['model'], self.config['dataset']))
+        self.optimizer = self.optimizer_pretrain
+        for epoch_idx in range(self.start_epoch, self.pretrain_epochs):
+            t0 = time()
+            loss = self._train_epoch_with_mask(train_data, epoch_idx, self.model.calculate_loss, None)
+            self.train_loss_dict[epoch_idx] = loss
+            if verbose:
+                self.logger.info(self._generate_train_loss_output(epoch_idx, t0, time(), loss))
+        if saved:
+            self.save_pretrained_model(self.saved_pretrain_model_file)
+            ck = torch.load(self.saved_pretrain_model_file, weights_only=False)
+            self.model.load_state_dict(ck['state_dict'])
+
+    def fit(self, train_data, valid_data=None, verbose=True, saved=True, show_progress=False, callback_fn=None):
+        if self.model.train_stage == 'pretrain':
+            self.pretrain(train_data, valid_data, verbose, saved, show_progress)
+            self.start_epoch, self.cur_step, self.train_loss_dict = 0, 0, dict()     # reset_params, trainer.py:560-577
+            self.model.train_stage = 'finetune'
+        elif self.model.train_stage != 'finetune':
+            raise ValueError("Please make sure that the 'train_stage' is 'pretrain' or 'finetune'!")
+        return Trainer.fit(self, train_data, valid_data, verbose, saved, show_progress, callback_fn)
+
+    def _save_checkpoint(self, epoch, verbose=True, **kwargs):
+        saved_model_file = kwargs.pop('saved_model_file', self.saved_model_file)
+        torch.save({'config': dict(self.config.final_config_dict), 'epoch': epoch, 'cur_step': self.cur_step,
+                    'best_valid_score': self.best_valid_score, 'state_dict': self.model.state_dict(),
+                    'other_parameter': self.model.other_parameter(), 'optimizer_filter': self.optimizer_filter.state_dict(),
+                    'optimizer_dis': self.optimizer_dis.state_dict()}, saved_model_file)
+
+
+class FairGo_PMFTrainer(FairGoTrainer):
+    pass
+
+
+class FairGo_GCNTrainer(FairGoTrainer):
     pass

@@ -97,3 +97,42 @@ def test_fairgo_training_matches_reference_golden(path):
             close(v, z[f"final.dis.{s}.{k}"], f"dis.{s}.{k}")
     eng.check_device_errors()
     np.testing.assert_allclose(model.predict(inter).cpu().numpy(), z["predict_last"], rtol=2e-4, atol=2e-6)
+
+
+def test_fairgo_trainer_pretrain_then_finetune(tmp_path):
+    """FairGoTrainer: pretrain epochs with optimizer_pretrain, checkpoint, stage switch, alternating finetune epochs."""
+    from fairrec.config import Config
+    from fairrec.data.dataloader import TrainDataLoader
+    from fairrec.data.dataset import InteractionDataset
+    from fairrec.data.interaction import Interaction
+    from fairrec.utils import get_model, get_trainer, init_seed
+    init_seed(3)
+    n_users, n_items, n = 40, 30, 300
+    g = torch.Generator().manual_seed(2)
+    inter = Interaction({"user_id": torch.randint(1, n_users, (n,), generator=g), "item_id": torch.randint(1, n_items, (n,), generator=g),
+                         "rating": torch.randint(1, 6, (n,), generator=g).float()})
+    users = Interaction({"user_id": torch.arange(n_users), "gender": (torch.rand(n_users, generator=g) < 0.5).float()})
+    users["gender"][1:3] = torch.tensor([0.0, 1.0])
+    cfg = Config(model="FairGo_PMF", dataset="synth", config_dict={
+        "embedding_size": 16, "aggr_method": "WAP", "n_layers": 2, "filter_hidden_size_list": [16, 8], "dis_hidden_size_list": [8, 4],
+        "train_batch_size": 100, "epochs": 2, "pretrain_epochs": 2, "train_epoch_interval": 1, "device": "cuda",
+        "checkpoint_dir": str(tmp_path)})
+
+    class DS(InteractionDataset):
+        def inter_matrix(self, form="coo", value_field=None):
+            return sp.coo_matrix((self.inter_feat["rating"].numpy(), (self.inter_feat["user_id"].numpy(),
+                                                                       self.inter_feat["item_id"].numpy())), shape=(n_users, n_items))
+
+    ds = DS(cfg, inter, users, n_users, n_items)
+    model = get_model("FairGo_PMF")(cfg, ds).to("cuda")
+    trainer = get_trainer(None, "FairGo_PMF")(cfg, model)
+    assert type(trainer).__name__ == "FairGo_PMFTrainer" and model.train_stage == "pretrain"
+    w0 = model.user_embedding_layer.weight.detach().clone()
+    trainer.fit(TrainDataLoader(cfg, ds, shuffle=False), valid_data=None, verbose=False, saved=True)
+    assert model.train_stage == "finetune"
+    eng = model.hip_engine()
+    assert eng._tables["user_embedding_layer.weight"].step == 2 * 3           # 2 pretrain epochs x 3 batches, then frozen
+    assert not torch.equal(model.user_embedding_layer.weight, w0)
+    assert all(d.step == 2 * 3 for k, d in eng._dense.items() if k.startswith("filter."))   # every finetune epoch (interval 1)
+    assert os.path.exists(trainer.saved_pretrain_model_file)
+    assert get_model("FairGo_GCN").__mro__[1].__name__ == "FairGo_PMF"

@@ -96,6 +96,7 @@ def test_flush_matches_dense_torch_adam_with_zero_grads():
                                     w0.numel(), ctypes.byref(hyper.c()), 1, _C.current_stream()), "adam_dense")
     tab.last.fill_(1)
     tab.step = 151
+    tab._dirty = True      # state poked in by hand: tell the table it has rows behind `step`
     rows = torch.tensor([0, 5, 299, 5], device="cuda")
     got = tab.gather(hyper, rows).cpu().numpy()         # read-only catch-up
     np.testing.assert_allclose(got, ref.detach().numpy()[[0, 5, 299, 5]], rtol=1e-4, atol=1e-6)
