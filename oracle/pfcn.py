@@ -57,14 +57,45 @@ class MLP:
             out[f"{prefix}.mlp_layers.{4 * l + 2}.running_var"] = self.rv[l].numpy().copy()
 
 
+class PlainMLP:
+    """MLPLayers without BatchNorm (PFCN_MLP's scorer, PFCN_DMF's towers): Dropout(0) -> Linear -> activation per layer."""
+
+    def __init__(self, z, prefix: str, act):
+        self.act = act
+        self.W, self.b = [], []
+        l = 0
+        while f"{prefix}.mlp_layers.{3 * l + 1}.weight" in z:
+            self.W.append(torch.tensor(z[f"{prefix}.mlp_layers.{3 * l + 1}.weight"]).requires_grad_())
+            self.b.append(torch.tensor(z[f"{prefix}.mlp_layers.{3 * l + 1}.bias"]).requires_grad_())
+            l += 1
+
+    def params(self):
+        return [t for pair in zip(self.W, self.b) for t in pair]
+
+    def __call__(self, x):
+        for W, b in zip(self.W, self.b):
+            x = self.act(F.linear(x, W, b))
+        return x
+
+    def export(self, prefix, out):
+        for l, (W, b) in enumerate(zip(self.W, self.b)):
+            out[f"{prefix}.mlp_layers.{3 * l + 1}.weight"] = W.detach().numpy().copy()
+            out[f"{prefix}.mlp_layers.{3 * l + 1}.bias"] = b.detach().numpy().copy()
+
+
 class Model:
     def __init__(self, z):
         self.kind, self.mode = str(z["model"]), str(z["mode"])
         self.attrs = [str(a) for a in z["attrs"]]
         self.lr, self.wd, self.dis_weight, self.p = (float(x) for x in z["hyper"])
         t = lambda k: torch.tensor(z["init.model." + k]).requires_grad_()
-        self.U, self.I = t("user_embedding_layer.weight"), t("item_embedding_layer.weight")
+        self.uname = "user_embedding" if self.kind == "PFCN_MLP" else "user_embedding_layer"
+        self.iname = "item_embedding" if self.kind == "PFCN_MLP" else "item_embedding_layer"
+        self.U, self.I = t(self.uname + ".weight"), t(self.iname + ".weight")
         self.biased = self.kind == "PFCN_BiasedMF"
+        self.scorer = PlainMLP(z, "init.model.mlp_layer", torch.relu) if self.kind == "PFCN_MLP" else None
+        self.user_mlp = PlainMLP(z, "init.model.user_mlp", torch.relu) if self.kind == "PFCN_DMF" else None
+        self.item_mlp = PlainMLP(z, "init.model.item_mlp", torch.relu) if self.kind == "PFCN_DMF" else None
         if self.biased:
             self.bu, self.bi, self.gb = t("user_bias.weight"), t("item_bias.weight"), t("global_bias")
         self.filters: Dict[int, MLP] = {}
@@ -88,12 +119,19 @@ class Model:
             ps += f.params()
         if self.biased:
             ps += [self.bu, self.bi, self.gb]
+        return ps + self.base_mlp_params()
+
+    def base_mlp_params(self):
+        ps = []
+        for m in (self.scorer, self.user_mlp, self.item_mlp):
+            if m is not None:
+                ps += m.params()
         return ps
 
-    def all_params(self):        # nn.Module.parameters() order of the reference model with filter_mode none
+    def all_params(self):        # nn.Module.parameters() of the reference model with filter_mode none
         if self.biased:
             return [self.gb, self.U, self.bu, self.I, self.bi]
-        return [self.U, self.I]
+        return [self.U, self.I] + self.base_mlp_params()
 
     def dis_params(self):
         ps = []
@@ -105,6 +143,8 @@ class Model:
         """forward(), pfcn_biasedmf.py:144-166: none: raw rows; sm: ONE filter picked by the bit-mask sum; cm: sum of the
         selected attributes' filters divided by the number of ALL filters (App. B-2)."""
         ue = self.U[user]
+        if self.user_mlp is not None:          # PFCN_DMF: tower before the filter (pfcn_dmf.py:150-151)
+            ue = self.user_mlp(ue)
         if self.mode == "none":
             return ue
         if self.mode == "sm":
@@ -131,7 +171,13 @@ class Model:
         """calculate_loss, pfcn_biasedmf.py:180-200 incl. the [B] + [B,1] -> [B,B] broadcast of BiasedMF (App. B-1)."""
         ue = self.user_embed(user, sst_list)
         pe, ne = self.I[pos], self.I[neg]
-        ps, ns = (ue * pe).sum(-1), (ue * ne).sum(-1)
+        if self.kind == "PFCN_MLP":            # pfcn_mlp.py:185-186: scorer on cat(user, item), BPR on [B,1] scores
+            ps, ns = self.scorer(torch.cat((ue, pe), 1)), self.scorer(torch.cat((ue, ne), 1))
+        elif self.kind == "PFCN_DMF":          # pfcn_dmf.py:189-194: item tower, cosine similarity * 10
+            ps = F.cosine_similarity(ue, self.item_mlp(pe)) * 10
+            ns = F.cosine_similarity(ue, self.item_mlp(ne)) * 10
+        else:
+            ps, ns = (ue * pe).sum(-1), (ue * ne).sum(-1)
         if self.biased:
             ps = ps + self.bu[user] + self.bi[pos] + self.gb
             ns = ns + self.bu[user] + self.bi[neg] + self.gb
@@ -142,6 +188,10 @@ class Model:
 
     def predict(self, user, item, sst_list):
         ue = self.user_embed(user, sst_list)
+        if self.kind == "PFCN_MLP":
+            return torch.sigmoid(self.scorer(torch.cat((ue, self.I[item]), 1)))
+        if self.kind == "PFCN_DMF":
+            return torch.sigmoid(F.cosine_similarity(ue, self.item_mlp(self.I[item])))
         s = (ue * self.I[item]).sum(-1, keepdim=True)
         if self.biased:
             s = s + self.bu[user] + self.bi[item] + self.gb
@@ -169,8 +219,11 @@ def train(z) -> Dict[str, np.ndarray]:
         l.backward()
         opt.step()
     out: Dict[str, np.ndarray] = {"loss": np.array(losses)}
-    out["final.model.user_embedding_layer.weight"] = m.U.detach().numpy().copy()
-    out["final.model.item_embedding_layer.weight"] = m.I.detach().numpy().copy()
+    out[f"final.model.{m.uname}.weight"] = m.U.detach().numpy().copy()
+    out[f"final.model.{m.iname}.weight"] = m.I.detach().numpy().copy()
+    for name, mlp in (("mlp_layer", m.scorer), ("user_mlp", m.user_mlp), ("item_mlp", m.item_mlp)):
+        if mlp is not None:
+            mlp.export(f"final.model.{name}", out)
     if m.biased:
         out["final.model.user_bias.weight"] = m.bu.detach().numpy().copy()
         out["final.model.item_bias.weight"] = m.bi.detach().numpy().copy()

@@ -27,6 +27,8 @@ from ..layers import MLPLayers
 class PFCNBase(FairRecommender):
     input_type = InputType.PAIRWISE
     biased = False
+    user_table_attr = "user_embedding_layer"     # attribute / state_dict names of the two tables
+    item_table_attr = "item_embedding_layer"
 
     def __init__(self, config, dataset):
         super().__init__(config, dataset)
@@ -45,10 +47,11 @@ class PFCNBase(FairRecommender):
             self.dis_hidden_size_list = config['dis_hidden_size_list']
         self.activation = config['activation']
 
-        self.user_embedding_layer = nn.Embedding(self.n_users, self.embedding_size)
+        setattr(self, self.user_table_attr, nn.Embedding(self.n_users, self.embedding_size))
         if self.biased:
             self.user_bias = nn.Embedding(self.n_users, 1)
-        self.item_embedding_layer = nn.Embedding(self.n_items, self.embedding_size)
+        setattr(self, self.item_table_attr, nn.Embedding(self.n_items, self.embedding_size))
+        self._build_base_layers(config)
         if self.biased:
             self.item_bias = nn.Embedding(self.n_items, 1)
             self.global_bias = nn.Parameter(torch.tensor(0.1))
@@ -56,6 +59,37 @@ class PFCNBase(FairRecommender):
             self.filter_layer = self.init_filter()
             self.dis_layer_dict = self.init_dis_layer()
         self._engine = None
+
+    # --- hooks of the base recommender (PMF: nothing; MLP: scorer; DMF: towers + cosine) ------------------------------
+    def _build_base_layers(self, config):
+        pass
+
+    def _base_dense_modules(self):
+        """{state_dict prefix: registered MLP module} trained by optimizer_filter / the default optimizer."""
+        return {}
+
+    def _user_tower(self, rows):
+        return rows
+
+    def _item_tower(self, rows):
+        return rows
+
+    def _score(self, user_embed, item_embed):
+        return RowDot.apply(user_embed, item_embed)
+
+    def _filter_activation(self):
+        return self.activation
+
+    def _dis_activation(self):
+        return self.activation
+
+    @property
+    def _utab(self):
+        return self.user_table_attr + ".weight"
+
+    @property
+    def _itab(self):
+        return self.item_table_attr + ".weight"
 
     # --- construction (pfcn_biasedmf.py:67-142) ---------------------------------------------------------------
     def _get_filter_info(self):
@@ -75,7 +109,7 @@ class PFCNBase(FairRecommender):
 
     def init_filter(self):
         D = self.embedding_size
-        return {i + 1: MLPLayers([D, D * 2, D], activation=self.activation, bn=True, init_method='norm').to(self.device)
+        return {i + 1: MLPLayers([D, D * 2, D], activation=self._filter_activation(), bn=True, init_method='norm').to(self.device)
                 for i in range(self.filter_num)}
 
     def init_dis_layer(self):
@@ -86,17 +120,20 @@ class PFCNBase(FairRecommender):
             if output_dim == 2:
                 output_dim = 1
             out[sst] = MLPLayers([D] + list(self.dis_hidden_size_list) + [output_dim], dropout=self.dis_drop_out,
-                                 activation=self.activation, bn=True, init_method='norm').to(self.device)
+                                 activation=self._dis_activation(), bn=True, init_method='norm').to(self.device)
         return out
 
     # --- engine: which optimizer owns what (trainer.py:1201-1235) ---------------------------------------------------
     def hip_engine(self) -> GenericEngine:
-        uw = self.user_embedding_layer.weight
-        if self._engine is None or self._engine._tables["user_embedding_layer.weight"].weight.data_ptr() != uw.data_ptr():
+        uw = getattr(self, self.user_table_attr).weight
+        if self._engine is None or self._engine._tables[self._utab].weight.data_ptr() != uw.data_ptr():
             eng = GenericEngine(uw.device)
             g = 'filter' if self.filter_mode != 'none' else None
-            eng.add_table("user_embedding_layer.weight", uw, group=g)
-            eng.add_table("item_embedding_layer.weight", self.item_embedding_layer.weight, group=g)
+            eng.add_table(self._utab, uw, group=g)
+            eng.add_table(self._itab, getattr(self, self.item_table_attr).weight, group=g)
+            for prefix, mod in self._base_dense_modules().items():
+                for n, p in mod.named_parameters():
+                    eng.add_dense(f"{prefix}.{n}", p, group=g)
             if self.biased:
                 eng.add_table("user_bias.weight", self.user_bias.weight, group=g)
                 eng.add_table("item_bias.weight", self.item_bias.weight, group=g)
@@ -127,8 +164,8 @@ class PFCNBase(FairRecommender):
 
     def forward(self, user, item=None, sst_list=None):
         eng = self.hip_engine()
-        user_embed = self._filter(eng.lookup("user_embedding_layer.weight", user), sst_list)
-        item_embed = eng.lookup("item_embedding_layer.weight", item) if item is not None else None
+        user_embed = self._filter(self._user_tower(eng.lookup(self._utab, user)), sst_list)
+        item_embed = self._item_tower(eng.lookup(self._itab, item)) if item is not None else None
         return user_embed, item_embed
 
     def _dis_terms(self, user_embed, interaction, sst_list):
@@ -150,7 +187,7 @@ class PFCNBase(FairRecommender):
         eng = self.hip_engine()
         user = interaction[self.USER_ID]
         with torch.no_grad():
-            user_embed = self._filter(eng.lookup("user_embedding_layer.weight", user), sst_list)
+            user_embed = self._filter(self._user_tower(eng.lookup(self._utab, user)), sst_list)
         return self._dis_terms(user_embed, interaction, sst_list)
 
     def calculate_loss(self, interaction, sst_list=None):
@@ -158,12 +195,12 @@ class PFCNBase(FairRecommender):
         user = interaction[self.USER_ID]
         pos_item, neg_item = interaction[self.POS_ITEM_ID], interaction[self.NEG_ITEM_ID]
         B = user.numel()
-        ue_raw = eng.lookup("user_embedding_layer.weight", user)
-        user_embed = self._filter(ue_raw, sst_list)
+        ue_raw = eng.lookup(self._utab, user)
+        user_embed = self._filter(self._user_tower(ue_raw), sst_list)
         items = torch.cat([pos_item.to(eng.device), neg_item.to(eng.device)])     # one gather for both id lists
-        ie = eng.lookup("item_embedding_layer.weight", items)
-        pos_e, neg_e = ie[:B], ie[B:]
-        dp, dn = RowDot.apply(user_embed, pos_e), RowDot.apply(user_embed, neg_e)
+        ie = eng.lookup(self._itab, items)
+        pos_e, neg_e = self._item_tower(ie[:B]), self._item_tower(ie[B:])
+        dp, dn = self._score(user_embed, pos_e), self._score(user_embed, neg_e)
         if self.biased:
             ub = eng.lookup("user_bias.weight", user)
             ib = eng.lookup("item_bias.weight", items)
@@ -173,7 +210,7 @@ class PFCNBase(FairRecommender):
         if self.filter_mode != 'none':
             # the reference calls forward() a second time inside calculate_dis_loss (pfcn_biasedmf.py:209): same rows,
             # filters applied again (BatchNorm statistics advance twice), gradient flows through both passes
-            dis_loss = self._dis_terms(self._filter(ue_raw, sst_list), interaction, sst_list)
+            dis_loss = self._dis_terms(self._filter(self._user_tower(ue_raw), sst_list), interaction, sst_list)
             return bpr_loss - self.dis_weight * dis_loss
         return bpr_loss
 
@@ -182,10 +219,13 @@ class PFCNBase(FairRecommender):
         user, item = interaction[self.USER_ID], interaction[self.ITEM_ID]
         with torch.no_grad():
             ue, ie = self.forward(user, item, sst_list)
-            score = RowDot.apply(ue, ie).unsqueeze(-1)
+            score = self._predict_score(ue, ie)
             if self.biased:
                 score = score + eng.lookup("user_bias.weight", user) + eng.lookup("item_bias.weight", item) + self.global_bias
             return torch.sigmoid(score)
+
+    def _predict_score(self, ue, ie):
+        return RowDot.apply(ue, ie).unsqueeze(-1)
 
     def get_sst_embed(self, user_data, sst_list=None):
         ret = {}

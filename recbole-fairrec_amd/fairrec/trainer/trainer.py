@@ -307,6 +307,14 @@ class PFCN_BiasedMFTrainer(PFCNTrainer):
     pass
 
 
+class PFCN_MLPTrainer(PFCNTrainer):
+    pass
+
+
+class PFCN_DMFTrainer(PFCNTrainer):
+    pass
+
+
 class FairGoTrainer(PFCNTrainer):
     """recbole/trainer/trainer.py:534-736: `pretrain_epochs` of plain MF regression with optimizer_pretrain, a pretrain
     checkpoint, then the same alternating filter / discriminator schedule as PFCN with optimizer_filter /

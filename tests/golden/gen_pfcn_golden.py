@@ -23,6 +23,8 @@ import torch  # noqa: E402
 import torch.nn as nn  # noqa: E402
 from recbole.data.interaction import Interaction  # noqa: E402
 from recbole.model.fair_recommender.pfcn_biasedmf import PFCN_BiasedMF  # noqa: E402
+from recbole.model.fair_recommender.pfcn_dmf import PFCN_DMF  # noqa: E402
+from recbole.model.fair_recommender.pfcn_mlp import PFCN_MLP  # noqa: E402
 from recbole.model.fair_recommender.pfcn_pmf import PFCN_PMF  # noqa: E402
 
 
@@ -87,7 +89,11 @@ def run_case(name, cls, mode, attrs, phases, sst_lists, D, B, dis_hidden, seed, 
     feats["gender"][1:3] = [0.0, 1.0]
     cfg = _Cfg(USER_ID_FIELD="user_id", ITEM_ID_FIELD="item_id", NEG_PREFIX="neg_", device=torch.device("cpu"),
                embedding_size=D, sst_attr_list=list(attrs), filter_mode=mode, dis_dropout=p_drop, dis_weight=dis_weight,
-               dis_hidden_size_list=list(dis_hidden), activation="leakyrelu")
+               dis_hidden_size_list=list(dis_hidden), activation="leakyrelu",
+               # PFCN_MLP scorer / PFCN_DMF towers: their own dropout is 0 here (the mask path is pinned by the
+               # discriminators and by the NFCF vectors); sizes kept small
+               dropout=0.0, mlp_hidden_size_list=[8, 4], num_layers=2, mlp_dropout=0.0, mlp_activation="relu",
+               dis_activation="leakyrelu")
     model = cls(cfg, _FakeDataset(n_users, n_items, feats))
     out = {"mode": np.array(mode), "model": np.array(cls.__name__), "attrs": np.array(list(attrs)),
            "dis_hidden": np.array(dis_hidden), "hyper": np.array([lr, wd, dis_weight, p_drop]),
@@ -103,10 +109,17 @@ def run_case(name, cls, mode, attrs, phases, sst_lists, D, B, dis_hidden, seed, 
         opt_f = torch.optim.Adam(model.parameters(), lr=lr, weight_decay=wd)                 # trainer.py:139
         opt_d = None
     else:
-        groups = [{"params": model.user_embedding_layer.weight}, {"params": model.item_embedding_layer.weight}]
+        if cls is PFCN_MLP:                                                                   # trainer.py:1193-1198
+            groups = [{"params": model.user_embedding.weight}, {"params": model.item_embedding.weight}]
+        else:
+            groups = [{"params": model.user_embedding_layer.weight}, {"params": model.item_embedding_layer.weight}]
         groups += [{"params": m.parameters()} for m in model.filter_layer.values()]
         if cls is PFCN_BiasedMF:                                                              # trainer.py:1205-1211
             groups += [{"params": model.user_bias.weight}, {"params": model.item_bias.weight}, {"params": model.global_bias}]
+        if cls is PFCN_MLP:
+            groups += [{"params": model.mlp_layer.parameters()}]
+        if cls is PFCN_DMF:                                                                   # trainer.py:1219-1224
+            groups += [{"params": model.user_mlp.parameters()}, {"params": model.item_mlp.parameters()}]
         opt_f = torch.optim.Adam(groups, lr=lr, weight_decay=wd)
         opt_d = torch.optim.Adam([{"params": m.parameters()} for m in model.dis_layer_dict.values()], lr=lr, weight_decay=wd)
     T = len(phases)
@@ -165,6 +178,10 @@ def main():
     run_case("pmf_sm2", PFCN_PMF, "sm", ga, "FDFD", [ga, ga, ("age",), ("age",)], D=8, B=32, dis_hidden=(16, 8), seed=4)
     run_case("bmf_none", PFCN_BiasedMF, "none", g, "FFFFFF", [g] * 6, D=8, B=32, dis_hidden=(16, 8), seed=5)
     run_case("bmf_sm", PFCN_BiasedMF, "sm", g, "FFDDFD", [g] * 6, D=8, B=32, dis_hidden=(16, 8), seed=6)
+    run_case("mlp_none", PFCN_MLP, "none", g, "FFFF", [g] * 4, D=8, B=32, dis_hidden=(16, 8), seed=8)
+    run_case("mlp_sm", PFCN_MLP, "sm", g, "FFDDFD", [g] * 6, D=8, B=32, dis_hidden=(16, 8), seed=9)
+    run_case("dmf_none", PFCN_DMF, "none", g, "FFFF", [g] * 4, D=8, B=32, dis_hidden=(16, 8), seed=10, wd=1e-3)
+    run_case("dmf_cm2", PFCN_DMF, "cm", ga, "FDFDFD", [ga, ga, g, g, ("age",), ("age",)], D=8, B=32, dis_hidden=(16, 8), seed=11, wd=1e-3)
     run_case("bmf_sm_d64", PFCN_BiasedMF, "sm", g, "FDF", [g] * 3, D=64, B=96, dis_hidden=(128, 256, 128, 128, 64, 32), seed=7)
 
 

@@ -40,11 +40,15 @@ def test_pfcn_training_matches_reference_golden(path):
     name, mode = str(z["model"]), str(z["mode"])
     attrs = [str(a) for a in z["attrs"]]
     lr, wd, dis_weight, p = (float(x) for x in z["hyper"])
-    n_users, D = z["init.model.user_embedding_layer.weight"].shape
-    n_items = z["init.model.item_embedding_layer.weight"].shape[0]
+    utab = "user_embedding" if name == "PFCN_MLP" else "user_embedding_layer"
+    itab = "item_embedding" if name == "PFCN_MLP" else "item_embedding_layer"
+    n_users, D = z[f"init.model.{utab}.weight"].shape
+    n_items = z[f"init.model.{itab}.weight"].shape[0]
     cfg = Config(model=name, config_dict={"embedding_size": D, "sst_attr_list": attrs, "filter_mode": mode,
                                           "dis_hidden_size_list": [int(h) for h in z["dis_hidden"]], "dis_dropout": p,
-                                          "dis_weight": dis_weight, "device": "cuda"})
+                                          "dis_weight": dis_weight, "device": "cuda", "dropout": 0.0,
+                                          "mlp_hidden_size_list": [8, 4], "num_layers": 2, "mlp_dropout": 0.0,
+                                          "mlp_activation": "relu", "dis_activation": "leakyrelu", "activation": "leakyrelu"})
     model = get_model(name)(cfg, _DS(n_users, n_items, z))
     model.load_state_dict({k[11:]: torch.tensor(z[k]) for k in z.files if k.startswith("init.model.")})
     model = model.to("cuda")
