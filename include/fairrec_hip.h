@@ -228,12 +228,15 @@ FR_API int fr_linear_bwd_weight(const float* dY, const float* Y, int32_t act, co
 
 /* BatchNorm1d on batch statistics between Linear and activation (MLPLayers(bn=True), layers.py:66-67; the PFCN filters
  * and discriminators, which the reference never puts in eval mode).  Z [M,N] -> Y = act(gamma * xhat + beta);
- * xhat [M,N] and invstd [N] are kept for fr_bn_bwd; running_mean/var (may be NULL) follow torch (momentum, unbiased). */
+ * xhat [M,N] and invstd [N] are kept for fr_bn_bwd; running_mean/var (may be NULL) follow torch (momentum, unbiased).
+ * ws (fr_bn_workspace_bytes) holds the per-row-chunk partial statistics of the two-launch reduction. */
+FR_API size_t fr_bn_workspace_bytes(int64_t M, int32_t N);
 FR_API int fr_bn_fwd(const float* Z, const float* gamma, const float* beta, float eps, float momentum,
                      float* running_mean, float* running_var, int64_t M, int32_t N, int32_t act, float* Y, float* xhat,
-                     float* invstd, void* stream);
+                     float* invstd, void* ws, size_t ws_bytes, void* stream);
 FR_API int fr_bn_bwd(const float* dY, const float* Y, int32_t act, const float* xhat, const float* invstd,
-                     const float* gamma, int64_t M, int32_t N, float* dZ, float* dgamma, float* dbeta, void* stream);
+                     const float* gamma, int64_t M, int32_t N, float* dZ, float* dgamma, float* dbeta, void* ws,
+                     size_t ws_bytes, void* stream);
 
 /* ---- PFCN scoring / losses (pfcn_pmf.py, pfcn_biasedmf.py, loss.py) -------------------------------------------------
  * fr_rowdot_*   : torch.mul(a, b).sum(-1) on gathered rows and its backward (da = g*b, db = g*a; either may be NULL)

@@ -8,7 +8,11 @@
 
 namespace fr {
 
-// Y[r,:] = sum_{j in row r} val[j] * X[col[j],:]      one wave per row, lane = column (strided), fixed order
+// Y[r,:] = sum_{j in row r} val[j] * X[col[j],:]      one wave per row, fixed (ascending j) order.
+// V > 0: D == 64 * V and lane l owns columns [l*V, l*V+V) (one 64*V*4-byte gather per nonzero); the row's (col, val)
+// pairs are loaded 64 at a time, one per lane, and broadcast with readlane so that the gathers of consecutive
+// nonzeros are independent loads in flight.  V == 0: any D, strided columns.
+template <int V>
 __global__ __launch_bounds__(256) void spmm_csr_kernel(const long long* __restrict__ indptr, const int* __restrict__ col,
                                                        const float* __restrict__ val, const float* __restrict__ X,
                                                        long long n_rows, int D, float* __restrict__ Y) {
@@ -16,10 +20,33 @@ __global__ __launch_bounds__(256) void spmm_csr_kernel(const long long* __restri
     const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= n_rows) return;
     const long long j0 = indptr[r], j1 = indptr[r + 1];
-    for (int d = lane; d < D; d += 64) {
-        float acc = 0.f;
-        for (long long j = j0; j < j1; ++j) acc = fmaf(val[j], X[(size_t)col[j] * D + d], acc);
-        Y[(size_t)r * D + d] = acc;
+    if constexpr (V == 0) {
+        for (int d = lane; d < D; d += 64) {
+            float acc = 0.f;
+            for (long long j = j0; j < j1; ++j) acc = fmaf(val[j], X[(size_t)col[j] * D + d], acc);
+            Y[(size_t)r * D + d] = acc;
+        }
+    } else {
+        typedef float vec __attribute__((ext_vector_type(V)));
+        vec acc = {};
+        for (long long jb = j0; jb < j1; jb += 64) {
+            const int cnt = (int)min((long long)64, j1 - jb);
+            int my_c = 0;
+            float my_v = 0.f;
+            if (lane < cnt) {
+                my_c = col[jb + lane];
+                my_v = val[jb + lane];
+            }
+#pragma unroll 4
+            for (int t = 0; t < cnt; ++t) {
+                const int c = __builtin_amdgcn_readlane(my_c, t);
+                const float v = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_v), t));
+                const vec x = *reinterpret_cast<const vec*>(X + (size_t)c * D + lane * V);
+#pragma unroll
+                for (int e = 0; e < V; ++e) acc[e] = fmaf(v, x[e], acc[e]);
+            }
+        }
+        *reinterpret_cast<vec*>(Y + (size_t)r * D + lane * V) = acc;
     }
 }
 
@@ -93,8 +120,17 @@ extern "C" int fr_spmm_csr(const int64_t* indptr, const int32_t* col, const floa
     hipStream_t stream = (hipStream_t)stream_;
     FR_CHECK_ARG(indptr && col && val && X && Y && n_rows >= 1 && dim >= 1, "fr_spmm_csr: bad argument");
     ProfScope prof(K_SPMM, stream);
-    FR_LAUNCH(prof, spmm_csr_kernel, dim3((unsigned)((n_rows + 3) / 4)), dim3(256), 0, stream, (const long long*)indptr, col,
-              val, X, (long long)n_rows, (int)dim, Y);
+    const dim3 grid((unsigned)((n_rows + 3) / 4));
+#define FR_SPMM(V)                                                                                              \
+    FR_LAUNCH(prof, spmm_csr_kernel<V>, grid, dim3(256), 0, stream, (const long long*)indptr, col, val, X, \
+              (long long)n_rows, (int)dim, Y)
+    switch (dim) {
+        case 64: FR_SPMM(1); break;
+        case 128: FR_SPMM(2); break;
+        case 256: FR_SPMM(4); break;
+        default: FR_SPMM(0); break;
+    }
+#undef FR_SPMM
     FR_CHECK_LAUNCH();
     return FR_OK;
 }

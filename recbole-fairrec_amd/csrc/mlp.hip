@@ -8,6 +8,8 @@
 //   linear_bwd_input  dX = ((dY o act'(Y)) W) o mask*scale
 //   linear_bwd_weight dW = (dY o act'(Y))^T (X o mask*scale)   (split over the batch, fixed-order reduction), db
 // Tiles: 256 threads = 4 waves, 64x64 output tile, each wave one 32x32 MFMA tile, 32-deep K chunks through LDS.
+#include <algorithm>
+
 #include "common.hpp"
 #include "kernels.hpp"
 
@@ -159,7 +161,7 @@ __global__ __launch_bounds__(256) void linear_bwd_input_kernel(const float* __re
 __global__ __launch_bounds__(256) void linear_bwd_weight_kernel(const float* __restrict__ dY, const float* __restrict__ Y,
                                                                 int act, CatMat X, const unsigned char* __restrict__ mask,
                                                                 float scale, int M, int N, int K, int rows_per_split,
-                                                                float* __restrict__ slab) {
+                                                                float* __restrict__ slab, float* __restrict__ bslab) {
     __shared__ float Gs[TK * (TM + 1)];   // [m chunk][n tile]
     __shared__ float Xs[TK * (TN + 1)];   // [m chunk][k tile]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -167,6 +169,8 @@ __global__ __launch_bounds__(256) void linear_bwd_weight_kernel(const float* __r
     const int n0 = blockIdx.x * TM, c0 = blockIdx.y * TN, s = blockIdx.z;
     const int mlo = s * rows_per_split, mhi = min(M, mlo + rows_per_split);
     f32x16 acc = {0};
+    float bsum = 0.f;                        // bias gradient of column n0 + tid (blocks of the first k tile, tid < TM)
+    const bool do_bias = bslab && blockIdx.y == 0 && tid < TM;
     for (int mb = mlo; mb < mhi; mb += TK) {
 #pragma unroll
         for (int q = 0; q < (TM * TK) / 256; ++q) {
@@ -196,8 +200,13 @@ __global__ __launch_bounds__(256) void linear_bwd_weight_kernel(const float* __r
             const float b = Xs[(kk + (lane >> 5)) * (TN + 1) + wn * 32 + (lane & 31)];
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
         }
+        if (do_bias) {
+#pragma unroll
+            for (int r = 0; r < TK; ++r) bsum += Gs[r * (TM + 1) + tid];
+        }
         __syncthreads();
     }
+    if (do_bias && n0 + tid < N) bslab[(size_t)s * N + n0 + tid] = bsum;
     float* out = slab + (size_t)s * N * K;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -207,28 +216,21 @@ __global__ __launch_bounds__(256) void linear_bwd_weight_kernel(const float* __r
     }
 }
 
-// dW[i] = sum_s slab[s][i] in split order (fixed order => reproducible)
-__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slab, int splits, long long n,
-                                                          float* __restrict__ out) {
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+// dW[i] = sum_s slab[s][i] and db[n] = sum_s bslab[s][n], both in split order (fixed order => reproducible)
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slab, const float* __restrict__ bslab,
+                                                          int splits, long long n, int nb, float* __restrict__ out,
+                                                          float* __restrict__ db) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n + nb; i += (long long)gridDim.x * 256) {
         float a = 0.f;
-        for (int s = 0; s < splits; ++s) a += slab[(size_t)s * n + i];
-        out[i] = a;
+        if (i < n) {
+            for (int s = 0; s < splits; ++s) a += slab[(size_t)s * n + i];
+            out[i] = a;
+        } else {
+            const long long j = i - n;
+            for (int s = 0; s < splits; ++s) a += bslab[(size_t)s * nb + j];
+            db[j] = a;
+        }
     }
-}
-
-// db[n] = sum_m (dY o act'(Y))[m,n]: one wave per column block of 64, rows in fixed strides, LDS tree over 4 waves
-__global__ __launch_bounds__(256) void linear_bwd_bias_kernel(const float* __restrict__ dY, const float* __restrict__ Y,
-                                                              int act, int M, int N, float* __restrict__ db) {
-    __shared__ float red[4][64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int n = blockIdx.x * 64 + lane;
-    float a = 0.f;
-    if (n < N)
-        for (int m = wave; m < M; m += 4) a += dY[(size_t)m * N + n] * act_bwd(Y[(size_t)m * N + n], act);
-    red[wave][lane] = a;
-    __syncthreads();
-    if (wave == 0 && n < N) db[n] = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
 }
 
 }  // namespace fr
@@ -267,11 +269,16 @@ extern "C" int fr_linear_bwd_input(const float* dY, const float* Y, int32_t act,
     return FR_OK;
 }
 
+// row splits of the weight gradient: >= 512 rows each, enough blocks to fill 256 CUs, slab bounded by 64 MiB
+static long long bwd_weight_splits(int64_t M, int32_t N, int32_t K) {
+    long long splits = (M + 511) / 512;
+    const long long cap = std::max<long long>(1, (64ll << 20) / ((long long)N * (K + 1) * (long long)sizeof(float)));
+    return std::max<long long>(1, std::min<long long>(splits, std::min<long long>(cap, 1024)));
+}
+
 extern "C" size_t fr_linear_bwd_weight_workspace_bytes(int64_t M, int32_t N, int32_t K) {
     if (M < 1 || N < 1 || K < 1) return 0;
-    long long splits = (M + 511) / 512;
-    if (splits > 64) splits = 64;
-    return (size_t)splits * N * K * sizeof(float);
+    return (size_t)bwd_weight_splits(M, N, K) * N * (K + 1) * sizeof(float);
 }
 
 extern "C" int fr_linear_bwd_weight(const float* dY, const float* Y, int32_t act, const float* x0, int32_t k0,
@@ -281,144 +288,221 @@ extern "C" int fr_linear_bwd_weight(const float* dY, const float* Y, int32_t act
     FR_CHECK_ARG(dY && Y && x0 && dW && ws && M >= 1 && N >= 1 && k0 >= 1 && k1 >= 0 && (k1 == 0 || x1) && act_ok(act),
                  "fr_linear_bwd_weight: bad argument");
     const int K = k0 + k1;
-    long long splits = (M + 511) / 512;
-    if (splits > 64) splits = 64;
+    const long long splits = bwd_weight_splits(M, N, K);
     const int rows_per_split = (int)(((M + splits - 1) / splits + TK - 1) / TK * TK);
-    FR_CHECK_ARG(ws_bytes >= (size_t)splits * N * K * sizeof(float), "fr_linear_bwd_weight: workspace too small");
+    FR_CHECK_ARG(ws_bytes >= (size_t)splits * N * (K + 1) * sizeof(float), "fr_linear_bwd_weight: workspace too small");
     CatMat X{x0, x1, k0, k1};
+    float* slab = (float*)ws;
+    float* bslab = db ? slab + (size_t)splits * N * K : nullptr;
     {
         ProfScope prof(K_LINEAR_BWD_WEIGHT, stream);
         FR_LAUNCH(prof, linear_bwd_weight_kernel,
                   dim3((unsigned)((N + TM - 1) / TM), (unsigned)((K + TN - 1) / TN), (unsigned)splits), dim3(256), 0, stream,
-                  dY, Y, (int)act, X, mask, scale, (int)M, (int)N, K, rows_per_split, (float*)ws);
+                  dY, Y, (int)act, X, mask, scale, (int)M, (int)N, K, rows_per_split, slab, bslab);
     }
     FR_CHECK_LAUNCH();
-    const long long n = (long long)N * K;
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256)), dim3(256), 0,
-                       stream, (const float*)ws, (int)splits, n, dW);
+    const long long n = (long long)N * K, tot = n + (db ? N : 0);
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)std::min<long long>(2048, (tot + 255) / 256)), dim3(256), 0,
+                       stream, (const float*)slab, (const float*)bslab, (int)splits, n, db ? (int)N : 0, dW, db);
     FR_CHECK_LAUNCH();
-    if (db) {
-        hipLaunchKernelGGL(linear_bwd_bias_kernel, dim3((unsigned)((N + 63) / 64)), dim3(256), 0, stream, dY, Y, (int)act,
-                           (int)M, (int)N, db);
-        FR_CHECK_LAUNCH();
-    }
     return FR_OK;
 }
 
 // ---- BatchNorm1d on batch statistics (training mode) --------------------------------------------------------------
 // Replaces nn.BatchNorm1d inside MLPLayers(bn=True) (layers.py:66-67; PFCN filters / discriminators, which the
-// reference never switches to eval mode -- SURVEY.md App. B-3).  One 1024-thread block per 64 columns: lane = column,
-// 16 waves stride over the rows, partial sums combined through LDS in wave order (fixed order => reproducible).
+// reference never switches to eval mode -- SURVEY.md App. B-3).  The batch is cut into row chunks so that a
+// [8192, 256] activation fills the chip: grid = (column blocks of 64) x (row chunks).  A "stats" launch leaves one
+// partial per (chunk, column); the "apply" launch folds the partials in chunk order (fixed order => reproducible)
+// and writes its chunk.  Forward partials are (mean, M2) pairs folded with Chan's formula, so the variance is the
+// two-pass one (no E[x^2]-E[x]^2 cancellation).
 namespace fr {
 
-__device__ __forceinline__ float col_reduce_16(float a, float (*red)[64], int wave, int lane) {
+constexpr int BN_THREADS = 256;     // 4 waves: lane = column, waves stride over the rows of the chunk
+constexpr int BN_WAVES = BN_THREADS / 64;
+
+static inline int bn_chunk_rows(int64_t M) {       // >= 128 rows per chunk, <= 256 chunks
+    long long rc = 128;
+    while ((M + rc - 1) / rc > 256) rc *= 2;
+    return (int)rc;
+}
+
+__device__ __forceinline__ float col_reduce(float a, float (*red)[64], int wave, int lane) {
     __syncthreads();
     red[wave][lane] = a;
     __syncthreads();
     float s = 0.f;
 #pragma unroll
-    for (int w = 0; w < 16; ++w) s += red[w][lane];
+    for (int w = 0; w < BN_WAVES; ++w) s += red[w][lane];
     return s;
+}
+
+// part[(chunk * N + n) * 2 + {0,1}] = mean and sum of squared deviations of column n over the chunk's rows
+__global__ __launch_bounds__(BN_THREADS) void bn_fwd_stats_kernel(const float* __restrict__ Z, int M, int N, int rc,
+                                                                  float* __restrict__ part) {
+    __shared__ float red[BN_WAVES][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + lane;
+    const int m0 = blockIdx.y * rc, m1 = min(M, m0 + rc);
+    const bool ok = n < N;
+    float s = 0.f;
+    if (ok) {
+#pragma unroll 4
+        for (int m = m0 + wave; m < m1; m += BN_WAVES) s += Z[(size_t)m * N + n];
+    }
+    const float mean = col_reduce(s, red, wave, lane) / (float)(m1 - m0);
+    float q = 0.f;
+    if (ok) {
+#pragma unroll 4
+        for (int m = m0 + wave; m < m1; m += BN_WAVES) {
+            const float d = Z[(size_t)m * N + n] - mean;
+            q = fmaf(d, d, q);
+        }
+    }
+    const float m2 = col_reduce(q, red, wave, lane);
+    if (ok && wave == 0) {
+        part[((size_t)blockIdx.y * N + n) * 2] = mean;
+        part[((size_t)blockIdx.y * N + n) * 2 + 1] = m2;
+    }
 }
 
 // Y = act(gamma * (Z - mean) / sqrt(var + eps) + beta); xhat and invstd are kept for the backward;
 // running_mean / running_var follow torch (momentum, unbiased variance).
-__global__ __launch_bounds__(1024) void bn_fwd_kernel(const float* __restrict__ Z, const float* __restrict__ gamma,
-                                                      const float* __restrict__ beta, float eps, float momentum,
-                                                      float* __restrict__ rmean, float* __restrict__ rvar, int M, int N,
-                                                      int act, float* __restrict__ Y, float* __restrict__ xhat,
-                                                      float* __restrict__ invstd_out) {
-    __shared__ float red[16][64];
+__global__ __launch_bounds__(BN_THREADS) void bn_fwd_apply_kernel(const float* __restrict__ Z, const float* __restrict__ part,
+                                                                  const float* __restrict__ gamma,
+                                                                  const float* __restrict__ beta, float eps, float momentum,
+                                                                  float* __restrict__ rmean, float* __restrict__ rvar, int M,
+                                                                  int N, int rc, int act, float* __restrict__ Y,
+                                                                  float* __restrict__ xhat, float* __restrict__ invstd_out) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n = blockIdx.x * 64 + lane;
-    const bool ok = n < N;
-    float s = 0.f;
-    if (ok)
-        for (int m = wave; m < M; m += 16) s += Z[(size_t)m * N + n];
-    const float mean = col_reduce_16(s, red, wave, lane) / (float)M;
-    float q = 0.f;
-    if (ok)
-        for (int m = wave; m < M; m += 16) {
-            const float d = Z[(size_t)m * N + n] - mean;
-            q += d * d;
-        }
-    const float ssq = col_reduce_16(q, red, wave, lane);
-    const float var = ssq / (float)M;
+    if (n >= N) return;
+    const int chunks = gridDim.y;
+    float cnt = 0.f, mean = 0.f, m2 = 0.f;          // Chan et al. pairwise update, chunks in ascending order
+    for (int c = 0; c < chunks; ++c) {
+        const float nb = (float)(min(M, (c + 1) * rc) - c * rc);
+        const float mb = part[((size_t)c * N + n) * 2], qb = part[((size_t)c * N + n) * 2 + 1];
+        const float tot = cnt + nb, delta = mb - mean;
+        mean += delta * (nb / tot);
+        m2 += qb + delta * delta * (cnt * nb / tot);
+        cnt = tot;
+    }
+    const float var = m2 / (float)M;
     const float invstd = 1.f / sqrtf(var + eps);
-    if (ok) {
-        const float g = gamma[n], b = beta[n];
-        for (int m = wave; m < M; m += 16) {
-            const float xh = (Z[(size_t)m * N + n] - mean) * invstd;
-            xhat[(size_t)m * N + n] = xh;
-            Y[(size_t)m * N + n] = act_fwd(fmaf(g, xh, b), act);
-        }
-        if (wave == 0) {
-            invstd_out[n] = invstd;
-            if (rmean) {
-                rmean[n] = (1.f - momentum) * rmean[n] + momentum * mean;
-                rvar[n] = (1.f - momentum) * rvar[n] + momentum * (M > 1 ? ssq / (float)(M - 1) : var);
-            }
+    const float g = gamma[n], b = beta[n];
+    const int m0 = blockIdx.y * rc, m1 = min(M, m0 + rc);
+#pragma unroll 4
+    for (int m = m0 + wave; m < m1; m += BN_WAVES) {
+        const float xh = (Z[(size_t)m * N + n] - mean) * invstd;
+        xhat[(size_t)m * N + n] = xh;
+        Y[(size_t)m * N + n] = act_fwd(fmaf(g, xh, b), act);
+    }
+    if (blockIdx.y == 0 && wave == 0) {
+        invstd_out[n] = invstd;
+        if (rmean) {
+            rmean[n] = (1.f - momentum) * rmean[n] + momentum * mean;
+            rvar[n] = (1.f - momentum) * rvar[n] + momentum * (M > 1 ? m2 / (float)(M - 1) : var);
         }
     }
 }
 
-// dZ = invstd * gamma * (dA - mean(dA) - xhat * mean(dA * xhat)),  dA = dY o act'(Y);  dgamma = sum dA*xhat, dbeta = sum dA
-__global__ __launch_bounds__(1024) void bn_bwd_kernel(const float* __restrict__ dY, const float* __restrict__ Y, int act,
-                                                      const float* __restrict__ xhat, const float* __restrict__ invstd,
-                                                      const float* __restrict__ gamma, int M, int N,
-                                                      float* __restrict__ dZ, float* __restrict__ dgamma,
-                                                      float* __restrict__ dbeta) {
-    __shared__ float red[16][64];
+// part[(chunk * N + n) * 2 + {0,1}] = sum dA, sum dA * xhat over the chunk's rows,  dA = dY o act'(Y)
+__global__ __launch_bounds__(BN_THREADS) void bn_bwd_stats_kernel(const float* __restrict__ dY, const float* __restrict__ Y,
+                                                                  int act, const float* __restrict__ xhat, int M, int N,
+                                                                  int rc, float* __restrict__ part) {
+    __shared__ float red[BN_WAVES][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n = blockIdx.x * 64 + lane;
+    const int m0 = blockIdx.y * rc, m1 = min(M, m0 + rc);
     const bool ok = n < N;
     float s1 = 0.f, s2 = 0.f;
-    if (ok)
-        for (int m = wave; m < M; m += 16) {
+    if (ok) {
+#pragma unroll 4
+        for (int m = m0 + wave; m < m1; m += BN_WAVES) {
             const size_t i = (size_t)m * N + n;
             const float da = dY[i] * act_bwd(Y[i], act);
             s1 += da;
-            s2 += da * xhat[i];
+            s2 = fmaf(da, xhat[i], s2);
         }
-    const float sum_da = col_reduce_16(s1, red, wave, lane);
-    const float sum_dax = col_reduce_16(s2, red, wave, lane);
-    if (ok) {
-        const float g = gamma[n], is = invstd[n];
-        const float m1 = sum_da / (float)M, m2 = sum_dax / (float)M;
-        for (int m = wave; m < M; m += 16) {
-            const size_t i = (size_t)m * N + n;
-            const float da = dY[i] * act_bwd(Y[i], act);
-            dZ[i] = is * g * (da - m1 - xhat[i] * m2);
-        }
-        if (wave == 0) {
-            dgamma[n] = sum_dax;
-            dbeta[n] = sum_da;
-        }
+    }
+    const float t1 = col_reduce(s1, red, wave, lane);
+    const float t2 = col_reduce(s2, red, wave, lane);
+    if (ok && wave == 0) {
+        part[((size_t)blockIdx.y * N + n) * 2] = t1;
+        part[((size_t)blockIdx.y * N + n) * 2 + 1] = t2;
+    }
+}
+
+// dZ = invstd * gamma * (dA - mean(dA) - xhat * mean(dA * xhat));  dgamma = sum dA*xhat, dbeta = sum dA
+__global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(const float* __restrict__ dY, const float* __restrict__ Y,
+                                                                  int act, const float* __restrict__ xhat,
+                                                                  const float* __restrict__ invstd,
+                                                                  const float* __restrict__ gamma,
+                                                                  const float* __restrict__ part, int M, int N, int rc,
+                                                                  float* __restrict__ dZ, float* __restrict__ dgamma,
+                                                                  float* __restrict__ dbeta) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + lane;
+    if (n >= N) return;
+    const int chunks = gridDim.y;
+    float sum_da = 0.f, sum_dax = 0.f;
+    for (int c = 0; c < chunks; ++c) {
+        sum_da += part[((size_t)c * N + n) * 2];
+        sum_dax += part[((size_t)c * N + n) * 2 + 1];
+    }
+    const float g = gamma[n], is = invstd[n];
+    const float a1 = sum_da / (float)M, a2 = sum_dax / (float)M;
+    const int m0 = blockIdx.y * rc, m1 = min(M, m0 + rc);
+#pragma unroll 4
+    for (int m = m0 + wave; m < m1; m += BN_WAVES) {
+        const size_t i = (size_t)m * N + n;
+        const float da = dY[i] * act_bwd(Y[i], act);
+        dZ[i] = is * g * (da - a1 - xhat[i] * a2);
+    }
+    if (blockIdx.y == 0 && wave == 0) {
+        dgamma[n] = sum_dax;
+        dbeta[n] = sum_da;
     }
 }
 
 }  // namespace fr
 
+extern "C" size_t fr_bn_workspace_bytes(int64_t M, int32_t N) {
+    if (M < 1 || N < 1) return 0;
+    const int rc = bn_chunk_rows(M);
+    return (size_t)((M + rc - 1) / rc) * N * 2 * sizeof(float);
+}
+
 extern "C" int fr_bn_fwd(const float* Z, const float* gamma, const float* beta, float eps, float momentum,
                          float* running_mean, float* running_var, int64_t M, int32_t N, int32_t act, float* Y,
-                         float* xhat, float* invstd, void* stream_) {
+                         float* xhat, float* invstd, void* ws, size_t ws_bytes, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    FR_CHECK_ARG(Z && gamma && beta && Y && xhat && invstd && M >= 1 && N >= 1 && act_ok(act), "fr_bn_fwd: bad argument");
+    FR_CHECK_ARG(Z && gamma && beta && Y && xhat && invstd && ws && M >= 1 && N >= 1 && act_ok(act) &&
+                     ws_bytes >= fr_bn_workspace_bytes(M, N), "fr_bn_fwd: bad argument");
+    const int rc = bn_chunk_rows(M);
+    const dim3 grid((unsigned)((N + 63) / 64), (unsigned)((M + rc - 1) / rc));
     ProfScope prof(K_BN_FWD, stream);
-    FR_LAUNCH(prof, bn_fwd_kernel, dim3((unsigned)((N + 63) / 64)), dim3(1024), 0, stream, Z, gamma, beta, eps, momentum,
-              running_mean, running_var, (int)M, (int)N, (int)act, Y, xhat, invstd);
+    FR_LAUNCH(prof, bn_fwd_stats_kernel, grid, dim3(BN_THREADS), 0, stream, Z, (int)M, (int)N, rc, (float*)ws);
+    FR_CHECK_LAUNCH();
+    FR_LAUNCH(prof, bn_fwd_apply_kernel, grid, dim3(BN_THREADS), 0, stream, Z, (const float*)ws, gamma, beta, eps, momentum,
+              running_mean, running_var, (int)M, (int)N, rc, (int)act, Y, xhat, invstd);
     FR_CHECK_LAUNCH();
     return FR_OK;
 }
 
 extern "C" int fr_bn_bwd(const float* dY, const float* Y, int32_t act, const float* xhat, const float* invstd,
-                         const float* gamma, int64_t M, int32_t N, float* dZ, float* dgamma, float* dbeta, void* stream_) {
+                         const float* gamma, int64_t M, int32_t N, float* dZ, float* dgamma, float* dbeta, void* ws,
+                         size_t ws_bytes, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    FR_CHECK_ARG(dY && Y && xhat && invstd && gamma && dZ && dgamma && dbeta && M >= 1 && N >= 1 && act_ok(act),
-                 "fr_bn_bwd: bad argument");
+    FR_CHECK_ARG(dY && Y && xhat && invstd && gamma && dZ && dgamma && dbeta && ws && M >= 1 && N >= 1 && act_ok(act) &&
+                     ws_bytes >= fr_bn_workspace_bytes(M, N), "fr_bn_bwd: bad argument");
+    const int rc = bn_chunk_rows(M);
+    const dim3 grid((unsigned)((N + 63) / 64), (unsigned)((M + rc - 1) / rc));
     ProfScope prof(K_BN_BWD, stream);
-    FR_LAUNCH(prof, bn_bwd_kernel, dim3((unsigned)((N + 63) / 64)), dim3(1024), 0, stream, dY, Y, (int)act, xhat, invstd,
-              gamma, (int)M, (int)N, dZ, dgamma, dbeta);
+    FR_LAUNCH(prof, bn_bwd_stats_kernel, grid, dim3(BN_THREADS), 0, stream, dY, Y, (int)act, xhat, (int)M, (int)N, rc,
+              (float*)ws);
+    FR_CHECK_LAUNCH();
+    FR_LAUNCH(prof, bn_bwd_apply_kernel, grid, dim3(BN_THREADS), 0, stream, dY, Y, (int)act, xhat, invstd, gamma,
+              (const float*)ws, (int)M, (int)N, rc, dZ, dgamma, dbeta);
     FR_CHECK_LAUNCH();
     return FR_OK;
 }

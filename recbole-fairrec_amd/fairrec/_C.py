@@ -77,10 +77,11 @@ _PROTOS = {
     "fr_nfcf_loss_workspace_bytes": (c_size_t, [c_int64]),
     "fr_nfcf_loss": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_float, c_void_p, c_size_t, c_int32, c_void_p,
                              c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
+    "fr_bn_workspace_bytes": (c_size_t, [c_int64, c_int32]),
     "fr_bn_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_float, c_void_p, c_void_p, c_int64, c_int32, c_int32,
-                          c_void_p, c_void_p, c_void_p, c_void_p]),
+                          c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "fr_bn_bwd": (c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p,
-                          c_void_p, c_void_p]),
+                          c_void_p, c_void_p, c_size_t, c_void_p]),
     "fr_rowdot_fwd": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p]),
     "fr_rowdot_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p]),
     "fr_bpr_workspace_bytes": (c_size_t, [c_int64, c_int32]),

@@ -68,8 +68,10 @@ class _HipMLP(torch.autograd.Function):
                 Y = torch.empty_like(Z)
                 xh = torch.empty_like(Z)
                 inv = torch.empty(N, dtype=torch.float32, device=dev)
+                ws = torch.empty(lib.fr_bn_workspace_bytes(M, N), dtype=torch.uint8, device=dev)
                 _C.check(lib.fr_bn_fwd(Z.data_ptr(), g.data_ptr(), be.data_ptr(), eps, mom, _C.ptr(rm), _C.ptr(rv), M, N, act,
-                                       Y.data_ptr(), xh.data_ptr(), inv.data_ptr(), st), "fr_bn_fwd")
+                                       Y.data_ptr(), xh.data_ptr(), inv.data_ptr(), ws.data_ptr(), ws.numel(), st),
+                         "fr_bn_fwd")
                 xhats.append(xh)
                 invstds.append(inv)
             outs.append(Y)
@@ -109,8 +111,10 @@ class _HipMLP(torch.autograd.Function):
                 dZ = torch.empty_like(Y)
                 dg = torch.empty(N, dtype=torch.float32, device=dev)
                 dbt = torch.empty(N, dtype=torch.float32, device=dev)
+                ws = torch.empty(lib.fr_bn_workspace_bytes(M, N), dtype=torch.uint8, device=dev)
                 _C.check(lib.fr_bn_bwd(dY.data_ptr(), Y.data_ptr(), act, xhats[l].data_ptr(), invstds[l].data_ptr(),
-                                       g.data_ptr(), M, N, dZ.data_ptr(), dg.data_ptr(), dbt.data_ptr(), st), "fr_bn_bwd")
+                                       g.data_ptr(), M, N, dZ.data_ptr(), dg.data_ptr(), dbt.data_ptr(), ws.data_ptr(),
+                                       ws.numel(), st), "fr_bn_bwd")
                 grads[per * l + 2], grads[per * l + 3] = dg, dbt
                 dY, Y, act = dZ, dZ, 0
             need = lib.fr_linear_bwd_weight_workspace_bytes(M, N, K)

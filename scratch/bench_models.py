@@ -1,0 +1,88 @@
+"""Step times of the non-headline models at (or near) BASELINE.json config sizes on one MI355X (informational)."""
+import sys, os, time
+import numpy as np, torch, scipy.sparse as sp
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "recbole-fairrec_amd")]
+from fairrec.config import Config
+from fairrec.data.interaction import Interaction
+from fairrec.optim import FusedLazyAdam
+from fairrec.utils import get_model
+
+class DS:
+    def __init__(self, nu, ni, graph=None):
+        self._n = {"user_id": nu, "item_id": ni}
+        g = torch.Generator().manual_seed(0)
+        self._uf = Interaction({"user_id": torch.arange(nu), "gender": (torch.rand(nu, generator=g) < 0.5).float()})
+        self._uf["gender"][1:3] = torch.tensor([0.0, 1.0])
+        self.inter_feat = {"rating": torch.tensor([1.0, 5.0])}
+        self._graph = graph
+    def num(self, f): return self._n[f]
+    def get_user_feature(self): return self._uf
+    def inter_matrix(self, form="coo", value_field=None): return self._graph
+
+def batches(nu, ni, B, T, pair=False):
+    g = torch.Generator().manual_seed(1)
+    out = []
+    for _ in range(T):
+        u = torch.randint(1, nu, (B,), generator=g)
+        d = {"user_id": u, "item_id": torch.randint(1, ni, (B,), generator=g)}
+        if pair: d["neg_item_id"] = torch.randint(1, ni, (B,), generator=g)
+        d["rating"] = torch.randint(1, 6, (B,), generator=g).float()
+        d["label"] = (d["rating"] >= 3).float()
+        out.append(d)
+    return out
+
+def run(name, model, opts, loss_fns, data, gender, W=5, K=20):
+    dev = "cuda"
+    inters = []
+    for d in data:
+        d = dict(d); d["gender"] = gender[d["user_id"]]
+        inters.append(Interaction(d).to(dev))
+    def step(k):
+        for opt, fn in zip(opts, loss_fns):
+            opt.zero_grad(); loss = fn(inters[k % len(inters)]); loss.backward(); opt.step()
+    for k in range(W): step(k)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for k in range(W, W + K): step(k)
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / K
+    B = inters[0].length
+    print(f"{name}: {dt*1e3:.3f} ms per step ({len(opts)} optimizer passes), {B/dt/1e6:.2f} M interactions/s, "
+          f"mem {torch.cuda.max_memory_allocated()/2**30:.1f} GiB", flush=True)
+
+which = sys.argv[1:] or ["nfcf", "pfcn", "fairgo"]
+B = 8192
+if "nfcf" in which:
+    nu, ni, D = 10_000_001, 1_000_001, 256
+    cfg = Config(model="NFCF", config_dict={"embedding_size": D, "device": "cuda", "load_pretrain_path": None})
+    ds = DS(nu, ni)
+    m = get_model("NFCF")(cfg, ds).to("cuda"); m.train()
+    opt = FusedLazyAdam(m.hip_engine(), lr=1e-3, weight_decay=1e-6)
+    run(f"NFCF pretrain {nu}x{ni} D={D} B={B}", m, [opt], [m.calculate_loss], batches(nu, ni, B, 8), ds._uf["gender"])
+    del m, opt; torch.cuda.empty_cache()
+if "pfcn" in which:
+    nu, ni, D = 10_000_001, 1_000_001, 128
+    cfg = Config(model="PFCN_BiasedMF", config_dict={"embedding_size": D, "device": "cuda", "filter_mode": "sm"})
+    ds = DS(nu, ni)
+    m = get_model("PFCN_BiasedMF")(cfg, ds).to("cuda"); m.train()
+    of = FusedLazyAdam(m.hip_engine(), lr=1e-3, weight_decay=1e-4, group="filter")
+    od = FusedLazyAdam(m.hip_engine(), lr=1e-3, weight_decay=1e-4, group="dis")
+    sl = ["gender"]
+    data = batches(nu, ni, B, 8, pair=True)
+    run(f"PFCN_BiasedMF sm filter-phase step {nu}x{ni} D={D} B={B}", m, [of], [lambda it: m.calculate_loss(it, sl)], data, ds._uf["gender"])
+    run(f"PFCN_BiasedMF sm dis-phase step", m, [od], [lambda it: m.calculate_dis_loss(it, sl)], data, ds._uf["gender"])
+    del m, of, od; torch.cuda.empty_cache()
+if "fairgo" in which:
+    nu, ni, D = 1_000_001, 100_001, 128
+    rng = np.random.default_rng(0)
+    nnz = 20 * nu
+    gu, gi = rng.integers(1, nu, nnz), rng.integers(1, ni, nnz)
+    graph = sp.coo_matrix((rng.integers(1, 6, nnz).astype(np.float32), (gu, gi)), shape=(nu, ni))
+    cfg = Config(model="FairGo_PMF", config_dict={"embedding_size": D, "device": "cuda", "aggr_method": "WAP", "n_layers": 2})
+    ds = DS(nu, ni, graph)
+    m = get_model("FairGo_PMF")(cfg, ds).to("cuda"); m.train(); m.train_stage = "finetune"
+    of = FusedLazyAdam(m.hip_engine(), lr=1e-3, weight_decay=1e-4, group="filter")
+    od = FusedLazyAdam(m.hip_engine(), lr=1e-3, weight_decay=1e-4, group="dis")
+    sl = ["gender"]
+    data = batches(nu, ni, B, 4)
+    run(f"FairGo_PMF WAP finetune filter-phase step {nu}x{ni} D={D} B={B} (whole-table filters + 2 SpMM, nnz={2*nnz})", m, [of], [lambda it: m.calculate_loss(it, sl)], data, ds._uf["gender"], W=2, K=5)
+    run(f"FairGo_PMF WAP finetune dis-phase step", m, [od], [lambda it: m.calculate_dis_loss(it, sl)], data, ds._uf["gender"], W=2, K=5)

@@ -66,3 +66,78 @@ def test_linear_forward_and_backward_match_torch(M, k0, k1, N, act, drop):
     _C.check(lib.fr_linear_bwd_weight(dYd.data_ptr(), Y.data_ptr(), act, x0d.data_ptr(), k0, _C.ptr(x1d), k1, _C.ptr(md),
                                       scale, M, N, dW2.data_ptr(), db.data_ptr(), ws.data_ptr(), ws.numel(), st), "bwd_w")
     assert torch.equal(dW, dW2)
+
+
+@pytest.mark.parametrize("M,N,act", [(32, 8, 2), (128, 64, 1), (300, 70, 2), (8192, 256, 2), (40000, 33, 0), (1, 5, 1)])
+def test_batchnorm_forward_and_backward_match_torch(M, N, act):
+    """Row-chunked BatchNorm1d (stats + apply launches) against nn.BatchNorm1d in training mode, including a
+    far-from-zero column mean (the Chan fold must not cancel) and the running statistics."""
+    _C = _lib()
+    lib = _C.lib()
+    g = torch.Generator().manual_seed(M * 7 + N)
+    Z = torch.randn(M, N, generator=g) * (torch.rand(N, generator=g) * 3 + 0.1) + torch.randn(N, generator=g) * 50
+    gamma = torch.rand(N, generator=g) + 0.5
+    beta = torch.randn(N, generator=g)
+    dY = torch.randn(M, N, generator=g)
+    bn = torch.nn.BatchNorm1d(N)
+    with torch.no_grad():
+        bn.weight.copy_(gamma)
+        bn.bias.copy_(beta)
+    if M > 1:
+        Zr = Z.clone().requires_grad_()
+        pre = bn(Zr)
+        Yr = ACTS[act](pre)
+        # an output within rounding of the activation's kink may take the other slope: no gradient through those
+        smooth = (pre.detach().abs() > 1e-4) if act in (1, 2) else torch.ones_like(dY, dtype=torch.bool)
+        assert smooth.float().mean() > 0.999
+        dY = dY * smooth
+        Yr.backward(dY)
+    dev = "cuda"
+    Zd, gd, bd, dYd = Z.to(dev), gamma.to(dev), beta.to(dev), dY.to(dev)
+    rm, rv = torch.zeros(N, device=dev), torch.ones(N, device=dev)
+    Y, xh, inv = torch.empty(M, N, device=dev), torch.empty(M, N, device=dev), torch.empty(N, device=dev)
+    ws = torch.empty(lib.fr_bn_workspace_bytes(M, N), dtype=torch.uint8, device=dev)
+    st = _C.current_stream()
+    _C.check(lib.fr_bn_fwd(Zd.data_ptr(), gd.data_ptr(), bd.data_ptr(), 1e-5, 0.1, rm.data_ptr(), rv.data_ptr(), M, N, act,
+                           Y.data_ptr(), xh.data_ptr(), inv.data_ptr(), ws.data_ptr(), ws.numel(), st), "bn_fwd")
+    if M == 1:      # torch refuses a single row in training mode; the kernel yields xhat = 0
+        assert torch.equal(xh.cpu(), torch.zeros(1, N))
+        return
+    torch.testing.assert_close(Y.cpu(), Yr.detach(), rtol=2e-4, atol=2e-4)
+    torch.testing.assert_close(rm.cpu(), bn.running_mean, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(rv.cpu(), bn.running_var, rtol=1e-4, atol=1e-6)
+    dZ, dg, db = torch.empty(M, N, device=dev), torch.empty(N, device=dev), torch.empty(N, device=dev)
+    _C.check(lib.fr_bn_bwd(dYd.data_ptr(), Y.data_ptr(), act, xh.data_ptr(), inv.data_ptr(), gd.data_ptr(), M, N,
+                           dZ.data_ptr(), dg.data_ptr(), db.data_ptr(), ws.data_ptr(), ws.numel(), st), "bn_bwd")
+    s = float(Zr.grad.abs().max())
+    torch.testing.assert_close(dZ.cpu(), Zr.grad, rtol=5e-4, atol=2e-4 * max(s, 1e-3))
+    torch.testing.assert_close(dg.cpu(), bn.weight.grad, rtol=5e-4, atol=1e-4 * max(1.0, float(bn.weight.grad.abs().max())))
+    torch.testing.assert_close(db.cpu(), bn.bias.grad, rtol=5e-4, atol=1e-4 * max(1.0, float(bn.bias.grad.abs().max())))
+
+
+@pytest.mark.parametrize("D", [8, 64, 128, 256, 100])
+def test_spmm_csr_matches_torch_sparse(D):
+    """fr_spmm_csr (vector-gather variants for D = 64/128/256, strided otherwise) against torch.sparse.mm, with rows
+    longer than one 64-nonzero batch and empty rows."""
+    import scipy.sparse as sp
+    _C = _lib()
+    lib = _C.lib()
+    rng = np.random.default_rng(D)
+    n = 500
+    dens = sp.random(n, n, density=0.05, random_state=3, format="lil", dtype=np.float32)
+    dens[7, :] = rng.random(n).astype(np.float32)          # a 500-nonzero row
+    dens[11, :] = 0                                        # an empty row
+    csr = dens.tocsr()
+    X = torch.from_numpy(rng.standard_normal((n, D)).astype(np.float32))
+    ref = torch.sparse.mm(torch.sparse_csr_tensor(torch.from_numpy(csr.indptr.astype(np.int64)),
+                                                  torch.from_numpy(csr.indices.astype(np.int64)),
+                                                  torch.from_numpy(csr.data), size=(n, n)), X)
+    dev = "cuda"
+    ip = torch.from_numpy(csr.indptr.astype(np.int64)).to(dev)
+    ci = torch.from_numpy(csr.indices.astype(np.int32)).to(dev)
+    va = torch.from_numpy(csr.data).to(dev)
+    Xd = X.to(dev)
+    Y = torch.empty(n, D, device=dev)
+    _C.check(lib.fr_spmm_csr(ip.data_ptr(), ci.data_ptr(), va.data_ptr(), Xd.data_ptr(), n, D, Y.data_ptr(),
+                             _C.current_stream()), "spmm")
+    torch.testing.assert_close(Y.cpu(), ref, rtol=1e-4, atol=1e-4)
