@@ -168,18 +168,49 @@ FR_API int fr_table_gather(const fr_table* t, const fr_adam* adam, const int64_t
  *                           embedding_dense_backward does), apply Adam step t->step, write the row back; plus the
  *                           sweeper slice.  Replaces loss.backward() on the embedding + optimizer.step().
  * `t->step` is the step being applied in both calls; M <= FR_SORT_MAX.
+ *
+ * Slot layout (chunk, stride) of idx / rows_out / rows / grad_rows: logical position j sits at
+ * (j / chunk) * stride + j % chunk  rows (ids) from the pointer; chunk = 0 is the dense [M, ...] layout.  With
+ * chunk = cap, stride = T*cap and pointers advanced by t*cap rows, table t of T works in place on a shared
+ * [G, T, cap, ...] all-to-all buffer (multi-GPU path), so the exchange needs no packing copies.
  */
 FR_API size_t fr_table_train_workspace_bytes(int64_t M, int32_t dim);
-FR_API int fr_table_gather_train(const fr_table* t, const fr_adam* adam, const int64_t* idx, int64_t M,
-                                 float* rows_out, void* ws, size_t ws_bytes, uint32_t* err_flag, void* stream);
-FR_API int fr_table_apply_grad(const fr_table* t, const fr_adam* adam, int64_t M, const float* rows,
-                               const float* grad_rows, int32_t sweep_period, void* ws, size_t ws_bytes, void* stream);
+FR_API int fr_table_gather_train(const fr_table* t, const fr_adam* adam, const int64_t* idx, int64_t M, int32_t chunk,
+                                 int32_t stride, float* rows_out, void* ws, size_t ws_bytes, uint32_t* err_flag,
+                                 void* stream);
+FR_API int fr_table_apply_grad(const fr_table* t, const fr_adam* adam, int64_t M, int32_t chunk, int32_t stride,
+                               const float* rows, const float* grad_rows, int32_t sweep_period, void* ws,
+                               size_t ws_bytes, void* stream);
+/* The same for TWO tables of equal dim and M in one launch each (one sort workgroup / one grid slice per table):
+ * the user and item table of a step.  ws_a != ws_b, each of fr_table_train_workspace_bytes(M, dim). */
+FR_API int fr_table_gather_train2(const fr_table* ta, const fr_table* tb, const fr_adam* adam, const int64_t* idx_a,
+                                  const int64_t* idx_b, int64_t M, int32_t chunk, int32_t stride, float* rows_a,
+                                  float* rows_b, void* ws_a, void* ws_b, size_t ws_bytes, uint32_t* err_flag,
+                                  void* stream);
+FR_API int fr_table_apply_grad2(const fr_table* ta, const fr_table* tb, const fr_adam* adam, int64_t M, int32_t chunk,
+                                int32_t stride, const float* rows_a, const float* grad_a, const float* rows_b,
+                                const float* grad_b, int32_t sweep_a, int32_t sweep_b, void* ws_a, void* ws_b,
+                                size_t ws_bytes, void* stream);
 
 /* ---- row-sharded tables (multi-GPU) -----------------------------------------------------
  * owner(row) = row mod G, local row = row div G.  All exchange buffers have the fixed shape [G, cap] slots so
- * that a step needs no host sync; -1 ids are padding (ignored by fr_sort_segments / fr_table_gather_train). */
-FR_API int fr_bucket_by_owner(const int64_t* idx, int64_t M, int32_t G, int32_t cap, int64_t* send_ids,
-                              int32_t* slot_of, int32_t* counts, uint32_t* err_flag, void* stream);
+ * that a step needs no host sync; -1 ids are padding (ignored by fr_sort_segments / fr_table_gather_train).
+ * fr_bucket_by_owner: stable partition of idx by owner; slot (o, k) = o*stride + offset + k is where the k-th id owned
+ * by rank o sits in send_ids and where its answer will sit in every reply buffer (slot_of[pos], -1 on overflow).
+ * stride = cap, offset = 0: a [G, cap] buffer of its own; stride = T*cap, offset = t*cap: list t of a shared
+ * [G, T, cap] buffer (one all-to-all for T id lists).
+ * aux (may be NULL): (min, max) of that float column over the M positions is written, as two floats, into the int64
+ * slot o*stride + aux_slot of every owner's chunk (a slot outside the id lists), so batch-wide extrema ride along
+ * with the id exchange (FOCF: the two sensitive-attribute values present in the global batch, focf.py:77-79). */
+FR_API int fr_bucket_by_owner(const int64_t* idx, int64_t M, int32_t G, int32_t cap, int32_t stride, int32_t offset,
+                              int64_t* send_ids, int32_t* slot_of, int32_t* counts, const float* aux, int32_t aux_slot,
+                              uint32_t* err_flag, void* stream);
+/* Two id lists of the same length in ONE launch (one workgroup each): list a at offset_a, list b at offset_b of the
+ * same [G, stride] buffer; counts = [2, G]; aux / aux_slot as above (computed by list b's workgroup). */
+FR_API int fr_bucket_pair_by_owner(const int64_t* idx_a, const int64_t* idx_b, int64_t M, int32_t G, int32_t cap,
+                                   int32_t stride, int32_t offset_a, int32_t offset_b, int64_t* send_ids,
+                                   int32_t* slot_a, int32_t* slot_b, int32_t* counts, const float* aux,
+                                   int32_t aux_slot, uint32_t* err_flag, void* stream);
 /* out[j,:] = src[slot_of[j],:]  (reply buffer in slot order -> batch order) */
 FR_API int fr_unbucket_rows(const float* src, const int32_t* slot_of, int64_t M, int32_t dim, float* out, void* stream);
 /* dst[slot_of[j],:] = scale[j] * src[j,:]  (batch order -> slot order; scale may be NULL; dst pre-zeroed) */
@@ -189,24 +220,40 @@ FR_API int fr_bucket_rows(const float* src, const float* scale, const int32_t* s
 /*
  * Row-sharded FOCF step (one rank's share of focf.py:152-169 on the GLOBAL batch = concatenation of all ranks'
  * batches).  Requester side works on the rows returned by the owners ([G*cap, dim] slot order):
- *   fr_focf_shard_score : pred, MSE part of dLoss/dpred (2(pred-r)/n_global), sum of squared errors, and the
- *                         (pred, rating, sst) records in item-slot order for the item owners   (rec = [3][n_slots])
+ *   fr_focf_shard_score : pred, MSE part of dLoss/dpred (2(pred-r)/n_global), sum of squared errors (sq_err_sum; NULL:
+ *                         only the (B+3)/4 per-workgroup partials in `scratch`, for fr_focf_shard_fair), and the
+ *                         (pred, rating, sst) records for the item owners: rec = [G, 3, cap], record of item slot
+ *                         s = o*slot_stride + slot_offset + k (as produced by fr_bucket_by_owner) at rec[o][0..2][k]
  *   fr_focf_shard_fair  : on the item OWNER, over the segments fr_table_gather_train left in the item table's
- *                         workspace: per-item group statistics of the received records -> fairness part of
- *                         dLoss/dpred per slot, NOT yet divided by K (sums[0] = sum of smooth-L1 terms; K = sum of
- *                         the owners' segment counts, known after an all-reduce)
- *   fr_focf_shard_grads : gradient rows c*ie / c*ue written in user-slot / item-slot order for the owners
+ *                         workspace: per-item group statistics of the received records ([G(src), 3, cap]) ->
+ *                         fairness part of dLoss/dpred per slot, NOT yet divided by K, into the reply buffer
+ *                         [G, cap + FR_SHARD_TAIL]; the tail of every chunk = (this owner's distinct items, its sum
+ *                         of smooth-L1 terms, this rank's sum of squared errors = sum of sq_part[0..n_sq_part), the
+ *                         partials fr_focf_shard_score left in its scratch), written by the last workgroup to
+ *                         arrive, so the scalars of the loss ride along with the reply exchange (no all-reduce).
+ *                         scratch: >= n_slots/64 + 32 floats, scratch[0] zero on first use (arrival ticket).
+ *                         minmax: mm_count (min, max) pairs, mm_stride floats apart (one per source rank, as
+ *                         delivered by fr_bucket_by_owner's aux slot), folded in the kernel
+ *   fr_focf_shard_grads : gradient rows c*ie / c*ue written at the user / item slots for the owners.  coef_slots =
+ *                         the RECEIVED reply buffer (NULL for fair_objective none): K, fairness sum and squared-error
+ *                         sum are folded over its G tails in rank order (identical on every rank) and
+ *                         loss_out[0..2] = loss, mse, fair is written (may be NULL)
+ * rows_u / rows_i / grad_*_slots are addressed by slot, so both may point at one shared [G, 2, cap, dim] buffer.
  */
+#define FR_SHARD_TAIL 3
 FR_API int fr_focf_shard_score(const float* rows_u, const float* rows_i, const int32_t* slot_u, const int32_t* slot_i,
                                const float* rating, const float* sst, int64_t B, int32_t dim, int64_t n_global,
-                               float* pred, float* coef, float* rec, int64_t n_slots, float* sq_err_sum,
-                               float* scratch, void* stream);
+                               float* pred, float* coef, float* rec, int32_t cap, int32_t slot_stride,
+                               int32_t slot_offset, float* sq_err_sum, float* scratch, void* stream);
 FR_API int fr_focf_shard_fair(void* item_ws, size_t ws_bytes, int64_t n_slots, int32_t dim, const float* rec,
-                              const float* minmax, int32_t objective, float fair_weight, float* coef_slots,
-                              float* sums, float* scratch, uint32_t* err_flag, void* stream);
+                              int32_t cap, const float* minmax, int32_t mm_count, int32_t mm_stride, int32_t objective,
+                              float fair_weight, float* reply, const float* sq_part, int32_t n_sq_part, float* scratch,
+                              uint32_t* err_flag, void* stream);
 FR_API int fr_focf_shard_grads(const float* rows_u, const float* rows_i, const int32_t* slot_u, const int32_t* slot_i,
-                               const float* coef, const float* coef_slots, const float* inv_k, int64_t B, int32_t dim,
-                               float* grad_u_slots, float* grad_i_slots, void* stream);
+                               const float* coef, const float* coef_slots, int32_t G, int64_t n_global,
+                               float fair_weight, float* loss_out, int32_t cap, int32_t slot_stride,
+                               int32_t slot_offset, int64_t B, int32_t dim, float* grad_u_slots, float* grad_i_slots,
+                               void* stream);
 
 /* ---- dense layers (fp32 MFMA) ---------------------------------------------------------------------------
  * One layer of recbole/model/layers.py MLPLayers (:62-72): Dropout -> Linear -> activation, forward and backward.

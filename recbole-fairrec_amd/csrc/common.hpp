@@ -54,6 +54,16 @@ __device__ __forceinline__ float group_sum(float x) {  // sum over aligned group
 
 __device__ __forceinline__ int uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
 
+// Slot layout of an exchange buffer (fairrec_hip.h): logical row j sits at (j / chunk) * stride + j % chunk rows
+// from the pointer; chunk == 0 is the dense layout.  Lets several tables share one [G, T, cap, ...] all-to-all
+// buffer without copies.
+struct Lay {
+    int chunk, stride;
+    __host__ __device__ __forceinline__ long long at(long long j) const {
+        return chunk ? (j / chunk) * (long long)stride + (j % chunk) : j;
+    }
+};
+
 // Adam constants in the form the kernels consume.
 struct AdamC {
     const float2* sc;  // per-step (step_size, 1/sqrt(bias_correction2)); entry 0 unused

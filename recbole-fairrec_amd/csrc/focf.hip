@@ -166,9 +166,12 @@ __device__ __forceinline__ float smooth_l1(float x) {  // F.smooth_l1_loss(|x|, 
 // members are exchange-buffer slots on the item's owner rank and `pred/rating/sst` are the received records.
 struct FairArgs {
     const int32_t *perm, *seg_start, *nseg;
-    const float* minmax;       // [2] min / max of the sst column over the (global) batch
+    const float* minmax;       // (min, max) of the sst column; sharded: one pair per source rank, mm_stride floats
+    int mm_count, mm_stride;   //   apart (they arrive with the id exchange), folded here over the global batch
     const float *pred, *rating, *sst;
+    Lay mlay;                  // layout of the three member columns (sharded: planes of a [G, 3, cap] record buffer)
     float* coef;               // dLoss/dpred of every member
+    Lay clay;                  // its layout (sharded: [G, cap + 3] reply buffer)
     float* fair_part;          // [gridDim.x] partial sums of the smooth-L1 terms
     int accumulate;            // 1: coef[b] += g, 0: coef[b] = g
     // optional in-launch finalisation by the last block to arrive (single-GPU path): loss = mse + fw * fair
@@ -176,6 +179,9 @@ struct FairArgs {
     const float* mse_part;     // [n_mse_part] partial sums of squared errors (written by an EARLIER launch)
     int n_mse_part, batch;
     float* loss_out;           // [3] loss, mse, fair
+    // sharded finalisation instead: tail of every destination's chunk of the reply buffer = (K_owner, fair_owner, sq_rank)
+    float* tails;              // reply + cap; nullptr = single-GPU finalisation into loss_out
+    int tail_count, tail_stride;
 };
 
 __global__ __launch_bounds__(FAIR_THREADS) void focf_fair_kernel(FairArgs w, int objective, float fair_weight,
@@ -184,7 +190,11 @@ __global__ __launch_bounds__(FAIR_THREADS) void focf_fair_kernel(FairArgs w, int
     const int gib = threadIdx.x / FAIR_GROUP;
     const int k = blockIdx.x * (FAIR_THREADS / FAIR_GROUP) + gib;
     const int K = w.nseg[0];
-    const float smin = w.minmax[0], smax = w.minmax[1];
+    float smin = w.minmax[0], smax = w.minmax[1];
+    for (int q = 1; q < w.mm_count; ++q) {
+        smin = fminf(smin, w.minmax[q * w.mm_stride]);
+        smax = fmaxf(smax, w.minmax[q * w.mm_stride + 1]);
+    }
     __shared__ float red[FAIR_THREADS / FAIR_GROUP];
     float term = 0.f;
     if (k < K) {
@@ -193,7 +203,8 @@ __global__ __launch_bounds__(FAIR_THREADS) void focf_fair_kernel(FairArgs w, int
         bool bad = false;
         for (int j = j0 + sub; j < j1; j += FAIR_GROUP) {
             const int b = w.perm[j];
-            const float s = w.sst[b], pr = w.pred[b], r = w.rating[b];
+            const long long bp = w.mlay.at(b);
+            const float s = w.sst[bp], pr = w.pred[bp], r = w.rating[bp];
             bad |= (s != smin && s != smax);
             if (s == smin) {
                 sp0 += pr; st0 += r; n0 += 1.f;
@@ -230,8 +241,9 @@ __global__ __launch_bounds__(FAIR_THREADS) void focf_fair_kernel(FairArgs w, int
         const float g0 = dx * q0 / c0, g1 = -dx * q1 / c1;
         for (int j = j0 + sub; j < j1; j += FAIR_GROUP) {
             const int b = w.perm[j];
-            const float g = (w.sst[b] == smin) ? g0 : g1;
-            w.coef[b] = w.accumulate ? w.coef[b] + g : g;
+            const float g = (w.sst[w.mlay.at(b)] == smin) ? g0 : g1;
+            const long long cp = w.clay.at(b);
+            w.coef[cp] = w.accumulate ? w.coef[cp] + g : g;
         }
     }
     if (sub == 0) red[gib] = term;
@@ -277,11 +289,20 @@ __global__ __launch_bounds__(FAIR_THREADS) void focf_fair_kernel(FairArgs w, int
             a += red2[0][q];
             fsum += red2[1][q];
         }
-        const float mse = a / (float)w.batch;
-        const float fair = fsum / (float)K;
-        w.loss_out[0] = mse + fair_weight * fair;
-        w.loss_out[1] = mse;
-        w.loss_out[2] = fair;
+        if (w.tails) {
+            for (int g = 0; g < w.tail_count; ++g) {
+                float* t = w.tails + (size_t)g * w.tail_stride;
+                t[0] = (float)K;
+                t[1] = fsum;
+                t[2] = a;
+            }
+        } else {
+            const float mse = a / (float)w.batch;
+            const float fair = fsum / (float)K;
+            w.loss_out[0] = mse + fair_weight * fair;
+            w.loss_out[1] = mse;
+            w.loss_out[2] = fair;
+        }
         *w.ticket = 0u;
     }
 }
@@ -389,7 +410,8 @@ __global__ __launch_bounds__(256) void focf_shard_score_kernel(const float* __re
                                                                const float* __restrict__ sst, int B, int D,
                                                                float inv_n, float* __restrict__ pred,
                                                                float* __restrict__ coef, float* __restrict__ rec,
-                                                               long long n_slots, float* __restrict__ part) {
+                                                               int cap, int slot_stride, int slot_offset,
+                                                               float* __restrict__ part) {
     const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
     const int b = blockIdx.x * 4 + wib;
     __shared__ float red[4];
@@ -406,10 +428,11 @@ __global__ __launch_bounds__(256) void focf_shard_score_kernel(const float* __re
         if (lane == 0) {
             pred[b] = dot;
             coef[b] = 2.f * er * inv_n;
-            if (rec && si >= 0) {
-                rec[si] = dot;
-                rec[n_slots + si] = r;
-                rec[2 * n_slots + si] = sst ? sst[b] : 0.f;
+            if (rec && si >= 0) {   // item slot (g, k) -> planes of the [G, 3, cap] record buffer
+                float* rg = rec + (size_t)(si / slot_stride) * 3 * cap + (si % slot_stride - slot_offset);
+                rg[0] = dot;
+                rg[cap] = r;
+                rg[2 * cap] = sst ? sst[b] : 0.f;
             }
         }
     }
@@ -440,15 +463,37 @@ __global__ __launch_bounds__(256) void focf_shard_grads_kernel(const float* __re
                                                                const int32_t* __restrict__ slot_i,
                                                                const float* __restrict__ coef,
                                                                const float* __restrict__ coef_slots,
-                                                               const float* __restrict__ inv_k, int B, int D,
+                                                               int G, float inv_n, float fair_weight,
+                                                               float* __restrict__ loss_out, int cap,
+                                                               int slot_stride, int slot_offset, int B, int D,
                                                                float* __restrict__ grad_u, float* __restrict__ grad_i) {
     const int lane = threadIdx.x & 63;
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    // K, fairness sum and squared-error sum of the GLOBAL batch from the tails of the received reply chunks, owners
+    // in rank order (so every rank and every wave gets the same bits); wave 0 also reports the loss
+    float K = 1.f;
+    if (coef_slots) {
+        float fs = 0.f, sq = 0.f;
+        K = 0.f;
+        for (int g = 0; g < G; ++g) {
+            const float* t = coef_slots + (size_t)g * (cap + FR_SHARD_TAIL) + cap;
+            K += t[0];
+            fs += t[1];
+            sq += t[2];
+        }
+        if (b == 0 && lane == 0 && loss_out) {
+            const float mse = sq * inv_n, fair = fs / K;
+            loss_out[0] = mse + fair_weight * fair;
+            loss_out[1] = mse;
+            loss_out[2] = fair;
+        }
+    }
     if (b >= B) return;
     const int su = uniform(slot_u[b]), si = uniform(slot_i[b]);
     if (su < 0 || si < 0) return;
     float c = coef[b];
-    if (coef_slots) c += coef_slots[si] * (inv_k ? inv_k[0] : 1.f);
+    if (coef_slots)   // the fairness part of the reply still lacks 1/K
+        c += coef_slots[(size_t)(si / slot_stride) * (cap + FR_SHARD_TAIL) + (si % slot_stride - slot_offset)] / K;
     for (int d = lane; d < D; d += 64) {
         const float ue = rows_u[(size_t)su * D + d], ie = rows_i[(size_t)si * D + d];
         grad_u[(size_t)su * D + d] = c * ie;   // product rounded once: the owner adds the rows of duplicates
@@ -540,7 +585,7 @@ extern "C" int fr_focf_forward(const fr_table* U, const fr_table* I, const fr_ad
     } else if (objective != FR_FOCF_NONE) {
         {
             ProfScope prof(K_FOCF_FAIR, stream);
-            FairArgs fa{w.perm_i, w.seg_start_i, w.nseg_i, w.sst_minmax, w.pred, rating, sst, w.coef, w.fair_part, 1,
+            FairArgs fa{w.perm_i, w.seg_start_i, w.nseg_i, w.sst_minmax, 1, 0, w.pred, rating, sst, Lay{0, 0}, w.coef, Lay{0, 0}, w.fair_part, 1,
                         w.ticket, w.mse_part, w.n_gather_blocks, (int)B, loss_out};
             FR_LAUNCH(prof, focf_fair_kernel, dim3(w.n_fair_blocks), dim3(FAIR_THREADS), 0, stream, fa, objective,
                                fair_weight, 0, err_flag);
@@ -607,61 +652,75 @@ extern "C" int fr_focf_predict(const fr_table* U, const fr_table* I, const fr_ad
 
 extern "C" int fr_focf_shard_score(const float* rows_u, const float* rows_i, const int32_t* slot_u,
                                    const int32_t* slot_i, const float* rating, const float* sst, int64_t B,
-                                   int32_t dim, int64_t n_global, float* pred, float* coef, float* rec,
-                                   int64_t n_slots, float* sq_err_sum, float* scratch, void* stream_) {
+                                   int32_t dim, int64_t n_global, float* pred, float* coef, float* rec, int32_t cap,
+                                   int32_t slot_stride, int32_t slot_offset, float* sq_err_sum, float* scratch,
+                                   void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    FR_CHECK_ARG(rows_u && rows_i && slot_u && slot_i && rating && pred && coef && sq_err_sum && scratch && B >= 1 &&
-                     dim >= 1 && n_global >= B,
+    FR_CHECK_ARG(rows_u && rows_i && slot_u && slot_i && rating && pred && coef && scratch && B >= 1 &&
+                     dim >= 1 && n_global >= B && cap >= 1 && slot_offset >= 0 && slot_stride >= slot_offset + cap,
                  "fr_focf_shard_score: bad argument");
     const int blocks = (int)((B + 3) / 4);
     {
         ProfScope prof(K_FOCF_SHARD_SCORE, stream);
         FR_LAUNCH(prof, focf_shard_score_kernel, dim3(blocks), dim3(256), 0, stream, rows_u, rows_i, slot_u, slot_i,
-                           rating, sst, (int)B, (int)dim, 1.f / (float)n_global, pred, coef, rec, (long long)n_slots,
-                           scratch);
+                           rating, sst, (int)B, (int)dim, 1.f / (float)n_global, pred, coef, rec, (int)cap,
+                           (int)slot_stride, (int)slot_offset, scratch);
     }
     FR_CHECK_LAUNCH();
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, stream, scratch, blocks, sq_err_sum,
-                       (const int32_t*)nullptr);
-    FR_CHECK_LAUNCH();
+    if (sq_err_sum) {   // NULL: the caller hands the (B+3)/4 partials in `scratch` to fr_focf_shard_fair instead
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, stream, scratch, blocks, sq_err_sum,
+                           (const int32_t*)nullptr);
+        FR_CHECK_LAUNCH();
+    }
     return FR_OK;
 }
 
 extern "C" int fr_focf_shard_fair(void* item_ws, size_t ws_bytes, int64_t n_slots, int32_t dim, const float* rec,
-                                  const float* minmax, int32_t objective, float fair_weight, float* coef_slots,
-                                  float* sums, float* scratch, uint32_t* err_flag, void* stream_) {
+                                  int32_t cap, const float* minmax, int32_t mm_count, int32_t mm_stride,
+                                  int32_t objective, float fair_weight, float* reply, const float* sq_part,
+                                  int32_t n_sq_part, float* scratch, uint32_t* err_flag, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    FR_CHECK_ARG(item_ws && rec && minmax && coef_slots && sums && scratch && n_slots >= 1, "fr_focf_shard_fair: bad argument");
+    FR_CHECK_ARG(item_ws && rec && minmax && reply && sq_part && n_sq_part >= 0 && scratch && n_slots >= 1 && cap >= 1 &&
+                     n_slots % cap == 0 && n_slots / cap <= 64 && mm_count >= 1, "fr_focf_shard_fair: bad argument");
     FR_CHECK_ARG(objective >= FR_FOCF_VALUE && objective <= FR_FOCF_OVER,
                  "fr_focf_shard_fair: objective %d has no per-item statistics", objective);
     TableWs tw = table_layout(item_ws, n_slots, dim);
     FR_CHECK_ARG(ws_bytes >= tw.bytes, "fr_focf_shard_fair: workspace too small");
+    {
+        int rc = side_join(item_ws, stream);
+        if (rc) return rc;
+    }
     const int blocks = (int)((n_slots * FAIR_GROUP + FAIR_THREADS - 1) / FAIR_THREADS);
-    FR_CHECK_HIP(hipMemsetAsync(coef_slots, 0, (size_t)n_slots * 4, stream));
     {
         ProfScope prof(K_FOCF_FAIR, stream);
-        FairArgs fa{tw.perm, tw.seg_start, tw.nseg, minmax, rec, rec + n_slots, rec + 2 * n_slots, coef_slots, scratch, 0,
-                    nullptr, nullptr, 0, 0, nullptr};
+        // records of slot (g, k): planes rec[g][0..2][k]; padding slots are in no segment, so never read or written.
+        // scratch[0] is the arrival ticket (zero between launches), partials follow; the last block to arrive writes
+        // the tails (K_owner, fair_owner, sum of the sq_part partials) of all destination chunks
+        FairArgs fa{tw.perm, tw.seg_start, tw.nseg, minmax, (int)mm_count, (int)mm_stride, rec, rec + cap, rec + 2 * cap,
+                    Lay{cap, 3 * cap}, reply, Lay{cap, cap + FR_SHARD_TAIL}, scratch + 16, 0,
+                    reinterpret_cast<unsigned int*>(scratch), sq_part, (int)n_sq_part, 0, nullptr,
+                    reply + cap, (int)(n_slots / cap), cap + FR_SHARD_TAIL};
         FR_LAUNCH(prof, focf_fair_kernel, dim3(blocks), dim3(FAIR_THREADS), 0, stream, fa, objective, fair_weight, 1,
                            err_flag);
     }
-    FR_CHECK_LAUNCH();
-    hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, stream, scratch, blocks, sums,
-                       (const int32_t*)tw.nseg);
     FR_CHECK_LAUNCH();
     return FR_OK;
 }
 
 extern "C" int fr_focf_shard_grads(const float* rows_u, const float* rows_i, const int32_t* slot_u,
-                                   const int32_t* slot_i, const float* coef, const float* coef_slots,
-                                   const float* inv_k, int64_t B, int32_t dim, float* grad_u_slots,
-                                   float* grad_i_slots, void* stream_) {
+                                   const int32_t* slot_i, const float* coef, const float* coef_slots, int32_t G,
+                                   int64_t n_global, float fair_weight, float* loss_out, int32_t cap,
+                                   int32_t slot_stride, int32_t slot_offset, int64_t B, int32_t dim,
+                                   float* grad_u_slots, float* grad_i_slots, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    FR_CHECK_ARG(rows_u && rows_i && slot_u && slot_i && coef && grad_u_slots && grad_i_slots && B >= 1 && dim >= 1,
+    FR_CHECK_ARG(rows_u && rows_i && slot_u && slot_i && coef && grad_u_slots && grad_i_slots && B >= 1 && dim >= 1 &&
+                     cap >= 1 && slot_offset >= 0 && slot_stride >= slot_offset + cap && G >= 1 && n_global >= 1,
                  "fr_focf_shard_grads: bad argument");
     ProfScope prof(K_FOCF_SHARD_GRADS, stream);
     FR_LAUNCH(prof, focf_shard_grads_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, stream, rows_u, rows_i,
-                       slot_u, slot_i, coef, coef_slots, inv_k, (int)B, (int)dim, grad_u_slots, grad_i_slots);
+                       slot_u, slot_i, coef, coef_slots, (int)G, 1.f / (float)n_global, fair_weight, loss_out, (int)cap,
+                       (int)slot_stride, (int)slot_offset, (int)B, (int)dim, grad_u_slots,
+                       grad_i_slots);
     FR_CHECK_LAUNCH();
     return FR_OK;
 }

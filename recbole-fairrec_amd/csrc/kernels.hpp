@@ -44,6 +44,13 @@ struct SideStream {
 };
 SideStream* side_stream();
 
+// Deferred join for work launched on the side stream on behalf of a workspace (the index sort of
+// fr_table_gather_train): side_mark(ws) records its completion, side_join(ws, stream) makes `stream` wait for it
+// (no-op when nothing is pending).  The consumers of the sort results (fr_table_apply_grad, fr_focf_shard_fair)
+// join; everything launched in between overlaps with the sort.
+int side_mark(const void* ws);
+int side_join(const void* ws, hipStream_t stream);
+
 struct SortJob {
     const int64_t* idx;
     int64_t n_rows;
@@ -54,6 +61,7 @@ struct SortJob {
     int32_t* n_seg;
     const float* aux;   // optional float column to min/max-reduce alongside (may be null)
     float* aux_minmax;  // [2]
+    Lay lay;            // layout of idx (zero-initialised = dense)
 };
 
 // Sort one (b == nullptr) or two index lists of the same length M in one launch (one workgroup each).

@@ -5,6 +5,10 @@
 #include <mutex>
 #include <vector>
 
+#include <unordered_map>
+#include <vector>
+#include <mutex>
+
 #include "common.hpp"
 #include "kernels.hpp"
 
@@ -92,6 +96,42 @@ SideStream* side_stream() {
             state = 1;
     }
     return state == 1 ? &ss : nullptr;
+}
+
+namespace {
+std::mutex g_side_mu;
+std::unordered_map<const void*, hipEvent_t> g_side_pending;
+std::vector<hipEvent_t> g_side_pool;
+}  // namespace
+
+int side_mark(const void* ws) {
+    SideStream* ss = side_stream();
+    if (!ss) return FR_OK;
+    std::lock_guard<std::mutex> lk(g_side_mu);
+    hipEvent_t ev;
+    auto it = g_side_pending.find(ws);
+    if (it != g_side_pending.end()) {
+        ev = it->second;   // a sort of the same workspace that nobody consumed: later work on the side stream follows it
+    } else if (!g_side_pool.empty()) {
+        ev = g_side_pool.back();
+        g_side_pool.pop_back();
+    } else {
+        FR_CHECK_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    }
+    g_side_pending[ws] = ev;
+    FR_CHECK_HIP(hipEventRecord(ev, ss->stream));
+    return FR_OK;
+}
+
+int side_join(const void* ws, hipStream_t stream) {
+    std::lock_guard<std::mutex> lk(g_side_mu);
+    auto it = g_side_pending.find(ws);
+    if (it == g_side_pending.end()) return FR_OK;
+    hipEvent_t ev = it->second;
+    g_side_pending.erase(it);
+    g_side_pool.push_back(ev);
+    FR_CHECK_HIP(hipStreamWaitEvent(stream, ev, 0));
+    return FR_OK;
 }
 }  // namespace fr
 

@@ -11,22 +11,25 @@ namespace fr {
 
 static constexpr int BUCKET_THREADS = 1024;
 static constexpr int MAX_OWNERS = 16;
+static constexpr int BUCKET_STAGE_MAX = 16384;   // id lists / slot counts up to this length are staged in LDS (64 KB)
+static constexpr size_t BUCKET_LDS_MAX = 160 * 1024;
 
-__device__ __forceinline__ int bucket_scan_1024(int x, int* scratch, int& total) {
+template <typename T>
+__device__ __forceinline__ T bucket_scan_1024(T x, T* scratch, T& total) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    int inc = x;
+    T inc = x;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
-        int y = __shfl_up(inc, o, 64);
+        T y = __shfl_up(inc, o, 64);
         if (lane >= o) inc += y;
     }
     __syncthreads();   // scratch may still be read by the previous call
     if (lane == 63) scratch[wid] = inc;
     __syncthreads();
-    int woff = 0, tot = 0;
+    T woff = 0, tot = 0;
 #pragma unroll
     for (int w = 0; w < 16; ++w) {
-        const int v = scratch[w];
+        const T v = scratch[w];
         woff += w < wid ? v : 0;
         tot += v;
     }
@@ -34,55 +37,177 @@ __device__ __forceinline__ int bucket_scan_1024(int x, int* scratch, int& total)
     return woff + inc - x;
 }
 
-// Stable partition of the batch positions by owner rank.
-//   send_ids[o*cap + k] = local row (idx div G) of the k-th position whose owner is o, -1 beyond the bucket's fill
-//   slot_of[pos]        = o*cap + k  (where the answer for `pos` will sit in every [G, cap, ...] reply), -1 on overflow
+// Stable partition of the batch positions by owner rank.  Slot (o, k) of this id list sits at o*stride + offset + k of
+// the exchange buffers (stride = cap, offset = 0: a [G, cap] buffer of its own; stride = T*cap, offset = t*cap: list t
+// of a shared [G, T, cap] buffer).
+//   send_ids[slot(o,k)] = local row (idx div G) of the k-th position whose owner is o, -1 beyond the bucket's fill
+//   slot_of[pos]        = slot(o,k)  (where the answer for `pos` will sit in every reply buffer), -1 on overflow
 //   counts[o]           = bucket fill
-__global__ __launch_bounds__(BUCKET_THREADS) void bucket_by_owner_kernel(const int64_t* __restrict__ idx, int M, int G,
-                                                                         int cap, int64_t* __restrict__ send_ids,
-                                                                         int32_t* __restrict__ slot_of,
-                                                                         int32_t* __restrict__ counts, uint32_t* err) {
+// aux != nullptr: (min, max) of the float column aux[0..M) is written, as two floats, into the int64 slot
+// o*stride + aux_slot of every owner's chunk, so the batch-wide extrema ride along with the id exchange.
+struct BucketJob {
+    const int64_t* idx;
+    int offset;          // first slot of this list inside every owner's chunk
+    int32_t* slot_of;
+    int32_t* counts;
+    const float* aux;    // optional float column whose (min, max) goes to slot aux_slot of every chunk
+    int aux_slot;
+};
+
+// LDS plan of the bucket kernel (ints): cnt [G][1024] | scratch [64] | tot [16] | ids [M] (staged) | sendst [G*cap]
+// (staged send).  Staging keeps every global access coalesced: the id column is read once with unit stride, and
+// slot_of / send_ids are written with unit stride from LDS at the end (a thread's own range of positions is
+// contiguous, so direct stores would touch 64 cache lines per wave instruction).
+// positions per thread: the next power of two of ceil(M / 1024), so that position -> (thread, offset) is a shift/mask
+static __host__ __device__ inline int bucket_range(long long M) {
+    int c = 1;
+    while ((long long)c * BUCKET_THREADS < M) c <<= 1;
+    return c;
+}
+
+struct BucketPlan {
+    bool stage_ids, stage_send;
+    size_t lds_bytes;
+};
+
+static BucketPlan bucket_plan(int64_t M, int G, int cap) {
+    BucketPlan p;
+    size_t ints = (size_t)G * BUCKET_THREADS + 64 + 16;
+    p.stage_ids = M <= BUCKET_STAGE_MAX;
+    if (p.stage_ids) ints += (size_t)BUCKET_THREADS * (bucket_range(M) + 1);
+    p.stage_send = p.stage_ids && (size_t)G * cap <= BUCKET_STAGE_MAX && (ints + (size_t)G * cap) * 4 <= BUCKET_LDS_MAX;
+    if (p.stage_send) ints += (size_t)G * cap;
+    p.lds_bytes = ints * 4;
+    return p;
+}
+
+// One workgroup per id list (blockIdx.x).  Row ids are < 2^31 (checked by the table kernels), so owner and local row
+// come from 32-bit division.
+__global__ __launch_bounds__(BUCKET_THREADS) void bucket_by_owner_kernel(BucketJob j0, BucketJob j1, int M, int G,
+                                                                         int cap, int stride, int stage_ids,
+                                                                         int stage_send,
+                                                                         int64_t* __restrict__ send_ids,
+                                                                         uint32_t* err) {
     extern __shared__ __align__(16) unsigned char smem[];
+    const BucketJob job = blockIdx.x == 0 ? j0 : j1;
+    const int64_t* __restrict__ idx = job.idx;
+    const int offset = job.offset;
     int* cnt = reinterpret_cast<int*>(smem);            // [G][1024]
-    int* scratch = cnt + G * BUCKET_THREADS;            // [32]
+    int* scratch = cnt + G * BUCKET_THREADS;            // [64]
+    int* tot = scratch + 64;                            // [16] bucket fills
+    unsigned* ids = reinterpret_cast<unsigned*>(tot + 16);        // [M]: row ids, later the slots
     const int tid = threadIdx.x;
-    const int C = (M + BUCKET_THREADS - 1) / BUCKET_THREADS;
-    const int lo = tid * C, hi = min(lo + C, M);
+    const int C = bucket_range(M), logC = __ffs(C) - 1;
+    const int Cp = C + 1;   // odd stride between the threads' ranges in `ids`: no LDS bank conflicts in the range loops
+    unsigned* sendst = ids + (stage_ids ? BUCKET_THREADS * Cp : 0);   // [G*cap]: local rows in slot order
+    const int lo = min(tid * C, M), hi = min(lo + C, M);
+    auto pad = [&](int j) { return (j >> logC) * Cp + (j & (C - 1)); };
+    // owner / local row of a row id: shift and mask when G is a power of two (1, 2, 4, 8 GPUs)
+    const bool pow2 = (G & (G - 1)) == 0;
+    const int logG = __ffs(G) - 1;
+    auto owner = [&](unsigned r) { return pow2 ? (int)(r & (unsigned)(G - 1)) : (int)(r % (unsigned)G); };
+    auto local = [&](unsigned r) { return pow2 ? r >> logG : r / (unsigned)G; };
     for (int o = 0; o < G; ++o) cnt[o * BUCKET_THREADS + tid] = 0;
-    for (int j = tid; j < G * cap; j += BUCKET_THREADS) send_ids[j] = -1;
+    if (!stage_send)
+        for (int o = 0; o < G; ++o)
+            for (int k = tid; k < cap; k += BUCKET_THREADS) send_ids[o * stride + offset + k] = -1;
     bool bad = false;
-    for (int j = lo; j < hi; ++j) {
-        long long r = idx[j];
-        if (r < 0) {
-            bad = true;
-            r = 0;
+    if (stage_ids) {
+        for (int j = tid; j < M; j += BUCKET_THREADS) {
+            const long long r64 = idx[j];
+            const bool oob = r64 < 0 || r64 > 0x7fffffffll;
+            bad |= oob;
+            ids[pad(j)] = oob ? 0u : (unsigned)r64;
         }
-        cnt[(int)(r % G) * BUCKET_THREADS + tid] += 1;
+        __syncthreads();
     }
-    for (int o = 0; o < G; ++o) {
-        int total;
-        const int mine = cnt[o * BUCKET_THREADS + tid];
-        const int ex = bucket_scan_1024(mine, scratch, total);
-        cnt[o * BUCKET_THREADS + tid] = ex;
-        if (tid == 0) {
-            counts[o] = total < cap ? total : cap;
-            if (total > cap && err) atomicOr(err, FR_DEV_ERR_BUCKET_OVERFLOW);
+    auto id_at = [&](int j) -> unsigned {
+        if (stage_ids) return ids[tid * Cp + (j - lo)];
+        const long long r64 = idx[j];
+        const bool oob = r64 < 0 || r64 > 0x7fffffffll;
+        bad |= oob;
+        return oob ? 0u : (unsigned)r64;
+    };
+    for (int j = lo; j < hi; ++j) cnt[owner(id_at(j)) * BUCKET_THREADS + tid] += 1;
+    auto publish = [&](int o, int total) {
+        tot[o] = total < cap ? total : cap;
+        job.counts[o] = total < cap ? total : cap;
+        if (total > cap && err) atomicOr(err, FR_DEV_ERR_BUCKET_OVERFLOW);
+    };
+    if (stage_ids) {   // M <= 16384: four owners' counts share one 64-bit scan (16 bits each can not overflow)
+        for (int o4 = 0; o4 < G; o4 += 4) {
+            unsigned long long mine = 0;
+            for (int q = 0; q < 4 && o4 + q < G; ++q)
+                mine |= (unsigned long long)cnt[(o4 + q) * BUCKET_THREADS + tid] << (16 * q);
+            unsigned long long total;
+            const unsigned long long ex = bucket_scan_1024(mine, reinterpret_cast<unsigned long long*>(scratch), total);
+            for (int q = 0; q < 4 && o4 + q < G; ++q) {
+                cnt[(o4 + q) * BUCKET_THREADS + tid] = (int)((ex >> (16 * q)) & 0xffffu);
+                if (tid == 0) publish(o4 + q, (int)((total >> (16 * q)) & 0xffffu));
+            }
+        }
+    } else {
+        for (int o = 0; o < G; ++o) {
+            int total;
+            const int mine = cnt[o * BUCKET_THREADS + tid];
+            const int ex = bucket_scan_1024(mine, scratch, total);
+            cnt[o * BUCKET_THREADS + tid] = ex;
+            if (tid == 0) publish(o, total);
         }
     }
     __syncthreads();   // the -1 fill (other threads' stores) is complete before the real ids overwrite it
     for (int j = lo; j < hi; ++j) {
-        long long r = idx[j];
-        if (r < 0) r = 0;
-        const int o = (int)(r % G);
+        const unsigned r = id_at(j);
+        const int o = owner(r);
         const int k = cnt[o * BUCKET_THREADS + tid]++;
+        const int slot = k < cap ? o * stride + offset + k : -1;
         if (k < cap) {
-            send_ids[o * cap + k] = r / G;
-            slot_of[j] = o * cap + k;
-        } else {
-            slot_of[j] = -1;
+            if (stage_send) sendst[o * cap + k] = local(r);
+            else send_ids[o * stride + offset + k] = (long long)local(r);
         }
+        if (stage_ids) ids[tid * Cp + (j - lo)] = (unsigned)slot;
+        else job.slot_of[j] = slot;
+    }
+    if (stage_ids) {
+        __syncthreads();
+        for (int j = tid; j < M; j += BUCKET_THREADS) job.slot_of[j] = (int)ids[pad(j)];
+        if (stage_send)
+            for (int o = 0; o < G; ++o) {
+                const int fill = tot[o];
+                for (int k = tid; k < cap; k += BUCKET_THREADS)
+                    send_ids[o * stride + offset + k] = k < fill ? (long long)sendst[o * cap + k] : -1ll;
+            }
     }
     if (bad && err) atomicOr(err, FR_DEV_ERR_INDEX_RANGE);
+    if (job.aux) {
+        float lo_v = INFINITY, hi_v = -INFINITY;
+        for (int j = tid; j < M; j += BUCKET_THREADS) {
+            const float a = job.aux[j];
+            lo_v = fminf(lo_v, a);
+            hi_v = fmaxf(hi_v, a);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            lo_v = fminf(lo_v, __shfl_xor(lo_v, o, 64));
+            hi_v = fmaxf(hi_v, __shfl_xor(hi_v, o, 64));
+        }
+        float* fs = reinterpret_cast<float*>(scratch);
+        __syncthreads();
+        if ((tid & 63) == 0) {
+            fs[2 * (tid >> 6)] = lo_v;
+            fs[2 * (tid >> 6) + 1] = hi_v;
+        }
+        __syncthreads();
+        if (tid < G) {
+            for (int w = 0; w < BUCKET_THREADS / 64; ++w) {
+                lo_v = fminf(lo_v, fs[2 * w]);
+                hi_v = fmaxf(hi_v, fs[2 * w + 1]);
+            }
+            float* dst = reinterpret_cast<float*>(send_ids + (size_t)tid * stride + job.aux_slot);
+            dst[0] = lo_v;
+            dst[1] = hi_v;
+        }
+    }
 }
 
 // out[j, :] = slot >= 0 ? src[slot_of[j], :] : 0        (replies in [G*cap, D] slot order -> batch order)
@@ -114,24 +239,49 @@ __global__ __launch_bounds__(256) void bucket_rows_kernel(const float* __restric
 
 using namespace fr;
 
-extern "C" int fr_bucket_by_owner(const int64_t* idx, int64_t M, int32_t G, int32_t cap, int64_t* send_ids,
-                                  int32_t* slot_of, int32_t* counts, uint32_t* err_flag, void* stream_) {
-    FR_CHECK_ARG(idx && send_ids && slot_of && counts, "fr_bucket_by_owner: null pointer");
-    FR_CHECK_ARG(M >= 1 && M <= 65536 && G >= 1 && G <= MAX_OWNERS && cap >= 1, "fr_bucket_by_owner: bad size");
-    const size_t lds = ((size_t)G * BUCKET_THREADS + 64) * sizeof(int);
+static int launch_bucket(const BucketJob& a, const BucketJob* b, int64_t M, int32_t G, int32_t cap, int32_t stride,
+                         int64_t* send_ids, uint32_t* err_flag, hipStream_t stream) {
+    const BucketPlan plan = bucket_plan(M, G, cap);
     static bool attr_set = false;
     if (!attr_set) {
         FR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(bucket_by_owner_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         (int)(((size_t)MAX_OWNERS * BUCKET_THREADS + 64) * sizeof(int))));
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)BUCKET_LDS_MAX));
         attr_set = true;
     }
-    hipStream_t stream = (hipStream_t)stream_;
     ProfScope prof(K_BUCKET, stream);
-    FR_LAUNCH(prof, bucket_by_owner_kernel, dim3(1), dim3(BUCKET_THREADS), lds, stream, idx, (int)M, (int)G,
-                       (int)cap, send_ids, slot_of, counts, err_flag);
+    FR_LAUNCH(prof, bucket_by_owner_kernel, dim3(b ? 2 : 1), dim3(BUCKET_THREADS), plan.lds_bytes, stream, a, b ? *b : a,
+              (int)M, (int)G, (int)cap, (int)stride, (int)plan.stage_ids, (int)plan.stage_send, send_ids, err_flag);
     FR_CHECK_LAUNCH();
     return FR_OK;
+}
+
+static bool bucket_args_ok(int64_t M, int32_t G, int32_t cap, int32_t stride, int32_t offset, const float* aux,
+                           int32_t aux_slot) {
+    return M >= 1 && M <= 65536 && G >= 1 && G <= MAX_OWNERS && cap >= 1 && offset >= 0 && stride >= offset + cap &&
+           (!aux || (aux_slot >= 0 && aux_slot < stride && (aux_slot < offset || aux_slot >= offset + cap)));
+}
+
+extern "C" int fr_bucket_by_owner(const int64_t* idx, int64_t M, int32_t G, int32_t cap, int32_t stride, int32_t offset,
+                                  int64_t* send_ids, int32_t* slot_of, int32_t* counts, const float* aux,
+                                  int32_t aux_slot, uint32_t* err_flag, void* stream_) {
+    FR_CHECK_ARG(idx && send_ids && slot_of && counts, "fr_bucket_by_owner: null pointer");
+    FR_CHECK_ARG(bucket_args_ok(M, G, cap, stride, offset, aux, aux_slot), "fr_bucket_by_owner: bad size / slot");
+    BucketJob a{idx, offset, slot_of, counts, aux, aux_slot};
+    return launch_bucket(a, nullptr, M, G, cap, stride, send_ids, err_flag, (hipStream_t)stream_);
+}
+
+extern "C" int fr_bucket_pair_by_owner(const int64_t* idx_a, const int64_t* idx_b, int64_t M, int32_t G, int32_t cap,
+                                       int32_t stride, int32_t offset_a, int32_t offset_b, int64_t* send_ids,
+                                       int32_t* slot_a, int32_t* slot_b, int32_t* counts, const float* aux,
+                                       int32_t aux_slot, uint32_t* err_flag, void* stream_) {
+    FR_CHECK_ARG(idx_a && idx_b && send_ids && slot_a && slot_b && counts, "fr_bucket_pair_by_owner: null pointer");
+    FR_CHECK_ARG(bucket_args_ok(M, G, cap, stride, offset_a, aux, aux_slot) &&
+                     bucket_args_ok(M, G, cap, stride, offset_b, aux, aux_slot) &&
+                     (offset_a + cap <= offset_b || offset_b + cap <= offset_a),
+                 "fr_bucket_pair_by_owner: bad size / overlapping lists");
+    BucketJob a{idx_a, offset_a, slot_a, counts, nullptr, 0};
+    BucketJob b{idx_b, offset_b, slot_b, counts + G, aux, aux_slot};
+    return launch_bucket(a, &b, M, G, cap, stride, send_ids, err_flag, (hipStream_t)stream_);
 }
 
 extern "C" int fr_unbucket_rows(const float* src, const int32_t* slot_of, int64_t M, int32_t dim, float* out,

@@ -77,7 +77,7 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_segments_kernel(SortJob job
     for (int j = tid; j < P; j += SORT_THREADS) {
         unsigned long long k = ~0ull;
         if (j < M) {
-            long long r = job.idx[j];
+            long long r = job.idx[job.lay.at(j)];
             if (r == -1) {
                 r = 0xFFFFFFFFll;   // padding slot ("hole"): sorts behind every real row, belongs to no segment
             } else if (r < 0 || r >= job.n_rows) {

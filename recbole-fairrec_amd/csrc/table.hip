@@ -4,6 +4,8 @@
 //
 // Replaces: nn.Embedding forward (nfcf.py:70-71, pfcn_biasedmf.py:145-148), embedding_dense_backward and the
 // per-tensor torch.optim.Adam state/step (trainer.py:139,196).
+#include <algorithm>
+
 #include "common.hpp"
 #include "kernels.hpp"
 #include "table.hpp"
@@ -59,22 +61,31 @@ __global__ __launch_bounds__(256) void adam_dense_kernel(float* __restrict__ p, 
 
 
 // ------------------------------------------------------------------------------------------------
-// generic training pair
+// generic training pair (one or two tables per launch: blockIdx.y selects the table)
 // ------------------------------------------------------------------------------------------------
+struct GatherJob {
+    TableV T;
+    const int64_t* idx;
+    float* rows_out;
+    TableWs w;
+};
+
 template <int E>
-__global__ __launch_bounds__(256) void table_gather_train_kernel(TableV T, AdamC c, const int64_t* __restrict__ idx,
-                                                                 long long M, float* __restrict__ rows_out, TableWs w,
-                                                                 uint32_t* err) {
+__global__ __launch_bounds__(256) void table_gather_train_kernel(GatherJob ja, GatherJob jb, AdamC c, long long M,
+                                                                 Lay lay, uint32_t* err) {
+    const GatherJob& J = blockIdx.y == 0 ? ja : jb;
+    const TableV& T = J.T;
     const int lane = threadIdx.x & 63;
     const long long j = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (j >= M) return;
-    long long r = idx[j];
+    const long long jp = lay.at(j);          // where logical position j sits in idx / rows_out
+    long long r = J.idx[jp];
     const int D = T.D;
     if (r == -1) {   // padding slot of a fixed-capacity exchange buffer: no row, zero output
         RowFrag<E> z;
 #pragma unroll
         for (int e = 0; e < E; ++e) z.x[e] = 0.f;
-        store_row<E>(z, rows_out + (size_t)j * D, D, lane);
+        store_row<E>(z, J.rows_out + (size_t)jp * D, D, lane);
         return;
     }
     if (r < 0 || r >= T.n_rows) {
@@ -88,27 +99,34 @@ __global__ __launch_bounds__(256) void table_gather_train_kernel(TableV T, AdamC
     load_row<E>(m, T.m + (size_t)row * D, D, lane);
     load_row<E>(v, T.v + (size_t)row * D, D, lane);
     replay<E>(p, m, v, t0, T.step - 1, c, lane);
-    store_row<E>(p, rows_out + (size_t)j * D, D, lane);
-    store_row<E>(m, w.m_side + (size_t)j * D, D, lane);
-    store_row<E>(v, w.v_side + (size_t)j * D, D, lane);
+    store_row<E>(p, J.rows_out + (size_t)jp * D, D, lane);
+    store_row<E>(m, J.w.m_side + (size_t)j * D, D, lane);
+    store_row<E>(v, J.w.v_side + (size_t)j * D, D, lane);
     if (lane == 0) T.stamp[row] = T.step;
 }
 
+struct ApplyJob {
+    TableV T;
+    TableWs w;
+    const float* rows;
+    const float* grad_rows;
+    long long sw_lo;
+    int sw_n;
+};
+
 template <int E>
-__global__ __launch_bounds__(256) void table_apply_grad_kernel(TableV T, AdamC c, long long M, TableWs w,
-                                                               const float* __restrict__ rows,
-                                                               const float* __restrict__ grad_rows, long long sw_lo,
-                                                               int sw_n) {
+__global__ __launch_bounds__(256) void table_apply_grad_kernel(ApplyJob ja, ApplyJob jb, AdamC c, long long M, Lay lay) {
+    const ApplyJob& J = blockIdx.y == 0 ? ja : jb;
     const int lane = threadIdx.x & 63;
     long long wv = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (wv < sw_n) {   // longest jobs first
-        sweep_row<E>(T, c, sw_lo + wv, T.step, true, lane);
+    if (wv < J.sw_n) {   // longest jobs first
+        sweep_row<E>(J.T, c, J.sw_lo + wv, J.T.step, true, lane);
         return;
     }
-    wv -= sw_n;
-    if (wv < M && wv < w.nseg[0])
-        segment_update<E>(T, c, (int)wv, w.seg_start, w.seg_row, w.perm, nullptr, rows, w.m_side, w.v_side, grad_rows,
-                          lane);
+    wv -= J.sw_n;
+    if (wv < M && wv < J.w.nseg[0])
+        segment_update<E>(J.T, c, (int)wv, J.w.seg_start, J.w.seg_row, J.w.perm, nullptr, J.rows, J.w.m_side, J.w.v_side,
+                          J.grad_rows, lane, lay);
 }
 
 }  // namespace fr
@@ -169,56 +187,106 @@ extern "C" size_t fr_table_train_workspace_bytes(int64_t M, int32_t dim) {
     return table_layout(nullptr, M, dim).bytes;
 }
 
-extern "C" int fr_table_gather_train(const fr_table* t, const fr_adam* adam, const int64_t* idx, int64_t M,
-                                     float* rows_out, void* ws, size_t ws_bytes, uint32_t* err_flag, void* stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
+static inline bool lay_ok(int32_t chunk, int32_t stride) { return chunk == 0 || (chunk > 0 && stride >= chunk); }
+
+// one (tb == nullptr) or two tables of the same dim and M per call: one sort launch (a workgroup per table) on the
+// side stream, one gather launch
+static int gather_train_impl(const char* who, const fr_table* ta, const fr_table* tb, const fr_adam* adam,
+                             const int64_t* idx_a, const int64_t* idx_b, int64_t M, int32_t chunk, int32_t stride,
+                             float* rows_a, float* rows_b, void* ws_a, void* ws_b, size_t ws_bytes, uint32_t* err_flag,
+                             hipStream_t stream) {
     int rc;
-    if ((rc = check_table(t, "fr_table_gather_train")) || (rc = check_adam(adam, "fr_table_gather_train"))) return rc;
-    FR_CHECK_ARG(idx && rows_out && ws && M >= 1 && M <= FR_SORT_MAX && t->step >= 1,
-                 "fr_table_gather_train: bad argument (M=%lld, step=%d)", (long long)M, t->step);
-    TableWs w = table_layout(ws, M, t->dim);
-    FR_CHECK_ARG(ws_bytes >= w.bytes, "fr_table_gather_train: workspace %zu < %zu bytes", ws_bytes, w.bytes);
-    SortJob job{idx, t->n_rows, w.perm, w.seg_start, w.seg_row, nullptr, w.nseg, nullptr, nullptr};
+    if ((rc = check_table(ta, who)) || (tb && (rc = check_table(tb, who))) || (rc = check_adam(adam, who))) return rc;
+    FR_CHECK_ARG(idx_a && rows_a && ws_a && M >= 1 && M <= FR_SORT_MAX && ta->step >= 1 && lay_ok(chunk, stride),
+                 "%s: bad argument (M=%lld, step=%d)", who, (long long)M, ta->step);
+    FR_CHECK_ARG(!tb || (idx_b && rows_b && ws_b && ws_b != ws_a && tb->dim == ta->dim && tb->step >= 1),
+                 "%s: bad second table", who);
+    const Lay lay{chunk, stride};
+    TableWs wa = table_layout(ws_a, M, ta->dim);
+    TableWs wb = tb ? table_layout(ws_b, M, tb->dim) : wa;
+    FR_CHECK_ARG(ws_bytes >= wa.bytes, "%s: workspace %zu < %zu bytes", who, ws_bytes, wa.bytes);
+    SortJob sa{idx_a, ta->n_rows, wa.perm, wa.seg_start, wa.seg_row, nullptr, wa.nseg, nullptr, nullptr, lay};
+    SortJob sb{idx_b, tb ? tb->n_rows : 0, wb.perm, wb.seg_start, wb.seg_row, nullptr, wb.nseg, nullptr, nullptr, lay};
     SideStream* ss = side_stream();
     const bool overlap = ss != nullptr && !prof_on();
     if (overlap) {
         FR_CHECK_HIP(hipEventRecord(ss->fork, stream));
         FR_CHECK_HIP(hipStreamWaitEvent(ss->stream, ss->fork, 0));
-        if ((rc = launch_sort(job, nullptr, M, err_flag, ss->stream))) return rc;
-        FR_CHECK_HIP(hipEventRecord(ss->join, ss->stream));
-    } else if ((rc = launch_sort(job, nullptr, M, err_flag, stream))) {
+        if ((rc = launch_sort(sa, tb ? &sb : nullptr, M, err_flag, ss->stream))) return rc;
+        // joined by the first consumer of the segments (apply_grad / shard_fair)
+        if ((rc = side_mark(ws_a)) || (tb && (rc = side_mark(ws_b)))) return rc;
+    } else if ((rc = launch_sort(sa, tb ? &sb : nullptr, M, err_flag, stream))) {
         return rc;
     }
     const AdamC c = make_adamc(adam);
-    const TableV Tv = view(t);
+    GatherJob ja{view(ta), idx_a, rows_a, wa};
+    GatherJob jb = tb ? GatherJob{view(tb), idx_b, rows_b, wb} : ja;
     {
         ProfScope prof(K_TABLE_GATHER_TRAIN, stream);
-        FR_DISPATCH_E(t->dim, FR_LAUNCH(prof, (table_gather_train_kernel<E>), dim3((unsigned)((M + 3) / 4)), dim3(256), 0, stream, Tv, c, idx, (long long)M, rows_out, w, err_flag));
+        FR_DISPATCH_E(ta->dim, FR_LAUNCH(prof, (table_gather_train_kernel<E>), dim3((unsigned)((M + 3) / 4), tb ? 2 : 1), dim3(256), 0, stream, ja, jb, c, (long long)M, lay, err_flag));
     }
     FR_CHECK_LAUNCH();
-    if (overlap) FR_CHECK_HIP(hipStreamWaitEvent(stream, ss->join, 0));
     return FR_OK;
 }
 
-extern "C" int fr_table_apply_grad(const fr_table* t, const fr_adam* adam, int64_t M, const float* rows,
-                                   const float* grad_rows, int32_t sweep_period, void* ws, size_t ws_bytes,
-                                   void* stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
+extern "C" int fr_table_gather_train(const fr_table* t, const fr_adam* adam, const int64_t* idx, int64_t M,
+                                     int32_t chunk, int32_t stride, float* rows_out, void* ws, size_t ws_bytes,
+                                     uint32_t* err_flag, void* stream_) {
+    return gather_train_impl("fr_table_gather_train", t, nullptr, adam, idx, nullptr, M, chunk, stride, rows_out, nullptr,
+                             ws, nullptr, ws_bytes, err_flag, (hipStream_t)stream_);
+}
+
+extern "C" int fr_table_gather_train2(const fr_table* ta, const fr_table* tb, const fr_adam* adam, const int64_t* idx_a,
+                                      const int64_t* idx_b, int64_t M, int32_t chunk, int32_t stride, float* rows_a,
+                                      float* rows_b, void* ws_a, void* ws_b, size_t ws_bytes, uint32_t* err_flag,
+                                      void* stream_) {
+    FR_CHECK_ARG(tb, "fr_table_gather_train2: second table is null");
+    return gather_train_impl("fr_table_gather_train2", ta, tb, adam, idx_a, idx_b, M, chunk, stride, rows_a, rows_b, ws_a,
+                             ws_b, ws_bytes, err_flag, (hipStream_t)stream_);
+}
+
+static int apply_grad_impl(const char* who, const fr_table* ta, const fr_table* tb, const fr_adam* adam, int64_t M,
+                           int32_t chunk, int32_t stride, const float* rows_a, const float* grad_a, const float* rows_b,
+                           const float* grad_b, int32_t sweep_a, int32_t sweep_b, void* ws_a, void* ws_b, size_t ws_bytes,
+                           hipStream_t stream) {
     int rc;
-    if ((rc = check_table(t, "fr_table_apply_grad")) || (rc = check_adam(adam, "fr_table_apply_grad"))) return rc;
-    FR_CHECK_ARG(rows && grad_rows && ws && M >= 1 && M <= FR_SORT_MAX && t->step >= 1,
-                 "fr_table_apply_grad: bad argument");
-    TableWs w = table_layout(ws, M, t->dim);
-    FR_CHECK_ARG(ws_bytes >= w.bytes, "fr_table_apply_grad: workspace %zu < %zu bytes", ws_bytes, w.bytes);
-    long long lo, hi;
-    sweep_range(t->n_rows, t->step, sweep_period, lo, hi);
-    const long long waves = M + (hi - lo);
+    if ((rc = check_table(ta, who)) || (tb && (rc = check_table(tb, who))) || (rc = check_adam(adam, who))) return rc;
+    FR_CHECK_ARG(rows_a && grad_a && ws_a && M >= 1 && M <= FR_SORT_MAX && ta->step >= 1 && lay_ok(chunk, stride),
+                 "%s: bad argument", who);
+    FR_CHECK_ARG(!tb || (rows_b && grad_b && ws_b && ws_b != ws_a && tb->dim == ta->dim && tb->step >= 1),
+                 "%s: bad second table", who);
+    const Lay lay{chunk, stride};
+    TableWs wa = table_layout(ws_a, M, ta->dim);
+    TableWs wb = tb ? table_layout(ws_b, M, tb->dim) : wa;
+    FR_CHECK_ARG(ws_bytes >= wa.bytes, "%s: workspace %zu < %zu bytes", who, ws_bytes, wa.bytes);
+    if ((rc = side_join(ws_a, stream)) || (tb && (rc = side_join(ws_b, stream)))) return rc;
+    long long lo_a, hi_a, lo_b = 0, hi_b = 0;
+    sweep_range(ta->n_rows, ta->step, sweep_a, lo_a, hi_a);
+    if (tb) sweep_range(tb->n_rows, tb->step, sweep_b, lo_b, hi_b);
+    const long long waves = M + std::max(hi_a - lo_a, hi_b - lo_b);
     const AdamC c = make_adamc(adam);
-    const TableV Tv = view(t);
+    ApplyJob ja{view(ta), wa, rows_a, grad_a, lo_a, (int)(hi_a - lo_a)};
+    ApplyJob jb = tb ? ApplyJob{view(tb), wb, rows_b, grad_b, lo_b, (int)(hi_b - lo_b)} : ja;
     {
         ProfScope prof(K_TABLE_APPLY_GRAD, stream);
-        FR_DISPATCH_E(t->dim, FR_LAUNCH(prof, (table_apply_grad_kernel<E>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, stream, Tv, c, (long long)M, w, rows, grad_rows, lo, (int)(hi - lo)));
+        FR_DISPATCH_E(ta->dim, FR_LAUNCH(prof, (table_apply_grad_kernel<E>), dim3((unsigned)((waves + 3) / 4), tb ? 2 : 1), dim3(256), 0, stream, ja, jb, c, (long long)M, lay));
     }
     FR_CHECK_LAUNCH();
     return FR_OK;
+}
+
+extern "C" int fr_table_apply_grad(const fr_table* t, const fr_adam* adam, int64_t M, int32_t chunk, int32_t stride,
+                                   const float* rows, const float* grad_rows, int32_t sweep_period, void* ws,
+                                   size_t ws_bytes, void* stream_) {
+    return apply_grad_impl("fr_table_apply_grad", t, nullptr, adam, M, chunk, stride, rows, grad_rows, nullptr, nullptr,
+                           sweep_period, 0, ws, nullptr, ws_bytes, (hipStream_t)stream_);
+}
+
+extern "C" int fr_table_apply_grad2(const fr_table* ta, const fr_table* tb, const fr_adam* adam, int64_t M,
+                                    int32_t chunk, int32_t stride, const float* rows_a, const float* grad_a,
+                                    const float* rows_b, const float* grad_b, int32_t sweep_a, int32_t sweep_b,
+                                    void* ws_a, void* ws_b, size_t ws_bytes, void* stream_) {
+    FR_CHECK_ARG(tb, "fr_table_apply_grad2: second table is null");
+    return apply_grad_impl("fr_table_apply_grad2", ta, tb, adam, M, chunk, stride, rows_a, grad_a, rows_b, grad_b, sweep_a,
+                           sweep_b, ws_a, ws_b, ws_bytes, (hipStream_t)stream_);
 }

@@ -13,13 +13,13 @@ template <int E>
 __device__ __forceinline__ void segment_update(const TableV& T, const AdamC& c, int k, const int32_t* seg_start,
                                                const int32_t* seg_row, const int32_t* perm, const float* coef,
                                                const float* sp, const float* sm, const float* sv, const float* other,
-                                               int lane) {
+                                               int lane, Lay lay = Lay{0, 0}) {   // lay: layout of sp and other
     const int D = T.D;
     const int j0 = uniform(seg_start[k]), j1 = uniform(seg_start[k + 1]);
     const int row = uniform(seg_row[k]);
     const int b0 = uniform(perm[j0]);
     RowFrag<E> p, m, v, g;
-    load_row<E>(p, sp + (size_t)b0 * D, D, lane);
+    load_row<E>(p, sp + (size_t)lay.at(b0) * D, D, lane);
     load_row<E>(m, sm + (size_t)b0 * D, D, lane);
     load_row<E>(v, sv + (size_t)b0 * D, D, lane);
 #pragma unroll
@@ -28,7 +28,7 @@ __device__ __forceinline__ void segment_update(const TableV& T, const AdamC& c, 
         const int b = uniform(perm[j]);
         const float cb = coef ? coef[b] : 1.f;
         RowFrag<E> o;
-        load_row<E>(o, other + (size_t)b * D, D, lane);
+        load_row<E>(o, other + (size_t)lay.at(b) * D, D, lane);
         {
 #pragma clang fp contract(off)  // product rounded, then added: grad_row += coef * other_row (autograd order)
 #pragma unroll

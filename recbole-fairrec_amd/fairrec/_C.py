@@ -53,20 +53,30 @@ _PROTOS = {
     "fr_table_gather": (c_int, [POINTER(FrTable), POINTER(FrAdam), c_void_p, c_int64, c_void_p, c_void_p,
                                 c_void_p]),
     "fr_table_train_workspace_bytes": (c_size_t, [c_int64, c_int32]),
-    "fr_table_gather_train": (c_int, [POINTER(FrTable), POINTER(FrAdam), c_void_p, c_int64, c_void_p, c_void_p,
-                                      c_size_t, c_void_p, c_void_p]),
-    "fr_table_apply_grad": (c_int, [POINTER(FrTable), POINTER(FrAdam), c_int64, c_void_p, c_void_p, c_int32,
-                                    c_void_p, c_size_t, c_void_p]),
-    "fr_bucket_by_owner": (c_int, [c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p,
-                                   c_void_p]),
+    "fr_table_gather_train": (c_int, [POINTER(FrTable), POINTER(FrAdam), c_void_p, c_int64, c_int32, c_int32, c_void_p,
+                                      c_void_p, c_size_t, c_void_p, c_void_p]),
+    "fr_table_apply_grad": (c_int, [POINTER(FrTable), POINTER(FrAdam), c_int64, c_int32, c_int32, c_void_p, c_void_p,
+                                    c_int32, c_void_p, c_size_t, c_void_p]),
+    "fr_bucket_by_owner": (c_int, [c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
+                                   c_void_p, c_int32, c_void_p, c_void_p]),
+    "fr_bucket_pair_by_owner": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p,
+                                        c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p]),
     "fr_unbucket_rows": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p]),
     "fr_bucket_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p]),
     "fr_focf_shard_score": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32,
-                                    c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
-    "fr_focf_shard_fair": (c_int, [c_void_p, c_size_t, c_int64, c_int32, c_void_p, c_void_p, c_int32, c_float,
-                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
-    "fr_focf_shard_grads": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
-                                    c_int32, c_void_p, c_void_p, c_void_p]),
+                                    c_int64, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p,
+                                    c_void_p]),
+    "fr_focf_shard_fair": (c_int, [c_void_p, c_size_t, c_int64, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_int32,
+                                   c_int32, c_float, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p]),
+    "fr_focf_shard_grads": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_float,
+                                    c_void_p, c_int32, c_int32, c_int32, c_int64, c_int32, c_void_p, c_void_p,
+                                    c_void_p]),
+    "fr_table_gather_train2": (c_int, [POINTER(FrTable), POINTER(FrTable), POINTER(FrAdam), c_void_p, c_void_p, c_int64,
+                                       c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p,
+                                       c_void_p]),
+    "fr_table_apply_grad2": (c_int, [POINTER(FrTable), POINTER(FrTable), POINTER(FrAdam), c_int64, c_int32, c_int32,
+                                     c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p,
+                                     c_size_t, c_void_p]),
     "fr_linear_fwd": (c_int, [c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_float, c_void_p, c_void_p, c_int64,
                               c_int32, c_int32, c_void_p, c_void_p]),
     "fr_linear_bwd_input": (c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_float, c_int64, c_int32,

@@ -83,6 +83,7 @@ class LazyTable:
         self.m = self.v = self.last = self.stamp = None
         self._ws = None
         self._pending = None
+        self._keep = None
         self._grad_rows = None
         self._dirty = False      # some row may be behind `step` (set by an update, cleared by flush)
 
@@ -128,18 +129,26 @@ class LazyTable:
         `apply_grad` can finish the step."""
         idx = idx.contiguous()
         M = idx.numel()
+        rows = torch.empty((M, self.dim), dtype=torch.float32, device=self.weight.device)
+        self.gather_train_into(hyper, idx.data_ptr(), M, rows.data_ptr(), err_flag=err_flag)
+        self._pending = (M, rows)
+        self._keep = idx
+        return rows
+
+    def gather_train_into(self, hyper: AdamHyper, idx_ptr: int, M: int, rows_ptr: int, chunk: int = 0, stride: int = 0,
+                          err_flag: Optional[torch.Tensor] = None):
+        """The same on raw device pointers with a slot layout (fairrec_hip.h): M ids read from / M rows written into
+        exchange buffers in place.  The caller keeps the buffers alive until `apply_grad_from`."""
         need = _C.lib().fr_table_train_workspace_bytes(M, self.dim)
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.weight.device)
-        rows = torch.empty((M, self.dim), dtype=torch.float32, device=self.weight.device)
         t = self.c(self.step + 1)
         hyper.check_step(self.step + 1)
-        _C.check(_C.lib().fr_table_gather_train(ctypes.byref(t), ctypes.byref(hyper.c()), idx.data_ptr(), M,
-                                                rows.data_ptr(), self._ws.data_ptr(), self._ws.numel(),
-                                                _C.ptr(err_flag), _C.current_stream()), "fr_table_gather_train")
-        self._pending = (M, rows)
+        _C.check(_C.lib().fr_table_gather_train(ctypes.byref(t), ctypes.byref(hyper.c()), idx_ptr, M, chunk, stride,
+                                                rows_ptr, self._ws.data_ptr(), self._ws.numel(), _C.ptr(err_flag),
+                                                _C.current_stream()), "fr_table_gather_train")
+        self._pending = (M, None)
         self._grad_rows = None
-        return rows
 
     def apply_grad(self, hyper: AdamHyper, grad_rows: Optional[torch.Tensor] = None, sweep_period: int = 0):
         """fr_table_apply_grad: duplicate-summed gradient + Adam step `self.step + 1` + sweeper slice."""
@@ -151,14 +160,61 @@ class LazyTable:
             raise _C.FairrecError("no gradient reached the gathered rows (loss.backward() not called?)")
         g = g.contiguous()
         assert g.shape == rows.shape and g.dtype == torch.float32
+        self.apply_grad_from(hyper, M, rows.data_ptr(), g.data_ptr(), sweep_period)
+
+    def apply_grad_from(self, hyper: AdamHyper, M: int, rows_ptr: int, grad_ptr: int, sweep_period: int = 0,
+                        chunk: int = 0, stride: int = 0):
+        """fr_table_apply_grad on raw device pointers with a slot layout (the rows of the preceding
+        `gather_train_into` and the gradient rows that came back for them)."""
+        if self._pending is None or self._pending[0] != M:
+            raise _C.FairrecError("apply_grad without a matching gather_train")
         t = self.c(self.step + 1)
-        _C.check(_C.lib().fr_table_apply_grad(ctypes.byref(t), ctypes.byref(hyper.c()), M, rows.data_ptr(),
-                                              g.data_ptr(), int(sweep_period), self._ws.data_ptr(),
-                                              self._ws.numel(), _C.current_stream()), "fr_table_apply_grad")
+        _C.check(_C.lib().fr_table_apply_grad(ctypes.byref(t), ctypes.byref(hyper.c()), M, chunk, stride, rows_ptr,
+                                              grad_ptr, int(sweep_period), self._ws.data_ptr(), self._ws.numel(),
+                                              _C.current_stream()), "fr_table_apply_grad")
         self.step += 1
         self._dirty = True
         self._pending = None
         self._grad_rows = None
+        self._keep = None
+
+    # --- two tables of a step in one launch each (the user and item table of the row-sharded step) ------
+    @staticmethod
+    def gather_train_pair(ta: "LazyTable", tb: "LazyTable", hyper: AdamHyper, idx_a: int, idx_b: int, M: int, rows_a: int,
+                          rows_b: int, chunk: int = 0, stride: int = 0, err_flag: Optional[torch.Tensor] = None):
+        assert ta.dim == tb.dim and ta.step == tb.step
+        need = _C.lib().fr_table_train_workspace_bytes(M, ta.dim)
+        for t in (ta, tb):
+            if t._ws is None or t._ws.numel() < need:
+                t._ws = torch.empty(need, dtype=torch.uint8, device=t.weight.device)
+        hyper.check_step(ta.step + 1)
+        ca, cb = ta.c(ta.step + 1), tb.c(tb.step + 1)
+        _C.check(_C.lib().fr_table_gather_train2(ctypes.byref(ca), ctypes.byref(cb), ctypes.byref(hyper.c()), idx_a, idx_b,
+                                                 M, chunk, stride, rows_a, rows_b, ta._ws.data_ptr(), tb._ws.data_ptr(),
+                                                 min(ta._ws.numel(), tb._ws.numel()), _C.ptr(err_flag),
+                                                 _C.current_stream()), "fr_table_gather_train2")
+        for t in (ta, tb):
+            t._pending = (M, None)
+            t._grad_rows = None
+
+    @staticmethod
+    def apply_grad_pair(ta: "LazyTable", tb: "LazyTable", hyper: AdamHyper, M: int, rows_a: int, grad_a: int, rows_b: int,
+                        grad_b: int, sweep_a: int, sweep_b: int, chunk: int = 0, stride: int = 0):
+        for t in (ta, tb):
+            if t._pending is None or t._pending[0] != M:
+                raise _C.FairrecError("apply_grad without a matching gather_train")
+        ca, cb = ta.c(ta.step + 1), tb.c(tb.step + 1)
+        _C.check(_C.lib().fr_table_apply_grad2(ctypes.byref(ca), ctypes.byref(cb), ctypes.byref(hyper.c()), M, chunk,
+                                               stride, rows_a, grad_a, rows_b, grad_b, int(sweep_a), int(sweep_b),
+                                               ta._ws.data_ptr(), tb._ws.data_ptr(),
+                                               min(ta._ws.numel(), tb._ws.numel()), _C.current_stream()),
+                 "fr_table_apply_grad2")
+        for t in (ta, tb):
+            t.step += 1
+            t._dirty = True
+            t._pending = None
+            t._grad_rows = None
+            t._keep = None
 
     def default_sweep(self, M: int) -> int:
         return max(8, math.ceil(self.n_rows / max(M, 1)))

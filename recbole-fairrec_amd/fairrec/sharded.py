@@ -4,11 +4,23 @@ torch.distributed).
 Semantics: ONE optimizer step on the global batch = concatenation of every rank's local batch (rank order), i.e.
 exactly what the single-device reference computes on that batch: loss = MSE over G*B interactions +
 fair_weight * mean over the distinct items of the GLOBAL batch.  Tables are split by `row mod G`; Adam state
-lives with its rows.  Per step (no host sync, fixed-capacity [G, cap] buffers):
+lives with its rows.
 
-    bucket ids by owner -> all-to-all(ids) -> owners: lazy gather -> all-to-all(rows) -> score
-    -> all-to-all(records) -> owners: per-item fairness statistics -> all-reduce(3 scalars)
-    -> all-to-all(fairness coefficients) -> gradient rows -> all-to-all(grads) -> owners: duplicate-sum + Adam
+Per step, 5 all-to-alls on fixed-capacity buffers, no all-reduce, no host sync, no packing copies (the kernels read
+and write the exchange layouts in place, fairrec_hip.h "slot layout"):
+
+    ids    [G, 2*cap+1]      user ids | item ids | (min, max) of the local sensitive column
+    rows   [G, 2*cap+1, D]   owners: lazy gather of the requested rows, written in place
+    rec    [G, 3, cap]       (pred, rating, sst) of every interaction, to the item's owner
+    reply  [G, cap+3]        owners: fairness part of dLoss/dpred per record | (K_owner, fair_owner, sq_rank)
+    grads  [G, 2*cap+1, D]   gradient rows back to the owners -> duplicate-sum + Adam
+
+Launches per step: bucket (both id lists) | sort (both tables, side stream) + gather (both tables) | score | fair |
+grads (+ loss) | apply (both tables) = 7 kernels around the 5 collectives.
+
+The three scalars at the tail of every reply chunk give each rank K, the fairness sum and the squared-error sum of
+the global batch (summed in rank order, so identical everywhere).  fair_objective none needs no rec/reply; its
+loss takes one 1-float all-reduce.
 
 The kernels come from an `ops` object (default: the HIP library through fairrec._C).  Tests inject a CPU double
 to exercise this exchange schedule over gloo without a GPU; the product path is HIP only.
@@ -25,6 +37,9 @@ import torch.distributed as dist
 from . import _C
 from .optim import AdamHyper, LazyTable
 
+SORT_MAX = 16384      # FR_SORT_MAX: an owner sorts the G*cap ids it receives for one table in one workgroup
+TAIL = 3              # FR_SHARD_TAIL
+
 
 def shard_rows(n_rows: int, rank: int, world: int) -> int:
     """Number of rows r < n_rows with r mod world == rank."""
@@ -36,8 +51,15 @@ def shard_of(full: torch.Tensor, rank: int, world: int) -> torch.Tensor:
     return full[rank::world].contiguous()
 
 
+def exchange_capacity(B: int, G: int, capacity_factor: float) -> int:
+    """Slots per (requester, owner) pair: the mean fill B/G times `capacity_factor`, bounded by what one owner can
+    sort in one launch (G*cap <= FR_SORT_MAX)."""
+    return max(1, min(B, int(math.ceil(capacity_factor * B / G)) + 64, SORT_MAX // G))
+
+
 class HipOps:
-    """The kernels of the sharded step, bound to the HIP library."""
+    """The kernels of the sharded step, bound to the HIP library.  Buffers are flat tensors; `*_off` are element
+    (row) offsets into them."""
 
     def __init__(self, device):
         self.device = torch.device(device)
@@ -46,60 +68,86 @@ class HipOps:
     def make_table(self, weight):
         return LazyTable(weight)
 
-    def bucket_by_owner(self, idx, G, cap, err):
-        M = idx.numel()
-        send = torch.empty(G * cap, dtype=torch.int64, device=idx.device)
-        slot = torch.empty(M, dtype=torch.int32, device=idx.device)
-        counts = torch.empty(G, dtype=torch.int32, device=idx.device)
-        _C.check(_C.lib().fr_bucket_by_owner(idx.data_ptr(), M, G, cap, send.data_ptr(), slot.data_ptr(),
-                                             counts.data_ptr(), err.data_ptr(), _C.current_stream()), "fr_bucket_by_owner")
-        return send, slot, counts
+    def bucket_by_owner(self, idx, G, cap, stride, offset, send, slot, counts, aux, aux_slot, err):
+        _C.check(_C.lib().fr_bucket_by_owner(idx.data_ptr(), idx.numel(), G, cap, stride, offset, send.data_ptr(),
+                                             slot.data_ptr(), counts.data_ptr(), _C.ptr(aux), aux_slot, err.data_ptr(),
+                                             _C.current_stream()), "fr_bucket_by_owner")
 
-    def gather_train(self, table, hyper, ids, err):
-        return table.gather_train(hyper, ids, err)
+    def bucket_pair(self, idx_a, idx_b, G, cap, stride, off_a, off_b, send, slot_a, slot_b, counts, aux, aux_slot, err):
+        _C.check(_C.lib().fr_bucket_pair_by_owner(idx_a.data_ptr(), idx_b.data_ptr(), idx_a.numel(), G, cap, stride, off_a,
+                                                  off_b, send.data_ptr(), slot_a.data_ptr(), slot_b.data_ptr(),
+                                                  counts.data_ptr(), _C.ptr(aux), aux_slot, err.data_ptr(),
+                                                  _C.current_stream()), "fr_bucket_pair_by_owner")
 
-    def apply_grad(self, table, hyper, grads, sweep):
-        table.apply_grad(hyper, grads, sweep)
+    def gather_train_pair(self, ta, tb, hyper, ids, off_a, off_b, M, chunk, stride, rows, err):
+        D = ta.dim
+        LazyTable.gather_train_pair(ta, tb, hyper, ids.data_ptr() + 8 * off_a, ids.data_ptr() + 8 * off_b, M,
+                                    rows.data_ptr() + 4 * off_a * D, rows.data_ptr() + 4 * off_b * D, chunk, stride, err)
+
+    def apply_grad_pair(self, ta, tb, hyper, M, chunk, stride, rows, grads, off_a, off_b, sweep_a, sweep_b):
+        D = ta.dim
+        LazyTable.apply_grad_pair(ta, tb, hyper, M, rows.data_ptr() + 4 * off_a * D, grads.data_ptr() + 4 * off_a * D,
+                                  rows.data_ptr() + 4 * off_b * D, grads.data_ptr() + 4 * off_b * D, sweep_a, sweep_b,
+                                  chunk, stride)
 
     def flush(self, table, hyper):
         table.flush(hyper)
 
-    def shard_score(self, rows_u, rows_i, slot_u, slot_i, rating, sst, n_global, want_rec):
-        B, D = slot_u.numel(), rows_u.shape[1]
-        n_slots = rows_i.shape[0]
-        dev = rows_u.device
-        pred = torch.empty(B, dtype=torch.float32, device=dev)
-        coef = torch.empty(B, dtype=torch.float32, device=dev)
-        rec = torch.zeros((3, n_slots), dtype=torch.float32, device=dev) if want_rec else None
-        sq = torch.empty(1, dtype=torch.float32, device=dev)
-        scratch = torch.empty((B + 3) // 4 + 1, dtype=torch.float32, device=dev)
-        _C.check(_C.lib().fr_focf_shard_score(rows_u.data_ptr(), rows_i.data_ptr(), slot_u.data_ptr(), slot_i.data_ptr(),
+    def shard_score(self, rows, slot_u, slot_i, rating, sst, n_global, pred, coef, rec, cap, slot_stride, slot_offset,
+                    sq, sq_part):
+        """sq: [1] sum of squared errors, or None to leave only the per-workgroup partials in sq_part."""
+        B, D = slot_u.numel(), rows.shape[1]
+        _C.check(_C.lib().fr_focf_shard_score(rows.data_ptr(), rows.data_ptr(), slot_u.data_ptr(), slot_i.data_ptr(),
                                               rating.data_ptr(), _C.ptr(sst), B, D, n_global, pred.data_ptr(),
-                                              coef.data_ptr(), _C.ptr(rec), n_slots, sq.data_ptr(), scratch.data_ptr(),
-                                              _C.current_stream()), "fr_focf_shard_score")
-        return pred, coef, rec, sq
+                                              coef.data_ptr(), _C.ptr(rec), cap, slot_stride, slot_offset, _C.ptr(sq),
+                                              sq_part.data_ptr(), _C.current_stream()), "fr_focf_shard_score")
 
-    def shard_fair(self, item_table, rec, minmax, objective, fair_weight, err):
-        n_slots = rec.shape[1]
-        dev = rec.device
-        coef_slots = torch.empty(n_slots, dtype=torch.float32, device=dev)
-        sums = torch.zeros(2, dtype=torch.float32, device=dev)
-        scratch = torch.empty(n_slots // 16 + 2, dtype=torch.float32, device=dev)
+    def shard_fair(self, item_table, n_slots, rec, cap, ids_recv, mm_slot, stride, objective, fair_weight, reply,
+                   sq_part, n_sq_part, scratch, err):
         ws = item_table._ws
-        _C.check(_C.lib().fr_focf_shard_fair(ws.data_ptr(), ws.numel(), n_slots, item_table.dim, rec.data_ptr(),
-                                             minmax.data_ptr(), _C.FOCF_OBJECTIVES[objective], fair_weight,
-                                             coef_slots.data_ptr(), sums.data_ptr(), scratch.data_ptr(),
-                                             err.data_ptr(), _C.current_stream()), "fr_focf_shard_fair")
-        return coef_slots, sums
+        G = n_slots // cap
+        _C.check(_C.lib().fr_focf_shard_fair(ws.data_ptr(), ws.numel(), n_slots, item_table.dim, rec.data_ptr(), cap,
+                                             ids_recv.data_ptr() + 8 * mm_slot, G, 2 * stride,
+                                             _C.FOCF_OBJECTIVES[objective], fair_weight, reply.data_ptr(),
+                                             sq_part.data_ptr(), n_sq_part, scratch.data_ptr(), err.data_ptr(),
+                                             _C.current_stream()), "fr_focf_shard_fair")
 
-    def shard_grads(self, rows_u, rows_i, slot_u, slot_i, coef, coef_slots, inv_k):
-        B, D = slot_u.numel(), rows_u.shape[1]
-        gu = torch.empty_like(rows_u)
-        gi = torch.empty_like(rows_i)
-        _C.check(_C.lib().fr_focf_shard_grads(rows_u.data_ptr(), rows_i.data_ptr(), slot_u.data_ptr(), slot_i.data_ptr(),
-                                              coef.data_ptr(), _C.ptr(coef_slots), _C.ptr(inv_k), B, D, gu.data_ptr(),
-                                              gi.data_ptr(), _C.current_stream()), "fr_focf_shard_grads")
-        return gu, gi
+    def shard_grads(self, rows, slot_u, slot_i, coef, reply, G, n_global, fair_weight, loss_out, cap, slot_stride,
+                    slot_offset, grads):
+        B, D = slot_u.numel(), rows.shape[1]
+        _C.check(_C.lib().fr_focf_shard_grads(rows.data_ptr(), rows.data_ptr(), slot_u.data_ptr(), slot_i.data_ptr(),
+                                              coef.data_ptr(), _C.ptr(reply), G, n_global, fair_weight,
+                                              _C.ptr(loss_out), cap, slot_stride, slot_offset, B, D, grads.data_ptr(),
+                                              grads.data_ptr(), _C.current_stream()), "fr_focf_shard_grads")
+
+
+class _Buffers:
+    """Exchange and scratch buffers of one (B, cap, D) shape, allocated once (a captured step replays on them)."""
+
+    def __init__(self, G, B, cap, D, dev):
+        S = 2 * cap + 1
+        self.B, self.cap, self.S = B, cap, S
+        f32, i64, i32 = torch.float32, torch.int64, torch.int32
+        self.ids_send = torch.full((G * S,), -1, dtype=i64, device=dev)
+        self.ids_recv = torch.empty(G * S, dtype=i64, device=dev)
+        self.rows_send = torch.zeros((G * S, D), dtype=f32, device=dev)
+        self.rows_recv = torch.empty((G * S, D), dtype=f32, device=dev)
+        self.g_send = torch.zeros((G * S, D), dtype=f32, device=dev)
+        self.g_recv = torch.empty((G * S, D), dtype=f32, device=dev)
+        self.rec_send = torch.zeros(G * 3 * cap, dtype=f32, device=dev)
+        self.rec_recv = torch.empty(G * 3 * cap, dtype=f32, device=dev)
+        self.reply_send = torch.zeros(G * (cap + TAIL), dtype=f32, device=dev)
+        self.reply_recv = torch.empty(G * (cap + TAIL), dtype=f32, device=dev)
+        self.slot_u = torch.empty(B, dtype=i32, device=dev)
+        self.slot_i = torch.empty(B, dtype=i32, device=dev)
+        self.counts = torch.empty(2 * G, dtype=i32, device=dev)
+        self.pred = torch.empty(B, dtype=f32, device=dev)
+        self.coef = torch.empty(B, dtype=f32, device=dev)
+        self.sq = torch.zeros(1, dtype=f32, device=dev)
+        self.loss = torch.zeros(3, dtype=f32, device=dev)
+        self.n_sq_part = (B + 3) // 4
+        self.sq_part = torch.zeros(self.n_sq_part + 1, dtype=f32, device=dev)
+        self.scratch = torch.zeros(G * cap // 64 + 32, dtype=f32, device=dev)   # [0] = arrival ticket, kept zero
 
 
 class ShardedFocfEngine:
@@ -120,77 +168,64 @@ class ShardedFocfEngine:
         self.capacity_factor = capacity_factor
         self.sweep_period = sweep_period
         self.err = torch.zeros(1, dtype=torch.int32, device=self.device)
-        self._ctx = None
+        self._buf: Optional[_Buffers] = None
+        self._armed = False
         self.step_count = 0
 
     # --- collectives ------------------------------------------------------------------------------------
-    def _a2a(self, t: torch.Tensor) -> torch.Tensor:
-        """t[g] goes to rank g; returns r with r[g] = what rank g sent to me.  t is [G, ...] contiguous."""
-        out = torch.empty_like(t)
+    def _a2a(self, out: torch.Tensor, t: torch.Tensor):
+        """Chunk g of `t` goes to rank g; chunk g of `out` is what rank g sent to me."""
         dist.all_to_all_single(out, t, group=self.group)
-        return out
 
     def capacity(self, B: int) -> int:
-        return min(B, int(math.ceil(self.capacity_factor * B / self.G)) + 64)
+        return exchange_capacity(B, self.G, self.capacity_factor)
+
+    def _buffers(self, B: int) -> _Buffers:
+        if self._buf is None or self._buf.B != B:
+            self._buf = _Buffers(self.G, B, self.capacity(B), self.U.dim, self.device)
+        return self._buf
 
     # --- step -------------------------------------------------------------------------------------------
     def forward(self, user, item, rating, sst):
-        """Everything up to the loss of the global batch; returns the loss as a 0-dim device tensor."""
+        """Everything up to the loss of the global batch; returns (loss as a 0-dim device tensor, pred [B])."""
         G, ops = self.G, self.ops
         B = user.numel()
-        cap = self.capacity(B)
+        b = self._buffers(B)
+        cap, S = b.cap, b.S
         n_slots = G * cap
         fair = self.objective != "none"
-        send_u, slot_u, _ = ops.bucket_by_owner(user, G, cap, self.err)
-        send_i, slot_i, _ = ops.bucket_by_owner(item, G, cap, self.err)
-        ids = self._a2a(torch.cat([send_u.view(G, cap), send_i.view(G, cap)], dim=1).contiguous())
-        req_u = ids[:, :cap].reshape(-1).contiguous()
-        req_i = ids[:, cap:].reshape(-1).contiguous()
-        minmax = None
+        ops.bucket_pair(user, item, G, cap, S, 0, cap, b.ids_send, b.slot_u, b.slot_i, b.counts, sst if fair else None,
+                        2 * cap, self.err)
+        self._a2a(b.ids_recv, b.ids_send)
+        ops.gather_train_pair(self.U, self.I, self.hyper, b.ids_recv, 0, cap, n_slots, cap, S, b.rows_send, self.err)
+        self._a2a(b.rows_recv, b.rows_send)
+        ops.shard_score(b.rows_recv, b.slot_u, b.slot_i, rating, sst if fair else None, G * B, b.pred, b.coef,
+                        b.rec_send if fair else None, cap, S, cap, None if fair else b.sq, b.sq_part)
         if fair:
-            mm = torch.stack([sst.min(), -sst.max()])
-            dist.all_reduce(mm, op=dist.ReduceOp.MIN, group=self.group)
-            minmax = torch.stack([mm[0], -mm[1]])
-        own_u = ops.gather_train(self.U, self.hyper, req_u, self.err)      # [G*cap, D], rows I own, per requester
-        own_i = ops.gather_train(self.I, self.hyper, req_i, self.err)
-        D = own_u.shape[1]
-        rows = self._a2a(torch.cat([own_u.view(G, cap, D), own_i.view(G, cap, D)], dim=1).contiguous())
-        rows_u = rows[:, :cap].reshape(n_slots, D).contiguous()            # my requests, slot order
-        rows_i = rows[:, cap:].reshape(n_slots, D).contiguous()
-        pred, coef, rec, sq = ops.shard_score(rows_u, rows_i, slot_u, slot_i, rating, sst, G * B, fair)
-        scal = torch.zeros(3, dtype=torch.float32, device=self.device)
-        scal[0:1] = sq
-        coef_own = None
-        if fair:
-            rec_in = self._a2a(rec.view(3, G, cap).permute(1, 0, 2).contiguous())        # [G(src), 3, cap]
-            rec_own = rec_in.permute(1, 0, 2).reshape(3, n_slots).contiguous()
-            coef_own, sums = ops.shard_fair(self.I, rec_own, minmax, self.objective, self.fair_weight, self.err)
-            scal[1:3] = sums
-        dist.all_reduce(scal, op=dist.ReduceOp.SUM, group=self.group)
-        mse = scal[0] / float(G * B)
-        loss = mse + self.fair_weight * scal[1] / scal[2] if fair else mse
-        self._ctx = dict(B=B, cap=cap, slot_u=slot_u, slot_i=slot_i, rows_u=rows_u, rows_i=rows_i, coef=coef,
-                         coef_own=coef_own, inv_k=(1.0 / scal[2]).reshape(1) if fair else None, own_u=own_u, own_i=own_i)
-        return loss, pred
+            self._a2a(b.rec_recv, b.rec_send)
+            ops.shard_fair(self.I, n_slots, b.rec_recv, cap, b.ids_recv, 2 * cap, S, self.objective, self.fair_weight,
+                           b.reply_send, b.sq_part, b.n_sq_part, b.scratch, self.err)
+            self._a2a(b.reply_recv, b.reply_send)
+        else:
+            dist.all_reduce(b.sq, op=dist.ReduceOp.SUM, group=self.group)
+        # gradient rows for the owners; with a fairness term this kernel also folds the reply tails into the loss
+        ops.shard_grads(b.rows_recv, b.slot_u, b.slot_i, b.coef, b.reply_recv if fair else None, G, G * B,
+                        self.fair_weight, b.loss if fair else None, cap, S, cap, b.g_send)
+        loss = b.loss[0] if fair else b.sq[0] / float(G * B)
+        self._armed = True
+        return loss, b.pred
 
     def backward_adam(self):
-        c, G, ops = self._ctx, self.G, self.ops
-        if c is None:
+        G, ops, b = self.G, self.ops, self._buf
+        if not self._armed:
             raise _C.FairrecError("backward_adam without forward")
-        cap, n_slots = c["cap"], G * c["cap"]
-        coef_reply = None
-        if c["coef_own"] is not None:
-            coef_reply = self._a2a(c["coef_own"].view(G, cap).contiguous()).reshape(-1).contiguous()
-        gu, gi = ops.shard_grads(c["rows_u"], c["rows_i"], c["slot_u"], c["slot_i"], c["coef"], coef_reply, c["inv_k"])
-        D = gu.shape[1]
-        g = self._a2a(torch.cat([gu.view(G, cap, D), gi.view(G, cap, D)], dim=1).contiguous())
-        gu_own = g[:, :cap].reshape(n_slots, D).contiguous()
-        gi_own = g[:, cap:].reshape(n_slots, D).contiguous()
+        cap, S = b.cap, b.S
+        n_slots = G * cap
+        self._a2a(b.g_recv, b.g_send)
         su = self.sweep_period if self.sweep_period is not None else max(8, math.ceil(self.U.n_rows / max(n_slots // 2, 1)))
         si = self.sweep_period if self.sweep_period is not None else max(8, math.ceil(self.I.n_rows / max(n_slots // 2, 1)))
-        ops.apply_grad(self.U, self.hyper, gu_own, su)
-        ops.apply_grad(self.I, self.hyper, gi_own, si)
-        self._ctx = None
+        ops.apply_grad_pair(self.U, self.I, self.hyper, n_slots, cap, S, b.rows_send, b.g_recv, 0, cap, su, si)
+        self._armed = False
         self.step_count += 1
 
     def flush(self):

@@ -1,9 +1,18 @@
 """TEST DOUBLE (never shipped, never imported by the product): torch-CPU stand-ins for the HIP kernels the
-row-sharded step calls, so that its exchange schedule can run over gloo on a machine without a GPU.
-Table updates use the oracle's dense Adam on every row (the reference's semantics), not the lazy replay."""
+row-sharded step calls, so that its exchange schedule can run over gloo on a machine without a GPU.  Same buffer
+layouts as the kernels (fairrec_hip.h "slot layout").  Table updates use the oracle's dense Adam on every row
+(the reference's semantics), not the lazy replay."""
 import torch
 
 from oracle import focf as O
+
+TAIL = 3
+
+
+def phys(n, chunk, stride, off=0):
+    """Physical positions of logical slots 0..n-1 of a (chunk, stride) layout starting `off` slots into the buffer."""
+    j = torch.arange(n)
+    return (j // chunk) * stride + j % chunk + off if chunk else j + off
 
 
 class CpuTable:
@@ -21,73 +30,107 @@ class CpuOps:
     def make_table(self, weight):
         return CpuTable(weight)
 
-    def bucket_by_owner(self, idx, G, cap, err):
+    def bucket_by_owner(self, idx, G, cap, stride, offset, send, slot, counts, aux, aux_slot, err):
         M = idx.numel()
-        send = torch.full((G * cap,), -1, dtype=torch.int64)
-        slot = torch.full((M,), -1, dtype=torch.int32)
-        counts = torch.zeros(G, dtype=torch.int32)
+        for o in range(G):
+            send[o * stride + offset:o * stride + offset + cap] = -1
+        slot.fill_(-1)
+        counts.zero_()
         for j in range(M):
             o = int(idx[j]) % G
             k = int(counts[o])
             if k < cap:
-                send[o * cap + k] = int(idx[j]) // G
-                slot[j] = o * cap + k
+                send[o * stride + offset + k] = int(idx[j]) // G
+                slot[j] = o * stride + offset + k
                 counts[o] += 1
             else:
                 err |= 4
-        return send, slot, counts
+        if aux is not None:
+            pair = torch.stack([aux.min(), aux.max()]).to(torch.float32).view(torch.int64)
+            for o in range(G):
+                send[o * stride + aux_slot] = pair[0]
 
-    def gather_train(self, table, hyper, ids, err):
-        table.ids = ids.clone()
-        rows = torch.zeros((ids.numel(), table.dim))
-        ok = ids >= 0
-        rows[ok] = table.weight[ids[ok]]
-        return rows
+    def bucket_pair(self, idx_a, idx_b, G, cap, stride, off_a, off_b, send, slot_a, slot_b, counts, aux, aux_slot, err):
+        self.bucket_by_owner(idx_a, G, cap, stride, off_a, send, slot_a, counts[:G], None, 0, err)
+        self.bucket_by_owner(idx_b, G, cap, stride, off_b, send, slot_b, counts[G:], aux, aux_slot, err)
 
-    def apply_grad(self, table, hyper, grads, sweep):
+    def gather_train(self, table, hyper, ids, ids_off, M, chunk, stride, rows, err):
+        p = phys(M, chunk, stride, ids_off)
+        table.ids = ids[p].clone()
+        ok = table.ids >= 0
+        out = torch.zeros((M, table.dim))
+        out[ok] = table.weight[table.ids[ok]]
+        rows[p] = out
+
+    def gather_train_pair(self, ta, tb, hyper, ids, off_a, off_b, M, chunk, stride, rows, err):
+        self.gather_train(ta, hyper, ids, off_a, M, chunk, stride, rows, err)
+        self.gather_train(tb, hyper, ids, off_b, M, chunk, stride, rows, err)
+
+    def apply_grad_pair(self, ta, tb, hyper, M, chunk, stride, rows, grads, off_a, off_b, sweep_a, sweep_b):
+        self.apply_grad(ta, hyper, M, chunk, stride, rows, grads, off_a, sweep_a)
+        self.apply_grad(tb, hyper, M, chunk, stride, rows, grads, off_b, sweep_b)
+
+    def apply_grad(self, table, hyper, M, chunk, stride, rows, grads, off, sweep):
+        p = phys(M, chunk, stride, off)
         g = torch.zeros_like(table.weight)
         ok = table.ids >= 0
-        g.index_add_(0, table.ids[ok], grads[ok])
+        g.index_add_(0, table.ids[ok], grads[p][ok])
         table.step += 1
         O.adam_dense_step_(table.weight, g, table.m, table.v, table.step, hyper.lr, hyper.weight_decay)
 
     def flush(self, table, hyper):
         pass
 
-    def shard_score(self, rows_u, rows_i, slot_u, slot_i, rating, sst, n_global, want_rec):
-        ue, ie = rows_u[slot_u.long()], rows_i[slot_i.long()]
-        pred = (ue * ie).sum(-1)
-        err = pred - rating
-        coef = 2 * err / n_global
-        rec = None
-        if want_rec:
-            rec = torch.zeros((3, rows_i.shape[0]))
-            rec[0, slot_i.long()] = pred
-            rec[1, slot_i.long()] = rating
-            rec[2, slot_i.long()] = sst
-        return pred, coef, rec, (err * err).sum().reshape(1)
+    def shard_score(self, rows, slot_u, slot_i, rating, sst, n_global, pred, coef, rec, cap, slot_stride, slot_offset,
+                    sq, sq_part):
+        su, si = slot_u.long(), slot_i.long()
+        p = (rows[su] * rows[si]).sum(-1)
+        e = p - rating
+        pred.copy_(p)
+        coef.copy_(2 * e / n_global)
+        sq_part.zero_()
+        sq_part[0] = (e * e).sum()
+        if sq is not None:
+            sq[0] = sq_part[0]
+        if rec is not None:
+            base = (si // slot_stride) * 3 * cap + (si % slot_stride - slot_offset)
+            rec[base] = p
+            rec[base + cap] = rating
+            rec[base + 2 * cap] = sst
 
-    def shard_fair(self, item_table, rec, minmax, objective, fair_weight, err):
+    def shard_fair(self, item_table, n_slots, rec, cap, ids_recv, mm_slot, stride, objective, fair_weight, reply,
+                   sq_part, n_sq_part, scratch, err):
+        G = n_slots // cap
+        pairs = torch.stack([ids_recv[g * stride + mm_slot:g * stride + mm_slot + 1].view(torch.float32) for g in range(G)])
+        smin, smax = pairs[:, 0].min(), pairs[:, 1].max()
         ok = item_table.ids >= 0
-        pred = rec[0, ok].clone().requires_grad_()
-        rating, sst, item = rec[1, ok], rec[2, ok], item_table.ids[ok]
-        P, T = O.item_group_means(pred, rating, (sst != minmax[0]).float() if minmax[0] != minmax[1] else sst, item)
+        pr = phys(n_slots, cap, 3 * cap)
+        pred = rec[pr][ok].clone().requires_grad_()
+        rating, sst, item = rec[pr + cap][ok], rec[pr + 2 * cap][ok], item_table.ids[ok]
+        P, T = O.item_group_means(pred, rating, (sst != smin).float() if smin != smax else sst, item)
         d = {"value": P - T, "absolute": (P - T).abs(), "under": torch.clamp(T - P, min=0),
              "over": torch.clamp(P - T, min=0)}[objective]
         x = (d[:, 0] - d[:, 1]).abs()
         s = torch.nn.functional.smooth_l1_loss(x, torch.zeros_like(x), reduction="sum")
         (fair_weight * s).backward()
-        coef = torch.zeros(rec.shape[1])
-        coef[ok] = pred.grad
-        return coef, torch.stack([s.detach(), torch.tensor(float(P.shape[0]))])
+        c = torch.zeros(n_slots)
+        c[ok] = pred.grad
+        reply[phys(n_slots, cap, cap + TAIL)] = c
+        for g in range(G):
+            t = g * (cap + TAIL) + cap
+            reply[t], reply[t + 1], reply[t + 2] = float(P.shape[0]), float(s.detach()), float(sq_part[:n_sq_part].sum())
 
-    def shard_grads(self, rows_u, rows_i, slot_u, slot_i, coef, coef_slots, inv_k):
+    def shard_grads(self, rows, slot_u, slot_i, coef, reply, G, n_global, fair_weight, loss_out, cap, slot_stride,
+                    slot_offset, grads):
         su, si = slot_u.long(), slot_i.long()
         c = coef.clone()
-        if coef_slots is not None:
-            c = c + coef_slots[si] * inv_k
-        gu = torch.zeros_like(rows_u)
-        gi = torch.zeros_like(rows_i)
-        gu[su] = c[:, None] * rows_i[si]
-        gi[si] = c[:, None] * rows_u[su]
-        return gu, gi
+        if reply is not None:
+            tails = torch.stack([reply[g * (cap + TAIL) + cap:g * (cap + TAIL) + cap + TAIL] for g in range(G)])
+            K, fs, sqs = tails[:, 0].sum(), tails[:, 1].sum(), tails[:, 2].sum()
+            if loss_out is not None:
+                loss_out[1] = sqs / n_global
+                loss_out[2] = fs / K
+                loss_out[0] = loss_out[1] + fair_weight * loss_out[2]
+            c = c + reply[(si // slot_stride) * (cap + TAIL) + (si % slot_stride - slot_offset)] / K
+        grads[su] = c[:, None] * rows[si]
+        grads[si] = c[:, None] * rows[su]

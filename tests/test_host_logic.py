@@ -120,3 +120,14 @@ def test_nfcf_reset_params_matches_reference_golden(tmp_path):
     np.testing.assert_allclose(m.user_embedding.weight.detach().numpy(), z["init.user_embedding.weight"], rtol=1e-6, atol=1e-7)
     assert not m.user_embedding.weight.requires_grad and m.item_embedding.weight.requires_grad
     assert get_model("NFCF") is NFCF and get_trainer(None, "NFCF").__name__ == "Trainer"
+
+
+def test_exchange_capacity_fits_the_owner_sort():
+    """An owner sorts the G*cap ids it receives for one table in one launch (FR_SORT_MAX); the bench shapes
+    (B = 8192 per rank, G = 1, 2, 4, 8) must fit, and the mean fill B/G must leave head-room."""
+    from fairrec.sharded import SORT_MAX, exchange_capacity
+    for G in (1, 2, 3, 4, 8, 16):
+        for B in (64, 2048, 8192):
+            cap = exchange_capacity(B, G, 2.0)
+            assert G * cap <= max(SORT_MAX, G) and cap >= min(B, -(-B // G))
+    assert exchange_capacity(8192, 8, 2.0) == 2048 and exchange_capacity(8192, 1, 2.0) == 8192

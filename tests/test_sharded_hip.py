@@ -49,26 +49,41 @@ def test_sharded_hip_matches_reference_golden(pg, case):
 
 
 def test_bucket_by_owner_bit_exact():
+    """Dense [G, cap] layout and the shared [G, 2*cap+1] layout (second list + the (min, max) pair of an aux column in
+    the trailing slot of every chunk)."""
     from fairrec.sharded import HipOps
     ops = HipOps("cuda")
     g = torch.Generator().manual_seed(5)
-    for M, G, cap in ((1, 1, 1), (100, 2, 80), (8192, 8, 1200), (8192, 4, 8192), (5000, 3, 100)):
+    for M, G, cap, shared in ((1, 1, 1, False), (100, 2, 80, True), (8192, 8, 1200, True), (8192, 4, 8192, False),
+                              (5000, 3, 100, True), (8192, 8, 2048, True)):
         idx = torch.randint(0, 10 ** 6, (M,), generator=g, dtype=torch.int64)
+        aux = torch.randn(M, generator=g) if shared else None
+        stride, offset, aux_slot = (2 * cap + 1, cap, 2 * cap) if shared else (cap, 0, 0)
         err = torch.zeros(1, dtype=torch.int32, device="cuda")
-        send, slot, counts = ops.bucket_by_owner(idx.cuda(), G, cap, err)
+        send = torch.full((G * stride,), -7, dtype=torch.int64, device="cuda")
+        slot = torch.empty(M, dtype=torch.int32, device="cuda")
+        counts = torch.empty(G, dtype=torch.int32, device="cuda")
+        ops.bucket_by_owner(idx.cuda(), G, cap, stride, offset, send, slot, counts, aux.cuda() if shared else None,
+                            aux_slot, err)
         send, slot, counts = send.cpu().numpy(), slot.cpu().numpy(), counts.cpu().numpy()
-        exp_send = np.full(G * cap, -1, dtype=np.int64)
+        exp_send = np.full(G * stride, -7, dtype=np.int64)          # slots of the other list stay untouched
+        for o in range(G):
+            exp_send[o * stride + offset:o * stride + offset + cap] = -1
         exp_slot = np.full(M, -1, dtype=np.int32)
         fill = np.zeros(G, dtype=np.int64)
         overflow = False
         for j, r in enumerate(idx.numpy()):
             o = r % G
             if fill[o] < cap:
-                exp_send[o * cap + fill[o]] = r // G
-                exp_slot[j] = o * cap + fill[o]
+                exp_send[o * stride + offset + fill[o]] = r // G
+                exp_slot[j] = o * stride + offset + fill[o]
                 fill[o] += 1
             else:
                 overflow = True
+        if shared:
+            pair = np.array([aux.min().item(), aux.max().item()], dtype=np.float32).view(np.int64)[0]
+            for o in range(G):
+                exp_send[o * stride + aux_slot] = pair
         np.testing.assert_array_equal(send, exp_send)
         np.testing.assert_array_equal(slot, exp_slot)
         np.testing.assert_array_equal(counts, fill)
