@@ -128,8 +128,9 @@ def main():
     n_batches = u.shape[0]
 
     def step(k):
-        if sharded:
-            eng.forward(u[k], i[k], r[k], s[k])
+        if sharded:   # look-ahead of the index work, not across the warm-up / captured-graph boundary
+            nxt = (u[k + 1], i[k + 1], s[k + 1]) if k + 1 < n_batches and k != W - 1 else None
+            eng.forward(u[k], i[k], r[k], s[k], next_batch=nxt)
         else:   # the next batch's index sort is launched one step ahead (dataloader-style prefetch of the ids)
             nxt = (u[k + 1], i[k + 1], s[k + 1]) if k + 1 < n_batches else None
             eng.forward(u[k], i[k], r[k], s[k], next_batch=nxt)
@@ -149,9 +150,13 @@ def main():
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         graph = torch.cuda.CUDAGraph()
+        if sharded:
+            # let the RCCL watchdog thread retire the warm-up collectives before capture begins: it polls their events
+            # from another thread, which a capture in progress does not tolerate
+            time.sleep(1.0)
         try:
             with torch.cuda.stream(side):
-                with torch.cuda.graph(graph, stream=side):
+                with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):
                     for k in range(W, W + K):
                         step(k)
         except Exception as e:   # e.g. a collective that refuses capture: fall back to eager launches
@@ -186,7 +191,8 @@ def main():
         _C.prof_enable(rank == 0)
         for k in range(K):
             if sharded:
-                eng.forward(u2[k], i2[k], r2[k], s2[k])
+                nxt = (u2[k + 1], i2[k + 1], s2[k + 1]) if k + 1 < K else None
+                eng.forward(u2[k], i2[k], r2[k], s2[k], next_batch=nxt)
             else:
                 nxt = (u2[k + 1], i2[k + 1], s2[k + 1]) if k + 1 < K else None
                 eng.forward(u2[k], i2[k], r2[k], s2[k], next_batch=nxt)

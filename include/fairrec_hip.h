@@ -183,10 +183,17 @@ FR_API int fr_table_apply_grad(const fr_table* t, const fr_adam* adam, int64_t M
                                size_t ws_bytes, void* stream);
 /* The same for TWO tables of equal dim and M in one launch each (one sort workgroup / one grid slice per table):
  * the user and item table of a step.  ws_a != ws_b, each of fr_table_train_workspace_bytes(M, dim). */
+#define FR_TABLE_PREPARED 1   /* flags: fr_table_sort2 already ran for these id lists on these workspaces */
 FR_API int fr_table_gather_train2(const fr_table* ta, const fr_table* tb, const fr_adam* adam, const int64_t* idx_a,
                                   const int64_t* idx_b, int64_t M, int32_t chunk, int32_t stride, float* rows_a,
-                                  float* rows_b, void* ws_a, void* ws_b, size_t ws_bytes, uint32_t* err_flag,
-                                  void* stream);
+                                  float* rows_b, int32_t flags, void* ws_a, void* ws_b, size_t ws_bytes,
+                                  uint32_t* err_flag, void* stream);
+/* The index-only part of fr_table_gather_train2 (sort + segmentation of both id lists into the workspaces), callable
+ * one batch AHEAD on another stream: it depends on nothing but the ids.  The caller orders it against the users of the
+ * workspaces with events. */
+FR_API int fr_table_sort2(const int64_t* idx_a, const int64_t* idx_b, int64_t n_rows_a, int64_t n_rows_b, int64_t M,
+                          int32_t chunk, int32_t stride, int32_t dim, void* ws_a, void* ws_b, size_t ws_bytes,
+                          uint32_t* err_flag, void* stream);
 FR_API int fr_table_apply_grad2(const fr_table* ta, const fr_table* tb, const fr_adam* adam, int64_t M, int32_t chunk,
                                 int32_t stride, const float* rows_a, const float* grad_a, const float* rows_b,
                                 const float* grad_b, int32_t sweep_a, int32_t sweep_b, void* ws_a, void* ws_b,

@@ -194,7 +194,7 @@ static inline bool lay_ok(int32_t chunk, int32_t stride) { return chunk == 0 || 
 static int gather_train_impl(const char* who, const fr_table* ta, const fr_table* tb, const fr_adam* adam,
                              const int64_t* idx_a, const int64_t* idx_b, int64_t M, int32_t chunk, int32_t stride,
                              float* rows_a, float* rows_b, void* ws_a, void* ws_b, size_t ws_bytes, uint32_t* err_flag,
-                             hipStream_t stream) {
+                             hipStream_t stream, bool prepared = false) {
     int rc;
     if ((rc = check_table(ta, who)) || (tb && (rc = check_table(tb, who))) || (rc = check_adam(adam, who))) return rc;
     FR_CHECK_ARG(idx_a && rows_a && ws_a && M >= 1 && M <= FR_SORT_MAX && ta->step >= 1 && lay_ok(chunk, stride),
@@ -209,7 +209,9 @@ static int gather_train_impl(const char* who, const fr_table* ta, const fr_table
     SortJob sb{idx_b, tb ? tb->n_rows : 0, wb.perm, wb.seg_start, wb.seg_row, nullptr, wb.nseg, nullptr, nullptr, lay};
     SideStream* ss = side_stream();
     const bool overlap = ss != nullptr && !prof_on();
-    if (overlap) {
+    if (prepared) {
+        // fr_table_sort2 already left the segments of these id lists in the workspaces (one step ahead)
+    } else if (overlap) {
         FR_CHECK_HIP(hipEventRecord(ss->fork, stream));
         FR_CHECK_HIP(hipStreamWaitEvent(ss->stream, ss->fork, 0));
         if ((rc = launch_sort(sa, tb ? &sb : nullptr, M, err_flag, ss->stream))) return rc;
@@ -238,11 +240,27 @@ extern "C" int fr_table_gather_train(const fr_table* t, const fr_adam* adam, con
 
 extern "C" int fr_table_gather_train2(const fr_table* ta, const fr_table* tb, const fr_adam* adam, const int64_t* idx_a,
                                       const int64_t* idx_b, int64_t M, int32_t chunk, int32_t stride, float* rows_a,
-                                      float* rows_b, void* ws_a, void* ws_b, size_t ws_bytes, uint32_t* err_flag,
-                                      void* stream_) {
+                                      float* rows_b, int32_t flags, void* ws_a, void* ws_b, size_t ws_bytes,
+                                      uint32_t* err_flag, void* stream_) {
     FR_CHECK_ARG(tb, "fr_table_gather_train2: second table is null");
     return gather_train_impl("fr_table_gather_train2", ta, tb, adam, idx_a, idx_b, M, chunk, stride, rows_a, rows_b, ws_a,
-                             ws_b, ws_bytes, err_flag, (hipStream_t)stream_);
+                             ws_b, ws_bytes, err_flag, (hipStream_t)stream_, (flags & FR_TABLE_PREPARED) != 0);
+}
+
+// The index-only part of fr_table_gather_train2, callable one batch AHEAD on another stream (it depends on nothing
+// but the id lists): sort + segmentation into the two workspaces.  The caller orders it against the users of the
+// workspaces with events and passes FR_TABLE_PREPARED to fr_table_gather_train2.
+extern "C" int fr_table_sort2(const int64_t* idx_a, const int64_t* idx_b, int64_t n_rows_a, int64_t n_rows_b, int64_t M,
+                              int32_t chunk, int32_t stride, int32_t dim, void* ws_a, void* ws_b, size_t ws_bytes,
+                              uint32_t* err_flag, void* stream_) {
+    FR_CHECK_ARG(idx_a && idx_b && ws_a && ws_b && ws_a != ws_b && M >= 1 && M <= FR_SORT_MAX && dim >= 1 && n_rows_a >= 1 &&
+                     n_rows_b >= 1 && lay_ok(chunk, stride), "fr_table_sort2: bad argument");
+    TableWs wa = table_layout(ws_a, M, dim), wb = table_layout(ws_b, M, dim);
+    FR_CHECK_ARG(ws_bytes >= wa.bytes, "fr_table_sort2: workspace %zu < %zu bytes", ws_bytes, wa.bytes);
+    const Lay lay{chunk, stride};
+    SortJob sa{idx_a, n_rows_a, wa.perm, wa.seg_start, wa.seg_row, nullptr, wa.nseg, nullptr, nullptr, lay};
+    SortJob sb{idx_b, n_rows_b, wb.perm, wb.seg_start, wb.seg_row, nullptr, wb.nseg, nullptr, nullptr, lay};
+    return launch_sort(sa, &sb, M, err_flag, (hipStream_t)stream_);
 }
 
 static int apply_grad_impl(const char* who, const fr_table* ta, const fr_table* tb, const fr_adam* adam, int64_t M,

@@ -72,8 +72,10 @@ _PROTOS = {
                                     c_void_p, c_int32, c_int32, c_int32, c_int64, c_int32, c_void_p, c_void_p,
                                     c_void_p]),
     "fr_table_gather_train2": (c_int, [POINTER(FrTable), POINTER(FrTable), POINTER(FrAdam), c_void_p, c_void_p, c_int64,
-                                       c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p,
-                                       c_void_p]),
+                                       c_int32, c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_size_t,
+                                       c_void_p, c_void_p]),
+    "fr_table_sort2": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int32, c_int32, c_int32, c_void_p, c_void_p,
+                               c_size_t, c_void_p, c_void_p]),
     "fr_table_apply_grad2": (c_int, [POINTER(FrTable), POINTER(FrTable), POINTER(FrAdam), c_int64, c_int32, c_int32,
                                      c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p,
                                      c_size_t, c_void_p]),

@@ -180,17 +180,28 @@ class LazyTable:
 
     # --- two tables of a step in one launch each (the user and item table of the row-sharded step) ------
     @staticmethod
+    def sort_pair(ta: "LazyTable", tb: "LazyTable", idx_a: int, idx_b: int, M: int, ws_a: torch.Tensor, ws_b: torch.Tensor,
+                  chunk: int = 0, stride: int = 0, err_flag: Optional[torch.Tensor] = None):
+        """fr_table_sort2 into the given workspaces (one step ahead, on the current -- side -- stream)."""
+        _C.check(_C.lib().fr_table_sort2(idx_a, idx_b, ta.n_rows, tb.n_rows, M, chunk, stride, ta.dim, ws_a.data_ptr(),
+                                         ws_b.data_ptr(), min(ws_a.numel(), ws_b.numel()), _C.ptr(err_flag),
+                                         _C.current_stream()), "fr_table_sort2")
+
+    @staticmethod
     def gather_train_pair(ta: "LazyTable", tb: "LazyTable", hyper: AdamHyper, idx_a: int, idx_b: int, M: int, rows_a: int,
-                          rows_b: int, chunk: int = 0, stride: int = 0, err_flag: Optional[torch.Tensor] = None):
+                          rows_b: int, chunk: int = 0, stride: int = 0, err_flag: Optional[torch.Tensor] = None,
+                          prepared: bool = False):
         assert ta.dim == tb.dim and ta.step == tb.step
         need = _C.lib().fr_table_train_workspace_bytes(M, ta.dim)
         for t in (ta, tb):
             if t._ws is None or t._ws.numel() < need:
+                assert not prepared, "prepared workspaces must be installed as table._ws by the caller"
                 t._ws = torch.empty(need, dtype=torch.uint8, device=t.weight.device)
         hyper.check_step(ta.step + 1)
         ca, cb = ta.c(ta.step + 1), tb.c(tb.step + 1)
         _C.check(_C.lib().fr_table_gather_train2(ctypes.byref(ca), ctypes.byref(cb), ctypes.byref(hyper.c()), idx_a, idx_b,
-                                                 M, chunk, stride, rows_a, rows_b, ta._ws.data_ptr(), tb._ws.data_ptr(),
+                                                 M, chunk, stride, rows_a, rows_b, 1 if prepared else 0,
+                                                 ta._ws.data_ptr(), tb._ws.data_ptr(),
                                                  min(ta._ws.numel(), tb._ws.numel()), _C.ptr(err_flag),
                                                  _C.current_stream()), "fr_table_gather_train2")
         for t in (ta, tb):

@@ -15,8 +15,12 @@ and write the exchange layouts in place, fairrec_hip.h "slot layout"):
     reply  [G, cap+3]        owners: fairness part of dLoss/dpred per record | (K_owner, fair_owner, sq_rank)
     grads  [G, 2*cap+1, D]   gradient rows back to the owners -> duplicate-sum + Adam
 
-Launches per step: bucket (both id lists) | sort (both tables, side stream) + gather (both tables) | score | fair |
-grads (+ loss) | apply (both tables) = 7 kernels around the 5 collectives.
+Launches per step: bucket (both id lists) | sort (both tables) | gather (both tables) | score | fair | grads (+ loss) |
+apply (both tables) = 7 kernels around the 5 collectives.  The first two kernels and the id exchange depend on
+nothing but the id columns: when the caller names the next batch (`next_batch`, the trainer's one-batch dataloader
+look-ahead) they run one step AHEAD on a side stream, on the second copy of the index-side buffers, so the dependent
+chain of a step starts at the gather.  The look-ahead id exchange uses the same communicator and is issued while
+the fairness kernel runs, where the main chain leaves it idle.
 
 The three scalars at the tail of every reply chunk give each rank K, the fairness sum and the squared-error sum of
 the global batch (summed in rank order, so identical everywhere).  fair_objective none needs no rec/reply; its
@@ -79,10 +83,32 @@ class HipOps:
                                                   counts.data_ptr(), _C.ptr(aux), aux_slot, err.data_ptr(),
                                                   _C.current_stream()), "fr_bucket_pair_by_owner")
 
-    def gather_train_pair(self, ta, tb, hyper, ids, off_a, off_b, M, chunk, stride, rows, err):
+    # --- look-ahead: the index-only part of the NEXT step runs on a side stream -------------------------
+    def side(self, fork=True):
+        """Context: launches go to the side stream; fork: it first waits for everything enqueued on the current one."""
+        if not hasattr(self, "_side"):
+            self._side = torch.cuda.Stream(device=self.device)
+        if fork:
+            self._side.wait_stream(torch.cuda.current_stream())
+        return torch.cuda.stream(self._side)
+
+    def join_side(self):
+        torch.cuda.current_stream().wait_stream(self._side)
+
+    def alloc_ws(self, table, M):
+        return torch.empty(_C.lib().fr_table_train_workspace_bytes(M, table.dim), dtype=torch.uint8, device=self.device)
+
+    def sort_pair(self, ta, tb, ids, off_a, off_b, M, chunk, stride, ws_a, ws_b, err):
+        LazyTable.sort_pair(ta, tb, ids.data_ptr() + 8 * off_a, ids.data_ptr() + 8 * off_b, M, ws_a, ws_b, chunk, stride,
+                            err)
+
+    def gather_train_pair(self, ta, tb, hyper, ids, off_a, off_b, M, chunk, stride, rows, ws_a, ws_b, err):
+        """Segments of both id lists are already in ws_a / ws_b (sort_pair)."""
         D = ta.dim
+        ta._ws, tb._ws = ws_a, ws_b
         LazyTable.gather_train_pair(ta, tb, hyper, ids.data_ptr() + 8 * off_a, ids.data_ptr() + 8 * off_b, M,
-                                    rows.data_ptr() + 4 * off_a * D, rows.data_ptr() + 4 * off_b * D, chunk, stride, err)
+                                    rows.data_ptr() + 4 * off_a * D, rows.data_ptr() + 4 * off_b * D, chunk, stride, err,
+                                    prepared=True)
 
     def apply_grad_pair(self, ta, tb, hyper, M, chunk, stride, rows, grads, off_a, off_b, sweep_a, sweep_b):
         D = ta.dim
@@ -124,12 +150,18 @@ class HipOps:
 class _Buffers:
     """Exchange and scratch buffers of one (B, cap, D) shape, allocated once (a captured step replays on them)."""
 
-    def __init__(self, G, B, cap, D, dev):
+    def __init__(self, G, B, cap, D, dev, ops, U, I):
         S = 2 * cap + 1
         self.B, self.cap, self.S = B, cap, S
         f32, i64, i32 = torch.float32, torch.int64, torch.int32
-        self.ids_send = torch.full((G * S,), -1, dtype=i64, device=dev)
-        self.ids_recv = torch.empty(G * S, dtype=i64, device=dev)
+        # index-side state exists twice: the NEXT step's bucket / id exchange / owner sort runs while this step computes
+        self.ids_send = [torch.full((G * S,), -1, dtype=i64, device=dev) for _ in range(2)]
+        self.ids_recv = [torch.full((G * S,), -1, dtype=i64, device=dev) for _ in range(2)]
+        self.slot_u = [torch.empty(B, dtype=i32, device=dev) for _ in range(2)]
+        self.slot_i = [torch.empty(B, dtype=i32, device=dev) for _ in range(2)]
+        self.counts = [torch.empty(2 * G, dtype=i32, device=dev) for _ in range(2)]
+        self.ws_u = [ops.alloc_ws(U, G * cap) for _ in range(2)]
+        self.ws_i = [ops.alloc_ws(I, G * cap) for _ in range(2)]
         self.rows_send = torch.zeros((G * S, D), dtype=f32, device=dev)
         self.rows_recv = torch.empty((G * S, D), dtype=f32, device=dev)
         self.g_send = torch.zeros((G * S, D), dtype=f32, device=dev)
@@ -138,9 +170,6 @@ class _Buffers:
         self.rec_recv = torch.empty(G * 3 * cap, dtype=f32, device=dev)
         self.reply_send = torch.zeros(G * (cap + TAIL), dtype=f32, device=dev)
         self.reply_recv = torch.empty(G * (cap + TAIL), dtype=f32, device=dev)
-        self.slot_u = torch.empty(B, dtype=i32, device=dev)
-        self.slot_i = torch.empty(B, dtype=i32, device=dev)
-        self.counts = torch.empty(2 * G, dtype=i32, device=dev)
         self.pred = torch.empty(B, dtype=f32, device=dev)
         self.coef = torch.empty(B, dtype=f32, device=dev)
         self.sq = torch.zeros(1, dtype=f32, device=dev)
@@ -170,46 +199,90 @@ class ShardedFocfEngine:
         self.err = torch.zeros(1, dtype=torch.int32, device=self.device)
         self._buf: Optional[_Buffers] = None
         self._armed = False
+        self._sel = 0                 # which copy of the index-side state the current step uses
+        self._prep_key = None         # identity of the batch whose index work is in flight on the side stream
         self.step_count = 0
 
     # --- collectives ------------------------------------------------------------------------------------
-    def _a2a(self, out: torch.Tensor, t: torch.Tensor):
+    def _a2a(self, out: torch.Tensor, t: torch.Tensor, group=None):
         """Chunk g of `t` goes to rank g; chunk g of `out` is what rank g sent to me."""
-        dist.all_to_all_single(out, t, group=self.group)
+        dist.all_to_all_single(out, t, group=group if group is not None else self.group)
 
     def capacity(self, B: int) -> int:
         return exchange_capacity(B, self.G, self.capacity_factor)
 
     def _buffers(self, B: int) -> _Buffers:
         if self._buf is None or self._buf.B != B:
-            self._buf = _Buffers(self.G, B, self.capacity(B), self.U.dim, self.device)
+            self._buf = _Buffers(self.G, B, self.capacity(B), self.U.dim, self.device, self.ops, self.U, self.I)
+            self._prep_key = None
         return self._buf
 
     # --- step -------------------------------------------------------------------------------------------
-    def forward(self, user, item, rating, sst):
-        """Everything up to the loss of the global batch; returns (loss as a 0-dim device tensor, pred [B])."""
+    @staticmethod
+    def _key(user, item):
+        return (user.data_ptr(), item.data_ptr(), user.numel())
+
+    # The index-only part of a step (a pure function of the id columns), in two halves so that the look-ahead can
+    # place its collective where the main chain leaves the communicator idle:
+    def _prepare_bucket(self, b: _Buffers, sel: int, user, item, sst):
+        """bucket both id lists by owner (+ the local extrema of the sensitive column)"""
+        G, cap, S, fair = self.G, b.cap, b.S, self.objective != "none"
+        self.ops.bucket_pair(user, item, G, cap, S, 0, cap, b.ids_send[sel], b.slot_u[sel], b.slot_i[sel], b.counts[sel],
+                             sst if fair else None, 2 * cap, self.err)
+
+    def _prepare_exchange(self, b: _Buffers, sel: int):
+        """exchange the id lists and sort what this rank received into segments of equal rows"""
+        G, cap, S = self.G, b.cap, b.S
+        self._a2a(b.ids_recv[sel], b.ids_send[sel])
+        self.ops.sort_pair(self.U, self.I, b.ids_recv[sel], 0, cap, G * cap, cap, S, b.ws_u[sel], b.ws_i[sel], self.err)
+
+    def forward(self, user, item, rating, sst, next_batch=None):
+        """Everything up to the loss of the global batch and the gradient rows; returns (loss as a 0-dim device
+        tensor, pred [B]).  next_batch = (user, item, sst) of the FOLLOWING step, when known (dataloader look-ahead):
+        its index work is started on a side stream now and overlaps with this step."""
         G, ops = self.G, self.ops
         B = user.numel()
         b = self._buffers(B)
-        cap, S = b.cap, b.S
+        cap, S, sel = b.cap, b.S, self._sel
         n_slots = G * cap
         fair = self.objective != "none"
-        ops.bucket_pair(user, item, G, cap, S, 0, cap, b.ids_send, b.slot_u, b.slot_i, b.counts, sst if fair else None,
-                        2 * cap, self.err)
-        self._a2a(b.ids_recv, b.ids_send)
-        ops.gather_train_pair(self.U, self.I, self.hyper, b.ids_recv, 0, cap, n_slots, cap, S, b.rows_send, self.err)
+        if self._prep_key == self._key(user, item):
+            ops.join_side()
+        else:
+            if self._prep_key is not None:      # a look-ahead for some other batch is in flight: let it finish first
+                ops.join_side()
+            self._prepare_bucket(b, sel, user, item, sst)
+            self._prepare_exchange(b, sel)
+        self._prep_key = None
+        ahead = next_batch is not None and next_batch[0].numel() == B
+        if ahead:   # the next step's bucket kernel starts now, beside this step's gather
+            with ops.side():
+                self._prepare_bucket(b, sel ^ 1, next_batch[0], next_batch[1], next_batch[2])
+            self._prep_key = self._key(next_batch[0], next_batch[1])
+
+        def exchange_ahead():
+            # One communicator serves both streams, so collectives run in issue order: the next step's id exchange is
+            # issued where the main chain leaves the communicator idle (while the fairness / score kernel runs).
+            if ahead:
+                with ops.side(fork=False):
+                    self._prepare_exchange(b, sel ^ 1)
+        slot_u, slot_i, ids_recv = b.slot_u[sel], b.slot_i[sel], b.ids_recv[sel]
+        ops.gather_train_pair(self.U, self.I, self.hyper, ids_recv, 0, cap, n_slots, cap, S, b.rows_send, b.ws_u[sel],
+                              b.ws_i[sel], self.err)
         self._a2a(b.rows_recv, b.rows_send)
-        ops.shard_score(b.rows_recv, b.slot_u, b.slot_i, rating, sst if fair else None, G * B, b.pred, b.coef,
+        ops.shard_score(b.rows_recv, slot_u, slot_i, rating, sst if fair else None, G * B, b.pred, b.coef,
                         b.rec_send if fair else None, cap, S, cap, None if fair else b.sq, b.sq_part)
         if fair:
             self._a2a(b.rec_recv, b.rec_send)
-            ops.shard_fair(self.I, n_slots, b.rec_recv, cap, b.ids_recv, 2 * cap, S, self.objective, self.fair_weight,
+            exchange_ahead()
+            ops.shard_fair(self.I, n_slots, b.rec_recv, cap, ids_recv, 2 * cap, S, self.objective, self.fair_weight,
                            b.reply_send, b.sq_part, b.n_sq_part, b.scratch, self.err)
             self._a2a(b.reply_recv, b.reply_send)
         else:
             dist.all_reduce(b.sq, op=dist.ReduceOp.SUM, group=self.group)
+            exchange_ahead()
         # gradient rows for the owners; with a fairness term this kernel also folds the reply tails into the loss
-        ops.shard_grads(b.rows_recv, b.slot_u, b.slot_i, b.coef, b.reply_recv if fair else None, G, G * B,
+        ops.shard_grads(b.rows_recv, slot_u, slot_i, b.coef, b.reply_recv if fair else None, G, G * B,
                         self.fair_weight, b.loss if fair else None, cap, S, cap, b.g_send)
         loss = b.loss[0] if fair else b.sq[0] / float(G * B)
         self._armed = True
@@ -226,6 +299,7 @@ class ShardedFocfEngine:
         si = self.sweep_period if self.sweep_period is not None else max(8, math.ceil(self.I.n_rows / max(n_slots // 2, 1)))
         ops.apply_grad_pair(self.U, self.I, self.hyper, n_slots, cap, S, b.rows_send, b.g_recv, 0, cap, su, si)
         self._armed = False
+        self._sel ^= 1
         self.step_count += 1
 
     def flush(self):

@@ -62,7 +62,20 @@ class CpuOps:
         out[ok] = table.weight[table.ids[ok]]
         rows[p] = out
 
-    def gather_train_pair(self, ta, tb, hyper, ids, off_a, off_b, M, chunk, stride, rows, err):
+    def side(self, fork=True):
+        import contextlib
+        return contextlib.nullcontext()
+
+    def join_side(self):
+        pass
+
+    def alloc_ws(self, table, M):
+        return None
+
+    def sort_pair(self, ta, tb, ids, off_a, off_b, M, chunk, stride, ws_a, ws_b, err):
+        pass
+
+    def gather_train_pair(self, ta, tb, hyper, ids, off_a, off_b, M, chunk, stride, rows, ws_a, ws_b, err):
         self.gather_train(ta, hyper, ids, off_a, M, chunk, stride, rows, err)
         self.gather_train(tb, hyper, ids, off_b, M, chunk, stride, rows, err)
 

@@ -36,10 +36,12 @@ def _worker(rank, world, port, objective, out_dir):
                                 ops=CpuOps(), capacity_factor=1.5)
         T, B = 6, z["user_id"].shape[1] // world
         losses = []
+        sl = slice(rank * B, (rank + 1) * B)
+        batches = [[torch.tensor(z[k][t][sl]) for k in ("user_id", "item_id", "rating", "sst")] for t in range(T)]
         for t in range(T):
-            sl = slice(rank * B, (rank + 1) * B)
-            cols = [torch.tensor(z[k][t][sl]) for k in ("user_id", "item_id", "rating", "sst")]
-            loss, _ = eng.forward(*cols)
+            # every other step names its successor: both the look-ahead and the inline index path are exercised
+            nxt = (batches[t + 1][0], batches[t + 1][1], batches[t + 1][3]) if t + 1 < T and t % 3 != 2 else None
+            loss, _ = eng.forward(*batches[t], next_batch=nxt)
             losses.append(float(loss))
             eng.backward_adam()
         assert int(eng.err.item()) == 0

@@ -22,9 +22,10 @@ def pg():
     dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("lookahead", [False, True], ids=["inline", "lookahead"])
 @pytest.mark.parametrize("case", ["focf_none", "focf_value", "focf_absolute", "focf_under", "focf_over",
                                   "focf_value_grouped", "focf_value_d128", "focf_value_pad", "focf_value_long"])
-def test_sharded_hip_matches_reference_golden(pg, case):
+def test_sharded_hip_matches_reference_golden(pg, case, lookahead):
     from fairrec.sharded import ShardedFocfEngine
     z = np.load(os.path.join(GOLDEN, case + ".npz"))
     lr, wd, fw = (float(x) for x in z["hyper"][:3])
@@ -32,9 +33,13 @@ def test_sharded_hip_matches_reference_golden(pg, case):
                             str(z["objective"]), fw, lr, wd, capacity_factor=1.0)
     snaps = set(int(s) for s in z["snaps"])
     losses = []
-    for t in range(z["user_id"].shape[0]):
-        cols = [torch.tensor(z[k][t], device="cuda") for k in ("user_id", "item_id", "rating", "sst")]
-        loss, pred = eng.forward(*cols)
+    T = z["user_id"].shape[0]
+    batches = [[torch.tensor(z[k][t], device="cuda") for k in ("user_id", "item_id", "rating", "sst")] for t in range(T)]
+    for t in range(T):
+        nxt = None
+        if lookahead and t + 1 < T and t % 4 != 3:   # the next step's bucket / id exchange / sort runs on a side stream
+            nxt = (batches[t + 1][0], batches[t + 1][1], batches[t + 1][3])
+        loss, pred = eng.forward(*batches[t], next_batch=nxt)
         losses.append(loss.reshape(1).clone())
         if t == 0:
             np.testing.assert_allclose(pred.cpu().numpy(), z["pred_step1"], rtol=1e-4, atol=1e-6)
