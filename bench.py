@@ -153,7 +153,7 @@ def main():
         if sharded:
             # let the RCCL watchdog thread retire the warm-up collectives before capture begins: it polls their events
             # from another thread, which a capture in progress does not tolerate
-            time.sleep(1.0)
+            time.sleep(2.0)
         try:
             with torch.cuda.stream(side):
                 with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):
