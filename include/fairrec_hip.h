@@ -341,6 +341,26 @@ FR_API int fr_nfcf_loss(const float* y, const float* label, const float* sst, in
 FR_API int fr_adam_dense(float* p, const float* g, float* m, float* v, int64_t n, const fr_adam* adam, int32_t step,
                   void* stream);
 
+/* ---- negative sampler (next-row f-1: the batch feed), bit-exact with the reference's host sampler ---------------
+ * state: numpy's legacy RandomState layout in device memory, uint32 key[624] followed by uint32 pos (625 words), so the
+ * stream can be exchanged with np.random.get_state() / set_state() at any point.
+ *   fr_mt19937_seed     : np.random.seed(seed)                          (numpy mt19937_seed)
+ *   fr_sample_negatives : Sampler.sample_by_user_ids, sampler.py:283-303 -> sample_by_key_ids :145-197 with
+ *                         _uni_sampling = np.random.randint(low, high, .) :240-241:
+ *                         out[j] for j in [0, n_keys*num) is drawn for key key_ids[j % n_keys]; draw all, then re-draw
+ *                         -- from the continuing stream, in ascending position order -- exactly the positions whose
+ *                         value is in the key's used-set, until none is left (rounds_out[0] = number of rounds).
+ *                         used-set of key u = used_items[used_indptr[u] .. used_indptr[u+1]) sorted ascending.
+ *                         used_indptr = NULL: plain np.random.randint(low, high, n_keys*num) (key_ids unused).
+ *                         high - 1 - low < 2^32 - 1 (numpy then draws single 32-bit words, masked rejection).
+ * One workgroup per call; the state after the call is exactly numpy's, so calls chain without host syncs. */
+FR_API int fr_mt19937_seed(uint32_t* state, uint32_t seed, void* stream);
+FR_API size_t fr_sample_negatives_workspace_bytes(int64_t total);
+FR_API int fr_sample_negatives(uint32_t* state, int64_t low, int64_t high, const int64_t* key_ids, int64_t n_keys,
+                               int32_t num, const int64_t* used_indptr, const int32_t* used_items, int64_t n_users,
+                               int64_t* out, int32_t* rounds_out, void* ws, size_t ws_bytes, uint32_t* err_flag,
+                               void* stream);
+
 /* ---- built-in profiler -------------------------------------------------------------------------------
  * When enabled every kernel launch of this library is bracketed by a hipEvent pair recorded on the
  * launch stream; fr_prof_read synchronises the outstanding events and returns the accumulated device

@@ -61,6 +61,10 @@ _PROTOS = {
                                    c_void_p, c_int32, c_void_p, c_void_p]),
     "fr_bucket_pair_by_owner": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p,
                                         c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p]),
+    "fr_mt19937_seed": (c_int, [c_void_p, c_uint32, c_void_p]),
+    "fr_sample_negatives_workspace_bytes": (c_size_t, [c_int64]),
+    "fr_sample_negatives": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_int64,
+                                    c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
     "fr_unbucket_rows": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p]),
     "fr_bucket_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p]),
     "fr_focf_shard_score": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32,

@@ -58,3 +58,5 @@ def init_seed(seed, reproducibility=True):
     if torch.cuda.is_available():
         torch.cuda.manual_seed(seed)
         torch.cuda.manual_seed_all(seed)
+    from ..sampler.sampler import seed_all     # the device mirrors of numpy's global generator
+    seed_all(seed)

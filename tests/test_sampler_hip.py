@@ -1,0 +1,135 @@
+"""GPU: the device negative sampler (fr_sample_negatives through fairrec.sampler) is BIT-EXACT with the reference's
+numpy-based sampler: against numpy's own generator (available on the GPU box: it is the third-party arithmetic the
+reference calls), against the oracle, and against golden vectors produced by running the reference's Sampler."""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+CASES = sorted(glob.glob(os.path.join(GOLDEN, "sampler_*.npz")))
+
+
+def _rs(seed=None):
+    from fairrec.sampler import DeviceRandomState
+    return DeviceRandomState("cuda", seed)
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2020, 2 ** 32 - 1])
+def test_seed_matches_numpy_state(seed):
+    rs = _rs(seed)
+    np.random.seed(seed)
+    st, ref = rs.get_state(), np.random.get_state()
+    np.testing.assert_array_equal(st[1], ref[1])
+    assert st[2] == ref[2] == 624
+
+
+@pytest.mark.parametrize("high,n", [(3, 10), (5, 1000), (1026, 5000), (1683, 2048), (100001, 8192), (1000001, 8192),
+                                    (2 ** 31, 700), (2 ** 32 - 5, 1300), (2, 7), (1683, 1), (1683, 623), (1683, 625)])
+def test_randint_stream_is_numpy_bit_for_bit(high, n):
+    rs = _rs(2020)
+    np.random.seed(2020)
+    for k in range(4):                                   # one continuing stream across calls
+        a = rs.randint(1, high, n + 3 * k).cpu().numpy()
+        b = np.random.randint(1, high, n + 3 * k)
+        np.testing.assert_array_equal(a, b)
+    st, ref = rs.get_state(), np.random.get_state()
+    np.testing.assert_array_equal(st[1], ref[1])
+    assert st[2] == ref[2]
+
+
+def test_stream_hand_over_numpy_device_numpy():
+    rs = _rs(7)
+    np.random.seed(7)
+    np.testing.assert_array_equal(rs.randint(1, 1000, 333).cpu().numpy(), np.random.randint(1, 1000, 333))
+    np.random.set_state(rs.get_state())                  # host takes the stream over (e.g. the trainer's mask draws)
+    host = np.random.choice([0, 1], 5)
+    rs.set_state(np.random.get_state())                  # and hands it back
+    a = rs.randint(1, 77, 1000).cpu().numpy()
+    np.random.seed(7)
+    np.random.randint(1, 1000, 333)
+    np.testing.assert_array_equal(host, np.random.choice([0, 1], 5))
+    np.testing.assert_array_equal(a, np.random.randint(1, 77, 1000))
+
+
+class _DS:
+    uid_field, iid_field = "user_id", "item_id"
+
+    def __init__(self, user_num, item_num, u, i):
+        self.user_num, self.item_num = user_num, item_num
+        self.inter_feat = {"user_id": torch.from_numpy(u), "item_id": torch.from_numpy(i)}
+
+
+@pytest.mark.parametrize("path", CASES, ids=[os.path.basename(p)[8:-4] for p in CASES])
+def test_sampler_matches_reference_golden(path):
+    from fairrec.sampler import Sampler
+    z = np.load(path)
+    item_num, user_num = int(z["item_num"]), int(z["user_num"])
+    rs = _rs(int(z["seed"]))
+    sampler = Sampler("train", _DS(user_num, item_num, z["train_user"], z["train_item"]), "uniform", device="cuda",
+                      random_state=rs).set_phase("train")
+    for c in range(int(z["n_calls"])):
+        users = z[f"users{c}"]
+        neg = sampler.sample_by_user_ids(torch.from_numpy(users).cuda(), None, int(z[f"num{c}"]))
+        np.testing.assert_array_equal(neg.cpu().numpy(), z[f"neg{c}"])
+    st = rs.get_state()
+    np.testing.assert_array_equal(st[1], z["final_key"])
+    assert st[2] == int(z["final_pos"])
+    assert int(rs.err_flag.item()) == 0
+
+
+def test_sampler_matches_oracle_on_adversarial_used_sets():
+    """Users whose used-set is everything but one or two items (long rejection chains), interleaved with empty users,
+    B not a multiple of the wave or block size, num > 1."""
+    from fairrec.sampler import Sampler
+    from oracle import sampler as OS
+    rng = np.random.default_rng(3)
+    user_num, item_num = 40, 67
+    u, i = [], []
+    for usr in range(1, 12):                              # users 1..11: all items but (usr % 3 + 1) of them
+        keep = rng.choice(np.arange(1, item_num), size=usr % 3 + 1, replace=False)
+        its = np.setdiff1d(np.arange(1, item_num), keep)
+        u += [usr] * len(its)
+        i += list(its)
+    u, i = np.array(u, dtype=np.int64), np.array(i, dtype=np.int64)
+    used = [set() for _ in range(user_num)]
+    for a, b in zip(u, i):
+        used[a].add(int(b))
+    rs = _rs(99)
+    ors = OS.MT19937(99)
+    sampler = Sampler("train", _DS(user_num, item_num, u, i), device="cuda", random_state=rs).set_phase("train")
+    rounds = torch.zeros(1, dtype=torch.int32, device="cuda")
+    for n, num in ((1, 1), (63, 1), (65, 2), (1025, 1), (3000, 3)):
+        users = rng.integers(1, 25, size=n).astype(np.int64)
+        indptr, items, _ = sampler.used_ids
+        neg = rs.sample_excluding(1, item_num, torch.from_numpy(users).cuda(), num, indptr, items, rounds)
+        ref = OS.sample_by_key_ids(ors, users, num, used, item_num)
+        np.testing.assert_array_equal(neg.cpu().numpy(), ref)
+        assert int(rounds.item()) >= 1
+    st = rs.get_state()
+    np.testing.assert_array_equal(st[1], ors.key)
+    assert st[2] == ors.pos
+
+
+def test_full_size_batch_properties():
+    """BASELINE sizes (B = 8192, 1,000,001 items, 1,000,001 users x 20 interactions): every negative is in range and
+    outside its user's used-set; the stream position matches numpy when no rejection by used-set occurs."""
+    from fairrec.sampler import Sampler
+    g = torch.Generator().manual_seed(0)
+    user_num = item_num = 1_000_001
+    u = torch.arange(1, user_num).repeat_interleave(20)
+    i = torch.randint(1, item_num, (u.numel(),), generator=g)
+    rs = _rs(2020)
+    sampler = Sampler("train", _DS(user_num, item_num, u.numpy(), i.numpy()), device="cuda", random_state=rs).set_phase("train")
+    users = torch.randint(1, user_num, (8192,), generator=g)
+    neg = sampler.sample_by_user_ids(users.cuda(), None, 1).cpu()
+    assert int(neg.min()) >= 1 and int(neg.max()) < item_num
+    key = u * item_num + i
+    assert not torch.isin(users * item_num + neg, key).any()
+    np.random.seed(2020)
+    ref = np.random.randint(1, item_num, 8192)
+    same = neg.numpy() == ref
+    assert same.mean() > 0.99          # the rare used-set hits are re-drawn from later in the stream
