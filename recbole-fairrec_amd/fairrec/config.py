@@ -60,6 +60,28 @@ class Config:
             d["device"] = torch.device(d["device"])
         if isinstance(d.get("valid_metric"), str):
             d.setdefault("valid_metric_bigger", True)
+        self._set_train_neg_sample_args()
+        if d.get("MODEL_INPUT_TYPE") is None and d.get("model") is not None:   # configurator.py:274-275
+            try:
+                from .utils import get_model
+                d["MODEL_INPUT_TYPE"] = get_model(d["model"]).input_type
+            except (ValueError, ImportError):
+                pass
+
+    def _set_train_neg_sample_args(self):
+        """configurator.py:350-373: `neg_sampling: {uniform: 1}` -> train_neg_sample_args."""
+        d = self.final_config_dict
+        neg_sampling = d.get("neg_sampling")
+        if neg_sampling is None:
+            d["train_neg_sample_args"] = {"strategy": "none"}
+            return
+        if not isinstance(neg_sampling, dict):
+            raise ValueError(f"neg_sampling:[{neg_sampling}] should be a dict.")
+        distribution = list(neg_sampling.keys())[0]
+        if distribution not in ["uniform", "popularity"]:
+            raise ValueError(f"The distribution [{distribution}] of neg_sampling should in ['uniform', 'popularity']")
+        d["train_neg_sample_args"] = {"strategy": "by", "by": neg_sampling[distribution], "distribution": distribution,
+                                      "dynamic": neg_sampling.get("dynamic", "none")}
 
     def __getitem__(self, item):
         return self.final_config_dict.get(item, None)

@@ -42,11 +42,60 @@ class AbstractDataLoader:
 
 
 class TrainDataLoader(AbstractDataLoader):
-    """Fixed-size batches in (shuffled) dataset order, user features joined in."""
+    """general_dataloader.py:25-65 + NegSampleDataLoader (abstract_dataloader.py:110-198): fixed-size batches in
+    (shuffled) dataset order, user features joined in, and -- when `train_neg_sample_args` asks for it and a
+    `sampler` is given -- negatives drawn per batch and assembled pair-wise (`neg_<item field>` column) or point-wise
+    (negatives appended, `LABEL_FIELD` 1/0).  The sampler is fairrec.sampler.Sampler: ids are drawn on the device from
+    the device mirror of numpy's generator, bit-identical to the reference's host draws, so the batch never has to
+    leave the GPU (keep `dataset.inter_feat` there: `dataset.to(device)`)."""
+
+    def __init__(self, config, dataset, sampler=None, shuffle=False):
+        super().__init__(config, dataset, shuffle=shuffle)
+        self.sampler = sampler
+        self.uid_field, self.iid_field = dataset.uid_field, dataset.iid_field
+        self.neg_sample_args = config['train_neg_sample_args'] or {'strategy': 'none'}
+        self.times = 1
+        if sampler is not None and self.neg_sample_args['strategy'] == 'by':
+            if self.neg_sample_args.get('dynamic', 'none') != 'none':
+                raise NotImplementedError('dynamic negative sampling is not on the device path')
+            self.neg_sample_num = int(self.neg_sample_args['by'])
+            self.dl_format = config['MODEL_INPUT_TYPE']
+            from ..utils.enum_type import InputType
+            if self.dl_format == InputType.POINTWISE:
+                self.times = 1 + self.neg_sample_num
+                self.label_field = config['LABEL_FIELD']
+            elif self.dl_format == InputType.PAIRWISE:
+                self.times = self.neg_sample_num
+                self.neg_item_id = config['NEG_PREFIX'] + self.iid_field
+            else:
+                raise ValueError(f'`neg sampling by` with dl_format [{self.dl_format}] not been implemented.')
+            batch_num = max(int(config['train_batch_size']) // self.times, 1)     # general_dataloader.py:41-50
+            self.step = batch_num
+        else:
+            self.sampler = None
+
+    def _neg_sampling(self, inter_feat):
+        from ..utils.enum_type import InputType
+        neg = self.sampler.sample_by_user_ids(inter_feat[self.uid_field], inter_feat[self.iid_field], self.neg_sample_num)
+        dev = inter_feat[self.uid_field].device
+        neg = neg.to(dev)
+        if self.dl_format == InputType.PAIRWISE:                 # abstract_dataloader.py:182-188
+            out = inter_feat.repeat(self.times)
+            out.update(Interaction({self.neg_item_id: neg}))
+            return out
+        pos = len(inter_feat)                                    # abstract_dataloader.py:190-198
+        out = inter_feat.repeat(self.times)
+        out[self.iid_field][pos:] = neg
+        labels = torch.zeros(pos * self.times, device=dev)
+        labels[:pos] = 1.0
+        out.update(Interaction({self.label_field: labels}))
+        return out
 
     def _next_batch_data(self):
         cur = self.dataset[self.pr:self.pr + self.step]
         self.pr += self.step
+        if self.sampler is not None:
+            cur = self._neg_sampling(cur)
         return self.dataset.join(cur)
 
 

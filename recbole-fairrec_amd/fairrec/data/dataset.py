@@ -51,6 +51,13 @@ class InteractionDataset:
     def __getitem__(self, index):
         return self.inter_feat[index]
 
+    def to(self, device):
+        """Keep the interaction and user-feature columns resident on `device` (the batch feed then never leaves it)."""
+        self.inter_feat = self.inter_feat.to(device)
+        if self.user_feat is not None:
+            self.user_feat = self.user_feat.to(device)
+        return self
+
     def sort(self, by, ascending=True):
         self.inter_feat.sort(by=by, ascending=ascending)
 

@@ -110,7 +110,8 @@ class Interaction:
 
     def _reindex(self, index):
         for k in self.interaction:
-            self.interaction[k] = self.interaction[k][index]
+            v = self.interaction[k]
+            self.interaction[k] = v[index.to(v.device)]
 
     def shuffle(self):
         self._reindex(torch.randperm(self.length))   # same RNG consumer as interaction.py:293-297

@@ -133,3 +133,55 @@ def test_full_size_batch_properties():
     ref = np.random.randint(1, item_num, 8192)
     same = neg.numpy() == ref
     assert same.mean() > 0.99          # the rare used-set hits are re-drawn from later in the stream
+
+
+@pytest.mark.parametrize("model,pairwise", [("PFCN_PMF", True), ("NFCF", False)])
+def test_train_dataloader_negative_sampling_on_device(model, pairwise):
+    """TrainDataLoader with `neg_sampling: {uniform: k}`: epoch shuffle by torch.randperm (interaction.py:293-297), one
+    continuing numpy-compatible stream across batches and epochs, pair-wise / point-wise assembly
+    (abstract_dataloader.py:182-198); everything stays on the GPU."""
+    from fairrec.config import Config
+    from fairrec.data.dataloader import TrainDataLoader
+    from fairrec.data.dataset import synthetic_dataset
+    from fairrec.sampler import DeviceRandomState, Sampler
+    from oracle import sampler as OS
+    k = 1 if pairwise else 2
+    cfg = Config(model=model, config_dict={"train_batch_size": 96, "neg_sampling": {"uniform": k}, "device": "cuda",
+                                           "LABEL_FIELD": "label"})
+    ds = synthetic_dataset(cfg, n_users=60, n_items=50, n_inter=500, seed=3)
+    u_all, i_all = ds.inter_feat["user_id"].numpy().copy(), ds.inter_feat["item_id"].numpy().copy()
+    used = [set() for _ in range(60)]
+    for a, b in zip(u_all, i_all):
+        used[a].add(int(b))
+    rs = DeviceRandomState("cuda", 2020)
+    sampler = Sampler("train", ds, device="cuda", random_state=rs).set_phase("train")
+    ds.to("cuda")
+    dl = TrainDataLoader(cfg, ds, sampler=sampler, shuffle=True)
+    step = 96 // (k if pairwise else 1 + k)
+    assert dl.step == step
+    ors = OS.MT19937(2020)
+    torch.manual_seed(5)
+    order = np.arange(500)
+    for epoch in range(2):
+        batches = list(dl)
+        gen = torch.Generator().manual_seed(5)
+        for _ in range(epoch + 1):
+            perm = torch.randperm(500, generator=gen).numpy()
+        order = order[perm] if epoch else perm          # the dataset is re-shuffled in place every epoch
+        u_ep, i_ep = u_all[order], i_all[order]
+        assert len(batches) == -(-500 // step)
+        for b, inter in enumerate(batches):
+            us, its = u_ep[b * step:(b + 1) * step], i_ep[b * step:(b + 1) * step]
+            neg = OS.sample_by_key_ids(ors, us, k, used, 50)
+            assert inter["user_id"].is_cuda
+            if pairwise:
+                np.testing.assert_array_equal(inter["user_id"].cpu().numpy(), np.tile(us, k))
+                np.testing.assert_array_equal(inter["item_id"].cpu().numpy(), np.tile(its, k))
+                np.testing.assert_array_equal(inter["neg_item_id"].cpu().numpy(), neg)
+            else:
+                np.testing.assert_array_equal(inter["user_id"].cpu().numpy(), np.tile(us, 1 + k))
+                np.testing.assert_array_equal(inter["item_id"].cpu().numpy(), np.concatenate([its, neg]))
+                lab = np.zeros(len(us) * (1 + k), dtype=np.float32)
+                lab[:len(us)] = 1.0
+                np.testing.assert_array_equal(inter["label"].cpu().numpy(), lab)
+            assert "gender" in inter            # user features joined on the device
