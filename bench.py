@@ -43,6 +43,13 @@ def synth_batches(n_batches, batch, n_users, n_items, seed, item_dist="uniform")
     if item_dist == "zipf":
         x = torch.rand((n_batches, batch), generator=g)
         i = ((n_items - 1) * x * x).floor().to(torch.int64) + 1
+    elif item_dist == "grouped":
+        # the shape of FOCFDataLoader's item-complete batches (focf_dataloader.py:37-51): a batch is the
+        # union of ~100-interaction item histories, K ~ 82 distinct items, hot item rows
+        per = 100
+        k_items = batch // per + (1 if batch % per else 0)
+        picks = torch.randint(1, n_items, (n_batches, k_items), generator=g, dtype=torch.int64)
+        i = picks.repeat_interleave(per, dim=1)[:, :batch].contiguous()
     else:
         i = torch.randint(1, n_items, (n_batches, batch), generator=g, dtype=torch.int64)
     r = torch.randint(1, 6, (n_batches, batch), generator=g).to(torch.float32)
@@ -85,7 +92,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly instead of one hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--item-dist", default="uniform", choices=["uniform", "zipf"])
+    ap.add_argument("--item-dist", default="uniform", choices=["uniform", "zipf", "grouped"])
     ap.add_argument("--sweep", type=int, default=None, help="lazy-Adam sweep period (default: auto)")
     ap.add_argument("--force-sharded", action="store_true", help="use the row-sharded engine even on one GPU")
     args = ap.parse_args()

@@ -24,17 +24,69 @@ __device__ __forceinline__ void segment_update(const TableV& T, const AdamC& c, 
     load_row<E>(v, sv + (size_t)b0 * D, D, lane);
 #pragma unroll
     for (int e = 0; e < E; ++e) g.x[e] = 0.f;
-    for (int j = j0; j < j1; ++j) {
-        const int b = uniform(perm[j]);
-        const float cb = coef ? coef[b] : 1.f;
-        RowFrag<E> o;
-        load_row<E>(o, other + (size_t)lay.at(b) * D, D, lane);
-        {
+    // Members in ascending batch position (the reference's accumulation order).  A hot row can have hundreds of
+    // members (item-complete FOCF batches: ~100 per item), so the loop must not be a chain of dependent loads: the
+    // member ids and coefficients of up to 64 members are read with one coalesced load each and broadcast by
+    // readlane, and the rows of SEG_UNROLL members are in flight before the first of them is added.
+    constexpr int SEG_UNROLL = 8;
+    if (j1 - j0 < SEG_UNROLL) {      // the common case (uniform batches: one or two members): plain uniform loads
+        for (int j = j0; j < j1; ++j) {
+            const int b = uniform(perm[j]);
+            const float c1 = coef ? coef[b] : 1.f;
+            RowFrag<E> o;
+            load_row<E>(o, other + (size_t)lay.at(b) * D, D, lane);
+            {
+#pragma clang fp contract(off)
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    float prod = c1 * o.x[e];
+                    g.x[e] = g.x[e] + prod;
+                }
+            }
+        }
+    } else
+    for (int jb = j0; jb < j1; jb += 64) {
+        const int cnt = min(64, j1 - jb);
+        int my_b = 0;
+        float my_c = 1.f;
+        if (lane < cnt) {
+            my_b = perm[jb + lane];
+            if (coef) my_c = coef[my_b];
+        }
+        int t0 = 0;
+        for (; t0 + SEG_UNROLL <= cnt; t0 += SEG_UNROLL) {
+            RowFrag<E> o[SEG_UNROLL];
+            float cb[SEG_UNROLL];
+#pragma unroll
+            for (int q = 0; q < SEG_UNROLL; ++q) {
+                const int b = __builtin_amdgcn_readlane(my_b, t0 + q);
+                cb[q] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_c), t0 + q));
+                load_row<E>(o[q], other + (size_t)lay.at(b) * D, D, lane);
+            }
+            {
 #pragma clang fp contract(off)  // product rounded, then added: grad_row += coef * other_row (autograd order)
 #pragma unroll
-            for (int e = 0; e < E; ++e) {
-                float prod = cb * o.x[e];
-                g.x[e] = g.x[e] + prod;
+                for (int q = 0; q < SEG_UNROLL; ++q) {
+#pragma unroll
+                    for (int e = 0; e < E; ++e) {
+                        float prod = cb[q] * o[q].x[e];
+                        g.x[e] = g.x[e] + prod;
+                    }
+                }
+            }
+        }
+        for (; t0 < cnt; ++t0) {      // short segments (the common case: one or two members) and the tail
+            const int b = __builtin_amdgcn_readlane(my_b, t0);
+            const float c1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_c), t0));
+            RowFrag<E> o;
+            load_row<E>(o, other + (size_t)lay.at(b) * D, D, lane);
+            {
+#pragma clang fp contract(off)
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    float prod = c1 * o.x[e];
+                    g.x[e] = g.x[e] + prod;
+                }
             }
         }
     }
