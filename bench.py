@@ -57,6 +57,21 @@ def synth_batches(n_batches, batch, n_users, n_items, seed, item_dist="uniform")
     return u, i, r, s
 
 
+def stream_copy_ceiling(device, n_bytes=1 << 30, reps=10):
+    """On-box streaming ceiling: device-to-device copy of 1 GiB, read + write bytes per second."""
+    src = torch.empty(n_bytes // 4, dtype=torch.float32, device=device).normal_()
+    dst = torch.empty_like(src)
+    for _ in range(2):
+        dst.copy_(src)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        dst.copy_(src)
+    b.record()
+    torch.cuda.synchronize()
+    return 2.0 * n_bytes * reps / (a.elapsed_time(b) * 1e-3) / 1e9
+
+
 def xavier_tables(n_users, n_items, dim, seed, device):
     g = torch.Generator(device="cpu").manual_seed(seed + 1)
     U = torch.randn(n_users, dim, generator=g) * math.sqrt(2.0 / (n_users + dim))
@@ -219,8 +234,10 @@ def main():
         pmc_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc_file):
             traffic = json.load(open(pmc_file)).get(dom)
+        copy_gbs = stream_copy_ceiling(dev)
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "measured_copy_ceiling": round(copy_gbs, 1), "frac_of_measured_ceiling": round(achieved / copy_gbs, 4),
                     "algorithmic_bytes_per_launch": algo_bytes,
                     "kernel_us": {k: round(v, 2) for k, v in sorted(per_kernel.items())},
                     "dominant_rule": "longest kernel of the dependent chain; sort_segments_kernel runs on 1-2 workgroups, "

@@ -81,6 +81,11 @@ class GenericEngine:
             return LazyLookup.apply(self._weights[name], t, self._hyper(name), idx, self.err_flag)
         return t.gather(self._hyper(name), idx, self.err_flag)
 
+    def batch_segments(self, name: str):
+        """The object a loss kernel reads the sorted segments of the batch ids of table `name` from (`._ws`, `.dim`):
+        here the table itself, whose workspace the preceding lookup filled."""
+        return self._tables[name]
+
     # --- optimizer.step() -------------------------------------------------------------------------------
     def zero_grad(self, group=None):
         for name, d in self._dense.items():

@@ -61,3 +61,18 @@ class FairRecommender(AbstractRecommender):
         self.n_users = dataset.num(self.USER_ID)
         self.n_items = dataset.num(self.ITEM_ID)
         self.device = config['device']
+        # `row_sharded: True` under an initialised torch.distributed world: every embedding table of the model holds only
+        # the rows r with r mod world == rank (local row r div world), SURVEY.md §8-e
+        self.shard = None
+        if config['row_sharded']:
+            import torch.distributed as dist
+            if not dist.is_initialized():
+                raise RuntimeError('row_sharded needs an initialised torch.distributed process group')
+            self.shard = (dist.get_rank(), dist.get_world_size())
+
+    def _table_rows(self, n_rows):
+        """Rows of an n_rows table this rank holds."""
+        if self.shard is None:
+            return n_rows
+        rank, world = self.shard
+        return (n_rows - rank + world - 1) // world if n_rows > rank else 0

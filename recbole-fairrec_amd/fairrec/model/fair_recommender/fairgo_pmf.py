@@ -32,6 +32,10 @@ class FairGo_PMF(FairRecommender):
 
     def __init__(self, config, dataset):
         super().__init__(config, dataset)
+        if self.shard is not None:
+            # the finetune stage filters and propagates the WHOLE frozen tables every step (fairgo_pmf.py:175-199): it wants
+            # replicas (exact), not shards; the pretrain stage alone could shard like PFCN_PMF
+            raise NotImplementedError('FairGo on row-sharded tables is not built: run it with replicated tables')
         self.RATING = config['RATING_FIELD']
         self.n_layers = config['n_layers']
         self.act = config['activation']

@@ -61,8 +61,8 @@ class NFCF(FairRecommender):
         self.fair_weight = config['fair_weight']
         self.load_pretrain_path = config['load_pretrain_path']
 
-        self.user_embedding = nn.Embedding(self.n_users, self.embedding_size)      # default N(0,1) init, as nfcf.py:38-39
-        self.item_embedding = nn.Embedding(self.n_items, self.embedding_size)
+        self.user_embedding = nn.Embedding(self._table_rows(self.n_users), self.embedding_size)   # default N(0,1) init, as nfcf.py:38-39
+        self.item_embedding = nn.Embedding(self._table_rows(self.n_items), self.embedding_size)
         self.mlp_layers = MLPLayers([2 * self.embedding_size] + list(self.mlp_hidden_size) + [1], self.dropout)
         self._engine = None
         if self.load_pretrain_path is not None:
@@ -73,23 +73,50 @@ class NFCF(FairRecommender):
         (rows 1..), freeze it, re-initialise the item table.  One-off, whole-table, host-driven torch ops."""
         checkpoint = torch.load(pretrain_path, weights_only=False)
         self.load_state_dict(checkpoint['state_dict'], strict=False)
-        sst = user_data[self.sst_attr].to(self.user_embedding.weight.device)
+        dev = self.user_embedding.weight.device
+        sst = user_data[self.sst_attr].to(dev)
         vals = torch.unique(sst)
-        e = self.user_embedding.weight.data[1:].clone()
-        m1 = e[sst == vals[0]].mean(dim=0)
-        m2 = e[sst == vals[1]].mean(dim=0)
-        vb = (m1 - m2) / torch.linalg.norm(m1 - m2, keepdim=True)
-        self.user_embedding.weight.data[1:] = e - torch.mul(e, vb).sum(dim=1, keepdim=True) * vb
+        if self.shard is None:
+            e = self.user_embedding.weight.data[1:].clone()
+            m1 = e[sst == vals[0]].mean(dim=0)
+            m2 = e[sst == vals[1]].mean(dim=0)
+            vb = (m1 - m2) / torch.linalg.norm(m1 - m2, keepdim=True)
+            self.user_embedding.weight.data[1:] = e - torch.mul(e, vb).sum(dim=1, keepdim=True) * vb
+        else:
+            # the checkpoint holds this rank's shard; the two group means need every rank's rows: one all-reduce of
+            # two D-vectors + two counts (SURVEY.md §8-a19).  Global row of local row l: l * world + rank; row 0 = [PAD].
+            import torch.distributed as dist
+            rank, world = self.shard
+            w = self.user_embedding.weight.data
+            rows = torch.arange(w.shape[0], device=dev) * world + rank
+            real = rows >= 1
+            s_loc = torch.zeros(w.shape[0], dtype=sst.dtype, device=dev)
+            s_loc[real] = sst[rows[real] - 1]
+            g0, g1 = real & (s_loc == vals[0]), real & (s_loc == vals[1])
+            red = torch.cat([w[g0].sum(0), w[g1].sum(0), g0.sum().reshape(1).to(w.dtype), g1.sum().reshape(1).to(w.dtype)])
+            dist.all_reduce(red)
+            D = w.shape[1]
+            m1, m2 = red[:D] / red[2 * D], red[D:2 * D] / red[2 * D + 1]
+            vb = (m1 - m2) / torch.linalg.norm(m1 - m2, keepdim=True)
+            e = w[real].clone()
+            w[real] = e - torch.mul(e, vb).sum(dim=1, keepdim=True) * vb
         self.user_embedding.weight.requires_grad = False
-        self.item_embedding = nn.Embedding(self.n_items, self.embedding_size)
+        self.item_embedding = nn.Embedding(self._table_rows(self.n_items), self.embedding_size).to(dev)
 
     # --- engine -------------------------------------------------------------------------------------------
     def hip_engine(self) -> GenericEngine:
         uw = self.user_embedding.weight
         if self._engine is None or self._engine._tables["user_embedding.weight"].weight.data_ptr() != uw.data_ptr():
-            eng = GenericEngine(uw.device)
-            eng.add_table("user_embedding.weight", uw, trainable=uw.requires_grad)
-            eng.add_table("item_embedding.weight", self.item_embedding.weight, trainable=True)
+            if self.shard is None:
+                eng = GenericEngine(uw.device)
+                eng.add_table("user_embedding.weight", uw, trainable=uw.requires_grad)
+                eng.add_table("item_embedding.weight", self.item_embedding.weight, trainable=True)
+            else:
+                from ...sharded_engine import ShardedGenericEngine
+                eng = ShardedGenericEngine(uw.device)
+                eng.add_table("user_embedding.weight", uw, trainable=uw.requires_grad, n_rows_global=self.n_users)
+                eng.add_table("item_embedding.weight", self.item_embedding.weight, trainable=True,
+                              n_rows_global=self.n_items)
             for name, p in self.mlp_layers.named_parameters():
                 eng.add_dense("mlp_layers." + name, p)
             self._engine = eng
@@ -113,7 +140,7 @@ class NFCF(FairRecommender):
         y = self._score_logits(user, item)
         finetune = self.load_pretrain_path is not None
         sst = interaction[self.sst_attr].to(dev, torch.float32).contiguous() if finetune else None
-        item_table = eng._tables["item_embedding.weight"] if finetune else None
+        item_table = eng.batch_segments("item_embedding.weight") if finetune else None
         loss, _ = _NfcfLoss.apply(y, label, sst, float(self.fair_weight or 0.0), item_table, eng.err_flag)
         return loss
 

@@ -47,13 +47,13 @@ class PFCNBase(FairRecommender):
             self.dis_hidden_size_list = config['dis_hidden_size_list']
         self.activation = config['activation']
 
-        setattr(self, self.user_table_attr, nn.Embedding(self.n_users, self.embedding_size))
+        setattr(self, self.user_table_attr, nn.Embedding(self._table_rows(self.n_users), self.embedding_size))
         if self.biased:
-            self.user_bias = nn.Embedding(self.n_users, 1)
-        setattr(self, self.item_table_attr, nn.Embedding(self.n_items, self.embedding_size))
+            self.user_bias = nn.Embedding(self._table_rows(self.n_users), 1)
+        setattr(self, self.item_table_attr, nn.Embedding(self._table_rows(self.n_items), self.embedding_size))
         self._build_base_layers(config)
         if self.biased:
-            self.item_bias = nn.Embedding(self.n_items, 1)
+            self.item_bias = nn.Embedding(self._table_rows(self.n_items), 1)
             self.global_bias = nn.Parameter(torch.tensor(0.1))
         if self.filter_mode != 'none':
             self.filter_layer = self.init_filter()
@@ -127,16 +127,22 @@ class PFCNBase(FairRecommender):
     def hip_engine(self) -> GenericEngine:
         uw = getattr(self, self.user_table_attr).weight
         if self._engine is None or self._engine._tables[self._utab].weight.data_ptr() != uw.data_ptr():
-            eng = GenericEngine(uw.device)
             g = 'filter' if self.filter_mode != 'none' else None
-            eng.add_table(self._utab, uw, group=g)
-            eng.add_table(self._itab, getattr(self, self.item_table_attr).weight, group=g)
+            if self.shard is None:
+                eng = GenericEngine(uw.device)
+                tab = lambda name, w, n: eng.add_table(name, w, group=g)
+            else:   # row-sharded tables, replicated MLPs; BatchNorm statistics are per-rank (fairrec/sharded_engine.py)
+                from ...sharded_engine import ShardedGenericEngine
+                eng = ShardedGenericEngine(uw.device)
+                tab = lambda name, w, n: eng.add_table(name, w, group=g, n_rows_global=n)
+            tab(self._utab, uw, self.n_users)
+            tab(self._itab, getattr(self, self.item_table_attr).weight, self.n_items)
             for prefix, mod in self._base_dense_modules().items():
                 for n, p in mod.named_parameters():
                     eng.add_dense(f"{prefix}.{n}", p, group=g)
             if self.biased:
-                eng.add_table("user_bias.weight", self.user_bias.weight, group=g)
-                eng.add_table("item_bias.weight", self.item_bias.weight, group=g)
+                tab("user_bias.weight", self.user_bias.weight, self.n_users)
+                tab("item_bias.weight", self.item_bias.weight, self.n_items)
                 eng.add_dense("global_bias", self.global_bias, group=g)
             if self.filter_mode != 'none':
                 for i, mlp in self.filter_layer.items():

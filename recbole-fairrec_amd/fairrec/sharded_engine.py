@@ -1,0 +1,235 @@
+"""Row-sharded embedding tables for every model that trains through `GenericEngine` (NFCF, PFCN_*, FairGo_* pretrain):
+SURVEY.md §8-e items 1-3 and 5.  One process per GPU; table row r lives on rank `r mod G` as local row `r div G`, Adam
+state with it; the small dense parameters (MLPs, biases) are replicated and their gradients all-reduced.
+
+    lookup(name, idx):   bucket ids by owner -> all-to-all(ids) -> owners: lazy gather (fr_table_gather_train) ->
+                         all-to-all(rows) -> back to batch order              [differentiable: torch.autograd.Function]
+    backward:            dLoss/drows -> slot order (scaled 1/G) -> all-to-all -> parked on the owner
+    optimizer.step():    owners: duplicate-sum + Adam + sweeper (fr_table_apply_grad); dense: one flat all-reduce, then
+                         fr_adam_dense on every replica (identical inputs => replicas stay bit-identical)
+
+Semantics: every rank feeds its own batch; a step is ONE optimizer step whose embedding and dense gradients are those
+of the mean loss over the G local losses, i.e. the single-device step on the concatenated batch for every loss that is
+a mean over interactions (BCE, MSE, BPR).  Terms that are statistics OF the batch -- BatchNorm inside the PFCN MLPs,
+NFCF's differential-fairness regulariser, the B x B broadcast of PFCN_BiasedMF -- are evaluated per rank on the local
+batch ("parity is defined per-GPU-batch"); FOCF, whose fairness term needs the global per-item
+statistics, has its own exact engine (fairrec/sharded.py).
+
+Kernels come from an `ops` object (default: HIP through fairrec._C); tests inject a CPU double to run the schedule
+over gloo.  The product path is HIP only.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+from typing import Dict, Optional
+
+import torch
+import torch.distributed as dist
+
+from . import _C
+from .engine import GenericEngine
+from .optim import LazyTable
+from .sharded import exchange_capacity
+
+
+class HipTableOps:
+    """Per-table kernels of the sharded lookup (dense [G, cap] exchange buffers)."""
+
+    def bucket(self, idx, G, cap, send, slot, counts, err):
+        _C.check(_C.lib().fr_bucket_by_owner(idx.data_ptr(), idx.numel(), G, cap, cap, 0, send.data_ptr(), slot.data_ptr(),
+                                             counts.data_ptr(), None, 0, err.data_ptr(), _C.current_stream()),
+                 "fr_bucket_by_owner")
+
+    def gather_train(self, table, hyper, ids, M, rows, err):
+        table.gather_train_into(hyper, ids.data_ptr(), M, rows.data_ptr(), 0, 0, err)
+
+    def gather(self, table, hyper, ids, M, rows, err):
+        t = table.c(table.step)
+        _C.check(_C.lib().fr_table_gather(ctypes.byref(t), ctypes.byref(hyper.c()), ids.data_ptr(), M, rows.data_ptr(),
+                                          err.data_ptr(), _C.current_stream()), "fr_table_gather")
+
+    def unbucket_rows(self, src, slot, M, D, out):
+        _C.check(_C.lib().fr_unbucket_rows(src.data_ptr(), slot.data_ptr(), M, D, out.data_ptr(), _C.current_stream()),
+                 "fr_unbucket_rows")
+
+    def bucket_rows(self, src, scale, slot, M, D, dst):
+        _C.check(_C.lib().fr_bucket_rows(src.data_ptr(), _C.ptr(scale), slot.data_ptr(), M, D, dst.data_ptr(),
+                                         _C.current_stream()), "fr_bucket_rows")
+
+    def apply_grad(self, table, hyper, M, rows, grads, sweep):
+        table.apply_grad_from(hyper, M, rows.data_ptr(), grads.data_ptr(), sweep)
+
+    def adam_dense(self, p, g, m, v, hyper, step):
+        _C.check(_C.lib().fr_adam_dense(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(),
+                                        ctypes.byref(hyper.c()), step, _C.current_stream()), "fr_adam_dense")
+
+    def sort_local(self, idx, n_rows, dim, holder):
+        """Segments of a LOCAL id list in table-workspace layout (per-rank batch statistics, e.g. NFCF's DF term)."""
+        M = idx.numel()
+        need = _C.lib().fr_table_train_workspace_bytes(M, dim)
+        for k in ("_ws", "_ws_b"):
+            if getattr(holder, k, None) is None or getattr(holder, k).numel() < need:
+                setattr(holder, k, torch.empty(need, dtype=torch.uint8, device=idx.device))
+        _C.check(_C.lib().fr_table_sort2(idx.data_ptr(), idx.data_ptr(), n_rows, n_rows, M, 0, 0, dim, holder._ws.data_ptr(),
+                                         holder._ws_b.data_ptr(), need, None, _C.current_stream()), "fr_table_sort2")
+
+
+class _Exchange:
+    """Buffers of one table's lookup for one batch size."""
+
+    def __init__(self, G, M, cap, D, dev):
+        self.M, self.cap = M, cap
+        f32, i64, i32 = torch.float32, torch.int64, torch.int32
+        self.ids_send = torch.empty(G * cap, dtype=i64, device=dev)
+        self.ids_recv = torch.empty(G * cap, dtype=i64, device=dev)
+        self.slot = torch.empty(M, dtype=i32, device=dev)
+        self.counts = torch.empty(G, dtype=i32, device=dev)
+        self.rows_send = torch.zeros((G * cap, D), dtype=f32, device=dev)
+        self.rows_recv = torch.empty((G * cap, D), dtype=f32, device=dev)
+        self.g_send = torch.zeros((G * cap, D), dtype=f32, device=dev)
+        self.g_recv = torch.empty((G * cap, D), dtype=f32, device=dev)
+        self.scale = torch.full((M,), 1.0 / G, dtype=f32, device=dev)
+
+
+class _Segments:
+    """What a loss kernel needs from "the table the batch ids were looked up in": sorted segments + dim."""
+
+    def __init__(self, dim):
+        self.dim = dim
+        self._ws = None
+        self._ws_b = None
+
+
+class _ShardedLookup(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, weight, engine, name, idx):
+        ctx.engine, ctx.name = engine, name
+        return engine._exchange_forward(name, idx, train=True)
+
+    @staticmethod
+    def backward(ctx, grad_rows):
+        ctx.engine._exchange_backward(ctx.name, grad_rows)
+        return None, None, None, None
+
+
+class ShardedGenericEngine(GenericEngine):
+    def __init__(self, device, group=None, capacity_factor: float = 2.0, ops=None):
+        self.group = group
+        self.G = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.capacity_factor = capacity_factor
+        self.ops = ops
+        if ops is None:
+            super().__init__(device)
+            self.ops = HipTableOps()
+        else:                                   # CPU double (tests): no device library behind it
+            self._init_host_only(device)
+        self._ex: Dict[str, _Exchange] = {}
+        self._seg: Dict[str, _Segments] = {}
+        self._n_rows_global: Dict[str, int] = {}
+        self._flat: Optional[torch.Tensor] = None
+
+    def _init_host_only(self, device):
+        from .optim import AdamHyper
+        self.device = torch.device(device)
+        self._tables, self._weights, self._dense, self._group, self._hyper_of = {}, {}, {}, {}, {}
+        self.hyper = AdamHyper(device=self.device, cap=1)
+        self.optimizer, self.sweep_period = None, None
+        self.err_flag = torch.zeros(1, dtype=torch.int32, device=self.device)
+
+    # --- registration: `weight` is this rank's SHARD (rows rank, rank + G, ...) --------------------------------
+    def add_table(self, name, weight, trainable=True, group=None, n_rows_global: Optional[int] = None, table=None):
+        if table is not None:                   # CPU double supplies its own table object
+            self._tables[name], self._weights[name], self._group[name] = table, weight, group
+            t = table
+        else:
+            t = super().add_table(name, weight, trainable, group)
+        self._n_rows_global[name] = int(n_rows_global if n_rows_global is not None else t.n_rows * self.G)
+        return t
+
+    # --- exchange ------------------------------------------------------------------------------------------
+    def _a2a(self, out, t):
+        dist.all_to_all_single(out, t, group=self.group)
+
+    def _buffers(self, name, M) -> _Exchange:
+        ex = self._ex.get(name)
+        if ex is None or ex.M != M:
+            cap = exchange_capacity(M, self.G, self.capacity_factor)
+            ex = self._ex[name] = _Exchange(self.G, M, cap, self._tables[name].dim, self.device)
+        return ex
+
+    def _exchange_forward(self, name, idx, train):
+        t, ops, G = self._tables[name], self.ops, self.G
+        M = idx.numel()
+        ex = self._buffers(name, M)
+        n_slots = G * ex.cap
+        ops.bucket(idx, G, ex.cap, ex.ids_send, ex.slot, ex.counts, self.err_flag)
+        self._a2a(ex.ids_recv, ex.ids_send)
+        if train:
+            ops.gather_train(t, self._hyper(name), ex.ids_recv, n_slots, ex.rows_send, self.err_flag)
+        else:
+            ops.gather(t, self._hyper(name), ex.ids_recv, n_slots, ex.rows_send, self.err_flag)
+        self._a2a(ex.rows_recv, ex.rows_send)
+        out = torch.empty((M, t.dim), dtype=torch.float32, device=self.device)
+        ops.unbucket_rows(ex.rows_recv, ex.slot, M, t.dim, out)
+        self._last_idx = getattr(self, "_last_idx", {})
+        self._last_idx[name] = idx
+        return out
+
+    def _exchange_backward(self, name, grad_rows):
+        t, ex = self._tables[name], self._ex[name]
+        grad_rows = grad_rows.contiguous()
+        # the local loss is a mean over the local batch: 1/G makes the step that of the mean over the global batch
+        self.ops.bucket_rows(grad_rows, ex.scale, ex.slot, ex.M, t.dim, ex.g_send)
+        self._a2a(ex.g_recv, ex.g_send)
+        t._grad_rows = ex.g_recv
+
+    def lookup(self, name, idx):
+        t = self._tables[name]
+        idx = idx.to(self.device, torch.int64).contiguous()
+        if t.trainable and torch.is_grad_enabled():
+            return _ShardedLookup.apply(self._weights[name], self, name, idx)
+        return self._exchange_forward(name, idx, train=False)
+
+    def batch_segments(self, name):
+        """Sorted segments of THIS rank's ids of the last lookup in `name` (per-rank batch statistics)."""
+        seg = self._seg.setdefault(name, _Segments(self._tables[name].dim))
+        self.ops.sort_local(self._last_idx[name], self._n_rows_global[name], seg.dim, seg)
+        return seg
+
+    # --- optimizer.step() ------------------------------------------------------------------------------------
+    def backward_adam(self, group=None):
+        G = self.G
+        for name, t in self._tables.items():
+            if not (t.trainable and t._pending is not None):
+                continue
+            if not self._owned(name, group) or t._grad_rows is None:
+                t._pending = None
+                t._grad_rows = None
+                continue
+            ex = self._ex[name]
+            n_slots = G * ex.cap
+            s = self.sweep_period if self.sweep_period is not None else max(8, math.ceil(t.n_rows / max(n_slots // 2, 1)))
+            self.ops.apply_grad(t, self._hyper(name), n_slots, ex.rows_send, t._grad_rows, s)
+            t._grad_rows = None
+        live = [(name, d) for name, d in self._dense.items() if d.p.grad is not None and self._owned(name, group)]
+        if not live:
+            return
+        # one flat all-reduce for the replicated dense gradients
+        n = sum(d.p.numel() for _, d in live)
+        if self._flat is None or self._flat.numel() < n:
+            self._flat = torch.empty(n, dtype=torch.float32, device=self.device)
+        flat = self._flat[:n]
+        torch.cat([d.p.grad.reshape(-1) for _, d in live], out=flat)
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+        flat.mul_(1.0 / G)
+        off = 0
+        for name, d in live:
+            k = d.p.numel()
+            d.step += 1
+            h = self._hyper(name)
+            h.check_step(d.step)
+            self.ops.adam_dense(d.p.data, flat[off:off + k], d.m, d.v, h, d.step)
+            d.p.grad = None
+            off += k

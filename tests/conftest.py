@@ -19,3 +19,18 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(scope="session")
+def rccl_world1():
+    """A 1-rank RCCL world (every kernel and every collective call of the sharded paths runs; the multi-rank exchange
+    schedules are covered over gloo)."""
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29631")
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    yield
+    if dist.is_initialized():
+        dist.destroy_process_group()

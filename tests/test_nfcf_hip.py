@@ -24,8 +24,11 @@ class _DS:
         return self._uf
 
 
+@pytest.mark.parametrize("sharded", [False, True], ids=["single", "row_sharded"])
 @pytest.mark.parametrize("path", CASES, ids=[os.path.basename(p)[:-4] for p in CASES])
-def test_nfcf_training_matches_reference_golden(path, tmp_path):
+def test_nfcf_training_matches_reference_golden(path, tmp_path, sharded, request):
+    if sharded:     # the row-sharded engine as a 1-rank RCCL world: same goldens (fairrec/sharded_engine.py)
+        request.getfixturevalue("rccl_world1")
     from fairrec.config import Config
     from fairrec.data.interaction import Interaction
     from fairrec.model.fair_recommender.nfcf import NFCF
@@ -36,7 +39,8 @@ def test_nfcf_training_matches_reference_golden(path, tmp_path):
     n_users, D = z["init.user_embedding.weight"].shape
     n_items = z["init.item_embedding.weight"].shape[0]
     cfg = Config(model="NFCF", config_dict={"embedding_size": D, "mlp_hidden_size": [int(h) for h in z["hidden"]],
-                                            "dropout": p, "fair_weight": fw, "device": "cuda", "load_pretrain_path": None})
+                                            "dropout": p, "fair_weight": fw, "device": "cuda", "load_pretrain_path": None,
+                                            "row_sharded": sharded})
     model = NFCF(cfg, _DS(n_users, n_items, z["gender"]))
     init = {k[5:]: torch.tensor(z[k]) for k in z.files if k.startswith("init.")}
     if stage == "finetune":     # the state reset_params produced in the reference (its projection is pinned in the oracle test)

@@ -30,8 +30,11 @@ def _load_mlp(mlp, z, prefix):
     mlp.load_state_dict(sd)
 
 
+@pytest.mark.parametrize("sharded", [False, True], ids=["single", "row_sharded"])
 @pytest.mark.parametrize("path", CASES, ids=[os.path.basename(p)[:-4] for p in CASES])
-def test_pfcn_training_matches_reference_golden(path):
+def test_pfcn_training_matches_reference_golden(path, sharded, request):
+    if sharded:     # the row-sharded engine as a 1-rank RCCL world: same goldens (fairrec/sharded_engine.py)
+        request.getfixturevalue("rccl_world1")
     from fairrec.config import Config
     from fairrec.data.interaction import Interaction
     from fairrec.optim import FusedLazyAdam
@@ -48,7 +51,8 @@ def test_pfcn_training_matches_reference_golden(path):
                                           "dis_hidden_size_list": [int(h) for h in z["dis_hidden"]], "dis_dropout": p,
                                           "dis_weight": dis_weight, "device": "cuda", "dropout": 0.0,
                                           "mlp_hidden_size_list": [8, 4], "num_layers": 2, "mlp_dropout": 0.0,
-                                          "mlp_activation": "relu", "dis_activation": "leakyrelu", "activation": "leakyrelu"})
+                                          "mlp_activation": "relu", "dis_activation": "leakyrelu", "activation": "leakyrelu",
+                                          "row_sharded": sharded})
     model = get_model(name)(cfg, _DS(n_users, n_items, z))
     model.load_state_dict({k[11:]: torch.tensor(z[k]) for k in z.files if k.startswith("init.model.")})
     model = model.to("cuda")

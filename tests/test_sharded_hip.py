@@ -13,13 +13,8 @@ GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 
 
 @pytest.fixture(scope="module")
-def pg():
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29631")
-    if not dist.is_initialized():
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+def pg(rccl_world1):
     yield
-    dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("lookahead", [False, True], ids=["inline", "lookahead"])
