@@ -32,8 +32,17 @@ def run_recbole(model=None, dataset=None, config_file_list=None, config_dict=Non
         dataset = synthetic_dataset(config, config['synthetic_users'] or 1000, config['synthetic_items'] or 500,
                                     config['synthetic_interactions'] or 50000, seed=config['seed'])
     train_set, valid_set, test_set = split_dataset(dataset)
-    loader_cls = FOCFDataLoader if config['model'] == 'FOCF' and config['item_grouped_batches'] else TrainDataLoader
-    train_data = loader_cls(config, train_set, shuffle=True)
+    if config['model'] == 'FOCF' and config['item_grouped_batches']:
+        train_data = FOCFDataLoader(config, train_set, shuffle=True)
+    elif (config['train_neg_sample_args'] or {}).get('strategy') == 'by' and config['device'].type == 'cuda':
+        # negatives are drawn on the device, bit-identical to the reference's host sampler (fairrec/sampler); the
+        # interaction columns stay resident on the GPU
+        from .sampler import Sampler
+        sampler = Sampler(['train', 'valid', 'test'], [train_set, valid_set, test_set],
+                          config['train_neg_sample_args']['distribution'], device=config['device']).set_phase('train')
+        train_data = TrainDataLoader(config, train_set.to(config['device']), sampler=sampler, shuffle=True)
+    else:
+        train_data = TrainDataLoader(config, train_set, shuffle=True)
     valid_data = TrainDataLoader(config, valid_set)
     test_data = TrainDataLoader(config, test_set)
     init_seed(config['seed'], config['reproducibility'])
@@ -41,6 +50,10 @@ def run_recbole(model=None, dataset=None, config_file_list=None, config_dict=Non
     logger.info(model_obj)
     trainer = get_trainer(None, config['model'])(config, model_obj)
     best_valid_score, best_valid_result = trainer.fit(train_data, valid_data, saved=saved)
-    test_result = trainer.evaluate(test_data, load_best_model=saved)
+    try:
+        test_result = trainer.evaluate(test_data, load_best_model=saved)
+    except NotImplementedError as e:       # ranking evaluation of the filtered models: SURVEY.md §8 next-row f-2
+        logger.warning('evaluation skipped: %s', e)
+        test_result = None
     return {'best_valid_score': best_valid_score, 'valid_score_bigger': config['valid_metric_bigger'],
             'best_valid_result': best_valid_result, 'test_result': test_result}

@@ -93,6 +93,26 @@ def global_random_state(device) -> DeviceRandomState:
     return _GLOBAL[key]
 
 
+class host_numpy_stream:
+    """`with host_numpy_stream():` -- host code inside draws from np.random exactly where the reference would: the
+    device mirror(s) of numpy's global generator hand the stream to numpy on entry and take it back on exit (a 2.5 KB
+    copy each way; meant for the rare host draws between batches -- per-epoch attribute masks, FOCF's item picks).
+    Without a device mirror in use it does nothing."""
+
+    def __enter__(self):
+        self._rs = next(iter(_GLOBAL.values()), None)
+        if self._rs is not None:
+            np.random.set_state(self._rs.get_state())
+        return self
+
+    def __exit__(self, *exc):
+        if self._rs is not None:
+            st = np.random.get_state()
+            for rs in _GLOBAL.values():
+                rs.set_state(st)
+        return False
+
+
 def seed_all(seed: int):
     for rs in _GLOBAL.values():
         rs.seed(seed)

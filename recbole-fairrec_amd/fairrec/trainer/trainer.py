@@ -20,6 +20,7 @@ import numpy as np
 import torch
 
 from ..optim import FusedLazyAdam
+from ..sampler import host_numpy_stream
 from ..utils import calculate_valid_score, dict2str, early_stopping, ensure_dir, get_local_time
 
 
@@ -42,7 +43,7 @@ class Trainer(AbstractTrainer):
         self.learner = config['learner'] or 'adam'
         self.learning_rate = config['learning_rate']
         self.epochs = config['epochs']
-        self.eval_step = min(config['eval_step'] or 1, self.epochs)
+        self.eval_step = min(config['eval_step'] if config['eval_step'] is not None else 1, self.epochs)
         self.stopping_step = config['stopping_step']
         self.clip_grad_norm = config['clip_grad_norm']
         self.valid_metric = (config['valid_metric'] or 'rmse').lower()
@@ -251,8 +252,9 @@ class PFCNTrainer(Trainer):
         dis_loss, filter_loss = 0., 0.
         if self.filter_mode != 'none':
             mask = np.zeros(self.sst_num)
-            while mask.sum() == 0:
-                mask = np.random.choice([0, 1], self.sst_num)
+            with host_numpy_stream():      # same position in numpy's stream as the reference, also with a device feed
+                while mask.sum() == 0:
+                    mask = np.random.choice([0, 1], self.sst_num)
             sst_list = [sst for i, sst in self.mask_label.items() if mask[i] != 0]
             if epoch_idx % self.config['train_epoch_interval'] == 0:
                 self.optimizer = self.optimizer_filter

@@ -185,3 +185,31 @@ def test_train_dataloader_negative_sampling_on_device(model, pairwise):
                 lab[:len(us)] = 1.0
                 np.testing.assert_array_equal(inter["label"].cpu().numpy(), lab)
             assert "gender" in inter            # user features joined on the device
+
+
+def test_host_draws_interleave_with_device_draws_like_one_numpy_stream():
+    """The trainers' per-epoch attribute-mask draw (trainer.py:879-882) and the batches' negative draws consume ONE
+    numpy stream in the reference.  With the device feed the stream is handed to numpy for the host draw and back."""
+    from fairrec.sampler import global_random_state, host_numpy_stream
+    from fairrec.utils import init_seed
+    rs = global_random_state("cuda")
+    init_seed(123)
+    a1 = rs.randint(1, 500, 700).cpu().numpy()
+    with host_numpy_stream():
+        m = np.random.choice([0, 1], 3)
+    a2 = rs.randint(1, 90, 1300).cpu().numpy()
+    np.random.seed(123)
+    np.testing.assert_array_equal(a1, np.random.randint(1, 500, 700))
+    np.testing.assert_array_equal(m, np.random.choice([0, 1], 3))
+    np.testing.assert_array_equal(a2, np.random.randint(1, 90, 1300))
+
+
+def test_quick_start_pfcn_with_device_negative_sampling(tmp_path):
+    """run_recbole for a pairwise model with the reference's default `neg_sampling: {uniform: 1}`: dataset resident on
+    the GPU, negatives from the device sampler (never a positive of train / valid / test), training end to end."""
+    from fairrec.quick_start import run_recbole
+    out = run_recbole(model="PFCN_PMF", config_dict={
+        "embedding_size": 16, "sst_attr_list": ["gender"], "filter_mode": "none", "epochs": 2, "train_batch_size": 256,
+        "synthetic_users": 200, "synthetic_items": 150, "synthetic_interactions": 4000, "device": "cuda",
+        "checkpoint_dir": str(tmp_path), "eval_step": 0}, saved=False)
+    assert out["test_result"] is None or isinstance(out["test_result"], dict)
