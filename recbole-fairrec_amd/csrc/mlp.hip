@@ -171,29 +171,36 @@ __global__ __launch_bounds__(256) void linear_bwd_weight_kernel(const float* __r
     f32x16 acc = {0};
     float bsum = 0.f;                        // bias gradient of column n0 + tid (blocks of the first k tile, tid < TM)
     const bool do_bias = bslab && blockIdx.y == 0 && tid < TM;
-    for (int mb = mlo; mb < mhi; mb += TK) {
+    constexpr int Q = (TM * TK) / 256;
+    float gq[Q], xq[Q];                      // the next chunk's operands, fetched while the current chunk is multiplied
+    auto fetch = [&](int mb) {
 #pragma unroll
-        for (int q = 0; q < (TM * TK) / 256; ++q) {
+        for (int q = 0; q < Q; ++q) {
             const int e = q * 256 + tid;
             const int r = e / TM, c = e % TM;     // r: m within chunk, c: column within tile
             const int m = mb + r;
-            {
-                const int n = n0 + c;
-                float g = 0.f;
-                if (m < mhi && n < N) g = dY[(size_t)m * N + n] * act_bwd(Y[(size_t)m * N + n], act);
-                Gs[r * (TM + 1) + c] = g;
+            const int n = n0 + c, k = c0 + c;
+            float g = 0.f, x = 0.f;
+            if (m < mhi && n < N) g = dY[(size_t)m * N + n] * act_bwd(Y[(size_t)m * N + n], act);
+            if (m < mhi && k < K) {
+                x = X.at(m, k);
+                if (mask) x = mask[(size_t)m * K + k] ? x * scale : 0.f;
             }
-            {
-                const int k = c0 + c;
-                float x = 0.f;
-                if (m < mhi && k < K) {
-                    x = X.at(m, k);
-                    if (mask) x = mask[(size_t)m * K + k] ? x * scale : 0.f;
-                }
-                Xs[r * (TN + 1) + c] = x;
-            }
+            gq[q] = g;
+            xq[q] = x;
+        }
+    };
+    if (mlo < mhi) fetch(mlo);
+    for (int mb = mlo; mb < mhi; mb += TK) {
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const int e = q * 256 + tid;
+            const int r = e / TM, c = e % TM;
+            Gs[r * (TM + 1) + c] = gq[q];
+            Xs[r * (TN + 1) + c] = xq[q];
         }
         __syncthreads();
+        if (mb + TK < mhi) fetch(mb + TK);
 #pragma unroll
         for (int kk = 0; kk < TK; kk += 2) {
             const float a = Gs[(kk + (lane >> 5)) * (TM + 1) + wm * 32 + (lane & 31)];
@@ -269,9 +276,11 @@ extern "C" int fr_linear_bwd_input(const float* dY, const float* Y, int32_t act,
     return FR_OK;
 }
 
-// row splits of the weight gradient: >= 512 rows each, enough blocks to fill 256 CUs, slab bounded by 64 MiB
+// row splits of the weight gradient (slab bounded by 64 MiB)
 static long long bwd_weight_splits(int64_t M, int32_t N, int32_t K) {
-    long long splits = (M + 511) / 512;
+    // >= 128 rows per split: at B = 8192 that is 64 splits, i.e. 64 x (N/64) x (K/64) workgroups -- enough to fill 256 CUs
+    // for the 128..512-wide layers of the reference's MLPs
+    long long splits = (M + 127) / 128;
     const long long cap = std::max<long long>(1, (64ll << 20) / ((long long)N * (K + 1) * (long long)sizeof(float)));
     return std::max<long long>(1, std::min<long long>(splits, std::min<long long>(cap, 1024)));
 }
