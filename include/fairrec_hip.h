@@ -361,6 +361,26 @@ FR_API int fr_sample_negatives(uint32_t* state, int64_t low, int64_t high, const
                                int64_t* out, int32_t* rounds_out, void* ws, size_t ws_bytes, uint32_t* err_flag,
                                void* stream);
 
+/* ---- evaluation metrics (next-row f-2), recbole/evaluator/metrics.py ------------------------------------------------
+ *   fr_topk_metrics           : rec_topk int32 [n_users, k+1] = hit flags of the ranked list | number of positives
+ *                               (collector.py:146-154) -> out[5][k] doubles = Hit, MRR, NDCG, Recall, Precision @ 1..k,
+ *                               means over users (metrics.py:40-232)
+ *   fr_group_sums             : stats[s][g][0..2] = sum value, count, sum wtrue over the members
+ *                               perm[seg_start[s] .. seg_start[s+1]) of segment s whose group index is g (perm = NULL:
+ *                               identity).  The (item, group) tables of the fairness metrics (:948-970, :1322-1335)
+ *   fr_fair_metrics_from_stats: out[0..4] = Value, Absolute, Under, Over unfairness (n_groups == 2; `+ 1e-5` counts as
+ *                               the reference) and DifferentialFairness (float32 table, alpha = 1/n_segments) as means
+ *                               over the segments (:972-979, :1068-1075, :1164-1171, :1260-1267, :1337-1342)
+ * Double-precision sums in a fixed order. */
+FR_API size_t fr_topk_metrics_workspace_bytes(int64_t n_users, int32_t k);
+FR_API int fr_topk_metrics(const int32_t* rec_topk, int64_t n_users, int32_t k, double* out, void* ws, size_t ws_bytes,
+                           void* stream);
+FR_API int fr_group_sums(const int64_t* perm, const int64_t* seg_start, int64_t n_segments, const int32_t* group,
+                         const float* value, const float* wtrue, int32_t n_groups, double* stats, void* stream);
+FR_API size_t fr_fair_metrics_workspace_bytes(int64_t n_segments);
+FR_API int fr_fair_metrics_from_stats(const double* stats, int64_t n_segments, int32_t n_groups, double* out, void* ws,
+                                      size_t ws_bytes, void* stream);
+
 /* ---- built-in profiler -------------------------------------------------------------------------------
  * When enabled every kernel launch of this library is bracketed by a hipEvent pair recorded on the
  * launch stream; fr_prof_read synchronises the outstanding events and returns the accumulated device

@@ -1,0 +1,207 @@
+// Evaluation metrics on the device: the reductions of recbole/evaluator/metrics.py without the host
+// round trip and without the reference's Python loops over interactions (:950-960) or over items x groups (:1331-1335).
+//
+//   topk_metrics_kernel      Hit / MRR / NDCG / Recall / Precision @ 1..K from the `rec.topk` matrix (:40-232)
+//   group_sums_kernel        per (item segment, group): sum of scores, count, count of positives -- the tables every
+//                            fairness metric starts from (:948-970, :1322-1335); same segment machinery as the FOCF
+//                            fairness term (16 lanes per segment, fixed order)
+//   fair_from_stats_kernel   Value / Absolute / Under / Over unfairness (:972-979 and siblings) and DifferentialFairness
+//                            (:1337-1342, float32 tables like the reference) as means over the items
+// All sums are double precision in a fixed order (bit-reproducible).
+#include "common.hpp"
+#include "kernels.hpp"
+
+namespace fr {
+
+__device__ __forceinline__ double wave_sum_d(double x) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+    return x;
+}
+
+// one wave per 64 users (lane = user); part[block][m][k], m = hit, mrr, ndcg, recall, precision
+__global__ __launch_bounds__(64) void topk_metrics_kernel(const int32_t* __restrict__ rec_topk, long long U, int K,
+                                                          double* __restrict__ part) {
+    const int lane = threadIdx.x;
+    const long long u = (long long)blockIdx.x * 64 + lane;
+    const bool ok = u < U;
+    const int32_t* row = rec_topk + (ok ? u : 0) * (long long)(K + 1);
+    const int pos_len = ok ? row[K] : 1;
+    const int ilen = pos_len < K ? pos_len : K;
+    int csum = 0;
+    double first_rr = 0.0, dcg = 0.0, idcg = 0.0;
+    double* out = part + (size_t)blockIdx.x * 5 * K;
+    for (int k = 0; k < K; ++k) {
+        const bool hit = ok && row[k] != 0;
+        const double disc = 1.0 / log2((double)(k + 2));
+        if (hit && csum == 0) first_rr = 1.0 / (double)(k + 1);
+        csum += hit ? 1 : 0;
+        if (hit) dcg += disc;
+        if (k < ilen) idcg += disc;
+        const double v0 = ok && csum > 0 ? 1.0 : 0.0;
+        const double v1 = ok ? first_rr : 0.0;
+        const double v2 = ok ? dcg / idcg : 0.0;
+        const double v3 = ok ? (double)csum / (double)pos_len : 0.0;
+        const double v4 = ok ? (double)csum / (double)(k + 1) : 0.0;
+        const double s0 = wave_sum_d(v0), s1 = wave_sum_d(v1), s2 = wave_sum_d(v2), s3 = wave_sum_d(v3),
+                     s4 = wave_sum_d(v4);
+        if (lane == 0) {
+            out[0 * K + k] = s0;
+            out[1 * K + k] = s1;
+            out[2 * K + k] = s2;
+            out[3 * K + k] = s3;
+            out[4 * K + k] = s4;
+        }
+    }
+}
+
+// out[j] = (sum over blocks, in block order, of part[b][j]) * scale          j < n
+__global__ __launch_bounds__(256) void column_sum_kernel(const double* __restrict__ part, long long blocks, int n,
+                                                         double scale, double* __restrict__ out) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    double a = 0.0;
+    for (long long b = 0; b < blocks; ++b) a += part[b * n + j];
+    out[j] = a * scale;
+}
+
+static constexpr int GS_GROUP = 16, GS_THREADS = 256, GS_MAXG = 8;
+
+// stats[k][g][0..2] = sum value, count, sum wtrue over the members perm[seg_start[k] .. seg_start[k+1]) with group g
+__global__ __launch_bounds__(GS_THREADS) void group_sums_kernel(const int64_t* __restrict__ perm,
+                                                                const int64_t* __restrict__ seg_start, long long K,
+                                                                const int32_t* __restrict__ group,
+                                                                const float* __restrict__ value,
+                                                                const float* __restrict__ wtrue, int G,
+                                                                double* __restrict__ stats) {
+    const int sub = threadIdx.x & (GS_GROUP - 1);
+    const long long k = (long long)blockIdx.x * (GS_THREADS / GS_GROUP) + threadIdx.x / GS_GROUP;
+    if (k >= K) return;   // whole 16-lane groups leave together
+    double sv[GS_MAXG], sc[GS_MAXG], st[GS_MAXG];
+#pragma unroll
+    for (int g = 0; g < GS_MAXG; ++g) sv[g] = sc[g] = st[g] = 0.0;
+    const long long j0 = seg_start[k], j1 = seg_start[k + 1];
+    for (long long j = j0 + sub; j < j1; j += GS_GROUP) {
+        const long long b = perm ? perm[j] : j;
+        const int g = group[b];
+        const double v = (double)value[b], t = wtrue ? (double)wtrue[b] : 0.0;
+#pragma unroll
+        for (int q = 0; q < GS_MAXG; ++q)
+            if (q == g) {
+                sv[q] += v;
+                sc[q] += 1.0;
+                st[q] += t;
+            }
+    }
+#pragma unroll
+    for (int q = 0; q < GS_MAXG; ++q) {
+        if (q >= G) break;
+#pragma unroll
+        for (int o = GS_GROUP / 2; o > 0; o >>= 1) {
+            sv[q] += __shfl_xor(sv[q], o, 64);
+            sc[q] += __shfl_xor(sc[q], o, 64);
+            st[q] += __shfl_xor(st[q], o, 64);
+        }
+        if (sub == 0) {
+            double* o3 = stats + ((size_t)k * G + q) * 3;
+            o3[0] = sv[q];
+            o3[1] = sc[q];
+            o3[2] = st[q];
+        }
+    }
+}
+
+// part[block][0..4] = sums over the block's items of: value, absolute, under, over terms (G == 2) and the DF epsilon
+__global__ __launch_bounds__(256) void fair_from_stats_kernel(const double* __restrict__ stats, long long K, int G,
+                                                              double* __restrict__ part) {
+    const long long k = (long long)blockIdx.x * 256 + threadIdx.x;
+    double t[5] = {0, 0, 0, 0, 0};
+    if (k < K) {
+        const double* s = stats + (size_t)k * G * 3;
+        if (G == 2) {
+            const double n0 = s[1] + 1e-5, n1 = s[4] + 1e-5;                  // sst_num += 1e-5, metrics.py:962
+            const double p0 = s[0] / n0, p1 = s[3] / n1, r0 = s[2] / n0, r1 = s[5] / n1;
+            t[0] = fabs((p0 - r0) - (p1 - r1));
+            t[1] = fabs(fabs(p0 - r0) - fabs(p1 - r1));
+            t[2] = fabs((r0 - p0 > 0 ? r0 - p0 : 0.0) - (r1 - p1 > 0 ? r1 - p1 : 0.0));
+            t[3] = fabs((p0 - r0 > 0 ? p0 - r0 : 0.0) - (p1 - r1 > 0 ? p1 - r1 : 0.0));
+        }
+        // DifferentialFairness: float32 table (score_sum + 1/K) / (count + 1), epsilon = max pairwise |log a - log b|
+        float eps = 0.f;
+        const double alpha = 1.0 / (double)K;
+        for (int i = 0; i < G; ++i) {
+            const float a = (float)((s[i * 3] + alpha) / (s[i * 3 + 1] + 1.0));
+            for (int j = i + 1; j < G; ++j) {
+                const float b = (float)((s[j * 3] + alpha) / (s[j * 3 + 1] + 1.0));
+                const float e = fabsf(logf(a) - logf(b));
+                eps = e > eps ? e : eps;
+            }
+        }
+        t[4] = (double)eps;
+    }
+    __shared__ double red[4][5];
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+        const double w = wave_sum_d(t[q]);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][q] = w;
+    }
+    __syncthreads();
+    if (threadIdx.x < 5) {
+        const int q = threadIdx.x;
+        part[(size_t)blockIdx.x * 5 + q] = ((red[0][q] + red[1][q]) + red[2][q]) + red[3][q];
+    }
+}
+
+}  // namespace fr
+
+using namespace fr;
+
+extern "C" size_t fr_topk_metrics_workspace_bytes(int64_t n_users, int32_t k) {
+    return n_users < 1 || k < 1 ? 0 : (size_t)((n_users + 63) / 64) * 5 * k * sizeof(double);
+}
+
+extern "C" int fr_topk_metrics(const int32_t* rec_topk, int64_t n_users, int32_t k, double* out, void* ws, size_t ws_bytes,
+                               void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    FR_CHECK_ARG(rec_topk && out && ws && n_users >= 1 && k >= 1 && ws_bytes >= fr_topk_metrics_workspace_bytes(n_users, k),
+                 "fr_topk_metrics: bad argument");
+    const long long blocks = (n_users + 63) / 64;
+    hipLaunchKernelGGL(topk_metrics_kernel, dim3((unsigned)blocks), dim3(64), 0, stream, rec_topk, (long long)n_users, (int)k,
+                       (double*)ws);
+    FR_CHECK_LAUNCH();
+    hipLaunchKernelGGL(column_sum_kernel, dim3((unsigned)((5 * k + 255) / 256)), dim3(256), 0, stream, (const double*)ws,
+                       blocks, 5 * k, 1.0 / (double)n_users, out);
+    FR_CHECK_LAUNCH();
+    return FR_OK;
+}
+
+extern "C" int fr_group_sums(const int64_t* perm, const int64_t* seg_start, int64_t n_segments, const int32_t* group,
+                             const float* value, const float* wtrue, int32_t n_groups, double* stats, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    FR_CHECK_ARG(seg_start && group && value && stats && n_segments >= 1 && n_groups >= 1 && n_groups <= GS_MAXG,
+                 "fr_group_sums: bad argument (1 <= n_groups <= %d)", GS_MAXG);
+    const long long per_block = GS_THREADS / GS_GROUP;
+    hipLaunchKernelGGL(group_sums_kernel, dim3((unsigned)((n_segments + per_block - 1) / per_block)), dim3(GS_THREADS), 0,
+                       stream, perm, seg_start, (long long)n_segments, group, value, wtrue, (int)n_groups, stats);
+    FR_CHECK_LAUNCH();
+    return FR_OK;
+}
+
+extern "C" size_t fr_fair_metrics_workspace_bytes(int64_t n_segments) {
+    return n_segments < 1 ? 0 : (size_t)((n_segments + 255) / 256) * 5 * sizeof(double);
+}
+
+extern "C" int fr_fair_metrics_from_stats(const double* stats, int64_t n_segments, int32_t n_groups, double* out, void* ws,
+                                          size_t ws_bytes, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    FR_CHECK_ARG(stats && out && ws && n_segments >= 1 && n_groups >= 1 && n_groups <= GS_MAXG &&
+                     ws_bytes >= fr_fair_metrics_workspace_bytes(n_segments), "fr_fair_metrics_from_stats: bad argument");
+    const long long blocks = (n_segments + 255) / 256;
+    hipLaunchKernelGGL(fair_from_stats_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, stats, (long long)n_segments,
+                       (int)n_groups, (double*)ws);
+    FR_CHECK_LAUNCH();
+    hipLaunchKernelGGL(column_sum_kernel, dim3(1), dim3(256), 0, stream, (const double*)ws, blocks, 5,
+                       1.0 / (double)n_segments, out);
+    FR_CHECK_LAUNCH();
+    return FR_OK;
+}

@@ -1,0 +1,147 @@
+"""Evaluation metrics on the device with the result keys of recbole/evaluator/metrics.py:
+'hit@k', 'mrr@k', 'ndcg@k', 'recall@k', 'precision@k' and '<Name> Unfairness of sensitive attribute <sst>' /
+'Differential Fairness of sensitive attribute <sst>', rounded to `metric_decimal_place`.
+
+Inputs are the arrays the reference's Collector gathers (collector.py:131-205), as device tensors:
+  rec_topk       [users, max(topk) + 1]  hit flags of the ranked list | number of positives
+  pos_score, pos_i                        score and item id of every positive (user, item) pair
+  neg_score, neg_i                        (uni100-style modes) the first len(pos) negatives of the batch order
+  sst[<name>]                             the user's attribute value per positive pair
+The torch ops here are index plumbing (sort / unique of the id columns); every reduction is a HIP kernel
+(csrc/metrics.hip: fr_topk_metrics, fr_group_sums, fr_fair_metrics_from_stats).
+"""
+from __future__ import annotations
+
+from typing import Dict, Iterable, Optional
+
+import torch
+
+from .. import _C
+
+
+def topk_metrics(rec_topk: torch.Tensor, topk: Iterable[int]) -> Dict[str, float]:
+    lib = _C.lib()
+    rec = rec_topk.to(torch.int32).contiguous()
+    U, K = rec.shape[0], rec.shape[1] - 1
+    out = torch.empty(5 * K, dtype=torch.float64, device=rec.device)
+    ws = torch.empty(lib.fr_topk_metrics_workspace_bytes(U, K), dtype=torch.uint8, device=rec.device)
+    _C.check(lib.fr_topk_metrics(rec.data_ptr(), U, K, out.data_ptr(), ws.data_ptr(), ws.numel(), _C.current_stream()),
+             "fr_topk_metrics")
+    vals = out.view(5, K).cpu()
+    res = {}
+    for m, name in enumerate(("hit", "mrr", "ndcg", "recall", "precision")):
+        for k in topk:
+            res[f"{name}@{k}"] = float(vals[m, k - 1])
+    return res
+
+
+def _group_index(sst: torch.Tensor):
+    """np.unique(sst_value, return_inverse=True): group index = rank of the value among the values present."""
+    vals, inv = torch.unique(sst, sorted=True, return_inverse=True)
+    return int(vals.numel()), inv.to(torch.int32).contiguous()
+
+
+def _group_sums(items: Optional[torch.Tensor], group, value, wtrue, G):
+    """stats [K, G, 3] over the distinct items (items = None: one segment)."""
+    lib = _C.lib()
+    dev = value.device
+    n = value.numel()
+    if items is None:
+        perm, seg_start, K = None, torch.tensor([0, n], dtype=torch.int64, device=dev), 1
+    else:
+        keys, perm = torch.sort(items, stable=True)
+        _, counts = torch.unique_consecutive(keys, return_counts=True)
+        K = counts.numel()
+        seg_start = torch.zeros(K + 1, dtype=torch.int64, device=dev)
+        torch.cumsum(counts, 0, out=seg_start[1:])
+    stats = torch.empty((K, G, 3), dtype=torch.float64, device=dev)
+    _C.check(lib.fr_group_sums(_C.ptr(perm), seg_start.data_ptr(), K, group.data_ptr(), value.contiguous().data_ptr(),
+                               _C.ptr(wtrue), G, stats.data_ptr(), _C.current_stream()), "fr_group_sums")
+    return stats, K
+
+
+def _from_stats(stats, K, G):
+    lib = _C.lib()
+    out = torch.empty(5, dtype=torch.float64, device=stats.device)
+    ws = torch.empty(lib.fr_fair_metrics_workspace_bytes(K), dtype=torch.uint8, device=stats.device)
+    _C.check(lib.fr_fair_metrics_from_stats(stats.data_ptr(), K, G, out.data_ptr(), ws.data_ptr(), ws.numel(),
+                                            _C.current_stream()), "fr_fair_metrics_from_stats")
+    return out.cpu()
+
+
+def fairness_metrics(pos_score, pos_i, sst: Dict[str, torch.Tensor], neg_score=None, neg_i=None, mode="full",
+                     value_type=True) -> Dict[str, float]:
+    """NonParity + DifferentialFairness per attribute; Value / Absolute / Under / Over unfairness on the FIRST attribute
+    (as the reference's classes read `sst_attr_list[0]`, metrics.py:905)."""
+    res = {}
+    pos_score = pos_score.to(torch.float32).contiguous()
+    first = True
+    for name, col in sst.items():
+        G, gidx = _group_index(col)
+        if G < 2:
+            raise ValueError(f'there is only one value for {name} sensitive attribute')
+        # NonParity (metrics.py:864-882): |difference| of the two group means, population std for more groups
+        st, _ = _group_sums(None, gidx, pos_score, None, G)
+        means = (st[0, :, 0] / st[0, :, 1]).cpu()
+        res[f'NonParity Unfairness of sensitive attribute {name}'] = float(
+            (means[0] - means[1]).abs() if G == 2 else means.std(unbiased=False))
+        st, K = _group_sums(pos_i, gidx, pos_score, None, G)
+        res[f'Differential Fairness of sensitive attribute {name}'] = float(_from_stats(st, K, G)[4])
+        if first and value_type:
+            if G != 2:
+                raise ValueError('sensitive attribute must be binary')
+            P = pos_score.numel()
+            if mode != 'full' and neg_i is not None:
+                # the j-th negative is attributed to the group of the j-th positive's user (metrics.py:957-960)
+                m = min(neg_i.numel(), P)
+                items = torch.cat([pos_i, neg_i[:m]])
+                value = torch.cat([pos_score, neg_score[:m].to(torch.float32)])
+                group = torch.cat([gidx, gidx[:m]])
+                wtrue = torch.cat([torch.ones(P, device=value.device), torch.zeros(m, device=value.device)])
+            else:
+                items, value, group, wtrue = pos_i, pos_score, gidx, torch.ones(P, device=pos_score.device)
+            st, K = _group_sums(items, group.contiguous(), value.contiguous(), wtrue.contiguous(), 2)
+            v = _from_stats(st, K, 2)
+            for q, label in enumerate(("Value", "Absolute", "Underestimation", "Overestimation")):
+                res[f'{label} Unfairness of sensitive attribute {name}'] = float(v[q])
+        first = False
+    return res
+
+
+class Evaluator:
+    """recbole/evaluator/evaluator.py: metric names from `config['metrics']` -> one result dict."""
+
+    TOPK = {"hit", "mrr", "ndcg", "recall", "precision"}
+    FAIR = {"nonparityunfairness", "valueunfairness", "absoluteunfairness", "underunfairness", "overunfairness",
+            "differentialfairness"}
+
+    def __init__(self, config):
+        self.config = config
+        self.metrics = [m.lower() for m in (config['metrics'] or [])]
+        self.topk = config['topk'] or [10]
+        if isinstance(self.topk, int):
+            self.topk = [self.topk]
+        self.decimal_place = config['metric_decimal_place'] if config['metric_decimal_place'] is not None else 4
+        self.mode = (config['eval_args'] or {}).get('mode', 'full')
+        unknown = [m for m in self.metrics if m not in self.TOPK | self.FAIR]
+        if unknown:
+            raise NotImplementedError(f'metrics {unknown} are not on the device path')
+
+    def evaluate(self, collected: Dict[str, torch.Tensor]) -> Dict[str, float]:
+        res = {}
+        if self.TOPK & set(self.metrics):
+            allk = topk_metrics(collected['rec.topk'], self.topk)
+            res.update({k: v for k, v in allk.items() if k.split('@')[0] in self.metrics})
+        if self.FAIR & set(self.metrics):
+            sst = {s: collected['data.' + s] for s in self.config['sst_attr_list']}
+            fair = fairness_metrics(collected['rec.positive_score'], collected['data.positive_i'], sst,
+                                    collected.get('rec.negative_score'), collected.get('data.negative_i'), self.mode,
+                                    value_type=bool({"valueunfairness", "absoluteunfairness", "underunfairness",
+                                                     "overunfairness"} & set(self.metrics)))
+            want = {"nonparityunfairness": "NonParity", "valueunfairness": "Value Unfairness",
+                    "absoluteunfairness": "Absolute", "underunfairness": "Underestimation",
+                    "overunfairness": "Overestimation", "differentialfairness": "Differential"}
+            for k, v in fair.items():
+                if any(k.startswith(p) for m, p in want.items() if m in self.metrics):
+                    res[k] = v
+        return {k: round(v, self.decimal_place) for k, v in res.items()}
