@@ -131,3 +131,18 @@ def test_exchange_capacity_fits_the_owner_sort():
             cap = exchange_capacity(B, G, 2.0)
             assert G * cap <= max(SORT_MAX, G) and cap >= min(B, -(-B // G))
     assert exchange_capacity(8192, 8, 2.0) == 2048 and exchange_capacity(8192, 1, 2.0) == 8192
+
+
+def test_recbole_import_alias_resolves_to_the_native_package():
+    """User code written against the reference's package path keeps working (plugin surface by name)."""
+    import fairrec.model.abstract_recommender as native
+    from recbole.model.abstract_recommender import FairRecommender
+    from recbole.quick_start import run_recbole
+    from recbole.trainer import PFCN_BiasedMFTrainer, Trainer
+    from recbole.utils import InputType, get_model, get_trainer
+    assert FairRecommender is native.FairRecommender and callable(run_recbole)
+    assert get_model("FOCF").__name__ == "FOCF" and get_model("FOCF").input_type == InputType.POINTWISE
+    assert get_trainer(None, "PFCN_BiasedMF") is PFCN_BiasedMFTrainer and get_trainer(None, "FOCF") is Trainer
+    import pytest
+    with pytest.raises(ImportError):
+        import recbole.utils.wandblogger  # noqa: F401  (not part of the hot path, not provided)
