@@ -245,6 +245,10 @@ FR_API int fr_bucket_rows(const float* src, const float* scale, const int32_t* s
  *                         the RECEIVED reply buffer (NULL for fair_objective none): K, fairness sum and squared-error
  *                         sum are folded over its G tails in rank order (identical on every rank) and
  *                         loss_out[0..2] = loss, mse, fair is written (may be NULL)
+ *   fr_focf_shard_nonparity_sums / _coef : fair_objective nonparity (focf.py:127-134) needs no item statistics, only
+ *                         the two group means of pred over the GLOBAL batch: _sums leaves this rank's (sum err^2,
+ *                         sum pred|g0, n0, sum pred|g1, n1) in out5 (one 5-float all-reduce makes them global); _coef
+ *                         adds the fairness part of dLoss/dpred to coef[b] in place and writes loss_out[0..2]
  * rows_u / rows_i / grad_*_slots are addressed by slot, so both may point at one shared [G, 2, cap, dim] buffer.
  */
 #define FR_SHARD_TAIL 3
@@ -256,6 +260,12 @@ FR_API int fr_focf_shard_fair(void* item_ws, size_t ws_bytes, int64_t n_slots, i
                               int32_t cap, const float* minmax, int32_t mm_count, int32_t mm_stride, int32_t objective,
                               float fair_weight, float* reply, const float* sq_part, int32_t n_sq_part, float* scratch,
                               uint32_t* err_flag, void* stream);
+FR_API int fr_focf_shard_nonparity_sums(const float* pred, const float* sst, int64_t B, const float* minmax,
+                                        int32_t mm_count, int32_t mm_stride, const float* sq_part, int32_t n_sq_part,
+                                        float* out5, void* stream);
+FR_API int fr_focf_shard_nonparity_coef(float* coef, const float* sst, int64_t B, const float* minmax, int32_t mm_count,
+                                        int32_t mm_stride, const float* global5, int64_t n_global, float fair_weight,
+                                        float* loss_out, uint32_t* err_flag, void* stream);
 FR_API int fr_focf_shard_grads(const float* rows_u, const float* rows_i, const int32_t* slot_u, const int32_t* slot_i,
                                const float* coef, const float* coef_slots, int32_t G, int64_t n_global,
                                float fair_weight, float* loss_out, int32_t cap, int32_t slot_stride,

@@ -457,6 +457,70 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float* __res
     }
 }
 
+// nonparity on the row-sharded path (focf.py:127-134 on the GLOBAL batch): this rank's share of the two group sums.
+// out5 = (sum of squared errors, sum pred | g0, count g0, sum pred | g1, count g1); an all-reduce makes them global.
+__global__ __launch_bounds__(1024) void focf_shard_nonparity_sums_kernel(const float* __restrict__ pred,
+                                                                         const float* __restrict__ sst, int B,
+                                                                         const float* __restrict__ minmax, int mm_count,
+                                                                         int mm_stride, const float* __restrict__ sq_part,
+                                                                         int n_sq_part, float* __restrict__ out5) {
+    __shared__ float red[5][16];
+    float smin = minmax[0], smax = minmax[1];
+    for (int q = 1; q < mm_count; ++q) {
+        smin = fminf(smin, minmax[q * mm_stride]);
+        smax = fmaxf(smax, minmax[q * mm_stride + 1]);
+    }
+    float v[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int q = threadIdx.x; q < n_sq_part; q += 1024) v[0] += sq_part[q];
+    for (int b = threadIdx.x; b < B; b += 1024) {
+        const float s = sst[b], pr = pred[b];
+        if (s == smin) { v[1] += pr; v[2] += 1.f; }
+        else if (s == smax) { v[3] += pr; v[4] += 1.f; }   // rows of a third group are ignored, as in the reference
+    }
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+        const float w = wave_sum(v[q]);
+        if ((threadIdx.x & 63) == 0) red[q][threadIdx.x >> 6] = w;
+    }
+    __syncthreads();
+    if (threadIdx.x < 5) {
+        float a = 0.f;
+        for (int w = 0; w < 16; ++w) a += red[threadIdx.x][w];
+        out5[threadIdx.x] = a;
+    }
+}
+
+// ... and, from the all-reduced sums, the fairness part of dLoss/dpred added to coef[b] and the loss
+__global__ __launch_bounds__(256) void focf_shard_nonparity_coef_kernel(float* __restrict__ coef,
+                                                                        const float* __restrict__ sst, int B,
+                                                                        const float* __restrict__ minmax, int mm_count,
+                                                                        int mm_stride, const float* __restrict__ g5,
+                                                                        float inv_n, float fair_weight,
+                                                                        float* __restrict__ loss_out, uint32_t* err) {
+    float smin = minmax[0], smax = minmax[1];
+    for (int q = 1; q < mm_count; ++q) {
+        smin = fminf(smin, minmax[q * mm_stride]);
+        smax = fmaxf(smax, minmax[q * mm_stride + 1]);
+    }
+    const float n0 = g5[2], n1 = g5[4];
+    const bool one_group = smin == smax || n1 == 0.f;     // reference: IndexError (sst_unique_value[1]) -- flag it
+    const float delta = one_group ? 0.f : g5[1] / n0 - g5[3] / n1;
+    const float dl = fminf(fmaxf(delta, -1.f), 1.f) * fair_weight;
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b < B && !one_group) {
+        const float s = sst[b];
+        if (s == smin) coef[b] += dl / n0;
+        else if (s == smax) coef[b] -= dl / n1;
+    }
+    if (b == 0) {
+        const float mse = g5[0] * inv_n, fair = one_group ? 0.f : smooth_l1(delta);
+        loss_out[0] = mse + fair_weight * fair;
+        loss_out[1] = mse;
+        loss_out[2] = fair;
+        if (one_group && err) atomicOr(err, FR_DEV_ERR_SST_GROUPS);
+    }
+}
+
 __global__ __launch_bounds__(256) void focf_shard_grads_kernel(const float* __restrict__ rows_u,
                                                                const float* __restrict__ rows_i,
                                                                const int32_t* __restrict__ slot_u,
@@ -703,6 +767,29 @@ extern "C" int fr_focf_shard_fair(void* item_ws, size_t ws_bytes, int64_t n_slot
         FR_LAUNCH(prof, focf_fair_kernel, dim3(blocks), dim3(FAIR_THREADS), 0, stream, fa, objective, fair_weight, 1,
                            err_flag);
     }
+    FR_CHECK_LAUNCH();
+    return FR_OK;
+}
+
+extern "C" int fr_focf_shard_nonparity_sums(const float* pred, const float* sst, int64_t B, const float* minmax,
+                                            int32_t mm_count, int32_t mm_stride, const float* sq_part, int32_t n_sq_part,
+                                            float* out5, void* stream_) {
+    FR_CHECK_ARG(pred && sst && minmax && sq_part && out5 && B >= 1 && mm_count >= 1 && n_sq_part >= 0,
+                 "fr_focf_shard_nonparity_sums: bad argument");
+    hipLaunchKernelGGL(focf_shard_nonparity_sums_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream_, pred, sst, (int)B,
+                       minmax, (int)mm_count, (int)mm_stride, sq_part, (int)n_sq_part, out5);
+    FR_CHECK_LAUNCH();
+    return FR_OK;
+}
+
+extern "C" int fr_focf_shard_nonparity_coef(float* coef, const float* sst, int64_t B, const float* minmax,
+                                            int32_t mm_count, int32_t mm_stride, const float* global5, int64_t n_global,
+                                            float fair_weight, float* loss_out, uint32_t* err_flag, void* stream_) {
+    FR_CHECK_ARG(coef && sst && minmax && global5 && loss_out && B >= 1 && mm_count >= 1 && n_global >= 1,
+                 "fr_focf_shard_nonparity_coef: bad argument");
+    hipLaunchKernelGGL(focf_shard_nonparity_coef_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream_, coef, sst, (int)B, minmax, (int)mm_count, (int)mm_stride, global5,
+                       1.f / (float)n_global, fair_weight, loss_out, err_flag);
     FR_CHECK_LAUNCH();
     return FR_OK;
 }

@@ -77,6 +77,10 @@ _PROTOS = {
                                     c_void_p]),
     "fr_focf_shard_fair": (c_int, [c_void_p, c_size_t, c_int64, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_int32,
                                    c_int32, c_float, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p]),
+    "fr_focf_shard_nonparity_sums": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int32, c_int32, c_void_p, c_int32,
+                                             c_void_p, c_void_p]),
+    "fr_focf_shard_nonparity_coef": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int32, c_int32, c_void_p, c_int64,
+                                             c_float, c_void_p, c_void_p, c_void_p]),
     "fr_focf_shard_grads": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int64, c_float,
                                     c_void_p, c_int32, c_int32, c_int32, c_int64, c_int32, c_void_p, c_void_p,
                                     c_void_p]),

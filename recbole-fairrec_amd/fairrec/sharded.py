@@ -138,6 +138,18 @@ class HipOps:
                                              sq_part.data_ptr(), n_sq_part, scratch.data_ptr(), err.data_ptr(),
                                              _C.current_stream()), "fr_focf_shard_fair")
 
+    def nonparity_sums(self, pred, sst, ids_recv, mm_slot, stride, G, sq_part, n_sq_part, out5):
+        _C.check(_C.lib().fr_focf_shard_nonparity_sums(pred.data_ptr(), sst.data_ptr(), pred.numel(),
+                                                       ids_recv.data_ptr() + 8 * mm_slot, G, 2 * stride,
+                                                       sq_part.data_ptr(), n_sq_part, out5.data_ptr(),
+                                                       _C.current_stream()), "fr_focf_shard_nonparity_sums")
+
+    def nonparity_coef(self, coef, sst, ids_recv, mm_slot, stride, G, global5, n_global, fair_weight, loss_out, err):
+        _C.check(_C.lib().fr_focf_shard_nonparity_coef(coef.data_ptr(), sst.data_ptr(), coef.numel(),
+                                                       ids_recv.data_ptr() + 8 * mm_slot, G, 2 * stride,
+                                                       global5.data_ptr(), n_global, fair_weight, loss_out.data_ptr(),
+                                                       err.data_ptr(), _C.current_stream()), "fr_focf_shard_nonparity_coef")
+
     def shard_grads(self, rows, slot_u, slot_i, coef, reply, G, n_global, fair_weight, loss_out, cap, slot_stride,
                     slot_offset, grads):
         B, D = slot_u.numel(), rows.shape[1]
@@ -173,6 +185,7 @@ class _Buffers:
         self.pred = torch.empty(B, dtype=f32, device=dev)
         self.coef = torch.empty(B, dtype=f32, device=dev)
         self.sq = torch.zeros(1, dtype=f32, device=dev)
+        self.np5 = torch.zeros(5, dtype=f32, device=dev)
         self.loss = torch.zeros(3, dtype=f32, device=dev)
         self.n_sq_part = (B + 3) // 4
         self.sq_part = torch.zeros(self.n_sq_part + 1, dtype=f32, device=dev)
@@ -188,8 +201,6 @@ class ShardedFocfEngine:
         self.rank = dist.get_rank(group)
         self.device = user_shard.device
         self.ops = ops or HipOps(self.device)
-        if objective == "nonparity":
-            raise NotImplementedError("nonparity needs two global group means; not on the sharded path yet")
         self.objective, self.fair_weight = objective, float(fair_weight)
         self.U = self.ops.make_table(user_shard)
         self.I = self.ops.make_table(item_shard)
@@ -245,7 +256,8 @@ class ShardedFocfEngine:
         b = self._buffers(B)
         cap, S, sel = b.cap, b.S, self._sel
         n_slots = G * cap
-        fair = self.objective != "none"
+        fair = self.objective not in ("none", "nonparity")     # per-item statistics on the owners (rec / reply exchange)
+        nonparity = self.objective == "nonparity"
         if self._prep_key == self._key(user, item):
             ops.join_side()
         else:
@@ -271,20 +283,26 @@ class ShardedFocfEngine:
                               b.ws_i[sel], self.err)
         self._a2a(b.rows_recv, b.rows_send)
         ops.shard_score(b.rows_recv, slot_u, slot_i, rating, sst if fair else None, G * B, b.pred, b.coef,
-                        b.rec_send if fair else None, cap, S, cap, None if fair else b.sq, b.sq_part)
+                        b.rec_send if fair else None, cap, S, cap, None if (fair or nonparity) else b.sq, b.sq_part)
         if fair:
             self._a2a(b.rec_recv, b.rec_send)
             exchange_ahead()
             ops.shard_fair(self.I, n_slots, b.rec_recv, cap, ids_recv, 2 * cap, S, self.objective, self.fair_weight,
                            b.reply_send, b.sq_part, b.n_sq_part, b.scratch, self.err)
             self._a2a(b.reply_recv, b.reply_send)
+        elif nonparity:
+            # two group means of pred over the global batch: one 5-float all-reduce, no item exchange
+            ops.nonparity_sums(b.pred, sst, ids_recv, 2 * cap, S, G, b.sq_part, b.n_sq_part, b.np5)
+            dist.all_reduce(b.np5, op=dist.ReduceOp.SUM, group=self.group)
+            exchange_ahead()
+            ops.nonparity_coef(b.coef, sst, ids_recv, 2 * cap, S, G, b.np5, G * B, self.fair_weight, b.loss, self.err)
         else:
             dist.all_reduce(b.sq, op=dist.ReduceOp.SUM, group=self.group)
             exchange_ahead()
         # gradient rows for the owners; with a fairness term this kernel also folds the reply tails into the loss
         ops.shard_grads(b.rows_recv, slot_u, slot_i, b.coef, b.reply_recv if fair else None, G, G * B,
                         self.fair_weight, b.loss if fair else None, cap, S, cap, b.g_send)
-        loss = b.loss[0] if fair else b.sq[0] / float(G * B)
+        loss = b.loss[0] if (fair or nonparity) else b.sq[0] / float(G * B)
         self._armed = True
         return loss, b.pred
 

@@ -133,6 +133,28 @@ class CpuOps:
             t = g * (cap + TAIL) + cap
             reply[t], reply[t + 1], reply[t + 2] = float(P.shape[0]), float(s.detach()), float(sq_part[:n_sq_part].sum())
 
+    def _minmax(self, ids_recv, mm_slot, stride, G):
+        pairs = torch.stack([ids_recv[g * stride + mm_slot:g * stride + mm_slot + 1].view(torch.float32) for g in range(G)])
+        return pairs[:, 0].min(), pairs[:, 1].max()
+
+    def nonparity_sums(self, pred, sst, ids_recv, mm_slot, stride, G, sq_part, n_sq_part, out5):
+        smin, smax = self._minmax(ids_recv, mm_slot, stride, G)
+        g0, g1 = sst == smin, (sst == smax) & (sst != smin)
+        out5.copy_(torch.stack([sq_part[:n_sq_part].sum(), pred[g0].sum(), g0.sum().float(), pred[g1].sum(),
+                                g1.sum().float()]))
+
+    def nonparity_coef(self, coef, sst, ids_recv, mm_slot, stride, G, global5, n_global, fair_weight, loss_out, err):
+        smin, smax = self._minmax(ids_recv, mm_slot, stride, G)
+        n0, n1 = global5[2], global5[4]
+        delta = global5[1] / n0 - global5[3] / n1
+        dl = delta.clamp(-1, 1) * fair_weight
+        coef[sst == smin] += dl / n0
+        coef[(sst == smax) & (sst != smin)] -= dl / n1
+        a = delta.abs()
+        loss_out[1] = global5[0] / n_global
+        loss_out[2] = 0.5 * a * a if a < 1 else a - 0.5
+        loss_out[0] = loss_out[1] + fair_weight * loss_out[2]
+
     def shard_grads(self, rows, slot_u, slot_i, coef, reply, G, n_global, fair_weight, loss_out, cap, slot_stride,
                     slot_offset, grads):
         su, si = slot_u.long(), slot_i.long()

@@ -50,7 +50,7 @@ def _worker(rank, world, port, objective, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("objective", ["none", "value", "under"])
+@pytest.mark.parametrize("objective", ["none", "value", "under", "nonparity"])
 def test_two_rank_schedule_matches_oracle(tmp_path, objective):
     from oracle import focf as O
     world = 2

@@ -19,7 +19,8 @@ def pg(rccl_world1):
 
 @pytest.mark.parametrize("lookahead", [False, True], ids=["inline", "lookahead"])
 @pytest.mark.parametrize("case", ["focf_none", "focf_value", "focf_absolute", "focf_under", "focf_over",
-                                  "focf_value_grouped", "focf_value_d128", "focf_value_pad", "focf_value_long"])
+                                  "focf_value_grouped", "focf_value_d128", "focf_value_pad", "focf_value_long",
+                                  "focf_nonparity"])
 def test_sharded_hip_matches_reference_golden(pg, case, lookahead):
     from fairrec.sharded import ShardedFocfEngine
     z = np.load(os.path.join(GOLDEN, case + ".npz"))
