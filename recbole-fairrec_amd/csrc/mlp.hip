@@ -82,21 +82,32 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(CatMat X, const unsigne
     const int wm = wave >> 1, wn = wave & 1;
     const int m0 = blockIdx.x * TM, n0 = blockIdx.y * TN;
     f32x16 acc = {0};
-    for (int k0 = 0; k0 < K; k0 += TK) {
+    constexpr int Q = (TM * TK) / 256;
+    float xq[Q], wq[Q];                      // the next K chunk, fetched while the current one is multiplied
+    auto fetch = [&](int k0) {
 #pragma unroll
-        for (int q = 0; q < (TM * TK) / 256; ++q) {
+        for (int q = 0; q < Q; ++q) {
             const int e = q * 256 + tid, r = e / TK, c = e % TK;
-            const int m = m0 + r, k = k0 + c;
+            const int m = m0 + r, k = k0 + c, n = n0 + r;
             float x = 0.f;
             if (m < M && k < K) {
                 x = X.at(m, k);
                 if (mask) x = mask[(size_t)m * K + k] ? x * scale : 0.f;
             }
-            Xs[r * LDT + c] = x;
-            const int n = n0 + r;
-            Ws[r * LDT + c] = (n < N && k < K) ? W[(size_t)n * K + k] : 0.f;
+            xq[q] = x;
+            wq[q] = (n < N && k < K) ? W[(size_t)n * K + k] : 0.f;
+        }
+    };
+    fetch(0);
+    for (int k0 = 0; k0 < K; k0 += TK) {
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const int e = q * 256 + tid, r = e / TK, c = e % TK;
+            Xs[r * LDT + c] = xq[q];
+            Ws[r * LDT + c] = wq[q];
         }
         __syncthreads();
+        if (k0 + TK < K) fetch(k0 + TK);
 #pragma unroll
         for (int kk = 0; kk < TK; kk += 2) {
             const float a = Xs[(wm * 32 + (lane & 31)) * LDT + kk + (lane >> 5)];
@@ -119,24 +130,36 @@ __global__ __launch_bounds__(256) void linear_bwd_input_kernel(const float* __re
     const int wm = wave >> 1, wn = wave & 1;
     const int m0 = blockIdx.x * TM, c0 = blockIdx.y * TN;   // output tile: rows m, columns k
     f32x16 acc = {0};
-    for (int n0 = 0; n0 < N; n0 += TK) {
+    constexpr int Q = (TM * TK) / 256;
+    float gq[Q], wq[Q];                      // the next N chunk, fetched while the current one is multiplied
+    auto fetch = [&](int n0) {
 #pragma unroll
-        for (int q = 0; q < (TM * TK) / 256; ++q) {
+        for (int q = 0; q < Q; ++q) {
             const int e = q * 256 + tid;
             {
                 const int r = e / TK, c = e % TK;
                 const int m = m0 + r, n = n0 + c;
                 float g = 0.f;
                 if (m < M && n < N) g = dY[(size_t)m * N + n] * act_bwd(Y[(size_t)m * N + n], act);
-                Gs[r * LDT + c] = g;
+                gq[q] = g;
             }
             {
                 const int r = e / TN, c = e % TN;          // r: n within chunk, c: k within tile
                 const int n = n0 + r, k = c0 + c;
-                Ws[r * (TN + 1) + c] = (n < N && k < K) ? W[(size_t)n * K + k] : 0.f;
+                wq[q] = (n < N && k < K) ? W[(size_t)n * K + k] : 0.f;
             }
         }
+    };
+    fetch(0);
+    for (int n0 = 0; n0 < N; n0 += TK) {
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const int e = q * 256 + tid;
+            Gs[(e / TK) * LDT + e % TK] = gq[q];
+            Ws[(e / TN) * (TN + 1) + e % TN] = wq[q];
+        }
         __syncthreads();
+        if (n0 + TK < N) fetch(n0 + TK);
 #pragma unroll
         for (int kk = 0; kk < TK; kk += 2) {
             const float a = Gs[(wm * 32 + (lane & 31)) * LDT + kk + (lane >> 5)];
