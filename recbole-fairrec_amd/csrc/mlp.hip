@@ -246,20 +246,28 @@ __global__ __launch_bounds__(256) void linear_bwd_weight_kernel(const float* __r
     }
 }
 
-// dW[i] = sum_s slab[s][i] and db[n] = sum_s bslab[s][n], both in split order (fixed order => reproducible)
+// dW[i] = sum_s slab[s][i] and db[n] = sum_s bslab[s][n]: 64 outputs per workgroup, the splits of an output summed by 4
+// threads over contiguous quarters and combined in quarter order (fixed order => reproducible)
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slab, const float* __restrict__ bslab,
                                                           int splits, long long n, int nb, float* __restrict__ out,
                                                           float* __restrict__ db) {
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n + nb; i += (long long)gridDim.x * 256) {
-        float a = 0.f;
-        if (i < n) {
-            for (int s = 0; s < splits; ++s) a += slab[(size_t)s * n + i];
-            out[i] = a;
-        } else {
-            const long long j = i - n;
-            for (int s = 0; s < splits; ++s) a += bslab[(size_t)s * nb + j];
-            db[j] = a;
-        }
+    __shared__ float red[4][64];
+    const int e = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const long long i = (long long)blockIdx.x * 64 + e;
+    const int per = (splits + 3) / 4, s0 = part * per, s1 = min(splits, s0 + per);
+    float a = 0.f;
+    if (i < n) {
+        for (int s = s0; s < s1; ++s) a += slab[(size_t)s * n + i];
+    } else if (i < n + nb) {
+        const long long j = i - n;
+        for (int s = s0; s < s1; ++s) a += bslab[(size_t)s * nb + j];
+    }
+    red[part][e] = a;
+    __syncthreads();
+    if (part == 0) {
+        const float t = ((red[0][e] + red[1][e]) + red[2][e]) + red[3][e];
+        if (i < n) out[i] = t;
+        else if (i < n + nb) db[i - n] = t;
     }
 }
 
@@ -334,8 +342,8 @@ extern "C" int fr_linear_bwd_weight(const float* dY, const float* Y, int32_t act
     }
     FR_CHECK_LAUNCH();
     const long long n = (long long)N * K, tot = n + (db ? N : 0);
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)std::min<long long>(2048, (tot + 255) / 256)), dim3(256), 0,
-                       stream, (const float*)slab, (const float*)bslab, (int)splits, n, db ? (int)N : 0, dW, db);
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((tot + 63) / 64)), dim3(256), 0, stream, (const float*)slab,
+                       (const float*)bslab, (int)splits, n, db ? (int)N : 0, dW, db);
     FR_CHECK_LAUNCH();
     return FR_OK;
 }
