@@ -62,48 +62,66 @@ __global__ __launch_bounds__(256) void bpr_kernel(const float* __restrict__ pos,
 }
 
 // BiasedMF's broadcast form: x_ij = a_j + c_i, loss = mean_ij term(x_ij).
-// One block per 64 values of i (rows), every thread walks all j: gc_i = sum_j dterm / B^2, and per-block partial
-// column sums ga_part[block][j]; a second kernel adds the partials in block order.  B^2 transcendental pairs, nothing
-// of size B^2 is ever stored (the reference materialises the [B,B] matrix).
+// One block per OUTER_ROWS values of i; thread t walks the columns j = t, t + 256, ... and evaluates every (i, j) pair
+// ONCE: the pair's derivative goes into the thread's column sum and into its private row-sum register, the row sums are
+// reduced over the block at the end (butterfly + wave order: fixed order).  Per-block column partials ga_part[block][j]
+// are added in block order by a second kernel.  B^2 transcendental groups, nothing of size B^2 is ever stored (the
+// reference materialises the [B,B] matrix).
+static constexpr int OUTER_ROWS = 32;
+
+// -log(1e-10 + sigmoid(x)) and its derivative with hardware exp / log / rcp (1-2 ulp): with e = exp(-x), r = 1/(1+e):
+// sigmoid = r, 1 - sigmoid = e*r, so  term = -log(1e-10 + r),  dterm = -(r*r*e) / (1e-10 + r)
+__device__ __forceinline__ float bpr_term_fast(float x, float& dterm) {
+    const float e = __expf(-x);
+    const float r = __builtin_amdgcn_rcpf(1.f + e);
+    const float den = 1e-10f + r;
+    dterm = -(r * r * e) * __builtin_amdgcn_rcpf(den);
+    return -__logf(den);
+}
+
 __global__ __launch_bounds__(256) void bpr_outer_kernel(const float* __restrict__ a, const float* __restrict__ c, int B,
                                                         float* __restrict__ dc, float* __restrict__ ga_part,
                                                         float* __restrict__ loss_part) {
-    __shared__ float cs[64];
-    __shared__ float red[4];
-    const int i0 = blockIdx.x * 64;
-    if (threadIdx.x < 64) cs[threadIdx.x] = (i0 + threadIdx.x < B) ? c[i0 + threadIdx.x] : 0.f;
+    __shared__ float cs[OUTER_ROWS];
+    __shared__ float red[4][OUTER_ROWS + 1];
+    const int i0 = blockIdx.x * OUTER_ROWS;
+    if (threadIdx.x < OUTER_ROWS) cs[threadIdx.x] = (i0 + threadIdx.x < B) ? c[i0 + threadIdx.x] : 0.f;
     __syncthreads();
-    const int ni = min(64, B - i0);
+    const int ni = min(OUTER_ROWS, B - i0);
     const float inv = 1.f / ((float)B * (float)B);
     float lsum = 0.f;
-    // thread t owns columns j = t, t+256, ...: column sums over this block's rows
+    float rs[OUTER_ROWS];
+#pragma unroll
+    for (int i = 0; i < OUTER_ROWS; ++i) rs[i] = 0.f;
     for (int j = threadIdx.x; j < B; j += 256) {
         const float aj = a[j];
         float gcol = 0.f;
-        for (int i = 0; i < ni; ++i) {
-            float dt;
-            lsum += bpr_term(aj + cs[i], dt);
-            gcol += dt;
+#pragma unroll
+        for (int i = 0; i < OUTER_ROWS; ++i) {
+            if (i < ni) {
+                float dt;
+                lsum += bpr_term_fast(aj + cs[i], dt);
+                gcol += dt;
+                rs[i] += dt;
+            }
         }
         ga_part[(size_t)blockIdx.x * B + j] = gcol * inv;
     }
-    lsum = wave_sum(lsum);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = lsum;
-    __syncthreads();
-    if (threadIdx.x == 0) loss_part[blockIdx.x] = (((red[0] + red[1]) + red[2]) + red[3]) * inv;
-    // row sums gc_i: wave w of the block takes rows w, w+4, ...; lanes stride over j
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int i = wave; i < ni; i += 4) {
-        const float ci = cs[i];
-        float g = 0.f;
-        for (int j = lane; j < B; j += 64) {
-            float dt;
-            (void)bpr_term(a[j] + ci, dt);
-            g += dt;
-        }
-        g = wave_sum(g);
-        if (lane == 0) dc[i0 + i] = g * inv;
+    lsum = wave_sum(lsum);
+    if (lane == 0) red[wave][OUTER_ROWS] = lsum;
+#pragma unroll
+    for (int i = 0; i < OUTER_ROWS; ++i) {
+        const float v = wave_sum(rs[i]);
+        if (lane == 0) red[wave][i] = v;
     }
+    __syncthreads();
+    if (threadIdx.x < ni) {
+        const int i = threadIdx.x;
+        dc[i0 + i] = (((red[0][i] + red[1][i]) + red[2][i]) + red[3][i]) * inv;
+    }
+    if (threadIdx.x == 0)
+        loss_part[blockIdx.x] = (((red[0][OUTER_ROWS] + red[1][OUTER_ROWS]) + red[2][OUTER_ROWS]) + red[3][OUTER_ROWS]) * inv;
 }
 
 __global__ __launch_bounds__(256) void bpr_outer_reduce_kernel(const float* __restrict__ ga_part, int nblk, int B,
@@ -181,7 +199,7 @@ extern "C" int fr_rowdot_bwd(const float* g, const float* a, const float* b, int
 
 extern "C" size_t fr_bpr_workspace_bytes(int64_t B, int32_t outer) {
     if (B < 1) return 0;
-    const size_t nb = outer ? (size_t)(B + 63) / 64 : (size_t)(B + 255) / 256;
+    const size_t nb = outer ? (size_t)(B + fr::OUTER_ROWS - 1) / fr::OUTER_ROWS : (size_t)(B + 255) / 256;
     return align_up(nb * 4, 256) + (outer ? nb * (size_t)B * 4 : 0);
 }
 
@@ -209,7 +227,7 @@ extern "C" int fr_bpr_outer(const float* a, const float* c, int64_t B, float* lo
     hipStream_t stream = (hipStream_t)stream_;
     FR_CHECK_ARG(a && c && loss && da && dc && ws && B >= 1 && ws_bytes >= fr_bpr_workspace_bytes(B, 1),
                  "fr_bpr_outer: bad argument");
-    const int nb = (int)((B + 63) / 64);
+    const int nb = (int)((B + OUTER_ROWS - 1) / OUTER_ROWS);
     float* loss_part = (float*)ws;
     float* ga_part = (float*)((char*)ws + align_up((size_t)nb * 4, 256));
     {
