@@ -124,13 +124,19 @@ __global__ __launch_bounds__(256) void bpr_outer_kernel(const float* __restrict_
         loss_part[blockIdx.x] = (((red[0][OUTER_ROWS] + red[1][OUTER_ROWS]) + red[2][OUTER_ROWS]) + red[3][OUTER_ROWS]) * inv;
 }
 
+// da[j] = sum over the row blocks, in block order within quarters, quarters in order (fixed order => reproducible)
 __global__ __launch_bounds__(256) void bpr_outer_reduce_kernel(const float* __restrict__ ga_part, int nblk, int B,
                                                                float* __restrict__ da) {
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= B) return;
+    __shared__ float red[4][64];
+    const int e = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + e;
+    const int per = (nblk + 3) / 4, k0 = part * per, k1 = min(nblk, k0 + per);
     float s = 0.f;
-    for (int k = 0; k < nblk; ++k) s += ga_part[(size_t)k * B + j];
-    da[j] = s;
+    if (j < B)
+        for (int k = k0; k < k1; ++k) s += ga_part[(size_t)k * B + j];
+    red[part][e] = s;
+    __syncthreads();
+    if (part == 0 && j < B) da[j] = ((red[0][e] + red[1][e]) + red[2][e]) + red[3][e];
 }
 
 __global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restrict__ part, int n, float scale,
@@ -235,7 +241,7 @@ extern "C" int fr_bpr_outer(const float* a, const float* c, int64_t B, float* lo
         FR_LAUNCH(prof, bpr_outer_kernel, dim3(nb), dim3(256), 0, stream, a, c, (int)B, dc, ga_part, loss_part);
     }
     FR_CHECK_LAUNCH();
-    hipLaunchKernelGGL(bpr_outer_reduce_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, stream,
+    hipLaunchKernelGGL(bpr_outer_reduce_kernel, dim3((unsigned)((B + 63) / 64)), dim3(256), 0, stream,
                        (const float*)ga_part, nb, (int)B, da);
     FR_CHECK_LAUNCH();
     hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, stream, (const float*)loss_part, nb, 1.f, loss);
