@@ -350,6 +350,18 @@ FR_API int fr_nfcf_loss(const float* y, const float* label, const float* sst, in
  * torch.optim.Adam on a flat fp32 tensor, `step` = the step being applied. */
 FR_API int fr_adam_dense(float* p, const float* g, float* m, float* v, int64_t n, const fr_adam* adam, int32_t step,
                   void* stream);
+/* The same for many tensors at once (all dense parameters of an optimizer group: one launch per FR_ADAM_DENSE_MAX tensors
+ * instead of one per tensor); every tensor keeps its own step counter, as torch.optim.Adam's per-parameter state does. */
+#define FR_ADAM_DENSE_MAX 48
+typedef struct fr_dense_desc {
+    float* p;
+    const float* g;
+    float* m;
+    float* v;
+    int64_t n;
+    int32_t step;
+} fr_dense_desc;
+FR_API int fr_adam_dense_multi(const fr_dense_desc* descs, int32_t n_tensors, const fr_adam* adam, void* stream);
 
 /* ---- negative sampler (next-row f-1: the batch feed), bit-exact with the reference's host sampler ---------------
  * state: numpy's legacy RandomState layout in device memory, uint32 key[624] followed by uint32 pos (625 words), so the

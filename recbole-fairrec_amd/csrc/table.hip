@@ -60,6 +60,22 @@ __global__ __launch_bounds__(256) void adam_dense_kernel(float* __restrict__ p, 
 
 
 
+// every dense parameter tensor of an optimizer group in ONE launch (blockIdx.y = tensor): the descriptors travel as
+// kernel arguments, so there is no pointer table to upload
+struct DenseBatch {
+    fr_dense_desc t[FR_ADAM_DENSE_MAX];
+};
+
+__global__ __launch_bounds__(256) void adam_dense_multi_kernel(DenseBatch b, AdamC c) {
+    const fr_dense_desc& d = b.t[blockIdx.y];
+    const float2 s = step_scalars(c, d.step);
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < d.n; i += (long long)gridDim.x * 256) {
+        float pp = d.p[i], mm = d.m[i], vv = d.v[i];
+        adam_elem(pp, mm, vv, d.g[i], s.x, s.y, c);
+        d.p[i] = pp; d.m[i] = mm; d.v[i] = vv;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // generic training pair (one or two tables per launch: blockIdx.y selects the table)
 // ------------------------------------------------------------------------------------------------
@@ -179,6 +195,31 @@ extern "C" int fr_adam_dense(float* p, const float* g, float* m, float* v, int64
                            (long long)n, make_adamc(adam), step);
     }
     FR_CHECK_LAUNCH();
+    return FR_OK;
+}
+
+extern "C" int fr_adam_dense_multi(const fr_dense_desc* descs, int32_t n_tensors, const fr_adam* adam, void* stream_) {
+    int rc;
+    if ((rc = check_adam(adam, "fr_adam_dense_multi"))) return rc;
+    FR_CHECK_ARG(descs && n_tensors >= 0, "fr_adam_dense_multi: bad argument");
+    const AdamC c = make_adamc(adam);
+    for (int32_t base = 0; base < n_tensors; base += FR_ADAM_DENSE_MAX) {
+        const int cnt = std::min<int>(FR_ADAM_DENSE_MAX, n_tensors - base);
+        DenseBatch b;
+        long long nmax = 1;
+        for (int k = 0; k < cnt; ++k) {
+            const fr_dense_desc& d = descs[base + k];
+            FR_CHECK_ARG(d.p && d.g && d.m && d.v && d.n >= 0 && d.step >= 1, "fr_adam_dense_multi: bad descriptor %d", base + k);
+            b.t[k] = d;
+            nmax = std::max<long long>(nmax, d.n);
+        }
+        for (int k = cnt; k < FR_ADAM_DENSE_MAX; ++k) b.t[k] = fr_dense_desc{nullptr, nullptr, nullptr, nullptr, 0, 1};
+        const long long blocks = std::min<long long>((nmax + 255) / 256, 256);
+        ProfScope prof(K_ADAM_DENSE, (hipStream_t)stream_);
+        FR_LAUNCH(prof, adam_dense_multi_kernel, dim3((unsigned)blocks, (unsigned)cnt), dim3(256), 0, (hipStream_t)stream_, b,
+                  c);
+        FR_CHECK_LAUNCH();
+    }
     return FR_OK;
 }
 

@@ -24,6 +24,10 @@ class FrTable(Structure):
                 ("n_rows", c_int64), ("dim", c_int32), ("step", c_int32)]
 
 
+class FrDenseDesc(Structure):   # include/fairrec_hip.h: fr_dense_desc
+    _fields_ = [("p", c_void_p), ("g", c_void_p), ("m", c_void_p), ("v", c_void_p), ("n", c_int64), ("step", c_int32)]
+
+
 class FrAdam(Structure):
     _fields_ = [("scalars", c_void_p), ("cap", c_int32), ("reserved_", c_int32), ("weight_decay", c_double),
                 ("beta1", c_double), ("beta2", c_double), ("eps", c_double)]
@@ -70,6 +74,7 @@ _PROTOS = {
     "fr_group_sums": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p]),
     "fr_fair_metrics_workspace_bytes": (c_size_t, [c_int64]),
     "fr_fair_metrics_from_stats": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "fr_adam_dense_multi": (c_int, [POINTER(FrDenseDesc), c_int32, POINTER(FrAdam), c_void_p]),
     "fr_unbucket_rows": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p]),
     "fr_bucket_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p]),
     "fr_focf_shard_score": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32,

@@ -108,6 +108,7 @@ class GenericEngine:
             s = self.sweep_period if self.sweep_period is not None else t.default_sweep(M)
             t.apply_grad(self._hyper(name), None, s)
         st = _C.current_stream()
+        by_hyper = {}                     # all dense tensors of one optimizer in one launch (fr_adam_dense_multi)
         for name, d in self._dense.items():
             g = d.p.grad
             if g is None or not self._owned(name, group):
@@ -115,10 +116,15 @@ class GenericEngine:
             d.step += 1
             h = self._hyper(name)
             h.check_step(d.step)
-            g = g.contiguous()
-            _C.check(_C.lib().fr_adam_dense(d.p.data.data_ptr(), g.data_ptr(), d.m.data_ptr(), d.v.data_ptr(),
-                                            d.p.numel(), ctypes.byref(h.c()), d.step, st), "fr_adam_dense")
-            d.p.grad = None
+            by_hyper.setdefault(id(h), (h, []))[1].append((d, g.contiguous()))
+        for h, items in by_hyper.values():
+            descs = (_C.FrDenseDesc * len(items))()
+            for k, (d, g) in enumerate(items):
+                descs[k] = _C.FrDenseDesc(d.p.data.data_ptr(), g.data_ptr(), d.m.data_ptr(), d.v.data_ptr(), d.p.numel(),
+                                          d.step)
+            _C.check(_C.lib().fr_adam_dense_multi(descs, len(items), ctypes.byref(h.c()), st), "fr_adam_dense_multi")
+            for d, _ in items:
+                d.p.grad = None
 
     def flush(self):
         for name, t in self._tables.items():
