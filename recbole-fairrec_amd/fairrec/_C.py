@@ -149,6 +149,9 @@ def lib():
             raise FairrecError(
                 f"{LIB_PATH} not found: the HIP extension is not built. Run `python __graft_entry__.py` "
                 "(hipcc --offload-arch=gfx950). There is no CPU fallback for the training hot path.")
+        # torch first: it ships its own ROCm runtime (libamdhip64); loaded after ours, the process would hold two HIP
+        # runtimes and the kernels registered with one would not see the device context of the other
+        import torch  # noqa: F401
         handle = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in _PROTOS.items():
             fn = getattr(handle, name)  # AttributeError here = ABI mismatch between header and library
