@@ -189,6 +189,10 @@ def main():
             print(f"[bench] graph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
             graph = None
             torch.cuda.synchronize()
+            # forget the look-ahead that was in flight inside the failed capture and its (now invalid) side stream
+            eng._prep_key, eng._armed = None, False
+            if hasattr(eng.ops, "_side"):
+                del eng.ops._side
         torch.cuda.current_stream().wait_stream(side)
 
     barrier()
