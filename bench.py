@@ -24,7 +24,6 @@ for _p in (ROOT, os.path.join(ROOT, "recbole-fairrec_amd")):
     if _p not in sys.path:
         sys.path.insert(0, _p)
 
-import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
@@ -213,20 +212,16 @@ def main():
 
     # ---- per-kernel device time: K more steps, eager, with the library's HIP-event profiler -----------
     roofline = None
-    if True:   # every rank runs the extra steps (collectives need all ranks); rank 0 reports
-        u2, i2, r2, s2 = (t.to(dev) for t in synth_batches(K, BATCH, N_USERS, N_ITEMS, SEED + 7919 + rank, args.item_dist))
-        _C.prof_reset()
-        _C.prof_enable(rank == 0)
-        for k in range(K):
-            if sharded:
-                nxt = (u2[k + 1], i2[k + 1], s2[k + 1]) if k + 1 < K else None
-                eng.forward(u2[k], i2[k], r2[k], s2[k], next_batch=nxt)
-            else:
-                nxt = (u2[k + 1], i2[k + 1], s2[k + 1]) if k + 1 < K else None
-                eng.forward(u2[k], i2[k], r2[k], s2[k], next_batch=nxt)
-            eng.backward_adam()
-        torch.cuda.synchronize()
-        _C.prof_enable(False)
+    # every rank runs the extra steps (the collectives need all ranks); rank 0 reports
+    u2, i2, r2, s2 = (t.to(dev) for t in synth_batches(K, BATCH, N_USERS, N_ITEMS, SEED + 7919 + rank, args.item_dist))
+    _C.prof_reset()
+    _C.prof_enable(rank == 0)
+    for k in range(K):
+        nxt = (u2[k + 1], i2[k + 1], s2[k + 1]) if k + 1 < K else None
+        eng.forward(u2[k], i2[k], r2[k], s2[k], next_batch=nxt)
+        eng.backward_adam()
+    torch.cuda.synchronize()
+    _C.prof_enable(False)
     if rank == 0:
         prof = _C.prof_read()
         per_kernel = {name: ms / n * 1e3 for name, (ms, n) in prof.items()}   # us per launch

@@ -5,9 +5,8 @@ remapping and splitting are out of scope; synthetic genera
 """
 from __future__ import annotations
 
-from typing import Dict, Optional
+from typing import Optional
 
-import numpy as np
 import torch
 
 from .interaction import Interaction

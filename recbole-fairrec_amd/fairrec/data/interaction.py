@@ -6,7 +6,7 @@ by name, row indexing/slicing, `.to(device)`, `repeat`, `repeat_interleave`, `up
 """
 from __future__ import annotations
 
-from typing import Dict, Iterable, List, Optional, Union
+from typing import Dict, Iterable, List
 
 import numpy as np
 import torch

@@ -19,7 +19,6 @@ import scipy.sparse as sp
 import torch
 import torch.nn as nn
 
-from ... import _C
 from ...engine import GenericEngine
 from ...functional import CsrMatrix, Mse, RowDot, RowGather, SigmoidBce, SoftmaxCe, SpMM
 from ...utils.enum_type import InputType

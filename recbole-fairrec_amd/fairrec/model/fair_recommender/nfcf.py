@@ -7,7 +7,6 @@ the scorer runs on the fp32-MFMA kernels (csrc/mlp.hip), sigmoid + BCE + differe
 """
 from __future__ import annotations
 
-import ctypes
 
 import torch
 import torch.nn as nn

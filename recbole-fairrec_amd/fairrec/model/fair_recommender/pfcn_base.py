@@ -12,11 +12,9 @@ BPR / BCE / CE on csrc/pfcn.hip.
 """
 from __future__ import annotations
 
-import numpy as np
 import torch
 import torch.nn as nn
 
-from ... import _C
 from ...engine import GenericEngine
 from ...functional import Bpr, BprBroadcast, RowDot, SigmoidBce, SoftmaxCe
 from ...utils.enum_type import InputType

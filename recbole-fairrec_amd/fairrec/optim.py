@@ -10,7 +10,7 @@ from __future__ import annotations
 
 import ctypes
 import math
-from typing import Dict, Iterable, List, Optional
+from typing import Dict, Optional
 
 import numpy as np
 import torch

@@ -7,7 +7,6 @@ from logging import getLogger
 from .config import Config
 from .data.dataloader import FOCFDataLoader, TrainDataLoader
 from .data.dataset import InteractionDataset, synthetic_dataset
-from .data.interaction import Interaction
 from .utils import get_model, get_trainer, init_seed
 
 

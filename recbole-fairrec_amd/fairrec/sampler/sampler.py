@@ -11,7 +11,7 @@ back:   np.random.set_state(rs.get_state()); ...host draws...; rs.set_state(np.r
 from __future__ import annotations
 
 import copy
-from typing import Dict, List, Optional
+from typing import Dict, Optional
 
 import numpy as np
 import torch

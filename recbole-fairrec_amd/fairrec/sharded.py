@@ -31,7 +31,6 @@ to exercise this exchange schedule over gloo without a GPU; the product path is 
 """
 from __future__ import annotations
 
-import ctypes
 import math
 from typing import Optional
 

@@ -29,7 +29,6 @@ import torch.distributed as dist
 
 from . import _C
 from .engine import GenericEngine
-from .optim import LazyTable
 from .sharded import exchange_capacity
 
 
