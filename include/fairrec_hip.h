@@ -69,6 +69,11 @@ typedef struct fr_table {
     int64_t n_rows;
     int32_t dim;       /* embedding_size; 1..256 */
     int32_t step;      /* optimizer step count of this tensor so far (torch: state['step']) */
+    /* Optional device-resident step counter (NULL = none).  When set, the effective step of a call is
+     * *step_dev + step, read on the device: a training step captured once in a hipGraph can then be replayed every
+     * iteration (the host passes the constant offset, e.g. 1 for "the step being applied", and advances the counter
+     * with a kernel inside the graph).  Honoured by fr_table_gather / _gather_train / _apply_grad / _flush. */
+    const int32_t* step_dev;
 } fr_table;
 
 /*
@@ -360,6 +365,7 @@ typedef struct fr_dense_desc {
     float* v;
     int64_t n;
     int32_t step;
+    const int32_t* step_dev;   /* optional device counter, as fr_table.step_dev: effective step = *step_dev + step */
 } fr_dense_desc;
 FR_API int fr_adam_dense_multi(const fr_dense_desc* descs, int32_t n_tensors, const fr_adam* adam, void* stream);
 

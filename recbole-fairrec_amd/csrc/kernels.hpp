@@ -77,10 +77,17 @@ struct TableV {
     long long n_rows;
     int D;
     int step;
+    const int32_t* step_dev;   // optional device-resident counter: effective step = *step_dev + step (see fr_table)
 };
 
 inline TableV view(const fr_table* t) {
-    return TableV{t->p, t->m, t->v, t->last, t->stamp, (long long)t->n_rows, t->dim, t->step};
+    return TableV{t->p, t->m, t->v, t->last, t->stamp, (long long)t->n_rows, t->dim, t->step, t->step_dev};
+}
+
+// the table view with its effective step (one scalar load when a device counter is attached)
+__device__ __forceinline__ TableV resolved(TableV T) {
+    if (T.step_dev) T.step += *T.step_dev;
+    return T;
 }
 
 inline int check_table(const fr_table* t, const char* who) {
@@ -108,7 +115,7 @@ inline int check_adam(const fr_adam* a, const char* who) {
 }
 
 // Sweep slice of a table for optimizer step `step` with period S: rows [lo, hi).
-inline void sweep_range(long long n_rows, int step, int S, long long& lo, long long& hi) {
+__host__ __device__ inline void sweep_range(long long n_rows, int step, int S, long long& lo, long long& hi) {
     if (S <= 0) {
         lo = hi = 0;
         return;

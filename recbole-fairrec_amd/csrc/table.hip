@@ -16,7 +16,8 @@ namespace fr {
 // table maintenance
 // ------------------------------------------------------------------------------------------------
 template <int E>
-__global__ __launch_bounds__(256) void table_flush_kernel(TableV T, AdamC c) {
+__global__ __launch_bounds__(256) void table_flush_kernel(TableV T_, AdamC c) {
+    const TableV T = resolved(T_);
     const int lane = threadIdx.x & 63;
     const long long nw = (long long)gridDim.x * 4;
     for (long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); row < T.n_rows; row += nw)
@@ -24,8 +25,9 @@ __global__ __launch_bounds__(256) void table_flush_kernel(TableV T, AdamC c) {
 }
 
 template <int E>
-__global__ __launch_bounds__(256) void table_gather_kernel(TableV T, AdamC c, const int64_t* __restrict__ idx,
+__global__ __launch_bounds__(256) void table_gather_kernel(TableV T_, AdamC c, const int64_t* __restrict__ idx,
                                                            long long M, float* __restrict__ out, uint32_t* err) {
+    const TableV T = resolved(T_);
     const int lane = threadIdx.x & 63;
     const long long j = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (j >= M) return;
@@ -68,7 +70,7 @@ struct DenseBatch {
 
 __global__ __launch_bounds__(256) void adam_dense_multi_kernel(DenseBatch b, AdamC c) {
     const fr_dense_desc& d = b.t[blockIdx.y];
-    const float2 s = step_scalars(c, d.step);
+    const float2 s = step_scalars(c, d.step + (d.step_dev ? *d.step_dev : 0));
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < d.n; i += (long long)gridDim.x * 256) {
         float pp = d.p[i], mm = d.m[i], vv = d.v[i];
         adam_elem(pp, mm, vv, d.g[i], s.x, s.y, c);
@@ -90,7 +92,7 @@ template <int E>
 __global__ __launch_bounds__(256) void table_gather_train_kernel(GatherJob ja, GatherJob jb, AdamC c, long long M,
                                                                  Lay lay, uint32_t* err) {
     const GatherJob& J = blockIdx.y == 0 ? ja : jb;
-    const TableV& T = J.T;
+    const TableV T = resolved(J.T);
     const int lane = threadIdx.x & 63;
     const long long j = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (j >= M) return;
@@ -126,22 +128,25 @@ struct ApplyJob {
     TableWs w;
     const float* rows;
     const float* grad_rows;
-    long long sw_lo;
-    int sw_n;
+    int sweep_period;     // the sweeper slice is derived from the effective step on the device
+    int sw_n;             // waves reserved for it (= rows of the longest slice)
 };
 
 template <int E>
 __global__ __launch_bounds__(256) void table_apply_grad_kernel(ApplyJob ja, ApplyJob jb, AdamC c, long long M, Lay lay) {
     const ApplyJob& J = blockIdx.y == 0 ? ja : jb;
+    const TableV T = resolved(J.T);
     const int lane = threadIdx.x & 63;
     long long wv = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (wv < J.sw_n) {   // longest jobs first
-        sweep_row<E>(J.T, c, J.sw_lo + wv, J.T.step, true, lane);
+        long long lo, hi;
+        sweep_range(T.n_rows, T.step, J.sweep_period, lo, hi);
+        if (lo + wv < hi) sweep_row<E>(T, c, lo + wv, T.step, true, lane);
         return;
     }
     wv -= J.sw_n;
     if (wv < M && wv < J.w.nseg[0])
-        segment_update<E>(J.T, c, (int)wv, J.w.seg_start, J.w.seg_row, J.w.perm, nullptr, J.rows, J.w.m_side, J.w.v_side,
+        segment_update<E>(T, c, (int)wv, J.w.seg_start, J.w.seg_row, J.w.perm, nullptr, J.rows, J.w.m_side, J.w.v_side,
                           J.grad_rows, lane, lay);
 }
 
@@ -152,7 +157,7 @@ using namespace fr;
 extern "C" int fr_table_flush(const fr_table* t, const fr_adam* adam, void* stream_) {
     int rc;
     if ((rc = check_table(t, "fr_table_flush")) || (rc = check_adam(adam, "fr_table_flush"))) return rc;
-    if (t->step < 1) return FR_OK;
+    if (t->step < 1 && !t->step_dev) return FR_OK;
     const AdamC c = make_adamc(adam);
     const TableV Tv = view(t);
     long long blocks = (t->n_rows + 3) / 4;
@@ -209,11 +214,11 @@ extern "C" int fr_adam_dense_multi(const fr_dense_desc* descs, int32_t n_tensors
         long long nmax = 1;
         for (int k = 0; k < cnt; ++k) {
             const fr_dense_desc& d = descs[base + k];
-            FR_CHECK_ARG(d.p && d.g && d.m && d.v && d.n >= 0 && d.step >= 1, "fr_adam_dense_multi: bad descriptor %d", base + k);
+            FR_CHECK_ARG(d.p && d.g && d.m && d.v && d.n >= 0 && (d.step >= 1 || d.step_dev), "fr_adam_dense_multi: bad descriptor %d", base + k);
             b.t[k] = d;
             nmax = std::max<long long>(nmax, d.n);
         }
-        for (int k = cnt; k < FR_ADAM_DENSE_MAX; ++k) b.t[k] = fr_dense_desc{nullptr, nullptr, nullptr, nullptr, 0, 1};
+        for (int k = cnt; k < FR_ADAM_DENSE_MAX; ++k) b.t[k] = fr_dense_desc{nullptr, nullptr, nullptr, nullptr, 0, 1, nullptr};
         const long long blocks = std::min<long long>((nmax + 255) / 256, 256);
         ProfScope prof(K_ADAM_DENSE, (hipStream_t)stream_);
         FR_LAUNCH(prof, adam_dense_multi_kernel, dim3((unsigned)blocks, (unsigned)cnt), dim3(256), 0, (hipStream_t)stream_, b,
@@ -319,13 +324,14 @@ static int apply_grad_impl(const char* who, const fr_table* ta, const fr_table* 
     TableWs wb = tb ? table_layout(ws_b, M, tb->dim) : wa;
     FR_CHECK_ARG(ws_bytes >= wa.bytes, "%s: workspace %zu < %zu bytes", who, ws_bytes, wa.bytes);
     if ((rc = side_join(ws_a, stream)) || (tb && (rc = side_join(ws_b, stream)))) return rc;
-    long long lo_a, hi_a, lo_b = 0, hi_b = 0;
-    sweep_range(ta->n_rows, ta->step, sweep_a, lo_a, hi_a);
-    if (tb) sweep_range(tb->n_rows, tb->step, sweep_b, lo_b, hi_b);
-    const long long waves = M + std::max(hi_a - lo_a, hi_b - lo_b);
+    // waves reserved for the sweeper = rows of a full slice (the slice itself depends on the effective step, which may
+    // live on the device)
+    const long long sw_a = sweep_a > 0 ? (ta->n_rows + sweep_a - 1) / sweep_a : 0;
+    const long long sw_b = tb && sweep_b > 0 ? (tb->n_rows + sweep_b - 1) / sweep_b : 0;
+    const long long waves = M + std::max(sw_a, sw_b);
     const AdamC c = make_adamc(adam);
-    ApplyJob ja{view(ta), wa, rows_a, grad_a, lo_a, (int)(hi_a - lo_a)};
-    ApplyJob jb = tb ? ApplyJob{view(tb), wb, rows_b, grad_b, lo_b, (int)(hi_b - lo_b)} : ja;
+    ApplyJob ja{view(ta), wa, rows_a, grad_a, (int)sweep_a, (int)sw_a};
+    ApplyJob jb = tb ? ApplyJob{view(tb), wb, rows_b, grad_b, (int)sweep_b, (int)sw_b} : ja;
     {
         ProfScope prof(K_TABLE_APPLY_GRAD, stream);
         FR_DISPATCH_E(ta->dim, FR_LAUNCH(prof, (table_apply_grad_kernel<E>), dim3((unsigned)((waves + 3) / 4), tb ? 2 : 1), dim3(256), 0, stream, ja, jb, c, (long long)M, lay));

@@ -21,11 +21,12 @@ FOCF_OBJECTIVES = {"none": 0, "value": 1, "absolute": 2, "under": 3, "over": 4, 
 
 class FrTable(Structure):
     _fields_ = [("p", c_void_p), ("m", c_void_p), ("v", c_void_p), ("last", c_void_p), ("stamp", c_void_p),
-                ("n_rows", c_int64), ("dim", c_int32), ("step", c_int32)]
+                ("n_rows", c_int64), ("dim", c_int32), ("step", c_int32), ("step_dev", c_void_p)]
 
 
 class FrDenseDesc(Structure):   # include/fairrec_hip.h: fr_dense_desc
-    _fields_ = [("p", c_void_p), ("g", c_void_p), ("m", c_void_p), ("v", c_void_p), ("n", c_int64), ("step", c_int32)]
+    _fields_ = [("p", c_void_p), ("g", c_void_p), ("m", c_void_p), ("v", c_void_p), ("n", c_int64), ("step", c_int32),
+                ("step_dev", c_void_p)]
 
 
 class FrAdam(Structure):

@@ -23,6 +23,7 @@ class DenseState:
         self.m = torch.zeros_like(p.data)
         self.v = torch.zeros_like(p.data)
         self.step = 0
+        self.step_dev = None     # optional device-resident counter (graph mode), as LazyTable.step_dev
 
 
 class GenericEngine:
@@ -40,6 +41,49 @@ class GenericEngine:
         self.optimizer = None
         self.sweep_period: Optional[int] = None
         self.err_flag = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self._counters = None           # graph mode: one device int32 per entry (tables, then dense tensors)
+        self._counter_slot: Dict[str, int] = {}
+        self._advance_idx: Dict[tuple, torch.Tensor] = {}
+
+    # --- graph mode: step counters on the device ----------------------------------------------------------
+    def enable_graph_mode(self):
+        """Move every step counter to device memory, so that a training step captured in a hipGraph advances them on
+        replay (fairrec/graph.py).  From here on the device values are authoritative; `sync_steps()` refreshes the
+        host mirrors."""
+        if self._counters is not None:
+            return
+        names = list(self._tables) + list(self._dense)
+        self._counters = torch.zeros(len(names), dtype=torch.int32, device=self.device)
+        for k, name in enumerate(names):
+            self._counter_slot[name] = k
+            view = self._counters[k:k + 1]
+            if name in self._tables:
+                self._tables[name].ensure_state()
+                self._tables[name].attach_step_counter(view)
+            else:
+                view.fill_(self._dense[name].step)
+                self._dense[name].step_dev = view
+
+    def sync_steps(self):
+        if self._counters is None:
+            return
+        host = self._counters.cpu().tolist()
+        for name, k in self._counter_slot.items():
+            if name in self._tables:
+                self._tables[name].step = host[k]
+            else:
+                self._dense[name].step = host[k]
+
+    def _advance(self, names):
+        """counter += 1 for the entries stepped in this optimizer step (one launch; the index tensor is cached per set
+        so that nothing is uploaded inside a captured step)."""
+        if self._counters is None or not names:
+            return
+        key = tuple(sorted(self._counter_slot[n] for n in names))
+        idx = self._advance_idx.get(key)
+        if idx is None:
+            idx = self._advance_idx[key] = torch.tensor(key, dtype=torch.int64, device=self.device)
+        self._counters.index_add_(0, idx, torch.ones(len(key), dtype=torch.int32, device=self.device))
 
     # --- registration ---------------------------------------------------------------------------------
     def add_table(self, name: str, weight: torch.nn.Parameter, trainable: bool = True, group=None) -> LazyTable:
@@ -96,6 +140,7 @@ class GenericEngine:
                 t._grad_rows = None
 
     def backward_adam(self, group=None):
+        stepped = []
         for name, t in self._tables.items():
             if not (t.trainable and t._pending is not None):
                 continue
@@ -107,6 +152,7 @@ class GenericEngine:
             M = t._pending[0]
             s = self.sweep_period if self.sweep_period is not None else t.default_sweep(M)
             t.apply_grad(self._hyper(name), None, s)
+            stepped.append(name)
         st = _C.current_stream()
         by_hyper = {}                     # all dense tensors of one optimizer in one launch (fr_adam_dense_multi)
         for name, d in self._dense.items():
@@ -117,14 +163,20 @@ class GenericEngine:
             h = self._hyper(name)
             h.check_step(d.step)
             by_hyper.setdefault(id(h), (h, []))[1].append((d, g.contiguous()))
+            stepped.append(name)
         for h, items in by_hyper.values():
             descs = (_C.FrDenseDesc * len(items))()
             for k, (d, g) in enumerate(items):
-                descs[k] = _C.FrDenseDesc(d.p.data.data_ptr(), g.data_ptr(), d.m.data_ptr(), d.v.data_ptr(), d.p.numel(),
-                                          d.step)
+                if d.step_dev is not None:      # effective step = device counter + 1
+                    descs[k] = _C.FrDenseDesc(d.p.data.data_ptr(), g.data_ptr(), d.m.data_ptr(), d.v.data_ptr(),
+                                              d.p.numel(), 1, d.step_dev.data_ptr())
+                else:
+                    descs[k] = _C.FrDenseDesc(d.p.data.data_ptr(), g.data_ptr(), d.m.data_ptr(), d.v.data_ptr(),
+                                              d.p.numel(), d.step, None)
             _C.check(_C.lib().fr_adam_dense_multi(descs, len(items), ctypes.byref(h.c()), st), "fr_adam_dense_multi")
             for d, _ in items:
                 d.p.grad = None
+        self._advance(stepped)
 
     def flush(self):
         for name, t in self._tables.items():
@@ -138,6 +190,7 @@ class GenericEngine:
 
     # --- torch.optim.Adam-shaped state for checkpoints ----------------------------------------------------
     def dense_state(self, group=None):
+        self.sync_steps()
         return {k: {"step": torch.tensor(float(d.step)), "exp_avg": d.m, "exp_avg_sq": d.v}
                 for k, d in self._dense.items() if self._owned(k, group)}
 
@@ -145,5 +198,7 @@ class GenericEngine:
         for k, st in sd.items():
             d = self._dense[k]
             d.step = int(st["step"])
+            if d.step_dev is not None:
+                d.step_dev.fill_(d.step)
             d.m.copy_(st["exp_avg"])
             d.v.copy_(st["exp_avg_sq"])

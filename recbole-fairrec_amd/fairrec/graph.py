@@ -1,0 +1,74 @@
+"""One training step as a hipGraph: capture once, replay per batch.
+
+The generic models (NFCF, PFCN_*, FairGo_*) run tens to ~150 small launches per optimizer step; launched eagerly from
+Python a step is bound by launch overhead, not by the kernels.  `GraphedStep` captures
+
+    optimizer.zero_grad(); loss = loss_fn(batch, *args); loss.backward(); optimizer.step()
+
+-- HIP kernels called through the C ABI, torch's autograd glue and the dropout-mask draws alike -- into one
+torch.cuda.CUDAGraph on static input tensors and replays it for every later batch of the same shape.  What makes a
+captured optimizer step replayable is that nothing the kernels need changes on the host between steps: the step counters
+of the lazy tables and dense tensors live in device memory (`GenericEngine.enable_graph_mode`, fr_table.step_dev) and are
+advanced by a kernel inside the graph; the per-step Adam scalars are a device table indexed by that counter.
+
+Usage (what fairrec.trainer does when `graph_train_step: True`):
+    gs = GraphedStep(engine, optimizer, loss_fn)
+    for batch in loader: loss = gs(batch, *args)        # first calls run eagerly, then capture, then replay
+The returned loss is a device tensor that the next call overwrites; read it (`.item()`) or accumulate it before that.
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, Optional, Tuple
+
+import torch
+
+from .data.interaction import Interaction
+
+
+class GraphedStep:
+    def __init__(self, engine, optimizer, loss_fn: Callable, eager_steps: int = 2):
+        self.engine, self.optimizer, self.loss_fn = engine, optimizer, loss_fn
+        self.eager_left = eager_steps          # real training steps before capture (lazy initialisation happens here)
+        self.graph: Optional[torch.cuda.CUDAGraph] = None
+        self.static: Optional[Dict[str, torch.Tensor]] = None
+        self.static_args: Tuple = ()
+        self.loss: Optional[torch.Tensor] = None
+        engine.enable_graph_mode()
+
+    def _eager(self, inter: Interaction, args):
+        self.optimizer.zero_grad()
+        loss = self.loss_fn(inter, *args)
+        loss.backward()
+        self.optimizer.step()
+        return loss.detach()
+
+    def _signature(self, inter: Interaction):
+        return tuple((k, tuple(v.shape), v.dtype) for k, v in inter.interaction.items())
+
+    def __call__(self, inter: Interaction, *args):
+        dev = self.engine.device
+        inter = inter.to(dev)
+        if self.eager_left > 0:
+            self.eager_left -= 1
+            return self._eager(inter, args)
+        if self.graph is None:
+            # capture on this batch: copy it into static tensors, record the step, then replay it once (capture does not
+            # execute anything), so every batch is trained on exactly once
+            self.static = {k: v.clone() for k, v in inter.interaction.items()}
+            self.sig, self.static_args = self._signature(inter), args
+            static_inter = Interaction(self.static)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                self.loss = self._eager(static_inter, args)
+            self.graph = g
+            # the host ran the optimizer bookkeeping once during capture without the device doing the step: take the
+            # host mirrors back from the device counters
+            self.engine.sync_steps()
+        elif self._signature(inter) != self.sig or args != self.static_args:
+            return self._eager(inter, args)        # odd-sized last batch, other attribute subset: eager
+        else:
+            for k, v in inter.interaction.items():
+                self.static[k].copy_(v, non_blocking=True)
+        self.graph.replay()
+        return self.loss

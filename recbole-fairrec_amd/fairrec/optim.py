@@ -86,6 +86,9 @@ class LazyTable:
         self._keep = None
         self._grad_rows = None
         self._dirty = False      # some row may be behind `step` (set by an update, cleared by flush)
+        # optional device-resident step counter (int32 [1] view): once attached the device value is authoritative and
+        # `step` is a host mirror that replays of a captured hipGraph do not advance (see `sync_step`)
+        self.step_dev: Optional[torch.Tensor] = None
 
     def ensure_state(self):
         dev = self.weight.device
@@ -102,12 +105,25 @@ class LazyTable:
     def c(self, step: Optional[int] = None) -> "_C.FrTable":
         self.ensure_state()
         w = self.weight.data if isinstance(self.weight, torch.nn.Parameter) else self.weight
+        step = self.step if step is None else step
+        if self.step_dev is not None:       # the kernels add the device counter to this constant offset
+            return _C.FrTable(w.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), self.last.data_ptr(),
+                              self.stamp.data_ptr(), self.n_rows, self.dim, step - self.step, self.step_dev.data_ptr())
         return _C.FrTable(w.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), self.last.data_ptr(),
-                          self.stamp.data_ptr(), self.n_rows, self.dim, self.step if step is None else step)
+                          self.stamp.data_ptr(), self.n_rows, self.dim, step, None)
+
+    def attach_step_counter(self, counter: torch.Tensor):
+        """`counter`: int32 [1] device view that from now on holds this table's step count."""
+        counter.fill_(self.step)
+        self.step_dev = counter
+
+    def sync_step(self):
+        if self.step_dev is not None:
+            self.step = int(self.step_dev.item())
 
     def flush(self, hyper: AdamHyper):
         """Bring every row up to `self.step` (fr_table_flush)."""
-        if self.step == 0 or not self.trainable or not self._dirty:
+        if (self.step == 0 and self.step_dev is None) or not self.trainable or not self._dirty:
             return
         self._dirty = False
         t = self.c()
@@ -232,6 +248,7 @@ class LazyTable:
 
     # --- interchange with torch.optim.Adam.state_dict() (trainer.py:221-240 checkpoints) ---------------
     def adam_state(self, hyper: AdamHyper) -> Dict[str, torch.Tensor]:
+        self.sync_step()
         self.flush(hyper)
         return {"step": torch.tensor(float(self.step)), "exp_avg": self.m, "exp_avg_sq": self.v}
 
@@ -241,6 +258,8 @@ class LazyTable:
         self.m.copy_(state["exp_avg"])
         self.v.copy_(state["exp_avg_sq"])
         self.last.fill_(self.step)
+        if self.step_dev is not None:
+            self.step_dev.fill_(self.step)
         self._dirty = False
 
 

@@ -32,13 +32,22 @@ def batches(nu, ni, B, T, pair=False):
         out.append(d)
     return out
 
+GRAPH = os.environ.get("FAIRREC_GRAPH") == "1"
+
 def run(name, model, opts, loss_fns, data, gender, W=5, K=20):
     dev = "cuda"
     inters = []
     for d in data:
         d = dict(d); d["gender"] = gender[d["user_id"]]
         inters.append(Interaction(d).to(dev))
+    if GRAPH:
+        from fairrec.graph import GraphedStep
+        gss = [GraphedStep(model.hip_engine(), opt, fn, eager_steps=2) for opt, fn in zip(opts, loss_fns)]
+        name += " [hipGraph step]"
     def step(k):
+        if GRAPH:
+            for gs in gss: gs(inters[k % len(inters)])
+            return
         for opt, fn in zip(opts, loss_fns):
             opt.zero_grad(); loss = fn(inters[k % len(inters)]); loss.backward(); opt.step()
     for k in range(W): step(k)
