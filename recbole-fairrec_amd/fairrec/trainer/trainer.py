@@ -80,9 +80,26 @@ class Trainer(AbstractTrainer):
                              sweep_period=self.config['lazy_adam_sweep_period'])
 
     # --- training -----------------------------------------------------------------------------------------
+    def _graphed_step(self, key, loss_fn):
+        """`graph_train_step: True`: the optimizer step (zero_grad, loss, backward, step) of a generic-engine model as
+        one hipGraph, captured on its third batch and replayed afterwards (fairrec/graph.py).  One graph per
+        (loss function, attribute subset, optimizer)."""
+        if not self.config['graph_train_step']:
+            return None
+        eng = self.model.hip_engine()
+        if eng is None or not hasattr(eng, 'enable_graph_mode'):
+            return None                                   # FOCF: its fused engine has its own launch path
+        graphs = self.__dict__.setdefault('_step_graphs', {})
+        key = key + (id(self.optimizer),)
+        if key not in graphs:
+            from ..graph import GraphedStep
+            graphs[key] = GraphedStep(eng, self.optimizer, loss_fn)
+        return graphs[key]
+
     def _train_epoch(self, train_data, epoch_idx, loss_func=None, show_progress=False):
         self.model.train()
         loss_func = loss_func or self.model.calculate_loss
+        graphed = self._graphed_step(('plain', getattr(loss_func, '__name__', str(loss_func))), loss_func)
         total = None
         n_tuple = 0
         hint = getattr(self.model, 'hint_next_batch', None)
@@ -95,6 +112,10 @@ class Trainer(AbstractTrainer):
             nxt = nxt.to(self.device) if nxt is not None else None
             if hint is not None:
                 hint(nxt)                              # lets the model start the next batch's index sort early
+            if graphed is not None:
+                part = graphed(interaction).view(1)
+                total = part.clone() if total is None else total + part
+                continue
             self.optimizer.zero_grad()
             losses = loss_func(interaction)
             if isinstance(losses, tuple):
@@ -267,8 +288,14 @@ class PFCNTrainer(Trainer):
     def _train_epoch_with_mask(self, train_data, epoch_idx, loss_func=None, sst_list=None, show_progress=False):
         self.model.train()
         total = None
+        graphed = self._graphed_step(('mask', getattr(loss_func, '__name__', str(loss_func)), tuple(sst_list or ())),
+                                     lambda inter: loss_func(inter, sst_list))
         for interaction in train_data:
             interaction = interaction.to(self.device)
+            if graphed is not None:
+                loss = graphed(interaction)
+                total = loss.clone() if total is None else total + loss
+                continue
             self.optimizer.zero_grad()
             loss = loss_func(interaction, sst_list)
             total = loss.detach().clone() if total is None else total + loss.detach()

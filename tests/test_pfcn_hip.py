@@ -118,8 +118,10 @@ def test_pfcn_training_matches_reference_golden(path, sharded, request):
     np.testing.assert_allclose(pr, z["predict_last"], rtol=2e-4, atol=2e-6)
 
 
-def test_pfcn_trainer_alternating_schedule(tmp_path):
-    """PFCNTrainer: mask draw per epoch, filter pass every `train_epoch_interval` epochs, discriminator pass always."""
+@pytest.mark.parametrize("graph", [False, True], ids=["eager", "hipGraph"])
+def test_pfcn_trainer_alternating_schedule(tmp_path, graph):
+    """PFCNTrainer: mask draw per epoch, filter pass every `train_epoch_interval` epochs, discriminator pass always;
+    with `graph_train_step` every (phase, attribute subset) runs as replays of its own captured step."""
     from fairrec.config import Config
     from fairrec.data.dataloader import TrainDataLoader
     from fairrec.data.dataset import InteractionDataset
@@ -136,7 +138,8 @@ def test_pfcn_trainer_alternating_schedule(tmp_path):
     users["age"][1:4] = torch.tensor([0, 1, 2])
     cfg = Config(model="PFCN_BiasedMF", config_dict={
         "embedding_size": 16, "sst_attr_list": ["gender", "age"], "filter_mode": "cm", "dis_hidden_size_list": [16, 8],
-        "train_batch_size": 128, "epochs": 3, "train_epoch_interval": 2, "device": "cuda", "checkpoint_dir": str(tmp_path)})
+        "train_batch_size": 120, "epochs": 3, "train_epoch_interval": 2, "device": "cuda", "checkpoint_dir": str(tmp_path),
+        "graph_train_step": graph})
     ds = InteractionDataset(cfg, inter, users, n_users, n_items)
     model = get_model("PFCN_BiasedMF")(cfg, ds).to("cuda")
     trainer_cls = get_trainer(None, "PFCN_BiasedMF")
@@ -146,7 +149,8 @@ def test_pfcn_trainer_alternating_schedule(tmp_path):
     l = trainer.train_loss_dict
     assert set(l) == {0, 1, 2} and all(np.isfinite(v) for v in l.values())
     eng = model.hip_engine()
-    steps_per_epoch = 5                      # ceil(600 / 128)
+    eng.sync_steps()                         # graph mode keeps the step counters on the device
+    steps_per_epoch = 5                      # 600 / 120
     assert eng._tables["user_embedding_layer.weight"].step == 2 * steps_per_epoch          # filter epochs 0 and 2
     dis_steps = {d.step for k, d in eng._dense.items() if k.startswith("dis.")}
     # a discriminator steps in the epochs whose random mask selected its attribute (at least one attribute per epoch)
