@@ -400,6 +400,11 @@ FR_API int fr_sample_negatives(uint32_t* state, int64_t low, int64_t high, const
  *                               the reference) and DifferentialFairness (float32 table, alpha = 1/n_segments) as means
  *                               over the segments (:972-979, :1068-1075, :1164-1171, :1260-1267, :1337-1342)
  * Double-precision sums in a fixed order. */
+/* fr_eval_hits: the `rec.topk` matrix of a batch of users (collector.py:146-154): rec_topk int32 [n_rows, k+1], entry
+ * [u][j] = 1 if topk_idx[u][j] (the j-th ranked item id of row u) is a positive of row u, [u][k] = its number of
+ * positives.  pos_keys = the sorted keys row * n_items + item of the batch's positives (no dense 0/1 matrix). */
+FR_API int fr_eval_hits(const int64_t* topk_idx, int64_t n_rows, int32_t k, int64_t n_items, const int64_t* pos_keys,
+                        int64_t n_pos, int32_t* rec_topk, void* stream);
 FR_API size_t fr_topk_metrics_workspace_bytes(int64_t n_users, int32_t k);
 FR_API int fr_topk_metrics(const int32_t* rec_topk, int64_t n_users, int32_t k, double* out, void* ws, size_t ws_bytes,
                            void* stream);

@@ -55,6 +55,35 @@ __global__ __launch_bounds__(64) void topk_metrics_kernel(const int32_t* __restr
     }
 }
 
+// rec_topk[u][k] = 1 if the k-th ranked item of row u is one of its positives, rec_topk[u][K] = number of positives of
+// row u (collector.py:146-154 without the dense [users, items] 0/1 matrix): the positives arrive as the SORTED keys
+// row * n_items + item; membership and the per-row count are binary searches.
+__device__ __forceinline__ long long lower_bound_ll(const int64_t* __restrict__ a, long long n, long long key) {
+    long long lo = 0, hi = n;
+    while (lo < hi) {
+        const long long mid = (lo + hi) >> 1;
+        if (a[mid] < key) lo = mid + 1;
+        else hi = mid;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(256) void eval_hits_kernel(const int64_t* __restrict__ topk_idx, long long U, int K,
+                                                        long long n_items, const int64_t* __restrict__ pos_keys,
+                                                        long long n_pos, int32_t* __restrict__ rec_topk) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= U * (K + 1)) return;
+    const long long u = t / (K + 1);
+    const int k = (int)(t % (K + 1));
+    if (k == K) {
+        rec_topk[t] = (int32_t)(lower_bound_ll(pos_keys, n_pos, (u + 1) * n_items) - lower_bound_ll(pos_keys, n_pos, u * n_items));
+    } else {
+        const long long key = u * n_items + topk_idx[u * K + k];
+        const long long p = lower_bound_ll(pos_keys, n_pos, key);
+        rec_topk[t] = (p < n_pos && pos_keys[p] == key) ? 1 : 0;
+    }
+}
+
 // out[j] = (sum over blocks, in block order, of part[b][j]) * scale          j < n
 __global__ __launch_bounds__(256) void column_sum_kernel(const double* __restrict__ part, long long blocks, int n,
                                                          double scale, double* __restrict__ out) {
@@ -171,6 +200,17 @@ extern "C" int fr_topk_metrics(const int32_t* rec_topk, int64_t n_users, int32_t
     FR_CHECK_LAUNCH();
     hipLaunchKernelGGL(column_sum_kernel, dim3((unsigned)((5 * k + 255) / 256)), dim3(256), 0, stream, (const double*)ws,
                        blocks, 5 * k, 1.0 / (double)n_users, out);
+    FR_CHECK_LAUNCH();
+    return FR_OK;
+}
+
+extern "C" int fr_eval_hits(const int64_t* topk_idx, int64_t n_rows, int32_t k, int64_t n_items, const int64_t* pos_keys,
+                            int64_t n_pos, int32_t* rec_topk, void* stream_) {
+    FR_CHECK_ARG(topk_idx && rec_topk && (pos_keys || n_pos == 0) && n_rows >= 1 && k >= 1 && n_items >= 1 && n_pos >= 0,
+                 "fr_eval_hits: bad argument");
+    const long long n = (long long)n_rows * (k + 1);
+    hipLaunchKernelGGL(eval_hits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, topk_idx,
+                       (long long)n_rows, (int)k, (long long)n_items, pos_keys, (long long)n_pos, rec_topk);
     FR_CHECK_LAUNCH();
     return FR_OK;
 }

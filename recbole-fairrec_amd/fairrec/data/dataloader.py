@@ -127,3 +127,66 @@ class FOCFDataLoader(AbstractDataLoader):
             chunks.append(np.arange(lo, hi))
         self.pr += self.step
         return self.dataset.join(self.dataset[np.concatenate(chunks)])
+
+
+class FullSortEvalDataLoader:
+    """general_dataloader.py:170-262 for non-sequential models: iterates over the users of the evaluation set in id order,
+    `max(eval_batch_size // item_num, 1)` users per batch, and yields
+        (user_df, (history_u, history_i), positive_u, positive_i)
+    user_df = the users' feature rows; history = items to mask (used in an earlier phase, from `sampler.used_ids`, minus
+    the positives of this phase); positives = the items of this evaluation set; `*_u` are row indices into the batch.
+    Everything is a device tensor built from two CSRs (positives / history per user); positives are listed in ascending
+    item order (the reference lists them in Python-set order; every metric is order-invariant in full mode)."""
+
+    def __init__(self, config, dataset, sampler, shuffle=False):
+        self.config, self.dataset = config, dataset
+        self.uid_field, self.iid_field = dataset.uid_field, dataset.iid_field
+        self.device = torch.device(config['device'])
+        n_users, n_items = dataset.user_num, dataset.item_num
+        u = dataset.inter_feat[self.uid_field].to(self.device, torch.int64)
+        i = dataset.inter_feat[self.iid_field].to(self.device, torch.int64)
+        pos_keys = torch.unique(u * n_items + i)                                   # sorted by (user, item), distinct
+        self.pos_items = pos_keys % n_items
+        self.pos_indptr = self._indptr(pos_keys // n_items, n_users)
+        used_indptr, used_items, _ = sampler.used_ids                              # CSR of the phase (incl. earlier phases)
+        used_users = torch.repeat_interleave(torch.arange(n_users, device=self.device), used_indptr[1:] - used_indptr[:-1])
+        used_keys = used_users * n_items + used_items.to(torch.int64)
+        hist_keys = used_keys[~torch.isin(used_keys, pos_keys)]                    # history = used - positive
+        self.hist_items = hist_keys % n_items
+        self.hist_indptr = self._indptr(hist_keys // n_items, n_users)
+        self.uid_list = torch.unique(u)                                            # users that have positives, ascending
+        self.user_df = dataset.join(Interaction({self.uid_field: self.uid_list}))
+        self.step = max(int(config['eval_batch_size'] or 4096) // n_items, 1)
+        self.pr = 0
+
+    def _indptr(self, users, n_users):
+        counts = torch.bincount(users, minlength=n_users)
+        indptr = torch.zeros(n_users + 1, dtype=torch.int64, device=self.device)
+        torch.cumsum(counts, 0, out=indptr[1:])
+        return indptr
+
+    def __len__(self):
+        return math.ceil(len(self.uid_list) / self.step)
+
+    def __iter__(self):
+        self.pr = 0
+        return self
+
+    def _rows(self, indptr, items, uids):
+        lo, hi = indptr[uids], indptr[uids + 1]
+        n = hi - lo
+        row = torch.repeat_interleave(torch.arange(len(uids), device=self.device), n)
+        start = torch.repeat_interleave(lo - torch.cumsum(n, 0) + n, n)
+        return row, items[torch.arange(int(n.sum()), device=self.device) + start]
+
+    def __next__(self):
+        if self.pr >= len(self.uid_list):
+            self.pr = 0
+            raise StopIteration()
+        sl = slice(self.pr, self.pr + self.step)
+        self.pr += self.step
+        uids = self.uid_list[sl]
+        user_df = Interaction({k: v[sl] for k, v in self.user_df.interaction.items()})
+        history = self._rows(self.hist_indptr, self.hist_items, uids)
+        positive_u, positive_i = self._rows(self.pos_indptr, self.pos_items, uids)
+        return user_df, history, positive_u, positive_i

@@ -70,7 +70,8 @@ class InteractionDataset:
         uid = inter[self.uid_field].long()
         for k in self.user_feat.columns:
             if k != self.uid_field and k not in inter:
-                inter[k] = self.user_feat[k][uid]
+                col = self.user_feat[k]
+                inter[k] = col[uid.to(col.device)].to(uid.device)
         return inter
 
 

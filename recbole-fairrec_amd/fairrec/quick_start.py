@@ -42,8 +42,16 @@ def run_recbole(model=None, dataset=None, config_file_list=None, config_dict=Non
         train_data = TrainDataLoader(config, train_set.to(config['device']), sampler=sampler, shuffle=True)
     else:
         train_data = TrainDataLoader(config, train_set, shuffle=True)
-    valid_data = TrainDataLoader(config, valid_set)
-    test_data = TrainDataLoader(config, test_set)
+    if (config['eval_args'] or {}).get('mode') == 'full' and config['device'].type == 'cuda':
+        # full-sort ranking evaluation on the device: top-k and fairness metrics of config['metrics'] (fairrec/evaluator)
+        from .data.dataloader import FullSortEvalDataLoader
+        from .sampler import Sampler
+        phases = Sampler(['train', 'valid', 'test'], [train_set, valid_set, test_set], 'uniform', device=config['device'])
+        valid_data = FullSortEvalDataLoader(config, valid_set, phases.set_phase('valid'))
+        test_data = FullSortEvalDataLoader(config, test_set, phases.set_phase('test'))
+    else:
+        valid_data = TrainDataLoader(config, valid_set)
+        test_data = TrainDataLoader(config, test_set)
     init_seed(config['seed'], config['reproducibility'])
     model_obj = get_model(config['model'])(config, train_data.dataset).to(config['device'])
     logger.info(model_obj)

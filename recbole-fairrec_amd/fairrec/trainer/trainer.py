@@ -214,13 +214,61 @@ class Trainer(AbstractTrainer):
                     break
         return self.best_valid_score, self.best_valid_result
 
+    # --- full-sort ranking evaluation on the device (trainer.py:420-438, :458-515) ----------------------------
+    def _full_sort_scores(self, interaction, n_items, sst_list=None):
+        """[users, n_items] scores of a batch of users: `model.full_sort_predict`, or -- as the reference does when a
+        model has none (trainer.py:425-433) -- `predict` on every (user, item) pair, in chunks."""
+        extra = () if sst_list is None else (sst_list,)
+        from ..model.abstract_recommender import AbstractRecommender
+        if type(self.model).full_sort_predict is not AbstractRecommender.full_sort_predict:
+            try:
+                return self.model.full_sort_predict(interaction, *extra).view(-1, n_items)
+            except NotImplementedError:
+                pass
+        U = len(interaction)
+        items = torch.arange(n_items, device=self.device)
+        out = torch.empty((U, n_items), dtype=torch.float32, device=self.device)
+        per = max(int(self.config['eval_batch_size'] or 4096) // n_items, 1)
+        iid = self.config['ITEM_ID_FIELD']
+        for lo in range(0, U, per):
+            part = interaction[lo:lo + per].repeat_interleave(n_items)
+            part.update(type(part)({iid: items.repeat(min(per, U - lo))}))
+            out[lo:lo + per] = self.model.predict(part, *extra).view(-1, n_items)
+        return out
+
+    def _ranking_evaluate(self, eval_data, sst_lists=(None,)):
+        """One result over everything collected: every batch scored once per entry of `sst_lists` (None = no filter
+        argument; the filtered models' validation pools all attribute subsets, trainer.py:1005-1022)."""
+        from ..evaluator import Collector, Evaluator
+        collector, evaluator = Collector(self.config), Evaluator(self.config)
+        n_items = eval_data.dataset.item_num
+        for user_df, (hist_u, hist_i), positive_u, positive_i in eval_data:
+            user_df = user_df.to(self.device)
+            for sst_list in sst_lists:
+                scores = self._full_sort_scores(user_df, n_items, sst_list)
+                scores[:, 0] = -float('inf')                           # [PAD], trainer.py:435
+                scores[hist_u, hist_i] = -float('inf')                 # items of earlier phases, :436-437
+                collector.eval_batch_collect(scores, user_df, positive_u, positive_i)
+        return OrderedDict(evaluator.evaluate(collector.get_data_struct()))
+
+    def _load_for_eval(self, load_best_model, model_file):
+        if load_best_model:
+            checkpoint = torch.load(model_file or self.saved_model_file, weights_only=False)
+            self.model.load_state_dict(checkpoint['state_dict'])
+            self.model.load_other_parameter(checkpoint.get('other_parameter'))
+        self.model.eval()
+
     @torch.no_grad()
     def evaluate(self, eval_data, load_best_model=False, model_file=None, show_progress=False):
-        """Value-type evaluation of `model.predict` on (user, item, rating) batches: RMSE / MAE of the
-        de-normalised score.  The reference's ranking evaluation (uni100 negatives, top-k and fairness metrics,
-        trainer.py:458-515 + recbole/evaluator) is the next row f-2 of SURVEY.md §8 and not built yet."""
+        """A FullSortEvalDataLoader gets the reference's ranking evaluation (top-k and fairness metrics named in
+        `config['metrics']`, fairrec/evaluator); a plain loader of (user, item, rating) batches the value-type RMSE /
+        MAE of `model.predict`.  The `uni100` negative-sampling evaluation loader is not built."""
         if not eval_data:
             return None
+        from ..data.dataloader import FullSortEvalDataLoader
+        if isinstance(eval_data, FullSortEvalDataLoader):
+            self._load_for_eval(load_best_model, model_file)
+            return self._ranking_evaluate(eval_data)
         if load_best_model:
             checkpoint = torch.load(model_file or self.saved_model_file, weights_only=False)
             self.model.load_state_dict(checkpoint['state_dict'])
@@ -323,9 +371,43 @@ class PFCNTrainer(Trainer):
             state['optimizer'] = self.optimizer.state_dict()
         torch.save(state, saved_model_file)
 
+    def _subsets(self):
+        import itertools
+        attrs = self.config['sst_attr_list']
+        return [list(sub) for r in range(1, len(attrs) + 1) for sub in itertools.combinations(attrs, r)]
+
+    @torch.no_grad()
+    def pfcn_evaluate(self, eval_data, load_best_model=False, model_file=None, show_progress=False):
+        """trainer.py:968-1027 (validation during training): ONE result over the batches of every attribute subset."""
+        from ..data.dataloader import FullSortEvalDataLoader
+        if not eval_data:
+            return None
+        if not isinstance(eval_data, FullSortEvalDataLoader):
+            raise NotImplementedError("evaluation of the filtered models needs a FullSortEvalDataLoader")
+        self._load_for_eval(load_best_model, model_file)
+        return self._ranking_evaluate(eval_data, self._subsets() if self.filter_mode != 'none' else (None,))
+
+    def _valid_epoch(self, valid_data, show_progress=False):
+        valid_result = self.pfcn_evaluate(valid_data, load_best_model=False, show_progress=show_progress)
+        return calculate_valid_score(valid_result, self.valid_metric), valid_result
+
+    @torch.no_grad()
     def evaluate(self, eval_data, load_best_model=False, model_file=None, show_progress=False):
-        raise NotImplementedError("PFCN evaluation (ranking metrics per sensitive-attribute subset, trainer.py:1036-1106) "
-                                  "belongs to the evaluator row f-2 and is not built yet")
+        """trainer.py:1047-1106: one result per non-empty subset of the sensitive attributes, keyed
+        '<filter_mode>-<subset>' (filters on), or {'<filter_mode>': result}."""
+        from ..data.dataloader import FullSortEvalDataLoader
+        if eval_data and isinstance(eval_data, FullSortEvalDataLoader):
+            self._load_for_eval(load_best_model, model_file)
+            final = {}
+            if self.filter_mode != 'none':
+                for sub in self._subsets():
+                    final['{}-{}'.format(self.config['filter_mode'] or self.filter_mode, sub)] = \
+                        self._ranking_evaluate(eval_data, (sub,))
+            else:
+                final[self.config['filter_mode']] = self._ranking_evaluate(eval_data)
+            return final
+        raise NotImplementedError("evaluation of the filtered models needs a FullSortEvalDataLoader (ranking + fairness "
+                                  "metrics per sensitive-attribute subset); the uni100 loader is not built")
 
 
 class PFCN_PMFTrainer(PFCNTrainer):
@@ -371,6 +453,8 @@ class FairGoTrainer(PFCNTrainer):
             self.pretrain_epochs = config['pretrain_epochs']
             self.optimizer_pretrain = self._build_optimizer(group='pretrain')
 
+    _valid_epoch = Trainer._valid_epoch      # the reference's FairGoTrainer evaluates like the plain Trainer (:738-772)
+
     def save_pretrained_model(self, saved_model_file):
         torch.save({'config': dict(self.config.final_config_dict), 'state_dict': self.model.state_dict(),
                     'optimizer': self.optimizer.state_dict(), 'other_parameter': self.model.other_parameter()},
@@ -399,6 +483,23 @@ class FairGoTrainer(PFCNTrainer):
         elif self.model.train_stage != 'finetune':
             raise ValueError("Please make sure that the 'train_stage' is 'pretrain' or 'finetune'!")
         return Trainer.fit(self, train_data, valid_data, verbose, saved, show_progress, callback_fn)
+
+    @torch.no_grad()
+    def evaluate(self, eval_data, load_best_model=False, model_file=None, show_progress=False):
+        """trainer.py:738-772: during training the plain evaluation of the current stage; with `load_best_model` the
+        pretrain checkpoint ('pretrain-<metric>') and the finetuned one ('finetune-<metric>')."""
+        if not eval_data:
+            return None
+        if not load_best_model:
+            return Trainer.evaluate(self, eval_data, False, None, show_progress)
+        result = OrderedDict()
+        stages = ([] if self.load_pretrain_weight else [('pretrain', self.saved_pretrain_model_file)]) + \
+            [('finetune', model_file or self.saved_model_file)]
+        for stage, path in stages:
+            self.model.train_stage = stage
+            for key, value in Trainer.evaluate(self, eval_data, True, path, show_progress).items():
+                result[f'{stage}-{key}'] = value
+        return result
 
     def _save_checkpoint(self, epoch, verbose=True, **kwargs):
         saved_model_file = kwargs.pop('saved_model_file', self.saved_model_file)
