@@ -381,13 +381,21 @@ FR_API int fr_adam_dense_multi(const fr_dense_desc* descs, int32_t n_tensors, co
  *                         used-set of key u = used_items[used_indptr[u] .. used_indptr[u+1]) sorted ascending.
  *                         used_indptr = NULL: plain np.random.randint(low, high, n_keys*num) (key_ids unused).
  *                         high - 1 - low < 2^32 - 1 (numpy then draws single 32-bit words, masked rejection).
- * One workgroup per call; the state after the call is exactly numpy's, so calls chain without host syncs. */
+ * One workgroup per call; the state after the call is exactly numpy's, so calls chain without host syncs.
+ *   fr_sample_negatives_calls : a SEQUENCE of single-key calls on one stream in one launch: call c fills
+ *                         out[call_offsets[c] .. call_offsets[c+1]) for key call_keys[c] and completes its re-draw rounds
+ *                         before call c+1 draws -- the evaluation loader's user-by-user sampling
+ *                         (general_dataloader.py:141-146).  max_call >= the longest call (sizes the workspace). */
 FR_API int fr_mt19937_seed(uint32_t* state, uint32_t seed, void* stream);
 FR_API size_t fr_sample_negatives_workspace_bytes(int64_t total);
 FR_API int fr_sample_negatives(uint32_t* state, int64_t low, int64_t high, const int64_t* key_ids, int64_t n_keys,
                                int32_t num, const int64_t* used_indptr, const int32_t* used_items, int64_t n_users,
                                int64_t* out, int32_t* rounds_out, void* ws, size_t ws_bytes, uint32_t* err_flag,
                                void* stream);
+FR_API int fr_sample_negatives_calls(uint32_t* state, int64_t low, int64_t high, const int64_t* call_keys,
+                                     const int64_t* call_offsets, int64_t n_calls, int64_t max_call,
+                                     const int64_t* used_indptr, const int32_t* used_items, int64_t n_users, int64_t* out,
+                                     void* ws, size_t ws_bytes, uint32_t* err_flag, void* stream);
 
 /* ---- evaluation metrics (next-row f-2), recbole/evaluator/metrics.py ------------------------------------------------
  *   fr_topk_metrics           : rec_topk int32 [n_users, k+1] = hit flags of the ranked list | number of positives

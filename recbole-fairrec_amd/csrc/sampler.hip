@@ -76,11 +76,16 @@ __device__ __forceinline__ bool used_contains(const int32_t* __restrict__ items,
     return false;
 }
 
+// Two calling modes: one call over `total` positions keyed by key_ids[i % n_keys]  (call_offsets == nullptr), or a
+// SEQUENCE of calls c = 0..n_calls-1, call c drawing positions [call_offsets[c], call_offsets[c+1]) for the single key
+// call_keys[c] -- each call completes its re-draw rounds before the next one draws, exactly like consecutive
+// sample_by_user_ids calls on one numpy stream (the evaluation loader samples user by user, general_dataloader.py:141-146).
 __global__ __launch_bounds__(SAMPLER_THREADS) void sample_negatives_kernel(
     uint32_t* __restrict__ state, long long low, uint32_t span, uint32_t mask, const int64_t* __restrict__ key_ids,
-    long long n_keys, long long total, const int64_t* __restrict__ used_indptr, const int32_t* __restrict__ used_items,
-    long long n_users, int64_t* __restrict__ out, int32_t* __restrict__ list_a, int32_t* __restrict__ list_b,
-    int32_t* __restrict__ rounds_out, uint32_t* err) {
+    long long n_keys, long long total_all, const int64_t* __restrict__ call_keys,
+    const int64_t* __restrict__ call_offsets, long long n_calls, const int64_t* __restrict__ used_indptr,
+    const int32_t* __restrict__ used_items, long long n_users, int64_t* __restrict__ out_all,
+    int32_t* __restrict__ list_a, int32_t* __restrict__ list_b, int32_t* __restrict__ rounds_out, uint32_t* err) {
     __shared__ uint32_t mt[2][MT_N];
     __shared__ int wave_cnt[SAMPLER_THREADS / 64];
     __shared__ int s_last;
@@ -91,15 +96,22 @@ __global__ __launch_bounds__(SAMPLER_THREADS) void sample_negatives_kernel(
     __syncthreads();
 
     if (span == 0) {   // numpy: a one-value range consumes nothing
-        for (long long e = t; e < total; e += SAMPLER_THREADS) out[e] = low;
+        const long long n_out = call_offsets ? call_offsets[n_calls] : total_all;
+        for (long long e = t; e < n_out; e += SAMPLER_THREADS) out_all[e] = low;
         if (t == 0 && rounds_out) rounds_out[0] = 1;
         return;
     }
 
+    int rounds = 0;
+    const long long calls = call_offsets ? n_calls : 1;
+    for (long long call = 0; call < calls; ++call) {
+    const long long o0 = call_offsets ? call_offsets[call] : 0;
+    const long long total = call_offsets ? call_offsets[call + 1] - o0 : total_all;
+    int64_t* __restrict__ out = out_all + o0;
+    const long long call_key = call_keys ? call_keys[call] : -1;
     const int32_t* list = nullptr;      // positions to (re)draw, ascending; nullptr = all of [0, total)
     int32_t* next = list_a;
     long long need = total;
-    int rounds = 0;
     while (need > 0) {
         // ---- draw `need` values, in position order, from the continuing stream ----
         long long produced = 0;
@@ -144,7 +156,7 @@ __global__ __launch_bounds__(SAMPLER_THREADS) void sample_negatives_kernel(
             long long i = 0;
             if (e < need) {
                 i = list ? (long long)list[e] : e;
-                const long long u = key_ids[i % n_keys];
+                const long long u = call_keys ? call_key : key_ids[i % n_keys];
                 if (u < 0 || u >= n_users) {
                     if (err) atomicOr(err, FR_DEV_ERR_INDEX_RANGE);
                 } else {
@@ -161,6 +173,8 @@ __global__ __launch_bounds__(SAMPLER_THREADS) void sample_negatives_kernel(
         list = next;
         next = (next == list_a) ? list_b : list_a;
         need = kept;
+    }
+    __syncthreads();   // the next call reuses the collision lists
     }
     __syncthreads();
     if (t < MT_N) state[t] = mt[cur][t];
@@ -196,22 +210,15 @@ extern "C" size_t fr_sample_negatives_workspace_bytes(int64_t total) {
     return total < 1 ? 0 : 2 * align_up((size_t)total * sizeof(int32_t), 256);
 }
 
-extern "C" int fr_sample_negatives(uint32_t* state, int64_t low, int64_t high, const int64_t* key_ids, int64_t n_keys,
-                                   int32_t num, const int64_t* used_indptr, const int32_t* used_items, int64_t n_users,
-                                   int64_t* out, int32_t* rounds_out, void* ws, size_t ws_bytes, uint32_t* err_flag,
-                                   void* stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
-    FR_CHECK_ARG(state && out && n_keys >= 1 && num >= 1 && n_keys * (int64_t)num <= (1ll << 30),
-                 "fr_sample_negatives: bad size");
-    FR_CHECK_ARG(high > low && high - 1 - low < 0xffffffffll, "fr_sample_negatives: range [%lld, %lld) not below 2^32",
-                 (long long)low, (long long)high);
-    FR_CHECK_ARG(!used_indptr || (used_items && key_ids && n_users >= 1 && ws), "fr_sample_negatives: used-set arguments");
-    const int64_t total = n_keys * (int64_t)num;
+static int sample_launch(uint32_t* state, int64_t low, int64_t high, const int64_t* key_ids, int64_t n_keys, int64_t total,
+                         const int64_t* call_keys, const int64_t* call_offsets, int64_t n_calls, int64_t max_call,
+                         const int64_t* used_indptr, const int32_t* used_items, int64_t n_users, int64_t* out,
+                         int32_t* rounds_out, void* ws, size_t ws_bytes, uint32_t* err_flag, hipStream_t stream) {
     int32_t *la = nullptr, *lb = nullptr;
     if (used_indptr) {
-        FR_CHECK_ARG(ws_bytes >= fr_sample_negatives_workspace_bytes(total), "fr_sample_negatives: workspace too small");
+        FR_CHECK_ARG(ws && ws_bytes >= fr_sample_negatives_workspace_bytes(max_call), "fr_sample_negatives: workspace too small");
         la = (int32_t*)ws;
-        lb = (int32_t*)((char*)ws + align_up((size_t)total * sizeof(int32_t), 256));
+        lb = (int32_t*)((char*)ws + align_up((size_t)max_call * sizeof(int32_t), 256));
     }
     const uint32_t span = (uint32_t)(high - 1 - low);
     uint32_t mask = span;
@@ -222,8 +229,36 @@ extern "C" int fr_sample_negatives(uint32_t* state, int64_t low, int64_t high, c
     mask |= mask >> 16;
     ProfScope prof(K_SAMPLE_NEG, stream);
     FR_LAUNCH(prof, sample_negatives_kernel, dim3(1), dim3(SAMPLER_THREADS), 0, stream, state, (long long)low, span, mask,
-              key_ids, (long long)n_keys, (long long)total, used_indptr, used_items, (long long)n_users, out, la, lb,
-              rounds_out, err_flag);
+              key_ids, (long long)n_keys, (long long)total, call_keys, call_offsets, (long long)n_calls, used_indptr,
+              used_items, (long long)n_users, out, la, lb, rounds_out, err_flag);
     FR_CHECK_LAUNCH();
     return FR_OK;
+}
+
+extern "C" int fr_sample_negatives(uint32_t* state, int64_t low, int64_t high, const int64_t* key_ids, int64_t n_keys,
+                                   int32_t num, const int64_t* used_indptr, const int32_t* used_items, int64_t n_users,
+                                   int64_t* out, int32_t* rounds_out, void* ws, size_t ws_bytes, uint32_t* err_flag,
+                                   void* stream_) {
+    FR_CHECK_ARG(state && out && n_keys >= 1 && num >= 1 && n_keys * (int64_t)num <= (1ll << 30),
+                 "fr_sample_negatives: bad size");
+    FR_CHECK_ARG(high > low && high - 1 - low < 0xffffffffll, "fr_sample_negatives: range [%lld, %lld) not below 2^32",
+                 (long long)low, (long long)high);
+    FR_CHECK_ARG(!used_indptr || (used_items && key_ids && n_users >= 1 && ws), "fr_sample_negatives: used-set arguments");
+    const int64_t total = n_keys * (int64_t)num;
+    return sample_launch(state, low, high, key_ids, n_keys, total, nullptr, nullptr, 1, total, used_indptr, used_items,
+                         n_users, out, rounds_out, ws, ws_bytes, err_flag, (hipStream_t)stream_);
+}
+
+// A sequence of single-key calls on one stream: call c fills out[call_offsets[c] .. call_offsets[c+1]) for key
+// call_keys[c]; `max_call` >= the longest call sizes the workspace (fr_sample_negatives_workspace_bytes(max_call)).
+extern "C" int fr_sample_negatives_calls(uint32_t* state, int64_t low, int64_t high, const int64_t* call_keys,
+                                         const int64_t* call_offsets, int64_t n_calls, int64_t max_call,
+                                         const int64_t* used_indptr, const int32_t* used_items, int64_t n_users,
+                                         int64_t* out, void* ws, size_t ws_bytes, uint32_t* err_flag, void* stream_) {
+    FR_CHECK_ARG(state && out && call_keys && call_offsets && n_calls >= 1 && max_call >= 1 && max_call <= (1ll << 30),
+                 "fr_sample_negatives_calls: bad argument");
+    FR_CHECK_ARG(high > low && high - 1 - low < 0xffffffffll, "fr_sample_negatives_calls: range not below 2^32");
+    FR_CHECK_ARG(used_indptr && used_items && n_users >= 1 && ws, "fr_sample_negatives_calls: used-set arguments");
+    return sample_launch(state, low, high, nullptr, 1, 0, call_keys, call_offsets, n_calls, max_call, used_indptr, used_items,
+                         n_users, out, nullptr, ws, ws_bytes, err_flag, (hipStream_t)stream_);
 }

@@ -80,6 +80,27 @@ class DeviceRandomState:
         return out
 
 
+    def sample_calls(self, low: int, high: int, call_keys: torch.Tensor, call_counts: torch.Tensor,
+                     used_indptr: torch.Tensor, used_items: torch.Tensor) -> torch.Tensor:
+        """Consecutive single-key calls on this stream in one launch: call c draws call_counts[c] values for key
+        call_keys[c] (each call finishes its re-draw rounds before the next one draws).  Returns the concatenation."""
+        call_keys = call_keys.to(self.device, torch.int64).contiguous()
+        counts = call_counts.to(self.device, torch.int64)
+        offsets = torch.zeros(counts.numel() + 1, dtype=torch.int64, device=self.device)
+        torch.cumsum(counts, 0, out=offsets[1:])
+        total, max_call = int(offsets[-1].item()), int(counts.max().item()) if counts.numel() else 0
+        out = torch.empty(total, dtype=torch.int64, device=self.device)
+        if total:
+            ws = self._workspace(max_call)
+            _C.check(_C.lib().fr_sample_negatives_calls(self.state.data_ptr(), low, high, call_keys.data_ptr(),
+                                                        offsets.data_ptr(), call_keys.numel(), max_call,
+                                                        used_indptr.data_ptr(), used_items.data_ptr(),
+                                                        used_indptr.numel() - 1, out.data_ptr(), ws.data_ptr(), ws.numel(),
+                                                        self.err_flag.data_ptr(), _C.current_stream()),
+                     "fr_sample_negatives_calls")
+        return out
+
+
 _GLOBAL: Dict[str, DeviceRandomState] = {}
 
 

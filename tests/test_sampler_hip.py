@@ -213,3 +213,36 @@ def test_quick_start_pfcn_with_device_negative_sampling(tmp_path):
         "synthetic_users": 200, "synthetic_items": 150, "synthetic_interactions": 4000, "device": "cuda",
         "checkpoint_dir": str(tmp_path), "eval_step": 0}, saved=False)
     assert out["test_result"] is None or isinstance(out["test_result"], dict)
+
+
+def test_multi_call_sampling_equals_consecutive_single_key_calls():
+    """fr_sample_negatives_calls = the evaluation loader's user-by-user draws (general_dataloader.py:141-146: one
+    sample_by_user_ids call per user with all keys equal, 100 negatives per positive) in ONE launch, bit-exact with the
+    consecutive calls on one numpy stream (oracle) and with the single-call kernel."""
+    from fairrec.sampler import Sampler
+    from oracle import sampler as OS
+    rng = np.random.default_rng(5)
+    user_num, item_num = 60, 300
+    u = rng.integers(1, user_num, 2500).astype(np.int64)
+    i = rng.integers(1, item_num, 2500).astype(np.int64)
+    heavy = np.setdiff1d(np.arange(1, item_num), rng.choice(np.arange(1, item_num), 4, replace=False))
+    u, i = np.concatenate([u, np.full(len(heavy), 7)]), np.concatenate([i, heavy])        # user 7: 4 items left
+    used = [set() for _ in range(user_num)]
+    for a, b in zip(u, i):
+        used[a].add(int(b))
+    rs, rs1, ors = _rs(31), _rs(31), OS.MT19937(31)
+    smp = Sampler("test", _DS(user_num, item_num, u, i), device="cuda", random_state=rs).set_phase("test")
+    indptr, items, _ = smp.used_ids
+    keys = np.array([3, 7, 12, 7, 40, 41, 59], dtype=np.int64)
+    counts = np.array([200, 100, 300, 700, 0, 100, 1100], dtype=np.int64)                   # positives x 100, one empty
+    got = rs.sample_calls(1, item_num, torch.from_numpy(keys), torch.from_numpy(counts), indptr, items).cpu().numpy()
+    ref, single = [], []
+    for k, c in zip(keys, counts):
+        if c:
+            ref.append(OS.sample_by_key_ids(ors, np.full(c // 100, k), 100, used, item_num))
+            single.append(rs1.sample_excluding(1, item_num, torch.full((c // 100,), int(k)).cuda(), 100, indptr, items).cpu().numpy())
+    np.testing.assert_array_equal(got, np.concatenate(ref))
+    np.testing.assert_array_equal(got, np.concatenate(single))
+    st = rs.get_state()
+    np.testing.assert_array_equal(st[1], ors.key)
+    assert st[2] == ors.pos
