@@ -21,9 +21,7 @@ class Collector:
         topk = config['topk'] or [10]
         self.topk = [topk] if isinstance(topk, int) else list(topk)
         self.sst = list(config['sst_attr_list'] or [])
-        mode = (config['eval_args'] or {}).get('mode', 'full')
-        if 'full' not in mode:
-            raise NotImplementedError(f"evaluation mode [{mode}]: only full-sort evaluation is on the device path")
+        self.full = 'full' in (config['eval_args'] or {}).get('mode', 'full')
         self._parts: Dict[str, List[torch.Tensor]] = {}
 
     def _add(self, key, t):
@@ -46,6 +44,59 @@ class Collector:
         for s in self.sst:
             if s in interaction:
                 self._add('data.' + s, interaction[s].to(scores.device)[positive_u])
+
+    def eval_batch_collect_candidates(self, origin_scores: torch.Tensor, row_idx: torch.Tensor, interaction,
+                                      positive_u: torch.Tensor, positive_i: torch.Tensor, n_items: int):
+        """The negative-sampling (`uni100`) branch (collector.py:131-205 with full == False, fed by
+        trainer.py:440-456): `origin_scores[r]` is the prediction of row r of `interaction` (user row `row_idx[r]` of the
+        batch, item `interaction[item][r]`); a user's candidates are its positives and sampled negatives.  The reference
+        scatters them into a dense [users, n_items] -inf matrix; here a (row, item) -> score map is a sorted key array,
+        the ranking is a sort over the distinct candidates, and every lookup the reference makes in the dense matrix
+        -- including the ones that land on -inf -- is a binary search (missing = -inf).  `rec.negative_score` /
+        `data.negative_i` / `data.<sst>` follow the reference's row arithmetic literally: rows [P, 2P) of the batch and
+        the first P rows, P = number of positives in the batch."""
+        lib = _C.lib()
+        dev = origin_scores.device
+        iid = self.config['ITEM_ID_FIELD']
+        items = interaction[iid].to(dev, torch.int64)
+        row_idx = row_idx.to(dev, torch.int64)
+        positive_u, positive_i = positive_u.to(dev, torch.int64), positive_i.to(dev, torch.int64)
+        U = int(positive_u[-1].item()) + 1                                    # batch_user_num, trainer.py:453
+        keys, order = torch.sort(row_idx * n_items + items, stable=True)
+        first = torch.ones_like(keys, dtype=torch.bool)
+        first[1:] = keys[1:] != keys[:-1]
+        ckeys, cscore = keys[first], origin_scores.view(-1)[order][first]     # distinct candidates (equal pairs, equal score)
+
+        def lookup(rows, its):
+            q = rows * n_items + its
+            p = torch.searchsorted(ckeys, q).clamp_(max=ckeys.numel() - 1)
+            return torch.where(ckeys[p] == q, cscore[p], torch.full_like(cscore[p], -float('inf')))
+
+        # ranking among a user's candidates: stable sort by score (descending) inside each row
+        K = max(self.topk)
+        o1 = torch.sort(cscore, descending=True, stable=True).indices
+        o2 = torch.sort((ckeys // n_items)[o1], stable=True).indices
+        ranked = o1[o2]                                                        # candidates by (row asc, score desc)
+        rrow = (ckeys // n_items)[ranked]
+        start = torch.searchsorted(rrow, torch.arange(U, device=dev))
+        rank = torch.arange(ranked.numel(), device=dev) - start[rrow]
+        topk_idx = torch.zeros((U, K), dtype=torch.int64, device=dev)          # short lists are padded with [PAD] item 0
+        keep = rank < K
+        topk_idx[rrow[keep], rank[keep]] = (ckeys % n_items)[ranked][keep]
+        pos_keys = torch.sort(positive_u * n_items + positive_i).values
+        rec = torch.empty((U, K + 1), dtype=torch.int32, device=dev)
+        _C.check(lib.fr_eval_hits(topk_idx.data_ptr(), U, K, n_items, pos_keys.data_ptr(), pos_keys.numel(), rec.data_ptr(),
+                                  _C.current_stream()), "fr_eval_hits")
+        P = positive_u.numel()
+        self._add('rec.topk', rec)
+        self._add('rec.positive_score', lookup(positive_u, positive_i))
+        self._add('data.positive_i', positive_i)
+        neg_items = items[P:2 * P]
+        self._add('rec.negative_score', lookup(positive_u[:neg_items.numel()], neg_items))
+        self._add('data.negative_i', neg_items)
+        for s in self.sst:
+            if s in interaction:
+                self._add('data.' + s, interaction[s].to(dev)[:P])
 
     def get_data_struct(self) -> Dict[str, torch.Tensor]:
         out = {k: torch.cat(v, dim=0) for k, v in self._parts.items()}

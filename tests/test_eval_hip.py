@@ -11,7 +11,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
-CASES = sorted(glob.glob(os.path.join(GOLDEN, "collector_*.npz")))
+CASES = sorted(glob.glob(os.path.join(GOLDEN, "collector_full_*.npz")))
 
 
 @pytest.mark.parametrize("path", CASES, ids=[os.path.basename(p)[10:-4] for p in CASES])
@@ -98,3 +98,39 @@ def test_run_recbole_full_sort_evaluation(tmp_path):
     out = run_recbole(model="PFCN_PMF", config_dict=dict(common, filter_mode="sm", dis_hidden_size_list=[16, 8],
                                                          train_epoch_interval=1))
     assert list(out["test_result"]) == ["sm-['gender']"] and "ndcg@10" in out["test_result"]["sm-['gender']"]
+
+
+UNI_CASES = sorted(glob.glob(os.path.join(GOLDEN, "collector_uni_*.npz")))
+
+
+@pytest.mark.parametrize("path", UNI_CASES, ids=[os.path.basename(p)[14:-4] for p in UNI_CASES])
+def test_uni_collector_matches_reference_golden_including_its_quirks(path):
+    """Negative-sampling (`uni100`) branch: candidate lists instead of the dense -inf matrix; the reference's row
+    arithmetic for `rec.negative_score` (rows [P, 2P) of the batch) is reproduced, -inf / nan results included."""
+    from fairrec.config import Config
+    from fairrec.data.interaction import Interaction
+    from fairrec.evaluator import Collector, Evaluator
+    z = np.load(path)
+    n_items = int(z["n_items"])
+    cfg = Config(config_dict={"metrics": [str(m) for m in z["metrics"]], "topk": [int(k) for k in z["topk"]],
+                              "metric_decimal_place": 10, "sst_attr_list": ["gender"],
+                              "eval_args": {"mode": f"uni{int(z['n_neg'])}"}, "device": "cuda"})
+    col, ev = Collector(cfg), Evaluator(cfg)
+    assert not col.full
+    d = lambda k: torch.from_numpy(z[k]).cuda()
+    for b in range(int(z["n_batches"])):
+        inter = Interaction({"item_id": d(f"items{b}"), "gender": d(f"sst{b}")})
+        col.eval_batch_collect_candidates(d(f"origin{b}"), d(f"row_idx{b}"), inter, d(f"pos_u{b}"), d(f"pos_i{b}"), n_items)
+    struct = col.get_data_struct()
+    for key in ("rec.topk", "rec.positive_score", "data.positive_i", "rec.negative_score", "data.negative_i", "data.gender"):
+        if "collected." + key in z.files:
+            np.testing.assert_array_equal(struct[key].cpu().numpy(), z["collected." + key])
+    ref = json.loads(str(z["result_json"]))
+    got = ev.evaluate(struct)
+    assert set(got) == set(ref)
+    for k, v in ref.items():
+        if np.isnan(v):
+            assert np.isnan(got[k]), (k, got[k])
+        else:
+            tol = 5e-6 if "Differential" in k or "NonParity" in k else 1e-8
+            assert abs(got[k] - v) <= tol * max(1.0, abs(v)), (k, got[k], v)
