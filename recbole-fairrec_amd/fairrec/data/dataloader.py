@@ -190,3 +190,69 @@ class FullSortEvalDataLoader:
         history = self._rows(self.hist_indptr, self.hist_items, uids)
         positive_u, positive_i = self._rows(self.pos_indptr, self.pos_items, uids)
         return user_df, history, positive_u, positive_i
+
+
+class NegSampleEvalDataLoader:
+    """general_dataloader.py:68-158 with `eval_args.mode: uniN`: users in id order; per user its positives (dataset order
+    after a stable sort by user) followed by N sampled negatives per positive, drawn user by user from the numpy-compatible
+    device stream (fr_sample_negatives_calls: each user's re-draw rounds complete before the next user draws, exactly like
+    the reference's consecutive sample_by_user_ids calls).  Yields (interaction, row_idx, positive_u, positive_i); how many
+    users form a batch follows :100-117."""
+
+    def __init__(self, config, dataset, sampler, shuffle=False):
+        mode = (config['eval_args'] or {}).get('mode', '')
+        if mode[:3] != 'uni':
+            raise NotImplementedError(f"evaluation mode [{mode}]: uniN (uniform negatives) or full")
+        self.config, self.dataset, self.sampler = config, dataset, sampler
+        self.neg_sample_num = int(mode[3:])
+        self.times = 1 + self.neg_sample_num
+        self.uid_field, self.iid_field = dataset.uid_field, dataset.iid_field
+        self.device = torch.device(config['device'])
+        dataset.sort(by=self.uid_field, ascending=True)
+        u = dataset.inter_feat[self.uid_field].to(self.device, torch.int64)
+        self.items = dataset.inter_feat[self.iid_field].to(self.device, torch.int64)
+        self.uid_list, counts = torch.unique_consecutive(u, return_counts=True)
+        self.counts = counts
+        self.start = torch.cumsum(counts, 0) - counts
+        inters = sorted((counts * self.times).tolist(), reverse=True)           # :103-113
+        batch_size = int(config['eval_batch_size'] or 4096)
+        batch_num, size = 1, inters[0]
+        for k in range(1, len(inters)):
+            if size + inters[k] > batch_size:
+                break
+            batch_num, size = k + 1, size + inters[k]
+        self.step = batch_num
+        self.pr = 0
+
+    def __len__(self):
+        return math.ceil(len(self.uid_list) / self.step)
+
+    def __iter__(self):
+        self.pr = 0
+        return self
+
+    def __next__(self):
+        if self.pr >= len(self.uid_list):
+            self.pr = 0
+            raise StopIteration()
+        sl = slice(self.pr, self.pr + self.step)
+        self.pr += self.step
+        dev, N = self.device, self.neg_sample_num
+        uids, P, st = self.uid_list[sl], self.counts[sl], self.start[sl]
+        Ub = uids.numel()
+        indptr, used_items, _ = self.sampler.used_ids
+        neg = self.sampler.rs.sample_calls(1, self.dataset.item_num, uids, P * N, indptr, used_items)
+        blk = P * self.times
+        blk_off = torch.cumsum(blk, 0) - blk
+        rows = int(blk.sum())
+        row_idx = torch.repeat_interleave(torch.arange(Ub, device=dev), blk)
+        within = torch.arange(rows, device=dev) - blk_off[row_idx]
+        is_pos = within < P[row_idx]
+        item_col = torch.empty(rows, dtype=torch.int64, device=dev)
+        item_col[is_pos] = self.items[(st[row_idx] + within)[is_pos]]
+        neg_off = torch.cumsum(P * N, 0) - P * N
+        item_col[~is_pos] = neg[(neg_off[row_idx] + within - P[row_idx])[~is_pos]]
+        inter = self.dataset.join(Interaction({self.uid_field: uids[row_idx], self.iid_field: item_col}))
+        positive_u = row_idx[is_pos]
+        positive_i = item_col[is_pos]
+        return inter, row_idx, positive_u, positive_i

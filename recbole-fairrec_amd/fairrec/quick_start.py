@@ -42,13 +42,16 @@ def run_recbole(model=None, dataset=None, config_file_list=None, config_dict=Non
         train_data = TrainDataLoader(config, train_set.to(config['device']), sampler=sampler, shuffle=True)
     else:
         train_data = TrainDataLoader(config, train_set, shuffle=True)
-    if (config['eval_args'] or {}).get('mode') == 'full' and config['device'].type == 'cuda':
-        # full-sort ranking evaluation on the device: top-k and fairness metrics of config['metrics'] (fairrec/evaluator)
-        from .data.dataloader import FullSortEvalDataLoader
+    eval_mode = (config['eval_args'] or {}).get('mode') or ''
+    if (eval_mode == 'full' or eval_mode[:3] == 'uni') and config['device'].type == 'cuda':
+        # ranking evaluation on the device: top-k and fairness metrics of config['metrics'] (fairrec/evaluator); `uniN`
+        # draws N negatives per positive from the numpy-compatible device stream, `full` ranks the whole catalogue
+        from .data.dataloader import FullSortEvalDataLoader, NegSampleEvalDataLoader
         from .sampler import Sampler
         phases = Sampler(['train', 'valid', 'test'], [train_set, valid_set, test_set], 'uniform', device=config['device'])
-        valid_data = FullSortEvalDataLoader(config, valid_set, phases.set_phase('valid'))
-        test_data = FullSortEvalDataLoader(config, test_set, phases.set_phase('test'))
+        loader = FullSortEvalDataLoader if eval_mode == 'full' else NegSampleEvalDataLoader
+        valid_data = loader(config, valid_set, phases.set_phase('valid'))
+        test_data = loader(config, test_set, phases.set_phase('test'))
     else:
         valid_data = TrainDataLoader(config, valid_set)
         test_data = TrainDataLoader(config, test_set)

@@ -239,9 +239,19 @@ class Trainer(AbstractTrainer):
     def _ranking_evaluate(self, eval_data, sst_lists=(None,)):
         """One result over everything collected: every batch scored once per entry of `sst_lists` (None = no filter
         argument; the filtered models' validation pools all attribute subsets, trainer.py:1005-1022)."""
+        from ..data.dataloader import NegSampleEvalDataLoader
         from ..evaluator import Collector, Evaluator
         collector, evaluator = Collector(self.config), Evaluator(self.config)
         n_items = eval_data.dataset.item_num
+        if isinstance(eval_data, NegSampleEvalDataLoader):             # uniN: trainer.py:440-456
+            per = int(self.config['eval_batch_size'] or 4096)
+            for interaction, row_idx, positive_u, positive_i in eval_data:
+                for sst_list in sst_lists:
+                    extra = () if sst_list is None else (sst_list,)
+                    scores = torch.cat([self.model.predict(interaction[lo:lo + per], *extra).view(-1)
+                                        for lo in range(0, len(interaction), per)])
+                    collector.eval_batch_collect_candidates(scores, row_idx, interaction, positive_u, positive_i, n_items)
+            return OrderedDict(evaluator.evaluate(collector.get_data_struct()))
         for user_df, (hist_u, hist_i), positive_u, positive_i in eval_data:
             user_df = user_df.to(self.device)
             for sst_list in sst_lists:
@@ -265,8 +275,8 @@ class Trainer(AbstractTrainer):
         MAE of `model.predict`.  The `uni100` negative-sampling evaluation loader is not built."""
         if not eval_data:
             return None
-        from ..data.dataloader import FullSortEvalDataLoader
-        if isinstance(eval_data, FullSortEvalDataLoader):
+        from ..data.dataloader import FullSortEvalDataLoader, NegSampleEvalDataLoader
+        if isinstance(eval_data, (FullSortEvalDataLoader, NegSampleEvalDataLoader)):
             self._load_for_eval(load_best_model, model_file)
             return self._ranking_evaluate(eval_data)
         if load_best_model:
@@ -379,11 +389,11 @@ class PFCNTrainer(Trainer):
     @torch.no_grad()
     def pfcn_evaluate(self, eval_data, load_best_model=False, model_file=None, show_progress=False):
         """trainer.py:968-1027 (validation during training): ONE result over the batches of every attribute subset."""
-        from ..data.dataloader import FullSortEvalDataLoader
+        from ..data.dataloader import FullSortEvalDataLoader, NegSampleEvalDataLoader
         if not eval_data:
             return None
-        if not isinstance(eval_data, FullSortEvalDataLoader):
-            raise NotImplementedError("evaluation of the filtered models needs a FullSortEvalDataLoader")
+        if not isinstance(eval_data, (FullSortEvalDataLoader, NegSampleEvalDataLoader)):
+            raise NotImplementedError("evaluation of the filtered models needs a ranking evaluation loader")
         self._load_for_eval(load_best_model, model_file)
         return self._ranking_evaluate(eval_data, self._subsets() if self.filter_mode != 'none' else (None,))
 
@@ -395,8 +405,8 @@ class PFCNTrainer(Trainer):
     def evaluate(self, eval_data, load_best_model=False, model_file=None, show_progress=False):
         """trainer.py:1047-1106: one result per non-empty subset of the sensitive attributes, keyed
         '<filter_mode>-<subset>' (filters on), or {'<filter_mode>': result}."""
-        from ..data.dataloader import FullSortEvalDataLoader
-        if eval_data and isinstance(eval_data, FullSortEvalDataLoader):
+        from ..data.dataloader import FullSortEvalDataLoader, NegSampleEvalDataLoader
+        if eval_data and isinstance(eval_data, (FullSortEvalDataLoader, NegSampleEvalDataLoader)):
             self._load_for_eval(load_best_model, model_file)
             final = {}
             if self.filter_mode != 'none':
@@ -406,8 +416,8 @@ class PFCNTrainer(Trainer):
             else:
                 final[self.config['filter_mode']] = self._ranking_evaluate(eval_data)
             return final
-        raise NotImplementedError("evaluation of the filtered models needs a FullSortEvalDataLoader (ranking + fairness "
-                                  "metrics per sensitive-attribute subset); the uni100 loader is not built")
+        raise NotImplementedError("evaluation of the filtered models needs a ranking evaluation loader "
+                                  "(FullSortEvalDataLoader / NegSampleEvalDataLoader)")
 
 
 class PFCN_PMFTrainer(PFCNTrainer):

@@ -134,3 +134,72 @@ def test_uni_collector_matches_reference_golden_including_its_quirks(path):
         else:
             tol = 5e-6 if "Differential" in k or "NonParity" in k else 1e-8
             assert abs(got[k] - v) <= tol * max(1.0, abs(v)), (k, got[k], v)
+
+
+def test_neg_sample_eval_loader_against_the_reference_recipe():
+    """uniN loader: users in id order, per user [positives | N negatives per positive], negatives from consecutive
+    single-user sample_by_user_ids calls on ONE numpy stream (oracle), batch size rule of general_dataloader.py:100-117."""
+    from fairrec.config import Config
+    from fairrec.data.dataloader import NegSampleEvalDataLoader
+    from fairrec.data.dataset import InteractionDataset
+    from fairrec.data.interaction import Interaction
+    from fairrec.sampler import DeviceRandomState, Sampler
+    from oracle import sampler as OS
+    rng = np.random.default_rng(2)
+    n_users, n_items, N = 25, 60, 7
+    cfg = Config(config_dict={"eval_batch_size": 200, "device": "cuda", "eval_args": {"mode": f"uni{N}"}})
+    users = Interaction({"user_id": torch.arange(n_users), "gender": torch.from_numpy(rng.integers(0, 2, n_users).astype(np.float32))})
+    mk = lambda n: InteractionDataset(cfg, Interaction({"user_id": torch.from_numpy(rng.integers(1, n_users, n)),
+                                                        "item_id": torch.from_numpy(rng.integers(1, n_items, n))}),
+                                      users, n_users, n_items)
+    train, test = mk(200), mk(50)
+    tu, ti = test.inter_feat["user_id"].numpy().copy(), test.inter_feat["item_id"].numpy().copy()
+    used = [set() for _ in range(n_users)]
+    for a, b in list(zip(train.inter_feat["user_id"].tolist(), train.inter_feat["item_id"].tolist())) + list(zip(tu, ti)):
+        used[a].add(int(b))
+    rs = DeviceRandomState("cuda", 77)
+    sampler = Sampler(["train", "test"], [train, test], device="cuda", random_state=rs).set_phase("test")
+    dl = NegSampleEvalDataLoader(cfg, test, sampler)
+    order = np.argsort(tu, kind="stable")
+    su, si = tu[order], ti[order]
+    uid_list = np.unique(su)
+    sizes = sorted((np.bincount(su, minlength=n_users)[uid_list] * (1 + N)).tolist(), reverse=True)
+    step, tot = 1, sizes[0]
+    for k in range(1, len(sizes)):
+        if tot + sizes[k] > 200:
+            break
+        step, tot = k + 1, tot + sizes[k]
+    assert dl.step == step
+    ors = OS.MT19937(77)
+    seen = 0
+    for b, (inter, row_idx, pu, pi) in enumerate(dl):
+        uids = uid_list[b * step:(b + 1) * step]
+        exp_u, exp_i, exp_row, exp_pu, exp_pi = [], [], [], [], []
+        for r, u in enumerate(uids):
+            pos = si[su == u]
+            neg = OS.sample_by_key_ids(ors, np.full(len(pos), u), N, used, n_items)
+            exp_u += [u] * (len(pos) * (1 + N))
+            exp_i += list(pos) + list(neg)
+            exp_row += [r] * (len(pos) * (1 + N))
+            exp_pu += [r] * len(pos)
+            exp_pi += list(pos)
+        np.testing.assert_array_equal(inter["user_id"].cpu().numpy(), exp_u)
+        np.testing.assert_array_equal(inter["item_id"].cpu().numpy(), exp_i)
+        np.testing.assert_array_equal(row_idx.cpu().numpy(), exp_row)
+        np.testing.assert_array_equal(pu.cpu().numpy(), exp_pu)
+        np.testing.assert_array_equal(pi.cpu().numpy(), exp_pi)
+        np.testing.assert_array_equal(inter["gender"].cpu().numpy(), users["gender"].numpy()[np.array(exp_u)])
+        seen += len(uids)
+    assert seen == len(uid_list)
+
+
+def test_run_recbole_uni_evaluation(tmp_path):
+    from fairrec.quick_start import run_recbole
+    out = run_recbole(model="PFCN_PMF", config_dict={
+        "epochs": 1, "train_batch_size": 512, "synthetic_users": 120, "synthetic_items": 300, "synthetic_interactions": 3000,
+        "device": "cuda", "checkpoint_dir": str(tmp_path), "embedding_size": 16, "eval_args": {"mode": "uni20"},
+        "topk": [5, 10], "valid_metric": "ndcg@10", "valid_metric_bigger": True, "filter_mode": "none",
+        "metrics": ["NDCG", "Recall", "Hit", "MRR", "DifferentialFairness", "NonParityUnfairness"],
+        "sst_attr_list": ["gender"], "eval_batch_size": 2048, "metric_decimal_place": 4})
+    res = out["test_result"]["none"]
+    assert 0.0 <= res["ndcg@10"] <= 1.0 and np.isfinite(res["Differential Fairness of sensitive attribute gender"])
