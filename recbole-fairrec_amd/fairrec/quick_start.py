@@ -62,7 +62,7 @@ def run_recbole(model=None, dataset=None, config_file_list=None, config_dict=Non
     best_valid_score, best_valid_result = trainer.fit(train_data, valid_data, saved=saved)
     try:
         test_result = trainer.evaluate(test_data, load_best_model=saved)
-    except NotImplementedError as e:       # ranking evaluation of the filtered models: SURVEY.md §8 next-row f-2
+    except NotImplementedError as e:       # e.g. a filtered model evaluated without a ranking evaluation loader
         logger.warning('evaluation skipped: %s', e)
         test_result = None
     return {'best_valid_score': best_valid_score, 'valid_score_bigger': config['valid_metric_bigger'],

@@ -270,9 +270,9 @@ class Trainer(AbstractTrainer):
 
     @torch.no_grad()
     def evaluate(self, eval_data, load_best_model=False, model_file=None, show_progress=False):
-        """A FullSortEvalDataLoader gets the reference's ranking evaluation (top-k and fairness metrics named in
-        `config['metrics']`, fairrec/evaluator); a plain loader of (user, item, rating) batches the value-type RMSE /
-        MAE of `model.predict`.  The `uni100` negative-sampling evaluation loader is not built."""
+        """A FullSortEvalDataLoader / NegSampleEvalDataLoader gets the reference's ranking evaluation (top-k and
+        fairness metrics named in `config['metrics']`, fairrec/evaluator); a plain loader of (user, item, rating)
+        batches the value-type RMSE / MAE of `model.predict`."""
         if not eval_data:
             return None
         from ..data.dataloader import FullSortEvalDataLoader, NegSampleEvalDataLoader
