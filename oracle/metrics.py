@@ -100,6 +100,32 @@ def differential_fairness(score, iids, sst_value):
     return float(eps.mean())
 
 
+def gini_index(rec_items, num_items, topk):
+    """metrics.py:638-662: Gini index of the item exposure in the top-k lists."""
+    out = {}
+    for k in topk:
+        cnt = np.sort(np.unique(np.asarray(rec_items)[:, :k].ravel(), return_counts=True)[1])
+        idx = np.arange(num_items - len(cnt) + 1, num_items + 1)
+        total = rec_items.shape[0] * k
+        out[f"giniindex@{k}"] = float(np.sum((2 * idx - num_items - 1) * cnt) / total / num_items)
+    return out
+
+
+def popularity_percentage(rec_items, train_items, topk, popularity_ratio=None):
+    """metrics.py:749-821: share of "popular" items in the top-k lists; popular = the top `ratio` fraction of the items
+    that occur in training ordered by (count, id) descending (ratio <= 1) or the items with count >= ratio (> 1)."""
+    ratio = 0.1 if popularity_ratio is None or popularity_ratio <= 0 else popularity_ratio
+    items, cnt = np.unique(train_items, return_counts=True)
+    if ratio > 1:
+        popular = items[cnt >= ratio]
+    else:
+        order = np.lexsort((items, cnt))[::-1]
+        popular = items[order[:max(int(len(items) * ratio), 1)]]
+    hit = np.isin(np.asarray(rec_items), popular)
+    avg = (hit.cumsum(axis=1) / np.arange(1, hit.shape[1] + 1)).mean(axis=0)
+    return {f"popularitypercentage@{k}": float(avg[k - 1]) for k in topk}
+
+
 def all_metrics(z, topk, mode, sst_attrs):
     """Every metric of a golden case, with the reference's result keys."""
     out = topk_metrics(z["rec_topk"], topk)

@@ -23,6 +23,15 @@ class Collector:
         self.sst = list(config['sst_attr_list'] or [])
         self.full = 'full' in (config['eval_args'] or {}).get('mode', 'full')
         self._parts: Dict[str, List[torch.Tensor]] = {}
+        self._data: Dict[str, object] = {}
+
+    def data_collect(self, train_data):
+        """collector.py:80-97: what the exposure metrics need from the training data -- the catalogue size and how often
+        every item occurs in training (a dense count vector here, a Counter in the reference)."""
+        ds = train_data.dataset
+        items = ds.inter_feat[ds.iid_field].to(torch.int64)
+        self._data['data.num_items'] = int(ds.item_num)
+        self._data['data.count_items'] = torch.bincount(items.reshape(-1), minlength=int(ds.item_num))
 
     def _add(self, key, t):
         self._parts.setdefault(key, []).append(t)
@@ -39,6 +48,7 @@ class Collector:
         _C.check(lib.fr_eval_hits(topk_idx.data_ptr(), U, K, n_items, keys.data_ptr(), keys.numel(), rec.data_ptr(),
                                   _C.current_stream()), "fr_eval_hits")
         self._add('rec.topk', rec)
+        self._add('rec.items', topk_idx)
         self._add('rec.positive_score', scores[positive_u, positive_i])
         self._add('data.positive_i', positive_i)
         for s in self.sst:
@@ -89,6 +99,7 @@ class Collector:
                                   _C.current_stream()), "fr_eval_hits")
         P = positive_u.numel()
         self._add('rec.topk', rec)
+        self._add('rec.items', topk_idx)
         self._add('rec.positive_score', lookup(positive_u, positive_i))
         self._add('data.positive_i', positive_i)
         neg_items = items[P:2 * P]
@@ -100,5 +111,6 @@ class Collector:
 
     def get_data_struct(self) -> Dict[str, torch.Tensor]:
         out = {k: torch.cat(v, dim=0) for k, v in self._parts.items()}
+        out.update(self._data)
         self._parts = {}
         return out

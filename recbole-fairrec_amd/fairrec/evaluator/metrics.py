@@ -108,10 +108,39 @@ def fairness_metrics(pos_score, pos_i, sst: Dict[str, torch.Tensor], neg_score=N
     return res
 
 
+def gini_index(rec_items: torch.Tensor, num_items: int, topk) -> Dict[str, float]:
+    """GiniIndex@k (metrics.py:638-662) of the item exposure in the top-k lists: counts by bincount, no host loop."""
+    res = {}
+    for k in topk:
+        cnt = torch.bincount(rec_items[:, :k].reshape(-1), minlength=num_items)
+        cnt = torch.sort(cnt[cnt > 0]).values.to(torch.float64)
+        idx = torch.arange(num_items - cnt.numel() + 1, num_items + 1, device=cnt.device, dtype=torch.float64)
+        res[f'giniindex@{k}'] = float(((2 * idx - num_items - 1) * cnt).sum() / (rec_items.shape[0] * k) / num_items)
+    return res
+
+
+def popularity_percentage(rec_items: torch.Tensor, count_items: torch.Tensor, topk, popularity_ratio=None) -> Dict[str, float]:
+    """PopularityPercentage@k (metrics.py:749-821): popular = top `ratio` fraction of the items that occur in training,
+    ordered by (count, id) descending, or the items with count >= ratio when ratio > 1."""
+    ratio = 0.1 if popularity_ratio is None or popularity_ratio <= 0 else popularity_ratio
+    present = torch.nonzero(count_items > 0).view(-1)
+    if ratio > 1:
+        popular = count_items >= ratio
+    else:
+        cnt = count_items[present]
+        order = torch.sort(cnt * (count_items.numel() + 1) + present, descending=True).indices   # (count, id) descending
+        popular = torch.zeros_like(count_items, dtype=torch.bool)
+        popular[present[order[:max(int(present.numel() * ratio), 1)]]] = True
+    hit = popular[rec_items].to(torch.float64)
+    avg = (hit.cumsum(dim=1) / torch.arange(1, hit.shape[1] + 1, device=hit.device, dtype=torch.float64)).mean(dim=0).cpu()
+    return {f'popularitypercentage@{k}': float(avg[k - 1]) for k in topk}
+
+
 class Evaluator:
     """recbole/evaluator/evaluator.py: metric names from `config['metrics']` -> one result dict."""
 
     TOPK = {"hit", "mrr", "ndcg", "recall", "precision"}
+    EXPOSURE = {"giniindex", "popularitypercentage"}
     FAIR = {"nonparityunfairness", "valueunfairness", "absoluteunfairness", "underunfairness", "overunfairness",
             "differentialfairness"}
 
@@ -123,7 +152,7 @@ class Evaluator:
             self.topk = [self.topk]
         self.decimal_place = config['metric_decimal_place'] if config['metric_decimal_place'] is not None else 4
         self.mode = (config['eval_args'] or {}).get('mode', 'full')
-        unknown = [m for m in self.metrics if m not in self.TOPK | self.FAIR]
+        unknown = [m for m in self.metrics if m not in self.TOPK | self.FAIR | self.EXPOSURE]
         if unknown:
             raise NotImplementedError(f'metrics {unknown} are not on the device path')
 
@@ -132,6 +161,11 @@ class Evaluator:
         if self.TOPK & set(self.metrics):
             allk = topk_metrics(collected['rec.topk'], self.topk)
             res.update({k: v for k, v in allk.items() if k.split('@')[0] in self.metrics})
+        if "giniindex" in self.metrics:
+            res.update(gini_index(collected['rec.items'], collected['data.num_items'], self.topk))
+        if "popularitypercentage" in self.metrics:
+            res.update(popularity_percentage(collected['rec.items'], collected['data.count_items'], self.topk,
+                                             self.config['popularity_ratio']))
         if self.FAIR & set(self.metrics):
             sst = {s: collected['data.' + s] for s in self.config['sst_attr_list']}
             fair = fairness_metrics(collected['rec.positive_score'], collected['data.positive_i'], sst,

@@ -184,6 +184,7 @@ class Trainer(AbstractTrainer):
 
     def fit(self, train_data, valid_data=None, verbose=True, saved=True, show_progress=False, callback_fn=None):
         """reference trainer.py:332-418: returns (best_valid_score, best_valid_result)."""
+        self._train_data_for_eval = train_data                        # eval_collector.data_collect(train_data), :341
         if saved and self.start_epoch >= self.epochs:
             self._save_checkpoint(-1, verbose=verbose)
         for epoch_idx in range(self.start_epoch, self.epochs):
@@ -242,6 +243,8 @@ class Trainer(AbstractTrainer):
         from ..data.dataloader import NegSampleEvalDataLoader
         from ..evaluator import Collector, Evaluator
         collector, evaluator = Collector(self.config), Evaluator(self.config)
+        if getattr(self, '_train_data_for_eval', None) is not None:
+            collector.data_collect(self._train_data_for_eval)         # catalogue size / training popularity (:341)
         n_items = eval_data.dataset.item_num
         if isinstance(eval_data, NegSampleEvalDataLoader):             # uniN: trainer.py:440-456
             per = int(self.config['eval_batch_size'] or 4096)

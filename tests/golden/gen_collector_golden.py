@@ -29,12 +29,21 @@ class _Cfg(dict):
         return self.get(k, None)
 
 
-def run_case(name, seed, n_items, batches, topk, metrics):
+def run_case(name, seed, n_items, batches, topk, metrics, popularity_ratio=None):
     rng = np.random.default_rng(seed)
     cfg = _Cfg(metrics=metrics, topk=list(topk), metric_decimal_place=10, sst_attr_list=["gender"],
-               eval_args={"mode": "full"}, device=torch.device("cpu"), ITEM_ID_FIELD="item_id", USER_ID_FIELD="user_id")
+               eval_args={"mode": "full"}, device=torch.device("cpu"), ITEM_ID_FIELD="item_id", USER_ID_FIELD="user_id",
+               popularity_ratio=popularity_ratio)
     col, ev = Collector(cfg), Evaluator(cfg)
-    out = {"n_items": np.array(n_items), "topk": np.array(topk), "metrics": np.array(metrics), "n_batches": np.array(len(batches))}
+    out = {"n_items": np.array(n_items), "topk": np.array(topk), "metrics": np.array(metrics), "n_batches": np.array(len(batches)),
+           "popularity_ratio": np.array(-1.0 if popularity_ratio is None else popularity_ratio)}
+    # what Collector.data_collect(train_data) would provide (collector.py:80-97): the catalogue size and the training
+    # popularity of the items that occur in training (Counter: items absent from training are absent from it)
+    train_items = np.floor((n_items - 1) * rng.random(20 * n_items) ** 2).astype(np.int64) + 1
+    out["train_items"] = train_items
+    from collections import Counter
+    col.data_struct.set("data.num_items", n_items)
+    col.data_struct.set("data.count_items", Counter(train_items.tolist()))
     uid0 = 1
     for b, Ub in enumerate(batches):
         scores = rng.random((Ub, n_items)).astype(np.float32)              # predict() outputs are in [0, 1]
@@ -59,7 +68,7 @@ def run_case(name, seed, n_items, batches, topk, metrics):
         inter = Interaction({"user_id": torch.from_numpy(out[f"users{b}"]), "gender": torch.from_numpy(gender)})
         col.eval_batch_collect(s, inter, torch.from_numpy(pos_u), torch.from_numpy(pos_i))
     struct = col.get_data_struct()
-    for key in ("rec.topk", "rec.positive_score", "data.positive_i", "data.gender"):
+    for key in ("rec.topk", "rec.items", "rec.positive_score", "data.positive_i", "data.gender"):
         if key in struct:
             out["collected." + key] = struct.get(key).numpy()
     out["result_json"] = np.array(json.dumps({k: float(v) for k, v in ev.evaluate(struct).items()}))
@@ -75,6 +84,8 @@ def main():
     run_case("full_small", 1, 40, [7, 7, 3], (5, 10), ranking + fair)
     run_case("full_medium", 2, 600, [64, 64, 64, 17], (1, 10, 20), ranking + fair)
     run_case("full_ranking_only", 3, 90, [30, 11], (10,), ranking)
+    run_case("full_popularity", 4, 300, [50, 50, 21], (5, 20), ranking + ["GiniIndex", "PopularityPercentage"] + fair)
+    run_case("full_popularity_threshold", 5, 120, [40, 9], (10,), ["GiniIndex", "PopularityPercentage"], popularity_ratio=30)
 
 
 if __name__ == "__main__":

@@ -20,11 +20,15 @@ def test_collector_and_evaluator_match_reference_golden(path):
     from fairrec.data.interaction import Interaction
     from fairrec.evaluator import Collector, Evaluator
     z = np.load(path)
+    ratio = float(z["popularity_ratio"])
     cfg = Config(config_dict={"metrics": [str(m) for m in z["metrics"]], "topk": [int(k) for k in z["topk"]],
                               "metric_decimal_place": 10, "sst_attr_list": ["gender"], "eval_args": {"mode": "full"},
-                              "device": "cuda"})
+                              "device": "cuda", "popularity_ratio": None if ratio < 0 else ratio})
     col, ev = Collector(cfg), Evaluator(cfg)
     d = lambda k: torch.from_numpy(z[k]).cuda()
+    # what Collector.data_collect(train_data) provides: catalogue size and the items' training popularity
+    col._data["data.num_items"] = int(z["n_items"])
+    col._data["data.count_items"] = torch.bincount(d("train_items"), minlength=int(z["n_items"]))
     for b in range(int(z["n_batches"])):
         scores = d(f"scores{b}")
         scores[:, 0] = -float("inf")
@@ -32,8 +36,7 @@ def test_collector_and_evaluator_match_reference_golden(path):
         inter = Interaction({"user_id": d(f"users{b}"), "gender": d(f"gender{b}")})
         col.eval_batch_collect(scores, inter, d(f"pos_u{b}"), d(f"pos_i{b}"))
     struct = col.get_data_struct()
-    np.testing.assert_array_equal(struct["rec.topk"].cpu().numpy(), z["collected.rec.topk"])
-    for key in ("rec.positive_score", "data.positive_i", "data.gender"):     # collected by the reference only when a
+    for key in ("rec.topk", "rec.items", "rec.positive_score", "data.positive_i", "data.gender"):   # collected by the reference only when a
         if "collected." + key in z.files:                                     # registered metric needs them
             np.testing.assert_array_equal(struct[key].cpu().numpy(), z["collected." + key])
     ref = json.loads(str(z["result_json"]))
