@@ -7,6 +7,7 @@ from __future__ import annotations
 
 from typing import Optional
 
+import numpy as np
 import torch
 
 from .interaction import Interaction
@@ -49,6 +50,25 @@ class InteractionDataset:
 
     def __getitem__(self, index):
         return self.inter_feat[index]
+
+    def inter_matrix(self, form='coo', value_field=None):
+        """dataset.py:1596-1651 (`_create_sparse_matrix`): the user x item interaction matrix as scipy sparse, entries 1 or
+        the values of `value_field` (FairGo builds its rating-weighted graph from it, fairgo_pmf.py:102-129)."""
+        import scipy.sparse as sp
+        u = self.inter_feat[self.uid_field].cpu().numpy()
+        i = self.inter_feat[self.iid_field].cpu().numpy()
+        if value_field is None:
+            data = np.ones(len(u))
+        else:
+            if value_field not in self.inter_feat:
+                raise ValueError(f'Value_field [{value_field}] should be one of `df_feat`\'s features.')
+            data = self.inter_feat[value_field].cpu().numpy()
+        mat = sp.coo_matrix((data, (u, i)), shape=(self.user_num, self.item_num))
+        if form == 'coo':
+            return mat
+        if form == 'csr':
+            return mat.tocsr()
+        raise NotImplementedError(f'Sparse matrix format [{form}] has not been implemented.')
 
     def to(self, device):
         """Keep the interaction and user-feature columns resident on `device` (the batch feed then never leaves it)."""

@@ -31,7 +31,8 @@ class Collector:
         ds = train_data.dataset
         items = ds.inter_feat[ds.iid_field].to(torch.int64)
         self._data['data.num_items'] = int(ds.item_num)
-        self._data['data.count_items'] = torch.bincount(items.reshape(-1), minlength=int(ds.item_num))
+        self._data['data.count_items'] = torch.bincount(items.reshape(-1), minlength=int(ds.item_num)).to(
+            torch.device(self.config['device']))
 
     def _add(self, key, t):
         self._parts.setdefault(key, []).append(t)

@@ -206,3 +206,22 @@ def test_run_recbole_uni_evaluation(tmp_path):
         "sst_attr_list": ["gender"], "eval_batch_size": 2048, "metric_decimal_place": 4})
     res = out["test_result"]["none"]
     assert 0.0 <= res["ndcg@10"] <= 1.0 and np.isfinite(res["Differential Fairness of sensitive attribute gender"])
+
+
+def test_run_recbole_fairgo_with_the_reference_test_yaml_metrics(tmp_path):
+    """FairGo_PMF end to end with the metric list and evaluation mode of the reference's own test.yaml (uni100 there;
+    uni20 on this small catalogue): pretrain + finetune, validation per epoch, test results per stage."""
+    from fairrec.quick_start import run_recbole
+    out = run_recbole(model="FairGo_PMF", config_dict={
+        "epochs": 2, "pretrain_epochs": 2, "train_epoch_interval": 1, "train_batch_size": 512, "synthetic_users": 150,
+        "synthetic_items": 300, "synthetic_interactions": 4000, "device": "cuda", "checkpoint_dir": str(tmp_path),
+        "embedding_size": 16, "n_layers": 2, "dis_hidden_size_list": [16, 8, 4], "filter_hidden_size_list": [32, 16],
+        "aggr_method": "LBA", "vs_weights": [4, 1], "fair_weight": 0.1, "weight_decay": 1e-4,
+        "eval_args": {"mode": "uni20"}, "topk": [5], "valid_metric": "ndcg@5", "valid_metric_bigger": True,
+        "metrics": ["NDCG", "Recall", "Hit", "MRR", "DifferentialFairness", "GiniIndex", "PopularityPercentage",
+                    "ValueUnfairness", "AbsoluteUnfairness", "UnderUnfairness", "OverUnfairness", "NonParityUnfairness"],
+        "sst_attr_list": ["gender"], "eval_batch_size": 2048, "metric_decimal_place": 4, "neg_sampling": None})
+    res = out["test_result"]
+    assert {"pretrain-ndcg@5", "finetune-ndcg@5", "finetune-giniindex@5", "finetune-popularitypercentage@5",
+            "finetune-Differential Fairness of sensitive attribute gender"} <= set(res)
+    assert 0.0 <= res["finetune-ndcg@5"] <= 1.0 and 0.0 <= res["finetune-giniindex@5"] <= 1.0
