@@ -177,3 +177,51 @@ def train(z) -> Dict[str, np.ndarray]:
     with torch.no_grad():
         out["predict_last"] = m.predict(u, i).numpy().copy()
     return out
+
+
+# ---- FairGo_GCN pretrain stage: PARITY UNPINNED -----------------------------------------------------------------------
+# The reference calls torch_geometric.nn.GCN (fairgo_gcn.py:20, :52-57, :176), which is neither pinned by the reference
+# nor installed in this image, so nothing below could be checked against the real thing.  It restates PyG's published
+# GCNConv / BasicGNN semantics (default arguments) in dense torch, as the checker of the HIP path for that stage.
+def gcn_a_hat(n_users, n_items, tu, ti, tr) -> torch.Tensor:
+    """Dense Ahat = Dhat^-1/2 (A + I) Dhat^-1/2 for the reference's edge list (both directions of every rating)."""
+    N = n_users + n_items
+    A = torch.zeros((N, N), dtype=torch.float64)
+    tu_t, ti_t, tr_t = torch.as_tensor(tu), torch.as_tensor(ti) + n_users, torch.as_tensor(tr, dtype=torch.float64)
+    A.index_put_((tu_t, ti_t), tr_t, accumulate=True)
+    A.index_put_((ti_t, tu_t), tr_t, accumulate=True)
+    A += torch.eye(N, dtype=torch.float64)
+    deg = A.sum(dim=1)
+    dis = torch.where(deg > 0, deg.pow(-0.5), torch.zeros_like(deg))
+    return (dis[:, None] * A * dis[None, :]).to(torch.float32)
+
+
+def gcn_forward(x, a_hat, weights, biases, act=torch.relu, dropout_masks=None, p=0.0):
+    """BasicGNN forward: conv -> act -> dropout between layers, nothing after the last; conv = Ahat (X W^T) + b."""
+    for k, (W, b) in enumerate(zip(weights, biases)):
+        x = a_hat @ (x @ W.t()) + b
+        if k == len(weights) - 1:
+            break
+        x = act(x)
+        if dropout_masks is not None:
+            x = x * dropout_masks[k] / (1.0 - p)
+    return x
+
+
+def gcn_pretrain_steps(U0, I0, weights, biases, a_hat, users, items, ratings, lr, wd):
+    """T steps of MSE(sum(E_u[u] * E_i[i]), rating) with E = GCN(cat(U, I)) and torch.optim.Adam over U, I and the GCN
+    parameters (optimizer_pretrain, trainer.py:850-855); returns the losses and the final parameters."""
+    U, I = torch.nn.Parameter(U0.clone()), torch.nn.Parameter(I0.clone())
+    Ws = [torch.nn.Parameter(w.clone()) for w in weights]
+    bs = [torch.nn.Parameter(b.clone()) for b in biases]
+    opt = torch.optim.Adam([U, I] + Ws + bs, lr=lr, weight_decay=wd)
+    n_users = U0.shape[0]
+    losses = []
+    for u, i, r in zip(users, items, ratings):
+        opt.zero_grad()
+        E = gcn_forward(torch.cat([U, I], 0), a_hat, Ws, bs)
+        loss = torch.nn.functional.mse_loss((E[u] * E[i + n_users]).sum(-1), r)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    return losses, U.data, I.data, [w.data for w in Ws], [b.data for b in bs]

@@ -136,3 +136,69 @@ def test_fairgo_trainer_pretrain_then_finetune(tmp_path):
     assert all(d.step == 2 * 3 for k, d in eng._dense.items() if k.startswith("filter."))   # every finetune epoch (interval 1)
     assert os.path.exists(trainer.saved_pretrain_model_file)
     assert get_model("FairGo_GCN").__mro__[1].__name__ == "FairGo_PMF"
+
+
+def test_fairgo_gcn_pretrain_matches_the_restated_pyg_gcn(tmp_path):
+    """FairGo_GCN pretrain stage (whole table through a 2-layer GCN, dense Adam on tables + GCN) against the oracle's
+    dense restatement of PyG's published GCNConv / BasicGNN.  PARITY UNPINNED: torch_geometric is not pinned by the
+    reference and not installed, so this checks the HIP path against the restatement only."""
+    import scipy.sparse as sp
+    from fairrec.config import Config
+    from fairrec.data.interaction import Interaction
+    from fairrec.model.fair_recommender.fairgo_gcn import FairGo_GCN, gcn_norm_matrix
+    from fairrec.optim import FusedLazyAdam
+    from oracle import fairgo as OF
+    rng = np.random.default_rng(0)
+    n_users, n_items, D, B, T = 30, 25, 16, 64, 6
+    pairs = rng.choice((n_users - 1) * (n_items - 1), size=200, replace=False)
+    tu, ti = pairs // (n_items - 1) + 1, pairs % (n_items - 1) + 1
+    tr = rng.integers(1, 6, size=200).astype(np.float32)
+
+    class DS:
+        inter_feat = {"rating": torch.from_numpy(tr)}
+
+        def num(self, f):
+            return {"user_id": n_users, "item_id": n_items}[f]
+
+        def get_user_feature(self):
+            return Interaction({"user_id": torch.arange(n_users), "gender": torch.from_numpy(rng.integers(0, 2, n_users).astype(np.float32))})
+
+        def inter_matrix(self, form="coo", value_field=None):
+            return sp.coo_matrix((tr, (tu, ti)), shape=(n_users, n_items))
+    cfg = Config(model="FairGo_GCN", config_dict={
+        "embedding_size": D, "n_layers": 2, "dis_hidden_size_list": [8, 4], "filter_hidden_size_list": [16, 8],
+        "sst_attr_list": ["gender"], "aggr_method": "WAP", "fair_weight": 0.1, "hidden_channels": 8, "gcn_n_layers": 2,
+        "gcn_dropout": 0.0, "gcn_act": "relu", "device": "cuda", "load_pretrain_weight": False, "activation": "leakyrelu"})
+    model = FairGo_GCN(cfg, DS()).to("cuda").train()
+    model.train_stage = "pretrain"
+    a_hat = OF.gcn_a_hat(n_users, n_items, tu, ti, tr)
+    np.testing.assert_allclose(gcn_norm_matrix(n_users, n_items, DS().inter_matrix()).toarray(), a_hat.numpy(), rtol=1e-6, atol=1e-7)
+    U0, I0 = model.user_embedding_layer.weight.data.cpu().clone(), model.item_embedding_layer.weight.data.cpu().clone()
+    Ws = [c.lin.weight.data.cpu().clone() for c in model.gcn.convs]
+    bs = [c.bias.data.cpu().clone() for c in model.gcn.convs]
+    assert [tuple(w.shape) for w in Ws] == [(8, D), (D, 8)]
+    sel = rng.integers(0, 200, size=(T, B))
+    users, items = torch.from_numpy(tu[sel]), torch.from_numpy(ti[sel])
+    ratings = torch.from_numpy(tr[sel])
+    ref_loss, Ur, Ir, Wr, br = OF.gcn_pretrain_steps(U0, I0, Ws, bs, a_hat, users, items, ratings, 1e-2, 1e-4)
+    opt = FusedLazyAdam(model.hip_engine(), lr=1e-2, weight_decay=1e-4, group="pretrain")
+    losses = []
+    for t in range(T):
+        inter = Interaction({"user_id": users[t], "item_id": items[t], "rating": ratings[t]}).to("cuda")
+        opt.zero_grad()
+        loss = model.calculate_loss(inter, None)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    np.testing.assert_allclose(losses, ref_loss, rtol=1e-4)
+    for got, ref in ((model.user_embedding_layer.weight, Ur), (model.item_embedding_layer.weight, Ir),
+                     (model.gcn.convs[0].lin.weight, Wr[0]), (model.gcn.convs[1].lin.weight, Wr[1]),
+                     (model.gcn.convs[0].bias, br[0]), (model.gcn.convs[1].bias, br[1])):
+        a, b = got.data.cpu().numpy(), ref.numpy()
+        assert (np.abs(a - b) <= 2e-4 * np.abs(b) + 2e-6).all(), np.abs(a - b).max()
+    model.eval()
+    with torch.no_grad():          # predict in the pretrain stage also goes through the GCN (dropout off)
+        pr = model.predict(Interaction({"user_id": users[0], "item_id": items[0]}).to("cuda")).cpu()
+    E = OF.gcn_forward(torch.cat([Ur, Ir], 0), a_hat, Wr, br)
+    ref_pr = torch.clamp((E[users[0]] * E[items[0] + n_users]).sum(-1), 0, 5.0) / 5.0
+    np.testing.assert_allclose(pr.numpy(), ref_pr.numpy(), rtol=2e-3, atol=2e-5)
