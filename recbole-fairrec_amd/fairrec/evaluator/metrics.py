@@ -136,11 +136,53 @@ def popularity_percentage(rec_items: torch.Tensor, count_items: torch.Tensor, to
     return {f'popularitypercentage@{k}': float(avg[k - 1]) for k in topk}
 
 
+def _mean_at_k(values: torch.Tensor, name: str, topk) -> Dict[str, float]:
+    """mean over users of cumsum(values)[:k] / k (the `metric_info` / `topk_result` pair of the exposure metrics)."""
+    v = values.to(torch.float64)
+    avg = (v.cumsum(dim=1) / torch.arange(1, v.shape[1] + 1, device=v.device, dtype=torch.float64)).mean(dim=0).cpu()
+    return {f'{name}@{k}': float(avg[k - 1]) for k in topk}
+
+
+def item_coverage(rec_items, num_items, topk) -> Dict[str, float]:
+    """ItemCoverage@k (metrics.py:438-482): distinct recommended items / catalogue size."""
+    return {f'itemcoverage@{k}': float(torch.unique(rec_items[:, :k]).numel() / num_items) for k in topk}
+
+
+def average_popularity(rec_items, count_items, topk) -> Dict[str, float]:
+    """AveragePopularity@k (metrics.py:484-551): mean training popularity of the recommended items."""
+    return _mean_at_k(count_items[rec_items], 'averagepopularity', topk)
+
+
+def shannon_entropy(rec_items, topk) -> Dict[str, float]:
+    """ShannonEntropy@k (metrics.py:553-606): -sum p log p over the recommended items, divided by their number (as the
+    reference does)."""
+    res = {}
+    for k in topk:
+        cnt = torch.unique(rec_items[:, :k], return_counts=True)[1].to(torch.float64)
+        p = cnt / (rec_items.shape[0] * k)
+        res[f'shannonentropy@{k}'] = float((-p * torch.log(p)).sum() / cnt.numel())
+    return res
+
+
+def tail_percentage(rec_items, count_items, topk, tail_ratio=None) -> Dict[str, float]:
+    """TailPercentage@k (metrics.py:664-747): share of long-tail items; tail = the bottom `ratio` fraction of the items
+    that occur in training ordered by (count, id) ascending, or the items with count <= ratio when ratio > 1."""
+    ratio = 0.1 if tail_ratio is None or tail_ratio <= 0 else tail_ratio
+    present = torch.nonzero(count_items > 0).view(-1)
+    tail = torch.zeros_like(count_items, dtype=torch.bool)
+    if ratio > 1:
+        tail[present[count_items[present] <= ratio]] = True
+    else:
+        order = torch.sort(count_items[present] * (count_items.numel() + 1) + present).indices       # (count, id) ascending
+        tail[present[order[:max(int(present.numel() * ratio), 1)]]] = True
+    return _mean_at_k(tail[rec_items], 'tailpercentage', topk)
+
+
 class Evaluator:
     """recbole/evaluator/evaluator.py: metric names from `config['metrics']` -> one result dict."""
 
     TOPK = {"hit", "mrr", "ndcg", "recall", "precision"}
-    EXPOSURE = {"giniindex", "popularitypercentage"}
+    EXPOSURE = {"giniindex", "popularitypercentage", "itemcoverage", "averagepopularity", "shannonentropy", "tailpercentage"}
     FAIR = {"nonparityunfairness", "valueunfairness", "absoluteunfairness", "underunfairness", "overunfairness",
             "differentialfairness"}
 
@@ -166,6 +208,15 @@ class Evaluator:
         if "popularitypercentage" in self.metrics:
             res.update(popularity_percentage(collected['rec.items'], collected['data.count_items'], self.topk,
                                              self.config['popularity_ratio']))
+        if "itemcoverage" in self.metrics:
+            res.update(item_coverage(collected['rec.items'], collected['data.num_items'], self.topk))
+        if "averagepopularity" in self.metrics:
+            res.update(average_popularity(collected['rec.items'], collected['data.count_items'], self.topk))
+        if "shannonentropy" in self.metrics:
+            res.update(shannon_entropy(collected['rec.items'], self.topk))
+        if "tailpercentage" in self.metrics:
+            res.update(tail_percentage(collected['rec.items'], collected['data.count_items'], self.topk,
+                                       self.config['tail_ratio']))
         if self.FAIR & set(self.metrics):
             sst = {s: collected['data.' + s] for s in self.config['sst_attr_list']}
             fair = fairness_metrics(collected['rec.positive_score'], collected['data.positive_i'], sst,

@@ -29,14 +29,15 @@ class _Cfg(dict):
         return self.get(k, None)
 
 
-def run_case(name, seed, n_items, batches, topk, metrics, popularity_ratio=None):
+def run_case(name, seed, n_items, batches, topk, metrics, popularity_ratio=None, tail_ratio=None):
     rng = np.random.default_rng(seed)
     cfg = _Cfg(metrics=metrics, topk=list(topk), metric_decimal_place=10, sst_attr_list=["gender"],
                eval_args={"mode": "full"}, device=torch.device("cpu"), ITEM_ID_FIELD="item_id", USER_ID_FIELD="user_id",
-               popularity_ratio=popularity_ratio)
+               popularity_ratio=popularity_ratio, tail_ratio=tail_ratio)
     col, ev = Collector(cfg), Evaluator(cfg)
     out = {"n_items": np.array(n_items), "topk": np.array(topk), "metrics": np.array(metrics), "n_batches": np.array(len(batches)),
-           "popularity_ratio": np.array(-1.0 if popularity_ratio is None else popularity_ratio)}
+           "popularity_ratio": np.array(-1.0 if popularity_ratio is None else popularity_ratio),
+           "tail_ratio": np.array(-1.0 if tail_ratio is None else tail_ratio)}
     # what Collector.data_collect(train_data) would provide (collector.py:80-97): the catalogue size and the training
     # popularity of the items that occur in training (Counter: items absent from training are absent from it)
     train_items = np.floor((n_items - 1) * rng.random(20 * n_items) ** 2).astype(np.int64) + 1
@@ -84,8 +85,9 @@ def main():
     run_case("full_small", 1, 40, [7, 7, 3], (5, 10), ranking + fair)
     run_case("full_medium", 2, 600, [64, 64, 64, 17], (1, 10, 20), ranking + fair)
     run_case("full_ranking_only", 3, 90, [30, 11], (10,), ranking)
-    run_case("full_popularity", 4, 300, [50, 50, 21], (5, 20), ranking + ["GiniIndex", "PopularityPercentage"] + fair)
-    run_case("full_popularity_threshold", 5, 120, [40, 9], (10,), ["GiniIndex", "PopularityPercentage"], popularity_ratio=30)
+    exposure = ["GiniIndex", "PopularityPercentage", "ItemCoverage", "AveragePopularity", "ShannonEntropy", "TailPercentage"]
+    run_case("full_popularity", 4, 300, [50, 50, 21], (5, 20), ranking + exposure + fair)
+    run_case("full_popularity_threshold", 5, 120, [40, 9], (10,), exposure, popularity_ratio=30, tail_ratio=12)
 
 
 if __name__ == "__main__":

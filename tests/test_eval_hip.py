@@ -20,10 +20,11 @@ def test_collector_and_evaluator_match_reference_golden(path):
     from fairrec.data.interaction import Interaction
     from fairrec.evaluator import Collector, Evaluator
     z = np.load(path)
-    ratio = float(z["popularity_ratio"])
+    ratio, tail = float(z["popularity_ratio"]), float(z["tail_ratio"])
     cfg = Config(config_dict={"metrics": [str(m) for m in z["metrics"]], "topk": [int(k) for k in z["topk"]],
                               "metric_decimal_place": 10, "sst_attr_list": ["gender"], "eval_args": {"mode": "full"},
-                              "device": "cuda", "popularity_ratio": None if ratio < 0 else ratio})
+                              "device": "cuda", "popularity_ratio": None if ratio < 0 else ratio,
+                              "tail_ratio": None if tail < 0 else tail})
     col, ev = Collector(cfg), Evaluator(cfg)
     d = lambda k: torch.from_numpy(z[k]).cuda()
     # what Collector.data_collect(train_data) provides: catalogue size and the items' training popularity
