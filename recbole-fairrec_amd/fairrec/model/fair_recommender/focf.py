@@ -98,10 +98,12 @@ class FocfEngine:
         overlapping the kernels of the current batch.  Pure function of the id columns."""
         if self._side is None:
             self._side = torch.cuda.Stream(device=self.device)
+            self._ev_start = [torch.cuda.Event() for _ in range(2)]     # reused every step: one pair per workspace
+            self._ev_done = [torch.cuda.Event() for _ in range(2)]
         main = torch.cuda.current_stream()
         B = user.numel()
         ws = self._workspace(B, ws_index)
-        start = torch.cuda.Event()
+        start = self._ev_start[ws_index]
         start.record(main)                  # everything that last used ws[ws_index] was enqueued before this point
         self._side.wait_event(start)
         sst_arg = sst if self.objective != 0 else None
@@ -109,7 +111,7 @@ class FocfEngine:
                                       self.I.n_rows, self.U.dim, ws.data_ptr(), ws.numel(), self.err_flag.data_ptr(),
                                       self._side.cuda_stream)
         _C.check(rc, "fr_focf_prepare")
-        done = torch.cuda.Event()
+        done = self._ev_done[ws_index]
         done.record(self._side)
         self._prep = (self._key(user, item), ws_index, done)
 
@@ -189,6 +191,9 @@ class FOCF(FairRecommender):
     """MF + fairness regulariser; drop-in for recbole.model.fair_recommender.focf.FOCF."""
 
     input_type = InputType.POINTWISE
+    # the gradient never exists as a tensor: optimizer.step() runs backward + Adam in one launch.  `loss.backward()` stays
+    # legal (autograd edge in calculate_loss) for loops written against the reference; fairrec's own Trainer skips it.
+    fused_backward = True
 
     def __init__(self, config, dataset):
         super().__init__(config, dataset)

@@ -89,6 +89,7 @@ class LazyTable:
         # optional device-resident step counter (int32 [1] view): once attached the device value is authoritative and
         # `step` is a host mirror that replays of a captured hipGraph do not advance (see `sync_step`)
         self.step_dev: Optional[torch.Tensor] = None
+        self._cstruct, self._cstruct_key, self._cstruct_turn = None, None, 0
 
     def ensure_state(self):
         dev = self.weight.device
@@ -106,11 +107,19 @@ class LazyTable:
         self.ensure_state()
         w = self.weight.data if isinstance(self.weight, torch.nn.Parameter) else self.weight
         step = self.step if step is None else step
-        if self.step_dev is not None:       # the kernels add the device counter to this constant offset
-            return _C.FrTable(w.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), self.last.data_ptr(),
-                              self.stamp.data_ptr(), self.n_rows, self.dim, step - self.step, self.step_dev.data_ptr())
-        return _C.FrTable(w.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), self.last.data_ptr(),
-                          self.stamp.data_ptr(), self.n_rows, self.dim, step, None)
+        # the struct is rebuilt only when a buffer moved; per call just the step field changes (callers pass it to the
+        # library with byref() before asking for another one)
+        key = (w.data_ptr(), self.m.data_ptr(), self.step_dev.data_ptr() if self.step_dev is not None else 0)
+        if self._cstruct_key != key:
+            self._cstruct = [_C.FrTable(w.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), self.last.data_ptr(),
+                                        self.stamp.data_ptr(), self.n_rows, self.dim, 0,
+                                        self.step_dev.data_ptr() if self.step_dev is not None else None) for _ in range(2)]
+            self._cstruct_key, self._cstruct_turn = key, 0
+        self._cstruct_turn ^= 1                   # two structs alternate, so two consecutive c() results stay distinct
+        t = self._cstruct[self._cstruct_turn]
+        # with a device counter attached the kernels add it to this constant offset
+        t.step = step - self.step if self.step_dev is not None else step
+        return t
 
     def attach_step_counter(self, counter: torch.Tensor):
         """`counter`: int32 [1] device view that from now on holds this table's step count."""

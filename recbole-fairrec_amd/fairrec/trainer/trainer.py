@@ -100,6 +100,8 @@ class Trainer(AbstractTrainer):
         self.model.train()
         loss_func = loss_func or self.model.calculate_loss
         graphed = self._graphed_step(('plain', getattr(loss_func, '__name__', str(loss_func))), loss_func)
+        # a model whose optimizer.step() IS the backward pass (FOCF) needs no autograd round trip per step
+        fused = bool(getattr(self.model, 'fused_backward', False)) and loss_func == self.model.calculate_loss
         total = None
         n_tuple = 0
         hint = getattr(self.model, 'hint_next_batch', None)
@@ -115,6 +117,12 @@ class Trainer(AbstractTrainer):
             if graphed is not None:
                 part = graphed(interaction).view(1)
                 total = part.clone() if total is None else total + part
+                continue
+            if fused:
+                with torch.no_grad():
+                    part = loss_func(interaction).view(1)
+                total = part.clone() if total is None else total + part
+                self.optimizer.step()
                 continue
             self.optimizer.zero_grad()
             losses = loss_func(interaction)
