@@ -257,6 +257,8 @@ def main():
             "config": {"workload": "FOCF fair_objective=value, 1000001 users x 100001 items, embedding_size=64, "
                                    "B=8192 per GPU, Adam lr=1e-3 weight_decay=1e-3 (BASELINE.json configs[1])",
                        "item_distribution": args.item_dist, "launch": "eager" if graph is None else "hipGraph",
+                       "step": "gather / fair / backward_adam chain"
+                               + ("" if sharded else "; index sort + sweep slice one step ahead in one side launch"),
                        "lazy_adam_sweep_period": eng._sweep(BATCH) if not sharded else args.sweep,
                        "tables": "row-sharded over %d ranks, RCCL all-to-all" % world if sharded else "single GPU",
                        "global_batch": BATCH * world, "final_loss": round(loss_last, 6) if not sharded else None},

@@ -133,9 +133,21 @@ FR_API int fr_focf_forward(const fr_table* U, const fr_table* I, const fr_adam* 
  * batch AHEAD on another stream while the previous batch's kernels run: it depends on nothing but the ids, the
  * way a dataloader prefetches the next batch (trainer.py:181 iterates `train_data`).  Pass `sst` = NULL for
  * fair_objective none.  The caller orders it against the consumers of `ws` with events.
+ * `U`, `I` (both or neither; the tables the batch will be applied to): the stamp of every distinct row of the batch is
+ * set to `batch_step`, the optimizer step this batch will be applied as.  Stamps only ever tell a sweeper to leave a
+ * row to a batch, so an unused prepare is harmless.
+ * `sweep_period` > 0 and `sweep_step` >= 1 (needs U, I, adam): the launch also carries the bounded-staleness sweep slice
+ * of optimizer step `sweep_step` -- normally the step whose kernels run while this call's sort does -- as extra
+ * workgroups behind the two sorting ones: rows of the slice whose stamp is < sweep_step are brought to the state before
+ * that step (what fr_table_flush would leave; valid whether or not the step completes).  PRECONDITION: the batch of
+ * step `sweep_step` was itself prepared with stamps (its stamps are complete before this launch starts).
+ * fr_focf_backward_adam of step `sweep_step` then launches no sweeper of its own.  The sort keeps two workgroups busy
+ * for tens of microseconds while the step's kernels are latency-bound: the sweeper's VALU work disappears behind both.
  */
 FR_API int fr_focf_prepare(const int64_t* user, const int64_t* item, const float* sst, int64_t B, int64_t n_users,
-                    int64_t n_items, int32_t dim, void* ws, size_t ws_bytes, uint32_t* err_flag, void* stream);
+                    int64_t n_items, int32_t dim, void* ws, size_t ws_bytes, const fr_table* U, const fr_table* I,
+                    const fr_adam* adam, int32_t batch_step, int32_t sweep_period, int32_t sweep_step,
+                    uint32_t* err_flag, void* stream);
 
 /*
  * loss.backward() + optimizer.step() for the batch of the preceding fr_focf_forward on the same

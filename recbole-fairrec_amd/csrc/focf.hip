@@ -79,14 +79,13 @@ static FocfWs focf_layout(void* base, int64_t B, int D) {
 // gather: one wave per interaction
 // ------------------------------------------------------------------------------------------------
 template <int E, bool TRAIN>
-__global__ __launch_bounds__(GATHER_THREADS) void focf_gather_kernel(
-    TableV U, TableV I, AdamC c, const int64_t* __restrict__ user, const int64_t* __restrict__ item,
-    const float* __restrict__ rating, int B, int upto_u, int upto_i, FocfWs w, float max_rating,
-    float* __restrict__ predict_out, uint32_t* err) {
+__device__ __forceinline__ void focf_gather_body(
+    const TableV& U, const TableV& I, const AdamC& c, const int64_t* __restrict__ user, const int64_t* __restrict__ item,
+    const float* __restrict__ rating, int B, int upto_u, int upto_i, const FocfWs& w, float max_rating,
+    float* __restrict__ predict_out, uint32_t* err, int block, float* red) {
     const int lane = threadIdx.x & 63;
     const int wib = threadIdx.x >> 6;
-    const int b = blockIdx.x * (GATHER_THREADS / WAVE) + wib;
-    __shared__ float red[GATHER_THREADS / WAVE];
+    const int b = block * (GATHER_THREADS / WAVE) + wib;
     float e2 = 0.f;
     if (b < B) {
         long long ul = user[b], il = item[b];
@@ -97,16 +96,19 @@ __global__ __launch_bounds__(GATHER_THREADS) void focf_gather_kernel(
         }
         const int ur = uniform((int)ul), ir = uniform((int)il);
         const int D = U.D;
-        const int t0u = uniform(U.last[ur]), t0i = uniform(I.last[ir]);
         const float* up = U.p + (size_t)ur * D;
         const float* ip = I.p + (size_t)ir * D;
         RowFrag<E> pu, mu, vu, pi, mi, vi;
+        // one level of dependent loads: the rows and their `last` stamps are requested together (a wave-uniform value
+        // is a load + readfirstlane, i.e. a full memory round trip each time one is consumed: ~3-4 us per level here)
+        const int lu = U.last[ur], li = I.last[ir];
         load_row<E>(pu, up, D, lane);
         load_row<E>(pi, ip, D, lane);
         load_row<E>(mu, U.m + (size_t)ur * D, D, lane);
         load_row<E>(vu, U.v + (size_t)ur * D, D, lane);
         load_row<E>(mi, I.m + (size_t)ir * D, D, lane);
         load_row<E>(vi, I.v + (size_t)ir * D, D, lane);
+        const int t0u = uniform(lu), t0i = uniform(li);
 
         // replay the optimizer steps each row missed (zero data gradient, weight decay only): first the
         // steps only the staler row missed, then the common tail on both rows interleaved
@@ -148,19 +150,48 @@ __global__ __launch_bounds__(GATHER_THREADS) void focf_gather_kernel(
         if (lane == 0) red[wib] = e2;
         __syncthreads();
         if (threadIdx.x == 0) {
-            w.mse_part[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
-            if (blockIdx.x == 0) *w.ticket = 0u;   // arm the fair kernel's in-launch finalisation (next launch)
+            w.mse_part[block] = ((red[0] + red[1]) + red[2]) + red[3];
+            if (block == 0) *w.ticket = 0u;   // arm the fair kernel's in-launch finalisation (next launch)
         }
+    }
+}
+
+template <int E, bool TRAIN>
+__global__ __launch_bounds__(GATHER_THREADS) void focf_gather_kernel(
+    TableV U, TableV I, AdamC c, const int64_t* __restrict__ user, const int64_t* __restrict__ item,
+    const float* __restrict__ rating, int B, int upto_u, int upto_i, FocfWs w, float max_rating,
+    float* __restrict__ predict_out, uint32_t* err) {
+    __shared__ float red[GATHER_THREADS / WAVE];
+    focf_gather_body<E, TRAIN>(U, I, c, user, item, rating, B, upto_u, upto_i, w, max_rating, predict_out, err,
+                                      (int)blockIdx.x, red);
+}
+
+__device__ __forceinline__ float smooth_l1(float x) {  // F.smooth_l1_loss(|x|, 0), beta = 1
+    float a = fabsf(x);
+    return a < 1.f ? 0.5f * a * a : a - 0.5f;
+}
+
+// d_g = f(P_g - T_g) of the four per-item objectives (focf.py:93-125) and its derivative q_g = d d_g / d P_g
+__device__ __forceinline__ void focf_objective(int objective, float P0, float T0, float P1, float T1, float& d0,
+                                               float& d1, float& q0, float& q1) {
+    if (objective == FR_FOCF_VALUE) {
+        d0 = P0 - T0; d1 = P1 - T1; q0 = 1.f; q1 = 1.f;
+    } else if (objective == FR_FOCF_ABSOLUTE) {
+        d0 = fabsf(P0 - T0); d1 = fabsf(P1 - T1);
+        q0 = (P0 > T0) ? 1.f : (P0 < T0 ? -1.f : 0.f);
+        q1 = (P1 > T1) ? 1.f : (P1 < T1 ? -1.f : 0.f);
+    } else if (objective == FR_FOCF_UNDER) {
+        d0 = (T0 - P0 > 0.f) ? T0 - P0 : 0.f; d1 = (T1 - P1 > 0.f) ? T1 - P1 : 0.f;
+        q0 = (T0 - P0 > 0.f) ? -1.f : 0.f;    q1 = (T1 - P1 > 0.f) ? -1.f : 0.f;
+    } else {  // over
+        d0 = (P0 - T0 > 0.f) ? P0 - T0 : 0.f; d1 = (P1 - T1 > 0.f) ? P1 - T1 : 0.f;
+        q0 = (P0 - T0 > 0.f) ? 1.f : 0.f;     q1 = (P1 - T1 > 0.f) ? 1.f : 0.f;
     }
 }
 
 // ------------------------------------------------------------------------------------------------
 // fairness term on the distinct items of the batch: 16 lanes per item
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float smooth_l1(float x) {  // F.smooth_l1_loss(|x|, 0), beta = 1
-    float a = fabsf(x);
-    return a < 1.f ? 0.5f * a * a : a - 0.5f;
-}
 
 // Segment arrays + member columns of the fairness term.  Single GPU: members are batch positions; sharded:
 // members are exchange-buffer slots on the item's owner rank and `pred/rating/sst` are the received records.
@@ -219,19 +250,7 @@ __global__ __launch_bounds__(FAIR_THREADS) void focf_fair_kernel(FairArgs w, int
         const float c0 = n0 + 1e-5f, c1 = n1 + 1e-5f;          // sst_num += 1e-5, focf.py:89
         const float P0 = sp0 / c0, P1 = sp1 / c1, T0 = st0 / c0, T1 = st1 / c1;
         float d0, d1, q0, q1;  // d_g and d d_g / d P_g
-        if (objective == FR_FOCF_VALUE) {
-            d0 = P0 - T0; d1 = P1 - T1; q0 = 1.f; q1 = 1.f;
-        } else if (objective == FR_FOCF_ABSOLUTE) {
-            d0 = fabsf(P0 - T0); d1 = fabsf(P1 - T1);
-            q0 = (P0 > T0) ? 1.f : (P0 < T0 ? -1.f : 0.f);
-            q1 = (P1 > T1) ? 1.f : (P1 < T1 ? -1.f : 0.f);
-        } else if (objective == FR_FOCF_UNDER) {
-            d0 = (T0 - P0 > 0.f) ? T0 - P0 : 0.f; d1 = (T1 - P1 > 0.f) ? T1 - P1 : 0.f;
-            q0 = (T0 - P0 > 0.f) ? -1.f : 0.f;    q1 = (T1 - P1 > 0.f) ? -1.f : 0.f;
-        } else {  // over
-            d0 = (P0 - T0 > 0.f) ? P0 - T0 : 0.f; d1 = (P1 - T1 > 0.f) ? P1 - T1 : 0.f;
-            q0 = (P0 - T0 > 0.f) ? 1.f : 0.f;     q1 = (P1 - T1 > 0.f) ? 1.f : 0.f;
-        }
+        focf_objective(objective, P0, T0, P1, T1, d0, d1, q0, q1);
         const float delta = d0 - d1;
         const float x = fabsf(delta);
         term = smooth_l1(x);
@@ -369,23 +388,31 @@ __global__ __launch_bounds__(256) void focf_finalize_kernel(FocfWs w, int B, int
 // ------------------------------------------------------------------------------------------------
 // backward + Adam: one wave per distinct row, plus sweeper waves
 // ------------------------------------------------------------------------------------------------
+// The bounded-staleness sweeper of both tables: one wave per row of this step's slice.  Its own launch so that it can
+// run BESIDE the backward kernel on another stream: it is pure VALU work (up to S replayed steps per row) on rows no
+// other kernel of the step touches (rows of the batch carry this step's stamp and are skipped).
 template <int E>
-__global__ __launch_bounds__(256) void focf_backward_adam_kernel(TableV U, TableV I, AdamC c, int B, FocfWs w,
-                                                                 long long sw_lo_u, int sw_n_u, long long sw_lo_i,
-                                                                 int sw_n_i) {
+__global__ __launch_bounds__(256) void focf_sweep_kernel(TableV U, TableV I, AdamC c, long long sw_lo_u, int sw_n_u,
+                                                         long long sw_lo_i, int sw_n_i) {
     const int lane = threadIdx.x & 63;
     long long wv = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    // longest jobs first: the sweeper rows carry up to S replayed steps, the segment waves exactly one
-    if (wv < sw_n_u) {
-        sweep_row<E>(U, c, sw_lo_u + wv, U.step, true, lane);
+    const long long pu = (sw_n_u + 1) / 2, pi = (sw_n_i + 1) / 2;     // one wave per pair of rows
+    if (wv < pu) {
+        const long long a = 2 * wv, b = a + 1 < sw_n_u ? sw_lo_u + a + 1 : -1;
+        sweep_row_pair<E>(U, c, sw_lo_u + a, b, U.step, U.step, lane);
         return;
     }
-    wv -= sw_n_u;
-    if (wv < sw_n_i) {
-        sweep_row<E>(I, c, sw_lo_i + wv, I.step, true, lane);
-        return;
+    wv -= pu;
+    if (wv < pi) {
+        const long long a = 2 * wv, b = a + 1 < sw_n_i ? sw_lo_i + a + 1 : -1;
+        sweep_row_pair<E>(I, c, sw_lo_i + a, b, I.step, I.step, lane);
     }
-    wv -= sw_n_i;
+}
+
+template <int E>
+__global__ __launch_bounds__(256) void focf_backward_adam_kernel(TableV U, TableV I, AdamC c, int B, FocfWs w) {
+    const int lane = threadIdx.x & 63;
+    long long wv = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (wv < B) {
         if (wv < w.nseg_u[0])
             segment_update<E>(U, c, (int)wv, w.seg_start_u, w.seg_row_u, w.perm_u, w.coef, w.side[0], w.side[1],
@@ -575,20 +602,90 @@ extern "C" size_t fr_focf_workspace_bytes(int64_t B, int32_t dim) {
 }
 
 static int focf_launch_sort(const FocfWs& w, const int64_t* user, const int64_t* item, const float* sst, int64_t B,
-                            int64_t n_users, int64_t n_items, bool want_minmax, uint32_t* err_flag, hipStream_t stream) {
+                            int64_t n_users, int64_t n_items, bool want_minmax, uint32_t* err_flag, hipStream_t stream,
+                            int32_t* stamp_u = nullptr, int32_t* stamp_i = nullptr, int32_t stamp_value = 0,
+                            const SweepTail* sweep = nullptr) {
     SortJob ju{user, n_users, w.perm_u, w.seg_start_u, w.seg_row_u, nullptr, w.nseg_u, nullptr, nullptr};
     SortJob ji{item, n_items, w.perm_i, w.seg_start_i, w.seg_row_i, nullptr, w.nseg_i, want_minmax ? sst : nullptr,
                w.sst_minmax};
-    return launch_sort(ju, &ji, B, err_flag, stream);
+    ju.stamp = stamp_u;
+    ji.stamp = stamp_i;
+    ju.stamp_value = ji.stamp_value = stamp_value;
+    return launch_sort(ju, &ji, B, err_flag, stream, sweep);
 }
 
+// (table, optimizer step) whose sweep slice already rode along with an fr_focf_prepare launch
+static const void* g_sweep_table = nullptr;
+static int g_sweep_step = -1;
+
 extern "C" int fr_focf_prepare(const int64_t* user, const int64_t* item, const float* sst, int64_t B, int64_t n_users,
-                               int64_t n_items, int32_t dim, void* ws, size_t ws_bytes, uint32_t* err_flag,
-                               void* stream_) {
+                               int64_t n_items, int32_t dim, void* ws, size_t ws_bytes, const fr_table* U,
+                               const fr_table* I, const fr_adam* adam, int32_t batch_step, int32_t sweep_period,
+                               int32_t sweep_step, uint32_t* err_flag, void* stream_) {
     FR_CHECK_ARG(user && item && ws && B >= 1 && B <= FR_SORT_MAX && dim >= 1, "fr_focf_prepare: bad argument");
+    FR_CHECK_ARG((U == nullptr) == (I == nullptr), "fr_focf_prepare: both tables or neither");
     FocfWs w = focf_layout(ws, B, dim);
     FR_CHECK_ARG(ws_bytes >= w.bytes, "fr_focf_prepare: workspace %zu < %zu bytes", ws_bytes, w.bytes);
-    return focf_launch_sort(w, user, item, sst, B, n_users, n_items, sst != nullptr, err_flag, (hipStream_t)stream_);
+    SweepTail tail{};
+    bool sweep = false;
+    if (U) {
+        int rc;
+        if ((rc = check_table(U, "fr_focf_prepare(U)")) || (rc = check_table(I, "fr_focf_prepare(I)"))) return rc;
+        FR_CHECK_ARG(U->n_rows == n_users && I->n_rows == n_items && U->dim == dim && I->dim == dim,
+                     "fr_focf_prepare: tables do not match n_users / n_items / dim");
+        if (sweep_period > 0 && sweep_step >= 1) {
+            if ((rc = check_adam(adam, "fr_focf_prepare"))) return rc;
+            FR_CHECK_ARG(!U->step_dev && !I->step_dev, "fr_focf_prepare: sweeping needs host-side step counters");
+            long long hi_u, hi_i;
+            sweep_range(U->n_rows, sweep_step, sweep_period, tail.lo_u, hi_u);
+            sweep_range(I->n_rows, sweep_step, sweep_period, tail.lo_i, hi_i);
+            tail.n_u = (int)(hi_u - tail.lo_u);
+            tail.n_i = (int)(hi_i - tail.lo_i);
+            tail.U = view(U);
+            tail.I = view(I);
+            tail.c = make_adamc(adam);
+            tail.upto = sweep_step - 1;       // the state BEFORE that step: what a flush would leave, valid on its own
+            tail.skip_from = sweep_step;      // rows of the batch of step `sweep_step` (or a later one) are not ours
+            sweep = tail.n_u + tail.n_i > 0;
+        }
+    }
+    int rc = focf_launch_sort(w, user, item, sst, B, n_users, n_items, sst != nullptr, err_flag, (hipStream_t)stream_,
+                              U ? U->stamp : nullptr, I ? I->stamp : nullptr, batch_step, sweep ? &tail : nullptr);
+    if (rc == FR_OK && sweep) {
+        g_sweep_table = (const void*)U->p;
+        g_sweep_step = sweep_step;
+    }
+    return rc;
+}
+
+// The sweeper of one optimizer step as its own launch (nobody carried it ahead), on the library's side stream when
+// there is one: beside the backward kernel.
+static int focf_launch_sweep(const fr_table* U, const fr_table* I, const AdamC& c, int32_t sweep_period,
+                             hipStream_t stream, bool* forked) {
+    *forked = false;
+    long long lo_u, hi_u, lo_i, hi_i;
+    sweep_range(U->n_rows, U->step, sweep_period, lo_u, hi_u);
+    sweep_range(I->n_rows, I->step, sweep_period, lo_i, hi_i);
+    const long long n_sweep = (hi_u - lo_u + 1) / 2 + (hi_i - lo_i + 1) / 2;    // waves: one per pair of rows
+    if (n_sweep <= 0) return FR_OK;
+    SideStream* ss = side_stream();
+    hipStream_t sweep_stream = stream;
+    if (ss) {
+        FR_CHECK_HIP(hipEventRecord(ss->fork2, stream));
+        FR_CHECK_HIP(hipStreamWaitEvent(ss->stream, ss->fork2, 0));
+        sweep_stream = ss->stream;
+    }
+    const TableV Uv = view(U), Iv = view(I);
+    {
+        ProfScope prof(K_FOCF_SWEEP, sweep_stream);
+        FR_DISPATCH_E(U->dim, FR_LAUNCH(prof, (focf_sweep_kernel<E>), dim3((unsigned)((n_sweep + 3) / 4)), dim3(256), 0, sweep_stream, Uv, Iv, c, lo_u, (int)(hi_u - lo_u), lo_i, (int)(hi_i - lo_i)));
+    }
+    FR_CHECK_LAUNCH();
+    if (ss) {
+        FR_CHECK_HIP(hipEventRecord(ss->join2, ss->stream));
+        *forked = true;
+    }
+    return FR_OK;
 }
 
 extern "C" int fr_focf_forward(const fr_table* U, const fr_table* I, const fr_adam* adam, const int64_t* user,
@@ -676,17 +773,21 @@ extern "C" int fr_focf_backward_adam(const fr_table* U, const fr_table* I, const
     FR_CHECK_ARG(U->dim == I->dim && ws && B >= 1 && B <= FR_SORT_MAX, "fr_focf_backward_adam: bad argument");
     FocfWs w = focf_layout(ws, B, U->dim);
     FR_CHECK_ARG(ws_bytes >= w.bytes, "fr_focf_backward_adam: workspace %zu < %zu bytes", ws_bytes, w.bytes);
-    long long lo_u, hi_u, lo_i, hi_i;
-    sweep_range(U->n_rows, U->step, sweep_period, lo_u, hi_u);
-    sweep_range(I->n_rows, I->step, sweep_period, lo_i, hi_i);
-    const long long waves = 2 * B + (hi_u - lo_u) + (hi_i - lo_i);
     const AdamC c = make_adamc(adam);
     const TableV Uv = view(U), Iv = view(I);
+    // the sweep slice of this step: already done if it rode along with the fr_focf_prepare of the next batch (it ran
+    // beside this step's whole chain); otherwise launched here, beside the backward kernel (fork/join through events)
+    bool forked = false;
+    if (!(g_sweep_table == (const void*)U->p && g_sweep_step == U->step) &&
+        (rc = focf_launch_sweep(U, I, c, sweep_period, stream, &forked)))
+        return rc;
+    g_sweep_table = nullptr;
     {
         ProfScope prof(K_FOCF_BWD_ADAM, stream);
-        FR_DISPATCH_E(U->dim, FR_LAUNCH(prof, (focf_backward_adam_kernel<E>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, stream, Uv, Iv, c, (int)B, w, lo_u, (int)(hi_u - lo_u), lo_i, (int)(hi_i - lo_i)));
+        FR_DISPATCH_E(U->dim, FR_LAUNCH(prof, (focf_backward_adam_kernel<E>), dim3((unsigned)((2 * B + 3) / 4)), dim3(256), 0, stream, Uv, Iv, c, (int)B, w));
     }
     FR_CHECK_LAUNCH();
+    if (forked) FR_CHECK_HIP(hipStreamWaitEvent(stream, side_stream()->join2, 0));
     return FR_OK;
 }
 

@@ -8,6 +8,7 @@
 // Keys are (row id << 32 | batch position); the sort is a stable LSD radix sort on the row-id bits.
 #include "common.hpp"
 #include "kernels.hpp"
+#include "table.hpp"
 
 namespace fr {
 
@@ -54,9 +55,31 @@ __device__ __forceinline__ int block_exclusive_scan_1024(int x, int* scratch /*>
 // (wave, round, lane) order == batch order and ties keep ascending batch position.
 // The lanes of a round that share a digit find each other through a 64-bit lane mask OR-ed into LDS
 // (order-independent, hence deterministic): rank = popcount(mask & lower lanes).
+// workgroups behind the sorting ones: one wave per PAIR of rows of the sweep slice (rows 2w, 2w+1 of a table's slice)
+template <int E>
+__device__ __forceinline__ void sweep_tail_rows(const SweepTail& t, int n_sort_blocks) {
+    const int lane = threadIdx.x & 63;
+    long long wv = (long long)(blockIdx.x - n_sort_blocks) * (SORT_THREADS / 64) + (threadIdx.x >> 6);
+    const long long pu = (t.n_u + 1) / 2, pi = (t.n_i + 1) / 2;
+    if (wv < pu) {
+        const long long a = 2 * wv, b = a + 1 < t.n_u ? t.lo_u + a + 1 : -1;
+        sweep_row_pair<E>(t.U, t.c, t.lo_u + a, b, t.upto, t.skip_from, lane);
+        return;
+    }
+    wv -= pu;
+    if (wv < pi) {
+        const long long a = 2 * wv, b = a + 1 < t.n_i ? t.lo_i + a + 1 : -1;
+        sweep_row_pair<E>(t.I, t.c, t.lo_i + a, b, t.upto, t.skip_from, lane);
+    }
+}
+
 template <int KPT>
 __global__ __launch_bounds__(SORT_THREADS) void sort_segments_kernel(SortJob job0, SortJob job1, int M, int npass,
-                                                                     uint32_t* err) {
+                                                                     uint32_t* err, int n_sort_blocks, SweepTail tail) {
+    if ((int)blockIdx.x >= n_sort_blocks) {
+        FR_DISPATCH_E(tail.U.D, sweep_tail_rows<E>(tail, n_sort_blocks));
+        return;
+    }
     constexpr int P = KPT * SORT_THREADS;
     constexpr int DB = sort_digit_bits(KPT);
     constexpr int NB = 1 << DB;                    // bins per pass
@@ -237,6 +260,7 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_segments_kernel(SortJob job
             if ((bal[q] >> lane) & 1ull) {
                 job.seg_start[seg] = j;
                 job.seg_row[seg] = (int)(unsigned)(k >> 32);
+                if (job.stamp) job.stamp[(unsigned)(k >> 32)] = job.stamp_value;
             }
             if (job.seg_of) job.seg_of[b] = seg;
         }
@@ -249,7 +273,8 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_segments_kernel(SortJob job
 }
 
 template <int KPT>
-static int launch_sort_kpt(const SortJob& a, const SortJob* b, int M, int bits, uint32_t* err, hipStream_t stream) {
+static int launch_sort_kpt(const SortJob& a, const SortJob* b, int M, int bits, uint32_t* err, hipStream_t stream,
+                           const SweepTail* sweep) {
     const int npass = (bits + sort_digit_bits(KPT) - 1) / sort_digit_bits(KPT);
     constexpr int NB = 1 << sort_digit_bits(KPT);
     const size_t lds = (size_t)KPT * SORT_THREADS * 8 + (size_t)16 * NB * (8 + 4) + 64 * sizeof(int);
@@ -260,23 +285,28 @@ static int launch_sort_kpt(const SortJob& a, const SortJob* b, int M, int bits, 
         attr_set = true;
     }
     ProfScope prof(K_SORT, stream);
-    FR_LAUNCH(prof, sort_segments_kernel<KPT>, dim3(b ? 2 : 1), dim3(SORT_THREADS), lds, stream, a, b ? *b : a, M,
-                       npass, err);
+    const int nsb = b ? 2 : 1;
+    const long long n_sweep = sweep ? ((long long)sweep->n_u + 1) / 2 + ((long long)sweep->n_i + 1) / 2 : 0;   // waves
+    const unsigned extra = (unsigned)((n_sweep + SORT_THREADS / 64 - 1) / (SORT_THREADS / 64));
+    SweepTail none{};
+    FR_LAUNCH(prof, sort_segments_kernel<KPT>, dim3(nsb + extra), dim3(SORT_THREADS), lds, stream, a, b ? *b : a, M,
+                       npass, err, nsb, sweep ? *sweep : none);
     FR_CHECK_LAUNCH();
     return FR_OK;
 }
 
-int launch_sort(const SortJob& a, const SortJob* b, int64_t M, uint32_t* err, hipStream_t stream) {
+int launch_sort(const SortJob& a, const SortJob* b, int64_t M, uint32_t* err, hipStream_t stream,
+                const SweepTail* sweep) {
     FR_CHECK_ARG(M >= 0 && M <= FR_SORT_MAX, "sort: M=%lld exceeds FR_SORT_MAX=%d", (long long)M, FR_SORT_MAX);
     long long nmax = a.n_rows;
     if (b && b->n_rows > nmax) nmax = b->n_rows;
     int bits = 1;
     while (bits < 32 && (1ll << bits) < nmax) ++bits;
-    if (M <= 1 * SORT_THREADS) return launch_sort_kpt<1>(a, b, (int)M, bits, err, stream);
-    if (M <= 2 * SORT_THREADS) return launch_sort_kpt<2>(a, b, (int)M, bits, err, stream);
-    if (M <= 4 * SORT_THREADS) return launch_sort_kpt<4>(a, b, (int)M, bits, err, stream);
-    if (M <= 8 * SORT_THREADS) return launch_sort_kpt<8>(a, b, (int)M, bits, err, stream);
-    return launch_sort_kpt<16>(a, b, (int)M, bits, err, stream);
+    if (M <= 1 * SORT_THREADS) return launch_sort_kpt<1>(a, b, (int)M, bits, err, stream, sweep);
+    if (M <= 2 * SORT_THREADS) return launch_sort_kpt<2>(a, b, (int)M, bits, err, stream, sweep);
+    if (M <= 4 * SORT_THREADS) return launch_sort_kpt<4>(a, b, (int)M, bits, err, stream, sweep);
+    if (M <= 8 * SORT_THREADS) return launch_sort_kpt<8>(a, b, (int)M, bits, err, stream, sweep);
+    return launch_sort_kpt<16>(a, b, (int)M, bits, err, stream, sweep);
 }
 
 }  // namespace fr

@@ -21,7 +21,7 @@ __global__ __launch_bounds__(256) void table_flush_kernel(TableV T_, AdamC c) {
     const int lane = threadIdx.x & 63;
     const long long nw = (long long)gridDim.x * 4;
     for (long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); row < T.n_rows; row += nw)
-        sweep_row<E>(T, c, row, T.step, false, lane);
+        sweep_row<E>(T, c, row, T.step, 0x7fffffff, lane);
 }
 
 template <int E>
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) void table_apply_grad_kernel(ApplyJob ja, Appl
     if (wv < J.sw_n) {   // longest jobs first
         long long lo, hi;
         sweep_range(T.n_rows, T.step, J.sweep_period, lo, hi);
-        if (lo + wv < hi) sweep_row<E>(T, c, lo + wv, T.step, true, lane);
+        if (lo + wv < hi) sweep_row<E>(T, c, lo + wv, T.step, T.step, lane);
         return;
     }
     wv -= J.sw_n;

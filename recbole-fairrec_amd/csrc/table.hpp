@@ -99,23 +99,73 @@ __device__ __forceinline__ void segment_update(const TableV& T, const AdamC& c, 
     if (lane == 0) T.last[row] = T.step;
 }
 
-// Bring one untouched row up to `upto` (all missed steps have zero data gradient).
+// Bring one untouched row up to `upto` (all missed steps have zero data gradient).  Rows whose stamp is >= skip_from
+// belong to a batch of step skip_from or later (a segment wave owns them) and are left alone.
 template <int E>
-__device__ __forceinline__ void sweep_row(const TableV& T, const AdamC& c, long long row, int upto, bool check_stamp,
+__device__ __forceinline__ void sweep_row(const TableV& T, const AdamC& c, long long row, int upto, int skip_from,
                                           int lane) {
     const int D = T.D;
-    if (check_stamp && uniform(T.stamp[row]) == upto) return;  // touched this step: a segment wave owns it
-    const int t0 = uniform(T.last[row]);
-    if (t0 >= upto) return;
+    // stamp, last and the row itself in ONE round trip (the row is wasted for the few rows that are skipped)
+    const int st = T.stamp[row];
+    const int lt = T.last[row];
     RowFrag<E> p, m, v;
     load_row<E>(p, T.p + (size_t)row * D, D, lane);
     load_row<E>(m, T.m + (size_t)row * D, D, lane);
     load_row<E>(v, T.v + (size_t)row * D, D, lane);
+    if (uniform(st) >= skip_from) return;
+    const int t0 = uniform(lt);
+    if (t0 >= upto) return;
     replay<E>(p, m, v, t0, upto, c, lane);
     store_row<E>(p, T.p + (size_t)row * D, D, lane);
     store_row<E>(m, T.m + (size_t)row * D, D, lane);
     store_row<E>(v, T.v + (size_t)row * D, D, lane);
     if (lane == 0) T.last[row] = upto;
+}
+
+// Two rows of a sweep slice in one wave: both are requested at once (twice the rows in flight per wave slot) and their
+// common stretch of missed steps is replayed interleaved, which the compiler packs into v_pk_* instructions (26 instead
+// of 36 issue cycles per row and step).  rowB < 0: only rowA.
+template <int E>
+__device__ __forceinline__ void sweep_row_pair(const TableV& T, const AdamC& c, long long rowA, long long rowB, int upto,
+                                               int skip_from, int lane) {
+    if (rowB < 0) {
+        sweep_row<E>(T, c, rowA, upto, skip_from, lane);
+        return;
+    }
+    const int D = T.D;
+    const int sa = T.stamp[rowA], sb = T.stamp[rowB];
+    const int la = T.last[rowA], lb = T.last[rowB];
+    RowFrag<E> pa, ma, va, pb, mb, vb;
+    load_row<E>(pa, T.p + (size_t)rowA * D, D, lane);
+    load_row<E>(ma, T.m + (size_t)rowA * D, D, lane);
+    load_row<E>(va, T.v + (size_t)rowA * D, D, lane);
+    load_row<E>(pb, T.p + (size_t)rowB * D, D, lane);
+    load_row<E>(mb, T.m + (size_t)rowB * D, D, lane);
+    load_row<E>(vb, T.v + (size_t)rowB * D, D, lane);
+    const int ta = uniform(la), tb = uniform(lb);
+    const bool doA = uniform(sa) < skip_from && ta < upto;
+    const bool doB = uniform(sb) < skip_from && tb < upto;
+    if (doA && doB) {
+        if (ta < tb) replay<E>(pa, ma, va, ta, tb, c, lane);
+        else if (tb < ta) replay<E>(pb, mb, vb, tb, ta, c, lane);
+        replay2<E>(pa, ma, va, pb, mb, vb, ta > tb ? ta : tb, upto, c, lane);
+    } else if (doA) {
+        replay<E>(pa, ma, va, ta, upto, c, lane);
+    } else if (doB) {
+        replay<E>(pb, mb, vb, tb, upto, c, lane);
+    }
+    if (doA) {
+        store_row<E>(pa, T.p + (size_t)rowA * D, D, lane);
+        store_row<E>(ma, T.m + (size_t)rowA * D, D, lane);
+        store_row<E>(va, T.v + (size_t)rowA * D, D, lane);
+        if (lane == 0) T.last[rowA] = upto;
+    }
+    if (doB) {
+        store_row<E>(pb, T.p + (size_t)rowB * D, D, lane);
+        store_row<E>(mb, T.m + (size_t)rowB * D, D, lane);
+        store_row<E>(vb, T.v + (size_t)rowB * D, D, lane);
+        if (lane == 0) T.last[rowB] = upto;
+    }
 }
 
 // Workspace of the generic training pair (fr_table_gather_train / fr_table_apply_grad).

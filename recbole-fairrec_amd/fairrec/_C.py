@@ -49,6 +49,7 @@ _PROTOS = {
                                 c_void_p, c_int64, c_int32, c_float, c_int32, c_void_p, c_size_t, c_void_p, c_void_p,
                                 c_void_p, c_void_p]),
     "fr_focf_prepare": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int32, c_void_p, c_size_t,
+                                POINTER(FrTable), POINTER(FrTable), POINTER(FrAdam), c_int32, c_int32, c_int32,
                                 c_void_p, c_void_p]),
     "fr_focf_backward_adam": (c_int, [POINTER(FrTable), POINTER(FrTable), POINTER(FrAdam), c_int64, c_int32,
                                       c_void_p, c_size_t, c_void_p]),

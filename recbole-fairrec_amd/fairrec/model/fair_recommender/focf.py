@@ -93,9 +93,11 @@ class FocfEngine:
     def _key(user, item):
         return (user.data_ptr(), item.data_ptr(), user.numel())
 
-    def prepare(self, user, item, sst, ws_index: int):
+    def prepare(self, user, item, sst, ws_index: int, sweep_step: int = -1):
         """Index-only part of the NEXT batch (fr_focf_prepare: sort + segmentation + sst min/max) on a side stream,
-        overlapping the kernels of the current batch.  Pure function of the id columns."""
+        overlapping the kernels of the current batch.  With an optimizer bound it also stamps the batch's rows with the
+        step it will be applied as, and -- `sweep_step` >= 1 -- carries the sweep slice of that step in the same
+        launch (allowed when that step's own batch was prepared with stamps)."""
         if self._side is None:
             self._side = torch.cuda.Stream(device=self.device)
             self._ev_start = [torch.cuda.Event() for _ in range(2)]     # reused every step: one pair per workspace
@@ -107,13 +109,31 @@ class FocfEngine:
         start.record(main)                  # everything that last used ws[ws_index] was enqueued before this point
         self._side.wait_event(start)
         sst_arg = sst if self.objective != 0 else None
+        # the batch will be applied as optimizer step `step + 2` (the forward in flight is `step + 1`)
+        stamped = self.optimizer is not None
+        for_step = self.U.step + 2
+        null_t, null_a = ctypes.POINTER(_C.FrTable)(), ctypes.POINTER(_C.FrAdam)()
+        if stamped:
+            if sweep_step >= 1:
+                self.hyper.check_step(sweep_step)
+            tu, ti = self.U.c(for_step), self.I.c(for_step)
+            targs = (ctypes.byref(tu), ctypes.byref(ti), ctypes.byref(self.hyper.c()))
+        else:
+            targs = (null_t, null_t, null_a)
+            sweep_step = -1
         rc = _C.lib().fr_focf_prepare(user.data_ptr(), item.data_ptr(), _C.ptr(sst_arg), B, self.U.n_rows,
-                                      self.I.n_rows, self.U.dim, ws.data_ptr(), ws.numel(), self.err_flag.data_ptr(),
-                                      self._side.cuda_stream)
+                                      self.I.n_rows, self.U.dim, ws.data_ptr(), ws.numel(), *targs, for_step,
+                                      self._sweep(B) if sweep_step >= 1 else 0, sweep_step,
+                                      self.err_flag.data_ptr(), self._side.cuda_stream)
         _C.check(rc, "fr_focf_prepare")
         done = self._ev_done[ws_index]
         done.record(self._side)
-        self._prep = (self._key(user, item), ws_index, done)
+        self._prep = (self._key(user, item), ws_index, done, stamped, for_step)
+
+    def _join_prepare(self):
+        """A prepare launch may carry sweeper work on the tables: anything else that touches them waits for it."""
+        if self._prep is not None:
+            torch.cuda.current_stream().wait_event(self._prep[2])
 
     # --- launches -------------------------------------------------------------------------------------
     def forward(self, user, item, rating, sst, want_pred: bool = False, next_batch=None):
@@ -121,14 +141,20 @@ class FocfEngine:
         `next_batch` = (user, item, sst) of the following step, if known: its sort is launched now, one step ahead."""
         B = user.numel()
         flags = 0
-        if self._prep is not None and self._prep[0] == self._key(user, item):
-            _, self.ws_cur, done = self._prep
-            torch.cuda.current_stream().wait_event(done)
-            flags = 1                                            # FR_FOCF_PREPARED
+        stamped_now = False
+        if self._prep is not None:
+            key, ws_index, done, stamped, for_step = self._prep
+            torch.cuda.current_stream().wait_event(done)         # also when the batch differs: sweeper work may ride there
+            if key == self._key(user, item):
+                self.ws_cur = ws_index
+                flags = 1                                        # FR_FOCF_PREPARED
+                stamped_now = stamped and for_step == self.U.step + 1
         self._prep = None
         ws = self._workspace(B, self.ws_cur)
         if next_batch is not None:
-            self.prepare(next_batch[0], next_batch[1], next_batch[2], 1 - self.ws_cur)
+            # this batch's rows carry their stamps already => the sweep slice of this step may ride with the next sort
+            self.prepare(next_batch[0], next_batch[1], next_batch[2], 1 - self.ws_cur,
+                         sweep_step=self.U.step + 1 if stamped_now else -1)
         self.loss_slot = (self.loss_slot + 1) % self.LOSS_SLOTS
         loss = self.loss_ring[self.loss_slot]
         pred = torch.empty(B, dtype=torch.float32, device=self.device) if want_pred else None
@@ -161,6 +187,7 @@ class FocfEngine:
         self.backward_seen = False
 
     def predict(self, user, item):
+        self._join_prepare()
         B = user.numel()
         out = torch.empty(B, dtype=torch.float32, device=self.device)
         tu, ti = self.U.c(), self.I.c()
@@ -171,6 +198,7 @@ class FocfEngine:
         return out
 
     def flush(self):
+        self._join_prepare()
         self.U.flush(self.hyper)
         self.I.flush(self.hyper)
 

@@ -267,6 +267,7 @@ class LazyTable:
         self.m.copy_(state["exp_avg"])
         self.v.copy_(state["exp_avg_sq"])
         self.last.fill_(self.step)
+        self.stamp.zero_()          # stamps name the step of the batch that owns a row: none after a reload
         if self.step_dev is not None:
             self.step_dev.fill_(self.step)
         self._dirty = False

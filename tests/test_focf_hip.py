@@ -34,7 +34,9 @@ def _engine(z, sweep):
 @pytest.mark.parametrize("path", CASES, ids=[os.path.basename(p)[:-4] for p in CASES])
 def test_training_matches_reference_golden(path, sweep):
     z = np.load(path)
-    lookahead = sweep == "lookahead"       # next batch's index sort launched one step ahead on a side stream
+    # "lookahead": the next batch's index sort runs one step ahead on a side stream, stamps the batch's rows and carries
+    # the sweep slice of the step in flight
+    lookahead = sweep == "lookahead"
     eng = _engine(z, 3 if lookahead else sweep)
     snaps = set(int(s) for s in z["snaps"])
     T = z["user_id"].shape[0]
@@ -92,6 +94,64 @@ def test_lazy_equals_flush_every_step():
                 assert torch.equal(x, y)
             else:
                 torch.testing.assert_close(x, y, rtol=2e-5, atol=1e-8 * float(y.abs().max()) + 1e-12)
+
+
+def _synthetic(n_users, n_items, B, T, seed, item_dist):
+    g = torch.Generator().manual_seed(seed)
+    u = torch.randint(1, n_users, (T, B), generator=g)
+    if item_dist == "uniform":
+        i = torch.randint(1, n_items, (T, B), generator=g)
+    elif item_dist == "zipf":      # hot items: segments of every length, short and long
+        i = (torch.rand((T, B), generator=g) ** 3 * (n_items - 1)).long() + 1
+    else:                           # a few items only: every segment is long (the chain path inside a fused step)
+        i = torch.randint(1, 9, (T, B), generator=g)
+    u[:, 1] = u[:, 0]               # a repeated user in every batch ...
+    i[:, 3] = i[:, 2]
+    u[:, 3] = u[:, 2]               # ... and a repeated (user, item) pair
+    r = torch.randint(1, 6, (T, B), generator=g).float()
+    gender = torch.randint(0, 2, (n_users,), generator=g).float()
+    return u.cuda(), i.cuda(), r.cuda(), gender[u].cuda()
+
+
+@pytest.mark.parametrize("item_dist", ["uniform", "zipf", "few"])
+@pytest.mark.parametrize("dim", [64, 100, 256])
+@pytest.mark.parametrize("objective", ["none", "value", "nonparity"])
+def test_lookahead_sweep_equals_plain_chain(objective, dim, item_dist):
+    """The look-ahead prepare (sort + stamps + the sweep slice riding in the sort launch, rows brought to the state
+    BEFORE the step) against the plain chain (sort inside forward, sweeper beside the backward kernel) on the same
+    batches: same arithmetic per row except where a row is replayed in one stretch instead of two (rounding of the moment
+    scaling: a few ulp)."""
+    from fairrec.model.fair_recommender.focf import FocfEngine
+    from fairrec.optim import FusedLazyAdam
+    n_users, n_items, B, T = 3001, 1501, 1000, 14
+    u, i, r, s = _synthetic(n_users, n_items, B, T, 11, item_dist)
+    g = torch.Generator().manual_seed(5)
+    U0 = (torch.randn(n_users, dim, generator=g) * 0.1).cuda()
+    I0 = (torch.randn(n_items, dim, generator=g) * 0.1).cuda()
+    engs = []
+    modes = (False, True)       # look-ahead prepare off / on
+    for _ in modes:
+        eng = FocfEngine(U0.clone(), I0.clone(), objective, 0.5, 5.0)
+        FusedLazyAdam(eng, lr=1e-2, weight_decay=1e-3, sweep_period=4)
+        engs.append(eng)
+    for t in range(T):
+        nxt = (u[t + 1], i[t + 1], s[t + 1]) if t + 1 < T else None
+        out = []
+        for eng, ahead in zip(engs, modes):
+            loss, pred = eng.forward(u[t], i[t], r[t], s[t], want_pred=True, next_batch=nxt if ahead else None)
+            out.append((loss.clone(), pred))
+            eng.backward_adam()
+        for o in out[1:]:
+            torch.testing.assert_close(o[0][:3], out[0][0][:3], rtol=2e-5, atol=1e-7)
+            torch.testing.assert_close(o[1], out[0][1], rtol=2e-5, atol=1e-6)
+    for eng in engs:
+        eng.flush()
+        eng.check_device_errors()
+    a = engs[0]
+    for b in engs[1:]:
+        for x, y in ((b.U.weight, a.U.weight), (b.I.weight, a.I.weight), (b.U.m, a.U.m), (b.I.m, a.I.m),
+                     (b.U.v, a.U.v), (b.I.v, a.I.v)):
+            torch.testing.assert_close(x, y, rtol=5e-5, atol=1e-7 * float(y.abs().max()) + 1e-12)
 
 
 def test_device_error_flags():
