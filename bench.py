@@ -150,13 +150,18 @@ def main():
 
     n_batches = u.shape[0]
 
+    def coming(k, ub, ib, sb, stop=None):
+        # the next batches, dataloader-style prefetch queue: the engine sorts their id columns (and stamps their rows)
+        # ahead on a side stream, GROUP batches per launch
+        out = [(ub[j], ib[j], sb[j]) for j in range(k + 1, k + 11) if j < ub.shape[0] and (stop is None or j < stop)]
+        return out or None
+
     def step(k):
         if sharded:   # look-ahead of the index work, not across the warm-up / captured-graph boundary
             nxt = (u[k + 1], i[k + 1], s[k + 1]) if k + 1 < n_batches and k != W - 1 else None
             eng.forward(u[k], i[k], r[k], s[k], next_batch=nxt)
-        else:   # the next batch's index sort is launched one step ahead (dataloader-style prefetch of the ids)
-            nxt = (u[k + 1], i[k + 1], s[k + 1]) if k + 1 < n_batches else None
-            eng.forward(u[k], i[k], r[k], s[k], next_batch=nxt)
+        else:         # no look-ahead across the warm-up / captured-graph boundary either
+            eng.forward(u[k], i[k], r[k], s[k], next_batch=coming(k, u, i, s, stop=W if k < W else None))
         eng.backward_adam()
 
     def barrier():
@@ -217,7 +222,10 @@ def main():
     _C.prof_reset()
     _C.prof_enable(rank == 0)
     for k in range(K):
-        nxt = (u2[k + 1], i2[k + 1], s2[k + 1]) if k + 1 < K else None
+        if sharded:
+            nxt = (u2[k + 1], i2[k + 1], s2[k + 1]) if k + 1 < K else None
+        else:
+            nxt = coming(k, u2, i2, s2)
         eng.forward(u2[k], i2[k], r2[k], s2[k], next_batch=nxt)
         eng.backward_adam()
     torch.cuda.synchronize()
@@ -258,7 +266,7 @@ def main():
                                    "B=8192 per GPU, Adam lr=1e-3 weight_decay=1e-3 (BASELINE.json configs[1])",
                        "item_distribution": args.item_dist, "launch": "eager" if graph is None else "hipGraph",
                        "step": "gather / fair / backward_adam chain"
-                               + ("" if sharded else "; index sort + sweep slice one step ahead in one side launch"),
+                               + ("" if sharded else "; id columns of 8 coming batches sorted per side launch, sweep slice rides in the gather launch"),
                        "lazy_adam_sweep_period": eng._sweep(BATCH) if not sharded else args.sweep,
                        "tables": "row-sharded over %d ranks, RCCL all-to-all" % world if sharded else "single GPU",
                        "global_batch": BATCH * world, "final_loss": round(loss_last, 6) if not sharded else None},

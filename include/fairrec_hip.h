@@ -122,32 +122,40 @@ FR_API size_t fr_focf_workspace_bytes(int64_t B, int32_t dim);
  *   loss_out[0] = loss, loss_out[1] = mse part, loss_out[2] = fairness part (unweighted)   (device)
  *   pred_out    = pred_scores [B] (device, may be NULL)
  */
-#define FR_FOCF_PREPARED 1   /* flags: fr_focf_prepare already ran for this batch on this workspace */
+#define FR_FOCF_PREPARED 1   /* flags: fr_focf_prepare(_many) already ran for this batch on this workspace */
+/* `sweep_period` (the value fr_focf_backward_adam gets; 0 = none): with a per-item objective the first half of this step's
+ * bounded-staleness sweep slice rides in the fairness launch as extra workgroups -- rows outside the batch are brought
+ * to the state BEFORE this step, what fr_table_flush would leave, valid whether or not the step is completed -- and
+ * fr_focf_backward_adam carries only the second half. */
 FR_API int fr_focf_forward(const fr_table* U, const fr_table* I, const fr_adam* adam, const int64_t* user,
                     const int64_t* item, const float* rating, const float* sst, int64_t B, int32_t objective,
-                    float fair_weight, int32_t flags, void* ws, size_t ws_bytes, float* loss_out, float* pred_out,
-                    uint32_t* err_flag, void* stream);
+                    float fair_weight, int32_t flags, int32_t sweep_period, void* ws, size_t ws_bytes, float* loss_out,
+                    float* pred_out, uint32_t* err_flag, void* stream);
 
 /*
  * The index-only part of fr_focf_forward (sort + segmentation of the id columns, min/max of sst), callable one
  * batch AHEAD on another stream while the previous batch's kernels run: it depends on nothing but the ids, the
  * way a dataloader prefetches the next batch (trainer.py:181 iterates `train_data`).  Pass `sst` = NULL for
  * fair_objective none.  The caller orders it against the consumers of `ws` with events.
- * `U`, `I` (both or neither; the tables the batch will be applied to): the stamp of every distinct row of the batch is
- * set to `batch_step`, the optimizer step this batch will be applied as.  Stamps only ever tell a sweeper to leave a
- * row to a batch, so an unused prepare is harmless.
- * `sweep_period` > 0 and `sweep_step` >= 1 (needs U, I, adam): the launch also carries the bounded-staleness sweep slice
- * of optimizer step `sweep_step` -- normally the step whose kernels run while this call's sort does -- as extra
- * workgroups behind the two sorting ones: rows of the slice whose stamp is < sweep_step are brought to the state before
- * that step (what fr_table_flush would leave; valid whether or not the step completes).  PRECONDITION: the batch of
- * step `sweep_step` was itself prepared with stamps (its stamps are complete before this launch starts).
- * fr_focf_backward_adam of step `sweep_step` then launches no sweeper of its own.  The sort keeps two workgroups busy
- * for tens of microseconds while the step's kernels are latency-bound: the sweeper's VALU work disappears behind both.
  */
 FR_API int fr_focf_prepare(const int64_t* user, const int64_t* item, const float* sst, int64_t B, int64_t n_users,
-                    int64_t n_items, int32_t dim, void* ws, size_t ws_bytes, const fr_table* U, const fr_table* I,
-                    const fr_adam* adam, int32_t batch_step, int32_t sweep_period, int32_t sweep_step,
-                    uint32_t* err_flag, void* stream);
+                    int64_t n_items, int32_t dim, void* ws, size_t ws_bytes, uint32_t* err_flag, void* stream);
+
+/*
+ * The same for up to FR_FOCF_PREPARE_MAX COMING batches in one launch (one workgroup per id column: the sort is
+ * latency-bound, so n batches cost the time of one, and the per-step critical path holds no sort and no stream join).
+ */
+#define FR_FOCF_PREPARE_MAX 8
+typedef struct fr_focf_batch {
+    const int64_t* user;
+    const int64_t* item;
+    const float* sst;      /* NULL for fair_objective none */
+    int64_t B;
+    void* ws;
+    size_t ws_bytes;
+} fr_focf_batch;
+FR_API int fr_focf_prepare_many(const fr_focf_batch* batches, int32_t n, int64_t n_users, int64_t n_items, int32_t dim,
+                         uint32_t* err_flag, void* stream);
 
 /*
  * loss.backward() + optimizer.step() for the batch of the preceding fr_focf_forward on the same

@@ -156,6 +156,34 @@ __device__ __forceinline__ void focf_gather_body(
     }
 }
 
+// A slice of the bounded-staleness sweeper as extra workgroups of another kernel's launch: one wave per PAIR of rows.
+// It is pure VALU work on rows nothing else in the step touches (the gather kernel has stamped the batch by then), so it
+// hides behind the latency-bound kernels that carry it -- the fairness and the backward kernel, half each -- and needs
+// no stream (and no graph branch) of its own.
+struct SweepSlice {
+    long long lo_u, lo_i;
+    int n_u, n_i;          // rows of the slice in each table
+    int upto, skip_from;   // rows stamped >= skip_from are left to their batch; the others are brought to step `upto`
+};
+
+inline long long sweep_slice_waves(const SweepSlice& sw) { return ((long long)sw.n_u + 1) / 2 + ((long long)sw.n_i + 1) / 2; }
+
+template <int E>
+__device__ __forceinline__ void sweep_slice_wave(const TableV& U, const TableV& I, const AdamC& c, const SweepSlice& sw,
+                                                 long long wv, int lane) {
+    const long long pu = (sw.n_u + 1) / 2, pi = (sw.n_i + 1) / 2;
+    if (wv < pu) {
+        const long long a = 2 * wv, b = a + 1 < sw.n_u ? sw.lo_u + a + 1 : -1;
+        sweep_row_pair<E>(U, c, sw.lo_u + a, b, sw.upto, sw.skip_from, lane);
+        return;
+    }
+    wv -= pu;
+    if (wv < pi) {
+        const long long a = 2 * wv, b = a + 1 < sw.n_i ? sw.lo_i + a + 1 : -1;
+        sweep_row_pair<E>(I, c, sw.lo_i + a, b, sw.upto, sw.skip_from, lane);
+    }
+}
+
 template <int E, bool TRAIN>
 __global__ __launch_bounds__(GATHER_THREADS) void focf_gather_kernel(
     TableV U, TableV I, AdamC c, const int64_t* __restrict__ user, const int64_t* __restrict__ item,
@@ -163,7 +191,7 @@ __global__ __launch_bounds__(GATHER_THREADS) void focf_gather_kernel(
     float* __restrict__ predict_out, uint32_t* err) {
     __shared__ float red[GATHER_THREADS / WAVE];
     focf_gather_body<E, TRAIN>(U, I, c, user, item, rating, B, upto_u, upto_i, w, max_rating, predict_out, err,
-                                      (int)blockIdx.x, red);
+                               (int)blockIdx.x, red);
 }
 
 __device__ __forceinline__ float smooth_l1(float x) {  // F.smooth_l1_loss(|x|, 0), beta = 1
@@ -215,8 +243,20 @@ struct FairArgs {
     int tail_count, tail_stride;
 };
 
+struct FairSweep {
+    TableV U, I;
+    AdamC c;
+    SweepSlice sw;
+};
+
 __global__ __launch_bounds__(FAIR_THREADS) void focf_fair_kernel(FairArgs w, int objective, float fair_weight,
-                                                                 int defer_k, uint32_t* err) {
+                                                                 int defer_k, uint32_t* err, int n_fair_blocks,
+                                                                 FairSweep fs) {
+    if ((int)blockIdx.x >= n_fair_blocks) {   // passengers: this launch's share of the step's sweep slice
+        const long long wv = (long long)(blockIdx.x - n_fair_blocks) * (FAIR_THREADS / WAVE) + (threadIdx.x >> 6);
+        FR_DISPATCH_E(fs.U.D, sweep_slice_wave<E>(fs.U, fs.I, fs.c, fs.sw, wv, threadIdx.x & 63));
+        return;
+    }
     const int sub = threadIdx.x & (FAIR_GROUP - 1);
     const int gib = threadIdx.x / FAIR_GROUP;
     const int k = blockIdx.x * (FAIR_THREADS / FAIR_GROUP) + gib;
@@ -281,7 +321,7 @@ __global__ __launch_bounds__(FAIR_THREADS) void focf_fair_kernel(FairArgs w, int
             __hip_atomic_store(&w.fair_part[blockIdx.x], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const unsigned t = __hip_atomic_fetch_add(w.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            is_last = (t == gridDim.x - 1) ? 1 : 0;
+            is_last = (t == (unsigned)n_fair_blocks - 1) ? 1 : 0;
         } else {
             w.fair_part[blockIdx.x] = s;
         }
@@ -290,7 +330,7 @@ __global__ __launch_bounds__(FAIR_THREADS) void focf_fair_kernel(FairArgs w, int
     if (!is_last) return;
     float a = 0.f, fsum = 0.f;
     for (int q = threadIdx.x; q < w.n_mse_part; q += FAIR_THREADS) a += w.mse_part[q];
-    for (int q = threadIdx.x; q < (int)gridDim.x; q += FAIR_THREADS)
+    for (int q = threadIdx.x; q < n_fair_blocks; q += FAIR_THREADS)
         fsum += __hip_atomic_load(&w.fair_part[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     a = wave_sum(a);
     fsum = wave_sum(fsum);
@@ -388,31 +428,18 @@ __global__ __launch_bounds__(256) void focf_finalize_kernel(FocfWs w, int B, int
 // ------------------------------------------------------------------------------------------------
 // backward + Adam: one wave per distinct row, plus sweeper waves
 // ------------------------------------------------------------------------------------------------
-// The bounded-staleness sweeper of both tables: one wave per row of this step's slice.  Its own launch so that it can
-// run BESIDE the backward kernel on another stream: it is pure VALU work (up to S replayed steps per row) on rows no
-// other kernel of the step touches (rows of the batch carry this step's stamp and are skipped).
+// waves [0, sweep waves): the sweep slice when no earlier launch of the step carried it (longest jobs first: up to S
+// replayed steps per row, the segment waves exactly one); then one wave per distinct user row, per distinct item row
 template <int E>
-__global__ __launch_bounds__(256) void focf_sweep_kernel(TableV U, TableV I, AdamC c, long long sw_lo_u, int sw_n_u,
-                                                         long long sw_lo_i, int sw_n_i) {
+__global__ __launch_bounds__(256) void focf_backward_adam_kernel(TableV U, TableV I, AdamC c, int B, FocfWs w,
+                                                                 SweepSlice sw, int n_sweep_waves) {
     const int lane = threadIdx.x & 63;
     long long wv = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const long long pu = (sw_n_u + 1) / 2, pi = (sw_n_i + 1) / 2;     // one wave per pair of rows
-    if (wv < pu) {
-        const long long a = 2 * wv, b = a + 1 < sw_n_u ? sw_lo_u + a + 1 : -1;
-        sweep_row_pair<E>(U, c, sw_lo_u + a, b, U.step, U.step, lane);
+    if (wv < n_sweep_waves) {
+        sweep_slice_wave<E>(U, I, c, sw, wv, lane);
         return;
     }
-    wv -= pu;
-    if (wv < pi) {
-        const long long a = 2 * wv, b = a + 1 < sw_n_i ? sw_lo_i + a + 1 : -1;
-        sweep_row_pair<E>(I, c, sw_lo_i + a, b, I.step, I.step, lane);
-    }
-}
-
-template <int E>
-__global__ __launch_bounds__(256) void focf_backward_adam_kernel(TableV U, TableV I, AdamC c, int B, FocfWs w) {
-    const int lane = threadIdx.x & 63;
-    long long wv = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    wv -= n_sweep_waves;
     if (wv < B) {
         if (wv < w.nseg_u[0])
             segment_update<E>(U, c, (int)wv, w.seg_start_u, w.seg_row_u, w.perm_u, w.coef, w.side[0], w.side[1],
@@ -602,96 +629,66 @@ extern "C" size_t fr_focf_workspace_bytes(int64_t B, int32_t dim) {
 }
 
 static int focf_launch_sort(const FocfWs& w, const int64_t* user, const int64_t* item, const float* sst, int64_t B,
-                            int64_t n_users, int64_t n_items, bool want_minmax, uint32_t* err_flag, hipStream_t stream,
-                            int32_t* stamp_u = nullptr, int32_t* stamp_i = nullptr, int32_t stamp_value = 0,
-                            const SweepTail* sweep = nullptr) {
+                            int64_t n_users, int64_t n_items, bool want_minmax, uint32_t* err_flag, hipStream_t stream) {
     SortJob ju{user, n_users, w.perm_u, w.seg_start_u, w.seg_row_u, nullptr, w.nseg_u, nullptr, nullptr};
     SortJob ji{item, n_items, w.perm_i, w.seg_start_i, w.seg_row_i, nullptr, w.nseg_i, want_minmax ? sst : nullptr,
                w.sst_minmax};
-    ju.stamp = stamp_u;
-    ji.stamp = stamp_i;
-    ju.stamp_value = ji.stamp_value = stamp_value;
-    return launch_sort(ju, &ji, B, err_flag, stream, sweep);
+    return launch_sort(ju, &ji, B, err_flag, stream);
 }
 
-// (table, optimizer step) whose sweep slice already rode along with an fr_focf_prepare launch
+// (table, optimizer step) whose sweep slice the forward launch already carried
 static const void* g_sweep_table = nullptr;
 static int g_sweep_step = -1;
 
-extern "C" int fr_focf_prepare(const int64_t* user, const int64_t* item, const float* sst, int64_t B, int64_t n_users,
-                               int64_t n_items, int32_t dim, void* ws, size_t ws_bytes, const fr_table* U,
-                               const fr_table* I, const fr_adam* adam, int32_t batch_step, int32_t sweep_period,
-                               int32_t sweep_step, uint32_t* err_flag, void* stream_) {
-    FR_CHECK_ARG(user && item && ws && B >= 1 && B <= FR_SORT_MAX && dim >= 1, "fr_focf_prepare: bad argument");
-    FR_CHECK_ARG((U == nullptr) == (I == nullptr), "fr_focf_prepare: both tables or neither");
-    FocfWs w = focf_layout(ws, B, dim);
-    FR_CHECK_ARG(ws_bytes >= w.bytes, "fr_focf_prepare: workspace %zu < %zu bytes", ws_bytes, w.bytes);
-    SweepTail tail{};
-    bool sweep = false;
-    if (U) {
-        int rc;
-        if ((rc = check_table(U, "fr_focf_prepare(U)")) || (rc = check_table(I, "fr_focf_prepare(I)"))) return rc;
-        FR_CHECK_ARG(U->n_rows == n_users && I->n_rows == n_items && U->dim == dim && I->dim == dim,
-                     "fr_focf_prepare: tables do not match n_users / n_items / dim");
-        if (sweep_period > 0 && sweep_step >= 1) {
-            if ((rc = check_adam(adam, "fr_focf_prepare"))) return rc;
-            FR_CHECK_ARG(!U->step_dev && !I->step_dev, "fr_focf_prepare: sweeping needs host-side step counters");
-            long long hi_u, hi_i;
-            sweep_range(U->n_rows, sweep_step, sweep_period, tail.lo_u, hi_u);
-            sweep_range(I->n_rows, sweep_step, sweep_period, tail.lo_i, hi_i);
-            tail.n_u = (int)(hi_u - tail.lo_u);
-            tail.n_i = (int)(hi_i - tail.lo_i);
-            tail.U = view(U);
-            tail.I = view(I);
-            tail.c = make_adamc(adam);
-            tail.upto = sweep_step - 1;       // the state BEFORE that step: what a flush would leave, valid on its own
-            tail.skip_from = sweep_step;      // rows of the batch of step `sweep_step` (or a later one) are not ours
-            sweep = tail.n_u + tail.n_i > 0;
-        }
-    }
-    int rc = focf_launch_sort(w, user, item, sst, B, n_users, n_items, sst != nullptr, err_flag, (hipStream_t)stream_,
-                              U ? U->stamp : nullptr, I ? I->stamp : nullptr, batch_step, sweep ? &tail : nullptr);
-    if (rc == FR_OK && sweep) {
-        g_sweep_table = (const void*)U->p;
-        g_sweep_step = sweep_step;
-    }
-    return rc;
-}
-
-// The sweeper of one optimizer step as its own launch (nobody carried it ahead), on the library's side stream when
-// there is one: beside the backward kernel.
-static int focf_launch_sweep(const fr_table* U, const fr_table* I, const AdamC& c, int32_t sweep_period,
-                             hipStream_t stream, bool* forked) {
-    *forked = false;
+// half = 0 / 1: the first / second half of each table's slice of this step; -1: all of it
+static SweepSlice make_sweep_slice(const fr_table* U, const fr_table* I, int32_t sweep_period, int upto, int half) {
+    SweepSlice sw{};
     long long lo_u, hi_u, lo_i, hi_i;
     sweep_range(U->n_rows, U->step, sweep_period, lo_u, hi_u);
     sweep_range(I->n_rows, I->step, sweep_period, lo_i, hi_i);
-    const long long n_sweep = (hi_u - lo_u + 1) / 2 + (hi_i - lo_i + 1) / 2;    // waves: one per pair of rows
-    if (n_sweep <= 0) return FR_OK;
-    SideStream* ss = side_stream();
-    hipStream_t sweep_stream = stream;
-    if (ss) {
-        FR_CHECK_HIP(hipEventRecord(ss->fork2, stream));
-        FR_CHECK_HIP(hipStreamWaitEvent(ss->stream, ss->fork2, 0));
-        sweep_stream = ss->stream;
+    const long long mid_u = lo_u + ((hi_u - lo_u) / 4) * 2, mid_i = lo_i + ((hi_i - lo_i) / 4) * 2;   // even: rows go in pairs
+    if (half == 0) { hi_u = mid_u; hi_i = mid_i; }
+    if (half == 1) { lo_u = mid_u; lo_i = mid_i; }
+    sw.lo_u = lo_u;
+    sw.lo_i = lo_i;
+    sw.n_u = (int)(hi_u - lo_u);
+    sw.n_i = (int)(hi_i - lo_i);
+    sw.upto = upto;
+    sw.skip_from = U->step;
+    return sw;
+}
+
+extern "C" int fr_focf_prepare_many(const fr_focf_batch* batches, int32_t n, int64_t n_users, int64_t n_items,
+                                    int32_t dim, uint32_t* err_flag, void* stream_) {
+    FR_CHECK_ARG(batches && n >= 1 && 2 * n <= FR_SORT_JOBS && dim >= 1, "fr_focf_prepare_many: 1..%d batches",
+                 FR_SORT_JOBS / 2);
+    SortJobList jobs{};
+    for (int q = 0; q < n; ++q) {
+        const fr_focf_batch& b = batches[q];
+        FR_CHECK_ARG(b.user && b.item && b.ws && b.B >= 1 && b.B <= FR_SORT_MAX, "fr_focf_prepare_many: batch %d", q);
+        FocfWs w = focf_layout(b.ws, b.B, dim);
+        FR_CHECK_ARG(b.ws_bytes >= w.bytes, "fr_focf_prepare_many: workspace %zu < %zu bytes", b.ws_bytes, w.bytes);
+        SortJob ju{b.user, n_users, w.perm_u, w.seg_start_u, w.seg_row_u, nullptr, w.nseg_u, nullptr, nullptr};
+        SortJob ji{b.item, n_items, w.perm_i, w.seg_start_i, w.seg_row_i, nullptr, w.nseg_i, b.sst, w.sst_minmax};
+        jobs.j[2 * q] = ju;
+        jobs.j[2 * q + 1] = ji;
+        jobs.M[2 * q] = jobs.M[2 * q + 1] = (int)b.B;
     }
-    const TableV Uv = view(U), Iv = view(I);
-    {
-        ProfScope prof(K_FOCF_SWEEP, sweep_stream);
-        FR_DISPATCH_E(U->dim, FR_LAUNCH(prof, (focf_sweep_kernel<E>), dim3((unsigned)((n_sweep + 3) / 4)), dim3(256), 0, sweep_stream, Uv, Iv, c, lo_u, (int)(hi_u - lo_u), lo_i, (int)(hi_i - lo_i)));
-    }
-    FR_CHECK_LAUNCH();
-    if (ss) {
-        FR_CHECK_HIP(hipEventRecord(ss->join2, ss->stream));
-        *forked = true;
-    }
-    return FR_OK;
+    jobs.n = 2 * n;
+    return launch_sort_many(jobs, n_users > n_items ? n_users : n_items, err_flag, (hipStream_t)stream_);
+}
+
+extern "C" int fr_focf_prepare(const int64_t* user, const int64_t* item, const float* sst, int64_t B, int64_t n_users,
+                               int64_t n_items, int32_t dim, void* ws, size_t ws_bytes, uint32_t* err_flag,
+                               void* stream_) {
+    fr_focf_batch b{user, item, sst, B, ws, ws_bytes};
+    return fr_focf_prepare_many(&b, 1, n_users, n_items, dim, err_flag, stream_);
 }
 
 extern "C" int fr_focf_forward(const fr_table* U, const fr_table* I, const fr_adam* adam, const int64_t* user,
                                const int64_t* item, const float* rating, const float* sst, int64_t B,
-                               int32_t objective, float fair_weight, int32_t flags, void* ws, size_t ws_bytes,
-                               float* loss_out, float* pred_out, uint32_t* err_flag, void* stream_) {
+                               int32_t objective, float fair_weight, int32_t flags, int32_t sweep_period, void* ws,
+                               size_t ws_bytes, float* loss_out, float* pred_out, uint32_t* err_flag, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     int rc;
     if ((rc = check_table(U, "fr_focf_forward(U)")) || (rc = check_table(I, "fr_focf_forward(I)")) ||
@@ -730,6 +727,7 @@ extern "C" int fr_focf_forward(const fr_table* U, const fr_table* I, const fr_ad
 
     const AdamC c = make_adamc(adam);
     const TableV Uv = view(U), Iv = view(I);
+    g_sweep_table = nullptr;
     {
         ProfScope prof(K_FOCF_GATHER, stream);
         FR_DISPATCH_E(U->dim, FR_LAUNCH(prof, (focf_gather_kernel<E, true>), dim3(w.n_gather_blocks), dim3(GATHER_THREADS), 0, stream, Uv, Iv, c, user, item, rating, (int)B, U->step - 1, I->step - 1, w, 0.f, (float*)nullptr, err_flag));
@@ -745,11 +743,22 @@ extern "C" int fr_focf_forward(const fr_table* U, const fr_table* I, const fr_ad
         FR_CHECK_LAUNCH();
     } else if (objective != FR_FOCF_NONE) {
         {
+            // the first half of the step's sweep slice rides here (the gather kernel has stamped the batch): rows go to
+            // the state BEFORE this step, which is valid whether or not fr_focf_backward_adam follows; the backward
+            // launch carries the other half
+            FairSweep fs{Uv, Iv, c, SweepSlice{}};
+            unsigned sweep_blocks = 0;
+            if (sweep_period > 0 && U->step == I->step && !U->step_dev && !I->step_dev) {
+                fs.sw = make_sweep_slice(U, I, sweep_period, U->step - 1, 0);
+                sweep_blocks = (unsigned)((sweep_slice_waves(fs.sw) + FAIR_THREADS / WAVE - 1) / (FAIR_THREADS / WAVE));
+                g_sweep_table = (const void*)U->p;
+                g_sweep_step = U->step;
+            }
             ProfScope prof(K_FOCF_FAIR, stream);
             FairArgs fa{w.perm_i, w.seg_start_i, w.nseg_i, w.sst_minmax, 1, 0, w.pred, rating, sst, Lay{0, 0}, w.coef, Lay{0, 0}, w.fair_part, 1,
                         w.ticket, w.mse_part, w.n_gather_blocks, (int)B, loss_out};
-            FR_LAUNCH(prof, focf_fair_kernel, dim3(w.n_fair_blocks), dim3(FAIR_THREADS), 0, stream, fa, objective,
-                               fair_weight, 0, err_flag);
+            FR_LAUNCH(prof, focf_fair_kernel, dim3(w.n_fair_blocks + sweep_blocks), dim3(FAIR_THREADS), 0, stream, fa,
+                               objective, fair_weight, 0, err_flag, w.n_fair_blocks, fs);
         }
         FR_CHECK_LAUNCH();
     }
@@ -775,19 +784,21 @@ extern "C" int fr_focf_backward_adam(const fr_table* U, const fr_table* I, const
     FR_CHECK_ARG(ws_bytes >= w.bytes, "fr_focf_backward_adam: workspace %zu < %zu bytes", ws_bytes, w.bytes);
     const AdamC c = make_adamc(adam);
     const TableV Uv = view(U), Iv = view(I);
-    // the sweep slice of this step: already done if it rode along with the fr_focf_prepare of the next batch (it ran
-    // beside this step's whole chain); otherwise launched here, beside the backward kernel (fork/join through events)
-    bool forked = false;
-    if (!(g_sweep_table == (const void*)U->p && g_sweep_step == U->step) &&
-        (rc = focf_launch_sweep(U, I, c, sweep_period, stream, &forked)))
-        return rc;
+    // the sweep slice of this step (rows outside the batch -- the gather kernel stamped the batch): all of it, or the
+    // second half when the fairness launch of the forward carried the first
+    SweepSlice sw{};
+    long long sweep_waves = 0;
+    if (sweep_period > 0) {
+        const bool half_done = g_sweep_table == (const void*)U->p && g_sweep_step == U->step;
+        sw = make_sweep_slice(U, I, sweep_period, U->step, half_done ? 1 : -1);
+        sweep_waves = sweep_slice_waves(sw);
+    }
     g_sweep_table = nullptr;
     {
         ProfScope prof(K_FOCF_BWD_ADAM, stream);
-        FR_DISPATCH_E(U->dim, FR_LAUNCH(prof, (focf_backward_adam_kernel<E>), dim3((unsigned)((2 * B + 3) / 4)), dim3(256), 0, stream, Uv, Iv, c, (int)B, w));
+        FR_DISPATCH_E(U->dim, FR_LAUNCH(prof, (focf_backward_adam_kernel<E>), dim3((unsigned)((sweep_waves + 2 * B + 3) / 4)), dim3(256), 0, stream, Uv, Iv, c, (int)B, w, sw, (int)sweep_waves));
     }
     FR_CHECK_LAUNCH();
-    if (forked) FR_CHECK_HIP(hipStreamWaitEvent(stream, side_stream()->join2, 0));
     return FR_OK;
 }
 
@@ -866,7 +877,7 @@ extern "C" int fr_focf_shard_fair(void* item_ws, size_t ws_bytes, int64_t n_slot
                     reinterpret_cast<unsigned int*>(scratch), sq_part, (int)n_sq_part, 0, nullptr,
                     reply + cap, (int)(n_slots / cap), cap + FR_SHARD_TAIL};
         FR_LAUNCH(prof, focf_fair_kernel, dim3(blocks), dim3(FAIR_THREADS), 0, stream, fa, objective, fair_weight, 1,
-                           err_flag);
+                           err_flag, blocks, FairSweep{});
     }
     FR_CHECK_LAUNCH();
     return FR_OK;

@@ -10,7 +10,7 @@ enum KernelKind {
     K_SORT = 0, K_FOCF_GATHER, K_FOCF_FAIR, K_FOCF_NONPARITY, K_FOCF_FINALIZE, K_FOCF_BWD_ADAM, K_TABLE_FLUSH,
     K_TABLE_GATHER, K_ADAM_DENSE, K_TABLE_GATHER_TRAIN, K_TABLE_APPLY_GRAD, K_BUCKET, K_UNBUCKET,
     K_BUCKET_ROWS, K_FOCF_SHARD_SCORE, K_FOCF_SHARD_GRADS, K_LINEAR_FWD,
-    K_LINEAR_BWD_INPUT, K_LINEAR_BWD_WEIGHT, K_NFCF_LOSS, K_BN_FWD, K_BN_BWD, K_ROWDOT, K_BPR, K_SPMM, K_ROW_GATHER, K_SAMPLE_NEG, K_FOCF_SWEEP, K_COUNT
+    K_LINEAR_BWD_INPUT, K_LINEAR_BWD_WEIGHT, K_NFCF_LOSS, K_BN_FWD, K_BN_BWD, K_ROWDOT, K_BPR, K_SPMM, K_ROW_GATHER, K_SAMPLE_NEG, K_COUNT
 };
 bool prof_on();
 // Takes an event pair from the profiler's pool and registers it for kernel `kind` (not recorded here: the pair
@@ -41,7 +41,6 @@ inline void launch_kernel(const ProfScope& prof, K kernel, dim3 grid, dim3 block
 struct SideStream {
     hipStream_t stream;
     hipEvent_t fork, join;
-    hipEvent_t fork2, join2;   // second pair: the lazy-Adam sweeper of the FOCF step
 };
 SideStream* side_stream();
 
@@ -63,18 +62,20 @@ struct SortJob {
     const float* aux;   // optional float column to min/max-reduce alongside (may be null)
     float* aux_minmax;  // [2]
     Lay lay;            // layout of idx (zero-initialised = dense)
-    int32_t* stamp;     // optional [n_rows]: stamp[row] = stamp_value for every distinct valid row of the list
-    int32_t stamp_value;
 };
 
-// Optional passenger of a sort launch: extra workgroups that run one slice of the lazy-Adam sweeper of two tables
-// (rows [lo, lo + n) brought to step `upto`, rows stamped >= skip_from left alone).  The sort occupies two workgroups for
-// tens of microseconds; riding in the same launch the sweeper needs no stream (and no graph branch) of its own.
-struct SweepTail;
+// Sort index lists in one launch, one workgroup each: (a) or (a, b) of the same length M ...
+int launch_sort(const SortJob& a, const SortJob* b, int64_t M, uint32_t* err, hipStream_t stream);
 
-// Sort one (b == nullptr) or two index lists of the same length M in one launch (one workgroup each).
-int launch_sort(const SortJob& a, const SortJob* b, int64_t M, uint32_t* err, hipStream_t stream,
-                const SweepTail* sweep = nullptr);
+// ... or up to FR_SORT_JOBS lists of their own lengths (the id columns of several coming batches at once: the sort is
+// one latency-bound workgroup per list, so n lists cost the time of one)
+static constexpr int FR_SORT_JOBS = 16;
+struct SortJobList {
+    SortJob j[FR_SORT_JOBS];
+    int M[FR_SORT_JOBS];
+    int n;
+};
+int launch_sort_many(const SortJobList& jobs, int64_t n_rows_max, uint32_t* err, hipStream_t stream);
 
 // Device view of a lazy-Adam table.
 struct TableV {
@@ -87,14 +88,6 @@ struct TableV {
     int D;
     int step;
     const int32_t* step_dev;   // optional device-resident counter: effective step = *step_dev + step (see fr_table)
-};
-
-struct SweepTail {
-    TableV U, I;
-    AdamC c;
-    long long lo_u, lo_i;
-    int n_u, n_i;
-    int upto, skip_from;
 };
 
 inline TableV view(const fr_table* t) {

@@ -31,7 +31,7 @@ static const char* const kKernelNames[K_COUNT] = {
     "focf_shard_score_kernel", "focf_shard_grads_kernel", "linear_fwd_kernel",
     "linear_bwd_input_kernel", "linear_bwd_weight_kernel", "nfcf_bce_kernel",
     "bn_fwd_kernel", "bn_bwd_kernel", "rowdot_kernel", "bpr_kernel", "spmm_csr_kernel", "row_gather_scatter_kernel",
-    "sample_negatives_kernel", "focf_sweep_kernel"};
+    "sample_negatives_kernel"};
 
 struct ProfState {
     bool on = false;
@@ -93,9 +93,7 @@ SideStream* side_stream() {
         if (!(off && off[0] == '1') &&
             hipStreamCreateWithFlags(&ss.stream, hipStreamNonBlocking) == hipSuccess &&
             hipEventCreateWithFlags(&ss.fork, hipEventDisableTiming) == hipSuccess &&
-            hipEventCreateWithFlags(&ss.join, hipEventDisableTiming) == hipSuccess &&
-            hipEventCreateWithFlags(&ss.fork2, hipEventDisableTiming) == hipSuccess &&
-            hipEventCreateWithFlags(&ss.join2, hipEventDisableTiming) == hipSuccess)
+            hipEventCreateWithFlags(&ss.join, hipEventDisableTiming) == hipSuccess)
             state = 1;
     }
     return state == 1 ? &ss : nullptr;

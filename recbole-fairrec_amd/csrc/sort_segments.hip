@@ -8,7 +8,6 @@
 // Keys are (row id << 32 | batch position); the sort is a stable LSD radix sort on the row-id bits.
 #include "common.hpp"
 #include "kernels.hpp"
-#include "table.hpp"
 
 namespace fr {
 
@@ -55,31 +54,8 @@ __device__ __forceinline__ int block_exclusive_scan_1024(int x, int* scratch /*>
 // (wave, round, lane) order == batch order and ties keep ascending batch position.
 // The lanes of a round that share a digit find each other through a 64-bit lane mask OR-ed into LDS
 // (order-independent, hence deterministic): rank = popcount(mask & lower lanes).
-// workgroups behind the sorting ones: one wave per PAIR of rows of the sweep slice (rows 2w, 2w+1 of a table's slice)
-template <int E>
-__device__ __forceinline__ void sweep_tail_rows(const SweepTail& t, int n_sort_blocks) {
-    const int lane = threadIdx.x & 63;
-    long long wv = (long long)(blockIdx.x - n_sort_blocks) * (SORT_THREADS / 64) + (threadIdx.x >> 6);
-    const long long pu = (t.n_u + 1) / 2, pi = (t.n_i + 1) / 2;
-    if (wv < pu) {
-        const long long a = 2 * wv, b = a + 1 < t.n_u ? t.lo_u + a + 1 : -1;
-        sweep_row_pair<E>(t.U, t.c, t.lo_u + a, b, t.upto, t.skip_from, lane);
-        return;
-    }
-    wv -= pu;
-    if (wv < pi) {
-        const long long a = 2 * wv, b = a + 1 < t.n_i ? t.lo_i + a + 1 : -1;
-        sweep_row_pair<E>(t.I, t.c, t.lo_i + a, b, t.upto, t.skip_from, lane);
-    }
-}
-
 template <int KPT>
-__global__ __launch_bounds__(SORT_THREADS) void sort_segments_kernel(SortJob job0, SortJob job1, int M, int npass,
-                                                                     uint32_t* err, int n_sort_blocks, SweepTail tail) {
-    if ((int)blockIdx.x >= n_sort_blocks) {
-        FR_DISPATCH_E(tail.U.D, sweep_tail_rows<E>(tail, n_sort_blocks));
-        return;
-    }
+__global__ __launch_bounds__(SORT_THREADS) void sort_segments_kernel(SortJobList jobs, int npass, uint32_t* err) {
     constexpr int P = KPT * SORT_THREADS;
     constexpr int DB = sort_digit_bits(KPT);
     constexpr int NB = 1 << DB;                    // bins per pass
@@ -92,7 +68,8 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_segments_kernel(SortJob job
     float* fscratch = reinterpret_cast<float*>(scratch + 32);                       // [32]
 
     SORT_STAMP(0);
-    const SortJob job = blockIdx.x == 0 ? job0 : job1;
+    const SortJob& job = jobs.j[blockIdx.x];
+    const int M = jobs.M[blockIdx.x];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
 
@@ -260,7 +237,6 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_segments_kernel(SortJob job
             if ((bal[q] >> lane) & 1ull) {
                 job.seg_start[seg] = j;
                 job.seg_row[seg] = (int)(unsigned)(k >> 32);
-                if (job.stamp) job.stamp[(unsigned)(k >> 32)] = job.stamp_value;
             }
             if (job.seg_of) job.seg_of[b] = seg;
         }
@@ -273,8 +249,7 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_segments_kernel(SortJob job
 }
 
 template <int KPT>
-static int launch_sort_kpt(const SortJob& a, const SortJob* b, int M, int bits, uint32_t* err, hipStream_t stream,
-                           const SweepTail* sweep) {
+static int launch_sort_kpt(const SortJobList& jobs, int bits, uint32_t* err, hipStream_t stream) {
     const int npass = (bits + sort_digit_bits(KPT) - 1) / sort_digit_bits(KPT);
     constexpr int NB = 1 << sort_digit_bits(KPT);
     const size_t lds = (size_t)KPT * SORT_THREADS * 8 + (size_t)16 * NB * (8 + 4) + 64 * sizeof(int);
@@ -285,28 +260,41 @@ static int launch_sort_kpt(const SortJob& a, const SortJob* b, int M, int bits, 
         attr_set = true;
     }
     ProfScope prof(K_SORT, stream);
-    const int nsb = b ? 2 : 1;
-    const long long n_sweep = sweep ? ((long long)sweep->n_u + 1) / 2 + ((long long)sweep->n_i + 1) / 2 : 0;   // waves
-    const unsigned extra = (unsigned)((n_sweep + SORT_THREADS / 64 - 1) / (SORT_THREADS / 64));
-    SweepTail none{};
-    FR_LAUNCH(prof, sort_segments_kernel<KPT>, dim3(nsb + extra), dim3(SORT_THREADS), lds, stream, a, b ? *b : a, M,
-                       npass, err, nsb, sweep ? *sweep : none);
+    FR_LAUNCH(prof, sort_segments_kernel<KPT>, dim3(jobs.n), dim3(SORT_THREADS), lds, stream, jobs, npass, err);
     FR_CHECK_LAUNCH();
     return FR_OK;
 }
 
-int launch_sort(const SortJob& a, const SortJob* b, int64_t M, uint32_t* err, hipStream_t stream,
-                const SweepTail* sweep) {
-    FR_CHECK_ARG(M >= 0 && M <= FR_SORT_MAX, "sort: M=%lld exceeds FR_SORT_MAX=%d", (long long)M, FR_SORT_MAX);
-    long long nmax = a.n_rows;
-    if (b && b->n_rows > nmax) nmax = b->n_rows;
+int launch_sort_many(const SortJobList& jobs, int64_t n_rows_max, uint32_t* err, hipStream_t stream) {
+    FR_CHECK_ARG(jobs.n >= 1 && jobs.n <= FR_SORT_JOBS, "sort: %d lists not in 1..%d", jobs.n, FR_SORT_JOBS);
+    int M = 0;
+    for (int q = 0; q < jobs.n; ++q) {
+        FR_CHECK_ARG(jobs.M[q] >= 0 && jobs.M[q] <= FR_SORT_MAX, "sort: M=%d exceeds FR_SORT_MAX=%d", jobs.M[q], FR_SORT_MAX);
+        if (jobs.M[q] > M) M = jobs.M[q];
+    }
     int bits = 1;
-    while (bits < 32 && (1ll << bits) < nmax) ++bits;
-    if (M <= 1 * SORT_THREADS) return launch_sort_kpt<1>(a, b, (int)M, bits, err, stream, sweep);
-    if (M <= 2 * SORT_THREADS) return launch_sort_kpt<2>(a, b, (int)M, bits, err, stream, sweep);
-    if (M <= 4 * SORT_THREADS) return launch_sort_kpt<4>(a, b, (int)M, bits, err, stream, sweep);
-    if (M <= 8 * SORT_THREADS) return launch_sort_kpt<8>(a, b, (int)M, bits, err, stream, sweep);
-    return launch_sort_kpt<16>(a, b, (int)M, bits, err, stream, sweep);
+    while (bits < 32 && (1ll << bits) < n_rows_max) ++bits;
+    if (M <= 1 * SORT_THREADS) return launch_sort_kpt<1>(jobs, bits, err, stream);
+    if (M <= 2 * SORT_THREADS) return launch_sort_kpt<2>(jobs, bits, err, stream);
+    if (M <= 4 * SORT_THREADS) return launch_sort_kpt<4>(jobs, bits, err, stream);
+    if (M <= 8 * SORT_THREADS) return launch_sort_kpt<8>(jobs, bits, err, stream);
+    return launch_sort_kpt<16>(jobs, bits, err, stream);
+}
+
+int launch_sort(const SortJob& a, const SortJob* b, int64_t M, uint32_t* err, hipStream_t stream) {
+    FR_CHECK_ARG(M >= 0 && M <= FR_SORT_MAX, "sort: M=%lld exceeds FR_SORT_MAX=%d", (long long)M, FR_SORT_MAX);
+    SortJobList jobs{};
+    jobs.j[0] = a;
+    jobs.M[0] = (int)M;
+    jobs.n = 1;
+    long long nmax = a.n_rows;
+    if (b) {
+        jobs.j[1] = *b;
+        jobs.M[1] = (int)M;
+        jobs.n = 2;
+        if (b->n_rows > nmax) nmax = b->n_rows;
+    }
+    return launch_sort_many(jobs, nmax, err, stream);
 }
 
 }  // namespace fr

@@ -34,6 +34,11 @@ class FrAdam(Structure):
                 ("beta1", c_double), ("beta2", c_double), ("eps", c_double)]
 
 
+class FrFocfBatch(Structure):
+    _fields_ = [("user", c_void_p), ("item", c_void_p), ("sst", c_void_p), ("B", c_int64), ("ws", c_void_p),
+                ("ws_bytes", c_size_t)]
+
+
 class FairrecError(RuntimeError):
     pass
 
@@ -46,11 +51,11 @@ _PROTOS = {
                                  c_void_p, c_void_p]),
     "fr_focf_workspace_bytes": (c_size_t, [c_int64, c_int32]),
     "fr_focf_forward": (c_int, [POINTER(FrTable), POINTER(FrTable), POINTER(FrAdam), c_void_p, c_void_p, c_void_p,
-                                c_void_p, c_int64, c_int32, c_float, c_int32, c_void_p, c_size_t, c_void_p, c_void_p,
-                                c_void_p, c_void_p]),
+                                c_void_p, c_int64, c_int32, c_float, c_int32, c_int32, c_void_p, c_size_t, c_void_p,
+                                c_void_p, c_void_p, c_void_p]),
     "fr_focf_prepare": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int32, c_void_p, c_size_t,
-                                POINTER(FrTable), POINTER(FrTable), POINTER(FrAdam), c_int32, c_int32, c_int32,
                                 c_void_p, c_void_p]),
+    "fr_focf_prepare_many": (c_int, [POINTER(FrFocfBatch), c_int32, c_int64, c_int64, c_int32, c_void_p, c_void_p]),
     "fr_focf_backward_adam": (c_int, [POINTER(FrTable), POINTER(FrTable), POINTER(FrAdam), c_int64, c_int32,
                                       c_void_p, c_size_t, c_void_p]),
     "fr_focf_predict": (c_int, [POINTER(FrTable), POINTER(FrTable), POINTER(FrAdam), c_void_p, c_void_p, c_int64,

@@ -41,6 +41,9 @@ class FocfEngine:
     """Owns the two lazy-Adam tables, the per-batch workspace and the kernel launches of FOCF."""
 
     LOSS_SLOTS = 256
+    GROUP = 8         # coming batches whose id columns are sorted in ONE launch (FR_FOCF_PREPARE_MAX)
+    LOW_WATER = 2     # ... launched when this few prepared batches are left, so its join is steps old when reached
+    N_WS = 12         # workspaces: the batch in flight + LOW_WATER + GROUP prepared ones + one spare
 
     def __init__(self, user_weight: torch.Tensor, item_weight: torch.Tensor, objective: str, fair_weight: float,
                  max_rating: float):
@@ -56,10 +59,10 @@ class FocfEngine:
         self.hyper = AdamHyper(device=self.device, cap=1)  # placeholder until an optimizer binds (step 0: no replay)
         self.optimizer: Optional[FusedLazyAdam] = None
         self.sweep_period: Optional[int] = None
-        self.ws = [None, None]          # double-buffered per-batch workspaces (the next batch's sort runs one step ahead)
+        self.ws = [None] * self.N_WS    # ring of per-batch workspaces (the sorts of the next batches run ahead)
         self.ws_cur = 0
-        self._side = None               # stream of the look-ahead sort
-        self._prep = None               # (key, ws index, done-event) of the batch prepared ahead
+        self._side = None               # stream of the look-ahead sorts
+        self._prep = {}                 # batch key -> (ws index, launch group) of the batches prepared ahead
         self.loss_ring = torch.zeros((self.LOSS_SLOTS, 4), dtype=torch.float32, device=self.device)
         self.loss_slot = 0
         self.err_flag = torch.zeros(1, dtype=torch.int32, device=self.device)
@@ -93,68 +96,72 @@ class FocfEngine:
     def _key(user, item):
         return (user.data_ptr(), item.data_ptr(), user.numel())
 
-    def prepare(self, user, item, sst, ws_index: int, sweep_step: int = -1):
-        """Index-only part of the NEXT batch (fr_focf_prepare: sort + segmentation + sst min/max) on a side stream,
-        overlapping the kernels of the current batch.  With an optimizer bound it also stamps the batch's rows with the
-        step it will be applied as, and -- `sweep_step` >= 1 -- carries the sweep slice of that step in the same
-        launch (allowed when that step's own batch was prepared with stamps)."""
+    def prepare_many(self, batches):
+        """Index-only part of COMING batches (fr_focf_prepare_many: sort + segmentation + sst min/max of each, one
+        launch for all of them) on a side stream, overlapping the kernels of the batches in flight.  `batches` =
+        [(user, item, sst)] in the order they will be applied.  Pure function of the id columns."""
         if self._side is None:
             self._side = torch.cuda.Stream(device=self.device)
-            self._ev_start = [torch.cuda.Event() for _ in range(2)]     # reused every step: one pair per workspace
-            self._ev_done = [torch.cuda.Event() for _ in range(2)]
+            self._ws_next = 0
         main = torch.cuda.current_stream()
-        B = user.numel()
-        ws = self._workspace(B, ws_index)
-        start = self._ev_start[ws_index]
-        start.record(main)                  # everything that last used ws[ws_index] was enqueued before this point
+        busy = {self.ws_cur} | {v[0] for v in self._prep.values()}
+        arr = (_C.FrFocfBatch * len(batches))()
+        group = {"done": torch.cuda.Event(), "joined": False}
+        entries = []
+        for q, (user, item, sst) in enumerate(batches):
+            if len(busy) >= self.N_WS:
+                raise _C.FairrecError("too many batches prepared ahead")
+            while self._ws_next in busy:
+                self._ws_next = (self._ws_next + 1) % self.N_WS
+            k = self._ws_next
+            busy.add(k)
+            B = user.numel()
+            ws = self._workspace(B, k)
+            arr[q] = _C.FrFocfBatch(user.data_ptr(), item.data_ptr(), _C.ptr(sst if self.objective != 0 else None), B,
+                                    ws.data_ptr(), ws.numel())
+            entries.append((self._key(user, item), (k, group)))
+        # everything that last used these workspaces was enqueued before this point
+        start = torch.cuda.Event()
+        start.record(main)
         self._side.wait_event(start)
-        sst_arg = sst if self.objective != 0 else None
-        # the batch will be applied as optimizer step `step + 2` (the forward in flight is `step + 1`)
-        stamped = self.optimizer is not None
-        for_step = self.U.step + 2
-        null_t, null_a = ctypes.POINTER(_C.FrTable)(), ctypes.POINTER(_C.FrAdam)()
-        if stamped:
-            if sweep_step >= 1:
-                self.hyper.check_step(sweep_step)
-            tu, ti = self.U.c(for_step), self.I.c(for_step)
-            targs = (ctypes.byref(tu), ctypes.byref(ti), ctypes.byref(self.hyper.c()))
-        else:
-            targs = (null_t, null_t, null_a)
-            sweep_step = -1
-        rc = _C.lib().fr_focf_prepare(user.data_ptr(), item.data_ptr(), _C.ptr(sst_arg), B, self.U.n_rows,
-                                      self.I.n_rows, self.U.dim, ws.data_ptr(), ws.numel(), *targs, for_step,
-                                      self._sweep(B) if sweep_step >= 1 else 0, sweep_step,
-                                      self.err_flag.data_ptr(), self._side.cuda_stream)
-        _C.check(rc, "fr_focf_prepare")
-        done = self._ev_done[ws_index]
-        done.record(self._side)
-        self._prep = (self._key(user, item), ws_index, done, stamped, for_step)
+        rc = _C.lib().fr_focf_prepare_many(arr, len(batches), self.U.n_rows, self.I.n_rows, self.U.dim,
+                                           self.err_flag.data_ptr(), self._side.cuda_stream)
+        _C.check(rc, "fr_focf_prepare_many")
+        group["done"].record(self._side)
+        self._prep.update(entries)
 
     def _join_prepare(self):
-        """A prepare launch may carry sweeper work on the tables: anything else that touches them waits for it."""
-        if self._prep is not None:
-            torch.cuda.current_stream().wait_event(self._prep[2])
+        """Order the current stream behind every sort launch still in flight, and forget what they prepared."""
+        for v in self._prep.values():
+            torch.cuda.current_stream().wait_event(v[1]["done"])
+        self._prep.clear()
 
     # --- launches -------------------------------------------------------------------------------------
     def forward(self, user, item, rating, sst, want_pred: bool = False, next_batch=None):
         """fr_focf_forward for the step `step+1`; returns (loss[4] device view, pred or None).
-        `next_batch` = (user, item, sst) of the following step, if known: its sort is launched now, one step ahead."""
+        `next_batch` = (user, item, sst) of the following step, if known, or a list of such triples for the next steps in
+        order (a dataloader's prefetch queue): their index sorts are launched ahead, GROUP batches per launch."""
         B = user.numel()
         flags = 0
-        stamped_now = False
-        if self._prep is not None:
-            key, ws_index, done, stamped, for_step = self._prep
-            torch.cuda.current_stream().wait_event(done)         # also when the batch differs: sweeper work may ride there
-            if key == self._key(user, item):
-                self.ws_cur = ws_index
-                flags = 1                                        # FR_FOCF_PREPARED
-                stamped_now = stamped and for_step == self.U.step + 1
-        self._prep = None
+        hit = self._prep.pop(self._key(user, item), None)
+        if hit is not None:
+            self.ws_cur, group = hit
+            if not group["joined"]:                              # one join per GROUP of batches, not per step
+                torch.cuda.current_stream().wait_event(group["done"])
+                group["joined"] = True
+            flags = 1                                            # FR_FOCF_PREPARED
         ws = self._workspace(B, self.ws_cur)
+        coming = []
         if next_batch is not None:
-            # this batch's rows carry their stamps already => the sweep slice of this step may ride with the next sort
-            self.prepare(next_batch[0], next_batch[1], next_batch[2], 1 - self.ws_cur,
-                         sweep_step=self.U.step + 1 if stamped_now else -1)
+            coming = [next_batch] if isinstance(next_batch[0], torch.Tensor) else [nb for nb in next_batch if nb is not None]
+        if self._prep:      # prepared batches that are not announced any more: forget them (their buffers may be reused)
+            alive = {self._key(nb[0], nb[1]) for nb in coming}
+            for k in [k for k in self._prep if k not in alive]:
+                torch.cuda.current_stream().wait_event(self._prep.pop(k)[1]["done"])
+        if coming and len(self._prep) <= self.LOW_WATER:
+            todo = [nb for nb in coming if self._key(nb[0], nb[1]) not in self._prep]
+            if todo:
+                self.prepare_many(todo[:self.GROUP])
         self.loss_slot = (self.loss_slot + 1) % self.LOSS_SLOTS
         loss = self.loss_ring[self.loss_slot]
         pred = torch.empty(B, dtype=torch.float32, device=self.device) if want_pred else None
@@ -162,7 +169,7 @@ class FocfEngine:
         self.hyper.check_step(self.U.step + 1)
         rc = _C.lib().fr_focf_forward(ctypes.byref(tu), ctypes.byref(ti), ctypes.byref(self.hyper.c()),
                                       user.data_ptr(), item.data_ptr(), rating.data_ptr(), _C.ptr(sst), B,
-                                      self.objective, self.fair_weight, flags, ws.data_ptr(), ws.numel(),
+                                      self.objective, self.fair_weight, flags, self._sweep(B), ws.data_ptr(), ws.numel(),
                                       loss.data_ptr(), _C.ptr(pred), self.err_flag.data_ptr(), _C.current_stream())
         _C.check(rc, "fr_focf_forward")
         self.pending_B = B
@@ -273,16 +280,19 @@ class FOCF(FairRecommender):
         ie = eng.I.gather(eng.hyper, item, eng.err_flag)
         return (ue * ie).sum(-1), ue, ie
 
-    def hint_next_batch(self, interaction):
-        """Optional trainer hook: the batch that will follow the next `calculate_loss` (None at the epoch end)."""
-        self._next_cols = self._cols(interaction) if interaction is not None else None
+    PREFETCH = 10     # batches a trainer may announce ahead (FocfEngine.LOW_WATER + GROUP)
+
+    def hint_next_batch(self, *interactions):
+        """Optional trainer hook: the batches that will follow the next `calculate_loss`, in order (none at the epoch
+        end).  Their index sorts are launched ahead, several batches per launch."""
+        self._next_cols = [self._cols(x) for x in interactions if x is not None] or None
 
     def calculate_loss(self, interaction):
         eng = self.hip_engine()
         u, i, r, s = self._cols(interaction)
         nxt = getattr(self, '_next_cols', None)
         self._next_cols = None
-        loss, _ = eng.forward(u, i, r, s, next_batch=(nxt[0], nxt[1], nxt[3]) if nxt is not None else None)
+        loss, _ = eng.forward(u, i, r, s, next_batch=[(c[0], c[1], c[3]) for c in nxt] if nxt else None)
         if torch.is_grad_enabled():
             return _LossHandle.apply(loss[0], eng, self.user_embedding_layer.weight, self.item_embedding_layer.weight)
         return loss[0]

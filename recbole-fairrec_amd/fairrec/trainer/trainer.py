@@ -16,6 +16,8 @@ from collections import OrderedDict
 from logging import getLogger
 from time import time
 
+import collections
+
 import numpy as np
 import torch
 
@@ -106,14 +108,27 @@ class Trainer(AbstractTrainer):
         n_tuple = 0
         hint = getattr(self.model, 'hint_next_batch', None)
         it = iter(train_data)
-        nxt = next(it, None)
-        nxt = nxt.to(self.device) if nxt is not None else None
-        while nxt is not None:
-            interaction = nxt
-            nxt = next(it, None)                       # dataloader look-ahead by one batch
-            nxt = nxt.to(self.device) if nxt is not None else None
+        # dataloader look-ahead: a model that can use it (FOCF sorts the coming batches' ids ahead, several per launch)
+        # says how many batches it wants announced
+        depth = max(1, int(getattr(self.model, 'PREFETCH', 1))) if hint is not None else 1
+        queue = collections.deque()
+
+        done = []
+
+        def fill():
+            while not done and len(queue) < depth + 1:
+                b = next(it, None)
+                if b is None:
+                    done.append(True)            # a recbole-style loader rewinds after StopIteration: never ask again
+                    return
+                queue.append(b.to(self.device))
+
+        fill()
+        while queue:
+            interaction = queue.popleft()
+            fill()
             if hint is not None:
-                hint(nxt)                              # lets the model start the next batch's index sort early
+                hint(*queue)                           # lets the model start the coming batches' index sorts early
             if graphed is not None:
                 part = graphed(interaction).view(1)
                 total = part.clone() if total is None else total + part

@@ -30,13 +30,14 @@ def _engine(z, sweep):
     return eng
 
 
-@pytest.mark.parametrize("sweep", [0, 3, None, "lookahead"], ids=["nosweep", "sweep3", "sweepdefault", "lookahead"])
+@pytest.mark.parametrize("sweep", [0, 3, None, "lookahead", "lookahead2"],
+                         ids=["nosweep", "sweep3", "sweepdefault", "lookahead", "lookahead2"])
 @pytest.mark.parametrize("path", CASES, ids=[os.path.basename(p)[:-4] for p in CASES])
 def test_training_matches_reference_golden(path, sweep):
     z = np.load(path)
     # "lookahead": the next batch's index sort runs one step ahead on a side stream, stamps the batch's rows and carries
     # the sweep slice of the step in flight
-    lookahead = sweep == "lookahead"
+    lookahead = {"lookahead": 1, "lookahead2": 5}.get(sweep, 0)      # how many coming batches are announced
     eng = _engine(z, 3 if lookahead else sweep)
     snaps = set(int(s) for s in z["snaps"])
     T = z["user_id"].shape[0]
@@ -45,7 +46,8 @@ def test_training_matches_reference_golden(path, sweep):
     cols = {k: torch.tensor(z[k], device=dev) for k in ("user_id", "item_id", "rating", "sst")}
     for t in range(T):
         u, i, r, s = (cols[k][t] for k in ("user_id", "item_id", "rating", "sst"))
-        nxt = (cols["user_id"][t + 1], cols["item_id"][t + 1], cols["sst"][t + 1]) if lookahead and t + 1 < T else None
+        nxt = [(cols["user_id"][j], cols["item_id"][j], cols["sst"][j]) for j in range(t + 1, t + 1 + lookahead) if j < T]
+        nxt = (nxt[0] if lookahead == 1 else nxt) if nxt else None
         loss, pred = eng.forward(u, i, r, s, want_pred=(t == 0), next_batch=nxt)
         losses.append(loss.clone())
         if t == 0:
@@ -129,16 +131,16 @@ def test_lookahead_sweep_equals_plain_chain(objective, dim, item_dist):
     U0 = (torch.randn(n_users, dim, generator=g) * 0.1).cuda()
     I0 = (torch.randn(n_items, dim, generator=g) * 0.1).cuda()
     engs = []
-    modes = (False, True)       # look-ahead prepare off / on
+    modes = (0, 1, 6)           # coming batches announced to the engine
     for _ in modes:
         eng = FocfEngine(U0.clone(), I0.clone(), objective, 0.5, 5.0)
         FusedLazyAdam(eng, lr=1e-2, weight_decay=1e-3, sweep_period=4)
         engs.append(eng)
     for t in range(T):
-        nxt = (u[t + 1], i[t + 1], s[t + 1]) if t + 1 < T else None
         out = []
         for eng, ahead in zip(engs, modes):
-            loss, pred = eng.forward(u[t], i[t], r[t], s[t], want_pred=True, next_batch=nxt if ahead else None)
+            nxt = [(u[j], i[j], s[j]) for j in range(t + 1, t + 1 + ahead) if j < T] or None
+            loss, pred = eng.forward(u[t], i[t], r[t], s[t], want_pred=True, next_batch=nxt)
             out.append((loss.clone(), pred))
             eng.backward_adam()
         for o in out[1:]:
