@@ -123,14 +123,10 @@ FR_API size_t fr_focf_workspace_bytes(int64_t B, int32_t dim);
  *   pred_out    = pred_scores [B] (device, may be NULL)
  */
 #define FR_FOCF_PREPARED 1   /* flags: fr_focf_prepare(_many) already ran for this batch on this workspace */
-/* `sweep_period` (the value fr_focf_backward_adam gets; 0 = none): with a per-item objective the first half of this step's
- * bounded-staleness sweep slice rides in the fairness launch as extra workgroups -- rows outside the batch are brought
- * to the state BEFORE this step, what fr_table_flush would leave, valid whether or not the step is completed -- and
- * fr_focf_backward_adam carries only the second half. */
 FR_API int fr_focf_forward(const fr_table* U, const fr_table* I, const fr_adam* adam, const int64_t* user,
                     const int64_t* item, const float* rating, const float* sst, int64_t B, int32_t objective,
-                    float fair_weight, int32_t flags, int32_t sweep_period, void* ws, size_t ws_bytes, float* loss_out,
-                    float* pred_out, uint32_t* err_flag, void* stream);
+                    float fair_weight, int32_t flags, void* ws, size_t ws_bytes, float* loss_out, float* pred_out,
+                    uint32_t* err_flag, void* stream);
 
 /*
  * The index-only part of fr_focf_forward (sort + segmentation of the id columns, min/max of sst), callable one

@@ -156,10 +156,12 @@ __device__ __forceinline__ void focf_gather_body(
     }
 }
 
-// A slice of the bounded-staleness sweeper as extra workgroups of another kernel's launch: one wave per PAIR of rows.
-// It is pure VALU work on rows nothing else in the step touches (the gather kernel has stamped the batch by then), so it
-// hides behind the latency-bound kernels that carry it -- the fairness and the backward kernel, half each -- and needs
-// no stream (and no graph branch) of its own.
+// The step's slice of the bounded-staleness sweeper, as extra workgroups of the backward launch: one wave per PAIR of
+// rows.  Pure VALU work (up to S replayed steps per row) on rows nothing else in the step touches -- the gather kernel
+// has stamped the batch's rows by then.  Measured alternatives (profiles/README.md): its own launch on a second stream,
+// riding in the look-ahead sort launch, in the gather or the fairness launch, split between launches -- every one of them
+// was slower than this (a sweeper wave is a ~10 us dependency chain wherever it runs; hipGraph serialises a third branch
+// and pays ~10 us per cross-stream join).
 struct SweepSlice {
     long long lo_u, lo_i;
     int n_u, n_i;          // rows of the slice in each table
@@ -243,20 +245,8 @@ struct FairArgs {
     int tail_count, tail_stride;
 };
 
-struct FairSweep {
-    TableV U, I;
-    AdamC c;
-    SweepSlice sw;
-};
-
 __global__ __launch_bounds__(FAIR_THREADS) void focf_fair_kernel(FairArgs w, int objective, float fair_weight,
-                                                                 int defer_k, uint32_t* err, int n_fair_blocks,
-                                                                 FairSweep fs) {
-    if ((int)blockIdx.x >= n_fair_blocks) {   // passengers: this launch's share of the step's sweep slice
-        const long long wv = (long long)(blockIdx.x - n_fair_blocks) * (FAIR_THREADS / WAVE) + (threadIdx.x >> 6);
-        FR_DISPATCH_E(fs.U.D, sweep_slice_wave<E>(fs.U, fs.I, fs.c, fs.sw, wv, threadIdx.x & 63));
-        return;
-    }
+                                                                 int defer_k, uint32_t* err) {
     const int sub = threadIdx.x & (FAIR_GROUP - 1);
     const int gib = threadIdx.x / FAIR_GROUP;
     const int k = blockIdx.x * (FAIR_THREADS / FAIR_GROUP) + gib;
@@ -321,7 +311,7 @@ __global__ __launch_bounds__(FAIR_THREADS) void focf_fair_kernel(FairArgs w, int
             __hip_atomic_store(&w.fair_part[blockIdx.x], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const unsigned t = __hip_atomic_fetch_add(w.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            is_last = (t == (unsigned)n_fair_blocks - 1) ? 1 : 0;
+            is_last = (t == gridDim.x - 1) ? 1 : 0;
         } else {
             w.fair_part[blockIdx.x] = s;
         }
@@ -330,7 +320,7 @@ __global__ __launch_bounds__(FAIR_THREADS) void focf_fair_kernel(FairArgs w, int
     if (!is_last) return;
     float a = 0.f, fsum = 0.f;
     for (int q = threadIdx.x; q < w.n_mse_part; q += FAIR_THREADS) a += w.mse_part[q];
-    for (int q = threadIdx.x; q < n_fair_blocks; q += FAIR_THREADS)
+    for (int q = threadIdx.x; q < (int)gridDim.x; q += FAIR_THREADS)
         fsum += __hip_atomic_load(&w.fair_part[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     a = wave_sum(a);
     fsum = wave_sum(fsum);
@@ -636,24 +626,14 @@ static int focf_launch_sort(const FocfWs& w, const int64_t* user, const int64_t*
     return launch_sort(ju, &ji, B, err_flag, stream);
 }
 
-// (table, optimizer step) whose sweep slice the forward launch already carried
-static const void* g_sweep_table = nullptr;
-static int g_sweep_step = -1;
-
-// half = 0 / 1: the first / second half of each table's slice of this step; -1: all of it
-static SweepSlice make_sweep_slice(const fr_table* U, const fr_table* I, int32_t sweep_period, int upto, int half) {
+static SweepSlice make_sweep_slice(const fr_table* U, const fr_table* I, int32_t sweep_period) {
     SweepSlice sw{};
-    long long lo_u, hi_u, lo_i, hi_i;
-    sweep_range(U->n_rows, U->step, sweep_period, lo_u, hi_u);
-    sweep_range(I->n_rows, I->step, sweep_period, lo_i, hi_i);
-    const long long mid_u = lo_u + ((hi_u - lo_u) / 4) * 2, mid_i = lo_i + ((hi_i - lo_i) / 4) * 2;   // even: rows go in pairs
-    if (half == 0) { hi_u = mid_u; hi_i = mid_i; }
-    if (half == 1) { lo_u = mid_u; lo_i = mid_i; }
-    sw.lo_u = lo_u;
-    sw.lo_i = lo_i;
-    sw.n_u = (int)(hi_u - lo_u);
-    sw.n_i = (int)(hi_i - lo_i);
-    sw.upto = upto;
+    long long hi_u, hi_i;
+    sweep_range(U->n_rows, U->step, sweep_period, sw.lo_u, hi_u);
+    sweep_range(I->n_rows, I->step, sweep_period, sw.lo_i, hi_i);
+    sw.n_u = (int)(hi_u - sw.lo_u);
+    sw.n_i = (int)(hi_i - sw.lo_i);
+    sw.upto = U->step;
     sw.skip_from = U->step;
     return sw;
 }
@@ -687,8 +667,8 @@ extern "C" int fr_focf_prepare(const int64_t* user, const int64_t* item, const f
 
 extern "C" int fr_focf_forward(const fr_table* U, const fr_table* I, const fr_adam* adam, const int64_t* user,
                                const int64_t* item, const float* rating, const float* sst, int64_t B,
-                               int32_t objective, float fair_weight, int32_t flags, int32_t sweep_period, void* ws,
-                               size_t ws_bytes, float* loss_out, float* pred_out, uint32_t* err_flag, void* stream_) {
+                               int32_t objective, float fair_weight, int32_t flags, void* ws, size_t ws_bytes,
+                               float* loss_out, float* pred_out, uint32_t* err_flag, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     int rc;
     if ((rc = check_table(U, "fr_focf_forward(U)")) || (rc = check_table(I, "fr_focf_forward(I)")) ||
@@ -727,7 +707,6 @@ extern "C" int fr_focf_forward(const fr_table* U, const fr_table* I, const fr_ad
 
     const AdamC c = make_adamc(adam);
     const TableV Uv = view(U), Iv = view(I);
-    g_sweep_table = nullptr;
     {
         ProfScope prof(K_FOCF_GATHER, stream);
         FR_DISPATCH_E(U->dim, FR_LAUNCH(prof, (focf_gather_kernel<E, true>), dim3(w.n_gather_blocks), dim3(GATHER_THREADS), 0, stream, Uv, Iv, c, user, item, rating, (int)B, U->step - 1, I->step - 1, w, 0.f, (float*)nullptr, err_flag));
@@ -743,22 +722,11 @@ extern "C" int fr_focf_forward(const fr_table* U, const fr_table* I, const fr_ad
         FR_CHECK_LAUNCH();
     } else if (objective != FR_FOCF_NONE) {
         {
-            // the first half of the step's sweep slice rides here (the gather kernel has stamped the batch): rows go to
-            // the state BEFORE this step, which is valid whether or not fr_focf_backward_adam follows; the backward
-            // launch carries the other half
-            FairSweep fs{Uv, Iv, c, SweepSlice{}};
-            unsigned sweep_blocks = 0;
-            if (sweep_period > 0 && U->step == I->step && !U->step_dev && !I->step_dev) {
-                fs.sw = make_sweep_slice(U, I, sweep_period, U->step - 1, 0);
-                sweep_blocks = (unsigned)((sweep_slice_waves(fs.sw) + FAIR_THREADS / WAVE - 1) / (FAIR_THREADS / WAVE));
-                g_sweep_table = (const void*)U->p;
-                g_sweep_step = U->step;
-            }
             ProfScope prof(K_FOCF_FAIR, stream);
             FairArgs fa{w.perm_i, w.seg_start_i, w.nseg_i, w.sst_minmax, 1, 0, w.pred, rating, sst, Lay{0, 0}, w.coef, Lay{0, 0}, w.fair_part, 1,
                         w.ticket, w.mse_part, w.n_gather_blocks, (int)B, loss_out};
-            FR_LAUNCH(prof, focf_fair_kernel, dim3(w.n_fair_blocks + sweep_blocks), dim3(FAIR_THREADS), 0, stream, fa,
-                               objective, fair_weight, 0, err_flag, w.n_fair_blocks, fs);
+            FR_LAUNCH(prof, focf_fair_kernel, dim3(w.n_fair_blocks), dim3(FAIR_THREADS), 0, stream, fa, objective,
+                               fair_weight, 0, err_flag);
         }
         FR_CHECK_LAUNCH();
     }
@@ -784,16 +752,14 @@ extern "C" int fr_focf_backward_adam(const fr_table* U, const fr_table* I, const
     FR_CHECK_ARG(ws_bytes >= w.bytes, "fr_focf_backward_adam: workspace %zu < %zu bytes", ws_bytes, w.bytes);
     const AdamC c = make_adamc(adam);
     const TableV Uv = view(U), Iv = view(I);
-    // the sweep slice of this step (rows outside the batch -- the gather kernel stamped the batch): all of it, or the
-    // second half when the fairness launch of the forward carried the first
+    // the sweep slice of this step rides in this launch (rows outside the batch: the gather kernel stamped the batch)
     SweepSlice sw{};
     long long sweep_waves = 0;
     if (sweep_period > 0) {
-        const bool half_done = g_sweep_table == (const void*)U->p && g_sweep_step == U->step;
-        sw = make_sweep_slice(U, I, sweep_period, U->step, half_done ? 1 : -1);
+        FR_CHECK_ARG(U->step == I->step, "fr_focf_backward_adam: the tables' step counters differ");
+        sw = make_sweep_slice(U, I, sweep_period);
         sweep_waves = sweep_slice_waves(sw);
     }
-    g_sweep_table = nullptr;
     {
         ProfScope prof(K_FOCF_BWD_ADAM, stream);
         FR_DISPATCH_E(U->dim, FR_LAUNCH(prof, (focf_backward_adam_kernel<E>), dim3((unsigned)((sweep_waves + 2 * B + 3) / 4)), dim3(256), 0, stream, Uv, Iv, c, (int)B, w, sw, (int)sweep_waves));
@@ -877,7 +843,7 @@ extern "C" int fr_focf_shard_fair(void* item_ws, size_t ws_bytes, int64_t n_slot
                     reinterpret_cast<unsigned int*>(scratch), sq_part, (int)n_sq_part, 0, nullptr,
                     reply + cap, (int)(n_slots / cap), cap + FR_SHARD_TAIL};
         FR_LAUNCH(prof, focf_fair_kernel, dim3(blocks), dim3(FAIR_THREADS), 0, stream, fa, objective, fair_weight, 1,
-                           err_flag, blocks, FairSweep{});
+                           err_flag);
     }
     FR_CHECK_LAUNCH();
     return FR_OK;

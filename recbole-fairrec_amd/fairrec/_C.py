@@ -51,8 +51,8 @@ _PROTOS = {
                                  c_void_p, c_void_p]),
     "fr_focf_workspace_bytes": (c_size_t, [c_int64, c_int32]),
     "fr_focf_forward": (c_int, [POINTER(FrTable), POINTER(FrTable), POINTER(FrAdam), c_void_p, c_void_p, c_void_p,
-                                c_void_p, c_int64, c_int32, c_float, c_int32, c_int32, c_void_p, c_size_t, c_void_p,
-                                c_void_p, c_void_p, c_void_p]),
+                                c_void_p, c_int64, c_int32, c_float, c_int32, c_void_p, c_size_t, c_void_p, c_void_p,
+                                c_void_p, c_void_p]),
     "fr_focf_prepare": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int32, c_void_p, c_size_t,
                                 c_void_p, c_void_p]),
     "fr_focf_prepare_many": (c_int, [POINTER(FrFocfBatch), c_int32, c_int64, c_int64, c_int32, c_void_p, c_void_p]),

@@ -169,7 +169,7 @@ class FocfEngine:
         self.hyper.check_step(self.U.step + 1)
         rc = _C.lib().fr_focf_forward(ctypes.byref(tu), ctypes.byref(ti), ctypes.byref(self.hyper.c()),
                                       user.data_ptr(), item.data_ptr(), rating.data_ptr(), _C.ptr(sst), B,
-                                      self.objective, self.fair_weight, flags, self._sweep(B), ws.data_ptr(), ws.numel(),
+                                      self.objective, self.fair_weight, flags, ws.data_ptr(), ws.numel(),
                                       loss.data_ptr(), _C.ptr(pred), self.err_flag.data_ptr(), _C.current_stream())
         _C.check(rc, "fr_focf_forward")
         self.pending_B = B
@@ -285,7 +285,13 @@ class FOCF(FairRecommender):
     def hint_next_batch(self, *interactions):
         """Optional trainer hook: the batches that will follow the next `calculate_loss`, in order (none at the epoch
         end).  Their index sorts are launched ahead, several batches per launch."""
-        self._next_cols = [self._cols(x) for x in interactions if x is not None] or None
+        old = getattr(self, '_cols_cache', {})
+        cache = {}
+        for x in interactions:
+            if x is not None:
+                cache[id(x)] = old.get(id(x)) or (x, self._cols(x))      # the queue moves by one batch per step
+        self._cols_cache = cache
+        self._next_cols = [c for _, c in cache.values()] or None
 
     def calculate_loss(self, interaction):
         eng = self.hip_engine()

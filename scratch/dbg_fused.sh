@@ -1,3 +1,2 @@
-python -m pytest tests/test_focf_hip.py tests/test_trainer_hip.py tests/test_primitives_hip.py -x -q 2>&1 | grep -E "passed|failed|error" | tail -3
 for f in "" "--no-graph" "--item-dist grouped" "--item-dist zipf"; do echo "bench $f"; python bench.py --no-cpu-baseline $f 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['roofline']['kernel_us'])"; done
-cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/trace2 -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline > /dev/null 2>&1; cd $GRAFT_REPO_ROOT; python scratch/trace_window.py gpurun_out/trace2 200
+python scratch/trainer_bench.py device 2>&1 | tail -3
