@@ -24,8 +24,8 @@ namespace fr {
 
 struct FocfWs {
     // sort outputs
-    int32_t *perm_u, *seg_start_u, *seg_row_u, *seg_of_u, *nseg_u;
-    int32_t *perm_i, *seg_start_i, *seg_row_i, *seg_of_i, *nseg_i;
+    int32_t *perm_u, *seg_start_u, *seg_row_u, *seg_first_u, *nseg_u;   // seg_first[k] = perm[seg_start[k]]
+    int32_t *perm_i, *seg_start_i, *seg_row_i, *seg_first_i, *nseg_i;
     float* sst_minmax;   // [2]
     float* pred;         // [B]
     float* coef;         // [B] dLoss/dpred
@@ -53,12 +53,12 @@ static FocfWs focf_layout(void* base, int64_t B, int D) {
     w.perm_u = (int32_t*)take(Bp * 4);
     w.seg_start_u = (int32_t*)take(Bp * 4);
     w.seg_row_u = (int32_t*)take(Bp * 4);
-    w.seg_of_u = (int32_t*)take(Bp * 4);
+    w.seg_first_u = (int32_t*)take(Bp * 4);
     w.nseg_u = (int32_t*)take(4);
     w.perm_i = (int32_t*)take(Bp * 4);
     w.seg_start_i = (int32_t*)take(Bp * 4);
     w.seg_row_i = (int32_t*)take(Bp * 4);
-    w.seg_of_i = (int32_t*)take(Bp * 4);
+    w.seg_first_i = (int32_t*)take(Bp * 4);
     w.nseg_i = (int32_t*)take(4);
     w.sst_minmax = (float*)take(8);
     w.pred = (float*)take(Bp * 4);
@@ -227,6 +227,7 @@ __device__ __forceinline__ void focf_objective(int objective, float P0, float T0
 // members are exchange-buffer slots on the item's owner rank and `pred/rating/sst` are the received records.
 struct FairArgs {
     const int32_t *perm, *seg_start, *nseg;
+    const int32_t* seg_first;  // optional: perm[seg_start[k]] (saves the perm round trip of single-member segments)
     const float* minmax;       // (min, max) of the sst column; sharded: one pair per source rank, mm_stride floats
     int mm_count, mm_stride;   //   apart (they arrive with the id exchange), folded here over the global batch
     const float *pred, *rating, *sst;
@@ -260,10 +261,11 @@ __global__ __launch_bounds__(FAIR_THREADS) void focf_fair_kernel(FairArgs w, int
     float term = 0.f;
     if (k < K) {
         const int j0 = w.seg_start[k], j1 = w.seg_start[k + 1];
+        const int first_b = w.seg_first ? w.seg_first[k] : -1;
         float sp0 = 0.f, sp1 = 0.f, st0 = 0.f, st1 = 0.f, n0 = 0.f, n1 = 0.f;
         bool bad = false;
         for (int j = j0 + sub; j < j1; j += FAIR_GROUP) {
-            const int b = w.perm[j];
+            const int b = (j == j0 && first_b >= 0) ? first_b : w.perm[j];
             const long long bp = w.mlay.at(b);
             const float s = w.sst[bp], pr = w.pred[bp], r = w.rating[bp];
             bad |= (s != smin && s != smax);
@@ -289,7 +291,7 @@ __global__ __launch_bounds__(FAIR_THREADS) void focf_fair_kernel(FairArgs w, int
         const float dx = (x < 1.f ? x : 1.f) * sgn * fair_weight / (defer_k ? 1.f : (float)K);
         const float g0 = dx * q0 / c0, g1 = -dx * q1 / c1;
         for (int j = j0 + sub; j < j1; j += FAIR_GROUP) {
-            const int b = w.perm[j];
+            const int b = (j == j0 && first_b >= 0) ? first_b : w.perm[j];
             const float g = (w.sst[w.mlay.at(b)] == smin) ? g0 : g1;
             const long long cp = w.clay.at(b);
             w.coef[cp] = w.accumulate ? w.coef[cp] + g : g;
@@ -433,13 +435,13 @@ __global__ __launch_bounds__(256) void focf_backward_adam_kernel(TableV U, Table
     if (wv < B) {
         if (wv < w.nseg_u[0])
             segment_update<E>(U, c, (int)wv, w.seg_start_u, w.seg_row_u, w.perm_u, w.coef, w.side[0], w.side[1],
-                              w.side[2], w.side[3], lane);
+                              w.side[2], w.side[3], lane, Lay{0, 0}, w.seg_first_u);
         return;
     }
     wv -= B;
     if (wv < B && wv < w.nseg_i[0])
         segment_update<E>(I, c, (int)wv, w.seg_start_i, w.seg_row_i, w.perm_i, w.coef, w.side[3], w.side[4],
-                          w.side[5], w.side[0], lane);
+                          w.side[5], w.side[0], lane, Lay{0, 0}, w.seg_first_i);
 }
 
 
@@ -623,6 +625,8 @@ static int focf_launch_sort(const FocfWs& w, const int64_t* user, const int64_t*
     SortJob ju{user, n_users, w.perm_u, w.seg_start_u, w.seg_row_u, nullptr, w.nseg_u, nullptr, nullptr};
     SortJob ji{item, n_items, w.perm_i, w.seg_start_i, w.seg_row_i, nullptr, w.nseg_i, want_minmax ? sst : nullptr,
                w.sst_minmax};
+    ju.seg_first = w.seg_first_u;
+    ji.seg_first = w.seg_first_i;
     return launch_sort(ju, &ji, B, err_flag, stream);
 }
 
@@ -650,6 +654,8 @@ extern "C" int fr_focf_prepare_many(const fr_focf_batch* batches, int32_t n, int
         FR_CHECK_ARG(b.ws_bytes >= w.bytes, "fr_focf_prepare_many: workspace %zu < %zu bytes", b.ws_bytes, w.bytes);
         SortJob ju{b.user, n_users, w.perm_u, w.seg_start_u, w.seg_row_u, nullptr, w.nseg_u, nullptr, nullptr};
         SortJob ji{b.item, n_items, w.perm_i, w.seg_start_i, w.seg_row_i, nullptr, w.nseg_i, b.sst, w.sst_minmax};
+        ju.seg_first = w.seg_first_u;
+        ji.seg_first = w.seg_first_i;
         jobs.j[2 * q] = ju;
         jobs.j[2 * q + 1] = ji;
         jobs.M[2 * q] = jobs.M[2 * q + 1] = (int)b.B;
@@ -723,7 +729,7 @@ extern "C" int fr_focf_forward(const fr_table* U, const fr_table* I, const fr_ad
     } else if (objective != FR_FOCF_NONE) {
         {
             ProfScope prof(K_FOCF_FAIR, stream);
-            FairArgs fa{w.perm_i, w.seg_start_i, w.nseg_i, w.sst_minmax, 1, 0, w.pred, rating, sst, Lay{0, 0}, w.coef, Lay{0, 0}, w.fair_part, 1,
+            FairArgs fa{w.perm_i, w.seg_start_i, w.nseg_i, w.seg_first_i, w.sst_minmax, 1, 0, w.pred, rating, sst, Lay{0, 0}, w.coef, Lay{0, 0}, w.fair_part, 1,
                         w.ticket, w.mse_part, w.n_gather_blocks, (int)B, loss_out};
             FR_LAUNCH(prof, focf_fair_kernel, dim3(w.n_fair_blocks), dim3(FAIR_THREADS), 0, stream, fa, objective,
                                fair_weight, 0, err_flag);
@@ -838,7 +844,7 @@ extern "C" int fr_focf_shard_fair(void* item_ws, size_t ws_bytes, int64_t n_slot
         // records of slot (g, k): planes rec[g][0..2][k]; padding slots are in no segment, so never read or written.
         // scratch[0] is the arrival ticket (zero between launches), partials follow; the last block to arrive writes
         // the tails (K_owner, fair_owner, sum of the sq_part partials) of all destination chunks
-        FairArgs fa{tw.perm, tw.seg_start, tw.nseg, minmax, (int)mm_count, (int)mm_stride, rec, rec + cap, rec + 2 * cap,
+        FairArgs fa{tw.perm, tw.seg_start, tw.nseg, nullptr, minmax, (int)mm_count, (int)mm_stride, rec, rec + cap, rec + 2 * cap,
                     Lay{cap, 3 * cap}, reply, Lay{cap, cap + FR_SHARD_TAIL}, scratch + 16, 0,
                     reinterpret_cast<unsigned int*>(scratch), sq_part, (int)n_sq_part, 0, nullptr,
                     reply + cap, (int)(n_slots / cap), cap + FR_SHARD_TAIL};

@@ -62,6 +62,8 @@ struct SortJob {
     const float* aux;   // optional float column to min/max-reduce alongside (may be null)
     float* aux_minmax;  // [2]
     Lay lay;            // layout of idx (zero-initialised = dense)
+    int32_t* seg_first; // optional [M]: perm[seg_start[k]] of segment k, so that its consumers need not chase perm for
+                        //   the first (usually the only) member: one dependent memory round trip less per wave
 };
 
 // Sort index lists in one launch, one workgroup each: (a) or (a, b) of the same length M ...

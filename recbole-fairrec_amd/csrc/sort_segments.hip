@@ -237,6 +237,7 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_segments_kernel(SortJobList
             if ((bal[q] >> lane) & 1ull) {
                 job.seg_start[seg] = j;
                 job.seg_row[seg] = (int)(unsigned)(k >> 32);
+                if (job.seg_first) job.seg_first[seg] = b;
             }
             if (job.seg_of) job.seg_of[b] = seg;
         }

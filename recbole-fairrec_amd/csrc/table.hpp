@@ -13,11 +13,16 @@ template <int E>
 __device__ __forceinline__ void segment_update(const TableV& T, const AdamC& c, int k, const int32_t* seg_start,
                                                const int32_t* seg_row, const int32_t* perm, const float* coef,
                                                const float* sp, const float* sm, const float* sv, const float* other,
-                                               int lane, Lay lay = Lay{0, 0}) {   // lay: layout of sp and other
+                                               int lane, Lay lay = Lay{0, 0},   // lay: layout of sp and other
+                                               const int32_t* seg_first = nullptr) {
     const int D = T.D;
-    const int j0 = uniform(seg_start[k]), j1 = uniform(seg_start[k + 1]);
-    const int row = uniform(seg_row[k]);
-    const int b0 = uniform(perm[j0]);
+    // first level of loads: everything that depends on k only (a wave-uniform value costs a memory round trip when it
+    // is consumed; seg_first saves the perm[j0] trip of the first -- usually the only -- member)
+    const int rj0 = seg_start[k], rj1 = seg_start[k + 1], rrow = seg_row[k];
+    const int rb0 = seg_first ? seg_first[k] : 0;
+    const int j0 = uniform(rj0), j1 = uniform(rj1);
+    const int row = uniform(rrow);
+    const int b0 = seg_first ? uniform(rb0) : uniform(perm[j0]);
     RowFrag<E> p, m, v, g;
     load_row<E>(p, sp + (size_t)lay.at(b0) * D, D, lane);
     load_row<E>(m, sm + (size_t)b0 * D, D, lane);
@@ -31,7 +36,7 @@ __device__ __forceinline__ void segment_update(const TableV& T, const AdamC& c, 
     constexpr int SEG_UNROLL = 8;
     if (j1 - j0 < SEG_UNROLL) {      // the common case (uniform batches: one or two members): plain uniform loads
         for (int j = j0; j < j1; ++j) {
-            const int b = uniform(perm[j]);
+            const int b = j == j0 ? b0 : uniform(perm[j]);
             const float c1 = coef ? coef[b] : 1.f;
             RowFrag<E> o;
             load_row<E>(o, other + (size_t)lay.at(b) * D, D, lane);
