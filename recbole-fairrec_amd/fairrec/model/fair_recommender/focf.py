@@ -295,7 +295,8 @@ class FOCF(FairRecommender):
 
     def calculate_loss(self, interaction):
         eng = self.hip_engine()
-        u, i, r, s = self._cols(interaction)
+        hit = getattr(self, '_cols_cache', {}).get(id(interaction))      # announced earlier: converted already
+        u, i, r, s = hit[1] if hit is not None and hit[0] is interaction else self._cols(interaction)
         nxt = getattr(self, '_next_cols', None)
         self._next_cols = None
         loss, _ = eng.forward(u, i, r, s, next_batch=[(c[0], c[1], c[3]) for c in nxt] if nxt else None)
