@@ -260,9 +260,9 @@ def main():
                     "measured_copy_ceiling": round(copy_gbs, 1), "frac_of_measured_ceiling": round(achieved / copy_gbs, 4),
                     "algorithmic_bytes_per_launch": algo_bytes,
                     "kernel_us": {k: round(v, 2) for k, v in sorted(per_kernel.items())},
-                    "dominant_rule": "longest kernel of the dependent chain; sort_segments_kernel runs on 1-2 workgroups, "
-                                     + ("concurrently with the gather kernels on a side stream" if sharded else
-                                        "one step ahead, overlapped with the chain"),
+                    "dominant_rule": "longest kernel of the dependent chain; sort_segments_kernel runs "
+                                     + ("on 1-2 workgroups concurrently with the gather kernels on a side stream" if sharded
+                                        else "once per 8 steps (16 workgroups) on a side stream, ahead of the chain"),
                     "measured": f"hipExtLaunchKernelGGL start/stop events on every launch, {K} eager steps after the "
                                 "timed region (same look-ahead sort overlap as the timed steps)"}
 
@@ -277,7 +277,7 @@ def main():
                                    "B=8192 per GPU, Adam lr=1e-3 weight_decay=1e-3 (BASELINE.json configs[1])",
                        "item_distribution": args.item_dist, "launch": "eager" if graph is None else "hipGraph",
                        "step": "gather / fair / backward_adam chain"
-                               + ("" if sharded else "; id columns of 8 coming batches sorted per side launch, sweep slice rides in the gather launch"),
+                               + ("" if sharded else "; id columns of 8 coming batches sorted per side launch, sweep slice rides in the backward launch"),
                        "lazy_adam_sweep_period": eng._sweep(BATCH) if not sharded else args.sweep,
                        "tables": "row-sharded over %d ranks, RCCL all-to-all" % world if sharded else "single GPU",
                        "global_batch": BATCH * world, "final_loss": round(loss_last, 6) if not sharded else None},
