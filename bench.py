@@ -109,6 +109,9 @@ def main():
     ap.add_argument("--item-dist", default="uniform", choices=["uniform", "zipf", "grouped"])
     ap.add_argument("--sweep", type=int, default=None, help="lazy-Adam sweep period (default: auto)")
     ap.add_argument("--force-sharded", action="store_true", help="use the row-sharded engine even on one GPU")
+    ap.add_argument("--age", type=int, default=0,
+                    help="optimizer steps run before the warm-up so that the lazy-Adam staleness is stationary "
+                         "(default: one sweep period)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -180,6 +183,17 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    # Age the optimizer state first (set-up, not measured): every row's replay length depends on how long ago it was
+    # last touched, and that distribution is stationary only after one full sweep period -- a fresh table has nothing
+    # to replay, which would flatter the first `sweep_period` timed steps.
+    if not sharded and args.age >= 0:
+        n_age = args.age if args.age else (eng._sweep(BATCH) if (args.sweep is None or args.sweep > 0) else 256)
+        ua, ia, ra, sa = (t.to(dev) for t in synth_batches(n_age, BATCH, N_USERS, N_ITEMS, SEED + 104729 + rank, args.item_dist))
+        for k in range(n_age):
+            eng.forward(ua[k], ia[k], ra[k], sa[k], next_batch=coming(k, ua, ia, sa))
+            eng.backward_adam()
+        torch.cuda.synchronize()
+        del ua, ia, ra, sa
     for k in range(W):
         step(k)
     barrier()
@@ -280,7 +294,8 @@ def main():
                                + ("" if sharded else "; id columns of 8 coming batches sorted per side launch, sweep slice rides in the backward launch"),
                        "lazy_adam_sweep_period": eng._sweep(BATCH) if not sharded else args.sweep,
                        "tables": "row-sharded over %d ranks, RCCL all-to-all" % world if sharded else "single GPU",
-                       "global_batch": BATCH * world, "final_loss": round(loss_last, 6) if not sharded else None},
+                       "global_batch": BATCH * world, "final_loss": round(loss_last, 6) if not sharded else None,
+                       "aged_steps": None if sharded else n_age},
             "roofline": roofline,
         }
         if not args.no_cpu_baseline and world == 1:
