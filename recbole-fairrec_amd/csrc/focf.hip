@@ -264,9 +264,17 @@ __global__ __launch_bounds__(FAIR_THREADS) void focf_fair_kernel(FairArgs w, int
         const int first_b = w.seg_first ? w.seg_first[k] : -1;
         float sp0 = 0.f, sp1 = 0.f, st0 = 0.f, st1 = 0.f, n0 = 0.f, n1 = 0.f;
         bool bad = false;
+        // this lane's first member: its dL/dpred so far (the MSE part) is requested together with its values, so that
+        // the read-modify-write at the end is not one more dependent round trip
+        float c_first = 0.f;
+        int b_first = -1;
         for (int j = j0 + sub; j < j1; j += FAIR_GROUP) {
             const int b = (j == j0 && first_b >= 0) ? first_b : w.perm[j];
             const long long bp = w.mlay.at(b);
+            if (j == j0 + sub) {
+                b_first = b;
+                if (w.accumulate) c_first = w.coef[w.clay.at(b)];
+            }
             const float s = w.sst[bp], pr = w.pred[bp], r = w.rating[bp];
             bad |= (s != smin && s != smax);
             if (s == smin) {
@@ -291,10 +299,11 @@ __global__ __launch_bounds__(FAIR_THREADS) void focf_fair_kernel(FairArgs w, int
         const float dx = (x < 1.f ? x : 1.f) * sgn * fair_weight / (defer_k ? 1.f : (float)K);
         const float g0 = dx * q0 / c0, g1 = -dx * q1 / c1;
         for (int j = j0 + sub; j < j1; j += FAIR_GROUP) {
-            const int b = (j == j0 && first_b >= 0) ? first_b : w.perm[j];
+            const bool first = j == j0 + sub;
+            const int b = first ? b_first : w.perm[j];
             const float g = (w.sst[w.mlay.at(b)] == smin) ? g0 : g1;
             const long long cp = w.clay.at(b);
-            w.coef[cp] = w.accumulate ? w.coef[cp] + g : g;
+            w.coef[cp] = w.accumulate ? (first ? c_first : w.coef[cp]) + g : g;
         }
     }
     if (sub == 0) red[gib] = term;
