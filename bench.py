@@ -151,6 +151,7 @@ def main():
         U, I = xavier_tables(N_USERS, N_ITEMS, DIM, SEED, dev)
         eng = FocfEngine(U, I, OBJECTIVE, FAIR_WEIGHT, 5.0)
         FusedLazyAdam(eng, lr=LR, weight_decay=WD, sweep_period=args.sweep)
+        eng.defer_loss = True     # every forward below is followed by backward_adam; the loss is read at the end
     else:
         from fairrec.sharded import ShardedFocfEngine, shard_rows
         if not torch.distributed.is_initialized():

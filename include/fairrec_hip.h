@@ -123,6 +123,10 @@ FR_API size_t fr_focf_workspace_bytes(int64_t B, int32_t dim);
  *   pred_out    = pred_scores [B] (device, may be NULL)
  */
 #define FR_FOCF_PREPARED 1   /* flags: fr_focf_prepare(_many) already ran for this batch on this workspace */
+/* FR_FOCF_DEFER_LOSS: loss_out is written by the fr_focf_backward_adam that follows on the same workspace and stream
+ * (one extra workgroup of its launch) instead of by this call -- for step loops that read the loss after optimizer.step().
+ * Takes the reduction's ticket round trip off the end of the fairness kernel, i.e. off the step's critical path. */
+#define FR_FOCF_DEFER_LOSS 2
 FR_API int fr_focf_forward(const fr_table* U, const fr_table* I, const fr_adam* adam, const int64_t* user,
                     const int64_t* item, const float* rating, const float* sst, int64_t B, int32_t objective,
                     float fair_weight, int32_t flags, void* ws, size_t ws_bytes, float* loss_out, float* pred_out,

@@ -402,8 +402,9 @@ __global__ __launch_bounds__(1024) void focf_nonparity_kernel(FocfWs w, const fl
     if (threadIdx.x == 0) w.fair_part[0] = smooth_l1(delta);
 }
 
-__global__ __launch_bounds__(256) void focf_finalize_kernel(FocfWs w, int B, int objective, float fair_weight,
-                                                            float* __restrict__ loss_out) {
+// fixed-order reduction of the partial sums of one batch -> loss (one block of 256 threads)
+__device__ __forceinline__ void focf_finalize_block(const FocfWs& w, int B, int objective, float fair_weight,
+                                                    float* __restrict__ loss_out) {
     __shared__ float red[2][4];
     float a = 0.f, f = 0.f;
     for (int q = threadIdx.x; q < w.n_gather_blocks; q += 256) a += w.mse_part[q];
@@ -426,6 +427,19 @@ __global__ __launch_bounds__(256) void focf_finalize_kernel(FocfWs w, int B, int
     }
 }
 
+__global__ __launch_bounds__(256) void focf_finalize_kernel(FocfWs w, int B, int objective, float fair_weight,
+                                                            float* __restrict__ loss_out) {
+    focf_finalize_block(w, B, objective, fair_weight, loss_out);
+}
+
+// FR_FOCF_DEFER_LOSS: the loss of the batch is reduced by one extra workgroup of the backward launch instead of inside
+// the forward (where it costs a ticket round trip at the end of the fairness kernel, on the step's critical path)
+struct DeferLoss {
+    float* loss_out;   // nullptr = nothing deferred
+    int objective;
+    float fair_weight;
+};
+
 // ------------------------------------------------------------------------------------------------
 // backward + Adam: one wave per distinct row, plus sweeper waves
 // ------------------------------------------------------------------------------------------------
@@ -433,9 +447,13 @@ __global__ __launch_bounds__(256) void focf_finalize_kernel(FocfWs w, int B, int
 // replayed steps per row, the segment waves exactly one); then one wave per distinct user row, per distinct item row
 template <int E>
 __global__ __launch_bounds__(256) void focf_backward_adam_kernel(TableV U, TableV I, AdamC c, int B, FocfWs w,
-                                                                 SweepSlice sw, int n_sweep_waves) {
+                                                                 SweepSlice sw, int n_sweep_waves, DeferLoss dl) {
+    if (dl.loss_out && blockIdx.x == 0) {   // the extra workgroup, first so that it overlaps with everything else
+        focf_finalize_block(w, B, dl.objective, dl.fair_weight, dl.loss_out);
+        return;
+    }
     const int lane = threadIdx.x & 63;
-    long long wv = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    long long wv = (long long)(blockIdx.x - (dl.loss_out ? 1 : 0)) * 4 + (threadIdx.x >> 6);
     if (wv < n_sweep_waves) {
         sweep_slice_wave<E>(U, I, c, sw, wv, lane);
         return;
@@ -639,6 +657,10 @@ static int focf_launch_sort(const FocfWs& w, const int64_t* user, const int64_t*
     return launch_sort(ju, &ji, B, err_flag, stream);
 }
 
+// workspace whose batch loss fr_focf_backward_adam still has to reduce (FR_FOCF_DEFER_LOSS)
+static const void* g_defer_ws = nullptr;
+static DeferLoss g_defer{nullptr, 0, 0.f};
+
 static SweepSlice make_sweep_slice(const fr_table* U, const fr_table* I, int32_t sweep_period) {
     SweepSlice sw{};
     long long hi_u, hi_i;
@@ -722,6 +744,8 @@ extern "C" int fr_focf_forward(const fr_table* U, const fr_table* I, const fr_ad
 
     const AdamC c = make_adamc(adam);
     const TableV Uv = view(U), Iv = view(I);
+    const bool defer = (flags & FR_FOCF_DEFER_LOSS) != 0;
+    g_defer_ws = nullptr;
     {
         ProfScope prof(K_FOCF_GATHER, stream);
         FR_DISPATCH_E(U->dim, FR_LAUNCH(prof, (focf_gather_kernel<E, true>), dim3(w.n_gather_blocks), dim3(GATHER_THREADS), 0, stream, Uv, Iv, c, user, item, rating, (int)B, U->step - 1, I->step - 1, w, 0.f, (float*)nullptr, err_flag));
@@ -739,13 +763,16 @@ extern "C" int fr_focf_forward(const fr_table* U, const fr_table* I, const fr_ad
         {
             ProfScope prof(K_FOCF_FAIR, stream);
             FairArgs fa{w.perm_i, w.seg_start_i, w.nseg_i, w.seg_first_i, w.sst_minmax, 1, 0, w.pred, rating, sst, Lay{0, 0}, w.coef, Lay{0, 0}, w.fair_part, 1,
-                        w.ticket, w.mse_part, w.n_gather_blocks, (int)B, loss_out};
+                        defer ? nullptr : w.ticket, w.mse_part, w.n_gather_blocks, (int)B, loss_out};
             FR_LAUNCH(prof, focf_fair_kernel, dim3(w.n_fair_blocks), dim3(FAIR_THREADS), 0, stream, fa, objective,
                                fair_weight, 0, err_flag);
         }
         FR_CHECK_LAUNCH();
     }
-    if (objective == FR_FOCF_NONE || objective == FR_FOCF_NONPARITY) {
+    if (defer) {
+        g_defer_ws = ws;
+        g_defer = DeferLoss{loss_out, (int)objective, fair_weight};
+    } else if (objective == FR_FOCF_NONE || objective == FR_FOCF_NONPARITY) {
         ProfScope prof(K_FOCF_FINALIZE, stream);
         FR_LAUNCH(prof, focf_finalize_kernel, dim3(1), dim3(256), 0, stream, w, (int)B, objective, fair_weight,
                            loss_out);
@@ -777,7 +804,9 @@ extern "C" int fr_focf_backward_adam(const fr_table* U, const fr_table* I, const
     }
     {
         ProfScope prof(K_FOCF_BWD_ADAM, stream);
-        FR_DISPATCH_E(U->dim, FR_LAUNCH(prof, (focf_backward_adam_kernel<E>), dim3((unsigned)((sweep_waves + 2 * B + 3) / 4)), dim3(256), 0, stream, Uv, Iv, c, (int)B, w, sw, (int)sweep_waves));
+        const DeferLoss dl = g_defer_ws == ws ? g_defer : DeferLoss{nullptr, 0, 0.f};
+        g_defer_ws = nullptr;
+        FR_DISPATCH_E(U->dim, FR_LAUNCH(prof, (focf_backward_adam_kernel<E>), dim3((unsigned)((sweep_waves + 2 * B + 3) / 4) + (dl.loss_out ? 1u : 0u)), dim3(256), 0, stream, Uv, Iv, c, (int)B, w, sw, (int)sweep_waves, dl));
     }
     FR_CHECK_LAUNCH();
     return FR_OK;

@@ -68,6 +68,9 @@ class FocfEngine:
         self.err_flag = torch.zeros(1, dtype=torch.int32, device=self.device)
         self.pending_B = 0
         self.backward_seen = False
+        # FR_FOCF_DEFER_LOSS: the loss slot is filled by backward_adam() instead of forward().  Only for step loops that
+        # read the loss after optimizer.step() (fairrec's Trainer fast path, bench.py).
+        self.defer_loss = False
 
     # --- optimizer plumbing ---------------------------------------------------------------------------
     def tables(self) -> Dict[str, LazyTable]:
@@ -150,6 +153,8 @@ class FocfEngine:
                 torch.cuda.current_stream().wait_event(group["done"])
                 group["joined"] = True
             flags = 1                                            # FR_FOCF_PREPARED
+        if self.defer_loss and self.optimizer is not None:
+            flags |= 2                                           # FR_FOCF_DEFER_LOSS
         ws = self._workspace(B, self.ws_cur)
         coming = []
         if next_batch is not None:

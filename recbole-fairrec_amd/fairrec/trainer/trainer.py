@@ -107,6 +107,16 @@ class Trainer(AbstractTrainer):
         total = None
         n_tuple = 0
         hint = getattr(self.model, 'hint_next_batch', None)
+        if fused:
+            eng = self.model.hip_engine()
+            eng.defer_loss = True        # the loop below reads the loss only after optimizer.step()
+            try:
+                return self._train_epoch_body(train_data, loss_func, hint, graphed, fused, total, n_tuple)
+            finally:
+                eng.defer_loss = False
+        return self._train_epoch_body(train_data, loss_func, hint, graphed, fused, total, n_tuple)
+
+    def _train_epoch_body(self, train_data, loss_func, hint, graphed, fused, total, n_tuple):
         it = iter(train_data)
         # dataloader look-ahead: a model that can use it (FOCF sorts the coming batches' ids ahead, several per launch)
         # says how many batches it wants announced
@@ -135,9 +145,9 @@ class Trainer(AbstractTrainer):
                 continue
             if fused:
                 with torch.no_grad():
-                    part = loss_func(interaction).view(1)
+                    part = loss_func(interaction).view(1)     # a view of the engine's loss slot of this step ...
+                self.optimizer.step()                         # ... which the backward launch fills (defer_loss)
                 total = part.clone() if total is None else total + part
-                self.optimizer.step()
                 continue
             self.optimizer.zero_grad()
             losses = loss_func(interaction)

@@ -132,17 +132,18 @@ def test_lookahead_sweep_equals_plain_chain(objective, dim, item_dist):
     I0 = (torch.randn(n_items, dim, generator=g) * 0.1).cuda()
     engs = []
     modes = (0, 1, 6)           # coming batches announced to the engine
-    for _ in modes:
+    for ahead in modes:
         eng = FocfEngine(U0.clone(), I0.clone(), objective, 0.5, 5.0)
         FusedLazyAdam(eng, lr=1e-2, weight_decay=1e-3, sweep_period=4)
+        eng.defer_loss = ahead == 6      # loss reduced by the backward launch (read after backward_adam below)
         engs.append(eng)
     for t in range(T):
         out = []
         for eng, ahead in zip(engs, modes):
             nxt = [(u[j], i[j], s[j]) for j in range(t + 1, t + 1 + ahead) if j < T] or None
             loss, pred = eng.forward(u[t], i[t], r[t], s[t], want_pred=True, next_batch=nxt)
-            out.append((loss.clone(), pred))
             eng.backward_adam()
+            out.append((loss.clone(), pred))
         for o in out[1:]:
             torch.testing.assert_close(o[0][:3], out[0][0][:3], rtol=2e-5, atol=1e-7)
             torch.testing.assert_close(o[1], out[0][1], rtol=2e-5, atol=1e-6)
