@@ -657,9 +657,42 @@ static int focf_launch_sort(const FocfWs& w, const int64_t* user, const int64_t*
     return launch_sort(ju, &ji, B, err_flag, stream);
 }
 
-// workspace whose batch loss fr_focf_backward_adam still has to reduce (FR_FOCF_DEFER_LOSS)
-static const void* g_defer_ws = nullptr;
-static DeferLoss g_defer{nullptr, 0, 0.f};
+// workspaces whose batch loss fr_focf_backward_adam still has to reduce (FR_FOCF_DEFER_LOSS); a handful of engines may
+// have a forward in flight at the same time (one slot per workspace, reused round-robin)
+static constexpr int DEFER_SLOTS = 16;
+static const void* g_defer_ws[DEFER_SLOTS] = {nullptr};
+static DeferLoss g_defer[DEFER_SLOTS];
+static int g_defer_next = 0;
+
+static void defer_forget(const void* ws) {
+    for (int q = 0; q < DEFER_SLOTS; ++q)
+        if (g_defer_ws[q] == ws) g_defer_ws[q] = nullptr;
+}
+
+static void defer_put(const void* ws, const DeferLoss& d) {
+    defer_forget(ws);
+    for (int q = 0; q < DEFER_SLOTS; ++q) {
+        const int k = (g_defer_next + q) % DEFER_SLOTS;
+        if (!g_defer_ws[k]) {
+            g_defer_ws[k] = ws;
+            g_defer[k] = d;
+            g_defer_next = (k + 1) % DEFER_SLOTS;
+            return;
+        }
+    }
+    g_defer_ws[g_defer_next] = ws;      // all slots taken by forwards that never got their backward: overwrite the oldest
+    g_defer[g_defer_next] = d;
+    g_defer_next = (g_defer_next + 1) % DEFER_SLOTS;
+}
+
+static DeferLoss defer_take(const void* ws) {
+    for (int q = 0; q < DEFER_SLOTS; ++q)
+        if (g_defer_ws[q] == ws) {
+            g_defer_ws[q] = nullptr;
+            return g_defer[q];
+        }
+    return DeferLoss{nullptr, 0, 0.f};
+}
 
 static SweepSlice make_sweep_slice(const fr_table* U, const fr_table* I, int32_t sweep_period) {
     SweepSlice sw{};
@@ -745,7 +778,7 @@ extern "C" int fr_focf_forward(const fr_table* U, const fr_table* I, const fr_ad
     const AdamC c = make_adamc(adam);
     const TableV Uv = view(U), Iv = view(I);
     const bool defer = (flags & FR_FOCF_DEFER_LOSS) != 0;
-    g_defer_ws = nullptr;
+    defer_forget(ws);
     {
         ProfScope prof(K_FOCF_GATHER, stream);
         FR_DISPATCH_E(U->dim, FR_LAUNCH(prof, (focf_gather_kernel<E, true>), dim3(w.n_gather_blocks), dim3(GATHER_THREADS), 0, stream, Uv, Iv, c, user, item, rating, (int)B, U->step - 1, I->step - 1, w, 0.f, (float*)nullptr, err_flag));
@@ -770,8 +803,7 @@ extern "C" int fr_focf_forward(const fr_table* U, const fr_table* I, const fr_ad
         FR_CHECK_LAUNCH();
     }
     if (defer) {
-        g_defer_ws = ws;
-        g_defer = DeferLoss{loss_out, (int)objective, fair_weight};
+        defer_put(ws, DeferLoss{loss_out, (int)objective, fair_weight});
     } else if (objective == FR_FOCF_NONE || objective == FR_FOCF_NONPARITY) {
         ProfScope prof(K_FOCF_FINALIZE, stream);
         FR_LAUNCH(prof, focf_finalize_kernel, dim3(1), dim3(256), 0, stream, w, (int)B, objective, fair_weight,
@@ -804,8 +836,7 @@ extern "C" int fr_focf_backward_adam(const fr_table* U, const fr_table* I, const
     }
     {
         ProfScope prof(K_FOCF_BWD_ADAM, stream);
-        const DeferLoss dl = g_defer_ws == ws ? g_defer : DeferLoss{nullptr, 0, 0.f};
-        g_defer_ws = nullptr;
+        const DeferLoss dl = defer_take(ws);
         FR_DISPATCH_E(U->dim, FR_LAUNCH(prof, (focf_backward_adam_kernel<E>), dim3((unsigned)((sweep_waves + 2 * B + 3) / 4) + (dl.loss_out ? 1u : 0u)), dim3(256), 0, stream, Uv, Iv, c, (int)B, w, sw, (int)sweep_waves, dl));
     }
     FR_CHECK_LAUNCH();

@@ -157,6 +157,25 @@ def test_lookahead_sweep_equals_plain_chain(objective, dim, item_dist):
             torch.testing.assert_close(x, y, rtol=5e-5, atol=1e-7 * float(y.abs().max()) + 1e-12)
 
 
+def test_deferred_loss_with_interleaved_engines():
+    """FR_FOCF_DEFER_LOSS: the backward launch reduces the loss of ITS workspace's batch, also when another engine's
+    forward ran in between."""
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "focf_value.npz"))
+    ref, a, b = _engine(z, 3), _engine(z, 3), _engine(z, 3)
+    a.defer_loss = b.defer_loss = True
+    for t in range(6):
+        cols = [torch.tensor(z[k][t], device="cuda") for k in ("user_id", "item_id", "rating", "sst")]
+        lr, _ = ref.forward(*cols)
+        lr = lr.clone()
+        ref.backward_adam()
+        la, _ = a.forward(*cols)
+        lb, _ = b.forward(*cols)
+        a.backward_adam()
+        b.backward_adam()
+        torch.testing.assert_close(la[:3], lr[:3], rtol=1e-6, atol=0)
+        torch.testing.assert_close(lb[:3], lr[:3], rtol=1e-6, atol=0)
+
+
 def test_device_error_flags():
     z = np.load(os.path.join(os.path.dirname(__file__), "golden", "focf_value.npz"))
     eng = _engine(z, 0)
