@@ -152,6 +152,7 @@ def main():
         eng = FocfEngine(U, I, OBJECTIVE, FAIR_WEIGHT, 5.0)
         FusedLazyAdam(eng, lr=LR, weight_decay=WD, sweep_period=args.sweep)
         eng.defer_loss = True     # every forward below is followed by backward_adam; the loss is read at the end
+        eng.item_runs = args.item_dist == "grouped"    # what the Trainer sets when it is fed by FOCFDataLoader
     else:
         from fairrec.sharded import ShardedFocfEngine, shard_rows
         if not torch.distributed.is_initialized():

@@ -127,6 +127,10 @@ FR_API size_t fr_focf_workspace_bytes(int64_t B, int32_t dim);
  * (one extra workgroup of its launch) instead of by this call -- for step loops that read the loss after optimizer.step().
  * Takes the reduction's ticket round trip off the end of the fairness kernel, i.e. off the step's critical path. */
 #define FR_FOCF_DEFER_LOSS 2
+/* FR_FOCF_ITEM_RUNS: a hint -- the interactions of an item sit next to each other in the batch (item-complete batches,
+ * focf_dataloader.py:37-51).  The gather kernel then replays an item row once per workgroup instead of once per wave (the
+ * item row carries the longest replay there: 25.6 -> 21.1 us at K = 82 items per batch).  Same results either way. */
+#define FR_FOCF_ITEM_RUNS 4
 FR_API int fr_focf_forward(const fr_table* U, const fr_table* I, const fr_adam* adam, const int64_t* user,
                     const int64_t* item, const float* rating, const float* sst, int64_t B, int32_t objective,
                     float fair_weight, int32_t flags, void* ws, size_t ws_bytes, float* loss_out, float* pred_out,

@@ -78,49 +78,111 @@ static FocfWs focf_layout(void* base, int64_t B, int D) {
 // ------------------------------------------------------------------------------------------------
 // gather: one wave per interaction
 // ------------------------------------------------------------------------------------------------
-template <int E, bool TRAIN>
+// LDS of one gather workgroup: the item row of each of its waves and room for the caught-up item rows that waves of the
+// same item share (item-complete batches -- the shape FOCFDataLoader produces, focf_dataloader.py:37-51 -- put the ~100
+// interactions of an item side by side, and the item row carries the longest replay of the wave: replaying it once per
+// workgroup instead of once per wave takes it off three waves out of four)
+template <int E>
+struct GatherLds {
+    float red[GATHER_THREADS / WAVE];
+    float irow[GATHER_THREADS / WAVE][3][64 * E + 1];   // E = 0: not used (one float each)
+};
+
+template <int E, bool TRAIN, bool SHARE>
 __device__ __forceinline__ void focf_gather_body(
     const TableV& U, const TableV& I, const AdamC& c, const int64_t* __restrict__ user, const int64_t* __restrict__ item,
     const float* __restrict__ rating, int B, int upto_u, int upto_i, const FocfWs& w, float max_rating,
-    float* __restrict__ predict_out, uint32_t* err, int block, float* red) {
+    float* __restrict__ predict_out, uint32_t* err, int block, GatherLds<SHARE ? E : 0>& lds) {
+    constexpr int NW = GATHER_THREADS / WAVE;
     const int lane = threadIdx.x & 63;
     const int wib = threadIdx.x >> 6;
-    const int b = block * (GATHER_THREADS / WAVE) + wib;
+    const int b = block * NW + wib;
+    const bool valid = b < B;
+    const int D = U.D;
     float e2 = 0.f;
-    if (b < B) {
+    int ur = 0, ir = -1 - wib;       // an idle wave's "item" matches nobody's
+    if (valid) {
         long long ul = user[b], il = item[b];
         if (ul < 0 || ul >= U.n_rows || il < 0 || il >= I.n_rows) {
             if (lane == 0 && err) atomicOr(err, FR_DEV_ERR_INDEX_RANGE);
             ul = ul < 0 || ul >= U.n_rows ? 0 : ul;
             il = il < 0 || il >= I.n_rows ? 0 : il;
         }
-        const int ur = uniform((int)ul), ir = uniform((int)il);
-        const int D = U.D;
-        const float* up = U.p + (size_t)ur * D;
-        const float* ip = I.p + (size_t)ir * D;
-        RowFrag<E> pu, mu, vu, pi, mi, vi;
+        ur = uniform((int)ul);
+        ir = uniform((int)il);
+    }
+    // the first wave of the workgroup with the same item replays its row for all of them; every wave reads the item ids
+    // of the whole workgroup itself (one cache line, same round trip as its own ids): no barrier unless rows are shared
+    int lead = wib;
+    bool shares = false;
+    if (SHARE) {
+        int it[NW];
+#pragma unroll
+        for (int q = 0; q < NW; ++q) {
+            const int bq = block * NW + q;
+            long long v = bq < B ? item[bq] : -1;
+            it[q] = (v < 0 || v >= I.n_rows) ? (bq < B ? 0 : -1 - q) : (int)v;     // same clamping as above
+        }
+#pragma unroll
+        for (int q = NW - 1; q >= 0; --q) {
+            if (q < wib && it[q] == ir) lead = q;
+#pragma unroll
+            for (int r = 0; r < q; ++r) shares |= it[q] == it[r];
+        }
+    }
+    lead = uniform(lead);
+    shares = uniform((int)shares) != 0;
+    RowFrag<E> pu, mu, vu, pi, mi, vi;
+    if (valid) {
         // one level of dependent loads: the rows and their `last` stamps are requested together (a wave-uniform value
         // is a load + readfirstlane, i.e. a full memory round trip each time one is consumed: ~3-4 us per level here)
-        const int lu = U.last[ur], li = I.last[ir];
-        load_row<E>(pu, up, D, lane);
-        load_row<E>(pi, ip, D, lane);
+        const int lu = U.last[ur];
+        const int li = lead == wib ? I.last[ir] : 0;
+        load_row<E>(pu, U.p + (size_t)ur * D, D, lane);
+        if (lead == wib) load_row<E>(pi, I.p + (size_t)ir * D, D, lane);
         load_row<E>(mu, U.m + (size_t)ur * D, D, lane);
         load_row<E>(vu, U.v + (size_t)ur * D, D, lane);
-        load_row<E>(mi, I.m + (size_t)ir * D, D, lane);
-        load_row<E>(vi, I.v + (size_t)ir * D, D, lane);
-        const int t0u = uniform(lu), t0i = uniform(li);
-
+        if (lead == wib) {
+            load_row<E>(mi, I.m + (size_t)ir * D, D, lane);
+            load_row<E>(vi, I.v + (size_t)ir * D, D, lane);
+        }
+        const int t0u = uniform(lu);
         // replay the optimizer steps each row missed (zero data gradient, weight decay only): first the
         // steps only the staler row missed, then the common tail on both rows interleaved
-        if (upto_u == upto_i) {
-            if (t0u < t0i) replay<E>(pu, mu, vu, t0u, t0i, c, lane);
-            else if (t0i < t0u) replay<E>(pi, mi, vi, t0i, t0u, c, lane);
-            replay2<E>(pu, mu, vu, pi, mi, vi, t0u > t0i ? t0u : t0i, upto_u, c, lane);
-        } else {
+        if (lead != wib) {
             replay<E>(pu, mu, vu, t0u, upto_u, c, lane);
-            replay<E>(pi, mi, vi, t0i, upto_i, c, lane);
+        } else {
+            const int t0i = uniform(li);
+            if (upto_u == upto_i) {
+                if (t0u < t0i) replay<E>(pu, mu, vu, t0u, t0i, c, lane);
+                else if (t0i < t0u) replay<E>(pi, mi, vi, t0i, t0u, c, lane);
+                replay2<E>(pu, mu, vu, pi, mi, vi, t0u > t0i ? t0u : t0i, upto_u, c, lane);
+            } else {
+                replay<E>(pu, mu, vu, t0u, upto_u, c, lane);
+                replay<E>(pi, mi, vi, t0i, upto_i, c, lane);
+            }
         }
-
+    }
+    if (SHARE && shares) {      // workgroup-uniform: hand the caught-up item rows over through LDS
+        if (valid && lead == wib) {
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                lds.irow[wib][0][lane + 64 * e] = pi.x[e];
+                lds.irow[wib][1][lane + 64 * e] = mi.x[e];
+                lds.irow[wib][2][lane + 64 * e] = vi.x[e];
+            }
+        }
+        __syncthreads();
+        if (valid && lead != wib) {
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                pi.x[e] = lds.irow[lead][0][lane + 64 * e];
+                mi.x[e] = lds.irow[lead][1][lane + 64 * e];
+                vi.x[e] = lds.irow[lead][2][lane + 64 * e];
+            }
+        }
+    }
+    if (valid) {
         float dot = 0.f;
 #pragma unroll
         for (int e = 0; e < E; ++e) dot = fmaf(pu.x[e], pi.x[e], dot);
@@ -147,13 +209,24 @@ __device__ __forceinline__ void focf_gather_body(
         }
     }
     if (TRAIN) {
-        if (lane == 0) red[wib] = e2;
+        if (lane == 0) lds.red[wib] = e2;
         __syncthreads();
         if (threadIdx.x == 0) {
-            w.mse_part[block] = ((red[0] + red[1]) + red[2]) + red[3];
+            w.mse_part[block] = ((lds.red[0] + lds.red[1]) + lds.red[2]) + lds.red[3];
             if (block == 0) *w.ticket = 0u;   // arm the fair kernel's in-launch finalisation (next launch)
         }
     }
+}
+
+// SHARE: waves of a workgroup that hold the same item share its replay (FR_FOCF_ITEM_RUNS: item-complete batches)
+template <int E, bool TRAIN, bool SHARE>
+__global__ __launch_bounds__(GATHER_THREADS) void focf_gather_kernel(
+    TableV U, TableV I, AdamC c, const int64_t* __restrict__ user, const int64_t* __restrict__ item,
+    const float* __restrict__ rating, int B, int upto_u, int upto_i, FocfWs w, float max_rating,
+    float* __restrict__ predict_out, uint32_t* err) {
+    __shared__ GatherLds<SHARE ? E : 0> lds;
+    focf_gather_body<E, TRAIN, SHARE>(U, I, c, user, item, rating, B, upto_u, upto_i, w, max_rating, predict_out, err,
+                                      (int)blockIdx.x, lds);
 }
 
 // The step's slice of the bounded-staleness sweeper, as extra workgroups of the backward launch: one wave per PAIR of
@@ -184,16 +257,6 @@ __device__ __forceinline__ void sweep_slice_wave(const TableV& U, const TableV& 
         const long long a = 2 * wv, b = a + 1 < sw.n_i ? sw.lo_i + a + 1 : -1;
         sweep_row_pair<E>(I, c, sw.lo_i + a, b, sw.upto, sw.skip_from, lane);
     }
-}
-
-template <int E, bool TRAIN>
-__global__ __launch_bounds__(GATHER_THREADS) void focf_gather_kernel(
-    TableV U, TableV I, AdamC c, const int64_t* __restrict__ user, const int64_t* __restrict__ item,
-    const float* __restrict__ rating, int B, int upto_u, int upto_i, FocfWs w, float max_rating,
-    float* __restrict__ predict_out, uint32_t* err) {
-    __shared__ float red[GATHER_THREADS / WAVE];
-    focf_gather_body<E, TRAIN>(U, I, c, user, item, rating, B, upto_u, upto_i, w, max_rating, predict_out, err,
-                               (int)blockIdx.x, red);
 }
 
 __device__ __forceinline__ float smooth_l1(float x) {  // F.smooth_l1_loss(|x|, 0), beta = 1
@@ -268,6 +331,7 @@ __global__ __launch_bounds__(FAIR_THREADS) void focf_fair_kernel(FairArgs w, int
         // the read-modify-write at the end is not one more dependent round trip
         float c_first = 0.f;
         int b_first = -1;
+#pragma unroll 4
         for (int j = j0 + sub; j < j1; j += FAIR_GROUP) {
             const int b = (j == j0 && first_b >= 0) ? first_b : w.perm[j];
             const long long bp = w.mlay.at(b);
@@ -781,7 +845,11 @@ extern "C" int fr_focf_forward(const fr_table* U, const fr_table* I, const fr_ad
     defer_forget(ws);
     {
         ProfScope prof(K_FOCF_GATHER, stream);
-        FR_DISPATCH_E(U->dim, FR_LAUNCH(prof, (focf_gather_kernel<E, true>), dim3(w.n_gather_blocks), dim3(GATHER_THREADS), 0, stream, Uv, Iv, c, user, item, rating, (int)B, U->step - 1, I->step - 1, w, 0.f, (float*)nullptr, err_flag));
+        if (flags & FR_FOCF_ITEM_RUNS) {
+            FR_DISPATCH_E(U->dim, FR_LAUNCH(prof, (focf_gather_kernel<E, true, true>), dim3(w.n_gather_blocks), dim3(GATHER_THREADS), 0, stream, Uv, Iv, c, user, item, rating, (int)B, U->step - 1, I->step - 1, w, 0.f, (float*)nullptr, err_flag));
+        } else {
+            FR_DISPATCH_E(U->dim, FR_LAUNCH(prof, (focf_gather_kernel<E, true, false>), dim3(w.n_gather_blocks), dim3(GATHER_THREADS), 0, stream, Uv, Iv, c, user, item, rating, (int)B, U->step - 1, I->step - 1, w, 0.f, (float*)nullptr, err_flag));
+        }
     }
     FR_CHECK_LAUNCH();
     if (overlap) FR_CHECK_HIP(hipStreamWaitEvent(stream, ss->join, 0));
@@ -859,7 +927,7 @@ extern "C" int fr_focf_predict(const fr_table* U, const fr_table* I, const fr_ad
     const unsigned blocks = (unsigned)((B * WAVE + GATHER_THREADS - 1) / GATHER_THREADS);
     {
         ProfScope prof(K_FOCF_GATHER, stream);
-        FR_DISPATCH_E(U->dim, FR_LAUNCH(prof, (focf_gather_kernel<E, false>), dim3(blocks), dim3(GATHER_THREADS), 0, stream, Uv, Iv, c, user, item, (const float*)nullptr, (int)B, U->step,
+        FR_DISPATCH_E(U->dim, FR_LAUNCH(prof, (focf_gather_kernel<E, false, false>), dim3(blocks), dim3(GATHER_THREADS), 0, stream, Uv, Iv, c, user, item, (const float*)nullptr, (int)B, U->step,
                                                   I->step, w, max_rating, out, err_flag));
     }
     FR_CHECK_LAUNCH();

@@ -71,6 +71,9 @@ class FocfEngine:
         # FR_FOCF_DEFER_LOSS: the loss slot is filled by backward_adam() instead of forward().  Only for step loops that
         # read the loss after optimizer.step() (fairrec's Trainer fast path, bench.py).
         self.defer_loss = False
+        # FR_FOCF_ITEM_RUNS (a hint, same results either way): the batches are item-complete (FOCFDataLoader), the
+        # interactions of an item sit side by side -- the gather kernel then replays an item row once per workgroup
+        self.item_runs = False
 
     # --- optimizer plumbing ---------------------------------------------------------------------------
     def tables(self) -> Dict[str, LazyTable]:
@@ -155,6 +158,8 @@ class FocfEngine:
             flags = 1                                            # FR_FOCF_PREPARED
         if self.defer_loss and self.optimizer is not None:
             flags |= 2                                           # FR_FOCF_DEFER_LOSS
+        if self.item_runs:
+            flags |= 4                                           # FR_FOCF_ITEM_RUNS
         ws = self._workspace(B, self.ws_cur)
         coming = []
         if next_batch is not None:

@@ -110,6 +110,7 @@ class Trainer(AbstractTrainer):
         if fused:
             eng = self.model.hip_engine()
             eng.defer_loss = True        # the loop below reads the loss only after optimizer.step()
+            eng.item_runs = type(train_data).__name__ == 'FOCFDataLoader'     # item-complete batches
             try:
                 return self._train_epoch_body(train_data, loss_func, hint, graphed, fused, total, n_tuple)
             finally:

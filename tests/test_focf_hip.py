@@ -136,6 +136,7 @@ def test_lookahead_sweep_equals_plain_chain(objective, dim, item_dist):
         eng = FocfEngine(U0.clone(), I0.clone(), objective, 0.5, 5.0)
         FusedLazyAdam(eng, lr=1e-2, weight_decay=1e-3, sweep_period=4)
         eng.defer_loss = ahead == 6      # loss reduced by the backward launch (read after backward_adam below)
+        eng.item_runs = ahead == 1       # item row replayed once per workgroup of the gather kernel (a hint only)
         engs.append(eng)
     for t in range(T):
         out = []
