@@ -39,7 +39,8 @@ struct FocfWs {
 
 static constexpr int GATHER_THREADS = 256;  // 4 waves = 4 interactions per block
 static constexpr int FAIR_THREADS = 1024;   // 16 lanes per item segment -> 64 segments per block (few blocks: cheap ticket)
-static constexpr int FAIR_GROUP = 16;
+static constexpr int FAIR_GROUP = 16;        // lanes per item segment ...
+static constexpr int FAIR_GROUP_RUNS = 64;   // ... and in item-complete batches (few items, ~100 members each)
 
 static FocfWs focf_layout(void* base, int64_t B, int D) {
     FocfWs w;
@@ -68,7 +69,7 @@ static FocfWs focf_layout(void* base, int64_t B, int D) {
     if (w.n_gather_blocks < 1) w.n_gather_blocks = 1;
     if (w.n_fair_blocks < 1) w.n_fair_blocks = 1;
     w.mse_part = (float*)take((size_t)w.n_gather_blocks * 4);
-    w.fair_part = (float*)take((size_t)w.n_fair_blocks * 4);
+    w.fair_part = (float*)take((size_t)w.n_fair_blocks * (FAIR_GROUP_RUNS / FAIR_GROUP) * 4);   // room for either group size
     w.ticket = (unsigned int*)take(4);
     for (int k = 0; k < 6; ++k) w.side[k] = (float*)take((size_t)B * D * 4);
     w.bytes = off;
@@ -309,6 +310,7 @@ struct FairArgs {
     int tail_count, tail_stride;
 };
 
+template <int FAIR_GROUP>
 __global__ __launch_bounds__(FAIR_THREADS) void focf_fair_kernel(FairArgs w, int objective, float fair_weight,
                                                                  int defer_k, uint32_t* err) {
     const int sub = threadIdx.x & (FAIR_GROUP - 1);
@@ -468,11 +470,11 @@ __global__ __launch_bounds__(1024) void focf_nonparity_kernel(FocfWs w, const fl
 
 // fixed-order reduction of the partial sums of one batch -> loss (one block of 256 threads)
 __device__ __forceinline__ void focf_finalize_block(const FocfWs& w, int B, int objective, float fair_weight,
-                                                    float* __restrict__ loss_out) {
+                                                    float* __restrict__ loss_out, int n_fair_part) {
     __shared__ float red[2][4];
     float a = 0.f, f = 0.f;
     for (int q = threadIdx.x; q < w.n_gather_blocks; q += 256) a += w.mse_part[q];
-    int nf = objective == FR_FOCF_NONE ? 0 : (objective == FR_FOCF_NONPARITY ? 1 : w.n_fair_blocks);
+    int nf = objective == FR_FOCF_NONE ? 0 : (objective == FR_FOCF_NONPARITY ? 1 : n_fair_part);
     for (int q = threadIdx.x; q < nf; q += 256) f += w.fair_part[q];
     a = wave_sum(a);
     f = wave_sum(f);
@@ -493,7 +495,7 @@ __device__ __forceinline__ void focf_finalize_block(const FocfWs& w, int B, int 
 
 __global__ __launch_bounds__(256) void focf_finalize_kernel(FocfWs w, int B, int objective, float fair_weight,
                                                             float* __restrict__ loss_out) {
-    focf_finalize_block(w, B, objective, fair_weight, loss_out);
+    focf_finalize_block(w, B, objective, fair_weight, loss_out, w.n_fair_blocks);
 }
 
 // FR_FOCF_DEFER_LOSS: the loss of the batch is reduced by one extra workgroup of the backward launch instead of inside
@@ -502,6 +504,7 @@ struct DeferLoss {
     float* loss_out;   // nullptr = nothing deferred
     int objective;
     float fair_weight;
+    int n_fair_part;   // workgroups of the fairness launch that wrote a partial sum
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -513,7 +516,7 @@ template <int E>
 __global__ __launch_bounds__(256) void focf_backward_adam_kernel(TableV U, TableV I, AdamC c, int B, FocfWs w,
                                                                  SweepSlice sw, int n_sweep_waves, DeferLoss dl) {
     if (dl.loss_out && blockIdx.x == 0) {   // the extra workgroup, first so that it overlaps with everything else
-        focf_finalize_block(w, B, dl.objective, dl.fair_weight, dl.loss_out);
+        focf_finalize_block(w, B, dl.objective, dl.fair_weight, dl.loss_out, dl.n_fair_part);
         return;
     }
     const int lane = threadIdx.x & 63;
@@ -523,16 +526,18 @@ __global__ __launch_bounds__(256) void focf_backward_adam_kernel(TableV U, Table
         return;
     }
     wv -= n_sweep_waves;
+    // item rows before user rows: an item has more members in the batch than a user (~100 in item-complete batches),
+    // so its wave sums more rows -- longest jobs first
     if (wv < B) {
-        if (wv < w.nseg_u[0])
-            segment_update<E>(U, c, (int)wv, w.seg_start_u, w.seg_row_u, w.perm_u, w.coef, w.side[0], w.side[1],
-                              w.side[2], w.side[3], lane, Lay{0, 0}, w.seg_first_u);
+        if (wv < w.nseg_i[0])
+            segment_update<E>(I, c, (int)wv, w.seg_start_i, w.seg_row_i, w.perm_i, w.coef, w.side[3], w.side[4],
+                              w.side[5], w.side[0], lane, Lay{0, 0}, w.seg_first_i);
         return;
     }
     wv -= B;
-    if (wv < B && wv < w.nseg_i[0])
-        segment_update<E>(I, c, (int)wv, w.seg_start_i, w.seg_row_i, w.perm_i, w.coef, w.side[3], w.side[4],
-                          w.side[5], w.side[0], lane, Lay{0, 0}, w.seg_first_i);
+    if (wv < B && wv < w.nseg_u[0])
+        segment_update<E>(U, c, (int)wv, w.seg_start_u, w.seg_row_u, w.perm_u, w.coef, w.side[0], w.side[1],
+                          w.side[2], w.side[3], lane, Lay{0, 0}, w.seg_first_u);
 }
 
 
@@ -755,7 +760,7 @@ static DeferLoss defer_take(const void* ws) {
             g_defer_ws[q] = nullptr;
             return g_defer[q];
         }
-    return DeferLoss{nullptr, 0, 0.f};
+    return DeferLoss{nullptr, 0, 0.f, 0};
 }
 
 static SweepSlice make_sweep_slice(const fr_table* U, const fr_table* I, int32_t sweep_period) {
@@ -843,6 +848,7 @@ extern "C" int fr_focf_forward(const fr_table* U, const fr_table* I, const fr_ad
     const TableV Uv = view(U), Iv = view(I);
     const bool defer = (flags & FR_FOCF_DEFER_LOSS) != 0;
     defer_forget(ws);
+    int n_fair_part = w.n_fair_blocks;
     {
         ProfScope prof(K_FOCF_GATHER, stream);
         if (flags & FR_FOCF_ITEM_RUNS) {
@@ -865,13 +871,19 @@ extern "C" int fr_focf_forward(const fr_table* U, const fr_table* I, const fr_ad
             ProfScope prof(K_FOCF_FAIR, stream);
             FairArgs fa{w.perm_i, w.seg_start_i, w.nseg_i, w.seg_first_i, w.sst_minmax, 1, 0, w.pred, rating, sst, Lay{0, 0}, w.coef, Lay{0, 0}, w.fair_part, 1,
                         defer ? nullptr : w.ticket, w.mse_part, w.n_gather_blocks, (int)B, loss_out};
-            FR_LAUNCH(prof, focf_fair_kernel, dim3(w.n_fair_blocks), dim3(FAIR_THREADS), 0, stream, fa, objective,
-                               fair_weight, 0, err_flag);
+            if (flags & FR_FOCF_ITEM_RUNS) {   // few items with many members each: a whole wave per item segment
+                n_fair_part = w.n_fair_blocks * (FAIR_GROUP_RUNS / FAIR_GROUP);
+                FR_LAUNCH(prof, focf_fair_kernel<FAIR_GROUP_RUNS>, dim3(n_fair_part), dim3(FAIR_THREADS), 0, stream, fa,
+                                   objective, fair_weight, 0, err_flag);
+            } else {
+                FR_LAUNCH(prof, focf_fair_kernel<FAIR_GROUP>, dim3(w.n_fair_blocks), dim3(FAIR_THREADS), 0, stream, fa,
+                                   objective, fair_weight, 0, err_flag);
+            }
         }
         FR_CHECK_LAUNCH();
     }
     if (defer) {
-        defer_put(ws, DeferLoss{loss_out, (int)objective, fair_weight});
+        defer_put(ws, DeferLoss{loss_out, (int)objective, fair_weight, n_fair_part});
     } else if (objective == FR_FOCF_NONE || objective == FR_FOCF_NONPARITY) {
         ProfScope prof(K_FOCF_FINALIZE, stream);
         FR_LAUNCH(prof, focf_finalize_kernel, dim3(1), dim3(256), 0, stream, w, (int)B, objective, fair_weight,
@@ -985,8 +997,8 @@ extern "C" int fr_focf_shard_fair(void* item_ws, size_t ws_bytes, int64_t n_slot
                     Lay{cap, 3 * cap}, reply, Lay{cap, cap + FR_SHARD_TAIL}, scratch + 16, 0,
                     reinterpret_cast<unsigned int*>(scratch), sq_part, (int)n_sq_part, 0, nullptr,
                     reply + cap, (int)(n_slots / cap), cap + FR_SHARD_TAIL};
-        FR_LAUNCH(prof, focf_fair_kernel, dim3(blocks), dim3(FAIR_THREADS), 0, stream, fa, objective, fair_weight, 1,
-                           err_flag);
+        FR_LAUNCH(prof, focf_fair_kernel<FAIR_GROUP>, dim3(blocks), dim3(FAIR_THREADS), 0, stream, fa, objective,
+                           fair_weight, 1, err_flag);
     }
     FR_CHECK_LAUNCH();
     return FR_OK;
