@@ -64,6 +64,8 @@ class FocfEngine:
         self._side = None               # stream of the look-ahead sorts
         self._prep = {}                 # batch key -> (ws index, launch group) of the batches prepared ahead
         self.loss_ring = torch.zeros((self.LOSS_SLOTS, 4), dtype=torch.float32, device=self.device)
+        self._loss_views = [self.loss_ring[k] for k in range(self.LOSS_SLOTS)]
+        self._ws_need = {}
         self.loss_slot = 0
         self.err_flag = torch.zeros(1, dtype=torch.int32, device=self.device)
         self.pending_B = 0
@@ -93,7 +95,9 @@ class FocfEngine:
         return max(8, math.ceil(max(self.U.n_rows, self.I.n_rows) / max(B, 1)))
 
     def _workspace(self, B: int, k: int):
-        need = _C.lib().fr_focf_workspace_bytes(B, self.U.dim)
+        need = self._ws_need.get(B)
+        if need is None:
+            need = self._ws_need[B] = _C.lib().fr_focf_workspace_bytes(B, self.U.dim)
         if self.ws[k] is None or self.ws[k].numel() < need:
             self.ws[k] = torch.empty(need, dtype=torch.uint8, device=self.device)
         return self.ws[k]
@@ -164,7 +168,9 @@ class FocfEngine:
         coming = []
         if next_batch is not None:
             coming = [next_batch] if isinstance(next_batch[0], torch.Tensor) else [nb for nb in next_batch if nb is not None]
-        if self._prep:      # prepared batches that are not announced any more: forget them (their buffers may be reused)
+        if self._prep and (hit is None or len(self._prep) > len(coming)):
+            # prepared batches that are not announced any more (a loop that was cut short): forget them, their buffers
+            # may be reused.  Checked only when something looks off -- a miss, or more prepared than announced.
             alive = {self._key(nb[0], nb[1]) for nb in coming}
             for k in [k for k in self._prep if k not in alive]:
                 torch.cuda.current_stream().wait_event(self._prep.pop(k)[1]["done"])
@@ -173,7 +179,7 @@ class FocfEngine:
             if todo:
                 self.prepare_many(todo[:self.GROUP])
         self.loss_slot = (self.loss_slot + 1) % self.LOSS_SLOTS
-        loss = self.loss_ring[self.loss_slot]
+        loss = self._loss_views[self.loss_slot]
         pred = torch.empty(B, dtype=torch.float32, device=self.device) if want_pred else None
         tu, ti = self.U.c(self.U.step + 1), self.I.c(self.I.step + 1)
         self.hyper.check_step(self.U.step + 1)
