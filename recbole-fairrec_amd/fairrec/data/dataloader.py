@@ -107,7 +107,7 @@ class FOCFDataLoader(AbstractDataLoader):
         super().__init__(config, dataset, shuffle=False)
         self.ITEM_ID = config['ITEM_ID_FIELD']
         self.dataset.sort(by=self.ITEM_ID)                      # focf_dataloader.py:11
-        items = self.dataset.inter_feat[self.ITEM_ID].numpy()
+        items = self.dataset.inter_feat[self.ITEM_ID].cpu().numpy()      # the batch composition stays host logic
         self.item_num = self.dataset.item_num
         self.item_uniques = np.unique(items)
         # CSR by item over the item-sorted interaction array

@@ -31,8 +31,11 @@ def run_recbole(model=None, dataset=None, config_file_list=None, config_dict=Non
         dataset = synthetic_dataset(config, config['synthetic_users'] or 1000, config['synthetic_items'] or 500,
                                     config['synthetic_interactions'] or 50000, seed=config['seed'])
     train_set, valid_set, test_set = split_dataset(dataset)
+    on_gpu = config['device'].type == 'cuda'
     if config['model'] == 'FOCF' and config['item_grouped_batches']:
-        train_data = FOCFDataLoader(config, train_set, shuffle=True)
+        # the interaction columns live on the device (a host-resident dataset costs a copy per batch: 4.3 ms per step
+        # instead of 0.07 at B = 8192); which interactions form a batch stays the reference's host logic
+        train_data = FOCFDataLoader(config, train_set.to(config['device']) if on_gpu else train_set, shuffle=True)
     elif (config['train_neg_sample_args'] or {}).get('strategy') == 'by' and config['device'].type == 'cuda':
         # negatives are drawn on the device, bit-identical to the reference's host sampler (fairrec/sampler); the
         # interaction columns stay resident on the GPU
@@ -41,7 +44,7 @@ def run_recbole(model=None, dataset=None, config_file_list=None, config_dict=Non
                           config['train_neg_sample_args']['distribution'], device=config['device']).set_phase('train')
         train_data = TrainDataLoader(config, train_set.to(config['device']), sampler=sampler, shuffle=True)
     else:
-        train_data = TrainDataLoader(config, train_set, shuffle=True)
+        train_data = TrainDataLoader(config, train_set.to(config['device']) if on_gpu else train_set, shuffle=True)
     eval_mode = (config['eval_args'] or {}).get('mode') or ''
     if (eval_mode == 'full' or eval_mode[:3] == 'uni') and config['device'].type == 'cuda':
         # ranking evaluation on the device: top-k and fairness metrics of config['metrics'] (fairrec/evaluator); `uniN`
