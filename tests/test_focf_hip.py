@@ -158,6 +158,45 @@ def test_lookahead_sweep_equals_plain_chain(objective, dim, item_dist):
             torch.testing.assert_close(x, y, rtol=5e-5, atol=1e-7 * float(y.abs().max()) + 1e-12)
 
 
+def test_full_size_steps_match_the_oracle():
+    """BASELINE.json configs[1] at its real size (1 000 001 users x 100 001 items, D = 64, B = 8192, Adam lr 1e-3 wd 1e-3,
+    fair_objective value): a few optimizer steps of the HIP path -- look-ahead sorts, sweeper, lazy replay -- against the
+    oracle's dense step (the reference's arithmetic: autograd gradient + stock torch.optim.Adam over both whole tables).
+    Every row of both tables is compared after a flush, so rows that were never in a batch (pure weight-decay replay)
+    are checked too."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+    from oracle.focf import CpuTrainerBaseline
+    from fairrec.model.fair_recommender.focf import FocfEngine
+    from fairrec.optim import FusedLazyAdam
+    n_users, n_items, D, B, T = 1_000_001, 100_001, 64, 8192, 5
+    ref = CpuTrainerBaseline(n_users, n_items, D, 1e-3, 1e-3, 0.5, "value", seed=7, threads=8)
+    eng = FocfEngine(ref.U.detach().clone().cuda(), ref.I.detach().clone().cuda(), "value", 0.5, 5.0)
+    FusedLazyAdam(eng, lr=1e-3, weight_decay=1e-3, sweep_period=3)     # short period: the sweeper visits every row
+    eng.defer_loss = True
+    g = torch.Generator().manual_seed(3)
+    u = torch.randint(1, n_users, (T, B), generator=g)
+    i = torch.randint(1, n_items, (T, B), generator=g)
+    r = torch.randint(1, 6, (T, B), generator=g).float()
+    gender = (torch.rand(n_users, generator=g) < 0.5).float()
+    s = gender[u]
+    ud, idv, rd, sd = u.cuda(), i.cuda(), r.cuda(), s.cuda()
+    for t in range(T):
+        want = ref.step(u[t], i[t], r[t], s[t])
+        coming = [(ud[j], idv[j], sd[j]) for j in range(t + 1, T)] or None
+        loss, _ = eng.forward(ud[t], idv[t], rd[t], sd[t], next_batch=coming)
+        eng.backward_adam()
+        assert abs(float(loss[0]) - want) <= 1e-4 * abs(want), (t, float(loss[0]), want)
+    eng.flush()
+    eng.check_device_errors()
+    _close(eng.U.weight.cpu().numpy(), ref.U.detach().numpy(), "user table after %d steps" % T)
+    _close(eng.I.weight.cpu().numpy(), ref.I.detach().numpy(), "item table after %d steps" % T)
+    st = ref.opt.state[ref.U]
+    _close(eng.U.m.cpu().numpy(), st["exp_avg"].numpy(), "user exp_avg", atol=1e-6 * float(st["exp_avg"].abs().max()))
+    _close(eng.U.v.cpu().numpy(), st["exp_avg_sq"].numpy(), "user exp_avg_sq",
+           atol=1e-6 * float(st["exp_avg_sq"].abs().max()))
+
+
 def test_deferred_loss_with_interleaved_engines():
     """FR_FOCF_DEFER_LOSS: the backward launch reduces the loss of ITS workspace's batch, also when another engine's
     forward ran in between."""
