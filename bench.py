@@ -128,12 +128,12 @@ def main():
         import torch.distributed as dist
 
         # a multi-rank run that stops making progress (a collective that never completes) must not hold the node: report
-        # and leave after FAIRREC_BENCH_DEADLINE seconds (default 15 min; the whole run takes about one)
+        # and leave after FAIRREC_BENCH_DEADLINE seconds (default 10 min; the whole run takes about one)
         def _deadline():
             print(f"[bench] rank {rank}: no result after the deadline, giving up", file=sys.stderr, flush=True)
             os._exit(3)
 
-        t = threading.Timer(float(os.environ.get("FAIRREC_BENCH_DEADLINE", "900")), _deadline)
+        t = threading.Timer(float(os.environ.get("FAIRREC_BENCH_DEADLINE", "600")), _deadline)
         t.daemon = True
         t.start()
         dist.init_process_group("nccl", device_id=dev)
