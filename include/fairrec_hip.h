@@ -162,6 +162,18 @@ FR_API int fr_focf_prepare_many(const fr_focf_batch* batches, int32_t n, int64_t
                          uint32_t* err_flag, void* stream);
 
 /*
+ * torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm, norm_type=2) of the reference's step loop
+ * (trainer.py:194-195, config `clip_grad_norm`), for the batch of the preceding fr_focf_forward on this workspace and
+ * before its fr_focf_backward_adam.  The dense embedding gradients are never materialised: their squared 2-norm is
+ * the sum over the distinct rows of the batch of |sum_b dLoss/dpred[b] * other_row[b]|^2 (one wave per row, fixed
+ * order), `extra_sqnorm` (device float, may be NULL) adds other parameters' share, clip_coef = min(1, max_norm /
+ * (norm + 1e-6)) scales dLoss/dpred in the workspace, i.e. every gradient row the backward launch forms.
+ * `norm_out` (device float[2], may be NULL) receives (total_norm, clip_coef).
+ */
+FR_API int fr_focf_clip_grad_norm(const fr_table* U, const fr_table* I, int64_t B, float max_norm,
+                           const float* extra_sqnorm, float* norm_out, void* ws, size_t ws_bytes, void* stream);
+
+/*
  * loss.backward() + optimizer.step() for the batch of the preceding fr_focf_forward on the same
  * workspace: autograd of focf.py:152-169 (dense embedding gradient) followed by Adam.step()
  * (trainer.py:193-196).  Duplicate rows are summed in batch order before the update, rows not in the

@@ -105,7 +105,7 @@ def adam_dense_step_(p, g, m, v, step: int, lr: float, wd: float, b1=0.9, b2=0.9
 
 
 def train(objective: str, U0, I0, user, item, rating, sst, lr, wd, fair_weight, snaps=(), use_torch_adam=True,
-          b1=0.9, b2=0.999, eps=1e-8) -> Dict[str, np.ndarray]:
+          b1=0.9, b2=0.999, eps=1e-8, clip_max_norm=None) -> Dict[str, np.ndarray]:
     """The reference step loop (trainer.py:183-196) on T recorded batches.
 
     user/item/rating/sst: arrays [T, B].  Returns loss per step, dense grads of step 1 and snapshots
@@ -116,7 +116,7 @@ def train(objective: str, U0, I0, user, item, rating, sst, lr, wd, fair_weight, 
     opt = torch.optim.Adam([U, I], lr=lr, weight_decay=wd, betas=(b1, b2), eps=eps) if use_torch_adam else None
     mom = {id(t): (torch.zeros_like(t), torch.zeros_like(t)) for t in (U, I)}
     out: Dict[str, np.ndarray] = {}
-    losses = []
+    losses, norms = [], []
     T = len(user)
     for t in range(T):
         u = torch.as_tensor(np.asarray(user[t]), dtype=torch.int64)
@@ -132,6 +132,8 @@ def train(objective: str, U0, I0, user, item, rating, sst, lr, wd, fair_weight, 
             out["pred_step1"] = pred.detach().numpy().copy()
             out["gradU_step1"] = U.grad.numpy().copy()
             out["gradI_step1"] = I.grad.numpy().copy()
+        if clip_max_norm:      # config `clip_grad_norm` (trainer.py:194-195): norm over all parameters, 2-norm
+            norms.append(float(torch.nn.utils.clip_grad_norm_([U, I], clip_max_norm, norm_type=2)))
         if opt is not None:
             opt.step()
         else:
@@ -148,6 +150,7 @@ def train(objective: str, U0, I0, user, item, rating, sst, lr, wd, fair_weight, 
                 out[f"m{tag}_after{t + 1}"] = mm.numpy().copy()
                 out[f"v{tag}_after{t + 1}"] = vv.numpy().copy()
     out["loss"] = np.array(losses, dtype=np.float64)
+    out["grad_norm"] = np.array(norms, dtype=np.float64)
     return out
 
 

@@ -32,6 +32,7 @@ struct FocfWs {
     float* mse_part;     // [gather blocks]
     float* fair_part;    // [fair blocks]
     unsigned int* ticket;  // in-launch finalisation counter of the fair kernel (kept zero between launches)
+    float* clip_part;      // [(2B + 3) / 4] squared-norm partials of fr_focf_clip_grad_norm
     float* side[6];      // ue, mu, vu, ie, mi, vi : [B, D] each
     int n_gather_blocks, n_fair_blocks;
     size_t bytes;
@@ -71,6 +72,7 @@ static FocfWs focf_layout(void* base, int64_t B, int D) {
     w.mse_part = (float*)take((size_t)w.n_gather_blocks * 4);
     w.fair_part = (float*)take((size_t)w.n_fair_blocks * (FAIR_GROUP_RUNS / FAIR_GROUP) * 4);   // room for either group size
     w.ticket = (unsigned int*)take(4);
+    w.clip_part = (float*)take(((2 * (size_t)B + 3) / 4) * 4);
     for (int k = 0; k < 6; ++k) w.side[k] = (float*)take((size_t)B * D * 4);
     w.bytes = off;
     return w;
@@ -510,6 +512,72 @@ struct DeferLoss {
 // ------------------------------------------------------------------------------------------------
 // backward + Adam: one wave per distinct row, plus sweeper waves
 // ------------------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------------
+// clip_grad_norm_ (trainer.py:194-195) on gradients that are never materialised
+// ------------------------------------------------------------------------------------------------
+// squared 2-norm of the dense embedding gradient = sum over the distinct rows of the batch of |sum_b coef_b * other_b|^2:
+// one wave per distinct row (users, then items), one partial per workgroup
+template <int E>
+__global__ __launch_bounds__(256) void focf_grad_sqnorm_kernel(int B, int D, FocfWs w) {
+    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
+    long long wv = (long long)blockIdx.x * 4 + wib;
+    __shared__ float red[4];
+    float sq = 0.f;
+    const bool users = wv < B;
+    if (!users) wv -= B;
+    const int32_t* seg_start = users ? w.seg_start_u : w.seg_start_i;
+    const int32_t* perm = users ? w.perm_u : w.perm_i;
+    const int32_t* seg_first = users ? w.seg_first_u : w.seg_first_i;
+    const int nseg = users ? w.nseg_u[0] : w.nseg_i[0];
+    if (wv < B && wv < nseg) {
+        const int rj0 = seg_start[wv], rj1 = seg_start[wv + 1], rb0 = seg_first[wv];
+        const int j0 = uniform(rj0), j1 = uniform(rj1), b0 = uniform(rb0);
+        RowFrag<E> g;
+#pragma unroll
+        for (int e = 0; e < E; ++e) g.x[e] = 0.f;
+        segment_grad_sum<E>(g, j0, j1, b0, perm, w.coef, users ? w.side[3] : w.side[0], D, lane, Lay{0, 0});
+#pragma unroll
+        for (int e = 0; e < E; ++e) sq = fmaf(g.x[e], g.x[e], sq);
+        sq = wave_sum(sq);
+    }
+    if (lane == 0) red[wib] = sq;
+    __syncthreads();
+    if (threadIdx.x == 0) w.clip_part[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
+}
+
+// one workgroup: total norm (fixed-order sum of the partials + the other parameters' share), the clip coefficient
+// min(1, max_norm / (norm + 1e-6)) of torch.nn.utils.clip_grad_norm_, and dLoss/dpred scaled by it -- which scales every
+// gradient row the backward kernel will form
+__global__ __launch_bounds__(1024) void focf_clip_scale_kernel(int B, FocfWs w, int n_part, float max_norm,
+                                                               const float* __restrict__ extra_sqnorm,
+                                                               float* __restrict__ norm_out) {
+    __shared__ float red[16];
+    __shared__ float coef_s;
+    float a = 0.f;
+    for (int q = threadIdx.x; q < n_part; q += 1024) a += w.clip_part[q];
+    a = wave_sum(a);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t += red[q];
+        if (extra_sqnorm) t += extra_sqnorm[0];
+        const float norm = sqrtf(t);
+        float cc = max_norm / (norm + 1e-6f);
+        cc = cc < 1.f ? cc : 1.f;
+        coef_s = cc;
+        if (norm_out) {
+            norm_out[0] = norm;
+            norm_out[1] = cc;
+        }
+    }
+    __syncthreads();
+    const float cc = coef_s;
+    if (cc < 1.f)
+        for (int b = threadIdx.x; b < B; b += 1024) w.coef[b] *= cc;
+}
+
 // waves [0, sweep waves): the sweep slice when no earlier launch of the step carried it (longest jobs first: up to S
 // replayed steps per row, the segment waves exactly one); then one wave per distinct user row, per distinct item row
 template <int E>
@@ -891,6 +959,26 @@ extern "C" int fr_focf_forward(const fr_table* U, const fr_table* I, const fr_ad
         FR_CHECK_LAUNCH();
     }
     if (pred_out) FR_CHECK_HIP(hipMemcpyAsync(pred_out, w.pred, (size_t)B * 4, hipMemcpyDeviceToDevice, stream));
+    return FR_OK;
+}
+
+extern "C" int fr_focf_clip_grad_norm(const fr_table* U, const fr_table* I, int64_t B, float max_norm,
+                                      const float* extra_sqnorm, float* norm_out, void* ws, size_t ws_bytes,
+                                      void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    int rc;
+    if ((rc = check_table(U, "fr_focf_clip_grad_norm(U)")) || (rc = check_table(I, "fr_focf_clip_grad_norm(I)")))
+        return rc;
+    FR_CHECK_ARG(U->dim == I->dim && ws && B >= 1 && B <= FR_SORT_MAX && max_norm > 0.f,
+                 "fr_focf_clip_grad_norm: bad argument");
+    FocfWs w = focf_layout(ws, B, U->dim);
+    FR_CHECK_ARG(ws_bytes >= w.bytes, "fr_focf_clip_grad_norm: workspace %zu < %zu bytes", ws_bytes, w.bytes);
+    const unsigned blocks = (unsigned)((2 * B + 3) / 4);
+    FR_DISPATCH_E(U->dim, hipLaunchKernelGGL((focf_grad_sqnorm_kernel<E>), dim3(blocks), dim3(256), 0, stream, (int)B, (int)U->dim, w));
+    FR_CHECK_LAUNCH();
+    hipLaunchKernelGGL(focf_clip_scale_kernel, dim3(1), dim3(1024), 0, stream, (int)B, w, (int)blocks, max_norm,
+                       extra_sqnorm, norm_out);
+    FR_CHECK_LAUNCH();
     return FR_OK;
 }
 

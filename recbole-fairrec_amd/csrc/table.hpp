@@ -5,28 +5,13 @@
 
 namespace fr {
 
-// One distinct row of a batch: sum the contributions of its members in ascending batch position, apply the
-// Adam step `T.step` to the caught-up state parked in the workspace, write the row back once.
+// Gradient row of one distinct row of a batch: sum of the contributions of its members [j0, j1) of the sorted list in
+// ascending batch position (the reference's accumulation order); b0 = perm[j0] is known already.
 //   coef != nullptr : contribution of member b = coef[b] * other[b,:]   (rank-1 form: MF models)
 //   coef == nullptr : contribution of member b = other[b,:]             (gradient rows from an MLP backward)
 template <int E>
-__device__ __forceinline__ void segment_update(const TableV& T, const AdamC& c, int k, const int32_t* seg_start,
-                                               const int32_t* seg_row, const int32_t* perm, const float* coef,
-                                               const float* sp, const float* sm, const float* sv, const float* other,
-                                               int lane, Lay lay = Lay{0, 0},   // lay: layout of sp and other
-                                               const int32_t* seg_first = nullptr) {
-    const int D = T.D;
-    // first level of loads: everything that depends on k only (a wave-uniform value costs a memory round trip when it
-    // is consumed; seg_first saves the perm[j0] trip of the first -- usually the only -- member)
-    const int rj0 = seg_start[k], rj1 = seg_start[k + 1], rrow = seg_row[k];
-    const int rb0 = seg_first ? seg_first[k] : 0;
-    const int j0 = uniform(rj0), j1 = uniform(rj1);
-    const int row = uniform(rrow);
-    const int b0 = seg_first ? uniform(rb0) : uniform(perm[j0]);
-    RowFrag<E> p, m, v, g;
-    load_row<E>(p, sp + (size_t)lay.at(b0) * D, D, lane);
-    load_row<E>(m, sm + (size_t)b0 * D, D, lane);
-    load_row<E>(v, sv + (size_t)b0 * D, D, lane);
+__device__ __forceinline__ void segment_grad_sum(RowFrag<E>& g, int j0, int j1, int b0, const int32_t* perm,
+                                                 const float* coef, const float* other, int D, int lane, Lay lay) {
 #pragma unroll
     for (int e = 0; e < E; ++e) g.x[e] = 0.f;
     // Members in ascending batch position (the reference's accumulation order).  A hot row can have hundreds of
@@ -95,6 +80,31 @@ __device__ __forceinline__ void segment_update(const TableV& T, const AdamC& c, 
             }
         }
     }
+}
+
+// One distinct row of a batch: sum the contributions of its members in ascending batch position, apply the
+// Adam step `T.step` to the caught-up state parked in the workspace, write the row back once.
+//   coef != nullptr : contribution of member b = coef[b] * other[b,:]   (rank-1 form: MF models)
+//   coef == nullptr : contribution of member b = other[b,:]             (gradient rows from an MLP backward)
+template <int E>
+__device__ __forceinline__ void segment_update(const TableV& T, const AdamC& c, int k, const int32_t* seg_start,
+                                               const int32_t* seg_row, const int32_t* perm, const float* coef,
+                                               const float* sp, const float* sm, const float* sv, const float* other,
+                                               int lane, Lay lay = Lay{0, 0},   // lay: layout of sp and other
+                                               const int32_t* seg_first = nullptr) {
+    const int D = T.D;
+    // first level of loads: everything that depends on k only (a wave-uniform value costs a memory round trip when it
+    // is consumed; seg_first saves the perm[j0] trip of the first -- usually the only -- member)
+    const int rj0 = seg_start[k], rj1 = seg_start[k + 1], rrow = seg_row[k];
+    const int rb0 = seg_first ? seg_first[k] : 0;
+    const int j0 = uniform(rj0), j1 = uniform(rj1);
+    const int row = uniform(rrow);
+    const int b0 = seg_first ? uniform(rb0) : uniform(perm[j0]);
+    RowFrag<E> p, m, v, g;
+    load_row<E>(p, sp + (size_t)lay.at(b0) * D, D, lane);
+    load_row<E>(m, sm + (size_t)b0 * D, D, lane);
+    load_row<E>(v, sv + (size_t)b0 * D, D, lane);
+    segment_grad_sum<E>(g, j0, j1, b0, perm, coef, other, D, lane, lay);
     const float2 s = step_scalars(c, T.step);
 #pragma unroll
     for (int e = 0; e < E; ++e) adam_elem(p.x[e], m.x[e], v.x[e], g.x[e], s.x, s.y, c);

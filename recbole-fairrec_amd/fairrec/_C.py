@@ -56,6 +56,8 @@ _PROTOS = {
     "fr_focf_prepare": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int32, c_void_p, c_size_t,
                                 c_void_p, c_void_p]),
     "fr_focf_prepare_many": (c_int, [POINTER(FrFocfBatch), c_int32, c_int64, c_int64, c_int32, c_void_p, c_void_p]),
+    "fr_focf_clip_grad_norm": (c_int, [POINTER(FrTable), POINTER(FrTable), c_int64, c_float, c_void_p, c_void_p,
+                                       c_void_p, c_size_t, c_void_p]),
     "fr_focf_backward_adam": (c_int, [POINTER(FrTable), POINTER(FrTable), POINTER(FrAdam), c_int64, c_int32,
                                       c_void_p, c_size_t, c_void_p]),
     "fr_focf_predict": (c_int, [POINTER(FrTable), POINTER(FrTable), POINTER(FrAdam), c_void_p, c_void_p, c_int64,

@@ -191,6 +191,20 @@ class FocfEngine:
         self.pending_B = B
         return loss, pred
 
+    def clip_grad_norm(self, max_norm: float):
+        """torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm) on the pending batch's (never materialised)
+        embedding gradients (fr_focf_clip_grad_norm); returns the device pair (total_norm, clip_coef)."""
+        if self.pending_B == 0:
+            raise _C.FairrecError("clip_grad_norm without a preceding calculate_loss()")
+        if not hasattr(self, "_clip_out"):
+            self._clip_out = torch.zeros(2, dtype=torch.float32, device=self.device)
+        tu, ti = self.U.c(self.U.step + 1), self.I.c(self.I.step + 1)
+        ws = self.ws[self.ws_cur]
+        rc = _C.lib().fr_focf_clip_grad_norm(ctypes.byref(tu), ctypes.byref(ti), self.pending_B, float(max_norm), None,
+                                             self._clip_out.data_ptr(), ws.data_ptr(), ws.numel(), _C.current_stream())
+        _C.check(rc, "fr_focf_clip_grad_norm")
+        return self._clip_out
+
     def backward_adam(self):
         """loss.backward() + optimizer.step() of the pending batch (fr_focf_backward_adam)."""
         if self.pending_B == 0:

@@ -299,9 +299,18 @@ class FusedLazyAdam:
     engine's tensors (PFCN's optimizer_filter / optimizer_dis, trainer.py:1201-1212).
     """
 
-    def __init__(self, engine, lr=1e-3, weight_decay=0.0, betas=(0.9, 0.999), eps=1e-8, sweep_period=None, group=None):
+    def __init__(self, engine, lr=1e-3, weight_decay=0.0, betas=(0.9, 0.999), eps=1e-8, sweep_period=None, group=None,
+                 clip_grad_norm=None):
         self.engine = engine
         self.group = group
+        # config `clip_grad_norm` = kwargs of torch.nn.utils.clip_grad_norm_, which the reference's loop calls between
+        # backward() and step() (trainer.py:194-195); the gradient only exists inside step() here, so it is clipped there
+        self.clip = dict(clip_grad_norm) if clip_grad_norm else None
+        if self.clip:
+            if not hasattr(engine, "clip_grad_norm"):
+                raise NotImplementedError("clip_grad_norm: this model's engine has no global-gradient-norm pass yet")
+            if float(self.clip.get("norm_type", 2)) != 2.0:
+                raise NotImplementedError("clip_grad_norm: only norm_type 2 is on the device path")
         self.hyper = AdamHyper(lr, weight_decay, betas, eps, device=engine.device)
         self.defaults = dict(lr=lr, weight_decay=weight_decay, betas=betas, eps=eps)
         if group is None:
@@ -316,6 +325,8 @@ class FusedLazyAdam:
     def step(self, closure=None):
         if closure is not None:
             raise NotImplementedError("closure-based step is not supported by the fused path")
+        if self.clip:
+            self.engine.clip_grad_norm(float(self.clip["max_norm"]))
         if self.group is not None:
             self.engine.backward_adam(self.group)
         else:

@@ -76,10 +76,8 @@ class Trainer(AbstractTrainer):
             raise NotImplementedError(f'{type(self.model).__name__} exposes no HIP engine')
         if learner.lower() != 'adam':
             raise NotImplementedError(f"learner '{learner}' is not on the MI355X hot path yet (adam only)")
-        if self.clip_grad_norm:
-            raise NotImplementedError('clip_grad_norm needs a global gradient norm before the fused update; not supported yet')
         return FusedLazyAdam(engine, lr=learning_rate, weight_decay=weight_decay,
-                             sweep_period=self.config['lazy_adam_sweep_period'])
+                             sweep_period=self.config['lazy_adam_sweep_period'], clip_grad_norm=self.clip_grad_norm)
 
     # --- training -----------------------------------------------------------------------------------------
     def _graphed_step(self, key, loss_fn):

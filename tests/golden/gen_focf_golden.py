@@ -67,7 +67,7 @@ def make_batches(rng, T, B, n_users, n_items, mode):
             np.stack(rs), np.stack(ss))
 
 
-def run_case(name, objective, n_users, n_items, D, B, T, snaps, lr, wd, fair_weight, seed, mode="uniform"):
+def run_case(name, objective, n_users, n_items, D, B, T, snaps, lr, wd, fair_weight, seed, mode="uniform", clip=None):
     torch.manual_seed(seed)
     rng = np.random.default_rng(seed)
     cfg = _Cfg(USER_ID_FIELD="user_id", ITEM_ID_FIELD="item_id", NEG_PREFIX="neg_", device=torch.device("cpu"),
@@ -82,7 +82,7 @@ def run_case(name, objective, n_users, n_items, D, B, T, snaps, lr, wd, fair_wei
     out["hyper"] = np.array([lr, wd, fair_weight, 0.9, 0.999, 1e-8, 5.0], dtype=np.float64)
     out["objective"] = np.array(objective)
     opt = torch.optim.Adam(model.parameters(), lr=lr, weight_decay=wd)  # trainer.py:139
-    losses = []
+    losses, norms = [], []
     for t in range(T):
         inter = Interaction({"user_id": torch.from_numpy(u[t]), "item_id": torch.from_numpy(i[t]),
                              "rating": torch.from_numpy(r[t]), "gender": torch.from_numpy(s[t])})
@@ -94,6 +94,9 @@ def run_case(name, objective, n_users, n_items, D, B, T, snaps, lr, wd, fair_wei
             out["pred_step1"] = model.forward(inter["user_id"], inter["item_id"])[0].detach().numpy().copy()
             out["gradU_step1"] = model.user_embedding_layer.weight.grad.numpy().copy()
             out["gradI_step1"] = model.item_embedding_layer.weight.grad.numpy().copy()
+        if clip:      # config `clip_grad_norm`, trainer.py:194-195
+            from torch.nn.utils.clip_grad import clip_grad_norm_
+            norms.append(float(clip_grad_norm_(model.parameters(), **clip)))
         opt.step()
         if (t + 1) in snaps:
             for tag, p in (("U", model.user_embedding_layer.weight), ("I", model.item_embedding_layer.weight)):
@@ -102,6 +105,9 @@ def run_case(name, objective, n_users, n_items, D, B, T, snaps, lr, wd, fair_wei
                 out[f"m{tag}_after{t + 1}"] = st["exp_avg"].numpy().copy()
                 out[f"v{tag}_after{t + 1}"] = st["exp_avg_sq"].numpy().copy()
     out["loss"] = np.array(losses, dtype=np.float64)
+    if clip:
+        out["clip_max_norm"] = np.array(float(clip["max_norm"]))
+        out["grad_norm"] = np.array(norms, dtype=np.float64)      # what clip_grad_norm_ returned: the norm BEFORE clipping
     out["snaps"] = np.array(sorted(snaps), dtype=np.int64)
     # predict() on the last batch with the final weights (focf.py:145-150) pins row a6
     with torch.no_grad():
@@ -128,6 +134,11 @@ def main():
              wd=1e-3, fair_weight=0.5, seed=400)
     run_case("none_wd0", "none", n_users=60, n_items=50, D=8, B=16, T=40, snaps=(40,), lr=1e-3, wd=0.0,
              fair_weight=0.0, seed=401)
+    # config clip_grad_norm (trainer.py:194-195): always active (0.05), and active on some steps only (D = 64, grouped)
+    run_case("value_clip", "value", D=8, B=64, T=12, snaps=(1, 12), seed=500, clip=dict(max_norm=0.05, norm_type=2),
+             **common)
+    run_case("grouped_clip", "absolute", D=64, B=100, T=8, snaps=(1, 8), seed=501, mode="grouped",
+             clip=dict(max_norm=1.2, norm_type=2), **common)
 
 
 if __name__ == "__main__":

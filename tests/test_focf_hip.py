@@ -52,6 +52,9 @@ def test_training_matches_reference_golden(path, sweep):
         losses.append(loss.clone())
         if t == 0:
             _close(pred.cpu().numpy(), z["pred_step1"], "pred step 1", atol=1e-6)
+        if "clip_max_norm" in z:      # config clip_grad_norm: the optimizer's step() calls this before the backward launch
+            norm = eng.clip_grad_norm(float(z["clip_max_norm"]))
+            _close(float(norm[0]), z["grad_norm"][t], f"gradient norm step {t + 1}")
         eng.backward_adam()
         if (t + 1) in snaps:
             eng.flush()
@@ -195,6 +198,33 @@ def test_full_size_steps_match_the_oracle():
     _close(eng.U.m.cpu().numpy(), st["exp_avg"].numpy(), "user exp_avg", atol=1e-6 * float(st["exp_avg"].abs().max()))
     _close(eng.U.v.cpu().numpy(), st["exp_avg_sq"].numpy(), "user exp_avg_sq",
            atol=1e-6 * float(st["exp_avg_sq"].abs().max()))
+
+
+def test_optimizer_step_clips_like_the_reference_loop():
+    """config `clip_grad_norm` reaches FusedLazyAdam, whose step() clips before the backward launch -- same numbers as
+    clipping by hand (the golden cases above do that) -- and other norm types / engines without a norm pass are refused."""
+    from fairrec.model.fair_recommender.focf import FocfEngine
+    from fairrec.optim import FusedLazyAdam
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "focf_value_clip.npz"))
+    lr, wd, fw = (float(x) for x in z["hyper"][:3])
+    mn = float(z["clip_max_norm"])
+    engs = []
+    for cfg in (dict(max_norm=mn, norm_type=2), None):
+        eng = FocfEngine(torch.tensor(z["U0"], device="cuda"), torch.tensor(z["I0"], device="cuda"), "value", fw, 5.0)
+        opt = FusedLazyAdam(eng, lr=lr, weight_decay=wd, sweep_period=3, clip_grad_norm=cfg)
+        engs.append((eng, opt))
+    for t in range(4):
+        cols = [torch.tensor(z[k][t], device="cuda") for k in ("user_id", "item_id", "rating", "sst")]
+        for eng, opt in engs:
+            eng.forward(*cols)
+            if opt.clip is None:
+                eng.clip_grad_norm(mn)
+            opt.step()
+    for eng, _ in engs:
+        eng.flush()
+    assert torch.equal(engs[0][0].U.weight, engs[1][0].U.weight) and torch.equal(engs[0][0].I.weight, engs[1][0].I.weight)
+    with pytest.raises(NotImplementedError):
+        FusedLazyAdam(engs[0][0], lr=lr, weight_decay=wd, clip_grad_norm=dict(max_norm=1.0, norm_type=1))
 
 
 def test_deferred_loss_with_interleaved_engines():

@@ -23,7 +23,10 @@ def test_oracle_matches_reference_golden(path, torch_adam):
     lr, wd, fw = z["hyper"][:3]
     snaps = tuple(int(s) for s in z["snaps"])
     out = O.train(str(z["objective"]), z["U0"], z["I0"], z["user_id"], z["item_id"], z["rating"], z["sst"],
-                  float(lr), float(wd), float(fw), snaps=snaps, use_torch_adam=torch_adam)
+                  float(lr), float(wd), float(fw), snaps=snaps, use_torch_adam=torch_adam,
+                  clip_max_norm=float(z["clip_max_norm"]) if "clip_max_norm" in z else None)
+    if "clip_max_norm" in z:
+        np.testing.assert_allclose(out["grad_norm"], z["grad_norm"], rtol=1e-6)
     # same torch kernels as the reference -> the torch-Adam oracle is expected to be (near) bit-identical
     tol = dict(rtol=0, atol=0) if torch_adam else dict(rtol=1e-6, atol=1e-8)
     np.testing.assert_allclose(out["loss"], z["loss"], rtol=1e-7 if torch_adam else 1e-5)
