@@ -200,6 +200,49 @@ def test_full_size_steps_match_the_oracle():
            atol=1e-6 * float(st["exp_avg_sq"].abs().max()))
 
 
+def test_prefetch_queue_over_epochs_matches_plain_steps():
+    """The trainer's usage pattern over several epochs: a prefetch queue of up to 10 announced batches that drains at
+    every epoch end, a flush (evaluation / checkpoint) between epochs, item-complete batches of varying size.  The tables
+    must equal those of an engine that is stepped plainly (no look-ahead at all)."""
+    from fairrec.model.fair_recommender.focf import FocfEngine
+    from fairrec.optim import FusedLazyAdam
+    n_users, n_items, D = 4001, 601, 64
+    g = torch.Generator().manual_seed(21)
+    U0 = (torch.randn(n_users, D, generator=g) * 0.05).cuda()
+    I0 = (torch.randn(n_items, D, generator=g) * 0.05).cuda()
+    gender = torch.randint(0, 2, (n_users,), generator=g).float()
+    engs = []
+    for k in range(2):
+        eng = FocfEngine(U0.clone(), I0.clone(), "value", 0.3, 5.0)
+        FusedLazyAdam(eng, lr=5e-3, weight_decay=1e-3, sweep_period=7)
+        eng.defer_loss = eng.item_runs = k == 1
+        engs.append(eng)
+    for epoch in range(3):
+        batches = []
+        for _ in range(23 + 5 * epoch):
+            B = int(torch.randint(700, 1100, (1,), generator=g))
+            items = torch.randint(1, n_items, (12,), generator=g)
+            i = items[torch.arange(B) * 12 // B]                    # runs of equal items, like FOCFDataLoader's batches
+            u = torch.randint(1, n_users, (B,), generator=g)
+            r = torch.randint(1, 6, (B,), generator=g).float()
+            batches.append((u.cuda(), i.cuda(), r.cuda(), gender[u].cuda()))
+        for t, (u, i, r, s) in enumerate(batches):
+            engs[0].forward(u, i, r, s)
+            engs[0].backward_adam()
+            queue = [(b[0], b[1], b[3]) for b in batches[t + 1:t + 11]] or None
+            engs[1].forward(u, i, r, s, next_batch=queue)
+            engs[1].backward_adam()
+        for eng in engs:
+            eng.flush()                                              # evaluation / checkpoint between epochs
+            eng.check_device_errors()
+        assert not engs[1]._prep, "the queue must be empty at an epoch end"
+    a, b = engs
+    for x, y in ((b.U.weight, a.U.weight), (b.I.weight, a.I.weight), (b.U.v, a.U.v), (b.I.m, a.I.m)):
+        # the two schedules split a row's replay into different stretches (rounding of the moment scaling): the parity
+        # tolerance, with the absolute floor scaled to the tensor
+        torch.testing.assert_close(x, y, rtol=1e-4, atol=1e-6 * float(y.abs().max()) + 1e-12)
+
+
 def test_optimizer_step_clips_like_the_reference_loop():
     """config `clip_grad_norm` reaches FusedLazyAdam, whose step() clips before the backward launch -- same numbers as
     clipping by hand (the golden cases above do that) -- and other norm types / engines without a norm pass are refused."""
