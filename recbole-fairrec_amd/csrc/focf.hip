@@ -242,23 +242,35 @@ struct SweepSlice {
     long long lo_u, lo_i;
     int n_u, n_i;          // rows of the slice in each table
     int upto, skip_from;   // rows stamped >= skip_from are left to their batch; the others are brought to step `upto`
+    int per_wave;          // rows a wave takes: 2 at D <= 64 (sweep_row_pair), 1 beyond (see sweep_pairs)
 };
 
-inline long long sweep_slice_waves(const SweepSlice& sw) { return ((long long)sw.n_u + 1) / 2 + ((long long)sw.n_i + 1) / 2; }
+inline long long sweep_slice_waves(const SweepSlice& sw) {
+    return ((long long)sw.n_u + sw.per_wave - 1) / sw.per_wave + ((long long)sw.n_i + sw.per_wave - 1) / sw.per_wave;
+}
 
 template <int E>
 __device__ __forceinline__ void sweep_slice_wave(const TableV& U, const TableV& I, const AdamC& c, const SweepSlice& sw,
                                                  long long wv, int lane) {
-    const long long pu = (sw.n_u + 1) / 2, pi = (sw.n_i + 1) / 2;
+    constexpr int PW = sweep_pairs(E) ? 2 : 1;
+    const long long pu = (sw.n_u + PW - 1) / PW, pi = (sw.n_i + PW - 1) / PW;
     if (wv < pu) {
-        const long long a = 2 * wv, b = a + 1 < sw.n_u ? sw.lo_u + a + 1 : -1;
-        sweep_row_pair<E>(U, c, sw.lo_u + a, b, sw.upto, sw.skip_from, lane);
+        if (PW == 2) {
+            const long long a = 2 * wv;
+            sweep_row_pair<E>(U, c, sw.lo_u + a, a + 1 < sw.n_u ? sw.lo_u + a + 1 : -1, sw.upto, sw.skip_from, lane);
+        } else {
+            sweep_row<E>(U, c, sw.lo_u + wv, sw.upto, sw.skip_from, lane);
+        }
         return;
     }
     wv -= pu;
     if (wv < pi) {
-        const long long a = 2 * wv, b = a + 1 < sw.n_i ? sw.lo_i + a + 1 : -1;
-        sweep_row_pair<E>(I, c, sw.lo_i + a, b, sw.upto, sw.skip_from, lane);
+        if (PW == 2) {
+            const long long a = 2 * wv;
+            sweep_row_pair<E>(I, c, sw.lo_i + a, a + 1 < sw.n_i ? sw.lo_i + a + 1 : -1, sw.upto, sw.skip_from, lane);
+        } else {
+            sweep_row<E>(I, c, sw.lo_i + wv, sw.upto, sw.skip_from, lane);
+        }
     }
 }
 
@@ -840,6 +852,7 @@ static SweepSlice make_sweep_slice(const fr_table* U, const fr_table* I, int32_t
     sw.n_i = (int)(hi_i - sw.lo_i);
     sw.upto = U->step;
     sw.skip_from = U->step;
+    sw.per_wave = sweep_pairs((U->dim + 63) / 64) ? 2 : 1;
     return sw;
 }
 
@@ -1081,7 +1094,7 @@ extern "C" int fr_focf_shard_fair(void* item_ws, size_t ws_bytes, int64_t n_slot
         // records of slot (g, k): planes rec[g][0..2][k]; padding slots are in no segment, so never read or written.
         // scratch[0] is the arrival ticket (zero between launches), partials follow; the last block to arrive writes
         // the tails (K_owner, fair_owner, sum of the sq_part partials) of all destination chunks
-        FairArgs fa{tw.perm, tw.seg_start, tw.nseg, nullptr, minmax, (int)mm_count, (int)mm_stride, rec, rec + cap, rec + 2 * cap,
+        FairArgs fa{tw.perm, tw.seg_start, tw.nseg, tw.seg_first, minmax, (int)mm_count, (int)mm_stride, rec, rec + cap, rec + 2 * cap,
                     Lay{cap, 3 * cap}, reply, Lay{cap, cap + FR_SHARD_TAIL}, scratch + 16, 0,
                     reinterpret_cast<unsigned int*>(scratch), sq_part, (int)n_sq_part, 0, nullptr,
                     reply + cap, (int)(n_slots / cap), cap + FR_SHARD_TAIL};

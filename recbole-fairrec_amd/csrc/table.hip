@@ -111,11 +111,12 @@ __global__ __launch_bounds__(256) void table_gather_train_kernel(GatherJob ja, G
         r = 0;
     }
     const int row = uniform((int)r);
-    const int t0 = uniform(T.last[row]);
+    const int lt = T.last[row];        // requested together with the row: one dependent round trip, not two
     RowFrag<E> p, m, v;
     load_row<E>(p, T.p + (size_t)row * D, D, lane);
     load_row<E>(m, T.m + (size_t)row * D, D, lane);
     load_row<E>(v, T.v + (size_t)row * D, D, lane);
+    const int t0 = uniform(lt);
     replay<E>(p, m, v, t0, T.step - 1, c, lane);
     store_row<E>(p, J.rows_out + (size_t)jp * D, D, lane);
     store_row<E>(m, J.w.m_side + (size_t)j * D, D, lane);
@@ -129,7 +130,7 @@ struct ApplyJob {
     const float* rows;
     const float* grad_rows;
     int sweep_period;     // the sweeper slice is derived from the effective step on the device
-    int sw_n;             // waves reserved for it (= rows of the longest slice)
+    int sw_n;             // waves reserved for it (= pairs of rows of the longest slice)
 };
 
 template <int E>
@@ -141,13 +142,18 @@ __global__ __launch_bounds__(256) void table_apply_grad_kernel(ApplyJob ja, Appl
     if (wv < J.sw_n) {   // longest jobs first
         long long lo, hi;
         sweep_range(T.n_rows, T.step, J.sweep_period, lo, hi);
-        if (lo + wv < hi) sweep_row<E>(T, c, lo + wv, T.step, T.step, lane);
+        if (sweep_pairs(E)) {     // a wave takes two adjacent rows of the slice (see sweep_row_pair)
+            const long long a = lo + 2 * wv;
+            if (a < hi) sweep_row_pair<E>(T, c, a, a + 1 < hi ? a + 1 : -1, T.step, T.step, lane);
+        } else if (lo + wv < hi) {
+            sweep_row<E>(T, c, lo + wv, T.step, T.step, lane);
+        }
         return;
     }
     wv -= J.sw_n;
     if (wv < M && wv < J.w.nseg[0])
         segment_update<E>(T, c, (int)wv, J.w.seg_start, J.w.seg_row, J.w.perm, nullptr, J.rows, J.w.m_side, J.w.v_side,
-                          J.grad_rows, lane, lay);
+                          J.grad_rows, lane, lay, J.w.seg_first);
 }
 
 }  // namespace fr
@@ -253,6 +259,8 @@ static int gather_train_impl(const char* who, const fr_table* ta, const fr_table
     FR_CHECK_ARG(ws_bytes >= wa.bytes, "%s: workspace %zu < %zu bytes", who, ws_bytes, wa.bytes);
     SortJob sa{idx_a, ta->n_rows, wa.perm, wa.seg_start, wa.seg_row, nullptr, wa.nseg, nullptr, nullptr, lay};
     SortJob sb{idx_b, tb ? tb->n_rows : 0, wb.perm, wb.seg_start, wb.seg_row, nullptr, wb.nseg, nullptr, nullptr, lay};
+    sa.seg_first = wa.seg_first;
+    sb.seg_first = wb.seg_first;
     SideStream* ss = side_stream();
     const bool overlap = ss != nullptr && !prof_on();
     if (prepared) {
@@ -306,6 +314,8 @@ extern "C" int fr_table_sort2(const int64_t* idx_a, const int64_t* idx_b, int64_
     const Lay lay{chunk, stride};
     SortJob sa{idx_a, n_rows_a, wa.perm, wa.seg_start, wa.seg_row, nullptr, wa.nseg, nullptr, nullptr, lay};
     SortJob sb{idx_b, n_rows_b, wb.perm, wb.seg_start, wb.seg_row, nullptr, wb.nseg, nullptr, nullptr, lay};
+    sa.seg_first = wa.seg_first;
+    sb.seg_first = wb.seg_first;
     return launch_sort(sa, &sb, M, err_flag, (hipStream_t)stream_);
 }
 
@@ -326,8 +336,9 @@ static int apply_grad_impl(const char* who, const fr_table* ta, const fr_table* 
     if ((rc = side_join(ws_a, stream)) || (tb && (rc = side_join(ws_b, stream)))) return rc;
     // waves reserved for the sweeper = rows of a full slice (the slice itself depends on the effective step, which may
     // live on the device)
-    const long long sw_a = sweep_a > 0 ? (ta->n_rows + sweep_a - 1) / sweep_a : 0;
-    const long long sw_b = tb && sweep_b > 0 ? (tb->n_rows + sweep_b - 1) / sweep_b : 0;
+    const int per_wave = sweep_pairs((ta->dim + 63) / 64) ? 2 : 1;
+    const long long sw_a = sweep_a > 0 ? ((ta->n_rows + sweep_a - 1) / sweep_a + per_wave - 1) / per_wave : 0;
+    const long long sw_b = tb && sweep_b > 0 ? ((tb->n_rows + sweep_b - 1) / sweep_b + per_wave - 1) / per_wave : 0;
     const long long waves = M + std::max(sw_a, sw_b);
     const AdamC c = make_adamc(adam);
     ApplyJob ja{view(ta), wa, rows_a, grad_a, (int)sweep_a, (int)sw_a};

@@ -137,6 +137,11 @@ __device__ __forceinline__ void sweep_row(const TableV& T, const AdamC& c, long 
     if (lane == 0) T.last[row] = upto;
 }
 
+// Pairs pay off while both rows' fragments fit a small register budget: D <= 64 (one register per fragment).  Measured
+// with pairs at every width: NFCF (D = 256) step 0.49 -> 0.60 ms, PFCN (D = 128) filter pass 2.09 -> 2.43 ms -- the extra
+// fragments cost more occupancy than the packed VALU saves -- so wider rows go one per wave.
+__host__ __device__ constexpr bool sweep_pairs(int E) { return E <= 1; }
+
 // Two rows of a sweep slice in one wave: both are requested at once (twice the rows in flight per wave slot) and their
 // common stretch of missed steps is replayed interleaved, which the compiler packs into v_pk_* instructions (26 instead
 // of 36 issue cycles per row and step).  rowB < 0: only rowA.
@@ -186,6 +191,7 @@ __device__ __forceinline__ void sweep_row_pair(const TableV& T, const AdamC& c, 
 // Workspace of the generic training pair (fr_table_gather_train / fr_table_apply_grad).
 struct TableWs {
     int32_t *perm, *seg_start, *seg_row, *nseg;
+    int32_t* seg_first;       // perm[seg_start[k]]: the first (usually the only) member of segment k
     float *m_side, *v_side;   // [M, D] caught-up moments of the gathered rows
     size_t bytes;
 };
@@ -203,6 +209,7 @@ inline TableWs table_layout(void* base, int64_t M, int D) {
     w.seg_start = (int32_t*)take(Mp * 4);
     w.seg_row = (int32_t*)take(Mp * 4);
     w.nseg = (int32_t*)take(4);
+    w.seg_first = (int32_t*)take(Mp * 4);
     w.m_side = (float*)take((size_t)M * D * 4);
     w.v_side = (float*)take((size_t)M * D * 4);
     w.bytes = off;
