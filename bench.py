@@ -302,6 +302,8 @@ def main():
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "measured_copy_ceiling": round(copy_gbs, 1), "frac_of_measured_ceiling": round(achieved / copy_gbs, 4),
                     "algorithmic_bytes_per_launch": algo_bytes,
+                    # the same bytes over the WHOLE step (all kernels of the chain + gaps), for orientation
+                    "whole_step_GBps": round(algo_bytes / (dt / K) / 1e9, 1),
                     "kernel_us": {k: round(v, 2) for k, v in sorted(per_kernel.items())},
                     "dominant_rule": "longest kernel of the dependent chain; sort_segments_kernel runs "
                                      + ("on 1-2 workgroups concurrently with the gather kernels on a side stream" if sharded
