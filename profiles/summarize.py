@@ -27,6 +27,8 @@ def one(pattern):
 shutil.copy(one("stats/**/*_kernel_stats.csv"), os.path.join(dst, f"{rnd}_kernel_stats.csv"))
 if os.path.exists(os.path.join(src, "bench_line.json")):
     shutil.copy(os.path.join(src, "bench_line.json"), os.path.join(dst, f"{rnd}_bench_under_rocprof.json"))
+if os.path.exists(os.path.join(src, "graph_window.txt")):
+    shutil.copy(os.path.join(src, "graph_window.txt"), os.path.join(dst, f"{rnd}_graph_window.txt"))
 
 
 def counters(path, name):
