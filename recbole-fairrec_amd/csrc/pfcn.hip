@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void bpr_kernel(const float* __restrict__ pos,
 // reduced over the block at the end (butterfly + wave order: fixed order).  Per-block column partials ga_part[block][j]
 // are added in block order by a second kernel.  B^2 transcendental groups, nothing of size B^2 is ever stored (the
 // reference materialises the [B,B] matrix).
-static constexpr int OUTER_ROWS = 16;
+static constexpr int OUTER_ROWS = 32;
 
 // -log(1e-10 + sigmoid(x)) and its derivative with hardware exp / log / rcp (1-2 ulp): with e = exp(-x), r = 1/(1+e):
 // sigmoid = r, 1 - sigmoid = e*r, so  term = -log(1e-10 + r),  dterm = -(r*r*e) / (1e-10 + r)
