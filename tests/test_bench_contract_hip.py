@@ -1,0 +1,38 @@
+"""bench.py's one-line JSON contract (task statement + ④): run a short bench on the GPU and check the fields the driver and
+the judge read.  Also the item-complete distribution (the shape FOCFDataLoader produces) and the eager-only mode."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(*args):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "12", "--warmup", "2", "--age", "8",
+                          "--no-cpu-baseline", *args], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]          # ONE JSON line
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("args", [(), ("--item-dist", "grouped"), ("--no-graph",)], ids=["default", "grouped", "eager"])
+def test_bench_json_contract(args):
+    d = _bench(*args)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 12 and d["warmup"] == 2 and d["higher_is_better"] is True
+    assert d["unit"] == "interactions/s" and d["dtype"] == "f32" and d["data"] == "synthetic" and d["vs_baseline"] is None
+    assert "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - 12 * 8192 / (d["ms_per_step"] * 12e-3)) <= 1e-3 * d["value"]
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel"):
+        assert k in r, k
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 0.0 < r["frac"] < 1.0
+    assert d["config"]["final_loss"] == d["config"]["final_loss"]      # not NaN
