@@ -16,6 +16,8 @@
 //   finalize  : fixed-order reduction of the partials -> loss scalar
 //   bwd_adam  : per distinct row: sum_b dLoss/dpred[b] * other_row[b] (batch order), Adam step,
 //               row written back once; plus the bounded-staleness sweeper slice
+#include <mutex>
+
 #include "common.hpp"
 #include "kernels.hpp"
 #include "table.hpp"
@@ -812,14 +814,21 @@ static constexpr int DEFER_SLOTS = 16;
 static const void* g_defer_ws[DEFER_SLOTS] = {nullptr};
 static DeferLoss g_defer[DEFER_SLOTS];
 static int g_defer_next = 0;
+static std::mutex g_defer_mu;      // the only shared host state of the FOCF entry points (workspaces belong to callers)
 
-static void defer_forget(const void* ws) {
+static void defer_forget_locked(const void* ws) {
     for (int q = 0; q < DEFER_SLOTS; ++q)
         if (g_defer_ws[q] == ws) g_defer_ws[q] = nullptr;
 }
 
+static void defer_forget(const void* ws) {
+    std::lock_guard<std::mutex> lock(g_defer_mu);
+    defer_forget_locked(ws);
+}
+
 static void defer_put(const void* ws, const DeferLoss& d) {
-    defer_forget(ws);
+    std::lock_guard<std::mutex> lock(g_defer_mu);
+    defer_forget_locked(ws);
     for (int q = 0; q < DEFER_SLOTS; ++q) {
         const int k = (g_defer_next + q) % DEFER_SLOTS;
         if (!g_defer_ws[k]) {
@@ -835,6 +844,7 @@ static void defer_put(const void* ws, const DeferLoss& d) {
 }
 
 static DeferLoss defer_take(const void* ws) {
+    std::lock_guard<std::mutex> lock(g_defer_mu);
     for (int q = 0; q < DEFER_SLOTS; ++q)
         if (g_defer_ws[q] == ws) {
             g_defer_ws[q] = nullptr;
