@@ -125,7 +125,8 @@ FR_API size_t fr_focf_workspace_bytes(int64_t B, int32_t dim);
 #define FR_FOCF_PREPARED 1   /* flags: fr_focf_prepare(_many) already ran for this batch on this workspace */
 /* FR_FOCF_DEFER_LOSS: loss_out is written by the fr_focf_backward_adam that follows on the same workspace and stream
  * (one extra workgroup of its launch) instead of by this call -- for step loops that read the loss after optimizer.step().
- * Takes the reduction's ticket round trip off the end of the fairness kernel, i.e. off the step's critical path. */
+ * Takes the reduction's ticket round trip off the end of the fairness kernel, i.e. off the step's critical path.
+ * The record of what is still to be reduced travels in the workspace (device memory): the library keeps no host state. */
 #define FR_FOCF_DEFER_LOSS 2
 /* FR_FOCF_ITEM_RUNS: a hint -- the interactions of an item sit next to each other in the batch (item-complete batches,
  * focf_dataloader.py:37-51).  The gather kernel then replays an item row once per workgroup instead of once per wave (the
@@ -184,6 +185,40 @@ FR_API int fr_focf_clip_grad_norm(const fr_table* U, const fr_table* I, int64_t 
  */
 FR_API int fr_focf_backward_adam(const fr_table* U, const fr_table* I, const fr_adam* adam, int64_t B,
                           int32_t sweep_period, void* ws, size_t ws_bytes, void* stream);
+
+/*
+ * The whole training step of one batch as ONE launch: FOCF.calculate_loss (focf.py:152-169) + loss.backward()
+ * (trainer.py:193) + optimizer.step() (trainer.py:196), for step loops that read the loss after the optimizer step
+ * (what FR_FOCF_DEFER_LOSS serves on the three-launch path).  Same results as fr_focf_forward + fr_focf_backward_adam;
+ * objectives none / value / absolute / under / over (nonparity and clip_grad_norm need batch-wide values between the
+ * forward and the update: use the three-launch path).  A wave keeps both rows of its interaction in registers from
+ * the gather to the Adam write-back; rows shared by several interactions of the batch are finished by the last of
+ * their waves to arrive (csrc/focf_step.hip).
+ *   fr_focf_prepare_step : fr_focf_prepare_many plus what the fused launch needs from the index side: per batch
+ *                          position the extent of its user / item segment, zeroed arrival counters, and
+ *                          stamp[row] = max(stamp[row], stamps[q]) on every row of batch q in both tables -- the
+ *                          sweeper waves of fr_focf_step leave rows stamped >= its `stamp` argument alone.  Callable
+ *                          ahead on another stream (depends on the id columns only; the stamp raise is an atomic max).
+ *                          stamps[q]: any value >= every stamp handed out before (the engine uses the step at which
+ *                          the batch is expected to be applied).
+ *   fr_focf_step         : the step (U->step == I->step = the step being applied).  `stamp` = the value given to
+ *                          fr_focf_prepare_step for this batch.  The loss needs every wave of the launch, so it is
+ *                          reduced LATER: by the next fr_focf_step (prev_ws / prev_B / prev_loss_out name the earlier
+ *                          batch; one extra workgroup) or by fr_focf_step_finish.  loss_acc (device float[3], may be
+ *                          NULL) += (loss, mse, fair) of every reduced batch: a running total for epoch loops.
+ *                          loss_out is where THIS batch's loss will be written by that later reduction (recorded by the
+ *                          caller; not written here).
+ *   fr_focf_step_finish  : the reduction for a batch no later step will reduce (end of an epoch, before reading).
+ */
+FR_API int fr_focf_prepare_step(const fr_focf_batch* batches, const int32_t* stamps, int32_t n, const fr_table* U,
+                                const fr_table* I, uint32_t* err_flag, void* stream);
+FR_API int fr_focf_step(const fr_table* U, const fr_table* I, const fr_adam* adam, const int64_t* user,
+                        const int64_t* item, const float* rating, const float* sst, int64_t B, int32_t objective,
+                        float fair_weight, int32_t sweep_period, int32_t stamp, void* ws, size_t ws_bytes,
+                        float* loss_out, void* prev_ws, int64_t prev_B, float* prev_loss_out, float* loss_acc,
+                        uint32_t* err_flag, void* stream);
+FR_API int fr_focf_step_finish(void* ws, size_t ws_bytes, int64_t B, int32_t dim, int32_t objective, float fair_weight,
+                               float* loss_out, float* loss_acc, void* stream);
 
 /* FOCF.predict, focf.py:145-150: clamp(pred, 0, max_rating) / max_rating on up-to-date rows (read only). */
 FR_API int fr_focf_predict(const fr_table* U, const fr_table* I, const fr_adam* adam, const int64_t* user,

@@ -16,69 +16,13 @@
 //   finalize  : fixed-order reduction of the partials -> loss scalar
 //   bwd_adam  : per distinct row: sum_b dLoss/dpred[b] * other_row[b] (batch order), Adam step,
 //               row written back once; plus the bounded-staleness sweeper slice
-#include <mutex>
-
 #include "common.hpp"
 #include "kernels.hpp"
 #include "table.hpp"
+#include "focf_ws.hpp"
 
 namespace fr {
 
-struct FocfWs {
-    // sort outputs
-    int32_t *perm_u, *seg_start_u, *seg_row_u, *seg_first_u, *nseg_u;   // seg_first[k] = perm[seg_start[k]]
-    int32_t *perm_i, *seg_start_i, *seg_row_i, *seg_first_i, *nseg_i;
-    float* sst_minmax;   // [2]
-    float* pred;         // [B]
-    float* coef;         // [B] dLoss/dpred
-    float* mse_part;     // [gather blocks]
-    float* fair_part;    // [fair blocks]
-    unsigned int* ticket;  // in-launch finalisation counter of the fair kernel (kept zero between launches)
-    float* clip_part;      // [(2B + 3) / 4] squared-norm partials of fr_focf_clip_grad_norm
-    float* side[6];      // ue, mu, vu, ie, mi, vi : [B, D] each
-    int n_gather_blocks, n_fair_blocks;
-    size_t bytes;
-};
-
-static constexpr int GATHER_THREADS = 256;  // 4 waves = 4 interactions per block
-static constexpr int FAIR_THREADS = 1024;   // 16 lanes per item segment -> 64 segments per block (few blocks: cheap ticket)
-static constexpr int FAIR_GROUP = 16;        // lanes per item segment ...
-static constexpr int FAIR_GROUP_RUNS = 64;   // ... and in item-complete batches (few items, ~100 members each)
-
-static FocfWs focf_layout(void* base, int64_t B, int D) {
-    FocfWs w;
-    size_t off = 0;
-    auto take = [&](size_t nbytes) {
-        void* p = base ? (void*)((char*)base + off) : nullptr;
-        off = align_up(off + nbytes, 256);
-        return p;
-    };
-    const size_t Bp = (size_t)B + 1;
-    w.perm_u = (int32_t*)take(Bp * 4);
-    w.seg_start_u = (int32_t*)take(Bp * 4);
-    w.seg_row_u = (int32_t*)take(Bp * 4);
-    w.seg_first_u = (int32_t*)take(Bp * 4);
-    w.nseg_u = (int32_t*)take(4);
-    w.perm_i = (int32_t*)take(Bp * 4);
-    w.seg_start_i = (int32_t*)take(Bp * 4);
-    w.seg_row_i = (int32_t*)take(Bp * 4);
-    w.seg_first_i = (int32_t*)take(Bp * 4);
-    w.nseg_i = (int32_t*)take(4);
-    w.sst_minmax = (float*)take(8);
-    w.pred = (float*)take(Bp * 4);
-    w.coef = (float*)take(Bp * 4);
-    w.n_gather_blocks = (int)((B * WAVE + GATHER_THREADS - 1) / GATHER_THREADS);
-    w.n_fair_blocks = (int)((B * FAIR_GROUP + FAIR_THREADS - 1) / FAIR_THREADS);
-    if (w.n_gather_blocks < 1) w.n_gather_blocks = 1;
-    if (w.n_fair_blocks < 1) w.n_fair_blocks = 1;
-    w.mse_part = (float*)take((size_t)w.n_gather_blocks * 4);
-    w.fair_part = (float*)take((size_t)w.n_fair_blocks * (FAIR_GROUP_RUNS / FAIR_GROUP) * 4);   // room for either group size
-    w.ticket = (unsigned int*)take(4);
-    w.clip_part = (float*)take(((2 * (size_t)B + 3) / 4) * 4);
-    for (int k = 0; k < 6; ++k) w.side[k] = (float*)take((size_t)B * D * 4);
-    w.bytes = off;
-    return w;
-}
 
 // ------------------------------------------------------------------------------------------------
 // gather: one wave per interaction
@@ -204,8 +148,9 @@ __device__ __forceinline__ void focf_gather_body(
             const float er = dot - rating[b];
             e2 = er * er;
             if (lane == 0) {
-                U.stamp[ur] = upto_u + 1;
-                I.stamp[ir] = upto_i + 1;
+                // never lowered: a look-ahead fr_focf_prepare_step may already have stamped the row for a later batch
+                atomicMax(&U.stamp[ur], upto_u + 1);
+                atomicMax(&I.stamp[ir], upto_i + 1);
                 w.pred[b] = dot;
                 w.coef[b] = 2.f * er / (float)B;  // d mean((pred-r)^2) / d pred
             }
@@ -228,76 +173,14 @@ template <int E, bool TRAIN, bool SHARE>
 __global__ __launch_bounds__(GATHER_THREADS) void focf_gather_kernel(
     TableV U, TableV I, AdamC c, const int64_t* __restrict__ user, const int64_t* __restrict__ item,
     const float* __restrict__ rating, int B, int upto_u, int upto_i, FocfWs w, float max_rating,
-    float* __restrict__ predict_out, uint32_t* err) {
+    float* __restrict__ predict_out, uint32_t* err, DeferLoss dl) {
     __shared__ GatherLds<SHARE ? E : 0> lds;
+    if (TRAIN && blockIdx.x == 0 && threadIdx.x == 0) *w.defer = dl;   // what the backward launch still has to reduce
     focf_gather_body<E, TRAIN, SHARE>(U, I, c, user, item, rating, B, upto_u, upto_i, w, max_rating, predict_out, err,
                                       (int)blockIdx.x, lds);
 }
 
-// The step's slice of the bounded-staleness sweeper, as extra workgroups of the backward launch: one wave per PAIR of
-// rows.  Pure VALU work (up to S replayed steps per row) on rows nothing else in the step touches -- the gather kernel
-// has stamped the batch's rows by then.  Measured alternatives (profiles/README.md): its own launch on a second stream,
-// riding in the look-ahead sort launch, in the gather or the fairness launch, split between launches -- every one of them
-// was slower than this (a sweeper wave is a ~10 us dependency chain wherever it runs; hipGraph serialises a third branch
-// and pays ~10 us per cross-stream join).
-struct SweepSlice {
-    long long lo_u, lo_i;
-    int n_u, n_i;          // rows of the slice in each table
-    int upto, skip_from;   // rows stamped >= skip_from are left to their batch; the others are brought to step `upto`
-    int per_wave;          // rows a wave takes: 2 at D <= 64 (sweep_row_pair), 1 beyond (see sweep_pairs)
-};
 
-inline long long sweep_slice_waves(const SweepSlice& sw) {
-    return ((long long)sw.n_u + sw.per_wave - 1) / sw.per_wave + ((long long)sw.n_i + sw.per_wave - 1) / sw.per_wave;
-}
-
-template <int E>
-__device__ __forceinline__ void sweep_slice_wave(const TableV& U, const TableV& I, const AdamC& c, const SweepSlice& sw,
-                                                 long long wv, int lane) {
-    constexpr int PW = sweep_pairs(E) ? 2 : 1;
-    const long long pu = (sw.n_u + PW - 1) / PW, pi = (sw.n_i + PW - 1) / PW;
-    if (wv < pu) {
-        if (PW == 2) {
-            const long long a = 2 * wv;
-            sweep_row_pair<E>(U, c, sw.lo_u + a, a + 1 < sw.n_u ? sw.lo_u + a + 1 : -1, sw.upto, sw.skip_from, lane);
-        } else {
-            sweep_row<E>(U, c, sw.lo_u + wv, sw.upto, sw.skip_from, lane);
-        }
-        return;
-    }
-    wv -= pu;
-    if (wv < pi) {
-        if (PW == 2) {
-            const long long a = 2 * wv;
-            sweep_row_pair<E>(I, c, sw.lo_i + a, a + 1 < sw.n_i ? sw.lo_i + a + 1 : -1, sw.upto, sw.skip_from, lane);
-        } else {
-            sweep_row<E>(I, c, sw.lo_i + wv, sw.upto, sw.skip_from, lane);
-        }
-    }
-}
-
-__device__ __forceinline__ float smooth_l1(float x) {  // F.smooth_l1_loss(|x|, 0), beta = 1
-    float a = fabsf(x);
-    return a < 1.f ? 0.5f * a * a : a - 0.5f;
-}
-
-// d_g = f(P_g - T_g) of the four per-item objectives (focf.py:93-125) and its derivative q_g = d d_g / d P_g
-__device__ __forceinline__ void focf_objective(int objective, float P0, float T0, float P1, float T1, float& d0,
-                                               float& d1, float& q0, float& q1) {
-    if (objective == FR_FOCF_VALUE) {
-        d0 = P0 - T0; d1 = P1 - T1; q0 = 1.f; q1 = 1.f;
-    } else if (objective == FR_FOCF_ABSOLUTE) {
-        d0 = fabsf(P0 - T0); d1 = fabsf(P1 - T1);
-        q0 = (P0 > T0) ? 1.f : (P0 < T0 ? -1.f : 0.f);
-        q1 = (P1 > T1) ? 1.f : (P1 < T1 ? -1.f : 0.f);
-    } else if (objective == FR_FOCF_UNDER) {
-        d0 = (T0 - P0 > 0.f) ? T0 - P0 : 0.f; d1 = (T1 - P1 > 0.f) ? T1 - P1 : 0.f;
-        q0 = (T0 - P0 > 0.f) ? -1.f : 0.f;    q1 = (T1 - P1 > 0.f) ? -1.f : 0.f;
-    } else {  // over
-        d0 = (P0 - T0 > 0.f) ? P0 - T0 : 0.f; d1 = (P1 - T1 > 0.f) ? P1 - T1 : 0.f;
-        q0 = (P0 - T0 > 0.f) ? 1.f : 0.f;     q1 = (P1 - T1 > 0.f) ? 1.f : 0.f;
-    }
-}
 
 // ------------------------------------------------------------------------------------------------
 // fairness term on the distinct items of the batch: 16 lanes per item
@@ -369,17 +252,9 @@ __global__ __launch_bounds__(FAIR_THREADS) void focf_fair_kernel(FairArgs w, int
         sp0 = group_sum<FAIR_GROUP>(sp0); sp1 = group_sum<FAIR_GROUP>(sp1);
         st0 = group_sum<FAIR_GROUP>(st0); st1 = group_sum<FAIR_GROUP>(st1);
         n0 = group_sum<FAIR_GROUP>(n0);   n1 = group_sum<FAIR_GROUP>(n1);
-        const float c0 = n0 + 1e-5f, c1 = n1 + 1e-5f;          // sst_num += 1e-5, focf.py:89
-        const float P0 = sp0 / c0, P1 = sp1 / c1, T0 = st0 / c0, T1 = st1 / c1;
-        float d0, d1, q0, q1;  // d_g and d d_g / d P_g
-        focf_objective(objective, P0, T0, P1, T1, d0, d1, q0, q1);
-        const float delta = d0 - d1;
-        const float x = fabsf(delta);
-        term = smooth_l1(x);
-        const float sgn = delta > 0.f ? 1.f : (delta < 0.f ? -1.f : 0.f);
         // d(fw * mean_k sl1)/d delta; sharded: K is only known after an all-reduce, the requester divides later
-        const float dx = (x < 1.f ? x : 1.f) * sgn * fair_weight / (defer_k ? 1.f : (float)K);
-        const float g0 = dx * q0 / c0, g1 = -dx * q1 / c1;
+        float g0, g1;
+        focf_fair_eval(objective, fair_weight, defer_k ? 1.f : (float)K, sp0, sp1, st0, st1, n0, n1, term, g0, g1);
         for (int j = j0 + sub; j < j1; j += FAIR_GROUP) {
             const bool first = j == j0 + sub;
             const int b = first ? b_first : w.perm[j];
@@ -514,14 +389,6 @@ __global__ __launch_bounds__(256) void focf_finalize_kernel(FocfWs w, int B, int
     focf_finalize_block(w, B, objective, fair_weight, loss_out, w.n_fair_blocks);
 }
 
-// FR_FOCF_DEFER_LOSS: the loss of the batch is reduced by one extra workgroup of the backward launch instead of inside
-// the forward (where it costs a ticket round trip at the end of the fairness kernel, on the step's critical path)
-struct DeferLoss {
-    float* loss_out;   // nullptr = nothing deferred
-    int objective;
-    float fair_weight;
-    int n_fair_part;   // workgroups of the fairness launch that wrote a partial sum
-};
 
 // ------------------------------------------------------------------------------------------------
 // backward + Adam: one wave per distinct row, plus sweeper waves
@@ -596,13 +463,17 @@ __global__ __launch_bounds__(1024) void focf_clip_scale_kernel(int B, FocfWs w, 
 // replayed steps per row, the segment waves exactly one); then one wave per distinct user row, per distinct item row
 template <int E>
 __global__ __launch_bounds__(256) void focf_backward_adam_kernel(TableV U, TableV I, AdamC c, int B, FocfWs w,
-                                                                 SweepSlice sw, int n_sweep_waves, DeferLoss dl) {
-    if (dl.loss_out && blockIdx.x == 0) {   // the extra workgroup, first so that it overlaps with everything else
-        focf_finalize_block(w, B, dl.objective, dl.fair_weight, dl.loss_out, dl.n_fair_part);
+                                                                 SweepSlice sw, int n_sweep_waves) {
+    if (blockIdx.x == 0) {   // the extra workgroup, first so that it overlaps with everything else
+        const DeferLoss dl = *w.defer;      // left by the forward launch of this batch (workgroup-uniform)
+        if (dl.loss_out) {
+            focf_finalize_block(w, B, dl.objective, dl.fair_weight, dl.loss_out, dl.n_fair_part);
+            if (threadIdx.x == 0) w.defer->loss_out = nullptr;
+        }
         return;
     }
     const int lane = threadIdx.x & 63;
-    long long wv = (long long)(blockIdx.x - (dl.loss_out ? 1 : 0)) * 4 + (threadIdx.x >> 6);
+    long long wv = (long long)(blockIdx.x - 1) * 4 + (threadIdx.x >> 6);
     if (wv < n_sweep_waves) {
         sweep_slice_wave<E>(U, I, c, sw, wv, lane);
         return;
@@ -808,64 +679,6 @@ static int focf_launch_sort(const FocfWs& w, const int64_t* user, const int64_t*
     return launch_sort(ju, &ji, B, err_flag, stream);
 }
 
-// workspaces whose batch loss fr_focf_backward_adam still has to reduce (FR_FOCF_DEFER_LOSS); a handful of engines may
-// have a forward in flight at the same time (one slot per workspace, reused round-robin)
-static constexpr int DEFER_SLOTS = 16;
-static const void* g_defer_ws[DEFER_SLOTS] = {nullptr};
-static DeferLoss g_defer[DEFER_SLOTS];
-static int g_defer_next = 0;
-static std::mutex g_defer_mu;      // the only shared host state of the FOCF entry points (workspaces belong to callers)
-
-static void defer_forget_locked(const void* ws) {
-    for (int q = 0; q < DEFER_SLOTS; ++q)
-        if (g_defer_ws[q] == ws) g_defer_ws[q] = nullptr;
-}
-
-static void defer_forget(const void* ws) {
-    std::lock_guard<std::mutex> lock(g_defer_mu);
-    defer_forget_locked(ws);
-}
-
-static void defer_put(const void* ws, const DeferLoss& d) {
-    std::lock_guard<std::mutex> lock(g_defer_mu);
-    defer_forget_locked(ws);
-    for (int q = 0; q < DEFER_SLOTS; ++q) {
-        const int k = (g_defer_next + q) % DEFER_SLOTS;
-        if (!g_defer_ws[k]) {
-            g_defer_ws[k] = ws;
-            g_defer[k] = d;
-            g_defer_next = (k + 1) % DEFER_SLOTS;
-            return;
-        }
-    }
-    g_defer_ws[g_defer_next] = ws;      // all slots taken by forwards that never got their backward: overwrite the oldest
-    g_defer[g_defer_next] = d;
-    g_defer_next = (g_defer_next + 1) % DEFER_SLOTS;
-}
-
-static DeferLoss defer_take(const void* ws) {
-    std::lock_guard<std::mutex> lock(g_defer_mu);
-    for (int q = 0; q < DEFER_SLOTS; ++q)
-        if (g_defer_ws[q] == ws) {
-            g_defer_ws[q] = nullptr;
-            return g_defer[q];
-        }
-    return DeferLoss{nullptr, 0, 0.f, 0};
-}
-
-static SweepSlice make_sweep_slice(const fr_table* U, const fr_table* I, int32_t sweep_period) {
-    SweepSlice sw{};
-    long long hi_u, hi_i;
-    sweep_range(U->n_rows, U->step, sweep_period, sw.lo_u, hi_u);
-    sweep_range(I->n_rows, I->step, sweep_period, sw.lo_i, hi_i);
-    sw.n_u = (int)(hi_u - sw.lo_u);
-    sw.n_i = (int)(hi_i - sw.lo_i);
-    sw.upto = U->step;
-    sw.skip_from = U->step;
-    sw.per_wave = sweep_pairs((U->dim + 63) / 64) ? 2 : 1;
-    return sw;
-}
-
 extern "C" int fr_focf_prepare_many(const fr_focf_batch* batches, int32_t n, int64_t n_users, int64_t n_items,
                                     int32_t dim, uint32_t* err_flag, void* stream_) {
     FR_CHECK_ARG(batches && n >= 1 && 2 * n <= FR_SORT_JOBS && dim >= 1, "fr_focf_prepare_many: 1..%d batches",
@@ -938,14 +751,17 @@ extern "C" int fr_focf_forward(const fr_table* U, const fr_table* I, const fr_ad
     const AdamC c = make_adamc(adam);
     const TableV Uv = view(U), Iv = view(I);
     const bool defer = (flags & FR_FOCF_DEFER_LOSS) != 0;
-    defer_forget(ws);
-    int n_fair_part = w.n_fair_blocks;
+    const bool runs = (flags & FR_FOCF_ITEM_RUNS) != 0;
+    // loss reduction left to the backward launch: the record travels in the workspace (no host state)
+    const int n_fair_part = (objective >= FR_FOCF_VALUE && objective <= FR_FOCF_OVER && runs)
+                          ? w.n_fair_blocks * (FAIR_GROUP_RUNS / FAIR_GROUP) : w.n_fair_blocks;
+    const DeferLoss dl{defer ? loss_out : nullptr, (int)objective, fair_weight, n_fair_part};
     {
         ProfScope prof(K_FOCF_GATHER, stream);
         if (flags & FR_FOCF_ITEM_RUNS) {
-            FR_DISPATCH_E(U->dim, FR_LAUNCH(prof, (focf_gather_kernel<E, true, true>), dim3(w.n_gather_blocks), dim3(GATHER_THREADS), 0, stream, Uv, Iv, c, user, item, rating, (int)B, U->step - 1, I->step - 1, w, 0.f, (float*)nullptr, err_flag));
+            FR_DISPATCH_E(U->dim, FR_LAUNCH(prof, (focf_gather_kernel<E, true, true>), dim3(w.n_gather_blocks), dim3(GATHER_THREADS), 0, stream, Uv, Iv, c, user, item, rating, (int)B, U->step - 1, I->step - 1, w, 0.f, (float*)nullptr, err_flag, dl));
         } else {
-            FR_DISPATCH_E(U->dim, FR_LAUNCH(prof, (focf_gather_kernel<E, true, false>), dim3(w.n_gather_blocks), dim3(GATHER_THREADS), 0, stream, Uv, Iv, c, user, item, rating, (int)B, U->step - 1, I->step - 1, w, 0.f, (float*)nullptr, err_flag));
+            FR_DISPATCH_E(U->dim, FR_LAUNCH(prof, (focf_gather_kernel<E, true, false>), dim3(w.n_gather_blocks), dim3(GATHER_THREADS), 0, stream, Uv, Iv, c, user, item, rating, (int)B, U->step - 1, I->step - 1, w, 0.f, (float*)nullptr, err_flag, dl));
         }
     }
     FR_CHECK_LAUNCH();
@@ -963,7 +779,6 @@ extern "C" int fr_focf_forward(const fr_table* U, const fr_table* I, const fr_ad
             FairArgs fa{w.perm_i, w.seg_start_i, w.nseg_i, w.seg_first_i, w.sst_minmax, 1, 0, w.pred, rating, sst, Lay{0, 0}, w.coef, Lay{0, 0}, w.fair_part, 1,
                         defer ? nullptr : w.ticket, w.mse_part, w.n_gather_blocks, (int)B, loss_out};
             if (flags & FR_FOCF_ITEM_RUNS) {   // few items with many members each: a whole wave per item segment
-                n_fair_part = w.n_fair_blocks * (FAIR_GROUP_RUNS / FAIR_GROUP);
                 FR_LAUNCH(prof, focf_fair_kernel<FAIR_GROUP_RUNS>, dim3(n_fair_part), dim3(FAIR_THREADS), 0, stream, fa,
                                    objective, fair_weight, 0, err_flag);
             } else {
@@ -973,9 +788,7 @@ extern "C" int fr_focf_forward(const fr_table* U, const fr_table* I, const fr_ad
         }
         FR_CHECK_LAUNCH();
     }
-    if (defer) {
-        defer_put(ws, DeferLoss{loss_out, (int)objective, fair_weight, n_fair_part});
-    } else if (objective == FR_FOCF_NONE || objective == FR_FOCF_NONPARITY) {
+    if (!defer && (objective == FR_FOCF_NONE || objective == FR_FOCF_NONPARITY)) {
         ProfScope prof(K_FOCF_FINALIZE, stream);
         FR_LAUNCH(prof, focf_finalize_kernel, dim3(1), dim3(256), 0, stream, w, (int)B, objective, fair_weight,
                            loss_out);
@@ -1027,8 +840,7 @@ extern "C" int fr_focf_backward_adam(const fr_table* U, const fr_table* I, const
     }
     {
         ProfScope prof(K_FOCF_BWD_ADAM, stream);
-        const DeferLoss dl = defer_take(ws);
-        FR_DISPATCH_E(U->dim, FR_LAUNCH(prof, (focf_backward_adam_kernel<E>), dim3((unsigned)((sweep_waves + 2 * B + 3) / 4) + (dl.loss_out ? 1u : 0u)), dim3(256), 0, stream, Uv, Iv, c, (int)B, w, sw, (int)sweep_waves, dl));
+        FR_DISPATCH_E(U->dim, FR_LAUNCH(prof, (focf_backward_adam_kernel<E>), dim3((unsigned)((sweep_waves + 2 * B + 3) / 4) + 1u), dim3(256), 0, stream, Uv, Iv, c, (int)B, w, sw, (int)sweep_waves));
     }
     FR_CHECK_LAUNCH();
     return FR_OK;
@@ -1051,7 +863,7 @@ extern "C" int fr_focf_predict(const fr_table* U, const fr_table* I, const fr_ad
     {
         ProfScope prof(K_FOCF_GATHER, stream);
         FR_DISPATCH_E(U->dim, FR_LAUNCH(prof, (focf_gather_kernel<E, false, false>), dim3(blocks), dim3(GATHER_THREADS), 0, stream, Uv, Iv, c, user, item, (const float*)nullptr, (int)B, U->step,
-                                                  I->step, w, max_rating, out, err_flag));
+                                                  I->step, w, max_rating, out, err_flag, DeferLoss{}));
     }
     FR_CHECK_LAUNCH();
     return FR_OK;

@@ -10,7 +10,7 @@ enum KernelKind {
     K_SORT = 0, K_FOCF_GATHER, K_FOCF_FAIR, K_FOCF_NONPARITY, K_FOCF_FINALIZE, K_FOCF_BWD_ADAM, K_TABLE_FLUSH,
     K_TABLE_GATHER, K_ADAM_DENSE, K_TABLE_GATHER_TRAIN, K_TABLE_APPLY_GRAD, K_BUCKET, K_UNBUCKET,
     K_BUCKET_ROWS, K_FOCF_SHARD_SCORE, K_FOCF_SHARD_GRADS, K_LINEAR_FWD,
-    K_LINEAR_BWD_INPUT, K_LINEAR_BWD_WEIGHT, K_NFCF_LOSS, K_BN_FWD, K_BN_BWD, K_ROWDOT, K_BPR, K_SPMM, K_ROW_GATHER, K_SAMPLE_NEG, K_COUNT
+    K_LINEAR_BWD_INPUT, K_LINEAR_BWD_WEIGHT, K_NFCF_LOSS, K_BN_FWD, K_BN_BWD, K_ROWDOT, K_BPR, K_SPMM, K_ROW_GATHER, K_SAMPLE_NEG, K_FOCF_STEP, K_COUNT
 };
 bool prof_on();
 // Takes an event pair from the profiler's pool and registers it for kernel `kind` (not recorded here: the pair
@@ -64,6 +64,11 @@ struct SortJob {
     Lay lay;            // layout of idx (zero-initialised = dense)
     int32_t* seg_first; // optional [M]: perm[seg_start[k]] of segment k, so that its consumers need not chase perm for
                         //   the first (usually the only) member: one dependent memory round trip less per wave
+    // optional outputs for the fused FOCF step (focf_step.hip):
+    int2* info;         // [M] per position b: (first sorted position j0 of its segment | members n << 16, segment index)
+    unsigned int* cnt;  // [n_seg] arrival counters of the segments, zeroed here
+    int32_t* stamp;     // table stamps: stamp[row] = max(stamp[row], stamp_val) for every distinct row of the list, so
+    int stamp_val;      //   that the sweeper waves of the step's launch leave the rows of the batch alone
 };
 
 // Sort index lists in one launch, one workgroup each: (a) or (a, b) of the same length M ...

@@ -246,6 +246,35 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_segments_kernel(SortJobList
         job.seg_start[total] = scratch[17];   // number of real (non-padding) ids
         job.n_seg[0] = total;
     }
+    if (job.info) {
+        // per batch position: where its segment starts and how many members it has (the sorted keys in LDS are not needed
+        // any more: their space holds the segment starts)
+        int* ss = reinterpret_cast<int*>(keys);
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < KPT; ++q) {
+            const int j = q * SORT_THREADS + tid;
+            if ((bal[q] >> lane) & 1ull) {
+                const int seg = wcnt[q * 16 + wid] + __popcll(bal[q] & lt_mask);
+                ss[seg] = j;
+                if (job.stamp) atomicMax(&job.stamp[(unsigned)(key[q] >> 32)], job.stamp_val);
+            }
+        }
+        if (tid == 0) ss[total] = scratch[17];
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < KPT; ++q) {
+            const int j = q * SORT_THREADS + tid;
+            const unsigned long long k = key[q];
+            if (j < M && (unsigned)(k >> 32) != 0xFFFFFFFFu) {
+                const int seg = wcnt[q * 16 + wid] + __popcll(bal[q] & (lt_mask | (1ull << lane))) - 1;
+                const int j0 = ss[seg];
+                job.info[(unsigned)k] = make_int2(j0 | ((ss[seg + 1] - j0) << 16), seg);
+            }
+        }
+        if (job.cnt)
+            for (int q = tid; q < total; q += SORT_THREADS) job.cnt[q] = 0u;
+    }
     SORT_STAMP(14);
 }
 

@@ -76,6 +76,16 @@ class FocfEngine:
         # FR_FOCF_ITEM_RUNS (a hint, same results either way): the batches are item-complete (FOCFDataLoader), the
         # interactions of an item sit side by side -- the gather kernel then replays an item row once per workgroup
         self.item_runs = False
+        # fr_focf_step: the whole step as ONE launch (rows stay in registers from the gather to the Adam write-back).
+        # Taken when the loss is read after optimizer.step() (defer_loss), the objective needs no batch-wide value between
+        # forward and update (all but nonparity), no clip_grad_norm is asked for and the batches are not item-complete
+        # (rows shared by ~100 interactions are finished by ONE wave there; the three-launch chain spreads them).
+        self.fused_step = True
+        self._stash = None              # batch of a fused step: launched by backward_adam()
+        self._prev = None               # (workspace, B, loss view) of the last fused step, its loss not reduced yet
+        self._stamp_last = 0            # stamps handed to fr_focf_prepare_step never decrease
+        self._stamp_gen = (self.U.stamp_gen, self.I.stamp_gen)
+        self.loss_acc = torch.zeros(4, dtype=torch.float32, device=self.device)   # running (loss, mse, fair) total
 
     # --- optimizer plumbing ---------------------------------------------------------------------------
     def tables(self) -> Dict[str, LazyTable]:
@@ -116,8 +126,10 @@ class FocfEngine:
         main = torch.cuda.current_stream()
         busy = {self.ws_cur} | {v[0] for v in self._prep.values()}
         arr = (_C.FrFocfBatch * len(batches))()
+        stamps = (ctypes.c_int32 * len(batches))()
         group = {"done": torch.cuda.Event(), "joined": False}
         entries = []
+        self._check_stamp_gen()
         for q, (user, item, sst) in enumerate(batches):
             if len(busy) >= self.N_WS:
                 raise _C.FairrecError("too many batches prepared ahead")
@@ -129,16 +141,33 @@ class FocfEngine:
             ws = self._workspace(B, k)
             arr[q] = _C.FrFocfBatch(user.data_ptr(), item.data_ptr(), _C.ptr(sst if self.objective != 0 else None), B,
                                     ws.data_ptr(), ws.numel())
-            entries.append((self._key(user, item), (k, group)))
+            stamps[q] = self._next_stamp(q)
+            entries.append((self._key(user, item), (k, group, int(stamps[q]))))
         # everything that last used these workspaces was enqueued before this point
         start = torch.cuda.Event()
         start.record(main)
         self._side.wait_event(start)
-        rc = _C.lib().fr_focf_prepare_many(arr, len(batches), self.U.n_rows, self.I.n_rows, self.U.dim,
+        self.U.ensure_state()
+        self.I.ensure_state()
+        tu, ti = self.U.c(), self.I.c()
+        rc = _C.lib().fr_focf_prepare_step(arr, stamps, len(batches), ctypes.byref(tu), ctypes.byref(ti),
                                            self.err_flag.data_ptr(), self._side.cuda_stream)
-        _C.check(rc, "fr_focf_prepare_many")
+        _C.check(rc, "fr_focf_prepare_step")
         group["done"].record(self._side)
         self._prep.update(entries)
+
+    def _next_stamp(self, ahead: int = 0) -> int:
+        """Stamp of a batch about to be prepared: the step at which it is expected to be applied, never decreasing."""
+        s = max(self._stamp_last + 1, self.U.step + 1 + ahead)
+        self._stamp_last = s
+        return s
+
+    def _check_stamp_gen(self):
+        """The tables' stamps were reset (optimizer state reloaded): what was prepared ahead lost its stamps."""
+        gen = (self.U.stamp_gen, self.I.stamp_gen)
+        if gen != self._stamp_gen:
+            self._stamp_gen = gen
+            self._join_prepare()
 
     def _join_prepare(self):
         """Order the current stream behind every sort launch still in flight, and forget what they prepared."""
@@ -153,13 +182,21 @@ class FocfEngine:
         order (a dataloader's prefetch queue): their index sorts are launched ahead, GROUP batches per launch."""
         B = user.numel()
         flags = 0
+        self._check_stamp_gen()
+        if self._stash is not None:
+            raise _C.FairrecError("calculate_loss twice without optimizer.step() in between (fused step)")
         hit = self._prep.pop(self._key(user, item), None)
+        stamp = None
         if hit is not None:
-            self.ws_cur, group = hit
+            self.ws_cur, group, stamp = hit
             if not group["joined"]:                              # one join per GROUP of batches, not per step
                 torch.cuda.current_stream().wait_event(group["done"])
                 group["joined"] = True
             flags = 1                                            # FR_FOCF_PREPARED
+        elif self._prev is not None and self._prev[0] is self.ws[self.ws_cur]:
+            self.ws_cur = (self.ws_cur + 1) % self.N_WS          # that workspace still holds an unreduced loss
+            while self.ws_cur in {v[0] for v in self._prep.values()}:
+                self.ws_cur = (self.ws_cur + 1) % self.N_WS
         if self.defer_loss and self.optimizer is not None:
             flags |= 2                                           # FR_FOCF_DEFER_LOSS
         if self.item_runs:
@@ -180,9 +217,28 @@ class FocfEngine:
                 self.prepare_many(todo[:self.GROUP])
         self.loss_slot = (self.loss_slot + 1) % self.LOSS_SLOTS
         loss = self._loss_views[self.loss_slot]
-        pred = torch.empty(B, dtype=torch.float32, device=self.device) if want_pred else None
-        tu, ti = self.U.c(self.U.step + 1), self.I.c(self.I.step + 1)
         self.hyper.check_step(self.U.step + 1)
+        if (self.fused_step and self.defer_loss and self.optimizer is not None and self.objective != 5 and not want_pred
+                and not self.item_runs and self.U.step == self.I.step):
+            # one launch for the whole step, issued by backward_adam(); the index side must be there first
+            if stamp is None:
+                arr = (_C.FrFocfBatch * 1)(_C.FrFocfBatch(user.data_ptr(), item.data_ptr(),
+                                                          _C.ptr(sst if self.objective != 0 else None), B, ws.data_ptr(),
+                                                          ws.numel()))
+                stamp = self._next_stamp()
+                tu, ti = self.U.c(), self.I.c()
+                rc = _C.lib().fr_focf_prepare_step(arr, (ctypes.c_int32 * 1)(stamp), 1, ctypes.byref(tu), ctypes.byref(ti),
+                                                   self.err_flag.data_ptr(), _C.current_stream())
+                _C.check(rc, "fr_focf_prepare_step")
+            self._stash = (user, item, rating, sst, B, ws, stamp, loss)
+            self.pending_B = B
+            return loss, None
+        pred = torch.empty(B, dtype=torch.float32, device=self.device) if want_pred else None
+        return self._forward_chain(user, item, rating, sst, B, flags, ws, loss, pred)
+
+    def _forward_chain(self, user, item, rating, sst, B, flags, ws, loss, pred):
+        """fr_focf_forward: the three-launch chain (gather, fairness, [loss]); backward_adam() finishes the step."""
+        tu, ti = self.U.c(self.U.step + 1), self.I.c(self.I.step + 1)
         rc = _C.lib().fr_focf_forward(ctypes.byref(tu), ctypes.byref(ti), ctypes.byref(self.hyper.c()),
                                       user.data_ptr(), item.data_ptr(), rating.data_ptr(), _C.ptr(sst), B,
                                       self.objective, self.fair_weight, flags, ws.data_ptr(), ws.numel(),
@@ -196,6 +252,10 @@ class FocfEngine:
         embedding gradients (fr_focf_clip_grad_norm); returns the device pair (total_norm, clip_coef)."""
         if self.pending_B == 0:
             raise _C.FairrecError("clip_grad_norm without a preceding calculate_loss()")
+        if self._stash is not None:       # the norm needs every gradient row before any update: three-launch chain
+            user, item, rating, sst, B, ws, _, loss = self._stash
+            self._stash = None
+            self._forward_chain(user, item, rating, sst, B, 1 | 2, ws, loss, None)    # PREPARED | DEFER_LOSS
         if not hasattr(self, "_clip_out"):
             self._clip_out = torch.zeros(2, dtype=torch.float32, device=self.device)
         tu, ti = self.U.c(self.U.step + 1), self.I.c(self.I.step + 1)
@@ -213,15 +273,38 @@ class FocfEngine:
             raise _C.FairrecError("no optimizer bound: build fairrec.optim.FusedLazyAdam(model.hip_engine(), ...)")
         B = self.pending_B
         tu, ti = self.U.c(self.U.step + 1), self.I.c(self.I.step + 1)
-        rc = _C.lib().fr_focf_backward_adam(ctypes.byref(tu), ctypes.byref(ti), ctypes.byref(self.hyper.c()), B,
-                                            self._sweep(B), self.ws[self.ws_cur].data_ptr(),
-                                            self.ws[self.ws_cur].numel(), _C.current_stream())
-        _C.check(rc, "fr_focf_backward_adam")
+        if self._stash is not None:
+            user, item, rating, sst, B, ws, stamp, loss = self._stash
+            self._stash = None
+            pw, pB, ploss = self._prev if self._prev is not None else (None, 0, None)
+            rc = _C.lib().fr_focf_step(ctypes.byref(tu), ctypes.byref(ti), ctypes.byref(self.hyper.c()),
+                                       user.data_ptr(), item.data_ptr(), rating.data_ptr(), _C.ptr(sst), B,
+                                       self.objective, self.fair_weight, self._sweep(B), stamp, ws.data_ptr(), ws.numel(),
+                                       loss.data_ptr(), _C.ptr(pw), pB, _C.ptr(ploss), self.loss_acc.data_ptr(),
+                                       self.err_flag.data_ptr(), _C.current_stream())
+            _C.check(rc, "fr_focf_step")
+            self._prev = (ws, B, loss)
+            self._keep = (user, item, rating, sst)
+        else:
+            rc = _C.lib().fr_focf_backward_adam(ctypes.byref(tu), ctypes.byref(ti), ctypes.byref(self.hyper.c()), B,
+                                                self._sweep(B), self.ws[self.ws_cur].data_ptr(),
+                                                self.ws[self.ws_cur].numel(), _C.current_stream())
+            _C.check(rc, "fr_focf_backward_adam")
         self.U.step += 1
         self.I.step += 1
         self.U._dirty = self.I._dirty = True
         self.pending_B = 0
         self.backward_seen = False
+
+    def finish(self):
+        """Reduce the loss of the last fused step (fr_focf_step_finish): its loss slot and `loss_acc` are complete on the
+        stream after this.  A later fused step would have done it in passing."""
+        if self._prev is not None:
+            ws, B, loss = self._prev
+            self._prev = None
+            rc = _C.lib().fr_focf_step_finish(ws.data_ptr(), ws.numel(), B, self.U.dim, self.objective, self.fair_weight,
+                                              loss.data_ptr(), self.loss_acc.data_ptr(), _C.current_stream())
+            _C.check(rc, "fr_focf_step_finish")
 
     def predict(self, user, item):
         self._join_prepare()
@@ -236,11 +319,13 @@ class FocfEngine:
 
     def flush(self):
         self._join_prepare()
+        self.finish()
         self.U.flush(self.hyper)
         self.I.flush(self.hyper)
 
     def check_device_errors(self):
         """Host sync: raise what the reference would have raised eagerly (IndexError)."""
+        self.finish()
         e = int(self.err_flag.item())
         if e:
             self.err_flag.zero_()

@@ -81,6 +81,7 @@ class LazyTable:
         self.trainable = trainable
         self.step = 0            # optimizer steps applied so far (torch: state['step'])
         self.m = self.v = self.last = self.stamp = None
+        self.stamp_gen = 0       # bumped whenever the stamps are reset: look-ahead stamping done before is void
         self._ws = None
         self._pending = None
         self._keep = None
@@ -268,6 +269,7 @@ class LazyTable:
         self.v.copy_(state["exp_avg_sq"])
         self.last.fill_(self.step)
         self.stamp.zero_()          # stamps name the step of the batch that owns a row: none after a reload
+        self.stamp_gen += 1
         if self.step_dev is not None:
             self.step_dev.fill_(self.step)
         self._dirty = False

@@ -30,15 +30,19 @@ def _engine(z, sweep):
     return eng
 
 
-@pytest.mark.parametrize("sweep", [0, 3, None, "lookahead", "lookahead2"],
-                         ids=["nosweep", "sweep3", "sweepdefault", "lookahead", "lookahead2"])
+@pytest.mark.parametrize("sweep", [0, 3, None, "lookahead", "lookahead2", "fused", "fused_ahead", "fused_nosweep"],
+                         ids=["nosweep", "sweep3", "sweepdefault", "lookahead", "lookahead2", "fused", "fused_ahead",
+                              "fused_nosweep"])
 @pytest.mark.parametrize("path", CASES, ids=[os.path.basename(p)[:-4] for p in CASES])
 def test_training_matches_reference_golden(path, sweep):
     z = np.load(path)
     # "lookahead": the next batch's index sort runs one step ahead on a side stream, stamps the batch's rows and carries
     # the sweep slice of the step in flight
-    lookahead = {"lookahead": 1, "lookahead2": 5}.get(sweep, 0)      # how many coming batches are announced
-    eng = _engine(z, 3 if lookahead else sweep)
+    lookahead = {"lookahead": 1, "lookahead2": 5, "fused_ahead": 5}.get(sweep, 0)   # coming batches announced
+    # "fused*": the whole step as ONE launch (fr_focf_step); the loss of a step is reduced by the next step's launch
+    fused = isinstance(sweep, str) and sweep.startswith("fused")
+    eng = _engine(z, 0 if sweep == "fused_nosweep" else (3 if (lookahead or fused) else sweep))
+    eng.defer_loss = fused
     snaps = set(int(s) for s in z["snaps"])
     T = z["user_id"].shape[0]
     dev = "cuda"
@@ -48,9 +52,9 @@ def test_training_matches_reference_golden(path, sweep):
         u, i, r, s = (cols[k][t] for k in ("user_id", "item_id", "rating", "sst"))
         nxt = [(cols["user_id"][j], cols["item_id"][j], cols["sst"][j]) for j in range(t + 1, t + 1 + lookahead) if j < T]
         nxt = (nxt[0] if lookahead == 1 else nxt) if nxt else None
-        loss, pred = eng.forward(u, i, r, s, want_pred=(t == 0), next_batch=nxt)
-        losses.append(loss.clone())
-        if t == 0:
+        loss, pred = eng.forward(u, i, r, s, want_pred=(t == 0 and not fused), next_batch=nxt)
+        losses.append(loss if fused else loss.clone())
+        if t == 0 and not fused:
             _close(pred.cpu().numpy(), z["pred_step1"], "pred step 1", atol=1e-6)
         if "clip_max_norm" in z:      # config clip_grad_norm: the optimizer's step() calls this before the backward launch
             norm = eng.clip_grad_norm(float(z["clip_max_norm"]))
@@ -64,6 +68,10 @@ def test_training_matches_reference_golden(path, sweep):
                 mref, vref = z[f"m{tag}_after{t + 1}"], z[f"v{tag}_after{t + 1}"]
                 _close(tab.m.cpu().numpy(), mref, f"m{tag} after {t + 1}", atol=1e-6 * np.abs(mref).max())
                 _close(tab.v.cpu().numpy(), vref, f"v{tag} after {t + 1}", atol=1e-6 * np.abs(vref).max())
+    eng.finish()
+    if fused and "clip_max_norm" not in z and str(z["objective"]) != "nonparity":
+        assert eng._prev is None and eng.U.step == T
+        np.testing.assert_allclose(float(eng.loss_acc[0]), float(np.sum(z["loss"], dtype=np.float64)), rtol=1e-4)
     got = torch.stack(losses).cpu().numpy()[:, 0]
     _close(got, z["loss"], "loss curve", atol=1e-6)
     eng.check_device_errors()
@@ -134,23 +142,33 @@ def test_lookahead_sweep_equals_plain_chain(objective, dim, item_dist):
     U0 = (torch.randn(n_users, dim, generator=g) * 0.1).cuda()
     I0 = (torch.randn(n_items, dim, generator=g) * 0.1).cuda()
     engs = []
-    modes = (0, 1, 6)           # coming batches announced to the engine
+    modes = (0, 1, 6, 7)        # coming batches announced to the engine; 7: the whole step as one launch (fr_focf_step)
     for ahead in modes:
         eng = FocfEngine(U0.clone(), I0.clone(), objective, 0.5, 5.0)
         FusedLazyAdam(eng, lr=1e-2, weight_decay=1e-3, sweep_period=4)
-        eng.defer_loss = ahead == 6      # loss reduced by the backward launch (read after backward_adam below)
+        eng.defer_loss = ahead >= 6      # loss reduced by the backward launch (read after backward_adam below)
         eng.item_runs = ahead == 1       # item row replayed once per workgroup of the gather kernel (a hint only)
         engs.append(eng)
+    fused_losses = []
     for t in range(T):
         out = []
         for eng, ahead in zip(engs, modes):
             nxt = [(u[j], i[j], s[j]) for j in range(t + 1, t + 1 + ahead) if j < T] or None
-            loss, pred = eng.forward(u[t], i[t], r[t], s[t], want_pred=True, next_batch=nxt)
+            loss, pred = eng.forward(u[t], i[t], r[t], s[t], want_pred=ahead != 7, next_batch=nxt)
             eng.backward_adam()
-            out.append((loss.clone(), pred))
+            if ahead == 7:
+                fused_losses.append(loss)          # filled by the next step's launch / finish()
+                assert (eng._prev is not None) == (objective != "nonparity")
+            else:
+                out.append((loss.clone(), pred))
         for o in out[1:]:
             torch.testing.assert_close(o[0][:3], out[0][0][:3], rtol=2e-5, atol=1e-7)
             torch.testing.assert_close(o[1], out[0][1], rtol=2e-5, atol=1e-6)
+        if t > 0:
+            torch.testing.assert_close(fused_losses[t - 1][:3], prev_loss, rtol=2e-5, atol=1e-7)
+        prev_loss = out[0][0][:3]
+    engs[-1].finish()
+    torch.testing.assert_close(fused_losses[-1][:3], prev_loss, rtol=2e-5, atol=1e-7)
     for eng in engs:
         eng.flush()
         eng.check_device_errors()
@@ -189,6 +207,8 @@ def test_full_size_steps_match_the_oracle():
         coming = [(ud[j], idv[j], sd[j]) for j in range(t + 1, T)] or None
         loss, _ = eng.forward(ud[t], idv[t], rd[t], sd[t], next_batch=coming)
         eng.backward_adam()
+        assert eng._prev is not None          # the fused one-launch step (fr_focf_step) is what runs here
+        eng.finish()
         assert abs(float(loss[0]) - want) <= 1e-4 * abs(want), (t, float(loss[0]), want)
     eng.flush()
     eng.check_device_errors()
@@ -212,10 +232,11 @@ def test_prefetch_queue_over_epochs_matches_plain_steps():
     I0 = (torch.randn(n_items, D, generator=g) * 0.05).cuda()
     gender = torch.randint(0, 2, (n_users,), generator=g).float()
     engs = []
-    for k in range(2):
+    for k in range(3):      # 0: plain steps; 1: prefetch queue, three-launch chain; 2: prefetch queue, one-launch step
         eng = FocfEngine(U0.clone(), I0.clone(), "value", 0.3, 5.0)
         FusedLazyAdam(eng, lr=5e-3, weight_decay=1e-3, sweep_period=7)
-        eng.defer_loss = eng.item_runs = k == 1
+        eng.defer_loss = k >= 1
+        eng.item_runs = k == 1
         engs.append(eng)
     for epoch in range(3):
         batches = []
@@ -230,17 +251,20 @@ def test_prefetch_queue_over_epochs_matches_plain_steps():
             engs[0].forward(u, i, r, s)
             engs[0].backward_adam()
             queue = [(b[0], b[1], b[3]) for b in batches[t + 1:t + 11]] or None
-            engs[1].forward(u, i, r, s, next_batch=queue)
-            engs[1].backward_adam()
+            for eng in engs[1:]:
+                eng.forward(u, i, r, s, next_batch=queue)
+                eng.backward_adam()
+            assert engs[1]._prev is None and engs[2]._prev is not None
         for eng in engs:
             eng.flush()                                              # evaluation / checkpoint between epochs
             eng.check_device_errors()
-        assert not engs[1]._prep, "the queue must be empty at an epoch end"
-    a, b = engs
-    for x, y in ((b.U.weight, a.U.weight), (b.I.weight, a.I.weight), (b.U.v, a.U.v), (b.I.m, a.I.m)):
-        # the two schedules split a row's replay into different stretches (rounding of the moment scaling): the parity
-        # tolerance, with the absolute floor scaled to the tensor
-        torch.testing.assert_close(x, y, rtol=1e-4, atol=1e-6 * float(y.abs().max()) + 1e-12)
+        assert not engs[1]._prep and not engs[2]._prep, "the queue must be empty at an epoch end"
+    a = engs[0]
+    for b in engs[1:]:
+        for x, y in ((b.U.weight, a.U.weight), (b.I.weight, a.I.weight), (b.U.v, a.U.v), (b.I.m, a.I.m)):
+            # the schedules split a row's replay into different stretches (rounding of the moment scaling): the parity
+            # tolerance, with the absolute floor scaled to the tensor
+            torch.testing.assert_close(x, y, rtol=1e-4, atol=1e-6 * float(y.abs().max()) + 1e-12)
 
 
 def test_optimizer_step_clips_like_the_reference_loop():
@@ -276,6 +300,7 @@ def test_deferred_loss_with_interleaved_engines():
     z = np.load(os.path.join(os.path.dirname(__file__), "golden", "focf_value.npz"))
     ref, a, b = _engine(z, 3), _engine(z, 3), _engine(z, 3)
     a.defer_loss = b.defer_loss = True
+    b.fused_step = False          # a: one-launch step (loss reduced by the next step / finish()); b: three-launch chain
     for t in range(6):
         cols = [torch.tensor(z[k][t], device="cuda") for k in ("user_id", "item_id", "rating", "sst")]
         lr, _ = ref.forward(*cols)
@@ -285,6 +310,7 @@ def test_deferred_loss_with_interleaved_engines():
         lb, _ = b.forward(*cols)
         a.backward_adam()
         b.backward_adam()
+        a.finish()
         torch.testing.assert_close(la[:3], lr[:3], rtol=1e-6, atol=0)
         torch.testing.assert_close(lb[:3], lr[:3], rtol=1e-6, atol=0)
 
