@@ -169,12 +169,12 @@ def main():
 
     _rows = {}
 
-    def coming(k, ub, ib, sb, stop=None):
+    def coming(k, ub, ib, sb, rb, stop=None):
         # the next batches, dataloader-style prefetch queue: the engine sorts their id columns ahead on a side stream,
         # GROUP batches per launch (the row views are made once per tensor, not once per step)
         key = id(ub)
         if key not in _rows:
-            _rows[key] = [(ub[j], ib[j], sb[j]) for j in range(ub.shape[0])]
+            _rows[key] = [(ub[j], ib[j], sb[j], rb[j]) for j in range(ub.shape[0])]
         rows = _rows[key]
         hi = min(k + 11, len(rows), stop if stop is not None else len(rows))
         return rows[k + 1:hi] or None
@@ -184,7 +184,7 @@ def main():
             nxt = (u[k + 1], i[k + 1], s[k + 1]) if k + 1 < n_batches and k != W - 1 else None
             eng.forward(u[k], i[k], r[k], s[k], next_batch=nxt)
         else:         # no look-ahead across the warm-up / captured-graph boundary either
-            eng.forward(u[k], i[k], r[k], s[k], next_batch=coming(k, u, i, s, stop=W if k < W else None))
+            eng.forward(u[k], i[k], r[k], s[k], next_batch=coming(k, u, i, s, r, stop=W if k < W else None))
         eng.backward_adam()
 
     def barrier():
@@ -195,11 +195,12 @@ def main():
     # Age the optimizer state first (set-up, not measured): every row's replay length depends on how long ago it was
     # last touched, and that distribution is stationary only after one full sweep period -- a fresh table has nothing
     # to replay, which would flatter the first `sweep_period` timed steps.
+    n_age = 0
     if not sharded and args.age >= 0:
         n_age = args.age if args.age else (eng._sweep(BATCH) if (args.sweep is None or args.sweep > 0) else 256)
         ua, ia, ra, sa = (t.to(dev) for t in synth_batches(n_age, BATCH, N_USERS, N_ITEMS, SEED + 104729 + rank, args.item_dist))
         for k in range(n_age):
-            eng.forward(ua[k], ia[k], ra[k], sa[k], next_batch=coming(k, ua, ia, sa))
+            eng.forward(ua[k], ia[k], ra[k], sa[k], next_batch=coming(k, ua, ia, sa, ra))
             eng.backward_adam()
         torch.cuda.synchronize()
         del ua, ia, ra, sa
@@ -255,11 +256,11 @@ def main():
         # worth of work launched eagerly as well (fresh batches, same distribution) and report the faster of the two
         # regions; both times are in `config`.
         ue, ie, re_, se = (t.to(dev) for t in synth_batches(K, BATCH, N_USERS, N_ITEMS, SEED + 15485863 + rank, args.item_dist))
-        coming(0, ue, ie, se)           # row views made outside the timed region, as for the graph's batches
+        coming(0, ue, ie, se, re_)      # row views made outside the timed region, as for the graph's batches
         barrier()
         t0 = time.perf_counter()
         for k in range(K):
-            eng.forward(ue[k], ie[k], re_[k], se[k], next_batch=coming(k, ue, ie, se))
+            eng.forward(ue[k], ie[k], re_[k], se[k], next_batch=coming(k, ue, ie, se, re_))
             eng.backward_adam()
         barrier()
         dt_eager = time.perf_counter() - t0
@@ -279,7 +280,7 @@ def main():
         if sharded:
             nxt = (u2[k + 1], i2[k + 1], s2[k + 1]) if k + 1 < K else None
         else:
-            nxt = coming(k, u2, i2, s2)
+            nxt = coming(k, u2, i2, s2, r2)
         eng.forward(u2[k], i2[k], r2[k], s2[k], next_batch=nxt)
         eng.backward_adam()
     torch.cuda.synchronize()

@@ -158,6 +158,7 @@ typedef struct fr_focf_batch {
     int64_t B;
     void* ws;
     size_t ws_bytes;
+    const float* rating;   /* fr_focf_prepare_step only (fr_focf_prepare_many ignores it) */
 } fr_focf_batch;
 FR_API int fr_focf_prepare_many(const fr_focf_batch* batches, int32_t n, int64_t n_users, int64_t n_items, int32_t dim,
                          uint32_t* err_flag, void* stream);
@@ -195,7 +196,9 @@ FR_API int fr_focf_backward_adam(const fr_table* U, const fr_table* I, const fr_
  * the gather to the Adam write-back; rows shared by several interactions of the batch are finished by the last of
  * their waves to arrive (csrc/focf_step.hip).
  *   fr_focf_prepare_step : fr_focf_prepare_many plus what the fused launch needs from the index side: per batch
- *                          position the extent of its user / item segment, zeroed arrival counters, and
+ *                          position one packed record (user row, item row, rating, sst) -- ids range-checked here, so
+ *                          the step itself reads no id column -- and the extent of its user / item segment, zeroed
+ *                          arrival counters, and
  *                          stamp[row] = max(stamp[row], stamps[q]) on every row of batch q in both tables -- the
  *                          sweeper waves of fr_focf_step leave rows stamped >= its `stamp` argument alone.  Callable
  *                          ahead on another stream (depends on the id columns only; the stamp raise is an atomic max).

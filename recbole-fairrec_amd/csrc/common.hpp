@@ -219,28 +219,104 @@ __device__ __forceinline__ void replay_loop(RowFrag<E>* (&p)[NR], RowFrag<E>* (&
     }
 }
 
+// The scaled replay on N values per lane held as explicit 2-vectors: v_pk_fma_f32 / v_pk_mul_f32 do two elements per
+// issue slot (the two transcendentals stay one element each), 4.5 instead of 7 VALU instructions per 64-element row and
+// step when two rows (or two 64-column halves of one row) go through together.  Left to the SLP vectoriser the loop came
+// out packing m with v of ONE row behind extra moves (7.2 instructions per row and step, measured with SQ_INSTS_VALU).
+typedef float v2f_ __attribute__((ext_vector_type(2)));
+typedef const v2f_ __attribute__((address_space(4))) * ConstF2Ptr;
+
+template <int NP, bool ODD>
+__device__ __forceinline__ void replay_scaled_step(v2f_ (&P)[NP ? NP : 1], v2f_ (&M)[NP ? NP : 1], v2f_ (&V)[NP ? NP : 1],
+                                                   float& ps, float& ms, float& vs, float A, float Bc, float b1,
+                                                   float b2) {
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+        M[k] = __builtin_elementwise_fma(v2f_{b1, b1}, M[k], P[k]);
+        V[k] = __builtin_elementwise_fma(v2f_{b2, b2}, V[k], P[k] * P[k]);
+        const v2f_ sq = {__builtin_amdgcn_sqrtf(V[k].x), __builtin_amdgcn_sqrtf(V[k].y)};
+        const v2f_ den = __builtin_elementwise_fma(sq, v2f_{A, A}, v2f_{Bc, Bc});
+        const v2f_ r = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+        P[k] = __builtin_elementwise_fma(-M[k], r, P[k]);
+    }
+    if (ODD) {
+        ms = fmaf(b1, ms, ps);
+        vs = fmaf(b2, vs, ps * ps);
+        const float den = fmaf(__builtin_amdgcn_sqrtf(vs), A, Bc);
+        ps = fmaf(-ms, __builtin_amdgcn_rcpf(den), ps);
+    }
+}
+
+template <int E, int NR>
+__device__ __forceinline__ void replay_scaled(RowFrag<E>* (&p)[NR], RowFrag<E>* (&m)[NR], RowFrag<E>* (&v)[NR], int j,
+                                              int to, const AdamC& c) {
+    constexpr int N = E * NR, NP = N / 2;
+    constexpr bool ODD = (N & 1) != 0;
+    // element k of the flat list = (row k % NR, fragment k / NR): the two rows of a pair share a 2-vector
+    v2f_ P[NP ? NP : 1], M[NP ? NP : 1], V[NP ? NP : 1];
+    float ps = 0.f, ms = 0.f, vs = 0.f;
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+        const int a = 2 * k, b = 2 * k + 1;
+        P[k] = v2f_{p[a % NR]->x[a / NR] , p[b % NR]->x[b / NR]};
+        M[k] = v2f_{m[a % NR]->x[a / NR] * c.inv_k1, m[b % NR]->x[b / NR] * c.inv_k1};
+        V[k] = v2f_{v[a % NR]->x[a / NR] * c.inv_k2, v[b % NR]->x[b / NR] * c.inv_k2};
+    }
+    if (ODD) {
+        ps = p[(N - 1) % NR]->x[(N - 1) / NR];
+        ms = m[(N - 1) % NR]->x[(N - 1) / NR] * c.inv_k1;
+        vs = v[(N - 1) % NR]->x[(N - 1) / NR] * c.inv_k2;
+    }
+    auto one = [&](float A, float Bc) { replay_scaled_step<NP, ODD>(P, M, V, ps, ms, vs, A, Bc, c.b1, c.b2); };
+    // main part: 4 steps per iteration; their (A, B) pairs are fetched (four s_load_dwordx2: 8 SGPRs, not the 16 of whole
+    // table entries) one iteration ahead
+    const int lim = to < c.cap ? to : c.cap;
+    if (j + 3 <= lim) {
+        ConstF2Ptr tab = (ConstF2Ptr)(c.sc + 2 * j) + 1;   // c.sc is float2*: entry j = floats 4j..4j+3, (A, B) = its 2nd half
+        v2f_ c0 = tab[0], c1 = tab[2], c2 = tab[4], c3 = tab[6];
+        for (; j + 7 <= lim; j += 4) {
+            tab += 8;
+            const v2f_ n0 = tab[0], n1 = tab[2], n2 = tab[4], n3 = tab[6];
+            one(c0.x, c0.y);
+            one(c1.x, c1.y);
+            one(c2.x, c2.y);
+            one(c3.x, c3.y);
+            c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        }
+        one(c0.x, c0.y);
+        one(c1.x, c1.y);
+        one(c2.x, c2.y);
+        one(c3.x, c3.y);
+        j += 4;
+    }
+    // remainder (< 4 steps inside the table, and every step beyond `cap`, where the scalars are constant)
+    for (; j <= to; ++j) {
+        const float4 s = step_scalars4(c, j);
+        one(s.z, s.w);
+    }
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+        const int a = 2 * k, b = 2 * k + 1;
+        p[a % NR]->x[a / NR] = P[k].x;
+        p[b % NR]->x[b / NR] = P[k].y;
+        m[a % NR]->x[a / NR] = M[k].x * c.k1;
+        m[b % NR]->x[b / NR] = M[k].y * c.k1;
+        v[a % NR]->x[a / NR] = V[k].x * c.k2;
+        v[b % NR]->x[b / NR] = V[k].y * c.k2;
+    }
+    if (ODD) {
+        p[(N - 1) % NR]->x[(N - 1) / NR] = ps;
+        m[(N - 1) % NR]->x[(N - 1) / NR] = ms * c.k1;
+        v[(N - 1) % NR]->x[(N - 1) / NR] = vs * c.k2;
+    }
+}
+
 template <int E, int NR>
 __device__ __forceinline__ void replay_n(RowFrag<E>* (&p)[NR], RowFrag<E>* (&m)[NR], RowFrag<E>* (&v)[NR], int from,
                                          int to, const AdamC& c) {
     if (from >= to) return;
     if (!FR_ADAM_PRECISE && c.k1 != 0.f) {   // wave-uniform: weight decay on -> scaled moments
-#pragma unroll
-        for (int r = 0; r < NR; ++r) {
-#pragma unroll
-            for (int e = 0; e < E; ++e) {
-                m[r]->x[e] *= c.inv_k1;
-                v[r]->x[e] *= c.inv_k2;
-            }
-        }
-        replay_loop<E, NR, true>(p, m, v, from + 1, to, c);
-#pragma unroll
-        for (int r = 0; r < NR; ++r) {
-#pragma unroll
-            for (int e = 0; e < E; ++e) {
-                m[r]->x[e] *= c.k1;
-                v[r]->x[e] *= c.k2;
-            }
-        }
+        replay_scaled<E, NR>(p, m, v, from + 1, to, c);
     } else {
         replay_loop<E, NR, false>(p, m, v, from + 1, to, c);
     }

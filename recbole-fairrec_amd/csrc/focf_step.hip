@@ -22,6 +22,10 @@
 // The sweeper slice of the step (bounded staleness) rides in the same launch: its rows are told from the
 // batch's rows by stamps that the look-ahead sort wrote (fr_focf_prepare_step), so both kinds of wave start at once and the
 // sweeper's VALU work hides the interaction waves' two dependent load levels.
+#include <stdlib.h>
+
+#include <algorithm>
+
 #include "common.hpp"
 #include "kernels.hpp"
 #include "table.hpp"
@@ -41,19 +45,34 @@ struct PrevLoss {
     float* acc;        // optional [3]: += the three values (a running epoch total kept on the device)
 };
 
+// Kernel arguments, kept to what the common path reads (every pointer is two SGPRs that stay live across the whole
+// kernel; 256-thread workgroups are admitted 8 per CU only up to 80 SGPRs): the rare path derives the other workspace
+// arrays from `ws` on the device.
 struct StepArgs {
-    TableV U, I;
+    float *Up, *Um, *Uv;
+    int32_t *Ulast, *Ustamp;
+    float *Ip, *Im, *Iv;
+    int32_t *Ilast, *Istamp;
+    int D, step;              // embedding size and the optimizer step being applied (the same for both tables)
     AdamC c;
-    const int64_t *user, *item;
-    const float *rating, *sst;
     int B, objective;
     float fair_weight;
-    FocfWs w;
-    SweepSlice sw;
-    int n_sweep_blocks, n_inter_blocks;
+    const int4* rec;          // [B] (user row, item row, rating, sst), ids range-checked by fr_focf_prepare_step
+    const int4* info;         // [B] (j0 | n << 16, segment) of the user segment, then of the item segment
+    const int32_t* hdr;       // (K = distinct items, -, smin, smax)
+    float* mse_e;             // [B]
+    float* term;              // [K]
+    void* ws;
+    long long lo_u, lo_i;     // sweep slice: rows [lo, lo + n) of each table, brought to `step`;
+    int n_u, n_i, skip_from;  //   rows stamped >= skip_from belong to this or a coming batch and are left alone
     uint32_t* err;
     PrevLoss prev;
 };
+
+// The kernel reads its arguments through a reference into the kernarg segment (constant address space: scalar loads) that
+// is made opaque once per task: each task re-reads the handful of fields it needs right where it needs them, instead of
+// the compiler parking every field of the struct in SGPRs around the wave's task loop (106 SGPRs + 130 spilled ones).
+typedef const StepArgs __attribute__((address_space(4)))& SA;
 
 __device__ __forceinline__ float ld_sc1(const float* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -93,28 +112,28 @@ __device__ __forceinline__ bool arrive_last(unsigned int* cnt, int n, int lane) 
     return true;
 }
 
-// Adam step `T.step` with data gradient g on a caught-up row held in registers; the row is written back once
+// Adam step `step` with data gradient g on a caught-up row held in registers; the row is written back once
 template <int E>
-__device__ __forceinline__ void adam_write(const TableV& T, const AdamC& c, int row, RowFrag<E>& p, RowFrag<E>& m,
-                                           RowFrag<E>& v, const RowFrag<E>& g, float2 s, int lane) {
-    const int D = T.D;
+__device__ __forceinline__ void adam_write(float* Tp, float* Tm, float* Tv, int32_t* Tlast, int D, int step,
+                                           const AdamC& c, int row, RowFrag<E>& p, RowFrag<E>& m, RowFrag<E>& v,
+                                           const RowFrag<E>& g, float2 s, int lane) {
 #pragma unroll
     for (int e = 0; e < E; ++e) adam_elem(p.x[e], m.x[e], v.x[e], g.x[e], s.x, s.y, c);
-    store_row<E>(p, T.p + (size_t)row * D, D, lane);
-    store_row<E>(m, T.m + (size_t)row * D, D, lane);
-    store_row<E>(v, T.v + (size_t)row * D, D, lane);
-    if (lane == 0) T.last[row] = T.step;
+    store_row<E>(p, Tp + (size_t)row * D, D, lane);
+    store_row<E>(m, Tm + (size_t)row * D, D, lane);
+    store_row<E>(v, Tv + (size_t)row * D, D, lane);
+    if (lane == 0) Tlast[row] = step;
 }
 
 // g = sum over the members [j0, j0 + n) of a segment, in ascending batch position, of coef[b] * other[b, :] -- the product
 // rounded, then added (embedding_dense_backward's accumulation order), as segment_grad_sum of table.hpp, but on values
-// other waves of this launch handed over: sc1 loads throughout
+// other waves of this launch handed over: sc1 loads throughout.  Two members in flight (rare path: kept lean in registers).
 template <int E>
 __device__ __forceinline__ void handed_grad_sum(RowFrag<E>& g, int j0, int n, const int32_t* perm, const float* coef,
                                                 const float* other, int D, int lane) {
 #pragma unroll
     for (int e = 0; e < E; ++e) g.x[e] = 0.f;
-    constexpr int UN = 4;
+    constexpr int UN = 2;
     for (int jb = 0; jb < n; jb += 64) {
         const int cnt = min(64, n - jb);
         int my_b = 0;
@@ -128,7 +147,7 @@ __device__ __forceinline__ void handed_grad_sum(RowFrag<E>& g, int j0, int n, co
             float cb[UN];
 #pragma unroll
             for (int q = 0; q < UN; ++q) {
-                const int t = t0 + q < cnt ? t0 + q : cnt - 1;     // tail: re-read the last member, weight 0
+                const int t = t0 + q < cnt ? t0 + q : cnt - 1;     // tail: re-read the last member, not added
                 const int b = __builtin_amdgcn_readlane(my_b, t);
                 cb[q] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_c), t));
                 load_row_sc1<E>(o[q], other + (size_t)b * D, D, lane);
@@ -150,137 +169,110 @@ __device__ __forceinline__ void handed_grad_sum(RowFrag<E>& g, int j0, int n, co
     }
 }
 
+// Two rows A and B, current as of steps tA and tB, brought to `upto` (t >= upto: nothing to do for that row): the steps
+// only the staler row missed run on that row alone, the common tail on both rows as packed pairs.  ONE instance of this
+// serves the sweeper (two neighbouring rows of the slice) and the interactions (the user row and the item row).
+template <int E>
+struct TwoRows {
+    RowFrag<E> pA, mA, vA, pB, mB, vB;
+};
+
+template <int E>
+__device__ __forceinline__ void replay_two(TwoRows<E>& r, int tA, int tB, int upto, const AdamC& c, int lane) {
+    tA = tA < upto ? tA : upto;
+    tB = tB < upto ? tB : upto;
+    if (tA != tB) {     // wave-uniform
+        const bool a_old = tA < tB;
+        RowFrag<E> p, m, v;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            p.x[e] = a_old ? r.pA.x[e] : r.pB.x[e];
+            m.x[e] = a_old ? r.mA.x[e] : r.mB.x[e];
+            v.x[e] = a_old ? r.vA.x[e] : r.vB.x[e];
+        }
+        replay<E>(p, m, v, a_old ? tA : tB, a_old ? tB : tA, c, lane);
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            if (a_old) {
+                r.pA.x[e] = p.x[e]; r.mA.x[e] = m.x[e]; r.vA.x[e] = v.x[e];
+            } else {
+                r.pB.x[e] = p.x[e]; r.mB.x[e] = m.x[e]; r.vB.x[e] = v.x[e];
+            }
+        }
+    }
+    replay2<E>(r.pA, r.mA, r.vA, r.pB, r.mB, r.vB, tA > tB ? tA : tB, upto, c, lane);
+}
+
+// ---- rare path ----------------------------------------------------------------------------------------------------
 // The last wave to arrive at a user segment: sum the members' gradient rows coef[b] * (item row of b before its update),
 // one Adam step on the user's caught-up row (parked by its first member), write back.
 template <int E>
-__device__ __forceinline__ void user_finish(const StepArgs& a, int j0u, int nu, float2 s, int lane) {
-    const int D = a.U.D;
-    const int c0 = uniform(a.w.perm_u[j0u]);
-    long long ul = a.user[c0];
-    if (ul < 0 || ul >= a.U.n_rows) ul = 0;     // reported by the member's own wave
-    const int ur = uniform((int)ul);
+__device__ __forceinline__ void user_finish(SA a, const AdamC& c, const FocfWs& w, int j0u, int nu, float2 s, int lane) {
+    const int D = a.D;
+    const int c0 = uniform(w.perm_u[j0u]);
+    const int ur = uniform(a.rec[c0].x);
     RowFrag<E> p, m, v, g;
-    load_row_sc1<E>(p, a.w.side[0] + (size_t)c0 * D, D, lane);
-    load_row_sc1<E>(m, a.w.side[1] + (size_t)c0 * D, D, lane);
-    load_row_sc1<E>(v, a.w.side[2] + (size_t)c0 * D, D, lane);
-    handed_grad_sum<E>(g, j0u, nu, a.w.perm_u, a.w.coef, a.w.side[3], D, lane);
-    adam_write<E>(a.U, a.c, ur, p, m, v, g, s, lane);
+    load_row_sc1<E>(p, w.side[0] + (size_t)c0 * D, D, lane);
+    load_row_sc1<E>(m, w.side[1] + (size_t)c0 * D, D, lane);
+    load_row_sc1<E>(v, w.side[2] + (size_t)c0 * D, D, lane);
+    handed_grad_sum<E>(g, j0u, nu, w.perm_u, w.coef, w.side[3], D, lane);
+    adam_write<E>(a.Up, a.Um, a.Uv, a.Ulast, D, a.step, c, ur, p, m, v, g, s, lane);
 }
 
-// One interaction of the batch.
+// The rest of an interaction whose user or item row is shared with other interactions of the batch: hand over, then
+// whoever arrives last at a segment finishes it (3 % / 8 % of the interactions for uniform pairs at the BASELINE sizes).
 template <int E>
-__device__ __forceinline__ void step_interaction(const StepArgs& a, int b, int lane) {
-    const TableV& U = a.U;
-    const TableV& I = a.I;
-    const AdamC& c = a.c;
-    const int D = U.D;
+__device__ __forceinline__ void step_shared_rows(SA a, const AdamC& c, int b, int lane, int ur, int ir, int iux, int iix,
+                                                 int seg_u, int seg_i, float dot, float coef, float smin, float smax,
+                                                 float K, TwoRows<E>& r2) {
+    const int D = a.D;
     const bool fair = a.objective != FR_FOCF_NONE;
-    // ---- level 1: everything addressed by the batch position
-    long long ul = a.user[b], il = a.item[b];
-    const float r = a.rating[b];
-    const float s = fair ? a.sst[b] : 0.f;
-    const int2 riu = a.w.info_u[b], rii = a.w.info_i[b];
-    const int rK = a.w.nseg_i[0];
-    const float smin = fair ? a.w.sst_minmax[0] : 0.f, smax = fair ? a.w.sst_minmax[1] : 0.f;
-    if (ul < 0 || ul >= U.n_rows || il < 0 || il >= I.n_rows) {
-        if (lane == 0 && a.err) atomicOr(a.err, FR_DEV_ERR_INDEX_RANGE);
-        ul = ul < 0 || ul >= U.n_rows ? 0 : ul;      // the sort clamped the same way
-        il = il < 0 || il >= I.n_rows ? 0 : il;
-    }
-    const int ur = uniform((int)ul), ir = uniform((int)il);
-    const int iux = uniform(riu.x), iix = uniform(rii.x), seg_u = uniform(riu.y), seg_i = uniform(rii.y);
     const int nu = iux >> 16, ni = iix >> 16, j0u = iux & 0xffff, j0i = iix & 0xffff;
-    const float K = (float)uniform(rK);
-    // ---- level 2: the rows and their `last` stamps, requested together
-    const int lu = U.last[ur], li = I.last[ir];
-    RowFrag<E> pu, mu, vu, pi, mi, vi;
-    load_row<E>(pu, U.p + (size_t)ur * D, D, lane);
-    load_row<E>(pi, I.p + (size_t)ir * D, D, lane);
-    load_row<E>(mu, U.m + (size_t)ur * D, D, lane);
-    load_row<E>(vu, U.v + (size_t)ur * D, D, lane);
-    load_row<E>(mi, I.m + (size_t)ir * D, D, lane);
-    load_row<E>(vi, I.v + (size_t)ir * D, D, lane);
-    const int t0u = uniform(lu), t0i = uniform(li);
-    // replay the optimizer steps each row missed (zero data gradient, weight decay only): first the steps only the staler
-    // row missed, then the common tail on both rows interleaved
-    const int upto_u = U.step - 1, upto_i = I.step - 1;
-    if (upto_u == upto_i) {
-        if (t0u < t0i) replay<E>(pu, mu, vu, t0u, t0i, c, lane);
-        else if (t0i < t0u) replay<E>(pi, mi, vi, t0i, t0u, c, lane);
-        replay2<E>(pu, mu, vu, pi, mi, vi, t0u > t0i ? t0u : t0i, upto_u, c, lane);
-    } else {
-        replay<E>(pu, mu, vu, t0u, upto_u, c, lane);
-        replay<E>(pi, mi, vi, t0i, upto_i, c, lane);
-    }
-    float dot = 0.f;
-#pragma unroll
-    for (int e = 0; e < E; ++e) dot = fmaf(pu.x[e], pi.x[e], dot);
-    dot = wave_sum(dot);
-    const float er = dot - r;
-    if (lane == 0) a.w.mse_e[b] = er * er;
-    const float cm = 2.f * er / (float)a.B;        // d mean((pred - r)^2) / d pred
-    const float2 su = step_scalars(c, U.step), si = step_scalars(c, I.step);
+    const float2 s = step_scalars(c, a.step);
+    // the workspace arrays of this path, from the base pointer (opaque to the optimiser on purpose: hoisted out of the
+    // task loop the two dozen pointers would occupy SGPRs on the common path)
+    int Bq = a.B;
+    asm volatile("" : "+s"(Bq));
+    const FocfWs w = focf_layout(a.ws, Bq, D);
+    RowFrag<E>&pu = r2.pA, &mu = r2.mA, &vu = r2.vA, &pi = r2.pB, &mi = r2.mB, &vi = r2.vB;
 
-    // dLoss/dpred of an interaction whose item has no other member in the batch: its per-item statistics are its own
-    float coef = cm;
-    if (ni == 1 && fair) {
-        const bool in0 = s == smin;
-        if (s != smin && s != smax && lane == 0 && a.err) atomicOr(a.err, FR_DEV_ERR_SST_GROUPS);
-        float term, g0, g1;
-        focf_fair_eval(a.objective, a.fair_weight, K, in0 ? dot : 0.f, in0 ? 0.f : dot, in0 ? r : 0.f, in0 ? 0.f : r,
-                       in0 ? 1.f : 0.f, in0 ? 0.f : 1.f, term, g0, g1);
-        coef = cm + (in0 ? g0 : g1);
-        if (lane == 0) a.w.term[seg_i] = term;
-    }
-
-    if (ni == 1 && nu == 1) {      // ---- nobody else touches either row: finish here
-        RowFrag<E> gu, gi;
-#pragma unroll
-        for (int e = 0; e < E; ++e) {
-            gu.x[e] = coef * pi.x[e];
-            gi.x[e] = coef * pu.x[e];
-        }
-        adam_write<E>(U, c, ur, pu, mu, vu, gu, su, lane);
-        adam_write<E>(I, c, ir, pi, mi, vi, gi, si, lane);
-        return;
-    }
-
-    // ---- shared rows: hand over, then whoever arrives last at a segment finishes it
     const size_t so = (size_t)b * D;
-    store_row_sc1<E>(pu, a.w.side[0] + so, D, lane);
-    store_row_sc1<E>(mu, a.w.side[1] + so, D, lane);
-    store_row_sc1<E>(vu, a.w.side[2] + so, D, lane);
-    if (nu > 1) store_row_sc1<E>(pi, a.w.side[3] + so, D, lane);     // the item row BEFORE its update: users' gradients
-    RowFrag<E> pi0 = pi;
+    store_row_sc1<E>(pu, w.side[0] + so, D, lane);
+    store_row_sc1<E>(mu, w.side[1] + so, D, lane);
+    store_row_sc1<E>(vu, w.side[2] + so, D, lane);
+    if (nu > 1) store_row_sc1<E>(pi, w.side[3] + so, D, lane);     // the item row BEFORE its update: users' gradients
     if (ni == 1) {
         // item level is this wave alone; the user has other members
         RowFrag<E> gi;
 #pragma unroll
         for (int e = 0; e < E; ++e) gi.x[e] = coef * pu.x[e];
-        adam_write<E>(I, c, ir, pi, mi, vi, gi, si, lane);
-        if (lane == 0) st_sc1(a.w.coef + b, coef);
+        adam_write<E>(a.Ip, a.Im, a.Iv, a.Ilast, D, a.step, c, ir, pi, mi, vi, gi, s, lane);
+        if (lane == 0) st_sc1(w.coef + b, coef);
         drain_stores();
-        if (arrive_last(a.w.cnt_u + seg_u, nu, lane)) user_finish<E>(a, j0u, nu, su, lane);
+        if (arrive_last(w.cnt_u + seg_u, nu, lane)) user_finish<E>(a, c, w, j0u, nu, s, lane);
         return;
     }
-    if (lane == 0) st_sc1(a.w.pred + b, dot);
+    RowFrag<E> pi0 = pi;
+    if (lane == 0) st_sc1(w.pred + b, dot);
     drain_stores();
-    if (!arrive_last(a.w.cnt_i + seg_i, ni, lane)) return;
+    if (!arrive_last(w.cnt_i + seg_i, ni, lane)) return;
 
     // ---- item level, last arriver: statistics of the item over its members (the order of focf_fair_kernel: 16 lanes,
     // members strided over them, butterfly), dLoss/dpred of every member, the item row's gradient and update
-    float sp0 = 0.f, sp1 = 0.f, st0 = 0.f, st1 = 0.f, n0 = 0.f, n1 = 0.f;
+    float term = 0.f, g0 = 0.f, g1 = 0.f;
     if (fair) {
+        float sp0 = 0.f, sp1 = 0.f, st0 = 0.f, st1 = 0.f, n0 = 0.f, n1 = 0.f;
         bool bad = false;
         if (lane < FAIR_GROUP) {
             for (int j = j0i + lane; j < j0i + ni; j += FAIR_GROUP) {
-                const int bq = a.w.perm_i[j];
-                const float sq = a.sst[bq], pr = ld_sc1(a.w.pred + bq), rq = a.rating[bq];
+                const int bq = w.perm_i[j];
+                const int4 rq = a.rec[bq];
+                const float sq = __int_as_float(rq.w), pr = ld_sc1(w.pred + bq), rr = __int_as_float(rq.z);
                 bad |= (sq != smin && sq != smax);
                 if (sq == smin) {
-                    sp0 += pr; st0 += rq; n0 += 1.f;
+                    sp0 += pr; st0 += rr; n0 += 1.f;
                 } else {
-                    sp1 += pr; st1 += rq; n1 += 1.f;
+                    sp1 += pr; st1 += rr; n1 += 1.f;
                 }
             }
         }
@@ -294,40 +286,37 @@ __device__ __forceinline__ void step_interaction(const StepArgs& a, int b, int l
         st1 = __builtin_bit_cast(float, uniform(__builtin_bit_cast(int, st1)));
         n0 = __builtin_bit_cast(float, uniform(__builtin_bit_cast(int, n0)));
         n1 = __builtin_bit_cast(float, uniform(__builtin_bit_cast(int, n1)));
-    }
-    float term = 0.f, g0 = 0.f, g1 = 0.f;
-    if (fair) {
         focf_fair_eval(a.objective, a.fair_weight, K, sp0, sp1, st0, st1, n0, n1, term, g0, g1);
-        if (lane == 0) a.w.term[seg_i] = term;
+        if (lane == 0) a.term[seg_i] = term;
     }
     // dLoss/dpred of the members, 64 at a time (one per lane), written for the user level
     for (int jb = 0; jb < ni; jb += 64) {
         if (jb + lane < ni) {
-            const int bq = a.w.perm_i[j0i + jb + lane];
-            const float erq = ld_sc1(a.w.pred + bq) - a.rating[bq];
+            const int bq = w.perm_i[j0i + jb + lane];
+            const int4 rq = a.rec[bq];
+            const float erq = ld_sc1(w.pred + bq) - __int_as_float(rq.z);
             float cq = 2.f * erq / (float)a.B;
-            if (fair) cq = cq + (a.sst[bq] == smin ? g0 : g1);
-            st_sc1(a.w.coef + bq, cq);
+            if (fair) cq = cq + (__int_as_float(rq.w) == smin ? g0 : g1);
+            st_sc1(w.coef + bq, cq);
         }
     }
     drain_stores();      // this wave reads them back below (sc1 loads are served past the L1)
     {
         RowFrag<E> gi;
-        handed_grad_sum<E>(gi, j0i, ni, a.w.perm_i, a.w.coef, a.w.side[0], D, lane);
-        adam_write<E>(I, c, ir, pi, mi, vi, gi, si, lane);
+        handed_grad_sum<E>(gi, j0i, ni, w.perm_i, w.coef, w.side[0], D, lane);
+        adam_write<E>(a.Ip, a.Im, a.Iv, a.Ilast, D, a.step, c, ir, pi, mi, vi, gi, s, lane);
     }
-    // ---- user level of every member, ascending; members whose user is theirs alone are updated here, four in flight
-    constexpr int UN = 4;
+    // ---- user level of every member, ascending; members whose user is theirs alone are updated here, two in flight
+    constexpr int UN = 2;
     for (int jb = 0; jb < ni; jb += 64) {
         const int cnt = min(64, ni - jb);
         int my_b = 0, my_u = 0, my_iux = 0, my_seg = 0;
         float my_c = 0.f;
         if (lane < cnt) {
-            my_b = a.w.perm_i[j0i + jb + lane];
-            my_c = ld_sc1(a.w.coef + my_b);
-            long long uq = a.user[my_b];
-            my_u = (uq < 0 || uq >= U.n_rows) ? 0 : (int)uq;
-            const int2 q = a.w.info_u[my_b];
+            my_b = w.perm_i[j0i + jb + lane];
+            my_c = ld_sc1(w.coef + my_b);
+            my_u = a.rec[my_b].x;
+            const int4 q = a.info[my_b];
             my_iux = q.x;
             my_seg = q.y;
         }
@@ -344,9 +333,9 @@ __device__ __forceinline__ void step_interaction(const StepArgs& a, int b, int l
                 cq[q] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_c), t));
                 if (t0 + q < cnt && nq[q] == 1) {
                     const size_t sq = (size_t)bq[q] * D;
-                    load_row_sc1<E>(p[q], a.w.side[0] + sq, D, lane);
-                    load_row_sc1<E>(m[q], a.w.side[1] + sq, D, lane);
-                    load_row_sc1<E>(v[q], a.w.side[2] + sq, D, lane);
+                    load_row_sc1<E>(p[q], w.side[0] + sq, D, lane);
+                    load_row_sc1<E>(m[q], w.side[1] + sq, D, lane);
+                    load_row_sc1<E>(v[q], w.side[2] + sq, D, lane);
                 }
             }
 #pragma unroll
@@ -356,16 +345,127 @@ __device__ __forceinline__ void step_interaction(const StepArgs& a, int b, int l
                     RowFrag<E> gu;
 #pragma unroll
                     for (int e = 0; e < E; ++e) gu.x[e] = cq[q] * pi0.x[e];
-                    adam_write<E>(U, c, uq[q], p[q], m[q], v[q], gu, su, lane);
+                    adam_write<E>(a.Up, a.Um, a.Uv, a.Ulast, D, a.step, c, uq[q], p[q], m[q], v[q], gu, s, lane);
                 } else {
                     const int t = t0 + q;
                     const int sg = __builtin_amdgcn_readlane(my_seg, t);
                     const int j0 = __builtin_amdgcn_readlane(my_iux, t) & 0xffff;
-                    if (arrive_last(a.w.cnt_u + sg, nq[q], lane)) user_finish<E>(a, j0, nq[q], su, lane);
+                    if (arrive_last(w.cnt_u + sg, nq[q], lane)) user_finish<E>(a, c, w, j0, nq[q], s, lane);
                 }
             }
         }
     }
+}
+
+// ---- the tasks ----------------------------------------------------------------------------------------------------
+// A wave's task is "two rows brought up to date, then something done with them":
+//   sweeper task q  : rows 2q, 2q + 1 of the step's slice (users first, then items), written back at step `step`;
+//   interaction b   : its user row and item row as of step - 1, then score, dLoss/dpred, both gradients, both updates.
+template <int E>
+__device__ __forceinline__ void step_task(SA a, bool sweeper, int q, int lane) {
+    // `lane` made opaque per task: otherwise every per-lane address (10 table pointers + lane) is hoisted out of the
+    // wave's task loop and parked in VGPR pairs for the whole kernel (101 VGPRs = 4 waves per SIMD)
+    asm volatile("" : "+v"(lane));
+    AdamC c;
+    c.sc = a.c.sc; c.cap = a.c.cap; c.wd = a.c.wd; c.b1 = a.c.b1; c.omb1 = a.c.omb1; c.b2 = a.c.b2; c.omb2 = a.c.omb2;
+    c.eps = a.c.eps; c.k1 = a.c.k1; c.k2 = a.c.k2; c.inv_k1 = a.c.inv_k1; c.inv_k2 = a.c.inv_k2;
+    const int D = a.D;
+    TwoRows<E> r;
+    int tA, tB;
+    if (sweeper) {
+        const int pairs_u = (a.n_u + 1) >> 1;
+        const bool inU = q < pairs_u;
+        const int k = inU ? q : q - pairs_u;
+        const long long rowA = (inU ? a.lo_u : a.lo_i) + 2 * k;
+        const bool hasB = 2 * k + 1 < (inU ? a.n_u : a.n_i);
+        const long long rowB = hasB ? rowA + 1 : rowA;
+        float* Tp = inU ? a.Up : a.Ip;
+        float* Tm = inU ? a.Um : a.Im;
+        float* Tv = inU ? a.Uv : a.Iv;
+        int32_t* Tl = inU ? a.Ulast : a.Ilast;
+        const int32_t* Ts = inU ? a.Ustamp : a.Istamp;
+        // stamps, `last` and the rows in ONE round trip (a row is wasted for the few that are skipped)
+        const int sa = Ts[rowA], sb = Ts[rowB];
+        const int la = Tl[rowA], lb = Tl[rowB];
+        load_row<E>(r.pA, Tp + (size_t)rowA * D, D, lane);
+        load_row<E>(r.mA, Tm + (size_t)rowA * D, D, lane);
+        load_row<E>(r.vA, Tv + (size_t)rowA * D, D, lane);
+        load_row<E>(r.pB, Tp + (size_t)rowB * D, D, lane);
+        load_row<E>(r.mB, Tm + (size_t)rowB * D, D, lane);
+        load_row<E>(r.vB, Tv + (size_t)rowB * D, D, lane);
+        const int upto = a.step;
+        tA = uniform(sa) >= a.skip_from ? upto : uniform(la);
+        tB = (!hasB || uniform(sb) >= a.skip_from) ? upto : uniform(lb);
+        const bool doA = tA < upto, doB = tB < upto;
+        replay_two<E>(r, tA, tB, upto, c, lane);
+        if (doA) {
+            store_row<E>(r.pA, Tp + (size_t)rowA * D, D, lane);
+            store_row<E>(r.mA, Tm + (size_t)rowA * D, D, lane);
+            store_row<E>(r.vA, Tv + (size_t)rowA * D, D, lane);
+            if (lane == 0) Tl[rowA] = upto;
+        }
+        if (doB) {
+            store_row<E>(r.pB, Tp + (size_t)rowB * D, D, lane);
+            store_row<E>(r.mB, Tm + (size_t)rowB * D, D, lane);
+            store_row<E>(r.vB, Tv + (size_t)rowB * D, D, lane);
+            if (lane == 0) Tl[rowB] = upto;
+        }
+        return;
+    }
+    const int b = q;
+    const bool fair = a.objective != FR_FOCF_NONE;
+    // ---- level 1: two 16-byte records addressed by the batch position, and the batch header
+    const int4 rec = a.rec[b];
+    const int4 inf = a.info[b];
+    const int4 hd = *reinterpret_cast<const int4*>(a.hdr);
+    const int ur = uniform(rec.x), ir = uniform(rec.y);
+    const float rt = __int_as_float(uniform(rec.z)), s = __int_as_float(uniform(rec.w));
+    const int iux = uniform(inf.x), seg_u = uniform(inf.y), iix = uniform(inf.z), seg_i = uniform(inf.w);
+    const float K = (float)uniform(hd.x);
+    const float smin = __int_as_float(uniform(hd.z)), smax = __int_as_float(uniform(hd.w));
+    const int nu = iux >> 16, ni = iix >> 16;
+    // ---- level 2: the rows and their `last` stamps, requested together
+    const int lu = a.Ulast[ur], li = a.Ilast[ir];
+    load_row<E>(r.pA, a.Up + (size_t)ur * D, D, lane);
+    load_row<E>(r.pB, a.Ip + (size_t)ir * D, D, lane);
+    load_row<E>(r.mA, a.Um + (size_t)ur * D, D, lane);
+    load_row<E>(r.vA, a.Uv + (size_t)ur * D, D, lane);
+    load_row<E>(r.mB, a.Im + (size_t)ir * D, D, lane);
+    load_row<E>(r.vB, a.Iv + (size_t)ir * D, D, lane);
+    tA = uniform(lu);
+    tB = uniform(li);
+    replay_two<E>(r, tA, tB, a.step - 1, c, lane);
+    float dot = 0.f;
+#pragma unroll
+    for (int e = 0; e < E; ++e) dot = fmaf(r.pA.x[e], r.pB.x[e], dot);
+    dot = wave_sum(dot);
+    const float er = dot - rt;
+    if (lane == 0) a.mse_e[b] = er * er;
+    const float cm = 2.f * er / (float)a.B;        // d mean((pred - r)^2) / d pred
+    // dLoss/dpred of an interaction whose item has no other member in the batch: its per-item statistics are its own
+    float coef = cm;
+    if (ni == 1 && fair) {
+        const bool in0 = s == smin;
+        if (s != smin && s != smax && lane == 0 && a.err) atomicOr(a.err, FR_DEV_ERR_SST_GROUPS);
+        float term, g0, g1;
+        focf_fair_eval(a.objective, a.fair_weight, K, in0 ? dot : 0.f, in0 ? 0.f : dot, in0 ? rt : 0.f, in0 ? 0.f : rt,
+                       in0 ? 1.f : 0.f, in0 ? 0.f : 1.f, term, g0, g1);
+        coef = cm + (in0 ? g0 : g1);
+        if (lane == 0) a.term[seg_i] = term;
+    }
+    if (ni == 1 && nu == 1) {      // ---- nobody else touches either row: finish here
+        const float2 sc = step_scalars(c, a.step);
+        RowFrag<E> gu, gi;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            gu.x[e] = coef * r.pB.x[e];
+            gi.x[e] = coef * r.pA.x[e];
+        }
+        adam_write<E>(a.Up, a.Um, a.Uv, a.Ulast, D, a.step, c, ur, r.pA, r.mA, r.vA, gu, sc, lane);
+        adam_write<E>(a.Ip, a.Im, a.Iv, a.Ilast, D, a.step, c, ir, r.pB, r.mB, r.vB, gi, sc, lane);
+        return;
+    }
+    step_shared_rows<E>(a, c, b, lane, ur, ir, iux, iix, seg_u, seg_i, dot, coef, smin, smax, K, r);
 }
 
 // fixed-order reduction of one batch's squared errors and per-item terms -> loss (one workgroup of 256 threads).  The
@@ -415,27 +515,59 @@ __device__ __forceinline__ void step_reduce_loss(const PrevLoss& pl) {
     }
 }
 
-// Block roles: block 0 reduces an earlier step's loss (if any); the sweeper blocks and the interaction blocks are dealt
-// evenly through the rest of the grid, so that from the first moment the resident waves are a mix of sweeper waves (one
-// round trip, then up to S replayed steps of pure VALU work) and interaction waves (two dependent round trips first).
+// Block 0 reduces an earlier step's loss (if any); the sweeper blocks and the interaction blocks are dealt evenly through
+// the rest of the grid (one task per wave), so that from the first moment the resident waves are a mix of sweeper waves
+// (one round trip, then up to S replayed steps of pure VALU work) and interaction waves (two dependent round trips first).
+// Measured (FR_STEP_TRACE wave timeline, cfg 2): the launch is VALU-throughput-bound (46 k VALU cycles per SIMD of the
+// 73 k the kernel lasts), every SIMD time-shared by its 6-8 resident waves; residency 3..8 waves per SIMD moves the
+// kernel by < 2 % (fewer waves = shorter waves but less latency hiding), a single residency of persistent waves with
+// static task lists was slower (no dynamic balancing, one memory round trip per task exposed).
+#ifndef FR_STEP_TRACE
+#define FR_STEP_TRACE 0
+#endif
+#if FR_STEP_TRACE   // diagnostic build: (start, end) in 10 ns ticks, role and placement of every wave of one launch
+__device__ unsigned long long g_step_trace[4 * 65536];
+#endif
+
+#ifndef FR_STEP_WAVES
+#define FR_STEP_WAVES 6      // waves per SIMD the register budget is cut for
+#endif
 template <int E>
-__global__ __launch_bounds__(256) void focf_step_kernel(StepArgs a) {
+__global__ __launch_bounds__(256, FR_STEP_WAVES) void focf_step_kernel(StepArgs a) {
+#if FR_STEP_TRACE
+    const unsigned long long tr0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    const int lane = threadIdx.x & 63;
+    const int wib = uniform((int)(threadIdx.x >> 6));      // wave-uniform, and the compiler has to know it
+    int role = 0;
     if (blockIdx.x == 0) {
         if (a.prev.loss_out) step_reduce_loss(a.prev);
-        return;
+    } else {
+        typedef const StepArgs __attribute__((address_space(4)))* ArgP;
+        ArgP ap = (ArgP)__builtin_amdgcn_kernarg_segment_ptr();
+        const int x = (int)blockIdx.x - 1;
+        const int n_pairs = ((a.n_u + 1) >> 1) + ((a.n_i + 1) >> 1);
+        const long long ns = (n_pairs + 3) >> 2, nt = ns + ((a.B + 3) >> 2);
+        // sweeper blocks before x: floor(x * ns / nt); block x is a sweeper block when that count steps at x + 1
+        const int before = (int)((long long)x * ns / nt);
+        const bool sweeper = (int)((long long)(x + 1) * ns / nt) != before;
+        const int q = (sweeper ? before : x - before) * 4 + wib;
+        role = sweeper ? 1 : 2;
+        if (q < (sweeper ? n_pairs : a.B)) step_task<E>(*ap, sweeper, q, lane);
     }
-    const int x = blockIdx.x - 1;
-    const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
-    const long long ns = a.n_sweep_blocks, nt = (long long)a.n_sweep_blocks + a.n_inter_blocks;
-    // sweeper blocks before x: floor(x * ns / nt); block x is a sweeper block when that count steps at x + 1
-    const long long before = (long long)x * ns / nt;
-    const bool sweeper = ((long long)(x + 1) * ns / nt) != before;
-    if (sweeper) {
-        sweep_slice_wave<E>(a.U, a.I, a.c, a.sw, before * 4 + wib, lane);
-        return;
+#if FR_STEP_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long tr1 = __builtin_amdgcn_s_memrealtime();
+    unsigned hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    const unsigned wq = blockIdx.x * 4 + wib;
+    if (lane == 0 && wq < 65536) {
+        g_step_trace[4 * wq] = tr0;
+        g_step_trace[4 * wq + 1] = tr1;
+        g_step_trace[4 * wq + 2] = role;
+        g_step_trace[4 * wq + 3] = hw;
     }
-    const int b = (int)(x - before) * 4 + wib;
-    if (b < a.B) step_interaction<E>(a, b, lane);
+#endif
 }
 
 __global__ __launch_bounds__(256) void focf_step_finish_kernel(PrevLoss pl) { step_reduce_loss(pl); }
@@ -468,15 +600,21 @@ extern "C" int fr_focf_prepare_step(const fr_focf_batch* batches, const int32_t*
     SortJobList jobs{};
     for (int q = 0; q < n; ++q) {
         const fr_focf_batch& b = batches[q];
-        FR_CHECK_ARG(b.user && b.item && b.ws && b.B >= 1 && b.B <= FR_SORT_MAX, "fr_focf_prepare_step: batch %d", q);
+        FR_CHECK_ARG(b.user && b.item && b.rating && b.ws && b.B >= 1 && b.B <= FR_SORT_MAX,
+                     "fr_focf_prepare_step: batch %d", q);
         FocfWs w = focf_layout(b.ws, b.B, U->dim);
         FR_CHECK_ARG(b.ws_bytes >= w.bytes, "fr_focf_prepare_step: workspace %zu < %zu bytes", b.ws_bytes, w.bytes);
         SortJob ju{b.user, U->n_rows, w.perm_u, w.seg_start_u, w.seg_row_u, nullptr, w.nseg_u, nullptr, nullptr};
         SortJob ji{b.item, I->n_rows, w.perm_i, w.seg_start_i, w.seg_row_i, nullptr, w.nseg_i, b.sst, w.sst_minmax};
         ju.seg_first = w.seg_first_u;
         ji.seg_first = w.seg_first_i;
-        ju.info = w.info_u;
-        ji.info = w.info_i;
+        ju.info = reinterpret_cast<int2*>(w.info);          // one 16-byte record per position: user half, item half
+        ji.info = reinterpret_cast<int2*>(w.info) + 1;
+        ju.info_stride = ji.info_stride = 2;
+        ji.rec = w.rec;
+        ji.rec_idx = b.user;
+        ji.rec_rows = U->n_rows;
+        ji.rec_f0 = b.rating;
         ju.cnt = w.cnt_u;
         ji.cnt = w.cnt_i;
         ju.stamp = U->stamp;
@@ -501,7 +639,8 @@ extern "C" int fr_focf_step(const fr_table* U, const fr_table* I, const fr_adam*
         (rc = check_adam(adam, "fr_focf_step")))
         return rc;
     FR_CHECK_ARG(U->dim == I->dim, "fr_focf_step: user dim %d != item dim %d", U->dim, I->dim);
-    FR_CHECK_ARG(user && item && rating && ws, "fr_focf_step: null pointer");
+    FR_CHECK_ARG(ws, "fr_focf_step: null pointer");
+    (void)user; (void)item; (void)rating;    // fr_focf_prepare_step packed them into the workspace
     FR_CHECK_ARG(objective >= FR_FOCF_NONE && objective <= FR_FOCF_OVER,
                  "fr_focf_step: objective %d needs batch-wide statistics before the update (use fr_focf_forward)", objective);
     FR_CHECK_ARG(objective == FR_FOCF_NONE || sst, "fr_focf_step: sst column required for a fairness objective");
@@ -510,36 +649,48 @@ extern "C" int fr_focf_step(const fr_table* U, const fr_table* I, const fr_adam*
                  "the same for both tables");
     FR_CHECK_ARG(!U->step_dev && !I->step_dev, "fr_focf_step: device step counters are not supported");
     StepArgs a{};
-    a.w = focf_layout(ws, B, U->dim);
-    FR_CHECK_ARG(ws_bytes >= a.w.bytes, "fr_focf_step: workspace %zu < %zu bytes", ws_bytes, a.w.bytes);
-    a.U = view(U);
-    a.I = view(I);
+    const FocfWs w = focf_layout(ws, B, U->dim);
+    FR_CHECK_ARG(ws_bytes >= w.bytes, "fr_focf_step: workspace %zu < %zu bytes", ws_bytes, w.bytes);
+    a.Up = U->p; a.Um = U->m; a.Uv = U->v; a.Ulast = U->last; a.Ustamp = U->stamp;
+    a.Ip = I->p; a.Im = I->m; a.Iv = I->v; a.Ilast = I->last; a.Istamp = I->stamp;
+    a.D = U->dim;
+    a.step = U->step;
     a.c = make_adamc(adam);
-    a.user = user;
-    a.item = item;
-    a.rating = rating;
-    a.sst = sst;
     a.B = (int)B;
     a.objective = objective;
     a.fair_weight = fair_weight;
+    a.rec = w.rec;
+    a.info = w.info;
+    a.hdr = w.nseg_i;
+    a.mse_e = w.mse_e;
+    a.term = w.term;
+    a.ws = ws;
     a.err = err_flag;
     long long sweep_waves = 0;
     if (sweep_period > 0) {
-        a.sw = make_sweep_slice(U, I, sweep_period);
-        a.sw.skip_from = stamp;      // the rows of this batch (and of batches prepared for later steps) carry stamps >= it
-        sweep_waves = sweep_slice_waves(a.sw);
+        const SweepSlice sw = make_sweep_slice(U, I, sweep_period);
+        a.lo_u = sw.lo_u; a.lo_i = sw.lo_i; a.n_u = sw.n_u; a.n_i = sw.n_i;
+        a.skip_from = stamp;      // the rows of this batch (and of batches prepared for later steps) carry stamps >= it
+        sweep_waves = ((long long)a.n_u + 1) / 2 + ((long long)a.n_i + 1) / 2;
     }
-    a.n_sweep_blocks = (int)((sweep_waves + 3) / 4);
-    a.n_inter_blocks = (int)((B + 3) / 4);
     a.prev = prev_of(prev_ws, prev_B, U->dim, objective, fair_weight, prev_loss_out, loss_acc);
     (void)loss_out;   // reduced by the NEXT fr_focf_step (prev_*) or by fr_focf_step_finish
     {
         ProfScope prof(K_FOCF_STEP, stream);
-        FR_DISPATCH_E(U->dim, FR_LAUNCH(prof, (focf_step_kernel<E>), dim3((unsigned)(1 + a.n_sweep_blocks + a.n_inter_blocks)), dim3(256), 0, stream, a));
+        const unsigned blocks = (unsigned)(1 + (sweep_waves + 3) / 4 + (B + 3) / 4);
+        FR_DISPATCH_E(U->dim, FR_LAUNCH(prof, (focf_step_kernel<E>), dim3(blocks), dim3(256), 0, stream, a));
     }
     FR_CHECK_LAUNCH();
     return FR_OK;
 }
+
+#if FR_STEP_TRACE
+extern "C" __attribute__((visibility("default"))) int fr_debug_step_trace(unsigned long long* host_out, int n_waves) {
+    FR_CHECK_HIP(hipDeviceSynchronize());
+    FR_CHECK_HIP(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_step_trace), (size_t)n_waves * 32));
+    return FR_OK;
+}
+#endif
 
 extern "C" int fr_focf_step_finish(void* ws, size_t ws_bytes, int64_t B, int32_t dim, int32_t objective,
                                    float fair_weight, float* loss_out, float* loss_acc, void* stream_) {

@@ -28,9 +28,11 @@ struct FocfWs {
     unsigned int* ticket;  // in-launch finalisation counter of the fair kernel (kept zero between launches)
     float* clip_part;      // [(2B + 3) / 4] squared-norm partials of fr_focf_clip_grad_norm
     float* side[6];      // ue, mu, vu, ie, mi, vi : [B, D] each
-    // fused step (focf_step.hip): per batch position (first sorted position j0 | members n << 16, segment index) of its
-    // user / item segment, arrival counters per segment, per-interaction squared errors, per-item smooth-L1 terms
-    int2 *info_u, *info_i;
+    // fused step (focf_step.hip): per batch position ONE record (user row, item row, rating, sst) and ONE record
+    // (first sorted position j0 | members n << 16, segment index) x (user segment, item segment); arrival counters per
+    // segment, per-interaction squared errors, per-item smooth-L1 terms
+    int4* rec;
+    int4* info;
     unsigned int *cnt_u, *cnt_i;
     float* mse_e;        // [B]
     float* term;         // [B] indexed by item segment
@@ -44,12 +46,12 @@ constexpr int FAIR_THREADS = 1024;   // 16 lanes per item segment -> 64 segments
 constexpr int FAIR_GROUP = 16;        // lanes per item segment ...
 constexpr int FAIR_GROUP_RUNS = 64;   // ... and in item-complete batches (few items, ~100 members each)
 
-inline FocfWs focf_layout(void* base, int64_t B, int D) {
+__host__ __device__ inline FocfWs focf_layout(void* base, int64_t B, int D) {
     FocfWs w;
     size_t off = 0;
     auto take = [&](size_t nbytes) {
         void* p = base ? (void*)((char*)base + off) : nullptr;
-        off = align_up(off + nbytes, 256);
+        off = (off + nbytes + 255) / 256 * 256;
         return p;
     };
     const size_t Bp = (size_t)B + 1;
@@ -62,8 +64,8 @@ inline FocfWs focf_layout(void* base, int64_t B, int D) {
     w.seg_start_i = (int32_t*)take(Bp * 4);
     w.seg_row_i = (int32_t*)take(Bp * 4);
     w.seg_first_i = (int32_t*)take(Bp * 4);
-    w.nseg_i = (int32_t*)take(4);
-    w.sst_minmax = (float*)take(8);
+    w.nseg_i = (int32_t*)take(16);                  // header of the fused step: (K, -, smin, smax) in one 16-byte read
+    w.sst_minmax = (float*)(base ? w.nseg_i + 2 : nullptr);
     w.pred = (float*)take(Bp * 4);
     w.coef = (float*)take(Bp * 4);
     w.n_gather_blocks = (int)((B * WAVE + GATHER_THREADS - 1) / GATHER_THREADS);
@@ -74,8 +76,8 @@ inline FocfWs focf_layout(void* base, int64_t B, int D) {
     w.fair_part = (float*)take((size_t)w.n_fair_blocks * (FAIR_GROUP_RUNS / FAIR_GROUP) * 4);   // room for either group size
     w.ticket = (unsigned int*)take(4);
     w.clip_part = (float*)take(((2 * (size_t)B + 3) / 4) * 4);
-    w.info_u = (int2*)take(Bp * 8);
-    w.info_i = (int2*)take(Bp * 8);
+    w.rec = (int4*)take(Bp * 16);
+    w.info = (int4*)take(Bp * 16);
     w.cnt_u = (unsigned int*)take(Bp * 4);
     w.cnt_i = (unsigned int*)take(Bp * 4);
     w.mse_e = (float*)take(Bp * 4);

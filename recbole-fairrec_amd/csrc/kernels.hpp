@@ -65,10 +65,17 @@ struct SortJob {
     int32_t* seg_first; // optional [M]: perm[seg_start[k]] of segment k, so that its consumers need not chase perm for
                         //   the first (usually the only) member: one dependent memory round trip less per wave
     // optional outputs for the fused FOCF step (focf_step.hip):
-    int2* info;         // [M] per position b: (first sorted position j0 of its segment | members n << 16, segment index)
+    int2* info;         // per position b: (first sorted position j0 of its segment | members n << 16, segment index), at
+    int info_stride;    //   info[b * info_stride] (two lists can interleave their halves of one 16-byte record per b)
     unsigned int* cnt;  // [n_seg] arrival counters of the segments, zeroed here
     int32_t* stamp;     // table stamps: stamp[row] = max(stamp[row], stamp_val) for every distinct row of the list, so
     int stamp_val;      //   that the sweeper waves of the step's launch leave the rows of the batch alone
+    // ... and one 16-byte record per position for its consumer: (row id of `rec_idx`, row id of this list, rec_f0, aux),
+    // both ids range-checked and clamped like the sort keys; a -1 id counts as out of range here (no padding holes)
+    int4* rec;
+    const int64_t* rec_idx;
+    int64_t rec_rows;
+    const float* rec_f0;
 };
 
 // Sort index lists in one launch, one workgroup each: (a) or (a, b) of the same length M ...

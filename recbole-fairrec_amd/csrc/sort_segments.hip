@@ -78,13 +78,21 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_segments_kernel(SortJobList
         unsigned long long k = ~0ull;
         if (j < M) {
             long long r = job.idx[job.lay.at(j)];
-            if (r == -1) {
+            if (r == -1 && !job.rec) {
                 r = 0xFFFFFFFFll;   // padding slot ("hole"): sorts behind every real row, belongs to no segment
             } else if (r < 0 || r >= job.n_rows) {
                 bad = true;
                 r = 0;
             }
             k = ((unsigned long long)r << 32) | (unsigned)j;
+            if (job.rec) {
+                long long o = job.rec_idx[j];
+                if (o < 0 || o >= job.rec_rows) {
+                    bad = true;
+                    o = 0;
+                }
+                job.rec[j] = make_int4((int)o, (int)r, __float_as_int(job.rec_f0[j]), job.aux ? __float_as_int(job.aux[j]) : 0);
+            }
         }
         keys[j] = k;
     }
@@ -269,7 +277,7 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_segments_kernel(SortJobList
             if (j < M && (unsigned)(k >> 32) != 0xFFFFFFFFu) {
                 const int seg = wcnt[q * 16 + wid] + __popcll(bal[q] & (lt_mask | (1ull << lane))) - 1;
                 const int j0 = ss[seg];
-                job.info[(unsigned)k] = make_int2(j0 | ((ss[seg + 1] - j0) << 16), seg);
+                job.info[(size_t)(unsigned)k * job.info_stride] = make_int2(j0 | ((ss[seg + 1] - j0) << 16), seg);
             }
         }
         if (job.cnt)

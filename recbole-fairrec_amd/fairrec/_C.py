@@ -36,7 +36,7 @@ class FrAdam(Structure):
 
 class FrFocfBatch(Structure):
     _fields_ = [("user", c_void_p), ("item", c_void_p), ("sst", c_void_p), ("B", c_int64), ("ws", c_void_p),
-                ("ws_bytes", c_size_t)]
+                ("ws_bytes", c_size_t), ("rating", c_void_p)]
 
 
 class FairrecError(RuntimeError):

@@ -117,9 +117,11 @@ class FocfEngine:
         return (user.data_ptr(), item.data_ptr(), user.numel())
 
     def prepare_many(self, batches):
-        """Index-only part of COMING batches (fr_focf_prepare_many: sort + segmentation + sst min/max of each, one
-        launch for all of them) on a side stream, overlapping the kernels of the batches in flight.  `batches` =
-        [(user, item, sst)] in the order they will be applied.  Pure function of the id columns."""
+        """Index-only part of COMING batches (fr_focf_prepare_step: sort + segmentation + sst min/max of each, the packed
+        per-interaction records and the row stamps of the one-launch step; one launch for all of them) on a side stream,
+        overlapping the kernels of the batches in flight.  `batches` = [(user, item, sst, rating)] in the order they
+        will be applied ((user, item, sst) triples are accepted: such a batch is prepared for the three-launch chain
+        only)."""
         if self._side is None:
             self._side = torch.cuda.Stream(device=self.device)
             self._ws_next = 0
@@ -130,7 +132,9 @@ class FocfEngine:
         group = {"done": torch.cuda.Event(), "joined": False}
         entries = []
         self._check_stamp_gen()
-        for q, (user, item, sst) in enumerate(batches):
+        full = all(len(bt) >= 4 and bt[3] is not None for bt in batches)
+        for q, bt in enumerate(batches):
+            user, item, sst = bt[:3]
             if len(busy) >= self.N_WS:
                 raise _C.FairrecError("too many batches prepared ahead")
             while self._ws_next in busy:
@@ -140,19 +144,24 @@ class FocfEngine:
             B = user.numel()
             ws = self._workspace(B, k)
             arr[q] = _C.FrFocfBatch(user.data_ptr(), item.data_ptr(), _C.ptr(sst if self.objective != 0 else None), B,
-                                    ws.data_ptr(), ws.numel())
-            stamps[q] = self._next_stamp(q)
-            entries.append((self._key(user, item), (k, group, int(stamps[q]))))
+                                    ws.data_ptr(), ws.numel(), _C.ptr(bt[3]) if full else None)
+            stamps[q] = self._next_stamp(q) if full else 0
+            entries.append((self._key(user, item), (k, group, int(stamps[q]) if full else None)))
         # everything that last used these workspaces was enqueued before this point
         start = torch.cuda.Event()
         start.record(main)
         self._side.wait_event(start)
-        self.U.ensure_state()
-        self.I.ensure_state()
-        tu, ti = self.U.c(), self.I.c()
-        rc = _C.lib().fr_focf_prepare_step(arr, stamps, len(batches), ctypes.byref(tu), ctypes.byref(ti),
-                                           self.err_flag.data_ptr(), self._side.cuda_stream)
-        _C.check(rc, "fr_focf_prepare_step")
+        if full:
+            self.U.ensure_state()
+            self.I.ensure_state()
+            tu, ti = self.U.c(), self.I.c()
+            rc = _C.lib().fr_focf_prepare_step(arr, stamps, len(batches), ctypes.byref(tu), ctypes.byref(ti),
+                                               self.err_flag.data_ptr(), self._side.cuda_stream)
+            _C.check(rc, "fr_focf_prepare_step")
+        else:
+            rc = _C.lib().fr_focf_prepare_many(arr, len(batches), self.U.n_rows, self.I.n_rows, self.U.dim,
+                                               self.err_flag.data_ptr(), self._side.cuda_stream)
+            _C.check(rc, "fr_focf_prepare_many")
         group["done"].record(self._side)
         self._prep.update(entries)
 
@@ -178,8 +187,8 @@ class FocfEngine:
     # --- launches -------------------------------------------------------------------------------------
     def forward(self, user, item, rating, sst, want_pred: bool = False, next_batch=None):
         """fr_focf_forward for the step `step+1`; returns (loss[4] device view, pred or None).
-        `next_batch` = (user, item, sst) of the following step, if known, or a list of such triples for the next steps in
-        order (a dataloader's prefetch queue): their index sorts are launched ahead, GROUP batches per launch."""
+        `next_batch` = (user, item, sst, rating) of the following step, if known, or a list of such tuples for the next
+        steps in order (a dataloader's prefetch queue): their index sorts are launched ahead, GROUP batches per launch."""
         B = user.numel()
         flags = 0
         self._check_stamp_gen()
@@ -224,7 +233,7 @@ class FocfEngine:
             if stamp is None:
                 arr = (_C.FrFocfBatch * 1)(_C.FrFocfBatch(user.data_ptr(), item.data_ptr(),
                                                           _C.ptr(sst if self.objective != 0 else None), B, ws.data_ptr(),
-                                                          ws.numel()))
+                                                          ws.numel(), rating.data_ptr()))
                 stamp = self._next_stamp()
                 tu, ti = self.U.c(), self.I.c()
                 rc = _C.lib().fr_focf_prepare_step(arr, (ctypes.c_int32 * 1)(stamp), 1, ctypes.byref(tu), ctypes.byref(ti),
@@ -290,11 +299,18 @@ class FocfEngine:
                                                 self._sweep(B), self.ws[self.ws_cur].data_ptr(),
                                                 self.ws[self.ws_cur].numel(), _C.current_stream())
             _C.check(rc, "fr_focf_backward_adam")
+            if self.defer_loss:         # keep the running total the one-launch step keeps on the device
+                self.loss_acc[:3] += self._loss_views[self.loss_slot][:3]
         self.U.step += 1
         self.I.step += 1
         self.U._dirty = self.I._dirty = True
         self.pending_B = 0
         self.backward_seen = False
+
+    def reset_loss_acc(self):
+        """Start a new running loss total (`loss_acc`: sums of loss, mse, fair over the steps taken with defer_loss on)."""
+        self.finish()
+        self.loss_acc.zero_()
 
     def finish(self):
         """Reduce the loss of the last fused step (fr_focf_step_finish): its loss slot and `loss_acc` are complete on the
@@ -414,7 +430,7 @@ class FOCF(FairRecommender):
         u, i, r, s = hit[1] if hit is not None and hit[0] is interaction else self._cols(interaction)
         nxt = getattr(self, '_next_cols', None)
         self._next_cols = None
-        loss, _ = eng.forward(u, i, r, s, next_batch=[(c[0], c[1], c[3]) for c in nxt] if nxt else None)
+        loss, _ = eng.forward(u, i, r, s, next_batch=[(c[0], c[1], c[3], c[2]) for c in nxt] if nxt else None)
         if torch.is_grad_enabled():
             return _LossHandle.apply(loss[0], eng, self.user_embedding_layer.weight, self.item_embedding_layer.weight)
         return loss[0]

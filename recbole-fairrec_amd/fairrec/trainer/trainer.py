@@ -107,8 +107,9 @@ class Trainer(AbstractTrainer):
         hint = getattr(self.model, 'hint_next_batch', None)
         if fused:
             eng = self.model.hip_engine()
-            eng.defer_loss = True        # the loop below reads the loss only after optimizer.step()
+            eng.defer_loss = True        # the loop below reads the loss only at the epoch end (the engine's running total)
             eng.item_runs = type(train_data).__name__ == 'FOCFDataLoader'     # item-complete batches
+            eng.reset_loss_acc()
             try:
                 return self._train_epoch_body(train_data, loss_func, hint, graphed, fused, total, n_tuple)
             finally:
@@ -144,9 +145,9 @@ class Trainer(AbstractTrainer):
                 continue
             if fused:
                 with torch.no_grad():
-                    part = loss_func(interaction).view(1)     # a view of the engine's loss slot of this step ...
-                self.optimizer.step()                         # ... which the backward launch fills (defer_loss)
-                total = part.clone() if total is None else total + part
+                    loss_func(interaction)                    # the step's loss goes into the engine's running total ...
+                self.optimizer.step()                         # ... on the device (FocfEngine.loss_acc), read once below
+                total = True
                 continue
             self.optimizer.zero_grad()
             losses = loss_func(interaction)
@@ -162,6 +163,10 @@ class Trainer(AbstractTrainer):
             self.optimizer.step()
         if total is None:
             return 0.0
+        if total is True:
+            eng = self.model.hip_engine()
+            eng.finish()
+            total = eng.loss_acc[:1]
         vals = total.cpu().tolist()                 # the epoch's only host sync
         self._check_nan(torch.tensor(vals))
         eng = self.model.hip_engine()

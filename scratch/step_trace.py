@@ -1,0 +1,45 @@
+"""Timeline of the waves of ONE fr_focf_step launch (library built with -DFR_STEP_TRACE=1)."""
+import ctypes, os, sys
+import numpy as np
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "recbole-fairrec_amd")]
+import bench
+from fairrec import _C
+from fairrec.model.fair_recommender.focf import FocfEngine
+from fairrec.optim import FusedLazyAdam
+dev = torch.device("cuda")
+K = 200
+u, i, r, s = (t.to(dev) for t in bench.synth_batches(K, bench.BATCH, bench.N_USERS, bench.N_ITEMS, bench.SEED))
+U, I = bench.xavier_tables(bench.N_USERS, bench.N_ITEMS, bench.DIM, bench.SEED, dev)
+eng = FocfEngine(U, I, bench.OBJECTIVE, bench.FAIR_WEIGHT, 5.0)
+FusedLazyAdam(eng, lr=bench.LR, weight_decay=bench.WD, sweep_period=int(os.environ.get("SWEEP", "0")) or None)
+eng.defer_loss = True
+rows = [(u[k], i[k], s[k], r[k]) for k in range(K)]
+for k in range(K):
+    eng.forward(u[k], i[k], r[k], s[k], next_batch=rows[k + 1:k + 11] or None)
+    eng.backward_adam()
+torch.cuda.synchronize()
+lib = ctypes.CDLL(_C.LIB_PATH)
+n = 16384
+buf = np.zeros((n, 4), dtype=np.uint64)
+rc = lib.fr_debug_step_trace(buf.ctypes.data_as(ctypes.c_void_p), n)
+assert rc == 0
+buf = buf[buf[:, 1] > 0]
+t0 = buf[:, 0].min()
+st = (buf[:, 0] - t0).astype(np.float64) / 100.0   # us
+en = (buf[:, 1] - t0).astype(np.float64) / 100.0
+role = buf[:, 2]
+print("waves", len(buf), "kernel span %.2f us" % en.max())
+for rl, name in ((1, "sweeper"), (2, "interaction")):
+    m = role == rl
+    if not m.any():
+        continue
+    d = en[m] - st[m]
+    print(f"{name:12s} n={m.sum():6d} start: min {st[m].min():6.2f} median {np.median(st[m]):6.2f} p90 {np.percentile(st[m], 90):6.2f} max {st[m].max():6.2f} | "
+          f"dur: min {d.min():6.2f} median {np.median(d):6.2f} p90 {np.percentile(d, 90):6.2f} max {d.max():6.2f} | end: median {np.median(en[m]):6.2f} p90 {np.percentile(en[m], 90):6.2f} max {en[m].max():6.2f}")
+# resident waves over time
+ts = np.linspace(0, en.max(), 40)
+occ = [(int(((st <= t) & (en > t) & (role == 1)).sum()), int(((st <= t) & (en > t) & (role == 2)).sum())) for t in ts]
+print("t(us): resident sweeper / interaction waves")
+print("  ".join(f"{t:.1f}:{a}/{b}" for t, (a, b) in zip(ts, occ)))

@@ -50,7 +50,8 @@ def test_training_matches_reference_golden(path, sweep):
     cols = {k: torch.tensor(z[k], device=dev) for k in ("user_id", "item_id", "rating", "sst")}
     for t in range(T):
         u, i, r, s = (cols[k][t] for k in ("user_id", "item_id", "rating", "sst"))
-        nxt = [(cols["user_id"][j], cols["item_id"][j], cols["sst"][j]) for j in range(t + 1, t + 1 + lookahead) if j < T]
+        nxt = [(cols["user_id"][j], cols["item_id"][j], cols["sst"][j], cols["rating"][j])
+               for j in range(t + 1, t + 1 + lookahead) if j < T]
         nxt = (nxt[0] if lookahead == 1 else nxt) if nxt else None
         loss, pred = eng.forward(u, i, r, s, want_pred=(t == 0 and not fused), next_batch=nxt)
         losses.append(loss if fused else loss.clone())
@@ -153,7 +154,7 @@ def test_lookahead_sweep_equals_plain_chain(objective, dim, item_dist):
     for t in range(T):
         out = []
         for eng, ahead in zip(engs, modes):
-            nxt = [(u[j], i[j], s[j]) for j in range(t + 1, t + 1 + ahead) if j < T] or None
+            nxt = [(u[j], i[j], s[j], r[j]) for j in range(t + 1, t + 1 + ahead) if j < T] or None
             loss, pred = eng.forward(u[t], i[t], r[t], s[t], want_pred=ahead != 7, next_batch=nxt)
             eng.backward_adam()
             if ahead == 7:
@@ -204,7 +205,7 @@ def test_full_size_steps_match_the_oracle():
     ud, idv, rd, sd = u.cuda(), i.cuda(), r.cuda(), s.cuda()
     for t in range(T):
         want = ref.step(u[t], i[t], r[t], s[t])
-        coming = [(ud[j], idv[j], sd[j]) for j in range(t + 1, T)] or None
+        coming = [(ud[j], idv[j], sd[j], rd[j]) for j in range(t + 1, T)] or None
         loss, _ = eng.forward(ud[t], idv[t], rd[t], sd[t], next_batch=coming)
         eng.backward_adam()
         assert eng._prev is not None          # the fused one-launch step (fr_focf_step) is what runs here
@@ -250,7 +251,7 @@ def test_prefetch_queue_over_epochs_matches_plain_steps():
         for t, (u, i, r, s) in enumerate(batches):
             engs[0].forward(u, i, r, s)
             engs[0].backward_adam()
-            queue = [(b[0], b[1], b[3]) for b in batches[t + 1:t + 11]] or None
+            queue = [(b[0], b[1], b[3], b[2]) for b in batches[t + 1:t + 11]] or None
             for eng in engs[1:]:
                 eng.forward(u, i, r, s, next_batch=queue)
                 eng.backward_adam()
