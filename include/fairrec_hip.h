@@ -203,7 +203,10 @@ FR_API int fr_focf_backward_adam(const fr_table* U, const fr_table* I, const fr_
  *                          sweeper waves of fr_focf_step leave rows stamped >= its `stamp` argument alone.  Callable
  *                          ahead on another stream (depends on the id columns only; the stamp raise is an atomic max).
  *                          stamps[q]: any value >= every stamp handed out before (the engine uses the step at which
- *                          the batch is expected to be applied).
+ *                          the batch is expected to be applied).  It also leaves a START ORDER of the interactions,
+ *                          longest estimated replay first (from the rows' `last` as of now; replay_cap = the sweep
+ *                          period that bounds a replay, 0 = unbounded): the step's launch ends one wave latency after
+ *                          its last wave starts, so long replays must not start last.  Order only, never a result.
  *   fr_focf_step         : the step (U->step == I->step = the step being applied).  `stamp` = the value given to
  *                          fr_focf_prepare_step for this batch.  The loss needs every wave of the launch, so it is
  *                          reduced LATER: by the next fr_focf_step (prev_ws / prev_B / prev_loss_out name the earlier
@@ -214,7 +217,7 @@ FR_API int fr_focf_backward_adam(const fr_table* U, const fr_table* I, const fr_
  *   fr_focf_step_finish  : the reduction for a batch no later step will reduce (end of an epoch, before reading).
  */
 FR_API int fr_focf_prepare_step(const fr_focf_batch* batches, const int32_t* stamps, int32_t n, const fr_table* U,
-                                const fr_table* I, uint32_t* err_flag, void* stream);
+                                const fr_table* I, int32_t replay_cap, uint32_t* err_flag, void* stream);
 FR_API int fr_focf_step(const fr_table* U, const fr_table* I, const fr_adam* adam, const int64_t* user,
                         const int64_t* item, const float* rating, const float* sst, int64_t B, int32_t objective,
                         float fair_weight, int32_t sweep_period, int32_t stamp, void* ws, size_t ws_bytes,

@@ -57,8 +57,9 @@ struct StepArgs {
     AdamC c;
     int B, objective;
     float fair_weight;
-    const int4* rec;          // [B] (user row, item row, rating, sst), ids range-checked by fr_focf_prepare_step
-    const int4* info;         // [B] (j0 | n << 16, segment) of the user segment, then of the item segment
+    const int4* task_rec;     // [B] (user row, item row, rating, sst) in start order, ids range-checked by the prepare
+    const int4* task_info;    // [B] (user j0 | n << 16, item j0 | n << 16, user seg | item seg << 16, batch position)
+    int lead;                 // interaction workgroups placed in front of the sweeper workgroups (the longest replays)
     const int32_t* hdr;       // (K = distinct items, -, smin, smax)
     float* mse_e;             // [B]
     float* term;              // [K]
@@ -73,6 +74,16 @@ struct StepArgs {
 // is made opaque once per task: each task re-reads the handful of fields it needs right where it needs them, instead of
 // the compiler parking every field of the struct in SGPRs around the wave's task loop (106 SGPRs + 130 spilled ones).
 typedef const StepArgs __attribute__((address_space(4)))& SA;
+
+// Wave-uniform reads of per-task data (the prepared records, the rows' `last` stamps): vector loads + readfirstlane.
+// (As scalar loads through the constant address space they cost 8 us per wave at launch: thousands of waves missing
+// in the small scalar caches at once.)  Records needed again after the replay are re-read then, so that no register holds
+// them across it.
+__device__ __forceinline__ int4 uload4(const int4* p, int idx) {
+    const int4 v = p[idx];
+    return make_int4(uniform(v.x), uniform(v.y), uniform(v.z), uniform(v.w));
+}
+__device__ __forceinline__ int uload(const int32_t* p, long long idx) { return uniform(p[idx]); }
 
 __device__ __forceinline__ float ld_sc1(const float* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -127,7 +138,7 @@ __device__ __forceinline__ void adam_write(float* Tp, float* Tm, float* Tv, int3
 
 // g = sum over the members [j0, j0 + n) of a segment, in ascending batch position, of coef[b] * other[b, :] -- the product
 // rounded, then added (embedding_dense_backward's accumulation order), as segment_grad_sum of table.hpp, but on values
-// other waves of this launch handed over: sc1 loads throughout.  Two members in flight (rare path: kept lean in registers).
+// other waves of this launch handed over: sc1 loads throughout.  One member in flight (rare path: kept lean in registers).
 template <int E>
 __device__ __forceinline__ void handed_grad_sum(RowFrag<E>& g, int j0, int n, const int32_t* perm, const float* coef,
                                                 const float* other, int D, int lane) {
@@ -210,7 +221,7 @@ template <int E>
 __device__ __forceinline__ void user_finish(SA a, const AdamC& c, const FocfWs& w, int j0u, int nu, float2 s, int lane) {
     const int D = a.D;
     const int c0 = uniform(w.perm_u[j0u]);
-    const int ur = uniform(a.rec[c0].x);
+    const int ur = uniform(w.rec[c0].x);
     RowFrag<E> p, m, v, g;
     load_row_sc1<E>(p, w.side[0] + (size_t)c0 * D, D, lane);
     load_row_sc1<E>(m, w.side[1] + (size_t)c0 * D, D, lane);
@@ -224,7 +235,8 @@ __device__ __forceinline__ void user_finish(SA a, const AdamC& c, const FocfWs& 
 template <int E>
 __device__ __forceinline__ void step_shared_rows(SA a, const AdamC& c, int b, int lane, int ur, int ir, int iux, int iix,
                                                  int seg_u, int seg_i, float dot, float coef, float smin, float smax,
-                                                 float K, TwoRows<E>& r2) {
+                                                 float K, RowFrag<E>& pu, RowFrag<E>& mu, RowFrag<E>& vu, RowFrag<E>& pi,
+                                                 RowFrag<E>& mi, RowFrag<E>& vi) {
     const int D = a.D;
     const bool fair = a.objective != FR_FOCF_NONE;
     const int nu = iux >> 16, ni = iix >> 16, j0u = iux & 0xffff, j0i = iix & 0xffff;
@@ -234,7 +246,6 @@ __device__ __forceinline__ void step_shared_rows(SA a, const AdamC& c, int b, in
     int Bq = a.B;
     asm volatile("" : "+s"(Bq));
     const FocfWs w = focf_layout(a.ws, Bq, D);
-    RowFrag<E>&pu = r2.pA, &mu = r2.mA, &vu = r2.vA, &pi = r2.pB, &mi = r2.mB, &vi = r2.vB;
 
     const size_t so = (size_t)b * D;
     store_row_sc1<E>(pu, w.side[0] + so, D, lane);
@@ -266,7 +277,7 @@ __device__ __forceinline__ void step_shared_rows(SA a, const AdamC& c, int b, in
         if (lane < FAIR_GROUP) {
             for (int j = j0i + lane; j < j0i + ni; j += FAIR_GROUP) {
                 const int bq = w.perm_i[j];
-                const int4 rq = a.rec[bq];
+                const int4 rq = w.rec[bq];
                 const float sq = __int_as_float(rq.w), pr = ld_sc1(w.pred + bq), rr = __int_as_float(rq.z);
                 bad |= (sq != smin && sq != smax);
                 if (sq == smin) {
@@ -293,7 +304,7 @@ __device__ __forceinline__ void step_shared_rows(SA a, const AdamC& c, int b, in
     for (int jb = 0; jb < ni; jb += 64) {
         if (jb + lane < ni) {
             const int bq = w.perm_i[j0i + jb + lane];
-            const int4 rq = a.rec[bq];
+            const int4 rq = w.rec[bq];
             const float erq = ld_sc1(w.pred + bq) - __int_as_float(rq.z);
             float cq = 2.f * erq / (float)a.B;
             if (fair) cq = cq + (__int_as_float(rq.w) == smin ? g0 : g1);
@@ -306,8 +317,9 @@ __device__ __forceinline__ void step_shared_rows(SA a, const AdamC& c, int b, in
         handed_grad_sum<E>(gi, j0i, ni, w.perm_i, w.coef, w.side[0], D, lane);
         adam_write<E>(a.Ip, a.Im, a.Iv, a.Ilast, D, a.step, c, ir, pi, mi, vi, gi, s, lane);
     }
-    // ---- user level of every member, ascending; members whose user is theirs alone are updated here, two in flight
-    constexpr int UN = 2;
+    // ---- user level of every member, ascending; members whose user is theirs alone are updated here (one at a time:
+    // this path is rare and must not set the kernel's register budget)
+    constexpr int UN = 1;
     for (int jb = 0; jb < ni; jb += 64) {
         const int cnt = min(64, ni - jb);
         int my_b = 0, my_u = 0, my_iux = 0, my_seg = 0;
@@ -315,8 +327,8 @@ __device__ __forceinline__ void step_shared_rows(SA a, const AdamC& c, int b, in
         if (lane < cnt) {
             my_b = w.perm_i[j0i + jb + lane];
             my_c = ld_sc1(w.coef + my_b);
-            my_u = a.rec[my_b].x;
-            const int4 q = a.info[my_b];
+            my_u = w.rec[my_b].x;
+            const int4 q = w.info[my_b];
             my_iux = q.x;
             my_seg = q.y;
         }
@@ -357,12 +369,109 @@ __device__ __forceinline__ void step_shared_rows(SA a, const AdamC& c, int b, in
     }
 }
 
+// The fairness term of an item with ONE member in the batch, from that member's own values: focf_fair_eval with the other
+// group's sums at zero (its P = T = 0 / 1e-5 = 0, and every objective maps 0 to d = 0), same operations on the member's
+// group, so both forms give the same bits.
+__device__ __forceinline__ void focf_fair_single(int objective, float fair_weight, float K, bool in0, float pred,
+                                                 float rating, float& term, float& g) {
+    const float cc = 1.f + 1e-5f;
+    const float P = pred / cc, T = rating / cc;
+    float d, q;
+    if (objective == FR_FOCF_VALUE) {
+        d = P - T; q = 1.f;
+    } else if (objective == FR_FOCF_ABSOLUTE) {
+        d = fabsf(P - T); q = (P > T) ? 1.f : (P < T ? -1.f : 0.f);
+    } else if (objective == FR_FOCF_UNDER) {
+        d = (T - P > 0.f) ? T - P : 0.f; q = (T - P > 0.f) ? -1.f : 0.f;
+    } else {
+        d = (P - T > 0.f) ? P - T : 0.f; q = (P - T > 0.f) ? 1.f : 0.f;
+    }
+    const float delta = in0 ? d - 0.f : 0.f - d;
+    const float x = fabsf(delta);
+    term = smooth_l1(x);
+    const float sgn = delta > 0.f ? 1.f : (delta < 0.f ? -1.f : 0.f);
+    const float dx = (x < 1.f ? x : 1.f) * sgn * fair_weight / K;
+    g = in0 ? dx * q / cc : -dx * q / cc;
+}
+
+// One interaction with both rows caught up (x.A = its user row, x.B = its item row): score, squared error, dLoss/dpred,
+// and -- when nobody else in the batch touches either row -- both gradients and both Adam steps, the two rows as packed
+// pairs.  iux / iix = (j0 | n << 16) of its user / item segment, segs = user segment | item segment << 16, b = position.
+template <int E>
+__device__ __forceinline__ void step_finish(SA a, const AdamC& c, int lane, int q, RowFrag<E>& pu, RowFrag<E>& mu,
+                                            RowFrag<E>& vu, RowFrag<E>& pi, RowFrag<E>& mi, RowFrag<E>& vi) {
+    const int D = a.D;
+    const bool fair = a.objective != FR_FOCF_NONE;
+    // the interaction's records again (scalar loads, cache hits): nothing of them was kept across the replay
+    const int4 vrec = a.task_rec[q], vinf = a.task_info[q], vhd = *reinterpret_cast<const int4*>(a.hdr);
+    const int4 rec = make_int4(uniform(vrec.x), uniform(vrec.y), uniform(vrec.z), uniform(vrec.w));
+    const int4 inf = make_int4(uniform(vinf.x), uniform(vinf.y), uniform(vinf.z), uniform(vinf.w));
+    const int4 hd = make_int4(uniform(vhd.x), 0, uniform(vhd.z), uniform(vhd.w));
+    const int ur = rec.x, ir = rec.y;
+    const float rt = __int_as_float(rec.z), s = __int_as_float(rec.w);
+    const int iux = inf.x, iix = inf.y, b = inf.w;
+    const float K = (float)hd.x, smin = __int_as_float(hd.z), smax = __int_as_float(hd.w);
+    const int nu = iux >> 16, ni = iix >> 16, seg_u = inf.z & 0xffff, seg_i = inf.z >> 16;
+    float dot = 0.f;
+#pragma unroll
+    for (int e = 0; e < E; ++e) dot = fmaf(pu.x[e], pi.x[e], dot);
+    dot = wave_sum(dot);
+    const float er = dot - rt;
+    if (lane == 0) a.mse_e[b] = er * er;
+    const float cm = 2.f * er / (float)a.B;        // d mean((pred - r)^2) / d pred
+    // dLoss/dpred of an interaction whose item has no other member in the batch: its per-item statistics are its own
+    float coef = cm;
+    if (ni == 1 && fair) {
+        const bool in0 = s == smin;
+        if (s != smin && s != smax && lane == 0 && a.err) atomicOr(a.err, FR_DEV_ERR_SST_GROUPS);
+        float term, g;
+        focf_fair_single(a.objective, a.fair_weight, K, in0, dot, rt, term, g);
+        coef = cm + g;
+        if (lane == 0) a.term[seg_i] = term;
+    }
+    if (ni == 1 && nu == 1) {      // ---- nobody else touches either row: finish here
+        const float2 sc = step_scalars(c, a.step);
+#pragma unroll
+        for (int e = 0; e < E; ++e) {       // adam_elem on the pair (user element, item element)
+            v2f_ P = {pu.x[e], pi.x[e]}, M = {mu.x[e], mi.x[e]}, V = {vu.x[e], vi.x[e]};
+            const v2f_ G = __builtin_elementwise_fma(v2f_{c.wd, c.wd}, P, v2f_{coef * P.y, coef * P.x});
+            M = __builtin_elementwise_fma(v2f_{c.omb1, c.omb1}, G - M, M);
+            V = __builtin_elementwise_fma(G * c.omb2, G, V * c.b2);
+            const v2f_ den = __builtin_elementwise_fma(v2f_{__builtin_amdgcn_sqrtf(V.x), __builtin_amdgcn_sqrtf(V.y)},
+                                                      v2f_{sc.y, sc.y}, v2f_{c.eps, c.eps});
+            P = __builtin_elementwise_fma(M * -sc.x, v2f_{__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)}, P);
+            pu.x[e] = P.x; pi.x[e] = P.y;
+            mu.x[e] = M.x; mi.x[e] = M.y;
+            vu.x[e] = V.x; vi.x[e] = V.y;
+        }
+        store_row<E>(pu, a.Up + (size_t)ur * D, D, lane);
+        store_row<E>(mu, a.Um + (size_t)ur * D, D, lane);
+        store_row<E>(vu, a.Uv + (size_t)ur * D, D, lane);
+        store_row<E>(pi, a.Ip + (size_t)ir * D, D, lane);
+        store_row<E>(mi, a.Im + (size_t)ir * D, D, lane);
+        store_row<E>(vi, a.Iv + (size_t)ir * D, D, lane);
+        if (lane == 0) {
+            a.Ulast[ur] = a.step;
+            a.Ilast[ir] = a.step;
+        }
+        return;
+    }
+    step_shared_rows<E>(a, c, b, lane, ur, ir, iux, iix, seg_u, seg_i, dot, coef, smin, smax, K, pu, mu, vu, pi, mi, vi);
+}
+
+#if FR_STEP_TRACE
+#define g_phase phase_stamps     // per-wave (registers): set by the interaction path, stored by the kernel epilogue
+#endif
 // ---- the tasks ----------------------------------------------------------------------------------------------------
 // A wave's task is "two rows brought up to date, then something done with them":
 //   sweeper task q  : rows 2q, 2q + 1 of the step's slice (users first, then items), written back at step `step`;
 //   interaction b   : its user row and item row as of step - 1, then score, dLoss/dpred, both gradients, both updates.
-template <int E>
-__device__ __forceinline__ void step_task(SA a, bool sweeper, int q, int lane) {
+template <int E, bool PAIR>
+__device__ __forceinline__ void step_task(SA a, bool sweeper, int q, int lane
+#if FR_STEP_TRACE
+                                          , unsigned long long (&phase_stamps)[4]
+#endif
+) {
     // `lane` made opaque per task: otherwise every per-lane address (10 table pointers + lane) is hoisted out of the
     // wave's task loop and parked in VGPR pairs for the whole kernel (101 VGPRs = 4 waves per SIMD)
     asm volatile("" : "+v"(lane));
@@ -412,19 +521,57 @@ __device__ __forceinline__ void step_task(SA a, bool sweeper, int q, int lane) {
         }
         return;
     }
-    const int b = q;
-    const bool fair = a.objective != FR_FOCF_NONE;
-    // ---- level 1: two 16-byte records addressed by the batch position, and the batch header
-    const int4 rec = a.rec[b];
-    const int4 inf = a.info[b];
-    const int4 hd = *reinterpret_cast<const int4*>(a.hdr);
-    const int ur = uniform(rec.x), ir = uniform(rec.y);
-    const float rt = __int_as_float(uniform(rec.z)), s = __int_as_float(uniform(rec.w));
-    const int iux = uniform(inf.x), seg_u = uniform(inf.y), iix = uniform(inf.z), seg_i = uniform(inf.w);
-    const float K = (float)uniform(hd.x);
-    const float smin = __int_as_float(uniform(hd.z)), smax = __int_as_float(uniform(hd.w));
-    const int nu = iux >> 16, ni = iix >> 16;
-    // ---- level 2: the rows and their `last` stamps, requested together
+    if (PAIR) {
+        // ---- two interactions per wave, neighbours in the start order (= similar replay lengths): their two user rows go
+        // through the replay as one packed pair and so do their two item rows (4.5 instead of 7 VALU instructions per row
+        // and step); each interaction is then finished on its own
+        const bool has1 = q + 1 < a.B;
+        const int q1 = has1 ? q + 1 : q;
+        const int4 vrec0 = a.task_rec[q], vrec1 = a.task_rec[q1];
+        const int u0 = uniform(vrec0.x), i0 = uniform(vrec0.y), u1 = uniform(vrec1.x), i1 = uniform(vrec1.y);
+#if FR_STEP_TRACE
+        g_phase[2] = __builtin_amdgcn_s_memrealtime();     // level-1 records have arrived
+#endif
+        const int lu0 = a.Ulast[u0], lu1 = a.Ulast[u1], li0 = a.Ilast[i0], li1 = a.Ilast[i1];
+        TwoRows<E> it;       // r = the two user rows, it = the two item rows
+        load_row<E>(r.pA, a.Up + (size_t)u0 * D, D, lane);
+        load_row<E>(r.pB, a.Up + (size_t)u1 * D, D, lane);
+        load_row<E>(it.pA, a.Ip + (size_t)i0 * D, D, lane);
+        load_row<E>(it.pB, a.Ip + (size_t)i1 * D, D, lane);
+        load_row<E>(r.mA, a.Um + (size_t)u0 * D, D, lane);
+        load_row<E>(r.vA, a.Uv + (size_t)u0 * D, D, lane);
+        load_row<E>(r.mB, a.Um + (size_t)u1 * D, D, lane);
+        load_row<E>(r.vB, a.Uv + (size_t)u1 * D, D, lane);
+        load_row<E>(it.mA, a.Im + (size_t)i0 * D, D, lane);
+        load_row<E>(it.vA, a.Iv + (size_t)i0 * D, D, lane);
+        load_row<E>(it.mB, a.Im + (size_t)i1 * D, D, lane);
+        load_row<E>(it.vB, a.Iv + (size_t)i1 * D, D, lane);
+        const int upto = a.step - 1;
+        const int tu0 = uniform(lu0), tu1 = uniform(lu1), ti0 = uniform(li0), ti1 = uniform(li1);
+#if FR_STEP_TRACE
+        g_phase[0] = __builtin_amdgcn_s_memrealtime();     // rows have arrived
+        g_phase[3] = (unsigned long long)((upto - tu0) + (upto - tu1) + (upto - ti0) + (upto - ti1));
+#endif
+        replay_two<E>(r, tu0, tu1, upto, c, lane);
+        replay_two<E>(it, ti0, ti1, upto, c, lane);
+#if FR_STEP_TRACE
+        g_phase[1] = __builtin_amdgcn_s_memrealtime();     // replay done
+#endif
+        for (int k = 0; k < (has1 ? 2 : 1); ++k) {        // ONE instance of the finish: it works on the A rows
+            if (k) {                                      // second turn: the B rows take the A rows' place
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    r.pA.x[e] = r.pB.x[e]; r.mA.x[e] = r.mB.x[e]; r.vA.x[e] = r.vB.x[e];
+                    it.pA.x[e] = it.pB.x[e]; it.mA.x[e] = it.mB.x[e]; it.vA.x[e] = it.vB.x[e];
+                }
+            }
+            step_finish<E>(a, c, lane, q + k, r.pA, r.mA, r.vA, it.pA, it.mA, it.vA);
+        }
+        return;
+    }
+    // ---- one interaction per wave (wide rows: two interactions' rows would not fit the register budget)
+    const int4 vrec = a.task_rec[q];
+    const int ur = uniform(vrec.x), ir = uniform(vrec.y);
     const int lu = a.Ulast[ur], li = a.Ilast[ir];
     load_row<E>(r.pA, a.Up + (size_t)ur * D, D, lane);
     load_row<E>(r.pB, a.Ip + (size_t)ir * D, D, lane);
@@ -435,37 +582,7 @@ __device__ __forceinline__ void step_task(SA a, bool sweeper, int q, int lane) {
     tA = uniform(lu);
     tB = uniform(li);
     replay_two<E>(r, tA, tB, a.step - 1, c, lane);
-    float dot = 0.f;
-#pragma unroll
-    for (int e = 0; e < E; ++e) dot = fmaf(r.pA.x[e], r.pB.x[e], dot);
-    dot = wave_sum(dot);
-    const float er = dot - rt;
-    if (lane == 0) a.mse_e[b] = er * er;
-    const float cm = 2.f * er / (float)a.B;        // d mean((pred - r)^2) / d pred
-    // dLoss/dpred of an interaction whose item has no other member in the batch: its per-item statistics are its own
-    float coef = cm;
-    if (ni == 1 && fair) {
-        const bool in0 = s == smin;
-        if (s != smin && s != smax && lane == 0 && a.err) atomicOr(a.err, FR_DEV_ERR_SST_GROUPS);
-        float term, g0, g1;
-        focf_fair_eval(a.objective, a.fair_weight, K, in0 ? dot : 0.f, in0 ? 0.f : dot, in0 ? rt : 0.f, in0 ? 0.f : rt,
-                       in0 ? 1.f : 0.f, in0 ? 0.f : 1.f, term, g0, g1);
-        coef = cm + (in0 ? g0 : g1);
-        if (lane == 0) a.term[seg_i] = term;
-    }
-    if (ni == 1 && nu == 1) {      // ---- nobody else touches either row: finish here
-        const float2 sc = step_scalars(c, a.step);
-        RowFrag<E> gu, gi;
-#pragma unroll
-        for (int e = 0; e < E; ++e) {
-            gu.x[e] = coef * r.pB.x[e];
-            gi.x[e] = coef * r.pA.x[e];
-        }
-        adam_write<E>(a.Up, a.Um, a.Uv, a.Ulast, D, a.step, c, ur, r.pA, r.mA, r.vA, gu, sc, lane);
-        adam_write<E>(a.Ip, a.Im, a.Iv, a.Ilast, D, a.step, c, ir, r.pB, r.mB, r.vB, gi, sc, lane);
-        return;
-    }
-    step_shared_rows<E>(a, c, b, lane, ur, ir, iux, iix, seg_u, seg_i, dot, coef, smin, smax, K, r);
+    step_finish<E>(a, c, lane, q, r.pA, r.mA, r.vA, r.pB, r.mB, r.vB);
 }
 
 // fixed-order reduction of one batch's squared errors and per-item terms -> loss (one workgroup of 256 threads).  The
@@ -515,6 +632,9 @@ __device__ __forceinline__ void step_reduce_loss(const PrevLoss& pl) {
     }
 }
 
+// two interactions per wave while their twelve row fragments fit the register budget without scratch (D <= 64)
+__host__ __device__ constexpr bool step_pairs(int E) { return E <= 1; }
+
 // Block 0 reduces an earlier step's loss (if any); the sweeper blocks and the interaction blocks are dealt evenly through
 // the rest of the grid (one task per wave), so that from the first moment the resident waves are a mix of sweeper waves
 // (one round trip, then up to S replayed steps of pure VALU work) and interaction waves (two dependent round trips first).
@@ -526,7 +646,7 @@ __device__ __forceinline__ void step_reduce_loss(const PrevLoss& pl) {
 #define FR_STEP_TRACE 0
 #endif
 #if FR_STEP_TRACE   // diagnostic build: (start, end) in 10 ns ticks, role and placement of every wave of one launch
-__device__ unsigned long long g_step_trace[4 * 65536];
+__device__ unsigned long long g_step_trace[8 * 65536];
 #endif
 
 #ifndef FR_STEP_WAVES
@@ -536,6 +656,7 @@ template <int E>
 __global__ __launch_bounds__(256, FR_STEP_WAVES) void focf_step_kernel(StepArgs a) {
 #if FR_STEP_TRACE
     const unsigned long long tr0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long ph[4] = {0, 0, 0, 0};
 #endif
     const int lane = threadIdx.x & 63;
     const int wib = uniform((int)(threadIdx.x >> 6));      // wave-uniform, and the compiler has to know it
@@ -547,13 +668,18 @@ __global__ __launch_bounds__(256, FR_STEP_WAVES) void focf_step_kernel(StepArgs 
         ArgP ap = (ArgP)__builtin_amdgcn_kernarg_segment_ptr();
         const int x = (int)blockIdx.x - 1;
         const int n_pairs = ((a.n_u + 1) >> 1) + ((a.n_i + 1) >> 1);
-        const long long ns = (n_pairs + 3) >> 2, nt = ns + ((a.B + 3) >> 2);
-        // sweeper blocks before x: floor(x * ns / nt); block x is a sweeper block when that count steps at x + 1
-        const int before = (int)((long long)x * ns / nt);
-        const bool sweeper = (int)((long long)(x + 1) * ns / nt) != before;
-        const int q = (sweeper ? before : x - before) * 4 + wib;
+        const int ns = (n_pairs + 3) >> 2;
+        // longest jobs first: the `lead` workgroups of the interactions with the longest replays (the task list is in
+        // that order), then the sweeper workgroups (a full period of replay each), then the other interactions
+        constexpr bool PAIR = step_pairs(E);
+        const bool sweeper = x >= a.lead && x < a.lead + ns;
+        const int q = ((sweeper ? x - a.lead : (x < a.lead ? x : x - ns)) * 4 + wib) * (!sweeper && PAIR ? 2 : 1);
         role = sweeper ? 1 : 2;
-        if (q < (sweeper ? n_pairs : a.B)) step_task<E>(*ap, sweeper, q, lane);
+#if FR_STEP_TRACE
+        if (q < (sweeper ? n_pairs : a.B)) step_task<E, PAIR>(*ap, sweeper, q, lane, ph);
+#else
+        if (q < (sweeper ? n_pairs : a.B)) step_task<E, PAIR>(*ap, sweeper, q, lane);
+#endif
     }
 #if FR_STEP_TRACE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -566,11 +692,88 @@ __global__ __launch_bounds__(256, FR_STEP_WAVES) void focf_step_kernel(StepArgs 
         g_step_trace[4 * wq + 1] = tr1;
         g_step_trace[4 * wq + 2] = role;
         g_step_trace[4 * wq + 3] = hw;
+        g_step_trace[4 * (65536 + wq)] = ph[2];
+        g_step_trace[4 * (65536 + wq) + 1] = ph[0];
+        g_step_trace[4 * (65536 + wq) + 2] = ph[1];
+        g_step_trace[4 * (65536 + wq) + 3] = ph[3];
     }
 #endif
 }
 
 __global__ __launch_bounds__(256) void focf_step_finish_kernel(PrevLoss pl) { step_reduce_loss(pl); }
+
+// Start order of the interactions of a batch: longest replay first (the launch ends one wave latency after its last wave
+// starts, and a wave's latency is its replay length: 3.4 us with nothing to replay, 25 us with 2 x 123 steps).  One
+// workgroup per batch, behind the index sort on the look-ahead stream: estimated VALU cost from the rows' `last` stamps as
+// of NOW (a row touched again before the batch runs has less to replay than estimated -- only the order is affected,
+// never a result), counting sort on 256 cost classes, records rewritten in that order.
+struct LptJob {
+    const int4 *rec, *info;
+    int4 *task_rec, *task_info;
+    int B, upto;
+};
+struct LptJobs {
+    LptJob j[FR_FOCF_PREPARE_MAX];
+    const int32_t *Ulast, *Ilast;
+    int cap;      // replay lengths are bounded by the sweep period
+};
+
+__global__ __launch_bounds__(1024) void focf_lpt_kernel(LptJobs jobs) {
+    const LptJob& J = jobs.j[blockIdx.x];
+    __shared__ int hist[256];
+    __shared__ int wsum[4];
+    constexpr int PT = FR_SORT_MAX / 1024;
+    const int tid = threadIdx.x;
+    if (tid < 256) hist[tid] = 0;
+    __syncthreads();
+    int key[PT];
+    const int cap = jobs.cap > 0 ? jobs.cap : 1024;
+#pragma unroll
+    for (int q = 0; q < PT; ++q) {
+        const int b = q * 1024 + tid;
+        key[q] = -1;
+        if (b < J.B) {
+            const int4 r = J.rec[b];
+            int cu = J.upto - jobs.Ulast[r.x], ci = J.upto - jobs.Ilast[r.y];
+            cu = cu < 0 ? 0 : (cu > cap ? cap : cu);
+            ci = ci < 0 ? 0 : (ci > cap ? cap : ci);
+            const int hi = cu > ci ? cu : ci, lo = cu > ci ? ci : cu;
+            const int cost = 7 * hi + 2 * lo;                          // VALU instructions: alone 7, as a pair 9 per step
+            const int k = 255 - min(255, cost * 255 / (9 * cap));      // class 0 = the longest
+            key[q] = k;
+            atomicAdd(&hist[k], 1);
+        }
+    }
+    __syncthreads();
+    if (tid < 256) {       // exclusive scan of the 256 class counts (4 waves)
+        const int x = hist[tid];
+        int inc = x;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int y = __shfl_up(inc, o, 64);
+            if ((tid & 63) >= o) inc += y;
+        }
+        if ((tid & 63) == 63) wsum[tid >> 6] = inc;
+        hist[tid] = inc - x;
+    }
+    __syncthreads();
+    if (tid < 256) {
+        int off = 0;
+        for (int w = 0; w < (tid >> 6); ++w) off += wsum[w];
+        hist[tid] += off;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < PT; ++q) {
+        const int b = q * 1024 + tid;
+        if (key[q] >= 0) {
+            const int pos = atomicAdd(&hist[key[q]], 1);     // ties in arrival order: any order gives the same results
+            const int4 f = J.info[b];
+            J.task_rec[pos] = J.rec[b];
+            J.task_info[pos] = make_int4(f.x, f.z, f.y | (f.w << 16), b);
+        }
+    }
+}
 
 static PrevLoss prev_of(void* ws, int64_t B, int dim, int objective, float fair_weight, float* loss_out, float* acc) {
     PrevLoss pl{};
@@ -592,7 +795,7 @@ static PrevLoss prev_of(void* ws, int64_t B, int dim, int objective, float fair_
 using namespace fr;
 
 extern "C" int fr_focf_prepare_step(const fr_focf_batch* batches, const int32_t* stamps, int32_t n, const fr_table* U,
-                                    const fr_table* I, uint32_t* err_flag, void* stream_) {
+                                    const fr_table* I, int32_t replay_cap, uint32_t* err_flag, void* stream_) {
     int rc;
     if ((rc = check_table(U, "fr_focf_prepare_step(U)")) || (rc = check_table(I, "fr_focf_prepare_step(I)"))) return rc;
     FR_CHECK_ARG(batches && stamps && n >= 1 && 2 * n <= FR_SORT_JOBS && U->dim == I->dim,
@@ -625,7 +828,19 @@ extern "C" int fr_focf_prepare_step(const fr_focf_batch* batches, const int32_t*
         jobs.M[2 * q] = jobs.M[2 * q + 1] = (int)b.B;
     }
     jobs.n = 2 * n;
-    return launch_sort_many(jobs, U->n_rows > I->n_rows ? U->n_rows : I->n_rows, err_flag, (hipStream_t)stream_);
+    if ((rc = launch_sort_many(jobs, U->n_rows > I->n_rows ? U->n_rows : I->n_rows, err_flag, (hipStream_t)stream_)))
+        return rc;
+    LptJobs lj{};
+    for (int q = 0; q < n; ++q) {
+        const FocfWs w = focf_layout(batches[q].ws, batches[q].B, U->dim);
+        lj.j[q] = LptJob{w.rec, w.info, w.task_rec, w.task_info, (int)batches[q].B, stamps[q] - 1};
+    }
+    lj.Ulast = U->last;
+    lj.Ilast = I->last;
+    lj.cap = replay_cap;
+    hipLaunchKernelGGL(focf_lpt_kernel, dim3(n), dim3(1024), 0, (hipStream_t)stream_, lj);
+    FR_CHECK_LAUNCH();
+    return FR_OK;
 }
 
 extern "C" int fr_focf_step(const fr_table* U, const fr_table* I, const fr_adam* adam, const int64_t* user,
@@ -659,8 +874,9 @@ extern "C" int fr_focf_step(const fr_table* U, const fr_table* I, const fr_adam*
     a.B = (int)B;
     a.objective = objective;
     a.fair_weight = fair_weight;
-    a.rec = w.rec;
-    a.info = w.info;
+    a.task_rec = w.task_rec;
+    a.task_info = w.task_info;
+    static const int lead_pct = getenv("FAIRREC_STEP_LEAD") ? atoi(getenv("FAIRREC_STEP_LEAD")) : 100;
     a.hdr = w.nseg_i;
     a.mse_e = w.mse_e;
     a.term = w.term;
@@ -677,7 +893,10 @@ extern "C" int fr_focf_step(const fr_table* U, const fr_table* I, const fr_adam*
     (void)loss_out;   // reduced by the NEXT fr_focf_step (prev_*) or by fr_focf_step_finish
     {
         ProfScope prof(K_FOCF_STEP, stream);
-        const unsigned blocks = (unsigned)(1 + (sweep_waves + 3) / 4 + (B + 3) / 4);
+        const long long per_wave = step_pairs((U->dim + 63) / 64) ? 2 : 1;
+        const long long inter_blocks = ((B + per_wave - 1) / per_wave + 3) / 4;
+        const unsigned blocks = (unsigned)(1 + (sweep_waves + 3) / 4 + inter_blocks);
+        a.lead = (int)(inter_blocks * lead_pct / 100);
         FR_DISPATCH_E(U->dim, FR_LAUNCH(prof, (focf_step_kernel<E>), dim3(blocks), dim3(256), 0, stream, a));
     }
     FR_CHECK_LAUNCH();
@@ -688,6 +907,8 @@ extern "C" int fr_focf_step(const fr_table* U, const fr_table* I, const fr_adam*
 extern "C" __attribute__((visibility("default"))) int fr_debug_step_trace(unsigned long long* host_out, int n_waves) {
     FR_CHECK_HIP(hipDeviceSynchronize());
     FR_CHECK_HIP(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_step_trace), (size_t)n_waves * 32));
+    FR_CHECK_HIP(hipMemcpyFromSymbol(host_out + 4 * (size_t)n_waves, HIP_SYMBOL(g_step_trace), (size_t)n_waves * 32,
+                                     (size_t)65536 * 32));
     return FR_OK;
 }
 #endif

@@ -33,6 +33,10 @@ struct FocfWs {
     // segment, per-interaction squared errors, per-item smooth-L1 terms
     int4* rec;
     int4* info;
+    // ... and the same two records in the order the launch should START the interactions (longest replay first), the
+    // second one repacked as (user j0 | n << 16, item j0 | n << 16, user segment | item segment << 16, batch position)
+    int4* task_rec;
+    int4* task_info;
     unsigned int *cnt_u, *cnt_i;
     float* mse_e;        // [B]
     float* term;         // [B] indexed by item segment
@@ -78,6 +82,8 @@ __host__ __device__ inline FocfWs focf_layout(void* base, int64_t B, int D) {
     w.clip_part = (float*)take(((2 * (size_t)B + 3) / 4) * 4);
     w.rec = (int4*)take(Bp * 16);
     w.info = (int4*)take(Bp * 16);
+    w.task_rec = (int4*)take(Bp * 16);
+    w.task_info = (int4*)take(Bp * 16);
     w.cnt_u = (unsigned int*)take(Bp * 4);
     w.cnt_i = (unsigned int*)take(Bp * 4);
     w.mse_e = (float*)take(Bp * 4);

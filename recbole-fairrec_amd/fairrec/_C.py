@@ -61,7 +61,7 @@ _PROTOS = {
     "fr_focf_backward_adam": (c_int, [POINTER(FrTable), POINTER(FrTable), POINTER(FrAdam), c_int64, c_int32,
                                       c_void_p, c_size_t, c_void_p]),
     "fr_focf_prepare_step": (c_int, [POINTER(FrFocfBatch), POINTER(c_int32), c_int32, POINTER(FrTable), POINTER(FrTable),
-                                     c_void_p, c_void_p]),
+                                     c_int32, c_void_p, c_void_p]),
     "fr_focf_step": (c_int, [POINTER(FrTable), POINTER(FrTable), POINTER(FrAdam), c_void_p, c_void_p, c_void_p, c_void_p,
                              c_int64, c_int32, c_float, c_int32, c_int32, c_void_p, c_size_t, c_void_p, c_void_p, c_int64,
                              c_void_p, c_void_p, c_void_p, c_void_p]),

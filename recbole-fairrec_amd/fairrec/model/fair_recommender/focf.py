@@ -156,7 +156,8 @@ class FocfEngine:
             self.I.ensure_state()
             tu, ti = self.U.c(), self.I.c()
             rc = _C.lib().fr_focf_prepare_step(arr, stamps, len(batches), ctypes.byref(tu), ctypes.byref(ti),
-                                               self.err_flag.data_ptr(), self._side.cuda_stream)
+                                               self._sweep(batches[0][0].numel()), self.err_flag.data_ptr(),
+                                               self._side.cuda_stream)
             _C.check(rc, "fr_focf_prepare_step")
         else:
             rc = _C.lib().fr_focf_prepare_many(arr, len(batches), self.U.n_rows, self.I.n_rows, self.U.dim,
@@ -237,7 +238,7 @@ class FocfEngine:
                 stamp = self._next_stamp()
                 tu, ti = self.U.c(), self.I.c()
                 rc = _C.lib().fr_focf_prepare_step(arr, (ctypes.c_int32 * 1)(stamp), 1, ctypes.byref(tu), ctypes.byref(ti),
-                                                   self.err_flag.data_ptr(), _C.current_stream())
+                                                   self._sweep(B), self.err_flag.data_ptr(), _C.current_stream())
                 _C.check(rc, "fr_focf_prepare_step")
             self._stash = (user, item, rating, sst, B, ws, stamp, loss)
             self.pending_B = B

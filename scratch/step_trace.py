@@ -22,10 +22,12 @@ for k in range(K):
 torch.cuda.synchronize()
 lib = ctypes.CDLL(_C.LIB_PATH)
 n = 16384
-buf = np.zeros((n, 4), dtype=np.uint64)
-rc = lib.fr_debug_step_trace(buf.ctypes.data_as(ctypes.c_void_p), n)
+both = np.zeros((2 * n, 4), dtype=np.uint64)
+rc = lib.fr_debug_step_trace(both.ctypes.data_as(ctypes.c_void_p), n)
 assert rc == 0
-buf = buf[buf[:, 1] > 0]
+buf, phs = both[:n], both[n:]
+keep = buf[:, 1] > 0
+buf, phs = buf[keep], phs[keep]
 t0 = buf[:, 0].min()
 st = (buf[:, 0] - t0).astype(np.float64) / 100.0   # us
 en = (buf[:, 1] - t0).astype(np.float64) / 100.0
@@ -43,3 +45,15 @@ ts = np.linspace(0, en.max(), 40)
 occ = [(int(((st <= t) & (en > t) & (role == 1)).sum()), int(((st <= t) & (en > t) & (role == 2)).sum())) for t in ts]
 print("t(us): resident sweeper / interaction waves")
 print("  ".join(f"{t:.1f}:{a}/{b}" for t, (a, b) in zip(ts, occ)))
+
+m = (role == 2) & (phs[:, 0] > 0)
+l1 = (phs[m, 0] - buf[m, 0]).astype(np.float64) / 100.0
+l2 = (phs[m, 1] - phs[m, 0]).astype(np.float64) / 100.0
+rp = (phs[m, 2] - phs[m, 1]).astype(np.float64) / 100.0
+fin = (buf[m, 1] - phs[m, 2]).astype(np.float64) / 100.0
+steps = phs[m, 3].astype(np.float64)
+print("interaction phases (us): level-1 %.2f/%.2f  level-2 %.2f/%.2f  replay %.2f/%.2f  finish %.2f/%.2f  (median/p90); row-steps median %.0f mean %.0f max %.0f"
+      % (np.median(l1), np.percentile(l1, 90), np.median(l2), np.percentile(l2, 90), np.median(rp), np.percentile(rp, 90),
+         np.median(fin), np.percentile(fin, 90), np.median(steps), steps.mean(), steps.max()))
+ok = steps > 20
+print("replay us per row-step: median %.4f  p10 %.4f p90 %.4f" % (np.median(rp[ok] / steps[ok]), np.percentile(rp[ok] / steps[ok], 10), np.percentile(rp[ok] / steps[ok], 90)))

@@ -177,7 +177,7 @@ def test_lookahead_sweep_equals_plain_chain(objective, dim, item_dist):
     for b in engs[1:]:
         for x, y in ((b.U.weight, a.U.weight), (b.I.weight, a.I.weight), (b.U.m, a.U.m), (b.I.m, a.I.m),
                      (b.U.v, a.U.v), (b.I.v, a.I.v)):
-            torch.testing.assert_close(x, y, rtol=5e-5, atol=1e-7 * float(y.abs().max()) + 1e-12)
+            torch.testing.assert_close(x, y, rtol=1e-4, atol=1e-6 * float(y.abs().max()) + 1e-12)
 
 
 def test_full_size_steps_match_the_oracle():
