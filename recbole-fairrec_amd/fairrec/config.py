@@ -27,6 +27,12 @@ def _yaml_loader():
     return loader
 
 
+# the reference's `smaller_metrics` (evaluator/register.py:62: every metric class with `smaller = True`)
+SMALLER_METRICS = frozenset(("mae", "rmse", "logloss", "averagepopularity", "giniindex", "nonparityunfairness",
+                             "valueunfairness", "absoluteunfairness", "underunfairness", "overunfairness",
+                             "differentialfairness"))
+
+
 class Config:
     def __init__(self, model: Optional[str] = None, dataset: Optional[str] = None,
                  config_file_list: Optional[Iterable[str]] = None, config_dict: Optional[Dict] = None):
@@ -59,7 +65,9 @@ class Config:
         elif isinstance(d["device"], str):
             d["device"] = torch.device(d["device"])
         if isinstance(d.get("valid_metric"), str):
-            d.setdefault("valid_metric_bigger", True)
+            # configurator.py:306-307: always derived from the metric's name (a config cannot set it): False exactly for
+            # the metrics the reference's classes declare `smaller = True` (evaluator/metrics.py)
+            d["valid_metric_bigger"] = d["valid_metric"].split("@")[0].lower() not in SMALLER_METRICS
         self._set_train_neg_sample_args()
         if d.get("MODEL_INPUT_TYPE") is None and d.get("model") is not None:   # configurator.py:274-275
             try:

@@ -42,6 +42,16 @@ class AbstractRecommender(nn.Module):
     def hip_engine(self):
         return None
 
+    def load_state_dict(self, state_dict, *args, **kwargs):
+        """The reference evaluates / resumes exactly the checkpointed weights (trainer.py:258-284, :478-483).  A lazy-Adam
+        table may still hold rows that are behind the optimizer step (any epoch that did not end in a flush): left alone,
+        their missed zero-gradient steps would later be replayed ON TOP of the loaded weights.  So bring every row up to
+        date first (flush: `last == step`, nothing left to replay), then copy."""
+        eng = getattr(self, '_engine', None)
+        if eng is not None and hasattr(eng, 'flush'):
+            eng.flush()
+        return super().load_state_dict(state_dict, *args, **kwargs)
+
     def __str__(self):
         n = sum(int(np.prod(p.size())) for p in self.parameters() if p.requires_grad)
         return super().__str__() + f'\nTrainable parameters: {n}'

@@ -421,6 +421,24 @@ class PFCNTrainer(Trainer):
             state['optimizer'] = self.optimizer.state_dict()
         torch.save(state, saved_model_file)
 
+    def resume_checkpoint(self, resume_file):
+        """trainer.py:1156-1186 as intended: the two optimizers of the filtered modes, the plain one for filter_mode none
+        (the reference has the two branches swapped, SURVEY.md App. B-10, and raises on either)."""
+        resume_file = str(resume_file)
+        self.saved_model_file = resume_file
+        checkpoint = torch.load(resume_file, weights_only=False)
+        self.start_epoch = checkpoint['epoch'] + 1
+        self.cur_step = checkpoint['cur_step']
+        self.best_valid_score = checkpoint['best_valid_score']
+        self.model.load_state_dict(checkpoint['state_dict'])
+        self.model.load_other_parameter(checkpoint.get('other_parameter'))
+        if self.filter_mode != 'none':
+            self.optimizer_filter.load_state_dict(checkpoint['optimizer_filter'])
+            self.optimizer_dis.load_state_dict(checkpoint['optimizer_dis'])
+        else:
+            self.optimizer.load_state_dict(checkpoint['optimizer'])
+        self.logger.info('Checkpoint loaded. Resume training from epoch %d', self.start_epoch)
+
     def _subsets(self):
         import itertools
         attrs = self.config['sst_attr_list']

@@ -136,6 +136,22 @@ def test_fairgo_trainer_pretrain_then_finetune(tmp_path):
     assert all(d.step == 2 * 3 for k, d in eng._dense.items() if k.startswith("filter."))   # every finetune epoch (interval 1)
     assert os.path.exists(trainer.saved_pretrain_model_file)
     assert get_model("FairGo_GCN").__mro__[1].__name__ == "FairGo_PMF"
+    # resume of the finetune checkpoint (trainer.py:807-834): optimizer_filter / optimizer_dis come back
+    ck = torch.load(trainer.saved_model_file, weights_only=False)
+    cfg2 = Config(model="FairGo_PMF", dataset="synth", config_dict=dict(
+        {k: cfg[k] for k in ("embedding_size", "aggr_method", "n_layers", "filter_hidden_size_list", "dis_hidden_size_list",
+                             "train_batch_size", "epochs", "pretrain_epochs", "train_epoch_interval", "checkpoint_dir")},
+        device="cuda", pretrain_model_file_path=trainer.saved_pretrain_model_file))
+    model2 = get_model("FairGo_PMF")(cfg2, ds).to("cuda")
+    trainer2 = get_trainer(None, "FairGo_PMF")(cfg2, model2)
+    trainer2.resume_checkpoint(trainer.saved_model_file)
+    assert trainer2.start_epoch == ck["epoch"] + 1
+    eng2 = model2.hip_engine()
+    for k, st in list(ck["optimizer_filter"]["state"].items()) + list(ck["optimizer_dis"]["state"].items()):
+        if k in eng2._dense:
+            assert eng2._dense[k].step == int(st["step"])
+            assert torch.equal(eng2._dense[k].m, st["exp_avg"].to("cuda"))
+    assert torch.equal(model2.user_embedding_layer.weight, model.state_dict()["user_embedding_layer.weight"])
 
 
 def test_fairgo_gcn_pretrain_matches_the_restated_pyg_gcn(tmp_path):

@@ -45,6 +45,19 @@ def test_config_priority_and_missing_keys(tmp_path):
     assert c["learner"] == "adam" and c["learning_rate"] == 0.001
 
 
+def test_valid_metric_bigger_follows_the_metric_name():
+    """configurator.py:306-307: `valid_metric_bigger` is derived from the metric (False for the reference's
+    smaller-is-better classes), whatever a config says -- FOCF.yaml's `valid_metric: NDCG@5` must be maximised."""
+    from fairrec.config import Config
+    for metric, bigger in (("NDCG@5", True), ("rmse", False), ("MRR@10", True), ("ValueUnfairness", False),
+                           ("DifferentialFairness", False), ("GiniIndex@10", False), ("Recall@20", True)):
+        for given in (True, False, None):
+            d = {"valid_metric": metric, "device": "cpu"}
+            if given is not None:
+                d["valid_metric_bigger"] = given
+            assert Config(model=None, config_dict=d)["valid_metric_bigger"] is bigger, (metric, given)
+
+
 def test_adam_scalars_match_torch_formula():
     tab = adam_step_scalars(1e-3, 0.9, 0.999, 40000)
     for j in (1, 2, 10, 1000, 20000, 40000):

@@ -158,3 +158,28 @@ def test_pfcn_trainer_alternating_schedule(tmp_path, graph):
     assert eng._dense["global_bias"].step == 2 * steps_per_epoch    # zero gradient, but present: it still steps (App. B-1)
     ck = torch.load(trainer.saved_model_file, weights_only=False)
     assert {"optimizer_filter", "optimizer_dis", "state_dict"} <= set(ck)
+    # resume (trainer.py:1156-1186 as intended): both optimizers' lazy state comes back, training continues from there
+    init_seed(7)
+    model2 = get_model("PFCN_BiasedMF")(cfg, ds).to("cuda")
+    trainer2 = trainer_cls(cfg, model2)
+    trainer2.resume_checkpoint(trainer.saved_model_file)
+    assert trainer2.start_epoch == ck["epoch"] + 1
+    eng2 = model2.hip_engine()
+    eng2.sync_steps()
+    t2 = eng2._tables["user_embedding_layer.weight"]
+    assert t2.step == int(ck["optimizer_filter"]["state"]["user_embedding_layer.weight"]["step"]) > 0
+    assert torch.equal(t2.m, ck["optimizer_filter"]["state"]["user_embedding_layer.weight"]["exp_avg"].to("cuda"))
+    assert torch.equal(model2.user_embedding_layer.weight, ck["state_dict"]["user_embedding_layer.weight"].to("cuda"))
+    for k, st in ck["optimizer_dis"]["state"].items():
+        assert eng2._dense[k].step == int(st["step"])
+    cfg_none = Config(model="PFCN_BiasedMF", config_dict={
+        "embedding_size": 16, "sst_attr_list": ["gender", "age"], "filter_mode": "none", "train_batch_size": 120,
+        "epochs": 1, "device": "cuda", "checkpoint_dir": str(tmp_path / "none")})
+    os.makedirs(str(tmp_path / "none"), exist_ok=True)
+    m3 = get_model("PFCN_BiasedMF")(cfg_none, ds).to("cuda")
+    t3 = trainer_cls(cfg_none, m3)
+    t3.fit(TrainDataLoader(cfg_none, ds, shuffle=True), valid_data=None, verbose=False, saved=True)
+    m4 = get_model("PFCN_BiasedMF")(cfg_none, ds).to("cuda")
+    t4 = trainer_cls(cfg_none, m4)
+    t4.resume_checkpoint(t3.saved_model_file)
+    assert m4.hip_engine()._tables["user_embedding_layer.weight"].step == 5

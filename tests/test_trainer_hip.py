@@ -96,3 +96,26 @@ def test_unsupported_paths_fail_loudly(tmp_path):
     with pytest.raises(ValueError):
         cfg2 = Config(model="FOCF", config_dict={"device": "cuda", "fair_objective": "bogus"})
         get_model("FOCF")(cfg2, ds)
+
+
+def test_evaluate_load_best_model_after_a_non_saving_epoch(tmp_path):
+    """evaluate(load_best_model=True) must score exactly the checkpointed weights (reference trainer.py:478-483), also
+    when the epochs after the checkpoint left rows of the lazy-Adam tables behind the optimizer step: loading must not
+    let their missed zero-gradient steps be replayed on top of the loaded weights."""
+    cfg, ds, train, model, trainer = _setup(tmp_path, epochs=1)
+    trainer._train_epoch(train, 0)
+    trainer._save_checkpoint(0, verbose=False)
+    trainer._train_epoch(train, 1)                 # an epoch that saves nothing: rows stay behind `step`
+    eng = model.hip_engine()
+    assert eng.U._dirty or eng.I._dirty
+    ckpt = torch.load(trainer.saved_model_file, weights_only=False)
+    trainer._load_for_eval(True, None)
+    b = next(iter(train)).to("cuda")
+    got = model.predict(b)
+    fs = model.full_sort_predict(b[:4])
+    cfg2, ds2, train2, fresh, _ = _setup(tmp_path, epochs=1)
+    fresh.load_state_dict(ckpt["state_dict"])
+    want = fresh.predict(b)
+    assert torch.equal(got, want)
+    assert torch.equal(fs, fresh.full_sort_predict(b[:4]))
+    assert torch.equal(model.user_embedding_layer.weight, ckpt["state_dict"]["user_embedding_layer.weight"].to("cuda"))
