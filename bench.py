@@ -7,8 +7,9 @@ already resident in HBM.  Workload: FOCF, fair_objective=value, 1 000 001 users 
 embedding_size 64, B = 8192 per GPU, Adam lr 1e-3 with the reference's coupled weight_decay 1e-3
 (SURVEY.md §8-d cfg 2; uniform-random pairs = the figure of record).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W]          (N > 1 without a launcher: spawns torch.distributed.run itself)
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --workload nfcf100m [--gpus N]               (BASELINE.json configs[4]: NFCF finetune, tables row-sharded)
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`.
 """
@@ -99,8 +100,130 @@ def cpu_baseline(budget_s=20.0):
                       f"oracle FOCF step + dense torch.optim.Adam, {dt:.1f} s"}
 
 
+NFCF_ALGO_BYTES = 16 + 8 + 4 * 256 * 2 + 8 * 256 * 1 + 12 * 256 * 1      # SURVEY.md §8-d cfg 5 finetune = 7192 B / interaction
+
+
+def bench_nfcf(args, rank, world, dev):
+    """BASELINE.json configs[4]: NFCF finetune (fair_weight 0.1, mlp_hidden_size [128, 64], user table frozen, item table
+    lazy Adam) at --nfcf-users x --nfcf-items, D = 256, B = 8192 per rank; with more than one rank both tables are
+    row-sharded over the ranks (fairrec/sharded_engine.py: 3 all-to-alls per lookup + one flat all-reduce of the dense
+    gradients).  One step = zero_grad, calculate_loss, backward, optimizer.step() through the plugin surface."""
+    from fairrec.config import Config
+    from fairrec.data.interaction import Interaction
+    from fairrec.optim import FusedLazyAdam
+    from fairrec.utils import get_model
+    nu, ni, D, B = args.nfcf_users, args.nfcf_items, 256, BATCH
+    K, W = args.steps, args.warmup
+
+    class DS:
+        inter_feat = {"rating": torch.tensor([1.0, 5.0])}
+
+        def num(self, f):
+            return {"user_id": nu, "item_id": ni}[f]
+
+        def get_user_feature(self):
+            return Interaction({"user_id": torch.arange(4), "gender": torch.tensor([0., 1., 0., 1.])})
+
+    cfg = Config(model="NFCF", config_dict={"embedding_size": D, "device": dev, "load_pretrain_path": None, "fair_weight": 0.1,
+                                            "mlp_hidden_size": [128, 64], "row_sharded": world > 1,
+                                            "graph_train_step": False})
+    torch.manual_seed(SEED)          # the replicated scorer MLP must start identical on every rank
+    with torch.device(dev):
+        m = get_model("NFCF")(cfg, DS())
+    m = m.to(dev).train()
+    m.load_pretrain_path = "finetune"                 # the finetune branch of calculate_loss (differential fairness term)
+    m.user_embedding.weight.requires_grad = False     # what reset_params leaves behind: the projected user table is frozen
+    opt = FusedLazyAdam(m.hip_engine(), lr=LR, weight_decay=1e-6)
+    g = torch.Generator().manual_seed(SEED + 1 + rank)
+    data = []
+    for _ in range(16):
+        u = torch.randint(1, nu, (B,), generator=g)
+        r = torch.randint(1, 6, (B,), generator=g).float()
+        data.append(Interaction({"user_id": u, "item_id": torch.randint(1, ni, (B,), generator=g), "rating": r,
+                                 "label": (r >= 3).float(), "gender": (u % 2).float()}).to(dev))
+
+    def step(k):
+        opt.zero_grad()
+        loss = m.calculate_loss(data[k % len(data)])
+        loss.backward()
+        opt.step()
+        return loss
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for k in range(W):
+        step(k)
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(W, W + K):
+        loss = step(k)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    m.hip_engine().check_device_errors()
+    total = K * B * world
+    achieved = NFCF_ALGO_BYTES * B / (dt / K) / 1e9
+    return {
+        "metric": "training interactions/sec + achieved HBM GB/s, NFCF finetune emb=256 (BASELINE.json configs[4])",
+        "value": round(total / dt, 1), "unit": "interactions/s", "n_gpus": world, "steps": K, "warmup": W,
+        "ms_per_step": round(dt / K * 1e3, 5), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"NFCF finetune, {nu} users x {ni} items, embedding_size={D}, B={B} per GPU, user table frozen, "
+                               "item table lazy Adam lr=1e-3 wd=1e-6, mlp [512,128,64,1], fair_weight 0.1",
+                   "tables": f"row-sharded over {world} ranks (owner = row mod {world}), RCCL all-to-all" if world > 1 else "single GPU",
+                   "global_batch": B * world, "launch": "eager", "final_loss": round(float(loss), 6),
+                   "peak_mem_GiB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)},
+        "roofline": {"bound": "hbm", "kernel": "whole step (no dominant kernel: gather, MLP, loss, apply)",
+                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                     "algorithmic_bytes_per_launch": NFCF_ALGO_BYTES * B},
+    }
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start N ranks with torch.distributed.run as a CHILD process --
+    before anything in this process has touched the GPU -- relay what they print (rank 0's JSON line) and leave with
+    their exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    proc = subprocess.run(cmd, env=env)
+    raise SystemExit(proc.returncode)
+
+
+def dry_launch(args, rank, world):
+    """Launch-path check without a GPU: the ranks rendezvous over gloo, all-reduce one number, rank 0 reports."""
+    import torch.distributed as dist
+    dist.init_process_group("gloo")
+    t = torch.ones(1) * (rank + 1)
+    dist.all_reduce(t)
+    dist.barrier()
+    if rank == 0:
+        print(json.dumps({"dry_launch": True, "n_gpus": world, "ranks_seen": world, "sum_of_ranks": float(t.item()),
+                          "workload": args.workload}), flush=True)
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="focf", choices=["focf", "nfcf100m"],
+                    help="focf = BASELINE.json configs[1] (the headline metric); nfcf100m = configs[4], NFCF finetune at "
+                         "100 000 001 x 10 000 001, D = 256, both tables row-sharded over the ranks")
+    ap.add_argument("--dry-launch", action="store_true", help="only prove the N-rank launch path (gloo, no GPU)")
+    ap.add_argument("--nfcf-users", type=int, default=100_000_001)
+    ap.add_argument("--nfcf-items", type=int, default=10_000_001)
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
@@ -117,9 +240,13 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        self_launch(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if args.dry_launch:
+        return dry_launch(args, rank, world)
     if os.environ.get("FAIRREC_BENCH_SHARE_GPU") == "1":   # test rig only: several ranks on one GPU (if RCCL lets them)
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -142,6 +269,17 @@ def main():
     from fairrec import _C
     from fairrec.model.fair_recommender.focf import FocfEngine
     from fairrec.optim import FusedLazyAdam
+
+    if args.workload == "nfcf100m":
+        out = bench_nfcf(args, rank, world, dev)
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+        if world > 1:
+            sys.stderr.flush()
+            os._exit(0)
+        return
 
     K, W = args.steps, args.warmup
     sharded = world > 1 or args.force_sharded
@@ -251,10 +389,9 @@ def main():
     loss_last = float(eng.loss_ring[eng.loss_slot][0].item()) if not sharded else float("nan")
     launch, other = ("hipGraph" if graph is not None else "eager"), None
     if graph is not None and not sharded and not args.graph_only:
-        # Single-GPU FOCF: three launches per step and one stream join per 8 steps -- a host that keeps ahead of the GPU
-        # does not need the graph, and the graph pays ~11 us for each of its cross-stream joins.  Time the same K steps'
-        # worth of work launched eagerly as well (fresh batches, same distribution) and report the faster of the two
-        # regions; both times are in `config`.
+        # Single-GPU FOCF: one launch per step and one stream join per 8 steps.  `value` is ALWAYS the hipGraph replay of
+        # the K steps (one fixed launch mode); the same K steps' worth of work launched eagerly (fresh batches, same
+        # distribution) is timed as well and reported in `config.launch_modes_timed` for orientation only.
         ue, ie, re_, se = (t.to(dev) for t in synth_batches(K, BATCH, N_USERS, N_ITEMS, SEED + 15485863 + rank, args.item_dist))
         coming(0, ue, ie, se, re_)      # row views made outside the timed region, as for the graph's batches
         barrier()
@@ -266,9 +403,6 @@ def main():
         dt_eager = time.perf_counter() - t0
         eng.check_device_errors()
         other = {"hipGraph_ms_per_step": round(dt / K * 1e3, 5), "eager_ms_per_step": round(dt_eager / K * 1e3, 5)}
-        if dt_eager < dt:
-            dt, launch = dt_eager, "eager"
-            loss_last = float(eng.loss_ring[eng.loss_slot][0].item())
 
     # ---- per-kernel device time: K more steps, eager, with the library's HIP-event profiler -----------
     roofline = None
@@ -303,12 +437,14 @@ def main():
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "measured_copy_ceiling": round(copy_gbs, 1), "frac_of_measured_ceiling": round(achieved / copy_gbs, 4),
                     "algorithmic_bytes_per_launch": algo_bytes,
-                    # the same bytes over the WHOLE step (all kernels of the chain + gaps), for orientation
+                    # the same bytes over the WHOLE timed step (every launch of the step + gaps): the honest figure
                     "whole_step_GBps": round(algo_bytes / (dt / K) / 1e9, 1),
+                    "frac_step": round(algo_bytes / (dt / K) / 1e9 / HBM_PEAK_GBS, 4),
                     "kernel_us": {k: round(v, 2) for k, v in sorted(per_kernel.items())},
-                    "dominant_rule": "longest kernel of the dependent chain; sort_segments_kernel runs "
-                                     + ("on 1-2 workgroups concurrently with the gather kernels on a side stream" if sharded
-                                        else "once per 8 steps (16 workgroups) on a side stream, ahead of the chain"),
+                    "dominant_rule": ("longest kernel of the dependent chain; sort_segments_kernel runs on 1-2 workgroups "
+                                      "concurrently with the gather kernels on a side stream" if sharded else
+                                      "the step IS one kernel (focf_step_kernel); sort_segments_kernel + focf_lpt_kernel run "
+                                      "once per 8 steps (16 + 8 workgroups) on a side stream, ahead of the steps they serve"),
                     "measured": f"hipExtLaunchKernelGGL start/stop events on every launch, {K} eager steps after the "
                                 "timed region (same look-ahead sort overlap as the timed steps)"}
 
@@ -322,8 +458,9 @@ def main():
             "config": {"workload": "FOCF fair_objective=value, 1000001 users x 100001 items, embedding_size=64, "
                                    "B=8192 per GPU, Adam lr=1e-3 weight_decay=1e-3 (BASELINE.json configs[1])",
                        "item_distribution": args.item_dist, "launch": launch, "launch_modes_timed": other,
-                       "step": "gather / fair / backward_adam chain"
-                               + ("" if sharded else "; id columns of 8 coming batches sorted per side launch, sweep slice rides in the backward launch"),
+                       "step": ("gather / fair / backward_adam chain over 5 all-to-alls" if sharded else
+                                "ONE launch per step (fr_focf_step: gather + lazy-Adam replay + dot + fairness + backward + Adam + "
+                                "sweep slice); id columns of 8 coming batches sorted and packed per side launch"),
                        "lazy_adam_sweep_period": eng._sweep(BATCH) if not sharded else args.sweep,
                        "tables": "row-sharded over %d ranks, RCCL all-to-all" % world if sharded else "single GPU",
                        "global_batch": BATCH * world, "final_loss": round(loss_last, 6) if not sharded else None,

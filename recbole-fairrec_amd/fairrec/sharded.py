@@ -60,6 +60,12 @@ def exchange_capacity(B: int, G: int, capacity_factor: float) -> int:
     return max(1, min(B, int(math.ceil(capacity_factor * B / G)) + 64, SORT_MAX // G))
 
 
+def capacity_is_sort_bound(B: int, G: int, capacity_factor: float) -> bool:
+    """True when the owner-side sort (FR_SORT_MAX ids per table and launch), not `capacity_factor`, sets the capacity:
+    raising the factor can then not help a skewed batch, only a smaller per-rank batch (or more ranks) can."""
+    return SORT_MAX // G < min(B, int(math.ceil(capacity_factor * B / G)) + 64)
+
+
 class HipOps:
     """The kernels of the sharded step, bound to the HIP library.  Buffers are flat tensors; `*_off` are element
     (row) offsets into them."""
@@ -252,6 +258,7 @@ class ShardedFocfEngine:
         its index work is started on a side stream now and overlaps with this step."""
         G, ops = self.G, self.ops
         B = user.numel()
+        self._last_B = B
         b = self._buffers(B)
         cap, S, sel = b.cap, b.S, self._sel
         n_slots = G * cap
@@ -328,5 +335,12 @@ class ShardedFocfEngine:
         if e:
             self.err.zero_()
             if e & _C.DEV_ERR_BUCKET_OVERFLOW:
-                raise _C.FairrecError("an exchange bucket overflowed: raise capacity_factor (skewed ids)")
+                B = self._last_B if hasattr(self, "_last_B") else 0
+                if B and capacity_is_sort_bound(B, self.G, self.capacity_factor):
+                    raise _C.FairrecError(
+                        f"an exchange bucket overflowed (skewed ids) and its capacity {self.capacity(B)} is already the most "
+                        f"one owner can sort per launch (FR_SORT_MAX // G = {SORT_MAX // self.G}): lower the per-rank "
+                        "batch size; the overflowing interactions of that step were NOT applied")
+                raise _C.FairrecError("an exchange bucket overflowed (skewed ids): raise capacity_factor; the "
+                                      "overflowing interactions of that step were NOT applied")
             raise IndexError(f"device error word {e}")

@@ -36,3 +36,17 @@ def test_bench_json_contract(args):
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 0.0 < r["frac"] < 1.0
     assert d["config"]["final_loss"] == d["config"]["final_loss"]      # not NaN
+
+
+def test_bench_nfcf_workload_contract():
+    """`--workload nfcf100m` (BASELINE.json configs[4]) at a reduced table size: same JSON contract, NFCF finetune step."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "nfcf100m", "--nfcf-users", "200001",
+                          "--nfcf-items", "50001", "--steps", "6", "--warmup", "2"], capture_output=True, text=True,
+                         timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["steps"] == 6 and d["unit"] == "interactions/s" and d["value"] > 0
+    assert "NFCF finetune" in d["config"]["workload"] and d["roofline"]["algorithmic_bytes_per_launch"] == 7192 * 8192
+    assert d["config"]["final_loss"] == d["config"]["final_loss"]

@@ -144,6 +144,10 @@ def test_exchange_capacity_fits_the_owner_sort():
             cap = exchange_capacity(B, G, 2.0)
             assert G * cap <= max(SORT_MAX, G) and cap >= min(B, -(-B // G))
     assert exchange_capacity(8192, 8, 2.0) == 2048 and exchange_capacity(8192, 1, 2.0) == 8192
+    from fairrec.sharded import capacity_is_sort_bound
+    # at G = 8, B = 8192 the owner-side sort bounds the capacity (the overflow message must not suggest capacity_factor)
+    assert capacity_is_sort_bound(8192, 8, 2.0) and not capacity_is_sort_bound(8192, 8, 1.5)
+    assert not capacity_is_sort_bound(1024, 2, 2.0)
 
 
 def test_recbole_import_alias_resolves_to_the_native_package():
