@@ -337,16 +337,38 @@ class FusedLazyAdam:
     def _tables(self):
         return self.engine.tables(self.group) if self.group is not None else self.engine.tables()
 
-    def state_dict(self):
+    def state_dict(self, param_names=None):
+        """torch.optim.Adam's state_dict content (`exp_avg`, `exp_avg_sq`, `step` per parameter, flushed to the current
+        step).  Keys: parameter NAMES by default; with `param_names` (the names of the parameters in the order the
+        reference hands them to its optimizer, i.e. `[n for n, _ in model.named_parameters()]`) torch's own layout --
+        integer indices and `param_groups[0]['params'] = [0, 1, ...]` -- which a reference `optimizer.load_state_dict`
+        accepts as it is (trainer.py:221-240, :258-284)."""
         state = {name: t.adam_state(self.hyper) for name, t in self._tables().items()}
         if hasattr(self.engine, "dense_state"):
             state.update(self.engine.dense_state(self.group) if self.group is not None else self.engine.dense_state())
+        if param_names is not None:
+            idx = {n: k for k, n in enumerate(param_names)}
+            missing = [n for n in state if n not in idx]
+            if missing:
+                raise KeyError(f"state_dict(param_names=...): no index for {missing}")
+            state = {idx[n]: st for n, st in state.items()}
+            groups = dict(self.defaults, params=sorted(state.keys()), amsgrad=False, maximize=False, foreach=None,
+                          capturable=False, differentiable=False, fused=None)
+            return {"state": state, "param_groups": [groups]}
         return {"state": state, "param_groups": [dict(self.defaults, params=list(state.keys()))]}
 
-    def load_state_dict(self, sd):
+    def load_state_dict(self, sd, param_names=None):
+        """Accepts this class's name-keyed layout and torch.optim.Adam's integer-keyed one (a checkpoint written by the
+        reference); the latter needs `param_names`, the parameter names in the reference optimizer's order."""
         tables = self._tables()
         dense = {}
-        for name, st in sd["state"].items():
+        state = sd["state"]
+        if state and all(isinstance(k, int) for k in state):
+            if param_names is None:
+                raise KeyError("optimizer state with torch's integer parameter indices: pass param_names "
+                               "([n for n, _ in model.named_parameters()]) to name them")
+            state = {param_names[k]: st for k, st in state.items()}
+        for name, st in state.items():
             if name in tables:
                 tables[name].load_adam_state(st)
             else:

@@ -207,7 +207,10 @@ class Trainer(AbstractTrainer):
         self.best_valid_score = checkpoint['best_valid_score']
         self.model.load_state_dict(checkpoint['state_dict'])
         self.model.load_other_parameter(checkpoint.get('other_parameter'))
-        self.optimizer.load_state_dict(checkpoint['optimizer'])
+        # a checkpoint written by the reference carries torch.optim.Adam's integer parameter indices: its optimizer was
+        # built over model.parameters() (trainer.py:129), so index k is the k-th named parameter
+        self.optimizer.load_state_dict(checkpoint['optimizer'],
+                                       param_names=[n for n, _ in self.model.named_parameters()])
         self.logger.info('Checkpoint loaded. Resume training from epoch %d', self.start_epoch)
 
     def _generate_train_loss_output(self, epoch_idx, s_time, e_time, losses):

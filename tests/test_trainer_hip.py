@@ -119,3 +119,93 @@ def test_evaluate_load_best_model_after_a_non_saving_epoch(tmp_path):
     assert torch.equal(got, want)
     assert torch.equal(fs, fresh.full_sort_predict(b[:4]))
     assert torch.equal(model.user_embedding_layer.weight, ckpt["state_dict"]["user_embedding_layer.weight"].to("cuda"))
+
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _focf_from_fixture(z, tmp_path):
+    from fairrec.config import Config
+    from fairrec.data.dataset import synthetic_dataset
+    from fairrec.utils import get_model, get_trainer
+    lr, wd, fw = (float(x) for x in z["hyper"])
+    cfg = Config(model="FOCF", config_dict={"embedding_size": int(z["U0"].shape[1]), "fair_objective": "value",
+                                            "fair_weight": fw, "learning_rate": lr, "weight_decay": wd, "device": "cuda",
+                                            "checkpoint_dir": str(tmp_path), "epochs": 1})
+    ds = synthetic_dataset(cfg, z["U0"].shape[0], z["I0"].shape[0], 100, seed=1)
+    model = get_model("FOCF")(cfg, ds).to("cuda")
+    return cfg, model, get_trainer(None, "FOCF")(cfg, model)
+
+
+def test_resume_from_a_reference_written_checkpoint(tmp_path):
+    """f-4: a checkpoint as the REFERENCE's Trainer._save_checkpoint writes it (trainer.py:221-240; fixture = its key names
+    and tensors, tests/golden/gen_checkpoint_golden.py) must load through resume_checkpoint -- torch.optim.Adam's
+    integer-keyed state included -- and the resumed run must continue like the reference did."""
+    import json
+    z = np.load(os.path.join(GOLDEN, "checkpoint_focf.npz"))
+    cfg, model, trainer = _focf_from_fixture(z, tmp_path)
+    sd_keys = json.loads(str(z["state_dict_keys"]))
+    assert sd_keys == list(model.state_dict().keys())                    # same parameter names, same order
+    opt_keys = json.loads(str(z["opt_state_keys"]))
+    ck = {"config": None, "epoch": int(z["epoch"]), "cur_step": int(z["cur_step"]),
+          "best_valid_score": float(z["best_valid_score"]), "other_parameter": json.loads(str(z["other_parameter"])),
+          "state_dict": {k: torch.from_numpy(z["sd::" + k]) for k in sd_keys},
+          "optimizer": {"state": {int(k): {n: torch.from_numpy(np.asarray(z[f"opt::{k}::{n}"])) for n in names}
+                                  for k, names in opt_keys.items()},
+                        "param_groups": json.loads(str(z["opt_param_groups"]))}}
+    assert sorted(k for k in ck if k != "config") == json.loads(str(z["ck_keys"]))
+    path = str(tmp_path / "FOCF-ref.pth")
+    torch.save(ck, path)
+    trainer.resume_checkpoint(path)
+    assert trainer.start_epoch == int(z["epoch"]) + 1 and trainer.cur_step == int(z["cur_step"])
+    eng = model.hip_engine()
+    assert eng.U.step == eng.I.step == int(z["opt::0::step"]) == 3
+    assert torch.equal(eng.U.m.cpu(), ck["optimizer"]["state"][0]["exp_avg"])
+    assert torch.equal(eng.I.v.cpu(), ck["optimizer"]["state"][1]["exp_avg_sq"])
+    t = z["user_id"].shape[0] - 1
+    cols = [torch.tensor(z[k][t], device="cuda") for k in ("user_id", "item_id", "rating", "sst")]
+    loss, _ = eng.forward(*cols)
+    loss = float(loss[0])
+    eng.backward_adam()
+    eng.flush()
+    assert abs(loss - float(z["loss_next"])) <= 1e-4 * abs(float(z["loss_next"]))
+    for got, want in ((eng.U.weight, z["U_next"]), (eng.I.weight, z["I_next"])):
+        a = got.cpu().numpy()
+        assert (np.abs(a - want) <= 1e-4 * np.abs(want) + 1e-6).all()
+    # ... and the other way: the optimizer state in torch's own layout, which a stock torch.optim.Adam (= the reference's
+    # optimizer, trainer.py:139) loads as it is
+    names = [n for n, _ in model.named_parameters()]
+    sd = trainer.optimizer.state_dict(param_names=names)
+    assert sorted(sd["state"]) == [0, 1] and sd["param_groups"][0]["params"] == [0, 1]
+    for st in sd["state"].values():
+        assert sorted(st) == ["exp_avg", "exp_avg_sq", "step"] and float(st["step"]) == 4.0
+    ref_params = [torch.nn.Parameter(p.detach().cpu().clone()) for _, p in model.named_parameters()]
+    ref_opt = torch.optim.Adam(ref_params, lr=1e-3, weight_decay=1e-3)
+    ref_opt.load_state_dict({"state": {k: {n: v.cpu() if torch.is_tensor(v) else v for n, v in st.items()}
+                                       for k, st in sd["state"].items()}, "param_groups": sd["param_groups"]})
+    assert torch.equal(ref_opt.state[ref_params[0]]["exp_avg"], eng.U.m.cpu())
+
+
+def test_focf_dataloader_device_resident_matches_reference_golden():
+    """f-3: the item-complete batcher with the interaction table RESIDENT ON THE DEVICE (what the trainer feeds from)
+    yields the reference's batches (tests/golden/gen_dataloader_golden.py ran focf_dataloader.py:37-51), row for row."""
+    from fairrec.config import Config
+    from fairrec.data.dataloader import FOCFDataLoader
+    from fairrec.data.dataset import InteractionDataset
+    from fairrec.data.interaction import Interaction
+    z = np.load(os.path.join(GOLDEN, "dataloader_focf.npz"))
+    c = Config(model="FOCF", config_dict={"train_batch_size": int(z["step"]), "device": "cuda"})
+    inter = Interaction({"user_id": torch.from_numpy(z["user_id"]), "item_id": torch.from_numpy(z["item_id"]),
+                         "rating": torch.from_numpy(z["rating"])})
+    users = Interaction({"user_id": torch.arange(100), "gender": (torch.arange(100) % 2).float()})
+    ds = InteractionDataset(c, inter, users, n_users=100, n_items=int(z["item_num"]))
+    ds.to("cuda")
+    dl = FOCFDataLoader(c, ds)
+    np.random.seed(int(z["np_seed"]))
+    it = iter(dl)
+    for b in range(4):
+        batch = next(it)
+        assert batch["user_id"].device.type == "cuda"
+        for col, key in (("user", "user_id"), ("item", "item_id"), ("rating", "rating")):
+            np.testing.assert_array_equal(batch[key].cpu().numpy(), z[f"batch{b}_{col}"])
+        np.testing.assert_array_equal(batch["gender"].cpu().numpy(), (z[f"batch{b}_user"] % 2).astype(np.float32))
