@@ -235,3 +235,23 @@ def train(z) -> Dict[str, np.ndarray]:
     with torch.no_grad():
         out["predict_last"] = m.predict(u, pi, m.attrs if m.mode != "none" else None).numpy().copy()
     return out
+
+
+def bpr_outer(a: torch.Tensor, c: torch.Tensor, chunk: int = 512):
+    """PFCN_BiasedMF's BPR under the `[B] + [B,1] -> [B,B]` broadcast of pfcn_biasedmf.py:192-195 with BPRLoss
+    (loss.py:45-47): mean over all (i, j) of -log(1e-10 + sigmoid(a_j + c_i)), where a = (u.pos - u.neg) per row j and
+    c = (pos item bias - neg item bias) per row i.  The reference materialises the [B, B] matrix; this restatement walks
+    it in row chunks in float64 and returns (loss, dLoss/da, dLoss/dc).  Test infrastructure."""
+    a64, c64 = a.double(), c.double()
+    B = a64.numel()
+    total = torch.zeros((), dtype=torch.float64)
+    da, dc = torch.zeros(B, dtype=torch.float64), torch.zeros(B, dtype=torch.float64)
+    for lo in range(0, B, chunk):
+        x = a64[None, :] + c64[lo:lo + chunk, None]               # rows i = lo.., columns j
+        s = torch.sigmoid(x)
+        total += -torch.log(1e-10 + s).sum()
+        g = -(s * (1 - s)) / (1e-10 + s)                           # d(-log(1e-10 + sigmoid(x))) / dx
+        da += g.sum(0)
+        dc[lo:lo + chunk] = g.sum(1)
+    n = float(B) * float(B)
+    return total / n, da / n, dc / n

@@ -65,7 +65,16 @@ def patch_dropout(model, p, queue):
             seq[k] = RecordedDropout(p, queue)
 
 
-def run_case(name, stage, n_users, n_items, D, hidden, B, T, snaps, lr, wd, p_drop, fair_weight, seed):
+ONLY = [s for s in os.environ.get("GOLDEN_ONLY", "").split(",") if s]
+
+
+def run_case(name, *args, **kwargs):
+    if ONLY and name not in ONLY:
+        return
+    return _run_case(name, *args, **kwargs)
+
+
+def _run_case(name, stage, n_users, n_items, D, hidden, B, T, snaps, lr, wd, p_drop, fair_weight, seed):
     torch.manual_seed(seed)
     rng = np.random.default_rng(seed)
     gender = rng.integers(0, 2, size=n_users).astype(np.float32)
@@ -155,6 +164,10 @@ def main():
     run_case("finetune", "finetune", D=8, hidden=(16, 8), T=10, snaps=(1, 10), wd=1e-6, p_drop=0.0, fair_weight=0.1, seed=5, **c)
     run_case("finetune_dropout", "finetune", D=8, hidden=(16, 8), T=6, snaps=(6,), wd=1e-6, p_drop=0.2, fair_weight=0.5, seed=6, **c)
     run_case("finetune_d64", "finetune", D=64, hidden=(128, 64), T=4, snaps=(4,), wd=1e-6, p_drop=0.0, fair_weight=0.1, seed=7, **c)
+    # BASELINE.json configs[4]'s width: embedding_size 256, mlp_hidden_size [128, 64], B = 200
+    c256 = dict(n_users=120, n_items=90, B=200, lr=1e-3)
+    run_case("pretrain_d256", "pretrain", D=256, hidden=(128, 64), T=4, snaps=(4,), wd=1e-6, p_drop=0.2, fair_weight=0.1, seed=8, **c256)
+    run_case("finetune_d256", "finetune", D=256, hidden=(128, 64), T=4, snaps=(4,), wd=1e-6, p_drop=0.0, fair_weight=0.1, seed=9, **c256)
 
 
 if __name__ == "__main__":

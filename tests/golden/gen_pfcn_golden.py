@@ -79,7 +79,16 @@ def dump_state(model, mode, prefix, out):
                 out[f"{prefix}.dis.{sst}.{k}"] = v.detach().numpy().copy()
 
 
-def run_case(name, cls, mode, attrs, phases, sst_lists, D, B, dis_hidden, seed, p_drop=0.3, lr=1e-3, wd=1e-4,
+ONLY = [s for s in os.environ.get("GOLDEN_ONLY", "").split(",") if s]
+
+
+def run_case(name, *args, **kwargs):
+    if ONLY and name not in ONLY:
+        return
+    return _run_case(name, *args, **kwargs)
+
+
+def _run_case(name, cls, mode, attrs, phases, sst_lists, D, B, dis_hidden, seed, p_drop=0.3, lr=1e-3, wd=1e-4,
              dis_weight=10.0, n_users=40, n_items=30):
     torch.manual_seed(seed)
     rng = np.random.default_rng(seed)
@@ -183,6 +192,9 @@ def main():
     run_case("dmf_none", PFCN_DMF, "none", g, "FFFF", [g] * 4, D=8, B=32, dis_hidden=(16, 8), seed=10, wd=1e-3)
     run_case("dmf_cm2", PFCN_DMF, "cm", ga, "FDFDFD", [ga, ga, g, g, ("age",), ("age",)], D=8, B=32, dis_hidden=(16, 8), seed=11, wd=1e-3)
     run_case("bmf_sm_d64", PFCN_BiasedMF, "sm", g, "FDF", [g] * 3, D=64, B=96, dis_hidden=(128, 256, 128, 128, 64, 32), seed=7)
+    # BASELINE.json configs[2]'s width: embedding_size 128 with the full-size discriminator, sm and cm
+    run_case("bmf_sm_d128", PFCN_BiasedMF, "sm", g, "FDFD", [g] * 4, D=128, B=200, dis_hidden=(128, 256, 128, 128, 64, 32), seed=12)
+    run_case("bmf_cm_d128", PFCN_BiasedMF, "cm", ga, "FDFD", [ga, ga, g, g], D=128, B=200, dis_hidden=(128, 256, 128, 128, 64, 32), seed=13)
 
 
 if __name__ == "__main__":

@@ -81,12 +81,17 @@ def test_fairgo_training_matches_reference_golden(path):
         losses.append(loss.detach().reshape(1).clone())
         loss.backward()
         opts[ph].step()
-    np.testing.assert_allclose(torch.cat(losses).cpu().numpy(), z["loss"], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(torch.cat(losses).cpu().numpy(), z["loss"], rtol=1e-4, atol=1e-6)
+    worst = [0.0, ""]
 
     def close(a, ref, what):
-        a = a.detach().cpu().numpy()
-        bad = np.abs(a - ref) > 1e-4 * np.abs(ref) + 1e-5 * max(1e-2, float(np.abs(ref).max()))
-        assert not bad.any(), (what, float(np.abs(a - ref).max()))
+        # north star: 1e-4 relative; absolute floor 1e-6 of the tensor's scale (no BatchNorm in FairGo's MLPs, so no
+        # tensor here is noise-amplified: the measured worst error is printed below)
+        a = a.detach().cpu().numpy().astype(np.float64)
+        ratio = np.abs(a - ref) / (1e-4 * np.abs(ref) + 1e-6 * max(1e-2, float(np.abs(ref).max())))
+        if ratio.max() > worst[0]:
+            worst[:] = [float(ratio.max()), what]
+        assert ratio.max() <= 1.0, (what, float(np.abs(a - ref).max()), float(ratio.max()))
 
     for k, v in model.state_dict().items():
         close(v, z["final.model." + k], k)
@@ -95,8 +100,9 @@ def test_fairgo_training_matches_reference_golden(path):
             close(v, z[f"final.filter.{s}.{k}"], f"filter.{s}.{k}")
         for k, v in model.dis_layer_dict[s].state_dict().items():
             close(v, z[f"final.dis.{s}.{k}"], f"dis.{s}.{k}")
+    print("worst |err| / tolerance:", round(worst[0], 3), worst[1])
     eng.check_device_errors()
-    np.testing.assert_allclose(model.predict(inter).cpu().numpy(), z["predict_last"], rtol=2e-4, atol=2e-6)
+    np.testing.assert_allclose(model.predict(inter).cpu().numpy(), z["predict_last"], rtol=1e-4, atol=1e-6)
 
 
 def test_fairgo_trainer_pretrain_then_finetune(tmp_path):

@@ -1,4 +1,6 @@
 """GPU: the fp32-MFMA dense-layer kernels against stock torch (same op, fp32)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -141,3 +143,28 @@ def test_spmm_csr_matches_torch_sparse(D):
     _C.check(lib.fr_spmm_csr(ip.data_ptr(), ci.data_ptr(), va.data_ptr(), Xd.data_ptr(), n, D, Y.data_ptr(),
                              _C.current_stream()), "spmm")
     torch.testing.assert_close(Y.cpu(), ref, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("B", [200, 8192])
+def test_bpr_outer_at_the_baseline_batch(B):
+    """fr_bpr_outer (PFCN_BiasedMF's [B] + [B,1] -> [B,B] BPR, pfcn_biasedmf.py:192-195) at BASELINE.json configs[2]'s
+    B = 8192 -- 67 M exp/log pairs, nothing of size B^2 stored -- against the float64 restatement of the reference's
+    expression (oracle/pfcn.py::bpr_outer, which walks the matrix in row chunks)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+    from oracle.pfcn import bpr_outer
+    from fairrec.functional import BprBroadcast
+    g = torch.Generator().manual_seed(B)
+    dp, dn = torch.randn(B, generator=g) * 2.0, torch.randn(B, generator=g) * 2.0
+    bp, bn = torch.randn(B, 1, generator=g) * 0.5, torch.randn(B, 1, generator=g) * 0.5
+    want, wda, wdc = bpr_outer(dp - dn, (bp - bn).view(-1))
+    leaves = [t.cuda().requires_grad_(True) for t in (dp, dn, torch.zeros(B, 1), bp, bn, torch.zeros(1))]
+    loss = BprBroadcast.apply(*leaves)
+    loss.backward()
+    assert abs(float(loss) - float(want)) <= 1e-5 * abs(float(want))
+    scale = float(wda.abs().max())
+    for got, ref in ((leaves[0].grad, wda), (leaves[1].grad, -wda), (leaves[3].grad.view(-1), wdc),
+                     (leaves[4].grad.view(-1), -wdc)):
+        err = (got.cpu().double() - ref).abs()
+        assert bool((err <= 1e-4 * ref.abs() + 1e-6 * scale).all()), float(err.max())
+    assert float(leaves[2].grad.abs().max()) == 0.0 and float(leaves[5].grad.abs().max()) == 0.0   # App. B-1: exactly zero

@@ -84,38 +84,61 @@ def test_pfcn_training_matches_reference_golden(path, sharded, request):
         losses.append(loss.detach().reshape(1).clone())
         loss.backward()
         opt.step()
-    np.testing.assert_allclose(torch.cat(losses).cpu().numpy(), z["loss"], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(torch.cat(losses).cpu().numpy(), z["loss"], rtol=1e-4, atol=1e-6)
     sd = model.state_dict()
+    steps = len(z["phases"])
 
-    def close(a, ref, what):
-        a = a.detach().cpu().numpy()
-        bad = np.abs(a - ref) > 1e-4 * np.abs(ref) + 1e-5 * max(1.0, float(np.abs(ref).max()))
-        assert not bad.any(), (what, float(np.abs(a - ref).max()))
+    # |a - ref| <= 1e-4 |ref| + floor(kind of tensor).  The floors are the reference's OWN fp32 noise: the same torch ops
+    # with 1 instead of 8 threads (another reduction order) move a tensor by this much (tests/golden/noise_floor.py,
+    # measured on the full-size discriminators at D = 128 / 64), doubled; a tighter test would reject the reference
+    # against itself.
+    FLOOR = {"Linear weight": 2e-5,        # self-noise 8.7e-6 at scale 4e-2
+             "BatchNorm gamma": 1e-6,      # 2.4e-7 at scale 1
+             "BatchNorm beta": 2e-4,       # 1.0e-4 at scale 2e-3: Adam turns a cancelling column sum into +-lr-sized steps
+             "BatchNorm running_var": 1e-6}
+    worst = {}
+
+    def kind_of(k):
+        parts = k.split(".")
+        if len(parts) >= 2 and parts[-2].isdigit():
+            lin = int(parts[-2]) % 4 == 1
+            if parts[-1] == "weight":
+                return "Linear weight" if lin else "BatchNorm gamma"
+            if parts[-1] == "bias":
+                return "Linear bias feeding BatchNorm" if lin else "BatchNorm beta"
+            return "BatchNorm " + parts[-1]
+        return "table"
+
+    def close(a, ref, what, kind=None):
+        a = a.detach().cpu().numpy().astype(np.float64)
+        kind = kind or kind_of(what)
+        if kind in ("Linear bias feeding BatchNorm", "BatchNorm running_mean"):
+            # A Linear bias that feeds BatchNorm has an exactly-zero true gradient (the batch mean is subtracted again);
+            # what reaches Adam is rounding noise whose SIGN Adam turns into +-lr steps (self-noise 3.5e-3 at lr 1e-3,
+            # larger than the values), and running_mean averages it: not comparable, and neither can influence an
+            # output.  What CAN be asserted: they moved by no more than Adam can move anything, lr per step.
+            assert float(np.abs(a - ref).max()) <= 2 * steps * lr + 1e-6, (what, float(np.abs(a - ref).max()))
+            return
+        if kind == "BatchNorm num_batches_tracked":
+            return
+        floor = FLOOR.get(kind, 1e-6 * max(1.0, float(np.abs(ref).max())))      # tables: 1e-6 of the tensor's scale
+        ratio = np.abs(a - ref) / (1e-4 * np.abs(ref) + floor)
+        worst[kind] = max(worst.get(kind, 0.0), float(ratio.max()))
+        assert ratio.max() <= 1.0, (what, kind, float(np.abs(a - ref).max()), float(ratio.max()))
 
     for k, v in sd.items():
-        close(v, z["final.model." + k], k)
-
-    def skip(k):
-        # A Linear bias that feeds BatchNorm has an exactly-zero true gradient (the batch mean is subtracted again);
-        # what reaches Adam is rounding noise of order 1e-9 whose SIGN Adam turns into +-lr steps, so its trajectory
-        # is implementation noise in the reference too -- and it cannot influence any output.  Not comparable.
-        parts = k.split(".")
-        # BatchNorm's running_mean is the average of (x W^T + that bias), so it inherits the same noise; running_var does not.
-        return (k.endswith("num_batches_tracked") or k.endswith("running_mean")
-                or (parts[-1] == "bias" and int(parts[-2]) % 4 == 1))
-
+        close(v, z["final.model." + k], k, kind=None if ".mlp_layers." in k else "table")
     if mode != "none":
         for i, mlp in model.filter_layer.items():
             for k, v in mlp.state_dict().items():
-                if not skip(k):
-                    close(v, z[f"final.filter.{i}.{k}"], f"filter.{i}.{k}")
+                close(v, z[f"final.filter.{i}.{k}"], f"filter.{i}.{k}")
         for s, mlp in model.dis_layer_dict.items():
             for k, v in mlp.state_dict().items():
-                if not skip(k):
-                    close(v, z[f"final.dis.{s}.{k}"], f"dis.{s}.{k}")
+                close(v, z[f"final.dis.{s}.{k}"], f"dis.{s}.{k}")
+    print("worst |err| / tolerance per kind:", {k: round(v, 3) for k, v in worst.items()})
     eng.check_device_errors()
     pr = model.predict(inter, attrs if mode != "none" else None).cpu().numpy()
-    np.testing.assert_allclose(pr, z["predict_last"], rtol=2e-4, atol=2e-6)
+    np.testing.assert_allclose(pr, z["predict_last"], rtol=1e-4, atol=1e-6)
 
 
 @pytest.mark.parametrize("graph", [False, True], ids=["eager", "hipGraph"])
