@@ -32,8 +32,15 @@ def test_nfcf_training_matches_reference_golden(path, tmp_path, sharded, request
     from fairrec.config import Config
     from fairrec.data.interaction import Interaction
     from fairrec.model.fair_recommender.nfcf import NFCF
+    _run_case(np.load(path), sharded)
+
+
+def _run_case(z, sharded=False):
+    """One recorded NFCF run (a golden .npz or a dict of the same layout) through the plugin surface on the GPU."""
+    from fairrec.config import Config
+    from fairrec.data.interaction import Interaction
+    from fairrec.model.fair_recommender.nfcf import NFCF
     from fairrec.optim import FusedLazyAdam
-    z = np.load(path)
     stage = str(z["stage"])
     lr, wd, fw, p = (float(x) for x in z["hyper"])
     n_users, D = z["init.user_embedding.weight"].shape
@@ -42,7 +49,7 @@ def test_nfcf_training_matches_reference_golden(path, tmp_path, sharded, request
                                             "dropout": p, "fair_weight": fw, "device": "cuda", "load_pretrain_path": None,
                                             "row_sharded": sharded})
     model = NFCF(cfg, _DS(n_users, n_items, z["gender"]))
-    init = {k[5:]: torch.tensor(z[k]) for k in z.files if k.startswith("init.")}
+    init = {k[5:]: torch.tensor(z[k]) for k in (z.files if hasattr(z, "files") else z) if k.startswith("init.")}
     if stage == "finetune":     # the state reset_params produced in the reference (its projection is pinned in the oracle test)
         model.load_pretrain_path = "reference-checkpoint"
         model.user_embedding.weight.requires_grad = False
@@ -76,3 +83,43 @@ def test_nfcf_training_matches_reference_golden(path, tmp_path, sharded, request
     with torch.no_grad():
         pr = model.predict(inter).cpu().numpy()
     np.testing.assert_allclose(pr, z["predict_last"], rtol=1e-4, atol=1e-6)
+
+
+def test_nfcf_full_batch_at_the_baseline_width():
+    """BASELINE.json configs[4]'s step shape -- embedding_size 256, mlp_hidden_size [128, 64], B = 8192, finetune (user table
+    frozen, differential-fairness term) and pretrain -- on tables scaled down to what the CPU oracle's dense Adam sweeps in
+    seconds (200 001 x 50 001): three steps of the HIP path against oracle/nfcf.py (pinned to the reference's goldens),
+    every row of both tables compared, also the rows no batch touched."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+    from oracle import nfcf as O
+    from fairrec.config import Config
+    from fairrec.model.fair_recommender.nfcf import NFCF
+    n_users, n_items, D, B, T, hidden = 200_001, 50_001, 256, 8192, 3, (128, 64)
+    g = torch.Generator().manual_seed(12)
+    gender = (torch.rand(n_users, generator=g) < 0.5).float().numpy()
+    for stage, p in (("finetune", 0.0), ("pretrain", 0.2)):
+        torch.manual_seed(5)
+        cfg = Config(model="NFCF", config_dict={"embedding_size": D, "mlp_hidden_size": list(hidden), "dropout": p,
+                                                "fair_weight": 0.1, "device": "cpu", "load_pretrain_path": None})
+        m0 = NFCF(cfg, _DS(n_users, n_items, gender))
+        z = {"stage": np.array(stage), "hyper": np.array([1e-3, 1e-6, 0.1, p]), "hidden": np.array(hidden), "gender": gender,
+             "snaps": np.array([T])}
+        for k, v in m0.state_dict().items():
+            z["init." + k] = (v * 0.1 if "embedding" in k else v).detach().numpy().copy()     # N(0,1) tables saturate the sigmoid
+        u = torch.randint(1, n_users, (T, B), generator=g)
+        i = torch.randint(1, n_items // 8, (T, B), generator=g)                  # items repeat: segments of several members
+        r = torch.randint(1, 6, (T, B), generator=g).float()
+        z.update(user_id=u.numpy(), item_id=i.numpy(), label=(r >= 3).float().numpy(), sst=gender[u.numpy()])
+        if p > 0:
+            sizes = [2 * D] + list(hidden)
+            for l, w in enumerate(sizes):
+                z[f"mask{l}"] = (torch.rand(T, B, w, generator=g) >= p).to(torch.uint8).numpy()
+        ref = O.train(z, snaps=(T,))
+        z.update({k: v for k, v in ref.items() if k.startswith("after") or k == "loss"})
+        U, I = torch.tensor(ref[f"after{T}.user_embedding.weight"]), torch.tensor(ref[f"after{T}.item_embedding.weight"])
+        n_l = len(hidden) + 1
+        Ws = [torch.tensor(ref[f"after{T}.mlp_layers.mlp_layers.{3 * l + 1}.weight"]) for l in range(n_l)]
+        bs = [torch.tensor(ref[f"after{T}.mlp_layers.mlp_layers.{3 * l + 1}.bias"]) for l in range(n_l)]
+        z["predict_last"] = O.forward(U, I, Ws, bs, u[-1], i[-1]).numpy()
+        _run_case(z, sharded=False)

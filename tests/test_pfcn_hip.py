@@ -26,7 +26,7 @@ class _DS:
 
 
 def _load_mlp(mlp, z, prefix):
-    sd = {k[len(prefix) + 1:]: torch.tensor(z[k]) for k in z.files if k.startswith(prefix + ".")}
+    sd = {k[len(prefix) + 1:]: torch.tensor(z[k]) for k in (z.files if hasattr(z, "files") else z) if k.startswith(prefix + ".")}
     mlp.load_state_dict(sd)
 
 
@@ -35,11 +35,17 @@ def _load_mlp(mlp, z, prefix):
 def test_pfcn_training_matches_reference_golden(path, sharded, request):
     if sharded:     # the row-sharded engine as a 1-rank RCCL world: same goldens (fairrec/sharded_engine.py)
         request.getfixturevalue("rccl_world1")
+    _run_case(np.load(path), sharded)
+
+
+def _run_case(z, sharded=False, noise=None):
+    """One recorded PFCN run (a golden .npz or a dict of the same layout) through the plugin surface on the GPU.
+    noise: optional {key: absolute self-noise of the reference arithmetic on THIS case} (measured by running the CPU
+    restatement with another reduction order), added to the tolerances."""
     from fairrec.config import Config
     from fairrec.data.interaction import Interaction
     from fairrec.optim import FusedLazyAdam
     from fairrec.utils import get_model
-    z = np.load(path)
     name, mode = str(z["model"]), str(z["mode"])
     attrs = [str(a) for a in z["attrs"]]
     lr, wd, dis_weight, p = (float(x) for x in z["hyper"])
@@ -54,7 +60,8 @@ def test_pfcn_training_matches_reference_golden(path, sharded, request):
                                           "mlp_activation": "relu", "dis_activation": "leakyrelu", "activation": "leakyrelu",
                                           "row_sharded": sharded})
     model = get_model(name)(cfg, _DS(n_users, n_items, z))
-    model.load_state_dict({k[11:]: torch.tensor(z[k]) for k in z.files if k.startswith("init.model.")})
+    model.load_state_dict({k[11:]: torch.tensor(z[k]) for k in (z.files if hasattr(z, "files") else z)
+                           if k.startswith("init.model.")})
     model = model.to("cuda")
     if mode != "none":
         for i, mlp in model.filter_layer.items():
@@ -84,7 +91,10 @@ def test_pfcn_training_matches_reference_golden(path, sharded, request):
         losses.append(loss.detach().reshape(1).clone())
         loss.backward()
         opt.step()
-    np.testing.assert_allclose(torch.cat(losses).cpu().numpy(), z["loss"], rtol=1e-4, atol=1e-6)
+    noise = noise or {}
+    got_loss = torch.cat(losses).cpu().numpy().astype(np.float64)
+    assert (np.abs(got_loss - z["loss"]) <= 1e-4 * np.abs(z["loss"]) + 1e-6 + noise.get("loss", 0.0)).all(), \
+        (got_loss, z["loss"], noise.get("loss"))
     sd = model.state_dict()
     steps = len(z["phases"])
 
@@ -122,23 +132,34 @@ def test_pfcn_training_matches_reference_golden(path, sharded, request):
         if kind == "BatchNorm num_batches_tracked":
             return
         floor = FLOOR.get(kind, 1e-6 * max(1.0, float(np.abs(ref).max())))      # tables: 1e-6 of the tensor's scale
+        floor = floor + noise.get(what, 0.0)
         ratio = np.abs(a - ref) / (1e-4 * np.abs(ref) + floor)
+        if noise and kind != "table" and ratio.max() > 1.0:
+            # Self-noise runs only (synthetic full-batch cases): an element whose gradient cancels to rounding noise takes
+            # Adam steps of +-lr by the SIGN of that noise (the first step is lr * g / |g|) -- in the reference as well, on
+            # other elements from run to run.  Such elements may be off by whole steps; they must be few.
+            out = ratio > 1.0
+            assert out.sum() <= max(2, 0.005 * out.size) and float(np.abs(a - ref)[out].max()) <= 2 * steps * lr + 1e-6, \
+                (what, kind, float(out.mean()), float(np.abs(a - ref).max()))
+            ratio = np.where(out, 0.0, ratio)
         worst[kind] = max(worst.get(kind, 0.0), float(ratio.max()))
         assert ratio.max() <= 1.0, (what, kind, float(np.abs(a - ref).max()), float(ratio.max()))
 
     for k, v in sd.items():
-        close(v, z["final.model." + k], k, kind=None if ".mlp_layers." in k else "table")
+        close(v, z["final.model." + k], "model." + k, kind=None if ".mlp_layers." in k else "table")
     if mode != "none":
         for i, mlp in model.filter_layer.items():
             for k, v in mlp.state_dict().items():
-                close(v, z[f"final.filter.{i}.{k}"], f"filter.{i}.{k}")
+                if not k.endswith("num_batches_tracked"):
+                    close(v, z[f"final.filter.{i}.{k}"], f"filter.{i}.{k}")
         for s, mlp in model.dis_layer_dict.items():
             for k, v in mlp.state_dict().items():
-                close(v, z[f"final.dis.{s}.{k}"], f"dis.{s}.{k}")
+                if not k.endswith("num_batches_tracked"):
+                    close(v, z[f"final.dis.{s}.{k}"], f"dis.{s}.{k}")
     print("worst |err| / tolerance per kind:", {k: round(v, 3) for k, v in worst.items()})
     eng.check_device_errors()
     pr = model.predict(inter, attrs if mode != "none" else None).cpu().numpy()
-    np.testing.assert_allclose(pr, z["predict_last"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(pr, z["predict_last"], rtol=1e-4, atol=1e-6 + noise.get("predict_last", 0.0))
 
 
 @pytest.mark.parametrize("graph", [False, True], ids=["eager", "hipGraph"])
@@ -206,3 +227,60 @@ def test_pfcn_trainer_alternating_schedule(tmp_path, graph):
     t4 = trainer_cls(cfg_none, m4)
     t4.resume_checkpoint(t3.saved_model_file)
     assert m4.hip_engine()._tables["user_embedding_layer.weight"].step == 5
+
+
+@pytest.mark.parametrize("mode", ["sm", "cm"])
+def test_pfcn_biasedmf_full_batch_at_the_baseline_width(mode):
+    """BASELINE.json configs[2]'s step shape -- PFCN_BiasedMF, embedding_size 128, the full-size discriminator
+    [128, 256, 128, 128, 64, 32] with dropout 0.3, B = 8192 (the [B,B] BPR broadcast: 67 M terms) -- on tables scaled down to
+    what the CPU oracle's dense Adam sweeps in seconds: filter / discriminator / filter steps of the HIP path against
+    oracle/pfcn.py (pinned to the reference's goldens), every tensor compared."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+    from oracle import pfcn as O
+    from fairrec.config import Config
+    from fairrec.utils import get_model
+    n_users, n_items, D, B = 100_001, 20_001, 128, 8192
+    hidden, p = (128, 256, 128, 128, 64, 32), 0.3
+    attrs = ["gender"] if mode == "sm" else ["gender", "age"]
+    phases, lists = "FDF", [attrs, attrs, attrs[:1]]
+    g = torch.Generator().manual_seed(31)
+    z = {"model": np.array("PFCN_BiasedMF"), "mode": np.array(mode), "attrs": np.array(attrs), "dis_hidden": np.array(hidden),
+         "hyper": np.array([1e-3, 1e-4, 10.0, p]), "gender": (torch.rand(n_users, generator=g) < 0.5).float().numpy(),
+         "age": torch.randint(0, 3, (n_users,), generator=g).numpy(), "phases": np.array(list(phases)),
+         "sst_lists": np.array([",".join(s) for s in lists])}
+    torch.manual_seed(9)
+    cfg = Config(model="PFCN_BiasedMF", config_dict={"embedding_size": D, "sst_attr_list": attrs, "filter_mode": mode,
+                                                     "dis_hidden_size_list": list(hidden), "dis_dropout": p, "dis_weight": 10.0,
+                                                     "device": "cpu", "activation": "leakyrelu", "dis_activation": "leakyrelu"})
+    m0 = get_model("PFCN_BiasedMF")(cfg, _DS(n_users, n_items, z))
+    for k, v in m0.state_dict().items():
+        z["init.model." + k] = (v * 0.1 if "embedding" in k else v).detach().numpy().copy()
+    for i, mlp in m0.filter_layer.items():
+        for k, v in mlp.state_dict().items():
+            z[f"init.filter.{i}.{k}"] = v.detach().numpy().copy()
+    for s, mlp in m0.dis_layer_dict.items():
+        for k, v in mlp.state_dict().items():
+            z[f"init.dis.{s}.{k}"] = v.detach().numpy().copy()
+    T = len(phases)
+    z["user_id"] = torch.randint(1, n_users, (T, B), generator=g).numpy()
+    z["item_id"] = torch.randint(1, n_items, (T, B), generator=g).numpy()
+    z["neg_item_id"] = torch.randint(1, n_items, (T, B), generator=g).numpy()
+    sizes = [D] + list(hidden)
+    for t in range(T):
+        for s in lists[t]:
+            for l, w in enumerate(sizes):
+                z[f"mask.{s}.{t}.{l}"] = (torch.rand(B, w, generator=g) >= p).float().numpy()
+    ref = O.train(z)
+    # the reference's own fp32 noise on this case: the same ops with one thread (another reduction order).  After a
+    # discriminator step the 8192-row BatchNorm column sums differ in the last bits, Adam turns that into +-lr-sized moves
+    # of betas and biases, and the next loss moves by ~6e-4 relative (x dis_weight 10) -- in the reference itself.
+    torch.set_num_threads(1)
+    alt = O.train(z)
+    torch.set_num_threads(8)
+    # (one pair of runs is one sample of a sign-flip process, not a bound: allow four times their distance)
+    noise = {k[6:] if k.startswith("final.") else k: 4.0 * np.abs(np.asarray(alt[k], dtype=np.float64) - ref[k]).max()
+             for k in ref if k != "loss"}
+    noise["loss"] = 4.0 * np.abs(alt["loss"] - ref["loss"])
+    z.update(ref)
+    _run_case(z, sharded=False, noise=noise)
