@@ -275,12 +275,16 @@ def test_pfcn_biasedmf_full_batch_at_the_baseline_width(mode):
     # the reference's own fp32 noise on this case: the same ops with one thread (another reduction order).  After a
     # discriminator step the 8192-row BatchNorm column sums differ in the last bits, Adam turns that into +-lr-sized moves
     # of betas and biases, and the next loss moves by ~6e-4 relative (x dis_weight 10) -- in the reference itself.
-    torch.set_num_threads(1)
-    alt = O.train(z)
+    alts = []
+    for nt in (1, 2, 4):
+        torch.set_num_threads(nt)
+        alts.append(O.train(z))
     torch.set_num_threads(8)
-    # (one pair of runs is one sample of a sign-flip process, not a bound: allow four times their distance)
-    noise = {k[6:] if k.startswith("final.") else k: 4.0 * np.abs(np.asarray(alt[k], dtype=np.float64) - ref[k]).max()
-             for k in ref if k != "loss"}
-    noise["loss"] = 4.0 * np.abs(alt["loss"] - ref["loss"])
+    # (a handful of runs are samples of a sign-flip process, not a bound: allow twice their spread around the reference)
+    def spread(k):
+        vals = np.stack([np.asarray(o[k], dtype=np.float64) for o in alts + [ref]])
+        return 2.0 * (vals.max(0) - vals.min(0))
+    noise = {k[6:] if k.startswith("final.") else k: float(spread(k).max()) for k in ref if k != "loss"}
+    noise["loss"] = spread("loss")
     z.update(ref)
     _run_case(z, sharded=False, noise=noise)
