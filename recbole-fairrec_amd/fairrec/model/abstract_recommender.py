@@ -79,6 +79,16 @@ class FairRecommender(AbstractRecommender):
             if not dist.is_initialized():
                 raise RuntimeError('row_sharded needs an initialised torch.distributed process group')
             self.shard = (dist.get_rank(), dist.get_world_size())
+        # `data_parallel: True`: REPLICATED tables, the batch sharded over the ranks, gradients of the replicated
+        # parameters averaged per step (fairrec/replicated_engine.py) -- for the models that read whole tables (FairGo)
+        self.replicas = None
+        if config['data_parallel']:
+            import torch.distributed as dist
+            if not dist.is_initialized():
+                raise RuntimeError('data_parallel needs an initialised torch.distributed process group')
+            if self.shard is not None:
+                raise ValueError('row_sharded and data_parallel exclude each other')
+            self.replicas = (dist.get_rank(), dist.get_world_size())
 
     def _table_rows(self, n_rows):
         """Rows of an n_rows table this rank holds."""

@@ -102,7 +102,11 @@ class FairGo_GCN(FairGo_PMF):
     def hip_engine(self) -> GenericEngine:
         uw = self.user_embedding_layer.weight
         if self._engine is None or self._engine._dense["user_embedding_layer.weight"].p.data_ptr() != uw.data_ptr():
-            eng = GenericEngine(uw.device)
+            if self.replicas is not None:      # one replica per GPU, batch sharded: the tables are dense parameters here
+                from ...replicated_engine import ReplicatedGenericEngine      # (the GCN makes their gradient dense), so
+                eng = ReplicatedGenericEngine(uw.device)                      # the flat all-reduce covers them too
+            else:
+                eng = GenericEngine(uw.device)
             eng.add_dense("user_embedding_layer.weight", uw, group='pretrain')
             eng.add_dense("item_embedding_layer.weight", self.item_embedding_layer.weight, group='pretrain')
             for n, p in self.gcn.named_parameters():

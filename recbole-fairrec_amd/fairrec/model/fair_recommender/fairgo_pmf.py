@@ -34,7 +34,8 @@ class FairGo_PMF(FairRecommender):
         if self.shard is not None:
             # the finetune stage filters and propagates the WHOLE frozen tables every step (fairgo_pmf.py:175-199): it wants
             # replicas (exact), not shards; the pretrain stage alone could shard like PFCN_PMF
-            raise NotImplementedError('FairGo on row-sharded tables is not built: run it with replicated tables')
+            raise NotImplementedError('FairGo reads whole tables every finetune step: run it with replicated tables '
+                                      '(data_parallel: True), not row_sharded')
         self.RATING = config['RATING_FIELD']
         self.n_layers = config['n_layers']
         self.act = config['activation']
@@ -105,7 +106,11 @@ class FairGo_PMF(FairRecommender):
     def hip_engine(self) -> GenericEngine:
         uw = self.user_embedding_layer.weight
         if self._engine is None or self._engine._tables["user_embedding_layer.weight"].weight.data_ptr() != uw.data_ptr():
-            eng = GenericEngine(uw.device)
+            if self.replicas is not None:      # one replica per GPU, batch sharded (fairrec/replicated_engine.py)
+                from ...replicated_engine import ReplicatedGenericEngine
+                eng = ReplicatedGenericEngine(uw.device)
+            else:
+                eng = GenericEngine(uw.device)
             eng.add_table("user_embedding_layer.weight", uw, group='pretrain')
             eng.add_table("item_embedding_layer.weight", self.item_embedding_layer.weight, group='pretrain')
             for s, mlp in self.filter_layer_dict.items():

@@ -31,8 +31,11 @@ class _DS:
         return self._coo
 
 
+@pytest.mark.parametrize("replicated", [False, True], ids=["single", "data_parallel"])
 @pytest.mark.parametrize("path", CASES, ids=[os.path.basename(p)[:-4] for p in CASES])
-def test_fairgo_training_matches_reference_golden(path):
+def test_fairgo_training_matches_reference_golden(path, replicated, request):
+    if replicated:     # the data-parallel engine (replicated tables, fairrec/replicated_engine.py) as a 1-rank RCCL world:
+        request.getfixturevalue("rccl_world1")      # every collective call runs; 2 ranks are covered over gloo
     from fairrec.config import Config
     from fairrec.data.interaction import Interaction
     from fairrec.optim import FusedLazyAdam
@@ -45,7 +48,8 @@ def test_fairgo_training_matches_reference_golden(path):
     cfg = Config(model="FairGo_PMF", config_dict={
         "embedding_size": D, "sst_attr_list": attrs, "aggr_method": str(z["aggr"]), "n_layers": int(z["n_layers"]),
         "filter_hidden_size_list": [int(h) for h in z["filter_hidden"]], "dis_hidden_size_list": [int(h) for h in z["dis_hidden"]],
-        "vs_weights": [float(v) for v in z["vs_weights"]], "fair_weight": fw, "device": "cuda"})
+        "vs_weights": [float(v) for v in z["vs_weights"]], "fair_weight": fw, "device": "cuda",
+        "data_parallel": replicated})
     model = get_model("FairGo_PMF")(cfg, _DS(n_users, n_items, z))
     # the reference's L = D^-1 A, entry for entry
     L = model._norm_csr_host.tocoo()
