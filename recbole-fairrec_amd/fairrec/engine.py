@@ -41,6 +41,7 @@ class GenericEngine:
         self.optimizer = None
         self.sweep_period: Optional[int] = None
         self.err_flag = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self._group_version: Dict[Optional[str], int] = {}   # optimizer group -> steps taken (eager or graph replays)
         self._counters = None           # graph mode: one device int32 per entry (tables, then dense tensors)
         self._counter_slot: Dict[str, int] = {}
         self._advance_idx: Dict[tuple, torch.Tensor] = {}
@@ -132,14 +133,26 @@ class GenericEngine:
 
     # --- optimizer.step() -------------------------------------------------------------------------------
     def zero_grad(self, group=None):
+        """optimizer.zero_grad() of the optimizer that owns `group`.  The gradients of the OTHER groups' dense parameters
+        are dropped as well: the reference lets them pile up untouched between their own phases (a
+        discriminator collects gradients all through the filter pass and nobody reads them), but here a stale `.grad`
+        tensor is a hazard -- a step captured as a hipGraph accumulates into it IN PLACE, i.e. the graph keeps the address
+        of a tensor that the owning optimizer's next zero_grad() frees, and every later replay writes through it."""
         for name, d in self._dense.items():
-            if self._owned(name, group):
-                d.p.grad = None
+            d.p.grad = None
         for name, t in self._tables.items():
             if self._owned(name, group):
                 t._grad_rows = None
 
+    def note_stepped(self, group=None):
+        """An optimizer step of `group` was issued (here, or as a replay of a captured step: fairrec/graph.py)."""
+        self._group_version[group] = self._group_version.get(group, 0) + 1
+
+    def group_version(self, group=None) -> int:
+        return self._group_version.get(group, 0)
+
     def backward_adam(self, group=None):
+        self.note_stepped(group)
         stepped = []
         for name, t in self._tables.items():
             if not (t.trainable and t._pending is not None):

@@ -42,6 +42,17 @@ class GraphedStep:
         self.optimizer.step()
         return loss.detach()
 
+    @staticmethod
+    def _quiesce_rccl():
+        """A process that holds an RCCL process group runs ProcessGroupNCCL's watchdog thread, which polls the events of
+        earlier eager collectives from ANOTHER thread; a capture that begins before it has retired them makes that poll
+        fail (hipErrorCapturedEvent) and the watchdog aborts the process.  Give it time to drain; once per
+        captured step, not per replay."""
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl":
+            import time
+            time.sleep(2.0)
+
     def _signature(self, inter: Interaction):
         return tuple((k, tuple(v.shape), v.dtype) for k, v in inter.interaction.items())
 
@@ -58,6 +69,7 @@ class GraphedStep:
             self.sig, self.static_args = self._signature(inter), args
             static_inter = Interaction(self.static)
             torch.cuda.synchronize()
+            self._quiesce_rccl()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 self.loss = self._eager(static_inter, args)
@@ -71,4 +83,6 @@ class GraphedStep:
             for k, v in inter.interaction.items():
                 self.static[k].copy_(v, non_blocking=True)
         self.graph.replay()
+        if hasattr(self.engine, "note_stepped"):      # a replay is an optimizer step the host code did not run
+            self.engine.note_stepped(getattr(self.optimizer, "group", None))
         return self.loss

@@ -70,6 +70,8 @@ class FairGo_PMF(FairRecommender):
         self._norm_csr_host = self.get_norm_rating_matrix()      # scipy CSR of L = D^-1 A (one-off host preprocessing)
         self._L = None
         self._engine = None
+        # discriminator phase: filtered table + propagated embeddings per attribute subset, valid while the filters rest
+        self._dis_cache = {}
 
     # --- construction ---------------------------------------------------------------------------------------------
     def _get_sst_size(self, user_feature):
@@ -154,27 +156,38 @@ class FairGo_PMF(FairRecommender):
         x = _HipMLP.apply(x, None, code, 0.0, None, None, lins[1].weight, lins[1].bias)
         return _HipMLP.apply(x, None, 0, 0.0, None, None, lins[2].weight, lins[2].bias)
 
-    def _dis_terms(self, E, interaction, sst_list):
-        """calculate_dis_loss, fairgo_pmf.py:190-238, on an already filtered whole table E."""
-        eng = self.hip_engine()
-        user = interaction[self.USER_ID].to(eng.device)
-        node = RowGather.apply(E, user, eng.err_flag)
+    def _propagate(self, E):
+        """H_1 = L E, H_2 = L H_1, ... (fairgo_pmf.py:198-201) and what the aggregation needs of them as whole tables:
+        WAP: their mean; LBA: their concatenation (aggr_layer itself is row-wise: it runs on the batch's rows only --
+        the same rows of the same function as the reference's whole-table pass); LVA: the layers themselves."""
         H, hs = E, []
         for _ in range(self.n_layers):
             H = SpMM.apply(H, self._L)
             hs.append(H)
-        lva = self.aggr_method == 'LVA' and self.n_layers > 1
         if self.n_layers == 1:
-            G = hs[0]
-        elif self.aggr_method == 'WAP':
-            G = torch.stack(hs, dim=1).mean(dim=1)
-        elif self.aggr_method == 'LBA':
-            G = self._aggr(torch.cat(hs, dim=1))
+            return [hs[0]]
+        if self.aggr_method == 'WAP':
+            return [torch.stack(hs, dim=1).mean(dim=1)]
+        if self.aggr_method == 'LBA':
+            return [torch.cat(hs, dim=1)]
+        return hs
+
+    def _dis_terms(self, E, interaction, sst_list, props=None):
+        """calculate_dis_loss, fairgo_pmf.py:190-238, on an already filtered whole table E."""
+        eng = self.hip_engine()
+        user = interaction[self.USER_ID].to(eng.device)
+        node = RowGather.apply(E, user, eng.err_flag)
+        props = self._propagate(E) if props is None else props
+        lva = self.aggr_method == 'LVA' and self.n_layers > 1
         if lva:
-            locals_ = [RowGather.apply(h, user, eng.err_flag) for h in hs]
-            vs = self.vs_weights.to(eng.device)
+            locals_ = [RowGather.apply(h, user, eng.err_flag) for h in props]
+            if self.vs_weights.device != eng.device:       # once: no host-to-device copy inside a captured step
+                self.vs_weights = self.vs_weights.to(eng.device)
+            vs = self.vs_weights
         else:
-            local = RowGather.apply(G, user, eng.err_flag)
+            local = RowGather.apply(props[0], user, eng.err_flag)
+            if self.aggr_method == 'LBA' and self.n_layers > 1:
+                local = self._aggr(local)
         node_l, local_l = 0.0, 0.0
         for sst in sst_list:
             d = self.dis_layer_dict[sst]
@@ -196,8 +209,33 @@ class FairGo_PMF(FairRecommender):
                     local_l = local_l + SoftmaxCe.apply(torch.sigmoid(d(local)), label.long(), eng.err_flag)
         return node_l + local_l
 
+    def _filters_version(self):
+        eng = self.hip_engine()
+        return (self.train_stage, eng.group_version('filter'), eng.group_version('pretrain'))
+
+    def begin_dis_phase(self, sst_list):
+        """Trainer hook, called before a pass with optimizer_dis (trainer.py:893-896).  The filters and the tables do not
+        move during that pass, so the filtered whole table and its `n_layers` graph propagations -- two whole-table MLP
+        passes and `n_layers` SpMMs per STEP in the reference -- are the same tensors for every batch of the pass: they
+        are computed once here, into buffers that keep their addresses (a step captured as a hipGraph reads them)."""
+        key = tuple(sst_list)
+        with torch.no_grad():
+            E = self._filtered_table(list(sst_list))
+            props = self._propagate(E)
+        c = self._dis_cache.get(key)
+        if c is None or c["E"].shape != E.shape:
+            c = self._dis_cache[key] = {"E": E.clone(), "props": [h.clone() for h in props]}
+        else:
+            c["E"].copy_(E)
+            for dst, src in zip(c["props"], props):
+                dst.copy_(src)
+        c["version"] = self._filters_version()
+
     def calculate_dis_loss(self, interaction, sst_list):
         """Discriminator phase: only the discriminators (+ aggr_layer) train, so the filters run without a gradient path."""
+        c = self._dis_cache.get(tuple(sst_list))
+        if c is not None and c["version"] == self._filters_version():
+            return self._dis_terms(c["E"], interaction, sst_list, c["props"])
         with torch.no_grad():
             E = self._filtered_table(sst_list)
         return self._dis_terms(E, interaction, sst_list)
@@ -218,8 +256,10 @@ class FairGo_PMF(FairRecommender):
         E = self._filtered_table(sst_list)
         rows = RowGather.apply(E, torch.cat([user, item + self.n_users]), eng.err_flag)
         mse = Mse.apply(RowDot.apply(rows[:B], rows[B:]), rating)
-        # the reference's calculate_dis_loss runs forward() again: same values, second pass through the filters
-        fair = self._dis_terms(self._filtered_table(sst_list), interaction, sst_list)
+        # the reference's calculate_dis_loss runs forward() a second time (fairgo_pmf.py:205-206): the same values from the
+        # same parameters, so ONE filtered table serves both terms -- its gradient is the sum of the two uses, which is
+        # what the two backward passes through the filters add up to (linear in dLoss/dE; rounding-level difference)
+        fair = self._dis_terms(E, interaction, sst_list)
         return mse - self.fair_weight * fair
 
     def predict(self, interaction):

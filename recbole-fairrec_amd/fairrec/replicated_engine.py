@@ -56,7 +56,7 @@ class ReplicatedGenericEngine(GenericEngine):
             self.hyper = AdamHyper(device=self.device, cap=1)
             self.optimizer, self.sweep_period = None, None
             self.err_flag = torch.zeros(1, dtype=torch.int32, device=self.device)
-            self._counters = None
+            self._counters, self._group_version = None, {}
         self._buf: Dict[str, dict] = {}
         self._flat: Optional[torch.Tensor] = None
 
@@ -101,6 +101,7 @@ class ReplicatedGenericEngine(GenericEngine):
 
     # --- optimizer.step() --------------------------------------------------------------------------------------------
     def backward_adam(self, group=None):
+        self.note_stepped(group)
         G = self.G
         for name, t in self._tables.items():
             if not (t.trainable and t._pending is not None):

@@ -136,6 +136,7 @@ class ShardedGenericEngine(GenericEngine):
         self.hyper = AdamHyper(device=self.device, cap=1)
         self.optimizer, self.sweep_period = None, None
         self.err_flag = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self._group_version = {}
 
     # --- registration: `weight` is this rank's SHARD (rows rank, rank + G, ...) --------------------------------
     def add_table(self, name, weight, trainable=True, group=None, n_rows_global: Optional[int] = None, table=None):
@@ -199,6 +200,7 @@ class ShardedGenericEngine(GenericEngine):
 
     # --- optimizer.step() ------------------------------------------------------------------------------------
     def backward_adam(self, group=None):
+        self.note_stepped(group)
         G = self.G
         for name, t in self._tables.items():
             if not (t.trainable and t._pending is not None):

@@ -382,6 +382,8 @@ class PFCNTrainer(Trainer):
                 self.optimizer = self.optimizer_filter
                 filter_loss = self._train_epoch_with_mask(train_data, epoch_idx, self.model.calculate_loss, sst_list)
             self.optimizer = self.optimizer_dis
+            if hasattr(self.model, 'begin_dis_phase'):     # what does not move during a discriminator pass is computed once
+                self.model.begin_dis_phase(sst_list)
             dis_loss = self._train_epoch_with_mask(train_data, epoch_idx, self.model.calculate_dis_loss, sst_list)
             return filter_loss, dis_loss
         return self._train_epoch_with_mask(train_data, epoch_idx, self.model.calculate_loss, None)

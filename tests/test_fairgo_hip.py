@@ -146,6 +146,24 @@ def test_fairgo_trainer_pretrain_then_finetune(tmp_path):
     assert all(d.step == 2 * 3 for k, d in eng._dense.items() if k.startswith("filter."))   # every finetune epoch (interval 1)
     assert os.path.exists(trainer.saved_pretrain_model_file)
     assert get_model("FairGo_GCN").__mro__[1].__name__ == "FairGo_PMF"
+    # the discriminator pass reads the filtered table and its propagations from the per-pass cache (begin_dis_phase): the
+    # same bits as recomputing them per step, and a filter step invalidates it
+    b = next(iter(TrainDataLoader(cfg, ds, shuffle=False))).to("cuda")
+    model._dis_cache.clear()
+    with torch.no_grad():
+        plain = model.calculate_dis_loss(b, ["gender"]).clone()
+    model.begin_dis_phase(["gender"])
+    c = model._dis_cache[("gender",)]
+    assert c["version"] == model._filters_version()
+    with torch.no_grad():
+        assert torch.equal(model.calculate_dis_loss(b, ["gender"]), plain)
+    trainer.optimizer_filter.zero_grad()
+    model.calculate_loss(b, ["gender"]).backward()
+    trainer.optimizer_filter.step()
+    assert c["version"] != model._filters_version()          # stale now: the next call recomputes
+    with torch.no_grad():
+        moved = model.calculate_dis_loss(b, ["gender"])
+    assert not torch.equal(moved, plain)
     # resume of the finetune checkpoint (trainer.py:807-834): optimizer_filter / optimizer_dis come back
     ck = torch.load(trainer.saved_model_file, weights_only=False)
     cfg2 = Config(model="FairGo_PMF", dataset="synth", config_dict=dict(
