@@ -50,6 +50,10 @@ def synth_batches(n_batches, batch, n_users, n_items, seed, item_dist="uniform")
         k_items = batch // per + (1 if batch % per else 0)
         picks = torch.randint(1, n_items, (n_batches, k_items), generator=g, dtype=torch.int64)
         i = picks.repeat_interleave(per, dim=1)[:, :batch].contiguous()
+    elif item_dist == "unique":
+        # no row occurs twice in a batch (diagnostic: every interaction takes the kernel's common path)
+        i = torch.stack([torch.randperm(n_items - 1, generator=g)[:batch] + 1 for _ in range(n_batches)])
+        u = torch.stack([torch.randperm(n_users - 1, generator=g)[:batch] + 1 for _ in range(n_batches)])
     else:
         i = torch.randint(1, n_items, (n_batches, batch), generator=g, dtype=torch.int64)
     r = torch.randint(1, 6, (n_batches, batch), generator=g).to(torch.float32)
@@ -230,7 +234,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly instead of one hipGraph")
     ap.add_argument("--graph-only", action="store_true", help="do not also time eager launches (single-GPU default: both)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--item-dist", default="uniform", choices=["uniform", "zipf", "grouped"])
+    ap.add_argument("--item-dist", default="uniform", choices=["uniform", "zipf", "grouped", "unique"])
     ap.add_argument("--sweep", type=int, default=None, help="lazy-Adam sweep period (default: auto)")
     ap.add_argument("--force-sharded", action="store_true", help="use the row-sharded engine even on one GPU")
     ap.add_argument("--age", type=int, default=0,

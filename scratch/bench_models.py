@@ -81,17 +81,21 @@ if "pfcn" in which:
     run(f"PFCN_BiasedMF sm dis-phase step", m, [od], [lambda it: m.calculate_dis_loss(it, sl)], data, ds._uf["gender"])
     del m, of, od; torch.cuda.empty_cache()
 if "fairgo" in which:
-    nu, ni, D = 1_000_001, 100_001, 128
+    nu, ni, D = int(os.environ.get("FG_NU", 1_000_001)), int(os.environ.get("FG_NI", 100_001)), 128
     rng = np.random.default_rng(0)
+    t_host = time.time()
     nnz = 20 * nu
     gu, gi = rng.integers(1, nu, nnz), rng.integers(1, ni, nnz)
     graph = sp.coo_matrix((rng.integers(1, 6, nnz).astype(np.float32), (gu, gi)), shape=(nu, ni))
     cfg = Config(model="FairGo_PMF", config_dict={"embedding_size": D, "device": "cuda", "aggr_method": "WAP", "n_layers": 2})
     ds = DS(nu, ni, graph)
     m = get_model("FairGo_PMF")(cfg, ds).to("cuda"); m.train(); m.train_stage = "finetune"
+    m.hip_engine(); torch.cuda.synchronize()
+    print(f"FairGo graph + model built in {time.time() - t_host:.0f} s (host)", flush=True)
     of = FusedLazyAdam(m.hip_engine(), lr=1e-3, weight_decay=1e-4, group="filter")
     od = FusedLazyAdam(m.hip_engine(), lr=1e-3, weight_decay=1e-4, group="dis")
     sl = ["gender"]
     data = batches(nu, ni, B, 4)
     run(f"FairGo_PMF WAP finetune filter-phase step {nu}x{ni} D={D} B={B} (whole-table filters + 2 SpMM, nnz={2*nnz})", m, [of], [lambda it: m.calculate_loss(it, sl)], data, ds._uf["gender"], W=2, K=5)
-    run(f"FairGo_PMF WAP finetune dis-phase step", m, [od], [lambda it: m.calculate_dis_loss(it, sl)], data, ds._uf["gender"], W=2, K=5)
+    m.begin_dis_phase(sl)       # what the trainer does before a discriminator pass: filtered table + propagations, once
+    run(f"FairGo_PMF WAP finetune dis-phase step (per-pass cache)", m, [od], [lambda it: m.calculate_dis_loss(it, sl)], data, ds._uf["gender"], W=2, K=5)
