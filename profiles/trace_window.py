@@ -7,11 +7,11 @@ for r in csv.DictReader(open(f)):
     rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), name))
 rows.sort()
 K = int(sys.argv[2]) if len(sys.argv) > 2 else 200
-g = [k for k, r in enumerate(rows) if r[2].startswith("focf_gather")]
+g = [k for k, r in enumerate(rows) if r[2].startswith("focf_step_kernel") or r[2].startswith("focf_gather")]
 # densest window of K consecutive gather launches
 best = min(range(len(g) - K + 1), key=lambda a: rows[g[a + K - 1]][0] - rows[g[a]][0])
 t0, t1 = rows[g[best]][0], rows[g[best + K - 1]][1]
-print("window: %d gather launches, %.2f us per step" % (K, (rows[g[best + K - 1]][0] - t0) / (K - 1) / 1e3))
+print("window: %d step (gather) launches, %.2f us per step" % (K, (rows[g[best + K - 1]][0] - t0) / (K - 1) / 1e3))
 acc = collections.defaultdict(list)
 for s, e, n in rows:
     if t0 <= s <= t1:

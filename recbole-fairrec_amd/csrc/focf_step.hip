@@ -22,6 +22,7 @@
 // The sweeper slice of the step (bounded staleness) rides in the same launch: its rows are told from the
 // batch's rows by stamps that the look-ahead sort wrote (fr_focf_prepare_step), so both kinds of wave start at once and the
 // sweeper's VALU work hides the interaction waves' two dependent load levels.
+#include <stddef.h>
 #include <stdlib.h>
 
 #include <algorithm>
@@ -70,10 +71,29 @@ struct StepArgs {
     PrevLoss prev;
 };
 
-// The kernel reads its arguments through a reference into the kernarg segment (constant address space: scalar loads) that
-// is made opaque once per task: each task re-reads the handful of fields it needs right where it needs them, instead of
-// the compiler parking every field of the struct in SGPRs around the wave's task loop (106 SGPRs + 130 spilled ones).
-typedef const StepArgs __attribute__((address_space(4)))& SA;
+// How a wave reads its kernel arguments: ONE vector load at kernel entry puts the whole argument block into two VGPRs
+// (lane l holds dwords l and 64 + l of the kernarg segment); a field is then a v_readlane away wherever it is needed.
+// As scalar loads from the kernarg segment the ~40 fields of the common path either stay live in SGPRs for the whole
+// kernel (106 SGPRs + spills = 6 workgroups per CU) or are fetched just in time one after the other, each behind its own
+// s_waitcnt: 7 us before an interaction wave had even requested its records (FR_STEP_TRACE).
+struct KV {
+    unsigned v0, v1;
+};
+template <typename T>
+__device__ __forceinline__ T karg(KV kv, int off) {
+    static_assert(sizeof(T) == 4 || sizeof(T) == 8, "4- or 8-byte argument fields");
+    const int d = off >> 2;
+    auto word = [&](int i) { return (unsigned)__builtin_amdgcn_readlane((int)(i < 64 ? kv.v0 : kv.v1), i & 63); };
+    if constexpr (sizeof(T) == 4) {
+        return __builtin_bit_cast(T, word(d));
+    } else {
+        const unsigned long long q = (unsigned long long)word(d) | ((unsigned long long)word(d + 1) << 32);
+        return __builtin_bit_cast(T, q);
+    }
+}
+#define KA(field) karg<decltype(StepArgs::field)>(kv, (int)offsetof(StepArgs, field))
+#define KAC(field) karg<decltype(AdamC::field)>(kv, (int)(offsetof(StepArgs, c) + offsetof(AdamC, field)))
+static_assert(sizeof(StepArgs) <= 512, "the argument block must fit two VGPRs of dwords");
 
 // Wave-uniform reads of per-task data (the prepared records, the rows' `last` stamps): vector loads + readfirstlane.
 // (As scalar loads through the constant address space they cost 8 us per wave at launch: thousands of waves missing
@@ -218,8 +238,8 @@ __device__ __forceinline__ void replay_two(TwoRows<E>& r, int tA, int tB, int up
 // The last wave to arrive at a user segment: sum the members' gradient rows coef[b] * (item row of b before its update),
 // one Adam step on the user's caught-up row (parked by its first member), write back.
 template <int E>
-__device__ __forceinline__ void user_finish(SA a, const AdamC& c, const FocfWs& w, int j0u, int nu, float2 s, int lane) {
-    const int D = a.D;
+__device__ __forceinline__ void user_finish(KV kv, const AdamC& c, const FocfWs& w, int j0u, int nu, float2 s, int lane) {
+    const int D = KA(D);
     const int c0 = uniform(w.perm_u[j0u]);
     const int ur = uniform(w.rec[c0].x);
     RowFrag<E> p, m, v, g;
@@ -227,25 +247,25 @@ __device__ __forceinline__ void user_finish(SA a, const AdamC& c, const FocfWs& 
     load_row_sc1<E>(m, w.side[1] + (size_t)c0 * D, D, lane);
     load_row_sc1<E>(v, w.side[2] + (size_t)c0 * D, D, lane);
     handed_grad_sum<E>(g, j0u, nu, w.perm_u, w.coef, w.side[3], D, lane);
-    adam_write<E>(a.Up, a.Um, a.Uv, a.Ulast, D, a.step, c, ur, p, m, v, g, s, lane);
+    adam_write<E>(KA(Up), KA(Um), KA(Uv), KA(Ulast), D, KA(step), c, ur, p, m, v, g, s, lane);
 }
 
 // The rest of an interaction whose user or item row is shared with other interactions of the batch: hand over, then
 // whoever arrives last at a segment finishes it (3 % / 8 % of the interactions for uniform pairs at the BASELINE sizes).
 template <int E>
-__device__ __forceinline__ void step_shared_rows(SA a, const AdamC& c, int b, int lane, int ur, int ir, int iux, int iix,
+__device__ __forceinline__ void step_shared_rows(KV kv, const AdamC& c, int b, int lane, int ur, int ir, int iux, int iix,
                                                  int seg_u, int seg_i, float dot, float coef, float smin, float smax,
                                                  float K, RowFrag<E>& pu, RowFrag<E>& mu, RowFrag<E>& vu, RowFrag<E>& pi,
                                                  RowFrag<E>& mi, RowFrag<E>& vi) {
-    const int D = a.D;
-    const bool fair = a.objective != FR_FOCF_NONE;
+    const int D = KA(D);
+    const bool fair = KA(objective) != FR_FOCF_NONE;
     const int nu = iux >> 16, ni = iix >> 16, j0u = iux & 0xffff, j0i = iix & 0xffff;
-    const float2 s = step_scalars(c, a.step);
+    const float2 s = step_scalars(c, KA(step));
     // the workspace arrays of this path, from the base pointer (opaque to the optimiser on purpose: hoisted out of the
     // task loop the two dozen pointers would occupy SGPRs on the common path)
-    int Bq = a.B;
+    int Bq = KA(B);
     asm volatile("" : "+s"(Bq));
-    const FocfWs w = focf_layout(a.ws, Bq, D);
+    const FocfWs w = focf_layout(KA(ws), Bq, D);
 
     const size_t so = (size_t)b * D;
     store_row_sc1<E>(pu, w.side[0] + so, D, lane);
@@ -257,10 +277,10 @@ __device__ __forceinline__ void step_shared_rows(SA a, const AdamC& c, int b, in
         RowFrag<E> gi;
 #pragma unroll
         for (int e = 0; e < E; ++e) gi.x[e] = coef * pu.x[e];
-        adam_write<E>(a.Ip, a.Im, a.Iv, a.Ilast, D, a.step, c, ir, pi, mi, vi, gi, s, lane);
+        adam_write<E>(KA(Ip), KA(Im), KA(Iv), KA(Ilast), D, KA(step), c, ir, pi, mi, vi, gi, s, lane);
         if (lane == 0) st_sc1(w.coef + b, coef);
         drain_stores();
-        if (arrive_last(w.cnt_u + seg_u, nu, lane)) user_finish<E>(a, c, w, j0u, nu, s, lane);
+        if (arrive_last(w.cnt_u + seg_u, nu, lane)) user_finish<E>(kv, c, w, j0u, nu, s, lane);
         return;
     }
     RowFrag<E> pi0 = pi;
@@ -287,7 +307,7 @@ __device__ __forceinline__ void step_shared_rows(SA a, const AdamC& c, int b, in
                 }
             }
         }
-        if (bad && a.err) atomicOr(a.err, FR_DEV_ERR_SST_GROUPS);
+        if (bad && KA(err)) atomicOr(KA(err), FR_DEV_ERR_SST_GROUPS);
         sp0 = group_sum<FAIR_GROUP>(sp0); sp1 = group_sum<FAIR_GROUP>(sp1);
         st0 = group_sum<FAIR_GROUP>(st0); st1 = group_sum<FAIR_GROUP>(st1);
         n0 = group_sum<FAIR_GROUP>(n0);   n1 = group_sum<FAIR_GROUP>(n1);
@@ -297,8 +317,8 @@ __device__ __forceinline__ void step_shared_rows(SA a, const AdamC& c, int b, in
         st1 = __builtin_bit_cast(float, uniform(__builtin_bit_cast(int, st1)));
         n0 = __builtin_bit_cast(float, uniform(__builtin_bit_cast(int, n0)));
         n1 = __builtin_bit_cast(float, uniform(__builtin_bit_cast(int, n1)));
-        focf_fair_eval(a.objective, a.fair_weight, K, sp0, sp1, st0, st1, n0, n1, term, g0, g1);
-        if (lane == 0) a.term[seg_i] = term;
+        focf_fair_eval(KA(objective), KA(fair_weight), K, sp0, sp1, st0, st1, n0, n1, term, g0, g1);
+        if (lane == 0) KA(term)[seg_i] = term;
     }
     // dLoss/dpred of the members, 64 at a time (one per lane), written for the user level
     for (int jb = 0; jb < ni; jb += 64) {
@@ -306,7 +326,7 @@ __device__ __forceinline__ void step_shared_rows(SA a, const AdamC& c, int b, in
             const int bq = w.perm_i[j0i + jb + lane];
             const int4 rq = w.rec[bq];
             const float erq = ld_sc1(w.pred + bq) - __int_as_float(rq.z);
-            float cq = 2.f * erq / (float)a.B;
+            float cq = 2.f * erq / (float)KA(B);
             if (fair) cq = cq + (__int_as_float(rq.w) == smin ? g0 : g1);
             st_sc1(w.coef + bq, cq);
         }
@@ -315,7 +335,7 @@ __device__ __forceinline__ void step_shared_rows(SA a, const AdamC& c, int b, in
     {
         RowFrag<E> gi;
         handed_grad_sum<E>(gi, j0i, ni, w.perm_i, w.coef, w.side[0], D, lane);
-        adam_write<E>(a.Ip, a.Im, a.Iv, a.Ilast, D, a.step, c, ir, pi, mi, vi, gi, s, lane);
+        adam_write<E>(KA(Ip), KA(Im), KA(Iv), KA(Ilast), D, KA(step), c, ir, pi, mi, vi, gi, s, lane);
     }
     // ---- user level of every member, ascending; members whose user is theirs alone are updated here (one at a time:
     // this path is rare and must not set the kernel's register budget)
@@ -357,12 +377,12 @@ __device__ __forceinline__ void step_shared_rows(SA a, const AdamC& c, int b, in
                     RowFrag<E> gu;
 #pragma unroll
                     for (int e = 0; e < E; ++e) gu.x[e] = cq[q] * pi0.x[e];
-                    adam_write<E>(a.Up, a.Um, a.Uv, a.Ulast, D, a.step, c, uq[q], p[q], m[q], v[q], gu, s, lane);
+                    adam_write<E>(KA(Up), KA(Um), KA(Uv), KA(Ulast), D, KA(step), c, uq[q], p[q], m[q], v[q], gu, s, lane);
                 } else {
                     const int t = t0 + q;
                     const int sg = __builtin_amdgcn_readlane(my_seg, t);
                     const int j0 = __builtin_amdgcn_readlane(my_iux, t) & 0xffff;
-                    if (arrive_last(w.cnt_u + sg, nq[q], lane)) user_finish<E>(a, c, w, j0, nq[q], s, lane);
+                    if (arrive_last(w.cnt_u + sg, nq[q], lane)) user_finish<E>(kv, c, w, j0, nq[q], s, lane);
                 }
             }
         }
@@ -398,12 +418,12 @@ __device__ __forceinline__ void focf_fair_single(int objective, float fair_weigh
 // and -- when nobody else in the batch touches either row -- both gradients and both Adam steps, the two rows as packed
 // pairs.  iux / iix = (j0 | n << 16) of its user / item segment, segs = user segment | item segment << 16, b = position.
 template <int E>
-__device__ __forceinline__ void step_finish(SA a, const AdamC& c, int lane, int q, RowFrag<E>& pu, RowFrag<E>& mu,
+__device__ __forceinline__ void step_finish(KV kv, const AdamC& c, int lane, int q, RowFrag<E>& pu, RowFrag<E>& mu,
                                             RowFrag<E>& vu, RowFrag<E>& pi, RowFrag<E>& mi, RowFrag<E>& vi) {
-    const int D = a.D;
-    const bool fair = a.objective != FR_FOCF_NONE;
+    const int D = KA(D);
+    const bool fair = KA(objective) != FR_FOCF_NONE;
     // the interaction's records again (scalar loads, cache hits): nothing of them was kept across the replay
-    const int4 vrec = a.task_rec[q], vinf = a.task_info[q], vhd = *reinterpret_cast<const int4*>(a.hdr);
+    const int4 vrec = KA(task_rec)[q], vinf = KA(task_info)[q], vhd = *reinterpret_cast<const int4*>(KA(hdr));
     const int4 rec = make_int4(uniform(vrec.x), uniform(vrec.y), uniform(vrec.z), uniform(vrec.w));
     const int4 inf = make_int4(uniform(vinf.x), uniform(vinf.y), uniform(vinf.z), uniform(vinf.w));
     const int4 hd = make_int4(uniform(vhd.x), 0, uniform(vhd.z), uniform(vhd.w));
@@ -417,20 +437,20 @@ __device__ __forceinline__ void step_finish(SA a, const AdamC& c, int lane, int 
     for (int e = 0; e < E; ++e) dot = fmaf(pu.x[e], pi.x[e], dot);
     dot = wave_sum(dot);
     const float er = dot - rt;
-    if (lane == 0) a.mse_e[b] = er * er;
-    const float cm = 2.f * er / (float)a.B;        // d mean((pred - r)^2) / d pred
+    if (lane == 0) KA(mse_e)[b] = er * er;
+    const float cm = 2.f * er / (float)KA(B);        // d mean((pred - r)^2) / d pred
     // dLoss/dpred of an interaction whose item has no other member in the batch: its per-item statistics are its own
     float coef = cm;
     if (ni == 1 && fair) {
         const bool in0 = s == smin;
-        if (s != smin && s != smax && lane == 0 && a.err) atomicOr(a.err, FR_DEV_ERR_SST_GROUPS);
+        if (s != smin && s != smax && lane == 0 && KA(err)) atomicOr(KA(err), FR_DEV_ERR_SST_GROUPS);
         float term, g;
-        focf_fair_single(a.objective, a.fair_weight, K, in0, dot, rt, term, g);
+        focf_fair_single(KA(objective), KA(fair_weight), K, in0, dot, rt, term, g);
         coef = cm + g;
-        if (lane == 0) a.term[seg_i] = term;
+        if (lane == 0) KA(term)[seg_i] = term;
     }
     if (ni == 1 && nu == 1) {      // ---- nobody else touches either row: finish here
-        const float2 sc = step_scalars(c, a.step);
+        const float2 sc = step_scalars(c, KA(step));
 #pragma unroll
         for (int e = 0; e < E; ++e) {       // adam_elem on the pair (user element, item element)
             v2f_ P = {pu.x[e], pi.x[e]}, M = {mu.x[e], mi.x[e]}, V = {vu.x[e], vi.x[e]};
@@ -444,19 +464,19 @@ __device__ __forceinline__ void step_finish(SA a, const AdamC& c, int lane, int 
             mu.x[e] = M.x; mi.x[e] = M.y;
             vu.x[e] = V.x; vi.x[e] = V.y;
         }
-        store_row<E>(pu, a.Up + (size_t)ur * D, D, lane);
-        store_row<E>(mu, a.Um + (size_t)ur * D, D, lane);
-        store_row<E>(vu, a.Uv + (size_t)ur * D, D, lane);
-        store_row<E>(pi, a.Ip + (size_t)ir * D, D, lane);
-        store_row<E>(mi, a.Im + (size_t)ir * D, D, lane);
-        store_row<E>(vi, a.Iv + (size_t)ir * D, D, lane);
+        store_row<E>(pu, KA(Up) + (size_t)ur * D, D, lane);
+        store_row<E>(mu, KA(Um) + (size_t)ur * D, D, lane);
+        store_row<E>(vu, KA(Uv) + (size_t)ur * D, D, lane);
+        store_row<E>(pi, KA(Ip) + (size_t)ir * D, D, lane);
+        store_row<E>(mi, KA(Im) + (size_t)ir * D, D, lane);
+        store_row<E>(vi, KA(Iv) + (size_t)ir * D, D, lane);
         if (lane == 0) {
-            a.Ulast[ur] = a.step;
-            a.Ilast[ir] = a.step;
+            KA(Ulast)[ur] = KA(step);
+            KA(Ilast)[ir] = KA(step);
         }
         return;
     }
-    step_shared_rows<E>(a, c, b, lane, ur, ir, iux, iix, seg_u, seg_i, dot, coef, smin, smax, K, pu, mu, vu, pi, mi, vi);
+    step_shared_rows<E>(kv, c, b, lane, ur, ir, iux, iix, seg_u, seg_i, dot, coef, smin, smax, K, pu, mu, vu, pi, mi, vi);
 }
 
 #if FR_STEP_TRACE
@@ -467,7 +487,7 @@ __device__ __forceinline__ void step_finish(SA a, const AdamC& c, int lane, int 
 //   sweeper task q  : rows 2q, 2q + 1 of the step's slice (users first, then items), written back at step `step`;
 //   interaction b   : its user row and item row as of step - 1, then score, dLoss/dpred, both gradients, both updates.
 template <int E, bool PAIR>
-__device__ __forceinline__ void step_task(SA a, bool sweeper, int q, int lane
+__device__ __forceinline__ void step_task(KV kv, bool sweeper, int q, int lane
 #if FR_STEP_TRACE
                                           , unsigned long long (&phase_stamps)[4]
 #endif
@@ -476,23 +496,23 @@ __device__ __forceinline__ void step_task(SA a, bool sweeper, int q, int lane
     // wave's task loop and parked in VGPR pairs for the whole kernel (101 VGPRs = 4 waves per SIMD)
     asm volatile("" : "+v"(lane));
     AdamC c;
-    c.sc = a.c.sc; c.cap = a.c.cap; c.wd = a.c.wd; c.b1 = a.c.b1; c.omb1 = a.c.omb1; c.b2 = a.c.b2; c.omb2 = a.c.omb2;
-    c.eps = a.c.eps; c.k1 = a.c.k1; c.k2 = a.c.k2; c.inv_k1 = a.c.inv_k1; c.inv_k2 = a.c.inv_k2;
-    const int D = a.D;
+    c.sc = KAC(sc); c.cap = KAC(cap); c.wd = KAC(wd); c.b1 = KAC(b1); c.omb1 = KAC(omb1); c.b2 = KAC(b2); c.omb2 = KAC(omb2);
+    c.eps = KAC(eps); c.k1 = KAC(k1); c.k2 = KAC(k2); c.inv_k1 = KAC(inv_k1); c.inv_k2 = KAC(inv_k2);
+    const int D = KA(D);
     TwoRows<E> r;
     int tA, tB;
     if (sweeper) {
-        const int pairs_u = (a.n_u + 1) >> 1;
+        const int pairs_u = (KA(n_u) + 1) >> 1;
         const bool inU = q < pairs_u;
         const int k = inU ? q : q - pairs_u;
-        const long long rowA = (inU ? a.lo_u : a.lo_i) + 2 * k;
-        const bool hasB = 2 * k + 1 < (inU ? a.n_u : a.n_i);
+        const long long rowA = (inU ? KA(lo_u) : KA(lo_i)) + 2 * k;
+        const bool hasB = 2 * k + 1 < (inU ? KA(n_u) : KA(n_i));
         const long long rowB = hasB ? rowA + 1 : rowA;
-        float* Tp = inU ? a.Up : a.Ip;
-        float* Tm = inU ? a.Um : a.Im;
-        float* Tv = inU ? a.Uv : a.Iv;
-        int32_t* Tl = inU ? a.Ulast : a.Ilast;
-        const int32_t* Ts = inU ? a.Ustamp : a.Istamp;
+        float* Tp = inU ? KA(Up) : KA(Ip);
+        float* Tm = inU ? KA(Um) : KA(Im);
+        float* Tv = inU ? KA(Uv) : KA(Iv);
+        int32_t* Tl = inU ? KA(Ulast) : KA(Ilast);
+        const int32_t* Ts = inU ? KA(Ustamp) : KA(Istamp);
         // stamps, `last` and the rows in ONE round trip (a row is wasted for the few that are skipped)
         const int sa = Ts[rowA], sb = Ts[rowB];
         const int la = Tl[rowA], lb = Tl[rowB];
@@ -502,9 +522,9 @@ __device__ __forceinline__ void step_task(SA a, bool sweeper, int q, int lane
         load_row<E>(r.pB, Tp + (size_t)rowB * D, D, lane);
         load_row<E>(r.mB, Tm + (size_t)rowB * D, D, lane);
         load_row<E>(r.vB, Tv + (size_t)rowB * D, D, lane);
-        const int upto = a.step;
-        tA = uniform(sa) >= a.skip_from ? upto : uniform(la);
-        tB = (!hasB || uniform(sb) >= a.skip_from) ? upto : uniform(lb);
+        const int upto = KA(step);
+        tA = uniform(sa) >= KA(skip_from) ? upto : uniform(la);
+        tB = (!hasB || uniform(sb) >= KA(skip_from)) ? upto : uniform(lb);
         const bool doA = tA < upto, doB = tB < upto;
         replay_two<E>(r, tA, tB, upto, c, lane);
         if (doA) {
@@ -525,28 +545,28 @@ __device__ __forceinline__ void step_task(SA a, bool sweeper, int q, int lane
         // ---- two interactions per wave, neighbours in the start order (= similar replay lengths): their two user rows go
         // through the replay as one packed pair and so do their two item rows (4.5 instead of 7 VALU instructions per row
         // and step); each interaction is then finished on its own
-        const bool has1 = q + 1 < a.B;
+        const bool has1 = q + 1 < KA(B);
         const int q1 = has1 ? q + 1 : q;
-        const int4 vrec0 = a.task_rec[q], vrec1 = a.task_rec[q1];
+        const int4 vrec0 = KA(task_rec)[q], vrec1 = KA(task_rec)[q1];
         const int u0 = uniform(vrec0.x), i0 = uniform(vrec0.y), u1 = uniform(vrec1.x), i1 = uniform(vrec1.y);
 #if FR_STEP_TRACE
         g_phase[2] = __builtin_amdgcn_s_memrealtime();     // level-1 records have arrived
 #endif
-        const int lu0 = a.Ulast[u0], lu1 = a.Ulast[u1], li0 = a.Ilast[i0], li1 = a.Ilast[i1];
+        const int lu0 = KA(Ulast)[u0], lu1 = KA(Ulast)[u1], li0 = KA(Ilast)[i0], li1 = KA(Ilast)[i1];
         TwoRows<E> it;       // r = the two user rows, it = the two item rows
-        load_row<E>(r.pA, a.Up + (size_t)u0 * D, D, lane);
-        load_row<E>(r.pB, a.Up + (size_t)u1 * D, D, lane);
-        load_row<E>(it.pA, a.Ip + (size_t)i0 * D, D, lane);
-        load_row<E>(it.pB, a.Ip + (size_t)i1 * D, D, lane);
-        load_row<E>(r.mA, a.Um + (size_t)u0 * D, D, lane);
-        load_row<E>(r.vA, a.Uv + (size_t)u0 * D, D, lane);
-        load_row<E>(r.mB, a.Um + (size_t)u1 * D, D, lane);
-        load_row<E>(r.vB, a.Uv + (size_t)u1 * D, D, lane);
-        load_row<E>(it.mA, a.Im + (size_t)i0 * D, D, lane);
-        load_row<E>(it.vA, a.Iv + (size_t)i0 * D, D, lane);
-        load_row<E>(it.mB, a.Im + (size_t)i1 * D, D, lane);
-        load_row<E>(it.vB, a.Iv + (size_t)i1 * D, D, lane);
-        const int upto = a.step - 1;
+        load_row<E>(r.pA, KA(Up) + (size_t)u0 * D, D, lane);
+        load_row<E>(r.pB, KA(Up) + (size_t)u1 * D, D, lane);
+        load_row<E>(it.pA, KA(Ip) + (size_t)i0 * D, D, lane);
+        load_row<E>(it.pB, KA(Ip) + (size_t)i1 * D, D, lane);
+        load_row<E>(r.mA, KA(Um) + (size_t)u0 * D, D, lane);
+        load_row<E>(r.vA, KA(Uv) + (size_t)u0 * D, D, lane);
+        load_row<E>(r.mB, KA(Um) + (size_t)u1 * D, D, lane);
+        load_row<E>(r.vB, KA(Uv) + (size_t)u1 * D, D, lane);
+        load_row<E>(it.mA, KA(Im) + (size_t)i0 * D, D, lane);
+        load_row<E>(it.vA, KA(Iv) + (size_t)i0 * D, D, lane);
+        load_row<E>(it.mB, KA(Im) + (size_t)i1 * D, D, lane);
+        load_row<E>(it.vB, KA(Iv) + (size_t)i1 * D, D, lane);
+        const int upto = KA(step) - 1;
         const int tu0 = uniform(lu0), tu1 = uniform(lu1), ti0 = uniform(li0), ti1 = uniform(li1);
 #if FR_STEP_TRACE
         g_phase[0] = __builtin_amdgcn_s_memrealtime();     // rows have arrived
@@ -565,24 +585,24 @@ __device__ __forceinline__ void step_task(SA a, bool sweeper, int q, int lane
                     it.pA.x[e] = it.pB.x[e]; it.mA.x[e] = it.mB.x[e]; it.vA.x[e] = it.vB.x[e];
                 }
             }
-            step_finish<E>(a, c, lane, q + k, r.pA, r.mA, r.vA, it.pA, it.mA, it.vA);
+            step_finish<E>(kv, c, lane, q + k, r.pA, r.mA, r.vA, it.pA, it.mA, it.vA);
         }
         return;
     }
     // ---- one interaction per wave (wide rows: two interactions' rows would not fit the register budget)
-    const int4 vrec = a.task_rec[q];
+    const int4 vrec = KA(task_rec)[q];
     const int ur = uniform(vrec.x), ir = uniform(vrec.y);
-    const int lu = a.Ulast[ur], li = a.Ilast[ir];
-    load_row<E>(r.pA, a.Up + (size_t)ur * D, D, lane);
-    load_row<E>(r.pB, a.Ip + (size_t)ir * D, D, lane);
-    load_row<E>(r.mA, a.Um + (size_t)ur * D, D, lane);
-    load_row<E>(r.vA, a.Uv + (size_t)ur * D, D, lane);
-    load_row<E>(r.mB, a.Im + (size_t)ir * D, D, lane);
-    load_row<E>(r.vB, a.Iv + (size_t)ir * D, D, lane);
+    const int lu = KA(Ulast)[ur], li = KA(Ilast)[ir];
+    load_row<E>(r.pA, KA(Up) + (size_t)ur * D, D, lane);
+    load_row<E>(r.pB, KA(Ip) + (size_t)ir * D, D, lane);
+    load_row<E>(r.mA, KA(Um) + (size_t)ur * D, D, lane);
+    load_row<E>(r.vA, KA(Uv) + (size_t)ur * D, D, lane);
+    load_row<E>(r.mB, KA(Im) + (size_t)ir * D, D, lane);
+    load_row<E>(r.vB, KA(Iv) + (size_t)ir * D, D, lane);
     tA = uniform(lu);
     tB = uniform(li);
-    replay_two<E>(r, tA, tB, a.step - 1, c, lane);
-    step_finish<E>(a, c, lane, q, r.pA, r.mA, r.vA, r.pB, r.mB, r.vB);
+    replay_two<E>(r, tA, tB, KA(step) - 1, c, lane);
+    step_finish<E>(kv, c, lane, q, r.pA, r.mA, r.vA, r.pB, r.mB, r.vB);
 }
 
 // fixed-order reduction of one batch's squared errors and per-item terms -> loss (one workgroup of 256 threads).  The
@@ -664,8 +684,11 @@ __global__ __launch_bounds__(256, FR_STEP_WAVES) void focf_step_kernel(StepArgs 
     if (blockIdx.x == 0) {
         if (a.prev.loss_out) step_reduce_loss(a.prev);
     } else {
-        typedef const StepArgs __attribute__((address_space(4)))* ArgP;
-        ArgP ap = (ArgP)__builtin_amdgcn_kernarg_segment_ptr();
+        const unsigned* kp = reinterpret_cast<const unsigned*>(
+            (const void*)(const __attribute__((address_space(4))) void*)__builtin_amdgcn_kernarg_segment_ptr());
+        KV kv;
+        kv.v0 = kp[lane];
+        kv.v1 = lane < (int)(sizeof(StepArgs) / 4) - 64 ? kp[64 + lane] : 0u;
         const int x = (int)blockIdx.x - 1;
         const int n_pairs = ((a.n_u + 1) >> 1) + ((a.n_i + 1) >> 1);
         const int ns = (n_pairs + 3) >> 2;
@@ -676,9 +699,9 @@ __global__ __launch_bounds__(256, FR_STEP_WAVES) void focf_step_kernel(StepArgs 
         const int q = ((sweeper ? x - a.lead : (x < a.lead ? x : x - ns)) * 4 + wib) * (!sweeper && PAIR ? 2 : 1);
         role = sweeper ? 1 : 2;
 #if FR_STEP_TRACE
-        if (q < (sweeper ? n_pairs : a.B)) step_task<E, PAIR>(*ap, sweeper, q, lane, ph);
+        if (q < (sweeper ? n_pairs : a.B)) step_task<E, PAIR>(kv, sweeper, q, lane, ph);
 #else
-        if (q < (sweeper ? n_pairs : a.B)) step_task<E, PAIR>(*ap, sweeper, q, lane);
+        if (q < (sweeper ? n_pairs : a.B)) step_task<E, PAIR>(kv, sweeper, q, lane);
 #endif
     }
 #if FR_STEP_TRACE
@@ -706,73 +729,125 @@ __global__ __launch_bounds__(256) void focf_step_finish_kernel(PrevLoss pl) { st
 // starts, and a wave's latency is its replay length: 3.4 us with nothing to replay, 25 us with 2 x 123 steps).  One
 // workgroup per batch, behind the index sort on the look-ahead stream: estimated VALU cost from the rows' `last` stamps as
 // of NOW (a row touched again before the batch runs has less to replay than estimated -- only the order is affected,
-// never a result), counting sort on 256 cost classes, records rewritten in that order.
+// never a result), stable partition into 8 cost classes, records rewritten in that order.
 struct LptJob {
+    const int32_t *age_u, *age_i;
     const int4 *rec, *info;
     int4 *task_rec, *task_info;
     int B, upto;
 };
 struct LptJobs {
     LptJob j[FR_FOCF_PREPARE_MAX];
-    const int32_t *Ulast, *Ilast;
     int cap;      // replay lengths are bounded by the sweep period
 };
 
+#ifdef FR_LPT_STAMPS   // diagnostic build only: phase time stamps of block 0 / thread 0
+__device__ unsigned long long g_lpt_stamps[8];
+#define LPT_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_lpt_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define LPT_STAMP(i) do {} while (0)
+#endif
+
+constexpr int LPT_SPLIT = 4;
+
+template <int PT>   // rounds of 1024 positions: B <= PT * 1024
 __global__ __launch_bounds__(1024) void focf_lpt_kernel(LptJobs jobs) {
-    const LptJob& J = jobs.j[blockIdx.x];
-    __shared__ int hist[256];
-    __shared__ int wsum[4];
-    constexpr int PT = FR_SORT_MAX / 1024;
-    const int tid = threadIdx.x;
-    if (tid < 256) hist[tid] = 0;
-    __syncthreads();
-    int key[PT];
+    // Stable partition into NC cost classes (class 0 = the longest replays) with ballots and prefix counts -- no atomics
+    // (a counting sort on LDS counters serialises the 64 lanes of every wave on the few hot cost classes).
+    // LPT_SPLIT workgroups per batch: each classifies and scans the whole batch (coalesced reads, cheap) and rewrites
+    // its share of the rounds (16-byte stores to scattered places, what a single CU is slow at).
+    const LptJob& J = jobs.j[blockIdx.x / LPT_SPLIT];
+    const int part = blockIdx.x % LPT_SPLIT;
+    constexpr int NC = 8, NW = 16, N = NC * PT * NW, EPT = (N + 1023) / 1024;
+    __shared__ int cnt[N];          // [class][round][wave], scanned in that order
+    __shared__ int wsum[NW];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned long long lt = (1ull << lane) - 1ull;
     const int cap = jobs.cap > 0 ? jobs.cap : 1024;
+    int cls[PT], rank[PT];
+    // every load of a phase is issued before the first one is waited for (clamped positions instead of branches: with a
+    // branch per round the compiler serialises the rounds' memory round trips); the rows' `last` stamps were gathered
+    // by the stamp workgroups of the sort launch (16K random misses from this one CU took 16 us)
+    int lu[PT], li[PT];
+    LPT_STAMP(0);
+#pragma unroll
+    for (int q = 0; q < PT; ++q) {
+        const int b = q * 1024 + tid, bc = b < J.B ? b : 0;
+        lu[q] = J.age_u[bc];
+        li[q] = J.age_i[bc];
+    }
+    LPT_STAMP(1);
 #pragma unroll
     for (int q = 0; q < PT; ++q) {
         const int b = q * 1024 + tid;
-        key[q] = -1;
+        int k = -1;
         if (b < J.B) {
-            const int4 r = J.rec[b];
-            int cu = J.upto - jobs.Ulast[r.x], ci = J.upto - jobs.Ilast[r.y];
+            int cu = J.upto - lu[q], ci = J.upto - li[q];
             cu = cu < 0 ? 0 : (cu > cap ? cap : cu);
             ci = ci < 0 ? 0 : (ci > cap ? cap : ci);
             const int hi = cu > ci ? cu : ci, lo = cu > ci ? ci : cu;
             const int cost = 7 * hi + 2 * lo;                          // VALU instructions: alone 7, as a pair 9 per step
-            const int k = 255 - min(255, cost * 255 / (9 * cap));      // class 0 = the longest
-            key[q] = k;
-            atomicAdd(&hist[k], 1);
+            k = NC - 1 - min(NC - 1, cost * NC / (9 * cap + 1));
+        }
+        cls[q] = k;
+        rank[q] = 0;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const unsigned long long m = __ballot(k == c);
+            if (k == c) rank[q] = __popcll(m & lt);
+            if (lane == 0) cnt[(c * PT + q) * NW + wave] = __popcll(m);
         }
     }
+    LPT_STAMP(2);
     __syncthreads();
-    if (tid < 256) {       // exclusive scan of the 256 class counts (4 waves)
-        const int x = hist[tid];
-        int inc = x;
+    {   // exclusive scan of the N counts, EPT consecutive ones per thread
+        int x[EPT], own = 0;
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            const int i = tid * EPT + e;
+            x[e] = i < N ? cnt[i] : 0;
+            own += x[e];
+        }
+        int inc = own;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
             const int y = __shfl_up(inc, o, 64);
-            if ((tid & 63) >= o) inc += y;
+            if (lane >= o) inc += y;
         }
-        if ((tid & 63) == 63) wsum[tid >> 6] = inc;
-        hist[tid] = inc - x;
-    }
-    __syncthreads();
-    if (tid < 256) {
-        int off = 0;
-        for (int w = 0; w < (tid >> 6); ++w) off += wsum[w];
-        hist[tid] += off;
-    }
-    __syncthreads();
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        int ex = inc - own;
+        for (int w = 0; w < wave; ++w) ex += wsum[w];
 #pragma unroll
-    for (int q = 0; q < PT; ++q) {
-        const int b = q * 1024 + tid;
-        if (key[q] >= 0) {
-            const int pos = atomicAdd(&hist[key[q]], 1);     // ties in arrival order: any order gives the same results
-            const int4 f = J.info[b];
-            J.task_rec[pos] = J.rec[b];
-            J.task_info[pos] = make_int4(f.x, f.z, f.y | (f.w << 16), b);
+        for (int e = 0; e < EPT; ++e) {
+            const int i = tid * EPT + e;
+            if (i < N) cnt[i] = ex;
+            ex += x[e];
         }
     }
+    __syncthreads();
+    LPT_STAMP(3);
+    constexpr int CH = (PT + LPT_SPLIT - 1) / LPT_SPLIT;   // rounds of this workgroup: part, part + LPT_SPLIT, ...
+    int4 f[CH], r[CH];
+#pragma unroll
+    for (int q = 0; q < CH; ++q) {
+        const int b = (q * LPT_SPLIT + part) * 1024 + tid, bc = b < J.B ? b : 0;
+        f[q] = J.info[bc];
+        r[q] = J.rec[bc];
+    }
+#pragma unroll
+    for (int q = 0; q < CH; ++q) {
+#pragma unroll
+        for (int pp = 0; pp < LPT_SPLIT; ++pp) {   // (static register indexing: the round is q * LPT_SPLIT + part)
+            const int qq = q * LPT_SPLIT + pp;
+            if (pp == part && qq < PT && cls[qq] >= 0) {
+                const int pos = cnt[(cls[qq] * PT + qq) * NW + wave] + rank[qq];
+                J.task_rec[pos] = r[q];
+                J.task_info[pos] = make_int4(f[q].x, f[q].z, f[q].y | (f[q].w << 16), qq * 1024 + tid);
+            }
+        }
+    }
+    LPT_STAMP(4);
 }
 
 static PrevLoss prev_of(void* ws, int64_t B, int dim, int objective, float fair_weight, float* loss_out, float* acc) {
@@ -823,6 +898,10 @@ extern "C" int fr_focf_prepare_step(const fr_focf_batch* batches, const int32_t*
         ju.stamp = U->stamp;
         ji.stamp = I->stamp;
         ju.stamp_val = ji.stamp_val = stamps[q];
+        ju.last = U->last;
+        ji.last = I->last;
+        ju.last_out = w.age_u;
+        ji.last_out = w.age_i;
         jobs.j[2 * q] = ju;
         jobs.j[2 * q + 1] = ji;
         jobs.M[2 * q] = jobs.M[2 * q + 1] = (int)b.B;
@@ -833,12 +912,18 @@ extern "C" int fr_focf_prepare_step(const fr_focf_batch* batches, const int32_t*
     LptJobs lj{};
     for (int q = 0; q < n; ++q) {
         const FocfWs w = focf_layout(batches[q].ws, batches[q].B, U->dim);
-        lj.j[q] = LptJob{w.rec, w.info, w.task_rec, w.task_info, (int)batches[q].B, stamps[q] - 1};
+        lj.j[q] = LptJob{w.age_u, w.age_i, w.rec, w.info, w.task_rec, w.task_info, (int)batches[q].B, stamps[q] - 1};
     }
-    lj.Ulast = U->last;
-    lj.Ilast = I->last;
     lj.cap = replay_cap;
-    hipLaunchKernelGGL(focf_lpt_kernel, dim3(n), dim3(1024), 0, (hipStream_t)stream_, lj);
+    int Bmax = 1;
+    for (int q = 0; q < n; ++q) Bmax = batches[q].B > Bmax ? (int)batches[q].B : Bmax;
+    hipStream_t st = (hipStream_t)stream_;
+    ProfScope prof(K_FOCF_LPT, st);
+    if (Bmax <= 1024) FR_LAUNCH(prof, focf_lpt_kernel<1>, dim3(n * LPT_SPLIT), dim3(1024), 0, st, lj);
+    else if (Bmax <= 2048) FR_LAUNCH(prof, focf_lpt_kernel<2>, dim3(n * LPT_SPLIT), dim3(1024), 0, st, lj);
+    else if (Bmax <= 4096) FR_LAUNCH(prof, focf_lpt_kernel<4>, dim3(n * LPT_SPLIT), dim3(1024), 0, st, lj);
+    else if (Bmax <= 8192) FR_LAUNCH(prof, focf_lpt_kernel<8>, dim3(n * LPT_SPLIT), dim3(1024), 0, st, lj);
+    else FR_LAUNCH(prof, focf_lpt_kernel<16>, dim3(n * LPT_SPLIT), dim3(1024), 0, st, lj);
     FR_CHECK_LAUNCH();
     return FR_OK;
 }
@@ -902,6 +987,14 @@ extern "C" int fr_focf_step(const fr_table* U, const fr_table* I, const fr_adam*
     FR_CHECK_LAUNCH();
     return FR_OK;
 }
+
+#ifdef FR_LPT_STAMPS
+extern "C" __attribute__((visibility("default"))) int fr_debug_lpt_stamps(unsigned long long* host_out) {
+    FR_CHECK_HIP(hipDeviceSynchronize());
+    FR_CHECK_HIP(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_lpt_stamps), sizeof(unsigned long long) * 8));
+    return FR_OK;
+}
+#endif
 
 #if FR_STEP_TRACE
 extern "C" __attribute__((visibility("default"))) int fr_debug_step_trace(unsigned long long* host_out, int n_waves) {

@@ -38,6 +38,7 @@ struct FocfWs {
     int4* task_rec;
     int4* task_info;
     unsigned int *cnt_u, *cnt_i;
+    int32_t *age_u, *age_i;   // [B] `last` stamp of each position's user / item row as of the prepare launch
     float* mse_e;        // [B]
     float* term;         // [B] indexed by item segment
     DeferLoss* defer;    // [1] written by the forward launch, consumed (and cleared) by the backward launch
@@ -86,6 +87,8 @@ __host__ __device__ inline FocfWs focf_layout(void* base, int64_t B, int D) {
     w.task_info = (int4*)take(Bp * 16);
     w.cnt_u = (unsigned int*)take(Bp * 4);
     w.cnt_i = (unsigned int*)take(Bp * 4);
+    w.age_u = (int32_t*)take(Bp * 4);
+    w.age_i = (int32_t*)take(Bp * 4);
     w.mse_e = (float*)take(Bp * 4);
     w.term = (float*)take(Bp * 4);
     w.defer = (DeferLoss*)take(sizeof(DeferLoss));

@@ -10,7 +10,7 @@ enum KernelKind {
     K_SORT = 0, K_FOCF_GATHER, K_FOCF_FAIR, K_FOCF_NONPARITY, K_FOCF_FINALIZE, K_FOCF_BWD_ADAM, K_TABLE_FLUSH,
     K_TABLE_GATHER, K_ADAM_DENSE, K_TABLE_GATHER_TRAIN, K_TABLE_APPLY_GRAD, K_BUCKET, K_UNBUCKET,
     K_BUCKET_ROWS, K_FOCF_SHARD_SCORE, K_FOCF_SHARD_GRADS, K_LINEAR_FWD,
-    K_LINEAR_BWD_INPUT, K_LINEAR_BWD_WEIGHT, K_NFCF_LOSS, K_BN_FWD, K_BN_BWD, K_ROWDOT, K_BPR, K_SPMM, K_ROW_GATHER, K_SAMPLE_NEG, K_FOCF_STEP, K_COUNT
+    K_LINEAR_BWD_INPUT, K_LINEAR_BWD_WEIGHT, K_NFCF_LOSS, K_BN_FWD, K_BN_BWD, K_ROWDOT, K_BPR, K_SPMM, K_ROW_GATHER, K_SAMPLE_NEG, K_FOCF_STEP, K_FOCF_LPT, K_COUNT
 };
 bool prof_on();
 // Takes an event pair from the profiler's pool and registers it for kernel `kind` (not recorded here: the pair
@@ -68,8 +68,10 @@ struct SortJob {
     int2* info;         // per position b: (first sorted position j0 of its segment | members n << 16, segment index), at
     int info_stride;    //   info[b * info_stride] (two lists can interleave their halves of one 16-byte record per b)
     unsigned int* cnt;  // [n_seg] arrival counters of the segments, zeroed here
-    int32_t* stamp;     // table stamps: stamp[row] = max(stamp[row], stamp_val) for every distinct row of the list, so
-    int stamp_val;      //   that the sweeper waves of the step's launch leave the rows of the batch alone
+    int32_t* stamp;     // table stamps: stamp[row] = max(stamp[row], stamp_val) for every row of the list, so that the
+    int stamp_val;      //   sweeper waves of the step's launch leave the rows of the batch alone ...
+    const int32_t* last;   // ... and, alongside, last_out[j] = last[row of position j]: how stale each row is now (the
+    int32_t* last_out;     //   launch order of the step is derived from it); both by extra workgroups of the sort launch
     // ... and one 16-byte record per position for its consumer: (row id of `rec_idx`, row id of this list, rec_f0, aux),
     // both ids range-checked and clamped like the sort keys; a -1 id counts as out of range here (no padding holes)
     int4* rec;

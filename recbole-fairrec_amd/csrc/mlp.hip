@@ -8,6 +8,8 @@
 //   linear_bwd_input  dX = ((dY o act'(Y)) W) o mask*scale
 //   linear_bwd_weight dW = (dY o act'(Y))^T (X o mask*scale)   (split over the batch, fixed-order reduction), db
 // Tiles: 256 threads = 4 waves, 64x64 output tile, each wave one 32x32 MFMA tile, 32-deep K chunks through LDS.
+#include <stdlib.h>
+
 #include <algorithm>
 
 #include "common.hpp"
@@ -117,6 +119,116 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(CatMat X, const unsigne
         __syncthreads();
     }
     store_tile(acc, wm, wn, lane, m0, n0, M, N, bias, act, Y);
+}
+
+
+// ---- forward, fast form ---------------------------------------------------------------------------------------------
+// The same product for the shapes the models use (K a multiple of 4 and both blocks of a concatenated input a multiple of
+// 4 wide), with the operand traffic cut to what the f32 matrix pipe (64 cycles per 32x32x2 MFMA) can be fed with:
+//   * a workgroup owns 64 rows x BN columns (BN = 128: every wave a 32 x 64 strip = two MFMA tiles that share their A
+//     fragment; BN = 64 when that would leave CUs without a workgroup), so X is read from HBM once per 128 columns;
+//   * 32-deep K chunks in LDS with the K index permuted so that the 16 values a lane feeds to the chunk's 16 MFMA steps
+//     (k = 2 i + lane / 32) are contiguous: four ds_read_b128 per fragment instead of sixteen ds_read_b32 (row stride
+//     36 floats: conflict-free for the 16 rows of a b128 lane group);
+//   * two LDS buffers: the global loads of chunk c + 1 are in flight while chunk c is multiplied, one barrier per chunk.
+template <int BN>
+__global__ __launch_bounds__(256) void linear_fwd_fast_kernel(CatMat X, const unsigned char* __restrict__ mask, float scale,
+                                                              const float* __restrict__ W, const float* __restrict__ bias,
+                                                              int M, int N, int K, int act, float* __restrict__ Y) {
+    constexpr int BM = 64, CK = 32, LD = 36, JT = BN / 64;      // JT MFMA tiles per wave along N
+    constexpr int AQ = BM * CK / 4 / 256, BQ = BN * CK / 4 / 256;   // float4 loads per thread and chunk
+    __shared__ __align__(16) float As[2][BM * LD];
+    __shared__ __align__(16) float Bs[2][BN * LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    f32x16 acc[JT];
+#pragma unroll
+    for (int j = 0; j < JT; ++j) acc[j] = f32x16{0};
+    float4 aq[AQ], bq[BQ];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int q = 0; q < AQ; ++q) {
+            const int e = q * 256 + tid, r = e >> 3, c = (e & 7) * 4;       // 8 float4 per 32-wide row
+            const int m = m0 + r, k = k0 + c;
+            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m < M && k < K) {
+                x = k < X.ka ? *reinterpret_cast<const float4*>(X.a + (size_t)m * X.ka + k)
+                             : *reinterpret_cast<const float4*>(X.b + (size_t)m * X.kb + (k - X.ka));
+                if (mask) {
+                    const uchar4 mk = *reinterpret_cast<const uchar4*>(mask + (size_t)m * K + k);
+                    x.x = mk.x ? x.x * scale : 0.f; x.y = mk.y ? x.y * scale : 0.f;
+                    x.z = mk.z ? x.z * scale : 0.f; x.w = mk.w ? x.w * scale : 0.f;
+                }
+            }
+            aq[q] = x;
+        }
+#pragma unroll
+        for (int q = 0; q < BQ; ++q) {
+            const int e = q * 256 + tid, r = e >> 3, c = (e & 7) * 4;
+            const int n = n0 + r, k = k0 + c;
+            bq[q] = (n < N && k < K) ? *reinterpret_cast<const float4*>(W + (size_t)n * K + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    // k = c .. c + 3 of a row go to positions (c / 2, c / 2 + 1) of the even half and of the odd half
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < AQ; ++q) {
+            const int e = q * 256 + tid, r = e >> 3, c = (e & 7) * 4;
+            float* d = &As[buf][r * LD + (c >> 1)];
+            *reinterpret_cast<float2*>(d) = make_float2(aq[q].x, aq[q].z);
+            *reinterpret_cast<float2*>(d + 16) = make_float2(aq[q].y, aq[q].w);
+        }
+#pragma unroll
+        for (int q = 0; q < BQ; ++q) {
+            const int e = q * 256 + tid, r = e >> 3, c = (e & 7) * 4;
+            float* d = &Bs[buf][r * LD + (c >> 1)];
+            *reinterpret_cast<float2*>(d) = make_float2(bq[q].x, bq[q].z);
+            *reinterpret_cast<float2*>(d + 16) = make_float2(bq[q].y, bq[q].w);
+        }
+    };
+    fetch(0);
+    stage(0);
+    __syncthreads();
+    const int half = (lane >> 5) * 16, lr = lane & 31;
+    int buf = 0;
+    for (int k0 = 0; k0 < K; k0 += CK, buf ^= 1) {
+        const bool more = k0 + CK < K;
+        if (more) fetch(k0 + CK);
+        float4 af[4], bf[JT][4];
+        const float* ap = &As[buf][(wm * 32 + lr) * LD + half];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) af[v] = *reinterpret_cast<const float4*>(ap + 4 * v);
+#pragma unroll
+        for (int j = 0; j < JT; ++j) {
+            const float* bp = &Bs[buf][((wn * JT + j) * 32 + lr) * LD + half];
+#pragma unroll
+            for (int v = 0; v < 4; ++v) bf[j][v] = *reinterpret_cast<const float4*>(bp + 4 * v);
+        }
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const float a4[4] = {af[v].x, af[v].y, af[v].z, af[v].w};
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+#pragma unroll
+                for (int j = 0; j < JT; ++j) {
+                    const float b4[4] = {bf[j][v].x, bf[j][v].y, bf[j][v].z, bf[j][v].w};
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[s], b4[s], acc[j], 0, 0, 0);
+                }
+            }
+        }
+        if (more) stage(buf ^ 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < JT; ++j) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const int col = n0 + (wn * JT + j) * 32 + lr;
+            if (row < M && col < N) Y[(size_t)row * N + col] = act_fwd(acc[j][r] + (bias ? bias[col] : 0.f), act);
+        }
+    }
 }
 
 // dX[M,K] = ((dY o act'(Y)) W) o mask*scale
@@ -286,8 +398,22 @@ extern "C" int fr_linear_fwd(const float* x0, int32_t k0, const float* x1, int32
     const int K = k0 + k1;
     CatMat X{x0, x1, k0, k1};
     ProfScope prof(K_LINEAR_FWD, stream);
-    FR_LAUNCH(prof, linear_fwd_kernel, dim3((unsigned)((M + TM - 1) / TM), (unsigned)((N + TN - 1) / TN)), dim3(256), 0,
-              stream, X, mask, scale, W, bias, (int)M, (int)N, K, (int)act, Y);
+    const bool aligned = K % 4 == 0 && k0 % 4 == 0 && k1 % 4 == 0 && ((uintptr_t)x0 & 15) == 0 && ((uintptr_t)W & 15) == 0 &&
+                         (!x1 || ((uintptr_t)x1 & 15) == 0) && (!mask || ((uintptr_t)mask & 3) == 0);
+    static const bool slow_only = getenv("FAIRREC_LINEAR_SLOW") != nullptr;
+    if (aligned && !slow_only) {
+        const long long mb = (M + 63) / 64;
+        if (N > 64 && mb * ((N + 127) / 128) >= 256) {      // wide tiles once they still fill the chip
+            FR_LAUNCH(prof, linear_fwd_fast_kernel<128>, dim3((unsigned)mb, (unsigned)((N + 127) / 128)), dim3(256), 0, stream,
+                      X, mask, scale, W, bias, (int)M, (int)N, K, (int)act, Y);
+        } else {
+            FR_LAUNCH(prof, linear_fwd_fast_kernel<64>, dim3((unsigned)mb, (unsigned)((N + 63) / 64)), dim3(256), 0, stream, X,
+                      mask, scale, W, bias, (int)M, (int)N, K, (int)act, Y);
+        }
+    } else {
+        FR_LAUNCH(prof, linear_fwd_kernel, dim3((unsigned)((M + TM - 1) / TM), (unsigned)((N + TN - 1) / TN)), dim3(256), 0,
+                  stream, X, mask, scale, W, bias, (int)M, (int)N, K, (int)act, Y);
+    }
     FR_CHECK_LAUNCH();
     return FR_OK;
 }

@@ -68,33 +68,76 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_segments_kernel(SortJobList
     float* fscratch = reinterpret_cast<float*>(scratch + 32);                       // [32]
 
     SORT_STAMP(0);
-    const SortJob& job = jobs.j[blockIdx.x];
-    const int M = jobs.M[blockIdx.x];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
 
-    bool bad = false;
-    for (int j = tid; j < P; j += SORT_THREADS) {
-        unsigned long long k = ~0ull;
-        if (j < M) {
-            long long r = job.idx[job.lay.at(j)];
-            if (r == -1 && !job.rec) {
-                r = 0xFFFFFFFFll;   // padding slot ("hole"): sorts behind every real row, belongs to no segment
-            } else if (r < 0 || r >= job.n_rows) {
-                bad = true;
-                r = 0;
-            }
-            k = ((unsigned long long)r << 32) | (unsigned)j;
-            if (job.rec) {
-                long long o = job.rec_idx[j];
-                if (o < 0 || o >= job.rec_rows) {
-                    bad = true;
-                    o = 0;
+    if (blockIdx.x >= jobs.n) {
+        // Stamp workgroups (fused FOCF step only): stamp[row] = max(stamp[row], stamp_val) and last_out[j] = last[row]
+        // for every id of every list, 1024 ids per workgroup.  Random accesses that miss every cache: issued by ONE
+        // workgroup per list they took 17 us each (a CU has a bounded number of misses in flight); spread over M / 1024
+        // CUs they are not seen.
+        int x = blockIdx.x - jobs.n;
+        for (int q = 0; q < jobs.n; ++q) {
+            const int nb = jobs.j[q].stamp ? (jobs.M[q] + SORT_THREADS - 1) / SORT_THREADS : 0;
+            if (x < nb) {
+                const SortJob& sj = jobs.j[q];
+                const int j = x * SORT_THREADS + tid;
+                if (j < jobs.M[q]) {
+                    const long long r = sj.idx[sj.lay.at(j)];
+                    const bool ok = r >= 0 && r < sj.n_rows;   // a bad id is the sorter's to report
+                    if (ok) atomicMax(&sj.stamp[r], sj.stamp_val);
+                    if (sj.last_out) sj.last_out[j] = ok ? sj.last[r] : 0;
+                    if (sj.rec) {   // (id of the other list, own id, rec_f0, aux); ids clamped like the sort keys
+                        long long o = sj.rec_idx[j];
+                        if (o < 0 || o >= sj.rec_rows) o = 0;
+                        sj.rec[j] = make_int4((int)o, ok ? (int)r : 0, __float_as_int(sj.rec_f0[j]),
+                                              sj.aux ? __float_as_int(sj.aux[j]) : 0);
+                    }
                 }
-                job.rec[j] = make_int4((int)o, (int)r, __float_as_int(job.rec_f0[j]), job.aux ? __float_as_int(job.aux[j]) : 0);
+                return;
             }
+            x -= nb;
         }
-        keys[j] = k;
+        return;
+    }
+
+    const SortJob& job = jobs.j[blockIdx.x];
+    const int M = jobs.M[blockIdx.x];
+    bool bad = false;
+    float lo = INFINITY, hi = -INFINITY;
+    if (M > 0) {
+        // all the loads of the list in flight at once (positions clamped instead of branched around)
+        long long r_[KPT];
+        float ax_[KPT];
+#pragma unroll
+        for (int q = 0; q < KPT; ++q) {
+            const int j = q * SORT_THREADS + tid, jc = j < M ? j : M - 1;
+            r_[q] = job.idx[job.lay.at(jc)];
+            if (job.aux) ax_[q] = job.aux[jc];
+        }
+#pragma unroll
+        for (int q = 0; q < KPT; ++q) {
+            const int j = q * SORT_THREADS + tid;
+            unsigned long long k = ~0ull;
+            if (j < M) {
+                long long r = r_[q];
+                if (r == -1 && !job.rec) {
+                    r = 0xFFFFFFFFll;   // padding slot ("hole"): sorts behind every real row, belongs to no segment
+                } else if (r < 0 || r >= job.n_rows) {
+                    bad = true;
+                    r = 0;
+                }
+                k = ((unsigned long long)r << 32) | (unsigned)j;
+                if (job.aux) {
+                    lo = fminf(lo, ax_[q]);
+                    hi = fmaxf(hi, ax_[q]);
+                }
+            }
+            keys[j] = k;
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < KPT; ++q) keys[q * SORT_THREADS + tid] = ~0ull;
     }
     if (bad && err) atomicOr(err, FR_DEV_ERR_INDEX_RANGE);
     for (int j = tid; j < 16 * NB; j += SORT_THREADS) masks[j] = 0ull;
@@ -102,12 +145,6 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_segments_kernel(SortJobList
     // optional min/max of a float column (the sensitive attribute): the group of a row is its rank
     // among the values present in the batch (focf.py:77)
     if (job.aux) {
-        float lo = INFINITY, hi = -INFINITY;
-        for (int j = tid; j < M; j += SORT_THREADS) {
-            float a = job.aux[j];
-            lo = fminf(lo, a);
-            hi = fmaxf(hi, a);
-        }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             lo = fminf(lo, __shfl_xor(lo, o, 64));
@@ -120,13 +157,13 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_segments_kernel(SortJobList
     }
     __syncthreads();
     if (job.aux && tid == 0) {
-        float lo = fscratch[0], hi = fscratch[16];
+        float l2 = fscratch[0], h2 = fscratch[16];
         for (int w = 1; w < 16; ++w) {
-            lo = fminf(lo, fscratch[w]);
-            hi = fmaxf(hi, fscratch[16 + w]);
+            l2 = fminf(l2, fscratch[w]);
+            h2 = fmaxf(h2, fscratch[16 + w]);
         }
-        job.aux_minmax[0] = lo;
-        job.aux_minmax[1] = hi;
+        job.aux_minmax[0] = l2;
+        job.aux_minmax[1] = h2;
     }
 
     SORT_STAMP(1);
@@ -146,6 +183,8 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_segments_kernel(SortJobList
         for (int r = 0; r < KPT; ++r) {
             const int d = (int)(key[r] >> shift) & (NB - 1);
             // one LDS round trip per round: OR my lane bit in, then read the mask and the running count back
+            // (measured: taking the bit back with a second atomic and counting with a third, so that no round waits for
+            // the previous one, is not faster -- the phase is bound by the LDS atomics, not by their latency)
             __hip_atomic_fetch_or(&mymask[d], 1ull << lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             const unsigned long long peers = *(volatile unsigned long long*)&mymask[d];
             const int before = *(volatile int*)&myhist[d];   // same-digit keys of this wave's earlier rounds
@@ -262,11 +301,7 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_segments_kernel(SortJobList
 #pragma unroll
         for (int q = 0; q < KPT; ++q) {
             const int j = q * SORT_THREADS + tid;
-            if ((bal[q] >> lane) & 1ull) {
-                const int seg = wcnt[q * 16 + wid] + __popcll(bal[q] & lt_mask);
-                ss[seg] = j;
-                if (job.stamp) atomicMax(&job.stamp[(unsigned)(key[q] >> 32)], job.stamp_val);
-            }
+            if ((bal[q] >> lane) & 1ull) ss[wcnt[q * 16 + wid] + __popcll(bal[q] & lt_mask)] = j;
         }
         if (tid == 0) ss[total] = scratch[17];
         __syncthreads();
@@ -297,8 +332,11 @@ static int launch_sort_kpt(const SortJobList& jobs, int bits, uint32_t* err, hip
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
+    int n_stamp = 0;   // workgroups that only stamp table rows (see the kernel)
+    for (int q = 0; q < jobs.n; ++q)
+        if (jobs.j[q].stamp) n_stamp += (jobs.M[q] + SORT_THREADS - 1) / SORT_THREADS;
     ProfScope prof(K_SORT, stream);
-    FR_LAUNCH(prof, sort_segments_kernel<KPT>, dim3(jobs.n), dim3(SORT_THREADS), lds, stream, jobs, npass, err);
+    FR_LAUNCH(prof, sort_segments_kernel<KPT>, dim3(jobs.n + n_stamp), dim3(SORT_THREADS), lds, stream, jobs, npass, err);
     FR_CHECK_LAUNCH();
     return FR_OK;
 }

@@ -42,8 +42,8 @@ class FocfEngine:
 
     LOSS_SLOTS = 256
     GROUP = 8         # coming batches whose id columns are sorted in ONE launch (FR_FOCF_PREPARE_MAX)
-    LOW_WATER = 2     # ... launched when this few prepared batches are left, so its join is steps old when reached
-    N_WS = 12         # workspaces: the batch in flight + LOW_WATER + GROUP prepared ones + one spare
+    LOW_WATER = 4     # ... launched when this few prepared batches are left, so its join is steps old when reached
+    N_WS = 15         # workspaces: the batch in flight + the last one (its loss) + LOW_WATER + GROUP prepared + a spare
 
     def __init__(self, user_weight: torch.Tensor, item_weight: torch.Tensor, objective: str, fair_weight: float,
                  max_rating: float):
@@ -127,6 +127,8 @@ class FocfEngine:
             self._ws_next = 0
         main = torch.cuda.current_stream()
         busy = {self.ws_cur} | {v[0] for v in self._prep.values()}
+        if self._prev is not None:   # the last fused step's loss is reduced by the NEXT launch, from its workspace
+            busy |= {k for k, w in enumerate(self.ws) if w is self._prev[0]}
         arr = (_C.FrFocfBatch * len(batches))()
         stamps = (ctypes.c_int32 * len(batches))()
         group = {"done": torch.cuda.Event(), "joined": False}
@@ -412,7 +414,7 @@ class FOCF(FairRecommender):
         ie = eng.I.gather(eng.hyper, item, eng.err_flag)
         return (ue * ie).sum(-1), ue, ie
 
-    PREFETCH = 10     # batches a trainer may announce ahead (FocfEngine.LOW_WATER + GROUP)
+    PREFETCH = 12     # batches a trainer may announce ahead (FocfEngine.LOW_WATER + GROUP)
 
     def hint_next_batch(self, *interactions):
         """Optional trainer hook: the batches that will follow the next `calculate_loss`, in order (none at the epoch
