@@ -41,9 +41,10 @@ class FocfEngine:
     """Owns the two lazy-Adam tables, the per-batch workspace and the kernel launches of FOCF."""
 
     LOSS_SLOTS = 256
-    GROUP = 8         # coming batches whose id columns are sorted in ONE launch (FR_FOCF_PREPARE_MAX)
+    GROUP = 16        # coming batches prepared per fork of the side stream (FR_FOCF_PREPARE_MAX of them per launch)
+    PER_LAUNCH = 8    # FR_FOCF_PREPARE_MAX
     LOW_WATER = 4     # ... launched when this few prepared batches are left, so its join is steps old when reached
-    N_WS = 15         # workspaces: the batch in flight + the last one (its loss) + LOW_WATER + GROUP prepared + a spare
+    N_WS = 23         # workspaces: the batch in flight + the last one (its loss) + LOW_WATER + GROUP prepared + a spare
 
     def __init__(self, user_weight: torch.Tensor, item_weight: torch.Tensor, objective: str, fair_weight: float,
                  max_rating: float):
@@ -153,18 +154,25 @@ class FocfEngine:
         start = torch.cuda.Event()
         start.record(main)
         self._side.wait_event(start)
+        PL = self.PER_LAUNCH
         if full:
             self.U.ensure_state()
             self.I.ensure_state()
             tu, ti = self.U.c(), self.I.c()
-            rc = _C.lib().fr_focf_prepare_step(arr, stamps, len(batches), ctypes.byref(tu), ctypes.byref(ti),
-                                               self._sweep(batches[0][0].numel()), self.err_flag.data_ptr(),
-                                               self._side.cuda_stream)
-            _C.check(rc, "fr_focf_prepare_step")
+            for a in range(0, len(batches), PL):
+                n = min(PL, len(batches) - a)
+                rc = _C.lib().fr_focf_prepare_step(ctypes.cast(ctypes.addressof(arr) + a * ctypes.sizeof(_C.FrFocfBatch), ctypes.POINTER(_C.FrFocfBatch)),
+                                                   ctypes.cast(ctypes.addressof(stamps) + a * 4, ctypes.POINTER(ctypes.c_int32)), n, ctypes.byref(tu), ctypes.byref(ti),
+                                                   self._sweep(batches[0][0].numel()), self.err_flag.data_ptr(),
+                                                   self._side.cuda_stream)
+                _C.check(rc, "fr_focf_prepare_step")
         else:
-            rc = _C.lib().fr_focf_prepare_many(arr, len(batches), self.U.n_rows, self.I.n_rows, self.U.dim,
-                                               self.err_flag.data_ptr(), self._side.cuda_stream)
-            _C.check(rc, "fr_focf_prepare_many")
+            for a in range(0, len(batches), PL):
+                n = min(PL, len(batches) - a)
+                rc = _C.lib().fr_focf_prepare_many(ctypes.cast(ctypes.addressof(arr) + a * ctypes.sizeof(_C.FrFocfBatch), ctypes.POINTER(_C.FrFocfBatch)), n, self.U.n_rows,
+                                                   self.I.n_rows, self.U.dim, self.err_flag.data_ptr(),
+                                                   self._side.cuda_stream)
+                _C.check(rc, "fr_focf_prepare_many")
         group["done"].record(self._side)
         self._prep.update(entries)
 
@@ -414,7 +422,7 @@ class FOCF(FairRecommender):
         ie = eng.I.gather(eng.hyper, item, eng.err_flag)
         return (ue * ie).sum(-1), ue, ie
 
-    PREFETCH = 12     # batches a trainer may announce ahead (FocfEngine.LOW_WATER + GROUP)
+    PREFETCH = 20     # batches a trainer may announce ahead (FocfEngine.LOW_WATER + GROUP)
 
     def hint_next_batch(self, *interactions):
         """Optional trainer hook: the batches that will follow the next `calculate_loss`, in order (none at the epoch
