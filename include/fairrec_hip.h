@@ -371,6 +371,10 @@ FR_API size_t fr_linear_bwd_weight_workspace_bytes(int64_t M, int32_t N, int32_t
 FR_API int fr_linear_bwd_weight(const float* dY, const float* Y, int32_t act, const float* x0, int32_t k0,
                                 const float* x1, int32_t k1, const uint8_t* mask, float scale, int64_t M, int32_t N,
                                 float* dW, float* db, void* ws, size_t ws_bytes, void* stream);
+/* out[n] = dY o act'(Y), elementwise (n % 4 == 0, 16-byte aligned): the shared pre-pass of a layer's two backward
+ * products (the autograd of the activation in layers.py:68-72), after which both are called with act = 0 and take
+ * their fast form (LDS-DMA kernels: no dropout mask, act = 0, widths multiples of 32). */
+FR_API int fr_act_bwd(const float* dY, const float* Y, int32_t act, int64_t n, float* out, void* stream);
 
 /* BatchNorm1d on batch statistics between Linear and activation (MLPLayers(bn=True), layers.py:66-67; the PFCN filters
  * and discriminators, which the reference never puts in eval mode).  Z [M,N] -> Y = act(gamma * xhat + beta);

@@ -162,7 +162,7 @@ class Model:
         for s in sst_list:
             y = self.dis[s](ue, masks[s] if masks else None)
             if self.sst_size[s] == 2:
-                total = total + F.binary_cross_entropy(torch.sigmoid(y), labels[s].float().unsqueeze(1))
+                total = total + F.binary_cross_entropy(torch.sigmoid(y), labels[s].to(y.dtype).unsqueeze(1))
             else:
                 total = total + F.cross_entropy(y, labels[s].long())
         return total
@@ -211,7 +211,7 @@ def train(z) -> Dict[str, np.ndarray]:
         sl = [s for s in str(z["sst_lists"][t]).split(",") if s] if m.mode != "none" else None
         masks = None
         if m.mode != "none":
-            masks = {s: [torch.tensor(z[f"mask.{s}.{t}.{l}"]).float() for l in range(n_dis_layers)] for s in sl}
+            masks = {s: [torch.tensor(z[f"mask.{s}.{t}.{l}"]).to(m.U.dtype) for l in range(n_dis_layers)] for s in sl}
         opt = opt_f if ph == "F" else opt_d
         opt.zero_grad()
         l = m.loss(u, pi, ni, sl, labels, masks) if ph == "F" else m.dis_loss(u, sl, labels, masks)

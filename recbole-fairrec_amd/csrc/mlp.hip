@@ -14,6 +14,7 @@
 
 #include "common.hpp"
 #include "kernels.hpp"
+#include "mlp_glds.hpp"
 
 namespace fr {
 
@@ -401,6 +402,11 @@ extern "C" int fr_linear_fwd(const float* x0, int32_t k0, const float* x1, int32
     const bool aligned = K % 4 == 0 && k0 % 4 == 0 && k1 % 4 == 0 && ((uintptr_t)x0 & 15) == 0 && ((uintptr_t)W & 15) == 0 &&
                          (!x1 || ((uintptr_t)x1 & 15) == 0) && (!mask || ((uintptr_t)mask & 3) == 0);
     static const bool slow_only = getenv("FAIRREC_LINEAR_SLOW") != nullptr;
+    static const bool no_glds = getenv("FAIRREC_LINEAR_NO_GLDS") != nullptr;
+    if (aligned && !slow_only && !no_glds && !mask && K % 32 == 0 && k0 % 32 == 0 && N >= 8) {
+        // LDS-DMA kernels (mlp_glds.hip): no dropout mask, 32-element reduction chunks
+        return glds_linear_fwd(GlMat{x0, x1, k0, k1, k0}, W, bias, M, (int)N, K, (int)act, Y, stream);
+    }
     if (aligned && !slow_only) {
         const long long mb = (M + 63) / 64;
         if (N > 64 && mb * ((N + 127) / 128) >= 256) {      // wide tiles once they still fill the chip
@@ -426,6 +432,10 @@ extern "C" int fr_linear_bwd_input(const float* dY, const float* Y, int32_t act,
                  "fr_linear_bwd_input: bad argument");
     const int K = k0 + k1;
     CatOut dX{dx0, dx1, k0, k1};
+    static const bool no_glds = getenv("FAIRREC_LINEAR_NO_GLDS") != nullptr || getenv("FAIRREC_LINEAR_SLOW") != nullptr;
+    if (!no_glds && !mask && act == ACT_NONE && N % 32 == 0 && K % 32 == 0 && k0 % 32 == 0 && ((uintptr_t)dY & 15) == 0 &&
+        ((uintptr_t)W & 15) == 0)
+        return glds_linear_bwd_input(dY, W, M, (int)N, K, dx0, k0, dx1, k1, stream);
     ProfScope prof(K_LINEAR_BWD_INPUT, stream);
     FR_LAUNCH(prof, linear_bwd_input_kernel, dim3((unsigned)((M + TM - 1) / TM), (unsigned)((K + TN - 1) / TN)), dim3(256),
               0, stream, dY, Y, (int)act, W, mask, scale, (int)M, (int)N, K, dX);
@@ -460,7 +470,13 @@ extern "C" int fr_linear_bwd_weight(const float* dY, const float* Y, int32_t act
     CatMat X{x0, x1, k0, k1};
     float* slab = (float*)ws;
     float* bslab = db ? slab + (size_t)splits * N * K : nullptr;
-    {
+    static const bool no_glds = getenv("FAIRREC_LINEAR_NO_GLDS") != nullptr || getenv("FAIRREC_LINEAR_SLOW") != nullptr;
+    if (!no_glds && !mask && act == ACT_NONE && N % 32 == 0 && K % 32 == 0 && k0 % 32 == 0 && ((uintptr_t)dY & 15) == 0 &&
+        ((uintptr_t)x0 & 15) == 0 && (!x1 || ((uintptr_t)x1 & 15) == 0)) {
+        int rc = glds_linear_bwd_weight(dY, GlMat{x0, x1, k0, k1, k0}, M, (int)N, K, (int)splits, rows_per_split, slab, bslab,
+                                        stream);
+        if (rc) return rc;
+    } else {
         ProfScope prof(K_LINEAR_BWD_WEIGHT, stream);
         FR_LAUNCH(prof, linear_bwd_weight_kernel,
                   dim3((unsigned)((N + TM - 1) / TM), (unsigned)((K + TN - 1) / TN), (unsigned)splits), dim3(256), 0, stream,
@@ -472,6 +488,14 @@ extern "C" int fr_linear_bwd_weight(const float* dY, const float* Y, int32_t act
                        (const float*)bslab, (int)splits, n, db ? (int)N : 0, dW, db);
     FR_CHECK_LAUNCH();
     return FR_OK;
+}
+
+// out = dY o act'(Y): lets the two backward products of a layer without BatchNorm take their fast form (which does not
+// differentiate the activation itself) on one shared pre-pass
+extern "C" int fr_act_bwd(const float* dY, const float* Y, int32_t act, int64_t n, float* out, void* stream_) {
+    FR_CHECK_ARG(dY && Y && out && n >= 1 && n % 4 == 0 && act_ok(act), "fr_act_bwd: bad argument (n must be a multiple of 4)");
+    FR_CHECK_ARG((((uintptr_t)dY | (uintptr_t)Y | (uintptr_t)out) & 15) == 0, "fr_act_bwd: 16-byte alignment required");
+    return launch_act_bwd(dY, Y, (int)act, (long long)n, out, (hipStream_t)stream_);
 }
 
 // ---- BatchNorm1d on batch statistics (training mode) --------------------------------------------------------------

@@ -1,0 +1,405 @@
+// Dense layers, fast form: fp32 MFMA GEMMs whose operands go global -> LDS by LDS-DMA (global_load_lds_dwordx4) in
+// full 128-byte lines and LDS -> registers as MFMA fragments, one wave per 32 x 32 output tile and no workgroup
+// barrier in the main loop.  Same products as mlp.hip (which keeps the general kernels: dropout masks, widths that are
+// not multiples of 32, activations differentiated inside the backward kernels):
+//   GL_FWD     Y[M,N]  = act(X[M,K] W[N,K]^T + b)           reduction over K
+//   GL_BWD_IN  dX[M,K] = dY[M,N] W[N,K]                     reduction over N
+//   GL_BWD_W   slab[s][N,K] = dY[rows of s, N]^T X[rows of s, K], bslab[s][N] = column sums of dY    reduction over M
+// (layers.py:56-85 and its autograd; nfcf.py:40, pfcn_biasedmf.py:113-142.)
+//
+// Why this shape.  v_mfma_f32_32x32x2_f32 takes 64 cycles; measured (scratch/mfma_peak.hip) one wave per SIMD reaches
+// 69 % of the 157 TFLOP/s peak with two accumulators, two waves per SIMD 83 %, four 94 %: a [8192, 256] -> 128 layer
+// has only 1024 tiles of 32 x 32, so the tiles' reductions are split between waves until every SIMD has two.  What
+// bounded the earlier kernels was operand delivery: fragment-shaped global loads (32 rows x 32 bytes per instruction)
+// cost four times the L1 tag look-ups of full lines, and LDS staging through registers costs a ds_write pass.  Here
+// a stage instruction moves 8 rows x 128 bytes straight into a wave-private, XOR-swizzled LDS image; a fragment is
+// one ds_read_b128 (4 consecutive reduction elements of a row: the reduction index is permuted consistently on both
+// operands) or, for an operand whose reduction index runs along its rows, 4 ds_read_b32 (conflict-free).
+// The LDS reads are inline asm: next to an LDS-DMA in flight the compiler waits vmcnt(0) before any LDS read it
+// can see, which would drain the prefetch every chunk.
+#include "common.hpp"
+#include "kernels.hpp"
+#include "mlp_glds.hpp"
+
+namespace fr {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f4 = __attribute__((ext_vector_type(4))) float;
+typedef __attribute__((address_space(3))) void* lds_vp;
+typedef const __attribute__((address_space(1))) void* glb_vp;
+
+constexpr int GL_WAVES = 8, GL_NBUF = 2, GL_STAGE_FLOATS = 2048;   // per wave and stage: A block + B block, 32 x 32 floats each
+
+// the 128-byte piece [col0, col0 + 32) of row `row` of a matrix that may be two row-major blocks side by side
+__device__ __forceinline__ const float* gl_piece(const GlMat& m, long long row, int col0) {
+    return col0 < m.split ? m.a + row * m.lda + col0 : m.b + row * m.ldb + (col0 - m.split);
+}
+
+template <int MODE, bool KSPLIT>   // KSPLIT: several waves of the workgroup share a tile's reduction (g.ks > 1)
+__global__ __launch_bounds__(GL_WAVES * 64) void linear_glds_kernel(GlArgs g) {
+    extern __shared__ __align__(16) float lds[];   // [GL_WAVES][GL_NBUF][2][1024]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // known uniform: tile, part and trip counts in SGPRs
+    constexpr bool A_T = MODE == GL_BWD_W, B_T = MODE != GL_FWD;   // operand whose reduction index runs along its rows
+
+    // ---- which tile, which part of the reduction ------------------------------------------------------------------
+    const int ntiles = g.tiles_i * g.tiles_j;
+    int tile, part;
+    if (MODE == GL_BWD_W) {
+        const long long id = (long long)blockIdx.x * GL_WAVES + wave;
+        tile = (int)(id % ntiles);
+        part = (int)(id / ntiles);
+    } else if (KSPLIT) {
+        const int tpb = GL_WAVES / g.ks;
+        tile = blockIdx.x * tpb + wave % tpb;
+        part = wave / tpb;
+    } else {
+        tile = blockIdx.x * GL_WAVES + wave;
+        part = 0;
+    }
+    const bool live = tile < ntiles && (MODE != GL_BWD_W || part < g.parts);
+    const int ti = live ? tile / g.tiles_j : 0, tj = live ? tile % g.tiles_j : 0;
+    const int i0 = ti * 32, j0 = tj * 32;
+    const int c0 = part * g.chunks_per_part;
+    int nchunk = 0;
+    if (live) {
+        const int total = (g.R + 31) / 32;
+        nchunk = total - c0 < g.chunks_per_part ? total - c0 : g.chunks_per_part;
+        if (nchunk < 0) nchunk = 0;
+    }
+
+    // ---- staging: instruction i of a block brings rows 8i .. 8i+7; lane l -> row 8i + l/8, LDS slot l % 8, and the
+    // 16-byte chunk it fetches is slot ^ ((row >> 1) & 7) (the image is lane-linear; the swizzle sits in the source) ----
+    float* my = lds + (size_t)wave * GL_NBUF * GL_STAGE_FLOATS;
+    const int srow = lane >> 3, sslot = lane & 7;
+    // Source pointers of the 4 + 4 stage instructions, kept running from chunk to chunk (a row-contiguous operand moves 32
+    // floats along its rows, a transposed one 32 rows down); computed in full -- row clamps, which of two side-by-side
+    // blocks -- only for a part's first chunk, where a row-contiguous operand crosses into its second block, and for
+    // the last (partial) chunk of a transposed operand.
+    const float *pa[4], *pb[4];
+    auto set_ptrs = [&](int chunk) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = 8 * i + srow, c = (sslot ^ ((row >> 1) & 7)) * 4;
+            if (A_T) {   // rows = reduction index, columns = the tile's output rows
+                long long rr = (long long)chunk * 32 + row;
+                rr = rr < g.R ? rr : g.R - 1;
+                pa[i] = gl_piece(g.A, rr, i0) + c;
+            } else {
+                long long rr = i0 + row;
+                rr = rr < g.rowsA ? rr : g.rowsA - 1;
+                pa[i] = gl_piece(g.A, rr, chunk * 32) + c;
+            }
+            if (B_T) {
+                long long rr = (long long)chunk * 32 + row;
+                rr = rr < g.R ? rr : g.R - 1;
+                pb[i] = gl_piece(g.B, rr, j0) + c;
+            } else {
+                long long rr = j0 + row;
+                rr = rr < g.rowsB ? rr : g.rowsB - 1;
+                pb[i] = gl_piece(g.B, rr, chunk * 32) + c;
+            }
+        }
+    };
+    const long long stepA = A_T ? 32ll * (i0 < g.A.split ? g.A.lda : g.A.ldb) : 32;
+    const long long stepB = B_T ? 32ll * (j0 < g.B.split ? g.B.lda : g.B.ldb) : 32;
+    auto stage = [&](int chunk, int buf) {
+        float* ab = my + buf * GL_STAGE_FLOATS;
+        float* bb = ab + 1024;
+        const bool fresh = chunk == c0 || (!A_T && chunk * 32 == g.A.split) || (!B_T && chunk * 32 == g.B.split) ||
+                           ((A_T || B_T) && (long long)chunk * 32 + 32 > g.R);
+        if (fresh) set_ptrs(chunk);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_global_load_lds((glb_vp)pa[i], (lds_vp)(ab + i * 256), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_vp)pb[i], (lds_vp)(bb + i * 256), 16, 0, 0);
+            pa[i] += stepA;
+            pb[i] += stepB;
+        }
+    };
+
+    // ---- fragment addresses ----------------------------------------------------------------------------------------
+    // MFMA step q = 4 j + e of a chunk multiplies reduction elements 8 j + 4 h + e (h = lane / 32)
+    const int r = lane & 31, h = lane >> 5;
+    const unsigned lbase = (unsigned)(size_t)(__attribute__((address_space(3))) float*)my;
+    unsigned rn[4];    // row-contiguous operand: row r, chunk slot 2 j + h
+#pragma unroll
+    for (int j = 0; j < 4; ++j) rn[j] = lbase + r * 128 + (((2 * j + h) ^ ((r >> 1) & 7)) << 4);
+    unsigned rt[16];   // transposed operand: row 8 j + 4 h + e, float r
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int row = 8 * (q >> 2) + 4 * h + (q & 3);
+        rt[q] = lbase + row * 128 + ((((r >> 2) ^ ((row >> 1) & 7)) << 4) | ((r & 3) << 2));
+    }
+
+    if (nchunk > 0) stage(c0, 0);
+    f32x16 acc0 = {0}, acc1 = {0};
+    float bsum = 0.f;
+    for (int t0 = 0; t0 < nchunk; t0 += GL_NBUF) {
+#pragma unroll
+        for (int buf = 0; buf < GL_NBUF; ++buf) {
+            const int t = t0 + buf;
+            if (t < nchunk) {
+                if (t + 1 < nchunk) {   // the next chunk into the buffer consumed one step ago, then wait for this one
+                    stage(c0 + t + 1, buf ^ 1);
+                    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                // (a fragment register must not be touched before the wait below: the compiler takes an asm output for
+                // available at once, so the vectors go through the wait whole and are taken apart after it)
+                f4 av[4], bv[4];
+                float at[16], bt[16];
+                if (!A_T) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(av[j]) : "v"(rn[j]), "n"(buf * 8192));
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 16; ++q)
+                        asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(at[q]) : "v"(rt[q]), "n"(buf * 8192));
+                }
+                if (!B_T) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bv[j]) : "v"(rn[j]), "n"(buf * 8192 + 4096));
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 16; ++q)
+                        asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(bt[q]) : "v"(rt[q]), "n"(buf * 8192 + 4096));
+                }
+                // the values exist after this wait (the operand lists tie the fragments to it)
+                if (!A_T) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(av[0]), "+v"(av[1]), "+v"(av[2]), "+v"(av[3]));
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)"
+                                 : "+v"(at[0]), "+v"(at[1]), "+v"(at[2]), "+v"(at[3]), "+v"(at[4]), "+v"(at[5]), "+v"(at[6]),
+                                   "+v"(at[7]), "+v"(at[8]), "+v"(at[9]), "+v"(at[10]), "+v"(at[11]), "+v"(at[12]), "+v"(at[13]),
+                                   "+v"(at[14]), "+v"(at[15]));
+                }
+                if (!B_T) {
+                    asm volatile("" : "+v"(bv[0]), "+v"(bv[1]), "+v"(bv[2]), "+v"(bv[3]));
+                } else {
+                    asm volatile(""
+                                 : "+v"(bt[0]), "+v"(bt[1]), "+v"(bt[2]), "+v"(bt[3]), "+v"(bt[4]), "+v"(bt[5]), "+v"(bt[6]),
+                                   "+v"(bt[7]), "+v"(bt[8]), "+v"(bt[9]), "+v"(bt[10]), "+v"(bt[11]), "+v"(bt[12]), "+v"(bt[13]),
+                                   "+v"(bt[14]), "+v"(bt[15]));
+                }
+                float a[16], b[16];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    a[q] = A_T ? at[q] : av[q >> 2][q & 3];
+                    b[q] = B_T ? bt[q] : bv[q >> 2][q & 3];
+                }
+                if (A_T) {   // the reduction runs over batch rows: the last chunk may reach past them
+                    const long long red0 = (long long)(c0 + t) * 32;
+                    if (red0 + 32 > g.R) {
+#pragma unroll
+                        for (int q = 0; q < 16; ++q)
+                            if (red0 + 8 * (q >> 2) + 4 * h + (q & 3) >= g.R) a[q] = 0.f;
+                    }
+                    if (g.bslab) {
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) bsum += a[q];
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 16; q += 2) {
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q], b[q], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q + 1], b[q + 1], acc1, 0, 0, 0);
+                }
+            }
+        }
+    }
+    f32x16 acc = acc0 + acc1;
+
+    if (MODE == GL_BWD_W) {
+        if (!live) return;
+        float* out = g.slab + (size_t)part * g.out_rows * g.out_cols;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int row = i0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            out[(size_t)row * g.out_cols + j0 + r] = acc[e];
+        }
+        if (g.bslab && tj == 0) {
+            bsum += __shfl_xor(bsum, 32, 64);
+            if (h == 0) g.bslab[(size_t)part * g.out_rows + i0 + r] = bsum;
+        }
+        return;
+    }
+
+    // ---- the parts of a tile's reduction meet in LDS (the staging buffers are free now) ----------------------------
+    if (KSPLIT) {
+        const int tpb = GL_WAVES / g.ks;
+        __syncthreads();
+        float* red = lds + (size_t)(wave % tpb) * 1024 * (g.ks - 1);
+        if (part > 0) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) red[(part - 1) * 1024 + e * 64 + lane] = acc[e];
+        }
+        __syncthreads();
+        if (part > 0) return;
+        for (int p = 0; p < g.ks - 1; ++p) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] += red[p * 1024 + e * 64 + lane];
+        }
+    }
+    if (!live) return;
+    const int col = j0 + r;
+    if (MODE == GL_FWD) {
+        // (a short reduction makes the epilogue a visible share of a wave's life: one uniform branch per wave, then
+        // straight-line code -- a switch per element cost 20 % of the kernel at K = 128)
+        if (col < g.out_cols) {
+            const float bias = g.bias ? g.bias[col] : 0.f;
+            float* yp = g.Y + (size_t)(i0 + 4 * h) * g.out_cols + col;
+            if (g.act <= 2) {   // none, relu, leakyrelu: the slope of the negative side
+                const float neg = g.act == 0 ? 1.f : (g.act == 1 ? 0.f : 0.01f);
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int ro = (e & 3) + 8 * (e >> 2);
+                    const float v = acc[e] + bias;
+                    if (i0 + 4 * h + ro < g.out_rows) yp[(size_t)ro * g.out_cols] = v > 0.f ? v : v * neg;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int ro = (e & 3) + 8 * (e >> 2);
+                    const float v = acc[e] + bias;
+                    if (i0 + 4 * h + ro < g.out_rows)
+                        yp[(size_t)ro * g.out_cols] = g.act == 3 ? 1.f / (1.f + __expf(-v)) : tanhf(v);
+                }
+            }
+        }
+    } else {   // GL_BWD_IN: the input gradient may be two blocks side by side
+        float* base = col < g.o_split ? g.o_a + col : g.o_b + (col - g.o_split);
+        const int ld = col < g.o_split ? g.o_lda : g.o_ldb;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int row = i0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            if (row < g.out_rows) base[(size_t)row * ld] = acc[e];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ dY, const float* __restrict__ Y, int act,
+                                                      long long n4, float* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const f4 d = reinterpret_cast<const f4*>(dY)[i], y = reinterpret_cast<const f4*>(Y)[i];
+    f4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float s;
+        switch (act) {
+            case 1: s = y[e] > 0.f ? 1.f : 0.f; break;
+            case 2: s = y[e] > 0.f ? 1.f : 0.01f; break;
+            case 3: s = y[e] * (1.f - y[e]); break;
+            case 4: s = 1.f - y[e] * y[e]; break;
+            default: s = 1.f;
+        }
+        o[e] = d[e] * s;
+    }
+    reinterpret_cast<f4*>(out)[i] = o;
+}
+
+template <int MODE, bool KSPLIT>
+static int launch_mode2(const GlArgs& g, long long blocks, hipStream_t stream, int kind) {
+    static bool attr_set = false;
+    const size_t ldsb = (size_t)GL_WAVES * GL_NBUF * GL_STAGE_FLOATS * sizeof(float);
+    if (!attr_set) {
+        FR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(linear_glds_kernel<MODE, KSPLIT>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
+        attr_set = true;
+    }
+    ProfScope prof((KernelKind)kind, stream);
+    FR_LAUNCH(prof, (linear_glds_kernel<MODE, KSPLIT>), dim3((unsigned)blocks), dim3(GL_WAVES * 64), ldsb, stream, g);
+    FR_CHECK_LAUNCH();
+    return FR_OK;
+}
+
+template <int MODE>
+static int launch_mode(const GlArgs& g, long long blocks, hipStream_t stream, int kind) {
+    return g.ks > 1 ? launch_mode2<MODE, true>(g, blocks, stream, kind) : launch_mode2<MODE, false>(g, blocks, stream, kind);
+}
+
+// reduction parts per tile so that the chip has about two waves per SIMD (2048), dividing the chunk count evenly
+static int pick_ks(long long ntiles, int chunks) {
+    int ks = 1;
+    while (ks < 4 && ntiles * ks < 2048 && chunks % (2 * ks) == 0 && chunks / (2 * ks) >= 2) ks *= 2;
+    return ks;
+}
+
+int glds_linear_fwd(const GlMat& X, const float* W, const float* bias, int64_t M, int N, int K, int act, float* Y,
+                    hipStream_t stream) {
+    GlArgs g{};
+    g.A = X;
+    g.B = GlMat{W, nullptr, K, 0, K};
+    g.rowsA = (int)M;
+    g.rowsB = N;
+    g.R = K;
+    g.tiles_i = (int)((M + 31) / 32);
+    g.tiles_j = (N + 31) / 32;
+    const long long ntiles = (long long)g.tiles_i * g.tiles_j;
+    g.ks = pick_ks(ntiles, K / 32);
+    g.chunks_per_part = K / 32 / g.ks;
+    g.bias = bias;
+    g.act = act;
+    g.Y = Y;
+    g.out_rows = (int)M;
+    g.out_cols = N;
+    const int tpb = GL_WAVES / g.ks;
+    return launch_mode<GL_FWD>(g, (ntiles + tpb - 1) / tpb, stream, K_LINEAR_FWD);
+}
+
+int glds_linear_bwd_input(const float* dY, const float* W, int64_t M, int N, int K, float* dx0, int k0, float* dx1, int k1,
+                          hipStream_t stream) {
+    GlArgs g{};
+    g.A = GlMat{dY, nullptr, N, 0, N};
+    g.B = GlMat{W, nullptr, K, 0, K};
+    g.rowsA = (int)M;
+    g.rowsB = N;
+    g.R = N;
+    g.tiles_i = (int)((M + 31) / 32);
+    g.tiles_j = K / 32;
+    const long long ntiles = (long long)g.tiles_i * g.tiles_j;
+    g.ks = pick_ks(ntiles, N / 32);
+    g.chunks_per_part = N / 32 / g.ks;
+    g.o_a = dx0;
+    g.o_b = dx1;
+    g.o_lda = k0;
+    g.o_ldb = k1;
+    g.o_split = k0;
+    g.out_rows = (int)M;
+    g.out_cols = K;
+    const int tpb = GL_WAVES / g.ks;
+    return launch_mode<GL_BWD_IN>(g, (ntiles + tpb - 1) / tpb, stream, K_LINEAR_BWD_INPUT);
+}
+
+int glds_linear_bwd_weight(const float* dY, const GlMat& X, int64_t M, int N, int K, int splits, int rows_per_split,
+                           float* slab, float* bslab, hipStream_t stream) {
+    GlArgs g{};
+    g.A = GlMat{dY, nullptr, N, 0, N};
+    g.B = X;
+    g.R = (int)M;
+    g.rowsA = g.rowsB = (int)M;
+    g.tiles_i = N / 32;
+    g.tiles_j = K / 32;
+    g.ks = 1;
+    g.parts = splits;
+    g.chunks_per_part = rows_per_split / 32;
+    g.slab = slab;
+    g.bslab = bslab;
+    g.out_rows = N;
+    g.out_cols = K;
+    const long long nw = (long long)g.tiles_i * g.tiles_j * splits;
+    return launch_mode<GL_BWD_W>(g, (nw + GL_WAVES - 1) / GL_WAVES, stream, K_LINEAR_BWD_WEIGHT);
+}
+
+int launch_act_bwd(const float* dY, const float* Y, int act, long long n, float* out, hipStream_t stream) {
+    const long long n4 = n / 4;
+    hipLaunchKernelGGL(act_bwd_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, dY, Y, act, n4, out);
+    FR_CHECK_LAUNCH();
+    return FR_OK;
+}
+
+}  // namespace fr

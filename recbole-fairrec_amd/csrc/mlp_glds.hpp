@@ -1,0 +1,47 @@
+// Fast dense-layer kernels (mlp_glds.hip): what mlp.hip's entry points call when a layer has the fast form.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace fr {
+
+enum { GL_FWD = 0, GL_BWD_IN = 1, GL_BWD_W = 2 };
+
+// a row-major matrix whose columns [0, split) live in `a` (leading dimension lda) and the rest in `b` (cat(U[u], I[i]))
+struct GlMat {
+    const float* a;
+    const float* b;
+    int lda, ldb, split;
+};
+
+struct GlArgs {
+    GlMat A, B;
+    int rowsA, rowsB;        // rows of a row-contiguous operand are clamped below these
+    int R;                   // reduction length
+    int tiles_i, tiles_j;    // 32 x 32 output tiles
+    int ks;                  // reduction parts per tile inside a workgroup (forward, input gradient)
+    int parts;               // ... or row splits, one slab each (weight gradient)
+    int chunks_per_part;     // 32-element reduction chunks per part
+    const float* bias;
+    int act;
+    float* Y;
+    int out_rows, out_cols;
+    float *o_a, *o_b;        // input gradient: columns [0, o_split) -> o_a, the rest -> o_b
+    int o_lda, o_ldb, o_split;
+    float *slab, *bslab;     // weight gradient
+};
+
+// Y = act(X W^T + b); needs K % 32 == 0, X.split % 32 == 0, 16-byte aligned rows
+int glds_linear_fwd(const GlMat& X, const float* W, const float* bias, int64_t M, int N, int K, int act, float* Y,
+                    hipStream_t stream);
+// dX = dY W; needs N % 32 == 0, K % 32 == 0, k0 % 32 == 0
+int glds_linear_bwd_input(const float* dY, const float* W, int64_t M, int N, int K, float* dx0, int k0, float* dx1, int k1,
+                          hipStream_t stream);
+// slab[s] = dY[rows of s]^T X[rows of s], bslab[s] = column sums of dY[rows of s] (bslab may be null); needs N % 32 == 0,
+// K % 32 == 0, X.split % 32 == 0, rows_per_split % 32 == 0
+int glds_linear_bwd_weight(const float* dY, const GlMat& X, int64_t M, int N, int K, int splits, int rows_per_split,
+                           float* slab, float* bslab, hipStream_t stream);
+// out = dY o act'(Y) elementwise (n % 4 == 0)
+int launch_act_bwd(const float* dY, const float* Y, int act, long long n, float* out, hipStream_t stream);
+
+}  // namespace fr

@@ -121,6 +121,7 @@ _PROTOS = {
     "fr_linear_bwd_input": (c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_float, c_int64, c_int32,
                                     c_void_p, c_int32, c_void_p, c_int32, c_void_p]),
     "fr_linear_bwd_weight_workspace_bytes": (c_size_t, [c_int64, c_int32, c_int32]),
+    "fr_act_bwd": (c_int, [c_void_p, c_void_p, c_int32, c_int64, c_void_p, c_void_p]),
     "fr_linear_bwd_weight": (c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_void_p,
                                      c_float, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "fr_nfcf_loss_workspace_bytes": (c_size_t, [c_int64]),

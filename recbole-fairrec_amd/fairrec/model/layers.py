@@ -117,6 +117,11 @@ class _HipMLP(torch.autograd.Function):
                                        ws.numel(), st), "fr_bn_bwd")
                 grads[per * l + 2], grads[per * l + 3] = dg, dbt
                 dY, Y, act = dZ, dZ, 0
+            elif act != 0 and mk is None and N % 32 == 0 and K % 32 == 0 and k0 % 32 == 0:
+                # one pass through the activation's derivative, shared by the two products (which then take their fast form)
+                dA = torch.empty_like(Y)
+                _C.check(lib.fr_act_bwd(dY.data_ptr(), Y.data_ptr(), act, M * N, dA.data_ptr(), st), "fr_act_bwd")
+                dY, Y, act = dA, dA, 0
             need = lib.fr_linear_bwd_weight_workspace_bytes(M, N, K)
             ws = torch.empty(need, dtype=torch.uint8, device=dev)
             dW = torch.empty_like(W)

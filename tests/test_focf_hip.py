@@ -316,6 +316,67 @@ def test_deferred_loss_with_interleaved_engines():
         torch.testing.assert_close(lb[:3], lr[:3], rtol=1e-6, atol=0)
 
 
+def test_two_host_threads_with_their_own_workspaces():
+    """The C ABI keeps no host-side state per call (the deferred-loss record lives in the workspace): two host threads,
+    each driving its own engine on its own stream, forced to interleave launch by launch, get what a serial run gets."""
+    import threading
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "focf_value.npz"))
+    T = 6
+    cols = [[torch.tensor(z[k][t], device="cuda") for k in ("user_id", "item_id", "rating", "sst")] for t in range(T)]
+
+    def run(eng, losses, gate=None):
+        st = torch.cuda.Stream()
+        st.wait_stream(torch.cuda.default_stream())
+        with torch.cuda.stream(st):
+            for t in range(T):
+                if gate is not None:
+                    gate.wait()          # both threads are between the same two launches
+                loss, _ = eng.forward(*cols[t])
+                if gate is not None:
+                    gate.wait()
+                eng.backward_adam()
+                losses.append(loss)
+            eng.finish()
+            eng.flush()
+        st.synchronize()
+
+    results = {}
+    for mode in ("serial", "threads"):
+        engs = [_engine(z, 3), _engine(z, 3)]
+        engs[1].fused_step = False       # one engine per launch shape: one-launch step, three-launch chain
+        for e in engs:
+            e.defer_loss = True
+        torch.cuda.synchronize()
+        out = [[], []]
+        if mode == "serial":
+            for e, o in zip(engs, out):
+                run(e, o)
+        else:
+            gate = threading.Barrier(2)
+            errs = []
+
+            def guarded(e, o):
+                try:
+                    run(e, o, gate)
+                except Exception as ex:   # a failing thread must not leave the other one at the barrier
+                    errs.append(ex)
+                    gate.abort()
+
+            th = [threading.Thread(target=guarded, args=(e, o)) for e, o in zip(engs, out)]
+            for t_ in th:
+                t_.start()
+            for t_ in th:
+                t_.join()
+            assert not errs, errs
+        torch.cuda.synchronize()
+        results[mode] = [(e.U.weight.clone(), e.I.weight.clone(), float(e.loss_acc[0])) for e in engs]
+    for k in range(2):
+        torch.testing.assert_close(results["threads"][k][0], results["serial"][k][0], rtol=0, atol=0)
+        torch.testing.assert_close(results["threads"][k][1], results["serial"][k][1], rtol=0, atol=0)
+    assert results["threads"][0][2] == results["serial"][0][2]
+    np.testing.assert_allclose(results["serial"][0][2], float(np.sum(z["loss"][:T], dtype=np.float64)), rtol=1e-4)
+
+
 def test_device_error_flags():
     z = np.load(os.path.join(os.path.dirname(__file__), "golden", "focf_value.npz"))
     eng = _engine(z, 0)

@@ -8,7 +8,8 @@ import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
-CASES = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "pfcn_*.npz")))
+CASES = sorted(p for p in glob.glob(os.path.join(os.path.dirname(__file__), "golden", "pfcn_*.npz"))
+               if not p.endswith("_f64.npz"))   # <case>_f64.npz: the case's float64 companion (gen_pfcn_exact64.py)
 
 
 class _DS:
@@ -35,10 +36,11 @@ def _load_mlp(mlp, z, prefix):
 def test_pfcn_training_matches_reference_golden(path, sharded, request):
     if sharded:     # the row-sharded engine as a 1-rank RCCL world: same goldens (fairrec/sharded_engine.py)
         request.getfixturevalue("rccl_world1")
-    _run_case(np.load(path), sharded)
+    f64 = path[:-4] + "_f64.npz"
+    _run_case(np.load(path), sharded, exact=np.load(f64) if os.path.exists(f64) else None)
 
 
-def _run_case(z, sharded=False, noise=None):
+def _run_case(z, sharded=False, noise=None, exact=None):
     """One recorded PFCN run (a golden .npz or a dict of the same layout) through the plugin surface on the GPU.
     noise: optional {key: absolute self-noise of the reference arithmetic on THIS case} (measured by running the CPU
     restatement with another reduction order), added to the tolerances."""
@@ -133,7 +135,19 @@ def _run_case(z, sharded=False, noise=None):
             return
         floor = FLOOR.get(kind, 1e-6 * max(1.0, float(np.abs(ref).max())))      # tables: 1e-6 of the tensor's scale
         floor = floor + noise.get(what, 0.0)
-        ratio = np.abs(a - ref) / (1e-4 * np.abs(ref) + floor)
+        # An element must lie between the reference's fp32 execution (the golden) and its float64 execution of the same
+        # steps (tests/golden/gen_pfcn_exact64.py), give or take the tolerance: the HIP GEMMs are closer to exact than
+        # torch's CPU sgemm (scratch/linear_acc.py), and on the few dozen Linear-weight elements whose gradient nearly
+        # cancels the reference's own rounding has carried ITS fp32 run up to 9e-5 from its float64 run
+        # (tests/golden/noise_floor.py) -- exactly the elements and the distance at which this path differs from the golden.
+        ref64 = exact["final." + what] if exact is not None and ("final." + what) in exact.files else None
+        if ref64 is None:
+            dist = np.abs(a - ref)
+        else:
+            ref64 = ref64.astype(np.float64)
+            lo, hi = np.minimum(ref, ref64), np.maximum(ref, ref64)
+            dist = np.maximum(np.maximum(lo - a, a - hi), 0.0)
+        ratio = dist / (1e-4 * np.abs(ref) + floor)
         if noise and kind != "table" and ratio.max() > 1.0:
             # Self-noise runs only (synthetic full-batch cases): an element whose gradient cancels to rounding noise takes
             # Adam steps of +-lr by the SIGN of that noise (the first step is lr * g / |g|) -- in the reference as well, on
@@ -143,7 +157,8 @@ def _run_case(z, sharded=False, noise=None):
                 (what, kind, float(out.mean()), float(np.abs(a - ref).max()))
             ratio = np.where(out, 0.0, ratio)
         worst[kind] = max(worst.get(kind, 0.0), float(ratio.max()))
-        assert ratio.max() <= 1.0, (what, kind, float(np.abs(a - ref).max()), float(ratio.max()))
+        assert ratio.max() <= 1.0, (what, kind, float(np.abs(a - ref).max()), float(ratio.max()), int((ratio > 1.0).sum()),
+                                    ratio.size)
 
     for k, v in sd.items():
         close(v, z["final.model." + k], "model." + k, kind=None if ".mlp_layers." in k else "table")
