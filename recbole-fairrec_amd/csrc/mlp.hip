@@ -502,17 +502,19 @@ extern "C" int fr_act_bwd(const float* dY, const float* Y, int32_t act, int64_t 
 // Replaces nn.BatchNorm1d inside MLPLayers(bn=True) (layers.py:66-67; PFCN filters / discriminators, which the
 // reference never switches to eval mode -- SURVEY.md App. B-3).  The batch is cut into row chunks so that a
 // [8192, 256] activation fills the chip: grid = (column blocks of 64) x (row chunks).  A "stats" launch leaves one
-// partial per (chunk, column); the "apply" launch folds the partials in chunk order (fixed order => reproducible)
-// and writes its chunk.  Forward partials are (mean, M2) pairs folded with Chan's formula, so the variance is the
+// partial per (chunk, column); a one-workgroup-per-64-columns "fold" launch combines the partials in chunk order (fixed
+// order => reproducible) into the column statistics; the "apply" launch writes its chunk.  (Folding inside every apply
+// workgroup, and 128-row chunks -- 0.5 wave per SIMD, eight dependent batches of loads per wave -- made the two apply
+// kernels 24 and 22 us at [8192, 128], eight times their memory time.)  Forward partials are (mean, M2) pairs folded with Chan's formula, so the variance is the
 // two-pass one (no E[x^2]-E[x]^2 cancellation).
 namespace fr {
 
 constexpr int BN_THREADS = 256;     // 4 waves: lane = column, waves stride over the rows of the chunk
 constexpr int BN_WAVES = BN_THREADS / 64;
 
-static inline int bn_chunk_rows(int64_t M) {       // >= 128 rows per chunk, <= 256 chunks
-    long long rc = 128;
-    while ((M + rc - 1) / rc > 256) rc *= 2;
+static inline int bn_chunk_rows(int64_t M) {       // >= 32 rows per chunk (8 per wave: two batches of loads), <= 1024 chunks
+    long long rc = 32;
+    while ((M + rc - 1) / rc > 1024) rc *= 2;
     return (int)rc;
 }
 
@@ -536,13 +538,13 @@ __global__ __launch_bounds__(BN_THREADS) void bn_fwd_stats_kernel(const float* _
     const bool ok = n < N;
     float s = 0.f;
     if (ok) {
-#pragma unroll 4
+#pragma unroll 8
         for (int m = m0 + wave; m < m1; m += BN_WAVES) s += Z[(size_t)m * N + n];
     }
     const float mean = col_reduce(s, red, wave, lane) / (float)(m1 - m0);
     float q = 0.f;
     if (ok) {
-#pragma unroll 4
+#pragma unroll 8
         for (int m = m0 + wave; m < m1; m += BN_WAVES) {
             const float d = Z[(size_t)m * N + n] - mean;
             q = fmaf(d, d, q);
@@ -557,41 +559,69 @@ __global__ __launch_bounds__(BN_THREADS) void bn_fwd_stats_kernel(const float* _
 
 // Y = act(gamma * (Z - mean) / sqrt(var + eps) + beta); xhat and invstd are kept for the backward;
 // running_mean / running_var follow torch (momentum, unbiased variance).
-__global__ __launch_bounds__(BN_THREADS) void bn_fwd_apply_kernel(const float* __restrict__ Z, const float* __restrict__ part,
-                                                                  const float* __restrict__ gamma,
-                                                                  const float* __restrict__ beta, float eps, float momentum,
-                                                                  float* __restrict__ rmean, float* __restrict__ rvar, int M,
-                                                                  int N, int rc, int act, float* __restrict__ Y,
-                                                                  float* __restrict__ xhat, float* __restrict__ invstd_out) {
+// fin[2n], fin[2n+1] = mean and 1/sqrt(var + eps) of column n; running statistics and invstd_out updated here.
+// Four waves fold a quarter of the chunks each (Chan et al. pairwise update, ascending), wave 0 combines the four
+// quarters in order: a fixed tree, a quarter of the dependent chain.
+__global__ __launch_bounds__(BN_THREADS) void bn_fwd_fold_kernel(const float* __restrict__ part, int chunks, int M, int N, int rc,
+                                                                 float eps, float momentum, float* __restrict__ rmean,
+                                                                 float* __restrict__ rvar, float* __restrict__ fin,
+                                                                 float* __restrict__ invstd_out) {
+    __shared__ float sh[BN_WAVES][3][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n = blockIdx.x * 64 + lane;
-    if (n >= N) return;
-    const int chunks = gridDim.y;
-    float cnt = 0.f, mean = 0.f, m2 = 0.f;          // Chan et al. pairwise update, chunks in ascending order
-    for (int c = 0; c < chunks; ++c) {
-        const float nb = (float)(min(M, (c + 1) * rc) - c * rc);
-        const float mb = part[((size_t)c * N + n) * 2], qb = part[((size_t)c * N + n) * 2 + 1];
-        const float tot = cnt + nb, delta = mb - mean;
-        mean += delta * (nb / tot);
-        m2 += qb + delta * delta * (cnt * nb / tot);
-        cnt = tot;
+    const int q = (chunks + BN_WAVES - 1) / BN_WAVES, c0 = wave * q, c1 = min(chunks, c0 + q);
+    float cnt = 0.f, mean = 0.f, m2 = 0.f;
+    if (n < N) {
+#pragma unroll 8
+        for (int c = c0; c < c1; ++c) {
+            const float nb = (float)(min(M, (c + 1) * rc) - c * rc);
+            const float2 p = reinterpret_cast<const float2*>(part)[(size_t)c * N + n];
+            const float tot = cnt + nb, delta = p.x - mean;
+            mean += delta * (nb / tot);
+            m2 += p.y + delta * delta * (cnt * nb / tot);
+            cnt = tot;
+        }
+    }
+    sh[wave][0][lane] = cnt;
+    sh[wave][1][lane] = mean;
+    sh[wave][2][lane] = m2;
+    __syncthreads();
+    if (wave != 0 || n >= N) return;
+    for (int w = 1; w < BN_WAVES; ++w) {
+        const float nb = sh[w][0][lane], mb = sh[w][1][lane], qb = sh[w][2][lane];
+        if (nb > 0.f) {
+            const float tot = cnt + nb, delta = mb - mean;
+            mean += delta * (nb / tot);
+            m2 += qb + delta * delta * (cnt * nb / tot);
+            cnt = tot;
+        }
     }
     const float var = m2 / (float)M;
     const float invstd = 1.f / sqrtf(var + eps);
+    fin[2 * n] = mean;
+    fin[2 * n + 1] = invstd;
+    invstd_out[n] = invstd;
+    if (rmean) {
+        rmean[n] = (1.f - momentum) * rmean[n] + momentum * mean;
+        rvar[n] = (1.f - momentum) * rvar[n] + momentum * (M > 1 ? m2 / (float)(M - 1) : var);
+    }
+}
+
+__global__ __launch_bounds__(BN_THREADS) void bn_fwd_apply_kernel(const float* __restrict__ Z, const float* __restrict__ fin,
+                                                                  const float* __restrict__ gamma,
+                                                                  const float* __restrict__ beta, int M, int N, int rc,
+                                                                  int act, float* __restrict__ Y, float* __restrict__ xhat) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + lane;
+    if (n >= N) return;
+    const float mean = fin[2 * n], invstd = fin[2 * n + 1];
     const float g = gamma[n], b = beta[n];
     const int m0 = blockIdx.y * rc, m1 = min(M, m0 + rc);
-#pragma unroll 4
+#pragma unroll 8
     for (int m = m0 + wave; m < m1; m += BN_WAVES) {
         const float xh = (Z[(size_t)m * N + n] - mean) * invstd;
         xhat[(size_t)m * N + n] = xh;
         Y[(size_t)m * N + n] = act_fwd(fmaf(g, xh, b), act);
-    }
-    if (blockIdx.y == 0 && wave == 0) {
-        invstd_out[n] = invstd;
-        if (rmean) {
-            rmean[n] = (1.f - momentum) * rmean[n] + momentum * mean;
-            rvar[n] = (1.f - momentum) * rvar[n] + momentum * (M > 1 ? m2 / (float)(M - 1) : var);
-        }
     }
 }
 
@@ -606,7 +636,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_stats_kernel(const float* _
     const bool ok = n < N;
     float s1 = 0.f, s2 = 0.f;
     if (ok) {
-#pragma unroll 4
+#pragma unroll 8
         for (int m = m0 + wave; m < m1; m += BN_WAVES) {
             const size_t i = (size_t)m * N + n;
             const float da = dY[i] * act_bwd(Y[i], act);
@@ -622,35 +652,57 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_stats_kernel(const float* _
     }
 }
 
-// dZ = invstd * gamma * (dA - mean(dA) - xhat * mean(dA * xhat));  dgamma = sum dA*xhat, dbeta = sum dA
+// fin[2n], fin[2n+1] = sum dA, sum dA * xhat of column n = dbeta, dgamma (four waves sum a quarter of the chunks each in
+// ascending order, wave 0 adds the quarters in order)
+__global__ __launch_bounds__(BN_THREADS) void bn_bwd_fold_kernel(const float* __restrict__ part, int chunks, int N,
+                                                                 float* __restrict__ fin, float* __restrict__ dgamma,
+                                                                 float* __restrict__ dbeta) {
+    __shared__ float sh[BN_WAVES][2][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + lane;
+    const int q = (chunks + BN_WAVES - 1) / BN_WAVES, c0 = wave * q, c1 = min(chunks, c0 + q);
+    float sum_da = 0.f, sum_dax = 0.f;
+    if (n < N) {
+#pragma unroll 8
+        for (int c = c0; c < c1; ++c) {
+            const float2 p = reinterpret_cast<const float2*>(part)[(size_t)c * N + n];
+            sum_da += p.x;
+            sum_dax += p.y;
+        }
+    }
+    sh[wave][0][lane] = sum_da;
+    sh[wave][1][lane] = sum_dax;
+    __syncthreads();
+    if (wave != 0 || n >= N) return;
+    for (int w = 1; w < BN_WAVES; ++w) {
+        sum_da += sh[w][0][lane];
+        sum_dax += sh[w][1][lane];
+    }
+    fin[2 * n] = sum_da;
+    fin[2 * n + 1] = sum_dax;
+    dgamma[n] = sum_dax;
+    dbeta[n] = sum_da;
+}
+
+// dZ = invstd * gamma * (dA - mean(dA) - xhat * mean(dA * xhat))
 __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(const float* __restrict__ dY, const float* __restrict__ Y,
                                                                   int act, const float* __restrict__ xhat,
                                                                   const float* __restrict__ invstd,
                                                                   const float* __restrict__ gamma,
-                                                                  const float* __restrict__ part, int M, int N, int rc,
-                                                                  float* __restrict__ dZ, float* __restrict__ dgamma,
-                                                                  float* __restrict__ dbeta) {
+                                                                  const float* __restrict__ fin, int M, int N, int rc,
+                                                                  float* __restrict__ dZ) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n = blockIdx.x * 64 + lane;
     if (n >= N) return;
-    const int chunks = gridDim.y;
-    float sum_da = 0.f, sum_dax = 0.f;
-    for (int c = 0; c < chunks; ++c) {
-        sum_da += part[((size_t)c * N + n) * 2];
-        sum_dax += part[((size_t)c * N + n) * 2 + 1];
-    }
+    const float sum_da = fin[2 * n], sum_dax = fin[2 * n + 1];
     const float g = gamma[n], is = invstd[n];
     const float a1 = sum_da / (float)M, a2 = sum_dax / (float)M;
     const int m0 = blockIdx.y * rc, m1 = min(M, m0 + rc);
-#pragma unroll 4
+#pragma unroll 8
     for (int m = m0 + wave; m < m1; m += BN_WAVES) {
         const size_t i = (size_t)m * N + n;
         const float da = dY[i] * act_bwd(Y[i], act);
         dZ[i] = is * g * (da - a1 - xhat[i] * a2);
-    }
-    if (blockIdx.y == 0 && wave == 0) {
-        dgamma[n] = sum_dax;
-        dbeta[n] = sum_da;
     }
 }
 
@@ -659,7 +711,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(const float* _
 extern "C" size_t fr_bn_workspace_bytes(int64_t M, int32_t N) {
     if (M < 1 || N < 1) return 0;
     const int rc = bn_chunk_rows(M);
-    return (size_t)((M + rc - 1) / rc) * N * 2 * sizeof(float);
+    return ((size_t)((M + rc - 1) / rc) + 1) * N * 2 * sizeof(float);   // per-chunk partials + the folded column statistics
 }
 
 extern "C" int fr_bn_fwd(const float* Z, const float* gamma, const float* beta, float eps, float momentum,
@@ -673,8 +725,12 @@ extern "C" int fr_bn_fwd(const float* Z, const float* gamma, const float* beta, 
     ProfScope prof(K_BN_FWD, stream);
     FR_LAUNCH(prof, bn_fwd_stats_kernel, grid, dim3(BN_THREADS), 0, stream, Z, (int)M, (int)N, rc, (float*)ws);
     FR_CHECK_LAUNCH();
-    FR_LAUNCH(prof, bn_fwd_apply_kernel, grid, dim3(BN_THREADS), 0, stream, Z, (const float*)ws, gamma, beta, eps, momentum,
-              running_mean, running_var, (int)M, (int)N, rc, (int)act, Y, xhat, invstd);
+    float* fin = (float*)ws + (size_t)grid.y * N * 2;
+    FR_LAUNCH(prof, bn_fwd_fold_kernel, dim3(grid.x), dim3(BN_THREADS), 0, stream, (const float*)ws, (int)grid.y, (int)M, (int)N, rc, eps,
+              momentum, running_mean, running_var, fin, invstd);
+    FR_CHECK_LAUNCH();
+    FR_LAUNCH(prof, bn_fwd_apply_kernel, grid, dim3(BN_THREADS), 0, stream, Z, (const float*)fin, gamma, beta, (int)M, (int)N, rc,
+              (int)act, Y, xhat);
     FR_CHECK_LAUNCH();
     return FR_OK;
 }
@@ -691,8 +747,12 @@ extern "C" int fr_bn_bwd(const float* dY, const float* Y, int32_t act, const flo
     FR_LAUNCH(prof, bn_bwd_stats_kernel, grid, dim3(BN_THREADS), 0, stream, dY, Y, (int)act, xhat, (int)M, (int)N, rc,
               (float*)ws);
     FR_CHECK_LAUNCH();
+    float* fin = (float*)ws + (size_t)grid.y * N * 2;
+    FR_LAUNCH(prof, bn_bwd_fold_kernel, dim3(grid.x), dim3(BN_THREADS), 0, stream, (const float*)ws, (int)grid.y, (int)N, fin, dgamma,
+              dbeta);
+    FR_CHECK_LAUNCH();
     FR_LAUNCH(prof, bn_bwd_apply_kernel, grid, dim3(BN_THREADS), 0, stream, dY, Y, (int)act, xhat, invstd, gamma,
-              (const float*)ws, (int)M, (int)N, rc, dZ, dgamma, dbeta);
+              (const float*)fin, (int)M, (int)N, rc, dZ);
     FR_CHECK_LAUNCH();
     return FR_OK;
 }
