@@ -86,7 +86,7 @@ def train(z: Dict[str, np.ndarray], snaps=()) -> Dict[str, np.ndarray]:
     params = ([U] if stage == "pretrain" else []) + [I] + [t for pair in zip(Ws, bs) for t in pair]
     opt = torch.optim.Adam(params, lr=lr, weight_decay=wd)
     out: Dict[str, np.ndarray] = {}
-    losses = []
+    losses, norms = [], []
     for t in range(len(z["user_id"])):
         u, i = torch.tensor(z["user_id"][t]), torch.tensor(z["item_id"][t])
         lab, s = torch.tensor(z["label"][t]), torch.tensor(z["sst"][t])
@@ -98,6 +98,8 @@ def train(z: Dict[str, np.ndarray], snaps=()) -> Dict[str, np.ndarray]:
         if t == 0:
             out["grad_step1.mlp0"] = Ws[0].grad.numpy().copy()
             out["grad_step1.item"] = I.grad.numpy().copy()
+        if "clip_max_norm" in z:      # trainer.py:194-195
+            norms.append(float(torch.nn.utils.clip_grad_norm_(params, max_norm=float(z["clip_max_norm"]))))
         opt.step()
         if (t + 1) in snaps:
             out[f"after{t + 1}.user_embedding.weight"] = U.detach().numpy().copy()
@@ -106,4 +108,6 @@ def train(z: Dict[str, np.ndarray], snaps=()) -> Dict[str, np.ndarray]:
                 out[f"after{t + 1}.mlp_layers.mlp_layers.{3 * l + 1}.weight"] = Ws[l].detach().numpy().copy()
                 out[f"after{t + 1}.mlp_layers.mlp_layers.{3 * l + 1}.bias"] = bs[l].detach().numpy().copy()
     out["loss"] = np.array(losses)
+    if norms:
+        out["grad_norm"] = np.array(norms)
     return out

@@ -133,6 +133,12 @@ class Model:
             return [self.gb, self.U, self.bu, self.I, self.bi]
         return [self.U, self.I] + self.base_mlp_params()
 
+    def registered_params(self):   # nn.Module.parameters() of the reference model: the dict-held filter / discriminator
+        ps = [self.U, self.I]      # MLPs are not among them (pfcn_biasedmf.py:110-142)
+        if self.biased:
+            ps += [self.bu, self.bi, self.gb]
+        return ps + self.base_mlp_params()
+
     def dis_params(self):
         ps = []
         for d in self.dis.values():
@@ -203,7 +209,7 @@ def train(z) -> Dict[str, np.ndarray]:
     opt_f = torch.optim.Adam(m.all_params() if m.mode == "none" else m.filter_params(), lr=m.lr, weight_decay=m.wd)
     opt_d = torch.optim.Adam(m.dis_params(), lr=m.lr, weight_decay=m.wd) if m.mode != "none" else None
     phases = [str(p) for p in z["phases"]]
-    losses = []
+    losses, norms = [], []
     n_dis_layers = len(z["dis_hidden"]) + 1
     for t, ph in enumerate(phases):
         u, pi, ni = (torch.tensor(z[k][t]) for k in ("user_id", "item_id", "neg_item_id"))
@@ -217,8 +223,12 @@ def train(z) -> Dict[str, np.ndarray]:
         l = m.loss(u, pi, ni, sl, labels, masks) if ph == "F" else m.dis_loss(u, sl, labels, masks)
         losses.append(float(l.item()))
         l.backward()
+        if "clip_max_norm" in z:       # trainer.py:925-926
+            norms.append(float(torch.nn.utils.clip_grad_norm_(m.registered_params(), max_norm=float(z["clip_max_norm"]))))
         opt.step()
     out: Dict[str, np.ndarray] = {"loss": np.array(losses)}
+    if norms:
+        out["grad_norm"] = np.array(norms)
     out[f"final.model.{m.uname}.weight"] = m.U.detach().numpy().copy()
     out[f"final.model.{m.iname}.weight"] = m.I.detach().numpy().copy()
     for name, mlp in (("mlp_layer", m.scorer), ("user_mlp", m.user_mlp), ("item_mlp", m.item_mlp)):

@@ -144,6 +144,46 @@ class GenericEngine:
             if self._owned(name, group):
                 t._grad_rows = None
 
+    # Parameters the reference model holds in plain dicts (pfcn_biasedmf.py:110-142 filter_layer / dis_layer_dict,
+    # fairgo_pmf.py:141-157) are not in `model.parameters()`: torch.nn.utils.clip_grad_norm_(model.parameters(), ...) of the
+    # reference loop (trainer.py:731-732, :925-926) neither measures nor scales their gradients.
+    NOT_MODEL_PARAMETERS = ("filter.", "dis.")
+
+    def clip_grad_norm(self, max_norm: float, group=None):
+        """clip_grad_norm_(model.parameters(), max_norm) between backward() and step(), on the gradients as they are held
+        here: a table's gradient is the parked [M, D] rows of the batch (duplicates summed in ascending batch position
+        before squaring -- the dense gradient's rows), a dense parameter's its `.grad`.  Norm of the per-tensor norms,
+        coefficient max_norm / (total + 1e-6) clamped to 1 and applied to every measured gradient, as torch does.
+        Consequences of the reference's call that are kept: a discriminator step of PFCN / FairGo is not affected at all
+        (its parameters are not in model.parameters()), a filter step only through the embedding / bias / registered-MLP
+        gradients.  Returns the device scalar total_norm.  Eager only (data-dependent shapes): a GraphedStep whose
+        optimizer clips runs its steps eagerly."""
+        norms, held = [], []
+        for name, t in self._tables.items():
+            if name.startswith(self.NOT_MODEL_PARAMETERS) or not t.trainable or t._grad_rows is None:
+                continue
+            idx, g = t._keep.reshape(-1), t._grad_rows
+            order = torch.argsort(idx, stable=True)
+            _, counts = torch.unique_consecutive(idx[order], return_counts=True)
+            dense_rows = torch.segment_reduce(g[order].contiguous(), "sum", lengths=counts, axis=0)
+            norms.append(torch.linalg.vector_norm(dense_rows))
+            held.append(("table", t))
+        for name, d in self._dense.items():
+            if name.startswith(self.NOT_MODEL_PARAMETERS) or d.p.grad is None:
+                continue
+            norms.append(torch.linalg.vector_norm(d.p.grad))
+            held.append(("dense", d))
+        if not norms:
+            return torch.zeros((), device=self.device)
+        total = torch.linalg.vector_norm(torch.stack(norms))
+        coef = torch.clamp(max_norm / (total + 1e-6), max=1.0)
+        for kind, x in held:
+            if kind == "table":
+                x._grad_rows = x._grad_rows * coef
+            else:
+                x.p.grad.mul_(coef)
+        return total
+
     def note_stepped(self, group=None):
         """An optimizer step of `group` was issued (here, or as a replay of a captured step: fairrec/graph.py)."""
         self._group_version[group] = self._group_version.get(group, 0) + 1

@@ -59,8 +59,9 @@ class GraphedStep:
     def __call__(self, inter: Interaction, *args):
         dev = self.engine.device
         inter = inter.to(dev)
-        if self.eager_left > 0:
-            self.eager_left -= 1
+        if self.eager_left > 0 or getattr(self.optimizer, "clip", None):
+            # (clip_grad_norm measures the batch's distinct rows: data-dependent shapes, not capturable)
+            self.eager_left = max(0, self.eager_left - 1)
             return self._eager(inter, args)
         if self.graph is None:
             # capture on this batch: copy it into static tensors, record the step, then replay it once (capture does not

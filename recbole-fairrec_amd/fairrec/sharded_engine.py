@@ -113,6 +113,10 @@ class _ShardedLookup(torch.autograd.Function):
 
 
 class ShardedGenericEngine(GenericEngine):
+    def clip_grad_norm(self, max_norm: float, group=None):
+        raise NotImplementedError("clip_grad_norm on row-sharded tables (a norm over gradient rows held by their owners "
+                                  "plus one all-reduce) is not built: use the single-GPU or the replicated engine")
+
     def __init__(self, device, group=None, capacity_factor: float = 2.0, ops=None):
         self.group = group
         self.G = dist.get_world_size(group)

@@ -364,11 +364,12 @@ class PFCNTrainer(Trainer):
         if group is None and self.filter_mode != 'none':
             return None           # the reference's default optimizer is never stepped when filters are on (PFCN, FairGo)
         from ..optim import FusedLazyAdam
-        if (kwargs.get('learner', self.learner) or 'adam').lower() != 'adam' or self.clip_grad_norm:
-            raise NotImplementedError('only learner adam without clip_grad_norm is on the MI355X hot path')
+        if (kwargs.get('learner', self.learner) or 'adam').lower() != 'adam':
+            raise NotImplementedError('only learner adam is on the MI355X hot path')
         return FusedLazyAdam(self.model.hip_engine(), lr=kwargs.get('learning_rate', self.learning_rate),
                              weight_decay=kwargs.get('weight_decay', self.weight_decay),
-                             sweep_period=self.config['lazy_adam_sweep_period'], group=group)
+                             sweep_period=self.config['lazy_adam_sweep_period'], group=group,
+                             clip_grad_norm=self.clip_grad_norm)
 
     def _train_epoch(self, train_data, epoch_idx, loss_func=None, show_progress=False):
         dis_loss, filter_loss = 0., 0.

@@ -74,7 +74,7 @@ def run_case(name, *args, **kwargs):
     return _run_case(name, *args, **kwargs)
 
 
-def _run_case(name, stage, n_users, n_items, D, hidden, B, T, snaps, lr, wd, p_drop, fair_weight, seed):
+def _run_case(name, stage, n_users, n_items, D, hidden, B, T, snaps, lr, wd, p_drop, fair_weight, seed, clip=None):
     torch.manual_seed(seed)
     rng = np.random.default_rng(seed)
     gender = rng.integers(0, 2, size=n_users).astype(np.float32)
@@ -109,6 +109,7 @@ def _run_case(name, stage, n_users, n_items, D, hidden, B, T, snaps, lr, wd, p_d
         out["init." + k] = v.detach().numpy().copy()
     opt = torch.optim.Adam(model.parameters(), lr=lr, weight_decay=wd)   # trainer.py:139
     us, its, labs, ss, masks, losses = [], [], [], [], [], []
+    norms = []
     sizes = [2 * D] + list(hidden)
     for t in range(T):
         u = rng.integers(1, n_users, size=B)
@@ -132,6 +133,8 @@ def _run_case(name, stage, n_users, n_items, D, hidden, B, T, snaps, lr, wd, p_d
             with torch.no_grad():
                 out["grad_step1.mlp0"] = model.mlp_layers.mlp_layers[1].weight.grad.numpy().copy()
                 out["grad_step1.item"] = model.item_embedding.weight.grad.numpy().copy()
+        if clip:      # config clip_grad_norm (trainer.py:194-195): every parameter of NFCF is in model.parameters()
+            norms.append(float(torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=clip)))
         opt.step()
         us.append(u); its.append(i); labs.append(lab); ss.append(s); masks.append(step_masks)
         if (t + 1) in snaps:
@@ -142,6 +145,9 @@ def _run_case(name, stage, n_users, n_items, D, hidden, B, T, snaps, lr, wd, p_d
                     out[f"after{t + 1}.m." + pname] = opt.state[prm]["exp_avg"].numpy().copy()
     out.update(user_id=np.stack(us).astype(np.int64), item_id=np.stack(its).astype(np.int64), label=np.stack(labs),
                sst=np.stack(ss), loss=np.array(losses), snaps=np.array(sorted(snaps)))
+    if clip:
+        out["clip_max_norm"] = np.array(float(clip))
+        out["grad_norm"] = np.array(norms)
     if p_drop > 0:
         for li in range(len(sizes)):
             out[f"mask{li}"] = np.stack([masks[t][li] for t in range(T)]).astype(np.uint8)
@@ -163,6 +169,8 @@ def main():
     run_case("pretrain_d64", "pretrain", D=64, hidden=(128, 64), T=4, snaps=(4,), wd=1e-6, p_drop=0.2, fair_weight=0.1, seed=4, **c)
     run_case("finetune", "finetune", D=8, hidden=(16, 8), T=10, snaps=(1, 10), wd=1e-6, p_drop=0.0, fair_weight=0.1, seed=5, **c)
     run_case("finetune_dropout", "finetune", D=8, hidden=(16, 8), T=6, snaps=(6,), wd=1e-6, p_drop=0.2, fair_weight=0.5, seed=6, **c)
+    run_case("pretrain_clip", "pretrain", D=8, hidden=(16, 8), T=6, snaps=(6,), wd=1e-6, p_drop=0.0, fair_weight=0.1, seed=10, clip=0.05, **c)
+    run_case("finetune_clip", "finetune", D=8, hidden=(16, 8), T=6, snaps=(6,), wd=1e-6, p_drop=0.2, fair_weight=0.5, seed=11, clip=0.05, **c)
     run_case("finetune_d64", "finetune", D=64, hidden=(128, 64), T=4, snaps=(4,), wd=1e-6, p_drop=0.0, fair_weight=0.1, seed=7, **c)
     # BASELINE.json configs[4]'s width: embedding_size 256, mlp_hidden_size [128, 64], B = 200
     c256 = dict(n_users=120, n_items=90, B=200, lr=1e-3)

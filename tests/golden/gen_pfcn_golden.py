@@ -89,7 +89,7 @@ def run_case(name, *args, **kwargs):
 
 
 def _run_case(name, cls, mode, attrs, phases, sst_lists, D, B, dis_hidden, seed, p_drop=0.3, lr=1e-3, wd=1e-4,
-             dis_weight=10.0, n_users=40, n_items=30):
+             dis_weight=10.0, n_users=40, n_items=30, clip=None):
     torch.manual_seed(seed)
     rng = np.random.default_rng(seed)
     feats = {"gender": rng.integers(0, 2, size=n_users).astype(np.float32),
@@ -134,6 +134,7 @@ def _run_case(name, cls, mode, attrs, phases, sst_lists, D, B, dis_hidden, seed,
     T = len(phases)
     cols = {k: [] for k in ("user_id", "item_id", "neg_item_id")}
     losses, masks = [], {sst: [[] for _ in range(T)] for sst in attrs}
+    norms = []
     dis_sizes = [D] + list(dis_hidden)
     for t in range(T):
         u = rng.integers(1, n_users, size=B)
@@ -153,11 +154,15 @@ def _run_case(name, cls, mode, attrs, phases, sst_lists, D, B, dis_hidden, seed,
             opt_f.zero_grad()
             loss = model.calculate_loss(inter, sl)
             loss.backward()
+            if clip:      # trainer.py:925-926: model.parameters() = what nn.Module registered (no dict-held MLP)
+                norms.append(float(torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=clip)))
             opt_f.step()
         else:
             opt_d.zero_grad()
             loss = model.calculate_dis_loss(inter, sl)
             loss.backward()
+            if clip:
+                norms.append(float(torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=clip)))
             opt_d.step()
         losses.append(float(loss.item()))
         for k, v in (("user_id", u), ("item_id", pi), ("neg_item_id", ni)):
@@ -166,6 +171,9 @@ def _run_case(name, cls, mode, attrs, phases, sst_lists, D, B, dis_hidden, seed,
     for k in cols:
         out[k] = np.stack(cols[k]).astype(np.int64)
     out["loss"] = np.array(losses)
+    if clip:
+        out["clip_max_norm"] = np.array(float(clip))
+        out["grad_norm"] = np.array(norms)
     for sst in attrs:
         for t in range(T):
             for l, m in enumerate(masks[sst][t]):
@@ -194,6 +202,9 @@ def main():
     run_case("bmf_sm_d64", PFCN_BiasedMF, "sm", g, "FDF", [g] * 3, D=64, B=96, dis_hidden=(128, 256, 128, 128, 64, 32), seed=7)
     # BASELINE.json configs[2]'s width: embedding_size 128 with the full-size discriminator, sm and cm
     run_case("bmf_sm_d128", PFCN_BiasedMF, "sm", g, "FDFD", [g] * 4, D=128, B=200, dis_hidden=(128, 256, 128, 128, 64, 32), seed=12)
+    # config clip_grad_norm = {max_norm: ...} (trainer.py:925-926), small enough to bite on every filter step
+    run_case("bmf_sm_clip", PFCN_BiasedMF, "sm", g, "FFDDFD", [g] * 6, D=8, B=32, dis_hidden=(16, 8), seed=14, clip=0.05)
+    run_case("mlp_sm_clip", PFCN_MLP, "sm", g, "FDFD", [g] * 4, D=8, B=32, dis_hidden=(16, 8), seed=15, clip=0.05)
     run_case("bmf_cm_d128", PFCN_BiasedMF, "cm", ga, "FDFD", [ga, ga, g, g], D=128, B=200, dis_hidden=(128, 256, 128, 128, 64, 32), seed=13)
 
 

@@ -32,6 +32,8 @@ def test_nfcf_training_matches_reference_golden(path, tmp_path, sharded, request
     from fairrec.config import Config
     from fairrec.data.interaction import Interaction
     from fairrec.model.fair_recommender.nfcf import NFCF
+    if sharded and "clip_max_norm" in np.load(path):
+        pytest.skip("clip_grad_norm is not built for row-sharded tables (raises NotImplementedError)")
     _run_case(np.load(path), sharded)
 
 
@@ -56,7 +58,9 @@ def _run_case(z, sharded=False):
     model.load_state_dict(init)
     model = model.to("cuda")
     model.train()
-    opt = FusedLazyAdam(model.hip_engine(), lr=lr, weight_decay=wd, sweep_period=3)
+    # config clip_grad_norm (trainer.py:194-195): clipped inside step(), where the embedding gradient exists
+    clip = {"max_norm": float(z["clip_max_norm"])} if "clip_max_norm" in z else None
+    opt = FusedLazyAdam(model.hip_engine(), lr=lr, weight_decay=wd, sweep_period=3, clip_grad_norm=clip)
     n_layers = len(z["hidden"]) + 1
     snaps = set(int(s) for s in z["snaps"])
     losses = []
@@ -70,6 +74,8 @@ def _run_case(z, sharded=False):
         losses.append(loss.detach().reshape(1).clone())
         loss.backward()
         opt.step()
+        if clip:
+            np.testing.assert_allclose(float(opt.last_grad_norm), z["grad_norm"][t], rtol=1e-4)
         if (t + 1) in snaps:
             sd = model.state_dict()
             for k, v in sd.items():

@@ -36,6 +36,8 @@ def _load_mlp(mlp, z, prefix):
 def test_pfcn_training_matches_reference_golden(path, sharded, request):
     if sharded:     # the row-sharded engine as a 1-rank RCCL world: same goldens (fairrec/sharded_engine.py)
         request.getfixturevalue("rccl_world1")
+    if sharded and "clip_max_norm" in np.load(path):
+        pytest.skip("clip_grad_norm is not built for row-sharded tables (raises NotImplementedError)")
     f64 = path[:-4] + "_f64.npz"
     _run_case(np.load(path), sharded, exact=np.load(f64) if os.path.exists(f64) else None)
 
@@ -71,11 +73,13 @@ def _run_case(z, sharded=False, noise=None, exact=None):
         for s, mlp in model.dis_layer_dict.items():
             _load_mlp(mlp, z, f"init.dis.{s}")
     eng = model.hip_engine()
+    # config clip_grad_norm (trainer.py:925-926): the optimizer clips inside step(), where the gradient exists
+    clip = {"max_norm": float(z["clip_max_norm"])} if "clip_max_norm" in z else None
     if mode == "none":
-        opt_f, opt_d = FusedLazyAdam(eng, lr=lr, weight_decay=wd, sweep_period=2), None
+        opt_f, opt_d = FusedLazyAdam(eng, lr=lr, weight_decay=wd, sweep_period=2, clip_grad_norm=clip), None
     else:
-        opt_f = FusedLazyAdam(eng, lr=lr, weight_decay=wd, sweep_period=2, group="filter")
-        opt_d = FusedLazyAdam(eng, lr=lr, weight_decay=wd, sweep_period=2, group="dis")
+        opt_f = FusedLazyAdam(eng, lr=lr, weight_decay=wd, sweep_period=2, group="filter", clip_grad_norm=clip)
+        opt_d = FusedLazyAdam(eng, lr=lr, weight_decay=wd, sweep_period=2, group="dis", clip_grad_norm=clip)
     n_dis = len(z["dis_hidden"]) + 1
     losses = []
     for t, ph in enumerate(str(x) for x in z["phases"]):
@@ -93,6 +97,12 @@ def _run_case(z, sharded=False, noise=None, exact=None):
         losses.append(loss.detach().reshape(1).clone())
         loss.backward()
         opt.step()
+        if clip and ph == "F":
+            # the norm over model.parameters() = embeddings, biases, registered MLPs.  (On a "D" step the reference measures
+            # the embeddings' gradient too -- the stale clipped one of the last filter step plus what the discriminator pass
+            # added -- and scales it; the next filter step zeroes it unread and the discriminators are not in
+            # model.parameters(), so that call changes no state and its norm is not reproduced here.)
+            np.testing.assert_allclose(float(opt.last_grad_norm), z["grad_norm"][t], rtol=1e-4)
     noise = noise or {}
     got_loss = torch.cat(losses).cpu().numpy().astype(np.float64)
     assert (np.abs(got_loss - z["loss"]) <= 1e-4 * np.abs(z["loss"]) + 1e-6 + noise.get("loss", 0.0)).all(), \
