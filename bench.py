@@ -441,6 +441,10 @@ def main():
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "measured_copy_ceiling": round(copy_gbs, 1), "frac_of_measured_ceiling": round(achieved / copy_gbs, 4),
                     "algorithmic_bytes_per_launch": algo_bytes,
+                    # ... plus the launch's slice of the bounded-staleness sweep (rows / period, p m v read and written, last
+                    # written): traffic the lazy update owes for the rows no batch touched -- what `traffic` is to be held against
+                    "sweep_bytes_per_launch": (0 if sharded or not eng._sweep(BATCH) else
+                                               int((N_USERS + N_ITEMS) / eng._sweep(BATCH) * (6 * 4 * DIM + 8))),
                     # the same bytes over the WHOLE timed step (every launch of the step + gaps): the honest figure
                     "whole_step_GBps": round(algo_bytes / (dt / K) / 1e9, 1),
                     "frac_step": round(algo_bytes / (dt / K) / 1e9 / HBM_PEAK_GBS, 4),
@@ -448,7 +452,7 @@ def main():
                     "dominant_rule": ("longest kernel of the dependent chain; sort_segments_kernel runs on 1-2 workgroups "
                                       "concurrently with the gather kernels on a side stream" if sharded else
                                       "the step IS one kernel (focf_step_kernel); sort_segments_kernel + focf_lpt_kernel run "
-                                      "once per 8 steps (16 + 8 workgroups) on a side stream, ahead of the steps they serve"),
+                                      "twice per 16 steps on a side stream, ahead of the steps they serve"),
                     "measured": f"hipExtLaunchKernelGGL start/stop events on every launch, {K} eager steps after the "
                                 "timed region (same look-ahead sort overlap as the timed steps)"}
 
@@ -464,7 +468,7 @@ def main():
                        "item_distribution": args.item_dist, "launch": launch, "launch_modes_timed": other,
                        "step": ("gather / fair / backward_adam chain over 5 all-to-alls" if sharded else
                                 "ONE launch per step (fr_focf_step: gather + lazy-Adam replay + dot + fairness + backward + Adam + "
-                                "sweep slice); id columns of 8 coming batches sorted and packed per side launch"),
+                                "sweep slice); id columns of 16 coming batches sorted and packed per fork of the side stream"),
                        "lazy_adam_sweep_period": eng._sweep(BATCH) if not sharded else args.sweep,
                        "tables": "row-sharded over %d ranks, RCCL all-to-all" % world if sharded else "single GPU",
                        "global_batch": BATCH * world, "final_loss": round(loss_last, 6) if not sharded else None,

@@ -1,7 +1,7 @@
 """Calibration + measurement run for rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (one counter per pass).
 1) table_flush_kernel on a 1M x 64 table with every row exactly 1 step stale: reads N*(3*D*4 + 4) bytes
    (p,m,v rows + last) and writes the same -> known byte count in OUR access pattern (dword per lane, 256-B rows).
-2) 40 FOCF steps of the bench workload."""
+2) 340 FOCF steps of the bench workload, launched as bench.py launches them (one-launch step, 16 batches prepared ahead)."""
 import sys, os
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -24,7 +24,10 @@ u, i, r, s = (t.to(dev) for t in bench.synth_batches(K, bench.BATCH, bench.N_USE
 U, I = bench.xavier_tables(bench.N_USERS, bench.N_ITEMS, bench.DIM, bench.SEED, dev)
 eng = FocfEngine(U, I, bench.OBJECTIVE, bench.FAIR_WEIGHT, 5.0)
 FusedLazyAdam(eng, lr=bench.LR, weight_decay=bench.WD)
+eng.defer_loss = True
+rows = [(u[k], i[k], s[k], r[k]) for k in range(K)]
 for k in range(K):
-    eng.forward(u[k], i[k], r[k], s[k]); eng.backward_adam()
+    eng.forward(u[k], i[k], r[k], s[k], next_batch=rows[k + 1:k + 21] or None); eng.backward_adam()
+eng.finish()
 torch.cuda.synchronize()
 print("done", K, "steps; sweep", eng._sweep(bench.BATCH))

@@ -96,6 +96,6 @@ if "fairgo" in which:
     od = FusedLazyAdam(m.hip_engine(), lr=1e-3, weight_decay=1e-4, group="dis")
     sl = ["gender"]
     data = batches(nu, ni, B, 4)
-    run(f"FairGo_PMF WAP finetune filter-phase step {nu}x{ni} D={D} B={B} (whole-table filters + 2 SpMM, nnz={2*nnz})", m, [of], [lambda it: m.calculate_loss(it, sl)], data, ds._uf["gender"], W=2, K=5)
+    run(f"FairGo_PMF WAP finetune filter-phase step {nu}x{ni} D={D} B={B} (whole-table filters + 2 SpMM, nnz={2*nnz})", m, [of], [lambda it: m.calculate_loss(it, sl)], data, ds._uf["gender"], W=4, K=10)
     m.begin_dis_phase(sl)       # what the trainer does before a discriminator pass: filtered table + propagations, once
-    run(f"FairGo_PMF WAP finetune dis-phase step (per-pass cache)", m, [od], [lambda it: m.calculate_dis_loss(it, sl)], data, ds._uf["gender"], W=2, K=5)
+    run(f"FairGo_PMF WAP finetune dis-phase step (per-pass cache)", m, [od], [lambda it: m.calculate_dis_loss(it, sl)], data, ds._uf["gender"], W=4, K=20)

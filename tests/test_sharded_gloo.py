@@ -1,5 +1,6 @@
-"""CPU, world_size 2 over gloo: the exchange schedule of the row-sharded FOCF step (fairrec/sharded.py) with a
-CPU test double for the kernels reproduces the single-process oracle on the concatenated global batch."""
+"""CPU, world_size 2 and 4 over gloo: the exchange schedule of the row-sharded FOCF step (fairrec/sharded.py) with a
+CPU test double for the kernels reproduces the single-process oracle on the concatenated global batch -- also when most
+of the batch's items live on ONE owner (a Zipf-hot owner: buckets of very different fill)."""
 import os
 import socket
 import sys
@@ -21,7 +22,20 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, objective, out_dir):
+def _case(hot: bool, world: int):
+    """The step data: the golden case's batches, or (hot) the same with 70 % of the item ids moved onto owner 0."""
+    z = dict(np.load(os.path.join(ROOT, "tests", "golden", "focf_value_d64.npz")))
+    if hot:
+        rng = np.random.default_rng(7)
+        n_items = z["I0"].shape[0]
+        item = z["item_id"].copy()
+        move = rng.random(item.shape) < 0.7
+        item[move] = world * rng.integers(1, (n_items - 1) // world + 1, size=int(move.sum()))   # ids = 0 (mod world)
+        z["item_id"] = np.minimum(item, n_items - 1 - (n_items - 1) % world)
+    return z
+
+
+def _worker(rank, world, port, objective, out_dir, hot=False):
     for p in (ROOT, os.path.join(ROOT, "recbole-fairrec_amd"), os.path.join(ROOT, "tests")):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -30,10 +44,10 @@ def _worker(rank, world, port, objective, out_dir):
     try:
         from cpu_ops import CpuOps
         from fairrec.sharded import ShardedFocfEngine, shard_of
-        z = np.load(os.path.join(ROOT, "tests", "golden", "focf_value_d64.npz"))
+        z = _case(hot, world)
         U0, I0 = torch.tensor(z["U0"]), torch.tensor(z["I0"])
         eng = ShardedFocfEngine(shard_of(U0, rank, world), shard_of(I0, rank, world), objective, 0.8, 1e-3, 1e-3,
-                                ops=CpuOps(), capacity_factor=1.5)
+                                ops=CpuOps(), capacity_factor=4.0 if hot else 1.5)
         T, B = 6, z["user_id"].shape[1] // world
         losses = []
         sl = slice(rank * B, (rank + 1) * B)
@@ -50,21 +64,29 @@ def _worker(rank, world, port, objective, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("objective", ["none", "value", "under", "nonparity"])
-def test_two_rank_schedule_matches_oracle(tmp_path, objective):
+def _check(tmp_path, objective, world, hot):
     from oracle import focf as O
-    world = 2
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, objective, str(tmp_path)), nprocs=world, join=True)
-    z = np.load(os.path.join(ROOT, "tests", "golden", "focf_value_d64.npz"))
+    mp.spawn(_worker, args=(world, port, objective, str(tmp_path), hot), nprocs=world, join=True)
+    z = _case(hot, world)
     T, B = 6, (z["user_id"].shape[1] // world) * world
     ref = O.train(objective, z["U0"], z["I0"], z["user_id"][:T, :B], z["item_id"][:T, :B], z["rating"][:T, :B],
                   z["sst"][:T, :B], 1e-3, 1e-3, 0.8, snaps=(T,))
     parts = [torch.load(os.path.join(str(tmp_path), f"r{r}.pt")) for r in range(world)]
-    np.testing.assert_allclose(parts[0]["loss"], ref["loss"], rtol=1e-5)
-    np.testing.assert_allclose(parts[1]["loss"], ref["loss"], rtol=1e-5)
+    for r in range(world):
+        np.testing.assert_allclose(parts[r]["loss"], ref["loss"], rtol=1e-5)
     for tag in ("U", "I"):
         full = np.zeros_like(ref[f"{tag}_after{T}"])
         for r in range(world):
             full[r::world] = parts[r][tag].numpy()
         np.testing.assert_allclose(full, ref[f"{tag}_after{T}"], rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("objective", ["none", "value", "under", "nonparity"])
+def test_two_rank_schedule_matches_oracle(tmp_path, objective):
+    _check(tmp_path, objective, 2, False)
+
+
+@pytest.mark.parametrize("objective,hot", [("value", False), ("value", True), ("nonparity", True)])
+def test_four_rank_schedule_matches_oracle(tmp_path, objective, hot):
+    _check(tmp_path, objective, 4, hot)
