@@ -18,7 +18,11 @@ def _lib():
 
 @pytest.mark.parametrize("M,k0,k1,N,act,drop", [
     (64, 16, 0, 16, 1, False), (100, 8, 8, 16, 1, True), (8192, 64, 64, 128, 1, True), (8192, 128, 0, 64, 2, False),
-    (777, 64, 0, 1, 1, False), (513, 37, 11, 70, 3, True), (2048, 256, 256, 128, 4, False), (33, 5, 0, 3, 0, True)])
+    (777, 64, 0, 1, 1, False), (513, 37, 11, 70, 3, True), (2048, 256, 256, 128, 4, False), (33, 5, 0, 3, 0, True),
+    # act = 0, no mask, widths multiples of 32: all three products take their LDS-DMA form (csrc/mlp_glds.hip) -- rows that
+    # are not a multiple of 32 (tail tiles, reduction tail of the weight gradient), two-block input, split reductions
+    (1000, 64, 64, 96, 0, False), (8192, 256, 0, 128, 0, False), (50, 32, 0, 32, 0, False), (4100, 128, 0, 256, 0, False),
+    (8192, 512, 0, 128, 0, False)])
 def test_linear_forward_and_backward_match_torch(M, k0, k1, N, act, drop):
     _C = _lib()
     lib = _C.lib()
@@ -68,6 +72,22 @@ def test_linear_forward_and_backward_match_torch(M, k0, k1, N, act, drop):
     _C.check(lib.fr_linear_bwd_weight(dYd.data_ptr(), Y.data_ptr(), act, x0d.data_ptr(), k0, _C.ptr(x1d), k1, _C.ptr(md),
                                       scale, M, N, dW2.data_ptr(), db.data_ptr(), ws.data_ptr(), ws.numel(), st), "bwd_w")
     assert torch.equal(dW, dW2)
+
+
+@pytest.mark.parametrize("act", [1, 2, 3, 4])
+def test_act_bwd_prepass(act):
+    """fr_act_bwd: dY o act'(Y), the pre-pass that lets a layer's two backward products run with act = 0."""
+    _C = _lib()
+    lib = _C.lib()
+    g = torch.Generator().manual_seed(act)
+    X = torch.randn(513, 64, generator=g).requires_grad_()
+    Y = ACTS[act](X)
+    dY = torch.randn(513, 64, generator=g)
+    Y.backward(dY)
+    Yd, dYd = Y.detach().cuda(), dY.cuda()
+    out = torch.empty_like(Yd)
+    _C.check(lib.fr_act_bwd(dYd.data_ptr(), Yd.data_ptr(), act, Yd.numel(), out.data_ptr(), _C.current_stream()), "act_bwd")
+    torch.testing.assert_close(out.cpu(), X.grad, rtol=1e-5, atol=1e-6)
 
 
 @pytest.mark.parametrize("M,N,act", [(32, 8, 2), (128, 64, 1), (300, 70, 2), (8192, 256, 2), (40000, 33, 0), (1, 5, 1)])
