@@ -52,15 +52,27 @@ class _HipMLP(torch.autograd.Function):
         scale = 1.0 / (1.0 - p_drop) if p_drop > 0 else 1.0
         cur = (x0, x1)
         outs, xhats, invstds = [], [], []
+        premul, ins, masks8 = [], [], []
         for l in range(n_layers):
             W, b = params[per * l].contiguous(), params[per * l + 1].contiguous()
             a, c = cur
             k0, k1 = a.shape[1], (c.shape[1] if c is not None else 0)
             N = W.shape[0]
             Y = torch.empty((M, N), dtype=torch.float32, device=dev)
-            mk = masks[l] if masks is not None else None
-            _C.check(lib.fr_linear_fwd(a.data_ptr(), k0, _C.ptr(c), k1, _C.ptr(mk), scale, W.data_ptr(), b.data_ptr(), M, N,
-                                       0 if use_bn else act, Y.data_ptr(), st), "fr_linear_fwd")
+            mk = masks[l] if masks is not None else None      # fp32 keep scales [M, K] (0 or 1/(1-p)), or None
+            mk8 = None
+            if mk is not None and c is None and k0 % 32 == 0:
+                a = a * mk                                      # the layer's input with dropout applied; kept for backward
+                premul.append(True)
+                _C.check(lib.fr_linear_fwd(a.data_ptr(), k0, None, 0, None, 1.0, W.data_ptr(), b.data_ptr(), M, N,
+                                           0 if use_bn else act, Y.data_ptr(), st), "fr_linear_fwd")
+            else:
+                premul.append(False)
+                mk8 = (mk != 0).to(torch.uint8) if mk is not None else None
+                _C.check(lib.fr_linear_fwd(a.data_ptr(), k0, _C.ptr(c), k1, _C.ptr(mk8), scale, W.data_ptr(), b.data_ptr(), M,
+                                           N, 0 if use_bn else act, Y.data_ptr(), st), "fr_linear_fwd")
+            ins.append(a if premul[-1] else None)
+            masks8.append(mk8)
             if use_bn:
                 g, be = params[per * l + 2].contiguous(), params[per * l + 3].contiguous()
                 rm, rv, eps, mom = bn_buffers[l]
@@ -77,6 +89,7 @@ class _HipMLP(torch.autograd.Function):
             outs.append(Y)
             cur = (Y, None)
         ctx.act, ctx.scale, ctx.masks, ctx.n_layers, ctx.use_bn = act, scale, masks, n_layers, use_bn
+        ctx.premul, ctx.ins, ctx.masks8 = premul, ins, masks8
         ctx.has_x1 = x1 is not None
         ctx.n_params = len(params)
         ctx.save_for_backward(x0, *([x1] if x1 is not None else []), *params, *outs, *xhats, *invstds)
@@ -104,7 +117,10 @@ class _HipMLP(torch.autograd.Function):
             a, c = (outs[l - 1], None) if l > 0 else (x0, x1)
             k0, k1 = a.shape[1], (c.shape[1] if c is not None else 0)
             N, K = W.shape
-            mk = ctx.masks[l] if ctx.masks is not None else None
+            mk = ctx.masks8[l]                    # byte mask for the general kernels (None: no dropout, or pre-multiplied)
+            scale = ctx.scale
+            if ctx.premul[l]:                     # X o mask*scale was formed in the forward: the products see a plain input
+                a, c, k1, scale = ctx.ins[l], None, 0, 1.0
             act = ctx.act
             if ctx.use_bn:   # through activation + BatchNorm first; the linear layer then sees a plain gradient
                 g = params[per * l + 2].contiguous()
@@ -127,15 +143,17 @@ class _HipMLP(torch.autograd.Function):
             dW = torch.empty_like(W)
             db = torch.empty(N, dtype=torch.float32, device=dev)
             _C.check(lib.fr_linear_bwd_weight(dY.data_ptr(), Y.data_ptr(), act, a.data_ptr(), k0, _C.ptr(c), k1,
-                                              _C.ptr(mk), ctx.scale, M, N, dW.data_ptr(), db.data_ptr(), ws.data_ptr(),
+                                              _C.ptr(mk), scale, M, N, dW.data_ptr(), db.data_ptr(), ws.data_ptr(),
                                               ws.numel(), st), "fr_linear_bwd_weight")
             grads[per * l], grads[per * l + 1] = dW, db
             need_dx = l > 0 or ctx.needs_input_grad[0] or (ctx.has_x1 and ctx.needs_input_grad[1])
             if need_dx:
                 da = torch.empty((M, k0), dtype=torch.float32, device=dev)
                 dc = torch.empty((M, k1), dtype=torch.float32, device=dev) if k1 else None
-                _C.check(lib.fr_linear_bwd_input(dY.data_ptr(), Y.data_ptr(), act, W.data_ptr(), _C.ptr(mk), ctx.scale,
+                _C.check(lib.fr_linear_bwd_input(dY.data_ptr(), Y.data_ptr(), act, W.data_ptr(), _C.ptr(mk), scale,
                                                  M, N, da.data_ptr(), k0, _C.ptr(dc), k1, st), "fr_linear_bwd_input")
+                if ctx.premul[l]:
+                    da = da * ctx.masks[l]        # back through the dropout of this layer's input
                 if l > 0:
                     dY = da
                 else:
@@ -198,12 +216,21 @@ class MLPLayers(nn.Module):
             params = [t for lin in lins for t in (lin.weight, lin.bias)]
             bn_buffers = None
         p = float(self.dropout) if self.training else 0.0
+        # Dropout masks as fp32 "keep scales" (0 or 1/(1-p)): ONE draw for all layers of the MLP (3 launches instead of 3 per
+        # layer); a layer in the fast form multiplies its input by them once (so that the LDS-DMA GEMMs, which take no mask,
+        # serve it), the others get the same mask as bytes.
         masks = None
         if self.forced_masks is not None:
-            masks = [m.to(input_feature.device, torch.uint8).contiguous() for m in self.forced_masks]
+            scale = 1.0 / (1.0 - p) if p > 0 else 1.0
+            masks = [m.to(input_feature.device, torch.float32).contiguous() * scale for m in self.forced_masks]
         elif p > 0.0:
             M = input_feature.shape[0]
-            masks = [(torch.rand((M, lin.in_features), device=input_feature.device) >= p).to(torch.uint8) for lin in lins]
+            widths = [lin.in_features for lin in lins]
+            keep = (torch.rand(M * sum(widths), device=input_feature.device) >= p).to(torch.float32) * (1.0 / (1.0 - p))
+            masks, o = [], 0
+            for w in widths:
+                masks.append(keep[o:o + M * w].view(M, w))
+                o += M * w
         name = self.activation.lower() if isinstance(self.activation, str) else self.activation
         return _HipMLP.apply(input_feature, second_block, ACT_CODES[name], p if masks is not None else 0.0, masks,
                              bn_buffers, *params)
