@@ -289,7 +289,10 @@ def main():
     sharded = world > 1 or args.force_sharded
     # every rank feeds its own B interactions per step; N > 1: ONE optimizer step on the global batch of
     # world*B interactions, tables row-sharded over the ranks (fairrec/sharded.py)
-    u, i, r, s = (t.to(dev) for t in synth_batches(K + W, BATCH, N_USERS, N_ITEMS, SEED + rank, args.item_dist))
+    # single GPU: PIPE more batches than are stepped on, so that the look-ahead queue stays full to the last timed step (the
+    # timed region then prepares exactly K batches ahead while it applies K, as any K consecutive steps of an epoch do)
+    PIPE = 0 if (world > 1 or args.force_sharded) else 24
+    u, i, r, s = (t.to(dev) for t in synth_batches(K + W + PIPE, BATCH, N_USERS, N_ITEMS, SEED + rank, args.item_dist))
     if not sharded:
         U, I = xavier_tables(N_USERS, N_ITEMS, DIM, SEED, dev)
         eng = FocfEngine(U, I, OBJECTIVE, FAIR_WEIGHT, 5.0)
@@ -318,15 +321,15 @@ def main():
         if key not in _rows:
             _rows[key] = [(ub[j], ib[j], sb[j], rb[j]) for j in range(ub.shape[0])]
         rows = _rows[key]
-        hi = min(k + 21, len(rows), stop if stop is not None else len(rows))
+        hi = min(k + 5 + int(os.environ.get("FAIRREC_FOCF_GROUP", "16")), len(rows), stop if stop is not None else len(rows))
         return rows[k + 1:hi] or None
 
     def step(k):
         if sharded:   # look-ahead of the index work, not across the warm-up / captured-graph boundary
             nxt = (u[k + 1], i[k + 1], s[k + 1]) if k + 1 < n_batches and k != W - 1 else None
             eng.forward(u[k], i[k], r[k], s[k], next_batch=nxt)
-        else:         # no look-ahead across the warm-up / captured-graph boundary either
-            eng.forward(u[k], i[k], r[k], s[k], next_batch=coming(k, u, i, s, r, stop=W if k < W else None))
+        else:         # the dataloader-style queue runs through: the warm-up steps already announce the first timed batches
+            eng.forward(u[k], i[k], r[k], s[k], next_batch=coming(k, u, i, s, r))
         eng.backward_adam()
 
     def barrier():
@@ -349,6 +352,8 @@ def main():
     for k in range(W):
         step(k)
     barrier()
+    if not sharded:
+        eng.prepared_is_complete()      # (synchronised above) the captured steps do not wait for pre-capture side-stream work
 
     graph = None
     if not args.no_graph:   # K steps (kernels and, when sharded, the RCCL collectives) captured in one hipGraph
@@ -364,6 +369,8 @@ def main():
                 with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):
                     for k in range(W, W + K):
                         step(k)
+                    if not sharded:
+                        eng.join_prepared()     # the queue runs past the timed steps: its last fork is joined here
         except Exception as e:   # e.g. a collective that refuses capture: fall back to eager launches
             if not sharded:
                 raise

@@ -41,10 +41,10 @@ class FocfEngine:
     """Owns the two lazy-Adam tables, the per-batch workspace and the kernel launches of FOCF."""
 
     LOSS_SLOTS = 256
-    GROUP = 16        # coming batches prepared per fork of the side stream (FR_FOCF_PREPARE_MAX of them per launch)
+    GROUP = int(__import__('os').environ.get('FAIRREC_FOCF_GROUP', '16'))        # coming batches prepared per fork of the side stream (FR_FOCF_PREPARE_MAX of them per launch)
     PER_LAUNCH = 8    # FR_FOCF_PREPARE_MAX
     LOW_WATER = 4     # ... launched when this few prepared batches are left, so its join is steps old when reached
-    N_WS = 23         # workspaces: the batch in flight + the last one (its loss) + LOW_WATER + GROUP prepared + a spare
+    N_WS = 7 + GROUP  # workspaces: the batch in flight + the last one (its loss) + LOW_WATER + GROUP prepared + a spare
 
     def __init__(self, user_weight: torch.Tensor, item_weight: torch.Tensor, objective: str, fair_weight: float,
                  max_rating: float):
@@ -175,6 +175,21 @@ class FocfEngine:
                 _C.check(rc, "fr_focf_prepare_many")
         group["done"].record(self._side)
         self._prep.update(entries)
+
+    def prepared_is_complete(self):
+        """The caller has synchronised with the device: every prepare launched so far has finished, so the steps that use
+        those batches need not wait for the side stream (e.g. before capturing them into a hipGraph, where a wait on an event
+        recorded outside the capture has no place)."""
+        for _, group, _ in self._prep.values():
+            group["joined"] = True
+
+    def join_prepared(self):
+        """Make the current stream wait for every prepare in flight (the end of a captured region must leave no side-stream
+        work unjoined)."""
+        for _, group, _ in self._prep.values():
+            if not group["joined"]:
+                torch.cuda.current_stream().wait_event(group["done"])
+                group["joined"] = True
 
     def _next_stamp(self, ahead: int = 0) -> int:
         """Stamp of a batch about to be prepared: the step at which it is expected to be applied, never decreasing."""
