@@ -61,17 +61,19 @@ class _HipMLP(torch.autograd.Function):
             Y = torch.empty((M, N), dtype=torch.float32, device=dev)
             mk = masks[l] if masks is not None else None      # fp32 keep scales [M, K] (0 or 1/(1-p)), or None
             mk8 = None
-            if mk is not None and c is None and k0 % 32 == 0:
-                a = a * mk                                      # the layer's input with dropout applied; kept for backward
+            if mk is not None and k0 % 32 == 0 and k1 % 32 == 0:
+                # the layer's input with dropout applied (both blocks of a two-block input); kept for backward
+                a = a * (mk if c is None else mk[:, :k0])
+                c = c * mk[:, k0:] if c is not None else None
                 premul.append(True)
-                _C.check(lib.fr_linear_fwd(a.data_ptr(), k0, None, 0, None, 1.0, W.data_ptr(), b.data_ptr(), M, N,
+                _C.check(lib.fr_linear_fwd(a.data_ptr(), k0, _C.ptr(c), k1, None, 1.0, W.data_ptr(), b.data_ptr(), M, N,
                                            0 if use_bn else act, Y.data_ptr(), st), "fr_linear_fwd")
             else:
                 premul.append(False)
                 mk8 = (mk != 0).to(torch.uint8) if mk is not None else None
                 _C.check(lib.fr_linear_fwd(a.data_ptr(), k0, _C.ptr(c), k1, _C.ptr(mk8), scale, W.data_ptr(), b.data_ptr(), M,
                                            N, 0 if use_bn else act, Y.data_ptr(), st), "fr_linear_fwd")
-            ins.append(a if premul[-1] else None)
+            ins.append((a, c) if premul[-1] else None)
             masks8.append(mk8)
             if use_bn:
                 g, be = params[per * l + 2].contiguous(), params[per * l + 3].contiguous()
@@ -120,7 +122,7 @@ class _HipMLP(torch.autograd.Function):
             mk = ctx.masks8[l]                    # byte mask for the general kernels (None: no dropout, or pre-multiplied)
             scale = ctx.scale
             if ctx.premul[l]:                     # X o mask*scale was formed in the forward: the products see a plain input
-                a, c, k1, scale = ctx.ins[l], None, 0, 1.0
+                (a, c), scale = ctx.ins[l], 1.0
             act = ctx.act
             if ctx.use_bn:   # through activation + BatchNorm first; the linear layer then sees a plain gradient
                 g = params[per * l + 2].contiguous()
@@ -152,8 +154,9 @@ class _HipMLP(torch.autograd.Function):
                 dc = torch.empty((M, k1), dtype=torch.float32, device=dev) if k1 else None
                 _C.check(lib.fr_linear_bwd_input(dY.data_ptr(), Y.data_ptr(), act, W.data_ptr(), _C.ptr(mk), scale,
                                                  M, N, da.data_ptr(), k0, _C.ptr(dc), k1, st), "fr_linear_bwd_input")
-                if ctx.premul[l]:
-                    da = da * ctx.masks[l]        # back through the dropout of this layer's input
+                if ctx.premul[l]:                 # back through the dropout of this layer's input
+                    da = da * (ctx.masks[l] if dc is None else ctx.masks[l][:, :k0])
+                    dc = dc * ctx.masks[l][:, k0:] if dc is not None else None
                 if l > 0:
                     dY = da
                 else:
