@@ -195,6 +195,18 @@ class MLPLayers(nn.Module):
             if module.bias is not None:
                 module.bias.data.fill_(0.0)
 
+    def _count_batch(self, bns):
+        """`num_batches_tracked += 1` of every BatchNorm layer in ONE launch: the counters are kept as views of one shared
+        int64 tensor (re-made whenever .to() / a fresh module replaced the buffers; load_state_dict copies in place, so the
+        views survive it)."""
+        sh = getattr(self, "_nbt_shared", None)
+        if sh is None or any(bn.num_batches_tracked.data_ptr() != sh[i].data_ptr() for i, bn in enumerate(bns)):
+            sh = torch.stack([bn.num_batches_tracked.detach().reshape(()) for bn in bns])
+            for i, bn in enumerate(bns):
+                bn.num_batches_tracked = sh[i]
+            self._nbt_shared = sh
+        sh += 1
+
     def linears(self) -> List[nn.Linear]:
         return [m for m in self.mlp_layers if isinstance(m, nn.Linear)]
 
@@ -213,8 +225,7 @@ class MLPLayers(nn.Module):
         if self.use_bn:
             params = [t for lin, bn in zip(lins, bns) for t in (lin.weight, lin.bias, bn.weight, bn.bias)]
             bn_buffers = [(bn.running_mean, bn.running_var, float(bn.eps), float(bn.momentum)) for bn in bns]
-            for bn in bns:
-                bn.num_batches_tracked += 1
+            self._count_batch(bns)
         else:
             params = [t for lin in lins for t in (lin.weight, lin.bias)]
             bn_buffers = None
