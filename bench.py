@@ -331,7 +331,7 @@ def main():
         if key not in _rows:
             _rows[key] = [(ub[j], ib[j], sb[j], rb[j]) for j in range(ub.shape[0])]
         rows = _rows[key]
-        hi = min(k + 5 + int(os.environ.get("FAIRREC_FOCF_GROUP", "16")), len(rows), stop if stop is not None else len(rows))
+        hi = min(k + 21, len(rows), stop if stop is not None else len(rows))
         return rows[k + 1:hi] or None
 
     def step(k):

@@ -41,10 +41,11 @@ class FocfEngine:
     """Owns the two lazy-Adam tables, the per-batch workspace and the kernel launches of FOCF."""
 
     LOSS_SLOTS = 256
-    GROUP = int(__import__('os').environ.get('FAIRREC_FOCF_GROUP', '16'))        # coming batches prepared per fork of the side stream (FR_FOCF_PREPARE_MAX of them per launch)
+    GROUP = 16        # coming batches prepared per fork of the side stream (FR_FOCF_PREPARE_MAX of them per launch; 32 and 48
+                      # measured slower: rows stamped further ahead are left to their batch by more sweeps)
     PER_LAUNCH = 8    # FR_FOCF_PREPARE_MAX
     LOW_WATER = 4     # ... launched when this few prepared batches are left, so its join is steps old when reached
-    N_WS = 7 + GROUP  # workspaces: the batch in flight + the last one (its loss) + LOW_WATER + GROUP prepared + a spare
+    N_WS = 23         # workspaces: the batch in flight + the last one (its loss) + LOW_WATER + GROUP prepared + a spare
 
     def __init__(self, user_weight: torch.Tensor, item_weight: torch.Tensor, objective: str, fair_weight: float,
                  max_rating: float):
