@@ -17,7 +17,7 @@ FusedLazyAdam(eng, lr=bench.LR, weight_decay=bench.WD, sweep_period=int(os.envir
 eng.defer_loss = True
 rows = [(u[k], i[k], s[k], r[k]) for k in range(K)]
 for k in range(K):
-    eng.forward(u[k], i[k], r[k], s[k], next_batch=rows[k + 1:k + 11] or None)
+    eng.forward(u[k], i[k], r[k], s[k], next_batch=rows[k + 1:k + 21] or None)
     eng.backward_adam()
 torch.cuda.synchronize()
 lib = ctypes.CDLL(_C.LIB_PATH)
