@@ -126,6 +126,10 @@ class GenericEngine:
             return LazyLookup.apply(self._weights[name], t, self._hyper(name), idx, self.err_flag)
         return t.gather(self._hyper(name), idx, self.err_flag)
 
+    def lookup_pair(self, name_a: str, idx_a: torch.Tensor, name_b: str, idx_b: torch.Tensor):
+        """Two lookups of one step (the row-sharded engine packs their exchanges into one buffer per direction)."""
+        return self.lookup(name_a, idx_a), self.lookup(name_b, idx_b)
+
     def batch_segments(self, name: str):
         """The object a loss kernel reads the sorted segments of the batch ids of table `name` from (`._ws`, `.dim`):
         here the table itself, whose workspace the preceding lookup filled."""

@@ -124,8 +124,7 @@ class NFCF(FairRecommender):
     # --- plugin surface -------------------------------------------------------------------------------------
     def _score_logits(self, user, item):
         eng = self.hip_engine()
-        ue = eng.lookup("user_embedding.weight", user)
-        ie = eng.lookup("item_embedding.weight", item)
+        ue, ie = eng.lookup_pair("user_embedding.weight", user, "item_embedding.weight", item)
         return self.mlp_layers(ue, ie)                     # [B, 1], after the last ReLU
 
     def forward(self, user, item):

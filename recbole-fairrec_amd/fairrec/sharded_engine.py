@@ -43,6 +43,20 @@ class HipTableOps:
     def gather_train(self, table, hyper, ids, M, rows, err):
         table.gather_train_into(hyper, ids.data_ptr(), M, rows.data_ptr(), 0, 0, err)
 
+    # the same on one table's part of a PACKED exchange buffer (slot layout of fairrec_hip.h: chunk g of the buffer holds
+    # `chunk` slots of this table at element offset `off`, chunks are `stride` slots apart)
+    def bucket_at(self, idx, G, cap, stride, off, send, slot, counts, err):
+        _C.check(_C.lib().fr_bucket_by_owner(idx.data_ptr(), idx.numel(), G, cap, stride, off, send.data_ptr(),
+                                             slot.data_ptr(), counts.data_ptr(), None, 0, err.data_ptr(),
+                                             _C.current_stream()), "fr_bucket_by_owner")
+
+    def gather_train_at(self, table, hyper, ids, off, M, chunk, stride, rows, err):
+        table.gather_train_into(hyper, ids.data_ptr() + 8 * off, M, rows.data_ptr() + 4 * off * table.dim, chunk, stride, err)
+
+    def apply_grad_at(self, table, hyper, M, rows, grads, off, chunk, stride, sweep):
+        D = table.dim
+        table.apply_grad_from(hyper, M, rows.data_ptr() + 4 * off * D, grads.data_ptr() + 4 * off * D, sweep, chunk, stride)
+
     def gather(self, table, hyper, ids, M, rows, err):
         t = table.c(table.step)
         _C.check(_C.lib().fr_table_gather(ctypes.byref(t), ctypes.byref(hyper.c()), ids.data_ptr(), M, rows.data_ptr(),
@@ -89,6 +103,38 @@ class _Exchange:
         self.g_send = torch.zeros((G * cap, D), dtype=f32, device=dev)
         self.g_recv = torch.empty((G * cap, D), dtype=f32, device=dev)
         self.scale = torch.full((M,), 1.0 / G, dtype=f32, device=dev)
+
+
+class _ExchangePair:
+    """Buffers of a PACKED lookup in two tables of the same width for one batch size: one id / row / gradient buffer per
+    direction, chunk g = [cap slots of table a | cap slots of table b] -> 3 all-to-alls per step instead of 6."""
+
+    def __init__(self, G, M, cap, D, dev):
+        self.M, self.cap, self.S = M, cap, 2 * cap
+        f32, i64, i32 = torch.float32, torch.int64, torch.int32
+        n = G * self.S
+        self.ids_send = torch.full((n,), -1, dtype=i64, device=dev)
+        self.ids_recv = torch.full((n,), -1, dtype=i64, device=dev)
+        self.slot = [torch.empty(M, dtype=i32, device=dev) for _ in range(2)]
+        self.counts = [torch.empty(G, dtype=i32, device=dev) for _ in range(2)]
+        self.rows_send = torch.zeros((n, D), dtype=f32, device=dev)
+        self.rows_recv = torch.empty((n, D), dtype=f32, device=dev)
+        self.g_send = torch.zeros((n, D), dtype=f32, device=dev)
+        self.g_recv = torch.empty((n, D), dtype=f32, device=dev)
+        self.scale = torch.full((M,), 1.0 / G, dtype=f32, device=dev)
+
+
+class _ShardedLookupPair(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, wa, wb, engine, name_a, name_b, idx_a, idx_b):
+        ctx.engine, ctx.names = engine, (name_a, name_b)
+        ra, rb = engine._pair_forward(name_a, idx_a, name_b, idx_b, train=True)
+        return ra, rb
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        ctx.engine._pair_backward(ctx.names, (ga, gb))
+        return None, None, None, None, None, None, None
 
 
 class _Segments:
@@ -196,6 +242,71 @@ class ShardedGenericEngine(GenericEngine):
             return _ShardedLookup.apply(self._weights[name], self, name, idx)
         return self._exchange_forward(name, idx, train=False)
 
+    # --- two tables of one step in ONE exchange -------------------------------------------------------------
+    def lookup_pair(self, name_a, idx_a, name_b, idx_b):
+        """rows of `name_a` at idx_a and of `name_b` at idx_b with the ids, the rows and (backward) the gradient rows of both
+        tables packed into one buffer per direction: 3 all-to-alls per step instead of 3 per table."""
+        ta, tb = self._tables[name_a], self._tables[name_b]
+        idx_a = idx_a.to(self.device, torch.int64).contiguous()
+        idx_b = idx_b.to(self.device, torch.int64).contiguous()
+        if ta.dim != tb.dim or idx_a.numel() != idx_b.numel():
+            return self.lookup(name_a, idx_a), self.lookup(name_b, idx_b)
+        if torch.is_grad_enabled() and (ta.trainable or tb.trainable):
+            return _ShardedLookupPair.apply(self._weights[name_a], self._weights[name_b], self, name_a, name_b, idx_a, idx_b)
+        return self._pair_forward(name_a, idx_a, name_b, idx_b, train=False)
+
+    def _pair_forward(self, name_a, idx_a, name_b, idx_b, train):
+        ops, G = self.ops, self.G
+        M = idx_a.numel()
+        key = (name_a, name_b)
+        ex = self._ex_pair.get(key) if hasattr(self, "_ex_pair") else None
+        if ex is None or ex.M != M:
+            if not hasattr(self, "_ex_pair"):
+                self._ex_pair, self._lay = {}, {}
+            cap = exchange_capacity(M, G, self.capacity_factor)
+            ex = self._ex_pair[key] = _ExchangePair(G, M, cap, self._tables[name_a].dim, self.device)
+        cap, S = ex.cap, ex.S
+        n_slots = G * cap
+        for k, (name, idx) in enumerate(((name_a, idx_a), (name_b, idx_b))):
+            ops.bucket_at(idx, G, cap, S, k * cap, ex.ids_send, ex.slot[k], ex.counts[k], self.err_flag)
+        self._a2a(ex.ids_recv, ex.ids_send)
+        outs = []
+        for k, (name, idx) in enumerate(((name_a, idx_a), (name_b, idx_b))):
+            t = self._tables[name]
+            if train and t.trainable:
+                ops.gather_train_at(t, self._hyper(name), ex.ids_recv, k * cap, n_slots, cap, S, ex.rows_send, self.err_flag)
+                self._lay[name] = (ex, k * cap)
+            else:   # read-only table: its ids out of the packed buffer, its rows into it (two strided copies)
+                ids = ex.ids_recv.view(G, S)[:, k * cap:(k + 1) * cap].contiguous().view(-1)
+                rows = torch.empty((n_slots, t.dim), dtype=torch.float32, device=self.device)
+                ops.gather(t, self._hyper(name), ids, n_slots, rows, self.err_flag)
+                ex.rows_send.view(G, S, t.dim)[:, k * cap:(k + 1) * cap].copy_(rows.view(G, cap, t.dim))
+        self._a2a(ex.rows_recv, ex.rows_send)
+        self._last_idx = getattr(self, "_last_idx", {})
+        for k, (name, idx) in enumerate(((name_a, idx_a), (name_b, idx_b))):
+            out = torch.empty((M, self._tables[name].dim), dtype=torch.float32, device=self.device)
+            ops.unbucket_rows(ex.rows_recv, ex.slot[k], M, out.shape[1], out)
+            outs.append(out)
+            self._last_idx[name] = idx
+        return outs[0], outs[1]
+
+    def _pair_backward(self, names, grads):
+        ex = self._ex_pair[names]
+        sent = False
+        for k, (name, g) in enumerate(zip(names, grads)):
+            t = self._tables[name]
+            if g is None or not t.trainable or name not in self._lay:
+                continue
+            # the local loss is a mean over the local batch: 1/G makes the step that of the mean over the global batch
+            self.ops.bucket_rows(g.contiguous(), ex.scale, ex.slot[k], ex.M, t.dim, ex.g_send)
+            sent = True
+        if not sent:
+            return
+        self._a2a(ex.g_recv, ex.g_send)
+        for name in names:
+            if name in self._lay and self._tables[name].trainable:
+                self._tables[name]._grad_rows = ex.g_recv
+
     def batch_segments(self, name):
         """Sorted segments of THIS rank's ids of the last lookup in `name` (per-rank batch statistics)."""
         seg = self._seg.setdefault(name, _Segments(self._tables[name].dim))
@@ -213,10 +324,14 @@ class ShardedGenericEngine(GenericEngine):
                 t._pending = None
                 t._grad_rows = None
                 continue
-            ex = self._ex[name]
+            lay = getattr(self, "_lay", {}).pop(name, None)
+            ex = lay[0] if lay is not None else self._ex[name]
             n_slots = G * ex.cap
             s = self.sweep_period if self.sweep_period is not None else max(8, math.ceil(t.n_rows / max(n_slots // 2, 1)))
-            self.ops.apply_grad(t, self._hyper(name), n_slots, ex.rows_send, t._grad_rows, s)
+            if lay is not None:     # this step's lookup went through a packed exchange (lookup_pair)
+                self.ops.apply_grad_at(t, self._hyper(name), n_slots, ex.rows_send, t._grad_rows, lay[1], ex.cap, ex.S, s)
+            else:
+                self.ops.apply_grad(t, self._hyper(name), n_slots, ex.rows_send, t._grad_rows, s)
             t._grad_rows = None
         live = [(name, d) for name, d in self._dense.items() if d.p.grad is not None and self._owned(name, group)]
         if not live:

@@ -24,13 +24,13 @@ def _free_port():
     return p
 
 
-def _data():
+def _data(world=2):
     g = torch.Generator().manual_seed(11)
     U0, I0 = torch.randn(NU, D, generator=g) * 0.3, torch.randn(NI, D, generator=g) * 0.3
     w0, b0 = torch.randn(D, generator=g) * 0.5, torch.zeros(1)
-    u = torch.randint(1, NU, (T, 2 * B), generator=g)
-    i = torch.randint(1, NI, (T, 2 * B), generator=g)
-    r = torch.randn(T, 2 * B, generator=g)
+    u = torch.randint(1, NU, (T, world * B), generator=g)
+    i = torch.randint(1, NI, (T, world * B), generator=g)
+    r = torch.randn(T, world * B, generator=g)
     return U0, I0, w0, b0, u, i, r
 
 
@@ -86,12 +86,38 @@ class _Ops:                        # CPU double of HipTableOps
         O.adam_dense_step_(table.weight, g, table.m, table.v, table.step, hyper.lr, hyper.weight_decay)
         table._pending = None
 
+    # --- one table's part of a packed exchange buffer: chunk g = `chunk` slots at offset `off`, chunks `stride` apart
+    def bucket_at(self, idx, G, cap, stride, off, send, slot, counts, err):
+        counts.zero_()
+        sv = send.view(G, stride)
+        sv[:, off:off + cap] = -1
+        for j, r in enumerate(idx.tolist()):
+            o, k = r % G, int(counts[r % G])
+            assert k < cap
+            sv[o, off + k], slot[j] = r // G, o * stride + off + k
+            counts[o] += 1
+
+    def gather_train_at(self, table, hyper, ids, off, M, chunk, stride, rows, err):
+        G = M // chunk
+        mine = ids.view(G, stride)[:, off:off + chunk].reshape(-1).clone()
+        table.ids = mine
+        ok = mine >= 0
+        out = torch.zeros((M, table.dim))
+        out[ok] = table.weight[mine[ok]]
+        rows.view(G, stride, table.dim)[:, off:off + chunk] = out.view(G, chunk, table.dim)
+        table._pending = (M, None)
+
+    def apply_grad_at(self, table, hyper, M, rows, grads, off, chunk, stride, sweep):
+        G = M // chunk
+        g = grads.view(G, stride, table.dim)[:, off:off + chunk].reshape(M, table.dim)
+        self.apply_grad(table, hyper, M, None, g, sweep)
+
     def adam_dense(self, p, g, m, v, hyper, step):
         from oracle import focf as O
         O.adam_dense_step_(p, g.clone(), m, v, step, hyper.lr, hyper.weight_decay)
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, mode="single"):
     for p in (ROOT, os.path.join(ROOT, "recbole-fairrec_amd"), os.path.join(ROOT, "tests")):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -100,10 +126,12 @@ def _worker(rank, world, port, out_dir):
     try:
         from fairrec.optim import AdamHyper
         from fairrec.sharded_engine import ShardedGenericEngine
-        U0, I0, w0, b0, u, i, r = _data()
+        U0, I0, w0, b0, u, i, r = _data(world)
         eng = ShardedGenericEngine("cpu", ops=_Ops())
         Us, Is = U0[rank::world].clone(), I0[rank::world].clone()
-        eng.add_table("U", torch.nn.Parameter(Us), table=_Table(Us), n_rows_global=NU)
+        frozen = mode == "pair_frozen_user"      # NFCF finetune: the user table is read-only
+        eng.add_table("U", torch.nn.Parameter(Us, requires_grad=not frozen), table=_Table(Us, trainable=not frozen),
+                      n_rows_global=NU)
         eng.add_table("I", torch.nn.Parameter(Is), table=_Table(Is), n_rows_global=NI)
         w, b = torch.nn.Parameter(w0.clone()), torch.nn.Parameter(b0.clone())
         eng.add_dense("w", w)
@@ -113,7 +141,11 @@ def _worker(rank, world, port, out_dir):
         for t in range(T):
             sl = slice(rank * B, (rank + 1) * B)
             eng.zero_grad()
-            loss = _loss(eng.lookup("U", u[t][sl]), eng.lookup("I", i[t][sl]), w, b, r[t][sl])
+            if mode == "single":
+                ue, ie = eng.lookup("U", u[t][sl]), eng.lookup("I", i[t][sl])
+            else:       # both tables through ONE packed exchange per direction
+                ue, ie = eng.lookup_pair("U", u[t][sl], "I", i[t][sl])
+            loss = _loss(ue, ie, w, b, r[t][sl])
             loss.backward()
             eng.backward_adam()
             losses.append(float(loss))
@@ -122,12 +154,14 @@ def _worker(rank, world, port, out_dir):
         dist.destroy_process_group()
 
 
-def test_two_rank_generic_engine_equals_single_process(tmp_path):
+@pytest.mark.parametrize("world,mode", [(2, "single"), (2, "pair"), (4, "pair"), (2, "pair_frozen_user")])
+def test_generic_engine_equals_single_process(tmp_path, world, mode):
     from oracle import focf as O
-    world = 2
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
-    U0, I0, w0, b0, u, i, r = _data()
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), mode), nprocs=world, join=True)
+    U0, I0, w0, b0, u, i, r = _data(world)
     P = [torch.nn.Parameter(x.clone()) for x in (U0, I0, w0, b0)]
+    if mode == "pair_frozen_user":
+        P[0].requires_grad_(False)
     ms, vs = [torch.zeros_like(p) for p in P], [torch.zeros_like(p) for p in P]
     ref_loss = []
     for t in range(T):
@@ -136,10 +170,11 @@ def test_two_rank_generic_engine_equals_single_process(tmp_path):
         loss = _loss(P[0][u[t]], P[1][i[t]], P[2], P[3], r[t])
         loss.backward()
         for k, p in enumerate(P):
-            O.adam_dense_step_(p.data, p.grad, ms[k], vs[k], t + 1, LR, WD)
+            if p.grad is not None:
+                O.adam_dense_step_(p.data, p.grad, ms[k], vs[k], t + 1, LR, WD)
         ref_loss.append(float(loss))
     parts = [torch.load(os.path.join(str(tmp_path), f"r{q}.pt")) for q in range(world)]
-    # the global loss is the mean of the two local means (equal batch sizes)
+    # the global loss is the mean of the local means (equal batch sizes)
     np.testing.assert_allclose(np.mean([p["loss"] for p in parts], axis=0), ref_loss, rtol=1e-5)
     for tag, ref in (("U", P[0]), ("I", P[1])):
         full = torch.zeros_like(ref.data)
