@@ -480,8 +480,8 @@ FR_API int fr_sample_negatives_calls(uint32_t* state, int64_t low, int64_t high,
 
 /* ---- evaluation metrics (next-row f-2), recbole/evaluator/metrics.py ------------------------------------------------
  *   fr_topk_metrics           : rec_topk int32 [n_users, k+1] = hit flags of the ranked list | number of positives
- *                               (collector.py:146-154) -> out[5][k] doubles = Hit, MRR, NDCG, Recall, Precision @ 1..k,
- *                               means over users (metrics.py:40-232)
+ *                               (collector.py:146-154) -> out[6][k] doubles = Hit, MRR, NDCG, Recall, Precision, MAP
+ *                               @ 1..k, means over users (metrics.py:40-232)
  *   fr_group_sums             : stats[s][g][0..2] = sum value, count, sum wtrue over the members
  *                               perm[seg_start[s] .. seg_start[s+1]) of segment s whose group index is g (perm = NULL:
  *                               identity).  The (item, group) tables of the fairness metrics (:948-970, :1322-1335)

@@ -11,7 +11,7 @@ import numpy as np
 
 
 def topk_metrics(rec_topk, topk):
-    """{'hit@k', 'mrr@k', 'ndcg@k', 'recall@k', 'precision@k'} means over users (base_metric.py:61-77)."""
+    """{'hit@k', 'mrr@k', 'ndcg@k', 'recall@k', 'precision@k', 'map@k'} means over users (base_metric.py:61-77)."""
     rec_topk = np.asarray(rec_topk)
     pos = rec_topk[:, :-1].astype(bool)
     pos_len = rec_topk[:, -1].astype(np.int64)
@@ -30,8 +30,13 @@ def topk_metrics(rec_topk, topk):
     idcg_len = np.minimum(pos_len, K)
     idcg = idcg_all[np.minimum(ranks[None, :], idcg_len[:, None]) - 1]
     ndcg = dcg / idcg
+    # MAP, metrics.py:127-139: sum_{j <= k, hit j} Precision@j over min(k, min(|positives|, K)) (all K when there are none)
+    sum_pre = np.cumsum(precision * pos, axis=1)
+    lens = np.minimum(pos_len, K)
+    denom = np.where(lens[:, None] > 0, np.minimum(ranks[None, :], np.maximum(lens, 1)[:, None]), K)
+    ap = sum_pre / denom
     out = {}
-    for name, val in (("hit", hit), ("mrr", mrr), ("ndcg", ndcg), ("recall", recall), ("precision", precision)):
+    for name, val in (("hit", hit), ("mrr", mrr), ("ndcg", ndcg), ("recall", recall), ("precision", precision), ("map", ap)):
         avg = val.mean(axis=0)
         for k in topk:
             out[f"{name}@{k}"] = float(avg[k - 1])

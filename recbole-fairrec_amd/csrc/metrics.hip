@@ -1,7 +1,7 @@
 // Evaluation metrics on the device: the reductions of recbole/evaluator/metrics.py without the host
 // round trip and without the reference's Python loops over interactions (:950-960) or over items x groups (:1331-1335).
 //
-//   topk_metrics_kernel      Hit / MRR / NDCG / Recall / Precision @ 1..K from the `rec.topk` matrix (:40-232)
+//   topk_metrics_kernel      Hit / MRR / NDCG / Recall / Precision / MAP @ 1..K from the `rec.topk` matrix (:40-232)
 //   group_sums_kernel        per (item segment, group): sum of scores, count, count of positives -- the tables every
 //                            fairness metric starts from (:948-970, :1322-1335); same segment machinery as the FOCF
 //                            fairness term (16 lanes per segment, fixed order)
@@ -19,7 +19,7 @@ __device__ __forceinline__ double wave_sum_d(double x) {
     return x;
 }
 
-// one wave per 64 users (lane = user); part[block][m][k], m = hit, mrr, ndcg, recall, precision
+// one wave per 64 users (lane = user); part[block][m][k], m = hit, mrr, ndcg, recall, precision, map
 __global__ __launch_bounds__(64) void topk_metrics_kernel(const int32_t* __restrict__ rec_topk, long long U, int K,
                                                           double* __restrict__ part) {
     const int lane = threadIdx.x;
@@ -29,8 +29,8 @@ __global__ __launch_bounds__(64) void topk_metrics_kernel(const int32_t* __restr
     const int pos_len = ok ? row[K] : 1;
     const int ilen = pos_len < K ? pos_len : K;
     int csum = 0;
-    double first_rr = 0.0, dcg = 0.0, idcg = 0.0;
-    double* out = part + (size_t)blockIdx.x * 5 * K;
+    double first_rr = 0.0, dcg = 0.0, idcg = 0.0, sum_pre = 0.0;
+    double* out = part + (size_t)blockIdx.x * 6 * K;
     for (int k = 0; k < K; ++k) {
         const bool hit = ok && row[k] != 0;
         const double disc = 1.0 / log2((double)(k + 2));
@@ -43,14 +43,18 @@ __global__ __launch_bounds__(64) void topk_metrics_kernel(const int32_t* __restr
         const double v2 = ok ? dcg / idcg : 0.0;
         const double v3 = ok ? (double)csum / (double)pos_len : 0.0;
         const double v4 = ok ? (double)csum / (double)(k + 1) : 0.0;
+        // MAP (metrics.py:100-139): sum over the hits so far of Precision@j, over min(k + 1, min(positives, K))
+        if (hit) sum_pre += (double)csum / (double)(k + 1);
+        const double v5 = ok && ilen > 0 ? sum_pre / (double)(k + 1 < ilen ? k + 1 : ilen) : 0.0;
         const double s0 = wave_sum_d(v0), s1 = wave_sum_d(v1), s2 = wave_sum_d(v2), s3 = wave_sum_d(v3),
-                     s4 = wave_sum_d(v4);
+                     s4 = wave_sum_d(v4), s5 = wave_sum_d(v5);
         if (lane == 0) {
             out[0 * K + k] = s0;
             out[1 * K + k] = s1;
             out[2 * K + k] = s2;
             out[3 * K + k] = s3;
             out[4 * K + k] = s4;
+            out[5 * K + k] = s5;
         }
     }
 }
@@ -186,7 +190,7 @@ __global__ __launch_bounds__(256) void fair_from_stats_kernel(const double* __re
 using namespace fr;
 
 extern "C" size_t fr_topk_metrics_workspace_bytes(int64_t n_users, int32_t k) {
-    return n_users < 1 || k < 1 ? 0 : (size_t)((n_users + 63) / 64) * 5 * k * sizeof(double);
+    return n_users < 1 || k < 1 ? 0 : (size_t)((n_users + 63) / 64) * 6 * k * sizeof(double);
 }
 
 extern "C" int fr_topk_metrics(const int32_t* rec_topk, int64_t n_users, int32_t k, double* out, void* ws, size_t ws_bytes,
@@ -198,8 +202,8 @@ extern "C" int fr_topk_metrics(const int32_t* rec_topk, int64_t n_users, int32_t
     hipLaunchKernelGGL(topk_metrics_kernel, dim3((unsigned)blocks), dim3(64), 0, stream, rec_topk, (long long)n_users, (int)k,
                        (double*)ws);
     FR_CHECK_LAUNCH();
-    hipLaunchKernelGGL(column_sum_kernel, dim3((unsigned)((5 * k + 255) / 256)), dim3(256), 0, stream, (const double*)ws,
-                       blocks, 5 * k, 1.0 / (double)n_users, out);
+    hipLaunchKernelGGL(column_sum_kernel, dim3((unsigned)((6 * k + 255) / 256)), dim3(256), 0, stream, (const double*)ws,
+                       blocks, 6 * k, 1.0 / (double)n_users, out);
     FR_CHECK_LAUNCH();
     return FR_OK;
 }

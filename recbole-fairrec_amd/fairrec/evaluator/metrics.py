@@ -23,13 +23,13 @@ def topk_metrics(rec_topk: torch.Tensor, topk: Iterable[int]) -> Dict[str, float
     lib = _C.lib()
     rec = rec_topk.to(torch.int32).contiguous()
     U, K = rec.shape[0], rec.shape[1] - 1
-    out = torch.empty(5 * K, dtype=torch.float64, device=rec.device)
+    out = torch.empty(6 * K, dtype=torch.float64, device=rec.device)
     ws = torch.empty(lib.fr_topk_metrics_workspace_bytes(U, K), dtype=torch.uint8, device=rec.device)
     _C.check(lib.fr_topk_metrics(rec.data_ptr(), U, K, out.data_ptr(), ws.data_ptr(), ws.numel(), _C.current_stream()),
              "fr_topk_metrics")
-    vals = out.view(5, K).cpu()
+    vals = out.view(6, K).cpu()
     res = {}
-    for m, name in enumerate(("hit", "mrr", "ndcg", "recall", "precision")):
+    for m, name in enumerate(("hit", "mrr", "ndcg", "recall", "precision", "map")):
         for k in topk:
             res[f"{name}@{k}"] = float(vals[m, k - 1])
     return res
@@ -181,7 +181,7 @@ def tail_percentage(rec_items, count_items, topk, tail_ratio=None) -> Dict[str, 
 class Evaluator:
     """recbole/evaluator/evaluator.py: metric names from `config['metrics']` -> one result dict."""
 
-    TOPK = {"hit", "mrr", "ndcg", "recall", "precision"}
+    TOPK = {"hit", "mrr", "ndcg", "recall", "precision", "map"}
     EXPOSURE = {"giniindex", "popularitypercentage", "itemcoverage", "averagepopularity", "shannonentropy", "tailpercentage"}
     FAIR = {"nonparityunfairness", "valueunfairness", "absoluteunfairness", "underunfairness", "overunfairness",
             "differentialfairness"}

@@ -28,7 +28,7 @@ class _Cfg(dict):
         return self.get(k, None)
 
 
-TOPK_METRICS = ["Hit", "MRR", "NDCG", "Recall", "Precision"]
+TOPK_METRICS = ["Hit", "MRR", "NDCG", "Recall", "Precision", "MAP"]
 FAIR_METRICS = ["NonParityUnfairness", "ValueUnfairness", "AbsoluteUnfairness", "UnderUnfairness", "OverUnfairness",
                 "DifferentialFairness"]
 

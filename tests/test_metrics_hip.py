@@ -29,7 +29,7 @@ def test_device_metrics_match_reference_golden(path):
     z = np.load(path)
     ref = json.loads(str(z["result_json"]))
     sst = ["gender"] + (["age"] if "age" in z.files else [])
-    metrics = ["Hit", "MRR", "NDCG", "Recall", "Precision", "NonParityUnfairness", "DifferentialFairness"]
+    metrics = ["Hit", "MRR", "NDCG", "Recall", "Precision", "MAP", "NonParityUnfairness", "DifferentialFairness"]
     if len(sst) == 1:
         metrics += ["ValueUnfairness", "AbsoluteUnfairness", "UnderUnfairness", "OverUnfairness"]
     cfg = Config(config_dict={"metrics": metrics, "topk": [int(k) for k in z["topk"]], "metric_decimal_place": 10,
