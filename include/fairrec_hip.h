@@ -257,6 +257,14 @@ FR_API int fr_table_gather(const fr_table* t, const fr_adam* adam, const int64_t
  * [G, T, cap, ...] all-to-all buffer (multi-GPU path), so the exchange needs no packing copies.
  */
 FR_API size_t fr_table_train_workspace_bytes(int64_t M, int32_t dim);
+/* The first fr_table_segments_bytes(M) bytes of a workspace hold the sorted segments of the id list (independent of the
+ * table's width).  fr_table_gather_train_prepared skips the sort: the caller has put the segments of `idx` there, e.g. by
+ * copying them from the workspace of another table with the same number of rows looked up with the same ids in this step
+ * (PFCN_BiasedMF's bias tables next to the embedding tables, pfcn_biasedmf.py:186-190). */
+FR_API size_t fr_table_segments_bytes(int64_t M);
+FR_API int fr_table_gather_train_prepared(const fr_table* t, const fr_adam* adam, const int64_t* idx, int64_t M,
+                                          int32_t chunk, int32_t stride, float* rows_out, void* ws, size_t ws_bytes,
+                                          uint32_t* err_flag, void* stream);
 FR_API int fr_table_gather_train(const fr_table* t, const fr_adam* adam, const int64_t* idx, int64_t M, int32_t chunk,
                                  int32_t stride, float* rows_out, void* ws, size_t ws_bytes, uint32_t* err_flag,
                                  void* stream);

@@ -292,6 +292,23 @@ extern "C" int fr_table_gather_train(const fr_table* t, const fr_adam* adam, con
                              ws, nullptr, ws_bytes, err_flag, (hipStream_t)stream_);
 }
 
+// The same with the segments of `idx` already in ws (FR_TABLE_PREPARED), e.g. copied from the workspace of another table
+// that was looked up with the SAME id list in this step (fr_table_segments_bytes leading bytes of a workspace hold them,
+// whatever the table's width): a bias table next to its embedding table needs no second sort.
+extern "C" size_t fr_table_segments_bytes(int64_t M) {
+    if (M < 1) return 0;
+    char* const base = reinterpret_cast<char*>(256);      // (table_layout hands out null pointers for a null base)
+    TableWs w = table_layout(base, M, 1);
+    return (size_t)((char*)w.m_side - base);
+}
+
+extern "C" int fr_table_gather_train_prepared(const fr_table* t, const fr_adam* adam, const int64_t* idx, int64_t M,
+                                              int32_t chunk, int32_t stride, float* rows_out, void* ws, size_t ws_bytes,
+                                              uint32_t* err_flag, void* stream_) {
+    return gather_train_impl("fr_table_gather_train_prepared", t, nullptr, adam, idx, nullptr, M, chunk, stride, rows_out,
+                             nullptr, ws, nullptr, ws_bytes, err_flag, (hipStream_t)stream_, true);
+}
+
 extern "C" int fr_table_gather_train2(const fr_table* ta, const fr_table* tb, const fr_adam* adam, const int64_t* idx_a,
                                       const int64_t* idx_b, int64_t M, int32_t chunk, int32_t stride, float* rows_a,
                                       float* rows_b, int32_t flags, void* ws_a, void* ws_b, size_t ws_bytes,

@@ -73,8 +73,11 @@ _PROTOS = {
     "fr_table_gather": (c_int, [POINTER(FrTable), POINTER(FrAdam), c_void_p, c_int64, c_void_p, c_void_p,
                                 c_void_p]),
     "fr_table_train_workspace_bytes": (c_size_t, [c_int64, c_int32]),
+    "fr_table_segments_bytes": (c_size_t, [c_int64]),
     "fr_table_gather_train": (c_int, [POINTER(FrTable), POINTER(FrAdam), c_void_p, c_int64, c_int32, c_int32, c_void_p,
                                       c_void_p, c_size_t, c_void_p, c_void_p]),
+    "fr_table_gather_train_prepared": (c_int, [POINTER(FrTable), POINTER(FrAdam), c_void_p, c_int64, c_int32, c_int32,
+                                               c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
     "fr_table_apply_grad": (c_int, [POINTER(FrTable), POINTER(FrAdam), c_int64, c_int32, c_int32, c_void_p, c_void_p,
                                     c_int32, c_void_p, c_size_t, c_void_p]),
     "fr_bucket_by_owner": (c_int, [c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p,

@@ -47,6 +47,8 @@ class GenericEngine:
         self._advance_idx: Dict[tuple, torch.Tensor] = {}
 
     # --- graph mode: step counters on the device ----------------------------------------------------------
+    _seg_src: dict = {}     # (id tensor, rows) -> the table whose workspace holds that id list's segments, this step only
+
     def enable_graph_mode(self):
         """Move every step counter to device memory, so that a training step captured in a hipGraph advances them on
         replay (fairrec/graph.py).  From here on the device values are authoritative; `sync_steps()` refreshes the
@@ -123,7 +125,13 @@ class GenericEngine:
         t = self._tables[name]
         idx = idx.to(self.device, torch.int64).contiguous()
         if t.trainable and torch.is_grad_enabled():
-            return LazyLookup.apply(self._weights[name], t, self._hyper(name), idx, self.err_flag)
+            # a table with as many rows already looked up with this very id tensor in this step has the sorted segments
+            key = (idx.data_ptr(), idx.numel(), t.n_rows)
+            src = self._seg_src.get(key)
+            if src is None or src is t:
+                self._seg_src[key] = t
+                src = None
+            return LazyLookup.apply(self._weights[name], t, self._hyper(name), idx, self.err_flag, src)
         return t.gather(self._hyper(name), idx, self.err_flag)
 
     def lookup_pair(self, name_a: str, idx_a: torch.Tensor, name_b: str, idx_b: torch.Tensor):
@@ -144,6 +152,7 @@ class GenericEngine:
         of a tensor that the owning optimizer's next zero_grad() frees, and every later replay writes through it."""
         for name, d in self._dense.items():
             d.p.grad = None
+        self._seg_src = {}
         for name, t in self._tables.items():
             if self._owned(name, group):
                 t._grad_rows = None
@@ -197,6 +206,7 @@ class GenericEngine:
 
     def backward_adam(self, group=None):
         self.note_stepped(group)
+        self._seg_src = {}
         stepped = []
         for name, t in self._tables.items():
             if not (t.trainable and t._pending is not None):

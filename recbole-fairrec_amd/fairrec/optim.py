@@ -150,19 +150,22 @@ class LazyTable:
         return out
 
     # --- generic training pair (models with an MLP between the embeddings and the loss) -----------------
-    def gather_train(self, hyper: AdamHyper, idx: torch.Tensor, err_flag: Optional[torch.Tensor] = None) -> torch.Tensor:
+    def gather_train(self, hyper: AdamHyper, idx: torch.Tensor, err_flag: Optional[torch.Tensor] = None,
+                     segments_of: Optional["LazyTable"] = None) -> torch.Tensor:
         """fr_table_gather_train for step `self.step + 1`: caught-up rows [M, dim]; remembers the batch so that
-        `apply_grad` can finish the step."""
+        `apply_grad` can finish the step.  `segments_of` = a table with as many rows that was looked up with the SAME id
+        tensor in this step: its sorted segments are copied instead of sorting again (a bias table next to its embedding
+        table)."""
         idx = idx.contiguous()
         M = idx.numel()
         rows = torch.empty((M, self.dim), dtype=torch.float32, device=self.weight.device)
-        self.gather_train_into(hyper, idx.data_ptr(), M, rows.data_ptr(), err_flag=err_flag)
+        self.gather_train_into(hyper, idx.data_ptr(), M, rows.data_ptr(), err_flag=err_flag, segments_of=segments_of)
         self._pending = (M, rows)
         self._keep = idx
         return rows
 
     def gather_train_into(self, hyper: AdamHyper, idx_ptr: int, M: int, rows_ptr: int, chunk: int = 0, stride: int = 0,
-                          err_flag: Optional[torch.Tensor] = None):
+                          err_flag: Optional[torch.Tensor] = None, segments_of: Optional["LazyTable"] = None):
         """The same on raw device pointers with a slot layout (fairrec_hip.h): M ids read from / M rows written into
         exchange buffers in place.  The caller keeps the buffers alive until `apply_grad_from`."""
         need = _C.lib().fr_table_train_workspace_bytes(M, self.dim)
@@ -170,9 +173,17 @@ class LazyTable:
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.weight.device)
         t = self.c(self.step + 1)
         hyper.check_step(self.step + 1)
-        _C.check(_C.lib().fr_table_gather_train(ctypes.byref(t), ctypes.byref(hyper.c()), idx_ptr, M, chunk, stride,
-                                                rows_ptr, self._ws.data_ptr(), self._ws.numel(), _C.ptr(err_flag),
-                                                _C.current_stream()), "fr_table_gather_train")
+        if segments_of is not None and segments_of._ws is not None and segments_of.n_rows == self.n_rows:
+            n = _C.lib().fr_table_segments_bytes(M)
+            self._ws[:n].copy_(segments_of._ws[:n])
+            _C.check(_C.lib().fr_table_gather_train_prepared(ctypes.byref(t), ctypes.byref(hyper.c()), idx_ptr, M, chunk,
+                                                             stride, rows_ptr, self._ws.data_ptr(), self._ws.numel(),
+                                                             _C.ptr(err_flag), _C.current_stream()),
+                     "fr_table_gather_train_prepared")
+        else:
+            _C.check(_C.lib().fr_table_gather_train(ctypes.byref(t), ctypes.byref(hyper.c()), idx_ptr, M, chunk, stride,
+                                                    rows_ptr, self._ws.data_ptr(), self._ws.numel(), _C.ptr(err_flag),
+                                                    _C.current_stream()), "fr_table_gather_train")
         self._pending = (M, None)
         self._grad_rows = None
 
@@ -281,15 +292,15 @@ class LazyLookup(torch.autograd.Function):
     of nn.Embedding is never built."""
 
     @staticmethod
-    def forward(ctx, weight, table, hyper, idx, err_flag):
+    def forward(ctx, weight, table, hyper, idx, err_flag, segments_of=None):
         ctx.table = table
-        return table.gather_train(hyper, idx, err_flag)
+        return table.gather_train(hyper, idx, err_flag, segments_of)
 
     @staticmethod
     def backward(ctx, grad_rows):
         t = ctx.table
         t._grad_rows = grad_rows if t._grad_rows is None else t._grad_rows + grad_rows
-        return None, None, None, None, None
+        return None, None, None, None, None, None
 
 
 class FusedLazyAdam:
