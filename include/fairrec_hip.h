@@ -514,7 +514,11 @@ FR_API int fr_fair_metrics_from_stats(const double* stats, int64_t n_segments, i
 /* ---- built-in profiler -------------------------------------------------------------------------------
  * When enabled every kernel launch of this library is bracketed by a hipEvent pair recorded on the
  * launch stream; fr_prof_read synchronises the outstanding events and returns the accumulated device
- * time and launch count of one kernel kind (bench.py's `roofline.achieved` comes from here). */
+ * time and launch count of one kernel kind (bench.py's `roofline.achieved` comes from here).
+ * Process-global diagnostic state (one table of kernel kinds per process = per GPU), guarded by a mutex: any thread may
+ * launch while it is on, the counts of all threads are summed; enable / reset / read from one thread at a time.  Apart
+ * from this table, the library's helper stream and the last-error string (thread-local), the entry points keep no state
+ * between calls: everything lives in the caller's tables and workspaces. */
 FR_API int fr_prof_enable(int on);
 FR_API int fr_prof_reset(void);
 FR_API int fr_prof_kernel_count(void);
