@@ -141,7 +141,8 @@ def seed_all(seed: int):
 
 class Sampler:
     """recbole.sampler.Sampler (sampler.py:200-303): negative items per user, never one of the user's positive items
-    of the current or an earlier phase.  Distribution 'uniform' (the reference default, overall.yaml)."""
+    of the current or an earlier phase.  Distribution 'uniform' (the reference default, overall.yaml) on the device,
+    'popularity' with numpy on the shared stream."""
 
     def __init__(self, phases, datasets, distribution='uniform', device=None, random_state: Optional[DeviceRandomState] = None):
         if not isinstance(phases, list):
@@ -150,8 +151,8 @@ class Sampler:
             datasets = [datasets]
         if len(phases) != len(datasets):
             raise ValueError(f'Phases {phases} and datasets {datasets} should have the same length.')
-        if distribution != 'uniform':
-            raise NotImplementedError(f'The sampling distribution [{distribution}] is not implemented on the device path.')
+        if distribution not in ('uniform', 'popularity'):
+            raise NotImplementedError(f'The sampling distribution [{distribution}] is not implemented.')
         self.phases, self.datasets, self.distribution = phases, datasets, distribution
         self.uid_field, self.iid_field = datasets[0].uid_field, datasets[0].iid_field
         self.user_num, self.item_num = datasets[0].user_num, datasets[0].item_num
@@ -159,6 +160,8 @@ class Sampler:
         self.rs = random_state if random_state is not None else global_random_state(self.device)
         self.used_ids = self.get_used_ids()
         self.phase = None
+        if distribution == 'popularity':
+            self._build_alias_table()
 
     def get_used_ids(self):
         """Per phase a CSR (indptr int64 [user_num+1], items int32 sorted per user) of the items used up to and
@@ -179,6 +182,65 @@ class Sampler:
                              'them. Please set `user_inter_num_interval` to filter those users.')
         return out
 
+    # --- popularity-biased sampling (sampler.py:72-118): alias method over the items of all phases' interactions.  Not a
+    # device kernel: the draws are numpy's (`randint` for the slot, `random` for the coin), made inside
+    # `host_numpy_stream()` so that they sit at the reference's position of the ONE generator stream the device sampler
+    # shares with numpy -- same ids as the reference, at host speed (the uniform default runs on the device).
+    def _build_alias_table(self):
+        from collections import Counter
+        cand = []
+        for ds in self.datasets:                                   # _get_candidates_list, sampler.py:229-233
+            cand.extend(ds.inter_feat[self.iid_field].cpu().numpy())
+        prob = dict(Counter(cand))                                 # insertion order = first occurrence, as in the reference
+        alias = prob.copy()
+        large_q, small_q = [], []
+        for i in prob:
+            alias[i] = -1
+            prob[i] = prob[i] / len(cand) * len(prob)
+            if prob[i] > 1:
+                large_q.append(i)
+            elif prob[i] < 1:
+                small_q.append(i)
+        while len(large_q) != 0 and len(small_q) != 0:
+            l, s = large_q.pop(0), small_q.pop(0)
+            alias[s] = l
+            prob[l] = prob[l] - (1 - prob[s])
+            if prob[l] < 1:
+                small_q.append(l)
+            elif prob[l] > 1:
+                large_q.append(l)
+        keys = np.array(list(prob.keys()), dtype=np.int64)
+        self._pop = (keys, np.array([prob[k] for k in keys], dtype=np.float64),
+                     np.array([alias[k] for k in keys], dtype=np.int64))
+
+    def _pop_sampling(self, n):
+        keys, prob, alias = self._pop
+        idx = np.random.randint(0, len(keys), n)
+        coin = np.random.random(n)
+        return np.where(prob[idx] > coin, keys[idx], alias[idx])
+
+    def _pop_sample_by_user_ids(self, user_ids, num):
+        indptr, items, _ = self.used_ids
+        if not hasattr(self, "_used_host") or self._used_host[0] is not indptr:
+            self._used_host = (indptr, indptr.cpu().numpy(), items.cpu().numpy().astype(np.int64))
+        _, ip, it = self._used_host
+        keys = np.tile(np.asarray(user_ids.cpu() if torch.is_tensor(user_ids) else user_ids, dtype=np.int64), num)
+        used_key = keys * self.item_num                            # membership in the user's used-set = a sorted (user, item) key
+        allk = np.repeat(np.arange(self.user_num, dtype=np.int64), np.diff(ip)) * self.item_num + it
+        value = np.zeros(len(keys), dtype=np.int64)
+        check = np.arange(len(keys))
+        np.random.set_state(self.rs.get_state())                   # numpy continues the stream where the device mirror stands ...
+        while len(check) > 0:                                      # sample_by_key_ids, sampler.py:178-195
+            value[check] = self._pop_sampling(len(check))
+            k = used_key[check] + value[check]
+            pos = np.searchsorted(allk, k)
+            hit = (pos < len(allk)) & (allk[np.minimum(pos, len(allk) - 1)] == k)
+            check = check[hit]
+        st = np.random.get_state()                                 # ... and hands it back
+        for rs in ([self.rs] if self.rs not in _GLOBAL.values() else list(_GLOBAL.values())):
+            rs.set_state(st)
+        return torch.from_numpy(value).to(self.device)
+
     def set_phase(self, phase):
         if phase not in self.phases:
             raise ValueError(f'Phase [{phase}] not exist.')
@@ -194,5 +256,7 @@ class Sampler:
             raise ValueError('call set_phase() first')
         if not torch.is_tensor(user_ids):
             user_ids = torch.as_tensor(np.asarray(user_ids), dtype=torch.int64)
+        if self.distribution == 'popularity':
+            return self._pop_sample_by_user_ids(user_ids, int(num))
         indptr, items, _ = self.used_ids
         return self.rs.sample_excluding(1, self.item_num, user_ids, int(num), indptr, items)

@@ -30,7 +30,7 @@ class _DS:
         self.inter_feat = {"user_id": torch.from_numpy(u), "item_id": torch.from_numpy(i)}
 
 
-def run_case(name, seed, user_num, item_num, n_inter, calls, heavy=()):
+def run_case(name, seed, user_num, item_num, n_inter, calls, heavy=(), distribution="uniform"):
     rng = np.random.default_rng(seed)
     u = rng.integers(1, user_num, size=n_inter).astype(np.int64)
     i = rng.integers(1, item_num, size=n_inter).astype(np.int64)
@@ -38,8 +38,8 @@ def run_case(name, seed, user_num, item_num, n_inter, calls, heavy=()):
         items = rng.choice(np.arange(1, item_num), size=int(frac * (item_num - 1)), replace=False)
         u = np.concatenate([u, np.full(len(items), hu, dtype=np.int64)])
         i = np.concatenate([i, items.astype(np.int64)])
-    sampler = Sampler("train", _DS(user_num, item_num, u, i), "uniform").set_phase("train")
-    out = {"seed": np.array(seed), "user_num": np.array(user_num), "item_num": np.array(item_num),
+    sampler = Sampler("train", _DS(user_num, item_num, u, i), distribution).set_phase("train")
+    out = {"distribution": np.array(distribution), "seed": np.array(seed), "user_num": np.array(user_num), "item_num": np.array(item_num),
            "train_user": u, "train_item": i, "n_calls": np.array(len(calls))}
     np.random.seed(seed)
     for c, (kind, n, num) in enumerate(calls):
@@ -70,6 +70,9 @@ def main():
              heavy=((3, 0.95), (4, 0.80), (5, 0.50)))
     run_case("pow2_range", 11, 300, 1026, 3000, [("mixed", 1500, 1), ("mixed", 1, 1), ("mixed", 625, 2)])   # rng = 1024-... mask edge
     run_case("tiny_catalogue", 5, 40, 5, 12, [("mixed", 100, 1)])        # item_num - 2 = 3: two-bit mask, no rejection by range
+    # popularity-biased sampling (alias method, sampler.py:72-118): randint for the slot + random() for the coin
+    run_case("popularity", 3, 200, 400, 5000, [("mixed", 1000, 1), ("same", 200, 1), ("mixed", 300, 2)], heavy=((7, 0.5),),
+             distribution="popularity")
     run_case("large", 2020, 20000, 100001, 200000, [("mixed", 8192, 1), ("mixed", 8192, 1), ("mixed", 4096, 2)])
 
 

@@ -10,7 +10,8 @@ import pytest
 from oracle import sampler as OS
 
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
-CASES = sorted(glob.glob(os.path.join(GOLDEN, "sampler_*.npz")))
+CASES = sorted(p for p in glob.glob(os.path.join(GOLDEN, "sampler_*.npz"))
+               if not p.endswith("sampler_popularity.npz"))   # the oracle restates the uniform sampler; popularity IS numpy (GPU test)
 
 
 @pytest.mark.parametrize("seed", [0, 1, 5, 2020, 2 ** 32 - 1])

@@ -69,7 +69,8 @@ def test_sampler_matches_reference_golden(path):
     z = np.load(path)
     item_num, user_num = int(z["item_num"]), int(z["user_num"])
     rs = _rs(int(z["seed"]))
-    sampler = Sampler("train", _DS(user_num, item_num, z["train_user"], z["train_item"]), "uniform", device="cuda",
+    dist = str(z["distribution"]) if "distribution" in z.files else "uniform"      # "popularity": numpy draws on the shared stream
+    sampler = Sampler("train", _DS(user_num, item_num, z["train_user"], z["train_item"]), dist, device="cuda",
                       random_state=rs).set_phase("train")
     for c in range(int(z["n_calls"])):
         users = z[f"users{c}"]
