@@ -310,7 +310,7 @@ def main():
         eng.defer_loss = True     # every forward below is followed by backward_adam; the loss is read at the end
         eng.item_runs = args.item_dist == "grouped"    # what the Trainer sets when it is fed by FOCFDataLoader
     else:
-        from fairrec.sharded import ShardedFocfEngine, shard_rows
+        from fairrec.sharded import ShardedFocfEngine, ShardedFocfEngineV2, shard_rows
         if not torch.distributed.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29655")
@@ -318,7 +318,15 @@ def main():
         g = torch.Generator(device="cpu").manual_seed(SEED + 1 + 1000 * rank)
         Us = (torch.randn(shard_rows(N_USERS, rank, world), DIM, generator=g) * math.sqrt(2.0 / (N_USERS + DIM))).to(dev)
         Is = (torch.randn(shard_rows(N_ITEMS, rank, world), DIM, generator=g) * math.sqrt(2.0 / (N_ITEMS + DIM))).to(dev)
-        eng = ShardedFocfEngine(Us, Is, OBJECTIVE, FAIR_WEIGHT, LR, WD, sweep_period=args.sweep)
+        # Two exchange schedules.  "item_owner": 2 all-to-alls on the step's dependent chain (the index exchanges run a step
+        # ahead), the default over real links; "requester": 4, but one collective and a few launches fewer in all, which
+        # wins where a collective is a local copy (one rank: 93 us against 107 us).  FAIRREC_SHARD_SCHEDULE overrides.
+        schedule = os.environ.get("FAIRREC_SHARD_SCHEDULE", "item_owner" if world > 1 else "requester")
+        if schedule not in ("item_owner", "requester"):
+            raise SystemExit("FAIRREC_SHARD_SCHEDULE must be item_owner or requester")
+        Eng = ShardedFocfEngineV2 if schedule == "item_owner" else ShardedFocfEngine
+        eng = Eng(Us, Is, OBJECTIVE, FAIR_WEIGHT, LR, WD, sweep_period=args.sweep)
+        eng.defer_loss = True       # (V2) the step loop reads no loss: its all-reduce runs after the update
 
     n_batches = u.shape[0]
 
@@ -336,7 +344,7 @@ def main():
 
     def step(k):
         if sharded:   # look-ahead of the index work, not across the warm-up / captured-graph boundary
-            nxt = (u[k + 1], i[k + 1], s[k + 1]) if k + 1 < n_batches and k != W - 1 else None
+            nxt = (u[k + 1], i[k + 1], s[k + 1], r[k + 1]) if k + 1 < n_batches and k != W - 1 else None
             eng.forward(u[k], i[k], r[k], s[k], next_batch=nxt)
         else:         # the dataloader-style queue runs through: the warm-up steps already announce the first timed batches
             eng.forward(u[k], i[k], r[k], s[k], next_batch=coming(k, u, i, s, r))
@@ -433,7 +441,7 @@ def main():
     _C.prof_enable(rank == 0)
     for k in range(K):
         if sharded:
-            nxt = (u2[k + 1], i2[k + 1], s2[k + 1]) if k + 1 < K else None
+            nxt = (u2[k + 1], i2[k + 1], s2[k + 1], r2[k + 1]) if k + 1 < K else None
         else:
             nxt = coming(k, u2, i2, s2, r2)
         eng.forward(u2[k], i2[k], r2[k], s2[k], next_batch=nxt)
@@ -483,7 +491,10 @@ def main():
             "config": {"workload": "FOCF fair_objective=value, 1000001 users x 100001 items, embedding_size=64, "
                                    "B=8192 per GPU, Adam lr=1e-3 weight_decay=1e-3 (BASELINE.json configs[1])",
                        "item_distribution": args.item_dist, "launch": launch, "launch_modes_timed": other,
-                       "step": ("gather / fair / backward_adam chain over 5 all-to-alls" if sharded else
+                       "step": (("item-owner-computes: records and user-row requests exchanged one step ahead; gather -> all-to-all(user rows) -> "
+                                 "score / fair / grads -> all-to-all(user gradients) -> apply" if sharded and
+                                 schedule == "item_owner" else
+                                 "gather / fair / backward_adam chain over 5 all-to-alls") if sharded else
                                 "ONE launch per step (fr_focf_step: gather + lazy-Adam replay + dot + fairness + backward + Adam + "
                                 "sweep slice); id columns of 16 coming batches sorted and packed per fork of the side stream"),
                        "lazy_adam_sweep_period": eng._sweep(BATCH) if not sharded else args.sweep,

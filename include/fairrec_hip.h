@@ -304,6 +304,27 @@ FR_API int fr_bucket_by_owner(const int64_t* idx, int64_t M, int32_t G, int32_t 
                               uint32_t* err_flag, void* stream);
 /* Two id lists of the same length in ONE launch (one workgroup each): list a at offset_a, list b at offset_b of the
  * same [G, stride] buffer; counts = [2, G]; aux / aux_slot as above (computed by list b's workgroup). */
+/* Item-owner-computes schedule of the row-sharded FOCF step (fairrec/sharded.py, ShardedFocfEngineV2): every interaction is
+ * sent to the rank that owns its item row.  A record chunk is [4 * cap + 1] int64: item local rows (fr_bucket_by_owner with
+ * stride 4 * cap + 1, offset 0; -1 = empty) | user ids | rating bits | sst bits | the sender's (min, max) of sst (the bucket
+ * kernel's aux pair).  fr_shard_pack_records fills planes 1-3 at the slots the bucket kernel assigned; the receiver's
+ * fr_shard_unpack_records turns its G chunks into per-slot arrays (item row, user id, own slot index or -1, rating or 0,
+ * sst) and the G (min, max) pairs.  fr_shard_post_fair / fr_shard_loss_finish: see csrc/shard.hip. */
+FR_API int fr_shard_pack_records(const int32_t* slot, const int64_t* user, const float* rating, const float* sst, int64_t B,
+                                 int32_t cap, int64_t* send, void* stream);
+FR_API int fr_shard_unpack_records(const int64_t* recv, int32_t G, int32_t cap, int64_t* iid, int64_t* uid, int32_t* islot,
+                                   float* rating, float* sst, int64_t* mm, void* stream);
+/* out[0] = number of distinct ids >= 0 of the list; bitmap = (n_rows + 31) / 32 words, all zero before and after; count = one
+ * zero int32, zero again afterwards. */
+FR_API int fr_shard_count_distinct(const int64_t* ids, int64_t n, int64_t n_rows, uint32_t* bitmap, int32_t* count, float* out,
+                                   void* stream);
+FR_API int fr_shard_post_fair(float* reply, const float* k_all, int32_t G, int32_t cap, float* sums, void* stream);
+FR_API int fr_shard_loss_finish(const float* sums, const float* k_all, int32_t G, int64_t n_global, float fair_weight,
+                                int32_t fair, float* loss, void* stream);
+/* fr_bucket_by_owner for a list with EMPTY positions (id -1, the padding of a received exchange buffer): they are
+ * given to no owner (slot -1) and raise no error. */
+FR_API int fr_bucket_by_owner_sparse(const int64_t* idx, int64_t M, int32_t G, int32_t cap, int32_t stride, int32_t offset,
+                                     int64_t* send_ids, int32_t* slot_of, int32_t* counts, uint32_t* err_flag, void* stream);
 FR_API int fr_bucket_pair_by_owner(const int64_t* idx_a, const int64_t* idx_b, int64_t M, int32_t G, int32_t cap,
                                    int32_t stride, int32_t offset_a, int32_t offset_b, int64_t* send_ids,
                                    int32_t* slot_a, int32_t* slot_b, int32_t* counts, const float* aux,

@@ -83,11 +83,13 @@ static BucketPlan bucket_plan(int64_t M, int G, int cap) {
 
 // One workgroup per id list (blockIdx.x).  Row ids are < 2^31 (checked by the table kernels), so owner and local row
 // come from 32-bit division.
+// holes: an id of -1 is an empty position (it goes to no owner, slot -1, no error) instead of an out-of-range id.
 __global__ __launch_bounds__(BUCKET_THREADS) void bucket_by_owner_kernel(BucketJob j0, BucketJob j1, int M, int G,
                                                                          int cap, int stride, int stage_ids,
                                                                          int stage_send,
                                                                          int64_t* __restrict__ send_ids,
-                                                                         uint32_t* err) {
+                                                                         uint32_t* err, int holes) {
+    constexpr unsigned HOLE = 0xFFFFFFFFu;
     extern __shared__ __align__(16) unsigned char smem[];
     const BucketJob job = blockIdx.x == 0 ? j0 : j1;
     const int64_t* __restrict__ idx = job.idx;
@@ -115,20 +117,25 @@ __global__ __launch_bounds__(BUCKET_THREADS) void bucket_by_owner_kernel(BucketJ
     if (stage_ids) {
         for (int j = tid; j < M; j += BUCKET_THREADS) {
             const long long r64 = idx[j];
-            const bool oob = r64 < 0 || r64 > 0x7fffffffll;
+            const bool hole = holes && r64 == -1;
+            const bool oob = !hole && (r64 < 0 || r64 > 0x7fffffffll);
             bad |= oob;
-            ids[pad(j)] = oob ? 0u : (unsigned)r64;
+            ids[pad(j)] = hole ? HOLE : (oob ? 0u : (unsigned)r64);
         }
         __syncthreads();
     }
     auto id_at = [&](int j) -> unsigned {
         if (stage_ids) return ids[tid * Cp + (j - lo)];
         const long long r64 = idx[j];
+        if (holes && r64 == -1) return HOLE;
         const bool oob = r64 < 0 || r64 > 0x7fffffffll;
         bad |= oob;
         return oob ? 0u : (unsigned)r64;
     };
-    for (int j = lo; j < hi; ++j) cnt[owner(id_at(j)) * BUCKET_THREADS + tid] += 1;
+    for (int j = lo; j < hi; ++j) {
+        const unsigned r = id_at(j);
+        if (r != HOLE) cnt[owner(r) * BUCKET_THREADS + tid] += 1;
+    }
     auto publish = [&](int o, int total) {
         tot[o] = total < cap ? total : cap;
         job.counts[o] = total < cap ? total : cap;
@@ -158,8 +165,9 @@ __global__ __launch_bounds__(BUCKET_THREADS) void bucket_by_owner_kernel(BucketJ
     __syncthreads();   // the -1 fill (other threads' stores) is complete before the real ids overwrite it
     for (int j = lo; j < hi; ++j) {
         const unsigned r = id_at(j);
-        const int o = owner(r);
-        const int k = cnt[o * BUCKET_THREADS + tid]++;
+        const bool hole = r == HOLE;
+        const int o = hole ? 0 : owner(r);
+        const int k = hole ? cap : cnt[o * BUCKET_THREADS + tid]++;
         const int slot = k < cap ? o * stride + offset + k : -1;
         if (k < cap) {
             if (stage_send) sendst[o * cap + k] = local(r);
@@ -235,12 +243,145 @@ __global__ __launch_bounds__(256) void bucket_rows_kernel(const float* __restric
     for (int d = lane; d < D; d += 64) dst[(size_t)s * D + d] = c * src[(size_t)j * D + d];
 }
 
+// ---- item-owner-computes schedule (fairrec/sharded.py, ShardedFocfEngineV2): records to the item owners --------------
+// A record chunk is [4 * cap + 1] int64: item local rows (written by the bucket kernel, -1 = empty) | user ids | rating
+// bits | sst bits | the sender's (min, max) of sst as a float pair.
+__global__ __launch_bounds__(256) void shard_pack_records_kernel(const int32_t* __restrict__ slot, const int64_t* __restrict__ user,
+                                                                 const float* __restrict__ rating, const float* __restrict__ sst,
+                                                                 int B, int cap, int64_t* __restrict__ send) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= B) return;
+    const int s = slot[b];
+    if (s < 0) return;        // overflowed its bucket (error bit already set)
+    send[s + cap] = user[b];
+    send[s + 2 * cap] = (long long)__float_as_int(rating[b]);
+    send[s + 3 * cap] = sst ? (long long)__float_as_int(sst[b]) : 0ll;
+}
+
+// what an item owner keeps of the G record chunks it received: per record slot s = g * cap + k the item row (-1 = empty),
+// the user id (-1 = empty), its own position as "item slot" (-1 = empty), rating (0 when empty) and sst; per sender the
+// (min, max) pair
+__global__ __launch_bounds__(256) void shard_unpack_records_kernel(const int64_t* __restrict__ recv, int G, int cap,
+                                                                   int64_t* __restrict__ iid, int64_t* __restrict__ uid,
+                                                                   int32_t* __restrict__ islot, float* __restrict__ rating,
+                                                                   float* __restrict__ sst, int64_t* __restrict__ mm) {
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    const int S = 4 * cap + 1;
+    if (s < G) mm[s] = recv[(size_t)s * S + 4 * cap];
+    if (s >= G * cap) return;
+    const int g = s / cap, k = s % cap;
+    const int64_t* c = recv + (size_t)g * S;
+    const long long it = c[k];
+    const bool held = it >= 0;
+    iid[s] = it;
+    uid[s] = held ? c[cap + k] : -1ll;
+    islot[s] = held ? s : -1;
+    rating[s] = held ? __int_as_float((int)c[2 * cap + k]) : 0.f;
+    sst[s] = held ? __int_as_float((int)c[3 * cap + k]) : 0.f;
+}
+
+// Number of distinct real ids of a list, by marking a bitmap over the owner's rows (kept all-zero between calls): the count an
+// item owner reports to the other ranks must not wait for the sort of the list (it is exchanged by a collective, and every
+// collective of the step queues behind it).
+__global__ __launch_bounds__(256) void shard_mark_distinct_kernel(const int64_t* __restrict__ ids, int n, unsigned* __restrict__ bitmap,
+                                                                  int* __restrict__ count) {
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= n) return;
+    const long long id = ids[s];
+    if (id < 0) return;
+    const unsigned bit = 1u << (id & 31);
+    if (!(atomicOr(&bitmap[id >> 5], bit) & bit)) atomicAdd(count, 1);
+}
+__global__ __launch_bounds__(256) void shard_clear_distinct_kernel(const int64_t* __restrict__ ids, int n, unsigned* __restrict__ bitmap,
+                                                                   int* __restrict__ count, float* __restrict__ out) {
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    if (s == 0) out[0] = (float)*count;
+    if (s >= n) return;
+    const long long id = ids[s];
+    if (id >= 0) bitmap[id >> 5] = 0u;
+}
+__global__ void shard_zero_int_kernel(int* p) { *p = 0; }
+
+// After the owner-side fairness kernel: (fairness sum, squared-error sum) of THIS owner out of the reply tails, and the
+// tails' first entry replaced by every owner's distinct-item count (gathered one step ahead): the gradient kernel sums
+// them to K of the global batch.
+__global__ void shard_post_fair_kernel(float* __restrict__ reply, const float* __restrict__ k_all, int G, int cap, int tail,
+                                       float* __restrict__ sums) {
+    const int g = threadIdx.x;
+    if (g == 0) {
+        sums[0] = reply[cap + 1];
+        sums[1] = reply[cap + 2];
+    }
+    if (g < G) reply[(size_t)g * (cap + tail) + cap] = k_all[g];
+}
+
+// loss of the global batch from the all-reduced (fairness sum, squared-error sum) and the owners' distinct-item counts
+__global__ void shard_loss_finish_kernel(const float* __restrict__ sums, const float* __restrict__ k_all, int G, float inv_n,
+                                         float fair_weight, int fair, float* __restrict__ loss) {
+    if (threadIdx.x != 0) return;
+    float K = 0.f;
+    for (int g = 0; g < G; ++g) K += k_all[g];
+    const float mse = sums[1] * inv_n, fv = fair ? sums[0] / K : 0.f;
+    loss[0] = mse + fair_weight * fv;
+    loss[1] = mse;
+    loss[2] = fv;
+}
+
 }  // namespace fr
 
 using namespace fr;
 
+extern "C" int fr_shard_pack_records(const int32_t* slot, const int64_t* user, const float* rating, const float* sst,
+                                     int64_t B, int32_t cap, int64_t* send, void* stream_) {
+    FR_CHECK_ARG(slot && user && rating && send && B >= 1 && cap >= 1, "fr_shard_pack_records: bad argument");
+    hipLaunchKernelGGL(shard_pack_records_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, slot,
+                       user, rating, sst, (int)B, (int)cap, send);
+    FR_CHECK_LAUNCH();
+    return FR_OK;
+}
+
+extern "C" int fr_shard_unpack_records(const int64_t* recv, int32_t G, int32_t cap, int64_t* iid, int64_t* uid,
+                                       int32_t* islot, float* rating, float* sst, int64_t* mm, void* stream_) {
+    FR_CHECK_ARG(recv && iid && uid && islot && rating && sst && mm && G >= 1 && cap >= 1,
+                 "fr_shard_unpack_records: bad argument");
+    const long long n = (long long)G * cap;
+    hipLaunchKernelGGL(shard_unpack_records_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, recv,
+                       (int)G, (int)cap, iid, uid, islot, rating, sst, mm);
+    FR_CHECK_LAUNCH();
+    return FR_OK;
+}
+
+extern "C" int fr_shard_count_distinct(const int64_t* ids, int64_t n, int64_t n_rows, uint32_t* bitmap, int32_t* count,
+                                       float* out, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    FR_CHECK_ARG(ids && bitmap && count && out && n >= 1 && n_rows >= 1, "fr_shard_count_distinct: bad argument");
+    const unsigned blocks = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(shard_mark_distinct_kernel, dim3(blocks), dim3(256), 0, stream, ids, (int)n, bitmap, count);
+    hipLaunchKernelGGL(shard_clear_distinct_kernel, dim3(blocks), dim3(256), 0, stream, ids, (int)n, bitmap, count, out);
+    hipLaunchKernelGGL(shard_zero_int_kernel, dim3(1), dim3(1), 0, stream, count);
+    FR_CHECK_LAUNCH();
+    return FR_OK;
+}
+
+extern "C" int fr_shard_post_fair(float* reply, const float* k_all, int32_t G, int32_t cap, float* sums, void* stream_) {
+    FR_CHECK_ARG(reply && k_all && sums && G >= 1 && G <= 64 && cap >= 1, "fr_shard_post_fair: bad argument");
+    hipLaunchKernelGGL(shard_post_fair_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream_, reply, k_all, (int)G, (int)cap,
+                       (int)FR_SHARD_TAIL, sums);
+    FR_CHECK_LAUNCH();
+    return FR_OK;
+}
+
+extern "C" int fr_shard_loss_finish(const float* sums, const float* k_all, int32_t G, int64_t n_global, float fair_weight,
+                                    int32_t fair, float* loss, void* stream_) {
+    FR_CHECK_ARG(sums && k_all && loss && G >= 1 && n_global >= 1, "fr_shard_loss_finish: bad argument");
+    hipLaunchKernelGGL(shard_loss_finish_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream_, sums, k_all, (int)G,
+                       1.f / (float)n_global, fair_weight, (int)fair, loss);
+    FR_CHECK_LAUNCH();
+    return FR_OK;
+}
+
 static int launch_bucket(const BucketJob& a, const BucketJob* b, int64_t M, int32_t G, int32_t cap, int32_t stride,
-                         int64_t* send_ids, uint32_t* err_flag, hipStream_t stream) {
+                         int64_t* send_ids, uint32_t* err_flag, hipStream_t stream, int holes = 0) {
     const BucketPlan plan = bucket_plan(M, G, cap);
     static bool attr_set = false;
     if (!attr_set) {
@@ -250,7 +391,7 @@ static int launch_bucket(const BucketJob& a, const BucketJob* b, int64_t M, int3
     }
     ProfScope prof(K_BUCKET, stream);
     FR_LAUNCH(prof, bucket_by_owner_kernel, dim3(b ? 2 : 1), dim3(BUCKET_THREADS), plan.lds_bytes, stream, a, b ? *b : a,
-              (int)M, (int)G, (int)cap, (int)stride, (int)plan.stage_ids, (int)plan.stage_send, send_ids, err_flag);
+              (int)M, (int)G, (int)cap, (int)stride, (int)plan.stage_ids, (int)plan.stage_send, send_ids, err_flag, holes);
     FR_CHECK_LAUNCH();
     return FR_OK;
 }
@@ -268,6 +409,16 @@ extern "C" int fr_bucket_by_owner(const int64_t* idx, int64_t M, int32_t G, int3
     FR_CHECK_ARG(bucket_args_ok(M, G, cap, stride, offset, aux, aux_slot), "fr_bucket_by_owner: bad size / slot");
     BucketJob a{idx, offset, slot_of, counts, aux, aux_slot};
     return launch_bucket(a, nullptr, M, G, cap, stride, send_ids, err_flag, (hipStream_t)stream_);
+}
+
+// The same for a list with empty positions (id -1: the padding of a received exchange buffer): they go to no owner.
+extern "C" int fr_bucket_by_owner_sparse(const int64_t* idx, int64_t M, int32_t G, int32_t cap, int32_t stride,
+                                         int32_t offset, int64_t* send_ids, int32_t* slot_of, int32_t* counts,
+                                         uint32_t* err_flag, void* stream_) {
+    FR_CHECK_ARG(idx && send_ids && slot_of && counts, "fr_bucket_by_owner_sparse: null pointer");
+    FR_CHECK_ARG(bucket_args_ok(M, G, cap, stride, offset, nullptr, 0), "fr_bucket_by_owner_sparse: bad size / slot");
+    BucketJob a{idx, offset, slot_of, counts, nullptr, 0};
+    return launch_bucket(a, nullptr, M, G, cap, stride, send_ids, err_flag, (hipStream_t)stream_, 1);
 }
 
 extern "C" int fr_bucket_pair_by_owner(const int64_t* idx_a, const int64_t* idx_b, int64_t M, int32_t G, int32_t cap,

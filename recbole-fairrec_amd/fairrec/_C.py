@@ -80,6 +80,14 @@ _PROTOS = {
                                                c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
     "fr_table_apply_grad": (c_int, [POINTER(FrTable), POINTER(FrAdam), c_int64, c_int32, c_int32, c_void_p, c_void_p,
                                     c_int32, c_void_p, c_size_t, c_void_p]),
+    "fr_shard_pack_records": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p]),
+    "fr_shard_unpack_records": (c_int, [c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                        c_void_p]),
+    "fr_shard_count_distinct": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "fr_shard_post_fair": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p]),
+    "fr_shard_loss_finish": (c_int, [c_void_p, c_void_p, c_int32, c_int64, c_float, c_int32, c_void_p, c_void_p]),
+    "fr_bucket_by_owner_sparse": (c_int, [c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p,
+                                          c_void_p, c_void_p, c_void_p]),
     "fr_bucket_by_owner": (c_int, [c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
                                    c_void_p, c_int32, c_void_p, c_void_p]),
     "fr_bucket_pair_by_owner": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p,

@@ -164,6 +164,53 @@ class HipOps:
                                               grads.data_ptr(), _C.current_stream()), "fr_focf_shard_grads")
 
 
+    # --- item-owner-computes schedule (ShardedFocfEngineV2) ---------------------------------------------------------
+    def bucket_sparse(self, idx, G, cap, stride, offset, send, slot, counts, err):
+        """bucket_by_owner of a list with empty positions (id -1: they go nowhere)"""
+        _C.check(_C.lib().fr_bucket_by_owner_sparse(idx.data_ptr(), idx.numel(), G, cap, stride, offset, send.data_ptr(),
+                                                    slot.data_ptr(), counts.data_ptr(), err.data_ptr(),
+                                                    _C.current_stream()), "fr_bucket_by_owner_sparse")
+
+    def pack_records(self, slot, user, rating, sst, cap, send):
+        _C.check(_C.lib().fr_shard_pack_records(slot.data_ptr(), user.data_ptr(), rating.data_ptr(), _C.ptr(sst), slot.numel(),
+                                                cap, send.data_ptr(), _C.current_stream()), "fr_shard_pack_records")
+
+    def unpack_records(self, recv, G, cap, iid, uid, islot, rating, sst, mm):
+        _C.check(_C.lib().fr_shard_unpack_records(recv.data_ptr(), G, cap, iid.data_ptr(), uid.data_ptr(), islot.data_ptr(),
+                                                  rating.data_ptr(), sst.data_ptr(), mm.data_ptr(), _C.current_stream()),
+                 "fr_shard_unpack_records")
+
+    def post_fair(self, reply, k_all, G, cap, sums):
+        _C.check(_C.lib().fr_shard_post_fair(reply.data_ptr(), k_all.data_ptr(), G, cap, sums.data_ptr(), _C.current_stream()),
+                 "fr_shard_post_fair")
+
+    def loss_finish(self, sums, k_all, G, n_global, fair_weight, fair, loss):
+        _C.check(_C.lib().fr_shard_loss_finish(sums.data_ptr(), k_all.data_ptr(), G, n_global, fair_weight, int(fair),
+                                               loss.data_ptr(), _C.current_stream()), "fr_shard_loss_finish")
+
+    def count_distinct(self, ids, n_rows, bitmap, count, out):
+        """out[0] = number of distinct real ids of the list (bitmap over the owner's rows, left all-zero)"""
+        _C.check(_C.lib().fr_shard_count_distinct(ids.data_ptr(), ids.numel(), n_rows, bitmap.data_ptr(), count.data_ptr(),
+                                                  out.data_ptr(), _C.current_stream()), "fr_shard_count_distinct")
+
+    def shard_score2(self, rows_u, rows_i, slot_u, slot_i, rating, sst, n_global, pred, coef, rec, cap, slot_stride,
+                     slot_offset, sq, sq_part):
+        """shard_score with the user rows and the item rows in two buffers"""
+        B, D = slot_u.numel(), rows_u.shape[1]
+        _C.check(_C.lib().fr_focf_shard_score(rows_u.data_ptr(), rows_i.data_ptr(), slot_u.data_ptr(), slot_i.data_ptr(),
+                                              rating.data_ptr(), _C.ptr(sst), B, D, n_global, pred.data_ptr(),
+                                              coef.data_ptr(), _C.ptr(rec), cap, slot_stride, slot_offset, _C.ptr(sq),
+                                              sq_part.data_ptr(), _C.current_stream()), "fr_focf_shard_score")
+
+    def shard_grads2(self, rows_u, rows_i, slot_u, slot_i, coef, reply, G, n_global, fair_weight, loss_out, cap,
+                     slot_stride, slot_offset, grad_u, grad_i):
+        B, D = slot_u.numel(), rows_u.shape[1]
+        _C.check(_C.lib().fr_focf_shard_grads(rows_u.data_ptr(), rows_i.data_ptr(), slot_u.data_ptr(), slot_i.data_ptr(),
+                                              coef.data_ptr(), _C.ptr(reply), G, n_global, fair_weight,
+                                              _C.ptr(loss_out), cap, slot_stride, slot_offset, B, D, grad_u.data_ptr(),
+                                              grad_i.data_ptr(), _C.current_stream()), "fr_focf_shard_grads")
+
+
 class _Buffers:
     """Exchange and scratch buffers of one (B, cap, D) shape, allocated once (a captured step replays on them)."""
 
@@ -344,3 +391,162 @@ class ShardedFocfEngine:
                 raise _C.FairrecError("an exchange bucket overflowed (skewed ids): raise capacity_factor; the "
                                       "overflowing interactions of that step were NOT applied")
             raise IndexError(f"device error word {e}")
+
+
+# ======================================================================================================================
+# Item-owner-computes schedule (round 2): every interaction is routed to the rank that owns its ITEM row.  That rank has
+# all interactions of its items, so the per-item fairness statistics, the scores and both gradients are formed where the
+# item rows live; only the USER rows travel (owner -> item owner) and only the user gradients travel back.  The step's
+# dependent chain holds 2 all-to-alls (user rows, user gradient rows) instead of 4; the index-only exchanges (records to
+# the item owners, user-id requests to the user owners, the owners' distinct-item counts and sst extrema) depend on nothing
+# but the id columns and run one step ahead on the side stream, like the id exchange of the schedule above.
+#
+#     recs   [G, 4*cap]       int64 planes: item local row | user id | rating bits | sst bits      -> item owners
+#     ureq   [G, cap]         user local rows an item owner asks each user owner for                -> user owners
+#     meta   [G, 3] floats    all-gather: (distinct items held, min sst, max sst) of every rank
+#     urows  [G, cap, D]      user rows (lazy gather at the owner)                                  -> item owners
+#     ugrad  [G, cap, D]      user gradient rows                                                    -> user owners
+#     2 floats all-reduce     (fairness sum, squared-error sum) for the reported loss, off the chain
+#
+# Objectives none / value / absolute / under / over; non-parity (two global means before any gradient) stays on the
+# schedule above.  Same kernels (`ops`), other wiring: an item owner treats the G*cap record slots it received as a batch
+# whose item rows are local (slot = record position) and whose user rows sit in the row buffer that came back.
+class ShardedFocfEngineV2(ShardedFocfEngine):
+    class _Buf:
+        def __init__(self, G, B, cap, D, dev, ops, U, I):
+            f32, i64, i32 = torch.float32, torch.int64, torch.int32
+            n = G * cap
+            self.B, self.cap, self.n, self.RS = B, cap, n, 4 * cap + 1
+            two = range(2)
+            # index-side state exists twice: the NEXT step's exchanges run while this step computes
+            self.rec_send = [torch.full((G * self.RS,), -1, dtype=i64, device=dev) for _ in two]
+            self.rec_recv = [torch.full((G * self.RS,), -1, dtype=i64, device=dev) for _ in two]
+            self.slot_i = [torch.empty(B, dtype=i32, device=dev) for _ in two]
+            self.cnt_i = [torch.empty(G, dtype=i32, device=dev) for _ in two]
+            self.ids2 = [torch.full((2 * n,), -1, dtype=i64, device=dev) for _ in two]   # [user-row requests received | item rows held]
+            self.uid = [torch.empty(n, dtype=i64, device=dev) for _ in two]      # user ids of the records held (-1: empty slot)
+            self.ureq_send = [torch.full((n,), -1, dtype=i64, device=dev) for _ in two]
+            self.uslot = [torch.empty(n, dtype=i32, device=dev) for _ in two]
+            self.cnt_u = [torch.empty(G, dtype=i32, device=dev) for _ in two]
+            self.islot = [torch.empty(n, dtype=i32, device=dev) for _ in two]
+            self.rating = [torch.zeros(n, dtype=f32, device=dev) for _ in two]
+            self.sst = [torch.zeros(n, dtype=f32, device=dev) for _ in two]
+            self.k_send = [torch.zeros(1, dtype=f32, device=dev) for _ in two]
+            self.k_all = [torch.zeros(G, dtype=f32, device=dev) for _ in two]    # distinct items held by every owner
+            self.mm = [torch.zeros(G, dtype=i64, device=dev) for _ in two]       # (min, max) float pairs of every rank's sst
+            self.ws_u = [ops.alloc_ws(U, n) for _ in two]
+            self.ws_i = [ops.alloc_ws(I, n) for _ in two]
+            self.rows = torch.zeros((2 * n, D), dtype=f32, device=dev)           # [user rows gathered for others | item rows held]
+            self.urows = torch.empty((n, D), dtype=f32, device=dev)
+            self.grads = torch.zeros((2 * n, D), dtype=f32, device=dev)          # [user gradients received | item gradients]
+            self.g_send = torch.zeros((n, D), dtype=f32, device=dev)
+            self.rec = torch.zeros(G * 3 * cap, dtype=f32, device=dev)
+            self.reply = torch.zeros(G * (cap + TAIL), dtype=f32, device=dev)
+            self.pred = torch.empty(n, dtype=f32, device=dev)
+            self.coef = torch.empty(n, dtype=f32, device=dev)
+            self.sums = torch.zeros(2, dtype=f32, device=dev)
+            self.loss = torch.zeros(3, dtype=f32, device=dev)
+            self.n_sq_part = (n + 3) // 4
+            self.sq_part = torch.zeros(self.n_sq_part + 1, dtype=f32, device=dev)
+            self.scratch = torch.zeros(n // 64 + 32, dtype=f32, device=dev)
+            self.bitmap = torch.zeros((I.n_rows + 31) // 32, dtype=i32, device=dev)     # all zero between uses
+            self.count = torch.zeros(1, dtype=i32, device=dev)
+
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        if self.objective == "nonparity":
+            raise NotImplementedError("ShardedFocfEngineV2: fair_objective nonparity runs on ShardedFocfEngine")
+        self.defer_loss = False      # True: the loss is all-reduced at the end of backward_adam instead of inside forward
+
+    def _buffers(self, B):
+        if self._buf is None or self._buf.B != B:
+            self._buf = self._Buf(self.G, B, self.capacity(B), self.U.dim, self.device, self.ops, self.U, self.I)
+            self._prep_key = None
+        return self._buf
+
+    # --- index-only part, a pure function of the id columns (+ rating / sst payload): 5 launches, 3 collectives ---------
+    def _index_a(self, b, sel, user, item, rating, sst):
+        """bucket the interactions by item owner and pack the records"""
+        G, cap, fair = self.G, b.cap, self.objective != "none"
+        self.ops.bucket_by_owner(item, G, cap, b.RS, 0, b.rec_send[sel], b.slot_i[sel], b.cnt_i[sel], sst if fair else None,
+                                 4 * cap, self.err)
+        self.ops.pack_records(b.slot_i[sel], user, rating, sst if fair else None, cap, b.rec_send[sel])
+
+    def _index_b(self, b, sel):
+        """records to the item owners; their user-row requests to the user owners; the owners' sorts and item counts"""
+        G, cap, n, ops = self.G, b.cap, b.n, self.ops
+        self._a2a(b.rec_recv[sel], b.rec_send[sel])
+        iid = b.ids2[sel][n:]
+        ops.unpack_records(b.rec_recv[sel], G, cap, iid, b.uid[sel], b.islot[sel], b.rating[sel], b.sst[sel], b.mm[sel])
+        if self.objective != "none":
+            # how many distinct items this owner holds, to every rank -- before the slow part (the owner sorts): every later
+            # collective of either stream queues behind this one
+            ops.count_distinct(iid, self.I.n_rows, b.bitmap, b.count, b.k_send[sel])
+            dist.all_gather_into_tensor(b.k_all[sel], b.k_send[sel], group=self.group)
+        ops.bucket_sparse(b.uid[sel], G, cap, cap, 0, b.ureq_send[sel], b.uslot[sel], b.cnt_u[sel], self.err)
+        self._a2a(b.ids2[sel][:n], b.ureq_send[sel])
+        ops.sort_pair(self.U, self.I, b.ids2[sel], 0, n, n, 0, 0, b.ws_u[sel], b.ws_i[sel], self.err)
+
+    def forward(self, user, item, rating, sst, next_batch=None):
+        """loss of the global batch (0-dim device tensor; with `defer_loss` complete after backward_adam) and None (the
+        scores live with the item owners).  next_batch = (user, item, sst, rating) of the FOLLOWING step: its index work
+        and exchanges start on the side stream now."""
+        G, ops = self.G, self.ops
+        B = user.numel()
+        self._last_B = B
+        b = self._buffers(B)
+        cap, n, sel = b.cap, b.n, self._sel
+        fair = self.objective != "none"
+        if self._prep_key == self._key(user, item):
+            ops.join_side()
+        else:
+            if self._prep_key is not None:
+                ops.join_side()
+            self._index_a(b, sel, user, item, rating, sst)
+            self._index_b(b, sel)
+        self._prep_key = None
+        ahead = next_batch is not None and len(next_batch) >= 4 and next_batch[0].numel() == B
+        if ahead:
+            with ops.side():
+                self._index_a(b, sel ^ 1, next_batch[0], next_batch[1], next_batch[3], next_batch[2])
+            self._prep_key = self._key(next_batch[0], next_batch[1])
+        # user owners gather the requested rows, item owners their own rows: one launch
+        ops.gather_train_pair(self.U, self.I, self.hyper, b.ids2[sel], 0, n, n, 0, 0, b.rows, b.ws_u[sel], b.ws_i[sel], self.err)
+        self._a2a(b.urows, b.rows[:n])
+        if ahead:       # the next step's exchanges where the chain leaves the communicator idle
+            with ops.side(fork=False):
+                self._index_b(b, sel ^ 1)
+        ops.shard_score2(b.urows, b.rows[n:], b.uslot[sel], b.islot[sel], b.rating[sel], b.sst[sel] if fair else None,
+                         G * B, b.pred, b.coef, b.rec if fair else None, cap, cap, 0, None if fair else b.sums[1:2], b.sq_part)
+        if fair:
+            ops.shard_fair(self.I, n, b.rec, cap, b.mm[sel], 0, 1, self.objective, self.fair_weight, b.reply, b.sq_part,
+                           b.n_sq_part, b.scratch, self.err)
+            ops.post_fair(b.reply, b.k_all[sel], G, cap, b.sums)      # sums <- (fair, sq) of this owner; tails <- every owner's K
+        ops.shard_grads2(b.urows, b.rows[n:], b.uslot[sel], b.islot[sel], b.coef, b.reply if fair else None, G, G * B,
+                         self.fair_weight, None, cap, cap, 0, b.g_send, b.grads[n:])
+        self._loss_sel = sel
+        if not self.defer_loss:
+            self._finish_loss(b, B)
+        self._armed = True
+        return b.loss[0], None
+
+    def _finish_loss(self, b, B):
+        """the reported loss: two sums over the ranks (off the dependent chain when deferred)"""
+        dist.all_reduce(b.sums, op=dist.ReduceOp.SUM, group=self.group)
+        self.ops.loss_finish(b.sums, b.k_all[self._loss_sel], self.G, self.G * B, self.fair_weight, self.objective != "none",
+                             b.loss)
+
+    def backward_adam(self):
+        G, ops, b = self.G, self.ops, self._buf
+        if not self._armed:
+            raise _C.FairrecError("backward_adam without forward")
+        n = b.n
+        self._a2a(b.grads[:n], b.g_send)
+        su = self.sweep_period if self.sweep_period is not None else max(8, math.ceil(self.U.n_rows / max(n // 2, 1)))
+        si = self.sweep_period if self.sweep_period is not None else max(8, math.ceil(self.I.n_rows / max(n // 2, 1)))
+        ops.apply_grad_pair(self.U, self.I, self.hyper, n, 0, 0, b.rows, b.grads, 0, n, su, si)
+        if self.defer_loss:
+            self._finish_loss(b, self._last_B)
+        self._armed = False
+        self._sel ^= 1
+        self.step_count += 1

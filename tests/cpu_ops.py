@@ -169,3 +169,83 @@ class CpuOps:
             c = c + reply[(si // slot_stride) * (cap + TAIL) + (si % slot_stride - slot_offset)] / K
         grads[su] = c[:, None] * rows[si]
         grads[si] = c[:, None] * rows[su]
+
+    # --- item-owner-computes schedule (ShardedFocfEngineV2): lists with empty positions, two row buffers ----------------
+    def bucket_sparse(self, idx, G, cap, stride, offset, send, slot, counts, err):
+        for o in range(G):
+            send[o * stride + offset:o * stride + offset + cap] = -1
+        slot.fill_(-1)
+        counts.zero_()
+        for j in range(idx.numel()):
+            r = int(idx[j])
+            if r < 0:
+                continue
+            o, k = r % G, int(counts[r % G])
+            if k < cap:
+                send[o * stride + offset + k] = r // G
+                slot[j] = o * stride + offset + k
+                counts[o] += 1
+            else:
+                err |= 4
+
+    def pack_records(self, slot, user, rating, sst, cap, send):
+        ok = slot >= 0
+        s = slot[ok].long()
+        send[s + cap] = user[ok]
+        send[s + 2 * cap] = rating[ok].view(torch.int32).to(torch.int64)
+        send[s + 3 * cap] = sst[ok].view(torch.int32).to(torch.int64) if sst is not None else 0
+
+    def unpack_records(self, recv, G, cap, iid, uid, islot, rating, sst, mm):
+        rv = recv.view(G, 4 * cap + 1)
+        it = rv[:, :cap].reshape(-1)
+        held = it >= 0
+        iid.copy_(it)
+        uid.copy_(torch.where(held, rv[:, cap:2 * cap].reshape(-1), torch.full((), -1, dtype=torch.int64)))
+        islot.copy_(torch.where(held, torch.arange(G * cap, dtype=torch.int32), torch.full((), -1, dtype=torch.int32)))
+        rating.copy_(torch.where(held, rv[:, 2 * cap:3 * cap].reshape(-1).to(torch.int32).view(torch.float32), torch.zeros(())))
+        sst.copy_(torch.where(held, rv[:, 3 * cap:4 * cap].reshape(-1).to(torch.int32).view(torch.float32), torch.zeros(())))
+        mm.copy_(rv[:, 4 * cap])
+
+    def post_fair(self, reply, k_all, G, cap, sums):
+        sums[0], sums[1] = float(reply[cap + 1]), float(reply[cap + 2])
+        for g in range(G):
+            reply[g * (cap + TAIL) + cap] = k_all[g]
+
+    def loss_finish(self, sums, k_all, G, n_global, fair_weight, fair, loss):
+        mse = sums[1] / n_global
+        fv = sums[0] / k_all.sum() if fair else torch.zeros(())
+        loss[0], loss[1], loss[2] = mse + fair_weight * fv, mse, fv
+
+    def count_distinct(self, ids, n_rows, bitmap, count, out):
+        out[0] = float(torch.unique(ids[ids >= 0]).numel())
+
+    def shard_score2(self, rows_u, rows_i, slot_u, slot_i, rating, sst, n_global, pred, coef, rec, cap, slot_stride,
+                     slot_offset, sq, sq_part):
+        su, si = slot_u.long(), slot_i.long()
+        ok = (su >= 0) & (si >= 0)
+        p = torch.where(ok, (rows_u[su.clamp(min=0)] * rows_i[si.clamp(min=0)]).sum(-1), torch.zeros(()))
+        e = p - rating
+        pred.copy_(p)
+        coef.copy_(2 * e / n_global)
+        sq_part.zero_()
+        sq_part[0] = (e * e).sum()
+        if sq is not None:
+            sq[0] = sq_part[0]
+        if rec is not None:
+            held = si >= 0
+            base = (si[held] // slot_stride) * 3 * cap + (si[held] % slot_stride - slot_offset)
+            rec[base] = p[held]
+            rec[base + cap] = rating[held]
+            rec[base + 2 * cap] = sst[held]
+
+    def shard_grads2(self, rows_u, rows_i, slot_u, slot_i, coef, reply, G, n_global, fair_weight, loss_out, cap,
+                     slot_stride, slot_offset, grad_u, grad_i):
+        su, si = slot_u.long(), slot_i.long()
+        ok = (su >= 0) & (si >= 0)
+        su, si = su[ok], si[ok]
+        c = coef[ok].clone()
+        if reply is not None:
+            K = sum(float(reply[g * (cap + TAIL) + cap]) for g in range(G))
+            c = c + reply[(si // slot_stride) * (cap + TAIL) + (si % slot_stride - slot_offset)] / K
+        grad_u[su] = c[:, None] * rows_i[si]
+        grad_i[si] = c[:, None] * rows_u[su]

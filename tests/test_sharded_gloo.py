@@ -35,7 +35,7 @@ def _case(hot: bool, world: int):
     return z
 
 
-def _worker(rank, world, port, objective, out_dir, hot=False):
+def _worker(rank, world, port, objective, out_dir, hot=False, v2=False):
     for p in (ROOT, os.path.join(ROOT, "recbole-fairrec_amd"), os.path.join(ROOT, "tests")):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -43,10 +43,11 @@ def _worker(rank, world, port, objective, out_dir, hot=False):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from cpu_ops import CpuOps
-        from fairrec.sharded import ShardedFocfEngine, shard_of
+        from fairrec.sharded import ShardedFocfEngine, ShardedFocfEngineV2, shard_of
+        Engine = ShardedFocfEngineV2 if v2 else ShardedFocfEngine
         z = _case(hot, world)
         U0, I0 = torch.tensor(z["U0"]), torch.tensor(z["I0"])
-        eng = ShardedFocfEngine(shard_of(U0, rank, world), shard_of(I0, rank, world), objective, 0.8, 1e-3, 1e-3,
+        eng = Engine(shard_of(U0, rank, world), shard_of(I0, rank, world), objective, 0.8, 1e-3, 1e-3,
                                 ops=CpuOps(), capacity_factor=4.0 if hot else 1.5)
         T, B = 6, z["user_id"].shape[1] // world
         losses = []
@@ -54,7 +55,7 @@ def _worker(rank, world, port, objective, out_dir, hot=False):
         batches = [[torch.tensor(z[k][t][sl]) for k in ("user_id", "item_id", "rating", "sst")] for t in range(T)]
         for t in range(T):
             # every other step names its successor: both the look-ahead and the inline index path are exercised
-            nxt = (batches[t + 1][0], batches[t + 1][1], batches[t + 1][3]) if t + 1 < T and t % 3 != 2 else None
+            nxt = (batches[t + 1][0], batches[t + 1][1], batches[t + 1][3], batches[t + 1][2]) if t + 1 < T and t % 3 != 2 else None
             loss, _ = eng.forward(*batches[t], next_batch=nxt)
             losses.append(float(loss))
             eng.backward_adam()
@@ -64,10 +65,10 @@ def _worker(rank, world, port, objective, out_dir, hot=False):
         dist.destroy_process_group()
 
 
-def _check(tmp_path, objective, world, hot):
+def _check(tmp_path, objective, world, hot, v2=False):
     from oracle import focf as O
     port = _free_port()
-    mp.spawn(_worker, args=(world, port, objective, str(tmp_path), hot), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, objective, str(tmp_path), hot, v2), nprocs=world, join=True)
     z = _case(hot, world)
     T, B = 6, (z["user_id"].shape[1] // world) * world
     ref = O.train(objective, z["U0"], z["I0"], z["user_id"][:T, :B], z["item_id"][:T, :B], z["rating"][:T, :B],
@@ -90,3 +91,10 @@ def test_two_rank_schedule_matches_oracle(tmp_path, objective):
 @pytest.mark.parametrize("objective,hot", [("value", False), ("value", True), ("nonparity", True)])
 def test_four_rank_schedule_matches_oracle(tmp_path, objective, hot):
     _check(tmp_path, objective, 4, hot)
+
+
+@pytest.mark.parametrize("objective,world,hot", [("none", 2, False), ("value", 2, False), ("under", 2, False),
+                                                 ("value", 4, False), ("value", 4, True), ("absolute", 2, True)])
+def test_item_owner_schedule_matches_oracle(tmp_path, objective, world, hot):
+    """ShardedFocfEngineV2: interactions routed to the item owners, 2 dependent all-to-alls per step."""
+    _check(tmp_path, objective, world, hot, v2=True)

@@ -17,16 +17,21 @@ def pg(rccl_world1):
     yield
 
 
+@pytest.mark.parametrize("schedule", ["requester", "item_owner"])
 @pytest.mark.parametrize("lookahead", [False, True], ids=["inline", "lookahead"])
 @pytest.mark.parametrize("case", ["focf_none", "focf_value", "focf_absolute", "focf_under", "focf_over",
                                   "focf_value_grouped", "focf_value_d128", "focf_value_pad", "focf_value_long",
                                   "focf_nonparity"])
-def test_sharded_hip_matches_reference_golden(pg, case, lookahead):
-    from fairrec.sharded import ShardedFocfEngine
+def test_sharded_hip_matches_reference_golden(pg, case, lookahead, schedule):
+    from fairrec.sharded import ShardedFocfEngine, ShardedFocfEngineV2
     z = np.load(os.path.join(GOLDEN, case + ".npz"))
     lr, wd, fw = (float(x) for x in z["hyper"][:3])
-    eng = ShardedFocfEngine(torch.tensor(z["U0"], device="cuda"), torch.tensor(z["I0"], device="cuda"),
-                            str(z["objective"]), fw, lr, wd, capacity_factor=1.0)
+    v2 = schedule == "item_owner"     # interactions routed to the item owners: 2 dependent all-to-alls per step
+    if v2 and str(z["objective"]) == "nonparity":
+        pytest.skip("non-parity runs on the requester-computes schedule")
+    eng = (ShardedFocfEngineV2 if v2 else ShardedFocfEngine)(
+        torch.tensor(z["U0"], device="cuda"), torch.tensor(z["I0"], device="cuda"), str(z["objective"]), fw, lr, wd,
+        capacity_factor=1.0)
     snaps = set(int(s) for s in z["snaps"])
     losses = []
     T = z["user_id"].shape[0]
@@ -34,10 +39,10 @@ def test_sharded_hip_matches_reference_golden(pg, case, lookahead):
     for t in range(T):
         nxt = None
         if lookahead and t + 1 < T and t % 4 != 3:   # the next step's bucket / id exchange / sort runs on a side stream
-            nxt = (batches[t + 1][0], batches[t + 1][1], batches[t + 1][3])
+            nxt = (batches[t + 1][0], batches[t + 1][1], batches[t + 1][3], batches[t + 1][2])
         loss, pred = eng.forward(*batches[t], next_batch=nxt)
         losses.append(loss.reshape(1).clone())
-        if t == 0:
+        if t == 0 and pred is not None:      # (the item-owner schedule leaves the scores with the item owners)
             np.testing.assert_allclose(pred.cpu().numpy(), z["pred_step1"], rtol=1e-4, atol=1e-6)
         eng.backward_adam()
         if (t + 1) in snaps:
@@ -99,3 +104,108 @@ def test_sort_ignores_padding_slots():
     assert seg_row[:3].tolist() == [0, 3, 5]
     assert seg_start[:4].tolist() == [0, 1, 3, 5]        # 5 real ids; the two -1 slots belong to no segment
     assert perm[:5].tolist() == [5, 2, 6, 0, 3]
+
+
+def test_item_owner_kernels_match_their_cpu_doubles():
+    """The kernels only the item-owner schedule uses, on the layouts of a 4-rank world (the 1-rank golden runs above see one
+    chunk only), against the pure-torch doubles the gloo tests run the same schedule with (tests/cpu_ops.py)."""
+    from cpu_ops import CpuOps, TAIL
+    from fairrec.sharded import HipOps
+    hip, cpu = HipOps("cuda"), CpuOps()
+    g = torch.Generator().manual_seed(11)
+    G, M, cap, D, n_users, n_items = 4, 3000, 900, 64, 50_000, 7_000
+    RS = 4 * cap + 1
+
+    def pair(shape, dtype, fill):
+        return torch.full(shape, fill, dtype=dtype), torch.full(shape, fill, dtype=dtype, device="cuda")
+
+    def same(a, b, **kw):
+        np.testing.assert_array_equal(a.numpy(), b.cpu().numpy(), **kw)
+
+    item = torch.randint(0, n_items, (M,), generator=g, dtype=torch.int64)
+    user = torch.randint(0, n_users, (M,), generator=g, dtype=torch.int64)
+    rating = torch.rand(M, generator=g) * 4 + 1
+    sst = torch.randint(0, 2, (M,), generator=g).float()
+
+    # stage 1 (sender): items to their owners with the interaction's record beside each
+    send_c, send_g = pair((G * RS,), torch.int64, -7)
+    slot_c, slot_g = pair((M,), torch.int32, 0)
+    cnt_c, cnt_g = pair((G,), torch.int32, 0)
+    err_c, err_g = pair((1,), torch.int32, 0)
+    cpu.bucket_by_owner(item, G, cap, RS, 0, send_c, slot_c, cnt_c, sst, 4 * cap, err_c)
+    hip.bucket_by_owner(item.cuda(), G, cap, RS, 0, send_g, slot_g, cnt_g, sst.cuda(), 4 * cap, err_g)
+    cpu.pack_records(slot_c, user, rating, sst, cap, send_c)
+    hip.pack_records(slot_g, user.cuda(), rating.cuda(), sst.cuda(), cap, send_g)
+    real = torch.zeros(G * RS, dtype=torch.bool)                # record fields beside an empty slot are not defined
+    for o in range(G):
+        k = int(cnt_c[o])
+        for f in range(4):
+            real[o * RS + f * cap:o * RS + f * cap + k] = True
+        real[o * RS:o * RS + cap] = True
+        real[o * RS + 4 * cap] = True
+    same(send_c[real], send_g.cpu()[real])
+    same(slot_c, slot_g); same(cnt_c, cnt_g)
+
+    # stage 2 (owner): what arrived -> id lists with holes, the users' requests, the distinct-item count
+    recv = torch.where(real, send_c, torch.zeros((), dtype=torch.int64))
+    n = G * cap
+    outs_c = [torch.zeros(n, dtype=torch.int64), torch.zeros(n, dtype=torch.int64), torch.zeros(n, dtype=torch.int32),
+              torch.zeros(n), torch.zeros(n), torch.zeros(G, dtype=torch.int64)]
+    outs_g = [t.cuda() for t in outs_c]
+    cpu.unpack_records(recv, G, cap, *outs_c)
+    hip.unpack_records(recv.cuda(), G, cap, *outs_g)
+    for a, b in zip(outs_c, outs_g):
+        same(a, b)
+    iid, uid = outs_c[0], outs_c[1]
+    ureq_c, ureq_g = pair((G * cap,), torch.int64, -7)
+    uslot_c, uslot_g = pair((n,), torch.int32, 0)
+    cpu.bucket_sparse(uid, G, cap, cap, 0, ureq_c, uslot_c, cnt_c, err_c)
+    hip.bucket_sparse(uid.cuda(), G, cap, cap, 0, ureq_g, uslot_g, cnt_g, err_g)
+    same(ureq_c, ureq_g); same(uslot_c, uslot_g); same(cnt_c, cnt_g)
+    assert int(err_c.item()) == int(err_g.item())
+    k_c, k_g = pair((1,), torch.float32, 0.0)
+    bitmap = torch.zeros((n_items + 31) // 32, dtype=torch.int32, device="cuda")
+    count = torch.zeros(1, dtype=torch.int32, device="cuda")
+    for rep in range(2):                                        # the bitmap and the counter are left clean
+        cpu.count_distinct(iid, n_items, None, None, k_c)
+        hip.count_distinct(iid.cuda(), n_items, bitmap, count, k_g)
+        same(k_c, k_g)
+    assert int(bitmap.abs().sum().item()) == 0 and int(count.item()) == 0
+
+    # stage 3 (owner): predictions and gradient rows from two row buffers
+    rows_u, rows_i = torch.randn(n, D, generator=g) * 0.1, torch.randn(n, D, generator=g) * 0.1
+    islot = outs_c[2]
+    pred_c, pred_g = pair((n,), torch.float32, 0.0)
+    coef_c, coef_g = pair((n,), torch.float32, 0.0)
+    rec_c, rec_g = pair((G * 3 * cap,), torch.float32, 0.0)
+    sq_c, sq_g = pair(((n + 3) // 4,), torch.float32, 0.0)      # one partial per 4 positions
+    cpu.shard_score2(rows_u, rows_i, uslot_c, islot, outs_c[3], outs_c[4], G * M, pred_c, coef_c, rec_c, cap, cap, 0, None, sq_c)
+    hip.shard_score2(rows_u.cuda(), rows_i.cuda(), uslot_g, islot.cuda(), outs_g[3], outs_g[4], G * M, pred_g, coef_g, rec_g,
+                     cap, cap, 0, None, sq_g)
+    np.testing.assert_allclose(pred_g.cpu().numpy(), pred_c.numpy(), rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(coef_g.cpu().numpy(), coef_c.numpy(), rtol=1e-5, atol=1e-9)
+    np.testing.assert_allclose(rec_g.cpu().numpy(), rec_c.numpy(), rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(float(sq_g.sum().item()), float(sq_c[0]), rtol=1e-5)
+
+    reply = torch.randn(G * (cap + TAIL), generator=g)
+    k_all = torch.tensor([700.0, 650.0, 712.0, 3.0])
+    rep_c, rep_g = reply.clone(), reply.cuda()
+    sums_c, sums_g = pair((2,), torch.float32, 0.0)
+    cpu.post_fair(rep_c, k_all, G, cap, sums_c)
+    hip.post_fair(rep_g, k_all.cuda(), G, cap, sums_g)
+    same(rep_c, rep_g); same(sums_c, sums_g)
+    for fair in (True, False):
+        loss_c, loss_g = pair((3,), torch.float32, 0.0)
+        cpu.loss_finish(sums_c, k_all, G, G * M, 0.3, fair, loss_c)
+        hip.loss_finish(sums_g, k_all.cuda(), G, G * M, 0.3, fair, loss_g)
+        np.testing.assert_allclose(loss_g.cpu().numpy(), loss_c.numpy(), rtol=1e-6)
+
+    gu_c, gu_g = pair((n, D), torch.float32, 0.0)
+    gi_c, gi_g = pair((n, D), torch.float32, 0.0)
+    lo_c, lo_g = pair((3,), torch.float32, 0.0)
+    cpu.shard_grads2(rows_u, rows_i, uslot_c, islot, coef_c, rep_c, G, G * M, 0.3, lo_c, cap, cap, 0, gu_c, gi_c)
+    hip.shard_grads2(rows_u.cuda(), rows_i.cuda(), uslot_g, islot.cuda(), coef_g, rep_g, G, G * M, 0.3, lo_g, cap, cap, 0,
+                     gu_g, gi_g)
+    touched_u, touched_i = uslot_c[(uslot_c >= 0) & (islot >= 0)].long(), islot[(uslot_c >= 0) & (islot >= 0)].long()
+    np.testing.assert_allclose(gu_g.cpu().numpy()[touched_u], gu_c.numpy()[touched_u], rtol=2e-5, atol=1e-9)
+    np.testing.assert_allclose(gi_g.cpu().numpy()[touched_i], gi_c.numpy()[touched_i], rtol=2e-5, atol=1e-9)
