@@ -404,6 +404,27 @@ FR_API int fr_linear_bwd_weight(const float* dY, const float* Y, int32_t act, co
  * products (the autograd of the activation in layers.py:68-72), after which both are called with act = 0 and take
  * their fast form (LDS-DMA kernels: no dropout mask, act = 0, widths multiples of 32). */
 FR_API int fr_act_bwd(const float* dY, const float* Y, int32_t act, int64_t n, float* out, void* stream);
+/* The same pre-pass through a ReLU whose OUTPUT went through dropout in place: Yd = relu(z) o keep (keep = 0 or scale),
+ * dY = gradient with respect to Yd; out = dY o scale o [Yd > 0] = dY o keep o relu'(z).  Replaces the reference's
+ * Dropout.backward + ReLU.backward pair between two Linear layers (recbole/model/layers.py:62-72). */
+FR_API int fr_act_bwd_dropped(const float* dY, const float* Yd, float scale, int64_t n, float* out, void* stream);
+
+/* ---- dropout without a stored mask (csrc/dropout.hip) ----------------------------------------------------------------
+ * out[i] = x[i] * keep_i for i < n (in place allowed), keep_i = 0 with probability p, else 1/(1-p); keep_i is a pure
+ * function (Philox4x32-10) of (seed, *counter, offset + i).  offset % 4 == 0; x, out 16-byte aligned.
+ *   counter     device int64: the call counter to use.  A forward pass hands its state word; the backward pass the
+ *               value that forward recorded, so that it regenerates the same pattern.
+ *   used_out    optional device int64[1]: receives the counter value this launch used.
+ *   tick_state  optional device int64[2] {counter, ticket}, ticket == 0 between launches: this launch advances the
+ *               counter by one AFTER all of its workgroups have read it (pass it with the LAST launch of a forward pass,
+ *               whose launches then all see the same value; `counter` must then be tick_state).
+ * nn.Dropout of the reference's MLPLayers (recbole/model/layers.py:62-63); see DESIGN.md §8a. */
+FR_API int fr_dropout_apply(const float* x, int64_t n, float p, uint64_t seed, uint64_t offset, const int64_t* counter,
+                            int64_t* used_out, int64_t* tick_state, float* out, void* stream);
+
+/* n <= FR_COPY_MAX device-to-device copies of bytes[j] bytes in ONE launch (jobs must not overlap each other). */
+#define FR_COPY_MAX 16
+FR_API int fr_copy_many(const void* const* src, void* const* dst, const int64_t* bytes, int32_t n, void* stream);
 
 /* BatchNorm1d on batch statistics between Linear and activation (MLPLayers(bn=True), layers.py:66-67; the PFCN filters
  * and discriminators, which the reference never puts in eval mode).  Z [M,N] -> Y = act(gamma * xhat + beta);

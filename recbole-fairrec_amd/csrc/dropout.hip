@@ -1,0 +1,141 @@
+// Dropout as a pure function of (seed, call counter, element index): out = x * keep, keep = 0 with probability p and
+// 1/(1-p) otherwise.  Nothing is stored: the backward pass regenerates the pattern of its forward call from the counter
+// value that call used.  The counter lives in device memory and is advanced by the forward's last launch itself, so a
+// captured step (hipGraph) draws a fresh pattern on every replay with no host involvement.
+//
+// Replaces, per MLP forward of the reference's `nn.Dropout` layers (recbole/model/layers.py:62-63), torch's
+// rand / ge / cast / mul launches and a [B, sum of layer widths] fp32 mask read twice per step.  The pattern is NOT
+// torch's (the reference's dropout stream is not reproducible across devices either); tests/ pin the arithmetic with
+// recorded masks through MLPLayers.forced_masks and this generator through its own properties.
+#include "kernels.hpp"
+
+namespace fr {
+
+// Philox4x32-10 (Salmon et al., SC'11): 4 x 32 random bits per (counter, key).
+__device__ __forceinline__ uint4 philox4x32(uint4 c, uint2 k) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
+        const unsigned hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
+        c = make_uint4(hi1 ^ c.y ^ k.x, lo1, hi0 ^ c.w ^ k.y, lo0);
+        k.x += 0x9E3779B9u;
+        k.y += 0xBB67AE85u;
+    }
+    return c;
+}
+
+// state = {call counter, ticket}.  Every workgroup takes the counter through ONE load of its first thread; when `tick`
+// is set that thread then draws a ticket whose increment depends on the loaded value (so the load has completed), and
+// the holder of the last ticket -- every workgroup has read the counter by then -- advances it and resets the tickets.
+__global__ __launch_bounds__(256) void dropout_apply_kernel(const float* __restrict__ x, long long n, unsigned thr,
+                                                            float scale, unsigned long long seed,
+                                                            unsigned long long off4,
+                                                            const unsigned long long* __restrict__ ctr_src,
+                                                            unsigned long long* __restrict__ used_out,
+                                                            unsigned long long* __restrict__ tick,
+                                                            float* __restrict__ out) {
+    __shared__ unsigned long long ctr_s;
+    if (threadIdx.x == 0) {
+        const unsigned long long c = __hip_atomic_load(ctr_src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ctr_s = c;
+        if (used_out && blockIdx.x == 0) *used_out = c;
+        if (tick) {
+            const unsigned long long t = atomicAdd(&tick[1], 1ull + (c >> 63));
+            if (t == gridDim.x - 1) {
+                tick[1] = 0ull;
+                tick[0] = c + 1ull;
+            }
+        }
+    }
+    __syncthreads();
+    const unsigned long long ctr = ctr_s;
+    const long long q = (long long)blockIdx.x * 256 + threadIdx.x;      // this thread's group of 4 elements
+    const long long i = q * 4;
+    if (i >= n) return;
+    const unsigned long long g = off4 + (unsigned long long)q;
+    const uint4 r = philox4x32(make_uint4((unsigned)g, (unsigned)(g >> 32), (unsigned)ctr, (unsigned)(ctr >> 32)),
+                               make_uint2((unsigned)seed, (unsigned)(seed >> 32)));
+    const float k0 = r.x >= thr ? scale : 0.f, k1 = r.y >= thr ? scale : 0.f, k2 = r.z >= thr ? scale : 0.f,
+                k3 = r.w >= thr ? scale : 0.f;
+    if (i + 4 <= n) {
+        const float4 v = *reinterpret_cast<const float4*>(x + i);
+        *reinterpret_cast<float4*>(out + i) = make_float4(v.x * k0, v.y * k1, v.z * k2, v.w * k3);
+    } else {
+        const float k[4] = {k0, k1, k2, k3};
+        for (int e = 0; i + e < n; ++e) out[i + e] = x[i + e] * k[e];
+    }
+}
+
+}  // namespace fr
+
+extern "C" int fr_dropout_apply(const float* x, int64_t n, float p, uint64_t seed, uint64_t offset, const int64_t* counter,
+                                int64_t* used_out, int64_t* tick_state, float* out, void* stream_) {
+    using namespace fr;
+    hipStream_t stream = (hipStream_t)stream_;
+    FR_CHECK_ARG(x && out && counter && n >= 1 && p >= 0.f && p < 1.f && offset % 4 == 0, "fr_dropout_apply: bad argument");
+    FR_CHECK_ARG((((uintptr_t)x | (uintptr_t)out) & 15) == 0, "fr_dropout_apply: 16-byte alignment required");
+    const double t = (double)p * 4294967296.0;
+    const unsigned thr = t >= 4294967295.0 ? 0xFFFFFFFFu : (unsigned)t;     // keep <=> 32 random bits >= thr
+    const long long groups = (n + 3) / 4;
+    hipLaunchKernelGGL(dropout_apply_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, stream, x, (long long)n, thr,
+                       1.f / (1.f - p), (unsigned long long)seed, (unsigned long long)(offset / 4),
+                       (const unsigned long long*)counter, (unsigned long long*)used_out, (unsigned long long*)tick_state, out);
+    FR_CHECK_LAUNCH();
+    return FR_OK;
+}
+
+// ---- several small device-to-device copies in one launch ------------------------------------------------------------------
+// A captured training step reads its batch from static tensors; refreshing them column by column costs one ~5 us copy
+// launch per column (fairrec/graph.py).  One launch: workgroup b copies 4 KiB chunk (b - first[j]) of job j.
+namespace fr {
+struct CopyJobs {
+    const unsigned char* src[FR_COPY_MAX];
+    unsigned char* dst[FR_COPY_MAX];
+    unsigned long long bytes[FR_COPY_MAX];
+    unsigned first[FR_COPY_MAX + 1];     // first workgroup of job j
+    int n;
+};
+
+__global__ __launch_bounds__(256) void copy_many_kernel(CopyJobs J) {
+    int j = 0;
+    while (j + 1 < J.n && blockIdx.x >= J.first[j + 1]) ++j;
+    const unsigned long long base = (unsigned long long)(blockIdx.x - J.first[j]) * 4096ull;
+    const unsigned char* s = J.src[j] + base;
+    unsigned char* d = J.dst[j] + base;
+    const unsigned long long left = J.bytes[j] - base;
+    const unsigned len = left < 4096ull ? (unsigned)left : 4096u;
+    if (((((uintptr_t)s) | ((uintptr_t)d)) & 15) == 0) {
+        const unsigned o = threadIdx.x * 16;
+        if (o + 16 <= len) *reinterpret_cast<uint4*>(d + o) = *reinterpret_cast<const uint4*>(s + o);
+        else
+            for (unsigned e = o; e < len; ++e) d[e] = s[e];
+    } else {
+        for (unsigned e = threadIdx.x; e < len; e += 256) d[e] = s[e];
+    }
+}
+}  // namespace fr
+
+extern "C" int fr_copy_many(const void* const* src, void* const* dst, const int64_t* bytes, int32_t n, void* stream_) {
+    using namespace fr;
+    hipStream_t stream = (hipStream_t)stream_;
+    FR_CHECK_ARG(src && dst && bytes && n >= 1 && n <= FR_COPY_MAX, "fr_copy_many: bad argument (1..FR_COPY_MAX jobs)");
+    CopyJobs J{};
+    unsigned blocks = 0;
+    int m = 0;
+    for (int j = 0; j < n; ++j) {
+        FR_CHECK_ARG(bytes[j] >= 0 && (bytes[j] == 0 || (src[j] && dst[j])), "fr_copy_many: bad job");
+        if (bytes[j] == 0) continue;
+        J.src[m] = (const unsigned char*)src[j];
+        J.dst[m] = (unsigned char*)dst[j];
+        J.bytes[m] = (unsigned long long)bytes[j];
+        J.first[m] = blocks;
+        blocks += (unsigned)((bytes[j] + 4095) / 4096);
+        ++m;
+    }
+    if (m == 0) return FR_OK;
+    J.first[m] = blocks;
+    J.n = m;
+    hipLaunchKernelGGL(copy_many_kernel, dim3(blocks), dim3(256), 0, stream, J);
+    FR_CHECK_LAUNCH();
+    return FR_OK;
+}

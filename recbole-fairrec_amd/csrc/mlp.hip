@@ -495,7 +495,16 @@ extern "C" int fr_linear_bwd_weight(const float* dY, const float* Y, int32_t act
 extern "C" int fr_act_bwd(const float* dY, const float* Y, int32_t act, int64_t n, float* out, void* stream_) {
     FR_CHECK_ARG(dY && Y && out && n >= 1 && n % 4 == 0 && act_ok(act), "fr_act_bwd: bad argument (n must be a multiple of 4)");
     FR_CHECK_ARG((((uintptr_t)dY | (uintptr_t)Y | (uintptr_t)out) & 15) == 0, "fr_act_bwd: 16-byte alignment required");
-    return launch_act_bwd(dY, Y, (int)act, (long long)n, out, (hipStream_t)stream_);
+    return launch_act_bwd(dY, Y, (int)act, 1.f, (long long)n, out, (hipStream_t)stream_);
+}
+
+// ... with a dropout of the activation's OUTPUT folded in: Y is the dropped output Yd = act(z) o keep, dY the gradient with
+// respect to Yd, `scale` = 1/(1-p).  ReLU only: there Yd > 0 exactly where z > 0 and the element was kept, so
+// dY o keep o act'(z) = dY o scale o [Yd > 0] and neither z nor the keep pattern is needed.
+extern "C" int fr_act_bwd_dropped(const float* dY, const float* Yd, float scale, int64_t n, float* out, void* stream_) {
+    FR_CHECK_ARG(dY && Yd && out && n >= 1 && n % 4 == 0 && scale > 0.f, "fr_act_bwd_dropped: bad argument (n must be a multiple of 4)");
+    FR_CHECK_ARG((((uintptr_t)dY | (uintptr_t)Yd | (uintptr_t)out) & 15) == 0, "fr_act_bwd_dropped: 16-byte alignment required");
+    return launch_act_bwd(dY, Yd, ACT_RELU, scale, (long long)n, out, (hipStream_t)stream_);
 }
 
 // ---- BatchNorm1d on batch statistics (training mode) --------------------------------------------------------------

@@ -282,7 +282,7 @@ __global__ __launch_bounds__(GL_WAVES * 64) void linear_glds_kernel(GlArgs g) {
 }
 
 __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ dY, const float* __restrict__ Y, int act,
-                                                      long long n4, float* __restrict__ out) {
+                                                      float scale, long long n4, float* __restrict__ out) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n4) return;
     const f4 d = reinterpret_cast<const f4*>(dY)[i], y = reinterpret_cast<const f4*>(Y)[i];
@@ -297,7 +297,7 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ 
             case 4: s = 1.f - y[e] * y[e]; break;
             default: s = 1.f;
         }
-        o[e] = d[e] * s;
+        o[e] = d[e] * (s * scale);
     }
     reinterpret_cast<f4*>(out)[i] = o;
 }
@@ -395,9 +395,9 @@ int glds_linear_bwd_weight(const float* dY, const GlMat& X, int64_t M, int N, in
     return launch_mode<GL_BWD_W>(g, (nw + GL_WAVES - 1) / GL_WAVES, stream, K_LINEAR_BWD_WEIGHT);
 }
 
-int launch_act_bwd(const float* dY, const float* Y, int act, long long n, float* out, hipStream_t stream) {
+int launch_act_bwd(const float* dY, const float* Y, int act, float scale, long long n, float* out, hipStream_t stream) {
     const long long n4 = n / 4;
-    hipLaunchKernelGGL(act_bwd_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, dY, Y, act, n4, out);
+    hipLaunchKernelGGL(act_bwd_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, dY, Y, act, scale, n4, out);
     FR_CHECK_LAUNCH();
     return FR_OK;
 }

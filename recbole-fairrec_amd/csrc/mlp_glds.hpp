@@ -42,6 +42,6 @@ int glds_linear_bwd_input(const float* dY, const float* W, int64_t M, int N, int
 int glds_linear_bwd_weight(const float* dY, const GlMat& X, int64_t M, int N, int K, int splits, int rows_per_split,
                            float* slab, float* bslab, hipStream_t stream);
 // out = dY o act'(Y) elementwise (n % 4 == 0)
-int launch_act_bwd(const float* dY, const float* Y, int act, long long n, float* out, hipStream_t stream);
+int launch_act_bwd(const float* dY, const float* Y, int act, float scale, long long n, float* out, hipStream_t stream);
 
 }  // namespace fr

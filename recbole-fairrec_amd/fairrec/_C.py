@@ -7,7 +7,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_size_t, c_uint32, c_void_p
+from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_size_t, c_uint32, c_uint64, c_void_p
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libfairrec_hip.so")
 
@@ -133,6 +133,10 @@ _PROTOS = {
                                     c_void_p, c_int32, c_void_p, c_int32, c_void_p]),
     "fr_linear_bwd_weight_workspace_bytes": (c_size_t, [c_int64, c_int32, c_int32]),
     "fr_act_bwd": (c_int, [c_void_p, c_void_p, c_int32, c_int64, c_void_p, c_void_p]),
+    "fr_act_bwd_dropped": (c_int, [c_void_p, c_void_p, c_float, c_int64, c_void_p, c_void_p]),
+    "fr_dropout_apply": (c_int, [c_void_p, c_int64, c_float, c_uint64, c_uint64, c_void_p, c_void_p, c_void_p, c_void_p,
+                                 c_void_p]),
+    "fr_copy_many": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),
     "fr_linear_bwd_weight": (c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_void_p,
                                      c_float, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "fr_nfcf_loss_workspace_bytes": (c_size_t, [c_int64]),

@@ -83,10 +83,12 @@ class GenericEngine:
         if self._counters is None or not names:
             return
         key = tuple(sorted(self._counter_slot[n] for n in names))
-        idx = self._advance_idx.get(key)
-        if idx is None:
-            idx = self._advance_idx[key] = torch.tensor(key, dtype=torch.int64, device=self.device)
-        self._counters.index_add_(0, idx, torch.ones(len(key), dtype=torch.int32, device=self.device))
+        inc = self._advance_idx.get(key)
+        if inc is None:     # a 0/1 vector over all counters: one add, no fill and no index launch
+            inc = torch.zeros(self._counters.numel(), dtype=torch.int32)
+            inc[list(key)] = 1
+            inc = self._advance_idx[key] = inc.to(self.device)
+        self._counters += inc
 
     # --- registration ---------------------------------------------------------------------------------
     def add_table(self, name: str, weight: torch.nn.Parameter, trainable: bool = True, group=None) -> LazyTable:

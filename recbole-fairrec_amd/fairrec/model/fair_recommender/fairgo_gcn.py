@@ -54,7 +54,7 @@ class _GCNConv(nn.Module):
         self.register_buffer("_zero_bias", torch.zeros(out_channels), persistent=False)
 
     def forward(self, x, a_hat: CsrMatrix):
-        xw = _HipMLP.apply(x, None, 0, 0.0, None, None, self.lin.weight, self._zero_bias)     # X W^T (no bias)
+        xw = _HipMLP.apply(x, None, 0, 0.0, None, None, None, self.lin.weight, self._zero_bias)     # X W^T (no bias)
         return SpMM.apply(xw, a_hat) + self.bias
 
 

@@ -152,9 +152,9 @@ class FairGo_PMF(FairRecommender):
     def _aggr(self, x):
         code = ACT_CODES[self.act.lower()]
         lins = [m for m in self.aggr_layer if isinstance(m, nn.Linear)]
-        x = _HipMLP.apply(x, None, code, 0.0, None, None, lins[0].weight, lins[0].bias)
-        x = _HipMLP.apply(x, None, code, 0.0, None, None, lins[1].weight, lins[1].bias)
-        return _HipMLP.apply(x, None, 0, 0.0, None, None, lins[2].weight, lins[2].bias)
+        x = _HipMLP.apply(x, None, code, 0.0, None, None, None, lins[0].weight, lins[0].bias)
+        x = _HipMLP.apply(x, None, code, 0.0, None, None, None, lins[1].weight, lins[1].bias)
+        return _HipMLP.apply(x, None, 0, 0.0, None, None, None, lins[2].weight, lins[2].bias)
 
     def _propagate(self, E):
         """H_1 = L E, H_2 = L H_1, ... (fairgo_pmf.py:198-201) and what the aggregation needs of them as whole tables:

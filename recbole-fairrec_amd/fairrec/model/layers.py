@@ -34,12 +34,47 @@ def activation_layer(activation_name='relu', emb_dim=None):
     raise NotImplementedError("activation function {} is not implemented".format(activation_name))
 
 
+class _Drop:
+    """Dropout of one MLP forward pass drawn by csrc/dropout.hip: nothing stored, the pattern is a function of
+    (seed, call counter, element offset).  `state` = device int64 {counter, ticket}; the LAST apply of a forward pass
+    advances the counter on the device (replay-safe inside a hipGraph); `used` records the value for the backward pass."""
+
+    def __init__(self, seed: int, state: torch.Tensor, p: float, n_launches: int):
+        self.seed, self.state, self.p, self.left = seed & (2 ** 64 - 1), state, p, n_launches
+        self.used = torch.empty(1, dtype=torch.int64, device=state.device)
+        self.off = 0
+        self.first = True
+
+    def forward(self, x: torch.Tensor, out: torch.Tensor) -> int:
+        """out = dropout(x); returns the element offset of this launch (what `again` needs)."""
+        off, n = self.off, x.numel()
+        self.left -= 1
+        _C.check(_C.lib().fr_dropout_apply(x.data_ptr(), n, self.p, self.seed, off, self.state.data_ptr(),
+                                           self.used.data_ptr() if self.first else None,
+                                           self.state.data_ptr() if self.left == 0 else None, out.data_ptr(),
+                                           _C.current_stream()), "fr_dropout_apply")
+        self.first = False
+        self.off += (n + 3) // 4 * 4
+        return off
+
+    def again(self, g: torch.Tensor, off: int):
+        """g *= the keep pattern the forward launch at `off` drew (in place)."""
+        _C.check(_C.lib().fr_dropout_apply(g.data_ptr(), g.numel(), self.p, self.seed, off, self.used.data_ptr(), None, None,
+                                           g.data_ptr(), _C.current_stream()), "fr_dropout_apply")
+
+
 class _HipMLP(torch.autograd.Function):
-    """y = MLP([x0 | x1]) on the HIP kernels: per layer fr_linear_fwd [-> fr_bn_fwd] with the activation fused into
-    the last of the two; saves the post-activation outputs, the dropout masks and the BatchNorm statistics."""
+    """y = MLP([x0 | x1]) on the HIP kernels: per layer [dropout ->] fr_linear_fwd [-> fr_bn_fwd] with the activation fused
+    into the last of the two; saves the post-activation outputs and the BatchNorm statistics.
+
+    Dropout comes in two forms.  `masks` (tests: recorded patterns as fp32 keep-scales) multiply a layer's input, or go to
+    the general kernels as bytes when the input's width does not suit the fast GEMMs.  `drop` (training) draws the pattern
+    on the device with nothing stored: the input of the first layer is dropped into a copy and its gradient through the
+    regenerated pattern; a hidden layer's input is the previous layer's OUTPUT, dropped in place when that layer ends in a
+    plain ReLU -- the backward pass then needs neither the pattern nor the undropped output (fr_act_bwd_dropped)."""
 
     @staticmethod
-    def forward(ctx, x0, x1, act, p_drop, masks, bn_buffers, *params):
+    def forward(ctx, x0, x1, act, p_drop, masks, drop, bn_buffers, *params):
         lib = _C.lib()
         st = _C.current_stream()
         use_bn = bn_buffers is not None
@@ -53,6 +88,8 @@ class _HipMLP(torch.autograd.Function):
         cur = (x0, x1)
         outs, xhats, invstds = [], [], []
         premul, ins, masks8 = [], [], []
+        drop_off = [None] * n_layers          # (offset of block a, offset of block c) of a regenerated pattern
+        dropped_out = [False] * n_layers      # layer l's output was dropped in place for layer l + 1
         for l in range(n_layers):
             W, b = params[per * l].contiguous(), params[per * l + 1].contiguous()
             a, c = cur
@@ -61,7 +98,23 @@ class _HipMLP(torch.autograd.Function):
             Y = torch.empty((M, N), dtype=torch.float32, device=dev)
             mk = masks[l] if masks is not None else None      # fp32 keep scales [M, K] (0 or 1/(1-p)), or None
             mk8 = None
-            if mk is not None and k0 % 32 == 0 and k1 % 32 == 0:
+            if drop is not None:
+                if l > 0 and not use_bn and act == 1 and a.numel() % 4 == 0:
+                    drop.forward(a, a)                          # a IS outs[l - 1]
+                    dropped_out[l - 1] = True
+                    premul.append(False)
+                else:
+                    ad = torch.empty_like(a)
+                    oa = drop.forward(a, ad)
+                    cd, oc = None, 0
+                    if c is not None:
+                        cd = torch.empty_like(c)
+                        oc = drop.forward(c, cd)
+                    a, c, drop_off[l] = ad, cd, (oa, oc)
+                    premul.append(True)
+                _C.check(lib.fr_linear_fwd(a.data_ptr(), k0, _C.ptr(c), k1, None, 1.0, W.data_ptr(), b.data_ptr(), M, N,
+                                           0 if use_bn else act, Y.data_ptr(), st), "fr_linear_fwd")
+            elif mk is not None and k0 % 32 == 0 and k1 % 32 == 0:
                 # the layer's input with dropout applied (both blocks of a two-block input); kept for backward
                 a = a * (mk if c is None else mk[:, :k0])
                 c = c * mk[:, k0:] if c is not None else None
@@ -92,6 +145,7 @@ class _HipMLP(torch.autograd.Function):
             cur = (Y, None)
         ctx.act, ctx.scale, ctx.masks, ctx.n_layers, ctx.use_bn = act, scale, masks, n_layers, use_bn
         ctx.premul, ctx.ins, ctx.masks8 = premul, ins, masks8
+        ctx.drop, ctx.drop_off, ctx.dropped_out = drop, drop_off, dropped_out
         ctx.has_x1 = x1 is not None
         ctx.n_params = len(params)
         ctx.save_for_backward(x0, *([x1] if x1 is not None else []), *params, *outs, *xhats, *invstds)
@@ -113,6 +167,7 @@ class _HipMLP(torch.autograd.Function):
         grads: List[Optional[torch.Tensor]] = [None] * ctx.n_params
         dY = dY.contiguous()
         dx0 = dx1 = None
+        drop = ctx.drop
         for l in range(L - 1, -1, -1):
             W = params[per * l].contiguous()
             Y = outs[l]
@@ -123,8 +178,16 @@ class _HipMLP(torch.autograd.Function):
             scale = ctx.scale
             if ctx.premul[l]:                     # X o mask*scale was formed in the forward: the products see a plain input
                 (a, c), scale = ctx.ins[l], 1.0
+            elif drop is not None:
+                scale = 1.0                       # the input is the previous layer's output, dropped in place
             act = ctx.act
-            if ctx.use_bn:   # through activation + BatchNorm first; the linear layer then sees a plain gradient
+            if ctx.dropped_out[l]:
+                # Y is relu(z) o keep and dY the gradient with respect to it: one pass gives the gradient at z
+                dA = torch.empty_like(Y)
+                _C.check(lib.fr_act_bwd_dropped(dY.data_ptr(), Y.data_ptr(), ctx.scale, M * N, dA.data_ptr(), st),
+                         "fr_act_bwd_dropped")
+                dY, Y, act = dA, dA, 0
+            elif ctx.use_bn:   # through activation + BatchNorm first; the linear layer then sees a plain gradient
                 g = params[per * l + 2].contiguous()
                 dZ = torch.empty_like(Y)
                 dg = torch.empty(N, dtype=torch.float32, device=dev)
@@ -148,20 +211,26 @@ class _HipMLP(torch.autograd.Function):
                                               _C.ptr(mk), scale, M, N, dW.data_ptr(), db.data_ptr(), ws.data_ptr(),
                                               ws.numel(), st), "fr_linear_bwd_weight")
             grads[per * l], grads[per * l + 1] = dW, db
-            need_dx = l > 0 or ctx.needs_input_grad[0] or (ctx.has_x1 and ctx.needs_input_grad[1])
-            if need_dx:
+            need0 = l > 0 or ctx.needs_input_grad[0]
+            need1 = l == 0 and ctx.has_x1 and ctx.needs_input_grad[1]
+            if need0 or need1:
                 da = torch.empty((M, k0), dtype=torch.float32, device=dev)
                 dc = torch.empty((M, k1), dtype=torch.float32, device=dev) if k1 else None
                 _C.check(lib.fr_linear_bwd_input(dY.data_ptr(), Y.data_ptr(), act, W.data_ptr(), _C.ptr(mk), scale,
                                                  M, N, da.data_ptr(), k0, _C.ptr(dc), k1, st), "fr_linear_bwd_input")
-                if ctx.premul[l]:                 # back through the dropout of this layer's input
+                if drop is not None and ctx.premul[l]:      # back through this layer's input dropout: the pattern again
+                    if need0:
+                        drop.again(da, ctx.drop_off[l][0])
+                    if dc is not None and need1:
+                        drop.again(dc, ctx.drop_off[l][1])
+                elif ctx.premul[l]:               # back through the dropout of this layer's input
                     da = da * (ctx.masks[l] if dc is None else ctx.masks[l][:, :k0])
                     dc = dc * ctx.masks[l][:, k0:] if dc is not None else None
                 if l > 0:
                     dY = da
                 else:
-                    dx0, dx1 = da, dc
-        return (dx0, dx1, None, None, None, None, *grads)
+                    dx0, dx1 = (da if need0 else None), (dc if need1 else None)
+        return (dx0, dx1, None, None, None, None, None, *grads)
 
 
 class MLPLayers(nn.Module):
@@ -230,21 +299,35 @@ class MLPLayers(nn.Module):
             params = [t for lin in lins for t in (lin.weight, lin.bias)]
             bn_buffers = None
         p = float(self.dropout) if self.training else 0.0
-        # Dropout masks as fp32 "keep scales" (0 or 1/(1-p)): ONE draw for all layers of the MLP (3 launches instead of 3 per
-        # layer); a layer in the fast form multiplies its input by them once (so that the LDS-DMA GEMMs, which take no mask,
-        # serve it), the others get the same mask as bytes.
-        masks = None
+        # Dropout: drawn on the device with nothing stored (csrc/dropout.hip, `_Drop`); recorded patterns (tests) come as fp32
+        # "keep scales" (0 or 1/(1-p)) that a layer in the fast form multiplies its input by, the others get as bytes.
+        masks = drop = None
         if self.forced_masks is not None:
             scale = 1.0 / (1.0 - p) if p > 0 else 1.0
             masks = [m.to(input_feature.device, torch.float32).contiguous() * scale for m in self.forced_masks]
         elif p > 0.0:
-            M = input_feature.shape[0]
-            widths = [lin.in_features for lin in lins]
-            keep = (torch.rand(M * sum(widths), device=input_feature.device) >= p).to(torch.float32) * (1.0 / (1.0 - p))
-            masks, o = [], 0
-            for w in widths:
-                masks.append(keep[o:o + M * w].view(M, w))
-                o += M * w
+            drop = _Drop(self._drop_seed(), self._drop_state(input_feature.device), p,
+                         len(lins) + (1 if second_block is not None else 0))
         name = self.activation.lower() if isinstance(self.activation, str) else self.activation
-        return _HipMLP.apply(input_feature, second_block, ACT_CODES[name], p if masks is not None else 0.0, masks,
-                             bn_buffers, *params)
+        return _HipMLP.apply(input_feature, second_block, ACT_CODES[name], p if (masks is not None or drop is not None) else 0.0,
+                             masks, drop, bn_buffers, *params)
+
+    _instances = 0
+
+    def _drop_seed(self) -> int:
+        """Seed of this module's dropout stream: torch's seed when the module first drops, mixed with the module's
+        construction rank (same program + same torch.manual_seed => same patterns)."""
+        s = getattr(self, "_seed", None)
+        if s is None:
+            import torch.distributed as dist
+            MLPLayers._instances += 1
+            rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0      # ranks drop independently
+            s = self._seed = (torch.initial_seed() * 0x9E3779B97F4A7C15 + MLPLayers._instances * 0xD1B54A32D192ED03
+                              + rank * 0xA0761D6478BD642F) % 2 ** 64
+        return s
+
+    def _drop_state(self, device) -> torch.Tensor:
+        st = getattr(self, "_dstate", None)
+        if st is None or st.device != device:
+            st = self._dstate = torch.zeros(2, dtype=torch.int64, device=device)     # {call counter, ticket}
+        return st
