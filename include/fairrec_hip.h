@@ -257,6 +257,10 @@ FR_API int fr_table_gather(const fr_table* t, const fr_adam* adam, const int64_t
  * [G, T, cap, ...] all-to-all buffer (multi-GPU path), so the exchange needs no packing copies.
  */
 FR_API size_t fr_table_train_workspace_bytes(int64_t M, int32_t dim);
+/* Orders `stream` behind the index work (the sort fr_table_gather_train launches on the library's side stream) still pending
+ * on workspace `ws`.  fr_table_apply_grad, fr_focf_shard_fair and fr_nfcf_loss do this themselves; a caller that reads the
+ * segments of a workspace on its own (copying them for fr_table_gather_train_prepared) calls this first. */
+FR_API int fr_table_join(const void* ws, void* stream);
 /* The first fr_table_segments_bytes(M) bytes of a workspace hold the sorted segments of the id list (independent of the
  * table's width).  fr_table_gather_train_prepared skips the sort: the caller has put the segments of `idx` there, e.g. by
  * copying them from the workspace of another table with the same number of rows looked up with the same ids in this step
@@ -403,6 +407,12 @@ FR_API int fr_linear_bwd_weight(const float* dY, const float* Y, int32_t act, co
 /* out[n] = dY o act'(Y), elementwise (n % 4 == 0, 16-byte aligned): the shared pre-pass of a layer's two backward
  * products (the autograd of the activation in layers.py:68-72), after which both are called with act = 0 and take
  * their fast form (LDS-DMA kernels: no dropout mask, act = 0, widths multiples of 32). */
+/* Both backward products of a layer with ONE output (N == 1, one input block, no mask) in one pass over X: dW [K], db [1]
+ * (may be NULL) and dX [M, K] (may be NULL) -- what fr_linear_bwd_weight + fr_linear_bwd_input give for that shape.
+ * FR_EUNSUPPORTED unless K % 64 == 0, K <= 512 and X, W, dX are 16-byte aligned (take the two general calls then).
+ * ws: fr_linear_bwd_weight_workspace_bytes(M, 1, K). */
+FR_API int fr_linear_n1_bwd(const float* dY, const float* Y, int32_t act, const float* X, int32_t K, const float* W, int64_t M,
+                            float* dX, float* dW, float* db, void* ws, size_t ws_bytes, void* stream);
 FR_API int fr_act_bwd(const float* dY, const float* Y, int32_t act, int64_t n, float* out, void* stream);
 /* The same pre-pass through a ReLU whose OUTPUT went through dropout in place: Yd = relu(z) o keep (keep = 0 or scale),
  * dY = gradient with respect to Yd; out = dY o scale o [Yd > 0] = dY o keep o relu'(z).  Replaces the reference's

@@ -390,6 +390,96 @@ using namespace fr;
 
 static inline int act_ok(int act) { return act >= ACT_NONE && act <= ACT_TANH; }
 
+// ---- layers with ONE output (the last layer of a scorer / discriminator: recbole/model/layers.py MLPLayers([..., 1])) ------
+// A [M, K] x [K] product is a row-wise dot: the matrix tiles above spend a 64 x 64 tile (and three launches in the backward
+// pass) on a single column.  16 lanes per row, one float4 each per 64 columns; K % 64 == 0, K <= 512.
+static constexpr int N1_MAXQ = 8;
+
+__global__ __launch_bounds__(256) void linear_n1_fwd_kernel(const float* __restrict__ X, const float* __restrict__ W,
+                                                            const float* __restrict__ bias, int M, int K, int act,
+                                                            float* __restrict__ Y) {
+    const int sub = threadIdx.x & 15;
+    const long long m = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);
+    float acc = 0.f;
+    if (m < M) {
+        const float4* x = reinterpret_cast<const float4*>(X + m * K);
+        const float4* w = reinterpret_cast<const float4*>(W);
+        for (int q = sub; q < K / 4; q += 16) {
+            const float4 a = x[q], b = w[q];
+            acc = fmaf(a.x, b.x, acc); acc = fmaf(a.y, b.y, acc); acc = fmaf(a.z, b.z, acc); acc = fmaf(a.w, b.w, acc);
+        }
+    }
+    acc = group_sum<16>(acc);
+    if (m < M && sub == 0) Y[m] = act_fwd(acc + (bias ? bias[0] : 0.f), act);
+}
+
+// Backward of the same layer in one pass over X: dz = dY o act'(Y);  dX[m, :] = dz[m] * W;  per-workgroup partial sums of
+// dW = sum_m dz[m] X[m, :] and db = sum_m dz[m] into slab[blockIdx][K] / bslab[blockIdx] (summed by slab_reduce_kernel in
+// workgroup order: reproducible).
+__global__ __launch_bounds__(256) void linear_n1_bwd_kernel(const float* __restrict__ dY, const float* __restrict__ Y, int act,
+                                                            const float* __restrict__ X, const float* __restrict__ W, int M,
+                                                            int K, int rows_per_block, float* __restrict__ dX,
+                                                            float* __restrict__ slab, float* __restrict__ bslab) {
+    const int sub = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const int nq = K / 64;                                       // float4 columns per lane
+    float4 acc[N1_MAXQ];
+#pragma unroll
+    for (int q = 0; q < N1_MAXQ; ++q) acc[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    float accb = 0.f;
+    float4 w[N1_MAXQ];
+#pragma unroll
+    for (int q = 0; q < N1_MAXQ; ++q)
+        w[q] = q < nq ? reinterpret_cast<const float4*>(W)[q * 16 + sub] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const long long m0 = (long long)blockIdx.x * rows_per_block;
+    const long long m1 = m0 + rows_per_block < M ? m0 + rows_per_block : M;
+    for (long long m = m0 + grp; m < m1; m += 16) {
+        const float dz = dY[m] * act_bwd(Y[m], act);
+        const float4* x = reinterpret_cast<const float4*>(X + m * K);
+        float4* dx = dX ? reinterpret_cast<float4*>(dX + m * K) : nullptr;
+#pragma unroll
+        for (int q = 0; q < N1_MAXQ; ++q)
+            if (q < nq) {
+                const float4 a = x[q * 16 + sub];
+                acc[q].x = fmaf(dz, a.x, acc[q].x); acc[q].y = fmaf(dz, a.y, acc[q].y);
+                acc[q].z = fmaf(dz, a.z, acc[q].z); acc[q].w = fmaf(dz, a.w, acc[q].w);
+                if (dx) dx[q * 16 + sub] = make_float4(dz * w[q].x, dz * w[q].y, dz * w[q].z, dz * w[q].w);
+            }
+        if (sub == 0) accb += dz;
+    }
+    // the 16 row groups of the workgroup, combined in group order
+    __shared__ float4 red[16][16];
+    __shared__ float redb[16];
+    float* out = slab + (size_t)blockIdx.x * K;
+#pragma unroll
+    for (int q = 0; q < N1_MAXQ; ++q) {
+        if (q >= nq) break;
+        red[grp][sub] = acc[q];
+        __syncthreads();
+        if (grp == 0) {
+            float4 s = red[0][sub];
+            for (int g = 1; g < 16; ++g) {
+                const float4 t = red[g][sub];
+                s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+            }
+            reinterpret_cast<float4*>(out)[q * 16 + sub] = s;
+        }
+        __syncthreads();
+    }
+    if (sub == 0) redb[grp] = accb;
+    __syncthreads();
+    if (threadIdx.x == 0 && bslab) {
+        float s = redb[0];
+        for (int g = 1; g < 16; ++g) s += redb[g];
+        bslab[blockIdx.x] = s;
+    }
+}
+
+static inline bool n1_ok(int32_t N, int K, int32_t k1, const void* mask, const void* x0, const void* W) {
+    static const bool off = getenv("FAIRREC_LINEAR_SLOW") != nullptr || getenv("FAIRREC_LINEAR_NO_N1") != nullptr;
+    return !off && N == 1 && k1 == 0 && !mask && K % 64 == 0 && K <= 64 * N1_MAXQ && (((uintptr_t)x0 | (uintptr_t)W) & 15) == 0;
+}
+
+
 extern "C" int fr_linear_fwd(const float* x0, int32_t k0, const float* x1, int32_t k1, const uint8_t* mask, float scale,
                              const float* W, const float* bias, int64_t M, int32_t N, int32_t act, float* Y,
                              void* stream_) {
@@ -399,6 +489,12 @@ extern "C" int fr_linear_fwd(const float* x0, int32_t k0, const float* x1, int32
     const int K = k0 + k1;
     CatMat X{x0, x1, k0, k1};
     ProfScope prof(K_LINEAR_FWD, stream);
+    if (n1_ok(N, K, k1, mask, x0, W)) {
+        FR_LAUNCH(prof, linear_n1_fwd_kernel, dim3((unsigned)((M + 15) / 16)), dim3(256), 0, stream, x0, W, bias, (int)M, K,
+                  (int)act, Y);
+        FR_CHECK_LAUNCH();
+        return FR_OK;
+    }
     const bool aligned = K % 4 == 0 && k0 % 4 == 0 && k1 % 4 == 0 && ((uintptr_t)x0 & 15) == 0 && ((uintptr_t)W & 15) == 0 &&
                          (!x1 || ((uintptr_t)x1 & 15) == 0) && (!mask || ((uintptr_t)mask & 3) == 0);
     static const bool slow_only = getenv("FAIRREC_LINEAR_SLOW") != nullptr;
@@ -486,6 +582,37 @@ extern "C" int fr_linear_bwd_weight(const float* dY, const float* Y, int32_t act
     const long long n = (long long)N * K, tot = n + (db ? N : 0);
     hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((tot + 63) / 64)), dim3(256), 0, stream, (const float*)slab,
                        (const float*)bslab, (int)splits, n, db ? (int)N : 0, dW, db);
+    FR_CHECK_LAUNCH();
+    return FR_OK;
+}
+
+// Both backward products of a layer with ONE output in one pass over X (plus the slab reduction): what
+// fr_linear_bwd_weight + fr_linear_bwd_input compute for N == 1, k1 == 0, no mask.  dX may be NULL (first layer of a
+// model whose input needs no gradient).  Returns FR_EUNSUPPORTED when the shape does not suit (K % 64, K <= 512, 16-byte
+// aligned X and W): the caller then takes the two general calls.  ws as for fr_linear_bwd_weight.
+extern "C" int fr_linear_n1_bwd(const float* dY, const float* Y, int32_t act, const float* X, int32_t K, const float* W,
+                                int64_t M, float* dX, float* dW, float* db, void* ws, size_t ws_bytes, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    FR_CHECK_ARG(dY && Y && X && W && dW && ws && M >= 1 && K >= 1 && act_ok(act), "fr_linear_n1_bwd: bad argument");
+    if (!n1_ok(1, K, 0, nullptr, X, W) || (dX && ((uintptr_t)dX & 15) != 0)) {
+        set_error("fr_linear_n1_bwd: shape not supported (K %% 64 == 0, K <= %d, 16-byte aligned operands)", 64 * N1_MAXQ);
+        return FR_EUNSUPPORTED;
+    }
+    const long long splits = bwd_weight_splits(M, 1, K);
+    const int rows_per_block = (int)((M + splits - 1) / splits);
+    FR_CHECK_ARG(ws_bytes >= (size_t)splits * (K + 1) * sizeof(float), "fr_linear_n1_bwd: workspace too small");
+    float* slab = (float*)ws;
+    float* bslab = db ? slab + (size_t)splits * K : nullptr;
+    const int blocks = (int)((M + rows_per_block - 1) / rows_per_block);
+    {
+        ProfScope prof(K_LINEAR_BWD_WEIGHT, stream);
+        FR_LAUNCH(prof, linear_n1_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, dY, Y, (int)act, X, W, (int)M, (int)K,
+                  rows_per_block, dX, slab, bslab);
+    }
+    FR_CHECK_LAUNCH();
+    const long long tot = K + (db ? 1 : 0);
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((tot + 63) / 64)), dim3(256), 0, stream, (const float*)slab,
+                       (const float*)bslab, blocks, (long long)K, db ? 1 : 0, dW, db);
     FR_CHECK_LAUNCH();
     return FR_OK;
 }

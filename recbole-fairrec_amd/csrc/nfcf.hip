@@ -11,12 +11,28 @@ namespace fr {
 
 // y = last MLP layer's output AFTER its ReLU (layers.py:63-70), out = sigmoid(y).
 // dy[b] = d mean(BCE) / d y[b]  with torch's BCE backward: (out - label) / max(out*(1-out), 1e-12) / B * out*(1-out)
+// With `sst`: mm_part[2 * block] = (min, max) of the sensitive attribute over the block's POSITIVE rows
+// (torch.unique(sst[label == 1]), nfcf.py:79; reduced by the fairness kernels).
 __global__ __launch_bounds__(256) void nfcf_bce_kernel(const float* __restrict__ y, const float* __restrict__ label, int B,
                                                        float* __restrict__ out, float* __restrict__ dy,
-                                                       float* __restrict__ part) {
-    __shared__ float red[4];
+                                                       float* __restrict__ part, const float* __restrict__ sst,
+                                                       float* __restrict__ mm_part) {
+    __shared__ float red[4], lo_s[4], hi_s[4];
     const int b = blockIdx.x * 256 + threadIdx.x;
     float l = 0.f;
+    if (sst) {
+        float lo = INFINITY, hi = -INFINITY;
+        if (b < B && label[b] == 1.f) lo = hi = sst[b];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            lo = fminf(lo, __shfl_xor(lo, o, 64));
+            hi = fmaxf(hi, __shfl_xor(hi, o, 64));
+        }
+        if ((threadIdx.x & 63) == 0) {
+            lo_s[threadIdx.x >> 6] = lo;
+            hi_s[threadIdx.x >> 6] = hi;
+        }
+    }
     if (b < B) {
         const float o = 1.f / (1.f + __expf(-y[b]));
         const float t = label[b];
@@ -30,40 +46,33 @@ __global__ __launch_bounds__(256) void nfcf_bce_kernel(const float* __restrict__
     l = wave_sum(l);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = l;
     __syncthreads();
-    if (threadIdx.x == 0) part[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
+    if (threadIdx.x == 0) {
+        part[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
+        if (sst) {
+            mm_part[2 * blockIdx.x] = fminf(fminf(lo_s[0], lo_s[1]), fminf(lo_s[2], lo_s[3]));
+            mm_part[2 * blockIdx.x + 1] = fmaxf(fmaxf(hi_s[0], hi_s[1]), fmaxf(hi_s[2], hi_s[3]));
+        }
+    }
 }
 
-// min / max of the sensitive attribute over the POSITIVE rows (torch.unique(sst[label == 1]), nfcf.py:79)
-__global__ __launch_bounds__(1024) void nfcf_pos_minmax_kernel(const float* __restrict__ sst,
-                                                              const float* __restrict__ label, int B,
-                                                              float* __restrict__ minmax) {
-    __shared__ float lo_s[16], hi_s[16];
-    float lo = INFINITY, hi = -INFINITY;
-    for (int b = threadIdx.x; b < B; b += 1024)
-        if (label[b] == 1.f) {
-            lo = fminf(lo, sst[b]);
-            hi = fmaxf(hi, sst[b]);
+// (min, max) over the per-block pairs of nfcf_bce_kernel, by the first wave of the calling workgroup; every thread gets
+// the pair after the barrier inside.
+__device__ __forceinline__ float2 pos_minmax(const float* __restrict__ mm_part, int n, float2* sh) {
+    if (threadIdx.x < 64) {
+        float lo = INFINITY, hi = -INFINITY;
+        for (int q = threadIdx.x; q < n; q += 64) {
+            lo = fminf(lo, mm_part[2 * q]);
+            hi = fmaxf(hi, mm_part[2 * q + 1]);
         }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        lo = fminf(lo, __shfl_xor(lo, o, 64));
-        hi = fmaxf(hi, __shfl_xor(hi, o, 64));
-    }
-    if ((threadIdx.x & 63) == 0) {
-        lo_s[threadIdx.x >> 6] = lo;
-        hi_s[threadIdx.x >> 6] = hi;
+        for (int o = 32; o > 0; o >>= 1) {
+            lo = fminf(lo, __shfl_xor(lo, o, 64));
+            hi = fmaxf(hi, __shfl_xor(hi, o, 64));
+        }
+        if (threadIdx.x == 0) *sh = make_float2(lo, hi);
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int w = 1; w < 16; ++w) {
-            lo = fminf(lo, lo_s[w]);
-            hi = fmaxf(hi, hi_s[w]);
-        }
-        lo = fminf(lo, lo_s[0]);
-        hi = fmaxf(hi, hi_s[0]);
-        minmax[0] = lo;
-        minmax[1] = hi;
-    }
+    return *sh;
 }
 
 static constexpr int DF_THREADS = 256, DF_GROUP = 16;
@@ -72,13 +81,20 @@ static constexpr int DF_THREADS = 256, DF_GROUP = 16;
 __global__ __launch_bounds__(DF_THREADS) void nfcf_df_stats_kernel(TableWs w, const float* __restrict__ out,
                                                                    const float* __restrict__ label,
                                                                    const float* __restrict__ sst,
-                                                                   const float* __restrict__ minmax,
+                                                                   const float* __restrict__ mm_part, int n_mm,
+                                                                   float* __restrict__ minmax,
                                                                    float4* __restrict__ stats, int* __restrict__ kpart,
                                                                    uint32_t* err) {
     const int sub = threadIdx.x & (DF_GROUP - 1), gib = threadIdx.x / DF_GROUP;
     const int k = blockIdx.x * (DF_THREADS / DF_GROUP) + gib;
     const int nseg = w.nseg[0];
-    const float smin = minmax[0], smax = minmax[1];
+    __shared__ float2 mm_sh;
+    const float2 mm = pos_minmax(mm_part, n_mm, &mm_sh);
+    const float smin = mm.x, smax = mm.y;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {      // for the second pass
+        minmax[0] = smin;
+        minmax[1] = smax;
+    }
     __shared__ int cnt[DF_THREADS / DF_GROUP];
     int has = 0;
     if (k < nseg) {
@@ -196,7 +212,7 @@ using namespace fr;
 extern "C" size_t fr_nfcf_loss_workspace_bytes(int64_t B) {
     if (B < 1) return 0;
     const size_t nb = (size_t)(B + 255) / 256, ndf = (size_t)(B * DF_GROUP + DF_THREADS - 1) / DF_THREADS;
-    return align_up(nb * 4, 256) + align_up(ndf * 4, 256) * 2 + align_up((size_t)B * 16, 256) + 256 * 2;
+    return align_up(nb * 4, 256) + align_up(ndf * 4, 256) * 2 + align_up((size_t)B * 16, 256) + 256 * 2 + align_up(nb * 8, 256);
 }
 
 // y [B] = scorer output after its ReLU; writes out = sigmoid(y) [B], dy [B] = dLoss/dy, loss[3].
@@ -215,21 +231,23 @@ extern "C" int fr_nfcf_loss(const float* y, const float* label, const float* sst
     int* kpart = (int*)p; p += align_up((size_t)ndf * 4, 256);
     float4* stats = (float4*)p; p += align_up((size_t)B * 16, 256);
     float* minmax = (float*)p; p += 256;
-    float* kout = (float*)p;
+    float* kout = (float*)p; p += 256;
+    float* mm_part = (float*)p;
+    const bool df = item_ws != nullptr;
     {
         ProfScope prof(K_NFCF_LOSS, stream);
-        FR_LAUNCH(prof, nfcf_bce_kernel, dim3(nb), dim3(256), 0, stream, y, label, (int)B, out, dy, bce_part);
+        FR_LAUNCH(prof, nfcf_bce_kernel, dim3(nb), dim3(256), 0, stream, y, label, (int)B, out, dy, bce_part,
+                  df ? sst : (const float*)nullptr, mm_part);
     }
     FR_CHECK_LAUNCH();
-    const bool df = item_ws != nullptr;
     if (df) {
         FR_CHECK_ARG(sst, "fr_nfcf_loss: the fairness term needs the sst column");
         TableWs tw = table_layout(item_ws, B, dim);
         FR_CHECK_ARG(item_ws_bytes >= tw.bytes, "fr_nfcf_loss: item workspace too small");
-        hipLaunchKernelGGL(nfcf_pos_minmax_kernel, dim3(1), dim3(1024), 0, stream, sst, label, (int)B, minmax);
-        FR_CHECK_LAUNCH();
+        // the sort that fills the segments runs on the side stream behind fr_table_gather_train: wait for it here
+        if (int rc = side_join(item_ws, stream)) return rc;
         hipLaunchKernelGGL(nfcf_df_stats_kernel, dim3(ndf), dim3(DF_THREADS), 0, stream, tw, (const float*)out, label, sst,
-                           (const float*)minmax, stats, kpart, err_flag);
+                           (const float*)mm_part, nb, minmax, stats, kpart, err_flag);
         FR_CHECK_LAUNCH();
         hipLaunchKernelGGL(nfcf_df_coef_kernel, dim3(ndf), dim3(DF_THREADS), 0, stream, tw, (const float*)out, label, sst,
                            (const float*)minmax, (const float4*)stats, (const int*)kpart, ndf, fair_weight, dy, df_part,

@@ -302,6 +302,13 @@ extern "C" size_t fr_table_segments_bytes(int64_t M) {
     return (size_t)((char*)w.m_side - base);
 }
 
+// Orders `stream` behind the index work (the sort of fr_table_gather_train, which runs on the library's side stream) still
+// pending on workspace `ws`: for callers that read the segments themselves (copying them to a second table's workspace).
+extern "C" int fr_table_join(const void* ws, void* stream_) {
+    FR_CHECK_ARG(ws, "fr_table_join: null workspace");
+    return side_join(ws, (hipStream_t)stream_);
+}
+
 extern "C" int fr_table_gather_train_prepared(const fr_table* t, const fr_adam* adam, const int64_t* idx, int64_t M,
                                               int32_t chunk, int32_t stride, float* rows_out, void* ws, size_t ws_bytes,
                                               uint32_t* err_flag, void* stream_) {

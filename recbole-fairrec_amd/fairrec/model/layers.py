@@ -207,24 +207,32 @@ class _HipMLP(torch.autograd.Function):
             ws = torch.empty(need, dtype=torch.uint8, device=dev)
             dW = torch.empty_like(W)
             db = torch.empty(N, dtype=torch.float32, device=dev)
-            _C.check(lib.fr_linear_bwd_weight(dY.data_ptr(), Y.data_ptr(), act, a.data_ptr(), k0, _C.ptr(c), k1,
-                                              _C.ptr(mk), scale, M, N, dW.data_ptr(), db.data_ptr(), ws.data_ptr(),
-                                              ws.numel(), st), "fr_linear_bwd_weight")
-            grads[per * l], grads[per * l + 1] = dW, db
             need0 = l > 0 or ctx.needs_input_grad[0]
             need1 = l == 0 and ctx.has_x1 and ctx.needs_input_grad[1]
+            da = dc = None
+            if N == 1 and c is None and mk is None and K % 64 == 0 and K <= 512:
+                # a layer with one output: both products in one pass over its input
+                da = torch.empty((M, k0), dtype=torch.float32, device=dev) if need0 else None
+                _C.check(lib.fr_linear_n1_bwd(dY.data_ptr(), Y.data_ptr(), act, a.data_ptr(), K, W.data_ptr(), M, _C.ptr(da),
+                                              dW.data_ptr(), db.data_ptr(), ws.data_ptr(), ws.numel(), st), "fr_linear_n1_bwd")
+            else:
+                _C.check(lib.fr_linear_bwd_weight(dY.data_ptr(), Y.data_ptr(), act, a.data_ptr(), k0, _C.ptr(c), k1,
+                                                  _C.ptr(mk), scale, M, N, dW.data_ptr(), db.data_ptr(), ws.data_ptr(),
+                                                  ws.numel(), st), "fr_linear_bwd_weight")
+                if need0 or need1:
+                    da = torch.empty((M, k0), dtype=torch.float32, device=dev)
+                    dc = torch.empty((M, k1), dtype=torch.float32, device=dev) if k1 else None
+                    _C.check(lib.fr_linear_bwd_input(dY.data_ptr(), Y.data_ptr(), act, W.data_ptr(), _C.ptr(mk), scale,
+                                                     M, N, da.data_ptr(), k0, _C.ptr(dc), k1, st), "fr_linear_bwd_input")
+            grads[per * l], grads[per * l + 1] = dW, db
             if need0 or need1:
-                da = torch.empty((M, k0), dtype=torch.float32, device=dev)
-                dc = torch.empty((M, k1), dtype=torch.float32, device=dev) if k1 else None
-                _C.check(lib.fr_linear_bwd_input(dY.data_ptr(), Y.data_ptr(), act, W.data_ptr(), _C.ptr(mk), scale,
-                                                 M, N, da.data_ptr(), k0, _C.ptr(dc), k1, st), "fr_linear_bwd_input")
                 if drop is not None and ctx.premul[l]:      # back through this layer's input dropout: the pattern again
                     if need0:
                         drop.again(da, ctx.drop_off[l][0])
                     if dc is not None and need1:
                         drop.again(dc, ctx.drop_off[l][1])
                 elif ctx.premul[l]:               # back through the dropout of this layer's input
-                    da = da * (ctx.masks[l] if dc is None else ctx.masks[l][:, :k0])
+                    da = da * (ctx.masks[l] if dc is None else ctx.masks[l][:, :k0]) if da is not None else None
                     dc = dc * ctx.masks[l][:, k0:] if dc is not None else None
                 if l > 0:
                     dY = da

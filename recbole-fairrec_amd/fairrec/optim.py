@@ -175,6 +175,8 @@ class LazyTable:
         hyper.check_step(self.step + 1)
         if segments_of is not None and segments_of._ws is not None and segments_of.n_rows == self.n_rows:
             n = _C.lib().fr_table_segments_bytes(M)
+            # (the other table's sort runs on the library's side stream: wait for it before reading its result)
+            _C.check(_C.lib().fr_table_join(segments_of._ws.data_ptr(), _C.current_stream()), "fr_table_join")
             self._ws[:n].copy_(segments_of._ws[:n])
             _C.check(_C.lib().fr_table_gather_train_prepared(ctypes.byref(t), ctypes.byref(hyper.c()), idx_ptr, M, chunk,
                                                              stride, rows_ptr, self._ws.data_ptr(), self._ws.numel(),

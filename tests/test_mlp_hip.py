@@ -74,6 +74,63 @@ def test_linear_forward_and_backward_match_torch(M, k0, k1, N, act, drop):
     assert torch.equal(dW, dW2)
 
 
+@pytest.mark.parametrize("M,K,act,need_dx", [(8192, 64, 1, True), (777, 128, 3, True), (5000, 512, 0, False), (1, 64, 4, True),
+                                             (8192, 64, 2, False)])
+def test_one_output_layer_forward_and_fused_backward_match_torch(M, K, act, need_dx):
+    """N == 1 (a scorer's / discriminator's last layer): fr_linear_fwd takes its row-dot form, fr_linear_n1_bwd gives dW, db
+    and dX in one pass; shapes the form does not cover are refused so that the caller takes the general calls."""
+    _C = _lib()
+    lib = _C.lib()
+    g = torch.Generator().manual_seed(M + K)
+    X = torch.randn(M, K, generator=g)
+    W = torch.randn(1, K, generator=g) * 0.3
+    b = torch.randn(1, generator=g)
+    dY = torch.randn(M, 1, generator=g)
+    Xr, Wr, br = X.clone().requires_grad_(), W.clone().requires_grad_(), b.clone().requires_grad_()
+    Yr = ACTS[act](F.linear(Xr, Wr, br))
+    Yr.backward(dY)
+    Xd, Wd, bd, dYd = X.cuda(), W.cuda(), b.cuda(), dY.cuda()
+    st = _C.current_stream()
+    Y = torch.empty(M, 1, device="cuda")
+    _C.check(lib.fr_linear_fwd(Xd.data_ptr(), K, None, 0, None, 1.0, Wd.data_ptr(), bd.data_ptr(), M, 1, act, Y.data_ptr(), st),
+             "fwd")
+    torch.testing.assert_close(Y.cpu(), Yr.detach(), rtol=2e-4, atol=2e-5 * max(1.0, float(Yr.abs().max())))
+    ws = torch.empty(lib.fr_linear_bwd_weight_workspace_bytes(M, 1, K), dtype=torch.uint8, device="cuda")
+    dW, db = torch.empty(1, K, device="cuda"), torch.empty(1, device="cuda")
+    dX = torch.empty(M, K, device="cuda") if need_dx else None
+    for rep in range(2):
+        out = torch.empty_like(dW)
+        _C.check(lib.fr_linear_n1_bwd(dYd.data_ptr(), Y.data_ptr(), act, Xd.data_ptr(), K, Wd.data_ptr(), M, _C.ptr(dX),
+                                      out.data_ptr(), db.data_ptr(), ws.data_ptr(), ws.numel(), st), "n1_bwd")
+        assert rep == 0 or torch.equal(out, dW)                     # fixed reduction order
+        dW = out
+    torch.testing.assert_close(dW.cpu(), Wr.grad, rtol=3e-4, atol=3e-5 * max(1.0, float(Wr.grad.abs().max())))
+    torch.testing.assert_close(db.cpu(), br.grad, rtol=3e-4, atol=3e-5 * max(1.0, float(br.grad.abs().max())))
+    if need_dx:
+        torch.testing.assert_close(dX.cpu(), Xr.grad, rtol=2e-4, atol=2e-5 * max(1.0, float(Xr.grad.abs().max())))
+    # not this form: K not a multiple of 64
+    rc = lib.fr_linear_n1_bwd(dYd.data_ptr(), Y.data_ptr(), act, Xd.data_ptr(), 48, Wd.data_ptr(), M, None, dW.data_ptr(),
+                              db.data_ptr(), ws.data_ptr(), ws.numel(), st)
+    assert rc == -3                                                 # FR_EUNSUPPORTED
+
+
+def test_act_bwd_through_a_relu_dropped_in_place():
+    """fr_act_bwd_dropped: Yd = relu(z) o keep, gradient at z = dY o keep o relu'(z) without z or the keep pattern."""
+    _C = _lib()
+    lib = _C.lib()
+    g = torch.Generator().manual_seed(5)
+    z = torch.randn(513, 64, generator=g).requires_grad_()
+    keep = (torch.rand(513, 64, generator=g) >= 0.3).float() / 0.7
+    Yd = torch.relu(z) * keep
+    dY = torch.randn(513, 64, generator=g)
+    Yd.backward(dY)
+    out = torch.empty(513, 64, device="cuda")
+    dYd, Ydd = dY.cuda(), Yd.detach().cuda()
+    _C.check(lib.fr_act_bwd_dropped(dYd.data_ptr(), Ydd.data_ptr(), 1 / 0.7, Yd.numel(), out.data_ptr(),
+                                    _C.current_stream()), "act_bwd_dropped")
+    torch.testing.assert_close(out.cpu(), z.grad, rtol=1e-6, atol=1e-7)
+
+
 @pytest.mark.parametrize("act", [1, 2, 3, 4])
 def test_act_bwd_prepass(act):
     """fr_act_bwd: dY o act'(Y), the pre-pass that lets a layer's two backward products run with act = 0."""
