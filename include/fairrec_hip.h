@@ -410,9 +410,16 @@ FR_API int fr_linear_bwd_weight(const float* dY, const float* Y, int32_t act, co
 /* Both backward products of a layer with ONE output (N == 1, one input block, no mask) in one pass over X: dW [K], db [1]
  * (may be NULL) and dX [M, K] (may be NULL) -- what fr_linear_bwd_weight + fr_linear_bwd_input give for that shape.
  * FR_EUNSUPPORTED unless K % 64 == 0, K <= 512 and X, W, dX are 16-byte aligned (take the two general calls then).
- * ws: fr_linear_bwd_weight_workspace_bytes(M, 1, K). */
+ * ws: fr_linear_bwd_weight_workspace_bytes(M, 1, K).
+ * relu_scale > 0: X is the previous layer's ReLU output dropped in place (keep = 0 or relu_scale) and dX comes out as the
+ * gradient at that layer's pre-activation (fr_act_bwd_dropped folded in); 0: plain dX. */
 FR_API int fr_linear_n1_bwd(const float* dY, const float* Y, int32_t act, const float* X, int32_t K, const float* W, int64_t M,
-                            float* dX, float* dW, float* db, void* ws, size_t ws_bytes, void* stream);
+                            float relu_scale, float* dX, float* dW, float* db, void* ws, size_t ws_bytes, void* stream);
+/* dA = (dY W) o scale o [Xd > 0]: fr_linear_bwd_input followed by fr_act_bwd_dropped, in one launch, for a layer whose
+ * input Xd [M, K] is the previous layer's ReLU output dropped in place.  Fast form only (FR_EUNSUPPORTED unless N % 32 == 0,
+ * K % 32 == 0, 16-byte aligned operands). */
+FR_API int fr_linear_bwd_input_relu(const float* dY, const float* W, int64_t M, int32_t N, int32_t K, const float* Xd,
+                                    float scale, float* dA, void* stream);
 FR_API int fr_act_bwd(const float* dY, const float* Y, int32_t act, int64_t n, float* out, void* stream);
 /* The same pre-pass through a ReLU whose OUTPUT went through dropout in place: Yd = relu(z) o keep (keep = 0 or scale),
  * dY = gradient with respect to Yd; out = dY o scale o [Yd > 0] = dY o keep o relu'(z).  Replaces the reference's

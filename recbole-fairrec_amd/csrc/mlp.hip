@@ -418,8 +418,9 @@ __global__ __launch_bounds__(256) void linear_n1_fwd_kernel(const float* __restr
 // workgroup order: reproducible).
 __global__ __launch_bounds__(256) void linear_n1_bwd_kernel(const float* __restrict__ dY, const float* __restrict__ Y, int act,
                                                             const float* __restrict__ X, const float* __restrict__ W, int M,
-                                                            int K, int rows_per_block, float* __restrict__ dX,
-                                                            float* __restrict__ slab, float* __restrict__ bslab) {
+                                                            int K, int rows_per_block, float relu_scale,
+                                                            float* __restrict__ dX, float* __restrict__ slab,
+                                                            float* __restrict__ bslab) {
     const int sub = threadIdx.x & 15, grp = threadIdx.x >> 4;
     const int nq = K / 64;                                       // float4 columns per lane
     float4 acc[N1_MAXQ];
@@ -442,7 +443,14 @@ __global__ __launch_bounds__(256) void linear_n1_bwd_kernel(const float* __restr
                 const float4 a = x[q * 16 + sub];
                 acc[q].x = fmaf(dz, a.x, acc[q].x); acc[q].y = fmaf(dz, a.y, acc[q].y);
                 acc[q].z = fmaf(dz, a.z, acc[q].z); acc[q].w = fmaf(dz, a.w, acc[q].w);
-                if (dx) dx[q * 16 + sub] = make_float4(dz * w[q].x, dz * w[q].y, dz * w[q].z, dz * w[q].w);
+                if (dx) {
+                    float4 o = make_float4(dz * w[q].x, dz * w[q].y, dz * w[q].z, dz * w[q].w);
+                    if (relu_scale > 0.f) {   // on through the dropped ReLU that produced X (X = relu(z) o keep)
+                        o.x = a.x > 0.f ? o.x * relu_scale : 0.f; o.y = a.y > 0.f ? o.y * relu_scale : 0.f;
+                        o.z = a.z > 0.f ? o.z * relu_scale : 0.f; o.w = a.w > 0.f ? o.w * relu_scale : 0.f;
+                    }
+                    dx[q * 16 + sub] = o;
+                }
             }
         if (sub == 0) accb += dz;
     }
@@ -539,6 +547,20 @@ extern "C" int fr_linear_bwd_input(const float* dY, const float* Y, int32_t act,
     return FR_OK;
 }
 
+// dA = (dY W) o scale o [Xd > 0]: the input gradient of a layer whose input Xd [M, K] is the previous layer's ReLU output
+// dropped in place, taken on through that ReLU in the epilogue (fr_linear_bwd_input + fr_act_bwd_dropped in one launch).
+// Fast form only: FR_EUNSUPPORTED unless N % 32 == 0, K % 32 == 0 and the operands are 16-byte aligned.
+extern "C" int fr_linear_bwd_input_relu(const float* dY, const float* W, int64_t M, int32_t N, int32_t K, const float* Xd,
+                                        float scale, float* dA, void* stream_) {
+    FR_CHECK_ARG(dY && W && Xd && dA && M >= 1 && N >= 1 && K >= 1 && scale > 0.f, "fr_linear_bwd_input_relu: bad argument");
+    static const bool no_glds = getenv("FAIRREC_LINEAR_NO_GLDS") != nullptr || getenv("FAIRREC_LINEAR_SLOW") != nullptr;
+    if (no_glds || N % 32 != 0 || K % 32 != 0 || (((uintptr_t)dY | (uintptr_t)W) & 15) != 0) {
+        set_error("fr_linear_bwd_input_relu: shape not supported (N %% 32 == 0, K %% 32 == 0, 16-byte aligned operands)");
+        return FR_EUNSUPPORTED;
+    }
+    return glds_linear_bwd_input(dY, W, M, (int)N, (int)K, dA, (int)K, nullptr, 0, (hipStream_t)stream_, Xd, scale);
+}
+
 // row splits of the weight gradient (slab bounded by 64 MiB)
 static long long bwd_weight_splits(int64_t M, int32_t N, int32_t K) {
     // >= 128 rows per split: at B = 8192 that is 64 splits, i.e. 64 x (N/64) x (K/64) workgroups -- enough to fill 256 CUs
@@ -589,9 +611,11 @@ extern "C" int fr_linear_bwd_weight(const float* dY, const float* Y, int32_t act
 // Both backward products of a layer with ONE output in one pass over X (plus the slab reduction): what
 // fr_linear_bwd_weight + fr_linear_bwd_input compute for N == 1, k1 == 0, no mask.  dX may be NULL (first layer of a
 // model whose input needs no gradient).  Returns FR_EUNSUPPORTED when the shape does not suit (K % 64, K <= 512, 16-byte
-// aligned X and W): the caller then takes the two general calls.  ws as for fr_linear_bwd_weight.
+// aligned X and W): the caller then takes the two general calls.  ws as for fr_linear_bwd_weight.  relu_scale > 0: X is the
+// previous layer's output dropped in place (relu(z) o keep, keep = 0 or relu_scale) and dX comes out as the gradient at z.
 extern "C" int fr_linear_n1_bwd(const float* dY, const float* Y, int32_t act, const float* X, int32_t K, const float* W,
-                                int64_t M, float* dX, float* dW, float* db, void* ws, size_t ws_bytes, void* stream_) {
+                                int64_t M, float relu_scale, float* dX, float* dW, float* db, void* ws, size_t ws_bytes,
+                                void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     FR_CHECK_ARG(dY && Y && X && W && dW && ws && M >= 1 && K >= 1 && act_ok(act), "fr_linear_n1_bwd: bad argument");
     if (!n1_ok(1, K, 0, nullptr, X, W) || (dX && ((uintptr_t)dX & 15) != 0)) {
@@ -607,7 +631,7 @@ extern "C" int fr_linear_n1_bwd(const float* dY, const float* Y, int32_t act, co
     {
         ProfScope prof(K_LINEAR_BWD_WEIGHT, stream);
         FR_LAUNCH(prof, linear_n1_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, dY, Y, (int)act, X, W, (int)M, (int)K,
-                  rows_per_block, dX, slab, bslab);
+                  rows_per_block, relu_scale, dX, slab, bslab);
     }
     FR_CHECK_LAUNCH();
     const long long tot = K + (db ? 1 : 0);

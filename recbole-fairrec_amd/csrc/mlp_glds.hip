@@ -273,10 +273,20 @@ __global__ __launch_bounds__(GL_WAVES * 64) void linear_glds_kernel(GlArgs g) {
     } else {   // GL_BWD_IN: the input gradient may be two blocks side by side
         float* base = col < g.o_split ? g.o_a + col : g.o_b + (col - g.o_split);
         const int ld = col < g.o_split ? g.o_lda : g.o_ldb;
+        if (g.relu_src) {   // on through the dropped ReLU that produced this layer's input (one uniform branch per wave)
+            const float* src = g.relu_src + col;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int row = i0 + (e & 3) + 8 * (e >> 2) + 4 * h;
-            if (row < g.out_rows) base[(size_t)row * ld] = acc[e];
+            for (int e = 0; e < 16; ++e) {
+                const int row = i0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (row < g.out_rows)
+                    base[(size_t)row * ld] = src[(size_t)row * g.out_cols] > 0.f ? acc[e] * g.relu_scale : 0.f;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = i0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (row < g.out_rows) base[(size_t)row * ld] = acc[e];
+            }
         }
     }
 }
@@ -352,8 +362,10 @@ int glds_linear_fwd(const GlMat& X, const float* W, const float* bias, int64_t M
 }
 
 int glds_linear_bwd_input(const float* dY, const float* W, int64_t M, int N, int K, float* dx0, int k0, float* dx1, int k1,
-                          hipStream_t stream) {
+                          hipStream_t stream, const float* relu_src, float relu_scale) {
     GlArgs g{};
+    g.relu_src = relu_src;
+    g.relu_scale = relu_scale;
     g.A = GlMat{dY, nullptr, N, 0, N};
     g.B = GlMat{W, nullptr, K, 0, K};
     g.rowsA = (int)M;

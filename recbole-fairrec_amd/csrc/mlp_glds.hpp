@@ -29,6 +29,8 @@ struct GlArgs {
     float *o_a, *o_b;        // input gradient: columns [0, o_split) -> o_a, the rest -> o_b
     int o_lda, o_ldb, o_split;
     float *slab, *bslab;     // weight gradient
+    const float* relu_src;   // input gradient, optional: the layer's input Xd = relu(z) o keep, leading dimension out_cols;
+    float relu_scale;        //   the result is then the gradient at z: (dY W) o relu_scale o [Xd > 0]
 };
 
 // Y = act(X W^T + b); needs K % 32 == 0, X.split % 32 == 0, 16-byte aligned rows
@@ -36,7 +38,7 @@ int glds_linear_fwd(const GlMat& X, const float* W, const float* bias, int64_t M
                     hipStream_t stream);
 // dX = dY W; needs N % 32 == 0, K % 32 == 0, k0 % 32 == 0
 int glds_linear_bwd_input(const float* dY, const float* W, int64_t M, int N, int K, float* dx0, int k0, float* dx1, int k1,
-                          hipStream_t stream);
+                          hipStream_t stream, const float* relu_src = nullptr, float relu_scale = 1.f);
 // slab[s] = dY[rows of s]^T X[rows of s], bslab[s] = column sums of dY[rows of s] (bslab may be null); needs N % 32 == 0,
 // K % 32 == 0, X.split % 32 == 0, rows_per_split % 32 == 0
 int glds_linear_bwd_weight(const float* dY, const GlMat& X, int64_t M, int N, int K, int splits, int rows_per_split,

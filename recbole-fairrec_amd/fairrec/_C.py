@@ -133,8 +133,10 @@ _PROTOS = {
                                     c_void_p, c_int32, c_void_p, c_int32, c_void_p]),
     "fr_linear_bwd_weight_workspace_bytes": (c_size_t, [c_int64, c_int32, c_int32]),
     "fr_table_join": (c_int, [c_void_p, c_void_p]),
-    "fr_linear_n1_bwd": (c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int64, c_void_p, c_void_p,
-                                 c_void_p, c_void_p, c_size_t, c_void_p]),
+    "fr_linear_n1_bwd": (c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int64, c_float, c_void_p,
+                                 c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "fr_linear_bwd_input_relu": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_float, c_void_p,
+                                         c_void_p]),
     "fr_act_bwd": (c_int, [c_void_p, c_void_p, c_int32, c_int64, c_void_p, c_void_p]),
     "fr_act_bwd_dropped": (c_int, [c_void_p, c_void_p, c_float, c_int64, c_void_p, c_void_p]),
     "fr_dropout_apply": (c_int, [c_void_p, c_int64, c_float, c_uint64, c_uint64, c_void_p, c_void_p, c_void_p, c_void_p,

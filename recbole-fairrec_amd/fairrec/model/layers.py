@@ -5,6 +5,7 @@ csrc/mlp.hip through one autograd Function; there is no torch fallback for CUDA 
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional, Sequence
 
 import torch
@@ -168,6 +169,7 @@ class _HipMLP(torch.autograd.Function):
         dY = dY.contiguous()
         dx0 = dx1 = None
         drop = ctx.drop
+        at_z = False          # dY already is the gradient at this layer's pre-activation (folded into the layer above)
         for l in range(L - 1, -1, -1):
             W = params[per * l].contiguous()
             Y = outs[l]
@@ -181,7 +183,9 @@ class _HipMLP(torch.autograd.Function):
             elif drop is not None:
                 scale = 1.0                       # the input is the previous layer's output, dropped in place
             act = ctx.act
-            if ctx.dropped_out[l]:
+            if at_z:
+                Y, act, at_z = dY, 0, False
+            elif ctx.dropped_out[l]:
                 # Y is relu(z) o keep and dY the gradient with respect to it: one pass gives the gradient at z
                 dA = torch.empty_like(Y)
                 _C.check(lib.fr_act_bwd_dropped(dY.data_ptr(), Y.data_ptr(), ctx.scale, M * N, dA.data_ptr(), st),
@@ -213,8 +217,10 @@ class _HipMLP(torch.autograd.Function):
             if N == 1 and c is None and mk is None and K % 64 == 0 and K <= 512:
                 # a layer with one output: both products in one pass over its input
                 da = torch.empty((M, k0), dtype=torch.float32, device=dev) if need0 else None
-                _C.check(lib.fr_linear_n1_bwd(dY.data_ptr(), Y.data_ptr(), act, a.data_ptr(), K, W.data_ptr(), M, _C.ptr(da),
-                                              dW.data_ptr(), db.data_ptr(), ws.data_ptr(), ws.numel(), st), "fr_linear_n1_bwd")
+                at_z = l > 0 and ctx.dropped_out[l - 1]        # ... and on through the dropped ReLU below, in the same pass
+                _C.check(lib.fr_linear_n1_bwd(dY.data_ptr(), Y.data_ptr(), act, a.data_ptr(), K, W.data_ptr(), M,
+                                              ctx.scale if at_z else 0.0, _C.ptr(da), dW.data_ptr(), db.data_ptr(),
+                                              ws.data_ptr(), ws.numel(), st), "fr_linear_n1_bwd")
             else:
                 _C.check(lib.fr_linear_bwd_weight(dY.data_ptr(), Y.data_ptr(), act, a.data_ptr(), k0, _C.ptr(c), k1,
                                                   _C.ptr(mk), scale, M, N, dW.data_ptr(), db.data_ptr(), ws.data_ptr(),
@@ -222,8 +228,15 @@ class _HipMLP(torch.autograd.Function):
                 if need0 or need1:
                     da = torch.empty((M, k0), dtype=torch.float32, device=dev)
                     dc = torch.empty((M, k1), dtype=torch.float32, device=dev) if k1 else None
-                    _C.check(lib.fr_linear_bwd_input(dY.data_ptr(), Y.data_ptr(), act, W.data_ptr(), _C.ptr(mk), scale,
-                                                     M, N, da.data_ptr(), k0, _C.ptr(dc), k1, st), "fr_linear_bwd_input")
+                    if l > 0 and ctx.dropped_out[l - 1] and act == 0 and N % 32 == 0 and K % 32 == 0 and \
+                            os.environ.get("FAIRREC_LINEAR_NO_GLDS") is None and os.environ.get("FAIRREC_LINEAR_SLOW") is None:
+                        # the input is the dropped ReLU output of the layer below: on through it in the epilogue
+                        _C.check(lib.fr_linear_bwd_input_relu(dY.data_ptr(), W.data_ptr(), M, N, K, a.data_ptr(), ctx.scale,
+                                                              da.data_ptr(), st), "fr_linear_bwd_input_relu")
+                        at_z = True
+                    else:
+                        _C.check(lib.fr_linear_bwd_input(dY.data_ptr(), Y.data_ptr(), act, W.data_ptr(), _C.ptr(mk), scale,
+                                                         M, N, da.data_ptr(), k0, _C.ptr(dc), k1, st), "fr_linear_bwd_input")
             grads[per * l], grads[per * l + 1] = dW, db
             if need0 or need1:
                 if drop is not None and ctx.premul[l]:      # back through this layer's input dropout: the pattern again

@@ -100,7 +100,7 @@ def test_one_output_layer_forward_and_fused_backward_match_torch(M, K, act, need
     dX = torch.empty(M, K, device="cuda") if need_dx else None
     for rep in range(2):
         out = torch.empty_like(dW)
-        _C.check(lib.fr_linear_n1_bwd(dYd.data_ptr(), Y.data_ptr(), act, Xd.data_ptr(), K, Wd.data_ptr(), M, _C.ptr(dX),
+        _C.check(lib.fr_linear_n1_bwd(dYd.data_ptr(), Y.data_ptr(), act, Xd.data_ptr(), K, Wd.data_ptr(), M, 0.0, _C.ptr(dX),
                                       out.data_ptr(), db.data_ptr(), ws.data_ptr(), ws.numel(), st), "n1_bwd")
         assert rep == 0 or torch.equal(out, dW)                     # fixed reduction order
         dW = out
@@ -109,9 +109,39 @@ def test_one_output_layer_forward_and_fused_backward_match_torch(M, K, act, need
     if need_dx:
         torch.testing.assert_close(dX.cpu(), Xr.grad, rtol=2e-4, atol=2e-5 * max(1.0, float(Xr.grad.abs().max())))
     # not this form: K not a multiple of 64
-    rc = lib.fr_linear_n1_bwd(dYd.data_ptr(), Y.data_ptr(), act, Xd.data_ptr(), 48, Wd.data_ptr(), M, None, dW.data_ptr(),
+    rc = lib.fr_linear_n1_bwd(dYd.data_ptr(), Y.data_ptr(), act, Xd.data_ptr(), 48, Wd.data_ptr(), M, 0.0, None, dW.data_ptr(),
                               db.data_ptr(), ws.data_ptr(), ws.numel(), st)
     assert rc == -3                                                 # FR_EUNSUPPORTED
+
+
+@pytest.mark.parametrize("M,N,K", [(8192, 64, 128), (1000, 128, 512), (8192, 1, 64), (333, 1, 128)])
+def test_input_gradient_taken_on_through_a_dropped_relu(M, N, K):
+    """fr_linear_bwd_input_relu / fr_linear_n1_bwd(relu_scale): the layer's input is Xd = relu(z) o keep; the result is the
+    gradient at z, i.e. what fr_linear_bwd_input followed by fr_act_bwd_dropped give."""
+    _C = _lib()
+    lib = _C.lib()
+    g = torch.Generator().manual_seed(M + N + K)
+    z = torch.randn(M, K, generator=g).requires_grad_()
+    keep = (torch.rand(M, K, generator=g) >= 0.4).float() / 0.6
+    Xd = torch.relu(z) * keep
+    W = (torch.randn(N, K, generator=g) * 0.3)
+    dY = torch.randn(M, N, generator=g)
+    (Xd @ W.t()).backward(dY)
+    Xdd, Wd, dYd = Xd.detach().cuda(), W.cuda(), dY.cuda()
+    dA = torch.empty(M, K, device="cuda")
+    st = _C.current_stream()
+    if N == 1:
+        ws = torch.empty(lib.fr_linear_bwd_weight_workspace_bytes(M, 1, K), dtype=torch.uint8, device="cuda")
+        dW, db = torch.empty(1, K, device="cuda"), torch.empty(1, device="cuda")
+        _C.check(lib.fr_linear_n1_bwd(dYd.data_ptr(), dYd.data_ptr(), 0, Xdd.data_ptr(), K, Wd.data_ptr(), M, 1 / 0.6,
+                                      dA.data_ptr(), dW.data_ptr(), db.data_ptr(), ws.data_ptr(), ws.numel(), st), "n1_bwd")
+        torch.testing.assert_close(dW.cpu(), (dY.t() @ Xd.detach()), rtol=3e-4, atol=3e-4)
+    else:
+        _C.check(lib.fr_linear_bwd_input_relu(dYd.data_ptr(), Wd.data_ptr(), M, N, K, Xdd.data_ptr(), 1 / 0.6, dA.data_ptr(), st),
+                 "bwd_input_relu")
+    torch.testing.assert_close(dA.cpu(), z.grad, rtol=2e-4, atol=2e-5 * max(1.0, float(z.grad.abs().max())))
+    rc = lib.fr_linear_bwd_input_relu(dYd.data_ptr(), Wd.data_ptr(), M, 24, K, Xdd.data_ptr(), 1 / 0.6, dA.data_ptr(), st)
+    assert rc == -3
 
 
 def test_act_bwd_through_a_relu_dropped_in_place():
