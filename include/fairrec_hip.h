@@ -438,6 +438,10 @@ FR_API int fr_act_bwd_dropped(const float* dY, const float* Yd, float scale, int
  * nn.Dropout of the reference's MLPLayers (recbole/model/layers.py:62-63); see DESIGN.md §8a. */
 FR_API int fr_dropout_apply(const float* x, int64_t n, float p, uint64_t seed, uint64_t offset, const int64_t* counter,
                             int64_t* used_out, int64_t* tick_state, float* out, void* stream);
+/* The same for two tensors in ONE launch (the two blocks [x0 | x1] of a first layer's input); x1 may be NULL. */
+FR_API int fr_dropout_apply2(const float* x0, int64_t n0, uint64_t offset0, float* out0, const float* x1, int64_t n1,
+                             uint64_t offset1, float* out1, float p, uint64_t seed, const int64_t* counter,
+                             int64_t* used_out, int64_t* tick_state, void* stream);
 
 /* n <= FR_COPY_MAX device-to-device copies of bytes[j] bytes in ONE launch (jobs must not overlap each other). */
 #define FR_COPY_MAX 16

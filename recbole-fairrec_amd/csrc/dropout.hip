@@ -27,13 +27,19 @@ __device__ __forceinline__ uint4 philox4x32(uint4 c, uint2 k) {
 // state = {call counter, ticket}.  Every workgroup takes the counter through ONE load of its first thread; when `tick`
 // is set that thread then draws a ticket whose increment depends on the loaded value (so the load has completed), and
 // the holder of the last ticket -- every workgroup has read the counter by then -- advances it and resets the tickets.
-__global__ __launch_bounds__(256) void dropout_apply_kernel(const float* __restrict__ x, long long n, unsigned thr,
+// Up to two tensors per launch (the two blocks of a first layer's input): job 1 takes the workgroups from `blocks0` on.
+struct DropJob {
+    const float* x;
+    float* out;
+    long long n;
+    unsigned long long off4;
+};
+
+__global__ __launch_bounds__(256) void dropout_apply_kernel(DropJob j0, DropJob j1, unsigned blocks0, unsigned thr,
                                                             float scale, unsigned long long seed,
-                                                            unsigned long long off4,
                                                             const unsigned long long* __restrict__ ctr_src,
                                                             unsigned long long* __restrict__ used_out,
-                                                            unsigned long long* __restrict__ tick,
-                                                            float* __restrict__ out) {
+                                                            unsigned long long* __restrict__ tick) {
     __shared__ unsigned long long ctr_s;
     if (threadIdx.x == 0) {
         const unsigned long long c = __hip_atomic_load(ctr_src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -49,7 +55,12 @@ __global__ __launch_bounds__(256) void dropout_apply_kernel(const float* __restr
     }
     __syncthreads();
     const unsigned long long ctr = ctr_s;
-    const long long q = (long long)blockIdx.x * 256 + threadIdx.x;      // this thread's group of 4 elements
+    const bool second = blockIdx.x >= blocks0;
+    const float* __restrict__ x = second ? j1.x : j0.x;
+    float* __restrict__ out = second ? j1.out : j0.out;
+    const long long n = second ? j1.n : j0.n;
+    const unsigned long long off4 = second ? j1.off4 : j0.off4;
+    const long long q = (long long)(blockIdx.x - (second ? blocks0 : 0u)) * 256 + threadIdx.x;   // this thread's 4 elements
     const long long i = q * 4;
     if (i >= n) return;
     const unsigned long long g = off4 + (unsigned long long)q;
@@ -68,20 +79,30 @@ __global__ __launch_bounds__(256) void dropout_apply_kernel(const float* __restr
 
 }  // namespace fr
 
-extern "C" int fr_dropout_apply(const float* x, int64_t n, float p, uint64_t seed, uint64_t offset, const int64_t* counter,
-                                int64_t* used_out, int64_t* tick_state, float* out, void* stream_) {
+extern "C" int fr_dropout_apply2(const float* x0, int64_t n0, uint64_t offset0, float* out0, const float* x1, int64_t n1,
+                                 uint64_t offset1, float* out1, float p, uint64_t seed, const int64_t* counter,
+                                 int64_t* used_out, int64_t* tick_state, void* stream_) {
     using namespace fr;
     hipStream_t stream = (hipStream_t)stream_;
-    FR_CHECK_ARG(x && out && counter && n >= 1 && p >= 0.f && p < 1.f && offset % 4 == 0, "fr_dropout_apply: bad argument");
-    FR_CHECK_ARG((((uintptr_t)x | (uintptr_t)out) & 15) == 0, "fr_dropout_apply: 16-byte alignment required");
+    FR_CHECK_ARG(x0 && out0 && counter && n0 >= 1 && p >= 0.f && p < 1.f && offset0 % 4 == 0, "fr_dropout_apply: bad argument");
+    FR_CHECK_ARG((((uintptr_t)x0 | (uintptr_t)out0) & 15) == 0, "fr_dropout_apply: 16-byte alignment required");
+    FR_CHECK_ARG(!x1 || (out1 && n1 >= 1 && offset1 % 4 == 0 && (((uintptr_t)x1 | (uintptr_t)out1) & 15) == 0),
+                 "fr_dropout_apply2: bad second tensor");
     const double t = (double)p * 4294967296.0;
     const unsigned thr = t >= 4294967295.0 ? 0xFFFFFFFFu : (unsigned)t;     // keep <=> 32 random bits >= thr
-    const long long groups = (n + 3) / 4;
-    hipLaunchKernelGGL(dropout_apply_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, stream, x, (long long)n, thr,
-                       1.f / (1.f - p), (unsigned long long)seed, (unsigned long long)(offset / 4),
-                       (const unsigned long long*)counter, (unsigned long long*)used_out, (unsigned long long*)tick_state, out);
+    const unsigned b0 = (unsigned)(((n0 + 3) / 4 + 255) / 256), b1 = x1 ? (unsigned)(((n1 + 3) / 4 + 255) / 256) : 0u;
+    const DropJob j0{x0, out0, (long long)n0, (unsigned long long)(offset0 / 4)};
+    const DropJob j1{x1, out1, (long long)(x1 ? n1 : 0), (unsigned long long)(offset1 / 4)};
+    hipLaunchKernelGGL(dropout_apply_kernel, dim3(b0 + b1), dim3(256), 0, stream, j0, j1, b0, thr, 1.f / (1.f - p),
+                       (unsigned long long)seed, (const unsigned long long*)counter, (unsigned long long*)used_out,
+                       (unsigned long long*)tick_state);
     FR_CHECK_LAUNCH();
     return FR_OK;
+}
+
+extern "C" int fr_dropout_apply(const float* x, int64_t n, float p, uint64_t seed, uint64_t offset, const int64_t* counter,
+                                int64_t* used_out, int64_t* tick_state, float* out, void* stream_) {
+    return fr_dropout_apply2(x, n, offset, out, nullptr, 0, 0, nullptr, p, seed, counter, used_out, tick_state, stream_);
 }
 
 // ---- several small device-to-device copies in one launch ------------------------------------------------------------------

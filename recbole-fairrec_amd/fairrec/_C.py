@@ -141,6 +141,8 @@ _PROTOS = {
     "fr_act_bwd_dropped": (c_int, [c_void_p, c_void_p, c_float, c_int64, c_void_p, c_void_p]),
     "fr_dropout_apply": (c_int, [c_void_p, c_int64, c_float, c_uint64, c_uint64, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_void_p]),
+    "fr_dropout_apply2": (c_int, [c_void_p, c_int64, c_uint64, c_void_p, c_void_p, c_int64, c_uint64, c_void_p, c_float, c_uint64,
+                                  c_void_p, c_void_p, c_void_p, c_void_p]),
     "fr_copy_many": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),
     "fr_linear_bwd_weight": (c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_void_p,
                                      c_float, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
@@ -220,6 +222,25 @@ def current_stream() -> int:
         return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
     except AttributeError:      # private API moved: fall back to the public one
         return torch.cuda.current_stream().cuda_stream
+
+
+_ONES = {}
+
+
+def one(device):
+    """A cached fp32 scalar 1 on `device`: the seed `GraphedStep` hands to `loss.backward()`.  A loss Function that finds
+    exactly this tensor as its incoming gradient skips the multiplication by it (`is_one`)."""
+    import torch
+    device = torch.device(device)
+    t = _ONES.get(device)
+    if t is None:
+        t = _ONES[device] = torch.ones((), dtype=torch.float32, device=device)
+    return t
+
+
+def is_one(t) -> bool:
+    c = _ONES.get(t.device)
+    return c is not None and t.data_ptr() == c.data_ptr() and t.dim() == 0
 
 
 def prof_enable(on: bool):

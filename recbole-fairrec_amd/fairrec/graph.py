@@ -33,15 +33,13 @@ class GraphedStep:
         self.static: Optional[Dict[str, torch.Tensor]] = None
         self.static_args: Tuple = ()
         self.loss: Optional[torch.Tensor] = None
-        self._one: Optional[torch.Tensor] = None        # the seed of backward(), made once instead of per step
         engine.enable_graph_mode()
 
     def _eager(self, inter: Interaction, args):
         self.optimizer.zero_grad()
         loss = self.loss_fn(inter, *args)
-        if self._one is None or self._one.device != loss.device:
-            self._one = torch.ones((), dtype=loss.dtype, device=loss.device)
-        loss.backward(self._one if loss.dim() == 0 and loss.dtype == self._one.dtype else None)
+        from . import _C
+        loss.backward(_C.one(loss.device) if loss.dim() == 0 and loss.dtype == torch.float32 else None)
         self.optimizer.step()
         return loss.detach()
 

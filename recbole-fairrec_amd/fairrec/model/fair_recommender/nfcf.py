@@ -44,6 +44,8 @@ class _NfcfLoss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_loss, g_out):
         (dy,) = ctx.saved_tensors
+        if _C.is_one(g_loss):               # GraphedStep's seed: nothing to scale by
+            return dy.view(-1, 1), None, None, None, None, None
         return (dy * g_loss).view(-1, 1), None, None, None, None, None
 
 

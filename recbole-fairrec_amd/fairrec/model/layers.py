@@ -58,6 +58,24 @@ class _Drop:
         self.off += (n + 3) // 4 * 4
         return off
 
+    def forward2(self, x0, out0, x1, out1):
+        """The two blocks of a first layer's input in one launch; returns their offsets."""
+        o0, o1 = self.off, self.off + (x0.numel() + 3) // 4 * 4
+        self.left -= 2
+        _C.check(_C.lib().fr_dropout_apply2(x0.data_ptr(), x0.numel(), o0, out0.data_ptr(), x1.data_ptr(), x1.numel(), o1,
+                                            out1.data_ptr(), self.p, self.seed, self.state.data_ptr(),
+                                            self.used.data_ptr() if self.first else None,
+                                            self.state.data_ptr() if self.left == 0 else None, _C.current_stream()),
+                 "fr_dropout_apply2")
+        self.first = False
+        self.off = o1 + (x1.numel() + 3) // 4 * 4
+        return o0, o1
+
+    def again2(self, g0, off0, g1, off1):
+        _C.check(_C.lib().fr_dropout_apply2(g0.data_ptr(), g0.numel(), off0, g0.data_ptr(), g1.data_ptr(), g1.numel(), off1,
+                                            g1.data_ptr(), self.p, self.seed, self.used.data_ptr(), None, None,
+                                            _C.current_stream()), "fr_dropout_apply2")
+
     def again(self, g: torch.Tensor, off: int):
         """g *= the keep pattern the forward launch at `off` drew (in place)."""
         _C.check(_C.lib().fr_dropout_apply(g.data_ptr(), g.numel(), self.p, self.seed, off, self.used.data_ptr(), None, None,
@@ -106,11 +124,12 @@ class _HipMLP(torch.autograd.Function):
                     premul.append(False)
                 else:
                     ad = torch.empty_like(a)
-                    oa = drop.forward(a, ad)
                     cd, oc = None, 0
                     if c is not None:
                         cd = torch.empty_like(c)
-                        oc = drop.forward(c, cd)
+                        oa, oc = drop.forward2(a, ad, c, cd)
+                    else:
+                        oa = drop.forward(a, ad)
                     a, c, drop_off[l] = ad, cd, (oa, oc)
                     premul.append(True)
                 _C.check(lib.fr_linear_fwd(a.data_ptr(), k0, _C.ptr(c), k1, None, 1.0, W.data_ptr(), b.data_ptr(), M, N,
@@ -240,9 +259,11 @@ class _HipMLP(torch.autograd.Function):
             grads[per * l], grads[per * l + 1] = dW, db
             if need0 or need1:
                 if drop is not None and ctx.premul[l]:      # back through this layer's input dropout: the pattern again
-                    if need0:
+                    if need0 and dc is not None and need1:
+                        drop.again2(da, ctx.drop_off[l][0], dc, ctx.drop_off[l][1])
+                    elif need0:
                         drop.again(da, ctx.drop_off[l][0])
-                    if dc is not None and need1:
+                    elif dc is not None and need1:
                         drop.again(dc, ctx.drop_off[l][1])
                 elif ctx.premul[l]:               # back through the dropout of this layer's input
                     da = da * (ctx.masks[l] if dc is None else ctx.masks[l][:, :k0]) if da is not None else None
