@@ -39,11 +39,14 @@ class _NfcfLoss(torch.autograd.Function):
         ctx.save_for_backward(dy)
         ctx.shape = y.shape
         ctx.mark_non_differentiable(out)
+        ctx.set_materialize_grads(False)      # no zero tensor for the gradient of `out` (one fill launch per step)
         return loss[0], out
 
     @staticmethod
     def backward(ctx, g_loss, g_out):
         (dy,) = ctx.saved_tensors
+        if g_loss is None:
+            return None, None, None, None, None, None
         if _C.is_one(g_loss):               # GraphedStep's seed: nothing to scale by
             return dy.view(-1, 1), None, None, None, None, None
         return (dy * g_loss).view(-1, 1), None, None, None, None, None

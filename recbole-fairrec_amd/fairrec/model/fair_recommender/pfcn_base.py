@@ -153,16 +153,16 @@ class PFCNBase(FairRecommender):
         return self._engine
 
     # --- forward pieces -------------------------------------------------------------------------------------------
-    def _filter(self, user_embed, sst_list):
+    def _filter(self, user_embed, sst_list, passes=1):
         """pfcn_biasedmf.py:149-164: sm = ONE filter picked by the bit-mask sum of the selected attributes;
         cm = sum of the selected attributes' filters divided by the number of ALL filters."""
         if self.filter_mode == 'none':
             return user_embed
         if self.filter_mode == 'sm':
-            return self.filter_layer[sum(self.sst_dict[s] for s in sst_list)](user_embed)
+            return self.filter_layer[sum(self.sst_dict[s] for s in sst_list)](user_embed, passes=passes)
         tmp = None
         for s in sst_list:
-            e = self.filter_layer[self.sst_dict[s]](user_embed)
+            e = self.filter_layer[self.sst_dict[s]](user_embed, passes=passes)
             tmp = e if tmp is None else tmp + e
         return tmp / len(self.filter_layer)
 
@@ -200,7 +200,12 @@ class PFCNBase(FairRecommender):
         pos_item, neg_item = interaction[self.POS_ITEM_ID], interaction[self.NEG_ITEM_ID]
         B = user.numel()
         ue_raw = eng.lookup(self._utab, user)
-        user_embed = self._filter(self._user_tower(ue_raw), sst_list)
+        # The reference runs the user side twice per filter step (forward() again inside calculate_dis_loss,
+        # pfcn_biasedmf.py:209): same rows, same filters, both results used.  When nothing on that path is random (identity
+        # tower; the filters have no dropout) it is evaluated once with the BatchNorm bookkeeping of two passes
+        # (MLPLayers.forward, `passes`).
+        once = self.filter_mode != 'none' and type(self)._user_tower is PFCNBase._user_tower
+        user_embed = self._filter(self._user_tower(ue_raw), sst_list, passes=2 if once else 1)
         items = torch.cat([pos_item.to(eng.device), neg_item.to(eng.device)])     # one gather for both id lists
         ie = eng.lookup(self._itab, items)
         pos_e, neg_e = self._item_tower(ie[:B]), self._item_tower(ie[B:])
@@ -214,7 +219,8 @@ class PFCNBase(FairRecommender):
         if self.filter_mode != 'none':
             # the reference calls forward() a second time inside calculate_dis_loss (pfcn_biasedmf.py:209): same rows,
             # filters applied again (BatchNorm statistics advance twice), gradient flows through both passes
-            dis_loss = self._dis_terms(self._filter(self._user_tower(ue_raw), sst_list), interaction, sst_list)
+            again = user_embed if once else self._filter(self._user_tower(ue_raw), sst_list)
+            dis_loss = self._dis_terms(again, interaction, sst_list)
             return bpr_loss - self.dis_weight * dis_loss
         return bpr_loss
 

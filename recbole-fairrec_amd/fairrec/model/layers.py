@@ -306,7 +306,7 @@ class MLPLayers(nn.Module):
             if module.bias is not None:
                 module.bias.data.fill_(0.0)
 
-    def _count_batch(self, bns):
+    def _count_batch(self, bns, passes=1):
         """`num_batches_tracked += 1` of every BatchNorm layer in ONE launch: the counters are kept as views of one shared
         int64 tensor (re-made whenever .to() / a fresh module replaced the buffers; load_state_dict copies in place, so the
         views survive it)."""
@@ -316,7 +316,7 @@ class MLPLayers(nn.Module):
             for i, bn in enumerate(bns):
                 bn.num_batches_tracked = sh[i]
             self._nbt_shared = sh
-        sh += 1
+        sh += passes
 
     def linears(self) -> List[nn.Linear]:
         return [m for m in self.mlp_layers if isinstance(m, nn.Linear)]
@@ -324,8 +324,13 @@ class MLPLayers(nn.Module):
     def batchnorms(self) -> List[nn.BatchNorm1d]:
         return [m for m in self.mlp_layers if isinstance(m, nn.BatchNorm1d)]
 
-    def forward(self, input_feature, second_block=None):
+    def forward(self, input_feature, second_block=None, passes=1):
         """MLP(cat(input_feature, second_block)); `second_block` avoids materialising the concatenation.
+        `passes` = 2 stands for the module being evaluated twice on the same input with both results used (the reference's
+        PFCN filter pass does that, pfcn_biasedmf.py:209): without dropout the two evaluations are the same function at the
+        same point, so ONE evaluation whose output feeds both consumers gives the same values and the same gradient
+        (J^T (g1 + g2)); what differs is the BatchNorm bookkeeping, which advances twice: two momentum updates with the
+        same batch statistics are one update with momentum 1 - (1 - m)^2, and the batch counter moves by two.
         BatchNorm layers always use batch statistics while `self.training` (and the reference's dict-held PFCN MLPs are
         never switched to eval mode); eval-mode BatchNorm (running statistics) is not on this path."""
         if input_feature.device.type != "cuda":
@@ -335,8 +340,11 @@ class MLPLayers(nn.Module):
             raise NotImplementedError("eval-mode BatchNorm (running statistics) is not on the HIP path")
         if self.use_bn:
             params = [t for lin, bn in zip(lins, bns) for t in (lin.weight, lin.bias, bn.weight, bn.bias)]
-            bn_buffers = [(bn.running_mean, bn.running_var, float(bn.eps), float(bn.momentum)) for bn in bns]
-            self._count_batch(bns)
+            if passes != 1 and (self.training and float(self.dropout) > 0.0):
+                raise ValueError("passes > 1 needs a module without dropout (two evaluations would differ)")
+            bn_buffers = [(bn.running_mean, bn.running_var, float(bn.eps), 1.0 - (1.0 - float(bn.momentum)) ** passes)
+                          for bn in bns]
+            self._count_batch(bns, passes)
         else:
             params = [t for lin in lins for t in (lin.weight, lin.bias)]
             bn_buffers = None

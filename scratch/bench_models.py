@@ -77,8 +77,10 @@ if "pfcn" in which:
     od = FusedLazyAdam(m.hip_engine(), lr=1e-3, weight_decay=1e-4, group="dis")
     sl = ["gender"]
     data = batches(nu, ni, B, 8, pair=True)
-    run(f"PFCN_BiasedMF sm filter-phase step {nu}x{ni} D={D} B={B}", m, [of], [lambda it: m.calculate_loss(it, sl)], data, ds._uf["gender"])
-    run(f"PFCN_BiasedMF sm dis-phase step", m, [od], [lambda it: m.calculate_dis_loss(it, sl)], data, ds._uf["gender"])
+    if os.environ.get("PFCN_PHASE", "both") in ("filter", "both"):
+      run(f"PFCN_BiasedMF sm filter-phase step {nu}x{ni} D={D} B={B}", m, [of], [lambda it: m.calculate_loss(it, sl)], data, ds._uf["gender"])
+    if os.environ.get("PFCN_PHASE", "both") in ("dis", "both"):
+      run(f"PFCN_BiasedMF sm dis-phase step", m, [od], [lambda it: m.calculate_dis_loss(it, sl)], data, ds._uf["gender"])
     del m, of, od; torch.cuda.empty_cache()
 if "fairgo" in which:
     nu, ni, D = int(os.environ.get("FG_NU", 1_000_001)), int(os.environ.get("FG_NI", 100_001)), 128

@@ -25,9 +25,24 @@ def step(k, which):
     opt.zero_grad(); loss = fn(inters[k % 4]); loss.backward(); opt.step()
 for k in range(3): step(k, "F"); step(k, "D")
 torch.cuda.synchronize()
-from torch.profiler import profile, ProfilerActivity
+import traceback
+from collections import Counter
+from torch.utils._python_dispatch import TorchDispatchMode
+rows = Counter()
+class Log(TorchDispatchMode):
+    def __torch_dispatch__(self, func, types_, args=(), kwargs=None):
+        name = str(func)
+        if not any(s in name for s in ("view", "detach", "empty", "slice", "select", "reshape", "squeeze", "expand", "as_strided", "t.default", "alias")):
+            fr = [f for f in traceback.extract_stack() if "fairrec" in f.filename]
+            where = f"{fr[-1].filename.split('recbole-fairrec_amd/')[-1]}:{fr[-1].lineno}" if fr else "(autograd / torch)"
+            shape = next((tuple(a.shape) for a in args if isinstance(a, torch.Tensor)), ())
+            rows[(name, where, shape)] += 1
+        return func(*args, **(kwargs or {}))
 for which in ("F", "D"):
-    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
-        step(5, which); torch.cuda.synchronize()
-    print("=====", which)
-    print(prof.key_averages(group_by_stack_n=4).table(sort_by="self_cuda_time_total", row_limit=28, max_name_column_width=40, max_src_column_width=90))
+    rows.clear()
+    with Log():
+        step(5, which)
+    torch.cuda.synchronize()
+    print("=====", which, sum(rows.values()), "ops")
+    for (n, w, s), c in sorted(rows.items(), key=lambda t: (t[0][1], t[0][0])):
+        print(f"{c:4d} {n:36s} {str(s):18s} {w}")
