@@ -172,11 +172,13 @@ class PFCNBase(FairRecommender):
         item_embed = self._item_tower(eng.lookup(self._itab, item)) if item is not None else None
         return user_embed, item_embed
 
-    def _dis_terms(self, user_embed, interaction, sst_list):
+    def _dis_terms(self, user_embed, interaction, sst_list, frozen=False):
+        """`frozen`: inside the filter pass the discriminators only pass the gradient on to the filters and embeddings;
+        their own parameter gradients would be dropped unread by the next zero_grad (engine.zero_grad)."""
         eng = self.hip_engine()
         total = 0.0
         for sst in sst_list:
-            y = self.dis_layer_dict[sst](user_embed)
+            y = self.dis_layer_dict[sst](user_embed, frozen=frozen)
             label = interaction[sst].to(eng.device)
             if self.sst_size[sst] == 2:
                 total = total + SigmoidBce.apply(y, label.float())
@@ -220,7 +222,7 @@ class PFCNBase(FairRecommender):
             # the reference calls forward() a second time inside calculate_dis_loss (pfcn_biasedmf.py:209): same rows,
             # filters applied again (BatchNorm statistics advance twice), gradient flows through both passes
             again = user_embed if once else self._filter(self._user_tower(ue_raw), sst_list)
-            dis_loss = self._dis_terms(again, interaction, sst_list)
+            dis_loss = self._dis_terms(again, interaction, sst_list, frozen=True)
             return bpr_loss - self.dis_weight * dis_loss
         return bpr_loss
 

@@ -219,21 +219,24 @@ class _HipMLP(torch.autograd.Function):
                 _C.check(lib.fr_bn_bwd(dY.data_ptr(), Y.data_ptr(), act, xhats[l].data_ptr(), invstds[l].data_ptr(),
                                        g.data_ptr(), M, N, dZ.data_ptr(), dg.data_ptr(), dbt.data_ptr(), ws.data_ptr(),
                                        ws.numel(), st), "fr_bn_bwd")
-                grads[per * l + 2], grads[per * l + 3] = dg, dbt
+                if ctx.needs_input_grad[7 + per * l + 2] or ctx.needs_input_grad[7 + per * l + 3]:
+                    grads[per * l + 2], grads[per * l + 3] = dg, dbt
                 dY, Y, act = dZ, dZ, 0
             elif act != 0 and mk is None and N % 32 == 0 and K % 32 == 0 and k0 % 32 == 0:
                 # one pass through the activation's derivative, shared by the two products (which then take their fast form)
                 dA = torch.empty_like(Y)
                 _C.check(lib.fr_act_bwd(dY.data_ptr(), Y.data_ptr(), act, M * N, dA.data_ptr(), st), "fr_act_bwd")
                 dY, Y, act = dA, dA, 0
-            need = lib.fr_linear_bwd_weight_workspace_bytes(M, N, K)
+            # (a module evaluated with `frozen=True` -- a discriminator inside the filter pass -- asks for no weight gradients)
+            need_w = ctx.needs_input_grad[7 + per * l] or ctx.needs_input_grad[7 + per * l + 1]
+            need = lib.fr_linear_bwd_weight_workspace_bytes(M, N, K) if need_w else 16
             ws = torch.empty(need, dtype=torch.uint8, device=dev)
-            dW = torch.empty_like(W)
-            db = torch.empty(N, dtype=torch.float32, device=dev)
+            dW = torch.empty_like(W) if need_w else None
+            db = torch.empty(N, dtype=torch.float32, device=dev) if need_w else None
             need0 = l > 0 or ctx.needs_input_grad[0]
             need1 = l == 0 and ctx.has_x1 and ctx.needs_input_grad[1]
             da = dc = None
-            if N == 1 and c is None and mk is None and K % 64 == 0 and K <= 512:
+            if need_w and N == 1 and c is None and mk is None and K % 64 == 0 and K <= 512:
                 # a layer with one output: both products in one pass over its input
                 da = torch.empty((M, k0), dtype=torch.float32, device=dev) if need0 else None
                 at_z = l > 0 and ctx.dropped_out[l - 1]        # ... and on through the dropped ReLU below, in the same pass
@@ -241,9 +244,10 @@ class _HipMLP(torch.autograd.Function):
                                               ctx.scale if at_z else 0.0, _C.ptr(da), dW.data_ptr(), db.data_ptr(),
                                               ws.data_ptr(), ws.numel(), st), "fr_linear_n1_bwd")
             else:
-                _C.check(lib.fr_linear_bwd_weight(dY.data_ptr(), Y.data_ptr(), act, a.data_ptr(), k0, _C.ptr(c), k1,
-                                                  _C.ptr(mk), scale, M, N, dW.data_ptr(), db.data_ptr(), ws.data_ptr(),
-                                                  ws.numel(), st), "fr_linear_bwd_weight")
+                if need_w:
+                    _C.check(lib.fr_linear_bwd_weight(dY.data_ptr(), Y.data_ptr(), act, a.data_ptr(), k0, _C.ptr(c), k1,
+                                                      _C.ptr(mk), scale, M, N, dW.data_ptr(), db.data_ptr(), ws.data_ptr(),
+                                                      ws.numel(), st), "fr_linear_bwd_weight")
                 if need0 or need1:
                     da = torch.empty((M, k0), dtype=torch.float32, device=dev)
                     dc = torch.empty((M, k1), dtype=torch.float32, device=dev) if k1 else None
@@ -324,13 +328,15 @@ class MLPLayers(nn.Module):
     def batchnorms(self) -> List[nn.BatchNorm1d]:
         return [m for m in self.mlp_layers if isinstance(m, nn.BatchNorm1d)]
 
-    def forward(self, input_feature, second_block=None, passes=1):
+    def forward(self, input_feature, second_block=None, passes=1, frozen=False):
         """MLP(cat(input_feature, second_block)); `second_block` avoids materialising the concatenation.
         `passes` = 2 stands for the module being evaluated twice on the same input with both results used (the reference's
         PFCN filter pass does that, pfcn_biasedmf.py:209): without dropout the two evaluations are the same function at the
         same point, so ONE evaluation whose output feeds both consumers gives the same values and the same gradient
         (J^T (g1 + g2)); what differs is the BatchNorm bookkeeping, which advances twice: two momentum updates with the
         same batch statistics are one update with momentum 1 - (1 - m)^2, and the batch counter moves by two.
+        `frozen`: the parameters take no gradient from this evaluation (only the input does): a discriminator inside the filter
+        pass, whose gradients the reference computes and then never reads.
         BatchNorm layers always use batch statistics while `self.training` (and the reference's dict-held PFCN MLPs are
         never switched to eval mode); eval-mode BatchNorm (running statistics) is not on this path."""
         if input_feature.device.type != "cuda":
@@ -358,6 +364,8 @@ class MLPLayers(nn.Module):
         elif p > 0.0:
             drop = _Drop(self._drop_seed(), self._drop_state(input_feature.device), p,
                          len(lins) + (1 if second_block is not None else 0))
+        if frozen:
+            params = [t.detach() for t in params]
         name = self.activation.lower() if isinstance(self.activation, str) else self.activation
         return _HipMLP.apply(input_feature, second_block, ACT_CODES[name], p if (masks is not None or drop is not None) else 0.0,
                              masks, drop, bn_buffers, *params)
