@@ -473,6 +473,17 @@ FR_API int fr_bpr(const float* pos, const float* neg, int64_t B, float* loss, fl
                   size_t ws_bytes, void* stream);
 FR_API int fr_bpr_outer(const float* a, const float* c, int64_t B, float* loss, float* da, float* dc, void* ws,
                         size_t ws_bytes, void* stream);
+/* The same on the four columns themselves: a = pos - neg and c = pos_bias - neg_bias are formed in the kernel and the
+ * gradients of all four come out (d_neg = -d_pos, d_neg_bias = -d_pos_bias): no elementwise launches around the loss. */
+FR_API int fr_bpr_outer2(const float* pos, const float* neg, const float* pos_bias, const float* neg_bias, int64_t B,
+                         float* loss, float* d_pos, float* d_neg, float* d_pos_bias, float* d_neg_bias, void* ws,
+                         size_t ws_bytes, void* stream);
+/* Row dots with the rows of a [A, dim] reused by `reps` row blocks of b [reps*A, dim] (a user row against its positive and
+ * its negative item row of one [2B, dim] lookup): out[r*A + i] = a[i] . b[r*A + i];
+ * da[i] = sum_r g[r*A + i] b[r*A + i] (in r order), db[r*A + i] = g[r*A + i] a[i]; da or db may be NULL. */
+FR_API int fr_rowdot_rep_fwd(const float* a, const float* b, int64_t A, int32_t reps, int32_t dim, float* out, void* stream);
+FR_API int fr_rowdot_rep_bwd(const float* g, const float* a, const float* b, int64_t A, int32_t reps, int32_t dim, float* da,
+                             float* db, void* stream);
 FR_API int fr_softmax_ce(const float* logits, const int64_t* label, int64_t M, int32_t C, float* loss, float* dlogits,
                          void* ws, size_t ws_bytes, uint32_t* err_flag, void* stream);
 

@@ -35,6 +35,42 @@ __global__ __launch_bounds__(256) void rowdot_bwd_kernel(const float* __restrict
     }
 }
 
+// The same with the rows of `a` [A, D] reused by R row blocks of `b` [R*A, D] (one user row against its positive AND its
+// negative item row, both gathered in one [2B, D] lookup): out[r*A + i] = a[i] . b[r*A + i]; one wave per row of a.
+__global__ __launch_bounds__(256) void rowdot_rep_fwd_kernel(const float* __restrict__ a, const float* __restrict__ b, int A,
+                                                             int R, int D, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= A) return;
+    for (int r = 0; r < R; ++r) {
+        const size_t row = (size_t)r * A + i;
+        float s = 0.f;
+        for (int d = lane; d < D; d += 64) s = fmaf(a[(size_t)i * D + d], b[row * D + d], s);
+        s = wave_sum(s);
+        if (lane == 0) out[row] = s;
+    }
+}
+
+// da[i,:] = sum_r g[r*A + i] * b[r*A + i,:] (in r order),  db[r*A + i,:] = g[r*A + i] * a[i,:]
+__global__ __launch_bounds__(256) void rowdot_rep_bwd_kernel(const float* __restrict__ g, const float* __restrict__ a,
+                                                             const float* __restrict__ b, int A, int R, int D,
+                                                             float* __restrict__ da, float* __restrict__ db) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= A) return;
+    for (int d = lane; d < D; d += 64) {
+        const float av = a[(size_t)i * D + d];
+        float s = 0.f;
+        for (int r = 0; r < R; ++r) {
+            const size_t row = (size_t)r * A + i;
+            const float gr = g[row];
+            if (da) s = fmaf(gr, b[row * D + d], s);
+            if (db) db[row * D + d] = gr * av;
+        }
+        if (da) da[(size_t)i * D + d] = s;
+    }
+}
+
 __device__ __forceinline__ float bpr_term(float x, float& dterm) {
     // -log(1e-10 + sigmoid(x)) and its derivative  -sigmoid'(x) / (1e-10 + sigmoid(x))
     const float s = 1.f / (1.f + __expf(-x));
@@ -79,13 +115,16 @@ __device__ __forceinline__ float bpr_term_fast(float x, float& dterm) {
     return -__logf(den);
 }
 
-__global__ __launch_bounds__(256) void bpr_outer_kernel(const float* __restrict__ a, const float* __restrict__ c, int B,
-                                                        float* __restrict__ dc, float* __restrict__ ga_part,
-                                                        float* __restrict__ loss_part) {
+// a2 / c2 (optional): the inputs are the differences a - a2 and c - c2, formed here; ndc (optional) receives -dc.
+__global__ __launch_bounds__(256) void bpr_outer_kernel(const float* __restrict__ a, const float* __restrict__ a2,
+                                                        const float* __restrict__ c, const float* __restrict__ c2, int B,
+                                                        float* __restrict__ dc, float* __restrict__ ndc,
+                                                        float* __restrict__ ga_part, float* __restrict__ loss_part) {
     __shared__ float cs[OUTER_ROWS];
     __shared__ float red[4][OUTER_ROWS + 1];
     const int i0 = blockIdx.x * OUTER_ROWS;
-    if (threadIdx.x < OUTER_ROWS) cs[threadIdx.x] = (i0 + threadIdx.x < B) ? c[i0 + threadIdx.x] : 0.f;
+    if (threadIdx.x < OUTER_ROWS)
+        cs[threadIdx.x] = (i0 + threadIdx.x < B) ? c[i0 + threadIdx.x] - (c2 ? c2[i0 + threadIdx.x] : 0.f) : 0.f;
     __syncthreads();
     const int ni = min(OUTER_ROWS, B - i0);
     const float inv = 1.f / ((float)B * (float)B);
@@ -94,7 +133,7 @@ __global__ __launch_bounds__(256) void bpr_outer_kernel(const float* __restrict_
 #pragma unroll
     for (int i = 0; i < OUTER_ROWS; ++i) rs[i] = 0.f;
     for (int j = threadIdx.x; j < B; j += 256) {
-        const float aj = a[j];
+        const float aj = a2 ? a[j] - a2[j] : a[j];
         float gcol = 0.f;
 #pragma unroll
         for (int i = 0; i < OUTER_ROWS; ++i) {
@@ -118,7 +157,9 @@ __global__ __launch_bounds__(256) void bpr_outer_kernel(const float* __restrict_
     __syncthreads();
     if (threadIdx.x < ni) {
         const int i = threadIdx.x;
-        dc[i0 + i] = (((red[0][i] + red[1][i]) + red[2][i]) + red[3][i]) * inv;
+        const float v = (((red[0][i] + red[1][i]) + red[2][i]) + red[3][i]) * inv;
+        dc[i0 + i] = v;
+        if (ndc) ndc[i0 + i] = -v;
     }
     if (threadIdx.x == 0)
         loss_part[blockIdx.x] = (((red[0][OUTER_ROWS] + red[1][OUTER_ROWS]) + red[2][OUTER_ROWS]) + red[3][OUTER_ROWS]) * inv;
@@ -126,7 +167,7 @@ __global__ __launch_bounds__(256) void bpr_outer_kernel(const float* __restrict_
 
 // da[j] = sum over the row blocks, in block order within quarters, quarters in order (fixed order => reproducible)
 __global__ __launch_bounds__(256) void bpr_outer_reduce_kernel(const float* __restrict__ ga_part, int nblk, int B,
-                                                               float* __restrict__ da) {
+                                                               float* __restrict__ da, float* __restrict__ nda) {
     __shared__ float red[4][64];
     const int e = threadIdx.x & 63, part = threadIdx.x >> 6;
     const int j = blockIdx.x * 64 + e;
@@ -136,7 +177,11 @@ __global__ __launch_bounds__(256) void bpr_outer_reduce_kernel(const float* __re
         for (int k = k0; k < k1; ++k) s += ga_part[(size_t)k * B + j];
     red[part][e] = s;
     __syncthreads();
-    if (part == 0 && j < B) da[j] = ((red[0][e] + red[1][e]) + red[2][e]) + red[3][e];
+    if (part == 0 && j < B) {
+        const float v = ((red[0][e] + red[1][e]) + red[2][e]) + red[3][e];
+        da[j] = v;
+        if (nda) nda[j] = -v;
+    }
 }
 
 __global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restrict__ part, int n, float scale,
@@ -192,6 +237,28 @@ extern "C" int fr_rowdot_fwd(const float* a, const float* b, int64_t B, int32_t 
     return FR_OK;
 }
 
+extern "C" int fr_rowdot_rep_fwd(const float* a, const float* b, int64_t A, int32_t reps, int32_t dim, float* out,
+                                 void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    FR_CHECK_ARG(a && b && out && A >= 1 && reps >= 1 && dim >= 1, "fr_rowdot_rep_fwd: bad argument");
+    ProfScope prof(K_ROWDOT, stream);
+    FR_LAUNCH(prof, rowdot_rep_fwd_kernel, dim3((unsigned)((A + 3) / 4)), dim3(256), 0, stream, a, b, (int)A, (int)reps,
+              (int)dim, out);
+    FR_CHECK_LAUNCH();
+    return FR_OK;
+}
+
+extern "C" int fr_rowdot_rep_bwd(const float* g, const float* a, const float* b, int64_t A, int32_t reps, int32_t dim,
+                                 float* da, float* db, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    FR_CHECK_ARG(g && a && b && (da || db) && A >= 1 && reps >= 1 && dim >= 1, "fr_rowdot_rep_bwd: bad argument");
+    ProfScope prof(K_ROWDOT, stream);
+    FR_LAUNCH(prof, rowdot_rep_bwd_kernel, dim3((unsigned)((A + 3) / 4)), dim3(256), 0, stream, g, a, b, (int)A, (int)reps,
+              (int)dim, da, db);
+    FR_CHECK_LAUNCH();
+    return FR_OK;
+}
+
 extern "C" int fr_rowdot_bwd(const float* g, const float* a, const float* b, int64_t B, int32_t dim, float* da, float* db,
                              void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
@@ -228,9 +295,26 @@ extern "C" int fr_bpr(const float* pos, const float* neg, int64_t B, float* loss
 
 // The [B] + [B,1] broadcast of PFCN_BiasedMF: loss[0] = mean_{i,j} -log(1e-10 + sigmoid(a_j + c_i)),
 // a = (u.p - u.n) per row, c = (pos item bias - neg item bias) per row; da, dc = dLoss/d(a, c).
+// fr_bpr_outer2: the same on the four score / bias columns themselves -- a = pos - neg and c = pos_bias - neg_bias are
+// formed in the kernel, and the gradients of all four come out (d_neg = -d_pos, d_neg_bias = -d_pos_bias).
+static int bpr_outer_impl(const float* a, const float* a2, const float* c, const float* c2, int64_t B, float* loss, float* da,
+                          float* nda, float* dc, float* ndc, void* ws, size_t ws_bytes, hipStream_t stream);
+
+extern "C" int fr_bpr_outer2(const float* pos, const float* neg, const float* pos_bias, const float* neg_bias, int64_t B,
+                             float* loss, float* d_pos, float* d_neg, float* d_pos_bias, float* d_neg_bias, void* ws,
+                             size_t ws_bytes, void* stream_) {
+    FR_CHECK_ARG(pos && neg && pos_bias && neg_bias && d_neg && d_neg_bias, "fr_bpr_outer2: bad argument");
+    return bpr_outer_impl(pos, neg, pos_bias, neg_bias, B, loss, d_pos, d_neg, d_pos_bias, d_neg_bias, ws, ws_bytes,
+                          (hipStream_t)stream_);
+}
+
 extern "C" int fr_bpr_outer(const float* a, const float* c, int64_t B, float* loss, float* da, float* dc, void* ws,
                             size_t ws_bytes, void* stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
+    return bpr_outer_impl(a, nullptr, c, nullptr, B, loss, da, nullptr, dc, nullptr, ws, ws_bytes, (hipStream_t)stream_);
+}
+
+static int bpr_outer_impl(const float* a, const float* a2, const float* c, const float* c2, int64_t B, float* loss, float* da,
+                          float* nda, float* dc, float* ndc, void* ws, size_t ws_bytes, hipStream_t stream) {
     FR_CHECK_ARG(a && c && loss && da && dc && ws && B >= 1 && ws_bytes >= fr_bpr_workspace_bytes(B, 1),
                  "fr_bpr_outer: bad argument");
     const int nb = (int)((B + OUTER_ROWS - 1) / OUTER_ROWS);
@@ -238,11 +322,11 @@ extern "C" int fr_bpr_outer(const float* a, const float* c, int64_t B, float* lo
     float* ga_part = (float*)((char*)ws + align_up((size_t)nb * 4, 256));
     {
         ProfScope prof(K_BPR, stream);
-        FR_LAUNCH(prof, bpr_outer_kernel, dim3(nb), dim3(256), 0, stream, a, c, (int)B, dc, ga_part, loss_part);
+        FR_LAUNCH(prof, bpr_outer_kernel, dim3(nb), dim3(256), 0, stream, a, a2, c, c2, (int)B, dc, ndc, ga_part, loss_part);
     }
     FR_CHECK_LAUNCH();
     hipLaunchKernelGGL(bpr_outer_reduce_kernel, dim3((unsigned)((B + 63) / 64)), dim3(256), 0, stream,
-                       (const float*)ga_part, nb, (int)B, da);
+                       (const float*)ga_part, nb, (int)B, da, nda);
     FR_CHECK_LAUNCH();
     hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, stream, (const float*)loss_part, nb, 1.f, loss);
     FR_CHECK_LAUNCH();

@@ -143,6 +143,10 @@ _PROTOS = {
                                  c_void_p]),
     "fr_dropout_apply2": (c_int, [c_void_p, c_int64, c_uint64, c_void_p, c_void_p, c_int64, c_uint64, c_void_p, c_float, c_uint64,
                                   c_void_p, c_void_p, c_void_p, c_void_p]),
+    "fr_bpr_outer2": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                              c_void_p, c_size_t, c_void_p]),
+    "fr_rowdot_rep_fwd": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p]),
+    "fr_rowdot_rep_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
     "fr_copy_many": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),
     "fr_linear_bwd_weight": (c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_void_p,
                                      c_float, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
@@ -235,6 +239,20 @@ def one(device):
     t = _ONES.get(device)
     if t is None:
         t = _ONES[device] = torch.ones((), dtype=torch.float32, device=device)
+    return t
+
+
+_ZEROS = {}
+
+
+def zeros_cached(shape, device):
+    """A shared all-zero fp32 tensor (the exactly-zero gradients some reference losses keep in the graph): read-only by
+    contract -- nothing on this path writes into a gradient it was handed."""
+    import torch
+    key = (tuple(shape), torch.device(device))
+    t = _ZEROS.get(key)
+    if t is None:
+        t = _ZEROS[key] = torch.zeros(tuple(shape), dtype=torch.float32, device=device)
     return t
 
 

@@ -35,6 +35,34 @@ class RowDot(torch.autograd.Function):
         return da, db
 
 
+class RowDotRep(torch.autograd.Function):
+    """RowDot with the rows of `a` [A, D] reused by the R = b.shape[0] / A row blocks of `b`: out[r*A + i] = a[i] . b[r*A + i]
+    (a user row against its positive and its negative item row, which one lookup gathered as [2B, D])."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = a.contiguous(), b.contiguous()
+        A, D = a.shape
+        reps = b.shape[0] // A
+        assert b.shape[0] == reps * A and b.shape[1] == D
+        out = torch.empty(b.shape[0], dtype=torch.float32, device=a.device)
+        _C.check(_C.lib().fr_rowdot_rep_fwd(a.data_ptr(), b.data_ptr(), A, reps, D, out.data_ptr(), _C.current_stream()),
+                 "fr_rowdot_rep_fwd")
+        ctx.save_for_backward(a, b)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        g = g.contiguous()
+        da = torch.empty_like(a) if ctx.needs_input_grad[0] else None
+        db = torch.empty_like(b) if ctx.needs_input_grad[1] else None
+        if da is not None or db is not None:
+            _C.check(_C.lib().fr_rowdot_rep_bwd(g.data_ptr(), a.data_ptr(), b.data_ptr(), a.shape[0], b.shape[0] // a.shape[0],
+                                                a.shape[1], _C.ptr(da), _C.ptr(db), _C.current_stream()), "fr_rowdot_rep_bwd")
+        return da, db
+
+
 class Bpr(torch.autograd.Function):
     """BPRLoss(pos, neg), loss.py:45-47."""
 
@@ -82,6 +110,39 @@ class BprBroadcast(torch.autograd.Function):
         dev = da.device
         return (da * g, -da * g, torch.zeros(ub, device=dev), (dc * g).reshape(pb), (-dc * g).reshape(pb),
                 torch.zeros(gb, device=dev))
+
+
+class BprBroadcastPacked(torch.autograd.Function):
+    """BprBroadcast on packed columns: `scores` = [pos | neg] ([2B], RowDotRep's output), `item_bias` = the [2B, 1] lookup of
+    [pos items | neg items].  The differences are formed in the kernel and the four gradient columns come out of it, so the
+    loss costs no elementwise launches (the unpacked form: 2 subtractions before, 6 products / negations and 2 slice
+    gradients after)."""
+
+    @staticmethod
+    def forward(ctx, scores, user_bias, item_bias, global_bias):
+        scores = scores.contiguous()
+        ib = item_bias.contiguous()
+        B, dev = scores.numel() // 2, scores.device
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        ds = torch.empty_like(scores)
+        dib = torch.empty(2 * B, dtype=torch.float32, device=dev)
+        ws = _ws(_C.lib().fr_bpr_workspace_bytes(B, 1), dev)
+        sp, bp = scores.data_ptr(), ib.data_ptr()
+        _C.check(_C.lib().fr_bpr_outer2(sp, sp + 4 * B, bp, bp + 4 * B, B, loss.data_ptr(), ds.data_ptr(), ds.data_ptr() + 4 * B,
+                                        dib.data_ptr(), dib.data_ptr() + 4 * B, ws.data_ptr(), ws.numel(),
+                                        _C.current_stream()), "fr_bpr_outer2")
+        ctx.save_for_backward(ds, dib)
+        ctx.shapes = (user_bias.shape, item_bias.shape, global_bias.shape)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        ds, dib = ctx.saved_tensors
+        ub, ibs, gb = ctx.shapes
+        dev = ds.device
+        if not _C.is_one(g):
+            ds, dib = ds * g, dib * g
+        return ds, _C.zeros_cached(ub, dev), dib.reshape(ibs), _C.zeros_cached(gb, dev)
 
 
 class SigmoidBce(torch.autograd.Function):

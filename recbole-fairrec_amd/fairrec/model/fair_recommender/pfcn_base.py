@@ -16,7 +16,7 @@ import torch
 import torch.nn as nn
 
 from ...engine import GenericEngine
-from ...functional import Bpr, BprBroadcast, RowDot, SigmoidBce, SoftmaxCe
+from ...functional import Bpr, BprBroadcastPacked, RowDot, SigmoidBce, SoftmaxCe
 from ...utils.enum_type import InputType
 from ..abstract_recommender import FairRecommender
 from ..layers import MLPLayers
@@ -212,10 +212,15 @@ class PFCNBase(FairRecommender):
         ie = eng.lookup(self._itab, items)
         pos_e, neg_e = self._item_tower(ie[:B]), self._item_tower(ie[B:])
         dp, dn = self._score(user_embed, pos_e), self._score(user_embed, neg_e)
+        # (functional.RowDotRep scores both in one launch each way; it sums the two user-row gradients with one rounding
+        # less than autograd does, and the d128 golden sits within that of a LeakyReLU kink -- DESIGN.md §7 -- so the pair of
+        # RowDot calls stays)
         if self.biased:
             ub = eng.lookup("user_bias.weight", user)
             ib = eng.lookup("item_bias.weight", items)
-            bpr_loss = BprBroadcast.apply(dp, dn, ub, ib[:B], ib[B:], self.global_bias)
+            # packed columns: the differences and all four gradient columns come out of the loss kernel (bit-identical to
+            # BprBroadcast on the slices, without its ten elementwise launches)
+            bpr_loss = BprBroadcastPacked.apply(torch.cat([dp, dn]), ub, ib, self.global_bias)
         else:
             bpr_loss = Bpr.apply(dp, dn)
         if self.filter_mode != 'none':
@@ -223,7 +228,7 @@ class PFCNBase(FairRecommender):
             # filters applied again (BatchNorm statistics advance twice), gradient flows through both passes
             again = user_embed if once else self._filter(self._user_tower(ue_raw), sst_list)
             dis_loss = self._dis_terms(again, interaction, sst_list, frozen=True)
-            return bpr_loss - self.dis_weight * dis_loss
+            return torch.sub(bpr_loss, dis_loss, alpha=self.dis_weight)     # one launch; bpr_loss's gradient is the seed itself
         return bpr_loss
 
     def predict(self, interaction, sst_list=None):

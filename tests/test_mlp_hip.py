@@ -275,3 +275,38 @@ def test_bpr_outer_at_the_baseline_batch(B):
         err = (got.cpu().double() - ref).abs()
         assert bool((err <= 1e-4 * ref.abs() + 1e-6 * scale).all()), float(err.max())
     assert float(leaves[2].grad.abs().max()) == 0.0 and float(leaves[5].grad.abs().max()) == 0.0   # App. B-1: exactly zero
+
+
+@pytest.mark.parametrize("B,seeded", [(200, False), (8192, True)])
+def test_packed_bpr_and_repeated_row_dots_equal_the_unpacked_forms(B, seeded):
+    """RowDotRep + BprBroadcastPacked (PFCN_BiasedMF's score / loss on one [2B] lookup of [pos | neg] items) against
+    RowDot x 2 + BprBroadcast on the slices: same loss, same gradients for the user rows, item rows, item biases; exactly
+    zero for user bias and global bias.  `seeded`: backward() from the cached one the graphed step uses (no scaling launches)
+    and from an arbitrary upstream gradient."""
+    from fairrec import _C
+    from fairrec.functional import BprBroadcast, BprBroadcastPacked, RowDot, RowDotRep
+    g = torch.Generator().manual_seed(B)
+    D = 64
+    ue = (torch.randn(B, D, generator=g) * 0.3).cuda()
+    ie = (torch.randn(2 * B, D, generator=g) * 0.3).cuda()
+    ub = torch.randn(B, 1, generator=g).cuda()
+    ib = (torch.randn(2 * B, 1, generator=g) * 0.5).cuda()
+    gb = torch.zeros(1).cuda()
+
+    def leaves():
+        return [t.clone().requires_grad_(True) for t in (ue, ie, ub, ib, gb)]
+
+    a = leaves()
+    loss_a = BprBroadcast.apply(RowDot.apply(a[0], a[1][:B]), RowDot.apply(a[0], a[1][B:]), a[2], a[3][:B], a[3][B:], a[4])
+    b = leaves()
+    loss_b = BprBroadcastPacked.apply(RowDotRep.apply(b[0], b[1]), b[2], b[3], b[4])
+    if seeded:
+        loss_a.backward(_C.one("cuda"))
+        loss_b.backward(_C.one("cuda"))
+    else:
+        (loss_a * 0.37).backward()
+        (loss_b * 0.37).backward()
+    assert abs(float(loss_a) - float(loss_b)) <= 1e-6 * abs(float(loss_a))
+    for x, y in zip(a, b):
+        torch.testing.assert_close(y.grad, x.grad, rtol=1e-5, atol=1e-7 * max(1.0, float(x.grad.abs().max())))
+    assert float(b[2].grad.abs().max()) == 0.0 and float(b[4].grad.abs().max()) == 0.0
