@@ -455,6 +455,13 @@ FR_API size_t fr_bn_workspace_bytes(int64_t M, int32_t N);
 FR_API int fr_bn_fwd(const float* Z, const float* gamma, const float* beta, float eps, float momentum,
                      float* running_mean, float* running_var, int64_t M, int32_t N, int32_t act, float* Y, float* xhat,
                      float* invstd, void* ws, size_t ws_bytes, void* stream);
+/* fr_bn_fwd that also writes Yd = dropout(Y), the next layer's input, from its last launch: what
+ * fr_dropout_apply(Y, M*N, p, seed, offset, counter, used_out, tick_state, Yd) would give (same pattern, same counter
+ * protocol), without the extra pass.  N % 4 == 0; all tensors 16-byte aligned. */
+FR_API int fr_bn_fwd_drop(const float* Z, const float* gamma, const float* beta, float eps, float momentum,
+                          float* running_mean, float* running_var, int64_t M, int32_t N, int32_t act, float* Y, float* xhat,
+                          float* invstd, void* ws, size_t ws_bytes, float* Yd, float p, uint64_t seed, uint64_t offset,
+                          const int64_t* counter, int64_t* used_out, int64_t* tick_state, void* stream);
 FR_API int fr_bn_bwd(const float* dY, const float* Y, int32_t act, const float* xhat, const float* invstd,
                      const float* gamma, int64_t M, int32_t N, float* dZ, float* dgamma, float* dbeta, void* ws,
                      size_t ws_bytes, void* stream);

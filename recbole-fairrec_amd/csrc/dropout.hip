@@ -8,25 +8,10 @@
 // torch's (the reference's dropout stream is not reproducible across devices either); tests/ pin the arithmetic with
 // recorded masks through MLPLayers.forced_masks and this generator through its own properties.
 #include "kernels.hpp"
+#include "dropout.hpp"
 
 namespace fr {
 
-// Philox4x32-10 (Salmon et al., SC'11): 4 x 32 random bits per (counter, key).
-__device__ __forceinline__ uint4 philox4x32(uint4 c, uint2 k) {
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const unsigned hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
-        const unsigned hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
-        c = make_uint4(hi1 ^ c.y ^ k.x, lo1, hi0 ^ c.w ^ k.y, lo0);
-        k.x += 0x9E3779B9u;
-        k.y += 0xBB67AE85u;
-    }
-    return c;
-}
-
-// state = {call counter, ticket}.  Every workgroup takes the counter through ONE load of its first thread; when `tick`
-// is set that thread then draws a ticket whose increment depends on the loaded value (so the load has completed), and
-// the holder of the last ticket -- every workgroup has read the counter by then -- advances it and resets the tickets.
 // Up to two tensors per launch (the two blocks of a first layer's input): job 1 takes the workgroups from `blocks0` on.
 struct DropJob {
     const float* x;
@@ -41,20 +26,7 @@ __global__ __launch_bounds__(256) void dropout_apply_kernel(DropJob j0, DropJob 
                                                             unsigned long long* __restrict__ used_out,
                                                             unsigned long long* __restrict__ tick) {
     __shared__ unsigned long long ctr_s;
-    if (threadIdx.x == 0) {
-        const unsigned long long c = __hip_atomic_load(ctr_src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        ctr_s = c;
-        if (used_out && blockIdx.x == 0) *used_out = c;
-        if (tick) {
-            const unsigned long long t = atomicAdd(&tick[1], 1ull + (c >> 63));
-            if (t == gridDim.x - 1) {
-                tick[1] = 0ull;
-                tick[0] = c + 1ull;
-            }
-        }
-    }
-    __syncthreads();
-    const unsigned long long ctr = ctr_s;
+    const unsigned long long ctr = drop_counter_enter(ctr_src, used_out, tick, &ctr_s);
     const bool second = blockIdx.x >= blocks0;
     const float* __restrict__ x = second ? j1.x : j0.x;
     float* __restrict__ out = second ? j1.out : j0.out;
@@ -64,10 +36,8 @@ __global__ __launch_bounds__(256) void dropout_apply_kernel(DropJob j0, DropJob 
     const long long i = q * 4;
     if (i >= n) return;
     const unsigned long long g = off4 + (unsigned long long)q;
-    const uint4 r = philox4x32(make_uint4((unsigned)g, (unsigned)(g >> 32), (unsigned)ctr, (unsigned)(ctr >> 32)),
-                               make_uint2((unsigned)seed, (unsigned)(seed >> 32)));
-    const float k0 = r.x >= thr ? scale : 0.f, k1 = r.y >= thr ? scale : 0.f, k2 = r.z >= thr ? scale : 0.f,
-                k3 = r.w >= thr ? scale : 0.f;
+    const float4 kp = drop_keep4(seed, ctr, g, thr, scale);
+    const float k0 = kp.x, k1 = kp.y, k2 = kp.z, k3 = kp.w;
     if (i + 4 <= n) {
         const float4 v = *reinterpret_cast<const float4*>(x + i);
         *reinterpret_cast<float4*>(out + i) = make_float4(v.x * k0, v.y * k1, v.z * k2, v.w * k3);
@@ -88,8 +58,7 @@ extern "C" int fr_dropout_apply2(const float* x0, int64_t n0, uint64_t offset0, 
     FR_CHECK_ARG((((uintptr_t)x0 | (uintptr_t)out0) & 15) == 0, "fr_dropout_apply: 16-byte alignment required");
     FR_CHECK_ARG(!x1 || (out1 && n1 >= 1 && offset1 % 4 == 0 && (((uintptr_t)x1 | (uintptr_t)out1) & 15) == 0),
                  "fr_dropout_apply2: bad second tensor");
-    const double t = (double)p * 4294967296.0;
-    const unsigned thr = t >= 4294967295.0 ? 0xFFFFFFFFu : (unsigned)t;     // keep <=> 32 random bits >= thr
+    const unsigned thr = drop_threshold(p);
     const unsigned b0 = (unsigned)(((n0 + 3) / 4 + 255) / 256), b1 = x1 ? (unsigned)(((n1 + 3) / 4 + 255) / 256) : 0u;
     const DropJob j0{x0, out0, (long long)n0, (unsigned long long)(offset0 / 4)};
     const DropJob j1{x1, out1, (long long)(x1 ? n1 : 0), (unsigned long long)(offset1 / 4)};

@@ -15,6 +15,7 @@
 #include "common.hpp"
 #include "kernels.hpp"
 #include "mlp_glds.hpp"
+#include "dropout.hpp"
 
 namespace fr {
 
@@ -788,6 +789,35 @@ __global__ __launch_bounds__(BN_THREADS) void bn_fwd_apply_kernel(const float* _
     }
 }
 
+// The same pass with the dropout of the NEXT layer's input folded in: also writes Yd = Y o keep (csrc/dropout.hpp: the
+// pattern of element i is that of group (off4 + i / 4), exactly what fr_dropout_apply would draw for Y at that offset).
+// Four consecutive columns per thread (one Philox call per thread); N % 4 == 0.
+__global__ __launch_bounds__(256) void bn_fwd_apply_drop_kernel(const float* __restrict__ Z, const float* __restrict__ fin,
+                                                                const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, long long quads, int N4,
+                                                                int act, float* __restrict__ Y, float* __restrict__ xhat,
+                                                                float* __restrict__ Yd, unsigned thr, float scale,
+                                                                unsigned long long seed, unsigned long long off4,
+                                                                const unsigned long long* __restrict__ ctr_src,
+                                                                unsigned long long* __restrict__ used_out,
+                                                                unsigned long long* __restrict__ tick) {
+    __shared__ unsigned long long ctr_s;
+    const unsigned long long ctr = drop_counter_enter(ctr_src, used_out, tick, &ctr_s);
+    const long long q = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (q >= quads) return;
+    const int c4 = (int)(q % N4);
+    const float4 z = reinterpret_cast<const float4*>(Z)[q];
+    const float4 f0 = reinterpret_cast<const float4*>(fin)[2 * c4], f1 = reinterpret_cast<const float4*>(fin)[2 * c4 + 1];
+    const float4 g = reinterpret_cast<const float4*>(gamma)[c4], b = reinterpret_cast<const float4*>(beta)[c4];
+    const float4 xh = make_float4((z.x - f0.x) * f0.y, (z.y - f0.z) * f0.w, (z.z - f1.x) * f1.y, (z.w - f1.z) * f1.w);
+    const float4 y = make_float4(act_fwd(fmaf(g.x, xh.x, b.x), act), act_fwd(fmaf(g.y, xh.y, b.y), act),
+                                 act_fwd(fmaf(g.z, xh.z, b.z), act), act_fwd(fmaf(g.w, xh.w, b.w), act));
+    const float4 k = drop_keep4(seed, ctr, off4 + (unsigned long long)q, thr, scale);
+    reinterpret_cast<float4*>(xhat)[q] = xh;
+    reinterpret_cast<float4*>(Y)[q] = y;
+    reinterpret_cast<float4*>(Yd)[q] = make_float4(y.x * k.x, y.y * k.y, y.z * k.z, y.w * k.w);
+}
+
 // part[(chunk * N + n) * 2 + {0,1}] = sum dA, sum dA * xhat over the chunk's rows,  dA = dY o act'(Y)
 __global__ __launch_bounds__(BN_THREADS) void bn_bwd_stats_kernel(const float* __restrict__ dY, const float* __restrict__ Y,
                                                                   int act, const float* __restrict__ xhat, int M, int N,
@@ -877,10 +907,36 @@ extern "C" size_t fr_bn_workspace_bytes(int64_t M, int32_t N) {
     return ((size_t)((M + rc - 1) / rc) + 1) * N * 2 * sizeof(float);   // per-chunk partials + the folded column statistics
 }
 
+static int bn_fwd_impl(const float* Z, const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                       float* running_var, int64_t M, int32_t N, int32_t act, float* Y, float* xhat, float* invstd, void* ws,
+                       size_t ws_bytes, hipStream_t stream, float* Yd, float p, uint64_t seed, uint64_t offset,
+                       const int64_t* counter, int64_t* used_out, int64_t* tick_state);
+
 extern "C" int fr_bn_fwd(const float* Z, const float* gamma, const float* beta, float eps, float momentum,
                          float* running_mean, float* running_var, int64_t M, int32_t N, int32_t act, float* Y,
                          float* xhat, float* invstd, void* ws, size_t ws_bytes, void* stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
+    return bn_fwd_impl(Z, gamma, beta, eps, momentum, running_mean, running_var, M, N, act, Y, xhat, invstd, ws, ws_bytes,
+                       (hipStream_t)stream_, nullptr, 0.f, 0, 0, nullptr, nullptr, nullptr);
+}
+
+// fr_bn_fwd that also writes Yd = dropout(Y), the next layer's input, in its last launch: what fr_dropout_apply(Y, ...,
+// out = Yd) would give with the same (p, seed, offset, counter, used_out, tick_state); N % 4 == 0.
+extern "C" int fr_bn_fwd_drop(const float* Z, const float* gamma, const float* beta, float eps, float momentum,
+                              float* running_mean, float* running_var, int64_t M, int32_t N, int32_t act, float* Y,
+                              float* xhat, float* invstd, void* ws, size_t ws_bytes, float* Yd, float p, uint64_t seed,
+                              uint64_t offset, const int64_t* counter, int64_t* used_out, int64_t* tick_state,
+                              void* stream_) {
+    FR_CHECK_ARG(Yd && counter && N % 4 == 0 && p >= 0.f && p < 1.f && offset % 4 == 0 &&
+                     (((uintptr_t)Z | (uintptr_t)Y | (uintptr_t)Yd | (uintptr_t)xhat | (uintptr_t)gamma | (uintptr_t)beta) & 15) == 0,
+                 "fr_bn_fwd_drop: bad argument (N % 4 == 0, 16-byte aligned tensors)");
+    return bn_fwd_impl(Z, gamma, beta, eps, momentum, running_mean, running_var, M, N, act, Y, xhat, invstd, ws, ws_bytes,
+                       (hipStream_t)stream_, Yd, p, seed, offset, counter, used_out, tick_state);
+}
+
+static int bn_fwd_impl(const float* Z, const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                       float* running_var, int64_t M, int32_t N, int32_t act, float* Y, float* xhat, float* invstd, void* ws,
+                       size_t ws_bytes, hipStream_t stream, float* Yd, float p, uint64_t seed, uint64_t offset,
+                       const int64_t* counter, int64_t* used_out, int64_t* tick_state) {
     FR_CHECK_ARG(Z && gamma && beta && Y && xhat && invstd && ws && M >= 1 && N >= 1 && act_ok(act) &&
                      ws_bytes >= fr_bn_workspace_bytes(M, N), "fr_bn_fwd: bad argument");
     const int rc = bn_chunk_rows(M);
@@ -892,8 +948,16 @@ extern "C" int fr_bn_fwd(const float* Z, const float* gamma, const float* beta, 
     FR_LAUNCH(prof, bn_fwd_fold_kernel, dim3(grid.x), dim3(BN_THREADS), 0, stream, (const float*)ws, (int)grid.y, (int)M, (int)N, rc, eps,
               momentum, running_mean, running_var, fin, invstd);
     FR_CHECK_LAUNCH();
-    FR_LAUNCH(prof, bn_fwd_apply_kernel, grid, dim3(BN_THREADS), 0, stream, Z, (const float*)fin, gamma, beta, (int)M, (int)N, rc,
-              (int)act, Y, xhat);
+    if (Yd) {
+        const long long quads = (long long)M * N / 4;
+        FR_LAUNCH(prof, bn_fwd_apply_drop_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, stream, Z, (const float*)fin,
+                  gamma, beta, quads, (int)(N / 4), (int)act, Y, xhat, Yd, drop_threshold(p), 1.f / (1.f - p),
+                  (unsigned long long)seed, (unsigned long long)(offset / 4), (const unsigned long long*)counter,
+                  (unsigned long long*)used_out, (unsigned long long*)tick_state);
+    } else {
+        FR_LAUNCH(prof, bn_fwd_apply_kernel, grid, dim3(BN_THREADS), 0, stream, Z, (const float*)fin, gamma, beta, (int)M, (int)N, rc,
+                  (int)act, Y, xhat);
+    }
     FR_CHECK_LAUNCH();
     return FR_OK;
 }

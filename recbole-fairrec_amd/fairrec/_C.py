@@ -156,6 +156,9 @@ _PROTOS = {
     "fr_bn_workspace_bytes": (c_size_t, [c_int64, c_int32]),
     "fr_bn_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_float, c_void_p, c_void_p, c_int64, c_int32, c_int32,
                           c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "fr_bn_fwd_drop": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_float, c_void_p, c_void_p, c_int64, c_int32, c_int32,
+                               c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_float, c_uint64, c_uint64,
+                               c_void_p, c_void_p, c_void_p, c_void_p]),
     "fr_bn_bwd": (c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p,
                           c_void_p, c_void_p, c_size_t, c_void_p]),
     "fr_rowdot_fwd": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p]),

@@ -46,16 +46,21 @@ class _Drop:
         self.off = 0
         self.first = True
 
-    def forward(self, x: torch.Tensor, out: torch.Tensor) -> int:
-        """out = dropout(x); returns the element offset of this launch (what `again` needs)."""
-        off, n = self.off, x.numel()
+    def take(self, n: int):
+        """Books one launch that drops n elements: (offset, `used` pointer or None, tick-state pointer or None)."""
+        off = self.off
         self.left -= 1
-        _C.check(_C.lib().fr_dropout_apply(x.data_ptr(), n, self.p, self.seed, off, self.state.data_ptr(),
-                                           self.used.data_ptr() if self.first else None,
-                                           self.state.data_ptr() if self.left == 0 else None, out.data_ptr(),
-                                           _C.current_stream()), "fr_dropout_apply")
+        used = self.used.data_ptr() if self.first else None
+        tick = self.state.data_ptr() if self.left == 0 else None
         self.first = False
         self.off += (n + 3) // 4 * 4
+        return off, used, tick
+
+    def forward(self, x: torch.Tensor, out: torch.Tensor) -> int:
+        """out = dropout(x); returns the element offset of this launch (what `again` needs)."""
+        off, used, tick = self.take(x.numel())
+        _C.check(_C.lib().fr_dropout_apply(x.data_ptr(), x.numel(), self.p, self.seed, off, self.state.data_ptr(), used, tick,
+                                           out.data_ptr(), _C.current_stream()), "fr_dropout_apply")
         return off
 
     def forward2(self, x0, out0, x1, out1):
@@ -107,6 +112,7 @@ class _HipMLP(torch.autograd.Function):
         cur = (x0, x1)
         outs, xhats, invstds = [], [], []
         premul, ins, masks8 = [], [], []
+        fused_in = None                       # (dropped input of the next layer, its offset) written by fr_bn_fwd_drop
         drop_off = [None] * n_layers          # (offset of block a, offset of block c) of a regenerated pattern
         dropped_out = [False] * n_layers      # layer l's output was dropped in place for layer l + 1
         for l in range(n_layers):
@@ -117,7 +123,15 @@ class _HipMLP(torch.autograd.Function):
             Y = torch.empty((M, N), dtype=torch.float32, device=dev)
             mk = masks[l] if masks is not None else None      # fp32 keep scales [M, K] (0 or 1/(1-p)), or None
             mk8 = None
-            if drop is not None:
+            if drop is not None and fused_in is not None:
+                # the BatchNorm pass of the layer below already wrote this layer's dropped input
+                a, c = fused_in[0], None
+                drop_off[l] = (fused_in[1], 0)
+                fused_in = None
+                premul.append(True)
+                _C.check(lib.fr_linear_fwd(a.data_ptr(), k0, None, 0, None, 1.0, W.data_ptr(), b.data_ptr(), M, N,
+                                           0 if use_bn else act, Y.data_ptr(), st), "fr_linear_fwd")
+            elif drop is not None:
                 if l > 0 and not use_bn and act == 1 and a.numel() % 4 == 0:
                     drop.forward(a, a)                          # a IS outs[l - 1]
                     dropped_out[l - 1] = True
@@ -156,9 +170,19 @@ class _HipMLP(torch.autograd.Function):
                 xh = torch.empty_like(Z)
                 inv = torch.empty(N, dtype=torch.float32, device=dev)
                 ws = torch.empty(lib.fr_bn_workspace_bytes(M, N), dtype=torch.uint8, device=dev)
-                _C.check(lib.fr_bn_fwd(Z.data_ptr(), g.data_ptr(), be.data_ptr(), eps, mom, _C.ptr(rm), _C.ptr(rv), M, N, act,
-                                       Y.data_ptr(), xh.data_ptr(), inv.data_ptr(), ws.data_ptr(), ws.numel(), st),
-                         "fr_bn_fwd")
+                if drop is not None and l + 1 < n_layers and N % 4 == 0:
+                    # ... and the next layer's dropout in the same pass (Yd next to Y, which the backward pass needs)
+                    Yd = torch.empty_like(Z)
+                    off, used, tick = drop.take(M * N)
+                    _C.check(lib.fr_bn_fwd_drop(Z.data_ptr(), g.data_ptr(), be.data_ptr(), eps, mom, _C.ptr(rm), _C.ptr(rv), M, N,
+                                                act, Y.data_ptr(), xh.data_ptr(), inv.data_ptr(), ws.data_ptr(), ws.numel(),
+                                                Yd.data_ptr(), drop.p, drop.seed, off, drop.state.data_ptr(), used, tick, st),
+                             "fr_bn_fwd_drop")
+                    fused_in = (Yd, off)
+                else:
+                    _C.check(lib.fr_bn_fwd(Z.data_ptr(), g.data_ptr(), be.data_ptr(), eps, mom, _C.ptr(rm), _C.ptr(rv), M, N, act,
+                                           Y.data_ptr(), xh.data_ptr(), inv.data_ptr(), ws.data_ptr(), ws.numel(), st),
+                             "fr_bn_fwd")
                 xhats.append(xh)
                 invstds.append(inv)
             outs.append(Y)
