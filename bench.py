@@ -318,10 +318,12 @@ def main():
         g = torch.Generator(device="cpu").manual_seed(SEED + 1 + 1000 * rank)
         Us = (torch.randn(shard_rows(N_USERS, rank, world), DIM, generator=g) * math.sqrt(2.0 / (N_USERS + DIM))).to(dev)
         Is = (torch.randn(shard_rows(N_ITEMS, rank, world), DIM, generator=g) * math.sqrt(2.0 / (N_ITEMS + DIM))).to(dev)
-        # Two exchange schedules.  "item_owner": 2 all-to-alls on the step's dependent chain (the index exchanges run a step
-        # ahead), the default over real links; "requester": 4, but one collective and a few launches fewer in all, which
-        # wins where a collective is a local copy (one rank: 93 us against 107 us).  FAIRREC_SHARD_SCHEDULE overrides.
-        schedule = os.environ.get("FAIRREC_SHARD_SCHEDULE", "item_owner" if world > 1 else "requester")
+        # Two exchange schedules.  "requester": 5 collectives per step, 4 of them on the step's dependent chain.  "item_owner":
+        # 2 on the chain, but 6 in all (3 run a step ahead).  Collectives of one communicator execute one after the other
+        # whatever stream issued them, so a step costs (number of collectives) x (collective time) + the kernels between the
+        # dependent ones: until the item-owner schedule's scalars ride in its other exchanges the requester
+        # schedule has one collective less, and it is the default.  FAIRREC_SHARD_SCHEDULE=item_owner selects the other.
+        schedule = os.environ.get("FAIRREC_SHARD_SCHEDULE", "requester")
         if schedule not in ("item_owner", "requester"):
             raise SystemExit("FAIRREC_SHARD_SCHEDULE must be item_owner or requester")
         Eng = ShardedFocfEngineV2 if schedule == "item_owner" else ShardedFocfEngine
