@@ -50,6 +50,13 @@ def run(name, model, opts, loss_fns, data, gender, W=5, K=20):
             return
         for opt, fn in zip(opts, loss_fns):
             opt.zero_grad(); loss = fn(inters[k % len(inters)]); loss.backward(); opt.step()
+    # age the lazy-Adam state for one sweep period of the largest trainable table (see bench.py): AGE=0 disables
+    B_ = inters[0].length
+    n_age = int(os.environ.get("AGE", -1))
+    if n_age < 0:
+        n_age = max([t.default_sweep(B_) for t in model.hip_engine()._tables.values() if t.trainable] + [0])
+    for k in range(n_age): step(k)
+    name += f" [aged {n_age} steps]"
     for k in range(W): step(k)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for k in range(W, W + K): step(k)
