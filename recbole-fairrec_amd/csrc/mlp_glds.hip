@@ -312,6 +312,306 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ 
     reinterpret_cast<f4*>(out)[i] = o;
 }
 
+// =====================================================================================================================
+// The same three products with the operand chunks SHARED by the four waves of a 64 x 64 macro tile (2 x 2 tiles of
+// 32 x 32): per 32-element reduction chunk the group brings two 32-row blocks of A and two of B -- each wave stages ONE of
+// the four -- for four tiles' worth of MFMAs, half the L2 -> LDS bytes per flop of the wave-private form above
+// (scratch/gemm_glds64.hip: 15-20 % faster from [8192,128] -> 128 to [1.1 M,128] -> 128).  One s_barrier per chunk: a wave
+// waits for its own block of chunk t, the barrier makes every block of chunk t visible AND proves that all four waves are
+// done reading the buffer of chunk t - 1, into which the next stage then goes (ring of NBUF buffers).  Every output
+// element is accumulated in exactly the order of the wave-private kernel (same parts, same chunk order, same two
+// accumulators), so the two forms are bit-identical (tests/test_mlp_hip.py).  KS reduction parts of a macro tile = KS
+// groups of four waves in one workgroup.
+template <int MODE, int KS, int NBUF>
+__global__ __launch_bounds__(256 * KS) void linear_glds64_kernel(GlArgs g) {
+    extern __shared__ __align__(16) float lds[];   // [KS][NBUF][A0 A1 B0 B1][1024]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    constexpr bool A_T = MODE == GL_BWD_W, B_T = MODE != GL_FWD;
+    const int w4 = wave & 3, wi = w4 >> 1, wj = w4 & 1;
+    const int mt_j = (g.tiles_j + 1) / 2, nmt = ((g.tiles_i + 1) / 2) * mt_j;
+    int mt, part;
+    if (MODE == GL_BWD_W) {
+        mt = (int)(blockIdx.x % (unsigned)nmt);
+        part = (int)(blockIdx.x / (unsigned)nmt);
+    } else {
+        mt = blockIdx.x;
+        part = wave >> 2;
+    }
+    const int mi = mt / mt_j, mj = mt % mt_j;
+    const int ti = 2 * mi + wi, tj = 2 * mj + wj;
+    const bool live = ti < g.tiles_i && tj < g.tiles_j;
+    const int i0 = ti * 32, j0 = tj * 32;
+    const int c0 = part * g.chunks_per_part;
+    int nchunk;
+    {
+        const int total = (g.R + 31) / 32;
+        nchunk = total - c0 < g.chunks_per_part ? total - c0 : g.chunks_per_part;
+        if (nchunk < 0) nchunk = 0;
+    }
+    const int nloop = KS > 1 ? g.chunks_per_part : nchunk;      // every group of the workgroup meets at every barrier
+
+    // ---- staging: this wave brings block w4 of the group's four (0, 1: the two 32-row blocks of A; 2, 3: of B); a block
+    // past the matrix (odd tile count) repeats the last one ---------------------------------------------------------------
+    float* grp = lds + (size_t)(KS > 1 ? part : 0) * NBUF * 4096;
+    const bool stA = w4 < 2;
+    int s0;   // first output row (A) / column (B) of the staged block
+    if (stA) {
+        const int t = 2 * mi + w4;
+        s0 = 32 * (t < g.tiles_i ? t : g.tiles_i - 1);
+    } else {
+        const int t = 2 * mj + (w4 - 2);
+        s0 = 32 * (t < g.tiles_j ? t : g.tiles_j - 1);
+    }
+    const int srow = lane >> 3, sslot = lane & 7;
+    const float* ps[4];
+    auto set_ptrs = [&](int chunk) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = 8 * i + srow, c = (sslot ^ ((row >> 1) & 7)) * 4;
+            if (stA) {
+                if (A_T) {
+                    long long rr = (long long)chunk * 32 + row;
+                    rr = rr < g.R ? rr : g.R - 1;
+                    ps[i] = gl_piece(g.A, rr, s0) + c;
+                } else {
+                    long long rr = s0 + row;
+                    rr = rr < g.rowsA ? rr : g.rowsA - 1;
+                    ps[i] = gl_piece(g.A, rr, chunk * 32) + c;
+                }
+            } else {
+                if (B_T) {
+                    long long rr = (long long)chunk * 32 + row;
+                    rr = rr < g.R ? rr : g.R - 1;
+                    ps[i] = gl_piece(g.B, rr, s0) + c;
+                } else {
+                    long long rr = s0 + row;
+                    rr = rr < g.rowsB ? rr : g.rowsB - 1;
+                    ps[i] = gl_piece(g.B, rr, chunk * 32) + c;
+                }
+            }
+        }
+    };
+    const bool sT = stA ? A_T : B_T;
+    const GlMat& sm = stA ? g.A : g.B;
+    const long long step = sT ? 32ll * (s0 < sm.split ? sm.lda : sm.ldb) : 32;
+    auto stage = [&](int chunk, int buf) {
+        float* dst = grp + buf * 4096 + w4 * 1024;
+        const bool fresh = chunk == c0 || (!sT && chunk * 32 == sm.split) || (sT && (long long)chunk * 32 + 32 > g.R);
+        if (fresh) set_ptrs(chunk);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_global_load_lds((glb_vp)ps[i], (lds_vp)(dst + i * 256), 16, 0, 0);
+            ps[i] += step;
+        }
+    };
+
+    // ---- fragment addresses: A from block wi, B from block 2 + wj of the current buffer ---------------------------------
+    const int r = lane & 31, h = lane >> 5;
+    const unsigned lbase = (unsigned)(size_t)(__attribute__((address_space(3))) float*)grp;
+    const unsigned abase = lbase + wi * 4096, bbase = lbase + (2 + wj) * 4096;
+    unsigned rn[4];    // row-contiguous operand: row r, chunk slot 2 j + h (offset inside a block)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) rn[j] = r * 128 + (((2 * j + h) ^ ((r >> 1) & 7)) << 4);
+    unsigned rt[16];   // transposed operand: row 8 j + 4 h + e, float r
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int row = 8 * (q >> 2) + 4 * h + (q & 3);
+        rt[q] = row * 128 + ((((r >> 2) ^ ((row >> 1) & 7)) << 4) | ((r & 3) << 2));
+    }
+    unsigned aaddr[A_T ? 16 : 4], baddr[B_T ? 16 : 4];
+#pragma unroll
+    for (int q = 0; q < (A_T ? 16 : 4); ++q) aaddr[q] = abase + (A_T ? rt[q] : rn[q]);
+#pragma unroll
+    for (int q = 0; q < (B_T ? 16 : 4); ++q) baddr[q] = bbase + (B_T ? rt[q] : rn[q]);
+
+#pragma unroll
+    for (int b = 0; b < NBUF - 1; ++b)
+        if (b < nchunk) stage(c0 + b, b);
+    f32x16 acc0 = {0}, acc1 = {0};
+    float bsum = 0.f;
+    for (int t0 = 0; t0 < nloop; t0 += NBUF) {
+#pragma unroll
+        for (int buf = 0; buf < NBUF; ++buf) {
+            const int t = t0 + buf;
+            if (t < nloop) {
+                // own block of chunk t has landed (newer chunks stay in flight) ...
+                const int newer = nchunk - 1 - t < NBUF - 2 ? nchunk - 1 - t : NBUF - 2;
+                if (NBUF >= 4 && newer >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else if (NBUF >= 3 && newer == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                // ... and everyone's; all waves are also done with the buffer of chunk t - 1, which the next stage reuses
+                __builtin_amdgcn_s_barrier();
+                if (t + NBUF - 1 < nchunk) stage(c0 + t + NBUF - 1, (buf + NBUF - 1) % NBUF);
+                if (t < nchunk) {
+                    f4 av[4], bv[4];
+                    float at[16], bt[16];
+                    if (!A_T) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(av[j]) : "v"(aaddr[j]), "n"(buf * 16384));
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 16; ++q)
+                            asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(at[q]) : "v"(aaddr[q]), "n"(buf * 16384));
+                    }
+                    if (!B_T) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bv[j]) : "v"(baddr[j]), "n"(buf * 16384));
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 16; ++q)
+                            asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(bt[q]) : "v"(baddr[q]), "n"(buf * 16384));
+                    }
+                    if (!A_T) {
+                        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(av[0]), "+v"(av[1]), "+v"(av[2]), "+v"(av[3]));
+                    } else {
+                        asm volatile("s_waitcnt lgkmcnt(0)"
+                                     : "+v"(at[0]), "+v"(at[1]), "+v"(at[2]), "+v"(at[3]), "+v"(at[4]), "+v"(at[5]), "+v"(at[6]),
+                                       "+v"(at[7]), "+v"(at[8]), "+v"(at[9]), "+v"(at[10]), "+v"(at[11]), "+v"(at[12]),
+                                       "+v"(at[13]), "+v"(at[14]), "+v"(at[15]));
+                    }
+                    if (!B_T) {
+                        asm volatile("" : "+v"(bv[0]), "+v"(bv[1]), "+v"(bv[2]), "+v"(bv[3]));
+                    } else {
+                        asm volatile(""
+                                     : "+v"(bt[0]), "+v"(bt[1]), "+v"(bt[2]), "+v"(bt[3]), "+v"(bt[4]), "+v"(bt[5]), "+v"(bt[6]),
+                                       "+v"(bt[7]), "+v"(bt[8]), "+v"(bt[9]), "+v"(bt[10]), "+v"(bt[11]), "+v"(bt[12]),
+                                       "+v"(bt[13]), "+v"(bt[14]), "+v"(bt[15]));
+                    }
+                    float a[16], b[16];
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        a[q] = A_T ? at[q] : av[q >> 2][q & 3];
+                        b[q] = B_T ? bt[q] : bv[q >> 2][q & 3];
+                    }
+                    if (A_T) {   // the reduction runs over batch rows: the last chunk may reach past them
+                        const long long red0 = (long long)(c0 + t) * 32;
+                        if (red0 + 32 > g.R) {
+#pragma unroll
+                            for (int q = 0; q < 16; ++q)
+                                if (red0 + 8 * (q >> 2) + 4 * h + (q & 3) >= g.R) a[q] = 0.f;
+                        }
+                        if (g.bslab) {
+#pragma unroll
+                            for (int q = 0; q < 16; ++q) bsum += a[q];
+                        }
+                    }
+#pragma unroll
+                    for (int q = 0; q < 16; q += 2) {
+                        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q], b[q], acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[q + 1], b[q + 1], acc1, 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    f32x16 acc = acc0 + acc1;
+
+    if (MODE == GL_BWD_W) {
+        if (!live) return;
+        float* out = g.slab + (size_t)part * g.out_rows * g.out_cols;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int row = i0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            out[(size_t)row * g.out_cols + j0 + r] = acc[e];
+        }
+        if (g.bslab && tj == 0) {
+            bsum += __shfl_xor(bsum, 32, 64);
+            if (h == 0) g.bslab[(size_t)part * g.out_rows + i0 + r] = bsum;
+        }
+        return;
+    }
+
+    if (KS > 1) {   // the parts of a tile's reduction meet in LDS (the staging buffers are free after the barrier)
+        __syncthreads();
+        float* red = lds + (size_t)w4 * 1024 * (KS - 1);
+        if (part > 0) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) red[(part - 1) * 1024 + e * 64 + lane] = acc[e];
+        }
+        __syncthreads();
+        if (part > 0) return;
+        for (int p = 0; p < KS - 1; ++p) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] += red[p * 1024 + e * 64 + lane];
+        }
+    }
+    if (!live) return;
+    const int col = j0 + r;
+    if (MODE == GL_FWD) {
+        if (col < g.out_cols) {
+            const float bias = g.bias ? g.bias[col] : 0.f;
+            float* yp = g.Y + (size_t)(i0 + 4 * h) * g.out_cols + col;
+            if (g.act <= 2) {
+                const float neg = g.act == 0 ? 1.f : (g.act == 1 ? 0.f : 0.01f);
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int ro = (e & 3) + 8 * (e >> 2);
+                    const float v = acc[e] + bias;
+                    if (i0 + 4 * h + ro < g.out_rows) yp[(size_t)ro * g.out_cols] = v > 0.f ? v : v * neg;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int ro = (e & 3) + 8 * (e >> 2);
+                    const float v = acc[e] + bias;
+                    if (i0 + 4 * h + ro < g.out_rows)
+                        yp[(size_t)ro * g.out_cols] = g.act == 3 ? 1.f / (1.f + __expf(-v)) : tanhf(v);
+                }
+            }
+        }
+    } else {
+        float* base = col < g.o_split ? g.o_a + col : g.o_b + (col - g.o_split);
+        const int ld = col < g.o_split ? g.o_lda : g.o_ldb;
+        if (g.relu_src) {
+            const float* src = g.relu_src + col;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = i0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (row < g.out_rows)
+                    base[(size_t)row * ld] = src[(size_t)row * g.out_cols] > 0.f ? acc[e] * g.relu_scale : 0.f;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = i0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (row < g.out_rows) base[(size_t)row * ld] = acc[e];
+            }
+        }
+    }
+}
+
+template <int MODE, int KS, int NBUF>
+static int launch64(const GlArgs& g, long long blocks, hipStream_t stream, int kind) {
+    static bool attr_set = false;
+    const size_t ldsb = (size_t)KS * NBUF * 4096 * sizeof(float);
+    if (!attr_set) {
+        FR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(linear_glds64_kernel<MODE, KS, NBUF>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
+        attr_set = true;
+    }
+    ProfScope prof((KernelKind)kind, stream);
+    FR_LAUNCH(prof, (linear_glds64_kernel<MODE, KS, NBUF>), dim3((unsigned)blocks), dim3(256 * KS), ldsb, stream, g);
+    FR_CHECK_LAUNCH();
+    return FR_OK;
+}
+
+// the macro-tile form of a launch described for the wave-private kernel (same g.ks / g.parts / chunks_per_part)
+template <int MODE>
+static int launch_shared(const GlArgs& g, hipStream_t stream, int kind) {
+    const long long nmt = (long long)((g.tiles_i + 1) / 2) * ((g.tiles_j + 1) / 2);
+    if (MODE == GL_BWD_W) return launch64<MODE, 1, 3>(g, nmt * g.parts, stream, kind);
+    if (g.ks == 1) return launch64<MODE, 1, 3>(g, nmt, stream, kind);
+    if (g.ks == 2) return launch64<MODE, 2, 3>(g, nmt, stream, kind);
+    return launch64<MODE, 4, 2>(g, nmt, stream, kind);
+}
+
+static bool use_shared() {   // (read per call: a test flips it inside one process to compare the two forms bit for bit)
+    return getenv("FAIRREC_LINEAR_NO_SHARED") == nullptr;
+}
+
 template <int MODE, bool KSPLIT>
 static int launch_mode2(const GlArgs& g, long long blocks, hipStream_t stream, int kind) {
     static bool attr_set = false;
@@ -357,6 +657,7 @@ int glds_linear_fwd(const GlMat& X, const float* W, const float* bias, int64_t M
     g.Y = Y;
     g.out_rows = (int)M;
     g.out_cols = N;
+    if (use_shared()) return launch_shared<GL_FWD>(g, stream, K_LINEAR_FWD);
     const int tpb = GL_WAVES / g.ks;
     return launch_mode<GL_FWD>(g, (ntiles + tpb - 1) / tpb, stream, K_LINEAR_FWD);
 }
@@ -383,6 +684,7 @@ int glds_linear_bwd_input(const float* dY, const float* W, int64_t M, int N, int
     g.o_split = k0;
     g.out_rows = (int)M;
     g.out_cols = K;
+    if (use_shared()) return launch_shared<GL_BWD_IN>(g, stream, K_LINEAR_BWD_INPUT);
     const int tpb = GL_WAVES / g.ks;
     return launch_mode<GL_BWD_IN>(g, (ntiles + tpb - 1) / tpb, stream, K_LINEAR_BWD_INPUT);
 }
@@ -403,6 +705,7 @@ int glds_linear_bwd_weight(const float* dY, const GlMat& X, int64_t M, int N, in
     g.bslab = bslab;
     g.out_rows = N;
     g.out_cols = K;
+    if (use_shared()) return launch_shared<GL_BWD_W>(g, stream, K_LINEAR_BWD_WEIGHT);
     const long long nw = (long long)g.tiles_i * g.tiles_j * splits;
     return launch_mode<GL_BWD_W>(g, (nw + GL_WAVES - 1) / GL_WAVES, stream, K_LINEAR_BWD_WEIGHT);
 }

@@ -310,3 +310,47 @@ def test_packed_bpr_and_repeated_row_dots_equal_the_unpacked_forms(B, seeded):
     for x, y in zip(a, b):
         torch.testing.assert_close(y.grad, x.grad, rtol=1e-5, atol=1e-7 * max(1.0, float(x.grad.abs().max())))
     assert float(b[2].grad.abs().max()) == 0.0 and float(b[4].grad.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("M,k0,k1,N", [(8192, 256, 0, 128), (8192, 256, 256, 128), (1000, 64, 64, 96), (50, 32, 0, 32),
+                                        (4100, 128, 0, 256), (8192, 128, 0, 64), (200, 128, 0, 128), (333, 96, 32, 160)])
+def test_shared_tile_gemms_are_bit_identical_to_the_wave_private_form(M, k0, k1, N):
+    """The LDS-DMA kernels with operand chunks shared by the four waves of a 64 x 64 macro tile (csrc/mlp_glds.hip,
+    linear_glds64_kernel) accumulate every output in the order of the wave-private kernel: forward, input gradient and
+    weight gradient must come out bit for bit the same (odd tile counts, two-block inputs, split reductions included)."""
+    _C = _lib()
+    lib = _C.lib()
+    g = torch.Generator().manual_seed(M + N + k0)
+    K = k0 + k1
+    x0 = torch.randn(M, k0, generator=g).cuda()
+    x1 = (torch.randn(M, k1, generator=g) * 0.5).cuda() if k1 else None
+    W = (torch.randn(N, K, generator=g) * 0.3).cuda()
+    b = torch.randn(N, generator=g).cuda()
+    dY = torch.randn(M, N, generator=g).cuda()
+    st = _C.current_stream()
+
+    def products():
+        Y = torch.empty(M, N, device="cuda")
+        _C.check(lib.fr_linear_fwd(x0.data_ptr(), k0, _C.ptr(x1), k1, None, 1.0, W.data_ptr(), b.data_ptr(), M, N, 1,
+                                   Y.data_ptr(), st), "fwd")
+        dx0 = torch.empty(M, k0, device="cuda")
+        dx1 = torch.empty(M, k1, device="cuda") if k1 else None
+        _C.check(lib.fr_linear_bwd_input(dY.data_ptr(), dY.data_ptr(), 0, W.data_ptr(), None, 1.0, M, N, dx0.data_ptr(), k0,
+                                         _C.ptr(dx1), k1, st), "bwd_input")
+        ws = torch.empty(lib.fr_linear_bwd_weight_workspace_bytes(M, N, K), dtype=torch.uint8, device="cuda")
+        dW, db = torch.empty(N, K, device="cuda"), torch.empty(N, device="cuda")
+        _C.check(lib.fr_linear_bwd_weight(dY.data_ptr(), dY.data_ptr(), 0, x0.data_ptr(), k0, _C.ptr(x1), k1, None, 1.0, M, N,
+                                          dW.data_ptr(), db.data_ptr(), ws.data_ptr(), ws.numel(), st), "bwd_w")
+        torch.cuda.synchronize()
+        return [Y, dx0] + ([dx1] if k1 else []) + [dW, db]
+
+    shared = products()
+    os.environ["FAIRREC_LINEAR_NO_SHARED"] = "1"
+    try:
+        private = products()
+    finally:
+        del os.environ["FAIRREC_LINEAR_NO_SHARED"]
+    for a, c in zip(shared, private):
+        assert torch.equal(a, c)
+    X = torch.cat([x0, x1], 1) if k1 else x0
+    torch.testing.assert_close(shared[0], torch.relu(X @ W.t() + b), rtol=2e-4, atol=2e-4)
