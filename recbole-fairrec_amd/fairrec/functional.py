@@ -81,6 +81,8 @@ class Bpr(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         dpos, dneg = ctx.saved_tensors
+        if _C.is_one(g):            # GraphedStep's backward seed: nothing to scale by
+            return dpos, dneg
         return dpos * g, dneg * g
 
 
@@ -168,7 +170,7 @@ class SigmoidBce(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (dy,) = ctx.saved_tensors
-        return (dy * g).view(ctx.shape), None
+        return (dy if _C.is_one(g) else dy * g).view(ctx.shape), None
 
 
 class SoftmaxCe(torch.autograd.Function):
@@ -191,7 +193,7 @@ class SoftmaxCe(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (dl,) = ctx.saved_tensors
-        return dl * g, None, None
+        return (dl if _C.is_one(g) else dl * g), None, None
 
 
 class Mse(torch.autograd.Function):
@@ -212,7 +214,7 @@ class Mse(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (dp,) = ctx.saved_tensors
-        return dp * g, None
+        return (dp if _C.is_one(g) else dp * g), None
 
 
 class CsrMatrix:
