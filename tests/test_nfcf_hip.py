@@ -144,3 +144,56 @@ def test_nfcf_full_batch_at_the_baseline_width():
         bs = [torch.tensor(ref[f"after{T}.mlp_layers.mlp_layers.{3 * l + 1}.bias"]) for l in range(n_l)]
         z["predict_last"] = O.forward(U, I, Ws, bs, u[-1], i[-1]).numpy()
         _run_case(z, sharded=False)
+
+
+@pytest.mark.parametrize("sharded", [False, True], ids=["single", "row_sharded"])
+def test_reset_params_on_the_device_then_finetune(tmp_path, sharded, request):
+    """NFCF.reset_params (nfcf.py:49-67) with the model on the GPU: the pre-trained checkpoint is loaded, the gender direction
+    projected out of the user table on the device (row-sharded: the two group means through one all-reduce, here as a 1-rank
+    RCCL world), the table frozen, the item table re-initialised -- against the state the reference's reset_params left
+    (golden `init.*`), and the finetune steps then run from THAT state (not from a state loaded out of the golden) to the
+    reference's first snapshot."""
+    if sharded:
+        request.getfixturevalue("rccl_world1")
+    from fairrec.config import Config
+    from fairrec.model.fair_recommender.nfcf import NFCF
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "nfcf_finetune.npz"))
+    n_users, D = z["pretrain_user_embedding"].shape
+    n_items = z["init.item_embedding.weight"].shape[0]
+    ck = tmp_path / "pre.pth"
+    torch.save({"state_dict": {"user_embedding.weight": torch.tensor(z["pretrain_user_embedding"])}}, ck)
+    lr, wd, fw, p = (float(x) for x in z["hyper"])
+    cfg = Config(model="NFCF", config_dict={"embedding_size": D, "mlp_hidden_size": [int(h) for h in z["hidden"]], "dropout": p,
+                                            "fair_weight": fw, "device": "cuda", "load_pretrain_path": str(ck),
+                                            "row_sharded": sharded})
+    with torch.device("cuda"):
+        model = NFCF(cfg, _DS(n_users, n_items, z["gender"]))
+    model = model.to("cuda")
+    assert model.user_embedding.weight.is_cuda and not model.user_embedding.weight.requires_grad
+    assert model.item_embedding.weight.requires_grad
+    np.testing.assert_allclose(model.user_embedding.weight.detach().cpu().numpy(), z["init.user_embedding.weight"],
+                               rtol=1e-5, atol=1e-6)
+    # the rest of the state the reference started its finetune stage from (fresh item table, scorer), then its steps
+    init = {k[5:]: torch.tensor(z[k]) for k in z.files if k.startswith("init.") and "user_embedding" not in k}
+    model.load_state_dict(init, strict=False)
+    from fairrec.data.interaction import Interaction
+    from fairrec.optim import FusedLazyAdam
+    model.train()
+    opt = FusedLazyAdam(model.hip_engine(), lr=lr, weight_decay=wd, sweep_period=3)
+    n_layers = len(z["hidden"]) + 1
+    first = min(int(s) for s in z["snaps"])
+    losses = []
+    for t in range(first):
+        inter = Interaction({"user_id": torch.tensor(z["user_id"][t]), "item_id": torch.tensor(z["item_id"][t]),
+                             "label": torch.tensor(z["label"][t]), "gender": torch.tensor(z["sst"][t])}).to("cuda")
+        if p > 0:
+            model.mlp_layers.forced_masks = [torch.tensor(z[f"mask{l}"][t]) for l in range(n_layers)]
+        opt.zero_grad()
+        loss = model.calculate_loss(inter)
+        losses.append(float(loss))
+        loss.backward()
+        opt.step()
+    np.testing.assert_allclose(losses, z["loss"][:first], rtol=1e-4)
+    for k, v in model.state_dict().items():
+        ref = z[f"after{first}." + k]
+        np.testing.assert_allclose(v.cpu().numpy(), ref, rtol=2e-4, atol=1e-5 * max(1.0, float(np.abs(ref).max())), err_msg=k)
