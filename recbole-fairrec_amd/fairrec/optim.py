@@ -341,7 +341,7 @@ class FusedLazyAdam:
         if closure is not None:
             raise NotImplementedError("closure-based step is not supported by the fused path")
         if self.clip:
-            self.last_grad_norm = self.engine.clip_grad_norm(float(self.clip["max_norm"]))
+            self.last_grad_norm = self.engine.clip_grad_norm(float(self.clip["max_norm"]), self.group)
         if self.group is not None:
             self.engine.backward_adam(self.group)
         else:

@@ -160,8 +160,74 @@ class _ShardedLookup(torch.autograd.Function):
 
 class ShardedGenericEngine(GenericEngine):
     def clip_grad_norm(self, max_norm: float, group=None):
-        raise NotImplementedError("clip_grad_norm on row-sharded tables (a norm over gradient rows held by their owners "
-                                  "plus one all-reduce) is not built: use the single-GPU or the replicated engine")
+        """GenericEngine.clip_grad_norm on row-sharded tables: the gradient of a table is held by the owners of its rows
+        (the rows every requester sent back, duplicates summed per owned row in slot order: requester rank, then batch
+        position), so the squared norms add over the ranks -- ONE all-reduce of a scalar; the dense gradients are measured
+        after their flat all-reduce (done here instead of in backward_adam, which then finds them averaged).  Every rank
+        computes the same total and the same coefficient."""
+        G = self.G
+        self._sync_dense(group)
+        sq_tables = torch.zeros((), dtype=torch.float32, device=self.device)
+        held = []
+        for name, t in self._tables.items():
+            if name.startswith(self.NOT_MODEL_PARAMETERS) or not t.trainable or t._grad_rows is None:
+                continue
+            lay = getattr(self, "_lay", {}).get(name)
+            ex = lay[0] if lay is not None else self._ex[name]
+            if lay is not None:      # packed exchange: chunk g = [cap slots of table a | cap slots of table b]
+                off, cap = lay[1], ex.cap
+                ids = ex.ids_recv.view(G, ex.S)[:, off:off + cap].reshape(-1)
+                g = t._grad_rows.view(G, ex.S, t.dim)[:, off:off + cap].reshape(-1, t.dim)
+            else:
+                ids, g = ex.ids_recv, t._grad_rows
+            valid = ids >= 0
+            ids_v, g_v = ids[valid], g[valid]
+            if ids_v.numel():
+                order = torch.argsort(ids_v, stable=True)
+                _, counts = torch.unique_consecutive(ids_v[order], return_counts=True)
+                rows = torch.segment_reduce(g_v[order].contiguous(), "sum", lengths=counts, axis=0)
+                sq_tables = sq_tables + (rows * rows).sum()
+            held.append(t)
+        dist.all_reduce(sq_tables, op=dist.ReduceOp.SUM, group=self.group)
+        sq = sq_tables
+        dense = []
+        synced = self._synced[1] if self._synced is not None else {}
+        for name, d in self._dense.items():
+            if name.startswith(self.NOT_MODEL_PARAMETERS) or d.p.grad is None:
+                continue
+            gview = synced.get(name, d.p.grad)          # averaged over the ranks when this step's group owns it
+            sq = sq + (gview * gview).sum()
+            dense.append(gview)
+        if not held and not dense:
+            return torch.zeros((), device=self.device)
+        total = torch.sqrt(sq)
+        coef = torch.clamp(max_norm / (total + 1e-6), max=1.0)
+        for t in held:
+            t._grad_rows = t._grad_rows * coef
+        for gview in dense:
+            gview.mul_(coef)
+        return total
+
+    def _sync_dense(self, group=None):
+        """One flat all-reduce (mean over the ranks) of the replicated dense gradients the stepping group owns
+        (SURVEY.md §8-e item 5); kept until backward_adam consumes it."""
+        live = [(name, d) for name, d in self._dense.items() if d.p.grad is not None and self._owned(name, group)]
+        if not live:
+            self._synced = None
+            return
+        n = sum(d.p.numel() for _, d in live)
+        if self._flat is None or self._flat.numel() < n:
+            self._flat = torch.empty(n, dtype=torch.float32, device=self.device)
+        flat = self._flat[:n]
+        torch.cat([d.p.grad.reshape(-1) for _, d in live], out=flat)
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+        flat.mul_(1.0 / self.G)
+        views, off = {}, 0
+        for name, d in live:
+            k = d.p.numel()
+            views[name] = flat[off:off + k]
+            off += k
+        self._synced = (live, views)
 
     def __init__(self, device, group=None, capacity_factor: float = 2.0, ops=None):
         self.group = group
@@ -178,6 +244,7 @@ class ShardedGenericEngine(GenericEngine):
         self._seg: Dict[str, _Segments] = {}
         self._n_rows_global: Dict[str, int] = {}
         self._flat: Optional[torch.Tensor] = None
+        self._synced = None          # (live dense entries, their averaged-gradient views of _flat) between clip and step
 
     def _init_host_only(self, device):
         from .optim import AdamHyper
@@ -333,23 +400,15 @@ class ShardedGenericEngine(GenericEngine):
             else:
                 self.ops.apply_grad(t, self._hyper(name), n_slots, ex.rows_send, t._grad_rows, s)
             t._grad_rows = None
-        live = [(name, d) for name, d in self._dense.items() if d.p.grad is not None and self._owned(name, group)]
-        if not live:
+        if self._synced is None:      # (clip_grad_norm has done it already when the optimizer clips)
+            self._sync_dense(group)
+        if self._synced is None:
             return
-        # one flat all-reduce for the replicated dense gradients
-        n = sum(d.p.numel() for _, d in live)
-        if self._flat is None or self._flat.numel() < n:
-            self._flat = torch.empty(n, dtype=torch.float32, device=self.device)
-        flat = self._flat[:n]
-        torch.cat([d.p.grad.reshape(-1) for _, d in live], out=flat)
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
-        flat.mul_(1.0 / G)
-        off = 0
+        live, views = self._synced
+        self._synced = None
         for name, d in live:
-            k = d.p.numel()
             d.step += 1
             h = self._hyper(name)
             h.check_step(d.step)
-            self.ops.adam_dense(d.p.data, flat[off:off + k], d.m, d.v, h, d.step)
+            self.ops.adam_dense(d.p.data, views[name], d.m, d.v, h, d.step)
             d.p.grad = None
-            off += k

@@ -33,8 +33,6 @@ def test_nfcf_training_matches_reference_golden(path, tmp_path, sharded, request
     from fairrec.config import Config
     from fairrec.data.interaction import Interaction
     from fairrec.model.fair_recommender.nfcf import NFCF
-    if sharded and "clip_max_norm" in np.load(path):
-        pytest.skip("clip_grad_norm is not built for row-sharded tables (raises NotImplementedError)")
     f64 = path[:-4] + "_f64.npz"
     _run_case(np.load(path), sharded, exact=np.load(f64) if os.path.exists(f64) else None)
 

@@ -36,8 +36,6 @@ def _load_mlp(mlp, z, prefix):
 def test_pfcn_training_matches_reference_golden(path, sharded, request):
     if sharded:     # the row-sharded engine as a 1-rank RCCL world: same goldens (fairrec/sharded_engine.py)
         request.getfixturevalue("rccl_world1")
-    if sharded and "clip_max_norm" in np.load(path):
-        pytest.skip("clip_grad_norm is not built for row-sharded tables (raises NotImplementedError)")
     f64 = path[:-4] + "_f64.npz"
     _run_case(np.load(path), sharded, exact=np.load(f64) if os.path.exists(f64) else None)
 

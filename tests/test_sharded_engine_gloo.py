@@ -129,7 +129,7 @@ def _worker(rank, world, port, out_dir, mode="single"):
         U0, I0, w0, b0, u, i, r = _data(world)
         eng = ShardedGenericEngine("cpu", ops=_Ops())
         Us, Is = U0[rank::world].clone(), I0[rank::world].clone()
-        frozen = mode == "pair_frozen_user"      # NFCF finetune: the user table is read-only
+        frozen = mode.startswith("pair_frozen_user")      # NFCF finetune: the user table is read-only
         eng.add_table("U", torch.nn.Parameter(Us, requires_grad=not frozen), table=_Table(Us, trainable=not frozen),
                       n_rows_global=NU)
         eng.add_table("I", torch.nn.Parameter(Is), table=_Table(Is), n_rows_global=NI)
@@ -137,38 +137,47 @@ def _worker(rank, world, port, out_dir, mode="single"):
         eng.add_dense("w", w)
         eng.add_dense("b", b)
         eng.hyper = AdamHyper(LR, WD, device="cpu")
-        losses = []
+        losses, norms = [], []
         for t in range(T):
             sl = slice(rank * B, (rank + 1) * B)
             eng.zero_grad()
-            if mode == "single":
+            if mode.startswith("single"):
                 ue, ie = eng.lookup("U", u[t][sl]), eng.lookup("I", i[t][sl])
             else:       # both tables through ONE packed exchange per direction
                 ue, ie = eng.lookup_pair("U", u[t][sl], "I", i[t][sl])
             loss = _loss(ue, ie, w, b, r[t][sl])
             loss.backward()
+            if mode.endswith("_clip"):      # what FusedLazyAdam.step() does when the config clips
+                norms.append(float(eng.clip_grad_norm(CLIP)))
             eng.backward_adam()
             losses.append(float(loss))
-        torch.save({"U": Us, "I": Is, "w": w.data, "b": b.data, "loss": losses}, os.path.join(out_dir, f"r{rank}.pt"))
+        torch.save({"U": Us, "I": Is, "w": w.data, "b": b.data, "loss": losses, "norm": norms},
+                   os.path.join(out_dir, f"r{rank}.pt"))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,mode", [(2, "single"), (2, "pair"), (4, "pair"), (2, "pair_frozen_user")])
+CLIP = 0.05     # well below the gradient norms of the toy problem: every step is clipped
+
+
+@pytest.mark.parametrize("world,mode", [(2, "single"), (2, "pair"), (4, "pair"), (2, "pair_frozen_user"),
+                                        (2, "single_clip"), (3, "pair_clip"), (2, "pair_frozen_user_clip")])
 def test_generic_engine_equals_single_process(tmp_path, world, mode):
     from oracle import focf as O
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), mode), nprocs=world, join=True)
     U0, I0, w0, b0, u, i, r = _data(world)
     P = [torch.nn.Parameter(x.clone()) for x in (U0, I0, w0, b0)]
-    if mode == "pair_frozen_user":
+    if mode.startswith("pair_frozen_user"):
         P[0].requires_grad_(False)
     ms, vs = [torch.zeros_like(p) for p in P], [torch.zeros_like(p) for p in P]
-    ref_loss = []
+    ref_loss, ref_norm = [], []
     for t in range(T):
         for p in P:
             p.grad = None
         loss = _loss(P[0][u[t]], P[1][i[t]], P[2], P[3], r[t])
         loss.backward()
+        if mode.endswith("_clip"):
+            ref_norm.append(float(torch.nn.utils.clip_grad_norm_([p for p in P if p.grad is not None], CLIP)))
         for k, p in enumerate(P):
             if p.grad is not None:
                 O.adam_dense_step_(p.data, p.grad, ms[k], vs[k], t + 1, LR, WD)
@@ -176,6 +185,10 @@ def test_generic_engine_equals_single_process(tmp_path, world, mode):
     parts = [torch.load(os.path.join(str(tmp_path), f"r{q}.pt")) for q in range(world)]
     # the global loss is the mean of the local means (equal batch sizes)
     np.testing.assert_allclose(np.mean([p["loss"] for p in parts], axis=0), ref_loss, rtol=1e-5)
+    if mode.endswith("_clip"):      # every rank measures the norm of the GLOBAL batch's gradient
+        assert min(ref_norm) > CLIP
+        for q in range(world):
+            np.testing.assert_allclose(parts[q]["norm"], ref_norm, rtol=2e-5)
     for tag, ref in (("U", P[0]), ("I", P[1])):
         full = torch.zeros_like(ref.data)
         for q in range(world):
