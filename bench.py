@@ -449,19 +449,45 @@ def main():
     roofline = None
     # every rank runs the extra steps (the collectives need all ranks); rank 0 reports
     u2, i2, r2, s2 = (t.to(dev) for t in synth_batches(K, BATCH, N_USERS, N_ITEMS, SEED + 7919 + rank, args.item_dist))
-    _C.prof_reset()
-    _C.prof_enable(rank == 0)
-    for k in range(K):
-        if sharded:
-            nxt = (u2[k + 1], i2[k + 1], s2[k + 1], r2[k + 1]) if k + 1 < K else None
-        else:
-            nxt = coming(k, u2, i2, s2, r2)
-        eng.forward(u2[k], i2[k], r2[k], s2[k], next_batch=nxt)
-        eng.backward_adam()
-    torch.cuda.synchronize()
-    _C.prof_enable(False)
+    def profiled_pass(sync_every_step):
+        _C.prof_reset()
+        _C.prof_enable(rank == 0)
+        torch.cuda.synchronize()
+        t_pass = time.perf_counter()
+        for k in range(K):
+            if sharded:
+                nxt = (u2[k + 1], i2[k + 1], s2[k + 1], r2[k + 1]) if k + 1 < K else None
+            else:
+                nxt = coming(k, u2, i2, s2, r2)
+            eng.forward(u2[k], i2[k], r2[k], s2[k], next_batch=nxt)
+            eng.backward_adam()
+            if sync_every_step:
+                torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        t_pass = time.perf_counter() - t_pass
+        _C.prof_enable(False)
+        return (_C.prof_read() if rank == 0 else {}), t_pass
+
+    prof, t_pass = profiled_pass(False)
+    # On one stream the step kernels run one after the other, so a launch cannot be longer than the step the hipGraph replay
+    # just timed.  Seen in about one run in five on a fresh box: the eager pass with event pairs on every launch runs ten
+    # times slower (380 us per 32 us kernel -- the runtime's profiling path, not the kernel).  Such a pass is taken again with
+    # the queue kept empty (a synchronise after every step); if that does not help either, the kernel's time is taken to be
+    # the whole timed step (an upper bound: the step IS that one launch) and the JSON says so.
+    events_ok = True
+    if rank == 0 and not sharded:
+        def step_kernel_us(pr):
+            ms, n = pr.get("focf_step_kernel", (0.0, 0))
+            return ms / n * 1e3 if n else 0.0
+        if step_kernel_us(prof) > 1.3 * dt / K * 1e6:
+            print(f"[bench] per-launch events inconsistent with the timed step ({step_kernel_us(prof):.1f} us per launch against "
+                  f"{dt / K * 1e6:.1f} us per step); measuring again with an empty queue", file=sys.stderr)
+            prof, t_pass = profiled_pass(True)
+            if step_kernel_us(prof) > 1.3 * dt / K * 1e6:
+                events_ok = False
+                ms, n = prof["focf_step_kernel"]
+                prof["focf_step_kernel"] = (dt / K * 1e3 * n, n)
     if rank == 0:
-        prof = _C.prof_read()
         per_kernel = {name: ms / n * 1e3 for name, (ms, n) in prof.items()}   # us per launch
         # dominant = the longest kernel of the dependent chain gather -> fair -> backward_adam; sort_segments runs on
         # 2 CUs, one step ahead and concurrently with that chain (fr_focf_prepare), so it is not on the critical path
@@ -485,12 +511,23 @@ def main():
                     # the same bytes over the WHOLE timed step (every launch of the step + gaps): the honest figure
                     "whole_step_GBps": round(algo_bytes / (dt / K) / 1e9, 1),
                     "frac_step": round(algo_bytes / (dt / K) / 1e9 / HBM_PEAK_GBS, 4),
+                    # What actually bounds the kernel: with the reference's weight_decay != 0 every row of both
+                    # tables takes one Adam step per training step, replayed lazily without traffic -- (N_users + N_items)
+                    # row-steps of 64 elements per launch at 34 SIMD cycles each (two quarter-rate transcendentals are 32 of
+                    # them; measured with table_flush_kernel), on 1024 SIMDs at 2.4 GHz.  Informative only: `frac` stays the
+                    # HBM figure the contract asks for.
+                    "valu_floor_us_per_launch": (None if sharded else
+                                                 round((N_USERS + N_ITEMS) * (DIM / 64) * 34 / (1024 * 2.4e9) * 1e6, 2)),
+                    "frac_of_valu_floor": (None if sharded else
+                                           round((N_USERS + N_ITEMS) * (DIM / 64) * 34 / (1024 * 2.4e9) * 1e6 / per_kernel[dom], 4)),
                     "kernel_us": {k: round(v, 2) for k, v in sorted(per_kernel.items())},
                     "dominant_rule": ("longest kernel of the dependent chain; sort_segments_kernel runs on 1-2 workgroups "
                                       "concurrently with the gather kernels on a side stream" if sharded else
                                       "the step IS one kernel (focf_step_kernel); sort_segments_kernel + focf_lpt_kernel run "
                                       "twice per 16 steps on a side stream, ahead of the steps they serve"),
-                    "measured": f"hipExtLaunchKernelGGL start/stop events on every launch, {K} eager steps after the "
+                    "measured": ("" if events_ok else "FALLBACK for focf_step_kernel: the timed step itself (per-launch events "
+                                 "were inconsistent in this run, twice); otherwise ") +
+                                f"hipExtLaunchKernelGGL start/stop events on every launch, {K} eager steps after the "
                                 "timed region (same look-ahead sort overlap as the timed steps)"}
 
     if rank == 0:
