@@ -478,6 +478,8 @@ def main():
     if rank == 0 and not sharded:
         def step_kernel_us(pr):
             ms, n = pr.get("focf_step_kernel", (0.0, 0))
+            if os.environ.get("FAIRREC_BENCH_TEST_EVENT_FLAKE"):     # (exercises the two branches below in a test run)
+                ms *= 12
             return ms / n * 1e3 if n else 0.0
         if step_kernel_us(prof) > 1.3 * dt / K * 1e6:
             print(f"[bench] per-launch events inconsistent with the timed step ({step_kernel_us(prof):.1f} us per launch against "
