@@ -93,6 +93,11 @@ def test_four_rank_schedule_matches_oracle(tmp_path, objective, hot):
     _check(tmp_path, objective, 4, hot)
 
 
+def test_eight_rank_schedule_matches_oracle(tmp_path):
+    """The node size bench.py --gpus 8 runs at (requester schedule, its default)."""
+    _check(tmp_path, "value", 8, False)
+
+
 @pytest.mark.parametrize("objective,world,hot", [("none", 2, False), ("value", 2, False), ("under", 2, False),
                                                  ("value", 4, False), ("value", 4, True), ("absolute", 2, True)])
 def test_item_owner_schedule_matches_oracle(tmp_path, objective, world, hot):
