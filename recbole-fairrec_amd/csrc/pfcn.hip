@@ -173,8 +173,10 @@ __global__ __launch_bounds__(256) void bpr_outer_reduce_kernel(const float* __re
     const int j = blockIdx.x * 64 + e;
     const int per = (nblk + 3) / 4, k0 = part * per, k1 = min(nblk, k0 + per);
     float s = 0.f;
-    if (j < B)
-        for (int k = k0; k < k1; ++k) s += ga_part[(size_t)k * B + j];
+    if (j < B) {
+#pragma unroll 16
+        for (int k = k0; k < k1; ++k) s += ga_part[(size_t)k * B + j];   // (sixteen loads in flight; the sum stays in k order)
+    }
     red[part][e] = s;
     __syncthreads();
     if (part == 0 && j < B) {
