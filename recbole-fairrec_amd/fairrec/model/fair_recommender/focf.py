@@ -283,7 +283,7 @@ class FocfEngine:
         self.pending_B = B
         return loss, pred
 
-    def clip_grad_norm(self, max_norm: float):
+    def clip_grad_norm(self, max_norm: float, group=None):
         """torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm) on the pending batch's (never materialised)
         embedding gradients (fr_focf_clip_grad_norm); returns the device pair (total_norm, clip_coef)."""
         if self.pending_B == 0:
