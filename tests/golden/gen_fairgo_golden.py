@@ -24,6 +24,27 @@ from recbole.data.interaction import Interaction  # noqa: E402
 from recbole.model.fair_recommender.fairgo_pmf import FairGo_PMF  # noqa: E402
 
 
+def _fairgo_gcn_class():
+    """The reference's FairGo_GCN class itself, for its FINETUNE stage (BASELINE.json configs[3]).  Its module imports
+    torch_geometric.nn.GCN (fairgo_gcn.py:20), which this image does not have; the finetune stage never calls it
+    (fairgo_gcn.py:175-176 applies self.gcn in the pretrain stage only), so a parameter-free placeholder module whose
+    forward raises stands in for the import.  The pretrain stage stays unpinned."""
+    import types
+    if "torch_geometric.nn" not in sys.modules:
+        class GCN(torch.nn.Module):
+            def __init__(self, **kw):
+                super().__init__()
+
+            def forward(self, *a, **kw):
+                raise RuntimeError("torch_geometric is not installed: the GCN pretrain stage can not be run here")
+        tg, tgn = types.ModuleType("torch_geometric"), types.ModuleType("torch_geometric.nn")
+        tgn.GCN = GCN
+        tg.nn = tgn
+        sys.modules["torch_geometric"], sys.modules["torch_geometric.nn"] = tg, tgn
+    from recbole.model.fair_recommender.fairgo_gcn import FairGo_GCN
+    return FairGo_GCN
+
+
 class _Cfg(dict):
     def __getitem__(self, k):
         return self.get(k, None)
@@ -60,13 +81,12 @@ def dump(model, prefix, out):
 
 
 def run_case(name, aggr, attrs, phases, sst_lists, seed, n_layers=2, D=8, B=32, n_users=30, n_items=25, lr=1e-3, wd=1e-4,
-             fair_weight=0.1, filter_hidden=(16, 8), dis_hidden=(8, 4), vs_weights=(4, 1)):
+             fair_weight=0.1, filter_hidden=(16, 8), dis_hidden=(8, 4), vs_weights=(4, 1), n_train=200, gcn=False):
     torch.manual_seed(seed)
     rng = np.random.default_rng(seed)
     feats = {"gender": rng.integers(0, 2, size=n_users).astype(np.float32), "age": rng.integers(0, 3, size=n_users).astype(np.int64)}
     feats["age"][1:4] = [0, 1, 2]
     feats["gender"][1:3] = [0.0, 1.0]
-    n_train = 200
     pairs = rng.choice((n_users - 1) * (n_items - 1), size=n_train, replace=False)   # distinct (user, item) pairs
     tu, ti = pairs // (n_items - 1) + 1, pairs % (n_items - 1) + 1
     tr = rng.integers(1, 6, size=n_train).astype(np.float32)
@@ -74,8 +94,10 @@ def run_case(name, aggr, attrs, phases, sst_lists, seed, n_layers=2, D=8, B=32, 
                RATING_FIELD="rating", n_layers=n_layers, activation="leakyrelu", embedding_size=D,
                dis_hidden_size_list=list(dis_hidden), filter_hidden_size_list=list(filter_hidden), sst_attr_list=list(attrs),
                fair_weight=fair_weight, load_pretrain_weight=False, aggr_method=aggr, vs_weights=list(vs_weights))
-    model = FairGo_PMF(cfg, _FakeDataset(n_users, n_items, feats, tu, ti, tr))
-    out = {"aggr": np.array(aggr), "attrs": np.array(list(attrs)), "phases": np.array(list(phases)),
+    if gcn:
+        cfg.update(hidden_channels=32, gcn_n_layers=2, gcn_dropout=0.2, gcn_act="relu")
+    model = (_fairgo_gcn_class() if gcn else FairGo_PMF)(cfg, _FakeDataset(n_users, n_items, feats, tu, ti, tr))
+    out = {"model": np.array("FairGo_GCN" if gcn else "FairGo_PMF"), "aggr": np.array(aggr), "attrs": np.array(list(attrs)), "phases": np.array(list(phases)),
            "sst_lists": np.array([",".join(s) for s in sst_lists]), "hyper": np.array([lr, wd, fair_weight]),
            "n_layers": np.array(n_layers), "filter_hidden": np.array(filter_hidden), "dis_hidden": np.array(dis_hidden),
            "vs_weights": np.array(vs_weights, dtype=np.float32), "gender": feats["gender"], "age": feats["age"],
@@ -135,6 +157,10 @@ def main():
     run_case("wap2", "WAP", ga, "PFDFDFD", [ga, ga, ga, g, g, ("age",), ("age",)], seed=4)
     run_case("lva2", "LVA", ga, "PFDFD", [ga, ga, ga, ("age",), ("age",)], seed=5)
     run_case("one_layer", "WAP", g, "FDFD", [g] * 4, seed=6, n_layers=1)
+    # BASELINE.json configs[3]'s widths through the reference's FairGo_GCN class (finetune stage, fairgo_gcn.py:173-250):
+    # embedding 128, filters [128, 64], discriminators [16, 8, 4], WAP, two graph layers
+    run_case("gcn_wap_d128", "WAP", g, "FDFDFD", [g] * 6, seed=7, D=128, B=256, n_users=300, n_items=250, n_train=4000,
+             filter_hidden=(128, 64), dis_hidden=(16, 8, 4), gcn=True)
 
 
 if __name__ == "__main__":

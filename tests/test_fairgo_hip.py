@@ -45,19 +45,20 @@ def test_fairgo_training_matches_reference_golden(path, replicated, request):
     lr, wd, fw = (float(x) for x in z["hyper"])
     n_users, D = z["init.model.user_embedding_layer.weight"].shape
     n_items = z["init.model.item_embedding_layer.weight"].shape[0]
-    cfg = Config(model="FairGo_PMF", config_dict={
+    name = str(z["model"])       # FairGo_GCN cases: the reference's FairGo_GCN class in its finetune stage (fairgo_gcn.py:173-250)
+    cfg = Config(model=name, config_dict={
         "embedding_size": D, "sst_attr_list": attrs, "aggr_method": str(z["aggr"]), "n_layers": int(z["n_layers"]),
         "filter_hidden_size_list": [int(h) for h in z["filter_hidden"]], "dis_hidden_size_list": [int(h) for h in z["dis_hidden"]],
         "vs_weights": [float(v) for v in z["vs_weights"]], "fair_weight": fw, "device": "cuda",
         "data_parallel": replicated})
-    model = get_model("FairGo_PMF")(cfg, _DS(n_users, n_items, z))
+    model = get_model(name)(cfg, _DS(n_users, n_items, z))
     # the reference's L = D^-1 A, entry for entry
     L = model._norm_csr_host.tocoo()
     order = np.lexsort((L.col, L.row))
     np.testing.assert_array_equal(L.row[order], z["L_row"])
     np.testing.assert_array_equal(L.col[order], z["L_col"])
     np.testing.assert_allclose(L.data[order], z["L_val"], rtol=1e-6)
-    model.load_state_dict({k[11:]: torch.tensor(z[k]) for k in z.files if k.startswith("init.model.")})
+    model.load_state_dict({k[11:]: torch.tensor(z[k]) for k in z.files if k.startswith("init.model.")}, strict=name != "FairGo_GCN")
     model = model.to("cuda")
     for s in attrs:
         model.filter_layer_dict[s].load_state_dict({k[len(f"init.filter.{s}."):]: torch.tensor(z[k]) for k in z.files
@@ -98,7 +99,8 @@ def test_fairgo_training_matches_reference_golden(path, replicated, request):
         assert ratio.max() <= 1.0, (what, float(np.abs(a - ref).max()), float(ratio.max()))
 
     for k, v in model.state_dict().items():
-        close(v, z["final.model." + k], k)
+        if not k.startswith("gcn."):        # the pretrain stage's GCN: not in the reference-side placeholder, untouched here
+            close(v, z["final.model." + k], k)
     for s in attrs:
         for k, v in model.filter_layer_dict[s].state_dict().items():
             close(v, z[f"final.filter.{s}.{k}"], f"filter.{s}.{k}")
@@ -107,6 +109,89 @@ def test_fairgo_training_matches_reference_golden(path, replicated, request):
     print("worst |err| / tolerance:", round(worst[0], 3), worst[1])
     eng.check_device_errors()
     np.testing.assert_allclose(model.predict(inter).cpu().numpy(), z["predict_last"], rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("replicated", [False, True], ids=["single", "data_parallel"])
+def test_fairgo_full_batch_at_the_baseline_width(replicated, request):
+    """BASELINE.json configs[3]'s step shape -- FairGo_GCN finetune (fairgo_gcn.py:173-250), WAP, embedding_size 128, filters
+    [128, 64], discriminators [16, 8, 4], n_layers 2, B = 8192 -- on tables scaled down to what the CPU oracle evaluates in
+    seconds (20 001 users x 5 001 items, 20 training ratings per user): filter and discriminator steps in the trainer's
+    order through the HIP path against oracle/fairgo.py (pinned to the reference's goldens, tests/test_oracle_fairgo.py),
+    every tensor of the filter / discriminator MLPs, the per-step losses and the last predictions compared."""
+    if replicated:
+        request.getfixturevalue("rccl_world1")
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+    from oracle import fairgo as O
+    from fairrec.config import Config
+    from fairrec.data.interaction import Interaction
+    from fairrec.optim import FusedLazyAdam
+    from fairrec.utils import get_model
+    n_users, n_items, D, B = 20_001, 5_001, 128, 8192
+    filt, dis, phases = (128, 64), (16, 8, 4), "FDFDF"
+    rng = np.random.default_rng(21)
+    torch.manual_seed(21)
+    gender = rng.integers(0, 2, n_users).astype(np.float32)
+    tu = np.repeat(np.arange(1, n_users), 20)
+    ti = rng.integers(1, n_items, tu.size)
+    pair = np.unique(tu.astype(np.int64) * n_items + ti)          # distinct (user, item) pairs, as a rating matrix has
+    tu, ti = pair // n_items, pair % n_items
+    tr = rng.integers(1, 6, tu.size).astype(np.float32)
+    z = {"model": np.array("FairGo_GCN"), "aggr": np.array("WAP"), "attrs": np.array(["gender"]), "phases": np.array(list(phases)),
+         "sst_lists": np.array(["gender"] * len(phases)), "hyper": np.array([1e-3, 1e-4, 0.1]), "n_layers": np.array(2),
+         "filter_hidden": np.array(filt), "dis_hidden": np.array(dis), "vs_weights": np.array([4, 1], dtype=np.float32),
+         "gender": gender, "age": np.zeros(n_users, dtype=np.int64), "train_user": tu, "train_item": ti, "train_rating": tr}
+    cfg = Config(model="FairGo_GCN", config_dict={
+        "embedding_size": D, "sst_attr_list": ["gender"], "aggr_method": "WAP", "n_layers": 2,
+        "filter_hidden_size_list": list(filt), "dis_hidden_size_list": list(dis), "vs_weights": [4.0, 1.0], "fair_weight": 0.1,
+        "device": "cuda", "data_parallel": replicated})
+    model = get_model("FairGo_GCN")(cfg, _DS(n_users, n_items, z))
+    # a pretrained-looking state (N(0, 0.1) tables: scores of O(1), nothing saturated), the reference's default init of the MLPs
+    with torch.no_grad():
+        model.user_embedding_layer.weight.normal_(0, 0.1)
+        model.item_embedding_layer.weight.normal_(0, 0.1)
+    for k, v in model.state_dict().items():
+        if not k.startswith("gcn."):
+            z["init.model." + k] = v.detach().cpu().numpy().copy()
+    for s, m in model.filter_layer_dict.items():
+        for k, v in m.state_dict().items():
+            z[f"init.filter.{s}.{k}"] = v.detach().cpu().numpy().copy()
+    for s, m in model.dis_layer_dict.items():
+        for k, v in m.state_dict().items():
+            z[f"init.dis.{s}.{k}"] = v.detach().cpu().numpy().copy()
+    L = O.norm_rating_matrix(n_users, n_items, tu, ti, tr)
+    z["L_row"], z["L_col"], z["L_val"] = L.indices()[0].numpy(), L.indices()[1].numpy(), L.values().numpy()
+    sel = rng.integers(0, tu.size, size=(len(phases), B))
+    z["user_id"], z["item_id"], z["rating"] = tu[sel], ti[sel], tr[sel]
+    ref = O.train(z)
+    model = model.to("cuda")
+    model.train_stage = "finetune"
+    eng = model.hip_engine()
+    opts = {ph: FusedLazyAdam(eng, lr=1e-3, weight_decay=1e-4, group=g) for ph, g in (("F", "filter"), ("D", "dis"))}
+    losses = []
+    for t, ph in enumerate(phases):
+        u = z["user_id"][t]
+        inter = Interaction({"user_id": torch.tensor(u), "item_id": torch.tensor(z["item_id"][t]),
+                             "rating": torch.tensor(z["rating"][t]), "gender": torch.tensor(gender[u])}).to("cuda")
+        opts[ph].zero_grad()
+        loss = model.calculate_loss(inter, ["gender"]) if ph == "F" else model.calculate_dis_loss(inter, ["gender"])
+        losses.append(loss.detach().reshape(1).clone())
+        loss.backward()
+        opts[ph].step()
+    np.testing.assert_allclose(torch.cat(losses).cpu().numpy(), ref["loss"], rtol=1e-4, atol=1e-6)
+    worst = [0.0, ""]
+    for kind, d in (("filter", model.filter_layer_dict), ("dis", model.dis_layer_dict)):
+        for k, v in d["gender"].state_dict().items():
+            a, b = v.detach().cpu().numpy().astype(np.float64), ref[f"final.{kind}.gender.{k}"]
+            ratio = np.abs(a - b) / (1e-4 * np.abs(b) + 1e-6 * max(1e-2, float(np.abs(b).max())))
+            if ratio.max() > worst[0]:
+                worst[:] = [float(ratio.max()), f"{kind}.{k}"]
+            assert ratio.max() <= 1.0, (kind, k, float(np.abs(a - b).max()), float(ratio.max()))
+    print("worst |err| / tolerance:", round(worst[0], 3), worst[1])
+    for k in ("user_embedding_layer.weight", "item_embedding_layer.weight"):         # frozen in the finetune stage
+        np.testing.assert_array_equal(model.state_dict()[k].cpu().numpy(), z["init.model." + k])
+    eng.check_device_errors()
+    np.testing.assert_allclose(model.predict(inter).cpu().numpy(), ref["predict_last"], rtol=1e-4, atol=1e-6)
 
 
 def test_fairgo_trainer_pretrain_then_finetune(tmp_path):
