@@ -283,27 +283,48 @@ __device__ __forceinline__ void step_shared_rows(KV kv, const AdamC& c, int b, i
         if (arrive_last(w.cnt_u + seg_u, nu, lane)) user_finish<E>(kv, c, w, j0u, nu, s, lane);
         return;
     }
-    RowFrag<E> pi0 = pi;
     if (lane == 0) st_sc1(w.pred + b, dot);
     drain_stores();
     if (!arrive_last(w.cnt_i + seg_i, ni, lane)) return;
 
-    // ---- item level, last arriver: statistics of the item over its members (the order of focf_fair_kernel: 16 lanes,
-    // members strided over them, butterfly), dLoss/dpred of every member, the item row's gradient and update
+    // ---- item level, last arriver.  THREE dependent load levels for the whole segment (it is the longest chain of the
+    // launch): (1) the members' batch positions, one per lane; (2) their records and scores; (3) their parked user rows,
+    // UN members in flight.  Statistics, dLoss/dpred, the item row's gradient and the members' user updates are formed in
+    // registers in between -- nothing this wave needs again goes through memory.
+    const bool big = ni > 64;       // more than one chunk of 64 members: the chunks are loaded again for each phase
+    int my_b = 0, my_u = 0, my_iux = 0, my_seg = 0;
+    float my_pr = 0.f, my_rt = 0.f, my_s = 0.f;
+    auto load_chunk = [&](int jb) {
+        my_b = 0; my_u = 0; my_iux = 0; my_seg = 0;
+        my_pr = 0.f; my_rt = 0.f; my_s = 0.f;
+        if (jb + lane < ni) {
+            my_b = w.perm_i[j0i + jb + lane];
+            const int4 rq = w.rec[my_b];
+            const int4 fq = w.info[my_b];
+            my_pr = ld_sc1(w.pred + my_b);
+            my_u = rq.x; my_rt = __int_as_float(rq.z); my_s = __int_as_float(rq.w);
+            my_iux = fq.x; my_seg = fq.y;
+        }
+    };
     float term = 0.f, g0 = 0.f, g1 = 0.f;
     if (fair) {
+        // statistics of the item over its members in the order of focf_fair_kernel: 16 lanes, lane l takes the members
+        // l, l + 16, l + 32, ... one after the other, then a butterfly
         float sp0 = 0.f, sp1 = 0.f, st0 = 0.f, st1 = 0.f, n0 = 0.f, n1 = 0.f;
         bool bad = false;
-        if (lane < FAIR_GROUP) {
-            for (int j = j0i + lane; j < j0i + ni; j += FAIR_GROUP) {
-                const int bq = w.perm_i[j];
-                const int4 rq = w.rec[bq];
-                const float sq = __int_as_float(rq.w), pr = ld_sc1(w.pred + bq), rr = __int_as_float(rq.z);
-                bad |= (sq != smin && sq != smax);
-                if (sq == smin) {
-                    sp0 += pr; st0 += rr; n0 += 1.f;
-                } else {
-                    sp1 += pr; st1 += rr; n1 += 1.f;
+        for (int jb = 0; jb < ni; jb += 64) {
+            load_chunk(jb);
+#pragma unroll
+            for (int k = 0; k < 64 / FAIR_GROUP; ++k) {
+                const int src = (lane & (FAIR_GROUP - 1)) + FAIR_GROUP * k;
+                const float pr = __shfl(my_pr, src, 64), rr = __shfl(my_rt, src, 64), sq = __shfl(my_s, src, 64);
+                if (lane < FAIR_GROUP && jb + src < ni) {
+                    bad |= (sq != smin && sq != smax);
+                    if (sq == smin) {
+                        sp0 += pr; st0 += rr; n0 += 1.f;
+                    } else {
+                        sp1 += pr; st1 += rr; n1 += 1.f;
+                    }
                 }
             }
         }
@@ -320,71 +341,76 @@ __device__ __forceinline__ void step_shared_rows(KV kv, const AdamC& c, int b, i
         focf_fair_eval(KA(objective), KA(fair_weight), K, sp0, sp1, st0, st1, n0, n1, term, g0, g1);
         if (lane == 0) KA(term)[seg_i] = term;
     }
-    // dLoss/dpred of the members, 64 at a time (one per lane), written for the user level
+    // dLoss/dpred of every member (one per lane), the item row's gradient summed over the members in ascending batch
+    // position -- coef * (user row), the product rounded, then added: embedding_dense_backward's order -- and the Adam step
+    // of every member whose user is its alone (gradient coef * item row BEFORE its update: `pi` is updated last)
+    constexpr int UN = E == 1 ? 4 : (E == 2 ? 2 : 1);
+    RowFrag<E> gi;
+#pragma unroll
+    for (int e = 0; e < E; ++e) gi.x[e] = 0.f;
+    bool shared_users = false;
     for (int jb = 0; jb < ni; jb += 64) {
-        if (jb + lane < ni) {
-            const int bq = w.perm_i[j0i + jb + lane];
-            const int4 rq = w.rec[bq];
-            const float erq = ld_sc1(w.pred + bq) - __int_as_float(rq.z);
-            float cq = 2.f * erq / (float)KA(B);
-            if (fair) cq = cq + (__int_as_float(rq.w) == smin ? g0 : g1);
-            st_sc1(w.coef + bq, cq);
-        }
-    }
-    drain_stores();      // this wave reads them back below (sc1 loads are served past the L1)
-    {
-        RowFrag<E> gi;
-        handed_grad_sum<E>(gi, j0i, ni, w.perm_i, w.coef, w.side[0], D, lane);
-        adam_write<E>(KA(Ip), KA(Im), KA(Iv), KA(Ilast), D, KA(step), c, ir, pi, mi, vi, gi, s, lane);
-    }
-    // ---- user level of every member, ascending; members whose user is theirs alone are updated here (one at a time:
-    // this path is rare and must not set the kernel's register budget)
-    constexpr int UN = 1;
-    for (int jb = 0; jb < ni; jb += 64) {
+        if (big || !fair) load_chunk(jb);
         const int cnt = min(64, ni - jb);
-        int my_b = 0, my_u = 0, my_iux = 0, my_seg = 0;
         float my_c = 0.f;
         if (lane < cnt) {
-            my_b = w.perm_i[j0i + jb + lane];
-            my_c = ld_sc1(w.coef + my_b);
-            my_u = w.rec[my_b].x;
-            const int4 q = w.info[my_b];
-            my_iux = q.x;
-            my_seg = q.y;
+            const float erq = my_pr - my_rt;
+            my_c = 2.f * erq / (float)KA(B);
+            if (fair) my_c = my_c + (my_s == smin ? g0 : g1);
+            if ((my_iux >> 16) > 1) st_sc1(w.coef + my_b, my_c);      // read by the user level of that member's user
         }
+        shared_users |= __ballot(lane < cnt && (my_iux >> 16) > 1) != 0ull;
         for (int t0 = 0; t0 < cnt; t0 += UN) {
             RowFrag<E> p[UN], m[UN], v[UN];
-            int bq[UN], uq[UN], nq[UN];
+            int uq[UN], nq[UN];
             float cq[UN];
 #pragma unroll
             for (int q = 0; q < UN; ++q) {
-                const int t = t0 + q < cnt ? t0 + q : cnt - 1;
-                bq[q] = __builtin_amdgcn_readlane(my_b, t);
+                const int t = t0 + q < cnt ? t0 + q : cnt - 1;     // tail: the last member again, not used
+                const int bq = __builtin_amdgcn_readlane(my_b, t);
                 uq[q] = __builtin_amdgcn_readlane(my_u, t);
                 nq[q] = __builtin_amdgcn_readlane(my_iux, t) >> 16;
                 cq[q] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_c), t));
-                if (t0 + q < cnt && nq[q] == 1) {
-                    const size_t sq = (size_t)bq[q] * D;
-                    load_row_sc1<E>(p[q], w.side[0] + sq, D, lane);
-                    load_row_sc1<E>(m[q], w.side[1] + sq, D, lane);
-                    load_row_sc1<E>(v[q], w.side[2] + sq, D, lane);
-                }
+                const size_t sq = (size_t)bq * D;
+                load_row_sc1<E>(p[q], w.side[0] + sq, D, lane);
+                load_row_sc1<E>(m[q], w.side[1] + sq, D, lane);
+                load_row_sc1<E>(v[q], w.side[2] + sq, D, lane);
             }
 #pragma unroll
             for (int q = 0; q < UN; ++q) {
                 if (t0 + q >= cnt) continue;
+                {
+#pragma clang fp contract(off)
+#pragma unroll
+                    for (int e = 0; e < E; ++e) {
+                        float prod = cq[q] * p[q].x[e];
+                        gi.x[e] = gi.x[e] + prod;
+                    }
+                }
                 if (nq[q] == 1) {
                     RowFrag<E> gu;
 #pragma unroll
-                    for (int e = 0; e < E; ++e) gu.x[e] = cq[q] * pi0.x[e];
+                    for (int e = 0; e < E; ++e) gu.x[e] = cq[q] * pi.x[e];
                     adam_write<E>(KA(Up), KA(Um), KA(Uv), KA(Ulast), D, KA(step), c, uq[q], p[q], m[q], v[q], gu, s, lane);
-                } else {
-                    const int t = t0 + q;
-                    const int sg = __builtin_amdgcn_readlane(my_seg, t);
-                    const int j0 = __builtin_amdgcn_readlane(my_iux, t) & 0xffff;
-                    if (arrive_last(w.cnt_u + sg, nq[q], lane)) user_finish<E>(kv, c, w, j0, nq[q], s, lane);
                 }
             }
+        }
+    }
+    adam_write<E>(KA(Ip), KA(Im), KA(Iv), KA(Ilast), D, KA(step), c, ir, pi, mi, vi, gi, s, lane);
+    if (!shared_users) return;
+    // ---- members whose user has other interactions in the batch: arrive at the user's counter (this member's dLoss/dpred
+    // and item row are in memory once the stores above have drained); whoever arrives last finishes that user
+    drain_stores();
+    for (int jb = 0; jb < ni; jb += 64) {
+        if (big) load_chunk(jb);
+        const int cnt = min(64, ni - jb);
+        unsigned long long todo = __ballot(lane < cnt && (my_iux >> 16) > 1);
+        while (todo) {
+            const int t = __builtin_ctzll(todo);
+            todo &= todo - 1;
+            const int iq = __builtin_amdgcn_readlane(my_iux, t);
+            const int sg = __builtin_amdgcn_readlane(my_seg, t);
+            if (arrive_last(w.cnt_u + sg, iq >> 16, lane)) user_finish<E>(kv, c, w, iq & 0xffff, iq >> 16, s, lane);
         }
     }
 }
@@ -707,14 +733,15 @@ __global__ __launch_bounds__(256, FR_STEP_WAVES) void focf_step_kernel(StepArgs 
 #if FR_STEP_TRACE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const unsigned long long tr1 = __builtin_amdgcn_s_memrealtime();
-    unsigned hw;
+    unsigned hw, xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
     const unsigned wq = blockIdx.x * 4 + wib;
     if (lane == 0 && wq < 65536) {
         g_step_trace[4 * wq] = tr0;
         g_step_trace[4 * wq + 1] = tr1;
         g_step_trace[4 * wq + 2] = role;
-        g_step_trace[4 * wq + 3] = hw;
+        g_step_trace[4 * wq + 3] = (unsigned long long)hw | ((unsigned long long)xcc << 32);
         g_step_trace[4 * (65536 + wq)] = ph[2];
         g_step_trace[4 * (65536 + wq) + 1] = ph[0];
         g_step_trace[4 * (65536 + wq) + 2] = ph[1];
@@ -749,6 +776,9 @@ __device__ unsigned long long g_lpt_stamps[8];
 #endif
 
 constexpr int LPT_SPLIT = 4;
+#ifndef FR_LPT_SHARED_FIRST
+#define FR_LPT_SHARED_FIRST 1
+#endif
 
 template <int PT>   // rounds of 1024 positions: B <= PT * 1024
 __global__ __launch_bounds__(1024) void focf_lpt_kernel(LptJobs jobs) {
@@ -769,12 +799,19 @@ __global__ __launch_bounds__(1024) void focf_lpt_kernel(LptJobs jobs) {
     // branch per round the compiler serialises the rounds' memory round trips); the rows' `last` stamps were gathered
     // by the stamp workgroups of the sort launch (16K random misses from this one CU took 16 us)
     int lu[PT], li[PT];
+    bool sh[PT];     // the interaction shares its user or its item row with another interaction of the batch
     LPT_STAMP(0);
 #pragma unroll
     for (int q = 0; q < PT; ++q) {
         const int b = q * 1024 + tid, bc = b < J.B ? b : 0;
         lu[q] = J.age_u[bc];
         li[q] = J.age_i[bc];
+#if FR_LPT_SHARED_FIRST
+        const int4 f = J.info[bc];
+        sh[q] = (f.x >> 16) > 1 || (f.z >> 16) > 1;
+#else
+        sh[q] = false;
+#endif
     }
     LPT_STAMP(1);
 #pragma unroll
@@ -788,6 +825,9 @@ __global__ __launch_bounds__(1024) void focf_lpt_kernel(LptJobs jobs) {
             const int hi = cu > ci ? cu : ci, lo = cu > ci ? ci : cu;
             const int cost = 7 * hi + 2 * lo;                          // VALU instructions: alone 7, as a pair 9 per step
             k = NC - 1 - min(NC - 1, cost * NC / (9 * cap + 1));
+            // a shared row is finished by the last of its waves to arrive, behind a hand-off through memory and three more
+            // dependent load levels: the longest chain of the launch whatever its replay length, so it starts first
+            if (sh[q]) k = 0;
         }
         cls[q] = k;
         rank[q] = 0;

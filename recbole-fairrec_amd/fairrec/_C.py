@@ -9,7 +9,9 @@ import ctypes
 import os
 from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_size_t, c_uint32, c_uint64, c_void_p
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libfairrec_hip.so")
+# FAIRREC_HIP_LIB: another build of the SAME library (diagnostic / A-B builds made with `make VARIANT=...`); never a fallback
+LIB_PATH = os.environ.get("FAIRREC_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib",
+                                                             "libfairrec_hip.so")
 
 FR_SORT_MAX = 16384
 DEV_ERR_INDEX_RANGE = 1

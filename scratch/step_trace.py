@@ -1,4 +1,6 @@
-"""Timeline of the waves of ONE fr_focf_step launch (library built with -DFR_STEP_TRACE=1)."""
+"""Timeline of the waves of ONE fr_focf_step launch (library built with -DFR_STEP_TRACE=1: `make VARIANT=trace
+EXTRA=-DFR_STEP_TRACE=1`, run with FAIRREC_HIP_LIB=scratch/lib/libfairrec_hip_trace.so).  Prints a summary and, with
+TRACE_OUT=<file.npz>, saves the raw per-wave records (start, end, role, hw id, phase stamps) for offline analysis."""
 import ctypes, os, sys
 import numpy as np
 import torch
@@ -9,12 +11,14 @@ from fairrec import _C
 from fairrec.model.fair_recommender.focf import FocfEngine
 from fairrec.optim import FusedLazyAdam
 dev = torch.device("cuda")
-K = 200
-u, i, r, s = (t.to(dev) for t in bench.synth_batches(K, bench.BATCH, bench.N_USERS, bench.N_ITEMS, bench.SEED))
+K = int(os.environ.get("TRACE_STEPS", "200"))
+dist = os.environ.get("TRACE_ITEM_DIST", "uniform")
+u, i, r, s = (t.to(dev) for t in bench.synth_batches(K, bench.BATCH, bench.N_USERS, bench.N_ITEMS, bench.SEED, dist))
 U, I = bench.xavier_tables(bench.N_USERS, bench.N_ITEMS, bench.DIM, bench.SEED, dev)
 eng = FocfEngine(U, I, bench.OBJECTIVE, bench.FAIR_WEIGHT, 5.0)
 FusedLazyAdam(eng, lr=bench.LR, weight_decay=bench.WD, sweep_period=int(os.environ.get("SWEEP", "0")) or None)
 eng.defer_loss = True
+eng.item_runs = dist == "grouped"
 rows = [(u[k], i[k], s[k], r[k]) for k in range(K)]
 for k in range(K):
     eng.forward(u[k], i[k], r[k], s[k], next_batch=rows[k + 1:k + 21] or None)
@@ -28,6 +32,8 @@ assert rc == 0
 buf, phs = both[:n], both[n:]
 keep = buf[:, 1] > 0
 buf, phs = buf[keep], phs[keep]
+if os.environ.get("TRACE_OUT"):
+    np.savez_compressed(os.environ["TRACE_OUT"], buf=buf, phs=phs, wq=np.nonzero(keep)[0])
 t0 = buf[:, 0].min()
 st = (buf[:, 0] - t0).astype(np.float64) / 100.0   # us
 en = (buf[:, 1] - t0).astype(np.float64) / 100.0
@@ -45,6 +51,14 @@ ts = np.linspace(0, en.max(), 40)
 occ = [(int(((st <= t) & (en > t) & (role == 1)).sum()), int(((st <= t) & (en > t) & (role == 2)).sum())) for t in ts]
 print("t(us): resident sweeper / interaction waves")
 print("  ".join(f"{t:.1f}:{a}/{b}" for t, (a, b) in zip(ts, occ)))
+# per-SIMD: when its last wave ends, how many waves it ran (the hardware id: simd 5:4, cu 11:8, sh 12, se 15:13; xcc in the high word)
+hw = buf[:, 3]
+simd = ((hw >> 4) & 3) | (((hw >> 8) & 0xf) << 2) | (((hw >> 12) & 1) << 6) | (((hw >> 13) & 7) << 7) | (((hw >> 32) & 0xf) << 10)
+ids, inv = np.unique(simd, return_inverse=True)
+last_end = np.zeros(len(ids)); nw = np.zeros(len(ids), dtype=int); busy = np.zeros(len(ids))
+np.maximum.at(last_end, inv, en); np.add.at(nw, inv, 1); np.add.at(busy, inv, en - st)
+print(f"SIMDs seen {len(ids)}; waves per SIMD min {nw.min()} median {np.median(nw):.0f} max {nw.max()}; last wave of a SIMD ends: "
+      f"p10 {np.percentile(last_end, 10):.1f} median {np.median(last_end):.1f} p90 {np.percentile(last_end, 90):.1f} max {last_end.max():.1f} us")
 
 m = (role == 2) & (phs[:, 0] > 0)
 l1 = (phs[m, 0] - buf[m, 0]).astype(np.float64) / 100.0
