@@ -311,7 +311,8 @@ def main():
     # world*B interactions, tables row-sharded over the ranks (fairrec/sharded.py)
     # single GPU: PIPE more batches than are stepped on, so that the look-ahead queue stays full to the last timed step (the
     # timed region then prepares exactly K batches ahead while it applies K, as any K consecutive steps of an epoch do)
-    PIPE = 0 if (world > 1 or args.force_sharded) else 24
+    AHEAD = FocfEngine.LOW_WATER + FocfEngine.GROUP      # batches a dataloader-style queue announces ahead
+    PIPE = 0 if (world > 1 or args.force_sharded) else AHEAD + 4
     u, i, r, s = (t.to(dev) for t in synth_batches(K + W + PIPE, BATCH, N_USERS, N_ITEMS, SEED + rank, args.item_dist))
     if not sharded:
         U, I = xavier_tables(N_USERS, N_ITEMS, DIM, SEED, dev)
@@ -351,7 +352,7 @@ def main():
         if key not in _rows:
             _rows[key] = [(ub[j], ib[j], sb[j], rb[j]) for j in range(ub.shape[0])]
         rows = _rows[key]
-        hi = min(k + 21, len(rows), stop if stop is not None else len(rows))
+        hi = min(k + 1 + AHEAD, len(rows), stop if stop is not None else len(rows))
         return rows[k + 1:hi] or None
 
     def step(k):

@@ -67,6 +67,8 @@ struct StepArgs {
     void* ws;
     long long lo_u, lo_i;     // sweep slice: rows [lo, lo + n) of each table, brought to `step`;
     int n_u, n_i, skip_from;  //   rows stamped >= skip_from belong to this or a coming batch and are left alone
+    const int32_t* sw_order;  // [n_pairs + 1] start order of the slice's pairs of rows (longest replay first), then the
+                              //   number of pairs it was built for; the identity order is used when that does not match
     uint32_t* err;
     PrevLoss prev;
 };
@@ -133,6 +135,30 @@ __device__ __forceinline__ void store_row_sc1(const RowFrag<E>& f, float* base, 
     }
 }
 
+// The write-back of a finished table row.  FR_STEP_STORE_MODE: 0 plain (the lines stay dirty in the XCD's L2 until the
+// end-of-kernel release writes them back), 1 nontemporal, 2 write-through (sc1)
+#ifndef FR_STEP_STORE_MODE
+#define FR_STEP_STORE_MODE 0
+#endif
+template <int E>
+__device__ __forceinline__ void store_trow(const RowFrag<E>& f, float* base, int D, int lane) {
+#if FR_STEP_STORE_MODE == 0
+    store_row<E>(f, base, D, lane);
+#else
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int d = lane + 64 * e;
+        if (d < D) {
+#if FR_STEP_STORE_MODE == 1
+            __builtin_nontemporal_store(f.x[e], base + d);
+#else
+            st_sc1(base + d, f.x[e]);
+#endif
+        }
+    }
+#endif
+}
+
 // arrival at a segment's counter; true for the wave whose add came last (it then owns the segment's work)
 __device__ __forceinline__ bool arrive_last(unsigned int* cnt, int n, int lane) {
     unsigned t = 0;
@@ -150,9 +176,9 @@ __device__ __forceinline__ void adam_write(float* Tp, float* Tm, float* Tv, int3
                                            const RowFrag<E>& g, float2 s, int lane) {
 #pragma unroll
     for (int e = 0; e < E; ++e) adam_elem(p.x[e], m.x[e], v.x[e], g.x[e], s.x, s.y, c);
-    store_row<E>(p, Tp + (size_t)row * D, D, lane);
-    store_row<E>(m, Tm + (size_t)row * D, D, lane);
-    store_row<E>(v, Tv + (size_t)row * D, D, lane);
+    store_trow<E>(p, Tp + (size_t)row * D, D, lane);
+    store_trow<E>(m, Tm + (size_t)row * D, D, lane);
+    store_trow<E>(v, Tv + (size_t)row * D, D, lane);
     if (lane == 0) Tlast[row] = step;
 }
 
@@ -490,12 +516,12 @@ __device__ __forceinline__ void step_finish(KV kv, const AdamC& c, int lane, int
             mu.x[e] = M.x; mi.x[e] = M.y;
             vu.x[e] = V.x; vi.x[e] = V.y;
         }
-        store_row<E>(pu, KA(Up) + (size_t)ur * D, D, lane);
-        store_row<E>(mu, KA(Um) + (size_t)ur * D, D, lane);
-        store_row<E>(vu, KA(Uv) + (size_t)ur * D, D, lane);
-        store_row<E>(pi, KA(Ip) + (size_t)ir * D, D, lane);
-        store_row<E>(mi, KA(Im) + (size_t)ir * D, D, lane);
-        store_row<E>(vi, KA(Iv) + (size_t)ir * D, D, lane);
+        store_trow<E>(pu, KA(Up) + (size_t)ur * D, D, lane);
+        store_trow<E>(mu, KA(Um) + (size_t)ur * D, D, lane);
+        store_trow<E>(vu, KA(Uv) + (size_t)ur * D, D, lane);
+        store_trow<E>(pi, KA(Ip) + (size_t)ir * D, D, lane);
+        store_trow<E>(mi, KA(Im) + (size_t)ir * D, D, lane);
+        store_trow<E>(vi, KA(Iv) + (size_t)ir * D, D, lane);
         if (lane == 0) {
             KA(Ulast)[ur] = KA(step);
             KA(Ilast)[ir] = KA(step);
@@ -513,7 +539,7 @@ __device__ __forceinline__ void step_finish(KV kv, const AdamC& c, int lane, int
 //   sweeper task q  : rows 2q, 2q + 1 of the step's slice (users first, then items), written back at step `step`;
 //   interaction b   : its user row and item row as of step - 1, then score, dLoss/dpred, both gradients, both updates.
 template <int E, bool PAIR>
-__device__ __forceinline__ void step_task(KV kv, bool sweeper, int q, int lane
+__device__ __forceinline__ void step_task(KV kv, bool sweeper, int q, int n_pairs, int lane
 #if FR_STEP_TRACE
                                           , unsigned long long (&phase_stamps)[4]
 #endif
@@ -528,6 +554,13 @@ __device__ __forceinline__ void step_task(KV kv, bool sweeper, int q, int lane
     TwoRows<E> r;
     int tA, tB;
     if (sweeper) {
+        // start order of the slice's pairs (fr_focf_prepare_step: longest estimated replay first, so that the four waves
+        // of a workgroup -- one per SIMD of its CU -- carry alike loads and the launch ends on its shortest tasks); an
+        // order built for another slice size (a batch applied at another step than it was prepared for) is not used
+        if (const int32_t* so = KA(sw_order)) {
+            const int oq = so[q], on = so[n_pairs];
+            q = uniform(on) == n_pairs ? uniform(oq) : q;
+        }
         const int pairs_u = (KA(n_u) + 1) >> 1;
         const bool inU = q < pairs_u;
         const int k = inU ? q : q - pairs_u;
@@ -554,15 +587,15 @@ __device__ __forceinline__ void step_task(KV kv, bool sweeper, int q, int lane
         const bool doA = tA < upto, doB = tB < upto;
         replay_two<E>(r, tA, tB, upto, c, lane);
         if (doA) {
-            store_row<E>(r.pA, Tp + (size_t)rowA * D, D, lane);
-            store_row<E>(r.mA, Tm + (size_t)rowA * D, D, lane);
-            store_row<E>(r.vA, Tv + (size_t)rowA * D, D, lane);
+            store_trow<E>(r.pA, Tp + (size_t)rowA * D, D, lane);
+            store_trow<E>(r.mA, Tm + (size_t)rowA * D, D, lane);
+            store_trow<E>(r.vA, Tv + (size_t)rowA * D, D, lane);
             if (lane == 0) Tl[rowA] = upto;
         }
         if (doB) {
-            store_row<E>(r.pB, Tp + (size_t)rowB * D, D, lane);
-            store_row<E>(r.mB, Tm + (size_t)rowB * D, D, lane);
-            store_row<E>(r.vB, Tv + (size_t)rowB * D, D, lane);
+            store_trow<E>(r.pB, Tp + (size_t)rowB * D, D, lane);
+            store_trow<E>(r.mB, Tm + (size_t)rowB * D, D, lane);
+            store_trow<E>(r.vB, Tv + (size_t)rowB * D, D, lane);
             if (lane == 0) Tl[rowB] = upto;
         }
         return;
@@ -634,36 +667,42 @@ __device__ __forceinline__ void step_task(KV kv, bool sweeper, int q, int lane
 // fixed-order reduction of one batch's squared errors and per-item terms -> loss (one workgroup of 256 threads).  The
 // association is that of the three-launch path (per 4 interactions, then strided over 256 threads, butterfly, 4 waves;
 // terms per 64 items, then the same), so both paths report the same bits.
+template <int NT>     // threads of the calling workgroup: 64, 128 or 256 (they stand in for 256 "virtual" threads)
 __device__ __forceinline__ void step_reduce_loss(const PrevLoss& pl) {
     __shared__ float red[2][4];
+    constexpr int VT = 256 / NT;      // virtual threads per thread: virtual thread j * NT + threadIdx.x, its wave = that / 64
     const int B = pl.B;
     const int nb = (B + 3) / 4;
-    float a = 0.f, f = 0.f;
-    for (int q = threadIdx.x; q < nb; q += 256) {
-        const int b0 = 4 * q;
-        const float e0 = pl.mse_e[b0], e1 = b0 + 1 < B ? pl.mse_e[b0 + 1] : 0.f, e2 = b0 + 2 < B ? pl.mse_e[b0 + 2] : 0.f,
-                    e3 = b0 + 3 < B ? pl.mse_e[b0 + 3] : 0.f;
-        a += ((e0 + e1) + e2) + e3;
-    }
     const bool per_item = pl.objective >= FR_FOCF_VALUE && pl.objective <= FR_FOCF_OVER;
     const int K = pl.nseg_i[0];
-    if (per_item) {
-        constexpr int PER = FAIR_THREADS / FAIR_GROUP;     // items per workgroup of the fairness launch
-        const int nf = (B * FAIR_GROUP + FAIR_THREADS - 1) / FAIR_THREADS;
-        for (int q = threadIdx.x; q < nf; q += 256) {
-            float sblk = 0.f;
-            const int k1 = min(K, (q + 1) * PER);
-            for (int k = q * PER; k < k1; ++k) sblk += pl.term[k];
-            f += sblk;
+#pragma unroll
+    for (int j = 0; j < VT; ++j) {
+        const int vt = j * NT + (int)threadIdx.x;
+        float a = 0.f, f = 0.f;
+        for (int q = vt; q < nb; q += 256) {
+            const int b0 = 4 * q;
+            const float e0 = pl.mse_e[b0], e1 = b0 + 1 < B ? pl.mse_e[b0 + 1] : 0.f, e2 = b0 + 2 < B ? pl.mse_e[b0 + 2] : 0.f,
+                        e3 = b0 + 3 < B ? pl.mse_e[b0 + 3] : 0.f;
+            a += ((e0 + e1) + e2) + e3;
         }
+        if (per_item) {
+            constexpr int PER = FAIR_THREADS / FAIR_GROUP;     // items per workgroup of the fairness launch
+            const int nf = (B * FAIR_GROUP + FAIR_THREADS - 1) / FAIR_THREADS;
+            for (int q = vt; q < nf; q += 256) {
+                float sblk = 0.f;
+                const int k1 = min(K, (q + 1) * PER);
+                for (int k = q * PER; k < k1; ++k) sblk += pl.term[k];
+                f += sblk;
+            }
+        }
+        a = wave_sum(a);
+        f = wave_sum(f);
+        if ((threadIdx.x & 63) == 0) { red[0][vt >> 6] = a; red[1][vt >> 6] = f; }
     }
-    a = wave_sum(a);
-    f = wave_sum(f);
-    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = a; red[1][threadIdx.x >> 6] = f; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        a = ((red[0][0] + red[0][1]) + red[0][2]) + red[0][3];
-        f = ((red[1][0] + red[1][1]) + red[1][2]) + red[1][3];
+        const float a = ((red[0][0] + red[0][1]) + red[0][2]) + red[0][3];
+        const float f = ((red[1][0] + red[1][1]) + red[1][2]) + red[1][3];
         const float mse = a / (float)B;
         const float fairv = per_item ? f / (float)K : 0.f;
         const float loss = per_item ? mse + pl.fair_weight * fairv : mse;
@@ -693,22 +732,28 @@ __host__ __device__ constexpr bool step_pairs(int E) { return E <= 1; }
 #endif
 #if FR_STEP_TRACE   // diagnostic build: (start, end) in 10 ns ticks, role and placement of every wave of one launch
 __device__ unsigned long long g_step_trace[8 * 65536];
+__device__ int g_trace_step = -1;      // >= 0: only the launch that applies this optimizer step is recorded
 #endif
 
 #ifndef FR_STEP_WAVES
 #define FR_STEP_WAVES 6      // waves per SIMD the register budget is cut for
 #endif
+#ifndef FR_STEP_WPB
+#define FR_STEP_WPB 4        // waves (= tasks) per workgroup: the granule the hardware dispatcher hands to a CU
+#endif
+constexpr int STEP_WPB = FR_STEP_WPB;
 template <int E>
-__global__ __launch_bounds__(256, FR_STEP_WAVES) void focf_step_kernel(StepArgs a) {
+__global__ __launch_bounds__(64 * STEP_WPB, FR_STEP_WAVES) void focf_step_kernel(StepArgs a) {
 #if FR_STEP_TRACE
     const unsigned long long tr0 = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long mt0 = __builtin_amdgcn_s_memtime();      // shader clock: the clock the chip holds under this load
     unsigned long long ph[4] = {0, 0, 0, 0};
 #endif
     const int lane = threadIdx.x & 63;
     const int wib = uniform((int)(threadIdx.x >> 6));      // wave-uniform, and the compiler has to know it
     int role = 0;
     if (blockIdx.x == 0) {
-        if (a.prev.loss_out) step_reduce_loss(a.prev);
+        if (a.prev.loss_out) step_reduce_loss<64 * STEP_WPB>(a.prev);
     } else {
         const unsigned* kp = reinterpret_cast<const unsigned*>(
             (const void*)(const __attribute__((address_space(4))) void*)__builtin_amdgcn_kernarg_segment_ptr());
@@ -717,32 +762,33 @@ __global__ __launch_bounds__(256, FR_STEP_WAVES) void focf_step_kernel(StepArgs 
         kv.v1 = lane < (int)(sizeof(StepArgs) / 4) - 64 ? kp[64 + lane] : 0u;
         const int x = (int)blockIdx.x - 1;
         const int n_pairs = ((a.n_u + 1) >> 1) + ((a.n_i + 1) >> 1);
-        const int ns = (n_pairs + 3) >> 2;
+        const int ns = (n_pairs + STEP_WPB - 1) / STEP_WPB;
         // longest jobs first: the `lead` workgroups of the interactions with the longest replays (the task list is in
         // that order), then the sweeper workgroups (a full period of replay each), then the other interactions
         constexpr bool PAIR = step_pairs(E);
         const bool sweeper = x >= a.lead && x < a.lead + ns;
-        const int q = ((sweeper ? x - a.lead : (x < a.lead ? x : x - ns)) * 4 + wib) * (!sweeper && PAIR ? 2 : 1);
+        const int q = ((sweeper ? x - a.lead : (x < a.lead ? x : x - ns)) * STEP_WPB + wib) * (!sweeper && PAIR ? 2 : 1);
         role = sweeper ? 1 : 2;
 #if FR_STEP_TRACE
-        if (q < (sweeper ? n_pairs : a.B)) step_task<E, PAIR>(kv, sweeper, q, lane, ph);
+        if (q < (sweeper ? n_pairs : a.B)) step_task<E, PAIR>(kv, sweeper, q, n_pairs, lane, ph);
 #else
-        if (q < (sweeper ? n_pairs : a.B)) step_task<E, PAIR>(kv, sweeper, q, lane);
+        if (q < (sweeper ? n_pairs : a.B)) step_task<E, PAIR>(kv, sweeper, q, n_pairs, lane);
 #endif
     }
 #if FR_STEP_TRACE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const unsigned long long tr1 = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long mt1 = __builtin_amdgcn_s_memtime();
     unsigned hw, xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    const unsigned wq = blockIdx.x * 4 + wib;
-    if (lane == 0 && wq < 65536) {
+    const unsigned wq = blockIdx.x * STEP_WPB + wib;
+    if (lane == 0 && wq < 65536 && (g_trace_step < 0 || g_trace_step == a.step)) {
         g_step_trace[4 * wq] = tr0;
         g_step_trace[4 * wq + 1] = tr1;
         g_step_trace[4 * wq + 2] = role;
         g_step_trace[4 * wq + 3] = (unsigned long long)hw | ((unsigned long long)xcc << 32);
-        g_step_trace[4 * (65536 + wq)] = ph[2];
+        g_step_trace[4 * (65536 + wq)] = (ph[2] ? ((ph[2] - tr0) << 40) : 0ull) | (mt1 - mt0);   // level-1 ticks | shader cycles
         g_step_trace[4 * (65536 + wq) + 1] = ph[0];
         g_step_trace[4 * (65536 + wq) + 2] = ph[1];
         g_step_trace[4 * (65536 + wq) + 3] = ph[3];
@@ -750,7 +796,101 @@ __global__ __launch_bounds__(256, FR_STEP_WAVES) void focf_step_kernel(StepArgs 
 #endif
 }
 
-__global__ __launch_bounds__(256) void focf_step_finish_kernel(PrevLoss pl) { step_reduce_loss(pl); }
+__global__ __launch_bounds__(256) void focf_step_finish_kernel(PrevLoss pl) { step_reduce_loss<256>(pl); }
+
+// Start order of the sweeper tasks of ONE step (task = a pair of neighbouring rows of that step's sweep slice): longest
+// estimated replay first.  The hardware hands the launch's workgroups to the CUs in index order, one wave of a workgroup
+// per SIMD; with the tasks in slice order a SIMD's load is a sum of random replay lengths (0 .. 2 S row-steps per task)
+// and the launch ends on its unluckiest SIMD (FR_STEP_TRACE: the SIMDs of one CU finish 3 us apart, the CUs 6 us).  In
+// this order the four tasks of a workgroup are alike and the last tasks to start are the shortest.  Estimated from the
+// rows' `last` stamps as of the prepare launch, like the interactions' order: only the order depends on it.
+struct SwOrderJob {
+    const int32_t *Ulast, *Ustamp, *Ilast, *Istamp;
+    long long lo_u, lo_i;
+    int n_u, n_i, upto, skip_from;
+    int32_t* order;
+};
+constexpr int SW_NC = 16;     // cost classes of the sweeper order
+
+// One workgroup of 1024 threads (an extra workgroup of the launch-order launch); cnt: [SW_NC * PT * 16] ints of LDS
+template <int PT>   // rounds of 1024 tasks
+__device__ __forceinline__ void sweep_order_body(const SwOrderJob& J, int cap_, int* cnt, int* wsum) {
+    constexpr int NC = SW_NC, NW = 16, N = NC * PT * NW, EPT = (N + 1023) / 1024;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const int cap = cap_ > 0 ? cap_ : 1024;
+    const int pairs_u = (J.n_u + 1) >> 1, n_pairs = pairs_u + ((J.n_i + 1) >> 1);
+    if (!J.order) return;
+    if (n_pairs > PT * 1024) {      // a slice larger than this launch ranks (an unusually short sweep period): index order
+        if (tid == 0 && n_pairs <= SWEEP_ORDER_MAX) J.order[n_pairs] = -1;
+        return;
+    }
+    int la[PT], lb[PT], sa[PT], sb[PT];
+#pragma unroll
+    for (int r = 0; r < PT; ++r) {      // every load of the phase in flight before the first is used
+        const int q = r * 1024 + tid, qc = q < n_pairs ? q : 0;
+        const bool inU = qc < pairs_u;
+        const int k = inU ? qc : qc - pairs_u;
+        const long long rowA = (inU ? J.lo_u : J.lo_i) + 2 * k;
+        const long long rowB = 2 * k + 1 < (inU ? J.n_u : J.n_i) ? rowA + 1 : rowA;
+        const int32_t* Tl = inU ? J.Ulast : J.Ilast;
+        const int32_t* Ts = inU ? J.Ustamp : J.Istamp;
+        la[r] = Tl[rowA]; lb[r] = Tl[rowB]; sa[r] = Ts[rowA]; sb[r] = Ts[rowB];
+    }
+    int cls[PT], rank[PT];
+#pragma unroll
+    for (int r = 0; r < PT; ++r) {
+        const int q = r * 1024 + tid;
+        int k = -1;
+        if (q < n_pairs) {
+            int ca = sa[r] >= J.skip_from ? 0 : J.upto - la[r], cb = sb[r] >= J.skip_from ? 0 : J.upto - lb[r];
+            ca = ca < 0 ? 0 : (ca > cap ? cap : ca);
+            cb = cb < 0 ? 0 : (cb > cap ? cap : cb);
+            const int hi = ca > cb ? ca : cb, lo = ca > cb ? cb : ca;
+            const int cost = 7 * hi + 2 * lo;                          // VALU instructions: alone 7, as a pair 9 per step
+            k = NC - 1 - min(NC - 1, cost * NC / (9 * cap + 1));
+        }
+        cls[r] = k;
+        rank[r] = 0;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const unsigned long long m = __ballot(k == c);
+            if (k == c) rank[r] = __popcll(m & lt);
+            if (lane == 0) cnt[(c * PT + r) * NW + wave] = __popcll(m);
+        }
+    }
+    __syncthreads();
+    {   // exclusive scan of the N counts, EPT consecutive ones per thread
+        int x[EPT], own = 0;
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            const int i = tid * EPT + e;
+            x[e] = i < N ? cnt[i] : 0;
+            own += x[e];
+        }
+        int inc = own;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int y = __shfl_up(inc, o, 64);
+            if (lane >= o) inc += y;
+        }
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        int ex = inc - own;
+        for (int w = 0; w < wave; ++w) ex += wsum[w];
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            const int i = tid * EPT + e;
+            if (i < N) cnt[i] = ex;
+            ex += x[e];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < PT; ++r)
+        if (cls[r] >= 0) J.order[cnt[(cls[r] * PT + r) * NW + wave] + rank[r]] = r * 1024 + tid;
+    if (tid == 0) J.order[n_pairs] = n_pairs;
+}
 
 // Start order of the interactions of a batch: longest replay first (the launch ends one wave latency after its last wave
 // starts, and a wave's latency is its replay length: 3.4 us with nothing to replay, 25 us with 2 x 123 steps).  One
@@ -765,6 +905,8 @@ struct LptJob {
 };
 struct LptJobs {
     LptJob j[FR_FOCF_PREPARE_MAX];
+    SwOrderJob sw[FR_FOCF_PREPARE_MAX];   // the same steps' sweeper tasks: ranked by one extra workgroup per batch
+    int n;        // batches
     int cap;      // replay lengths are bounded by the sweep period
 };
 
@@ -786,11 +928,15 @@ __global__ __launch_bounds__(1024) void focf_lpt_kernel(LptJobs jobs) {
     // (a counting sort on LDS counters serialises the 64 lanes of every wave on the few hot cost classes).
     // LPT_SPLIT workgroups per batch: each classifies and scans the whole batch (coalesced reads, cheap) and rewrites
     // its share of the rounds (16-byte stores to scattered places, what a single CU is slow at).
+    constexpr int NC = 8, NW = 16, N = NC * PT * NW, EPT = (N + 1023) / 1024;
+    __shared__ int cnt[SW_NC * PT * NW];     // [class][round][wave], scanned in that order (sized for the sweeper ranking)
+    __shared__ int wsum[NW];
+    if ((int)blockIdx.x >= jobs.n * LPT_SPLIT) {
+        sweep_order_body<PT>(jobs.sw[blockIdx.x - jobs.n * LPT_SPLIT], jobs.cap, cnt, wsum);
+        return;
+    }
     const LptJob& J = jobs.j[blockIdx.x / LPT_SPLIT];
     const int part = blockIdx.x % LPT_SPLIT;
-    constexpr int NC = 8, NW = 16, N = NC * PT * NW, EPT = (N + 1023) / 1024;
-    __shared__ int cnt[N];          // [class][round][wave], scanned in that order
-    __shared__ int wsum[NW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const unsigned long long lt = (1ull << lane) - 1ull;
     const int cap = jobs.cap > 0 ? jobs.cap : 1024;
@@ -955,15 +1101,24 @@ extern "C" int fr_focf_prepare_step(const fr_focf_batch* batches, const int32_t*
         lj.j[q] = LptJob{w.age_u, w.age_i, w.rec, w.info, w.task_rec, w.task_info, (int)batches[q].B, stamps[q] - 1};
     }
     lj.cap = replay_cap;
+    lj.n = n;
+    for (int q = 0; q < n; ++q) {      // start order of each step's sweeper tasks (the slice is a function of the step the batch is
+        const FocfWs w = focf_layout(batches[q].ws, batches[q].B, U->dim);      // stamped for); no sweeper, no order
+        fr_table tu = *U, ti = *I;
+        tu.step = ti.step = stamps[q];
+        const SweepSlice sw = make_sweep_slice(&tu, &ti, replay_cap);
+        lj.sw[q] = SwOrderJob{U->last, U->stamp, I->last, I->stamp, sw.lo_u, sw.lo_i, sw.n_u, sw.n_i, stamps[q], stamps[q],
+                              replay_cap > 0 ? w.sw_order : nullptr};
+    }
     int Bmax = 1;
     for (int q = 0; q < n; ++q) Bmax = batches[q].B > Bmax ? (int)batches[q].B : Bmax;
     hipStream_t st = (hipStream_t)stream_;
     ProfScope prof(K_FOCF_LPT, st);
-    if (Bmax <= 1024) FR_LAUNCH(prof, focf_lpt_kernel<1>, dim3(n * LPT_SPLIT), dim3(1024), 0, st, lj);
-    else if (Bmax <= 2048) FR_LAUNCH(prof, focf_lpt_kernel<2>, dim3(n * LPT_SPLIT), dim3(1024), 0, st, lj);
-    else if (Bmax <= 4096) FR_LAUNCH(prof, focf_lpt_kernel<4>, dim3(n * LPT_SPLIT), dim3(1024), 0, st, lj);
-    else if (Bmax <= 8192) FR_LAUNCH(prof, focf_lpt_kernel<8>, dim3(n * LPT_SPLIT), dim3(1024), 0, st, lj);
-    else FR_LAUNCH(prof, focf_lpt_kernel<16>, dim3(n * LPT_SPLIT), dim3(1024), 0, st, lj);
+    if (Bmax <= 1024) FR_LAUNCH(prof, focf_lpt_kernel<1>, dim3(n * (LPT_SPLIT + 1)), dim3(1024), 0, st, lj);
+    else if (Bmax <= 2048) FR_LAUNCH(prof, focf_lpt_kernel<2>, dim3(n * (LPT_SPLIT + 1)), dim3(1024), 0, st, lj);
+    else if (Bmax <= 4096) FR_LAUNCH(prof, focf_lpt_kernel<4>, dim3(n * (LPT_SPLIT + 1)), dim3(1024), 0, st, lj);
+    else if (Bmax <= 8192) FR_LAUNCH(prof, focf_lpt_kernel<8>, dim3(n * (LPT_SPLIT + 1)), dim3(1024), 0, st, lj);
+    else FR_LAUNCH(prof, focf_lpt_kernel<16>, dim3(n * (LPT_SPLIT + 1)), dim3(1024), 0, st, lj);
     FR_CHECK_LAUNCH();
     return FR_OK;
 }
@@ -1002,6 +1157,7 @@ extern "C" int fr_focf_step(const fr_table* U, const fr_table* I, const fr_adam*
     a.task_rec = w.task_rec;
     a.task_info = w.task_info;
     static const int lead_pct = getenv("FAIRREC_STEP_LEAD") ? atoi(getenv("FAIRREC_STEP_LEAD")) : 100;
+
     a.hdr = w.nseg_i;
     a.mse_e = w.mse_e;
     a.term = w.term;
@@ -1013,16 +1169,17 @@ extern "C" int fr_focf_step(const fr_table* U, const fr_table* I, const fr_adam*
         a.lo_u = sw.lo_u; a.lo_i = sw.lo_i; a.n_u = sw.n_u; a.n_i = sw.n_i;
         a.skip_from = stamp;      // the rows of this batch (and of batches prepared for later steps) carry stamps >= it
         sweep_waves = ((long long)a.n_u + 1) / 2 + ((long long)a.n_i + 1) / 2;
+        a.sw_order = sweep_waves <= SWEEP_ORDER_MAX ? w.sw_order : nullptr;
     }
     a.prev = prev_of(prev_ws, prev_B, U->dim, objective, fair_weight, prev_loss_out, loss_acc);
     (void)loss_out;   // reduced by the NEXT fr_focf_step (prev_*) or by fr_focf_step_finish
     {
         ProfScope prof(K_FOCF_STEP, stream);
         const long long per_wave = step_pairs((U->dim + 63) / 64) ? 2 : 1;
-        const long long inter_blocks = ((B + per_wave - 1) / per_wave + 3) / 4;
-        const unsigned blocks = (unsigned)(1 + (sweep_waves + 3) / 4 + inter_blocks);
+        const long long inter_blocks = ((B + per_wave - 1) / per_wave + STEP_WPB - 1) / STEP_WPB;
+        const unsigned blocks = (unsigned)(1 + (sweep_waves + STEP_WPB - 1) / STEP_WPB + inter_blocks);
         a.lead = (int)(inter_blocks * lead_pct / 100);
-        FR_DISPATCH_E(U->dim, FR_LAUNCH(prof, (focf_step_kernel<E>), dim3(blocks), dim3(256), 0, stream, a));
+        FR_DISPATCH_E(U->dim, FR_LAUNCH(prof, (focf_step_kernel<E>), dim3(blocks), dim3(64 * STEP_WPB), 0, stream, a));
     }
     FR_CHECK_LAUNCH();
     return FR_OK;
@@ -1037,6 +1194,10 @@ extern "C" __attribute__((visibility("default"))) int fr_debug_lpt_stamps(unsign
 #endif
 
 #if FR_STEP_TRACE
+extern "C" __attribute__((visibility("default"))) int fr_debug_set_trace_step(int step) {
+    FR_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_trace_step), &step, sizeof(int)));
+    return FR_OK;
+}
 extern "C" __attribute__((visibility("default"))) int fr_debug_step_trace(unsigned long long* host_out, int n_waves) {
     FR_CHECK_HIP(hipDeviceSynchronize());
     FR_CHECK_HIP(hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_step_trace), (size_t)n_waves * 32));

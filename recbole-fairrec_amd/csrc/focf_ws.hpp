@@ -41,11 +41,14 @@ struct FocfWs {
     int32_t *age_u, *age_i;   // [B] `last` stamp of each position's user / item row as of the prepare launch
     float* mse_e;        // [B]
     float* term;         // [B] indexed by item segment
+    int32_t* sw_order;   // [SWEEP_ORDER_MAX + 1] start order of the step's sweeper tasks (pairs of rows of the sweep slice),
+                         //   followed by the number of pairs it was built for (focf_sweep_order_kernel)
     DeferLoss* defer;    // [1] written by the forward launch, consumed (and cleared) by the backward launch
     int n_gather_blocks, n_fair_blocks;
     size_t bytes;
 };
 
+constexpr int SWEEP_ORDER_MAX = 16384;   // pairs of rows per sweep slice that get a start order (beyond: index order)
 constexpr int GATHER_THREADS = 256;  // 4 waves = 4 interactions per block
 constexpr int FAIR_THREADS = 1024;   // 16 lanes per item segment -> 64 segments per block (few blocks: cheap ticket)
 constexpr int FAIR_GROUP = 16;        // lanes per item segment ...
@@ -91,6 +94,7 @@ __host__ __device__ inline FocfWs focf_layout(void* base, int64_t B, int D) {
     w.age_i = (int32_t*)take(Bp * 4);
     w.mse_e = (float*)take(Bp * 4);
     w.term = (float*)take(Bp * 4);
+    w.sw_order = (int32_t*)take(((size_t)SWEEP_ORDER_MAX + 1) * 4);
     w.defer = (DeferLoss*)take(sizeof(DeferLoss));
     for (int k = 0; k < 6; ++k) w.side[k] = (float*)take((size_t)B * D * 4);
     w.bytes = off;

@@ -10,6 +10,7 @@ from __future__ import annotations
 
 import ctypes
 import math
+import os
 from typing import Dict, Optional
 
 import torch
@@ -41,11 +42,13 @@ class FocfEngine:
     """Owns the two lazy-Adam tables, the per-batch workspace and the kernel launches of FOCF."""
 
     LOSS_SLOTS = 256
-    GROUP = 16        # coming batches prepared per fork of the side stream (FR_FOCF_PREPARE_MAX of them per launch; 32 and 48
-                      # measured slower: rows stamped further ahead are left to their batch by more sweeps)
+    GROUP = int(os.environ.get("FAIRREC_FOCF_GROUP", 16))       # coming batches prepared per fork of the side stream
+                      # (FR_FOCF_PREPARE_MAX of them per launch; 32 and 48 measured slower: rows stamped further ahead are
+                      # left to their batch by more sweeps)
     PER_LAUNCH = 8    # FR_FOCF_PREPARE_MAX
-    LOW_WATER = 4     # ... launched when this few prepared batches are left, so its join is steps old when reached
-    N_WS = 23         # workspaces: the batch in flight + the last one (its loss) + LOW_WATER + GROUP prepared + a spare
+    LOW_WATER = int(os.environ.get("FAIRREC_FOCF_LOW_WATER", 4))  # ... launched when this few prepared batches are left, so
+                      # that its join is steps old when reached
+    N_WS = GROUP + LOW_WATER + 3   # workspaces: the batch in flight + the last one (its loss) + the prepared ones + a spare
 
     def __init__(self, user_weight: torch.Tensor, item_weight: torch.Tensor, objective: str, fair_weight: float,
                  max_rating: float):
@@ -118,12 +121,13 @@ class FocfEngine:
     def _key(user, item):
         return (user.data_ptr(), item.data_ptr(), user.numel())
 
-    def prepare_many(self, batches):
+    def prepare_many(self, batches, ahead: int = 0):
         """Index-only part of COMING batches (fr_focf_prepare_step: sort + segmentation + sst min/max of each, the packed
         per-interaction records and the row stamps of the one-launch step; one launch for all of them) on a side stream,
         overlapping the kernels of the batches in flight.  `batches` = [(user, item, sst, rating)] in the order they
         will be applied ((user, item, sst) triples are accepted: such a batch is prepared for the three-launch chain
-        only)."""
+        only); `ahead` = optimizer steps that will be applied before the first of them (1 when called from inside
+        forward(): the current batch comes first)."""
         if self._side is None:
             self._side = torch.cuda.Stream(device=self.device)
             self._ws_next = 0
@@ -149,7 +153,7 @@ class FocfEngine:
             ws = self._workspace(B, k)
             arr[q] = _C.FrFocfBatch(user.data_ptr(), item.data_ptr(), _C.ptr(sst if self.objective != 0 else None), B,
                                     ws.data_ptr(), ws.numel(), _C.ptr(bt[3]) if full else None)
-            stamps[q] = self._next_stamp(q) if full else 0
+            stamps[q] = self._next_stamp(q + ahead) if full else 0
             entries.append((self._key(user, item), (k, group, int(stamps[q]) if full else None)))
         # everything that last used these workspaces was enqueued before this point
         start = torch.cuda.Event()
@@ -193,7 +197,8 @@ class FocfEngine:
                 group["joined"] = True
 
     def _next_stamp(self, ahead: int = 0) -> int:
-        """Stamp of a batch about to be prepared: the step at which it is expected to be applied, never decreasing."""
+        """Stamp of a batch about to be prepared: the step at which it is expected to be applied (`ahead` steps after the
+        next one), strictly increasing from one call to the next."""
         s = max(self._stamp_last + 1, self.U.step + 1 + ahead)
         self._stamp_last = s
         return s
@@ -247,21 +252,26 @@ class FocfEngine:
             alive = {self._key(nb[0], nb[1]) for nb in coming}
             for k in [k for k in self._prep if k not in alive]:
                 torch.cuda.current_stream().wait_event(self._prep.pop(k)[1]["done"])
+        fused = (self.fused_step and self.defer_loss and self.optimizer is not None and self.objective != 5 and not want_pred
+                 and not self.item_runs and self.U.step == self.I.step)
+        # A stamp is the optimizer step at which its batch is applied: the current batch (if nobody prepared it) takes its
+        # stamp BEFORE the coming ones take theirs, so that stamps rise in application order -- the sweeper leaves a row to
+        # its batch by comparing stamps, and the start order of a step's sweeper tasks is built for the stamped step's slice
+        stamp_now = self._next_stamp() if (fused and stamp is None) else None
         if coming and len(self._prep) <= self.LOW_WATER:
             todo = [nb for nb in coming if self._key(nb[0], nb[1]) not in self._prep]
             if todo:
-                self.prepare_many(todo[:self.GROUP])
+                self.prepare_many(todo[:self.GROUP], ahead=1)
         self.loss_slot = (self.loss_slot + 1) % self.LOSS_SLOTS
         loss = self._loss_views[self.loss_slot]
         self.hyper.check_step(self.U.step + 1)
-        if (self.fused_step and self.defer_loss and self.optimizer is not None and self.objective != 5 and not want_pred
-                and not self.item_runs and self.U.step == self.I.step):
+        if fused:
             # one launch for the whole step, issued by backward_adam(); the index side must be there first
             if stamp is None:
                 arr = (_C.FrFocfBatch * 1)(_C.FrFocfBatch(user.data_ptr(), item.data_ptr(),
                                                           _C.ptr(sst if self.objective != 0 else None), B, ws.data_ptr(),
                                                           ws.numel(), rating.data_ptr()))
-                stamp = self._next_stamp()
+                stamp = stamp_now
                 tu, ti = self.U.c(), self.I.c()
                 rc = _C.lib().fr_focf_prepare_step(arr, (ctypes.c_int32 * 1)(stamp), 1, ctypes.byref(tu), ctypes.byref(ti),
                                                    self._sweep(B), self.err_flag.data_ptr(), _C.current_stream())
@@ -438,7 +448,7 @@ class FOCF(FairRecommender):
         ie = eng.I.gather(eng.hyper, item, eng.err_flag)
         return (ue * ie).sum(-1), ue, ie
 
-    PREFETCH = 20     # batches a trainer may announce ahead (FocfEngine.LOW_WATER + GROUP)
+    PREFETCH = FocfEngine.LOW_WATER + FocfEngine.GROUP     # batches a trainer may announce ahead
 
     def hint_next_batch(self, *interactions):
         """Optional trainer hook: the batches that will follow the next `calculate_loss`, in order (none at the epoch

@@ -1,0 +1,16 @@
+#!/bin/bash
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/r3_4
+mkdir -p $O
+cd $R
+L=$R/scratch/lib
+run() { local tag=$1 lib=$2; shift 2
+  if [ "$lib" = "-" ]; then unset FAIRREC_HIP_LIB; else export FAIRREC_HIP_LIB=$L/libfairrec_hip_$lib.so; fi
+  TAG=$tag python scratch/step_bench.py "$@" 2>$O/$tag.err | tee -a $O/summary.txt; }
+for rep in 1 2; do
+  run new_$rep -
+  run fill500_$rep fill500
+  run fill1000_$rep fill1000
+done
+FAIRREC_HIP_LIB=$L/libfairrec_hip_trace.so TRACE_OUT=$O/trace.npz python scratch/step_trace.py > $O/trace.log 2>&1
+tail -8 $O/trace.log

@@ -1,0 +1,17 @@
+"""bench.py's FOCF workload with what-if knobs for kernel experiments (diagnostics only, never a reported number):
+OBJ=<none|value|...> replaces the fairness objective; other arguments are bench.py's.  Prints `tag us/step kernel_us`."""
+import io, json, os, sys, contextlib
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "recbole-fairrec_amd")]
+import bench
+if os.environ.get("OBJ"):
+    bench.OBJECTIVE = os.environ["OBJ"]
+tag = os.environ.get("TAG", "run")
+sys.argv = ["bench.py", "--no-cpu-baseline", "--graph-only"] + sys.argv[1:]
+buf = io.StringIO()
+with contextlib.redirect_stdout(buf):
+    bench.main()
+line = [l for l in buf.getvalue().splitlines() if l.startswith("{")][-1]
+d = json.loads(line)
+print(f"{tag:28s} {d['ms_per_step'] * 1e3:7.2f} us/step   step_kernel {d['roofline']['kernel_us'].get('focf_step_kernel', 0):6.2f}  "
+      f"lpt {d['roofline']['kernel_us'].get('focf_lpt_kernel', 0):5.1f} sort {d['roofline']['kernel_us'].get('sort_segments_kernel', 0):5.1f}", flush=True)

@@ -13,13 +13,14 @@ from fairrec.optim import FusedLazyAdam
 dev = torch.device("cuda")
 K = int(os.environ.get("TRACE_STEPS", "200"))
 dist = os.environ.get("TRACE_ITEM_DIST", "uniform")
-u, i, r, s = (t.to(dev) for t in bench.synth_batches(K, bench.BATCH, bench.N_USERS, bench.N_ITEMS, bench.SEED, dist))
+PIPE = int(os.environ.get("TRACE_PIPE", "24"))      # batches announced past the last step: the traced launch is a steady-state one
+u, i, r, s = (t.to(dev) for t in bench.synth_batches(K + PIPE, bench.BATCH, bench.N_USERS, bench.N_ITEMS, bench.SEED, dist))
 U, I = bench.xavier_tables(bench.N_USERS, bench.N_ITEMS, bench.DIM, bench.SEED, dev)
 eng = FocfEngine(U, I, bench.OBJECTIVE, bench.FAIR_WEIGHT, 5.0)
 FusedLazyAdam(eng, lr=bench.LR, weight_decay=bench.WD, sweep_period=int(os.environ.get("SWEEP", "0")) or None)
 eng.defer_loss = True
 eng.item_runs = dist == "grouped"
-rows = [(u[k], i[k], s[k], r[k]) for k in range(K)]
+rows = [(u[k], i[k], s[k], r[k]) for k in range(K + PIPE)]
 for k in range(K):
     eng.forward(u[k], i[k], r[k], s[k], next_batch=rows[k + 1:k + 21] or None)
     eng.backward_adam()
@@ -60,6 +61,23 @@ np.maximum.at(last_end, inv, en); np.add.at(nw, inv, 1); np.add.at(busy, inv, en
 print(f"SIMDs seen {len(ids)}; waves per SIMD min {nw.min()} median {np.median(nw):.0f} max {nw.max()}; last wave of a SIMD ends: "
       f"p10 {np.percentile(last_end, 10):.1f} median {np.median(last_end):.1f} p90 {np.percentile(last_end, 90):.1f} max {last_end.max():.1f} us")
 
+cyc = (phs[:, 0] & np.uint64((1 << 40) - 1)).astype(np.float64)
+dur = (buf[:, 1] - buf[:, 0]).astype(np.float64) * 10.0          # ns
+ok = dur > 2000
+print("shader clock over a wave's life (s_memtime / s_memrealtime): median %.3f GHz  p10 %.3f  p90 %.3f" %
+      tuple(np.percentile(cyc[ok] / dur[ok], [50, 10, 90])))
+m = (role == 2) & (phs[:, 1] > 0)
+l0 = (phs[m, 0] >> np.uint64(40)).astype(np.float64) / 100.0          # start -> records
+l1 = (phs[m, 1] - buf[m, 0]).astype(np.float64) / 100.0 - l0        # records -> rows
+rp = (phs[m, 2] - phs[m, 1]).astype(np.float64) / 100.0
+fin = (buf[m, 1] - phs[m, 2]).astype(np.float64) / 100.0
+steps = phs[m, 3].astype(np.float64)
+print("interaction phases (us): level-1 %.2f/%.2f  level-2 %.2f/%.2f  replay %.2f/%.2f  finish %.2f/%.2f  (median/p90); row-steps median %.0f mean %.0f max %.0f"
+      % (np.median(l0), np.percentile(l0, 90), np.median(l1), np.percentile(l1, 90), np.median(rp), np.percentile(rp, 90),
+         np.median(fin), np.percentile(fin, 90), np.median(steps), steps.mean(), steps.max()))
+ok = steps > 20
+print("replay us per row-step: median %.4f  p10 %.4f p90 %.4f" % (np.median(rp[ok] / steps[ok]), np.percentile(rp[ok] / steps[ok], 10), np.percentile(rp[ok] / steps[ok], 90)))
+raise SystemExit
 m = (role == 2) & (phs[:, 0] > 0)
 l1 = (phs[m, 0] - buf[m, 0]).astype(np.float64) / 100.0
 l2 = (phs[m, 1] - phs[m, 0]).astype(np.float64) / 100.0

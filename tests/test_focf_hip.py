@@ -393,3 +393,34 @@ def test_device_error_flags():
     eng.forward(u2, i, r, torch.tensor(z["sst"][0], device="cuda"))
     with pytest.raises(IndexError):
         eng.check_device_errors()
+
+
+def test_lookahead_stamps_are_the_apply_steps():
+    """Every batch of a fused-step loop is stamped with the optimizer step at which it is applied -- prepared by a side
+    launch many steps ahead or in line, first batch of an epoch (nothing announced before it) included: the sweeper tells a
+    batch's rows from its own by that stamp, and the start order of a step's sweeper tasks is built for the stamped step."""
+    from fairrec.model.fair_recommender.focf import FocfEngine
+    from fairrec.optim import FusedLazyAdam
+    n_users, n_items, D, B = 3001, 501, 64, 512
+    g = torch.Generator().manual_seed(5)
+    eng = FocfEngine((torch.randn(n_users, D, generator=g) * 0.05).cuda(), (torch.randn(n_items, D, generator=g) * 0.05).cuda(),
+                     "value", 0.5, 5.0)
+    FusedLazyAdam(eng, lr=1e-3, weight_decay=1e-3, sweep_period=5)
+    eng.defer_loss = True
+    gender = torch.randint(0, 2, (n_users,), generator=g).float()
+    seen = []
+    for epoch in range(2):
+        batches = []
+        for _ in range(45):
+            u = torch.randint(1, n_users, (B,), generator=g)
+            batches.append((u.cuda(), torch.randint(1, n_items, (B,), generator=g).cuda(),
+                            torch.randint(1, 6, (B,), generator=g).float().cuda(), gender[u].cuda()))
+        for t, (u, i, r, s) in enumerate(batches):
+            queue = [(b[0], b[1], b[3], b[2]) for b in batches[t + 1:t + 21]] or None
+            eng.forward(u, i, r, s, next_batch=queue)
+            assert eng._stash is not None, "the one-launch step must be taken"
+            seen.append((eng._stash[6], eng.U.step + 1))
+            eng.backward_adam()
+        eng.flush()
+    eng.check_device_errors()
+    assert all(a == b for a, b in seen), [x for x in seen if x[0] != x[1]][:5]
