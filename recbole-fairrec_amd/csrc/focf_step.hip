@@ -117,46 +117,75 @@ __device__ __forceinline__ void st_sc1(float* p, float v) {
 // drops it)
 __device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-template <int E>
+// Row accesses of this kernel.  FULL: the embedding size is exactly 64 * E, so no lane is masked off (a masked access is
+// a saveexec / branch / restore around every load and store) and D is a compile-time constant; the pointers are cast to
+// the global address space, so that the compiler emits global_load / global_store with the row's base address in an SGPR
+// pair (the kernel arguments come out of v_readlane as integers: as generic pointers every access is a flat_ one with a
+// 64-bit per-lane address computed in VALU).
+typedef __attribute__((address_space(1))) float gfloat;
+typedef __attribute__((address_space(1))) int32_t gint;
+__device__ __forceinline__ const gfloat* gp(const float* p) { return (const gfloat*)p; }
+__device__ __forceinline__ gfloat* gp(float* p) { return (gfloat*)p; }
+__device__ __forceinline__ const gint* gp(const int32_t* p) { return (const gint*)p; }
+__device__ __forceinline__ gint* gp(int32_t* p) { return (gint*)p; }
+typedef int v4i_ __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) v4i_ gint4;
+struct GInt4Ptr {       // a const int4 array read through the global address space
+    const gint4* p;
+    __device__ __forceinline__ int4 operator[](long long i) const {
+        const v4i_ v = p[i];
+        return make_int4(v.x, v.y, v.z, v.w);
+    }
+};
+__device__ __forceinline__ GInt4Ptr gp(const int4* p) { return GInt4Ptr{(const gint4*)p}; }
+
+__device__ __forceinline__ void st_sc1g(gfloat* p, float v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <int E, bool FULL>
+__device__ __forceinline__ void ldrow(RowFrag<E>& f, const float* base, int D, int lane) {
+    const gfloat* g = gp(base);
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int d = lane + 64 * e;
+        f.x[e] = (FULL || d < D) ? g[d] : 0.f;
+    }
+}
+
+template <int E, bool FULL>
 __device__ __forceinline__ void load_row_sc1(RowFrag<E>& f, const float* base, int D, int lane) {
+    const gfloat* g = gp(base);
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         const int d = lane + 64 * e;
-        f.x[e] = d < D ? ld_sc1(base + d) : 0.f;
+        f.x[e] = (FULL || d < D) ? __hip_atomic_load(g + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
     }
 }
 
-template <int E>
+template <int E, bool FULL>
 __device__ __forceinline__ void store_row_sc1(const RowFrag<E>& f, float* base, int D, int lane) {
+    gfloat* g = gp(base);
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         const int d = lane + 64 * e;
-        if (d < D) st_sc1(base + d, f.x[e]);
+        // (through an opaque register copy: the builtin reads its operand as an integer through memory, and that one access
+        // of another type keeps the whole row structure `f` belongs to out of registers -- 16 bytes per lane of LDS or scratch)
+        float val = f.x[e];
+        asm volatile("" : "+v"(val));
+        if (FULL || d < D) st_sc1g(g + d, val);
     }
 }
 
-// The write-back of a finished table row.  FR_STEP_STORE_MODE: 0 plain (the lines stay dirty in the XCD's L2 until the
-// end-of-kernel release writes them back), 1 nontemporal, 2 write-through (sc1)
-#ifndef FR_STEP_STORE_MODE
-#define FR_STEP_STORE_MODE 0
-#endif
-template <int E>
+// The write-back of a finished table row
+template <int E, bool FULL>
 __device__ __forceinline__ void store_trow(const RowFrag<E>& f, float* base, int D, int lane) {
-#if FR_STEP_STORE_MODE == 0
-    store_row<E>(f, base, D, lane);
-#else
+    gfloat* g = gp(base);
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         const int d = lane + 64 * e;
-        if (d < D) {
-#if FR_STEP_STORE_MODE == 1
-            __builtin_nontemporal_store(f.x[e], base + d);
-#else
-            st_sc1(base + d, f.x[e]);
-#endif
-        }
+        if (FULL || d < D) g[d] = f.x[e];
     }
-#endif
 }
 
 // arrival at a segment's counter; true for the wave whose add came last (it then owns the segment's work)
@@ -170,22 +199,22 @@ __device__ __forceinline__ bool arrive_last(unsigned int* cnt, int n, int lane) 
 }
 
 // Adam step `step` with data gradient g on a caught-up row held in registers; the row is written back once
-template <int E>
+template <int E, bool FULL>
 __device__ __forceinline__ void adam_write(float* Tp, float* Tm, float* Tv, int32_t* Tlast, int D, int step,
                                            const AdamC& c, int row, RowFrag<E>& p, RowFrag<E>& m, RowFrag<E>& v,
                                            const RowFrag<E>& g, float2 s, int lane) {
 #pragma unroll
     for (int e = 0; e < E; ++e) adam_elem(p.x[e], m.x[e], v.x[e], g.x[e], s.x, s.y, c);
-    store_trow<E>(p, Tp + (size_t)row * D, D, lane);
-    store_trow<E>(m, Tm + (size_t)row * D, D, lane);
-    store_trow<E>(v, Tv + (size_t)row * D, D, lane);
+    store_trow<E, FULL>(p, Tp + (size_t)row * D, D, lane);
+    store_trow<E, FULL>(m, Tm + (size_t)row * D, D, lane);
+    store_trow<E, FULL>(v, Tv + (size_t)row * D, D, lane);
     if (lane == 0) Tlast[row] = step;
 }
 
 // g = sum over the members [j0, j0 + n) of a segment, in ascending batch position, of coef[b] * other[b, :] -- the product
 // rounded, then added (embedding_dense_backward's accumulation order), as segment_grad_sum of table.hpp, but on values
 // other waves of this launch handed over: sc1 loads throughout.  One member in flight (rare path: kept lean in registers).
-template <int E>
+template <int E, bool FULL>
 __device__ __forceinline__ void handed_grad_sum(RowFrag<E>& g, int j0, int n, const int32_t* perm, const float* coef,
                                                 const float* other, int D, int lane) {
 #pragma unroll
@@ -207,7 +236,7 @@ __device__ __forceinline__ void handed_grad_sum(RowFrag<E>& g, int j0, int n, co
                 const int t = t0 + q < cnt ? t0 + q : cnt - 1;     // tail: re-read the last member, not added
                 const int b = __builtin_amdgcn_readlane(my_b, t);
                 cb[q] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_c), t));
-                load_row_sc1<E>(o[q], other + (size_t)b * D, D, lane);
+                load_row_sc1<E, FULL>(o[q], other + (size_t)b * D, D, lane);
             }
             {
 #pragma clang fp contract(off)
@@ -263,27 +292,27 @@ __device__ __forceinline__ void replay_two(TwoRows<E>& r, int tA, int tB, int up
 // ---- rare path ----------------------------------------------------------------------------------------------------
 // The last wave to arrive at a user segment: sum the members' gradient rows coef[b] * (item row of b before its update),
 // one Adam step on the user's caught-up row (parked by its first member), write back.
-template <int E>
+template <int E, bool FULL>
 __device__ __forceinline__ void user_finish(KV kv, const AdamC& c, const FocfWs& w, int j0u, int nu, float2 s, int lane) {
-    const int D = KA(D);
+    const int D = FULL ? 64 * E : KA(D);
     const int c0 = uniform(w.perm_u[j0u]);
     const int ur = uniform(w.rec[c0].x);
     RowFrag<E> p, m, v, g;
-    load_row_sc1<E>(p, w.side[0] + (size_t)c0 * D, D, lane);
-    load_row_sc1<E>(m, w.side[1] + (size_t)c0 * D, D, lane);
-    load_row_sc1<E>(v, w.side[2] + (size_t)c0 * D, D, lane);
-    handed_grad_sum<E>(g, j0u, nu, w.perm_u, w.coef, w.side[3], D, lane);
-    adam_write<E>(KA(Up), KA(Um), KA(Uv), KA(Ulast), D, KA(step), c, ur, p, m, v, g, s, lane);
+    load_row_sc1<E, FULL>(p, w.side[0] + (size_t)c0 * D, D, lane);
+    load_row_sc1<E, FULL>(m, w.side[1] + (size_t)c0 * D, D, lane);
+    load_row_sc1<E, FULL>(v, w.side[2] + (size_t)c0 * D, D, lane);
+    handed_grad_sum<E, FULL>(g, j0u, nu, w.perm_u, w.coef, w.side[3], D, lane);
+    adam_write<E, FULL>(KA(Up), KA(Um), KA(Uv), KA(Ulast), D, KA(step), c, ur, p, m, v, g, s, lane);
 }
 
 // The rest of an interaction whose user or item row is shared with other interactions of the batch: hand over, then
 // whoever arrives last at a segment finishes it (3 % / 8 % of the interactions for uniform pairs at the BASELINE sizes).
-template <int E>
+template <int E, bool FULL>
 __device__ __forceinline__ void step_shared_rows(KV kv, const AdamC& c, int b, int lane, int ur, int ir, int iux, int iix,
                                                  int seg_u, int seg_i, float dot, float coef, float smin, float smax,
                                                  float K, RowFrag<E>& pu, RowFrag<E>& mu, RowFrag<E>& vu, RowFrag<E>& pi,
                                                  RowFrag<E>& mi, RowFrag<E>& vi) {
-    const int D = KA(D);
+    const int D = FULL ? 64 * E : KA(D);
     const bool fair = KA(objective) != FR_FOCF_NONE;
     const int nu = iux >> 16, ni = iix >> 16, j0u = iux & 0xffff, j0i = iix & 0xffff;
     const float2 s = step_scalars(c, KA(step));
@@ -294,19 +323,19 @@ __device__ __forceinline__ void step_shared_rows(KV kv, const AdamC& c, int b, i
     const FocfWs w = focf_layout(KA(ws), Bq, D);
 
     const size_t so = (size_t)b * D;
-    store_row_sc1<E>(pu, w.side[0] + so, D, lane);
-    store_row_sc1<E>(mu, w.side[1] + so, D, lane);
-    store_row_sc1<E>(vu, w.side[2] + so, D, lane);
-    if (nu > 1) store_row_sc1<E>(pi, w.side[3] + so, D, lane);     // the item row BEFORE its update: users' gradients
+    store_row_sc1<E, FULL>(pu, w.side[0] + so, D, lane);
+    store_row_sc1<E, FULL>(mu, w.side[1] + so, D, lane);
+    store_row_sc1<E, FULL>(vu, w.side[2] + so, D, lane);
+    if (nu > 1) store_row_sc1<E, FULL>(pi, w.side[3] + so, D, lane);     // the item row BEFORE its update: users' gradients
     if (ni == 1) {
         // item level is this wave alone; the user has other members
         RowFrag<E> gi;
 #pragma unroll
         for (int e = 0; e < E; ++e) gi.x[e] = coef * pu.x[e];
-        adam_write<E>(KA(Ip), KA(Im), KA(Iv), KA(Ilast), D, KA(step), c, ir, pi, mi, vi, gi, s, lane);
+        adam_write<E, FULL>(KA(Ip), KA(Im), KA(Iv), KA(Ilast), D, KA(step), c, ir, pi, mi, vi, gi, s, lane);
         if (lane == 0) st_sc1(w.coef + b, coef);
         drain_stores();
-        if (arrive_last(w.cnt_u + seg_u, nu, lane)) user_finish<E>(kv, c, w, j0u, nu, s, lane);
+        if (arrive_last(w.cnt_u + seg_u, nu, lane)) user_finish<E, FULL>(kv, c, w, j0u, nu, s, lane);
         return;
     }
     if (lane == 0) st_sc1(w.pred + b, dot);
@@ -398,9 +427,9 @@ __device__ __forceinline__ void step_shared_rows(KV kv, const AdamC& c, int b, i
                 nq[q] = __builtin_amdgcn_readlane(my_iux, t) >> 16;
                 cq[q] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_c), t));
                 const size_t sq = (size_t)bq * D;
-                load_row_sc1<E>(p[q], w.side[0] + sq, D, lane);
-                load_row_sc1<E>(m[q], w.side[1] + sq, D, lane);
-                load_row_sc1<E>(v[q], w.side[2] + sq, D, lane);
+                load_row_sc1<E, FULL>(p[q], w.side[0] + sq, D, lane);
+                load_row_sc1<E, FULL>(m[q], w.side[1] + sq, D, lane);
+                load_row_sc1<E, FULL>(v[q], w.side[2] + sq, D, lane);
             }
 #pragma unroll
             for (int q = 0; q < UN; ++q) {
@@ -417,12 +446,12 @@ __device__ __forceinline__ void step_shared_rows(KV kv, const AdamC& c, int b, i
                     RowFrag<E> gu;
 #pragma unroll
                     for (int e = 0; e < E; ++e) gu.x[e] = cq[q] * pi.x[e];
-                    adam_write<E>(KA(Up), KA(Um), KA(Uv), KA(Ulast), D, KA(step), c, uq[q], p[q], m[q], v[q], gu, s, lane);
+                    adam_write<E, FULL>(KA(Up), KA(Um), KA(Uv), KA(Ulast), D, KA(step), c, uq[q], p[q], m[q], v[q], gu, s, lane);
                 }
             }
         }
     }
-    adam_write<E>(KA(Ip), KA(Im), KA(Iv), KA(Ilast), D, KA(step), c, ir, pi, mi, vi, gi, s, lane);
+    adam_write<E, FULL>(KA(Ip), KA(Im), KA(Iv), KA(Ilast), D, KA(step), c, ir, pi, mi, vi, gi, s, lane);
     if (!shared_users) return;
     // ---- members whose user has other interactions in the batch: arrive at the user's counter (this member's dLoss/dpred
     // and item row are in memory once the stores above have drained); whoever arrives last finishes that user
@@ -436,7 +465,7 @@ __device__ __forceinline__ void step_shared_rows(KV kv, const AdamC& c, int b, i
             todo &= todo - 1;
             const int iq = __builtin_amdgcn_readlane(my_iux, t);
             const int sg = __builtin_amdgcn_readlane(my_seg, t);
-            if (arrive_last(w.cnt_u + sg, iq >> 16, lane)) user_finish<E>(kv, c, w, iq & 0xffff, iq >> 16, s, lane);
+            if (arrive_last(w.cnt_u + sg, iq >> 16, lane)) user_finish<E, FULL>(kv, c, w, iq & 0xffff, iq >> 16, s, lane);
         }
     }
 }
@@ -469,10 +498,10 @@ __device__ __forceinline__ void focf_fair_single(int objective, float fair_weigh
 // One interaction with both rows caught up (x.A = its user row, x.B = its item row): score, squared error, dLoss/dpred,
 // and -- when nobody else in the batch touches either row -- both gradients and both Adam steps, the two rows as packed
 // pairs.  iux / iix = (j0 | n << 16) of its user / item segment, segs = user segment | item segment << 16, b = position.
-template <int E>
+template <int E, bool FULL>
 __device__ __forceinline__ void step_finish(KV kv, const AdamC& c, int lane, int q, RowFrag<E>& pu, RowFrag<E>& mu,
                                             RowFrag<E>& vu, RowFrag<E>& pi, RowFrag<E>& mi, RowFrag<E>& vi) {
-    const int D = KA(D);
+    const int D = FULL ? 64 * E : KA(D);
     const bool fair = KA(objective) != FR_FOCF_NONE;
     // the interaction's records again (scalar loads, cache hits): nothing of them was kept across the replay
     const int4 vrec = KA(task_rec)[q], vinf = KA(task_info)[q], vhd = *reinterpret_cast<const int4*>(KA(hdr));
@@ -516,19 +545,142 @@ __device__ __forceinline__ void step_finish(KV kv, const AdamC& c, int lane, int
             mu.x[e] = M.x; mi.x[e] = M.y;
             vu.x[e] = V.x; vi.x[e] = V.y;
         }
-        store_trow<E>(pu, KA(Up) + (size_t)ur * D, D, lane);
-        store_trow<E>(mu, KA(Um) + (size_t)ur * D, D, lane);
-        store_trow<E>(vu, KA(Uv) + (size_t)ur * D, D, lane);
-        store_trow<E>(pi, KA(Ip) + (size_t)ir * D, D, lane);
-        store_trow<E>(mi, KA(Im) + (size_t)ir * D, D, lane);
-        store_trow<E>(vi, KA(Iv) + (size_t)ir * D, D, lane);
+        store_trow<E, FULL>(pu, KA(Up) + (size_t)ur * D, D, lane);
+        store_trow<E, FULL>(mu, KA(Um) + (size_t)ur * D, D, lane);
+        store_trow<E, FULL>(vu, KA(Uv) + (size_t)ur * D, D, lane);
+        store_trow<E, FULL>(pi, KA(Ip) + (size_t)ir * D, D, lane);
+        store_trow<E, FULL>(mi, KA(Im) + (size_t)ir * D, D, lane);
+        store_trow<E, FULL>(vi, KA(Iv) + (size_t)ir * D, D, lane);
         if (lane == 0) {
             KA(Ulast)[ur] = KA(step);
             KA(Ilast)[ir] = KA(step);
         }
         return;
     }
-    step_shared_rows<E>(kv, c, b, lane, ur, ir, iux, iix, seg_u, seg_i, dot, coef, smin, smax, K, pu, mu, vu, pi, mi, vi);
+    step_shared_rows<E, FULL>(kv, c, b, lane, ur, ir, iux, iix, seg_u, seg_i, dot, coef, smin, smax, K, pu, mu, vu, pi, mi, vi);
+}
+
+// One Adam step with data gradient coef * (the other row) on an interaction's two rows -- nobody else in the batch touches
+// either -- as packed pairs (user element, item element), and the write-back
+template <int E, bool FULL>
+__device__ __forceinline__ void adam_store_both(KV kv, const AdamC& c, int lane, int ur, int ir, float coef, float2 sc,
+                                                RowFrag<E> pu, RowFrag<E> mu, RowFrag<E> vu, RowFrag<E> pi,
+                                                RowFrag<E> mi, RowFrag<E> vi) {      // rows by value: the caller's stay as they are
+    const int D = FULL ? 64 * E : KA(D);
+#pragma unroll
+    for (int e = 0; e < E; ++e) {       // adam_elem on the pair (user element, item element)
+        v2f_ P = {pu.x[e], pi.x[e]}, M = {mu.x[e], mi.x[e]}, V = {vu.x[e], vi.x[e]};
+        const v2f_ G = __builtin_elementwise_fma(v2f_{c.wd, c.wd}, P, v2f_{coef * P.y, coef * P.x});
+        M = __builtin_elementwise_fma(v2f_{c.omb1, c.omb1}, G - M, M);
+        V = __builtin_elementwise_fma(G * c.omb2, G, V * c.b2);
+        const v2f_ den = __builtin_elementwise_fma(v2f_{__builtin_amdgcn_sqrtf(V.x), __builtin_amdgcn_sqrtf(V.y)},
+                                                  v2f_{sc.y, sc.y}, v2f_{c.eps, c.eps});
+        P = __builtin_elementwise_fma(M * -sc.x, v2f_{__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)}, P);
+        pu.x[e] = P.x; pi.x[e] = P.y;
+        mu.x[e] = M.x; mi.x[e] = M.y;
+        vu.x[e] = V.x; vi.x[e] = V.y;
+    }
+    store_trow<E, FULL>(pu, KA(Up) + (size_t)ur * D, D, lane);
+    store_trow<E, FULL>(mu, KA(Um) + (size_t)ur * D, D, lane);
+    store_trow<E, FULL>(vu, KA(Uv) + (size_t)ur * D, D, lane);
+    store_trow<E, FULL>(pi, KA(Ip) + (size_t)ir * D, D, lane);
+    store_trow<E, FULL>(mi, KA(Im) + (size_t)ir * D, D, lane);
+    store_trow<E, FULL>(vi, KA(Iv) + (size_t)ir * D, D, lane);
+    if (lane == 0) {
+        gp(KA(Ulast))[ur] = KA(step);
+        gp(KA(Ilast))[ir] = KA(step);
+    }
+}
+
+// The two interactions of a pair wave with their rows caught up (us.A / is.A = user and item row of interaction q, us.B /
+// is.B of interaction q + 1), finished TOGETHER: their records in one batch of loads, the two scores through one
+// interleaved butterfly, and everything that is one value per interaction (error, dLoss/dpred, the fairness term of a
+// one-member item with its IEEE divisions) computed once, lane parity choosing the interaction -- each as step_finish
+// does it for one, same operations, same bits.
+template <int E, bool FULL>
+__device__ __forceinline__ void step_finish_pair(KV kv, const AdamC& c, int lane, int q, bool has1, TwoRows<E> us,
+                                                 TwoRows<E> is) {
+    const int obj = KA(objective);
+    const bool fair = obj != FR_FOCF_NONE;
+    const int q1 = has1 ? q + 1 : q;
+    const GInt4Ptr trec = gp(KA(task_rec));
+    const GInt4Ptr tinf = gp(KA(task_info));
+    const int4 vr0 = trec[q], vr1 = trec[q1], vi0 = tinf[q], vi1 = tinf[q1];
+    const int4 vhd = gp(reinterpret_cast<const int4*>(KA(hdr)))[0];
+    float d0 = 0.f, d1 = 0.f;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        d0 = fmaf(us.pA.x[e], is.pA.x[e], d0);
+        d1 = fmaf(us.pB.x[e], is.pB.x[e], d1);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {      // wave_sum of both
+        const float y0 = __shfl_xor(d0, o, 64), y1 = __shfl_xor(d1, o, 64);
+        d0 += y0;
+        d1 += y1;
+    }
+    // ---- per interaction, in the lanes of its parity
+    const bool odd = (lane & 1) != 0;
+    // (component by component: a select between two int4 structs is lowered through memory)
+    const int rec_z = odd ? vr1.z : vr0.z, rec_w = odd ? vr1.w : vr0.w;
+    const int inf_y = odd ? vi1.y : vi0.y, inf_z = odd ? vi1.z : vi0.z, inf_w = odd ? vi1.w : vi0.w;
+    const float dot = odd ? d1 : d0;
+    const float rt = __int_as_float(rec_z), sst = __int_as_float(rec_w);
+    const float K = (float)vhd.x, smin = __int_as_float(vhd.z), smax = __int_as_float(vhd.w);
+    const int ni_l = inf_y >> 16;
+    const float er = dot - rt;
+    const float cm = 2.f * er / (float)KA(B);        // d mean((pred - r)^2) / d pred
+    float coef = cm, term = 0.f;
+    const bool single = fair && ni_l == 1;            // the item's per-item statistics are this interaction's own
+    if (fair) {
+        float g;
+        focf_fair_single(obj, KA(fair_weight), K, sst == smin, dot, rt, term, g);
+        if (single) coef = cm + g;
+    }
+    if (lane < (has1 ? 2 : 1)) {
+        gp(KA(mse_e))[inf_w] = er * er;
+        if (single) {
+            gp(KA(term))[inf_z >> 16] = term;
+            if (sst != smin && sst != smax && KA(err)) atomicOr(KA(err), FR_DEV_ERR_SST_GROUPS);
+        }
+    }
+    // ---- back to wave-uniform values
+    const float coef0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, coef), 0));
+    const float coef1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, coef), 1));
+    const int ur0 = uniform(vr0.x), ir0 = uniform(vr0.y), ur1 = uniform(vr1.x), ir1 = uniform(vr1.y);
+    const int iux0 = uniform(vi0.x), iix0 = uniform(vi0.y), iux1 = uniform(vi1.x), iix1 = uniform(vi1.y);
+    const bool un0 = (iux0 >> 16) == 1 && (iix0 >> 16) == 1;
+    const bool un1 = has1 && (iux1 >> 16) == 1 && (iix1 >> 16) == 1;
+    const float2 sc = step_scalars(c, KA(step));
+    // rows nobody else touches are finished first (two independent chains when both interactions are of that kind) ...
+    if (un0 && un1) {
+        // (both at once, from plain copies of the twelve fragments: two independent chains for the scheduler)
+        RowFrag<E> a0 = us.pA, a1 = us.mA, a2 = us.vA, a3 = is.pA, a4 = is.mA, a5 = is.vA;
+        RowFrag<E> b0 = us.pB, b1 = us.mB, b2 = us.vB, b3 = is.pB, b4 = is.mB, b5 = is.vB;
+        adam_store_both<E, FULL>(kv, c, lane, ur0, ir0, coef0, sc, a0, a1, a2, a3, a4, a5);
+        adam_store_both<E, FULL>(kv, c, lane, ur1, ir1, coef1, sc, b0, b1, b2, b3, b4, b5);
+        return;
+    }
+    if (un0) adam_store_both<E, FULL>(kv, c, lane, ur0, ir0, coef0, sc, us.pA, us.mA, us.vA, is.pA, is.mA, is.vA);
+    if (un1) adam_store_both<E, FULL>(kv, c, lane, ur1, ir1, coef1, sc, us.pB, us.mB, us.vB, is.pB, is.mB, is.vB);
+    // ... then the hand-offs of shared rows, each a chain of dependent round trips (ONE instance of that path: the second
+    // interaction's rows take the place of the first's)
+    if (un0 && (un1 || !has1)) return;
+    for (int k = 0; k < (has1 ? 2 : 1); ++k) {
+        if (k) {                                      // second turn: the B rows take the A rows' place
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                us.pA.x[e] = us.pB.x[e]; us.mA.x[e] = us.mB.x[e]; us.vA.x[e] = us.vB.x[e];
+                is.pA.x[e] = is.pB.x[e]; is.mA.x[e] = is.mB.x[e]; is.vA.x[e] = is.vB.x[e];
+            }
+        }
+        if (!(k ? un1 : un0)) {
+            const int sg = uniform(k ? vi1.z : vi0.z);
+            step_shared_rows<E, FULL>(kv, c, uniform(k ? vi1.w : vi0.w), lane, k ? ur1 : ur0, k ? ir1 : ir0, k ? iux1 : iux0,
+                                      k ? iix1 : iix0, sg & 0xffff, sg >> 16, k ? d1 : d0, k ? coef1 : coef0, smin, smax, K,
+                                      us.pA, us.mA, us.vA, is.pA, is.mA, is.vA);
+        }
+    }
 }
 
 #if FR_STEP_TRACE
@@ -538,7 +690,7 @@ __device__ __forceinline__ void step_finish(KV kv, const AdamC& c, int lane, int
 // A wave's task is "two rows brought up to date, then something done with them":
 //   sweeper task q  : rows 2q, 2q + 1 of the step's slice (users first, then items), written back at step `step`;
 //   interaction b   : its user row and item row as of step - 1, then score, dLoss/dpred, both gradients, both updates.
-template <int E, bool PAIR>
+template <int E, bool FULL, bool PAIR>
 __device__ __forceinline__ void step_task(KV kv, bool sweeper, int q, int n_pairs, int lane
 #if FR_STEP_TRACE
                                           , unsigned long long (&phase_stamps)[4]
@@ -550,7 +702,7 @@ __device__ __forceinline__ void step_task(KV kv, bool sweeper, int q, int n_pair
     AdamC c;
     c.sc = KAC(sc); c.cap = KAC(cap); c.wd = KAC(wd); c.b1 = KAC(b1); c.omb1 = KAC(omb1); c.b2 = KAC(b2); c.omb2 = KAC(omb2);
     c.eps = KAC(eps); c.k1 = KAC(k1); c.k2 = KAC(k2); c.inv_k1 = KAC(inv_k1); c.inv_k2 = KAC(inv_k2);
-    const int D = KA(D);
+    const int D = FULL ? 64 * E : KA(D);
     TwoRows<E> r;
     int tA, tB;
     if (sweeper) {
@@ -573,30 +725,30 @@ __device__ __forceinline__ void step_task(KV kv, bool sweeper, int q, int n_pair
         int32_t* Tl = inU ? KA(Ulast) : KA(Ilast);
         const int32_t* Ts = inU ? KA(Ustamp) : KA(Istamp);
         // stamps, `last` and the rows in ONE round trip (a row is wasted for the few that are skipped)
-        const int sa = Ts[rowA], sb = Ts[rowB];
-        const int la = Tl[rowA], lb = Tl[rowB];
-        load_row<E>(r.pA, Tp + (size_t)rowA * D, D, lane);
-        load_row<E>(r.mA, Tm + (size_t)rowA * D, D, lane);
-        load_row<E>(r.vA, Tv + (size_t)rowA * D, D, lane);
-        load_row<E>(r.pB, Tp + (size_t)rowB * D, D, lane);
-        load_row<E>(r.mB, Tm + (size_t)rowB * D, D, lane);
-        load_row<E>(r.vB, Tv + (size_t)rowB * D, D, lane);
+        const int sa = gp(Ts)[rowA], sb = gp(Ts)[rowB];
+        const int la = gp((const int32_t*)Tl)[rowA], lb = gp((const int32_t*)Tl)[rowB];
+        ldrow<E, FULL>(r.pA, Tp + (size_t)rowA * D, D, lane);
+        ldrow<E, FULL>(r.mA, Tm + (size_t)rowA * D, D, lane);
+        ldrow<E, FULL>(r.vA, Tv + (size_t)rowA * D, D, lane);
+        ldrow<E, FULL>(r.pB, Tp + (size_t)rowB * D, D, lane);
+        ldrow<E, FULL>(r.mB, Tm + (size_t)rowB * D, D, lane);
+        ldrow<E, FULL>(r.vB, Tv + (size_t)rowB * D, D, lane);
         const int upto = KA(step);
         tA = uniform(sa) >= KA(skip_from) ? upto : uniform(la);
         tB = (!hasB || uniform(sb) >= KA(skip_from)) ? upto : uniform(lb);
         const bool doA = tA < upto, doB = tB < upto;
         replay_two<E>(r, tA, tB, upto, c, lane);
         if (doA) {
-            store_trow<E>(r.pA, Tp + (size_t)rowA * D, D, lane);
-            store_trow<E>(r.mA, Tm + (size_t)rowA * D, D, lane);
-            store_trow<E>(r.vA, Tv + (size_t)rowA * D, D, lane);
-            if (lane == 0) Tl[rowA] = upto;
+            store_trow<E, FULL>(r.pA, Tp + (size_t)rowA * D, D, lane);
+            store_trow<E, FULL>(r.mA, Tm + (size_t)rowA * D, D, lane);
+            store_trow<E, FULL>(r.vA, Tv + (size_t)rowA * D, D, lane);
+            if (lane == 0) gp(Tl)[rowA] = upto;
         }
         if (doB) {
-            store_trow<E>(r.pB, Tp + (size_t)rowB * D, D, lane);
-            store_trow<E>(r.mB, Tm + (size_t)rowB * D, D, lane);
-            store_trow<E>(r.vB, Tv + (size_t)rowB * D, D, lane);
-            if (lane == 0) Tl[rowB] = upto;
+            store_trow<E, FULL>(r.pB, Tp + (size_t)rowB * D, D, lane);
+            store_trow<E, FULL>(r.mB, Tm + (size_t)rowB * D, D, lane);
+            store_trow<E, FULL>(r.vB, Tv + (size_t)rowB * D, D, lane);
+            if (lane == 0) gp(Tl)[rowB] = upto;
         }
         return;
     }
@@ -606,25 +758,26 @@ __device__ __forceinline__ void step_task(KV kv, bool sweeper, int q, int n_pair
         // and step); each interaction is then finished on its own
         const bool has1 = q + 1 < KA(B);
         const int q1 = has1 ? q + 1 : q;
-        const int4 vrec0 = KA(task_rec)[q], vrec1 = KA(task_rec)[q1];
+        const int4 vrec0 = gp(KA(task_rec))[q], vrec1 = gp(KA(task_rec))[q1];
         const int u0 = uniform(vrec0.x), i0 = uniform(vrec0.y), u1 = uniform(vrec1.x), i1 = uniform(vrec1.y);
 #if FR_STEP_TRACE
         g_phase[2] = __builtin_amdgcn_s_memrealtime();     // level-1 records have arrived
 #endif
-        const int lu0 = KA(Ulast)[u0], lu1 = KA(Ulast)[u1], li0 = KA(Ilast)[i0], li1 = KA(Ilast)[i1];
+        const int lu0 = gp((const int32_t*)KA(Ulast))[u0], lu1 = gp((const int32_t*)KA(Ulast))[u1];
+        const int li0 = gp((const int32_t*)KA(Ilast))[i0], li1 = gp((const int32_t*)KA(Ilast))[i1];
         TwoRows<E> it;       // r = the two user rows, it = the two item rows
-        load_row<E>(r.pA, KA(Up) + (size_t)u0 * D, D, lane);
-        load_row<E>(r.pB, KA(Up) + (size_t)u1 * D, D, lane);
-        load_row<E>(it.pA, KA(Ip) + (size_t)i0 * D, D, lane);
-        load_row<E>(it.pB, KA(Ip) + (size_t)i1 * D, D, lane);
-        load_row<E>(r.mA, KA(Um) + (size_t)u0 * D, D, lane);
-        load_row<E>(r.vA, KA(Uv) + (size_t)u0 * D, D, lane);
-        load_row<E>(r.mB, KA(Um) + (size_t)u1 * D, D, lane);
-        load_row<E>(r.vB, KA(Uv) + (size_t)u1 * D, D, lane);
-        load_row<E>(it.mA, KA(Im) + (size_t)i0 * D, D, lane);
-        load_row<E>(it.vA, KA(Iv) + (size_t)i0 * D, D, lane);
-        load_row<E>(it.mB, KA(Im) + (size_t)i1 * D, D, lane);
-        load_row<E>(it.vB, KA(Iv) + (size_t)i1 * D, D, lane);
+        ldrow<E, FULL>(r.pA, KA(Up) + (size_t)u0 * D, D, lane);
+        ldrow<E, FULL>(r.pB, KA(Up) + (size_t)u1 * D, D, lane);
+        ldrow<E, FULL>(it.pA, KA(Ip) + (size_t)i0 * D, D, lane);
+        ldrow<E, FULL>(it.pB, KA(Ip) + (size_t)i1 * D, D, lane);
+        ldrow<E, FULL>(r.mA, KA(Um) + (size_t)u0 * D, D, lane);
+        ldrow<E, FULL>(r.vA, KA(Uv) + (size_t)u0 * D, D, lane);
+        ldrow<E, FULL>(r.mB, KA(Um) + (size_t)u1 * D, D, lane);
+        ldrow<E, FULL>(r.vB, KA(Uv) + (size_t)u1 * D, D, lane);
+        ldrow<E, FULL>(it.mA, KA(Im) + (size_t)i0 * D, D, lane);
+        ldrow<E, FULL>(it.vA, KA(Iv) + (size_t)i0 * D, D, lane);
+        ldrow<E, FULL>(it.mB, KA(Im) + (size_t)i1 * D, D, lane);
+        ldrow<E, FULL>(it.vB, KA(Iv) + (size_t)i1 * D, D, lane);
         const int upto = KA(step) - 1;
         const int tu0 = uniform(lu0), tu1 = uniform(lu1), ti0 = uniform(li0), ti1 = uniform(li1);
 #if FR_STEP_TRACE
@@ -636,32 +789,23 @@ __device__ __forceinline__ void step_task(KV kv, bool sweeper, int q, int n_pair
 #if FR_STEP_TRACE
         g_phase[1] = __builtin_amdgcn_s_memrealtime();     // replay done
 #endif
-        for (int k = 0; k < (has1 ? 2 : 1); ++k) {        // ONE instance of the finish: it works on the A rows
-            if (k) {                                      // second turn: the B rows take the A rows' place
-#pragma unroll
-                for (int e = 0; e < E; ++e) {
-                    r.pA.x[e] = r.pB.x[e]; r.mA.x[e] = r.mB.x[e]; r.vA.x[e] = r.vB.x[e];
-                    it.pA.x[e] = it.pB.x[e]; it.mA.x[e] = it.mB.x[e]; it.vA.x[e] = it.vB.x[e];
-                }
-            }
-            step_finish<E>(kv, c, lane, q + k, r.pA, r.mA, r.vA, it.pA, it.mA, it.vA);
-        }
+        step_finish_pair<E, FULL>(kv, c, lane, q, has1, r, it);
         return;
     }
     // ---- one interaction per wave (wide rows: two interactions' rows would not fit the register budget)
     const int4 vrec = KA(task_rec)[q];
     const int ur = uniform(vrec.x), ir = uniform(vrec.y);
     const int lu = KA(Ulast)[ur], li = KA(Ilast)[ir];
-    load_row<E>(r.pA, KA(Up) + (size_t)ur * D, D, lane);
-    load_row<E>(r.pB, KA(Ip) + (size_t)ir * D, D, lane);
-    load_row<E>(r.mA, KA(Um) + (size_t)ur * D, D, lane);
-    load_row<E>(r.vA, KA(Uv) + (size_t)ur * D, D, lane);
-    load_row<E>(r.mB, KA(Im) + (size_t)ir * D, D, lane);
-    load_row<E>(r.vB, KA(Iv) + (size_t)ir * D, D, lane);
+    ldrow<E, FULL>(r.pA, KA(Up) + (size_t)ur * D, D, lane);
+    ldrow<E, FULL>(r.pB, KA(Ip) + (size_t)ir * D, D, lane);
+    ldrow<E, FULL>(r.mA, KA(Um) + (size_t)ur * D, D, lane);
+    ldrow<E, FULL>(r.vA, KA(Uv) + (size_t)ur * D, D, lane);
+    ldrow<E, FULL>(r.mB, KA(Im) + (size_t)ir * D, D, lane);
+    ldrow<E, FULL>(r.vB, KA(Iv) + (size_t)ir * D, D, lane);
     tA = uniform(lu);
     tB = uniform(li);
     replay_two<E>(r, tA, tB, KA(step) - 1, c, lane);
-    step_finish<E>(kv, c, lane, q, r.pA, r.mA, r.vA, r.pB, r.mB, r.vB);
+    step_finish<E, FULL>(kv, c, lane, q, r.pA, r.mA, r.vA, r.pB, r.mB, r.vB);
 }
 
 // fixed-order reduction of one batch's squared errors and per-item terms -> loss (one workgroup of 256 threads).  The
@@ -742,7 +886,7 @@ __device__ int g_trace_step = -1;      // >= 0: only the launch that applies thi
 #define FR_STEP_WPB 4        // waves (= tasks) per workgroup: the granule the hardware dispatcher hands to a CU
 #endif
 constexpr int STEP_WPB = FR_STEP_WPB;
-template <int E>
+template <int E, bool FULL>
 __global__ __launch_bounds__(64 * STEP_WPB, FR_STEP_WAVES) void focf_step_kernel(StepArgs a) {
 #if FR_STEP_TRACE
     const unsigned long long tr0 = __builtin_amdgcn_s_memrealtime();
@@ -770,9 +914,9 @@ __global__ __launch_bounds__(64 * STEP_WPB, FR_STEP_WAVES) void focf_step_kernel
         const int q = ((sweeper ? x - a.lead : (x < a.lead ? x : x - ns)) * STEP_WPB + wib) * (!sweeper && PAIR ? 2 : 1);
         role = sweeper ? 1 : 2;
 #if FR_STEP_TRACE
-        if (q < (sweeper ? n_pairs : a.B)) step_task<E, PAIR>(kv, sweeper, q, n_pairs, lane, ph);
+        if (q < (sweeper ? n_pairs : a.B)) step_task<E, FULL, PAIR>(kv, sweeper, q, n_pairs, lane, ph);
 #else
-        if (q < (sweeper ? n_pairs : a.B)) step_task<E, PAIR>(kv, sweeper, q, n_pairs, lane);
+        if (q < (sweeper ? n_pairs : a.B)) step_task<E, FULL, PAIR>(kv, sweeper, q, n_pairs, lane);
 #endif
     }
 #if FR_STEP_TRACE
@@ -1179,7 +1323,11 @@ extern "C" int fr_focf_step(const fr_table* U, const fr_table* I, const fr_adam*
         const long long inter_blocks = ((B + per_wave - 1) / per_wave + STEP_WPB - 1) / STEP_WPB;
         const unsigned blocks = (unsigned)(1 + (sweep_waves + STEP_WPB - 1) / STEP_WPB + inter_blocks);
         a.lead = (int)(inter_blocks * lead_pct / 100);
-        FR_DISPATCH_E(U->dim, FR_LAUNCH(prof, (focf_step_kernel<E>), dim3(blocks), dim3(64 * STEP_WPB), 0, stream, a));
+        if (U->dim % 64 == 0) {
+            FR_DISPATCH_E(U->dim, FR_LAUNCH(prof, (focf_step_kernel<E, true>), dim3(blocks), dim3(64 * STEP_WPB), 0, stream, a));
+        } else {
+            FR_DISPATCH_E(U->dim, FR_LAUNCH(prof, (focf_step_kernel<E, false>), dim3(blocks), dim3(64 * STEP_WPB), 0, stream, a));
+        }
     }
     FR_CHECK_LAUNCH();
     return FR_OK;
