@@ -521,6 +521,35 @@ FR_API int fr_nfcf_loss(const float* y, const float* label, const float* sst, in
                         size_t item_ws_bytes, int32_t dim, float* out, float* dy, float* loss, void* ws, size_t ws_bytes,
                         uint32_t* err_flag, void* stream);
 
+/* The differential-fairness term (nfcf.py:76-97) of a ROW-SHARDED step on the GLOBAL batch (one process per GPU, item
+ * table row r on rank r mod G): M[k, g], K and the mean of eps are statistics of the whole batch, so every positive row's
+ * (score, attribute) travels to the owner of its item and the per-(item, group) sums come back -- two all-to-alls that
+ * the caller issues between the three launches below.  Both buffers have one chunk of `cap` slots + 1 tail per peer:
+ *   rec   [G, cap + 1, 2] floats  slot = (sigmoid score, or -1 where label != 1; attribute), tail = the sender's (min, max)
+ *                                 of the attribute over its positive rows
+ *   reply [G, cap + 1, 4] floats  slot = (S0 with the sign bit set on the ONE member that reports the item's eps, S1, n0, n1),
+ *                                 tail = (K_owner = owned items with a positive row, smin, smax, 0)
+ * A row's slot is the one its item id took in the lookup's id exchange: slot[b] = o * slot_stride + slot_off + k
+ * (fr_bucket_by_owner), i.e. chunk o, position k.
+ *   fr_nfcf_df_pack  (requester) writes the records of this rank's B rows and the tails.
+ *   fr_nfcf_df_owner (owner) reduces over the segments of the ids it received (`item_ws` = the item table's workspace after
+ *                    fr_table_gather_train on the G * cap received slots; members in rank order, then batch position = the
+ *                    order of the concatenated batch) and writes the reply.
+ *   fr_nfcf_df_apply (requester) K = sum of the tails' K_owner; M = (S + 1/K) / (n + 1); eps = |log M0 - log M1|;
+ *                    dy[b] += scale * fair_weight * d(mean eps)/d score_b * out_b (1 - out_b); loss[0] += fair_weight *
+ *                    scale * (sum of the eps this rank reports) / K, loss[2] = that DF share.  scale = G where the caller
+ *                    averages the ranks' gradients and losses (the DF term is not a per-rank mean).
+ * `ws` (fr_nfcf_df_workspace_bytes(B, G * cap), ZERO-initialised once, reusable) holds partial sums and arrival tickets. */
+FR_API size_t fr_nfcf_df_workspace_bytes(int64_t B, int64_t n_slots);
+FR_API int fr_nfcf_df_pack(const float* out, const float* label, const float* sst, const int32_t* slot, int32_t slot_stride,
+                           int32_t slot_off, int32_t cap, int64_t B, int32_t G, float* rec, void* ws, size_t ws_bytes,
+                           void* stream);
+FR_API int fr_nfcf_df_owner(void* item_ws, size_t item_ws_bytes, int32_t dim, const float* rec, int32_t G, int32_t cap,
+                            float* reply, void* ws, size_t ws_bytes, int64_t B, uint32_t* err_flag, void* stream);
+FR_API int fr_nfcf_df_apply(const float* reply, const int32_t* slot, int32_t slot_stride, int32_t slot_off, int32_t cap,
+                            int32_t G, const float* out, const float* label, const float* sst, int64_t B, float fair_weight,
+                            float scale, float* dy, float* loss, void* ws, size_t ws_bytes, void* stream);
+
 /* Dense fused Adam step for small dense parameters (MLP weights, biases): one step of
  * torch.optim.Adam on a flat fp32 tensor, `step` = the step being applied. */
 FR_API int fr_adam_dense(float* p, const float* g, float* m, float* v, int64_t n, const fr_adam* adam, int32_t step,

@@ -205,6 +205,201 @@ __global__ __launch_bounds__(256) void nfcf_finalize_kernel(const float* __restr
     }
 }
 
+
+// ---- differential fairness on the GLOBAL batch of a row-sharded step (one process per GPU) ------------------------------
+// nfcf.py:76-97 computes M[k, g], K and the mean of eps over the whole batch.  With the item table row-sharded, every
+// interaction's (score, label, group) travels to the owner of its item in the slot its item id took in the lookup's id
+// exchange; the owner, whose sorted segments of the received ids ARE the per-item groups of the global batch (members in
+// rank order, then batch position = the order of the concatenated batch), reduces the per-(item, group) sums and sends
+// them back to every member; the requester then forms M, eps and dLoss/dscore for its own rows.  K = sum of the owners'
+// counts of items with a positive row, and the groups present (min, max of the positive rows' attribute) ride in the
+// tails of the two exchanges.  Buffers (one chunk of cap slots + 1 tail per peer rank):
+//   rec   float2 [G, cap + 1]: (score, or -1 for a row with label != 1; attribute); tail = the sender's (min, max)
+//   reply float4 [G, cap + 1]: (S0 | sign bit = "this member reports the item's eps", S1, n0, n1);
+//                              tail = (K_owner, smin, smax, 0)
+__device__ __forceinline__ long long df_phys(int j, int cap) { return (long long)(j / cap) * (cap + 1) + j % cap; }
+
+// requester: records into the slots of the item lookup (slot[b] = o * S + off + k of the packed id exchange)
+__global__ __launch_bounds__(256) void nfcf_df_pack_kernel(const float* __restrict__ out, const float* __restrict__ label,
+                                                           const float* __restrict__ sst, const int32_t* __restrict__ slot,
+                                                           int S, int off, int cap, int B, int G, float2* __restrict__ rec,
+                                                           float* __restrict__ part, unsigned int* __restrict__ ticket) {
+    __shared__ float lo_s[4], hi_s[4];
+    __shared__ bool last;
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    float lo = INFINITY, hi = -INFINITY;
+    if (b < B) {
+        const int sl = slot[b];
+        const bool pos = label[b] == 1.f;
+        const float s = sst[b];
+        rec[(long long)(sl / S) * (cap + 1) + (sl % S - off)] = make_float2(pos ? out[b] : -1.f, s);
+        if (pos) lo = hi = s;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        lo = fminf(lo, __shfl_xor(lo, o, 64));
+        hi = fmaxf(hi, __shfl_xor(hi, o, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        lo_s[threadIdx.x >> 6] = lo;
+        hi_s[threadIdx.x >> 6] = hi;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(part + 2 * blockIdx.x, fminf(fminf(lo_s[0], lo_s[1]), fminf(lo_s[2], lo_s[3])), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(part + 2 * blockIdx.x + 1, fmaxf(fmaxf(hi_s[0], hi_s[1]), fmaxf(hi_s[2], hi_s[3])),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last = t == gridDim.x - 1;
+        if (last) *ticket = 0u;
+    }
+    __syncthreads();
+    if (!last) return;
+    if (threadIdx.x < 64) {      // the last block to arrive: (min, max) over the blocks -> the tail of every chunk
+        lo = INFINITY; hi = -INFINITY;
+        for (int q = threadIdx.x; q < (int)gridDim.x; q += 64) {
+            lo = fminf(lo, __hip_atomic_load(part + 2 * q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            hi = fmaxf(hi, __hip_atomic_load(part + 2 * q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            lo = fminf(lo, __shfl_xor(lo, o, 64));
+            hi = fmaxf(hi, __shfl_xor(hi, o, 64));
+        }
+        for (int g = threadIdx.x; g < G; g += 64) rec[(long long)g * (cap + 1) + cap] = make_float2(lo, hi);
+    }
+}
+
+// owner: per distinct received item (16 lanes) the sums over its positive members, written back to every positive member
+__global__ __launch_bounds__(DF_THREADS) void nfcf_df_owner_kernel(TableWs w, const float2* __restrict__ rec, int G, int cap,
+                                                                   float4* __restrict__ reply, int* __restrict__ kpart,
+                                                                   unsigned int* __restrict__ ticket, uint32_t* err) {
+    const int sub = threadIdx.x & (DF_GROUP - 1), gib = threadIdx.x / DF_GROUP;
+    const int k = blockIdx.x * (DF_THREADS / DF_GROUP) + gib;
+    const int nseg = w.nseg[0];
+    __shared__ float2 mm_sh;
+    __shared__ int cnt[DF_THREADS / DF_GROUP];
+    __shared__ bool last;
+    if (threadIdx.x < 64) {      // the groups present in the global batch: over the G senders' tails
+        float lo = INFINITY, hi = -INFINITY;
+        for (int g = threadIdx.x; g < G; g += 64) {
+            const float2 t = rec[(long long)g * (cap + 1) + cap];
+            lo = fminf(lo, t.x);
+            hi = fmaxf(hi, t.y);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            lo = fminf(lo, __shfl_xor(lo, o, 64));
+            hi = fmaxf(hi, __shfl_xor(hi, o, 64));
+        }
+        if (threadIdx.x == 0) mm_sh = make_float2(lo, hi);
+    }
+    __syncthreads();
+    const float smin = mm_sh.x, smax = mm_sh.y;
+    int has = 0;
+    if (k < nseg) {
+        const int j0 = w.seg_start[k], j1 = w.seg_start[k + 1];
+        float s0 = 0.f, s1 = 0.f, n0 = 0.f, n1 = 0.f;
+        int first = 0x7fffffff;       // sorted position of this lane's first positive member
+        bool bad = false;
+        for (int j = j0 + sub; j < j1; j += DF_GROUP) {
+            const float2 r = rec[df_phys(w.perm[j], cap)];
+            if (r.x >= 0.f) {
+                bad |= (r.y != smin && r.y != smax);
+                if (r.y == smin) { s0 += r.x; n0 += 1.f; }
+                else { s1 += r.x; n1 += 1.f; }
+                first = min(first, j);
+            }
+        }
+        if (bad && err) atomicOr(err, FR_DEV_ERR_SST_GROUPS);
+        s0 = group_sum<DF_GROUP>(s0); s1 = group_sum<DF_GROUP>(s1);
+        n0 = group_sum<DF_GROUP>(n0); n1 = group_sum<DF_GROUP>(n1);
+#pragma unroll
+        for (int o = DF_GROUP / 2; o > 0; o >>= 1) first = min(first, __shfl_xor(first, o, 64));
+        has = (n0 + n1) > 0.f ? 1 : 0;
+        for (int j = j0 + sub; j < j1; j += DF_GROUP) {
+            const long long ph = df_phys(w.perm[j], cap);
+            if (rec[ph].x >= 0.f)
+                reply[ph] = make_float4(j == first ? __uint_as_float(__float_as_uint(s0) | 0x80000000u) : s0, s1, n0, n1);
+        }
+    }
+    if (sub == 0) cnt[gib] = has;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int c = 0;
+#pragma unroll
+        for (int q = 0; q < DF_THREADS / DF_GROUP; ++q) c += cnt[q];
+        __hip_atomic_store(kpart + blockIdx.x, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last = t == gridDim.x - 1;
+        if (last) *ticket = 0u;
+    }
+    __syncthreads();
+    if (!last || threadIdx.x >= 64) return;
+    int c = 0;     // K of this owner: items with a positive row, summed over the blocks in a fixed order
+    for (int q = threadIdx.x; q < (int)gridDim.x; q += 64) c += __hip_atomic_load(kpart + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    for (int g = threadIdx.x; g < G; g += 64) reply[(long long)g * (cap + 1) + cap] = make_float4((float)c, smin, smax, 0.f);
+}
+
+// requester: M, eps and the gradient of fair_weight * DF wrt this rank's positive rows; `scale` = G (the engine averages the
+// ranks' gradients, the DF term is not a per-rank mean).  loss[0] += fair_weight * scale * (sum of the eps this rank
+// reports) / K, so that the mean of the ranks' losses is the loss of the global batch; loss[2] = its DF share.
+__global__ __launch_bounds__(256) void nfcf_df_apply_kernel(const float4* __restrict__ reply, const int32_t* __restrict__ slot,
+                                                            int S, int off, int cap, int G, const float* __restrict__ out,
+                                                            const float* __restrict__ label, const float* __restrict__ sst,
+                                                            int B, float fair_weight, float scale, float* __restrict__ dy,
+                                                            float* __restrict__ loss, float* __restrict__ part,
+                                                            unsigned int* __restrict__ ticket) {
+    __shared__ float red[4];
+    __shared__ bool last;
+    float Kf = 0.f;
+    for (int g = 0; g < G; ++g) Kf += reply[(long long)g * (cap + 1) + cap].x;      // fixed order: the same bits on every rank
+    const float4 tail = reply[cap];
+    const float smin = tail.y, smax = tail.z;
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    float eps_mine = 0.f;
+    if (b < B && label[b] == 1.f && Kf > 0.f && smin != smax) {
+        const int sl = slot[b];
+        const float4 st = reply[(long long)(sl / S) * (cap + 1) + (sl % S - off)];
+        const bool rep = (__float_as_uint(st.x) & 0x80000000u) != 0u;
+        const float S0 = fabsf(st.x);
+        const float alpha = 1.f / Kf;                  // dirichlet_alpha, nfcf.py:85-86
+        const float M0 = (S0 + alpha) / (st.z + 1.f), M1 = (st.y + alpha) / (st.w + 1.f);
+        const float d = __logf(M0) - __logf(M1);
+        const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+        const float g0 = fair_weight * sgn / Kf / M0 / (st.z + 1.f);
+        const float g1 = -fair_weight * sgn / Kf / M1 / (st.w + 1.f);
+        const float o = out[b];
+        dy[b] += scale * ((sst[b] == smin) ? g0 : g1) * o * (1.f - o);   // through the sigmoid
+        if (rep) eps_mine = fabsf(d);
+    }
+    eps_mine = wave_sum(eps_mine);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = eps_mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(part + blockIdx.x, ((red[0] + red[1]) + red[2]) + red[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last = t == gridDim.x - 1;
+        if (last) *ticket = 0u;
+    }
+    __syncthreads();
+    if (!last || threadIdx.x >= 64) return;
+    float e = 0.f;
+    for (int q = threadIdx.x; q < (int)gridDim.x; q += 64) e += __hip_atomic_load(part + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    e = wave_sum(e);
+    if (threadIdx.x == 0) {
+        const float df = (Kf > 0.f && smin != smax) ? scale * e / Kf : 0.f;
+        loss[0] += fair_weight * df;
+        loss[2] = df;
+    }
+}
+
 }  // namespace fr
 
 using namespace fr;
@@ -256,6 +451,76 @@ extern "C" int fr_nfcf_loss(const float* y, const float* label, const float* sst
     }
     hipLaunchKernelGGL(nfcf_finalize_kernel, dim3(1), dim3(256), 0, stream, (const float*)bce_part, nb,
                        (const float*)df_part, df ? ndf : 0, (const float*)kout, (int)B, fair_weight, loss);
+    FR_CHECK_LAUNCH();
+    return FR_OK;
+}
+
+/* ---- differential fairness of a row-sharded NFCF step on the GLOBAL batch (three launches around two all-to-alls) ---- */
+extern "C" size_t fr_nfcf_df_workspace_bytes(int64_t B, int64_t n_slots) {
+    if (B < 1 || n_slots < 1) return 0;
+    const size_t nb = (size_t)(B + 255) / 256;
+    const size_t ndf = (size_t)(n_slots * DF_GROUP + DF_THREADS - 1) / DF_THREADS;
+    return align_up(nb * 8, 256) + align_up(ndf * 4, 256) + align_up(nb * 4, 256) + 256;
+}
+
+struct DfWs {
+    float* mm_part;
+    int* kpart;
+    float* eps_part;
+    unsigned int* ticket;     // [3], kept zero between launches
+};
+static DfWs df_layout(void* ws, int64_t B, int64_t n_slots) {
+    const size_t nb = (size_t)(B + 255) / 256;
+    const size_t ndf = (size_t)(n_slots * DF_GROUP + DF_THREADS - 1) / DF_THREADS;
+    char* p = (char*)ws;
+    DfWs w;
+    w.mm_part = (float*)p; p += align_up(nb * 8, 256);
+    w.kpart = (int*)p; p += align_up(ndf * 4, 256);
+    w.eps_part = (float*)p; p += align_up(nb * 4, 256);
+    w.ticket = (unsigned int*)p;
+    return w;
+}
+
+extern "C" int fr_nfcf_df_pack(const float* out, const float* label, const float* sst, const int32_t* slot, int32_t slot_stride,
+                               int32_t slot_off, int32_t cap, int64_t B, int32_t G, float* rec, void* ws, size_t ws_bytes,
+                               void* stream_) {
+    FR_CHECK_ARG(out && label && sst && slot && rec && ws && B >= 1 && G >= 1 && cap >= 1 && slot_stride >= cap,
+                 "fr_nfcf_df_pack: bad argument");
+    FR_CHECK_ARG(ws_bytes >= fr_nfcf_df_workspace_bytes(B, (int64_t)G * cap), "fr_nfcf_df_pack: workspace too small");
+    const DfWs w = df_layout(ws, B, (int64_t)G * cap);
+    hipLaunchKernelGGL(nfcf_df_pack_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, out, label,
+                       sst, slot, slot_stride, slot_off, cap, (int)B, G, (float2*)rec, w.mm_part, w.ticket);
+    FR_CHECK_LAUNCH();
+    return FR_OK;
+}
+
+extern "C" int fr_nfcf_df_owner(void* item_ws, size_t item_ws_bytes, int32_t dim, const float* rec, int32_t G, int32_t cap,
+                                float* reply, void* ws, size_t ws_bytes, int64_t B, uint32_t* err_flag, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    const int64_t M = (int64_t)G * cap;
+    FR_CHECK_ARG(item_ws && rec && reply && ws && G >= 1 && cap >= 1 && B >= 1, "fr_nfcf_df_owner: bad argument");
+    FR_CHECK_ARG(ws_bytes >= fr_nfcf_df_workspace_bytes(B, M), "fr_nfcf_df_owner: workspace too small");
+    TableWs tw = table_layout(item_ws, M, dim);
+    FR_CHECK_ARG(item_ws_bytes >= tw.bytes, "fr_nfcf_df_owner: item workspace too small");
+    if (int rc = side_join(item_ws, stream)) return rc;     // the owner's sort of the received ids runs on the side stream
+    const DfWs w = df_layout(ws, B, M);
+    const unsigned ndf = (unsigned)((M * DF_GROUP + DF_THREADS - 1) / DF_THREADS);
+    hipLaunchKernelGGL(nfcf_df_owner_kernel, dim3(ndf), dim3(DF_THREADS), 0, stream, tw, (const float2*)rec, G, cap,
+                       (float4*)reply, w.kpart, w.ticket + 1, err_flag);
+    FR_CHECK_LAUNCH();
+    return FR_OK;
+}
+
+extern "C" int fr_nfcf_df_apply(const float* reply, const int32_t* slot, int32_t slot_stride, int32_t slot_off, int32_t cap,
+                                int32_t G, const float* out, const float* label, const float* sst, int64_t B, float fair_weight,
+                                float scale, float* dy, float* loss, void* ws, size_t ws_bytes, void* stream_) {
+    FR_CHECK_ARG(reply && slot && out && label && sst && dy && loss && ws && B >= 1 && G >= 1 && cap >= 1,
+                 "fr_nfcf_df_apply: bad argument");
+    FR_CHECK_ARG(ws_bytes >= fr_nfcf_df_workspace_bytes(B, (int64_t)G * cap), "fr_nfcf_df_apply: workspace too small");
+    const DfWs w = df_layout(ws, B, (int64_t)G * cap);
+    hipLaunchKernelGGL(nfcf_df_apply_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, (hipStream_t)stream_,
+                       (const float4*)reply, slot, slot_stride, slot_off, cap, G, out, label, sst, (int)B, fair_weight, scale,
+                       dy, loss, w.eps_part, w.ticket + 2);
     FR_CHECK_LAUNCH();
     return FR_OK;
 }

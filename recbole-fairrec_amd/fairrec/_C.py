@@ -155,6 +155,13 @@ _PROTOS = {
     "fr_nfcf_loss_workspace_bytes": (c_size_t, [c_int64]),
     "fr_nfcf_loss": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_float, c_void_p, c_size_t, c_int32, c_void_p,
                              c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
+    "fr_nfcf_df_workspace_bytes": (c_size_t, [c_int64, c_int64]),
+    "fr_nfcf_df_pack": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int64, c_int32, c_void_p,
+                                c_void_p, c_size_t, c_void_p]),
+    "fr_nfcf_df_owner": (c_int, [c_void_p, c_size_t, c_int32, c_void_p, c_int32, c_int32, c_void_p, c_void_p, c_size_t,
+                                 c_int64, c_void_p, c_void_p]),
+    "fr_nfcf_df_apply": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
+                                 c_int64, c_float, c_float, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "fr_bn_workspace_bytes": (c_size_t, [c_int64, c_int32]),
     "fr_bn_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_float, c_void_p, c_void_p, c_int64, c_int32, c_int32,
                           c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),

@@ -22,7 +22,9 @@ class _NfcfLoss(torch.autograd.Function):
     """loss = BCE(sigmoid(y), label) [+ fair_weight * DF]  via fr_nfcf_loss; backward scales the stored dLoss/dy."""
 
     @staticmethod
-    def forward(ctx, y, label, sst, fair_weight, item_table, err_flag):
+    def forward(ctx, y, label, sst, fair_weight, item_table, err_flag, sharded=None):
+        """`sharded` = (row-sharded engine, item table name): the differential-fairness term is evaluated on the GLOBAL
+        batch (ShardedGenericEngine.global_item_df) instead of on this rank's rows."""
         lib = _C.lib()
         B = y.numel()
         y = y.contiguous().view(-1)
@@ -32,10 +34,13 @@ class _NfcfLoss(torch.autograd.Function):
         loss = torch.empty(3, dtype=torch.float32, device=dev)
         ws = torch.empty(lib.fr_nfcf_loss_workspace_bytes(B), dtype=torch.uint8, device=dev)
         iws = item_table._ws if item_table is not None else None
-        _C.check(lib.fr_nfcf_loss(y.data_ptr(), label.data_ptr(), _C.ptr(sst), B, fair_weight, _C.ptr(iws),
-                                  iws.numel() if iws is not None else 0, item_table.dim if item_table is not None else 1,
+        _C.check(lib.fr_nfcf_loss(y.data_ptr(), label.data_ptr(), _C.ptr(sst) if sharded is None else None, B, fair_weight,
+                                  _C.ptr(iws), iws.numel() if iws is not None else 0,
+                                  item_table.dim if item_table is not None else 1,
                                   out.data_ptr(), dy.data_ptr(), loss.data_ptr(), ws.data_ptr(), ws.numel(),
                                   err_flag.data_ptr(), _C.current_stream()), "fr_nfcf_loss")
+        if sharded is not None:
+            sharded[0].global_item_df(sharded[1], out, label, sst, fair_weight, dy, loss)
         ctx.save_for_backward(dy)
         ctx.shape = y.shape
         ctx.mark_non_differentiable(out)
@@ -46,10 +51,10 @@ class _NfcfLoss(torch.autograd.Function):
     def backward(ctx, g_loss, g_out):
         (dy,) = ctx.saved_tensors
         if g_loss is None:
-            return None, None, None, None, None, None
+            return None, None, None, None, None, None, None
         if _C.is_one(g_loss):               # GraphedStep's seed: nothing to scale by
-            return dy.view(-1, 1), None, None, None, None, None
-        return (dy * g_loss).view(-1, 1), None, None, None, None, None
+            return dy.view(-1, 1), None, None, None, None, None, None
+        return (dy * g_loss).view(-1, 1), None, None, None, None, None, None
 
 
 class NFCF(FairRecommender):
@@ -143,6 +148,11 @@ class NFCF(FairRecommender):
         y = self._score_logits(user, item)
         finetune = self.load_pretrain_path is not None
         sst = interaction[self.sst_attr].to(dev, torch.float32).contiguous() if finetune else None
+        if finetune and self.shard is not None:
+            # row-sharded tables: the fairness term of the GLOBAL batch (per-group sums reduced on the items' owners)
+            loss, _ = _NfcfLoss.apply(y, label, sst, float(self.fair_weight or 0.0), None, eng.err_flag,
+                                      (eng, "item_embedding.weight"))
+            return loss
         item_table = eng.batch_segments("item_embedding.weight") if finetune else None
         loss, _ = _NfcfLoss.apply(y, label, sst, float(self.fair_weight or 0.0), item_table, eng.err_flag)
         return loss

@@ -10,10 +10,13 @@ state with it; the small dense parameters (MLPs, biases) are replicated and thei
 
 Semantics: every rank feeds its own batch; a step is ONE optimizer step whose embedding and dense gradients are those
 of the mean loss over the G local losses, i.e. the single-device step on the concatenated batch for every loss that is
-a mean over interactions (BCE, MSE, BPR).  Terms that are statistics OF the batch -- BatchNorm inside the PFCN MLPs,
-NFCF's differential-fairness regulariser, the B x B broadcast of PFCN_BiasedMF -- are evaluated per rank on the local
-batch ("parity is defined per-GPU-batch"); FOCF, whose fairness term needs the global per-item
-statistics, has its own exact engine (fairrec/sharded.py).
+a mean over interactions (BCE, MSE, BPR).  NFCF's differential-fairness regulariser is a statistic OF the batch (per-item,
+per-group score sums, the number of items K): `global_item_df` evaluates it on the GLOBAL batch -- every positive row's
+(score, group) goes to the owner of its item in the slot its id took in the lookup, the owner's per-(item, group) sums
+come back, K and the groups present ride in the tails: two small all-to-alls, and a G-rank step equals the single-device
+step on the concatenated batch (nfcf.py:76-97).  BatchNorm inside the PFCN MLPs and the B x B broadcast of PFCN_BiasedMF
+are evaluated per rank on the local batch ("parity is defined per-GPU-batch"); FOCF, whose fairness
+term needs the global per-item statistics, has its own exact engine (fairrec/sharded.py).
 
 Kernels come from an `ops` object (default: HIP through fairrec._C); tests inject a CPU double to run the schedule
 over gloo.  The product path is HIP only.
@@ -76,6 +79,25 @@ class HipTableOps:
     def adam_dense(self, p, g, m, v, hyper, step):
         _C.check(_C.lib().fr_adam_dense(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(),
                                         ctypes.byref(hyper.c()), step, _C.current_stream()), "fr_adam_dense")
+
+    # --- differential fairness on the global batch (fr_nfcf_df_*: fairrec_hip.h) ---------------------------------------
+    def df_pack(self, out, label, sst, slot, S, off, cap, G, rec, ws):
+        _C.check(_C.lib().fr_nfcf_df_pack(out.data_ptr(), label.data_ptr(), sst.data_ptr(), slot.data_ptr(), S, off, cap,
+                                          out.numel(), G, rec.data_ptr(), ws.data_ptr(), ws.numel(), _C.current_stream()),
+                 "fr_nfcf_df_pack")
+
+    def df_owner(self, table, rec, G, cap, reply, ws, B, err):
+        _C.check(_C.lib().fr_nfcf_df_owner(table._ws.data_ptr(), table._ws.numel(), table.dim, rec.data_ptr(), G, cap,
+                                           reply.data_ptr(), ws.data_ptr(), ws.numel(), B, err.data_ptr(),
+                                           _C.current_stream()), "fr_nfcf_df_owner")
+
+    def df_apply(self, reply, slot, S, off, cap, G, out, label, sst, fair_weight, scale, dy, loss, ws):
+        _C.check(_C.lib().fr_nfcf_df_apply(reply.data_ptr(), slot.data_ptr(), S, off, cap, G, out.data_ptr(), label.data_ptr(),
+                                           sst.data_ptr(), out.numel(), fair_weight, scale, dy.data_ptr(), loss.data_ptr(),
+                                           ws.data_ptr(), ws.numel(), _C.current_stream()), "fr_nfcf_df_apply")
+
+    def df_workspace(self, B, n_slots, device):
+        return torch.zeros(_C.lib().fr_nfcf_df_workspace_bytes(B, n_slots), dtype=torch.uint8, device=device)
 
     def sort_local(self, idx, n_rows, dim, holder):
         """Segments of a LOCAL id list in table-workspace layout (per-rank batch statistics, e.g. NFCF's DF term)."""
@@ -373,6 +395,37 @@ class ShardedGenericEngine(GenericEngine):
         for name in names:
             if name in self._lay and self._tables[name].trainable:
                 self._tables[name]._grad_rows = ex.g_recv
+
+    def global_item_df(self, name, out, label, sst, fair_weight, dy, loss):
+        """NFCF's differential-fairness term (nfcf.py:76-97) on the GLOBAL batch, for the rows this rank looked up in table
+        `name` (the item table) in the current step: adds this rank's share of d(fair_weight * DF)/dy to `dy` (scaled by G:
+        the engine averages the ranks' gradients) and of fair_weight * DF to loss[0] (the mean of the ranks' losses is the
+        global loss).  Two all-to-alls of [G, cap + 1] records; K and the groups present ride in their tails."""
+        t, G, ops = self._tables[name], self.G, self.ops
+        lay = getattr(self, "_lay", {}).get(name)
+        if lay is not None:                 # the lookup went through a packed exchange: chunk g = [.. | cap slots of `name` | ..]
+            ex, off = lay
+            S, cap, slot = ex.S, ex.cap, ex.slot[off // ex.cap]
+        else:
+            ex = self._ex[name]
+            S, cap, off, slot = ex.cap, ex.cap, 0, ex.slot
+        B = out.numel()
+        key = (name, B, cap)
+        buf = getattr(self, "_df_buf", {}).get(key)
+        if buf is None:
+            if not hasattr(self, "_df_buf"):
+                self._df_buf = {}
+            n = G * (cap + 1)
+            f32 = torch.float32
+            buf = self._df_buf[key] = dict(
+                rec_send=torch.zeros(n * 2, dtype=f32, device=self.device), rec_recv=torch.zeros(n * 2, dtype=f32, device=self.device),
+                rep_send=torch.zeros(n * 4, dtype=f32, device=self.device), rep_recv=torch.zeros(n * 4, dtype=f32, device=self.device),
+                ws=ops.df_workspace(B, G * cap, self.device))
+        ops.df_pack(out, label, sst, slot, S, off, cap, G, buf["rec_send"], buf["ws"])
+        self._a2a(buf["rec_recv"], buf["rec_send"])
+        ops.df_owner(t, buf["rec_recv"], G, cap, buf["rep_send"], buf["ws"], B, self.err_flag)
+        self._a2a(buf["rep_recv"], buf["rep_send"])
+        ops.df_apply(buf["rep_recv"], slot, S, off, cap, G, out, label, sst, float(fair_weight), float(G), dy, loss, buf["ws"])
 
     def batch_segments(self, name):
         """Sorted segments of THIS rank's ids of the last lookup in `name` (per-rank batch statistics)."""

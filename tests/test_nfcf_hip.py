@@ -195,3 +195,83 @@ def test_reset_params_on_the_device_then_finetune(tmp_path, sharded, request):
     for k, v in model.state_dict().items():
         ref = z[f"after{first}." + k]
         np.testing.assert_allclose(v.cpu().numpy(), ref, rtol=2e-4, atol=1e-5 * max(1.0, float(np.abs(ref).max())), err_msg=k)
+
+
+def test_global_df_kernels_match_their_cpu_doubles():
+    """fr_nfcf_df_pack / _owner / _apply (the differential-fairness term of a row-sharded step on the GLOBAL batch) against
+    the CPU doubles that tests/test_sharded_engine_gloo.py runs the exchange schedule with (and proves equal to the
+    single-process step at 2 and 4 ranks), on a 4-rank layout: this process plays one requester and one owner, the records
+    "received" are another draw of the same shape (no collective here; the 1-rank RCCL goldens run the whole path)."""
+    import sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    from test_sharded_engine_gloo import _Ops, _Table
+    from fairrec.optim import AdamHyper, LazyTable
+    from fairrec.sharded_engine import HipTableOps
+    cpu, hip = _Ops(), HipTableOps()
+    g = torch.Generator().manual_seed(3)
+    G, B, n_items, D = 4, 600, 97, 64
+    cap, S, off = 320, 640, 320                   # the item half of a packed [G, 2 * cap] exchange
+    # requester side: slots of this rank's B rows, counted per owner like fr_bucket_by_owner does
+    item = torch.randint(1, n_items, (B,), generator=g)
+    cnt = [0] * G
+    slot = torch.zeros(B, dtype=torch.int32)
+    for b, it in enumerate(item.tolist()):
+        o = it % G
+        slot[b] = o * S + off + cnt[o]
+        cnt[o] += 1
+    out = torch.rand(B, generator=g) * 0.98 + 0.01
+    label = (torch.rand(B, generator=g) < 0.6).float()
+    sst = (torch.rand(B, generator=g) < 0.5).float()
+    n = G * (cap + 1)
+    rec_c, rec_g = torch.zeros(n * 2), torch.zeros(n * 2, device="cuda")
+    ws = hip.df_workspace(B, G * cap, "cuda")
+    cpu.df_pack(out, label, sst, slot, S, off, cap, G, rec_c, None)
+    hip.df_pack(out.cuda(), label.cuda(), sst.cuda(), slot.cuda(), S, off, cap, G, rec_g, ws)
+    assert torch.equal(rec_c, rec_g.cpu())
+    # owner side: ids received from the four requesters (padding -1), their records, the owner's sorted segments
+    ids = torch.full((G, cap), -1, dtype=torch.int64)
+    recv = torch.zeros(G, cap + 1, 2)
+    for q in range(G):
+        m = int(torch.randint(150, cap, (1,), generator=g))
+        ids[q, :m] = torch.randint(0, 25, (m,), generator=g)                   # local rows: many members per item
+        pos = torch.rand(m, generator=g) < 0.6
+        recv[q, :m, 0] = torch.where(pos, torch.rand(m, generator=g) * 0.98 + 0.01, torch.full((m,), -1.0))
+        recv[q, :m, 1] = (torch.rand(m, generator=g) < 0.5).float()
+        recv[q, cap] = torch.tensor([0.0, 1.0])
+    recv[2, cap] = torch.tensor([1.0, 1.0])                                     # a sender whose positives are all of one group
+    tab_c = _Table(torch.zeros(25, D))
+    tab_c.ids = ids.view(-1)
+    tab_g = LazyTable(torch.zeros(25, D, device="cuda"))
+    tab_g.ensure_state()
+    hyper = AdamHyper(1e-3, 0.0, device="cuda")
+    rows = torch.empty(G * cap, D, device="cuda")
+    err = torch.zeros(1, dtype=torch.int32, device="cuda")
+    tab_g.gather_train_into(hyper, ids.view(-1).cuda().data_ptr(), G * cap, rows.data_ptr(), 0, 0, err)
+    rep_c, rep_g = torch.zeros(n * 4), torch.zeros(n * 4, device="cuda")
+    for rep in range(2):                                                        # the arrival tickets are left clean
+        cpu.df_owner(tab_c, recv.view(-1), G, cap, rep_c, None, B, None)
+        hip.df_owner(tab_g, recv.view(-1).cuda(), G, cap, rep_g, ws, B, err)
+        a, b = rep_c.view(G, cap + 1, 4), rep_g.cpu().view(G, cap + 1, 4)
+        used = (ids >= 0) & (recv[:, :cap, 0] >= 0)
+        assert torch.equal(torch.signbit(a[:, :cap, 0][used]), torch.signbit(b[:, :cap, 0][used]))
+        np.testing.assert_allclose(b[:, :cap][used].numpy(), a[:, :cap][used].numpy(), rtol=1e-6)
+        assert torch.equal(a[:, cap], b[:, cap])                                # K_owner, smin, smax
+    assert int(err.item()) == 0
+    # requester side again: a reply of this rank's layout
+    reply = torch.zeros(G, cap + 1, 4)
+    reply[:, :cap, 0] = torch.rand(G, cap, generator=g) * 3
+    reply[:, :cap, 1] = torch.rand(G, cap, generator=g) * 3
+    reply[:, :cap, 2:] = torch.randint(0, 5, (G, cap, 2), generator=g).float()
+    flip = torch.rand(G, cap, generator=g) < 0.3
+    reply[:, :cap, 0] = torch.where(flip, -reply[:, :cap, 0], reply[:, :cap, 0])
+    reply[:, cap] = torch.tensor([[11.0, 0.0, 1.0, 0.0], [9.0, 0.0, 1.0, 0.0], [0.0, 0.0, 1.0, 0.0], [14.0, 0.0, 1.0, 0.0]])
+    dy0 = torch.randn(B, generator=g) * 1e-3
+    for fw in (0.1, 0.0):
+        dy_c, dy_g = dy0.clone(), dy0.clone().cuda()
+        l_c, l_g = torch.tensor([0.7, 0.7, 0.0]), torch.tensor([0.7, 0.7, 0.0], device="cuda")
+        cpu.df_apply(reply.view(-1), slot, S, off, cap, G, out, label, sst, fw, float(G), dy_c, l_c, None)
+        hip.df_apply(reply.view(-1).cuda(), slot.cuda(), S, off, cap, G, out.cuda(), label.cuda(), sst.cuda(), fw, float(G), dy_g,
+                     l_g, ws)
+        np.testing.assert_allclose(dy_g.cpu().numpy(), dy_c.numpy(), rtol=2e-5, atol=1e-9)
+        np.testing.assert_allclose(l_g.cpu().numpy(), l_c.numpy(), rtol=2e-5)
+    assert int(ws.view(torch.int32)[-64:].abs().sum().item()) == 0             # tickets back at zero

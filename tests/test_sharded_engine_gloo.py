@@ -116,6 +116,56 @@ class _Ops:                        # CPU double of HipTableOps
         from oracle import focf as O
         O.adam_dense_step_(p, g.clone(), m, v, step, hyper.lr, hyper.weight_decay)
 
+    # --- CPU doubles of fr_nfcf_df_pack / _owner / _apply (include/fairrec_hip.h: buffers [G, cap + 1, 2] and [G, cap + 1, 4])
+    def df_workspace(self, B, n_slots, device):
+        return torch.zeros(8, dtype=torch.uint8)
+
+    def df_pack(self, out, label, sst, slot, S, off, cap, G, rec, ws):
+        r = rec.view(G, cap + 1, 2)
+        o, k = (slot // S).long(), (slot % S - off).long()
+        pos = label == 1
+        r[o, k, 0] = torch.where(pos, out, torch.full_like(out, -1.0))
+        r[o, k, 1] = sst
+        r[:, cap, 0] = sst[pos].min() if pos.any() else float("inf")
+        r[:, cap, 1] = sst[pos].max() if pos.any() else float("-inf")
+
+    def df_owner(self, table, rec, G, cap, reply, ws, B, err):
+        r, rp = rec.view(G, cap + 1, 2), reply.view(G, cap + 1, 4)
+        smin, smax = float(r[:, cap, 0].min()), float(r[:, cap, 1].max())
+        ids = table.ids.view(-1)                                    # [G * cap] received ids, -1 = padding
+        score, s = r[:, :cap, 0].reshape(-1), r[:, :cap, 1].reshape(-1)
+        valid = (ids >= 0) & (score >= 0)
+        flat = rp[:, :cap].reshape(-1, 4)
+        K = 0
+        for it in torch.unique(ids[valid]).tolist():
+            mem = torch.nonzero(valid & (ids == it)).view(-1)       # ascending slot = rank, then batch position
+            g0 = s[mem] == smin
+            st = torch.tensor([float(score[mem][g0].sum()), float(score[mem][~g0].sum()), float(g0.sum()), float((~g0).sum())])
+            flat[mem] = st
+            flat[mem[0], 0] = -st[0] if st[0] > 0 else -0.0          # the sign bit: this member reports the item's eps
+            K += 1
+        rp[:, :cap] = flat.view(G, cap, 4)
+        rp[:, cap] = torch.tensor([float(K), smin, smax, 0.0])
+
+    def df_apply(self, reply, slot, S, off, cap, G, out, label, sst, fair_weight, scale, dy, loss, ws):
+        rp = reply.view(G, cap + 1, 4)
+        K, smin, smax = float(rp[:, cap, 0].sum()), float(rp[0, cap, 1]), float(rp[0, cap, 2])
+        if K <= 0 or smin == smax:
+            loss[2] = 0.0
+            return
+        st = rp[(slot // S).long(), (slot % S - off).long()]
+        pos = label == 1
+        rep = torch.signbit(st[:, 0]) & pos
+        S0, S1, n0, n1 = st[:, 0].abs(), st[:, 1], st[:, 2], st[:, 3]
+        M0, M1 = (S0 + 1.0 / K) / (n0 + 1.0), (S1 + 1.0 / K) / (n1 + 1.0)
+        d = torch.log(M0) - torch.log(M1)
+        g = torch.where(sst == smin, fair_weight * torch.sign(d) / K / M0 / (n0 + 1.0),
+                        -fair_weight * torch.sign(d) / K / M1 / (n1 + 1.0))
+        dy += torch.where(pos, scale * g * out * (1 - out), torch.zeros_like(out))
+        df = scale * float(d.abs()[rep].sum()) / K
+        loss[0] += fair_weight * df
+        loss[2] = df
+
 
 def _worker(rank, world, port, out_dir, mode="single"):
     for p in (ROOT, os.path.join(ROOT, "recbole-fairrec_amd"), os.path.join(ROOT, "tests")):
@@ -244,3 +294,88 @@ def test_reset_params_on_row_sharded_tables_matches_the_reference(tmp_path, worl
     for rank in range(world):
         got = np.load(os.path.join(str(tmp_path), f"user{rank}.npy"))
         np.testing.assert_allclose(got, z["init.user_embedding.weight"][rank::world], rtol=1e-5, atol=1e-6)
+
+
+FW = 0.3
+
+
+def _df_data(world):
+    g = torch.Generator().manual_seed(23)
+    lab = (torch.rand(T, world * B, generator=g) < 0.6).float()
+    gender = (torch.rand(NU, generator=g) < 0.5).float()
+    gender[1:3] = torch.tensor([0.0, 1.0])
+    return lab, gender
+
+
+def _df_worker(rank, world, port, out_dir):
+    for p in (ROOT, os.path.join(ROOT, "recbole-fairrec_amd"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import torch.nn.functional as F
+        from fairrec.optim import AdamHyper
+        from fairrec.sharded_engine import ShardedGenericEngine
+        U0, I0, w0, b0, u, i, r = _data(world)
+        lab, gender = _df_data(world)
+        eng = ShardedGenericEngine("cpu", ops=_Ops())
+        Us, Is = U0[rank::world].clone(), I0[rank::world].clone()
+        eng.add_table("U", torch.nn.Parameter(Us, requires_grad=False), table=_Table(Us, trainable=False), n_rows_global=NU)
+        eng.add_table("I", torch.nn.Parameter(Is), table=_Table(Is), n_rows_global=NI)
+        w, b = torch.nn.Parameter(w0.clone()), torch.nn.Parameter(b0.clone())
+        eng.add_dense("w", w)
+        eng.add_dense("b", b)
+        eng.hyper = AdamHyper(LR, WD, device="cpu")
+        losses = []
+        for t in range(T):
+            sl = slice(rank * B, (rank + 1) * B)
+            eng.zero_grad()
+            ue, ie = eng.lookup_pair("U", u[t][sl], "I", i[t][sl])          # NFCF finetune: the user table is frozen
+            y = ((ue * ie) * w).sum(-1) + b
+            out = torch.sigmoid(y)
+            label, sst = lab[t][sl], gender[u[t][sl]]
+            dy, l3 = torch.zeros(B), torch.zeros(3)
+            eng.global_item_df("I", out.detach(), label, sst, FW, dy, l3)
+            loss = F.binary_cross_entropy(out, label) + (y * dy).sum() - (y * dy).sum().detach() + l3[0]
+            loss.backward()
+            eng.backward_adam()
+            losses.append(float(loss))
+        torch.save({"I": Is, "w": w.data, "b": b.data, "loss": losses}, os.path.join(out_dir, f"r{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_global_differential_fairness_equals_single_process(tmp_path, world):
+    """NFCF finetune shape on row-sharded tables: BCE + fair_weight * differential fairness (nfcf.py:76-97).  M[k, g], K and
+    the mean of eps are statistics of the GLOBAL batch: with `global_item_df` (records to the items' owners, per-group sums
+    back, K and the groups present in the tails) the G-rank step must equal the single-process step on the concatenated batch
+    -- same losses (mean of the ranks' losses), same item table, same dense parameters."""
+    import torch.nn.functional as F
+    from oracle import focf as O
+    from oracle import nfcf as ON
+    mp.spawn(_df_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    U0, I0, w0, b0, u, i, r = _data(world)
+    lab, gender = _df_data(world)
+    P = [torch.nn.Parameter(x.clone()) for x in (I0, w0, b0)]
+    ms, vs = [torch.zeros_like(p) for p in P], [torch.zeros_like(p) for p in P]
+    ref_loss = []
+    for t in range(T):
+        for p in P:
+            p.grad = None
+        out = torch.sigmoid(((U0[u[t]] * P[0][i[t]]) * P[1]).sum(-1) + P[2])
+        loss = F.binary_cross_entropy(out, lab[t]) + FW * ON.differential_fairness(out, lab[t], gender[u[t]], i[t])
+        loss.backward()
+        for k, p in enumerate(P):
+            O.adam_dense_step_(p.data, p.grad, ms[k], vs[k], t + 1, LR, WD)
+        ref_loss.append(float(loss))
+    parts = [torch.load(os.path.join(str(tmp_path), f"r{q}.pt")) for q in range(world)]
+    np.testing.assert_allclose(np.mean([p["loss"] for p in parts], axis=0), ref_loss, rtol=1e-5)
+    full = torch.zeros_like(I0)
+    for q in range(world):
+        full[q::world] = parts[q]["I"]
+    np.testing.assert_allclose(full.numpy(), P[0].data.numpy(), rtol=2e-5, atol=1e-7)
+    for q in range(world):
+        np.testing.assert_allclose(parts[q]["w"].numpy(), P[1].data.numpy(), rtol=2e-5, atol=1e-7)
+        np.testing.assert_allclose(parts[q]["b"].numpy(), P[2].data.numpy(), rtol=2e-5, atol=1e-7)
