@@ -45,9 +45,9 @@ class GenericEngine:
         self._counters = None           # graph mode: one device int32 per entry (tables, then dense tensors)
         self._counter_slot: Dict[str, int] = {}
         self._advance_idx: Dict[tuple, torch.Tensor] = {}
+        self._seg_src: dict = {}        # (id tensor, rows) -> the table whose workspace holds that id list's segments, this step only
 
     # --- graph mode: step counters on the device ----------------------------------------------------------
-    _seg_src: dict = {}     # (id tensor, rows) -> the table whose workspace holds that id list's segments, this step only
 
     def enable_graph_mode(self):
         """Move every step counter to device memory, so that a training step captured in a hipGraph advances them on

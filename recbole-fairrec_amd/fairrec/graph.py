@@ -51,8 +51,14 @@ class GraphedStep:
         captured step, not per replay."""
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl":
+            import os
             import time
-            time.sleep(2.0)
+            # every rank's earlier collectives are complete on the device before anyone waits: what is left is the
+            # watchdog's own polling interval (it retires finished work on its next pass, ~100 ms apart); the wait can
+            # be tuned with FAIRREC_RCCL_QUIESCE_S where a node is known to need more (or less)
+            dist.barrier()
+            torch.cuda.synchronize()
+            time.sleep(float(os.environ.get("FAIRREC_RCCL_QUIESCE_S", "2.0")))
 
     def _refresh(self, inter: Interaction):
         """The batch into the static tensors the graph reads: ONE launch for all columns (a copy launch per column is ~5 us
@@ -89,8 +95,16 @@ class GraphedStep:
             torch.cuda.synchronize()
             self._quiesce_rccl()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                self.loss = self._eager(static_inter, args)
+            try:
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    self.loss = self._eager(static_inter, args)
+            except RuntimeError as e:      # an operation that refuses capture: this step object stays eager from here on
+                import warnings
+                warnings.warn(f"hipGraph capture of the training step failed ({e}); running it eagerly")
+                torch.cuda.synchronize()
+                self.engine.sync_steps()
+                self.eager_left = 1 << 60
+                return self._eager(inter, args)
             self.graph = g
             # the host ran the optimizer bookkeeping once during capture without the device doing the step: take the
             # host mirrors back from the device counters

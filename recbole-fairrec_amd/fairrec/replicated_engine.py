@@ -57,8 +57,10 @@ class ReplicatedGenericEngine(GenericEngine):
             self.optimizer, self.sweep_period = None, None
             self.err_flag = torch.zeros(1, dtype=torch.int32, device=self.device)
             self._counters, self._group_version = None, {}
+            self._seg_src = {}
         self._buf: Dict[str, dict] = {}
         self._flat: Optional[torch.Tensor] = None
+        self._synced = None          # (live dense entries, their averaged-gradient views of _flat) between clip and step
 
     def enable_graph_mode(self):
         raise NotImplementedError("collectives inside a captured step are not enabled for the replicated engine: "
@@ -115,23 +117,72 @@ class ReplicatedGenericEngine(GenericEngine):
             s = self.sweep_period if self.sweep_period is not None else max(8, math.ceil(t.n_rows / max(n, 1)))
             self.ops.apply_grad(t, self._hyper(name), n, b["rows"], t._grad_rows, s)
             t._grad_rows = None
+        if self._synced is None:      # (clip_grad_norm has done it already when the optimizer clips)
+            self._sync_dense(group)
+        if self._synced is None:
+            return
+        live, views = self._synced
+        self._synced = None
+        for name, d in live:
+            d.step += 1
+            h = self._hyper(name)
+            h.check_step(d.step)
+            self.ops.adam_dense(d.p.data, views[name], d.m, d.v, h, d.step)
+            d.p.grad = None
+
+    def _sync_dense(self, group=None):
+        """One flat all-reduce (mean over the replicas) of the dense gradients the stepping group owns (SURVEY.md §8-e
+        item 5); kept until backward_adam consumes it."""
         live = [(name, d) for name, d in self._dense.items() if d.p.grad is not None and self._owned(name, group)]
         if not live:
+            self._synced = None
             return
-        # one flat all-reduce for the replicated dense gradients
         n = sum(d.p.numel() for _, d in live)
         if self._flat is None or self._flat.numel() < n:
             self._flat = torch.empty(n, dtype=torch.float32, device=self.device)
         flat = self._flat[:n]
         torch.cat([d.p.grad.reshape(-1) for _, d in live], out=flat)
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.pg)
-        flat.mul_(1.0 / G)
-        off = 0
+        flat.mul_(1.0 / self.G)
+        views, off = {}, 0
         for name, d in live:
             k = d.p.numel()
-            d.step += 1
-            h = self._hyper(name)
-            h.check_step(d.step)
-            self.ops.adam_dense(d.p.data, flat[off:off + k], d.m, d.v, h, d.step)
-            d.p.grad = None
+            views[name] = flat[off:off + k]
             off += k
+        self._synced = (live, views)
+
+    def clip_grad_norm(self, max_norm: float, group=None):
+        """GenericEngine.clip_grad_norm on replicas: the norm of the GLOBAL batch's gradient, one coefficient for every
+        replica.  A trainable table's gradient is the all-gathered [G * M, D] rows (identical on every rank), duplicates
+        summed per global id before squaring; a dense parameter's is measured AFTER the flat all-reduce (done here instead
+        of in backward_adam, which then finds it averaged) -- clipping each replica's local gradient first would give every
+        rank its own coefficient and the step would not be the single-device clip of the averaged gradient."""
+        self._sync_dense(group)
+        sq = torch.zeros((), dtype=torch.float32, device=self.device)
+        held = []
+        for name, t in self._tables.items():
+            if name.startswith(self.NOT_MODEL_PARAMETERS) or not t.trainable or t._grad_rows is None:
+                continue
+            ids, g = self._buf[name]["ids"], t._grad_rows
+            order = torch.argsort(ids, stable=True)
+            _, counts = torch.unique_consecutive(ids[order], return_counts=True)
+            rows = torch.segment_reduce(g[order].contiguous(), "sum", lengths=counts, axis=0)
+            sq = sq + (rows * rows).sum()
+            held.append(t)
+        dense = []
+        synced = self._synced[1] if self._synced is not None else {}
+        for name, d in self._dense.items():
+            if name.startswith(self.NOT_MODEL_PARAMETERS) or d.p.grad is None:
+                continue
+            gview = synced.get(name, d.p.grad)          # averaged over the replicas when this step's group owns it
+            sq = sq + (gview * gview).sum()
+            dense.append(gview)
+        if not held and not dense:
+            return torch.zeros((), device=self.device)
+        total = torch.sqrt(sq)
+        coef = torch.clamp(max_norm / (total + 1e-6), max=1.0)
+        for t in held:
+            t._grad_rows = t._grad_rows * coef
+        for gview in dense:
+            gview.mul_(coef)
+        return total

@@ -276,6 +276,7 @@ class ShardedGenericEngine(GenericEngine):
         self.optimizer, self.sweep_period = None, None
         self.err_flag = torch.zeros(1, dtype=torch.int32, device=self.device)
         self._group_version = {}
+        self._seg_src = {}
 
     # --- registration: `weight` is this rank's SHARD (rows rank, rank + G, ...) --------------------------------
     def add_table(self, name, weight, trainable=True, group=None, n_rows_global: Optional[int] = None, table=None):

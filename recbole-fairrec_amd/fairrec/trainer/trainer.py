@@ -183,8 +183,15 @@ class Trainer(AbstractTrainer):
         return calculate_valid_score(valid_result, self.valid_metric), valid_result
 
     def _save_checkpoint(self, epoch, verbose=True, **kwargs):
-        """Same keys as trainer.py:221-240; model.state_dict() flushes the lazy tables first."""
+        """Same keys as trainer.py:221-240; model.state_dict() flushes the lazy tables first.  The optimizer state goes out
+        in torch.optim.Adam's own layout (integer parameter indices in model.named_parameters() order) whenever every
+        tensor it holds is a model parameter, so that the reference's `optimizer.load_state_dict` takes the file as it is;
+        resume_checkpoint reads both layouts."""
         saved_model_file = kwargs.pop('saved_model_file', self.saved_model_file)
+        try:
+            opt_state = self.optimizer.state_dict(param_names=[n for n, _ in self.model.named_parameters()])
+        except KeyError:         # tensors outside model.parameters() (dict-held MLPs): the name-keyed layout
+            opt_state = self.optimizer.state_dict()
         state = {
             'config': dict(self.config.final_config_dict) if hasattr(self.config, 'final_config_dict') else None,
             'epoch': epoch,
@@ -192,7 +199,7 @@ class Trainer(AbstractTrainer):
             'best_valid_score': self.best_valid_score,
             'state_dict': self.model.state_dict(),
             'other_parameter': self.model.other_parameter(),
-            'optimizer': self.optimizer.state_dict(),
+            'optimizer': opt_state,
         }
         torch.save(state, saved_model_file)
         if verbose:
@@ -442,7 +449,8 @@ class PFCNTrainer(Trainer):
             self.optimizer_filter.load_state_dict(checkpoint['optimizer_filter'])
             self.optimizer_dis.load_state_dict(checkpoint['optimizer_dis'])
         else:
-            self.optimizer.load_state_dict(checkpoint['optimizer'])
+            self.optimizer.load_state_dict(checkpoint['optimizer'],
+                                           param_names=[n for n, _ in self.model.named_parameters()])
         self.logger.info('Checkpoint loaded. Resume training from epoch %d', self.start_epoch)
 
     def _subsets(self):

@@ -6,6 +6,7 @@ import os
 import sys
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -48,7 +49,10 @@ class _Ops:
         O.adam_dense_step_(p, g.clone(), m, v, step, hyper.lr, hyper.weight_decay)
 
 
-def _worker(rank, world, port, out_dir, frozen):
+CLIP = 0.05     # well below the gradient norms of the toy problem: every step is clipped
+
+
+def _worker(rank, world, port, out_dir, frozen, clip=False):
     for p in (ROOT, os.path.join(ROOT, "recbole-fairrec_amd"), os.path.join(ROOT, "tests")):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -66,35 +70,39 @@ def _worker(rank, world, port, out_dir, frozen):
         eng.add_dense("w", w)
         eng.add_dense("b", b)
         eng.hyper = AdamHyper(LR, WD, device="cpu")
-        losses = []
+        losses, norms = [], []
         for t in range(T):
             sl = slice(rank * B, (rank + 1) * B)
             eng.zero_grad()
             loss = _loss(eng.lookup("U", u[t][sl]), eng.lookup("I", i[t][sl]), w, b, r[t][sl])
             loss.backward()
+            if clip:      # what FusedLazyAdam.step() does when the config clips
+                norms.append(float(eng.clip_grad_norm(CLIP)))
             eng.backward_adam()
             losses.append(float(loss))
-        torch.save({"U": Ur, "I": Ir, "w": w.data, "b": b.data, "loss": losses}, os.path.join(out_dir, f"r{rank}.pt"))
+        torch.save({"U": Ur, "I": Ir, "w": w.data, "b": b.data, "loss": losses, "norm": norms}, os.path.join(out_dir, f"r{rank}.pt"))
     finally:
         dist.destroy_process_group()
 
 
-def _reference(frozen):
+def _reference(frozen, clip=False):
     from oracle import focf as O
     U0, I0, w0, b0, u, i, r = _data()
     P = [torch.nn.Parameter(x.clone(), requires_grad=not (frozen and k < 2)) for k, x in enumerate((U0, I0, w0, b0))]
     ms, vs = [torch.zeros_like(p) for p in P], [torch.zeros_like(p) for p in P]
-    ref_loss = []
+    ref_loss, ref_norm = [], []
     for t in range(T):
         for p in P:
             p.grad = None
         loss = _loss(P[0][u[t]], P[1][i[t]], P[2], P[3], r[t])
         loss.backward()
+        if clip:
+            ref_norm.append(float(torch.nn.utils.clip_grad_norm_([p for p in P if p.grad is not None], CLIP)))
         for k, p in enumerate(P):
             if p.grad is not None:
                 O.adam_dense_step_(p.data, p.grad, ms[k], vs[k], t + 1, LR, WD)
         ref_loss.append(float(loss))
-    return P, ref_loss
+    return (P, ref_loss, ref_norm) if clip else (P, ref_loss)
 
 
 def _check(tmp_path, frozen):
@@ -118,3 +126,22 @@ def test_two_replicas_with_frozen_tables_equal_single_process(tmp_path):
 def test_two_replicas_training_the_tables_equal_single_process(tmp_path):
     """The pretrain stage: the tables train on the global batch (all-gathered ids and gradient rows)."""
     _check(tmp_path, frozen=False)
+
+
+@pytest.mark.parametrize("frozen", [False, True], ids=["tables_train", "tables_frozen"])
+def test_clip_grad_norm_on_replicas_is_the_single_process_clip(tmp_path, frozen):
+    """config clip_grad_norm with data_parallel replicas: every replica must measure the norm of the GLOBAL batch's gradient
+    (tables: the all-gathered rows, duplicates summed; dense: after the flat all-reduce) and apply ONE coefficient -- the
+    step of torch.nn.utils.clip_grad_norm_ on the concatenated batch."""
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), frozen, True), nprocs=world, join=True)
+    P, ref_loss, ref_norm = _reference(frozen, clip=True)
+    assert min(ref_norm) > CLIP
+    parts = [torch.load(os.path.join(str(tmp_path), f"r{q}.pt")) for q in range(world)]
+    np.testing.assert_allclose(np.mean([p["loss"] for p in parts], axis=0), ref_loss, rtol=1e-5)
+    for q in range(world):
+        np.testing.assert_allclose(parts[q]["norm"], ref_norm, rtol=2e-5)
+        for tag, ref in (("U", P[0]), ("I", P[1]), ("w", P[2]), ("b", P[3])):
+            np.testing.assert_allclose(parts[q][tag].numpy(), ref.data.numpy(), rtol=2e-5, atol=1e-7, err_msg=tag)
+    for tag in ("U", "I", "w", "b"):
+        assert torch.equal(parts[0][tag], parts[1][tag]), tag
