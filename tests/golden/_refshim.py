@@ -71,3 +71,25 @@ def install():
     except Exception:
         pass
     del sys.argv[1:]
+
+
+class float64_reference:
+    """Context in which the reference's own model code runs in float64: torch's default dtype is float64 (parameters,
+    buffers and every tensor the reference creates without a dtype) and `Tensor.float()` -- which the reference calls on
+    label columns right before a loss (pfcn_biasedmf.py, nfcf.py) -- widens instead of narrowing.  Used by the golden
+    generators for the <case>_f64.npz companions: the SAME reference code, the same recorded batches / masks / initial
+    state, executed in near-exact arithmetic."""
+
+    def __enter__(self):
+        import torch
+        self._torch = torch
+        self._dtype = torch.get_default_dtype()
+        self._float = torch.Tensor.float
+        torch.set_default_dtype(torch.float64)
+        torch.Tensor.float = lambda t, *a, **k: t.double()
+        return self
+
+    def __exit__(self, *exc):
+        self._torch.Tensor.float = self._float
+        self._torch.set_default_dtype(self._dtype)
+        return False

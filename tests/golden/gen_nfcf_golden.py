@@ -159,6 +159,44 @@ def _run_case(name, stage, n_users, n_items, D, hidden, B, T, snaps, lr, wd, p_d
     path = os.path.join(HERE, f"nfcf_{name}.npz")
     np.savez_compressed(path, **out)
     print(f"{path}: loss[0]={losses[0]:.6f} loss[-1]={losses[-1]:.6f} {os.path.getsize(path) / 1024:.1f} KiB")
+    _run_f64(name, out, base, ds, stage, sizes, T, snaps, lr, wd, p_drop, clip)
+
+
+def _run_f64(name, z, base, ds, stage, sizes, T, snaps, lr, wd, p_drop, clip):
+    """<case>_f64.npz: the REFERENCE's NFCF run again in float64 from the recorded initial state, batches and dropout masks
+    (see _refshim.float64_reference).  The parity tests accept a parameter element that lies between the reference's fp32
+    execution (the golden) and this one: Adam divides a gradient by its own magnitude, so where a gradient nearly cancels
+    the fp32 run's rounding noise moves the element by a visible fraction of lr (tests/golden/noise_floor.py)."""
+    with _refshim.float64_reference():
+        model = NFCF(_Cfg(base, load_pretrain_path=None), ds)
+        if stage == "finetune":       # the state reset_params left (z["init.*"]): frozen user table, fairness term on
+            model.load_pretrain_path = "recorded"
+            model.user_embedding.weight.requires_grad = False
+        model.load_state_dict({k[5:]: torch.from_numpy(v).double() for k, v in z.items() if k.startswith("init.")})
+        queue = []
+        patch_dropout(model, p_drop, queue)
+        opt = torch.optim.Adam(model.parameters(), lr=lr, weight_decay=wd)
+        keep = {}
+        for t in range(T):
+            if p_drop > 0:
+                for li in range(len(sizes)):
+                    queue.append(torch.from_numpy(z[f"mask{li}"][t].astype(np.float64)))
+            inter = Interaction({"user_id": torch.from_numpy(z["user_id"][t]), "item_id": torch.from_numpy(z["item_id"][t]),
+                                 "label": torch.from_numpy(z["label"][t]).double(), "gender": torch.from_numpy(z["sst"][t]).double()})
+            opt.zero_grad()
+            loss = model.calculate_loss(inter)
+            assert loss.dtype == torch.float64
+            loss.backward()
+            if clip:
+                torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=clip)
+            opt.step()
+            if (t + 1) in snaps:
+                for k, v in model.state_dict().items():
+                    keep[f"after{t + 1}." + k] = v.detach().numpy().astype(np.float32)
+    path = os.path.join(HERE, f"nfcf_{name}_f64.npz")
+    np.savez_compressed(path, **keep)
+    worst = max(float(np.abs(keep[k].astype(np.float64) - z[k]).max()) for k in keep)
+    print(f"{path}: {len(keep)} arrays, max |reference float64 - reference float32| = {worst:.2e}")
 
 
 def main():

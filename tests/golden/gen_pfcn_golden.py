@@ -184,6 +184,72 @@ def _run_case(name, cls, mode, attrs, phases, sst_lists, D, B, dis_hidden, seed,
     path = os.path.join(HERE, f"pfcn_{name}.npz")
     np.savez_compressed(path, **out)
     print(f"{path}: loss {losses[0]:.5f} -> {losses[-1]:.5f}  {os.path.getsize(path) / 1024:.1f} KiB")
+    if not clip:
+        _run_f64(name, out, cls, cfg, feats, mode, attrs, phases, sst_lists, dis_sizes, p_drop, lr, wd, n_users, n_items)
+
+
+def _optimizers(cls, model, mode, lr, wd):
+    if mode == "none":
+        return torch.optim.Adam(model.parameters(), lr=lr, weight_decay=wd), None                 # trainer.py:139
+    if cls is PFCN_MLP:                                                                   # trainer.py:1193-1198
+        groups = [{"params": model.user_embedding.weight}, {"params": model.item_embedding.weight}]
+    else:
+        groups = [{"params": model.user_embedding_layer.weight}, {"params": model.item_embedding_layer.weight}]
+    groups += [{"params": m.parameters()} for m in model.filter_layer.values()]
+    if cls is PFCN_BiasedMF:                                                              # trainer.py:1205-1211
+        groups += [{"params": model.user_bias.weight}, {"params": model.item_bias.weight}, {"params": model.global_bias}]
+    if cls is PFCN_MLP:
+        groups += [{"params": model.mlp_layer.parameters()}]
+    if cls is PFCN_DMF:                                                                   # trainer.py:1219-1224
+        groups += [{"params": model.user_mlp.parameters()}, {"params": model.item_mlp.parameters()}]
+    return (torch.optim.Adam(groups, lr=lr, weight_decay=wd),
+            torch.optim.Adam([{"params": m.parameters()} for m in model.dis_layer_dict.values()], lr=lr, weight_decay=wd))
+
+
+def _run_f64(name, z, cls, cfg, feats, mode, attrs, phases, sst_lists, dis_sizes, p_drop, lr, wd, n_users, n_items):
+    """<case>_f64.npz: the REFERENCE's model again in float64 from the recorded initial state, batches and dropout masks
+    (see _refshim.float64_reference) -- the far end of the band the parity tests accept (tests/test_pfcn_hip.py): an
+    element may lie between the reference's fp32 execution (the golden) and this float64 execution of the same steps."""
+    with _refshim.float64_reference():
+        model = cls(cfg, _FakeDataset(n_users, n_items, feats))
+        model.load_state_dict({k[11:]: torch.from_numpy(v).double() for k, v in z.items() if k.startswith("init.model.")})
+        queues = {}
+        if mode != "none":
+            for idx, mlp in model.filter_layer.items():
+                mlp.load_state_dict({k[len(f"init.filter.{idx}."):]: torch.from_numpy(v).double() for k, v in z.items()
+                                     if k.startswith(f"init.filter.{idx}.")})
+            for sst, mlp in model.dis_layer_dict.items():
+                mlp.load_state_dict({k[len(f"init.dis.{sst}."):]: torch.from_numpy(v).double() for k, v in z.items()
+                                     if k.startswith(f"init.dis.{sst}.")})
+                queues[sst] = []
+                patch_dropout(mlp, p_drop, queues[sst])
+        opt_f, opt_d = _optimizers(cls, model, mode, lr, wd)
+        losses = []
+        for t in range(len(phases)):
+            u = z["user_id"][t]
+            inter = Interaction({"user_id": torch.from_numpy(u), "item_id": torch.from_numpy(z["item_id"][t]),
+                                 "neg_item_id": torch.from_numpy(z["neg_item_id"][t]),
+                                 "gender": torch.from_numpy(feats["gender"][u]).double(), "age": torch.from_numpy(feats["age"][u])})
+            sl = list(sst_lists[t]) if mode != "none" else None
+            if mode != "none":
+                for sst in sl:
+                    for l in range(len(dis_sizes)):
+                        queues[sst].append(torch.from_numpy(z[f"mask.{sst}.{t}.{l}"].astype(np.float64)))
+            opt = opt_f if phases[t] == "F" else opt_d
+            opt.zero_grad()
+            loss = model.calculate_loss(inter, sl) if phases[t] == "F" else model.calculate_dis_loss(inter, sl)
+            assert loss.dtype == torch.float64
+            loss.backward()
+            opt.step()
+            losses.append(float(loss.item()))
+        keep = {}
+        dump_state(model, mode, "final", keep)
+        keep = {k: v.astype(np.float32) for k, v in keep.items()}
+        keep["loss"] = np.array(losses)
+    path = os.path.join(HERE, f"pfcn_{name}_f64.npz")
+    np.savez_compressed(path, **keep)
+    worst = max(float(np.abs(keep[k].astype(np.float64) - z[k]).max()) for k in keep if k != "loss")
+    print(f"{path}: {len(keep)} arrays, max |reference float64 - reference float32| = {worst:.2e}")
 
 
 def main():

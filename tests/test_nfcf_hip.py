@@ -9,7 +9,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 CASES = sorted(p for p in glob.glob(os.path.join(os.path.dirname(__file__), "golden", "nfcf_*.npz"))
-               if not p.endswith("_f64.npz"))   # <case>_f64.npz: the case's float64 companion (gen_nfcf_exact64.py)
+               if not p.endswith("_f64.npz"))   # <case>_f64.npz: the REFERENCE's float64 execution of the case (gen_nfcf_golden.py)
 
 
 class _DS:
@@ -81,13 +81,16 @@ def _run_case(z, sharded=False, exact=None):
             for k, v in sd.items():
                 ref = z[f"after{t + 1}." + k]
                 a = v.cpu().numpy()
-                # between the reference's fp32 execution (the golden) and its float64 execution of the same steps
-                # (tests/golden/gen_nfcf_exact64.py), give or take the tolerance -- see tests/test_pfcn_hip.py
+                # between the reference's fp32 execution (the golden) and the reference's float64 execution of the same
+                # steps (tests/golden/gen_nfcf_golden.py::_run_f64), give or take the tolerance -- see tests/test_pfcn_hip.py
                 key = f"after{t + 1}." + k
                 r64 = exact[key] if exact is not None and key in exact.files else ref
                 lo, hi = np.minimum(ref, r64), np.maximum(ref, r64)
                 dist = np.maximum(np.maximum(lo - a, a - hi), 0.0)
-                out = dist > 1e-4 * np.abs(ref) + 2e-6
+                tol = 1e-4 * np.abs(ref) + 2e-6
+                used = (np.abs(a - ref) > tol) & (dist <= tol)          # elements that NEED the band: the exception
+                assert used.sum() <= max(4, 0.005 * used.size), (k, t + 1, int(used.sum()), used.size)
+                out = dist > tol
                 # Adam divides a gradient by its own magnitude: where a weight gradient nearly cancels, ITS rounding noise
                 # (different in every correct implementation) moves the element by a visible fraction of lr.  One element
                 # per 10 000 (at least two) may therefore leave the band, by at most 0.25 % of what Adam can move anything

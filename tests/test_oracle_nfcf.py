@@ -9,7 +9,7 @@ import torch
 from oracle import nfcf as O
 
 CASES = sorted(p for p in glob.glob(os.path.join(os.path.dirname(__file__), "golden", "nfcf_*.npz"))
-               if not p.endswith("_f64.npz"))   # <case>_f64.npz: the case's float64 companion (gen_nfcf_exact64.py)
+               if not p.endswith("_f64.npz"))   # <case>_f64.npz: the case's float64 companion (the reference in float64: gen_nfcf_golden.py::_run_f64)
 
 
 @pytest.mark.parametrize("path", CASES, ids=[os.path.basename(p)[:-4] for p in CASES])

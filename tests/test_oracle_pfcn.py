@@ -8,7 +8,7 @@ import pytest
 from oracle import pfcn as O
 
 CASES = sorted(p for p in glob.glob(os.path.join(os.path.dirname(__file__), "golden", "pfcn_*.npz"))
-               if not p.endswith("_f64.npz"))   # <case>_f64.npz: the case's float64 companion (gen_pfcn_exact64.py)
+               if not p.endswith("_f64.npz"))   # <case>_f64.npz: the case's float64 companion (the reference in float64: gen_pfcn_golden.py::_run_f64)
 
 
 @pytest.mark.parametrize("path", CASES, ids=[os.path.basename(p)[:-4] for p in CASES])

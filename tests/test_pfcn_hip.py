@@ -9,7 +9,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 CASES = sorted(p for p in glob.glob(os.path.join(os.path.dirname(__file__), "golden", "pfcn_*.npz"))
-               if not p.endswith("_f64.npz"))   # <case>_f64.npz: the case's float64 companion (gen_pfcn_exact64.py)
+               if not p.endswith("_f64.npz"))   # <case>_f64.npz: the case's float64 companion (the reference in float64: gen_pfcn_golden.py::_run_f64)
 
 
 class _DS:
@@ -116,7 +116,7 @@ def _run_case(z, sharded=False, noise=None, exact=None):
              "BatchNorm gamma": 1e-6,      # 2.4e-7 at scale 1
              "BatchNorm beta": 2e-4,       # 1.0e-4 at scale 2e-3: Adam turns a cancelling column sum into +-lr-sized steps
              "BatchNorm running_var": 1e-6}
-    worst = {}
+    worst, band_used = {}, {}
 
     def kind_of(k):
         parts = k.split(".")
@@ -143,8 +143,9 @@ def _run_case(z, sharded=False, noise=None, exact=None):
             return
         floor = FLOOR.get(kind, 1e-6 * max(1.0, float(np.abs(ref).max())))      # tables: 1e-6 of the tensor's scale
         floor = floor + noise.get(what, 0.0)
-        # An element must lie between the reference's fp32 execution (the golden) and its float64 execution of the same
-        # steps (tests/golden/gen_pfcn_exact64.py), give or take the tolerance: the HIP GEMMs are closer to exact than
+        # An element must lie between the REFERENCE's fp32 execution (the golden) and the REFERENCE's float64 execution of the
+        # same steps (<case>_f64.npz, written by tests/golden/gen_pfcn_golden.py::_run_f64 from the reference's own model
+        # code under _refshim.float64_reference), give or take the tolerance: the HIP GEMMs are closer to exact than
         # torch's CPU sgemm (scratch/linear_acc.py), and on the few dozen Linear-weight elements whose gradient nearly
         # cancels the reference's own rounding has carried ITS fp32 run up to 9e-5 from its float64 run
         # (tests/golden/noise_floor.py) -- exactly the elements and the distance at which this path differs from the golden.
@@ -155,6 +156,11 @@ def _run_case(z, sharded=False, noise=None, exact=None):
             ref64 = ref64.astype(np.float64)
             lo, hi = np.minimum(ref, ref64), np.maximum(ref, ref64)
             dist = np.maximum(np.maximum(lo - a, a - hi), 0.0)
+            # how many elements NEED the band (outside the plain tolerance around the fp32 golden, inside the band): they
+            # must be the exception -- at most 0.5 % of a tensor, never fewer than 4 allowed (measured: <= 0.2 %)
+            used = (np.abs(a - ref) > 1e-4 * np.abs(ref) + floor) & (dist <= 1e-4 * np.abs(ref) + floor)
+            band_used[what] = int(used.sum())
+            assert used.sum() <= max(4, 0.005 * used.size), (what, kind, int(used.sum()), used.size)
         ratio = dist / (1e-4 * np.abs(ref) + floor)
         if noise and kind != "table" and ratio.max() > 1.0:
             # Self-noise runs only (synthetic full-batch cases): an element whose gradient cancels to rounding noise takes
@@ -180,6 +186,7 @@ def _run_case(z, sharded=False, noise=None, exact=None):
                 if not k.endswith("num_batches_tracked"):
                     close(v, z[f"final.dis.{s}.{k}"], f"dis.{s}.{k}")
     print("worst |err| / tolerance per kind:", {k: round(v, 3) for k, v in worst.items()})
+    print("elements that needed the fp32..float64 band:", {k: v for k, v in band_used.items() if v} or "none")
     eng.check_device_errors()
     pr = model.predict(inter, attrs if mode != "none" else None).cpu().numpy()
     np.testing.assert_allclose(pr, z["predict_last"], rtol=1e-4, atol=1e-6 + noise.get("predict_last", 0.0))
