@@ -191,6 +191,21 @@ def bench_nfcf(args, rank, world, dev):
     m.hip_engine().check_device_errors()
     total = K * B * world
     achieved = NFCF_ALGO_BYTES * B / (dt / K) / 1e9
+    # the lazy-Adam replay of the trainable (item) table: one row-step per row and step in steady state, 30 SIMD cycles per
+    # 64-element fragment at D >= 128 -- the floor an exact-parity step has whatever its memory traffic
+    rows_local = sum(t.n_rows for t in m.hip_engine()._tables.values() if t.trainable)
+    valu_floor_ms = rows_local * (D / 64) * 30 / (1024 * 2.4e9) * 1e3
+    detail = None
+    if world == 1:      # per-kernel picture (eager pass with the library's HIP-event profiler, after the timed region)
+        import bench_workloads as BW
+
+        def eager(k):
+            opt.zero_grad()
+            l_ = m.calculate_loss(data[k % len(data)])
+            l_.backward()
+            opt.step()
+        prof = BW._profiled(eager, min(K, 10), n_age + W + K)
+        detail = dict(BW._gemm_summary(prof), kernels=BW._kernel_table(prof))
     return {
         "metric": "training interactions/sec + achieved HBM GB/s, NFCF finetune emb=256 (BASELINE.json configs[4])",
         "value": round(total / dt, 1), "unit": "interactions/s", "n_gpus": world, "steps": K, "warmup": W,
@@ -199,6 +214,8 @@ def bench_nfcf(args, rank, world, dev):
         "config": {"workload": f"NFCF finetune, {nu} users x {ni} items, embedding_size={D}, B={B} per GPU, user table frozen, "
                                "item table lazy Adam lr=1e-3 wd=1e-6, mlp [512,128,64,1], fair_weight 0.1",
                    "tables": f"row-sharded over {world} ranks (owner = row mod {world}), RCCL all-to-all" if world > 1 else "single GPU",
+                   "fairness_term": ("differential fairness on the GLOBAL batch (records to the items' owners, per-group sums back: "
+                                     "2 all-to-alls); the scorer MLP has no BatchNorm") if world > 1 else "single device",
                    "global_batch": B * world, "launch": "hipGraph step" if graphed is not None else "eager",
                    "aged_steps": n_age,
                    "final_loss": round(float(loss), 6),
@@ -206,7 +223,10 @@ def bench_nfcf(args, rank, world, dev):
         "roofline": {"bound": "hbm", "kernel": "whole step (no dominant kernel: gather, MLP, loss, apply)",
                      "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                     "algorithmic_bytes_per_launch": NFCF_ALGO_BYTES * B},
+                     "algorithmic_bytes_per_launch": NFCF_ALGO_BYTES * B,
+                     "valu_floor_ms_per_step": round(valu_floor_ms, 4),
+                     "frac_of_valu_floor": round(valu_floor_ms / (dt / K * 1e3), 4),
+                     "gemm": detail},
     }
 
 
@@ -242,9 +262,13 @@ def dry_launch(args, rank, world):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--workload", default="focf", choices=["focf", "nfcf100m"],
+    ap.add_argument("--workload", default="focf", choices=["focf", "nfcf100m", "pfcn10m", "fairgo10m"],
                     help="focf = BASELINE.json configs[1] (the headline metric); nfcf100m = configs[4], NFCF finetune at "
-                         "100 000 001 x 10 000 001, D = 256, both tables row-sharded over the ranks")
+                         "100 000 001 x 10 000 001, D = 256, both tables row-sharded over the ranks; pfcn10m = configs[2] "
+                         "(PFCN_BiasedMF sm, MFMA roofline per pass); fairgo10m = configs[3] on one GPU (SpMM GB/s and GEMM "
+                         "TFLOP/s) -- the last two in bench_workloads.py")
+    ap.add_argument("--users", type=int, default=0, help="pfcn10m / fairgo10m: override the number of users (smaller runs)")
+    ap.add_argument("--items", type=int, default=0, help="pfcn10m / fairgo10m: override the number of items")
     ap.add_argument("--dry-launch", action="store_true", help="only prove the N-rank launch path (gloo, no GPU)")
     ap.add_argument("--nfcf-users", type=int, default=100_000_001)
     ap.add_argument("--nfcf-items", type=int, default=10_000_001)
@@ -294,6 +318,15 @@ def main():
     from fairrec.model.fair_recommender.focf import FocfEngine
     from fairrec.optim import FusedLazyAdam
 
+    if args.workload in ("pfcn10m", "fairgo10m"):
+        if world != 1:
+            raise SystemExit(f"--workload {args.workload} is a single-GPU measurement")
+        import bench_workloads
+        out = (bench_workloads.bench_pfcn if args.workload == "pfcn10m" else bench_workloads.bench_fairgo)(args, dev)
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+        print(json.dumps(out), flush=True)
+        return
     if args.workload == "nfcf100m":
         out = bench_nfcf(args, rank, world, dev)
         import ctypes

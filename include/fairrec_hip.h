@@ -634,6 +634,10 @@ FR_API int fr_prof_reset(void);
 FR_API int fr_prof_kernel_count(void);
 FR_API const char* fr_prof_kernel_name(int kind);
 FR_API int fr_prof_read(int kind, double* total_ms, int64_t* count);
+/* Algorithmic work the launches of `kind` stood for since the last reset: FLOP (2 M N K per product) for linear_fwd /
+ * linear_bwd_input / linear_bwd_weight, bytes (12 nnz + 8 n_rows dim) for spmm_csr, 0 for the kinds that do not account.
+ * work / total_ms is the rate bench.py holds against the MFMA / HBM peak. */
+FR_API int fr_prof_read_work(int kind, double* work);
 
 #ifdef __cplusplus
 }

@@ -120,6 +120,14 @@ extern "C" int fr_spmm_csr(const int64_t* indptr, const int32_t* col, const floa
     hipStream_t stream = (hipStream_t)stream_;
     FR_CHECK_ARG(indptr && col && val && X && Y && n_rows >= 1 && dim >= 1, "fr_spmm_csr: bad argument");
     ProfScope prof(K_SPMM, stream);
+    if (prof_on()) {      // bytes of SURVEY.md §8-d: (col, val) per nonzero + X read and Y written once per row; nnz from the host
+        static thread_local long long nnz_cache = -1;     // copy of indptr[n_rows] (one 8-byte read per call while profiling)
+        long long nnz = 0;
+        if (hipMemcpyAsync(&nnz, indptr + n_rows, 8, hipMemcpyDeviceToHost, stream) == hipSuccess &&
+            hipStreamSynchronize(stream) == hipSuccess)
+            nnz_cache = nnz;
+        prof_work(K_SPMM, 12.0 * (double)nnz_cache + 8.0 * (double)n_rows * dim);
+    }
     const dim3 grid((unsigned)((n_rows + 3) / 4));
 #define FR_SPMM(V)                                                                                              \
     FR_LAUNCH(prof, spmm_csr_kernel<V>, grid, dim3(256), 0, stream, (const long long*)indptr, col, val, X, \

@@ -13,6 +13,8 @@ enum KernelKind {
     K_LINEAR_BWD_INPUT, K_LINEAR_BWD_WEIGHT, K_NFCF_LOSS, K_BN_FWD, K_BN_BWD, K_ROWDOT, K_BPR, K_SPMM, K_ROW_GATHER, K_SAMPLE_NEG, K_FOCF_STEP, K_FOCF_LPT, K_COUNT
 };
 bool prof_on();
+// algorithmic work of a launch of `kind` (FLOP of a dense product, bytes of an SpMM), summed while the profiler is on
+void prof_work(int kind, double amount);
 // Takes an event pair from the profiler's pool and registers it for kernel `kind` (not recorded here: the pair
 // is handed to hipExtLaunchKernelGGL, which stamps it at the kernel's own start and end on the GPU).
 bool prof_take(int kind, hipEvent_t* start, hipEvent_t* stop);

@@ -497,6 +497,7 @@ extern "C" int fr_linear_fwd(const float* x0, int32_t k0, const float* x1, int32
                  "fr_linear_fwd: bad argument");
     const int K = k0 + k1;
     CatMat X{x0, x1, k0, k1};
+    prof_work(K_LINEAR_FWD, 2.0 * (double)M * N * K);
     ProfScope prof(K_LINEAR_FWD, stream);
     if (n1_ok(N, K, k1, mask, x0, W)) {
         FR_LAUNCH(prof, linear_n1_fwd_kernel, dim3((unsigned)((M + 15) / 16)), dim3(256), 0, stream, x0, W, bias, (int)M, K,
@@ -536,6 +537,7 @@ extern "C" int fr_linear_bwd_input(const float* dY, const float* Y, int32_t act,
     FR_CHECK_ARG(dY && Y && W && dx0 && M >= 1 && N >= 1 && k0 >= 1 && k1 >= 0 && (k1 == 0 || dx1) && act_ok(act),
                  "fr_linear_bwd_input: bad argument");
     const int K = k0 + k1;
+    prof_work(K_LINEAR_BWD_INPUT, 2.0 * (double)M * N * K);
     CatOut dX{dx0, dx1, k0, k1};
     static const bool no_glds = getenv("FAIRREC_LINEAR_NO_GLDS") != nullptr || getenv("FAIRREC_LINEAR_SLOW") != nullptr;
     if (!no_glds && !mask && act == ACT_NONE && N % 32 == 0 && K % 32 == 0 && k0 % 32 == 0 && ((uintptr_t)dY & 15) == 0 &&
@@ -554,6 +556,7 @@ extern "C" int fr_linear_bwd_input(const float* dY, const float* Y, int32_t act,
 extern "C" int fr_linear_bwd_input_relu(const float* dY, const float* W, int64_t M, int32_t N, int32_t K, const float* Xd,
                                         float scale, float* dA, void* stream_) {
     FR_CHECK_ARG(dY && W && Xd && dA && M >= 1 && N >= 1 && K >= 1 && scale > 0.f, "fr_linear_bwd_input_relu: bad argument");
+    prof_work(K_LINEAR_BWD_INPUT, 2.0 * (double)M * N * K);
     static const bool no_glds = getenv("FAIRREC_LINEAR_NO_GLDS") != nullptr || getenv("FAIRREC_LINEAR_SLOW") != nullptr;
     if (no_glds || N % 32 != 0 || K % 32 != 0 || (((uintptr_t)dY | (uintptr_t)W) & 15) != 0) {
         set_error("fr_linear_bwd_input_relu: shape not supported (N %% 32 == 0, K %% 32 == 0, 16-byte aligned operands)");
@@ -588,6 +591,7 @@ extern "C" int fr_linear_bwd_weight(const float* dY, const float* Y, int32_t act
                  "fr_linear_bwd_weight: bad argument");
     const int K = k0 + k1;
     const long long splits = bwd_weight_splits(M, N, K);
+    prof_work(K_LINEAR_BWD_WEIGHT, 2.0 * (double)M * N * K);
     const int rows_per_split = (int)(((M + splits - 1) / splits + TK - 1) / TK * TK);
     FR_CHECK_ARG(ws_bytes >= (size_t)splits * N * (K + 1) * sizeof(float), "fr_linear_bwd_weight: workspace too small");
     CatMat X{x0, x1, k0, k1};
@@ -628,6 +632,7 @@ extern "C" int fr_linear_n1_bwd(const float* dY, const float* Y, int32_t act, co
         return FR_EUNSUPPORTED;
     }
     const long long splits = bwd_weight_splits(M, 1, K);
+    prof_work(K_LINEAR_BWD_WEIGHT, (dX ? 4.0 : 2.0) * (double)M * K);
     const int rows_per_block = (int)((M + splits - 1) / splits);
     FR_CHECK_ARG(ws_bytes >= (size_t)splits * (K + 1) * sizeof(float), "fr_linear_n1_bwd: workspace too small");
     float* slab = (float*)ws;

@@ -44,10 +44,17 @@ struct ProfState {
     std::vector<Pair> open;
     double total_ms[K_COUNT] = {0};
     long long count[K_COUNT] = {0};
+    double work[K_COUNT] = {0};       // algorithmic work of the launches of a kind: FLOP for the dense layers, bytes for SpMM
 };
 static ProfState g_prof;
 
 bool prof_on() { return g_prof.on; }
+
+void prof_work(int kind, double amount) {
+    if (!g_prof.on) return;
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    g_prof.work[kind] += amount;
+}
 
 static hipEvent_t take_event() {
     if (!g_prof.pool.empty()) {
@@ -154,7 +161,15 @@ extern "C" int fr_prof_reset(void) {
     for (int k = 0; k < K_COUNT; ++k) {
         g_prof.total_ms[k] = 0;
         g_prof.count[k] = 0;
+        g_prof.work[k] = 0;
     }
+    return FR_OK;
+}
+
+extern "C" int fr_prof_read_work(int kind, double* work) {
+    FR_CHECK_ARG(kind >= 0 && kind < K_COUNT && work, "fr_prof_read_work: bad argument");
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    *work = g_prof.work[kind];
     return FR_OK;
 }
 

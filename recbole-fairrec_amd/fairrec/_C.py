@@ -188,6 +188,7 @@ _PROTOS = {
     "fr_prof_kernel_count": (c_int, []),
     "fr_prof_kernel_name": (c_char_p, [c_int]),
     "fr_prof_read": (c_int, [c_int, POINTER(c_double), POINTER(c_int64)]),
+    "fr_prof_read_work": (c_int, [c_int, POINTER(c_double)]),
     "fr_adam_dense": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, POINTER(FrAdam), c_int32,
                               c_void_p]),
 }
@@ -279,6 +280,17 @@ def prof_enable(on: bool):
 
 def prof_reset():
     check(lib().fr_prof_reset(), "fr_prof_reset")
+
+
+def prof_read_work():
+    """{kernel name: algorithmic work (FLOP / bytes, fairrec_hip.h: fr_prof_read_work)} of the kinds that account for it."""
+    out = {}
+    for k in range(lib().fr_prof_kernel_count()):
+        w = c_double(0)
+        check(lib().fr_prof_read_work(k, ctypes.byref(w)), "fr_prof_read_work")
+        if w.value:
+            out[lib().fr_prof_kernel_name(k).decode()] = w.value
+    return out
 
 
 def prof_read():
