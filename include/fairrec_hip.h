@@ -482,6 +482,13 @@ FR_API int fr_bpr_outer(const float* a, const float* c, int64_t B, float* loss, 
                         size_t ws_bytes, void* stream);
 /* The same on the four columns themselves: a = pos - neg and c = pos_bias - neg_bias are formed in the kernel and the
  * gradients of all four come out (d_neg = -d_pos, d_neg_bias = -d_pos_bias): no elementwise launches around the loss. */
+/* fr_bpr_outer_rect: the same term matrix for Nc rows (c) and Na columns (a) of possibly different batches, scaled by
+ * `inv`: loss[0] = inv * sum_ij -log(1e-10 + sigmoid(a_j + c_i)); da [Na] / dc [Nc] (either may be NULL) = the column / row
+ * sums of its derivative.  A row-sharded step evaluates its part of the GLOBAL batch's [G B, G B] matrix with it: own
+ * columns against all rows (da), own rows against all columns (dc), inv = 1 / (G B)^2 (fairrec/functional.py). */
+FR_API size_t fr_bpr_outer_rect_workspace_bytes(int64_t Na, int64_t Nc);
+FR_API int fr_bpr_outer_rect(const float* a, int64_t Na, const float* c, int64_t Nc, float inv, float* loss, float* da,
+                             float* dc, void* ws, size_t ws_bytes, void* stream);
 FR_API int fr_bpr_outer2(const float* pos, const float* neg, const float* pos_bias, const float* neg_bias, int64_t B,
                          float* loss, float* d_pos, float* d_neg, float* d_pos_bias, float* d_neg_bias, void* ws,
                          size_t ws_bytes, void* stream);

@@ -116,10 +116,13 @@ __device__ __forceinline__ float bpr_term_fast(float x, float& dterm) {
 }
 
 // a2 / c2 (optional): the inputs are the differences a - a2 and c - c2, formed here; ndc (optional) receives -dc.
+// Rectangular form: Nc rows (c) x Na columns (a), every term scaled by `inv` (the square loss: Na = Nc = B, inv = 1 / B^2);
+// a row-sharded step evaluates its rows / columns of the GLOBAL batch's matrix with it (fr_bpr_outer_rect).
 __global__ __launch_bounds__(256) void bpr_outer_kernel(const float* __restrict__ a, const float* __restrict__ a2,
-                                                        const float* __restrict__ c, const float* __restrict__ c2, int B,
-                                                        float* __restrict__ dc, float* __restrict__ ndc,
+                                                        const float* __restrict__ c, const float* __restrict__ c2, int Na,
+                                                        int Nc, float inv, float* __restrict__ dc, float* __restrict__ ndc,
                                                         float* __restrict__ ga_part, float* __restrict__ loss_part) {
+    const int B = Nc;      // rows
     __shared__ float cs[OUTER_ROWS];
     __shared__ float red[4][OUTER_ROWS + 1];
     const int i0 = blockIdx.x * OUTER_ROWS;
@@ -127,12 +130,11 @@ __global__ __launch_bounds__(256) void bpr_outer_kernel(const float* __restrict_
         cs[threadIdx.x] = (i0 + threadIdx.x < B) ? c[i0 + threadIdx.x] - (c2 ? c2[i0 + threadIdx.x] : 0.f) : 0.f;
     __syncthreads();
     const int ni = min(OUTER_ROWS, B - i0);
-    const float inv = 1.f / ((float)B * (float)B);
     float lsum = 0.f;
     float rs[OUTER_ROWS];
 #pragma unroll
     for (int i = 0; i < OUTER_ROWS; ++i) rs[i] = 0.f;
-    for (int j = threadIdx.x; j < B; j += 256) {
+    for (int j = threadIdx.x; j < Na; j += 256) {
         const float aj = a2 ? a[j] - a2[j] : a[j];
         float gcol = 0.f;
 #pragma unroll
@@ -144,7 +146,7 @@ __global__ __launch_bounds__(256) void bpr_outer_kernel(const float* __restrict_
                 rs[i] += dt;
             }
         }
-        ga_part[(size_t)blockIdx.x * B + j] = gcol * inv;
+        ga_part[(size_t)blockIdx.x * Na + j] = gcol * inv;
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     lsum = wave_sum(lsum);
@@ -158,7 +160,7 @@ __global__ __launch_bounds__(256) void bpr_outer_kernel(const float* __restrict_
     if (threadIdx.x < ni) {
         const int i = threadIdx.x;
         const float v = (((red[0][i] + red[1][i]) + red[2][i]) + red[3][i]) * inv;
-        dc[i0 + i] = v;
+        if (dc) dc[i0 + i] = v;
         if (ndc) ndc[i0 + i] = -v;
     }
     if (threadIdx.x == 0)
@@ -324,12 +326,47 @@ static int bpr_outer_impl(const float* a, const float* a2, const float* c, const
     float* ga_part = (float*)((char*)ws + align_up((size_t)nb * 4, 256));
     {
         ProfScope prof(K_BPR, stream);
-        FR_LAUNCH(prof, bpr_outer_kernel, dim3(nb), dim3(256), 0, stream, a, a2, c, c2, (int)B, dc, ndc, ga_part, loss_part);
+        FR_LAUNCH(prof, bpr_outer_kernel, dim3(nb), dim3(256), 0, stream, a, a2, c, c2, (int)B, (int)B,
+                  1.f / ((float)B * (float)B), dc, ndc, ga_part, loss_part);
     }
     FR_CHECK_LAUNCH();
     hipLaunchKernelGGL(bpr_outer_reduce_kernel, dim3((unsigned)((B + 63) / 64)), dim3(256), 0, stream,
                        (const float*)ga_part, nb, (int)B, da, nda);
     FR_CHECK_LAUNCH();
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, stream, (const float*)loss_part, nb, 1.f, loss);
+    FR_CHECK_LAUNCH();
+    return FR_OK;
+}
+
+// The same term matrix for Nc rows and Na columns that need not be the same batch: loss[0] = inv * sum_{i < Nc, j < Na}
+// -log(1e-10 + sigmoid(a_j + c_i)), da[j] = inv * sum_i f'(a_j + c_i), dc[i] = inv * sum_j f'(a_j + c_i) (either may be
+// NULL).  A row-sharded PFCN_BiasedMF step evaluates its share of the GLOBAL batch's [G B, G B] matrix with two calls
+// (its columns against every row, its rows against every column; inv = 1 / (G B)^2).
+extern "C" size_t fr_bpr_outer_rect_workspace_bytes(int64_t Na, int64_t Nc) {
+    if (Na < 1 || Nc < 1) return 0;
+    const size_t nb = (size_t)(Nc + fr::OUTER_ROWS - 1) / fr::OUTER_ROWS;
+    return align_up(nb * 4, 256) + nb * (size_t)Na * 4;
+}
+
+extern "C" int fr_bpr_outer_rect(const float* a, int64_t Na, const float* c, int64_t Nc, float inv, float* loss, float* da,
+                                 float* dc, void* ws, size_t ws_bytes, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    FR_CHECK_ARG(a && c && loss && ws && Na >= 1 && Nc >= 1 && Na < (1ll << 31) && Nc < (1ll << 31) &&
+                 ws_bytes >= fr_bpr_outer_rect_workspace_bytes(Na, Nc), "fr_bpr_outer_rect: bad argument");
+    const int nb = (int)((Nc + OUTER_ROWS - 1) / OUTER_ROWS);
+    float* loss_part = (float*)ws;
+    float* ga_part = (float*)((char*)ws + align_up((size_t)nb * 4, 256));
+    {
+        ProfScope prof(K_BPR, stream);
+        FR_LAUNCH(prof, bpr_outer_kernel, dim3(nb), dim3(256), 0, stream, a, (const float*)nullptr, c, (const float*)nullptr,
+                  (int)Na, (int)Nc, inv, dc, (float*)nullptr, ga_part, loss_part);
+    }
+    FR_CHECK_LAUNCH();
+    if (da) {
+        hipLaunchKernelGGL(bpr_outer_reduce_kernel, dim3((unsigned)((Na + 63) / 64)), dim3(256), 0, stream,
+                           (const float*)ga_part, nb, (int)Na, da, (float*)nullptr);
+        FR_CHECK_LAUNCH();
+    }
     hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, stream, (const float*)loss_part, nb, 1.f, loss);
     FR_CHECK_LAUNCH();
     return FR_OK;

@@ -174,6 +174,9 @@ _PROTOS = {
     "fr_rowdot_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p]),
     "fr_bpr_workspace_bytes": (c_size_t, [c_int64, c_int32]),
     "fr_bpr": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "fr_bpr_outer_rect_workspace_bytes": (c_size_t, [c_int64, c_int64]),
+    "fr_bpr_outer_rect": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
+                                  c_size_t, c_void_p]),
     "fr_bpr_outer": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "fr_softmax_ce": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p,
                               c_void_p]),

@@ -147,6 +147,33 @@ class BprBroadcastPacked(torch.autograd.Function):
         return ds, _C.zeros_cached(ub, dev), dib.reshape(ibs), _C.zeros_cached(gb, dev)
 
 
+class BprBroadcastGlobal(torch.autograd.Function):
+    """BprBroadcastPacked on row-sharded tables: the [B] + [B, 1] broadcast runs over the GLOBAL batch (every rank's rows and
+    columns: ShardedGenericEngine.global_bpr_broadcast), so a G-rank step is the single-device step on the concatenated
+    batch."""
+
+    @staticmethod
+    def forward(ctx, scores, user_bias, item_bias, global_bias, engine):
+        B = scores.numel() // 2
+        ib = item_bias.reshape(-1)
+        a = (scores[:B] - scores[B:]).contiguous()
+        c = (ib[:B] - ib[B:]).contiguous()
+        loss, da, dc = engine.global_bpr_broadcast(a, c)
+        ctx.save_for_backward(da, dc)
+        ctx.shapes = (user_bias.shape, item_bias.shape, global_bias.shape)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        da, dc = ctx.saved_tensors
+        ub, ibs, gb = ctx.shapes
+        dev = da.device
+        if not _C.is_one(g):
+            da, dc = da * g, dc * g
+        return (torch.cat([da, -da]), torch.zeros(ub, device=dev), torch.cat([dc, -dc]).reshape(ibs), torch.zeros(gb, device=dev),
+                None)
+
+
 class SigmoidBce(torch.autograd.Function):
     """nn.BCELoss()(sigmoid(y), label) (pfcn_biasedmf.py:212-213) -- the BCE leg of fr_nfcf_loss."""
 

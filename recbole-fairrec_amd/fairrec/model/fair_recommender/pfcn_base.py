@@ -16,7 +16,7 @@ import torch
 import torch.nn as nn
 
 from ...engine import GenericEngine
-from ...functional import Bpr, BprBroadcastPacked, RowDot, SigmoidBce, SoftmaxCe
+from ...functional import Bpr, BprBroadcastGlobal, BprBroadcastPacked, RowDot, SigmoidBce, SoftmaxCe
 from ...utils.enum_type import InputType
 from ..abstract_recommender import FairRecommender
 from ..layers import MLPLayers
@@ -220,7 +220,10 @@ class PFCNBase(FairRecommender):
             ib = eng.lookup("item_bias.weight", items)
             # packed columns: the differences and all four gradient columns come out of the loss kernel (bit-identical to
             # BprBroadcast on the slices, without its ten elementwise launches)
-            bpr_loss = BprBroadcastPacked.apply(torch.cat([dp, dn]), ub, ib, self.global_bias)
+            if self.shard is not None:      # row-sharded tables: the broadcast runs over the GLOBAL batch (one all-gather)
+                bpr_loss = BprBroadcastGlobal.apply(torch.cat([dp, dn]), ub, ib, self.global_bias, eng)
+            else:
+                bpr_loss = BprBroadcastPacked.apply(torch.cat([dp, dn]), ub, ib, self.global_bias)
         else:
             bpr_loss = Bpr.apply(dp, dn)
         if self.filter_mode != 'none':

@@ -14,9 +14,11 @@ a mean over interactions (BCE, MSE, BPR).  NFCF's differential-fairness regulari
 per-group score sums, the number of items K): `global_item_df` evaluates it on the GLOBAL batch -- every positive row's
 (score, group) goes to the owner of its item in the slot its id took in the lookup, the owner's per-(item, group) sums
 come back, K and the groups present ride in the tails: two small all-to-alls, and a G-rank step equals the single-device
-step on the concatenated batch (nfcf.py:76-97).  BatchNorm inside the PFCN MLPs and the B x B broadcast of PFCN_BiasedMF
-are evaluated per rank on the local batch ("parity is defined per-GPU-batch"); FOCF, whose fairness
-term needs the global per-item statistics, has its own exact engine (fairrec/sharded.py).
+step on the concatenated batch (nfcf.py:76-97).  PFCN_BiasedMF's [B] + [B, 1] -> [B, B] broadcast loss runs over the global
+batch as well (`global_bpr_broadcast`: the term matrix factors into row and column sums, one all-gather of two [B] columns).
+Only BatchNorm inside the PFCN MLPs is evaluated per rank on the local batch ("parity is defined
+per-GPU-batch"); FOCF, whose fairness term needs the global per-item statistics, has its own exact engine
+(fairrec/sharded.py).
 
 Kernels come from an `ops` object (default: HIP through fairrec._C); tests inject a CPU double to run the schedule
 over gloo.  The product path is HIP only.
@@ -95,6 +97,16 @@ class HipTableOps:
         _C.check(_C.lib().fr_nfcf_df_apply(reply.data_ptr(), slot.data_ptr(), S, off, cap, G, out.data_ptr(), label.data_ptr(),
                                            sst.data_ptr(), out.numel(), fair_weight, scale, dy.data_ptr(), loss.data_ptr(),
                                            ws.data_ptr(), ws.numel(), _C.current_stream()), "fr_nfcf_df_apply")
+
+    def bpr_outer_rect(self, a, c, inv, loss, da, dc, ws_holder):
+        """fr_bpr_outer_rect: rows c x columns a of PFCN_BiasedMF's broadcast loss matrix, scaled by inv."""
+        lib = _C.lib()
+        need = lib.fr_bpr_outer_rect_workspace_bytes(a.numel(), c.numel())
+        ws = ws_holder.get("ws")
+        if ws is None or ws.numel() < need:
+            ws = ws_holder["ws"] = torch.empty(need, dtype=torch.uint8, device=a.device)
+        _C.check(lib.fr_bpr_outer_rect(a.data_ptr(), a.numel(), c.data_ptr(), c.numel(), inv, loss.data_ptr(), _C.ptr(da),
+                                       _C.ptr(dc), ws.data_ptr(), ws.numel(), _C.current_stream()), "fr_bpr_outer_rect")
 
     def df_workspace(self, B, n_slots, device):
         return torch.zeros(_C.lib().fr_nfcf_df_workspace_bytes(B, n_slots), dtype=torch.uint8, device=device)
@@ -427,6 +439,26 @@ class ShardedGenericEngine(GenericEngine):
         ops.df_owner(t, buf["rec_recv"], G, cap, buf["rep_send"], buf["ws"], B, self.err_flag)
         self._a2a(buf["rep_recv"], buf["rep_send"])
         ops.df_apply(buf["rep_recv"], slot, S, off, cap, G, out, label, sst, float(fair_weight), float(G), dy, loss, buf["ws"])
+
+    def global_bpr_broadcast(self, a, c):
+        """PFCN_BiasedMF's [B] + [B, 1] -> [B, B] training loss (pfcn_biasedmf.py:192-195) on the GLOBAL batch: the term matrix
+        of G B rows x G B columns factors into row and column sums, so one all-gather of the ranks' (a, c) columns and two
+        rectangular passes (this rank's columns against every row, its rows against every column) give this rank's exact
+        gradients.  Returns (loss share, da, dc) scaled so that the engine's mean over the ranks is the global loss / the
+        global gradient (x G)."""
+        G, B = self.G, a.numel()
+        mine = torch.cat([a, c]).contiguous()
+        allv = torch.empty(G * 2 * B, dtype=torch.float32, device=self.device)
+        dist.all_gather_into_tensor(allv, mine, group=self.group)
+        allv = allv.view(G, 2, B)
+        a_all, c_all = allv[:, 0].reshape(-1).contiguous(), allv[:, 1].reshape(-1).contiguous()
+        inv = 1.0 / (float(G * B) ** 2)
+        loss, scratch = torch.empty(1, dtype=torch.float32, device=self.device), torch.empty(1, dtype=torch.float32, device=self.device)
+        da, dc = torch.empty_like(a), torch.empty_like(c)
+        hold = self.__dict__.setdefault("_bpr_ws", [{}, {}])
+        self.ops.bpr_outer_rect(a, c_all, inv, loss, da, None, hold[0])          # own columns x all rows
+        self.ops.bpr_outer_rect(a_all, c, inv, scratch, None, dc, hold[1])      # all columns x own rows
+        return loss * float(G), da * float(G), dc * float(G)
 
     def batch_segments(self, name):
         """Sorted segments of THIS rank's ids of the last lookup in `name` (per-rank batch statistics)."""

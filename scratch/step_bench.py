@@ -7,9 +7,16 @@ import bench
 if os.environ.get("OBJ"):
     bench.OBJECTIVE = os.environ["OBJ"]
 tag = os.environ.get("TAG", "run")
-sys.argv = ["bench.py", "--no-cpu-baseline", "--graph-only"] + sys.argv[1:]
+sys.argv = ["bench.py", "--no-cpu-baseline"] + (["--graph-only"] if "--no-graph" not in sys.argv else []) + sys.argv[1:]
 buf = io.StringIO()
-with contextlib.redirect_stdout(buf):
+import torch
+prio = os.environ.get("MAIN_PRIO")
+ctx = torch.cuda.stream(torch.cuda.Stream(priority=int(prio))) if prio is not None else contextlib.nullcontext()
+if os.environ.get("SIDE_PRIO") is not None:      # the look-ahead stream of the FOCF engine at another priority
+    import fairrec.model.fair_recommender.focf as F
+    _orig = torch.cuda.Stream
+    F.torch.cuda.Stream = lambda *a, **k: _orig(*a, priority=int(os.environ["SIDE_PRIO"]), **k)
+with contextlib.redirect_stdout(buf), ctx:
     bench.main()
 line = [l for l in buf.getvalue().splitlines() if l.startswith("{")][-1]
 d = json.loads(line)

@@ -318,3 +318,26 @@ def test_pfcn_biasedmf_full_batch_at_the_baseline_width(mode):
     noise["loss"] = spread("loss")
     z.update(ref)
     _run_case(z, sharded=False, noise=noise)
+
+
+def test_bpr_outer_rect_matches_float64_torch():
+    """fr_bpr_outer_rect (rows c x columns a of PFCN_BiasedMF's broadcast loss, the piece a row-sharded step evaluates of
+    the GLOBAL batch's matrix) against the term matrix in float64; Na != Nc, neither a multiple of the tile sizes."""
+    from fairrec.sharded_engine import HipTableOps
+    g = torch.Generator().manual_seed(4)
+    Na, Nc = 1000, 2300
+    a, c = torch.randn(Na, generator=g), torch.randn(Nc, generator=g) * 0.5
+    inv = 1.0 / (Na * Nc)
+    x = (a[None, :] + c[:, None]).double()
+    sig = torch.sigmoid(x)
+    d = -(sig * (1 - sig)) / (1e-10 + sig) * inv
+    ops = HipTableOps()
+    loss, da, dc = torch.zeros(1, device="cuda"), torch.zeros(Na, device="cuda"), torch.zeros(Nc, device="cuda")
+    hold = {}
+    ops.bpr_outer_rect(a.cuda(), c.cuda(), inv, loss, da, dc, hold)
+    np.testing.assert_allclose(float(loss), float((-torch.log(1e-10 + sig)).sum() * inv), rtol=2e-5)
+    np.testing.assert_allclose(da.cpu().numpy(), d.sum(0).float().numpy(), rtol=2e-4, atol=1e-9)
+    np.testing.assert_allclose(dc.cpu().numpy(), d.sum(1).float().numpy(), rtol=2e-4, atol=1e-9)
+    da2 = torch.zeros(Na, device="cuda")
+    ops.bpr_outer_rect(a.cuda(), c.cuda(), inv, loss, da2, None, hold)        # either gradient may be left out
+    assert torch.equal(da, da2)

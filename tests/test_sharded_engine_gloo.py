@@ -116,6 +116,16 @@ class _Ops:                        # CPU double of HipTableOps
         from oracle import focf as O
         O.adam_dense_step_(p, g.clone(), m, v, step, hyper.lr, hyper.weight_decay)
 
+    def bpr_outer_rect(self, a, c, inv, loss, da, dc, ws_holder):      # CPU double of fr_bpr_outer_rect
+        x = (a[None, :] + c[:, None]).double()
+        sig = torch.sigmoid(x)
+        loss[0] = float((-torch.log(1e-10 + sig)).sum() * inv)
+        d = -(sig * (1 - sig)) / (1e-10 + sig) * inv
+        if da is not None:
+            da.copy_(d.sum(0).float())
+        if dc is not None:
+            dc.copy_(d.sum(1).float())
+
     # --- CPU doubles of fr_nfcf_df_pack / _owner / _apply (include/fairrec_hip.h: buffers [G, cap + 1, 2] and [G, cap + 1, 4])
     def df_workspace(self, B, n_slots, device):
         return torch.zeros(8, dtype=torch.uint8)
@@ -379,3 +389,74 @@ def test_global_differential_fairness_equals_single_process(tmp_path, world):
     for q in range(world):
         np.testing.assert_allclose(parts[q]["w"].numpy(), P[1].data.numpy(), rtol=2e-5, atol=1e-7)
         np.testing.assert_allclose(parts[q]["b"].numpy(), P[2].data.numpy(), rtol=2e-5, atol=1e-7)
+
+
+def _bpr_worker(rank, world, port, out_dir):
+    for p in (ROOT, os.path.join(ROOT, "recbole-fairrec_amd"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from fairrec.optim import AdamHyper
+        from fairrec.sharded_engine import ShardedGenericEngine
+        U0, I0, w0, b0, u, i, r = _data(world)
+        g = torch.Generator().manual_seed(31)
+        bias0 = torch.randn(NI, 1, generator=g) * 0.2
+        neg = torch.randint(1, NI, (T, world * B), generator=g)
+        eng = ShardedGenericEngine("cpu", ops=_Ops())
+        Us, Is, Bs = U0[rank::world].clone(), I0[rank::world].clone(), bias0[rank::world].clone()
+        eng.add_table("U", torch.nn.Parameter(Us), table=_Table(Us), n_rows_global=NU)
+        eng.add_table("I", torch.nn.Parameter(Is), table=_Table(Is), n_rows_global=NI)
+        eng.add_table("bias", torch.nn.Parameter(Bs), table=_Table(Bs), n_rows_global=NI)
+        eng.hyper = AdamHyper(LR, WD, device="cpu")
+        losses = []
+        for t in range(T):
+            sl = slice(rank * B, (rank + 1) * B)
+            eng.zero_grad()
+            items = torch.cat([i[t][sl], neg[t][sl]])
+            ue, ie, ib = eng.lookup("U", u[t][sl]), eng.lookup("I", items), eng.lookup("bias", items).reshape(-1)
+            a = (ue * ie[:B]).sum(-1) - (ue * ie[B:]).sum(-1)
+            c = ib[:B] - ib[B:]
+            loss_v, da, dc = eng.global_bpr_broadcast(a.detach().contiguous(), c.detach().contiguous())
+            loss = (a * da).sum() - (a * da).sum().detach() + (c * dc).sum() - (c * dc).sum().detach() + loss_v[0]
+            loss.backward()
+            eng.backward_adam()
+            losses.append(float(loss))
+        torch.save({"U": Us, "I": Is, "bias": Bs, "loss": losses}, os.path.join(out_dir, f"r{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_global_bpr_broadcast_equals_single_process(tmp_path, world):
+    """PFCN_BiasedMF's training loss (pfcn_biasedmf.py:192-195: `[B] + [B, 1] -> [B, B]`, mean over all pairs (i, j)) on
+    row-sharded tables: with `global_bpr_broadcast` the G-rank step equals the single-process step on the concatenated batch
+    -- the (G B)^2 matrix of the GLOBAL batch, not G matrices of B^2."""
+    from oracle import focf as O
+    mp.spawn(_bpr_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    U0, I0, w0, b0, u, i, r = _data(world)
+    g = torch.Generator().manual_seed(31)
+    bias0 = torch.randn(NI, 1, generator=g) * 0.2
+    neg = torch.randint(1, NI, (T, world * B), generator=g)
+    P = [torch.nn.Parameter(x.clone()) for x in (U0, I0, bias0)]
+    ms, vs = [torch.zeros_like(p) for p in P], [torch.zeros_like(p) for p in P]
+    ref_loss = []
+    for t in range(T):
+        for p in P:
+            p.grad = None
+        ue = P[0][u[t]]
+        a = (ue * P[1][i[t]]).sum(-1) - (ue * P[1][neg[t]]).sum(-1)                      # [G B]
+        c = P[2][i[t]] - P[2][neg[t]]                                                   # [G B, 1]
+        loss = -torch.log(1e-10 + torch.sigmoid(a + c)).mean()                          # the reference's broadcast
+        loss.backward()
+        for k, p in enumerate(P):
+            O.adam_dense_step_(p.data, p.grad, ms[k], vs[k], t + 1, LR, WD)
+        ref_loss.append(float(loss))
+    parts = [torch.load(os.path.join(str(tmp_path), f"r{q}.pt")) for q in range(world)]
+    np.testing.assert_allclose(np.mean([p["loss"] for p in parts], axis=0), ref_loss, rtol=1e-5)
+    for tag, ref in (("U", P[0]), ("I", P[1]), ("bias", P[2])):
+        full = torch.zeros_like(ref.data)
+        for q in range(world):
+            full[q::world] = parts[q][tag]
+        np.testing.assert_allclose(full.numpy(), ref.data.numpy(), rtol=2e-5, atol=1e-7, err_msg=tag)
