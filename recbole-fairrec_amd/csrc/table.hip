@@ -20,6 +20,11 @@ __global__ __launch_bounds__(256) void table_flush_kernel(TableV T_, AdamC c) {
     const TableV T = resolved(T_);
     const int lane = threadIdx.x & 63;
     const long long nw = (long long)gridDim.x * 4;
+    if (E == 1 && T.D == 1) {      // narrow table: 64 rows per wave (table.hpp)
+        for (long long w = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); w * 64 < T.n_rows; w += nw)
+            sweep_rows_narrow(T, c, w * 64, T.n_rows, T.step, 0x7fffffff, lane);
+        return;
+    }
     for (long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); row < T.n_rows; row += nw)
         sweep_row<E>(T, c, row, T.step, 0x7fffffff, lane);
 }
@@ -142,7 +147,10 @@ __global__ __launch_bounds__(256) void table_apply_grad_kernel(ApplyJob ja, Appl
     if (wv < J.sw_n) {   // longest jobs first
         long long lo, hi;
         sweep_range(T.n_rows, T.step, J.sweep_period, lo, hi);
-        if (sweep_pairs(E)) {     // a wave takes two adjacent rows of the slice (see sweep_row_pair)
+        if (E == 1 && T.D == 1) {     // narrow table: 64 adjacent rows of the slice, one per lane
+            const long long a = lo + 64 * wv;
+            if (a < hi) sweep_rows_narrow(T, c, a, hi, T.step, T.step, lane);
+        } else if (sweep_pairs(E)) {     // a wave takes two adjacent rows of the slice (see sweep_row_pair)
             const long long a = lo + 2 * wv;
             if (a < hi) sweep_row_pair<E>(T, c, a, a + 1 < hi ? a + 1 : -1, T.step, T.step, lane);
         } else if (lo + wv < hi) {
@@ -369,7 +377,7 @@ static int apply_grad_impl(const char* who, const fr_table* ta, const fr_table* 
     if ((rc = side_join(ws_a, stream)) || (tb && (rc = side_join(ws_b, stream)))) return rc;
     // waves reserved for the sweeper = rows of a full slice (the slice itself depends on the effective step, which may
     // live on the device)
-    const int per_wave = sweep_pairs((ta->dim + 63) / 64) ? 2 : 1;
+    const int per_wave = sweep_rows_per_wave(ta->dim);
     const long long sw_a = sweep_a > 0 ? ((ta->n_rows + sweep_a - 1) / sweep_a + per_wave - 1) / per_wave : 0;
     const long long sw_b = tb && sweep_b > 0 ? ((tb->n_rows + sweep_b - 1) / sweep_b + per_wave - 1) / per_wave : 0;
     const long long waves = M + std::max(sw_a, sw_b);

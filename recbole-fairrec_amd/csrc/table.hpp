@@ -137,6 +137,78 @@ __device__ __forceinline__ void sweep_row(const TableV& T, const AdamC& c, long 
     if (lane == 0) T.last[row] = upto;
 }
 
+// A NARROW table (D == 1: the user / item bias columns of PFCN_BiasedMF, [N, 1]): a wave takes 64 consecutive rows of the
+// sweep slice, one row per lane, instead of one row with 63 idle lanes -- the bias tables' share of a PFCN filter step went
+// from as much VALU time as the embedding tables' sweep (128 us of 1.2 ms at 10 M rows) to a few us.  Every lane replays its
+// own stretch (last[row], upto] inside one wave-uniform loop over the steps (the per-step scalars are the same for all rows),
+// masked off before its own first step: the same operations per element as replay<1>, so the same bits.
+__device__ __forceinline__ void sweep_rows_narrow(const TableV& T, const AdamC& c, long long row0, long long hi, int upto,
+                                                  int skip_from, int lane) {
+    const long long row = row0 + lane;
+    const bool in = row < hi;
+    const int st = in ? T.stamp[row] : 0x7fffffff;
+    const int lt = in ? T.last[row] : upto;
+    float p = in ? T.p[row] : 0.f, m = in ? T.m[row] : 0.f, v = in ? T.v[row] : 0.f;
+    const bool act = in && st < skip_from && lt < upto;
+    const int t0 = act ? lt : upto;
+    int jmin = t0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) jmin = min(jmin, __shfl_xor(jmin, o, 64));
+    jmin = uniform(jmin);
+    if (jmin >= upto) return;
+    const bool scaled = !FR_ADAM_PRECISE && c.k1 != 0.f;       // as replay_n chooses
+    if (scaled) {
+        m *= c.inv_k1;
+        v *= c.inv_k2;
+    }
+    int j = jmin + 1;
+    if (scaled) {
+        auto one = [&](int jj, float A, float Bc) {      // computed by every lane, kept by the lanes whose stretch has begun
+            float pn = p, mn = m, vn = v;                 // (selects, not a branch: no exec-mask round trip per step)
+            adam_zero_scaled(pn, mn, vn, A, Bc, c);
+            const bool on = jj > t0;
+            p = on ? pn : p;
+            m = on ? mn : m;
+            v = on ? vn : v;
+        };
+        // The per-step scalars (A_j, B_j) of 64 steps arrive with ONE vector load (lane l: step jb + l) and are handed out by
+        // v_readlane; the next 64 are requested before the current ones are used.  (As scalar loads four steps ahead -- the
+        // way the wide tables' loops get them -- every iteration waited for the scalar cache: with one such wave per SIMD
+        // nothing hides that, 220 cycles per step.)
+        auto fetch = [&](int jb) {
+            const int jj = jb + lane < c.cap ? jb + lane : c.cap;
+            return c.sc[2 * jj + 1];
+        };
+        float2 cur = fetch(j);
+        for (int jb = j; jb <= upto; jb += 64) {
+            const float2 nxt = fetch(jb + 64);
+            const int n = upto - jb + 1 < 64 ? upto - jb + 1 : 64;
+            for (int t = 0; t < n; ++t) {
+                const float A = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cur.x), t));
+                const float Bc = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cur.y), t));
+                one(jb + t, A, Bc);
+            }
+            cur = nxt;
+        }
+        m *= c.k1;
+        v *= c.k2;
+    } else {
+        for (; j <= upto; ++j) {
+            const float4 s = step_scalars4(c, j);
+            if (j > t0) adam_zero(p, m, v, s.x, s.y, c);
+        }
+    }
+    if (act) {
+        T.p[row] = p;
+        T.m[row] = m;
+        T.v[row] = v;
+        T.last[row] = upto;
+    }
+}
+
+// rows of a sweep slice one sweeper wave takes
+__host__ __device__ constexpr int sweep_rows_per_wave(int dim) { return dim == 1 ? 64 : (dim <= 64 ? 2 : 1); }
+
 // Pairs pay off while both rows' fragments fit a small register budget: D <= 64 (one register per fragment).  Measured
 // with pairs at every width: NFCF (D = 256) step 0.49 -> 0.60 ms, PFCN (D = 128) filter pass 2.09 -> 2.43 ms -- the extra
 // fragments cost more occupancy than the packed VALU saves -- so wider rows go one per wave.
