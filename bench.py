@@ -281,6 +281,9 @@ def main():
     ap.add_argument("--item-dist", default="uniform", choices=["uniform", "zipf", "grouped", "unique"])
     ap.add_argument("--sweep", type=int, default=None, help="lazy-Adam sweep period (default: auto)")
     ap.add_argument("--force-sharded", action="store_true", help="use the row-sharded engine even on one GPU")
+    ap.add_argument("--force-fused", action="store_true",
+                    help="--item-dist grouped: take the one-launch step although the batches are item-complete (the engine "
+                         "takes the three-launch chain for them by default: ~100 interactions share every item row)")
     ap.add_argument("--age", type=int, default=0,
                     help="optimizer steps run before the warm-up so that the lazy-Adam staleness is stationary "
                          "(default: one sweep period)")
@@ -352,7 +355,7 @@ def main():
         eng = FocfEngine(U, I, OBJECTIVE, FAIR_WEIGHT, 5.0)
         FusedLazyAdam(eng, lr=LR, weight_decay=WD, sweep_period=args.sweep)
         eng.defer_loss = True     # every forward below is followed by backward_adam; the loss is read at the end
-        eng.item_runs = args.item_dist == "grouped"    # what the Trainer sets when it is fed by FOCFDataLoader
+        eng.item_runs = args.item_dist == "grouped" and not args.force_fused    # what the Trainer sets when fed by FOCFDataLoader
     else:
         from fairrec.sharded import ShardedFocfEngine, ShardedFocfEngineV2, shard_rows
         if not torch.distributed.is_initialized():

@@ -1,14 +1,17 @@
 #!/bin/bash
 # Collects the rocprofv3 evidence for one round on the GPU box (run through gpurun from the repo root):
-#   gpurun -- 'bash profiles/collect.sh r01'
+#   gpurun -- 'bash profiles/collect.sh r03'
 # 1) --kernel-trace --stats of the default `bench.py` command (same command whose JSON line is reported)
 # 2) --pmc FETCH_SIZE and 3) --pmc WRITE_SIZE (separate passes, TCC slot limits) of profiles/pmc_workload.py,
 #    which first runs table_flush_kernel on a known byte count to calibrate the counters in our access pattern.
 # 4) --kernel-trace of `bench.py --graph-only`, reduced by profiles/trace_window.py to the hipGraph replay window
+# 5) plain (un-profiled) bench lines: default, --steps 20, --item-dist zipf / grouped (chain and one-launch step)
+# 6) the other BASELINE configs: bench.py --workload pfcn10m / nfcf100m / fairgo10m, each plain and under --kernel-trace --stats
+# 7) --pmc SQ_VALU_MFMA_BUSY_CYCLES ... of profiles/pmc_pfcn.py (MFMA utilisation of the PFCN step)
 # Raw output lands in gpurun_out/<round>/ (scratch); `python profiles/summarize.py <round>` then writes the
 # tracked summaries into profiles/.
 set -u
-ROUND=${1:-r01}
+ROUND=${1:-r03}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$ROUND
 mkdir -p $OUT
@@ -17,7 +20,25 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $R/profiles/pmc_workload.py > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $R/profiles/pmc_workload.py > $OUT/pmc_write.log 2>&1
 grep -h '^{' $OUT/bench_under_rocprof.log | tail -1 > $OUT/bench_line.json
-# 4) kernel trace of the hipGraph replay alone -> per-kernel durations and a two-step timeline inside the replay window
 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace -- python3 $R/bench.py --no-cpu-baseline --graph-only > $OUT/trace.log 2>&1
 python3 $R/profiles/trace_window.py $OUT/trace 200 > $OUT/graph_window.txt 2>&1
-ls -R $OUT | head -30
+cd $R
+python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
+python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_steps20.json 2> $OUT/bench_steps20.err
+python3 bench.py --no-cpu-baseline --graph-only --item-dist zipf > $OUT/bench_zipf.json 2>/dev/null
+python3 bench.py --no-cpu-baseline --graph-only --item-dist grouped > $OUT/bench_grouped_chain.json 2>/dev/null
+python3 bench.py --no-cpu-baseline --graph-only --item-dist grouped --force-fused > $OUT/bench_grouped_fused.json 2>/dev/null
+python3 bench.py --workload pfcn10m --steps 20 --warmup 5 > $OUT/pfcn10m.json 2> $OUT/pfcn10m.err
+python3 bench.py --workload nfcf100m --steps 20 --warmup 5 > $OUT/nfcf100m.json 2> $OUT/nfcf100m.err
+python3 bench.py --workload nfcf100m --nfcf-users 1000001 --nfcf-items 100001 --steps 20 --warmup 5 > $OUT/nfcf1m.json 2> $OUT/nfcf1m.err
+timeout 2400 python3 bench.py --workload fairgo10m --steps 3 --warmup 3 > $OUT/fairgo10m.json 2> $OUT/fairgo10m.err
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_pfcn -- python3 $R/bench.py --workload pfcn10m --steps 10 --warmup 5 > $OUT/pfcn_under_rocprof.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_nfcf -- python3 $R/bench.py --workload nfcf100m --nfcf-users 1000001 --nfcf-items 100001 --steps 10 --warmup 5 > $OUT/nfcf_under_rocprof.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_fairgo -- python3 $R/bench.py --workload fairgo10m --users 1000001 --items 100001 --steps 3 --warmup 3 > $OUT/fairgo_under_rocprof.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 --output-format csv -d $OUT/pmc_mfma -- python3 $R/profiles/pmc_pfcn.py > $OUT/pmc_mfma.log 2>&1
+python3 $R/profiles/pmc_mfma_summary.py $OUT/pmc_mfma $OUT/pmc_mfma_pfcn.json > $OUT/pmc_mfma.md 2>&1
+if [ -f $R/scratch/lib/libfairrec_hip_trace.so ]; then
+  cd $R && FAIRREC_HIP_LIB=$R/scratch/lib/libfairrec_hip_trace.so python3 scratch/step_trace.py > $OUT/wave_trace.txt 2>&1
+fi
+ls $OUT | head -60

@@ -67,3 +67,21 @@ for k in sorted(set(fetch) | set(write)):
 open(os.path.join(dst, f"{rnd}_pmc.md"), "w").write("\n".join(lines) + "\n")
 json.dump(traffic, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
 print("\n".join(lines))
+
+# ---- round 3: plain bench lines, the other workloads, MFMA counters, the wave timeline -------------------------------------
+for name in ("bench.json", "bench_steps20.json", "bench_zipf.json", "bench_grouped_chain.json", "bench_grouped_fused.json",
+             "pfcn10m.json", "nfcf100m.json", "nfcf1m.json", "fairgo10m.json", "pmc_mfma.md", "wave_trace.txt"):
+    f = os.path.join(src, name)
+    if os.path.exists(f) and os.path.getsize(f) > 0:
+        if name.endswith(".json"):      # keep the JSON line only
+            lines_ = [l for l in open(f).read().splitlines() if l.startswith("{")]
+            if lines_:
+                open(os.path.join(dst, f"{rnd}_{name}"), "w").write(lines_[-1] + "\n")
+        else:
+            shutil.copy(f, os.path.join(dst, f"{rnd}_{name}"))
+if os.path.exists(os.path.join(src, "pmc_mfma_pfcn.json")):
+    shutil.copy(os.path.join(src, "pmc_mfma_pfcn.json"), os.path.join(dst, "pmc_mfma_pfcn.json"))
+for tag in ("pfcn", "nfcf", "fairgo"):
+    files = glob.glob(os.path.join(src, f"stats_{tag}/**/*_kernel_stats.csv"), recursive=True)
+    if files:
+        shutil.copy(max(files, key=os.path.getmtime), os.path.join(dst, f"{rnd}_{tag}_kernel_stats.csv"))
