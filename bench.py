@@ -541,6 +541,8 @@ def main():
         copy_gbs = stream_copy_ceiling(dev)
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    # `traffic` is not measured by this run: it is the PMC figure of the last profiles/collect.sh pass
+                    "traffic_source": "profiles/pmc_traffic.json" if traffic is not None else None,
                     "measured_copy_ceiling": round(copy_gbs, 1), "frac_of_measured_ceiling": round(achieved / copy_gbs, 4),
                     "algorithmic_bytes_per_launch": algo_bytes,
                     # ... plus the launch's slice of the bounded-staleness sweep (rows / period, p m v read and written, last

@@ -175,6 +175,11 @@ class Trainer(AbstractTrainer):
         return tuple(vals) if n_tuple else vals[0]
 
     def _check_nan(self, loss):
+        """trainer.py:286-288 raises on the STEP whose loss is NaN, before its backward (trainer.py:192-193), at the price of
+        one `.item()` host sync per step.  Here the per-step losses are summed on the device and the sum is looked at once
+        per epoch: a NaN is sticky through the sum, so the same ValueError is raised for the same epoch -- but at its end,
+        after the remaining steps of that epoch have been applied to parameters nobody will use (training aborts either
+        way; the last checkpoint is from an earlier, finite epoch in both).  Deliberate deviation, stated in DESIGN.md §9."""
         if torch.isnan(loss).any():
             raise ValueError('Training loss is nan')
 
