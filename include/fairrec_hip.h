@@ -226,6 +226,42 @@ FR_API int fr_focf_step(const fr_table* U, const fr_table* I, const fr_adam* ada
 FR_API int fr_focf_step_finish(void* ws, size_t ws_bytes, int64_t B, int32_t dim, int32_t objective, float fair_weight,
                                float* loss_out, float* loss_acc, void* stream);
 
+/*
+ * The same step with the index work of the COMING batches riding in the step launches themselves, instead of a look-ahead
+ * sort on a second stream (fr_focf_prepare_step): no sort, no stream fork / join in the step loop.  Every table row has
+ * one 64-bit word per generation (`row_words`: fr_focf_row_words() words, zeroed once by the caller; three generations =
+ * the batch being applied and the two behind it), and a batch goes through two stages of a few workgroups each:
+ *   claim (two launches before its step): one thread per interaction counts itself into its rows' words (stamp << 29 |
+ *         members << 14 | base; a word left by an older batch is first raised to the new stamp by an atomic maximum, so
+ *         nothing is ever reset), stamps the rows for the sweeper, takes a place in its start class by replay length; K and
+ *         the sensitive values by atomics; the sweeper tasks of the stamped step are classed the same way;
+ *   place (one launch before): counts are final -- (members of its user, of its item) per interaction, a slice of the
+ *         member list per shared row, the records written in start order.
+ * In the step, the members of a shared row enter their batch position in the row's list and leave the word one by one;
+ * whoever brings the count to zero reads the list, orders it (ascending batch position, in registers) and finishes the
+ * row exactly as the sorted path does: same sums in the same order, bit-identical parameters.  The reported fairness
+ * value sums the items' terms in batch order of their first members instead of item-id order (last-bit differences in
+ * the loss value only).
+ *   fr_focf_stage        : stages on their own launch (the first batches of a loop; either batch may be NULL).
+ *   fr_focf_step_staged  : fr_focf_step for a batch that went through both stages with stamp `stamp`, carrying the
+ *                          claim of one coming batch and the place of another (either may be NULL).  Stamps must be
+ *                          handed out in strictly increasing order; batches stamped s, s + 1, s + 2 may be in flight.
+ *   fr_focf_step_finish_staged : fr_focf_step_finish for such a batch (also returns its workspace's counters to zero,
+ *                          as the next fr_focf_step_staged would have).
+ * A workspace must be zero-filled before its first claim.
+ */
+FR_API size_t fr_focf_row_words(int64_t n_users, int64_t n_items);
+FR_API int fr_focf_stage(const fr_table* U, const fr_table* I, const fr_focf_batch* claim, int32_t claim_stamp,
+                         const fr_focf_batch* place, int32_t place_stamp, int32_t sweep_period, uint64_t* row_words,
+                         uint32_t* err_flag, void* stream);
+FR_API int fr_focf_step_staged(const fr_table* U, const fr_table* I, const fr_adam* adam, const float* sst, int64_t B,
+                               int32_t objective, float fair_weight, int32_t sweep_period, int32_t stamp, void* ws,
+                               size_t ws_bytes, void* prev_ws, int64_t prev_B, float* prev_loss_out, float* loss_acc,
+                               uint64_t* row_words, const fr_focf_batch* claim, int32_t claim_stamp,
+                               const fr_focf_batch* place, int32_t place_stamp, uint32_t* err_flag, void* stream);
+FR_API int fr_focf_step_finish_staged(void* ws, size_t ws_bytes, int64_t B, int32_t dim, int32_t objective,
+                                      float fair_weight, float* loss_out, float* loss_acc, void* stream);
+
 /* FOCF.predict, focf.py:145-150: clamp(pred, 0, max_rating) / max_rating on up-to-date rows (read only). */
 FR_API int fr_focf_predict(const fr_table* U, const fr_table* I, const fr_adam* adam, const int64_t* user,
                     const int64_t* item, int64_t B, float max_rating, float* out, uint32_t* err_flag, void* stream);

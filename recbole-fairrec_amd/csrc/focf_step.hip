@@ -34,6 +34,14 @@
 
 namespace fr {
 
+#ifndef FR_LPT_SHARED_FIRST
+#define FR_LPT_SHARED_FIRST 1
+#endif
+#ifndef FR_STEP_WPB
+#define FR_STEP_WPB 4        // waves (= tasks) per workgroup: the granule the hardware dispatcher hands to a CU
+#endif
+constexpr int STEP_WPB = FR_STEP_WPB;
+
 // loss of an EARLIER step still to be reduced (its per-interaction squared errors and per-item terms are complete once
 // its launch has ended): one extra workgroup of the next launch, or fr_focf_step_finish, does it
 struct PrevLoss {
@@ -44,6 +52,8 @@ struct PrevLoss {
     float fair_weight;
     float* loss_out;   // [3] loss, mse, fair; nullptr = nothing to reduce
     float* acc;        // optional [3]: += the three values (a running epoch total kept on the device)
+    int by_pos;        // in-launch prepare: `term` is indexed by batch position (an item's term at its first member, 0 elsewhere)
+    int32_t* cp;       // ... and the batch's counters are zeroed once its loss is reduced: the workspace is free again
 };
 
 // Kernel arguments, kept to what the common path reads (every pointer is two SGPRs that stay live across the whole
@@ -70,6 +80,7 @@ struct StepArgs {
     const int32_t* sw_order;  // [n_pairs + 1] start order of the slice's pairs of rows (longest replay first), then the
                               //   number of pairs it was built for; the identity order is used when that does not match
     uint32_t* err;
+    unsigned long long *hcu, *hci;   // in-launch prepare: the row words (see "In-launch prepare") of the batch's generation
     PrevLoss prev;
 };
 
@@ -188,6 +199,291 @@ __device__ __forceinline__ void store_trow(const RowFrag<E>& f, float* base, int
     }
 }
 
+// ---- In-launch prepare -------------------------------------------------------------------------------------------
+// What the step needs to know about a batch's ids before it can run -- which rows are shared by several interactions,
+// by how many, who they are, K and the two sensitive values, a start order -- without a sort and without a second
+// stream: every table row has a 64-bit WORD per generation (three generations: the batch being applied, the next one,
+// the one after), and the stages below ride as a few extra workgroups in the step launches that precede the batch's own:
+//   launch t - 2  CLAIM   one thread per interaction: max(word, tag) brings a word left by an older batch to
+//                         (tag = the batch's stamp, count 0, base 0) -- stamps only grow, so no word is ever reset --
+//                         then add(word, one member) returns the interaction's ARRIVAL RANK r at that row.  Rows are
+//                         stamped for the sweeper, the replay cost is estimated from `last`, and the interaction takes a
+//                         place in its start class (one atomic per wave and class).  K = interactions with item rank 0;
+//                         the sensitive values by two ordered-int atomic maxima.
+//   launch t - 1  PLACE   the counts are final: (n_u, n_i) of every interaction; the rank-0 member of a shared row
+//                         reserves n slots of the batch's member list and adds their base to the word; the records go to
+//                         their place in the start order (class base + rank within the class).
+//   launch t      the step: a member of a shared row writes its batch position at list[base + r], hands over as before
+//                         and subtracts one member from the word: whoever brings the count to zero is the last arriver
+//                         and reads the n members in one load, sorted ascending in registers (all sums of the shared path
+//                         run in ascending batch position, so no result depends on the ranks or on who arrives last).
+// The same two stages rank the sweeper tasks of the stamped step (class and rank at t - 2, position at t - 1).
+// Against the look-ahead sort on a side stream (fr_focf_prepare_step): no stream fork / join in the step loop and no
+// 1024-thread sort workgroups running for 40 us beside the step launches (measured: 2.5-3 us per step at B = 8192).
+constexpr int SW_NC = 16;     // cost classes of the sweeper order
+constexpr int HC_TAG_SHIFT = 29;                       // word = stamp << 29 | members << 14 | base of the member list
+constexpr unsigned long long HC_CNT1 = 1ull << 14;
+__device__ __forceinline__ int hc_base(unsigned long long w) { return (int)(w & 0x3fffull); }
+__device__ __forceinline__ int hc_cnt(unsigned long long w) { return (int)((w >> 14) & 0x7fffull); }
+static_assert(FR_SORT_MAX <= (1 << 14), "a batch's member list is addressed with 14 bits");
+
+// floats as unsigned integers of the same order (0 is below every float: the identity of an atomic maximum)
+__device__ __forceinline__ unsigned ord_enc(float x) {
+    const unsigned b = __float_as_uint(x);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float ord_dec(unsigned e) { return __uint_as_float((e & 0x80000000u) ? (e & 0x7fffffffu) : ~e); }
+
+struct ClaimJob {        // a batch two steps ahead, and the sweeper tasks of the step it is stamped for
+    const int64_t *user, *item;
+    const float *rating, *sst;
+    int4 *rec, *info;
+    int32_t* cp;
+    unsigned long long *hcu, *hci;
+    int B, stamp;
+    long long lo_u, lo_i;
+    int n_u, n_i;
+    int32_t* sw_tmp;
+};
+struct PlaceJob {        // the batch of the next step
+    int4 *rec, *info, *task_rec, *task_info;
+    int32_t *cp, *hdr;
+    unsigned long long *hcu, *hci;
+    int B, n_pairs;
+    const int32_t* sw_tmp;
+    int32_t* sw_order;
+};
+struct StageArgs {
+    ClaimJob c;
+    PlaceJob p;
+    int nb_claim, nb_sa, nb_place, nb_sb;      // workgroups of each stage (0 = the stage is not in this launch)
+    int32_t *Ulast, *Ustamp, *Ilast, *Istamp;
+    int n_rows_u, n_rows_i, cap;
+    uint32_t* err;
+};
+constexpr int STAGE_THREADS = 64 * STEP_WPB;     // stage workgroups have the shape of the step launch's
+
+// The wave's members of class k (k < 0: none) take consecutive places behind counters[k]: one atomic per class present,
+// all of them in one round trip (lane c speaks for class c).
+template <int NC>
+__device__ __forceinline__ int class_rank(int k, int32_t* counters, int lane) {
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    unsigned long long m[NC];
+    int mine = 0;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        m[c] = __ballot(k == c);
+        if (lane == c) mine = __popcll(m[c]);
+    }
+    int got = 0;
+    if (lane < NC && mine) got = atomicAdd(counters + lane, mine);
+    int rk = 0;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int base = __shfl(got, c, 64);
+        if (k == c) rk = base + __popcll(m[c] & lt);
+    }
+    return rk;
+}
+
+__device__ __forceinline__ int replay_class(int a, int b, int cap, int NC) {     // the cost classes of focf_lpt_kernel
+    a = a < 0 ? 0 : (a > cap ? cap : a);
+    b = b < 0 ? 0 : (b > cap ? cap : b);
+    const int hi = a > b ? a : b, lo = a > b ? b : a;
+    const int cost = 7 * hi + 2 * lo;                          // VALU instructions: alone 7, as a pair 9 per step
+    return NC - 1 - min(NC - 1, cost * NC / (9 * cap + 1));
+}
+
+__device__ __forceinline__ void stage_claim(const StageArgs& s, int sb) {
+    const ClaimJob& J = s.c;
+    const int lane = threadIdx.x & 63;
+    const int b = sb * STAGE_THREADS + (int)threadIdx.x;
+    const bool ok = b < J.B;
+    const int bc = ok ? b : 0;
+    long long u = J.user[bc], i = J.item[bc];
+    const float rt = J.rating[bc], ss = J.sst ? J.sst[bc] : 0.f;
+    const bool bad = u < 0 || u >= s.n_rows_u || i < 0 || i >= s.n_rows_i;
+    if (u < 0 || u >= s.n_rows_u) u = 0;
+    if (i < 0 || i >= s.n_rows_i) i = 0;
+    if (ok && bad && s.err) atomicOr(s.err, FR_DEV_ERR_INDEX_RANGE);
+    const int cap = s.cap > 0 ? s.cap : 1024;
+    int ru = 0, ri = 0, k = -1;
+    if (ok) {
+        const unsigned long long T = (unsigned long long)J.stamp << HC_TAG_SHIFT;
+        // (the add is issued only once the maximum has returned: its operand depends on the returned word -- on a bit
+        // that is never set, a stamp has 31 bits)
+        const unsigned long long mu = __hip_atomic_fetch_max(J.hcu + u, T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long mi = __hip_atomic_fetch_max(J.hci + i, T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int lu = s.Ulast[u], li = s.Ilast[i];
+        atomicMax(s.Ustamp + u, J.stamp);
+        atomicMax(s.Istamp + i, J.stamp);
+        const unsigned long long ou =
+            __hip_atomic_fetch_add(J.hcu + u, HC_CNT1 + (mu >> 63), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long oi =
+            __hip_atomic_fetch_add(J.hci + i, HC_CNT1 + (mi >> 63), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ru = hc_cnt(ou);
+        ri = hc_cnt(oi);
+        J.rec[b] = make_int4((int)u, (int)i, __float_as_int(rt), __float_as_int(ss));
+        k = replay_class(J.stamp - 1 - lu, J.stamp - 1 - li, cap, 8);
+        // an interaction that found somebody at one of its rows: the shared path is the longest chain of the launch
+        // whatever its replay length, so it starts first (the first comer of such a row cannot know)
+        if (FR_LPT_SHARED_FIRST && (ru > 0 || ri > 0)) k = 0;
+    }
+    const int rk = class_rank<8>(k, J.cp, lane);
+    if (ok) J.info[b] = make_int4(ru, ri, rk, k);
+    const unsigned long long first = __ballot(ok && ri == 0);
+    if (lane == 0 && first) atomicAdd(J.cp + 8, __popcll(first));
+    if (J.sst) {
+        unsigned e1 = ok ? ord_enc(ss) : 0u, e2 = ok ? ord_enc(-ss) : 0u;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            e1 = max(e1, (unsigned)__shfl_xor((int)e1, o, 64));
+            e2 = max(e2, (unsigned)__shfl_xor((int)e2, o, 64));
+        }
+        if (lane == 0) {
+            atomicMax(reinterpret_cast<unsigned*>(J.cp + 9), e1);
+            atomicMax(reinterpret_cast<unsigned*>(J.cp + 10), e2);
+        }
+    }
+}
+
+// class and rank of the sweeper tasks of the step the claimed batch is stamped for (sweep_order_body's cost)
+__device__ __forceinline__ void stage_sweep_class(const StageArgs& s, int sb) {
+    const ClaimJob& J = s.c;
+    const int lane = threadIdx.x & 63;
+    const int q = sb * STAGE_THREADS + (int)threadIdx.x;
+    const int pairs_u = (J.n_u + 1) >> 1, n_pairs = pairs_u + ((J.n_i + 1) >> 1);
+    const bool ok = q < n_pairs;
+    const int qc = ok ? q : 0;
+    const bool inU = qc < pairs_u;
+    const int kk = inU ? qc : qc - pairs_u;
+    const long long rowA = (inU ? J.lo_u : J.lo_i) + 2 * kk;
+    const long long rowB = 2 * kk + 1 < (inU ? J.n_u : J.n_i) ? rowA + 1 : rowA;
+    const int32_t* Tl = inU ? s.Ulast : s.Ilast;
+    const int32_t* Ts = inU ? s.Ustamp : s.Istamp;
+    const int la = Tl[rowA], lb = Tl[rowB], sa = Ts[rowA], sb_ = Ts[rowB];
+    const int cap = s.cap > 0 ? s.cap : 1024;
+    const int k = ok ? replay_class(sa >= J.stamp ? 0 : J.stamp - la, sb_ >= J.stamp ? 0 : J.stamp - lb, cap, SW_NC) : -1;
+    const int rk = class_rank<SW_NC>(k, J.cp + 16, lane);
+    if (ok) J.sw_tmp[q] = k << 20 | rk;
+}
+
+__device__ __forceinline__ void stage_place(const StageArgs& s, int sb) {
+    const PlaceJob& J = s.p;
+    const int b = sb * STAGE_THREADS + (int)threadIdx.x;
+    const bool ok = b < J.B;
+    const int bc = ok ? b : 0;
+    const int4 rec = J.rec[bc], f = J.info[bc];            // f = (rank at the user row, rank at the item row, rank in class, class)
+    const unsigned long long wu = J.hcu[rec.x], wi = J.hci[rec.y];
+    int cnt[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) cnt[c] = J.cp[c];
+    const int nu = hc_cnt(wu), ni = hc_cnt(wi);
+    if (ok && nu > 1 && f.x == 0) {
+        const int base = atomicAdd(J.cp + 11, nu);
+        __hip_atomic_fetch_add(J.hcu + rec.x, (unsigned long long)base, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (ok && ni > 1 && f.y == 0) {
+        const int base = atomicAdd(J.cp + 12, ni);
+        __hip_atomic_fetch_add(J.hci + rec.y, (unsigned long long)base, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    int pos = f.z;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) pos += c < f.w ? cnt[c] : 0;
+    if (ok) {
+        J.task_rec[pos] = rec;
+        J.task_info[pos] = make_int4(f.x | nu << 16, f.y | ni << 16, 0, b);     // the records' layout of the sorted prepare,
+        J.info[b] = make_int4(f.x, f.y, nu, ni);                                //   ranks in the place of list positions
+    }
+    if (b == 0) {
+        const unsigned e1 = (unsigned)J.cp[9], e2 = (unsigned)J.cp[10];
+        *reinterpret_cast<int4*>(J.hdr) = make_int4(J.cp[8], 0, __float_as_int(-ord_dec(e2)), __float_as_int(ord_dec(e1)));
+    }
+}
+
+__device__ __forceinline__ void stage_sweep_place(const StageArgs& s, int sb) {
+    const PlaceJob& J = s.p;
+    const int q = sb * STAGE_THREADS + (int)threadIdx.x;
+    int cnt[SW_NC];
+#pragma unroll
+    for (int c = 0; c < SW_NC; ++c) cnt[c] = J.cp[16 + c];
+    if (q < J.n_pairs) {
+        const int v = J.sw_tmp[q], k = v >> 20;
+        int pos = v & 0xfffff;
+#pragma unroll
+        for (int c = 0; c < SW_NC; ++c) pos += c < k ? cnt[c] : 0;
+        J.sw_order[pos] = q;
+    }
+    if (q == 0) J.sw_order[J.n_pairs] = J.n_pairs;
+}
+
+// stage workgroup `sb` of a launch (the claim stages first: their atomics are the longest chains)
+__device__ __forceinline__ void stage_block(const StageArgs& s, int sb) {
+    if (sb < s.nb_claim) return stage_claim(s, sb);
+    sb -= s.nb_claim;
+    if (sb < s.nb_sa) return stage_sweep_class(s, sb);
+    sb -= s.nb_sa;
+    if (sb < s.nb_place) return stage_place(s, sb);
+    sb -= s.nb_place;
+    if (sb < s.nb_sb) stage_sweep_place(s, sb);
+}
+
+__device__ __forceinline__ unsigned long long uniform64(unsigned long long x) {
+    return (unsigned long long)(unsigned)uniform((int)(unsigned)x) | ((unsigned long long)(unsigned)uniform((int)(x >> 32)) << 32);
+}
+__device__ __forceinline__ int ld_sc1_int(const int32_t* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_sc1_int(int32_t* p, int v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// one member leaves a row's word; returns the word as it was (count 1: this wave is the last arriver)
+__device__ __forceinline__ unsigned long long hc_arrive(unsigned long long* p, int lane) {
+    unsigned long long t = 0;
+    if (lane == 0) t = __hip_atomic_fetch_add(p, 0ull - HC_CNT1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return uniform64(t);
+}
+
+// The members of a shared row as its last arriver sees them: batch positions in ascending order.  Up to 64 of them (every
+// row of a uniform batch, all but the hottest of a skewed one) stay in registers -- one load, each member's rank by
+// comparison with the others, one ds_permute; longer lists are ranked chunk against chunk and written out in order.
+struct Members {
+    int reg;                 // n <= 64: member `lane`
+    const int32_t* sorted;   // n > 64: the sorted list
+    int n;
+};
+__device__ __forceinline__ Members load_members(const int32_t* list, int32_t* sorted, int base, int n, int lane) {
+    Members m;
+    m.n = n;
+    m.reg = 0;
+    m.sorted = sorted + base;
+    if (n <= 64) {
+        const int v = lane < n ? ld_sc1_int(list + base + lane) : 0x7fffffff;
+        int rank = 0;
+        for (int t = 0; t < n; ++t) rank += __builtin_amdgcn_readlane(v, t) < v ? 1 : 0;
+        m.reg = __builtin_amdgcn_ds_permute(rank << 2, v);       // (the lanes past n all push to lane n, which nobody reads)
+        return m;
+    }
+    for (int jb = 0; jb < n; jb += 64) {
+        const int v = jb + lane < n ? ld_sc1_int(list + base + jb + lane) : 0x7fffffff;
+        int rank = 0;
+        for (int jc = 0; jc < n; jc += 64) {
+            const int x = jc + lane < n ? ld_sc1_int(list + base + jc + lane) : 0x7fffffff;
+            const int cn = min(64, n - jc);
+            for (int t = 0; t < cn; ++t) rank += __builtin_amdgcn_readlane(x, t) < v ? 1 : 0;
+        }
+        if (jb + lane < n) st_sc1_int(sorted + base + rank, v);
+    }
+    drain_stores();
+    return m;
+}
+__device__ __forceinline__ int members_chunk(const Members& m, int jb, int lane) {     // member jb + lane (0 past the end)
+    if (m.n <= 64) return lane < m.n ? m.reg : 0;
+    int idx = jb + lane;
+    asm volatile("" : "+v"(idx));      // (not a per-lane address kept in registers across the caller's loops)
+    return idx < m.n ? ld_sc1_int(m.sorted + idx) : 0;
+}
+
 // arrival at a segment's counter; true for the wave whose add came last (it then owns the segment's work)
 __device__ __forceinline__ bool arrive_last(unsigned int* cnt, int n, int lane) {
     unsigned t = 0;
@@ -214,20 +510,18 @@ __device__ __forceinline__ void adam_write(float* Tp, float* Tm, float* Tv, int3
 // g = sum over the members [j0, j0 + n) of a segment, in ascending batch position, of coef[b] * other[b, :] -- the product
 // rounded, then added (embedding_dense_backward's accumulation order), as segment_grad_sum of table.hpp, but on values
 // other waves of this launch handed over: sc1 loads throughout.  One member in flight (rare path: kept lean in registers).
-template <int E, bool FULL>
-__device__ __forceinline__ void handed_grad_sum(RowFrag<E>& g, int j0, int n, const int32_t* perm, const float* coef,
-                                                const float* other, int D, int lane) {
+template <int E, bool FULL, typename Chunk>     // chunk(jb) = batch position of member jb + lane (any value past the end)
+__device__ __forceinline__ void handed_grad_sum(RowFrag<E>& g, int n, Chunk chunk, const float* coef, const float* other,
+                                                int D, int lane) {
 #pragma unroll
     for (int e = 0; e < E; ++e) g.x[e] = 0.f;
     constexpr int UN = 2;
     for (int jb = 0; jb < n; jb += 64) {
         const int cnt = min(64, n - jb);
-        int my_b = 0;
+        int my_b = chunk(jb);
         float my_c = 0.f;
-        if (lane < cnt) {
-            my_b = perm[j0 + jb + lane];
-            my_c = ld_sc1(coef + my_b);
-        }
+        if (lane >= cnt) my_b = 0;
+        if (lane < cnt) my_c = ld_sc1(coef + my_b);
         for (int t0 = 0; t0 < cnt; t0 += UN) {
             RowFrag<E> o[UN];
             float cb[UN];
@@ -301,13 +595,32 @@ __device__ __forceinline__ void user_finish(KV kv, const AdamC& c, const FocfWs&
     load_row_sc1<E, FULL>(p, w.side[0] + (size_t)c0 * D, D, lane);
     load_row_sc1<E, FULL>(m, w.side[1] + (size_t)c0 * D, D, lane);
     load_row_sc1<E, FULL>(v, w.side[2] + (size_t)c0 * D, D, lane);
-    handed_grad_sum<E, FULL>(g, j0u, nu, w.perm_u, w.coef, w.side[3], D, lane);
+    handed_grad_sum<E, FULL>(g, nu, [&](int jb) { return jb + lane < nu ? w.perm_u[j0u + jb + lane] : 0; }, w.coef, w.side[3],
+                             D, lane);
+    adam_write<E, FULL>(KA(Up), KA(Um), KA(Uv), KA(Ulast), D, KA(step), c, ur, p, m, v, g, s, lane);
+}
+
+// ... the same for a batch prepared in the launches before (row words and member lists instead of sorted segments)
+template <int E, bool FULL>
+__device__ __forceinline__ void user_finish_c(KV kv, const AdamC& c, const FocfWs& w, int ur, int base, int nu, float2 s,
+                                              int lane) {
+    const int D = FULL ? 64 * E : KA(D);
+    const Members mem = load_members(w.perm_u, w.seg_start_u, base, nu, lane);
+    const int c0 = __builtin_amdgcn_readlane(members_chunk(mem, 0, lane), 0);
+    RowFrag<E> p, m, v, g;
+    load_row_sc1<E, FULL>(p, w.side[0] + (size_t)c0 * D, D, lane);
+    load_row_sc1<E, FULL>(m, w.side[1] + (size_t)c0 * D, D, lane);
+    load_row_sc1<E, FULL>(v, w.side[2] + (size_t)c0 * D, D, lane);
+    handed_grad_sum<E, FULL>(g, nu, [&](int jb) { return members_chunk(mem, jb, lane); }, w.coef, w.side[3], D, lane);
     adam_write<E, FULL>(KA(Up), KA(Um), KA(Uv), KA(Ulast), D, KA(step), c, ur, p, m, v, g, s, lane);
 }
 
 // The rest of an interaction whose user or item row is shared with other interactions of the batch: hand over, then
 // whoever arrives last at a segment finishes it (3 % / 8 % of the interactions for uniform pairs at the BASELINE sizes).
-template <int E, bool FULL>
+// CLAIM: the batch was prepared in the launches before this one ("In-launch prepare"): iux / iix = the interaction's
+// arrival rank at its user / item row | members << 16, the counters are the rows' words, the member lists are written
+// here.  Otherwise (sorted prepare) iux / iix = first sorted position | members << 16 and seg_u / seg_i the segments.
+template <int E, bool FULL, bool CLAIM>
 __device__ __forceinline__ void step_shared_rows(KV kv, const AdamC& c, int b, int lane, int ur, int ir, int iux, int iix,
                                                  int seg_u, int seg_i, float dot, float coef, float smin, float smax,
                                                  float K, RowFrag<E>& pu, RowFrag<E>& mu, RowFrag<E>& vu, RowFrag<E>& pi,
@@ -322,6 +635,16 @@ __device__ __forceinline__ void step_shared_rows(KV kv, const AdamC& c, int b, i
     asm volatile("" : "+s"(Bq));
     const FocfWs w = focf_layout(KA(ws), Bq, D);
 
+    if constexpr (CLAIM) {
+        // this member's entry in the member list of each shared row it belongs to (base of the list: in the row's word)
+        unsigned long long wu = 0, wi = 0;
+        if (nu > 1) wu = __hip_atomic_load(KA(hcu) + ur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (ni > 1) wi = __hip_atomic_load(KA(hci) + ir, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) {
+            if (nu > 1) st_sc1_int(w.perm_u + hc_base(wu) + j0u, b);
+            if (ni > 1) st_sc1_int(w.perm_i + hc_base(wi) + j0i, b);
+        }
+    }
     const size_t so = (size_t)b * D;
     store_row_sc1<E, FULL>(pu, w.side[0] + so, D, lane);
     store_row_sc1<E, FULL>(mu, w.side[1] + so, D, lane);
@@ -335,30 +658,52 @@ __device__ __forceinline__ void step_shared_rows(KV kv, const AdamC& c, int b, i
         adam_write<E, FULL>(KA(Ip), KA(Im), KA(Iv), KA(Ilast), D, KA(step), c, ir, pi, mi, vi, gi, s, lane);
         if (lane == 0) st_sc1(w.coef + b, coef);
         drain_stores();
-        if (arrive_last(w.cnt_u + seg_u, nu, lane)) user_finish<E, FULL>(kv, c, w, j0u, nu, s, lane);
+        if constexpr (CLAIM) {
+            const unsigned long long old = hc_arrive(KA(hcu) + ur, lane);
+            if (hc_cnt(old) == 1) user_finish_c<E, FULL>(kv, c, w, ur, hc_base(old), nu, s, lane);
+        } else {
+            if (arrive_last(w.cnt_u + seg_u, nu, lane)) user_finish<E, FULL>(kv, c, w, j0u, nu, s, lane);
+        }
         return;
     }
-    if (lane == 0) st_sc1(w.pred + b, dot);
+    if (lane == 0) {
+        st_sc1(w.pred + b, dot);
+        if (CLAIM && fair) st_sc1(w.term + b, 0.f);      // the item's term goes to its first member's place (below)
+    }
     drain_stores();
-    if (!arrive_last(w.cnt_i + seg_i, ni, lane)) return;
+    Members mem{};
+    if constexpr (CLAIM) {
+        const unsigned long long old = hc_arrive(KA(hci) + ir, lane);
+        if (hc_cnt(old) != 1) return;
+        mem = load_members(w.perm_i, w.seg_start_i, hc_base(old), ni, lane);
+    } else {
+        if (!arrive_last(w.cnt_i + seg_i, ni, lane)) return;
+    }
 
     // ---- item level, last arriver.  THREE dependent load levels for the whole segment (it is the longest chain of the
     // launch): (1) the members' batch positions, one per lane; (2) their records and scores; (3) their parked user rows,
     // UN members in flight.  Statistics, dLoss/dpred, the item row's gradient and the members' user updates are formed in
     // registers in between -- nothing this wave needs again goes through memory.
     const bool big = ni > 64;       // more than one chunk of 64 members: the chunks are loaded again for each phase
-    int my_b = 0, my_u = 0, my_iux = 0, my_seg = 0;
-    float my_pr = 0.f, my_rt = 0.f, my_s = 0.f;
+    int my_b = 0, my_u = 0, my_iux = 0, my_seg = 0;     // my_iux: (sorted prepare) first position | members << 16 of the
+    float my_pr = 0.f, my_rt = 0.f, my_s = 0.f;         //   member's user; (CLAIM) members << 16
     auto load_chunk = [&](int jb) {
         my_b = 0; my_u = 0; my_iux = 0; my_seg = 0;
         my_pr = 0.f; my_rt = 0.f; my_s = 0.f;
+        int mb = 0;
+        if constexpr (CLAIM) mb = members_chunk(mem, jb, lane);
         if (jb + lane < ni) {
-            my_b = w.perm_i[j0i + jb + lane];
+            if constexpr (CLAIM) my_b = mb;
+            else my_b = w.perm_i[j0i + jb + lane];
             const int4 rq = w.rec[my_b];
             const int4 fq = w.info[my_b];
             my_pr = ld_sc1(w.pred + my_b);
             my_u = rq.x; my_rt = __int_as_float(rq.z); my_s = __int_as_float(rq.w);
-            my_iux = fq.x; my_seg = fq.y;
+            if constexpr (CLAIM) {
+                my_iux = fq.z << 16;          // (rank at the user, rank at the item, the user's members, the item's)
+            } else {
+                my_iux = fq.x; my_seg = fq.y;
+            }
         }
     };
     float term = 0.f, g0 = 0.f, g1 = 0.f;
@@ -367,8 +712,10 @@ __device__ __forceinline__ void step_shared_rows(KV kv, const AdamC& c, int b, i
         // l, l + 16, l + 32, ... one after the other, then a butterfly
         float sp0 = 0.f, sp1 = 0.f, st0 = 0.f, st1 = 0.f, n0 = 0.f, n1 = 0.f;
         bool bad = false;
+        int first_b = 0;
         for (int jb = 0; jb < ni; jb += 64) {
             load_chunk(jb);
+            if (jb == 0) first_b = __builtin_amdgcn_readlane(my_b, 0);
 #pragma unroll
             for (int k = 0; k < 64 / FAIR_GROUP; ++k) {
                 const int src = (lane & (FAIR_GROUP - 1)) + FAIR_GROUP * k;
@@ -394,7 +741,9 @@ __device__ __forceinline__ void step_shared_rows(KV kv, const AdamC& c, int b, i
         n0 = __builtin_bit_cast(float, uniform(__builtin_bit_cast(int, n0)));
         n1 = __builtin_bit_cast(float, uniform(__builtin_bit_cast(int, n1)));
         focf_fair_eval(KA(objective), KA(fair_weight), K, sp0, sp1, st0, st1, n0, n1, term, g0, g1);
-        if (lane == 0) KA(term)[seg_i] = term;
+        // (CLAIM: at the place of the item's first member in batch order -- every member has zeroed its own place before
+        // it arrived -- so that the loss sums the terms in an order that does not depend on who arrived last)
+        if (lane == 0) KA(term)[CLAIM ? first_b : seg_i] = term;
     }
     // dLoss/dpred of every member (one per lane), the item row's gradient summed over the members in ascending batch
     // position -- coef * (user row), the product rounded, then added: embedding_dense_backward's order -- and the Adam step
@@ -464,8 +813,14 @@ __device__ __forceinline__ void step_shared_rows(KV kv, const AdamC& c, int b, i
             const int t = __builtin_ctzll(todo);
             todo &= todo - 1;
             const int iq = __builtin_amdgcn_readlane(my_iux, t);
-            const int sg = __builtin_amdgcn_readlane(my_seg, t);
-            if (arrive_last(w.cnt_u + sg, iq >> 16, lane)) user_finish<E, FULL>(kv, c, w, iq & 0xffff, iq >> 16, s, lane);
+            if constexpr (CLAIM) {
+                const int uu = __builtin_amdgcn_readlane(my_u, t);
+                const unsigned long long old = hc_arrive(KA(hcu) + uu, lane);
+                if (hc_cnt(old) == 1) user_finish_c<E, FULL>(kv, c, w, uu, hc_base(old), iq >> 16, s, lane);
+            } else {
+                const int sg = __builtin_amdgcn_readlane(my_seg, t);
+                if (arrive_last(w.cnt_u + sg, iq >> 16, lane)) user_finish<E, FULL>(kv, c, w, iq & 0xffff, iq >> 16, s, lane);
+            }
         }
     }
 }
@@ -498,7 +853,7 @@ __device__ __forceinline__ void focf_fair_single(int objective, float fair_weigh
 // One interaction with both rows caught up (x.A = its user row, x.B = its item row): score, squared error, dLoss/dpred,
 // and -- when nobody else in the batch touches either row -- both gradients and both Adam steps, the two rows as packed
 // pairs.  iux / iix = (j0 | n << 16) of its user / item segment, segs = user segment | item segment << 16, b = position.
-template <int E, bool FULL>
+template <int E, bool FULL, bool CLAIM>
 __device__ __forceinline__ void step_finish(KV kv, const AdamC& c, int lane, int q, RowFrag<E>& pu, RowFrag<E>& mu,
                                             RowFrag<E>& vu, RowFrag<E>& pi, RowFrag<E>& mi, RowFrag<E>& vi) {
     const int D = FULL ? 64 * E : KA(D);
@@ -528,7 +883,7 @@ __device__ __forceinline__ void step_finish(KV kv, const AdamC& c, int lane, int
         float term, g;
         focf_fair_single(KA(objective), KA(fair_weight), K, in0, dot, rt, term, g);
         coef = cm + g;
-        if (lane == 0) KA(term)[seg_i] = term;
+        if (lane == 0) KA(term)[CLAIM ? b : seg_i] = term;
     }
     if (ni == 1 && nu == 1) {      // ---- nobody else touches either row: finish here
         const float2 sc = step_scalars(c, KA(step));
@@ -557,7 +912,8 @@ __device__ __forceinline__ void step_finish(KV kv, const AdamC& c, int lane, int
         }
         return;
     }
-    step_shared_rows<E, FULL>(kv, c, b, lane, ur, ir, iux, iix, seg_u, seg_i, dot, coef, smin, smax, K, pu, mu, vu, pi, mi, vi);
+    step_shared_rows<E, FULL, CLAIM>(kv, c, b, lane, ur, ir, iux, iix, seg_u, seg_i, dot, coef, smin, smax, K, pu, mu, vu, pi, mi,
+                                     vi);
 }
 
 // One Adam step with data gradient coef * (the other row) on an interaction's two rows -- nobody else in the batch touches
@@ -597,7 +953,7 @@ __device__ __forceinline__ void adam_store_both(KV kv, const AdamC& c, int lane,
 // interleaved butterfly, and everything that is one value per interaction (error, dLoss/dpred, the fairness term of a
 // one-member item with its IEEE divisions) computed once, lane parity choosing the interaction -- each as step_finish
 // does it for one, same operations, same bits.
-template <int E, bool FULL>
+template <int E, bool FULL, bool CLAIM>
 __device__ __forceinline__ void step_finish_pair(KV kv, const AdamC& c, int lane, int q, bool has1, TwoRows<E> us,
                                                  TwoRows<E> is) {
     const int obj = KA(objective);
@@ -640,7 +996,7 @@ __device__ __forceinline__ void step_finish_pair(KV kv, const AdamC& c, int lane
     if (lane < (has1 ? 2 : 1)) {
         gp(KA(mse_e))[inf_w] = er * er;
         if (single) {
-            gp(KA(term))[inf_z >> 16] = term;
+            gp(KA(term))[CLAIM ? inf_w : inf_z >> 16] = term;
             if (sst != smin && sst != smax && KA(err)) atomicOr(KA(err), FR_DEV_ERR_SST_GROUPS);
         }
     }
@@ -676,7 +1032,7 @@ __device__ __forceinline__ void step_finish_pair(KV kv, const AdamC& c, int lane
         }
         if (!(k ? un1 : un0)) {
             const int sg = uniform(k ? vi1.z : vi0.z);
-            step_shared_rows<E, FULL>(kv, c, uniform(k ? vi1.w : vi0.w), lane, k ? ur1 : ur0, k ? ir1 : ir0, k ? iux1 : iux0,
+            step_shared_rows<E, FULL, CLAIM>(kv, c, uniform(k ? vi1.w : vi0.w), lane, k ? ur1 : ur0, k ? ir1 : ir0, k ? iux1 : iux0,
                                       k ? iix1 : iix0, sg & 0xffff, sg >> 16, k ? d1 : d0, k ? coef1 : coef0, smin, smax, K,
                                       us.pA, us.mA, us.vA, is.pA, is.mA, is.vA);
         }
@@ -690,7 +1046,7 @@ __device__ __forceinline__ void step_finish_pair(KV kv, const AdamC& c, int lane
 // A wave's task is "two rows brought up to date, then something done with them":
 //   sweeper task q  : rows 2q, 2q + 1 of the step's slice (users first, then items), written back at step `step`;
 //   interaction b   : its user row and item row as of step - 1, then score, dLoss/dpred, both gradients, both updates.
-template <int E, bool FULL, bool PAIR>
+template <int E, bool FULL, bool PAIR, bool CLAIM>
 __device__ __forceinline__ void step_task(KV kv, bool sweeper, int q, int n_pairs, int lane
 #if FR_STEP_TRACE
                                           , unsigned long long (&phase_stamps)[4]
@@ -789,7 +1145,7 @@ __device__ __forceinline__ void step_task(KV kv, bool sweeper, int q, int n_pair
 #if FR_STEP_TRACE
         g_phase[1] = __builtin_amdgcn_s_memrealtime();     // replay done
 #endif
-        step_finish_pair<E, FULL>(kv, c, lane, q, has1, r, it);
+        step_finish_pair<E, FULL, CLAIM>(kv, c, lane, q, has1, r, it);
         return;
     }
     // ---- one interaction per wave (wide rows: two interactions' rows would not fit the register budget)
@@ -805,7 +1161,7 @@ __device__ __forceinline__ void step_task(KV kv, bool sweeper, int q, int n_pair
     tA = uniform(lu);
     tB = uniform(li);
     replay_two<E>(r, tA, tB, KA(step) - 1, c, lane);
-    step_finish<E, FULL>(kv, c, lane, q, r.pA, r.mA, r.vA, r.pB, r.mB, r.vB);
+    step_finish<E, FULL, CLAIM>(kv, c, lane, q, r.pA, r.mA, r.vA, r.pB, r.mB, r.vB);
 }
 
 // fixed-order reduction of one batch's squared errors and per-item terms -> loss (one workgroup of 256 threads).  The
@@ -829,7 +1185,14 @@ __device__ __forceinline__ void step_reduce_loss(const PrevLoss& pl) {
                         e3 = b0 + 3 < B ? pl.mse_e[b0 + 3] : 0.f;
             a += ((e0 + e1) + e2) + e3;
         }
-        if (per_item) {
+        if (per_item && pl.by_pos) {      // one term per batch position (zero where no item has its first member): as `a`
+            for (int q = vt; q < nb; q += 256) {
+                const int b0 = 4 * q;
+                const float e0 = pl.term[b0], e1 = b0 + 1 < B ? pl.term[b0 + 1] : 0.f, e2 = b0 + 2 < B ? pl.term[b0 + 2] : 0.f,
+                            e3 = b0 + 3 < B ? pl.term[b0 + 3] : 0.f;
+                f += ((e0 + e1) + e2) + e3;
+            }
+        } else if (per_item) {
             constexpr int PER = FAIR_THREADS / FAIR_GROUP;     // items per workgroup of the fairness launch
             const int nf = (B * FAIR_GROUP + FAIR_THREADS - 1) / FAIR_THREADS;
             for (int q = vt; q < nf; q += 256) {
@@ -859,6 +1222,7 @@ __device__ __forceinline__ void step_reduce_loss(const PrevLoss& pl) {
             pl.acc[2] += fairv;
         }
     }
+    if (pl.cp && threadIdx.x < FOCF_CP_INTS) pl.cp[threadIdx.x] = 0;      // nothing of the batch is needed any more
 }
 
 // two interactions per wave while their twelve row fragments fit the register budget without scratch (D <= 64)
@@ -882,12 +1246,8 @@ __device__ int g_trace_step = -1;      // >= 0: only the launch that applies thi
 #ifndef FR_STEP_WAVES
 #define FR_STEP_WAVES 6      // waves per SIMD the register budget is cut for
 #endif
-#ifndef FR_STEP_WPB
-#define FR_STEP_WPB 4        // waves (= tasks) per workgroup: the granule the hardware dispatcher hands to a CU
-#endif
-constexpr int STEP_WPB = FR_STEP_WPB;
-template <int E, bool FULL>
-__global__ __launch_bounds__(64 * STEP_WPB, FR_STEP_WAVES) void focf_step_kernel(StepArgs a) {
+template <int E, bool FULL, bool CLAIM>
+__global__ __launch_bounds__(64 * STEP_WPB, FR_STEP_WAVES) void focf_step_kernel(StepArgs a, StageArgs st) {
 #if FR_STEP_TRACE
     const unsigned long long tr0 = __builtin_amdgcn_s_memrealtime();
     const unsigned long long mt0 = __builtin_amdgcn_s_memtime();      // shader clock: the clock the chip holds under this load
@@ -896,15 +1256,20 @@ __global__ __launch_bounds__(64 * STEP_WPB, FR_STEP_WAVES) void focf_step_kernel
     const int lane = threadIdx.x & 63;
     const int wib = uniform((int)(threadIdx.x >> 6));      // wave-uniform, and the compiler has to know it
     int role = 0;
+    const int n_stage = CLAIM ? st.nb_claim + st.nb_sa + st.nb_place + st.nb_sb : 0;
     if (blockIdx.x == 0) {
         if (a.prev.loss_out) step_reduce_loss<64 * STEP_WPB>(a.prev);
+    } else if (CLAIM && (int)blockIdx.x <= n_stage) {
+        // the index work of the two coming batches ("In-launch prepare"): first in the grid, done within a few us
+        if constexpr (CLAIM) stage_block(st, (int)blockIdx.x - 1);
+        role = 3;
     } else {
         const unsigned* kp = reinterpret_cast<const unsigned*>(
             (const void*)(const __attribute__((address_space(4))) void*)__builtin_amdgcn_kernarg_segment_ptr());
         KV kv;
         kv.v0 = kp[lane];
         kv.v1 = lane < (int)(sizeof(StepArgs) / 4) - 64 ? kp[64 + lane] : 0u;
-        const int x = (int)blockIdx.x - 1;
+        const int x = (int)blockIdx.x - 1 - n_stage;
         const int n_pairs = ((a.n_u + 1) >> 1) + ((a.n_i + 1) >> 1);
         const int ns = (n_pairs + STEP_WPB - 1) / STEP_WPB;
         // longest jobs first: the `lead` workgroups of the interactions with the longest replays (the task list is in
@@ -914,9 +1279,9 @@ __global__ __launch_bounds__(64 * STEP_WPB, FR_STEP_WAVES) void focf_step_kernel
         const int q = ((sweeper ? x - a.lead : (x < a.lead ? x : x - ns)) * STEP_WPB + wib) * (!sweeper && PAIR ? 2 : 1);
         role = sweeper ? 1 : 2;
 #if FR_STEP_TRACE
-        if (q < (sweeper ? n_pairs : a.B)) step_task<E, FULL, PAIR>(kv, sweeper, q, n_pairs, lane, ph);
+        if (q < (sweeper ? n_pairs : a.B)) step_task<E, FULL, PAIR, CLAIM>(kv, sweeper, q, n_pairs, lane, ph);
 #else
-        if (q < (sweeper ? n_pairs : a.B)) step_task<E, FULL, PAIR>(kv, sweeper, q, n_pairs, lane);
+        if (q < (sweeper ? n_pairs : a.B)) step_task<E, FULL, PAIR, CLAIM>(kv, sweeper, q, n_pairs, lane);
 #endif
     }
 #if FR_STEP_TRACE
@@ -942,6 +1307,9 @@ __global__ __launch_bounds__(64 * STEP_WPB, FR_STEP_WAVES) void focf_step_kernel
 
 __global__ __launch_bounds__(256) void focf_step_finish_kernel(PrevLoss pl) { step_reduce_loss<256>(pl); }
 
+// the stages on their own (the first steps of a loop, whose batches no earlier launch could carry)
+__global__ __launch_bounds__(STAGE_THREADS) void focf_stage_kernel(StageArgs st) { stage_block(st, (int)blockIdx.x); }
+
 // Start order of the sweeper tasks of ONE step (task = a pair of neighbouring rows of that step's sweep slice): longest
 // estimated replay first.  The hardware hands the launch's workgroups to the CUs in index order, one wave of a workgroup
 // per SIMD; with the tasks in slice order a SIMD's load is a sum of random replay lengths (0 .. 2 S row-steps per task)
@@ -954,7 +1322,6 @@ struct SwOrderJob {
     int n_u, n_i, upto, skip_from;
     int32_t* order;
 };
-constexpr int SW_NC = 16;     // cost classes of the sweeper order
 
 // One workgroup of 1024 threads (an extra workgroup of the launch-order launch); cnt: [SW_NC * PT * 16] ints of LDS
 template <int PT>   // rounds of 1024 tasks
@@ -1062,9 +1429,6 @@ __device__ unsigned long long g_lpt_stamps[8];
 #endif
 
 constexpr int LPT_SPLIT = 4;
-#ifndef FR_LPT_SHARED_FIRST
-#define FR_LPT_SHARED_FIRST 1
-#endif
 
 template <int PT>   // rounds of 1024 positions: B <= PT * 1024
 __global__ __launch_bounds__(1024) void focf_lpt_kernel(LptJobs jobs) {
@@ -1180,10 +1544,13 @@ __global__ __launch_bounds__(1024) void focf_lpt_kernel(LptJobs jobs) {
     LPT_STAMP(4);
 }
 
-static PrevLoss prev_of(void* ws, int64_t B, int dim, int objective, float fair_weight, float* loss_out, float* acc) {
+static PrevLoss prev_of(void* ws, int64_t B, int dim, int objective, float fair_weight, float* loss_out, float* acc,
+                        bool staged = false) {
     PrevLoss pl{};
     if (!ws || !loss_out) return pl;
     const FocfWs w = focf_layout(ws, B, dim);
+    pl.by_pos = staged ? 1 : 0;
+    pl.cp = staged ? w.cp : nullptr;
     pl.mse_e = w.mse_e;
     pl.term = w.term;
     pl.nseg_i = w.nseg_i;
@@ -1267,19 +1634,105 @@ extern "C" int fr_focf_prepare_step(const fr_focf_batch* batches, const int32_t*
     return FR_OK;
 }
 
-extern "C" int fr_focf_step(const fr_table* U, const fr_table* I, const fr_adam* adam, const int64_t* user,
-                            const int64_t* item, const float* rating, const float* sst, int64_t B, int32_t objective,
-                            float fair_weight, int32_t sweep_period, int32_t stamp, void* ws, size_t ws_bytes,
-                            float* loss_out, void* prev_ws, int64_t prev_B, float* prev_loss_out, float* loss_acc,
-                            uint32_t* err_flag, void* stream_) {
+// generation of the row words a batch stamped `stamp` uses: [3][n_users + n_items] words
+static unsigned long long* words_of(uint64_t* row_words, int32_t stamp, const fr_table* U, const fr_table* I, bool item) {
+    const size_t per = (size_t)U->n_rows + (size_t)I->n_rows;
+    return reinterpret_cast<unsigned long long*>(row_words) + (size_t)(stamp % 3) * per + (item ? (size_t)U->n_rows : 0);
+}
+
+// the stage descriptors of a launch: `claim` = the batch two steps ahead (or null), `place` = the next one (or null)
+static int make_stages(StageArgs& st, const fr_table* U, const fr_table* I, const fr_focf_batch* claim, int32_t claim_stamp,
+                       const fr_focf_batch* place, int32_t place_stamp, int32_t sweep_period, uint64_t* row_words,
+                       uint32_t* err_flag) {
+    st = StageArgs{};
+    st.Ulast = U->last; st.Ustamp = U->stamp; st.Ilast = I->last; st.Istamp = I->stamp;
+    st.n_rows_u = (int)U->n_rows; st.n_rows_i = (int)I->n_rows;
+    st.cap = sweep_period;
+    st.err = err_flag;
+    FR_CHECK_ARG(row_words && U->n_rows <= INT32_MAX && I->n_rows <= INT32_MAX, "fr_focf_stage: row words missing");
+    FR_CHECK_ARG(U->stamp && I->stamp && U->last && I->last, "fr_focf_stage: the tables need their last / stamp arrays");
+    auto slice_of = [&](int32_t stamp) {
+        fr_table tu = *U, ti = *I;
+        tu.step = ti.step = stamp;
+        return make_sweep_slice(&tu, &ti, sweep_period);
+    };
+    if (claim) {
+        const fr_focf_batch& b = *claim;
+        FR_CHECK_ARG(b.user && b.item && b.rating && b.ws && b.B >= 1 && b.B <= FR_SORT_MAX && claim_stamp >= 1,
+                     "fr_focf_stage: batch to claim");
+        const FocfWs w = focf_layout(b.ws, b.B, U->dim);
+        FR_CHECK_ARG(b.ws_bytes >= w.bytes, "fr_focf_stage: workspace %zu < %zu bytes", b.ws_bytes, w.bytes);
+        ClaimJob& J = st.c;
+        J.user = b.user; J.item = b.item; J.rating = b.rating; J.sst = b.sst;
+        J.rec = w.rec; J.info = w.info; J.cp = w.cp;
+        J.hcu = words_of(row_words, claim_stamp, U, I, false);
+        J.hci = words_of(row_words, claim_stamp, U, I, true);
+        J.B = (int)b.B; J.stamp = claim_stamp;
+        st.nb_claim = (int)((b.B + STAGE_THREADS - 1) / STAGE_THREADS);
+        if (sweep_period > 0) {
+            const SweepSlice sw = slice_of(claim_stamp);
+            const long long n_pairs = ((long long)sw.n_u + 1) / 2 + ((long long)sw.n_i + 1) / 2;
+            if (n_pairs <= SWEEP_ORDER_MAX) {
+                J.lo_u = sw.lo_u; J.lo_i = sw.lo_i; J.n_u = sw.n_u; J.n_i = sw.n_i;
+                J.sw_tmp = w.sw_tmp;
+                st.nb_sa = (int)((n_pairs + STAGE_THREADS - 1) / STAGE_THREADS);
+            }
+        }
+    }
+    if (place) {
+        const fr_focf_batch& b = *place;
+        FR_CHECK_ARG(b.ws && b.B >= 1 && b.B <= FR_SORT_MAX && place_stamp >= 1, "fr_focf_stage: batch to place");
+        const FocfWs w = focf_layout(b.ws, b.B, U->dim);
+        FR_CHECK_ARG(b.ws_bytes >= w.bytes, "fr_focf_stage: workspace %zu < %zu bytes", b.ws_bytes, w.bytes);
+        PlaceJob& J = st.p;
+        J.rec = w.rec; J.info = w.info; J.task_rec = w.task_rec; J.task_info = w.task_info;
+        J.cp = w.cp; J.hdr = w.nseg_i;
+        J.hcu = words_of(row_words, place_stamp, U, I, false);
+        J.hci = words_of(row_words, place_stamp, U, I, true);
+        J.B = (int)b.B;
+        st.nb_place = (int)((b.B + STAGE_THREADS - 1) / STAGE_THREADS);
+        if (sweep_period > 0) {
+            const SweepSlice sw = slice_of(place_stamp);
+            const long long n_pairs = ((long long)sw.n_u + 1) / 2 + ((long long)sw.n_i + 1) / 2;
+            if (n_pairs <= SWEEP_ORDER_MAX) {
+                J.n_pairs = (int)n_pairs;
+                J.sw_tmp = w.sw_tmp; J.sw_order = w.sw_order;
+                st.nb_sb = (int)((n_pairs + STAGE_THREADS - 1) / STAGE_THREADS);
+            }
+        }
+    }
+    return FR_OK;
+}
+
+extern "C" size_t fr_focf_row_words(int64_t n_users, int64_t n_items) { return 3 * ((size_t)n_users + (size_t)n_items); }
+
+extern "C" int fr_focf_stage(const fr_table* U, const fr_table* I, const fr_focf_batch* claim, int32_t claim_stamp,
+                             const fr_focf_batch* place, int32_t place_stamp, int32_t sweep_period, uint64_t* row_words,
+                             uint32_t* err_flag, void* stream_) {
+    int rc;
+    if ((rc = check_table(U, "fr_focf_stage(U)")) || (rc = check_table(I, "fr_focf_stage(I)"))) return rc;
+    FR_CHECK_ARG(U->dim == I->dim && (claim || place), "fr_focf_stage: nothing to do");
+    StageArgs st;
+    if ((rc = make_stages(st, U, I, claim, claim_stamp, place, place_stamp, sweep_period, row_words, err_flag))) return rc;
+    const int nb = st.nb_claim + st.nb_sa + st.nb_place + st.nb_sb;
+    ProfScope prof(K_FOCF_LPT, (hipStream_t)stream_);
+    FR_LAUNCH(prof, focf_stage_kernel, dim3(nb), dim3(STAGE_THREADS), 0, (hipStream_t)stream_, st);
+    FR_CHECK_LAUNCH();
+    return FR_OK;
+}
+
+static int focf_step_impl(const fr_table* U, const fr_table* I, const fr_adam* adam, const float* sst, int64_t B,
+                          int32_t objective, float fair_weight, int32_t sweep_period, int32_t stamp, void* ws,
+                          size_t ws_bytes, void* prev_ws, int64_t prev_B, float* prev_loss_out, float* loss_acc,
+                          uint32_t* err_flag, void* stream_, const StageArgs* stages, uint64_t* row_words) {
     hipStream_t stream = (hipStream_t)stream_;
+    const bool staged = row_words != nullptr;
     int rc;
     if ((rc = check_table(U, "fr_focf_step(U)")) || (rc = check_table(I, "fr_focf_step(I)")) ||
         (rc = check_adam(adam, "fr_focf_step")))
         return rc;
     FR_CHECK_ARG(U->dim == I->dim, "fr_focf_step: user dim %d != item dim %d", U->dim, I->dim);
     FR_CHECK_ARG(ws, "fr_focf_step: null pointer");
-    (void)user; (void)item; (void)rating;    // fr_focf_prepare_step packed them into the workspace
     FR_CHECK_ARG(objective >= FR_FOCF_NONE && objective <= FR_FOCF_OVER,
                  "fr_focf_step: objective %d needs batch-wide statistics before the update (use fr_focf_forward)", objective);
     FR_CHECK_ARG(objective == FR_FOCF_NONE || sst, "fr_focf_step: sst column required for a fairness objective");
@@ -1315,22 +1768,62 @@ extern "C" int fr_focf_step(const fr_table* U, const fr_table* I, const fr_adam*
         sweep_waves = ((long long)a.n_u + 1) / 2 + ((long long)a.n_i + 1) / 2;
         a.sw_order = sweep_waves <= SWEEP_ORDER_MAX ? w.sw_order : nullptr;
     }
-    a.prev = prev_of(prev_ws, prev_B, U->dim, objective, fair_weight, prev_loss_out, loss_acc);
-    (void)loss_out;   // reduced by the NEXT fr_focf_step (prev_*) or by fr_focf_step_finish
+    a.prev = prev_of(prev_ws, prev_B, U->dim, objective, fair_weight, prev_loss_out, loss_acc, staged);
+    StageArgs st{};
+    if (staged) {
+        a.hcu = words_of(row_words, stamp, U, I, false);
+        a.hci = words_of(row_words, stamp, U, I, true);
+        if (stages) st = *stages;
+    }
     {
         ProfScope prof(K_FOCF_STEP, stream);
         const long long per_wave = step_pairs((U->dim + 63) / 64) ? 2 : 1;
         const long long inter_blocks = ((B + per_wave - 1) / per_wave + STEP_WPB - 1) / STEP_WPB;
-        const unsigned blocks = (unsigned)(1 + (sweep_waves + STEP_WPB - 1) / STEP_WPB + inter_blocks);
+        const unsigned blocks = (unsigned)(1 + st.nb_claim + st.nb_sa + st.nb_place + st.nb_sb +
+                                           (sweep_waves + STEP_WPB - 1) / STEP_WPB + inter_blocks);
         a.lead = (int)(inter_blocks * lead_pct / 100);
-        if (U->dim % 64 == 0) {
-            FR_DISPATCH_E(U->dim, FR_LAUNCH(prof, (focf_step_kernel<E, true>), dim3(blocks), dim3(64 * STEP_WPB), 0, stream, a));
+        const dim3 block(64 * STEP_WPB);
+        if (staged) {
+            if (U->dim % 64 == 0) {
+                FR_DISPATCH_E(U->dim, FR_LAUNCH(prof, (focf_step_kernel<E, true, true>), dim3(blocks), block, 0, stream, a, st));
+            } else {
+                FR_DISPATCH_E(U->dim, FR_LAUNCH(prof, (focf_step_kernel<E, false, true>), dim3(blocks), block, 0, stream, a, st));
+            }
+        } else if (U->dim % 64 == 0) {
+            FR_DISPATCH_E(U->dim, FR_LAUNCH(prof, (focf_step_kernel<E, true, false>), dim3(blocks), block, 0, stream, a, st));
         } else {
-            FR_DISPATCH_E(U->dim, FR_LAUNCH(prof, (focf_step_kernel<E, false>), dim3(blocks), dim3(64 * STEP_WPB), 0, stream, a));
+            FR_DISPATCH_E(U->dim, FR_LAUNCH(prof, (focf_step_kernel<E, false, false>), dim3(blocks), block, 0, stream, a, st));
         }
     }
     FR_CHECK_LAUNCH();
     return FR_OK;
+}
+
+extern "C" int fr_focf_step(const fr_table* U, const fr_table* I, const fr_adam* adam, const int64_t* user,
+                            const int64_t* item, const float* rating, const float* sst, int64_t B, int32_t objective,
+                            float fair_weight, int32_t sweep_period, int32_t stamp, void* ws, size_t ws_bytes,
+                            float* loss_out, void* prev_ws, int64_t prev_B, float* prev_loss_out, float* loss_acc,
+                            uint32_t* err_flag, void* stream_) {
+    (void)user; (void)item; (void)rating;    // fr_focf_prepare_step packed them into the workspace
+    (void)loss_out;                          // reduced by the NEXT fr_focf_step (prev_*) or by fr_focf_step_finish
+    return focf_step_impl(U, I, adam, sst, B, objective, fair_weight, sweep_period, stamp, ws, ws_bytes, prev_ws, prev_B,
+                          prev_loss_out, loss_acc, err_flag, stream_, nullptr, nullptr);
+}
+
+extern "C" int fr_focf_step_staged(const fr_table* U, const fr_table* I, const fr_adam* adam, const float* sst, int64_t B,
+                                   int32_t objective, float fair_weight, int32_t sweep_period, int32_t stamp, void* ws,
+                                   size_t ws_bytes, void* prev_ws, int64_t prev_B, float* prev_loss_out, float* loss_acc,
+                                   uint64_t* row_words, const fr_focf_batch* claim, int32_t claim_stamp,
+                                   const fr_focf_batch* place, int32_t place_stamp, uint32_t* err_flag, void* stream_) {
+    FR_CHECK_ARG(row_words, "fr_focf_step_staged: row words missing");
+    StageArgs st{};
+    if (claim || place) {
+        int rc;
+        if ((rc = check_table(U, "fr_focf_step_staged(U)")) || (rc = check_table(I, "fr_focf_step_staged(I)"))) return rc;
+        if ((rc = make_stages(st, U, I, claim, claim_stamp, place, place_stamp, sweep_period, row_words, err_flag))) return rc;
+    }
+    return focf_step_impl(U, I, adam, sst, B, objective, fair_weight, sweep_period, stamp, ws, ws_bytes, prev_ws, prev_B,
+                          prev_loss_out, loss_acc, err_flag, stream_, &st, row_words);
 }
 
 #ifdef FR_LPT_STAMPS
@@ -1360,6 +1853,16 @@ extern "C" int fr_focf_step_finish(void* ws, size_t ws_bytes, int64_t B, int32_t
     FR_CHECK_ARG(ws && loss_out && B >= 1 && B <= FR_SORT_MAX && dim >= 1, "fr_focf_step_finish: bad argument");
     FR_CHECK_ARG(ws_bytes >= focf_layout(nullptr, B, dim).bytes, "fr_focf_step_finish: workspace too small");
     const PrevLoss pl = prev_of(ws, B, dim, objective, fair_weight, loss_out, loss_acc);
+    hipLaunchKernelGGL(focf_step_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream_, pl);
+    FR_CHECK_LAUNCH();
+    return FR_OK;
+}
+
+extern "C" int fr_focf_step_finish_staged(void* ws, size_t ws_bytes, int64_t B, int32_t dim, int32_t objective,
+                                          float fair_weight, float* loss_out, float* loss_acc, void* stream_) {
+    FR_CHECK_ARG(ws && loss_out && B >= 1 && B <= FR_SORT_MAX && dim >= 1, "fr_focf_step_finish_staged: bad argument");
+    FR_CHECK_ARG(ws_bytes >= focf_layout(nullptr, B, dim).bytes, "fr_focf_step_finish_staged: workspace too small");
+    const PrevLoss pl = prev_of(ws, B, dim, objective, fair_weight, loss_out, loss_acc, true);
     hipLaunchKernelGGL(focf_step_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream_, pl);
     FR_CHECK_LAUNCH();
     return FR_OK;

@@ -43,11 +43,17 @@ struct FocfWs {
     float* term;         // [B] indexed by item segment
     int32_t* sw_order;   // [SWEEP_ORDER_MAX + 1] start order of the step's sweeper tasks (pairs of rows of the sweep slice),
                          //   followed by the number of pairs it was built for (focf_sweep_order_kernel)
+    // in-launch prepare (focf_step.hip, stages riding in the step launches): counters of the batch -- [0..7] interactions
+    // per start class, [8] distinct items, [9] / [10] ordered-int maxima of sst / -sst, [11] / [12] fill of the member
+    // lists of shared user / item rows, [16..31] sweeper tasks per start class.  Zero whenever no batch owns the workspace.
+    int32_t* cp;         // [FOCF_CP_INTS]
+    int32_t* sw_tmp;     // [SWEEP_ORDER_MAX] class << 20 | rank within the class of each sweeper task
     DeferLoss* defer;    // [1] written by the forward launch, consumed (and cleared) by the backward launch
     int n_gather_blocks, n_fair_blocks;
     size_t bytes;
 };
 
+constexpr int FOCF_CP_INTS = 32;
 constexpr int SWEEP_ORDER_MAX = 16384;   // pairs of rows per sweep slice that get a start order (beyond: index order)
 constexpr int GATHER_THREADS = 256;  // 4 waves = 4 interactions per block
 constexpr int FAIR_THREADS = 1024;   // 16 lanes per item segment -> 64 segments per block (few blocks: cheap ticket)
@@ -63,6 +69,7 @@ __host__ __device__ inline FocfWs focf_layout(void* base, int64_t B, int D) {
         return p;
     };
     const size_t Bp = (size_t)B + 1;
+    w.cp = (int32_t*)take(FOCF_CP_INTS * 4);     // first: at the same place whatever B the buffer is used for next
     w.perm_u = (int32_t*)take(Bp * 4);
     w.seg_start_u = (int32_t*)take(Bp * 4);
     w.seg_row_u = (int32_t*)take(Bp * 4);
@@ -95,6 +102,7 @@ __host__ __device__ inline FocfWs focf_layout(void* base, int64_t B, int D) {
     w.mse_e = (float*)take(Bp * 4);
     w.term = (float*)take(Bp * 4);
     w.sw_order = (int32_t*)take(((size_t)SWEEP_ORDER_MAX + 1) * 4);
+    w.sw_tmp = (int32_t*)take((size_t)SWEEP_ORDER_MAX * 4);
     w.defer = (DeferLoss*)take(sizeof(DeferLoss));
     for (int k = 0; k < 6; ++k) w.side[k] = (float*)take((size_t)B * D * 4);
     w.bytes = off;

@@ -49,6 +49,9 @@ class FocfEngine:
     LOW_WATER = int(os.environ.get("FAIRREC_FOCF_LOW_WATER", 4))  # ... launched when this few prepared batches are left, so
                       # that its join is steps old when reached
     N_WS = GROUP + LOW_WATER + 3   # workspaces: the batch in flight + the last one (its loss) + the prepared ones + a spare
+    # fr_focf_step_staged: the index work of the two coming batches rides in the step launches themselves (no sort, no side
+    # stream); FAIRREC_FOCF_STAGED=0 goes back to the look-ahead sort (fr_focf_prepare_step) for the one-launch step
+    STAGED = os.environ.get("FAIRREC_FOCF_STAGED", "1") != "0"
 
     def __init__(self, user_weight: torch.Tensor, item_weight: torch.Tensor, objective: str, fair_weight: float,
                  max_rating: float):
@@ -91,6 +94,10 @@ class FocfEngine:
         self._stamp_last = 0            # stamps handed to fr_focf_prepare_step never decrease
         self._stamp_gen = (self.U.stamp_gen, self.I.stamp_gen)
         self.loss_acc = torch.zeros(4, dtype=torch.float32, device=self.device)   # running (loss, mse, fair) total
+        self.staged = self.STAGED
+        self._st = {}                   # batch key -> entry of a batch on its way through the claim / place stages
+        self._row_words = None          # [3][n_users + n_items] 64-bit words (fr_focf_row_words), zero to begin with
+        self._ws_dirty = set()          # workspaces whose stage counters may be left over from a batch that never ran
 
     # --- optimizer plumbing ---------------------------------------------------------------------------
     def tables(self) -> Dict[str, LazyTable]:
@@ -114,7 +121,7 @@ class FocfEngine:
         if need is None:
             need = self._ws_need[B] = _C.lib().fr_focf_workspace_bytes(B, self.U.dim)
         if self.ws[k] is None or self.ws[k].numel() < need:
-            self.ws[k] = torch.empty(need, dtype=torch.uint8, device=self.device)
+            self.ws[k] = torch.zeros(need, dtype=torch.uint8, device=self.device)     # (the stage counters start at zero)
         return self.ws[k]
 
     @staticmethod
@@ -209,12 +216,94 @@ class FocfEngine:
         if gen != self._stamp_gen:
             self._stamp_gen = gen
             self._join_prepare()
+            self._forget_staged()
 
     def _join_prepare(self):
         """Order the current stream behind every sort launch still in flight, and forget what they prepared."""
         for v in self._prep.values():
             torch.cuda.current_stream().wait_event(v[1]["done"])
         self._prep.clear()
+
+    # --- in-launch prepare (fr_focf_stage / fr_focf_step_staged) -----------------------------------------
+    def _st_entry(self, user, item, sst, rating, ahead: int):
+        """A batch enters the pipeline: a workspace of its own and the stamp of the step it is expected at."""
+        busy = {self.ws_cur} | {e["k"] for e in self._st.values()}
+        if self._prev is not None:
+            busy |= {k for k, w in enumerate(self.ws) if w is self._prev[0]}
+        if self._stash is not None:
+            busy |= {k for k, w in enumerate(self.ws) if w is self._stash[5]}
+        k = next(j for j in range(self.N_WS) if j not in busy)
+        B = user.numel()
+        ws = self._workspace(B, k)
+        if k in self._ws_dirty:
+            ws.zero_()
+            self._ws_dirty.discard(k)
+        batch = _C.FrFocfBatch(user.data_ptr(), item.data_ptr(), _C.ptr(sst if self.objective != 0 else None), B,
+                               ws.data_ptr(), ws.numel(), rating.data_ptr())
+        return {"k": k, "ws": ws, "B": B, "stamp": self._next_stamp(ahead), "stage": 0, "batch": batch,
+                "cols": (user, item, sst, rating)}
+
+    def _stage_now(self, claim=None, place=None):
+        """Stages on a launch of their own (the first batches of a loop: no earlier step launch could carry them)."""
+        tu, ti = self.U.c(), self.I.c()
+        rc = _C.lib().fr_focf_stage(ctypes.byref(tu), ctypes.byref(ti),
+                                    ctypes.byref(claim["batch"]) if claim else None, claim["stamp"] if claim else 0,
+                                    ctypes.byref(place["batch"]) if place else None, place["stamp"] if place else 0,
+                                    self._sweep((claim or place)["B"]), self._words().data_ptr(), self.err_flag.data_ptr(),
+                                    _C.current_stream())
+        _C.check(rc, "fr_focf_stage")
+        if claim:
+            claim["stage"] = 1
+        if place:
+            place["stage"] = 2
+
+    def _words(self):
+        if self._row_words is None:
+            n = _C.lib().fr_focf_row_words(self.U.n_rows, self.I.n_rows)
+            self._row_words = torch.zeros(n, dtype=torch.int64, device=self.device)
+        return self._row_words
+
+    def _forget_staged(self):
+        """Batches that were claimed but will not be applied (a loop cut short, a batch nobody announced): their words are
+        overwritten by the first later batch that touches the row (stamps only grow); their workspaces' counters are not."""
+        for e in self._st.values():
+            self._ws_dirty.add(e["k"])
+        self._st.clear()
+
+    def _staged_forward(self, user, item, rating, sst, B, coming, loss):
+        self.U.ensure_state()
+        self.I.ensure_state()
+        ent = self._st.pop(self._key(user, item), None)
+        alive = {self._key(nb[0], nb[1]) for nb in coming[:2]}
+        if ent is None or any(k not in alive for k in self._st):
+            self._forget_staged()
+        if ent is None:
+            ent = self._st_entry(user, item, sst, rating, 0)
+        if ent["stage"] < 1:
+            self._stage_now(claim=ent)
+        if ent["stage"] < 2:
+            self._stage_now(place=ent)
+        self.ws_cur = ent["k"]
+        place = claim = None
+        if coming:
+            nb = coming[0]
+            e1 = self._st.get(self._key(nb[0], nb[1]))
+            if e1 is None:
+                e1 = self._st[self._key(nb[0], nb[1])] = self._st_entry(nb[0], nb[1], nb[2], nb[3], 1)
+            if e1["stage"] < 1:
+                self._stage_now(claim=e1)
+            if e1["stage"] < 2:
+                place = e1
+        if len(coming) > 1:
+            nb = coming[1]
+            e2 = self._st.get(self._key(nb[0], nb[1]))
+            if e2 is None:
+                e2 = self._st[self._key(nb[0], nb[1])] = self._st_entry(nb[0], nb[1], nb[2], nb[3], 2)
+            if e2["stage"] < 1:
+                claim = e2
+        self._stash = (user, item, rating, sst, B, ent["ws"], ent["stamp"], loss, claim, place)
+        self.pending_B = B
+        return loss, None
 
     # --- launches -------------------------------------------------------------------------------------
     def forward(self, user, item, rating, sst, want_pred: bool = False, next_batch=None):
@@ -226,6 +315,17 @@ class FocfEngine:
         self._check_stamp_gen()
         if self._stash is not None:
             raise _C.FairrecError("calculate_loss twice without optimizer.step() in between (fused step)")
+        if (self.staged and self.fused_step and self.defer_loss and self.optimizer is not None and self.objective != 5
+                and not want_pred and not self.item_runs and self.U.step == self.I.step and rating is not None):
+            coming = []
+            if next_batch is not None:
+                coming = [next_batch] if isinstance(next_batch[0], torch.Tensor) else [nb for nb in next_batch if nb is not None]
+            coming = [nb for nb in coming[:2] if len(nb) >= 4 and nb[3] is not None]
+            self.loss_slot = (self.loss_slot + 1) % self.LOSS_SLOTS
+            self.hyper.check_step(self.U.step + 1)
+            return self._staged_forward(user, item, rating, sst, B, coming, self._loss_views[self.loss_slot])
+        if self._st:
+            self._forget_staged()
         hit = self._prep.pop(self._key(user, item), None)
         stamp = None
         if hit is not None:
@@ -299,9 +399,12 @@ class FocfEngine:
         if self.pending_B == 0:
             raise _C.FairrecError("clip_grad_norm without a preceding calculate_loss()")
         if self._stash is not None:       # the norm needs every gradient row before any update: three-launch chain
-            user, item, rating, sst, B, ws, _, loss = self._stash
+            user, item, rating, sst, B, ws, _, loss = self._stash[:8]
+            staged = len(self._stash) > 8
             self._stash = None
-            self._forward_chain(user, item, rating, sst, B, 1 | 2, ws, loss, None)    # PREPARED | DEFER_LOSS
+            if staged:                    # no sorted segments in that workspace, and its stage counters stay behind
+                self._ws_dirty.add(self.ws_cur)
+            self._forward_chain(user, item, rating, sst, B, 2 if staged else 1 | 2, ws, loss, None)   # [PREPARED |] DEFER_LOSS
         if not hasattr(self, "_clip_out"):
             self._clip_out = torch.zeros(2, dtype=torch.float32, device=self.device)
         tu, ti = self.U.c(self.U.step + 1), self.I.c(self.I.step + 1)
@@ -319,17 +422,39 @@ class FocfEngine:
             raise _C.FairrecError("no optimizer bound: build fairrec.optim.FusedLazyAdam(model.hip_engine(), ...)")
         B = self.pending_B
         tu, ti = self.U.c(self.U.step + 1), self.I.c(self.I.step + 1)
-        if self._stash is not None:
+        if self._stash is not None and len(self._stash) > 8:
+            user, item, rating, sst, B, ws, stamp, loss, claim, place = self._stash
+            self._stash = None
+            if self._prev is not None and not self._prev[3]:
+                self.finish()
+            pw, pB, ploss, _ = self._prev if self._prev is not None else (None, 0, None, True)
+            rc = _C.lib().fr_focf_step_staged(ctypes.byref(tu), ctypes.byref(ti), ctypes.byref(self.hyper.c()), _C.ptr(sst), B,
+                                              self.objective, self.fair_weight, self._sweep(B), stamp, ws.data_ptr(),
+                                              ws.numel(), _C.ptr(pw), pB, _C.ptr(ploss), self.loss_acc.data_ptr(),
+                                              self._words().data_ptr(),
+                                              ctypes.byref(claim["batch"]) if claim else None, claim["stamp"] if claim else 0,
+                                              ctypes.byref(place["batch"]) if place else None, place["stamp"] if place else 0,
+                                              self.err_flag.data_ptr(), _C.current_stream())
+            _C.check(rc, "fr_focf_step_staged")
+            if claim:
+                claim["stage"] = 1
+            if place:
+                place["stage"] = 2
+            self._prev = (ws, B, loss, True)
+            self._keep = (user, item, rating, sst)
+        elif self._stash is not None:
             user, item, rating, sst, B, ws, stamp, loss = self._stash
             self._stash = None
-            pw, pB, ploss = self._prev if self._prev is not None else (None, 0, None)
+            if self._prev is not None and self._prev[3]:
+                self.finish()
+            pw, pB, ploss, _ = self._prev if self._prev is not None else (None, 0, None, False)
             rc = _C.lib().fr_focf_step(ctypes.byref(tu), ctypes.byref(ti), ctypes.byref(self.hyper.c()),
                                        user.data_ptr(), item.data_ptr(), rating.data_ptr(), _C.ptr(sst), B,
                                        self.objective, self.fair_weight, self._sweep(B), stamp, ws.data_ptr(), ws.numel(),
                                        loss.data_ptr(), _C.ptr(pw), pB, _C.ptr(ploss), self.loss_acc.data_ptr(),
                                        self.err_flag.data_ptr(), _C.current_stream())
             _C.check(rc, "fr_focf_step")
-            self._prev = (ws, B, loss)
+            self._prev = (ws, B, loss, False)
             self._keep = (user, item, rating, sst)
         else:
             rc = _C.lib().fr_focf_backward_adam(ctypes.byref(tu), ctypes.byref(ti), ctypes.byref(self.hyper.c()), B,
@@ -353,10 +478,11 @@ class FocfEngine:
         """Reduce the loss of the last fused step (fr_focf_step_finish): its loss slot and `loss_acc` are complete on the
         stream after this.  A later fused step would have done it in passing."""
         if self._prev is not None:
-            ws, B, loss = self._prev
+            ws, B, loss, staged = self._prev
             self._prev = None
-            rc = _C.lib().fr_focf_step_finish(ws.data_ptr(), ws.numel(), B, self.U.dim, self.objective, self.fair_weight,
-                                              loss.data_ptr(), self.loss_acc.data_ptr(), _C.current_stream())
+            fn = _C.lib().fr_focf_step_finish_staged if staged else _C.lib().fr_focf_step_finish
+            rc = fn(ws.data_ptr(), ws.numel(), B, self.U.dim, self.objective, self.fair_weight, loss.data_ptr(),
+                    self.loss_acc.data_ptr(), _C.current_stream())
             _C.check(rc, "fr_focf_step_finish")
 
     def predict(self, user, item):
