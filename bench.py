@@ -564,8 +564,12 @@ def main():
                     "kernel_us": {k: round(v, 2) for k, v in sorted(per_kernel.items())},
                     "dominant_rule": ("longest kernel of the dependent chain; sort_segments_kernel runs on 1-2 workgroups "
                                       "concurrently with the gather kernels on a side stream" if sharded else
-                                      "the step IS one kernel (focf_step_kernel); sort_segments_kernel + focf_lpt_kernel run "
-                                      "twice per 16 steps on a side stream, ahead of the steps they serve"),
+                                      ("the step IS one kernel (focf_step_kernel), and the index work of the two coming "
+                                       "batches rides in it as ~100 extra workgroups (claim / place stages); "
+                                       "focf_stage_kernel = those stages on their own launch for the first two batches of a loop"
+                                       if getattr(eng, "staged", False) else
+                                       "the step IS one kernel (focf_step_kernel); sort_segments_kernel + focf_lpt_kernel run "
+                                       "twice per 16 steps on a side stream, ahead of the steps they serve")),
                     "measured": ("" if events_ok else "FALLBACK for focf_step_kernel: the timed step itself (per-launch events "
                                  "were inconsistent in this run, twice); otherwise ") +
                                 f"hipExtLaunchKernelGGL start/stop events on every launch, {K} eager steps after the "
@@ -585,8 +589,11 @@ def main():
                                  "score / fair / grads -> all-to-all(user gradients) -> apply" if sharded and
                                  schedule == "item_owner" else
                                  "gather / fair / backward_adam chain over 5 all-to-alls") if sharded else
-                                "ONE launch per step (fr_focf_step: gather + lazy-Adam replay + dot + fairness + backward + Adam + "
-                                "sweep slice); id columns of 16 coming batches sorted and packed per fork of the side stream"),
+                                ("ONE launch per step and nothing else on the device (fr_focf_step_staged: gather + lazy-Adam "
+                                 "replay + dot + fairness + backward + Adam + sweep slice + the claim stage of the batch two "
+                                 "steps ahead + the place stage of the next one)" if getattr(eng, "staged", False) else
+                                 "ONE launch per step (fr_focf_step: gather + lazy-Adam replay + dot + fairness + backward + Adam + "
+                                 "sweep slice); id columns of 16 coming batches sorted and packed per fork of the side stream")),
                        "lazy_adam_sweep_period": eng._sweep(BATCH) if not sharded else args.sweep,
                        "tables": "row-sharded over %d ranks, RCCL all-to-all" % world if sharded else "single GPU",
                        "global_batch": BATCH * world, "final_loss": round(loss_last, 6) if not sharded else None,

@@ -245,20 +245,23 @@ FR_API int fr_focf_step_finish(void* ws, size_t ws_bytes, int64_t B, int32_t dim
  *   fr_focf_stage        : stages on their own launch (the first batches of a loop; either batch may be NULL).
  *   fr_focf_step_staged  : fr_focf_step for a batch that went through both stages with stamp `stamp`, carrying the
  *                          claim of one coming batch and the place of another (either may be NULL).  Stamps must be
- *                          handed out in strictly increasing order; batches stamped s, s + 1, s + 2 may be in flight.
+ *                          handed out in strictly increasing order.  `gen` (0..2) names the generation of row words a
+ *                          batch uses from its claim to its step: the (up to) three batches in flight at any time --
+ *                          claimed, placed, being applied -- must hold three different ones.
  *   fr_focf_step_finish_staged : fr_focf_step_finish for such a batch (also returns its workspace's counters to zero,
  *                          as the next fr_focf_step_staged would have).
  * A workspace must be zero-filled before its first claim.
  */
 FR_API size_t fr_focf_row_words(int64_t n_users, int64_t n_items);
 FR_API int fr_focf_stage(const fr_table* U, const fr_table* I, const fr_focf_batch* claim, int32_t claim_stamp,
-                         const fr_focf_batch* place, int32_t place_stamp, int32_t sweep_period, uint64_t* row_words,
-                         uint32_t* err_flag, void* stream);
+                         int32_t claim_gen, const fr_focf_batch* place, int32_t place_stamp, int32_t place_gen,
+                         int32_t sweep_period, uint64_t* row_words, uint32_t* err_flag, void* stream);
 FR_API int fr_focf_step_staged(const fr_table* U, const fr_table* I, const fr_adam* adam, const float* sst, int64_t B,
-                               int32_t objective, float fair_weight, int32_t sweep_period, int32_t stamp, void* ws,
-                               size_t ws_bytes, void* prev_ws, int64_t prev_B, float* prev_loss_out, float* loss_acc,
-                               uint64_t* row_words, const fr_focf_batch* claim, int32_t claim_stamp,
-                               const fr_focf_batch* place, int32_t place_stamp, uint32_t* err_flag, void* stream);
+                               int32_t objective, float fair_weight, int32_t sweep_period, int32_t stamp, int32_t gen,
+                               void* ws, size_t ws_bytes, void* prev_ws, int64_t prev_B, float* prev_loss_out,
+                               float* loss_acc, uint64_t* row_words, const fr_focf_batch* claim, int32_t claim_stamp,
+                               int32_t claim_gen, const fr_focf_batch* place, int32_t place_stamp, int32_t place_gen,
+                               uint32_t* err_flag, void* stream);
 FR_API int fr_focf_step_finish_staged(void* ws, size_t ws_bytes, int64_t B, int32_t dim, int32_t objective,
                                       float fair_weight, float* loss_out, float* loss_acc, void* stream);
 

@@ -207,17 +207,22 @@ __device__ __forceinline__ void store_trow(const RowFrag<E>& f, float* base, int
 //   launch t - 2  CLAIM   one thread per interaction: max(word, tag) brings a word left by an older batch to
 //                         (tag = the batch's stamp, count 0, base 0) -- stamps only grow, so no word is ever reset --
 //                         then add(word, one member) returns the interaction's ARRIVAL RANK r at that row.  Rows are
-//                         stamped for the sweeper, the replay cost is estimated from `last`, and the interaction takes a
-//                         place in its start class (one atomic per wave and class).  K = interactions with item rank 0;
-//                         the sensitive values by two ordered-int atomic maxima.
+//                         stamped for the sweeper.  K = interactions with item rank 0; the sensitive values by two
+//                         ordered-int atomic maxima.
 //   launch t - 1  PLACE   the counts are final: (n_u, n_i) of every interaction; the rank-0 member of a shared row
-//                         reserves n slots of the batch's member list and adds their base to the word; the records go to
-//                         their place in the start order (class base + rank within the class).
+//                         reserves n slots of the batch's member list and adds their base to the word.  Start order:
+//                         the interactions with a shared row (the longest chains of the launch) take places from the
+//                         front of the task list, the others from its back, one atomic per wave and end -- a dense list
+//                         without knowing how many there are of each kind, so the step maps task q to record q as it
+//                         does after the sorted prepare (an order by replay length among the unshared ones, which the
+//                         sorted prepare builds, measured no gain).
+//                         The sweeper tasks of the stamped step ARE ordered by replay length, sixteen classes: class and
+//                         rank within the class at the claim stage (one atomic per wave and class), place = class base +
+//                         rank here, where the class counts are final.
 //   launch t      the step: a member of a shared row writes its batch position at list[base + r], hands over as before
 //                         and subtracts one member from the word: whoever brings the count to zero is the last arriver
 //                         and reads the n members in one load, sorted ascending in registers (all sums of the shared path
 //                         run in ascending batch position, so no result depends on the ranks or on who arrives last).
-// The same two stages rank the sweeper tasks of the stamped step (class and rank at t - 2, position at t - 1).
 // Against the look-ahead sort on a side stream (fr_focf_prepare_step): no stream fork / join in the step loop and no
 // 1024-thread sort workgroups running for 40 us beside the step launches (measured: 2.5-3 us per step at B = 8192).
 constexpr int SW_NC = 16;     // cost classes of the sweeper order
@@ -243,13 +248,13 @@ struct ClaimJob {        // a batch two steps ahead, and the sweeper tasks of th
     int B, stamp;
     long long lo_u, lo_i;
     int n_u, n_i;
-    int32_t* sw_tmp;
+    int32_t* sw_tmp;        // nullptr: no start order for the sweeper tasks
 };
 struct PlaceJob {        // the batch of the next step
     int4 *rec, *info, *task_rec, *task_info;
     int32_t *cp, *hdr;
     unsigned long long *hcu, *hci;
-    int B, n_pairs;
+    int B, n_pairs, stamp;
     const int32_t* sw_tmp;
     int32_t* sw_order;
 };
@@ -306,15 +311,13 @@ __device__ __forceinline__ void stage_claim(const StageArgs& s, int sb) {
     if (u < 0 || u >= s.n_rows_u) u = 0;
     if (i < 0 || i >= s.n_rows_i) i = 0;
     if (ok && bad && s.err) atomicOr(s.err, FR_DEV_ERR_INDEX_RANGE);
-    const int cap = s.cap > 0 ? s.cap : 1024;
-    int ru = 0, ri = 0, k = -1;
+    int ru = 0, ri = 0;
     if (ok) {
         const unsigned long long T = (unsigned long long)J.stamp << HC_TAG_SHIFT;
         // (the add is issued only once the maximum has returned: its operand depends on the returned word -- on a bit
         // that is never set, a stamp has 31 bits)
         const unsigned long long mu = __hip_atomic_fetch_max(J.hcu + u, T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned long long mi = __hip_atomic_fetch_max(J.hci + i, T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int lu = s.Ulast[u], li = s.Ilast[i];
         atomicMax(s.Ustamp + u, J.stamp);
         atomicMax(s.Istamp + i, J.stamp);
         const unsigned long long ou =
@@ -324,13 +327,8 @@ __device__ __forceinline__ void stage_claim(const StageArgs& s, int sb) {
         ru = hc_cnt(ou);
         ri = hc_cnt(oi);
         J.rec[b] = make_int4((int)u, (int)i, __float_as_int(rt), __float_as_int(ss));
-        k = replay_class(J.stamp - 1 - lu, J.stamp - 1 - li, cap, 8);
-        // an interaction that found somebody at one of its rows: the shared path is the longest chain of the launch
-        // whatever its replay length, so it starts first (the first comer of such a row cannot know)
-        if (FR_LPT_SHARED_FIRST && (ru > 0 || ri > 0)) k = 0;
+        J.info[b] = make_int4(ru, ri, 0, 0);
     }
-    const int rk = class_rank<8>(k, J.cp, lane);
-    if (ok) J.info[b] = make_int4(ru, ri, rk, k);
     const unsigned long long first = __ballot(ok && ri == 0);
     if (lane == 0 && first) atomicAdd(J.cp + 8, __popcll(first));
     if (J.sst) {
@@ -370,14 +368,13 @@ __device__ __forceinline__ void stage_sweep_class(const StageArgs& s, int sb) {
 
 __device__ __forceinline__ void stage_place(const StageArgs& s, int sb) {
     const PlaceJob& J = s.p;
+    const int lane = threadIdx.x & 63;
     const int b = sb * STAGE_THREADS + (int)threadIdx.x;
     const bool ok = b < J.B;
     const int bc = ok ? b : 0;
-    const int4 rec = J.rec[bc], f = J.info[bc];            // f = (rank at the user row, rank at the item row, rank in class, class)
+    const int4 rec = J.rec[bc], f = J.info[bc];            // f = (rank at the user row, rank at the item row, -, -)
     const unsigned long long wu = J.hcu[rec.x], wi = J.hci[rec.y];
-    int cnt[8];
-#pragma unroll
-    for (int c = 0; c < 8; ++c) cnt[c] = J.cp[c];
+    const int lu = s.Ulast[rec.x], li = s.Ilast[rec.y];
     const int nu = hc_cnt(wu), ni = hc_cnt(wi);
     if (ok && nu > 1 && f.x == 0) {
         const int base = atomicAdd(J.cp + 11, nu);
@@ -387,10 +384,34 @@ __device__ __forceinline__ void stage_place(const StageArgs& s, int sb) {
         const int base = atomicAdd(J.cp + 12, ni);
         __hip_atomic_fetch_add(J.hci + rec.y, (unsigned long long)base, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    int pos = f.z;
-#pragma unroll
-    for (int c = 0; c < 8; ++c) pos += c < f.w ? cnt[c] : 0;
+    // a shared row is finished by the last of its waves to arrive, behind a hand-off through memory and three more
+    // dependent load levels: the longest chain of the launch whatever its replay length, so those start first
+    const int k = !ok ? -1 : ((nu > 1 || ni > 1) && FR_LPT_SHARED_FIRST ? 0 : 1);
+    // Within the places its wave takes at either end, an interaction stands by estimated replay cost (longest towards the
+    // front): the step gives two neighbours of the list to one wave and replays their user rows, and their item rows, as
+    // packed pairs over the steps both rows of a pair missed -- rows of like staleness share most of them.
+    int key = 0;
     if (ok) {
+        const int cap = s.cap > 0 ? s.cap : 1024;
+        int cu = J.stamp - 1 - lu, ci = J.stamp - 1 - li;
+        cu = cu < 0 ? 0 : (cu > cap ? cap : cu);
+        ci = ci < 0 ? 0 : (ci > cap ? cap : ci);
+        key = 7 * (cu > ci ? cu : ci) + 2 * (cu > ci ? ci : cu);      // the cost of focf_lpt_kernel
+    }
+    int before = 0;                  // members of this lane's band in the wave that stand before it
+    for (int t = 0; t < 64; ++t) {
+        const int kt = __builtin_amdgcn_readlane(k, t), ct = __builtin_amdgcn_readlane(key, t);
+        before += (kt == k && (ct > key || (ct == key && t < lane))) ? 1 : 0;
+    }
+    const unsigned long long m0 = __ballot(k == 0), m1 = __ballot(k == 1);
+    const unsigned long long band = k == 0 ? m0 : m1;
+    const int band_n = __popcll(band);
+    // places taken from the front (cp[0]) and from the back (cp[1]): the wave's first place of the lane's band
+    const int base = class_rank<2>(k, J.cp, lane) - __popcll(band & ((1ull << lane) - 1ull));
+    if (ok) {
+        // front band: [base, base + n) by falling cost; back band: the wave's n places end at B - 1 - base, falling cost too
+        const int rk = k == 0 ? base + before : base + (band_n - 1 - before);
+        const int pos = k == 0 ? rk : J.B - 1 - rk;
         J.task_rec[pos] = rec;
         J.task_info[pos] = make_int4(f.x | nu << 16, f.y | ni << 16, 0, b);     // the records' layout of the sorted prepare,
         J.info[b] = make_int4(f.x, f.y, nu, ni);                                //   ranks in the place of list positions
@@ -954,11 +975,10 @@ __device__ __forceinline__ void adam_store_both(KV kv, const AdamC& c, int lane,
 // one-member item with its IEEE divisions) computed once, lane parity choosing the interaction -- each as step_finish
 // does it for one, same operations, same bits.
 template <int E, bool FULL, bool CLAIM>
-__device__ __forceinline__ void step_finish_pair(KV kv, const AdamC& c, int lane, int q, bool has1, TwoRows<E> us,
-                                                 TwoRows<E> is) {
+__device__ __forceinline__ void step_finish_pair(KV kv, const AdamC& c, int lane, int q, int q1, bool has1, TwoRows<E> us,
+                                                 TwoRows<E> is) {      // q, q1: the two interactions' record slots
     const int obj = KA(objective);
     const bool fair = obj != FR_FOCF_NONE;
-    const int q1 = has1 ? q + 1 : q;
     const GInt4Ptr trec = gp(KA(task_rec));
     const GInt4Ptr tinf = gp(KA(task_info));
     const int4 vr0 = trec[q], vr1 = trec[q1], vi0 = tinf[q], vi1 = tinf[q1];
@@ -1145,7 +1165,7 @@ __device__ __forceinline__ void step_task(KV kv, bool sweeper, int q, int n_pair
 #if FR_STEP_TRACE
         g_phase[1] = __builtin_amdgcn_s_memrealtime();     // replay done
 #endif
-        step_finish_pair<E, FULL, CLAIM>(kv, c, lane, q, has1, r, it);
+        step_finish_pair<E, FULL, CLAIM>(kv, c, lane, q, q1, has1, r, it);
         return;
     }
     // ---- one interaction per wave (wide rows: two interactions' rows would not fit the register budget)
@@ -1238,6 +1258,7 @@ __host__ __device__ constexpr bool step_pairs(int E) { return E <= 1; }
 #ifndef FR_STEP_TRACE
 #define FR_STEP_TRACE 0
 #endif
+
 #if FR_STEP_TRACE   // diagnostic build: (start, end) in 10 ns ticks, role and placement of every wave of one launch
 __device__ unsigned long long g_step_trace[8 * 65536];
 __device__ int g_trace_step = -1;      // >= 0: only the launch that applies this optimizer step is recorded
@@ -1257,11 +1278,18 @@ __global__ __launch_bounds__(64 * STEP_WPB, FR_STEP_WAVES) void focf_step_kernel
     const int wib = uniform((int)(threadIdx.x >> 6));      // wave-uniform, and the compiler has to know it
     int role = 0;
     const int n_stage = CLAIM ? st.nb_claim + st.nb_sa + st.nb_place + st.nb_sb : 0;
+    // Where the stage workgroups sit in the grid: behind the `lead` interaction workgroups (2, default), first (0) or
+    // last (1).  Measured at the BASELINE sizes, hipGraph replay: 29.2-29.6 / 29.9-30.2 / 31.3-31.7 us per step (last: the
+    // stages' dependent atomics then end the launch); further back among the sweeper workgroups: as (2).
+#ifndef FR_STAGE_POS
+#define FR_STAGE_POS 2
+#endif
+    const int stage0 = FR_STAGE_POS == 0 ? 1 : (FR_STAGE_POS == 1 ? (int)gridDim.x - n_stage : 1 + a.lead);
     if (blockIdx.x == 0) {
         if (a.prev.loss_out) step_reduce_loss<64 * STEP_WPB>(a.prev);
-    } else if (CLAIM && (int)blockIdx.x <= n_stage) {
-        // the index work of the two coming batches ("In-launch prepare"): first in the grid, done within a few us
-        if constexpr (CLAIM) stage_block(st, (int)blockIdx.x - 1);
+    } else if (CLAIM && (int)blockIdx.x >= stage0 && (int)blockIdx.x < stage0 + n_stage) {
+        // the index work of the two coming batches ("In-launch prepare"): a few us of dependent atomics each
+        if constexpr (CLAIM) stage_block(st, (int)blockIdx.x - stage0);
         role = 3;
     } else {
         const unsigned* kp = reinterpret_cast<const unsigned*>(
@@ -1269,7 +1297,7 @@ __global__ __launch_bounds__(64 * STEP_WPB, FR_STEP_WAVES) void focf_step_kernel
         KV kv;
         kv.v0 = kp[lane];
         kv.v1 = lane < (int)(sizeof(StepArgs) / 4) - 64 ? kp[64 + lane] : 0u;
-        const int x = (int)blockIdx.x - 1 - n_stage;
+        const int x = (int)blockIdx.x - 1 - ((int)blockIdx.x >= stage0 ? n_stage : 0);
         const int n_pairs = ((a.n_u + 1) >> 1) + ((a.n_i + 1) >> 1);
         const int ns = (n_pairs + STEP_WPB - 1) / STEP_WPB;
         // longest jobs first: the `lead` workgroups of the interactions with the longest replays (the task list is in
@@ -1634,16 +1662,16 @@ extern "C" int fr_focf_prepare_step(const fr_focf_batch* batches, const int32_t*
     return FR_OK;
 }
 
-// generation of the row words a batch stamped `stamp` uses: [3][n_users + n_items] words
-static unsigned long long* words_of(uint64_t* row_words, int32_t stamp, const fr_table* U, const fr_table* I, bool item) {
+// generation `gen` (0..2) of the row words: [3][n_users + n_items] words
+static unsigned long long* words_of(uint64_t* row_words, int32_t gen, const fr_table* U, const fr_table* I, bool item) {
     const size_t per = (size_t)U->n_rows + (size_t)I->n_rows;
-    return reinterpret_cast<unsigned long long*>(row_words) + (size_t)(stamp % 3) * per + (item ? (size_t)U->n_rows : 0);
+    return reinterpret_cast<unsigned long long*>(row_words) + (size_t)gen * per + (item ? (size_t)U->n_rows : 0);
 }
 
 // the stage descriptors of a launch: `claim` = the batch two steps ahead (or null), `place` = the next one (or null)
 static int make_stages(StageArgs& st, const fr_table* U, const fr_table* I, const fr_focf_batch* claim, int32_t claim_stamp,
-                       const fr_focf_batch* place, int32_t place_stamp, int32_t sweep_period, uint64_t* row_words,
-                       uint32_t* err_flag) {
+                       int32_t claim_gen, const fr_focf_batch* place, int32_t place_stamp, int32_t place_gen,
+                       int32_t sweep_period, uint64_t* row_words, uint32_t* err_flag) {
     st = StageArgs{};
     st.Ulast = U->last; st.Ustamp = U->stamp; st.Ilast = I->last; st.Istamp = I->stamp;
     st.n_rows_u = (int)U->n_rows; st.n_rows_i = (int)I->n_rows;
@@ -1658,15 +1686,15 @@ static int make_stages(StageArgs& st, const fr_table* U, const fr_table* I, cons
     };
     if (claim) {
         const fr_focf_batch& b = *claim;
-        FR_CHECK_ARG(b.user && b.item && b.rating && b.ws && b.B >= 1 && b.B <= FR_SORT_MAX && claim_stamp >= 1,
-                     "fr_focf_stage: batch to claim");
+        FR_CHECK_ARG(b.user && b.item && b.rating && b.ws && b.B >= 1 && b.B <= FR_SORT_MAX && claim_stamp >= 1 &&
+                         claim_gen >= 0 && claim_gen < 3, "fr_focf_stage: batch to claim");
         const FocfWs w = focf_layout(b.ws, b.B, U->dim);
         FR_CHECK_ARG(b.ws_bytes >= w.bytes, "fr_focf_stage: workspace %zu < %zu bytes", b.ws_bytes, w.bytes);
         ClaimJob& J = st.c;
         J.user = b.user; J.item = b.item; J.rating = b.rating; J.sst = b.sst;
         J.rec = w.rec; J.info = w.info; J.cp = w.cp;
-        J.hcu = words_of(row_words, claim_stamp, U, I, false);
-        J.hci = words_of(row_words, claim_stamp, U, I, true);
+        J.hcu = words_of(row_words, claim_gen, U, I, false);
+        J.hci = words_of(row_words, claim_gen, U, I, true);
         J.B = (int)b.B; J.stamp = claim_stamp;
         st.nb_claim = (int)((b.B + STAGE_THREADS - 1) / STAGE_THREADS);
         if (sweep_period > 0) {
@@ -1681,15 +1709,16 @@ static int make_stages(StageArgs& st, const fr_table* U, const fr_table* I, cons
     }
     if (place) {
         const fr_focf_batch& b = *place;
-        FR_CHECK_ARG(b.ws && b.B >= 1 && b.B <= FR_SORT_MAX && place_stamp >= 1, "fr_focf_stage: batch to place");
+        FR_CHECK_ARG(b.ws && b.B >= 1 && b.B <= FR_SORT_MAX && place_stamp >= 1 && place_gen >= 0 && place_gen < 3,
+                     "fr_focf_stage: batch to place");
         const FocfWs w = focf_layout(b.ws, b.B, U->dim);
         FR_CHECK_ARG(b.ws_bytes >= w.bytes, "fr_focf_stage: workspace %zu < %zu bytes", b.ws_bytes, w.bytes);
         PlaceJob& J = st.p;
         J.rec = w.rec; J.info = w.info; J.task_rec = w.task_rec; J.task_info = w.task_info;
         J.cp = w.cp; J.hdr = w.nseg_i;
-        J.hcu = words_of(row_words, place_stamp, U, I, false);
-        J.hci = words_of(row_words, place_stamp, U, I, true);
-        J.B = (int)b.B;
+        J.hcu = words_of(row_words, place_gen, U, I, false);
+        J.hci = words_of(row_words, place_gen, U, I, true);
+        J.B = (int)b.B; J.stamp = place_stamp;
         st.nb_place = (int)((b.B + STAGE_THREADS - 1) / STAGE_THREADS);
         if (sweep_period > 0) {
             const SweepSlice sw = slice_of(place_stamp);
@@ -1707,15 +1736,17 @@ static int make_stages(StageArgs& st, const fr_table* U, const fr_table* I, cons
 extern "C" size_t fr_focf_row_words(int64_t n_users, int64_t n_items) { return 3 * ((size_t)n_users + (size_t)n_items); }
 
 extern "C" int fr_focf_stage(const fr_table* U, const fr_table* I, const fr_focf_batch* claim, int32_t claim_stamp,
-                             const fr_focf_batch* place, int32_t place_stamp, int32_t sweep_period, uint64_t* row_words,
-                             uint32_t* err_flag, void* stream_) {
+                             int32_t claim_gen, const fr_focf_batch* place, int32_t place_stamp, int32_t place_gen,
+                             int32_t sweep_period, uint64_t* row_words, uint32_t* err_flag, void* stream_) {
     int rc;
     if ((rc = check_table(U, "fr_focf_stage(U)")) || (rc = check_table(I, "fr_focf_stage(I)"))) return rc;
     FR_CHECK_ARG(U->dim == I->dim && (claim || place), "fr_focf_stage: nothing to do");
     StageArgs st;
-    if ((rc = make_stages(st, U, I, claim, claim_stamp, place, place_stamp, sweep_period, row_words, err_flag))) return rc;
+    if ((rc = make_stages(st, U, I, claim, claim_stamp, claim_gen, place, place_stamp, place_gen, sweep_period, row_words,
+                          err_flag)))
+        return rc;
     const int nb = st.nb_claim + st.nb_sa + st.nb_place + st.nb_sb;
-    ProfScope prof(K_FOCF_LPT, (hipStream_t)stream_);
+    ProfScope prof(K_FOCF_STAGE, (hipStream_t)stream_);
     FR_LAUNCH(prof, focf_stage_kernel, dim3(nb), dim3(STAGE_THREADS), 0, (hipStream_t)stream_, st);
     FR_CHECK_LAUNCH();
     return FR_OK;
@@ -1724,7 +1755,7 @@ extern "C" int fr_focf_stage(const fr_table* U, const fr_table* I, const fr_focf
 static int focf_step_impl(const fr_table* U, const fr_table* I, const fr_adam* adam, const float* sst, int64_t B,
                           int32_t objective, float fair_weight, int32_t sweep_period, int32_t stamp, void* ws,
                           size_t ws_bytes, void* prev_ws, int64_t prev_B, float* prev_loss_out, float* loss_acc,
-                          uint32_t* err_flag, void* stream_, const StageArgs* stages, uint64_t* row_words) {
+                          uint32_t* err_flag, void* stream_, const StageArgs* stages, uint64_t* row_words, int32_t gen) {
     hipStream_t stream = (hipStream_t)stream_;
     const bool staged = row_words != nullptr;
     int rc;
@@ -1771,8 +1802,8 @@ static int focf_step_impl(const fr_table* U, const fr_table* I, const fr_adam* a
     a.prev = prev_of(prev_ws, prev_B, U->dim, objective, fair_weight, prev_loss_out, loss_acc, staged);
     StageArgs st{};
     if (staged) {
-        a.hcu = words_of(row_words, stamp, U, I, false);
-        a.hci = words_of(row_words, stamp, U, I, true);
+        a.hcu = words_of(row_words, gen, U, I, false);
+        a.hci = words_of(row_words, gen, U, I, true);
         if (stages) st = *stages;
     }
     {
@@ -1807,23 +1838,28 @@ extern "C" int fr_focf_step(const fr_table* U, const fr_table* I, const fr_adam*
     (void)user; (void)item; (void)rating;    // fr_focf_prepare_step packed them into the workspace
     (void)loss_out;                          // reduced by the NEXT fr_focf_step (prev_*) or by fr_focf_step_finish
     return focf_step_impl(U, I, adam, sst, B, objective, fair_weight, sweep_period, stamp, ws, ws_bytes, prev_ws, prev_B,
-                          prev_loss_out, loss_acc, err_flag, stream_, nullptr, nullptr);
+                          prev_loss_out, loss_acc, err_flag, stream_, nullptr, nullptr, 0);
 }
 
 extern "C" int fr_focf_step_staged(const fr_table* U, const fr_table* I, const fr_adam* adam, const float* sst, int64_t B,
-                                   int32_t objective, float fair_weight, int32_t sweep_period, int32_t stamp, void* ws,
-                                   size_t ws_bytes, void* prev_ws, int64_t prev_B, float* prev_loss_out, float* loss_acc,
-                                   uint64_t* row_words, const fr_focf_batch* claim, int32_t claim_stamp,
-                                   const fr_focf_batch* place, int32_t place_stamp, uint32_t* err_flag, void* stream_) {
-    FR_CHECK_ARG(row_words, "fr_focf_step_staged: row words missing");
+                                   int32_t objective, float fair_weight, int32_t sweep_period, int32_t stamp, int32_t gen,
+                                   void* ws, size_t ws_bytes, void* prev_ws, int64_t prev_B, float* prev_loss_out,
+                                   float* loss_acc, uint64_t* row_words, const fr_focf_batch* claim, int32_t claim_stamp,
+                                   int32_t claim_gen, const fr_focf_batch* place, int32_t place_stamp, int32_t place_gen,
+                                   uint32_t* err_flag, void* stream_) {
+    FR_CHECK_ARG(row_words && gen >= 0 && gen < 3, "fr_focf_step_staged: row words / generation");
+    FR_CHECK_ARG((!claim || claim_gen != gen) && (!place || place_gen != gen) && (!claim || !place || claim_gen != place_gen),
+                 "fr_focf_step_staged: the three batches in flight need three different generations of row words");
     StageArgs st{};
     if (claim || place) {
         int rc;
         if ((rc = check_table(U, "fr_focf_step_staged(U)")) || (rc = check_table(I, "fr_focf_step_staged(I)"))) return rc;
-        if ((rc = make_stages(st, U, I, claim, claim_stamp, place, place_stamp, sweep_period, row_words, err_flag))) return rc;
+        if ((rc = make_stages(st, U, I, claim, claim_stamp, claim_gen, place, place_stamp, place_gen, sweep_period, row_words,
+                              err_flag)))
+            return rc;
     }
     return focf_step_impl(U, I, adam, sst, B, objective, fair_weight, sweep_period, stamp, ws, ws_bytes, prev_ws, prev_B,
-                          prev_loss_out, loss_acc, err_flag, stream_, &st, row_words);
+                          prev_loss_out, loss_acc, err_flag, stream_, &st, row_words, gen);
 }
 
 #ifdef FR_LPT_STAMPS

@@ -43,8 +43,8 @@ struct FocfWs {
     float* term;         // [B] indexed by item segment
     int32_t* sw_order;   // [SWEEP_ORDER_MAX + 1] start order of the step's sweeper tasks (pairs of rows of the sweep slice),
                          //   followed by the number of pairs it was built for (focf_sweep_order_kernel)
-    // in-launch prepare (focf_step.hip, stages riding in the step launches): counters of the batch -- [0..7] interactions
-    // per start class, [8] distinct items, [9] / [10] ordered-int maxima of sst / -sst, [11] / [12] fill of the member
+    // in-launch prepare (focf_step.hip, stages riding in the step launches): counters of the batch -- [0] / [1] places taken
+    // from the front / the back of the task list, [8] distinct items, [9] / [10] ordered-int maxima of sst / -sst, [11] / [12] fill of the member
     // lists of shared user / item rows, [16..31] sweeper tasks per start class.  Zero whenever no batch owns the workspace.
     int32_t* cp;         // [FOCF_CP_INTS]
     int32_t* sw_tmp;     // [SWEEP_ORDER_MAX] class << 20 | rank within the class of each sweeper task

@@ -10,7 +10,7 @@ enum KernelKind {
     K_SORT = 0, K_FOCF_GATHER, K_FOCF_FAIR, K_FOCF_NONPARITY, K_FOCF_FINALIZE, K_FOCF_BWD_ADAM, K_TABLE_FLUSH,
     K_TABLE_GATHER, K_ADAM_DENSE, K_TABLE_GATHER_TRAIN, K_TABLE_APPLY_GRAD, K_BUCKET, K_UNBUCKET,
     K_BUCKET_ROWS, K_FOCF_SHARD_SCORE, K_FOCF_SHARD_GRADS, K_LINEAR_FWD,
-    K_LINEAR_BWD_INPUT, K_LINEAR_BWD_WEIGHT, K_NFCF_LOSS, K_BN_FWD, K_BN_BWD, K_ROWDOT, K_BPR, K_SPMM, K_ROW_GATHER, K_SAMPLE_NEG, K_FOCF_STEP, K_FOCF_LPT, K_COUNT
+    K_LINEAR_BWD_INPUT, K_LINEAR_BWD_WEIGHT, K_NFCF_LOSS, K_BN_FWD, K_BN_BWD, K_ROWDOT, K_BPR, K_SPMM, K_ROW_GATHER, K_SAMPLE_NEG, K_FOCF_STEP, K_FOCF_LPT, K_FOCF_STAGE, K_COUNT
 };
 bool prof_on();
 // algorithmic work of a launch of `kind` (FLOP of a dense product, bytes of an SpMM), summed while the profiler is on

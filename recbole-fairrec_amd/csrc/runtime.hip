@@ -31,7 +31,7 @@ static const char* const kKernelNames[K_COUNT] = {
     "focf_shard_score_kernel", "focf_shard_grads_kernel", "linear_fwd_kernel",
     "linear_bwd_input_kernel", "linear_bwd_weight_kernel", "nfcf_bce_kernel",
     "bn_fwd_kernel", "bn_bwd_kernel", "rowdot_kernel", "bpr_kernel", "spmm_csr_kernel", "row_gather_scatter_kernel",
-    "sample_negatives_kernel", "focf_step_kernel", "focf_lpt_kernel"};
+    "sample_negatives_kernel", "focf_step_kernel", "focf_lpt_kernel", "focf_stage_kernel"};
 
 struct ProfState {
     bool on = false;

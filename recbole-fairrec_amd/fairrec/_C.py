@@ -70,11 +70,12 @@ _PROTOS = {
     "fr_focf_step_finish": (c_int, [c_void_p, c_size_t, c_int64, c_int32, c_int32, c_float, c_void_p, c_void_p,
                                     c_void_p]),
     "fr_focf_row_words": (c_size_t, [c_int64, c_int64]),
-    "fr_focf_stage": (c_int, [POINTER(FrTable), POINTER(FrTable), POINTER(FrFocfBatch), c_int32, POINTER(FrFocfBatch),
-                              c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
+    "fr_focf_stage": (c_int, [POINTER(FrTable), POINTER(FrTable), POINTER(FrFocfBatch), c_int32, c_int32,
+                              POINTER(FrFocfBatch), c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
     "fr_focf_step_staged": (c_int, [POINTER(FrTable), POINTER(FrTable), POINTER(FrAdam), c_void_p, c_int64, c_int32, c_float,
-                                    c_int32, c_int32, c_void_p, c_size_t, c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
-                                    POINTER(FrFocfBatch), c_int32, POINTER(FrFocfBatch), c_int32, c_void_p, c_void_p]),
+                                    c_int32, c_int32, c_int32, c_void_p, c_size_t, c_void_p, c_int64, c_void_p, c_void_p,
+                                    c_void_p, POINTER(FrFocfBatch), c_int32, c_int32, POINTER(FrFocfBatch), c_int32, c_int32,
+                                    c_void_p, c_void_p]),
     "fr_focf_step_finish_staged": (c_int, [c_void_p, c_size_t, c_int64, c_int32, c_int32, c_float, c_void_p, c_void_p,
                                            c_void_p]),
     "fr_focf_predict": (c_int, [POINTER(FrTable), POINTER(FrTable), POINTER(FrAdam), c_void_p, c_void_p, c_int64,

@@ -98,6 +98,7 @@ class FocfEngine:
         self._st = {}                   # batch key -> entry of a batch on its way through the claim / place stages
         self._row_words = None          # [3][n_users + n_items] 64-bit words (fr_focf_row_words), zero to begin with
         self._ws_dirty = set()          # workspaces whose stage counters may be left over from a batch that never ran
+        self._gen_cur = None            # generation of row words of the batch being applied
 
     # --- optimizer plumbing ---------------------------------------------------------------------------
     def tables(self) -> Dict[str, LazyTable]:
@@ -240,7 +241,10 @@ class FocfEngine:
             self._ws_dirty.discard(k)
         batch = _C.FrFocfBatch(user.data_ptr(), item.data_ptr(), _C.ptr(sst if self.objective != 0 else None), B,
                                ws.data_ptr(), ws.numel(), rating.data_ptr())
-        return {"k": k, "ws": ws, "B": B, "stamp": self._next_stamp(ahead), "stage": 0, "batch": batch,
+        # a generation of row words nobody in flight holds (the batch being applied, the placed one, the claimed one)
+        held = {e["gen"] for e in self._st.values()} | ({self._gen_cur} if self._gen_cur is not None else set())
+        gen = next(j for j in range(3) if j not in held)
+        return {"k": k, "ws": ws, "B": B, "stamp": self._next_stamp(ahead), "gen": gen, "stage": 0, "batch": batch,
                 "cols": (user, item, sst, rating)}
 
     def _stage_now(self, claim=None, place=None):
@@ -248,8 +252,9 @@ class FocfEngine:
         tu, ti = self.U.c(), self.I.c()
         rc = _C.lib().fr_focf_stage(ctypes.byref(tu), ctypes.byref(ti),
                                     ctypes.byref(claim["batch"]) if claim else None, claim["stamp"] if claim else 0,
+                                    claim["gen"] if claim else 0,
                                     ctypes.byref(place["batch"]) if place else None, place["stamp"] if place else 0,
-                                    self._sweep((claim or place)["B"]), self._words().data_ptr(), self.err_flag.data_ptr(),
+                                    place["gen"] if place else 0, self._sweep((claim or place)["B"]), self._words().data_ptr(), self.err_flag.data_ptr(),
                                     _C.current_stream())
         _C.check(rc, "fr_focf_stage")
         if claim:
@@ -278,7 +283,9 @@ class FocfEngine:
         if ent is None or any(k not in alive for k in self._st):
             self._forget_staged()
         if ent is None:
+            self._gen_cur = None
             ent = self._st_entry(user, item, sst, rating, 0)
+        self._gen_cur = ent["gen"]
         if ent["stage"] < 1:
             self._stage_now(claim=ent)
         if ent["stage"] < 2:
@@ -301,7 +308,7 @@ class FocfEngine:
                 e2 = self._st[self._key(nb[0], nb[1])] = self._st_entry(nb[0], nb[1], nb[2], nb[3], 2)
             if e2["stage"] < 1:
                 claim = e2
-        self._stash = (user, item, rating, sst, B, ent["ws"], ent["stamp"], loss, claim, place)
+        self._stash = (user, item, rating, sst, B, ent["ws"], (ent["stamp"], ent["gen"]), loss, claim, place)
         self.pending_B = B
         return loss, None
 
@@ -429,12 +436,13 @@ class FocfEngine:
                 self.finish()
             pw, pB, ploss, _ = self._prev if self._prev is not None else (None, 0, None, True)
             rc = _C.lib().fr_focf_step_staged(ctypes.byref(tu), ctypes.byref(ti), ctypes.byref(self.hyper.c()), _C.ptr(sst), B,
-                                              self.objective, self.fair_weight, self._sweep(B), stamp, ws.data_ptr(),
-                                              ws.numel(), _C.ptr(pw), pB, _C.ptr(ploss), self.loss_acc.data_ptr(),
-                                              self._words().data_ptr(),
+                                              self.objective, self.fair_weight, self._sweep(B), stamp[0], stamp[1],
+                                              ws.data_ptr(), ws.numel(), _C.ptr(pw), pB, _C.ptr(ploss),
+                                              self.loss_acc.data_ptr(), self._words().data_ptr(),
                                               ctypes.byref(claim["batch"]) if claim else None, claim["stamp"] if claim else 0,
+                                              claim["gen"] if claim else 0,
                                               ctypes.byref(place["batch"]) if place else None, place["stamp"] if place else 0,
-                                              self.err_flag.data_ptr(), _C.current_stream())
+                                              place["gen"] if place else 0, self.err_flag.data_ptr(), _C.current_stream())
             _C.check(rc, "fr_focf_step_staged")
             if claim:
                 claim["stage"] = 1

@@ -23,7 +23,7 @@ if os.environ.get("TRACE_OUT"):
 t0 = b[:, 0].min()
 st, en, role = (b[:, 0] - t0) / 100.0, (b[:, 1] - t0) / 100.0, b[:, 2]
 print("step", target, "waves", len(b), "span %.2f us" % en.max())
-for rl, name in ((0, "loss"), (1, "sweeper"), (2, "interaction")):
+for rl, name in ((0, "loss"), (1, "sweeper"), (2, "interaction"), (3, "stage")):
     m = role == rl
     if m.any():
         print(f"{name:12s} n={m.sum():5d} start med {np.median(st[m]):6.2f} max {st[m].max():6.2f} | end med {np.median(en[m]):6.2f} p90 {np.percentile(en[m], 90):6.2f} max {en[m].max():6.2f}")

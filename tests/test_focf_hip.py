@@ -180,6 +180,68 @@ def test_lookahead_sweep_equals_plain_chain(objective, dim, item_dist):
             torch.testing.assert_close(x, y, rtol=1e-4, atol=1e-6 * float(y.abs().max()) + 1e-12)
 
 
+@pytest.mark.parametrize("dim", [64, 100, 128])
+@pytest.mark.parametrize("objective", ["none", "value", "absolute"])
+def test_in_launch_prepare_equals_sorted_prepare(objective, dim):
+    """The one-launch step with the coming batches' index work riding in the step launches (fr_focf_step_staged: claim /
+    place stages on the rows' 64-bit words, member lists ordered by the last arriver) against the same step prepared by
+    the look-ahead sort (fr_focf_prepare_step): every sum of the shared-row path runs in ascending batch position in both,
+    so the tables and moments must be EQUAL BIT FOR BIT; only the reported fairness value may differ in its last bits (the
+    items' terms are summed in another order).  The batches hold rows shared by 2..3 interactions, hot items and hot
+    users with more than 64 members (the chunked member lists), a queue that announces two batches ahead, steps nobody
+    announced and a queue that is cut short (claimed batches that never run)."""
+    from fairrec.model.fair_recommender.focf import FocfEngine
+    from fairrec.optim import FusedLazyAdam
+    n_users, n_items, B, T = 5001, 2501, 1500, 16
+    g = torch.Generator().manual_seed(17)
+    u = torch.randint(1, n_users, (T + 4, B), generator=g)
+    i = torch.randint(1, n_items, (T + 4, B), generator=g)
+    i[:, 100:250] = torch.randint(1, 4, (T + 4, 150), generator=g)       # three hot items: ~50 members each
+    i[:, 300:520] = 7                                                    # one item with 220 members
+    u[:, 600:700] = 11                                                   # one user with 100 members
+    u[:, 640:660] = u[:, 300:320]                                        # ... and users shared between hot rows
+    r = torch.randint(1, 6, (T + 4, B), generator=g).float()
+    gender = torch.randint(0, 2, (n_users,), generator=g).float()
+    u, i, r = u.cuda(), i.cuda(), r.cuda()
+    s = gender.cuda()[u]
+    U0 = (torch.randn(n_users, dim, generator=g) * 0.1).cuda()
+    I0 = (torch.randn(n_items, dim, generator=g) * 0.1).cuda()
+    engs = []
+    for staged in (False, True):
+        eng = FocfEngine(U0.clone(), I0.clone(), objective, 0.5, 5.0)
+        FusedLazyAdam(eng, lr=1e-2, weight_decay=1e-3, sweep_period=5)
+        eng.defer_loss = True
+        eng.staged = staged
+        engs.append(eng)
+    losses = [[], []]
+    for t in range(T):
+        if t < 6:
+            nxt = [(u[j], i[j], s[j], r[j]) for j in range(t + 1, min(t + 4, T))]      # the queue runs
+        elif t == 6:
+            nxt = [(u[T + 1], i[T + 1], s[T + 1], r[T + 1]), (u[T + 2], i[T + 2], s[T + 2], r[T + 2])]   # ... announces batches
+        elif t < 10:                                                                              #     that never come
+            nxt = None                                                                 # nobody announces anything
+        else:
+            nxt = [(u[j], i[j], s[j], r[j]) for j in range(t + 1, min(t + 3, T))]
+        for k, eng in enumerate(engs):
+            loss, _ = eng.forward(u[t], i[t], r[t], s[t], next_batch=nxt or None)
+            eng.backward_adam()
+            assert eng._prev is not None and eng._prev[3] == (k == 1)
+            losses[k].append(loss)
+        for eng in engs:      # (every step: which steps of a row's replay run in one stretch depends on when the sweeper
+            eng.flush()       # meets the row, and that on how far ahead its stamps were written -- a few ulp otherwise)
+        a, b = engs
+        for name in ("weight", "m", "v"):
+            assert torch.equal(getattr(a.U, name), getattr(b.U, name)), "user %s after step %d" % (name, t)
+            assert torch.equal(getattr(a.I, name), getattr(b.I, name)), "item %s after step %d" % (name, t)
+    for eng in engs:
+        eng.finish()
+        eng.check_device_errors()
+    for la, lb in zip(*losses):
+        assert torch.equal(la[1], lb[1])                                     # mse: the same sum
+        torch.testing.assert_close(lb[:3], la[:3], rtol=1e-5, atol=1e-7)     # fairness value: another summation order
+
+
 def test_full_size_steps_match_the_oracle():
     """BASELINE.json configs[1] at its real size (1 000 001 users x 100 001 items, D = 64, B = 8192, Adam lr 1e-3 wd 1e-3,
     fair_objective value): a few optimizer steps of the HIP path -- look-ahead sorts, sweeper, lazy replay -- against the
@@ -395,10 +457,12 @@ def test_device_error_flags():
         eng.check_device_errors()
 
 
-def test_lookahead_stamps_are_the_apply_steps():
+@pytest.mark.parametrize("staged", [False, True])
+def test_lookahead_stamps_are_the_apply_steps(staged):
     """Every batch of a fused-step loop is stamped with the optimizer step at which it is applied -- prepared by a side
-    launch many steps ahead or in line, first batch of an epoch (nothing announced before it) included: the sweeper tells a
-    batch's rows from its own by that stamp, and the start order of a step's sweeper tasks is built for the stamped step."""
+    launch many steps ahead, by the stages riding in the two step launches before its own, or in line; first batch of an
+    epoch (nothing announced before it) included: the sweeper tells a batch's rows from its own by that stamp, and the start
+    order of a step's sweeper tasks is built for the stamped step."""
     from fairrec.model.fair_recommender.focf import FocfEngine
     from fairrec.optim import FusedLazyAdam
     n_users, n_items, D, B = 3001, 501, 64, 512
@@ -407,6 +471,7 @@ def test_lookahead_stamps_are_the_apply_steps():
                      "value", 0.5, 5.0)
     FusedLazyAdam(eng, lr=1e-3, weight_decay=1e-3, sweep_period=5)
     eng.defer_loss = True
+    eng.staged = staged
     gender = torch.randint(0, 2, (n_users,), generator=g).float()
     seen = []
     for epoch in range(2):
@@ -419,7 +484,8 @@ def test_lookahead_stamps_are_the_apply_steps():
             queue = [(b[0], b[1], b[3], b[2]) for b in batches[t + 1:t + 21]] or None
             eng.forward(u, i, r, s, next_batch=queue)
             assert eng._stash is not None, "the one-launch step must be taken"
-            seen.append((eng._stash[6], eng.U.step + 1))
+            stamp = eng._stash[6]
+            seen.append((stamp[0] if staged else stamp, eng.U.step + 1))      # (staged: stamp and generation of row words)
             eng.backward_adam()
         eng.flush()
     eng.check_device_errors()
