@@ -299,40 +299,79 @@ __device__ __forceinline__ int replay_class(int a, int b, int cap, int NC) {    
     return NC - 1 - min(NC - 1, cost * NC / (9 * cap + 1));
 }
 
+// Every stage thread takes STAGE_EPT elements, a block of STAGE_THREADS apart, with the loads and atomics of all of them in
+// flight together: half the stage waves (each holds a wave slot for 7-19 us of dependent round trips that a sweeper task
+// could have started in), chains of the same length.  Measured (uniform / zipf items, us per step): one element per thread
+// everywhere 29.97 / 33.7; two, the place stage one 29.61 / 33.8 (kept); two everywhere 29.61 / 34.2; four 33-43.
+#ifndef FR_STAGE_EPT
+#define FR_STAGE_EPT 2
+#endif
+constexpr int STAGE_EPT = FR_STAGE_EPT;
+constexpr int STAGE_BLOCK = STAGE_THREADS * STAGE_EPT;       // elements per stage workgroup
+
 __device__ __forceinline__ void stage_claim(const StageArgs& s, int sb) {
     const ClaimJob& J = s.c;
     const int lane = threadIdx.x & 63;
-    const int b = sb * STAGE_THREADS + (int)threadIdx.x;
-    const bool ok = b < J.B;
-    const int bc = ok ? b : 0;
-    long long u = J.user[bc], i = J.item[bc];
-    const float rt = J.rating[bc], ss = J.sst ? J.sst[bc] : 0.f;
-    const bool bad = u < 0 || u >= s.n_rows_u || i < 0 || i >= s.n_rows_i;
-    if (u < 0 || u >= s.n_rows_u) u = 0;
-    if (i < 0 || i >= s.n_rows_i) i = 0;
-    if (ok && bad && s.err) atomicOr(s.err, FR_DEV_ERR_INDEX_RANGE);
-    int ru = 0, ri = 0;
-    if (ok) {
-        const unsigned long long T = (unsigned long long)J.stamp << HC_TAG_SHIFT;
-        // (the add is issued only once the maximum has returned: its operand depends on the returned word -- on a bit
-        // that is never set, a stamp has 31 bits)
-        const unsigned long long mu = __hip_atomic_fetch_max(J.hcu + u, T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned long long mi = __hip_atomic_fetch_max(J.hci + i, T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        atomicMax(s.Ustamp + u, J.stamp);
-        atomicMax(s.Istamp + i, J.stamp);
-        const unsigned long long ou =
-            __hip_atomic_fetch_add(J.hcu + u, HC_CNT1 + (mu >> 63), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned long long oi =
-            __hip_atomic_fetch_add(J.hci + i, HC_CNT1 + (mi >> 63), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        ru = hc_cnt(ou);
-        ri = hc_cnt(oi);
-        J.rec[b] = make_int4((int)u, (int)i, __float_as_int(rt), __float_as_int(ss));
-        J.info[b] = make_int4(ru, ri, 0, 0);
+    constexpr int EPT = STAGE_EPT;
+    int b[EPT];
+    bool ok[EPT];
+    long long u[EPT], i[EPT];
+    float rt[EPT], ss[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        b[e] = (sb * EPT + e) * STAGE_THREADS + (int)threadIdx.x;
+        ok[e] = b[e] < J.B;
+        const int bc = ok[e] ? b[e] : 0;
+        u[e] = J.user[bc];
+        i[e] = J.item[bc];
+        rt[e] = J.rating[bc];
+        ss[e] = J.sst ? J.sst[bc] : 0.f;
     }
-    const unsigned long long first = __ballot(ok && ri == 0);
-    if (lane == 0 && first) atomicAdd(J.cp + 8, __popcll(first));
+    bool bad = false;
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        bad |= ok[e] && (u[e] < 0 || u[e] >= s.n_rows_u || i[e] < 0 || i[e] >= s.n_rows_i);
+        if (u[e] < 0 || u[e] >= s.n_rows_u) u[e] = 0;
+        if (i[e] < 0 || i[e] >= s.n_rows_i) i[e] = 0;
+    }
+    if (bad && s.err) atomicOr(s.err, FR_DEV_ERR_INDEX_RANGE);
+    const unsigned long long T = (unsigned long long)J.stamp << HC_TAG_SHIFT;
+    unsigned long long mu[EPT], mi[EPT], ou[EPT], oi[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        mu[e] = mi[e] = 0ull;
+        if (ok[e]) {
+            mu[e] = __hip_atomic_fetch_max(J.hcu + u[e], T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            mi[e] = __hip_atomic_fetch_max(J.hci + i[e], T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            atomicMax(s.Ustamp + u[e], J.stamp);
+            atomicMax(s.Istamp + i[e], J.stamp);
+        }
+    }
+    // (an add is issued only once its row's maximum has returned: its operand depends on the returned word -- on a bit that
+    // is never set, a stamp has 31 bits)
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        ou[e] = oi[e] = 0ull;
+        if (ok[e]) {
+            ou[e] = __hip_atomic_fetch_add(J.hcu + u[e], HC_CNT1 + (mu[e] >> 63), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            oi[e] = __hip_atomic_fetch_add(J.hci + i[e], HC_CNT1 + (mi[e] >> 63), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    int first = 0;
+    unsigned e1 = 0u, e2 = 0u;
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        const int ru = hc_cnt(ou[e]), ri = hc_cnt(oi[e]);
+        if (ok[e]) {
+            J.rec[b[e]] = make_int4((int)u[e], (int)i[e], __float_as_int(rt[e]), __float_as_int(ss[e]));
+            J.info[b[e]] = make_int4(ru, ri, 0, 0);
+            e1 = max(e1, ord_enc(ss[e]));
+            e2 = max(e2, ord_enc(-ss[e]));
+        }
+        first += __popcll(__ballot(ok[e] && ri == 0));
+    }
+    if (lane == 0 && first) atomicAdd(J.cp + 8, first);
     if (J.sst) {
-        unsigned e1 = ok ? ord_enc(ss) : 0u, e2 = ok ? ord_enc(-ss) : 0u;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             e1 = max(e1, (unsigned)__shfl_xor((int)e1, o, 64));
@@ -349,74 +388,142 @@ __device__ __forceinline__ void stage_claim(const StageArgs& s, int sb) {
 __device__ __forceinline__ void stage_sweep_class(const StageArgs& s, int sb) {
     const ClaimJob& J = s.c;
     const int lane = threadIdx.x & 63;
-    const int q = sb * STAGE_THREADS + (int)threadIdx.x;
+    constexpr int EPT = STAGE_EPT;
     const int pairs_u = (J.n_u + 1) >> 1, n_pairs = pairs_u + ((J.n_i + 1) >> 1);
-    const bool ok = q < n_pairs;
-    const int qc = ok ? q : 0;
-    const bool inU = qc < pairs_u;
-    const int kk = inU ? qc : qc - pairs_u;
-    const long long rowA = (inU ? J.lo_u : J.lo_i) + 2 * kk;
-    const long long rowB = 2 * kk + 1 < (inU ? J.n_u : J.n_i) ? rowA + 1 : rowA;
-    const int32_t* Tl = inU ? s.Ulast : s.Ilast;
-    const int32_t* Ts = inU ? s.Ustamp : s.Istamp;
-    const int la = Tl[rowA], lb = Tl[rowB], sa = Ts[rowA], sb_ = Ts[rowB];
     const int cap = s.cap > 0 ? s.cap : 1024;
-    const int k = ok ? replay_class(sa >= J.stamp ? 0 : J.stamp - la, sb_ >= J.stamp ? 0 : J.stamp - lb, cap, SW_NC) : -1;
-    const int rk = class_rank<SW_NC>(k, J.cp + 16, lane);
-    if (ok) J.sw_tmp[q] = k << 20 | rk;
+    int q[EPT], la[EPT], lb[EPT], sa[EPT], sb_[EPT], k[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        q[e] = (sb * EPT + e) * STAGE_THREADS + (int)threadIdx.x;
+        const int qc = q[e] < n_pairs ? q[e] : 0;
+        const bool inU = qc < pairs_u;
+        const int kk = inU ? qc : qc - pairs_u;
+        const long long rowA = (inU ? J.lo_u : J.lo_i) + 2 * kk;
+        const long long rowB = 2 * kk + 1 < (inU ? J.n_u : J.n_i) ? rowA + 1 : rowA;
+        const int32_t* Tl = inU ? s.Ulast : s.Ilast;
+        const int32_t* Ts = inU ? s.Ustamp : s.Istamp;
+        la[e] = Tl[rowA]; lb[e] = Tl[rowB]; sa[e] = Ts[rowA]; sb_[e] = Ts[rowB];
+    }
+    int mine = 0;          // lane c: the wave's tasks of class c
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        k[e] = q[e] < n_pairs ? replay_class(sa[e] >= J.stamp ? 0 : J.stamp - la[e], sb_[e] >= J.stamp ? 0 : J.stamp - lb[e],
+                                            cap, SW_NC)
+                              : -1;
+#pragma unroll
+        for (int c = 0; c < SW_NC; ++c) {
+            const int n = __popcll(__ballot(k[e] == c));
+            if (lane == c) mine += n;
+        }
+    }
+    int got = 0;
+    if (lane < SW_NC && mine) got = atomicAdd(J.cp + 16 + lane, mine);
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    int rk[EPT];
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) rk[e] = 0;
+#pragma unroll
+    for (int c = 0; c < SW_NC; ++c) {
+        int run = __shfl(got, c, 64);
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            const unsigned long long m = __ballot(k[e] == c);
+            if (k[e] == c) rk[e] = run + __popcll(m & lt);
+            run += __popcll(m);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < EPT; ++e)
+        if (k[e] >= 0) J.sw_tmp[q[e]] = k[e] << 20 | rk[e];
 }
 
+#ifndef FR_PLACE_EPT
+#define FR_PLACE_EPT 1
+#endif
+constexpr int PLACE_EPT = FR_PLACE_EPT;      // (the place stage ranks its wave's interactions: 64 EPT^2 compare steps)
 __device__ __forceinline__ void stage_place(const StageArgs& s, int sb) {
     const PlaceJob& J = s.p;
     const int lane = threadIdx.x & 63;
-    const int b = sb * STAGE_THREADS + (int)threadIdx.x;
-    const bool ok = b < J.B;
-    const int bc = ok ? b : 0;
-    const int4 rec = J.rec[bc], f = J.info[bc];            // f = (rank at the user row, rank at the item row, -, -)
-    const unsigned long long wu = J.hcu[rec.x], wi = J.hci[rec.y];
-    const int lu = s.Ulast[rec.x], li = s.Ilast[rec.y];
-    const int nu = hc_cnt(wu), ni = hc_cnt(wi);
-    if (ok && nu > 1 && f.x == 0) {
-        const int base = atomicAdd(J.cp + 11, nu);
-        __hip_atomic_fetch_add(J.hcu + rec.x, (unsigned long long)base, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    constexpr int EPT = PLACE_EPT;
+    int b[EPT];
+    bool ok[EPT];
+    int4 rec[EPT], f[EPT];           // f = (rank at the user row, rank at the item row, -, -)
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        b[e] = (sb * EPT + e) * STAGE_THREADS + (int)threadIdx.x;
+        ok[e] = b[e] < J.B;
+        const int bc = ok[e] ? b[e] : 0;
+        rec[e] = J.rec[bc];
+        f[e] = J.info[bc];
     }
-    if (ok && ni > 1 && f.y == 0) {
-        const int base = atomicAdd(J.cp + 12, ni);
-        __hip_atomic_fetch_add(J.hci + rec.y, (unsigned long long)base, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int nu[EPT], ni[EPT], k[EPT], key[EPT];
+    {
+        unsigned long long wu[EPT], wi[EPT];
+        int lu[EPT], li[EPT];
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            wu[e] = J.hcu[rec[e].x];
+            wi[e] = J.hci[rec[e].y];
+            lu[e] = s.Ulast[rec[e].x];
+            li[e] = s.Ilast[rec[e].y];
+        }
+        const int cap = s.cap > 0 ? s.cap : 1024;
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            nu[e] = hc_cnt(wu[e]);
+            ni[e] = hc_cnt(wi[e]);
+            if (ok[e] && nu[e] > 1 && f[e].x == 0) {
+                const int base = atomicAdd(J.cp + 11, nu[e]);
+                __hip_atomic_fetch_add(J.hcu + rec[e].x, (unsigned long long)base, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (ok[e] && ni[e] > 1 && f[e].y == 0) {
+                const int base = atomicAdd(J.cp + 12, ni[e]);
+                __hip_atomic_fetch_add(J.hci + rec[e].y, (unsigned long long)base, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            // a shared row is finished by the last of its waves to arrive, behind a hand-off through memory and three more
+            // dependent load levels: the longest chain of the launch whatever its replay length, so those start first
+            k[e] = !ok[e] ? -1 : ((nu[e] > 1 || ni[e] > 1) && FR_LPT_SHARED_FIRST ? 0 : 1);
+            int cu = J.stamp - 1 - lu[e], ci = J.stamp - 1 - li[e];
+            cu = cu < 0 ? 0 : (cu > cap ? cap : cu);
+            ci = ci < 0 ? 0 : (ci > cap ? cap : ci);
+            key[e] = 7 * (cu > ci ? cu : ci) + 2 * (cu > ci ? ci : cu);      // the cost of focf_lpt_kernel
+        }
     }
-    // a shared row is finished by the last of its waves to arrive, behind a hand-off through memory and three more
-    // dependent load levels: the longest chain of the launch whatever its replay length, so those start first
-    const int k = !ok ? -1 : ((nu > 1 || ni > 1) && FR_LPT_SHARED_FIRST ? 0 : 1);
     // Within the places its wave takes at either end, an interaction stands by estimated replay cost (longest towards the
     // front): the step gives two neighbours of the list to one wave and replays their user rows, and their item rows, as
-    // packed pairs over the steps both rows of a pair missed -- rows of like staleness share most of them.
-    int key = 0;
-    if (ok) {
-        const int cap = s.cap > 0 ? s.cap : 1024;
-        int cu = J.stamp - 1 - lu, ci = J.stamp - 1 - li;
-        cu = cu < 0 ? 0 : (cu > cap ? cap : cu);
-        ci = ci < 0 ? 0 : (ci > cap ? cap : ci);
-        key = 7 * (cu > ci ? cu : ci) + 2 * (cu > ci ? ci : cu);      // the cost of focf_lpt_kernel
+    // packed pairs over the steps both rows of a pair missed -- rows of like staleness share most of them.  (By the exact
+    // estimate: with the eight cost classes of the sorted prepare in its place a step takes 0.5 us longer.  The ranking is
+    // 64 EPT^2 compare steps per wave, which is what bounds EPT: at 4 a place wave outlasts the launch.)
+    int before[EPT];                     // members of the element's band in the wave that stand before it
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) before[e] = 0;
+    int n0 = 0, n1 = 0;                  // the wave's interactions of either band
+#pragma unroll
+    for (int e2 = 0; e2 < EPT; ++e2) {
+        n0 += __popcll(__ballot(k[e2] == 0));
+        n1 += __popcll(__ballot(k[e2] == 1));
+        for (int t = 0; t < 64; ++t) {
+            const int kt = __builtin_amdgcn_readlane(k[e2], t), ct = __builtin_amdgcn_readlane(key[e2], t);
+#pragma unroll
+            for (int e = 0; e < EPT; ++e)
+                before[e] += (kt == k[e] && (ct > key[e] || (ct == key[e] && (e2 < e || (e2 == e && t < lane))))) ? 1 : 0;
+        }
     }
-    int before = 0;                  // members of this lane's band in the wave that stand before it
-    for (int t = 0; t < 64; ++t) {
-        const int kt = __builtin_amdgcn_readlane(k, t), ct = __builtin_amdgcn_readlane(key, t);
-        before += (kt == k && (ct > key || (ct == key && t < lane))) ? 1 : 0;
-    }
-    const unsigned long long m0 = __ballot(k == 0), m1 = __ballot(k == 1);
-    const unsigned long long band = k == 0 ? m0 : m1;
-    const int band_n = __popcll(band);
-    // places taken from the front (cp[0]) and from the back (cp[1]): the wave's first place of the lane's band
-    const int base = class_rank<2>(k, J.cp, lane) - __popcll(band & ((1ull << lane) - 1ull));
-    if (ok) {
+    // places taken from the front (cp[0]) and from the back (cp[1]): the wave's first place of either band
+    int got = 0;
+    if (lane == 0 && n0) got = atomicAdd(J.cp, n0);
+    if (lane == 1 && n1) got = atomicAdd(J.cp + 1, n1);
+    const int base0 = __shfl(got, 0, 64), base1 = __shfl(got, 1, 64);
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+        if (!ok[e]) continue;
         // front band: [base, base + n) by falling cost; back band: the wave's n places end at B - 1 - base, falling cost too
-        const int rk = k == 0 ? base + before : base + (band_n - 1 - before);
-        const int pos = k == 0 ? rk : J.B - 1 - rk;
-        J.task_rec[pos] = rec;
-        J.task_info[pos] = make_int4(f.x | nu << 16, f.y | ni << 16, 0, b);     // the records' layout of the sorted prepare,
-        J.info[b] = make_int4(f.x, f.y, nu, ni);                                //   ranks in the place of list positions
+        const int pos = k[e] == 0 ? base0 + before[e] : J.B - 1 - (base1 + (n1 - 1 - before[e]));
+        J.task_rec[pos] = rec[e];
+        J.task_info[pos] = make_int4(f[e].x | nu[e] << 16, f[e].y | ni[e] << 16, 0, b[e]);   // the records' layout of the sorted
+        J.info[b[e]] = make_int4(f[e].x, f[e].y, nu[e], ni[e]);                             //   prepare, ranks for list positions
     }
-    if (b == 0) {
+    if (sb == 0 && threadIdx.x == 0) {
         const unsigned e1 = (unsigned)J.cp[9], e2 = (unsigned)J.cp[10];
         *reinterpret_cast<int4*>(J.hdr) = make_int4(J.cp[8], 0, __float_as_int(-ord_dec(e2)), __float_as_int(ord_dec(e1)));
     }
@@ -424,18 +531,27 @@ __device__ __forceinline__ void stage_place(const StageArgs& s, int sb) {
 
 __device__ __forceinline__ void stage_sweep_place(const StageArgs& s, int sb) {
     const PlaceJob& J = s.p;
-    const int q = sb * STAGE_THREADS + (int)threadIdx.x;
     int cnt[SW_NC];
 #pragma unroll
     for (int c = 0; c < SW_NC; ++c) cnt[c] = J.cp[16 + c];
-    if (q < J.n_pairs) {
-        const int v = J.sw_tmp[q], k = v >> 20;
-        int pos = v & 0xfffff;
+    int v[STAGE_EPT];
 #pragma unroll
-        for (int c = 0; c < SW_NC; ++c) pos += c < k ? cnt[c] : 0;
-        J.sw_order[pos] = q;
+    for (int e = 0; e < STAGE_EPT; ++e) {
+        const int q = (sb * STAGE_EPT + e) * STAGE_THREADS + (int)threadIdx.x;
+        v[e] = q < J.n_pairs ? J.sw_tmp[q] : -1;
     }
-    if (q == 0) J.sw_order[J.n_pairs] = J.n_pairs;
+#pragma unroll
+    for (int e = 0; e < STAGE_EPT; ++e) {
+        const int q = (sb * STAGE_EPT + e) * STAGE_THREADS + (int)threadIdx.x;
+        if (v[e] >= 0) {
+            const int k = v[e] >> 20;
+            int pos = v[e] & 0xfffff;
+#pragma unroll
+            for (int c = 0; c < SW_NC; ++c) pos += c < k ? cnt[c] : 0;
+            J.sw_order[pos] = q;
+        }
+    }
+    if (sb == 0 && threadIdx.x == 0) J.sw_order[J.n_pairs] = J.n_pairs;
 }
 
 // stage workgroup `sb` of a launch (the claim stages first: their atomics are the longest chains)
@@ -1696,14 +1812,14 @@ static int make_stages(StageArgs& st, const fr_table* U, const fr_table* I, cons
         J.hcu = words_of(row_words, claim_gen, U, I, false);
         J.hci = words_of(row_words, claim_gen, U, I, true);
         J.B = (int)b.B; J.stamp = claim_stamp;
-        st.nb_claim = (int)((b.B + STAGE_THREADS - 1) / STAGE_THREADS);
+        st.nb_claim = (int)((b.B + STAGE_BLOCK - 1) / STAGE_BLOCK);
         if (sweep_period > 0) {
             const SweepSlice sw = slice_of(claim_stamp);
             const long long n_pairs = ((long long)sw.n_u + 1) / 2 + ((long long)sw.n_i + 1) / 2;
             if (n_pairs <= SWEEP_ORDER_MAX) {
                 J.lo_u = sw.lo_u; J.lo_i = sw.lo_i; J.n_u = sw.n_u; J.n_i = sw.n_i;
                 J.sw_tmp = w.sw_tmp;
-                st.nb_sa = (int)((n_pairs + STAGE_THREADS - 1) / STAGE_THREADS);
+                st.nb_sa = (int)((n_pairs + STAGE_BLOCK - 1) / STAGE_BLOCK);
             }
         }
     }
@@ -1719,14 +1835,14 @@ static int make_stages(StageArgs& st, const fr_table* U, const fr_table* I, cons
         J.hcu = words_of(row_words, place_gen, U, I, false);
         J.hci = words_of(row_words, place_gen, U, I, true);
         J.B = (int)b.B; J.stamp = place_stamp;
-        st.nb_place = (int)((b.B + STAGE_THREADS - 1) / STAGE_THREADS);
+        st.nb_place = (int)((b.B + STAGE_THREADS * PLACE_EPT - 1) / (STAGE_THREADS * PLACE_EPT));
         if (sweep_period > 0) {
             const SweepSlice sw = slice_of(place_stamp);
             const long long n_pairs = ((long long)sw.n_u + 1) / 2 + ((long long)sw.n_i + 1) / 2;
             if (n_pairs <= SWEEP_ORDER_MAX) {
                 J.n_pairs = (int)n_pairs;
                 J.sw_tmp = w.sw_tmp; J.sw_order = w.sw_order;
-                st.nb_sb = (int)((n_pairs + STAGE_THREADS - 1) / STAGE_THREADS);
+                st.nb_sb = (int)((n_pairs + STAGE_BLOCK - 1) / STAGE_BLOCK);
             }
         }
     }

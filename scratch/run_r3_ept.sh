@@ -1,0 +1,22 @@
+#!/bin/bash
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/ept
+mkdir -p $O
+cd $R
+L=$R/scratch/lib
+timeout 900 python -m pytest tests/test_focf_hip.py -x -q -m gpu > $O/pytest.log 2>&1; grep -n "passed\|failed" $O/pytest.log | tail -2
+run() { local tag=$1 lib=$2; shift 2
+  if [ "$lib" = "-" ]; then unset FAIRREC_HIP_LIB; else export FAIRREC_HIP_LIB=$L/libfairrec_hip_$lib.so; fi
+  TAG=$tag timeout 300 python scratch/step_bench.py "$@" 2>$O/$tag.err | tee -a $O/summary.txt; }
+for rep in 1 2 3; do
+run ept2_$rep -
+run ept1b_$rep ept1
+run ept1_$rep ept1
+FAIRREC_FOCF_STAGED=0 run sorted$rep -
+done
+run zipf_ept2 - --item-dist zipf
+run zipf_ept1 ept1 --item-dist zipf
+run unique_ept2 - --item-dist unique
+run unique_ept1 ept1 --item-dist unique
+export FAIRREC_HIP_LIB=$L/libfairrec_hip_trace.so
+FAIRREC_FOCF_STAGED=1 TRACE_STEP=260 timeout 300 python scratch/graph_trace.py > $O/trace.txt 2>$O/err.txt; cat $O/trace.txt
