@@ -242,6 +242,47 @@ def test_in_launch_prepare_equals_sorted_prepare(objective, dim):
         torch.testing.assert_close(lb[:3], la[:3], rtol=1e-5, atol=1e-7)     # fairness value: another summation order
 
 
+@pytest.mark.parametrize("B", [1, 2, 63, 65, 257])
+def test_in_launch_prepare_with_tiny_and_ragged_batches(B):
+    """Batch sizes around the wave and workgroup granules of the stages (one interaction, an odd one out of the last pair,
+    a partly filled stage wave), every row shared or none: staged and sorted prepare give the same tables bit for bit."""
+    from fairrec.model.fair_recommender.focf import FocfEngine
+    from fairrec.optim import FusedLazyAdam
+    n_users, n_items, D, T = 301, 151, 64, 7
+    g = torch.Generator().manual_seed(B)
+    u = torch.randint(1, n_users, (T, B), generator=g)
+    i = torch.randint(1, n_items, (T, B), generator=g)
+    i[2] = i[2, 0]                      # one step with a single item (every interaction on the shared path) ...
+    u[3] = u[3, 0]                      # ... and one with a single user
+    r = torch.randint(1, 6, (T, B), generator=g).float()
+    gender = torch.randint(0, 2, (n_users,), generator=g).float()
+    u, i, r = u.cuda(), i.cuda(), r.cuda()
+    s = gender.cuda()[u]
+    U0 = (torch.randn(n_users, D, generator=g) * 0.1).cuda()
+    I0 = (torch.randn(n_items, D, generator=g) * 0.1).cuda()
+    engs = []
+    for staged in (False, True):
+        eng = FocfEngine(U0.clone(), I0.clone(), "value", 0.5, 5.0)
+        FusedLazyAdam(eng, lr=1e-2, weight_decay=1e-3, sweep_period=3)
+        eng.defer_loss = True
+        eng.staged = staged
+        engs.append(eng)
+    for t in range(T):
+        nxt = [(u[j], i[j], s[j], r[j]) for j in range(t + 1, min(t + 3, T))] or None
+        for eng in engs:
+            eng.forward(u[t], i[t], r[t], s[t], next_batch=nxt)
+            eng.backward_adam()
+            eng.flush()
+        a, b = engs
+        for name in ("weight", "m", "v"):
+            assert torch.equal(getattr(a.U, name), getattr(b.U, name)), "user %s after step %d" % (name, t)
+            assert torch.equal(getattr(a.I, name), getattr(b.I, name)), "item %s after step %d" % (name, t)
+    for eng in engs:
+        eng.finish()
+        eng.check_device_errors()
+    torch.testing.assert_close(engs[1].loss_acc[:3], engs[0].loss_acc[:3], rtol=1e-5, atol=1e-7)
+
+
 def test_full_size_steps_match_the_oracle():
     """BASELINE.json configs[1] at its real size (1 000 001 users x 100 001 items, D = 64, B = 8192, Adam lr 1e-3 wd 1e-3,
     fair_objective value): a few optimizer steps of the HIP path -- look-ahead sorts, sweeper, lazy replay -- against the
