@@ -1396,7 +1396,8 @@ __global__ __launch_bounds__(64 * STEP_WPB, FR_STEP_WAVES) void focf_step_kernel
     const int n_stage = CLAIM ? st.nb_claim + st.nb_sa + st.nb_place + st.nb_sb : 0;
     // Where the stage workgroups sit in the grid: behind the `lead` interaction workgroups (2, default), first (0) or
     // last (1).  Measured at the BASELINE sizes, hipGraph replay: 29.2-29.6 / 29.9-30.2 / 31.3-31.7 us per step (last: the
-    // stages' dependent atomics then end the launch); further back among the sweeper workgroups: as (2).
+    // stages' dependent atomics then end the launch); further back among the sweeper workgroups: as (2).  Stage waves at a
+    // raised priority (s_setprio 3) end sooner (p90 12.8 instead of 17 us) and cost the step 1.8 us: dropped.
 #ifndef FR_STAGE_POS
 #define FR_STAGE_POS 2
 #endif
