@@ -218,7 +218,7 @@ def bench_nfcf(args, rank, world, dev):
                                      "2 all-to-alls); the scorer MLP has no BatchNorm") if world > 1 else "single device",
                    "global_batch": B * world, "launch": "hipGraph step" if graphed is not None else "eager",
                    "aged_steps": n_age,
-                   "final_loss": round(float(loss), 6),
+                   "final_loss": round(float(loss.detach()), 6),
                    "peak_mem_GiB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)},
         "roofline": {"bound": "hbm", "kernel": "whole step (no dominant kernel: gather, MLP, loss, apply)",
                      "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
