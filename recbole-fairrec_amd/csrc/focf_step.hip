@@ -188,14 +188,40 @@ __device__ __forceinline__ void store_row_sc1(const RowFrag<E>& f, float* base, 
     }
 }
 
+// a finished row's `last` stamp, and the other one-word results of a task, with the rows' store policy
+__device__ __forceinline__ void store_word(int32_t* p, int v) {
+#if FR_TROW_STORE == 1 && FR_WORD_STORE
+    __hip_atomic_store((gint*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+    *(gint*)p = v;
+#endif
+}
+__device__ __forceinline__ void store_word(float* p, float v) {
+#if FR_TROW_STORE == 1 && FR_WORD_STORE
+    st_sc1g((gfloat*)p, v);
+#else
+    *(gfloat*)p = v;
+#endif
+}
+
 // The write-back of a finished table row
-template <int E, bool FULL>
-__device__ __forceinline__ void store_trow(const RowFrag<E>& f, float* base, int D, int lane) {
+template <int E, bool FULL, bool WT = true>     // WT: subject to FR_TROW_STORE (the shared-row path drains its stores
+__device__ __forceinline__ void store_trow(const RowFrag<E>& f, float* base, int D, int lane) {      // between hand-offs: plain there)
     gfloat* g = gp(base);
 #pragma unroll
     for (int e = 0; e < E; ++e) {
         const int d = lane + 64 * e;
+#if FR_TROW_STORE == 1
+        if (WT) {
+            if (FULL || d < D) { float val = f.x[e]; asm volatile("" : "+v"(val)); st_sc1g(g + d, val); }
+        } else if (FULL || d < D) g[d] = f.x[e];
+#elif FR_TROW_STORE == 2
+        if (WT) {
+            if (FULL || d < D) __builtin_nontemporal_store(f.x[e], g + d);
+        } else if (FULL || d < D) g[d] = f.x[e];
+#else
         if (FULL || d < D) g[d] = f.x[e];
+#endif
     }
 }
 
@@ -303,6 +329,19 @@ __device__ __forceinline__ int replay_class(int a, int b, int cap, int NC) {    
 // flight together: half the stage waves (each holds a wave slot for 7-19 us of dependent round trips that a sweeper task
 // could have started in), chains of the same length.  Measured (uniform / zipf items, us per step): one element per thread
 // everywhere 29.97 / 33.7; two, the place stage one 29.61 / 33.8 (kept); two everywhere 29.61 / 34.2; four 33-43.
+// Finished table rows (and the tasks' one-word results) are stored WRITE-THROUGH (1; 0 plain, 2 non-temporal): a launch writes
+// 22 MB, the eight L2s together hold 32 MB, so with write-back stores most of it is still dirty when the last wave ends and
+// the launch's end-of-kernel release writes it out before the next launch may start -- 3.2 us from the last wave to the next
+// launch's first against ~1.5 us for a launch that leaves nothing behind.  Measured (same box, us per step, uniform / zipf /
+// --steps 20): plain 29.98 / 33.7 / 30.8, rows write-through 29.41 / 33.6 / 29.9, rows and words 29.05 / 33.4, non-temporal
+// 29.8.  Not on the shared-row path: its hand-offs drain the wave's stores, and a write-through store is acknowledged by
+// memory, not by the L2 (zipf items 33.6 -> 39.4 us with write-through rows there).
+#ifndef FR_TROW_STORE
+#define FR_TROW_STORE 1
+#endif
+#ifndef FR_WORD_STORE
+#define FR_WORD_STORE 1
+#endif
 #ifndef FR_STAGE_EPT
 #define FR_STAGE_EPT 2
 #endif
@@ -638,9 +677,9 @@ __device__ __forceinline__ void adam_write(float* Tp, float* Tm, float* Tv, int3
                                            const RowFrag<E>& g, float2 s, int lane) {
 #pragma unroll
     for (int e = 0; e < E; ++e) adam_elem(p.x[e], m.x[e], v.x[e], g.x[e], s.x, s.y, c);
-    store_trow<E, FULL>(p, Tp + (size_t)row * D, D, lane);
-    store_trow<E, FULL>(m, Tm + (size_t)row * D, D, lane);
-    store_trow<E, FULL>(v, Tv + (size_t)row * D, D, lane);
+    store_trow<E, FULL, false>(p, Tp + (size_t)row * D, D, lane);
+    store_trow<E, FULL, false>(m, Tm + (size_t)row * D, D, lane);
+    store_trow<E, FULL, false>(v, Tv + (size_t)row * D, D, lane);
     if (lane == 0) Tlast[row] = step;
 }
 
@@ -1010,7 +1049,7 @@ __device__ __forceinline__ void step_finish(KV kv, const AdamC& c, int lane, int
     for (int e = 0; e < E; ++e) dot = fmaf(pu.x[e], pi.x[e], dot);
     dot = wave_sum(dot);
     const float er = dot - rt;
-    if (lane == 0) KA(mse_e)[b] = er * er;
+    if (lane == 0) store_word(KA(mse_e) + b, er * er);
     const float cm = 2.f * er / (float)KA(B);        // d mean((pred - r)^2) / d pred
     // dLoss/dpred of an interaction whose item has no other member in the batch: its per-item statistics are its own
     float coef = cm;
@@ -1044,8 +1083,8 @@ __device__ __forceinline__ void step_finish(KV kv, const AdamC& c, int lane, int
         store_trow<E, FULL>(mi, KA(Im) + (size_t)ir * D, D, lane);
         store_trow<E, FULL>(vi, KA(Iv) + (size_t)ir * D, D, lane);
         if (lane == 0) {
-            KA(Ulast)[ur] = KA(step);
-            KA(Ilast)[ir] = KA(step);
+            store_word(KA(Ulast) + ur, KA(step));
+            store_word(KA(Ilast) + ir, KA(step));
         }
         return;
     }
@@ -1080,8 +1119,8 @@ __device__ __forceinline__ void adam_store_both(KV kv, const AdamC& c, int lane,
     store_trow<E, FULL>(mi, KA(Im) + (size_t)ir * D, D, lane);
     store_trow<E, FULL>(vi, KA(Iv) + (size_t)ir * D, D, lane);
     if (lane == 0) {
-        gp(KA(Ulast))[ur] = KA(step);
-        gp(KA(Ilast))[ir] = KA(step);
+        store_word(KA(Ulast) + ur, KA(step));
+        store_word(KA(Ilast) + ir, KA(step));
     }
 }
 
@@ -1130,9 +1169,9 @@ __device__ __forceinline__ void step_finish_pair(KV kv, const AdamC& c, int lane
         if (single) coef = cm + g;
     }
     if (lane < (has1 ? 2 : 1)) {
-        gp(KA(mse_e))[inf_w] = er * er;
+        store_word(KA(mse_e) + inf_w, er * er);
         if (single) {
-            gp(KA(term))[CLAIM ? inf_w : inf_z >> 16] = term;
+            store_word(KA(term) + (CLAIM ? inf_w : inf_z >> 16), term);
             if (sst != smin && sst != smax && KA(err)) atomicOr(KA(err), FR_DEV_ERR_SST_GROUPS);
         }
     }
@@ -1234,13 +1273,13 @@ __device__ __forceinline__ void step_task(KV kv, bool sweeper, int q, int n_pair
             store_trow<E, FULL>(r.pA, Tp + (size_t)rowA * D, D, lane);
             store_trow<E, FULL>(r.mA, Tm + (size_t)rowA * D, D, lane);
             store_trow<E, FULL>(r.vA, Tv + (size_t)rowA * D, D, lane);
-            if (lane == 0) gp(Tl)[rowA] = upto;
+            if (lane == 0) store_word(Tl + rowA, upto);
         }
         if (doB) {
             store_trow<E, FULL>(r.pB, Tp + (size_t)rowB * D, D, lane);
             store_trow<E, FULL>(r.mB, Tm + (size_t)rowB * D, D, lane);
             store_trow<E, FULL>(r.vB, Tv + (size_t)rowB * D, D, lane);
-            if (lane == 0) gp(Tl)[rowB] = upto;
+            if (lane == 0) store_word(Tl + rowB, upto);
         }
         return;
     }
