@@ -1222,7 +1222,8 @@ __device__ __forceinline__ void step_finish_pair(KV kv, const AdamC& c, int lane
 //   sweeper task q  : rows 2q, 2q + 1 of the step's slice (users first, then items), written back at step `step`;
 //   interaction b   : its user row and item row as of step - 1, then score, dLoss/dpred, both gradients, both updates.
 template <int E, bool FULL, bool PAIR, bool CLAIM>
-__device__ __forceinline__ void step_task(KV kv, bool sweeper, int q, int n_pairs, int lane
+__device__ __forceinline__ void step_task(KV kv, bool sweeper, int q, int n_pairs, int lane, const int4* rec0,
+                                          const int32_t* order0, int B0
 #if FR_STEP_TRACE
                                           , unsigned long long (&phase_stamps)[4]
 #endif
@@ -1240,7 +1241,7 @@ __device__ __forceinline__ void step_task(KV kv, bool sweeper, int q, int n_pair
         // start order of the slice's pairs (fr_focf_prepare_step: longest estimated replay first, so that the four waves
         // of a workgroup -- one per SIMD of its CU -- carry alike loads and the launch ends on its shortest tasks); an
         // order built for another slice size (a batch applied at another step than it was prepared for) is not used
-        if (const int32_t* so = KA(sw_order)) {
+        if (const int32_t* so = order0) {
             const int oq = so[q], on = so[n_pairs];
             q = uniform(on) == n_pairs ? uniform(oq) : q;
         }
@@ -1287,9 +1288,9 @@ __device__ __forceinline__ void step_task(KV kv, bool sweeper, int q, int n_pair
         // ---- two interactions per wave, neighbours in the start order (= similar replay lengths): their two user rows go
         // through the replay as one packed pair and so do their two item rows (4.5 instead of 7 VALU instructions per row
         // and step); each interaction is then finished on its own
-        const bool has1 = q + 1 < KA(B);
+        const bool has1 = q + 1 < B0;
         const int q1 = has1 ? q + 1 : q;
-        const int4 vrec0 = gp(KA(task_rec))[q], vrec1 = gp(KA(task_rec))[q1];
+        const int4 vrec0 = gp(rec0)[q], vrec1 = gp(rec0)[q1];
         const int u0 = uniform(vrec0.x), i0 = uniform(vrec0.y), u1 = uniform(vrec1.x), i1 = uniform(vrec1.y);
 #if FR_STEP_TRACE
         g_phase[2] = __builtin_amdgcn_s_memrealtime();     // level-1 records have arrived
@@ -1324,7 +1325,7 @@ __device__ __forceinline__ void step_task(KV kv, bool sweeper, int q, int n_pair
         return;
     }
     // ---- one interaction per wave (wide rows: two interactions' rows would not fit the register budget)
-    const int4 vrec = KA(task_rec)[q];
+    const int4 vrec = rec0[q];
     const int ur = uniform(vrec.x), ir = uniform(vrec.y);
     const int lu = KA(Ulast)[ur], li = KA(Ilast)[ir];
     ldrow<E, FULL>(r.pA, KA(Up) + (size_t)ur * D, D, lane);
@@ -1422,8 +1423,19 @@ __device__ int g_trace_step = -1;      // >= 0: only the launch that applies thi
 #ifndef FR_STEP_WAVES
 #define FR_STEP_WAVES 6      // waves per SIMD the register budget is cut for
 #endif
+// The leading scalar arguments are the ones a wave needs before it can issue its first load -- its role and task from the
+// grid shape, the task list, the sweeper order -- and are PRELOADED into SGPRs by the dispatcher (the file is compiled with
+// -amdgpu-kernarg-preload-count, Makefile): the first records are requested in the wave's first cycles, beside the vector
+// load of the argument block instead of behind it (one dependent round trip less in every wave's prologue and in the
+// launch's ramp).  They repeat fields of StepArgs / StageArgs, which the rest of the kernel reads as before.  Measured:
+// little -- 29.77 against 29.89 us per step in graph replay (five interleaved runs each), 30.8 against 31.4 us per launch in
+// the event-timed eager pass: a wave's prologue latency is hidden by the other waves of its SIMD.
+constexpr int STEP_PRELOAD_DWORDS = 10;      // pre_rec, pre_order (2 each), pre_B, pre_lead, pre_nu, pre_ni, pre_stage, pad
 template <int E, bool FULL, bool CLAIM>
-__global__ __launch_bounds__(64 * STEP_WPB, FR_STEP_WAVES) void focf_step_kernel(StepArgs a, StageArgs st) {
+__global__ __launch_bounds__(64 * STEP_WPB, FR_STEP_WAVES) void focf_step_kernel(const int4* pre_rec, const int32_t* pre_order,
+                                                                                 int pre_B, int pre_lead, int pre_nu, int pre_ni,
+                                                                                 int pre_stage, int pre_pad, StepArgs a,
+                                                                                 StageArgs st) {
 #if FR_STEP_TRACE
     const unsigned long long tr0 = __builtin_amdgcn_s_memrealtime();
     const unsigned long long mt0 = __builtin_amdgcn_s_memtime();      // shader clock: the clock the chip holds under this load
@@ -1432,7 +1444,8 @@ __global__ __launch_bounds__(64 * STEP_WPB, FR_STEP_WAVES) void focf_step_kernel
     const int lane = threadIdx.x & 63;
     const int wib = uniform((int)(threadIdx.x >> 6));      // wave-uniform, and the compiler has to know it
     int role = 0;
-    const int n_stage = CLAIM ? st.nb_claim + st.nb_sa + st.nb_place + st.nb_sb : 0;
+    const int n_stage = CLAIM ? pre_stage : 0;
+    (void)pre_pad;
     // Where the stage workgroups sit in the grid: behind the `lead` interaction workgroups (2, default), first (0) or
     // last (1).  Measured at the BASELINE sizes, hipGraph replay: 29.2-29.6 / 29.9-30.2 / 31.3-31.7 us per step (last: the
     // stages' dependent atomics then end the launch); further back among the sweeper workgroups: as (2).  Stage waves at a
@@ -1440,7 +1453,7 @@ __global__ __launch_bounds__(64 * STEP_WPB, FR_STEP_WAVES) void focf_step_kernel
 #ifndef FR_STAGE_POS
 #define FR_STAGE_POS 2
 #endif
-    const int stage0 = FR_STAGE_POS == 0 ? 1 : (FR_STAGE_POS == 1 ? (int)gridDim.x - n_stage : 1 + a.lead);
+    const int stage0 = FR_STAGE_POS == 0 ? 1 : (FR_STAGE_POS == 1 ? (int)gridDim.x - n_stage : 1 + pre_lead);
     if (blockIdx.x == 0) {
         if (a.prev.loss_out) step_reduce_loss<64 * STEP_WPB>(a.prev);
     } else if (CLAIM && (int)blockIdx.x >= stage0 && (int)blockIdx.x < stage0 + n_stage) {
@@ -1451,21 +1464,22 @@ __global__ __launch_bounds__(64 * STEP_WPB, FR_STEP_WAVES) void focf_step_kernel
         const unsigned* kp = reinterpret_cast<const unsigned*>(
             (const void*)(const __attribute__((address_space(4))) void*)__builtin_amdgcn_kernarg_segment_ptr());
         KV kv;
-        kv.v0 = kp[lane];
-        kv.v1 = lane < (int)(sizeof(StepArgs) / 4) - 64 ? kp[64 + lane] : 0u;
+        static_assert(STEP_PRELOAD_DWORDS * 4 % alignof(StepArgs) == 0, "StepArgs follows the preloaded scalars without padding");
+        kv.v0 = kp[STEP_PRELOAD_DWORDS + lane];
+        kv.v1 = lane < (int)(sizeof(StepArgs) / 4) - 64 ? kp[STEP_PRELOAD_DWORDS + 64 + lane] : 0u;
         const int x = (int)blockIdx.x - 1 - ((int)blockIdx.x >= stage0 ? n_stage : 0);
-        const int n_pairs = ((a.n_u + 1) >> 1) + ((a.n_i + 1) >> 1);
+        const int n_pairs = ((pre_nu + 1) >> 1) + ((pre_ni + 1) >> 1);
         const int ns = (n_pairs + STEP_WPB - 1) / STEP_WPB;
         // longest jobs first: the `lead` workgroups of the interactions with the longest replays (the task list is in
         // that order), then the sweeper workgroups (a full period of replay each), then the other interactions
         constexpr bool PAIR = step_pairs(E);
-        const bool sweeper = x >= a.lead && x < a.lead + ns;
-        const int q = ((sweeper ? x - a.lead : (x < a.lead ? x : x - ns)) * STEP_WPB + wib) * (!sweeper && PAIR ? 2 : 1);
+        const bool sweeper = x >= pre_lead && x < pre_lead + ns;
+        const int q = ((sweeper ? x - pre_lead : (x < pre_lead ? x : x - ns)) * STEP_WPB + wib) * (!sweeper && PAIR ? 2 : 1);
         role = sweeper ? 1 : 2;
 #if FR_STEP_TRACE
-        if (q < (sweeper ? n_pairs : a.B)) step_task<E, FULL, PAIR, CLAIM>(kv, sweeper, q, n_pairs, lane, ph);
+        if (q < (sweeper ? n_pairs : pre_B)) step_task<E, FULL, PAIR, CLAIM>(kv, sweeper, q, n_pairs, lane, pre_rec, pre_order, pre_B, ph);
 #else
-        if (q < (sweeper ? n_pairs : a.B)) step_task<E, FULL, PAIR, CLAIM>(kv, sweeper, q, n_pairs, lane);
+        if (q < (sweeper ? n_pairs : pre_B)) step_task<E, FULL, PAIR, CLAIM>(kv, sweeper, q, n_pairs, lane, pre_rec, pre_order, pre_B);
 #endif
     }
 #if FR_STEP_TRACE
@@ -1970,17 +1984,20 @@ static int focf_step_impl(const fr_table* U, const fr_table* I, const fr_adam* a
                                            (sweep_waves + STEP_WPB - 1) / STEP_WPB + inter_blocks);
         a.lead = (int)(inter_blocks * lead_pct / 100);
         const dim3 block(64 * STEP_WPB);
+        const int n_stage = st.nb_claim + st.nb_sa + st.nb_place + st.nb_sb;
+#define STEP_PRE a.task_rec, a.sw_order, a.B, a.lead, a.n_u, a.n_i, n_stage, 0
         if (staged) {
             if (U->dim % 64 == 0) {
-                FR_DISPATCH_E(U->dim, FR_LAUNCH(prof, (focf_step_kernel<E, true, true>), dim3(blocks), block, 0, stream, a, st));
+                FR_DISPATCH_E(U->dim, FR_LAUNCH(prof, (focf_step_kernel<E, true, true>), dim3(blocks), block, 0, stream, STEP_PRE, a, st));
             } else {
-                FR_DISPATCH_E(U->dim, FR_LAUNCH(prof, (focf_step_kernel<E, false, true>), dim3(blocks), block, 0, stream, a, st));
+                FR_DISPATCH_E(U->dim, FR_LAUNCH(prof, (focf_step_kernel<E, false, true>), dim3(blocks), block, 0, stream, STEP_PRE, a, st));
             }
         } else if (U->dim % 64 == 0) {
-            FR_DISPATCH_E(U->dim, FR_LAUNCH(prof, (focf_step_kernel<E, true, false>), dim3(blocks), block, 0, stream, a, st));
+            FR_DISPATCH_E(U->dim, FR_LAUNCH(prof, (focf_step_kernel<E, true, false>), dim3(blocks), block, 0, stream, STEP_PRE, a, st));
         } else {
-            FR_DISPATCH_E(U->dim, FR_LAUNCH(prof, (focf_step_kernel<E, false, false>), dim3(blocks), block, 0, stream, a, st));
+            FR_DISPATCH_E(U->dim, FR_LAUNCH(prof, (focf_step_kernel<E, false, false>), dim3(blocks), block, 0, stream, STEP_PRE, a, st));
         }
+#undef STEP_PRE
     }
     FR_CHECK_LAUNCH();
     return FR_OK;
