@@ -248,7 +248,11 @@ def test_fairgo_trainer_pretrain_then_finetune(tmp_path):
     assert c["version"] != model._filters_version()          # stale now: the next call recomputes
     with torch.no_grad():
         moved = model.calculate_dis_loss(b, ["gender"])
-    assert not torch.equal(moved, plain)
+        # (the loss itself sits at 2 ln 2 for an untrained discriminator and may round to the same float: the recomputed
+        # filtered table is what must have moved with the filters, and the loss must be the one of THAT table)
+        E_now = model._filtered_table(["gender"])
+        assert not torch.equal(E_now, c["E"])
+        assert torch.equal(moved, model._dis_terms(E_now, b, ["gender"]))
     # resume of the finetune checkpoint (trainer.py:807-834): optimizer_filter / optimizer_dis come back
     ck = torch.load(trainer.saved_model_file, weights_only=False)
     cfg2 = Config(model="FairGo_PMF", dataset="synth", config_dict=dict(
