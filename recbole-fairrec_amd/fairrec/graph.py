@@ -20,6 +20,8 @@ from __future__ import annotations
 
 from typing import Callable, Dict, Optional, Tuple
 
+import os
+
 import torch
 
 from .data.interaction import Interaction
@@ -99,8 +101,10 @@ class GraphedStep:
                 with torch.cuda.graph(g, capture_error_mode="thread_local"):
                     self.loss = self._eager(static_inter, args)
             except RuntimeError as e:      # an operation that refuses capture: this step object stays eager from here on
+                import traceback
                 import warnings
-                warnings.warn(f"hipGraph capture of the training step failed ({e}); running it eagerly")
+                where = "".join(traceback.format_tb(e.__traceback__)[-4:]) if os.environ.get("FAIRREC_GRAPH_DEBUG") else ""
+                warnings.warn(f"hipGraph capture of the training step failed ({e}); running it eagerly\n{where}")
                 torch.cuda.synchronize()
                 self.engine.sync_steps()
                 self.eager_left = 1 << 60
