@@ -283,6 +283,49 @@ def test_in_launch_prepare_with_tiny_and_ragged_batches(B):
     torch.testing.assert_close(engs[1].loss_acc[:3], engs[0].loss_acc[:3], rtol=1e-5, atol=1e-7)
 
 
+@pytest.mark.parametrize("item_dist", ["uniform", "zipf"])
+def test_in_launch_prepare_at_the_baseline_size_over_a_sweep_period(item_dist):
+    """BASELINE.json configs[1] at its real size, more steps than one sweep period (every row is replayed and swept at least
+    once, every generation of row words is reused many times): the engine with the in-launch prepare and the one with the
+    sorted prepare must report the SAME running squared error to the bit (every prediction of every step equal to fp32
+    rounding of the same sums) and hold the same tables up to the rounding of a replay run in one stretch or in two."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+    import bench
+    from fairrec.model.fair_recommender.focf import FocfEngine
+    from fairrec.optim import FusedLazyAdam
+    dev = torch.device("cuda")
+    T = 150
+    u, i, r, s = (t.to(dev) for t in bench.synth_batches(T, bench.BATCH, bench.N_USERS, bench.N_ITEMS, 7, item_dist))
+    engs = []
+    for staged in (False, True):
+        U, I = bench.xavier_tables(bench.N_USERS, bench.N_ITEMS, bench.DIM, 3, dev)
+        eng = FocfEngine(U, I, bench.OBJECTIVE, bench.FAIR_WEIGHT, 5.0)
+        FusedLazyAdam(eng, lr=bench.LR, weight_decay=bench.WD)
+        eng.defer_loss = True
+        eng.staged = staged
+        engs.append(eng)
+    rows = [(u[k], i[k], s[k], r[k]) for k in range(T)]
+    for k in range(T):
+        for eng in engs:
+            eng.forward(u[k], i[k], r[k], s[k], next_batch=rows[k + 1:k + 21] or None)
+            eng.backward_adam()
+    for eng in engs:
+        eng.finish()
+        eng.flush()
+        eng.check_device_errors()
+    a, b = engs
+    assert torch.equal(a.loss_acc[1], b.loss_acc[1]), (a.loss_acc.tolist(), b.loss_acc.tolist())       # sum of the steps' MSE
+    torch.testing.assert_close(b.loss_acc[:3], a.loss_acc[:3], rtol=1e-5, atol=1e-6)
+    for tab in ("U", "I"):
+        for name in ("weight", "m", "v"):
+            x, y = getattr(getattr(a, tab), name), getattr(getattr(b, tab), name)
+            # (rows no batch touches wobble around zero by Adam steps of ~1e-7; a different split of their replay moves them by
+            # a fraction of one such step)
+            tol = 2e-3 * bench.LR if name == "weight" else 1e-3 * float(x.abs().max())
+            assert float((x - y).abs().max()) <= tol, (tab, name, float((x - y).abs().max()), tol)
+
+
 def test_full_size_steps_match_the_oracle():
     """BASELINE.json configs[1] at its real size (1 000 001 users x 100 001 items, D = 64, B = 8192, Adam lr 1e-3 wd 1e-3,
     fair_objective value): a few optimizer steps of the HIP path -- look-ahead sorts, sweeper, lazy replay -- against the
