@@ -1421,8 +1421,8 @@ __device__ int g_trace_step = -1;      // >= 0: only the launch that applies thi
 #endif
 
 #ifndef FR_STEP_WAVES
-#define FR_STEP_WAVES 6      // waves per SIMD the register budget is cut for
-#endif
+#define FR_STEP_WAVES 6      // waves per SIMD the register budget is cut for (end of round 3, us per step: 5 -> 29.8, 6 -> 29.5,
+#endif                       //   7 -> 30.1 (72 VGPRs, 12 bytes of scratch), 8 -> 32.5 (64 VGPRs, 60 bytes of scratch))
 // The leading scalar arguments are the ones a wave needs before it can issue its first load -- its role and task from the
 // grid shape, the task list, the sweeper order -- and are PRELOADED into SGPRs by the dispatcher (the file is compiled with
 // -amdgpu-kernarg-preload-count, Makefile): the first records are requested in the wave's first cycles, beside the vector
