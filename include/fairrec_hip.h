@@ -300,6 +300,15 @@ FR_API size_t fr_table_train_workspace_bytes(int64_t M, int32_t dim);
  * on workspace `ws`.  fr_table_apply_grad, fr_focf_shard_fair and fr_nfcf_loss do this themselves; a caller that reads the
  * segments of a workspace on its own (copying them for fr_table_gather_train_prepared) calls this first. */
 FR_API int fr_table_join(const void* ws, void* stream);
+
+/*
+ * The stream fr_table_gather_train runs its id sort on, beside the caller's stream (NULL when it sorts in line: profiler on,
+ * FAIRREC_NO_OVERLAP=1).  The sort reads the id list and writes the workspace until the consumer of the segments
+ * (fr_table_apply_grad, fr_table_join) has ordered the caller's stream behind it; a caller whose allocator recycles memory in
+ * stream order must tell it that both buffers are in use on this stream as well (torch: Tensor.record_stream), or a buffer
+ * freed after a forward pass that no backward pass followed can be handed out again while the sort still writes to it.
+ */
+FR_API void* fr_side_stream_handle(void);
 /* The first fr_table_segments_bytes(M) bytes of a workspace hold the sorted segments of the id list (independent of the
  * table's width).  fr_table_gather_train_prepared skips the sort: the caller has put the segments of `idx` there, e.g. by
  * copying them from the workspace of another table with the same number of rows looked up with the same ids in this step

@@ -145,6 +145,13 @@ int side_join(const void* ws, hipStream_t stream) {
 
 using namespace fr;
 
+// the stream the library's own look-ahead work runs on (NULL: none) -- for callers whose allocator must know every stream
+// a buffer is used on before it hands the buffer's memory to somebody else
+extern "C" void* fr_side_stream_handle(void) {
+    SideStream* ss = side_stream();
+    return ss ? (void*)ss->stream : nullptr;
+}
+
 extern "C" int fr_version(void) { return 1; }
 extern "C" const char* fr_last_error(void) { return g_err; }
 

@@ -69,6 +69,7 @@ _PROTOS = {
                              c_void_p, c_void_p, c_void_p, c_void_p]),
     "fr_focf_step_finish": (c_int, [c_void_p, c_size_t, c_int64, c_int32, c_int32, c_float, c_void_p, c_void_p,
                                     c_void_p]),
+    "fr_side_stream_handle": (c_void_p, []),
     "fr_focf_row_words": (c_size_t, [c_int64, c_int64]),
     "fr_focf_stage": (c_int, [POINTER(FrTable), POINTER(FrTable), POINTER(FrFocfBatch), c_int32, c_int32,
                               POINTER(FrFocfBatch), c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
@@ -241,6 +242,21 @@ def check(rc: int, what: str):
 def ptr(t) -> int:
     """Device pointer of a torch tensor (0 for None)."""
     return 0 if t is None else t.data_ptr()
+
+
+_SIDE = {}
+
+
+def side_stream(device):
+    """The library's own side stream as a torch stream (None when it has none), for Tensor.record_stream: the id sort of
+    fr_table_gather_train reads the id list and writes the table's workspace there, and torch's allocator recycles memory
+    in the order of the streams IT knows a tensor was used on."""
+    import torch
+    key = (device.type, device.index)
+    if key not in _SIDE:
+        h = lib().fr_side_stream_handle() if device.type == "cuda" else None
+        _SIDE[key] = torch.cuda.ExternalStream(h, device=device) if h else None
+    return _SIDE[key]
 
 
 def current_stream() -> int:

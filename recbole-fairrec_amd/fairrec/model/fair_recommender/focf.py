@@ -159,6 +159,12 @@ class FocfEngine:
             busy.add(k)
             B = user.numel()
             ws = self._workspace(B, k)
+            if not torch.cuda.is_current_stream_capturing():
+                # (the allocator recycles memory in the order of the streams it knows a tensor was used on: these are read
+                # and written on the side stream, and an engine may go out of scope with such work still queued)
+                for tns in (ws, user, item, sst, bt[3] if len(bt) >= 4 else None):
+                    if tns is not None:
+                        tns.record_stream(self._side)
             arr[q] = _C.FrFocfBatch(user.data_ptr(), item.data_ptr(), _C.ptr(sst if self.objective != 0 else None), B,
                                     ws.data_ptr(), ws.numel(), _C.ptr(bt[3]) if full else None)
             stamps[q] = self._next_stamp(q + ahead) if full else 0

@@ -40,6 +40,19 @@ def adam_step_scalars(lr: float, beta1: float, beta2: float, cap: int, weight_de
     return out
 
 
+def _used_on_side_stream(t: torch.Tensor):
+    """fr_table_gather_train sorts the id list on the library's OWN stream, beside the gather: the sort reads `idx` and writes
+    the table's workspace until fr_table_apply_grad (or fr_table_join) orders the caller's stream behind it.  torch's
+    allocator recycles a freed tensor's memory in the order of the streams it knows the tensor was used on, so it is told:
+    without this, a forward pass that no backward pass follows (a loss computed and dropped, a table that goes out of
+    scope) can leave a sort writing into memory the allocator has already handed to somebody else."""
+    if t is None or not t.is_cuda or torch.cuda.is_current_stream_capturing():
+        return          # (inside a capture the library sorts in line)
+    side = _C.side_stream(t.device)
+    if side is not None:
+        t.record_stream(side)
+
+
 class AdamHyper:
     """lr / weight_decay / betas / eps + the device table of per-step scalars (fr_adam in the C ABI)."""
 
@@ -162,6 +175,7 @@ class LazyTable:
         self.gather_train_into(hyper, idx.data_ptr(), M, rows.data_ptr(), err_flag=err_flag, segments_of=segments_of)
         self._pending = (M, rows)
         self._keep = idx
+        _used_on_side_stream(idx)
         return rows
 
     def gather_train_into(self, hyper: AdamHyper, idx_ptr: int, M: int, rows_ptr: int, chunk: int = 0, stride: int = 0,
@@ -186,6 +200,7 @@ class LazyTable:
             _C.check(_C.lib().fr_table_gather_train(ctypes.byref(t), ctypes.byref(hyper.c()), idx_ptr, M, chunk, stride,
                                                     rows_ptr, self._ws.data_ptr(), self._ws.numel(), _C.ptr(err_flag),
                                                     _C.current_stream()), "fr_table_gather_train")
+            _used_on_side_stream(self._ws)
         self._pending = (M, None)
         self._grad_rows = None
 
@@ -238,6 +253,9 @@ class LazyTable:
                 t._ws = torch.empty(need, dtype=torch.uint8, device=t.weight.device)
         hyper.check_step(ta.step + 1)
         ca, cb = ta.c(ta.step + 1), tb.c(tb.step + 1)
+        if not prepared:
+            _used_on_side_stream(ta._ws)
+            _used_on_side_stream(tb._ws)
         _C.check(_C.lib().fr_table_gather_train2(ctypes.byref(ca), ctypes.byref(cb), ctypes.byref(hyper.c()), idx_a, idx_b,
                                                  M, chunk, stride, rows_a, rows_b, 1 if prepared else 0,
                                                  ta._ws.data_ptr(), tb._ws.data_ptr(),

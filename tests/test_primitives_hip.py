@@ -143,3 +143,33 @@ def test_generic_table_ops_match_reference_golden(case):
                 assert (np.abs(a - b) <= 1e-4 * np.abs(b) + 1e-6).all(), (tag, t + 1, np.abs(a - b).max())
     np.testing.assert_allclose(losses, z["loss"], rtol=1e-4)
     assert int(err.item()) == 0
+
+
+def test_workspace_of_a_dropped_table_is_not_recycled_under_its_sort():
+    """fr_table_gather_train sorts the id list on the library's own stream.  A forward pass that nothing follows (no
+    apply_grad, no join) and whose table then goes out of scope leaves that sort queued behind the caller's stream; torch's
+    allocator must not hand the workspace's (or the id list's) memory to the next tensor before the sort has run
+    (LazyTable tells it with Tensor.record_stream on fr_side_stream_handle()).  Without that, half of these trials find
+    their freshly filled tensor overwritten -- which is how a test file could corrupt the parameters of the NEXT test's
+    model (the round-3 flake of tests/test_fairgo_hip.py)."""
+    from fairrec.optim import AdamHyper, LazyTable
+    from fairrec import _C as C
+    dev = torch.device("cuda")
+    if C.side_stream(dev) is None:
+        pytest.skip("the library sorts in line (FAIRREC_NO_OVERLAP=1)")
+    for trial in range(12):
+        t = LazyTable(torch.randn(5000, 64, device=dev))
+        t.ensure_state()
+        hyper = AdamHyper(device=dev, cap=8)
+        idx = torch.randint(0, 5000, (4096,), device=dev)
+        a = torch.randn(6144, 6144, device=dev)
+        torch.cuda.synchronize()
+        for _ in range(6):
+            a = a @ a * 1e-4          # tens of ms of queued work: the sort's fork point lies behind it
+        rows = t.gather_train(hyper, idx)
+        n = t._ws.numel()
+        del rows, t, idx
+        x = torch.full((n,), 7, dtype=torch.uint8, device=dev)       # the allocator's first candidate: the freed workspace
+        y = torch.full((4096,), 3, dtype=torch.int64, device=dev)    # ... and the freed id list
+        torch.cuda.synchronize()
+        assert bool((x == 7).all()) and bool((y == 3).all()), "trial %d: memory recycled under the side-stream sort" % trial
