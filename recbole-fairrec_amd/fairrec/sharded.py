@@ -100,6 +100,28 @@ class HipOps:
     def join_side(self):
         torch.cuda.current_stream().wait_stream(self._side)
 
+    def used_on_side(self, *things):
+        """Tell torch's allocator that these tensors (or every tensor held by these objects) are used on the side stream as
+        well: it recycles a freed tensor's memory in the order of the streams it knows the tensor was used on, and an engine
+        may be dropped with look-ahead work still queued."""
+        if not hasattr(self, "_side"):
+            self._side = torch.cuda.Stream(device=self.device)
+        if torch.cuda.is_current_stream_capturing():
+            return
+
+        def walk(x, depth=0):
+            if isinstance(x, torch.Tensor):
+                if x.is_cuda:
+                    x.record_stream(self._side)
+            elif isinstance(x, (list, tuple)) and depth < 3:
+                for y in x:
+                    walk(y, depth + 1)
+            elif hasattr(x, "__dict__") and depth < 1:
+                for y in vars(x).values():
+                    walk(y, depth + 1)
+        for t in things:
+            walk(t)
+
     def alloc_ws(self, table, M):
         return torch.empty(_C.lib().fr_table_train_workspace_bytes(M, table.dim), dtype=torch.uint8, device=self.device)
 
@@ -277,6 +299,7 @@ class ShardedFocfEngine:
     def _buffers(self, B: int) -> _Buffers:
         if self._buf is None or self._buf.B != B:
             self._buf = _Buffers(self.G, B, self.capacity(B), self.U.dim, self.device, self.ops, self.U, self.I)
+            self.ops.used_on_side(self._buf)
             self._prep_key = None
         return self._buf
 
@@ -321,6 +344,7 @@ class ShardedFocfEngine:
         self._prep_key = None
         ahead = next_batch is not None and next_batch[0].numel() == B
         if ahead:   # the next step's bucket kernel starts now, beside this step's gather
+            ops.used_on_side(next_batch)
             with ops.side():
                 self._prepare_bucket(b, sel ^ 1, next_batch[0], next_batch[1], next_batch[2])
             self._prep_key = self._key(next_batch[0], next_batch[1])
@@ -461,6 +485,7 @@ class ShardedFocfEngineV2(ShardedFocfEngine):
     def _buffers(self, B):
         if self._buf is None or self._buf.B != B:
             self._buf = self._Buf(self.G, B, self.capacity(B), self.U.dim, self.device, self.ops, self.U, self.I)
+            self.ops.used_on_side(self._buf)
             self._prep_key = None
         return self._buf
 
@@ -507,6 +532,7 @@ class ShardedFocfEngineV2(ShardedFocfEngine):
         self._prep_key = None
         ahead = next_batch is not None and len(next_batch) >= 4 and next_batch[0].numel() == B
         if ahead:
+            ops.used_on_side(next_batch)
             with ops.side():
                 self._index_a(b, sel ^ 1, next_batch[0], next_batch[1], next_batch[3], next_batch[2])
             self._prep_key = self._key(next_batch[0], next_batch[1])
