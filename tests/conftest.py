@@ -33,4 +33,8 @@ def rccl_world1():
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     yield
     if dist.is_initialized():
+        if os.environ.get("FAIRREC_TEST_PG_SYNC", "1") == "1":
+            torch.cuda.synchronize()        # nothing of this test is in flight when the communicator goes away
         dist.destroy_process_group()
+        if os.environ.get("FAIRREC_TEST_PG_SYNC", "1") == "1":
+            torch.cuda.synchronize()
