@@ -232,7 +232,9 @@ __global__ __launch_bounds__(256) void nfcf_df_pack_kernel(const float* __restri
         const int sl = slot[b];
         const bool pos = label[b] == 1.f;
         const float s = sst[b];
-        rec[(long long)(sl / S) * (cap + 1) + (sl % S - off)] = make_float2(pos ? out[b] : -1.f, s);
+        // sl < 0: fr_bucket_by_owner found the owner's bucket full (device error bit FR_DEV_ERR_BUCKET_OVERFLOW is set and the
+        // step is void): no slot to write to -- the row is skipped like in fr_bucket_rows / fr_shard_pack_records
+        if (sl >= 0) rec[(long long)(sl / S) * (cap + 1) + (sl % S - off)] = make_float2(pos ? out[b] : -1.f, s);
         if (pos) lo = hi = s;
     }
 #pragma unroll
@@ -365,7 +367,8 @@ __global__ __launch_bounds__(256) void nfcf_df_apply_kernel(const float4* __rest
     float eps_mine = 0.f;
     if (b < B && label[b] == 1.f && Kf > 0.f && smin != smax) {
         const int sl = slot[b];
-        const float4 st = reply[(long long)(sl / S) * (cap + 1) + (sl % S - off)];
+        // (sl < 0: the row found no slot in its owner's bucket -- no reply to read; the overflow error bit voids the step)
+        const float4 st = sl >= 0 ? reply[(long long)(sl / S) * (cap + 1) + (sl % S - off)] : make_float4(0.f, 0.f, 0.f, 0.f);
         const bool rep = (__float_as_uint(st.x) & 0x80000000u) != 0u;
         const float S0 = fabsf(st.x);
         const float alpha = 1.f / Kf;                  // dirichlet_alpha, nfcf.py:85-86

@@ -103,6 +103,15 @@ class GraphedStep:
             except RuntimeError as e:      # an operation that refuses capture: this step object stays eager from here on
                 import traceback
                 import warnings
+                msg = str(e).lower()
+                # only what the runtime says about the CAPTURE itself is survivable; an argument error of the library, a
+                # device error word or an out-of-memory inside the step is a bug or a limit of its own and stays loud
+                if not any(w in msg for w in ("captur", "hiperrorstream", "cudaerrorstream")):
+                    raise
+                # the failed capture pass ran the host side of a step without the device doing it: drop what it parked
+                self.optimizer.zero_grad()
+                for t in getattr(self.engine, "_tables", {}).values():
+                    t._pending = None
                 where = "".join(traceback.format_tb(e.__traceback__)[-4:]) if os.environ.get("FAIRREC_GRAPH_DEBUG") else ""
                 warnings.warn(f"hipGraph capture of the training step failed ({e}); running it eagerly\n{where}")
                 torch.cuda.synchronize()

@@ -383,7 +383,10 @@ class FusedLazyAdam:
             if missing:
                 raise KeyError(f"state_dict(param_names=...): no index for {missing}")
             state = {idx[n]: st for n, st in state.items()}
-            groups = dict(self.defaults, params=sorted(state.keys()), amsgrad=False, maximize=False, foreach=None,
+            # torch lists EVERY parameter the optimizer was built on, in order, and keeps state only for those that were
+            # stepped (a frozen table -- NFCF's user table after reset_params, FairGo's tables in the finetune stage -- has
+            # an index and no state); load_state_dict maps saved ids to parameters by POSITION and checks the group length
+            groups = dict(self.defaults, params=list(range(len(param_names))), amsgrad=False, maximize=False, foreach=None,
                           capturable=False, differentiable=False, fused=None)
             return {"state": state, "param_groups": [groups]}
         return {"state": state, "param_groups": [dict(self.defaults, params=list(state.keys()))]}

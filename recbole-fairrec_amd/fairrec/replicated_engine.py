@@ -123,6 +123,9 @@ class ReplicatedGenericEngine(GenericEngine):
             return
         live, views = self._synced
         self._synced = None
+        for name, d in self._dense.items():          # an other group's gradient that the clip averaged and scaled: its
+            if name in views and (name, d) not in live and d.p.grad is not None:     # .grad holds that result, as torch's would
+                d.p.grad.copy_(views[name].view_as(d.p.grad))
         for name, d in live:
             d.step += 1
             h = self._hyper(name)
@@ -130,22 +133,27 @@ class ReplicatedGenericEngine(GenericEngine):
             self.ops.adam_dense(d.p.data, views[name], d.m, d.v, h, d.step)
             d.p.grad = None
 
-    def _sync_dense(self, group=None):
+    def _sync_dense(self, group=None, measured=False):
         """One flat all-reduce (mean over the replicas) of the dense gradients the stepping group owns (SURVEY.md §8-e
-        item 5); kept until backward_adam consumes it."""
+        item 5); kept until backward_adam consumes it.  `measured` (clip_grad_norm): the gradients of the OTHER groups'
+        model parameters ride along -- they enter the global norm, so every replica must see their average too or each rank
+        would clip by its own coefficient and the replicas would drift apart."""
         live = [(name, d) for name, d in self._dense.items() if d.p.grad is not None and self._owned(name, group)]
-        if not live:
+        extra = [(name, d) for name, d in self._dense.items()
+                 if measured and d.p.grad is not None and not self._owned(name, group)
+                 and not name.startswith(self.NOT_MODEL_PARAMETERS)]
+        if not live and not extra:
             self._synced = None
             return
-        n = sum(d.p.numel() for _, d in live)
+        n = sum(d.p.numel() for _, d in live + extra)
         if self._flat is None or self._flat.numel() < n:
             self._flat = torch.empty(n, dtype=torch.float32, device=self.device)
         flat = self._flat[:n]
-        torch.cat([d.p.grad.reshape(-1) for _, d in live], out=flat)
+        torch.cat([d.p.grad.reshape(-1) for _, d in live + extra], out=flat)
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.pg)
         flat.mul_(1.0 / self.G)
         views, off = {}, 0
-        for name, d in live:
+        for name, d in live + extra:
             k = d.p.numel()
             views[name] = flat[off:off + k]
             off += k
@@ -157,7 +165,7 @@ class ReplicatedGenericEngine(GenericEngine):
         summed per global id before squaring; a dense parameter's is measured AFTER the flat all-reduce (done here instead
         of in backward_adam, which then finds it averaged) -- clipping each replica's local gradient first would give every
         rank its own coefficient and the step would not be the single-device clip of the averaged gradient."""
-        self._sync_dense(group)
+        self._sync_dense(group, measured=True)
         sq = torch.zeros((), dtype=torch.float32, device=self.device)
         held = []
         for name, t in self._tables.items():
@@ -174,7 +182,7 @@ class ReplicatedGenericEngine(GenericEngine):
         for name, d in self._dense.items():
             if name.startswith(self.NOT_MODEL_PARAMETERS) or d.p.grad is None:
                 continue
-            gview = synced.get(name, d.p.grad)          # averaged over the replicas when this step's group owns it
+            gview = synced[name]                        # averaged over the replicas (own group's and measured others')
             sq = sq + (gview * gview).sum()
             dense.append(gview)
         if not held and not dense:

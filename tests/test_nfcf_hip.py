@@ -107,6 +107,47 @@ def _run_case(z, sharded=False, exact=None):
     np.testing.assert_allclose(pr, z["predict_last"], rtol=1e-4, atol=1e-6)
 
 
+def test_optimizer_state_of_a_model_with_a_frozen_table_loads_into_stock_adam():
+    """f-4: NFCF finetune freezes the user table (nfcf.py:62-63); the reference builds its Adam on ALL of model.parameters()
+    (trainer.py:139) and torch maps saved state to parameters by POSITION, checking the group length -- so the state written
+    for a reference `optimizer.load_state_dict` must list every parameter's index and keep state only for the stepped ones."""
+    from fairrec.config import Config
+    from fairrec.data.interaction import Interaction
+    from fairrec.model.fair_recommender.nfcf import NFCF
+    from fairrec.optim import FusedLazyAdam
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "nfcf_finetune.npz"))
+    lr, wd, fw, p = (float(x) for x in z["hyper"])
+    n_users, D = z["init.user_embedding.weight"].shape
+    n_items = z["init.item_embedding.weight"].shape[0]
+    cfg = Config(model="NFCF", config_dict={"embedding_size": D, "mlp_hidden_size": [int(h) for h in z["hidden"]], "dropout": 0.0,
+                                            "fair_weight": fw, "device": "cuda", "load_pretrain_path": None})
+    model = NFCF(cfg, _DS(n_users, n_items, z["gender"]))
+    model.load_pretrain_path = "reference-checkpoint"
+    model.user_embedding.weight.requires_grad = False
+    model.load_state_dict({k[5:]: torch.tensor(z[k]) for k in z.files if k.startswith("init.")})
+    model = model.to("cuda").train()
+    opt = FusedLazyAdam(model.hip_engine(), lr=lr, weight_decay=wd, sweep_period=3)
+    for t in range(2):
+        inter = Interaction({"user_id": torch.tensor(z["user_id"][t]), "item_id": torch.tensor(z["item_id"][t]),
+                             "label": torch.tensor(z["label"][t]), "gender": torch.tensor(z["sst"][t])}).to("cuda")
+        opt.zero_grad()
+        model.calculate_loss(inter).backward()
+        opt.step()
+    names = [n for n, _ in model.named_parameters()]
+    sd = opt.state_dict(param_names=names)
+    frozen = names.index("user_embedding.weight")
+    assert sd["param_groups"][0]["params"] == list(range(len(names)))
+    assert frozen not in sd["state"] and sorted(sd["state"]) == [k for k in range(len(names)) if k != frozen]
+    ref_params = [torch.nn.Parameter(q.detach().cpu().clone(), requires_grad=q.requires_grad) for _, q in model.named_parameters()]
+    ref_opt = torch.optim.Adam(ref_params, lr=lr, weight_decay=wd)
+    ref_opt.load_state_dict({"state": {k: {n: (v.cpu() if torch.is_tensor(v) else v) for n, v in st.items()}
+                                       for k, st in sd["state"].items()}, "param_groups": sd["param_groups"]})
+    item = names.index("item_embedding.weight")
+    eng = model.hip_engine()
+    assert torch.equal(ref_opt.state[ref_params[item]]["exp_avg"], eng._tables["item_embedding.weight"].m.cpu())
+    assert float(ref_opt.state[ref_params[item]]["step"]) == 2.0 and ref_params[frozen] not in ref_opt.state
+
+
 def test_nfcf_full_batch_at_the_baseline_width():
     """BASELINE.json configs[4]'s step shape -- embedding_size 256, mlp_hidden_size [128, 64], B = 8192, finetune (user table
     frozen, differential-fairness term) and pretrain -- on tables scaled down to what the CPU oracle's dense Adam sweeps in
@@ -278,3 +319,54 @@ def test_global_df_kernels_match_their_cpu_doubles():
         np.testing.assert_allclose(dy_g.cpu().numpy(), dy_c.numpy(), rtol=2e-5, atol=1e-9)
         np.testing.assert_allclose(l_g.cpu().numpy(), l_c.numpy(), rtol=2e-5)
     assert int(ws.view(torch.int32)[-64:].abs().sum().item()) == 0             # tickets back at zero
+
+
+def test_global_df_kernels_skip_rows_that_found_no_slot():
+    """fr_bucket_by_owner writes slot -1 for a row whose owner's bucket is full (skewed item ids; the overflow error bit voids
+    the step at the epoch's check).  Until then nothing may be written or read through such a slot: fr_nfcf_df_pack used to
+    store its record 8 bytes in front of the exchange buffer and fr_nfcf_df_apply to read its reply from there."""
+    from fairrec.sharded_engine import HipTableOps
+    hip = HipTableOps()
+    g = torch.Generator().manual_seed(5)
+    G, B = 4, 300
+    cap, S, off = 64, 128, 64
+    slot = torch.full((B,), -1, dtype=torch.int32)
+    cnt = [0] * G
+    for b in range(B):                         # every owner's bucket overflows: B / G = 75 rows for cap = 64 slots
+        o = b % G
+        if cnt[o] < cap:
+            slot[b] = o * S + off + cnt[o]
+            cnt[o] += 1
+    assert int((slot < 0).sum()) == B - G * cap
+    out = torch.rand(B, generator=g) * 0.98 + 0.01
+    label = torch.ones(B)
+    sst = (torch.rand(B, generator=g) < 0.5).float()
+    n = G * (cap + 1)
+    guard = 64
+    buf = torch.full((guard + n * 2 + guard,), 7.25, device="cuda")             # guard bands around the record buffer
+    rec = buf[guard:guard + n * 2]
+    rec.zero_()
+    ws = hip.df_workspace(B, G * cap, "cuda")
+    hip.df_pack(out.cuda(), label.cuda(), sst.cuda(), slot.cuda(), S, off, cap, G, rec, ws)
+    torch.cuda.synchronize()
+    assert bool((buf[:guard] == 7.25).all()) and bool((buf[-guard:] == 7.25).all())
+    r = rec.cpu().view(G, cap + 1, 2)
+    ok = slot >= 0
+    want = torch.zeros(G, cap, 2)
+    want[(slot[ok] // S).long(), (slot[ok] % S - off).long()] = torch.stack([out[ok], sst[ok]], dim=1)
+    assert torch.equal(r[:, :cap], want)
+    # apply: rows without a slot take no fairness gradient (and read nothing)
+    reply = torch.zeros(G, cap + 1, 4)
+    reply[:, :cap, :2] = torch.rand(G, cap, 2, generator=g) * 3
+    reply[:, :cap, 2:] = torch.randint(1, 5, (G, cap, 2), generator=g).float()
+    reply[:, cap] = torch.tensor([5.0, 0.0, 1.0, 0.0])
+    rbuf = torch.full((guard * 4 + n * 4 + guard * 4,), float("nan"), device="cuda")
+    rbuf[guard * 4:guard * 4 + n * 4] = reply.view(-1).cuda()
+    dy0 = torch.randn(B, generator=g) * 1e-3
+    dy = dy0.clone().cuda()
+    loss = torch.tensor([0.7, 0.7, 0.0], device="cuda")
+    hip.df_apply(rbuf[guard * 4:guard * 4 + n * 4], slot.cuda(), S, off, cap, G, out.cuda(), label.cuda(), sst.cuda(), 0.1, float(G), dy,
+                 loss, ws)
+    d = dy.cpu()
+    assert bool(torch.isfinite(d).all()) and bool(torch.isfinite(loss).all())
+    assert torch.equal(d[~ok], dy0[~ok]) and not torch.equal(d[ok], dy0[ok])
