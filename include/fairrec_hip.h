@@ -557,6 +557,14 @@ FR_API int fr_softmax_ce(const float* logits, const int64_t* label, int64_t M, i
  * fr_mse             : nn.MSELoss (fairgo_pmf.py:182): loss[0], dpred = 2 (pred - target) / B */
 FR_API int fr_spmm_csr(const int64_t* indptr, const int32_t* col, const float* val, const float* X, int64_t n_rows,
                        int32_t dim, float* Y, void* stream);
+/* fr_spmm_csr_sel : the same product where the batch can see it (the frontier-restricted propagation of
+ *                   fairgo_pmf.py:196-200, :204-216): Y[i,:] = sum_j val[j] * X[xrow(col[j]),:] over the nonzeros of row
+ *                   rows[i] (rows == NULL: row i) in ascending j, xrow(c) = map ? map[c] : c, nonzeros with map[c] < 0
+ *                   skipped.  `rows` (int32 [n_out]) makes Y compact; `map` (int32 [number of columns]) lets X be a compact
+ *                   block of a whole-table operand or, on the CSR of L^T, names the columns that carry a gradient row.
+ *                   Kept terms are added in fr_spmm_csr's order: the rows equal the whole-table product's. */
+FR_API int fr_spmm_csr_sel(const int64_t* indptr, const int32_t* col, const float* val, const float* X, const int32_t* rows,
+                           int64_t n_out, const int32_t* map, int32_t dim, float* Y, void* stream);
 FR_API int fr_row_gather(const float* X, const int64_t* idx, int64_t M, int64_t n_rows, int32_t dim, float* out,
                          uint32_t* err_flag, void* stream);
 FR_API size_t fr_row_scatter_workspace_bytes(int64_t M);

@@ -3,6 +3,10 @@
 //
 // Replaces fairgo_pmf.py:196-200 (torch.sparse.mm(L, E), L = D^-1 A of get_norm_rating_matrix :102-129), the
 // `all_embeddings[user]` indexing (:178-179, :194) with its index_put backward, and nn.MSELoss (:182).
+#include <stdlib.h>
+
+#include <algorithm>
+
 #include "common.hpp"
 #include "kernels.hpp"
 
@@ -50,6 +54,60 @@ __global__ __launch_bounds__(256) void spmm_csr_kernel(const long long* __restri
     }
 }
 
+// Y[i,:] = sum over the nonzeros j of row r = (rows ? rows[i] : i), in ascending j, of val[j] * X[xrow(col[j]),:] with
+// xrow(c) = map ? map[c] : c, nonzeros whose map entry is negative SKIPPED.  The frontier-restricted graph propagation of
+// FairGo (fairgo_pmf.py:196-200 evaluated only where the batch can see it): `rows` selects the output rows (compact Y),
+// `map` lets X be a compact [n_x, D] block of a whole-table operand -- or, in the backward direction on the CSR of L^T, names
+// the columns whose gradient rows exist at all.  Every kept term is added in the order spmm_csr_kernel adds it and a
+// skipped term is one that kernel would add as an exact zero, so the results are those of the whole-table product.
+// The hits of a 64-nonzero chunk are walked through a ballot mask: a row of L^T with 20 nonzeros of which none is mapped
+// costs one (col, map) load pair, no row gather.
+template <int V>
+__global__ __launch_bounds__(256) void spmm_csr_sel_kernel(const long long* __restrict__ indptr, const int* __restrict__ col,
+                                                           const float* __restrict__ val, const float* __restrict__ X,
+                                                           const int* __restrict__ rows, long long n_out,
+                                                           const int* __restrict__ map, int D, float* __restrict__ Y) {
+    const int lane = threadIdx.x & 63;
+    const long long i = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n_out) return;
+    const long long r = rows ? (long long)rows[i] : i;
+    const long long j0 = indptr[r], j1 = indptr[r + 1];
+    if constexpr (V == 0) {
+        for (int d = lane; d < D; d += 64) {
+            float acc = 0.f;
+            for (long long j = j0; j < j1; ++j) {
+                const int c = map ? map[col[j]] : col[j];
+                if (c >= 0) acc = fmaf(val[j], X[(size_t)c * D + d], acc);
+            }
+            Y[(size_t)i * D + d] = acc;
+        }
+    } else {
+        typedef float vec __attribute__((ext_vector_type(V)));
+        vec acc = {};
+        for (long long jb = j0; jb < j1; jb += 64) {
+            const int cnt = (int)min((long long)64, j1 - jb);
+            int my_c = -1;
+            float my_v = 0.f;
+            if (lane < cnt) {
+                my_c = col[jb + lane];
+                if (map) my_c = map[my_c];
+                if (my_c >= 0) my_v = val[jb + lane];
+            }
+            unsigned long long hits = __ballot(my_c >= 0);
+            while (hits) {
+                const int t = __ffsll((long long)hits) - 1;
+                hits &= hits - 1;
+                const int c = __builtin_amdgcn_readlane(my_c, t);
+                const float v = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_v), t));
+                const vec x = *reinterpret_cast<const vec*>(X + (size_t)c * D + lane * V);
+#pragma unroll
+                for (int e = 0; e < V; ++e) acc[e] = fmaf(v, x[e], acc[e]);
+            }
+        }
+        *reinterpret_cast<vec*>(Y + (size_t)i * D + lane * V) = acc;
+    }
+}
+
 // out[j,:] = X[idx[j],:]
 __global__ __launch_bounds__(256) void row_gather_kernel(const float* __restrict__ X, const long long* __restrict__ idx,
                                                          long long M, long long n_rows, int D, float* __restrict__ out,
@@ -81,6 +139,19 @@ __global__ __launch_bounds__(256) void row_scatter_sum_kernel(const float* __res
         for (int j = j0; j < j1; ++j) acc += g[(size_t)perm[j] * D + d];
         dX[row * D + d] = acc;
     }
+}
+
+// p[0 .. n) = 0 as a KERNEL (float4 stores over the 16-byte aligned middle, grid-stride): see fr_row_scatter_sum for why
+// this is not hipMemsetAsync
+__global__ __launch_bounds__(256) void zero_fill_kernel(float* __restrict__ p, size_t n) {
+    const size_t head = min(n, (size_t)((16 - ((uintptr_t)p & 15)) & 15) / 4);     // floats before the first aligned one
+    const size_t n4 = (n - head) / 4;
+    float4* p4 = reinterpret_cast<float4*>(p + head);
+    const size_t stride = (size_t)gridDim.x * 256, t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (size_t i = t; i < n4; i += stride) p4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (t < head) p[t] = 0.f;
+    const size_t done = head + 4 * n4;
+    if (t < n - done) p[done + t] = 0.f;
 }
 
 // nn.MSELoss: partial sums of (pred - target)^2 and d/dpred = 2 (pred - target) / B
@@ -143,6 +214,27 @@ extern "C" int fr_spmm_csr(const int64_t* indptr, const int32_t* col, const floa
     return FR_OK;
 }
 
+extern "C" int fr_spmm_csr_sel(const int64_t* indptr, const int32_t* col, const float* val, const float* X, const int32_t* rows,
+                               int64_t n_out, const int32_t* map, int32_t dim, float* Y, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    FR_CHECK_ARG(indptr && col && val && X && Y && n_out >= 0 && dim >= 1, "fr_spmm_csr_sel: bad argument");
+    if (n_out == 0) return FR_OK;
+    ProfScope prof(K_SPMM, stream);
+    const dim3 grid((unsigned)((n_out + 3) / 4));
+#define FR_SPMM_SEL(V)                                                                                              \
+    FR_LAUNCH(prof, spmm_csr_sel_kernel<V>, grid, dim3(256), 0, stream, (const long long*)indptr, col, val, X, rows, \
+              (long long)n_out, map, (int)dim, Y)
+    switch (dim) {
+        case 64: FR_SPMM_SEL(1); break;
+        case 128: FR_SPMM_SEL(2); break;
+        case 256: FR_SPMM_SEL(4); break;
+        default: FR_SPMM_SEL(0); break;
+    }
+#undef FR_SPMM_SEL
+    FR_CHECK_LAUNCH();
+    return FR_OK;
+}
+
 extern "C" int fr_row_gather(const float* X, const int64_t* idx, int64_t M, int64_t n_rows, int32_t dim, float* out,
                              uint32_t* err_flag, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
@@ -173,7 +265,21 @@ extern "C" int fr_row_scatter_sum(const float* g, const int64_t* idx, int64_t M,
     SortJob job{idx, n_rows, perm, seg_start, seg_row, nullptr, nseg, nullptr, nullptr};
     int rc = launch_sort(job, nullptr, M, err_flag, stream);
     if (rc) return rc;
-    FR_CHECK_HIP(hipMemsetAsync(dX, 0, (size_t)n_rows * dim * sizeof(float), stream));
+    // The zero fill is a kernel, not hipMemsetAsync: inside a stream capture a memset becomes a memset NODE, and on this
+    // runtime (ROCm 7.0 / 7.2) the node of a replayed graph did not reliably clear the captured address -- rows no member of
+    // the batch touches kept what the block's previous tenant had left there, i.e. the gradient of the whole filtered
+    // table carried garbage rows into every filter weight ("the captured-step NaN"; pinned by
+    // tests/test_graph_hip.py::test_captured_pieces_are_idempotent_under_allocator_churn).  FAIRREC_SCATTER_MEMSET=1 restores
+    // the memset for A/B runs.
+    static const bool use_memset = getenv("FAIRREC_SCATTER_MEMSET") != nullptr;
+    const size_t n = (size_t)n_rows * dim;
+    if (use_memset) {
+        FR_CHECK_HIP(hipMemsetAsync(dX, 0, n * sizeof(float), stream));
+    } else {
+        const unsigned blocks = (unsigned)std::min<size_t>(std::max<size_t>((n / 4 + 255) / 256, 1), 4096);
+        hipLaunchKernelGGL(zero_fill_kernel, dim3(blocks), dim3(256), 0, stream, dX, n);
+        FR_CHECK_LAUNCH();
+    }
     ProfScope prof(K_ROW_GATHER, stream);
     FR_LAUNCH(prof, row_scatter_sum_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, stream, g, (const int32_t*)perm,
               (const int32_t*)seg_start, (const int32_t*)seg_row, (const int32_t*)nseg, (int)M, (int)dim, dX);

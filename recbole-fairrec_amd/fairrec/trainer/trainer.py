@@ -56,6 +56,7 @@ class Trainer(AbstractTrainer):
         ensure_dir(self.checkpoint_dir)
         self.saved_model_file = os.path.join(self.checkpoint_dir, '{}-{}.pth'.format(config['model'], get_local_time()))
         self.weight_decay = config['weight_decay'] or 0.0
+        self.saved_sst_embed_file = os.path.join(self.checkpoint_dir, '{}_embed.pth'.format(config['model']))
 
         self.start_epoch = 0
         self.cur_step = 0
@@ -265,7 +266,24 @@ class Trainer(AbstractTrainer):
                     callback_fn(epoch_idx, valid_score)
                 if stop_flag:
                     break
+        # store embedding and sst if the task needs an attacker after training (trainer.py:413-415)
+        if self.config['save_sst_embed'] and os.path.exists(self.saved_model_file):
+            self._save_sst_embed(train_data)
         return self.best_valid_score, self.best_valid_result
+
+    def _reload_for_sst_embed(self):
+        ck = torch.load(self.saved_model_file, weights_only=False)
+        self.model.load_state_dict(ck['state_dict'])
+        self.model.load_other_parameter(ck.get('other_parameter'))
+        self.model.eval()
+
+    def _save_sst_embed(self, data):
+        """trainer.py:242-256: the saved model's user embeddings next to the users' sensitive attributes, for an attacker
+        trained afterwards.  (The reference reloads the checkpoint first; the dict-held filter MLPs are not in it, are never
+        put in eval mode and take one more BatchNorm batch from this pass -- SURVEY.md App. B-3 -- and so they do here.)"""
+        self._reload_for_sst_embed()
+        user_features = data.dataset.get_user_feature()
+        torch.save(self.model.get_sst_embed(user_features[1:]), self.saved_sst_embed_file)
 
     # --- full-sort ranking evaluation on the device (trainer.py:420-438, :458-515) ----------------------------
     def _full_sort_scores(self, interaction, n_items, sst_list=None):
@@ -458,6 +476,20 @@ class PFCNTrainer(Trainer):
                                            param_names=[n for n, _ in self.model.named_parameters()])
         self.logger.info('Checkpoint loaded. Resume training from epoch %d', self.start_epoch)
 
+    def _save_sst_embed(self, data):
+        """trainer.py:1108-1131: one file per attribute subset (the filtered modes), `<model>_embed-<mode>-[a_b].pth`."""
+        import itertools
+        self._reload_for_sst_embed()
+        user_features = data.dataset.get_user_feature()[1:]
+        if self.filter_mode != 'none':
+            for i in range(1, 4):
+                for attr_list in (list(c) for c in itertools.combinations(self.config['sst_attr_list'], i)):
+                    name = '{}_embed-{}-[{}].pth'.format(self.config['model'], self.config['filter_mode'], '_'.join(attr_list))
+                    torch.save(self.model.get_sst_embed(user_features, attr_list), os.path.join(self.checkpoint_dir, name))
+        else:
+            name = '{}_embed-{}.pth'.format(self.config['model'], self.config['filter_mode'])
+            torch.save(self.model.get_sst_embed(user_features), os.path.join(self.checkpoint_dir, name))
+
     def _subsets(self):
         import itertools
         attrs = self.config['sst_attr_list']
@@ -528,6 +560,8 @@ class FairGoTrainer(PFCNTrainer):
         self.optimizer_filter = self._build_optimizer(group='filter')
         self.optimizer_dis = self._build_optimizer(group='dis')
         self.optimizer_pretrain = None
+        self.saved_sst_embed_file = os.path.join(self.checkpoint_dir, '{}-{}_embed-[{}].pth'.format(
+            config['model'], config['aggr_method'], '_'.join(config['sst_attr_list'])))     # trainer.py:557-559
         if config['pretrain_model_file_path'] is not None:
             ck = torch.load(config['pretrain_model_file_path'], weights_only=False)
             self.model.load_state_dict(ck['state_dict'])
@@ -541,6 +575,12 @@ class FairGoTrainer(PFCNTrainer):
             self.optimizer_pretrain = self._build_optimizer(group='pretrain')
 
     _valid_epoch = Trainer._valid_epoch      # the reference's FairGoTrainer evaluates like the plain Trainer (:738-772)
+
+    def _train_epoch(self, train_data, epoch_idx, loss_func=None, show_progress=False):
+        """trainer.py:687-704: the same alternating epoch as PFCN's, but the reference's FairGoTrainer returns the pair as
+        (dis_loss, filter_loss) -- the order its epoch log lines and train_loss_dict consumers see."""
+        filter_loss, dis_loss = PFCNTrainer._train_epoch(self, train_data, epoch_idx, loss_func, show_progress)
+        return dis_loss, filter_loss
 
     def save_pretrained_model(self, saved_model_file):
         torch.save({'config': dict(self.config.final_config_dict), 'state_dict': self.model.state_dict(),
@@ -561,6 +601,9 @@ class FairGoTrainer(PFCNTrainer):
             self.save_pretrained_model(self.saved_pretrain_model_file)
             ck = torch.load(self.saved_pretrain_model_file, weights_only=False)
             self.model.load_state_dict(ck['state_dict'])
+            if self.config['save_sst_embed']:      # trainer.py:681-682
+                self._save_sst_embed(train_data, os.path.join(self.checkpoint_dir, '{}-{}-pretrain_embed[none].pth'.format(
+                    self.config['model'], self.config['dataset'])))
 
     def fit(self, train_data, valid_data=None, verbose=True, saved=True, show_progress=False, callback_fn=None):
         if self.model.train_stage == 'pretrain':
@@ -587,6 +630,13 @@ class FairGoTrainer(PFCNTrainer):
             for key, value in Trainer.evaluate(self, eval_data, True, path, show_progress).items():
                 result[f'{stage}-{key}'] = value
         return result
+
+    def _save_sst_embed(self, data, saved_sst_embed_file=None):
+        """trainer.py:774-782: no checkpoint reload here; every attribute of `mask_label` at once."""
+        self.model.eval()
+        user_features = data.dataset.get_user_feature()[1:]
+        stored = self.model.get_sst_embed(user_features, [a for a in self.mask_label.values()])
+        torch.save(stored, saved_sst_embed_file or self.saved_sst_embed_file)
 
     def _save_checkpoint(self, epoch, verbose=True, **kwargs):
         saved_model_file = kwargs.pop('saved_model_file', self.saved_model_file)

@@ -1,0 +1,240 @@
+#!/usr/bin/env python3
+"""End-to-end golden fixtures from RUNS OF THE REFERENCE'S OWN TRAINERS (SURVEY.md §8-c fixture kind 5, BASELINE.json configs[0]).
+
+Nothing of the reference is restated here: the script drives `recbole.quick_start.run_recbole`'s own sequence
+(quick_start.py:32-61: Config -> init_seed -> create_dataset -> data_preparation -> init_seed -> get_model -> get_trainer ->
+trainer.fit) with the reference's classes -- `Trainer` + `FOCFDataLoader` for FOCF on recbole/dataset_example/ml-100k,
+`PFCN_BiasedMFTrainer`, `FairGo_PMFTrainer` and `Trainer` (NFCF) on a small synthetic atomic dataset -- and only LISTENS:
+`calculate_loss` / `calculate_dis_loss` of the model instance are wrapped so that every call leaves the batch it was given
+(the columns of the Interaction), the attribute subset, and the loss it returned.  Stored per case, as data only:
+
+  init.*            every parameter / buffer before the first step (state_dict + the dict-held filter / discriminator MLPs)
+  step<k>.*         the columns of the k-th batch, in the order the trainer produced them
+  kind, sst, loss   per step: which loss function ('L' calculate_loss / 'D' calculate_dis_loss), the attribute subset, the loss
+  epoch_loss        what `_train_epoch` returned per epoch (train_loss_dict)
+  final.*           every parameter after the last epoch
+  train.* / used.*  the training split as the trainer's loader holds it, and per-user used-item sets of the sampler
+  rng.np_*          numpy's global generator state when trainer.fit starts (the stream the negative sampler, FOCFDataLoader's
+                    item draws and the trainers' attribute masks share); rng.torch = torch's CPU generator state
+
+Build container only (imports /root/reference).  Usage: python tests/golden/gen_e2e_golden.py [case ...]
+"""
+import json
+import os
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+ARGV = list(sys.argv[1:])          # (_refshim.install() clears argv: the reference's Config parses it)
+import _refshim  # noqa: E402
+
+_refshim.install()
+import torch  # noqa: E402
+import yaml  # noqa: E402
+
+REF = _refshim.REFERENCE_ROOT
+
+
+def write_synthetic_atomic(root, name, n_users=200, n_items=120, per_user=(8, 30), seed=11):
+    """A tiny dataset in the reference's atomic-file format: <name>.inter (user_id, item_id, rating, timestamp) and
+    <name>.user (user_id, gender:float in {0, 1} -- the adversarial models need a float 0/1 column)."""
+    rng = np.random.default_rng(seed)
+    d = os.path.join(root, name)
+    os.makedirs(d, exist_ok=True)
+    with open(os.path.join(d, f"{name}.inter"), "w") as f:
+        f.write("user_id:token\titem_id:token\trating:float\ttimestamp:float\n")
+        t = 1_000_000
+        for u in range(1, n_users + 1):
+            k = int(rng.integers(per_user[0], per_user[1]))
+            # popularity-skewed items so that items have several raters
+            items = np.unique((n_items * rng.random(k) ** 1.7).astype(int) + 1)
+            for it in items:
+                t += int(rng.integers(1, 50))
+                f.write(f"{u}\t{it}\t{int(rng.integers(1, 6))}\t{t}\n")
+    with open(os.path.join(d, f"{name}.user"), "w") as f:
+        f.write("user_id:token\tgender:float\n")
+        for u in range(1, n_users + 1):
+            f.write(f"{u}\t{int(rng.integers(0, 2))}\n")
+    return d
+
+
+class Listener:
+    """Wraps the loss functions of ONE model instance; the reference's loops run unchanged around it."""
+
+    def __init__(self, model):
+        self.steps = []
+        self.depth = 0
+        for kind, name in (("L", "calculate_loss"), ("D", "calculate_dis_loss")):
+            fn = getattr(model, name, None)
+            if fn is None:
+                continue
+            setattr(model, name, self._wrap(kind, fn))
+
+    def _wrap(self, kind, fn):
+        def wrapped(interaction, *args, **kw):
+            self.depth += 1
+            try:
+                out = fn(interaction, *args, **kw)
+            finally:
+                self.depth -= 1
+            if self.depth:          # calculate_loss of the adversarial models calls calculate_dis_loss itself: not a step
+                return out
+            sst = args[0] if args else kw.get("sst_list")
+            cols = {k: v.detach().cpu().numpy().copy() for k, v in interaction.interaction.items()}
+            loss = [float(x.item()) for x in out] if isinstance(out, tuple) else [float(out.item())]
+            self.steps.append({"kind": kind, "sst": ",".join(sst) if sst else "", "cols": cols, "loss": loss})
+            return out
+        return wrapped
+
+
+def dict_mlps(model):
+    out = {}
+    for attr in ("filter_layer", "filter_layer_dict", "dis_layer_dict"):
+        d = getattr(model, attr, None)
+        if isinstance(d, dict):
+            for key, mlp in d.items():
+                for k, v in mlp.state_dict().items():
+                    out[f"{attr}.{key}.{k}"] = v.detach().cpu().numpy().copy()
+    return out
+
+
+def narrow(a):
+    """ids as int32, small-integer float columns as int8 (ratings 1..5, 0/1 flags): smaller files, lossless."""
+    if a.dtype == np.int64 and (a.size == 0 or (a.min() >= -2 ** 31 and a.max() < 2 ** 31)):
+        return a.astype(np.int32)
+    if a.dtype == np.float32 and a.size and np.all(a == np.round(a)) and np.abs(a).max() < 100:
+        return a.astype(np.int8)
+    return a
+
+
+def run_reference(case, model_name, dataset, overrides, trainer_expected, loader_expected):
+    from recbole.config import Config
+    from recbole.data import create_dataset, data_preparation
+    from recbole.utils import get_model, get_trainer, init_seed
+    work = tempfile.mkdtemp(prefix="e2e_")
+    cwd = os.getcwd()
+    os.chdir(work)                       # the reference writes ./log, ./log_tensorboard, ./saved
+    try:
+        ypath = os.path.join(work, "override.yaml")
+        with open(ypath, "w") as f:
+            yaml.safe_dump(overrides, f)
+        config = Config(model=model_name, dataset=dataset, config_file_list=[ypath])      # quick_start.py:32
+        init_seed(config["seed"], config["reproducibility"])
+        ds = create_dataset(config)
+        train_data, valid_data, test_data = data_preparation(config, ds)
+        init_seed(config["seed"], config["reproducibility"])
+        model = get_model(config["model"])(config, train_data.dataset).to(config["device"])
+        trainer = get_trainer(config["MODEL_TYPE"], config["model"])(config, model)
+        assert type(trainer).__name__ == trainer_expected, type(trainer).__name__
+        assert type(train_data).__name__ == loader_expected, type(train_data).__name__
+        out = {}
+        for k, v in model.state_dict().items():
+            out["init." + k] = v.detach().cpu().numpy().copy()
+        for k, v in dict_mlps(model).items():
+            out["init." + k] = v
+        # the training split and the sampler's used-item sets, as the loader holds them when fit starts
+        feat = train_data.dataset.inter_feat
+        for k in feat.interaction:
+            out["train." + k] = narrow(feat[k].numpy().copy())
+        uf = train_data.dataset.get_user_feature()
+        for k in uf.interaction:
+            out["user_feat." + k] = narrow(uf[k].numpy().copy())
+        out["n_users"], out["n_items"] = np.array(train_data.dataset.user_num), np.array(train_data.dataset.item_num)
+        smp = getattr(train_data, "sampler", None)
+        if smp is not None and getattr(smp, "used_ids", None) is not None:
+            used = smp.used_ids
+            out["used.ptr"] = np.cumsum([0] + [len(s) for s in used]).astype(np.int64)
+            out["used.ids"] = np.concatenate([np.sort(np.fromiter(s, dtype=np.int64, count=len(s))) for s in used]).astype(np.int32)
+        st = np.random.get_state()
+        out["rng.np_key"], out["rng.np_pos"] = st[1].copy(), np.array(st[2])
+        out["rng.torch"] = torch.get_rng_state().numpy().copy()
+        lis = Listener(model)
+        epoch_losses = []
+        orig_epoch = trainer._train_epoch
+
+        def epoch(*a, **kw):
+            r = orig_epoch(*a, **kw)
+            epoch_losses.append([float(x) for x in r] if isinstance(r, tuple) else [float(r)])
+            return r
+        trainer._train_epoch = epoch
+        # trainer.fit as quick_start.py:52-54 calls it; valid_data=None: no evaluation between the epochs (an evaluation draws
+        # 100 negatives per positive from the same numpy stream and is pinned by its own goldens)
+        trainer.fit(train_data, None, saved=True, show_progress=False, verbose=False)
+        for k, v in model.state_dict().items():
+            out["final." + k] = v.detach().cpu().numpy().copy()
+        for k, v in dict_mlps(model).items():
+            out["final." + k] = v
+        out["kind"] = np.array([s["kind"] for s in lis.steps])
+        out["sst"] = np.array([s["sst"] for s in lis.steps])
+        width = max(len(s["loss"]) for s in lis.steps)
+        out["loss"] = np.array([s["loss"] + [np.nan] * (width - len(s["loss"])) for s in lis.steps], dtype=np.float64)
+        out["epoch_loss"] = np.array(json.dumps(epoch_losses))
+        for k, s in enumerate(lis.steps):
+            for name, col in s["cols"].items():
+                out[f"step{k}.{name}"] = narrow(col)
+        keep = ("embedding_size", "learning_rate", "weight_decay", "train_batch_size", "epochs", "fair_objective", "fair_weight",
+                "filter_mode", "dis_weight", "dis_hidden_size_list", "dis_dropout", "activation", "train_epoch_interval",
+                "sst_attr_list", "aggr_method", "vs_weights", "n_layers", "filter_hidden_size_list", "pretrain_epochs",
+                "mlp_hidden_size", "dropout", "neg_sampling", "seed", "RATING_FIELD", "LABEL_FIELD", "threshold", "clip_grad_norm",
+                "save_sst_embed")
+        out["config"] = np.array(json.dumps({k: config[k] for k in keep if k in config.final_config_dict}, default=str))
+        out["model"], out["trainer"], out["loader"] = np.array(model_name), np.array(trainer_expected), np.array(loader_expected)
+        path = os.path.join(HERE, f"e2e_{case}.npz")
+        np.savez_compressed(path, **out)
+        n = len(lis.steps)
+        print(f"{path}: {n} steps, kinds {''.join(out['kind'][:12])}..., epoch losses {epoch_losses}, "
+              f"{os.path.getsize(path) / 1e6:.2f} MB, B of first steps {[len(s['cols']['user_id']) for s in lis.steps[:4]]}")
+    finally:
+        os.chdir(cwd)
+
+
+def case_focf_ml100k():
+    """BASELINE.json configs[0]: `run_recbole.py -m FOCF -d ml-100k`, embedding_size 64, with the override yaml SURVEY.md §8-d /
+    App. B-11 prescribes (the model yaml's data settings are shadowed by sample.yaml / ml-100k.yaml)."""
+    run_reference("focf_ml100k", "FOCF", "ml-100k", {
+        "data_path": os.path.join(REF, "recbole", "dataset_example") + "/", "RATING_FIELD": "rating", "LABEL_FIELD": "label",
+        "threshold": {"rating": 3.0}, "load_col": {"inter": ["user_id", "item_id", "rating"], "user": ["user_id", "gender"]},
+        "embedding_size": 64, "fair_objective": "value", "fair_weight": 1.0, "epochs": 2, "seed": 2020, "use_gpu": False,
+        "show_progress": False}, "Trainer", "FOCFDataLoader")
+
+
+def _synth_root():
+    root = tempfile.mkdtemp(prefix="e2e_data_")
+    write_synthetic_atomic(root, "synth")
+    return root + "/"
+
+
+COMMON = {"RATING_FIELD": "rating", "LABEL_FIELD": "label", "threshold": {"rating": 3.0}, "sst_attr_list": ["gender"],
+          "load_col": {"inter": ["user_id", "item_id", "rating", "timestamp"], "user": ["user_id", "gender"]},
+          "seed": 2020, "use_gpu": False, "show_progress": False, "train_batch_size": 256, "epochs": 2}
+
+
+def case_pfcn_biasedmf():
+    run_reference("pfcn_biasedmf_sm", "PFCN_BiasedMF", "synth", dict(COMMON, **{
+        "data_path": _synth_root(), "embedding_size": 16, "filter_mode": "sm", "dis_hidden_size_list": [32, 16], "dis_dropout": 0.0,
+        "dis_weight": 10, "train_epoch_interval": 1, "weight_decay": 1e-4}), "PFCN_BiasedMFTrainer", "TrainDataLoader")
+
+
+def case_fairgo_pmf():
+    run_reference("fairgo_pmf_wap", "FairGo_PMF", "synth", dict(COMMON, **{
+        "data_path": _synth_root(), "embedding_size": 16, "aggr_method": "WAP", "n_layers": 2, "dis_hidden_size_list": [16, 8, 4],
+        "filter_hidden_size_list": [32, 16], "pretrain_epochs": 2, "train_epoch_interval": 1, "weight_decay": 1e-4,
+        "fair_weight": 0.1}), "FairGo_PMFTrainer", "TrainDataLoader")
+
+
+def case_nfcf_pretrain():
+    run_reference("nfcf_pretrain", "NFCF", "synth", dict(COMMON, **{
+        "data_path": _synth_root(), "embedding_size": 16, "mlp_hidden_size": [32, 16], "dropout": 0.0, "load_pretrain_path": None,
+        "weight_decay": 1e-6}), "Trainer", "TrainDataLoader")
+
+
+CASES = {"focf_ml100k": case_focf_ml100k, "pfcn_biasedmf": case_pfcn_biasedmf, "fairgo_pmf": case_fairgo_pmf,
+         "nfcf_pretrain": case_nfcf_pretrain}
+
+if __name__ == "__main__":
+    names = [a for a in ARGV if a in CASES] or list(CASES)
+    for n in names:
+        CASES[n]()

@@ -135,3 +135,145 @@ def test_graphed_step_draws_fresh_dropout_masks_and_handles_odd_batches():
     assert np.isfinite(float(gs(batch(B // 2 + 3))))          # odd size: eager fallback
     eng.sync_steps()
     assert eng._tables["item_embedding.weight"].step == 6
+
+
+# --- a captured piece must own everything it reads -----------------------------------------------------------------------
+def _churn(keep):
+    """Hand every cached free block of torch's default pool out once more, filled with 0xFF bytes (NaN as float, -1 as
+    int), keep them alive, and give 128 MiB of the same back to the driver: whatever a graph reads that it does not own --
+    a dangling pointer to a tensor that lived at capture time, an uninitialised buffer -- now reads NaN."""
+    torch.cuda.synchronize()
+    size = 1 << 26
+    while size >= 512:
+        while True:
+            before = torch.cuda.memory_reserved()
+            t = torch.empty(size, dtype=torch.uint8, device="cuda")
+            if torch.cuda.memory_reserved() > before:      # a NEW segment, not a cached block: give it back, next size
+                del t
+                break
+            keep.append(t.fill_(0xFF))
+        size >>= 1
+    t = torch.full((32 << 18,), -1, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    del t
+    torch.cuda.empty_cache()
+
+
+def _replays_are_idempotent(fn, replays=3):
+    """fn() -> list of output tensors.  Eager twice, capture, replay, churn, replay x3: the outputs of every replay must be
+    the first replay's, bit for bit, and the first replay's the eager result."""
+    for _ in range(2):
+        eager = [o.detach().clone() for o in fn()]
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, capture_error_mode="thread_local"):
+        outs = fn()
+    g.replay()
+    torch.cuda.synchronize()
+    first = [o.detach().clone() for o in outs]
+    for a, b in zip(eager, first):
+        assert torch.equal(a, b), "first replay differs from the eager result"
+    keep = []
+    _churn(keep)
+    for r in range(replays):
+        g.replay()
+        torch.cuda.synchronize()
+        for k, (a, b) in enumerate(zip(first, outs)):
+            assert torch.equal(a, b), f"output {k} moved on replay {r + 2} after the allocator's free memory was churned"
+    del keep
+
+
+def test_captured_pieces_are_idempotent_under_allocator_churn():
+    """Round 4's root cause of the FairGo 'Training loss is nan' flake, pinned: every autograd Function of the generic steps,
+    forward + backward inside ONE hipGraph, replayed after the allocator's free memory was filled with NaN patterns.  Before
+    the fix RowGather's backward failed here on every run: its dense gradient was cleared by hipMemsetAsync, i.e. by a memset
+    NODE once captured, which this runtime executes on the graph's first launch only -- later replays summed the batch's rows
+    into whatever the block's previous tenant had left."""
+    from fairrec import _C
+    from fairrec.functional import CsrMatrix, Mse, RowDot, RowGather, SigmoidBce, SoftmaxCe, SpMM
+    from fairrec.model.layers import MLPLayers
+    import scipy.sparse as sp
+    g = torch.Generator().manual_seed(5)
+    N, D, B = 70, 16, 96
+    E0 = torch.randn(N, D, generator=g).cuda()
+    idx = torch.randint(0, N, (B,), generator=g).cuda()
+    idx2 = torch.randint(0, N, (B,), generator=g).cuda()
+    target = torch.randint(1, 6, (B,), generator=g).float().cuda()
+    label = (torch.rand(B, generator=g) < 0.5).float().cuda()
+    cls = torch.randint(0, 3, (B,), generator=g).cuda()
+    dense = (torch.rand(N, N, generator=g) < 0.08).float() * torch.rand(N, N, generator=g)
+    L = CsrMatrix(sp.csr_matrix(dense.numpy()), "cuda")
+    mlp = MLPLayers([D, 16, 8, D], activation="leakyrelu").cuda()
+    mlp_bn = MLPLayers([D, 32, 1], activation="leakyrelu", bn=True).cuda().train()
+    head3 = MLPLayers([D, 8, 3], activation="leakyrelu").cuda()
+    err = torch.zeros(1, dtype=torch.int32, device="cuda")
+    one = _C.one(torch.device("cuda", 0))
+
+    def piece(make):
+        def fn():
+            x = E0.clone().requires_grad_(True)
+            y = make(x)
+            for p in list(mlp.parameters()) + list(mlp_bn.parameters()) + list(head3.parameters()):
+                p.grad = None
+            y.backward(one if y.dim() == 0 else torch.ones_like(y))
+            return [y.detach().reshape(-1), x.grad]
+        return fn
+
+    pieces = {
+        "RowGather": lambda x: RowGather.apply(x, idx, err).sum(),
+        "SpMM": lambda x: SpMM.apply(x, L).sum(),
+        "RowDot+Mse": lambda x: Mse.apply(RowDot.apply(RowGather.apply(x, idx, err), RowGather.apply(x, idx2, err)), target),
+        "MLP": lambda x: mlp(x).sum(),
+        "MLP+BN+SigmoidBce": lambda x: SigmoidBce.apply(mlp_bn(RowGather.apply(x, idx, err)), label),
+        "MLP+SoftmaxCe": lambda x: SoftmaxCe.apply(head3(RowGather.apply(x, idx, err)), cls, err),
+        "two-layer propagation": lambda x: RowGather.apply(torch.stack([SpMM.apply(x, L), SpMM.apply(SpMM.apply(x, L), L)], dim=1).mean(dim=1),
+                                                           idx, err).sum(),
+    }
+    for name, make in pieces.items():
+        try:
+            _replays_are_idempotent(piece(make))
+        except AssertionError as e:
+            raise AssertionError(f"{name}: {e}") from None
+    assert int(err.item()) == 0
+
+
+def test_captured_lazy_table_step_is_idempotent_under_allocator_churn():
+    """The same for the lazy-table pair of a generic step: LazyLookup (fr_table_gather_train, sort in line when capturing) ->
+    loss -> backward -> FusedLazyAdam.step() (fr_table_apply_grad + dense Adam) in one graph; the state is put back before
+    every replay, so every replay must produce the same table, moments and loss."""
+    from fairrec import _C
+    from fairrec.engine import GenericEngine
+    from fairrec.functional import Mse, RowDot
+    from fairrec.optim import FusedLazyAdam
+    g = torch.Generator().manual_seed(6)
+    NU, NI, D, B = 300, 200, 64, 256
+    U = torch.nn.Parameter((torch.randn(NU, D, generator=g) * 0.1).cuda())
+    I = torch.nn.Parameter((torch.randn(NI, D, generator=g) * 0.1).cuda())
+    eng = GenericEngine("cuda")
+    tu, ti = eng.add_table("U", U), eng.add_table("I", I)
+    opt = FusedLazyAdam(eng, lr=1e-3, weight_decay=1e-3, sweep_period=4)
+    eng.enable_graph_mode()
+    u = torch.randint(1, NU, (B,), generator=g).cuda()
+    i = torch.randint(1, NI, (B,), generator=g).cuda()
+    r = torch.randint(1, 6, (B,), generator=g).float().cuda()
+    one = _C.one(torch.device("cuda", 0))
+    state = lambda: [U.data, I.data, tu.m, tu.v, tu.last, ti.m, ti.v, ti.last, eng._counters]
+    snap = None
+
+    def fn():
+        if snap is not None:
+            for dst, src in zip(state(), snap):
+                dst.copy_(src)
+        opt.zero_grad()
+        loss = Mse.apply(RowDot.apply(eng.lookup("U", u), eng.lookup("I", i)), r)
+        loss.backward(one)
+        opt.step()
+        return [loss.detach().reshape(1)] + [t for t in state()[:8]]
+
+    for _ in range(3):      # a few real steps first: rows of different staleness
+        fn()
+    eng.sync_steps()
+    snap = [t.detach().clone() for t in state()]
+    _replays_are_idempotent(fn)
+    eng.sync_steps()
+    eng.check_device_errors()

@@ -163,3 +163,58 @@ def test_recbole_import_alias_resolves_to_the_native_package():
     import pytest
     with pytest.raises(ImportError):
         import recbole.utils.wandblogger  # noqa: F401  (not part of the hot path, not provided)
+
+
+def _e2e(case):
+    z = np.load(os.path.join(GOLDEN, f"e2e_{case}.npz"))
+    import json
+    c = {k: v for k, v in json.loads(str(z["config"])).items() if v is not None or k == "neg_sampling"}
+    c.pop("seed", None)
+    cfg = Config(model=str(z["model"]), config_dict=dict(c, device="cpu"))
+    cols = {k[6:]: torch.from_numpy(z[k].astype(np.int64) if k.endswith("_id") else z[k].astype(np.float32))
+            for k in z.files if k.startswith("train.")}
+    users = {k[10:]: torch.from_numpy(z[k].astype(np.int64) if k.endswith("_id") else z[k].astype(np.float32))
+             for k in z.files if k.startswith("user_feat.")}
+    ds = InteractionDataset(cfg, Interaction(cols), Interaction(users), int(z["n_users"]), int(z["n_items"]))
+    return z, cfg, ds
+
+
+def test_focf_loader_reproduces_the_reference_run_on_ml100k():
+    """BASELINE.json configs[0] on the host: from numpy's generator state at the start of the reference's trainer.fit, the
+    item-complete batcher yields the reference FOCFDataLoader's 80 batches of its 2-epoch ml-100k run, row for row
+    (tests/golden/gen_e2e_golden.py; focf_dataloader.py:37-51)."""
+    z, cfg, ds = _e2e("focf_ml100k")
+    dl = FOCFDataLoader(cfg, ds)
+    np.random.set_state(("MT19937", z["rng.np_key"].astype(np.uint32), int(z["rng.np_pos"]), 0, 0.0))
+    t = 0
+    for epoch in range(2):
+        for batch in dl:
+            for col in ("user_id", "item_id", "rating", "gender"):
+                np.testing.assert_array_equal(batch[col].numpy().astype(np.int64), z[f"step{t}.{col}"].astype(np.int64),
+                                              err_msg=f"batch {t} column {col}")
+            t += 1
+    assert t == len(z["kind"]) == 80
+
+
+@pytest.mark.parametrize("case", ["pfcn_biasedmf_sm", "fairgo_pmf_wap", "nfcf_pretrain"])
+def test_epoch_shuffles_reproduce_the_reference_run(case):
+    """The positive rows of every batch of the reference trainers' 2-epoch runs (pair-wise: all rows; point-wise: the first
+    half) from torch's CPU generator state at the start of trainer.fit: one torch.randperm per pass over the loader
+    (general_dataloader.py:59-60 -> interaction.py:293-297), also through the filter / discriminator alternation."""
+    from fairrec.utils.enum_type import InputType
+    z, cfg, ds = _e2e(case)
+    dl = TrainDataLoader(cfg, ds, sampler=None, shuffle=True)
+    pointwise = cfg["MODEL_INPUT_TYPE"] == InputType.POINTWISE
+    dl.step = int(cfg["train_batch_size"]) // (2 if pointwise else 1)          # what a sampler would make it (:41-50)
+    torch.set_rng_state(torch.from_numpy(z["rng.torch"]))
+    t, T = 0, len(z["kind"])
+    while t < T:
+        for batch in dl:
+            ref_u, ref_i = z[f"step{t}.user_id"], z[f"step{t}.item_id"]
+            n = len(ref_u) // 2 if pointwise else len(ref_u)
+            np.testing.assert_array_equal(batch["user_id"].numpy(), ref_u[:n].astype(np.int64), err_msg=f"step {t}")
+            np.testing.assert_array_equal(batch["item_id"].numpy(), ref_i[:n].astype(np.int64), err_msg=f"step {t}")
+            if pointwise:      # the negatives' rows repeat the positives' users (abstract_dataloader.py:190-198)
+                np.testing.assert_array_equal(ref_u[n:], ref_u[:n])
+            t += 1
+    assert t == T
