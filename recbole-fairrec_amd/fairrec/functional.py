@@ -285,6 +285,37 @@ class SpMM(torch.autograd.Function):
         return dX, None
 
 
+class SpMMSel(torch.autograd.Function):
+    """Rows of Y = L X where the batch can see them (fr_spmm_csr_sel): Y[i] = sum_j L[rows[i], j] * X[xmap[j]] with the
+    nonzeros in CSR order and nonzeros whose `xmap` entry is -1 skipped.  `rows` / `rpos` (int32 [R] / its inverse map over
+    the rows of L, -1 elsewhere) select the output rows; `xrows` / `xmap` (int32 [n_x] / inverse over the columns) say which
+    columns the rows of a COMPACT X stand for; either pair may be None (all rows / X is the whole table).  The backward is the
+    same kernel on the CSR of L^T with the two pairs swapped.  Kept terms are added in SpMM's order and skipped terms are the
+    ones SpMM adds as exact zeros, so values and gradients are those of the whole-table product restricted to the rows."""
+
+    @staticmethod
+    def forward(ctx, X, L: CsrMatrix, rows, rpos, xrows, xmap):
+        X = X.contiguous()
+        n_out = L.shape[0] if rows is None else rows.numel()
+        Y = torch.empty((n_out, X.shape[1]), dtype=torch.float32, device=X.device)
+        ip, col, val = L.fwd
+        _C.check(_C.lib().fr_spmm_csr_sel(ip.data_ptr(), col.data_ptr(), val.data_ptr(), X.data_ptr(), _C.ptr(rows), n_out,
+                                          _C.ptr(xmap), X.shape[1], Y.data_ptr(), _C.current_stream()), "fr_spmm_csr_sel")
+        ctx.L, ctx.sel, ctx.n_x = L, (rows, rpos, xrows, xmap), X.shape[0]
+        return Y
+
+    @staticmethod
+    def backward(ctx, dY):
+        L = ctx.L
+        rows, rpos, xrows, xmap = ctx.sel
+        dY = dY.contiguous()
+        dX = torch.empty((ctx.n_x, dY.shape[1]), dtype=torch.float32, device=dY.device)
+        ip, col, val = L.bwd
+        _C.check(_C.lib().fr_spmm_csr_sel(ip.data_ptr(), col.data_ptr(), val.data_ptr(), dY.data_ptr(), _C.ptr(xrows), ctx.n_x,
+                                          _C.ptr(rpos), dY.shape[1], dX.data_ptr(), _C.current_stream()), "fr_spmm_csr_sel")
+        return dX, None, None, None, None, None
+
+
 class RowGather(torch.autograd.Function):
     """X[idx] on a whole-table activation (fairgo_pmf.py:178-179); backward = dense gradient with duplicates summed in
     ascending batch position (fixed order, no atomics)."""

@@ -20,7 +20,7 @@ import torch
 import torch.nn as nn
 
 from ...engine import GenericEngine
-from ...functional import CsrMatrix, Mse, RowDot, RowGather, SigmoidBce, SoftmaxCe, SpMM
+from ...functional import CsrMatrix, Mse, RowDot, RowGather, SigmoidBce, SoftmaxCe, SpMM, SpMMSel
 from ...utils.enum_type import InputType
 from ..abstract_recommender import FairRecommender
 from ..layers import ACT_CODES, MLPLayers, _HipMLP, activation_layer
@@ -48,6 +48,7 @@ class FairGo_PMF(FairRecommender):
         self.train_stage = None
         self.aggr_method = config['aggr_method'].upper()
         self.vs_weights = None
+        self.frontier_mode = config['fairgo_frontier'] if config['fairgo_frontier'] is not None else 'auto'
         if config['vs_weights'] is not None:
             vs = torch.tensor(config['vs_weights'], dtype=torch.float32)
             self.vs_weights = vs / vs.sum()
@@ -172,20 +173,98 @@ class FairGo_PMF(FairRecommender):
             return [torch.cat(hs, dim=1)]
         return hs
 
+    # --- frontier-restricted propagation (SURVEY.md section 7 hard part 3; fairgo_pmf.py:196-216) -------------------------
+    FRONTIER_MIN_NNZ = 1 << 22      # `fairgo_frontier: auto`: graphs below this are cheaper to propagate whole (and captured)
+    FRONTIER_MAX_SHARE = 0.5        # a frontier that covers more of the graph than this gains nothing: whole tables then
+
+    def use_frontier(self) -> bool:
+        """Whether a filter step propagates only the rows the batch can see.  Config `fairgo_frontier`: True / False / 'auto'
+        (default: on for graphs of >= 4 M nonzeros).  Such a step has data-dependent shapes (the frontier of every batch is
+        its own) and is launched eagerly: `step_capturable`."""
+        mode = self.frontier_mode
+        if isinstance(mode, str) and mode.lower() == 'auto':
+            return int(self._norm_csr_host.nnz) >= self.FRONTIER_MIN_NNZ
+        return bool(mode)
+
+    def step_capturable(self, loss_name: str) -> bool:
+        """Trainer hook (fairrec/trainer: `_graphed_step`): can a step on this loss function be captured as a hipGraph?"""
+        return not (self.train_stage == 'finetune' and loss_name == 'calculate_loss' and self.use_frontier())
+
+    def _frontier(self, user):
+        """Row sets S_1 .. S_n (sorted, distinct, int32) with their inverse maps over the N graph rows (-1 elsewhere): the
+        rows of H_l = L H_(l-1) that the batch's local embeddings depend on.  S_n = the batch's users; S_(l-1) = S_n plus the
+        columns of the rows S_l (every layer's rows of the batch's users are aggregated, fairgo_pmf.py:204-216).  None when
+        the frontier covers so much of the graph that whole-table products are as cheap."""
+        L = self._L
+        ip, col, _ = L.fwd
+        N = L.shape[0]
+        dev = ip.device
+        base = torch.unique(user.to(dev, torch.int64))
+        sets, cur = [], base
+        for l in range(self.n_layers, 0, -1):
+            sets.append(cur)
+            if l > 1:
+                lo = ip[cur]
+                deg = ip[cur + 1] - lo
+                tot = int(deg.sum().item())
+                if tot > self.FRONTIER_MAX_SHARE * col.numel():
+                    return None
+                start = torch.repeat_interleave(lo - (torch.cumsum(deg, 0) - deg), deg)
+                nb = col[start + torch.arange(tot, device=dev)].to(torch.int64)
+                cur = torch.unique(torch.cat([base, nb]))
+                if cur.numel() > self.FRONTIER_MAX_SHARE * N:
+                    return None
+        out = []
+        for rows in reversed(sets):                      # S_1 first
+            pos = torch.full((N,), -1, dtype=torch.int32, device=dev)
+            pos[rows] = torch.arange(rows.numel(), dtype=torch.int32, device=dev)
+            out.append((rows.to(torch.int32), pos))
+        return out
+
+    def _propagate_rows(self, E, user):
+        """[H_1[user], ..., H_n[user]] ([B, D] each) through products over the frontier's rows only; None = not worth it."""
+        fr = self._frontier(user)
+        if fr is None:
+            return None
+        eng = self.hip_engine()
+        H, prev, rows_out = E, (None, None), []
+        for rows, pos in fr:
+            H = SpMMSel.apply(H, self._L, rows, pos, prev[0], prev[1])
+            prev = (rows, pos)
+            rows_out.append(RowGather.apply(H, pos[user].to(torch.int64), eng.err_flag))
+        return rows_out
+
     def _dis_terms(self, E, interaction, sst_list, props=None):
         """calculate_dis_loss, fairgo_pmf.py:190-238, on an already filtered whole table E."""
         eng = self.hip_engine()
         user = interaction[self.USER_ID].to(eng.device)
         node = RowGather.apply(E, user, eng.err_flag)
-        props = self._propagate(E) if props is None else props
         lva = self.aggr_method == 'LVA' and self.n_layers > 1
+        layer_rows = None
+        if props is None and self.use_frontier() and not torch.cuda.is_current_stream_capturing():
+            layer_rows = self._propagate_rows(E, user)
+        if layer_rows is not None:
+            # the same aggregation as _propagate's, row-wise on the batch's rows (mean / concatenation / per-layer weights act
+            # on a row at a time, so the batch's rows of the aggregated table ARE the aggregate of the layers' batch rows)
+            if lva:
+                locals_ = layer_rows
+            elif self.n_layers == 1:
+                local = layer_rows[0]
+            elif self.aggr_method == 'WAP':
+                local = torch.stack(layer_rows, dim=1).mean(dim=1)
+            else:
+                local = torch.cat(layer_rows, dim=1)
+        else:
+            props = self._propagate(E) if props is None else props
+            if lva:
+                locals_ = [RowGather.apply(h, user, eng.err_flag) for h in props]
+            else:
+                local = RowGather.apply(props[0], user, eng.err_flag)
         if lva:
-            locals_ = [RowGather.apply(h, user, eng.err_flag) for h in props]
             if self.vs_weights.device != eng.device:       # once: no host-to-device copy inside a captured step
                 self.vs_weights = self.vs_weights.to(eng.device)
             vs = self.vs_weights
         else:
-            local = RowGather.apply(props[0], user, eng.err_flag)
             if self.aggr_method == 'LBA' and self.n_layers > 1:
                 local = self._aggr(local)
         node_l, local_l = 0.0, 0.0

@@ -52,6 +52,7 @@ class FocfEngine:
     # fr_focf_step_staged: the index work of the two coming batches rides in the step launches themselves (no sort, no side
     # stream); FAIRREC_FOCF_STAGED=0 goes back to the look-ahead sort (fr_focf_prepare_step) for the one-launch step
     STAGED = os.environ.get("FAIRREC_FOCF_STAGED", "1") != "0"
+    RUNS = os.environ.get("FAIRREC_FOCF_RUNS", "1") != "0"
 
     def __init__(self, user_weight: torch.Tensor, item_weight: torch.Tensor, objective: str, fair_weight: float,
                  max_rating: float):
@@ -365,8 +366,10 @@ class FocfEngine:
             alive = {self._key(nb[0], nb[1]) for nb in coming}
             for k in [k for k in self._prep if k not in alive]:
                 torch.cuda.current_stream().wait_event(self._prep.pop(k)[1]["done"])
+        # item-complete batches (FOCFDataLoader) take the one-launch step of csrc/focf_runs.hip (a workgroup per chunk of an
+        # item's run); FAIRREC_FOCF_RUNS=0 sends them through the three-launch chain as before round 4
         fused = (self.fused_step and self.defer_loss and self.optimizer is not None and self.objective != 5 and not want_pred
-                 and not self.item_runs and self.U.step == self.I.step)
+                 and (not self.item_runs or (self.RUNS and rating is not None)) and self.U.step == self.I.step)
         # A stamp is the optimizer step at which its batch is applied: the current batch (if nobody prepared it) takes its
         # stamp BEFORE the coming ones take theirs, so that stamps rise in application order -- the sweeper leaves a row to
         # its batch by comparing stamps, and the start order of a step's sweeper tasks is built for the stamped step's slice
@@ -390,6 +393,7 @@ class FocfEngine:
                                                    self._sweep(B), self.err_flag.data_ptr(), _C.current_stream())
                 _C.check(rc, "fr_focf_prepare_step")
             self._stash = (user, item, rating, sst, B, ws, stamp, loss)
+            self._stash_runs = bool(self.item_runs)
             self.pending_B = B
             return loss, None
         pred = torch.empty(B, dtype=torch.float32, device=self.device) if want_pred else None
@@ -462,12 +466,19 @@ class FocfEngine:
             if self._prev is not None and self._prev[3]:
                 self.finish()
             pw, pB, ploss, _ = self._prev if self._prev is not None else (None, 0, None, False)
-            rc = _C.lib().fr_focf_step(ctypes.byref(tu), ctypes.byref(ti), ctypes.byref(self.hyper.c()),
-                                       user.data_ptr(), item.data_ptr(), rating.data_ptr(), _C.ptr(sst), B,
-                                       self.objective, self.fair_weight, self._sweep(B), stamp, ws.data_ptr(), ws.numel(),
-                                       loss.data_ptr(), _C.ptr(pw), pB, _C.ptr(ploss), self.loss_acc.data_ptr(),
-                                       self.err_flag.data_ptr(), _C.current_stream())
-            _C.check(rc, "fr_focf_step")
+            if getattr(self, "_stash_runs", False):
+                rc = _C.lib().fr_focf_step_runs(ctypes.byref(tu), ctypes.byref(ti), ctypes.byref(self.hyper.c()), _C.ptr(sst), B,
+                                                self.objective, self.fair_weight, self._sweep(B), stamp, ws.data_ptr(),
+                                                ws.numel(), _C.ptr(pw), pB, _C.ptr(ploss), self.loss_acc.data_ptr(),
+                                                self.err_flag.data_ptr(), _C.current_stream())
+                _C.check(rc, "fr_focf_step_runs")
+            else:
+                rc = _C.lib().fr_focf_step(ctypes.byref(tu), ctypes.byref(ti), ctypes.byref(self.hyper.c()),
+                                           user.data_ptr(), item.data_ptr(), rating.data_ptr(), _C.ptr(sst), B,
+                                           self.objective, self.fair_weight, self._sweep(B), stamp, ws.data_ptr(), ws.numel(),
+                                           loss.data_ptr(), _C.ptr(pw), pB, _C.ptr(ploss), self.loss_acc.data_ptr(),
+                                           self.err_flag.data_ptr(), _C.current_stream())
+                _C.check(rc, "fr_focf_step")
             self._prev = (ws, B, loss, False)
             self._keep = (user, item, rating, sst)
         else:

@@ -90,6 +90,9 @@ class Trainer(AbstractTrainer):
         eng = self.model.hip_engine()
         if eng is None or not hasattr(eng, 'enable_graph_mode'):
             return None                                   # FOCF: its fused engine has its own launch path
+        capturable = getattr(self.model, 'step_capturable', None)
+        if capturable is not None and not capturable(key[1]):
+            return None                                   # e.g. FairGo's frontier-restricted filter step: data-dependent shapes
         graphs = self.__dict__.setdefault('_step_graphs', {})
         key = key + (id(self.optimizer),)
         if key not in graphs:

@@ -357,3 +357,61 @@ def test_fairgo_gcn_pretrain_matches_the_restated_pyg_gcn(tmp_path):
     E = OF.gcn_forward(torch.cat([Ur, Ir], 0), a_hat, Wr, br)
     ref_pr = torch.clamp((E[users[0]] * E[items[0] + n_users]).sum(-1), 0, 5.0) / 5.0
     np.testing.assert_allclose(pr.numpy(), ref_pr.numpy(), rtol=2e-3, atol=2e-5)
+
+
+@pytest.mark.parametrize("aggr,n_layers,D", [("WAP", 2, 64), ("LBA", 2, 128), ("LVA", 2, 16), ("WAP", 3, 64), ("WAP", 1, 64)])
+def test_frontier_restricted_propagation_equals_whole_table(aggr, n_layers, D):
+    """SURVEY.md section 7 hard part 3 (fairgo_pmf.py:196-216): a filter step needs H_l = L H_(l-1) only on the batch's users
+    and, below the top layer, on what those rows read.  fr_spmm_csr_sel computes exactly those rows, term for term in the
+    whole-table product's order, so the loss must be the SAME BITS and every filter / discriminator gradient equal up to
+    the order in which autograd adds the (identical) contributions to dLoss/dE."""
+    from fairrec.config import Config
+    from fairrec.data.interaction import Interaction
+    from fairrec.utils import get_model
+    n_users, n_items, B = 3001, 801, 160
+    rng = np.random.default_rng(4)
+    torch.manual_seed(4)
+    tu = np.repeat(np.arange(1, n_users), 6)
+    ti = rng.integers(1, n_items, tu.size)
+    pair = np.unique(tu.astype(np.int64) * n_items + ti)
+    tu, ti = pair // n_items, pair % n_items
+    tr = rng.integers(1, 6, tu.size).astype(np.float32)
+    gender = rng.integers(0, 2, n_users).astype(np.float32)
+    z = {"gender": gender, "age": np.zeros(n_users, dtype=np.int64), "train_user": tu, "train_item": ti, "train_rating": tr}
+    u = rng.integers(1, n_users, B)
+    u[:8] = u[8:16]                                     # duplicate users in the batch
+    sel = np.array([rng.choice(np.flatnonzero(tu == x)) for x in u])
+    inter = Interaction({"user_id": torch.tensor(u), "item_id": torch.tensor(ti[sel]), "rating": torch.tensor(tr[sel]),
+                         "gender": torch.tensor(gender[u])}).to("cuda")
+    results = {}
+    for mode in (False, True):
+        torch.manual_seed(11)
+        cfg = Config(model="FairGo_PMF", config_dict={
+            "embedding_size": D, "sst_attr_list": ["gender"], "aggr_method": aggr, "n_layers": n_layers,
+            "filter_hidden_size_list": [32, 16], "dis_hidden_size_list": [16, 8], "vs_weights": [3.0, 1.0, 1.0][:n_layers],
+            "fair_weight": 0.1, "device": "cuda", "fairgo_frontier": mode})
+        model = get_model("FairGo_PMF")(cfg, _DS(n_users, n_items, z)).to("cuda")
+        model.FRONTIER_MAX_SHARE = 1.0                  # (this small graph's 2-hop frontier is most of it: restrict anyway)
+        model.train_stage = "finetune"
+        assert model.use_frontier() is mode and model.step_capturable("calculate_loss") is (not mode)
+        assert model.step_capturable("calculate_dis_loss")
+        params = list(model.filter_layer_dict["gender"].parameters()) + list(model.dis_layer_dict["gender"].parameters()) + \
+            (list(model.aggr_layer.parameters()) if aggr == "LBA" else [])
+        loss = model.calculate_loss(inter, ["gender"])
+        loss.backward()
+        with torch.no_grad():
+            dis = model.calculate_dis_loss(inter, ["gender"])
+        results[mode] = (loss.detach().clone(), dis.clone(), [p.grad.clone() for p in params])
+        if mode:
+            fr = model._frontier(inter["user_id"])
+            assert len(fr) == n_layers and fr[-1][0].numel() == len(set(u.tolist()))
+            if n_layers > 1:
+                assert fr[0][0].numel() > fr[-1][0].numel()
+        model.hip_engine().check_device_errors()
+    (l0, d0, g0), (l1, d1, g1) = results[False], results[True]
+    assert torch.equal(l0, l1), (float(l0), float(l1))
+    assert torch.equal(d0, d1)
+    for a, b in zip(g0, g1):
+        scale = float(a.abs().max())
+        assert float((a - b).abs().max()) <= 1e-5 * scale + 1e-12, (float((a - b).abs().max()), scale)
+    assert any(float(g.abs().max()) > 0 for g in g0)

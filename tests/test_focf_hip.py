@@ -30,19 +30,23 @@ def _engine(z, sweep):
     return eng
 
 
-@pytest.mark.parametrize("sweep", [0, 3, None, "lookahead", "lookahead2", "fused", "fused_ahead", "fused_nosweep"],
+@pytest.mark.parametrize("sweep", [0, 3, None, "lookahead", "lookahead2", "fused", "fused_ahead", "fused_nosweep", "fused_runs",
+                                   "fused_runs_ahead"],
                          ids=["nosweep", "sweep3", "sweepdefault", "lookahead", "lookahead2", "fused", "fused_ahead",
-                              "fused_nosweep"])
+                              "fused_nosweep", "runs", "runs_ahead"])
 @pytest.mark.parametrize("path", CASES, ids=[os.path.basename(p)[:-4] for p in CASES])
 def test_training_matches_reference_golden(path, sweep):
     z = np.load(path)
     # "lookahead": the next batch's index sort runs one step ahead on a side stream, stamps the batch's rows and carries
     # the sweep slice of the step in flight
-    lookahead = {"lookahead": 1, "lookahead2": 5, "fused_ahead": 5}.get(sweep, 0)   # coming batches announced
+    lookahead = {"lookahead": 1, "lookahead2": 5, "fused_ahead": 5, "fused_runs_ahead": 5}.get(sweep, 0)   # coming batches announced
     # "fused*": the whole step as ONE launch (fr_focf_step); the loss of a step is reduced by the next step's launch
     fused = isinstance(sweep, str) and sweep.startswith("fused")
     eng = _engine(z, 0 if sweep == "fused_nosweep" else (3 if (lookahead or fused) else sweep))
     eng.defer_loss = fused
+    # "runs*": the one-launch step for item-complete batches (fr_focf_step_runs: a workgroup per chunk of the item-sorted
+    # order, csrc/focf_runs.hip) -- on EVERY golden, item-complete or not: what it computes does not depend on the shape
+    eng.item_runs = isinstance(sweep, str) and "runs" in sweep
     snaps = set(int(s) for s in z["snaps"])
     T = z["user_id"].shape[0]
     dev = "cuda"
@@ -574,3 +578,65 @@ def test_lookahead_stamps_are_the_apply_steps(staged):
         eng.flush()
     eng.check_device_errors()
     assert all(a == b for a, b in seen), [x for x in seen if x[0] != x[1]][:5]
+
+
+def _item_complete_batches(n_users, n_items, T, target, seed, degree=(20, 140)):
+    """Batches as FOCFDataLoader forms them (focf_dataloader.py:37-51): random items, ALL interactions of each, until >= target
+    rows; users recur under several items of a batch; one item much longer than a stage-2 pass of the kernel."""
+    rng = np.random.default_rng(seed)
+    gender = rng.integers(0, 2, n_users).astype(np.float32)
+    out = []
+    for t in range(T):
+        us, its = [], []
+        picked = rng.permutation(np.arange(1, n_items))
+        k = 0
+        while sum(len(x) for x in us) < target:
+            deg = int(rng.integers(*degree)) if k != 1 else 330          # (a run of 330 members: four passes at D = 64)
+            us.append(rng.choice(np.arange(1, n_users), size=deg, replace=False))
+            its.append(np.full(deg, picked[k]))
+            k += 1
+        u, i = np.concatenate(us), np.concatenate(its)
+        r = rng.integers(1, 6, u.size).astype(np.float32)
+        out.append(tuple(torch.tensor(x, device="cuda") for x in (u, i, r, gender[u])))
+    return out
+
+
+@pytest.mark.parametrize("objective", ["value", "none", "under"])
+@pytest.mark.parametrize("dim", [64, 128, 40])
+def test_runs_step_matches_chain_and_is_bit_reproducible(objective, dim):
+    """fr_focf_step_runs against the three-launch chain on item-complete batches of ragged sizes (what FOCFDataLoader feeds):
+    the same sums in the same order, so the tables agree to the rounding of where a replay is cut in two (a few ulp); and
+    against ITSELF, with and without announced batches: torch.equal -- no result may depend on which chunk arrives last."""
+    from fairrec.model.fair_recommender.focf import FocfEngine
+    from fairrec.optim import FusedLazyAdam
+    n_users, n_items, T = 1501, 401, 9
+    batches = _item_complete_batches(n_users, n_items, T, 900, seed=dim)
+    g = torch.Generator().manual_seed(1)
+    U0 = (torch.randn(n_users, dim, generator=g) * 0.1).cuda()
+    I0 = (torch.randn(n_items, dim, generator=g) * 0.1).cuda()
+
+    def run(mode):
+        eng = FocfEngine(U0.clone(), I0.clone(), objective, 0.7, 5.0)
+        FusedLazyAdam(eng, lr=1e-3, weight_decay=1e-3, sweep_period=4)
+        eng.defer_loss = True
+        eng.item_runs = True
+        eng.fused_step = mode != "chain"
+        for t, (u, i, r, s) in enumerate(batches):
+            nxt = [(b[0], b[1], b[3], b[2]) for b in batches[t + 1:t + 4]] if mode == "runs_ahead" else None
+            eng.forward(u, i, r, s, next_batch=nxt or None)
+            eng.backward_adam()
+        eng.finish()
+        eng.flush()
+        eng.check_device_errors()
+        return eng
+
+    chain, a, b, c = run("chain"), run("runs"), run("runs"), run("runs_ahead")
+    for x, y, z in ((a.U.weight, b.U.weight, c.U.weight), (a.I.weight, b.I.weight, c.I.weight), (a.U.m, b.U.m, c.U.m),
+                    (a.I.v, b.I.v, c.I.v)):
+        assert torch.equal(x, y)
+    for x, z in ((a.U.weight, c.U.weight), (a.I.weight, c.I.weight)):      # announced ahead: rows may be swept at other steps
+        torch.testing.assert_close(x, z, rtol=2e-5, atol=1e-8)
+    for x, y in ((a.U.weight, chain.U.weight), (a.I.weight, chain.I.weight), (a.U.m, chain.U.m), (a.I.m, chain.I.m),
+                 (a.U.v, chain.U.v), (a.I.v, chain.I.v)):
+        torch.testing.assert_close(x, y, rtol=2e-5, atol=1e-8 * float(y.abs().max()) + 1e-12)
+    np.testing.assert_allclose(a.loss_acc.cpu().numpy()[:3], chain.loss_acc.cpu().numpy()[:3], rtol=1e-5)
