@@ -61,6 +61,65 @@ def synth_batches(n_batches, batch, n_users, n_items, seed, item_dist="uniform")
     return u, i, r, s
 
 
+def focf_shape_block(item_dist, K, W, dev, sweep):
+    """The same FOCF step on another batch shape, measured the same way as the headline (fresh engine, optimizer state aged by
+    one sweep period, K steps captured in one hipGraph and replayed): `grouped` = item-complete batches, the shape the
+    reference's own FOCFDataLoader feeds (focf_dataloader.py:37-51; SURVEY.md section 8-d says this run "must also be reported"),
+    `zipf` = popularity-skewed items.  Bytes: SURVEY.md section 8-d's UNIQUE-ROW definition for these shapes --
+    8 R B + 4 (1 + S) B + sum over tables of distinct rows x D x (4 gathered + 8 Adam state read + 12 written)."""
+    from fairrec.model.fair_recommender.focf import FocfEngine
+    from fairrec.optim import FusedLazyAdam
+    U, I = xavier_tables(N_USERS, N_ITEMS, DIM, SEED, dev)
+    eng = FocfEngine(U, I, OBJECTIVE, FAIR_WEIGHT, 5.0)
+    FusedLazyAdam(eng, lr=LR, weight_decay=WD, sweep_period=sweep)
+    eng.defer_loss = True
+    eng.item_runs = item_dist == "grouped"          # what the Trainer sets when it is fed by FOCFDataLoader
+    ahead = FocfEngine.LOW_WATER + FocfEngine.GROUP
+    n_age = eng._sweep(BATCH) if (sweep is None or sweep > 0) else 256
+    n = n_age + W + K + ahead + 4
+    u, i, r, s = (t.to(dev) for t in synth_batches(n, BATCH, N_USERS, N_ITEMS, SEED + 31337, item_dist))
+    rows = [(u[j], i[j], s[j], r[j]) for j in range(n)]
+
+    def step(k):
+        eng.forward(u[k], i[k], r[k], s[k], next_batch=rows[k + 1:k + 1 + ahead] or None)
+        eng.backward_adam()
+    for k in range(n_age + W):
+        step(k)
+    torch.cuda.synchronize()
+    eng.prepared_is_complete()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):
+            for k in range(n_age + W, n_age + W + K):
+                step(k)
+            eng.join_prepared()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    graph.replay()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    eng.check_device_errors()
+    lo, hi = n_age + W, n_age + W + K
+    uniq_u = sum(int(torch.unique(u[k]).numel()) for k in range(lo, hi)) / K
+    uniq_i = sum(int(torch.unique(i[k]).numel()) for k in range(lo, hi)) / K
+    step_bytes = 8 * 2 * BATCH + 4 * 2 * BATCH + (uniq_u + uniq_i) * DIM * (4 + 8 + 12)
+    gbs = step_bytes / (dt / K) / 1e9
+    kind = ("one launch per step (fr_focf_step_runs: a workgroup per chunk of the item-sorted order)" if eng.item_runs and eng.RUNS
+            else ("one launch per step (fr_focf_step_staged)" if eng.staged and not eng.item_runs else "three-launch chain"))
+    graph.reset()
+    del graph, eng, U, I, u, i, r, s, rows
+    torch.cuda.synchronize()
+    return {"item_distribution": item_dist, "us_per_step": round(dt / K * 1e6, 2),
+            "interactions_per_s": round(K * BATCH / dt, 1), "step": kind,
+            "distinct_user_rows_per_batch": round(uniq_u, 1), "distinct_item_rows_per_batch": round(uniq_i, 1),
+            "bytes_definition": "SURVEY.md 8-d unique rows: 8*R*B + 4*(1+S)*B + distinct rows * D * (4 + 8 + 12)",
+            "algorithmic_bytes_per_step": int(step_bytes), "bytes_per_interaction": round(step_bytes / BATCH, 1),
+            "achieved_GBps": round(gbs, 1), "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4)}
+
+
 def stream_copy_ceiling(device, n_bytes=1 << 30, reps=10):
     """On-box streaming ceiling: device-to-device copy of 1 GiB, read + write bytes per second."""
     src = torch.empty(n_bytes // 4, dtype=torch.float32, device=device).normal_()
@@ -278,6 +337,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly instead of one hipGraph")
     ap.add_argument("--graph-only", action="store_true", help="do not also time eager launches (single-GPU default: both)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-shapes", action="store_true", help="skip the grouped / zipf blocks of the default FOCF run")
     ap.add_argument("--item-dist", default="uniform", choices=["uniform", "zipf", "grouped", "unique"])
     ap.add_argument("--sweep", type=int, default=None, help="lazy-Adam sweep period (default: auto)")
     ap.add_argument("--force-sharded", action="store_true", help="use the row-sharded engine even on one GPU")
@@ -534,15 +594,26 @@ def main():
         dom = max(chain, key=chain.get)
         algo_bytes = ALGO_BYTES_PER_INTERACTION * BATCH
         achieved = algo_bytes / (per_kernel[dom] * 1e-6) / 1e9
-        traffic = None
+        traffic, traffic_stale = None, None
         pmc_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc_file):
-            traffic = json.load(open(pmc_file)).get(dom)
+            pmc = json.load(open(pmc_file))
+            traffic = pmc.get(dom)
+            # the figure is a stored one (the last profiles/collect.sh pass): say so when the kernel sources have moved since
+            import hashlib
+            src = os.path.join(ROOT, "recbole-fairrec_amd", "csrc")
+            now = hashlib.sha1(b"".join(open(os.path.join(src, f), "rb").read()
+                                        for f in ("focf_step.hip", "focf_ws.hpp", "common.hpp"))).hexdigest()
+            traffic_stale = pmc.get("_kernel_source_sha1") != now
+            if traffic is not None and traffic_stale:
+                print("[bench] roofline.traffic comes from profiles/pmc_traffic.json, collected on OTHER kernel sources than "
+                      "the ones running now: re-run profiles/collect.sh", file=sys.stderr)
         copy_gbs = stream_copy_ceiling(dev)
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                     # `traffic` is not measured by this run: it is the PMC figure of the last profiles/collect.sh pass
                     "traffic_source": "profiles/pmc_traffic.json" if traffic is not None else None,
+                    "traffic_stale": traffic_stale if traffic is not None else None,
                     "measured_copy_ceiling": round(copy_gbs, 1), "frac_of_measured_ceiling": round(achieved / copy_gbs, 4),
                     "algorithmic_bytes_per_launch": algo_bytes,
                     # ... plus the launch's slice of the bounded-staleness sweep (rows / period, p m v read and written, last
@@ -600,6 +671,15 @@ def main():
                        "aged_steps": None if sharded else n_age},
             "roofline": roofline,
         }
+        if world == 1 and not sharded and args.item_dist == "uniform" and not args.no_shapes:
+            # the figure of record is the uniform run above; the item-complete shape FOCF's real loader
+            # produces (and a popularity-skewed one) are reported next to it, each under the bytes definition it names
+            if graph is not None:
+                graph.reset()
+                graph = None
+            del eng, U, I
+            torch.cuda.empty_cache()
+            out["other_batch_shapes"] = [focf_shape_block(d, K, W, dev, args.sweep) for d in ("grouped", "zipf")]
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
     # The JSON line is the LAST thing on stdout: RCCL's banner sits in C stdio buffers until flushed, so flush first.

@@ -210,8 +210,9 @@ FR_API int fr_focf_backward_adam(const fr_table* U, const fr_table* I, const fr_
  *   fr_focf_step         : the step (U->step == I->step = the step being applied).  `stamp` = the value given to
  *                          fr_focf_prepare_step for this batch.  The loss needs every wave of the launch, so it is
  *                          reduced LATER: by the next fr_focf_step (prev_ws / prev_B / prev_loss_out name the earlier
- *                          batch; one extra workgroup) or by fr_focf_step_finish.  loss_acc (device float[3], may be
- *                          NULL) += (loss, mse, fair) of every reduced batch: a running total for epoch loops.
+ *                          batch; one extra workgroup) or by fr_focf_step_finish.  loss_acc (device float[8], may be
+ *                          NULL): [0..2] += (loss, mse, fair) of every reduced batch, [3] += 1, [4] = 1-based index of the
+ *                          first reduced batch whose loss was NaN (sticky; 0 = none): a running total for epoch loops.
  *                          loss_out is where THIS batch's loss will be written by that later reduction (recorded by the
  *                          caller; not written here).
  *   fr_focf_step_finish  : the reduction for a batch no later step will reduce (end of an epoch, before reading).
@@ -505,6 +506,13 @@ FR_API int fr_dropout_apply(const float* x, int64_t n, float p, uint64_t seed, u
 FR_API int fr_dropout_apply2(const float* x0, int64_t n0, uint64_t offset0, float* out0, const float* x1, int64_t n1,
                              uint64_t offset1, float* out1, float p, uint64_t seed, const int64_t* counter,
                              int64_t* used_out, int64_t* tick_state, void* stream);
+
+/* The running loss total of a step loop that reads its losses once per epoch (trainer.py:184-193 reads `.item()` and checks
+ * `isnan` every step: two host syncs per step).  acc = device float[8]: acc[0..n-1] += part[0..n-1] (n <= 3 loss values of this
+ * step), acc[3] += 1 (steps so far), and the FIRST step whose loss was not a number is remembered in acc[4] (1-based, 0 =
+ * none; sticky): the ValueError('Training loss is nan') raised at the epoch's end names the step the reference would have
+ * stopped at.  The one-launch FOCF steps keep the same record in their `loss_acc` (csrc/focf_loss.hpp). */
+FR_API int fr_loss_accumulate(const float* part, int32_t n, float* acc, void* stream);
 
 /* n <= FR_COPY_MAX device-to-device copies of bytes[j] bytes in ONE launch (jobs must not overlap each other). */
 #define FR_COPY_MAX 16

@@ -65,6 +65,12 @@ for k in sorted(set(fetch) | set(write)):
     traffic[k] = int(rb + wb)
     lines.append(f"| {k} | {len(fetch.get(k, []))} | {fm:.1f} | {wm:.1f} | {rb / 1e6:.2f} | {wb / 1e6:.2f} | {(rb + wb) / 1e6:.2f} |")
 open(os.path.join(dst, f"{rnd}_pmc.md"), "w").write("\n".join(lines) + "\n")
+# what the counters were collected ON: bench.py compares this with the sources it runs and flags a stale figure
+import hashlib
+_src = os.path.join(os.path.dirname(dst), "recbole-fairrec_amd", "csrc")
+traffic["_kernel_source_sha1"] = hashlib.sha1(b"".join(open(os.path.join(_src, f), "rb").read() for f in
+                                                       ("focf_step.hip", "focf_ws.hpp", "common.hpp"))).hexdigest()
+traffic["_round"] = rnd
 json.dump(traffic, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
 print("\n".join(lines))
 

@@ -78,6 +78,11 @@ __device__ __forceinline__ void step_reduce_loss(const PrevLoss& pl) {
             pl.acc[0] += loss;
             pl.acc[1] += mse;
             pl.acc[2] += fairv;
+            // a sticky record of the FIRST step whose loss was not a number (trainer.py:192 raises at that step; here the
+            // epoch's sum is read once, and this says where it went wrong): [3] = steps reduced into the total so far,
+            // [4] = 1-based index of the first NaN step among them, 0 = none (fr_loss_accumulate keeps the same record)
+            pl.acc[3] += 1.f;
+            if (loss != loss && pl.acc[4] == 0.f) pl.acc[4] = pl.acc[3];
         }
     }
     if (pl.cp && threadIdx.x < FOCF_CP_INTS) pl.cp[threadIdx.x] = 0;      // nothing of the batch is needed any more

@@ -42,7 +42,7 @@
 namespace fr {
 
 #ifndef FR_RUN_WAVES
-#define FR_RUN_WAVES 8
+#define FR_RUN_WAVES 16     // 8: 62 us per step, 16: 54-56, 4: 86 (BASELINE sizes, item-complete batches; see the kernel)
 #endif
 constexpr int RUN_WAVES = FR_RUN_WAVES;
 constexpr int RUN_THREADS = 64 * RUN_WAVES;
@@ -69,8 +69,25 @@ struct RunArgs {
 
 namespace {
 
-__device__ __forceinline__ float ld1(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void st1(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// Every pointer of this kernel comes out of v_readlane as an integer, i.e. as a GENERIC pointer: left like that, every access
+// is a flat_ instruction (per-lane 64-bit address, LDS aperture check, both wait counters).  The casts below say "global".
+typedef __attribute__((address_space(1))) float gfloat_;
+typedef __attribute__((address_space(1))) int32_t gint_;
+typedef __attribute__((address_space(1))) unsigned int guint_;
+typedef int v4i__ __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) v4i__ gint4_;
+__device__ __forceinline__ const gfloat_* G(const float* p) { return (const gfloat_*)p; }
+__device__ __forceinline__ gfloat_* G(float* p) { return (gfloat_*)p; }
+__device__ __forceinline__ const gint_* G(const int32_t* p) { return (const gint_*)p; }
+__device__ __forceinline__ gint_* G(int32_t* p) { return (gint_*)p; }
+__device__ __forceinline__ guint_* G(unsigned int* p) { return (guint_*)p; }
+__device__ __forceinline__ int4 ld4(const int4* p, long long i) {
+    const v4i__ v = ((const gint4_*)p)[i];
+    return make_int4(v.x, v.y, v.z, v.w);
+}
+
+__device__ __forceinline__ float ld1(const float* p) { return __hip_atomic_load(G(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st1(float* p, float v) { __hip_atomic_store(G(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 template <int E>
@@ -93,7 +110,50 @@ __device__ __forceinline__ void store_row1(const RowFrag<E>& f, float* base, int
     }
 }
 
+template <int E>
+__device__ __forceinline__ void gload_row(RowFrag<E>& f, const float* base, int D, int lane) {       // plain, global
+    const gfloat_* g = G(base);
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int d = lane + 64 * e;
+        f.x[e] = d < D ? g[d] : 0.f;
+    }
+}
+
+template <int E>
+__device__ __forceinline__ void gstore_row(const RowFrag<E>& f, float* base, int D, int lane) {
+    gfloat_* g = G(base);
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int d = lane + 64 * e;
+        if (d < D) g[d] = f.x[e];
+    }
+}
+
 __device__ __forceinline__ int4 uni4(int4 v) { return make_int4(uniform(v.x), uniform(v.y), uniform(v.z), uniform(v.w)); }
+
+// The kernel's argument block, taken ONCE through VGPRs: lane l of register i loads dword 64 i + l of the kernarg segment (one
+// vector load per 64 dwords), every field is then a v_readlane away.  Left to scalar loads, the ~100 fields of RunArgs do not
+// fit the SGPR file: the compiler re-fetches them where they are used, each behind its own s_waitcnt, and with thousands of
+// waves starting at once those loads miss the small scalar caches (several us per dependent level: the same finding as
+// focf_step.hip's KV).  Values that came out of v_readlane cannot be re-fetched, so under pressure they are spilled to VGPR
+// lanes instead -- no memory round trip either way.
+template <typename T>
+__device__ __forceinline__ T args_through_vgprs(int lane) {
+    constexpr int ND = (int)((sizeof(T) + 3) / 4);
+    static_assert(ND <= 256, "argument block too large for four VGPRs of dwords");
+    const unsigned* kp = reinterpret_cast<const unsigned*>(
+        (const void*)(const __attribute__((address_space(4))) void*)__builtin_amdgcn_kernarg_segment_ptr());
+    unsigned v[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int i = 0; i < (ND + 63) / 64; ++i) v[i] = 64 * i + lane < ND ? kp[64 * i + lane] : 0u;
+    unsigned d[ND];
+#pragma unroll
+    for (int i = 0; i < ND; ++i) d[i] = (unsigned)__builtin_amdgcn_readlane((int)v[i >> 6], i & 63);
+    T out;
+    __builtin_memcpy(&out, d, sizeof(T));
+    return out;
+}
 
 }  // namespace
 
@@ -105,18 +165,18 @@ __device__ __forceinline__ void run_finish_item(const RunArgs& a, int k, int ij0
     const FocfWs& w = a.w;
     const int D = a.U.D, step = a.U.step, B = a.B;
     const bool per_item = a.objective >= FR_FOCF_VALUE && a.objective <= FR_FOCF_OVER;
-    const float smin = w.sst_minmax[0];
+    const float smin = G(w.sst_minmax)[0];
     // (a) the per-(item, group) sums of focf.py:75-91 in focf_fair_kernel<64>'s order: lane `sub` takes members sub, sub + 64,
     //     ... one after the other, then the butterfly
     if (wv == 0) {
         float term = 0.f, g0 = 0.f, g1 = 0.f;
         if (per_item) {
-            const float smax = w.sst_minmax[1];
+            const float smax = G(w.sst_minmax)[1];
             float sp0 = 0.f, sp1 = 0.f, st0 = 0.f, st1_ = 0.f, n0 = 0.f, n1 = 0.f;
             bool bad = false;
             for (int j = ij0 + lane; j < ij0 + n; j += 64) {
-                const int b = w.perm_i[j];
-                const int4 rc = w.rec[b];
+                const int b = G(w.perm_i)[j];
+                const int4 rc = ld4(w.rec, b);
                 const float pr = ld1(w.pred + b), r = __int_as_float(rc.z), s = __int_as_float(rc.w);
                 bad |= (s != smin && s != smax);
                 if (s == smin) {
@@ -129,12 +189,12 @@ __device__ __forceinline__ void run_finish_item(const RunArgs& a, int k, int ij0
             sp0 = group_sum<64>(sp0); sp1 = group_sum<64>(sp1);
             st0 = group_sum<64>(st0); st1_ = group_sum<64>(st1_);
             n0 = group_sum<64>(n0);   n1 = group_sum<64>(n1);
-            focf_fair_eval(a.objective, a.fair_weight, (float)w.nseg_i[0], sp0, sp1, st0, st1_, n0, n1, term, g0, g1);
+            focf_fair_eval(a.objective, a.fair_weight, (float)G(w.nseg_i)[0], sp0, sp1, st0, st1_, n0, n1, term, g0, g1);
         }
         if (lane == 0) {
             sh[0] = g0;
             sh[1] = g1;
-            w.term[k] = term;
+            G(w.term)[k] = term;
         }
     }
     __syncthreads();
@@ -156,9 +216,9 @@ __device__ __forceinline__ void run_finish_item(const RunArgs& a, int k, int ij0
         int4 lrc = make_int4(0, 0, 0, 0), linf = make_int4(0, 0, 0, 0);
         float lpr = 0.f;
         if (lane < mine) {
-            lb = w.perm_i[ij0 + base + wv + RUN_WAVES * lane];
-            lrc = w.rec[lb];
-            linf = w.info[lb];
+            lb = G(w.perm_i)[ij0 + base + wv + RUN_WAVES * lane];
+            lrc = ld4(w.rec, lb);
+            linf = ld4(w.info, lb);
             lpr = ld1(w.pred + lb);
         }
         constexpr int MB = 4;
@@ -209,14 +269,23 @@ __device__ __forceinline__ void run_finish_item(const RunArgs& a, int k, int ij0
                     if (lane == 0) st1(w.coef + b, coef);
                     drain();
                     unsigned old = 0;
-                    if (lane == 0) old = __hip_atomic_fetch_add(w.cnt_u + useg, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (lane == 0) old = __hip_atomic_fetch_add(G(w.cnt_u) + useg, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     old = (unsigned)uniform((int)old);
                     finish = (int)old + 1 == nu;
                     if (finish) {
+                        // the caught-up state of the user's FIRST member, as segment_update takes it: every occurrence
+                        // replayed the row beside another neighbour (another cut of the replay: a few ulp apart), and which of
+                        // them arrives last must not show in the result
+                        const int bf = uniform(G(w.perm_u)[uj0]);
+                        if (bf != b) {
+                            load_row1<E>(pu[u], w.side[0] + (size_t)bf * D, D, lane);
+                            load_row1<E>(mu[u], w.side[1] + (size_t)bf * D, D, lane);
+                            load_row1<E>(vu[u], w.side[2] + (size_t)bf * D, D, lane);
+                        }
                         for (int ju = uj0; ju < uj0 + nu; ++ju) {
-                            const int bb = uniform(w.perm_u[ju]);
+                            const int bb = uniform(G(w.perm_u)[ju]);
                             const float cb = ld1(w.coef + bb);
-                            const int kk = uniform(w.info[bb].w);
+                            const int kk = uniform(ld4(w.info, bb).w);
                             RowFrag<E> o;
                             load_row1<E>(o, w.side[3] + (size_t)kk * D, D, lane);
                             {
@@ -233,10 +302,10 @@ __device__ __forceinline__ void run_finish_item(const RunArgs& a, int k, int ij0
                 if (finish) {
 #pragma unroll
                     for (int e = 0; e < E; ++e) adam_elem(pu[u].x[e], mu[u].x[e], vu[u].x[e], g.x[e], sc.x, sc.y, a.c);
-                    store_row<E>(pu[u], a.U.p + (size_t)ur * D, D, lane);
-                    store_row<E>(mu[u], a.U.m + (size_t)ur * D, D, lane);
-                    store_row<E>(vu[u], a.U.v + (size_t)ur * D, D, lane);
-                    if (lane == 0) a.U.last[ur] = step;
+                    gstore_row<E>(pu[u], a.U.p + (size_t)ur * D, D, lane);
+                    gstore_row<E>(mu[u], a.U.m + (size_t)ur * D, D, lane);
+                    gstore_row<E>(vu[u], a.U.v + (size_t)ur * D, D, lane);
+                    if (lane == 0) G(a.U.last)[ur] = step;
                 }
             }
         }
@@ -260,18 +329,19 @@ __device__ __forceinline__ void run_finish_item(const RunArgs& a, int k, int ij0
         RowFrag<E> mi, vi;
         load_row1<E>(mi, w.side[4] + (size_t)k * D, D, lane);
         load_row1<E>(vi, w.side[5] + (size_t)k * D, D, lane);
-        const int ir = uniform(w.seg_row_i[k]);
+        const int ir = uniform(G(w.seg_row_i)[k]);
 #pragma unroll
         for (int e = 0; e < E; ++e) adam_elem(pi.x[e], mi.x[e], vi.x[e], gi.x[e], sc.x, sc.y, a.c);
-        store_row<E>(pi, a.I.p + (size_t)ir * D, D, lane);
-        store_row<E>(mi, a.I.m + (size_t)ir * D, D, lane);
-        store_row<E>(vi, a.I.v + (size_t)ir * D, D, lane);
-        if (lane == 0) a.I.last[ir] = step;
+        gstore_row<E>(pi, a.I.p + (size_t)ir * D, D, lane);
+        gstore_row<E>(mi, a.I.m + (size_t)ir * D, D, lane);
+        gstore_row<E>(vi, a.I.v + (size_t)ir * D, D, lane);
+        if (lane == 0) G(a.I.last)[ir] = step;
     }
 }
 
 template <int E>
-__global__ __launch_bounds__(RUN_THREADS) void focf_runs_kernel(RunArgs a) {
+__global__ __launch_bounds__(RUN_THREADS) void focf_runs_kernel(RunArgs a_kernarg) {
+    const RunArgs a = args_through_vgprs<RunArgs>((int)(threadIdx.x & 63));       // (the ONLY kernel argument: offset 0)
     constexpr int PW = run_pw(E), C = run_chunk(E), CAP = run_cap(E);
     constexpr int ROW = 64 * E;
     // LDS: stage 1 = the caught-up item rows of the chunk's leads [C][ROW]; stage 2 = a pass of user rows [CAP][ROW] + coefs
@@ -291,10 +361,34 @@ __global__ __launch_bounds__(RUN_THREADS) void focf_runs_kernel(RunArgs a) {
         return;
     }
     blk -= 1;
-    if (blk >= a.n_chunks) {             // the step's slice of the bounded-staleness sweep: one wave per pair of rows
-        const long long wave = (long long)(blk - a.n_chunks) * RUN_WAVES + wv;
-        if (wave < a.n_sweep_waves) sweep_slice_wave<E>(a.U, a.I, a.c, a.sw, wave, lane);
-        return;
+    // Chunk workgroups first, sweeper workgroups behind them (FR_RUN_INTERLEAVE=1 alternates the two kinds instead).  Measured
+    // at the BASELINE sizes, item-complete batches, hipGraph replay: chunk-first 62 us per step with 8 waves per chunk and 54-56
+    // with 16; alternating 84 -- at 75-89 VGPRs only one or two of these workgroups fit a CU, so every sweeper workgroup dealt
+    // in early pushes a chunk workgroup (a long chain of dependent round trips) to a later round.
+    {
+        const int n_sw = (int)((a.n_sweep_waves + RUN_WAVES - 1) / RUN_WAVES);
+        bool sweeper;
+        int idx;
+#if defined(FR_RUN_INTERLEAVE)
+        const int both = min(a.n_chunks, n_sw);
+        if (blk < 2 * both) {
+            sweeper = (blk & 1) != 0;
+            idx = blk >> 1;
+        } else {
+            sweeper = n_sw > a.n_chunks;
+            idx = blk - both;
+        }
+#else
+        (void)n_sw;
+        sweeper = blk >= a.n_chunks;
+        idx = sweeper ? blk - a.n_chunks : blk;
+#endif
+        if (sweeper) {                   // the step's slice of the bounded-staleness sweep: one wave per pair of rows
+            const long long wave = (long long)idx * RUN_WAVES + wv;
+            if (wave < a.n_sweep_waves) sweep_slice_wave<E>(a.U, a.I, a.c, a.sw, wave, lane);
+            return;
+        }
+        blk = idx;
     }
     const int D = a.U.D, step = a.U.step, B = a.B;
     const int cstart = blk * C, cend = min(B, cstart + C);
@@ -312,9 +406,9 @@ __global__ __launch_bounds__(RUN_THREADS) void focf_runs_kernel(RunArgs a) {
         bpos[t] = 0; ijs[t] = 0; ins[t] = 0; iks[t] = 0; irs[t] = 0; urs[t] = 0; tu[t] = step - 1; rat[t] = 0.f;
         lead[t] = false;
         if (val[t]) {
-            const int b = uniform(w.perm_i[j]);
-            const int4 rc = uni4(w.rec[b]);
-            const int4 inf = uni4(w.info[b]);
+            const int b = uniform(G(w.perm_i)[j]);
+            const int4 rc = uni4(ld4(w.rec, b));
+            const int4 inf = uni4(ld4(w.info, b));
             bpos[t] = b;
             urs[t] = rc.x;
             irs[t] = rc.y;
@@ -328,10 +422,10 @@ __global__ __launch_bounds__(RUN_THREADS) void focf_runs_kernel(RunArgs a) {
 #pragma unroll
     for (int t = 0; t < PW; ++t) {
         if (val[t]) {
-            const int lu = a.U.last[urs[t]];
-            load_row<E>(pu[t], a.U.p + (size_t)urs[t] * D, D, lane);
-            load_row<E>(mu[t], a.U.m + (size_t)urs[t] * D, D, lane);
-            load_row<E>(vu[t], a.U.v + (size_t)urs[t] * D, D, lane);
+            const int lu = G(a.U.last)[urs[t]];
+            gload_row<E>(pu[t], a.U.p + (size_t)urs[t] * D, D, lane);
+            gload_row<E>(mu[t], a.U.m + (size_t)urs[t] * D, D, lane);
+            gload_row<E>(vu[t], a.U.v + (size_t)urs[t] * D, D, lane);
             tu[t] = uniform(lu);
         }
     }
@@ -341,10 +435,10 @@ __global__ __launch_bounds__(RUN_THREADS) void focf_runs_kernel(RunArgs a) {
     for (int t = 0; t < PW; ++t) {
         if (val[t] && lead[t]) {
             RowFrag<E> pi, mi, vi;
-            const int li = a.I.last[irs[t]];
-            load_row<E>(pi, a.I.p + (size_t)irs[t] * D, D, lane);
-            load_row<E>(mi, a.I.m + (size_t)irs[t] * D, D, lane);
-            load_row<E>(vi, a.I.v + (size_t)irs[t] * D, D, lane);
+            const int li = G(a.I.last)[irs[t]];
+            gload_row<E>(pi, a.I.p + (size_t)irs[t] * D, D, lane);
+            gload_row<E>(mi, a.I.m + (size_t)irs[t] * D, D, lane);
+            gload_row<E>(vi, a.I.v + (size_t)irs[t] * D, D, lane);
             replay<E>(pi, mi, vi, uniform(li), step - 1, a.c, lane);
             const int slot = wv * PW + t;
 #pragma unroll
@@ -383,7 +477,7 @@ __global__ __launch_bounds__(RUN_THREADS) void focf_runs_kernel(RunArgs a) {
             if (lane == 0) {
                 const float er = dot - rat[t];
                 st1(w.pred + b, dot);
-                w.mse_e[b] = er * er;
+                G(w.mse_e)[b] = er * er;
             }
         }
     }
@@ -393,7 +487,7 @@ __global__ __launch_bounds__(RUN_THREADS) void focf_runs_kernel(RunArgs a) {
     for (int t = 0; t < PW; ++t) {
         if (val[t] && lead[t] && lane == 0) {
             const int in_chunk = min(ijs[t] + ins[t], cend) - max(ijs[t], cstart);
-            const unsigned old = __hip_atomic_fetch_add(w.cnt_i + iks[t], (unsigned)in_chunk, __ATOMIC_RELAXED,
+            const unsigned old = __hip_atomic_fetch_add(G(w.cnt_i) + iks[t], (unsigned)in_chunk, __ATOMIC_RELAXED,
                                                         __HIP_MEMORY_SCOPE_AGENT);
             if ((int)old + in_chunk == ins[t]) {
                 const int slot = atomicAdd(&fin[0], 1);
@@ -417,7 +511,9 @@ __global__ __launch_bounds__(RUN_THREADS) void focf_runs_kernel(RunArgs a) {
         if (threadIdx.x == 0)
             for (int q = 0; q < nfin; ++q)
                 if (fin[1 + q] == kmin) fin[1 + q] = -1;
+#if !defined(FR_RUN_SKIP_STAGE2)      // (diagnostic builds only: what stage 1 costs alone)
         run_finish_item<E>(a, kmin, arg & 0xffff, (arg >> 16) & 0xffff, lds_rows, coef_s, sh, lane, wv);
+#endif
         __syncthreads();
     }
 }

@@ -192,3 +192,24 @@ extern "C" int fr_prof_read(int kind, double* total_ms, int64_t* count) {
     *count = g_prof.count[kind];
     return FR_OK;
 }
+
+// ---- running loss total of a step loop, with a sticky record of the first NaN step ------------------------------------
+namespace fr {
+__global__ void loss_accumulate_kernel(const float* __restrict__ part, int n, float* __restrict__ acc) {
+    bool bad = false;
+    for (int q = 0; q < n; ++q) {
+        const float x = part[q];
+        acc[q] += x;
+        bad |= x != x;
+    }
+    acc[3] += 1.f;
+    if (bad && acc[4] == 0.f) acc[4] = acc[3];
+}
+}  // namespace fr
+
+extern "C" int fr_loss_accumulate(const float* part, int32_t n, float* acc, void* stream) {
+    FR_CHECK_ARG(part && acc && n >= 1 && n <= 3, "fr_loss_accumulate: 1..3 loss values, acc = float[8]");
+    hipLaunchKernelGGL(fr::loss_accumulate_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, part, (int)n, acc);
+    FR_CHECK_LAUNCH();
+    return FR_OK;
+}

@@ -94,7 +94,8 @@ class FocfEngine:
         self._prev = None               # (workspace, B, loss view) of the last fused step, its loss not reduced yet
         self._stamp_last = 0            # stamps handed to fr_focf_prepare_step never decrease
         self._stamp_gen = (self.U.stamp_gen, self.I.stamp_gen)
-        self.loss_acc = torch.zeros(4, dtype=torch.float32, device=self.device)   # running (loss, mse, fair) total
+        # running (loss, mse, fair) total, [3] = steps in it, [4] = 1-based index of the first NaN step (0 = none; sticky)
+        self.loss_acc = torch.zeros(8, dtype=torch.float32, device=self.device)
         self.staged = self.STAGED
         self._st = {}                   # batch key -> entry of a batch on its way through the claim / place stages
         self._row_words = None          # [3][n_users + n_items] 64-bit words (fr_focf_row_words), zero to begin with
@@ -486,8 +487,9 @@ class FocfEngine:
                                                 self._sweep(B), self.ws[self.ws_cur].data_ptr(),
                                                 self.ws[self.ws_cur].numel(), _C.current_stream())
             _C.check(rc, "fr_focf_backward_adam")
-            if self.defer_loss:         # keep the running total the one-launch step keeps on the device
-                self.loss_acc[:3] += self._loss_views[self.loss_slot][:3]
+            if self.defer_loss:         # keep the running total the one-launch step keeps on the device (and its NaN record)
+                _C.check(_C.lib().fr_loss_accumulate(self._loss_views[self.loss_slot].data_ptr(), 3, self.loss_acc.data_ptr(),
+                                                     _C.current_stream()), "fr_loss_accumulate")
         self.U.step += 1
         self.I.step += 1
         self.U._dirty = self.I._dirty = True
@@ -628,10 +630,18 @@ class FOCF(FairRecommender):
         return self.hip_engine().predict(u, i)
 
     def full_sort_predict(self, interaction):
+        """focf.py:171-178: clamp(U[user] @ I^T, 0, max_rating) / max_rating over ALL items, flattened [b * n_items].  The
+        users' rows come caught-up from the lazy table (fr_table_gather), the item table is flushed once (every row is read),
+        the product runs on the library's fp32-MFMA kernel (fr_linear_fwd: Y = X W^T with W = the [n_items, D] item table)."""
         eng = self.hip_engine()
-        eng.flush()
-        user = interaction[self.USER_ID].to(eng.device)
-        scores = torch.mm(self.user_embedding_layer.weight.data[user], self.item_embedding_layer.weight.data.t())
+        eng.finish()
+        eng.I.flush(eng.hyper)
+        user = interaction[self.USER_ID].to(eng.device, torch.int64).contiguous()
+        ue = eng.U.gather(eng.hyper, user, eng.err_flag)
+        W = self.item_embedding_layer.weight.data
+        scores = torch.empty((user.numel(), W.shape[0]), dtype=torch.float32, device=eng.device)
+        _C.check(_C.lib().fr_linear_fwd(ue.data_ptr(), ue.shape[1], None, 0, None, 1.0, W.data_ptr(), None, user.numel(),
+                                        W.shape[0], 0, scores.data_ptr(), _C.current_stream()), "fr_linear_fwd")
         return (torch.clamp(scores, min=0., max=eng.max_rating) / eng.max_rating).view(-1)
 
     def state_dict(self, *args, **kwargs):

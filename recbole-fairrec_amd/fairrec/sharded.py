@@ -269,7 +269,9 @@ class _Buffers:
 class ShardedFocfEngine:
     def __init__(self, user_shard: torch.Tensor, item_shard: torch.Tensor, objective: str, fair_weight: float,
                  lr: float, weight_decay: float, group=None, capacity_factor: float = 2.0, ops=None,
-                 sweep_period: Optional[int] = None):
+                 sweep_period: Optional[int] = None, strict_overflow: bool = True):
+        # strict_overflow: never apply a step in which an exchange bucket overflowed (`_settle_capacity`)
+        self.strict_overflow = strict_overflow
         self.group = group
         self.G = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
@@ -322,6 +324,45 @@ class ShardedFocfEngine:
         self._a2a(b.ids_recv[sel], b.ids_send[sel])
         self.ops.sort_pair(self.U, self.I, b.ids_recv[sel], 0, cap, G * cap, cap, S, b.ws_u[sel], b.ws_i[sel], self.err)
 
+    def _settle_capacity(self, b: _Buffers, sel: int, user, item, sst, bucketed: bool):
+        """NEVER DROP AN INTERACTION.  fr_bucket_by_owner gives an interaction whose owner's bucket is full slot -1 and sets
+        a device error bit; left at that, the step would apply the rest of the batch and the error would surface at the
+        epoch's check.  Here, before anything of the step is exchanged for good: did ANY rank overflow ANY bucket (one MAX
+        all-reduce of a flag + one host read per step -- the price of the guarantee; skipped inside a stream capture, where
+        a host read has no place and the caller vouches for its batches)?  Then the exchange capacity is doubled and the
+        batch bucketed again (item-complete batches put whole item histories on few owners: the default factor 2 is for
+        uniform ids); when the capacity is already what one owner can sort per launch (FR_SORT_MAX // G), the step is
+        REFUSED with nothing applied on any rank.  Returns the buffers to use and whether the id exchange is still to do."""
+        B = user.numel()
+        capturing = torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
+        if not self.strict_overflow or capturing:
+            return b, not bucketed
+        redo = not bucketed
+        for _ in range(8):
+            if redo:
+                self._prepare_bucket(b, sel, user, item, sst)
+            flag = ((b.slot_u[sel] < 0).any() | (b.slot_i[sel] < 0).any()).to(torch.int32).reshape(1)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group)
+            if not bool(flag.item()):
+                return b, redo
+            self.ops.join_side()                    # whatever ran ahead for this batch used the too-small buffers
+            self._prep_key = None
+            self.err.bitwise_and_(~_C.DEV_ERR_BUCKET_OVERFLOW)
+            old = b.cap
+            if capacity_is_sort_bound(B, self.G, self.capacity_factor) or old >= B:
+                raise _C.FairrecError(
+                    f"an exchange bucket overflowed (skewed ids) and its capacity {old} is already the most one owner can sort "
+                    f"per launch (FR_SORT_MAX // G = {SORT_MAX // self.G}): lower the per-rank batch size.  Nothing of this "
+                    "step was applied on any rank")
+            self.capacity_factor *= 2.0
+            self._buf = None
+            b = self._buffers(B)
+            if b.cap <= old:
+                raise _C.FairrecError(f"an exchange bucket overflowed and the capacity cannot grow beyond {old}: lower the "
+                                      "per-rank batch size.  Nothing of this step was applied on any rank")
+            redo = True
+        raise _C.FairrecError("exchange capacity did not settle")
+
     def forward(self, user, item, rating, sst, next_batch=None):
         """Everything up to the loss of the global batch and the gradient rows; returns (loss as a 0-dim device
         tensor, pred [B]).  next_batch = (user, item, sst) of the FOLLOWING step, when known (dataloader look-ahead):
@@ -330,18 +371,25 @@ class ShardedFocfEngine:
         B = user.numel()
         self._last_B = B
         b = self._buffers(B)
-        cap, S, sel = b.cap, b.S, self._sel
-        n_slots = G * cap
+        sel = self._sel
         fair = self.objective not in ("none", "nonparity")     # per-item statistics on the owners (rec / reply exchange)
         nonparity = self.objective == "nonparity"
         if self._prep_key == self._key(user, item):
             ops.join_side()
+            b2, todo = self._settle_capacity(b, sel, user, item, sst, bucketed=True)
+            if b2 is not b or todo:             # the look-ahead's exchange used buckets that overflowed: again, larger
+                b = b2
+                self._prepare_exchange(b, sel)
         else:
             if self._prep_key is not None:      # a look-ahead for some other batch is in flight: let it finish first
                 ops.join_side()
-            self._prepare_bucket(b, sel, user, item, sst)
+            b, _ = self._settle_capacity(b, sel, user, item, sst, bucketed=False)
+            if not self.strict_overflow or (torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()):
+                self._prepare_bucket(b, sel, user, item, sst)
             self._prepare_exchange(b, sel)
         self._prep_key = None
+        cap, S = b.cap, b.S
+        n_slots = G * cap
         ahead = next_batch is not None and next_batch[0].numel() == B
         if ahead:   # the next step's bucket kernel starts now, beside this step's gather
             ops.used_on_side(next_batch)

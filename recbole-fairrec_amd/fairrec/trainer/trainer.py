@@ -21,6 +21,7 @@ import collections
 import numpy as np
 import torch
 
+from .. import _C
 from ..optim import FusedLazyAdam
 from ..sampler import host_numpy_stream
 from ..utils import calculate_valid_score, dict2str, early_stopping, ensure_dir, get_local_time
@@ -144,8 +145,7 @@ class Trainer(AbstractTrainer):
             if hint is not None:
                 hint(*queue)                           # lets the model start the coming batches' index sorts early
             if graphed is not None:
-                part = graphed(interaction).view(1)
-                total = part.clone() if total is None else total + part
+                total = self._accumulate(total, graphed(interaction).view(1))
                 continue
             if fused:
                 with torch.no_grad():
@@ -162,7 +162,7 @@ class Trainer(AbstractTrainer):
             else:
                 loss = losses
                 part = losses.detach().view(1)
-            total = part.clone() if total is None else total + part
+            total = self._accumulate(total, part)
             loss.backward()
             self.optimizer.step()
         if total is None:
@@ -170,22 +170,37 @@ class Trainer(AbstractTrainer):
         if total is True:
             eng = self.model.hip_engine()
             eng.finish()
-            total = eng.loss_acc[:1]
-        vals = total.cpu().tolist()                 # the epoch's only host sync
-        self._check_nan(torch.tensor(vals))
+            total = eng.loss_acc
+            n_tuple_or_one = 1
+        else:
+            n_tuple_or_one = max(n_tuple, 1)
+        acc = total.cpu().tolist()                  # the epoch's only host sync
+        vals = acc[:n_tuple_or_one]
+        self._check_nan(torch.tensor(vals), first_bad_step=int(acc[4]))
         eng = self.model.hip_engine()
         if eng is not None:
             eng.check_device_errors()
         return tuple(vals) if n_tuple else vals[0]
 
-    def _check_nan(self, loss):
+    def _accumulate(self, acc, part):
+        """acc[0..n-1] += the step's n loss values on the device, plus the sticky record of the first NaN step
+        (fr_loss_accumulate: one launch, what `total + part` cost before)."""
+        part = part.detach().reshape(-1).to(torch.float32).contiguous()
+        if acc is None:
+            acc = torch.zeros(8, dtype=torch.float32, device=part.device)
+        _C.check(_C.lib().fr_loss_accumulate(part.data_ptr(), part.numel(), acc.data_ptr(), _C.current_stream()),
+                 "fr_loss_accumulate")
+        return acc
+
+    def _check_nan(self, loss, first_bad_step=0):
         """trainer.py:286-288 raises on the STEP whose loss is NaN, before its backward (trainer.py:192-193), at the price of
         one `.item()` host sync per step.  Here the per-step losses are summed on the device and the sum is looked at once
         per epoch: a NaN is sticky through the sum, so the same ValueError is raised for the same epoch -- but at its end,
         after the remaining steps of that epoch have been applied to parameters nobody will use (training aborts either
         way; the last checkpoint is from an earlier, finite epoch in both).  Deliberate deviation, stated in DESIGN.md §9."""
         if torch.isnan(loss).any():
-            raise ValueError('Training loss is nan')
+            # (same message as trainer.py:286-288; the step at which the reference would have stopped rides along)
+            raise ValueError('Training loss is nan' + (f' (first at step {first_bad_step} of this pass)' if first_bad_step else ''))
 
     def _valid_epoch(self, valid_data, show_progress=False):
         valid_result = self.evaluate(valid_data, load_best_model=False, show_progress=show_progress)
@@ -430,18 +445,18 @@ class PFCNTrainer(Trainer):
         for interaction in train_data:
             interaction = interaction.to(self.device)
             if graphed is not None:
-                loss = graphed(interaction)
-                total = loss.clone() if total is None else total + loss
+                total = self._accumulate(total, graphed(interaction))
                 continue
             self.optimizer.zero_grad()
             loss = loss_func(interaction, sst_list)
-            total = loss.detach().clone() if total is None else total + loss.detach()
+            total = self._accumulate(total, loss)
             loss.backward()
             self.optimizer.step()
         if total is None:
             return 0.0
-        val = float(total.item())
-        self._check_nan(torch.tensor(val))
+        acc = total.cpu().tolist()                  # the pass's only host sync
+        val = float(acc[0])
+        self._check_nan(torch.tensor(val), first_bad_step=int(acc[4]))
         self.model.hip_engine().check_device_errors()
         return val
 

@@ -36,6 +36,17 @@ def test_bench_json_contract(args):
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 0.0 < r["frac"] < 1.0
     assert d["config"]["final_loss"] == d["config"]["final_loss"]      # not NaN
+    if "--item-dist" not in args:
+        # the item-complete shape FOCF's real loader produces is reported next to the figure of record,
+        # under the unique-row bytes definition it names
+        shapes = {x["item_distribution"]: x for x in d["other_batch_shapes"]}
+        assert set(shapes) == {"grouped", "zipf"}
+        g = shapes["grouped"]
+        assert "unique rows" in g["bytes_definition"] and g["us_per_step"] > 0 and "fr_focf_step_runs" in g["step"]
+        assert 60 < g["distinct_item_rows_per_batch"] < 100 and g["bytes_per_interaction"] < 3096
+        assert abs(g["frac_of_hbm_peak"] - g["achieved_GBps"] / 8000.0) < 1e-3
+    else:
+        assert "other_batch_shapes" not in d
 
 
 def test_bench_nfcf_workload_contract():

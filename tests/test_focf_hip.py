@@ -383,11 +383,15 @@ def test_prefetch_queue_over_epochs_matches_plain_steps():
     I0 = (torch.randn(n_items, D, generator=g) * 0.05).cuda()
     gender = torch.randint(0, 2, (n_users,), generator=g).float()
     engs = []
-    for k in range(3):      # 0: plain steps; 1: prefetch queue, three-launch chain; 2: prefetch queue, one-launch step
+    # 0: plain steps; 1: prefetch queue, three-launch chain (item-complete hint, the one-launch runs step switched off);
+    # 2: prefetch queue, one-launch step; 3: prefetch queue, one-launch step for item-complete batches (fr_focf_step_runs)
+    for k in range(4):
         eng = FocfEngine(U0.clone(), I0.clone(), "value", 0.3, 5.0)
         FusedLazyAdam(eng, lr=5e-3, weight_decay=1e-3, sweep_period=7)
         eng.defer_loss = k >= 1
-        eng.item_runs = k == 1
+        eng.item_runs = k in (1, 3)
+        if k == 1:
+            eng.RUNS = False
         engs.append(eng)
     for epoch in range(3):
         batches = []
@@ -405,11 +409,11 @@ def test_prefetch_queue_over_epochs_matches_plain_steps():
             for eng in engs[1:]:
                 eng.forward(u, i, r, s, next_batch=queue)
                 eng.backward_adam()
-            assert engs[1]._prev is None and engs[2]._prev is not None
+            assert engs[1]._prev is None and engs[2]._prev is not None and engs[3]._prev is not None
         for eng in engs:
             eng.flush()                                              # evaluation / checkpoint between epochs
             eng.check_device_errors()
-        assert not engs[1]._prep and not engs[2]._prep, "the queue must be empty at an epoch end"
+        assert not engs[1]._prep and not engs[2]._prep and not engs[3]._prep, "the queue must be empty at an epoch end"
     a = engs[0]
     for b in engs[1:]:
         for x, y in ((b.U.weight, a.U.weight), (b.I.weight, a.I.weight), (b.U.v, a.U.v), (b.I.m, a.I.m)):

@@ -128,7 +128,7 @@ def _focf_from_fixture(z, tmp_path):
     from fairrec.config import Config
     from fairrec.data.dataset import synthetic_dataset
     from fairrec.utils import get_model, get_trainer
-    lr, wd, fw = (float(x) for x in z["hyper"])
+    lr, wd, fw = (float(x) for x in z["hyper"][:3])
     cfg = Config(model="FOCF", config_dict={"embedding_size": int(z["U0"].shape[1]), "fair_objective": "value",
                                             "fair_weight": fw, "learning_rate": lr, "weight_decay": wd, "device": "cuda",
                                             "checkpoint_dir": str(tmp_path), "epochs": 1})
@@ -209,3 +209,76 @@ def test_focf_dataloader_device_resident_matches_reference_golden():
         for col, key in (("user", "user_id"), ("item", "item_id"), ("rating", "rating")):
             np.testing.assert_array_equal(batch[key].cpu().numpy(), z[f"batch{b}_{col}"])
         np.testing.assert_array_equal(batch["gender"].cpu().numpy(), (z[f"batch{b}_user"] % 2).astype(np.float32))
+
+
+def test_full_sort_predict_values_match_the_oracle(tmp_path):
+    """a6, value level (focf.py:171-178): clamp(U[user] @ I^T, 0, max) / max over ALL items, after training steps that leave
+    rows of both lazy tables behind the optimizer step (no flush by the caller) -- against oracle.focf.predict on the
+    reference's weights after the same steps (golden focf_value: `U_after*`, produced by the reference's own run)."""
+    from fairrec.data.interaction import Interaction
+    from oracle import focf as O
+    z = np.load(os.path.join(GOLDEN, "focf_value.npz"))
+    cfg, model, trainer = _focf_from_fixture(z, tmp_path)
+    with torch.no_grad():
+        model.user_embedding_layer.weight.copy_(torch.from_numpy(z["U0"]))
+        model.item_embedding_layer.weight.copy_(torch.from_numpy(z["I0"]))
+    T = max(int(s) for s in z["snaps"])
+    for t in range(T):
+        b = Interaction({"user_id": torch.tensor(z["user_id"][t]), "item_id": torch.tensor(z["item_id"][t]),
+                         "rating": torch.tensor(z["rating"][t]), "gender": torch.tensor(z["sst"][t])}).to("cuda")
+        trainer.optimizer.zero_grad()
+        model.calculate_loss(b).backward()
+        trainer.optimizer.step()
+    eng = model.hip_engine()
+    assert eng.U._dirty and eng.I._dirty                       # rows are behind: full_sort_predict has to see them caught up
+    n_users, n_items = z["U0"].shape[0], z["I0"].shape[0]
+    users = torch.tensor([1, 2, 5, n_users - 1, 7, 7], device="cuda")
+    got = model.full_sort_predict(Interaction({"user_id": users})).cpu().numpy().reshape(len(users), n_items)
+    Uref, Iref = torch.from_numpy(z[f"U_after{T}"]), torch.from_numpy(z[f"I_after{T}"])
+    want = np.stack([O.predict(Uref, Iref, torch.full((n_items,), int(u)), torch.arange(n_items), 5.0).numpy()
+                     for u in users.cpu()])
+    assert got.shape == want.shape
+    np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-6)
+    assert 0.0 <= got.min() and got.max() <= 1.0 and (got > 0).any() and (got < 1).any()
+    # ... and pair by pair it is what predict() gives for the same (user, item)
+    pair = model.predict(Interaction({"user_id": users.repeat_interleave(n_items), "item_id": torch.arange(n_items, device="cuda").repeat(len(users))}))
+    np.testing.assert_allclose(got.reshape(-1), pair.cpu().numpy(), rtol=1e-5, atol=1e-6)
+    eng.check_device_errors()
+
+
+def test_nan_loss_names_the_step_it_first_appeared_at(tmp_path):
+    """trainer.py:192, :286-288 raise 'Training loss is nan' at the step whose loss is NaN; here the losses are summed on the
+    device and read once per epoch -- the sum carries a sticky record of the FIRST bad step (fr_loss_accumulate / the one-launch
+    steps' loss_acc[3:5]), so the same ValueError names the step the reference would have stopped at."""
+    from fairrec import _C
+    acc = torch.zeros(8, device="cuda")
+    for x in ([1.0, 2.0], [3.0, float("nan")], [float("nan"), 1.0], [1.0, 1.0]):
+        p = torch.tensor(x, device="cuda")
+        _C.check(_C.lib().fr_loss_accumulate(p.data_ptr(), 2, acc.data_ptr(), _C.current_stream()), "fr_loss_accumulate")
+    a = acc.cpu().tolist()
+    assert a[3] == 4.0 and a[4] == 2.0 and a[0] != a[0] and a[1] != a[1]
+    # the FOCF trainer loop (one launch per step, loss reduced by the next launch): a NaN rating in the 4th batch of the epoch
+    cfg, ds, train, model, trainer = _setup(tmp_path, epochs=1)
+    ds.inter_feat["rating"][3 * 200 + 5] = float("nan")
+    with pytest.raises(ValueError, match=r"Training loss is nan \(first at step 4 of this pass\)"):
+        trainer.fit(TrainDataLoader_(cfg, ds), valid_data=None, verbose=False, saved=False)
+    # ... and a generic-engine model (NFCF: losses accumulated by fr_loss_accumulate, captured steps included)
+    from fairrec.config import Config
+    from fairrec.data.dataset import synthetic_dataset
+    from fairrec.utils import get_model, get_trainer, init_seed
+    cfg2 = Config(model="NFCF", config_dict={"train_batch_size": 128, "embedding_size": 16, "mlp_hidden_size": [16, 8], "dropout": 0.0,
+                                             "epochs": 1, "device": "cuda", "checkpoint_dir": str(tmp_path), "neg_sampling": None,
+                                             "load_pretrain_path": None})
+    init_seed(3)
+    ds2 = synthetic_dataset(cfg2, 200, 80, 1024, seed=5)
+    ds2.inter_feat.update(type(ds2.inter_feat)({"label": (ds2.inter_feat["rating"] >= 3).float()}))
+    ds2.inter_feat["label"][5 * 128 + 7] = float("nan")
+    model2 = get_model("NFCF")(cfg2, ds2).to("cuda")
+    trainer2 = get_trainer(None, "NFCF")(cfg2, model2)
+    with pytest.raises(ValueError, match=r"first at step 6 of this pass"):
+        trainer2.fit(TrainDataLoader_(cfg2, ds2), valid_data=None, verbose=False, saved=False)
+
+
+def TrainDataLoader_(cfg, ds):
+    from fairrec.data.dataloader import TrainDataLoader
+    return TrainDataLoader(cfg, ds, shuffle=False)
