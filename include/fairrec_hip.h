@@ -230,17 +230,16 @@ FR_API int fr_focf_step_finish(void* ws, size_t ws_bytes, int64_t B, int32_t dim
  * fr_focf_step for ITEM-COMPLETE batches -- what the reference's own loader feeds FOCF with (focf_dataloader.py:37-51:
  * random items, all interactions of each, until >= train_batch_size rows: tens of distinct items of ~100 rows) -- same
  * contract (batch prepared by fr_focf_prepare_step with `stamp`, loss reduced by the next step or fr_focf_step_finish), same
- * results as fr_focf_forward(FR_FOCF_ITEM_RUNS) + fr_focf_backward_adam (every sum in the same order; a few ulp where a
- * row's replay is cut into two stretches at another step), bit-reproducible.  A workgroup takes a chunk of the
- * item-sorted order: the item row of a run is replayed once per chunk and shared through LDS, the chunk whose arrival
- * completes an item finishes it with all its waves (per-group sums by wave shuffles in the fairness kernel's lane order,
- * members' user rows updated in parallel, the item's gradient summed from LDS in ascending batch position); only users
- * that recur under several items of the batch go through a second arrival counter (csrc/focf_runs.hip).
+ * results as fr_focf_forward(FR_FOCF_ITEM_RUNS) + fr_focf_backward_adam (every sum in the same order), bit-reproducible.
+ * Two launches instead of three: the chain's gather, then ONE WORKGROUP PER ITEM RUN that forms the per-group sums by wave
+ * shuffles (the fairness kernel's lane order), updates the members' user rows with all its waves, sums the item's gradient
+ * from LDS in ascending batch position and updates the item row; the sweep slice rides in the second launch.  Only users that
+ * recur under several items of the batch go through an arrival counter (csrc/focf_runs.hip).
  */
-FR_API int fr_focf_step_runs(const fr_table* U, const fr_table* I, const fr_adam* adam, const float* sst, int64_t B,
-                             int32_t objective, float fair_weight, int32_t sweep_period, int32_t stamp, void* ws,
-                             size_t ws_bytes, void* prev_ws, int64_t prev_B, float* prev_loss_out, float* loss_acc,
-                             uint32_t* err_flag, void* stream);
+FR_API int fr_focf_step_runs(const fr_table* U, const fr_table* I, const fr_adam* adam, const int64_t* user,
+                             const int64_t* item, const float* rating, const float* sst, int64_t B, int32_t objective,
+                             float fair_weight, int32_t sweep_period, int32_t stamp, void* ws, size_t ws_bytes, void* prev_ws,
+                             int64_t prev_B, float* prev_loss_out, float* loss_acc, uint32_t* err_flag, void* stream);
 
 /*
  * The same step with the index work of the COMING batches riding in the step launches themselves, instead of a look-ahead

@@ -708,6 +708,22 @@ extern "C" int fr_focf_prepare(const int64_t* user, const int64_t* item, const f
     return fr_focf_prepare_many(&b, 1, n_users, n_items, dim, err_flag, stream_);
 }
 
+// The training gather of an item-complete batch as a launch of its own (shared with focf_runs.hip: the first of the two
+// launches of fr_focf_step_runs): rows caught up and parked at their batch positions, scores, the MSE part of dLoss/dpred.
+namespace fr {
+int focf_launch_gather_runs(const fr_table* U, const fr_table* I, const AdamC& c, const int64_t* user, const int64_t* item,
+                            const float* rating, int64_t B, const FocfWs& w, uint32_t* err_flag, hipStream_t stream) {
+    const TableV Uv = view(U), Iv = view(I);
+    const DeferLoss dl{nullptr, 0, 0.f, 0};
+    ProfScope prof(K_FOCF_GATHER, stream);
+    FR_DISPATCH_E(U->dim, FR_LAUNCH(prof, (focf_gather_kernel<E, true, true>), dim3(w.n_gather_blocks), dim3(GATHER_THREADS), 0,
+                                    stream, Uv, Iv, c, user, item, rating, (int)B, U->step - 1, I->step - 1, w, 0.f,
+                                    (float*)nullptr, err_flag, dl));
+    FR_CHECK_LAUNCH();
+    return FR_OK;
+}
+}  // namespace fr
+
 extern "C" int fr_focf_forward(const fr_table* U, const fr_table* I, const fr_adam* adam, const int64_t* user,
                                const int64_t* item, const float* rating, const float* sst, int64_t B,
                                int32_t objective, float fair_weight, int32_t flags, void* ws, size_t ws_bytes,

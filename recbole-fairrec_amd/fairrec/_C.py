@@ -67,9 +67,9 @@ _PROTOS = {
     "fr_focf_step": (c_int, [POINTER(FrTable), POINTER(FrTable), POINTER(FrAdam), c_void_p, c_void_p, c_void_p, c_void_p,
                              c_int64, c_int32, c_float, c_int32, c_int32, c_void_p, c_size_t, c_void_p, c_void_p, c_int64,
                              c_void_p, c_void_p, c_void_p, c_void_p]),
-    "fr_focf_step_runs": (c_int, [POINTER(FrTable), POINTER(FrTable), POINTER(FrAdam), c_void_p, c_int64, c_int32, c_float,
-                                  c_int32, c_int32, c_void_p, c_size_t, c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
-                                  c_void_p]),
+    "fr_focf_step_runs": (c_int, [POINTER(FrTable), POINTER(FrTable), POINTER(FrAdam), c_void_p, c_void_p, c_void_p, c_void_p,
+                                  c_int64, c_int32, c_float, c_int32, c_int32, c_void_p, c_size_t, c_void_p, c_int64, c_void_p,
+                                  c_void_p, c_void_p, c_void_p]),
     "fr_focf_step_finish": (c_int, [c_void_p, c_size_t, c_int64, c_int32, c_int32, c_float, c_void_p, c_void_p,
                                     c_void_p]),
     "fr_side_stream_handle": (c_void_p, []),

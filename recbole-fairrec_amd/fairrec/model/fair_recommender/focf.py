@@ -367,8 +367,8 @@ class FocfEngine:
             alive = {self._key(nb[0], nb[1]) for nb in coming}
             for k in [k for k in self._prep if k not in alive]:
                 torch.cuda.current_stream().wait_event(self._prep.pop(k)[1]["done"])
-        # item-complete batches (FOCFDataLoader) take the one-launch step of csrc/focf_runs.hip (a workgroup per chunk of an
-        # item's run); FAIRREC_FOCF_RUNS=0 sends them through the three-launch chain as before round 4
+        # item-complete batches (FOCFDataLoader) take the two-launch step of csrc/focf_runs.hip (the gather, then a workgroup per
+        # item run); FAIRREC_FOCF_RUNS=0 sends them through the three-launch chain as before round 4
         fused = (self.fused_step and self.defer_loss and self.optimizer is not None and self.objective != 5 and not want_pred
                  and (not self.item_runs or (self.RUNS and rating is not None)) and self.U.step == self.I.step)
         # A stamp is the optimizer step at which its batch is applied: the current batch (if nobody prepared it) takes its
@@ -468,7 +468,8 @@ class FocfEngine:
                 self.finish()
             pw, pB, ploss, _ = self._prev if self._prev is not None else (None, 0, None, False)
             if getattr(self, "_stash_runs", False):
-                rc = _C.lib().fr_focf_step_runs(ctypes.byref(tu), ctypes.byref(ti), ctypes.byref(self.hyper.c()), _C.ptr(sst), B,
+                rc = _C.lib().fr_focf_step_runs(ctypes.byref(tu), ctypes.byref(ti), ctypes.byref(self.hyper.c()),
+                                                user.data_ptr(), item.data_ptr(), rating.data_ptr(), _C.ptr(sst), B,
                                                 self.objective, self.fair_weight, self._sweep(B), stamp, ws.data_ptr(),
                                                 ws.numel(), _C.ptr(pw), pB, _C.ptr(ploss), self.loss_acc.data_ptr(),
                                                 self.err_flag.data_ptr(), _C.current_stream())
