@@ -182,6 +182,26 @@ __global__ __launch_bounds__(GATHER_THREADS) void focf_gather_kernel(
 
 
 
+// The training gather of an item-complete batch with a share of the step's sweep slice in FRONT of it (fr_focf_step_runs):
+// the gather waves spend their life waiting for rows, the sweeper waves are VALU work -- dispatched first, they run under the
+// gather's latency.  (The sweeper tells the batch's rows by their stamps, which fr_focf_prepare_step wrote before this launch.)
+template <int E>
+__global__ __launch_bounds__(GATHER_THREADS) void focf_gather_sweep_kernel(
+    TableV U, TableV I, AdamC c, const int64_t* __restrict__ user, const int64_t* __restrict__ item,
+    const float* __restrict__ rating, int B, int upto_u, int upto_i, FocfWs w, uint32_t* err, DeferLoss dl, SweepSlice sw,
+    long long sw_n) {
+    __shared__ GatherLds<E> lds;
+    const int nsb = (int)((sw_n + 3) / 4);
+    if ((int)blockIdx.x < nsb) {
+        const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+        if (wave < sw_n) sweep_slice_wave<E>(U, I, c, sw, wave, (int)(threadIdx.x & 63));
+        return;
+    }
+    const int block = (int)blockIdx.x - nsb;
+    if (block == 0 && threadIdx.x == 0) *w.defer = dl;
+    focf_gather_body<E, true, true>(U, I, c, user, item, rating, B, upto_u, upto_i, w, 0.f, nullptr, err, block, lds);
+}
+
 // ------------------------------------------------------------------------------------------------
 // fairness term on the distinct items of the batch: 16 lanes per item
 // ------------------------------------------------------------------------------------------------
@@ -712,13 +732,14 @@ extern "C" int fr_focf_prepare(const int64_t* user, const int64_t* item, const f
 // launches of fr_focf_step_runs): rows caught up and parked at their batch positions, scores, the MSE part of dLoss/dpred.
 namespace fr {
 int focf_launch_gather_runs(const fr_table* U, const fr_table* I, const AdamC& c, const int64_t* user, const int64_t* item,
-                            const float* rating, int64_t B, const FocfWs& w, uint32_t* err_flag, hipStream_t stream) {
+                            const float* rating, int64_t B, const FocfWs& w, uint32_t* err_flag, hipStream_t stream,
+                            const SweepSlice& sw, long long sweep_waves) {
     const TableV Uv = view(U), Iv = view(I);
     const DeferLoss dl{nullptr, 0, 0.f, 0};
     ProfScope prof(K_FOCF_GATHER, stream);
-    FR_DISPATCH_E(U->dim, FR_LAUNCH(prof, (focf_gather_kernel<E, true, true>), dim3(w.n_gather_blocks), dim3(GATHER_THREADS), 0,
-                                    stream, Uv, Iv, c, user, item, rating, (int)B, U->step - 1, I->step - 1, w, 0.f,
-                                    (float*)nullptr, err_flag, dl));
+    const unsigned blocks = (unsigned)(w.n_gather_blocks + (sweep_waves + 3) / 4);
+    FR_DISPATCH_E(U->dim, FR_LAUNCH(prof, (focf_gather_sweep_kernel<E>), dim3(blocks), dim3(GATHER_THREADS), 0, stream, Uv, Iv, c,
+                                    user, item, rating, (int)B, U->step - 1, I->step - 1, w, err_flag, dl, sw, sweep_waves));
     FR_CHECK_LAUNCH();
     return FR_OK;
 }

@@ -48,6 +48,9 @@ namespace fr {
                           // one 16-wave workgroup or three 8-wave ones)
 constexpr int RUN_WAVES = FR_RUN_WAVES;
 constexpr int RUN_THREADS = 64 * RUN_WAVES;
+#ifndef FR_RUN_DIAG
+#define FR_RUN_DIAG 0        // diagnostic builds: 1 skips the members' updates, 2 the item's gradient sum, 3 the statistics,
+#endif                     // 4 the whole item work (what the launch costs with its first and last workgroup only)
 #ifndef FR_RUN_CAP_BYTES
 #define FR_RUN_CAP_BYTES 32768        // LDS of a pass: RUN_CAP caught-up user rows (+ their coefficients)
 #endif
@@ -65,7 +68,7 @@ struct RunArgs {
     FocfWs w;
     SweepSlice sw;
     int n_item_blocks;
-    long long n_sweep_waves;
+    long long sweep_wave0, n_sweep_waves;     // this launch's share of the sweep slice: waves [wave0, wave0 + n)
     uint32_t* err;
     PrevLoss prev;
 };
@@ -160,43 +163,106 @@ __device__ __forceinline__ T args_through_vgprs(int lane) {
 
 }  // namespace
 
-// One item run [j0, j0 + n) of the item-sorted order, by all RUN_WAVES waves of a workgroup.
+#if FR_RUN_DIAG == 5       // wave time lines: (item k, wave 0 / last wave) x 8 stamps of the 100 MHz clock into the unused task_rec array
+#define RUN_STAMP(i) do { if (wv == 0 || wv == RUN_WAVES - 1) reinterpret_cast<unsigned long long*>(a.w.task_rec)[((size_t)k * 2 + (wv != 0)) * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define RUN_STAMP(i) do {} while (0)
+#endif
+
+// One item run [j0, j0 + n) of the item-sorted order, by all RUN_WAVES waves of a workgroup.  `bf` = batch position of the
+// run's first member (where launch 1 parked the item's caught-up row: every member's copy holds the same bits), `ir` = the
+// item's table row.  The loads are issued LEVEL BY LEVEL -- everything whose address is known goes out before the first
+// value is waited for -- because a dependent round trip costs ~2 us here and the run is a chain of them:
+//   level 1 (the caller)  K, the run's extent, bf, ir
+//   level 2               the item's parked (p, m, v); the members' batch positions (perm_i) for the statistics and for the
+//                         waves' own members
+//   level 3               the members' records, scores and MSE parts; the parked user rows of each wave's first four members
+//   (barrier behind the statistics)  ->  dLoss/dpred, Adam, stores; further members four at a time; the item's gradient from LDS
 template <int E>
-__device__ __forceinline__ void run_finish_item(const RunArgs& a, int k, int ij0, int n, float* pu_s, float* coef_s,
-                                                float* sh, int lane, int wv) {
-    constexpr int CAP = run_cap(E);
+__device__ __forceinline__ void run_finish_item(const RunArgs& a, int k, int ij0, int n, int bf, int ir, float* pu_s,
+                                                float* coef_s, float* sh, int lane, int wv) {
+    constexpr int CAP = run_cap(E), MB = E == 1 ? 8 : 4;      // parked user rows in flight per wave (x 3 row fragments)
     const FocfWs& w = a.w;
     const int D = a.U.D, step = a.U.step;
     const bool per_item = a.objective >= FR_FOCF_VALUE && a.objective <= FR_FOCF_OVER;
-    const float smin = per_item ? G(w.sst_minmax)[0] : 0.f;
-    // the run's first member: where launch 1 parked the item's caught-up row (every member's copy holds the same bits)
-    const int bf = uniform(G(w.perm_i)[ij0]);
-    RowFrag<E> pi;
+    RUN_STAMP(0);
+    // ---- level 2 -----------------------------------------------------------------------------------------------------------
+    RowFrag<E> pi, mi, vi;
     gload_row<E>(pi, w.side[3] + (size_t)bf * D, D, lane);
-    // (a) the per-(item, group) sums of focf.py:75-91 in focf_fair_kernel<64>'s order: lane `sub` takes members sub, sub + 64,
-    //     ... one after the other, then the butterfly
+    if (wv == 0) {
+        gload_row<E>(mi, w.side[4] + (size_t)bf * D, D, lane);
+        gload_row<E>(vi, w.side[5] + (size_t)bf * D, D, lane);
+    }
+    float smin = 0.f, smax = 0.f, Kf = 1.f;
+    if (per_item) {
+        smin = G(w.sst_minmax)[0];
+        smax = G(w.sst_minmax)[1];
+        Kf = (float)G(w.nseg_i)[0];
+    }
+    // statistics (wave 0): lane `sub` takes members sub, sub + 64, ... -- the first two positions now, further ones in a loop
+    int sb0 = 0, sb1 = 0;
+    const bool s0 = wv == 0 && per_item && lane < n, s1 = wv == 0 && per_item && lane + 64 < n;
+    if (s0) sb0 = G(w.perm_i)[ij0 + lane];
+    if (s1) sb1 = G(w.perm_i)[ij0 + lane + 64];
+    // this wave's members of the FIRST pass: every RUN_WAVES-th one, lane t holds the t-th
+    const int cnt0 = min(CAP, n);
+    const int mine0 = cnt0 > wv ? (cnt0 - wv + RUN_WAVES - 1) / RUN_WAVES : 0;
+    int lb = 0;
+    if (lane < mine0) lb = G(w.perm_i)[ij0 + wv + RUN_WAVES * lane];
+    // ---- level 3 -----------------------------------------------------------------------------------------------------------
+    int4 src0 = make_int4(0, 0, 0, 0), src1 = make_int4(0, 0, 0, 0);
+    float spr0 = 0.f, spr1 = 0.f;
+    if (s0) { src0 = ld4(w.rec, sb0); spr0 = G(w.pred)[sb0]; }
+    if (s1) { src1 = ld4(w.rec, sb1); spr1 = G(w.pred)[sb1]; }
+    int4 lrc = make_int4(0, 0, 0, 0), linf = make_int4(0, 0, 0, 0);
+    float lpr = 0.f, lcf = 0.f;
+    if (lane < mine0) {
+        lrc = ld4(w.rec, lb);
+        linf = ld4(w.info, lb);
+        lpr = G(w.pred)[lb];
+        lcf = G(w.coef)[lb];                   // the MSE part 2 (pred - r) / B, as focf_gather_kernel left it
+    }
+    RowFrag<E> pu[MB], mu[MB], vu[MB];
+    int bq[MB];
+#pragma unroll
+    for (int u = 0; u < MB; ++u) {
+        bq[u] = 0;
+        if (u < mine0) {
+            bq[u] = __builtin_amdgcn_readlane(lb, u);
+            gload_row<E>(pu[u], w.side[0] + (size_t)bq[u] * D, D, lane);
+            gload_row<E>(mu[u], w.side[1] + (size_t)bq[u] * D, D, lane);
+            gload_row<E>(vu[u], w.side[2] + (size_t)bq[u] * D, D, lane);
+        }
+    }
+    RUN_STAMP(1);
+    // (a) the per-(item, group) sums of focf.py:75-91 in focf_fair_kernel<64>'s order: lane `sub` adds its members one after
+    //     the other (ascending position), then the butterfly
     if (wv == 0) {
         float term = 0.f, g0 = 0.f, g1 = 0.f;
-        if (per_item) {
-            const float smax = G(w.sst_minmax)[1];
+        if (per_item && FR_RUN_DIAG != 3) {
             float sp0 = 0.f, sp1 = 0.f, st0 = 0.f, st1_ = 0.f, n0 = 0.f, n1 = 0.f;
             bool bad = false;
-            for (int j = ij0 + lane; j < ij0 + n; j += 64) {
-                const int b = G(w.perm_i)[j];
-                const int4 rc = ld4(w.rec, b);
-                const float pr = G(w.pred)[b], r = __int_as_float(rc.z), s = __int_as_float(rc.w);
+            auto add = [&](bool on, const int4& rc, float pr) {
+                if (!on) return;
+                const float r = __int_as_float(rc.z), s = __int_as_float(rc.w);
                 bad |= (s != smin && s != smax);
                 if (s == smin) {
                     sp0 += pr; st0 += r; n0 += 1.f;
                 } else {
                     sp1 += pr; st1_ += r; n1 += 1.f;
                 }
+            };
+            add(s0, src0, spr0);
+            add(s1, src1, spr1);
+            for (int j = ij0 + lane + 128; j < ij0 + n; j += 64) {       // runs of more than 128 members
+                const int b = G(w.perm_i)[j];
+                add(true, ld4(w.rec, b), G(w.pred)[b]);
             }
             if (bad && a.err) atomicOr(a.err, FR_DEV_ERR_SST_GROUPS);
             sp0 = group_sum<64>(sp0); sp1 = group_sum<64>(sp1);
             st0 = group_sum<64>(st0); st1_ = group_sum<64>(st1_);
             n0 = group_sum<64>(n0);   n1 = group_sum<64>(n1);
-            focf_fair_eval(a.objective, a.fair_weight, (float)G(w.nseg_i)[0], sp0, sp1, st0, st1_, n0, n1, term, g0, g1);
+            focf_fair_eval(a.objective, a.fair_weight, Kf, sp0, sp1, st0, st1_, n0, n1, term, g0, g1);
         }
         if (lane == 0) {
             sh[0] = g0;
@@ -204,44 +270,59 @@ __device__ __forceinline__ void run_finish_item(const RunArgs& a, int k, int ij0
             G(w.term)[k] = term;
         }
     }
+    RUN_STAMP(2);
+    __syncthreads();
+    RUN_STAMP(3);
+    const float g0 = sh[0], g1 = sh[1];
     const float2 sc = step_scalars(a.c, step);
     RowFrag<E> gi;
 #pragma unroll
     for (int e = 0; e < E; ++e) gi.x[e] = 0.f;
-    float g0 = 0.f, g1 = 0.f;
     for (int base = 0; base < n; base += CAP) {
         const int cnt = min(CAP, n - base);
-        // (b) the members of this pass, every RUN_WAVES-th one per wave.  Their records come with ONE gather per array (lane t
-        //     holds the wave's t-th member) BEFORE the barrier behind the statistics, the parked rows of four members are in
-        //     flight at a time: a member costs the wave a share of two dependent round trips, not five of its own
         const int mine = cnt > wv ? (cnt - wv + RUN_WAVES - 1) / RUN_WAVES : 0;
-        int lb = 0;
-        int4 lrc = make_int4(0, 0, 0, 0), linf = make_int4(0, 0, 0, 0);
-        float lpr = 0.f, lcf = 0.f;
-        if (lane < mine) {
-            lb = G(w.perm_i)[ij0 + base + wv + RUN_WAVES * lane];
-            lrc = ld4(w.rec, lb);
-            linf = ld4(w.info, lb);
-            lpr = G(w.pred)[lb];
-            lcf = G(w.coef)[lb];                   // the MSE part 2 (pred - r) / B, as focf_gather_kernel left it
+        if (base > 0) {                            // (a further pass of a long run: its records now)
+            lb = 0;
+            if (lane < mine) {
+                lb = G(w.perm_i)[ij0 + base + wv + RUN_WAVES * lane];
+                lrc = ld4(w.rec, lb);
+                linf = ld4(w.info, lb);
+                lpr = G(w.pred)[lb];
+                lcf = G(w.coef)[lb];
+            }
         }
-        if (base == 0) {
-            __syncthreads();                       // the statistics of (a)
-            g0 = sh[0];
-            g1 = sh[1];
+        // Users that occur under several items of the batch: ALL of this wave's such members arrive now, lane-parallel, before
+        // the wave has any row store in flight -- dLoss/dpred handed over (write-through), ONE drain, one atomic per lane.  Done
+        // member by member inside the loop below (store, drain, atomic, and for the last arriver a chain of loads), every such
+        // member held its wave for ~10 us behind the stores of the members before it, and most runs have one: 13 of the 24 us
+        // of this launch.
+        float lco = lcf;
+        if (per_item) lco = lcf + ((__int_as_float(lrc.w) == smin) ? g0 : g1);      // + the fairness part, as focf_fair_kernel adds it
+        const int lnu = (linf.x >> 16) & 0xffff;
+        const bool lmulti = lane < mine && lnu > 1;
+        unsigned lold = 0;
+        if (__ballot(lmulti)) {
+            if (lmulti) st1(w.coef + lb, lco);
+            drain();
+            if (lmulti) lold = __hip_atomic_fetch_add(G(w.cnt_u) + linf.y, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        constexpr int MB = 4;
+        const bool llast = lmulti && (int)lold + 1 == lnu;
+        // (b) the members of this pass, MB at a time
+#if FR_RUN_DIAG == 1
+        for (int t0 = 0; t0 < 0; t0 += MB) {
+#else
         for (int t0 = 0; t0 < mine; t0 += MB) {
-            RowFrag<E> pu[MB], mu[MB], vu[MB];
-            int bq[MB];
+#endif
+            if (base > 0 || t0 > 0) {
 #pragma unroll
-            for (int u = 0; u < MB; ++u) {
-                bq[u] = 0;
-                if (t0 + u < mine) {
-                    bq[u] = __builtin_amdgcn_readlane(lb, t0 + u);
-                    gload_row<E>(pu[u], w.side[0] + (size_t)bq[u] * D, D, lane);
-                    gload_row<E>(mu[u], w.side[1] + (size_t)bq[u] * D, D, lane);
-                    gload_row<E>(vu[u], w.side[2] + (size_t)bq[u] * D, D, lane);
+                for (int u = 0; u < MB; ++u) {
+                    bq[u] = 0;
+                    if (t0 + u < mine) {
+                        bq[u] = __builtin_amdgcn_readlane(lb, t0 + u);
+                        gload_row<E>(pu[u], w.side[0] + (size_t)bq[u] * D, D, lane);
+                        gload_row<E>(mu[u], w.side[1] + (size_t)bq[u] * D, D, lane);
+                        gload_row<E>(vu[u], w.side[2] + (size_t)bq[u] * D, D, lane);
+                    }
                 }
             }
 #pragma unroll
@@ -253,9 +334,9 @@ __device__ __forceinline__ void run_finish_item(const RunArgs& a, int k, int ij0
                 const float s = __int_as_float(__builtin_amdgcn_readlane(lrc.w, t));
                 const int ux = __builtin_amdgcn_readlane(linf.x, t), useg = __builtin_amdgcn_readlane(linf.y, t);
                 const float pr = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lpr), t));
-                float coef = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lcf), t));
-                if (per_item) coef = coef + ((s == smin) ? g0 : g1);      // + the fairness part, as focf_fair_kernel adds it
+                const float coef = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lco), t));
                 const float er = pr - r;
+                (void)s;
 #pragma unroll
                 for (int e = 0; e < E; ++e) pu_s[(size_t)q * (64 * E) + lane + 64 * e] = pu[u].x[e];
                 if (lane == 0) {
@@ -276,14 +357,10 @@ __device__ __forceinline__ void run_finish_item(const RunArgs& a, int k, int ij0
                         g.x[e] = g.x[e] + prod;
                     }
                 } else {
-                    // the user occurs under several items: hand dLoss/dpred over, arrive; the last arriver sums the user's
-                    // gradient rows in ascending batch position (segment_grad_sum's order) from the items' parked rows
-                    if (lane == 0) st1(w.coef + b, coef);
-                    drain();
-                    unsigned old = 0;
-                    if (lane == 0) old = __hip_atomic_fetch_add(G(w.cnt_u) + useg, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    old = (unsigned)uniform((int)old);
-                    finish = (int)old + 1 == nu;
+                    // the user occurs under several items (arrived above): its LAST arriver sums the user's gradient rows in
+                    // ascending batch position (segment_grad_sum's order) from the items' parked rows
+                    (void)useg;
+                    finish = __builtin_amdgcn_readlane((int)llast, t) != 0;
                     if (finish) {
                         // the caught-up state of the user's FIRST member, as segment_update takes it (launch 1 replayed the
                         // row once per occurrence: the same bits, but the rule keeps the result independent of who is last)
@@ -319,27 +396,52 @@ __device__ __forceinline__ void run_finish_item(const RunArgs& a, int k, int ij0
                 }
             }
         }
+        RUN_STAMP(4);
         __syncthreads();
+        RUN_STAMP(5);
         // (c) the item's gradient over this pass, members in ascending batch position (= ascending sorted position: the
         //     sort is stable), product rounded, then added
-        if (wv == 0) {
-#pragma clang fp contract(off)
-            for (int q = 0; q < cnt; ++q) {
-                const float cq = coef_s[q];
+        if (wv == 0 && FR_RUN_DIAG != 2) {
+            // (eight members' LDS reads in flight before the first product: left to itself the loop waited for every read,
+            // ~100 x an LDS round trip per run)
+            constexpr int GU = 8;
+            int q = 0;
+            for (; q + GU <= cnt; q += GU) {
+                float cq[GU], rq[GU][E];
 #pragma unroll
-                for (int e = 0; e < E; ++e) {
-                    const float prod = cq * pu_s[(size_t)q * (64 * E) + lane + 64 * e];
-                    gi.x[e] = gi.x[e] + prod;
+                for (int z = 0; z < GU; ++z) {
+                    cq[z] = coef_s[q + z];
+#pragma unroll
+                    for (int e = 0; e < E; ++e) rq[z][e] = pu_s[(size_t)(q + z) * (64 * E) + lane + 64 * e];
+                }
+                {
+#pragma clang fp contract(off)
+#pragma unroll
+                    for (int z = 0; z < GU; ++z) {
+#pragma unroll
+                        for (int e = 0; e < E; ++e) {
+                            const float prod = cq[z] * rq[z][e];
+                            gi.x[e] = gi.x[e] + prod;
+                        }
+                    }
+                }
+            }
+            {
+#pragma clang fp contract(off)
+                for (; q < cnt; ++q) {
+                    const float cz = coef_s[q];
+#pragma unroll
+                    for (int e = 0; e < E; ++e) {
+                        const float prod = cz * pu_s[(size_t)q * (64 * E) + lane + 64 * e];
+                        gi.x[e] = gi.x[e] + prod;
+                    }
                 }
             }
         }
         __syncthreads();
     }
+    RUN_STAMP(6);
     if (wv == 0) {
-        RowFrag<E> mi, vi;
-        gload_row<E>(mi, w.side[4] + (size_t)bf * D, D, lane);
-        gload_row<E>(vi, w.side[5] + (size_t)bf * D, D, lane);
-        const int ir = uniform(G(w.seg_row_i)[k]);
 #pragma unroll
         for (int e = 0; e < E; ++e) adam_elem(pi.x[e], mi.x[e], vi.x[e], gi.x[e], sc.x, sc.y, a.c);
         gstore_row<E>(pi, a.I.p + (size_t)ir * D, D, lane);
@@ -347,6 +449,7 @@ __device__ __forceinline__ void run_finish_item(const RunArgs& a, int k, int ij0
         gstore_row<E>(vi, a.I.v + (size_t)ir * D, D, lane);
         if (lane == 0) G(a.I.last)[ir] = step;
     }
+    RUN_STAMP(7);
 }
 
 template <int E>
@@ -368,13 +471,16 @@ __global__ __launch_bounds__(RUN_THREADS) void focf_runs_finish_kernel(RunArgs a
     blk -= 1;
     if (blk >= a.n_item_blocks) {        // the step's slice of the bounded-staleness sweep: one wave per pair of rows
         const long long wave = (long long)(blk - a.n_item_blocks) * RUN_WAVES + wv;
-        if (wave < a.n_sweep_waves) sweep_slice_wave<E>(a.U, a.I, a.c, a.sw, wave, lane);
+        if (wave < a.n_sweep_waves) sweep_slice_wave<E>(a.U, a.I, a.c, a.sw, a.sweep_wave0 + wave, lane);
         return;
     }
-    const int K = uniform(G(a.w.nseg_i)[0]);
-    for (int k = blk; k < K; k += a.n_item_blocks) {
-        const int j0 = uniform(G(a.w.seg_start_i)[k]), j1 = uniform(G(a.w.seg_start_i)[k + 1]);
-        run_finish_item<E>(a, k, j0, j1 - j0, lds_rows, coef_s, sh, lane, wv);
+    for (int k = blk; k < a.B; k += a.n_item_blocks) {
+        // level 1: everything about run k in ONE round trip (entries past the last run are read and not used)
+        const int rK = G(a.w.nseg_i)[0], rj0 = G(a.w.seg_start_i)[k], rj1 = G(a.w.seg_start_i)[k + 1];
+        const int rbf = G(a.w.seg_first_i)[k], rir = G(a.w.seg_row_i)[k];
+        if (k >= uniform(rK) || FR_RUN_DIAG == 4) break;
+        const int j0 = uniform(rj0);
+        run_finish_item<E>(a, k, j0, uniform(rj1) - j0, uniform(rbf), uniform(rir), lds_rows, coef_s, sh, lane, wv);
         __syncthreads();
     }
 }
@@ -414,15 +520,21 @@ extern "C" int fr_focf_step_runs(const fr_table* U, const fr_table* I, const fr_
     a.objective = objective;
     a.fair_weight = fair_weight;
     a.err = err_flag;
-    // launch 1: rows caught up and parked at their batch positions, scores, the MSE part of dLoss/dpred
-    if ((rc = focf_launch_gather_runs(U, I, a.c, user, item, rating, B, a.w, err_flag, stream))) return rc;
-    long long sweep_blocks = 0;
+    // The step's sweep slice (bounded staleness) is split between the two launches: FAIRREC_RUNS_SWEEP_SPLIT per cent of its
+    // waves ride in FRONT of the gather (a latency-bound launch with idle VALUs), the rest behind the item runs of launch 2.
+    static const int split_pct = getenv("FAIRREC_RUNS_SWEEP_SPLIT") ? atoi(getenv("FAIRREC_RUNS_SWEEP_SPLIT")) : 0;
+    long long sweep_blocks = 0, in_gather = 0;
     if (sweep_period > 0) {
         a.sw = make_sweep_slice(U, I, sweep_period);
         a.sw.skip_from = stamp;       // the rows of this batch (and of batches prepared for later steps) carry stamps >= it
-        a.n_sweep_waves = sweep_slice_waves(a.sw);
+        const long long total = sweep_slice_waves(a.sw);
+        in_gather = total * std::min(std::max(split_pct, 0), 100) / 100;
+        a.sweep_wave0 = in_gather;
+        a.n_sweep_waves = total - in_gather;
         sweep_blocks = (a.n_sweep_waves + RUN_WAVES - 1) / RUN_WAVES;
     }
+    // launch 1: rows caught up and parked at their batch positions, scores, the MSE part of dLoss/dpred
+    if ((rc = focf_launch_gather_runs(U, I, a.c, user, item, rating, B, a.w, err_flag, stream, a.sw, in_gather))) return rc;
     a.prev = prev_of(prev_ws, prev_B, U->dim, objective, fair_weight, prev_loss_out, loss_acc, false);
     a.n_item_blocks = (int)std::min<long long>(FR_RUN_ITEM_BLOCKS, B);
     ProfScope prof(K_FOCF_STEP, stream);

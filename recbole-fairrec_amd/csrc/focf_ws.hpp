@@ -194,8 +194,10 @@ __device__ __forceinline__ void focf_fair_eval(int objective, float fair_weight,
 }
 
 // focf.hip: focf_gather_kernel<E, TRAIN, SHARE> on an item-complete batch, as a launch of its own (fr_focf_step_runs)
+// (the first `sweep_waves` waves of the step's sweep slice `sw` ride in front of the gather)
 int focf_launch_gather_runs(const fr_table* U, const fr_table* I, const AdamC& c, const int64_t* user, const int64_t* item,
-                            const float* rating, int64_t B, const FocfWs& w, uint32_t* err_flag, hipStream_t stream);
+                            const float* rating, int64_t B, const FocfWs& w, uint32_t* err_flag, hipStream_t stream,
+                            const SweepSlice& sw, long long sweep_waves);
 
 inline SweepSlice make_sweep_slice(const fr_table* U, const fr_table* I, int32_t sweep_period) {
     SweepSlice sw{};

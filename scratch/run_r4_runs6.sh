@@ -1,0 +1,8 @@
+#!/bin/bash
+cd ${GRAFT_REPO_ROOT:-$(pwd)}
+mkdir -p gpurun_out/r4
+export PYTHONUNBUFFERED=1
+echo "=== focf tests"; timeout 1500 python -m pytest tests/test_focf_hip.py -q -m gpu -p no:cacheprovider -k "runs or prefetch" 2>&1 | tail -4 | cut -c1-300
+A="--item-dist grouped --steps 200 --graph-only"
+for s in 0 25; do echo "split $s"; FAIRREC_RUNS_SWEEP_SPLIT=$s python scratch/bench_brief.py $A; done
+python scratch/bench_brief.py $A --sweep 0
