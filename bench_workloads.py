@@ -208,9 +208,21 @@ def bench_fairgo(args, dev):
             loss.backward()
             opt.step()
         return s
-    f_step = eager(of, f_loss)        # 200 ms of whole-table kernels: launch overhead is nothing here, no graph needed
+    f_step = eager(of, f_loss)        # tens of ms of whole-table kernels: launch overhead is nothing here, no graph needed
+    # the filter pass twice: propagating over the batch's frontier only (fr_spmm_csr_sel; `fairgo_frontier: auto` turns it on at
+    # this graph's size) and, for reference, over whole tables as the reference's torch.sparse.mm does -- same loss bits
+    frontier = m.use_frontier()
+    t_whole = None
+    if frontier:
+        m.frontier_mode = False
+        t_whole = _timed(f_step, max(2, min(K, 3)), 2)
+        m.frontier_mode = True
     t_f = _timed(f_step, K, W)
     pf = _profiled(f_step, min(K, 3))
+    fr_rows = None
+    if frontier:
+        fr = m._frontier(data[0]["user_id"])
+        fr_rows = [int(x[0].numel()) for x in fr] if fr is not None else None
     m.begin_dis_phase(sl)             # what the trainer does before a discriminator pass: filtered table + propagations, once
     gd = GraphedStep(eng, od, d_loss, eager_steps=2)
     t_d = _timed(lambda k: gd(data[k % len(data)]), max(K, 20), W + 2)
@@ -233,9 +245,17 @@ def bench_fairgo(args, dev):
                                "filter MLP forward + backward, 2 + 2 SpMM) + one discriminator pass (filtered table and its "
                                "propagations cached per pass)",
                    "filter_pass_ms": round(t_f * 1e3, 4), "dis_pass_ms": round(t_d * 1e3, 4),
+                   "propagation": ("frontier-restricted (fr_spmm_csr_sel): rows of H_1 / H_2 computed = %s of %d graph rows"
+                                   % (fr_rows, nu + ni)) if frontier else "whole tables",
+                   "filter_pass_ms_whole_table_propagation": None if t_whole is None else round(t_whole * 1e3, 4),
                    "host_build_s": round(t_host, 1), "peak_mem_GiB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)},
-        "roofline": {"bound": "hbm", "kernel": "spmm_csr_kernel", "achieved": round(spmm_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(spmm_gbs / HBM_PEAK_GBS, 4), "traffic": None,
+        # with the propagation restricted to the batch's frontier the whole-table filter MLP (three dense products each way) is the
+        # dominant work of a filter pass: the roofline that bounds it is the fp32 MFMA peak; the SpMM figures stay next to it
+        "roofline": ({"bound": "mfma", "kernel": "linear_fwd / linear_bwd_input / linear_bwd_weight (whole-table filter MLP)",
+                      "achieved": gf_["gemm_tflops"], "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                      "frac": gf_["gemm_frac_of_mfma_peak"], "traffic": None} if frontier else
+                     {"bound": "hbm", "kernel": "spmm_csr_kernel", "achieved": round(spmm_gbs, 1), "peak": HBM_PEAK_GBS,
+                      "unit": "GB/s", "frac": round(spmm_gbs / HBM_PEAK_GBS, 4), "traffic": None}) | {
                      "algorithmic_bytes_per_launch": round(sp_bytes / max(pf.get("spmm_csr_kernel", (0, 1, 0))[1], 1)),
                      "spmm_ms_per_filter_pass": round(sp_ms, 3), "spmm_share_of_filter_pass": round(sp_ms / (t_f * 1e3), 3),
                      "spmm_requested_GBps": round(gathered_gbs, 1),

@@ -37,11 +37,24 @@ struct GatherLds {
     float irow[GATHER_THREADS / WAVE][3][64 * E + 1];   // E = 0: not used (one float each)
 };
 
-template <int E, bool TRAIN, bool SHARE>
+// SORTED (fr_focf_step_runs): everything a member leaves behind is parked at its position in the ITEM-SORTED order instead of
+// at its batch position, and its scalars are packed into two 16-byte records -- the workgroup that finishes an item run then
+// finds the run's members side by side and needs no id, permutation or record lookup first (a dependent round trip costs
+// ~3 us in that launch: profiles/r04_runs_finish_wave_trace.txt).
+struct SortedPark {
+    const int32_t* pos_of;     // [B] sorted position of a batch position (fr_focf_prepare_step)
+    const int4* info;          // [B] (user j0 | n << 16, user segment, item j0 | n << 16, item segment)
+    const float* sst;          // [B] or null
+    int4* recs;                // [B] by sorted position: (user row, user j0 | n << 16, user segment, batch position)
+    int4* vals;                // [B] by sorted position: (rating, sst, pred, MSE part of dLoss/dpred) as float bits
+    float* mse_e;              // [B] squared errors (any fixed order serves the loss reduction: by batch position)
+};
+
+template <int E, bool TRAIN, bool SHARE, bool SORTED = false>
 __device__ __forceinline__ void focf_gather_body(
     const TableV& U, const TableV& I, const AdamC& c, const int64_t* __restrict__ user, const int64_t* __restrict__ item,
     const float* __restrict__ rating, int B, int upto_u, int upto_i, const FocfWs& w, float max_rating,
-    float* __restrict__ predict_out, uint32_t* err, int block, GatherLds<SHARE ? E : 0>& lds) {
+    float* __restrict__ predict_out, uint32_t* err, int block, GatherLds<SHARE ? E : 0>& lds, SortedPark sp = SortedPark{}) {
     constexpr int NW = GATHER_THREADS / WAVE;
     const int lane = threadIdx.x & 63;
     const int wib = threadIdx.x >> 6;
@@ -50,6 +63,14 @@ __device__ __forceinline__ void focf_gather_body(
     const int D = U.D;
     float e2 = 0.f;
     int ur = 0, ir = -1 - wib;       // an idle wave's "item" matches nobody's
+    int js = b;                      // where this member parks: its batch position, or (SORTED) its place in the item order
+    int4 inf = make_int4(0, 0, 0, 0);
+    float sv = 0.f;
+    if (SORTED && valid) {           // (requested together with the ids: the same round trip)
+        js = sp.pos_of[b];
+        inf = sp.info[b];
+        if (sp.sst) sv = sp.sst[b];
+    }
     if (valid) {
         long long ul = user[b], il = item[b];
         if (ul < 0 || ul >= U.n_rows || il < 0 || il >= I.n_rows) {
@@ -138,7 +159,7 @@ __device__ __forceinline__ void focf_gather_body(
         dot = wave_sum(dot);
 
         if (TRAIN) {
-            const size_t so = (size_t)b * D;
+            const size_t so = (size_t)(SORTED ? uniform(js) : b) * D;
             store_row<E>(pu, w.side[0] + so, D, lane);
             store_row<E>(mu, w.side[1] + so, D, lane);
             store_row<E>(vu, w.side[2] + so, D, lane);
@@ -151,8 +172,15 @@ __device__ __forceinline__ void focf_gather_body(
                 // never lowered: a look-ahead fr_focf_prepare_step may already have stamped the row for a later batch
                 atomicMax(&U.stamp[ur], upto_u + 1);
                 atomicMax(&I.stamp[ir], upto_i + 1);
-                w.pred[b] = dot;
-                w.coef[b] = 2.f * er / (float)B;  // d mean((pred-r)^2) / d pred
+                const float cm = 2.f * er / (float)B;  // d mean((pred-r)^2) / d pred
+                if (SORTED) {
+                    sp.recs[js] = make_int4(ur, inf.x, inf.y, b);
+                    sp.vals[js] = make_int4(__float_as_int(rating[b]), __float_as_int(sv), __float_as_int(dot), __float_as_int(cm));
+                    sp.mse_e[b] = e2;
+                } else {
+                    w.pred[b] = dot;
+                    w.coef[b] = cm;
+                }
             }
         } else if (lane == 0) {
             predict_out[b] = fminf(fmaxf(dot, 0.f), max_rating) / max_rating;
@@ -189,7 +217,7 @@ template <int E>
 __global__ __launch_bounds__(GATHER_THREADS) void focf_gather_sweep_kernel(
     TableV U, TableV I, AdamC c, const int64_t* __restrict__ user, const int64_t* __restrict__ item,
     const float* __restrict__ rating, int B, int upto_u, int upto_i, FocfWs w, uint32_t* err, DeferLoss dl, SweepSlice sw,
-    long long sw_n) {
+    long long sw_n, SortedPark sp) {
     __shared__ GatherLds<E> lds;
     const int nsb = (int)((sw_n + 3) / 4);
     if ((int)blockIdx.x < nsb) {
@@ -199,7 +227,7 @@ __global__ __launch_bounds__(GATHER_THREADS) void focf_gather_sweep_kernel(
     }
     const int block = (int)blockIdx.x - nsb;
     if (block == 0 && threadIdx.x == 0) *w.defer = dl;
-    focf_gather_body<E, true, true>(U, I, c, user, item, rating, B, upto_u, upto_i, w, 0.f, nullptr, err, block, lds);
+    focf_gather_body<E, true, true, true>(U, I, c, user, item, rating, B, upto_u, upto_i, w, 0.f, nullptr, err, block, lds, sp);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -732,14 +760,15 @@ extern "C" int fr_focf_prepare(const int64_t* user, const int64_t* item, const f
 // launches of fr_focf_step_runs): rows caught up and parked at their batch positions, scores, the MSE part of dLoss/dpred.
 namespace fr {
 int focf_launch_gather_runs(const fr_table* U, const fr_table* I, const AdamC& c, const int64_t* user, const int64_t* item,
-                            const float* rating, int64_t B, const FocfWs& w, uint32_t* err_flag, hipStream_t stream,
-                            const SweepSlice& sw, long long sweep_waves) {
+                            const float* rating, const float* sst, int64_t B, const FocfWs& w, uint32_t* err_flag,
+                            hipStream_t stream, const SweepSlice& sw, long long sweep_waves) {
     const TableV Uv = view(U), Iv = view(I);
     const DeferLoss dl{nullptr, 0, 0.f, 0};
+    const SortedPark sp{w.pos_i, w.info, sst, w.task_rec, w.task_info, w.mse_e};
     ProfScope prof(K_FOCF_GATHER, stream);
     const unsigned blocks = (unsigned)(w.n_gather_blocks + (sweep_waves + 3) / 4);
     FR_DISPATCH_E(U->dim, FR_LAUNCH(prof, (focf_gather_sweep_kernel<E>), dim3(blocks), dim3(GATHER_THREADS), 0, stream, Uv, Iv, c,
-                                    user, item, rating, (int)B, U->step - 1, I->step - 1, w, err_flag, dl, sw, sweep_waves));
+                                    user, item, rating, (int)B, U->step - 1, I->step - 1, w, err_flag, dl, sw, sweep_waves, sp));
     FR_CHECK_LAUNCH();
     return FR_OK;
 }

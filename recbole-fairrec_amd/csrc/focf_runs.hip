@@ -7,8 +7,9 @@
 //   loss.backward()      trainer.py:193   dense embedding_dense_backward of both tables
 //   optimizer.step()     trainer.py:196   dense torch.optim.Adam over both tables
 //
-//   launch 1  focf_gather_kernel (focf.hip, unchanged): one wave per interaction, rows caught up (the item row of a run
-//             replayed once per workgroup), scores, the caught-up (p, m, v) parked at the batch position.
+//   launch 1  the chain's gather (focf.hip: one wave per interaction, rows caught up, the item row of a run replayed once per
+//             workgroup, scores) in its SORTED form: what a member leaves behind -- caught-up (p, m, v) of both rows, two packed
+//             16-byte records -- is parked at the member's position in the item-sorted order, so a run's members sit side by side.
 //   launch 2  focf_runs_finish_kernel: ONE WORKGROUP PER ITEM RUN, RUN_WAVES waves.  Wave 0 forms the per-(item, group) sums of
 //             focf.py:75-91 in focf_fair_kernel<64>'s lane order (64 lanes strided over the members, butterfly: the same bits);
 //             every wave then takes every RUN_WAVES-th member -- dLoss/dpred = MSE part + fairness part, the member's user row
@@ -169,29 +170,26 @@ __device__ __forceinline__ T args_through_vgprs(int lane) {
 #define RUN_STAMP(i) do {} while (0)
 #endif
 
-// One item run [j0, j0 + n) of the item-sorted order, by all RUN_WAVES waves of a workgroup.  `bf` = batch position of the
-// run's first member (where launch 1 parked the item's caught-up row: every member's copy holds the same bits), `ir` = the
-// item's table row.  The loads are issued LEVEL BY LEVEL -- everything whose address is known goes out before the first
-// value is waited for -- because a dependent round trip costs ~2 us here and the run is a chain of them:
-//   level 1 (the caller)  K, the run's extent, bf, ir
-//   level 2               the item's parked (p, m, v); the members' batch positions (perm_i) for the statistics and for the
-//                         waves' own members
-//   level 3               the members' records, scores and MSE parts; the parked user rows of each wave's first four members
-//   (barrier behind the statistics)  ->  dLoss/dpred, Adam, stores; further members four at a time; the item's gradient from LDS
+// One item run [j0, j0 + n) of the item-sorted order, by all RUN_WAVES waves of a workgroup; `ir` = the item's table row.
+// Launch 1 parked everything BY SORTED POSITION (SortedPark, focf.hip): member q of the run sits at j0 + q -- its packed
+// records (user row, the extent of the user's segment, batch position | rating, sst, score, MSE part of dLoss/dpred) and its
+// caught-up rows -- and every member's copy of the item's caught-up row holds the same bits (the run's first one is read).
+// So ONE level of loads serves the whole run: a dependent round trip costs ~3 us in this launch, and the first version of this
+// function (positions -> records -> rows, four members at a time) was a chain of six (profiles/r04_runs_finish_wave_trace.txt).
 template <int E>
-__device__ __forceinline__ void run_finish_item(const RunArgs& a, int k, int ij0, int n, int bf, int ir, float* pu_s,
-                                                float* coef_s, float* sh, int lane, int wv) {
+__device__ __forceinline__ void run_finish_item(const RunArgs& a, int k, int ij0, int n, int ir, float* pu_s, float* coef_s,
+                                                float* sh, int lane, int wv) {
     constexpr int CAP = run_cap(E), MB = E == 1 ? 8 : 4;      // parked user rows in flight per wave (x 3 row fragments)
     const FocfWs& w = a.w;
     const int D = a.U.D, step = a.U.step;
     const bool per_item = a.objective >= FR_FOCF_VALUE && a.objective <= FR_FOCF_OVER;
     RUN_STAMP(0);
-    // ---- level 2 -----------------------------------------------------------------------------------------------------------
+    // ---- the one level of loads ---------------------------------------------------------------------------------------------
     RowFrag<E> pi, mi, vi;
-    gload_row<E>(pi, w.side[3] + (size_t)bf * D, D, lane);
+    gload_row<E>(pi, w.side[3] + (size_t)ij0 * D, D, lane);
     if (wv == 0) {
-        gload_row<E>(mi, w.side[4] + (size_t)bf * D, D, lane);
-        gload_row<E>(vi, w.side[5] + (size_t)bf * D, D, lane);
+        gload_row<E>(mi, w.side[4] + (size_t)ij0 * D, D, lane);
+        gload_row<E>(vi, w.side[5] + (size_t)ij0 * D, D, lane);
     }
     float smin = 0.f, smax = 0.f, Kf = 1.f;
     if (per_item) {
@@ -199,39 +197,27 @@ __device__ __forceinline__ void run_finish_item(const RunArgs& a, int k, int ij0
         smax = G(w.sst_minmax)[1];
         Kf = (float)G(w.nseg_i)[0];
     }
-    // statistics (wave 0): lane `sub` takes members sub, sub + 64, ... -- the first two positions now, further ones in a loop
-    int sb0 = 0, sb1 = 0;
+    // statistics (wave 0): lane `sub` takes members sub, sub + 64, ... -- the first two now, further ones in a loop
     const bool s0 = wv == 0 && per_item && lane < n, s1 = wv == 0 && per_item && lane + 64 < n;
-    if (s0) sb0 = G(w.perm_i)[ij0 + lane];
-    if (s1) sb1 = G(w.perm_i)[ij0 + lane + 64];
-    // this wave's members of the FIRST pass: every RUN_WAVES-th one, lane t holds the t-th
+    int4 sv0 = make_int4(0, 0, 0, 0), sv1 = make_int4(0, 0, 0, 0);
+    if (s0) sv0 = ld4(w.task_info, ij0 + lane);
+    if (s1) sv1 = ld4(w.task_info, ij0 + lane + 64);
+    // this wave's members of the FIRST pass: every RUN_WAVES-th one, lane t holds the records of the t-th
     const int cnt0 = min(CAP, n);
     const int mine0 = cnt0 > wv ? (cnt0 - wv + RUN_WAVES - 1) / RUN_WAVES : 0;
-    int lb = 0;
-    if (lane < mine0) lb = G(w.perm_i)[ij0 + wv + RUN_WAVES * lane];
-    // ---- level 3 -----------------------------------------------------------------------------------------------------------
-    int4 src0 = make_int4(0, 0, 0, 0), src1 = make_int4(0, 0, 0, 0);
-    float spr0 = 0.f, spr1 = 0.f;
-    if (s0) { src0 = ld4(w.rec, sb0); spr0 = G(w.pred)[sb0]; }
-    if (s1) { src1 = ld4(w.rec, sb1); spr1 = G(w.pred)[sb1]; }
-    int4 lrc = make_int4(0, 0, 0, 0), linf = make_int4(0, 0, 0, 0);
-    float lpr = 0.f, lcf = 0.f;
+    int4 lrc = make_int4(0, 0, 0, 0), lvl = make_int4(0, 0, 0, 0);
     if (lane < mine0) {
-        lrc = ld4(w.rec, lb);
-        linf = ld4(w.info, lb);
-        lpr = G(w.pred)[lb];
-        lcf = G(w.coef)[lb];                   // the MSE part 2 (pred - r) / B, as focf_gather_kernel left it
+        lrc = ld4(w.task_rec, ij0 + wv + RUN_WAVES * lane);
+        lvl = ld4(w.task_info, ij0 + wv + RUN_WAVES * lane);
     }
     RowFrag<E> pu[MB], mu[MB], vu[MB];
-    int bq[MB];
 #pragma unroll
     for (int u = 0; u < MB; ++u) {
-        bq[u] = 0;
         if (u < mine0) {
-            bq[u] = __builtin_amdgcn_readlane(lb, u);
-            gload_row<E>(pu[u], w.side[0] + (size_t)bq[u] * D, D, lane);
-            gload_row<E>(mu[u], w.side[1] + (size_t)bq[u] * D, D, lane);
-            gload_row<E>(vu[u], w.side[2] + (size_t)bq[u] * D, D, lane);
+            const size_t so = (size_t)(ij0 + wv + RUN_WAVES * u) * D;
+            gload_row<E>(pu[u], w.side[0] + so, D, lane);
+            gload_row<E>(mu[u], w.side[1] + so, D, lane);
+            gload_row<E>(vu[u], w.side[2] + so, D, lane);
         }
     }
     RUN_STAMP(1);
@@ -242,9 +228,9 @@ __device__ __forceinline__ void run_finish_item(const RunArgs& a, int k, int ij0
         if (per_item && FR_RUN_DIAG != 3) {
             float sp0 = 0.f, sp1 = 0.f, st0 = 0.f, st1_ = 0.f, n0 = 0.f, n1 = 0.f;
             bool bad = false;
-            auto add = [&](bool on, const int4& rc, float pr) {
+            auto add = [&](bool on, const int4& v) {
                 if (!on) return;
-                const float r = __int_as_float(rc.z), s = __int_as_float(rc.w);
+                const float r = __int_as_float(v.x), s = __int_as_float(v.y), pr = __int_as_float(v.z);
                 bad |= (s != smin && s != smax);
                 if (s == smin) {
                     sp0 += pr; st0 += r; n0 += 1.f;
@@ -252,12 +238,9 @@ __device__ __forceinline__ void run_finish_item(const RunArgs& a, int k, int ij0
                     sp1 += pr; st1_ += r; n1 += 1.f;
                 }
             };
-            add(s0, src0, spr0);
-            add(s1, src1, spr1);
-            for (int j = ij0 + lane + 128; j < ij0 + n; j += 64) {       // runs of more than 128 members
-                const int b = G(w.perm_i)[j];
-                add(true, ld4(w.rec, b), G(w.pred)[b]);
-            }
+            add(s0, sv0);
+            add(s1, sv1);
+            for (int j = ij0 + lane + 128; j < ij0 + n; j += 64) add(true, ld4(w.task_info, j));      // runs of > 128 members
             if (bad && a.err) atomicOr(a.err, FR_DEV_ERR_SST_GROUPS);
             sp0 = group_sum<64>(sp0); sp1 = group_sum<64>(sp1);
             st0 = group_sum<64>(st0); st1_ = group_sum<64>(st1_);
@@ -282,29 +265,25 @@ __device__ __forceinline__ void run_finish_item(const RunArgs& a, int k, int ij0
         const int cnt = min(CAP, n - base);
         const int mine = cnt > wv ? (cnt - wv + RUN_WAVES - 1) / RUN_WAVES : 0;
         if (base > 0) {                            // (a further pass of a long run: its records now)
-            lb = 0;
+            lrc = make_int4(0, 0, 0, 0);
+            lvl = make_int4(0, 0, 0, 0);
             if (lane < mine) {
-                lb = G(w.perm_i)[ij0 + base + wv + RUN_WAVES * lane];
-                lrc = ld4(w.rec, lb);
-                linf = ld4(w.info, lb);
-                lpr = G(w.pred)[lb];
-                lcf = G(w.coef)[lb];
+                lrc = ld4(w.task_rec, ij0 + base + wv + RUN_WAVES * lane);
+                lvl = ld4(w.task_info, ij0 + base + wv + RUN_WAVES * lane);
             }
         }
         // Users that occur under several items of the batch: ALL of this wave's such members arrive now, lane-parallel, before
-        // the wave has any row store in flight -- dLoss/dpred handed over (write-through), ONE drain, one atomic per lane.  Done
-        // member by member inside the loop below (store, drain, atomic, and for the last arriver a chain of loads), every such
-        // member held its wave for ~10 us behind the stores of the members before it, and most runs have one: 13 of the 24 us
-        // of this launch.
-        float lco = lcf;
-        if (per_item) lco = lcf + ((__int_as_float(lrc.w) == smin) ? g0 : g1);      // + the fairness part, as focf_fair_kernel adds it
-        const int lnu = (linf.x >> 16) & 0xffff;
+        // the wave has any row store in flight -- dLoss/dpred handed over (write-through, by batch position), ONE drain, one
+        // atomic per lane.
+        float lco = __int_as_float(lvl.w);         // the MSE part 2 (pred - r) / B, as focf_gather_kernel formed it
+        if (per_item) lco = lco + ((__int_as_float(lvl.y) == smin) ? g0 : g1);      // + the fairness part, as focf_fair_kernel adds it
+        const int lnu = (lrc.y >> 16) & 0xffff;
         const bool lmulti = lane < mine && lnu > 1;
         unsigned lold = 0;
         if (__ballot(lmulti)) {
-            if (lmulti) st1(w.coef + lb, lco);
+            if (lmulti) st1(w.coef + lrc.w, lco);
             drain();
-            if (lmulti) lold = __hip_atomic_fetch_add(G(w.cnt_u) + linf.y, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lmulti) lold = __hip_atomic_fetch_add(G(w.cnt_u) + lrc.z, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         const bool llast = lmulti && (int)lold + 1 == lnu;
         // (b) the members of this pass, MB at a time
@@ -316,33 +295,24 @@ __device__ __forceinline__ void run_finish_item(const RunArgs& a, int k, int ij0
             if (base > 0 || t0 > 0) {
 #pragma unroll
                 for (int u = 0; u < MB; ++u) {
-                    bq[u] = 0;
                     if (t0 + u < mine) {
-                        bq[u] = __builtin_amdgcn_readlane(lb, t0 + u);
-                        gload_row<E>(pu[u], w.side[0] + (size_t)bq[u] * D, D, lane);
-                        gload_row<E>(mu[u], w.side[1] + (size_t)bq[u] * D, D, lane);
-                        gload_row<E>(vu[u], w.side[2] + (size_t)bq[u] * D, D, lane);
+                        const size_t so = (size_t)(ij0 + base + wv + RUN_WAVES * (t0 + u)) * D;
+                        gload_row<E>(pu[u], w.side[0] + so, D, lane);
+                        gload_row<E>(mu[u], w.side[1] + so, D, lane);
+                        gload_row<E>(vu[u], w.side[2] + so, D, lane);
                     }
                 }
             }
 #pragma unroll
             for (int u = 0; u < MB; ++u) {
                 if (t0 + u >= mine) break;
-                const int t = t0 + u, q = wv + RUN_WAVES * t, b = bq[u];
+                const int t = t0 + u, q = wv + RUN_WAVES * t;
                 const int ur = __builtin_amdgcn_readlane(lrc.x, t);
-                const float r = __int_as_float(__builtin_amdgcn_readlane(lrc.z, t));
-                const float s = __int_as_float(__builtin_amdgcn_readlane(lrc.w, t));
-                const int ux = __builtin_amdgcn_readlane(linf.x, t), useg = __builtin_amdgcn_readlane(linf.y, t);
-                const float pr = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lpr), t));
+                const int ux = __builtin_amdgcn_readlane(lrc.y, t);
                 const float coef = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lco), t));
-                const float er = pr - r;
-                (void)s;
 #pragma unroll
                 for (int e = 0; e < E; ++e) pu_s[(size_t)q * (64 * E) + lane + 64 * e] = pu[u].x[e];
-                if (lane == 0) {
-                    coef_s[q] = coef;
-                    G(w.mse_e)[b] = er * er;
-                }
+                if (lane == 0) coef_s[q] = coef;
                 const int uj0 = ux & 0xffff, nu = (ux >> 16) & 0xffff;
                 RowFrag<E> g;
 #pragma unroll
@@ -359,22 +329,21 @@ __device__ __forceinline__ void run_finish_item(const RunArgs& a, int k, int ij0
                 } else {
                     // the user occurs under several items (arrived above): its LAST arriver sums the user's gradient rows in
                     // ascending batch position (segment_grad_sum's order) from the items' parked rows
-                    (void)useg;
                     finish = __builtin_amdgcn_readlane((int)llast, t) != 0;
                     if (finish) {
                         // the caught-up state of the user's FIRST member, as segment_update takes it (launch 1 replayed the
                         // row once per occurrence: the same bits, but the rule keeps the result independent of who is last)
                         const int bu = uniform(G(w.perm_u)[uj0]);
-                        if (bu != b) {
-                            gload_row<E>(pu[u], w.side[0] + (size_t)bu * D, D, lane);
-                            gload_row<E>(mu[u], w.side[1] + (size_t)bu * D, D, lane);
-                            gload_row<E>(vu[u], w.side[2] + (size_t)bu * D, D, lane);
-                        }
+                        const int ju0 = uniform(G(w.pos_i)[bu]);
+                        gload_row<E>(pu[u], w.side[0] + (size_t)ju0 * D, D, lane);
+                        gload_row<E>(mu[u], w.side[1] + (size_t)ju0 * D, D, lane);
+                        gload_row<E>(vu[u], w.side[2] + (size_t)ju0 * D, D, lane);
                         for (int ju = uj0; ju < uj0 + nu; ++ju) {
                             const int bb = uniform(G(w.perm_u)[ju]);
                             const float cb = ld1(w.coef + bb);
+                            const int jb = uniform(G(w.pos_i)[bb]);
                             RowFrag<E> o;
-                            gload_row<E>(o, w.side[3] + (size_t)bb * D, D, lane);      // member bb's copy of ITS item's row
+                            gload_row<E>(o, w.side[3] + (size_t)jb * D, D, lane);      // member bb's copy of ITS item's row
                             {
 #pragma clang fp contract(off)
 #pragma unroll
@@ -477,10 +446,10 @@ __global__ __launch_bounds__(RUN_THREADS) void focf_runs_finish_kernel(RunArgs a
     for (int k = blk; k < a.B; k += a.n_item_blocks) {
         // level 1: everything about run k in ONE round trip (entries past the last run are read and not used)
         const int rK = G(a.w.nseg_i)[0], rj0 = G(a.w.seg_start_i)[k], rj1 = G(a.w.seg_start_i)[k + 1];
-        const int rbf = G(a.w.seg_first_i)[k], rir = G(a.w.seg_row_i)[k];
+        const int rir = G(a.w.seg_row_i)[k];
         if (k >= uniform(rK) || FR_RUN_DIAG == 4) break;
         const int j0 = uniform(rj0);
-        run_finish_item<E>(a, k, j0, uniform(rj1) - j0, uniform(rbf), uniform(rir), lds_rows, coef_s, sh, lane, wv);
+        run_finish_item<E>(a, k, j0, uniform(rj1) - j0, uniform(rir), lds_rows, coef_s, sh, lane, wv);
         __syncthreads();
     }
 }
@@ -534,7 +503,7 @@ extern "C" int fr_focf_step_runs(const fr_table* U, const fr_table* I, const fr_
         sweep_blocks = (a.n_sweep_waves + RUN_WAVES - 1) / RUN_WAVES;
     }
     // launch 1: rows caught up and parked at their batch positions, scores, the MSE part of dLoss/dpred
-    if ((rc = focf_launch_gather_runs(U, I, a.c, user, item, rating, B, a.w, err_flag, stream, a.sw, in_gather))) return rc;
+    if ((rc = focf_launch_gather_runs(U, I, a.c, user, item, rating, sst, B, a.w, err_flag, stream, a.sw, in_gather))) return rc;
     a.prev = prev_of(prev_ws, prev_B, U->dim, objective, fair_weight, prev_loss_out, loss_acc, false);
     a.n_item_blocks = (int)std::min<long long>(FR_RUN_ITEM_BLOCKS, B);
     ProfScope prof(K_FOCF_STEP, stream);

@@ -1705,6 +1705,7 @@ extern "C" int fr_focf_prepare_step(const fr_focf_batch* batches, const int32_t*
         ji.last = I->last;
         ju.last_out = w.age_u;
         ji.last_out = w.age_i;
+        ji.pos_of = w.pos_i;
         jobs.j[2 * q] = ju;
         jobs.j[2 * q + 1] = ji;
         jobs.M[2 * q] = jobs.M[2 * q + 1] = (int)b.B;

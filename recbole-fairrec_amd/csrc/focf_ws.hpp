@@ -39,6 +39,7 @@ struct FocfWs {
     int4* task_info;
     unsigned int *cnt_u, *cnt_i;
     int32_t *age_u, *age_i;   // [B] `last` stamp of each position's user / item row as of the prepare launch
+    int32_t* pos_i;           // [B] sorted position of each batch position in the item order (inverse of perm_i; fr_focf_prepare_step)
     float* mse_e;        // [B]
     float* term;         // [B] indexed by item segment
     int32_t* sw_order;   // [SWEEP_ORDER_MAX + 1] start order of the step's sweeper tasks (pairs of rows of the sweep slice),
@@ -99,6 +100,7 @@ __host__ __device__ inline FocfWs focf_layout(void* base, int64_t B, int D) {
     w.cnt_i = (unsigned int*)take(Bp * 4);
     w.age_u = (int32_t*)take(Bp * 4);
     w.age_i = (int32_t*)take(Bp * 4);
+    w.pos_i = (int32_t*)take(Bp * 4);
     w.mse_e = (float*)take(Bp * 4);
     w.term = (float*)take(Bp * 4);
     w.sw_order = (int32_t*)take(((size_t)SWEEP_ORDER_MAX + 1) * 4);
@@ -196,8 +198,8 @@ __device__ __forceinline__ void focf_fair_eval(int objective, float fair_weight,
 // focf.hip: focf_gather_kernel<E, TRAIN, SHARE> on an item-complete batch, as a launch of its own (fr_focf_step_runs)
 // (the first `sweep_waves` waves of the step's sweep slice `sw` ride in front of the gather)
 int focf_launch_gather_runs(const fr_table* U, const fr_table* I, const AdamC& c, const int64_t* user, const int64_t* item,
-                            const float* rating, int64_t B, const FocfWs& w, uint32_t* err_flag, hipStream_t stream,
-                            const SweepSlice& sw, long long sweep_waves);
+                            const float* rating, const float* sst, int64_t B, const FocfWs& w, uint32_t* err_flag,
+                            hipStream_t stream, const SweepSlice& sw, long long sweep_waves);
 
 inline SweepSlice make_sweep_slice(const fr_table* U, const fr_table* I, int32_t sweep_period) {
     SweepSlice sw{};

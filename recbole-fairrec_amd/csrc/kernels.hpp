@@ -80,6 +80,8 @@ struct SortJob {
     const int64_t* rec_idx;
     int64_t rec_rows;
     const float* rec_f0;
+    int32_t* pos_of;       // optional [M]: sorted position j of batch position b (the inverse of perm), for consumers that park
+                           //   per-member data in SORTED order so that a segment's members sit side by side (focf_runs.hip)
 };
 
 // Sort index lists in one launch, one workgroup each: (a) or (a, b) of the same length M ...

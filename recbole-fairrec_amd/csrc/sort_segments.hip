@@ -281,6 +281,7 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_segments_kernel(SortJobList
             const int seg = wcnt[q * 16 + wid] + __popcll(bal[q] & (lt_mask | (1ull << lane))) - 1;
             const int b = (int)(unsigned)k;
             job.perm[j] = b;
+            if (job.pos_of) job.pos_of[b] = j;
             if ((bal[q] >> lane) & 1ull) {
                 job.seg_start[seg] = j;
                 job.seg_row[seg] = (int)(unsigned)(k >> 32);

@@ -234,11 +234,14 @@ class FairGo_PMF(FairRecommender):
             rows_out.append(RowGather.apply(H, pos[user].to(torch.int64), eng.err_flag))
         return rows_out
 
-    def _dis_terms(self, E, interaction, sst_list, props=None):
-        """calculate_dis_loss, fairgo_pmf.py:190-238, on an already filtered whole table E."""
+    def _dis_terms(self, E, interaction, sst_list, props=None, node=None):
+        """calculate_dis_loss, fairgo_pmf.py:190-238, on an already filtered whole table E.  `node` = E[user] when the caller
+        gathered those rows already (the filter step's rating term does): one gather -- and one dense [N, D] gradient with its
+        zero fill and scatter, 5.6 GB at BASELINE configs[3] -- instead of two."""
         eng = self.hip_engine()
         user = interaction[self.USER_ID].to(eng.device)
-        node = RowGather.apply(E, user, eng.err_flag)
+        if node is None:
+            node = RowGather.apply(E, user, eng.err_flag)
         lva = self.aggr_method == 'LVA' and self.n_layers > 1
         layer_rows = None
         if props is None and self.use_frontier() and not torch.cuda.is_current_stream_capturing():
@@ -338,7 +341,7 @@ class FairGo_PMF(FairRecommender):
         # the reference's calculate_dis_loss runs forward() a second time (fairgo_pmf.py:205-206): the same values from the
         # same parameters, so ONE filtered table serves both terms -- its gradient is the sum of the two uses, which is
         # what the two backward passes through the filters add up to (linear in dLoss/dE; rounding-level difference)
-        fair = self._dis_terms(E, interaction, sst_list)
+        fair = self._dis_terms(E, interaction, sst_list, node=rows[:B])
         return mse - self.fair_weight * fair
 
     def predict(self, interaction):
