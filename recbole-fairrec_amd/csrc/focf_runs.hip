@@ -52,6 +52,9 @@ constexpr int RUN_THREADS = 64 * RUN_WAVES;
 #ifndef FR_RUN_DIAG
 #define FR_RUN_DIAG 0        // diagnostic builds: 1 skips the members' updates, 2 the item's gradient sum, 3 the statistics,
 #endif                     // 4 the whole item work (what the launch costs with its first and last workgroup only)
+#ifndef FR_RUN_MB1
+#define FR_RUN_MB1 8         // members of a wave whose parked rows are in flight at once, D <= 64
+#endif
 #ifndef FR_RUN_CAP_BYTES
 #define FR_RUN_CAP_BYTES 32768        // LDS of a pass: RUN_CAP caught-up user rows (+ their coefficients)
 #endif
@@ -179,7 +182,7 @@ __device__ __forceinline__ T args_through_vgprs(int lane) {
 template <int E>
 __device__ __forceinline__ void run_finish_item(const RunArgs& a, int k, int ij0, int n, int ir, float* pu_s, float* coef_s,
                                                 float* sh, int lane, int wv) {
-    constexpr int CAP = run_cap(E), MB = E == 1 ? 8 : 4;      // parked user rows in flight per wave (x 3 row fragments)
+    constexpr int CAP = run_cap(E), MB = E == 1 ? FR_RUN_MB1 : 4;      // parked user rows in flight per wave (x 3 row fragments)
     const FocfWs& w = a.w;
     const int D = a.U.D, step = a.U.step;
     const bool per_item = a.objective >= FR_FOCF_VALUE && a.objective <= FR_FOCF_OVER;
