@@ -592,6 +592,10 @@ FR_API int fr_row_gather(const float* X, const int64_t* idx, int64_t M, int64_t 
 FR_API size_t fr_row_scatter_workspace_bytes(int64_t M);
 FR_API int fr_row_scatter_sum(const float* g, const int64_t* idx, int64_t M, int64_t n_rows, int32_t dim, float* dX,
                               void* ws, size_t ws_bytes, uint32_t* err_flag, void* stream);
+/* ... ADDED into a dX that already holds another contribution to the same gradient (no clear): the backward of a table that
+ * is both row-gathered and propagated (fairgo_pmf.py:178-201) then costs one dense [n_rows, dim] pass instead of three. */
+FR_API int fr_row_scatter_add(const float* g, const int64_t* idx, int64_t M, int64_t n_rows, int32_t dim, float* dX,
+                              void* ws, size_t ws_bytes, uint32_t* err_flag, void* stream);
 FR_API int fr_mse(const float* pred, const float* target, int64_t B, float* loss, float* dpred, void* ws, size_t ws_bytes,
                   void* stream);
 

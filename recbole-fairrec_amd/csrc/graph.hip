@@ -123,7 +123,9 @@ __global__ __launch_bounds__(256) void row_gather_kernel(const float* __restrict
     for (int d = lane; d < D; d += 64) out[(size_t)j * D + d] = X[(size_t)r * D + d];
 }
 
-// dX[seg_row[k],:] = sum over the segment's members (ascending position) of g[member,:]; dX is pre-zeroed
+// dX[seg_row[k],:] = sum over the segment's members (ascending position) of g[member,:]; dX is pre-zeroed -- or (ADD) holds
+// another contribution to the same gradient already, to which the segment's sum is added
+template <bool ADD>
 __global__ __launch_bounds__(256) void row_scatter_sum_kernel(const float* __restrict__ g, const int32_t* __restrict__ perm,
                                                               const int32_t* __restrict__ seg_start,
                                                               const int32_t* __restrict__ seg_row,
@@ -137,7 +139,7 @@ __global__ __launch_bounds__(256) void row_scatter_sum_kernel(const float* __res
     for (int d = lane; d < D; d += 64) {
         float acc = 0.f;
         for (int j = j0; j < j1; ++j) acc += g[(size_t)perm[j] * D + d];
-        dX[row * D + d] = acc;
+        dX[row * D + d] = ADD ? dX[row * D + d] + acc : acc;
     }
 }
 
@@ -251,11 +253,25 @@ extern "C" size_t fr_row_scatter_workspace_bytes(int64_t M) {
 }
 
 // dX [n_rows, dim] (zeroed here) += rows of g [M, dim] at idx, duplicates summed in ascending position
+static int row_scatter_impl(const float* g, const int64_t* idx, int64_t M, int64_t n_rows, int32_t dim, float* dX, void* ws,
+                            size_t ws_bytes, uint32_t* err_flag, void* stream_, bool add);
+
 extern "C" int fr_row_scatter_sum(const float* g, const int64_t* idx, int64_t M, int64_t n_rows, int32_t dim, float* dX,
                                   void* ws, size_t ws_bytes, uint32_t* err_flag, void* stream_) {
+    return row_scatter_impl(g, idx, M, n_rows, dim, dX, ws, ws_bytes, err_flag, stream_, false);
+}
+
+// ... the same into a dX that already holds another contribution to the gradient (no clear; the segment sums are ADDED)
+extern "C" int fr_row_scatter_add(const float* g, const int64_t* idx, int64_t M, int64_t n_rows, int32_t dim, float* dX,
+                                  void* ws, size_t ws_bytes, uint32_t* err_flag, void* stream_) {
+    return row_scatter_impl(g, idx, M, n_rows, dim, dX, ws, ws_bytes, err_flag, stream_, true);
+}
+
+static int row_scatter_impl(const float* g, const int64_t* idx, int64_t M, int64_t n_rows, int32_t dim, float* dX, void* ws,
+                            size_t ws_bytes, uint32_t* err_flag, void* stream_, bool add) {
     hipStream_t stream = (hipStream_t)stream_;
     FR_CHECK_ARG(g && idx && dX && ws && M >= 1 && M <= FR_SORT_MAX && dim >= 1 && ws_bytes >= fr_row_scatter_workspace_bytes(M),
-                 "fr_row_scatter_sum: bad argument");
+                 "fr_row_scatter_sum / _add: bad argument");
     char* p = (char*)ws;
     const size_t stride = align_up(((size_t)M + 1) * 4, 256);
     int32_t* perm = (int32_t*)p;
@@ -273,7 +289,9 @@ extern "C" int fr_row_scatter_sum(const float* g, const int64_t* idx, int64_t M,
     // the memset for A/B runs.
     static const bool use_memset = getenv("FAIRREC_SCATTER_MEMSET") != nullptr;
     const size_t n = (size_t)n_rows * dim;
-    if (use_memset) {
+    if (add) {
+        // nothing to clear
+    } else if (use_memset) {
         FR_CHECK_HIP(hipMemsetAsync(dX, 0, n * sizeof(float), stream));
     } else {
         const unsigned blocks = (unsigned)std::min<size_t>(std::max<size_t>((n / 4 + 255) / 256, 1), 4096);
@@ -281,8 +299,13 @@ extern "C" int fr_row_scatter_sum(const float* g, const int64_t* idx, int64_t M,
         FR_CHECK_LAUNCH();
     }
     ProfScope prof(K_ROW_GATHER, stream);
-    FR_LAUNCH(prof, row_scatter_sum_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, stream, g, (const int32_t*)perm,
-              (const int32_t*)seg_start, (const int32_t*)seg_row, (const int32_t*)nseg, (int)M, (int)dim, dX);
+    if (add) {
+        FR_LAUNCH(prof, row_scatter_sum_kernel<true>, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, stream, g, (const int32_t*)perm,
+                  (const int32_t*)seg_start, (const int32_t*)seg_row, (const int32_t*)nseg, (int)M, (int)dim, dX);
+    } else {
+        FR_LAUNCH(prof, row_scatter_sum_kernel<false>, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, stream, g, (const int32_t*)perm,
+                  (const int32_t*)seg_start, (const int32_t*)seg_row, (const int32_t*)nseg, (int)M, (int)dim, dX);
+    }
     FR_CHECK_LAUNCH();
     return FR_OK;
 }

@@ -200,6 +200,8 @@ _PROTOS = {
     "fr_row_scatter_workspace_bytes": (c_size_t, [c_int64]),
     "fr_row_scatter_sum": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int32, c_void_p, c_void_p, c_size_t, c_void_p,
                                    c_void_p]),
+    "fr_row_scatter_add": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int32, c_void_p, c_void_p, c_size_t, c_void_p,
+                                   c_void_p]),
     "fr_mse": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "fr_prof_enable": (c_int, [c_int]),
     "fr_prof_reset": (c_int, []),

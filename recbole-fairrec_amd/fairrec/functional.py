@@ -316,6 +316,50 @@ class SpMMSel(torch.autograd.Function):
         return dX, None, None, None, None, None
 
 
+class GatherAndSpMMSel(torch.autograd.Function):
+    """(X[idx], SpMMSel(X, L, rows, rpos)) of ONE whole-table operand as one autograd node: the two uses of X meet in the
+    backward as ONE dense [N, D] gradient -- fr_spmm_csr_sel writes it (every row: zeros where the batch sees nothing), then
+    fr_row_scatter_add adds the gathered rows' gradients, duplicates summed in ascending position -- where two nodes cost a
+    zero fill, a second dense tensor and autograd's addition of the two (three more whole-table passes).  The same two
+    addends per element: the same bits."""
+
+    @staticmethod
+    def forward(ctx, X, idx, err_flag, L: CsrMatrix, rows, rpos):
+        X = X.contiguous()
+        idx = idx.contiguous().to(torch.int64)
+        M, (N, D) = idx.numel(), X.shape
+        out = torch.empty((M, D), dtype=torch.float32, device=X.device)
+        _C.check(_C.lib().fr_row_gather(X.data_ptr(), idx.data_ptr(), M, N, D, out.data_ptr(), _C.ptr(err_flag),
+                                        _C.current_stream()), "fr_row_gather")
+        Y = torch.empty((rows.numel(), D), dtype=torch.float32, device=X.device)
+        ip, col, val = L.fwd
+        _C.check(_C.lib().fr_spmm_csr_sel(ip.data_ptr(), col.data_ptr(), val.data_ptr(), X.data_ptr(), rows.data_ptr(),
+                                          rows.numel(), None, D, Y.data_ptr(), _C.current_stream()), "fr_spmm_csr_sel")
+        ctx.save_for_backward(idx)
+        ctx.meta = (N, D, err_flag, L, rpos)
+        return out, Y
+
+    @staticmethod
+    def backward(ctx, g_rows, dY):
+        (idx,) = ctx.saved_tensors
+        N, D, err, L, rpos = ctx.meta
+        dX = torch.empty((N, D), dtype=torch.float32, device=idx.device)
+        ip, col, val = L.bwd
+        if dY is None:
+            dX.zero_()
+        else:
+            dY = dY.contiguous()
+            _C.check(_C.lib().fr_spmm_csr_sel(ip.data_ptr(), col.data_ptr(), val.data_ptr(), dY.data_ptr(), None, N,
+                                              rpos.data_ptr(), D, dX.data_ptr(), _C.current_stream()), "fr_spmm_csr_sel")
+        if g_rows is not None:
+            g_rows = g_rows.contiguous()
+            M = idx.numel()
+            ws = _ws(_C.lib().fr_row_scatter_workspace_bytes(M), dX.device)
+            _C.check(_C.lib().fr_row_scatter_add(g_rows.data_ptr(), idx.data_ptr(), M, N, D, dX.data_ptr(), ws.data_ptr(),
+                                                 ws.numel(), _C.ptr(err), _C.current_stream()), "fr_row_scatter_add")
+        return dX, None, None, None, None, None
+
+
 class RowGather(torch.autograd.Function):
     """X[idx] on a whole-table activation (fairgo_pmf.py:178-179); backward = dense gradient with duplicates summed in
     ascending batch position (fixed order, no atomics)."""

@@ -129,6 +129,8 @@ class FairGo_GCN(FairGo_PMF):
         self.hip_engine()
         if self.train_stage == 'pretrain' and torch.is_grad_enabled():
             return torch.cat([self.user_embedding_layer.weight, self.item_embedding_layer.weight], dim=0)
+        if self.train_stage == 'finetune':                 # frozen tables: the concatenation is kept (FairGo_PMF)
+            return super().get_ego_embeddings()
         return torch.cat([self.user_embedding_layer.weight.data, self.item_embedding_layer.weight.data], dim=0)
 
     def _filtered_table(self, sst_list):

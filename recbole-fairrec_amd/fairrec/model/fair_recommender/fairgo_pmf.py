@@ -20,7 +20,7 @@ import torch
 import torch.nn as nn
 
 from ...engine import GenericEngine
-from ...functional import CsrMatrix, Mse, RowDot, RowGather, SigmoidBce, SoftmaxCe, SpMM, SpMMSel
+from ...functional import CsrMatrix, GatherAndSpMMSel, Mse, RowDot, RowGather, SigmoidBce, SoftmaxCe, SpMM, SpMMSel
 from ...utils.enum_type import InputType
 from ..abstract_recommender import FairRecommender
 from ..layers import ACT_CODES, MLPLayers, _HipMLP, activation_layer
@@ -131,8 +131,20 @@ class FairGo_PMF(FairRecommender):
 
     # --- forward pieces -----------------------------------------------------------------------------------------------
     def get_ego_embeddings(self):
-        self.hip_engine().flush()      # no-op unless the pretrain stage left rows behind the optimizer step
-        return torch.cat([self.user_embedding_layer.weight.data, self.item_embedding_layer.weight.data], dim=0)
+        """cat(user table, item table) (fairgo_pmf.py:131-140).  The finetune stage freezes both tables (trainer.py:857-862), so the
+        concatenation of one step is the next step's: it is kept while neither table moved (torch's version counters for
+        in-place writes such as load_state_dict, the engine's step count of the 'pretrain' group for the kernels' writes) --
+        11 GB of copy traffic per filter step at BASELINE configs[3]."""
+        eng = self.hip_engine()
+        eng.flush()      # no-op unless the pretrain stage left rows behind the optimizer step
+        uw, iw = self.user_embedding_layer.weight, self.item_embedding_layer.weight
+        if self.train_stage != 'finetune':
+            return torch.cat([uw.data, iw.data], dim=0)
+        key = (uw.data_ptr(), iw.data_ptr(), uw._version, iw._version, eng.group_version('pretrain'))
+        c = getattr(self, '_ego_cache', None)
+        if c is None or c[0] != key:
+            c = self._ego_cache = (key, torch.cat([uw.data, iw.data], dim=0))
+        return c[1]
 
     def _filtered_table(self, sst_list):
         E = self.get_ego_embeddings()
@@ -143,7 +155,9 @@ class FairGo_PMF(FairRecommender):
             for sst in sst_list:
                 e = self.filter_layer_dict[sst](E)
                 tmp = e if tmp is None else tmp + e
-            E = tmp / len(self.filter_layer_dict)
+            # (x / 1 is x, bit for bit, and so is its gradient: with ONE filter the whole-table division and its backward --
+            # 22 GB of traffic per filter step at BASELINE configs[3] -- are skipped)
+            E = tmp if len(self.filter_layer_dict) == 1 else tmp / len(self.filter_layer_dict)
         return E
 
     def forward(self, sst_list=None):
@@ -221,20 +235,21 @@ class FairGo_PMF(FairRecommender):
             out.append((rows.to(torch.int32), pos))
         return out
 
-    def _propagate_rows(self, E, user):
-        """[H_1[user], ..., H_n[user]] ([B, D] each) through products over the frontier's rows only; None = not worth it."""
-        fr = self._frontier(user)
+    def _propagate_rows(self, E, user, fr=None, H1=None):
+        """[H_1[user], ..., H_n[user]] ([B, D] each) through products over the frontier's rows only; None = not worth it.
+        `fr`, `H1`: the frontier and its first layer's rows when the caller has them already (calculate_loss)."""
+        fr = self._frontier(user) if fr is None else fr
         if fr is None:
             return None
         eng = self.hip_engine()
         H, prev, rows_out = E, (None, None), []
-        for rows, pos in fr:
-            H = SpMMSel.apply(H, self._L, rows, pos, prev[0], prev[1])
+        for l, (rows, pos) in enumerate(fr):
+            H = H1 if (l == 0 and H1 is not None) else SpMMSel.apply(H, self._L, rows, pos, prev[0], prev[1])
             prev = (rows, pos)
             rows_out.append(RowGather.apply(H, pos[user].to(torch.int64), eng.err_flag))
         return rows_out
 
-    def _dis_terms(self, E, interaction, sst_list, props=None, node=None):
+    def _dis_terms(self, E, interaction, sst_list, props=None, node=None, frontier=None):
         """calculate_dis_loss, fairgo_pmf.py:190-238, on an already filtered whole table E.  `node` = E[user] when the caller
         gathered those rows already (the filter step's rating term does): one gather -- and one dense [N, D] gradient with its
         zero fill and scatter, 5.6 GB at BASELINE configs[3] -- instead of two."""
@@ -244,7 +259,9 @@ class FairGo_PMF(FairRecommender):
             node = RowGather.apply(E, user, eng.err_flag)
         lva = self.aggr_method == 'LVA' and self.n_layers > 1
         layer_rows = None
-        if props is None and self.use_frontier() and not torch.cuda.is_current_stream_capturing():
+        if frontier is not None:
+            layer_rows = self._propagate_rows(E, user, *frontier)
+        elif props is None and self.use_frontier() and not torch.cuda.is_current_stream_capturing():
             layer_rows = self._propagate_rows(E, user)
         if layer_rows is not None:
             # the same aggregation as _propagate's, row-wise on the batch's rows (mean / concatenation / per-layer weights act
@@ -336,12 +353,20 @@ class FairGo_PMF(FairRecommender):
             ie = ie * (item != 0).unsqueeze(1)
             return Mse.apply(RowDot.apply(ue, ie), rating)
         E = self._filtered_table(sst_list)
-        rows = RowGather.apply(E, torch.cat([user, item + self.n_users]), eng.err_flag)
+        idx = torch.cat([user, item + self.n_users])
+        fr = self._frontier(user) if self.use_frontier() and not torch.cuda.is_current_stream_capturing() else None
+        if fr is not None:
+            # the filtered table's two uses -- the batch's rows and the first propagation layer -- as ONE autograd node, so
+            # that dLoss/dE is written once (functional.GatherAndSpMMSel) instead of zero-filled, scattered into and added
+            rows, H1 = GatherAndSpMMSel.apply(E, idx, eng.err_flag, self._L, fr[0][0], fr[0][1])
+            frontier = (fr, H1)
+        else:
+            rows, frontier = RowGather.apply(E, idx, eng.err_flag), None
         mse = Mse.apply(RowDot.apply(rows[:B], rows[B:]), rating)
         # the reference's calculate_dis_loss runs forward() a second time (fairgo_pmf.py:205-206): the same values from the
         # same parameters, so ONE filtered table serves both terms -- its gradient is the sum of the two uses, which is
         # what the two backward passes through the filters add up to (linear in dLoss/dE; rounding-level difference)
-        fair = self._dis_terms(E, interaction, sst_list, node=rows[:B])
+        fair = self._dis_terms(E, interaction, sst_list, node=rows[:B], frontier=frontier)
         return mse - self.fair_weight * fair
 
     def predict(self, interaction):
