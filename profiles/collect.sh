@@ -39,6 +39,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_nfcf -- pytho
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_fairgo -- python3 $R/bench.py --workload fairgo10m --users 1000001 --items 100001 --steps 3 --warmup 3 > $OUT/fairgo_under_rocprof.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_F32 --output-format csv -d $OUT/pmc_mfma -- python3 $R/profiles/pmc_pfcn.py > $OUT/pmc_mfma.log 2>&1
 python3 $R/profiles/pmc_mfma_summary.py $OUT/pmc_mfma $OUT/pmc_mfma_pfcn.json > $OUT/pmc_mfma.md 2>&1
+# (the trace build is made from the same sources here, so that its C ABI is the product library's)
+make -C $R/recbole-fairrec_amd/csrc VARIANT=trace EXTRA=-DFR_STEP_TRACE=1 -j8 > $OUT/trace_build.log 2>&1
 if [ -f $R/scratch/lib/libfairrec_hip_trace.so ]; then
   cd $R && FAIRREC_HIP_LIB=$R/scratch/lib/libfairrec_hip_trace.so python3 scratch/step_trace.py > $OUT/wave_trace.txt 2>&1
 fi
