@@ -610,6 +610,66 @@ FR_API int fr_nfcf_loss(const float* y, const float* label, const float* sst, in
                         size_t item_ws_bytes, int32_t dim, float* out, float* dy, float* loss, void* ws, size_t ws_bytes,
                         uint32_t* err_flag, void* stream);
 
+/* The same loss head behind the fused scorer (fr_scorer_fwd below), which has already written out, the BCE share of dy and the
+ * per-workgroup partials: bce_part [n_part] (sums of the rows' BCE terms) and, with `sst`, mm_part [n_part, 2] ((min, max)
+ * of the attribute over each workgroup's positive rows).  Adds the differential-fairness share to dy (when item_ws != NULL)
+ * and writes loss[3]; ws as for fr_nfcf_loss. */
+FR_API int fr_nfcf_loss_tail(const float* label, const float* sst, int64_t B, float fair_weight, void* item_ws,
+                             size_t item_ws_bytes, int32_t dim, const float* out, float* dy, float* loss,
+                             const float* bce_part, const float* mm_part, int32_t n_part, void* ws, size_t ws_bytes,
+                             uint32_t* err_flag, void* stream);
+
+/* ---- the NFCF scorer in one forward and one backward launch (csrc/scorer.hip) ----------------------------------------
+ * MLPLayers([k0 + k1, n1, n2, 1], dropout p) on cat(x0, x1) (nfcf.py:40, :68-73; layers.py:56-85: per layer Dropout ->
+ * Linear -> ReLU, the last layer included).  Shapes: k0 == k1, multiples of 32, k0 + k1 <= 512; n1 in 32..128, n2 in 32..64,
+ * multiples of 32 (fr_scorer_supported; the layer-by-layer entry points above cover everything else).  Dropout is
+ * fr_dropout_apply's generator: `off_*` are the element offsets of the four dropped tensors inside the call's pattern
+ * (the layered form's: x0 at 0, x1 behind it, then the two hidden activations), `counter` / `used_out` / `tick_state` as
+ * there (the forward is the pattern's first and last launch).
+ *   fr_scorer_fwd  x0d / x1d [B, k] = the dropped inputs (p > 0 only; what the weight gradient multiplies), h1 [B, n1],
+ *                  h2 [B, n2] = the dropped hidden activations, y [B] = the output after its ReLU.  With `label`: out =
+ *                  sigmoid(y), dy = d mean(BCE) / dy, bce_part / mm_part [fr_scorer_blocks(B)] (see fr_nfcf_loss_tail).
+ *   fr_scorer_bwd  from dy (times gscale[0] when given): dz3 [B], dz2 [B, n2], dz1 [B, n1] = the gradients at the three
+ *                  pre-activations, dx0 / dx1 = the input blocks' gradients (either may be NULL: a frozen table), w3part
+ *                  [fr_scorer_blocks(B), n2 + 1] = per-workgroup shares of (dW3 | db3), summed by fr_parts_sum.
+ *                  dW1 / db1 = fr_linear_bwd_weight(dz1, x0d | x1d), dW2 / db2 = fr_linear_bwd_weight(dz2, h1). */
+typedef struct fr_scorer {
+    int32_t k0, k1, n1, n2;
+    const float *W1, *b1, *W2, *b2, *W3, *b3;
+    float p;
+    uint64_t seed;
+    uint64_t off_x0, off_x1, off_h1, off_h2;
+} fr_scorer;
+FR_API int fr_scorer_supported(const fr_scorer* s);
+FR_API int64_t fr_scorer_blocks(int64_t B);
+FR_API int fr_scorer_fwd(const fr_scorer* s, const float* x0, const float* x1, int64_t B, const int64_t* counter,
+                         int64_t* used_out, int64_t* tick_state, float* x0d, float* x1d, float* h1, float* h2, float* y,
+                         const float* label, const float* sst, float* out, float* dy, float* bce_part, float* mm_part,
+                         void* stream);
+FR_API int fr_scorer_bwd(const fr_scorer* s, const float* dy, const float* gscale, const float* y, const float* h1,
+                         const float* h2, int64_t B, const int64_t* used, float* dz1, float* dz2, float* dz3, float* dx0,
+                         float* dx1, float* w3part, void* stream);
+/* The weight gradients of several layers in two launches (every product, then every slab sum): job = fr_linear_bwd_weight's
+ * (dY at the pre-activation, x0 | x1, N) -> dW [N, k0 + k1], db [N] (may be NULL), fast form only (N, k0, k0 + k1 multiples
+ * of 32, 16-byte aligned; FR_EUNSUPPORTED otherwise).  A job with dY == NULL sums `n_parts` partial results
+ * parts[n_parts][N * (k0 + k1)] into dW (the scorer's last layer: fr_scorer_bwd's w3part).  At most 4 jobs. */
+typedef struct fr_wgrad_job {
+    const float* dY;
+    const float* x0;
+    int32_t k0;
+    const float* x1;
+    int32_t k1;
+    int32_t N;
+    float* dW;
+    float* db;
+    const float* parts;
+    int32_t n_parts;
+} fr_wgrad_job;
+FR_API size_t fr_linear_bwd_weight_multi_workspace_bytes(const fr_wgrad_job* jobs, int32_t n, int64_t M);
+FR_API int fr_linear_bwd_weight_multi(const fr_wgrad_job* jobs, int32_t n, int64_t M, void* ws, size_t ws_bytes, void* stream);
+/* out[i] = sum over the parts p of part[p * n + i], in a fixed order (64 interleaved ascending chains, then a butterfly) */
+FR_API int fr_parts_sum(const float* part, int32_t parts, int64_t n, float* out, void* stream);
+
 /* The differential-fairness term (nfcf.py:76-97) of a ROW-SHARDED step on the GLOBAL batch (one process per GPU, item
  * table row r on rank r mod G): M[k, g], K and the mean of eps are statistics of the whole batch, so every positive row's
  * (score, attribute) travels to the owner of its item and the per-(item, group) sums come back -- two all-to-alls that

@@ -617,6 +617,49 @@ extern "C" int fr_linear_bwd_weight(const float* dY, const float* Y, int32_t act
     return FR_OK;
 }
 
+// The weight gradients of several layers of one backward pass in two launches (all the products, then all the slab sums)
+// instead of two per layer.  Jobs in the fast form only (N, K, k0 multiples of 32, no mask, dY already at the pre-activation);
+// a job with dY == NULL only sums `n_parts` partial results [n_parts][N * K] that somebody else wrote (`parts`).
+extern "C" size_t fr_linear_bwd_weight_multi_workspace_bytes(const fr_wgrad_job* jobs, int32_t n, int64_t M) {
+    size_t tot = 0;
+    for (int j = 0; jobs && j < n; ++j)
+        if (jobs[j].dY) tot += align_up(fr_linear_bwd_weight_workspace_bytes(M, jobs[j].N, jobs[j].k0 + jobs[j].k1), 256);
+    return tot;
+}
+
+extern "C" int fr_linear_bwd_weight_multi(const fr_wgrad_job* jobs, int32_t n, int64_t M, void* ws, size_t ws_bytes,
+                                          void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    FR_CHECK_ARG(jobs && n >= 1 && n <= 4 && M >= 1, "fr_linear_bwd_weight_multi: bad argument (1..4 jobs)");
+    FR_CHECK_ARG(ws_bytes >= fr_linear_bwd_weight_multi_workspace_bytes(jobs, n, M) && (ws || ws_bytes == 0),
+                 "fr_linear_bwd_weight_multi: workspace too small");
+    GlWJob q[4];
+    char* p = (char*)ws;
+    for (int j = 0; j < n; ++j) {
+        const fr_wgrad_job& f = jobs[j];
+        const int K = f.k0 + f.k1;
+        FR_CHECK_ARG(f.dW && f.N >= 1 && f.k0 >= 1 && f.k1 >= 0, "fr_linear_bwd_weight_multi: bad job");
+        if (!f.dY) {
+            FR_CHECK_ARG(f.parts && f.n_parts >= 1 && !f.db, "fr_linear_bwd_weight_multi: a sum-only job needs parts and no db");
+            q[j] = GlWJob{nullptr, GlMat{}, f.N, K, f.n_parts, 0, const_cast<float*>(f.parts), nullptr, f.dW, nullptr};
+            continue;
+        }
+        if (f.N % 32 || K % 32 || f.k0 % 32 || ((uintptr_t)f.dY & 15) || ((uintptr_t)f.x0 & 15) || (f.x1 && ((uintptr_t)f.x1 & 15)) ||
+            !f.x0 || (f.k1 > 0 && !f.x1)) {
+            set_error("fr_linear_bwd_weight_multi: job %d is not in the fast form (N, K, k0 multiples of 32, 16-byte aligned)", j);
+            return FR_EUNSUPPORTED;
+        }
+        const long long splits = bwd_weight_splits(M, f.N, K);
+        const int rows_per_split = (int)(((M + splits - 1) / splits + TK - 1) / TK * TK);
+        prof_work(K_LINEAR_BWD_WEIGHT, 2.0 * (double)M * f.N * K);
+        float* slab = (float*)p;
+        p += align_up((size_t)splits * f.N * (K + 1) * sizeof(float), 256);
+        q[j] = GlWJob{f.dY, GlMat{f.x0, f.x1, f.k0, f.k1, f.k0}, f.N, K, (int)splits, rows_per_split, slab,
+                      f.db ? slab + (size_t)splits * f.N * K : nullptr, f.dW, f.db};
+    }
+    return glds_linear_bwd_weight_multi(q, n, M, stream);
+}
+
 // Both backward products of a layer with ONE output in one pass over X (plus the slab reduction): what
 // fr_linear_bwd_weight + fr_linear_bwd_input compute for N == 1, k1 == 0, no mask.  dX may be NULL (first layer of a
 // model whose input needs no gradient).  Returns FR_EUNSUPPORTED when the shape does not suit (K % 64, K <= 512, 16-byte

@@ -323,8 +323,7 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ 
 // accumulators), so the two forms are bit-identical (tests/test_mlp_hip.py).  KS reduction parts of a macro tile = KS
 // groups of four waves in one workgroup.
 template <int MODE, int KS, int NBUF>
-__global__ __launch_bounds__(256 * KS) void linear_glds64_kernel(GlArgs g) {
-    extern __shared__ __align__(16) float lds[];   // [KS][NBUF][A0 A1 B0 B1][1024]
+__device__ __forceinline__ void glds64_body(const GlArgs& g, const unsigned bid, float* lds) {   // lds: [KS][NBUF][A0 A1 B0 B1][1024]
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     constexpr bool A_T = MODE == GL_BWD_W, B_T = MODE != GL_FWD;
@@ -332,10 +331,10 @@ __global__ __launch_bounds__(256 * KS) void linear_glds64_kernel(GlArgs g) {
     const int mt_j = (g.tiles_j + 1) / 2, nmt = ((g.tiles_i + 1) / 2) * mt_j;
     int mt, part;
     if (MODE == GL_BWD_W) {
-        mt = (int)(blockIdx.x % (unsigned)nmt);
-        part = (int)(blockIdx.x / (unsigned)nmt);
+        mt = (int)(bid % (unsigned)nmt);
+        part = (int)(bid / (unsigned)nmt);
     } else {
-        mt = blockIdx.x;
+        mt = bid;
         part = wave >> 2;
     }
     const int mi = mt / mt_j, mj = mt % mt_j;
@@ -584,6 +583,66 @@ __global__ __launch_bounds__(256 * KS) void linear_glds64_kernel(GlArgs g) {
 }
 
 template <int MODE, int KS, int NBUF>
+__global__ __launch_bounds__(256 * KS) void linear_glds64_kernel(GlArgs g) {
+    extern __shared__ __align__(16) float lds[];
+    glds64_body<MODE, KS, NBUF>(g, blockIdx.x, lds);
+}
+
+// Several weight gradients of one backward pass in ONE launch (the three layers of the NFCF scorer, csrc/scorer.hip): job j
+// owns the workgroups [first[j], first[j + 1]); each is exactly linear_glds64_kernel<GL_BWD_W> on that job's arguments.
+constexpr int GL_MULTI_MAX = 4;
+struct GlMulti {
+    GlArgs g[GL_MULTI_MAX];
+    unsigned first[GL_MULTI_MAX + 1];
+    int n;
+};
+__global__ __launch_bounds__(256) void linear_glds64_wmulti_kernel(GlMulti m) {
+    extern __shared__ __align__(16) float lds[];
+    int j = 0;
+    while (j + 1 < m.n && blockIdx.x >= m.first[j + 1]) ++j;
+    glds64_body<GL_BWD_W, 1, 3>(m.g[j], blockIdx.x - m.first[j], lds);
+}
+
+// ... and their slab sums in one launch: job j = out[i] = sum over splits (four interleaved-by-quarter ascending chains, as
+// slab_reduce_kernel) of slab[s][i] for the weights, of bslab[s][i - n] for the bias behind them
+struct SlabJobs {
+    const float* slab[GL_MULTI_MAX];
+    const float* bslab[GL_MULTI_MAX];
+    float* out[GL_MULTI_MAX];
+    float* db[GL_MULTI_MAX];
+    long long n[GL_MULTI_MAX];
+    int nb[GL_MULTI_MAX], splits[GL_MULTI_MAX];
+    unsigned first[GL_MULTI_MAX + 1];
+    int njobs;
+};
+__global__ __launch_bounds__(256) void slab_reduce_multi_kernel(SlabJobs J) {
+    __shared__ float red[4][64];
+    int j = 0;
+    while (j + 1 < J.njobs && blockIdx.x >= J.first[j + 1]) ++j;
+    const float* __restrict__ slab = J.slab[j];
+    const float* __restrict__ bslab = J.bslab[j];
+    const long long n = J.n[j];
+    const int nb = J.nb[j], splits = J.splits[j];
+    const int e = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const long long i = (long long)(blockIdx.x - J.first[j]) * 64 + e;
+    const int per = (splits + 3) / 4, s0 = part * per, s1 = min(splits, s0 + per);
+    float a = 0.f;
+    if (i < n) {
+        for (int s = s0; s < s1; ++s) a += slab[(size_t)s * n + i];
+    } else if (i < n + nb) {
+        const long long k = i - n;
+        for (int s = s0; s < s1; ++s) a += bslab[(size_t)s * nb + k];
+    }
+    red[part][e] = a;
+    __syncthreads();
+    if (part == 0) {
+        const float t = ((red[0][e] + red[1][e]) + red[2][e]) + red[3][e];
+        if (i < n) J.out[j][i] = t;
+        else if (i < n + nb) J.db[j][i - n] = t;
+    }
+}
+
+template <int MODE, int KS, int NBUF>
 static int launch64(const GlArgs& g, long long blocks, hipStream_t stream, int kind) {
     static bool attr_set = false;
     const size_t ldsb = (size_t)KS * NBUF * 4096 * sizeof(float);
@@ -708,6 +767,63 @@ int glds_linear_bwd_weight(const float* dY, const GlMat& X, int64_t M, int N, in
     if (use_shared()) return launch_shared<GL_BWD_W>(g, stream, K_LINEAR_BWD_WEIGHT);
     const long long nw = (long long)g.tiles_i * g.tiles_j * splits;
     return launch_mode<GL_BWD_W>(g, (nw + GL_WAVES - 1) / GL_WAVES, stream, K_LINEAR_BWD_WEIGHT);
+}
+
+int glds_linear_bwd_weight_multi(const GlWJob* jobs, int n, int64_t M, hipStream_t stream) {
+    GlMulti m{};
+    SlabJobs J{};
+    unsigned blocks = 0, rblocks = 0;
+    int ng = 0;
+    for (int j = 0; j < n; ++j) {
+        const GlWJob& q = jobs[j];
+        J.slab[j] = q.slab;
+        J.bslab[j] = q.bslab;
+        J.out[j] = q.dW;
+        J.db[j] = q.db;
+        J.n[j] = (long long)q.N * q.K;
+        J.nb[j] = q.db ? q.N : 0;
+        J.splits[j] = q.splits;
+        J.first[j] = rblocks;
+        rblocks += (unsigned)((J.n[j] + J.nb[j] + 63) / 64);
+        if (!q.dY) continue;            // sums only: the slabs were written by somebody else (the scorer's last layer)
+        GlArgs& g = m.g[ng];
+        g = GlArgs{};
+        g.A = GlMat{q.dY, nullptr, q.N, 0, q.N};
+        g.B = q.X;
+        g.R = (int)M;
+        g.rowsA = g.rowsB = (int)M;
+        g.tiles_i = q.N / 32;
+        g.tiles_j = q.K / 32;
+        g.ks = 1;
+        g.parts = q.splits;
+        g.chunks_per_part = q.rows_per_split / 32;
+        g.slab = q.slab;
+        g.bslab = q.bslab;
+        g.out_rows = q.N;
+        g.out_cols = q.K;
+        m.first[ng] = blocks;
+        blocks += (unsigned)(((g.tiles_i + 1) / 2) * ((g.tiles_j + 1) / 2)) * (unsigned)q.splits;
+        ++ng;
+    }
+    m.first[ng] = blocks;
+    m.n = ng;
+    J.first[n] = rblocks;
+    J.njobs = n;
+    if (ng > 0) {
+        static bool attr_set = false;
+        const size_t ldsb = (size_t)3 * 4096 * sizeof(float);
+        if (!attr_set) {
+            FR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(linear_glds64_wmulti_kernel),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
+            attr_set = true;
+        }
+        ProfScope prof(K_LINEAR_BWD_WEIGHT, stream);
+        FR_LAUNCH(prof, linear_glds64_wmulti_kernel, dim3(blocks), dim3(256), ldsb, stream, m);
+        FR_CHECK_LAUNCH();
+    }
+    hipLaunchKernelGGL(slab_reduce_multi_kernel, dim3(rblocks), dim3(256), 0, stream, J);
+    FR_CHECK_LAUNCH();
+    return FR_OK;
 }
 
 int launch_act_bwd(const float* dY, const float* Y, int act, float scale, long long n, float* out, hipStream_t stream) {

@@ -43,6 +43,15 @@ int glds_linear_bwd_input(const float* dY, const float* W, int64_t M, int N, int
 // K % 32 == 0, X.split % 32 == 0, rows_per_split % 32 == 0
 int glds_linear_bwd_weight(const float* dY, const GlMat& X, int64_t M, int N, int K, int splits, int rows_per_split,
                            float* slab, float* bslab, hipStream_t stream);
+// Several weight gradients in one launch + their slab sums in a second (fr_linear_bwd_weight_multi).  A job without dY only
+// sums slabs that are already there (splits x [N, K] then, if db, splits x [N]).
+struct GlWJob {
+    const float* dY;
+    GlMat X;
+    int N, K, splits, rows_per_split;
+    float *slab, *bslab, *dW, *db;
+};
+int glds_linear_bwd_weight_multi(const GlWJob* jobs, int n, int64_t M, hipStream_t stream);
 // out = dY o act'(Y) elementwise (n % 4 == 0)
 int launch_act_bwd(const float* dY, const float* Y, int act, float scale, long long n, float* out, hipStream_t stream);
 

@@ -458,6 +458,41 @@ extern "C" int fr_nfcf_loss(const float* y, const float* label, const float* sst
     return FR_OK;
 }
 
+extern "C" int fr_nfcf_loss_tail(const float* label, const float* sst, int64_t B, float fair_weight, void* item_ws,
+                                 size_t item_ws_bytes, int32_t dim, const float* out, float* dy, float* loss,
+                                 const float* bce_part, const float* mm_part, int32_t n_part, void* ws, size_t ws_bytes,
+                                 uint32_t* err_flag, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    FR_CHECK_ARG(label && out && dy && loss && bce_part && ws && B >= 1 && n_part >= 1, "fr_nfcf_loss_tail: bad argument");
+    FR_CHECK_ARG(ws_bytes >= fr_nfcf_loss_workspace_bytes(B), "fr_nfcf_loss_tail: workspace too small");
+    const int nb = (int)((B + 255) / 256), ndf = (int)((B * DF_GROUP + DF_THREADS - 1) / DF_THREADS);
+    char* p = (char*)ws;
+    p += align_up((size_t)nb * 4, 256);
+    float* df_part = (float*)p; p += align_up((size_t)ndf * 4, 256);
+    int* kpart = (int*)p; p += align_up((size_t)ndf * 4, 256);
+    float4* stats = (float4*)p; p += align_up((size_t)B * 16, 256);
+    float* minmax = (float*)p; p += 256;
+    float* kout = (float*)p;
+    const bool df = item_ws != nullptr;
+    if (df) {
+        FR_CHECK_ARG(sst && mm_part, "fr_nfcf_loss_tail: the fairness term needs the sst column and the (min, max) partials");
+        TableWs tw = table_layout(item_ws, B, dim);
+        FR_CHECK_ARG(item_ws_bytes >= tw.bytes, "fr_nfcf_loss_tail: item workspace too small");
+        if (int rc = side_join(item_ws, stream)) return rc;
+        ProfScope prof(K_NFCF_LOSS, stream);
+        FR_LAUNCH(prof, nfcf_df_stats_kernel, dim3(ndf), dim3(DF_THREADS), 0, stream, tw, out, label, sst, mm_part, (int)n_part,
+                  minmax, stats, kpart, err_flag);
+        FR_CHECK_LAUNCH();
+        hipLaunchKernelGGL(nfcf_df_coef_kernel, dim3(ndf), dim3(DF_THREADS), 0, stream, tw, out, label, sst, (const float*)minmax,
+                           (const float4*)stats, (const int*)kpart, ndf, fair_weight, dy, df_part, kout);
+        FR_CHECK_LAUNCH();
+    }
+    hipLaunchKernelGGL(nfcf_finalize_kernel, dim3(1), dim3(256), 0, stream, bce_part, (int)n_part, (const float*)df_part,
+                       df ? ndf : 0, (const float*)kout, (int)B, fair_weight, loss);
+    FR_CHECK_LAUNCH();
+    return FR_OK;
+}
+
 /* ---- differential fairness of a row-sharded NFCF step on the GLOBAL batch (three launches around two all-to-alls) ---- */
 extern "C" size_t fr_nfcf_df_workspace_bytes(int64_t B, int64_t n_slots) {
     if (B < 1 || n_slots < 1) return 0;

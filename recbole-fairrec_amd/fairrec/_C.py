@@ -36,6 +36,17 @@ class FrAdam(Structure):
                 ("beta1", c_double), ("beta2", c_double), ("eps", c_double)]
 
 
+class FrScorer(Structure):      # include/fairrec_hip.h: fr_scorer
+    _fields_ = [("k0", c_int32), ("k1", c_int32), ("n1", c_int32), ("n2", c_int32), ("W1", c_void_p), ("b1", c_void_p),
+                ("W2", c_void_p), ("b2", c_void_p), ("W3", c_void_p), ("b3", c_void_p), ("p", c_float), ("seed", c_uint64),
+                ("off_x0", c_uint64), ("off_x1", c_uint64), ("off_h1", c_uint64), ("off_h2", c_uint64)]
+
+
+class FrWgradJob(Structure):    # include/fairrec_hip.h: fr_wgrad_job
+    _fields_ = [("dY", c_void_p), ("x0", c_void_p), ("k0", c_int32), ("x1", c_void_p), ("k1", c_int32), ("N", c_int32),
+                ("dW", c_void_p), ("db", c_void_p), ("parts", c_void_p), ("n_parts", c_int32)]
+
+
 class FrFocfBatch(Structure):
     _fields_ = [("user", c_void_p), ("item", c_void_p), ("sst", c_void_p), ("B", c_int64), ("ws", c_void_p),
                 ("ws_bytes", c_size_t), ("rating", c_void_p)]
@@ -169,6 +180,18 @@ _PROTOS = {
     "fr_nfcf_loss_workspace_bytes": (c_size_t, [c_int64]),
     "fr_nfcf_loss": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_float, c_void_p, c_size_t, c_int32, c_void_p,
                              c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
+    "fr_nfcf_loss_tail": (c_int, [c_void_p, c_void_p, c_int64, c_float, c_void_p, c_size_t, c_int32, c_void_p, c_void_p,
+                                  c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_size_t, c_void_p, c_void_p]),
+    "fr_scorer_supported": (c_int, [POINTER(FrScorer)]),
+    "fr_scorer_blocks": (c_int64, [c_int64]),
+    "fr_scorer_fwd": (c_int, [POINTER(FrScorer), c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
+                              c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                              c_void_p, c_void_p]),
+    "fr_scorer_bwd": (c_int, [POINTER(FrScorer), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p,
+                              c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "fr_parts_sum": (c_int, [c_void_p, c_int32, c_int64, c_void_p, c_void_p]),
+    "fr_linear_bwd_weight_multi_workspace_bytes": (c_size_t, [POINTER(FrWgradJob), c_int32, c_int64]),
+    "fr_linear_bwd_weight_multi": (c_int, [POINTER(FrWgradJob), c_int32, c_int64, c_void_p, c_size_t, c_void_p]),
     "fr_nfcf_df_workspace_bytes": (c_size_t, [c_int64, c_int64]),
     "fr_nfcf_df_pack": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int64, c_int32, c_void_p,
                                 c_void_p, c_size_t, c_void_p]),

@@ -7,6 +7,8 @@ the scorer runs on the fp32-MFMA kernels (csrc/mlp.hip), sigmoid + BCE + differe
 """
 from __future__ import annotations
 
+import ctypes
+import os
 
 import torch
 import torch.nn as nn
@@ -55,6 +57,101 @@ class _NfcfLoss(torch.autograd.Function):
         if _C.is_one(g_loss):               # GraphedStep's seed: nothing to scale by
             return dy.view(-1, 1), None, None, None, None, None, None
         return (dy * g_loss).view(-1, 1), None, None, None, None, None, None
+
+
+def _r4(n):
+    return (n + 3) // 4 * 4
+
+
+class _NfcfFused(torch.autograd.Function):
+    """calculate_loss (nfcf.py:99-110) on gathered rows as one autograd node: fr_scorer_fwd (the three layers, their dropouts,
+    sigmoid, BCE: one launch) + fr_nfcf_loss_tail (differential fairness, loss) forward; fr_scorer_bwd (one launch) + the two
+    weight-gradient products + fr_parts_sum backward.  Same values as MLPLayers + _NfcfLoss layer by layer -- same dropout
+    pattern included (the four offsets below are `_Drop`'s) -- up to the order of the fp32 sums."""
+
+    @staticmethod
+    def _desc(k0, k1, params, p, seed, B):
+        W1, b1, W2, b2, W3, b3 = params
+        n1, n2 = W1.shape[0], W2.shape[0]
+        o1 = _r4(B * k0)
+        o2 = o1 + _r4(B * k1)
+        return _C.FrScorer(k0, k1, n1, n2, W1.data_ptr(), b1.data_ptr(), W2.data_ptr(), b2.data_ptr(), W3.data_ptr(),
+                           b3.data_ptr(), p, seed, 0, o1, o2, o2 + _r4(B * n1))
+
+    @staticmethod
+    def supported(k0, k1, params, p) -> bool:
+        if len(params) != 6 or params[4].shape[0] != 1:
+            return False
+        return bool(_C.lib().fr_scorer_supported(_NfcfFused._desc(k0, k1, params, p, 0, 1)))
+
+    @staticmethod
+    def forward(ctx, x0, x1, label, sst, fair_weight, item_table, err_flag, drop, *params):
+        lib, st = _C.lib(), _C.current_stream()
+        x0, x1 = x0.contiguous(), x1.contiguous()
+        params = tuple(t.contiguous() for t in params)
+        B, k0, k1 = x0.shape[0], x0.shape[1], x1.shape[1]
+        n1, n2 = params[0].shape[0], params[2].shape[0]
+        dev = x0.device
+        p, seed, state = drop if drop is not None else (0.0, 0, None)
+        d = _NfcfFused._desc(k0, k1, params, p, seed, B)
+        f32 = dict(dtype=torch.float32, device=dev)
+        nblk = lib.fr_scorer_blocks(B)
+        x0d = torch.empty_like(x0) if p > 0 else None
+        x1d = torch.empty_like(x1) if p > 0 else None
+        used = torch.empty(1, dtype=torch.int64, device=dev) if p > 0 else None
+        h1, h2 = torch.empty((B, n1), **f32), torch.empty((B, n2), **f32)
+        y, out, dy = torch.empty(B, **f32), torch.empty(B, **f32), torch.empty(B, **f32)
+        part = torch.empty(3 * nblk, **f32)        # bce_part | mm_part
+        loss = torch.empty(3, **f32)
+        _C.check(lib.fr_scorer_fwd(ctypes.byref(d), x0.data_ptr(), x1.data_ptr(), B, _C.ptr(state), _C.ptr(used), _C.ptr(state),
+                                   _C.ptr(x0d), _C.ptr(x1d), h1.data_ptr(), h2.data_ptr(), y.data_ptr(), label.data_ptr(),
+                                   _C.ptr(sst), out.data_ptr(), dy.data_ptr(), part.data_ptr(), part[nblk:].data_ptr(), st),
+                 "fr_scorer_fwd")
+        ws = torch.empty(lib.fr_nfcf_loss_workspace_bytes(B), dtype=torch.uint8, device=dev)
+        iws = item_table._ws if item_table is not None else None
+        _C.check(lib.fr_nfcf_loss_tail(label.data_ptr(), _C.ptr(sst), B, fair_weight, _C.ptr(iws),
+                                       iws.numel() if iws is not None else 0, item_table.dim if item_table is not None else 1,
+                                       out.data_ptr(), dy.data_ptr(), loss.data_ptr(), part.data_ptr(), part[nblk:].data_ptr(),
+                                       nblk, ws.data_ptr(), ws.numel(), err_flag.data_ptr(), st), "fr_nfcf_loss_tail")
+        ctx.save_for_backward(dy, y, h1, h2, x0d if p > 0 else x0, x1d if p > 0 else x1, used, *params)
+        ctx.meta = (k0, k1, p, seed, B, nblk)
+        ctx.mark_non_differentiable(out)
+        ctx.set_materialize_grads(False)
+        return loss[0], out
+
+    @staticmethod
+    def backward(ctx, g_loss, g_out):
+        n_in = 8
+        if g_loss is None:
+            return (None,) * (n_in + 6)
+        lib, st = _C.lib(), _C.current_stream()
+        dy, y, h1, h2, xa, xb, used, *params = ctx.saved_tensors
+        k0, k1, p, seed, B, nblk = ctx.meta
+        n1, n2 = params[0].shape[0], params[2].shape[0]
+        dev = dy.device
+        d = _NfcfFused._desc(k0, k1, params, p, seed, B)
+        f32 = dict(dtype=torch.float32, device=dev)
+        gscale = None if _C.is_one(g_loss) else g_loss.detach().to(torch.float32).reshape(1).contiguous()
+        dz1, dz2, dz3 = torch.empty((B, n1), **f32), torch.empty((B, n2), **f32), torch.empty((B, 1), **f32)
+        dx0 = torch.empty((B, k0), **f32) if ctx.needs_input_grad[0] else None
+        dx1 = torch.empty((B, k1), **f32) if ctx.needs_input_grad[1] else None
+        w3part = torch.empty((nblk, n2 + 1), **f32)
+        _C.check(lib.fr_scorer_bwd(ctypes.byref(d), dy.data_ptr(), _C.ptr(gscale), y.data_ptr(), h1.data_ptr(), h2.data_ptr(), B,
+                                   _C.ptr(used), dz1.data_ptr(), dz2.data_ptr(), dz3.data_ptr(), _C.ptr(dx0), _C.ptr(dx1),
+                                   w3part.data_ptr(), st), "fr_scorer_bwd")
+        grads = [None] * 6
+        if any(ctx.needs_input_grad[n_in:]):
+            # the three layers' weight gradients: every product in one launch, every slab sum in a second
+            dW1, db1, dW2, db2 = (torch.empty_like(t) for t in params[:4])
+            w3 = torch.empty(n2 + 1, **f32)
+            jobs = (_C.FrWgradJob * 3)(
+                _C.FrWgradJob(dz1.data_ptr(), xa.data_ptr(), k0, xb.data_ptr(), k1, n1, dW1.data_ptr(), db1.data_ptr(), None, 0),
+                _C.FrWgradJob(dz2.data_ptr(), h1.data_ptr(), n1, None, 0, n2, dW2.data_ptr(), db2.data_ptr(), None, 0),
+                _C.FrWgradJob(None, None, n2 + 1, None, 0, 1, w3.data_ptr(), None, w3part.data_ptr(), nblk))
+            ws = torch.empty(lib.fr_linear_bwd_weight_multi_workspace_bytes(jobs, 3, B), dtype=torch.uint8, device=dev)
+            _C.check(lib.fr_linear_bwd_weight_multi(jobs, 3, B, ws.data_ptr(), ws.numel(), st), "fr_linear_bwd_weight_multi")
+            grads = [dW1, db1, dW2, db2, w3[:n2].view(1, n2), w3[n2:]]
+        return (dx0, dx1, None, None, None, None, None, None, *grads)
 
 
 class NFCF(FairRecommender):
@@ -140,14 +237,38 @@ class NFCF(FairRecommender):
     def forward(self, user, item):
         return torch.sigmoid(self._score_logits(user, item).squeeze(-1))
 
+    FUSED = os.environ.get("FAIRREC_NFCF_LAYERED") is None     # A/B switch: the layer-by-layer form of round 3
+
+    def _fused_scorer(self) -> bool:
+        """Does calculate_loss take the two-launch scorer (csrc/scorer.hip)?  [2 D, n1, n2, 1] with ReLU, no BatchNorm, no
+        recorded dropout masks, widths that are multiples of 32 within the kernel's LDS budget; anything else runs layer by
+        layer on the same device (fairrec/model/layers.py)."""
+        mlp = self.mlp_layers
+        act = mlp.activation.lower() if isinstance(mlp.activation, str) else mlp.activation
+        if not self.FUSED or mlp.use_bn or act != "relu" or mlp.forced_masks is not None:
+            return False
+        lins = mlp.linears()
+        p = float(mlp.dropout) if mlp.training else 0.0
+        return len(lins) == 3 and _NfcfFused.supported(self.embedding_size, self.embedding_size,
+                                                       [t for lin in lins for t in (lin.weight, lin.bias)], p)
+
     def calculate_loss(self, interaction):
         eng = self.hip_engine()
         dev = eng.device
         user, item = interaction[self.USER_ID], interaction[self.ITEM_ID]
         label = interaction[self.LABEL].to(dev, torch.float32).contiguous()
-        y = self._score_logits(user, item)
         finetune = self.load_pretrain_path is not None
         sst = interaction[self.sst_attr].to(dev, torch.float32).contiguous() if finetune else None
+        if self.shard is None and self._fused_scorer():
+            mlp = self.mlp_layers
+            ue, ie = eng.lookup_pair("user_embedding.weight", user, "item_embedding.weight", item)
+            p = float(mlp.dropout) if mlp.training else 0.0
+            drop = (p, mlp._drop_seed(), mlp._drop_state(dev)) if p > 0.0 else None
+            item_table = eng.batch_segments("item_embedding.weight") if finetune else None
+            params = [t for lin in mlp.linears() for t in (lin.weight, lin.bias)]
+            loss, _ = _NfcfFused.apply(ue, ie, label, sst, float(self.fair_weight or 0.0), item_table, eng.err_flag, drop, *params)
+            return loss
+        y = self._score_logits(user, item)
         if finetune and self.shard is not None:
             # row-sharded tables: the fairness term of the GLOBAL batch (per-group sums reduced on the items' owners)
             loss, _ = _NfcfLoss.apply(y, label, sst, float(self.fair_weight or 0.0), None, eng.err_flag,

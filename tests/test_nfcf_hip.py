@@ -370,3 +370,71 @@ def test_global_df_kernels_skip_rows_that_found_no_slot():
     d = dy.cpu()
     assert bool(torch.isfinite(d).all()) and bool(torch.isfinite(loss).all())
     assert torch.equal(d[~ok], dy0[~ok]) and not torch.equal(d[ok], dy0[ok])
+
+
+@pytest.mark.parametrize("D,hidden,p,finetune,B", [(64, (128, 64), 0.2, False, 1000), (256, (128, 64), 0.2, True, 8192),
+                                                   (32, (32, 32), 0.0, True, 77), (128, (96, 64), 0.5, False, 4097),
+                                                   (64, (64, 32), 0.3, True, 32)],
+                         ids=["d64_pretrain", "d256_finetune", "d32_tail_rows", "d128_n96", "one_tile"])
+def test_fused_scorer_matches_the_layered_form(D, hidden, p, finetune, B):
+    """csrc/scorer.hip (one forward + one backward launch) against the layer-by-layer form of round 3 on the same model,
+    batches and dropout stream (device-drawn pattern: same seed, counter and offsets => the same keep masks): per-step losses,
+    sigmoid scores, the scorer's weight gradients of the first step, and every parameter after three optimizer steps."""
+    from fairrec.config import Config
+    from fairrec.data.interaction import Interaction
+    from fairrec.model.fair_recommender.nfcf import NFCF
+    from fairrec.optim import FusedLazyAdam
+    n_users, n_items, T = 3001, 701, 3
+    g = torch.Generator().manual_seed(4)
+    gender = (torch.rand(n_users, generator=g) < 0.5).float().numpy()
+    u = torch.randint(1, n_users, (T, B), generator=g)
+    i = torch.randint(1, n_items, (T, B), generator=g)
+    label = (torch.rand(T, B, generator=g) < 0.6).float()
+    models = []
+    for fused in (True, False):
+        torch.manual_seed(9)
+        cfg = Config(model="NFCF", config_dict={"embedding_size": D, "mlp_hidden_size": list(hidden), "dropout": p, "fair_weight": 0.3,
+                                                "device": "cuda", "load_pretrain_path": None})
+        m = NFCF(cfg, _DS(n_users, n_items, gender))
+        with torch.no_grad():
+            m.user_embedding.weight.mul_(0.3)
+            m.item_embedding.weight.mul_(0.3)
+            for lin in m.mlp_layers.linears():
+                lin.bias.add_(0.05)        # biases that matter (the default init is small)
+        if finetune:
+            m.load_pretrain_path = "a-checkpoint"
+            m.user_embedding.weight.requires_grad = False
+        m = m.to("cuda").train()
+        m.FUSED = fused
+        m.mlp_layers._seed = 1234567
+        assert m._fused_scorer() == fused
+        models.append(m)
+    outs = []
+    for m in models:
+        opt = FusedLazyAdam(m.hip_engine(), lr=1e-3, weight_decay=1e-6, sweep_period=2)
+        rec = {"loss": [], "grads": None}
+        for t in range(T):
+            inter = Interaction({"user_id": u[t], "item_id": i[t], "label": label[t], "gender": torch.from_numpy(gender)[u[t]]}).to("cuda")
+            opt.zero_grad()
+            loss = m.calculate_loss(inter)
+            rec["loss"].append(float(loss))
+            loss.backward()
+            if t == 0:
+                rec["grads"] = [q.grad.detach().clone() for q in m.mlp_layers.parameters()]
+            opt.step()
+        m.hip_engine().check_device_errors()
+        rec["state"] = {k: v.detach().clone() for k, v in m.state_dict().items()}
+        with torch.no_grad():
+            m.eval()
+            rec["predict"] = m.predict(Interaction({"user_id": u[0], "item_id": i[0]}).to("cuda")).clone()
+        outs.append(rec)
+    a, b = outs
+    np.testing.assert_allclose(a["loss"], b["loss"], rtol=2e-5)
+    for ga, gb in zip(a["grads"], b["grads"]):
+        scale = float(gb.abs().max())
+        assert float((ga - gb).abs().max()) <= 2e-5 * scale + 1e-9, (ga.shape, float((ga - gb).abs().max()), scale)
+    for k in a["state"]:
+        va, vb = a["state"][k], b["state"][k]
+        assert float((va - vb).abs().max()) <= 2e-4 * float(vb.abs().max()) + 1e-7, k      # (Adam normalises: rounding-level
+        # differences of a gradient come back at the scale of lr)
+    torch.testing.assert_close(a["predict"], b["predict"], rtol=1e-4, atol=1e-6)
