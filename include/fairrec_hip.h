@@ -324,6 +324,12 @@ FR_API int fr_table_join(const void* ws, void* stream);
  * freed after a forward pass that no backward pass followed can be handed out again while the sort still writes to it.
  */
 FR_API void* fr_side_stream_handle(void);
+/* fr_table_gather_train(t, idx) and fr_table_gather(ro, ro_idx) -- a frozen table next to a training one: NFCF's finetune
+ * stage, nfcf.py:66-71 -- in ONE launch that also carries the sort of `idx` (same results as the two calls; falls back to
+ * them when the two tables' rows have different fragment counts or M is outside (0, 2048] / (4096, 8192]). */
+FR_API int fr_table_lookup_pair(const fr_table* t, const fr_adam* adam, const int64_t* idx, int64_t M, float* rows_out,
+                                void* ws, size_t ws_bytes, const fr_table* ro, const fr_adam* ro_adam, const int64_t* ro_idx,
+                                int64_t ro_M, float* ro_out, uint32_t* err_flag, void* stream);
 /* The first fr_table_segments_bytes(M) bytes of a workspace hold the sorted segments of the id list (independent of the
  * table's width).  fr_table_gather_train_prepared skips the sort: the caller has put the segments of `idx` there, e.g. by
  * copying them from the workspace of another table with the same number of rows looked up with the same ids in this step
@@ -628,7 +634,9 @@ FR_API int fr_nfcf_loss_tail(const float* label, const float* sst, int64_t B, fl
  * there (the forward is the pattern's first and last launch).
  *   fr_scorer_fwd  x0d / x1d [B, k] = the dropped inputs (p > 0 only; what the weight gradient multiplies), h1 [B, n1],
  *                  h2 [B, n2] = the dropped hidden activations, y [B] = the output after its ReLU.  With `label`: out =
- *                  sigmoid(y), dy = d mean(BCE) / dy, bce_part / mm_part [fr_scorer_blocks(B)] (see fr_nfcf_loss_tail).
+ *                  sigmoid(y), dy = d mean(BCE) / dy, bce_part / mm_part [fr_scorer_blocks(B)] (see fr_nfcf_loss_tail);
+ *                  `loss` != NULL (no fairness term follows: the pre-training stage): loss[3] = (mean BCE, mean BCE, 0),
+ *                  written by the launch's last workgroup -- no fr_nfcf_loss_tail call then.
  *   fr_scorer_bwd  from dy (times gscale[0] when given): dz3 [B], dz2 [B, n2], dz1 [B, n1] = the gradients at the three
  *                  pre-activations, dx0 / dx1 = the input blocks' gradients (either may be NULL: a frozen table), w3part
  *                  [fr_scorer_blocks(B), n2 + 1] = per-workgroup shares of (dW3 | db3), summed by fr_parts_sum.
@@ -645,7 +653,7 @@ FR_API int64_t fr_scorer_blocks(int64_t B);
 FR_API int fr_scorer_fwd(const fr_scorer* s, const float* x0, const float* x1, int64_t B, const int64_t* counter,
                          int64_t* used_out, int64_t* tick_state, float* x0d, float* x1d, float* h1, float* h2, float* y,
                          const float* label, const float* sst, float* out, float* dy, float* bce_part, float* mm_part,
-                         void* stream);
+                         float* loss, void* stream);
 FR_API int fr_scorer_bwd(const fr_scorer* s, const float* dy, const float* gscale, const float* y, const float* h1,
                          const float* h2, int64_t B, const int64_t* used, float* dz1, float* dz2, float* dz3, float* dx0,
                          float* dx1, float* w3part, void* stream);

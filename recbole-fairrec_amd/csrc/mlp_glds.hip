@@ -612,6 +612,7 @@ struct SlabJobs {
     float* db[GL_MULTI_MAX];
     long long n[GL_MULTI_MAX];
     int nb[GL_MULTI_MAX], splits[GL_MULTI_MAX];
+    int wide[GL_MULTI_MAX];      // many splits of a short vector: one WAVE per output (lane l adds splits l, l + 64, ..., then a butterfly)
     unsigned first[GL_MULTI_MAX + 1];
     int njobs;
 };
@@ -624,6 +625,20 @@ __global__ __launch_bounds__(256) void slab_reduce_multi_kernel(SlabJobs J) {
     const long long n = J.n[j];
     const int nb = J.nb[j], splits = J.splits[j];
     const int e = threadIdx.x & 63, part = threadIdx.x >> 6;
+    if (J.wide[j]) {
+        const long long o = (long long)(blockIdx.x - J.first[j]) * 4 + part;
+        if (o >= n + nb) return;
+        const float* __restrict__ src = o < n ? slab + o : bslab + (o - n);
+        const long long stride = o < n ? n : nb;
+        float a = 0.f;
+        for (int sp = e; sp < splits; sp += 64) a += src[(size_t)sp * stride];
+        a = wave_sum(a);
+        if (e == 0) {
+            if (o < n) J.out[j][o] = a;
+            else J.db[j][o - n] = a;
+        }
+        return;
+    }
     const long long i = (long long)(blockIdx.x - J.first[j]) * 64 + e;
     const int per = (splits + 3) / 4, s0 = part * per, s1 = min(splits, s0 + per);
     float a = 0.f;
@@ -784,7 +799,8 @@ int glds_linear_bwd_weight_multi(const GlWJob* jobs, int n, int64_t M, hipStream
         J.nb[j] = q.db ? q.N : 0;
         J.splits[j] = q.splits;
         J.first[j] = rblocks;
-        rblocks += (unsigned)((J.n[j] + J.nb[j] + 63) / 64);
+        J.wide[j] = q.splits > 64 && J.n[j] + J.nb[j] <= 4096;
+        rblocks += (unsigned)((J.n[j] + J.nb[j] + (J.wide[j] ? 3 : 63)) / (J.wide[j] ? 4 : 64));
         if (!q.dY) continue;            // sums only: the slabs were written by somebody else (the scorer's last layer)
         GlArgs& g = m.g[ng];
         g = GlArgs{};

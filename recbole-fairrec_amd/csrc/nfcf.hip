@@ -487,6 +487,7 @@ extern "C" int fr_nfcf_loss_tail(const float* label, const float* sst, int64_t B
                            (const float4*)stats, (const int*)kpart, ndf, fair_weight, dy, df_part, kout);
         FR_CHECK_LAUNCH();
     }
+    // (closing the loss inside pass 2 through an arrival ticket was measured: 11.7 us against 5.4 + 4.8 for the two launches)
     hipLaunchKernelGGL(nfcf_finalize_kernel, dim3(1), dim3(256), 0, stream, bce_part, (int)n_part, (const float*)df_part,
                        df ? ndf : 0, (const float*)kout, (int)B, fair_weight, loss);
     FR_CHECK_LAUNCH();

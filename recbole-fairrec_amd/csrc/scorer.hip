@@ -53,7 +53,10 @@ struct ScFwd {
     float *x0d, *x1d, *h1, *h2, *y;
     const float *label, *sst;
     float *out, *dy, *bce_part, *mm_part;
+    float* loss;                 // no fairness term behind this launch: the last workgroup to finish writes loss[3]
 };
+
+__device__ unsigned int sc_ticket;   // arrivals of a forward launch that closes its own loss (back to 0 when it ends)
 
 struct ScBwd {
     ScShape s;
@@ -342,10 +345,32 @@ __global__ __launch_bounds__(SC_THREADS) void scorer_fwd_kernel(ScFwd a) {
             lo = fminf(lo, lo_s[i]);
             hi = fmaxf(hi, hi_s[i]);
         }
-        a.bce_part[blockIdx.x] = l;
+        if (a.loss) __hip_atomic_store(a.bce_part + blockIdx.x, l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else a.bce_part[blockIdx.x] = l;
         if (a.sst) {
             a.mm_part[2 * blockIdx.x] = lo;
             a.mm_part[2 * blockIdx.x + 1] = hi;
+        }
+    }
+    if (a.loss) {      // loss = mean BCE (nfcf.py:105-107): summed by whoever arrives last, in workgroup order
+        __shared__ bool last;
+        if (tid == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this workgroup's partial (a device-scope store) has landed
+            const unsigned t = __hip_atomic_fetch_add(&sc_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            last = t == gridDim.x - 1;
+            if (last) sc_ticket = 0u;
+        }
+        __syncthreads();
+        if (last && tid < 64) {
+            float v = 0.f;
+            for (int q = tid; q < (int)gridDim.x; q += 64) v += __hip_atomic_load(a.bce_part + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            v = wave_sum(v);
+            if (tid == 0) {
+                const float bce = v / (float)s.B;
+                a.loss[0] = bce;
+                a.loss[1] = bce;
+                a.loss[2] = 0.f;
+            }
         }
     }
     SC_STAMP(14);
@@ -368,7 +393,37 @@ __global__ __launch_bounds__(SC_THREADS) void scorer_bwd_kernel(ScBwd a) {
     float* red = DZ1s + SC_ROWS * HS1;        // [4][16][64]
     float* DXs = red + 4096;                  // [32][DS]
     unsigned long long ctr = 0;
+    SC_STAMP(16);
+    // ---- the weights' fragments of both products and the ReLU masks, fetched before anything else: their latency passes under
+    // the elementwise phases (the products below would otherwise wait for each chunk's 16 strided loads in turn) --------------
+    const int T1 = s.n1 >> 5, C = s.n2 >> 5, C1 = s.n1 >> 5;
+    const int tile1 = wave % T1, part1 = wave / T1;
+    const bool live1 = part1 < C;
+    const int ntile = cend > cbeg ? (cend - cbeg) >> 5 : 0;
+    f4 w2f[4], h1m[4], w1f[4][4];
+    {
+        const float* wp = s.W2 + (size_t)((live1 ? part1 : 0) * 32 + 4 * h) * s.n1 + tile1 * 32 + r;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) w2f[j][e] = wp[(size_t)(8 * j + e) * s.n1];
+    }
+    auto fetch_w1 = [&](int tile) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (c < C1) {
+                const float* wp = s.W1 + (size_t)(c * 32 + 4 * h) * K0 + cbeg + tile * 32 + r;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) w1f[c][j][e] = wp[(size_t)(8 * j + e) * K0];
+            }
+        }
+    };
+    // (w1f holds one [n1, 32] column block as four chunks of 16 floats per lane: f4 w1f[c][j], element e)
+    if (wave < ntile) fetch_w1(wave);
     if (a.d.on) ctr = drop_counter_enter(a.d.ctr, nullptr, nullptr, &ctr_s);
+    SC_STAMP(17);
 
     if (tid < SC_ROWS) {
         const int b = i0 + tid;
@@ -400,29 +455,41 @@ __global__ __launch_bounds__(SC_THREADS) void scorer_bwd_kernel(ScBwd a) {
         }
     }
     __syncthreads();
-    if (tid <= s.n2) {      // this tile's share of dW3 (columns 0 .. n2 - 1) and db3 (column n2): rows in ascending order
+    SC_STAMP(18);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {      // the ReLU masks of the next product's epilogue: on their way during the dW3 shares
+        const long long gr = i0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        h1m[e >> 2][e & 3] = a.h1[(gr < s.B ? gr : s.B - 1) * s.n1 + tile1 * 32 + r];
+    }
+    {   // this tile's share of dW3 (columns 0 .. n2 - 1) and db3 (column n2): four runs of eight rows, added in run order
+        const int k = tid & 127, run = tid >> 7;
         float sum = 0.f;
-        for (int row = 0; row < SC_ROWS; ++row) sum += d3s[row] * (tid < s.n2 ? H2s[row * HS2 + tid] : 1.f);
-        a.w3part[(size_t)blockIdx.x * (s.n2 + 1) + tid] = sum;
+        if (k <= s.n2) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int row = run * 8 + q;
+                sum += d3s[row] * (k < s.n2 ? H2s[row * HS2 + k] : 1.f);
+            }
+            red[run * 128 + k] = sum;
+        }
+        __syncthreads();
+        if (run == 0 && k <= s.n2)
+            a.w3part[(size_t)blockIdx.x * (s.n2 + 1) + k] = ((red[k] + red[128 + k]) + red[256 + k]) + red[384 + k];
+        __syncthreads();
     }
 
+    SC_STAMP(19);
     // ---- dz1 = (dz2 W2) o [H1 > 0] scale -----------------------------------------------------------------------------------
     {
-        const int T1 = s.n1 >> 5, C = s.n2 >> 5;
-        const int tile = wave % T1, part = wave / T1;
-        const bool live = part < C;
+        const int tile = tile1, part = part1;
+        const bool live = live1;
         f32x16 c0 = {0}, c1 = {0};
         if (live) {
             const float* xa = DZ2s + r * HS2 + part * 32 + h * 4;
-            const float* wp = s.W2 + (size_t)(part * 32 + 4 * h) * s.n1 + tile * 32 + r;
-            f4 av[4], bv[4];
+            f4 av[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                av[j] = *reinterpret_cast<const f4*>(xa + j * 8);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) bv[j][e] = wp[(size_t)(8 * j + e) * s.n1];
-            }
-            SC_MFMA16(av, bv, c0, c1)
+            for (int j = 0; j < 4; ++j) av[j] = *reinterpret_cast<const f4*>(xa + j * 8);
+            SC_MFMA16(av, w2f, c0, c1)
         }
         f32x16 acc = c0 + c1;
         if (live && part > 0) {
@@ -432,44 +499,46 @@ __global__ __launch_bounds__(SC_THREADS) void scorer_bwd_kernel(ScBwd a) {
         __syncthreads();
         if (live && part == 0) {
             const int col = tile * 32 + r;
+            float other[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) other[e] = C > 1 ? red[(tile * 16 + e) * 64 + lane] : 0.f;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
                 float v = acc[e];
-                if (C > 1) v += red[(tile * 16 + e) * 64 + lane];
+                if (C > 1) v += other[e];
                 const long long gr = i0 + row;
-                const float hv = gr < s.B ? a.h1[gr * s.n1 + col] : 0.f;
-                v = hv > 0.f ? v * a.d.scale : 0.f;
+                v = (gr < s.B && h1m[e >> 2][e & 3] > 0.f) ? v * a.d.scale : 0.f;
                 DZ1s[row * HS1 + col] = v;
                 if (gr < s.B) a.dz1[gr * s.n1 + col] = v;
             }
         }
         __syncthreads();
     }
+    SC_STAMP(20);
     if (cend <= cbeg) return;
 
     // ---- dX = (dz1 W1) o keep, the blocks that train -------------------------------------------------------------------------
     {
-        const int ntile = (cend - cbeg) >> 5, C1 = s.n1 >> 5;
         for (int tile = wave; tile < ntile; tile += SC_THREADS / 64) {
+            if (tile != wave) fetch_w1(tile);        // (the first block of every wave came in at the top of the kernel)
             f32x16 c0 = {0}, c1 = {0};
-            for (int c = 0; c < C1; ++c) {
-                const float* xa = DZ1s + r * HS1 + c * 32 + h * 4;
-                const float* wp = s.W1 + (size_t)(c * 32 + 4 * h) * K0 + cbeg + tile * 32 + r;
-                f4 av[4], bv[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    av[j] = *reinterpret_cast<const f4*>(xa + j * 8);
+            for (int c = 0; c < 4; ++c) {
+                if (c < C1) {
+                    const float* xa = DZ1s + r * HS1 + c * 32 + h * 4;
+                    f4 av[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) bv[j][e] = wp[(size_t)(8 * j + e) * K0];
+                    for (int j = 0; j < 4; ++j) av[j] = *reinterpret_cast<const f4*>(xa + j * 8);
+                    SC_MFMA16(av, w1f[c], c0, c1)
                 }
-                SC_MFMA16(av, bv, c0, c1)
             }
             const f32x16 acc = c0 + c1;
 #pragma unroll
             for (int e = 0; e < 16; ++e) DXs[((e & 3) + 8 * (e >> 2) + 4 * h) * DS + tile * 32 + r] = acc[e];
         }
         __syncthreads();
+        SC_STAMP(21);
         const int qx = (cend - cbeg) >> 2;
         for (int idx = tid; idx < SC_ROWS * qx; idx += SC_THREADS) {
             const int row = idx / qx, c4 = idx - row * qx;
@@ -487,6 +556,7 @@ __global__ __launch_bounds__(SC_THREADS) void scorer_bwd_kernel(ScBwd a) {
             *reinterpret_cast<f4*>((second ? a.dx1 + gr * s.k1 : a.dx0 + gr * s.k0) + cc * 4) = v;
         }
     }
+    SC_STAMP(22);
 }
 
 // out[i] = sum over the parts p of part[p * n + i]: one wave per output, lane l adds parts l, l + 64, ... in ascending order and
@@ -535,7 +605,7 @@ extern "C" int64_t fr_scorer_blocks(int64_t B) { return B < 1 ? 0 : (B + SC_ROWS
 extern "C" int fr_scorer_fwd(const fr_scorer* s, const float* x0, const float* x1, int64_t B, const int64_t* counter,
                              int64_t* used_out, int64_t* tick_state, float* x0d, float* x1d, float* h1, float* h2, float* y,
                              const float* label, const float* sst, float* out, float* dy, float* bce_part, float* mm_part,
-                             void* stream_) {
+                             float* loss, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     FR_CHECK_ARG(shape_ok(s), "fr_scorer_fwd: shape not supported (k0 == k1, multiples of 32, k0 + k1 <= 512; n1 <= 128, n2 <= 64, multiples of 32)");
     FR_CHECK_ARG(x0 && x1 && h1 && h2 && y && B >= 1 && B < (1ll << 31) && s->W1 && s->b1 && s->W2 && s->b2 && s->W3 && s->b3,
@@ -553,6 +623,7 @@ extern "C" int fr_scorer_fwd(const fr_scorer* s, const float* x0, const float* x
     a.d.tick = (unsigned long long*)tick_state;
     a.x0 = x0; a.x1 = x1; a.x0d = x0d; a.x1d = x1d; a.h1 = h1; a.h2 = h2; a.y = y;
     a.label = label; a.sst = label ? sst : nullptr; a.out = out; a.dy = dy; a.bce_part = bce_part; a.mm_part = mm_part;
+    a.loss = label ? loss : nullptr;
     const int K0 = s->k0 + s->k1;
     const size_t ring = 3 * ((size_t)2 * SC_ROWS * 36 + (size_t)2 * s->n1 * 36);
     const size_t scratch = 4096 + (size_t)SC_ROWS * (s->n1 + 4) + (size_t)SC_ROWS * (s->n2 + 4) + 6 * 1024;

@@ -9,6 +9,7 @@
 #include "common.hpp"
 #include "kernels.hpp"
 #include "table.hpp"
+#include "sort_body.hpp"
 
 namespace fr {
 
@@ -30,11 +31,9 @@ __global__ __launch_bounds__(256) void table_flush_kernel(TableV T_, AdamC c) {
 }
 
 template <int E>
-__global__ __launch_bounds__(256) void table_gather_kernel(TableV T_, AdamC c, const int64_t* __restrict__ idx,
-                                                           long long M, float* __restrict__ out, uint32_t* err) {
+__device__ __forceinline__ void gather_row(const TableV& T_, const AdamC& c, const int64_t* __restrict__ idx, long long M,
+                                           float* __restrict__ out, uint32_t* err, const long long j, const int lane) {
     const TableV T = resolved(T_);
-    const int lane = threadIdx.x & 63;
-    const long long j = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (j >= M) return;
     long long r = idx[j];
     if (r < 0 || r >= T.n_rows) {
@@ -52,6 +51,12 @@ __global__ __launch_bounds__(256) void table_gather_kernel(TableV T_, AdamC c, c
         replay<E>(p, m, v, t0, T.step, c, lane);
     }
     store_row<E>(p, out + (size_t)j * D, D, lane);
+}
+
+template <int E>
+__global__ __launch_bounds__(256) void table_gather_kernel(TableV T_, AdamC c, const int64_t* __restrict__ idx,
+                                                           long long M, float* __restrict__ out, uint32_t* err) {
+    gather_row<E>(T_, c, idx, M, out, err, (long long)blockIdx.x * 4 + (threadIdx.x >> 6), threadIdx.x & 63);
 }
 
 __global__ __launch_bounds__(256) void adam_dense_kernel(float* __restrict__ p, const float* __restrict__ g,
@@ -94,12 +99,9 @@ struct GatherJob {
 };
 
 template <int E>
-__global__ __launch_bounds__(256) void table_gather_train_kernel(GatherJob ja, GatherJob jb, AdamC c, long long M,
-                                                                 Lay lay, uint32_t* err) {
-    const GatherJob& J = blockIdx.y == 0 ? ja : jb;
+__device__ __forceinline__ void gather_train_row(const GatherJob& J, const AdamC& c, long long M, const Lay& lay, uint32_t* err,
+                                                 const long long j, const int lane) {
     const TableV T = resolved(J.T);
-    const int lane = threadIdx.x & 63;
-    const long long j = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (j >= M) return;
     const long long jp = lay.at(j);          // where logical position j sits in idx / rows_out
     long long r = J.idx[jp];
@@ -127,6 +129,44 @@ __global__ __launch_bounds__(256) void table_gather_train_kernel(GatherJob ja, G
     store_row<E>(m, J.w.m_side + (size_t)j * D, D, lane);
     store_row<E>(v, J.w.v_side + (size_t)j * D, D, lane);
     if (lane == 0) T.stamp[row] = T.step;
+}
+
+template <int E>
+__global__ __launch_bounds__(256) void table_gather_train_kernel(GatherJob ja, GatherJob jb, AdamC c, long long M,
+                                                                 Lay lay, uint32_t* err) {
+    gather_train_row<E>(blockIdx.y == 0 ? ja : jb, c, M, lay, err, (long long)blockIdx.x * 4 + (threadIdx.x >> 6), threadIdx.x & 63);
+}
+
+// The lookups of a step in ONE launch: the sort of the id list(s) as the first workgroup(s) (sort_body.hpp: one latency-bound
+// 1024-thread workgroup per list), the training gathers of one or two tables and, optionally, the read-only gather of a frozen
+// table (NFCF finetune: nfcf.py:66) behind them, one row per wave.  Inside a captured step (hipGraph) nothing overlaps across
+// launches -- the sort in front of the gathers was 27 of NFCF's 171 us; here it runs beside them.
+struct PlainJob {
+    TableV T;
+    const int64_t* idx;
+    float* out;
+    long long M;
+};
+template <int E, int KPT>
+__global__ __launch_bounds__(SORT_THREADS) void table_lookup_kernel(SortJobList jobs, int npass, GatherJob ja, GatherJob jb,
+                                                                    int n_train, PlainJob pj, AdamC c, AdamC cp, long long M,
+                                                                    Lay lay, uint32_t* err) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    if ((int)blockIdx.x < jobs.n) {
+        sort_segments_body<KPT>(jobs, npass, err, blockIdx.x, smem);
+        return;
+    }
+    constexpr int WPB = SORT_THREADS / 64;
+    const int lane = threadIdx.x & 63;
+    const long long per = (M + WPB - 1) / WPB;                  // workgroups per training table
+    long long b = (long long)blockIdx.x - jobs.n;
+    if (b < per * n_train) {
+        const bool second = b >= per;
+        gather_train_row<E>(second ? jb : ja, c, M, lay, err, (second ? b - per : b) * WPB + (threadIdx.x >> 6), lane);
+        return;
+    }
+    b -= per * n_train;
+    gather_row<E>(pj.T, cp, pj.idx, pj.M, pj.out, err, b * WPB + (threadIdx.x >> 6), lane);
 }
 
 struct ApplyJob {
@@ -254,7 +294,9 @@ static inline bool lay_ok(int32_t chunk, int32_t stride) { return chunk == 0 || 
 static int gather_train_impl(const char* who, const fr_table* ta, const fr_table* tb, const fr_adam* adam,
                              const int64_t* idx_a, const int64_t* idx_b, int64_t M, int32_t chunk, int32_t stride,
                              float* rows_a, float* rows_b, void* ws_a, void* ws_b, size_t ws_bytes, uint32_t* err_flag,
-                             hipStream_t stream, bool prepared = false) {
+                             hipStream_t stream, bool prepared = false, const fr_table* ro = nullptr,
+                             const fr_adam* ro_adam = nullptr, const int64_t* ro_idx = nullptr, int64_t ro_M = 0,
+                             float* ro_out = nullptr) {
     int rc;
     if ((rc = check_table(ta, who)) || (tb && (rc = check_table(tb, who))) || (rc = check_adam(adam, who))) return rc;
     FR_CHECK_ARG(idx_a && rows_a && ws_a && M >= 1 && M <= FR_SORT_MAX && ta->step >= 1 && lay_ok(chunk, stride),
@@ -280,6 +322,57 @@ static int gather_train_impl(const char* who, const fr_table* ta, const fr_table
         capturing = hipStreamCaptureStatusNone;
     }
     const bool overlap = ss != nullptr && !prof_on() && capturing == hipStreamCaptureStatusNone;
+    // one launch for the sort and the gathers where nothing would overlap otherwise (and whenever a frozen table rides along)
+    static const bool no_merge = getenv("FAIRREC_LOOKUP_SEPARATE") != nullptr;
+    const int kpt = M <= 2 * SORT_THREADS ? 2 : (M > 4 * SORT_THREADS && M <= 8 * SORT_THREADS ? 8 : 0);
+    if (!prepared && !no_merge && kpt != 0 && (!overlap || ro) && (!ro || (ro->dim + 63) / 64 == (ta->dim + 63) / 64)) {
+        if (ro && ((rc = check_table(ro, who)) || (rc = check_adam(ro_adam, who)))) return rc;
+        FR_CHECK_ARG(!ro || (ro_idx && ro_out && ro_M >= 0), "%s: bad read-only lookup", who);
+        SortJobList jobs{};
+        jobs.j[0] = sa;
+        jobs.M[0] = (int)M;
+        jobs.n = 1;
+        long long nmax = sa.n_rows;
+        if (tb) {
+            jobs.j[1] = sb;
+            jobs.M[1] = (int)M;
+            jobs.n = 2;
+            nmax = std::max<long long>(nmax, sb.n_rows);
+        }
+        int bits = 1;
+        while (bits < 32 && (1ll << bits) < nmax) ++bits;
+        const AdamC c = make_adamc(adam);
+        const AdamC cp = ro ? make_adamc(ro_adam) : c;
+        GatherJob ja{view(ta), idx_a, rows_a, wa};
+        GatherJob jb = tb ? GatherJob{view(tb), idx_b, rows_b, wb} : ja;
+        PlainJob pj{ro ? view(ro) : view(ta), ro_idx, ro_out, ro ? (long long)ro_M : 0};
+        constexpr int WPB = SORT_THREADS / 64;
+        const long long blocks = jobs.n + (M + WPB - 1) / WPB * (tb ? 2 : 1) + (ro ? (ro_M + WPB - 1) / WPB : 0);
+        ProfScope prof(K_TABLE_GATHER_TRAIN, stream);
+#define FR_LOOKUP_LAUNCH(KPT)                                                                                              \
+    {                                                                                                                      \
+        static bool attr_set[5] = {false, false, false, false, false};                                                     \
+        if (!attr_set[E]) {                                                                                                \
+            FR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(table_lookup_kernel<E, KPT>),                   \
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_lds_bytes<KPT>()));     \
+            attr_set[E] = true;                                                                                            \
+        }                                                                                                                  \
+        const int npass = (bits + sort_digit_bits(KPT) - 1) / sort_digit_bits(KPT);                                        \
+        FR_LAUNCH(prof, (table_lookup_kernel<E, KPT>), dim3((unsigned)blocks), dim3(SORT_THREADS), sort_lds_bytes<KPT>(),  \
+                  stream, jobs, npass, ja, jb, tb ? 2 : 1, pj, c, cp, (long long)M, lay, err_flag);                        \
+    }
+        if (kpt == 2) {
+            FR_DISPATCH_E(ta->dim, FR_LOOKUP_LAUNCH(2));
+        } else {
+            FR_DISPATCH_E(ta->dim, FR_LOOKUP_LAUNCH(8));
+        }
+#undef FR_LOOKUP_LAUNCH
+        FR_CHECK_LAUNCH();
+        return FR_OK;
+    }
+    if (ro) {      // not mergeable: the read-only gather as its own launch
+        if ((rc = fr_table_gather(ro, ro_adam, ro_idx, ro_M, ro_out, err_flag, stream))) return rc;
+    }
     if (prepared) {
         // fr_table_sort2 already left the segments of these id lists in the workspaces (one step ahead)
     } else if (overlap) {
@@ -307,6 +400,16 @@ extern "C" int fr_table_gather_train(const fr_table* t, const fr_adam* adam, con
                                      uint32_t* err_flag, void* stream_) {
     return gather_train_impl("fr_table_gather_train", t, nullptr, adam, idx, nullptr, M, chunk, stride, rows_out, nullptr,
                              ws, nullptr, ws_bytes, err_flag, (hipStream_t)stream_);
+}
+
+// fr_table_gather_train on `t` and fr_table_gather on a second, read-only table `ro` (its own id list and hyper-parameters)
+// as one launch where the shapes allow (same fragment count per row, M <= 2048 or 4096 < M <= 8192), else as the two calls.
+extern "C" int fr_table_lookup_pair(const fr_table* t, const fr_adam* adam, const int64_t* idx, int64_t M, float* rows_out,
+                                    void* ws, size_t ws_bytes, const fr_table* ro, const fr_adam* ro_adam,
+                                    const int64_t* ro_idx, int64_t ro_M, float* ro_out, uint32_t* err_flag, void* stream_) {
+    FR_CHECK_ARG(ro && ro_adam && ro_idx && ro_out && ro_M >= 1, "fr_table_lookup_pair: bad read-only lookup");
+    return gather_train_impl("fr_table_lookup_pair", t, nullptr, adam, idx, nullptr, M, 0, 0, rows_out, nullptr, ws, nullptr,
+                             ws_bytes, err_flag, (hipStream_t)stream_, false, ro, ro_adam, ro_idx, ro_M, ro_out);
 }
 
 // The same with the segments of `idx` already in ws (FR_TABLE_PREPARED), e.g. copied from the workspace of another table

@@ -180,13 +180,15 @@ _PROTOS = {
     "fr_nfcf_loss_workspace_bytes": (c_size_t, [c_int64]),
     "fr_nfcf_loss": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_float, c_void_p, c_size_t, c_int32, c_void_p,
                              c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
+    "fr_table_lookup_pair": (c_int, [POINTER(FrTable), POINTER(FrAdam), c_void_p, c_int64, c_void_p, c_void_p, c_size_t,
+                                     POINTER(FrTable), POINTER(FrAdam), c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "fr_nfcf_loss_tail": (c_int, [c_void_p, c_void_p, c_int64, c_float, c_void_p, c_size_t, c_int32, c_void_p, c_void_p,
                                   c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_size_t, c_void_p, c_void_p]),
     "fr_scorer_supported": (c_int, [POINTER(FrScorer)]),
     "fr_scorer_blocks": (c_int64, [c_int64]),
     "fr_scorer_fwd": (c_int, [POINTER(FrScorer), c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                              c_void_p, c_void_p]),
+                              c_void_p, c_void_p, c_void_p]),
     "fr_scorer_bwd": (c_int, [POINTER(FrScorer), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p,
                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "fr_parts_sum": (c_int, [c_void_p, c_int32, c_int64, c_void_p, c_void_p]),

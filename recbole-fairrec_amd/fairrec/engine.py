@@ -137,7 +137,17 @@ class GenericEngine:
         return t.gather(self._hyper(name), idx, self.err_flag)
 
     def lookup_pair(self, name_a: str, idx_a: torch.Tensor, name_b: str, idx_b: torch.Tensor):
-        """Two lookups of one step (the row-sharded engine packs their exchanges into one buffer per direction)."""
+        """Two lookups of one step (the row-sharded engine packs their exchanges into one buffer per direction; here a frozen
+        table's read-only gather rides in the training gather's launch: fr_table_lookup_pair)."""
+        ta, tb = self._tables[name_a], self._tables[name_b]
+        if torch.is_grad_enabled() and tb.trainable and not ta.trainable and ta.dim == tb.dim:
+            idx_a = idx_a.to(self.device, torch.int64).contiguous()
+            idx_b = idx_b.to(self.device, torch.int64).contiguous()
+            self._seg_src[(idx_b.data_ptr(), idx_b.numel(), tb.n_rows)] = tb
+            got = []
+            rows_b = LazyLookup.apply(self._weights[name_b], tb, self._hyper(name_b), idx_b, self.err_flag, None,
+                                      (ta, self._hyper(name_a), idx_a, got))
+            return got[0], rows_b
         return self.lookup(name_a, idx_a), self.lookup(name_b, idx_b)
 
     def batch_segments(self, name: str):

@@ -105,14 +105,15 @@ class _NfcfFused(torch.autograd.Function):
         loss = torch.empty(3, **f32)
         _C.check(lib.fr_scorer_fwd(ctypes.byref(d), x0.data_ptr(), x1.data_ptr(), B, _C.ptr(state), _C.ptr(used), _C.ptr(state),
                                    _C.ptr(x0d), _C.ptr(x1d), h1.data_ptr(), h2.data_ptr(), y.data_ptr(), label.data_ptr(),
-                                   _C.ptr(sst), out.data_ptr(), dy.data_ptr(), part.data_ptr(), part[nblk:].data_ptr(), st),
-                 "fr_scorer_fwd")
-        ws = torch.empty(lib.fr_nfcf_loss_workspace_bytes(B), dtype=torch.uint8, device=dev)
+                                   _C.ptr(sst), out.data_ptr(), dy.data_ptr(), part.data_ptr(), part[nblk:].data_ptr(),
+                                   loss.data_ptr() if item_table is None else None, st), "fr_scorer_fwd")
         iws = item_table._ws if item_table is not None else None
-        _C.check(lib.fr_nfcf_loss_tail(label.data_ptr(), _C.ptr(sst), B, fair_weight, _C.ptr(iws),
-                                       iws.numel() if iws is not None else 0, item_table.dim if item_table is not None else 1,
-                                       out.data_ptr(), dy.data_ptr(), loss.data_ptr(), part.data_ptr(), part[nblk:].data_ptr(),
-                                       nblk, ws.data_ptr(), ws.numel(), err_flag.data_ptr(), st), "fr_nfcf_loss_tail")
+        if iws is not None:     # (without the fairness term the forward launch has closed the loss itself)
+            ws = torch.empty(lib.fr_nfcf_loss_workspace_bytes(B), dtype=torch.uint8, device=dev)
+            _C.check(lib.fr_nfcf_loss_tail(label.data_ptr(), _C.ptr(sst), B, fair_weight, _C.ptr(iws),
+                                           iws.numel(), item_table.dim, out.data_ptr(), dy.data_ptr(), loss.data_ptr(),
+                                           part.data_ptr(), part[nblk:].data_ptr(), nblk, ws.data_ptr(), ws.numel(),
+                                           err_flag.data_ptr(), st), "fr_nfcf_loss_tail")
         ctx.save_for_backward(dy, y, h1, h2, x0d if p > 0 else x0, x1d if p > 0 else x1, used, *params)
         ctx.meta = (k0, k1, p, seed, B, nblk)
         ctx.mark_non_differentiable(out)

@@ -178,6 +178,31 @@ class LazyTable:
         _used_on_side_stream(idx)
         return rows
 
+    def gather_train_with(self, hyper: AdamHyper, idx: torch.Tensor, ro: "LazyTable", ro_hyper: AdamHyper, ro_idx: torch.Tensor,
+                          err_flag: Optional[torch.Tensor] = None):
+        """`gather_train(idx)` on this table and `ro.gather(ro_idx)` on a read-only one in ONE launch (fr_table_lookup_pair: the
+        id sort rides in it as well).  Returns (rows, ro_rows)."""
+        idx, ro_idx = idx.contiguous(), ro_idx.contiguous()
+        M = idx.numel()
+        dev = self.weight.device
+        rows = torch.empty((M, self.dim), dtype=torch.float32, device=dev)
+        ro_rows = torch.empty((ro_idx.numel(), ro.dim), dtype=torch.float32, device=dev)
+        need = _C.lib().fr_table_train_workspace_bytes(M, self.dim)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        t, r = self.c(self.step + 1), ro.c()
+        hyper.check_step(self.step + 1)
+        _C.check(_C.lib().fr_table_lookup_pair(ctypes.byref(t), ctypes.byref(hyper.c()), idx.data_ptr(), M, rows.data_ptr(),
+                                               self._ws.data_ptr(), self._ws.numel(), ctypes.byref(r), ctypes.byref(ro_hyper.c()),
+                                               ro_idx.data_ptr(), ro_idx.numel(), ro_rows.data_ptr(), _C.ptr(err_flag),
+                                               _C.current_stream()), "fr_table_lookup_pair")
+        _used_on_side_stream(self._ws)
+        _used_on_side_stream(idx)
+        self._pending = (M, rows)
+        self._keep = idx
+        self._grad_rows = None
+        return rows, ro_rows
+
     def gather_train_into(self, hyper: AdamHyper, idx_ptr: int, M: int, rows_ptr: int, chunk: int = 0, stride: int = 0,
                           err_flag: Optional[torch.Tensor] = None, segments_of: Optional["LazyTable"] = None):
         """The same on raw device pointers with a slot layout (fairrec_hip.h): M ids read from / M rows written into
@@ -312,15 +337,21 @@ class LazyLookup(torch.autograd.Function):
     of nn.Embedding is never built."""
 
     @staticmethod
-    def forward(ctx, weight, table, hyper, idx, err_flag, segments_of=None):
+    def forward(ctx, weight, table, hyper, idx, err_flag, segments_of=None, ro=None):
+        """`ro` = (read-only table, its hyper-parameters, its ids, a list that receives its rows): a frozen table's gather in
+        the same launch (LazyTable.gather_train_with)."""
         ctx.table = table
+        if ro is not None:
+            rows, ro_rows = table.gather_train_with(hyper, idx, ro[0], ro[1], ro[2], err_flag)
+            ro[3].append(ro_rows)
+            return rows
         return table.gather_train(hyper, idx, err_flag, segments_of)
 
     @staticmethod
     def backward(ctx, grad_rows):
         t = ctx.table
         t._grad_rows = grad_rows if t._grad_rows is None else t._grad_rows + grad_rows
-        return None, None, None, None, None, None
+        return None, None, None, None, None, None, None
 
 
 class FusedLazyAdam:

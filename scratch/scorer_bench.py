@@ -29,7 +29,7 @@ for B in Bs:
         def fwd():
             _C.check(lib.fr_scorer_fwd(ctypes.byref(d), x0.data_ptr(), x1.data_ptr(), B, state.data_ptr(), used.data_ptr(), state.data_ptr(),
                                        x0d.data_ptr(), x1d.data_ptr(), h1.data_ptr(), h2.data_ptr(), y.data_ptr(), label.data_ptr(), sst.data_ptr(),
-                                       out.data_ptr(), dy.data_ptr(), part.data_ptr(), part[nblk:].data_ptr(), st), "fwd")
+                                       out.data_ptr(), dy.data_ptr(), part.data_ptr(), part[nblk:].data_ptr(), None, st), "fwd")
         def bwd(both):
             _C.check(lib.fr_scorer_bwd(ctypes.byref(d), dy.data_ptr(), None, y.data_ptr(), h1.data_ptr(), h2.data_ptr(), B, used.data_ptr(),
                                        dz1.data_ptr(), dz2.data_ptr(), dz3.data_ptr(), dx0.data_ptr() if both else None, dx1.data_ptr(), w3p.data_ptr(), st), "bwd")
@@ -40,4 +40,14 @@ for B in Bs:
             for _ in range(n): fn()
             b.record(); torch.cuda.synchronize()
             return a.elapsed_time(b) / n * 1e3
+        def lat(fn, n=50):
+            ts = []
+            for _ in range(n):
+                torch.cuda.synchronize()
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record(); fn(); b.record(); torch.cuda.synchronize()
+                ts.append(a.elapsed_time(b) * 1e3)
+            ts.sort()
+            return ts[len(ts) // 2]
+        print(f"   isolated launches (median): fwd {lat(fwd):.2f}  bwd(item half) {lat(lambda: bwd(False)):.2f}  bwd(both) {lat(lambda: bwd(True)):.2f}")
         print(f"B={B} D={D} p={p}: fwd {timeit(fwd):.2f} us  bwd(item half) {timeit(lambda: bwd(False)):.2f} us  bwd(both) {timeit(lambda: bwd(True)):.2f} us", flush=True)

@@ -23,7 +23,7 @@ for p in (0.0, 0.2):
     for it in range(5):
         _C.check(lib.fr_scorer_fwd(ctypes.byref(d), x0.data_ptr(), x1.data_ptr(), B, state.data_ptr(), used.data_ptr(), state.data_ptr(),
                                    x0d.data_ptr(), x1d.data_ptr(), h1.data_ptr(), h2.data_ptr(), y.data_ptr(), label.data_ptr(), sst.data_ptr(),
-                                   out.data_ptr(), dy.data_ptr(), part.data_ptr(), part[nblk:].data_ptr(), _C.current_stream()), "fwd")
+                                   out.data_ptr(), dy.data_ptr(), part.data_ptr(), part[nblk:].data_ptr(), None, _C.current_stream()), "fwd")
         torch.cuda.synchronize()
     buf = np.zeros(64, dtype=np.uint64)
     assert raw.fr_debug_scorer_trace(buf.ctypes.data_as(ctypes.c_void_p)) == 0
@@ -32,4 +32,12 @@ for p in (0.0, 0.2):
     print(f"p={p}: shader cycles since entry (and delta)")
     for k in range(15):
         print(f"   {names[k]:12s} {t[k]:9.0f}  (+{t[k] - t[k - 1] if k else 0:7.0f})")
+    dz1, dz2, dz3 = torch.empty(B, n1, device=dev), torch.empty(B, n2, device=dev), torch.empty(B, device=dev)
+    dx1 = torch.empty(B, D, device=dev); w3p = torch.empty(nblk, n2 + 1, device=dev)
+    for it in range(3):
+        _C.check(lib.fr_scorer_bwd(ctypes.byref(d), dy.data_ptr(), None, y.data_ptr(), h1.data_ptr(), h2.data_ptr(), B, used.data_ptr(),
+                                   dz1.data_ptr(), dz2.data_ptr(), dz3.data_ptr(), None, dx1.data_ptr(), w3p.data_ptr(), _C.current_stream()), "bwd")
+        torch.cuda.synchronize()
+    assert raw.fr_debug_scorer_trace(buf.ctypes.data_as(ctypes.c_void_p)) == 0
+    print("   bwd stamps (cycles): enter, counter, dz2, w3part, dz1, dX products, end:", (buf[16:23] - buf[16]).astype(np.float64).tolist())
     sys.stdout.flush()
