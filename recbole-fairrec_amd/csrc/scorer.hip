@@ -122,16 +122,19 @@ __global__ __launch_bounds__(SC_THREADS) void scorer_fwd_kernel(ScFwd a) {
         wsrc[i] = s.W1 + (size_t)(rem >> 3) * K0 + hf * NCH * 32 + (rem & 7) * 4;
         woff[i] = XST + (hf * s.n1 + (rem >> 3)) * 36 + (rem & 7) * 4;
     }
-    // chunks 0 and 1 are fetched together; from then on chunk t + 2 travels while chunk t is multiplied
-    f4 xv = *reinterpret_cast<const f4*>(xsrc);
-    f4 wv[4];
+    // chunks 0, 1 and 2 are fetched together; from then on chunk t + 3 is fetched during step t, written to its stage during
+    // step t + 1 (in front of that step's MFMAs, under which the writes then run) and multiplied in step t + 3
+    struct Fetch {
+        f4 x, w[4];
+    } fa_, fb_, fc_;
+    auto fetch = [&](Fetch& f, int t) {
+        f.x = *reinterpret_cast<const f4*>(xsrc + t * 32);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) wv[i] = *reinterpret_cast<const f4*>(wsrc[i]);
-    const int ch1 = NCH > 1 ? 1 : 0;
-    f4 xv1 = *reinterpret_cast<const f4*>(xsrc + ch1 * 32);
-    f4 wv1[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) wv1[i] = *reinterpret_cast<const f4*>(wsrc[i] + ch1 * 32);
+        for (int i = 0; i < 4; ++i) f.w[i] = *reinterpret_cast<const f4*>(wsrc[i] + t * 32);
+    };
+    fetch(fa_, 0);
+    fetch(fb_, NCH > 1 ? 1 : 0);
+    fetch(fc_, NCH > 2 ? 2 : 0);
 
     // ---- operands of the later phases, fetched now: their latency passes under the first product ----------------------------------
     const int half = wave >> 2, tw = wave & 3, n0 = tw * 32;
@@ -156,28 +159,23 @@ __global__ __launch_bounds__(SC_THREADS) void scorer_fwd_kernel(ScFwd a) {
     unsigned long long ctr = 0;
     if (a.d.on) ctr = drop_counter_enter(a.d.ctr, a.d.used, a.d.tick, &ctr_s);
     SC_STAMP(1);
-    auto put = [&](int t, float* stage) {      // the fetched chunk t: X dropped (and to memory), everything into the stage
+    auto put = [&](Fetch& f, int t, float* stage) {      // the fetched chunk t: X dropped (and to memory), everything into the stage
         if (a.d.on) {
-            xv = keep_mul(xv, drop_keep4(a.d.seed, ctr, xgrp + (unsigned long long)t * 8, a.d.thr, a.d.scale));
-            if (xok) *reinterpret_cast<f4*>(xdst + t * 32) = xv;
+            f.x = keep_mul(f.x, drop_keep4(a.d.seed, ctr, xgrp + (unsigned long long)t * 8, a.d.thr, a.d.scale));
+            if (xok) *reinterpret_cast<f4*>(xdst + t * 32) = f.x;
         }
-        *reinterpret_cast<f4*>(stage + xoff) = xv;
+        *reinterpret_cast<f4*>(stage + xoff) = f.x;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            if (wok[i]) *reinterpret_cast<f4*>(stage + woff[i]) = wv[i];
+            if (wok[i]) *reinterpret_cast<f4*>(stage + woff[i]) = f.w[i];
     };
-    put(0, lds);
-    if (NCH > 1) {
-        xv = xv1;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) wv[i] = wv1[i];
-        put(1, lds + STAGE);
-    }
+    put(fa_, 0, lds);
+    if (NCH > 1) put(fb_, 1, lds + STAGE);
     __syncthreads();
     SC_STAMP(3);
 
-    // ---- Z1 = X W1^T: a ring of three stages; the fragments of chunk t + 1 are read (and chunk t + 2 fetched) under the
-    // MFMAs of chunk t, so that neither the LDS traffic nor the fetch latency sits between two steps' products -------------
+    // ---- Z1 = X W1^T: a ring of three stages; the fragments of chunk t + 1 are read, chunk t + 2 written and chunk t + 3
+    // fetched under the MFMAs of chunk t, so that neither LDS traffic nor fetch latency sits between two steps' products ------
     const int fa = (half * SC_ROWS + r) * 36 + h * 4, fb = XST + (half * s.n1 + (live ? n0 : 0) + r) * 36 + h * 4;
     f4 av[4], bv[4], an[4], bn[4];
 #pragma unroll
@@ -185,34 +183,35 @@ __global__ __launch_bounds__(SC_THREADS) void scorer_fwd_kernel(ScFwd a) {
         av[j] = *reinterpret_cast<const f4*>(lds + fa + j * 8);
         bv[j] = *reinterpret_cast<const f4*>(lds + fb + j * 8);
     }
+    // (the first fragments have landed before the loop is entered: with reads still in flight at its head the compiler's wait
+    // insertion, which must cover both ways into the loop, puts an LDS wait in front of every step's MFMAs)
+    __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0)
     f32x16 acc0 = {0}, acc1 = {0};
-    int st1 = 1, st2 = 2;      // stage of chunk t + 1, of chunk t + 2
-    for (int t = 0; t < NCH; ++t) {
-        const bool more2 = t + 2 < NCH;
-        if (more2) {
-            xv = *reinterpret_cast<const f4*>(xsrc + (t + 2) * 32);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) wv[i] = *reinterpret_cast<const f4*>(wsrc[i] + (t + 2) * 32);
-        }
+    // one step; `cur` holds chunk t + 2 (fetched a step ago, or before the loop), `nxt` receives chunk t + 3
+    auto step = [&](int t, Fetch& cur, Fetch& nxt) {
         if (t + 1 < NCH) {
-            const float* nx = lds + st1 * STAGE;
+            const float* nx = lds + ((t + 1) % 3) * STAGE;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 an[j] = *reinterpret_cast<const f4*>(nx + fa + j * 8);
                 bn[j] = *reinterpret_cast<const f4*>(nx + fb + j * 8);
             }
         }
+        if (t + 2 < NCH) put(cur, t + 2, lds + ((t + 2) % 3) * STAGE);
+        // (fetched after the put, whose wait for `cur` would otherwise cover these loads as well: the memory counter is in order)
+        if (t + 3 < NCH) fetch(nxt, t + 3);
         if (live) { SC_MFMA16(av, bv, acc0, acc1) }
-        if (more2) put(t + 2, lds + st2 * STAGE);
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             av[j] = an[j];
             bv[j] = bn[j];
         }
-        st1 = st2;
-        st2 = st2 == 2 ? 0 : st2 + 1;
         SC_STAMP(4 + (t < 8 ? t : 7));
+    };
+    for (int t = 0; t < NCH; t += 2) {      // (two steps per trip: the two fetch buffers swap roles without a copy)
+        step(t, fc_, fa_);
+        if (t + 1 < NCH) step(t + 1, fa_, fc_);
     }
     f32x16 acc = acc0 + acc1;
     float* red = lds;                      // [4][16][64]
