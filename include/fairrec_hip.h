@@ -326,7 +326,7 @@ FR_API int fr_table_join(const void* ws, void* stream);
 FR_API void* fr_side_stream_handle(void);
 /* fr_table_gather_train(t, idx) and fr_table_gather(ro, ro_idx) -- a frozen table next to a training one: NFCF's finetune
  * stage, nfcf.py:66-71 -- in ONE launch that also carries the sort of `idx` (same results as the two calls; falls back to
- * them when the two tables' rows have different fragment counts or M is outside (0, 2048] / (4096, 8192]). */
+ * them when the two tables' rows have different fragment counts). */
 FR_API int fr_table_lookup_pair(const fr_table* t, const fr_adam* adam, const int64_t* idx, int64_t M, float* rows_out,
                                 void* ws, size_t ws_bytes, const fr_table* ro, const fr_adam* ro_adam, const int64_t* ro_idx,
                                 int64_t ro_M, float* ro_out, uint32_t* err_flag, void* stream);
@@ -590,9 +590,11 @@ FR_API int fr_spmm_csr(const int64_t* indptr, const int32_t* col, const float* v
  *                   rows[i] (rows == NULL: row i) in ascending j, xrow(c) = map ? map[c] : c, nonzeros with map[c] < 0
  *                   skipped.  `rows` (int32 [n_out]) makes Y compact; `map` (int32 [number of columns]) lets X be a compact
  *                   block of a whole-table operand or, on the CSR of L^T, names the columns that carry a gradient row.
- *                   Kept terms are added in fr_spmm_csr's order: the rows equal the whole-table product's. */
+ *                   `map_bits` (optional, uint32 [ceil(columns / 32)]): bit c set exactly where map[c] >= 0 -- the kernel
+ *                   then reads the map only at set bits (the bitmap of 11 M columns is 1.4 MB and lives in every L2; the
+ *                   map is 44 MB).  Kept terms are added in fr_spmm_csr's order: the rows equal the whole-table product's. */
 FR_API int fr_spmm_csr_sel(const int64_t* indptr, const int32_t* col, const float* val, const float* X, const int32_t* rows,
-                           int64_t n_out, const int32_t* map, int32_t dim, float* Y, void* stream);
+                           int64_t n_out, const int32_t* map, const uint32_t* map_bits, int32_t dim, float* Y, void* stream);
 FR_API int fr_row_gather(const float* X, const int64_t* idx, int64_t M, int64_t n_rows, int32_t dim, float* out,
                          uint32_t* err_flag, void* stream);
 FR_API size_t fr_row_scatter_workspace_bytes(int64_t M);

@@ -66,7 +66,8 @@ template <int V>
 __global__ __launch_bounds__(256) void spmm_csr_sel_kernel(const long long* __restrict__ indptr, const int* __restrict__ col,
                                                            const float* __restrict__ val, const float* __restrict__ X,
                                                            const int* __restrict__ rows, long long n_out,
-                                                           const int* __restrict__ map, int D, float* __restrict__ Y) {
+                                                           const int* __restrict__ map, const unsigned* __restrict__ bits,
+                                                           int D, float* __restrict__ Y) {
     const int lane = threadIdx.x & 63;
     const long long i = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= n_out) return;
@@ -90,21 +91,111 @@ __global__ __launch_bounds__(256) void spmm_csr_sel_kernel(const long long* __re
             float my_v = 0.f;
             if (lane < cnt) {
                 my_c = col[jb + lane];
-                if (map) my_c = map[my_c];
+                if (map) my_c = (!bits || ((bits[my_c >> 5] >> (my_c & 31)) & 1u)) ? map[my_c] : -1;
                 if (my_c >= 0) my_v = val[jb + lane];
             }
             unsigned long long hits = __ballot(my_c >= 0);
+            // four hits at a time: their row gathers are independent loads in flight together (one at a time the loop is a
+            // chain of memory round trips: 36 per row of the first layer); the terms are still added one by one in CSR order
             while (hits) {
-                const int t = __ffsll((long long)hits) - 1;
-                hits &= hits - 1;
-                const int c = __builtin_amdgcn_readlane(my_c, t);
-                const float v = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_v), t));
-                const vec x = *reinterpret_cast<const vec*>(X + (size_t)c * D + lane * V);
+                int c[4];
+                float v[4];
+                vec x[4];
+                int n = 0;
 #pragma unroll
-                for (int e = 0; e < V; ++e) acc[e] = fmaf(v, x[e], acc[e]);
+                for (int q = 0; q < 4; ++q) {
+                    if (hits) {     // wave-uniform
+                        const int t = __ffsll((long long)hits) - 1;
+                        hits &= hits - 1;
+                        c[q] = __builtin_amdgcn_readlane(my_c, t);
+                        v[q] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_v), t));
+                        x[q] = *reinterpret_cast<const vec*>(X + (size_t)c[q] * D + lane * V);
+                        n = q + 1;
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (q < n) {
+#pragma unroll
+                        for (int e = 0; e < V; ++e) acc[e] = fmaf(v[q], x[q][e], acc[e]);
+                    }
+                }
             }
         }
         *reinterpret_cast<vec*>(Y + (size_t)i * D + lane * V) = acc;
+    }
+}
+
+// The same for ALL rows of the matrix through a column map that keeps few of them -- the backward of the first selected
+// layer walks L^T's 11 M rows (36 nonzeros each at BASELINE configs[3]) to find the 1.4 % of nonzeros that carry a gradient
+// row: one wave per row is four dependent loads for half a chunk of columns, and the launch is bound by wave turnover
+// (11 M waves).  Here a wave takes EIGHT consecutive rows as one contiguous run of nonzeros (their boundaries sit in lanes
+// 0 .. 8), looks the columns up 64 at a time and, for the rare hit, finds its row among the boundaries; a row's terms are
+// still added in CSR order into one accumulator that is stored when the run moves on to the next row (rows without a hit
+// are stored as zeros): the same bits as the kernel above.
+template <int V>
+__global__ __launch_bounds__(256) void spmm_csr_sel_runs_kernel(const long long* __restrict__ indptr, const int* __restrict__ col,
+                                                                const float* __restrict__ val, const float* __restrict__ X,
+                                                                long long n_out, const int* __restrict__ map,
+                                                                const unsigned* __restrict__ bits, int D,
+                                                                float* __restrict__ Y) {
+    constexpr int R = 8;
+    typedef float vec __attribute__((ext_vector_type(V)));
+    const int lane = threadIdx.x & 63;
+    const long long r0 = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
+    if (r0 >= n_out) return;
+    const int nr = (int)min((long long)R, n_out - r0);
+    const long long bnd = lane <= nr ? indptr[r0 + lane] : 0x7fffffffffffffffll;
+    const long long j0 = __shfl(bnd, 0, 64), j1 = __shfl(bnd, nr, 64);
+    vec acc = {};
+    int cur = 0;
+    // four chunks of 64 nonzeros per trip: their column loads go out together, then their bitmap words (two levels of
+    // latency per 256 nonzeros instead of per 64); the chunks' hits are then walked in order
+    for (long long jq = j0; jq < j1; jq += 256) {
+        int cc4[4];
+        unsigned w4[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const long long j = jq + 64 * q + lane;
+            cc4[q] = j < j1 ? col[j] : -1;
+        }
+        // (`bits`: one bit per column, set where map >= 0 -- 1.4 MB for 11 M columns, resident in every L2, where the map
+        // itself is 44 MB and each look-up of it drags a cache line out of the memory-side cache: 8.0 -> 5.1 ms per launch)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) w4[q] = (bits && cc4[q] >= 0) ? bits[cc4[q] >> 5] : 0xFFFFFFFFu;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+        const long long jb = jq + 64 * q;
+        if (jb >= j1) break;
+        int my_c = -1;
+        float my_v = 0.f;
+        if (cc4[q] >= 0 && ((w4[q] >> (cc4[q] & 31)) & 1u)) {
+            my_c = map[cc4[q]];
+            if (my_c >= 0) my_v = val[jb + lane];
+        }
+        unsigned long long hits = __ballot(my_c >= 0);
+        while (hits) {
+            const int t = __ffsll((long long)hits) - 1;
+            hits &= hits - 1;
+            const long long j = jb + t;
+            const int row = __popcll(__ballot(lane >= 1 && lane <= nr && bnd <= j));      // rows of the run that end at or before j
+            while (cur < row) {
+                *reinterpret_cast<vec*>(Y + (size_t)(r0 + cur) * D + lane * V) = acc;
+                acc = vec{};
+                ++cur;
+            }
+            const int c = __builtin_amdgcn_readlane(my_c, t);
+            const float v = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_v), t));
+            const vec x = *reinterpret_cast<const vec*>(X + (size_t)c * D + lane * V);
+#pragma unroll
+            for (int e = 0; e < V; ++e) acc[e] = fmaf(v, x[e], acc[e]);
+        }
+        }
+    }
+    while (cur < nr) {
+        *reinterpret_cast<vec*>(Y + (size_t)(r0 + cur) * D + lane * V) = acc;
+        acc = vec{};
+        ++cur;
     }
 }
 
@@ -217,15 +308,32 @@ extern "C" int fr_spmm_csr(const int64_t* indptr, const int32_t* col, const floa
 }
 
 extern "C" int fr_spmm_csr_sel(const int64_t* indptr, const int32_t* col, const float* val, const float* X, const int32_t* rows,
-                               int64_t n_out, const int32_t* map, int32_t dim, float* Y, void* stream_) {
+                               int64_t n_out, const int32_t* map, const uint32_t* map_bits, int32_t dim, float* Y,
+                               void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    FR_CHECK_ARG(indptr && col && val && X && Y && n_out >= 0 && dim >= 1, "fr_spmm_csr_sel: bad argument");
+    FR_CHECK_ARG(indptr && col && val && X && Y && n_out >= 0 && dim >= 1 && (map || !map_bits), "fr_spmm_csr_sel: bad argument");
+    const unsigned* bits = map_bits;
     if (n_out == 0) return FR_OK;
     ProfScope prof(K_SPMM, stream);
+    if (!rows && map && n_out >= 1024 && (dim == 64 || dim == 128 || dim == 256) && !getenv("FAIRREC_SPMM_SEL_ROWWISE")) {
+        const dim3 g8((unsigned)((n_out + 31) / 32));      // 4 waves x 8 rows per workgroup
+        if (dim == 64) {
+            FR_LAUNCH(prof, spmm_csr_sel_runs_kernel<1>, g8, dim3(256), 0, stream, (const long long*)indptr, col, val, X,
+                      (long long)n_out, map, bits, (int)dim, Y);
+        } else if (dim == 128) {
+            FR_LAUNCH(prof, spmm_csr_sel_runs_kernel<2>, g8, dim3(256), 0, stream, (const long long*)indptr, col, val, X,
+                      (long long)n_out, map, bits, (int)dim, Y);
+        } else {
+            FR_LAUNCH(prof, spmm_csr_sel_runs_kernel<4>, g8, dim3(256), 0, stream, (const long long*)indptr, col, val, X,
+                      (long long)n_out, map, bits, (int)dim, Y);
+        }
+        FR_CHECK_LAUNCH();
+        return FR_OK;
+    }
     const dim3 grid((unsigned)((n_out + 3) / 4));
 #define FR_SPMM_SEL(V)                                                                                              \
     FR_LAUNCH(prof, spmm_csr_sel_kernel<V>, grid, dim3(256), 0, stream, (const long long*)indptr, col, val, X, rows, \
-              (long long)n_out, map, (int)dim, Y)
+              (long long)n_out, map, bits, (int)dim, Y)
     switch (dim) {
         case 64: FR_SPMM_SEL(1); break;
         case 128: FR_SPMM_SEL(2); break;

@@ -103,12 +103,17 @@ __global__ __launch_bounds__(256) void bpr_kernel(const float* __restrict__ pos,
 // reduced over the block at the end (butterfly + wave order: fixed order).  Per-block column partials ga_part[block][j]
 // are added in block order by a second kernel.  B^2 transcendental groups, nothing of size B^2 is ever stored (the
 // reference materialises the [B,B] matrix).
-static constexpr int OUTER_ROWS = 32;
+static constexpr int OUTER_ROWS = 16;      // (32 until round 4: 256 workgroups at B = 8192 left every SIMD with ONE wave of this
+                                           // transcendental-bound loop; 512 give the quarter-rate unit a second wave to issue from)
 
 // -log(1e-10 + sigmoid(x)) and its derivative with hardware exp / log / rcp (1-2 ulp): with e = exp(-x), r = 1/(1+e):
 // sigmoid = r, 1 - sigmoid = e*r, so  term = -log(1e-10 + r),  dterm = -(r*r*e) / (1e-10 + r)
-__device__ __forceinline__ float bpr_term_fast(float x, float& dterm) {
-    const float e = __expf(-x);
+__device__ __forceinline__ float bpr_term_e(float e, float& dterm);
+__device__ __forceinline__ float bpr_term_fast(float x, float& dterm) { return bpr_term_e(__expf(-x), dterm); }
+// ... from e = exp(-x) itself: the outer form has x_ij = a_j + c_i, so exp(-x_ij) = exp(-a_j) exp(-c_i) is ONE multiplication per
+// pair instead of an exponential (B exponentials per row block and per thread column instead of B^2; |a|, |c| < 40 or the
+// plain form is used: no overflow of a factor)
+__device__ __forceinline__ float bpr_term_e(float e, float& dterm) {
     const float r = __builtin_amdgcn_rcpf(1.f + e);
     const float den = 1e-10f + r;
     dterm = -(r * r * e) * __builtin_amdgcn_rcpf(den);
@@ -123,12 +128,20 @@ __global__ __launch_bounds__(256) void bpr_outer_kernel(const float* __restrict_
                                                         int Nc, float inv, float* __restrict__ dc, float* __restrict__ ndc,
                                                         float* __restrict__ ga_part, float* __restrict__ loss_part) {
     const int B = Nc;      // rows
-    __shared__ float cs[OUTER_ROWS];
+    __shared__ float cs[OUTER_ROWS], ecs[OUTER_ROWS];
     __shared__ float red[4][OUTER_ROWS + 1];
+    __shared__ int rows_small;
     const int i0 = blockIdx.x * OUTER_ROWS;
-    if (threadIdx.x < OUTER_ROWS)
-        cs[threadIdx.x] = (i0 + threadIdx.x < B) ? c[i0 + threadIdx.x] - (c2 ? c2[i0 + threadIdx.x] : 0.f) : 0.f;
+    if (threadIdx.x == 0) rows_small = 1;
     __syncthreads();
+    if (threadIdx.x < OUTER_ROWS) {
+        const float cv = (i0 + threadIdx.x < B) ? c[i0 + threadIdx.x] - (c2 ? c2[i0 + threadIdx.x] : 0.f) : 0.f;
+        cs[threadIdx.x] = cv;
+        ecs[threadIdx.x] = __expf(-cv);
+        if (!(fabsf(cv) < 40.f)) rows_small = 0;
+    }
+    __syncthreads();
+    const bool rows_ok = rows_small != 0;
     const int ni = min(OUTER_ROWS, B - i0);
     float lsum = 0.f;
     float rs[OUTER_ROWS];
@@ -137,13 +150,26 @@ __global__ __launch_bounds__(256) void bpr_outer_kernel(const float* __restrict_
     for (int j = threadIdx.x; j < Na; j += 256) {
         const float aj = a2 ? a[j] - a2[j] : a[j];
         float gcol = 0.f;
+        if (rows_ok && fabsf(aj) < 40.f) {
+            const float ea = __expf(-aj);
 #pragma unroll
-        for (int i = 0; i < OUTER_ROWS; ++i) {
-            if (i < ni) {
-                float dt;
-                lsum += bpr_term_fast(aj + cs[i], dt);
-                gcol += dt;
-                rs[i] += dt;
+            for (int i = 0; i < OUTER_ROWS; ++i) {
+                if (i < ni) {
+                    float dt;
+                    lsum += bpr_term_e(ea * ecs[i], dt);
+                    gcol += dt;
+                    rs[i] += dt;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < OUTER_ROWS; ++i) {
+                if (i < ni) {
+                    float dt;
+                    lsum += bpr_term_fast(aj + cs[i], dt);
+                    gcol += dt;
+                    rs[i] += dt;
+                }
             }
         }
         ga_part[(size_t)blockIdx.x * Na + j] = gcol * inv;

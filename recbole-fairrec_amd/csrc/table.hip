@@ -324,7 +324,7 @@ static int gather_train_impl(const char* who, const fr_table* ta, const fr_table
     const bool overlap = ss != nullptr && !prof_on() && capturing == hipStreamCaptureStatusNone;
     // one launch for the sort and the gathers where nothing would overlap otherwise (and whenever a frozen table rides along)
     static const bool no_merge = getenv("FAIRREC_LOOKUP_SEPARATE") != nullptr;
-    const int kpt = M <= 2 * SORT_THREADS ? 2 : (M > 4 * SORT_THREADS && M <= 8 * SORT_THREADS ? 8 : 0);
+    const int kpt = M <= 2 * SORT_THREADS ? 2 : (M <= 4 * SORT_THREADS ? 4 : (M <= 8 * SORT_THREADS ? 8 : 16));
     if (!prepared && !no_merge && kpt != 0 && (!overlap || ro) && (!ro || (ro->dim + 63) / 64 == (ta->dim + 63) / 64)) {
         if (ro && ((rc = check_table(ro, who)) || (rc = check_adam(ro_adam, who)))) return rc;
         FR_CHECK_ARG(!ro || (ro_idx && ro_out && ro_M >= 0), "%s: bad read-only lookup", who);
@@ -363,8 +363,12 @@ static int gather_train_impl(const char* who, const fr_table* ta, const fr_table
     }
         if (kpt == 2) {
             FR_DISPATCH_E(ta->dim, FR_LOOKUP_LAUNCH(2));
-        } else {
+        } else if (kpt == 4) {
+            FR_DISPATCH_E(ta->dim, FR_LOOKUP_LAUNCH(4));
+        } else if (kpt == 8) {
             FR_DISPATCH_E(ta->dim, FR_LOOKUP_LAUNCH(8));
+        } else {
+            FR_DISPATCH_E(ta->dim, FR_LOOKUP_LAUNCH(16));
         }
 #undef FR_LOOKUP_LAUNCH
         FR_CHECK_LAUNCH();

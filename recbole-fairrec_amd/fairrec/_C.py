@@ -220,7 +220,8 @@ _PROTOS = {
     "fr_softmax_ce": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p,
                               c_void_p]),
     "fr_spmm_csr": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p]),
-    "fr_spmm_csr_sel": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int32, c_void_p, c_void_p]),
+    "fr_spmm_csr_sel": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int32, c_void_p,
+                                c_void_p]),
     "fr_row_gather": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int32, c_void_p, c_void_p, c_void_p]),
     "fr_row_scatter_workspace_bytes": (c_size_t, [c_int64]),
     "fr_row_scatter_sum": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int32, c_void_p, c_void_p, c_size_t, c_void_p,

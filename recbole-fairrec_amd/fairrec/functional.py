@@ -294,26 +294,29 @@ class SpMMSel(torch.autograd.Function):
     ones SpMM adds as exact zeros, so values and gradients are those of the whole-table product restricted to the rows."""
 
     @staticmethod
-    def forward(ctx, X, L: CsrMatrix, rows, rpos, xrows, xmap):
+    def forward(ctx, X, L: CsrMatrix, rows, rpos, xrows, xmap, rbits=None, xbits=None):
+        """`rbits` / `xbits`: the bitmaps of `rpos` / `xmap` (bit c set where the map is >= 0; fr_spmm_csr_sel)."""
         X = X.contiguous()
         n_out = L.shape[0] if rows is None else rows.numel()
         Y = torch.empty((n_out, X.shape[1]), dtype=torch.float32, device=X.device)
         ip, col, val = L.fwd
         _C.check(_C.lib().fr_spmm_csr_sel(ip.data_ptr(), col.data_ptr(), val.data_ptr(), X.data_ptr(), _C.ptr(rows), n_out,
-                                          _C.ptr(xmap), X.shape[1], Y.data_ptr(), _C.current_stream()), "fr_spmm_csr_sel")
-        ctx.L, ctx.sel, ctx.n_x = L, (rows, rpos, xrows, xmap), X.shape[0]
+                                          _C.ptr(xmap), _C.ptr(xbits), X.shape[1], Y.data_ptr(), _C.current_stream()),
+                 "fr_spmm_csr_sel")
+        ctx.L, ctx.sel, ctx.n_x = L, (rows, rpos, xrows, xmap, rbits), X.shape[0]
         return Y
 
     @staticmethod
     def backward(ctx, dY):
         L = ctx.L
-        rows, rpos, xrows, xmap = ctx.sel
+        rows, rpos, xrows, xmap, rbits = ctx.sel
         dY = dY.contiguous()
         dX = torch.empty((ctx.n_x, dY.shape[1]), dtype=torch.float32, device=dY.device)
         ip, col, val = L.bwd
         _C.check(_C.lib().fr_spmm_csr_sel(ip.data_ptr(), col.data_ptr(), val.data_ptr(), dY.data_ptr(), _C.ptr(xrows), ctx.n_x,
-                                          _C.ptr(rpos), dY.shape[1], dX.data_ptr(), _C.current_stream()), "fr_spmm_csr_sel")
-        return dX, None, None, None, None, None
+                                          _C.ptr(rpos), _C.ptr(rbits), dY.shape[1], dX.data_ptr(), _C.current_stream()),
+                 "fr_spmm_csr_sel")
+        return dX, None, None, None, None, None, None, None
 
 
 class GatherAndSpMMSel(torch.autograd.Function):
@@ -324,7 +327,7 @@ class GatherAndSpMMSel(torch.autograd.Function):
     addends per element: the same bits."""
 
     @staticmethod
-    def forward(ctx, X, idx, err_flag, L: CsrMatrix, rows, rpos):
+    def forward(ctx, X, idx, err_flag, L: CsrMatrix, rows, rpos, rbits=None):
         X = X.contiguous()
         idx = idx.contiguous().to(torch.int64)
         M, (N, D) = idx.numel(), X.shape
@@ -334,15 +337,15 @@ class GatherAndSpMMSel(torch.autograd.Function):
         Y = torch.empty((rows.numel(), D), dtype=torch.float32, device=X.device)
         ip, col, val = L.fwd
         _C.check(_C.lib().fr_spmm_csr_sel(ip.data_ptr(), col.data_ptr(), val.data_ptr(), X.data_ptr(), rows.data_ptr(),
-                                          rows.numel(), None, D, Y.data_ptr(), _C.current_stream()), "fr_spmm_csr_sel")
+                                          rows.numel(), None, None, D, Y.data_ptr(), _C.current_stream()), "fr_spmm_csr_sel")
         ctx.save_for_backward(idx)
-        ctx.meta = (N, D, err_flag, L, rpos)
+        ctx.meta = (N, D, err_flag, L, rpos, rbits)
         return out, Y
 
     @staticmethod
     def backward(ctx, g_rows, dY):
         (idx,) = ctx.saved_tensors
-        N, D, err, L, rpos = ctx.meta
+        N, D, err, L, rpos, rbits = ctx.meta
         dX = torch.empty((N, D), dtype=torch.float32, device=idx.device)
         ip, col, val = L.bwd
         if dY is None:
@@ -350,14 +353,15 @@ class GatherAndSpMMSel(torch.autograd.Function):
         else:
             dY = dY.contiguous()
             _C.check(_C.lib().fr_spmm_csr_sel(ip.data_ptr(), col.data_ptr(), val.data_ptr(), dY.data_ptr(), None, N,
-                                              rpos.data_ptr(), D, dX.data_ptr(), _C.current_stream()), "fr_spmm_csr_sel")
+                                              rpos.data_ptr(), _C.ptr(rbits), D, dX.data_ptr(), _C.current_stream()),
+                     "fr_spmm_csr_sel")
         if g_rows is not None:
             g_rows = g_rows.contiguous()
             M = idx.numel()
             ws = _ws(_C.lib().fr_row_scatter_workspace_bytes(M), dX.device)
             _C.check(_C.lib().fr_row_scatter_add(g_rows.data_ptr(), idx.data_ptr(), M, N, D, dX.data_ptr(), ws.data_ptr(),
                                                  ws.numel(), _C.ptr(err), _C.current_stream()), "fr_row_scatter_add")
-        return dX, None, None, None, None, None
+        return dX, None, None, None, None, None, None
 
 
 class RowGather(torch.autograd.Function):

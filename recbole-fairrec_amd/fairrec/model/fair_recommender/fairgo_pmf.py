@@ -213,7 +213,11 @@ class FairGo_PMF(FairRecommender):
         ip, col, _ = L.fwd
         N = L.shape[0]
         dev = ip.device
-        base = torch.unique(user.to(dev, torch.int64))
+        # (distinct sorted ids through a flag per graph row and `nonzero`, not through torch.unique: a sort of the 5.7 M
+        # neighbour ids of a BASELINE configs[3] batch costs several ms per step, marking 11 M flags a fraction of one)
+        flags = torch.zeros(N, dtype=torch.bool, device=dev)
+        flags[user.to(dev, torch.int64)] = True
+        base = flags.nonzero().squeeze(1)
         sets, cur = [], base
         for l in range(self.n_layers, 0, -1):
             sets.append(cur)
@@ -225,14 +229,19 @@ class FairGo_PMF(FairRecommender):
                     return None
                 start = torch.repeat_interleave(lo - (torch.cumsum(deg, 0) - deg), deg)
                 nb = col[start + torch.arange(tot, device=dev)].to(torch.int64)
-                cur = torch.unique(torch.cat([base, nb]))
+                flags[nb] = True            # (the batch's users stay marked: S_(l-1) includes S_n)
+                cur = flags.nonzero().squeeze(1)
                 if cur.numel() > self.FRONTIER_MAX_SHARE * N:
                     return None
         out = []
         for rows in reversed(sets):                      # S_1 first
             pos = torch.full((N,), -1, dtype=torch.int32, device=dev)
             pos[rows] = torch.arange(rows.numel(), dtype=torch.int32, device=dev)
-            out.append((rows.to(torch.int32), pos))
+            # bit c of the bitmap = (pos[c] >= 0): what the product kernels test before they touch the 4-byte map (the rows
+            # are distinct, so the words are plain sums of distinct powers of two)
+            bits = torch.zeros((N + 31) // 32, dtype=torch.int32, device=dev)
+            bits.index_add_(0, rows >> 5, (torch.ones_like(rows) << (rows & 31)).to(torch.int32))
+            out.append((rows.to(torch.int32), pos, bits))
         return out
 
     def _propagate_rows(self, E, user, fr=None, H1=None):
@@ -242,10 +251,10 @@ class FairGo_PMF(FairRecommender):
         if fr is None:
             return None
         eng = self.hip_engine()
-        H, prev, rows_out = E, (None, None), []
-        for l, (rows, pos) in enumerate(fr):
-            H = H1 if (l == 0 and H1 is not None) else SpMMSel.apply(H, self._L, rows, pos, prev[0], prev[1])
-            prev = (rows, pos)
+        H, prev, rows_out = E, (None, None, None), []
+        for l, (rows, pos, bits) in enumerate(fr):
+            H = H1 if (l == 0 and H1 is not None) else SpMMSel.apply(H, self._L, rows, pos, prev[0], prev[1], bits, prev[2])
+            prev = (rows, pos, bits)
             rows_out.append(RowGather.apply(H, pos[user].to(torch.int64), eng.err_flag))
         return rows_out
 
@@ -358,7 +367,7 @@ class FairGo_PMF(FairRecommender):
         if fr is not None:
             # the filtered table's two uses -- the batch's rows and the first propagation layer -- as ONE autograd node, so
             # that dLoss/dE is written once (functional.GatherAndSpMMSel) instead of zero-filled, scattered into and added
-            rows, H1 = GatherAndSpMMSel.apply(E, idx, eng.err_flag, self._L, fr[0][0], fr[0][1])
+            rows, H1 = GatherAndSpMMSel.apply(E, idx, eng.err_flag, self._L, fr[0][0], fr[0][1], fr[0][2])
             frontier = (fr, H1)
         else:
             rows, frontier = RowGather.apply(E, idx, eng.err_flag), None

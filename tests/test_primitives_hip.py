@@ -173,3 +173,76 @@ def test_workspace_of_a_dropped_table_is_not_recycled_under_its_sort():
         y = torch.full((4096,), 3, dtype=torch.int64, device=dev)    # ... and the freed id list
         torch.cuda.synchronize()
         assert bool((x == 7).all()) and bool((y == 3).all()), "trial %d: memory recycled under the side-stream sort" % trial
+
+
+@pytest.mark.parametrize("M,D,captured", [(700, 64, False), (8192, 256, False), (3000, 128, True), (12000, 64, False)],
+                         ids=["m700_d64", "m8192_d256", "m3000_d128_captured", "m12000_d64"])
+def test_lookup_pair_in_one_launch_equals_the_separate_calls(M, D, captured):
+    """fr_table_lookup_pair (the id sort as the first workgroup of the launch, the training gather and a frozen table's read-only
+    gather behind it) against fr_table_gather_train + fr_table_gather on twin tables that were aged the same way: gathered
+    rows, the side copies of the moments, the sorted segments, and the tables after the step's apply_grad, all bit for bit.
+    The captured case replays the launch inside a hipGraph (where the separate form sorts in line)."""
+    import ctypes
+    from fairrec import _C
+    from fairrec.optim import AdamHyper, LazyTable
+    n_a, n_b = 5000, 900
+    g = torch.Generator().manual_seed(M + D)
+    hyper = AdamHyper(lr=1e-2, weight_decay=1e-3, device="cuda")
+    tabs = []
+    for twin in range(2):
+        torch.manual_seed(3)
+        ro = LazyTable(torch.randn(n_a, D, device="cuda") * 0.1, trainable=False)
+        tr = LazyTable(torch.randn(n_b, D, device="cuda") * 0.1)
+        ro.ensure_state()
+        tr.ensure_state()
+        tabs.append((ro, tr))
+    err = torch.zeros(1, dtype=torch.int32, device="cuda")
+    for step in range(3):
+        ia = torch.randint(0, n_a, (M,), generator=g).cuda()
+        ib = torch.randint(0, n_b, (M,), generator=g).cuda()
+        grad = torch.randn(M, D, generator=g).cuda() * 1e-2
+        outs = []
+        for twin, (ro, tr) in enumerate(tabs):
+            if twin == 0:
+                if captured and step == 2:
+                    torch.cuda.synchronize()
+                    gr = torch.cuda.CUDAGraph()
+                    s = torch.cuda.Stream()
+                    s.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(s):
+                        tr.gather_train_with(hyper, ib, ro, hyper, ia, err)        # warm-up on the capture stream
+                        tr._pending = None
+                    torch.cuda.current_stream().wait_stream(s)
+                    with torch.cuda.graph(gr):
+                        rows, ro_rows = tr.gather_train_with(hyper, ib, ro, hyper, ia, err)
+                    rows.zero_()
+                    gr.replay()
+                else:
+                    rows, ro_rows = tr.gather_train_with(hyper, ib, ro, hyper, ia, err)
+            else:
+                rows = tr.gather_train(hyper, ib, err)
+                ro_rows = ro.gather(hyper, ia, err)
+            torch.cuda.synchronize()
+            nseg_bytes = _C.lib().fr_table_segments_bytes(M)
+            _C.check(_C.lib().fr_table_join(tr._ws.data_ptr(), _C.current_stream()), "join")
+            torch.cuda.synchronize()
+            outs.append((rows.clone(), ro_rows.clone(), tr._ws[:nseg_bytes + 2 * M * D * 4].clone()))
+            tr.apply_grad(hyper, grad, sweep_period=4)
+        for a, b in zip(outs[0][:2], outs[1][:2]):
+            assert torch.equal(a, b)
+        wa, wb = outs[0][2], outs[1][2]
+        seg = _C.lib().fr_table_segments_bytes(M)
+        # perm / seg_start / seg_row / nseg: the segments' prefix is defined up to nseg entries; compare what both wrote
+        nseg_off = 3 * (((M + 1) * 4 + 255) // 256 * 256)
+        nseg = int(wa[nseg_off:nseg_off + 4].view(torch.int32).item())
+        assert nseg == int(wb[nseg_off:nseg_off + 4].view(torch.int32).item())
+        blk = ((M + 1) * 4 + 255) // 256 * 256
+        assert torch.equal(wa[:M * 4], wb[:M * 4])                                            # perm
+        assert torch.equal(wa[blk:blk + (nseg + 1) * 4], wb[blk:blk + (nseg + 1) * 4])        # seg_start
+        assert torch.equal(wa[2 * blk:2 * blk + nseg * 4], wb[2 * blk:2 * blk + nseg * 4])    # seg_row
+        assert torch.equal(wa[seg:], wb[seg:])                                                # m_side | v_side
+    for (roa, tra), (rob, trb) in [tabs]:
+        tra.flush(hyper)
+        trb.flush(hyper)
+        assert torch.equal(tra.weight, trb.weight) and torch.equal(tra.m, trb.m) and torch.equal(tra.v, trb.v)
+    assert int(err.item()) == 0
