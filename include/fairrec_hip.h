@@ -43,6 +43,7 @@ extern "C" {
 #define FR_DEV_ERR_SST_GROUPS 2u    /* >2 distinct sensitive values in one batch (reference: IndexError at focf.py:86) */
 
 #define FR_DEV_ERR_BUCKET_OVERFLOW 4u /* a per-owner exchange bucket exceeded its fixed capacity (raise shard_capacity) */
+#define FR_DEV_ERR_PIPE_WAIT 8u     /* fr_focf_step_runs_pipe: a row of the previous batch was not published within the wait bound */
 
 /* FOCF fairness objectives -- FOCF.get_loss_fun, focf.py:50-68 */
 enum fr_focf_objective {
@@ -240,6 +241,17 @@ FR_API int fr_focf_step_runs(const fr_table* U, const fr_table* I, const fr_adam
                              const int64_t* item, const float* rating, const float* sst, int64_t B, int32_t objective,
                              float fair_weight, int32_t sweep_period, int32_t stamp, void* ws, size_t ws_bytes, void* prev_ws,
                              int64_t prev_B, float* prev_loss_out, float* loss_acc, uint32_t* err_flag, void* stream);
+/* The same step with the two launches of CONSECUTIVE steps side by side (csrc/focf_runs.hip): one launch = the item runs of
+ * the batch the previous call gathered (`fin_ws`, `fin_B`, applied at `fin_step`; NULL: none) + the gather of this call's batch
+ * (`user` == NULL: none -- the call that drains the pipeline) + this step's sweep slice + the loss reduction of the batch
+ * the previous call finished (`prev_ws`).  A row that both batches hold is taken by the gather only after the finisher has
+ * published it.  `own_u` / `own_i`: int32 [2 * n_rows] each, zero-initialised (and zeroed again when the tables' steps are
+ * rewound).  Same results as fr_focf_step_runs; U / I carry the step of the batch being gathered (fin_step if there is none). */
+FR_API int fr_focf_step_runs_pipe(const fr_table* U, const fr_table* I, const fr_adam* adam, const int64_t* user,
+                                  const int64_t* item, const float* rating, const float* sst, int64_t B, int32_t objective,
+                                  float fair_weight, int32_t sweep_period, int32_t stamp, void* ws, size_t ws_bytes, void* fin_ws,
+                                  int64_t fin_B, int32_t fin_step, void* prev_ws, int64_t prev_B, float* prev_loss_out,
+                                  float* loss_acc, int32_t* own_u, int32_t* own_i, uint32_t* err_flag, void* stream);
 
 /*
  * The same step with the index work of the COMING batches riding in the step launches themselves, instead of a look-ahead

@@ -40,6 +40,7 @@
 #include "table.hpp"
 #include "focf_ws.hpp"
 #include "focf_loss.hpp"
+#include "focf_gather.hpp"
 
 namespace fr {
 
@@ -75,6 +76,8 @@ struct RunArgs {
     long long sweep_wave0, n_sweep_waves;     // this launch's share of the sweep slice: waves [wave0, wave0 + n)
     uint32_t* err;
     PrevLoss prev;
+    int publish;      // pipelined form: the next batch's gather runs beside this finisher -- rows are stored write-through and
+                      // `last` only after they have drained (see PipeWait, focf_gather.hpp)
 };
 
 namespace {
@@ -99,6 +102,7 @@ __device__ __forceinline__ int4 ld4(const int4* p, long long i) {
 __device__ __forceinline__ float ld1(const float* p) { return __hip_atomic_load(G(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st1(float* p, float v) { __hip_atomic_store(G(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void st1i(int32_t* p, int v) { __hip_atomic_store(G(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 template <int E>
 __device__ __forceinline__ void load_row1(RowFrag<E>& f, const float* base, int D, int lane) {      // write-through data
@@ -179,10 +183,10 @@ __device__ __forceinline__ T args_through_vgprs(int lane) {
 // caught-up rows -- and every member's copy of the item's caught-up row holds the same bits (the run's first one is read).
 // So ONE level of loads serves the whole run: a dependent round trip costs ~3 us in this launch, and the first version of this
 // function (positions -> records -> rows, four members at a time) was a chain of six (profiles/r04_runs_finish_wave_trace.txt).
-template <int E>
+template <int E, int MB = (E == 1 ? FR_RUN_MB1 : 4)>
 __device__ __forceinline__ void run_finish_item(const RunArgs& a, int k, int ij0, int n, int ir, float* pu_s, float* coef_s,
                                                 float* sh, int lane, int wv) {
-    constexpr int CAP = run_cap(E), MB = E == 1 ? FR_RUN_MB1 : 4;      // parked user rows in flight per wave (x 3 row fragments)
+    constexpr int CAP = run_cap(E);      // MB = parked user rows in flight per wave (x 3 row fragments)
     const FocfWs& w = a.w;
     const int D = a.U.D, step = a.U.step;
     const bool per_item = a.objective >= FR_FOCF_VALUE && a.objective <= FR_FOCF_OVER;
@@ -289,6 +293,7 @@ __device__ __forceinline__ void run_finish_item(const RunArgs& a, int k, int ij0
             if (lmulti) lold = __hip_atomic_fetch_add(G(w.cnt_u) + lrc.z, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         const bool llast = lmulti && (int)lold + 1 == lnu;
+        unsigned long long done_mask = 0ull;      // (publish) members whose user row this wave wrote in this pass
         // (b) the members of this pass, MB at a time
 #if FR_RUN_DIAG == 1
         for (int t0 = 0; t0 < 0; t0 += MB) {
@@ -361,12 +366,23 @@ __device__ __forceinline__ void run_finish_item(const RunArgs& a, int k, int ij0
                 if (finish) {
 #pragma unroll
                     for (int e = 0; e < E; ++e) adam_elem(pu[u].x[e], mu[u].x[e], vu[u].x[e], g.x[e], sc.x, sc.y, a.c);
-                    gstore_row<E>(pu[u], a.U.p + (size_t)ur * D, D, lane);
-                    gstore_row<E>(mu[u], a.U.m + (size_t)ur * D, D, lane);
-                    gstore_row<E>(vu[u], a.U.v + (size_t)ur * D, D, lane);
-                    if (lane == 0) G(a.U.last)[ur] = step;
+                    if (a.publish) {
+                        store_row1<E>(pu[u], a.U.p + (size_t)ur * D, D, lane);
+                        store_row1<E>(mu[u], a.U.m + (size_t)ur * D, D, lane);
+                        store_row1<E>(vu[u], a.U.v + (size_t)ur * D, D, lane);
+                        done_mask |= 1ull << t;
+                    } else {
+                        gstore_row<E>(pu[u], a.U.p + (size_t)ur * D, D, lane);
+                        gstore_row<E>(mu[u], a.U.m + (size_t)ur * D, D, lane);
+                        gstore_row<E>(vu[u], a.U.v + (size_t)ur * D, D, lane);
+                        if (lane == 0) G(a.U.last)[ur] = step;
+                    }
                 }
             }
+        }
+        if (a.publish && done_mask) {      // this pass's rows have landed device-wide: now their `last`, lane t for member t
+            drain();
+            if ((done_mask >> lane) & 1ull) st1i(a.U.last + lrc.x, step);
         }
         RUN_STAMP(4);
         __syncthreads();
@@ -416,10 +432,18 @@ __device__ __forceinline__ void run_finish_item(const RunArgs& a, int k, int ij0
     if (wv == 0) {
 #pragma unroll
         for (int e = 0; e < E; ++e) adam_elem(pi.x[e], mi.x[e], vi.x[e], gi.x[e], sc.x, sc.y, a.c);
-        gstore_row<E>(pi, a.I.p + (size_t)ir * D, D, lane);
-        gstore_row<E>(mi, a.I.m + (size_t)ir * D, D, lane);
-        gstore_row<E>(vi, a.I.v + (size_t)ir * D, D, lane);
-        if (lane == 0) G(a.I.last)[ir] = step;
+        if (a.publish) {
+            store_row1<E>(pi, a.I.p + (size_t)ir * D, D, lane);
+            store_row1<E>(mi, a.I.m + (size_t)ir * D, D, lane);
+            store_row1<E>(vi, a.I.v + (size_t)ir * D, D, lane);
+            drain();
+            if (lane == 0) st1i(a.I.last + ir, step);
+        } else {
+            gstore_row<E>(pi, a.I.p + (size_t)ir * D, D, lane);
+            gstore_row<E>(mi, a.I.m + (size_t)ir * D, D, lane);
+            gstore_row<E>(vi, a.I.v + (size_t)ir * D, D, lane);
+            if (lane == 0) G(a.I.last)[ir] = step;
+        }
     }
     RUN_STAMP(7);
 }
@@ -457,9 +481,206 @@ __global__ __launch_bounds__(RUN_THREADS) void focf_runs_finish_kernel(RunArgs a
     }
 }
 
+// ---- the two launches of consecutive steps side by side ---------------------------------------------------------------------
+// Launch k of the pipelined form = the finisher of batch k - 1 (first in the grid) + the gather of batch k + the sweep slice of
+// step k.  The two chains that follow each other inside a step (gather ~22 us, item runs ~25 us) run beside each other here;
+// what ties them -- a row that both batches hold -- goes through PipeWait (focf_gather.hpp).
+#ifndef FR_PIPE_MB
+#define FR_PIPE_MB 4      // (the finisher's rows in flight per wave here: fewer registers, so that three workgroups fit a CU)
+#endif
+struct PipeArgs {
+    RunArgs fin;              // FIRST member: the finisher role takes it through VGPRs from offset 0.  fin.B == 0: nothing to finish
+    TableV U, I;              // the batch being gathered (B == 0: none): tables at ITS step
+    AdamC c;
+    const int64_t *user, *item;
+    const float* rating;
+    int B, upto;
+    FocfWs w;
+    SortedPark sp;
+    PipeWait pw;
+    uint32_t* err;
+    int n_fin_blocks, n_gather_blocks, n_sweep_blocks, n_sweep_front;      // item-run / gather / sweeper workgroups (of these: in front)
+    SweepSlice sw;
+    long long n_sweep_waves;
+};
+
+#ifndef FR_PIPE_PRIO
+#define FR_PIPE_PRIO 1    // item-run waves issue ahead of gather waves ahead of sweeper waves: the item runs end at 25 us as in a
+#endif                    // launch of their own instead of at 33 (role spans, -DFR_PIPE_TRACE: scratch/pipe_trace.py)
+#ifndef FR_PIPE_WPE
+#define FR_PIPE_WPE 8     // waves per SIMD the allocator aims at (64 registers, six spilled in the finisher's rare path): the
+#endif                    // launch lives on how many gather waves wait for their rows at once -- 16 per CU at the 91 registers
+                          // the compiler takes when left alone, 32 here
+#ifdef FR_PIPE_TRACE      // diagnostic build: first start / last end of every role's waves (100 MHz clock), of the LAST launch
+__device__ unsigned long long pipe_dbg[8 * 8];      // a ring of eight launches (slot = step & 7); launch n clears slot n + 4
+struct PipeSpan {
+    int role, slot;
+    __device__ PipeSpan(int r, int step) : role(r), slot(step & 7) {
+        if (r == 0 && threadIdx.x < 8) pipe_dbg[((step + 4) & 7) * 8 + threadIdx.x] = (threadIdx.x & 1) ? 0ull : ~0ull;
+        if (threadIdx.x == 0 && (blockIdx.x & 15) == 0) atomicMin(&pipe_dbg[slot * 8 + 2 * role], __builtin_amdgcn_s_memrealtime());
+    }
+    __device__ ~PipeSpan() {
+        if ((threadIdx.x & 63) == 0 && (blockIdx.x & 15) == 0) atomicMax(&pipe_dbg[slot * 8 + 2 * role + 1], __builtin_amdgcn_s_memrealtime());
+    }
+};
+#define PIPE_SPAN(r) PipeSpan span_(r, p.upto)
+#else
+#define PIPE_SPAN(r) do {} while (0)
+#endif
+
+template <int E>
+__global__ __launch_bounds__(RUN_THREADS) __attribute__((amdgpu_waves_per_eu(FR_PIPE_WPE, FR_PIPE_WPE))) void focf_runs_pipe_kernel(PipeArgs p) {
+    constexpr int CAP = run_cap(E);
+    __shared__ __align__(16) float lds_rows[CAP * 64 * E];
+    __shared__ float coef_s[CAP];
+    __shared__ float sh[4];
+    __shared__ GatherLds<E, RUN_WAVES> glds;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int blk = (int)blockIdx.x;
+    // Grid order = start order: the loss, then the SWEEPER (its tasks are the longest single chains of the launch -- a pair of rows
+    // replays up to two sweep periods, 13 us median, 26 us at worst -- and behind the gathers they started 13 us late and ended
+    // the launch at 40 us), then the previous batch's item runs, then this batch's gathers (which wait for nobody but those).
+    if (blk == 0) {
+        PIPE_SPAN(0);
+        const RunArgs a = args_through_vgprs<RunArgs>(lane);
+        if (a.prev.loss_out && threadIdx.x < 256) step_reduce_loss<256>(a.prev);
+        return;
+    }
+    blk -= 1;
+    if (blk < p.n_sweep_front) {         // the head of the sweeper's start order: its longest tasks
+        PIPE_SPAN(1);
+        const long long wave = (long long)blk * RUN_WAVES + wv;
+        if (wave < p.n_sweep_waves) sweep_slice_wave<E>(p.U, p.I, p.c, p.sw, wave, lane);
+        return;
+    }
+    blk -= p.n_sweep_front;
+    if (blk < p.n_fin_blocks) {          // the previous batch: focf_runs_finish_kernel's item-run workgroups
+        PIPE_SPAN(2);
+#if FR_PIPE_PRIO
+        __builtin_amdgcn_s_setprio(3);
+#endif
+        const RunArgs a = args_through_vgprs<RunArgs>(lane);
+        for (int k = blk; k < a.B; k += a.n_item_blocks) {
+            const int rK = G(a.w.nseg_i)[0], rj0 = G(a.w.seg_start_i)[k], rj1 = G(a.w.seg_start_i)[k + 1];
+            const int rir = G(a.w.seg_row_i)[k];
+            if (k >= uniform(rK)) break;
+            const int j0 = uniform(rj0);
+            run_finish_item<E, FR_PIPE_MB>(a, k, j0, uniform(rj1) - j0, uniform(rir), lds_rows, coef_s, sh, lane, wv);
+            __syncthreads();
+        }
+        return;
+    }
+    blk -= p.n_fin_blocks;
+    if (blk < p.n_gather_blocks) {       // this batch's gather: one interaction per wave
+        PIPE_SPAN(3);
+#if FR_PIPE_PRIO
+        __builtin_amdgcn_s_setprio(2);
+#endif
+        if (blk == 0 && threadIdx.x == 0) *p.w.defer = DeferLoss{nullptr, 0, 0.f, 0};
+        focf_gather_body<E, true, true, true, true, RUN_WAVES>(p.U, p.I, p.c, p.user, p.item, p.rating, p.B, p.upto, p.upto, p.w, 0.f,
+                                                               nullptr, p.err, blk, glds, p.sp, p.pw);
+        return;
+    }
+    blk -= p.n_gather_blocks;            // the tail of the sweeper's start order: short tasks, into the slots the gathers leave
+    {
+        PIPE_SPAN(1);
+        const long long wave = (long long)(p.n_sweep_front + blk) * RUN_WAVES + wv;
+        if (wave < p.n_sweep_waves) sweep_slice_wave<E>(p.U, p.I, p.c, p.sw, wave, lane);
+    }
+}
+
 }  // namespace fr
 
 using namespace fr;
+
+#ifdef FR_PIPE_TRACE
+extern "C" __attribute__((visibility("default"))) int fr_debug_pipe_trace(unsigned long long* out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(pipe_dbg), sizeof(unsigned long long) * 64) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long init[64];
+        for (int i = 0; i < 64; ++i) init[i] = (i & 1) ? 0ull : ~0ull;
+        if (hipMemcpyToSymbol(HIP_SYMBOL(pipe_dbg), init, sizeof(init)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
+
+// The pipelined form of fr_focf_step_runs: ONE launch = the finisher of the batch gathered by the previous call (`fin_ws`,
+// `fin_B`, applied at `fin_step`; NULL: none) + the gather of this call's batch (`user` NULL / B == 0: none -- the call that
+// drains the pipeline) + this step's sweep slice + the loss of the batch finished by the previous call (`prev_ws`).  `own`:
+// int32 [2][n_users] and [2][n_items], zeroed by the caller when the tables' steps are rewound; parity of the step selects
+// the half a gather writes.  U / I carry the step of the batch being gathered (or fin_step when there is none).
+extern "C" int fr_focf_step_runs_pipe(const fr_table* U, const fr_table* I, const fr_adam* adam, const int64_t* user,
+                                      const int64_t* item, const float* rating, const float* sst, int64_t B, int32_t objective,
+                                      float fair_weight, int32_t sweep_period, int32_t stamp, void* ws, size_t ws_bytes,
+                                      void* fin_ws, int64_t fin_B, int32_t fin_step, void* prev_ws, int64_t prev_B,
+                                      float* prev_loss_out, float* loss_acc, int32_t* own_u, int32_t* own_i, uint32_t* err_flag,
+                                      void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    int rc;
+    if ((rc = check_table(U, "fr_focf_step_runs_pipe(U)")) || (rc = check_table(I, "fr_focf_step_runs_pipe(I)")) ||
+        (rc = check_adam(adam, "fr_focf_step_runs_pipe")))
+        return rc;
+    const bool gather = user != nullptr && B > 0, finish = fin_ws != nullptr && fin_B > 0;
+    FR_CHECK_ARG(U->dim == I->dim && U->step >= 1 && U->step == I->step && !U->step_dev && !I->step_dev,
+                 "fr_focf_step_runs_pipe: tables of one width at one host-side step");
+    FR_CHECK_ARG(objective >= FR_FOCF_NONE && objective <= FR_FOCF_OVER, "fr_focf_step_runs_pipe: objective %d", objective);
+    FR_CHECK_ARG(!gather || (item && rating && ws && own_u && own_i && B <= FR_SORT_MAX && (objective == FR_FOCF_NONE || sst)),
+                 "fr_focf_step_runs_pipe: bad batch");
+    FR_CHECK_ARG(!finish || (fin_step >= 1 && fin_B <= FR_SORT_MAX && (!gather || fin_step == U->step - 1)),
+                 "fr_focf_step_runs_pipe: the batch to finish must be the previous step's");
+    PipeArgs p{};
+    p.c = make_adamc(adam);
+    p.err = err_flag;
+    // -- the finisher's side
+    RunArgs& a = p.fin;
+    a.c = p.c;
+    a.objective = objective;
+    a.fair_weight = fair_weight;
+    a.err = err_flag;
+    a.publish = gather ? 1 : 0;
+    fr_table Uf = *U, If = *I;
+    if (finish) {
+        Uf.step = If.step = fin_step;
+        a.w = focf_layout(fin_ws, fin_B, U->dim);
+        a.B = (int)fin_B;
+        a.n_item_blocks = (int)std::min<long long>(FR_RUN_ITEM_BLOCKS, fin_B);
+    }
+    a.U = view(&Uf);
+    a.I = view(&If);
+    a.prev = prev_of(prev_ws, prev_B, U->dim, objective, fair_weight, prev_loss_out, loss_acc, false);
+    p.n_fin_blocks = a.n_item_blocks;
+    // -- the gather's side
+    if (gather) {
+        p.w = focf_layout(ws, B, U->dim);
+        FR_CHECK_ARG(ws_bytes >= p.w.bytes, "fr_focf_step_runs_pipe: workspace %zu < %zu bytes", ws_bytes, p.w.bytes);
+        p.U = view(U);
+        p.I = view(I);
+        p.user = user;
+        p.item = item;
+        p.rating = rating;
+        p.B = (int)B;
+        p.upto = U->step - 1;
+        p.sp = SortedPark{p.w.pos_i, p.w.info, sst, p.w.task_rec, p.w.task_info, p.w.mse_e};
+        const int cur = U->step & 1, prv = cur ^ 1;
+        p.pw = PipeWait{own_u + (size_t)prv * U->n_rows, own_i + (size_t)prv * I->n_rows, own_u + (size_t)cur * U->n_rows,
+                        own_i + (size_t)cur * I->n_rows, finish ? fin_step : -1};
+        p.n_gather_blocks = (int)((B + RUN_WAVES - 1) / RUN_WAVES);
+        if (sweep_period > 0) {
+            p.sw = make_sweep_slice(U, I, sweep_period);
+            p.sw.skip_from = finish ? std::min(stamp, fin_step) : stamp;      // the finisher's rows are not the sweeper's either
+            p.n_sweep_waves = sweep_slice_waves(p.sw);
+        }
+    }
+    p.n_sweep_blocks = (int)((p.n_sweep_waves + RUN_WAVES - 1) / RUN_WAVES);
+    static const int front_pct = getenv("FAIRREC_PIPE_SWEEP_FRONT") ? atoi(getenv("FAIRREC_PIPE_SWEEP_FRONT")) : 100;
+    p.n_sweep_front = (int)((long long)p.n_sweep_blocks * std::min(std::max(front_pct, 0), 100) / 100);
+    const long long blocks = 1 + p.n_sweep_blocks + p.n_fin_blocks + p.n_gather_blocks;
+    ProfScope prof(K_FOCF_STEP, stream);
+    FR_DISPATCH_E(U->dim, FR_LAUNCH(prof, (focf_runs_pipe_kernel<E>), dim3((unsigned)blocks), dim3(RUN_THREADS), 0, stream, p));
+    FR_CHECK_LAUNCH();
+    return FR_OK;
+}
 
 // One optimizer step of FOCF on an item-complete batch; same contract as fr_focf_step (the batch was prepared by
 // fr_focf_prepare_step with `stamp`, table.step = the step being applied, the loss is reduced by the next launch or by

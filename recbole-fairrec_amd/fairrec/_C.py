@@ -17,6 +17,7 @@ FR_SORT_MAX = 16384
 DEV_ERR_INDEX_RANGE = 1
 DEV_ERR_SST_GROUPS = 2
 DEV_ERR_BUCKET_OVERFLOW = 4
+DEV_ERR_PIPE_WAIT = 8
 
 FOCF_OBJECTIVES = {"none": 0, "value": 1, "absolute": 2, "under": 3, "over": 4, "nonparity": 5}
 
@@ -81,6 +82,9 @@ _PROTOS = {
     "fr_focf_step_runs": (c_int, [POINTER(FrTable), POINTER(FrTable), POINTER(FrAdam), c_void_p, c_void_p, c_void_p, c_void_p,
                                   c_int64, c_int32, c_float, c_int32, c_int32, c_void_p, c_size_t, c_void_p, c_int64, c_void_p,
                                   c_void_p, c_void_p, c_void_p]),
+    "fr_focf_step_runs_pipe": (c_int, [POINTER(FrTable), POINTER(FrTable), POINTER(FrAdam), c_void_p, c_void_p, c_void_p, c_void_p,
+                                       c_int64, c_int32, c_float, c_int32, c_int32, c_void_p, c_size_t, c_void_p, c_int64, c_int32,
+                                       c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "fr_focf_step_finish": (c_int, [c_void_p, c_size_t, c_int64, c_int32, c_int32, c_float, c_void_p, c_void_p,
                                     c_void_p]),
     "fr_side_stream_handle": (c_void_p, []),

@@ -48,11 +48,15 @@ class FocfEngine:
     PER_LAUNCH = 8    # FR_FOCF_PREPARE_MAX
     LOW_WATER = int(os.environ.get("FAIRREC_FOCF_LOW_WATER", 4))  # ... launched when this few prepared batches are left, so
                       # that its join is steps old when reached
-    N_WS = GROUP + LOW_WATER + 3   # workspaces: the batch in flight + the last one (its loss) + the prepared ones + a spare
+    N_WS = GROUP + LOW_WATER + 4   # workspaces: the batch in flight + the last two (item runs pending / loss) + the prepared ones + a spare
     # fr_focf_step_staged: the index work of the two coming batches rides in the step launches themselves (no sort, no side
     # stream); FAIRREC_FOCF_STAGED=0 goes back to the look-ahead sort (fr_focf_prepare_step) for the one-launch step
     STAGED = os.environ.get("FAIRREC_FOCF_STAGED", "1") != "0"
     RUNS = os.environ.get("FAIRREC_FOCF_RUNS", "1") != "0"
+    # fr_focf_step_runs_pipe: the item runs of batch k - 1 and the gather of batch k in ONE launch (the two ~22-25 us chains of
+    # an item-complete step side by side instead of one after the other).  The tables then lag one finisher behind `step`
+    # between calls: everything that reads them goes through finish() first.
+    PIPE = os.environ.get("FAIRREC_FOCF_PIPE", "0") == "1"
 
     def __init__(self, user_weight: torch.Tensor, item_weight: torch.Tensor, objective: str, fair_weight: float,
                  max_rating: float):
@@ -92,6 +96,8 @@ class FocfEngine:
         self.fused_step = True
         self._stash = None              # batch of a fused step: launched by backward_adam()
         self._prev = None               # (workspace, B, loss view) of the last fused step, its loss not reduced yet
+        self._pipe = None               # pipelined item-run steps: (workspace, B, step, loss view, columns) gathered, item runs pending
+        self._own = None                # ... their record of which batch gathered a row last (int32 [2][n_users], [2][n_items])
         self._stamp_last = 0            # stamps handed to fr_focf_prepare_step never decrease
         self._stamp_gen = (self.U.stamp_gen, self.I.stamp_gen)
         # running (loss, mse, fair) total, [3] = steps in it, [4] = 1-based index of the first NaN step (0 = none; sticky)
@@ -104,6 +110,8 @@ class FocfEngine:
 
     # --- optimizer plumbing ---------------------------------------------------------------------------
     def tables(self) -> Dict[str, LazyTable]:
+        if self._pipe is not None:      # whoever asks for the tables reads them: the pending item runs first
+            self.finish()
         return {"user_embedding_layer.weight": self.U, "item_embedding_layer.weight": self.I}
 
     def bind_optimizer(self, opt: FusedLazyAdam, sweep_period: Optional[int]):
@@ -145,6 +153,8 @@ class FocfEngine:
         busy = {self.ws_cur} | {v[0] for v in self._prep.values()}
         if self._prev is not None:   # the last fused step's loss is reduced by the NEXT launch, from its workspace
             busy |= {k for k, w in enumerate(self.ws) if w is self._prev[0]}
+        if self._pipe is not None:   # ... and a pipelined step's item runs ride in the next launch
+            busy |= {k for k, w in enumerate(self.ws) if w is self._pipe[0]}
         arr = (_C.FrFocfBatch * len(batches))()
         stamps = (ctypes.c_int32 * len(batches))()
         group = {"done": torch.cuda.Event(), "joined": False}
@@ -226,6 +236,10 @@ class FocfEngine:
             self._stamp_gen = gen
             self._join_prepare()
             self._forget_staged()
+            self._pipe = None               # (its tables are gone with the old state)
+            if self._own is not None:
+                self._own[0].zero_()
+                self._own[1].zero_()
 
     def _join_prepare(self):
         """Order the current stream behind every sort launch still in flight, and forget what they prepared."""
@@ -349,9 +363,10 @@ class FocfEngine:
                 torch.cuda.current_stream().wait_event(group["done"])
                 group["joined"] = True
             flags = 1                                            # FR_FOCF_PREPARED
-        elif self._prev is not None and self._prev[0] is self.ws[self.ws_cur]:
-            self.ws_cur = (self.ws_cur + 1) % self.N_WS          # that workspace still holds an unreduced loss
-            while self.ws_cur in {v[0] for v in self._prep.values()}:
+        else:
+            held = [t[0] for t in (self._prev, self._pipe) if t is not None]       # an unreduced loss / pending item runs
+            taken = {v[0] for v in self._prep.values()}
+            while any(w is self.ws[self.ws_cur] for w in held) or (held and self.ws_cur in taken):
                 self.ws_cur = (self.ws_cur + 1) % self.N_WS
         if self.defer_loss and self.optimizer is not None:
             flags |= 2                                           # FR_FOCF_DEFER_LOSS
@@ -371,6 +386,8 @@ class FocfEngine:
         # item run); FAIRREC_FOCF_RUNS=0 sends them through the three-launch chain as before round 4
         fused = (self.fused_step and self.defer_loss and self.optimizer is not None and self.objective != 5 and not want_pred
                  and (not self.item_runs or (self.RUNS and rating is not None)) and self.U.step == self.I.step)
+        if self._pipe is not None and not (fused and self.item_runs and self.PIPE):
+            self.finish()                   # this step takes another path: the pending item runs first
         # A stamp is the optimizer step at which its batch is applied: the current batch (if nobody prepared it) takes its
         # stamp BEFORE the coming ones take theirs, so that stamps rise in application order -- the sweeper leaves a row to
         # its batch by comparing stamps, and the start order of a step's sweeper tasks is built for the stamped step's slice
@@ -416,6 +433,8 @@ class FocfEngine:
         embedding gradients (fr_focf_clip_grad_norm); returns the device pair (total_norm, clip_coef)."""
         if self.pending_B == 0:
             raise _C.FairrecError("clip_grad_norm without a preceding calculate_loss()")
+        if self._pipe is not None:
+            self.finish()
         if self._stash is not None:       # the norm needs every gradient row before any update: three-launch chain
             user, item, rating, sst, B, ws, _, loss = self._stash[:8]
             staged = len(self._stash) > 8
@@ -467,6 +486,29 @@ class FocfEngine:
             if self._prev is not None and self._prev[3]:
                 self.finish()
             pw, pB, ploss, _ = self._prev if self._prev is not None else (None, 0, None, False)
+            if getattr(self, "_stash_runs", False) and self.PIPE:
+                fin = self._pipe
+                own_u, own_i = self._own_arrays()
+                rc = _C.lib().fr_focf_step_runs_pipe(ctypes.byref(tu), ctypes.byref(ti), ctypes.byref(self.hyper.c()),
+                                                     user.data_ptr(), item.data_ptr(), rating.data_ptr(), _C.ptr(sst), B,
+                                                     self.objective, self.fair_weight, self._sweep(B), stamp, ws.data_ptr(),
+                                                     ws.numel(), _C.ptr(fin[0]) if fin else None, fin[1] if fin else 0,
+                                                     fin[2] if fin else 0, _C.ptr(pw), pB, _C.ptr(ploss), self.loss_acc.data_ptr(),
+                                                     own_u.data_ptr(), own_i.data_ptr(), self.err_flag.data_ptr(),
+                                                     _C.current_stream())
+                _C.check(rc, "fr_focf_step_runs_pipe")
+                self._pipe = (ws, B, self.U.step + 1, loss, (user, item, rating, sst))
+                self._prev = (fin[0], fin[1], fin[3], False) if fin else None     # finished in this launch: its loss comes next
+                self._keep = (user, item, rating, sst)
+                self.U.step += 1
+                self.I.step += 1
+                self.U._dirty = self.I._dirty = True
+                self.pending_B = 0
+                self.backward_seen = False
+                return
+            if self._pipe is not None:
+                self.finish()
+                pw, pB, ploss, _ = self._prev if self._prev is not None else (None, 0, None, False)
             if getattr(self, "_stash_runs", False):
                 rc = _C.lib().fr_focf_step_runs(ctypes.byref(tu), ctypes.byref(ti), ctypes.byref(self.hyper.c()),
                                                 user.data_ptr(), item.data_ptr(), rating.data_ptr(), _C.ptr(sst), B,
@@ -505,6 +547,18 @@ class FocfEngine:
     def finish(self):
         """Reduce the loss of the last fused step (fr_focf_step_finish): its loss slot and `loss_acc` are complete on the
         stream after this.  A later fused step would have done it in passing."""
+        if self._pipe is not None:           # the item runs of the last pipelined step (and the loss of the one before it)
+            fin, self._pipe = self._pipe, None
+            pw, pB, ploss, _ = self._prev if self._prev is not None else (None, 0, None, False)
+            own_u, own_i = self._own_arrays()
+            tu, ti = self.U.c(fin[2]), self.I.c(fin[2])
+            rc = _C.lib().fr_focf_step_runs_pipe(ctypes.byref(tu), ctypes.byref(ti), ctypes.byref(self.hyper.c()), None, None,
+                                                 None, None, 0, self.objective, self.fair_weight, 0, 0, None, 0,
+                                                 fin[0].data_ptr(), fin[1], fin[2], _C.ptr(pw), pB, _C.ptr(ploss),
+                                                 self.loss_acc.data_ptr(), own_u.data_ptr(), own_i.data_ptr(),
+                                                 self.err_flag.data_ptr(), _C.current_stream())
+            _C.check(rc, "fr_focf_step_runs_pipe")
+            self._prev = (fin[0], fin[1], fin[3], False)
         if self._prev is not None:
             ws, B, loss, staged = self._prev
             self._prev = None
@@ -513,8 +567,15 @@ class FocfEngine:
                     self.loss_acc.data_ptr(), _C.current_stream())
             _C.check(rc, "fr_focf_step_finish")
 
+    def _own_arrays(self):
+        if self._own is None:
+            self._own = (torch.zeros(2 * self.U.n_rows, dtype=torch.int32, device=self.device),
+                         torch.zeros(2 * self.I.n_rows, dtype=torch.int32, device=self.device))
+        return self._own
+
     def predict(self, user, item):
         self._join_prepare()
+        self.finish()
         B = user.numel()
         out = torch.empty(B, dtype=torch.float32, device=self.device)
         tu, ti = self.U.c(), self.I.c()
@@ -541,6 +602,9 @@ class FocfEngine:
                 msgs.append("index out of range in embedding gather")
             if e & _C.DEV_ERR_SST_GROUPS:
                 msgs.append("a batch must hold exactly the 1..2 sensitive groups the objective expects")
+            if e & _C.DEV_ERR_PIPE_WAIT:
+                raise _C.FairrecError("pipelined item-run step: a row of the previous batch was never published "
+                                      "(FAIRREC_FOCF_PIPE=0 selects the two-launch step)")
             raise IndexError("; ".join(msgs))
 
 
