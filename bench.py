@@ -107,7 +107,9 @@ def focf_shape_block(item_dist, K, W, dev, sweep):
     uniq_i = sum(int(torch.unique(i[k]).numel()) for k in range(lo, hi)) / K
     step_bytes = 8 * 2 * BATCH + 4 * 2 * BATCH + (uniq_u + uniq_i) * DIM * (4 + 8 + 12)
     gbs = step_bytes / (dt / K) / 1e9
-    kind = ("two launches per step (fr_focf_step_runs: the gather, then a workgroup per item run)" if eng.item_runs and eng.RUNS
+    kind = ("one launch per step (fr_focf_step_runs_pipe: the item runs of the previous batch beside the gather of this one)"
+            if eng.item_runs and eng.RUNS and eng.PIPE else
+            "two launches per step (fr_focf_step_runs: the gather, then a workgroup per item run)" if eng.item_runs and eng.RUNS
             else ("one launch per step (fr_focf_step_staged)" if eng.staged and not eng.item_runs else "three-launch chain"))
     graph.reset()
     del graph, eng, U, I, u, i, r, s, rows

@@ -56,7 +56,7 @@ class FocfEngine:
     # fr_focf_step_runs_pipe: the item runs of batch k - 1 and the gather of batch k in ONE launch (the two ~22-25 us chains of
     # an item-complete step side by side instead of one after the other).  The tables then lag one finisher behind `step`
     # between calls: everything that reads them goes through finish() first.
-    PIPE = os.environ.get("FAIRREC_FOCF_PIPE", "0") == "1"
+    PIPE = os.environ.get("FAIRREC_FOCF_PIPE", "1") == "1"
 
     def __init__(self, user_weight: torch.Tensor, item_weight: torch.Tensor, objective: str, fair_weight: float,
                  max_rating: float):

@@ -409,7 +409,8 @@ def test_prefetch_queue_over_epochs_matches_plain_steps():
             for eng in engs[1:]:
                 eng.forward(u, i, r, s, next_batch=queue)
                 eng.backward_adam()
-            assert engs[1]._prev is None and engs[2]._prev is not None and engs[3]._prev is not None
+            assert engs[1]._prev is None and engs[2]._prev is not None
+            assert engs[3]._prev is not None or engs[3]._pipe is not None      # (pipelined: the step's item runs are pending)
         for eng in engs:
             eng.flush()                                              # evaluation / checkpoint between epochs
             eng.check_device_errors()
@@ -624,6 +625,7 @@ def test_runs_step_matches_chain_and_is_bit_reproducible(objective, dim):
         FusedLazyAdam(eng, lr=1e-3, weight_decay=1e-3, sweep_period=4)
         eng.defer_loss = True
         eng.item_runs = True
+        eng.PIPE = False          # the two-launch form itself (the pipelined form has its own tests below)
         eng.fused_step = mode != "chain"
         for t, (u, i, r, s) in enumerate(batches):
             nxt = [(b[0], b[1], b[3], b[2]) for b in batches[t + 1:t + 4]] if mode == "runs_ahead" else None
