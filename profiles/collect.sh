@@ -26,7 +26,8 @@ cd $R
 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_steps20.json 2> $OUT/bench_steps20.err
 python3 bench.py --no-cpu-baseline --graph-only --item-dist zipf > $OUT/bench_zipf.json 2>/dev/null
-python3 bench.py --no-cpu-baseline --graph-only --item-dist grouped > $OUT/bench_grouped_runs.json 2>/dev/null
+python3 bench.py --no-cpu-baseline --graph-only --item-dist grouped > $OUT/bench_grouped_pipe.json 2>/dev/null
+FAIRREC_FOCF_PIPE=0 python3 bench.py --no-cpu-baseline --graph-only --item-dist grouped > $OUT/bench_grouped_runs.json 2>/dev/null
 FAIRREC_FOCF_RUNS=0 python3 bench.py --no-cpu-baseline --graph-only --item-dist grouped > $OUT/bench_grouped_chain.json 2>/dev/null
 python3 bench.py --no-cpu-baseline --graph-only --item-dist grouped --force-fused > $OUT/bench_grouped_fused.json 2>/dev/null
 python3 bench.py --workload pfcn10m --steps 20 --warmup 5 > $OUT/pfcn10m.json 2> $OUT/pfcn10m.err
