@@ -721,7 +721,7 @@ struct TwoRows {
 };
 
 template <int E>
-__device__ __forceinline__ void replay_two(TwoRows<E>& r, int tA, int tB, int upto, const AdamC& c, int lane) {
+__device__ __forceinline__ TwoRows<E> replay_two_v(TwoRows<E> r, int tA, int tB, int upto, const AdamC& c, int lane) {
     tA = tA < upto ? tA : upto;
     tB = tB < upto ? tB : upto;
     if (tA != tB) {     // wave-uniform
@@ -744,6 +744,12 @@ __device__ __forceinline__ void replay_two(TwoRows<E>& r, int tA, int tB, int up
         }
     }
     replay2<E>(r.pA, r.mA, r.vA, r.pB, r.mB, r.vB, tA > tB ? tA : tB, upto, c, lane);
+    return r;
+}
+// (by value in, by value out: through a reference the fragments of E >= 2 stayed in scratch memory -- 40-88 bytes per lane)
+template <int E>
+__device__ __forceinline__ void replay_two(TwoRows<E>& r, int tA, int tB, int upto, const AdamC& c, int lane) {
+    r = replay_two_v<E>(r, tA, tB, upto, c, lane);
 }
 
 // ---- rare path ----------------------------------------------------------------------------------------------------
