@@ -674,7 +674,8 @@ FR_API int fr_scorer_bwd(const fr_scorer* s, const float* dy, const float* gscal
 /* The weight gradients of several layers in two launches (every product, then every slab sum): job = fr_linear_bwd_weight's
  * (dY at the pre-activation, x0 | x1, N) -> dW [N, k0 + k1], db [N] (may be NULL), fast form only (N, k0, k0 + k1 multiples
  * of 32, 16-byte aligned; FR_EUNSUPPORTED otherwise).  A job with dY == NULL sums `n_parts` partial results
- * parts[n_parts][N * (k0 + k1)] into dW (the scorer's last layer: fr_scorer_bwd's w3part).  At most 4 jobs. */
+ * parts[n_parts][N * (k0 + k1)] into dW (the scorer's last layer: fr_scorer_bwd's w3part).  At most FR_WGRAD_MAX jobs. */
+#define FR_WGRAD_MAX 8
 typedef struct fr_wgrad_job {
     const float* dY;
     const float* x0;

@@ -630,10 +630,10 @@ extern "C" size_t fr_linear_bwd_weight_multi_workspace_bytes(const fr_wgrad_job*
 extern "C" int fr_linear_bwd_weight_multi(const fr_wgrad_job* jobs, int32_t n, int64_t M, void* ws, size_t ws_bytes,
                                           void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    FR_CHECK_ARG(jobs && n >= 1 && n <= 4 && M >= 1, "fr_linear_bwd_weight_multi: bad argument (1..4 jobs)");
+    FR_CHECK_ARG(jobs && n >= 1 && n <= FR_WGRAD_MAX && M >= 1, "fr_linear_bwd_weight_multi: bad argument (1..FR_WGRAD_MAX jobs)");
     FR_CHECK_ARG(ws_bytes >= fr_linear_bwd_weight_multi_workspace_bytes(jobs, n, M) && (ws || ws_bytes == 0),
                  "fr_linear_bwd_weight_multi: workspace too small");
-    GlWJob q[4];
+    GlWJob q[FR_WGRAD_MAX];
     char* p = (char*)ws;
     for (int j = 0; j < n; ++j) {
         const fr_wgrad_job& f = jobs[j];

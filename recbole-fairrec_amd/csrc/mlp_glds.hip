@@ -590,7 +590,7 @@ __global__ __launch_bounds__(256 * KS) void linear_glds64_kernel(GlArgs g) {
 
 // Several weight gradients of one backward pass in ONE launch (the three layers of the NFCF scorer, csrc/scorer.hip): job j
 // owns the workgroups [first[j], first[j + 1]); each is exactly linear_glds64_kernel<GL_BWD_W> on that job's arguments.
-constexpr int GL_MULTI_MAX = 4;
+constexpr int GL_MULTI_MAX = 8;
 struct GlMulti {
     GlArgs g[GL_MULTI_MAX];
     unsigned first[GL_MULTI_MAX + 1];

@@ -18,6 +18,7 @@ DEV_ERR_INDEX_RANGE = 1
 DEV_ERR_SST_GROUPS = 2
 DEV_ERR_BUCKET_OVERFLOW = 4
 DEV_ERR_PIPE_WAIT = 8
+WGRAD_MAX = 8          # FR_WGRAD_MAX
 
 FOCF_OBJECTIVES = {"none": 0, "value": 1, "absolute": 2, "under": 3, "over": 4, "nonparity": 5}
 

@@ -213,6 +213,12 @@ class _HipMLP(torch.autograd.Function):
         dx0 = dx1 = None
         drop = ctx.drop
         at_z = False          # dY already is the gradient at this layer's pre-activation (folded into the layer above)
+        # weight gradients in the fast form wait here and go out together at the end: every product in ONE launch and every
+        # slab sum in a second (fr_linear_bwd_weight_multi) instead of two launches per layer -- the same kernels' bodies on
+        # the same arguments, so the same bits
+        deferred = []
+        defer_ok = (os.environ.get("FAIRREC_LINEAR_NO_GLDS") is None and os.environ.get("FAIRREC_LINEAR_SLOW") is None
+                    and os.environ.get("FAIRREC_WGRAD_PER_LAYER") is None)
         for l in range(L - 1, -1, -1):
             W = params[per * l].contiguous()
             Y = outs[l]
@@ -268,7 +274,10 @@ class _HipMLP(torch.autograd.Function):
                                               ctx.scale if at_z else 0.0, _C.ptr(da), dW.data_ptr(), db.data_ptr(),
                                               ws.data_ptr(), ws.numel(), st), "fr_linear_n1_bwd")
             else:
-                if need_w:
+                if need_w and defer_ok and act == 0 and mk is None and scale == 1.0 and N % 32 == 0 and K % 32 == 0 and k0 % 32 == 0 \
+                        and (dY.data_ptr() | a.data_ptr() | (c.data_ptr() if c is not None else 0)) % 16 == 0:
+                    deferred.append((dY, a, k0, c, k1, N, dW, db))
+                elif need_w:
                     _C.check(lib.fr_linear_bwd_weight(dY.data_ptr(), Y.data_ptr(), act, a.data_ptr(), k0, _C.ptr(c), k1,
                                                       _C.ptr(mk), scale, M, N, dW.data_ptr(), db.data_ptr(), ws.data_ptr(),
                                                       ws.numel(), st), "fr_linear_bwd_weight")
@@ -300,6 +309,14 @@ class _HipMLP(torch.autograd.Function):
                     dY = da
                 else:
                     dx0, dx1 = (da if need0 else None), (dc if need1 else None)
+        for q in range(0, len(deferred), _C.WGRAD_MAX):
+            chunk = deferred[q:q + _C.WGRAD_MAX]
+            jobs = (_C.FrWgradJob * len(chunk))(*[
+                _C.FrWgradJob(dy.data_ptr(), a.data_ptr(), k0, _C.ptr(c), k1, N, dW.data_ptr(), db.data_ptr(), None, 0)
+                for (dy, a, k0, c, k1, N, dW, db) in chunk])
+            wsm = torch.empty(lib.fr_linear_bwd_weight_multi_workspace_bytes(jobs, len(chunk), M), dtype=torch.uint8, device=dev)
+            _C.check(lib.fr_linear_bwd_weight_multi(jobs, len(chunk), M, wsm.data_ptr(), wsm.numel(), st),
+                     "fr_linear_bwd_weight_multi")
         return (dx0, dx1, None, None, None, None, None, *grads)
 
 
