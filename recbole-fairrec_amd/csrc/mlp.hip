@@ -962,7 +962,7 @@ extern "C" size_t fr_bn_workspace_bytes(int64_t M, int32_t N) {
 static int bn_fwd_impl(const float* Z, const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
                        float* running_var, int64_t M, int32_t N, int32_t act, float* Y, float* xhat, float* invstd, void* ws,
                        size_t ws_bytes, hipStream_t stream, float* Yd, float p, uint64_t seed, uint64_t offset,
-                       const int64_t* counter, int64_t* used_out, int64_t* tick_state);
+                       const int64_t* counter, int64_t* used_out, int64_t* tick_state, bool have_stats = false);
 
 extern "C" int fr_bn_fwd(const float* Z, const float* gamma, const float* beta, float eps, float momentum,
                          float* running_mean, float* running_var, int64_t M, int32_t N, int32_t act, float* Y,
@@ -988,14 +988,16 @@ extern "C" int fr_bn_fwd_drop(const float* Z, const float* gamma, const float* b
 static int bn_fwd_impl(const float* Z, const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
                        float* running_var, int64_t M, int32_t N, int32_t act, float* Y, float* xhat, float* invstd, void* ws,
                        size_t ws_bytes, hipStream_t stream, float* Yd, float p, uint64_t seed, uint64_t offset,
-                       const int64_t* counter, int64_t* used_out, int64_t* tick_state) {
+                       const int64_t* counter, int64_t* used_out, int64_t* tick_state, bool have_stats) {
     FR_CHECK_ARG(Z && gamma && beta && Y && xhat && invstd && ws && M >= 1 && N >= 1 && act_ok(act) &&
                      ws_bytes >= fr_bn_workspace_bytes(M, N), "fr_bn_fwd: bad argument");
     const int rc = bn_chunk_rows(M);
     const dim3 grid((unsigned)((N + 63) / 64), (unsigned)((M + rc - 1) / rc));
     ProfScope prof(K_BN_FWD, stream);
-    FR_LAUNCH(prof, bn_fwd_stats_kernel, grid, dim3(BN_THREADS), 0, stream, Z, (int)M, (int)N, rc, (float*)ws);
-    FR_CHECK_LAUNCH();
+    if (!have_stats) {      // (else: the producing product's epilogue wrote the partials, fr_linear_fwd_bnstats)
+        FR_LAUNCH(prof, bn_fwd_stats_kernel, grid, dim3(BN_THREADS), 0, stream, Z, (int)M, (int)N, rc, (float*)ws);
+        FR_CHECK_LAUNCH();
+    }
     float* fin = (float*)ws + (size_t)grid.y * N * 2;
     FR_LAUNCH(prof, bn_fwd_fold_kernel, dim3(grid.x), dim3(BN_THREADS), 0, stream, (const float*)ws, (int)grid.y, (int)M, (int)N, rc, eps,
               momentum, running_mean, running_var, fin, invstd);
@@ -1012,6 +1014,39 @@ static int bn_fwd_impl(const float* Z, const float* gamma, const float* beta, fl
     }
     FR_CHECK_LAUNCH();
     return FR_OK;
+}
+
+// Z = X W^T + b for a layer with BatchNorm behind it, the BatchNorm's per-chunk statistics written by the product's own
+// epilogue into `bn_ws` (fr_bn_workspace_bytes(M, N): what fr_bn_fwd's first launch would leave there): follow with
+// fr_bn_fwd_ex(..., have_stats = 1).  Fast form only (K, k0 multiples of 32, no mask, 32-row chunks, i.e. M <= 32768, the
+// macro-tile kernels): FR_EUNSUPPORTED otherwise -- the caller then takes fr_linear_fwd + fr_bn_fwd.
+extern "C" int fr_linear_fwd_bnstats(const float* x0, int32_t k0, const float* x1, int32_t k1, const float* W, const float* bias,
+                                     int64_t M, int32_t N, float* Z, void* bn_ws, size_t bn_ws_bytes, void* stream_) {
+    FR_CHECK_ARG(x0 && W && Z && bn_ws && M >= 1 && N >= 1 && k0 >= 1 && k1 >= 0 && (k1 == 0 || x1), "fr_linear_fwd_bnstats: bad argument");
+    FR_CHECK_ARG(bn_ws_bytes >= fr_bn_workspace_bytes(M, N), "fr_linear_fwd_bnstats: BatchNorm workspace too small");
+    const int K = k0 + k1;
+    static const bool off = getenv("FAIRREC_LINEAR_SLOW") != nullptr || getenv("FAIRREC_LINEAR_NO_GLDS") != nullptr ||
+                            getenv("FAIRREC_BN_STATS_LAUNCH") != nullptr;
+    const bool aligned = ((uintptr_t)x0 & 15) == 0 && ((uintptr_t)W & 15) == 0 && (!x1 || ((uintptr_t)x1 & 15) == 0);
+    if (off || !aligned || K % 32 != 0 || k0 % 32 != 0 || N < 8 || bn_chunk_rows(M) != 32 || !glds_shared_form()) {
+        set_error("fr_linear_fwd_bnstats: not in the fast form");
+        return FR_EUNSUPPORTED;
+    }
+    prof_work(K_LINEAR_FWD, 2.0 * (double)M * N * K);
+    return glds_linear_fwd(GlMat{x0, x1, k0, k1, k0}, W, bias, M, (int)N, K, ACT_NONE, Z, (hipStream_t)stream_, (float*)bn_ws);
+}
+
+// fr_bn_fwd / fr_bn_fwd_drop in one entry (Yd == NULL: no dropout of the output), `have_stats` != 0: the statistics launch is
+// skipped -- fr_linear_fwd_bnstats left the per-chunk partials in `ws`.
+extern "C" int fr_bn_fwd_ex(const float* Z, const float* gamma, const float* beta, float eps, float momentum,
+                            float* running_mean, float* running_var, int64_t M, int32_t N, int32_t act, float* Y, float* xhat,
+                            float* invstd, void* ws, size_t ws_bytes, int32_t have_stats, float* Yd, float p, uint64_t seed,
+                            uint64_t offset, const int64_t* counter, int64_t* used_out, int64_t* tick_state, void* stream_) {
+    FR_CHECK_ARG(!Yd || (counter && N % 4 == 0 && p >= 0.f && p < 1.f && offset % 4 == 0 &&
+                         (((uintptr_t)Z | (uintptr_t)Y | (uintptr_t)Yd | (uintptr_t)xhat | (uintptr_t)gamma | (uintptr_t)beta) & 15) == 0),
+                 "fr_bn_fwd_ex: bad argument (N % 4 == 0, 16-byte aligned tensors)");
+    return bn_fwd_impl(Z, gamma, beta, eps, momentum, running_mean, running_var, M, N, act, Y, xhat, invstd, ws, ws_bytes,
+                       (hipStream_t)stream_, Yd, p, seed, offset, counter, used_out, tick_state, have_stats != 0);
 }
 
 extern "C" int fr_bn_bwd(const float* dY, const float* Y, int32_t act, const float* xhat, const float* invstd,

@@ -543,6 +543,37 @@ __device__ __forceinline__ void glds64_body(const GlArgs& g, const unsigned bid,
         if (col < g.out_cols) {
             const float bias = g.bias ? g.bias[col] : 0.f;
             float* yp = g.Y + (size_t)(i0 + 4 * h) * g.out_cols + col;
+            if (g.bn_part) {
+                // BatchNorm behind this layer: the column statistics of this tile's 32 rows -- mean, then the sum of squared
+                // deviations from it, as bn_fwd_stats_kernel forms them for a 32-row chunk -- from the accumulators, so that
+                // the statistics launch (and its pass over Z) is not needed.  Lane (r, h) holds 16 rows of column r.
+                float sum = 0.f, cnt = 0.f;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int ro = (e & 3) + 8 * (e >> 2);
+                    if (i0 + 4 * h + ro < g.out_rows) {
+                        sum += acc[e] + bias;
+                        cnt += 1.f;
+                    }
+                }
+                sum += __shfl_xor(sum, 32, 64);
+                cnt += __shfl_xor(cnt, 32, 64);
+                const float mean = sum / cnt;
+                float m2 = 0.f;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int ro = (e & 3) + 8 * (e >> 2);
+                    if (i0 + 4 * h + ro < g.out_rows) {
+                        const float d = (acc[e] + bias) - mean;
+                        m2 = fmaf(d, d, m2);
+                    }
+                }
+                m2 += __shfl_xor(m2, 32, 64);
+                if (h == 0) {
+                    g.bn_part[((size_t)ti * g.out_cols + col) * 2] = mean;
+                    g.bn_part[((size_t)ti * g.out_cols + col) * 2 + 1] = m2;
+                }
+            }
             if (g.act <= 2) {
                 const float neg = g.act == 0 ? 1.f : (g.act == 1 ? 0.f : 0.01f);
 #pragma unroll
@@ -713,9 +744,12 @@ static int pick_ks(long long ntiles, int chunks) {
     return ks;
 }
 
+bool glds_shared_form() { return use_shared(); }
+
 int glds_linear_fwd(const GlMat& X, const float* W, const float* bias, int64_t M, int N, int K, int act, float* Y,
-                    hipStream_t stream) {
+                    hipStream_t stream, float* bn_part) {
     GlArgs g{};
+    g.bn_part = bn_part;
     g.A = X;
     g.B = GlMat{W, nullptr, K, 0, K};
     g.rowsA = (int)M;

@@ -29,13 +29,15 @@ struct GlArgs {
     float *o_a, *o_b;        // input gradient: columns [0, o_split) -> o_a, the rest -> o_b
     int o_lda, o_ldb, o_split;
     float *slab, *bslab;     // weight gradient
+    float* bn_part;          // forward, optional: per (32-row tile, column) (mean, M2) partials of Z = X W^T + b for the BatchNorm behind
     const float* relu_src;   // input gradient, optional: the layer's input Xd = relu(z) o keep, leading dimension out_cols;
     float relu_scale;        //   the result is then the gradient at z: (dY W) o relu_scale o [Xd > 0]
 };
 
 // Y = act(X W^T + b); needs K % 32 == 0, X.split % 32 == 0, 16-byte aligned rows
 int glds_linear_fwd(const GlMat& X, const float* W, const float* bias, int64_t M, int N, int K, int act, float* Y,
-                    hipStream_t stream);
+                    hipStream_t stream, float* bn_part = nullptr);
+bool glds_shared_form();     // the macro-tile kernels are selected (FAIRREC_LINEAR_NO_SHARED unset): the only ones that write bn_part
 // dX = dY W; needs N % 32 == 0, K % 32 == 0, k0 % 32 == 0
 int glds_linear_bwd_input(const float* dY, const float* W, int64_t M, int N, int K, float* dx0, int k0, float* dx1, int k1,
                           hipStream_t stream, const float* relu_src = nullptr, float relu_scale = 1.f);

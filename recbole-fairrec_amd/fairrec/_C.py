@@ -18,6 +18,7 @@ DEV_ERR_INDEX_RANGE = 1
 DEV_ERR_SST_GROUPS = 2
 DEV_ERR_BUCKET_OVERFLOW = 4
 DEV_ERR_PIPE_WAIT = 8
+EUNSUPPORTED = -3      # FR_EUNSUPPORTED
 WGRAD_MAX = 8          # FR_WGRAD_MAX
 
 FOCF_OBJECTIVES = {"none": 0, "value": 1, "absolute": 2, "under": 3, "over": 4, "nonparity": 5}
@@ -207,6 +208,11 @@ _PROTOS = {
     "fr_nfcf_df_apply": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
                                  c_int64, c_float, c_float, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "fr_bn_workspace_bytes": (c_size_t, [c_int64, c_int32]),
+    "fr_linear_fwd_bnstats": (c_int, [c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p,
+                                      c_size_t, c_void_p]),
+    "fr_bn_fwd_ex": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_float, c_void_p, c_void_p, c_int64, c_int32, c_int32,
+                             c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int32, c_void_p, c_float, c_uint64, c_uint64,
+                             c_void_p, c_void_p, c_void_p, c_void_p]),
     "fr_bn_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_float, c_void_p, c_void_p, c_int64, c_int32, c_int32,
                           c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "fr_bn_fwd_drop": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_float, c_void_p, c_void_p, c_int64, c_int32, c_int32,

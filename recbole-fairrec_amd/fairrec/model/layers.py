@@ -115,12 +115,29 @@ class _HipMLP(torch.autograd.Function):
         fused_in = None                       # (dropped input of the next layer, its offset) written by fr_bn_fwd_drop
         drop_off = [None] * n_layers          # (offset of block a, offset of block c) of a regenerated pattern
         dropped_out = [False] * n_layers      # layer l's output was dropped in place for layer l + 1
+        def product(a, k0, c, k1, W, b, N, Y, bn_ws):
+            """Y = [a | c] W^T + b (+ the layer's activation where no BatchNorm follows); with BatchNorm behind the layer, its
+            per-chunk statistics come out of the product's epilogue when the shapes allow (returns 1: fr_bn_fwd_ex skips its
+            statistics launch)."""
+            if bn_ws is not None:
+                rc = lib.fr_linear_fwd_bnstats(a.data_ptr(), k0, _C.ptr(c), k1, W.data_ptr(), b.data_ptr(), M, N, Y.data_ptr(),
+                                               bn_ws.data_ptr(), bn_ws.numel(), st)
+                if rc == 0:
+                    return 1
+                if rc != _C.EUNSUPPORTED:
+                    _C.check(rc, "fr_linear_fwd_bnstats")
+            _C.check(lib.fr_linear_fwd(a.data_ptr(), k0, _C.ptr(c), k1, None, 1.0, W.data_ptr(), b.data_ptr(), M, N,
+                                       0 if use_bn else act, Y.data_ptr(), st), "fr_linear_fwd")
+            return 0
+
         for l in range(n_layers):
             W, b = params[per * l].contiguous(), params[per * l + 1].contiguous()
             a, c = cur
             k0, k1 = a.shape[1], (c.shape[1] if c is not None else 0)
             N = W.shape[0]
             Y = torch.empty((M, N), dtype=torch.float32, device=dev)
+            bn_ws = torch.empty(lib.fr_bn_workspace_bytes(M, N), dtype=torch.uint8, device=dev) if use_bn else None
+            have_stats = 0
             mk = masks[l] if masks is not None else None      # fp32 keep scales [M, K] (0 or 1/(1-p)), or None
             mk8 = None
             if drop is not None and fused_in is not None:
@@ -129,8 +146,7 @@ class _HipMLP(torch.autograd.Function):
                 drop_off[l] = (fused_in[1], 0)
                 fused_in = None
                 premul.append(True)
-                _C.check(lib.fr_linear_fwd(a.data_ptr(), k0, None, 0, None, 1.0, W.data_ptr(), b.data_ptr(), M, N,
-                                           0 if use_bn else act, Y.data_ptr(), st), "fr_linear_fwd")
+                have_stats = product(a, k0, None, 0, W, b, N, Y, bn_ws)
             elif drop is not None:
                 if l > 0 and not use_bn and act == 1 and a.numel() % 4 == 0:
                     drop.forward(a, a)                          # a IS outs[l - 1]
@@ -146,20 +162,21 @@ class _HipMLP(torch.autograd.Function):
                         oa = drop.forward(a, ad)
                     a, c, drop_off[l] = ad, cd, (oa, oc)
                     premul.append(True)
-                _C.check(lib.fr_linear_fwd(a.data_ptr(), k0, _C.ptr(c), k1, None, 1.0, W.data_ptr(), b.data_ptr(), M, N,
-                                           0 if use_bn else act, Y.data_ptr(), st), "fr_linear_fwd")
+                have_stats = product(a, k0, c, k1, W, b, N, Y, bn_ws)
             elif mk is not None and k0 % 32 == 0 and k1 % 32 == 0:
                 # the layer's input with dropout applied (both blocks of a two-block input); kept for backward
                 a = a * (mk if c is None else mk[:, :k0])
                 c = c * mk[:, k0:] if c is not None else None
                 premul.append(True)
-                _C.check(lib.fr_linear_fwd(a.data_ptr(), k0, _C.ptr(c), k1, None, 1.0, W.data_ptr(), b.data_ptr(), M, N,
-                                           0 if use_bn else act, Y.data_ptr(), st), "fr_linear_fwd")
+                have_stats = product(a, k0, c, k1, W, b, N, Y, bn_ws)
             else:
                 premul.append(False)
                 mk8 = (mk != 0).to(torch.uint8) if mk is not None else None
-                _C.check(lib.fr_linear_fwd(a.data_ptr(), k0, _C.ptr(c), k1, _C.ptr(mk8), scale, W.data_ptr(), b.data_ptr(), M,
-                                           N, 0 if use_bn else act, Y.data_ptr(), st), "fr_linear_fwd")
+                if mk8 is None:
+                    have_stats = product(a, k0, c, k1, W, b, N, Y, bn_ws)
+                else:
+                    _C.check(lib.fr_linear_fwd(a.data_ptr(), k0, _C.ptr(c), k1, _C.ptr(mk8), scale, W.data_ptr(), b.data_ptr(), M,
+                                               N, 0 if use_bn else act, Y.data_ptr(), st), "fr_linear_fwd")
             ins.append((a, c) if premul[-1] else None)
             masks8.append(mk8)
             if use_bn:
@@ -169,20 +186,20 @@ class _HipMLP(torch.autograd.Function):
                 Y = torch.empty_like(Z)
                 xh = torch.empty_like(Z)
                 inv = torch.empty(N, dtype=torch.float32, device=dev)
-                ws = torch.empty(lib.fr_bn_workspace_bytes(M, N), dtype=torch.uint8, device=dev)
+                ws = bn_ws
                 if drop is not None and l + 1 < n_layers and N % 4 == 0:
                     # ... and the next layer's dropout in the same pass (Yd next to Y, which the backward pass needs)
                     Yd = torch.empty_like(Z)
                     off, used, tick = drop.take(M * N)
-                    _C.check(lib.fr_bn_fwd_drop(Z.data_ptr(), g.data_ptr(), be.data_ptr(), eps, mom, _C.ptr(rm), _C.ptr(rv), M, N,
-                                                act, Y.data_ptr(), xh.data_ptr(), inv.data_ptr(), ws.data_ptr(), ws.numel(),
-                                                Yd.data_ptr(), drop.p, drop.seed, off, drop.state.data_ptr(), used, tick, st),
-                             "fr_bn_fwd_drop")
+                    _C.check(lib.fr_bn_fwd_ex(Z.data_ptr(), g.data_ptr(), be.data_ptr(), eps, mom, _C.ptr(rm), _C.ptr(rv), M, N,
+                                              act, Y.data_ptr(), xh.data_ptr(), inv.data_ptr(), ws.data_ptr(), ws.numel(),
+                                              have_stats, Yd.data_ptr(), drop.p, drop.seed, off, drop.state.data_ptr(), used, tick,
+                                              st), "fr_bn_fwd_ex")
                     fused_in = (Yd, off)
                 else:
-                    _C.check(lib.fr_bn_fwd(Z.data_ptr(), g.data_ptr(), be.data_ptr(), eps, mom, _C.ptr(rm), _C.ptr(rv), M, N, act,
-                                           Y.data_ptr(), xh.data_ptr(), inv.data_ptr(), ws.data_ptr(), ws.numel(), st),
-                             "fr_bn_fwd")
+                    _C.check(lib.fr_bn_fwd_ex(Z.data_ptr(), g.data_ptr(), be.data_ptr(), eps, mom, _C.ptr(rm), _C.ptr(rv), M, N, act,
+                                              Y.data_ptr(), xh.data_ptr(), inv.data_ptr(), ws.data_ptr(), ws.numel(), have_stats,
+                                              None, 0.0, 0, 0, None, None, None, st), "fr_bn_fwd_ex")
                 xhats.append(xh)
                 invstds.append(inv)
             outs.append(Y)
