@@ -354,3 +354,45 @@ def test_shared_tile_gemms_are_bit_identical_to_the_wave_private_form(M, k0, k1,
         assert torch.equal(a, c)
     X = torch.cat([x0, x1], 1) if k1 else x0
     torch.testing.assert_close(shared[0], torch.relu(X @ W.t() + b), rtol=2e-4, atol=2e-4)
+
+
+@pytest.mark.parametrize("M,N,k0,k1", [(8192, 128, 128, 0), (1000, 40, 64, 32), (33, 256, 32, 0), (4097, 64, 96, 96)],
+                         ids=["full", "ragged_n40", "two_tiles", "ragged_two_blocks"])
+def test_bn_statistics_from_the_product_epilogue_equal_the_statistics_launch(M, N, k0, k1):
+    """fr_linear_fwd_bnstats + fr_bn_fwd_ex(have_stats = 1) against fr_linear_fwd + fr_bn_fwd: Z bit for bit (the same
+    product), the BatchNorm outputs, xhat, 1/std and the running statistics to rounding (the column sums of a 32-row chunk are
+    taken in another order) -- ragged last tiles and column counts that are no multiple of 32 included."""
+    from fairrec import _C
+    lib = _C.lib()
+    dev = torch.device("cuda")
+    g = torch.Generator(device="cuda").manual_seed(M + N)
+    x0 = torch.randn(M, k0, device=dev, generator=g)
+    x1 = torch.randn(M, k1, device=dev, generator=g) if k1 else None
+    W = torch.randn(N, k0 + k1, device=dev, generator=g) * 0.1
+    b = torch.randn(N, device=dev, generator=g)
+    gamma = torch.rand(N, device=dev, generator=g) + 0.5
+    beta = torch.randn(N, device=dev, generator=g)
+    st = _C.current_stream()
+    outs = []
+    for epilogue in (True, False):
+        Z = torch.empty(M, N, device=dev)
+        ws = torch.zeros(lib.fr_bn_workspace_bytes(M, N), dtype=torch.uint8, device=dev)
+        rm, rv = torch.zeros(N, device=dev), torch.ones(N, device=dev)
+        Y, xh, inv = torch.empty(M, N, device=dev), torch.empty(M, N, device=dev), torch.empty(N, device=dev)
+        if epilogue:
+            _C.check(lib.fr_linear_fwd_bnstats(x0.data_ptr(), k0, _C.ptr(x1), k1, W.data_ptr(), b.data_ptr(), M, N, Z.data_ptr(),
+                                               ws.data_ptr(), ws.numel(), st), "fr_linear_fwd_bnstats")
+        else:
+            _C.check(lib.fr_linear_fwd(x0.data_ptr(), k0, _C.ptr(x1), k1, None, 1.0, W.data_ptr(), b.data_ptr(), M, N, 0, Z.data_ptr(),
+                                       st), "fr_linear_fwd")
+        _C.check(lib.fr_bn_fwd_ex(Z.data_ptr(), gamma.data_ptr(), beta.data_ptr(), 1e-5, 0.1, rm.data_ptr(), rv.data_ptr(), M, N, 2,
+                                  Y.data_ptr(), xh.data_ptr(), inv.data_ptr(), ws.data_ptr(), ws.numel(), 1 if epilogue else 0,
+                                  None, 0.0, 0, 0, None, None, None, st), "fr_bn_fwd_ex")
+        torch.cuda.synchronize()
+        outs.append((Z, Y, xh, inv, rm, rv))
+    a, r = outs
+    assert torch.equal(a[0], r[0])
+    for x, y in zip(a[1:], r[1:]):
+        torch.testing.assert_close(x, y, rtol=2e-5, atol=2e-6)
+    ref = torch.nn.functional.batch_norm(r[0].double(), None, None, gamma.double(), beta.double(), True, 0.1, 1e-5)
+    torch.testing.assert_close(a[1].double(), torch.nn.functional.leaky_relu(ref, 0.01), rtol=1e-4, atol=1e-5)
