@@ -23,7 +23,8 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_segments_kernel(SortJobList
 
 template <int KPT>
 static int launch_sort_kpt(const SortJobList& jobs, int bits, uint32_t* err, hipStream_t stream) {
-    const int npass = (bits + sort_digit_bits(KPT) - 1) / sort_digit_bits(KPT);
+    const int passes = (bits + sort_digit_bits(KPT) - 1) / sort_digit_bits(KPT);
+    const int npass = passes | ((bits - sort_digit_bits(KPT) * (passes - 1)) << 8);      // (+ the last pass's bit count: sort_body.hpp)
     constexpr int NB = 1 << sort_digit_bits(KPT);
     const size_t lds = sort_lds_bytes<KPT>();
     static bool attr_set = false;
@@ -74,6 +75,12 @@ int launch_sort(const SortJob& a, const SortJob* b, int64_t M, uint32_t* err, hi
 }
 
 }  // namespace fr
+
+#ifdef FR_SORT_STAMPS
+extern "C" __attribute__((visibility("default"))) int fr_debug_sort_stamps(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(fr::g_sort_stamps), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : -1;
+}
+#endif
 
 extern "C" int fr_sort_segments(const int64_t* idx, int64_t M, int64_t n_rows, int32_t* perm, int32_t* seg_start,
                                 int32_t* seg_row, int32_t* seg_of, int32_t* n_seg, uint32_t* err_flag, void* stream) {

@@ -357,7 +357,8 @@ static int gather_train_impl(const char* who, const fr_table* ta, const fr_table
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)sort_lds_bytes<KPT>()));     \
             attr_set[E] = true;                                                                                            \
         }                                                                                                                  \
-        const int npass = (bits + sort_digit_bits(KPT) - 1) / sort_digit_bits(KPT);                                        \
+        const int passes_ = (bits + sort_digit_bits(KPT) - 1) / sort_digit_bits(KPT);                                      \
+        const int npass = passes_ | ((bits - sort_digit_bits(KPT) * (passes_ - 1)) << 8);                                  \
         FR_LAUNCH(prof, (table_lookup_kernel<E, KPT>), dim3((unsigned)blocks), dim3(SORT_THREADS), sort_lds_bytes<KPT>(),  \
                   stream, jobs, npass, ja, jb, tb ? 2 : 1, pj, c, cp, (long long)M, lay, err_flag);                        \
     }
