@@ -511,6 +511,14 @@ struct PipeArgs {
 #define FR_PIPE_WPE 8     // waves per SIMD the allocator aims at (64 registers, six spilled in the finisher's rare path): the
 #endif                    // launch lives on how many gather waves wait for their rows at once -- 16 per CU at the 91 registers
                           // the compiler takes when left alone, 32 here
+#ifndef FR_PIPE_PAIR_MAX_E
+#define FR_PIPE_PAIR_MAX_E 0      // widths (in 64-column fragments) whose gather takes TWO interactions per wave
+#endif                            // (focf_gather_pair_body: half the gather waves, packed replay of the two user rows).  0 = none:
+                                  // measured SLOWER at D = 64 (44.4-48.6 us per step against 42.9-43.3 on the same box, gathers
+                                  // ending at 37-39 us instead of 33.5): the launch is not short of VALU issue (the replay is ~17 us
+                                  // of it) but of independent chains, and a pair wave is one chain twice as long.  Same bits as
+                                  // the one-interaction gather (`-DFR_PIPE_PAIR_MAX_E=1` passes tests/test_focf_hip.py).
+__host__ __device__ constexpr bool pipe_pair(int E) { return E <= FR_PIPE_PAIR_MAX_E; }
 #ifdef FR_PIPE_TRACE      // diagnostic build: first start / last end of every role's waves (100 MHz clock), of the LAST launch
 __device__ unsigned long long pipe_dbg[8 * 8];      // a ring of eight launches (slot = step & 7); launch n clears slot n + 4
 struct PipeSpan {
@@ -534,7 +542,10 @@ __global__ __launch_bounds__(RUN_THREADS) __attribute__((amdgpu_waves_per_eu(FR_
     __shared__ __align__(16) float lds_rows[CAP * 64 * E];
     __shared__ float coef_s[CAP];
     __shared__ float sh[4];
-    __shared__ GatherLds<E, RUN_WAVES> glds;
+    // (a workgroup has one role: the gather's LDS lies in the item runs' row buffer)
+    using GLds = GatherLds<E, pipe_pair(E) ? 2 * RUN_WAVES : RUN_WAVES>;
+    static_assert(sizeof(GLds) <= sizeof(lds_rows), "the gather's LDS fits the item runs' row buffer");
+    GLds& glds = *reinterpret_cast<GLds*>(lds_rows);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     int blk = (int)blockIdx.x;
     // Grid order = start order: the loss, then the SWEEPER (its tasks are the longest single chains of the launch -- a pair of rows
@@ -571,14 +582,17 @@ __global__ __launch_bounds__(RUN_THREADS) __attribute__((amdgpu_waves_per_eu(FR_
         return;
     }
     blk -= p.n_fin_blocks;
-    if (blk < p.n_gather_blocks) {       // this batch's gather: one interaction per wave
+    if (blk < p.n_gather_blocks) {       // this batch's gather: one or two interactions per wave
         PIPE_SPAN(3);
 #if FR_PIPE_PRIO
         __builtin_amdgcn_s_setprio(2);
 #endif
         if (blk == 0 && threadIdx.x == 0) *p.w.defer = DeferLoss{nullptr, 0, 0.f, 0};
-        focf_gather_body<E, true, true, true, true, RUN_WAVES>(p.U, p.I, p.c, p.user, p.item, p.rating, p.B, p.upto, p.upto, p.w, 0.f,
-                                                               nullptr, p.err, blk, glds, p.sp, p.pw);
+        if constexpr (pipe_pair(E))
+            focf_gather_pair_body<E, RUN_WAVES>(p.U, p.I, p.c, p.user, p.item, p.rating, p.B, p.upto, p.w, p.err, blk, glds, p.sp, p.pw);
+        else
+            focf_gather_body<E, true, true, true, true, RUN_WAVES>(p.U, p.I, p.c, p.user, p.item, p.rating, p.B, p.upto, p.upto, p.w,
+                                                                   0.f, nullptr, p.err, blk, glds, p.sp, p.pw);
         return;
     }
     blk -= p.n_gather_blocks;            // the tail of the sweeper's start order: short tasks, into the slots the gathers leave
@@ -665,7 +679,8 @@ extern "C" int fr_focf_step_runs_pipe(const fr_table* U, const fr_table* I, cons
         const int cur = U->step & 1, prv = cur ^ 1;
         p.pw = PipeWait{own_u + (size_t)prv * U->n_rows, own_i + (size_t)prv * I->n_rows, own_u + (size_t)cur * U->n_rows,
                         own_i + (size_t)cur * I->n_rows, finish ? fin_step : -1};
-        p.n_gather_blocks = (int)((B + RUN_WAVES - 1) / RUN_WAVES);
+        const int per_block = pipe_pair((U->dim + 63) / 64) ? 2 * RUN_WAVES : RUN_WAVES;      // interactions per gather workgroup
+        p.n_gather_blocks = (int)((B + per_block - 1) / per_block);
         if (sweep_period > 0) {
             p.sw = make_sweep_slice(U, I, sweep_period);
             p.sw.skip_from = finish ? std::min(stamp, fin_step) : stamp;      // the finisher's rows are not the sweeper's either
