@@ -152,6 +152,9 @@ __device__ __forceinline__ void focf_gather_body(
                 if (lead == wib) pw.own_cur_i[ir] = upto_i + 1;
             }
         }
+#ifdef FR_DIAG_GATHER_NO_REPLAY     // timing experiment only (wrong numbers): what the launch costs when its gathers find fresh rows
+        if (PIPE) lu = upto_u, li = upto_i;
+#endif
         const int t0u = uniform(lu);
         // replay the optimizer steps each row missed (zero data gradient, weight decay only): first the
         // steps only the staler row missed, then the common tail on both rows interleaved
