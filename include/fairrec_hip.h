@@ -596,6 +596,11 @@ FR_API int fr_bpr_outer2(const float* pos, const float* neg, const float* pos_bi
 FR_API int fr_rowdot_rep_fwd(const float* a, const float* b, int64_t A, int32_t reps, int32_t dim, float* out, void* stream);
 FR_API int fr_rowdot_rep_bwd(const float* g, const float* a, const float* b, int64_t A, int32_t reps, int32_t dim, float* da,
                              float* db, void* stream);
+/* fr_rowdot_rep_bwd with the gradient of `a` left unsummed: da_sep[r*A + i] = g[r*A + i] b[r*A + i] ([reps*A, dim]) -- what
+ * `reps` fr_rowdot_bwd calls write, in one launch, for a caller whose autograd graph adds the parts up in its own order (the
+ * reference's two torch.mul(u, i).sum(-1) nodes, pfcn_pmf.py:182-183). */
+FR_API int fr_rowdot_rep_bwd_sep(const float* g, const float* a, const float* b, int64_t A, int32_t reps, int32_t dim,
+                                 float* da_sep, float* db, void* stream);
 FR_API int fr_softmax_ce(const float* logits, const int64_t* label, int64_t M, int32_t C, float* loss, float* dlogits,
                          void* ws, size_t ws_bytes, uint32_t* err_flag, void* stream);
 

@@ -71,6 +71,25 @@ __global__ __launch_bounds__(256) void rowdot_rep_bwd_kernel(const float* __rest
     }
 }
 
+// ... with the gradient of `a` left UNSUMMED: da_sep[r*A + i,:] = g[r*A + i] * b[r*A + i,:] -- what R separate rowdot_bwd
+// launches write (the same single product per element), for a caller whose autograd graph adds them up itself
+__global__ __launch_bounds__(256) void rowdot_rep_bwd_sep_kernel(const float* __restrict__ g, const float* __restrict__ a,
+                                                                 const float* __restrict__ b, int A, int R, int D,
+                                                                 float* __restrict__ da_sep, float* __restrict__ db) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= A) return;
+    for (int d = lane; d < D; d += 64) {
+        const float av = a[(size_t)i * D + d];
+        for (int r = 0; r < R; ++r) {
+            const size_t row = (size_t)r * A + i;
+            const float gr = g[row];
+            if (da_sep) da_sep[row * D + d] = gr * b[row * D + d];
+            if (db) db[row * D + d] = gr * av;
+        }
+    }
+}
+
 __device__ __forceinline__ float bpr_term(float x, float& dterm) {
     // -log(1e-10 + sigmoid(x)) and its derivative  -sigmoid'(x) / (1e-10 + sigmoid(x))
     const float s = 1.f / (1.f + __expf(-x));
@@ -285,6 +304,17 @@ extern "C" int fr_rowdot_rep_bwd(const float* g, const float* a, const float* b,
     ProfScope prof(K_ROWDOT, stream);
     FR_LAUNCH(prof, rowdot_rep_bwd_kernel, dim3((unsigned)((A + 3) / 4)), dim3(256), 0, stream, g, a, b, (int)A, (int)reps,
               (int)dim, da, db);
+    FR_CHECK_LAUNCH();
+    return FR_OK;
+}
+
+extern "C" int fr_rowdot_rep_bwd_sep(const float* g, const float* a, const float* b, int64_t A, int32_t reps, int32_t dim,
+                                     float* da_sep, float* db, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    FR_CHECK_ARG(g && a && b && (da_sep || db) && A >= 1 && reps >= 1 && dim >= 1, "fr_rowdot_rep_bwd_sep: bad argument");
+    ProfScope prof(K_ROWDOT, stream);
+    FR_LAUNCH(prof, rowdot_rep_bwd_sep_kernel, dim3((unsigned)((A + 3) / 4)), dim3(256), 0, stream, g, a, b, (int)A, (int)reps,
+              (int)dim, da_sep, db);
     FR_CHECK_LAUNCH();
     return FR_OK;
 }

@@ -179,6 +179,7 @@ _PROTOS = {
                               c_void_p, c_size_t, c_void_p]),
     "fr_rowdot_rep_fwd": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p]),
     "fr_rowdot_rep_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
+    "fr_rowdot_rep_bwd_sep": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
     "fr_loss_accumulate": (c_int, [c_void_p, c_int32, c_void_p, c_void_p]),
     "fr_copy_many": (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),
     "fr_linear_bwd_weight": (c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_int32, c_void_p,

@@ -11,6 +11,28 @@ def _ws(nbytes, dev):
     return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=dev)
 
 
+class SplitRows(torch.autograd.Function):
+    """(x[:n], x[n:]) of rows that ONE lookup gathered for two id lists.  Autograd's own slices give each half a backward of
+    its own -- a zero-filled [2B, D] buffer, a copy into it, and an add of the two buffers: five launches where the gradient
+    is simply the two halves side by side (one `cat`; the same values, x + 0 = x)."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        ctx.n, ctx.shape = int(n), x.shape
+        return x[:n], x[n:]
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        if ga is None and gb is None:
+            return None, None
+        ref = ga if ga is not None else gb
+        if ga is None:
+            ga = ref.new_zeros((ctx.n,) + tuple(ctx.shape[1:]))
+        if gb is None:
+            gb = ref.new_zeros((ctx.shape[0] - ctx.n,) + tuple(ctx.shape[1:]))
+        return torch.cat([ga, gb]), None
+
+
 class RowDot(torch.autograd.Function):
     """torch.mul(a, b).sum(-1) (pfcn_pmf.py:182-183)."""
 
@@ -61,6 +83,54 @@ class RowDotRep(torch.autograd.Function):
             _C.check(_C.lib().fr_rowdot_rep_bwd(g.data_ptr(), a.data_ptr(), b.data_ptr(), a.shape[0], b.shape[0] // a.shape[0],
                                                 a.shape[1], _C.ptr(da), _C.ptr(db), _C.current_stream()), "fr_rowdot_rep_bwd")
         return da, db
+
+
+class RowDotPair(torch.autograd.Function):
+    """cat(RowDot(a, b[:A]), RowDot(a, b[A:])) for the rows `b` [2A, D] that one lookup gathered for a positive and a negative
+    id list: ONE forward launch (fr_rowdot_rep_fwd) instead of two and a `cat`, ONE backward launch (fr_rowdot_rep_bwd_sep: the
+    products RowDot's two backward launches form, the gradient of `b` whole instead of two halves glued by autograd).  `a` is
+    passed TWICE -- `RowDotPair.apply(a, a, b)` -- so that its two gradients reach autograd unsummed and are added to
+    whatever else `a` feeds in the order the two RowDot nodes gave them (the negative's first: the later node runs first);
+    summing them here would round once differently (the d128 golden)."""
+
+    @staticmethod
+    def forward(ctx, a_neg, a_pos, b):
+        a, b = a_pos.contiguous(), b.contiguous()
+        A, D = a.shape
+        assert a_neg.data_ptr() == a_pos.data_ptr() and b.shape[0] == 2 * A and b.shape[1] == D
+        out = torch.empty(2 * A, dtype=torch.float32, device=a.device)
+        _C.check(_C.lib().fr_rowdot_rep_fwd(a.data_ptr(), b.data_ptr(), A, 2, D, out.data_ptr(), _C.current_stream()),
+                 "fr_rowdot_rep_fwd")
+        ctx.save_for_backward(a, b)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        g = g.contiguous()
+        A, D = a.shape
+        want_a = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        da = torch.empty_like(b) if want_a else None        # [pos part; neg part], unsummed
+        db = torch.empty_like(b) if ctx.needs_input_grad[2] else None
+        if da is not None or db is not None:
+            _C.check(_C.lib().fr_rowdot_rep_bwd_sep(g.data_ptr(), a.data_ptr(), b.data_ptr(), A, 2, D, _C.ptr(da), _C.ptr(db),
+                                                    _C.current_stream()), "fr_rowdot_rep_bwd_sep")
+        da_neg = da[A:] if ctx.needs_input_grad[0] else None
+        da_pos = da[:A] if ctx.needs_input_grad[1] else None
+        return da_neg, da_pos, db
+
+
+class SubScaled(torch.autograd.Function):
+    """a - alpha * b of two scalar losses: torch.sub's backward negates and scales in two launches; here one."""
+
+    @staticmethod
+    def forward(ctx, a, b, alpha):
+        ctx.alpha = float(alpha)
+        return torch.sub(a, b, alpha=alpha)
+
+    @staticmethod
+    def backward(ctx, g):
+        return (g if ctx.needs_input_grad[0] else None), (g * (-ctx.alpha) if ctx.needs_input_grad[1] else None), None
 
 
 class Bpr(torch.autograd.Function):

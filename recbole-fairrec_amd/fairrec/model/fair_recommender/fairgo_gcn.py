@@ -29,7 +29,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ...engine import GenericEngine
-from ...functional import CsrMatrix, Mse, RowDot, RowGather, SpMM
+from ...functional import CsrMatrix, Mse, RowDot, RowGather, SplitRows, SpMM
 from ..layers import _HipMLP
 from .fairgo_pmf import FairGo_PMF
 
@@ -147,5 +147,5 @@ class FairGo_GCN(FairGo_PMF):
         rating = interaction[self.RATING].to(eng.device, torch.float32)
         E = self._filtered_table(None)                      # whole table through the GCN (fairgo_gcn.py:187-196)
         rows = RowGather.apply(E, torch.cat([user, item + self.n_users]), eng.err_flag)
-        B = user.numel()
-        return Mse.apply(RowDot.apply(rows[:B], rows[B:]), rating)
+        u_rows, i_rows = SplitRows.apply(rows, user.numel())
+        return Mse.apply(RowDot.apply(u_rows, i_rows), rating)

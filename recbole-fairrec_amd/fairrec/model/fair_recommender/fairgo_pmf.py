@@ -20,7 +20,7 @@ import torch
 import torch.nn as nn
 
 from ...engine import GenericEngine
-from ...functional import CsrMatrix, GatherAndSpMMSel, Mse, RowDot, RowGather, SigmoidBce, SoftmaxCe, SpMM, SpMMSel
+from ...functional import CsrMatrix, GatherAndSpMMSel, Mse, RowDot, RowGather, SigmoidBce, SoftmaxCe, SplitRows, SpMM, SpMMSel
 from ...utils.enum_type import InputType
 from ..abstract_recommender import FairRecommender
 from ..layers import ACT_CODES, MLPLayers, _HipMLP, activation_layer
@@ -371,11 +371,12 @@ class FairGo_PMF(FairRecommender):
             frontier = (fr, H1)
         else:
             rows, frontier = RowGather.apply(E, idx, eng.err_flag), None
-        mse = Mse.apply(RowDot.apply(rows[:B], rows[B:]), rating)
+        u_rows, i_rows = SplitRows.apply(rows, B)      # (autograd's slices: a zero fill, a copy and an add each on the way back)
+        mse = Mse.apply(RowDot.apply(u_rows, i_rows), rating)
         # the reference's calculate_dis_loss runs forward() a second time (fairgo_pmf.py:205-206): the same values from the
         # same parameters, so ONE filtered table serves both terms -- its gradient is the sum of the two uses, which is
         # what the two backward passes through the filters add up to (linear in dLoss/dE; rounding-level difference)
-        fair = self._dis_terms(E, interaction, sst_list, node=rows[:B], frontier=frontier)
+        fair = self._dis_terms(E, interaction, sst_list, node=u_rows, frontier=frontier)
         return mse - self.fair_weight * fair
 
     def predict(self, interaction):

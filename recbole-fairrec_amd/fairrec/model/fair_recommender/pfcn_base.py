@@ -12,11 +12,13 @@ BPR / BCE / CE on csrc/pfcn.hip.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn as nn
 
 from ...engine import GenericEngine
-from ...functional import Bpr, BprBroadcastGlobal, BprBroadcastPacked, RowDot, SigmoidBce, SoftmaxCe
+from ...functional import Bpr, BprBroadcastGlobal, BprBroadcastPacked, RowDot, RowDotPair, SigmoidBce, SoftmaxCe, SplitRows, SubScaled
 from ...utils.enum_type import InputType
 from ..abstract_recommender import FairRecommender
 from ..layers import MLPLayers
@@ -176,15 +178,16 @@ class PFCNBase(FairRecommender):
         """`frozen`: inside the filter pass the discriminators only pass the gradient on to the filters and embeddings;
         their own parameter gradients would be dropped unread by the next zero_grad (engine.zero_grad)."""
         eng = self.hip_engine()
-        total = 0.0
+        total = None            # (0.0 + loss would be a launch of its own)
         for sst in sst_list:
             y = self.dis_layer_dict[sst](user_embed, frozen=frozen)
             label = interaction[sst].to(eng.device)
             if self.sst_size[sst] == 2:
-                total = total + SigmoidBce.apply(y, label.float())
+                term = SigmoidBce.apply(y, label.float())
             else:
-                total = total + SoftmaxCe.apply(y, label.long(), eng.err_flag)
-        return total
+                term = SoftmaxCe.apply(y, label.long(), eng.err_flag)
+            total = term if total is None else total + term
+        return total if total is not None else 0.0
 
     def calculate_dis_loss(self, interaction, sst_list):
         """pfcn_biasedmf.py:202-218, called on its own in the discriminator phase: only the discriminators are
@@ -210,28 +213,39 @@ class PFCNBase(FairRecommender):
         user_embed = self._filter(self._user_tower(ue_raw), sst_list, passes=2 if once else 1)
         items = torch.cat([pos_item.to(eng.device), neg_item.to(eng.device)])     # one gather for both id lists
         ie = eng.lookup(self._itab, items)
-        pos_e, neg_e = self._item_tower(ie[:B]), self._item_tower(ie[B:])
-        dp, dn = self._score(user_embed, pos_e), self._score(user_embed, neg_e)
-        # (functional.RowDotRep scores both in one launch each way; it sums the two user-row gradients with one rounding
-        # less than autograd does, and the d128 golden sits within that of a LeakyReLU kink -- DESIGN.md §7 -- so the pair of
-        # RowDot calls stays)
+        # plain row dots against rows of ONE lookup: both scores in one launch each way (functional.RowDotPair: RowDot's values,
+        # the user rows' two gradients handed to autograd unsummed and in RowDot's order); FAIRREC_PFCN_ROWDOT_SEPARATE=1 or a
+        # tower / scorer of its own: the pair of calls
+        pair = (type(self)._score is PFCNBase._score and type(self)._item_tower is PFCNBase._item_tower
+                and os.environ.get("FAIRREC_PFCN_ROWDOT_SEPARATE", "0") != "1")
+        if pair:
+            scores = RowDotPair.apply(user_embed, user_embed, ie)
+        else:
+            ie_pos, ie_neg = SplitRows.apply(ie, B)       # (autograd's slices cost five launches on the way back)
+            pos_e, neg_e = self._item_tower(ie_pos), self._item_tower(ie_neg)
+            dp, dn = self._score(user_embed, pos_e), self._score(user_embed, neg_e)
+            scores = None
         if self.biased:
             ub = eng.lookup("user_bias.weight", user)
             ib = eng.lookup("item_bias.weight", items)
+            if scores is None:
+                scores = torch.cat([dp, dn])
             # packed columns: the differences and all four gradient columns come out of the loss kernel (bit-identical to
             # BprBroadcast on the slices, without its ten elementwise launches)
             if self.shard is not None:      # row-sharded tables: the broadcast runs over the GLOBAL batch (one all-gather)
-                bpr_loss = BprBroadcastGlobal.apply(torch.cat([dp, dn]), ub, ib, self.global_bias, eng)
+                bpr_loss = BprBroadcastGlobal.apply(scores, ub, ib, self.global_bias, eng)
             else:
-                bpr_loss = BprBroadcastPacked.apply(torch.cat([dp, dn]), ub, ib, self.global_bias)
+                bpr_loss = BprBroadcastPacked.apply(scores, ub, ib, self.global_bias)
         else:
+            if scores is not None:
+                dp, dn = SplitRows.apply(scores, B)
             bpr_loss = Bpr.apply(dp, dn)
         if self.filter_mode != 'none':
             # the reference calls forward() a second time inside calculate_dis_loss (pfcn_biasedmf.py:209): same rows,
             # filters applied again (BatchNorm statistics advance twice), gradient flows through both passes
             again = user_embed if once else self._filter(self._user_tower(ue_raw), sst_list)
             dis_loss = self._dis_terms(again, interaction, sst_list, frozen=True)
-            return torch.sub(bpr_loss, dis_loss, alpha=self.dis_weight)     # one launch; bpr_loss's gradient is the seed itself
+            return SubScaled.apply(bpr_loss, dis_loss, self.dis_weight)     # one launch each way; bpr_loss's gradient is the seed itself
         return bpr_loss
 
     def predict(self, interaction, sst_list=None):

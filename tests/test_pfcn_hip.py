@@ -341,3 +341,56 @@ def test_bpr_outer_rect_matches_float64_torch():
     da2 = torch.zeros(Na, device="cuda")
     ops.bpr_outer_rect(a.cuda(), c.cuda(), inv, loss, da2, None, hold)        # either gradient may be left out
     assert torch.equal(da, da2)
+
+
+@pytest.mark.parametrize("name", ["PFCN_BiasedMF", "PFCN_PMF"])
+def test_paired_row_dots_equal_the_two_separate_calls_bit_for_bit(name, monkeypatch):
+    """calculate_loss scores the positive and the negative item rows in one launch each way (functional.RowDotPair) and
+    hands autograd the user rows' two gradients unsummed; the pair of RowDot calls it replaces
+    (FAIRREC_PFCN_ROWDOT_SEPARATE=1, the reference's two torch.mul(u, i).sum(-1) nodes, pfcn_pmf.py:182-183) must give the
+    same bits: every loss, every table row and every filter / discriminator parameter after filter, discriminator and
+    filter steps (dropout off so that the two runs see the same masks)."""
+    from fairrec.config import Config
+    from fairrec.data.interaction import Interaction
+    from fairrec.optim import FusedLazyAdam
+    from fairrec.utils import get_model
+    n_users, n_items, D, B = 3001, 801, 128, 1024
+    g = torch.Generator().manual_seed(5)
+    z = {"gender": (torch.rand(n_users, generator=g) < 0.5).float().numpy(), "age": torch.randint(0, 3, (n_users,), generator=g).numpy()}
+    batches = [(torch.randint(1, n_users, (B,), generator=g), torch.randint(1, n_items, (B,), generator=g),
+                torch.randint(1, n_items, (B,), generator=g)) for _ in range(3)]
+
+    def run(separate):
+        monkeypatch.setenv("FAIRREC_PFCN_ROWDOT_SEPARATE", "1" if separate else "0")
+        torch.manual_seed(17)
+        cfg = Config(model=name, config_dict={"embedding_size": D, "sst_attr_list": ["gender"], "filter_mode": "sm",
+                                              "dis_hidden_size_list": [32, 16], "dis_dropout": 0.0, "dis_weight": 10.0,
+                                              "device": "cuda", "activation": "leakyrelu", "dis_activation": "leakyrelu"})
+        model = get_model(name)(cfg, _DS(n_users, n_items, z)).to("cuda")
+        eng = model.hip_engine()
+        opt_f = FusedLazyAdam(eng, lr=1e-3, weight_decay=1e-4, sweep_period=2, group="filter")
+        opt_d = FusedLazyAdam(eng, lr=1e-3, weight_decay=1e-4, sweep_period=2, group="dis")
+        losses = []
+        for t, ph in enumerate("FDF"):
+            u, i, n = batches[t]
+            inter = Interaction({"user_id": u, "item_id": i, "neg_item_id": n, "gender": torch.tensor(z["gender"][u.numpy()]),
+                                 "age": torch.tensor(z["age"][u.numpy()])}).to("cuda")
+            opt = opt_f if ph == "F" else opt_d
+            opt.zero_grad()
+            loss = model.calculate_loss(inter, ["gender"]) if ph == "F" else model.calculate_dis_loss(inter, ["gender"])
+            losses.append(float(loss))
+            loss.backward()
+            opt.step()
+        out = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+        for i, mlp in model.filter_layer.items():
+            out.update({f"filter.{i}.{k}": v.detach().cpu().clone() for k, v in mlp.state_dict().items()})
+        for s, mlp in model.dis_layer_dict.items():
+            out.update({f"dis.{s}.{k}": v.detach().cpu().clone() for k, v in mlp.state_dict().items()})
+        return losses, out
+
+    la, a = run(separate=True)
+    lb, b = run(separate=False)
+    assert la == lb, (la, lb)
+    assert a.keys() == b.keys()
+    for k in a:
+        assert torch.equal(a[k], b[k]), (k, float((a[k].double() - b[k].double()).abs().max()))
