@@ -10,6 +10,7 @@ from __future__ import annotations
 
 import ctypes
 import math
+import os
 from typing import Dict, Optional
 
 import numpy as np
@@ -309,8 +310,15 @@ class LazyTable:
             t._grad_rows = None
             t._keep = None
 
+    NARROW_SWEEP = int(os.environ.get("FAIRREC_NARROW_SWEEP", 64))
+
     def default_sweep(self, M: int) -> int:
-        return max(8, math.ceil(self.n_rows / max(M, 1)))
+        """Sweep about M rows per step, so that no row is more than n_rows / M steps stale.  A one-column table (a bias) is
+        swept 64 rows per wave: at that period a 10 M-row bias is 128 waves, each a serial chain of 1221 replayed steps --
+        60 us of exposed latency per step for 2 us of arithmetic (profiles/README.md, round 4) -- so its period is capped:
+        more, shorter chains, the same row-steps in all (any period gives the same values: the replay is exact)."""
+        s = max(8, math.ceil(self.n_rows / max(M, 1)))
+        return min(s, max(8, self.NARROW_SWEEP)) if self.dim == 1 else s
 
     # --- interchange with torch.optim.Adam.state_dict() (trainer.py:221-240 checkpoints) ---------------
     def adam_state(self, hyper: AdamHyper) -> Dict[str, torch.Tensor]:

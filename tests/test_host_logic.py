@@ -218,3 +218,17 @@ def test_epoch_shuffles_reproduce_the_reference_run(case):
                 np.testing.assert_array_equal(ref_u[n:], ref_u[:n])
             t += 1
     assert t == T
+
+
+def test_default_sweep_period_of_a_one_column_table_is_capped():
+    """A table is swept about one batch of rows per step (period = n_rows / batch); a bias column is swept 64 rows per wave,
+    so at that period a 10 M-row bias would be 128 waves of 1221 serial replayed steps each: its period is capped at 64
+    (fairrec/optim.py::LazyTable.default_sweep; any period gives the same values)."""
+    from fairrec.optim import LazyTable
+    t = object.__new__(LazyTable)
+    t.n_rows, t.dim = 10_000_001, 128
+    assert t.default_sweep(8192) == 1221
+    t.dim = 1
+    assert t.default_sweep(8192) == 64
+    t.n_rows = 1000
+    assert t.default_sweep(8192) == 8
