@@ -373,6 +373,13 @@ FR_API int fr_table_apply_grad2(const fr_table* ta, const fr_table* tb, const fr
                                 int32_t stride, const float* rows_a, const float* grad_a, const float* rows_b,
                                 const float* grad_b, int32_t sweep_a, int32_t sweep_b, void* ws_a, void* ws_b,
                                 size_t ws_bytes, void* stream);
+/* fr_table_apply_grad on two tables of one width in ONE launch, each with its own id count (PFCN: the user rows of a batch and
+ * the item rows of its positive + negative ids, pfcn_pmf.py:169-176; their two bias columns likewise): the shorter table's
+ * update and sweep slice run beside the longer one's.  Same results as the two calls; both tables step under `adam`. */
+FR_API int fr_table_apply_grad_two(const fr_table* ta, const fr_table* tb, const fr_adam* adam, int64_t Ma, int64_t Mb,
+                                   const float* rows_a, const float* grad_a, const float* rows_b, const float* grad_b,
+                                   int32_t sweep_a, int32_t sweep_b, void* ws_a, size_t ws_a_bytes, void* ws_b,
+                                   size_t ws_b_bytes, void* stream);
 
 /* ---- row-sharded tables (multi-GPU) -----------------------------------------------------
  * owner(row) = row mod G, local row = row div G.  All exchange buffers have the fixed shape [G, cap] slots so

@@ -176,6 +176,7 @@ struct ApplyJob {
     const float* grad_rows;
     int sweep_period;     // the sweeper slice is derived from the effective step on the device
     int sw_n;             // waves reserved for it (= pairs of rows of the longest slice)
+    long long M;          // ids of this table's batch (fr_table_apply_grad_two: each table its own)
 };
 
 template <int E>
@@ -199,7 +200,7 @@ __global__ __launch_bounds__(256) void table_apply_grad_kernel(ApplyJob ja, Appl
         return;
     }
     wv -= J.sw_n;
-    if (wv < M && wv < J.w.nseg[0])
+    if (wv < J.M && wv < J.w.nseg[0])
         segment_update<E>(T, c, (int)wv, J.w.seg_start, J.w.seg_row, J.w.perm, nullptr, J.rows, J.w.m_side, J.w.v_side,
                           J.grad_rows, lane, lay, J.w.seg_first);
 }
@@ -471,27 +472,29 @@ extern "C" int fr_table_sort2(const int64_t* idx_a, const int64_t* idx_b, int64_
 static int apply_grad_impl(const char* who, const fr_table* ta, const fr_table* tb, const fr_adam* adam, int64_t M,
                            int32_t chunk, int32_t stride, const float* rows_a, const float* grad_a, const float* rows_b,
                            const float* grad_b, int32_t sweep_a, int32_t sweep_b, void* ws_a, void* ws_b, size_t ws_bytes,
-                           hipStream_t stream) {
+                           hipStream_t stream, int64_t Mb = -1, size_t ws_b_bytes = 0) {
     int rc;
+    if (Mb < 0) Mb = M, ws_b_bytes = ws_bytes;
     if ((rc = check_table(ta, who)) || (tb && (rc = check_table(tb, who))) || (rc = check_adam(adam, who))) return rc;
     FR_CHECK_ARG(rows_a && grad_a && ws_a && M >= 1 && M <= FR_SORT_MAX && ta->step >= 1 && lay_ok(chunk, stride),
                  "%s: bad argument", who);
-    FR_CHECK_ARG(!tb || (rows_b && grad_b && ws_b && ws_b != ws_a && tb->dim == ta->dim && tb->step >= 1),
+    FR_CHECK_ARG(!tb || (rows_b && grad_b && ws_b && ws_b != ws_a && tb->dim == ta->dim && tb->step >= 1 && Mb >= 1 &&
+                         Mb <= FR_SORT_MAX && (Mb == M || chunk == 0)),
                  "%s: bad second table", who);
     const Lay lay{chunk, stride};
     TableWs wa = table_layout(ws_a, M, ta->dim);
-    TableWs wb = tb ? table_layout(ws_b, M, tb->dim) : wa;
-    FR_CHECK_ARG(ws_bytes >= wa.bytes, "%s: workspace %zu < %zu bytes", who, ws_bytes, wa.bytes);
+    TableWs wb = tb ? table_layout(ws_b, Mb, tb->dim) : wa;
+    FR_CHECK_ARG(ws_bytes >= wa.bytes && (!tb || ws_b_bytes >= wb.bytes), "%s: workspace %zu < %zu bytes", who, ws_bytes, wa.bytes);
     if ((rc = side_join(ws_a, stream)) || (tb && (rc = side_join(ws_b, stream)))) return rc;
     // waves reserved for the sweeper = rows of a full slice (the slice itself depends on the effective step, which may
     // live on the device)
     const int per_wave = sweep_rows_per_wave(ta->dim);
     const long long sw_a = sweep_a > 0 ? ((ta->n_rows + sweep_a - 1) / sweep_a + per_wave - 1) / per_wave : 0;
     const long long sw_b = tb && sweep_b > 0 ? ((tb->n_rows + sweep_b - 1) / sweep_b + per_wave - 1) / per_wave : 0;
-    const long long waves = M + std::max(sw_a, sw_b);
+    const long long waves = std::max(M + sw_a, tb ? Mb + sw_b : 0);
     const AdamC c = make_adamc(adam);
-    ApplyJob ja{view(ta), wa, rows_a, grad_a, (int)sweep_a, (int)sw_a};
-    ApplyJob jb = tb ? ApplyJob{view(tb), wb, rows_b, grad_b, (int)sweep_b, (int)sw_b} : ja;
+    ApplyJob ja{view(ta), wa, rows_a, grad_a, (int)sweep_a, (int)sw_a, (long long)M};
+    ApplyJob jb = tb ? ApplyJob{view(tb), wb, rows_b, grad_b, (int)sweep_b, (int)sw_b, (long long)Mb} : ja;
     {
         ProfScope prof(K_TABLE_APPLY_GRAD, stream);
         FR_DISPATCH_E(ta->dim, FR_LAUNCH(prof, (table_apply_grad_kernel<E>), dim3((unsigned)((waves + 3) / 4), tb ? 2 : 1), dim3(256), 0, stream, ja, jb, c, (long long)M, lay));
@@ -514,4 +517,16 @@ extern "C" int fr_table_apply_grad2(const fr_table* ta, const fr_table* tb, cons
     FR_CHECK_ARG(tb, "fr_table_apply_grad2: second table is null");
     return apply_grad_impl("fr_table_apply_grad2", ta, tb, adam, M, chunk, stride, rows_a, grad_a, rows_b, grad_b, sweep_a,
                            sweep_b, ws_a, ws_b, ws_bytes, (hipStream_t)stream_);
+}
+
+// fr_table_apply_grad on TWO tables of one width in one launch, each with its own id count (a user table next to the item table
+// that was looked up with the positive and the negative ids): the shorter table's update and sweep slice run beside the
+// longer one's instead of in a launch behind it.  Same results as the two calls.
+extern "C" int fr_table_apply_grad_two(const fr_table* ta, const fr_table* tb, const fr_adam* adam, int64_t Ma, int64_t Mb,
+                                       const float* rows_a, const float* grad_a, const float* rows_b, const float* grad_b,
+                                       int32_t sweep_a, int32_t sweep_b, void* ws_a, size_t ws_a_bytes, void* ws_b,
+                                       size_t ws_b_bytes, void* stream_) {
+    FR_CHECK_ARG(tb && Mb >= 1, "fr_table_apply_grad_two: second table is null");
+    return apply_grad_impl("fr_table_apply_grad_two", ta, tb, adam, Ma, 0, 0, rows_a, grad_a, rows_b, grad_b, sweep_a, sweep_b,
+                           ws_a, ws_b, ws_a_bytes, (hipStream_t)stream_, Mb, ws_b_bytes);
 }

@@ -159,6 +159,8 @@ _PROTOS = {
     "fr_table_apply_grad2": (c_int, [POINTER(FrTable), POINTER(FrTable), POINTER(FrAdam), c_int64, c_int32, c_int32,
                                      c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_void_p,
                                      c_size_t, c_void_p]),
+    "fr_table_apply_grad_two": (c_int, [POINTER(FrTable), POINTER(FrTable), POINTER(FrAdam), c_int64, c_int64, c_void_p, c_void_p,
+                                        c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p]),
     "fr_linear_fwd": (c_int, [c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_float, c_void_p, c_void_p, c_int64,
                               c_int32, c_int32, c_void_p, c_void_p]),
     "fr_linear_bwd_input": (c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_float, c_int64, c_int32,

@@ -9,6 +9,7 @@ gradient in a step is skipped entirely (SURVEY.md §7 hard part 1).
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Dict, Optional
 
 import torch
@@ -220,6 +221,7 @@ class GenericEngine:
         self.note_stepped(group)
         self._seg_src = {}
         stepped = []
+        ready = []
         for name, t in self._tables.items():
             if not (t.trainable and t._pending is not None):
                 continue
@@ -230,8 +232,21 @@ class GenericEngine:
                 continue
             M = t._pending[0]
             s = self.sweep_period if self.sweep_period is not None else t.default_sweep(M)
-            t.apply_grad(self._hyper(name), None, s)
+            ready.append((name, t, s))
             stepped.append(name)
+        # two tables of one width and one optimizer share a launch (a user table next to its item table, their two bias
+        # columns): the shorter one's update and sweep slice run beside the longer one's (fr_table_apply_grad_two)
+        pair_ok = os.environ.get("FAIRREC_APPLY_SEPARATE") is None
+        while ready:
+            name, t, s = ready.pop(0)
+            mate = next((k for k, (nb, tb, sb) in enumerate(ready)
+                         if pair_ok and tb.dim == t.dim and self._hyper(nb) is self._hyper(name) and t._pending[1] is not None
+                         and tb._pending[1] is not None and (t.step_dev is None) == (tb.step_dev is None)), None)
+            if mate is None:
+                t.apply_grad(self._hyper(name), None, s)
+            else:
+                nb, tb, sb = ready.pop(mate)
+                LazyTable.apply_grad_two(t, tb, self._hyper(name), s, sb)
         st = _C.current_stream()
         by_hyper = {}                     # all dense tensors of one optimizer in one launch (fr_adam_dense_multi)
         for name, d in self._dense.items():

@@ -312,6 +312,33 @@ class LazyTable:
 
     NARROW_SWEEP = int(os.environ.get("FAIRREC_NARROW_SWEEP", 64))
 
+    @staticmethod
+    def apply_grad_two(ta: "LazyTable", tb: "LazyTable", hyper: AdamHyper, sweep_a: int, sweep_b: int):
+        """`ta.apply_grad(...)` and `tb.apply_grad(...)` -- two tables of one width, each with the rows its own gather_train
+        parked and the gradient rows autograd left -- in ONE launch (fr_table_apply_grad_two)."""
+        args = []
+        for t in (ta, tb):
+            if t._pending is None or t._pending[1] is None:
+                raise _C.FairrecError("apply_grad without a preceding gather_train")
+            if t._grad_rows is None:
+                raise _C.FairrecError("no gradient reached the gathered rows (loss.backward() not called?)")
+            M, rows = t._pending
+            g = t._grad_rows.contiguous()
+            assert g.shape == rows.shape and g.dtype == torch.float32
+            args.append((M, rows, g))
+        ca, cb = ta.c(ta.step + 1), tb.c(tb.step + 1)
+        (Ma, ra, ga), (Mb, rb, gb) = args
+        _C.check(_C.lib().fr_table_apply_grad_two(ctypes.byref(ca), ctypes.byref(cb), ctypes.byref(hyper.c()), Ma, Mb, ra.data_ptr(),
+                                                  ga.data_ptr(), rb.data_ptr(), gb.data_ptr(), int(sweep_a), int(sweep_b),
+                                                  ta._ws.data_ptr(), ta._ws.numel(), tb._ws.data_ptr(), tb._ws.numel(),
+                                                  _C.current_stream()), "fr_table_apply_grad_two")
+        for t in (ta, tb):
+            t.step += 1
+            t._dirty = True
+            t._pending = None
+            t._grad_rows = None
+            t._keep = None
+
     def default_sweep(self, M: int) -> int:
         """Sweep about M rows per step, so that no row is more than n_rows / M steps stale.  A one-column table (a bias) is
         swept 64 rows per wave: at that period a 10 M-row bias is 128 waves, each a serial chain of 1221 replayed steps --

@@ -343,9 +343,12 @@ def test_bpr_outer_rect_matches_float64_torch():
     assert torch.equal(da, da2)
 
 
+@pytest.mark.parametrize("switch", ["FAIRREC_PFCN_ROWDOT_SEPARATE", "FAIRREC_APPLY_SEPARATE"], ids=["row_dots", "apply_grad"])
 @pytest.mark.parametrize("name", ["PFCN_BiasedMF", "PFCN_PMF"])
-def test_paired_row_dots_equal_the_two_separate_calls_bit_for_bit(name, monkeypatch):
-    """calculate_loss scores the positive and the negative item rows in one launch each way (functional.RowDotPair) and
+def test_paired_row_dots_equal_the_two_separate_calls_bit_for_bit(name, switch, monkeypatch):
+    """(`apply_grad`: the same comparison for the optimizer step's table launches -- the user and the item table, and their two
+    bias columns, share a launch each (fr_table_apply_grad_two, each table with its own id count) unless
+    FAIRREC_APPLY_SEPARATE is set.)  calculate_loss scores the positive and the negative item rows in one launch each way (functional.RowDotPair) and
     hands autograd the user rows' two gradients unsummed; the pair of RowDot calls it replaces
     (FAIRREC_PFCN_ROWDOT_SEPARATE=1, the reference's two torch.mul(u, i).sum(-1) nodes, pfcn_pmf.py:182-183) must give the
     same bits: every loss, every table row and every filter / discriminator parameter after filter, discriminator and
@@ -361,7 +364,10 @@ def test_paired_row_dots_equal_the_two_separate_calls_bit_for_bit(name, monkeypa
                 torch.randint(1, n_items, (B,), generator=g)) for _ in range(3)]
 
     def run(separate):
-        monkeypatch.setenv("FAIRREC_PFCN_ROWDOT_SEPARATE", "1" if separate else "0")
+        if separate:
+            monkeypatch.setenv(switch, "1")
+        else:
+            monkeypatch.delenv(switch, raising=False)
         torch.manual_seed(17)
         cfg = Config(model=name, config_dict={"embedding_size": D, "sst_attr_list": ["gender"], "filter_mode": "sm",
                                               "dis_hidden_size_list": [32, 16], "dis_dropout": 0.0, "dis_weight": 10.0,
