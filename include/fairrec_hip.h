@@ -560,13 +560,15 @@ FR_API int fr_bn_fwd_drop(const float* Z, const float* gamma, const float* beta,
 /* The product of a layer that has BatchNorm behind it with the BatchNorm's per-chunk statistics formed in the product's epilogue
  * (into `bn_ws`, fr_bn_workspace_bytes(M, N)), and fr_bn_fwd / fr_bn_fwd_drop as one entry that can skip its statistics launch
  * (`have_stats`): layers.py:64-67 in two BatchNorm launches instead of three.  fr_linear_fwd_bnstats: fast form only
- * (FR_EUNSUPPORTED otherwise: fr_linear_fwd + fr_bn_fwd then). */
+ * (FR_EUNSUPPORTED otherwise: fr_linear_fwd + fr_bn_fwd then).  `num_batches_tracked` (may be NULL): the layer's int64 batch
+ * counter, moved by `passes` in the same launch that updates the running statistics (nn.BatchNorm1d's bookkeeping). */
 FR_API int fr_linear_fwd_bnstats(const float* x0, int32_t k0, const float* x1, int32_t k1, const float* W, const float* bias,
                                  int64_t M, int32_t N, float* Z, void* bn_ws, size_t bn_ws_bytes, void* stream);
 FR_API int fr_bn_fwd_ex(const float* Z, const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
                         float* running_var, int64_t M, int32_t N, int32_t act, float* Y, float* xhat, float* invstd, void* ws,
                         size_t ws_bytes, int32_t have_stats, float* Yd, float p, uint64_t seed, uint64_t offset,
-                        const int64_t* counter, int64_t* used_out, int64_t* tick_state, void* stream);
+                        const int64_t* counter, int64_t* used_out, int64_t* tick_state, int64_t* num_batches_tracked,
+                        int32_t passes, void* stream);
 FR_API int fr_bn_bwd(const float* dY, const float* Y, int32_t act, const float* xhat, const float* invstd,
                      const float* gamma, int64_t M, int32_t N, float* dZ, float* dgamma, float* dbeta, void* ws,
                      size_t ws_bytes, void* stream);

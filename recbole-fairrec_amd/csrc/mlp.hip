@@ -780,8 +780,11 @@ __global__ __launch_bounds__(BN_THREADS) void bn_fwd_stats_kernel(const float* _
 __global__ __launch_bounds__(BN_THREADS) void bn_fwd_fold_kernel(const float* __restrict__ part, int chunks, int M, int N, int rc,
                                                                  float eps, float momentum, float* __restrict__ rmean,
                                                                  float* __restrict__ rvar, float* __restrict__ fin,
-                                                                 float* __restrict__ invstd_out) {
+                                                                 float* __restrict__ invstd_out, long long* __restrict__ nbt,
+                                                                 int nbt_inc) {
     __shared__ float sh[BN_WAVES][64];
+    // num_batches_tracked += passes of this layer (layers.py's BatchNorm1d bookkeeping) rides here: no launch of its own
+    if (nbt && blockIdx.x == 0 && threadIdx.x == 0) *nbt += nbt_inc;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n = blockIdx.x * 64 + lane;
     const int q = (chunks + BN_WAVES - 1) / BN_WAVES, c0 = wave * q, c1 = min(chunks, c0 + q);
@@ -962,7 +965,8 @@ extern "C" size_t fr_bn_workspace_bytes(int64_t M, int32_t N) {
 static int bn_fwd_impl(const float* Z, const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
                        float* running_var, int64_t M, int32_t N, int32_t act, float* Y, float* xhat, float* invstd, void* ws,
                        size_t ws_bytes, hipStream_t stream, float* Yd, float p, uint64_t seed, uint64_t offset,
-                       const int64_t* counter, int64_t* used_out, int64_t* tick_state, bool have_stats = false);
+                       const int64_t* counter, int64_t* used_out, int64_t* tick_state, bool have_stats = false,
+                       int64_t* nbt = nullptr, int32_t nbt_inc = 0);
 
 extern "C" int fr_bn_fwd(const float* Z, const float* gamma, const float* beta, float eps, float momentum,
                          float* running_mean, float* running_var, int64_t M, int32_t N, int32_t act, float* Y,
@@ -988,7 +992,8 @@ extern "C" int fr_bn_fwd_drop(const float* Z, const float* gamma, const float* b
 static int bn_fwd_impl(const float* Z, const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
                        float* running_var, int64_t M, int32_t N, int32_t act, float* Y, float* xhat, float* invstd, void* ws,
                        size_t ws_bytes, hipStream_t stream, float* Yd, float p, uint64_t seed, uint64_t offset,
-                       const int64_t* counter, int64_t* used_out, int64_t* tick_state, bool have_stats) {
+                       const int64_t* counter, int64_t* used_out, int64_t* tick_state, bool have_stats, int64_t* nbt,
+                       int32_t nbt_inc) {
     FR_CHECK_ARG(Z && gamma && beta && Y && xhat && invstd && ws && M >= 1 && N >= 1 && act_ok(act) &&
                      ws_bytes >= fr_bn_workspace_bytes(M, N), "fr_bn_fwd: bad argument");
     const int rc = bn_chunk_rows(M);
@@ -1000,7 +1005,7 @@ static int bn_fwd_impl(const float* Z, const float* gamma, const float* beta, fl
     }
     float* fin = (float*)ws + (size_t)grid.y * N * 2;
     FR_LAUNCH(prof, bn_fwd_fold_kernel, dim3(grid.x), dim3(BN_THREADS), 0, stream, (const float*)ws, (int)grid.y, (int)M, (int)N, rc, eps,
-              momentum, running_mean, running_var, fin, invstd);
+              momentum, running_mean, running_var, fin, invstd, (long long*)nbt, (int)nbt_inc);
     FR_CHECK_LAUNCH();
     if (Yd) {
         const long long quads = (long long)M * N / 4;
@@ -1041,12 +1046,14 @@ extern "C" int fr_linear_fwd_bnstats(const float* x0, int32_t k0, const float* x
 extern "C" int fr_bn_fwd_ex(const float* Z, const float* gamma, const float* beta, float eps, float momentum,
                             float* running_mean, float* running_var, int64_t M, int32_t N, int32_t act, float* Y, float* xhat,
                             float* invstd, void* ws, size_t ws_bytes, int32_t have_stats, float* Yd, float p, uint64_t seed,
-                            uint64_t offset, const int64_t* counter, int64_t* used_out, int64_t* tick_state, void* stream_) {
+                            uint64_t offset, const int64_t* counter, int64_t* used_out, int64_t* tick_state,
+                            int64_t* num_batches_tracked, int32_t passes, void* stream_) {
     FR_CHECK_ARG(!Yd || (counter && N % 4 == 0 && p >= 0.f && p < 1.f && offset % 4 == 0 &&
                          (((uintptr_t)Z | (uintptr_t)Y | (uintptr_t)Yd | (uintptr_t)xhat | (uintptr_t)gamma | (uintptr_t)beta) & 15) == 0),
                  "fr_bn_fwd_ex: bad argument (N % 4 == 0, 16-byte aligned tensors)");
     return bn_fwd_impl(Z, gamma, beta, eps, momentum, running_mean, running_var, M, N, act, Y, xhat, invstd, ws, ws_bytes,
-                       (hipStream_t)stream_, Yd, p, seed, offset, counter, used_out, tick_state, have_stats != 0);
+                       (hipStream_t)stream_, Yd, p, seed, offset, counter, used_out, tick_state, have_stats != 0,
+                       num_batches_tracked, passes);
 }
 
 extern "C" int fr_bn_bwd(const float* dY, const float* Y, int32_t act, const float* xhat, const float* invstd,

@@ -215,7 +215,7 @@ _PROTOS = {
                                       c_size_t, c_void_p]),
     "fr_bn_fwd_ex": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_float, c_void_p, c_void_p, c_int64, c_int32, c_int32,
                              c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int32, c_void_p, c_float, c_uint64, c_uint64,
-                             c_void_p, c_void_p, c_void_p, c_void_p]),
+                             c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),
     "fr_bn_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_float, c_void_p, c_void_p, c_int64, c_int32, c_int32,
                           c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "fr_bn_fwd_drop": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_float, c_void_p, c_void_p, c_int64, c_int32, c_int32,

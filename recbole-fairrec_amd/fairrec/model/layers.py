@@ -181,7 +181,7 @@ class _HipMLP(torch.autograd.Function):
             masks8.append(mk8)
             if use_bn:
                 g, be = params[per * l + 2].contiguous(), params[per * l + 3].contiguous()
-                rm, rv, eps, mom = bn_buffers[l]
+                rm, rv, eps, mom, nbt, n_pass = bn_buffers[l]
                 Z = Y
                 Y = torch.empty_like(Z)
                 xh = torch.empty_like(Z)
@@ -194,12 +194,12 @@ class _HipMLP(torch.autograd.Function):
                     _C.check(lib.fr_bn_fwd_ex(Z.data_ptr(), g.data_ptr(), be.data_ptr(), eps, mom, _C.ptr(rm), _C.ptr(rv), M, N,
                                               act, Y.data_ptr(), xh.data_ptr(), inv.data_ptr(), ws.data_ptr(), ws.numel(),
                                               have_stats, Yd.data_ptr(), drop.p, drop.seed, off, drop.state.data_ptr(), used, tick,
-                                              st), "fr_bn_fwd_ex")
+                                              _C.ptr(nbt), n_pass, st), "fr_bn_fwd_ex")
                     fused_in = (Yd, off)
                 else:
                     _C.check(lib.fr_bn_fwd_ex(Z.data_ptr(), g.data_ptr(), be.data_ptr(), eps, mom, _C.ptr(rm), _C.ptr(rv), M, N, act,
                                               Y.data_ptr(), xh.data_ptr(), inv.data_ptr(), ws.data_ptr(), ws.numel(), have_stats,
-                                              None, 0.0, 0, 0, None, None, None, st), "fr_bn_fwd_ex")
+                                              None, 0.0, 0, 0, None, None, None, _C.ptr(nbt), n_pass, st), "fr_bn_fwd_ex")
                 xhats.append(xh)
                 invstds.append(inv)
             outs.append(Y)
@@ -368,18 +368,6 @@ class MLPLayers(nn.Module):
             if module.bias is not None:
                 module.bias.data.fill_(0.0)
 
-    def _count_batch(self, bns, passes=1):
-        """`num_batches_tracked += 1` of every BatchNorm layer in ONE launch: the counters are kept as views of one shared
-        int64 tensor (re-made whenever .to() / a fresh module replaced the buffers; load_state_dict copies in place, so the
-        views survive it)."""
-        sh = getattr(self, "_nbt_shared", None)
-        if sh is None or any(bn.num_batches_tracked.data_ptr() != sh[i].data_ptr() for i, bn in enumerate(bns)):
-            sh = torch.stack([bn.num_batches_tracked.detach().reshape(()) for bn in bns])
-            for i, bn in enumerate(bns):
-                bn.num_batches_tracked = sh[i]
-            self._nbt_shared = sh
-        sh += passes
-
     def linears(self) -> List[nn.Linear]:
         return [m for m in self.mlp_layers if isinstance(m, nn.Linear)]
 
@@ -406,9 +394,13 @@ class MLPLayers(nn.Module):
             params = [t for lin, bn in zip(lins, bns) for t in (lin.weight, lin.bias, bn.weight, bn.bias)]
             if passes != 1 and (self.training and float(self.dropout) > 0.0):
                 raise ValueError("passes > 1 needs a module without dropout (two evaluations would differ)")
-            bn_buffers = [(bn.running_mean, bn.running_var, float(bn.eps), 1.0 - (1.0 - float(bn.momentum)) ** passes)
-                          for bn in bns]
-            self._count_batch(bns, passes)
+            # (num_batches_tracked moves by `passes` in each layer's fold launch, fr_bn_fwd_ex: no launch of its own;
+            # FAIRREC_BN_COUNT_SEPARATE=1: one multi-tensor add per forward instead, for A/B runs)
+            own_launch = os.environ.get("FAIRREC_BN_COUNT_SEPARATE") is not None
+            bn_buffers = [(bn.running_mean, bn.running_var, float(bn.eps), 1.0 - (1.0 - float(bn.momentum)) ** passes,
+                           None if own_launch else bn.num_batches_tracked, int(passes)) for bn in bns]
+            if own_launch:
+                torch._foreach_add_([bn.num_batches_tracked for bn in bns], int(passes))
         else:
             params = [t for lin in lins for t in (lin.weight, lin.bias)]
             bn_buffers = None

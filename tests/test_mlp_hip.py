@@ -385,10 +385,12 @@ def test_bn_statistics_from_the_product_epilogue_equal_the_statistics_launch(M, 
         else:
             _C.check(lib.fr_linear_fwd(x0.data_ptr(), k0, _C.ptr(x1), k1, None, 1.0, W.data_ptr(), b.data_ptr(), M, N, 0, Z.data_ptr(),
                                        st), "fr_linear_fwd")
+        nbt = torch.full((1,), 5, dtype=torch.int64, device=dev)
         _C.check(lib.fr_bn_fwd_ex(Z.data_ptr(), gamma.data_ptr(), beta.data_ptr(), 1e-5, 0.1, rm.data_ptr(), rv.data_ptr(), M, N, 2,
                                   Y.data_ptr(), xh.data_ptr(), inv.data_ptr(), ws.data_ptr(), ws.numel(), 1 if epilogue else 0,
-                                  None, 0.0, 0, 0, None, None, None, st), "fr_bn_fwd_ex")
+                                  None, 0.0, 0, 0, None, None, None, nbt.data_ptr(), 2, st), "fr_bn_fwd_ex")
         torch.cuda.synchronize()
+        assert int(nbt.item()) == 7        # the layer's batch counter moves by `passes` in the fold launch
         outs.append((Z, Y, xh, inv, rm, rv))
     a, r = outs
     assert torch.equal(a[0], r[0])
