@@ -209,3 +209,189 @@ def test_item_owner_kernels_match_their_cpu_doubles():
     touched_u, touched_i = uslot_c[(uslot_c >= 0) & (islot >= 0)].long(), islot[(uslot_c >= 0) & (islot >= 0)].long()
     np.testing.assert_allclose(gu_g.cpu().numpy()[touched_u], gu_c.numpy()[touched_u], rtol=2e-5, atol=1e-9)
     np.testing.assert_allclose(gi_g.cpu().numpy()[touched_i], gi_c.numpy()[touched_i], rtol=2e-5, atol=1e-9)
+
+
+# ---- the HIP kernels of the row-sharded step with G > 1 ranks -- on ONE GPU -----------------------------------------------------
+class _ThreadWorld:
+    """G "ranks" as G threads of this process, all on cuda:0, with torch.distributed's calls in fairrec/sharded.py served from
+    shared memory: what a rank would send is left in a slot, a barrier, every rank copies its share.  Exactly one thread runs at
+    any time (a baton handed over inside the collectives), so the library sees the single-threaded call sequence it is built
+    for, and the device is synchronised around every exchange (ranks produce on side streams).  It stands for RCCL only in WHAT
+    moves; what it proves is the kernels' side of a multi-rank step: owner buckets with several chunks, padded gathers, records
+    for other owners, replies -- the layouts a 1-rank world never produces."""
+
+    ReduceOp = dist.ReduceOp
+
+    def __init__(self, G):
+        import threading
+        self.G, self.local = G, threading.local()
+        self.slots = [None] * G
+        self.barrier = threading.Barrier(G)
+        self.baton = threading.Lock()
+
+    def get_world_size(self, group=None):
+        return self.G
+
+    def get_rank(self, group=None):
+        return self.local.rank
+
+    def _wait(self):
+        self.local.have = False
+        self.baton.release()
+        self.barrier.wait()          # (BrokenBarrierError when another rank failed: propagates without the baton)
+        self.baton.acquire()
+        self.local.have = True
+
+    def _meet(self, mine):
+        torch.cuda.synchronize()
+        self.slots[self.local.rank] = mine
+        self._wait()
+
+    def _part(self):
+        torch.cuda.synchronize()
+        self._wait()
+
+    def all_to_all_single(self, out, inp, group=None):
+        self._meet(inp)
+        r, n = self.local.rank, inp.shape[0] // self.G
+        for j in range(self.G):
+            out[j * n:(j + 1) * n].copy_(self.slots[j][r * n:(r + 1) * n])
+        self._part()
+
+    def all_reduce(self, t, op=None, group=None):
+        self._meet(t.clone())
+        acc = self.slots[0].clone()
+        for j in range(1, self.G):
+            acc = torch.maximum(acc, self.slots[j]) if op == dist.ReduceOp.MAX else acc + self.slots[j]
+        t.copy_(acc)
+        self._part()
+
+    def all_gather_into_tensor(self, out, inp, group=None):
+        self._meet(inp)
+        n = inp.shape[0]
+        for j in range(self.G):
+            out[j * n:(j + 1) * n].copy_(self.slots[j])
+        self._part()
+
+    def run(self, fn):
+        import threading
+        results, errors = [None] * self.G, []
+
+        def body(rank):
+            self.local.rank = rank
+            self.baton.acquire()
+            self.local.have = True
+            try:
+                results[rank] = fn(rank)
+            except BaseException as e:       # noqa: BLE001 -- reported below; the others must not wait for this rank forever
+                errors.append((rank, e))
+                self.barrier.abort()
+            finally:
+                if self.local.have:
+                    self.baton.release()
+
+        threads = [threading.Thread(target=body, args=(r,)) for r in range(self.G)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        real = [(r, e) for r, e in errors if not isinstance(e, __import__("threading").BrokenBarrierError)]
+        if real or errors:
+            raise (real or errors)[0][1]
+        return results
+
+
+@pytest.mark.parametrize("world,schedule,objective,hot",
+                         [(2, "requester", "value", False), (4, "requester", "value", True), (4, "requester", "nonparity", True),
+                          (8, "requester", "value", False), (2, "item_owner", "under", False), (4, "item_owner", "value", True)])
+def test_hip_kernels_of_a_multi_rank_step_match_the_oracle(world, schedule, objective, hot, monkeypatch):
+    """tests/test_sharded_gloo.py's check -- the sharded step on the concatenated global batch equals the single-process oracle,
+    losses and both tables -- with the HIP kernels instead of their CPU doubles and `_ThreadWorld` instead of gloo: G = 2, 4, 8
+    ranks on one GPU, both schedules, a Zipf-hot owner, look-ahead and inline index work."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+    import fairrec.sharded as S
+    from oracle import focf as O
+    from test_sharded_gloo import _case
+    tw = _ThreadWorld(world)
+    monkeypatch.setattr(S, "dist", tw)
+    z = _case(hot, world)
+    T, B = 6, z["user_id"].shape[1] // world
+    Engine = S.ShardedFocfEngineV2 if schedule == "item_owner" else S.ShardedFocfEngine
+    U0, I0 = torch.tensor(z["U0"]), torch.tensor(z["I0"])
+
+    def rank_fn(rank):
+        eng = Engine(S.shard_of(U0, rank, world).cuda(), S.shard_of(I0, rank, world).cuda(), objective, 0.8, 1e-3, 1e-3,
+                     capacity_factor=4.0 if hot else 1.5)
+        sl = slice(rank * B, (rank + 1) * B)
+        batches = [[torch.tensor(z[k][t][sl]).cuda() for k in ("user_id", "item_id", "rating", "sst")] for t in range(T)]
+        losses = []
+        for t in range(T):
+            nxt = (batches[t + 1][0], batches[t + 1][1], batches[t + 1][3], batches[t + 1][2]) if t + 1 < T and t % 3 != 2 else None
+            loss, _ = eng.forward(*batches[t], next_batch=nxt)
+            losses.append(float(loss))
+            eng.backward_adam()
+        eng.flush()
+        eng.check_device_errors()
+        torch.cuda.synchronize()
+        return {"U": eng.U.weight.cpu(), "I": eng.I.weight.cpu(), "loss": losses}
+
+    parts = tw.run(rank_fn)
+    Bg = B * world
+    ref = O.train(objective, z["U0"], z["I0"], z["user_id"][:T, :Bg], z["item_id"][:T, :Bg], z["rating"][:T, :Bg],
+                  z["sst"][:T, :Bg], 1e-3, 1e-3, 0.8, snaps=(T,))
+    for r in range(world):
+        np.testing.assert_allclose(parts[r]["loss"], ref["loss"], rtol=1e-4)
+    for tag in ("U", "I"):
+        full = np.zeros_like(ref[f"{tag}_after{T}"])
+        for r in range(world):
+            full[r::world] = parts[r][tag].numpy()
+        b = ref[f"{tag}_after{T}"]
+        assert (np.abs(full - b) <= 1e-4 * np.abs(b) + 1e-6).all(), (tag, np.abs(full - b).max())
+
+
+def test_hip_kernels_eight_ranks_item_complete_batches_drop_nothing(monkeypatch):
+    """tests/test_sharded_gloo.py::test_eight_ranks_item_complete_batches_drop_nothing with the HIP kernels: item-complete
+    batches whose items live on two of eight owners overflow the default exchange capacity; the engine notices on the device
+    (bucket fill counters, a MAX all-reduce), doubles the capacity, buckets again -- and every step equals the single-device
+    step on the concatenated batch."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+    import fairrec.sharded as S
+    from oracle import focf as O
+    from test_sharded_gloo import _item_complete_case
+    world = 8
+    tw = _ThreadWorld(world)
+    monkeypatch.setattr(S, "dist", tw)
+    z = _item_complete_case(world)
+    T, B = z["user_id"].shape[0], z["user_id"].shape[1] // world
+    U0, I0 = torch.tensor(z["U0"]), torch.tensor(z["I0"])
+
+    def rank_fn(rank):
+        eng = S.ShardedFocfEngine(S.shard_of(U0, rank, world).cuda(), S.shard_of(I0, rank, world).cuda(), "value", 0.8, 1e-3,
+                                  1e-3, capacity_factor=2.0)
+        sl = slice(rank * B, (rank + 1) * B)
+        batches = [[torch.tensor(z[k][t][sl]).cuda() for k in ("user_id", "item_id", "rating", "sst")] for t in range(T)]
+        cap0, losses = eng.capacity(B), []
+        for t in range(T):
+            nxt = (batches[t + 1][0], batches[t + 1][1], batches[t + 1][3], batches[t + 1][2]) if t + 1 < T and t % 2 == 0 else None
+            loss, _ = eng.forward(*batches[t], next_batch=nxt)
+            losses.append(float(loss))
+            eng.backward_adam()
+        eng.flush()
+        eng.check_device_errors()
+        torch.cuda.synchronize()
+        return {"U": eng.U.weight.cpu(), "I": eng.I.weight.cpu(), "loss": losses, "cap0": cap0, "cap1": eng.capacity(B),
+                "steps": eng.step_count}
+
+    parts = tw.run(rank_fn)
+    ref = O.train("value", z["U0"], z["I0"], z["user_id"], z["item_id"], z["rating"], z["sst"], 1e-3, 1e-3, 0.8, snaps=(T,))
+    for r in range(world):
+        assert parts[r]["steps"] == T and parts[r]["cap1"] > parts[r]["cap0"]
+        np.testing.assert_allclose(parts[r]["loss"], ref["loss"], rtol=1e-4)
+    for tag in ("U", "I"):
+        full = np.zeros_like(ref[f"{tag}_after{T}"])
+        for r in range(world):
+            full[r::world] = parts[r][tag].numpy()
+        b = ref[f"{tag}_after{T}"]
+        assert (np.abs(full - b) <= 1e-4 * np.abs(b) + 1e-6).all(), (tag, np.abs(full - b).max())
