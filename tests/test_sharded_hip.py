@@ -245,7 +245,7 @@ class _ThreadWorld:
         r = self._rank()
         self.have[r] = False
         self.baton.release()
-        self.barrier.wait()          # (BrokenBarrierError when another rank failed: propagates without the baton)
+        self.barrier.wait(timeout=120)    # (BrokenBarrierError when another rank failed or never came: without the baton)
         self.baton.acquire()
         self.have[r], self.current = True, r
 
@@ -299,9 +299,11 @@ class _ThreadWorld:
 
         threads = [threading.Thread(target=body, args=(r,)) for r in range(self.G)]
         for t in threads:
+            t.daemon = True          # (a rank that hangs must not keep the test process alive)
             t.start()
         for t in threads:
-            t.join()
+            t.join(timeout=600)
+            assert not t.is_alive(), "a rank of the thread world did not finish"
         real = [(r, e) for r, e in errors if not isinstance(e, __import__("threading").BrokenBarrierError)]
         if real or errors:
             raise (real or errors)[0][1]
