@@ -213,9 +213,20 @@ __global__ __launch_bounds__(256) void bpr_outer_kernel(const float* __restrict_
 }
 
 // da[j] = sum over the row blocks, in block order within quarters, quarters in order (fixed order => reproducible)
+// (one extra workgroup behind the column blocks sums the loss partials -- sum_partials_kernel's body, its launch saved)
 __global__ __launch_bounds__(256) void bpr_outer_reduce_kernel(const float* __restrict__ ga_part, int nblk, int B,
-                                                               float* __restrict__ da, float* __restrict__ nda) {
+                                                               float* __restrict__ da, float* __restrict__ nda,
+                                                               const float* __restrict__ loss_part, float* __restrict__ loss) {
     __shared__ float red[4][64];
+    if (loss && blockIdx.x == gridDim.x - 1) {
+        float a = 0.f;
+        for (int q = threadIdx.x; q < nblk; q += 256) a += loss_part[q];
+        a = wave_sum(a);
+        if ((threadIdx.x & 63) == 0) red[0][threadIdx.x >> 6] = a;
+        __syncthreads();
+        if (threadIdx.x == 0) loss[0] = (((red[0][0] + red[0][1]) + red[0][2]) + red[0][3]) * 1.f;
+        return;
+    }
     const int e = threadIdx.x & 63, part = threadIdx.x >> 6;
     const int j = blockIdx.x * 64 + e;
     const int per = (nblk + 3) / 4, k0 = part * per, k1 = min(nblk, k0 + per);
@@ -386,10 +397,8 @@ static int bpr_outer_impl(const float* a, const float* a2, const float* c, const
                   1.f / ((float)B * (float)B), dc, ndc, ga_part, loss_part);
     }
     FR_CHECK_LAUNCH();
-    hipLaunchKernelGGL(bpr_outer_reduce_kernel, dim3((unsigned)((B + 63) / 64)), dim3(256), 0, stream,
-                       (const float*)ga_part, nb, (int)B, da, nda);
-    FR_CHECK_LAUNCH();
-    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, stream, (const float*)loss_part, nb, 1.f, loss);
+    hipLaunchKernelGGL(bpr_outer_reduce_kernel, dim3((unsigned)((B + 63) / 64) + 1), dim3(256), 0, stream,
+                       (const float*)ga_part, nb, (int)B, da, nda, (const float*)loss_part, loss);
     FR_CHECK_LAUNCH();
     return FR_OK;
 }
@@ -419,12 +428,13 @@ extern "C" int fr_bpr_outer_rect(const float* a, int64_t Na, const float* c, int
     }
     FR_CHECK_LAUNCH();
     if (da) {
-        hipLaunchKernelGGL(bpr_outer_reduce_kernel, dim3((unsigned)((Na + 63) / 64)), dim3(256), 0, stream,
-                           (const float*)ga_part, nb, (int)Na, da, (float*)nullptr);
+        hipLaunchKernelGGL(bpr_outer_reduce_kernel, dim3((unsigned)((Na + 63) / 64) + 1), dim3(256), 0, stream,
+                           (const float*)ga_part, nb, (int)Na, da, (float*)nullptr, (const float*)loss_part, loss);
+        FR_CHECK_LAUNCH();
+    } else {
+        hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, stream, (const float*)loss_part, nb, 1.f, loss);
         FR_CHECK_LAUNCH();
     }
-    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, stream, (const float*)loss_part, nb, 1.f, loss);
-    FR_CHECK_LAUNCH();
     return FR_OK;
 }
 
