@@ -291,6 +291,24 @@ FR_API int fr_focf_step_staged(const fr_table* U, const fr_table* I, const fr_ad
                                uint32_t* err_flag, void* stream);
 FR_API int fr_focf_step_finish_staged(void* ws, size_t ws_bytes, int64_t B, int32_t dim, int32_t objective,
                                       float fair_weight, float* loss_out, float* loss_acc, void* stream);
+/*
+ * The step loop itself (trainer.py:181-196: `for batch in train_data: zero_grad; calculate_loss; backward; step`) for a run
+ * of `n` batches in ONE call: n launches of fr_focf_step_staged issued by the library, so the host pays one foreign call
+ * per run instead of an interpreter round trip per step.  Batch k is applied at step U->step + k (U->step = the step of
+ * the FIRST batch, as everywhere), with stamp first_stamp + k and generation (first_gen + k) % 3; its launch carries the
+ * place stage of batch k + 1 and the claim stage of batch k + 2 and reduces the loss of batch k - 1 into
+ * loss_ring[4 * ((first_slot + k - 1) % loss_slots)] and loss_acc (batch 0's launch reduces `prev_*`, an earlier staged
+ * batch still unreduced, or nothing when prev_ws is NULL).  The first two batches' stages take two launches of their own.
+ * Any four consecutive batches (and prev_ws with the first three) need four different workspaces, each zero-filled before
+ * its first use.  Nothing may be in flight through the stages when the call starts; the LAST batch's loss stays unreduced
+ * (hand it to the next call as prev_*, or to fr_focf_step_finish_staged).  Same launches, same bits as n calls of
+ * fr_focf_step_staged.
+ */
+FR_API int fr_focf_steps_many(const fr_table* U, const fr_table* I, const fr_adam* adam, const fr_focf_batch* batches,
+                              int32_t n, int32_t objective, float fair_weight, int32_t sweep_period, int32_t first_stamp,
+                              int32_t first_gen, void* prev_ws, int64_t prev_B, float* prev_loss_out, float* loss_ring,
+                              int32_t loss_slots, int32_t first_slot, float* loss_acc, uint64_t* row_words,
+                              uint32_t* err_flag, void* stream);
 
 /* FOCF.predict, focf.py:145-150: clamp(pred, 0, max_rating) / max_rating on up-to-date rows (read only). */
 FR_API int fr_focf_predict(const fr_table* U, const fr_table* I, const fr_adam* adam, const int64_t* user,

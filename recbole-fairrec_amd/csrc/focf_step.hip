@@ -1950,6 +1950,57 @@ extern "C" int fr_focf_step_staged(const fr_table* U, const fr_table* I, const f
                           prev_loss_out, loss_acc, err_flag, stream_, &st, row_words, gen);
 }
 
+// n consecutive steps of fr_focf_step_staged in one call: the step loop of trainer.py:181-196 over a run of batches, issued
+// by the library instead of by one interpreter round trip per step.  Batch k is applied at step U->step + k with stamp
+// first_stamp + k and generation (first_gen + k) % 3, carries the place stage of batch k + 1 and the claim stage of batch
+// k + 2, and reduces the loss of batch k - 1 (of `prev_*` for k = 0).  The first two batches' stages take two launches of
+// their own (fr_focf_stage).  The LAST batch's loss is left to the caller (the next call's prev_*, or
+// fr_focf_step_finish_staged), exactly as after a single fr_focf_step_staged.
+extern "C" int fr_focf_steps_many(const fr_table* U, const fr_table* I, const fr_adam* adam, const fr_focf_batch* batches,
+                                  int32_t n, int32_t objective, float fair_weight, int32_t sweep_period, int32_t first_stamp,
+                                  int32_t first_gen, void* prev_ws, int64_t prev_B, float* prev_loss_out, float* loss_ring,
+                                  int32_t loss_slots, int32_t first_slot, float* loss_acc, uint64_t* row_words,
+                                  uint32_t* err_flag, void* stream_) {
+    FR_CHECK_ARG(U && I && batches && n >= 1, "fr_focf_steps_many: null pointer / no batch");
+    FR_CHECK_ARG(loss_ring && loss_slots >= 1 && first_slot >= 0 && first_slot < loss_slots,
+                 "fr_focf_steps_many: loss ring (float[4 * loss_slots]) and a first slot inside it");
+    FR_CHECK_ARG(first_stamp >= 1 && first_stamp <= INT32_MAX - n && first_gen >= 0 && first_gen < 3,
+                 "fr_focf_steps_many: first stamp / generation");
+    FR_CHECK_ARG(U->step >= 1 && U->step == I->step && U->step <= INT32_MAX - n,
+                 "fr_focf_steps_many: table.step must be the step the FIRST batch is applied at (>= 1), the same for both tables");
+    // a workspace is busy from its batch's claim (two launches before its step) to the launch after its step (loss
+    // reduction, counters back to zero): any four consecutive batches need four different ones
+    for (int k = 0; k < n; ++k) {
+        FR_CHECK_ARG(batches[k].ws && batches[k].user && batches[k].item && batches[k].rating,
+                     "fr_focf_steps_many: batch %d: null pointer", k);
+        for (int j = k + 1; j < n && j <= k + 3; ++j)
+            FR_CHECK_ARG(batches[j].ws != batches[k].ws, "fr_focf_steps_many: batches %d and %d share a workspace", k, j);
+        FR_CHECK_ARG(k > 2 || batches[k].ws != prev_ws,
+                     "fr_focf_steps_many: batch %d uses the workspace whose loss is still to be reduced", k);
+    }
+    auto gen_of = [&](int k) { return (first_gen + k) % 3; };
+    int rc;
+    if ((rc = fr_focf_stage(U, I, &batches[0], first_stamp, gen_of(0), nullptr, 0, 0, sweep_period, row_words, err_flag, stream_)))
+        return rc;
+    if ((rc = fr_focf_stage(U, I, n > 1 ? &batches[1] : nullptr, first_stamp + 1, gen_of(1), &batches[0], first_stamp, gen_of(0),
+                            sweep_period, row_words, err_flag, stream_)))
+        return rc;
+    fr_table tu = *U, ti = *I;
+    for (int k = 0; k < n; ++k) {
+        const fr_focf_batch& b = batches[k];
+        const fr_focf_batch* place = k + 1 < n ? &batches[k + 1] : nullptr;
+        const fr_focf_batch* claim = k + 2 < n ? &batches[k + 2] : nullptr;
+        rc = fr_focf_step_staged(&tu, &ti, adam, b.sst, b.B, objective, fair_weight, sweep_period, first_stamp + k, gen_of(k),
+                                 b.ws, b.ws_bytes, prev_ws, prev_B, prev_loss_out, loss_acc, row_words, claim,
+                                 first_stamp + k + 2, gen_of(k + 2), place, first_stamp + k + 1, gen_of(k + 1), err_flag, stream_);
+        if (rc) return rc;
+        prev_ws = b.ws; prev_B = b.B;
+        prev_loss_out = loss_ring + 4 * (size_t)((first_slot + k) % loss_slots);
+        ++tu.step; ++ti.step;
+    }
+    return FR_OK;
+}
+
 #ifdef FR_LPT_STAMPS
 extern "C" __attribute__((visibility("default"))) int fr_debug_lpt_stamps(unsigned long long* host_out) {
     FR_CHECK_HIP(hipDeviceSynchronize());

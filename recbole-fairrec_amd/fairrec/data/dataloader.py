@@ -108,6 +108,27 @@ class TrainDataLoader(AbstractDataLoader):
             cur = self._neg_sampling(cur)
         return self.dataset.join(cur)
 
+    @property
+    def sliceable(self):
+        """A batch is a slice of the (shuffled) dataset and nothing more: `take` can hand out runs of batches."""
+        return self.sampler is None
+
+    def take(self, n_batches):
+        """The next `n_batches` batches of this epoch as ONE Interaction (their rows back to back) and the batch size --
+        what `n_batches` calls of next() would have yielded, for a consumer that walks a run of batches itself
+        (Trainer._train_epoch hands it to `model.train_steps`: one library call per run instead of an interpreter round
+        trip per batch).  None when the epoch is over.  The shuffle of `__iter__` has happened by then, so the slices are the reference's batches
+        (general_dataloader.py:59-65)."""
+        if self.sampler is not None:
+            raise TypeError('take(): this loader draws negatives per batch (check `sliceable` first)')
+        if self.pr >= self.pr_end:
+            self.pr = 0                       # as __next__ does when it raises StopIteration
+            return None
+        hi = min(self.pr + self.step * int(n_batches), self.pr_end)
+        cur = self.dataset.join(self.dataset[self.pr:hi])
+        self.pr = hi
+        return cur, self.step
+
 
 class FOCFDataLoader(AbstractDataLoader):
     """Item-complete batches: keep picking a random not-yet-picked item and append ALL its interactions until
@@ -122,22 +143,39 @@ class FOCFDataLoader(AbstractDataLoader):
         self.item_uniques = np.unique(items)
         # CSR by item over the item-sorted interaction array
         self.indptr = np.searchsorted(items, np.arange(self.item_num + 1), side="left")
+        self._epoch = []                  # index lists of the batches still to come this epoch, last first
         _prejoin(self.dataset)
 
+    def _compose_epoch(self):
+        """The interaction index lists of ALL batches of the epoch, drawn in one go.  Which rows form a batch depends on
+        nothing but numpy's generator and the item CSR, and nothing else draws from that generator while a training epoch of
+        FOCF runs (no negatives, no attribute masks), so drawing the epoch's picks ahead leaves every consumer at the
+        reference's position of the stream -- with ONE hand-over between numpy and its device mirror per epoch
+        (`host_numpy_stream`: the evaluation loaders' negatives come from the mirror) instead of one per batch."""
+        from ..sampler import host_numpy_stream
+        batches, pr = [], self.pr
+        with host_numpy_stream():
+            while pr < self.pr_end:
+                cnt = 0
+                select_item = np.arange(0, self.item_num)
+                is_select = np.zeros(self.item_num, dtype=bool)
+                is_select[self.item_uniques] = True
+                chunks = []
+                while cnt < self.step and is_select.any():
+                    iid = np.random.choice(select_item[is_select], 1, False)[0]   # same RNG consumption as the reference
+                    lo, hi = self.indptr[iid], self.indptr[iid + 1]
+                    cnt += hi - lo
+                    is_select[iid] = False
+                    chunks.append(np.arange(lo, hi))
+                pr += self.step
+                batches.append(np.concatenate(chunks))
+        return batches
+
     def _next_batch_data(self):
-        cnt = 0
-        select_item = np.arange(0, self.item_num)
-        is_select = np.zeros(self.item_num, dtype=bool)
-        is_select[self.item_uniques] = True
-        chunks = []
-        while cnt < self.step and is_select.any():
-            iid = np.random.choice(select_item[is_select], 1, False)[0]   # same RNG consumption as the reference
-            lo, hi = self.indptr[iid], self.indptr[iid + 1]
-            cnt += hi - lo
-            is_select[iid] = False
-            chunks.append(np.arange(lo, hi))
+        if not self._epoch:
+            self._epoch = self._compose_epoch()[::-1]
         self.pr += self.step
-        return self.dataset.join(self.dataset[np.concatenate(chunks)])
+        return self.dataset.join(self.dataset[self._epoch.pop()])
 
 
 class FullSortEvalDataLoader:

@@ -109,9 +109,12 @@ class Interaction:
         del self.interaction[column]
 
     def _reindex(self, index):
+        on = {}                     # the index crosses to a device once, not once per column
         for k in self.interaction:
             v = self.interaction[k]
-            self.interaction[k] = v[index.to(v.device)]
+            if v.device not in on:
+                on[v.device] = index.to(v.device)
+            self.interaction[k] = v[on[v.device]]
 
     def shuffle(self):
         self._reindex(torch.randperm(self.length))   # same RNG consumer as interaction.py:293-297

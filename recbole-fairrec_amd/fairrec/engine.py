@@ -276,8 +276,8 @@ class GenericEngine:
         for name, t in self._tables.items():
             t.flush(self._hyper(name))
 
-    def check_device_errors(self):
-        e = int(self.err_flag.item())
+    def check_device_errors(self, word=None):
+        e = int(self.err_flag.item()) if word is None else int(word)
         if e:
             self.err_flag.zero_()
             raise IndexError(f"device error word {e} (1: row id out of range, 2: unexpected sensitive groups)")

@@ -23,6 +23,11 @@ from ..abstract_recommender import FairRecommender
 from ..init import xavier_normal_initialization
 
 
+# fr_focf_batch (include/fairrec_hip.h) as a numpy record: a run of batches is described without a Python loop
+_BATCH_DTYPE = [("user", "<u8"), ("item", "<u8"), ("sst", "<u8"), ("B", "<i8"), ("ws", "<u8"), ("ws_bytes", "<u8"),
+                ("rating", "<u8")]
+
+
 class _LossHandle(torch.autograd.Function):
     """Gives the device loss scalar an autograd edge so that `loss.backward()` (trainer.py:193) is legal;
     the real backward runs fused with the Adam update in FocfEngine.backward_adam()."""
@@ -539,6 +544,99 @@ class FocfEngine:
         self.pending_B = 0
         self.backward_seen = False
 
+    # --- the step loop in the library (fr_focf_steps_many) ----------------------------------------------
+    RING = 8          # workspaces a run of steps cycles through (any four consecutive batches need four different ones)
+
+    def can_step_many(self) -> bool:
+        """A run of batches can go through fr_focf_steps_many: the staged one-launch step applies (what forward() checks per
+        batch) and nothing has to happen between a batch's loss and its update (clip_grad_norm)."""
+        return bool(self.staged and self.fused_step and self.defer_loss and self.optimizer is not None and self.objective != 5
+                    and not self.item_runs and self.U.step == self.I.step and not getattr(self.optimizer, "clip", None))
+
+    def steps_many(self, user, item, rating, sst, sizes):
+        """`calculate_loss` + `optimizer.step()` for a run of batches in ONE library call (fr_focf_steps_many: the step
+        loop of trainer.py:181-196 issued by the library -- one staged launch per batch, the coming two batches' index work
+        riding in each).  The columns hold the batches back to back: `sizes` = rows per batch, an int (every batch that
+        size, the last one whatever is left) or a sequence.  Losses go to the engine's running total (`loss_acc`), as with
+        `defer_loss`; same launches and same bits as the per-batch calls."""
+        import numpy as np
+        if not self.can_step_many():
+            raise _C.FairrecError("steps_many: the staged one-launch step does not apply to this engine state")
+        if self._stash is not None:
+            raise _C.FairrecError("steps_many with a calculate_loss() pending")
+        total = user.numel()
+        if isinstance(sizes, int):
+            n = (total + sizes - 1) // sizes
+            size = np.full(n, sizes, dtype=np.int64)
+            size[-1] = total - sizes * (n - 1)
+        else:
+            size = np.asarray(sizes, dtype=np.int64)
+            n = size.shape[0]
+        if n == 0:
+            return 0
+        if int(size.sum()) != total or int(size.min()) < 1 or int(size.max()) > _C.FR_SORT_MAX:
+            raise _C.FairrecError("steps_many: batch sizes do not add up to the columns (or a batch outside 1..FR_SORT_MAX)")
+        self._check_stamp_gen()
+        self.U.ensure_state()
+        self.I.ensure_state()
+        if self._pipe is not None or (self._prev is not None and not self._prev[3]):
+            self.finish()
+        self._forget_staged()                       # nothing may be on its way through the stages
+        self._gen_cur = None
+        if self._prep:
+            self._join_prepare()
+        start = np.concatenate(([0], np.cumsum(size)[:-1]))
+        # the ring of workspaces, all as large as the largest batch of the run; the one a pending loss sits in is skipped
+        Bmax = int(size.max())
+        held = self._prev[0] if self._prev is not None else None
+        ring = []
+        for k in range(self.N_WS):
+            if len(ring) == self.RING:
+                break
+            ws = self._workspace(Bmax, k)
+            if ws is held:
+                continue
+            if k in self._ws_dirty:
+                ws.zero_()
+                self._ws_dirty.discard(k)
+            ring.append((k, ws))
+        arr = np.zeros(n, dtype=_BATCH_DTYPE)
+        arr["user"] = user.data_ptr() + 8 * start
+        arr["item"] = item.data_ptr() + 8 * start
+        arr["rating"] = rating.data_ptr() + 4 * start
+        if self.objective != 0:
+            arr["sst"] = sst.data_ptr() + 4 * start
+        arr["B"] = size
+        slot = np.arange(n) % len(ring)
+        arr["ws"] = np.array([w.data_ptr() for _, w in ring], dtype=np.uint64)[slot]
+        arr["ws_bytes"] = np.array([w.numel() for _, w in ring], dtype=np.uint64)[slot]
+        step0 = self.U.step + 1
+        self.hyper.check_step(step0 + n - 1)
+        stamp0 = self._next_stamp()
+        self._stamp_last = stamp0 + n - 1
+        pw, pB, ploss, _ = self._prev if self._prev is not None else (None, 0, None, True)
+        slot0 = (self.loss_slot + 1) % self.LOSS_SLOTS
+        tu, ti = self.U.c(step0), self.I.c(step0)
+        rc = _C.lib().fr_focf_steps_many(ctypes.byref(tu), ctypes.byref(ti), ctypes.byref(self.hyper.c()),
+                                         arr.ctypes.data, n, self.objective, self.fair_weight, self._sweep(Bmax), stamp0, 0,
+                                         _C.ptr(pw), pB, _C.ptr(ploss), self.loss_ring.data_ptr(), self.LOSS_SLOTS, slot0,
+                                         self.loss_acc.data_ptr(), self._words().data_ptr(), self.err_flag.data_ptr(),
+                                         _C.current_stream())
+        if rc:                                      # launches may have been issued: every workspace of the ring is suspect
+            self._ws_dirty.update(k for k, _ in ring)
+            self._prev = None
+        _C.check(rc, "fr_focf_steps_many")
+        self.loss_slot = (slot0 + n - 1) % self.LOSS_SLOTS
+        k_last, ws_last = ring[(n - 1) % len(ring)]
+        self.ws_cur = k_last
+        self._prev = (ws_last, int(size[-1]), self._loss_views[self.loss_slot], True)
+        self._keep = (user, item, rating, sst)      # the launches read the columns: keep them alive until the next call
+        self.U.step += n
+        self.I.step += n
+        self.U._dirty = self.I._dirty = True
+        self.pending_B = 0
+        return n
+
     def reset_loss_acc(self):
         """Start a new running loss total (`loss_acc`: sums of loss, mse, fair over the steps taken with defer_loss on)."""
         self.finish()
@@ -591,10 +689,11 @@ class FocfEngine:
         self.U.flush(self.hyper)
         self.I.flush(self.hyper)
 
-    def check_device_errors(self):
-        """Host sync: raise what the reference would have raised eagerly (IndexError)."""
+    def check_device_errors(self, word=None):
+        """Host sync (none when the caller read the error word itself and passes it): raise what the reference would have
+        raised eagerly (IndexError)."""
         self.finish()
-        e = int(self.err_flag.item())
+        e = int(self.err_flag.item()) if word is None else int(word)
         if e:
             self.err_flag.zero_()
             msgs = []
@@ -689,6 +788,22 @@ class FOCF(FairRecommender):
         if torch.is_grad_enabled():
             return _LossHandle.apply(loss[0], eng, self.user_embedding_layer.weight, self.item_embedding_layer.weight)
         return loss[0]
+
+    def train_steps_ready(self):
+        """Whether `train_steps` would take a run of batches now (asked once per epoch, before the loader shuffles)."""
+        return self.hip_engine().can_step_many()
+
+    def train_steps(self, interaction, sizes):
+        """Optional trainer hook: `calculate_loss` + `optimizer.step()` for a RUN of batches held back to back in one
+        Interaction (`sizes`: rows per batch -- an int, or a sequence for ragged batches), the per-batch loop issued by the
+        library (FocfEngine.steps_many).  Returns the number of steps taken, or None when the engine's state calls for
+        the per-batch path (nonparity, clip_grad_norm, item-complete batches, a graph capture ...): the caller then
+        iterates the batches itself."""
+        eng = self.hip_engine()
+        if not eng.can_step_many():
+            return None
+        u, i, r, s = self._cols(interaction)
+        return eng.steps_many(u, i, r, s, sizes)
 
     def predict(self, interaction):
         u, i, _, _ = self._cols(interaction, need_targets=False)

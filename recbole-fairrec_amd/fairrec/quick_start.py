@@ -20,19 +20,30 @@ def split_dataset(dataset: InteractionDataset, ratios=(0.8, 0.1, 0.1)):
     return mk(slice(0, a)), mk(slice(a, b)), mk(slice(b, n))
 
 
-def run_recbole(model=None, dataset=None, config_file_list=None, config_dict=None, saved=True):
+def run_recbole(model=None, dataset=None, config_file_list=None, config_dict=None, saved=True, splits=None,
+                before_fit=None):
     """`dataset` is an InteractionDataset, or None for a synthetic one sized by config keys
-    `synthetic_users / synthetic_items / synthetic_interactions`."""
+    `synthetic_users / synthetic_items / synthetic_interactions`.  `splits` = (train, valid, test) InteractionDatasets
+    takes the place of the random split (a split made elsewhere, e.g. by the reference's `data_preparation`);
+    `before_fit(model, trainer)` runs right before `trainer.fit` (tests/test_e2e_hip.py loads recorded initial
+    parameters and generator states there)."""
     config = Config(model=model, dataset=getattr(dataset, 'name', 'synthetic'), config_file_list=config_file_list,
                     config_dict=config_dict)
     init_seed(config['seed'], config['reproducibility'])
     logger = getLogger()
-    if dataset is None:
-        dataset = synthetic_dataset(config, config['synthetic_users'] or 1000, config['synthetic_items'] or 500,
-                                    config['synthetic_interactions'] or 50000, seed=config['seed'])
-    train_set, valid_set, test_set = split_dataset(dataset)
+    if splits is not None:
+        train_set, valid_set, test_set = splits
+        for part in splits:
+            part.config = config
+    else:
+        if dataset is None:
+            dataset = synthetic_dataset(config, config['synthetic_users'] or 1000, config['synthetic_items'] or 500,
+                                        config['synthetic_interactions'] or 50000, seed=config['seed'])
+        train_set, valid_set, test_set = split_dataset(dataset)
     on_gpu = config['device'].type == 'cuda'
-    if config['model'] == 'FOCF' and config['item_grouped_batches']:
+    # FOCF trains on item-complete batches (the reference registers FOCFDataLoader for it whatever the config says,
+    # data/utils.py:181-186, :218-220); `item_grouped_batches: False` asks for plain fixed-size batches instead
+    if config['model'] == 'FOCF' and config['item_grouped_batches'] is not False:
         # the interaction columns live on the device (a host-resident dataset costs a copy per batch: 4.3 ms per step
         # instead of 0.07 at B = 8192); which interactions form a batch stays the reference's host logic
         train_data = FOCFDataLoader(config, train_set.to(config['device']) if on_gpu else train_set, shuffle=True)
@@ -62,6 +73,8 @@ def run_recbole(model=None, dataset=None, config_file_list=None, config_dict=Non
     model_obj = get_model(config['model'])(config, train_data.dataset).to(config['device'])
     logger.info(model_obj)
     trainer = get_trainer(None, config['model'])(config, model_obj)
+    if before_fit is not None:
+        before_fit(model_obj, trainer)
     best_valid_score, best_valid_result = trainer.fit(train_data, valid_data, saved=saved)
     try:
         test_result = trainer.evaluate(test_data, load_best_model=saved)

@@ -121,7 +121,34 @@ class Trainer(AbstractTrainer):
                 eng.defer_loss = False
         return self._train_epoch_body(train_data, loss_func, hint, graphed, fused, total, n_tuple)
 
+    def _steps_per_call(self):
+        """config `train_steps_per_call` (default 256; 0 = the per-batch loop even where the library could run it)."""
+        v = self.config['train_steps_per_call']
+        return 256 if v is None else int(v)
+
+    def _train_epoch_runs(self, train_data):
+        """The epoch of a model whose step loop the library can issue itself (`model.train_steps`, FOCF) over a loader whose
+        batches are slices of the dataset (`train_data.take`): one foreign call per run of `train_steps_per_call` batches
+        instead of an interpreter round trip per batch -- trainer.py:181-196 with the loop body in C."""
+        per_call = self._steps_per_call()
+        iter(train_data)                                       # the epoch's shuffle (general_dataloader.py:59-60)
+        while True:
+            got = train_data.take(per_call)
+            if got is None:
+                return
+            run, size = got
+            run = run.to(self.device)
+            with torch.no_grad():
+                if self.model.train_steps(run, size) is None:  # the engine's state asks for the per-batch path after all
+                    for lo in range(0, len(run), size):
+                        self.model.calculate_loss(run[lo:lo + size])
+                        self.optimizer.step()
+
     def _train_epoch_body(self, train_data, loss_func, hint, graphed, fused, total, n_tuple):
+        if (fused and graphed is None and self._steps_per_call() > 0 and getattr(train_data, 'sliceable', False)
+                and getattr(self.model, 'train_steps_ready', lambda: False)()):
+            self._train_epoch_runs(train_data)
+            return self._epoch_loss(True, 0)
         it = iter(train_data)
         # dataloader look-ahead: a model that can use it (FOCF sorts the coming batches' ids ahead, several per launch)
         # says how many batches it wants announced
@@ -165,6 +192,9 @@ class Trainer(AbstractTrainer):
             total = self._accumulate(total, part)
             loss.backward()
             self.optimizer.step()
+        return self._epoch_loss(total, n_tuple)
+
+    def _epoch_loss(self, total, n_tuple):
         if total is None:
             return 0.0
         if total is True:
@@ -174,12 +204,19 @@ class Trainer(AbstractTrainer):
             n_tuple_or_one = 1
         else:
             n_tuple_or_one = max(n_tuple, 1)
-        acc = total.cpu().tolist()                  # the epoch's only host sync
+        eng = self.model.hip_engine()
+        err = getattr(eng, 'err_flag', None)
+        word = None
+        if err is not None and err.numel() == 1 and err.dtype == torch.int32 and err.device == total.device:
+            # the device error word rides in the same read: the epoch's ONLY host sync
+            host = torch.cat((total.view(torch.int32), err)).cpu()
+            acc, word = host[:-1].view(torch.float32).tolist(), int(host[-1])
+        else:
+            acc = total.cpu().tolist()
         vals = acc[:n_tuple_or_one]
         self._check_nan(torch.tensor(vals), first_bad_step=int(acc[4]))
-        eng = self.model.hip_engine()
         if eng is not None:
-            eng.check_device_errors()
+            eng.check_device_errors() if word is None else eng.check_device_errors(word)
         return tuple(vals) if n_tuple else vals[0]
 
     def _accumulate(self, acc, part):

@@ -6,7 +6,7 @@ from fairrec.config import Config
 from fairrec.data.dataloader import TrainDataLoader
 from fairrec.data.dataset import synthetic_dataset
 from fairrec.utils import get_model, get_trainer, init_seed
-NU, NI, B, STEPS = 1_000_001, 100_001, 8192, 300
+NU, NI, B, STEPS = 1_000_001, 100_001, 8192, int(os.environ.get("STEPS", 300))
 on_dev = sys.argv[1:] == ["device"]
 cfg = Config(model="FOCF", config_dict={"embedding_size": 64, "train_batch_size": B, "device": "cuda", "epochs": 1,
                                         "fair_objective": "value", "weight_decay": 1e-3, "eval_step": 0,

@@ -191,6 +191,176 @@ def run_reference(case, model_name, dataset, overrides, trainer_expected, loader
         os.chdir(cwd)
 
 
+def plain(res):
+    """A metric dict (or PFCN's dict of them, one per attribute subset) as plain floats."""
+    return {k: (plain(v) if isinstance(v, dict) else float(v)) for k, v in res.items()}
+
+
+def run_reference_flow(case, model_name, dataset, overrides, trainer_expected, loader_expected, full_ids=False):
+    """The WHOLE of quick_start.run_recbole (quick_start.py:32-61): fit WITH validation every epoch (trainer.py:332-418:
+    `_valid_epoch` -> `evaluate` -> early_stopping -> `_save_checkpoint` on improvement) and the final
+    `evaluate(test_data, load_best_model=True)` (trainer.py:458-515).  With `eval_args.mode: uni100` the evaluation loaders
+    draw 100 negatives per positive, user by user (general_dataloader.py:141-146), from the SAME numpy stream the training
+    loader's item picks / negative draws / attribute masks come from, so every evaluation moves the batches of the epochs
+    after it.  Recorded on top of run_reference's keys:
+
+      valid.* / test.*      the two evaluation splits as their loaders hold them (sorted by user)
+      step_sha / step_rows  per training batch k: sha256 over the int64 user, item (and negative item) columns of the k-th training batch, its size
+                            (the ids themselves for k < 2, or for every step when `full_ids`)
+      eval<j>.phase         'valid<epoch>' or 'test' for the j-th evaluate() call, eval<j>.result its metric dict (json)
+      eval<j>.sha / .rows   per batch k of that evaluation: sha256 over the int64 item column (positives then sampled negatives,
+                            user by user) followed by the user column, and its size; eval<j>.b<k>.item_id / user_id in full for
+                            k = 0 (every batch when `full_ids`)
+      saved_epochs          epochs at which the trainer wrote its checkpoint; best_valid_score, best_valid_result, test_result
+    """
+    import hashlib
+    from recbole.config import Config
+    from recbole.data import create_dataset, data_preparation
+    from recbole.utils import get_model, get_trainer, init_seed
+    work = tempfile.mkdtemp(prefix="e2e_")
+    cwd = os.getcwd()
+    os.chdir(work)
+    try:
+        ypath = os.path.join(work, "override.yaml")
+        with open(ypath, "w") as f:
+            yaml.safe_dump(overrides, f)
+        config = Config(model=model_name, dataset=dataset, config_file_list=[ypath])
+        init_seed(config["seed"], config["reproducibility"])
+        ds = create_dataset(config)
+        train_data, valid_data, test_data = data_preparation(config, ds)
+        init_seed(config["seed"], config["reproducibility"])
+        model = get_model(config["model"])(config, train_data.dataset).to(config["device"])
+        trainer = get_trainer(config["MODEL_TYPE"], config["model"])(config, model)
+        assert type(trainer).__name__ == trainer_expected, type(trainer).__name__
+        assert type(train_data).__name__ == loader_expected, type(train_data).__name__
+        assert type(valid_data).__name__ == "NegSampleEvalDataLoader", type(valid_data).__name__
+        out = {}
+        for k, v in model.state_dict().items():
+            out["init." + k] = v.detach().cpu().numpy().copy()
+        for k, v in dict_mlps(model).items():
+            out["init." + k] = v
+        for tag, data in (("train", train_data), ("valid", valid_data), ("test", test_data)):
+            feat = data.dataset.inter_feat
+            for k in feat.interaction:
+                out[f"{tag}." + k] = narrow(feat[k].numpy().copy())
+        uf = train_data.dataset.get_user_feature()
+        for k in uf.interaction:
+            out["user_feat." + k] = narrow(uf[k].numpy().copy())
+        out["n_users"], out["n_items"] = np.array(train_data.dataset.user_num), np.array(train_data.dataset.item_num)
+        out["eval_step_users"] = np.array([valid_data.step, test_data.step])
+        st = np.random.get_state()
+        out["rng.np_key"], out["rng.np_pos"] = st[1].copy(), np.array(st[2])
+        out["rng.torch"] = torch.get_rng_state().numpy().copy()
+        lis = Listener(model)
+        epoch_losses, evals, saved_epochs = [], [], []
+        orig_epoch, orig_eval, orig_save, orig_predict = trainer._train_epoch, trainer.evaluate, trainer._save_checkpoint, model.predict
+        cur = {"batches": None}
+
+        def epoch(*a, **kw):
+            r = orig_epoch(*a, **kw)
+            epoch_losses.append([float(x) for x in r] if isinstance(r, tuple) else [float(r)])
+            return r
+
+        def listen_eval(fn):
+            def evaluate(eval_data, *a, **kw):
+                cur["batches"] = []
+                res = fn(eval_data, *a, **kw)
+                phase = "test" if eval_data is test_data else f"valid{len(epoch_losses) - 1}"
+                evals.append({"phase": phase, "result": plain(res), "batches": cur["batches"]})
+                cur["batches"] = None
+                return res
+            return evaluate
+
+        def predict(interaction, *a, **kw):
+            if cur["batches"] is not None:
+                cur["batches"].append({k: v.detach().cpu().numpy().copy() for k, v in interaction.interaction.items()
+                                       if k in ("user_id", "item_id")})
+            return orig_predict(interaction, *a, **kw)
+
+        def save(epoch_idx, *a, **kw):
+            saved_epochs.append(int(epoch_idx))
+            return orig_save(epoch_idx, *a, **kw)
+        trainer._train_epoch, trainer.evaluate, trainer._save_checkpoint, model.predict = epoch, listen_eval(orig_eval), save, predict
+        if hasattr(trainer, "pfcn_evaluate"):       # PFCNTrainer validates through a method of its own (trainer.py:965-1030)
+            trainer.pfcn_evaluate = listen_eval(trainer.pfcn_evaluate)
+        best_valid_score, best_valid_result = trainer.fit(train_data, valid_data, saved=True, show_progress=False, verbose=False)
+        test_result = trainer.evaluate(test_data, load_best_model=True, show_progress=False)
+        for k, v in model.state_dict().items():          # = the best checkpoint's parameters (loaded for the test evaluation)
+            out["final." + k] = v.detach().cpu().numpy().copy()
+        out["kind"] = np.array([s["kind"] for s in lis.steps])
+        out["sst"] = np.array([s["sst"] for s in lis.steps])
+        width = max(len(s["loss"]) for s in lis.steps)
+        out["loss"] = np.array([s["loss"] + [np.nan] * (width - len(s["loss"])) for s in lis.steps], dtype=np.float64)
+        out["epoch_loss"] = np.array(json.dumps(epoch_losses))
+        step_sha, step_rows = [], []
+        for k, s in enumerate(lis.steps):                 # ids only (the other columns follow from the splits): a digest per
+            h = hashlib.sha256()                          # training batch, the ids themselves for the first two
+            for name in ("user_id", "item_id", "neg_item_id"):
+                if name in s["cols"]:
+                    h.update(s["cols"][name].astype(np.int64).tobytes())
+                    if k < 2 or full_ids:
+                        out[f"step{k}.{name}"] = narrow(s["cols"][name])
+            step_sha.append(h.hexdigest())
+            step_rows.append(len(s["cols"]["user_id"]))
+        out["step_sha"], out["step_rows"] = np.array(step_sha), np.array(step_rows)
+        n_ids = 0
+        for j, ev in enumerate(evals):
+            out[f"eval{j}.phase"] = np.array(ev["phase"])
+            out[f"eval{j}.result"] = np.array(json.dumps(ev["result"]))
+            out[f"eval{j}.n_batches"] = np.array(len(ev["batches"]))
+            out[f"eval{j}.sha"] = np.array([hashlib.sha256(b["item_id"].astype(np.int64).tobytes() +
+                                                           b["user_id"].astype(np.int64).tobytes()).hexdigest() for b in ev["batches"]])
+            out[f"eval{j}.rows"] = np.array([len(b["item_id"]) for b in ev["batches"]])
+            for k, b in enumerate(ev["batches"]):
+                n_ids += len(b["item_id"])
+                if k == 0 or full_ids:
+                    out[f"eval{j}.b{k}.item_id"] = b["item_id"].astype(np.int16 if b["item_id"].max() < 2 ** 15 else np.int32)
+                    out[f"eval{j}.b{k}.user_id"] = b["user_id"].astype(np.int16 if b["user_id"].max() < 2 ** 15 else np.int32)
+        out["n_evals"] = np.array(len(evals))
+        out["saved_epochs"] = np.array(saved_epochs)
+        out["best_valid_score"] = np.array(float(best_valid_score))
+        out["best_valid_result"] = np.array(json.dumps(plain(best_valid_result)))
+        out["test_result"] = np.array(json.dumps(plain(test_result)))
+        keep = ("embedding_size", "learning_rate", "weight_decay", "train_batch_size", "epochs", "fair_objective", "fair_weight",
+                "filter_mode", "dis_weight", "dis_hidden_size_list", "dis_dropout", "activation", "train_epoch_interval",
+                "sst_attr_list", "neg_sampling", "seed", "RATING_FIELD", "LABEL_FIELD", "threshold", "clip_grad_norm",
+                "save_sst_embed", "eval_step", "stopping_step", "metrics", "topk", "valid_metric", "eval_batch_size",
+                "metric_decimal_place", "popularity_ratio", "eval_args")
+        out["config"] = np.array(json.dumps({k: config[k] for k in keep if k in config.final_config_dict}, default=str))
+        out["model"], out["trainer"], out["loader"] = np.array(model_name), np.array(trainer_expected), np.array(loader_expected)
+        path = os.path.join(HERE, f"e2e_{case}.npz")
+        np.savez_compressed(path, **out)
+        print(f"{path}: {len(lis.steps)} steps, {len(evals)} evaluations ({n_ids} scored ids), saved at epochs {saved_epochs}, "
+              f"best valid {best_valid_score}, epoch losses {epoch_losses}, {os.path.getsize(path) / 1e6:.2f} MB")
+        print("  test_result", test_result)
+    finally:
+        os.chdir(cwd)
+
+
+# the metric list, cut-off and evaluation mode of the reference's own test.yaml (test.yaml:34-43)
+TEST_YAML_EVAL = {"eval_args": {"split": {"RS": [8, 1, 1]}, "group_by": "user", "order": "RO", "mode": "uni100"},
+                  "metrics": ["NDCG", "Recall", "Hit", "MRR", "DifferentialFairness", "GiniIndex", "PopularityPercentage",
+                              "ValueUnfairness", "AbsoluteUnfairness", "UnderUnfairness", "OverUnfairness", "NonParityUnfairness"],
+                  "valid_metric": "NDCG@5", "topk": [5], "popularity_ratio": 0.1, "eval_batch_size": 8192, "eval_step": 1}
+
+
+def case_flow_focf_ml100k():
+    """BASELINE.json configs[0] as `run_recbole.py -m FOCF -d ml-100k` really runs: 3 epochs, validation after each, the best
+    checkpoint reloaded, test evaluation -- with test.yaml's evaluation settings."""
+    run_reference_flow("flow_focf_ml100k", "FOCF", "ml-100k", dict(TEST_YAML_EVAL, **{
+        "data_path": os.path.join(REF, "recbole", "dataset_example") + "/", "RATING_FIELD": "rating", "LABEL_FIELD": "label",
+        "threshold": {"rating": 3.0}, "load_col": {"inter": ["user_id", "item_id", "rating"], "user": ["user_id", "gender"]},
+        "sst_attr_list": ["gender"], "embedding_size": 64, "fair_objective": "value", "fair_weight": 1.0, "epochs": 3,
+        "seed": 2020, "use_gpu": False, "show_progress": False, "save_sst_embed": False}), "Trainer", "FOCFDataLoader")
+
+
+def case_flow_pfcn_biasedmf():
+    run_reference_flow("flow_pfcn_biasedmf_sm", "PFCN_BiasedMF", "synth", dict(COMMON, **dict(TEST_YAML_EVAL, **{
+        "data_path": _synth_root(), "embedding_size": 16, "filter_mode": "sm", "dis_hidden_size_list": [32, 16], "dis_dropout": 0.0,
+        "dis_weight": 10, "train_epoch_interval": 1, "weight_decay": 1e-4, "epochs": 3, "save_sst_embed": False})),
+        "PFCN_BiasedMFTrainer", "TrainDataLoader", full_ids=True)
+
+
 def case_focf_ml100k():
     """BASELINE.json configs[0]: `run_recbole.py -m FOCF -d ml-100k`, embedding_size 64, with the override yaml SURVEY.md §8-d /
     App. B-11 prescribes (the model yaml's data settings are shadowed by sample.yaml / ml-100k.yaml)."""
@@ -232,7 +402,8 @@ def case_nfcf_pretrain():
 
 
 CASES = {"focf_ml100k": case_focf_ml100k, "pfcn_biasedmf": case_pfcn_biasedmf, "fairgo_pmf": case_fairgo_pmf,
-         "nfcf_pretrain": case_nfcf_pretrain}
+         "nfcf_pretrain": case_nfcf_pretrain, "flow_focf_ml100k": case_flow_focf_ml100k,
+         "flow_pfcn_biasedmf": case_flow_pfcn_biasedmf}
 
 if __name__ == "__main__":
     names = [a for a in ARGV if a in CASES] or list(CASES)

@@ -249,3 +249,125 @@ def test_focf_ml100k_per_step_losses():
     worst = _check_final(z, model)
     assert worst[0] <= 1.0, worst
     eng.check_device_errors()
+
+
+# ---- the whole of run_recbole: fit WITH validation, early stopping bookkeeping, best checkpoint, test evaluation ---------
+FLOW_CASES = ["flow_focf_ml100k", "flow_pfcn_biasedmf_sm"]
+
+
+def _split(z, cfg, tag):
+    from fairrec.data.dataset import InteractionDataset
+    from fairrec.data.interaction import Interaction
+    as_t = lambda a, name: torch.from_numpy(a.astype(np.int64) if name.endswith("_id") else a.astype(np.float32))
+    cols = {k[len(tag) + 1:]: as_t(z[k], k[len(tag) + 1:]) for k in z.files if k.startswith(tag + ".")}
+    users = {k[10:]: as_t(z[k], k[10:]) for k in z.files if k.startswith("user_feat.")}
+    return InteractionDataset(cfg, Interaction(cols), Interaction(users), int(z["n_users"]), int(z["n_items"]))
+
+
+def _sha(*cols):
+    import hashlib
+    h = hashlib.sha256()
+    for c in cols:
+        h.update(c.detach().to(torch.int64).cpu().numpy().tobytes())
+    return h.hexdigest()
+
+
+def _same_metrics(got, ref, what, places=4):
+    """Metric dicts at the reference's `metric_decimal_place` (both sides round to it: one unit of the last place)."""
+    assert set(got) == set(ref), (what, sorted(got), sorted(ref))
+    for k, v in ref.items():
+        if isinstance(v, dict):
+            _same_metrics(got[k], v, f"{what}[{k}]", places)
+        elif v != v:
+            assert got[k] != got[k], (what, k, got[k])
+        else:
+            assert abs(float(got[k]) - v) <= 1.0001 * 10.0 ** -places, (what, k, float(got[k]), v)
+
+
+@pytest.mark.parametrize("case", FLOW_CASES)
+def test_run_recbole_with_validation_reproduces_the_reference_run(case, tmp_path):
+    """`run_recbole` as the reference runs it (quick_start.py:32-61; tests/golden/gen_e2e_golden.py::run_reference_flow):
+    trainer.fit(train_data, valid_data, saved=True) with `eval_step: 1`, `uni100` evaluation loaders and test.yaml's metric
+    list, then trainer.evaluate(test_data, load_best_model=True).  Every evaluation draws 100 negatives per positive from
+    the numpy stream the training loader draws from (FOCFDataLoader's item picks / the pair-wise negatives and the
+    attribute masks), so the flow is right only if EVERY consumer takes exactly its share in the reference's order.
+    fairrec.quick_start.run_recbole starts from the recorded splits, initial parameters and generator states and must
+    reproduce: every training batch and every scored evaluation batch bit for bit (sha256 of the id columns; the first
+    batch of every evaluation also id by id), the per-epoch losses, every validation result and the test result at the
+    reference's `metric_decimal_place`, the epochs at which a checkpoint was written, best_valid_score / best_valid_result."""
+    from fairrec.quick_start import run_recbole
+    from fairrec.trainer.trainer import Trainer
+    z = _load(case)
+    c = {k: v for k, v in json.loads(str(z["config"])).items() if v is not None or k in ("neg_sampling", "clip_grad_norm")}
+    # (eager steps: the listeners below sit on the loss functions, which a captured step calls once; the captured form of
+    # the same fits is held to the reference by test_captured_steps_reproduce_the_reference_run)
+    c.update(device="cuda", checkpoint_dir=str(tmp_path), graph_train_step=False)
+    from fairrec.config import Config
+    probe = Config(model=str(z["model"]), dataset="e2e", config_dict=c)
+    splits = tuple(_split(z, probe, tag) for tag in ("train", "valid", "test"))
+    seen = {"train": [], "evals": [], "saved": [], "epoch_loss": [], "cur": None}
+
+    def before_fit(model, trainer):
+        assert type(trainer).__name__ == str(z["trainer"])
+        _load_init(model, z)
+        orig_predict = model.predict
+        orig_eval, orig_save, orig_epoch = trainer._ranking_evaluate, trainer._save_checkpoint, trainer._train_epoch
+        seen["lis"] = _Listen(model)
+
+        def predict(interaction, *a, **kw):
+            if seen["cur"] is not None:
+                seen["cur"].append((_sha(interaction["item_id"], interaction["user_id"]), len(interaction),
+                                    (interaction["item_id"].clone(), interaction["user_id"].clone()) if not seen["cur"] else None))
+            return orig_predict(interaction, *a, **kw)
+
+        def evaluate(eval_data, *a, **kw):
+            seen["cur"] = []
+            res = orig_eval(eval_data, *a, **kw)
+            seen["evals"].append((res, seen["cur"]))
+            seen["cur"] = None
+            return res
+
+        def save(epoch, *a, **kw):
+            seen["saved"].append(int(epoch))
+            return orig_save(epoch, *a, **kw)
+
+        def epoch(*a, **kw):
+            r = orig_epoch(*a, **kw)
+            seen["epoch_loss"].append([float(x) for x in r] if isinstance(r, tuple) else [float(r)])
+            return r
+        model.predict = predict
+        trainer._ranking_evaluate, trainer._save_checkpoint, trainer._train_epoch = evaluate, save, epoch
+        _restore_streams(z)
+
+    out = run_recbole(model=str(z["model"]), config_dict=c, saved=True, splits=splits, before_fit=before_fit)
+
+    # training batches: every filter / discriminator step, in the reference's order, bit for bit
+    steps = seen["lis"].steps
+    assert [k for k, _, _, _ in steps] == [str(k) for k in z["kind"]]
+    assert [s for _, s, _, _ in steps] == [str(s) for s in z["sst"]]
+    for t, (kind, sst, cols, _) in enumerate(steps):
+        assert len(cols["user_id"]) == int(z["step_rows"][t]), (t, len(cols["user_id"]), int(z["step_rows"][t]))
+        sha = _sha(*(cols[k] for k in ("user_id", "item_id", "neg_item_id") if k in cols))
+        assert sha == str(z["step_sha"][t]), f"training batch {t} ({kind}) differs from the reference's"
+    # evaluations: phases, every scored batch, results
+    n_evals = int(z["n_evals"])
+    phases = [str(z[f"eval{j}.phase"]) for j in range(n_evals)]
+    assert len(seen["evals"]) == n_evals, (len(seen["evals"]), phases)      # (PFCN: one attribute subset, one call per phase)
+    for j, (res, batches) in enumerate(seen["evals"]):
+        want_sha, want_rows = [str(s) for s in z[f"eval{j}.sha"]], z[f"eval{j}.rows"].tolist()
+        assert [b[1] for b in batches] == want_rows, f"evaluation {j} ({phases[j]}): batch sizes"
+        items0, users0 = batches[0][2]
+        np.testing.assert_array_equal(items0.cpu().numpy(), z[f"eval{j}.b0.item_id"].astype(np.int64))
+        np.testing.assert_array_equal(users0.cpu().numpy(), z[f"eval{j}.b0.user_id"].astype(np.int64))
+        bad = [k for k, (b, s) in enumerate(zip(batches, want_sha)) if b[0] != s]
+        assert not bad, f"evaluation {j} ({phases[j]}): batches {bad[:5]}... differ (sampled negatives)"
+        ref = json.loads(str(z[f"eval{j}.result"]))
+        if phases[j] == "test" and str(z["model"]).startswith("PFCN"):
+            ref = next(iter(ref.values()))       # the reference's PFCN test result is keyed by the attribute subset
+        _same_metrics(dict(res), ref, f"evaluation {j} ({phases[j]})")
+    np.testing.assert_allclose(np.array(seen["epoch_loss"]), np.array(json.loads(str(z["epoch_loss"]))), rtol=1e-4)
+    assert seen["saved"] == z["saved_epochs"].tolist()
+    assert abs(out["best_valid_score"] - float(z["best_valid_score"])) <= 1.0001e-4
+    _same_metrics(dict(out["best_valid_result"]), json.loads(str(z["best_valid_result"])), "best_valid_result")
+    _same_metrics({k: (dict(v) if isinstance(v, dict) else v) for k, v in out["test_result"].items()},
+                  json.loads(str(z["test_result"])), "test_result")

@@ -287,6 +287,113 @@ def test_in_launch_prepare_with_tiny_and_ragged_batches(B):
     torch.testing.assert_close(engs[1].loss_acc[:3], engs[0].loss_acc[:3], rtol=1e-5, atol=1e-7)
 
 
+@pytest.mark.parametrize("path", CASES, ids=[os.path.basename(p)[:-4] for p in CASES])
+def test_steps_many_matches_reference_golden(path):
+    """The step loop issued by the library (fr_focf_steps_many: one call per run of batches, trainer.py:181-196 with its body
+    in C) on every golden it applies to: the runs are cut at the snapshot steps, every per-step loss comes out of the loss
+    ring the calls fill."""
+    z = np.load(path)
+    if "clip_max_norm" in z or str(z["objective"]) == "nonparity":
+        pytest.skip("needs a batch-wide value between loss and update: per-batch path")
+    eng = _engine(z, 3)
+    eng.defer_loss = True
+    assert eng.can_step_many()
+    T, B = z["user_id"].shape
+    cols = [torch.tensor(z[k], device="cuda").reshape(-1) for k in ("user_id", "item_id", "rating", "sst")]
+    snaps = sorted(set(int(s) for s in z["snaps"]) | {T})
+    t0 = 0
+    for t1 in snaps:
+        if t1 > t0:
+            assert eng.steps_many(*(c[t0 * B:t1 * B] for c in cols), B) == t1 - t0
+        t0 = t1
+        if f"U_after{t1}" in z:
+            eng.flush()
+            for tag, tab in (("U", eng.U), ("I", eng.I)):
+                _close(tab.weight.cpu().numpy(), z[f"{tag}_after{t1}"], f"{tag} after {t1}")
+                mref, vref = z[f"m{tag}_after{t1}"], z[f"v{tag}_after{t1}"]
+                _close(tab.m.cpu().numpy(), mref, f"m{tag} after {t1}", atol=1e-6 * np.abs(mref).max())
+                _close(tab.v.cpu().numpy(), vref, f"v{tag} after {t1}", atol=1e-6 * np.abs(vref).max())
+    eng.finish()
+    assert eng._prev is None and eng.U.step == T and T <= eng.LOSS_SLOTS
+    got = eng.loss_ring.cpu().numpy()[(np.arange(T) + 1) % eng.LOSS_SLOTS, 0]
+    _close(got, z["loss"], "loss curve", atol=1e-6)
+    np.testing.assert_allclose(float(eng.loss_acc[0]), float(np.sum(z["loss"], dtype=np.float64)), rtol=1e-4)
+    eng.check_device_errors()
+
+
+@pytest.mark.parametrize("wd", [0.0, 1e-3], ids=["wd0", "wd1e-3"])
+@pytest.mark.parametrize("ragged", [False, True], ids=["uniform", "ragged"])
+@pytest.mark.parametrize("objective", ["none", "value"])
+def test_steps_many_equals_the_per_batch_staged_loop(objective, ragged, wd):
+    """fr_focf_steps_many issues the launches of fr_focf_step_staged: against the per-batch loop fed by a two-deep queue --
+    with runs of 1, 2, 3 and many batches (the pipeline starts and drains inside every call), batch sizes that differ inside
+    a run, shared rows with long member lists, and per-batch steps taken between two runs (the pending loss handed from one
+    form to the other).  Without weight decay a replay is the same fp32 sequence however it is cut, so tables, moments,
+    every step's loss and the running total must be EQUAL BIT FOR BIT; with it, a row's missed steps replayed in one stretch
+    or in two (the sweeper of step k races the claim of batch k + 2 for the row's stamp, in either form) differ by the
+    rounding of the moment scaling: a few ulp."""
+    from fairrec.model.fair_recommender.focf import FocfEngine
+    from fairrec.optim import FusedLazyAdam
+    n_users, n_items, D, T, B = 4001, 2001, 64, 23, 1200
+    g = torch.Generator().manual_seed(29)
+    sizes = [B] * T
+    if ragged:
+        sizes = [int(x) for x in torch.randint(1, B + 1, (T,), generator=g)]
+        sizes[4], sizes[5] = 1, 65
+    tot = sum(sizes)
+    u = torch.randint(1, n_users, (tot,), generator=g)
+    i = torch.randint(1, n_items, (tot,), generator=g)
+    i[100:320] = 7                       # an item with 220 members in the first batch(es)
+    u[50:90] = 11
+    r = torch.randint(1, 6, (tot,), generator=g).float()
+    gender = torch.randint(0, 2, (n_users,), generator=g).float()
+    u, i, r = u.cuda(), i.cuda(), r.cuda()
+    s = gender.cuda()[u]
+    U0 = (torch.randn(n_users, D, generator=g) * 0.1).cuda()
+    I0 = (torch.randn(n_items, D, generator=g) * 0.1).cuda()
+    start = np.concatenate(([0], np.cumsum(sizes)))
+    cut = lambda c, a, b: c[int(start[a]):int(start[b])]
+    engs = []
+    for _ in range(2):
+        eng = FocfEngine(U0.clone(), I0.clone(), objective, 0.5, 5.0)
+        FusedLazyAdam(eng, lr=1e-2, weight_decay=wd, sweep_period=5)
+        eng.defer_loss = True
+        engs.append(eng)
+    a, b = engs
+    # a: one batch per call, the queue announcing two ahead INSIDE the same runs b takes (a run starts with nothing staged)
+    runs = [(0, 1), (1, 3), (3, 6), (6, 7), (7, 8), (8, 20), (20, T)]
+    per_batch_between = {6, 7}           # b takes these two single-batch runs through forward / backward_adam as well
+    for lo, hi in runs:
+        for t in range(lo, hi):
+            nxt = [tuple(cut(c, j, j + 1) for c in (u, i, s, r)) for j in range(t + 1, min(t + 3, hi))] or None
+            a.forward(cut(u, t, t + 1), cut(i, t, t + 1), cut(r, t, t + 1), cut(s, t, t + 1), next_batch=nxt)
+            a.backward_adam()
+        if lo in per_batch_between:
+            b.forward(cut(u, lo, hi), cut(i, lo, hi), cut(r, lo, hi), cut(s, lo, hi))
+            b.backward_adam()
+        else:
+            n = b.steps_many(cut(u, lo, hi), cut(i, lo, hi), cut(r, lo, hi), cut(s, lo, hi),
+                             sizes[lo:hi] if ragged else B)
+            assert n == hi - lo
+        assert a.U.step == b.U.step == hi
+    for eng in engs:
+        eng.flush()
+        eng.check_device_errors()
+    for name in ("weight", "m", "v", "last"):
+        for ta, tb, tag in ((a.U, b.U, "user "), (a.I, b.I, "item ")):
+            x, y = getattr(ta, name), getattr(tb, name)
+            if wd == 0.0 or name == "last":
+                assert torch.equal(x, y), tag + name
+            else:
+                torch.testing.assert_close(x, y, rtol=1e-4, atol=1e-6 * float(y.abs().max()) + 1e-12, msg=tag + name)
+    if wd == 0.0:
+        assert torch.equal(a.loss_acc, b.loss_acc)
+        assert torch.equal(a.loss_ring, b.loss_ring)
+    else:
+        torch.testing.assert_close(a.loss_ring, b.loss_ring, rtol=1e-5, atol=1e-7)
+        torch.testing.assert_close(a.loss_acc, b.loss_acc, rtol=1e-5, atol=1e-7)
+
+
 @pytest.mark.parametrize("item_dist", ["uniform", "zipf"])
 def test_in_launch_prepare_at_the_baseline_size_over_a_sweep_period(item_dist):
     """BASELINE.json configs[1] at its real size, more steps than one sweep period (every row is replayed and swept at least

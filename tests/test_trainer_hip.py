@@ -57,6 +57,86 @@ def test_fit_matches_oracle_loss_curve_and_weights(tmp_path):
     assert int(st["step"]) == 2 * T
 
 
+def _fit_pair(tmp_path, per_call, objective="value", n_inter=4100, bs=256, epochs=2, wd=1e-3):
+    from fairrec.config import Config
+    from fairrec.data.dataloader import TrainDataLoader
+    from fairrec.data.dataset import synthetic_dataset
+    from fairrec.utils import get_model, get_trainer, init_seed
+    cfg = Config(model="FOCF", config_dict={
+        "train_batch_size": bs, "embedding_size": 64, "fair_objective": objective, "fair_weight": 0.7, "weight_decay": wd,
+        "epochs": epochs, "device": "cuda", "checkpoint_dir": str(tmp_path), "learning_rate": 1e-2,
+        "train_steps_per_call": per_call, "lazy_adam_sweep_period": 4})
+    init_seed(5)
+    ds = synthetic_dataset(cfg, 700, 300, n_inter, seed=13).to("cuda")
+    train = TrainDataLoader(cfg, ds, shuffle=True)
+    model = get_model("FOCF")(cfg, ds).to("cuda")
+    trainer = get_trainer(None, "FOCF")(cfg, model)
+    return train, model, trainer
+
+
+@pytest.mark.parametrize("objective,wd", [("value", 0.0), ("value", 1e-3), ("nonparity", 0.0)])
+def test_epoch_issued_by_the_library_equals_the_per_batch_loop(tmp_path, objective, wd):
+    """Trainer._train_epoch over a sliceable loader hands runs of `train_steps_per_call` batches to the library
+    (TrainDataLoader.take -> FOCF.train_steps -> fr_focf_steps_many).  Same shuffles (one torch.randperm per epoch, the
+    reference's consumer), same batches (a short last one included), same launches: without weight decay parameters,
+    optimizer state and the epoch losses EQUAL the per-batch loop's (`train_steps_per_call: 0`) bit for bit; with it, up to
+    the rounding of a replay cut in another place (tests/test_focf_hip.py::test_steps_many_equals_the_per_batch_staged_loop).
+    nonparity needs a batch-wide value between loss and update: the trainer must notice and take the per-batch loop itself."""
+    out = []
+    for per_call in (0, 5, 256):
+        train, model, trainer = _fit_pair(tmp_path, per_call, objective, wd=wd)
+        calls = []
+        eng = model.hip_engine()
+        orig = eng.steps_many
+        eng.steps_many = lambda *a, **k: calls.append(1) or orig(*a, **k)
+        trainer.fit(train, valid_data=None, verbose=False, saved=False)
+        n_steps = 2 * len(train)
+        assert eng.U.step == n_steps
+        want_calls = 0 if (per_call == 0 or objective == "nonparity") else 2 * -(-len(train) // per_call)
+        assert len(calls) == want_calls
+        sd = model.state_dict()
+        out.append((sd["user_embedding_layer.weight"].clone(), sd["item_embedding_layer.weight"].clone(),
+                    eng.U.m.clone(), eng.I.v.clone(), [trainer.train_loss_dict[e] for e in range(2)]))
+    for o in out[1:]:
+        for x, y in zip(o[:4], out[0][:4]):
+            if wd == 0.0:
+                assert torch.equal(x, y)
+            else:
+                torch.testing.assert_close(x, y, rtol=1e-4, atol=1e-6 * float(y.abs().max()) + 1e-12)
+        if wd == 0.0:
+            assert o[4] == out[0][4]
+        else:
+            np.testing.assert_allclose(o[4], out[0][4], rtol=1e-5)
+
+
+def test_focf_epoch_keeps_its_launch_and_sync_budget(tmp_path):
+    """What the library-issued epoch must keep: about ONE launch per optimizer step (the step kernel; two stage launches
+    per run of 256 steps on top) and ONE host synchronisation per epoch (the loss total read at its end)."""
+    import warnings
+    from fairrec import _C
+    train, model, trainer = _fit_pair(tmp_path, 256, n_inter=256 * 300, epochs=1)
+    trainer._train_epoch(train, 0)                     # allocations, first-use work
+    torch.cuda.synchronize()
+    _C.prof_reset()
+    _C.prof_enable(True)
+    torch.cuda.set_sync_debug_mode("warn")
+    try:
+        with warnings.catch_warnings(record=True) as seen:
+            warnings.simplefilter("always")
+            trainer._train_epoch(train, 1)
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+        _C.prof_enable(False)
+    torch.cuda.synchronize()
+    launches = sum(n for _, n in _C.prof_read().values())
+    steps = len(train)
+    assert steps == 300 and launches <= 1.2 * steps, _C.prof_read()
+    syncs = [w for w in seen if "synchronizing" in str(w.message).lower()]
+    # the epoch's shuffle index crossing to the device (a pageable copy, before anything is queued) and the read at its end
+    # (loss total + device error word in one)
+    assert len(syncs) <= 2, [str(w.message) for w in syncs]
+
+
 def test_loss_backward_step_surface_and_checkpoint_roundtrip(tmp_path):
     cfg, ds, train, model, trainer = _setup(tmp_path, objective="absolute", epochs=1)
     b = next(iter(train)).to("cuda")
