@@ -122,6 +122,78 @@ def focf_shape_block(item_dist, K, W, dev, sweep):
             "achieved_GBps": round(gbs, 1), "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4)}
 
 
+def trainer_fit_block(dev, graph_us_per_step, steps=1024, sweep=None):
+    """What a user of the plugin surface gets: `fairrec.trainer.Trainer._train_epoch` (reference trainer.py:155-204) on the
+    BASELINE sizes, through the loaders -- not the bench's own step loop.  `uniform`: TrainDataLoader over a device-resident,
+    per-epoch shuffled interaction table; the trainer hands runs of `train_steps_per_call` batches to the library
+    (TrainDataLoader.take -> FOCF.train_steps -> fr_focf_steps_many).  `item_complete`: the reference's own batch shape,
+    FOCFDataLoader over ~100 interactions per item; the epoch's item picks (host numpy, the reference's draw order) are
+    composed before the clock starts and reported separately.  One warm-up epoch first (allocations; it also ages the
+    lazy-Adam state over more than a sweep period), then one timed epoch bracketed by synchronisations."""
+    from fairrec.config import Config
+    from fairrec.data.dataloader import FOCFDataLoader, TrainDataLoader
+    from fairrec.data.dataset import InteractionDataset, synthetic_dataset
+    from fairrec.data.interaction import Interaction
+    from fairrec.utils import get_model, get_trainer, init_seed
+    import tempfile
+    out = {"path": "Trainer._train_epoch -> loader -> model -> FusedLazyAdam (the plugin surface), one warm-up epoch, one timed"}
+    cfg = Config(model="FOCF", config_dict={"embedding_size": DIM, "train_batch_size": BATCH, "device": str(dev), "epochs": 1,
+                                            "fair_objective": OBJECTIVE, "fair_weight": FAIR_WEIGHT, "weight_decay": WD,
+                                            "learning_rate": LR, "eval_step": 0, "checkpoint_dir": tempfile.mkdtemp(),
+                                            "sst_attr_list": ["gender"], "lazy_adam_sweep_period": sweep})
+
+    def timed_epoch(loader, before=None):
+        init_seed(SEED)
+        model = get_model("FOCF")(cfg, loader.dataset).to(dev)
+        trainer = get_trainer(None, "FOCF")(cfg, model)
+        trainer._train_epoch(loader, 0)
+        if before is not None:
+            before()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        trainer._train_epoch(loader, 1)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        n, rows = model.hip_engine().U.step // 2, len(loader.dataset)
+        del trainer, model
+        torch.cuda.empty_cache()
+        return dt, n, rows
+
+    ds = synthetic_dataset(cfg, N_USERS, N_ITEMS, BATCH * steps, seed=SEED + 1).to(dev)
+    dt, n, rows = timed_epoch(TrainDataLoader(cfg, ds, shuffle=True))
+    out["uniform"] = {"loader": "TrainDataLoader(shuffle=True), dataset resident on the device", "steps": n,
+                      "us_per_step": round(dt / n * 1e6, 2), "interactions_per_s": round(rows / dt, 1),
+                      "steps_per_library_call": int(cfg["train_steps_per_call"]),
+                      "vs_graph_replay": round(dt / n * 1e6 / graph_us_per_step, 3)}
+    del ds
+    # item-complete: 5000 of the items carry ~100 interactions each (the shape of SURVEY.md 8-d's grouped run; a pick permutes
+    # the candidate list -- numpy's legacy choice(replace=False) -- so its host cost grows with the number of candidates)
+    g = torch.Generator(device="cpu").manual_seed(SEED + 2)
+    n_hot, per = 5000, 100
+    hot = torch.randperm(N_ITEMS - 1, generator=g)[:n_hot] + 1
+    i = hot.repeat_interleave(per)
+    u = torch.randint(1, N_USERS, (i.numel(),), generator=g, dtype=torch.int64)
+    r = torch.randint(1, 6, (i.numel(),), generator=g).to(torch.float32)
+    gender = (torch.rand(N_USERS, generator=g) < 0.5).to(torch.float32)
+    ds = InteractionDataset(cfg, Interaction({"user_id": u, "item_id": i, "rating": r}),
+                            Interaction({"user_id": torch.arange(N_USERS), "gender": gender}), N_USERS, N_ITEMS).to(dev)
+    loader = FOCFDataLoader(cfg, ds)
+    compose = {}
+
+    def precompose():
+        t0 = time.perf_counter()
+        loader._begin_epoch()
+        torch.cuda.synchronize()
+        compose["s"] = time.perf_counter() - t0
+    dt, n, rows = timed_epoch(loader, precompose)
+    out["item_complete"] = {"loader": "FOCFDataLoader (focf_dataloader.py:37-51), %d items x %d interactions, dataset resident "
+                                      "on the device; the epoch's item picks composed before the clock starts" % (n_hot, per),
+                            "steps": n, "us_per_step": round(dt / n * 1e6, 2), "interactions_per_s": round(rows / dt, 1),
+                            "rows_per_batch": round(rows / n, 1),
+                            "picks_us_per_batch_host": round(compose["s"] / n * 1e6, 1)}
+    return out
+
+
 def stream_copy_ceiling(device, n_bytes=1 << 30, reps=10):
     """On-box streaming ceiling: device-to-device copy of 1 GiB, read + write bytes per second."""
     src = torch.empty(n_bytes // 4, dtype=torch.float32, device=device).normal_()
@@ -683,6 +755,7 @@ def main():
             del eng, U, I
             torch.cuda.empty_cache()
             out["other_batch_shapes"] = [focf_shape_block(d, K, W, dev, args.sweep) for d in ("grouped", "zipf")]
+            out["trainer_fit"] = trainer_fit_block(dev, dt / K * 1e6, sweep=args.sweep)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
     # The JSON line is the LAST thing on stdout: RCCL's banner sits in C stdio buffers until flushed, so flush first.

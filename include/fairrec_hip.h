@@ -304,6 +304,23 @@ FR_API int fr_focf_step_finish_staged(void* ws, size_t ws_bytes, int64_t B, int3
  * (hand it to the next call as prev_*, or to fr_focf_step_finish_staged).  Same launches, same bits as n calls of
  * fr_focf_step_staged.
  */
+/*
+ * The same loop for ITEM-COMPLETE batches (the only shape the reference's FOCFDataLoader yields, focf_dataloader.py:37-51):
+ * n launches of fr_focf_step_runs_pipe issued by the library, the batches' sorted prepare (fr_focf_prepare_step,
+ * FR_FOCF_PREPARE_MAX batches per launch) running one group ahead on the library's side stream and joined once per group.
+ * Batch k is gathered at step U->step + k with stamp first_stamp + k; its item runs ride in the launch of batch k + 1, and the
+ * launch of batch k + 2 reduces its loss into loss_ring[4 * ((first_slot + k) % loss_slots)] and loss_acc.  `fin_*`: a batch
+ * the previous call gathered and nobody finished yet (fin_step = U->step - 1, fin_loss_out = its loss slot; NULL: none);
+ * `prev_*`: a finished batch whose loss is still unreduced (NULL: none).  When the call returns, batch n - 1 is in the `fin`
+ * position and batch n - 2 (or the incoming `fin`) in the `prev` position: hand them to the next call, or drain them with
+ * fr_focf_step_runs_pipe(user = NULL) + fr_focf_step_finish.  Batches closer than 2 * FR_FOCF_PREPARE_MAX + 2 in the run need
+ * different workspaces, none of them a pending one.  Same launches, same bits as n calls of fr_focf_step_runs_pipe.
+ */
+FR_API int fr_focf_runs_many(const fr_table* U, const fr_table* I, const fr_adam* adam, const fr_focf_batch* batches,
+                             int32_t n, int32_t objective, float fair_weight, int32_t sweep_period, int32_t first_stamp,
+                             void* fin_ws, int64_t fin_B, int32_t fin_step, float* fin_loss_out, void* prev_ws, int64_t prev_B,
+                             float* prev_loss_out, float* loss_ring, int32_t loss_slots, int32_t first_slot, float* loss_acc,
+                             int32_t* own_u, int32_t* own_i, uint32_t* err_flag, void* stream);
 FR_API int fr_focf_steps_many(const fr_table* U, const fr_table* I, const fr_adam* adam, const fr_focf_batch* batches,
                               int32_t n, int32_t objective, float fair_weight, int32_t sweep_period, int32_t first_stamp,
                               int32_t first_gen, void* prev_ws, int64_t prev_B, float* prev_loss_out, float* loss_ring,
@@ -809,6 +826,17 @@ FR_API int fr_sample_negatives_calls(uint32_t* state, int64_t low, int64_t high,
                                      const int64_t* call_offsets, int64_t n_calls, int64_t max_call,
                                      const int64_t* used_indptr, const int32_t* used_items, int64_t n_users, int64_t* out,
                                      void* ws, size_t ws_bytes, uint32_t* err_flag, void* stream);
+
+/* ---- epoch shuffle (next-row f-1: the batch feed): torch.randperm(n) on the device, bit-exact ---------------------------
+ * Replaces the `torch.randperm(self.length)` behind Interaction.shuffle (interaction.py:293-297), the training loader's
+ * per-epoch shuffle (abstract_dataloader.py:81-84).  Underneath: ATen's randperm_cpu for n < 2^32 / 20 -- r[i] = i, then for
+ * i = 0 .. n-2: swap(r[i], r[i + mt19937() % (n - i)]) on single 32-bit outputs of torch's CPU generator (the standard
+ * MT19937).  state: uint32 key[624] followed by uint32 pos (625 words; pos = index of the next unused word, 624 = regenerate
+ * first), taken from torch.get_rng_state() by the caller and left where the n - 1 draws put it, so the host generator can be
+ * set to exactly the state torch.randperm(n) would have left.  out: int64 [n].  The swap chain is resolved in parallel
+ * (csrc/randperm.hip); only the generator is walked sequentially, by one workgroup. */
+FR_API size_t fr_randperm_workspace_bytes(int64_t n);
+FR_API int fr_randperm(uint32_t* state, int64_t n, int64_t* out, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- evaluation metrics (next-row f-2), recbole/evaluator/metrics.py ------------------------------------------------
  *   fr_topk_metrics           : rec_topk int32 [n_users, k+1] = hit flags of the ranked list | number of positives

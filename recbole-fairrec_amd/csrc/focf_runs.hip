@@ -34,6 +34,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <vector>
 
 #include "common.hpp"
 #include "kernels.hpp"
@@ -749,5 +750,78 @@ extern "C" int fr_focf_step_runs(const fr_table* U, const fr_table* I, const fr_
     const unsigned blocks = (unsigned)(1 + a.n_item_blocks + sweep_blocks);
     FR_DISPATCH_E(U->dim, FR_LAUNCH(prof, (focf_runs_finish_kernel<E>), dim3(blocks), dim3(RUN_THREADS), 0, stream, a));
     FR_CHECK_LAUNCH();
+    return FR_OK;
+}
+
+// The step loop of trainer.py:181-196 over a run of ITEM-COMPLETE batches (what FOCFDataLoader yields) in one call: n launches
+// of fr_focf_step_runs_pipe, the sorted prepare of the batches (fr_focf_prepare_step, FR_FOCF_PREPARE_MAX per launch) one group
+// ahead on the library's side stream, joined once per group.  Batch k is gathered at step U->step + k with stamp
+// first_stamp + k; its item runs ride in the launch of batch k + 1, its loss is reduced by the launch of batch k + 2.
+extern "C" int fr_focf_runs_many(const fr_table* U, const fr_table* I, const fr_adam* adam, const fr_focf_batch* batches,
+                                 int32_t n, int32_t objective, float fair_weight, int32_t sweep_period, int32_t first_stamp,
+                                 void* fin_ws, int64_t fin_B, int32_t fin_step, float* fin_loss_out, void* prev_ws,
+                                 int64_t prev_B, float* prev_loss_out, float* loss_ring, int32_t loss_slots, int32_t first_slot,
+                                 float* loss_acc, int32_t* own_u, int32_t* own_i, uint32_t* err_flag, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    FR_CHECK_ARG(U && I && batches && n >= 1, "fr_focf_runs_many: null pointer / no batch");
+    FR_CHECK_ARG(loss_ring && loss_slots >= 1 && first_slot >= 0 && first_slot < loss_slots,
+                 "fr_focf_runs_many: loss ring (float[4 * loss_slots]) and a first slot inside it");
+    FR_CHECK_ARG(first_stamp >= 1 && first_stamp <= INT32_MAX - n, "fr_focf_runs_many: first stamp");
+    FR_CHECK_ARG(U->step >= 1 && U->step == I->step && U->step <= INT32_MAX - n,
+                 "fr_focf_runs_many: table.step must be the step the FIRST batch is applied at (>= 1), the same for both tables");
+    FR_CHECK_ARG(!fin_ws || (fin_loss_out && fin_step == U->step - 1),
+                 "fr_focf_runs_many: a pending batch must be the previous step's, with its loss slot");
+    constexpr int G = FR_FOCF_PREPARE_MAX;
+    // a workspace is written by its batch's prepare (up to 2 G - 1 launches before its gather) and read until the launch that
+    // reduces its loss (2 launches after): batches closer than 2 G + 2 need different ones, and none may be a pending one
+    for (int k = 0; k < n; ++k) {
+        FR_CHECK_ARG(batches[k].ws && batches[k].user && batches[k].item && batches[k].rating,
+                     "fr_focf_runs_many: batch %d: null pointer", k);
+        for (int j = k + 1; j < n && j < k + 2 * G + 2; ++j)
+            FR_CHECK_ARG(batches[j].ws != batches[k].ws, "fr_focf_runs_many: batches %d and %d share a workspace", k, j);
+        FR_CHECK_ARG(k >= 2 * G || (batches[k].ws != fin_ws && batches[k].ws != prev_ws),
+                     "fr_focf_runs_many: batch %d uses a workspace that is still pending", k);
+    }
+    std::vector<int32_t> stamps((size_t)n);
+    for (int k = 0; k < n; ++k) stamps[(size_t)k] = first_stamp + k;
+    SideStream* ss = side_stream();
+    static hipEvent_t ev_fork = nullptr, ev_done[2] = {nullptr, nullptr};
+    if (ss && !ev_fork) {
+        FR_CHECK_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+        FR_CHECK_HIP(hipEventCreateWithFlags(&ev_done[0], hipEventDisableTiming));
+        FR_CHECK_HIP(hipEventCreateWithFlags(&ev_done[1], hipEventDisableTiming));
+    }
+    int rc;
+    auto prepare = [&](int g, hipStream_t st) {
+        const int lo = g * G, cnt = std::min(G, n - lo);
+        return fr_focf_prepare_step(batches + lo, stamps.data() + lo, cnt, U, I, sweep_period, err_flag, st);
+    };
+    if ((rc = prepare(0, stream))) return rc;       // the first group on the caller's stream: nothing to overlap it with yet
+    fr_table tu = *U, ti = *I;
+    for (int k = 0; k < n; ++k) {
+        if (k % G == 0) {
+            const int g = k / G;
+            if (g > 0 && ss) FR_CHECK_HIP(hipStreamWaitEvent(stream, ev_done[g & 1], 0));
+            if ((g + 1) * G < n) {
+                if (ss) {      // (everything that last used the next group's workspaces was enqueued before this point)
+                    FR_CHECK_HIP(hipEventRecord(ev_fork, stream));
+                    FR_CHECK_HIP(hipStreamWaitEvent(ss->stream, ev_fork, 0));
+                    if ((rc = prepare(g + 1, ss->stream))) return rc;
+                    FR_CHECK_HIP(hipEventRecord(ev_done[(g + 1) & 1], ss->stream));
+                } else if ((rc = prepare(g + 1, stream))) {
+                    return rc;
+                }
+            }
+        }
+        const fr_focf_batch& b = batches[k];
+        rc = fr_focf_step_runs_pipe(&tu, &ti, adam, b.user, b.item, b.rating, b.sst, b.B, objective, fair_weight, sweep_period,
+                                    stamps[(size_t)k], b.ws, b.ws_bytes, fin_ws, fin_B, fin_step, prev_ws, prev_B, prev_loss_out,
+                                    loss_acc, own_u, own_i, err_flag, stream_);
+        if (rc) return rc;
+        prev_ws = fin_ws; prev_B = fin_B; prev_loss_out = fin_loss_out;      // finished in this launch: its loss comes next
+        fin_ws = b.ws; fin_B = b.B; fin_step = tu.step;
+        fin_loss_out = loss_ring + 4 * (size_t)((first_slot + k) % loss_slots);
+        ++tu.step; ++ti.step;
+    }
     return FR_OK;
 }

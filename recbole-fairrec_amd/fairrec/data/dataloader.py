@@ -143,7 +143,7 @@ class FOCFDataLoader(AbstractDataLoader):
         self.item_uniques = np.unique(items)
         # CSR by item over the item-sorted interaction array
         self.indptr = np.searchsorted(items, np.arange(self.item_num + 1), side="left")
-        self._epoch = []                  # index lists of the batches still to come this epoch, last first
+        self._sizes, self._rows, self._row_pr = [], None, 0     # the composed epoch: batch sizes still to come, its rows
         _prejoin(self.dataset)
 
     def _compose_epoch(self):
@@ -171,11 +171,36 @@ class FOCFDataLoader(AbstractDataLoader):
                 batches.append(np.concatenate(chunks))
         return batches
 
+    def _begin_epoch(self):
+        """Compose the epoch and gather its rows ONCE, in batch order (one index crossing to the device and one gather per
+        column per epoch, like the plain loader's shuffle): a batch is then a slice, a run of batches a longer slice."""
+        parts = self._compose_epoch()
+        self._sizes = [len(p) for p in parts][::-1]                     # sizes of the batches still to come, last first
+        self._rows = self.dataset.join(self.dataset[np.concatenate(parts)]) if parts else None
+        self._row_pr = 0
+
     def _next_batch_data(self):
-        if not self._epoch:
-            self._epoch = self._compose_epoch()[::-1]
+        if not self._sizes:
+            self._begin_epoch()
+        n = self._sizes.pop()
         self.pr += self.step
-        return self.dataset.join(self.dataset[self._epoch.pop()])
+        lo, self._row_pr = self._row_pr, self._row_pr + n
+        return self._rows[lo:lo + n]
+
+    sliceable = True
+
+    def take(self, n_batches):
+        """The next `n_batches` batches of this epoch as ONE Interaction (rows back to back) and their sizes (ragged: a
+        batch holds whole item histories) -- TrainDataLoader.take for item-complete batches.  None when the epoch is over."""
+        if self.pr >= self.pr_end:
+            self.pr = 0
+            return None
+        if not self._sizes:
+            self._begin_epoch()
+        sizes = [self._sizes.pop() for _ in range(min(int(n_batches), len(self._sizes)))]
+        self.pr += self.step * len(sizes)
+        lo, self._row_pr = self._row_pr, self._row_pr + sum(sizes)
+        return self._rows[lo:self._row_pr], sizes
 
 
 class FullSortEvalDataLoader:

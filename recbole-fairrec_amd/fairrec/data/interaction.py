@@ -49,6 +49,14 @@ class Interaction:
             return self.interaction[index]
         if isinstance(index, (list, np.ndarray)):
             index = torch.as_tensor(np.asarray(index))
+        if torch.is_tensor(index) and index.dtype != torch.bool:
+            on = {}                 # an index list crosses to a device once, not once per column
+            out = {}
+            for k, v in self.interaction.items():
+                if v.device not in on:
+                    on[v.device] = index.to(v.device)
+                out[k] = v[on[v.device]]
+            return Interaction(out)
         return Interaction({k: v[index] for k, v in self.interaction.items()})
 
     def __setitem__(self, key, value):
@@ -117,7 +125,15 @@ class Interaction:
             self.interaction[k] = v[on[v.device]]
 
     def shuffle(self):
-        self._reindex(torch.randperm(self.length))   # same RNG consumer as interaction.py:293-297
+        """interaction.py:293-297: reindex by torch.randperm(length) -- the same permutation and the same generator state
+        afterwards, but for columns that live on a GPU the permutation is computed THERE (fairrec/sampler/torch_stream.py:
+        the host's Fisher-Yates chain costs 30 ns per interaction, several times a training epoch at device step rates)."""
+        dev = next((v.device for v in self.interaction.values() if v.is_cuda), None)
+        if dev is None:
+            self._reindex(torch.randperm(self.length))
+        else:
+            from ..sampler.torch_stream import randperm
+            self._reindex(randperm(self.length, dev))
 
     def sort(self, by, ascending=True):
         if isinstance(by, str):

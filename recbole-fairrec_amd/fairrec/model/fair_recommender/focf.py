@@ -548,58 +548,32 @@ class FocfEngine:
     RING = 8          # workspaces a run of steps cycles through (any four consecutive batches need four different ones)
 
     def can_step_many(self) -> bool:
-        """A run of batches can go through fr_focf_steps_many: the staged one-launch step applies (what forward() checks per
-        batch) and nothing has to happen between a batch's loss and its update (clip_grad_norm)."""
-        return bool(self.staged and self.fused_step and self.defer_loss and self.optimizer is not None and self.objective != 5
-                    and not self.item_runs and self.U.step == self.I.step and not getattr(self.optimizer, "clip", None))
+        """A run of batches can go through the library's own step loop: the staged one-launch step (fr_focf_steps_many) or,
+        for item-complete batches, the pipelined item-run step (fr_focf_runs_many) applies -- what forward() checks per batch
+        -- and nothing has to happen between a batch's loss and its update (clip_grad_norm)."""
+        if not (self.fused_step and self.defer_loss and self.optimizer is not None and self.objective != 5
+                and self.U.step == self.I.step and not getattr(self.optimizer, "clip", None)):
+            return False
+        return bool(self.RUNS and self.PIPE) if self.item_runs else bool(self.staged)
 
-    def steps_many(self, user, item, rating, sst, sizes):
-        """`calculate_loss` + `optimizer.step()` for a run of batches in ONE library call (fr_focf_steps_many: the step
-        loop of trainer.py:181-196 issued by the library -- one staged launch per batch, the coming two batches' index work
-        riding in each).  The columns hold the batches back to back: `sizes` = rows per batch, an int (every batch that
-        size, the last one whatever is left) or a sequence.  Losses go to the engine's running total (`loss_acc`), as with
-        `defer_loss`; same launches and same bits as the per-batch calls."""
+    def _run_sizes(self, total, sizes):
         import numpy as np
-        if not self.can_step_many():
-            raise _C.FairrecError("steps_many: the staged one-launch step does not apply to this engine state")
-        if self._stash is not None:
-            raise _C.FairrecError("steps_many with a calculate_loss() pending")
-        total = user.numel()
         if isinstance(sizes, int):
             n = (total + sizes - 1) // sizes
             size = np.full(n, sizes, dtype=np.int64)
-            size[-1] = total - sizes * (n - 1)
+            if n:
+                size[-1] = total - sizes * (n - 1)
         else:
             size = np.asarray(sizes, dtype=np.int64)
-            n = size.shape[0]
-        if n == 0:
-            return 0
-        if int(size.sum()) != total or int(size.min()) < 1 or int(size.max()) > _C.FR_SORT_MAX:
+        if size.shape[0] and (int(size.sum()) != total or int(size.min()) < 1 or int(size.max()) > _C.FR_SORT_MAX):
             raise _C.FairrecError("steps_many: batch sizes do not add up to the columns (or a batch outside 1..FR_SORT_MAX)")
-        self._check_stamp_gen()
-        self.U.ensure_state()
-        self.I.ensure_state()
-        if self._pipe is not None or (self._prev is not None and not self._prev[3]):
-            self.finish()
-        self._forget_staged()                       # nothing may be on its way through the stages
-        self._gen_cur = None
-        if self._prep:
-            self._join_prepare()
+        return size
+
+    def _run_batches(self, user, item, rating, sst, size, ring):
+        """fr_focf_batch records of a run whose columns sit back to back, workspaces taken round-robin from `ring`."""
+        import numpy as np
+        n = size.shape[0]
         start = np.concatenate(([0], np.cumsum(size)[:-1]))
-        # the ring of workspaces, all as large as the largest batch of the run; the one a pending loss sits in is skipped
-        Bmax = int(size.max())
-        held = self._prev[0] if self._prev is not None else None
-        ring = []
-        for k in range(self.N_WS):
-            if len(ring) == self.RING:
-                break
-            ws = self._workspace(Bmax, k)
-            if ws is held:
-                continue
-            if k in self._ws_dirty:
-                ws.zero_()
-                self._ws_dirty.discard(k)
-            ring.append((k, ws))
         arr = np.zeros(n, dtype=_BATCH_DTYPE)
         arr["user"] = user.data_ptr() + 8 * start
         arr["item"] = item.data_ptr() + 8 * start
@@ -610,6 +584,104 @@ class FocfEngine:
         slot = np.arange(n) % len(ring)
         arr["ws"] = np.array([w.data_ptr() for _, w in ring], dtype=np.uint64)[slot]
         arr["ws_bytes"] = np.array([w.numel() for _, w in ring], dtype=np.uint64)[slot]
+        return arr
+
+    def _ring(self, Bmax, count, held):
+        ring = []
+        for k in range(self.N_WS):
+            if len(ring) == count:
+                break
+            ws = self._workspace(Bmax, k)
+            if any(ws is h for h in held):
+                continue
+            if k in self._ws_dirty:
+                ws.zero_()
+                self._ws_dirty.discard(k)
+            ring.append((k, ws))
+        if len(ring) < count:
+            raise _C.FairrecError("steps_many: not enough free workspaces")
+        return ring
+
+    def _runs_many(self, user, item, rating, sst, size):
+        """fr_focf_runs_many: the pipelined item-run steps of a run of item-complete batches, their sorted prepare one group
+        ahead on the library's side stream."""
+        from ...optim import _used_on_side_stream
+        n = size.shape[0]
+        if self._prev is not None and self._prev[3]:
+            self.finish()
+        self._forget_staged()
+        self._gen_cur = None
+        if self._prep:
+            self._join_prepare()
+        fin, prev = self._pipe, self._prev
+        held = [t[0] for t in (fin, prev) if t is not None]
+        ring = self._ring(int(size.max()), 2 * self.PER_LAUNCH + 2, held)
+        arr = self._run_batches(user, item, rating, sst, size, ring)
+        for t in (user, item, rating, sst) + tuple(w for _, w in ring):   # the prepare launches read / write them on the
+            _used_on_side_stream(t)                                       # library's side stream
+        step0 = self.U.step + 1
+        self.hyper.check_step(step0 + n - 1)
+        stamp0 = self._next_stamp()
+        self._stamp_last = stamp0 + n - 1
+        slot0 = (self.loss_slot + 1) % self.LOSS_SLOTS
+        own_u, own_i = self._own_arrays()
+        tu, ti = self.U.c(step0), self.I.c(step0)
+        rc = _C.lib().fr_focf_runs_many(ctypes.byref(tu), ctypes.byref(ti), ctypes.byref(self.hyper.c()), arr.ctypes.data, n,
+                                        self.objective, self.fair_weight, self._sweep(int(size.max())), stamp0,
+                                        _C.ptr(fin[0]) if fin else None, fin[1] if fin else 0, fin[2] if fin else 0,
+                                        _C.ptr(fin[3]) if fin else None, _C.ptr(prev[0]) if prev else None,
+                                        prev[1] if prev else 0, _C.ptr(prev[2]) if prev else None, self.loss_ring.data_ptr(),
+                                        self.LOSS_SLOTS, slot0, self.loss_acc.data_ptr(), own_u.data_ptr(), own_i.data_ptr(),
+                                        self.err_flag.data_ptr(), _C.current_stream())
+        if rc:
+            self._pipe = self._prev = None
+        _C.check(rc, "fr_focf_runs_many")
+        view = lambda k: self._loss_views[(slot0 + k) % self.LOSS_SLOTS]
+        last = ring[(n - 1) % len(ring)]
+        self._pipe = (last[1], int(size[-1]), step0 + n - 1, view(n - 1), (user, item, rating, sst))
+        if n >= 2:
+            self._prev = (ring[(n - 2) % len(ring)][1], int(size[-2]), view(n - 2), False)
+        else:
+            self._prev = (fin[0], fin[1], fin[3], False) if fin else None
+        self.loss_slot = (slot0 + n - 1) % self.LOSS_SLOTS
+        self.ws_cur = last[0]
+        self._keep = (user, item, rating, sst)
+        self.U.step += n
+        self.I.step += n
+        self.U._dirty = self.I._dirty = True
+        self.pending_B = 0
+        return n
+
+    def steps_many(self, user, item, rating, sst, sizes):
+        """`calculate_loss` + `optimizer.step()` for a run of batches in ONE library call (the step loop of
+        trainer.py:181-196 issued by the library): fr_focf_steps_many -- one staged launch per batch, the coming two batches'
+        index work riding in each -- or, with `item_runs` (item-complete batches), fr_focf_runs_many.  The columns hold the
+        batches back to back: `sizes` = rows per batch, an int (every batch that size, the last one whatever is left) or a
+        sequence.  Losses go to the engine's running total (`loss_acc`), as with `defer_loss`; same launches and same bits
+        as the per-batch calls."""
+        if not self.can_step_many():
+            raise _C.FairrecError("steps_many: neither the staged nor the pipelined item-run step applies to this engine state")
+        if self._stash is not None:
+            raise _C.FairrecError("steps_many with a calculate_loss() pending")
+        size = self._run_sizes(user.numel(), sizes)
+        n = size.shape[0]
+        if n == 0:
+            return 0
+        self._check_stamp_gen()
+        self.U.ensure_state()
+        self.I.ensure_state()
+        if self.item_runs:
+            return self._runs_many(user, item, rating, sst, size)
+        if self._pipe is not None or (self._prev is not None and not self._prev[3]):
+            self.finish()
+        self._forget_staged()                       # nothing may be on its way through the stages
+        self._gen_cur = None
+        if self._prep:
+            self._join_prepare()
+        # the ring of workspaces, all as large as the largest batch of the run; the one a pending loss sits in is skipped
+        Bmax = int(size.max())
+        ring = self._ring(Bmax, self.RING, [self._prev[0]] if self._prev is not None else [])
+        arr = self._run_batches(user, item, rating, sst, size, ring)
         step0 = self.U.step + 1
         self.hyper.check_step(step0 + n - 1)
         stamp0 = self._next_stamp()

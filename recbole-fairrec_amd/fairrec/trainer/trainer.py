@@ -140,9 +140,12 @@ class Trainer(AbstractTrainer):
             run = run.to(self.device)
             with torch.no_grad():
                 if self.model.train_steps(run, size) is None:  # the engine's state asks for the per-batch path after all
-                    for lo in range(0, len(run), size):
-                        self.model.calculate_loss(run[lo:lo + size])
+                    sizes = size if not isinstance(size, int) else [size] * -(-len(run) // size)
+                    lo = 0
+                    for n in sizes:
+                        self.model.calculate_loss(run[lo:lo + n])
                         self.optimizer.step()
+                        lo += n
 
     def _train_epoch_body(self, train_data, loss_func, hint, graphed, fused, total, n_tuple):
         if (fused and graphed is None and self._steps_per_call() > 0 and getattr(train_data, 'sliceable', False)

@@ -92,6 +92,20 @@ class _Listen:
             fn = getattr(model, name, None)
             if fn is not None:
                 setattr(model, name, self._wrap(kind, fn))
+        if hasattr(model, "train_steps"):       # FOCF: the trainer hands whole RUNS of batches to the library's step loop
+            model.train_steps = self._wrap_run(model.train_steps)
+
+    def _wrap_run(self, fn):
+        def wrapped(run, sizes):
+            n = fn(run, sizes)
+            if n is not None:
+                each = sizes if not isinstance(sizes, int) else [min(sizes, len(run) - lo) for lo in range(0, len(run), sizes)]
+                lo = 0
+                for b in each:
+                    self.steps.append(("L", "", {k: v[lo:lo + b].detach().clone() for k, v in run.interaction.items()}, None))
+                    lo += b
+            return n
+        return wrapped
 
     def _wrap(self, kind, fn):
         def wrapped(interaction, *args, **kw):

@@ -287,8 +287,9 @@ def test_in_launch_prepare_with_tiny_and_ragged_batches(B):
     torch.testing.assert_close(engs[1].loss_acc[:3], engs[0].loss_acc[:3], rtol=1e-5, atol=1e-7)
 
 
+@pytest.mark.parametrize("runs", [False, True], ids=["staged", "item_runs"])
 @pytest.mark.parametrize("path", CASES, ids=[os.path.basename(p)[:-4] for p in CASES])
-def test_steps_many_matches_reference_golden(path):
+def test_steps_many_matches_reference_golden(path, runs):
     """The step loop issued by the library (fr_focf_steps_many: one call per run of batches, trainer.py:181-196 with its body
     in C) on every golden it applies to: the runs are cut at the snapshot steps, every per-step loss comes out of the loss
     ring the calls fill."""
@@ -297,6 +298,7 @@ def test_steps_many_matches_reference_golden(path):
         pytest.skip("needs a batch-wide value between loss and update: per-batch path")
     eng = _engine(z, 3)
     eng.defer_loss = True
+    eng.item_runs = runs          # fr_focf_runs_many: the pipelined item-run steps (what it computes does not depend on the shape)
     assert eng.can_step_many()
     T, B = z["user_id"].shape
     cols = [torch.tensor(z[k], device="cuda").reshape(-1) for k in ("user_id", "item_id", "rating", "sst")]
@@ -821,6 +823,70 @@ def test_pipelined_runs_step_equals_the_two_launch_step(objective, dim):
         for x, y in ((other.U.m, ref.U.m), (other.I.m, ref.I.m), (other.U.v, ref.U.v), (other.I.v, ref.I.v)):
             torch.testing.assert_close(x, y, rtol=1e-4, atol=1e-6 * float(y.abs().max()) + 1e-14)
         np.testing.assert_allclose(other.loss_acc.cpu().numpy()[:4], ref.loss_acc.cpu().numpy()[:4], rtol=1e-5)
+
+
+@pytest.mark.parametrize("wd", [0.0, 1e-3], ids=["wd0", "wd1e-3"])
+@pytest.mark.parametrize("objective", ["none", "value"])
+def test_runs_many_equals_the_per_batch_pipelined_loop(objective, wd):
+    """fr_focf_runs_many (the library issues the pipelined item-run steps of a run of item-complete batches, their sorted
+    prepare one group ahead on its side stream) against the per-batch loop (forward / backward_adam, batches announced
+    ahead): 27 ragged batches -- more than three prepare groups -- whose neighbours share most users and one item run, cut
+    into runs of 1, 2, 9 and 15 batches with the pipeline handed from one call to the next, a drain (flush) in between.
+    Without weight decay: bit for bit (tables, moments, every loss); with it: to the rounding of where a replay is cut."""
+    from fairrec.model.fair_recommender.focf import FocfEngine
+    from fairrec.optim import FusedLazyAdam
+    n_users, n_items, T, D = 1501, 401, 27, 64
+    batches = _item_complete_batches(n_users, n_items, T, 700, seed=23)
+    linked = [batches[0]]
+    for t in range(1, T):
+        pu, pi_, pr, ps = linked[-1]
+        n_last = int((pi_ == pi_[-1]).sum())
+        u, i, r, s = batches[t]
+        keep = i != pi_[-1]
+        linked.append((torch.cat([pu[-n_last:], u[keep]]), torch.cat([pi_[-n_last:], i[keep]]),
+                       torch.cat([pr[-n_last:].flip(0), r[keep]]), torch.cat([ps[-n_last:], s[keep]])))
+    batches = linked
+    sizes = [int(b[0].numel()) for b in batches]
+    cols = [torch.cat([b[j] for b in batches]).contiguous() for j in range(4)]
+    start = np.concatenate(([0], np.cumsum(sizes)))
+    g = torch.Generator().manual_seed(1)
+    U0 = (torch.randn(n_users, D, generator=g) * 0.1).cuda()
+    I0 = (torch.randn(n_items, D, generator=g) * 0.1).cuda()
+    engs = []
+    for _ in range(2):
+        eng = FocfEngine(U0.clone(), I0.clone(), objective, 0.7, 5.0)
+        FusedLazyAdam(eng, lr=1e-2, weight_decay=wd, sweep_period=4)
+        eng.defer_loss = True
+        eng.item_runs = True
+        engs.append(eng)
+    a, b = engs
+    assert b.can_step_many()
+    for t, (u, i, r, s) in enumerate(batches):
+        a.forward(u, i, r, s, next_batch=[(x[0], x[1], x[3], x[2]) for x in batches[t + 1:t + 4]] or None)
+        a.backward_adam()
+        if t == 11:
+            a.flush()
+    for lo, hi in ((0, 1), (1, 3), (3, 12), (12, T)):
+        n = b.steps_many(*(c[int(start[lo]):int(start[hi])] for c in cols), sizes[lo:hi])
+        assert n == hi - lo and b.U.step == hi and b._pipe is not None
+        if hi == 12:
+            b.flush()
+    for eng in engs:
+        eng.flush()
+        eng.check_device_errors()
+        assert eng._pipe is None and eng._prev is None
+    for name in ("weight", "m", "v", "last"):
+        for ta, tb, tag in ((a.U, b.U, "user "), (a.I, b.I, "item ")):
+            x, y = getattr(ta, name), getattr(tb, name)
+            if wd == 0.0 or name == "last":
+                assert torch.equal(x, y), tag + name
+            else:
+                torch.testing.assert_close(x, y, rtol=1e-4, atol=1e-6 * float(y.abs().max()) + 1e-12, msg=tag + name)
+    if wd == 0.0:
+        assert torch.equal(a.loss_ring, b.loss_ring) and torch.equal(a.loss_acc, b.loss_acc)
+    else:
+        torch.testing.assert_close(a.loss_ring, b.loss_ring, rtol=1e-5, atol=1e-7)
+        torch.testing.assert_close(a.loss_acc, b.loss_acc, rtol=1e-5, atol=1e-7)
 
 
 def test_pipelined_runs_step_at_full_batch_size():

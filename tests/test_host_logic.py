@@ -232,3 +232,30 @@ def test_default_sweep_period_of_a_one_column_table_is_capped():
     assert t.default_sweep(8192) == 64
     t.n_rows = 1000
     assert t.default_sweep(8192) == 8
+
+
+def test_torch_generator_state_blob_round_trip():
+    """fairrec/sampler/torch_stream.py reads torch's CPU generator state (key words + position) out of get_rng_state()'s blob
+    and writes an advanced one back: reading what was written gives the same words, a blob rewritten with its own content
+    is the blob, and the position convention (left == 1 <=> regenerate first) holds right after seeding and inside a block."""
+    import numpy as np
+    import torch
+    from fairrec.sampler import torch_stream as ts
+    torch.manual_seed(11)
+    blob = torch.get_rng_state()
+    key, pos = ts._read(blob)
+    assert pos == 624 and key.dtype == np.uint32 and key.shape == (624,)        # freshly seeded: nothing generated yet
+    # (a seeded generator holds left = 1, next = 0; one whose draws ended on a block boundary left = 1, next = 624 -- both
+    # regenerate before the next draw, and only the second form is ever written back)
+    again = ts._read(ts._write(blob, key, pos))
+    assert again[1] == 624 and np.array_equal(again[0], key)
+    torch.randperm(10)                                                           # 9 draws: regenerates, then position 9
+    blob2 = torch.get_rng_state()
+    key2, pos2 = ts._read(blob2)
+    assert pos2 == 9 and not np.array_equal(key2, key)
+    assert torch.equal(ts._write(blob2, key2, pos2), blob2)
+    # a CPU "device" takes the host path and is torch.randperm itself
+    torch.manual_seed(5)
+    a = torch.randperm(100)
+    torch.manual_seed(5)
+    assert torch.equal(ts.randperm(100, "cpu"), a)

@@ -247,3 +247,42 @@ def test_multi_call_sampling_equals_consecutive_single_key_calls():
     st = rs.get_state()
     np.testing.assert_array_equal(st[1], ors.key)
     assert st[2] == ors.pos
+
+
+@pytest.mark.parametrize("n", [2, 3, 10, 623, 624, 625, 1000, 624 * 3 + 5, 70_001, 8192 * 1024 + 77])
+def test_device_randperm_is_torch_randperm(n):
+    """fr_randperm (the epoch shuffle of interaction.py:293-297 computed on the device) against torch.randperm itself, from
+    generator positions inside, at the end of and right behind a block of 624 words: the same permutation bit for bit, the
+    same generator state afterwards (what the next consumer of torch's CPU stream draws is unchanged), twice in a row."""
+    from fairrec.sampler.torch_stream import randperm
+    for skip in (0, 1, 300, 623, 624):
+        torch.manual_seed(1234 + n)
+        if skip:
+            torch.rand(skip)                      # (one 32-bit word per float draw... whatever it takes: both sides do it)
+        st = torch.get_rng_state()
+        want = [torch.randperm(n), torch.randperm(n)]
+        after = torch.rand(5)
+        torch.set_rng_state(st)
+        got = [randperm(n, "cuda"), randperm(n, "cuda")]
+        assert got[0].dtype == torch.int64 and got[0].is_cuda
+        for g, w in zip(got, want):
+            assert torch.equal(g.cpu(), w), (n, skip)
+        assert torch.equal(torch.rand(5), after), (n, skip)
+        if n > 100_000:
+            break
+
+
+def test_shuffle_of_a_device_resident_interaction_equals_the_host_shuffle():
+    from fairrec.data.interaction import Interaction
+    g = torch.Generator().manual_seed(3)
+    cols = {"user_id": torch.randint(1, 1000, (5000,), generator=g), "rating": torch.rand(5000, generator=g)}
+    host, dev = Interaction({k: v.clone() for k, v in cols.items()}), Interaction(cols).to("cuda")
+    for _ in range(3):
+        torch.manual_seed(7)
+        host.shuffle()
+        a = torch.get_rng_state()
+        torch.manual_seed(7)
+        dev.shuffle()
+        assert torch.equal(torch.get_rng_state(), a)
+        for k in cols:
+            assert torch.equal(dev[k].cpu(), host[k])
