@@ -33,6 +33,7 @@ LR, WD, FAIR_WEIGHT, OBJECTIVE = 1e-3, 1e-3, 1.0, "value"
 # idx 8*2 + scalars 4*2 + gather 4*D*2 + Adam read m,v 8*D*2 + write p,m,v 12*D*2
 ALGO_BYTES_PER_INTERACTION = 16 + 8 + 4 * DIM * 2 + 8 * DIM * 2 + 12 * DIM * 2   # = 3096 at D = 64
 SEED = 2020
+RANKS_SEEN = 1           # N > 1: what an RCCL all-reduce of ones returned right after the process group came up (main)
 
 
 def synth_batches(n_batches, batch, n_users, n_items, seed, item_dist="uniform"):
@@ -341,10 +342,11 @@ def bench_nfcf(args, rank, world, dev):
         detail = dict(BW._gemm_summary(prof), kernels=BW._kernel_table(prof))
     return {
         "metric": "training interactions/sec + achieved HBM GB/s, NFCF finetune emb=256 (BASELINE.json configs[4])",
-        "value": round(total / dt, 1), "unit": "interactions/s", "n_gpus": world, "steps": K, "warmup": W,
+        "value": round(total / dt, 1), "unit": "interactions/s", "n_gpus": RANKS_SEEN, "steps": K, "warmup": W,
         "ms_per_step": round(dt / K * 1e3, 5), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"NFCF finetune, {nu} users x {ni} items, embedding_size={D}, B={B} per GPU, user table frozen, "
+        "config": {"ranks_seen": RANKS_SEEN,
+                   "workload": f"NFCF finetune, {nu} users x {ni} items, embedding_size={D}, B={B} per GPU, user table frozen, "
                                "item table lazy Adam lr=1e-3 wd=1e-6, mlp [512,128,64,1], fair_weight 0.1",
                    "tables": f"row-sharded over {world} ranks (owner = row mod {world}), RCCL all-to-all" if world > 1 else "single GPU",
                    "fairness_term": ("differential fairness on the GLOBAL batch (records to the items' owners, per-group sums back: "
@@ -449,7 +451,17 @@ def main():
         t = threading.Timer(float(os.environ.get("FAIRREC_BENCH_DEADLINE", "600")), _deadline)
         t.daemon = True
         t.start()
+        os.environ.setdefault("TORCH_FR_BUFFER_SIZE", "4096")     # the flight recorder: quiesce_rccl's event-based wait
         dist.init_process_group("nccl", device_id=dev)
+        # prove the world this run is in: every rank adds one over RCCL; `n_gpus` in the report IS this number
+        seen = torch.ones(1, device=dev)
+        dist.all_reduce(seen)
+        global RANKS_SEEN
+        RANKS_SEEN = ranks_seen = int(seen.item())
+        if ranks_seen != args.gpus or dist.get_world_size() != args.gpus:
+            print(f"[bench] --gpus {args.gpus} but the RCCL all-reduce saw {ranks_seen} ranks (world size "
+                  f"{dist.get_world_size()})", file=sys.stderr, flush=True)
+            os._exit(4)
 
     from fairrec import _C
     from fairrec.model.fair_recommender.focf import FocfEngine
@@ -495,6 +507,7 @@ def main():
         if not torch.distributed.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29655")
+            os.environ.setdefault("TORCH_FR_BUFFER_SIZE", "4096")
             torch.distributed.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
         g = torch.Generator(device="cpu").manual_seed(SEED + 1 + 1000 * rank)
         Us = (torch.randn(shard_rows(N_USERS, rank, world), DIM, generator=g) * math.sqrt(2.0 / (N_USERS + DIM))).to(dev)
@@ -556,15 +569,17 @@ def main():
     if not sharded:
         eng.prepared_is_complete()      # (synchronised above) the captured steps do not wait for pre-capture side-stream work
 
-    graph = None
+    graph, quiesced = None, None
     if not args.no_graph:   # K steps (kernels and, when sharded, the RCCL collectives) captured in one hipGraph
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         graph = torch.cuda.CUDAGraph()
         if sharded:
             # let the RCCL watchdog thread retire the warm-up collectives before capture begins: it polls their events
-            # from another thread, which a capture in progress does not tolerate
-            time.sleep(2.0)
+            # from another thread, which a capture in progress does not tolerate (event-based: fairrec.graph.quiesce_rccl
+            # watches torch's flight recorder until every earlier collective is marked retired)
+            from fairrec.graph import quiesce_rccl
+            quiesced = quiesce_rccl()
         try:
             with torch.cuda.stream(side):
                 with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):
@@ -725,12 +740,14 @@ def main():
         total = K * BATCH * world
         out = {
             "metric": "training interactions/sec + achieved HBM GB/s, FOCF emb=64 at 1/2/4/8 MI355X",
-            "value": round(total / dt, 1), "unit": "interactions/s", "n_gpus": world, "steps": K, "warmup": W,
+            "value": round(total / dt, 1), "unit": "interactions/s", "n_gpus": RANKS_SEEN, "steps": K, "warmup": W,
             "ms_per_step": round(dt / K * 1e3, 5), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "FOCF fair_objective=value, 1000001 users x 100001 items, embedding_size=64, "
+            "config": {"ranks_seen": RANKS_SEEN,      # N > 1: counted by an RCCL all-reduce of ones when the group came up
+                       "workload": "FOCF fair_objective=value, 1000001 users x 100001 items, embedding_size=64, "
                                    "B=8192 per GPU, Adam lr=1e-3 weight_decay=1e-3 (BASELINE.json configs[1])",
                        "item_distribution": args.item_dist, "launch": launch, "launch_modes_timed": other,
+                       "rccl_quiesce_before_capture": quiesced,     # how the wait for the watchdog ended (fairrec.graph.quiesce_rccl)
                        "step": (("item-owner-computes: records and user-row requests exchanged one step ahead; gather -> all-to-all(user rows) -> "
                                  "score / fair / grads -> all-to-all(user gradients) -> apply" if sharded and
                                  schedule == "item_owner" else
@@ -758,6 +775,20 @@ def main():
             out["trainer_fit"] = trainer_fit_block(dev, dt / K * 1e6, sweep=args.sweep)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
+    if world > 1 and not args.no_shapes:
+        # BASELINE.json configs[4] next to the FOCF line: the config the >= 6 x scaling target is stated on (NFCF finetune,
+        # 100 000 001 x 10 000 001, D = 256, both tables row-sharded over the ranks).  Every rank runs it; rank 0 reports.
+        if graph is not None:
+            graph.reset()
+            graph = None
+        del eng
+        torch.cuda.empty_cache()
+        try:
+            nf = bench_nfcf(args, rank, world, dev)
+        except Exception as e:          # e.g. a node whose GPUs cannot hold their shard: the FOCF line still goes out
+            nf = {"error": f"{type(e).__name__}: {e}"}
+        if rank == 0:
+            out["nfcf100m"] = nf
     # The JSON line is the LAST thing on stdout: RCCL's banner sits in C stdio buffers until flushed, so flush first.
     barrier()
     import ctypes

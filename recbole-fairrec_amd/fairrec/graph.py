@@ -27,6 +27,44 @@ import torch
 from .data.interaction import Interaction
 
 
+def quiesce_rccl(timeout_s: float = 10.0):
+    """Wait until a stream capture may begin in a process that holds an RCCL process group.  ProcessGroupNCCL's watchdog
+    thread polls the events of earlier EAGER collectives from another thread until it has seen each of them complete and
+    RETIRED it; a capture that begins while it still holds one makes that poll fail (hipErrorCapturedEvent) and the
+    watchdog aborts the process.  Every rank first makes its earlier collectives complete on the device
+    (barrier + synchronize); then the wait is EVENT-BASED where torch's flight recorder runs (`TORCH_FR_BUFFER_SIZE` > 0,
+    set before the process group is created -- bench.py does): poll its records until every collective of this process is
+    marked `retired`, which is exactly "the watchdog has dropped it" (measured: one to two polling passes, 0.1-0.4 s).
+    Without the recorder there is nothing to observe: a fixed wait of FAIRREC_RCCL_QUIESCE_S seconds (default 2.0, twenty
+    watchdog passes), as before round 5."""
+    import os
+    import time
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl"):
+        return "no process group"
+    dist.barrier()
+    torch.cuda.synchronize()
+    try:
+        import pickle
+        from torch._C._distributed_c10d import _dump_nccl_trace
+        t0 = time.perf_counter()
+        seen = False
+        while time.perf_counter() - t0 < timeout_s:
+            entries = pickle.loads(_dump_nccl_trace(includeCollectives=True, includeStackTraces=False, onlyActive=False)).get("entries", [])
+            if not entries:
+                break                                   # the recorder is off (or was reset): nothing to observe
+            seen = True
+            if all(e.get("retired", False) for e in entries):
+                return "retired"
+            time.sleep(0.01)
+        if seen:
+            return "timeout"
+    except Exception:                                   # a torch build without the recorder's Python entry
+        pass
+    time.sleep(float(os.environ.get("FAIRREC_RCCL_QUIESCE_S", "2.0")))
+    return "timed wait"
+
+
 class GraphedStep:
     def __init__(self, engine, optimizer, loss_fn: Callable, eager_steps: int = 2):
         self.engine, self.optimizer, self.loss_fn = engine, optimizer, loss_fn
@@ -47,20 +85,7 @@ class GraphedStep:
 
     @staticmethod
     def _quiesce_rccl():
-        """A process that holds an RCCL process group runs ProcessGroupNCCL's watchdog thread, which polls the events of
-        earlier eager collectives from ANOTHER thread; a capture that begins before it has retired them makes that poll
-        fail (hipErrorCapturedEvent) and the watchdog aborts the process.  Give it time to drain; once per
-        captured step, not per replay."""
-        import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl":
-            import os
-            import time
-            # every rank's earlier collectives are complete on the device before anyone waits: what is left is the
-            # watchdog's own polling interval (it retires finished work on its next pass, ~100 ms apart); the wait can
-            # be tuned with FAIRREC_RCCL_QUIESCE_S where a node is known to need more (or less)
-            dist.barrier()
-            torch.cuda.synchronize()
-            time.sleep(float(os.environ.get("FAIRREC_RCCL_QUIESCE_S", "2.0")))
+        quiesce_rccl()
 
     def _refresh(self, inter: Interaction):
         """The batch into the static tensors the graph reads: ONE launch for all columns (a copy launch per column is ~5 us
