@@ -1486,9 +1486,12 @@ __device__ int g_trace_step = -1;      // >= 0: only the launch that applies thi
 // launch's ramp).  They repeat fields of StepArgs / StageArgs, which the rest of the kernel reads as before.  Measured:
 // little -- 29.77 against 29.89 us per step in graph replay (five interleaved runs each), 30.8 against 31.4 us per launch in
 // the event-timed eager pass: a wave's prologue latency is hidden by the other waves of its SIMD.
+// (D = 256: the six row fragments of a task are 24 registers, their packed copies as many: at the 85 registers six waves per
+// SIMD leave, 28-44 bytes per lane went to scratch memory; five waves -- 102 registers -- hold everything)
+__host__ __device__ constexpr int step_waves(int E) { return E >= 4 ? (FR_STEP_WAVES < 5 ? FR_STEP_WAVES : 5) : FR_STEP_WAVES; }
 constexpr int STEP_PRELOAD_DWORDS = 10;      // pre_rec, pre_order (2 each), pre_B, pre_lead, pre_nu, pre_ni, pre_stage, pad
 template <int E, bool FULL, bool CLAIM>
-__global__ __launch_bounds__(64 * STEP_WPB, FR_STEP_WAVES) void focf_step_kernel(const int4* pre_rec, const int32_t* pre_order,
+__global__ __launch_bounds__(64 * STEP_WPB, step_waves(E)) void focf_step_kernel(const int4* pre_rec, const int32_t* pre_order,
                                                                                  int pre_B, int pre_lead, int pre_nu, int pre_ni,
                                                                                  int pre_stage, int pre_pad, StepArgs a,
                                                                                  StageArgs st) {
