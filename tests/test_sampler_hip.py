@@ -286,3 +286,28 @@ def test_shuffle_of_a_device_resident_interaction_equals_the_host_shuffle():
         assert torch.equal(torch.get_rng_state(), a)
         for k in cols:
             assert torch.equal(dev[k].cpu(), host[k])
+
+
+def test_device_randperm_speculation_is_dropped_when_somebody_else_draws():
+    """randperm() computes the NEXT call's permutation ahead on a side stream and hands it out only if torch's CPU generator
+    is found in exactly the state the speculation started from.  A sequence of shuffles with and without foreign draws in
+    between (torch.rand, a randperm of another size, a re-seed) must equal the host's sequence call for call."""
+    from fairrec.sampler import torch_stream as ts
+    n = 50_000
+    def sequence(perm):
+        torch.manual_seed(99)
+        out = [perm(n), perm(n)]                  # second call: the speculation's hit
+        torch.rand(3)                             # a foreign draw: the speculation is stale
+        out.append(perm(n))
+        out.append(perm(777))                     # another size in between
+        out.append(perm(n))
+        torch.manual_seed(5)                      # re-seeded
+        out.append(perm(n))
+        out.append(torch.rand(4))
+        return out
+    want = sequence(torch.randperm)
+    ts._AHEAD.clear()
+    got = sequence(lambda k: ts.randperm(k, "cuda"))
+    assert len(ts._AHEAD) >= 1                    # something IS computed ahead
+    for g, w in zip(got, want):
+        assert torch.equal(g.cpu(), w)
