@@ -543,6 +543,12 @@ FR_API int fr_linear_n1_bwd(const float* dY, const float* Y, int32_t act, const 
  * K % 32 == 0, 16-byte aligned operands). */
 FR_API int fr_linear_bwd_input_relu(const float* dY, const float* W, int64_t M, int32_t N, int32_t K, const float* Xd,
                                     float scale, float* dA, void* stream);
+/* dA = (dY W) o act'(Yin): fr_linear_bwd_input followed by the fr_act_bwd of the layer BELOW, in one launch: Yin [M, K] is this
+ * layer's input = that layer's activation output (activation code `act`, 1..4), dA the gradient at its pre-activation --
+ * the autograd of `activation(Linear(...))` between two Linear layers (recbole/model/layers.py:62-72) without a pass of its
+ * own.  Same bits as the two calls.  Fast form only (FR_EUNSUPPORTED unless N % 32 == 0, K % 32 == 0, aligned operands). */
+FR_API int fr_linear_bwd_input_act(const float* dY, const float* W, int64_t M, int32_t N, int32_t K, const float* Yin,
+                                   int32_t act, float* dA, void* stream);
 FR_API int fr_act_bwd(const float* dY, const float* Y, int32_t act, int64_t n, float* out, void* stream);
 /* The same pre-pass through a ReLU whose OUTPUT went through dropout in place: Yd = relu(z) o keep (keep = 0 or scale),
  * dY = gradient with respect to Yd; out = dY o scale o [Yd > 0] = dY o keep o relu'(z).  Replaces the reference's

@@ -565,6 +565,22 @@ extern "C" int fr_linear_bwd_input_relu(const float* dY, const float* W, int64_t
     return glds_linear_bwd_input(dY, W, M, (int)N, (int)K, dA, (int)K, nullptr, 0, (hipStream_t)stream_, Xd, scale);
 }
 
+// dA = (dY W) o act'(Yin): the input gradient of a layer whose input Yin [M, K] is the previous layer's activation output,
+// taken on through that activation in the epilogue (fr_linear_bwd_input + the next layer's fr_act_bwd in one launch: one
+// pass over an [M, K] tensor and one launch less per hidden layer of an MLP's backward pass; the product is rounded to
+// fp32 and then multiplied, exactly as the two launches do).  Fast form only, like fr_linear_bwd_input_relu.
+extern "C" int fr_linear_bwd_input_act(const float* dY, const float* W, int64_t M, int32_t N, int32_t K, const float* Yin,
+                                       int32_t act, float* dA, void* stream_) {
+    FR_CHECK_ARG(dY && W && Yin && dA && M >= 1 && N >= 1 && K >= 1 && act >= 1 && act <= 4, "fr_linear_bwd_input_act: bad argument");
+    prof_work(K_LINEAR_BWD_INPUT, 2.0 * (double)M * N * K);
+    static const bool no_glds = getenv("FAIRREC_LINEAR_NO_GLDS") != nullptr || getenv("FAIRREC_LINEAR_SLOW") != nullptr;
+    if (no_glds || N % 32 != 0 || K % 32 != 0 || (((uintptr_t)dY | (uintptr_t)W) & 15) != 0) {
+        set_error("fr_linear_bwd_input_act: shape not supported (N %% 32 == 0, K %% 32 == 0, 16-byte aligned operands)");
+        return FR_EUNSUPPORTED;
+    }
+    return glds_linear_bwd_input(dY, W, M, (int)N, (int)K, dA, (int)K, nullptr, 0, (hipStream_t)stream_, Yin, 1.f, (int)act);
+}
+
 // row splits of the weight gradient (slab bounded by 64 MiB)
 static long long bwd_weight_splits(int64_t M, int32_t N, int32_t K) {
     // >= 128 rows per split: at B = 8192 that is 64 splits, i.e. 64 x (N/64) x (K/64) workgroups -- enough to fill 256 CUs

@@ -31,6 +31,17 @@ typedef const __attribute__((address_space(1))) void* glb_vp;
 constexpr int GL_WAVES = 8, GL_NBUF = 2, GL_STAGE_FLOATS = 2048;   // per wave and stage: A block + B block, 32 x 32 floats each
 
 // the 128-byte piece [col0, col0 + 32) of row `row` of a matrix that may be two row-major blocks side by side
+// derivative of an activation expressed through its OUTPUT y (csrc/mlp.hip: act_bwd; codes 1 relu, 2 leakyrelu, 3 sigmoid, 4 tanh)
+__device__ __forceinline__ float gl_act_bwd(float y, int act) {
+    switch (act) {
+        case 1: return y > 0.f ? 1.f : 0.f;
+        case 2: return y > 0.f ? 1.f : 0.01f;
+        case 3: return y * (1.f - y);
+        case 4: return 1.f - y * y;
+        default: return 1.f;
+    }
+}
+
 __device__ __forceinline__ const float* gl_piece(const GlMat& m, long long row, int col0) {
     return col0 < m.split ? m.a + row * m.lda + col0 : m.b + row * m.ldb + (col0 - m.split);
 }
@@ -278,8 +289,10 @@ __global__ __launch_bounds__(GL_WAVES * 64) void linear_glds_kernel(GlArgs g) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int row = i0 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                if (row < g.out_rows)
-                    base[(size_t)row * ld] = src[(size_t)row * g.out_cols] > 0.f ? acc[e] * g.relu_scale : 0.f;
+                if (row < g.out_rows) {
+                    const float y = src[(size_t)row * g.out_cols];
+                    base[(size_t)row * ld] = g.src_act ? acc[e] * gl_act_bwd(y, g.src_act) : (y > 0.f ? acc[e] * g.relu_scale : 0.f);
+                }
             }
         } else {
 #pragma unroll
@@ -600,8 +613,10 @@ __device__ __forceinline__ void glds64_body(const GlArgs& g, const unsigned bid,
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int row = i0 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                if (row < g.out_rows)
-                    base[(size_t)row * ld] = src[(size_t)row * g.out_cols] > 0.f ? acc[e] * g.relu_scale : 0.f;
+                if (row < g.out_rows) {
+                    const float y = src[(size_t)row * g.out_cols];
+                    base[(size_t)row * ld] = g.src_act ? acc[e] * gl_act_bwd(y, g.src_act) : (y > 0.f ? acc[e] * g.relu_scale : 0.f);
+                }
             }
         } else {
 #pragma unroll
@@ -771,10 +786,11 @@ int glds_linear_fwd(const GlMat& X, const float* W, const float* bias, int64_t M
 }
 
 int glds_linear_bwd_input(const float* dY, const float* W, int64_t M, int N, int K, float* dx0, int k0, float* dx1, int k1,
-                          hipStream_t stream, const float* relu_src, float relu_scale) {
+                          hipStream_t stream, const float* relu_src, float relu_scale, int src_act) {
     GlArgs g{};
     g.relu_src = relu_src;
     g.relu_scale = relu_scale;
+    g.src_act = src_act;
     g.A = GlMat{dY, nullptr, N, 0, N};
     g.B = GlMat{W, nullptr, K, 0, K};
     g.rowsA = (int)M;

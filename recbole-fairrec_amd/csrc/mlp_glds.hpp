@@ -32,6 +32,8 @@ struct GlArgs {
     float* bn_part;          // forward, optional: per (32-row tile, column) (mean, M2) partials of Z = X W^T + b for the BatchNorm behind
     const float* relu_src;   // input gradient, optional: the layer's input Xd = relu(z) o keep, leading dimension out_cols;
     float relu_scale;        //   the result is then the gradient at z: (dY W) o relu_scale o [Xd > 0]
+    int src_act;             // ... or (src_act != 0) the layer's input is Y = act(z), activation code src_act, and the result the
+                             //   gradient at z: (dY W) o act'(Y) -- the activation's backward pass in this epilogue
 };
 
 // Y = act(X W^T + b); needs K % 32 == 0, X.split % 32 == 0, 16-byte aligned rows
@@ -40,7 +42,7 @@ int glds_linear_fwd(const GlMat& X, const float* W, const float* bias, int64_t M
 bool glds_shared_form();     // the macro-tile kernels are selected (FAIRREC_LINEAR_NO_SHARED unset): the only ones that write bn_part
 // dX = dY W; needs N % 32 == 0, K % 32 == 0, k0 % 32 == 0
 int glds_linear_bwd_input(const float* dY, const float* W, int64_t M, int N, int K, float* dx0, int k0, float* dx1, int k1,
-                          hipStream_t stream, const float* relu_src = nullptr, float relu_scale = 1.f);
+                          hipStream_t stream, const float* relu_src = nullptr, float relu_scale = 1.f, int src_act = 0);
 // slab[s] = dY[rows of s]^T X[rows of s], bslab[s] = column sums of dY[rows of s] (bslab may be null); needs N % 32 == 0,
 // K % 32 == 0, X.split % 32 == 0, rows_per_split % 32 == 0
 int glds_linear_bwd_weight(const float* dY, const GlMat& X, int64_t M, int N, int K, int splits, int rows_per_split,

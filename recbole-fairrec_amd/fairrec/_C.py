@@ -179,6 +179,8 @@ _PROTOS = {
                                  c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "fr_linear_bwd_input_relu": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_float, c_void_p,
                                          c_void_p]),
+    "fr_linear_bwd_input_act": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_int32, c_void_p,
+                                        c_void_p]),
     "fr_act_bwd": (c_int, [c_void_p, c_void_p, c_int32, c_int64, c_void_p, c_void_p]),
     "fr_act_bwd_dropped": (c_int, [c_void_p, c_void_p, c_float, c_int64, c_void_p, c_void_p]),
     "fr_dropout_apply": (c_int, [c_void_p, c_int64, c_float, c_uint64, c_uint64, c_void_p, c_void_p, c_void_p, c_void_p,

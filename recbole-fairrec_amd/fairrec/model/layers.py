@@ -307,6 +307,17 @@ class _HipMLP(torch.autograd.Function):
                         _C.check(lib.fr_linear_bwd_input_relu(dY.data_ptr(), W.data_ptr(), M, N, K, a.data_ptr(), ctx.scale,
                                                               da.data_ptr(), st), "fr_linear_bwd_input_relu")
                         at_z = True
+                    elif (l > 0 and not ctx.use_bn and ctx.act != 0 and act == 0 and mk is None and scale == 1.0 and drop is None
+                          and ctx.masks is None and not ctx.premul[l] and not ctx.dropped_out[l - 1] and k1 == 0
+                          and N % 32 == 0 and K % 32 == 0 and params[per * (l - 1)].shape[1] % 32 == 0
+                          and (l - 1 > 0 or x1 is None or x0.shape[1] % 32 == 0)
+                          and os.environ.get("FAIRREC_LINEAR_NO_GLDS") is None and os.environ.get("FAIRREC_LINEAR_SLOW") is None
+                          and os.environ.get("FAIRREC_ACT_BWD_SEPARATE") is None):
+                        # the input is the activation output of the layer below: on through act' in the epilogue, so that layer
+                        # starts from the gradient at its pre-activation (no fr_act_bwd pass of its own; same bits)
+                        _C.check(lib.fr_linear_bwd_input_act(dY.data_ptr(), W.data_ptr(), M, N, K, a.data_ptr(), ctx.act,
+                                                             da.data_ptr(), st), "fr_linear_bwd_input_act")
+                        at_z = True
                     else:
                         _C.check(lib.fr_linear_bwd_input(dY.data_ptr(), Y.data_ptr(), act, W.data_ptr(), _C.ptr(mk), scale,
                                                          M, N, da.data_ptr(), k0, _C.ptr(dc), k1, st), "fr_linear_bwd_input")

@@ -144,6 +144,66 @@ def test_input_gradient_taken_on_through_a_dropped_relu(M, N, K):
     assert rc == -3
 
 
+@pytest.mark.parametrize("act", [1, 2, 3, 4])
+@pytest.mark.parametrize("M,N,K", [(8192, 64, 128), (1000, 128, 512), (333, 32, 32)])
+def test_input_gradient_taken_on_through_the_activation_below(M, N, K, act):
+    """fr_linear_bwd_input_act: dA = (dY W) o act'(Yin) -- what fr_linear_bwd_input followed by the fr_act_bwd of the layer
+    below give, BIT FOR BIT (the product is rounded, then multiplied, in both), and torch's autograd of act(z) @ W^T."""
+    _C = _lib()
+    lib = _C.lib()
+    g = torch.Generator().manual_seed(M + N + K + act)
+    z = torch.randn(M, K, generator=g).requires_grad_()
+    Yin = ACTS[act](z)
+    W = (torch.randn(N, K, generator=g) * 0.3)
+    dY = torch.randn(M, N, generator=g)
+    (Yin @ W.t()).backward(dY)
+    Yd, Wd, dYd = Yin.detach().cuda(), W.cuda(), dY.cuda()
+    st = _C.current_stream()
+    dA = torch.empty(M, K, device="cuda")
+    _C.check(lib.fr_linear_bwd_input_act(dYd.data_ptr(), Wd.data_ptr(), M, N, K, Yd.data_ptr(), act, dA.data_ptr(), st), "bwd_input_act")
+    dX = torch.empty(M, K, device="cuda")
+    two = torch.empty(M, K, device="cuda")
+    _C.check(lib.fr_linear_bwd_input(dYd.data_ptr(), dYd.data_ptr(), 0, Wd.data_ptr(), None, 1.0, M, N, dX.data_ptr(), K, None, 0, st),
+             "bwd_input")
+    _C.check(lib.fr_act_bwd(dX.data_ptr(), Yd.data_ptr(), act, dX.numel(), two.data_ptr(), st), "act_bwd")
+    assert torch.equal(dA, two)
+    torch.testing.assert_close(dA.cpu(), z.grad, rtol=2e-4, atol=2e-5 * max(1.0, float(z.grad.abs().max())))
+    assert lib.fr_linear_bwd_input_act(dYd.data_ptr(), Wd.data_ptr(), M, 24, K, Yd.data_ptr(), act, dA.data_ptr(), st) == -3
+
+
+@pytest.mark.parametrize("act", ["relu", "leakyrelu", "tanh"])
+def test_mlp_backward_with_the_activation_folded_into_the_product_below_equals_the_separate_pass(act, monkeypatch):
+    """MLPLayers.backward: a hidden layer's activation derivative rides in the epilogue of the input-gradient product of the
+    layer above (fr_linear_bwd_input_act) instead of a pass of its own (FAIRREC_ACT_BWD_SEPARATE=1 restores it): every
+    gradient equal bit for bit, one launch and one [M, width] pass less per hidden layer."""
+    from fairrec import _C
+    from fairrec.model.layers import MLPLayers
+    torch.manual_seed(3)
+    mlp = MLPLayers([128, 128, 64, 32], activation=act).cuda()
+    x = torch.randn(4096, 128, device="cuda")
+    grads, passes = [], []
+    lib = _C.lib()
+    real = lib.fr_act_bwd
+    calls = []
+    monkeypatch.setattr(lib, "fr_act_bwd", lambda *a: calls.append(1) or real(*a))
+    for separate in (True, False):
+        if separate:
+            monkeypatch.setenv("FAIRREC_ACT_BWD_SEPARATE", "1")
+        else:
+            monkeypatch.delenv("FAIRREC_ACT_BWD_SEPARATE")
+        xi = x.clone().requires_grad_()
+        for p in mlp.parameters():
+            p.grad = None
+        del calls[:]
+        mlp(xi).square().sum().backward()
+        torch.cuda.synchronize()
+        passes.append(len(calls))
+        grads.append([xi.grad.clone()] + [p.grad.clone() for p in mlp.parameters()])
+    for a, b in zip(*grads):
+        assert torch.equal(a, b)
+    assert passes == [3, 1], passes          # only the top layer's activation still takes a pass of its own
+
+
 def test_act_bwd_through_a_relu_dropped_in_place():
     """fr_act_bwd_dropped: Yd = relu(z) o keep, gradient at z = dY o keep o relu'(z) without z or the keep pattern."""
     _C = _lib()
