@@ -599,6 +599,7 @@ def main():
                 del eng.ops._side
         torch.cuda.current_stream().wait_stream(side)
 
+    # (the captured steps carry their optimizer step numbers and stamps as kernel arguments: this graph is replayed ONCE)
     barrier()
     t0 = time.perf_counter()
     if graph is not None:
@@ -630,6 +631,18 @@ def main():
         dt_eager = time.perf_counter() - t0
         eng.check_device_errors()
         other = {"hipGraph_ms_per_step": round(dt / K * 1e3, 5), "eager_ms_per_step": round(dt_eager / K * 1e3, 5)}
+        if eng.can_step_many():
+            # ... and the same K steps' worth issued by the LIBRARY's own step loop (fr_focf_steps_many: what Trainer._train_epoch
+            # calls, one foreign call for the run; its two stage launches for the first batches are inside the clock)
+            ul, il, rl, sl = (t.to(dev).reshape(-1) for t in synth_batches(K + 4, BATCH, N_USERS, N_ITEMS, SEED + 32452843 + rank, args.item_dist))
+            c4 = 4 * BATCH
+            eng.steps_many(ul[:c4], il[:c4], rl[:c4], sl[:c4], BATCH)      # (first use: the run's ring of workspaces is allocated)
+            barrier()
+            t0 = time.perf_counter()
+            eng.steps_many(ul[c4:], il[c4:], rl[c4:], sl[c4:], BATCH)
+            barrier()
+            other["library_loop_ms_per_step"] = round((time.perf_counter() - t0) / K * 1e3, 5)
+            eng.check_device_errors()
 
     # ---- per-kernel device time: K more steps, eager, with the library's HIP-event profiler -----------
     roofline = None
