@@ -11,7 +11,7 @@
 # Raw output lands in gpurun_out/<round>/ (scratch); `python profiles/summarize.py <round>` then writes the
 # tracked summaries into profiles/.
 set -u
-ROUND=${1:-r04}
+ROUND=${1:-r05}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$ROUND
 mkdir -p $OUT
@@ -34,6 +34,11 @@ python3 bench.py --workload pfcn10m --steps 20 --warmup 5 > $OUT/pfcn10m.json 2>
 python3 bench.py --workload nfcf100m --steps 20 --warmup 5 > $OUT/nfcf100m.json 2> $OUT/nfcf100m.err
 python3 bench.py --workload nfcf100m --nfcf-users 1000001 --nfcf-items 100001 --steps 20 --warmup 5 > $OUT/nfcf1m.json 2> $OUT/nfcf1m.err
 timeout 2400 python3 bench.py --workload fairgo10m --steps 3 --warmup 3 > $OUT/fairgo10m.json 2> $OUT/fairgo10m.err
+# 8) round 5: the plugin surface (Trainer._train_epoch through the loaders), the device shuffle, the VALU issue rates
+STEPS=1024 python3 scratch/trainer_bench.py device > $OUT/trainer_bench_device.txt 2>&1
+python3 scratch/randperm_bench.py > $OUT/randperm_bench.txt 2>&1
+hipcc -O3 --offload-arch=gfx950 scratch/valu_rates.hip -o /tmp/valu_rates > /dev/null 2>&1 && /tmp/valu_rates > $OUT/valu_rates.txt 2>&1
+hipcc -O3 --offload-arch=gfx950 scratch/replay_bench.hip -o /tmp/replay_bench > /dev/null 2>&1 && /tmp/replay_bench 128 3000 > $OUT/replay_bench.txt 2>&1
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_pfcn -- python3 $R/bench.py --workload pfcn10m --steps 10 --warmup 5 > $OUT/pfcn_under_rocprof.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_nfcf -- python3 $R/bench.py --workload nfcf100m --nfcf-users 1000001 --nfcf-items 100001 --steps 10 --warmup 5 > $OUT/nfcf_under_rocprof.log 2>&1
