@@ -1,5 +1,7 @@
 """Device randperm (fr_randperm) against torch.randperm on the host: time per call at the epoch sizes of the bench."""
-import os, sys, time, torch
+import os, sys, time
+os.environ.setdefault("FAIRREC_RANDPERM_AHEAD", "0")     # one permutation per call: no look-ahead launch beside the timed one
+import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "recbole-fairrec_amd")]
 from fairrec.sampler.torch_stream import randperm
