@@ -78,6 +78,46 @@ def test_train_dataloader_covers_dataset_once():
     assert torch.equal(b["gender"], ds.user_feat["gender"][b["user_id"]])
 
 
+@pytest.mark.parametrize("per_call", [1, 3, 100])
+def test_loaders_hand_out_runs_of_batches_equal_to_iterating_them(per_call):
+    """`take(n)` (what Trainer._train_epoch feeds `model.train_steps` with: the next n batches as ONE Interaction) against plain
+    iteration, for the shuffled fixed-size loader and for the item-complete one: same rows in the same order, same batch
+    boundaries (a short last batch; ragged item-complete sizes), the same generator consumption, epoch after epoch."""
+    c = Config(model="FOCF", config_dict={"train_batch_size": 128})
+    for kind in ("plain", "item_complete"):
+        def make():
+            ds = synthetic_dataset(c, 50, 40, 1000, seed=3)
+            return TrainDataLoader(c, ds, shuffle=True) if kind == "plain" else FOCFDataLoader(c, ds)
+        a, b = make(), make()
+        assert b.sliceable
+        torch.manual_seed(1); np.random.seed(1)
+        want = [[bt for bt in a] for _ in range(2)]
+        after_iterating = (torch.get_rng_state().clone(), np.random.get_state()[1].copy(), np.random.get_state()[2])
+        torch.manual_seed(1); np.random.seed(1)
+        for epoch in range(2):
+            iter(b)
+            got_rows, got_sizes = [], []
+            while True:
+                run = b.take(per_call)
+                if run is None:
+                    break
+                inter, size = run
+                sizes = [size] * -(-len(inter) // size) if isinstance(size, int) else list(size)
+                if isinstance(size, int):
+                    sizes[-1] = len(inter) - size * (len(sizes) - 1)
+                assert sum(sizes) == len(inter) and len(sizes) <= per_call
+                got_rows.append(inter)
+                got_sizes += sizes
+            assert got_sizes == [len(bt) for bt in want[epoch]], kind
+            for col in ("user_id", "item_id", "rating", "gender"):
+                np.testing.assert_array_equal(torch.cat([r[col] for r in got_rows]).numpy(),
+                                              torch.cat([bt[col] for bt in want[epoch]]).numpy(), err_msg=f"{kind} {col}")
+        # ... and both ways of walking two epochs took the same draws from both generators
+        assert torch.equal(torch.get_rng_state(), after_iterating[0])
+        st = np.random.get_state()
+        assert np.array_equal(st[1], after_iterating[1]) and st[2] == after_iterating[2]
+
+
 def test_focf_dataloader_matches_reference_golden():
     z = np.load(os.path.join(GOLDEN, "dataloader_focf.npz"))
     c = Config(model="FOCF", config_dict={"train_batch_size": int(z["step"])})

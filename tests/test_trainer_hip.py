@@ -281,7 +281,11 @@ def test_focf_dataloader_device_resident_matches_reference_golden():
     ds = InteractionDataset(c, inter, users, n_users=100, n_items=int(z["item_num"]))
     ds.to("cuda")
     dl = FOCFDataLoader(c, ds)
+    # (seeded the way `init_seed` does: numpy AND the device mirrors of its stream -- in a process that holds a mirror, the
+    # loader's picks are drawn inside host_numpy_stream(), i.e. from the one stream the device sampler shares)
+    from fairrec.sampler.sampler import seed_all
     np.random.seed(int(z["np_seed"]))
+    seed_all(int(z["np_seed"]))
     it = iter(dl)
     for b in range(4):
         batch = next(it)
