@@ -788,7 +788,7 @@ def main():
             out["trainer_fit"] = trainer_fit_block(dev, dt / K * 1e6, sweep=args.sweep)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
-    if world > 1 and not args.no_shapes:
+    if (world > 1 or os.environ.get("FAIRREC_BENCH_NFCF_BLOCK") == "1") and not args.no_shapes:      # (the env: this code path on one GPU)
         # BASELINE.json configs[4] next to the FOCF line: the config the >= 6 x scaling target is stated on (NFCF finetune,
         # 100 000 001 x 10 000 001, D = 256, both tables row-sharded over the ranks).  Every rank runs it; rank 0 reports.
         if graph is not None:
