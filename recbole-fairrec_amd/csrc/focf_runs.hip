@@ -785,12 +785,23 @@ extern "C" int fr_focf_runs_many(const fr_table* U, const fr_table* I, const fr_
     std::vector<int32_t> stamps((size_t)n);
     for (int k = 0; k < n; ++k) stamps[(size_t)k] = first_stamp + k;
     SideStream* ss = side_stream();
-    static hipEvent_t ev_fork = nullptr, ev_done[2] = {nullptr, nullptr};
-    if (ss && !ev_fork) {
-        FR_CHECK_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
-        FR_CHECK_HIP(hipEventCreateWithFlags(&ev_done[0], hipEventDisableTiming));
-        FR_CHECK_HIP(hipEventCreateWithFlags(&ev_done[1], hipEventDisableTiming));
+    // the call's own events (the library keeps no host state between calls: two host threads may drive two engines); an
+    // event destroyed while work recorded behind it is still in flight is released by the runtime when that work is done
+    struct Events {
+        hipEvent_t fork = nullptr, done[2] = {nullptr, nullptr};
+        ~Events() {
+            if (fork) (void)hipEventDestroy(fork);
+            if (done[0]) (void)hipEventDestroy(done[0]);
+            if (done[1]) (void)hipEventDestroy(done[1]);
+        }
+    } ev;
+    if (ss && n > G) {
+        FR_CHECK_HIP(hipEventCreateWithFlags(&ev.fork, hipEventDisableTiming));
+        FR_CHECK_HIP(hipEventCreateWithFlags(&ev.done[0], hipEventDisableTiming));
+        FR_CHECK_HIP(hipEventCreateWithFlags(&ev.done[1], hipEventDisableTiming));
     }
+    hipEvent_t ev_fork = ev.fork;
+    hipEvent_t* ev_done = ev.done;
     int rc;
     auto prepare = [&](int g, hipStream_t st) {
         const int lo = g * G, cnt = std::min(G, n - lo);
