@@ -213,6 +213,14 @@ class GenericEngine:
     def note_stepped(self, group=None):
         """An optimizer step of `group` was issued (here, or as a replay of a captured step: fairrec/graph.py)."""
         self._group_version[group] = self._group_version.get(group, 0) + 1
+        # a REPLAYED step runs none of the host code that marks a table's rows as behind the optimizer step: without this a
+        # flush that follows an earlier flush with only graph replays in between was skipped, and a whole-table reader (a
+        # checkpoint per epoch, FairGo's finetune stage reading the pretrained tables) got rows short of their last
+        # zero-gradient steps (found in round 5 when the FairGo trainer began to checkpoint after EVERY pretrain epoch, as the
+        # reference does: tests/test_fairgo_hip.py::test_fairgo_trainer_pretrain_then_finetune, graph against eager twin)
+        for name, t in self._tables.items():
+            if t.trainable and self._owned(name, group):
+                t._dirty = True
 
     def group_version(self, group=None) -> int:
         return self._group_version.get(group, 0)

@@ -646,28 +646,62 @@ class FairGoTrainer(PFCNTrainer):
                    saved_model_file)
 
     def pretrain(self, train_data, valid_data=None, verbose=True, saved=True, show_progress=False):
+        """trainer.py:606-685: `pretrain_epochs` of the plain regression with optimizer_pretrain; WITH validation data every
+        `eval_step`-th epoch is validated (the evaluation loader's negatives come from the numpy stream the training
+        negatives come from, so this moves every later batch), early stopping runs on the trainer's usual counters, the
+        pretrain checkpoint is written on improvement -- without validation data after every epoch -- and read back at the
+        end (the best pretrain model, not the last one, enters the finetune stage)."""
         self.saved_pretrain_model_file = os.path.join(
             self.checkpoint_dir, '{}-{}-pretrain.pth'.format(self.config['model'], self.config['dataset']))
+        self.eval_step = min(self.config['eval_step'] if self.config['eval_step'] is not None else 1, self.pretrain_epochs)
         self.optimizer = self.optimizer_pretrain
+        self._train_data_for_eval = train_data                        # eval_collector.data_collect(train_data), :621
         for epoch_idx in range(self.start_epoch, self.pretrain_epochs):
             t0 = time()
             loss = self._train_epoch_with_mask(train_data, epoch_idx, self.model.calculate_loss, None)
             self.train_loss_dict[epoch_idx] = loss
             if verbose:
                 self.logger.info(self._generate_train_loss_output(epoch_idx, t0, time(), loss))
-        if saved:
-            self.save_pretrained_model(self.saved_pretrain_model_file)
+            if self.eval_step <= 0 or not valid_data:
+                if saved:
+                    self.save_pretrained_model(self.saved_pretrain_model_file)
+                continue
+            if (epoch_idx + 1) % self.eval_step == 0:
+                valid_score, valid_result = self._valid_epoch(valid_data, show_progress=show_progress)
+                self.best_valid_score, self.cur_step, stop_flag, update_flag = early_stopping(
+                    valid_score, self.best_valid_score, self.cur_step, max_step=self.stopping_step,
+                    bigger=self.valid_metric_bigger)
+                if verbose:
+                    self.logger.info('epoch %d evaluating [valid_score: %f] %s', epoch_idx, valid_score, dict2str(valid_result))
+                if update_flag:
+                    if saved:
+                        self.save_pretrained_model(self.saved_pretrain_model_file)
+                    self.best_valid_result = valid_result
+                if stop_flag:
+                    break
+        if os.path.exists(self.saved_pretrain_model_file):            # (the reference reads it unconditionally, :677)
             ck = torch.load(self.saved_pretrain_model_file, weights_only=False)
             self.model.load_state_dict(ck['state_dict'])
+            self.model.load_other_parameter(ck.get('other_parameter'))
             if self.config['save_sst_embed']:      # trainer.py:681-682
                 self._save_sst_embed(train_data, os.path.join(self.checkpoint_dir, '{}-{}-pretrain_embed[none].pth'.format(
                     self.config['model'], self.config['dataset'])))
+        return self.best_valid_score, self.best_valid_result
+
+    def reset_params(self):
+        """trainer.py:560-577: the finetune stage starts from fresh counters."""
+        self.epochs = self.config['epochs']
+        self.eval_step = min(self.config['eval_step'] if self.config['eval_step'] is not None else 1, self.epochs)
+        self.start_epoch, self.cur_step = 0, 0
+        self.best_valid_score = -np.inf if self.valid_metric_bigger else np.inf
+        self.best_valid_result = None
+        self.train_loss_dict = dict()
+        self.model.train_stage = 'finetune'
 
     def fit(self, train_data, valid_data=None, verbose=True, saved=True, show_progress=False, callback_fn=None):
         if self.model.train_stage == 'pretrain':
             self.pretrain(train_data, valid_data, verbose, saved, show_progress)
-            self.start_epoch, self.cur_step, self.train_loss_dict = 0, 0, dict()     # reset_params, trainer.py:560-577
-            self.model.train_stage = 'finetune'
+            self.reset_params()
         elif self.model.train_stage != 'finetune':
             raise ValueError("Please make sure that the 'train_stage' is 'pretrain' or 'finetune'!")
         return Trainer.fit(self, train_data, valid_data, verbose, saved, show_progress, callback_fn)

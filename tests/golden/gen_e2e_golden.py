@@ -211,6 +211,7 @@ def run_reference_flow(case, model_name, dataset, overrides, trainer_expected, l
       eval<j>.sha / .rows   per batch k of that evaluation: sha256 over the int64 item column (positives then sampled negatives,
                             user by user) followed by the user column, and its size; eval<j>.b<k>.item_id / user_id in full for
                             k = 0 (every batch when `full_ids`)
+      eval<j>.tied_users    users of that evaluation whose top-k list is decided by an exact score tie between distinct candidates
       saved_epochs          epochs at which the trainer wrote its checkpoint; best_valid_score, best_valid_result, test_result
     """
     import hashlib
@@ -272,10 +273,20 @@ def run_reference_flow(case, model_name, dataset, overrides, trainer_expected, l
             return evaluate
 
         def predict(interaction, *a, **kw):
+            out = orig_predict(interaction, *a, **kw)
             if cur["batches"] is not None:
-                cur["batches"].append({k: v.detach().cpu().numpy().copy() for k, v in interaction.interaction.items()
-                                       if k in ("user_id", "item_id")})
-            return orig_predict(interaction, *a, **kw)
+                b = {k: v.detach().cpu().numpy().copy() for k, v in interaction.interaction.items() if k in ("user_id", "item_id")}
+                # users whose top-k list is decided by an exact score tie between DISTINCT candidates (torch.topk's tie order)
+                sc = out.detach().cpu().numpy().reshape(-1).astype(np.float64)
+                tied = 0
+                for u in np.unique(b["user_id"]):
+                    m = b["user_id"] == u
+                    _, first = np.unique(b["item_id"][m], return_index=True)
+                    v = np.sort(sc[m][first])[::-1][:max(config["topk"]) + 1]
+                    tied += int((v[1:] == v[:-1]).any())
+                b["tied"] = tied
+                cur["batches"].append(b)
+            return out
 
         def save(epoch_idx, *a, **kw):
             saved_epochs.append(int(epoch_idx))
@@ -311,6 +322,7 @@ def run_reference_flow(case, model_name, dataset, overrides, trainer_expected, l
             out[f"eval{j}.sha"] = np.array([hashlib.sha256(b["item_id"].astype(np.int64).tobytes() +
                                                            b["user_id"].astype(np.int64).tobytes()).hexdigest() for b in ev["batches"]])
             out[f"eval{j}.rows"] = np.array([len(b["item_id"]) for b in ev["batches"]])
+            out[f"eval{j}.tied_users"] = np.array(sum(b["tied"] for b in ev["batches"]))
             for k, b in enumerate(ev["batches"]):
                 n_ids += len(b["item_id"])
                 if k == 0 or full_ids:
@@ -325,11 +337,13 @@ def run_reference_flow(case, model_name, dataset, overrides, trainer_expected, l
                 "filter_mode", "dis_weight", "dis_hidden_size_list", "dis_dropout", "activation", "train_epoch_interval",
                 "sst_attr_list", "neg_sampling", "seed", "RATING_FIELD", "LABEL_FIELD", "threshold", "clip_grad_norm",
                 "save_sst_embed", "eval_step", "stopping_step", "metrics", "topk", "valid_metric", "eval_batch_size",
-                "metric_decimal_place", "popularity_ratio", "eval_args")
+                "metric_decimal_place", "popularity_ratio", "eval_args", "aggr_method", "vs_weights", "n_layers",
+                "filter_hidden_size_list", "pretrain_epochs", "mlp_hidden_size", "dropout")
         out["config"] = np.array(json.dumps({k: config[k] for k in keep if k in config.final_config_dict}, default=str))
         out["model"], out["trainer"], out["loader"] = np.array(model_name), np.array(trainer_expected), np.array(loader_expected)
         path = os.path.join(HERE, f"e2e_{case}.npz")
         np.savez_compressed(path, **out)
+        print("  users with a tied top-k per evaluation:", [sum(b["tied"] for b in ev["batches"]) for ev in evals])
         print(f"{path}: {len(lis.steps)} steps, {len(evals)} evaluations ({n_ids} scored ids), saved at epochs {saved_epochs}, "
               f"best valid {best_valid_score}, epoch losses {epoch_losses}, {os.path.getsize(path) / 1e6:.2f} MB")
         print("  test_result", test_result)
@@ -359,6 +373,22 @@ def case_flow_pfcn_biasedmf():
         "data_path": _synth_root(), "embedding_size": 16, "filter_mode": "sm", "dis_hidden_size_list": [32, 16], "dis_dropout": 0.0,
         "dis_weight": 10, "train_epoch_interval": 1, "weight_decay": 1e-4, "epochs": 3, "save_sst_embed": False})),
         "PFCN_BiasedMFTrainer", "TrainDataLoader", full_ids=True)
+
+
+def case_flow_nfcf():
+    run_reference_flow("flow_nfcf_pretrain", "NFCF", "synth", dict(COMMON, **dict(TEST_YAML_EVAL, **{
+        "data_path": _synth_root(), "embedding_size": 16, "mlp_hidden_size": [32, 16], "dropout": 0.0, "load_pretrain_path": None,
+        "weight_decay": 1e-6, "epochs": 3, "save_sst_embed": False,
+        # (at the default 1e-3 a few users' top-5 lists are decided by exact ties between candidates whose ReLU output is 0 --
+        # torch.topk's tie order, not the model, then fixes the metrics; at 2e-4 no list of any evaluation is)
+        "learning_rate": 2e-4})), "Trainer", "TrainDataLoader", full_ids=True)
+
+
+def case_flow_fairgo_pmf():
+    run_reference_flow("flow_fairgo_pmf_wap", "FairGo_PMF", "synth", dict(COMMON, **dict(TEST_YAML_EVAL, **{
+        "data_path": _synth_root(), "embedding_size": 16, "aggr_method": "WAP", "n_layers": 2, "dis_hidden_size_list": [16, 8, 4],
+        "filter_hidden_size_list": [32, 16], "pretrain_epochs": 2, "train_epoch_interval": 1, "weight_decay": 1e-4,
+        "fair_weight": 0.1, "epochs": 3, "save_sst_embed": False})), "FairGo_PMFTrainer", "TrainDataLoader", full_ids=True)
 
 
 def case_focf_ml100k():
@@ -403,7 +433,7 @@ def case_nfcf_pretrain():
 
 CASES = {"focf_ml100k": case_focf_ml100k, "pfcn_biasedmf": case_pfcn_biasedmf, "fairgo_pmf": case_fairgo_pmf,
          "nfcf_pretrain": case_nfcf_pretrain, "flow_focf_ml100k": case_flow_focf_ml100k,
-         "flow_pfcn_biasedmf": case_flow_pfcn_biasedmf}
+         "flow_pfcn_biasedmf": case_flow_pfcn_biasedmf, "flow_nfcf": case_flow_nfcf, "flow_fairgo_pmf": case_flow_fairgo_pmf}
 
 if __name__ == "__main__":
     names = [a for a in ARGV if a in CASES] or list(CASES)
