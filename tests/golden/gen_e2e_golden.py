@@ -338,7 +338,8 @@ def run_reference_flow(case, model_name, dataset, overrides, trainer_expected, l
                 "sst_attr_list", "neg_sampling", "seed", "RATING_FIELD", "LABEL_FIELD", "threshold", "clip_grad_norm",
                 "save_sst_embed", "eval_step", "stopping_step", "metrics", "topk", "valid_metric", "eval_batch_size",
                 "metric_decimal_place", "popularity_ratio", "eval_args", "aggr_method", "vs_weights", "n_layers",
-                "filter_hidden_size_list", "pretrain_epochs", "mlp_hidden_size", "dropout")
+                "filter_hidden_size_list", "pretrain_epochs", "mlp_hidden_size", "dropout", "mlp_dropout", "num_layers",
+                "mlp_activation", "dis_activation")
         out["config"] = np.array(json.dumps({k: config[k] for k in keep if k in config.final_config_dict}, default=str))
         out["model"], out["trainer"], out["loader"] = np.array(model_name), np.array(trainer_expected), np.array(loader_expected)
         path = os.path.join(HERE, f"e2e_{case}.npz")
@@ -391,6 +392,42 @@ def case_flow_fairgo_pmf():
         "fair_weight": 0.1, "epochs": 3, "save_sst_embed": False})), "FairGo_PMFTrainer", "TrainDataLoader", full_ids=True)
 
 
+def _flow(case, model, trainer, loader="TrainDataLoader", **over):
+    run_reference_flow(case, model, "synth", dict(COMMON, **dict(TEST_YAML_EVAL, **dict(
+        {"data_path": _synth_root(), "embedding_size": 16, "epochs": 3, "save_sst_embed": False}, **over))), trainer, loader,
+        full_ids=True)
+
+
+def case_flow_pfcn_pmf_none():
+    _flow("flow_pfcn_pmf_none", "PFCN_PMF", "PFCN_PMFTrainer", filter_mode="none", dis_hidden_size_list=[32, 16], dis_dropout=0.0,
+          dis_weight=10, train_epoch_interval=1, weight_decay=1e-4)
+
+
+def case_flow_pfcn_mlp_sm():
+    _flow("flow_pfcn_mlp_sm", "PFCN_MLP", "PFCN_MLPTrainer", filter_mode="sm", dis_hidden_size_list=[32, 16], dis_dropout=0.0,
+          dis_weight=10, train_epoch_interval=1, weight_decay=1e-4, mlp_hidden_size=[32, 16], dropout=0.0, mlp_dropout=0.0)
+
+
+def case_flow_pfcn_dmf_sm():
+    _flow("flow_pfcn_dmf_sm", "PFCN_DMF", "PFCN_DMFTrainer", filter_mode="sm", dis_hidden_size_list=[32, 16], dis_dropout=0.0,
+          dis_weight=10, train_epoch_interval=2, weight_decay=1e-4, mlp_dropout=0.0, num_layers=2)
+
+
+def case_flow_focf_absolute():
+    _flow("flow_focf_absolute", "FOCF", "Trainer", "FOCFDataLoader", embedding_size=32, fair_objective="absolute", fair_weight=0.5,
+          train_batch_size=512)
+
+
+def case_flow_focf_nonparity():
+    _flow("flow_focf_nonparity", "FOCF", "Trainer", "FOCFDataLoader", embedding_size=32, fair_objective="nonparity", fair_weight=0.5,
+          train_batch_size=512)
+
+
+def case_flow_fairgo_pmf_lba():
+    _flow("flow_fairgo_pmf_lba", "FairGo_PMF", "FairGo_PMFTrainer", aggr_method="LBA", n_layers=2, dis_hidden_size_list=[16, 8, 4],
+          filter_hidden_size_list=[32, 16], pretrain_epochs=2, train_epoch_interval=2, weight_decay=1e-4, fair_weight=0.1)
+
+
 def case_focf_ml100k():
     """BASELINE.json configs[0]: `run_recbole.py -m FOCF -d ml-100k`, embedding_size 64, with the override yaml SURVEY.md §8-d /
     App. B-11 prescribes (the model yaml's data settings are shadowed by sample.yaml / ml-100k.yaml)."""
@@ -433,7 +470,10 @@ def case_nfcf_pretrain():
 
 CASES = {"focf_ml100k": case_focf_ml100k, "pfcn_biasedmf": case_pfcn_biasedmf, "fairgo_pmf": case_fairgo_pmf,
          "nfcf_pretrain": case_nfcf_pretrain, "flow_focf_ml100k": case_flow_focf_ml100k,
-         "flow_pfcn_biasedmf": case_flow_pfcn_biasedmf, "flow_nfcf": case_flow_nfcf, "flow_fairgo_pmf": case_flow_fairgo_pmf}
+         "flow_pfcn_biasedmf": case_flow_pfcn_biasedmf, "flow_nfcf": case_flow_nfcf, "flow_fairgo_pmf": case_flow_fairgo_pmf,
+         "flow_pfcn_pmf_none": case_flow_pfcn_pmf_none, "flow_pfcn_mlp_sm": case_flow_pfcn_mlp_sm,
+         "flow_pfcn_dmf_sm": case_flow_pfcn_dmf_sm, "flow_focf_absolute": case_flow_focf_absolute,
+         "flow_focf_nonparity": case_flow_focf_nonparity, "flow_fairgo_pmf_lba": case_flow_fairgo_pmf_lba}
 
 if __name__ == "__main__":
     names = [a for a in ARGV if a in CASES] or list(CASES)
