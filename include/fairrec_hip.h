@@ -833,6 +833,17 @@ FR_API int fr_sample_negatives_calls(uint32_t* state, int64_t low, int64_t high,
                                      const int64_t* used_indptr, const int32_t* used_items, int64_t n_users, int64_t* out,
                                      void* ws, size_t ws_bytes, uint32_t* err_flag, void* stream);
 
+/* ---- FOCF's item-complete batcher (next-row f-3): the picks of a whole epoch in one HOST call ---------------------------------
+ * focf_dataloader.py:37-51 composes a batch by `np.random.choice(select_item[is_select], 1, False)` per picked item: numpy's
+ * legacy choice permutes the whole candidate list per pick and reads one element.  fr_focf_compose_epoch makes the same draws
+ * from the same stream (state: numpy's legacy layout key[624] + pos in HOST memory, advanced in place) and returns the same
+ * picks without building the permutations (csrc/focf_compose.hip).  item_uniques [n_uniq] ascending, indptr [n_items + 1] the
+ * CSR of the item-sorted interaction table, `pr` / `pr_end` / `step` the loader's counters; picks_out [cap] the picked items,
+ * batch_end_out[b] the number of picks up to and including batch b.  No device work, no stream. */
+FR_API int fr_focf_compose_epoch(uint32_t* state, const int64_t* item_uniques, int64_t n_uniq, const int64_t* indptr,
+                                 int64_t step, int64_t pr, int64_t pr_end, int64_t* picks_out, int64_t cap,
+                                 int64_t* batch_end_out, int64_t max_batches, int64_t* n_batches_out);
+
 /* ---- epoch shuffle (next-row f-1: the batch feed): torch.randperm(n) on the device, bit-exact ---------------------------
  * Replaces the `torch.randperm(self.length)` behind Interaction.shuffle (interaction.py:293-297), the training loader's
  * per-epoch shuffle (abstract_dataloader.py:81-84).  Underneath: ATen's randperm_cpu for n < 2^32 / 20 -- r[i] = i, then for

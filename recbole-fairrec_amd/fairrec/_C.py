@@ -99,6 +99,8 @@ _PROTOS = {
                                     c_void_p, c_void_p]),
     "fr_focf_step_finish_staged": (c_int, [c_void_p, c_size_t, c_int64, c_int32, c_int32, c_float, c_void_p, c_void_p,
                                            c_void_p]),
+    "fr_focf_compose_epoch": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64,
+                                      c_void_p, c_int64, c_void_p]),
     "fr_randperm_workspace_bytes": (c_size_t, [c_int64]),
     "fr_randperm": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),
     "fr_focf_runs_many": (c_int, [POINTER(FrTable), POINTER(FrTable), POINTER(FrAdam), c_void_p, c_int32, c_int32, c_float,

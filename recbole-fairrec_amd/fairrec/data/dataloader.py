@@ -130,6 +130,10 @@ class TrainDataLoader(AbstractDataLoader):
         return cur, self.step
 
 
+def _degree(indptr, ids):
+    return indptr[ids + 1] - indptr[ids]
+
+
 class FOCFDataLoader(AbstractDataLoader):
     """Item-complete batches: keep picking a random not-yet-picked item and append ALL its interactions until
     the batch holds >= train_batch_size rows (focf_dataloader.py:37-51)."""
@@ -153,23 +157,40 @@ class FOCFDataLoader(AbstractDataLoader):
         reference's position of the stream -- with ONE hand-over between numpy and its device mirror per epoch
         (`host_numpy_stream`: the evaluation loaders' negatives come from the mirror) instead of one per batch."""
         from ..sampler import host_numpy_stream
-        batches, pr = [], self.pr
+        from .. import _C
+        lib = _C.lib()
+        n_batches = max(-(-(self.pr_end - self.pr) // self.step), 0)
+        if n_batches == 0:
+            return []
+        # the picks: csrc/focf_compose.hip makes numpy's draws (`np.random.choice(select_item[is_select], 1, False)` per pick,
+        # focf_dataloader.py:41-44) without building the permutation behind each of them
+        uniq = np.ascontiguousarray(self.item_uniques, dtype=np.int64)
+        indptr = np.ascontiguousarray(self.indptr, dtype=np.int64)
+        deg = _degree(indptr, uniq)
+        worst = min(int(-(-self.step // max(int(deg.min()), 1))), uniq.size)      # picks of one batch, at most
+        usual = int(self.step / max(float(deg.mean()), 1.0)) + 64
+        ends = np.empty(n_batches, dtype=np.int64)
+        got = np.zeros(1, dtype=np.int64)
         with host_numpy_stream():
-            while pr < self.pr_end:
-                cnt = 0
-                select_item = np.arange(0, self.item_num)
-                is_select = np.zeros(self.item_num, dtype=bool)
-                is_select[self.item_uniques] = True
-                chunks = []
-                while cnt < self.step and is_select.any():
-                    iid = np.random.choice(select_item[is_select], 1, False)[0]   # same RNG consumption as the reference
-                    lo, hi = self.indptr[iid], self.indptr[iid + 1]
-                    cnt += hi - lo
-                    is_select[iid] = False
-                    chunks.append(np.arange(lo, hi))
-                pr += self.step
-                batches.append(np.concatenate(chunks))
-        return batches
+            name, key, pos, has_gauss, cached = np.random.get_state()
+            state = np.empty(625, dtype=np.uint32)
+            for per_batch in (min(2 * usual, worst), worst):         # a failed call leaves `state` where it was
+                state[:624], state[624] = key, pos
+                picks = np.empty(n_batches * per_batch, dtype=np.int64)
+                rc = lib.fr_focf_compose_epoch(state.ctypes.data, uniq.ctypes.data, uniq.size, indptr.ctypes.data,
+                                               int(self.step), int(self.pr), int(self.pr_end), picks.ctypes.data, picks.size,
+                                               ends.ctypes.data, ends.size, got.ctypes.data)
+                if rc == 0:
+                    break
+            _C.check(rc, "fr_focf_compose_epoch")
+            np.random.set_state((name, state[:624].copy(), int(state[624]), has_gauss, cached))
+        # the rows of a pick = its CSR range; all ranges of the epoch expanded at once
+        picks = picks[:ends[int(got[0]) - 1]]
+        lo, n = indptr[picks], _degree(indptr, picks)
+        first = np.cumsum(n) - n                                      # where each pick's rows start in the epoch's row list
+        rows = np.arange(int(n.sum()), dtype=np.int64) - np.repeat(first - lo, n)
+        cuts = first[ends[:int(got[0]) - 1]] if got[0] > 1 else []
+        return np.split(rows, cuts)
 
     def _begin_epoch(self):
         """Compose the epoch and gather its rows ONCE, in batch order (one index crossing to the device and one gather per

@@ -299,3 +299,54 @@ def test_torch_generator_state_blob_round_trip():
     a = torch.randperm(100)
     torch.manual_seed(5)
     assert torch.equal(ts.randperm(100, "cpu"), a)
+
+
+def _numpy_epoch(uniq, indptr, step, pr, pr_end):
+    """focf_dataloader.py:37-51 as the reference writes it: a boolean mask over the item ids and np.random.choice per pick."""
+    picks, ends = [], []
+    while pr < pr_end:
+        is_select = np.ones(uniq.size, dtype=bool)
+        cnt = 0
+        while cnt < step and is_select.any():
+            iid = np.random.choice(uniq[is_select], 1, False)[0]
+            is_select[np.searchsorted(uniq, iid)] = False
+            cnt += indptr[iid + 1] - indptr[iid]
+            picks.append(iid)
+        ends.append(len(picks))
+        pr += step
+    return np.array(picks, dtype=np.int64), np.array(ends, dtype=np.int64)
+
+
+@pytest.mark.parametrize("seed,n_items,n_rows,step", [(0, 50, 600, 64), (1, 1300, 9000, 512), (2, 7, 40, 100),
+                                                     (3, 700, 700, 16), (2020, 1, 5, 3), (5, 4000, 30000, 2048)])
+def test_compose_epoch_makes_numpys_draws(seed, n_items, n_rows, step):
+    """fr_focf_compose_epoch against numpy itself: same picks, same batch boundaries, the generator left at the same
+    position (the next draws of numpy agree) -- including batches that exhaust the candidates (step > rows), a single
+    candidate (no draw) and many regenerations of the 624 words."""
+    from fairrec import _C
+    lib = _C.lib()
+    g = np.random.RandomState(seed)
+    items = np.sort(g.randint(1, n_items + 1, n_rows))
+    uniq = np.unique(items).astype(np.int64)
+    indptr = np.searchsorted(items, np.arange(n_items + 2), side="left").astype(np.int64)
+    np.random.seed(seed + 77)
+    np.random.rand(seed % 5)                                    # an odd position in the 624 words
+    st0 = np.random.get_state()
+    want_picks, want_ends = _numpy_epoch(uniq, indptr, step, 0, n_rows)
+    want_next = np.random.randint(0, 1 << 30, 8)
+    state = np.empty(625, dtype=np.uint32)
+    state[:624], state[624] = st0[1], st0[2]
+    picks = np.empty(want_picks.size + 3, dtype=np.int64)
+    ends = np.empty(want_ends.size, dtype=np.int64)
+    got = np.zeros(1, dtype=np.int64)
+    # too little room: refused, and the state is where it was
+    before = state.copy()
+    rc = lib.fr_focf_compose_epoch(state.ctypes.data, uniq.ctypes.data, uniq.size, indptr.ctypes.data, step, 0, n_rows,
+                                   picks.ctypes.data, max(want_picks.size - 1, 0), ends.ctypes.data, ends.size, got.ctypes.data)
+    assert rc != 0 and np.array_equal(state, before)
+    _C.check(lib.fr_focf_compose_epoch(state.ctypes.data, uniq.ctypes.data, uniq.size, indptr.ctypes.data, step, 0, n_rows,
+                                       picks.ctypes.data, picks.size, ends.ctypes.data, ends.size, got.ctypes.data), "compose")
+    assert got[0] == want_ends.size
+    assert np.array_equal(ends, want_ends) and np.array_equal(picks[:ends[-1]], want_picks)
+    np.random.set_state(('MT19937', state[:624].copy(), int(state[624]), st0[3], st0[4]))
+    assert np.array_equal(np.random.randint(0, 1 << 30, 8), want_next)
