@@ -16,33 +16,12 @@
 #include "kernels.hpp"
 #include "mlp_glds.hpp"
 #include "dropout.hpp"
+#include "mlp_act.hpp"
+#include "mlp_bn_math.hpp"
 
 namespace fr {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
-
-enum { ACT_NONE = 0, ACT_RELU = 1, ACT_LEAKY = 2, ACT_SIGMOID = 3, ACT_TANH = 4 };
-
-__device__ __forceinline__ float act_fwd(float x, int act) {
-    switch (act) {
-        case ACT_RELU: return x > 0.f ? x : 0.f;
-        case ACT_LEAKY: return x > 0.f ? x : 0.01f * x;
-        case ACT_SIGMOID: return 1.f / (1.f + __expf(-x));
-        case ACT_TANH: return tanhf(x);
-        default: return x;
-    }
-}
-
-// derivative expressed through the OUTPUT y = act(x)
-__device__ __forceinline__ float act_bwd(float y, int act) {
-    switch (act) {
-        case ACT_RELU: return y > 0.f ? 1.f : 0.f;
-        case ACT_LEAKY: return y > 0.f ? 1.f : 0.01f;
-        case ACT_SIGMOID: return y * (1.f - y);
-        case ACT_TANH: return 1.f - y * y;
-        default: return 1.f;
-    }
-}
 
 // An [M, K] fp32 matrix that may be the column-wise concatenation of two row-major blocks (cat(U[u], I[i])).
 struct CatMat {
@@ -837,8 +816,8 @@ __global__ __launch_bounds__(BN_THREADS) void bn_fwd_fold_kernel(const float* __
     fin[2 * n + 1] = invstd;
     invstd_out[n] = invstd;
     if (rmean) {
-        rmean[n] = (1.f - momentum) * rmean[n] + momentum * mean;
-        rvar[n] = (1.f - momentum) * rvar[n] + momentum * (M > 1 ? m2 / (float)(M - 1) : var);
+        rmean[n] = bn_running(rmean[n], momentum, mean);
+        rvar[n] = bn_running(rvar[n], momentum, M > 1 ? m2 / (float)(M - 1) : var);
     }
 }
 
@@ -903,9 +882,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_stats_kernel(const float* _
 #pragma unroll 8
         for (int m = m0 + wave; m < m1; m += BN_WAVES) {
             const size_t i = (size_t)m * N + n;
-            const float da = dY[i] * act_bwd(Y[i], act);
-            s1 += da;
-            s2 = fmaf(da, xhat[i], s2);
+            bn_bwd_acc(dY[i], act_bwd(Y[i], act), xhat[i], s1, s2);
         }
     }
     const float t1 = col_reduce(s1, red, wave, lane);
@@ -959,14 +936,13 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(const float* _
     const int n = blockIdx.x * 64 + lane;
     if (n >= N) return;
     const float sum_da = fin[2 * n], sum_dax = fin[2 * n + 1];
-    const float g = gamma[n], is = invstd[n];
+    const float isg = __fmul_rn(invstd[n], gamma[n]);
     const float a1 = sum_da / (float)M, a2 = sum_dax / (float)M;
     const int m0 = blockIdx.y * rc, m1 = min(M, m0 + rc);
 #pragma unroll 8
     for (int m = m0 + wave; m < m1; m += BN_WAVES) {
         const size_t i = (size_t)m * N + n;
-        const float da = dY[i] * act_bwd(Y[i], act);
-        dZ[i] = is * g * (da - a1 - xhat[i] * a2);
+        dZ[i] = bn_bwd_dz(dY[i], act_bwd(Y[i], act), xhat[i], a1, a2, isg);
     }
 }
 

@@ -760,6 +760,7 @@ static int pick_ks(long long ntiles, int chunks) {
 }
 
 bool glds_shared_form() { return use_shared(); }
+int glds_pick_ks(long long ntiles, int chunks) { return pick_ks(ntiles, chunks); }
 
 int glds_linear_fwd(const GlMat& X, const float* W, const float* bias, int64_t M, int N, int K, int act, float* Y,
                     hipStream_t stream, float* bn_part) {

@@ -39,6 +39,7 @@ struct GlArgs {
 // Y = act(X W^T + b); needs K % 32 == 0, X.split % 32 == 0, 16-byte aligned rows
 int glds_linear_fwd(const GlMat& X, const float* W, const float* bias, int64_t M, int N, int K, int act, float* Y,
                     hipStream_t stream, float* bn_part = nullptr);
+int glds_pick_ks(long long ntiles, int chunks);   // reduction parts per 32 x 32 tile of the forward / input-gradient products (their summation order)
 bool glds_shared_form();     // the macro-tile kernels are selected (FAIRREC_LINEAR_NO_SHARED unset): the only ones that write bn_part
 // dX = dY W; needs N % 32 == 0, K % 32 == 0, k0 % 32 == 0
 int glds_linear_bwd_input(const float* dY, const float* W, int64_t M, int N, int K, float* dx0, int k0, float* dx1, int k1,
