@@ -852,8 +852,8 @@ FR_API int fr_sample_negatives_calls(uint32_t* state, int64_t low, int64_t high,
  *                   (may be NULL); dA[M, K] = dZ W back through the dropout of the layer's input (below->drop_*; drop_used =
  *                   the counter value fr_bnl_fwd recorded); with below->Z != NULL also the sums of the layer below (from dA
  *                   and that layer's Z) -> sums_below / dgamma_below / dbeta_below.
- * ws: fr_bnl_workspace_bytes(M, width of the statistics written); ticket: one zero-initialised device word the launches of a
- * stream share (it is zero again when a launch ends).  Widths: K % 32 == 0, K, N <= 256, otherwise FR_EUNSUPPORTED (the
+ * ws: fr_bnl_workspace_bytes(M, width of the statistics written); ticket: TWO zero-initialised device words the launches of a
+ * stream share (zero again when a launch ends).  Widths: K % 32 == 0, K, N <= 256, otherwise FR_EUNSUPPORTED (the
  * layered entries take every shape).  The same operations in the same order as the layered form (csrc/mlp_bn_math.hpp, the
  * products' summation order, the statistics' chunks): bit-identical where both forms apply (every width a multiple of 32), and
  * the same dropout patterns (tests/test_mlp_hip.py). */

@@ -784,28 +784,51 @@ __global__ __launch_bounds__(BN_THREADS) void bn_fwd_fold_kernel(const float* __
     const int n = blockIdx.x * 64 + lane;
     const int q = (chunks + BN_WAVES - 1) / BN_WAVES, c0 = wave * q, c1 = min(chunks, c0 + q);
     const bool ok = n < N;
-    float s = 0.f;
-    if (ok) {
+    // A quarter of up to 64 chunks is requested at once and kept in registers for both passes: ONE memory latency in this
+    // launch, which is nothing but a latency chain (7.6 us with the two passes loading eight at a time; same sums, same order).
+    constexpr int QMAX = 64;
+    const int nn = ok ? n : N - 1;
+    float s = 0.f, m2 = 0.f;
+    if (q <= QMAX) {
+        float2 pv[QMAX];
+#pragma unroll
+        for (int k = 0; k < QMAX; ++k)
+            if (c0 + k < c1) pv[k] = reinterpret_cast<const float2*>(part)[(size_t)(c0 + k) * N + nn];
+#pragma unroll
+        for (int k = 0; k < QMAX; ++k)
+            if (c0 + k < c1) s = fmaf((float)(min(M, (c0 + k + 1) * rc) - (c0 + k) * rc), pv[k].x, s);
+        sh[wave][lane] = s;
+        __syncthreads();
+        const float mean_ = (((sh[0][lane] + sh[1][lane]) + sh[2][lane]) + sh[3][lane]) / (float)M;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < QMAX; ++k)
+            if (c0 + k < c1) {
+                const float nb = (float)(min(M, (c0 + k + 1) * rc) - (c0 + k) * rc);
+                const float d = pv[k].x - mean_;
+                m2 += fmaf(nb * d, d, pv[k].y);
+            }
+        s = mean_;
+    } else {
 #pragma unroll 8
         for (int c = c0; c < c1; ++c) {
             const float nb = (float)(min(M, (c + 1) * rc) - c * rc);
-            s = fmaf(nb, part[((size_t)c * N + n) * 2], s);
+            s = fmaf(nb, part[((size_t)c * N + nn) * 2], s);
         }
-    }
-    sh[wave][lane] = s;
-    __syncthreads();
-    const float mean = (((sh[0][lane] + sh[1][lane]) + sh[2][lane]) + sh[3][lane]) / (float)M;
-    __syncthreads();
-    float m2 = 0.f;
-    if (ok) {
+        sh[wave][lane] = s;
+        __syncthreads();
+        const float mean_ = (((sh[0][lane] + sh[1][lane]) + sh[2][lane]) + sh[3][lane]) / (float)M;
+        __syncthreads();
 #pragma unroll 8
         for (int c = c0; c < c1; ++c) {
             const float nb = (float)(min(M, (c + 1) * rc) - c * rc);
-            const float2 p = reinterpret_cast<const float2*>(part)[(size_t)c * N + n];
-            const float d = p.x - mean;
+            const float2 p = reinterpret_cast<const float2*>(part)[(size_t)c * N + nn];
+            const float d = p.x - mean_;
             m2 += fmaf(nb * d, d, p.y);
         }
+        s = mean_;
     }
+    const float mean = s;
     sh[wave][lane] = m2;
     __syncthreads();
     if (wave != 0 || !ok) return;
@@ -903,10 +926,23 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_fold_kernel(const float* __
     const int n = blockIdx.x * 64 + lane;
     const int q = (chunks + BN_WAVES - 1) / BN_WAVES, c0 = wave * q, c1 = min(chunks, c0 + q);
     float sum_da = 0.f, sum_dax = 0.f;
-    if (n < N) {
+    constexpr int QMAX = 64;         // as bn_fwd_fold_kernel: a quarter of up to 64 chunks in one round of requests
+    const int nn = n < N ? n : N - 1;
+    if (q <= QMAX) {
+        float2 pv[QMAX];
+#pragma unroll
+        for (int k = 0; k < QMAX; ++k)
+            if (c0 + k < c1) pv[k] = reinterpret_cast<const float2*>(part)[(size_t)(c0 + k) * N + nn];
+#pragma unroll
+        for (int k = 0; k < QMAX; ++k)
+            if (c0 + k < c1) {
+                sum_da += pv[k].x;
+                sum_dax += pv[k].y;
+            }
+    } else {
 #pragma unroll 8
         for (int c = c0; c < c1; ++c) {
-            const float2 p = reinterpret_cast<const float2*>(part)[(size_t)c * N + n];
+            const float2 p = reinterpret_cast<const float2*>(part)[(size_t)c * N + nn];
             sum_da += p.x;
             sum_dax += p.y;
         }

@@ -45,6 +45,24 @@ typedef __attribute__((address_space(3))) void* lds_vp;
 typedef const __attribute__((address_space(1))) void* glb_vp;
 
 constexpr int BNL_THREADS = 256, BNL_WAVES = 4, BNL_MAXW = 256;
+constexpr int BNL_NBUF = 3;      // a wave's ring of W blocks: two chunks requested ahead (one ahead left 0.9 us of every 1.75 us chunk waiting)
+
+// -DBNL_TRACE=1 (a diagnostic build: make VARIANT=bnltrace EXTRA=-DBNL_TRACE=1): thread 0 of every workgroup stamps the phases of
+// its launch with the 100 MHz wall clock; scratch/bnl_trace.py reads them back through fr_bnl_trace_read.
+#ifndef BNL_TRACE
+#define BNL_TRACE 0
+#endif
+#if BNL_TRACE
+__device__ unsigned long long bnl_trace[4096 * 8];
+#define BNL_STAMP(k)                                                                        \
+    do {                                                                                    \
+        if (threadIdx.x == 0 && blockIdx.x < 4096) bnl_trace[blockIdx.x * 8 + (k)] = wall_clock64(); \
+    } while (0)
+#else
+#define BNL_STAMP(k) \
+    do {             \
+    } while (0)
+#endif
 
 struct BnlSrc {                // device form of fr_bn_src
     const float* Z;
@@ -83,53 +101,151 @@ __device__ __forceinline__ void bnl_norm1(const BnlSrc& s, const float z, const 
     y = act_fwd(fmaf(s.gamma[n], xh, s.beta[n]), s.act);
 }
 
+__device__ __forceinline__ float2 ld_dev2(const float* p) {     // an 8-byte aligned pair, device scope
+    const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return make_float2(__uint_as_float((unsigned)v), __uint_as_float((unsigned)(v >> 32)));
+}
+
+// Per-column constants of a source, parked in LDS once per workgroup: colc[n] = (mean, invstd, gamma, beta).  The loops that
+// form a tile then take them from LDS instead of four more global round trips per 16-byte unit (one wave per SIMD hides none).
+__device__ __forceinline__ void bnl_park_columns(const BnlSrc& s, int width, float4* colc) {
+    if (!s.fin) return;
+    for (int n = threadIdx.x; n < width; n += BNL_THREADS)
+        colc[n] = make_float4(s.fin[2 * n], s.fin[2 * n + 1], s.gamma[n], s.beta[n]);
+}
+__device__ __forceinline__ void bnl_norm4c(const BnlSrc& s, const float4* colc, const float4 z, const int kq, float4& xh, float4& y) {
+    if (!s.fin) {
+        xh = make_float4(0.f, 0.f, 0.f, 0.f);
+        y = z;
+        return;
+    }
+    const float4 c0 = colc[4 * kq], c1 = colc[4 * kq + 1], c2 = colc[4 * kq + 2], c3 = colc[4 * kq + 3];
+    xh = make_float4((z.x - c0.x) * c0.y, (z.y - c1.x) * c1.y, (z.z - c2.x) * c2.y, (z.w - c3.x) * c3.y);
+    y = make_float4(act_fwd(fmaf(c0.z, xh.x, c0.w), s.act), act_fwd(fmaf(c1.z, xh.y, c1.w), s.act),
+                    act_fwd(fmaf(c2.z, xh.z, c2.w), s.act), act_fwd(fmaf(c3.z, xh.w, c3.w), s.act));
+}
+constexpr int BNL_UMAX = BNL_MAXW / 32;      // 16-byte units of a 32-row tile per thread: width / 32
+
+// wait until this wave's stage of the current chunk has landed: `left` newer chunks exist, at most NBUF - 1 of them were requested
+// (4 TPW LDS-DMA instructions each)
+template <int TPW>
+__device__ __forceinline__ void bnl_wait_newer(int left) {
+    static_assert(BNL_NBUF == 3, "the wait counts below are written for a ring of three");
+    if (left >= 2) {
+        if (TPW == 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else if (left == 1) {
+        if (TPW == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+}
+
 // position of the 16-byte unit (row, slot) inside a 32 x 32 block of the LDS image (in units of float4)
 __device__ __forceinline__ int img_unit(int row, int slot) { return row * 8 + (slot ^ ((row >> 1) & 7)); }
 
-// Arrival of a workgroup whose partials (device-scope stores) are on their way; true for the one that arrives last.
-__device__ __forceinline__ bool bnl_arrive(unsigned* ticket, int* last_s) {
+// Arrival of a workgroup whose partials (device-scope stores) are on their way.  The fold of the partials is one latency chain
+// per (column, quarter of the tiles) -- done by ONE workgroup for all columns it was 20-28 us behind an 8 us product -- so the
+// LAST F workgroups to arrive share it, a block of 64 columns each (F = min(4, blocks of 64 columns, workgroups)): each of them
+// waits until everyone has arrived (the others it waits for are running or about to be dispatched: F <= 4 waiters never keep
+// them from a slot; the wait is bounded anyway), folds its blocks, and the last one out puts the two counters back to zero.
+// Returns the folder index, or -1 for a workgroup that is done.  tk[0]: arrivals, tk[1]: folders that are through.
+__device__ __forceinline__ int bnl_folders(int N) {
+    const int nb = (N + 63) >> 6;
+    const int f = nb < 4 ? nb : 4;
+    return f < (int)gridDim.x ? f : (int)gridDim.x;
+}
+__device__ __forceinline__ int bnl_arrive(unsigned* tk, int F, int* sh_f) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
-        const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int last = t == gridDim.x - 1;
-        if (last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        *last_s = last;
+        const unsigned T = gridDim.x;
+        const unsigned t = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int rank = (int)(T - 1u - t);
+        const int f = rank < F ? rank : -1;
+        BNL_STAMP(6);
+        if (f >= 0) {
+            for (unsigned spin = 0; spin < (1u << 24) && __hip_atomic_load(tk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < T; ++spin)
+                __builtin_amdgcn_s_sleep(4);
+        }
+        *sh_f = f;
     }
     __syncthreads();
-    return *last_s != 0;
+    return *sh_f;
+}
+__device__ __forceinline__ void bnl_leave(unsigned* tk, int F) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned d = __hip_atomic_fetch_add(tk + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((int)d == F - 1) {
+            __hip_atomic_store(tk + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
 
-// bn_fwd_fold_kernel (mlp.hip) for every block of 64 columns, by one workgroup: part[(c * N + n) * 2] = (mean, M2) of the
-// 32 rows of tile c.
-__device__ void bnl_fold_stats(const float* part, int chunks, int M, int N, float eps, float momentum, float* rmean, float* rvar,
-                               float* fin, float (*sh)[64]) {
+// bn_fwd_fold_kernel (mlp.hip) for the blocks of 64 columns f, f + F, ...: part[(c * N + n) * 2] = (mean, M2) of the 32 rows of
+// tile c.  The same chains (four waves take a quarter of the tiles each, in ascending order; the quarters are added in order);
+// a quarter of up to 64 tiles is REQUESTED at once (64 pairs in registers): one memory latency instead of one per batch of the
+// two passes -- this runs at the tail of a launch with nothing to overlap it.
+constexpr int BNL_QMAX = 64;
+__device__ __forceinline__ void bnl_fold_stats(const float* part, int chunks, int M, int N, float eps, float momentum, float* rmean, float* rvar,
+                               float* fin, float (*sh)[64], int f, int F) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q = (chunks + BNL_WAVES - 1) / BNL_WAVES, c0 = wave * q, c1 = min(chunks, c0 + q);
-    for (int nb = 0; nb < N; nb += 64) {
+    for (int nb = f * 64; nb < N; nb += F * 64) {
         const int n = nb + lane;
         const bool ok = n < N;
-        float s = 0.f;
-        if (ok) {
-#pragma unroll 8
-            for (int c = c0; c < c1; ++c) {
-                const float cnt = (float)(min(M, (c + 1) * 32) - c * 32);
-                s = fmaf(cnt, ld_dev(part + ((size_t)c * N + n) * 2), s);
+        const int nn = ok ? n : N - 1;
+        float s = 0.f, m2 = 0.f;
+        if (q <= BNL_QMAX) {
+            float2 pv[BNL_QMAX];
+#pragma unroll
+            for (int k = 0; k < BNL_QMAX; ++k)
+                if (c0 + k < c1) pv[k] = ld_dev2(part + ((size_t)(c0 + k) * N + nn) * 2);
+#pragma unroll
+            for (int k = 0; k < BNL_QMAX; ++k)
+                if (c0 + k < c1) s = fmaf((float)(min(M, (c0 + k + 1) * 32) - (c0 + k) * 32), pv[k].x, s);
+            sh[wave][lane] = s;
+            __syncthreads();
+            const float mean = (((sh[0][lane] + sh[1][lane]) + sh[2][lane]) + sh[3][lane]) / (float)M;
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < BNL_QMAX; ++k)
+                if (c0 + k < c1) {
+                    const float cnt = (float)(min(M, (c0 + k + 1) * 32) - (c0 + k) * 32);
+                    const float d = pv[k].x - mean;
+                    m2 += fmaf(cnt * d, d, pv[k].y);
+                }
+            sh[wave][lane] = m2;
+            __syncthreads();
+            if (wave == 0 && ok) {
+                m2 = ((sh[0][lane] + sh[1][lane]) + sh[2][lane]) + sh[3][lane];
+                const float var = m2 / (float)M;
+                const float invstd = 1.f / sqrtf(var + eps);
+                fin[2 * n] = mean;
+                fin[2 * n + 1] = invstd;
+                if (rmean) {
+                    rmean[n] = bn_running(rmean[n], momentum, mean);
+                    rvar[n] = bn_running(rvar[n], momentum, M > 1 ? m2 / (float)(M - 1) : var);
+                }
             }
+            __syncthreads();
+            continue;
         }
+#pragma unroll 16
+        for (int c = c0; c < c1; ++c) s = fmaf((float)(min(M, (c + 1) * 32) - c * 32), ld_dev(part + ((size_t)c * N + nn) * 2), s);
         sh[wave][lane] = s;
         __syncthreads();
         const float mean = (((sh[0][lane] + sh[1][lane]) + sh[2][lane]) + sh[3][lane]) / (float)M;
         __syncthreads();
-        float m2 = 0.f;
-        if (ok) {
-#pragma unroll 8
-            for (int c = c0; c < c1; ++c) {
-                const float cnt = (float)(min(M, (c + 1) * 32) - c * 32);
-                const float px = ld_dev(part + ((size_t)c * N + n) * 2), py = ld_dev(part + ((size_t)c * N + n) * 2 + 1);
-                const float d = px - mean;
-                m2 += fmaf(cnt * d, d, py);
-            }
+#pragma unroll 16
+        for (int c = c0; c < c1; ++c) {
+            const float cnt = (float)(min(M, (c + 1) * 32) - c * 32);
+            const float2 p = ld_dev2(part + ((size_t)c * N + nn) * 2);
+            const float d = p.x - mean;
+            m2 += fmaf(cnt * d, d, p.y);
         }
         sh[wave][lane] = m2;
         __syncthreads();
@@ -148,18 +264,32 @@ __device__ void bnl_fold_stats(const float* part, int chunks, int M, int N, floa
     }
 }
 
-// bn_bwd_fold_kernel for every block of 64 columns: part[(c * N + n) * 2] = (sum G, sum G xhat) over the rows of tile c
-__device__ void bnl_fold_sums(const float* part, int chunks, int N, float* sums, float* dgamma, float* dbeta, float (*sh)[64]) {
+// bn_bwd_fold_kernel for the blocks of 64 columns f, f + F, ...: part[(c * N + n) * 2] = (sum dy s, sum dy s xhat) over the rows of tile c
+__device__ __forceinline__ void bnl_fold_sums(const float* part, int chunks, int N, float* sums, float* dgamma, float* dbeta, float (*sh)[64], int f,
+                              int F) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q = (chunks + BNL_WAVES - 1) / BNL_WAVES, c0 = wave * q, c1 = min(chunks, c0 + q);
-    for (int nb = 0; nb < N; nb += 64) {
+    for (int nb = f * 64; nb < N; nb += F * 64) {
         const int n = nb + lane;
+        const int nn = n < N ? n : N - 1;
         float s1 = 0.f, s2 = 0.f;
-        if (n < N) {
-#pragma unroll 8
+        if (q <= BNL_QMAX) {
+            float2 pv[BNL_QMAX];
+#pragma unroll
+            for (int k = 0; k < BNL_QMAX; ++k)
+                if (c0 + k < c1) pv[k] = ld_dev2(part + ((size_t)(c0 + k) * N + nn) * 2);
+#pragma unroll
+            for (int k = 0; k < BNL_QMAX; ++k)
+                if (c0 + k < c1) {
+                    s1 += pv[k].x;
+                    s2 += pv[k].y;
+                }
+        } else {
+#pragma unroll 16
             for (int c = c0; c < c1; ++c) {
-                s1 += ld_dev(part + ((size_t)c * N + n) * 2);
-                s2 += ld_dev(part + ((size_t)c * N + n) * 2 + 1);
+                const float2 p = ld_dev2(part + ((size_t)c * N + nn) * 2);
+                s1 += p.x;
+                s2 += p.y;
             }
         }
         sh[wave][lane] = s1;
@@ -209,11 +339,12 @@ __global__ __launch_bounds__(BNL_THREADS) void bnl_fwd_kernel(BnlFwdArgs a) {
     __shared__ unsigned long long ctr_s;
     __shared__ int last_s;
     __shared__ float sh[BNL_WAVES][64];
+    __shared__ float4 colc[BNL_MAXW];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i0 = blockIdx.x * 32;
     const int nchunk = a.K >> 5, ntiles = (a.N + 31) >> 5;
     float* img = lds;
-    float* my = lds + (size_t)nchunk * 1024 + (size_t)wave * (2 * TPW * 1024);
+    float* my = lds + (size_t)nchunk * 1024 + (size_t)wave * (BNL_NBUF * TPW * 1024);
 
     // ---- this wave's tiles of W; a tile past the matrix repeats the wave's first (computed, never stored) -------------
     const bool has = wave < ntiles;
@@ -245,29 +376,46 @@ __global__ __launch_bounds__(BNL_THREADS) void bnl_fwd_kernel(BnlFwdArgs a) {
                 pb[i][q] += 32;
             }
     };
-    if (has) stage(0);
+    BNL_STAMP(0);
+    if (has) {
+#pragma unroll
+        for (int b = 0; b < BNL_NBUF - 1; ++b)
+            if (b < nchunk) stage(b);
+    }
 
     unsigned long long ctr = 0;
     if (a.in.thr) ctr = drop_counter_enter(a.ctr_src, a.used_out, a.tick, &ctr_s);
 
-    // ---- the tile of A, formed on the way into LDS ----------------------------------------------------------------------
+    // ---- the tile of A, formed on the way into LDS: every thread's K / 32 units are requested first, then worked on ----------
+    bnl_park_columns(a.in, a.K, colc);
     {
-        const int K4 = a.K >> 2, units = 32 * K4;
-        for (int u = tid; u < units; u += BNL_THREADS) {
-            const int row = u / K4, kq = u - row * K4;
-            const int gr = i0 + row < a.M ? i0 + row : a.M - 1;
-            const float4 z = reinterpret_cast<const float4*>(a.in.Z + (size_t)gr * a.K)[kq];
-            float4 xh, y;
-            bnl_norm4(a.in, z, kq, xh, y);
-            if (a.in.thr) {
-                const float4 k = drop_keep4(a.in.seed, ctr, a.in.off4 + (unsigned long long)gr * K4 + kq, a.in.thr, a.in.scale);
-                y = make_float4(y.x * k.x, y.y * k.y, y.z * k.z, y.w * k.w);
+        const int K4 = a.K >> 2, U = a.K >> 5;
+        float4 zv[BNL_UMAX];
+#pragma unroll
+        for (int i = 0; i < BNL_UMAX; ++i)
+            if (i < U) {
+                const int u = tid + i * BNL_THREADS, row = u / K4, kq = u - row * K4;
+                const int gr = i0 + row < a.M ? i0 + row : a.M - 1;
+                zv[i] = reinterpret_cast<const float4*>(a.in.Z + (size_t)gr * a.K)[kq];
             }
-            if (a.A_out && i0 + row < a.M) reinterpret_cast<float4*>(a.A_out + (size_t)gr * a.K)[kq] = y;
-            reinterpret_cast<float4*>(img)[(kq >> 3) * 256 + img_unit(row, kq & 7)] = y;
-        }
+        __syncthreads();                     // the parked columns
+#pragma unroll
+        for (int i = 0; i < BNL_UMAX; ++i)
+            if (i < U) {
+                const int u = tid + i * BNL_THREADS, row = u / K4, kq = u - row * K4;
+                const int gr = i0 + row < a.M ? i0 + row : a.M - 1;
+                float4 xh, y;
+                bnl_norm4c(a.in, colc, zv[i], kq, xh, y);
+                if (a.in.thr) {
+                    const float4 k = drop_keep4(a.in.seed, ctr, a.in.off4 + (unsigned long long)gr * K4 + kq, a.in.thr, a.in.scale);
+                    y = make_float4(y.x * k.x, y.y * k.y, y.z * k.z, y.w * k.w);
+                }
+                if (a.A_out && i0 + row < a.M) reinterpret_cast<float4*>(a.A_out + (size_t)gr * a.K)[kq] = y;
+                reinterpret_cast<float4*>(img)[(kq >> 3) * 256 + img_unit(row, kq & 7)] = y;
+            }
     }
     __syncthreads();
+    BNL_STAMP(1);
 
     // ---- Z tile = A W^T: A fragments from the shared image, W fragments from this wave's own ring -----------------------
     f32x16 acc[TPW][2];
@@ -284,15 +432,10 @@ __global__ __launch_bounds__(BNL_THREADS) void bnl_fwd_kernel(BnlFwdArgs a) {
         unsigned rn[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) rn[j] = r * 128 + (((2 * j + h) ^ ((r >> 1) & 7)) << 4);
+        int buf = 0, nxt = BNL_NBUF - 1;      // ring slots of chunk t and of chunk t + NBUF - 1
         for (int t = 0; t < nchunk; ++t) {
-            const int buf = t & 1;
-            if (t + 1 < nchunk) {
-                stage(buf ^ 1);
-                if (TPW == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            } else {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
+            if (t + BNL_NBUF - 1 < nchunk) stage(nxt);
+            bnl_wait_newer<TPW>(nchunk - 1 - t);        // chunk t has landed; up to NBUF - 1 newer ones stay in flight
             f4 av[4], bv[TPW][4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) asm volatile("ds_read_b128 %0, %1" : "=v"(av[j]) : "v"(ibase + t * 4096 + rn[j]));
@@ -317,6 +460,8 @@ __global__ __launch_bounds__(BNL_THREADS) void bnl_fwd_kernel(BnlFwdArgs a) {
                     acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[(q + 1) >> 2][(q + 1) & 3], bv[i][(q + 1) >> 2][(q + 1) & 3],
                                                                      acc[i][1], 0, 0, 0);
                 }
+            buf = buf + 1 == BNL_NBUF ? 0 : buf + 1;
+            nxt = nxt + 1 == BNL_NBUF ? 0 : nxt + 1;
             if (++in_part == a.cpp) {     // a part of the reduction ends: the parts are added in order, as the layered product adds them
                 in_part = 0;
 #pragma unroll
@@ -328,6 +473,7 @@ __global__ __launch_bounds__(BNL_THREADS) void bnl_fwd_kernel(BnlFwdArgs a) {
         }
     }
 
+    BNL_STAMP(2);
     // ---- epilogue: + bias, the tile's (mean, M2) per column, Z ----------------------------------------------------------
 #pragma unroll
     for (int i = 0; i < TPW; ++i) {
@@ -371,9 +517,14 @@ __global__ __launch_bounds__(BNL_THREADS) void bnl_fwd_kernel(BnlFwdArgs a) {
     }
 
     // ---- the last workgroup to arrive folds the partials of all tiles ---------------------------------------------------
-    if (bnl_arrive(a.ticket, &last_s)) {
-        bnl_fold_stats(a.part, (int)gridDim.x, a.M, a.N, a.eps, a.momentum, a.rmean, a.rvar, a.fin_out, sh);
-        if (a.nbt && tid == 0) *a.nbt += a.nbt_inc;
+    BNL_STAMP(3);
+    const int F = bnl_folders(a.N), f = bnl_arrive(a.ticket, F, &last_s);
+    BNL_STAMP(4);
+    if (f >= 0) {
+        bnl_fold_stats(a.part, (int)gridDim.x, a.M, a.N, a.eps, a.momentum, a.rmean, a.rvar, a.fin_out, sh, f, F);
+        if (a.nbt && f == 0 && tid == 0) *a.nbt += a.nbt_inc;
+        BNL_STAMP(5);
+        bnl_leave(a.ticket, F);
     }
 }
 
@@ -407,17 +558,21 @@ template <typename F>
 __device__ __forceinline__ void bnl_tile_sums(const BnlSrc& L, int M, int N, int i0, float* part, F dy_at) {
     for (int n = threadIdx.x; n < N; n += BNL_THREADS) {
         const float mean = L.fin[2 * n], is = L.fin[2 * n + 1], g = L.gamma[n], b = L.beta[n];
+        float zr[32];
+#pragma unroll
+        for (int row = 0; row < 32; ++row) zr[row] = L.Z[(size_t)(i0 + row < M ? i0 + row : M - 1) * N + n];   // all 32 in flight
+        float dyr[32];
+#pragma unroll
+        for (int row = 0; row < 32; ++row) dyr[row] = i0 + row < M ? dy_at(row, n) : 0.f;      // a row past M adds exactly nothing
         float p1[4], p2[4];
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
             float s1 = 0.f, s2 = 0.f;
 #pragma unroll
             for (int row = w; row < 32; row += 4) {
-                if (i0 + row < M) {
-                    const float xh = (L.Z[(size_t)(i0 + row) * N + n] - mean) * is;
-                    const float y = act_fwd(fmaf(g, xh, b), L.act);
-                    bn_bwd_acc(dy_at(row, n), act_bwd(y, L.act), xh, s1, s2);
-                }
+                const float xh = (zr[row] - mean) * is;
+                const float y = act_fwd(fmaf(g, xh, b), L.act);
+                bn_bwd_acc(dyr[row], act_bwd(y, L.act), xh, s1, s2);
             }
             p1[w] = s1;
             p2[w] = s2;
@@ -439,7 +594,11 @@ __global__ __launch_bounds__(BNL_THREADS) void bnl_top_kernel(const float* __res
     __shared__ float sh[2 * BNL_WAVES][64];
     const int i0 = blockIdx.x * 32;
     bnl_tile_sums(top, M, N, i0, part, [&](int row, int n) { return dY[(size_t)(i0 + row) * N + n]; });
-    if (bnl_arrive(ticket, &last_s)) bnl_fold_sums(part, (int)gridDim.x, N, sums, dgamma, dbeta, sh);
+    const int F = bnl_folders(N), f = bnl_arrive(ticket, F, &last_s);
+    if (f >= 0) {
+        bnl_fold_sums(part, (int)gridDim.x, N, sums, dgamma, dbeta, sh, f, F);
+        bnl_leave(ticket, F);
+    }
 }
 
 struct BnlBwdArgs {
@@ -466,11 +625,12 @@ __global__ __launch_bounds__(BNL_THREADS) void bnl_bwd_kernel(BnlBwdArgs a) {
     __shared__ unsigned long long ctr_s;
     __shared__ int last_s;
     __shared__ float sh[2 * BNL_WAVES][64];
+    __shared__ float4 colc[BNL_MAXW], cold[BNL_MAXW];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i0 = blockIdx.x * 32;
     const int nred = (a.N + 31) >> 5, ntiles = a.K >> 5;
     float* img = lds;
-    float* my = lds + (size_t)nred * 1024 + (size_t)wave * (2 * TPW * 1024);
+    float* my = lds + (size_t)nred * 1024 + (size_t)wave * (BNL_NBUF * TPW * 1024);
 
     const bool has = wave < ntiles;
     int tj[TPW];
@@ -495,7 +655,11 @@ __global__ __launch_bounds__(BNL_THREADS) void bnl_bwd_kernel(BnlBwdArgs a) {
                 __builtin_amdgcn_global_load_lds((glb_vp)p, (lds_vp)(my + (buf * TPW + i) * 1024 + q * 256), 16, 0, 0);
             }
     };
-    if (has) stage(0, 0);
+    if (has) {
+#pragma unroll
+        for (int b = 0; b < BNL_NBUF - 1; ++b)
+            if (b < nred) stage(b, b);
+    }
 
     if (tid == 0) ctr_s = a.below.thr ? *a.used : 0ull;
 
@@ -505,26 +669,40 @@ __global__ __launch_bounds__(BNL_THREADS) void bnl_bwd_kernel(BnlBwdArgs a) {
         const float fm = (float)a.M;
         const int act = a.self.act;
         if ((a.N & 3) == 0) {
-            const int N4 = a.N >> 2, P4 = nred * 8, units = 32 * P4;
-            for (int u = tid; u < units; u += BNL_THREADS) {
-                const int row = u / P4, kq = u - row * P4;
-                float4 dz = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (kq < N4) {
+            // (mean, invstd, gamma, beta) and (sum / M, sum / M, invstd gamma, -) per column in LDS; a thread's units requested first
+            bnl_park_columns(a.self, a.N, colc);
+            for (int n = tid; n < a.N; n += BNL_THREADS)
+                cold[n] = make_float4(a.sums[2 * n] / fm, a.sums[2 * n + 1] / fm, __fmul_rn(a.self.fin[2 * n + 1], a.self.gamma[n]), 0.f);
+            const int N4 = a.N >> 2, P4 = nred * 8, U = nred;
+            float4 gv[BNL_UMAX], zv[BNL_UMAX];
+#pragma unroll
+            for (int i = 0; i < BNL_UMAX; ++i)
+                if (i < U) {
+                    const int u = tid + i * BNL_THREADS, row = u / P4, kq = u - row * P4;
                     const int gr = i0 + row < a.M ? i0 + row : a.M - 1;
-                    const float4 dy = reinterpret_cast<const float4*>(a.G + (size_t)gr * a.N)[kq];
-                    float4 xh, y;
-                    bnl_norm4(a.self, reinterpret_cast<const float4*>(a.self.Z + (size_t)gr * a.N)[kq], kq, xh, y);
-                    const float4 f0 = reinterpret_cast<const float4*>(a.self.fin)[2 * kq], f1 = reinterpret_cast<const float4*>(a.self.fin)[2 * kq + 1];
-                    const float4 s0 = reinterpret_cast<const float4*>(a.sums)[2 * kq], s1 = reinterpret_cast<const float4*>(a.sums)[2 * kq + 1];
-                    const float4 gm = reinterpret_cast<const float4*>(a.self.gamma)[kq];
-                    dz.x = bn_bwd_dz(dy.x, act_bwd(y.x, act), xh.x, s0.x / fm, s0.y / fm, __fmul_rn(f0.y, gm.x));
-                    dz.y = bn_bwd_dz(dy.y, act_bwd(y.y, act), xh.y, s0.z / fm, s0.w / fm, __fmul_rn(f0.w, gm.y));
-                    dz.z = bn_bwd_dz(dy.z, act_bwd(y.z, act), xh.z, s1.x / fm, s1.y / fm, __fmul_rn(f1.y, gm.z));
-                    dz.w = bn_bwd_dz(dy.w, act_bwd(y.w, act), xh.w, s1.z / fm, s1.w / fm, __fmul_rn(f1.w, gm.w));
-                    if (a.dZ_out && i0 + row < a.M) reinterpret_cast<float4*>(a.dZ_out + (size_t)gr * a.N)[kq] = dz;
+                    const int kc = kq < N4 ? kq : N4 - 1;
+                    gv[i] = reinterpret_cast<const float4*>(a.G + (size_t)gr * a.N)[kc];
+                    zv[i] = reinterpret_cast<const float4*>(a.self.Z + (size_t)gr * a.N)[kc];
                 }
-                reinterpret_cast<float4*>(img)[(kq >> 3) * 256 + img_unit(row, kq & 7)] = dz;
-            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < BNL_UMAX; ++i)
+                if (i < U) {
+                    const int u = tid + i * BNL_THREADS, row = u / P4, kq = u - row * P4;
+                    float4 dz = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (kq < N4) {
+                        const int gr = i0 + row < a.M ? i0 + row : a.M - 1;
+                        float4 xh, y;
+                        bnl_norm4c(a.self, colc, zv[i], kq, xh, y);
+                        const float4 d0 = cold[4 * kq], d1 = cold[4 * kq + 1], d2 = cold[4 * kq + 2], d3 = cold[4 * kq + 3];
+                        dz.x = bn_bwd_dz(gv[i].x, act_bwd(y.x, act), xh.x, d0.x, d0.y, d0.z);
+                        dz.y = bn_bwd_dz(gv[i].y, act_bwd(y.y, act), xh.y, d1.x, d1.y, d1.z);
+                        dz.z = bn_bwd_dz(gv[i].z, act_bwd(y.z, act), xh.z, d2.x, d2.y, d2.z);
+                        dz.w = bn_bwd_dz(gv[i].w, act_bwd(y.w, act), xh.w, d3.x, d3.y, d3.z);
+                        if (a.dZ_out && i0 + row < a.M) reinterpret_cast<float4*>(a.dZ_out + (size_t)gr * a.N)[kq] = dz;
+                    }
+                    reinterpret_cast<float4*>(img)[(kq >> 3) * 256 + img_unit(row, kq & 7)] = dz;
+                }
         } else {
             const int P = nred * 32;
             for (int e = tid; e < 32 * P; e += BNL_THREADS) {
@@ -568,15 +746,10 @@ __global__ __launch_bounds__(BNL_THREADS) void bnl_bwd_kernel(BnlBwdArgs a) {
             const int row = 8 * (q >> 2) + 4 * h + (q & 3);
             rt[q] = row * 128 + ((((r >> 2) ^ ((row >> 1) & 7)) << 4) | ((r & 3) << 2));
         }
+        int buf = 0, nxt = BNL_NBUF - 1;
         for (int t = 0; t < nred; ++t) {
-            const int buf = t & 1;
-            if (t + 1 < nred) {
-                stage(t + 1, buf ^ 1);
-                if (TPW == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            } else {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
+            if (t + BNL_NBUF - 1 < nred) stage(t + BNL_NBUF - 1, nxt);
+            bnl_wait_newer<TPW>(nred - 1 - t);
             f4 av[4];
             float bt[TPW][16];
 #pragma unroll
@@ -604,6 +777,8 @@ __global__ __launch_bounds__(BNL_THREADS) void bnl_bwd_kernel(BnlBwdArgs a) {
                     acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q >> 2][q & 3], bt[i][q], acc[i][0], 0, 0, 0);
                     acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[(q + 1) >> 2][(q + 1) & 3], bt[i][q + 1], acc[i][1], 0, 0, 0);
                 }
+            buf = buf + 1 == BNL_NBUF ? 0 : buf + 1;
+            nxt = nxt + 1 == BNL_NBUF ? 0 : nxt + 1;
             if (++in_part == a.cpp || t + 1 == nred) {
                 in_part = 0;
 #pragma unroll
@@ -649,7 +824,11 @@ __global__ __launch_bounds__(BNL_THREADS) void bnl_bwd_kernel(BnlBwdArgs a) {
     if (!chain) return;
     __syncthreads();
     bnl_tile_sums(a.below, a.M, a.K, i0, a.part, [&](int row, int n) { return t1[row * a.K + n]; });
-    if (bnl_arrive(a.ticket, &last_s)) bnl_fold_sums(a.part, (int)gridDim.x, a.K, a.sums_out, a.dgamma, a.dbeta, sh);
+    const int F = bnl_folders(a.K), f = bnl_arrive(a.ticket, F, &last_s);
+    if (f >= 0) {
+        bnl_fold_sums(a.part, (int)gridDim.x, a.K, a.sums_out, a.dgamma, a.dbeta, sh, f, F);
+        bnl_leave(a.ticket, F);
+    }
 }
 
 }  // namespace fr
@@ -678,6 +857,14 @@ static int bnl_src(const fr_bn_src* s, int width, const char* who, BnlSrc* out, 
 }
 
 static bool bnl_widths_ok(int32_t K, int32_t N) { return K >= 32 && K % 32 == 0 && K <= BNL_MAXW && N >= 1 && N <= BNL_MAXW; }
+
+#if BNL_TRACE
+extern "C" __attribute__((visibility("default"))) int fr_bnl_trace_read(unsigned long long* out, int n_words) {
+    FR_CHECK_HIP(hipDeviceSynchronize());
+    FR_CHECK_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(bnl_trace), (size_t)n_words * 8));
+    return FR_OK;
+}
+#endif
 
 extern "C" size_t fr_bnl_workspace_bytes(int64_t M, int32_t width) {
     if (M < 1 || width < 1) return 0;
@@ -731,7 +918,7 @@ extern "C" int fr_bnl_fwd(const fr_bn_src* in, int64_t M, int32_t K, const float
     a.used_out = (unsigned long long*)drop_used;
     a.tick = (unsigned long long*)drop_tick;
     const int tpw = N > 128 ? 2 : 1;
-    const size_t ldsb = ((size_t)(K / 32) * 1024 + (size_t)BNL_WAVES * 2 * tpw * 1024) * sizeof(float);
+    const size_t ldsb = ((size_t)(K / 32) * 1024 + (size_t)BNL_WAVES * BNL_NBUF * tpw * 1024) * sizeof(float);
     const dim3 grid((unsigned)((M + 31) / 32));
     prof_work(K_LINEAR_FWD, 2.0 * (double)M * N * K);
     ProfScope prof(K_LINEAR_FWD, stream);
@@ -818,7 +1005,7 @@ extern "C" int fr_bnl_bwd(const float* G, const fr_bn_src* self, const float* su
     a.dbeta = dbeta_below;
     a.ticket = ticket;
     const int tpw = K > 128 ? 2 : 1;
-    const size_t gemm = ((size_t)((N + 31) / 32) * 1024 + (size_t)BNL_WAVES * 2 * tpw * 1024) * sizeof(float);
+    const size_t gemm = ((size_t)((N + 31) / 32) * 1024 + (size_t)BNL_WAVES * BNL_NBUF * tpw * 1024) * sizeof(float);
     const size_t tiles = (size_t)32 * K * sizeof(float);
     const size_t ldsb = gemm > tiles ? gemm : tiles;
     const dim3 grid((unsigned)((M + 31) / 32));

@@ -354,9 +354,15 @@ BNL_MAX_ROWS = 1 << 16       # one workgroup folds the statistics of all 32-row 
 
 
 def _bn_chain_ok(x0, x1, masks, params) -> bool:
-    """The one-launch-per-layer form of csrc/mlp_bn.hip takes this MLP: BatchNorm behind every layer, one input block, no
-    recorded masks, input widths multiples of 32, every width <= 256, a batch-sized M (`FAIRREC_BN_LAYERED=1`: never)."""
-    if x1 is not None or masks is not None or os.environ.get("FAIRREC_BN_LAYERED") is not None:
+    """The one-launch-per-layer form of csrc/mlp_bn.hip can take this MLP: BatchNorm behind every layer, one input block, no
+    recorded masks, input widths multiples of 32, every width <= 256, a batch-sized M.  It is OPT-IN (`FAIRREC_BN_FUSED=1`):
+    measured on MI355X it is the same numbers (bit for bit where every width is a multiple of 32) in a third of the launches
+    and 10-40 % SLOWER than the layered form at every batch size from 256 to 8192 -- a launch of it is one workgroup per 32 rows
+    walking load -> product -> store -> arrive -> fold as one latency chain at one wave per SIMD (DESIGN.md §4b has the
+    phase stamps) -- so the layered form stays the default."""
+    if os.environ.get("FAIRREC_BN_FUSED") is None or os.environ.get("FAIRREC_BN_LAYERED") is not None:
+        return False
+    if x1 is not None or masks is not None:
         return False
     if x0.dim() != 2 or x0.shape[0] > BNL_MAX_ROWS or x0.dtype != torch.float32:
         return False
@@ -607,10 +613,10 @@ class MLPLayers(nn.Module):
         return s
 
     def _bnl_ticket(self, device) -> torch.Tensor:
-        """The arrival counter the launches of csrc/mlp_bn.hip share (zero between launches)."""
+        """The two arrival counters the launches of csrc/mlp_bn.hip share (zero between launches)."""
         t = getattr(self, "_ticket", None)
         if t is None or t.device != device:
-            t = self._ticket = torch.zeros(1, dtype=torch.int32, device=device)
+            t = self._ticket = torch.zeros(2, dtype=torch.int32, device=device)
         return t
 
     def _drop_state(self, device) -> torch.Tensor:

@@ -487,7 +487,7 @@ def _bn_mlp_run(mlp, x, w_out, need_dx=True, frozen=False):
 @pytest.mark.parametrize("mode", ["train", "frozen", "no_dx"])
 def test_bn_chain_equals_the_layered_form(widths, p, act, M, mode, monkeypatch):
     """csrc/mlp_bn.hip (one launch per layer and direction, a layer normalised and dropped by the launch that consumes it)
-    against the layered form (FAIRREC_BN_LAYERED=1) on copies of one module: output, input gradient, every parameter gradient,
+    against the layered form (the default; the fused one is FAIRREC_BN_FUSED=1) on copies of one module: output, input gradient, every parameter gradient,
     the running statistics and the batch counter -- the same dropout patterns, so the comparison is element for element."""
     import copy
     from fairrec import _C
@@ -512,11 +512,12 @@ def test_bn_chain_equals_the_layered_form(widths, p, act, M, mode, monkeypatch):
         real = getattr(lib, name)
         monkeypatch.setattr(lib, name, (lambda real, name: lambda *args: calls.__setitem__(name, calls[name] + 1) or real(*args))(real, name))
     kw = dict(need_dx=mode != "no_dx", frozen=mode == "frozen")
+    monkeypatch.setenv("FAIRREC_BN_FUSED", "1")                   # opt-in: the layered form is the default (it measures faster)
     got = [_bn_mlp_run(a, x, w_out, **kw) for _ in range(2)]      # two passes: the second has another pattern and moved statistics
     L = len(widths) - 1
     assert calls["fr_bnl_fwd"] == 2 * L and calls["fr_bnl_bwd_top"] == 2 and calls["fr_bn_fwd_ex"] == 0 and calls["fr_bn_bwd"] == 0
     assert calls["fr_bnl_bwd"] == 2 * L
-    monkeypatch.setenv("FAIRREC_BN_LAYERED", "1")
+    monkeypatch.delenv("FAIRREC_BN_FUSED")
     want = [_bn_mlp_run(b, x, w_out, **kw) for _ in range(2)]
     assert calls["fr_bn_fwd_ex"] == 2 * L
     exact = all(w % 32 == 0 for w in widths)
@@ -555,9 +556,10 @@ def test_bn_chain_equals_the_layered_form(widths, p, act, M, mode, monkeypatch):
 
 
 @pytest.mark.parametrize("widths,act,M", [([128, 256, 128], "relu", 4096), ([64, 64, 32, 3], "tanh", 500), ([32, 1], "leakyrelu", 64)])
-def test_bn_chain_matches_torch_in_float64(widths, act, M):
+def test_bn_chain_matches_torch_in_float64(widths, act, M, monkeypatch):
     """The fused BatchNorm MLP against torch in float64 (no dropout): output, gradients, running statistics."""
     from fairrec.model.layers import MLPLayers
+    monkeypatch.setenv("FAIRREC_BN_FUSED", "1")
     torch.manual_seed(5)
     mlp = MLPLayers(widths, activation=act, bn=True).cuda().train()
     with torch.no_grad():
