@@ -764,6 +764,10 @@ int glds_pick_ks(long long ntiles, int chunks) { return pick_ks(ntiles, chunks);
 
 int glds_linear_fwd(const GlMat& X, const float* W, const float* bias, int64_t M, int N, int K, int act, float* Y,
                     hipStream_t stream, float* bn_part) {
+    if (!bn_part && (!X.b || X.split >= K) && X.lda == K) {      // many rows, few columns: the streaming form (mlp_stream.hip)
+        int rc;
+        if (stream_linear_fwd(X.a, W, bias, M, N, K, act, Y, stream, &rc)) return rc;
+    }
     GlArgs g{};
     g.bn_part = bn_part;
     g.A = X;
@@ -788,6 +792,10 @@ int glds_linear_fwd(const GlMat& X, const float* W, const float* bias, int64_t M
 
 int glds_linear_bwd_input(const float* dY, const float* W, int64_t M, int N, int K, float* dx0, int k0, float* dx1, int k1,
                           hipStream_t stream, const float* relu_src, float relu_scale, int src_act) {
+    if (k1 == 0 && (!relu_src || src_act != 0)) {
+        int rc;
+        if (stream_linear_bwd_input(dY, W, M, N, K, dx0, relu_src, src_act, stream, &rc)) return rc;
+    }
     GlArgs g{};
     g.relu_src = relu_src;
     g.relu_scale = relu_scale;

@@ -57,6 +57,12 @@ struct GlWJob {
     float *slab, *bslab, *dW, *db;
 };
 int glds_linear_bwd_weight_multi(const GlWJob* jobs, int n, int64_t M, hipStream_t stream);
+// The same two products for many rows and 64 / 128 output columns as one stream per persistent workgroup (mlp_stream.hip);
+// false: not that kernel's shape (the caller goes on to the macro-tile kernels), true: launched, *rc = its status.
+bool stream_linear_fwd(const float* X, const float* W, const float* bias, int64_t M, int N, int K, int act, float* Y,
+                       hipStream_t stream, int* rc);
+bool stream_linear_bwd_input(const float* dY, const float* W, int64_t M, int N, int K, float* dX, const float* src, int src_act,
+                             hipStream_t stream, int* rc);
 // out = dY o act'(Y) elementwise (n % 4 == 0)
 int launch_act_bwd(const float* dY, const float* Y, int act, float scale, long long n, float* out, hipStream_t stream);
 

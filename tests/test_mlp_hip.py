@@ -589,3 +589,42 @@ def test_bn_chain_matches_torch_in_float64(widths, act, M, monkeypatch):
             continue                                             # a bias in front of BatchNorm: gradient 0 + rounding noise
         torch.testing.assert_close(got["g." + n].double(), p.grad, rtol=1e-3, atol=2e-5 * max(1.0, float(p.grad.abs().max())),
                                    msg=lambda m: f"{n}: {m}")
+
+
+@pytest.mark.parametrize("M,K,N", [(20000, 128, 128), (16384, 128, 64), (33333, 64, 128), (50001, 96, 128), (70000, 32, 64)])
+def test_streaming_products_are_bit_identical_to_the_macro_tile_kernels(M, K, N, monkeypatch):
+    """csrc/mlp_stream.hip (many rows, 64 / 128 output columns: persistent workgroups, weights resident in LDS, the input rows
+    streamed once by loader waves) against the macro-tile kernels (FAIRREC_LINEAR_NO_STREAM=1): the forward product with every
+    activation, the input gradient plain and taken on through the activation below -- the same sums in the same order."""
+    _C = _lib()
+    lib = _C.lib()
+    st = _C.current_stream()
+    g = torch.Generator(device="cuda").manual_seed(M + K)
+    X = torch.randn(M, K, device="cuda", generator=g)
+    W = torch.randn(N, K, device="cuda", generator=g) * 0.2
+    b = torch.randn(N, device="cuda", generator=g)
+    dY = torch.randn(M, N, device="cuda", generator=g)
+    Yin = torch.rand(M, K, device="cuda", generator=g) - 0.3
+    outs = {}
+    for form in ("stream", "tiles"):
+        if form == "tiles":
+            monkeypatch.setenv("FAIRREC_LINEAR_NO_STREAM", "1")
+        res = []
+        for act in (0, 1, 2, 3, 4):
+            Y = torch.full((M, N), float("nan"), device="cuda")
+            _C.check(lib.fr_linear_fwd(X.data_ptr(), K, None, 0, None, 1.0, W.data_ptr(), b.data_ptr(), M, N, act, Y.data_ptr(), st), "fwd")
+            res.append(Y)
+        dX = torch.full((M, K), float("nan"), device="cuda")
+        _C.check(lib.fr_linear_bwd_input(dY.data_ptr(), dY.data_ptr(), 0, W.data_ptr(), None, 1.0, M, N, dX.data_ptr(), K, None, 0, st), "bwd")
+        res.append(dX)
+        for act in (1, 2, 4):
+            dA = torch.full((M, K), float("nan"), device="cuda")
+            _C.check(lib.fr_linear_bwd_input_act(dY.data_ptr(), W.data_ptr(), M, N, K, Yin.data_ptr(), act, dA.data_ptr(), st), "bwd_act")
+            res.append(dA)
+        torch.cuda.synchronize()
+        outs[form] = res
+    for a, c in zip(outs["stream"], outs["tiles"]):
+        assert not torch.isnan(c).any()
+        assert torch.equal(a, c), float((a - c).abs().max())
+    ref = torch.nn.functional.linear(X.double(), W.double(), b.double())
+    torch.testing.assert_close(outs["stream"][0].double(), ref, rtol=1e-4, atol=1e-4)
