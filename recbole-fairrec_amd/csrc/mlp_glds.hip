@@ -824,6 +824,10 @@ int glds_linear_bwd_input(const float* dY, const float* W, int64_t M, int N, int
 
 int glds_linear_bwd_weight(const float* dY, const GlMat& X, int64_t M, int N, int K, int splits, int rows_per_split,
                            float* slab, float* bslab, hipStream_t stream) {
+    if (!X.b || X.split >= K) {
+        int rc;
+        if (stream_linear_bwd_weight(dY, X.a, M, N, K, splits, rows_per_split, slab, bslab, stream, &rc)) return rc;
+    }
     GlArgs g{};
     g.A = GlMat{dY, nullptr, N, 0, N};
     g.B = X;
@@ -861,6 +865,13 @@ int glds_linear_bwd_weight_multi(const GlWJob* jobs, int n, int64_t M, hipStream
         J.wide[j] = q.splits > 64 && J.n[j] + J.nb[j] <= 4096;
         rblocks += (unsigned)((J.n[j] + J.nb[j] + (J.wide[j] ? 3 : 63)) / (J.wide[j] ? 4 : 64));
         if (!q.dY) continue;            // sums only: the slabs were written by somebody else (the scorer's last layer)
+        if (!q.X.b || q.X.split >= q.K) {       // many rows: the slabs of this job by the streaming kernel (mlp_stream.hip)
+            int rc;
+            if (stream_linear_bwd_weight(q.dY, q.X.a, M, q.N, q.K, q.splits, q.rows_per_split, q.slab, q.bslab, stream, &rc)) {
+                if (rc) return rc;
+                continue;
+            }
+        }
         GlArgs& g = m.g[ng];
         g = GlArgs{};
         g.A = GlMat{q.dY, nullptr, q.N, 0, q.N};

@@ -63,6 +63,8 @@ bool stream_linear_fwd(const float* X, const float* W, const float* bias, int64_
                        hipStream_t stream, int* rc);
 bool stream_linear_bwd_input(const float* dY, const float* W, int64_t M, int N, int K, float* dX, const float* src, int src_act,
                              hipStream_t stream, int* rc);
+bool stream_linear_bwd_weight(const float* dY, const float* X, int64_t M, int N, int K, int splits, int rows_per_split, float* slab,
+                              float* bslab, hipStream_t stream, int* rc);
 // out = dY o act'(Y) elementwise (n % 4 == 0)
 int launch_act_bwd(const float* dY, const float* Y, int act, float scale, long long n, float* out, hipStream_t stream);
 

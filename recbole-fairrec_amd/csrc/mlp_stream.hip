@@ -244,6 +244,182 @@ __global__ __launch_bounds__((2 * CT + ST_LOADERS) * 64) void linear_stream_kern
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The weight gradient dW = dY^T X over many rows: slab[s] = dY[rows of split s]^T X[rows of split s] for ALL of [N, K] by one
+// workgroup (the macro-tile kernel gives every 64 x 64 piece of it a workgroup of its own: dY and X are then read N / 64 and
+// K / 64 times over).  Nothing is resident here -- both operands stream, 32 rows of each per chunk, (N + K) / 32 blocks -- and the
+// accumulators stay in registers for the whole split.  Compute waves: one output row-tile i (32 columns of dY) and one or two
+// column tiles j (of X) each, eight waves at 128 x 128 / 128 x 64 / 64 x 128.  Splits, chunk order, the two accumulators and the
+// column sums of dY (bslab) are the macro-tile kernel's: the same slabs bit for bit, and the same slab reduction behind them.
+struct WgArgs {
+    const float* dY;     // [M, N]
+    const float* X;      // [M, K]
+    int M, N, K;
+    int splits, chunks_per_split;
+    float* slab;         // [splits][N][K]
+    float* bslab;        // [splits][N] or nullptr
+};
+
+constexpr int WG_SLOTS = 4, WG_AHEAD = 2;    // a chunk is (N + K) / 32 blocks = up to 32 KB: two ahead is > 3 us of MFMAs
+
+template <int NB>
+__device__ __forceinline__ void wg_wait_newer(int newer) {     // NB LDS-DMA instructions per chunk and loader wave
+    if (newer <= 0) st_wait_vm<0>();
+    else if (newer == 1) st_wait_vm<NB>();
+    else st_wait_vm<2 * NB>();
+}
+
+template <int NT, int KT>        // N / 32, K / 32
+__global__ __launch_bounds__(((NT * KT >= 8 ? 8 : NT * KT) + ST_LOADERS) * 64) void wgrad_stream_kernel(WgArgs g) {
+    constexpr int T = NT * KT, NCW = T >= 8 ? 8 : T, TPW = T / NCW, NB = NT + KT;
+    static_assert(TPW == 1 || (TPW == 2 && KT == 4), "two tiles per wave share the dY tile: K = 128");
+    extern __shared__ __align__(16) float lds[];    // ring [WG_SLOTS][NT + KT][1024]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int srow = lane >> 3, sslot = lane & 7;
+    const int CPS = g.chunks_per_split;
+    const int total_chunks = (g.M + 31) >> 5;
+    // this workgroup's splits s = blockIdx.x, + gridDim.x, ...; split s has chunks [s CPS, min((s + 1) CPS, total)) (possibly none)
+    const int n_my = (int)blockIdx.x < g.splits ? (g.splits - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+    auto chunks_of = [&](int s) {
+        const int n = total_chunks - s * CPS;
+        return n < 0 ? 0 : (n < CPS ? n : CPS);
+    };
+
+    if (wave >= NCW) {
+        // ================= loader waves: instruction lw of every block of every chunk ====================================================
+        const int lw = wave - NCW;
+        int G = 0;
+        for (int k = 0; k < n_my; ++k) G += chunks_of((int)blockIdx.x + k * (int)gridDim.x);
+        int st_k = 0, st_c = 0, st_slot = 0;
+        while (st_k < n_my && chunks_of((int)blockIdx.x + st_k * (int)gridDim.x) == 0) ++st_k;
+        auto stage = [&]() {
+            const int s = (int)blockIdx.x + st_k * (int)gridDim.x;
+            const int row = 8 * lw + srow;
+            long long rr = ((long long)s * CPS + st_c) * 32 + row;
+            rr = rr < g.M ? rr : g.M - 1;
+            const int sw = (sslot ^ ((row >> 1) & 7)) << 2;
+            float* dst = lds + (size_t)st_slot * NB * 1024 + lw * 256;
+#pragma unroll
+            for (int b = 0; b < NT; ++b)
+                __builtin_amdgcn_global_load_lds((glb_vp)(g.dY + rr * g.N + b * 32 + sw), (lds_vp)(dst + b * 1024), 16, 0, 0);
+#pragma unroll
+            for (int b = 0; b < KT; ++b)
+                __builtin_amdgcn_global_load_lds((glb_vp)(g.X + rr * g.K + b * 32 + sw), (lds_vp)(dst + (NT + b) * 1024), 16, 0, 0);
+            if (++st_c == chunks_of(s)) {
+                st_c = 0;
+                ++st_k;
+                while (st_k < n_my && chunks_of((int)blockIdx.x + st_k * (int)gridDim.x) == 0) ++st_k;
+            }
+            st_slot = st_slot + 1 == WG_SLOTS ? 0 : st_slot + 1;
+        };
+        int issued = 0;
+        for (; issued < WG_AHEAD && issued < G; ++issued) stage();
+        for (int k = 0; k < G; ++k) {
+            if (issued < G) {       // chunk k + 2 into the slot chunk k - 2 held: the compute waves are past B_(k-1), through chunk k - 2
+                stage();
+                ++issued;
+            }
+            wg_wait_newer<NB>(issued - 1 - k);
+            __builtin_amdgcn_s_barrier();             // B_k
+        }
+        return;
+    }
+
+    // ================= compute waves ===================================================================================================
+    const int ti = TPW == 2 ? wave >> 1 : wave / KT;                 // row tile of the output = column tile of dY
+    const int tj0 = TPW == 2 ? (wave & 1) : wave - ti * KT;          // column tile(s) of the output = of X: tj0 (and tj0 + 2)
+    const int r = lane & 31, h = lane >> 5;
+    const unsigned base = (unsigned)(size_t)(__attribute__((address_space(3))) float*)lds;
+    unsigned rtt[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int row = 8 * (q >> 2) + 4 * h + (q & 3);
+        rtt[q] = row * 128 + ((((r >> 2) ^ ((row >> 1) & 7)) << 4) | ((r & 3) << 2));
+    }
+    int slot = 0;
+    for (int k = 0; k < n_my; ++k) {
+        const int s = (int)blockIdx.x + k * (int)gridDim.x;
+        const int nchunk = chunks_of(s);
+        f32x16 acc[TPW][2];
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) acc[i][0] = acc[i][1] = f32x16{0};
+        float bsum = 0.f;
+        for (int c = 0; c < nchunk; ++c) {
+            __builtin_amdgcn_s_barrier();             // B: this chunk is in LDS
+            float at[16], bt[TPW][16];
+            const unsigned sb = base + (unsigned)slot * (NB * 4096);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) asm volatile("ds_read_b32 %0, %1" : "=v"(at[q]) : "v"(sb + ti * 4096 + rtt[q]));
+#pragma unroll
+            for (int i = 0; i < TPW; ++i)
+#pragma unroll
+                for (int q = 0; q < 16; ++q)
+                    asm volatile("ds_read_b32 %0, %1" : "=v"(bt[i][q]) : "v"(sb + (NT + tj0 + 2 * i) * 4096 + rtt[q]));
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(at[0]), "+v"(at[1]), "+v"(at[2]), "+v"(at[3]), "+v"(at[4]), "+v"(at[5]), "+v"(at[6]), "+v"(at[7]),
+                           "+v"(at[8]), "+v"(at[9]), "+v"(at[10]), "+v"(at[11]), "+v"(at[12]), "+v"(at[13]), "+v"(at[14]), "+v"(at[15]));
+#pragma unroll
+            for (int i = 0; i < TPW; ++i)
+                asm volatile(""
+                             : "+v"(bt[i][0]), "+v"(bt[i][1]), "+v"(bt[i][2]), "+v"(bt[i][3]), "+v"(bt[i][4]), "+v"(bt[i][5]), "+v"(bt[i][6]),
+                               "+v"(bt[i][7]), "+v"(bt[i][8]), "+v"(bt[i][9]), "+v"(bt[i][10]), "+v"(bt[i][11]), "+v"(bt[i][12]),
+                               "+v"(bt[i][13]), "+v"(bt[i][14]), "+v"(bt[i][15]));
+            // the reduction runs over batch rows: the last chunk may reach past them
+            const long long red0 = ((long long)s * CPS + c) * 32;
+            if (red0 + 32 > g.M) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q)
+                    if (red0 + 8 * (q >> 2) + 4 * h + (q & 3) >= g.M) at[q] = 0.f;
+            }
+            if (g.bslab) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) bsum += at[q];
+            }
+#pragma unroll
+            for (int q = 0; q < 16; q += 2)
+#pragma unroll
+                for (int i = 0; i < TPW; ++i) {
+                    acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(at[q], bt[i][q], acc[i][0], 0, 0, 0);
+                    acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(at[q + 1], bt[i][q + 1], acc[i][1], 0, 0, 0);
+                }
+            slot = slot + 1 == WG_SLOTS ? 0 : slot + 1;
+        }
+        float* out = g.slab + (size_t)s * g.N * g.K;
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) {
+            const f32x16 a = acc[i][0] + acc[i][1];
+            const int j0 = (tj0 + 2 * i) * 32;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = ti * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                out[(size_t)row * g.K + j0 + r] = a[e];
+            }
+        }
+        if (g.bslab && tj0 == 0) {
+            bsum += __shfl_xor(bsum, 32, 64);
+            if (h == 0) g.bslab[(size_t)s * g.N + ti * 32 + r] = bsum;
+        }
+    }
+}
+
+template <int NT, int KT>
+static int launch_wgrad(const WgArgs& a, hipStream_t stream) {
+    constexpr int NCW = NT * KT >= 8 ? 8 : NT * KT;
+    const size_t ldsb = (size_t)WG_SLOTS * (NT + KT) * 4096;
+    const int blocks = a.splits < 256 ? a.splits : 256;
+    static size_t have = 0;
+    if (ldsb > have) {
+        FR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_stream_kernel<NT, KT>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
+        have = ldsb;
+    }
+    ProfScope prof(K_LINEAR_BWD_WEIGHT, stream);
+    FR_LAUNCH(prof, (wgrad_stream_kernel<NT, KT>), dim3((unsigned)blocks), dim3((NCW + ST_LOADERS) * 64), ldsb, stream, a);
+    FR_CHECK_LAUNCH();
+    return FR_OK;
+}
+
 static bool stream_enabled() { return getenv("FAIRREC_LINEAR_NO_STREAM") == nullptr; }
 
 template <bool B_T, int CT>
@@ -289,4 +465,19 @@ bool stream_linear_bwd_input(const float* dY, const float* W, int64_t M, int N, 
     return true;
 }
 
+}  // namespace fr
+
+namespace fr {
+// slab[s] = dY[rows of s]^T X[rows of s] (+ bslab) for one row-major X [M, K]: the splits of glds_linear_bwd_weight, its slabs
+bool stream_linear_bwd_weight(const float* dY, const float* X, int64_t M, int N, int K, int splits, int rows_per_split, float* slab,
+                              float* bslab, hipStream_t stream, int* rc) {
+    if (!stream_enabled() || M < 16384 || M > 0x7fffffffLL / 128 || rows_per_split % 32 != 0 || (N != 64 && N != 128) || (K != 64 && K != 128))
+        return false;
+    WgArgs a{dY, X, (int)M, N, K, splits, rows_per_split / 32, slab, bslab};
+    if (N == 128 && K == 128) *rc = launch_wgrad<4, 4>(a, stream);
+    else if (N == 128) *rc = launch_wgrad<4, 2>(a, stream);
+    else if (K == 128) *rc = launch_wgrad<2, 4>(a, stream);
+    else *rc = launch_wgrad<2, 2>(a, stream);
+    return true;
+}
 }  // namespace fr

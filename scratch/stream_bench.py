@@ -13,7 +13,10 @@ for (M, K, N) in ((1800000, 128, 128), (1800000, 128, 64), (1800000, 64, 128), (
             os.environ["FAIRREC_LINEAR_NO_STREAM"] = "1"
         else:
             os.environ.pop("FAIRREC_LINEAR_NO_STREAM", None)
-        for name, call in (("fwd", lambda: lib.fr_linear_fwd(X.data_ptr(), K, None, 0, None, 1.0, W.data_ptr(), b.data_ptr(), M, N, 2, Y.data_ptr(), st)),
+        wsz = lib.fr_linear_bwd_weight_workspace_bytes(M, N, K)
+        ws = torch.empty(wsz, dtype=torch.uint8, device="cuda"); dW = torch.empty(N, K, device="cuda"); db = torch.empty(N, device="cuda")
+        for name, call in (("bwd_weight", lambda: lib.fr_linear_bwd_weight(Y.data_ptr(), Y.data_ptr(), 0, X.data_ptr(), K, None, 0, None, 1.0, M, N, dW.data_ptr(), db.data_ptr(), ws.data_ptr(), wsz, st)),
+                           ("fwd", lambda: lib.fr_linear_fwd(X.data_ptr(), K, None, 0, None, 1.0, W.data_ptr(), b.data_ptr(), M, N, 2, Y.data_ptr(), st)),
                            ("bwd_input", lambda: lib.fr_linear_bwd_input(Y.data_ptr(), Y.data_ptr(), 0, W.data_ptr(), None, 1.0, M, N, dX.data_ptr(), K, None, 0, st))):
             for _ in range(3):
                 call()

@@ -628,3 +628,38 @@ def test_streaming_products_are_bit_identical_to_the_macro_tile_kernels(M, K, N,
         assert torch.equal(a, c), float((a - c).abs().max())
     ref = torch.nn.functional.linear(X.double(), W.double(), b.double())
     torch.testing.assert_close(outs["stream"][0].double(), ref, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("M,N,K", [(20000, 128, 128), (16384, 128, 64), (33333, 64, 128), (50001, 64, 64), (300000, 128, 128)])
+def test_streaming_weight_gradient_is_bit_identical_to_the_macro_tile_kernel(M, N, K, monkeypatch):
+    """csrc/mlp_stream.hip's weight gradient (one workgroup per row split forms ALL of dY^T X: both operands read once) against
+    the macro-tile kernel (FAIRREC_LINEAR_NO_STREAM=1): the same splits, the same slabs, so dW and db bit for bit."""
+    _C = _lib()
+    lib = _C.lib()
+    st = _C.current_stream()
+    g = torch.Generator(device="cuda").manual_seed(M + N)
+    X = torch.randn(M, K, device="cuda", generator=g)
+    dY = torch.randn(M, N, device="cuda", generator=g)
+    got = {}
+    for form in ("stream", "tiles"):
+        if form == "tiles":
+            monkeypatch.setenv("FAIRREC_LINEAR_NO_STREAM", "1")
+        dW = torch.full((N, K), float("nan"), device="cuda")
+        db = torch.full((N,), float("nan"), device="cuda")
+        ws = torch.empty(lib.fr_linear_bwd_weight_workspace_bytes(M, N, K), dtype=torch.uint8, device="cuda")
+        _C.check(lib.fr_linear_bwd_weight(dY.data_ptr(), dY.data_ptr(), 0, X.data_ptr(), K, None, 0, None, 1.0, M, N, dW.data_ptr(),
+                                          db.data_ptr(), ws.data_ptr(), ws.numel(), st), "fr_linear_bwd_weight")
+        # ... and as a job of the multi-layer call (the path MLPLayers.backward takes)
+        dW2 = torch.full((N, K), float("nan"), device="cuda")
+        db2 = torch.full((N,), float("nan"), device="cuda")
+        jobs = (_C.FrWgradJob * 1)(_C.FrWgradJob(dY.data_ptr(), X.data_ptr(), K, None, 0, N, dW2.data_ptr(), db2.data_ptr(), None, 0))
+        wsm = torch.empty(lib.fr_linear_bwd_weight_multi_workspace_bytes(jobs, 1, M), dtype=torch.uint8, device="cuda")
+        _C.check(lib.fr_linear_bwd_weight_multi(jobs, 1, M, wsm.data_ptr(), wsm.numel(), st), "fr_linear_bwd_weight_multi")
+        torch.cuda.synchronize()
+        got[form] = (dW, db, dW2, db2)
+    for a, c in zip(got["stream"], got["tiles"]):
+        assert not torch.isnan(c).any()
+        assert torch.equal(a, c), float((a - c).abs().max())
+    ref = dY.double().t() @ X.double()
+    torch.testing.assert_close(got["stream"][0].double(), ref, rtol=1e-4, atol=1e-3 * float(ref.abs().max()))
+    torch.testing.assert_close(got["stream"][1].double(), dY.double().sum(0), rtol=1e-4, atol=1e-3 * float(M) ** 0.5)
