@@ -833,6 +833,20 @@ FR_API int fr_sample_negatives_calls(uint32_t* state, int64_t low, int64_t high,
                                      const int64_t* used_indptr, const int32_t* used_items, int64_t n_users, int64_t* out,
                                      void* ws, size_t ws_bytes, uint32_t* err_flag, void* stream);
 
+/* ---- the row sets of a frontier-restricted propagation (csrc/frontier.hip) -----------------------------------------------------
+ * Which rows of H_l = L H_(l-1) a batch can see (fairgo_pmf.py:196-216 aggregates every layer's rows of the batch's users): the
+ * sets fr_spmm_csr_sel takes.  A set is a bitmap over the graph rows (bits: (n_rows + 31) / 32 words, zeroed by the caller):
+ * fr_frontier_mark sets the bits of an id list (ids outside [0, n_rows) raise FR_DEV_ERR_INDEX_RANGE), fr_frontier_expand the
+ * bits of the columns of the listed rows of a CSR matrix, fr_frontier_count writes popcount(bits[w]) per word, and -- given the
+ * inclusive cumulative sum of those counts -- fr_frontier_scatter writes the set's row ids in ascending order (rows_out) and
+ * pos[row] = rank of the row in the set, -1 outside it (pos: n_rows entries, every one written). */
+FR_API int fr_frontier_mark(const int64_t* ids, int64_t n, int64_t n_rows, uint32_t* bits, uint32_t* err_flag, void* stream);
+FR_API int fr_frontier_expand(const int64_t* indptr, const int32_t* col, const int32_t* rows, int64_t n_list, uint32_t* bits,
+                              void* stream);
+FR_API int fr_frontier_count(const uint32_t* bits, int64_t n_rows, int32_t* count, void* stream);
+FR_API int fr_frontier_scatter(const uint32_t* bits, const int32_t* incl, int64_t n_rows, int32_t* rows_out, int32_t* pos,
+                               void* stream);
+
 /* ---- an MLP with BatchNorm behind every layer, one launch per layer and direction (csrc/mlp_bn.hip) -----------------------------
  * Replaces, for MLPLayers(..., bn=True) (layers.py:56-85; pfcn_biasedmf.py:113-142: PFCN's filters and discriminators), the
  * three launches per layer forward and four backward of fr_linear_fwd_bnstats / fr_bn_fwd_ex / fr_bn_bwd / fr_linear_bwd_input:

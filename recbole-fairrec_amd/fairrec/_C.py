@@ -227,6 +227,10 @@ _PROTOS = {
                                  c_int64, c_void_p, c_void_p]),
     "fr_nfcf_df_apply": (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
                                  c_int64, c_float, c_float, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "fr_frontier_mark": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
+    "fr_frontier_expand": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
+    "fr_frontier_count": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
+    "fr_frontier_scatter": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
     "fr_bnl_workspace_bytes": (c_size_t, [c_int64, c_int32]),
     "fr_bnl_fwd": (c_int, [POINTER(FrBnSrc), c_int64, c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_float, c_float,
                            c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p,

@@ -14,11 +14,14 @@ finetune  : embeddings frozen; per step, as in the reference, the filter MLPs ru
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import scipy.sparse as sp
 import torch
 import torch.nn as nn
 
+from ... import _C
 from ...engine import GenericEngine
 from ...functional import CsrMatrix, GatherAndSpMMSel, Mse, RowDot, RowGather, SigmoidBce, SoftmaxCe, SplitRows, SpMM, SpMMSel
 from ...utils.enum_type import InputType
@@ -209,6 +212,54 @@ class FairGo_PMF(FairRecommender):
         rows of H_l = L H_(l-1) that the batch's local embeddings depend on.  S_n = the batch's users; S_(l-1) = S_n plus the
         columns of the rows S_l (every layer's rows of the batch's users are aggregated, fairgo_pmf.py:204-216).  None when
         the frontier covers so much of the graph that whole-table products are as cheap."""
+        L = self._L
+        ip, col, _ = L.fwd
+        N = L.shape[0]
+        dev = ip.device
+        if os.environ.get("FAIRREC_FRONTIER_TORCH") is not None:
+            return self._frontier_torch(user)
+        # A set is a bitmap over the graph rows (csrc/frontier.hip): mark the batch's users, OR in the columns of a set's rows,
+        # and turn a bitmap into (ascending row ids, rank map) with one popcount launch, one cumulative sum and one scatter --
+        # 5 launches per layer on 1.4 MB bitmaps where the torch form below ran ~15 over 11 M-entry maps and the 5.7 M
+        # neighbour ids of a BASELINE configs[3] batch.  One host read per layer: the size of the set.
+        lib, st = _C.lib(), _C.current_stream()
+        eng = self.hip_engine()
+        nw = (N + 31) // 32
+        bits = torch.zeros(nw, dtype=torch.int32, device=dev)
+        ids = user.to(dev, torch.int64).contiguous()
+        _C.check(lib.fr_frontier_mark(ids.data_ptr(), ids.numel(), N, bits.data_ptr(), eng.err_flag.data_ptr(), st), "fr_frontier_mark")
+
+        def listed(bits):
+            cnt = torch.empty(nw, dtype=torch.int32, device=dev)
+            _C.check(lib.fr_frontier_count(bits.data_ptr(), N, cnt.data_ptr(), st), "fr_frontier_count")
+            incl = torch.cumsum(cnt, 0, dtype=torch.int32)
+            n = int(incl[-1].item())
+            rows = torch.empty(n, dtype=torch.int32, device=dev)
+            pos = torch.empty(N, dtype=torch.int32, device=dev)
+            _C.check(lib.fr_frontier_scatter(bits.data_ptr(), incl.data_ptr(), N, rows.data_ptr(), pos.data_ptr(), st),
+                     "fr_frontier_scatter")
+            return rows, pos
+
+        out = []
+        for l in range(self.n_layers, 0, -1):
+            rows, pos = listed(bits)
+            if l < self.n_layers and rows.numel() > self.FRONTIER_MAX_SHARE * N:
+                return None
+            out.append((rows, pos, bits))
+            if l > 1:
+                r64 = rows.to(torch.int64)
+                tot = int((ip[r64 + 1] - ip[r64]).sum().item())
+                if tot > self.FRONTIER_MAX_SHARE * col.numel():
+                    return None
+                bits = bits.clone()             # (the batch's users stay marked: S_(l-1) includes S_n)
+                _C.check(lib.fr_frontier_expand(ip.data_ptr(), col.data_ptr(), rows.data_ptr(), rows.numel(), bits.data_ptr(), st),
+                         "fr_frontier_expand")
+        out.reverse()                           # S_1 first
+        return out
+
+    def _frontier_torch(self, user):
+        """The same sets with stock torch ops (the form of round 4; `FAIRREC_FRONTIER_TORCH=1`, and what the tests hold the
+        kernels against)."""
         L = self._L
         ip, col, _ = L.fwd
         N = L.shape[0]

@@ -407,6 +407,12 @@ def test_frontier_restricted_propagation_equals_whole_table(aggr, n_layers, D):
             assert len(fr) == n_layers and fr[-1][0].numel() == len(set(u.tolist()))
             if n_layers > 1:
                 assert fr[0][0].numel() > fr[-1][0].numel()
+            # the bitmap kernels (csrc/frontier.hip) against the same sets built with stock torch ops: row lists, rank maps, bitmaps
+            ref = model._frontier_torch(inter["user_id"])
+            assert len(ref) == len(fr)
+            for (r0, p0, b0), (r1, p1, b1) in zip(fr, ref):
+                assert r0.dtype == r1.dtype == torch.int32 and torch.equal(r0, r1)
+                assert torch.equal(p0, p1) and torch.equal(b0, b1)
         model.hip_engine().check_device_errors()
     (l0, d0, g0), (l1, d1, g1) = results[False], results[True]
     assert torch.equal(l0, l1), (float(l0), float(l1))
