@@ -5,10 +5,10 @@
 // chunks of work behind a cold start (the first operand blocks: a memory latency with nothing to overlap), the weights fetched
 // again by every workgroup, and the input rows fetched once per 64 output columns.  Priced per launch ([1.8 M, 128] x 128): 0.38 ms
 // of MFMA time at peak, 0.38 ms of HBM time for input + output, 1.0 ms measured -- neither.  Here a workgroup is PERSISTENT: it
-// keeps the whole weight matrix in LDS (<= 64 KB), takes row tiles of 64 rows x ALL output columns in turn, and treats its tiles'
-// reduction chunks as one sequence: four LOADER waves issue the LDS-DMA of chunk g + 6 while the COMPUTE waves run the MFMAs of
-// chunk g, one 32 x 32 output tile per wave (two waves per SIMD at 128 columns: one wave's fragment reads under the other's
-// MFMAs).  Input rows are read once, weights once per workgroup, and
+// keeps the whole weight matrix in LDS (<= 64 KB), takes row tiles of 128 rows x ALL output columns in turn, and treats its tiles'
+// reduction chunks as one sequence: four LOADER waves issue the LDS-DMA of chunk g + 3 ... g + 6 (as many ring slots as LDS
+// leaves) while eight COMPUTE waves run the MFMAs of chunk g -- two per SIMD, one wave's fragment reads under the other's MFMAs;
+// at 128 columns a wave owns two row blocks of one column tile (four accumulator chains, the W fragments read once for both).  Input rows are read once, weights once per workgroup, and
 // the start-up latency is paid once per workgroup instead of once per tile.  Splitting the roles also keeps loads and stores in
 // different waves: s_waitcnt vmcnt counts both, they may retire out of order with respect to each other, and a compute wave that
 // stores a finished tile would otherwise have to drain the prefetch to know its next chunk has landed.
@@ -29,9 +29,7 @@ using f4 = __attribute__((ext_vector_type(4))) float;
 typedef __attribute__((address_space(3))) void* lds_vp;
 typedef const __attribute__((address_space(1))) void* glb_vp;
 
-constexpr int ST_LOADERS = 4;        // loader waves; compute waves: 2 row blocks x C / 32 column tiles, one 32 x 32 tile each
-constexpr int ST_SLOTS = 8;          // ring of chunk slots (two 32 x 32 blocks each)
-constexpr int ST_AHEAD = 6;          // chunks requested ahead of the one being multiplied (<= ST_SLOTS - 2, see the slot reuse note)
+constexpr int ST_LOADERS = 4;        // loader waves
 
 struct StArgs {
     const float* A;      // [M, R] row-major
@@ -39,6 +37,7 @@ struct StArgs {
     int ldw;
     int M, R, C;
     int cpp;             // chunks per part of a tile's reduction: the macro-tile kernels' summation order for this shape (glds_pick_ks)
+    int slots;           // ring slots (a chunk of a row tile each: ST_RB blocks); slots - 2 chunks are requested ahead
     const float* bias;   // forward
     int act;
     float* out;          // [M, C]
@@ -60,93 +59,95 @@ template <int N>
 __device__ __forceinline__ void st_wait_vm() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
-__device__ __forceinline__ void st_wait_newer(int newer) {     // 2 LDS-DMA instructions per chunk and loader wave
+template <int PER>     // PER LDS-DMA instructions per chunk and loader wave; at most 6 chunks are ever in flight behind the one awaited
+__device__ __forceinline__ void st_wait_newer(int newer) {
     switch (newer) {
         case 0: st_wait_vm<0>(); break;
-        case 1: st_wait_vm<2>(); break;
-        case 2: st_wait_vm<4>(); break;
-        case 3: st_wait_vm<6>(); break;
-        case 4: st_wait_vm<8>(); break;
-        case 5: st_wait_vm<10>(); break;
-        default: st_wait_vm<12>(); break;
+        case 1: st_wait_vm<PER>(); break;
+        case 2: st_wait_vm<2 * PER>(); break;
+        case 3: st_wait_vm<3 * PER>(); break;
+        case 4: st_wait_vm<4 * PER>(); break;
+        case 5: st_wait_vm<5 * PER>(); break;
+        default: st_wait_vm<6 * PER>(); break;
     }
 }
 
-template <bool B_T, int CT>      // B_T: the reduction index runs along W's rows (input gradient); CT = C / 32 column tiles
-__global__ __launch_bounds__((2 * CT + ST_LOADERS) * 64) void linear_stream_kernel(StArgs g) {
-    static_assert(ST_AHEAD == 6 && ST_AHEAD <= ST_SLOTS - 2, "st_wait_newer is written for six chunks ahead");
-    extern __shared__ __align__(16) float lds[];    // W image [R / 32][CT][1024], then the ring [ST_SLOTS][2][1024]
-    constexpr int NCW = 2 * CT;
+// B_T: the reduction index runs along W's rows (input gradient); CT = C / 32 column tiles; RPW: row blocks per compute wave (two
+// at 128 columns: four accumulator chains per wave and the W fragments read once for both -- half the barriers per MFMA)
+// ST_RB: 32-row blocks of a row tile (128 rows, or 64 where the registers of two row blocks per wave do not fit: the input gradient
+// through an activation at 128 columns keeps 32 `src` values per lane in flight)
+template <bool B_T, int CT, int ST_RB, int RPW, bool SRC>
+__global__ __launch_bounds__((ST_RB / RPW * CT + ST_LOADERS) * 64) void linear_stream_kernel(StArgs g) {
+    extern __shared__ __align__(16) float lds[];    // W image [R / 32][CT][1024], then the ring [slots][ST_RB][1024]
+    constexpr int NCW = ST_RB / RPW * CT;
+    static_assert(NCW == 8, "eight compute waves: two per SIMD");
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int RC = g.R >> 5;
+    const int RC = g.R >> 5, SLOTS = g.slots, AHEAD = g.slots - 2;
     float* wimg = lds;
     float* ring = lds + (size_t)RC * CT * 1024;
-    const int ntiles = (g.M + 63) >> 6;
+    const int ntiles = (g.M + 32 * ST_RB - 1) / (32 * ST_RB);
     const int n_my = (int)blockIdx.x < ntiles ? (ntiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
     const int G = n_my * RC;                         // this workgroup's chunks, tile after tile
     const int srow = lane >> 3, sslot = lane & 7;
 
     if (wave >= NCW) {
-        // ================= loader waves ===========================================================================================
+        // ================= loader waves: instruction lw of every block ===================================================================
         const int lw = wave - NCW;
-        // the weight image, once: block (c, j) = 32 reduction elements x 32 output columns; wave lw brings instruction lw of every block
+        const int row = 8 * lw + srow, sw = (sslot ^ ((row >> 1) & 7)) << 2;
+        // the weight image, once: block (c, j) = 32 reduction elements x 32 output columns
         for (int b = 0; b < RC * CT; ++b) {
             const int c = b / CT, j = b - c * CT;
-            const int row = 8 * lw + srow;
             const float* p;
             if (B_T) {
                 int n = c * 32 + row;
                 n = n < g.R ? n : g.R - 1;
-                p = g.W + (size_t)n * g.ldw + j * 32 + ((sslot ^ ((row >> 1) & 7)) << 2);
+                p = g.W + (size_t)n * g.ldw + j * 32 + sw;
             } else {
                 int n = j * 32 + row;
                 n = n < g.C ? n : g.C - 1;
-                p = g.W + (size_t)n * g.ldw + c * 32 + ((sslot ^ ((row >> 1) & 7)) << 2);
+                p = g.W + (size_t)n * g.ldw + c * 32 + sw;
             }
             __builtin_amdgcn_global_load_lds((glb_vp)p, (lds_vp)(wimg + (size_t)b * 1024 + lw * 256), 16, 0, 0);
         }
-        // chunk (tile t, c): block b2 = rows 64 rt + 32 b2 ..., columns 32 c ...; this wave brings instructions 2 (lw & 1), + 1 of block lw >> 1
-        const int blk = lw >> 1, q0 = 2 * (lw & 1);
-        int st_t = 0, st_c = 0, st_slot = 0;         // the next chunk to request
+        int st_t = 0, st_c = 0, st_slot = 0;         // the next chunk to request: (tile, chunk) -> ring slot
         auto stage = [&]() {
-            const long long rt = (long long)blockIdx.x + (long long)st_t * gridDim.x;
+            const long long r0 = ((long long)blockIdx.x + (long long)st_t * gridDim.x) * (32 * ST_RB) + row;
+            float* dst = ring + (size_t)st_slot * (ST_RB * 1024) + lw * 256;
 #pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const int q = q0 + k, row = 8 * q + srow;
-                long long rr = rt * 64 + blk * 32 + row;
+            for (int b = 0; b < ST_RB; ++b) {
+                long long rr = r0 + b * 32;
                 rr = rr < g.M ? rr : g.M - 1;
-                const float* p = g.A + rr * g.R + st_c * 32 + ((sslot ^ ((row >> 1) & 7)) << 2);
-                __builtin_amdgcn_global_load_lds((glb_vp)p, (lds_vp)(ring + (size_t)st_slot * 2048 + blk * 1024 + q * 256), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((glb_vp)(g.A + rr * g.R + st_c * 32 + sw), (lds_vp)(dst + b * 1024), 16, 0, 0);
             }
             if (++st_c == RC) {
                 st_c = 0;
                 ++st_t;
             }
-            st_slot = st_slot + 1 == ST_SLOTS ? 0 : st_slot + 1;
+            st_slot = st_slot + 1 == SLOTS ? 0 : st_slot + 1;
         };
         int issued = 0;
-        for (; issued < ST_AHEAD && issued < G; ++issued) stage();
-        st_wait_newer(issued);                        // the weight image has landed (everything older than the chunks)
+        for (; issued < AHEAD && issued < G; ++issued) stage();
+        st_wait_newer<ST_RB>(issued);                 // the weight image has landed (everything older than the chunks)
         __builtin_amdgcn_s_barrier();                 // B_w
         for (int k = 0; k < G; ++k) {
             if (issued < G) {
-                // chunk k + ST_AHEAD goes into the slot chunk k - 2 held: every compute wave is past B_(k-1), i.e. through the
+                // chunk k + AHEAD goes into the slot chunk k - 2 held: every compute wave is past B_(k-1), i.e. through the
                 // fragment reads AND the MFMAs of chunk k - 2
                 stage();
                 ++issued;
             }
-            st_wait_newer(issued - 1 - k);            // chunk k has landed
+            st_wait_newer<ST_RB>(issued - 1 - k);     // chunk k has landed
             __builtin_amdgcn_s_barrier();             // B_k
         }
         return;
     }
 
-    // ================= compute waves: one 32 x 32 output tile each, two per SIMD when C = 128 =========================================
-    const int wi = wave / CT, wj = wave - wi * CT;
+    // ================= compute waves: RPW row blocks x one column tile each, two waves per SIMD ========================================
+    const int wr = wave / CT, wj = wave - wr * CT;
     const int r = lane & 31, h = lane >> 5;
     const unsigned wbase = (unsigned)(size_t)(__attribute__((address_space(3))) float*)wimg + wj * 4096;
-    const unsigned rbase = (unsigned)(size_t)(__attribute__((address_space(3))) float*)ring + wi * 4096;
+    const unsigned rbase = (unsigned)(size_t)(__attribute__((address_space(3))) float*)ring + wr * RPW * 4096;
     unsigned rn[4], rtt[16];
 #pragma unroll
     for (int j = 0; j < 4; ++j) rn[j] = r * 128 + (((2 * j + h) ^ ((r >> 1) & 7)) << 4);
@@ -155,90 +156,108 @@ __global__ __launch_bounds__((2 * CT + ST_LOADERS) * 64) void linear_stream_kern
         const int row = 8 * (q >> 2) + 4 * h + (q & 3);
         rtt[q] = row * 128 + ((((r >> 2) ^ ((row >> 1) & 7)) << 4) | ((r & 3) << 2));
     }
-    f32x16 acc0 = {0}, acc1 = {0}, tot = {0};
+    f32x16 acc[RPW][2], tot[RPW];
+#pragma unroll
+    for (int p = 0; p < RPW; ++p) acc[p][0] = acc[p][1] = tot[p] = f32x16{0};
     const int col = wj * 32 + r;
     const float bias = (!B_T && g.bias) ? g.bias[col] : 0.f;      // once per wave: a load per tile would be a memory latency per tile
-    float sv[16];                                                  // the tile's `src` values, requested when the tile begins
+    float sv[SRC ? RPW : 1][16];                                   // the tile's `src` values, requested when the tile begins
     int in_part = 0;
 
     __builtin_amdgcn_s_barrier();                     // B_w: the weight image
     int c = 0, t = 0, slot = 0;
     for (int k = 0; k < G; ++k) {
-        if (B_T && g.src && c == 0) {
-            const long long i0 = ((long long)blockIdx.x + (long long)t * gridDim.x) * 64 + wi * 32 + 4 * h;
+        if (SRC && c == 0) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                long long row = i0 + (e & 3) + 8 * (e >> 2);
-                row = row < g.M ? row : g.M - 1;
-                sv[e] = g.src[(size_t)row * g.C + col];
+            for (int p = 0; p < RPW; ++p) {
+                const long long i0 = ((long long)blockIdx.x + (long long)t * gridDim.x) * (32 * ST_RB) + (wr * RPW + p) * 32 + 4 * h;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    long long row = i0 + (e & 3) + 8 * (e >> 2);
+                    row = row < g.M ? row : g.M - 1;
+                    sv[SRC ? p : 0][e] = g.src[(size_t)row * g.C + col];
+                }
             }
         }
         __builtin_amdgcn_s_barrier();                 // B_k: chunk k is in LDS
-        f4 av[4], bv[4];
+        f4 av[RPW][4], bv[4];
         float bt[16];
-        const unsigned ab = rbase + slot * 8192, bb = wbase + (unsigned)(c * CT) * 4096;
+        const unsigned ab = rbase + (unsigned)slot * (ST_RB * 4096), bb = wbase + (unsigned)(c * CT) * 4096;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) asm volatile("ds_read_b128 %0, %1" : "=v"(av[j]) : "v"(ab + rn[j]));
+        for (int p = 0; p < RPW; ++p)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) asm volatile("ds_read_b128 %0, %1" : "=v"(av[p][j]) : "v"(ab + p * 4096 + rn[j]));
         if (!B_T) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) asm volatile("ds_read_b128 %0, %1" : "=v"(bv[j]) : "v"(bb + rn[j]));
             asm volatile("s_waitcnt lgkmcnt(0)"
-                         : "+v"(av[0]), "+v"(av[1]), "+v"(av[2]), "+v"(av[3]), "+v"(bv[0]), "+v"(bv[1]), "+v"(bv[2]), "+v"(bv[3]));
+                         : "+v"(av[0][0]), "+v"(av[0][1]), "+v"(av[0][2]), "+v"(av[0][3]), "+v"(bv[0]), "+v"(bv[1]), "+v"(bv[2]), "+v"(bv[3]));
         } else {
 #pragma unroll
             for (int q = 0; q < 16; ++q) asm volatile("ds_read_b32 %0, %1" : "=v"(bt[q]) : "v"(bb + rtt[q]));
             asm volatile("s_waitcnt lgkmcnt(0)"
-                         : "+v"(av[0]), "+v"(av[1]), "+v"(av[2]), "+v"(av[3]), "+v"(bt[0]), "+v"(bt[1]), "+v"(bt[2]), "+v"(bt[3]),
+                         : "+v"(av[0][0]), "+v"(av[0][1]), "+v"(av[0][2]), "+v"(av[0][3]), "+v"(bt[0]), "+v"(bt[1]), "+v"(bt[2]), "+v"(bt[3]),
                            "+v"(bt[4]), "+v"(bt[5]), "+v"(bt[6]), "+v"(bt[7]), "+v"(bt[8]), "+v"(bt[9]), "+v"(bt[10]), "+v"(bt[11]),
                            "+v"(bt[12]), "+v"(bt[13]), "+v"(bt[14]), "+v"(bt[15]));
         }
+        if constexpr (RPW == 2) asm volatile("" : "+v"(av[RPW - 1][0]), "+v"(av[RPW - 1][1]), "+v"(av[RPW - 1][2]), "+v"(av[RPW - 1][3]));
 #pragma unroll
-        for (int q = 0; q < 16; q += 2) {
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q >> 2][q & 3], B_T ? bt[q] : bv[q >> 2][q & 3], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[(q + 1) >> 2][(q + 1) & 3], B_T ? bt[q + 1] : bv[(q + 1) >> 2][(q + 1) & 3], acc1, 0, 0, 0);
-        }
-        slot = slot + 1 == ST_SLOTS ? 0 : slot + 1;
+        for (int q = 0; q < 16; q += 2)
+#pragma unroll
+            for (int p = 0; p < RPW; ++p) {
+                acc[p][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[p][q >> 2][q & 3], B_T ? bt[q] : bv[q >> 2][q & 3], acc[p][0], 0, 0, 0);
+                acc[p][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[p][(q + 1) >> 2][(q + 1) & 3], B_T ? bt[q + 1] : bv[(q + 1) >> 2][(q + 1) & 3],
+                                                                 acc[p][1], 0, 0, 0);
+            }
+        slot = slot + 1 == SLOTS ? 0 : slot + 1;
         if (++in_part == g.cpp) {        // a part of the reduction ends: parts are added in order (the macro-tile kernels' KS split)
             in_part = 0;
-            tot += acc0 + acc1;
-            acc0 = acc1 = f32x16{0};
+#pragma unroll
+            for (int p = 0; p < RPW; ++p) {
+                tot[p] += acc[p][0] + acc[p][1];
+                acc[p][0] = acc[p][1] = f32x16{0};
+            }
         }
         if (++c < RC) continue;
         // ---- a tile is complete: the macro-tile kernels' epilogues --------------------------------------------------------------------
         c = 0;
-        const long long i0 = ((long long)blockIdx.x + (long long)t * gridDim.x) * 64 + wi * 32;
+        const long long tile0 = ((long long)blockIdx.x + (long long)t * gridDim.x) * (32 * ST_RB);
         ++t;
-        const f32x16 a = tot;
-        tot = f32x16{0};
-        float* op = g.out + (size_t)(i0 + 4 * h) * g.C + col;
-        if (!B_T) {
-            if (g.act <= 2) {
-                const float neg = g.act == 0 ? 1.f : (g.act == 1 ? 0.f : 0.01f);
+#pragma unroll
+        for (int p = 0; p < RPW; ++p) {
+            const long long i0 = tile0 + (wr * RPW + p) * 32;
+            const f32x16 a = tot[p];
+            tot[p] = f32x16{0};
+            float* op = g.out + (size_t)(i0 + 4 * h) * g.C + col;
+            if (!B_T) {
+                if (g.act <= 2) {
+                    const float neg = g.act == 0 ? 1.f : (g.act == 1 ? 0.f : 0.01f);
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int ro = (e & 3) + 8 * (e >> 2);
+                        const float v = a[e] + bias;
+                        if (i0 + 4 * h + ro < g.M) op[(size_t)ro * g.C] = v > 0.f ? v : v * neg;
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int ro = (e & 3) + 8 * (e >> 2);
+                        const float v = a[e] + bias;
+                        if (i0 + 4 * h + ro < g.M) op[(size_t)ro * g.C] = g.act == 3 ? 1.f / (1.f + __expf(-v)) : tanhf(v);
+                    }
+                }
+            } else if (SRC) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int ro = (e & 3) + 8 * (e >> 2);
-                    const float v = a[e] + bias;
-                    if (i0 + 4 * h + ro < g.M) op[(size_t)ro * g.C] = v > 0.f ? v : v * neg;
+                    if (i0 + 4 * h + ro < g.M) op[(size_t)ro * g.C] = a[e] * st_act_bwd(sv[SRC ? p : 0][e], g.src_act);
                 }
             } else {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int ro = (e & 3) + 8 * (e >> 2);
-                    const float v = a[e] + bias;
-                    if (i0 + 4 * h + ro < g.M) op[(size_t)ro * g.C] = g.act == 3 ? 1.f / (1.f + __expf(-v)) : tanhf(v);
+                    if (i0 + 4 * h + ro < g.M) op[(size_t)ro * g.C] = a[e];
                 }
-            }
-        } else if (g.src) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int ro = (e & 3) + 8 * (e >> 2);
-                if (i0 + 4 * h + ro < g.M) op[(size_t)ro * g.C] = a[e] * st_act_bwd(sv[e], g.src_act);
-            }
-        } else {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int ro = (e & 3) + 8 * (e >> 2);
-                if (i0 + 4 * h + ro < g.M) op[(size_t)ro * g.C] = a[e];
             }
         }
     }
@@ -422,25 +441,31 @@ static int launch_wgrad(const WgArgs& a, hipStream_t stream) {
 
 static bool stream_enabled() { return getenv("FAIRREC_LINEAR_NO_STREAM") == nullptr; }
 
-template <bool B_T, int CT>
-static int launch_stream_ct(const StArgs& a, hipStream_t stream, int kind) {
-    const size_t ldsb = ((size_t)(a.R / 32) * CT * 1024 + (size_t)ST_SLOTS * 2048) * sizeof(float);
-    const int ntiles = (a.M + 63) / 64;
+template <bool B_T, int CT, int ST_RB, int RPW, bool SRC>
+static int launch_stream_ct(StArgs a, hipStream_t stream, int kind) {
+    // as many ring slots as the 160 KB of LDS leave beside the weight image (with a margin), at most 8
+    const size_t wbytes = (size_t)(a.R / 32) * CT * 4096, slot = (size_t)ST_RB * 4096;
+    int slots = (int)((152 * 1024 - wbytes) / slot);
+    a.slots = slots > 8 ? 8 : slots;
+    const size_t ldsb = wbytes + (size_t)a.slots * slot;
+    const int ntiles = (a.M + 32 * ST_RB - 1) / (32 * ST_RB);
     const int blocks = ntiles < 256 ? ntiles : 256;      // one persistent workgroup per CU
     static size_t have = 0;
     if (ldsb > have) {
-        FR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(linear_stream_kernel<B_T, CT>),
+        FR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(linear_stream_kernel<B_T, CT, ST_RB, RPW, SRC>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
         have = ldsb;
     }
     ProfScope prof((KernelKind)kind, stream);
-    FR_LAUNCH(prof, (linear_stream_kernel<B_T, CT>), dim3((unsigned)blocks), dim3((2 * CT + ST_LOADERS) * 64), ldsb, stream, a);
+    FR_LAUNCH(prof, (linear_stream_kernel<B_T, CT, ST_RB, RPW, SRC>), dim3((unsigned)blocks), dim3((ST_RB / RPW * CT + ST_LOADERS) * 64), ldsb, stream, a);
     FR_CHECK_LAUNCH();
     return FR_OK;
 }
 template <bool B_T>
 static int launch_stream(const StArgs& a, hipStream_t stream, int kind) {
-    return a.C == 128 ? launch_stream_ct<B_T, 4>(a, stream, kind) : launch_stream_ct<B_T, 2>(a, stream, kind);
+    if (B_T && a.src)
+        return a.C == 128 ? launch_stream_ct<B_T, 4, 2, 1, true>(a, stream, kind) : launch_stream_ct<B_T, 2, 4, 1, true>(a, stream, kind);
+    return a.C == 128 ? launch_stream_ct<B_T, 4, 4, 2, false>(a, stream, kind) : launch_stream_ct<B_T, 2, 4, 1, false>(a, stream, kind);
 }
 
 static bool stream_shape(int64_t M, int R, int C) {
@@ -451,7 +476,7 @@ static bool stream_shape(int64_t M, int R, int C) {
 bool stream_linear_fwd(const float* X, const float* W, const float* bias, int64_t M, int N, int K, int act, float* Y,
                        hipStream_t stream, int* rc) {
     if (!stream_shape(M, K, N)) return false;
-    StArgs a{X, W, K, (int)M, K, N, K / 32 / glds_pick_ks((long long)((M + 31) / 32) * (N / 32), K / 32), bias, act, Y, nullptr, 0};
+    StArgs a{X, W, K, (int)M, K, N, K / 32 / glds_pick_ks((long long)((M + 31) / 32) * (N / 32), K / 32), 0, bias, act, Y, nullptr, 0};
     *rc = launch_stream<false>(a, stream, K_LINEAR_FWD);
     return true;
 }
@@ -460,7 +485,7 @@ bool stream_linear_fwd(const float* X, const float* W, const float* bias, int64_
 bool stream_linear_bwd_input(const float* dY, const float* W, int64_t M, int N, int K, float* dX, const float* src, int src_act,
                              hipStream_t stream, int* rc) {
     if (!stream_shape(M, N, K)) return false;
-    StArgs a{dY, W, K, (int)M, N, K, N / 32 / glds_pick_ks((long long)((M + 31) / 32) * (K / 32), N / 32), nullptr, 0, dX, src, src_act};
+    StArgs a{dY, W, K, (int)M, N, K, N / 32 / glds_pick_ks((long long)((M + 31) / 32) * (K / 32), N / 32), 0, nullptr, 0, dX, src, src_act};
     *rc = launch_stream<true>(a, stream, K_LINEAR_BWD_INPUT);
     return true;
 }
