@@ -804,11 +804,6 @@ typedef struct fr_dense_desc {
     const int32_t* step_dev;   /* optional device counter, as fr_table.step_dev: effective step = *step_dev + step */
 } fr_dense_desc;
 FR_API int fr_adam_dense_multi(const fr_dense_desc* descs, int32_t n_tensors, const fr_adam* adam, void* stream);
-/* ... as the LAST launch of an optimizer step whose step counters live on the device (fr_table.step_dev / fr_dense_desc.step_dev:
- * a step captured in a hipGraph): counters[k] += inc[k] for k < n_counters once every workgroup of the launch is through, instead
- * of a launch of its own behind it.  ticket: a zero-initialised device word (zero again when the launch ends). */
-FR_API int fr_adam_dense_multi_bump(const fr_dense_desc* descs, int32_t n_tensors, const fr_adam* adam, int32_t* counters,
-                                    const int32_t* inc, int32_t n_counters, uint32_t* ticket, void* stream);
 
 /* ---- negative sampler (next-row f-1: the batch feed), bit-exact with the reference's host sampler ---------------
  * state: numpy's legacy RandomState layout in device memory, uint32 key[624] followed by uint32 pos (625 words), so the

@@ -78,16 +78,7 @@ struct DenseBatch {
     fr_dense_desc t[FR_ADAM_DENSE_MAX];
 };
 
-// `bump`: the step counters of the optimizer step this launch ends (graph mode: one device int32 per table / tensor) move on here
-// -- counters[k] += inc[k] by the workgroup that finishes LAST (every workgroup of this launch has read its counter by then, and
-// every earlier launch of the step is over) -- instead of by a launch of their own behind it.
-struct DenseBump {
-    int32_t* counters;
-    const int32_t* inc;
-    int n;
-    unsigned* ticket;      // zero between launches
-};
-__global__ __launch_bounds__(256) void adam_dense_multi_kernel(DenseBatch b, AdamC c, DenseBump bump) {
+__global__ __launch_bounds__(256) void adam_dense_multi_kernel(DenseBatch b, AdamC c) {
     const fr_dense_desc& d = b.t[blockIdx.y];
     const float2 s = step_scalars(c, d.step + (d.step_dev ? *d.step_dev : 0));
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < d.n; i += (long long)gridDim.x * 256) {
@@ -95,17 +86,6 @@ __global__ __launch_bounds__(256) void adam_dense_multi_kernel(DenseBatch b, Ada
         adam_elem(pp, mm, vv, d.g[i], s.x, s.y, c);
         d.p[i] = pp; d.m[i] = mm; d.v[i] = vv;
     }
-    if (!bump.counters) return;
-    __shared__ int last;
-    __syncthreads();                 // (the counter read above is complete in every thread: its value was used)
-    if (threadIdx.x == 0) {
-        const unsigned t = __hip_atomic_fetch_add(bump.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        last = t == gridDim.x * gridDim.y - 1;
-        if (last) __hip_atomic_store(bump.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();
-    if (last)
-        for (int k = threadIdx.x; k < bump.n; k += 256) bump.counters[k] += bump.inc[k];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -278,18 +258,7 @@ extern "C" int fr_adam_dense(float* p, const float* g, float* m, float* v, int64
     return FR_OK;
 }
 
-static int adam_dense_multi_impl(const fr_dense_desc* descs, int32_t n_tensors, const fr_adam* adam, const DenseBump& bump,
-                                 void* stream_);
 extern "C" int fr_adam_dense_multi(const fr_dense_desc* descs, int32_t n_tensors, const fr_adam* adam, void* stream_) {
-    return adam_dense_multi_impl(descs, n_tensors, adam, DenseBump{nullptr, nullptr, 0, nullptr}, stream_);
-}
-extern "C" int fr_adam_dense_multi_bump(const fr_dense_desc* descs, int32_t n_tensors, const fr_adam* adam, int32_t* counters,
-                                        const int32_t* inc, int32_t n_counters, uint32_t* ticket, void* stream_) {
-    FR_CHECK_ARG(counters && inc && ticket && n_counters >= 1 && n_tensors >= 1, "fr_adam_dense_multi_bump: bad argument");
-    return adam_dense_multi_impl(descs, n_tensors, adam, DenseBump{counters, inc, n_counters, ticket}, stream_);
-}
-static int adam_dense_multi_impl(const fr_dense_desc* descs, int32_t n_tensors, const fr_adam* adam, const DenseBump& bump,
-                                 void* stream_) {
     int rc;
     if ((rc = check_adam(adam, "fr_adam_dense_multi"))) return rc;
     FR_CHECK_ARG(descs && n_tensors >= 0, "fr_adam_dense_multi: bad argument");
@@ -307,10 +276,8 @@ static int adam_dense_multi_impl(const fr_dense_desc* descs, int32_t n_tensors, 
         for (int k = cnt; k < FR_ADAM_DENSE_MAX; ++k) b.t[k] = fr_dense_desc{nullptr, nullptr, nullptr, nullptr, 0, 1, nullptr};
         const long long blocks = std::min<long long>((nmax + 255) / 256, 256);
         ProfScope prof(K_ADAM_DENSE, (hipStream_t)stream_);
-        // (the counters move with the LAST launch of the call)
-        const DenseBump u = base + FR_ADAM_DENSE_MAX >= n_tensors ? bump : DenseBump{nullptr, nullptr, 0, nullptr};
         FR_LAUNCH(prof, adam_dense_multi_kernel, dim3((unsigned)blocks, (unsigned)cnt), dim3(256), 0, (hipStream_t)stream_, b,
-                  c, u);
+                  c);
         FR_CHECK_LAUNCH();
     }
     return FR_OK;

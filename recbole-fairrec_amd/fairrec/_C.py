@@ -150,8 +150,6 @@ _PROTOS = {
     "fr_fair_metrics_workspace_bytes": (c_size_t, [c_int64]),
     "fr_fair_metrics_from_stats": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_size_t, c_void_p]),
     "fr_adam_dense_multi": (c_int, [POINTER(FrDenseDesc), c_int32, POINTER(FrAdam), c_void_p]),
-    "fr_adam_dense_multi_bump": (c_int, [POINTER(FrDenseDesc), c_int32, POINTER(FrAdam), c_void_p, c_void_p, c_int32, c_void_p,
-                                         c_void_p]),
     "fr_sample_negatives_calls": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p,
                                           c_int64, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
     "fr_unbucket_rows": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p]),

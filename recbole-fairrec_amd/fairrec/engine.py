@@ -78,26 +78,18 @@ class GenericEngine:
             else:
                 self._dense[name].step = host[k]
 
-    def _advance_vector(self, names):
-        """The 0/1 vector over all counters for the entries stepped in this optimizer step (cached per set, so that nothing is
-        uploaded inside a captured step); None outside graph mode."""
+    def _advance(self, names):
+        """counter += 1 for the entries stepped in this optimizer step (one launch; the index tensor is cached per set
+        so that nothing is uploaded inside a captured step)."""
         if self._counters is None or not names:
-            return None
+            return
         key = tuple(sorted(self._counter_slot[n] for n in names))
         inc = self._advance_idx.get(key)
-        if inc is None:
+        if inc is None:     # a 0/1 vector over all counters: one add, no fill and no index launch
             inc = torch.zeros(self._counters.numel(), dtype=torch.int32)
             inc[list(key)] = 1
             inc = self._advance_idx[key] = inc.to(self.device)
-        if getattr(self, "_bump_ticket", None) is None:
-            self._bump_ticket = torch.zeros(1, dtype=torch.int32, device=self.device)
-        return inc
-
-    def _advance(self, names):
-        """counter += 1 for the entries stepped in this optimizer step: one add, no fill and no index launch."""
-        inc = self._advance_vector(names)
-        if inc is not None:
-            self._counters += inc
+        self._counters += inc
 
     # --- registration ---------------------------------------------------------------------------------
     def add_table(self, name: str, weight: torch.nn.Parameter, trainable: bool = True, group=None) -> LazyTable:
@@ -274,12 +266,7 @@ class GenericEngine:
             h.check_step(d.step)
             by_hyper.setdefault(id(h), (h, []))[1].append((d, g.contiguous()))
             stepped.append(name)
-        # graph mode: the step counters move with the LAST dense launch of the step (fr_adam_dense_multi_bump) instead of by a
-        # launch of their own behind it; without a dense launch, `_advance`'s add
-        bump = self._advance_vector(stepped) if by_hyper and os.environ.get("FAIRREC_ADVANCE_SEPARATE") is None else None
-        n_launch = len(by_hyper)
         for h, items in by_hyper.values():
-            n_launch -= 1
             descs = (_C.FrDenseDesc * len(items))()
             for k, (d, g) in enumerate(items):
                 if d.step_dev is not None:      # effective step = device counter + 1
@@ -288,16 +275,10 @@ class GenericEngine:
                 else:
                     descs[k] = _C.FrDenseDesc(d.p.data.data_ptr(), g.data_ptr(), d.m.data_ptr(), d.v.data_ptr(),
                                               d.p.numel(), d.step, None)
-            if bump is not None and n_launch == 0:
-                _C.check(_C.lib().fr_adam_dense_multi_bump(descs, len(items), ctypes.byref(h.c()), self._counters.data_ptr(),
-                                                           bump.data_ptr(), bump.numel(), self._bump_ticket.data_ptr(), st),
-                         "fr_adam_dense_multi_bump")
-            else:
-                _C.check(_C.lib().fr_adam_dense_multi(descs, len(items), ctypes.byref(h.c()), st), "fr_adam_dense_multi")
+            _C.check(_C.lib().fr_adam_dense_multi(descs, len(items), ctypes.byref(h.c()), st), "fr_adam_dense_multi")
             for d, _ in items:
                 d.p.grad = None
-        if bump is None:
-            self._advance(stepped)
+        self._advance(stepped)
 
     def flush(self):
         for name, t in self._tables.items():
