@@ -15,7 +15,7 @@
 //
 // Same sums in the same order as the macro-tile kernels (chunks ascending, even / odd reduction steps in two accumulators, one
 // part): bit-identical outputs (tests/test_mlp_hip.py).  Shapes: output width 64 or 128, reduction length a multiple of 32 up to
-// 128, M >= 16384; everything else stays with mlp_glds.hip.
+// 128, M >= 32768 (the weight gradient: 65536); everything else stays with mlp_glds.hip.
 #include <stdlib.h>
 
 #include "common.hpp"
@@ -469,7 +469,8 @@ static int launch_stream(const StArgs& a, hipStream_t stream, int kind) {
 }
 
 static bool stream_shape(int64_t M, int R, int C) {
-    return stream_enabled() && M >= 16384 && M <= 0x7fffffffLL / 128 && R % 32 == 0 && R >= 32 && R <= 128 && (C == 64 || C == 128);
+    // (measured against the macro-tile kernels, profiles/r05_stream_gemm.txt: 0.8 x at 16 K rows -- half the CUs idle --, 1.2-1.4 x from 32 K)
+    return stream_enabled() && M >= 32768 && M <= 0x7fffffffLL / 128 && R % 32 == 0 && R >= 32 && R <= 128 && (C == 64 || C == 128);
 }
 
 // Y = act(X W^T + b) for one row-major X [M, K]; FR_EUNSUPPORTED-style `false` when the shape is not this kernel's
@@ -496,7 +497,8 @@ namespace fr {
 // slab[s] = dY[rows of s]^T X[rows of s] (+ bslab) for one row-major X [M, K]: the splits of glds_linear_bwd_weight, its slabs
 bool stream_linear_bwd_weight(const float* dY, const float* X, int64_t M, int N, int K, int splits, int rows_per_split, float* slab,
                               float* bslab, hipStream_t stream, int* rc) {
-    if (!stream_enabled() || M < 16384 || M > 0x7fffffffLL / 128 || rows_per_split % 32 != 0 || (N != 64 && N != 128) || (K != 64 && K != 128))
+    // (0.8 x the macro-tile kernel at 16-32 K rows, 1.0-1.1 x from 64 K, 1.3 x at 11 M)
+    if (!stream_enabled() || M < 65536 || M > 0x7fffffffLL / 128 || rows_per_split % 32 != 0 || (N != 64 && N != 128) || (K != 64 && K != 128))
         return false;
     WgArgs a{dY, X, (int)M, N, K, splits, rows_per_split / 32, slab, bslab};
     if (N == 128 && K == 128) *rc = launch_wgrad<4, 4>(a, stream);

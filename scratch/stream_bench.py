@@ -4,8 +4,10 @@ import torch
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "recbole-fairrec_amd"))
 from fairrec import _C
 lib = _C.lib()
+REPS = int(os.environ.get("REPS", 10))
 st = _C.current_stream()
-for (M, K, N) in ((1800000, 128, 128), (1800000, 128, 64), (1800000, 64, 128), (11000000, 128, 128)):
+SHAPES = [tuple(int(v) for v in t.split("x")) for t in os.environ.get("SHAPES", "1800000x128x128,1800000x128x64,1800000x64x128,11000000x128x128").split(",")]
+for (M, K, N) in SHAPES:
     X = torch.randn(M, K, device="cuda"); W = torch.randn(N, K, device="cuda"); b = torch.randn(N, device="cuda")
     Y = torch.empty(M, N, device="cuda"); dX = torch.empty(M, K, device="cuda")
     for form in ("stream", "tiles"):
@@ -22,11 +24,11 @@ for (M, K, N) in ((1800000, 128, 128), (1800000, 128, 64), (1800000, 64, 128), (
                 call()
             a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
-            for _ in range(10):
+            for _ in range(REPS):
                 call()
             e.record()
             torch.cuda.synchronize()
-            ms = a.elapsed_time(e) / 10
+            ms = a.elapsed_time(e) / REPS
             print("M=%9d K=%3d N=%3d %-7s %-9s %7.3f ms  %6.1f TFLOP/s  %6.2f TB/s (in + out once)" %
                   (M, K, N, form, name, ms, 2.0 * M * N * K / ms / 1e9, (M * (K + N) * 4) / ms / 1e9), flush=True)
     del X, Y, dX

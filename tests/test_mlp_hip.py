@@ -591,7 +591,7 @@ def test_bn_chain_matches_torch_in_float64(widths, act, M, monkeypatch):
                                    msg=lambda m: f"{n}: {m}")
 
 
-@pytest.mark.parametrize("M,K,N", [(20000, 128, 128), (16384, 128, 64), (33333, 64, 128), (50001, 96, 128), (70000, 32, 64)])
+@pytest.mark.parametrize("M,K,N", [(40000, 128, 128), (32768, 128, 64), (33333, 64, 128), (50001, 96, 128), (70000, 32, 64)])
 def test_streaming_products_are_bit_identical_to_the_macro_tile_kernels(M, K, N, monkeypatch):
     """csrc/mlp_stream.hip (many rows, 64 / 128 output columns: persistent workgroups, weights resident in LDS, the input rows
     streamed once by loader waves) against the macro-tile kernels (FAIRREC_LINEAR_NO_STREAM=1): the forward product with every
@@ -630,7 +630,7 @@ def test_streaming_products_are_bit_identical_to_the_macro_tile_kernels(M, K, N,
     torch.testing.assert_close(outs["stream"][0].double(), ref, rtol=1e-4, atol=1e-4)
 
 
-@pytest.mark.parametrize("M,N,K", [(20000, 128, 128), (16384, 128, 64), (33333, 64, 128), (50001, 64, 64), (300000, 128, 128)])
+@pytest.mark.parametrize("M,N,K", [(70000, 128, 128), (65536, 128, 64), (100001, 64, 128), (66001, 64, 64), (300000, 128, 128)])
 def test_streaming_weight_gradient_is_bit_identical_to_the_macro_tile_kernel(M, N, K, monkeypatch):
     """csrc/mlp_stream.hip's weight gradient (one workgroup per row split forms ALL of dY^T X: both operands read once) against
     the macro-tile kernel (FAIRREC_LINEAR_NO_STREAM=1): the same splits, the same slabs, so dW and db bit for bit."""
