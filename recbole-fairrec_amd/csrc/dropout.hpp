@@ -30,17 +30,19 @@ __device__ __forceinline__ float4 drop_keep4(unsigned long long seed, unsigned l
 // that thread then draws a ticket whose increment depends on the loaded value (so the load has completed), and the holder of
 // the last ticket -- every workgroup has read the counter by then -- advances it and resets the tickets.  Called by all
 // threads of a 1-D launch; `sh` is one shared word.  Returns the counter value of this launch.
+// (`first`, `nblocks`: which workgroup records `used_out` and how many take a ticket -- a 1-D launch by default)
 __device__ __forceinline__ unsigned long long drop_counter_enter(const unsigned long long* __restrict__ ctr_src,
                                                                  unsigned long long* __restrict__ used_out,
                                                                  unsigned long long* __restrict__ tick,
-                                                                 unsigned long long* sh) {
+                                                                 unsigned long long* sh, const bool first = blockIdx.x == 0,
+                                                                 const unsigned nblocks = gridDim.x) {
     if (threadIdx.x == 0) {
         const unsigned long long c = __hip_atomic_load(ctr_src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         *sh = c;
-        if (used_out && blockIdx.x == 0) *used_out = c;
+        if (used_out && first) *used_out = c;
         if (tick) {
             const unsigned long long t = atomicAdd(&tick[1], 1ull + (c >> 63));
-            if (t == gridDim.x - 1) {
+            if (t == nblocks - 1) {
                 tick[1] = 0ull;
                 tick[0] = c + 1ull;
             }

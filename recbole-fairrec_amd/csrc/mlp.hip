@@ -982,6 +982,189 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(const float* _
     }
 }
 
+// ---- the fold INSIDE the apply launch ------------------------------------------------------------------------------------------
+// A fold launch is 5-8 us of latency for 64 KB of partials per block of 64 columns, and the apply launch behind it cannot start
+// before it ends.  Here every apply workgroup -- 64 columns x a band of rows -- folds its own columns first (the chunk partials of a
+// quarter requested at once: one memory latency; the same chains as the fold kernels, so the same bits) and goes straight on to
+// its rows; the band is tall enough (>= 128 rows at [8192, 256]) that the partials are re-read by ~64 workgroups per column
+// block out of L2, 32 MB per launch.  The workgroups of the first band write what the fold kernel wrote (invstd, running
+// statistics, batch counter; dgamma / dbeta).  One launch per BatchNorm operator less, forward and backward.
+__device__ __forceinline__ float2 bn_fold_stats_inline(const float* __restrict__ part, int chunks, int M, int N, int rc, int n,
+                                                       float (*sh)[64]) {      // (mean, M2) of column n, valid in every wave
+    constexpr int QMAX = 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = (chunks + BN_WAVES - 1) / BN_WAVES, c0 = wave * q, c1 = min(chunks, c0 + q);
+    const int nn = n < N ? n : N - 1;
+    float s = 0.f, m2 = 0.f, mean;
+    if (q <= QMAX) {
+        float2 pv[QMAX];
+#pragma unroll
+        for (int k = 0; k < QMAX; ++k)
+            if (c0 + k < c1) pv[k] = reinterpret_cast<const float2*>(part)[(size_t)(c0 + k) * N + nn];
+#pragma unroll
+        for (int k = 0; k < QMAX; ++k)
+            if (c0 + k < c1) s = fmaf((float)(min(M, (c0 + k + 1) * rc) - (c0 + k) * rc), pv[k].x, s);
+        sh[wave][lane] = s;
+        __syncthreads();
+        mean = (((sh[0][lane] + sh[1][lane]) + sh[2][lane]) + sh[3][lane]) / (float)M;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < QMAX; ++k)
+            if (c0 + k < c1) {
+                const float nb = (float)(min(M, (c0 + k + 1) * rc) - (c0 + k) * rc);
+                const float d = pv[k].x - mean;
+                m2 += fmaf(nb * d, d, pv[k].y);
+            }
+    } else {
+#pragma unroll 8
+        for (int c = c0; c < c1; ++c) s = fmaf((float)(min(M, (c + 1) * rc) - c * rc), part[((size_t)c * N + nn) * 2], s);
+        sh[wave][lane] = s;
+        __syncthreads();
+        mean = (((sh[0][lane] + sh[1][lane]) + sh[2][lane]) + sh[3][lane]) / (float)M;
+        __syncthreads();
+#pragma unroll 8
+        for (int c = c0; c < c1; ++c) {
+            const float nb = (float)(min(M, (c + 1) * rc) - c * rc);
+            const float2 p = reinterpret_cast<const float2*>(part)[(size_t)c * N + nn];
+            const float d = p.x - mean;
+            m2 += fmaf(nb * d, d, p.y);
+        }
+    }
+    sh[wave][lane] = m2;
+    __syncthreads();
+    m2 = ((sh[0][lane] + sh[1][lane]) + sh[2][lane]) + sh[3][lane];
+    __syncthreads();
+    return make_float2(mean, m2);
+}
+
+template <bool DROP>
+__global__ __launch_bounds__(BN_THREADS) void bn_fwd_apply_fold_kernel(
+    const float* __restrict__ Z, const float* __restrict__ part, int chunks, int M, int N, int rc, float eps, float momentum,
+    float* __restrict__ rmean, float* __restrict__ rvar, float* __restrict__ invstd_out, long long* __restrict__ nbt, int nbt_inc,
+    const float* __restrict__ gamma, const float* __restrict__ beta, int act, float* __restrict__ Y, float* __restrict__ xhat,
+    int band, float* __restrict__ Yd, unsigned thr, float scale, unsigned long long seed, unsigned long long off4,
+    const unsigned long long* __restrict__ ctr_src, unsigned long long* __restrict__ used_out, unsigned long long* __restrict__ tick) {
+    __shared__ float sh[BN_WAVES][64];
+    __shared__ float4 cst[64];          // (mean, invstd, gamma, beta) of the block's columns
+    __shared__ unsigned long long ctr_s;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + lane;
+    unsigned long long ctr = 0;
+    if (DROP) ctr = drop_counter_enter(ctr_src, used_out, tick, &ctr_s, blockIdx.x == 0 && blockIdx.y == 0, gridDim.x * gridDim.y);
+    const float2 st = bn_fold_stats_inline(part, chunks, M, N, rc, n, sh);
+    const float var = st.y / (float)M;
+    const float invstd = 1.f / sqrtf(var + eps);
+    if (wave == 0) {
+        cst[lane] = n < N ? make_float4(st.x, invstd, gamma[n], beta[n]) : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (blockIdx.y == 0 && n < N) {     // what bn_fwd_fold_kernel leaves behind, once per column
+            invstd_out[n] = invstd;
+            if (rmean) {
+                rmean[n] = bn_running(rmean[n], momentum, st.x);
+                rvar[n] = bn_running(rvar[n], momentum, M > 1 ? st.y / (float)(M - 1) : var);
+            }
+        }
+        if (nbt && blockIdx.x == 0 && blockIdx.y == 0 && lane == 0) *nbt += nbt_inc;
+    }
+    __syncthreads();
+    const int m0 = blockIdx.y * band, m1 = min(M, m0 + band);
+    if (!DROP) {
+        if (n >= N) return;
+        const float4 c = cst[lane];
+#pragma unroll 8
+        for (int m = m0 + wave; m < m1; m += BN_WAVES) {
+            const float xh = (Z[(size_t)m * N + n] - c.x) * c.y;
+            xhat[(size_t)m * N + n] = xh;
+            Y[(size_t)m * N + n] = act_fwd(fmaf(c.z, xh, c.w), act);
+        }
+    } else {
+        // four neighbouring columns per thread (one Philox call, bn_fwd_apply_drop_kernel's groups: element offset / 4)
+        const int N4 = N >> 2, c4l = threadIdx.x & 15, c4 = blockIdx.x * 16 + c4l;
+        if (c4 >= N4) return;
+        const float4 k0 = cst[4 * c4l], k1 = cst[4 * c4l + 1], k2 = cst[4 * c4l + 2], k3 = cst[4 * c4l + 3];
+#pragma unroll 4
+        for (int m = m0 + (threadIdx.x >> 4); m < m1; m += BN_THREADS / 16) {
+            const long long qd = (long long)m * N4 + c4;
+            const float4 z = reinterpret_cast<const float4*>(Z)[qd];
+            const float4 xh = make_float4((z.x - k0.x) * k0.y, (z.y - k1.x) * k1.y, (z.z - k2.x) * k2.y, (z.w - k3.x) * k3.y);
+            const float4 y = make_float4(act_fwd(fmaf(k0.z, xh.x, k0.w), act), act_fwd(fmaf(k1.z, xh.y, k1.w), act),
+                                         act_fwd(fmaf(k2.z, xh.z, k2.w), act), act_fwd(fmaf(k3.z, xh.w, k3.w), act));
+            const float4 k = drop_keep4(seed, ctr, off4 + (unsigned long long)qd, thr, scale);
+            reinterpret_cast<float4*>(xhat)[qd] = xh;
+            reinterpret_cast<float4*>(Y)[qd] = y;
+            reinterpret_cast<float4*>(Yd)[qd] = make_float4(y.x * k.x, y.y * k.y, y.z * k.z, y.w * k.w);
+        }
+    }
+}
+
+__global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_fold_kernel(const float* __restrict__ dY, const float* __restrict__ Y,
+                                                                       int act, const float* __restrict__ xhat,
+                                                                       const float* __restrict__ invstd,
+                                                                       const float* __restrict__ gamma,
+                                                                       const float* __restrict__ part, int chunks, int M, int N,
+                                                                       int band, float* __restrict__ dgamma,
+                                                                       float* __restrict__ dbeta, float* __restrict__ dZ) {
+    __shared__ float sh[BN_WAVES][2][64];
+    __shared__ float2 tot[64];
+    constexpr int QMAX = 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + lane, nn = n < N ? n : N - 1;
+    const int q = (chunks + BN_WAVES - 1) / BN_WAVES, c0 = wave * q, c1 = min(chunks, c0 + q);
+    float sum_da = 0.f, sum_dax = 0.f;
+    if (q <= QMAX) {       // bn_bwd_fold_kernel's chains
+        float2 pv[QMAX];
+#pragma unroll
+        for (int k = 0; k < QMAX; ++k)
+            if (c0 + k < c1) pv[k] = reinterpret_cast<const float2*>(part)[(size_t)(c0 + k) * N + nn];
+#pragma unroll
+        for (int k = 0; k < QMAX; ++k)
+            if (c0 + k < c1) {
+                sum_da += pv[k].x;
+                sum_dax += pv[k].y;
+            }
+    } else {
+#pragma unroll 8
+        for (int c = c0; c < c1; ++c) {
+            const float2 p = reinterpret_cast<const float2*>(part)[(size_t)c * N + nn];
+            sum_da += p.x;
+            sum_dax += p.y;
+        }
+    }
+    sh[wave][0][lane] = sum_da;
+    sh[wave][1][lane] = sum_dax;
+    __syncthreads();
+    if (wave == 0) {
+        for (int w = 1; w < BN_WAVES; ++w) {
+            sum_da += sh[w][0][lane];
+            sum_dax += sh[w][1][lane];
+        }
+        tot[lane] = make_float2(sum_da, sum_dax);
+        if (blockIdx.y == 0 && n < N) {
+            dgamma[n] = sum_dax;
+            dbeta[n] = sum_da;
+        }
+    }
+    __syncthreads();
+    if (n >= N) return;
+    const float2 t = tot[lane];
+    const float isg = __fmul_rn(invstd[n], gamma[n]);
+    const float a1 = t.x / (float)M, a2 = t.y / (float)M;
+    const int m0 = blockIdx.y * band, m1 = min(M, m0 + band);
+#pragma unroll 8
+    for (int m = m0 + wave; m < m1; m += BN_WAVES) {
+        const size_t i = (size_t)m * N + n;
+        dZ[i] = bn_bwd_dz(dY[i], act_bwd(Y[i], act), xhat[i], a1, a2, isg);
+    }
+}
+
+// rows of an apply workgroup's band: ~256 workgroups per launch, never less than a statistics chunk
+static inline int bn_apply_band(int64_t M, int32_t N, int rc) {
+    const long long cols = (N + 63) / 64;
+    long long bands = std::max<long long>(1, 256 / cols);
+    long long band = (M + bands - 1) / bands;
+    band = std::max<long long>(band, rc);
+    return (int)((band + 3) / 4 * 4);
+}
+
 }  // namespace fr
 
 extern "C" size_t fr_bn_workspace_bytes(int64_t M, int32_t N) {
@@ -1032,6 +1215,22 @@ static int bn_fwd_impl(const float* Z, const float* gamma, const float* beta, fl
         FR_CHECK_LAUNCH();
     }
     float* fin = (float*)ws + (size_t)grid.y * N * 2;
+    if (getenv("FAIRREC_BN_FOLD_SEPARATE") == nullptr) {      // the fold inside the apply launch (one launch less)
+        const int band = bn_apply_band(M, N, rc);
+        const dim3 g2(grid.x, (unsigned)((M + band - 1) / band));
+        if (Yd)
+            FR_LAUNCH(prof, bn_fwd_apply_fold_kernel<true>, g2, dim3(BN_THREADS), 0, stream, Z, (const float*)ws, (int)grid.y, (int)M,
+                      (int)N, rc, eps, momentum, running_mean, running_var, invstd, (long long*)nbt, (int)nbt_inc, gamma, beta, (int)act,
+                      Y, xhat, band, Yd, drop_threshold(p), 1.f / (1.f - p), (unsigned long long)seed, (unsigned long long)(offset / 4),
+                      (const unsigned long long*)counter, (unsigned long long*)used_out, (unsigned long long*)tick_state);
+        else
+            FR_LAUNCH(prof, bn_fwd_apply_fold_kernel<false>, g2, dim3(BN_THREADS), 0, stream, Z, (const float*)ws, (int)grid.y, (int)M,
+                      (int)N, rc, eps, momentum, running_mean, running_var, invstd, (long long*)nbt, (int)nbt_inc, gamma, beta, (int)act,
+                      Y, xhat, band, (float*)nullptr, 0u, 1.f, 0ull, 0ull, (const unsigned long long*)nullptr,
+                      (unsigned long long*)nullptr, (unsigned long long*)nullptr);
+        FR_CHECK_LAUNCH();
+        return FR_OK;
+    }
     FR_LAUNCH(prof, bn_fwd_fold_kernel, dim3(grid.x), dim3(BN_THREADS), 0, stream, (const float*)ws, (int)grid.y, (int)M, (int)N, rc, eps,
               momentum, running_mean, running_var, fin, invstd, (long long*)nbt, (int)nbt_inc);
     FR_CHECK_LAUNCH();
@@ -1096,6 +1295,13 @@ extern "C" int fr_bn_bwd(const float* dY, const float* Y, int32_t act, const flo
     FR_LAUNCH(prof, bn_bwd_stats_kernel, grid, dim3(BN_THREADS), 0, stream, dY, Y, (int)act, xhat, (int)M, (int)N, rc,
               (float*)ws);
     FR_CHECK_LAUNCH();
+    if (getenv("FAIRREC_BN_FOLD_SEPARATE") == nullptr) {
+        const int band = bn_apply_band(M, N, rc);
+        FR_LAUNCH(prof, bn_bwd_apply_fold_kernel, dim3(grid.x, (unsigned)((M + band - 1) / band)), dim3(BN_THREADS), 0, stream, dY, Y,
+                  (int)act, xhat, invstd, gamma, (const float*)ws, (int)grid.y, (int)M, (int)N, band, dgamma, dbeta, dZ);
+        FR_CHECK_LAUNCH();
+        return FR_OK;
+    }
     float* fin = (float*)ws + (size_t)grid.y * N * 2;
     FR_LAUNCH(prof, bn_bwd_fold_kernel, dim3(grid.x), dim3(BN_THREADS), 0, stream, (const float*)ws, (int)grid.y, (int)N, fin, dgamma,
               dbeta);
