@@ -133,13 +133,12 @@ __global__ __launch_bounds__(256) void spmm_csr_sel_kernel(const long long* __re
 // 0 .. 8), looks the columns up 64 at a time and, for the rare hit, finds its row among the boundaries; a row's terms are
 // still added in CSR order into one accumulator that is stored when the run moves on to the next row (rows without a hit
 // are stored as zeros): the same bits as the kernel above.
-template <int V>
+template <int V, int R>
 __global__ __launch_bounds__(256) void spmm_csr_sel_runs_kernel(const long long* __restrict__ indptr, const int* __restrict__ col,
                                                                 const float* __restrict__ val, const float* __restrict__ X,
                                                                 long long n_out, const int* __restrict__ map,
                                                                 const unsigned* __restrict__ bits, int D,
                                                                 float* __restrict__ Y) {
-    constexpr int R = 8;
     typedef float vec __attribute__((ext_vector_type(V)));
     const int lane = threadIdx.x & 63;
     const long long r0 = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
@@ -316,17 +315,21 @@ extern "C" int fr_spmm_csr_sel(const int64_t* indptr, const int32_t* col, const 
     if (n_out == 0) return FR_OK;
     ProfScope prof(K_SPMM, stream);
     if (!rows && map && n_out >= 1024 && (dim == 64 || dim == 128 || dim == 256) && !getenv("FAIRREC_SPMM_SEL_ROWWISE")) {
-        const dim3 g8((unsigned)((n_out + 31) / 32));      // 4 waves x 8 rows per workgroup
-        if (dim == 64) {
-            FR_LAUNCH(prof, spmm_csr_sel_runs_kernel<1>, g8, dim3(256), 0, stream, (const long long*)indptr, col, val, X,
-                      (long long)n_out, map, bits, (int)dim, Y);
-        } else if (dim == 128) {
-            FR_LAUNCH(prof, spmm_csr_sel_runs_kernel<2>, g8, dim3(256), 0, stream, (const long long*)indptr, col, val, X,
-                      (long long)n_out, map, bits, (int)dim, Y);
-        } else {
-            FR_LAUNCH(prof, spmm_csr_sel_runs_kernel<4>, g8, dim3(256), 0, stream, (const long long*)indptr, col, val, X,
-                      (long long)n_out, map, bits, (int)dim, Y);
-        }
+        // rows per wave (one contiguous run of nonzeros): 8, or FAIRREC_SEL_RUNS_ROWS = 16 / 32 (A/B)
+        const char* e = getenv("FAIRREC_SEL_RUNS_ROWS");
+        const int R = e ? atoi(e) : 8;
+#define FR_SEL_RUNS(V, RR)                                                                                                 \
+    FR_LAUNCH(prof, (spmm_csr_sel_runs_kernel<V, RR>), dim3((unsigned)((n_out + 4 * RR - 1) / (4 * RR))), dim3(256), 0, stream, \
+              (const long long*)indptr, col, val, X, (long long)n_out, map, bits, (int)dim, Y)
+#define FR_SEL_RUNS_V(V)                  \
+    if (R == 32) { FR_SEL_RUNS(V, 32); }  \
+    else if (R == 16) { FR_SEL_RUNS(V, 16); } \
+    else { FR_SEL_RUNS(V, 8); }
+        if (dim == 64) { FR_SEL_RUNS_V(1) }
+        else if (dim == 128) { FR_SEL_RUNS_V(2) }
+        else { FR_SEL_RUNS_V(4) }
+#undef FR_SEL_RUNS_V
+#undef FR_SEL_RUNS
         FR_CHECK_LAUNCH();
         return FR_OK;
     }
