@@ -1070,7 +1070,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_fwd_apply_fold_kernel(
     if (!DROP) {
         if (n >= N) return;
         const float4 c = cst[lane];
-#pragma unroll 8
+#pragma unroll 16
         for (int m = m0 + wave; m < m1; m += BN_WAVES) {
             const float xh = (Z[(size_t)m * N + n] - c.x) * c.y;
             xhat[(size_t)m * N + n] = xh;
@@ -1081,7 +1081,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_fwd_apply_fold_kernel(
         const int N4 = N >> 2, c4l = threadIdx.x & 15, c4 = blockIdx.x * 16 + c4l;
         if (c4 >= N4) return;
         const float4 k0 = cst[4 * c4l], k1 = cst[4 * c4l + 1], k2 = cst[4 * c4l + 2], k3 = cst[4 * c4l + 3];
-#pragma unroll 4
+#pragma unroll 8
         for (int m = m0 + (threadIdx.x >> 4); m < m1; m += BN_THREADS / 16) {
             const long long qd = (long long)m * N4 + c4;
             const float4 z = reinterpret_cast<const float4*>(Z)[qd];
@@ -1149,7 +1149,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_fold_kernel(const flo
     const float isg = __fmul_rn(invstd[n], gamma[n]);
     const float a1 = t.x / (float)M, a2 = t.y / (float)M;
     const int m0 = blockIdx.y * band, m1 = min(M, m0 + band);
-#pragma unroll 8
+#pragma unroll 16
     for (int m = m0 + wave; m < m1; m += BN_WAVES) {
         const size_t i = (size_t)m * N + n;
         dZ[i] = bn_bwd_dz(dY[i], act_bwd(Y[i], act), xhat[i], a1, a2, isg);
@@ -1159,7 +1159,8 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_fold_kernel(const flo
 // rows of an apply workgroup's band: ~256 workgroups per launch, never less than a statistics chunk
 static inline int bn_apply_band(int64_t M, int32_t N, int rc) {
     const long long cols = (N + 63) / 64;
-    long long bands = std::max<long long>(1, 256 / cols);
+    static const long long target = getenv("FAIRREC_BN_APPLY_WGS") ? atoll(getenv("FAIRREC_BN_APPLY_WGS")) : 256;
+    long long bands = std::max<long long>(1, target / cols);
     long long band = (M + bands - 1) / bands;
     band = std::max<long long>(band, rc);
     return (int)((band + 3) / 4 * 4);
