@@ -76,7 +76,7 @@ __device__ __forceinline__ void st_wait_newer(int newer) {
 // at 128 columns: four accumulator chains per wave and the W fragments read once for both -- half the barriers per MFMA)
 // ST_RB: 32-row blocks of a row tile (128 rows, or 64 where the registers of two row blocks per wave do not fit: the input gradient
 // through an activation at 128 columns keeps 32 `src` values per lane in flight)
-template <bool B_T, int CT, int ST_RB, int RPW, bool SRC>
+template <bool B_T, int CT, int ST_RB, int RPW, bool SRC, bool ONEPART>
 __global__ __launch_bounds__((ST_RB / RPW * CT + ST_LOADERS) * 64) void linear_stream_kernel(StArgs g) {
     extern __shared__ __align__(16) float lds[];    // W image [R / 32][CT][1024], then the ring [slots][ST_RB][1024]
     constexpr int NCW = ST_RB / RPW * CT;
@@ -156,9 +156,12 @@ __global__ __launch_bounds__((ST_RB / RPW * CT + ST_LOADERS) * 64) void linear_s
         const int row = 8 * (q >> 2) + 4 * h + (q & 3);
         rtt[q] = row * 128 + ((((r >> 2) ^ ((row >> 1) & 7)) << 4) | ((r & 3) << 2));
     }
-    f32x16 acc[RPW][2], tot[RPW];
+    // (ONEPART: the reduction of a tile is one part -- every shape with >= 2048 output tiles -- and needs no running total)
+    f32x16 acc[RPW][2], tot[ONEPART ? 1 : RPW];
 #pragma unroll
-    for (int p = 0; p < RPW; ++p) acc[p][0] = acc[p][1] = tot[p] = f32x16{0};
+    for (int p = 0; p < RPW; ++p) acc[p][0] = acc[p][1] = f32x16{0};
+#pragma unroll
+    for (int p = 0; p < (ONEPART ? 1 : RPW); ++p) tot[p] = f32x16{0};
     const int col = wj * 32 + r;
     const float bias = (!B_T && g.bias) ? g.bias[col] : 0.f;      // once per wave: a load per tile would be a memory latency per tile
     float sv[SRC ? RPW : 1][16];                                   // the tile's `src` values, requested when the tile begins
@@ -210,11 +213,11 @@ __global__ __launch_bounds__((ST_RB / RPW * CT + ST_LOADERS) * 64) void linear_s
                                                                  acc[p][1], 0, 0, 0);
             }
         slot = slot + 1 == SLOTS ? 0 : slot + 1;
-        if (++in_part == g.cpp) {        // a part of the reduction ends: parts are added in order (the macro-tile kernels' KS split)
+        if (!ONEPART && ++in_part == g.cpp) {        // a part of the reduction ends: parts are added in order (the macro-tile kernels' KS split)
             in_part = 0;
 #pragma unroll
             for (int p = 0; p < RPW; ++p) {
-                tot[p] += acc[p][0] + acc[p][1];
+                tot[ONEPART ? 0 : p] += acc[p][0] + acc[p][1];
                 acc[p][0] = acc[p][1] = f32x16{0};
             }
         }
@@ -226,8 +229,14 @@ __global__ __launch_bounds__((ST_RB / RPW * CT + ST_LOADERS) * 64) void linear_s
 #pragma unroll
         for (int p = 0; p < RPW; ++p) {
             const long long i0 = tile0 + (wr * RPW + p) * 32;
-            const f32x16 a = tot[p];
-            tot[p] = f32x16{0};
+            f32x16 a;
+            if (ONEPART) {
+                a = acc[p][0] + acc[p][1];
+                acc[p][0] = acc[p][1] = f32x16{0};
+            } else {
+                a = tot[ONEPART ? 0 : p];
+                tot[ONEPART ? 0 : p] = f32x16{0};
+            }
             float* op = g.out + (size_t)(i0 + 4 * h) * g.C + col;
             if (!B_T) {
                 if (g.act <= 2) {
@@ -441,7 +450,7 @@ static int launch_wgrad(const WgArgs& a, hipStream_t stream) {
 
 static bool stream_enabled() { return getenv("FAIRREC_LINEAR_NO_STREAM") == nullptr; }
 
-template <bool B_T, int CT, int ST_RB, int RPW, bool SRC>
+template <bool B_T, int CT, int ST_RB, int RPW, bool SRC, bool ONEPART>
 static int launch_stream_ct(StArgs a, hipStream_t stream, int kind) {
     // as many ring slots as the 160 KB of LDS leave beside the weight image (with a margin), at most 8
     const size_t wbytes = (size_t)(a.R / 32) * CT * 4096, slot = (size_t)ST_RB * 4096;
@@ -452,20 +461,27 @@ static int launch_stream_ct(StArgs a, hipStream_t stream, int kind) {
     const int blocks = ntiles < 256 ? ntiles : 256;      // one persistent workgroup per CU
     static size_t have = 0;
     if (ldsb > have) {
-        FR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(linear_stream_kernel<B_T, CT, ST_RB, RPW, SRC>),
+        FR_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(linear_stream_kernel<B_T, CT, ST_RB, RPW, SRC, ONEPART>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb));
         have = ldsb;
     }
     ProfScope prof((KernelKind)kind, stream);
-    FR_LAUNCH(prof, (linear_stream_kernel<B_T, CT, ST_RB, RPW, SRC>), dim3((unsigned)blocks), dim3((ST_RB / RPW * CT + ST_LOADERS) * 64), ldsb, stream, a);
+    FR_LAUNCH(prof, (linear_stream_kernel<B_T, CT, ST_RB, RPW, SRC, ONEPART>), dim3((unsigned)blocks), dim3((ST_RB / RPW * CT + ST_LOADERS) * 64), ldsb, stream, a);
     FR_CHECK_LAUNCH();
     return FR_OK;
 }
+template <bool B_T, bool ONEPART>
+static int launch_stream_p(const StArgs& a, hipStream_t stream, int kind) {
+    if (B_T && a.src)      // (two row blocks per wave + 32 `src` values in flight fit the registers only without the running total)
+        return a.C == 128 ? (ONEPART ? launch_stream_ct<B_T, 4, 4, 2, true, ONEPART>(a, stream, kind)
+                                     : launch_stream_ct<B_T, 4, 2, 1, true, ONEPART>(a, stream, kind))
+                          : launch_stream_ct<B_T, 2, 4, 1, true, ONEPART>(a, stream, kind);
+    return a.C == 128 ? launch_stream_ct<B_T, 4, 4, 2, false, ONEPART>(a, stream, kind)
+                      : launch_stream_ct<B_T, 2, 4, 1, false, ONEPART>(a, stream, kind);
+}
 template <bool B_T>
 static int launch_stream(const StArgs& a, hipStream_t stream, int kind) {
-    if (B_T && a.src)
-        return a.C == 128 ? launch_stream_ct<B_T, 4, 2, 1, true>(a, stream, kind) : launch_stream_ct<B_T, 2, 4, 1, true>(a, stream, kind);
-    return a.C == 128 ? launch_stream_ct<B_T, 4, 4, 2, false>(a, stream, kind) : launch_stream_ct<B_T, 2, 4, 1, false>(a, stream, kind);
+    return a.cpp == a.R / 32 ? launch_stream_p<B_T, true>(a, stream, kind) : launch_stream_p<B_T, false>(a, stream, kind);
 }
 
 static bool stream_shape(int64_t M, int R, int C) {
