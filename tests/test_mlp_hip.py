@@ -663,3 +663,55 @@ def test_streaming_weight_gradient_is_bit_identical_to_the_macro_tile_kernel(M, 
     ref = dY.double().t() @ X.double()
     torch.testing.assert_close(got["stream"][0].double(), ref, rtol=1e-4, atol=1e-3 * float(ref.abs().max()))
     torch.testing.assert_close(got["stream"][1].double(), dY.double().sum(0), rtol=1e-4, atol=1e-3 * float(M) ** 0.5)
+
+
+def test_streaming_products_at_the_table_size_of_baseline_config_3():
+    """[11 000 002, 128] -- the whole embedding table FairGo's filter MLP runs over (BASELINE.json configs[3]) -- through the
+    streaming kernels: size-independent properties instead of a full reference.  The forward product is linear in its input
+    (no bias, no activation), sampled rows equal the float64 product, the input gradient is the transpose map (<dY, X W^T> =
+    <dY W, X>), and the weight gradient equals dY^T X on a sampled block of rows summed the slow way."""
+    _C = _lib()
+    lib = _C.lib()
+    st = _C.current_stream()
+    M, K, N = 11_000_002, 128, 128
+    g = torch.Generator(device="cuda").manual_seed(9)
+    X1 = torch.randn(M, K, device="cuda", generator=g)
+    X2 = torch.randn(M, K, device="cuda", generator=g)
+    W = torch.randn(N, K, device="cuda", generator=g) * 0.1
+
+    def fwd(X):
+        Y = torch.empty(M, N, device="cuda")
+        _C.check(lib.fr_linear_fwd(X.data_ptr(), K, None, 0, None, 1.0, W.data_ptr(), None, M, N, 0, Y.data_ptr(), st), "fwd")
+        return Y
+
+    Y1, Y2 = fwd(X1), fwd(X2)
+    X2.add_(X1)                                   # X2 <- X1 + X2
+    Y12 = fwd(X2)
+    err = (Y12 - (Y1 + Y2)).abs().max()
+    assert float(err) <= 1e-4 * float(Y12.abs().max()), float(err)
+    rows = torch.randint(0, M, (4096,), device="cuda", generator=g)
+    rows[:3] = torch.tensor([0, M - 1, M - 2], device="cuda")          # the ragged last tile included
+    ref = X1[rows].double() @ W.double().t()
+    torch.testing.assert_close(Y1[rows].double(), ref, rtol=1e-4, atol=1e-5)
+    del Y2, Y12
+    # input gradient: adjointness
+    dY = torch.randn(M, N, device="cuda", generator=g)
+    dX = torch.empty(M, K, device="cuda")
+    _C.check(lib.fr_linear_bwd_input(dY.data_ptr(), dY.data_ptr(), 0, W.data_ptr(), None, 1.0, M, N, dX.data_ptr(), K, None, 0, st), "bwd")
+    lhs = (dY.double() * Y1.double()).sum()
+    rhs = (dX.double() * X1.double()).sum()
+    assert abs(float(lhs - rhs)) <= 1e-6 * max(abs(float(lhs)), float((dY.double() ** 2).sum().sqrt() * (Y1.double() ** 2).sum().sqrt())), \
+        (float(lhs), float(rhs))
+    torch.testing.assert_close(dX[rows].double(), dY[rows].double() @ W.double(), rtol=1e-4, atol=1e-5)
+    # weight gradient: zero everything but a block of rows, whose contribution is known
+    blk = slice(7_000_001, 7_000_001 + 3000)
+    dYb = torch.zeros_like(dY)
+    dYb[blk] = dY[blk]
+    dW = torch.empty(N, K, device="cuda")
+    db = torch.empty(N, device="cuda")
+    ws = torch.empty(lib.fr_linear_bwd_weight_workspace_bytes(M, N, K), dtype=torch.uint8, device="cuda")
+    _C.check(lib.fr_linear_bwd_weight(dYb.data_ptr(), dYb.data_ptr(), 0, X1.data_ptr(), K, None, 0, None, 1.0, M, N, dW.data_ptr(),
+                                      db.data_ptr(), ws.data_ptr(), ws.numel(), st), "wgrad")
+    ref = dY[blk].double().t() @ X1[blk].double()
+    torch.testing.assert_close(dW.double(), ref, rtol=1e-4, atol=1e-4 * float(ref.abs().max()))
+    torch.testing.assert_close(db.double(), dY[blk].double().sum(0), rtol=1e-4, atol=1e-3)
