@@ -318,7 +318,9 @@ def _numpy_epoch(uniq, indptr, step, pr, pr_end):
 
 
 @pytest.mark.parametrize("seed,n_items,n_rows,step", [(0, 50, 600, 64), (1, 1300, 9000, 512), (2, 7, 40, 100),
-                                                     (3, 700, 700, 16), (2020, 1, 5, 3), (5, 4000, 30000, 2048)])
+                                                     (3, 700, 700, 16), (2020, 1, 5, 3), (5, 4000, 30000, 2048),
+                                                     (7, 100000, 16384, 8192)],     # BASELINE configs[1]'s item count and batch
+                         ids=["tiny", "ragged", "exhausted", "unit", "one_item", "mid", "baseline_items"])
 def test_compose_epoch_makes_numpys_draws(seed, n_items, n_rows, step):
     """fr_focf_compose_epoch against numpy itself: same picks, same batch boundaries, the generator left at the same
     position (the next draws of numpy agree) -- including batches that exhaust the candidates (step > rows), a single
