@@ -64,7 +64,7 @@ def synth_batches(n_batches, batch, n_users, n_items, seed, item_dist="uniform")
 
 def focf_shape_block(item_dist, K, W, dev, sweep):
     """The same FOCF step on another batch shape, measured the same way as the headline (fresh engine, optimizer state aged by
-    one sweep period, K steps captured in one hipGraph and replayed): `grouped` = item-complete batches, the shape the
+    one sweep period, K steps issued by the library's step loop, 256 per call): `grouped` = item-complete batches, the shape the
     reference's own FOCFDataLoader feeds (focf_dataloader.py:37-51; SURVEY.md section 8-d says this run "must also be reported"),
     `zipf` = popularity-skewed items.  Bytes: SURVEY.md section 8-d's UNIQUE-ROW definition for these shapes --
     8 R B + 4 (1 + S) B + sum over tables of distinct rows x D x (4 gathered + 8 Adam state read + 12 written)."""
@@ -77,14 +77,27 @@ def focf_shape_block(item_dist, K, W, dev, sweep):
     eng.item_runs = item_dist == "grouped"          # what the Trainer sets when it is fed by FOCFDataLoader
     ahead = FocfEngine.LOW_WATER + FocfEngine.GROUP
     n_age = eng._sweep(BATCH) if (sweep is None or sweep > 0) else 256
-    n = n_age + W + K + ahead + 4
+    n = n_age + W + K + W + K + ahead + 4
     u, i, r, s = (t.to(dev) for t in synth_batches(n, BATCH, N_USERS, N_ITEMS, SEED + 31337, item_dist))
+    def run(lo, hi):
+        for a in range(lo, hi, 256):
+            b = min(a + 256, hi)
+            eng.steps_many(u[a:b].reshape(-1), i[a:b].reshape(-1), r[a:b].reshape(-1), s[a:b].reshape(-1), BATCH)
+    assert eng.can_step_many()
+    run(0, n_age + W)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(n_age + W, n_age + W + K)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    # ... and the next K steps as per-batch launches captured in ONE hipGraph (how rounds 2-5 timed these shapes)
+    base = n_age + W + K
     rows = [(u[j], i[j], s[j], r[j]) for j in range(n)]
 
     def step(k):
         eng.forward(u[k], i[k], r[k], s[k], next_batch=rows[k + 1:k + 1 + ahead] or None)
         eng.backward_adam()
-    for k in range(n_age + W):
+    for k in range(base, base + W):
         step(k)
     torch.cuda.synchronize()
     eng.prepared_is_complete()
@@ -93,7 +106,7 @@ def focf_shape_block(item_dist, K, W, dev, sweep):
     graph = torch.cuda.CUDAGraph()
     with torch.cuda.stream(side):
         with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):
-            for k in range(n_age + W, n_age + W + K):
+            for k in range(base + W, base + W + K):
                 step(k)
             eng.join_prepared()
     torch.cuda.current_stream().wait_stream(side)
@@ -101,7 +114,9 @@ def focf_shape_block(item_dist, K, W, dev, sweep):
     t0 = time.perf_counter()
     graph.replay()
     torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    dt_graph = time.perf_counter() - t0
+    graph.reset()
+    del graph, rows
     eng.check_device_errors()
     lo, hi = n_age + W, n_age + W + K
     uniq_u = sum(int(torch.unique(u[k]).numel()) for k in range(lo, hi)) / K
@@ -112,10 +127,11 @@ def focf_shape_block(item_dist, K, W, dev, sweep):
             if eng.item_runs and eng.RUNS and eng.PIPE else
             "two launches per step (fr_focf_step_runs: the gather, then a workgroup per item run)" if eng.item_runs and eng.RUNS
             else ("one launch per step (fr_focf_step_staged)" if eng.staged and not eng.item_runs else "three-launch chain"))
-    graph.reset()
-    del graph, eng, U, I, u, i, r, s, rows
+    eng.finish()
+    del eng, U, I, u, i, r, s
     torch.cuda.synchronize()
-    return {"item_distribution": item_dist, "steps": K, "us_per_step": round(dt / K * 1e6, 2),
+    return {"item_distribution": item_dist, "steps": K, "us_per_step": round(dt / K * 1e6, 2), "launch": "library step loop, 256 steps per call",
+            "hipGraph_us_per_step": round(dt_graph / K * 1e6, 2),
             "interactions_per_s": round(K * BATCH / dt, 1), "step": kind,
             "distinct_user_rows_per_batch": round(uniq_u, 1), "distinct_item_rows_per_batch": round(uniq_i, 1),
             "bytes_definition": "SURVEY.md 8-d unique rows: 8*R*B + 4*(1+S)*B + distinct rows * D * (4 + 8 + 12)",
@@ -123,7 +139,7 @@ def focf_shape_block(item_dist, K, W, dev, sweep):
             "achieved_GBps": round(gbs, 1), "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 4)}
 
 
-def trainer_fit_block(dev, graph_us_per_step, steps=1024, sweep=None):
+def trainer_fit_block(dev, headline_us_per_step, steps=1024, sweep=None):
     """What a user of the plugin surface gets: `fairrec.trainer.Trainer._train_epoch` (reference trainer.py:155-204) on the
     BASELINE sizes, through the loaders -- not the bench's own step loop.  `uniform`: TrainDataLoader over a device-resident,
     per-epoch shuffled interaction table; the trainer hands runs of `train_steps_per_call` batches to the library
@@ -165,7 +181,7 @@ def trainer_fit_block(dev, graph_us_per_step, steps=1024, sweep=None):
     out["uniform"] = {"loader": "TrainDataLoader(shuffle=True), dataset resident on the device", "steps": n,
                       "us_per_step": round(dt / n * 1e6, 2), "interactions_per_s": round(rows / dt, 1),
                       "steps_per_library_call": int(cfg["train_steps_per_call"]),
-                      "vs_graph_replay": round(dt / n * 1e6 / graph_us_per_step, 3)}
+                      "vs_headline": round(dt / n * 1e6 / headline_us_per_step, 3)}
     del ds
     # item-complete: 5000 of the items carry ~100 interactions each (the shape of SURVEY.md 8-d's grouped run; a pick permutes
     # the candidate list -- numpy's legacy choice(replace=False) -- so its host cost grows with the number of candidates)
@@ -192,6 +208,49 @@ def trainer_fit_block(dev, graph_us_per_step, steps=1024, sweep=None):
                             "steps": n, "us_per_step": round(dt / n * 1e6, 2), "interactions_per_s": round(rows / dt, 1),
                             "rows_per_batch": round(rows / n, 1),
                             "picks_us_per_batch_host": round(compose["s"] / n * 1e6, 1)}
+    return out
+
+
+def other_workloads_block(args, dev, budget_s=None):
+    """BASELINE.json configs[2], [3], [4] under the same clock as the FOCF line (the driver runs ONE command): each workload of
+    `--workload pfcn10m | fairgo10m | nfcf100m` at its full table size, >= 20 timed steps, reduced to the figures a reader
+    compares -- ms per step, interactions/s, the roofline it is bound by and the fraction reached.  A workload that would not
+    fit the time budget (FAIRREC_BENCH_WORKLOADS_BUDGET seconds for all three, default 240; FairGo's one-off host preprocessing
+    of its 400 M-entry propagation matrix alone takes ~75 s) or that fails is reported with `skipped_reason`, not dropped."""
+    import argparse
+    import bench_workloads
+    budget = float(os.environ.get("FAIRREC_BENCH_WORKLOADS_BUDGET", "240")) if budget_s is None else budget_s
+    t_all = time.perf_counter()
+    expect = {"pfcn10m": 45.0, "nfcf100m": 60.0, "fairgo10m": 120.0}      # seconds a workload takes here, set-up included
+    out = {}
+    for name in ("pfcn10m", "nfcf100m", "fairgo10m"):
+        left = budget - (time.perf_counter() - t_all)
+        if left < expect[name]:
+            out[name] = {"skipped_reason": f"{left:.0f} s of the {budget:.0f} s budget left, the workload takes ~{expect[name]:.0f} s "
+                                           f"(python bench.py --workload {name} runs it on its own)"}
+            continue
+        a = argparse.Namespace(**vars(args))
+        a.workload, a.steps, a.warmup, a.age = name, 20, 4, 0
+        if name == "fairgo10m":
+            a.steps, a.warmup = 5, 2
+        t0 = time.perf_counter()
+        try:
+            torch.cuda.empty_cache()
+            torch.cuda.reset_peak_memory_stats()
+            d = (bench_nfcf(a, 0, 1, dev) if name == "nfcf100m" else
+                 (bench_workloads.bench_pfcn if name == "pfcn10m" else bench_workloads.bench_fairgo)(a, dev))
+            r = d["roofline"]
+            out[name] = {"workload": d["config"]["workload"], "steps": d["steps"], "ms_per_step": d["ms_per_step"],
+                         "interactions_per_s": d["value"], "launch": d["config"].get("launch"),
+                         "roofline": {k: r.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "frac_of_valu_floor",
+                                                            "whole_step_tflops") if r.get(k) is not None},
+                         "passes_ms": {k: d["config"][k] for k in ("filter_pass_ms", "dis_pass_ms") if k in d["config"]} or None,
+                         "peak_mem_GiB": d["config"].get("peak_mem_GiB"), "wall_s": round(time.perf_counter() - t0, 1)}
+        except Exception as e:      # e.g. a box whose GPU cannot hold the tables: the FOCF line still goes out
+            out[name] = {"skipped_reason": f"{type(e).__name__}: {e}", "wall_s": round(time.perf_counter() - t0, 1)}
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
     return out
 
 
@@ -410,10 +469,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly instead of one hipGraph")
-    ap.add_argument("--graph-only", action="store_true", help="do not also time eager launches (single-GPU default: both)")
+    ap.add_argument("--launch", default="library", choices=["library", "graph", "eager"],
+                    help="how the timed steps are issued on one GPU: the library's step loop (fr_focf_steps_many / fr_focf_runs_many: "
+                         "what Trainer._train_epoch calls; default), one hipGraph of per-batch steps, or per-batch eager launches")
+    ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly (= --launch eager; the N > 1 path: no hipGraph)")
+    ap.add_argument("--graph-only", action="store_true", help="do not also time the other launch modes (single-GPU default: all three)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-shapes", action="store_true", help="skip the grouped / zipf blocks of the default FOCF run")
+    ap.add_argument("--no-workloads", action="store_true",
+                    help="skip the other_workloads block of the default FOCF run (BASELINE configs[2..4] at full size, ~3 min)")
     ap.add_argument("--item-dist", default="uniform", choices=["uniform", "zipf", "grouped", "unique"])
     ap.add_argument("--sweep", type=int, default=None, help="lazy-Adam sweep period (default: auto)")
     ap.add_argument("--force-sharded", action="store_true", help="use the row-sharded engine even on one GPU")
@@ -538,13 +602,32 @@ def main():
         hi = min(k + 1 + AHEAD, len(rows), stop if stop is not None else len(rows))
         return rows[k + 1:hi] or None
 
-    def step(k):
+    def step(k, ub=None, ib=None, sb=None, rb=None):
+        if ub is None:
+            ub, ib, sb, rb = u, i, s, r
         if sharded:   # look-ahead of the index work, not across the warm-up / captured-graph boundary
-            nxt = (u[k + 1], i[k + 1], s[k + 1], r[k + 1]) if k + 1 < n_batches and k != W - 1 else None
-            eng.forward(u[k], i[k], r[k], s[k], next_batch=nxt)
+            nxt = (ub[k + 1], ib[k + 1], sb[k + 1], rb[k + 1]) if k + 1 < ub.shape[0] and k != W - 1 else None
+            eng.forward(ub[k], ib[k], rb[k], sb[k], next_batch=nxt)
         else:         # the dataloader-style queue runs through: the warm-up steps already announce the first timed batches
-            eng.forward(u[k], i[k], r[k], s[k], next_batch=coming(k, u, i, s, r))
+            eng.forward(ub[k], ib[k], rb[k], sb[k], next_batch=coming(k, ub, ib, sb, rb))
         eng.backward_adam()
+
+    # One GPU: the timed steps go through the LIBRARY's step loop -- fr_focf_steps_many (fr_focf_runs_many for item-complete
+    # batches), one foreign call per run of up to 256 batches: the launches Trainer._train_epoch issues (TrainDataLoader.take ->
+    # FOCF.train_steps), and 1.5-2 us per step faster than a hipGraph replay of the same launches.  `--launch graph | eager` time
+    # the per-batch entry points instead; the default run reports all three (config.launch_modes_timed).
+    launch_mode = "eager" if args.no_graph else args.launch
+    if sharded and launch_mode == "library":
+        launch_mode = "graph"
+    if launch_mode == "library" and not eng.can_step_many():
+        launch_mode = "graph"
+    LIB_RUN = 256
+
+    def lib_steps(ub, ib, sb, rb, lo, hi):
+        B = ub.shape[1]
+        for a in range(lo, hi, LIB_RUN):
+            b = min(a + LIB_RUN, hi)
+            eng.steps_many(ub[a:b].reshape(-1), ib[a:b].reshape(-1), rb[a:b].reshape(-1), sb[a:b].reshape(-1), B)
 
     def barrier():
         if world > 1:
@@ -558,19 +641,25 @@ def main():
     if not sharded and args.age >= 0:
         n_age = args.age if args.age else (eng._sweep(BATCH) if (args.sweep is None or args.sweep > 0) else 256)
         ua, ia, ra, sa = (t.to(dev) for t in synth_batches(n_age, BATCH, N_USERS, N_ITEMS, SEED + 104729 + rank, args.item_dist))
-        for k in range(n_age):
-            eng.forward(ua[k], ia[k], ra[k], sa[k], next_batch=coming(k, ua, ia, sa, ra))
-            eng.backward_adam()
+        if launch_mode == "library":
+            lib_steps(ua, ia, sa, ra, 0, n_age)
+        else:
+            for k in range(n_age):
+                eng.forward(ua[k], ia[k], ra[k], sa[k], next_batch=coming(k, ua, ia, sa, ra))
+                eng.backward_adam()
         torch.cuda.synchronize()
         del ua, ia, ra, sa
-    for k in range(W):
-        step(k)
+    if launch_mode == "library":
+        lib_steps(u, i, s, r, 0, W)
+    else:
+        for k in range(W):
+            step(k)
     barrier()
     if not sharded:
         eng.prepared_is_complete()      # (synchronised above) the captured steps do not wait for pre-capture side-stream work
 
     graph, quiesced = None, None
-    if not args.no_graph:   # K steps (kernels and, when sharded, the RCCL collectives) captured in one hipGraph
+    if launch_mode == "graph":   # K steps (kernels and, when sharded, the RCCL collectives) captured in one hipGraph
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         graph = torch.cuda.CUDAGraph()
@@ -602,7 +691,9 @@ def main():
     # (the captured steps carry their optimizer step numbers and stamps as kernel arguments: this graph is replayed ONCE)
     barrier()
     t0 = time.perf_counter()
-    if graph is not None:
+    if launch_mode == "library":
+        lib_steps(u, i, s, r, W, W + K)
+    elif graph is not None:
         graph.replay()
     else:
         for k in range(W, W + K):
@@ -615,31 +706,72 @@ def main():
         dt = float(t.item())
     eng.check_device_errors()
     loss_last = float(eng.loss_ring[eng.loss_slot][0].item()) if not sharded else float("nan")
-    launch, other = ("hipGraph" if graph is not None else "eager"), None
-    if graph is not None and not sharded and not args.graph_only:
-        # Single-GPU FOCF: one launch per step and one stream join per 8 steps.  `value` is ALWAYS the hipGraph replay of
-        # the K steps (one fixed launch mode); the same K steps' worth of work launched eagerly (fresh batches, same
-        # distribution) is timed as well and reported in `config.launch_modes_timed` for orientation only.
-        ue, ie, re_, se = (t.to(dev) for t in synth_batches(K, BATCH, N_USERS, N_ITEMS, SEED + 15485863 + rank, args.item_dist))
-        coming(0, ue, ie, se, re_)      # row views made outside the timed region, as for the graph's batches
-        barrier()
-        t0 = time.perf_counter()
-        for k in range(K):
-            eng.forward(ue[k], ie[k], re_[k], se[k], next_batch=coming(k, ue, ie, se, re_))
-            eng.backward_adam()
-        barrier()
-        dt_eager = time.perf_counter() - t0
-        eng.check_device_errors()
-        other = {"hipGraph_ms_per_step": round(dt / K * 1e3, 5), "eager_ms_per_step": round(dt_eager / K * 1e3, 5)}
-        if eng.can_step_many():
-            # ... and the same K steps' worth issued by the LIBRARY's own step loop (fr_focf_steps_many: what Trainer._train_epoch
-            # calls, one foreign call for the run; its two stage launches for the first batches are inside the clock)
-            ul, il, rl, sl = (t.to(dev).reshape(-1) for t in synth_batches(K + 4, BATCH, N_USERS, N_ITEMS, SEED + 32452843 + rank, args.item_dist))
-            c4 = 4 * BATCH
-            eng.steps_many(ul[:c4], il[:c4], rl[:c4], sl[:c4], BATCH)      # (first use: the run's ring of workspaces is allocated)
+    launch = {"library": "library step loop (fr_focf_runs_many)" if (not sharded and eng.item_runs) else "library step loop (fr_focf_steps_many)",
+              "graph": "hipGraph" if graph is not None else "eager", "eager": "eager"}[launch_mode]
+    other = None
+    if not sharded and not args.graph_only and launch_mode != "eager":
+        # Single-GPU FOCF: `value` is the launch mode named in config.launch (default: the library's step loop); the same K
+        # steps' worth of work in the other launch modes (fresh batches, same distribution) is timed as well and reported in
+        # `config.launch_modes_timed`, for orientation only.
+        key = {"library": "library_loop_ms_per_step", "graph": "hipGraph_ms_per_step"}[launch_mode]
+        other = {key: round(dt / K * 1e3, 5)}
+
+        def timed_graph(ub, ib, sb, rb):      # K per-batch steps behind W warm-up ones, captured in one hipGraph, replayed once
+            for k in range(W):
+                step(k, ub, ib, sb, rb)
+            barrier()
+            eng.prepared_is_complete()
+            sd = torch.cuda.Stream()
+            sd.wait_stream(torch.cuda.current_stream())
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.stream(sd):
+                with torch.cuda.graph(g, stream=sd, capture_error_mode="thread_local"):
+                    for k in range(W, W + K):
+                        step(k, ub, ib, sb, rb)
+                    eng.join_prepared()
+            torch.cuda.current_stream().wait_stream(sd)
             barrier()
             t0 = time.perf_counter()
-            eng.steps_many(ul[c4:], il[c4:], rl[c4:], sl[c4:], BATCH)
+            g.replay()
+            barrier()
+            t = time.perf_counter() - t0
+            g.reset()
+            return t
+
+        if launch_mode != "graph":
+            ug, ig, rg, sg = (t.to(dev) for t in synth_batches(K + W + PIPE, BATCH, N_USERS, N_ITEMS, SEED + 6700417 + rank, args.item_dist))
+            other["hipGraph_ms_per_step"] = round(timed_graph(ug, ig, sg, rg) / K * 1e3, 5)
+            eng.check_device_errors()
+            del ug, ig, rg, sg
+        # (per-batch eager launches: about one pass in five on a fresh box runs ten times slower than the next one -- 300-450 us per
+        # step, host side, seen since round 4 with and without event pairs on the launches; such a pass is taken once more and
+        # the line says so)
+        retimed = []
+        for rep_ in range(2):
+            ue, ie, re_, se = (t.to(dev) for t in synth_batches(K, BATCH, N_USERS, N_ITEMS, SEED + 15485863 + rank + 101 * rep_, args.item_dist))
+            coming(0, ue, ie, se, re_)      # row views made outside the timed region, as for the graph's batches
+            barrier()
+            t0 = time.perf_counter()
+            for k in range(K):
+                eng.forward(ue[k], ie[k], re_[k], se[k], next_batch=coming(k, ue, ie, se, re_))
+                eng.backward_adam()
+            barrier()
+            t_e = time.perf_counter() - t0
+            eng.check_device_errors()
+            if t_e < 3.0 * dt or rep_:
+                break
+            retimed.append(round(t_e / K * 1e3, 5))
+        other["eager_ms_per_step"] = round(t_e / K * 1e3, 5)
+        if retimed:
+            other["eager_ms_per_step_first_pass_discarded"] = retimed[0]
+        if launch_mode != "library" and eng.can_step_many():
+            # ... and the same K steps' worth issued by the LIBRARY's own step loop (what Trainer._train_epoch calls; the stage
+            # launches for the run's first batches are inside the clock)
+            ul, il, rl, sl = (t.to(dev) for t in synth_batches(K + 4, BATCH, N_USERS, N_ITEMS, SEED + 32452843 + rank, args.item_dist))
+            lib_steps(ul, il, sl, rl, 0, 4)      # (first use: the run's ring of workspaces is allocated)
+            barrier()
+            t0 = time.perf_counter()
+            lib_steps(ul, il, sl, rl, 4, K + 4)
             barrier()
             other["library_loop_ms_per_step"] = round((time.perf_counter() - t0) / K * 1e3, 5)
             eng.check_device_errors()
@@ -767,6 +899,11 @@ def main():
                                  "gather / fair / backward_adam chain over 5 all-to-alls") if sharded else
                                 ("ONE launch per step and nothing else on the device (fr_focf_step_staged: gather + lazy-Adam "
                                  "replay + dot + fairness + backward + Adam + sweep slice + the claim stage of the batch two "
+                                 "steps ahead + the place stage of the next one), the run of launches issued by ONE library call "
+                                 "per 256 steps (fr_focf_steps_many, the call Trainer._train_epoch makes)"
+                                 if getattr(eng, "staged", False) and launch_mode == "library" else
+                                 "ONE launch per step and nothing else on the device (fr_focf_step_staged: gather + lazy-Adam "
+                                 "replay + dot + fairness + backward + Adam + sweep slice + the claim stage of the batch two "
                                  "steps ahead + the place stage of the next one)" if getattr(eng, "staged", False) else
                                  "ONE launch per step (fr_focf_step: gather + lazy-Adam replay + dot + fairness + backward + Adam + "
                                  "sweep slice); id columns of 16 coming batches sorted and packed per fork of the side stream")),
@@ -789,6 +926,8 @@ def main():
             # slower than any stretch of an epoch does; the block says how many steps it timed)
             out["other_batch_shapes"] = [focf_shape_block(d, max(K, 200), W, dev, args.sweep) for d in ("grouped", "zipf")]
             out["trainer_fit"] = trainer_fit_block(dev, dt / K * 1e6, sweep=args.sweep)
+            if not args.no_workloads:
+                out["other_workloads"] = other_workloads_block(args, dev)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
     if (world > 1 or os.environ.get("FAIRREC_BENCH_NFCF_BLOCK") == "1") and not args.no_shapes:      # (the env: this code path on one GPU)

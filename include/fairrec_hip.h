@@ -269,7 +269,10 @@ FR_API int fr_focf_step_runs_pipe(const fr_table* U, const fr_table* I, const fr
  * row exactly as the sorted path does: same sums in the same order, bit-identical parameters.  The reported fairness
  * value sums the items' terms in batch order of their first members instead of item-id order (last-bit differences in
  * the loss value only).
- *   fr_focf_stage        : stages on their own launch (the first batches of a loop; either batch may be NULL).
+ *   fr_focf_stage        : stages on their own launch (the first batches of a loop; either batch may be NULL).  U->step /
+ *                          I->step = the optimizer step the batch to place -- without one, the batch to claim -- will be
+ *                          applied at (with both, the claimed batch is applied one step later): the start order of that
+ *                          step's sweeper tasks is built for the step's slice of the tables, whatever the stamps are.
  *   fr_focf_step_staged  : fr_focf_step for a batch that went through both stages with stamp `stamp`, carrying the
  *                          claim of one coming batch and the place of another (either may be NULL).  Stamps must be
  *                          handed out in strictly increasing order.  `gen` (0..2) names the generation of row words a

@@ -191,6 +191,16 @@ __device__ __forceinline__ void store_row_sc1(const RowFrag<E>& f, float* base, 
     }
 }
 
+// Store policy of finished table rows (FR_TROW_STORE: 1 write-through, 0 plain, 2 non-temporal) and of the tasks' one-word
+// results (FR_WORD_STORE); what was measured is with the stage constants below.  (Until round 6 these defaults stood BEHIND
+// their first use, where the preprocessor read the undefined names as 0: the product library stored plain, and the
+// write-through numbers of round 3 were only ever seen in A/B builds that passed -D.  Moved here: 29.4 -> 27.3 us per step.)
+#ifndef FR_TROW_STORE
+#define FR_TROW_STORE 1
+#endif
+#ifndef FR_WORD_STORE
+#define FR_WORD_STORE 1
+#endif
 // a finished row's `last` stamp, and the other one-word results of a task, with the rows' store policy
 __device__ __forceinline__ void store_word(int32_t* p, int v) {
 #if FR_TROW_STORE == 1 && FR_WORD_STORE
@@ -339,12 +349,6 @@ __device__ __forceinline__ int replay_class(int a, int b, int cap, int NC) {    
 // --steps 20): plain 29.98 / 33.7 / 30.8, rows write-through 29.41 / 33.6 / 29.9, rows and words 29.05 / 33.4, non-temporal
 // 29.8.  Not on the shared-row path: its hand-offs drain the wave's stores, and a write-through store is acknowledged by
 // memory, not by the L2 (zipf items 33.6 -> 39.4 us with write-through rows there).
-#ifndef FR_TROW_STORE
-#define FR_TROW_STORE 1
-#endif
-#ifndef FR_WORD_STORE
-#define FR_WORD_STORE 1
-#endif
 #ifndef FR_STAGE_EPT
 #define FR_STAGE_EPT 2
 #endif
@@ -1549,8 +1553,11 @@ __global__ __launch_bounds__(64 * STEP_WPB, step_waves(E)) void focf_step_kernel
     unsigned hw, xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    const unsigned wq = blockIdx.x * STEP_WPB + wib;
-    if (lane == 0 && wq < 65536 && (g_trace_step < 0 || g_trace_step == a.step)) {
+    // (g_trace_step >= 0: the launches that apply steps g_trace_step .. g_trace_step + 3, 16384 wave records each: consecutive
+    // launches side by side, scratch/chain_trace.py)
+    const int tsel = g_trace_step < 0 ? 0 : a.step - g_trace_step;
+    const unsigned wq = blockIdx.x * STEP_WPB + wib + (g_trace_step < 0 ? 0u : 16384u * (unsigned)(tsel & 3));
+    if (lane == 0 && wq < 65536 && (g_trace_step < 0 || (tsel >= 0 && tsel < 4 && blockIdx.x * STEP_WPB + wib < 16384))) {
         g_step_trace[4 * wq] = tr0;
         g_step_trace[4 * wq + 1] = tr1;
         g_step_trace[4 * wq + 2] = role;
@@ -1882,9 +1889,15 @@ static unsigned long long* words_of(uint64_t* row_words, int32_t gen, const fr_t
 }
 
 // the stage descriptors of a launch: `claim` = the batch two steps ahead (or null), `place` = the next one (or null)
+// claim_step / place_step: the optimizer steps the two batches will be APPLIED at -- what the sweep slice their sweeper orders
+// are built for hangs on.  A stamp only has to grow from batch to batch: it runs ahead of the steps once a claimed batch was
+// never applied (a loop cut short), and an order built for the stamp's slice is then an order for the wrong rows (the step
+// falls back to slice order: +3 us per step, which is what bench.py's eager and library-loop figures carried until round 6).
 static int make_stages(StageArgs& st, const fr_table* U, const fr_table* I, const fr_focf_batch* claim, int32_t claim_stamp,
                        int32_t claim_gen, const fr_focf_batch* place, int32_t place_stamp, int32_t place_gen,
-                       int32_t sweep_period, uint64_t* row_words, uint32_t* err_flag) {
+                       int32_t sweep_period, uint64_t* row_words, uint32_t* err_flag, int32_t claim_step, int32_t place_step) {
+    if (claim_step < 1) claim_step = claim_stamp;
+    if (place_step < 1) place_step = place_stamp;
     st = StageArgs{};
     st.Ulast = U->last; st.Ustamp = U->stamp; st.Ilast = I->last; st.Istamp = I->stamp;
     st.n_rows_u = (int)U->n_rows; st.n_rows_i = (int)I->n_rows;
@@ -1892,9 +1905,9 @@ static int make_stages(StageArgs& st, const fr_table* U, const fr_table* I, cons
     st.err = err_flag;
     FR_CHECK_ARG(row_words && U->n_rows <= INT32_MAX && I->n_rows <= INT32_MAX, "fr_focf_stage: row words missing");
     FR_CHECK_ARG(U->stamp && I->stamp && U->last && I->last, "fr_focf_stage: the tables need their last / stamp arrays");
-    auto slice_of = [&](int32_t stamp) {
+    auto slice_of = [&](int32_t step) {
         fr_table tu = *U, ti = *I;
-        tu.step = ti.step = stamp;
+        tu.step = ti.step = step;
         return make_sweep_slice(&tu, &ti, sweep_period);
     };
     if (claim) {
@@ -1911,7 +1924,7 @@ static int make_stages(StageArgs& st, const fr_table* U, const fr_table* I, cons
         J.B = (int)b.B; J.stamp = claim_stamp;
         st.nb_claim = (int)((b.B + STAGE_BLOCK - 1) / STAGE_BLOCK);
         if (sweep_period > 0) {
-            const SweepSlice sw = slice_of(claim_stamp);
+            const SweepSlice sw = slice_of(claim_step);
             const long long n_pairs = ((long long)sw.n_u + 1) / 2 + ((long long)sw.n_i + 1) / 2;
             if (n_pairs <= SWEEP_ORDER_MAX) {
                 J.lo_u = sw.lo_u; J.lo_i = sw.lo_i; J.n_u = sw.n_u; J.n_i = sw.n_i;
@@ -1934,7 +1947,7 @@ static int make_stages(StageArgs& st, const fr_table* U, const fr_table* I, cons
         J.B = (int)b.B; J.stamp = place_stamp;
         st.nb_place = (int)((b.B + STAGE_THREADS * PLACE_EPT - 1) / (STAGE_THREADS * PLACE_EPT));
         if (sweep_period > 0) {
-            const SweepSlice sw = slice_of(place_stamp);
+            const SweepSlice sw = slice_of(place_step);
             const long long n_pairs = ((long long)sw.n_u + 1) / 2 + ((long long)sw.n_i + 1) / 2;
             if (n_pairs <= SWEEP_ORDER_MAX) {
                 J.n_pairs = (int)n_pairs;
@@ -1955,8 +1968,10 @@ extern "C" int fr_focf_stage(const fr_table* U, const fr_table* I, const fr_focf
     if ((rc = check_table(U, "fr_focf_stage(U)")) || (rc = check_table(I, "fr_focf_stage(I)"))) return rc;
     FR_CHECK_ARG(U->dim == I->dim && (claim || place), "fr_focf_stage: nothing to do");
     StageArgs st;
+    // (U->step: the step the batch to place -- without one, the batch to claim -- will be applied at; with both, the claimed batch
+    // comes one step later)
     if ((rc = make_stages(st, U, I, claim, claim_stamp, claim_gen, place, place_stamp, place_gen, sweep_period, row_words,
-                          err_flag)))
+                          err_flag, place ? U->step + 1 : U->step, U->step)))
         return rc;
     const int nb = st.nb_claim + st.nb_sa + st.nb_place + st.nb_sb;
     ProfScope prof(K_FOCF_STAGE, (hipStream_t)stream_);
@@ -2070,8 +2085,9 @@ extern "C" int fr_focf_step_staged(const fr_table* U, const fr_table* I, const f
     if (claim || place) {
         int rc;
         if ((rc = check_table(U, "fr_focf_step_staged(U)")) || (rc = check_table(I, "fr_focf_step_staged(I)"))) return rc;
+        // (the batch to place is applied at the next step, the batch to claim at the one after)
         if ((rc = make_stages(st, U, I, claim, claim_stamp, claim_gen, place, place_stamp, place_gen, sweep_period, row_words,
-                              err_flag)))
+                              err_flag, U->step + 2, U->step + 1)))
             return rc;
     }
     return focf_step_impl(U, I, adam, sst, B, objective, fair_weight, sweep_period, stamp, ws, ws_bytes, prev_ws, prev_B,

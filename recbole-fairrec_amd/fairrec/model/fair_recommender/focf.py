@@ -271,12 +271,14 @@ class FocfEngine:
         # a generation of row words nobody in flight holds (the batch being applied, the placed one, the claimed one)
         held = {e["gen"] for e in self._st.values()} | ({self._gen_cur} if self._gen_cur is not None else set())
         gen = next(j for j in range(3) if j not in held)
-        return {"k": k, "ws": ws, "B": B, "stamp": self._next_stamp(ahead), "gen": gen, "stage": 0, "batch": batch,
-                "cols": (user, item, sst, rating)}
+        # (`step`: the optimizer step the batch is expected at -- the stamp may run ahead of it once a claimed batch was dropped)
+        return {"k": k, "ws": ws, "B": B, "stamp": self._next_stamp(ahead), "step": self.U.step + 1 + ahead, "gen": gen,
+                "stage": 0, "batch": batch, "cols": (user, item, sst, rating)}
 
     def _stage_now(self, claim=None, place=None):
         """Stages on a launch of their own (the first batches of a loop: no earlier step launch could carry them)."""
-        tu, ti = self.U.c(), self.I.c()
+        at = (place or claim)["step"]       # fr_focf_stage: table.step = the step the batch will be applied at
+        tu, ti = self.U.c(at), self.I.c(at)
         rc = _C.lib().fr_focf_stage(ctypes.byref(tu), ctypes.byref(ti),
                                     ctypes.byref(claim["batch"]) if claim else None, claim["stamp"] if claim else 0,
                                     claim["gen"] if claim else 0,

@@ -20,7 +20,11 @@ def _bench(*args):
     return json.loads(lines[0])
 
 
-@pytest.mark.parametrize("args", [(), ("--item-dist", "grouped"), ("--no-graph",)], ids=["default", "grouped", "eager"])
+SMALL = ("--users", "200001", "--items", "50001", "--nfcf-users", "200001", "--nfcf-items", "50001")   # the other_workloads tables
+
+
+@pytest.mark.parametrize("args", [SMALL, ("--item-dist", "grouped"), ("--no-graph", "--no-workloads"), ("--launch", "graph", "--no-workloads")],
+                         ids=["default", "grouped", "eager", "graph"])
 def test_bench_json_contract(args):
     d = _bench(*args)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
@@ -44,9 +48,25 @@ def test_bench_json_contract(args):
         g = shapes["grouped"]
         assert "unique rows" in g["bytes_definition"] and g["us_per_step"] > 0 and "fr_focf_step_runs" in g["step"]
         assert 60 < g["distinct_item_rows_per_batch"] < 100 and g["bytes_per_interaction"] < 3096
-        assert abs(g["frac_of_hbm_peak"] - g["achieved_GBps"] / 8000.0) < 1e-3
+        assert abs(g["frac_of_hbm_peak"] - g["achieved_GBps"] / 8000.0) < 1e-3 and g["hipGraph_us_per_step"] > 0
     else:
         assert "other_batch_shapes" not in d
+    mode = {"--no-graph": "eager", "--launch": "hipGraph"}.get(args[0] if args and args[0] in ("--no-graph", "--launch") else "", "library step loop")
+    assert d["config"]["launch"].startswith(mode), d["config"]["launch"]
+    if args is SMALL:
+        # BASELINE.json configs[2..4] ride in the default line (here on small tables): ms per step, rate, roofline of each
+        modes = d["config"]["launch_modes_timed"]
+        assert {"library_loop_ms_per_step", "hipGraph_ms_per_step", "eager_ms_per_step"} <= set(modes)
+        assert abs(modes["library_loop_ms_per_step"] - d["ms_per_step"]) < 1e-4
+        w = d["other_workloads"]
+        assert set(w) == {"pfcn10m", "nfcf100m", "fairgo10m"}
+        for name, x in w.items():
+            assert "skipped_reason" not in x, (name, x)
+            assert x["steps"] >= 5 and x["ms_per_step"] > 0 and x["interactions_per_s"] > 0, (name, x)
+            assert x["roofline"]["bound"] in ("hbm", "mfma") and 0.0 < x["roofline"]["frac"] < 1.0, (name, x)
+            assert abs(x["interactions_per_s"] - 8192 / (x["ms_per_step"] * 1e-3)) <= 2e-3 * x["interactions_per_s"], (name, x)
+    else:
+        assert "other_workloads" not in d
 
 
 def test_bench_nfcf_workload_contract():
