@@ -934,6 +934,11 @@ FR_API int fr_randperm(uint32_t* state, int64_t n, int64_t* out, void* ws, size_
  * positives.  pos_keys = the sorted keys row * n_items + item of the batch's positives (no dense 0/1 matrix). */
 FR_API int fr_eval_hits(const int64_t* topk_idx, int64_t n_rows, int32_t k, int64_t n_items, const int64_t* pos_keys,
                         int64_t n_pos, int32_t* rec_topk, void* stream);
+/* fr_topk_like_torch_cpu (HOST, no stream): torch.topk(rows, k, dim=-1) of the CPU backend with ITS order among equal values --
+ * what the reference's evaluation ranks with (collector.py:149 on the dense -inf matrix of trainer.py:441-456).  rows: float
+ * [n_rows, n] in host memory; idx_out int64 [n_rows, k] (val_out float [n_rows, k], optional).  For the user rows whose list
+ * hangs on an exact score tie; every other row is ranked on the device (csrc/topk_host.hip says why the order can be had). */
+FR_API int fr_topk_like_torch_cpu(const float* rows, int64_t n_rows, int64_t n, int32_t k, int64_t* idx_out, float* val_out);
 FR_API size_t fr_topk_metrics_workspace_bytes(int64_t n_users, int32_t k);
 FR_API int fr_topk_metrics(const int32_t* rec_topk, int64_t n_users, int32_t k, double* out, void* ws, size_t ws_bytes,
                            void* stream);

@@ -37,13 +37,29 @@ class Collector:
     def _add(self, key, t):
         self._parts.setdefault(key, []).append(t)
 
+    @staticmethod
+    def _host_topk(dense: torch.Tensor, K: int) -> torch.Tensor:
+        """`torch.topk(dense, K, dim=-1).indices` as the CPU backend orders EQUAL values (fr_topk_like_torch_cpu): the reference
+        ranks on the host (collector.py:149), and where a list hangs on an exact tie -- an untrained scorer that clamps, a
+        saturated sigmoid -- which candidates enter it and in which order is that kernel's doing (csrc/topk_host.hip).  `dense`:
+        the tied users' rows of the reference's [users, n_items] matrix (float32, any device)."""
+        rows = dense.to("cpu", torch.float32).contiguous()
+        out = torch.empty((rows.shape[0], K), dtype=torch.int64)
+        _C.check(_C.lib().fr_topk_like_torch_cpu(rows.data_ptr(), rows.shape[0], rows.shape[1], K, out.data_ptr(), None),
+                 "fr_topk_like_torch_cpu")
+        return out
+
     def eval_batch_collect(self, scores: torch.Tensor, interaction, positive_u: torch.Tensor, positive_i: torch.Tensor):
         lib = _C.lib()
         U, n_items = scores.shape
         K = min(max(self.topk), n_items)
         positive_u, positive_i = positive_u.to(scores.device, torch.int64), positive_i.to(scores.device, torch.int64)
-        _, topk_idx = torch.topk(scores, K, dim=-1)
-        topk_idx = topk_idx.contiguous()
+        vals, topk_idx = torch.topk(scores, min(K + 1, n_items), dim=-1)
+        topk_idx = topk_idx[:, :K].contiguous()
+        # rows whose list is decided by an exact tie (inside the list, or at its end): ranked as the reference's host kernel does
+        tied = (vals[:, 1:] == vals[:, :-1]).any(dim=1).nonzero().view(-1)
+        if tied.numel():
+            topk_idx[tied] = self._host_topk(scores[tied], K).to(scores.device)
         keys = torch.sort(positive_u * n_items + positive_i).values
         rec = torch.empty((U, K + 1), dtype=torch.int32, device=scores.device)
         _C.check(lib.fr_eval_hits(topk_idx.data_ptr(), U, K, n_items, keys.data_ptr(), keys.numel(), rec.data_ptr(),
@@ -94,6 +110,21 @@ class Collector:
         topk_idx = torch.zeros((U, K), dtype=torch.int64, device=dev)          # short lists are padded with [PAD] item 0
         keep = rank < K
         topk_idx[rrow[keep], rank[keep]] = (ckeys % n_items)[ranked][keep]
+        # users whose list is decided by an exact tie between candidates (ranks j - 1 and j equal, j <= K), or who have fewer
+        # than K candidates (the rest of the list is then the host kernel's pick among the -inf entries): their rows of the
+        # reference's dense -inf matrix are ranked on the host, in torch.topk's CPU order
+        sr = cscore[ranked]
+        pair = (rrow[1:] == rrow[:-1]) & (sr[1:] == sr[:-1]) & (rank[1:] <= K)
+        cnt = torch.bincount(rrow, minlength=U)
+        tied = torch.unique(torch.cat([rrow[1:][pair], (cnt < min(K + 1, n_items)).nonzero().view(-1)]))
+        if tied.numel():
+            slot = torch.full((U,), -1, dtype=torch.int64, device=dev)
+            slot[tied] = torch.arange(tied.numel(), device=dev)
+            crow = ckeys // n_items
+            sel = slot[crow] >= 0
+            dense = torch.full((tied.numel(), n_items), -float('inf'), dtype=torch.float32, device=dev)
+            dense[slot[crow[sel]], (ckeys % n_items)[sel]] = cscore[sel].to(torch.float32)
+            topk_idx[tied] = self._host_topk(dense, K).to(dev)
         pos_keys = torch.sort(positive_u * n_items + positive_i).values
         rec = torch.empty((U, K + 1), dtype=torch.int32, device=dev)
         _C.check(lib.fr_eval_hits(topk_idx.data_ptr(), U, K, n_items, pos_keys.data_ptr(), pos_keys.numel(), rec.data_ptr(),

@@ -352,3 +352,34 @@ def test_compose_epoch_makes_numpys_draws(seed, n_items, n_rows, step):
     assert np.array_equal(ends, want_ends) and np.array_equal(picks[:ends[-1]], want_picks)
     np.random.set_state(('MT19937', state[:624].copy(), int(state[624]), st0[3], st0[4]))
     assert np.array_equal(np.random.randint(0, 1 << 30, 8), want_next)
+
+
+def test_host_topk_orders_equal_values_as_torch_cpu_topk_does():
+    """fr_topk_like_torch_cpu against torch.topk itself (CPU backend: the kernel the reference's evaluation ranks with,
+    collector.py:149) on rows where ties decide the list: few distinct values, the dense -inf rows of the uni100 protocol
+    (trainer.py:441-456) with clamped scores, rows that are half -inf, and both branches of ATen's kernel (k * 64 <= n:
+    partial_sort; otherwise nth_element + sort) on either side of the switch."""
+    import ctypes
+    from fairrec import _C
+    lib = _C.lib()
+    rng = np.random.default_rng(0)
+    for n, k in ((120, 5), (1683, 5), (319, 5), (320, 5), (321, 5), (64, 1), (65, 1), (1000, 10), (50, 50), (7, 3)):
+        for trial in range(40):
+            nr, kind = 6, trial % 4
+            if kind == 0:
+                rows = rng.integers(0, 3, (nr, n)).astype(np.float32)
+            elif kind == 1:
+                rows = np.full((nr, n), -np.inf, np.float32)
+                for r in range(nr):
+                    c = rng.choice(n, min(n, max(k, int(rng.integers(k, min(n, 110) + 1)))), replace=False)
+                    rows[r, c] = rng.integers(0, 2, c.size) * rng.random(c.size).astype(np.float32).round(1)
+            elif kind == 2:
+                rows = np.zeros((nr, n), np.float32)
+                rows[:, rng.choice(n, n // 2, replace=False)] = -np.inf
+            else:
+                rows = rng.random((nr, n)).astype(np.float32).round(2)
+            idx, val = np.zeros((nr, k), np.int64), np.zeros((nr, k), np.float32)
+            assert lib.fr_topk_like_torch_cpu(rows.ctypes.data, nr, n, k, idx.ctypes.data, val.ctypes.data) == 0
+            tv, ti = torch.topk(torch.from_numpy(rows), k, dim=-1)
+            np.testing.assert_array_equal(idx, ti.numpy(), err_msg=f"n {n} k {k} kind {kind}")
+            np.testing.assert_array_equal(val, tv.numpy())
