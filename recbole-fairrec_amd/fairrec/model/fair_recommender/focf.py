@@ -876,6 +876,8 @@ class FOCF(FairRecommender):
         eng = self.hip_engine()
         if not eng.can_step_many():
             return None
+        if not isinstance(sizes, int) and len(sizes) and int(max(sizes)) > _C.FR_SORT_MAX:
+            return None       # a batch no step takes: the per-batch path reports it (FairrecError), not this hook
         u, i, r, s = self._cols(interaction)
         return eng.steps_many(u, i, r, s, sizes)
 

@@ -4,6 +4,9 @@ from __future__ import annotations
 
 from logging import getLogger
 
+import torch
+
+from . import _C
 from .config import Config
 from .data.dataloader import FOCFDataLoader, TrainDataLoader
 from .data.dataset import InteractionDataset, synthetic_dataset
@@ -18,6 +21,18 @@ def split_dataset(dataset: InteractionDataset, ratios=(0.8, 0.1, 0.1)):
     mk = lambda sl: InteractionDataset(dataset.config, dataset.inter_feat[sl], dataset.user_feat, dataset.user_num,
                                        dataset.item_num)
     return mk(slice(0, a)), mk(slice(a, b)), mk(slice(b, n))
+
+
+def worst_item_complete_batch(config, train_set) -> int:
+    """Rows the largest batch FOCFDataLoader can compose from `train_set` holds: it keeps adding whole item histories until the
+    batch has reached train_batch_size rows (focf_dataloader.py:37-51), so up to train_batch_size - 1 rows plus the most rated
+    item's.  Every FOCF step sorts its batch's id columns in ONE workgroup (at most FR_SORT_MAX rows); the reference has no such
+    bound (ML-20M's most rated item alone has ~67 k ratings).  A dataset whose worst batch would not fit is trained on
+    fixed-size batches instead, loudly -- not aborted in mid-epoch."""
+    items = train_set.inter_feat[config['ITEM_ID_FIELD']]
+    if not len(items):
+        return 0
+    return int(torch.bincount(items.reshape(-1).to(torch.int64)).max().item()) + int(config['train_batch_size']) - 1
 
 
 def run_recbole(model=None, dataset=None, config_file_list=None, config_dict=None, saved=True, splits=None,
@@ -43,7 +58,15 @@ def run_recbole(model=None, dataset=None, config_file_list=None, config_dict=Non
     on_gpu = config['device'].type == 'cuda'
     # FOCF trains on item-complete batches (the reference registers FOCFDataLoader for it whatever the config says,
     # data/utils.py:181-186, :218-220); `item_grouped_batches: False` asks for plain fixed-size batches instead
-    if config['model'] == 'FOCF' and config['item_grouped_batches'] is not False:
+    focf_item_batches = config['model'] == 'FOCF' and config['item_grouped_batches'] is not False
+    if focf_item_batches:
+        worst = worst_item_complete_batch(config, train_set)
+        if worst > _C.FR_SORT_MAX:
+            logger.warning(f"FOCF: an item-complete batch of this dataset can hold {worst} rows (train_batch_size - 1 + the most "
+                           f"rated item's {worst - int(config['train_batch_size']) + 1}), more than the {_C.FR_SORT_MAX} a step "
+                           "takes; training on fixed-size batches of train_batch_size rows instead (item_grouped_batches: False)")
+            focf_item_batches = False
+    if focf_item_batches:
         # the interaction columns live on the device (a host-resident dataset costs a copy per batch: 4.3 ms per step
         # instead of 0.07 at B = 8192); which interactions form a batch stays the reference's host logic
         train_data = FOCFDataLoader(config, train_set.to(config['device']) if on_gpu else train_set, shuffle=True)

@@ -64,6 +64,7 @@ def _launch(blob: torch.Tensor, n: int, device, stream):
 _AHEAD = {}
 _SIDE = {}
 LOOKAHEAD = os.environ.get("FAIRREC_RANDPERM_AHEAD", "1") != "0"
+_WARNED = False
 
 
 def randperm(n: int, device) -> torch.Tensor:
@@ -86,14 +87,26 @@ def randperm(n: int, device) -> torch.Tensor:
     blob = torch.get_rng_state()
     cur = torch.cuda.current_stream(device)
     hit = _AHEAD.pop((n, device), None)
-    if hit is not None and torch.equal(hit[0], blob):
-        _, out, pinned_out, done, keep = hit
-        done.synchronize()                               # (long past, when an epoch of training lies in between)
-        cur.wait_event(done)
-        out.record_stream(cur)
-    else:
-        out, pinned_out, done, keep = _launch(blob, n, device, cur)
-        done.synchronize()                               # the shuffle's one host sync: 2.5 KB of generator state back
+    try:
+        if hit is not None and torch.equal(hit[0], blob):
+            _, out, pinned_out, done, keep = hit
+            done.synchronize()                               # (long past, when an epoch of training lies in between)
+            cur.wait_event(done)
+            out.record_stream(cur)
+        else:
+            out, pinned_out, done, keep = _launch(blob, n, device, cur)
+            done.synchronize()                               # the shuffle's one host sync: 2.5 KB of generator state back
+    except _C.FairrecError as e:
+        # A generator whose state blob is not at::mt19937's 5056 bytes (another torch build), or a refused launch: the same
+        # permutation is a host call away -- slower (30 ns per element), never wrong.  Said once.
+        global _WARNED
+        if not _WARNED:
+            import warnings
+            warnings.warn(f"fairrec: device randperm not available ({e}); epoch shuffles fall back to torch.randperm on the host")
+            _WARNED = True
+        _AHEAD.clear()
+        torch.set_rng_state(blob)
+        return torch.randperm(n).to(device)
     w = pinned_out.numpy().view(np.uint32)
     after = _write(blob, w[:624].copy(), int(w[624]))
     torch.set_rng_state(after)

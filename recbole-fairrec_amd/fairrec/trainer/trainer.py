@@ -641,6 +641,7 @@ class FairGoTrainer(PFCNTrainer):
         return dis_loss, filter_loss
 
     def save_pretrained_model(self, saved_model_file):
+        self._pretrain_file_written = True
         torch.save({'config': dict(self.config.final_config_dict), 'state_dict': self.model.state_dict(),
                     'optimizer': self.optimizer.state_dict(), 'other_parameter': self.model.other_parameter()},
                    saved_model_file)
@@ -655,6 +656,7 @@ class FairGoTrainer(PFCNTrainer):
             self.checkpoint_dir, '{}-{}-pretrain.pth'.format(self.config['model'], self.config['dataset']))
         self.eval_step = min(self.config['eval_step'] if self.config['eval_step'] is not None else 1, self.pretrain_epochs)
         self.optimizer = self.optimizer_pretrain
+        self._pretrain_file_written = False
         self._train_data_for_eval = train_data                        # eval_collector.data_collect(train_data), :621
         for epoch_idx in range(self.start_epoch, self.pretrain_epochs):
             t0 = time()
@@ -679,7 +681,12 @@ class FairGoTrainer(PFCNTrainer):
                     self.best_valid_result = valid_result
                 if stop_flag:
                     break
-        if os.path.exists(self.saved_pretrain_model_file):            # (the reference reads it unconditionally, :677)
+        # (the reference reads the file unconditionally, :677 -- also one an EARLIER run left in checkpoint_dir when this run wrote
+        # none: saved=False, no pretrain epoch, no improvement.  Only what this run wrote is read back; otherwise the parameters
+        # just trained enter the finetune stage, and the log says so)
+        if os.path.exists(self.saved_pretrain_model_file) and not self._pretrain_file_written:
+            self.logger.info('pretrain: %s is not of this run -- not loaded', self.saved_pretrain_model_file)
+        if os.path.exists(self.saved_pretrain_model_file) and self._pretrain_file_written:
             ck = torch.load(self.saved_pretrain_model_file, weights_only=False)
             self.model.load_state_dict(ck['state_dict'])
             self.model.load_other_parameter(ck.get('other_parameter'))

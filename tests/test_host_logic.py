@@ -383,3 +383,22 @@ def test_host_topk_orders_equal_values_as_torch_cpu_topk_does():
             tv, ti = torch.topk(torch.from_numpy(rows), k, dim=-1)
             np.testing.assert_array_equal(idx, ti.numpy(), err_msg=f"n {n} k {k} kind {kind}")
             np.testing.assert_array_equal(val, tv.numpy())
+
+
+def test_item_complete_batches_that_no_step_takes_are_seen_before_training():
+    """FOCFDataLoader's batches are sized by the data (focf_dataloader.py:37-51): with one item rated 17 000 times a batch holds
+    more rows than a FOCF step sorts (FR_SORT_MAX); quick_start sees that from the item degrees when it builds the loaders
+    (and then trains on fixed-size batches, with a warning) instead of failing in mid-epoch."""
+    from fairrec import _C
+    from fairrec.quick_start import worst_item_complete_batch
+    cfg = Config(model="FOCF", config_dict={"train_batch_size": 2048, "device": "cpu"})
+    g = torch.Generator().manual_seed(1)
+    i = torch.cat([torch.full((17000,), 7, dtype=torch.int64), torch.randint(1, 50, (3000,), generator=g)])
+    u = torch.randint(1, 100, (i.numel(),), generator=g)
+    ds = InteractionDataset(cfg, Interaction({"user_id": u, "item_id": i, "rating": torch.ones(i.numel())}),
+                            Interaction({"user_id": torch.arange(100), "gender": torch.zeros(100)}), 100, 50)
+    worst = worst_item_complete_batch(cfg, ds)
+    assert worst >= 17000 + 2047 and worst > _C.FR_SORT_MAX
+    ok = InteractionDataset(cfg, Interaction({"user_id": u[17000:], "item_id": i[17000:], "rating": torch.ones(3000)}),
+                            Interaction({"user_id": torch.arange(100), "gender": torch.zeros(100)}), 100, 50)
+    assert worst_item_complete_batch(cfg, ok) <= _C.FR_SORT_MAX
