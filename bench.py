@@ -211,6 +211,68 @@ def trainer_fit_block(dev, headline_us_per_step, steps=1024, sweep=None):
     return out
 
 
+def next_rows_block(dev, n_inter=2_000_000):
+    """The rows either side of the step, timed at the BASELINE sizes: the ranking evaluation a `fit`
+    runs after every epoch (`Trainer.evaluate` on a NegSampleEvalDataLoader, `eval_args.mode: uni100`: 100 sampled negatives
+    per positive, scores, top-k, the twelve metrics of the reference's test.yaml) and the device negative sampler on its own
+    (bit-exact numpy stream, sampler.py:145-197).  A 1024-step training epoch of the headline takes ~29 ms."""
+    from fairrec.config import Config
+    from fairrec.data.dataloader import NegSampleEvalDataLoader
+    from fairrec.data.dataset import synthetic_dataset
+    from fairrec.quick_start import split_dataset
+    from fairrec.sampler import Sampler
+    from fairrec.utils import get_model, get_trainer, init_seed
+    import tempfile
+    per_batch_users = 4096
+    cfg = Config(model="FOCF", config_dict={
+        "embedding_size": DIM, "train_batch_size": BATCH, "device": str(dev), "epochs": 1, "fair_objective": OBJECTIVE,
+        "fair_weight": FAIR_WEIGHT, "weight_decay": WD, "learning_rate": LR, "checkpoint_dir": tempfile.mkdtemp(),
+        "sst_attr_list": ["gender"], "eval_args": {"split": {"RS": [8, 1, 1]}, "group_by": "user", "order": "RO", "mode": "uni100"},
+        "metrics": ["NDCG", "Recall", "Hit", "MRR", "DifferentialFairness", "GiniIndex", "PopularityPercentage", "ValueUnfairness",
+                    "AbsoluteUnfairness", "UnderUnfairness", "OverUnfairness", "NonParityUnfairness"],
+        "valid_metric": "NDCG@5", "topk": [5], "popularity_ratio": 0.1, "eval_batch_size": per_batch_users * 101, "eval_step": 1})
+    init_seed(SEED)
+    ds = synthetic_dataset(cfg, N_USERS, N_ITEMS, n_inter, seed=SEED + 3)
+    train_set, valid_set, test_set = split_dataset(ds)
+    phases = Sampler(["train", "valid", "test"], [train_set, valid_set, test_set], "uniform", device=dev)
+    valid = NegSampleEvalDataLoader(cfg, valid_set, phases.set_phase("valid"))
+    model = get_model("FOCF")(cfg, train_set).to(dev)
+    trainer = get_trainer(None, "FOCF")(cfg, model)
+    import types
+    trainer._train_data_for_eval = types.SimpleNamespace(dataset=train_set)      # (what fit() hands the exposure metrics)
+    trainer.evaluate(valid)                        # warm-up: allocations, the lazy tables' flush
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    res = trainer.evaluate(valid)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    users, rows = len(valid.uid_list), len(valid_set) * 101
+    out = {"eval_uni100": {"path": "Trainer.evaluate -> NegSampleEvalDataLoader (device sampler) -> FOCF.predict -> Collector -> Evaluator",
+                           "users": users, "positives": len(valid_set), "scored_rows": rows, "batches": len(valid),
+                           "users_per_batch": valid.step, "ms_per_evaluation": round(dt * 1e3, 2),
+                           "ms_per_batch": round(dt / max(len(valid), 1) * 1e3, 3), "users_per_s": round(users / dt, 1),
+                           "scored_rows_per_s": round(rows / dt, 1), "ndcg@5": float(res["ndcg@5"])}}
+    # the sampler on its own: 100 negatives for each of 8192 x 16 users per call, used-item sets of the training phase
+    smp = phases.set_phase("train")
+    g = torch.Generator(device="cpu").manual_seed(SEED + 4)
+    uids = torch.randint(1, N_USERS, (BATCH * 16,), generator=g).to(dev)
+    smp.sample_by_user_ids(uids, uids, 100)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    reps = 10
+    for _ in range(reps):
+        neg = smp.sample_by_user_ids(uids, uids, 100)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out["sampler"] = {"path": "Sampler.sample_by_user_ids (fr_sample_negatives: numpy's MT19937 stream + masked rejection on the device, "
+                              "re-draw rounds against the users' used-item sets)",
+                      "item_num": N_ITEMS, "negatives_per_call": int(neg.numel()), "ms_per_call": round(dt / reps * 1e3, 3),
+                      "negatives_per_s": round(reps * neg.numel() / dt, 1)}
+    del trainer, model, valid, phases
+    torch.cuda.empty_cache()
+    return out
+
+
 def other_workloads_block(args, dev, budget_s=None):
     """BASELINE.json configs[2], [3], [4] under the same clock as the FOCF line (the driver runs ONE command): each workload of
     `--workload pfcn10m | fairgo10m | nfcf100m` at its full table size, >= 20 timed steps, reduced to the figures a reader
@@ -926,6 +988,10 @@ def main():
             # slower than any stretch of an epoch does; the block says how many steps it timed)
             out["other_batch_shapes"] = [focf_shape_block(d, max(K, 200), W, dev, args.sweep) for d in ("grouped", "zipf")]
             out["trainer_fit"] = trainer_fit_block(dev, dt / K * 1e6, sweep=args.sweep)
+            try:
+                out["next_rows"] = next_rows_block(dev)
+            except Exception as e:      # (orientation figures: a failure here must not cost the line)
+                out["next_rows"] = {"error": f"{type(e).__name__}: {e}"}
             if not args.no_workloads:
                 out["other_workloads"] = other_workloads_block(args, dev)
         if not args.no_cpu_baseline and world == 1:

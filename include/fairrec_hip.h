@@ -827,6 +827,12 @@ FR_API int fr_adam_dense_multi(const fr_dense_desc* descs, int32_t n_tensors, co
  *                         (general_dataloader.py:141-146).  max_call >= the longest call (sizes the workspace). */
 FR_API int fr_mt19937_seed(uint32_t* state, uint32_t seed, void* stream);
 FR_API size_t fr_sample_negatives_workspace_bytes(int64_t total);
+/* ... for fr_sample_negatives_calls: with this much workspace (`total` = values of the whole sequence) a sequence of 16 or more
+ * calls is resolved SPECULATIVELY -- the stream's accepted values generated once, every call laid out as if none before it
+ * had collided with its used-set, the rare colliding call resolved round by round and the rest shifted (csrc/sampler.hip) --
+ * instead of call by call: the same values and the same generator state, 30 ms -> ~1.5 ms for the ~2 800 calls of an
+ * evaluation batch.  With fr_sample_negatives_workspace_bytes(max_call) bytes the calls run one after the other. */
+FR_API size_t fr_sample_negatives_calls_workspace_bytes(int64_t total, int64_t max_call);
 FR_API int fr_sample_negatives(uint32_t* state, int64_t low, int64_t high, const int64_t* key_ids, int64_t n_keys,
                                int32_t num, const int64_t* used_indptr, const int32_t* used_items, int64_t n_users,
                                int64_t* out, int32_t* rounds_out, void* ws, size_t ws_bytes, uint32_t* err_flag,
@@ -849,52 +855,6 @@ FR_API int fr_frontier_expand(const int64_t* indptr, const int32_t* col, const i
 FR_API int fr_frontier_count(const uint32_t* bits, int64_t n_rows, int32_t* count, void* stream);
 FR_API int fr_frontier_scatter(const uint32_t* bits, const int32_t* incl, int64_t n_rows, int32_t* rows_out, int32_t* pos,
                                void* stream);
-
-/* ---- an MLP with BatchNorm behind every layer, one launch per layer and direction (csrc/mlp_bn.hip) -----------------------------
- * Replaces, for MLPLayers(..., bn=True) (layers.py:56-85; pfcn_biasedmf.py:113-142: PFCN's filters and discriminators), the
- * three launches per layer forward and four backward of fr_linear_fwd_bnstats / fr_bn_fwd_ex / fr_bn_bwd / fr_linear_bwd_input:
- * a layer is NORMALISED BY THE LAUNCH THAT CONSUMES IT.  fr_bn_src describes an [M, width] activation that such a launch forms
- * while loading it: act(gamma (Z - mean) invstd + beta) from the pre-BatchNorm output Z of the layer below and that layer's
- * folded statistics fin = [width][2] (mean, 1 / sqrt(var + eps)) -- or Z as it is when fin == NULL (the MLP's input) -- with
- * dropout (csrc/dropout.hpp's stream: seed, the pass's call counter, element offset drop_off, a multiple of 4) on top when
- * drop_p > 0.
- *   fr_bnl_fwd      Z[M, N] = in W^T + bias; A_out (may be NULL) = the formed input, kept for the weight gradient; the layer's
- *                   statistics -> fin_out [N][2], running_mean / running_var (momentum; may be NULL), *nbt += nbt_inc.
- *                   drop_state / drop_used / drop_tick as fr_dropout_apply's `state`, `used_out`, `tick`.
- *   fr_bnl_out      Y[M, N] = the formed activation (the MLP's output).
- *   fr_bnl_bwd_top  sums [N][2] = column sums of dY s and dY s xhat for the top layer (s = act'(y); = dbeta, dgamma, also written
- *                   to dbeta / dgamma when not NULL).
- *   fr_bnl_bwd      G[M, N] = the gradient at the output y of layer `self` (Z, fin, gamma, beta, act): dY for the top layer, the
- *                   dA of the call above otherwise.  dZ = invstd gamma (G s - sum(G s) / M - xhat sum(G s xhat) / M) -> dZ_out
- *                   (may be NULL); dA[M, K] = dZ W back through the dropout of the layer's input (below->drop_*; drop_used =
- *                   the counter value fr_bnl_fwd recorded); with below->Z != NULL also the sums of the layer below (from dA
- *                   and that layer's Z) -> sums_below / dgamma_below / dbeta_below.
- * ws: fr_bnl_workspace_bytes(M, width of the statistics written); ticket: TWO zero-initialised device words the launches of a
- * stream share (zero again when a launch ends).  Widths: K % 32 == 0, K, N <= 256, otherwise FR_EUNSUPPORTED (the
- * layered entries take every shape).  The same operations in the same order as the layered form (csrc/mlp_bn_math.hpp, the
- * products' summation order, the statistics' chunks): bit-identical where both forms apply (every width a multiple of 32), and
- * the same dropout patterns (tests/test_mlp_hip.py). */
-typedef struct fr_bn_src {
-    const float* Z;
-    const float* fin;
-    const float* gamma;
-    const float* beta;
-    int32_t act;
-    float drop_p;
-    uint64_t drop_seed;
-    uint64_t drop_off;
-} fr_bn_src;
-FR_API size_t fr_bnl_workspace_bytes(int64_t M, int32_t width);
-FR_API int fr_bnl_fwd(const fr_bn_src* in, int64_t M, int32_t K, const float* W, const float* bias, int32_t N, float* Z, float* A_out,
-                      float eps, float momentum, float* running_mean, float* running_var, int64_t* nbt, int32_t nbt_inc,
-                      float* fin_out, void* ws, size_t ws_bytes, uint32_t* ticket, const uint64_t* drop_state, uint64_t* drop_used,
-                      uint64_t* drop_tick, void* stream);
-FR_API int fr_bnl_out(const fr_bn_src* src, int64_t M, int32_t N, float* Y, void* stream);
-FR_API int fr_bnl_bwd_top(const float* dY, const fr_bn_src* top, int64_t M, int32_t N, float* sums, float* dgamma, float* dbeta,
-                          void* ws, size_t ws_bytes, uint32_t* ticket, void* stream);
-FR_API int fr_bnl_bwd(const float* G, const fr_bn_src* self, const float* sums, int64_t M, int32_t N, const float* W, int32_t K,
-                      float* dZ_out, const fr_bn_src* below, const uint64_t* drop_used, float* dA, float* sums_below,
-                      float* dgamma_below, float* dbeta_below, void* ws, size_t ws_bytes, uint32_t* ticket, void* stream);
 
 /* ---- FOCF's item-complete batcher (next-row f-3): the picks of a whole epoch in one HOST call ---------------------------------
  * focf_dataloader.py:37-51 composes a batch by `np.random.choice(select_item[is_select], 1, False)` per picked item: numpy's

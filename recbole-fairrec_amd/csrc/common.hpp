@@ -341,17 +341,4 @@ __device__ __forceinline__ void replay2(RowFrag<E>& p0, RowFrag<E>& m0, RowFrag<
     replay_n<E, 2>(pp, mm, vv, from, to, c);
 }
 
-// four rows over one stretch of steps: two packed pairs whose chains are independent of each other -- the wait states a
-// transcendental's consumer needs (an s_nop after every v_sqrt / v_rcp pair of a lone chain: 4 of 13 issue slots per step)
-// are filled by the other pair's instructions
-template <int E>
-__device__ __forceinline__ void replay4(RowFrag<E>& p0, RowFrag<E>& m0, RowFrag<E>& v0, RowFrag<E>& p1, RowFrag<E>& m1,
-                                        RowFrag<E>& v1, RowFrag<E>& p2, RowFrag<E>& m2, RowFrag<E>& v2, RowFrag<E>& p3,
-                                        RowFrag<E>& m3, RowFrag<E>& v3, int from, int to, const AdamC& c) {
-    RowFrag<E>* pp[4] = {&p0, &p1, &p2, &p3};
-    RowFrag<E>* mm[4] = {&m0, &m1, &m2, &m3};
-    RowFrag<E>* vv[4] = {&v0, &v1, &v2, &v3};
-    replay_n<E, 4>(pp, mm, vv, from, to, c);
-}
-
 }  // namespace fr

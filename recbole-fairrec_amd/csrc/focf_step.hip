@@ -42,22 +42,6 @@ namespace fr {
 #define FR_STEP_WPB 4        // waves (= tasks) per workgroup: the granule the hardware dispatcher hands to a CU
 #endif
 constexpr int STEP_WPB = FR_STEP_WPB;
-// Two A/B switches of round 5, both measured SLOWER and off (the code stays for the record; DESIGN.md section 3a, "Round 5"):
-// the replay of a lone packed pair issues an s_nop behind every transcendental pair (4 of 13 issue slots per step), and a
-// wave that carries TWO independent pairs fills them (scratch/valu_rates.hip, scratch/replay_bench.hip: 69 -> 57 cycles per
-// pair and step with one wave per SIMD) -- but at the six waves per SIMD this kernel runs with, the other waves fill those
-// slots already: FR_SWEEP_QUAD (a sweeper wave takes two pairs of rows, neighbours in the start order: half as many,
-// twice as long sweeper tasks) 29.2-29.5 -> 32.7 us per step, FR_INTER_JOINT (an interaction wave replays its item pair
-// beside the last steps of its user pair) 29.2-29.5 -> 29.6-29.9.
-#ifndef FR_SWEEP_QUAD
-#define FR_SWEEP_QUAD 0
-#endif
-#ifndef FR_INTER_JOINT
-#define FR_INTER_JOINT 0
-#endif
-__host__ __device__ constexpr bool sweep_quad(int E) { return FR_SWEEP_QUAD && E <= 1; }
-// sweeper tasks (waves) for a slice of n_pairs pairs of rows
-__host__ __device__ constexpr long long sweep_tasks(long long n_pairs, int E) { return sweep_quad(E) ? (n_pairs + 1) / 2 : n_pairs; }
 
 // Kernel arguments, kept to what the common path reads (every pointer is two SGPRs that stay live across the whole
 // kernel; 256-thread workgroups are admitted 8 per CU only up to 80 SGPRs): the rare path derives the other workspace
@@ -772,44 +756,6 @@ __device__ __forceinline__ void replay_two(TwoRows<E>& r, int tA, int tB, int up
     r = replay_two_v<E>(r, tA, tB, upto, c, lane);
 }
 
-// Two pairs of rows (x: rows A and B, y: rows A and B) brought to `upto` TOGETHER: inside each pair the older row catches up
-// with the younger one alone, the older pair then runs until the younger pair starts, and from there all four rows go
-// through the steps as two independent packed chains (replay4: the other pair's instructions fill the wait states behind
-// every transcendental of a lone chain -- 69 -> ~57 SIMD cycles per pair and step, scratch/valu_rates.hip).  Row by row
-// the same operations as replay_two on each pair, cut into stretches at other steps (rounding of the moment scaling only).
-template <int E>
-__device__ __forceinline__ void replay_two_pairs(TwoRows<E>& x, TwoRows<E>& y, int txA, int txB, int tyA, int tyB, int upto,
-                                                 const AdamC& c, int lane) {
-    txA = txA < upto ? txA : upto; txB = txB < upto ? txB : upto;
-    tyA = tyA < upto ? tyA : upto; tyB = tyB < upto ? tyB : upto;
-    auto level = [&](TwoRows<E>& r, int tA, int tB) {       // the older row of a pair up to the younger one's step
-        if (tA == tB) return;
-        const bool a_old = tA < tB;
-        RowFrag<E> p, m, v;
-#pragma unroll
-        for (int e = 0; e < E; ++e) {
-            p.x[e] = a_old ? r.pA.x[e] : r.pB.x[e];
-            m.x[e] = a_old ? r.mA.x[e] : r.mB.x[e];
-            v.x[e] = a_old ? r.vA.x[e] : r.vB.x[e];
-        }
-        replay<E>(p, m, v, a_old ? tA : tB, a_old ? tB : tA, c, lane);
-#pragma unroll
-        for (int e = 0; e < E; ++e) {
-            if (a_old) {
-                r.pA.x[e] = p.x[e]; r.mA.x[e] = m.x[e]; r.vA.x[e] = v.x[e];
-            } else {
-                r.pB.x[e] = p.x[e]; r.mB.x[e] = m.x[e]; r.vB.x[e] = v.x[e];
-            }
-        }
-    };
-    level(x, txA, txB);
-    level(y, tyA, tyB);
-    const int sx = txA > txB ? txA : txB, sy = tyA > tyB ? tyA : tyB;
-    if (sx < sy) replay2<E>(x.pA, x.mA, x.vA, x.pB, x.mB, x.vB, sx, sy, c, lane);
-    else if (sy < sx) replay2<E>(y.pA, y.mA, y.vA, y.pB, y.mB, y.vB, sy, sx, c, lane);
-    replay4<E>(x.pA, x.mA, x.vA, x.pB, x.mB, x.vB, y.pA, y.mA, y.vA, y.pB, y.mB, y.vB, sx > sy ? sx : sy, upto, c);
-}
-
 // ---- rare path ----------------------------------------------------------------------------------------------------
 // The last wave to arrive at a user segment: sum the members' gradient rows coef[b] * (item row of b before its update),
 // one Adam step on the user's caught-up row (parked by its first member), write back.
@@ -1288,72 +1234,6 @@ __device__ __forceinline__ void step_task(KV kv, bool sweeper, int q, int n_pair
     const int D = FULL ? 64 * E : KA(D);
     TwoRows<E> r;
     int tA, tB;
-    if (sweeper && sweep_quad(E)) {
-        // ---- TWO pairs of rows per sweeper wave: neighbours in the start order (= alike replay lengths), so that their
-        // common stretch -- nearly all of it -- runs as two independent packed chains (replay_two_pairs)
-        int q0 = 2 * q, q1 = 2 * q + 1 < n_pairs ? 2 * q + 1 : 2 * q;
-        const bool has1 = 2 * q + 1 < n_pairs;
-        if (const int32_t* so = order0) {
-            const int o0 = so[q0], o1 = so[q1], on = so[n_pairs];
-            const bool use = uniform(on) == n_pairs;
-            q0 = use ? uniform(o0) : q0;
-            q1 = use ? uniform(o1) : q1;
-        }
-        const int pairs_u = (KA(n_u) + 1) >> 1;
-        const int upto = KA(step), skip = KA(skip_from);
-        struct PairAt { long long rowA, rowB; float *Tp, *Tm, *Tv; int32_t* Tl; const int32_t* Ts; bool hasB; };
-        auto at = [&](int qq) {
-            const bool inU = qq < pairs_u;
-            const int k = inU ? qq : qq - pairs_u;
-            PairAt a;
-            a.rowA = (inU ? KA(lo_u) : KA(lo_i)) + 2 * k;
-            a.hasB = 2 * k + 1 < (inU ? KA(n_u) : KA(n_i));
-            a.rowB = a.hasB ? a.rowA + 1 : a.rowA;
-            a.Tp = inU ? KA(Up) : KA(Ip); a.Tm = inU ? KA(Um) : KA(Im); a.Tv = inU ? KA(Uv) : KA(Iv);
-            a.Tl = inU ? KA(Ulast) : KA(Ilast); a.Ts = inU ? KA(Ustamp) : KA(Istamp);
-            return a;
-        };
-        const PairAt a0 = at(q0), a1 = at(q1);
-        TwoRows<E> y;
-        // stamps, `last` and the rows of both pairs in ONE round trip
-        const int s0a = gp(a0.Ts)[a0.rowA], s0b = gp(a0.Ts)[a0.rowB], s1a = gp(a1.Ts)[a1.rowA], s1b = gp(a1.Ts)[a1.rowB];
-        const int l0a = gp((const int32_t*)a0.Tl)[a0.rowA], l0b = gp((const int32_t*)a0.Tl)[a0.rowB];
-        const int l1a = gp((const int32_t*)a1.Tl)[a1.rowA], l1b = gp((const int32_t*)a1.Tl)[a1.rowB];
-        ldrow<E, FULL>(r.pA, a0.Tp + (size_t)a0.rowA * D, D, lane);
-        ldrow<E, FULL>(r.mA, a0.Tm + (size_t)a0.rowA * D, D, lane);
-        ldrow<E, FULL>(r.vA, a0.Tv + (size_t)a0.rowA * D, D, lane);
-        ldrow<E, FULL>(r.pB, a0.Tp + (size_t)a0.rowB * D, D, lane);
-        ldrow<E, FULL>(r.mB, a0.Tm + (size_t)a0.rowB * D, D, lane);
-        ldrow<E, FULL>(r.vB, a0.Tv + (size_t)a0.rowB * D, D, lane);
-        ldrow<E, FULL>(y.pA, a1.Tp + (size_t)a1.rowA * D, D, lane);
-        ldrow<E, FULL>(y.mA, a1.Tm + (size_t)a1.rowA * D, D, lane);
-        ldrow<E, FULL>(y.vA, a1.Tv + (size_t)a1.rowA * D, D, lane);
-        ldrow<E, FULL>(y.pB, a1.Tp + (size_t)a1.rowB * D, D, lane);
-        ldrow<E, FULL>(y.mB, a1.Tm + (size_t)a1.rowB * D, D, lane);
-        ldrow<E, FULL>(y.vB, a1.Tv + (size_t)a1.rowB * D, D, lane);
-        const int t0a = uniform(s0a) >= skip ? upto : uniform(l0a);
-        const int t0b = (!a0.hasB || uniform(s0b) >= skip) ? upto : uniform(l0b);
-        const int t1a = (!has1 || uniform(s1a) >= skip) ? upto : uniform(l1a);
-        const int t1b = (!has1 || !a1.hasB || uniform(s1b) >= skip) ? upto : uniform(l1b);
-        replay_two_pairs<E>(r, y, t0a, t0b, t1a, t1b, upto, c, lane);
-        auto put = [&](const PairAt& a, bool doA, bool doB, const TwoRows<E>& w) {
-            if (doA) {
-                store_trow<E, FULL>(w.pA, a.Tp + (size_t)a.rowA * D, D, lane);
-                store_trow<E, FULL>(w.mA, a.Tm + (size_t)a.rowA * D, D, lane);
-                store_trow<E, FULL>(w.vA, a.Tv + (size_t)a.rowA * D, D, lane);
-                if (lane == 0) store_word(a.Tl + a.rowA, upto);
-            }
-            if (doB) {
-                store_trow<E, FULL>(w.pB, a.Tp + (size_t)a.rowB * D, D, lane);
-                store_trow<E, FULL>(w.mB, a.Tm + (size_t)a.rowB * D, D, lane);
-                store_trow<E, FULL>(w.vB, a.Tv + (size_t)a.rowB * D, D, lane);
-                if (lane == 0) store_word(a.Tl + a.rowB, upto);
-            }
-        };
-        put(a0, t0a < upto, t0b < upto, r);
-        put(a1, t1a < upto, t1b < upto, y);
-        return;
-    }
     if (sweeper) {
         // start order of the slice's pairs (fr_focf_prepare_step: longest estimated replay first, so that the four waves
         // of a workgroup -- one per SIMD of its CU -- carry alike loads and the launch ends on its shortest tasks); an
@@ -1433,12 +1313,8 @@ __device__ __forceinline__ void step_task(KV kv, bool sweeper, int q, int n_pair
         g_phase[0] = __builtin_amdgcn_s_memrealtime();     // rows have arrived
         g_phase[3] = (unsigned long long)((upto - tu0) + (upto - tu1) + (upto - ti0) + (upto - ti1));
 #endif
-#if FR_INTER_JOINT
-        replay_two_pairs<E>(r, it, tu0, tu1, ti0, ti1, upto, c, lane);      // the item pair's stretch beside the user pair's last steps
-#else
         replay_two<E>(r, tu0, tu1, upto, c, lane);
         replay_two<E>(it, ti0, ti1, upto, c, lane);
-#endif
 #if FR_STEP_TRACE
         g_phase[1] = __builtin_amdgcn_s_memrealtime();     // replay done
 #endif
@@ -1532,7 +1408,7 @@ __global__ __launch_bounds__(64 * STEP_WPB, step_waves(E)) void focf_step_kernel
         kv.v1 = lane < (int)(sizeof(StepArgs) / 4) - 64 ? kp[STEP_PRELOAD_DWORDS + 64 + lane] : 0u;
         const int x = (int)blockIdx.x - 1 - ((int)blockIdx.x >= stage0 ? n_stage : 0);
         const int n_pairs = ((pre_nu + 1) >> 1) + ((pre_ni + 1) >> 1);
-        const int n_sweep = (int)sweep_tasks(n_pairs, E);
+        const int n_sweep = n_pairs;      // one sweeper task (wave) per pair of rows
         const int ns = (n_sweep + STEP_WPB - 1) / STEP_WPB;
         // longest jobs first: the `lead` workgroups of the interactions with the longest replays (the task list is in
         // that order), then the sweeper workgroups (a full period of replay each), then the other interactions
@@ -2038,7 +1914,7 @@ static int focf_step_impl(const fr_table* U, const fr_table* I, const fr_adam* a
         ProfScope prof(K_FOCF_STEP, stream);
         const long long per_wave = step_pairs((U->dim + 63) / 64) ? 2 : 1;
         const long long inter_blocks = ((B + per_wave - 1) / per_wave + STEP_WPB - 1) / STEP_WPB;
-        const long long sweep_wg = (sweep_tasks(sweep_waves, (U->dim + 63) / 64) + STEP_WPB - 1) / STEP_WPB;
+        const long long sweep_wg = (sweep_waves + STEP_WPB - 1) / STEP_WPB;
         const unsigned blocks = (unsigned)(1 + st.nb_claim + st.nb_sa + st.nb_place + st.nb_sb + sweep_wg + inter_blocks);
         a.lead = (int)(inter_blocks * lead_pct / 100);
         const dim3 block(64 * STEP_WPB);

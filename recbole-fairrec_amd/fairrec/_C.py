@@ -50,11 +50,6 @@ class FrWgradJob(Structure):    # include/fairrec_hip.h: fr_wgrad_job
                 ("dW", c_void_p), ("db", c_void_p), ("parts", c_void_p), ("n_parts", c_int32)]
 
 
-class FrBnSrc(Structure):       # include/fairrec_hip.h: fr_bn_src
-    _fields_ = [("Z", c_void_p), ("fin", c_void_p), ("gamma", c_void_p), ("beta", c_void_p), ("act", c_int32),
-                ("drop_p", c_float), ("drop_seed", c_uint64), ("drop_off", c_uint64)]
-
-
 class FrFocfBatch(Structure):
     _fields_ = [("user", c_void_p), ("item", c_void_p), ("sst", c_void_p), ("B", c_int64), ("ws", c_void_p),
                 ("ws_bytes", c_size_t), ("rating", c_void_p)]
@@ -141,6 +136,7 @@ _PROTOS = {
                                         c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p]),
     "fr_mt19937_seed": (c_int, [c_void_p, c_uint32, c_void_p]),
     "fr_sample_negatives_workspace_bytes": (c_size_t, [c_int64]),
+    "fr_sample_negatives_calls_workspace_bytes": (c_size_t, [c_int64, c_int64]),
     "fr_sample_negatives": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_int64,
                                     c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
     "fr_eval_hits": (c_int, [c_void_p, c_int64, c_int32, c_int64, c_void_p, c_int64, c_void_p, c_void_p]),
@@ -232,15 +228,6 @@ _PROTOS = {
     "fr_frontier_expand": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "fr_frontier_count": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     "fr_frontier_scatter": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
-    "fr_bnl_workspace_bytes": (c_size_t, [c_int64, c_int32]),
-    "fr_bnl_fwd": (c_int, [POINTER(FrBnSrc), c_int64, c_int32, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_float, c_float,
-                           c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p,
-                           c_void_p, c_void_p]),
-    "fr_bnl_out": (c_int, [POINTER(FrBnSrc), c_int64, c_int32, c_void_p, c_void_p]),
-    "fr_bnl_bwd_top": (c_int, [c_void_p, POINTER(FrBnSrc), c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
-                               c_void_p, c_void_p]),
-    "fr_bnl_bwd": (c_int, [c_void_p, POINTER(FrBnSrc), c_void_p, c_int64, c_int32, c_void_p, c_int32, c_void_p, POINTER(FrBnSrc),
-                           c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
     "fr_bn_workspace_bytes": (c_size_t, [c_int64, c_int32]),
     "fr_linear_fwd_bnstats": (c_int, [c_void_p, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p,
                                       c_size_t, c_void_p]),

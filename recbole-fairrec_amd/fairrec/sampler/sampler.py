@@ -91,7 +91,12 @@ class DeviceRandomState:
         total, max_call = int(offsets[-1].item()), int(counts.max().item()) if counts.numel() else 0
         out = torch.empty(total, dtype=torch.int64, device=self.device)
         if total:
-            ws = self._workspace(max_call)
+            # (room for the speculative form of a long call sequence: csrc/sampler.hip, sample_calls_fast_kernel)
+            need = max(_C.lib().fr_sample_negatives_calls_workspace_bytes(total, max_call),
+                       _C.lib().fr_sample_negatives_workspace_bytes(max_call))
+            if self._ws is None or self._ws.numel() < need:
+                self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            ws = self._ws
             _C.check(_C.lib().fr_sample_negatives_calls(self.state.data_ptr(), low, high, call_keys.data_ptr(),
                                                         offsets.data_ptr(), call_keys.numel(), max_call,
                                                         used_indptr.data_ptr(), used_items.data_ptr(),

@@ -249,6 +249,43 @@ def test_multi_call_sampling_equals_consecutive_single_key_calls():
     assert st[2] == ors.pos
 
 
+@pytest.mark.parametrize("heavy_share", [0.0, 0.05, 0.6], ids=["sparse", "some_heavy", "mostly_heavy"])
+def test_long_call_sequences_resolved_speculatively_equal_consecutive_calls(heavy_share):
+    """A sequence of hundreds of single-key calls (an evaluation batch: general_dataloader.py:141-146) takes the speculative
+    form of csrc/sampler.hip -- accepted values generated once, every call laid out as if none before it had collided, the
+    colliding ones resolved round by round and everything behind them shifted.  Against consecutive calls on one numpy stream
+    (oracle): the same values AND the same generator state afterwards -- with no collisions at all, with a few users whose
+    used-set leaves 4 items (every call of theirs collides for rounds on end), and with so many of those that the slack of
+    accepted values runs out and the kernel falls back to call-by-call consumption from the incoming state."""
+    from fairrec.sampler import Sampler
+    from oracle import sampler as OS
+    rng = np.random.default_rng(11)
+    user_num, item_num, n_calls = 400, 300, 600
+    u = rng.integers(1, user_num, 1500).astype(np.int64)
+    i = rng.integers(1, item_num, 1500).astype(np.int64)
+    heavy_users = rng.choice(np.arange(1, user_num), int(heavy_share * (user_num - 1)), replace=False)
+    for hu in heavy_users:
+        left = rng.choice(np.arange(1, item_num), 4, replace=False)
+        hv = np.setdiff1d(np.arange(1, item_num), left)
+        u, i = np.concatenate([u, np.full(len(hv), hu)]), np.concatenate([i, hv])
+    used = [set() for _ in range(user_num)]
+    for a, b in zip(u, i):
+        used[a].add(int(b))
+    rs, ors = _rs(77), OS.MT19937(77)
+    smp = Sampler("test", _DS(user_num, item_num, u, i), device="cuda", random_state=rs).set_phase("test")
+    indptr, items, _ = smp.used_ids
+    keys = rng.integers(1, user_num, n_calls).astype(np.int64)
+    counts = (rng.integers(0, 4, n_calls) * 100).astype(np.int64)            # 0-3 positives x 100 negatives
+    for rep in range(2):                                                     # (twice: the stream continues across launches)
+        got = rs.sample_calls(1, item_num, torch.from_numpy(keys), torch.from_numpy(counts), indptr, items).cpu().numpy()
+        ref = [OS.sample_by_key_ids(ors, np.full(c // 100, k), 100, used, item_num) for k, c in zip(keys, counts) if c]
+        np.testing.assert_array_equal(got, np.concatenate(ref))
+        st = rs.get_state()
+        np.testing.assert_array_equal(st[1], ors.key)
+        assert st[2] == ors.pos
+    rs.check_device_errors() if hasattr(rs, "check_device_errors") else None
+
+
 @pytest.mark.parametrize("n", [2, 3, 10, 623, 624, 625, 1000, 624 * 3 + 5, 70_001, 8192 * 1024 + 77])
 def test_device_randperm_is_torch_randperm(n):
     """fr_randperm (the epoch shuffle of interaction.py:293-297 computed on the device) against torch.randperm itself, from
