@@ -894,6 +894,15 @@ FR_API int fr_randperm(uint32_t* state, int64_t n, int64_t* out, void* ws, size_
  * positives.  pos_keys = the sorted keys row * n_items + item of the batch's positives (no dense 0/1 matrix). */
 FR_API int fr_eval_hits(const int64_t* topk_idx, int64_t n_rows, int32_t k, int64_t n_items, const int64_t* pos_keys,
                         int64_t n_pos, int32_t* rec_topk, void* stream);
+/* fr_eval_topk_segments: the ranked lists of an evaluation batch under the uniN protocol (trainer.py:441-456 + collector.py:149).
+ * User row u's candidates are rows [seg_start[u], seg_start[u+1]) of the batch (items int64, scores float); topk_idx int64
+ * [n_users, k] = its k best DISTINCT items, best first, padded with 0; flags int32 [n_users]: bit 0 = two of its first k + 1
+ * entries score equal (rank that row with fr_topk_like_torch_cpu), bit 1 = fewer than k + 1 distinct candidates.  1 <= k <= 62.
+ * fr_eval_lookup_segments: out[q] = the score of item q_items[q] among user row q_rows[q]'s candidates, -inf if absent. */
+FR_API int fr_eval_topk_segments(const int64_t* seg_start, int64_t n_users, const int64_t* items, const float* scores,
+                                 int32_t k, int64_t* topk_idx, int32_t* flags, void* stream);
+FR_API int fr_eval_lookup_segments(const int64_t* seg_start, int64_t n_users, const int64_t* items, const float* scores,
+                                   const int64_t* q_rows, const int64_t* q_items, int64_t n_q, float* out, void* stream);
 /* fr_topk_like_torch_cpu (HOST, no stream): torch.topk(rows, k, dim=-1) of the CPU backend with ITS order among equal values --
  * what the reference's evaluation ranks with (collector.py:149 on the dense -inf matrix of trainer.py:441-456).  rows: float
  * [n_rows, n] in host memory; idx_out int64 [n_rows, k] (val_out float [n_rows, k], optional).  For the user rows whose list

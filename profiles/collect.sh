@@ -11,25 +11,27 @@
 # Raw output lands in gpurun_out/<round>/ (scratch); `python profiles/summarize.py <round>` then writes the
 # tracked summaries into profiles/.
 set -u
-ROUND=${1:-r05}
+ROUND=${1:-r06}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$ROUND
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --no-cpu-baseline > $OUT/bench_under_rocprof.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --no-cpu-baseline --no-workloads > $OUT/bench_under_rocprof.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $R/profiles/pmc_workload.py > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $R/profiles/pmc_workload.py > $OUT/pmc_write.log 2>&1
 grep -h '^{' $OUT/bench_under_rocprof.log | tail -1 > $OUT/bench_line.json
-rocprofv3 --kernel-trace --output-format csv -d $OUT/trace -- python3 $R/bench.py --no-cpu-baseline --graph-only > $OUT/trace.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $OUT/trace -- python3 $R/bench.py --no-cpu-baseline --graph-only --no-workloads > $OUT/trace.log 2>&1
 python3 $R/profiles/trace_window.py $OUT/trace 200 > $OUT/graph_window.txt 2>&1
 cd $R
 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
-python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_steps20.json 2> $OUT/bench_steps20.err
+python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-workloads > $OUT/bench_steps20.json 2> $OUT/bench_steps20.err
+# (round 6: the headline is the library's step loop; the item-complete variants below keep rounds 4-5's hipGraph replay so that
+# their numbers stay comparable, the library-loop figure of each shape is in bench.json's other_batch_shapes)
 python3 bench.py --no-cpu-baseline --graph-only --item-dist zipf > $OUT/bench_zipf.json 2>/dev/null
-python3 bench.py --no-cpu-baseline --graph-only --item-dist grouped > $OUT/bench_grouped_pipe.json 2>/dev/null
-FAIRREC_FOCF_PIPE=0 python3 bench.py --no-cpu-baseline --graph-only --item-dist grouped > $OUT/bench_grouped_runs.json 2>/dev/null
-FAIRREC_FOCF_RUNS=0 python3 bench.py --no-cpu-baseline --graph-only --item-dist grouped > $OUT/bench_grouped_chain.json 2>/dev/null
-python3 bench.py --no-cpu-baseline --graph-only --item-dist grouped --force-fused > $OUT/bench_grouped_fused.json 2>/dev/null
+python3 bench.py --no-cpu-baseline --graph-only --launch graph --item-dist grouped > $OUT/bench_grouped_pipe.json 2>/dev/null
+FAIRREC_FOCF_PIPE=0 python3 bench.py --no-cpu-baseline --graph-only --launch graph --item-dist grouped > $OUT/bench_grouped_runs.json 2>/dev/null
+FAIRREC_FOCF_RUNS=0 python3 bench.py --no-cpu-baseline --graph-only --launch graph --item-dist grouped > $OUT/bench_grouped_chain.json 2>/dev/null
+python3 bench.py --no-cpu-baseline --graph-only --launch graph --item-dist grouped --force-fused > $OUT/bench_grouped_fused.json 2>/dev/null
 python3 bench.py --workload pfcn10m --steps 20 --warmup 5 > $OUT/pfcn10m.json 2> $OUT/pfcn10m.err
 python3 bench.py --workload nfcf100m --steps 20 --warmup 5 > $OUT/nfcf100m.json 2> $OUT/nfcf100m.err
 python3 bench.py --workload nfcf100m --nfcf-users 1000001 --nfcf-items 100001 --steps 20 --warmup 5 > $OUT/nfcf1m.json 2> $OUT/nfcf1m.err
@@ -50,4 +52,6 @@ make -C $R/recbole-fairrec_amd/csrc VARIANT=trace EXTRA=-DFR_STEP_TRACE=1 -j8 > 
 if [ -f $R/scratch/lib/libfairrec_hip_trace.so ]; then
   cd $R && FAIRREC_HIP_LIB=$R/scratch/lib/libfairrec_hip_trace.so python3 scratch/step_trace.py > $OUT/wave_trace.txt 2>&1
 fi
+# 9) round 6: where an evaluation batch's time goes
+python3 scratch/eval_probe.py 500000 > $OUT/eval_probe.txt 2>&1
 ls $OUT | head -60

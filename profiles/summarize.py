@@ -76,7 +76,7 @@ print("\n".join(lines))
 
 # ---- round 3: plain bench lines, the other workloads, MFMA counters, the wave timeline -------------------------------------
 for name in ("bench.json", "bench_steps20.json", "bench_zipf.json", "bench_grouped_pipe.json", "bench_grouped_runs.json", "bench_grouped_chain.json", "bench_grouped_fused.json",
-             "pfcn10m.json", "nfcf100m.json", "nfcf1m.json", "fairgo10m.json", "pmc_mfma.md", "wave_trace.txt"):
+             "pfcn10m.json", "nfcf100m.json", "nfcf1m.json", "fairgo10m.json", "pmc_mfma.md", "wave_trace.txt", "eval_probe.txt"):
     f = os.path.join(src, name)
     if os.path.exists(f) and os.path.getsize(f) > 0:
         if name.endswith(".json"):      # keep the JSON line only

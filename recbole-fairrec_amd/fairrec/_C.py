@@ -141,6 +141,8 @@ _PROTOS = {
                                     c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
     "fr_eval_hits": (c_int, [c_void_p, c_int64, c_int32, c_int64, c_void_p, c_int64, c_void_p, c_void_p]),
     "fr_topk_like_torch_cpu": (c_int, [c_void_p, c_int64, c_int64, c_int32, c_void_p, c_void_p]),
+    "fr_eval_topk_segments": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p]),
+    "fr_eval_lookup_segments": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "fr_topk_metrics_workspace_bytes": (c_size_t, [c_int64, c_int32]),
     "fr_topk_metrics": (c_int, [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_size_t, c_void_p]),
     "fr_group_sums": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p]),

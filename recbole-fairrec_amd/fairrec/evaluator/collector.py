@@ -89,6 +89,37 @@ class Collector:
         row_idx = row_idx.to(dev, torch.int64)
         positive_u, positive_i = positive_u.to(dev, torch.int64), positive_i.to(dev, torch.int64)
         U = int(positive_u[-1].item()) + 1                                    # batch_user_num, trainer.py:453
+        K = max(self.topk)
+        if K <= 62 and (row_idx.numel() < 2 or bool((row_idx[1:] >= row_idx[:-1]).all())):
+            # The evaluation loaders emit a batch user by user: a user's candidates are a contiguous segment, and the whole
+            # ranking is ONE launch, a wave per user (fr_eval_topk_segments); every lookup the reference makes in its dense
+            # -inf matrix is a scan of the user's segment (fr_eval_lookup_segments).  No sort of the batch's candidates.
+            items = items.contiguous()
+            sc = origin_scores.reshape(-1).to(torch.float32).contiguous()
+            seg = torch.searchsorted(row_idx, torch.arange(U + 1, device=dev, dtype=torch.int64)).contiguous()
+            topk_idx = torch.empty((U, K), dtype=torch.int64, device=dev)
+            flags = torch.empty(U, dtype=torch.int32, device=dev)
+            st = _C.current_stream()
+            _C.check(lib.fr_eval_topk_segments(seg.data_ptr(), U, items.data_ptr(), sc.data_ptr(), K, topk_idx.data_ptr(),
+                                               flags.data_ptr(), st), "fr_eval_topk_segments")
+            # users whose list hangs on an exact tie (or who have fewer than K + 1 distinct candidates): their rows of the reference's
+            # dense -inf matrix are ranked on the host, in torch.topk's CPU order (csrc/topk_host.hip)
+            tied = flags.nonzero().view(-1)
+            if tied.numel():
+                slot = torch.full((U,), -1, dtype=torch.int64, device=dev)
+                slot[tied] = torch.arange(tied.numel(), device=dev)
+                sel = slot[row_idx] >= 0
+                dense = torch.full((tied.numel(), n_items), -float('inf'), dtype=torch.float32, device=dev)
+                dense[slot[row_idx[sel]], items[sel]] = sc[sel]
+                topk_idx[tied] = self._host_topk(dense, K).to(dev)
+
+            def lookup(rows, its):
+                rows, its = rows.contiguous(), its.contiguous()
+                out = torch.empty(rows.numel(), dtype=torch.float32, device=dev)
+                _C.check(lib.fr_eval_lookup_segments(seg.data_ptr(), U, items.data_ptr(), sc.data_ptr(), rows.data_ptr(),
+                                                     its.data_ptr(), rows.numel(), out.data_ptr(), st), "fr_eval_lookup_segments")
+                return out.to(origin_scores.dtype)
+            return self._finish_candidates(topk_idx, lookup, interaction, items, positive_u, positive_i, n_items, U, K, dev)
         keys, order = torch.sort(row_idx * n_items + items, stable=True)
         first = torch.ones_like(keys, dtype=torch.bool)
         first[1:] = keys[1:] != keys[:-1]
@@ -99,8 +130,8 @@ class Collector:
             p = torch.searchsorted(ckeys, q).clamp_(max=ckeys.numel() - 1)
             return torch.where(ckeys[p] == q, cscore[p], torch.full_like(cscore[p], -float('inf')))
 
+        # (the general form, for a batch whose rows are not grouped by user, or K > 62)
         # ranking among a user's candidates: stable sort by score (descending) inside each row
-        K = max(self.topk)
         o1 = torch.sort(cscore, descending=True, stable=True).indices
         o2 = torch.sort((ckeys // n_items)[o1], stable=True).indices
         ranked = o1[o2]                                                        # candidates by (row asc, score desc)
@@ -125,6 +156,10 @@ class Collector:
             dense = torch.full((tied.numel(), n_items), -float('inf'), dtype=torch.float32, device=dev)
             dense[slot[crow[sel]], (ckeys % n_items)[sel]] = cscore[sel].to(torch.float32)
             topk_idx[tied] = self._host_topk(dense, K).to(dev)
+        return self._finish_candidates(topk_idx, lookup, interaction, items, positive_u, positive_i, n_items, U, K, dev)
+
+    def _finish_candidates(self, topk_idx, lookup, interaction, items, positive_u, positive_i, n_items, U, K, dev):
+        lib = _C.lib()
         pos_keys = torch.sort(positive_u * n_items + positive_i).values
         rec = torch.empty((U, K + 1), dtype=torch.int32, device=dev)
         _C.check(lib.fr_eval_hits(topk_idx.data_ptr(), U, K, n_items, pos_keys.data_ptr(), pos_keys.numel(), rec.data_ptr(),

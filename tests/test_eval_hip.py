@@ -226,3 +226,70 @@ def test_run_recbole_fairgo_with_the_reference_test_yaml_metrics(tmp_path):
     assert {"pretrain-ndcg@5", "finetune-ndcg@5", "finetune-giniindex@5", "finetune-popularitypercentage@5",
             "finetune-Differential Fairness of sensitive attribute gender"} <= set(res)
     assert 0.0 <= res["finetune-ndcg@5"] <= 1.0 and 0.0 <= res["finetune-giniindex@5"] <= 1.0
+
+
+@pytest.mark.parametrize("K", [1, 5, 20])
+def test_segment_topk_kernel_against_dense_rows(K):
+    """fr_eval_topk_segments / fr_eval_lookup_segments (the uniN ranking as one launch, a wave per user) against the reference's
+    recipe spelled out: scatter a user's candidates into a dense -inf row (trainer.py:441-456), torch.topk on the CPU
+    (collector.py:149).  Segments of 0 to 700 candidates, items drawn twice, users with fewer than K + 1 distinct candidates,
+    score ties inside and at the end of a list: where the kernel flags nothing its list must EQUAL the reference's, and it must
+    flag exactly the users whose first K + 1 distinct scores contain an equal pair (bit 0) or are fewer than K + 1 (bit 1)."""
+    from fairrec import _C
+    lib = _C.lib()
+    g = torch.Generator().manual_seed(K)
+    n_items, U = 500, 300
+    counts = torch.randint(0, 8, (U,), generator=g) * 101
+    counts[5], counts[6], counts[7] = 3, K, 0
+    counts[8] = 707
+    seg = torch.zeros(U + 1, dtype=torch.int64)
+    seg[1:] = torch.cumsum(counts, 0)
+    n = int(seg[-1])
+    items = torch.randint(1, n_items, (n,), generator=g)
+    scores = torch.rand(n, generator=g)
+    rows = torch.repeat_interleave(torch.arange(U), counts)
+    quant = (rows % 3 == 0)                                    # a third of the users: few distinct score values -> ties
+    scores[quant] = (scores[quant] * 6).floor() / 6
+    for u in range(U):                                         # an item drawn twice scores the same twice
+        a, b = int(seg[u]), int(seg[u + 1])
+        first = {}
+        for j in range(a, b):
+            it = int(items[j])
+            if it in first:
+                scores[j] = scores[first[it]]
+            else:
+                first[it] = j
+    d_seg, d_items, d_scores = seg.cuda(), items.cuda(), scores.cuda()
+    topk = torch.empty((U, K), dtype=torch.int64, device="cuda")
+    flags = torch.empty(U, dtype=torch.int32, device="cuda")
+    _C.check(lib.fr_eval_topk_segments(d_seg.data_ptr(), U, d_items.data_ptr(), d_scores.data_ptr(), K, topk.data_ptr(),
+                                       flags.data_ptr(), _C.current_stream()), "fr_eval_topk_segments")
+    topk, flags = topk.cpu(), flags.cpu()
+    for u in range(U):
+        a, b = int(seg[u]), int(seg[u + 1])
+        dense = torch.full((n_items,), -float("inf"))
+        dense[items[a:b]] = scores[a:b]
+        vals, idx = torch.topk(dense, K + 1)
+        distinct = int((dense > -float("inf")).sum())
+        short = distinct < K + 1
+        m = min(distinct, K + 1)
+        tie = bool((vals[1:m] == vals[:m - 1]).any()) if m >= 2 else False
+        assert int(flags[u]) == (1 if tie else 0) | (2 if short else 0), (u, int(flags[u]), tie, short)
+        if not tie and not short:
+            assert topk[u].tolist() == idx[:K].tolist(), u
+        elif not tie:
+            assert topk[u, :min(distinct, K)].tolist() == idx[:min(distinct, K)].tolist() and (topk[u, distinct:] == 0).all(), u
+    # lookups: present pairs, absent pairs, the second copy of a doubled item
+    q_rows = torch.randint(0, U, (4000,), generator=g)
+    q_items = torch.randint(1, n_items, (4000,), generator=g)
+    out = torch.empty(4000, dtype=torch.float32, device="cuda")
+    d_qr, d_qi = q_rows.cuda(), q_items.cuda()
+    _C.check(lib.fr_eval_lookup_segments(d_seg.data_ptr(), U, d_items.data_ptr(), d_scores.data_ptr(), d_qr.data_ptr(),
+                                         d_qi.data_ptr(), 4000, out.data_ptr(), _C.current_stream()), "fr_eval_lookup_segments")
+    out = out.cpu()
+    for q in range(0, 4000, 7):
+        u, it = int(q_rows[q]), int(q_items[q])
+        a, b = int(seg[u]), int(seg[u + 1])
+        hit = (items[a:b] == it).nonzero()
+        want = float(scores[a + int(hit[0])]) if len(hit) else -float("inf")
+        assert float(out[q]) == want, (q, u, it)
