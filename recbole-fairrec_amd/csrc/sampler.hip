@@ -280,15 +280,19 @@ __device__ __forceinline__ void calls_sequential(uint32_t (&mt)[2][MT_N], int& c
     }
 }
 
-// (A) ONE WAVE, no barriers: the generator's blocks twisted in place in LDS, 64 words at a time in mt19937_gen's own order (a
-// chunk reads old[k], old[k + 1] and old[k + 397] -- or the already new [k - 227] -- of its 64 words before it writes them), each
-// block kept, its words tempered, masked and the accepted ones appended with their raw index (ballot + popcount).  ~2 us per
-// block of 624 words; with 1024 threads the same work is seven workgroup barriers per block (25 us).
-__global__ __launch_bounds__(64) void sample_calls_accept_kernel(const uint32_t* __restrict__ state, uint32_t span, uint32_t mask,
-                                                                 const int64_t* __restrict__ call_offsets, long long n_calls,
-                                                                 uint32_t* __restrict__ acc_val, uint32_t* __restrict__ acc_raw,
-                                                                 long long cap, uint32_t* __restrict__ snap, long long nblk_max,
-                                                                 long long* __restrict__ n_acc_out) {
+// (A) The accepted values.  A1, ONE WAVE and no barriers: the generator's blocks twisted in place in LDS, 64 words at a time in
+// mt19937_gen's own order (a chunk's lanes read old[k], old[k + 1] and old[k + 397] -- or new[k - 227], a word of a chunk long
+// done -- before any of them writes), every block kept (with 1024 threads the same twist is four workgroup barriers per block).
+// The block count is what the wanted number of accepted values needs at the mask's acceptance rate plus a margin; should
+// chance leave fewer, (B) sees it and falls back.  A2, one wave per block over the chip: temper, mask, count the accepted
+// words.  A3, the same waves again: each sums the counts of the blocks before its own and writes its accepted words, with
+// their raw index in the stream, at their places.
+__device__ __forceinline__ long long calls_want(long long total) { return total + (total / 32 > 1024 ? total / 32 : 1024); }
+
+__global__ __launch_bounds__(64) void sample_calls_twist_kernel(const uint32_t* __restrict__ state, uint32_t span, uint32_t mask,
+                                                                const int64_t* __restrict__ call_offsets, long long n_calls,
+                                                                long long cap, uint32_t* __restrict__ snap, long long nblk_max,
+                                                                long long* __restrict__ hdr) {
     __shared__ uint32_t mt[MT_N + 1];
     const int l = threadIdx.x;
     for (int k = l; k < MT_N; k += 64) {
@@ -296,55 +300,74 @@ __global__ __launch_bounds__(64) void sample_calls_accept_kernel(const uint32_t*
         mt[k] = w;
         snap[k] = w;
     }
-    int pos = (int)state[MT_N];
-    const long long total = call_offsets[n_calls];
-    {
-        const long long want = total + (total / 32 > 1024 ? total / 32 : 1024);      // (the buffers may be larger than this sequence needs)
-        if (want < cap) cap = want;
-    }
-    long long produced = 0, blk = 0;
-    while (produced < cap) {
-        if (pos >= MT_N) {
-            if (blk + 1 >= nblk_max) break;
-            // mt19937_gen, in place: [0, 227) from old words, [227, 623) from the new words 227 back, word 623 from new[396], new[0]
-            // (a chunk's lanes read old[k], old[k + 1] and old[k + 397] -- or new[k - 227], a word of a chunk long done -- before any of
-            // them writes: one wave executes the reads of all its lanes before the write)
-            for (int k0 = 0; k0 < MT_N - 1; k0 += 64) {
-                const int k = k0 + l;
-                uint32_t nv = 0;
-                if (k < MT_N - 1) {
-                    const uint32_t a = mt[k], b = mt[k + 1];
-                    const uint32_t far = k < MT_N - MT_M ? mt[k + MT_M] : mt[k - (MT_N - MT_M)];
-                    nv = far ^ mt_mix(a, b);
-                }
-                __builtin_amdgcn_wave_barrier();
-                if (k < MT_N - 1) mt[k] = nv;
-                __builtin_amdgcn_wave_barrier();
-            }
-            if (l == 0) mt[MT_N - 1] = mt[MT_M - 1] ^ mt_mix(mt[MT_N - 1], mt[0]);
-            pos = 0;
-            ++blk;
-            for (int k = l; k < MT_N; k += 64) snap[blk * MT_N + k] = mt[k];
-        }
-        for (int k0 = pos & ~63; k0 < MT_N; k0 += 64) {
+    const int pos0 = (int)state[MT_N];
+    long long want = calls_want(call_offsets[n_calls]);
+    if (want > cap) want = cap;
+    // blocks beyond the incoming one: accepted words per block = 624 (span + 1) / (mask + 1) on average, 6 % and two blocks spare
+    const double rate = ((double)span + 1.0) / ((double)mask + 1.0);
+    long long need = want - (long long)((MT_N - pos0) * rate * 0.9);
+    long long nblk = need > 0 ? (long long)((double)need / (MT_N * rate * 0.94)) + 2 : 0;
+    if (nblk > nblk_max - 1) nblk = nblk_max - 1;
+    for (long long blk = 1; blk <= nblk; ++blk) {
+        for (int k0 = 0; k0 < MT_N - 1; k0 += 64) {
             const int k = k0 + l;
-            uint32_t v = 0;
-            bool acc = false;
-            if (k >= pos && k < MT_N) {
-                v = mt_temper(mt[k]) & mask;
-                acc = v <= span;
+            uint32_t nv = 0;
+            if (k < MT_N - 1) {
+                const uint32_t a = mt[k], b = mt[k + 1];
+                const uint32_t far = k < MT_N - MT_M ? mt[k + MT_M] : mt[k - (MT_N - MT_M)];
+                nv = far ^ mt_mix(a, b);
             }
-            const unsigned long long bal = __ballot(acc);
+            __builtin_amdgcn_wave_barrier();
+            if (k < MT_N - 1) mt[k] = nv;
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (l == 0) mt[MT_N - 1] = mt[MT_M - 1] ^ mt_mix(mt[MT_N - 1], mt[0]);
+        __builtin_amdgcn_wave_barrier();
+        for (int k = l; k < MT_N; k += 64) snap[blk * MT_N + k] = mt[k];
+    }
+    if (l == 0) {
+        hdr[1] = nblk + 1;      // blocks kept, the incoming one included
+        hdr[2] = pos0;
+        hdr[3] = want;
+    }
+}
+
+// PASS 0: cnt[blk] = accepted words of block blk; PASS 1: the words themselves, behind those of the blocks before
+template <int PASS>
+__global__ __launch_bounds__(64) void sample_calls_temper_kernel(uint32_t span, uint32_t mask, const uint32_t* __restrict__ snap,
+                                                                 long long* __restrict__ hdr, uint32_t* __restrict__ cnt,
+                                                                 uint32_t* __restrict__ acc_val, uint32_t* __restrict__ acc_raw) {
+    const long long blk = blockIdx.x, nblk = hdr[1];
+    if (blk >= nblk) return;
+    const int l = threadIdx.x, pos = blk == 0 ? (int)hdr[2] : 0;
+    const long long want = hdr[3];
+    long long before = 0;
+    if (PASS == 1) {
+        for (long long b0 = 0; b0 < blk; b0 += 64) before += b0 + l < blk ? cnt[b0 + l] : 0u;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) before += __shfl_xor((int)before, o, 64);      // (below 2^31: the buffers hold < 2^30 values)
+    }
+    long long produced = before;
+    for (int k0 = pos & ~63; k0 < MT_N; k0 += 64) {
+        const int k = k0 + l;
+        uint32_t v = 0;
+        bool acc = false;
+        if (k >= pos && k < MT_N) {
+            v = mt_temper(snap[blk * MT_N + k]) & mask;
+            acc = v <= span;
+        }
+        const unsigned long long bal = __ballot(acc);
+        if (PASS == 1) {
             const long long e = produced + __popcll(bal & ((1ull << l) - 1ull));
-            if (acc && e < cap) {
+            if (acc && e < want) {
                 acc_val[e] = v;
                 acc_raw[e] = (uint32_t)(blk * MT_N + k);
             }
-            produced += __popcll(bal);
         }
-        pos = MT_N;
+        produced += __popcll(bal);
     }
-    if (l == 0) n_acc_out[0] = produced < cap ? produced : cap;
+    if (PASS == 0 && l == 0) cnt[blk] = (uint32_t)(produced - before);
+    if (PASS == 1 && l == 0 && blk == nblk - 1) hdr[0] = produced < want ? produced : want;      // accepted values available
 }
 
 // (P) every position of the sequence, in parallel over the chip: its call, and for each shift d < CALLS_SHIFTS whether the
@@ -566,7 +589,7 @@ extern "C" int fr_sample_negatives(uint32_t* state, int64_t low, int64_t high, c
 // A sequence of single-key calls on one stream: call c fills out[call_offsets[c] .. call_offsets[c+1]) for key
 // call_keys[c]; `max_call` >= the longest call sizes the workspace (fr_sample_negatives_workspace_bytes(max_call)).
 // workspace of the speculative form of a call sequence of `total` values in all (0 values: the call-by-call form's)
-static void calls_fast_layout(int64_t total, int64_t max_call, size_t& cap, size_t& nblk, size_t off[8], size_t& bytes) {
+static void calls_fast_layout(int64_t total, int64_t max_call, size_t& cap, size_t& nblk, size_t off[9], size_t& bytes) {
     cap = (size_t)total + std::max<size_t>(1024, (size_t)total / 32);
     nblk = 2 * cap / MT_N + 4;      // the mask keeps more than every second word
     size_t o = 0;
@@ -576,14 +599,15 @@ static void calls_fast_layout(int64_t total, int64_t max_call, size_t& cap, size
     off[2] = take(nblk * MT_N * 4);         // the generator's blocks
     off[3] = take((size_t)max_call * 4);    // collision lists of the call being resolved
     off[4] = take((size_t)max_call * 4);
-    off[5] = take(8);                       // accepted values generated
+    off[5] = take(32);                      // (accepted values available, blocks kept, incoming position, values wanted)
     off[6] = take((size_t)total * 4);       // per position: for which shifts it collides
     off[7] = take((size_t)total * 4);       // ... and its call
+    off[8] = take(nblk * 4);                // accepted words per block
     bytes = o;
 }
 extern "C" size_t fr_sample_negatives_calls_workspace_bytes(int64_t total, int64_t max_call) {
     if (total < 1 || max_call < 1) return 0;
-    size_t cap, nblk, off[8], bytes;
+    size_t cap, nblk, off[9], bytes;
     calls_fast_layout(total, max_call, cap, nblk, off, bytes);
     return bytes;
 }
@@ -610,16 +634,22 @@ extern "C" int fr_sample_negatives_calls(uint32_t* state, int64_t low, int64_t h
             else hi_t = mid - 1;
         }
         if (lo_t >= n_calls) {      // (a workspace sized for the call-by-call form only: no room)
-            size_t cap, nblk, off[8], bytes;
+            size_t cap, nblk, off[9], bytes;
             calls_fast_layout(lo_t, max_call, cap, nblk, off, bytes);
             const uint32_t span = (uint32_t)(high - 1 - low);
             uint32_t mask = span;
             mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
             char* w = (char*)ws;
             ProfScope prof(K_SAMPLE_NEG, (hipStream_t)stream_);
-            FR_LAUNCH(prof, sample_calls_accept_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream_, (const uint32_t*)state, span, mask,
-                      call_offsets, (long long)n_calls, (uint32_t*)(w + off[0]), (uint32_t*)(w + off[1]), (long long)cap,
-                      (uint32_t*)(w + off[2]), (long long)nblk, (long long*)(w + off[5]));
+            FR_LAUNCH(prof, sample_calls_twist_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream_, (const uint32_t*)state, span, mask,
+                      call_offsets, (long long)n_calls, (long long)cap, (uint32_t*)(w + off[2]), (long long)nblk,
+                      (long long*)(w + off[5]));
+            FR_LAUNCH(prof, sample_calls_temper_kernel<0>, dim3((unsigned)nblk), dim3(64), 0, (hipStream_t)stream_, span, mask,
+                      (const uint32_t*)(w + off[2]), (long long*)(w + off[5]), (uint32_t*)(w + off[8]), (uint32_t*)(w + off[0]),
+                      (uint32_t*)(w + off[1]));
+            FR_LAUNCH(prof, sample_calls_temper_kernel<1>, dim3((unsigned)nblk), dim3(64), 0, (hipStream_t)stream_, span, mask,
+                      (const uint32_t*)(w + off[2]), (long long*)(w + off[5]), (uint32_t*)(w + off[8]), (uint32_t*)(w + off[0]),
+                      (uint32_t*)(w + off[1]));
             FR_LAUNCH(prof, sample_calls_hits_kernel, dim3((unsigned)((lo_t + 255) / 256)), dim3(256), 0, (hipStream_t)stream_,
                       (long long)low, call_keys, call_offsets, (long long)n_calls, used_indptr, used_items, (long long)n_users,
                       (const uint32_t*)(w + off[0]), (const long long*)(w + off[5]), (uint32_t*)(w + off[6]), (int32_t*)(w + off[7]),
