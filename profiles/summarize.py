@@ -15,7 +15,19 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
 src = os.path.join(ROOT, "gpurun_out", rnd)
+# (on the GPU box collect.sh passes a directory under gpurun_out/ as the destination -- the raw traces are too large to travel
+# back -- and the files are copied into profiles/ here afterwards: `python profiles/summarize.py r06 --take`)
 dst = os.path.join(ROOT, "profiles")
+if len(sys.argv) > 2 and sys.argv[2] == "--take":
+    n = 0
+    for f in sorted(glob.glob(os.path.join(src, "summary", "*"))):
+        shutil.copy(f, os.path.join(dst, os.path.basename(f)))
+        n += 1
+    print(f"{n} files from {src}/summary into profiles/")
+    sys.exit(0)
+if len(sys.argv) > 2:
+    dst = sys.argv[2]
+    os.makedirs(dst, exist_ok=True)
 
 
 def one(pattern):
@@ -67,7 +79,7 @@ for k in sorted(set(fetch) | set(write)):
 open(os.path.join(dst, f"{rnd}_pmc.md"), "w").write("\n".join(lines) + "\n")
 # what the counters were collected ON: bench.py compares this with the sources it runs and flags a stale figure
 import hashlib
-_src = os.path.join(os.path.dirname(dst), "recbole-fairrec_amd", "csrc")
+_src = os.path.join(ROOT, "recbole-fairrec_amd", "csrc")
 traffic["_kernel_source_sha1"] = hashlib.sha1(b"".join(open(os.path.join(_src, f), "rb").read() for f in
                                                        ("focf_step.hip", "focf_ws.hpp", "common.hpp"))).hexdigest()
 traffic["_round"] = rnd

@@ -280,24 +280,26 @@ __device__ __forceinline__ void calls_sequential(uint32_t (&mt)[2][MT_N], int& c
     }
 }
 
-// (A) The accepted values.  A1, ONE WAVE and no barriers: the generator's blocks twisted in place in LDS, 64 words at a time in
-// mt19937_gen's own order (a chunk's lanes read old[k], old[k + 1] and old[k + 397] -- or new[k - 227], a word of a chunk long
-// done -- before any of them writes), every block kept (with 1024 threads the same twist is four workgroup barriers per block).
+// (A) The accepted values.  A1, one small workgroup that does nothing but twist the generator's blocks in LDS, every block kept
+// (sample_calls_twist_kernel; the call-by-call kernel's 1024 threads spend four barriers per block AND temper, mask, scan).
 // The block count is what the wanted number of accepted values needs at the mask's acceptance rate plus a margin; should
 // chance leave fewer, (B) sees it and falls back.  A2, one wave per block over the chip: temper, mask, count the accepted
 // words.  A3, the same waves again: each sums the counts of the blocks before its own and writes its accepted words, with
 // their raw index in the stream, at their places.
 __device__ __forceinline__ long long calls_want(long long total) { return total + (total / 32 > 1024 ? total / 32 : 1024); }
 
-__global__ __launch_bounds__(64) void sample_calls_twist_kernel(const uint32_t* __restrict__ state, uint32_t span, uint32_t mask,
-                                                                const int64_t* __restrict__ call_offsets, long long n_calls,
-                                                                long long cap, uint32_t* __restrict__ snap, long long nblk_max,
-                                                                long long* __restrict__ hdr) {
-    __shared__ uint32_t mt[MT_N + 1];
-    const int l = threadIdx.x;
-    for (int k = l; k < MT_N; k += 64) {
+__global__ __launch_bounds__(256) void sample_calls_twist_kernel(const uint32_t* __restrict__ state, uint32_t span, uint32_t mask,
+                                                                 const int64_t* __restrict__ call_offsets, long long n_calls,
+                                                                 long long cap, uint32_t* __restrict__ snap, long long nblk_max,
+                                                                 long long* __restrict__ hdr) {
+    // Word n of the stream needs words n - 227, n - 623 and n - 624: a block of 624 is three dependent phases of <= 227 words.
+    // Four waves, two copies of the block (old -> new, so that no phase overwrites what a neighbour still reads), one barrier
+    // per phase: ~0.3 us per block (one wave walking the block 64 words at a time in place: 1.2 us).
+    __shared__ uint32_t buf[2][MT_N];
+    const int t = threadIdx.x;
+    for (int k = t; k < MT_N; k += 256) {
         const uint32_t w = state[k];
-        mt[k] = w;
+        buf[0][k] = w;
         snap[k] = w;
     }
     const int pos0 = (int)state[MT_N];
@@ -308,24 +310,26 @@ __global__ __launch_bounds__(64) void sample_calls_twist_kernel(const uint32_t* 
     long long need = want - (long long)((MT_N - pos0) * rate * 0.9);
     long long nblk = need > 0 ? (long long)((double)need / (MT_N * rate * 0.94)) + 2 : 0;
     if (nblk > nblk_max - 1) nblk = nblk_max - 1;
+    __syncthreads();
+    constexpr int H = MT_N - MT_M;      // 227
+    int cur = 0;
     for (long long blk = 1; blk <= nblk; ++blk) {
-        for (int k0 = 0; k0 < MT_N - 1; k0 += 64) {
-            const int k = k0 + l;
-            uint32_t nv = 0;
-            if (k < MT_N - 1) {
-                const uint32_t a = mt[k], b = mt[k + 1];
-                const uint32_t far = k < MT_N - MT_M ? mt[k + MT_M] : mt[k - (MT_N - MT_M)];
-                nv = far ^ mt_mix(a, b);
-            }
-            __builtin_amdgcn_wave_barrier();
-            if (k < MT_N - 1) mt[k] = nv;
-            __builtin_amdgcn_wave_barrier();
+        const uint32_t* __restrict__ o = buf[cur];
+        uint32_t* __restrict__ n = buf[cur ^ 1];
+        if (t < H) n[t] = o[t + MT_M] ^ mt_mix(o[t], o[t + 1]);
+        __syncthreads();
+        if (t < H) n[H + t] = n[t] ^ mt_mix(o[H + t], o[H + t + 1]);
+        __syncthreads();
+        {
+            const int k = 2 * H + t;
+            if (k < MT_N - 1) n[k] = n[k - H] ^ mt_mix(o[k], o[k + 1]);
+            else if (k == MT_N - 1) n[k] = n[MT_M - 1] ^ mt_mix(o[k], n[0]);
         }
-        if (l == 0) mt[MT_N - 1] = mt[MT_M - 1] ^ mt_mix(mt[MT_N - 1], mt[0]);
-        __builtin_amdgcn_wave_barrier();
-        for (int k = l; k < MT_N; k += 64) snap[blk * MT_N + k] = mt[k];
+        __syncthreads();
+        for (int k = t; k < MT_N; k += 256) snap[blk * MT_N + k] = n[k];
+        cur ^= 1;
     }
-    if (l == 0) {
+    if (t == 0) {
         hdr[1] = nblk + 1;      // blocks kept, the incoming one included
         hdr[2] = pos0;
         hdr[3] = want;
@@ -416,11 +420,10 @@ __global__ __launch_bounds__(SAMPLER_THREADS) void sample_calls_fast_kernel(
     const uint32_t* __restrict__ hmask, const int32_t* __restrict__ pos_call, int32_t* list_a, int32_t* list_b, uint32_t* err) {
     __shared__ uint32_t mt[2][MT_N];
     __shared__ int wave_cnt[SAMPLER_THREADS / 64];
-    __shared__ int s_last, s_over;
+    __shared__ int s_last;
     __shared__ long long s_first;
     const int t = threadIdx.x;
     int cur = 0;
-    if (t == 0) s_over = 0;
     int pos = (int)state[MT_N];
     const int pos0 = pos;
     const long long total = call_offsets[n_calls];
@@ -641,7 +644,7 @@ extern "C" int fr_sample_negatives_calls(uint32_t* state, int64_t low, int64_t h
             mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
             char* w = (char*)ws;
             ProfScope prof(K_SAMPLE_NEG, (hipStream_t)stream_);
-            FR_LAUNCH(prof, sample_calls_twist_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream_, (const uint32_t*)state, span, mask,
+            FR_LAUNCH(prof, sample_calls_twist_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream_, (const uint32_t*)state, span, mask,
                       call_offsets, (long long)n_calls, (long long)cap, (uint32_t*)(w + off[2]), (long long)nblk,
                       (long long*)(w + off[5]));
             FR_LAUNCH(prof, sample_calls_temper_kernel<0>, dim3((unsigned)nblk), dim3(64), 0, (hipStream_t)stream_, span, mask,
