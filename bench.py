@@ -544,9 +544,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--launch", default="library", choices=["library", "graph", "eager"],
+    ap.add_argument("--launch", default="auto", choices=["auto", "library", "graph", "eager"],
                     help="how the timed steps are issued on one GPU: the library's step loop (fr_focf_steps_many / fr_focf_runs_many: "
-                         "what Trainer._train_epoch calls; default), one hipGraph of per-batch steps, or per-batch eager launches")
+                         "what Trainer._train_epoch calls), one hipGraph of per-batch steps, or per-batch eager launches.  auto "
+                         "(default): the library loop when --steps >= 64, else the hipGraph -- a library call has a fixed cost "
+                         "(host preparation of the run + three stage launches, ~0.1 ms) that the trainer spreads over runs of 256 "
+                         "steps and a 20-step timed region cannot")
     ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly (= --launch eager; the N > 1 path: no hipGraph)")
     ap.add_argument("--graph-only", action="store_true", help="do not also time the other launch modes (single-GPU default: all three)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -692,6 +695,13 @@ def main():
     # FOCF.train_steps), and 1.5-2 us per step faster than a hipGraph replay of the same launches.  `--launch graph | eager` time
     # the per-batch entry points instead; the default run reports all three (config.launch_modes_timed).
     launch_mode = "eager" if args.no_graph else args.launch
+    auto_note = None
+    if launch_mode == "auto":
+        launch_mode = "library" if K >= 64 else "graph"
+        if launch_mode == "graph":
+            auto_note = (f"--launch auto with {K} timed steps: one hipGraph replay; the library's step loop (the trainer's path, "
+                         "timed beside it in launch_modes_timed and over 1024 steps in trainer_fit) pays ~0.1 ms per CALL, "
+                         "which its runs of 256 steps absorb and a 20-step region does not")
     if sharded and launch_mode == "library":
         launch_mode = "graph"
     if launch_mode == "library" and not eng.can_step_many():
@@ -966,7 +976,7 @@ def main():
             "config": {"ranks_seen": RANKS_SEEN,      # N > 1: counted by an RCCL all-reduce of ones when the group came up
                        "workload": "FOCF fair_objective=value, 1000001 users x 100001 items, embedding_size=64, "
                                    "B=8192 per GPU, Adam lr=1e-3 weight_decay=1e-3 (BASELINE.json configs[1])",
-                       "item_distribution": args.item_dist, "launch": launch, "launch_modes_timed": other,
+                       "item_distribution": args.item_dist, "launch": launch, "launch_note": auto_note, "launch_modes_timed": other,
                        "rccl_quiesce_before_capture": quiesced,     # how the wait for the watchdog ended (fairrec.graph.quiesce_rccl)
                        "step": (("item-owner-computes: records and user-row requests exchanged one step ahead; gather -> all-to-all(user rows) -> "
                                  "score / fair / grads -> all-to-all(user gradients) -> apply" if sharded and

@@ -243,23 +243,35 @@ __global__ __launch_bounds__(256) void eval_topk_segments_kernel(const int64_t* 
 
 // out[q] = the score of candidate item q_items[q] in the segment of user row q_rows[q], -inf if it is not one (a lookup in the
 // reference's dense -inf matrix: collector.py:160-175 reads positives' and negatives' scores back out of it)
+// (16 lanes per query walk the segment side by side -- every load of the walk in flight at once; one lane per query with a
+// break on the match was ~100 dependent loads: 38 us per launch against 13 for the ranking itself.  A candidate drawn twice
+// carries the same score twice, so which copy answers does not matter.)
+constexpr int LOOKUP_LANES = 16;
 __global__ __launch_bounds__(256) void eval_lookup_segments_kernel(const int64_t* __restrict__ seg_start, long long n_users,
                                                                    const int64_t* __restrict__ items, const float* __restrict__ scores,
                                                                    const int64_t* __restrict__ q_rows, const int64_t* __restrict__ q_items,
                                                                    long long n_q, float* __restrict__ out) {
-    const long long q = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (q >= n_q) return;
-    const long long r = q_rows[q];
+    const long long q = ((long long)blockIdx.x * 256 + threadIdx.x) / LOOKUP_LANES;
+    const int sub = threadIdx.x & (LOOKUP_LANES - 1);
+    const bool live = q < n_q;
+    const long long r = live ? q_rows[q] : -1;
     float v = -INFINITY;
+    bool found = false;
     if (r >= 0 && r < n_users) {
         const long long it = q_items[q];
-        for (long long j = seg_start[r]; j < seg_start[r + 1]; ++j)
+        const long long j1 = seg_start[r + 1];
+#pragma unroll 4
+        for (long long j = seg_start[r] + sub; j < j1; j += LOOKUP_LANES)
             if (items[j] == it) {
                 v = scores[j];
-                break;
+                found = true;
             }
     }
-    out[q] = v;
+    // the value of the first lane of the group that found it (not a maximum: a score may be NaN and has to come back as NaN)
+    const int lane = threadIdx.x & 63, base = lane & ~(LOOKUP_LANES - 1);
+    const unsigned bits = (unsigned)(__ballot(found) >> base) & ((1u << LOOKUP_LANES) - 1u);
+    const float got = __shfl(v, base + (bits ? __ffs((int)bits) - 1 : 0), 64);
+    if (live && sub == 0) out[q] = bits ? got : -INFINITY;
 }
 
 }  // namespace fr
@@ -300,7 +312,7 @@ extern "C" int fr_eval_lookup_segments(const int64_t* seg_start, int64_t n_users
     FR_CHECK_ARG(seg_start && items && scores && (n_q == 0 || (q_rows && q_items && out)) && n_users >= 1 && n_q >= 0,
                  "fr_eval_lookup_segments: bad argument");
     if (n_q == 0) return FR_OK;
-    hipLaunchKernelGGL(eval_lookup_segments_kernel, dim3((unsigned)((n_q + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, seg_start,
+    hipLaunchKernelGGL(eval_lookup_segments_kernel, dim3((unsigned)((n_q * LOOKUP_LANES + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, seg_start,
                        (long long)n_users, items, scores, q_rows, q_items, (long long)n_q, out);
     FR_CHECK_LAUNCH();
     return FR_OK;

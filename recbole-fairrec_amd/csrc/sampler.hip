@@ -312,20 +312,23 @@ __global__ __launch_bounds__(256) void sample_calls_twist_kernel(const uint32_t*
     if (nblk > nblk_max - 1) nblk = nblk_max - 1;
     __syncthreads();
     constexpr int H = MT_N - MT_M;      // 227
+    // (the phases hand LDS words to each other: the barrier waits for this wave's LDS traffic only, not for the block copies
+    // on their way to global memory, which __syncthreads' fence would drain three times per block)
+    auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
     int cur = 0;
     for (long long blk = 1; blk <= nblk; ++blk) {
         const uint32_t* __restrict__ o = buf[cur];
         uint32_t* __restrict__ n = buf[cur ^ 1];
         if (t < H) n[t] = o[t + MT_M] ^ mt_mix(o[t], o[t + 1]);
-        __syncthreads();
+        lds_barrier();
         if (t < H) n[H + t] = n[t] ^ mt_mix(o[H + t], o[H + t + 1]);
-        __syncthreads();
+        lds_barrier();
         {
             const int k = 2 * H + t;
             if (k < MT_N - 1) n[k] = n[k - H] ^ mt_mix(o[k], o[k + 1]);
             else if (k == MT_N - 1) n[k] = n[MT_M - 1] ^ mt_mix(o[k], n[0]);
         }
-        __syncthreads();
+        lds_barrier();
         for (int k = t; k < MT_N; k += 256) snap[blk * MT_N + k] = n[k];
         cur ^= 1;
     }

@@ -23,8 +23,9 @@ def _bench(*args):
 SMALL = ("--users", "200001", "--items", "50001", "--nfcf-users", "200001", "--nfcf-items", "50001")   # the other_workloads tables
 
 
-@pytest.mark.parametrize("args", [SMALL, ("--item-dist", "grouped"), ("--no-graph", "--no-workloads"), ("--launch", "graph", "--no-workloads")],
-                         ids=["default", "grouped", "eager", "graph"])
+@pytest.mark.parametrize("args", [SMALL, ("--item-dist", "grouped"), ("--no-graph", "--no-workloads"), ("--launch", "graph", "--no-workloads"),
+                                  ("--launch", "library", "--no-workloads"), ("--launch", "library", "--item-dist", "grouped")],
+                         ids=["default", "grouped", "eager", "graph", "library", "library_grouped"])
 def test_bench_json_contract(args):
     d = _bench(*args)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
@@ -51,13 +52,21 @@ def test_bench_json_contract(args):
         assert abs(g["frac_of_hbm_peak"] - g["achieved_GBps"] / 8000.0) < 1e-3 and g["hipGraph_us_per_step"] > 0
     else:
         assert "other_batch_shapes" not in d
-    mode = {"--no-graph": "eager", "--launch": "hipGraph"}.get(args[0] if args and args[0] in ("--no-graph", "--launch") else "", "library step loop")
+    # --launch auto (the default): 12 timed steps are one hipGraph replay (the library's step loop from 64 steps on), and the
+    # line says so
+    if "--no-graph" in args:
+        mode = "eager"
+    elif "--launch" in args:
+        mode = {"graph": "hipGraph", "library": "library step loop"}[args[args.index("--launch") + 1]]
+    else:
+        mode = "hipGraph"
+        assert "auto" in d["config"]["launch_note"]
     assert d["config"]["launch"].startswith(mode), d["config"]["launch"]
     if args is SMALL:
         # BASELINE.json configs[2..4] ride in the default line (here on small tables): ms per step, rate, roofline of each
         modes = d["config"]["launch_modes_timed"]
         assert {"library_loop_ms_per_step", "hipGraph_ms_per_step", "eager_ms_per_step"} <= set(modes)
-        assert abs(modes["library_loop_ms_per_step"] - d["ms_per_step"]) < 1e-4
+        assert abs(modes["hipGraph_ms_per_step"] - d["ms_per_step"]) < 1e-4
         w = d["other_workloads"]
         assert set(w) == {"pfcn10m", "nfcf100m", "fairgo10m"}
         for name, x in w.items():
