@@ -183,10 +183,11 @@ def trainer_fit_block(dev, headline_us_per_step, steps=1024, sweep=None):
                       "steps_per_library_call": int(cfg["train_steps_per_call"]),
                       "vs_headline": round(dt / n * 1e6 / headline_us_per_step, 3)}
     del ds
-    # item-complete: 5000 of the items carry ~100 interactions each (the shape of SURVEY.md 8-d's grouped run; a pick permutes
-    # the candidate list -- numpy's legacy choice(replace=False) -- so its host cost grows with the number of candidates)
+    # item-complete: 20 000 of the items carry ~100 interactions each (the shape of SURVEY.md 8-d's grouped run): an epoch of
+    # ~250 batches -- rounds 4-5 timed 62 (5000 items), where the epoch's fixed costs (the first group's prepare, the last
+    # batches' drain, one host synchronisation) were ~5 us of every step
     g = torch.Generator(device="cpu").manual_seed(SEED + 2)
-    n_hot, per = 5000, 100
+    n_hot, per = 20000, 100
     hot = torch.randperm(N_ITEMS - 1, generator=g)[:n_hot] + 1
     i = hot.repeat_interleave(per)
     u = torch.randint(1, N_USERS, (i.numel(),), generator=g, dtype=torch.int64)
