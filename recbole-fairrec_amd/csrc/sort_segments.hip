@@ -25,7 +25,6 @@ template <int KPT>
 static int launch_sort_kpt(const SortJobList& jobs, int bits, uint32_t* err, hipStream_t stream) {
     const int passes = (bits + sort_digit_bits(KPT) - 1) / sort_digit_bits(KPT);
     const int npass = passes | ((bits - sort_digit_bits(KPT) * (passes - 1)) << 8);      // (+ the last pass's bit count: sort_body.hpp)
-    constexpr int NB = 1 << sort_digit_bits(KPT);
     const size_t lds = sort_lds_bytes<KPT>();
     static bool attr_set = false;
     if (!attr_set) {

@@ -246,3 +246,59 @@ def test_lookup_pair_in_one_launch_equals_the_separate_calls(M, D, captured):
         trb.flush(hyper)
         assert torch.equal(tra.weight, trb.weight) and torch.equal(tra.m, trb.m) and torch.equal(tra.v, trb.v)
     assert int(err.item()) == 0
+
+
+@pytest.mark.parametrize("n_rows,D,wd", [(10_000_001, 256, 1e-6), (10_000_001, 128, 1e-4)],
+                         ids=["nfcf_item_table_of_config_4", "pfcn_user_table_of_config_2"])
+def test_generic_lazy_table_at_the_table_sizes_of_baseline_configs_2_and_4(n_rows, D, wd):
+    """The lazy table behind NFCF / PFCN / FairGo (csrc/table.hip: fr_table_gather_train + fr_table_apply_grad with its
+    sweeper slice) at the row counts BASELINE.json configs[4] (NFCF item table, 10 M x 256, wd 1e-6) and configs[2] (PFCN user
+    table, 10 M x 128, wd 1e-4) name -- sizes the goldens cannot reach.  Size-independent properties:
+      * rows of the batch, rows the sweeper caught and rows nobody touched all equal float64 dense Adam (torch.optim.Adam's
+        arithmetic: coupled L2, every row stepped at every step) on a sample of rows, after the final flush;
+      * the state that flushes EVERY step (dense semantics, the reference's) and the lazy state agree on every row of the
+        table to a few ulp (the zero-gradient steps are replayed in runs cut at different places)."""
+    from fairrec.optim import AdamHyper, LazyTable
+    lr, T, B = 1e-3, 5, 8192
+    g = torch.Generator(device="cuda").manual_seed(n_rows % 1000 + D)
+    w0 = torch.empty(n_rows, D, device="cuda").normal_(0.0, 0.05, generator=g)
+    hyper = AdamHyper(lr=lr, weight_decay=wd, device="cuda")
+    lazy, dense = LazyTable(w0.clone()), LazyTable(w0.clone())
+    ids = [torch.randint(1, n_rows, (B,), device="cuda", generator=g) for _ in range(T)]
+    for t in range(T):
+        ids[t][:64] = ids[0][:64]                    # rows that return in every batch, with duplicates inside a batch
+        ids[t][64:96] = ids[t][:32]
+    grads = [torch.empty(B, D, device="cuda").normal_(0.0, 0.01, generator=g) for _ in range(T)]
+    sweep = lazy.default_sweep(B)
+    for t in range(T):
+        for tab in (lazy, dense):
+            tab.gather_train(hyper, ids[t])
+            tab.apply_grad(hyper, grads[t], sweep_period=sweep)
+        dense.flush(hyper)
+    lazy.flush(hyper)
+    torch.cuda.synchronize()
+    # (1) a sample of rows against float64: every row of the first and the last batch's heads, rows next to them, far rows
+    sample = torch.cat([ids[0][:128], ids[T - 1][4000:4064], ids[2][100:164] + 1,
+                        torch.tensor([0, 1, 2, n_rows - 1, n_rows // 2, n_rows // 3], device="cuda")]).clamp_(0, n_rows - 1).unique()
+    p = w0[sample].double().cpu().numpy()
+    m, v = np.zeros_like(p), np.zeros_like(p)
+    pos = {int(r): k for k, r in enumerate(sample.tolist())}
+    b1, b2, eps = 0.9, 0.999, 1e-8
+    for t in range(T):
+        gs = np.zeros_like(p)
+        idt, gt = ids[t].cpu().numpy(), grads[t].double().cpu().numpy()
+        for j in np.nonzero(np.isin(idt, sample.cpu().numpy()))[0]:
+            gs[pos[int(idt[j])]] += gt[j]
+        gs += wd * p
+        m = b1 * m + (1 - b1) * gs
+        v = b2 * v + (1 - b2) * gs * gs
+        p = p - lr / (1 - b1 ** (t + 1)) * m / (np.sqrt(v) / np.sqrt(1 - b2 ** (t + 1)) + eps)
+    got = lazy.weight[sample].double().cpu().numpy()
+    assert np.abs(got - p).max() <= 1e-4 * np.abs(p).max() + 2e-6, np.abs(got - p).max()
+    # (2) lazy against flush-every-step on ALL rows, in slabs (the two [n_rows, D] tables stay on the device)
+    worst = 0.0                                      # in units of 2^-24 x the larger of |value| and the step size lr
+    for a in range(0, n_rows, 1 << 20):
+        x, y = lazy.weight[a:a + (1 << 20)], dense.weight[a:a + (1 << 20)]
+        worst = max(worst, float(((x - y).abs() / torch.clamp(y.abs(), min=lr)).max()) * 2.0 ** 24)
+    assert worst <= 64.0, worst
+    assert int(lazy.last.min()) == T and int(dense.last.min()) == T
