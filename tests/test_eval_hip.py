@@ -293,3 +293,29 @@ def test_segment_topk_kernel_against_dense_rows(K):
         hit = (items[a:b] == it).nonzero()
         want = float(scores[a + int(hit[0])]) if len(hit) else -float("inf")
         assert float(out[q]) == want, (q, u, it)
+
+
+def test_segment_lookup_hands_back_a_score_that_is_not_a_number():
+    """A diverged scorer's NaN sits in the reference's dense matrix and comes back out of it; the segment lookup must not lose
+    it to a maximum over its lanes.  Also: a query count that is not a multiple of the lanes per query, a one-candidate segment."""
+    from fairrec import _C
+    lib = _C.lib()
+    seg = torch.tensor([0, 1, 40, 40, 141], dtype=torch.int64)
+    items = torch.cat([torch.tensor([7]), torch.arange(1, 40), torch.arange(200, 301)])
+    scores = torch.arange(items.numel(), dtype=torch.float32) * 0.25 - 3.0
+    scores[0] = float("nan")
+    scores[17] = float("nan")
+    scores[140] = float("inf")
+    q_rows = torch.tensor([0, 0, 1, 1, 1, 2, 3, 3, 3, 1, 3], dtype=torch.int64)
+    q_items = torch.tensor([7, 8, 17, 1, 39, 5, 200, 300, 301, 40, 250], dtype=torch.int64)
+    out = torch.full((q_rows.numel(),), 123.0, device="cuda")
+    d = [t.cuda() for t in (seg, items, scores, q_rows, q_items)]
+    _C.check(lib.fr_eval_lookup_segments(d[0].data_ptr(), 4, d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(), d[4].data_ptr(),
+                                         q_rows.numel(), out.data_ptr(), _C.current_stream()), "fr_eval_lookup_segments")
+    got = out.cpu().numpy()
+    dense = np.full((4, 400), -np.inf, dtype=np.float32)
+    rows = np.repeat(np.arange(4), np.diff(seg.numpy()))
+    dense[rows, items.numpy()] = scores.numpy()
+    want = dense[q_rows.numpy(), q_items.numpy()]
+    assert np.array_equal(got, want, equal_nan=True), (got, want)
+    assert np.isnan(got[0]) and np.isnan(got[2]) and got[1] == -np.inf and got[7] == np.inf
