@@ -192,8 +192,8 @@ __global__ __launch_bounds__(256) void fair_from_stats_kernel(const double* __re
 // DISTINCT items of that segment (an item drawn twice scores the same twice and occupies one cell of the dense row).  A wave keeps
 // the K + 1 best so far in lanes 0..K (sorted, descending) and walks the segment 64 candidates at a time, each time pulling the
 // chunk's best through a wave maximum until it no longer beats the (K + 1)-th.  flags[u]: bit 0 = two of the first K + 1 entries
-// score EQUAL (which of them the reference ranks first is torch.topk's CPU tie order: the caller ranks that row on the host,
-// fr_topk_like_torch_cpu), bit 1 = fewer than K + 1 distinct candidates (the reference's list then continues into -inf cells).
+// score EQUAL or a candidate's score is NaN (which of them the reference ranks first is torch.topk's CPU order: the caller
+// ranks that row on the host, fr_topk_like_torch_cpu), bit 1 = fewer than K + 1 distinct candidates (the reference's list then continues into -inf cells).
 // Replaces three device sorts over the batch's candidates per evaluation batch (1.3 ms -> 0.1 ms at 280 k candidates).
 constexpr int TOPK_MAXK = 62;
 __global__ __launch_bounds__(256) void eval_topk_segments_kernel(const int64_t* __restrict__ seg_start, long long n_users,
@@ -206,11 +206,14 @@ __global__ __launch_bounds__(256) void eval_topk_segments_kernel(const int64_t* 
     float t_score = -INFINITY;      // lane j < n_in: the j-th best so far
     long long t_item = 0;
     int n_in = 0;
+    bool any_nan = false;
     for (long long base = s; base < e; base += 64) {
         const bool have = base + lane < e;
         float c_score = have ? scores[base + lane] : -INFINITY;
         const long long c_item = have ? items[base + lane] : 0;
-        unsigned long long valid = __ballot(have && c_score == c_score);      // (a NaN score ranks nowhere)
+        // (torch.topk ranks a NaN above every number; a user with one is handed to the host's ranking like a tied one)
+        any_nan |= __ballot(have && c_score != c_score) != 0ull;
+        unsigned long long valid = __ballot(have && c_score == c_score);
         while (valid) {
             float m = (valid >> lane) & 1ull ? c_score : -INFINITY;
 #pragma unroll
@@ -238,7 +241,7 @@ __global__ __launch_bounds__(256) void eval_topk_segments_kernel(const int64_t* 
     const float prev = __shfl_up(t_score, 1, 64);
     const bool tie = __ballot(lane >= 1 && lane < n_in && lane <= k && t_score == prev) != 0ull;
     if (lane < k) topk_idx[u * k + lane] = lane < n_in ? t_item : 0;       // (short lists are padded with [PAD] item 0)
-    if (lane == 0) flags[u] = (tie ? 1 : 0) | (n_in < k + 1 ? 2 : 0);
+    if (lane == 0) flags[u] = (tie || any_nan ? 1 : 0) | (n_in < k + 1 ? 2 : 0);
 }
 
 // out[q] = the score of candidate item q_items[q] in the segment of user row q_rows[q], -inf if it is not one (a lookup in the

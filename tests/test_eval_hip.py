@@ -319,3 +319,10 @@ def test_segment_lookup_hands_back_a_score_that_is_not_a_number():
     want = dense[q_rows.numpy(), q_items.numpy()]
     assert np.array_equal(got, want, equal_nan=True), (got, want)
     assert np.isnan(got[0]) and np.isnan(got[2]) and got[1] == -np.inf and got[7] == np.inf
+    # ... and the ranking hands a user with a NaN candidate to the host (torch.topk ranks NaN first): flag bit 0
+    topk = torch.empty((4, 5), dtype=torch.int64, device="cuda")
+    flags = torch.empty(4, dtype=torch.int32, device="cuda")
+    _C.check(lib.fr_eval_topk_segments(d[0].data_ptr(), 4, d[1].data_ptr(), d[2].data_ptr(), 5, topk.data_ptr(), flags.data_ptr(),
+                                       _C.current_stream()), "fr_eval_topk_segments")
+    assert flags.cpu().tolist() == [1 | 2, 1, 2, 0]
+    assert topk[3].cpu().tolist() == [300, 299, 298, 297, 296]
