@@ -684,6 +684,18 @@ FR_API int fr_row_scatter_sum(const float* g, const int64_t* idx, int64_t M, int
  * is both row-gathered and propagated (fairgo_pmf.py:178-201) then costs one dense [n_rows, dim] pass instead of three. */
 FR_API int fr_row_scatter_add(const float* g, const int64_t* idx, int64_t M, int64_t n_rows, int32_t dim, float* dX,
                               void* ws, size_t ws_bytes, uint32_t* err_flag, void* stream);
+/* The same two calls when the table they differentiate is the OUTPUT of an activation (FairGo's filtered table,
+ * fairgo_pmf.py:173-185 through layers.py:62-72) and what is wanted is the gradient at the activation's INPUT: every output
+ * row goes on through act'(act_src[row]) (act = 1 relu, 2 leaky relu, 3 sigmoid, 4 tanh; the derivative through the output,
+ * as fr_act_bwd takes it) inside the launches -- a row no term reaches is stored as zeros without reading act_src, a row whose
+ * bit in `skip_bits` (uint32 [ceil(n_out / 32)], optional) is set is left unscaled for fr_row_scatter_add_act, which scales
+ * the rows of `idx` after it has added to them.  Together: (L^T dY + scatter(g)) o act'(act_src), bit for bit what
+ * fr_spmm_csr_sel, fr_row_scatter_add and fr_act_bwd give in three whole-table passes. */
+FR_API int fr_spmm_csr_sel_act(const int64_t* indptr, const int32_t* col, const float* val, const float* X, const int32_t* rows,
+                               int64_t n_out, const int32_t* map, const uint32_t* map_bits, int32_t dim, float* Y,
+                               const float* act_src, int32_t act, const uint32_t* skip_bits, void* stream);
+FR_API int fr_row_scatter_add_act(const float* g, const int64_t* idx, int64_t M, int64_t n_rows, int32_t dim, float* dX,
+                                  void* ws, size_t ws_bytes, const float* act_src, int32_t act, uint32_t* err_flag, void* stream);
 FR_API int fr_mse(const float* pred, const float* target, int64_t B, float* loss, float* dpred, void* ws, size_t ws_bytes,
                   void* stream);
 

@@ -9,6 +9,7 @@
 
 #include "common.hpp"
 #include "kernels.hpp"
+#include "mlp_act.hpp"
 
 namespace fr {
 
@@ -54,6 +55,27 @@ __global__ __launch_bounds__(256) void spmm_csr_kernel(const long long* __restri
     }
 }
 
+// An output row on its way out through the derivative of an activation (fr_spmm_csr_sel_act: the product is the gradient at an
+// activation's OUTPUT, what goes on is the gradient at its input -- FairGo's filter step, where the whole-table gradient of
+// the filtered table otherwise takes a pass of its own through fr_act_bwd: 17 GB of traffic for a table of which the batch's
+// frontier touches a few per cent).  src = that output (act_bwd's argument) at the output rows; a row whose `skip` bit is set
+// is left as it is: a later pass adds to it first and scales the sum (fr_row_scatter_add_act).  A row no term reached is
+// stored as the zeros it is, without reading src.
+struct RowAct {
+    const float* src;
+    const unsigned* skip;
+    int act;
+};
+template <typename vec, int V>
+__device__ __forceinline__ vec row_act(vec acc, const RowAct& ra, long long i, int D, int lane) {
+    if (ra.skip && ((ra.skip[i >> 5] >> (i & 31)) & 1u)) return acc;
+    const vec y = *reinterpret_cast<const vec*>(ra.src + (size_t)i * D + lane * V);
+#pragma unroll
+    for (int e = 0; e < V; ++e) acc[e] = acc[e] * act_bwd(y[e], ra.act);
+    return acc;
+}
+
+
 // Y[i,:] = sum over the nonzeros j of row r = (rows ? rows[i] : i), in ascending j, of val[j] * X[xrow(col[j]),:] with
 // xrow(c) = map ? map[c] : c, nonzeros whose map entry is negative SKIPPED.  The frontier-restricted graph propagation of
 // FairGo (fairgo_pmf.py:196-200 evaluated only where the batch can see it): `rows` selects the output rows (compact Y),
@@ -62,12 +84,12 @@ __global__ __launch_bounds__(256) void spmm_csr_kernel(const long long* __restri
 // skipped term is one that kernel would add as an exact zero, so the results are those of the whole-table product.
 // The hits of a 64-nonzero chunk are walked through a ballot mask: a row of L^T with 20 nonzeros of which none is mapped
 // costs one (col, map) load pair, no row gather.
-template <int V>
+template <int V, bool ACT = false>
 __global__ __launch_bounds__(256) void spmm_csr_sel_kernel(const long long* __restrict__ indptr, const int* __restrict__ col,
                                                            const float* __restrict__ val, const float* __restrict__ X,
                                                            const int* __restrict__ rows, long long n_out,
                                                            const int* __restrict__ map, const unsigned* __restrict__ bits,
-                                                           int D, float* __restrict__ Y) {
+                                                           int D, float* __restrict__ Y, RowAct ra) {
     const int lane = threadIdx.x & 63;
     const long long i = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= n_out) return;
@@ -80,11 +102,13 @@ __global__ __launch_bounds__(256) void spmm_csr_sel_kernel(const long long* __re
                 const int c = map ? map[col[j]] : col[j];
                 if (c >= 0) acc = fmaf(val[j], X[(size_t)c * D + d], acc);
             }
+            if (ACT && !(ra.skip && ((ra.skip[i >> 5] >> (i & 31)) & 1u))) acc = acc * act_bwd(ra.src[(size_t)i * D + d], ra.act);
             Y[(size_t)i * D + d] = acc;
         }
     } else {
         typedef float vec __attribute__((ext_vector_type(V)));
         vec acc = {};
+        bool touched = false;
         for (long long jb = j0; jb < j1; jb += 64) {
             const int cnt = (int)min((long long)64, j1 - jb);
             int my_c = -1;
@@ -95,6 +119,7 @@ __global__ __launch_bounds__(256) void spmm_csr_sel_kernel(const long long* __re
                 if (my_c >= 0) my_v = val[jb + lane];
             }
             unsigned long long hits = __ballot(my_c >= 0);
+            touched |= hits != 0ull;
             // four hits at a time: their row gathers are independent loads in flight together (one at a time the loop is a
             // chain of memory round trips: 36 per row of the first layer); the terms are still added one by one in CSR order
             while (hits) {
@@ -122,6 +147,7 @@ __global__ __launch_bounds__(256) void spmm_csr_sel_kernel(const long long* __re
                 }
             }
         }
+        if (ACT && touched) acc = row_act<vec, V>(acc, ra, i, D, lane);
         *reinterpret_cast<vec*>(Y + (size_t)i * D + lane * V) = acc;
     }
 }
@@ -133,12 +159,12 @@ __global__ __launch_bounds__(256) void spmm_csr_sel_kernel(const long long* __re
 // 0 .. 8), looks the columns up 64 at a time and, for the rare hit, finds its row among the boundaries; a row's terms are
 // still added in CSR order into one accumulator that is stored when the run moves on to the next row (rows without a hit
 // are stored as zeros): the same bits as the kernel above.
-template <int V, int R>
+template <int V, int R, bool ACT = false>
 __global__ __launch_bounds__(256) void spmm_csr_sel_runs_kernel(const long long* __restrict__ indptr, const int* __restrict__ col,
                                                                 const float* __restrict__ val, const float* __restrict__ X,
                                                                 long long n_out, const int* __restrict__ map,
                                                                 const unsigned* __restrict__ bits, int D,
-                                                                float* __restrict__ Y) {
+                                                                float* __restrict__ Y, RowAct ra) {
     typedef float vec __attribute__((ext_vector_type(V)));
     const int lane = threadIdx.x & 63;
     const long long r0 = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
@@ -148,6 +174,9 @@ __global__ __launch_bounds__(256) void spmm_csr_sel_runs_kernel(const long long*
     const long long j0 = __shfl(bnd, 0, 64), j1 = __shfl(bnd, nr, 64);
     vec acc = {};
     int cur = 0;
+    bool touched = false;      // (wave-uniform) the row being accumulated has had a term
+    vec ycur = {};             // ACT: the activation's output at that row, requested at the row's first term
+    bool keep = false;         // ... and whether the row is left unscaled (skip bit)
     // four chunks of 64 nonzeros per trip: their column loads go out together, then their bitmap words (two levels of
     // latency per 256 nonzeros instead of per 64); the chunks' hits are then walked in order
     for (long long jq = j0; jq < j1; jq += 256) {
@@ -179,10 +208,21 @@ __global__ __launch_bounds__(256) void spmm_csr_sel_runs_kernel(const long long*
             const long long j = jb + t;
             const int row = __popcll(__ballot(lane >= 1 && lane <= nr && bnd <= j));      // rows of the run that end at or before j
             while (cur < row) {
+                if (ACT && touched && !keep) {
+#pragma unroll
+                    for (int e = 0; e < V; ++e) acc[e] = acc[e] * act_bwd(ycur[e], ra.act);
+                }
                 *reinterpret_cast<vec*>(Y + (size_t)(r0 + cur) * D + lane * V) = acc;
                 acc = vec{};
+                touched = false;
                 ++cur;
             }
+            if (ACT && !touched) {      // (in flight while the row's terms are gathered)
+                const long long i = r0 + cur;
+                keep = ra.skip && ((ra.skip[i >> 5] >> (i & 31)) & 1u);
+                ycur = *reinterpret_cast<const vec*>(ra.src + (size_t)i * D + lane * V);
+            }
+            touched = true;
             const int c = __builtin_amdgcn_readlane(my_c, t);
             const float v = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_v), t));
             const vec x = *reinterpret_cast<const vec*>(X + (size_t)c * D + lane * V);
@@ -192,8 +232,13 @@ __global__ __launch_bounds__(256) void spmm_csr_sel_runs_kernel(const long long*
         }
     }
     while (cur < nr) {
+        if (ACT && touched && !keep) {
+#pragma unroll
+            for (int e = 0; e < V; ++e) acc[e] = acc[e] * act_bwd(ycur[e], ra.act);
+        }
         *reinterpret_cast<vec*>(Y + (size_t)(r0 + cur) * D + lane * V) = acc;
         acc = vec{};
+        touched = false;
         ++cur;
     }
 }
@@ -220,7 +265,7 @@ __global__ __launch_bounds__(256) void row_scatter_sum_kernel(const float* __res
                                                               const int32_t* __restrict__ seg_start,
                                                               const int32_t* __restrict__ seg_row,
                                                               const int32_t* __restrict__ nseg, int M, int D,
-                                                              float* __restrict__ dX) {
+                                                              float* __restrict__ dX, const float* __restrict__ act_src, int act) {
     const int lane = threadIdx.x & 63;
     const int k = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (k >= M || k >= nseg[0]) return;
@@ -229,7 +274,9 @@ __global__ __launch_bounds__(256) void row_scatter_sum_kernel(const float* __res
     for (int d = lane; d < D; d += 64) {
         float acc = 0.f;
         for (int j = j0; j < j1; ++j) acc += g[(size_t)perm[j] * D + d];
-        dX[row * D + d] = ADD ? dX[row * D + d] + acc : acc;
+        float out = ADD ? dX[row * D + d] + acc : acc;
+        if (act_src) out = out * act_bwd(act_src[row * D + d], act);      // (fr_row_scatter_add_act: the sum, then the derivative)
+        dX[row * D + d] = out;
     }
 }
 
@@ -306,11 +353,30 @@ extern "C" int fr_spmm_csr(const int64_t* indptr, const int32_t* col, const floa
     return FR_OK;
 }
 
+static int spmm_csr_sel_impl(const int64_t* indptr, const int32_t* col, const float* val, const float* X, const int32_t* rows,
+                             int64_t n_out, const int32_t* map, const uint32_t* map_bits, int32_t dim, float* Y, RowAct ra,
+                             void* stream_);
+
 extern "C" int fr_spmm_csr_sel(const int64_t* indptr, const int32_t* col, const float* val, const float* X, const int32_t* rows,
                                int64_t n_out, const int32_t* map, const uint32_t* map_bits, int32_t dim, float* Y,
                                void* stream_) {
+    return spmm_csr_sel_impl(indptr, col, val, X, rows, n_out, map, map_bits, dim, Y, RowAct{nullptr, nullptr, 0}, stream_);
+}
+
+extern "C" int fr_spmm_csr_sel_act(const int64_t* indptr, const int32_t* col, const float* val, const float* X, const int32_t* rows,
+                                   int64_t n_out, const int32_t* map, const uint32_t* map_bits, int32_t dim, float* Y,
+                                   const float* act_src, int32_t act, const uint32_t* skip_bits, void* stream_) {
+    FR_CHECK_ARG(act_src && act >= 1 && act <= 4 && (((uintptr_t)act_src) & 15) == 0,
+                 "fr_spmm_csr_sel_act: the activation's output at the output rows (16-byte aligned) and its code 1..4");
+    return spmm_csr_sel_impl(indptr, col, val, X, rows, n_out, map, map_bits, dim, Y, RowAct{act_src, skip_bits, (int)act}, stream_);
+}
+
+static int spmm_csr_sel_impl(const int64_t* indptr, const int32_t* col, const float* val, const float* X, const int32_t* rows,
+                             int64_t n_out, const int32_t* map, const uint32_t* map_bits, int32_t dim, float* Y, RowAct ra,
+                             void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     FR_CHECK_ARG(indptr && col && val && X && Y && n_out >= 0 && dim >= 1 && (map || !map_bits), "fr_spmm_csr_sel: bad argument");
+    const bool with_act = ra.src != nullptr;
     const unsigned* bits = map_bits;
     if (n_out == 0) return FR_OK;
     ProfScope prof(K_SPMM, stream);
@@ -319,8 +385,13 @@ extern "C" int fr_spmm_csr_sel(const int64_t* indptr, const int32_t* col, const 
         const char* e = getenv("FAIRREC_SEL_RUNS_ROWS");
         const int R = e ? atoi(e) : 8;
 #define FR_SEL_RUNS(V, RR)                                                                                                 \
-    FR_LAUNCH(prof, (spmm_csr_sel_runs_kernel<V, RR>), dim3((unsigned)((n_out + 4 * RR - 1) / (4 * RR))), dim3(256), 0, stream, \
-              (const long long*)indptr, col, val, X, (long long)n_out, map, bits, (int)dim, Y)
+    if (with_act) {                                                                                                        \
+        FR_LAUNCH(prof, (spmm_csr_sel_runs_kernel<V, RR, true>), dim3((unsigned)((n_out + 4 * RR - 1) / (4 * RR))), dim3(256), 0, \
+                  stream, (const long long*)indptr, col, val, X, (long long)n_out, map, bits, (int)dim, Y, ra);            \
+    } else {                                                                                                               \
+        FR_LAUNCH(prof, (spmm_csr_sel_runs_kernel<V, RR, false>), dim3((unsigned)((n_out + 4 * RR - 1) / (4 * RR))), dim3(256), 0, \
+                  stream, (const long long*)indptr, col, val, X, (long long)n_out, map, bits, (int)dim, Y, ra);            \
+    }
 #define FR_SEL_RUNS_V(V)                  \
     if (R == 32) { FR_SEL_RUNS(V, 32); }  \
     else if (R == 16) { FR_SEL_RUNS(V, 16); } \
@@ -334,9 +405,14 @@ extern "C" int fr_spmm_csr_sel(const int64_t* indptr, const int32_t* col, const 
         return FR_OK;
     }
     const dim3 grid((unsigned)((n_out + 3) / 4));
-#define FR_SPMM_SEL(V)                                                                                              \
-    FR_LAUNCH(prof, spmm_csr_sel_kernel<V>, grid, dim3(256), 0, stream, (const long long*)indptr, col, val, X, rows, \
-              (long long)n_out, map, bits, (int)dim, Y)
+#define FR_SPMM_SEL(V)                                                                                                  \
+    if (with_act) {                                                                                                     \
+        FR_LAUNCH(prof, (spmm_csr_sel_kernel<V, true>), grid, dim3(256), 0, stream, (const long long*)indptr, col, val, X, rows, \
+                  (long long)n_out, map, bits, (int)dim, Y, ra);                                                        \
+    } else {                                                                                                            \
+        FR_LAUNCH(prof, (spmm_csr_sel_kernel<V, false>), grid, dim3(256), 0, stream, (const long long*)indptr, col, val, X, rows, \
+                  (long long)n_out, map, bits, (int)dim, Y, ra);                                                        \
+    }
     switch (dim) {
         case 64: FR_SPMM_SEL(1); break;
         case 128: FR_SPMM_SEL(2); break;
@@ -365,7 +441,8 @@ extern "C" size_t fr_row_scatter_workspace_bytes(int64_t M) {
 
 // dX [n_rows, dim] (zeroed here) += rows of g [M, dim] at idx, duplicates summed in ascending position
 static int row_scatter_impl(const float* g, const int64_t* idx, int64_t M, int64_t n_rows, int32_t dim, float* dX, void* ws,
-                            size_t ws_bytes, uint32_t* err_flag, void* stream_, bool add);
+                            size_t ws_bytes, uint32_t* err_flag, void* stream_, bool add, const float* act_src = nullptr,
+                            int act = 0);
 
 extern "C" int fr_row_scatter_sum(const float* g, const int64_t* idx, int64_t M, int64_t n_rows, int32_t dim, float* dX,
                                   void* ws, size_t ws_bytes, uint32_t* err_flag, void* stream_) {
@@ -378,8 +455,17 @@ extern "C" int fr_row_scatter_add(const float* g, const int64_t* idx, int64_t M,
     return row_scatter_impl(g, idx, M, n_rows, dim, dX, ws, ws_bytes, err_flag, stream_, true);
 }
 
+// ... and each row the batch touches, once its sum is complete, goes on through the derivative of the activation whose output
+// at that row is act_src[row] (the rows fr_spmm_csr_sel_act skipped)
+extern "C" int fr_row_scatter_add_act(const float* g, const int64_t* idx, int64_t M, int64_t n_rows, int32_t dim, float* dX,
+                                      void* ws, size_t ws_bytes, const float* act_src, int32_t act, uint32_t* err_flag,
+                                      void* stream_) {
+    FR_CHECK_ARG(act_src && act >= 1 && act <= 4, "fr_row_scatter_add_act: the activation's output [n_rows, dim] and its code 1..4");
+    return row_scatter_impl(g, idx, M, n_rows, dim, dX, ws, ws_bytes, err_flag, stream_, true, act_src, (int)act);
+}
+
 static int row_scatter_impl(const float* g, const int64_t* idx, int64_t M, int64_t n_rows, int32_t dim, float* dX, void* ws,
-                            size_t ws_bytes, uint32_t* err_flag, void* stream_, bool add) {
+                            size_t ws_bytes, uint32_t* err_flag, void* stream_, bool add, const float* act_src, int act) {
     hipStream_t stream = (hipStream_t)stream_;
     FR_CHECK_ARG(g && idx && dX && ws && M >= 1 && M <= FR_SORT_MAX && dim >= 1 && ws_bytes >= fr_row_scatter_workspace_bytes(M),
                  "fr_row_scatter_sum / _add: bad argument");
@@ -412,10 +498,10 @@ static int row_scatter_impl(const float* g, const int64_t* idx, int64_t M, int64
     ProfScope prof(K_ROW_GATHER, stream);
     if (add) {
         FR_LAUNCH(prof, row_scatter_sum_kernel<true>, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, stream, g, (const int32_t*)perm,
-                  (const int32_t*)seg_start, (const int32_t*)seg_row, (const int32_t*)nseg, (int)M, (int)dim, dX);
+                  (const int32_t*)seg_start, (const int32_t*)seg_row, (const int32_t*)nseg, (int)M, (int)dim, dX, act_src, act);
     } else {
         FR_LAUNCH(prof, row_scatter_sum_kernel<false>, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, stream, g, (const int32_t*)perm,
-                  (const int32_t*)seg_start, (const int32_t*)seg_row, (const int32_t*)nseg, (int)M, (int)dim, dX);
+                  (const int32_t*)seg_start, (const int32_t*)seg_row, (const int32_t*)nseg, (int)M, (int)dim, dX, act_src, act);
     }
     FR_CHECK_LAUNCH();
     return FR_OK;

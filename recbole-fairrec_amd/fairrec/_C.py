@@ -262,6 +262,10 @@ _PROTOS = {
                                    c_void_p]),
     "fr_row_scatter_add": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int32, c_void_p, c_void_p, c_size_t, c_void_p,
                                    c_void_p]),
+    "fr_spmm_csr_sel_act": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int32, c_void_p,
+                                    c_void_p, c_int32, c_void_p, c_void_p]),
+    "fr_row_scatter_add_act": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int32, c_void_p, c_void_p, c_size_t, c_void_p,
+                                       c_int32, c_void_p, c_void_p]),
     "fr_mse": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "fr_prof_enable": (c_int, [c_int]),
     "fr_prof_reset": (c_int, []),

@@ -397,7 +397,10 @@ class GatherAndSpMMSel(torch.autograd.Function):
     addends per element: the same bits."""
 
     @staticmethod
-    def forward(ctx, X, idx, err_flag, L: CsrMatrix, rows, rpos, rbits=None):
+    def forward(ctx, X, idx, err_flag, L: CsrMatrix, rows, rpos, rbits=None, act=0):
+        """`act` != 0: X is the output of that activation (an MLP built with `grad_at_z=True`) and the backward returns the
+        gradient at the activation's INPUT -- (L^T dY + scatter(g_rows)) o act'(X) -- from the same two launches
+        (fr_spmm_csr_sel_act / fr_row_scatter_add_act) instead of a third whole-table pass in the MLP's backward."""
         X = X.contiguous()
         idx = idx.contiguous().to(torch.int64)
         M, (N, D) = idx.numel(), X.shape
@@ -408,30 +411,50 @@ class GatherAndSpMMSel(torch.autograd.Function):
         ip, col, val = L.fwd
         _C.check(_C.lib().fr_spmm_csr_sel(ip.data_ptr(), col.data_ptr(), val.data_ptr(), X.data_ptr(), rows.data_ptr(),
                                           rows.numel(), None, None, D, Y.data_ptr(), _C.current_stream()), "fr_spmm_csr_sel")
-        ctx.save_for_backward(idx)
-        ctx.meta = (N, D, err_flag, L, rpos, rbits)
+        if act:
+            ctx.save_for_backward(idx, X)
+        else:
+            ctx.save_for_backward(idx)
+        ctx.meta = (N, D, err_flag, L, rpos, rbits, int(act))
         return out, Y
 
     @staticmethod
     def backward(ctx, g_rows, dY):
-        (idx,) = ctx.saved_tensors
-        N, D, err, L, rpos, rbits = ctx.meta
+        idx = ctx.saved_tensors[0]
+        N, D, err, L, rpos, rbits, act = ctx.meta
+        lib, st = _C.lib(), _C.current_stream()
         dX = torch.empty((N, D), dtype=torch.float32, device=idx.device)
         ip, col, val = L.bwd
+        if act and (dY is None or g_rows is None):      # (not FairGo's step: both uses carry a gradient there)
+            raise _C.FairrecError("GatherAndSpMMSel(act=...): both outputs must receive a gradient")
+        if act:
+            X = ctx.saved_tensors[1]
+            M = idx.numel()
+            # the rows the scatter adds to are scaled by IT, after the addition: a bitmap of them for the product to leave alone
+            skip = torch.zeros((N + 31) // 32, dtype=torch.int32, device=idx.device)
+            _C.check(lib.fr_frontier_mark(idx.data_ptr(), M, N, skip.data_ptr(), _C.ptr(err), st), "fr_frontier_mark")
+            dY = dY.contiguous()
+            _C.check(lib.fr_spmm_csr_sel_act(ip.data_ptr(), col.data_ptr(), val.data_ptr(), dY.data_ptr(), None, N, rpos.data_ptr(),
+                                             _C.ptr(rbits), D, dX.data_ptr(), X.data_ptr(), act, skip.data_ptr(), st),
+                     "fr_spmm_csr_sel_act")
+            g_rows = g_rows.contiguous()
+            ws = _ws(lib.fr_row_scatter_workspace_bytes(M), dX.device)
+            _C.check(lib.fr_row_scatter_add_act(g_rows.data_ptr(), idx.data_ptr(), M, N, D, dX.data_ptr(), ws.data_ptr(), ws.numel(),
+                                                X.data_ptr(), act, _C.ptr(err), st), "fr_row_scatter_add_act")
+            return dX, None, None, None, None, None, None, None
         if dY is None:
             dX.zero_()
         else:
             dY = dY.contiguous()
-            _C.check(_C.lib().fr_spmm_csr_sel(ip.data_ptr(), col.data_ptr(), val.data_ptr(), dY.data_ptr(), None, N,
-                                              rpos.data_ptr(), _C.ptr(rbits), D, dX.data_ptr(), _C.current_stream()),
-                     "fr_spmm_csr_sel")
+            _C.check(lib.fr_spmm_csr_sel(ip.data_ptr(), col.data_ptr(), val.data_ptr(), dY.data_ptr(), None, N,
+                                         rpos.data_ptr(), _C.ptr(rbits), D, dX.data_ptr(), st), "fr_spmm_csr_sel")
         if g_rows is not None:
             g_rows = g_rows.contiguous()
             M = idx.numel()
-            ws = _ws(_C.lib().fr_row_scatter_workspace_bytes(M), dX.device)
-            _C.check(_C.lib().fr_row_scatter_add(g_rows.data_ptr(), idx.data_ptr(), M, N, D, dX.data_ptr(), ws.data_ptr(),
-                                                 ws.numel(), _C.ptr(err), _C.current_stream()), "fr_row_scatter_add")
-        return dX, None, None, None, None, None, None
+            ws = _ws(lib.fr_row_scatter_workspace_bytes(M), dX.device)
+            _C.check(lib.fr_row_scatter_add(g_rows.data_ptr(), idx.data_ptr(), M, N, D, dX.data_ptr(), ws.data_ptr(),
+                                            ws.numel(), _C.ptr(err), st), "fr_row_scatter_add")
+        return dX, None, None, None, None, None, None, None
 
 
 class RowGather(torch.autograd.Function):

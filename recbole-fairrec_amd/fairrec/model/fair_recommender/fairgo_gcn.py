@@ -133,10 +133,10 @@ class FairGo_GCN(FairGo_PMF):
             return super().get_ego_embeddings()
         return torch.cat([self.user_embedding_layer.weight.data, self.item_embedding_layer.weight.data], dim=0)
 
-    def _filtered_table(self, sst_list):
+    def _filtered_table(self, sst_list, grad_at_z=False):
         if self.train_stage == 'pretrain':                 # fairgo_gcn.py:175-176
             return self.gcn(self.get_ego_embeddings(), self._a_hat)
-        return super()._filtered_table(sst_list)
+        return super()._filtered_table(sst_list, grad_at_z=grad_at_z)
 
     def calculate_loss(self, interaction, sst_list=None):
         if self.train_stage == 'finetune':

@@ -149,14 +149,28 @@ class FairGo_PMF(FairRecommender):
             c = self._ego_cache = (key, torch.cat([uw.data, iw.data], dim=0))
         return c[1]
 
-    def _filtered_table(self, sst_list):
+    def _top_fold_ok(self, sst_list) -> bool:
+        """May the filtered table's ONE consumer take the top activation's derivative into its own backward launches
+        (MLPLayers.forward(grad_at_z=True) + GatherAndSpMMSel(act=...))?  One filter whose output IS the table (no sum, no
+        division), a plain activation on its top layer, no BatchNorm, no dropout.  FAIRREC_FAIRGO_ACT_SEPARATE=1: never."""
+        if os.environ.get("FAIRREC_FAIRGO_ACT_SEPARATE") is not None or self.train_stage != 'finetune':
+            return False
+        sst_list = self.sst_attrs if sst_list is None else sst_list
+        if len(self.filter_layer_dict) != 1 or len(sst_list) != 1:
+            return False
+        mlp = self.filter_layer_dict[sst_list[0]]
+        name = mlp.activation.lower() if isinstance(mlp.activation, str) else mlp.activation
+        return (not mlp.use_bn and ACT_CODES[name] != 0 and mlp.forced_masks is None
+                and not (mlp.training and float(mlp.dropout) > 0.0))
+
+    def _filtered_table(self, sst_list, grad_at_z=False):
         E = self.get_ego_embeddings()
         if self.train_stage == 'finetune':
             if sst_list is None:
                 sst_list = self.sst_attrs
             tmp = None
             for sst in sst_list:
-                e = self.filter_layer_dict[sst](E)
+                e = self.filter_layer_dict[sst](E, grad_at_z=grad_at_z)
                 tmp = e if tmp is None else tmp + e
             # (x / 1 is x, bit for bit, and so is its gradient: with ONE filter the whole-table division and its backward --
             # 22 GB of traffic per filter step at BASELINE configs[3] -- are skipped)
@@ -412,13 +426,21 @@ class FairGo_PMF(FairRecommender):
             ue = ue * (user != 0).unsqueeze(1)
             ie = ie * (item != 0).unsqueeze(1)
             return Mse.apply(RowDot.apply(ue, ie), rating)
-        E = self._filtered_table(sst_list)
         idx = torch.cat([user, item + self.n_users])
         fr = self._frontier(user) if self.use_frontier() and not torch.cuda.is_current_stream_capturing() else None
+        # With a frontier the filtered table has ONE consumer below, which can hand the filter the gradient at its top layer's
+        # pre-activation from its own two launches: the whole-table pass through act' (fr_act_bwd: 2.8 of 33.9 ms at BASELINE
+        # configs[3]) is not run at all.
+        fold = fr is not None and self._top_fold_ok(sst_list)
+        E = self._filtered_table(sst_list, grad_at_z=fold)
         if fr is not None:
             # the filtered table's two uses -- the batch's rows and the first propagation layer -- as ONE autograd node, so
             # that dLoss/dE is written once (functional.GatherAndSpMMSel) instead of zero-filled, scattered into and added
-            rows, H1 = GatherAndSpMMSel.apply(E, idx, eng.err_flag, self._L, fr[0][0], fr[0][1], fr[0][2])
+            act = 0
+            if fold:
+                mlp = self.filter_layer_dict[(self.sst_attrs if sst_list is None else sst_list)[0]]
+                act = ACT_CODES[mlp.activation.lower() if isinstance(mlp.activation, str) else mlp.activation]
+            rows, H1 = GatherAndSpMMSel.apply(E, idx, eng.err_flag, self._L, fr[0][0], fr[0][1], fr[0][2], act)
             frontier = (fr, H1)
         else:
             rows, frontier = RowGather.apply(E, idx, eng.err_flag), None

@@ -102,7 +102,12 @@ class _HipMLP(torch.autograd.Function):
     def forward(ctx, x0, x1, act, p_drop, masks, drop, bn_buffers, *params):
         lib = _C.lib()
         st = _C.current_stream()
+        # bit 8 of `act` (MLPLayers.forward(grad_at_z=True)): the ONE consumer of the output hands back the gradient at the top
+        # layer's pre-activation, i.e. already through act' (functional.GatherAndSpMMSel does, inside its own launches)
+        top_at_z, act = bool(act & 0x100), act & 0xff
         use_bn = bn_buffers is not None
+        if top_at_z and (use_bn or act == 0 or p_drop > 0.0):
+            raise _C.FairrecError("grad_at_z: a plain activation on the top layer, no BatchNorm, no dropout")
         per = 4 if use_bn else 2
         n_layers = len(params) // per
         M = x0.shape[0]
@@ -209,6 +214,7 @@ class _HipMLP(torch.autograd.Function):
         ctx.premul, ctx.ins, ctx.masks8 = premul, ins, masks8
         ctx.drop, ctx.drop_off, ctx.dropped_out = drop, drop_off, dropped_out
         ctx.has_x1 = x1 is not None
+        ctx.top_at_z = top_at_z
         ctx.n_params = len(params)
         ctx.save_for_backward(x0, *([x1] if x1 is not None else []), *params, *outs, *xhats, *invstds)
         return outs[-1]
@@ -230,7 +236,7 @@ class _HipMLP(torch.autograd.Function):
         dY = dY.contiguous()
         dx0 = dx1 = None
         drop = ctx.drop
-        at_z = False          # dY already is the gradient at this layer's pre-activation (folded into the layer above)
+        at_z = ctx.top_at_z   # dY already is the gradient at this layer's pre-activation (folded into the layer above / the consumer)
         # weight gradients in the fast form wait here and go out together at the end: every product in ONE launch and every
         # slab sum in a second (fr_linear_bwd_weight_multi) instead of two launches per layer -- the same kernels' bodies on
         # the same arguments, so the same bits
@@ -386,7 +392,7 @@ class MLPLayers(nn.Module):
     def batchnorms(self) -> List[nn.BatchNorm1d]:
         return [m for m in self.mlp_layers if isinstance(m, nn.BatchNorm1d)]
 
-    def forward(self, input_feature, second_block=None, passes=1, frozen=False):
+    def forward(self, input_feature, second_block=None, passes=1, frozen=False, grad_at_z=False):
         """MLP(cat(input_feature, second_block)); `second_block` avoids materialising the concatenation.
         `passes` = 2 stands for the module being evaluated twice on the same input with both results used (the reference's
         PFCN filter pass does that, pfcn_biasedmf.py:209): without dropout the two evaluations are the same function at the
@@ -395,6 +401,9 @@ class MLPLayers(nn.Module):
         same batch statistics are one update with momentum 1 - (1 - m)^2, and the batch counter moves by two.
         `frozen`: the parameters take no gradient from this evaluation (only the input does): a discriminator inside the filter
         pass, whose gradients the reference computes and then never reads.
+        `grad_at_z`: the caller promises that the output has exactly ONE consumer in the autograd graph and that this consumer
+        returns the gradient at the top layer's PRE-activation (it has multiplied by act'(output) itself): the backward then
+        skips its own pass through the top activation's derivative (a whole-table pass for FairGo's filters).
         BatchNorm layers always use batch statistics while `self.training` (and the reference's dict-held PFCN MLPs are
         never switched to eval mode); eval-mode BatchNorm (running statistics) is not on this path."""
         if input_feature.device.type != "cuda":
@@ -429,8 +438,8 @@ class MLPLayers(nn.Module):
         if frozen:
             params = [t.detach() for t in params]
         name = self.activation.lower() if isinstance(self.activation, str) else self.activation
-        return _HipMLP.apply(input_feature, second_block, ACT_CODES[name], p if (masks is not None or drop is not None) else 0.0,
-                             masks, drop, bn_buffers, *params)
+        return _HipMLP.apply(input_feature, second_block, ACT_CODES[name] | (0x100 if grad_at_z else 0),
+                             p if (masks is not None or drop is not None) else 0.0, masks, drop, bn_buffers, *params)
 
     _instances = 0
 

@@ -384,7 +384,15 @@ def test_frontier_restricted_propagation_equals_whole_table(aggr, n_layers, D):
     inter = Interaction({"user_id": torch.tensor(u), "item_id": torch.tensor(ti[sel]), "rating": torch.tensor(tr[sel]),
                          "gender": torch.tensor(gender[u])}).to("cuda")
     results = {}
-    for mode in (False, True):
+    for mode in (False, True, "separate"):
+        # "separate": the frontier again, with the top activation's derivative as the filter's own whole-table pass
+        # (FAIRREC_FAIRGO_ACT_SEPARATE=1) instead of inside the table gradient's two launches (fr_spmm_csr_sel_act +
+        # fr_row_scatter_add_act): the same products in the same order, so the same BITS in every gradient
+        separate, mode = mode == "separate", bool(mode)
+        if separate:
+            os.environ["FAIRREC_FAIRGO_ACT_SEPARATE"] = "1"
+        else:
+            os.environ.pop("FAIRREC_FAIRGO_ACT_SEPARATE", None)
         torch.manual_seed(11)
         cfg = Config(model="FairGo_PMF", config_dict={
             "embedding_size": D, "sst_attr_list": ["gender"], "aggr_method": aggr, "n_layers": n_layers,
@@ -395,14 +403,15 @@ def test_frontier_restricted_propagation_equals_whole_table(aggr, n_layers, D):
         model.train_stage = "finetune"
         assert model.use_frontier() is mode and model.step_capturable("calculate_loss") is (not mode)
         assert model.step_capturable("calculate_dis_loss")
+        assert model._top_fold_ok(["gender"]) is (not separate)
         params = list(model.filter_layer_dict["gender"].parameters()) + list(model.dis_layer_dict["gender"].parameters()) + \
             (list(model.aggr_layer.parameters()) if aggr == "LBA" else [])
         loss = model.calculate_loss(inter, ["gender"])
         loss.backward()
         with torch.no_grad():
             dis = model.calculate_dis_loss(inter, ["gender"])
-        results[mode] = (loss.detach().clone(), dis.clone(), [p.grad.clone() for p in params])
-        if mode:
+        results["separate" if separate else mode] = (loss.detach().clone(), dis.clone(), [p.grad.clone() for p in params])
+        if mode and not separate:
             fr = model._frontier(inter["user_id"])
             assert len(fr) == n_layers and fr[-1][0].numel() == len(set(u.tolist()))
             if n_layers > 1:
@@ -414,6 +423,11 @@ def test_frontier_restricted_propagation_equals_whole_table(aggr, n_layers, D):
                 assert r0.dtype == r1.dtype == torch.int32 and torch.equal(r0, r1)
                 assert torch.equal(p0, p1) and torch.equal(b0, b1)
         model.hip_engine().check_device_errors()
+    os.environ.pop("FAIRREC_FAIRGO_ACT_SEPARATE", None)
+    (l1, d1, g1), (l2, d2, g2) = results[True], results["separate"]
+    assert torch.equal(l1, l2) and torch.equal(d1, d2)
+    for k, (a, b) in enumerate(zip(g1, g2)):
+        assert torch.equal(a, b), (k, float((a - b).abs().max()))
     (l0, d0, g0), (l1, d1, g1) = results[False], results[True]
     assert torch.equal(l0, l1), (float(l0), float(l1))
     assert torch.equal(d0, d1)
