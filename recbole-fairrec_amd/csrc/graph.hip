@@ -156,9 +156,13 @@ __global__ __launch_bounds__(256) void spmm_csr_sel_kernel(const long long* __re
 // layer walks L^T's 11 M rows (36 nonzeros each at BASELINE configs[3]) to find the 1.4 % of nonzeros that carry a gradient
 // row: one wave per row is four dependent loads for half a chunk of columns, and the launch is bound by wave turnover
 // (11 M waves).  Here a wave takes EIGHT consecutive rows as one contiguous run of nonzeros (their boundaries sit in lanes
-// 0 .. 8), looks the columns up 64 at a time and, for the rare hit, finds its row among the boundaries; a row's terms are
-// still added in CSR order into one accumulator that is stored when the run moves on to the next row (rows without a hit
-// are stored as zeros): the same bits as the kernel above.
+// 0 .. 8) and looks the columns up 256 at a time: column ids, then their bitmap words, then map entry AND value of the set
+// ones -- three round trips per 256 nonzeros.  The few hits (3.6 per trip) are compacted in CSR order into a wave-private list
+// in LDS and their gradient rows requested FOUR AT A TIME (round 6; one after the other, each behind the previous one's
+// accumulation, they were a memory round trip each: 6.5 -> see profiles/README.md); a row's terms are still added in CSR
+// order into one accumulator that is stored when the run moves on to the next row (rows without a hit are stored as zeros):
+// the same bits as the kernel above.
+constexpr int SEL_BATCH = 4;
 template <int V, int R, bool ACT = false>
 __global__ __launch_bounds__(256) void spmm_csr_sel_runs_kernel(const long long* __restrict__ indptr, const int* __restrict__ col,
                                                                 const float* __restrict__ val, const float* __restrict__ X,
@@ -166,22 +170,37 @@ __global__ __launch_bounds__(256) void spmm_csr_sel_runs_kernel(const long long*
                                                                 const unsigned* __restrict__ bits, int D,
                                                                 float* __restrict__ Y, RowAct ra) {
     typedef float vec __attribute__((ext_vector_type(V)));
+    __shared__ int4 stage_all[4][256];      // per wave: (mapped column, value bits, nonzero index within the trip, -)
     const int lane = threadIdx.x & 63;
+    int4* const stage = stage_all[threadIdx.x >> 6];
     const long long r0 = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
     if (r0 >= n_out) return;
     const int nr = (int)min((long long)R, n_out - r0);
     const long long bnd = lane <= nr ? indptr[r0 + lane] : 0x7fffffffffffffffll;
     const long long j0 = __shfl(bnd, 0, 64), j1 = __shfl(bnd, nr, 64);
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
     vec acc = {};
     int cur = 0;
     bool touched = false;      // (wave-uniform) the row being accumulated has had a term
-    vec ycur = {};             // ACT: the activation's output at that row, requested at the row's first term
+    vec ycur = {};             // ACT: the activation's output at that row
     bool keep = false;         // ... and whether the row is left unscaled (skip bit)
-    // four chunks of 64 nonzeros per trip: their column loads go out together, then their bitmap words (two levels of
-    // latency per 256 nonzeros instead of per 64); the chunks' hits are then walked in order
+    int yrow = -1;             // ... the row of the run whose activation row was requested last (once per row with a term)
+    auto flush_to = [&](int row) {
+        while (cur < row) {
+            if (ACT && touched && !keep) {
+#pragma unroll
+                for (int e = 0; e < V; ++e) acc[e] = acc[e] * act_bwd(ycur[e], ra.act);
+            }
+            *reinterpret_cast<vec*>(Y + (size_t)(r0 + cur) * D + lane * V) = acc;
+            acc = vec{};
+            touched = false;
+            ++cur;
+        }
+    };
     for (long long jq = j0; jq < j1; jq += 256) {
-        int cc4[4];
+        int cc4[4], mc4[4];
         unsigned w4[4];
+        float mv4[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const long long j = jq + 64 * q + lane;
@@ -192,55 +211,62 @@ __global__ __launch_bounds__(256) void spmm_csr_sel_runs_kernel(const long long*
 #pragma unroll
         for (int q = 0; q < 4; ++q) w4[q] = (bits && cc4[q] >= 0) ? bits[cc4[q] >> 5] : 0xFFFFFFFFu;
 #pragma unroll
+        for (int q = 0; q < 4; ++q) {      // a set bit says the map entry is a row: entry and value are requested together
+            const bool set = cc4[q] >= 0 && ((w4[q] >> (cc4[q] & 31)) & 1u);
+            mc4[q] = set ? map[cc4[q]] : -1;
+            mv4[q] = set ? val[jq + 64 * q + lane] : 0.f;
+        }
+        int n = 0;
+#pragma unroll
         for (int q = 0; q < 4; ++q) {
-        const long long jb = jq + 64 * q;
-        if (jb >= j1) break;
-        int my_c = -1;
-        float my_v = 0.f;
-        if (cc4[q] >= 0 && ((w4[q] >> (cc4[q] & 31)) & 1u)) {
-            my_c = map[cc4[q]];
-            if (my_c >= 0) my_v = val[jb + lane];
+            const bool hit = mc4[q] >= 0;
+            const unsigned long long hq = __ballot(hit);
+            if (hit) stage[n + __popcll(hq & lt_mask)] = make_int4(mc4[q], __builtin_bit_cast(int, mv4[q]), 64 * q + lane, 0);
+            n += __popcll(hq);
         }
-        unsigned long long hits = __ballot(my_c >= 0);
-        while (hits) {
-            const int t = __ffsll((long long)hits) - 1;
-            hits &= hits - 1;
-            const long long j = jb + t;
-            const int row = __popcll(__ballot(lane >= 1 && lane <= nr && bnd <= j));      // rows of the run that end at or before j
-            while (cur < row) {
-                if (ACT && touched && !keep) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int k0 = 0; k0 < n; k0 += SEL_BATCH) {
+            int rowe[SEL_BATCH];
+            float ve[SEL_BATCH];
+            vec xe[SEL_BATCH], ye[SEL_BATCH];
+            bool ke[SEL_BATCH], fresh[SEL_BATCH];
 #pragma unroll
-                    for (int e = 0; e < V; ++e) acc[e] = acc[e] * act_bwd(ycur[e], ra.act);
+            for (int e = 0; e < SEL_BATCH; ++e) {
+                if (k0 + e < n) {      // wave-uniform
+                    const int4 en = stage[k0 + e];
+                    const int c = __builtin_amdgcn_readfirstlane(en.x);
+                    ve[e] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(en.y));
+                    const long long j = jq + __builtin_amdgcn_readfirstlane(en.z);
+                    xe[e] = *reinterpret_cast<const vec*>(X + (size_t)c * D + lane * V);
+                    rowe[e] = __popcll(__ballot(lane >= 1 && lane <= nr && bnd <= j));      // rows of the run that end at or before j
+                    fresh[e] = ACT && rowe[e] != yrow;      // wave-uniform
+                    if (fresh[e]) {
+                        const long long i = r0 + rowe[e];
+                        ke[e] = ra.skip && ((ra.skip[i >> 5] >> (i & 31)) & 1u);
+                        ye[e] = *reinterpret_cast<const vec*>(ra.src + (size_t)i * D + lane * V);
+                        yrow = rowe[e];
+                    }
                 }
-                *reinterpret_cast<vec*>(Y + (size_t)(r0 + cur) * D + lane * V) = acc;
-                acc = vec{};
-                touched = false;
-                ++cur;
             }
-            if (ACT && !touched) {      // (in flight while the row's terms are gathered)
-                const long long i = r0 + cur;
-                keep = ra.skip && ((ra.skip[i >> 5] >> (i & 31)) & 1u);
-                ycur = *reinterpret_cast<const vec*>(ra.src + (size_t)i * D + lane * V);
+#pragma unroll
+            for (int e = 0; e < SEL_BATCH; ++e) {
+                if (k0 + e < n) {
+                    flush_to(rowe[e]);
+                    if (fresh[e]) {
+                        ycur = ye[e];
+                        keep = ke[e];
+                    }
+                    touched = true;
+#pragma unroll
+                    for (int q = 0; q < V; ++q) acc[q] = fmaf(ve[e], xe[e][q], acc[q]);
+                }
             }
-            touched = true;
-            const int c = __builtin_amdgcn_readlane(my_c, t);
-            const float v = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, my_v), t));
-            const vec x = *reinterpret_cast<const vec*>(X + (size_t)c * D + lane * V);
-#pragma unroll
-            for (int e = 0; e < V; ++e) acc[e] = fmaf(v, x[e], acc[e]);
         }
-        }
+        __builtin_amdgcn_wave_barrier();      // (the next trip's list goes into the same words)
     }
-    while (cur < nr) {
-        if (ACT && touched && !keep) {
-#pragma unroll
-            for (int e = 0; e < V; ++e) acc[e] = acc[e] * act_bwd(ycur[e], ra.act);
-        }
-        *reinterpret_cast<vec*>(Y + (size_t)(r0 + cur) * D + lane * V) = acc;
-        acc = vec{};
-        touched = false;
-        ++cur;
-    }
+    flush_to(nr);
 }
 
 // out[j,:] = X[idx[j],:]
