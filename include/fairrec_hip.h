@@ -616,6 +616,19 @@ FR_API int fr_bn_fwd_ex(const float* Z, const float* gamma, const float* beta, f
 FR_API int fr_bn_bwd(const float* dY, const float* Y, int32_t act, const float* xhat, const float* invstd,
                      const float* gamma, int64_t M, int32_t N, float* dZ, float* dgamma, float* dbeta, void* ws,
                      size_t ws_bytes, void* stream);
+/* A BatchNorm layer's backward fed by the product above it (layers.py:62-70 in reverse: Linear_l's input gradient is the
+ * gradient at the dropped output of BatchNorm layer l - 1): fr_linear_bwd_input_bnstats computes dX = (dY W) o keep -- the
+ * dropout's pattern regenerated from (p, seed, element offset, the call counter value in `used`), p = 0: none -- stores it, and
+ * leaves that layer's backward statistics per 32-row tile in bn_ws (fr_bn_workspace_bytes(M, K)); fr_bn_bwd_ex(have_stats = 1)
+ * on dY = dX and the same bn_ws is then the apply launch alone: one launch where there were three (product, dropout,
+ * statistics).  The tile sums are added in another order than fr_bn_bwd's statistics launch adds them (rounding-level
+ * differences).  Fast form only: FR_EUNSUPPORTED unless N % 32 == 0, K % 32 == 0, 16-byte aligned operands, M <= 32768. */
+FR_API int fr_linear_bwd_input_bnstats(const float* dY, const float* W, int64_t M, int32_t N, int32_t K, float* dX,
+                                       const float* Yb, const float* xhat_b, int32_t act_b, void* bn_ws, size_t bn_ws_bytes,
+                                       float p, uint64_t seed, uint64_t offset, const int64_t* used, void* stream);
+FR_API int fr_bn_bwd_ex(const float* dY, const float* Y, int32_t act, const float* xhat, const float* invstd,
+                        const float* gamma, int64_t M, int32_t N, float* dZ, float* dgamma, float* dbeta, void* ws,
+                        size_t ws_bytes, int32_t have_stats, void* stream);
 
 /* ---- PFCN scoring / losses (pfcn_pmf.py, pfcn_biasedmf.py, loss.py) -------------------------------------------------
  * fr_rowdot_*   : torch.mul(a, b).sum(-1) on gathered rows and its backward (da = g*b, db = g*a; either may be NULL)

@@ -560,6 +560,28 @@ extern "C" int fr_linear_bwd_input_act(const float* dY, const float* W, int64_t 
     return glds_linear_bwd_input(dY, W, M, (int)N, (int)K, dA, (int)K, nullptr, 0, (hipStream_t)stream_, Yin, 1.f, (int)act);
 }
 
+// dX = (dY W) o keep, stored, AND the backward statistics of the BatchNorm layer whose (dropped) output X is: per 32-row tile
+// and column sum dA and sum dA xhat (dA = dX o act'(Yb)) into bn_ws, exactly where fr_bn_bwd's statistics launch leaves its
+// per-chunk sums -- fr_bn_bwd_ex(have_stats = 1) then runs the apply launch alone.  One launch instead of three (product,
+// dropout, statistics) per BatchNorm layer of a backward pass.  p = 0: no dropout between the layers.  Fast form only
+// (N % 32 == 0, K % 32 == 0, aligned operands, the macro-tile kernels, M <= 32768): FR_EUNSUPPORTED otherwise.
+extern "C" int fr_linear_bwd_input_bnstats(const float* dY, const float* W, int64_t M, int32_t N, int32_t K, float* dX,
+                                           const float* Yb, const float* xhat_b, int32_t act_b, void* bn_ws, size_t bn_ws_bytes,
+                                           float p, uint64_t seed, uint64_t offset, const int64_t* used, void* stream_) {
+    FR_CHECK_ARG(dY && W && dX && Yb && xhat_b && bn_ws && M >= 1 && N >= 1 && K >= 1 && act_ok(act_b) &&
+                     bn_ws_bytes >= fr_bn_workspace_bytes(M, K), "fr_linear_bwd_input_bnstats: bad argument");
+    FR_CHECK_ARG(p >= 0.f && p < 1.f && (p == 0.f || (used && offset % 4 == 0)), "fr_linear_bwd_input_bnstats: bad dropout arguments");
+    prof_work(K_LINEAR_BWD_INPUT, 2.0 * (double)M * N * K);
+    static const bool no_glds = getenv("FAIRREC_LINEAR_NO_GLDS") != nullptr || getenv("FAIRREC_LINEAR_SLOW") != nullptr;
+    if (no_glds || N % 32 != 0 || K % 32 != 0 || (((uintptr_t)dY | (uintptr_t)W | (uintptr_t)dX) & 15) != 0 || M > 32768) {
+        set_error("fr_linear_bwd_input_bnstats: shape not supported (N %% 32 == 0, K %% 32 == 0, 16-byte aligned operands, M <= 32768)");
+        return FR_EUNSUPPORTED;
+    }
+    const GlBnb bnb{(float*)bn_ws, Yb, xhat_b, (int)act_b, p, (unsigned long long)seed, (unsigned long long)offset,
+                    (const unsigned long long*)used};
+    return glds_linear_bwd_input(dY, W, M, (int)N, (int)K, dX, (int)K, nullptr, 0, (hipStream_t)stream_, nullptr, 1.f, 0, &bnb);
+}
+
 // row splits of the weight gradient (slab bounded by 64 MiB)
 static long long bwd_weight_splits(int64_t M, int32_t N, int32_t K) {
     // >= 128 rows per split: at B = 8192 that is 64 splits, i.e. 64 x (N/64) x (K/64) workgroups -- enough to fill 256 CUs
@@ -1287,15 +1309,26 @@ extern "C" int fr_bn_fwd_ex(const float* Z, const float* gamma, const float* bet
 extern "C" int fr_bn_bwd(const float* dY, const float* Y, int32_t act, const float* xhat, const float* invstd,
                          const float* gamma, int64_t M, int32_t N, float* dZ, float* dgamma, float* dbeta, void* ws,
                          size_t ws_bytes, void* stream_) {
+    return fr_bn_bwd_ex(dY, Y, act, xhat, invstd, gamma, M, N, dZ, dgamma, dbeta, ws, ws_bytes, 0, stream_);
+}
+
+// have_stats != 0: ws already holds the per-chunk sums (fr_linear_bwd_input_bnstats left them): the apply launch alone
+extern "C" int fr_bn_bwd_ex(const float* dY, const float* Y, int32_t act, const float* xhat, const float* invstd,
+                            const float* gamma, int64_t M, int32_t N, float* dZ, float* dgamma, float* dbeta, void* ws,
+                            size_t ws_bytes, int32_t have_stats, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     FR_CHECK_ARG(dY && Y && xhat && invstd && gamma && dZ && dgamma && dbeta && ws && M >= 1 && N >= 1 && act_ok(act) &&
                      ws_bytes >= fr_bn_workspace_bytes(M, N), "fr_bn_bwd: bad argument");
     const int rc = bn_chunk_rows(M);
+    FR_CHECK_ARG(!have_stats || (rc == 32 && getenv("FAIRREC_BN_FOLD_SEPARATE") == nullptr),
+                 "fr_bn_bwd_ex: statistics from a product's epilogue are per 32-row tile (M <= 32768, fold inside the apply launch)");
     const dim3 grid((unsigned)((N + 63) / 64), (unsigned)((M + rc - 1) / rc));
     ProfScope prof(K_BN_BWD, stream);
-    FR_LAUNCH(prof, bn_bwd_stats_kernel, grid, dim3(BN_THREADS), 0, stream, dY, Y, (int)act, xhat, (int)M, (int)N, rc,
-              (float*)ws);
-    FR_CHECK_LAUNCH();
+    if (!have_stats) {
+        FR_LAUNCH(prof, bn_bwd_stats_kernel, grid, dim3(BN_THREADS), 0, stream, dY, Y, (int)act, xhat, (int)M, (int)N, rc,
+                  (float*)ws);
+        FR_CHECK_LAUNCH();
+    }
     if (getenv("FAIRREC_BN_FOLD_SEPARATE") == nullptr) {
         const int band = bn_apply_band(M, N, rc);
         FR_LAUNCH(prof, bn_bwd_apply_fold_kernel, dim3(grid.x, (unsigned)((M + band - 1) / band)), dim3(BN_THREADS), 0, stream, dY, Y,

@@ -20,6 +20,8 @@
 #include "common.hpp"
 #include "kernels.hpp"
 #include "mlp_glds.hpp"
+#include "dropout.hpp"
+#include "mlp_bn_math.hpp"
 
 namespace fr {
 
@@ -39,6 +41,21 @@ __device__ __forceinline__ float gl_act_bwd(float y, int act) {
         case 3: return y * (1.f - y);
         case 4: return 1.f - y * y;
         default: return 1.f;
+    }
+}
+
+// the value lane J of every aligned group of four lanes holds, in all four (DPP quad_perm: no LDS traffic)
+template <int J>
+__device__ __forceinline__ float quad_bcast(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), J | (J << 2) | (J << 4) | (J << 6),
+                                                                 0xf, 0xf, true));
+}
+__device__ __forceinline__ float quad_bcast_j(float v, int j) {      // j is a constant after unrolling
+    switch (j) {
+        case 0: return quad_bcast<0>(v);
+        case 1: return quad_bcast<1>(v);
+        case 2: return quad_bcast<2>(v);
+        default: return quad_bcast<3>(v);
     }
 }
 
@@ -608,6 +625,70 @@ __device__ __forceinline__ void glds64_body(const GlArgs& g, const unsigned bid,
     } else {
         float* base = col < g.o_split ? g.o_a + col : g.o_b + (col - g.o_split);
         const int ld = col < g.o_split ? g.o_lda : g.o_ldb;
+        if constexpr (MODE == GL_BWD_IN_BN) {
+            // (see GlArgs) the tile through the dropout's keep pattern, stored; then the BatchNorm layer's backward sums over
+            // the tile's 32 rows, ADDED IN bn_bwd_stats_kernel's ORDER so that the sums are its bits: that kernel's wave w
+            // walks rows w, w + 4, ..., w + 28 of a 32-row chunk and the four waves' sums are added 0, 1, 2, 3.  Lane (r, h)
+            // holds rows (e & 3) + 8 (e >> 2) + 4 h of column r, so chain w alternates between the two lanes of a column:
+            // each lane gets its partner's terms by a shuffle and both walk all four chains.  ld == out_cols (one block).
+            const unsigned long long ctr = g.dr_on ? *g.dr_used : 0ull;
+            const float* yb = g.bnb_y + col;
+            const float* xb = g.bnb_xhat + col;
+            // The keep factors: one Philox call covers four neighbouring columns of a row, i.e. the four lanes of a quad.  Lane q
+            // of a quad makes the calls of the quad's rows w + 8 q + 4 h (w = 0..3) -- four calls per lane instead of sixteen,
+            // v_mul_hi_u32 being quarter rate -- and the others take their column's component from it below.
+            // (requested before the Philox arithmetic, which then runs under their latency: nothing else does in this epilogue)
+            float ya[16], xa[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = i0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                const int rc = row < g.out_rows ? row : g.out_rows - 1;
+                ya[e] = yb[(size_t)rc * g.out_cols];
+                xa[e] = xb[(size_t)rc * g.out_cols];
+            }
+            float4 kq[4];
+            if (g.dr_on) {
+                const int q = r & 3;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    const size_t i4 = ((size_t)(i0 + w + 8 * q + 4 * h) * g.out_cols + (col & ~3)) >> 2;
+                    kq[w] = drop_keep4(g.dr_seed, ctr, g.dr_off4 + (unsigned long long)i4, g.dr_thr, g.dr_scale);
+                }
+            }
+            float c1[4] = {0.f, 0.f, 0.f, 0.f}, c2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    const int e = w + 4 * j;
+                    const int row = i0 + w + 8 * j + 4 * h;
+                    float keep = 1.f;
+                    if (g.dr_on) {      // (uniform) quad lane j holds this row's call
+                        const float k0 = quad_bcast_j(kq[w].x, j), k1 = quad_bcast_j(kq[w].y, j), k2 = quad_bcast_j(kq[w].z, j),
+                                    k3 = quad_bcast_j(kq[w].w, j);
+                        const int q = r & 3;
+                        keep = q == 0 ? k0 : (q == 1 ? k1 : (q == 2 ? k2 : k3));
+                    }
+                    float d = 0.f, sa = 0.f, xh = 0.f;      // (a row past the batch adds exact zeros: the chain skips it)
+                    if (row < g.out_rows) {
+                        d = acc[e];
+                        if (g.dr_on) d = d * keep;
+                        base[(size_t)row * ld] = d;
+                        sa = gl_act_bwd(ya[e], g.bnb_act);
+                        xh = xa[e];
+                    }
+                    const float dp = __shfl_xor(d, 32, 64), sp = __shfl_xor(sa, 32, 64), xp = __shfl_xor(xh, 32, 64);
+                    // row w + 8 j (the h = 0 lane's), then row w + 8 j + 4 (the h = 1 lane's)
+                    bn_bwd_acc(h ? dp : d, h ? sp : sa, h ? xp : xh, c1[w], c2[w]);
+                    bn_bwd_acc(h ? d : dp, h ? sa : sp, h ? xh : xp, c1[w], c2[w]);
+                }
+            }
+            if (h == 0) {
+                g.bnb_part[((size_t)(i0 >> 5) * g.out_cols + col) * 2] = (((0.f + c1[0]) + c1[1]) + c1[2]) + c1[3];
+                g.bnb_part[((size_t)(i0 >> 5) * g.out_cols + col) * 2 + 1] = (((0.f + c2[0]) + c2[1]) + c2[2]) + c2[3];
+            }
+            return;
+        }
         if (g.relu_src) {
             const float* src = g.relu_src + col;
 #pragma unroll
@@ -791,8 +872,12 @@ int glds_linear_fwd(const GlMat& X, const float* W, const float* bias, int64_t M
 }
 
 int glds_linear_bwd_input(const float* dY, const float* W, int64_t M, int N, int K, float* dx0, int k0, float* dx1, int k1,
-                          hipStream_t stream, const float* relu_src, float relu_scale, int src_act) {
-    if (k1 == 0 && (!relu_src || src_act != 0)) {
+                          hipStream_t stream, const float* relu_src, float relu_scale, int src_act, const GlBnb* bnb) {
+    if (bnb && (!use_shared() || k1 != 0 || relu_src || M > 32768)) {
+        set_error("fr_linear_bwd_input_bnstats: needs the macro-tile kernels, one input block and M <= 32768");
+        return FR_EUNSUPPORTED;
+    }
+    if (!bnb && k1 == 0 && (!relu_src || src_act != 0)) {
         int rc;
         if (stream_linear_bwd_input(dY, W, M, N, K, dx0, relu_src, src_act, stream, &rc)) return rc;
     }
@@ -817,6 +902,19 @@ int glds_linear_bwd_input(const float* dY, const float* W, int64_t M, int N, int
     g.o_split = k0;
     g.out_rows = (int)M;
     g.out_cols = K;
+    if (bnb) {
+        g.bnb_part = bnb->part;
+        g.bnb_y = bnb->y;
+        g.bnb_xhat = bnb->xhat;
+        g.bnb_act = bnb->act;
+        g.dr_on = bnb->p > 0.f;
+        g.dr_thr = drop_threshold(bnb->p);
+        g.dr_scale = 1.f / (1.f - bnb->p);
+        g.dr_seed = bnb->seed;
+        g.dr_off4 = bnb->offset / 4;
+        g.dr_used = bnb->used;
+    }
+    if (bnb) return launch_shared<GL_BWD_IN_BN>(g, stream, K_LINEAR_BWD_INPUT);
     if (use_shared()) return launch_shared<GL_BWD_IN>(g, stream, K_LINEAR_BWD_INPUT);
     const int tpb = GL_WAVES / g.ks;
     return launch_mode<GL_BWD_IN>(g, (ntiles + tpb - 1) / tpb, stream, K_LINEAR_BWD_INPUT);

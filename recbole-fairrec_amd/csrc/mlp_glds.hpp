@@ -5,7 +5,9 @@
 
 namespace fr {
 
-enum { GL_FWD = 0, GL_BWD_IN = 1, GL_BWD_W = 2 };
+enum { GL_FWD = 0, GL_BWD_IN = 1, GL_BWD_W = 2,
+       GL_BWD_IN_BN = 3 };      // GL_BWD_IN with the BatchNorm-backward epilogue (GlArgs::bnb_*): an instance of its own, so that
+                                // the plain input-gradient kernels keep their registers
 
 // a row-major matrix whose columns [0, split) live in `a` (leading dimension lda) and the rest in `b` (cat(U[u], I[i]))
 struct GlMat {
@@ -34,6 +36,29 @@ struct GlArgs {
     float relu_scale;        //   the result is then the gradient at z: (dY W) o relu_scale o [Xd > 0]
     int src_act;             // ... or (src_act != 0) the layer's input is Y = act(z), activation code src_act, and the result the
                              //   gradient at z: (dY W) o act'(Y) -- the activation's backward pass in this epilogue
+    // input gradient, optional (macro-tile form only): the layer's input is the output of a BatchNorm layer, dropped on its way
+    // up.  The epilogue then (1) multiplies the tile by the dropout's keep pattern (regenerated: dropout.hpp) before it stores
+    // it -- the gradient at the BatchNorm layer's activation output -- and (2) leaves that layer's backward statistics of the
+    // tile's 32 rows, sum dA and sum dA xhat per column (dA = the stored gradient o act'(Y)), in bnb_part[(tile, column)]:
+    // what bn_bwd_stats_kernel computes for a 32-row chunk, so that neither a dropout launch nor a statistics launch runs
+    // between this product and the BatchNorm layer's apply launch.
+    float* bnb_part;
+    const float* bnb_y;      // [M, out_cols] the BatchNorm layer's activation output
+    const float* bnb_xhat;   // [M, out_cols] its normalised input
+    int bnb_act;
+    int dr_on;               // a dropout between the two layers
+    unsigned dr_thr;
+    float dr_scale;
+    unsigned long long dr_seed, dr_off4;
+    const unsigned long long* dr_used;
+};
+struct GlBnb {               // the same, as the entry point hands it over
+    float* part;
+    const float *y, *xhat;
+    int act;
+    float p;
+    unsigned long long seed, offset;
+    const unsigned long long* used;
 };
 
 // Y = act(X W^T + b); needs K % 32 == 0, X.split % 32 == 0, 16-byte aligned rows
@@ -43,7 +68,8 @@ int glds_pick_ks(long long ntiles, int chunks);   // reduction parts per 32 x 32
 bool glds_shared_form();     // the macro-tile kernels are selected (FAIRREC_LINEAR_NO_SHARED unset): the only ones that write bn_part
 // dX = dY W; needs N % 32 == 0, K % 32 == 0, k0 % 32 == 0
 int glds_linear_bwd_input(const float* dY, const float* W, int64_t M, int N, int K, float* dx0, int k0, float* dx1, int k1,
-                          hipStream_t stream, const float* relu_src = nullptr, float relu_scale = 1.f, int src_act = 0);
+                          hipStream_t stream, const float* relu_src = nullptr, float relu_scale = 1.f, int src_act = 0,
+                          const GlBnb* bnb = nullptr);
 // slab[s] = dY[rows of s]^T X[rows of s], bslab[s] = column sums of dY[rows of s] (bslab may be null); needs N % 32 == 0,
 // K % 32 == 0, X.split % 32 == 0, rows_per_split % 32 == 0
 int glds_linear_bwd_weight(const float* dY, const GlMat& X, int64_t M, int N, int K, int splits, int rows_per_split,

@@ -243,6 +243,10 @@ _PROTOS = {
                                c_void_p, c_void_p, c_void_p, c_void_p]),
     "fr_bn_bwd": (c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p,
                           c_void_p, c_void_p, c_size_t, c_void_p]),
+    "fr_bn_bwd_ex": (c_int, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p,
+                             c_void_p, c_void_p, c_size_t, c_int32, c_void_p]),
+    "fr_linear_bwd_input_bnstats": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_int32,
+                                            c_void_p, c_size_t, c_float, c_uint64, c_uint64, c_void_p, c_void_p]),
     "fr_rowdot_fwd": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p]),
     "fr_rowdot_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p]),
     "fr_bpr_workspace_bytes": (c_size_t, [c_int64, c_int32]),

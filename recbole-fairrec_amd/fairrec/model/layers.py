@@ -237,6 +237,13 @@ class _HipMLP(torch.autograd.Function):
         dx0 = dx1 = None
         drop = ctx.drop
         at_z = ctx.top_at_z   # dY already is the gradient at this layer's pre-activation (folded into the layer above / the consumer)
+        # A BatchNorm layer's backward statistics may come out of the epilogue of the product above it, which then also takes
+        # the gradient through the dropout between the two layers (fr_linear_bwd_input_bnstats: one launch for product,
+        # dropout and statistics; FAIRREC_BN_BWD_SEPARATE=1: the three launches).  `bn_stats`: the workspace they are in.
+        bn_stats = None
+        bn_fuse = (ctx.use_bn and M <= 32768 and ctx.masks is None and os.environ.get("FAIRREC_BN_BWD_SEPARATE") is None
+                   and os.environ.get("FAIRREC_LINEAR_NO_GLDS") is None and os.environ.get("FAIRREC_LINEAR_SLOW") is None
+                   and os.environ.get("FAIRREC_LINEAR_NO_SHARED") is None and os.environ.get("FAIRREC_BN_FOLD_SEPARATE") is None)
         # weight gradients in the fast form wait here and go out together at the end: every product in ONE launch and every
         # slab sum in a second (fr_linear_bwd_weight_multi) instead of two launches per layer -- the same kernels' bodies on
         # the same arguments, so the same bits
@@ -249,6 +256,7 @@ class _HipMLP(torch.autograd.Function):
             a, c = (outs[l - 1], None) if l > 0 else (x0, x1)
             k0, k1 = a.shape[1], (c.shape[1] if c is not None else 0)
             N, K = W.shape
+            fused_here = False                    # this layer's input-gradient product carried the dropout and the statistics below
             mk = ctx.masks8[l]                    # byte mask for the general kernels (None: no dropout, or pre-multiplied)
             scale = ctx.scale
             if ctx.premul[l]:                     # X o mask*scale was formed in the forward: the products see a plain input
@@ -269,10 +277,16 @@ class _HipMLP(torch.autograd.Function):
                 dZ = torch.empty_like(Y)
                 dg = torch.empty(N, dtype=torch.float32, device=dev)
                 dbt = torch.empty(N, dtype=torch.float32, device=dev)
-                ws = torch.empty(lib.fr_bn_workspace_bytes(M, N), dtype=torch.uint8, device=dev)
-                _C.check(lib.fr_bn_bwd(dY.data_ptr(), Y.data_ptr(), act, xhats[l].data_ptr(), invstds[l].data_ptr(),
-                                       g.data_ptr(), M, N, dZ.data_ptr(), dg.data_ptr(), dbt.data_ptr(), ws.data_ptr(),
-                                       ws.numel(), st), "fr_bn_bwd")
+                if bn_stats is not None:      # the statistics are there already: the apply launch alone
+                    ws, bn_stats = bn_stats, None
+                    _C.check(lib.fr_bn_bwd_ex(dY.data_ptr(), Y.data_ptr(), act, xhats[l].data_ptr(), invstds[l].data_ptr(),
+                                              g.data_ptr(), M, N, dZ.data_ptr(), dg.data_ptr(), dbt.data_ptr(), ws.data_ptr(),
+                                              ws.numel(), 1, st), "fr_bn_bwd_ex")
+                else:
+                    ws = torch.empty(lib.fr_bn_workspace_bytes(M, N), dtype=torch.uint8, device=dev)
+                    _C.check(lib.fr_bn_bwd(dY.data_ptr(), Y.data_ptr(), act, xhats[l].data_ptr(), invstds[l].data_ptr(),
+                                           g.data_ptr(), M, N, dZ.data_ptr(), dg.data_ptr(), dbt.data_ptr(), ws.data_ptr(),
+                                           ws.numel(), st), "fr_bn_bwd")
                 if ctx.needs_input_grad[7 + per * l + 2] or ctx.needs_input_grad[7 + per * l + 3]:
                     grads[per * l + 2], grads[per * l + 3] = dg, dbt
                 dY, Y, act = dZ, dZ, 0
@@ -308,7 +322,19 @@ class _HipMLP(torch.autograd.Function):
                 if need0 or need1:
                     da = torch.empty((M, k0), dtype=torch.float32, device=dev)
                     dc = torch.empty((M, k1), dtype=torch.float32, device=dev) if k1 else None
-                    if l > 0 and ctx.dropped_out[l - 1] and act == 0 and N % 32 == 0 and K % 32 == 0 and \
+                    drop_here = drop is not None and ctx.premul[l]
+                    if (bn_fuse and l > 0 and k1 == 0 and act == 0 and mk is None and scale == 1.0 and N % 32 == 0 and K % 32 == 0
+                            and not ctx.dropped_out[l - 1] and (drop_here or (drop is None and not ctx.premul[l]))
+                            and (not drop_here or ctx.drop_off[l][0] % 4 == 0)
+                            and (dY.data_ptr() | W.data_ptr() | da.data_ptr()) % 16 == 0):
+                        bn_stats = torch.empty(lib.fr_bn_workspace_bytes(M, K), dtype=torch.uint8, device=dev)
+                        _C.check(lib.fr_linear_bwd_input_bnstats(
+                            dY.data_ptr(), W.data_ptr(), M, N, K, da.data_ptr(), outs[l - 1].data_ptr(), xhats[l - 1].data_ptr(),
+                            ctx.act, bn_stats.data_ptr(), bn_stats.numel(), drop.p if drop_here else 0.0,
+                            drop.seed if drop_here else 0, ctx.drop_off[l][0] if drop_here else 0,
+                            drop.used.data_ptr() if drop_here else None, st), "fr_linear_bwd_input_bnstats")
+                        fused_here = True
+                    elif l > 0 and ctx.dropped_out[l - 1] and act == 0 and N % 32 == 0 and K % 32 == 0 and \
                             os.environ.get("FAIRREC_LINEAR_NO_GLDS") is None and os.environ.get("FAIRREC_LINEAR_SLOW") is None:
                         # the input is the dropped ReLU output of the layer below: on through it in the epilogue
                         _C.check(lib.fr_linear_bwd_input_relu(dY.data_ptr(), W.data_ptr(), M, N, K, a.data_ptr(), ctx.scale,
@@ -329,7 +355,7 @@ class _HipMLP(torch.autograd.Function):
                         _C.check(lib.fr_linear_bwd_input(dY.data_ptr(), Y.data_ptr(), act, W.data_ptr(), _C.ptr(mk), scale,
                                                          M, N, da.data_ptr(), k0, _C.ptr(dc), k1, st), "fr_linear_bwd_input")
             grads[per * l], grads[per * l + 1] = dW, db
-            if need0 or need1:
+            if (need0 or need1) and not fused_here:
                 if drop is not None and ctx.premul[l]:      # back through this layer's input dropout: the pattern again
                     if need0 and dc is not None and need1:
                         drop.again2(da, ctx.drop_off[l][0], dc, ctx.drop_off[l][1])
@@ -340,6 +366,7 @@ class _HipMLP(torch.autograd.Function):
                 elif ctx.premul[l]:               # back through the dropout of this layer's input
                     da = da * (ctx.masks[l] if dc is None else ctx.masks[l][:, :k0]) if da is not None else None
                     dc = dc * ctx.masks[l][:, k0:] if dc is not None else None
+            if need0 or need1:
                 if l > 0:
                     dY = da
                 else:

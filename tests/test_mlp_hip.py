@@ -599,3 +599,40 @@ def test_streaming_products_at_the_table_size_of_baseline_config_3():
     ref = dY[blk].double().t() @ X1[blk].double()
     torch.testing.assert_close(dW.double(), ref, rtol=1e-4, atol=1e-4 * float(ref.abs().max()))
     torch.testing.assert_close(db.double(), dY[blk].double().sum(0), rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize("M", [200, 8192])
+@pytest.mark.parametrize("p", [0.0, 0.3])
+@pytest.mark.parametrize("widths", [[128, 256, 128, 128, 64, 32, 1], [64, 32, 32]], ids=["discriminator", "narrow"])
+def test_bn_backward_statistics_from_the_product_epilogue_are_the_three_launches_bits(M, p, widths):
+    """fr_linear_bwd_input_bnstats + fr_bn_bwd_ex(have_stats): the input-gradient product of a layer above a BatchNorm layer
+    takes the gradient through the dropout between them (pattern regenerated, one Philox call per four columns shared by a
+    quad of lanes) and leaves the BatchNorm layer's backward sums per 32-row tile, added in bn_bwd_stats_kernel's own order --
+    so every gradient of the MLP must EQUAL the product + dropout + statistics launches' (FAIRREC_BN_BWD_SEPARATE=1), with
+    the same dropout pattern (call counter restored), for a batch that ends inside a tile and for a full one."""
+    from fairrec.model.layers import MLPLayers
+    torch.manual_seed(M + len(widths))
+    mlp = MLPLayers(widths, dropout=p, activation="leakyrelu", bn=True).cuda().train()
+    x = (torch.randn(M, widths[0], device="cuda") * 0.1).requires_grad_()
+    tgt = torch.randn(M, widths[-1], device="cuda")
+    st = mlp._drop_state(x.device) if p > 0 else None
+    st0 = st.clone() if st is not None else None
+    res = {}
+    try:
+        for mode in ("fused", "separate"):
+            if mode == "separate":
+                os.environ["FAIRREC_BN_BWD_SEPARATE"] = "1"
+            else:
+                os.environ.pop("FAIRREC_BN_BWD_SEPARATE", None)
+            if st is not None:
+                st.copy_(st0)
+            for q in mlp.parameters():
+                q.grad = None
+            x.grad = None
+            ((mlp(x) - tgt) ** 2).mean().backward()
+            res[mode] = {"x": x.grad.clone(), **{n: q.grad.clone() for n, q in mlp.named_parameters()}}
+    finally:
+        os.environ.pop("FAIRREC_BN_BWD_SEPARATE", None)
+    assert float(res["fused"]["x"].abs().max()) > 0
+    for n in res["fused"]:
+        assert torch.equal(res["fused"][n], res["separate"][n]), n
