@@ -348,3 +348,32 @@ def test_device_randperm_speculation_is_dropped_when_somebody_else_draws():
     assert len(ts._AHEAD) >= 1                    # something IS computed ahead
     for g, w in zip(got, want):
         assert torch.equal(g.cpu(), w)
+
+
+def test_call_sequence_of_an_evaluation_batch_at_baseline_sizes():
+    """The evaluation loader's draws at the sizes of BASELINE configs[1] -- 100 001 items, 1 000 001 users with 20 interactions
+    each, a batch of 2 800 users x 100 negatives per positive (280 k values, ~290 calls with a collision among them): the
+    speculative form against the SAME calls issued one by one on a twin generator (the single-call kernel, itself held to
+    numpy by the tests above): every id, and the generator state afterwards."""
+    from fairrec.sampler import Sampler
+    g = torch.Generator().manual_seed(1)
+    user_num, item_num, n_calls = 1_000_001, 100_001, 2800
+    u = torch.arange(1, user_num).repeat_interleave(20)
+    i = torch.randint(1, item_num, (u.numel(),), generator=g)
+    rs, rs1 = _rs(404), _rs(404)
+    smp = Sampler("test", _DS(user_num, item_num, u.numpy(), i.numpy()), device="cuda", random_state=rs).set_phase("test")
+    indptr, items, _ = smp.used_ids
+    keys = torch.randint(1, user_num, (n_calls,), generator=g)
+    counts = torch.full((n_calls,), 100, dtype=torch.int64)
+    counts[::97] = 300
+    got = rs.sample_calls(1, item_num, keys, counts, indptr, items)
+    single = torch.cat([rs1.sample_excluding(1, item_num, torch.full((int(c) // 100,), int(k)).cuda(), 100, indptr, items)
+                        for k, c in zip(keys.tolist(), counts.tolist())])
+    assert torch.equal(got, single)
+    a, b = rs.get_state(), rs1.get_state()
+    np.testing.assert_array_equal(a[1], b[1])
+    assert a[2] == b[2]
+    # ... and no id is one its user has seen
+    owner = torch.repeat_interleave(keys, counts).cuda()
+    key_used = (u * item_num + i).cuda()
+    assert not torch.isin(owner * item_num + got, key_used).any()
