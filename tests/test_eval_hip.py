@@ -326,3 +326,39 @@ def test_segment_lookup_hands_back_a_score_that_is_not_a_number():
                                        _C.current_stream()), "fr_eval_topk_segments")
     assert flags.cpu().tolist() == [1 | 2, 1, 2, 0]
     assert topk[3].cpu().tolist() == [300, 299, 298, 297, 296]
+
+
+def test_segment_topk_at_baseline_sizes_against_the_dense_matrix():
+    """fr_eval_topk_segments at the sizes of BASELINE configs[1]'s evaluation (100 001 items, 2 800 users x (1-3 positives + 100
+    negatives each), K = 20): the reference's recipe -- candidates scattered into a dense [users, n_items] matrix of -inf,
+    torch.topk of it (trainer.py:441-456, collector.py:149) -- on the device; random fp32 scores, so no list hangs on a tie and
+    the lists must be EQUAL; items drawn twice carry one score."""
+    from fairrec import _C
+    lib = _C.lib()
+    g = torch.Generator(device="cuda").manual_seed(3)
+    U, n_items, K = 2800, 100_001, 20
+    counts = 101 + torch.randint(0, 3, (U,), device="cuda", generator=g)
+    seg = torch.zeros(U + 1, dtype=torch.int64, device="cuda")
+    seg[1:] = torch.cumsum(counts, 0)
+    n = int(seg[-1])
+    rows = torch.repeat_interleave(torch.arange(U, device="cuda"), counts)
+    items = torch.randint(1, n_items, (n,), device="cuda", generator=g)
+    scores = torch.rand(n, device="cuda", generator=g)
+    dense = torch.full((U, n_items), -float("inf"), device="cuda")
+    dense[rows, items] = scores                                  # (a duplicate: one of its scores, as in the reference)
+    scores = dense[rows, items].contiguous()                     # ... which both copies then carry
+    want = torch.topk(dense, K, dim=-1).indices
+    topk = torch.empty((U, K), dtype=torch.int64, device="cuda")
+    flags = torch.empty(U, dtype=torch.int32, device="cuda")
+    _C.check(lib.fr_eval_topk_segments(seg.data_ptr(), U, items.data_ptr(), scores.data_ptr(), K, topk.data_ptr(), flags.data_ptr(),
+                                       _C.current_stream()), "fr_eval_topk_segments")
+    clean = flags == 0
+    assert int(clean.sum()) >= U - 2                             # (an exact fp32 tie among 20 of 100 random scores: ~1e-4 per user)
+    assert torch.equal(topk[clean], want[clean])
+    # the lookups: every candidate's own score comes back
+    q = torch.randint(0, n, (50_000,), device="cuda", generator=g)
+    out = torch.empty(q.numel(), dtype=torch.float32, device="cuda")
+    qr, qi = rows[q].contiguous(), items[q].contiguous()
+    _C.check(lib.fr_eval_lookup_segments(seg.data_ptr(), U, items.data_ptr(), scores.data_ptr(), qr.data_ptr(), qi.data_ptr(),
+                                         q.numel(), out.data_ptr(), _C.current_stream()), "fr_eval_lookup_segments")
+    assert torch.equal(out, dense[qr, qi])
