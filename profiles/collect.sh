@@ -56,8 +56,8 @@ fi
 python3 scratch/eval_probe.py 500000 > $OUT/eval_probe.txt 2>&1
 # 10) the tracked summaries are made HERE (gpurun brings back at most 64 MiB; the raw traces are several times that)
 cd $R && python3 profiles/summarize.py $ROUND $OUT/summary > $OUT/summarize.log 2>&1
-python3 profiles/step_window.py $OUT/stats_nfcf table_lookup_kernel 8 > $OUT/summary/${ROUND}_nfcf_step.txt 2>&1
-python3 profiles/step_window.py $OUT/stats_pfcn bpr_outer_kernel 8 > $OUT/summary/${ROUND}_pfcn_step.txt 2>&1
+{ echo "# rocprofv3 --kernel-trace of bench.py --workload nfcf100m at 1 M x 100 k, reduced by profiles/step_window.py (anchor table_lookup_kernel)"; python3 profiles/step_window.py $OUT/stats_nfcf table_lookup_kernel 8; } > $OUT/summary/${ROUND}_nfcf_step.txt 2>&1
+{ echo "# rocprofv3 --kernel-trace of bench.py --workload pfcn10m, reduced by profiles/step_window.py (anchor bpr_outer_kernel): the FILTER pass of a step (the densest window is the aging phase, which runs filter passes only)"; python3 profiles/step_window.py $OUT/stats_pfcn bpr_outer_kernel 8; } > $OUT/summary/${ROUND}_pfcn_step.txt 2>&1
 for f in trainer_bench_device.txt randperm_bench.txt valu_rates.txt replay_bench.txt; do [ -s $OUT/$f ] && cp $OUT/$f $OUT/summary/${ROUND}_$f; done
 du -sh $OUT/* | sort -h | tail -12
 rm -rf $OUT/stats $OUT/stats_pfcn $OUT/stats_nfcf $OUT/stats_fairgo $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_mfma $OUT/trace
